@@ -1,0 +1,88 @@
+/*
+ * oracle/lo_oracle.h -- TEST INFRASTRUCTURE.  CPU restatement ("oracle") of the
+ * lmono per-scan hot path.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may build, link, import or call anything in oracle/.
+ *
+ * PARITY UNPINNED: the reference tree holds no source for the A-LOAM half
+ * (Aloam/ is an empty, un-pinned submodule, /root/reference/.gitmodules:1-3)
+ * and no tests / golden vectors for the lmono half.  The LiDAR functions here
+ * restate the public HKUST-Aerial-Robotics/A-LOAM algorithm (SURVEY.md
+ * Appendix A) that tops666/Aloam forks; the BA functions restate the in-tree
+ * factors line by line (file:line cited at each function).
+ */
+#ifndef LO_ORACLE_H
+#define LO_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { float x, y, z, i; } lo_pt; /* pcl::PointXYZI payload */
+
+#define LO_MAX_RINGS 64
+
+/* ---- scanRegistration (A-LOAM scanRegistration.cpp laserCloudHandler) ---- */
+typedef struct {
+    int n_cloud;                 /* ring-major cloud size after discards            */
+    int ring_begin[LO_MAX_RINGS + 1]; /* ring r occupies [ring_begin[r], ring_begin[r+1]) */
+    int scan_start[LO_MAX_RINGS];     /* ring_begin+5  (scanStartInd)                */
+    int scan_end[LO_MAX_RINGS];       /* ring_end-6    (scanEndInd)                  */
+    int n_sharp, n_less_sharp, n_flat, n_less_flat;
+} lo_scanreg_info;
+
+/* Buffers are caller-owned with capacity n (points) each:
+ * cloud[n], curvature[n], label[n] (int32), sharp/less_sharp/flat/less_flat[n]. */
+int lo_scanreg(const float *xyzi, int n, int n_scans, float min_range,
+               lo_pt *cloud, float *curvature, int32_t *label,
+               lo_pt *sharp, lo_pt *less_sharp, lo_pt *flat, lo_pt *less_flat,
+               lo_scanreg_info *info);
+
+/* ---- exact 1-NN (stands in for pcl::KdTreeFLANN::nearestKSearch(k=1)) ---- */
+typedef struct lo_kdtree lo_kdtree;
+lo_kdtree *lo_kdtree_build(const lo_pt *pts, int n);
+void lo_kdtree_free(lo_kdtree *t);
+/* returns index of nearest point (ties: lowest index), -1 if n==0; *d2 = float squared distance */
+int lo_kdtree_nn(const lo_kdtree *t, float qx, float qy, float qz, float *d2);
+int lo_brute_nn(const lo_pt *pts, int n, float qx, float qy, float qz, float *d2);
+
+/* ---- laserOdometry (A-LOAM laserOdometry.cpp main loop) ---- */
+typedef struct {
+    int n_corner_corr[2];   /* correspondences per outer iteration */
+    int n_plane_corr[2];
+    int lm_iters[2];        /* LM iterations executed (<=4)        */
+    double initial_cost[2], final_cost[2];
+} lo_odom_stats;
+
+/* One scan-to-scan step.  q = (x,y,z,w) and t are in/out (warm start = last increment).
+ * use_kdtree=0 selects brute force NN (validation of the kd-tree).
+ * corr_out (optional, may be NULL): int32[2][(n_sharp + n_flat) * 4] correspondence indices
+ *   per outer iteration: edge -> (a, b, -1, 1), plane -> (a, b, c, 2), none -> (-1,-1,-1,0). */
+int lo_odom_step(const lo_pt *sharp, int n_sharp, const lo_pt *flat, int n_flat,
+                 const lo_pt *corner_last, int n_corner_last,
+                 const lo_pt *surf_last, int n_surf_last,
+                 double q[4], double t[3], int use_kdtree,
+                 lo_odom_stats *stats, int32_t *corr_out);
+
+/* accumulate: t_w += q_w * t ; q_w = q_w * q  (quaternions xyzw) */
+void lo_pose_accumulate(double q_w[4], double t_w[3], const double q[4], const double t[3]);
+
+/* ---- synthetic HDL-64 generator S1 ---- */
+typedef struct {
+    int n_boxes;   const double *boxes;     /* [n_boxes][6]  xmin ymin zmin xmax ymax zmax */
+    int n_cyls;    const double *cyls;      /* [n_cyls][4]   cx cy radius height(top z)     */
+    double ground_z;
+    int n_rings;   const double *elev_rad;  /* [n_rings] elevation angles                  */
+    int n_az;                               /* azimuth steps per ring                       */
+    double range_sigma, dropout, max_range;
+    uint64_t seed;
+} lo_world;
+
+/* pose: sensor position (x,y,z) and yaw.  Writes up to n_rings*n_az points (ring-major,
+ * azimuth ascending in firing order) as xyzi float32; returns the number written. */
+int lo_synth_scan(const lo_world *w, const double pose_xyzyaw[4], uint64_t scan_id, float *xyzi_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

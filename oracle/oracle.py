@@ -1,0 +1,232 @@
+"""ctypes bindings of the CPU oracle (oracle/liblmono_oracle.so).
+
+TEST INFRASTRUCTURE: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  PARITY UNPINNED (see oracle/lo_oracle.h).  Also hosts the synthetic S1 world/trajectory
+definition because the generator is shared input plumbing for tests and bench.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liblmono_oracle.so")
+MAX_RINGS = 64
+
+
+def build(force=False):
+    """Compile the oracle with gcc (no-op when the .so is newer than its sources)."""
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    if (not force and os.path.exists(_LIB_PATH)
+            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(s) for s in srcs)):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-s", "-C", _HERE, "-B"])
+    return _LIB_PATH
+
+
+class ScanregInfo(C.Structure):
+    _fields_ = [("n_cloud", C.c_int),
+                ("ring_begin", C.c_int * (MAX_RINGS + 1)),
+                ("scan_start", C.c_int * MAX_RINGS),
+                ("scan_end", C.c_int * MAX_RINGS),
+                ("n_sharp", C.c_int), ("n_less_sharp", C.c_int), ("n_flat", C.c_int), ("n_less_flat", C.c_int)]
+
+
+class OdomStats(C.Structure):
+    _fields_ = [("n_corner_corr", C.c_int * 2), ("n_plane_corr", C.c_int * 2), ("lm_iters", C.c_int * 2),
+                ("initial_cost", C.c_double * 2), ("final_cost", C.c_double * 2)]
+
+
+class World(C.Structure):
+    _fields_ = [("n_boxes", C.c_int), ("boxes", C.POINTER(C.c_double)),
+                ("n_cyls", C.c_int), ("cyls", C.POINTER(C.c_double)),
+                ("ground_z", C.c_double),
+                ("n_rings", C.c_int), ("elev_rad", C.POINTER(C.c_double)),
+                ("n_az", C.c_int),
+                ("range_sigma", C.c_double), ("dropout", C.c_double), ("max_range", C.c_double),
+                ("seed", C.c_uint64)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.lo_kdtree_build.restype = C.c_void_p
+        _lib.lo_kdtree_nn.restype = C.c_int
+        _lib.lo_brute_nn.restype = C.c_int
+        _lib.lo_synth_scan.restype = C.c_int
+    return _lib
+
+
+def _fp(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def scanreg(xyzi, n_lines=64, min_range=5.0):
+    """Returns dict(cloud, curvature, label, sharp, less_sharp, flat, less_flat, info)."""
+    xyzi = np.ascontiguousarray(xyzi, dtype=np.float32).reshape(-1, 4)
+    n = xyzi.shape[0]
+    cap = max(n, 1)
+    cloud = np.zeros((cap, 4), np.float32)
+    curv = np.zeros(cap, np.float32)
+    label = np.zeros(cap, np.int32)
+    outs = [np.zeros((cap, 4), np.float32) for _ in range(4)]
+    info = ScanregInfo()
+    rc = lib().lo_scanreg(_fp(xyzi, C.c_float), C.c_int(n), C.c_int(n_lines), C.c_float(min_range),
+                          _fp(cloud, C.c_float), _fp(curv, C.c_float), _fp(label, C.c_int32),
+                          *[_fp(o, C.c_float) for o in outs], C.byref(info))
+    if rc != 0:
+        raise RuntimeError("lo_scanreg failed: %d" % rc)
+    nc = info.n_cloud
+    return dict(cloud=cloud[:nc], curvature=curv[:nc], label=label[:nc],
+                sharp=outs[0][:info.n_sharp], less_sharp=outs[1][:info.n_less_sharp],
+                flat=outs[2][:info.n_flat], less_flat=outs[3][:info.n_less_flat],
+                ring_begin=np.array(info.ring_begin[:], np.int32), info=info)
+
+
+def odom_step(sharp, flat, corner_last, surf_last, q, t, use_kdtree=True, want_corr=False):
+    arrs = [np.ascontiguousarray(a, np.float32).reshape(-1, 4) for a in (sharp, flat, corner_last, surf_last)]
+    q = np.array(q, np.float64).copy()
+    t = np.array(t, np.float64).copy()
+    st = OdomStats()
+    corr = np.zeros((2, arrs[0].shape[0] + arrs[1].shape[0], 4), np.int32) if want_corr else None
+    lib().lo_odom_step(_fp(arrs[0], C.c_float), C.c_int(arrs[0].shape[0]), _fp(arrs[1], C.c_float), C.c_int(arrs[1].shape[0]),
+                       _fp(arrs[2], C.c_float), C.c_int(arrs[2].shape[0]), _fp(arrs[3], C.c_float), C.c_int(arrs[3].shape[0]),
+                       _fp(q, C.c_double), _fp(t, C.c_double), C.c_int(1 if use_kdtree else 0), C.byref(st),
+                       _fp(corr, C.c_int32) if want_corr else None)
+    return q, t, st, corr
+
+
+def nn(points, queries, use_kdtree=True):
+    pts = np.ascontiguousarray(points, np.float32).reshape(-1, 4)
+    qs = np.ascontiguousarray(queries, np.float32).reshape(-1, 3)
+    idx = np.zeros(len(qs), np.int32)
+    d2 = np.zeros(len(qs), np.float32)
+    L = lib()
+    tree = C.c_void_p(L.lo_kdtree_build(_fp(pts, C.c_float), C.c_int(len(pts)))) if use_kdtree else None
+    dd = C.c_float()
+    for i, qq in enumerate(qs):
+        if use_kdtree:
+            idx[i] = L.lo_kdtree_nn(tree, C.c_float(qq[0]), C.c_float(qq[1]), C.c_float(qq[2]), C.byref(dd))
+        else:
+            idx[i] = L.lo_brute_nn(_fp(pts, C.c_float), C.c_int(len(pts)), C.c_float(qq[0]), C.c_float(qq[1]), C.c_float(qq[2]), C.byref(dd))
+        d2[i] = dd.value
+    if use_kdtree:
+        L.lo_kdtree_free(tree)
+    return idx, d2
+
+
+def run_sequence(xyzi, offsets, n_lines=64, min_range=5.0, n_chains=1, lead=0, use_kdtree=True, threads=1):
+    """Full CPU path over a sequence.  Returns dict(incr[n,7], poses[n,7], feat_counts[n,4], stage_ms[2])."""
+    xyzi = np.ascontiguousarray(xyzi, np.float32).reshape(-1, 4)
+    offsets = np.ascontiguousarray(offsets, np.int64)
+    n = len(offsets) - 1
+    incr = np.zeros((n, 7)); poses = np.zeros((n, 7))
+    counts = np.zeros((n, 4), np.int32)
+    ms = np.zeros(2)
+    rc = lib().lo_run_sequence(_fp(xyzi, C.c_float), _fp(offsets, C.c_int64), C.c_int(n), C.c_int(n_lines), C.c_float(min_range),
+                               C.c_int(n_chains), C.c_int(lead), C.c_int(1 if use_kdtree else 0), C.c_int(threads),
+                               _fp(incr, C.c_double), _fp(poses, C.c_double), _fp(counts, C.c_int32), _fp(ms, C.c_double))
+    if rc != 0:
+        raise RuntimeError("lo_run_sequence failed: %d" % rc)
+    return dict(incr=incr, poses=poses, feat_counts=counts, stage_ms=ms)
+
+
+# --------------------------------------------------------------------------------------------
+# Synthetic workload S1
+# --------------------------------------------------------------------------------------------
+def hdl64_elevations_rad():
+    """HDL-64E: upper bank +2 .. -8.33 deg step 1/3 deg (32 lasers), lower bank -8.83 .. -24.33 step 1/2."""
+    up = 2.0 - np.arange(32) / 3.0
+    lo = -8.83 - np.arange(32) / 2.0
+    return np.deg2rad(np.concatenate([up, lo]))
+
+
+class S1World:
+    """Ground plane z=-1.73 + 40 boxes + 60 poles in a 200 m x 200 m area, numpy default_rng(20240)."""
+
+    def __init__(self, seed=20240, n_az=2000, n_rings=64, range_sigma=0.02, dropout=0.05, max_range=120.0):
+        rng = np.random.default_rng(seed)
+        boxes = []
+        for _ in range(40):
+            cx, cy = rng.uniform(-95, 95, 2)
+            if abs(cx) < 6 and abs(cy) < 6:
+                cx += 15.0
+            sx, sy = rng.uniform(2, 20), rng.uniform(2, 20)
+            h = rng.uniform(2.5, 12)
+            boxes.append([cx - sx / 2, cy - sy / 2, -1.73, cx + sx / 2, cy + sy / 2, -1.73 + h])
+        cyls = []
+        for _ in range(60):
+            cx, cy = rng.uniform(-95, 95, 2)
+            cyls.append([cx, cy, 0.15, -1.73 + rng.uniform(3, 8)])
+        self.boxes = np.array(boxes, np.float64)
+        self.cyls = np.array(cyls, np.float64)
+        self.elev = hdl64_elevations_rad()[:n_rings].copy() if n_rings == 64 else np.deg2rad(np.linspace(15, -25, n_rings))
+        self.n_az = n_az
+        self.n_rings = n_rings
+        self.w = World(len(boxes), _fp(self.boxes, C.c_double), len(cyls), _fp(self.cyls, C.c_double), -1.73,
+                       n_rings, _fp(self.elev, C.c_double), n_az, range_sigma, dropout, max_range, seed)
+
+    def trajectory(self, n_scans, dt=0.1, speed=8.0):
+        """Planar figure-8 (Gerono lemniscate scaled so that |yaw rate| <= 0.3 rad/s), keeping clear of boxes is
+        not attempted: the sensor may pass through obstacles, rays then start inside them (harmless)."""
+        a = 60.0
+        # arc-length parameterisation by numerical integration
+        u = np.linspace(0, 2 * np.pi, 20001)
+        x = a * np.sin(u); y = a * np.sin(u) * np.cos(u) * 0.9
+        ds = np.hypot(np.diff(x), np.diff(y))
+        s = np.concatenate([[0], np.cumsum(ds)])
+        total = s[-1]
+        sk = (np.arange(n_scans) * dt * speed) % total
+        uk = np.interp(sk, s, u)
+        xk = a * np.sin(uk); yk = a * np.sin(uk) * np.cos(uk) * 0.9
+        dx = a * np.cos(uk); dy = a * 0.9 * (np.cos(uk) ** 2 - np.sin(uk) ** 2)
+        yaw = np.unwrap(np.arctan2(dy, dx))
+        return np.stack([xk, yk, np.zeros(n_scans), yaw], 1)
+
+    def scans(self, poses, scan_id0=0):
+        """Returns (xyzi [N,4] float32 concatenated, offsets int64 [n+1])."""
+        poses = np.ascontiguousarray(poses, np.float64)
+        n = len(poses)
+        slot = self.n_rings * self.n_az * 4
+        chunks, counts_all = [], []
+        L = lib()
+        for c0 in range(0, n, 128):
+            m = min(128, n - c0)
+            buf = np.empty((m, slot), np.float32)
+            counts = np.zeros(m, np.int32)
+            L.lo_synth_scans(C.byref(self.w), _fp(poses[c0:c0 + m], C.c_double), C.c_uint64(scan_id0 + c0), C.c_int(m),
+                             _fp(buf, C.c_float), C.c_int64(slot), _fp(counts, C.c_int32))
+            for i in range(m):
+                chunks.append(buf[i, :counts[i] * 4].reshape(-1, 4).copy())
+            counts_all.append(counts)
+        counts = np.concatenate(counts_all).astype(np.int64)
+        offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        return np.concatenate(chunks, 0), offsets
+
+
+def gt_relative(poses):
+    """Ground-truth sensor-frame poses relative to scan 0: returns [n,7] (q xyzw, t)."""
+    out = np.zeros((len(poses), 7))
+    x0, y0, _, yaw0 = poses[0]
+    c, s = np.cos(-yaw0), np.sin(-yaw0)
+    for k, (x, y, z, yaw) in enumerate(poses):
+        dx, dy = x - x0, y - y0
+        out[k, 4] = c * dx - s * dy
+        out[k, 5] = s * dx + c * dy
+        out[k, 6] = z - poses[0][2]
+        half = 0.5 * (yaw - yaw0)
+        out[k, 2] = np.sin(half); out[k, 3] = np.cos(half)
+    return out
+
+
+def ate(poses_a, poses_b):
+    """RMS translation difference between two [n,7] pose arrays expressed in the same frame (no alignment)."""
+    d = poses_a[:, 4:7] - poses_b[:, 4:7]
+    return float(np.sqrt((d ** 2).sum(1).mean()))
