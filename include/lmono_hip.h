@@ -1,0 +1,87 @@
+/*
+ * include/lmono_hip.h -- C ABI of the MI355X-native lmono per-scan hot path.
+ *
+ * The reference (bobocode/lmono, ROS-1 C++) has no FFI / plugin registry; its seams are ROS topics,
+ * the Estimator call surface and the Ceres cost-function ABI.  Each entry point below
+ * names the reference interface it stands in for.  All functions return 0 on success or a negative
+ * LMONO_E* code, never throw, and are re-entrant per context.  Pointers suffixed _d are device (HBM)
+ * pointers, _h host pointers.  No torch / HIP types appear in signatures (streams travel as void*).
+ */
+#ifndef LMONO_HIP_H
+#define LMONO_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LMONO_OK            0
+#define LMONO_EINVAL       -1   /* bad argument                                            */
+#define LMONO_ENODEV       -2   /* no usable gfx950 device / HIP runtime error              */
+#define LMONO_ENOMEM       -3   /* device allocation failed                                 */
+#define LMONO_ECAPACITY    -4   /* batch exceeds the capacity it was created with           */
+#define LMONO_ESCAN        -5   /* a scan violated a kernel limit (see lmono_batch_status)  */
+
+#define LMONO_MAX_RINGS     64
+#define LMONO_RING_CAP      4096  /* max points of one ring after filtering                 */
+#define LMONO_MAX_SHARP     (64 * 6 * 2)
+#define LMONO_MAX_LESS_SHARP (64 * 6 * 20)
+#define LMONO_MAX_FLAT      (64 * 6 * 4)
+
+typedef struct lmono_ctx lmono_ctx;
+typedef struct lmono_scan_batch lmono_scan_batch;
+
+/* ---- context ---------------------------------------------------------------------------- */
+lmono_ctx  *lmono_create(int device);           /* NULL when HIP / the device is unavailable */
+void        lmono_destroy(lmono_ctx *);
+const char *lmono_last_error(const lmono_ctx *);
+int         lmono_set_stream(lmono_ctx *, void *hip_stream); /* hipStream_t; NULL = default  */
+int         lmono_synchronize(lmono_ctx *);
+const char *lmono_version(void);
+
+/* ---- LiDAR front end: A-LOAM scanRegistration::laserCloudHandler ------------------------ *
+ * Reference interface: ROS node "ascanRegistration" subscribing /velodyne_points and
+ * publishing /laser_cloud_{sharp,less_sharp,flat,less_flat} (source absent from the reference tree:
+ * /root/reference/.gitmodules:1-3, README.md:54-60; behavioural spec SURVEY.md Appendix A.1).
+ * A batch holds the device-resident working set of n independent scans.                      */
+lmono_scan_batch *lmono_batch_create(lmono_ctx *, int n_scans_cap, int64_t total_points_cap);
+void              lmono_batch_destroy(lmono_scan_batch *);
+
+/* xyzi_d: [total][4] float32 (KITTI .bin layout) already resident in HBM; offsets_h: [n_scans+1]
+ * point offsets of each scan.  n_lines in {16,32,64}; min_range = A-LOAM `minimum_range`.    */
+int lmono_scanreg_batch(lmono_ctx *, lmono_scan_batch *, const float *xyzi_d, const int64_t *offsets_h,
+                        int n_scans, int n_lines, float min_range);
+
+/* counts_h: [n_scans][6] = n_cloud, n_sharp, n_less_sharp, n_flat, n_less_flat, status          */
+int lmono_batch_counts(lmono_ctx *, lmono_scan_batch *, int32_t *counts_h);
+/* which: 0 ring-sorted cloud, 1 sharp, 2 less_sharp, 3 flat, 4 less_flat.  out_h: [cap][4] float32.
+ * Returns the number of points copied (>= 0) or a negative error.                               */
+int lmono_batch_get_cloud(lmono_ctx *, lmono_scan_batch *, int scan, int which, float *out_h, int cap);
+/* curvature (float32) and label (int32: 2 sharp, 1 less sharp, -1 flat, 0 other) of the sorted cloud */
+int lmono_batch_get_curvature(lmono_ctx *, lmono_scan_batch *, int scan, float *curv_h, int32_t *label_h, int cap);
+
+/* ---- LiDAR odometry: A-LOAM laserOdometry main loop + lidarFactor.hpp + ceres::Solve ------- *
+ * Reference interface: ROS node "alaserOdometry" (feature clouds in, /laser_odom_to_init out; spec
+ * SURVEY.md Appendix A.2/A.3).  Runs scan-to-scan odometry over the scans of a registered batch.
+ * The sequence is cut into n_chains contiguous ranges processed concurrently; a range starting at
+ * scan s > 0 starts `lead` scans early from an identity warm start and discards its lead-in
+ * (n_chains = 1, lead = 0 = the strictly sequential reference behaviour).
+ * incr_h / poses_h (either may be NULL): [n_scans][7] = q(x,y,z,w), t of T(k-1 -> k) and of the
+ * accumulated pose t_w += q_w * t, q_w = q_w * q.                                              */
+int lmono_odom_batch(lmono_ctx *, lmono_scan_batch *, int n_chains, int lead, double *incr_h, double *poses_h);
+/* Same, results stay on the device: incr_d, poses_d [n_scans][7] float64 (may be NULL).       */
+int lmono_odom_batch_d(lmono_ctx *, lmono_scan_batch *, int n_chains, int lead, double *incr_d, double *poses_d);
+
+/* Debug/parity view of one odometry step: correspondences of outer iteration `outer` (0/1) for the scan
+ * pair (scan-1, scan) evaluated at pose q,t: corr_h [n_sharp + n_flat][4] = (a, b, c, kind).       */
+int lmono_odom_correspond(lmono_ctx *, lmono_scan_batch *, int scan, const double q[4], const double t[3],
+                          int32_t *corr_h, int cap);
+
+/* device time (ms) of the stages of the last lmono_scanreg_batch / lmono_odom_batch call, measured with
+ * hipEvents on the context stream: [0] scanreg total, [1] odometry total, [2..] per-kernel groups      */
+int lmono_last_timing(lmono_ctx *, double *ms_out, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

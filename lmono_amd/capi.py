@@ -1,0 +1,158 @@
+"""ctypes binding of include/lmono_hip.h (the drop-in C ABI).  Fails loudly when the library is absent."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+MAX_QUERIES = 64 * 6 * 2 + 64 * 6 * 4
+
+# every symbol include/lmono_hip.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "lmono_create", "lmono_destroy", "lmono_last_error", "lmono_set_stream", "lmono_synchronize", "lmono_version",
+    "lmono_batch_create", "lmono_batch_destroy", "lmono_scanreg_batch", "lmono_batch_counts", "lmono_batch_get_cloud",
+    "lmono_batch_get_curvature", "lmono_odom_batch", "lmono_odom_batch_d", "lmono_odom_correspond", "lmono_last_timing",
+]
+
+
+class LmonoError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "liblmono_hip.so")
+
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not os.path.exists(p):
+        raise LmonoError("HIP library %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`" % p)
+    L = C.CDLL(p)
+    L.lmono_create.restype = C.c_void_p
+    L.lmono_create.argtypes = [C.c_int]
+    L.lmono_destroy.argtypes = [C.c_void_p]
+    L.lmono_last_error.restype = C.c_char_p
+    L.lmono_last_error.argtypes = [C.c_void_p]
+    L.lmono_version.restype = C.c_char_p
+    L.lmono_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.lmono_synchronize.argtypes = [C.c_void_p]
+    L.lmono_batch_create.restype = C.c_void_p
+    L.lmono_batch_create.argtypes = [C.c_void_p, C.c_int, C.c_int64]
+    L.lmono_batch_destroy.argtypes = [C.c_void_p]
+    L.lmono_scanreg_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float]
+    L.lmono_batch_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.lmono_batch_get_cloud.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    L.lmono_batch_get_curvature.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    L.lmono_odom_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.lmono_odom_batch_d.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.lmono_odom_correspond.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.lmono_last_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    _lib = L
+    return L
+
+
+class Context:
+    """lmono_ctx wrapper.  One per process / GPU."""
+
+    def __init__(self, device=0):
+        self.L = load_library()
+        self.h = self.L.lmono_create(int(device))
+        if not self.h:
+            raise LmonoError("lmono_create(%d) failed: no usable HIP device" % device)
+        self.device = device
+
+    def check(self, rc):
+        if rc < 0:
+            raise LmonoError("lmono error %d: %s" % (rc, self.L.lmono_last_error(self.h).decode()))
+        return rc
+
+    def set_stream(self, raw_stream):
+        self.check(self.L.lmono_set_stream(self.h, C.c_void_p(raw_stream)))
+
+    def synchronize(self):
+        self.check(self.L.lmono_synchronize(self.h))
+
+    def timing(self):
+        ms = np.zeros(8)
+        self.check(self.L.lmono_last_timing(self.h, ms.ctypes.data, 8))
+        return ms
+
+    def close(self):
+        if self.h:
+            self.L.lmono_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ScanBatch:
+    """Device-resident working set of a batch of scans (lmono_scan_batch)."""
+
+    def __init__(self, ctx, n_scans_cap, total_points_cap):
+        self.ctx = ctx
+        self.h = ctx.L.lmono_batch_create(ctx.h, int(n_scans_cap), int(total_points_cap))
+        if not self.h:
+            raise LmonoError("lmono_batch_create failed: %s" % ctx.L.lmono_last_error(ctx.h).decode())
+        self.n_scans = 0
+        self._keep = None
+
+    def scanreg(self, xyzi_dev_ptr, offsets, n_lines=64, min_range=5.0, keepalive=None):
+        """xyzi_dev_ptr: raw device pointer of a [total,4] float32 array resident in HBM."""
+        offsets = np.ascontiguousarray(offsets, np.int64)
+        self.n_scans = len(offsets) - 1
+        self._keep = keepalive
+        self.ctx.check(self.ctx.L.lmono_scanreg_batch(self.ctx.h, self.h, C.c_void_p(xyzi_dev_ptr), offsets.ctypes.data,
+                                                       self.n_scans, int(n_lines), float(min_range)))
+
+    def counts(self):
+        out = np.zeros((self.n_scans, 6), np.int32)
+        self.ctx.check(self.ctx.L.lmono_batch_counts(self.ctx.h, self.h, out.ctypes.data))
+        return out
+
+    def cloud(self, scan, which, cap):
+        out = np.zeros((max(cap, 1), 4), np.float32)
+        n = self.ctx.check(self.ctx.L.lmono_batch_get_cloud(self.ctx.h, self.h, scan, which, out.ctypes.data, cap))
+        return out[:n]
+
+    def curvature(self, scan, cap):
+        cv = np.zeros(max(cap, 1), np.float32)
+        lb = np.zeros(max(cap, 1), np.int32)
+        n = self.ctx.check(self.ctx.L.lmono_batch_get_curvature(self.ctx.h, self.h, scan, cv.ctypes.data, lb.ctypes.data, cap))
+        return cv[:n], lb[:n]
+
+    def odometry(self, n_chains=1, lead=0):
+        incr = np.zeros((self.n_scans, 7))
+        poses = np.zeros((self.n_scans, 7))
+        self.ctx.check(self.ctx.L.lmono_odom_batch(self.ctx.h, self.h, n_chains, lead, incr.ctypes.data, poses.ctypes.data))
+        return incr, poses
+
+    def odometry_d(self, n_chains, lead, incr_ptr=None, poses_ptr=None):
+        self.ctx.check(self.ctx.L.lmono_odom_batch_d(self.ctx.h, self.h, n_chains, lead,
+                                                      C.c_void_p(incr_ptr or 0), C.c_void_p(poses_ptr or 0)))
+
+    def correspond(self, scan, q, t):
+        q = np.ascontiguousarray(q, np.float64); t = np.ascontiguousarray(t, np.float64)
+        out = np.zeros((MAX_QUERIES, 4), np.int32)
+        n = self.ctx.check(self.ctx.L.lmono_odom_correspond(self.ctx.h, self.h, scan, q.ctypes.data, t.ctypes.data, out.ctypes.data, MAX_QUERIES))
+        return out[:n]
+
+    def close(self):
+        if self.h:
+            self.ctx.L.lmono_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

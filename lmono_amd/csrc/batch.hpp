@@ -1,0 +1,54 @@
+// lmono_amd/csrc/batch.hpp -- device-resident working set of a batch of scans (HBM layout).
+#pragma once
+#include "common.hpp"
+
+namespace lmono {
+
+// hash grid over a "last" feature cloud (cell edge 1 m)
+constexpr int kCornerTable = 16384;   // >= 2 * kMaxLessSharp
+constexpr int kSurfTable = 131072;    // surf cloud capacity = kSurfTable / 2 points
+constexpr unsigned long long kEmptyKey = ~0ull;
+
+struct BatchView {
+    // ---- inputs
+    const float4 *in;        // [total] raw x y z reflectance
+    const int64_t *off;      // [n_scans + 1] point offsets (device copy)
+    int n_scans;
+    int n_lines;
+    float min_range;
+    // ---- ring-sorted cloud (same offsets as the input; n_cloud[s] valid points)
+    float4 *cloud;           // [total] x y z (ring + 0.1 relTime)
+    float *curv;             // [total]
+    int8_t *label;           // [total]
+    uint8_t *gap;            // [total] gap[i] = |p[i+1]-p[i]|^2 > 0.05
+    int8_t *ring_tmp;        // [total] ring id per input point (-1 = discarded)
+    float *ori_tmp;          // [total] -atan2(y, x) per input point
+    int *ring_begin;         // [n_scans][65]
+    int *n_cloud;            // [n_scans]
+    int *status;             // [n_scans]
+    // ---- per (scan, ring, sector) selections, indices local to the scan's cloud
+    int *sel_sharp;          // [n_scans][64][6][20]
+    int *sel_sharp_n;        // [n_scans][64][6]
+    int *sel_flat;           // [n_scans][64][6][4]
+    int *sel_flat_n;         // [n_scans][64][6]
+    float4 *lf_tmp;          // [total] voxel-filtered less-flat points in ring slots
+    int *lf_n;               // [n_scans][64]
+    // ---- final feature clouds
+    float4 *sharp;           // [n_scans][kMaxSharp]
+    float4 *less_sharp;      // [n_scans][kMaxLessSharp]
+    float4 *flat;            // [n_scans][kMaxFlat]
+    float4 *less_flat;       // [total] (scan offsets as input)
+    int *feat_n;             // [n_scans][4] sharp, less_sharp, flat, less_flat
+    int *ls_ring_start;      // [n_scans][65] first index with int(intensity) >= r in less_sharp
+    int *lf_ring_start;      // [n_scans][65] same for less_flat
+    // ---- hash grids of less_sharp / less_flat (used as the "last" clouds of the next scan)
+    unsigned long long *cg_key;  int *cg_cnt;  int *cg_start;   // [n_scans][kCornerTable]
+    unsigned long long *sg_key;  int *sg_cnt;  int *sg_start;   // [n_scans][kSurfTable]
+    float4 *cg_pts;          // [n_scans][kMaxLessSharp]  cell-sorted copy, .w = original index bits
+    float4 *sg_pts;          // [total]
+    int *grid_mask;          // [n_scans][2] table size - 1 actually used (corner, surf): power of two >= 2 n
+    int *sg_slot, *sg_rank;  // [total] scratch: table slot of each surf point / rank inside its cell
+    int *cg_slot, *cg_rank;  // [n_scans][kMaxLessSharp] same for corner points
+};
+
+} // namespace lmono

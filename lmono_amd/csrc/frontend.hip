@@ -1,0 +1,480 @@
+// lmono_amd/csrc/frontend.hip -- gfx950 kernels of the LiDAR front end (A-LOAM scanRegistration;
+// source absent from the reference tree, behavioural spec SURVEY.md Appendix A.1).
+//
+// Four kernels per batch of scans, every one a coalesced sweep over HBM-resident SoA/float4 pools:
+//   k_ring_sort  one workgroup per scan: filter, ring id, azimuth, stable counting sort into ring-major order
+//   k_curvature  one workgroup per 1024-point tile: LDS tile with +-5 halo, curvature and neighbour-gap flags
+//   k_select     one workgroup per (scan, ring): per-sector bitonic sort in LDS, wave-parallel edge/planar
+//                selection with neighbour suppression, voxel-grid down-sampling of the less-flat points
+//   k_compact    one workgroup per scan: prefix sums over (ring, sector) and compaction of the four clouds
+// Arithmetic is float/double exactly as the CPU restatement evaluates it (compiled with -ffp-contract=off).
+#include "batch.hpp"
+
+namespace lmono {
+
+__device__ __forceinline__ int ring_of(float angle, int n_lines, bool &discard)
+{
+    int id = 0;
+    discard = false;
+    if (n_lines == 16) {
+        id = (int)((double)((angle + 15.0f) / 2.0f) + 0.5);
+        if (id > n_lines - 1 || id < 0) discard = true;
+    } else if (n_lines == 32) {
+        id = (int)(((double)angle + 92.0 / 3.0) * 3.0 / 4.0);
+        if (id > n_lines - 1 || id < 0) discard = true;
+    } else {
+        if ((double)angle >= -8.83)
+            id = (int)((double)(2.0f - angle) * 3.0 + 0.5);
+        else
+            id = n_lines / 2 + (int)((-8.83 - (double)angle) * 2.0 + 0.5);
+        if ((double)angle > 2.0 || (double)angle < -24.33 || id > 50 || id < 0) discard = true;
+    }
+    return id;
+}
+
+__device__ __forceinline__ bool point_valid(const float4 &p, float mr2)
+{
+    return isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && !(p.x * p.x + p.y * p.y + p.z * p.z < mr2);
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_ring_sort(BatchView b)
+{
+    const int s = blockIdx.x;
+    const int64_t off = b.off[s];
+    const int n = (int)(b.off[s + 1] - off);
+    const float4 *in = b.in + off;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ int s_first, s_last, s_half;
+    __shared__ int s_cnt[64], s_base[64], s_tile[64];
+    __shared__ int s_wcnt[16][64];
+    __shared__ float s_ori[2];
+    if (tid < 64) s_cnt[tid] = 0;
+    if (tid == 0) { s_first = INT_MAX; s_last = -1; s_half = INT_MAX; }
+    __syncthreads();
+    const float mr2 = b.min_range * b.min_range;
+    int lf = INT_MAX, ll = -1;
+    for (int i = tid; i < n; i += 1024) {
+        const float4 p = in[i];
+        if (point_valid(p, mr2)) { lf = min(lf, i); ll = max(ll, i); }
+    }
+    lf = wave_min_i(lf); ll = wave_max_i(ll);
+    if (lane == 0) { atomicMin(&s_first, lf); atomicMax(&s_last, ll); }
+    __syncthreads();
+    int *rb = b.ring_begin + s * 65;
+    if (s_last < 0) {
+        if (tid < 65) rb[tid] = 0;
+        if (tid == 0) b.n_cloud[s] = 0;
+        return;
+    }
+    if (tid == 0) {
+        const float4 p0 = in[s_first], p1 = in[s_last];
+        const float startOri = (float)(-det_atan2((double)p0.y, (double)p0.x));
+        float endOri = (float)((double)(float)(-det_atan2((double)p1.y, (double)p1.x)) + 2.0 * LM_PI);
+        if ((double)(endOri - startOri) > 3.0 * LM_PI) endOri = (float)((double)endOri - 2.0 * LM_PI);
+        else if ((double)(endOri - startOri) < LM_PI) endOri = (float)((double)endOri + 2.0 * LM_PI);
+        s_ori[0] = startOri; s_ori[1] = endOri;
+    }
+    __syncthreads();
+    const float startOri = s_ori[0], endOri = s_ori[1];
+    const int n_lines = b.n_lines;
+    int lh = INT_MAX;
+    for (int i = tid; i < n; i += 1024) {
+        const float4 p = in[i];
+        int id = -1;
+        float ori = 0.f;
+        if (point_valid(p, mr2)) {
+            const float angle = (float)(det_atan((double)p.z / sqrt((double)(p.x * p.x + p.y * p.y))) * 180.0 / LM_PI);
+            bool discard;
+            const int r = ring_of(angle, n_lines, discard);
+            if (!discard) {
+                id = r;
+                ori = (float)(-det_atan2((double)p.y, (double)p.x));
+                float o1 = ori;
+                if ((double)o1 < (double)startOri - LM_PI / 2.0) o1 = (float)((double)o1 + 2.0 * LM_PI);
+                else if ((double)o1 > (double)startOri + LM_PI * 3.0 / 2.0) o1 = (float)((double)o1 - 2.0 * LM_PI);
+                if ((double)(o1 - startOri) > LM_PI) lh = min(lh, i);
+                atomicAdd(&s_cnt[id], 1);
+            }
+        }
+        b.ring_tmp[off + i] = (int8_t)id;
+        b.ori_tmp[off + i] = ori;
+    }
+    lh = wave_min_i(lh);
+    if (lane == 0 && lh != INT_MAX) atomicMin(&s_half, lh);
+    __syncthreads();
+    if (tid == 0) {
+        int t = 0;
+        for (int r = 0; r < 64; r++) { rb[r] = t; s_base[r] = t; t += s_cnt[r]; }
+        rb[64] = t;
+        b.n_cloud[s] = t;
+    }
+    __syncthreads();
+    const int half = s_half;
+    for (int t0 = 0; t0 < n; t0 += 1024) {
+        const int i = t0 + tid;
+        const int id = (i < n) ? (int)b.ring_tmp[off + i] : -1;
+        int rank = 0;
+        s_wcnt[wave][lane] = 0;
+        unsigned long long rem = __ballot(id >= 0);
+        while (rem) {
+            const int src = __ffsll((long long)rem) - 1;
+            const int k = __shfl(id, src);
+            const unsigned long long m = __ballot(id == k);
+            if (id == k) rank = __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == src) s_wcnt[wave][k] = __popcll(m);
+            rem &= ~m;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            int acc = 0;
+            for (int w = 0; w < 16; w++) { const int c = s_wcnt[w][tid]; s_wcnt[w][tid] = acc; acc += c; }
+            s_tile[tid] = acc;
+        }
+        __syncthreads();
+        if (id >= 0) {
+            const float4 p = in[i];
+            float ori = b.ori_tmp[off + i];
+            if (i <= half) {
+                if ((double)ori < (double)startOri - LM_PI / 2.0) ori = (float)((double)ori + 2.0 * LM_PI);
+                else if ((double)ori > (double)startOri + LM_PI * 3.0 / 2.0) ori = (float)((double)ori - 2.0 * LM_PI);
+            } else {
+                ori = (float)((double)ori + 2.0 * LM_PI);
+                if ((double)ori < (double)endOri - LM_PI * 3.0 / 2.0) ori = (float)((double)ori + 2.0 * LM_PI);
+                else if ((double)ori > (double)endOri + LM_PI / 2.0) ori = (float)((double)ori - 2.0 * LM_PI);
+            }
+            const float relTime = (ori - startOri) / (endOri - startOri);
+            const float inten = (float)((double)id + 0.1 * (double)relTime);
+            const int dst = s_base[id] + s_wcnt[wave][id] + rank;
+            b.cloud[off + dst] = make_float4(p.x, p.y, p.z, inten);
+        }
+        __syncthreads();
+        if (tid < 64) s_base[tid] += s_tile[tid];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+constexpr int kCurvTile = 1024;
+
+__global__ __launch_bounds__(256) void k_curvature(BatchView b)
+{
+    const int s = blockIdx.y;
+    const int n = b.n_cloud[s];
+    const int t0 = blockIdx.x * kCurvTile;
+    if (t0 >= n) return;
+    const int64_t off = b.off[s];
+    const float4 *c = b.cloud + off;
+    __shared__ float sx[kCurvTile + 10], sy[kCurvTile + 10], sz[kCurvTile + 10];
+    for (int k = threadIdx.x; k < kCurvTile + 10; k += 256) {
+        const int i = t0 - 5 + k;
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i >= 0 && i < n) p = c[i];
+        sx[k] = p.x; sy[k] = p.y; sz[k] = p.z;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < kCurvTile; k += 256) {
+        const int i = t0 + k;
+        if (i >= n) break;
+        const int q = k + 5;
+        float cv = 0.f;
+        if (i >= 5 && i < n - 5) {
+            const float dx = sx[q - 5] + sx[q - 4] + sx[q - 3] + sx[q - 2] + sx[q - 1] - 10 * sx[q] + sx[q + 1] + sx[q + 2] + sx[q + 3] + sx[q + 4] + sx[q + 5];
+            const float dy = sy[q - 5] + sy[q - 4] + sy[q - 3] + sy[q - 2] + sy[q - 1] - 10 * sy[q] + sy[q + 1] + sy[q + 2] + sy[q + 3] + sy[q + 4] + sy[q + 5];
+            const float dz = sz[q - 5] + sz[q - 4] + sz[q - 3] + sz[q - 2] + sz[q - 1] - 10 * sz[q] + sz[q + 1] + sz[q + 2] + sz[q + 3] + sz[q + 4] + sz[q + 5];
+            cv = dx * dx + dy * dy + dz * dz;
+        }
+        b.curv[off + i] = cv;
+        unsigned char g = 0;
+        if (i + 1 < n) {
+            const float gx = sx[q + 1] - sx[q], gy = sy[q + 1] - sy[q], gz = sz[q + 1] - sz[q];
+            g = ((double)(gx * gx + gy * gy + gz * gz) > 0.05) ? 1 : 0;
+        }
+        b.gap[off + i] = g;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// neighbour suppression after a pick at ring-local index pind: lanes 0..4 walk forward, lanes 5..9 backward,
+// each direction stops at the first gap whose squared length exceeds 0.05
+__device__ __forceinline__ void mark_neighbours(volatile unsigned char *picked, const unsigned char *gap, int pind, int lane)
+{
+    const bool fwd = lane < 5;
+    const bool active = lane < 10;
+    const int l = fwd ? lane + 1 : lane - 4;            // 1..5
+    const int gi = fwd ? pind + l - 1 : pind - l;        // gap between the two consecutive points of step l
+    const bool brk = active ? (gap[gi] != 0) : false;
+    const unsigned long long mb = __ballot(brk);
+    const unsigned int mf = (unsigned int)(mb & 0x1full), mbk = (unsigned int)((mb >> 5) & 0x1full);
+    const int lim_f = mf ? (__ffs((int)mf) - 1) : 5;
+    const int lim_b = mbk ? (__ffs((int)mbk) - 1) : 5;
+    if (active) {
+        const int li = fwd ? lane : lane - 5;
+        if (li < (fwd ? lim_f : lim_b)) picked[fwd ? pind + l : pind - l] = 1;
+    }
+}
+
+constexpr int kSelKeysBytes = kRingCap * 8;
+constexpr int kSelLds = kSelKeysBytes + kRingCap * 4 + kRingCap * 3 + 1024;
+
+__global__ __launch_bounds__(256) void k_select(BatchView b)
+{
+    const int r = blockIdx.x, s = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t off = b.off[s];
+    const int *rb = b.ring_begin + s * 65;
+    const int rbeg = rb[r], rend = rb[r + 1], len = rend - rbeg;
+    const int S = rbeg + 5, E = rend - 6;
+    int *sel_sh = b.sel_sharp + (size_t)((s * 64 + r) * kSectors) * 20;
+    int *sel_sh_n = b.sel_sharp_n + (s * 64 + r) * kSectors;
+    int *sel_fl = b.sel_flat + (size_t)((s * 64 + r) * kSectors) * 4;
+    int *sel_fl_n = b.sel_flat_n + (s * 64 + r) * kSectors;
+    if (E - S < 6 || len > kRingCap) {
+        if (tid < kSectors) { sel_sh_n[tid] = 0; sel_fl_n[tid] = 0; }
+        if (tid == 0) {
+            b.lf_n[s * 64 + r] = 0;
+            if (len > kRingCap) atomicOr(&b.status[s], kStatusRingOverflow);
+        }
+        for (int i = tid; i < len; i += 256) b.label[off + rbeg + i] = 0;
+        return;
+    }
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned long long *keys = (unsigned long long *)smem;
+    float *curv = (float *)(smem + kSelKeysBytes);
+    unsigned char *picked = smem + kSelKeysBytes + kRingCap * 4;
+    signed char *label = (signed char *)(picked + kRingCap);
+    unsigned char *gap = picked + 2 * kRingCap;
+    int *scr = (int *)(picked + 3 * kRingCap);   // 256 ints
+    volatile unsigned char *vpicked = picked;
+
+    for (int i = tid; i < len; i += 256) {
+        curv[i] = b.curv[off + rbeg + i];
+        gap[i] = b.gap[off + rbeg + i];
+        picked[i] = 0;
+        label[i] = 0;
+    }
+    __syncthreads();
+
+    const int span = E - S;
+    for (int j = 0; j < kSectors; j++) {
+        const int sp = 5 + span * j / 6;
+        const int ep = 5 + span * (j + 1) / 6 - 1;
+        const int slen = ep - sp + 1;
+        int np2 = next_pow2(slen);
+        if (np2 < 2) np2 = 2;
+        for (int i = tid; i < np2; i += 256)
+            keys[i] = (i < slen) ? pack_fu(curv[sp + i], (unsigned int)(sp + i)) : ~0ull;
+        __syncthreads();
+        bitonic_sort_u64(keys, np2);
+        if (wave == 0) {
+            // ---- largest curvature first: <= 2 sharp, <= 20 less sharp
+            int largest = 0;
+            bool stop = false;
+            for (int base = slen - 1; base >= 0 && !stop; base -= 64) {
+                const int pos = base - lane;
+                int ind = 0;
+                float c = 0.f;
+                if (pos >= 0) { ind = (int)(keys[pos] & 0xffffffffull); c = curv[ind]; }
+                const bool big = pos >= 0 && (double)c > 0.1;
+                if (!__ballot(big)) break;
+                while (true) {
+                    const bool cand = big && vpicked[ind] == 0;
+                    const unsigned long long m = __ballot(cand);
+                    if (!m) break;
+                    const int src = __ffsll((long long)m) - 1;
+                    const int pind = __shfl(ind, src);
+                    largest++;
+                    if (largest > 20) { stop = true; break; }
+                    if (lane == 0) {
+                        sel_sh[j * 20 + largest - 1] = rbeg + pind;
+                        label[pind] = largest <= 2 ? 2 : 1;
+                        vpicked[pind] = 1;
+                    }
+                    mark_neighbours(vpicked, gap, pind, lane);
+                }
+            }
+            if (lane == 0) sel_sh_n[j] = largest > 20 ? 20 : largest;
+            // ---- smallest curvature first: <= 4 flat
+            int smallest = 0;
+            stop = false;
+            for (int base = 0; base < slen && !stop; base += 64) {
+                const int pos = base + lane;
+                int ind = 0;
+                float c = 1.f;
+                if (pos < slen) { ind = (int)(keys[pos] & 0xffffffffull); c = curv[ind]; }
+                const bool small = pos < slen && (double)c < 0.1;
+                if (!__ballot(small)) break;
+                while (true) {
+                    const bool cand = small && vpicked[ind] == 0;
+                    const unsigned long long m = __ballot(cand);
+                    if (!m) break;
+                    const int src = __ffsll((long long)m) - 1;
+                    const int pind = __shfl(ind, src);
+                    if (lane == 0) { label[pind] = -1; sel_fl[j * 4 + smallest] = rbeg + pind; }
+                    smallest++;
+                    if (smallest >= 4) { stop = true; break; }
+                    if (lane == 0) vpicked[pind] = 1;
+                    mark_neighbours(vpicked, gap, pind, lane);
+                }
+            }
+            if (lane == 0) sel_fl_n[j] = smallest;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < len; i += 256) b.label[off + rbeg + i] = label[i];
+
+    // ---- less-flat candidates (label <= 0 inside the sectors) -> pcl::VoxelGrid(0.2) restated
+    const float4 *cl = b.cloud + off + rbeg;
+    const int c_lo = 5, c_hi = len - 7;   // sectors cover local [5, len-7]
+    float mnx = FLT_MAX, mny = FLT_MAX, mnz = FLT_MAX, mxx = -FLT_MAX, mxy = -FLT_MAX, mxz = -FLT_MAX;
+    int ncand = 0;
+    for (int i = c_lo + tid; i <= c_hi; i += 256) {
+        if (label[i] <= 0) {
+            const float4 p = cl[i];
+            mnx = fminf(mnx, p.x); mny = fminf(mny, p.y); mnz = fminf(mnz, p.z);
+            mxx = fmaxf(mxx, p.x); mxy = fmaxf(mxy, p.y); mxz = fmaxf(mxz, p.z);
+            ncand++;
+        }
+    }
+    float *fs = (float *)scr;   // [4 waves][6] + counts
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mnx = fminf(mnx, __shfl_xor(mnx, o)); mny = fminf(mny, __shfl_xor(mny, o)); mnz = fminf(mnz, __shfl_xor(mnz, o));
+        mxx = fmaxf(mxx, __shfl_xor(mxx, o)); mxy = fmaxf(mxy, __shfl_xor(mxy, o)); mxz = fmaxf(mxz, __shfl_xor(mxz, o));
+    }
+    ncand = wave_sum_i(ncand);
+    if (lane == 0) {
+        fs[wave * 6 + 0] = mnx; fs[wave * 6 + 1] = mny; fs[wave * 6 + 2] = mnz;
+        fs[wave * 6 + 3] = mxx; fs[wave * 6 + 4] = mxy; fs[wave * 6 + 5] = mxz;
+        scr[32 + wave] = ncand;
+    }
+    __syncthreads();
+    ncand = scr[32] + scr[33] + scr[34] + scr[35];
+    if (ncand == 0) {
+        if (tid == 0) b.lf_n[s * 64 + r] = 0;
+        return;
+    }
+    mnx = fminf(fminf(fs[0], fs[6]), fminf(fs[12], fs[18]));
+    mny = fminf(fminf(fs[1], fs[7]), fminf(fs[13], fs[19]));
+    mnz = fminf(fminf(fs[2], fs[8]), fminf(fs[14], fs[20]));
+    mxx = fmaxf(fmaxf(fs[3], fs[9]), fmaxf(fs[15], fs[21]));
+    mxy = fmaxf(fmaxf(fs[4], fs[10]), fmaxf(fs[16], fs[22]));
+    mxz = fmaxf(fmaxf(fs[5], fs[11]), fmaxf(fs[17], fs[23]));
+    const float inv_leaf = 5.0f;
+    const int minb0 = (int)floorf(mnx * inv_leaf), minb1 = (int)floorf(mny * inv_leaf), minb2 = (int)floorf(mnz * inv_leaf);
+    const int div0 = (int)floorf(mxx * inv_leaf) - minb0 + 1, div1 = (int)floorf(mxy * inv_leaf) - minb1 + 1;
+    const int mul1 = div0, mul2 = div0 * div1;
+    const int np2v = next_pow2(len);
+    __syncthreads();
+    for (int i = tid; i < np2v; i += 256) {
+        unsigned long long key = ~0ull;
+        if (i >= c_lo && i <= c_hi && label[i] <= 0) {
+            const float4 p = cl[i];
+            const int i0 = (int)(floorf(p.x * inv_leaf) - (float)minb0);
+            const int i1 = (int)(floorf(p.y * inv_leaf) - (float)minb1);
+            const int i2 = (int)(floorf(p.z * inv_leaf) - (float)minb2);
+            const unsigned int cell = (unsigned int)(i0 + i1 * mul1 + i2 * mul2);
+            key = ((unsigned long long)cell << 32) | (unsigned int)i;
+        }
+        keys[i] = key;
+    }
+    __syncthreads();
+    bitonic_sort_u64(keys, np2v);
+    // run starts -> output slots (block-wide exclusive scan over contiguous per-thread chunks)
+    const int chunk = (np2v + 255) / 256;
+    const int t_lo = tid * chunk, t_hi = min(t_lo + chunk, ncand);
+    int nstart = 0;
+    for (int t = t_lo; t < t_hi; t++) {
+        const unsigned int cell = (unsigned int)(keys[t] >> 32);
+        if (t == 0 || cell != (unsigned int)(keys[t - 1] >> 32)) nstart++;
+    }
+    const int incl = wave_scan_incl(nstart);
+    if (lane == 63) scr[40 + wave] = incl;
+    __syncthreads();
+    int base = incl - nstart;
+    for (int w = 0; w < wave; w++) base += scr[40 + w];
+    const int n_out = scr[40] + scr[41] + scr[42] + scr[43];
+    float4 *outp = b.lf_tmp + off + rbeg;
+    int o = base;
+    for (int t = t_lo; t < t_hi; t++) {
+        const unsigned int cell = (unsigned int)(keys[t] >> 32);
+        if (t == 0 || cell != (unsigned int)(keys[t - 1] >> 32)) {
+            float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+            int u = t;
+            for (; u < ncand && (unsigned int)(keys[u] >> 32) == cell; u++) {
+                const float4 p = cl[(int)(keys[u] & 0xffffffffull)];
+                sx += p.x; sy += p.y; sz += p.z; si += p.w;
+            }
+            const float cnt = (float)(u - t);
+            outp[o++] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
+        }
+    }
+    if (tid == 0) b.lf_n[s * 64 + r] = n_out;
+}
+
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ring_start_table(const float4 *pts, int n, int *rs, int *status, int tid, int nthreads)
+{
+    // rs[r] = first index whose int(intensity) >= r (65 entries); flags non-monotone arrays
+    bool bad = false;
+    for (int j = tid; j < n; j += nthreads) {
+        const int v = (int)pts[j].w;
+        const int pv = j > 0 ? (int)pts[j - 1].w : -1;
+        if (v < pv) bad = true;
+        for (int r = pv + 1; r <= v && r <= 64; r++) if (r >= 0) rs[r] = j;
+    }
+    if (tid == 0) {
+        const int last = n > 0 ? (int)pts[n - 1].w : -1;
+        for (int r = (last + 1 < 0 ? 0 : last + 1); r <= 64; r++) rs[r] = n;
+    }
+    if (bad) atomicOr(status, kStatusNonMonotone);
+}
+
+__global__ __launch_bounds__(256) void k_compact(BatchView b)
+{
+    const int s = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int64_t off = b.off[s];
+    constexpr int NE = kMaxRings * kSectors;   // 384
+    __shared__ int pre_sh[NE + 1], pre_ls[NE + 1], pre_fl[NE + 1], pre_lf[kMaxRings + 1];
+    const int *nsh = b.sel_sharp_n + s * NE;
+    const int *nfl = b.sel_flat_n + s * NE;
+    if (tid == 0) { int a = 0; for (int e = 0; e < NE; e++) { pre_sh[e] = a; a += min(nsh[e], 2); } pre_sh[NE] = a; }
+    if (tid == 64) { int a = 0; for (int e = 0; e < NE; e++) { pre_ls[e] = a; a += nsh[e]; } pre_ls[NE] = a; }
+    if (tid == 128) { int a = 0; for (int e = 0; e < NE; e++) { pre_fl[e] = a; a += nfl[e]; } pre_fl[NE] = a; }
+    if (tid == 192) { int a = 0; for (int r = 0; r < kMaxRings; r++) { pre_lf[r] = a; a += b.lf_n[s * 64 + r]; } pre_lf[kMaxRings] = a; }
+    __syncthreads();
+    const float4 *cl = b.cloud + off;
+    float4 *sharp = b.sharp + (size_t)s * kMaxSharp;
+    float4 *ls = b.less_sharp + (size_t)s * kMaxLessSharp;
+    float4 *flat = b.flat + (size_t)s * kMaxFlat;
+    float4 *lf = b.less_flat + off;
+    const int *ssel = b.sel_sharp + (size_t)s * NE * 20;
+    const int *fsel = b.sel_flat + (size_t)s * NE * 4;
+    for (int x = tid; x < NE * 20; x += 256) {
+        const int e = x / 20, k = x % 20;
+        if (k < nsh[e]) {
+            const float4 p = cl[ssel[x]];
+            ls[pre_ls[e] + k] = p;
+            if (k < 2) sharp[pre_sh[e] + k] = p;
+        }
+    }
+    for (int x = tid; x < NE * 4; x += 256) {
+        const int e = x / 4, k = x % 4;
+        if (k < nfl[e]) flat[pre_fl[e] + k] = cl[fsel[x]];
+    }
+    const int *rb = b.ring_begin + s * 65;
+    for (int r = 0; r < kMaxRings; r++) {
+        const int cnt = pre_lf[r + 1] - pre_lf[r];
+        const float4 *src = b.lf_tmp + off + rb[r];
+        for (int i = tid; i < cnt; i += 256) lf[pre_lf[r] + i] = src[i];
+    }
+    if (tid == 0) {
+        b.feat_n[s * 4 + 0] = pre_sh[NE]; b.feat_n[s * 4 + 1] = pre_ls[NE];
+        b.feat_n[s * 4 + 2] = pre_fl[NE]; b.feat_n[s * 4 + 3] = pre_lf[kMaxRings];
+    }
+    __syncthreads();
+    ring_start_table(ls, pre_ls[NE], b.ls_ring_start + s * 65, b.status + s, tid, 256);
+    ring_start_table(lf, pre_lf[kMaxRings], b.lf_ring_start + s * 65, b.status + s, tid, 256);
+}
+
+} // namespace lmono

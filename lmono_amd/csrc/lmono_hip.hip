@@ -1,0 +1,333 @@
+// lmono_amd/csrc/lmono_hip.hip -- C ABI (include/lmono_hip.h) over the gfx950 kernels.  Single translation unit:
+// the kernel files are included so that one `hipcc -shared` produces liblmono_hip.so.
+#include "frontend.hip"
+#include "odometry.hip"
+#include "ba.hip"
+
+#include <string>
+#include <vector>
+#include <cstdio>
+#include <cstring>
+
+using namespace lmono;
+
+struct lmono_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    hipEvent_t ev[8];
+    double timing[8] = { 0 };
+};
+
+struct lmono_scan_batch {
+    lmono_ctx *ctx = nullptr;
+    int n_cap = 0;
+    int64_t pts_cap = 0;
+    int n_scans = 0;
+    int64_t total = 0;
+    int max_pts = 0;
+    bool registered = false;
+    std::vector<int64_t> off_h;
+    std::vector<void *> allocs;
+    BatchView v{};
+    int64_t *off_d = nullptr;
+    // odometry workspace
+    int chains_cap = 0;
+    double *state = nullptr, *incr = nullptr, *poses = nullptr, *xq = nullptr;
+    int *corr = nullptr, *lm_info = nullptr, *corr_pair = nullptr;
+};
+
+#define HIP_TRY(ctx, expr)                                                                   \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                  \
+            return e_ == hipErrorOutOfMemory ? LMONO_ENOMEM : LMONO_ENODEV;                  \
+        }                                                                                    \
+    } while (0)
+
+extern "C" const char *lmono_version(void) { return "lmono-hip 0.1 (gfx950)"; }
+
+extern "C" lmono_ctx *lmono_create(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return nullptr;
+    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    lmono_ctx *c = new lmono_ctx();
+    c->device = device;
+    for (auto &e : c->ev)
+        if (hipEventCreate(&e) != hipSuccess) { delete c; return nullptr; }
+    // the selection kernel needs ~62 KB of dynamic LDS
+    if (hipFuncSetAttribute((const void *)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, kSelLds) != hipSuccess) { delete c; return nullptr; }
+    return c;
+}
+
+extern "C" void lmono_destroy(lmono_ctx *c)
+{
+    if (!c) return;
+    for (auto &e : c->ev) (void)hipEventDestroy(e);
+    delete c;
+}
+
+extern "C" const char *lmono_last_error(const lmono_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+extern "C" int lmono_set_stream(lmono_ctx *c, void *s)
+{
+    if (!c) return LMONO_EINVAL;
+    c->stream = (hipStream_t)s;
+    return LMONO_OK;
+}
+
+extern "C" int lmono_synchronize(lmono_ctx *c)
+{
+    if (!c) return LMONO_EINVAL;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return LMONO_OK;
+}
+
+template <typename T>
+static bool dalloc(lmono_scan_batch *b, T *&p, size_t count)
+{
+    void *q = nullptr;
+    if (hipMalloc(&q, (count > 0 ? count : 1) * sizeof(T)) != hipSuccess) return false;
+    b->allocs.push_back(q);
+    p = (T *)q;
+    return true;
+}
+
+extern "C" void lmono_batch_destroy(lmono_scan_batch *b)
+{
+    if (!b) return;
+    for (void *p : b->allocs) (void)hipFree(p);
+    delete b;
+}
+
+extern "C" lmono_scan_batch *lmono_batch_create(lmono_ctx *c, int n_cap, int64_t pts_cap)
+{
+    if (!c || n_cap <= 0 || pts_cap <= 0) return nullptr;
+    if (hipSetDevice(c->device) != hipSuccess) return nullptr;
+    lmono_scan_batch *b = new lmono_scan_batch();
+    b->ctx = c; b->n_cap = n_cap; b->pts_cap = pts_cap;
+    BatchView &v = b->v;
+    const size_t T = (size_t)pts_cap, N = (size_t)n_cap;
+    bool ok = true;
+    ok = ok && dalloc(b, b->off_d, N + 1);
+    ok = ok && dalloc(b, v.cloud, T) && dalloc(b, v.curv, T) && dalloc(b, v.label, T) && dalloc(b, v.gap, T);
+    ok = ok && dalloc(b, v.ring_tmp, T) && dalloc(b, v.ori_tmp, T);
+    ok = ok && dalloc(b, v.ring_begin, N * 65) && dalloc(b, v.n_cloud, N) && dalloc(b, v.status, N);
+    ok = ok && dalloc(b, v.sel_sharp, N * 64 * 6 * 20) && dalloc(b, v.sel_sharp_n, N * 64 * 6);
+    ok = ok && dalloc(b, v.sel_flat, N * 64 * 6 * 4) && dalloc(b, v.sel_flat_n, N * 64 * 6);
+    ok = ok && dalloc(b, v.lf_tmp, T) && dalloc(b, v.lf_n, N * 64);
+    ok = ok && dalloc(b, v.sharp, N * kMaxSharp) && dalloc(b, v.less_sharp, N * kMaxLessSharp);
+    ok = ok && dalloc(b, v.flat, N * kMaxFlat) && dalloc(b, v.less_flat, T);
+    ok = ok && dalloc(b, v.feat_n, N * 4) && dalloc(b, v.ls_ring_start, N * 65) && dalloc(b, v.lf_ring_start, N * 65);
+    ok = ok && dalloc(b, v.cg_key, N * kCornerTable) && dalloc(b, v.cg_cnt, N * kCornerTable) && dalloc(b, v.cg_start, N * kCornerTable);
+    ok = ok && dalloc(b, v.sg_key, N * kSurfTable) && dalloc(b, v.sg_cnt, N * kSurfTable) && dalloc(b, v.sg_start, N * kSurfTable);
+    ok = ok && dalloc(b, v.cg_pts, N * kMaxLessSharp) && dalloc(b, v.sg_pts, T) && dalloc(b, v.grid_mask, N * 2);
+    ok = ok && dalloc(b, v.sg_slot, T) && dalloc(b, v.sg_rank, T);
+    ok = ok && dalloc(b, v.cg_slot, N * kMaxLessSharp) && dalloc(b, v.cg_rank, N * kMaxLessSharp);
+    ok = ok && dalloc(b, b->incr, N * 7) && dalloc(b, b->poses, N * 7) && dalloc(b, b->xq, 8);
+    ok = ok && dalloc(b, b->corr_pair, (size_t)kMaxQueries * 4);
+    if (!ok) {
+        c->err = "lmono_batch_create: hipMalloc failed";
+        lmono_batch_destroy(b);
+        return nullptr;
+    }
+    v.off = b->off_d;
+    return b;
+}
+
+static int check_launch(lmono_ctx *c, const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { c->err = std::string(what) + ": " + hipGetErrorString(e); return LMONO_ENODEV; }
+    return LMONO_OK;
+}
+
+extern "C" int lmono_scanreg_batch(lmono_ctx *c, lmono_scan_batch *b, const float *xyzi_d, const int64_t *offsets_h,
+                                   int n_scans, int n_lines, float min_range)
+{
+    if (!c || !b || !xyzi_d || !offsets_h || n_scans <= 0) return LMONO_EINVAL;
+    if (n_lines != 16 && n_lines != 32 && n_lines != 64) { c->err = "n_lines must be 16, 32 or 64"; return LMONO_EINVAL; }
+    if (n_scans > b->n_cap) { c->err = "batch: too many scans"; return LMONO_ECAPACITY; }
+    int64_t max_pts = 0;
+    for (int s = 0; s < n_scans; s++) {
+        const int64_t m = offsets_h[s + 1] - offsets_h[s];
+        if (m < 0 || m > INT_MAX / 2) { c->err = "bad offsets"; return LMONO_EINVAL; }
+        max_pts = m > max_pts ? m : max_pts;
+    }
+    const int64_t total = offsets_h[n_scans] - offsets_h[0];
+    if (offsets_h[0] != 0) { c->err = "offsets must start at 0"; return LMONO_EINVAL; }
+    if (total > b->pts_cap) { c->err = "batch: too many points"; return LMONO_ECAPACITY; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    b->off_h.assign(offsets_h, offsets_h + n_scans + 1);
+    b->n_scans = n_scans; b->total = total; b->max_pts = (int)max_pts; b->registered = false;
+    BatchView &v = b->v;
+    v.in = (const float4 *)xyzi_d; v.n_scans = n_scans; v.n_lines = n_lines; v.min_range = min_range;
+    hipStream_t st = c->stream;
+    HIP_TRY(c, hipMemcpyAsync(b->off_d, b->off_h.data(), sizeof(int64_t) * (n_scans + 1), hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemsetAsync(v.status, 0, sizeof(int) * n_scans, st));
+    HIP_TRY(c, hipEventRecord(c->ev[0], st));
+    hipLaunchKernelGGL(k_ring_sort, dim3(n_scans), dim3(1024), 0, st, v);
+    HIP_TRY(c, hipEventRecord(c->ev[1], st));
+    const int tiles = (int)((max_pts + kCurvTile - 1) / kCurvTile);
+    if (tiles > 0) hipLaunchKernelGGL(k_curvature, dim3(tiles, n_scans), dim3(256), 0, st, v);
+    HIP_TRY(c, hipEventRecord(c->ev[2], st));
+    hipLaunchKernelGGL(k_select, dim3(kMaxRings, n_scans), dim3(256), kSelLds, st, v);
+    HIP_TRY(c, hipEventRecord(c->ev[3], st));
+    hipLaunchKernelGGL(k_compact, dim3(n_scans), dim3(256), 0, st, v);
+    HIP_TRY(c, hipEventRecord(c->ev[4], st));
+    hipLaunchKernelGGL(k_grid_build, dim3(n_scans, 2), dim3(1024), 0, st, v);
+    HIP_TRY(c, hipEventRecord(c->ev[5], st));
+    int rc = check_launch(c, "scanreg kernels");
+    if (rc) return rc;
+    b->registered = true;
+    return LMONO_OK;
+}
+
+extern "C" int lmono_last_timing(lmono_ctx *c, double *ms, int cap)
+{
+    if (!c || !ms) return LMONO_EINVAL;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    float t;
+    // [0] scanreg total (incl. grid build), [1] odometry total, [2] ring_sort, [3] curvature, [4] select, [5] compact, [6] grid_build
+    if (hipEventElapsedTime(&t, c->ev[0], c->ev[5]) == hipSuccess) c->timing[0] = t;
+    for (int i = 0; i < 5; i++)
+        if (hipEventElapsedTime(&t, c->ev[i], c->ev[i + 1]) == hipSuccess) c->timing[2 + i] = t;
+    if (hipEventElapsedTime(&t, c->ev[6], c->ev[7]) == hipSuccess) c->timing[1] = t;
+    for (int i = 0; i < cap && i < 7; i++) ms[i] = c->timing[i];
+    return LMONO_OK;
+}
+
+extern "C" int lmono_batch_counts(lmono_ctx *c, lmono_scan_batch *b, int32_t *counts_h)
+{
+    if (!c || !b || !counts_h || !b->registered) return LMONO_EINVAL;
+    const int n = b->n_scans;
+    std::vector<int> nc(n), fn(n * 4), stt(n);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(nc.data(), b->v.n_cloud, sizeof(int) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(fn.data(), b->v.feat_n, sizeof(int) * n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(stt.data(), b->v.status, sizeof(int) * n, hipMemcpyDeviceToHost));
+    for (int s = 0; s < n; s++) {
+        counts_h[6 * s] = nc[s];
+        for (int k = 0; k < 4; k++) counts_h[6 * s + 1 + k] = fn[4 * s + k];
+        counts_h[6 * s + 5] = stt[s];
+    }
+    return LMONO_OK;
+}
+
+extern "C" int lmono_batch_get_cloud(lmono_ctx *c, lmono_scan_batch *b, int scan, int which, float *out_h, int cap)
+{
+    if (!c || !b || !out_h || !b->registered || scan < 0 || scan >= b->n_scans || which < 0 || which > 4) return LMONO_EINVAL;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int n = 0;
+    const float4 *src = nullptr;
+    int fn[4];
+    HIP_TRY(c, hipMemcpy(fn, b->v.feat_n + scan * 4, sizeof(fn), hipMemcpyDeviceToHost));
+    switch (which) {
+    case 0: HIP_TRY(c, hipMemcpy(&n, b->v.n_cloud + scan, sizeof(int), hipMemcpyDeviceToHost)); src = b->v.cloud + b->off_h[scan]; break;
+    case 1: n = fn[0]; src = b->v.sharp + (size_t)scan * kMaxSharp; break;
+    case 2: n = fn[1]; src = b->v.less_sharp + (size_t)scan * kMaxLessSharp; break;
+    case 3: n = fn[2]; src = b->v.flat + (size_t)scan * kMaxFlat; break;
+    default: n = fn[3]; src = b->v.less_flat + b->off_h[scan]; break;
+    }
+    if (n > cap) { c->err = "get_cloud: output capacity too small"; return LMONO_ECAPACITY; }
+    if (n > 0) HIP_TRY(c, hipMemcpy(out_h, src, sizeof(float4) * n, hipMemcpyDeviceToHost));
+    return n;
+}
+
+extern "C" int lmono_batch_get_curvature(lmono_ctx *c, lmono_scan_batch *b, int scan, float *curv_h, int32_t *label_h, int cap)
+{
+    if (!c || !b || !b->registered || scan < 0 || scan >= b->n_scans) return LMONO_EINVAL;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int n = 0;
+    HIP_TRY(c, hipMemcpy(&n, b->v.n_cloud + scan, sizeof(int), hipMemcpyDeviceToHost));
+    if (n > cap) { c->err = "get_curvature: output capacity too small"; return LMONO_ECAPACITY; }
+    if (curv_h && n > 0) HIP_TRY(c, hipMemcpy(curv_h, b->v.curv + b->off_h[scan], sizeof(float) * n, hipMemcpyDeviceToHost));
+    if (label_h && n > 0) {
+        std::vector<int8_t> tmp(n);
+        HIP_TRY(c, hipMemcpy(tmp.data(), b->v.label + b->off_h[scan], n, hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; i++) label_h[i] = tmp[i];
+    }
+    return n;
+}
+
+static int ensure_odom_ws(lmono_ctx *c, lmono_scan_batch *b, int n_chains)
+{
+    if (n_chains <= b->chains_cap) return LMONO_OK;
+    // (re)allocate; old buffers stay in allocs and are freed with the batch
+    bool ok = dalloc(b, b->state, (size_t)n_chains * 8) && dalloc(b, b->corr, (size_t)n_chains * kMaxQueries * 4) &&
+              dalloc(b, b->lm_info, (size_t)n_chains * 4);
+    if (!ok) { c->err = "odometry workspace: hipMalloc failed"; return LMONO_ENOMEM; }
+    b->chains_cap = n_chains;
+    return LMONO_OK;
+}
+
+extern "C" int lmono_odom_batch_d(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, double *incr_d, double *poses_d)
+{
+    if (!c || !b || !b->registered || lead < 0) return LMONO_EINVAL;
+    const int n = b->n_scans;
+    if (n_chains < 1) n_chains = 1;
+    if (n_chains > n) n_chains = n;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = ensure_odom_ws(c, b, n_chains);
+    if (rc) return rc;
+    OdomView o;
+    o.n_scans = n; o.n_chains = n_chains; o.lead = lead;
+    o.state = b->state; o.corr = b->corr; o.incr = b->incr; o.lm_info = b->lm_info;
+    int max_steps = 0;
+    for (int ch = 0; ch < n_chains; ch++) {
+        const int s = (int)((long long)ch * n / n_chains), e = (int)((long long)(ch + 1) * n / n_chains);
+        const int begin = s - lead > 0 ? s - lead : 0;
+        const int steps = e - begin - 1;
+        max_steps = steps > max_steps ? steps : max_steps;
+    }
+    hipStream_t st = c->stream;
+    HIP_TRY(c, hipEventRecord(c->ev[6], st));
+    const int ninit = n > n_chains ? n : n_chains;
+    hipLaunchKernelGGL(k_odom_init, dim3((ninit + 255) / 256), dim3(256), 0, st, o);
+    for (int step = 0; step < max_steps; step++) {
+        for (int outer = 0; outer < 2; outer++) {
+            hipLaunchKernelGGL(k_correspond, dim3(kMaxQueries / 4, n_chains), dim3(256), 0, st, b->v, o, step);
+            hipLaunchKernelGGL(k_lm_solve, dim3((n_chains + 3) / 4), dim3(256), 0, st, b->v, o, step, outer);
+        }
+    }
+    hipLaunchKernelGGL(k_pose_prefix, dim3(1), dim3(64), 0, st, b->incr, b->poses, n);
+    HIP_TRY(c, hipEventRecord(c->ev[7], st));
+    rc = check_launch(c, "odometry kernels");
+    if (rc) return rc;
+    if (incr_d) HIP_TRY(c, hipMemcpyAsync(incr_d, b->incr, sizeof(double) * 7 * n, hipMemcpyDeviceToDevice, st));
+    if (poses_d) HIP_TRY(c, hipMemcpyAsync(poses_d, b->poses, sizeof(double) * 7 * n, hipMemcpyDeviceToDevice, st));
+    return LMONO_OK;
+}
+
+extern "C" int lmono_odom_batch(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, double *incr_h, double *poses_h)
+{
+    int rc = lmono_odom_batch_d(c, b, n_chains, lead, nullptr, nullptr);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const int n = b->n_scans;
+    if (incr_h) HIP_TRY(c, hipMemcpy(incr_h, b->incr, sizeof(double) * 7 * n, hipMemcpyDeviceToHost));
+    if (poses_h) HIP_TRY(c, hipMemcpy(poses_h, b->poses, sizeof(double) * 7 * n, hipMemcpyDeviceToHost));
+    return LMONO_OK;
+}
+
+extern "C" int lmono_odom_correspond(lmono_ctx *c, lmono_scan_batch *b, int scan, const double q[4], const double t[3],
+                                     int32_t *corr_h, int cap)
+{
+    if (!c || !b || !b->registered || scan < 1 || scan >= b->n_scans || !q || !t || !corr_h) return LMONO_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    double x[8] = { q[0], q[1], q[2], q[3], t[0], t[1], t[2], 0.0 };
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(b->xq, x, sizeof(x), hipMemcpyHostToDevice));
+    int fn[4];
+    HIP_TRY(c, hipMemcpy(fn, b->v.feat_n + scan * 4, sizeof(fn), hipMemcpyDeviceToHost));
+    const int nq = fn[0] + fn[2];
+    if (nq > cap) { c->err = "odom_correspond: output capacity too small"; return LMONO_ECAPACITY; }
+    hipLaunchKernelGGL(k_correspond_pair, dim3(kMaxQueries / 4), dim3(256), 0, c->stream, b->v, scan, (const double *)b->xq, b->corr_pair);
+    int rc = check_launch(c, "k_correspond_pair");
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (nq > 0) HIP_TRY(c, hipMemcpy(corr_h, b->corr_pair, sizeof(int) * 4 * nq, hipMemcpyDeviceToHost));
+    return nq;
+}

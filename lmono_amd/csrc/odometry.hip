@@ -1,0 +1,630 @@
+// lmono_amd/csrc/odometry.hip -- gfx950 kernels of scan-to-scan LiDAR odometry (A-LOAM laserOdometry main
+// loop + lidarFactor.hpp + the ceres::Solve call it makes; source absent from the reference tree,
+// behavioural spec SURVEY.md Appendix A.2/A.3/B).
+//
+//   k_grid_build  one workgroup per (scan, cloud): 1 m hash grid over less_sharp / less_flat (the "last" clouds
+//                 of the next scan).  Exact 1-NN needs only neighbours closer than 5 m (DISTANCE_SQ_THRESHOLD).
+//   k_correspond  one wave per feature point: de-skew transform (fp64), exact 1-NN by growing cell shells,
+//                 ring walk for the 2nd (and 3rd) point as coalesced sweeps over ring ranges
+//   k_lm_solve    one wave per chain: <= 4 Levenberg-Marquardt iterations restating Ceres' trust-region loop,
+//                 closed-form edge/plane Jacobians, wave-shuffle reduction into the 6x6 normal equations (fp64)
+//   k_pose_prefix sequential pose accumulation
+#include "batch.hpp"
+
+namespace lmono {
+
+constexpr float kCell = 1.0f;          // grid edge (m)
+constexpr float kInvCell = 1.0f;
+constexpr int kMaxShell = 6;           // shells 1..5 cover 5 m up to float slop; shell 6 makes d2 < 25 exact
+constexpr int kCoordOff = 1 << 20;
+
+__device__ __forceinline__ unsigned long long cell_key(int cx, int cy, int cz)
+{
+    return ((unsigned long long)(unsigned int)(cx + kCoordOff) << 42) |
+           ((unsigned long long)(unsigned int)(cy + kCoordOff) << 21) |
+           (unsigned long long)(unsigned int)(cz + kCoordOff);
+}
+__device__ __forceinline__ unsigned int hash_key(unsigned long long k)
+{
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+    return (unsigned int)k;
+}
+
+struct GridRef {
+    const unsigned long long *key;
+    const int *cnt;
+    const int *start;
+    const float4 *pts;
+    int mask;
+};
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_grid_build(BatchView b)
+{
+    const int s = blockIdx.x;
+    const bool surf = blockIdx.y == 1;
+    const int tid = threadIdx.x;
+    const int n = b.feat_n[s * 4 + (surf ? 3 : 1)];
+    const int Tcap = surf ? kSurfTable : kCornerTable;
+    int T = next_pow2(2 * n);
+    if (T < 1024) T = 1024;
+    const bool overflow = T > Tcap;
+    if (overflow) T = 1024;
+    const int mask = T - 1;
+    if (tid == 0) b.grid_mask[s * 2 + (surf ? 1 : 0)] = mask;
+    unsigned long long *key = surf ? b.sg_key + (size_t)s * kSurfTable : b.cg_key + (size_t)s * kCornerTable;
+    int *cnt = surf ? b.sg_cnt + (size_t)s * kSurfTable : b.cg_cnt + (size_t)s * kCornerTable;
+    int *start = surf ? b.sg_start + (size_t)s * kSurfTable : b.cg_start + (size_t)s * kCornerTable;
+    const float4 *src = surf ? b.less_flat + b.off[s] : b.less_sharp + (size_t)s * kMaxLessSharp;
+    float4 *dst = surf ? b.sg_pts + b.off[s] : b.cg_pts + (size_t)s * kMaxLessSharp;
+    int *slot_of = surf ? b.sg_slot + b.off[s] : b.cg_slot + (size_t)s * kMaxLessSharp;
+    int *rank_of = surf ? b.sg_rank + b.off[s] : b.cg_rank + (size_t)s * kMaxLessSharp;
+    for (int i = tid; i < T; i += 1024) { key[i] = kEmptyKey; cnt[i] = 0; }
+    if (overflow) {
+        if (tid == 0) atomicOr(&b.status[s], kStatusGridOverflow);
+        return;   // table stays empty: no correspondences for the next scan, flagged in status
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        const float4 p = src[i];
+        const unsigned long long k = cell_key((int)floorf(p.x * kInvCell), (int)floorf(p.y * kInvCell), (int)floorf(p.z * kInvCell));
+        unsigned int sl = hash_key(k) & mask;
+        while (true) {
+            const unsigned long long old = atomicCAS(&key[sl], kEmptyKey, k);
+            if (old == kEmptyKey || old == k) break;
+            sl = (sl + 1) & mask;
+        }
+        slot_of[i] = (int)sl;
+        rank_of[i] = atomicAdd(&cnt[sl], 1);
+    }
+    __syncthreads();
+    // exclusive prefix over the table counts (read with agent-scope atomic loads: the counts were produced by atomics)
+    __shared__ int s_part[1024];
+    const int chunk = T / 1024;
+    int local = 0;
+    for (int i = 0; i < chunk; i++) local += __hip_atomic_load(&cnt[tid * chunk + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_part[tid] = local;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over 1024 partials
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = tid >= o ? s_part[tid - o] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    int run = s_part[tid] - local;
+    for (int i = 0; i < chunk; i++) {
+        const int c = __hip_atomic_load(&cnt[tid * chunk + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        start[tid * chunk + i] = run;
+        run += c;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        const float4 p = src[i];
+        dst[start[slot_of[i]] + rank_of[i]] = make_float4(p.x, p.y, p.z, __int_as_float(i));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct OdomView {
+    int n_scans, n_chains, lead;
+    double *state;        // [n_chains][8]  q(xyzw), t, pad
+    int *corr;            // [n_chains][kMaxQueries][4]
+    double *incr;         // [n_scans][7]
+    int *lm_info;         // [n_chains][4]
+};
+
+__device__ __forceinline__ void chain_bounds(int n_scans, int n_chains, int c, int &s, int &e)
+{
+    s = (int)((long long)c * n_scans / n_chains);
+    e = (int)((long long)(c + 1) * n_scans / n_chains);
+}
+
+__device__ __forceinline__ void quat_rotate(const double *q, double vx, double vy, double vz, double &ox, double &oy, double &oz)
+{
+    const double ux = q[0], uy = q[1], uz = q[2], w = q[3];
+    const double uvx = 2.0 * (uy * vz - uz * vy);
+    const double uvy = 2.0 * (uz * vx - ux * vz);
+    const double uvz = 2.0 * (ux * vy - uy * vx);
+    ox = vx + w * uvx + (uy * uvz - uz * uvy);
+    oy = vy + w * uvy + (uz * uvx - ux * uvz);
+    oz = vz + w * uvz + (ux * uvy - uy * uvx);
+}
+
+// exact 1-NN of (qx,qy,qz) in a hash-gridded cloud; all 64 lanes cooperate.  Returns packed (d2 bits, index),
+// ~0 when the cloud holds no point closer than kMaxShell cells.  Ties resolve to the lowest original index.
+__device__ __forceinline__ unsigned long long wave_nn(const GridRef &g, float qx, float qy, float qz, int lane)
+{
+    const int cqx = (int)floorf(qx * kInvCell), cqy = (int)floorf(qy * kInvCell), cqz = (int)floorf(qz * kInvCell);
+    unsigned long long best = ~0ull;
+    for (int sh = 1; sh <= kMaxShell; sh++) {
+        const int side = 2 * sh + 1, ncell = side * side * side;
+        for (int ci = lane; ci < ncell; ci += 64) {
+            const int dx = ci % side - sh, dy = (ci / side) % side - sh, dz = ci / (side * side) - sh;
+            if (sh > 1 && max(max(abs(dx), abs(dy)), abs(dz)) < sh) continue;
+            const unsigned long long k = cell_key(cqx + dx, cqy + dy, cqz + dz);
+            unsigned int sl = hash_key(k) & g.mask;
+            int found = -1;
+            while (true) {
+                const unsigned long long t = g.key[sl];
+                if (t == k) { found = (int)sl; break; }
+                if (t == kEmptyKey) break;
+                sl = (sl + 1) & g.mask;
+            }
+            if (found < 0) continue;
+            const int st = g.start[found], cn = g.cnt[found];
+            for (int i = 0; i < cn; i++) {
+                const float4 p = g.pts[st + i];
+                const unsigned long long cand = pack_fu(dist2f(p.x, p.y, p.z, qx, qy, qz), (unsigned int)__float_as_int(p.w));
+                best = cand < best ? cand : best;
+            }
+        }
+        best = wave_min_u64(best);
+        if (best != ~0ull) {
+            const float bound = (float)sh * kCell * 0.9999f;
+            if (__uint_as_float((unsigned int)(best >> 32)) <= bound * bound) break;
+        }
+    }
+    return best;
+}
+
+// min over j in [lo, hi) of (d2, seq) where seq orders candidates the way the reference loops visit them
+__device__ __forceinline__ unsigned long long sweep_min(const float4 *cloud, int lo, int hi, int skip, float qx, float qy, float qz,
+                                                        int seq_base, bool descending, int lane, unsigned long long best)
+{
+    for (int j = lo + lane; j < hi; j += 64) {
+        if (j == skip) continue;
+        const float4 p = cloud[j];
+        const unsigned int seq = (unsigned int)(seq_base + (descending ? (hi - 1 - j) : (j - lo)));
+        const unsigned long long cand = pack_fu(dist2f(p.x, p.y, p.z, qx, qy, qz), seq);
+        best = cand < best ? cand : best;
+    }
+    return best;
+}
+
+constexpr unsigned int kSeqBack = 1u << 24;   // backward candidates rank after every forward candidate
+
+__device__ __forceinline__ int seq_to_index(unsigned int seq, int f_lo, int b_hi)
+{
+    return seq >= kSeqBack ? (b_hi - 1 - (int)(seq - kSeqBack)) : f_lo + (int)seq;
+}
+
+// Correspondence search for one feature point of scan k against scan k-1.  kind 1 = edge (a, b), 2 = plane (a, b, c).
+__device__ __forceinline__ int4 correspond_one(const BatchView &b, int k, int qi, const double *x, int lane)
+{
+    const int n_sharp = b.feat_n[k * 4 + 0];
+    const bool edge = qi < n_sharp;
+    const float4 p = edge ? b.sharp[(size_t)k * kMaxSharp + qi] : b.flat[(size_t)k * kMaxFlat + (qi - n_sharp)];
+    double rx, ry, rz;
+    quat_rotate(x, (double)p.x, (double)p.y, (double)p.z, rx, ry, rz);
+    const float qx = (float)(rx + x[4]), qy = (float)(ry + x[5]), qz = (float)(rz + x[6]);
+    const int l = k - 1;
+    GridRef g;
+    const float4 *cloud;
+    const int *rs;
+    int n_last;
+    if (edge) {
+        g.key = b.cg_key + (size_t)l * kCornerTable; g.cnt = b.cg_cnt + (size_t)l * kCornerTable;
+        g.start = b.cg_start + (size_t)l * kCornerTable; g.pts = b.cg_pts + (size_t)l * kMaxLessSharp; g.mask = b.grid_mask[l * 2 + 0];
+        cloud = b.less_sharp + (size_t)l * kMaxLessSharp; rs = b.ls_ring_start + l * 65; n_last = b.feat_n[l * 4 + 1];
+    } else {
+        g.key = b.sg_key + (size_t)l * kSurfTable; g.cnt = b.sg_cnt + (size_t)l * kSurfTable;
+        g.start = b.sg_start + (size_t)l * kSurfTable; g.pts = b.sg_pts + b.off[l]; g.mask = b.grid_mask[l * 2 + 1];
+        cloud = b.less_flat + b.off[l]; rs = b.lf_ring_start + l * 65; n_last = b.feat_n[l * 4 + 3];
+    }
+    int4 out = make_int4(-1, -1, -1, 0);
+    if (n_last == 0) return out;
+    const unsigned long long nn = wave_nn(g, qx, qy, qz, lane);
+    if (nn == ~0ull) return out;
+    const float d2 = __uint_as_float((unsigned int)(nn >> 32));
+    if (!((double)d2 < 25.0)) return out;
+    const int closest = (int)(unsigned int)(nn & 0xffffffffull);
+    const int ra = (int)cloud[closest].w;
+    const unsigned long long thr = pack_fu(25.0f, 0u);   // candidates need d2 < 25
+    if (b.status[l] & kStatusNonMonotone) {
+        // exact serial restatement of the reference loops (array order, continue / break on int(intensity))
+        int i2 = -1, i3 = -1;
+        if (lane == 0) {
+            double m2 = 25.0, m3 = 25.0;
+            for (int j = closest + 1; j < n_last; j++) {
+                const float4 c = cloud[j]; const int rj = (int)c.w;
+                if (edge && rj <= ra) continue;
+                if ((double)rj > (double)ra + 2.5) break;
+                const double d = (double)dist2f(c.x, c.y, c.z, qx, qy, qz);
+                if (edge) { if (d < m2) { m2 = d; i2 = j; } }
+                else if (rj <= ra && d < m2) { m2 = d; i2 = j; }
+                else if (rj > ra && d < m3) { m3 = d; i3 = j; }
+            }
+            for (int j = closest - 1; j >= 0; j--) {
+                const float4 c = cloud[j]; const int rj = (int)c.w;
+                if (edge && rj >= ra) continue;
+                if ((double)rj < (double)ra - 2.5) break;
+                const double d = (double)dist2f(c.x, c.y, c.z, qx, qy, qz);
+                if (edge) { if (d < m2) { m2 = d; i2 = j; } }
+                else if (rj >= ra && d < m2) { m2 = d; i2 = j; }
+                else if (rj < ra && d < m3) { m3 = d; i3 = j; }
+            }
+        }
+        i2 = __shfl(i2, 0); i3 = __shfl(i3, 0);
+        if (edge) { if (i2 >= 0) out = make_int4(closest, i2, -1, 1); }
+        else if (i2 >= 0 && i3 >= 0) out = make_int4(closest, i2, i3, 2);
+        return out;
+    }
+    auto ring_lo = [&](int r) { return rs[r < 0 ? 0 : (r > 64 ? 64 : r)]; };
+    // rings above: {ra+1, ra+2} in ascending array order; rings below: {ra-2, ra-1} in descending array order
+    const int f_lo = ring_lo(ra + 1), f_hi = ring_lo(ra + 3);
+    const int b_lo = ring_lo(ra - 2), b_hi = ring_lo(ra);
+    unsigned long long other = thr;
+    other = sweep_min(cloud, f_lo, f_hi, -1, qx, qy, qz, 0, false, lane, other);
+    other = sweep_min(cloud, b_lo, b_hi, -1, qx, qy, qz, (int)kSeqBack, true, lane, other);
+    other = wave_min_u64(other);
+    const int i_other = other < thr ? seq_to_index((unsigned int)(other & 0xffffffffull), f_lo, b_hi) : -1;
+    if (edge) {
+        if (i_other >= 0) out = make_int4(closest, i_other, -1, 1);
+        return out;
+    }
+    // same ring: forward (closest, ring end) ascending, then backward [ring start, closest) descending
+    const int s_lo = ring_lo(ra), s_hi = ring_lo(ra + 1);
+    unsigned long long same = thr;
+    same = sweep_min(cloud, closest + 1, s_hi, -1, qx, qy, qz, 0, false, lane, same);
+    same = sweep_min(cloud, s_lo, closest, -1, qx, qy, qz, (int)kSeqBack, true, lane, same);
+    same = wave_min_u64(same);
+    const int i_same = same < thr ? seq_to_index((unsigned int)(same & 0xffffffffull), closest + 1, closest) : -1;
+    if (i_same >= 0 && i_other >= 0) out = make_int4(closest, i_same, i_other, 2);
+    return out;
+}
+
+// step t of every chain: chain c works on scan k = begin_c + 1 + t
+__global__ __launch_bounds__(256) void k_correspond(BatchView b, OdomView o, int step)
+{
+    const int c = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int s, e;
+    chain_bounds(o.n_scans, o.n_chains, c, s, e);
+    const int begin = max(s - o.lead, 0);
+    const int k = begin + 1 + step;
+    if (k >= e) return;
+    const int nq = b.feat_n[k * 4 + 0] + b.feat_n[k * 4 + 2];
+    if (qi >= nq) return;
+    const int4 r = correspond_one(b, k, qi, o.state + c * 8, lane);
+    if (lane == 0) ((int4 *)o.corr)[(size_t)c * kMaxQueries + qi] = r;
+}
+
+// single-pair variant used by lmono_odom_correspond (parity/debug view)
+__global__ __launch_bounds__(256) void k_correspond_pair(BatchView b, int k, const double *x, int *corr)
+{
+    const int lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nq = b.feat_n[k * 4 + 0] + b.feat_n[k * 4 + 2];
+    if (qi >= nq) return;
+    const int4 r = correspond_one(b, k, qi, x, lane);
+    if (lane == 0) ((int4 *)corr)[qi] = r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Residual blocks.  lp = q * cp + t (Eigen _transformVector polynomial); edge r = ((lp-a) x (lp-b)) / |a-b| (3 rows),
+// plane r = (lp - j) . n (1 row).  d r / d lp is constant: [b-a]_x / |a-b| and n^T.
+struct LmAcc { double H[21]; double g[6]; double cost; };
+
+__device__ __forceinline__ void accumulate_row(LmAcc &a, const double *J, double r)
+{
+    int t = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        a.g[i] += J[i] * r;
+#pragma unroll
+        for (int j = i; j < 6; j++) a.H[t++] += J[i] * J[j];
+    }
+}
+
+__device__ __forceinline__ void huber(double s, double &rho0, double &rho1)
+{
+    const double a = 0.1, bb = 0.1 * 0.1;
+    if (s > bb) {
+        const double r = sqrt(s);
+        rho0 = 2.0 * a * r - bb;
+        rho1 = a / r;
+        if (rho1 < DBL_MIN) rho1 = DBL_MIN;
+    } else { rho0 = s; rho1 = 1.0; }
+}
+
+template <bool kJac>
+__device__ __forceinline__ void eval_block(const BatchView &b, int k, int qi, const int4 cr, const double *x, const double *Jp, LmAcc &acc)
+{
+    const int l = k - 1;
+    const int n_sharp = b.feat_n[k * 4 + 0];
+    const bool edge = cr.w == 1;
+    const float4 cp = edge ? b.sharp[(size_t)k * kMaxSharp + qi] : b.flat[(size_t)k * kMaxFlat + (qi - n_sharp)];
+    const float4 *cloud = edge ? b.less_sharp + (size_t)l * kMaxLessSharp : b.less_flat + b.off[l];
+    const double vx = (double)cp.x, vy = (double)cp.y, vz = (double)cp.z;
+    double lx, ly, lz;
+    quat_rotate(x, vx, vy, vz, lx, ly, lz);
+    lx += x[4]; ly += x[5]; lz += x[6];
+    const float4 A = cloud[cr.x], B = cloud[cr.y];
+    double res[3], D[3][3];   // D = d res / d lp
+    int nr;
+    if (edge) {
+        const double ax = lx - (double)A.x, ay = ly - (double)A.y, az = lz - (double)A.z;
+        const double bx = lx - (double)B.x, by = ly - (double)B.y, bz = lz - (double)B.z;
+        const double nux = ay * bz - az * by, nuy = az * bx - ax * bz, nuz = ax * by - ay * bx;
+        const double ex = (double)A.x - (double)B.x, ey = (double)A.y - (double)B.y, ez = (double)A.z - (double)B.z;
+        const double den = sqrt(ex * ex + ey * ey + ez * ez);
+        res[0] = nux / den; res[1] = nuy / den; res[2] = nuz / den;
+        if (kJac) {
+            const double inv = 1.0 / den;
+            // [b - a]_x with (b - a) = -e
+            D[0][0] = 0.0;       D[0][1] = ez * inv;  D[0][2] = -ey * inv;
+            D[1][0] = -ez * inv; D[1][1] = 0.0;       D[1][2] = ex * inv;
+            D[2][0] = ey * inv;  D[2][1] = -ex * inv; D[2][2] = 0.0;
+        }
+        nr = 3;
+    } else {
+        const float4 Cc = cloud[cr.z];
+        const double jx = (double)A.x, jy = (double)A.y, jz = (double)A.z;
+        const double ux = jx - (double)B.x, uy = jy - (double)B.y, uz = jz - (double)B.z;
+        const double wx = jx - (double)Cc.x, wy = jy - (double)Cc.y, wz = jz - (double)Cc.z;
+        double nx = uy * wz - uz * wy, ny = uz * wx - ux * wz, nz = ux * wy - uy * wx;
+        const double nn = sqrt(nx * nx + ny * ny + nz * nz);
+        if (nn > 0.0) { nx /= nn; ny /= nn; nz /= nn; }
+        res[0] = (lx - jx) * nx + (ly - jy) * ny + (lz - jz) * nz;
+        if (kJac) { D[0][0] = nx; D[0][1] = ny; D[0][2] = nz; }
+        nr = 1;
+    }
+    double sq = 0.0;
+    for (int r = 0; r < nr; r++) sq += res[r] * res[r];
+    double rho0, rho1;
+    huber(sq, rho0, rho1);
+    acc.cost += 0.5 * rho0;
+    if (!kJac) return;
+    const double sr = sqrt(rho1);
+    // d lp / d (qx,qy,qz,qw): columns of the 3x4 global Jacobian
+    const double ux = x[0], uy = x[1], uz = x[2], w = x[3];
+    const double cxv = uy * vz - uz * vy, cyv = uz * vx - ux * vz, czv = ux * vy - uy * vx;   // u x v
+    // d/du [ 2 w (u x v) + 2 u x (u x v) ] = -2 w [v]_x - 2 [u x v]_x - 2 [u]_x [v]_x
+    double G[3][4];
+    // [v]_x
+    const double V[3][3] = { { 0, -vz, vy }, { vz, 0, -vx }, { -vy, vx, 0 } };
+    const double U[3][3] = { { 0, -uz, uy }, { uz, 0, -ux }, { -uy, ux, 0 } };
+    const double Cx[3][3] = { { 0, -czv, cyv }, { czv, 0, -cxv }, { -cyv, cxv, 0 } };
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const double uv = U[i][0] * V[0][j] + U[i][1] * V[1][j] + U[i][2] * V[2][j];
+            G[i][j] = -2.0 * w * V[i][j] - 2.0 * Cx[i][j] - 2.0 * uv;
+        }
+    G[0][3] = 2.0 * cxv; G[1][3] = 2.0 * cyv; G[2][3] = 2.0 * czv;
+    // local: Gl = G (3x4) * Jp (4x3)
+    double Gl[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            Gl[i][j] = G[i][0] * Jp[j] + G[i][1] * Jp[3 + j] + G[i][2] * Jp[6 + j] + G[i][3] * Jp[9 + j];
+    for (int r = 0; r < nr; r++) {
+        double J[6];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            J[j] = (D[r][0] * Gl[0][j] + D[r][1] * Gl[1][j] + D[r][2] * Gl[2][j]) * sr;
+            J[3 + j] = D[r][j] * sr;
+        }
+        accumulate_row(acc, J, res[r] * sr);
+    }
+}
+
+template <bool kJac>
+__device__ __forceinline__ void evaluate_wave(const BatchView &b, int k, const int4 *corr, int nq, const double *x, LmAcc &acc, int lane)
+{
+    double Jp[12];
+    Jp[0] = x[3];  Jp[1] = x[2];   Jp[2] = -x[1];
+    Jp[3] = -x[2]; Jp[4] = x[3];   Jp[5] = x[0];
+    Jp[6] = x[1];  Jp[7] = -x[0];  Jp[8] = x[3];
+    Jp[9] = -x[0]; Jp[10] = -x[1]; Jp[11] = -x[2];
+    acc.cost = 0.0;
+    if (kJac) {
+#pragma unroll
+        for (int i = 0; i < 21; i++) acc.H[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) acc.g[i] = 0.0;
+    }
+    for (int qi = lane; qi < nq; qi += 64) {
+        const int4 cr = corr[qi];
+        if (cr.w == 0) continue;
+        eval_block<kJac>(b, k, qi, cr, x, Jp, acc);
+    }
+    acc.cost = wave_sum_d(acc.cost);
+    if (kJac) {
+#pragma unroll
+        for (int i = 0; i < 21; i++) acc.H[i] = wave_sum_d(acc.H[i]);
+#pragma unroll
+        for (int i = 0; i < 6; i++) acc.g[i] = wave_sum_d(acc.g[i]);
+    }
+}
+
+__device__ __forceinline__ bool chol_solve6(const double *A, const double *bvec, double *xo)
+{
+    double L[36];
+    for (int i = 0; i < 36; i++) L[i] = 0.0;
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j <= i; j++) {
+            double s = A[i * 6 + j];
+            for (int k = 0; k < j; k++) s -= L[i * 6 + k] * L[j * 6 + k];
+            if (i == j) { if (!(s > 0.0)) return false; L[i * 6 + i] = sqrt(s); }
+            else L[i * 6 + j] = s / L[j * 6 + j];
+        }
+    double y[6];
+    for (int i = 0; i < 6; i++) { double s = bvec[i]; for (int k = 0; k < i; k++) s -= L[i * 6 + k] * y[k]; y[i] = s / L[i * 6 + i]; }
+    for (int i = 5; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < 6; k++) s -= L[k * 6 + i] * xo[k]; xo[i] = s / L[i * 6 + i]; }
+    return true;
+}
+
+__device__ __forceinline__ void manifold_plus(const double *x, const double *d, double *o)
+{
+    const double nd = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    if (nd > 0.0) {
+        const double sc = sin(nd) / nd;
+        const double ax = sc * d[0], ay = sc * d[1], az = sc * d[2], aw = cos(nd);
+        const double bx = x[0], by = x[1], bz = x[2], bw = x[3];
+        o[3] = aw * bw - ax * bx - ay * by - az * bz;
+        o[0] = aw * bx + ax * bw + ay * bz - az * by;
+        o[1] = aw * by + ay * bw + az * bx - ax * bz;
+        o[2] = aw * bz + az * bw + ax * by - ay * bx;
+    } else { o[0] = x[0]; o[1] = x[1]; o[2] = x[2]; o[3] = x[3]; }
+    o[4] = x[4] + d[3]; o[5] = x[5] + d[4]; o[6] = x[6] + d[5];
+}
+
+__device__ __forceinline__ double norm7(const double *x)
+{
+    double s = 0.0;
+    for (int i = 0; i < 7; i++) s += x[i] * x[i];
+    return sqrt(s);
+}
+
+__device__ __forceinline__ void unpack_sym(const double *Hu, double *H)
+{
+    int t = 0;
+    for (int i = 0; i < 6; i++)
+        for (int j = i; j < 6; j++) { H[i * 6 + j] = Hu[t]; H[j * 6 + i] = Hu[t]; t++; }
+}
+
+// One wave per chain.  All lanes run the (uniform) trust-region control flow redundantly on wave-reduced sums.
+__global__ __launch_bounds__(256) void k_lm_solve(BatchView b, OdomView o, int step, int outer)
+{
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (c >= o.n_chains) return;
+    int s, e;
+    chain_bounds(o.n_scans, o.n_chains, c, s, e);
+    const int begin = max(s - o.lead, 0);
+    const int k = begin + 1 + step;
+    if (k >= e) return;
+    const int nq = b.feat_n[k * 4 + 0] + b.feat_n[k * 4 + 2];
+    const int4 *corr = (const int4 *)o.corr + (size_t)c * kMaxQueries;
+    double x[7];
+    for (int i = 0; i < 7; i++) x[i] = o.state[c * 8 + i];
+
+    const int max_iter = 4;
+    const double function_tol = 1e-6, gradient_tol = 1e-10, parameter_tol = 1e-8;
+    const double min_rel_decrease = 1e-3, min_diag = 1e-6, max_diag = 1e32, max_radius = 1e16, min_radius = 1e-32;
+    double radius = 1e4, decrease_factor = 2.0;
+    bool reuse_diagonal = false;
+    int invalid_steps = 0, iter = 0;
+    LmAcc acc;
+    evaluate_wave<true>(b, k, corr, nq, x, acc, lane);
+    double x_cost = acc.cost;
+    double H[36], g[6], scale[6], diag[6];
+    unpack_sym(acc.H, H);
+    for (int i = 0; i < 6; i++) g[i] = acc.g[i];
+    int n_used = 0;
+    for (int qi = lane; qi < nq; qi += 64) n_used += corr[qi].w != 0;
+    n_used = wave_sum_i(n_used);
+    double gmax = 0.0;
+    for (int i = 0; i < 6; i++) gmax = fmax(gmax, fabs(g[i]));
+    if (n_used > 0 && gmax > gradient_tol) {
+        double x_norm = norm7(x);
+        for (int i = 0; i < 6; i++) scale[i] = 1.0 / (1.0 + sqrt(H[i * 6 + i]));
+        while (iter < max_iter) {
+            iter++;
+            double Hs[36], gs[6], A[36], stepv[6];
+            for (int i = 0; i < 6; i++) { gs[i] = g[i] * scale[i]; for (int j = 0; j < 6; j++) Hs[i * 6 + j] = H[i * 6 + j] * scale[i] * scale[j]; }
+            if (!reuse_diagonal)
+                for (int i = 0; i < 6; i++) { double d = Hs[i * 6 + i]; d = d < min_diag ? min_diag : d; d = d > max_diag ? max_diag : d; diag[i] = d; }
+            for (int i = 0; i < 36; i++) A[i] = Hs[i];
+            for (int i = 0; i < 6; i++) A[i * 6 + i] += diag[i] / radius;
+            bool ok = chol_solve6(A, gs, stepv);
+            for (int i = 0; i < 6; i++) if (!isfinite(stepv[i])) ok = false;
+            double model_change = 0.0;
+            if (ok) {
+                for (int i = 0; i < 6; i++) stepv[i] = -stepv[i];
+                double dg = 0.0, dHd = 0.0;
+                for (int i = 0; i < 6; i++) { dg += stepv[i] * gs[i]; for (int j = 0; j < 6; j++) dHd += stepv[i] * Hs[i * 6 + j] * stepv[j]; }
+                model_change = -(dg + 0.5 * dHd);
+            }
+            if (!ok || !(model_change > 0.0)) {
+                if (++invalid_steps >= 5) break;
+                radius *= 0.5; reuse_diagonal = true;
+                continue;
+            }
+            invalid_steps = 0;
+            double delta[6], cand[7];
+            for (int i = 0; i < 6; i++) delta[i] = stepv[i] * scale[i];
+            manifold_plus(x, delta, cand);
+            LmAcc ca;
+            evaluate_wave<false>(b, k, corr, nq, cand, ca, lane);
+            const double cand_cost = ca.cost;
+            double sn = 0.0;
+            for (int i = 0; i < 7; i++) sn += (x[i] - cand[i]) * (x[i] - cand[i]);
+            sn = sqrt(sn);
+            if (sn <= parameter_tol * (x_norm + parameter_tol)) break;
+            if (fabs(x_cost - cand_cost) <= function_tol * x_cost) break;
+            const double rel = (x_cost - cand_cost) / model_change;
+            if (rel > min_rel_decrease) {
+                for (int i = 0; i < 7; i++) x[i] = cand[i];
+                x_norm = norm7(x);
+                evaluate_wave<true>(b, k, corr, nq, x, acc, lane);
+                x_cost = acc.cost;
+                unpack_sym(acc.H, H);
+                for (int i = 0; i < 6; i++) g[i] = acc.g[i];
+                const double tt = 2.0 * rel - 1.0;
+                double den = 1.0 - tt * tt * tt;
+                if (den < 1.0 / 3.0) den = 1.0 / 3.0;
+                radius = radius / den;
+                if (radius > max_radius) radius = max_radius;
+                decrease_factor = 2.0; reuse_diagonal = false;
+                gmax = 0.0;
+                for (int i = 0; i < 6; i++) gmax = fmax(gmax, fabs(g[i]));
+                if (gmax <= gradient_tol) break;
+            } else {
+                radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
+            }
+            if (radius <= min_radius) break;
+        }
+    }
+    if (lane == 0) {
+        for (int i = 0; i < 7; i++) o.state[c * 8 + i] = x[i];
+        if (outer == 1 && k >= s)
+            for (int i = 0; i < 7; i++) o.incr[(size_t)k * 7 + i] = x[i];
+        o.lm_info[c * 4 + outer] = iter;
+        o.lm_info[c * 4 + 2 + outer] = n_used;
+    }
+}
+
+__global__ void k_odom_init(OdomView o)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < o.n_chains) {
+        double *st = o.state + i * 8;
+        st[0] = st[1] = st[2] = 0.0; st[3] = 1.0; st[4] = st[5] = st[6] = 0.0; st[7] = 0.0;
+    }
+    if (i < o.n_scans) {
+        double *r = o.incr + (size_t)i * 7;
+        r[0] = r[1] = r[2] = 0.0; r[3] = 1.0; r[4] = r[5] = r[6] = 0.0;
+    }
+}
+
+// poses[k] = poses[k-1] (+) incr[k]  (t_w += q_w * t ; q_w = q_w * q), one lane, sequential like the reference
+__global__ void k_pose_prefix(const double *incr, double *poses, int n)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double qw[4] = { 0, 0, 0, 1 }, tw[3] = { 0, 0, 0 };
+    for (int k = 0; k < n; k++) {
+        if (k > 0) {
+            const double *q = incr + (size_t)k * 7, *t = q + 4;
+            double rx, ry, rz;
+            quat_rotate(qw, t[0], t[1], t[2], rx, ry, rz);
+            tw[0] += rx; tw[1] += ry; tw[2] += rz;
+            const double ax = qw[0], ay = qw[1], az = qw[2], aw = qw[3];
+            const double bx = q[0], by = q[1], bz = q[2], bw = q[3];
+            qw[3] = aw * bw - ax * bx - ay * by - az * bz;
+            qw[0] = aw * bx + ax * bw + ay * bz - az * by;
+            qw[1] = aw * by + ay * bw + az * bx - ax * bz;
+            qw[2] = aw * bz + az * bw + ax * by - ay * bx;
+        }
+        double *p = poses + (size_t)k * 7;
+        p[0] = qw[0]; p[1] = qw[1]; p[2] = qw[2]; p[3] = qw[3]; p[4] = tw[0]; p[5] = tw[1]; p[6] = tw[2];
+    }
+}
+
+} // namespace lmono
