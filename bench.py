@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: HDL-64 scans/sec through the MI355X LiDAR hot path.
+
+Workload (BASELINE.json configs[1]): KITTI seq-00-shaped sequence, 4541 HDL-64 scans (synthetic S1 world,
+~118 k returns/scan), scan registration + scan-to-scan laserOdometry only.  One "step" = one pass
+over the whole resident sequence: lmono_scanreg_batch + lmono_odom_batch_d (+ the RCCL pose exchange when N > 1).
+Inputs are resident in HBM before the timed region.  Weak scaling: every rank processes its own 4541-scan range of
+one long trajectory; value = scans of all ranks * steps / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scans", type=int, default=4541, help="scans per GPU (KITTI seq 00 = 4541)")
+    ap.add_argument("--chains", type=int, default=256, help="concurrent odometry chains per GPU")
+    ap.add_argument("--lead", type=int, default=5, help="lead-in scans of a chain that does not start at scan 0")
+    ap.add_argument("--az", type=int, default=2000, help="azimuth steps per ring (2000 = HDL-64 at 10 Hz)")
+    ap.add_argument("--cpu-sample", type=int, default=384, help="scans of the CPU baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import lmono_amd
+    from lmono_amd import sharding
+    from oracle import oracle as O   # synthetic generator (input plumbing) + cpu_baseline leg only
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    n = args.scans
+    n_total = n * world
+    load_begin, own_begin, own_end = sharding.shard_range(n_total, world, rank, args.lead)
+    lead_r = own_begin - load_begin
+    n_local = own_end - load_begin
+
+    t0 = time.time()
+    w = O.S1World(n_az=args.az)
+    traj = w.trajectory(n_total)
+    xyzi, off = w.scans(traj[load_begin:own_end], scan_id0=load_begin)
+    gen_s = time.time() - t0
+    total_pts = int(off[-1])
+
+    ctx = lmono_amd.Context(local_rank)
+    xyzi_t = torch.from_numpy(xyzi)
+    t0 = time.time()
+    xyzi_d = xyzi_t.to(dev)
+    torch.cuda.synchronize()
+    h2d_s = time.time() - t0
+    sample = None
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        m = min(args.cpu_sample, n_local)
+        sample = (np.ascontiguousarray(xyzi[:off[m]]), off[:m + 1].copy())
+    del xyzi, xyzi_t
+
+    batch = lmono_amd.ScanBatch(ctx, n_local, total_pts)
+    incr_d = torch.zeros((n_local, 7), dtype=torch.float64, device=dev)
+    poses_d = torch.zeros((n_local - lead_r, 7), dtype=torch.float64, device=dev)
+    chains = min(args.chains, n_local)
+
+    def step():
+        batch.scanreg(xyzi_d.data_ptr(), off, 64, 5.0, keepalive=xyzi_d)
+        batch.odometry_d(chains, args.lead, incr_d.data_ptr(), None)
+        ctx.pose_prefix_d(incr_d.data_ptr(), lead_r, n_local, poses_d.data_ptr())
+        if world > 1:
+            bases = sharding.gather_bases(poses_d[-1].clone())
+            # the first owned increment composes onto the previous rank's last pose
+            ctx.pose_rebase_d(bases.data_ptr(), rank, poses_d.data_ptr(), n_local - lead_r)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    groups, n_reg, n_odo = ctx.timing()
+
+    cnt = batch.counts()
+    status_or = int(np.bitwise_or.reduce(cnt[:, 5]))
+    n_cloud_mean = float(cnt[:, 0].mean())
+    gpu_incr = incr_d.cpu().numpy()
+
+    if rank == 0:
+        scans_per_s = n_total * args.steps / elapsed
+        # ---- roofline of the dominant kernel group (device time from hipEvents on the launch stream)
+        # algorithmic bytes per scan (DESIGN.md "Kernels"): N = raw points per scan, Nc = points kept in the ring-sorted cloud
+        N = total_pts / n_local
+        Nc = n_cloud_mean
+        nlf = float(cnt[:, 4].mean()); nls = float(cnt[:, 2].mean())
+        alg = {
+            "k_ring_sort": 16 * N + 16 * Nc,
+            "k_curvature": 16 * Nc + 5 * Nc,
+            "k_select": 5 * Nc + 16 * Nc + 1 * Nc + 16 * nlf,
+            "k_compact": 32 * (nlf + nls),
+            "k_grid_build": 48 * (nlf + nls),
+            "odometry_total": 0.77e6,
+        }
+        per_launch = {k: groups[k] / max(n_reg if k != "odometry_total" else n_odo, 1) for k in alg}
+        dom = max(per_launch, key=lambda k: per_launch[k])
+        ach = alg[dom] * n_local / (per_launch[dom] * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                    "ms_per_launch": round(per_launch[dom], 4),
+                    "frontend_fused_frac": round(37 * N * n_local / (groups["frontend_total"] / max(n_reg, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "group_ms_per_step": {k: round(v / max(args.steps, 1), 3) for k, v in groups.items()}}
+        out = {
+            "metric": "KITTI HDL-64 scans/sec (scanRegistration + laserOdometry)", "value": round(scans_per_s, 1),
+            "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 features / f64 solve", "data": "synthetic",
+            "config": {"workload": "KITTI-seq-00-shaped synthetic S1 HDL-64, laserOdometry-only (configs[1])",
+                       "scans_per_gpu": n, "points_per_scan": round(N), "azimuth_steps": args.az,
+                       "odometry_chains": chains, "chain_lead_in": args.lead, "parallelism": "scan-range shard x%d" % world,
+                       "status_or": status_or, "gen_s": round(gen_s, 1), "h2d_s": round(h2d_s, 2),
+                       "h2d_GBps": round(total_pts * 16 / h2d_s / 1e9, 1)},
+            "roofline": roofline,
+        }
+        if sample is not None:
+            sx, so = sample
+            m = len(so) - 1
+            t0 = time.time()
+            ref = O.run_sequence(sx, so, threads=1)
+            cpu_s = time.time() - t0
+            # parity of the timed GPU run against the CPU path on the sample: chain-sharded GPU vs strictly sequential CPU
+            gp = sharding.prefix(gpu_incr[:m])
+            out["cpu_baseline"] = {"value": round(m / cpu_s, 2), "unit": "scans/s", "cores": 1, "kind": "port",
+                                   "sample": "first %d scans of the same sequence, oracle/ C restatement (-O3, kd-tree), 1 thread: scanreg %.0f ms + odometry %.0f ms"
+                                             % (m, ref["stage_ms"][0], ref["stage_ms"][1])}
+            out["ate_vs_cpu_m"] = round(O.ate(gp, ref["poses"]), 6)
+            out["ate_vs_truth_m"] = round(O.ate(gp, O.gt_relative(traj[:m])), 4)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -77,9 +77,19 @@ int lmono_odom_batch_d(lmono_ctx *, lmono_scan_batch *, int n_chains, int lead, 
 int lmono_odom_correspond(lmono_ctx *, lmono_scan_batch *, int scan, const double q[4], const double t[3],
                           int32_t *corr_h, int cap);
 
-/* device time (ms) of the stages of the last lmono_scanreg_batch / lmono_odom_batch call, measured with
- * hipEvents on the context stream: [0] scanreg total, [1] odometry total, [2..] per-kernel groups      */
-int lmono_last_timing(lmono_ctx *, double *ms_out, int cap);
+/* ---- pose composition (laserOdometry: t_w_curr += q_w_curr * t_last_curr; q_w_curr *= q_last_curr) ------- *
+ * lmono_pose_prefix_d: poses_d[k - first] = incr[first+1] (+) ... (+) incr[k] for k in [first, n); scan `first`
+ * is the origin.  lmono_pose_rebase_d: poses[k] <- bases[0] (+) ... (+) bases[n_bases-1] (+) poses[k]; with scans
+ * sharded over GPUs, bases are the cumulative transforms of the lower ranks (one RCCL all-gather of 56 B/rank). */
+int lmono_pose_prefix_d(lmono_ctx *, const double *incr_d, int first, int n, double *poses_d);
+int lmono_pose_rebase_d(lmono_ctx *, const double *bases_d, int n_bases, double *poses_d, int n);
+
+/* Device-time accounting with hipEvents recorded on the context stream around every kernel group of every
+ * lmono_scanreg_batch / lmono_odom_batch call since the last reset.  ms_out[0..6] = summed milliseconds of:
+ * [0] front end total, [1] odometry total, [2] k_ring_sort, [3] k_curvature, [4] k_select, [5] k_compact,
+ * [6] k_grid_build.  Both calls synchronise the stream.                                                   */
+int lmono_timing_reset(lmono_ctx *);
+int lmono_timing_read(lmono_ctx *, double *ms_out, int cap, int *n_scanreg_calls, int *n_odom_calls);
 
 #ifdef __cplusplus
 }

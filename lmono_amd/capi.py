@@ -11,7 +11,8 @@ MAX_QUERIES = 64 * 6 * 2 + 64 * 6 * 4
 SYMBOLS = [
     "lmono_create", "lmono_destroy", "lmono_last_error", "lmono_set_stream", "lmono_synchronize", "lmono_version",
     "lmono_batch_create", "lmono_batch_destroy", "lmono_scanreg_batch", "lmono_batch_counts", "lmono_batch_get_cloud",
-    "lmono_batch_get_curvature", "lmono_odom_batch", "lmono_odom_batch_d", "lmono_odom_correspond", "lmono_last_timing",
+    "lmono_batch_get_curvature", "lmono_odom_batch", "lmono_odom_batch_d", "lmono_odom_correspond", "lmono_timing_reset", "lmono_timing_read",
+    "lmono_pose_prefix_d", "lmono_pose_rebase_d",
 ]
 
 
@@ -52,7 +53,10 @@ def load_library():
     L.lmono_odom_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.lmono_odom_batch_d.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.lmono_odom_correspond.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
-    L.lmono_last_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.lmono_timing_reset.argtypes = [C.c_void_p]
+    L.lmono_pose_prefix_d.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.lmono_pose_rebase_d.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    L.lmono_timing_read.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -78,10 +82,22 @@ class Context:
     def synchronize(self):
         self.check(self.L.lmono_synchronize(self.h))
 
+    def timing_reset(self):
+        self.check(self.L.lmono_timing_reset(self.h))
+
     def timing(self):
-        ms = np.zeros(8)
-        self.check(self.L.lmono_last_timing(self.h, ms.ctypes.data, 8))
-        return ms
+        """Summed device ms per kernel group since timing_reset(): dict + call counts."""
+        ms = np.zeros(7)
+        nr, no = C.c_int(0), C.c_int(0)
+        self.check(self.L.lmono_timing_read(self.h, ms.ctypes.data, 7, C.byref(nr), C.byref(no)))
+        names = ["frontend_total", "odometry_total", "k_ring_sort", "k_curvature", "k_select", "k_compact", "k_grid_build"]
+        return dict(zip(names, ms.tolist())), nr.value, no.value
+
+    def pose_prefix_d(self, incr_ptr, first, n, poses_ptr):
+        self.check(self.L.lmono_pose_prefix_d(self.h, C.c_void_p(incr_ptr), first, n, C.c_void_p(poses_ptr)))
+
+    def pose_rebase_d(self, bases_ptr, n_bases, poses_ptr, n):
+        self.check(self.L.lmono_pose_rebase_d(self.h, C.c_void_p(bases_ptr or 0), n_bases, C.c_void_p(poses_ptr), n))
 
     def close(self):
         if self.h:

@@ -39,8 +39,6 @@ struct BatchView {
     float4 *flat;            // [n_scans][kMaxFlat]
     float4 *less_flat;       // [total] (scan offsets as input)
     int *feat_n;             // [n_scans][4] sharp, less_sharp, flat, less_flat
-    int *ls_ring_start;      // [n_scans][65] first index with int(intensity) >= r in less_sharp
-    int *lf_ring_start;      // [n_scans][65] same for less_flat
     // ---- hash grids of less_sharp / less_flat (used as the "last" clouds of the next scan)
     unsigned long long *cg_key;  int *cg_cnt;  int *cg_start;   // [n_scans][kCornerTable]
     unsigned long long *sg_key;  int *sg_cnt;  int *sg_start;   // [n_scans][kSurfTable]

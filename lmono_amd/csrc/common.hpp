@@ -20,7 +20,6 @@ constexpr int kMaxQueries = kMaxSharp + kMaxFlat;
 // status bits per scan
 constexpr int kStatusRingOverflow = 1;   // a ring holds more than kRingCap points
 constexpr int kStatusGridOverflow = 2;   // a "last" cloud does not fit its hash grid
-constexpr int kStatusNonMonotone = 4;    // int(intensity) not monotone in a feature cloud: serial ring walk used
 
 #define LM_PI 3.14159265358979323846
 #define LM_PI_2 1.57079632679489661923

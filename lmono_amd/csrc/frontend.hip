@@ -412,23 +412,6 @@ __global__ __launch_bounds__(256) void k_select(BatchView b)
 }
 
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void ring_start_table(const float4 *pts, int n, int *rs, int *status, int tid, int nthreads)
-{
-    // rs[r] = first index whose int(intensity) >= r (65 entries); flags non-monotone arrays
-    bool bad = false;
-    for (int j = tid; j < n; j += nthreads) {
-        const int v = (int)pts[j].w;
-        const int pv = j > 0 ? (int)pts[j - 1].w : -1;
-        if (v < pv) bad = true;
-        for (int r = pv + 1; r <= v && r <= 64; r++) if (r >= 0) rs[r] = j;
-    }
-    if (tid == 0) {
-        const int last = n > 0 ? (int)pts[n - 1].w : -1;
-        for (int r = (last + 1 < 0 ? 0 : last + 1); r <= 64; r++) rs[r] = n;
-    }
-    if (bad) atomicOr(status, kStatusNonMonotone);
-}
-
 __global__ __launch_bounds__(256) void k_compact(BatchView b)
 {
     const int s = blockIdx.x;
@@ -472,9 +455,6 @@ __global__ __launch_bounds__(256) void k_compact(BatchView b)
         b.feat_n[s * 4 + 0] = pre_sh[NE]; b.feat_n[s * 4 + 1] = pre_ls[NE];
         b.feat_n[s * 4 + 2] = pre_fl[NE]; b.feat_n[s * 4 + 3] = pre_lf[kMaxRings];
     }
-    __syncthreads();
-    ring_start_table(ls, pre_ls[NE], b.ls_ring_start + s * 65, b.status + s, tid, 256);
-    ring_start_table(lf, pre_lf[kMaxRings], b.lf_ring_start + s * 65, b.status + s, tid, 256);
 }
 
 } // namespace lmono

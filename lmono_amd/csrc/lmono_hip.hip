@@ -11,12 +11,28 @@
 
 using namespace lmono;
 
+struct EvSet { hipEvent_t e[8]; bool reg = false, odom = false; };
+
 struct lmono_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
-    hipEvent_t ev[8];
-    double timing[8] = { 0 };
+    std::vector<EvSet> sets;   // one event set per scanreg/odometry call since the last lmono_timing_reset
+    int n_sets = 0;
+    hipEvent_t *ev = nullptr;  // events of the current call
+
+    hipEvent_t *next_set()
+    {
+        constexpr int kMaxSets = 1024;
+        if (n_sets == (int)sets.size()) {
+            if (n_sets >= kMaxSets) { sets[n_sets - 1].reg = sets[n_sets - 1].odom = false; return sets[n_sets - 1].e; }
+            EvSet s;
+            for (auto &e : s.e) if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            sets.push_back(s);
+        }
+        sets[n_sets].reg = sets[n_sets].odom = false;
+        return sets[n_sets++].e;
+    }
 };
 
 struct lmono_scan_batch {
@@ -55,8 +71,6 @@ extern "C" lmono_ctx *lmono_create(int device)
     if (hipSetDevice(device) != hipSuccess) return nullptr;
     lmono_ctx *c = new lmono_ctx();
     c->device = device;
-    for (auto &e : c->ev)
-        if (hipEventCreate(&e) != hipSuccess) { delete c; return nullptr; }
     // the selection kernel needs ~62 KB of dynamic LDS
     if (hipFuncSetAttribute((const void *)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, kSelLds) != hipSuccess) { delete c; return nullptr; }
     return c;
@@ -65,7 +79,7 @@ extern "C" lmono_ctx *lmono_create(int device)
 extern "C" void lmono_destroy(lmono_ctx *c)
 {
     if (!c) return;
-    for (auto &e : c->ev) (void)hipEventDestroy(e);
+    for (auto &s : c->sets) for (auto &e : s.e) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -120,7 +134,7 @@ extern "C" lmono_scan_batch *lmono_batch_create(lmono_ctx *c, int n_cap, int64_t
     ok = ok && dalloc(b, v.lf_tmp, T) && dalloc(b, v.lf_n, N * 64);
     ok = ok && dalloc(b, v.sharp, N * kMaxSharp) && dalloc(b, v.less_sharp, N * kMaxLessSharp);
     ok = ok && dalloc(b, v.flat, N * kMaxFlat) && dalloc(b, v.less_flat, T);
-    ok = ok && dalloc(b, v.feat_n, N * 4) && dalloc(b, v.ls_ring_start, N * 65) && dalloc(b, v.lf_ring_start, N * 65);
+    ok = ok && dalloc(b, v.feat_n, N * 4);
     ok = ok && dalloc(b, v.cg_key, N * kCornerTable) && dalloc(b, v.cg_cnt, N * kCornerTable) && dalloc(b, v.cg_start, N * kCornerTable);
     ok = ok && dalloc(b, v.sg_key, N * kSurfTable) && dalloc(b, v.sg_cnt, N * kSurfTable) && dalloc(b, v.sg_start, N * kSurfTable);
     ok = ok && dalloc(b, v.cg_pts, N * kMaxLessSharp) && dalloc(b, v.sg_pts, T) && dalloc(b, v.grid_mask, N * 2);
@@ -165,6 +179,9 @@ extern "C" int lmono_scanreg_batch(lmono_ctx *c, lmono_scan_batch *b, const floa
     BatchView &v = b->v;
     v.in = (const float4 *)xyzi_d; v.n_scans = n_scans; v.n_lines = n_lines; v.min_range = min_range;
     hipStream_t st = c->stream;
+    c->ev = c->next_set();
+    if (!c->ev) { c->err = "hipEventCreate failed"; return LMONO_ENODEV; }
+    c->sets[c->n_sets - 1].reg = true;
     HIP_TRY(c, hipMemcpyAsync(b->off_d, b->off_h.data(), sizeof(int64_t) * (n_scans + 1), hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemsetAsync(v.status, 0, sizeof(int) * n_scans, st));
     HIP_TRY(c, hipEventRecord(c->ev[0], st));
@@ -185,17 +202,37 @@ extern "C" int lmono_scanreg_batch(lmono_ctx *c, lmono_scan_batch *b, const floa
     return LMONO_OK;
 }
 
-extern "C" int lmono_last_timing(lmono_ctx *c, double *ms, int cap)
+extern "C" int lmono_timing_reset(lmono_ctx *c)
+{
+    if (!c) return LMONO_EINVAL;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->n_sets = 0;
+    return LMONO_OK;
+}
+
+extern "C" int lmono_timing_read(lmono_ctx *c, double *ms, int cap, int *n_scanreg_calls, int *n_odom_calls)
 {
     if (!c || !ms) return LMONO_EINVAL;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    double sum[7] = { 0 };
+    int nr = 0, no = 0;
     float t;
-    // [0] scanreg total (incl. grid build), [1] odometry total, [2] ring_sort, [3] curvature, [4] select, [5] compact, [6] grid_build
-    if (hipEventElapsedTime(&t, c->ev[0], c->ev[5]) == hipSuccess) c->timing[0] = t;
-    for (int i = 0; i < 5; i++)
-        if (hipEventElapsedTime(&t, c->ev[i], c->ev[i + 1]) == hipSuccess) c->timing[2 + i] = t;
-    if (hipEventElapsedTime(&t, c->ev[6], c->ev[7]) == hipSuccess) c->timing[1] = t;
-    for (int i = 0; i < cap && i < 7; i++) ms[i] = c->timing[i];
+    for (int i = 0; i < c->n_sets; i++) {
+        const EvSet &s = c->sets[i];
+        if (s.reg) {
+            nr++;
+            if (hipEventElapsedTime(&t, s.e[0], s.e[5]) == hipSuccess) sum[0] += t;
+            for (int k = 0; k < 5; k++)
+                if (hipEventElapsedTime(&t, s.e[k], s.e[k + 1]) == hipSuccess) sum[2 + k] += t;
+        }
+        if (s.odom) {
+            no++;
+            if (hipEventElapsedTime(&t, s.e[6], s.e[7]) == hipSuccess) sum[1] += t;
+        }
+    }
+    for (int i = 0; i < cap && i < 7; i++) ms[i] = sum[i];
+    if (n_scanreg_calls) *n_scanreg_calls = nr;
+    if (n_odom_calls) *n_odom_calls = no;
     return LMONO_OK;
 }
 
@@ -283,6 +320,9 @@ extern "C" int lmono_odom_batch_d(lmono_ctx *c, lmono_scan_batch *b, int n_chain
         max_steps = steps > max_steps ? steps : max_steps;
     }
     hipStream_t st = c->stream;
+    if (c->n_sets == 0 || c->sets[c->n_sets - 1].odom) c->ev = c->next_set();
+    if (!c->ev) { c->err = "hipEventCreate failed"; return LMONO_ENODEV; }
+    c->sets[c->n_sets - 1].odom = true;
     HIP_TRY(c, hipEventRecord(c->ev[6], st));
     const int ninit = n > n_chains ? n : n_chains;
     hipLaunchKernelGGL(k_odom_init, dim3((ninit + 255) / 256), dim3(256), 0, st, o);
@@ -292,7 +332,7 @@ extern "C" int lmono_odom_batch_d(lmono_ctx *c, lmono_scan_batch *b, int n_chain
             hipLaunchKernelGGL(k_lm_solve, dim3((n_chains + 3) / 4), dim3(256), 0, st, b->v, o, step, outer);
         }
     }
-    hipLaunchKernelGGL(k_pose_prefix, dim3(1), dim3(64), 0, st, b->incr, b->poses, n);
+    hipLaunchKernelGGL(k_pose_prefix, dim3(1), dim3(64), 0, st, (const double *)b->incr, b->poses, 0, n);
     HIP_TRY(c, hipEventRecord(c->ev[7], st));
     rc = check_launch(c, "odometry kernels");
     if (rc) return rc;
@@ -330,4 +370,20 @@ extern "C" int lmono_odom_correspond(lmono_ctx *c, lmono_scan_batch *b, int scan
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (nq > 0) HIP_TRY(c, hipMemcpy(corr_h, b->corr_pair, sizeof(int) * 4 * nq, hipMemcpyDeviceToHost));
     return nq;
+}
+
+extern "C" int lmono_pose_prefix_d(lmono_ctx *c, const double *incr_d, int first, int n, double *poses_d)
+{
+    if (!c || !incr_d || !poses_d || first < 0 || n <= first) return LMONO_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_pose_prefix, dim3(1), dim3(64), 0, c->stream, incr_d, poses_d, first, n);
+    return check_launch(c, "k_pose_prefix");
+}
+
+extern "C" int lmono_pose_rebase_d(lmono_ctx *c, const double *bases_d, int n_bases, double *poses_d, int n)
+{
+    if (!c || !poses_d || n <= 0 || n_bases < 0 || (n_bases > 0 && !bases_d)) return LMONO_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_pose_rebase, dim3((n + 255) / 256), dim3(256), 0, c->stream, bases_d, n_bases, poses_d, n);
+    return check_launch(c, "k_pose_rebase");
 }

@@ -169,25 +169,54 @@ __device__ __forceinline__ unsigned long long wave_nn(const GridRef &g, float qx
     return best;
 }
 
-// min over j in [lo, hi) of (d2, seq) where seq orders candidates the way the reference loops visit them
-__device__ __forceinline__ unsigned long long sweep_min(const float4 *cloud, int lo, int hi, int skip, float qx, float qy, float qz,
-                                                        int seq_base, bool descending, int lane, unsigned long long best)
-{
-    for (int j = lo + lane; j < hi; j += 64) {
-        if (j == skip) continue;
-        const float4 p = cloud[j];
-        const unsigned int seq = (unsigned int)(seq_base + (descending ? (hi - 1 - j) : (j - lo)));
-        const unsigned long long cand = pack_fu(dist2f(p.x, p.y, p.z, qx, qy, qz), seq);
-        best = cand < best ? cand : best;
-    }
-    return best;
-}
-
 constexpr unsigned int kSeqBack = 1u << 24;   // backward candidates rank after every forward candidate
 
-__device__ __forceinline__ int seq_to_index(unsigned int seq, int f_lo, int b_hi)
+// Wave-parallel restatement of the reference's two index walks around the nearest point `closest` of a feature
+// cloud whose int(intensity) is the scan line.  Forward: j = closest+1.. until the first line > ra + 2.5; backward:
+// j = closest-1.. until the first line < ra - 2.5.  Points on the near side of the closest line ("same": line <= ra
+// going forward, >= ra going backward) and on the far side ("other") are minimised separately; edges use only
+// "other".  Candidates are ordered like the reference visits them (forward ascending, then backward descending) so
+// that exact distance ties resolve identically.  No monotonicity of the line ids is assumed.
+__device__ __forceinline__ void line_walk(const float4 *cloud, int n_last, int closest, int ra, float qx, float qy, float qz,
+                                          int lane, unsigned long long &same, unsigned long long &other)
 {
-    return seq >= kSeqBack ? (b_hi - 1 - (int)(seq - kSeqBack)) : f_lo + (int)seq;
+    for (int base = closest + 1; base < n_last; base += 64) {
+        const int j = base + lane;
+        float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+        int v = INT_MAX;
+        if (j < n_last) { c = cloud[j]; v = (int)c.w; }
+        const bool brk = (j < n_last) && ((double)v > (double)ra + 2.5);
+        const unsigned long long mb = __ballot(brk);
+        const int stop = mb ? (__ffsll((long long)mb) - 1) : 64;
+        if (j < n_last && lane < stop) {
+            const unsigned long long cand = pack_fu(dist2f(c.x, c.y, c.z, qx, qy, qz), (unsigned int)(j - closest - 1));
+            if (v <= ra) same = cand < same ? cand : same;
+            else other = cand < other ? cand : other;
+        }
+        if (mb) break;
+    }
+    for (int base = closest - 1; base >= 0; base -= 64) {
+        const int j = base - lane;
+        float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+        int v = INT_MIN;
+        if (j >= 0) { c = cloud[j]; v = (int)c.w; }
+        const bool brk = (j >= 0) && ((double)v < (double)ra - 2.5);
+        const unsigned long long mb = __ballot(brk);
+        const int stop = mb ? (__ffsll((long long)mb) - 1) : 64;
+        if (j >= 0 && lane < stop) {
+            const unsigned long long cand = pack_fu(dist2f(c.x, c.y, c.z, qx, qy, qz), kSeqBack + (unsigned int)(closest - 1 - j));
+            if (v >= ra) same = cand < same ? cand : same;
+            else other = cand < other ? cand : other;
+        }
+        if (mb) break;
+    }
+    same = wave_min_u64(same);
+    other = wave_min_u64(other);
+}
+
+__device__ __forceinline__ int seq_to_index(unsigned int seq, int closest)
+{
+    return seq >= kSeqBack ? (closest - 1 - (int)(seq - kSeqBack)) : closest + 1 + (int)seq;
 }
 
 // Correspondence search for one feature point of scan k against scan k-1.  kind 1 = edge (a, b), 2 = plane (a, b, c).
@@ -202,16 +231,15 @@ __device__ __forceinline__ int4 correspond_one(const BatchView &b, int k, int qi
     const int l = k - 1;
     GridRef g;
     const float4 *cloud;
-    const int *rs;
     int n_last;
     if (edge) {
         g.key = b.cg_key + (size_t)l * kCornerTable; g.cnt = b.cg_cnt + (size_t)l * kCornerTable;
         g.start = b.cg_start + (size_t)l * kCornerTable; g.pts = b.cg_pts + (size_t)l * kMaxLessSharp; g.mask = b.grid_mask[l * 2 + 0];
-        cloud = b.less_sharp + (size_t)l * kMaxLessSharp; rs = b.ls_ring_start + l * 65; n_last = b.feat_n[l * 4 + 1];
+        cloud = b.less_sharp + (size_t)l * kMaxLessSharp; n_last = b.feat_n[l * 4 + 1];
     } else {
         g.key = b.sg_key + (size_t)l * kSurfTable; g.cnt = b.sg_cnt + (size_t)l * kSurfTable;
         g.start = b.sg_start + (size_t)l * kSurfTable; g.pts = b.sg_pts + b.off[l]; g.mask = b.grid_mask[l * 2 + 1];
-        cloud = b.less_flat + b.off[l]; rs = b.lf_ring_start + l * 65; n_last = b.feat_n[l * 4 + 3];
+        cloud = b.less_flat + b.off[l]; n_last = b.feat_n[l * 4 + 3];
     }
     int4 out = make_int4(-1, -1, -1, 0);
     if (n_last == 0) return out;
@@ -222,55 +250,14 @@ __device__ __forceinline__ int4 correspond_one(const BatchView &b, int k, int qi
     const int closest = (int)(unsigned int)(nn & 0xffffffffull);
     const int ra = (int)cloud[closest].w;
     const unsigned long long thr = pack_fu(25.0f, 0u);   // candidates need d2 < 25
-    if (b.status[l] & kStatusNonMonotone) {
-        // exact serial restatement of the reference loops (array order, continue / break on int(intensity))
-        int i2 = -1, i3 = -1;
-        if (lane == 0) {
-            double m2 = 25.0, m3 = 25.0;
-            for (int j = closest + 1; j < n_last; j++) {
-                const float4 c = cloud[j]; const int rj = (int)c.w;
-                if (edge && rj <= ra) continue;
-                if ((double)rj > (double)ra + 2.5) break;
-                const double d = (double)dist2f(c.x, c.y, c.z, qx, qy, qz);
-                if (edge) { if (d < m2) { m2 = d; i2 = j; } }
-                else if (rj <= ra && d < m2) { m2 = d; i2 = j; }
-                else if (rj > ra && d < m3) { m3 = d; i3 = j; }
-            }
-            for (int j = closest - 1; j >= 0; j--) {
-                const float4 c = cloud[j]; const int rj = (int)c.w;
-                if (edge && rj >= ra) continue;
-                if ((double)rj < (double)ra - 2.5) break;
-                const double d = (double)dist2f(c.x, c.y, c.z, qx, qy, qz);
-                if (edge) { if (d < m2) { m2 = d; i2 = j; } }
-                else if (rj >= ra && d < m2) { m2 = d; i2 = j; }
-                else if (rj < ra && d < m3) { m3 = d; i3 = j; }
-            }
-        }
-        i2 = __shfl(i2, 0); i3 = __shfl(i3, 0);
-        if (edge) { if (i2 >= 0) out = make_int4(closest, i2, -1, 1); }
-        else if (i2 >= 0 && i3 >= 0) out = make_int4(closest, i2, i3, 2);
-        return out;
-    }
-    auto ring_lo = [&](int r) { return rs[r < 0 ? 0 : (r > 64 ? 64 : r)]; };
-    // rings above: {ra+1, ra+2} in ascending array order; rings below: {ra-2, ra-1} in descending array order
-    const int f_lo = ring_lo(ra + 1), f_hi = ring_lo(ra + 3);
-    const int b_lo = ring_lo(ra - 2), b_hi = ring_lo(ra);
-    unsigned long long other = thr;
-    other = sweep_min(cloud, f_lo, f_hi, -1, qx, qy, qz, 0, false, lane, other);
-    other = sweep_min(cloud, b_lo, b_hi, -1, qx, qy, qz, (int)kSeqBack, true, lane, other);
-    other = wave_min_u64(other);
-    const int i_other = other < thr ? seq_to_index((unsigned int)(other & 0xffffffffull), f_lo, b_hi) : -1;
+    unsigned long long same = thr, other = thr;
+    line_walk(cloud, n_last, closest, ra, qx, qy, qz, lane, same, other);
+    const int i_other = other < thr ? seq_to_index((unsigned int)(other & 0xffffffffull), closest) : -1;
     if (edge) {
         if (i_other >= 0) out = make_int4(closest, i_other, -1, 1);
         return out;
     }
-    // same ring: forward (closest, ring end) ascending, then backward [ring start, closest) descending
-    const int s_lo = ring_lo(ra), s_hi = ring_lo(ra + 1);
-    unsigned long long same = thr;
-    same = sweep_min(cloud, closest + 1, s_hi, -1, qx, qy, qz, 0, false, lane, same);
-    same = sweep_min(cloud, s_lo, closest, -1, qx, qy, qz, (int)kSeqBack, true, lane, same);
-    same = wave_min_u64(same);
-    const int i_same = same < thr ? seq_to_index((unsigned int)(same & 0xffffffffull), closest + 1, closest) : -1;
+    const int i_same = same < thr ? seq_to_index((unsigned int)(same & 0xffffffffull), closest) : -1;
     if (i_same >= 0 && i_other >= 0) out = make_int4(closest, i_same, i_other, 2);
     return out;
 }
@@ -604,11 +591,14 @@ __global__ void k_odom_init(OdomView o)
     }
 }
 
-// poses[k] = poses[k-1] (+) incr[k]  (t_w += q_w * t ; q_w = q_w * q), one lane, sequential like the reference
-__global__ void k_pose_prefix(const double *incr, double *poses, int n)
+// poses[k] = poses[k-1] (+) incr[k]  (t_w += q_w * t ; q_w = q_w * q), one lane, sequential like the reference.
+// The scan at index `first` is the origin (identity pose); output row k - first.
+__global__ void k_pose_prefix(const double *incr, double *poses, int first, int n)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double qw[4] = { 0, 0, 0, 1 }, tw[3] = { 0, 0, 0 };
+    incr += (size_t)first * 7;
+    n -= first;
     for (int k = 0; k < n; k++) {
         if (k > 0) {
             const double *q = incr + (size_t)k * 7, *t = q + 4;
@@ -625,6 +615,30 @@ __global__ void k_pose_prefix(const double *incr, double *poses, int n)
         double *p = poses + (size_t)k * 7;
         p[0] = qw[0]; p[1] = qw[1]; p[2] = qw[2]; p[3] = qw[3]; p[4] = tw[0]; p[5] = tw[1]; p[6] = tw[2];
     }
+}
+
+// poses[k] <- base (+) poses[k] with base = bases[0] (+) ... (+) bases[n_bases-1]  (multi-GPU: cumulative
+// transforms of the lower ranks, gathered with one RCCL all-gather)
+__global__ void k_pose_rebase(const double *bases, int n_bases, double *poses, int n)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    double qw[4] = { 0, 0, 0, 1 }, tw[3] = { 0, 0, 0 };
+    for (int j = 0; j <= n_bases; j++) {
+        const double *q = j < n_bases ? bases + (size_t)j * 7 : poses + (size_t)k * 7;
+        const double *t = q + 4;
+        double rx, ry, rz;
+        quat_rotate(qw, t[0], t[1], t[2], rx, ry, rz);
+        tw[0] += rx; tw[1] += ry; tw[2] += rz;
+        const double ax = qw[0], ay = qw[1], az = qw[2], aw = qw[3];
+        const double bx = q[0], by = q[1], bz = q[2], bw = q[3];
+        qw[3] = aw * bw - ax * bx - ay * by - az * bz;
+        qw[0] = aw * bx + ax * bw + ay * bz - az * by;
+        qw[1] = aw * by + ay * bw + az * bx - ax * bz;
+        qw[2] = aw * bz + az * bw + ax * by - ay * bx;
+    }
+    double *p = poses + (size_t)k * 7;
+    p[0] = qw[0]; p[1] = qw[1]; p[2] = qw[2]; p[3] = qw[3]; p[4] = tw[0]; p[5] = tw[1]; p[6] = tw[2];
 }
 
 } // namespace lmono

@@ -1,0 +1,70 @@
+"""Host logic for sharding a scan sequence over the GPUs of one node.
+
+Each rank owns a contiguous range of scans plus a `lead`-scan lead-in; the only exchange step is ONE
+all-gather (RCCL over xGMI, 56 B per rank) of every rank's cumulative transform, after which each rank re-bases
+its poses locally.  The pose algebra below (numpy, fp64) mirrors k_pose_prefix / k_pose_rebase and follows
+laserOdometry's accumulation t_w += q_w * t ; q_w = q_w * q (quaternions x,y,z,w)."""
+import numpy as np
+
+
+def shard_range(n_total, world, rank, lead):
+    """Returns (load_begin, own_begin, own_end): rank processes scans [load_begin, own_end), owns [own_begin, own_end)."""
+    own_begin = rank * n_total // world
+    own_end = (rank + 1) * n_total // world
+    load_begin = max(own_begin - lead, 0)
+    return load_begin, own_begin, own_end
+
+
+def quat_rotate(q, v):
+    u = q[:3]; w = q[3]
+    uv = 2.0 * np.cross(u, v)
+    return v + w * uv + np.cross(u, uv)
+
+
+def quat_mul(a, b):
+    ax, ay, az, aw = a; bx, by, bz, bw = b
+    return np.array([aw * bx + ax * bw + ay * bz - az * by,
+                     aw * by + ay * bw + az * bx - ax * bz,
+                     aw * bz + az * bw + ax * by - ay * bx,
+                     aw * bw - ax * bx - ay * by - az * bz])
+
+
+def compose(a, b):
+    """a (+) b for 7-vectors (q xyzw, t)."""
+    out = np.empty(7)
+    out[4:] = a[4:] + quat_rotate(a[:4], b[4:])
+    out[:4] = quat_mul(a[:4], b[:4])
+    return out
+
+
+IDENTITY = np.array([0, 0, 0, 1, 0, 0, 0], np.float64)
+
+
+def prefix(incr, first=0):
+    """poses[k-first] = incr[first+1] (+) ... (+) incr[k]"""
+    n = len(incr) - first
+    out = np.empty((n, 7))
+    cur = IDENTITY.copy()
+    for k in range(n):
+        if k > 0:
+            cur = compose(cur, incr[first + k])
+        out[k] = cur
+    return out
+
+
+def rebase(bases, poses):
+    base = IDENTITY.copy()
+    for b in bases:
+        base = compose(base, b)
+    return np.stack([compose(base, p) for p in poses]) if len(poses) else poses
+
+
+def gather_bases(my_base, group=None):
+    """All-gather of each rank's cumulative transform: torch tensor [7] float64 (CPU for gloo, GPU for RCCL)
+    -> [world, 7].  my_base = T(last scan of the previous rank -> my last scan)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    out = torch.empty((world, 7), dtype=torch.float64, device=my_base.device)
+    dist.all_gather_into_tensor(out, my_base.contiguous(), group=group)
+    return out

@@ -24,6 +24,44 @@ int lo_synth_scan(const lo_world *w, const double pose[4], uint64_t scan_id, flo
     const double px = pose[0], py = pose[1], pz = pose[2], yaw = pose[3];
     const double cyaw = cos(yaw), syaw = sin(yaw);
     int n = 0;
+    /* azimuth-binned culling: objects whose bounding circle can be hit by rays of each world-azimuth bin */
+    enum { NB = 720, MAXOBJ = 256 };
+    const int nobj = w->n_boxes + w->n_cyls;
+    unsigned char *bins = NULL; short *bcount = NULL;
+    const int use_bins = nobj <= MAXOBJ;
+    if (use_bins) {
+        bins = (unsigned char *)malloc((size_t)NB * MAXOBJ);
+        bcount = (short *)calloc(NB, sizeof(short));
+        for (int o = 0; o < nobj; o++) {
+            double cx, cy, R;
+            if (o < w->n_boxes) {
+                const double *B = w->boxes + 6 * o;
+                cx = 0.5 * (B[0] + B[3]) - px; cy = 0.5 * (B[1] + B[4]) - py;
+                R = sqrt(0.25 * (B[3] - B[0]) * (B[3] - B[0]) + 0.25 * (B[4] - B[1]) * (B[4] - B[1]));
+            } else {
+                const double *Cc = w->cyls + 4 * (o - w->n_boxes);
+                cx = Cc[0] - px; cy = Cc[1] - py; R = Cc[2];
+            }
+            double d = sqrt(cx * cx + cy * cy);
+            int lo = 0, hi = NB - 1;
+            if (d > R * 1.0001) {
+                double th = atan2(cy, cx), al = asin(R / d) + 2.0 * M_PI / NB;
+                lo = (int)floor((th - al) / (2.0 * M_PI) * NB); hi = (int)floor((th + al) / (2.0 * M_PI) * NB);
+            }
+            for (int bb = lo; bb <= hi; bb++) {
+                int bi = ((bb % NB) + NB) % NB;
+                bins[bi * MAXOBJ + bcount[bi]++] = (unsigned char)o;
+            }
+        }
+    }
+    double *caz = (double *)malloc(sizeof(double) * 2 * (size_t)w->n_az);
+    int *kbin = (int *)malloc(sizeof(int) * (size_t)w->n_az);
+    for (int k = 0; k < w->n_az; k++) {
+        double az = M_PI - ((double)k + 0.5) * (2.0 * M_PI / (double)w->n_az);
+        caz[2 * k] = cos(az); caz[2 * k + 1] = sin(az);
+        int bi = (int)floor((az + yaw) / (2.0 * M_PI) * NB);
+        kbin[k] = ((bi % NB) + NB) % NB;
+    }
     for (int r = 0; r < w->n_rings; r++) {
         const double ce = cos(w->elev_rad[r]), se = sin(w->elev_rad[r]);
         for (int k = 0; k < w->n_az; k++) {
@@ -31,8 +69,7 @@ int lo_synth_scan(const lo_world *w, const double pose[4], uint64_t scan_id, flo
             uint64_t h1 = splitmix64(h0), h2 = splitmix64(h1);
             if (u01(h0) < w->dropout) continue;
             /* clockwise sweep starting just past the rear (-x) direction */
-            double az = M_PI - ((double)k + 0.5) * (2.0 * M_PI / (double)w->n_az);
-            double dsx = ce * cos(az), dsy = ce * sin(az), dsz = se;
+            double dsx = ce * caz[2 * k], dsy = ce * caz[2 * k + 1], dsz = se;
             double dx = cyaw * dsx - syaw * dsy, dy = syaw * dsx + cyaw * dsy, dz = dsz;
             double best = w->max_range;
             if (dz < 0.0) {
@@ -40,7 +77,14 @@ int lo_synth_scan(const lo_world *w, const double pose[4], uint64_t scan_id, flo
                 if (t > 0.0 && t < best) best = t;
             }
             const double d2n = dx * dx + dy * dy;
-            for (int b = 0; b < w->n_boxes; b++) {
+            int bi = 0, nlist = nobj;
+            if (use_bins) {
+                bi = kbin[k];
+                nlist = bcount[bi];
+            }
+            for (int li = 0; li < nlist; li++) {
+                const int b = use_bins ? bins[bi * MAXOBJ + li] : li;
+                if (b >= w->n_boxes) continue;
                 const double *B = w->boxes + 6 * b;
                 /* 2-D bounding-circle cull */
                 double cx = 0.5 * (B[0] + B[3]) - px, cy = 0.5 * (B[1] + B[4]) - py;
@@ -60,7 +104,10 @@ int lo_synth_scan(const lo_world *w, const double pose[4], uint64_t scan_id, flo
                 }
                 if (hit && t0 > 0.0 && t0 < best) best = t0;
             }
-            for (int c = 0; c < w->n_cyls; c++) {
+            for (int li = 0; li < nlist; li++) {
+                const int oc = use_bins ? bins[bi * MAXOBJ + li] : li;
+                if (oc < w->n_boxes) continue;
+                const int c = oc - w->n_boxes;
                 const double *C = w->cyls + 4 * c;
                 double cx = C[0] - px, cy = C[1] - py, R = C[2];
                 double cr = cx * dy - cy * dx;
@@ -86,6 +133,7 @@ int lo_synth_scan(const lo_world *w, const double pose[4], uint64_t scan_id, flo
             n++;
         }
     }
+    free(bins); free(bcount); free(caz); free(kbin);
     return n;
 }
 

@@ -195,20 +195,21 @@ class S1World:
         poses = np.ascontiguousarray(poses, np.float64)
         n = len(poses)
         slot = self.n_rings * self.n_az * 4
-        chunks, counts_all = [], []
         L = lib()
-        for c0 in range(0, n, 128):
-            m = min(128, n - c0)
-            buf = np.empty((m, slot), np.float32)
+        step = 64
+        buf = np.empty((min(step, n), slot), np.float32)      # reused across chunks
+        out = np.empty((n * self.n_rings * self.n_az, 4), np.float32)   # upper bound, trimmed at the end (lazy pages)
+        offsets = np.zeros(n + 1, np.int64)
+        for c0 in range(0, n, step):
+            m = min(step, n - c0)
             counts = np.zeros(m, np.int32)
             L.lo_synth_scans(C.byref(self.w), _fp(poses[c0:c0 + m], C.c_double), C.c_uint64(scan_id0 + c0), C.c_int(m),
                              _fp(buf, C.c_float), C.c_int64(slot), _fp(counts, C.c_int32))
             for i in range(m):
-                chunks.append(buf[i, :counts[i] * 4].reshape(-1, 4).copy())
-            counts_all.append(counts)
-        counts = np.concatenate(counts_all).astype(np.int64)
-        offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
-        return np.concatenate(chunks, 0), offsets
+                o = offsets[c0 + i]
+                out[o:o + counts[i]] = buf[i, :counts[i] * 4].reshape(-1, 4)
+                offsets[c0 + i + 1] = o + counts[i]
+        return out[:offsets[n]], offsets
 
 
 def gt_relative(poses):
