@@ -78,8 +78,8 @@ int lmono_odom_correspond(lmono_ctx *, lmono_scan_batch *, int scan, const doubl
                           int32_t *corr_h, int cap);
 
 /* ---- pose composition (laserOdometry: t_w_curr += q_w_curr * t_last_curr; q_w_curr *= q_last_curr) ------- *
- * lmono_pose_prefix_d: poses_d[k - first] = incr[first+1] (+) ... (+) incr[k] for k in [first, n); scan `first`
- * is the origin.  lmono_pose_rebase_d: poses[k] <- bases[0] (+) ... (+) bases[n_bases-1] (+) poses[k]; with scans
+ * lmono_pose_prefix_d: poses_d[k - first] = incr[first] (+) ... (+) incr[k] for k in [first, n) (incr[0] is the
+ * identity: first = 0 gives poses relative to scan 0, first > 0 poses relative to scan first-1).  lmono_pose_rebase_d: poses[k] <- bases[0] (+) ... (+) bases[n_bases-1] (+) poses[k]; with scans
  * sharded over GPUs, bases are the cumulative transforms of the lower ranks (one RCCL all-gather of 56 B/rank). */
 int lmono_pose_prefix_d(lmono_ctx *, const double *incr_d, int first, int n, double *poses_d);
 int lmono_pose_rebase_d(lmono_ctx *, const double *bases_d, int n_bases, double *poses_d, int n);

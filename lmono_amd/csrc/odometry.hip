@@ -591,8 +591,9 @@ __global__ void k_odom_init(OdomView o)
     }
 }
 
-// poses[k] = poses[k-1] (+) incr[k]  (t_w += q_w * t ; q_w = q_w * q), one lane, sequential like the reference.
-// The scan at index `first` is the origin (identity pose); output row k - first.
+// poses[k - first] = incr[first] (+) incr[first+1] (+) ... (+) incr[k]  (t_w += q_w * t ; q_w = q_w * q), one lane,
+// sequential like the reference.  incr[0] is the identity, so first = 0 gives poses relative to scan 0; for
+// first > 0 the result is relative to scan first-1 (the previous rank's last scan).
 __global__ void k_pose_prefix(const double *incr, double *poses, int first, int n)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -600,7 +601,7 @@ __global__ void k_pose_prefix(const double *incr, double *poses, int first, int 
     incr += (size_t)first * 7;
     n -= first;
     for (int k = 0; k < n; k++) {
-        if (k > 0) {
+        {
             const double *q = incr + (size_t)k * 7, *t = q + 4;
             double rx, ry, rz;
             quat_rotate(qw, t[0], t[1], t[2], rx, ry, rz);

@@ -41,13 +41,13 @@ IDENTITY = np.array([0, 0, 0, 1, 0, 0, 0], np.float64)
 
 
 def prefix(incr, first=0):
-    """poses[k-first] = incr[first+1] (+) ... (+) incr[k]"""
+    """poses[k-first] = incr[first] (+) ... (+) incr[k]; incr[0] is the identity, so first = 0 is relative to scan 0
+    and first > 0 relative to scan first-1 (the previous rank's last scan)."""
     n = len(incr) - first
     out = np.empty((n, 7))
     cur = IDENTITY.copy()
     for k in range(n):
-        if k > 0:
-            cur = compose(cur, incr[first + k])
+        cur = compose(cur, incr[first + k])
         out[k] = cur
     return out
 
@@ -61,10 +61,10 @@ def rebase(bases, poses):
 
 def gather_bases(my_base, group=None):
     """All-gather of each rank's cumulative transform: torch tensor [7] float64 (CPU for gloo, GPU for RCCL)
-    -> [world, 7].  my_base = T(last scan of the previous rank -> my last scan)."""
+    -> [world, 7].  my_base = T(last scan of the previous rank -> my last scan) = prefix(...)[-1]."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    out = torch.empty((world, 7), dtype=torch.float64, device=my_base.device)
-    dist.all_gather_into_tensor(out, my_base.contiguous(), group=group)
-    return out
+    out = torch.empty(world * 7, dtype=torch.float64, device=my_base.device)
+    dist.all_gather_into_tensor(out, my_base.contiguous().reshape(7), group=group)
+    return out.view(world, 7)

@@ -110,3 +110,26 @@ def test_odometry_full_resolution(oracle, gpu_ctx, full_seq):
     assert np.abs(incr - ref["incr"]).max() < 1e-9
     # the estimate must also be physically right: ~0.8 m forward per scan
     assert 0.6 < incr[2, 4] < 1.0
+
+
+def test_pose_prefix_and_rebase_kernels(gpu_ctx):
+    """k_pose_prefix / k_pose_rebase against the numpy mirror in lmono_amd.sharding (the N > 1 exchange path)."""
+    import torch
+    from lmono_amd import sharding
+    rng = np.random.default_rng(5)
+    n = 300
+    q = np.concatenate([rng.normal(0, 0.02, (n, 3)), np.ones((n, 1))], 1); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    incr = np.concatenate([q, rng.normal([0.8, 0, 0], 0.05, (n, 3))], 1)
+    incr[0] = sharding.IDENTITY
+    d_incr = torch.from_numpy(incr).cuda()
+    for first in (0, 7):
+        d_pose = torch.zeros((n - first, 7), dtype=torch.float64, device="cuda")
+        gpu_ctx.pose_prefix_d(d_incr.data_ptr(), first, n, d_pose.data_ptr())
+        torch.cuda.synchronize()
+        ref = sharding.prefix(incr, first)
+        assert np.abs(d_pose.cpu().numpy() - ref).max() < 1e-12
+    bases = incr[1:4].copy()
+    d_b = torch.from_numpy(bases).cuda()
+    gpu_ctx.pose_rebase_d(d_b.data_ptr(), 3, d_pose.data_ptr(), n - 7)
+    torch.cuda.synchronize()
+    assert np.abs(d_pose.cpu().numpy() - sharding.rebase(bases, ref)).max() < 1e-12

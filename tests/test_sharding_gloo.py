@@ -21,9 +21,6 @@ def _worker(rank, world, port, n_total, lead, incr_all, ret):
     local = incr_all[lb:oe].copy()
     local[: ob - lb] = 123.0
     poses = sharding.prefix(local, first=ob - lb)
-    # first owned increment composes onto the previous rank: origin row is identity, so re-insert incr[ob]
-    if rank > 0:
-        poses = np.stack([sharding.compose(local[ob - lb], p) for p in poses])
     bases = sharding.gather_bases(torch.from_numpy(poses[-1].copy()))
     glob = sharding.rebase(bases[:rank].numpy(), poses)
     ret[rank] = (ob, oe, glob)
