@@ -77,6 +77,29 @@ int lmono_odom_batch_d(lmono_ctx *, lmono_scan_batch *, int n_chains, int lead, 
 int lmono_odom_correspond(lmono_ctx *, lmono_scan_batch *, int scan, const double q[4], const double t[3],
                           int32_t *corr_h, int cap);
 
+/* ---- lmono BA factors: batched ceres::CostFunction::Evaluate -------------------------------------------- *
+ * Reference interfaces (paths under /root/reference/mono_lidar_mapping), one residual block per index:
+ *   kind 0 LASER   LASERFactor ctor + Evaluate            include/factor/LaserFactor.h:29-100
+ *          params[14] = pose_i, pose_j (x y z qx qy qz qw); consts[24] = L0_Ri, L0_Rj (3x3 row-major), L0_Pi, L0_Pj;
+ *          info[36] = LASERFactor::sqrt_info (Estimator.cc:95); r[6]; J[84] = J_i[6x7], J_j[6x7]
+ *   kind 1 MONO    MonoProjectionFactor::Evaluate          src/factor/MonoProjectionFactor.cc:40-174
+ *          params[22] = ex, pose_i, pose_j, inv_depth; consts[4] = pt_i.xy, pt_j.xy (normalised image points);
+ *          info[4] = MonoProjectionFactor::sqrt_info (Estimator.cc:94); r[2]; J[44] = J_ex, J_i, J_j [2x7 each], J_depth[2]
+ *   kind 2 PRIOR   PriorFactor ctor + Evaluate             include/factor/PriorFactor.h:29-69
+ *          params[7] = ex; consts[16] = 4x4 transform row-major; info[2] = PRIOR_T, PRIOR_R; r[6]; J[42]
+ *   kind 3 REPROJ  ReprojectionFactor ctor + Evaluate      include/factor/ReprojectionFactor.h:16-78
+ *          params[1] = inv_depth; consts[44] = pt_i.xy, pt_j.xy, Ri, Pi, Rj, Pj, EX(4x4); info[1] = FACTOR_WEIGHT; r[2]; J[2]
+ * Jacobians follow the Ceres layout (row-major, global block size, 7th pose column zero) and reproduce the reference's
+ * formulae literally, including their known non-analytic blocks.  J may be NULL (residuals only).   */
+#define LMONO_FACTOR_LASER  0
+#define LMONO_FACTOR_MONO   1
+#define LMONO_FACTOR_PRIOR  2
+#define LMONO_FACTOR_REPROJ 3
+int lmono_factor_eval(lmono_ctx *, int kind, int count, const double *params_h, const double *consts_h,
+                      const double *info_h, double *r_h, double *J_h);
+int lmono_factor_eval_d(lmono_ctx *, int kind, int count, const double *params_d, const double *consts_d,
+                        const double *info_d, double *r_d, double *J_d);
+
 /* ---- pose composition (laserOdometry: t_w_curr += q_w_curr * t_last_curr; q_w_curr *= q_last_curr) ------- *
  * lmono_pose_prefix_d: poses_d[k - first] = incr[first] (+) ... (+) incr[k] for k in [first, n) (incr[0] is the
  * identity: first = 0 gives poses relative to scan 0, first > 0 poses relative to scan first-1).  lmono_pose_rebase_d: poses[k] <- bases[0] (+) ... (+) bases[n_bases-1] (+) poses[k]; with scans

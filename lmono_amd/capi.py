@@ -12,7 +12,7 @@ SYMBOLS = [
     "lmono_create", "lmono_destroy", "lmono_last_error", "lmono_set_stream", "lmono_synchronize", "lmono_version",
     "lmono_batch_create", "lmono_batch_destroy", "lmono_scanreg_batch", "lmono_batch_counts", "lmono_batch_get_cloud",
     "lmono_batch_get_curvature", "lmono_odom_batch", "lmono_odom_batch_d", "lmono_odom_correspond", "lmono_timing_reset", "lmono_timing_read",
-    "lmono_pose_prefix_d", "lmono_pose_rebase_d",
+    "lmono_pose_prefix_d", "lmono_pose_rebase_d", "lmono_factor_eval", "lmono_factor_eval_d",
 ]
 
 
@@ -54,6 +54,8 @@ def load_library():
     L.lmono_odom_batch_d.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.lmono_odom_correspond.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.lmono_timing_reset.argtypes = [C.c_void_p]
+    L.lmono_factor_eval.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
+    L.lmono_factor_eval_d.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
     L.lmono_pose_prefix_d.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.lmono_pose_rebase_d.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     L.lmono_timing_read.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
@@ -92,6 +94,24 @@ class Context:
         self.check(self.L.lmono_timing_read(self.h, ms.ctypes.data, 7, C.byref(nr), C.byref(no)))
         names = ["frontend_total", "odometry_total", "k_ring_sort", "k_curvature", "k_select", "k_compact", "k_grid_build"]
         return dict(zip(names, ms.tolist())), nr.value, no.value
+
+    FACTOR_DIMS = {0: (14, 24, 36, 6, 84), 1: (22, 4, 4, 2, 44), 2: (7, 16, 2, 6, 42), 3: (1, 44, 1, 2, 2)}
+
+    def factor_eval(self, kind, params, consts, info, want_jac=True):
+        """Batched Evaluate of one BA factor kind on the GPU (host arrays in / out)."""
+        npar, ncon, ninf, nres, njac = self.FACTOR_DIMS[kind]
+        params = np.ascontiguousarray(params, np.float64).reshape(-1, npar)
+        consts = np.ascontiguousarray(consts, np.float64).reshape(-1, ncon)
+        info = np.ascontiguousarray(info, np.float64).reshape(ninf)
+        n = len(params)
+        r = np.zeros((n, nres)); J = np.zeros((n, njac)) if want_jac else None
+        self.check(self.L.lmono_factor_eval(self.h, kind, n, params.ctypes.data, consts.ctypes.data, info.ctypes.data,
+                                            r.ctypes.data, J.ctypes.data if want_jac else None))
+        return r, J
+
+    def factor_eval_d(self, kind, count, params_ptr, consts_ptr, info_ptr, r_ptr, J_ptr=None):
+        self.check(self.L.lmono_factor_eval_d(self.h, kind, count, C.c_void_p(params_ptr), C.c_void_p(consts_ptr),
+                                              C.c_void_p(info_ptr), C.c_void_p(r_ptr), C.c_void_p(J_ptr or 0)))
 
     def pose_prefix_d(self, incr_ptr, first, n, poses_ptr):
         self.check(self.L.lmono_pose_prefix_d(self.h, C.c_void_p(incr_ptr), first, n, C.c_void_p(poses_ptr)))

@@ -231,3 +231,28 @@ def ate(poses_a, poses_b):
     """RMS translation difference between two [n,7] pose arrays expressed in the same frame (no alignment)."""
     d = poses_a[:, 4:7] - poses_b[:, 4:7]
     return float(np.sqrt((d ** 2).sum(1).mean()))
+
+
+# --------------------------------------------------------------------------------------------
+# BA factors (oracle/lo_ba.c); packed layouts as in include/lmono_hip.h
+# --------------------------------------------------------------------------------------------
+FACTOR_DIMS = {  # kind: (n_params, n_consts, n_info, n_res, n_jac)
+    0: (14, 24, 36, 6, 84),    # LASER
+    1: (22, 4, 4, 2, 44),      # MONO
+    2: (7, 16, 2, 6, 42),      # PRIOR
+    3: (1, 44, 1, 2, 2),       # REPROJ
+}
+
+
+def factor_eval(kind, params, consts, info, want_jac=True):
+    npar, ncon, ninf, nres, njac = FACTOR_DIMS[kind]
+    params = np.ascontiguousarray(params, np.float64).reshape(-1, npar)
+    consts = np.ascontiguousarray(consts, np.float64).reshape(-1, ncon)
+    info = np.ascontiguousarray(info, np.float64).reshape(ninf)
+    n = len(params)
+    r = np.zeros((n, nres)); J = np.zeros((n, njac)) if want_jac else None
+    rc = lib().lo_factor_eval(C.c_int(kind), C.c_int(n), _fp(params, C.c_double), _fp(consts, C.c_double), _fp(info, C.c_double),
+                              _fp(r, C.c_double), _fp(J, C.c_double) if want_jac else None)
+    if rc != 0:
+        raise RuntimeError("lo_factor_eval failed")
+    return r, J
