@@ -9,6 +9,13 @@ constexpr int kCornerTable = 16384;   // >= 2 * kMaxLessSharp
 constexpr int kSurfTable = 131072;    // surf cloud capacity = kSurfTable / 2 points
 constexpr unsigned long long kEmptyKey = ~0ull;
 
+// one hash-grid slot: 16 B so that a probe is a single dwordx4 load
+struct __attribute__((aligned(16))) GridCell {
+    unsigned long long key;   // packed cell coordinates, kEmptyKey when unused
+    int start;                // first point of the cell in the cell-sorted copy
+    int cnt;                  // points in the cell
+};
+
 struct BatchView {
     // ---- inputs
     const float4 *in;        // [total] raw x y z reflectance
@@ -39,11 +46,16 @@ struct BatchView {
     float4 *flat;            // [n_scans][kMaxFlat]
     float4 *less_flat;       // [total] (scan offsets as input)
     int *feat_n;             // [n_scans][4] sharp, less_sharp, flat, less_flat
+    int *line_first_ge;      // [n_scans][2][66] (less_sharp, less_flat): first index with int(intensity) >= t
+    int *line_last_le;       // [n_scans][2][66] last index with int(intensity) <= t
     // ---- hash grids of less_sharp / less_flat (used as the "last" clouds of the next scan)
-    unsigned long long *cg_key;  int *cg_cnt;  int *cg_start;   // [n_scans][kCornerTable]
-    unsigned long long *sg_key;  int *sg_cnt;  int *sg_start;   // [n_scans][kSurfTable]
+    GridCell *cg_cell;       // [n_scans][kCornerTable]
+    GridCell *sg_cell;       // [n_scans][kSurfTable]
     float4 *cg_pts;          // [n_scans][kMaxLessSharp]  cell-sorted copy, .w = original index bits
     float4 *sg_pts;          // [total]
+    float4 *lbc_pts;         // [n_scans][kMaxLessSharp] less_sharp sorted by (line, azimuth bin), .w = original index bits
+    float4 *lbs_pts;         // [total] same for less_flat
+    int *lb_start;           // [n_scans][2][66*64+1] start of every (line, bin) bucket
     int *grid_mask;          // [n_scans][2] table size - 1 actually used (corner, surf): power of two >= 2 n
     int *sg_slot, *sg_rank;  // [total] scratch: table slot of each surf point / rank inside its cell
     int *cg_slot, *cg_rank;  // [n_scans][kMaxLessSharp] same for corner points

@@ -20,6 +20,8 @@ constexpr int kMaxQueries = kMaxSharp + kMaxFlat;
 // status bits per scan
 constexpr int kStatusRingOverflow = 1;   // a ring holds more than kRingCap points
 constexpr int kStatusGridOverflow = 2;   // a "last" cloud does not fit its hash grid
+constexpr int kStatusWalkOverflow = 8;    // more than 256 features share one scan line (walk truncated)
+constexpr int kStatusIrregularLines = 4; // scan-line ids of a feature cloud too disordered for the windowed walk (array-order walk used)
 
 #define LM_PI 3.14159265358979323846
 #define LM_PI_2 1.57079632679489661923

@@ -411,6 +411,40 @@ __global__ __launch_bounds__(256) void k_select(BatchView b)
     if (tid == 0) b.lf_n[s * 64 + r] = n_out;
 }
 
+// Line tables of a feature cloud (line = int(intensity), what laserOdometry reads as the scan line):
+//   first_ge[t] = first index whose line is >= t, last_le[t] = last index whose line is <= t  (t = 0..65).
+// The odometry walk around a nearest point of line ra visits exactly the index window (last_le[ra-3], first_ge[ra+3])
+// provided no point precedes a point whose line is >= 3 lower ("regular"); irregular clouds are flagged and walked
+// in array order instead.  Lines are not monotone in general: A-LOAM's relTime can be negative (line = ring - 1).
+__device__ __forceinline__ void line_tables(const float4 *pts, int n, int *first_ge, int *last_le, int *status, int tid,
+                                            int *s_first, int *s_last, int *s_flag)
+{
+    if (tid < 66) { s_first[tid] = INT_MAX; s_last[tid] = -1; }
+    if (tid == 0) *s_flag = 0;
+    __syncthreads();
+    for (int j = tid; j < n; j += 256) {
+        int v = (int)pts[j].w;
+        v = v < 0 ? 0 : (v > 65 ? 65 : v);
+        atomicMin(&s_first[v], j);
+        atomicMax(&s_last[v], j);
+    }
+    __syncthreads();
+    // irregular iff some line a >= b + 3 starts before line b ends
+    for (int x = tid; x < 66 * 66; x += 256) {
+        const int a = x / 66, bb = x % 66;
+        if (a >= bb + 3 && s_first[a] < s_last[bb]) *s_flag = 1;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int m = n;
+        for (int t = 65; t >= 0; t--) { m = min(m, s_first[t] == INT_MAX ? n : s_first[t]); first_ge[t] = m; }
+        int M = -1;
+        for (int t = 0; t <= 65; t++) { M = max(M, s_last[t]); last_le[t] = M; }
+        if (*s_flag) atomicOr(status, kStatusIrregularLines);
+    }
+    __syncthreads();
+}
+
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_compact(BatchView b)
 {
@@ -455,6 +489,10 @@ __global__ __launch_bounds__(256) void k_compact(BatchView b)
         b.feat_n[s * 4 + 0] = pre_sh[NE]; b.feat_n[s * 4 + 1] = pre_ls[NE];
         b.feat_n[s * 4 + 2] = pre_fl[NE]; b.feat_n[s * 4 + 3] = pre_lf[kMaxRings];
     }
+    __syncthreads();
+    __shared__ int s_first[66], s_last[66], s_flag;
+    line_tables(ls, pre_ls[NE], b.line_first_ge + (size_t)(s * 2 + 0) * 66, b.line_last_le + (size_t)(s * 2 + 0) * 66, b.status + s, tid, s_first, s_last, &s_flag);
+    line_tables(lf, pre_lf[kMaxRings], b.line_first_ge + (size_t)(s * 2 + 1) * 66, b.line_last_le + (size_t)(s * 2 + 1) * 66, b.status + s, tid, s_first, s_last, &s_flag);
 }
 
 } // namespace lmono

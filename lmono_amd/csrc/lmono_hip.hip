@@ -134,11 +134,11 @@ extern "C" lmono_scan_batch *lmono_batch_create(lmono_ctx *c, int n_cap, int64_t
     ok = ok && dalloc(b, v.lf_tmp, T) && dalloc(b, v.lf_n, N * 64);
     ok = ok && dalloc(b, v.sharp, N * kMaxSharp) && dalloc(b, v.less_sharp, N * kMaxLessSharp);
     ok = ok && dalloc(b, v.flat, N * kMaxFlat) && dalloc(b, v.less_flat, T);
-    ok = ok && dalloc(b, v.feat_n, N * 4);
-    ok = ok && dalloc(b, v.cg_key, N * kCornerTable) && dalloc(b, v.cg_cnt, N * kCornerTable) && dalloc(b, v.cg_start, N * kCornerTable);
-    ok = ok && dalloc(b, v.sg_key, N * kSurfTable) && dalloc(b, v.sg_cnt, N * kSurfTable) && dalloc(b, v.sg_start, N * kSurfTable);
+    ok = ok && dalloc(b, v.feat_n, N * 4) && dalloc(b, v.line_first_ge, N * 2 * 66) && dalloc(b, v.line_last_le, N * 2 * 66);
+    ok = ok && dalloc(b, v.cg_cell, N * kCornerTable) && dalloc(b, v.sg_cell, N * kSurfTable);
     ok = ok && dalloc(b, v.cg_pts, N * kMaxLessSharp) && dalloc(b, v.sg_pts, T) && dalloc(b, v.grid_mask, N * 2);
     ok = ok && dalloc(b, v.sg_slot, T) && dalloc(b, v.sg_rank, T);
+    ok = ok && dalloc(b, v.lbc_pts, N * kMaxLessSharp) && dalloc(b, v.lbs_pts, T) && dalloc(b, v.lb_start, N * 2 * (kLineKeys + 1));
     ok = ok && dalloc(b, v.cg_slot, N * kMaxLessSharp) && dalloc(b, v.cg_rank, N * kMaxLessSharp);
     ok = ok && dalloc(b, b->incr, N * 7) && dalloc(b, b->poses, N * 7) && dalloc(b, b->xq, 8);
     ok = ok && dalloc(b, b->corr_pair, (size_t)kMaxQueries * 4);
@@ -195,6 +195,7 @@ extern "C" int lmono_scanreg_batch(lmono_ctx *c, lmono_scan_batch *b, const floa
     hipLaunchKernelGGL(k_compact, dim3(n_scans), dim3(256), 0, st, v);
     HIP_TRY(c, hipEventRecord(c->ev[4], st));
     hipLaunchKernelGGL(k_grid_build, dim3(n_scans, 2), dim3(1024), 0, st, v);
+    hipLaunchKernelGGL(k_line_index, dim3(n_scans, 2), dim3(256), 0, st, v);
     HIP_TRY(c, hipEventRecord(c->ev[5], st));
     int rc = check_launch(c, "scanreg kernels");
     if (rc) return rc;
@@ -310,7 +311,7 @@ extern "C" int lmono_odom_batch_d(lmono_ctx *c, lmono_scan_batch *b, int n_chain
     int rc = ensure_odom_ws(c, b, n_chains);
     if (rc) return rc;
     OdomView o;
-    o.n_scans = n; o.n_chains = n_chains; o.lead = lead;
+    o.n_scans = n; o.n_chains = n_chains; o.lead = lead; o.fixed_k = -1;
     o.state = b->state; o.corr = b->corr; o.incr = b->incr; o.lm_info = b->lm_info;
     int max_steps = 0;
     for (int ch = 0; ch < n_chains; ch++) {
@@ -364,8 +365,11 @@ extern "C" int lmono_odom_correspond(lmono_ctx *c, lmono_scan_batch *b, int scan
     HIP_TRY(c, hipMemcpy(fn, b->v.feat_n + scan * 4, sizeof(fn), hipMemcpyDeviceToHost));
     const int nq = fn[0] + fn[2];
     if (nq > cap) { c->err = "odom_correspond: output capacity too small"; return LMONO_ECAPACITY; }
-    hipLaunchKernelGGL(k_correspond_pair, dim3(kMaxQueries / 4), dim3(256), 0, c->stream, b->v, scan, (const double *)b->xq, b->corr_pair);
-    int rc = check_launch(c, "k_correspond_pair");
+    OdomView o;
+    o.n_scans = b->n_scans; o.n_chains = 1; o.lead = 0; o.fixed_k = scan;
+    o.state = b->xq; o.corr = b->corr_pair; o.incr = nullptr; o.lm_info = nullptr;
+    hipLaunchKernelGGL(k_correspond, dim3(kMaxQueries / 4, 1), dim3(256), 0, c->stream, b->v, o, 0);
+    int rc = check_launch(c, "k_correspond");
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (nq > 0) HIP_TRY(c, hipMemcpy(corr_h, b->corr_pair, sizeof(int) * 4 * nq, hipMemcpyDeviceToHost));

@@ -4,8 +4,9 @@
 //
 //   k_grid_build  one workgroup per (scan, cloud): 1 m hash grid over less_sharp / less_flat (the "last" clouds
 //                 of the next scan).  Exact 1-NN needs only neighbours closer than 5 m (DISTANCE_SQ_THRESHOLD).
-//   k_correspond  one wave per feature point: de-skew transform (fp64), exact 1-NN by growing cell shells,
-//                 ring walk for the 2nd (and 3rd) point as coalesced sweeps over ring ranges
+//   k_line_index  one workgroup per (scan, cloud): copy of the cloud counting-sorted by (scan line, azimuth bin)
+//   k_correspond  one wave per feature point: de-skew transform (fp64), exact 1-NN by growing cell shells, then the
+//                 reference's scan-line walk restricted to the lines ra-2..ra+2 and the azimuth arc within 5 m
 //   k_lm_solve    one wave per chain: <= 4 Levenberg-Marquardt iterations restating Ceres' trust-region loop,
 //                 closed-form edge/plane Jacobians, wave-shuffle reduction into the 6x6 normal equations (fp64)
 //   k_pose_prefix sequential pose accumulation
@@ -31,9 +32,7 @@ __device__ __forceinline__ unsigned int hash_key(unsigned long long k)
 }
 
 struct GridRef {
-    const unsigned long long *key;
-    const int *cnt;
-    const int *start;
+    const GridCell *cell;
     const float4 *pts;
     int mask;
 };
@@ -52,14 +51,12 @@ __global__ __launch_bounds__(1024) void k_grid_build(BatchView b)
     if (overflow) T = 1024;
     const int mask = T - 1;
     if (tid == 0) b.grid_mask[s * 2 + (surf ? 1 : 0)] = mask;
-    unsigned long long *key = surf ? b.sg_key + (size_t)s * kSurfTable : b.cg_key + (size_t)s * kCornerTable;
-    int *cnt = surf ? b.sg_cnt + (size_t)s * kSurfTable : b.cg_cnt + (size_t)s * kCornerTable;
-    int *start = surf ? b.sg_start + (size_t)s * kSurfTable : b.cg_start + (size_t)s * kCornerTable;
+    GridCell *cell = surf ? b.sg_cell + (size_t)s * kSurfTable : b.cg_cell + (size_t)s * kCornerTable;
     const float4 *src = surf ? b.less_flat + b.off[s] : b.less_sharp + (size_t)s * kMaxLessSharp;
     float4 *dst = surf ? b.sg_pts + b.off[s] : b.cg_pts + (size_t)s * kMaxLessSharp;
     int *slot_of = surf ? b.sg_slot + b.off[s] : b.cg_slot + (size_t)s * kMaxLessSharp;
     int *rank_of = surf ? b.sg_rank + b.off[s] : b.cg_rank + (size_t)s * kMaxLessSharp;
-    for (int i = tid; i < T; i += 1024) { key[i] = kEmptyKey; cnt[i] = 0; }
+    for (int i = tid; i < T; i += 1024) { GridCell e; e.key = kEmptyKey; e.start = 0; e.cnt = 0; cell[i] = e; }
     if (overflow) {
         if (tid == 0) atomicOr(&b.status[s], kStatusGridOverflow);
         return;   // table stays empty: no correspondences for the next scan, flagged in status
@@ -71,19 +68,19 @@ __global__ __launch_bounds__(1024) void k_grid_build(BatchView b)
         const unsigned long long k = cell_key((int)floorf(p.x * kInvCell), (int)floorf(p.y * kInvCell), (int)floorf(p.z * kInvCell));
         unsigned int sl = hash_key(k) & mask;
         while (true) {
-            const unsigned long long old = atomicCAS(&key[sl], kEmptyKey, k);
+            const unsigned long long old = atomicCAS(&cell[sl].key, kEmptyKey, k);
             if (old == kEmptyKey || old == k) break;
             sl = (sl + 1) & mask;
         }
         slot_of[i] = (int)sl;
-        rank_of[i] = atomicAdd(&cnt[sl], 1);
+        rank_of[i] = atomicAdd(&cell[sl].cnt, 1);
     }
     __syncthreads();
     // exclusive prefix over the table counts (read with agent-scope atomic loads: the counts were produced by atomics)
     __shared__ int s_part[1024];
     const int chunk = T / 1024;
     int local = 0;
-    for (int i = 0; i < chunk; i++) local += __hip_atomic_load(&cnt[tid * chunk + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = 0; i < chunk; i++) local += __hip_atomic_load(&cell[tid * chunk + i].cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_part[tid] = local;
     __syncthreads();
     // Hillis-Steele inclusive scan over 1024 partials
@@ -95,20 +92,21 @@ __global__ __launch_bounds__(1024) void k_grid_build(BatchView b)
     }
     int run = s_part[tid] - local;
     for (int i = 0; i < chunk; i++) {
-        const int c = __hip_atomic_load(&cnt[tid * chunk + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        start[tid * chunk + i] = run;
+        const int c = __hip_atomic_load(&cell[tid * chunk + i].cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cell[tid * chunk + i].start = run;
         run += c;
     }
     __syncthreads();
     for (int i = tid; i < n; i += 1024) {
         const float4 p = src[i];
-        dst[start[slot_of[i]] + rank_of[i]] = make_float4(p.x, p.y, p.z, __int_as_float(i));
+        dst[cell[slot_of[i]].start + rank_of[i]] = make_float4(p.x, p.y, p.z, __int_as_float(i));
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 struct OdomView {
     int n_scans, n_chains, lead;
+    int fixed_k;          // >= 0: single-pair debug view, every chain works on this scan
     double *state;        // [n_chains][8]  q(xyzw), t, pad
     int *corr;            // [n_chains][kMaxQueries][4]
     double *incr;         // [n_scans][7]
@@ -140,24 +138,34 @@ __device__ __forceinline__ unsigned long long wave_nn(const GridRef &g, float qx
     unsigned long long best = ~0ull;
     for (int sh = 1; sh <= kMaxShell; sh++) {
         const int side = 2 * sh + 1, ncell = side * side * side;
-        for (int ci = lane; ci < ncell; ci += 64) {
-            const int dx = ci % side - sh, dy = (ci / side) % side - sh, dz = ci / (side * side) - sh;
-            if (sh > 1 && max(max(abs(dx), abs(dy)), abs(dz)) < sh) continue;
-            const unsigned long long k = cell_key(cqx + dx, cqy + dy, cqz + dz);
-            unsigned int sl = hash_key(k) & g.mask;
-            int found = -1;
-            while (true) {
-                const unsigned long long t = g.key[sl];
-                if (t == k) { found = (int)sl; break; }
-                if (t == kEmptyKey) break;
-                sl = (sl + 1) & g.mask;
+        for (int base = 0; base < ncell; base += 64) {
+            // every lane probes one cell of the shell (one 16-B load per probe step) ...
+            const int ci = base + lane;
+            int st = 0, cn = 0;
+            if (ci < ncell) {
+                const int dx = ci % side - sh, dy = (ci / side) % side - sh, dz = ci / (side * side) - sh;
+                if (sh == 1 || max(max(abs(dx), abs(dy)), abs(dz)) == sh) {
+                    const unsigned long long k = cell_key(cqx + dx, cqy + dy, cqz + dz);
+                    unsigned int sl = hash_key(k) & g.mask;
+                    while (true) {
+                        const GridCell e = g.cell[sl];
+                        if (e.key == k) { st = e.start; cn = e.cnt; break; }
+                        if (e.key == kEmptyKey) break;
+                        sl = (sl + 1) & g.mask;
+                    }
+                }
             }
-            if (found < 0) continue;
-            const int st = g.start[found], cn = g.cnt[found];
-            for (int i = 0; i < cn; i++) {
-                const float4 p = g.pts[st + i];
-                const unsigned long long cand = pack_fu(dist2f(p.x, p.y, p.z, qx, qy, qz), (unsigned int)__float_as_int(p.w));
-                best = cand < best ? cand : best;
+            // ... then the whole wave sweeps each non-empty cell's contiguous point run
+            unsigned long long m = __ballot(cn > 0);
+            while (m) {
+                const int src = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const int s0 = __shfl(st, src), n0 = __shfl(cn, src);
+                for (int i = lane; i < n0; i += 64) {
+                    const float4 p = g.pts[s0 + i];
+                    const unsigned long long cand = pack_fu(dist2f(p.x, p.y, p.z, qx, qy, qz), (unsigned int)__float_as_int(p.w));
+                    best = cand < best ? cand : best;
+                }
             }
         }
         best = wave_min_u64(best);
@@ -233,12 +241,10 @@ __device__ __forceinline__ int4 correspond_one(const BatchView &b, int k, int qi
     const float4 *cloud;
     int n_last;
     if (edge) {
-        g.key = b.cg_key + (size_t)l * kCornerTable; g.cnt = b.cg_cnt + (size_t)l * kCornerTable;
-        g.start = b.cg_start + (size_t)l * kCornerTable; g.pts = b.cg_pts + (size_t)l * kMaxLessSharp; g.mask = b.grid_mask[l * 2 + 0];
+        g.cell = b.cg_cell + (size_t)l * kCornerTable; g.pts = b.cg_pts + (size_t)l * kMaxLessSharp; g.mask = b.grid_mask[l * 2 + 0];
         cloud = b.less_sharp + (size_t)l * kMaxLessSharp; n_last = b.feat_n[l * 4 + 1];
     } else {
-        g.key = b.sg_key + (size_t)l * kSurfTable; g.cnt = b.sg_cnt + (size_t)l * kSurfTable;
-        g.start = b.sg_start + (size_t)l * kSurfTable; g.pts = b.sg_pts + b.off[l]; g.mask = b.grid_mask[l * 2 + 1];
+        g.cell = b.sg_cell + (size_t)l * kSurfTable; g.pts = b.sg_pts + b.off[l]; g.mask = b.grid_mask[l * 2 + 1];
         cloud = b.less_flat + b.off[l]; n_last = b.feat_n[l * 4 + 3];
     }
     int4 out = make_int4(-1, -1, -1, 0);
@@ -262,32 +268,193 @@ __device__ __forceinline__ int4 correspond_one(const BatchView &b, int k, int qi
     return out;
 }
 
-// step t of every chain: chain c works on scan k = begin_c + 1 + t
+// which scan does chain c work on at this step (-1: chain finished)
+__device__ __forceinline__ int chain_scan(const OdomView &o, int c, int step, int &own_begin)
+{
+    if (o.fixed_k >= 0) { own_begin = 0; return o.fixed_k; }
+    int s, e;
+    chain_bounds(o.n_scans, o.n_chains, c, s, e);
+    own_begin = s;
+    const int begin = max(s - o.lead, 0);
+    const int k = begin + 1 + step;
+    return k < e ? k : -1;
+}
+
+// ---- (line, azimuth-bin) index of a feature cloud -------------------------------------------------------------
+// The reference's scan-line walk only ever accepts candidates closer than 5 m to the (transformed) feature point, i.e.
+// within +-asin(5 / rho_xy) of its azimuth, and only on lines ra-2 .. ra+2.  k_line_index sorts a copy of every "last"
+// cloud by (line, azimuth bin) once per scan (counting sort in LDS), so that the walk of a feature is a handful of
+// short coalesced sweeps instead of a pass over five whole scan lines.
+constexpr int kAzBins = 64;
+constexpr int kLineKeys = 66 * kAzBins;
+
+__device__ __forceinline__ int az_bin(float x, float y)
+{
+    const float t = (atan2f(y, x) + 3.14159265f) * (kAzBins / 6.28318531f);
+    const int bi = (int)t;
+    return bi < 0 ? 0 : (bi >= kAzBins ? kAzBins - 1 : bi);
+}
+__device__ __forceinline__ int line_of(float w)
+{
+    const int v = (int)w;
+    return v < 0 ? 0 : (v > 65 ? 65 : v);
+}
+
+__global__ __launch_bounds__(256) void k_line_index(BatchView b)
+{
+    const int s = blockIdx.x;
+    const bool surf = blockIdx.y == 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = b.feat_n[s * 4 + (surf ? 3 : 1)];
+    const float4 *src = surf ? b.less_flat + b.off[s] : b.less_sharp + (size_t)s * kMaxLessSharp;
+    float4 *dst = surf ? b.lbs_pts + b.off[s] : b.lbc_pts + (size_t)s * kMaxLessSharp;
+    int *table = b.lb_start + (size_t)(s * 2 + (surf ? 1 : 0)) * (kLineKeys + 1);
+    __shared__ int s_cnt[kLineKeys], s_fill[kLineKeys], s_wsum[4];
+    for (int i = tid; i < kLineKeys; i += 256) { s_cnt[i] = 0; s_fill[i] = 0; }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const float4 p = src[i];
+        atomicAdd(&s_cnt[line_of(p.w) * kAzBins + az_bin(p.x, p.y)], 1);
+    }
+    __syncthreads();
+    // exclusive prefix over kLineKeys = 4224 counters: 17 per thread (last thread padded)
+    constexpr int kPer = (kLineKeys + 255) / 256;
+    int local = 0;
+    for (int i = 0; i < kPer; i++) { const int idx = tid * kPer + i; if (idx < kLineKeys) local += s_cnt[idx]; }
+    const int incl = wave_scan_incl(local);
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    int run = incl - local;
+    for (int w = 0; w < wave; w++) run += s_wsum[w];
+    for (int i = 0; i < kPer; i++) {
+        const int idx = tid * kPer + i;
+        if (idx < kLineKeys) { const int cnt = s_cnt[idx]; s_cnt[idx] = run; table[idx] = run; run += cnt; }
+    }
+    if (tid == 255) table[kLineKeys] = n;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const float4 p = src[i];
+        const int key = line_of(p.w) * kAzBins + az_bin(p.x, p.y);
+        const int d = s_cnt[key] + atomicAdd(&s_fill[key], 1);
+        dst[d] = make_float4(p.x, p.y, p.z, __int_as_float(i));
+    }
+}
+
+struct WalkBest { float d; unsigned int seq; };
+__device__ __forceinline__ void walk_update(WalkBest &bst, float d, unsigned int seq)
+{
+    const bool better = d < bst.d || (d == bst.d && seq < bst.seq);
+    bst.d = better ? d : bst.d;
+    bst.seq = better ? seq : bst.seq;
+}
+
+// Correspondence of one feature point: exact NN, then the scan-line walk over the (line, azimuth) index.
+__device__ __forceinline__ int4 correspond_indexed(const BatchView &b, int k, int qi, const double *x, int lane)
+{
+    const int n_sharp = b.feat_n[k * 4 + 0];
+    const bool edge = qi < n_sharp;
+    const float4 p = edge ? b.sharp[(size_t)k * kMaxSharp + qi] : b.flat[(size_t)k * kMaxFlat + (qi - n_sharp)];
+    double rx, ry, rz;
+    quat_rotate(x, (double)p.x, (double)p.y, (double)p.z, rx, ry, rz);
+    const float qx = (float)(rx + x[4]), qy = (float)(ry + x[5]), qz = (float)(rz + x[6]);
+    const int l = k - 1;
+    GridRef g;
+    const float4 *cloud, *lb_pts;
+    int n_last;
+    if (edge) {
+        g.cell = b.cg_cell + (size_t)l * kCornerTable; g.pts = b.cg_pts + (size_t)l * kMaxLessSharp; g.mask = b.grid_mask[l * 2 + 0];
+        cloud = b.less_sharp + (size_t)l * kMaxLessSharp; n_last = b.feat_n[l * 4 + 1];
+        lb_pts = b.lbc_pts + (size_t)l * kMaxLessSharp;
+    } else {
+        g.cell = b.sg_cell + (size_t)l * kSurfTable; g.pts = b.sg_pts + b.off[l]; g.mask = b.grid_mask[l * 2 + 1];
+        cloud = b.less_flat + b.off[l]; n_last = b.feat_n[l * 4 + 3];
+        lb_pts = b.lbs_pts + b.off[l];
+    }
+    int4 out = make_int4(-1, -1, -1, 0);
+    if (n_last == 0) return out;
+    const unsigned long long nn = wave_nn(g, qx, qy, qz, lane);
+    if (nn == ~0ull || !((double)__uint_as_float((unsigned int)(nn >> 32)) < 25.0)) return out;
+    const int closest = (int)(unsigned int)(nn & 0xffffffffull);
+    const int ra = line_of(cloud[closest].w);
+    const int cl = edge ? 0 : 1;
+    const int *fge = b.line_first_ge + (size_t)(l * 2 + cl) * 66;
+    const int *lle = b.line_last_le + (size_t)(l * 2 + cl) * 66;
+    const int *table = b.lb_start + (size_t)(l * 2 + cl) * (kLineKeys + 1);
+    const int w_lo = ra - 3 >= 0 ? lle[ra - 3] + 1 : 0;      // index window the reference loops can reach
+    const int w_hi = ra + 3 <= 65 ? fge[ra + 3] : n_last;
+    // arc of azimuth bins that can hold a point within 5 m of the query
+    const float rho = sqrtf(qx * qx + qy * qy);
+    int b_lo = 0, nb = kAzBins;
+    if (rho > 5.01f) {
+        const float alpha = asin_upper(5.0f / rho) + 1.5f * (6.28318531f / kAzBins);
+        const float th = atan2f(qy, qx) + 3.14159265f;
+        const int lo = (int)floorf((th - alpha) * (kAzBins / 6.28318531f));
+        const int hi = (int)floorf((th + alpha) * (kAzBins / 6.28318531f));
+        if (hi - lo + 1 < kAzBins) { b_lo = ((lo % kAzBins) + kAzBins) % kAzBins; nb = hi - lo + 1; }
+    }
+    const int b_end = b_lo + nb;
+    WalkBest bs = { 25.0f, 0u }, bo = { 25.0f, 0u };
+    // lanes 0..4 fetch the bucket bounds of lines ra-2..ra+2 (two runs when the arc wraps past bin 63)
+    int t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    {
+        const int v = ra - 2 + lane;
+        if (lane < 5 && v >= 0 && v <= 65 && !(edge && v == ra)) {
+            const int *row = table + v * kAzBins;
+            t0 = row[b_lo]; t1 = row[min(b_end, kAzBins)];
+            if (b_end > kAzBins) { t2 = row[0]; t3 = row[b_end - kAzBins]; }
+        }
+    }
+    for (int vi = 0; vi < 5; vi++) {
+        const int v = ra - 2 + vi;
+        for (int part = 0; part < 2; part++) {
+            const int r0 = __shfl(part ? t2 : t0, vi), r1 = __shfl(part ? t3 : t1, vi);
+            for (int i = r0 + lane; i < r1; i += 64) {
+                const float4 c = lb_pts[i];
+                const int j = __float_as_int(c.w);
+                if (j == closest || j < w_lo || j >= w_hi) continue;
+                const bool fwd = j > closest;
+                const unsigned int seq = fwd ? (unsigned int)(j - closest - 1) : kSeqBack + (unsigned int)(closest - 1 - j);
+                const float d = dist2f(c.x, c.y, c.z, qx, qy, qz);
+                const bool is_other = fwd ? (v > ra) : (v < ra);
+                if (is_other) walk_update(bo, d, seq);
+                else if (!edge) walk_update(bs, d, seq);
+            }
+        }
+    }
+    const unsigned long long thr = pack_fu(25.0f, 0u);
+    unsigned long long same = bs.d < 25.0f ? pack_fu(bs.d, bs.seq) : thr;
+    unsigned long long other = bo.d < 25.0f ? pack_fu(bo.d, bo.seq) : thr;
+    same = wave_min_u64(same); other = wave_min_u64(other);
+    const int i_other = other < thr ? seq_to_index((unsigned int)(other & 0xffffffffull), closest) : -1;
+    if (edge) {
+        if (i_other >= 0) out = make_int4(closest, i_other, -1, 1);
+        return out;
+    }
+    const int i_same = same < thr ? seq_to_index((unsigned int)(same & 0xffffffffull), closest) : -1;
+    if (i_same >= 0 && i_other >= 0) out = make_int4(closest, i_same, i_other, 2);
+    return out;
+}
+
+// asin(x) <= x (1 + 0.5708 x^2) on [0, 1] (equality at 0 and 1): conservative arc half-width without libm
+__device__ __forceinline__ float asin_upper(float x) { return x * (1.0f + 0.5708f * x * x); }
+
+// step t of every chain: one wave per feature point of the chain's current scan.
+// (A thread-per-feature variant was measured 2.9x slower: its dependent global loads leave no memory-level
+// parallelism at ~1 wave per SIMD; see profiles/r1/NOTES.md.)
 __global__ __launch_bounds__(256) void k_correspond(BatchView b, OdomView o, int step)
 {
     const int c = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
-    int s, e;
-    chain_bounds(o.n_scans, o.n_chains, c, s, e);
-    const int begin = max(s - o.lead, 0);
-    const int k = begin + 1 + step;
-    if (k >= e) return;
+    int own;
+    const int k = chain_scan(o, c, step, own);
+    if (k < 0) return;
     const int nq = b.feat_n[k * 4 + 0] + b.feat_n[k * 4 + 2];
     if (qi >= nq) return;
-    const int4 r = correspond_one(b, k, qi, o.state + c * 8, lane);
+    const double *x = o.state + c * 8;
+    const int4 r = (b.status[k - 1] & kStatusIrregularLines) ? correspond_one(b, k, qi, x, lane)
+                                                            : correspond_indexed(b, k, qi, x, lane);
     if (lane == 0) ((int4 *)o.corr)[(size_t)c * kMaxQueries + qi] = r;
-}
-
-// single-pair variant used by lmono_odom_correspond (parity/debug view)
-__global__ __launch_bounds__(256) void k_correspond_pair(BatchView b, int k, const double *x, int *corr)
-{
-    const int lane = threadIdx.x & 63;
-    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int nq = b.feat_n[k * 4 + 0] + b.feat_n[k * 4 + 2];
-    if (qi >= nq) return;
-    const int4 r = correspond_one(b, k, qi, x, lane);
-    if (lane == 0) ((int4 *)corr)[qi] = r;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -482,11 +649,9 @@ __global__ __launch_bounds__(256) void k_lm_solve(BatchView b, OdomView o, int s
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (c >= o.n_chains) return;
-    int s, e;
-    chain_bounds(o.n_scans, o.n_chains, c, s, e);
-    const int begin = max(s - o.lead, 0);
-    const int k = begin + 1 + step;
-    if (k >= e) return;
+    int s;
+    const int k = chain_scan(o, c, step, s);
+    if (k < 0) return;
     const int nq = b.feat_n[k * 4 + 0] + b.feat_n[k * 4 + 2];
     const int4 *corr = (const int4 *)o.corr + (size_t)c * kMaxQueries;
     double x[7];
