@@ -340,6 +340,9 @@ __global__ __launch_bounds__(256) void k_line_index(BatchView b)
     }
 }
 
+// asin(x) <= x (1 + 0.5708 x^2) on [0, 1] (equality at 0 and 1): conservative arc half-width without libm
+__device__ __forceinline__ float asin_upper(float x) { return x * (1.0f + 0.5708f * x * x); }
+
 struct WalkBest { float d; unsigned int seq; };
 __device__ __forceinline__ void walk_update(WalkBest &bst, float d, unsigned int seq)
 {
@@ -434,9 +437,6 @@ __device__ __forceinline__ int4 correspond_indexed(const BatchView &b, int k, in
     if (i_same >= 0 && i_other >= 0) out = make_int4(closest, i_same, i_other, 2);
     return out;
 }
-
-// asin(x) <= x (1 + 0.5708 x^2) on [0, 1] (equality at 0 and 1): conservative arc half-width without libm
-__device__ __forceinline__ float asin_upper(float x) { return x * (1.0f + 0.5708f * x * x); }
 
 // step t of every chain: one wave per feature point of the chain's current scan.
 // (A thread-per-feature variant was measured 2.9x slower: its dependent global loads leave no memory-level
