@@ -4,8 +4,9 @@
 // Four kernels per batch of scans, every one a coalesced sweep over HBM-resident SoA/float4 pools:
 //   k_ring_sort  one workgroup per scan: filter, ring id, azimuth, stable counting sort into ring-major order
 //   k_curvature  one workgroup per 1024-point tile: LDS tile with +-5 halo, curvature and neighbour-gap flags
-//   k_select     one workgroup per (scan, ring): per-sector bitonic sort in LDS, wave-parallel edge/planar
-//                selection with neighbour suppression, voxel-grid down-sampling of the less-flat points
+//   k_select     one wave per (scan, ring): per-sector edge/planar selection as repeated 64-lane arg-max/arg-min
+//                over register-resident (curvature, index) keys with neighbour suppression (no sort needed)
+//   k_voxel      one workgroup per (scan, ring): voxel-grid down-sampling of the less-flat points (LDS bitonic sort)
 //   k_compact    one workgroup per scan: prefix sums over (ring, sector) and compaction of the four clouds
 // Arithmetic is float/double exactly as the CPU restatement evaluates it (compiled with -ffp-contract=off).
 #include "batch.hpp"
@@ -194,32 +195,43 @@ __global__ __launch_bounds__(256) void k_curvature(BatchView b)
 }
 
 // ------------------------------------------------------------------------------------------------
-// neighbour suppression after a pick at ring-local index pind: lanes 0..4 walk forward, lanes 5..9 backward,
-// each direction stops at the first gap whose squared length exceeds 0.05
-__device__ __forceinline__ void mark_neighbours(volatile unsigned char *picked, const unsigned char *gap, int pind, int lane)
+// k_select: one WAVE per (scan, ring); 4 rings per 256-thread workgroup, no workgroup barriers.
+// The reference sorts every sector by curvature and walks the sorted order taking the next un-suppressed point
+// (<= 20 largest with c > 0.1, then <= 4 smallest with c < 0.1).  Walking a sorted order and repeatedly taking the
+// extremum of the not-yet-suppressed points visit the same points in the same order, so no sort is needed: each lane
+// keeps its sector elements (curvature, suppressed flag) in registers and a pick is one 64-lane arg-max / arg-min
+// over the packed key (curvature bits, index), which also reproduces the (curvature, index) tie order of the sort.
+constexpr int kSelMaxPerLane = (kRingCap / 6 + 1 + 63) / 64;   // 11 elements per lane for the largest legal sector
+constexpr int kSelWaveLds = 3 * kRingCap;                      // picked, label, gap bytes of one ring
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 {
-    const bool fwd = lane < 5;
-    const bool active = lane < 10;
-    const int l = fwd ? lane + 1 : lane - 4;            // 1..5
-    const int gi = fwd ? pind + l - 1 : pind - l;        // gap between the two consecutive points of step l
-    const bool brk = active ? (gap[gi] != 0) : false;
-    const unsigned long long mb = __ballot(brk);
-    const unsigned int mf = (unsigned int)(mb & 0x1full), mbk = (unsigned int)((mb >> 5) & 0x1full);
-    const int lim_f = mf ? (__ffs((int)mf) - 1) : 5;
-    const int lim_b = mbk ? (__ffs((int)mbk) - 1) : 5;
-    if (active) {
-        const int li = fwd ? lane : lane - 5;
-        if (li < (fwd ? lim_f : lim_b)) picked[fwd ? pind + l : pind - l] = 1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long w = __shfl_xor(v, o);
+        v = w > v ? w : v;
     }
+    return v;
 }
 
-constexpr int kSelKeysBytes = kRingCap * 8;
-constexpr int kSelLds = kSelKeysBytes + kRingCap * 4 + kRingCap * 3 + 1024;
+// after a pick at ring-local index pind: how far the suppression reaches forward / backward (0..5); lanes 0..4 look
+// at the forward gaps, lanes 5..9 at the backward gaps, and the first gap whose squared length exceeds 0.05 stops it
+__device__ __forceinline__ void suppression_reach(const unsigned char *gap, int pind, int lane, int &lf, int &lb)
+{
+    const bool fwd = lane < 5;
+    const int l = fwd ? lane + 1 : lane - 4;
+    const int gi = fwd ? pind + l - 1 : pind - l;
+    const bool brk = lane < 10 ? (gap[gi] != 0) : false;
+    const unsigned long long mb = __ballot(brk);
+    const unsigned int mf = (unsigned int)(mb & 0x1full), mbk = (unsigned int)((mb >> 5) & 0x1full);
+    lf = mf ? (__ffs((int)mf) - 1) : 5;
+    lb = mbk ? (__ffs((int)mbk) - 1) : 5;
+}
 
 __global__ __launch_bounds__(256) void k_select(BatchView b)
 {
-    const int r = blockIdx.x, s = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wave, s = blockIdx.y;
     const int64_t off = b.off[s];
     const int *rb = b.ring_begin + s * 65;
     const int rbeg = rb[r], rend = rb[r + 1], len = rend - rbeg;
@@ -229,100 +241,113 @@ __global__ __launch_bounds__(256) void k_select(BatchView b)
     int *sel_fl = b.sel_flat + (size_t)((s * 64 + r) * kSectors) * 4;
     int *sel_fl_n = b.sel_flat_n + (s * 64 + r) * kSectors;
     if (E - S < 6 || len > kRingCap) {
-        if (tid < kSectors) { sel_sh_n[tid] = 0; sel_fl_n[tid] = 0; }
-        if (tid == 0) {
-            b.lf_n[s * 64 + r] = 0;
-            if (len > kRingCap) atomicOr(&b.status[s], kStatusRingOverflow);
-        }
-        for (int i = tid; i < len; i += 256) b.label[off + rbeg + i] = 0;
+        if (lane < kSectors) { sel_sh_n[lane] = 0; sel_fl_n[lane] = 0; }
+        if (lane == 0 && len > kRingCap) atomicOr(&b.status[s], kStatusRingOverflow);
+        for (int i = lane; i < len; i += 64) b.label[off + rbeg + i] = 0;
         return;
     }
     extern __shared__ __align__(16) unsigned char smem[];
-    unsigned long long *keys = (unsigned long long *)smem;
-    float *curv = (float *)(smem + kSelKeysBytes);
-    unsigned char *picked = smem + kSelKeysBytes + kRingCap * 4;
+    unsigned char *picked = smem + wave * kSelWaveLds;
     signed char *label = (signed char *)(picked + kRingCap);
     unsigned char *gap = picked + 2 * kRingCap;
-    int *scr = (int *)(picked + 3 * kRingCap);   // 256 ints
-    volatile unsigned char *vpicked = picked;
-
-    for (int i = tid; i < len; i += 256) {
-        curv[i] = b.curv[off + rbeg + i];
-        gap[i] = b.gap[off + rbeg + i];
-        picked[i] = 0;
-        label[i] = 0;
-    }
-    __syncthreads();
+    const float *curv = b.curv + off + rbeg;
+    for (int i = lane; i < len; i += 64) { picked[i] = 0; label[i] = 0; gap[i] = b.gap[off + rbeg + i]; }
 
     const int span = E - S;
     for (int j = 0; j < kSectors; j++) {
         const int sp = 5 + span * j / 6;
         const int ep = 5 + span * (j + 1) / 6 - 1;
         const int slen = ep - sp + 1;
-        int np2 = next_pow2(slen);
-        if (np2 < 2) np2 = 2;
-        for (int i = tid; i < np2; i += 256)
-            keys[i] = (i < slen) ? pack_fu(curv[sp + i], (unsigned int)(sp + i)) : ~0ull;
-        __syncthreads();
-        bitonic_sort_u64(keys, np2);
-        if (wave == 0) {
-            // ---- largest curvature first: <= 2 sharp, <= 20 less sharp
-            int largest = 0;
-            bool stop = false;
-            for (int base = slen - 1; base >= 0 && !stop; base -= 64) {
-                const int pos = base - lane;
-                int ind = 0;
-                float c = 0.f;
-                if (pos >= 0) { ind = (int)(keys[pos] & 0xffffffffull); c = curv[ind]; }
-                const bool big = pos >= 0 && (double)c > 0.1;
-                if (!__ballot(big)) break;
-                while (true) {
-                    const bool cand = big && vpicked[ind] == 0;
-                    const unsigned long long m = __ballot(cand);
-                    if (!m) break;
-                    const int src = __ffsll((long long)m) - 1;
-                    const int pind = __shfl(ind, src);
-                    largest++;
-                    if (largest > 20) { stop = true; break; }
-                    if (lane == 0) {
-                        sel_sh[j * 20 + largest - 1] = rbeg + pind;
-                        label[pind] = largest <= 2 ? 2 : 1;
-                        vpicked[pind] = 1;
-                    }
-                    mark_neighbours(vpicked, gap, pind, lane);
-                }
-            }
-            if (lane == 0) sel_sh_n[j] = largest > 20 ? 20 : largest;
-            // ---- smallest curvature first: <= 4 flat
-            int smallest = 0;
-            stop = false;
-            for (int base = 0; base < slen && !stop; base += 64) {
-                const int pos = base + lane;
-                int ind = 0;
-                float c = 1.f;
-                if (pos < slen) { ind = (int)(keys[pos] & 0xffffffffull); c = curv[ind]; }
-                const bool small = pos < slen && (double)c < 0.1;
-                if (!__ballot(small)) break;
-                while (true) {
-                    const bool cand = small && vpicked[ind] == 0;
-                    const unsigned long long m = __ballot(cand);
-                    if (!m) break;
-                    const int src = __ffsll((long long)m) - 1;
-                    const int pind = __shfl(ind, src);
-                    if (lane == 0) { label[pind] = -1; sel_fl[j * 4 + smallest] = rbeg + pind; }
-                    smallest++;
-                    if (smallest >= 4) { stop = true; break; }
-                    if (lane == 0) vpicked[pind] = 1;
-                    mark_neighbours(vpicked, gap, pind, lane);
-                }
-            }
-            if (lane == 0) sel_fl_n[j] = smallest;
+        // register-resident sector: element m of this lane is ring-local index sp + lane + 64 m
+        float c[kSelMaxPerLane];
+        unsigned int dead = 0;     // bit m: element suppressed (picked) or out of range
+#pragma unroll
+        for (int m = 0; m < kSelMaxPerLane; m++) {
+            const int e = lane + 64 * m;
+            c[m] = 0.f;
+            if (e < slen) { c[m] = curv[sp + e]; if (picked[sp + e]) dead |= 1u << m; }
+            else dead |= 1u << m;
         }
-        __syncthreads();
+        // ---- largest curvature first
+        int largest = 0;
+        while (true) {
+            unsigned long long key = 0ull;
+#pragma unroll
+            for (int m = 0; m < kSelMaxPerLane; m++) {
+                if (!((dead >> m) & 1u) && (double)c[m] > 0.1) {
+                    const unsigned long long kk = pack_fu(c[m], (unsigned int)(sp + lane + 64 * m));
+                    key = kk > key ? kk : key;
+                }
+            }
+            key = wave_max_u64(key);
+            if (key == 0ull) break;
+            const int pind = (int)(unsigned int)(key & 0xffffffffull);
+            largest++;
+            if (largest > 20) break;
+            if (lane == 0) { sel_sh[j * 20 + largest - 1] = rbeg + pind; label[pind] = largest <= 2 ? 2 : 1; }
+            int lf, lb;
+            suppression_reach(gap, pind, lane, lf, lb);
+            if (lane <= lf + lb) picked[pind - lb + lane] = 1;
+#pragma unroll
+            for (int m = 0; m < kSelMaxPerLane; m++) {
+                const int idx = sp + lane + 64 * m;
+                if (idx >= pind - lb && idx <= pind + lf) dead |= 1u << m;
+            }
+        }
+        if (lane == 0) sel_sh_n[j] = largest > 20 ? 20 : largest;
+        // ---- smallest curvature first
+        int smallest = 0;
+        while (true) {
+            unsigned long long key = ~0ull;
+#pragma unroll
+            for (int m = 0; m < kSelMaxPerLane; m++) {
+                if (!((dead >> m) & 1u) && (double)c[m] < 0.1) {
+                    const unsigned long long kk = pack_fu(c[m], (unsigned int)(sp + lane + 64 * m));
+                    key = kk < key ? kk : key;
+                }
+            }
+            key = wave_min_u64(key);
+            if (key == ~0ull) break;
+            const int pind = (int)(unsigned int)(key & 0xffffffffull);
+            if (lane == 0) { label[pind] = -1; sel_fl[j * 4 + smallest] = rbeg + pind; }
+            smallest++;
+            if (smallest >= 4) break;
+            int lf, lb;
+            suppression_reach(gap, pind, lane, lf, lb);
+            if (lane <= lf + lb) picked[pind - lb + lane] = 1;
+#pragma unroll
+            for (int m = 0; m < kSelMaxPerLane; m++) {
+                const int idx = sp + lane + 64 * m;
+                if (idx >= pind - lb && idx <= pind + lf) dead |= 1u << m;
+            }
+        }
+        if (lane == 0) sel_fl_n[j] = smallest;
     }
-    for (int i = tid; i < len; i += 256) b.label[off + rbeg + i] = label[i];
+    for (int i = lane; i < len; i += 64) b.label[off + rbeg + i] = label[i];
+}
 
-    // ---- less-flat candidates (label <= 0 inside the sectors) -> pcl::VoxelGrid(0.2) restated
+// ------------------------------------------------------------------------------------------------
+// k_voxel: one workgroup per (scan, ring): pcl::VoxelGrid(0.2 m, all fields averaged) over the ring's less-flat
+// candidates (label <= 0 inside the sectors): bounding box, (cell, index) keys, in-LDS bitonic sort, run starts,
+// float centroids summed in (cell, index) order.
+constexpr int kVoxLds = kRingCap * 8 + 1024;
+
+__global__ __launch_bounds__(256) void k_voxel(BatchView b)
+{
+    const int r = blockIdx.x, s = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t off = b.off[s];
+    const int *rb = b.ring_begin + s * 65;
+    const int rbeg = rb[r], rend = rb[r + 1], len = rend - rbeg;
+    const int S = rbeg + 5, E = rend - 6;
+    if (E - S < 6 || len > kRingCap) {
+        if (tid == 0) b.lf_n[s * 64 + r] = 0;
+        return;
+    }
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned long long *keys = (unsigned long long *)smem;
+    int *scr = (int *)(smem + kRingCap * 8);   // 256 ints
+    const signed char *label = (const signed char *)(b.label + off + rbeg);
     const float4 *cl = b.cloud + off + rbeg;
     const int c_lo = 5, c_hi = len - 7;   // sectors cover local [5, len-7]
     float mnx = FLT_MAX, mny = FLT_MAX, mnz = FLT_MAX, mxx = -FLT_MAX, mxy = -FLT_MAX, mxz = -FLT_MAX;
@@ -358,7 +383,6 @@ __global__ __launch_bounds__(256) void k_select(BatchView b)
     mnz = fminf(fminf(fs[2], fs[8]), fminf(fs[14], fs[20]));
     mxx = fmaxf(fmaxf(fs[3], fs[9]), fmaxf(fs[15], fs[21]));
     mxy = fmaxf(fmaxf(fs[4], fs[10]), fmaxf(fs[16], fs[22]));
-    mxz = fmaxf(fmaxf(fs[5], fs[11]), fmaxf(fs[17], fs[23]));
     const float inv_leaf = 5.0f;
     const int minb0 = (int)floorf(mnx * inv_leaf), minb1 = (int)floorf(mny * inv_leaf), minb2 = (int)floorf(mnz * inv_leaf);
     const int div0 = (int)floorf(mxx * inv_leaf) - minb0 + 1, div1 = (int)floorf(mxy * inv_leaf) - minb1 + 1;
@@ -411,6 +435,7 @@ __global__ __launch_bounds__(256) void k_select(BatchView b)
     if (tid == 0) b.lf_n[s * 64 + r] = n_out;
 }
 
+// ------------------------------------------------------------------------------------------------
 // Line tables of a feature cloud (line = int(intensity), what laserOdometry reads as the scan line):
 //   first_ge[t] = first index whose line is >= t, last_le[t] = last index whose line is <= t  (t = 0..65).
 // The odometry walk around a nearest point of line ra visits exactly the index window (last_le[ra-3], first_ge[ra+3])

@@ -72,7 +72,8 @@ extern "C" lmono_ctx *lmono_create(int device)
     lmono_ctx *c = new lmono_ctx();
     c->device = device;
     // the selection kernel needs ~62 KB of dynamic LDS
-    if (hipFuncSetAttribute((const void *)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, kSelLds) != hipSuccess) { delete c; return nullptr; }
+    if (hipFuncSetAttribute((const void *)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kSelWaveLds) != hipSuccess) { delete c; return nullptr; }
+    if (hipFuncSetAttribute((const void *)k_voxel, hipFuncAttributeMaxDynamicSharedMemorySize, kVoxLds) != hipSuccess) { delete c; return nullptr; }
     return c;
 }
 
@@ -190,7 +191,8 @@ extern "C" int lmono_scanreg_batch(lmono_ctx *c, lmono_scan_batch *b, const floa
     const int tiles = (int)((max_pts + kCurvTile - 1) / kCurvTile);
     if (tiles > 0) hipLaunchKernelGGL(k_curvature, dim3(tiles, n_scans), dim3(256), 0, st, v);
     HIP_TRY(c, hipEventRecord(c->ev[2], st));
-    hipLaunchKernelGGL(k_select, dim3(kMaxRings, n_scans), dim3(256), kSelLds, st, v);
+    hipLaunchKernelGGL(k_select, dim3(kMaxRings / 4, n_scans), dim3(256), 4 * kSelWaveLds, st, v);
+    hipLaunchKernelGGL(k_voxel, dim3(kMaxRings, n_scans), dim3(256), kVoxLds, st, v);
     HIP_TRY(c, hipEventRecord(c->ev[3], st));
     hipLaunchKernelGGL(k_compact, dim3(n_scans), dim3(256), 0, st, v);
     HIP_TRY(c, hipEventRecord(c->ev[4], st));
