@@ -51,6 +51,7 @@ struct lmono_scan_batch {
     int chains_cap = 0;
     double *state = nullptr, *incr = nullptr, *poses = nullptr, *xq = nullptr;
     int *corr = nullptr, *lm_info = nullptr, *corr_pair = nullptr;
+    float4 *crec = nullptr, *crec_pair = nullptr;
 };
 
 #define HIP_TRY(ctx, expr)                                                                   \
@@ -142,7 +143,7 @@ extern "C" lmono_scan_batch *lmono_batch_create(lmono_ctx *c, int n_cap, int64_t
     ok = ok && dalloc(b, v.lbc_pts, N * kMaxLessSharp) && dalloc(b, v.lbs_pts, T) && dalloc(b, v.lb_start, N * 2 * (kLineKeys + 1));
     ok = ok && dalloc(b, v.cg_slot, N * kMaxLessSharp) && dalloc(b, v.cg_rank, N * kMaxLessSharp);
     ok = ok && dalloc(b, b->incr, N * 7) && dalloc(b, b->poses, N * 7) && dalloc(b, b->xq, 8);
-    ok = ok && dalloc(b, b->corr_pair, (size_t)kMaxQueries * 4);
+    ok = ok && dalloc(b, b->corr_pair, (size_t)kMaxQueries * 4) && dalloc(b, b->crec_pair, (size_t)kMaxQueries * 4);
     if (!ok) {
         c->err = "lmono_batch_create: hipMalloc failed";
         lmono_batch_destroy(b);
@@ -297,7 +298,7 @@ static int ensure_odom_ws(lmono_ctx *c, lmono_scan_batch *b, int n_chains)
     if (n_chains <= b->chains_cap) return LMONO_OK;
     // (re)allocate; old buffers stay in allocs and are freed with the batch
     bool ok = dalloc(b, b->state, (size_t)n_chains * 8) && dalloc(b, b->corr, (size_t)n_chains * kMaxQueries * 4) &&
-              dalloc(b, b->lm_info, (size_t)n_chains * 4);
+              dalloc(b, b->lm_info, (size_t)n_chains * 4) && dalloc(b, b->crec, (size_t)n_chains * kMaxQueries * 4);
     if (!ok) { c->err = "odometry workspace: hipMalloc failed"; return LMONO_ENOMEM; }
     b->chains_cap = n_chains;
     return LMONO_OK;
@@ -314,7 +315,7 @@ extern "C" int lmono_odom_batch_d(lmono_ctx *c, lmono_scan_batch *b, int n_chain
     if (rc) return rc;
     OdomView o;
     o.n_scans = n; o.n_chains = n_chains; o.lead = lead; o.fixed_k = -1;
-    o.state = b->state; o.corr = b->corr; o.incr = b->incr; o.lm_info = b->lm_info;
+    o.state = b->state; o.corr = b->corr; o.incr = b->incr; o.lm_info = b->lm_info; o.crec = b->crec;
     int max_steps = 0;
     for (int ch = 0; ch < n_chains; ch++) {
         const int s = (int)((long long)ch * n / n_chains), e = (int)((long long)(ch + 1) * n / n_chains);
@@ -332,7 +333,7 @@ extern "C" int lmono_odom_batch_d(lmono_ctx *c, lmono_scan_batch *b, int n_chain
     for (int step = 0; step < max_steps; step++) {
         for (int outer = 0; outer < 2; outer++) {
             hipLaunchKernelGGL(k_correspond, dim3(kMaxQueries / 4, n_chains), dim3(256), 0, st, b->v, o, step);
-            hipLaunchKernelGGL(k_lm_solve, dim3((n_chains + 3) / 4), dim3(256), 0, st, b->v, o, step, outer);
+            hipLaunchKernelGGL(k_lm_solve, dim3(n_chains), dim3(256), 0, st, b->v, o, step, outer);
         }
     }
     hipLaunchKernelGGL(k_pose_prefix, dim3(1), dim3(64), 0, st, (const double *)b->incr, b->poses, 0, n);
@@ -369,7 +370,7 @@ extern "C" int lmono_odom_correspond(lmono_ctx *c, lmono_scan_batch *b, int scan
     if (nq > cap) { c->err = "odom_correspond: output capacity too small"; return LMONO_ECAPACITY; }
     OdomView o;
     o.n_scans = b->n_scans; o.n_chains = 1; o.lead = 0; o.fixed_k = scan;
-    o.state = b->xq; o.corr = b->corr_pair; o.incr = nullptr; o.lm_info = nullptr;
+    o.state = b->xq; o.corr = b->corr_pair; o.incr = nullptr; o.lm_info = nullptr; o.crec = b->crec_pair;
     hipLaunchKernelGGL(k_correspond, dim3(kMaxQueries / 4, 1), dim3(256), 0, c->stream, b->v, o, 0);
     int rc = check_launch(c, "k_correspond");
     if (rc) return rc;

@@ -109,6 +109,7 @@ struct OdomView {
     int fixed_k;          // >= 0: single-pair debug view, every chain works on this scan
     double *state;        // [n_chains][8]  q(xyzw), t, pad
     int *corr;            // [n_chains][kMaxQueries][4]
+    float4 *crec;         // [n_chains][kMaxQueries][4] residual-block records: (cp, kind), a, b, c
     double *incr;         // [n_scans][7]
     int *lm_info;         // [n_chains][4]
 };
@@ -455,6 +456,22 @@ __global__ __launch_bounds__(256) void k_correspond(BatchView b, OdomView o, int
     const int4 r = (b.status[k - 1] & kStatusIrregularLines) ? correspond_one(b, k, qi, x, lane)
                                                             : correspond_indexed(b, k, qi, x, lane);
     if (lane == 0) ((int4 *)o.corr)[(size_t)c * kMaxQueries + qi] = r;
+    // residual-block record for the solver: the feature point and its 2 (edge) or 3 (plane) partners, 64 B
+    if (lane < 4) {
+        const int l = k - 1;
+        const int n_sharp = b.feat_n[k * 4 + 0];
+        const bool edge = qi < n_sharp;
+        const float4 *cloud = edge ? b.less_sharp + (size_t)l * kMaxLessSharp : b.less_flat + b.off[l];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane == 0) {
+            v = edge ? b.sharp[(size_t)k * kMaxSharp + qi] : b.flat[(size_t)k * kMaxFlat + (qi - n_sharp)];
+            v.w = __int_as_float(r.w);
+        } else if (r.w != 0) {
+            const int idx = lane == 1 ? r.x : (lane == 2 ? r.y : r.z);
+            if (idx >= 0) v = cloud[idx];
+        }
+        o.crec[((size_t)c * kMaxQueries + qi) * 4 + lane] = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -485,18 +502,16 @@ __device__ __forceinline__ void huber(double s, double &rho0, double &rho1)
 }
 
 template <bool kJac>
-__device__ __forceinline__ void eval_block(const BatchView &b, int k, int qi, const int4 cr, const double *x, const double *Jp, LmAcc &acc)
+__device__ __forceinline__ void eval_block(const float4 *rec, const double *x, const double *Jp, LmAcc &acc)
 {
-    const int l = k - 1;
-    const int n_sharp = b.feat_n[k * 4 + 0];
-    const bool edge = cr.w == 1;
-    const float4 cp = edge ? b.sharp[(size_t)k * kMaxSharp + qi] : b.flat[(size_t)k * kMaxFlat + (qi - n_sharp)];
-    const float4 *cloud = edge ? b.less_sharp + (size_t)l * kMaxLessSharp : b.less_flat + b.off[l];
+    const float4 cp = rec[0], A = rec[1], B = rec[2];
+    const int kind = __float_as_int(cp.w);
+    if (kind == 0) return;
+    const bool edge = kind == 1;
     const double vx = (double)cp.x, vy = (double)cp.y, vz = (double)cp.z;
     double lx, ly, lz;
     quat_rotate(x, vx, vy, vz, lx, ly, lz);
     lx += x[4]; ly += x[5]; lz += x[6];
-    const float4 A = cloud[cr.x], B = cloud[cr.y];
     double res[3], D[3][3];   // D = d res / d lp
     int nr;
     if (edge) {
@@ -515,7 +530,7 @@ __device__ __forceinline__ void eval_block(const BatchView &b, int k, int qi, co
         }
         nr = 3;
     } else {
-        const float4 Cc = cloud[cr.z];
+        const float4 Cc = rec[3];
         const double jx = (double)A.x, jy = (double)A.y, jz = (double)A.z;
         const double ux = jx - (double)B.x, uy = jy - (double)B.y, uz = jz - (double)B.z;
         const double wx = jx - (double)Cc.x, wy = jy - (double)Cc.y, wz = jz - (double)Cc.z;
@@ -538,7 +553,6 @@ __device__ __forceinline__ void eval_block(const BatchView &b, int k, int qi, co
     const double cxv = uy * vz - uz * vy, cyv = uz * vx - ux * vz, czv = ux * vy - uy * vx;   // u x v
     // d/du [ 2 w (u x v) + 2 u x (u x v) ] = -2 w [v]_x - 2 [u x v]_x - 2 [u]_x [v]_x
     double G[3][4];
-    // [v]_x
     const double V[3][3] = { { 0, -vz, vy }, { vz, 0, -vx }, { -vy, vx, 0 } };
     const double U[3][3] = { { 0, -uz, uy }, { uz, 0, -ux }, { -uy, ux, 0 } };
     const double Cx[3][3] = { { 0, -czv, cyv }, { czv, 0, -cxv }, { -cyv, cxv, 0 } };
@@ -568,9 +582,12 @@ __device__ __forceinline__ void eval_block(const BatchView &b, int k, int qi, co
     }
 }
 
+// Sum over all residual blocks of a chain by the 256 threads of its workgroup; every thread returns the same sums
+// (wave butterfly, then the four wave partials are added in fixed order).
 template <bool kJac>
-__device__ __forceinline__ void evaluate_wave(const BatchView &b, int k, const int4 *corr, int nq, const double *x, LmAcc &acc, int lane)
+__device__ __forceinline__ void evaluate_block(const float4 *crec, int nq, const double *x, LmAcc &acc, double (*s_red)[28])
 {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double Jp[12];
     Jp[0] = x[3];  Jp[1] = x[2];   Jp[2] = -x[1];
     Jp[3] = -x[2]; Jp[4] = x[3];   Jp[5] = x[0];
@@ -583,17 +600,27 @@ __device__ __forceinline__ void evaluate_wave(const BatchView &b, int k, const i
 #pragma unroll
         for (int i = 0; i < 6; i++) acc.g[i] = 0.0;
     }
-    for (int qi = lane; qi < nq; qi += 64) {
-        const int4 cr = corr[qi];
-        if (cr.w == 0) continue;
-        eval_block<kJac>(b, k, qi, cr, x, Jp, acc);
-    }
+    for (int qi = tid; qi < nq; qi += 256) eval_block<kJac>(crec + (size_t)qi * 4, x, Jp, acc);
     acc.cost = wave_sum_d(acc.cost);
     if (kJac) {
 #pragma unroll
         for (int i = 0; i < 21; i++) acc.H[i] = wave_sum_d(acc.H[i]);
 #pragma unroll
         for (int i = 0; i < 6; i++) acc.g[i] = wave_sum_d(acc.g[i]);
+    }
+    __syncthreads();   // previous readers of s_red are done
+    if (lane == 0) {
+        s_red[wave][27] = acc.cost;
+        if (kJac) {
+            for (int i = 0; i < 21; i++) s_red[wave][i] = acc.H[i];
+            for (int i = 0; i < 6; i++) s_red[wave][21 + i] = acc.g[i];
+        }
+    }
+    __syncthreads();
+    acc.cost = ((s_red[0][27] + s_red[1][27]) + s_red[2][27]) + s_red[3][27];
+    if (kJac) {
+        for (int i = 0; i < 21; i++) acc.H[i] = ((s_red[0][i] + s_red[1][i]) + s_red[2][i]) + s_red[3][i];
+        for (int i = 0; i < 6; i++) acc.g[i] = ((s_red[0][21 + i] + s_red[1][21 + i]) + s_red[2][21 + i]) + s_red[3][21 + i];
     }
 }
 
@@ -643,17 +670,19 @@ __device__ __forceinline__ void unpack_sym(const double *Hu, double *H)
         for (int j = i; j < 6; j++) { H[i * 6 + j] = Hu[t]; H[j * 6 + i] = Hu[t]; t++; }
 }
 
-// One wave per chain.  All lanes run the (uniform) trust-region control flow redundantly on wave-reduced sums.
+// One 256-thread workgroup per chain.  Every thread runs the (uniform) trust-region control flow redundantly on the
+// block-reduced sums; residual blocks come from the 64-B records written by k_correspond.
 __global__ __launch_bounds__(256) void k_lm_solve(BatchView b, OdomView o, int step, int outer)
 {
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (c >= o.n_chains) return;
+    const int c = blockIdx.x;
     int s;
     const int k = chain_scan(o, c, step, s);
     if (k < 0) return;
+    __shared__ double s_red[4][28];
+    __shared__ int s_used[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nq = b.feat_n[k * 4 + 0] + b.feat_n[k * 4 + 2];
-    const int4 *corr = (const int4 *)o.corr + (size_t)c * kMaxQueries;
+    const float4 *crec = o.crec + (size_t)c * kMaxQueries * 4;
     double x[7];
     for (int i = 0; i < 7; i++) x[i] = o.state[c * 8 + i];
 
@@ -664,14 +693,17 @@ __global__ __launch_bounds__(256) void k_lm_solve(BatchView b, OdomView o, int s
     bool reuse_diagonal = false;
     int invalid_steps = 0, iter = 0;
     LmAcc acc;
-    evaluate_wave<true>(b, k, corr, nq, x, acc, lane);
+    evaluate_block<true>(crec, nq, x, acc, s_red);
     double x_cost = acc.cost;
     double H[36], g[6], scale[6], diag[6];
     unpack_sym(acc.H, H);
     for (int i = 0; i < 6; i++) g[i] = acc.g[i];
     int n_used = 0;
-    for (int qi = lane; qi < nq; qi += 64) n_used += corr[qi].w != 0;
+    for (int qi = tid; qi < nq; qi += 256) n_used += __float_as_int(crec[(size_t)qi * 4].w) != 0;
     n_used = wave_sum_i(n_used);
+    if (lane == 0) s_used[wave] = n_used;
+    __syncthreads();
+    n_used = s_used[0] + s_used[1] + s_used[2] + s_used[3];
     double gmax = 0.0;
     for (int i = 0; i < 6; i++) gmax = fmax(gmax, fabs(g[i]));
     if (n_used > 0 && gmax > gradient_tol) {
@@ -704,7 +736,7 @@ __global__ __launch_bounds__(256) void k_lm_solve(BatchView b, OdomView o, int s
             for (int i = 0; i < 6; i++) delta[i] = stepv[i] * scale[i];
             manifold_plus(x, delta, cand);
             LmAcc ca;
-            evaluate_wave<false>(b, k, corr, nq, cand, ca, lane);
+            evaluate_block<false>(crec, nq, cand, ca, s_red);
             const double cand_cost = ca.cost;
             double sn = 0.0;
             for (int i = 0; i < 7; i++) sn += (x[i] - cand[i]) * (x[i] - cand[i]);
@@ -715,7 +747,7 @@ __global__ __launch_bounds__(256) void k_lm_solve(BatchView b, OdomView o, int s
             if (rel > min_rel_decrease) {
                 for (int i = 0; i < 7; i++) x[i] = cand[i];
                 x_norm = norm7(x);
-                evaluate_wave<true>(b, k, corr, nq, x, acc, lane);
+                evaluate_block<true>(crec, nq, x, acc, s_red);
                 x_cost = acc.cost;
                 unpack_sym(acc.H, H);
                 for (int i = 0; i < 6; i++) g[i] = acc.g[i];
@@ -734,12 +766,11 @@ __global__ __launch_bounds__(256) void k_lm_solve(BatchView b, OdomView o, int s
             if (radius <= min_radius) break;
         }
     }
-    if (lane == 0) {
+    if (tid == 0) {
         for (int i = 0; i < 7; i++) o.state[c * 8 + i] = x[i];
-        if (outer == 1 && k >= s)
+        if (o.incr && outer == 1 && k >= s)
             for (int i = 0; i < 7; i++) o.incr[(size_t)k * 7 + i] = x[i];
-        o.lm_info[c * 4 + outer] = iter;
-        o.lm_info[c * 4 + 2 + outer] = n_used;
+        if (o.lm_info) { o.lm_info[c * 4 + outer] = iter; o.lm_info[c * 4 + 2 + outer] = n_used; }
     }
 }
 
