@@ -332,7 +332,7 @@ extern "C" int lmono_odom_batch_d(lmono_ctx *c, lmono_scan_batch *b, int n_chain
     hipLaunchKernelGGL(k_odom_init, dim3((ninit + 255) / 256), dim3(256), 0, st, o);
     for (int step = 0; step < max_steps; step++) {
         for (int outer = 0; outer < 2; outer++) {
-            hipLaunchKernelGGL(k_correspond, dim3(kMaxQueries / 4, n_chains), dim3(256), 0, st, b->v, o, step);
+            hipLaunchKernelGGL(k_correspond, dim3(8 * ((n_chains + 7) / 8) * kCorrBlocks), dim3(256), 0, st, b->v, o, step);
             hipLaunchKernelGGL(k_lm_solve, dim3(n_chains), dim3(256), 0, st, b->v, o, step, outer);
         }
     }
@@ -371,7 +371,7 @@ extern "C" int lmono_odom_correspond(lmono_ctx *c, lmono_scan_batch *b, int scan
     OdomView o;
     o.n_scans = b->n_scans; o.n_chains = 1; o.lead = 0; o.fixed_k = scan;
     o.state = b->xq; o.corr = b->corr_pair; o.incr = nullptr; o.lm_info = nullptr; o.crec = b->crec_pair;
-    hipLaunchKernelGGL(k_correspond, dim3(kMaxQueries / 4, 1), dim3(256), 0, c->stream, b->v, o, 0);
+    hipLaunchKernelGGL(k_correspond, dim3(8 * kCorrBlocks), dim3(256), 0, c->stream, b->v, o, 0);
     int rc = check_launch(c, "k_correspond");
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));

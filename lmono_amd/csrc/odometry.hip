@@ -27,8 +27,11 @@ __device__ __forceinline__ unsigned long long cell_key(int cx, int cy, int cz)
 }
 __device__ __forceinline__ unsigned int hash_key(unsigned long long k)
 {
-    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
-    return (unsigned int)k;
+    // three 32-bit multiplies on the packed 21-bit cell coordinates (Teschner et al. primes) and a final fold
+    const unsigned int cz = (unsigned int)(k & 0x1fffffull), cy = (unsigned int)((k >> 21) & 0x1fffffull), cx = (unsigned int)(k >> 42);
+    unsigned int h = (cx * 73856093u) ^ (cy * 19349663u) ^ (cz * 83492791u);
+    h ^= h >> 15;
+    return h;
 }
 
 struct GridRef {
@@ -99,7 +102,8 @@ __global__ __launch_bounds__(1024) void k_grid_build(BatchView b)
     __syncthreads();
     for (int i = tid; i < n; i += 1024) {
         const float4 p = src[i];
-        dst[cell[slot_of[i]].start + rank_of[i]] = make_float4(p.x, p.y, p.z, __int_as_float(i));
+        const int ln = (int)p.w;
+        dst[cell[slot_of[i]].start + rank_of[i]] = make_float4(p.x, p.y, p.z, __int_as_float(i | ((ln < 0 ? 0 : (ln > 65 ? 65 : ln)) << 24)));
     }
 }
 
@@ -164,7 +168,7 @@ __device__ __forceinline__ unsigned long long wave_nn(const GridRef &g, float qx
                 const int s0 = __shfl(st, src), n0 = __shfl(cn, src);
                 for (int i = lane; i < n0; i += 64) {
                     const float4 p = g.pts[s0 + i];
-                    const unsigned long long cand = pack_fu(dist2f(p.x, p.y, p.z, qx, qy, qz), (unsigned int)__float_as_int(p.w));
+                    const unsigned long long cand = pack_fu(dist2f(p.x, p.y, p.z, qx, qy, qz), (unsigned int)__float_as_int(p.w) & 0xffffffu);
                     best = cand < best ? cand : best;
                 }
             }
@@ -439,38 +443,269 @@ __device__ __forceinline__ int4 correspond_indexed(const BatchView &b, int k, in
     return out;
 }
 
-// step t of every chain: one wave per feature point of the chain's current scan.
-// (A thread-per-feature variant was measured 2.9x slower: its dependent global loads leave no memory-level
-// parallelism at ~1 wave per SIMD; see profiles/r1/NOTES.md.)
+// ---- half-wave (32-lane) groups: two feature points per wave --------------------------------------------------
+// The per-feature work is dominated by scalar-like instructions (hashing, probing, bookkeeping) and by chains of
+// dependent loads, so each feature gets 32 lanes (the 27 cells of shell 1 fit) and independent loads are issued in
+// batches before any of them is consumed.  Variants measured: profiles/r1/NOTES.md.
+constexpr int kGroup = 32;
+
+__device__ __forceinline__ unsigned int group_ballot(bool pred, int gbase)
+{
+    return (unsigned int)((__ballot(pred) >> gbase) & 0xffffffffull);
+}
+__device__ __forceinline__ unsigned long long group_min_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int o = kGroup / 2; o > 0; o >>= 1) {
+        const unsigned long long w = __shfl_xor(v, o, kGroup);
+        v = w < v ? w : v;
+    }
+    return v;
+}
+
+struct NnBest { float d; int idx; int line; };
+__device__ __forceinline__ void nn_update(NnBest &bst, const float4 &p, float qx, float qy, float qz)
+{
+    const float d = dist2f(p.x, p.y, p.z, qx, qy, qz);
+    const int w = __float_as_int(p.w);
+    const int idx = w & 0xffffff;
+    const bool better = d < bst.d || (d == bst.d && idx < bst.idx);
+    bst.d = better ? d : bst.d;
+    bst.idx = better ? idx : bst.idx;
+    bst.line = better ? (w >> 24) : bst.line;
+}
+
+__device__ __forceinline__ void walk_point(const float4 &cpt, int v, int ra, int closest, int w_lo, int w_hi, bool edge,
+                                           float qx, float qy, float qz, WalkBest &bs, WalkBest &bo)
+{
+    const int j = __float_as_int(cpt.w);
+    if (j == closest || j < w_lo || j >= w_hi) return;
+    const bool fwd = j > closest;
+    const unsigned int seq = fwd ? (unsigned int)(j - closest - 1) : kSeqBack + (unsigned int)(closest - 1 - j);
+    const float d = dist2f(cpt.x, cpt.y, cpt.z, qx, qy, qz);
+    const bool is_other = fwd ? (v > ra) : (v < ra);
+    if (is_other) walk_update(bo, d, seq);
+    else if (!edge) walk_update(bs, d, seq);
+}
+
+// gl = lane inside the 32-lane group, gbase = first wave lane of the group (0 or 32)
+__device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi, const double *x, int gl, int gbase)
+{
+    const int n_sharp = b.feat_n[k * 4 + 0];
+    const bool edge = qi < n_sharp;
+    const float4 p = edge ? b.sharp[(size_t)k * kMaxSharp + qi] : b.flat[(size_t)k * kMaxFlat + (qi - n_sharp)];
+    double rx, ry, rz;
+    quat_rotate(x, (double)p.x, (double)p.y, (double)p.z, rx, ry, rz);
+    const float qx = (float)(rx + x[4]), qy = (float)(ry + x[5]), qz = (float)(rz + x[6]);
+    const int l = k - 1;
+    const int cl = edge ? 0 : 1;
+    const GridCell *cell = edge ? b.cg_cell + (size_t)l * kCornerTable : b.sg_cell + (size_t)l * kSurfTable;
+    const float4 *gpts = edge ? b.cg_pts + (size_t)l * kMaxLessSharp : b.sg_pts + b.off[l];
+    const float4 *lb_pts = edge ? b.lbc_pts + (size_t)l * kMaxLessSharp : b.lbs_pts + b.off[l];
+    const int n_last = b.feat_n[l * 4 + (edge ? 1 : 3)];
+    const unsigned int mask = (unsigned int)b.grid_mask[l * 2 + cl];
+    int4 out = make_int4(-1, -1, -1, 0);
+    if (n_last == 0) return out;
+
+    // ---- exact NN, shell 1: lanes 0..26 probe one cell each
+    const int cqx = (int)floorf(qx * kInvCell), cqy = (int)floorf(qy * kInvCell), cqz = (int)floorf(qz * kInvCell);
+    int st = 0, cn = 0;
+    if (gl < 27) {
+        const int dx = gl % 3 - 1, dy = (gl / 3) % 3 - 1, dz = gl / 9 - 1;
+        const unsigned long long kk = cell_key(cqx + dx, cqy + dy, cqz + dz);
+        unsigned int sl = hash_key(kk) & mask;
+        while (true) {
+            const GridCell e = cell[sl];
+            if (e.key == kk) { st = e.start; cn = e.cnt; break; }
+            if (e.key == kEmptyKey) break;
+            sl = (sl + 1) & mask;
+        }
+    }
+    NnBest nb = { __uint_as_float(0x7f800000u), 0x7fffffff, 0 };
+    unsigned int m = group_ballot(cn > 0, gbase);
+    while (m) {
+        // four non-empty cells per round: their first 32 points are loaded back to back before any is consumed
+        int s4[4], n4[4];
+        float4 v4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            n4[u] = 0; s4[u] = 0;
+            if (m) {
+                const int src = __ffs((int)m) - 1;
+                m &= m - 1;
+                s4[u] = __shfl(st, src, kGroup); n4[u] = __shfl(cn, src, kGroup);
+            }
+            v4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gl < n4[u]) v4[u] = gpts[s4[u] + gl];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (gl < n4[u]) nn_update(nb, v4[u], qx, qy, qz);
+            for (int i = gl + kGroup; i < n4[u]; i += kGroup) nn_update(nb, gpts[s4[u] + i], qx, qy, qz);
+        }
+    }
+    unsigned long long best = group_min_u64(nb.idx == 0x7fffffff ? ~0ull : pack_fu(nb.d, (unsigned int)nb.idx));
+    {
+        const float bound = kCell * 0.9999f;
+        const bool settled = best != ~0ull && __uint_as_float((unsigned int)(best >> 32)) <= bound * bound;
+        if (!settled) {
+            // rare: shells 2..6 with the generic (slower) cooperative search over the group's 32 lanes
+            for (int sh = 2; sh <= kMaxShell; sh++) {
+                const int side = 2 * sh + 1, ncell = side * side * side;
+                for (int base = 0; base < ncell; base += kGroup) {
+                    const int ci = base + gl;
+                    int st2 = 0, cn2 = 0;
+                    if (ci < ncell) {
+                        const int dx = ci % side - sh, dy = (ci / side) % side - sh, dz = ci / (side * side) - sh;
+                        if (max(max(abs(dx), abs(dy)), abs(dz)) == sh) {
+                            const unsigned long long kk = cell_key(cqx + dx, cqy + dy, cqz + dz);
+                            unsigned int sl = hash_key(kk) & mask;
+                            while (true) {
+                                const GridCell e = cell[sl];
+                                if (e.key == kk) { st2 = e.start; cn2 = e.cnt; break; }
+                                if (e.key == kEmptyKey) break;
+                                sl = (sl + 1) & mask;
+                            }
+                        }
+                    }
+                    unsigned int m2 = group_ballot(cn2 > 0, gbase);
+                    while (m2) {
+                        const int src = __ffs((int)m2) - 1;
+                        m2 &= m2 - 1;
+                        const int s0 = __shfl(st2, src, kGroup), n0 = __shfl(cn2, src, kGroup);
+                        for (int i = gl; i < n0; i += kGroup) nn_update(nb, gpts[s0 + i], qx, qy, qz);
+                    }
+                }
+                best = group_min_u64(nb.idx == 0x7fffffff ? ~0ull : pack_fu(nb.d, (unsigned int)nb.idx));
+                if (best != ~0ull) {
+                    const float bound2 = (float)sh * kCell * 0.9999f;
+                    if (__uint_as_float((unsigned int)(best >> 32)) <= bound2 * bound2) break;
+                }
+            }
+        }
+    }
+    if (best == ~0ull || !((double)__uint_as_float((unsigned int)(best >> 32)) < 25.0)) return out;
+    const int closest = (int)(unsigned int)(best & 0xffffffffull);
+    // the lane that holds the winner knows its line
+    const unsigned int wm = group_ballot(nb.idx == closest && pack_fu(nb.d, (unsigned int)nb.idx) == best, gbase);
+    const int ra = __shfl(nb.line, __ffs((int)wm) - 1, kGroup);
+
+    // ---- scan-line walk over the (line, azimuth) index
+    const int *fge = b.line_first_ge + (size_t)(l * 2 + cl) * 66;
+    const int *lle = b.line_last_le + (size_t)(l * 2 + cl) * 66;
+    const int *table = b.lb_start + (size_t)(l * 2 + cl) * (kLineKeys + 1);
+    const float rho = sqrtf(qx * qx + qy * qy);
+    int b_lo = 0, nbins = kAzBins;
+    if (rho > 5.01f) {
+        const float alpha = asin_upper(5.0f / rho) + 1.5f * (6.28318531f / kAzBins);
+        const float th = atan2f(qy, qx) + 3.14159265f;
+        const int lo = (int)floorf((th - alpha) * (kAzBins / 6.28318531f));
+        const int hi = (int)floorf((th + alpha) * (kAzBins / 6.28318531f));
+        if (hi - lo + 1 < kAzBins) { b_lo = ((lo % kAzBins) + kAzBins) % kAzBins; nbins = hi - lo + 1; }
+    }
+    const int b_end = b_lo + nbins;
+    // lanes 0..4: bucket bounds of lines ra-2..ra+2; lanes 5, 6: the index window
+    int t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    {
+        const int v = ra - 2 + gl;
+        if (gl < 5 && v >= 0 && v <= 65 && !(edge && v == ra)) {
+            const int *row = table + v * kAzBins;
+            t0 = row[b_lo]; t1 = row[min(b_end, kAzBins)];
+            if (b_end > kAzBins) { t2 = row[0]; t3 = row[b_end - kAzBins]; }
+        }
+        if (gl == 5) t0 = ra - 3 >= 0 ? lle[ra - 3] + 1 : 0;
+        if (gl == 6) t0 = ra + 3 <= 65 ? fge[ra + 3] : n_last;
+    }
+    const int w_lo = __shfl(t0, 5, kGroup), w_hi = __shfl(t0, 6, kGroup);
+    WalkBest bs = { 25.0f, 0u }, bo = { 25.0f, 0u };
+    for (int part = 0; part < 2; part++) {
+        if (part == 1 && b_end <= kAzBins) break;
+        int r0[5], r1[5];
+        float4 v5[5];
+#pragma unroll
+        for (int vi = 0; vi < 5; vi++) {
+            r0[vi] = __shfl(part ? t2 : t0, vi, kGroup); r1[vi] = __shfl(part ? t3 : t1, vi, kGroup);
+            v5[vi] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+            if (r0[vi] + gl < r1[vi]) v5[vi] = lb_pts[r0[vi] + gl];
+        }
+#pragma unroll
+        for (int vi = 0; vi < 5; vi++) {
+            const int v = ra - 2 + vi;
+            if (r0[vi] + gl < r1[vi]) walk_point(v5[vi], v, ra, closest, w_lo, w_hi, edge, qx, qy, qz, bs, bo);
+            for (int i = r0[vi] + gl + kGroup; i < r1[vi]; i += kGroup) walk_point(lb_pts[i], v, ra, closest, w_lo, w_hi, edge, qx, qy, qz, bs, bo);
+        }
+    }
+    const unsigned long long thr = pack_fu(25.0f, 0u);
+    unsigned long long same = bs.d < 25.0f ? pack_fu(bs.d, bs.seq) : thr;
+    unsigned long long other = bo.d < 25.0f ? pack_fu(bo.d, bo.seq) : thr;
+    same = group_min_u64(same); other = group_min_u64(other);
+    const int i_other = other < thr ? seq_to_index((unsigned int)(other & 0xffffffffull), closest) : -1;
+    if (edge) {
+        if (i_other >= 0) out = make_int4(closest, i_other, -1, 1);
+        return out;
+    }
+    const int i_same = same < thr ? seq_to_index((unsigned int)(same & 0xffffffffull), closest) : -1;
+    if (i_same >= 0 && i_other >= 0) out = make_int4(closest, i_same, i_other, 2);
+    return out;
+}
+
+// step t of every chain: one 32-lane group per feature point of the chain's current scan (8 features per workgroup).
+// XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an XCD and its 4 MB L2), so
+// the 1-D grid is decoded such that all blocks of a chain run on ONE XCD, one chain after the other: the ~2 MB of
+// grid / index / point data of a chain's "last" scan then stay in that XCD's L2 for its 1836 features.
+constexpr int kCorrBlocks = kMaxQueries / 8;
+
 __global__ __launch_bounds__(256) void k_correspond(BatchView b, OdomView o, int step)
 {
-    const int c = blockIdx.y;
+    const int xcd = blockIdx.x & 7, u = blockIdx.x >> 3;
+    const int c = (u / kCorrBlocks) * 8 + xcd;
+    const int qblock = u % kCorrBlocks;
+    if (c >= o.n_chains) return;
     const int lane = threadIdx.x & 63;
-    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int gl = threadIdx.x & (kGroup - 1), gbase = lane & ~(kGroup - 1);
     int own;
     const int k = chain_scan(o, c, step, own);
     if (k < 0) return;
-    const int nq = b.feat_n[k * 4 + 0] + b.feat_n[k * 4 + 2];
-    if (qi >= nq) return;
+    const int n_sharp = b.feat_n[k * 4 + 0];
+    const int nq = n_sharp + b.feat_n[k * 4 + 2];
     const double *x = o.state + c * 8;
-    const int4 r = (b.status[k - 1] & kStatusIrregularLines) ? correspond_one(b, k, qi, x, lane)
-                                                            : correspond_indexed(b, k, qi, x, lane);
-    if (lane == 0) ((int4 *)o.corr)[(size_t)c * kMaxQueries + qi] = r;
+    int4 *corr = (int4 *)o.corr + (size_t)c * kMaxQueries;
+    const int l = k - 1;
+    if (b.status[l] & kStatusIrregularLines) {
+        // rare: array-order walk with the whole wave, the wave's two features one after the other
+        for (int t = 0; t < 2; t++) {
+            const int qi = qblock * 8 + (threadIdx.x >> 6) * 2 + t;
+            if (qi >= nq) break;
+            const int4 r = correspond_one(b, k, qi, x, lane);
+            if (lane == 0) corr[qi] = r;
+            if (lane < 4) {
+                const bool edge = qi < n_sharp;
+                const float4 *cloud = edge ? b.less_sharp + (size_t)l * kMaxLessSharp : b.less_flat + b.off[l];
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (lane == 0) { v = edge ? b.sharp[(size_t)k * kMaxSharp + qi] : b.flat[(size_t)k * kMaxFlat + (qi - n_sharp)]; v.w = __int_as_float(r.w); }
+                else if (r.w != 0) { const int idx = lane == 1 ? r.x : (lane == 2 ? r.y : r.z); if (idx >= 0) v = cloud[idx]; }
+                o.crec[((size_t)c * kMaxQueries + qi) * 4 + lane] = v;
+            }
+        }
+        return;
+    }
+    const int qi = qblock * 8 + (threadIdx.x >> 5);
+    if (qi >= nq) return;
+    const int4 r = correspond_g32(b, k, qi, x, gl, gbase);
+    if (gl == 0) corr[qi] = r;
     // residual-block record for the solver: the feature point and its 2 (edge) or 3 (plane) partners, 64 B
-    if (lane < 4) {
-        const int l = k - 1;
-        const int n_sharp = b.feat_n[k * 4 + 0];
+    if (gl < 4) {
         const bool edge = qi < n_sharp;
         const float4 *cloud = edge ? b.less_sharp + (size_t)l * kMaxLessSharp : b.less_flat + b.off[l];
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (lane == 0) {
+        if (gl == 0) {
             v = edge ? b.sharp[(size_t)k * kMaxSharp + qi] : b.flat[(size_t)k * kMaxFlat + (qi - n_sharp)];
             v.w = __int_as_float(r.w);
         } else if (r.w != 0) {
-            const int idx = lane == 1 ? r.x : (lane == 2 ? r.y : r.z);
+            const int idx = gl == 1 ? r.x : (gl == 2 ? r.y : r.z);
             if (idx >= 0) v = cloud[idx];
         }
-        o.crec[((size_t)c * kMaxQueries + qi) * 4 + lane] = v;
+        o.crec[((size_t)c * kMaxQueries + qi) * 4 + gl] = v;
     }
 }
 
