@@ -108,9 +108,10 @@ int lmono_pose_prefix_d(lmono_ctx *, const double *incr_d, int first, int n, dou
 int lmono_pose_rebase_d(lmono_ctx *, const double *bases_d, int n_bases, double *poses_d, int n);
 
 /* Device-time accounting with hipEvents recorded on the context stream around every kernel group of every
- * lmono_scanreg_batch / lmono_odom_batch call since the last reset.  ms_out[0..6] = summed milliseconds of:
- * [0] front end total, [1] odometry total, [2] k_ring_sort, [3] k_curvature, [4] k_select, [5] k_compact,
- * [6] k_grid_build.  Both calls synchronise the stream.                                                   */
+ * lmono_scanreg_batch / lmono_odom_batch call since the last reset.  ms_out[0..8] = summed milliseconds of:
+ * [0] front end total, [1] odometry total, [2] k_ring_sort, [3] k_curvature, [4] k_select, [5] k_voxel,
+ * [6] k_compact, [7] k_grid_build, [8] k_line_index, [9] all k_correspond launches, [10] all k_lm_solve launches,
+ * [11] number of k_correspond (= k_lm_solve) launches.  Both calls synchronise the stream.                 */
 int lmono_timing_reset(lmono_ctx *);
 int lmono_timing_read(lmono_ctx *, double *ms_out, int cap, int *n_scanreg_calls, int *n_odom_calls);
 

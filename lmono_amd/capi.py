@@ -89,10 +89,11 @@ class Context:
 
     def timing(self):
         """Summed device ms per kernel group since timing_reset(): dict + call counts."""
-        ms = np.zeros(7)
+        ms = np.zeros(12)
         nr, no = C.c_int(0), C.c_int(0)
-        self.check(self.L.lmono_timing_read(self.h, ms.ctypes.data, 7, C.byref(nr), C.byref(no)))
-        names = ["frontend_total", "odometry_total", "k_ring_sort", "k_curvature", "k_select", "k_compact", "k_grid_build"]
+        self.check(self.L.lmono_timing_read(self.h, ms.ctypes.data, 12, C.byref(nr), C.byref(no)))
+        names = ["frontend_total", "odometry_total", "k_ring_sort", "k_curvature", "k_select", "k_voxel", "k_compact",
+                 "k_grid_build", "k_line_index", "k_correspond", "k_lm_solve", "odometry_launch_pairs"]
         return dict(zip(names, ms.tolist())), nr.value, no.value
 
     FACTOR_DIMS = {0: (14, 24, 36, 6, 84), 1: (22, 4, 4, 2, 44), 2: (7, 16, 2, 6, 42), 3: (1, 44, 1, 2, 2)}

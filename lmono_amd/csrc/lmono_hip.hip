@@ -11,7 +11,7 @@
 
 using namespace lmono;
 
-struct EvSet { hipEvent_t e[8]; bool reg = false, odom = false; };
+struct EvSet { hipEvent_t e[10]; bool reg = false, odom = false; std::vector<hipEvent_t> kev; int n_kev = 0; };  // kev: (begin, mid, end) per odometry launch pair
 
 struct lmono_ctx {
     int device = 0;
@@ -31,6 +31,7 @@ struct lmono_ctx {
             sets.push_back(s);
         }
         sets[n_sets].reg = sets[n_sets].odom = false;
+        sets[n_sets].n_kev = 0;
         return sets[n_sets++].e;
     }
 };
@@ -81,7 +82,7 @@ extern "C" lmono_ctx *lmono_create(int device)
 extern "C" void lmono_destroy(lmono_ctx *c)
 {
     if (!c) return;
-    for (auto &s : c->sets) for (auto &e : s.e) (void)hipEventDestroy(e);
+    for (auto &s : c->sets) { for (auto &e : s.e) (void)hipEventDestroy(e); for (auto &e : s.kev) (void)hipEventDestroy(e); }
     delete c;
 }
 
@@ -193,13 +194,15 @@ extern "C" int lmono_scanreg_batch(lmono_ctx *c, lmono_scan_batch *b, const floa
     if (tiles > 0) hipLaunchKernelGGL(k_curvature, dim3(tiles, n_scans), dim3(256), 0, st, v);
     HIP_TRY(c, hipEventRecord(c->ev[2], st));
     hipLaunchKernelGGL(k_select, dim3(kMaxRings / 4, n_scans), dim3(256), 4 * kSelWaveLds, st, v);
-    hipLaunchKernelGGL(k_voxel, dim3(kMaxRings, n_scans), dim3(256), kVoxLds, st, v);
     HIP_TRY(c, hipEventRecord(c->ev[3], st));
-    hipLaunchKernelGGL(k_compact, dim3(n_scans), dim3(256), 0, st, v);
+    hipLaunchKernelGGL(k_voxel, dim3(kMaxRings, n_scans), dim3(256), kVoxLds, st, v);
     HIP_TRY(c, hipEventRecord(c->ev[4], st));
-    hipLaunchKernelGGL(k_grid_build, dim3(n_scans, 2), dim3(1024), 0, st, v);
-    hipLaunchKernelGGL(k_line_index, dim3(n_scans, 2), dim3(256), 0, st, v);
+    hipLaunchKernelGGL(k_compact, dim3(n_scans), dim3(256), 0, st, v);
     HIP_TRY(c, hipEventRecord(c->ev[5], st));
+    hipLaunchKernelGGL(k_grid_build, dim3(n_scans, 2), dim3(1024), 0, st, v);
+    HIP_TRY(c, hipEventRecord(c->ev[6], st));
+    hipLaunchKernelGGL(k_line_index, dim3(n_scans, 2), dim3(256), 0, st, v);
+    HIP_TRY(c, hipEventRecord(c->ev[7], st));
     int rc = check_launch(c, "scanreg kernels");
     if (rc) return rc;
     b->registered = true;
@@ -218,23 +221,29 @@ extern "C" int lmono_timing_read(lmono_ctx *c, double *ms, int cap, int *n_scanr
 {
     if (!c || !ms) return LMONO_EINVAL;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    double sum[7] = { 0 };
+    double sum[12] = { 0 };
     int nr = 0, no = 0;
     float t;
     for (int i = 0; i < c->n_sets; i++) {
         const EvSet &s = c->sets[i];
         if (s.reg) {
             nr++;
-            if (hipEventElapsedTime(&t, s.e[0], s.e[5]) == hipSuccess) sum[0] += t;
-            for (int k = 0; k < 5; k++)
+            if (hipEventElapsedTime(&t, s.e[0], s.e[7]) == hipSuccess) sum[0] += t;
+            for (int k = 0; k < 7; k++)
                 if (hipEventElapsedTime(&t, s.e[k], s.e[k + 1]) == hipSuccess) sum[2 + k] += t;
         }
         if (s.odom) {
             no++;
-            if (hipEventElapsedTime(&t, s.e[6], s.e[7]) == hipSuccess) sum[1] += t;
+            if (hipEventElapsedTime(&t, s.e[8], s.e[9]) == hipSuccess) sum[1] += t;
+            for (int k = 0; k + 2 < s.n_kev; k += 3) {
+                if (k + 2 >= (int)s.kev.size()) break;
+                if (hipEventElapsedTime(&t, s.kev[k], s.kev[k + 1]) == hipSuccess) sum[9] += t;
+                if (hipEventElapsedTime(&t, s.kev[k + 1], s.kev[k + 2]) == hipSuccess) sum[10] += t;
+                sum[11] += 1.0;
+            }
         }
     }
-    for (int i = 0; i < cap && i < 7; i++) ms[i] = sum[i];
+    for (int i = 0; i < cap && i < 12; i++) ms[i] = sum[i];
     if (n_scanreg_calls) *n_scanreg_calls = nr;
     if (n_odom_calls) *n_odom_calls = no;
     return LMONO_OK;
@@ -327,17 +336,28 @@ extern "C" int lmono_odom_batch_d(lmono_ctx *c, lmono_scan_batch *b, int n_chain
     if (c->n_sets == 0 || c->sets[c->n_sets - 1].odom) c->ev = c->next_set();
     if (!c->ev) { c->err = "hipEventCreate failed"; return LMONO_ENODEV; }
     c->sets[c->n_sets - 1].odom = true;
-    HIP_TRY(c, hipEventRecord(c->ev[6], st));
+    HIP_TRY(c, hipEventRecord(c->ev[8], st));
     const int ninit = n > n_chains ? n : n_chains;
     hipLaunchKernelGGL(k_odom_init, dim3((ninit + 255) / 256), dim3(256), 0, st, o);
+    EvSet &es = c->sets[c->n_sets - 1];
+    auto kev = [&](int i) -> hipEvent_t {
+        while ((int)es.kev.size() <= i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; es.kev.push_back(e); }
+        return es.kev[i];
+    };
+    int ne = 0;
     for (int step = 0; step < max_steps; step++) {
         for (int outer = 0; outer < 2; outer++) {
+            hipEvent_t e0 = kev(ne), e1 = kev(ne + 1), e2 = kev(ne + 2);
+            if (e0 && e1 && e2) (void)hipEventRecord(e0, st);
             hipLaunchKernelGGL(k_correspond, dim3(8 * ((n_chains + 7) / 8) * kCorrBlocks), dim3(256), 0, st, b->v, o, step);
+            if (e0 && e1 && e2) (void)hipEventRecord(e1, st);
             hipLaunchKernelGGL(k_lm_solve, dim3(n_chains), dim3(256), 0, st, b->v, o, step, outer);
+            if (e0 && e1 && e2) { (void)hipEventRecord(e2, st); ne += 3; }
         }
     }
+    es.n_kev = ne;
     hipLaunchKernelGGL(k_pose_prefix, dim3(1), dim3(64), 0, st, (const double *)b->incr, b->poses, 0, n);
-    HIP_TRY(c, hipEventRecord(c->ev[7], st));
+    HIP_TRY(c, hipEventRecord(c->ev[9], st));
     rc = check_launch(c, "odometry kernels");
     if (rc) return rc;
     if (incr_d) HIP_TRY(c, hipMemcpyAsync(incr_d, b->incr, sizeof(double) * 7 * n, hipMemcpyDeviceToDevice, st));

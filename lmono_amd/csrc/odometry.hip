@@ -79,27 +79,26 @@ __global__ __launch_bounds__(1024) void k_grid_build(BatchView b)
         rank_of[i] = atomicAdd(&cell[sl].cnt, 1);
     }
     __syncthreads();
-    // exclusive prefix over the table counts (read with agent-scope atomic loads: the counts were produced by atomics)
-    __shared__ int s_part[1024];
-    const int chunk = T / 1024;
-    int local = 0;
-    for (int i = 0; i < chunk; i++) local += __hip_atomic_load(&cell[tid * chunk + i].cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_part[tid] = local;
+    // The counts were produced by L2 atomics: invalidate this CU's L1 once (agent-scope acquire), then read them with
+    // plain coalesced loads.  Exclusive prefix over the table in tiles of 1024 cells (wave scan + cross-wave carry).
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __shared__ int s_wsum[16];
+    __shared__ int s_carry;
+    if (tid == 0) s_carry = 0;
     __syncthreads();
-    // Hillis-Steele inclusive scan over 1024 partials
-    for (int o = 1; o < 1024; o <<= 1) {
-        const int v = tid >= o ? s_part[tid - o] : 0;
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int t0 = 0; t0 < T; t0 += 1024) {
+        const int c = cell[t0 + tid].cnt;
+        const int incl = wave_scan_incl(c);
+        if (lane == 63) s_wsum[wave] = incl;
         __syncthreads();
-        s_part[tid] += v;
+        int base = s_carry;
+        for (int w = 0; w < wave; w++) base += s_wsum[w];
+        cell[t0 + tid].start = base + incl - c;
+        __syncthreads();
+        if (tid == 1023) s_carry = base + incl;
         __syncthreads();
     }
-    int run = s_part[tid] - local;
-    for (int i = 0; i < chunk; i++) {
-        const int c = __hip_atomic_load(&cell[tid * chunk + i].cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        cell[tid * chunk + i].start = run;
-        run += c;
-    }
-    __syncthreads();
     for (int i = tid; i < n; i += 1024) {
         const float4 p = src[i];
         const int ln = (int)p.w;
