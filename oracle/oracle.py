@@ -256,3 +256,49 @@ def factor_eval(kind, params, consts, info, want_jac=True):
     if rc != 0:
         raise RuntimeError("lo_factor_eval failed")
     return r, J
+
+
+# --------------------------------------------------------------------------------------------
+# BA window solve (oracle/lo_ba_solve.c)
+# --------------------------------------------------------------------------------------------
+class BaProblemC(C.Structure):
+    _fields_ = [("n_poses", C.c_int), ("n_feat", C.c_int), ("n_obs", C.c_int),
+                ("use_prior", C.c_int), ("ex_constant", C.c_int), ("use_mono", C.c_int), ("max_iter", C.c_int),
+                ("poses", C.POINTER(C.c_double)), ("ex", C.POINTER(C.c_double)), ("inv_depth", C.POINTER(C.c_double)),
+                ("obs_feat", C.POINTER(C.c_int32)), ("obs_i", C.POINTER(C.c_int32)), ("obs_j", C.POINTER(C.c_int32)),
+                ("obs_pts", C.POINTER(C.c_double)), ("laser_consts", C.POINTER(C.c_double)),
+                ("laser_info", C.POINTER(C.c_double)), ("mono_info", C.POINTER(C.c_double)),
+                ("prior_T", C.POINTER(C.c_double)), ("prior_w", C.POINTER(C.c_double))]
+
+
+class BaSummary(C.Structure):
+    _fields_ = [("initial_cost", C.c_double), ("final_cost", C.c_double), ("iterations", C.c_int), ("termination", C.c_int),
+                ("n_successful", C.c_int), ("n_unsuccessful", C.c_int)]
+
+
+def ba_solve(w, max_iter=30):
+    """w: dict from tests/ba_cases.make_window().  Returns (poses, ex, inv_depth, summary) without touching w."""
+    poses = np.ascontiguousarray(w["poses"], np.float64).copy()
+    ex = np.ascontiguousarray(w["ex"], np.float64).copy()
+    invd = np.ascontiguousarray(w["inv_depth"], np.float64).copy()
+    keep = [np.ascontiguousarray(w[k], np.int32) for k in ("obs_feat", "obs_i", "obs_j")]
+    pts = np.ascontiguousarray(w["obs_pts"], np.float64)
+    lc = np.ascontiguousarray(w["laser_consts"], np.float64)
+    li = np.ascontiguousarray(w["laser_info"], np.float64); mi = np.ascontiguousarray(w["mono_info"], np.float64)
+    pT = np.ascontiguousarray(w["prior_T"], np.float64); pw = np.ascontiguousarray(w["prior_w"], np.float64)
+    p = BaProblemC(len(poses), len(invd), len(keep[0]), int(w["use_prior"]), int(w["ex_constant"]), int(w["use_mono"]), max_iter,
+                   _fp(poses, C.c_double), _fp(ex, C.c_double), _fp(invd, C.c_double),
+                   _fp(keep[0], C.c_int32), _fp(keep[1], C.c_int32), _fp(keep[2], C.c_int32),
+                   _fp(pts, C.c_double), _fp(lc, C.c_double), _fp(li, C.c_double), _fp(mi, C.c_double), _fp(pT, C.c_double), _fp(pw, C.c_double))
+    sm = BaSummary()
+    lib().lo_ba_solve(C.byref(p), C.byref(sm))
+    return poses, ex, invd, sm
+
+
+def ba_reanchor(poses, R0_before, P0_before):
+    poses = np.ascontiguousarray(poses, np.float64)
+    n = len(poses)
+    R = np.zeros((n, 9)); P = np.zeros((n, 3))
+    R0 = np.ascontiguousarray(R0_before, np.float64); P0 = np.ascontiguousarray(P0_before, np.float64)
+    lib().lo_ba_reanchor(_fp(poses, C.c_double), C.c_int(n), _fp(R0, C.c_double), _fp(P0, C.c_double), _fp(R, C.c_double), _fp(P, C.c_double))
+    return R.reshape(n, 3, 3), P
