@@ -100,6 +100,38 @@ int lmono_factor_eval(lmono_ctx *, int kind, int count, const double *params_h, 
 int lmono_factor_eval_d(lmono_ctx *, int kind, int count, const double *params_d, const double *consts_d,
                         const double *info_d, double *r_d, double *J_d);
 
+/* ---- lmono sliding-window BA: Estimator::optimization()'s solve, batched over independent windows ------------ *
+ * Reference interface: Estimator::optimization() -> ceres::Solve(DENSE_SCHUR, DOGLEG, max_num_iterations = NUM_ITERATIONS)
+ * (mono_lidar_mapping/src/image_process/Estimator.cc:1124-1305) over para_pose[11][7], para_ex[1][7],
+ * para_depth_inv[F][1] (Estimator.h:255-257) with PriorFactor / LASERFactor / MonoProjectionFactor+CauchyLoss(1).
+ * A window depends on its predecessor, so a batch holds windows of independent sequences.  All arrays are host
+ * pointers; lmono_ba_batch_create copies them into HBM once, lmono_ba_solve runs one workgroup per window.     */
+typedef struct lmono_ba_batch lmono_ba_batch;
+typedef struct {
+    int n_windows;
+    const int *feat_off;        /* [n_windows+1] features (inverse-depth blocks) of each window                     */
+    const int *obs_off;         /* [n_windows+1] MonoProjectionFactor blocks of each window                         */
+    const int *flags;           /* [n_windows][4] n_poses (= frame_count+1 <= 11), use_prior, ex_constant, use_mono   */
+    const double *poses;        /* [n_windows][11][7] para_pose, x y z qx qy qz qw                                  */
+    const double *ex;           /* [n_windows][7] para_ex                                                           */
+    const double *inv_depth;    /* [feat_off[n]] para_depth_inv                                                     */
+    const int *obs_feat;        /* [obs_off[n]] window-local feature index; blocks grouped by feature, ascending     */
+    const int *obs_i, *obs_j;   /* anchor frame (start_frame) and observing frame of each block                     */
+    const double *obs_pts;      /* [obs_off[n]][4] pt_i.xy, pt_j.xy (normalised image coordinates)                 */
+    const double *laser_consts; /* [n_windows][10][24] L0_Ri, L0_Rj, L0_Pi, L0_Pj of consecutive frames             */
+    const double *prior_T;      /* [n_windows][16] prior_trans = TLC[0] at solve time (Estimator.cc:1155-1160)       */
+    const double *laser_info;   /* [36] LASERFactor::sqrt_info; mono_info [4] MonoProjectionFactor::sqrt_info;      */
+    const double *mono_info;
+    const double *prior_w;      /* [2] PRIOR_T, PRIOR_R                                                             */
+} lmono_ba_desc;
+lmono_ba_batch *lmono_ba_batch_create(lmono_ctx *, const lmono_ba_desc *);
+void            lmono_ba_batch_destroy(lmono_ba_batch *);
+int lmono_ba_solve(lmono_ctx *, lmono_ba_batch *, int max_iterations);   /* asynchronous on the context stream    */
+int lmono_ba_batch_reset(lmono_ctx *, lmono_ba_batch *);                 /* restore the state given at creation   */
+/* poses_h [n][11][7], ex_h [n][7], inv_depth_h [F total], summary_h [n][6] = initial_cost, final_cost, iterations,
+ * termination (0 CONVERGENCE, 1 NO_CONVERGENCE, 2 FAILURE), successful steps, unsuccessful steps; any may be NULL */
+int lmono_ba_batch_read(lmono_ctx *, lmono_ba_batch *, double *poses_h, double *ex_h, double *inv_depth_h, double *summary_h);
+
 /* ---- pose composition (laserOdometry: t_w_curr += q_w_curr * t_last_curr; q_w_curr *= q_last_curr) ------- *
  * lmono_pose_prefix_d: poses_d[k - first] = incr[first] (+) ... (+) incr[k] for k in [first, n) (incr[0] is the
  * identity: first = 0 gives poses relative to scan 0, first > 0 poses relative to scan first-1).  lmono_pose_rebase_d: poses[k] <- bases[0] (+) ... (+) bases[n_bases-1] (+) poses[k]; with scans

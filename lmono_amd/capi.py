@@ -13,6 +13,7 @@ SYMBOLS = [
     "lmono_batch_create", "lmono_batch_destroy", "lmono_scanreg_batch", "lmono_batch_counts", "lmono_batch_get_cloud",
     "lmono_batch_get_curvature", "lmono_odom_batch", "lmono_odom_batch_d", "lmono_odom_correspond", "lmono_timing_reset", "lmono_timing_read",
     "lmono_pose_prefix_d", "lmono_pose_rebase_d", "lmono_factor_eval", "lmono_factor_eval_d",
+    "lmono_ba_batch_create", "lmono_ba_batch_destroy", "lmono_ba_solve", "lmono_ba_batch_reset", "lmono_ba_batch_read",
 ]
 
 
@@ -54,6 +55,12 @@ def load_library():
     L.lmono_odom_batch_d.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.lmono_odom_correspond.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.lmono_timing_reset.argtypes = [C.c_void_p]
+    L.lmono_ba_batch_create.restype = C.c_void_p
+    L.lmono_ba_batch_create.argtypes = [C.c_void_p, C.c_void_p]
+    L.lmono_ba_batch_destroy.argtypes = [C.c_void_p]
+    L.lmono_ba_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.lmono_ba_batch_reset.argtypes = [C.c_void_p, C.c_void_p]
+    L.lmono_ba_batch_read.argtypes = [C.c_void_p] * 6
     L.lmono_factor_eval.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
     L.lmono_factor_eval_d.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
     L.lmono_pose_prefix_d.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
@@ -186,6 +193,69 @@ class ScanBatch:
     def close(self):
         if self.h:
             self.ctx.L.lmono_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BaDesc(C.Structure):
+    _fields_ = [("n_windows", C.c_int), ("feat_off", C.c_void_p), ("obs_off", C.c_void_p), ("flags", C.c_void_p),
+                ("poses", C.c_void_p), ("ex", C.c_void_p), ("inv_depth", C.c_void_p), ("obs_feat", C.c_void_p),
+                ("obs_i", C.c_void_p), ("obs_j", C.c_void_p), ("obs_pts", C.c_void_p), ("laser_consts", C.c_void_p),
+                ("prior_T", C.c_void_p), ("laser_info", C.c_void_p), ("mono_info", C.c_void_p), ("prior_w", C.c_void_p)]
+
+
+class BaBatch:
+    """Batch of independent BA windows resident in HBM (lmono_ba_batch).  `windows`: list of dicts with the keys of
+    tests/ba_cases.make_window (poses [n,7], ex, inv_depth, obs_feat/obs_i/obs_j, obs_pts, laser_consts, prior_T, flags)."""
+
+    def __init__(self, ctx, windows):
+        self.ctx = ctx
+        W = len(windows)
+        self.W = W
+        self.n_poses = [len(w["poses"]) for w in windows]
+        feat_off = np.concatenate([[0], np.cumsum([len(w["inv_depth"]) for w in windows])]).astype(np.int32)
+        obs_off = np.concatenate([[0], np.cumsum([len(w["obs_feat"]) for w in windows])]).astype(np.int32)
+        flags = np.array([[len(w["poses"]), int(w["use_prior"]), int(w["ex_constant"]), int(w["use_mono"])] for w in windows], np.int32)
+        poses = np.zeros((W, 11, 7)); poses[:, :, 6] = 1.0
+        laser = np.zeros((W, 10, 24))
+        for k, w in enumerate(windows):
+            poses[k, :len(w["poses"])] = w["poses"]
+            laser[k, :len(w["laser_consts"])] = w["laser_consts"]
+        cat = lambda key, dt: np.ascontiguousarray(np.concatenate([np.asarray(w[key], dt).reshape(len(w[key]), -1) for w in windows]).ravel(), dt)
+        self._keep = dict(feat_off=feat_off, obs_off=obs_off, flags=flags, poses=poses,
+                          ex=np.ascontiguousarray([w["ex"] for w in windows], np.float64), inv_depth=cat("inv_depth", np.float64),
+                          obs_feat=cat("obs_feat", np.int32), obs_i=cat("obs_i", np.int32), obs_j=cat("obs_j", np.int32),
+                          obs_pts=cat("obs_pts", np.float64), laser=laser,
+                          prior=np.ascontiguousarray([np.asarray(w["prior_T"]).ravel() for w in windows], np.float64),
+                          li=np.ascontiguousarray(windows[0]["laser_info"], np.float64), mi=np.ascontiguousarray(windows[0]["mono_info"], np.float64),
+                          pw=np.ascontiguousarray(windows[0]["prior_w"], np.float64))
+        k = self._keep
+        d = BaDesc(W, *[k[n].ctypes.data for n in ("feat_off", "obs_off", "flags", "poses", "ex", "inv_depth", "obs_feat", "obs_i",
+                                                    "obs_j", "obs_pts", "laser", "prior", "li", "mi", "pw")])
+        self.feat_off = feat_off
+        self.h = ctx.L.lmono_ba_batch_create(ctx.h, C.byref(d))
+        if not self.h:
+            raise LmonoError("lmono_ba_batch_create failed: %s" % ctx.L.lmono_last_error(ctx.h).decode())
+
+    def solve(self, max_iter=30):
+        self.ctx.check(self.ctx.L.lmono_ba_solve(self.ctx.h, self.h, max_iter))
+
+    def reset(self):
+        self.ctx.check(self.ctx.L.lmono_ba_batch_reset(self.ctx.h, self.h))
+
+    def read(self):
+        poses = np.zeros((self.W, 11, 7)); ex = np.zeros((self.W, 7)); invd = np.zeros(int(self.feat_off[-1])); sm = np.zeros((self.W, 6))
+        self.ctx.check(self.ctx.L.lmono_ba_batch_read(self.ctx.h, self.h, poses.ctypes.data, ex.ctypes.data, invd.ctypes.data, sm.ctypes.data))
+        return poses, ex, invd, sm
+
+    def close(self):
+        if self.h:
+            self.ctx.L.lmono_ba_batch_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -3,6 +3,7 @@
 #include "frontend.hip"
 #include "odometry.hip"
 #include "ba.hip"
+#include "ba_solve.hip"
 
 #include <string>
 #include <vector>
@@ -454,4 +455,121 @@ extern "C" int lmono_factor_eval(lmono_ctx *c, int kind, int count, const double
 #undef TRYF
     cleanup();
     return rc;
+}
+
+// ---- BA window solve ---------------------------------------------------------------------------------------------
+struct lmono_ba_batch {
+    lmono_ctx *ctx = nullptr;
+    std::vector<void *> allocs;
+    BaBatch v{};
+    int n_windows = 0, total_feat = 0, total_obs = 0;
+    double *poses0 = nullptr, *ex0 = nullptr, *invd0 = nullptr;   // initial state for lmono_ba_batch_reset
+};
+
+template <typename T>
+static bool ba_upload(lmono_ba_batch *b, T *&dst, const T *src, size_t count)
+{
+    void *q = nullptr;
+    if (hipMalloc(&q, (count > 0 ? count : 1) * sizeof(T)) != hipSuccess) return false;
+    b->allocs.push_back(q);
+    dst = (T *)q;
+    if (src && count > 0 && hipMemcpy(q, src, count * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return false;
+    return true;
+}
+
+extern "C" void lmono_ba_batch_destroy(lmono_ba_batch *b)
+{
+    if (!b) return;
+    for (void *p : b->allocs) (void)hipFree(p);
+    delete b;
+}
+
+extern "C" lmono_ba_batch *lmono_ba_batch_create(lmono_ctx *c, const lmono_ba_desc *d)
+{
+    if (!c || !d || d->n_windows <= 0 || !d->feat_off || !d->obs_off || !d->flags || !d->poses || !d->ex) return nullptr;
+    if (hipSetDevice(c->device) != hipSuccess) return nullptr;
+    const int W = d->n_windows;
+    const int TF = d->feat_off[W], TO = d->obs_off[W];
+    for (int w = 0; w < W; w++) {
+        if (d->feat_off[w + 1] - d->feat_off[w] > kBaMaxFeat) { c->err = "lmono_ba_batch_create: more than 448 features in a window"; return nullptr; }
+        if (d->flags[4 * w] < 2 || d->flags[4 * w] > kBaMaxPoses) { c->err = "lmono_ba_batch_create: n_poses must be 2..11"; return nullptr; }
+    }
+    // first observation of every feature: observations must be grouped by (window, feature) in ascending order
+    std::vector<int> fo((size_t)TF + 1, 0);
+    {
+        int o = 0;
+        for (int w = 0; w < W; w++) {
+            const int f0 = d->feat_off[w], f1 = d->feat_off[w + 1], oe = d->obs_off[w + 1];
+            o = d->obs_off[w];
+            for (int f = f0; f < f1; f++) {
+                fo[f] = o;
+                while (o < oe && d->obs_feat[o] == f - f0) {
+                    const int np = d->flags[4 * w];
+                    if (d->obs_i[o] < 0 || d->obs_i[o] >= np || d->obs_j[o] < 0 || d->obs_j[o] >= np || d->obs_i[o] == d->obs_j[o]) { c->err = "lmono_ba_batch_create: bad observation frame"; return nullptr; }
+                    o++;
+                }
+            }
+            if (o != oe) { c->err = "lmono_ba_batch_create: observations are not grouped by feature"; return nullptr; }
+        }
+        fo[TF] = TO;
+    }
+    lmono_ba_batch *b = new lmono_ba_batch();
+    b->ctx = c; b->n_windows = W; b->total_feat = TF; b->total_obs = TO;
+    BaBatch &v = b->v;
+    v.n_windows = W; v.max_iter = 30;
+    double info[42];
+    memcpy(info, d->laser_info, 36 * sizeof(double)); memcpy(info + 36, d->mono_info, 4 * sizeof(double)); memcpy(info + 40, d->prior_w, 2 * sizeof(double));
+    int *feat_off = nullptr, *obs_off = nullptr, *flags = nullptr, *obs_feat = nullptr, *obs_i = nullptr, *obs_j = nullptr, *fobs = nullptr;
+    double *obs_pts = nullptr, *laser = nullptr, *prior = nullptr, *infod = nullptr;
+    bool ok = ba_upload(b, feat_off, d->feat_off, (size_t)W + 1) && ba_upload(b, obs_off, d->obs_off, (size_t)W + 1) &&
+              ba_upload(b, flags, d->flags, (size_t)W * 4) && ba_upload(b, v.poses, d->poses, (size_t)W * kBaMaxPoses * 7) &&
+              ba_upload(b, v.ex, d->ex, (size_t)W * 7) && ba_upload(b, v.inv_depth, d->inv_depth, (size_t)TF) &&
+              ba_upload(b, obs_feat, d->obs_feat, (size_t)TO) && ba_upload(b, obs_i, d->obs_i, (size_t)TO) && ba_upload(b, obs_j, d->obs_j, (size_t)TO) &&
+              ba_upload(b, obs_pts, d->obs_pts, (size_t)TO * 4) && ba_upload(b, fobs, fo.data(), (size_t)TF + 1) &&
+              ba_upload(b, laser, d->laser_consts, (size_t)W * 10 * 24) && ba_upload(b, prior, d->prior_T, (size_t)W * 16) &&
+              ba_upload(b, infod, info, (size_t)42) &&
+              ba_upload(b, b->poses0, d->poses, (size_t)W * kBaMaxPoses * 7) && ba_upload(b, b->ex0, d->ex, (size_t)W * 7) &&
+              ba_upload(b, b->invd0, d->inv_depth, (size_t)TF) &&
+              ba_upload(b, v.hpd, (const double *)nullptr, (size_t)W * kBaP * kBaMaxFeat) &&
+              ba_upload(b, v.cand, (const double *)nullptr, (size_t)W * kBaMaxFeat) && ba_upload(b, v.summary, (const double *)nullptr, (size_t)W * 6);
+    if (!ok) { c->err = "lmono_ba_batch_create: device allocation / upload failed"; lmono_ba_batch_destroy(b); return nullptr; }
+    v.feat_off = feat_off; v.obs_off = obs_off; v.flags = flags; v.obs_feat = obs_feat; v.obs_i = obs_i; v.obs_j = obs_j;
+    v.obs_pts = obs_pts; v.feat_obs_off = fobs; v.laser_consts = laser; v.prior_T = prior; v.info = infod;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)k_ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BaLds)) != hipSuccess) {
+            c->err = "k_ba_solve: cannot reserve LDS"; lmono_ba_batch_destroy(b); return nullptr;
+        }
+        attr_set = true;
+    }
+    return b;
+}
+
+extern "C" int lmono_ba_solve(lmono_ctx *c, lmono_ba_batch *b, int max_iterations)
+{
+    if (!c || !b || max_iterations < 0) return LMONO_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    b->v.max_iter = max_iterations;
+    hipLaunchKernelGGL(k_ba_solve, dim3(b->n_windows), dim3(256), sizeof(BaLds), c->stream, b->v);
+    return check_launch(c, "k_ba_solve");
+}
+
+extern "C" int lmono_ba_batch_reset(lmono_ctx *c, lmono_ba_batch *b)
+{
+    if (!c || !b) return LMONO_EINVAL;
+    HIP_TRY(c, hipMemcpyAsync(b->v.poses, b->poses0, sizeof(double) * (size_t)b->n_windows * kBaMaxPoses * 7, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(b->v.ex, b->ex0, sizeof(double) * (size_t)b->n_windows * 7, hipMemcpyDeviceToDevice, c->stream));
+    if (b->total_feat > 0) HIP_TRY(c, hipMemcpyAsync(b->v.inv_depth, b->invd0, sizeof(double) * (size_t)b->total_feat, hipMemcpyDeviceToDevice, c->stream));
+    return LMONO_OK;
+}
+
+extern "C" int lmono_ba_batch_read(lmono_ctx *c, lmono_ba_batch *b, double *poses_h, double *ex_h, double *inv_depth_h, double *summary_h)
+{
+    if (!c || !b) return LMONO_EINVAL;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (poses_h) HIP_TRY(c, hipMemcpy(poses_h, b->v.poses, sizeof(double) * (size_t)b->n_windows * kBaMaxPoses * 7, hipMemcpyDeviceToHost));
+    if (ex_h) HIP_TRY(c, hipMemcpy(ex_h, b->v.ex, sizeof(double) * (size_t)b->n_windows * 7, hipMemcpyDeviceToHost));
+    if (inv_depth_h && b->total_feat > 0) HIP_TRY(c, hipMemcpy(inv_depth_h, b->v.inv_depth, sizeof(double) * (size_t)b->total_feat, hipMemcpyDeviceToHost));
+    if (summary_h) HIP_TRY(c, hipMemcpy(summary_h, b->v.summary, sizeof(double) * (size_t)b->n_windows * 6, hipMemcpyDeviceToHost));
+    return LMONO_OK;
 }

@@ -1,0 +1,60 @@
+"""k_ba_solve (through the C ABI) against the CPU restatement of Estimator::optimization()'s solve."""
+import numpy as np
+import pytest
+
+from tests import ba_cases as K
+
+pytestmark = pytest.mark.gpu
+
+
+def _solve_gpu(gpu_ctx, windows, max_iter=30):
+    import lmono_amd
+    b = lmono_amd.BaBatch(gpu_ctx, windows)
+    b.solve(max_iter)
+    return b, b.read()
+
+
+def test_batch_of_windows_matches_oracle(oracle, gpu_ctx):
+    windows = [K.make_window(s) for s in range(6)]
+    windows[4]["use_mono"] = False          # static_status
+    windows[5]["ex_constant"] = True        # ESTIMATE_LASER == 0
+    windows.append(K.make_window(7, n_frames=6))   # window still filling up (frame_count < WINDOW_SIZE)
+    b, (poses, ex, invd, sm) = _solve_gpu(gpu_ctx, windows)
+    for k, w in enumerate(windows):
+        rp, re, rd, rs = oracle.ba_solve(w)
+        n = len(w["poses"])
+        assert abs(sm[k, 0] - rs.initial_cost) <= 1e-9 * rs.initial_cost
+        # same algorithm in fp64 with a different summation order: converged states agree far below the
+        # 1e-6 m / 1e-7 rad bound of SURVEY.md 8c
+        assert abs(sm[k, 1] - rs.final_cost) <= 1e-6 * rs.final_cost + 1e-9
+        assert int(sm[k, 2]) == rs.iterations and int(sm[k, 3]) == rs.termination
+        R1, P1 = oracle.ba_reanchor(poses[k, :n], w["gt_Rs"][0], w["gt_Ps"][0])
+        R2, P2 = oracle.ba_reanchor(rp, w["gt_Rs"][0], w["gt_Ps"][0])
+        assert np.abs(P1 - P2).max() < 1e-6 and np.abs(R1 - R2).max() < 1e-7
+        assert np.abs(ex[k] - re).max() < 1e-6
+        if w["use_mono"]:
+            f0, f1 = b.feat_off[k], b.feat_off[k + 1]
+            assert np.abs(invd[f0:f1] - rd).max() < 1e-6
+
+
+def test_reset_and_resolve_is_repeatable(oracle, gpu_ctx):
+    windows = [K.make_window(s) for s in (10, 11)]
+    b, first = _solve_gpu(gpu_ctx, windows)
+    b.reset(); b.solve(30)
+    second = b.read()
+    # LDS atomics make the summation order vary run to run, and the problem has a free 6-DoF gauge (no block is held
+    # constant, Estimator.cc:1150): compare the gauge-fixed (re-anchored, double2Matrix) poses, equal to rounding
+    for k, w in enumerate(windows):
+        R1, P1 = oracle.ba_reanchor(first[0][k], w["gt_Rs"][0], w["gt_Ps"][0])
+        R2, P2 = oracle.ba_reanchor(second[0][k], w["gt_Rs"][0], w["gt_Ps"][0])
+        assert np.abs(P1 - P2).max() < 1e-7 and np.abs(R1 - R2).max() < 1e-8
+    assert np.abs(first[3][:, 1] - second[3][:, 1]).max() < 1e-6 * first[3][:, 1].max()
+
+
+def test_large_batch_cost_decreases_everywhere(gpu_ctx):
+    """256 windows (one per CU): a property check at bench scale -- every window's cost drops by > 1000x."""
+    base = [K.make_window(s, n_landmarks=2500) for s in range(8)]
+    windows = [base[k % 8] for k in range(256)]
+    b, (poses, ex, invd, sm) = _solve_gpu(gpu_ctx, windows)
+    assert (sm[:, 1] < 1e-3 * sm[:, 0]).all() and (sm[:, 3] <= 1).all()
+    assert np.abs(np.linalg.norm(poses[:, :, 3:], axis=2) - 1).max() < 1e-12
