@@ -21,6 +21,51 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def bench_ba(args):
+    """Secondary workload (BASELINE configs[2] shape): batched Estimator::optimization() solves, S2 synthetic windows
+    (KITTI-05 intrinsics / extrinsic / weights, <=150 tracks per frame).  One step = every window solved once from its
+    initial state (<= 30 dogleg iterations).  Reported separately from the headline scans/s."""
+    import torch
+    import lmono_amd
+    from oracle import oracle as O
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from tests import ba_cases as K
+    assert torch.cuda.is_available()
+    ctx = lmono_amd.Context(0)
+    base = [K.make_window(s) for s in range(16)]
+    windows = [base[k % len(base)] for k in range(args.windows)]
+    b = lmono_amd.BaBatch(ctx, windows)
+    for _ in range(args.warmup):
+        b.reset(); b.solve(30)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        b.reset(); b.solve(30)
+    ctx.synchronize()
+    el = time.perf_counter() - t0
+    poses, ex, invd, sm = b.read()
+    t0 = time.time()
+    ref = [O.ba_solve(w) for w in base]
+    cpu_s = (time.time() - t0) / len(base)
+    n_obs = float(np.mean([len(w["obs_feat"]) for w in base])); n_f = float(np.mean([len(w["inv_depth"]) for w in base]))
+    iters = float(sm[:, 2].mean())
+    # SURVEY 8d: (44 O + 8 F + 42 k) B per iteration
+    alg = (44 * n_obs + 8 * n_f + 42e3) * iters
+    ms = el / args.steps * 1e3
+    out = {"metric": "BA window solves/sec (Estimator::optimization, S2 synthetic)", "value": round(args.windows * args.steps / el, 1),
+           "unit": "windows/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "S2 11-frame windows, %d independent windows" % args.windows, "mean_obs": n_obs, "mean_features": n_f,
+                      "mean_iterations": iters},
+           "roofline": {"bound": "hbm", "kernel": "k_ba_solve", "achieved": round(alg * args.windows / (ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(alg * args.windows / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
+                        "note": "72x72 reduced system per workgroup: latency-bound by design (SURVEY 8d), MFMA not used"},
+           "cpu_baseline": {"value": round(1.0 / cpu_s, 2), "unit": "windows/s", "cores": 1, "kind": "port",
+                            "sample": "16 windows, oracle/lo_ba_solve.c (-O3), 1 thread"},
+           "final_cost_rel_diff_vs_cpu": float(max(abs(sm[k, 1] - ref[k][3].final_cost) / ref[k][3].final_cost for k in range(len(base))))}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -31,7 +76,12 @@ def main():
     ap.add_argument("--lead", type=int, default=5, help="lead-in scans of a chain that does not start at scan 0")
     ap.add_argument("--az", type=int, default=2000, help="azimuth steps per ring (2000 = HDL-64 at 10 Hz)")
     ap.add_argument("--cpu-sample", type=int, default=384, help="scans of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--workload", default="lidar", choices=["lidar", "ba"],
+                    help="lidar = headline (BASELINE configs[1]); ba = configs[2]-shaped sliding-window BA solves (secondary)")
+    ap.add_argument("--windows", type=int, default=1024, help="ba: independent windows per GPU")
     args = ap.parse_args()
+    if args.workload == "ba":
+        return bench_ba(args)
 
     import torch
     import torch.distributed as dist

@@ -132,6 +132,25 @@ int lmono_ba_batch_reset(lmono_ctx *, lmono_ba_batch *);                 /* rest
  * termination (0 CONVERGENCE, 1 NO_CONVERGENCE, 2 FAILURE), successful steps, unsuccessful steps; any may be NULL */
 int lmono_ba_batch_read(lmono_ctx *, lmono_ba_batch *, double *poses_h, double *ex_h, double *inv_depth_h, double *summary_h);
 
+/* ---- per-feature numerics of FeatureManager / Estimator (batched over windows; host arrays) ---------------- *
+ * lmono_triangulate: FeatureManager::triangulate (src/image_process/FeatureManager.cc:75-255): linear multi-view
+ *   triangulation of every track with estimated_depth <= 0 and >= track_cnt observations, then (refine_max_iter >= 0)
+ *   the joint 1-D Ceres refinement with ReprojectionFactor + CauchyLoss(1) and setDepth()'s solve_flag (1 ok, 2 failed).
+ *   Rs_h [n][11][9], Ps_h [n][11][3] (row-major), tlc_h [n][16]; track f of a window starts at start_frame[f] and owns the
+ *   normalised points pts[obs_off[f] .. obs_off[f+1]) (first one = anchor); depth_h in/out.
+ * lmono_outlier_scores: Estimator::outliersRejection's statistic FACTOR_WEIGHT * mean reprojection error
+ *   (src/image_process/Estimator.cc:104-190); -1 for tracks shorter than track_cnt.
+ * lmono_shift_depth: FeatureManager::removeBackShiftDepth as called by Estimator::slideWindowOld
+ *   (FeatureManager.cc:540-590, Estimator.cc:744-763) for the tracks anchored at the dropped frame.               */
+int lmono_triangulate(lmono_ctx *, int n_windows, const int *feat_off_h, const double *Rs_h, const double *Ps_h, const double *tlc_h,
+                      const int *start_frame_h, const int *obs_off_h, const double *pts_h, double *depth_h, int *solve_flag_h,
+                      int track_cnt, int window_size, double factor_weight, int refine_max_iter);
+int lmono_outlier_scores(lmono_ctx *, int n_windows, const int *feat_off_h, const double *Rs_h, const double *Ps_h, const double *tlc_h,
+                         const int *start_frame_h, const int *obs_off_h, const double *pts_h, const double *depth_h,
+                         int track_cnt, double factor_weight, double *score_h);
+int lmono_shift_depth(lmono_ctx *, const double *back_R0, const double *back_P0, const double *R1, const double *P1, const double *tlc,
+                      int n, const double *pt_i_h, const double *depth_h, double *depth_out_h);
+
 /* ---- pose composition (laserOdometry: t_w_curr += q_w_curr * t_last_curr; q_w_curr *= q_last_curr) ------- *
  * lmono_pose_prefix_d: poses_d[k - first] = incr[first] (+) ... (+) incr[k] for k in [first, n) (incr[0] is the
  * identity: first = 0 gives poses relative to scan 0, first > 0 poses relative to scan first-1).  lmono_pose_rebase_d: poses[k] <- bases[0] (+) ... (+) bases[n_bases-1] (+) poses[k]; with scans

@@ -13,7 +13,7 @@ SYMBOLS = [
     "lmono_batch_create", "lmono_batch_destroy", "lmono_scanreg_batch", "lmono_batch_counts", "lmono_batch_get_cloud",
     "lmono_batch_get_curvature", "lmono_odom_batch", "lmono_odom_batch_d", "lmono_odom_correspond", "lmono_timing_reset", "lmono_timing_read",
     "lmono_pose_prefix_d", "lmono_pose_rebase_d", "lmono_factor_eval", "lmono_factor_eval_d",
-    "lmono_ba_batch_create", "lmono_ba_batch_destroy", "lmono_ba_solve", "lmono_ba_batch_reset", "lmono_ba_batch_read",
+    "lmono_triangulate", "lmono_outlier_scores", "lmono_shift_depth", "lmono_ba_batch_create", "lmono_ba_batch_destroy", "lmono_ba_solve", "lmono_ba_batch_reset", "lmono_ba_batch_read",
 ]
 
 
@@ -55,6 +55,9 @@ def load_library():
     L.lmono_odom_batch_d.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.lmono_odom_correspond.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.lmono_timing_reset.argtypes = [C.c_void_p]
+    L.lmono_triangulate.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 9 + [C.c_int, C.c_int, C.c_double, C.c_int]
+    L.lmono_outlier_scores.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_double, C.c_void_p]
+    L.lmono_shift_depth.argtypes = [C.c_void_p] * 6 + [C.c_int] + [C.c_void_p] * 3
     L.lmono_ba_batch_create.restype = C.c_void_p
     L.lmono_ba_batch_create.argtypes = [C.c_void_p, C.c_void_p]
     L.lmono_ba_batch_destroy.argtypes = [C.c_void_p]
@@ -120,6 +123,43 @@ class Context:
     def factor_eval_d(self, kind, count, params_ptr, consts_ptr, info_ptr, r_ptr, J_ptr=None):
         self.check(self.L.lmono_factor_eval_d(self.h, kind, count, C.c_void_p(params_ptr), C.c_void_p(consts_ptr),
                                               C.c_void_p(info_ptr), C.c_void_p(r_ptr), C.c_void_p(J_ptr or 0)))
+
+    @staticmethod
+    def _pack_windows(windows):
+        """windows: list of dicts(Rs [n,3,3], Ps [n,3], tlc 4x4, trk_start, trk_off, trk_pts)."""
+        W = len(windows)
+        Rs = np.zeros((W, 11, 9)); Ps = np.zeros((W, 11, 3))
+        for k, w in enumerate(windows):
+            n = len(w["Rs"]); Rs[k, :n] = np.asarray(w["Rs"]).reshape(n, 9); Ps[k, :n] = w["Ps"]
+        tlc = np.ascontiguousarray([np.asarray(w["tlc"]).ravel() for w in windows], np.float64)
+        feat_off = np.concatenate([[0], np.cumsum([len(w["trk_start"]) for w in windows])]).astype(np.int32)
+        start = np.ascontiguousarray(np.concatenate([w["trk_start"] for w in windows]), np.int32)
+        offs, base = [0], 0
+        for w in windows:
+            offs.extend((np.asarray(w["trk_off"][1:]) + base).tolist()); base += int(w["trk_off"][-1])
+        obs_off = np.array(offs, np.int32)
+        pts = np.ascontiguousarray(np.concatenate([np.asarray(w["trk_pts"]).reshape(-1, 2) for w in windows]), np.float64)
+        return W, feat_off, Rs, Ps, tlc, start, obs_off, pts
+
+    def triangulate(self, windows, depth, track_cnt=3, window_size=10, weight=1500.0, refine_iters=50):
+        W, feat_off, Rs, Ps, tlc, start, obs_off, pts = self._pack_windows(windows)
+        d = np.ascontiguousarray(depth, np.float64).copy(); flag = np.zeros(len(d), np.int32)
+        self.check(self.L.lmono_triangulate(self.h, W, feat_off.ctypes.data, Rs.ctypes.data, Ps.ctypes.data, tlc.ctypes.data, start.ctypes.data,
+                                            obs_off.ctypes.data, pts.ctypes.data, d.ctypes.data, flag.ctypes.data, track_cnt, window_size, weight, refine_iters))
+        return d, flag
+
+    def outlier_scores(self, windows, depth, track_cnt=3, weight=1500.0):
+        W, feat_off, Rs, Ps, tlc, start, obs_off, pts = self._pack_windows(windows)
+        d = np.ascontiguousarray(depth, np.float64); sc = np.zeros(len(d))
+        self.check(self.L.lmono_outlier_scores(self.h, W, feat_off.ctypes.data, Rs.ctypes.data, Ps.ctypes.data, tlc.ctypes.data, start.ctypes.data,
+                                               obs_off.ctypes.data, pts.ctypes.data, d.ctypes.data, track_cnt, weight, sc.ctypes.data))
+        return sc
+
+    def shift_depth(self, back_R0, back_P0, R1, P1, tlc, pt_i, depth):
+        a = [np.ascontiguousarray(v, np.float64).ravel() for v in (back_R0, back_P0, R1, P1, tlc)]
+        pt = np.ascontiguousarray(pt_i, np.float64).reshape(-1, 2); d = np.ascontiguousarray(depth, np.float64); out = np.zeros(len(d))
+        self.check(self.L.lmono_shift_depth(self.h, *[v.ctypes.data for v in a], len(d), pt.ctypes.data, d.ctypes.data, out.ctypes.data))
+        return out
 
     def pose_prefix_d(self, incr_ptr, first, n, poses_ptr):
         self.check(self.L.lmono_pose_prefix_d(self.h, C.c_void_p(incr_ptr), first, n, C.c_void_p(poses_ptr)))

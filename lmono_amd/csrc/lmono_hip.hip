@@ -4,6 +4,7 @@
 #include "odometry.hip"
 #include "ba.hip"
 #include "ba_solve.hip"
+#include "feat.hip"
 
 #include <string>
 #include <vector>
@@ -571,5 +572,99 @@ extern "C" int lmono_ba_batch_read(lmono_ctx *c, lmono_ba_batch *b, double *pose
     if (ex_h) HIP_TRY(c, hipMemcpy(ex_h, b->v.ex, sizeof(double) * (size_t)b->n_windows * 7, hipMemcpyDeviceToHost));
     if (inv_depth_h && b->total_feat > 0) HIP_TRY(c, hipMemcpy(inv_depth_h, b->v.inv_depth, sizeof(double) * (size_t)b->total_feat, hipMemcpyDeviceToHost));
     if (summary_h) HIP_TRY(c, hipMemcpy(summary_h, b->v.summary, sizeof(double) * (size_t)b->n_windows * 6, hipMemcpyDeviceToHost));
+    return LMONO_OK;
+}
+
+// ---- per-feature kernels (triangulation, depth refinement, outlier scores, depth shift) ---------------------------
+namespace {
+struct DevBuf {
+    std::vector<void *> p;
+    ~DevBuf() { for (void *q : p) (void)hipFree(q); }
+    template <typename T> T *up(const T *src, size_t n, bool &ok)
+    {
+        void *q = nullptr;
+        if (!ok || hipMalloc(&q, (n > 0 ? n : 1) * sizeof(T)) != hipSuccess) { ok = false; return nullptr; }
+        p.push_back(q);
+        if (src && n > 0 && hipMemcpy(q, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) ok = false;
+        return (T *)q;
+    }
+};
+}
+
+static int feat_setup(lmono_ctx *c, DevBuf &db, FeatBatch &B, int n_windows, const int *feat_off, const double *Rs, const double *Ps, const double *tlc,
+                      const int *start_frame, const int *obs_off, const double *pts, const double *depth)
+{
+    if (!c || n_windows <= 0 || !feat_off || !Rs || !Ps || !tlc || !start_frame || !obs_off || !pts || !depth) return LMONO_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int F = feat_off[n_windows];
+    for (int w = 0; w < n_windows; w++) if (feat_off[w + 1] - feat_off[w] > 1024) { c->err = "more than 1024 features in a window"; return LMONO_ECAPACITY; }
+    const int TO = F > 0 ? obs_off[F] : 0;
+    bool ok = true;
+    B.n_windows = n_windows;
+    B.feat_off = db.up(feat_off, (size_t)n_windows + 1, ok);
+    B.Rs = db.up(Rs, (size_t)n_windows * 99, ok); B.Ps = db.up(Ps, (size_t)n_windows * 33, ok); B.tlc = db.up(tlc, (size_t)n_windows * 16, ok);
+    B.start_frame = db.up(start_frame, (size_t)F, ok); B.obs_off = db.up(obs_off, (size_t)F + 1, ok); B.pts = db.up(pts, (size_t)TO * 2, ok);
+    B.depth = db.up(depth, (size_t)F, ok);
+    B.solve_flag = db.up((const int *)nullptr, (size_t)F, ok); B.score = db.up((const double *)nullptr, (size_t)F, ok);
+    B.x = nullptr; B.cand = nullptr;
+    if (!ok) { c->err = "per-feature kernels: device allocation / upload failed"; return LMONO_ENOMEM; }
+    return LMONO_OK;
+}
+
+extern "C" int lmono_triangulate(lmono_ctx *c, int n_windows, const int *feat_off_h, const double *Rs_h, const double *Ps_h, const double *tlc_h,
+                                 const int *start_frame_h, const int *obs_off_h, const double *pts_h, double *depth_h, int *solve_flag_h,
+                                 int track_cnt, int window_size, double factor_weight, int refine_max_iter)
+{
+    DevBuf db; FeatBatch B{};
+    int rc = feat_setup(c, db, B, n_windows, feat_off_h, Rs_h, Ps_h, tlc_h, start_frame_h, obs_off_h, pts_h, depth_h);
+    if (rc) return rc;
+    B.track_cnt = track_cnt; B.window_size = window_size; B.weight = factor_weight; B.max_iter = refine_max_iter;
+    const int F = feat_off_h[n_windows];
+    if (F == 0) return LMONO_OK;
+    hipLaunchKernelGGL(k_triangulate_init, dim3((F + 127) / 128), dim3(128), 0, c->stream, B);
+    if (refine_max_iter >= 0) hipLaunchKernelGGL(k_depth_refine, dim3(n_windows), dim3(256), 0, c->stream, B);
+    rc = check_launch(c, "k_triangulate_init/k_depth_refine");
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(depth_h, B.depth, sizeof(double) * F, hipMemcpyDeviceToHost));
+    if (solve_flag_h && refine_max_iter >= 0) HIP_TRY(c, hipMemcpy(solve_flag_h, B.solve_flag, sizeof(int) * F, hipMemcpyDeviceToHost));
+    return LMONO_OK;
+}
+
+extern "C" int lmono_outlier_scores(lmono_ctx *c, int n_windows, const int *feat_off_h, const double *Rs_h, const double *Ps_h, const double *tlc_h,
+                                    const int *start_frame_h, const int *obs_off_h, const double *pts_h, const double *depth_h,
+                                    int track_cnt, double factor_weight, double *score_h)
+{
+    if (!score_h) return LMONO_EINVAL;
+    DevBuf db; FeatBatch B{};
+    int rc = feat_setup(c, db, B, n_windows, feat_off_h, Rs_h, Ps_h, tlc_h, start_frame_h, obs_off_h, pts_h, depth_h);
+    if (rc) return rc;
+    B.track_cnt = track_cnt; B.window_size = 0; B.weight = factor_weight; B.max_iter = 0;
+    const int F = feat_off_h[n_windows];
+    if (F == 0) return LMONO_OK;
+    hipLaunchKernelGGL(k_outlier_scores, dim3((F + 127) / 128), dim3(128), 0, c->stream, B);
+    rc = check_launch(c, "k_outlier_scores");
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(score_h, B.score, sizeof(double) * F, hipMemcpyDeviceToHost));
+    return LMONO_OK;
+}
+
+extern "C" int lmono_shift_depth(lmono_ctx *c, const double *back_R0, const double *back_P0, const double *R1, const double *P1, const double *tlc,
+                                 int n, const double *pt_i_h, const double *depth_h, double *depth_out_h)
+{
+    if (!c || !back_R0 || !back_P0 || !R1 || !P1 || !tlc || n < 0 || !pt_i_h || !depth_h || !depth_out_h) return LMONO_EINVAL;
+    if (n == 0) return LMONO_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    double poses[40];
+    memcpy(poses, back_R0, 72); memcpy(poses + 9, back_P0, 24); memcpy(poses + 12, R1, 72); memcpy(poses + 21, P1, 24); memcpy(poses + 24, tlc, 128);
+    DevBuf db; bool ok = true;
+    double *pd = db.up(poses, 40, ok), *pt = db.up(pt_i_h, (size_t)n * 2, ok), *d = db.up(depth_h, (size_t)n, ok), *o = db.up((const double *)nullptr, (size_t)n, ok);
+    if (!ok) { c->err = "lmono_shift_depth: device allocation / upload failed"; return LMONO_ENOMEM; }
+    hipLaunchKernelGGL(k_shift_depth, dim3((n + 127) / 128), dim3(128), 0, c->stream, (const double *)pd, n, (const double *)pt, (const double *)d, o);
+    int rc = check_launch(c, "k_shift_depth");
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(depth_out_h, o, sizeof(double) * n, hipMemcpyDeviceToHost));
     return LMONO_OK;
 }

@@ -302,3 +302,46 @@ def ba_reanchor(poses, R0_before, P0_before):
     R0 = np.ascontiguousarray(R0_before, np.float64); P0 = np.ascontiguousarray(P0_before, np.float64)
     lib().lo_ba_reanchor(_fp(poses, C.c_double), C.c_int(n), _fp(R0, C.c_double), _fp(P0, C.c_double), _fp(R, C.c_double), _fp(P, C.c_double))
     return R.reshape(n, 3, 3), P
+
+
+# --------------------------------------------------------------------------------------------
+# per-feature numerics (oracle/lo_ba_feat.c)
+# --------------------------------------------------------------------------------------------
+def _feat_args(Rs, Ps, tlc, start, off, pts):
+    return (np.ascontiguousarray(Rs, np.float64).reshape(-1, 9), np.ascontiguousarray(Ps, np.float64).reshape(-1, 3),
+            np.ascontiguousarray(tlc, np.float64).reshape(16), np.ascontiguousarray(start, np.int32),
+            np.ascontiguousarray(off, np.int32), np.ascontiguousarray(pts, np.float64).reshape(-1, 2))
+
+
+def triangulate(Rs, Ps, tlc, start, off, pts, depth, track_cnt=3, window_size=10, weight=1500.0, refine_iters=50):
+    """FeatureManager::triangulate: returns (depth_after_init, depth_after_refine, solve_flag)."""
+    Rs, Ps, tlc, start, off, pts = _feat_args(Rs, Ps, tlc, start, off, pts)
+    n = len(start)
+    d = np.ascontiguousarray(depth, np.float64).copy()
+    lib().lo_triangulate_init(_fp(Rs, C.c_double), _fp(Ps, C.c_double), _fp(tlc, C.c_double), C.c_int(n), _fp(start, C.c_int32),
+                              _fp(off, C.c_int32), _fp(pts, C.c_double), _fp(d, C.c_double), C.c_int(track_cnt))
+    d0 = d.copy()
+    flag = np.zeros(n, np.int32)
+    if refine_iters >= 0:
+        lib().lo_depth_refine(_fp(Rs, C.c_double), _fp(Ps, C.c_double), _fp(tlc, C.c_double), C.c_int(n), _fp(start, C.c_int32),
+                              _fp(off, C.c_int32), _fp(pts, C.c_double), _fp(d, C.c_double), _fp(flag, C.c_int32), C.c_int(track_cnt),
+                              C.c_int(window_size), C.c_double(weight), C.c_int(refine_iters))
+    return d0, d, flag
+
+
+def outlier_scores(Rs, Ps, tlc, start, off, pts, depth, track_cnt=3, weight=1500.0):
+    Rs, Ps, tlc, start, off, pts = _feat_args(Rs, Ps, tlc, start, off, pts)
+    n = len(start)
+    d = np.ascontiguousarray(depth, np.float64)
+    sc = np.zeros(n)
+    lib().lo_outlier_scores(_fp(Rs, C.c_double), _fp(Ps, C.c_double), _fp(tlc, C.c_double), C.c_int(n), _fp(start, C.c_int32),
+                            _fp(off, C.c_int32), _fp(pts, C.c_double), _fp(d, C.c_double), C.c_int(track_cnt), C.c_double(weight), _fp(sc, C.c_double))
+    return sc
+
+
+def shift_depth(back_R0, back_P0, R1, P1, tlc, pt_i, depth):
+    a = [np.ascontiguousarray(v, np.float64).ravel() for v in (back_R0, back_P0, R1, P1, tlc)]
+    pt = np.ascontiguousarray(pt_i, np.float64).reshape(-1, 2); d = np.ascontiguousarray(depth, np.float64)
+    out = np.zeros(len(d))
+    lib().lo_shift_depth(*[_fp(v, C.c_double) for v in a], C.c_int(len(d)), _fp(pt, C.c_double), _fp(d, C.c_double), _fp(out, C.c_double))
+    return out

@@ -140,10 +140,13 @@ def make_window(seed=0, n_frames=11, n_landmarks=4000, max_tracks=150, pix_sigma
             un = (u[t] + rng.normal(0, pix_sigma) - CX) / FX; vn = (v[t] + rng.normal(0, pix_sigma) - CY) / FY
             tracks[t][1].append((un, vn))
     feat_depth, obs_feat, obs_i, obs_j, obs_pts = [], [], [], [], []
+    trk_start, trk_off, trk_pts, trk_true = [], [0], [], []
     for t, (k0, obs) in sorted(tracks.items(), key=lambda kv: (kv[1][0], kv[0])):
         if len(obs) < track_cnt:
             continue
         f = len(feat_depth)
+        trk_start.append(k0); trk_pts.extend(obs); trk_off.append(trk_off[-1] + len(obs))
+        trk_true.append((cam_R[k0].T @ (lm[t] - cam_P[k0]))[2])
         z0 = (cam_R[k0].T @ (lm[t] - cam_P[k0]))[2]
         feat_depth.append(z0 * (1 + rng.normal(0, 0.05)))
         for d, (un, vn) in enumerate(obs):
@@ -168,4 +171,6 @@ def make_window(seed=0, n_frames=11, n_landmarks=4000, max_tracks=150, pix_sigma
                 obs_feat=np.array(obs_feat, np.int32), obs_i=np.array(obs_i, np.int32), obs_j=np.array(obs_j, np.int32),
                 obs_pts=np.array(obs_pts), laser_consts=laser, laser_info=(3.0 * 1500.0) * np.eye(6), mono_info=1500.0 * np.eye(2),
                 prior_T=T.copy(), prior_w=np.array([1000.0, 1000.0]), use_prior=use_prior, ex_constant=False, use_mono=True,
-                gt_Rs=np.array(Rs), gt_Ps=np.array(Ps))
+                gt_Rs=np.array(Rs), gt_Ps=np.array(Ps), tlc=T.copy(),
+                trk_start=np.array(trk_start, np.int32), trk_off=np.array(trk_off, np.int32), trk_pts=np.array(trk_pts),
+                trk_true_depth=np.array(trk_true))
