@@ -1,0 +1,266 @@
+// lmono_amd/host/lmono_host.cpp -- see lmono_host.hpp.  Window / track bookkeeping on the host, numerics in the HIP library.
+#include "lmono_host.hpp"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace lmono_host {
+
+static void mat_mul(const double *A, const double *B, double *C) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) C[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j]; }
+static void mat_vec(const double *A, const double *v, double *o) { for (int i = 0; i < 3; i++) o[i] = A[i * 3] * v[0] + A[i * 3 + 1] * v[1] + A[i * 3 + 2] * v[2]; }
+
+// Eigen::Quaterniond(Matrix3d) / q.normalized().toRotationMatrix() as used by matrix2Double / double2Matrix
+static void R_to_q(const double *m, double *q)
+{
+    double t = m[0] + m[4] + m[8];
+    if (t > 0) { t = std::sqrt(t + 1.0); q[3] = 0.5 * t; t = 0.5 / t; q[0] = (m[7] - m[5]) * t; q[1] = (m[2] - m[6]) * t; q[2] = (m[3] - m[1]) * t; }
+    else {
+        int i = 0; if (m[4] > m[0]) i = 1; if (m[8] > m[i * 3 + i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = std::sqrt(m[i * 3 + i] - m[j * 3 + j] - m[k * 3 + k] + 1.0);
+        q[i] = 0.5 * t; t = 0.5 / t; q[3] = (m[k * 3 + j] - m[j * 3 + k]) * t; q[j] = (m[j * 3 + i] + m[i * 3 + j]) * t; q[k] = (m[k * 3 + i] + m[i * 3 + k]) * t;
+    }
+}
+static void q_to_R(const double *qin, double *R)
+{
+    const double n = std::sqrt(qin[0] * qin[0] + qin[1] * qin[1] + qin[2] * qin[2] + qin[3] * qin[3]);
+    const double x = qin[0] / n, y = qin[1] / n, z = qin[2] / n, w = qin[3] / n;
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z, twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy; R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx; R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+
+// ---- FeatureManager ---------------------------------------------------------------------------------------------
+int FeatureManager::getFeatureCount()
+{
+    int cnt = 0;
+    for (auto &it : feature) { it.used_num = (int)it.feature_per_frame.size(); if (it.used_num >= params->TRACK_CNT) cnt++; }
+    return cnt;
+}
+std::vector<double> FeatureManager::getDepthVector()
+{
+    std::vector<double> dep;
+    for (auto &it : feature) { it.used_num = (int)it.feature_per_frame.size(); if (it.used_num < params->TRACK_CNT) continue; dep.push_back(1.0 / it.estimated_depth); }
+    return dep;
+}
+void FeatureManager::setDepth(const std::vector<double> &x)
+{
+    int idx = -1;
+    for (auto &it : feature) {
+        it.used_num = (int)it.feature_per_frame.size();
+        if (it.used_num < params->TRACK_CNT) continue;
+        it.estimated_depth = 1.0 / x[++idx];
+        it.solve_flag = (it.estimated_depth < 0.1 || it.estimated_depth > 300) ? 2 : 1;
+    }
+}
+void FeatureManager::removeFailures()
+{
+    for (auto it = feature.begin(); it != feature.end();) { if (it->solve_flag == 2) it = feature.erase(it); else ++it; }
+}
+void FeatureManager::removeOutlier(const std::set<int> &ids)
+{
+    for (auto it = feature.begin(); it != feature.end();) { if (ids.count(it->feature_id)) it = feature.erase(it); else ++it; }
+}
+void FeatureManager::pack(std::vector<int> &start, std::vector<int> &off, std::vector<double> &pts, std::vector<double> &depth, bool all_tracks)
+{
+    start.clear(); off.assign(1, 0); pts.clear(); depth.clear();
+    for (auto &it : feature) {
+        it.used_num = (int)it.feature_per_frame.size();
+        if (!all_tracks && it.used_num < params->TRACK_CNT) continue;
+        start.push_back(it.start_frame);
+        for (auto &f : it.feature_per_frame) { pts.push_back(f.pt[0]); pts.push_back(f.pt[1]); }
+        off.push_back((int)pts.size() / 2);
+        depth.push_back(it.estimated_depth);
+    }
+}
+void FeatureManager::triangulate(int, const Mat3 Rs[], const Vec3 Ps[], const double tlc[16])
+{
+    std::vector<int> start, off; std::vector<double> pts, depth;
+    pack(start, off, pts, depth, true);      // tracks below TRACK_CNT are skipped inside the kernels
+    if (start.empty()) return;
+    const int feat_off[2] = { 0, (int)start.size() };
+    std::vector<double> R(99, 0.0), P(33, 0.0);
+    for (int i = 0; i <= WINDOW_SIZE; i++) { std::memcpy(&R[9 * i], Rs[i].m, 72); std::memcpy(&P[3 * i], Ps[i].v, 24); }
+    std::vector<int> flag(start.size(), 0);
+    hip->check(lmono_triangulate(hip->get(), 1, feat_off, R.data(), P.data(), tlc, start.data(), off.data(), pts.data(), depth.data(), flag.data(),
+                                 params->TRACK_CNT, WINDOW_SIZE, params->FACTOR_WEIGHT, 50), "lmono_triangulate");
+    size_t k = 0;
+    for (auto &it : feature) { it.estimated_depth = depth[k]; if (it.used_num >= params->TRACK_CNT) it.solve_flag = flag[k]; k++; }
+}
+void FeatureManager::removeBackShiftDepth(const Mat3 &R0, const Vec3 &P0, const Mat3 &R1, const Vec3 &P1, const double tlc[16])
+{
+    std::vector<double> pt, dep;
+    for (auto &it : feature) if (it.start_frame == 0 && it.feature_per_frame.size() >= 3) { pt.push_back(it.feature_per_frame[0].pt[0]); pt.push_back(it.feature_per_frame[0].pt[1]); dep.push_back(it.estimated_depth); }
+    std::vector<double> out(dep.size());
+    if (!dep.empty()) hip->check(lmono_shift_depth(hip->get(), R0.m, P0.v, R1.m, P1.v, tlc, (int)dep.size(), pt.data(), dep.data(), out.data()), "lmono_shift_depth");
+    size_t k = 0;
+    for (auto it = feature.begin(); it != feature.end();) {
+        if (it->start_frame != 0) { it->start_frame--; ++it; continue; }
+        const bool keep = it->feature_per_frame.size() >= 3;      // after erasing the first observation: size >= 2
+        it->feature_per_frame.erase(it->feature_per_frame.begin());
+        if (!keep) { it = feature.erase(it); continue; }
+        it->estimated_depth = out[k++];
+        ++it;
+    }
+}
+void FeatureManager::removeBack()
+{
+    for (auto it = feature.begin(); it != feature.end();) {
+        if (it->start_frame != 0) { it->start_frame--; ++it; continue; }
+        it->feature_per_frame.erase(it->feature_per_frame.begin());
+        if (it->feature_per_frame.empty()) it = feature.erase(it); else ++it;
+    }
+}
+void FeatureManager::removeFront(int frame_count)
+{
+    for (auto it = feature.begin(); it != feature.end();) {
+        if (it->start_frame == frame_count) { it->start_frame--; ++it; continue; }
+        const int j = WINDOW_SIZE - 1 - it->start_frame;
+        if (it->endFrame() < frame_count - 1) { ++it; continue; }
+        it->feature_per_frame.erase(it->feature_per_frame.begin() + j);
+        if (it->feature_per_frame.empty()) it = feature.erase(it); else ++it;
+    }
+}
+
+// ---- Estimator ----------------------------------------------------------------------------------------------------
+Estimator::Estimator(HipContext &hip, const Params &p) : hip_(hip), p_(p)
+{
+    for (auto &R : Rs) { std::memset(R.m, 0, sizeof(R.m)); R.m[0] = R.m[4] = R.m[8] = 1.0; }
+    for (auto &P : Ps) std::memset(P.v, 0, sizeof(P.v));
+    std::memset(TLC, 0, sizeof(TLC)); TLC[0] = TLC[5] = TLC[10] = TLC[15] = 1.0;
+    feature_manager.params = &p_; feature_manager.hip = &hip_;
+}
+void Estimator::matrix2Double()
+{
+    for (int i = 0; i <= WINDOW_SIZE; i++) { std::memcpy(para_pose[i], Ps[i].v, 24); R_to_q(Rs[i].m, para_pose[i] + 3); }
+    double R[9];
+    for (int i = 0; i < 3; i++) { para_ex[0][i] = TLC[i * 4 + 3]; for (int j = 0; j < 3; j++) R[i * 3 + j] = TLC[i * 4 + j]; }
+    R_to_q(R, para_ex[0] + 3);
+    para_depth_inv = feature_manager.getDepthVector();
+}
+void Estimator::double2Matrix()
+{
+    double R00[9], rot_diff[9];
+    q_to_R(para_pose[0] + 3, R00);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) rot_diff[i * 3 + j] = Rs[0].m[i * 3] * R00[j * 3] + Rs[0].m[i * 3 + 1] * R00[j * 3 + 1] + Rs[0].m[i * 3 + 2] * R00[j * 3 + 2];
+    const Vec3 origin_t0 = Ps[0];
+    for (int i = 0; i <= WINDOW_SIZE; i++) {
+        const double t[3] = { para_pose[i][0] - para_pose[0][0], para_pose[i][1] - para_pose[0][1], para_pose[i][2] - para_pose[0][2] };
+        double R[9], rt[3];
+        q_to_R(para_pose[i] + 3, R);
+        mat_vec(rot_diff, t, rt);
+        for (int k = 0; k < 3; k++) Ps[i].v[k] = rt[k] + origin_t0.v[k];
+        mat_mul(rot_diff, R, Rs[i].m);
+    }
+    double Rx[9];
+    q_to_R(para_ex[0] + 3, Rx);
+    for (int i = 0; i < 3; i++) { TLC[i * 4 + 3] = para_ex[0][i]; for (int j = 0; j < 3; j++) TLC[i * 4 + j] = Rx[i * 3 + j]; }
+    feature_manager.setDepth(para_depth_inv);
+    feature_manager.removeFailures();
+}
+bool Estimator::optimization()
+{
+    matrix2Double();
+    // residual blocks exactly as Estimator.cc:1155-1215 adds them
+    std::vector<int> obs_feat, obs_i, obs_j; std::vector<double> obs_pts;
+    const bool use_mono = p_.ESTIMATE_LASER && !static_status;
+    int feature_index = -1;
+    for (auto &it : feature_manager.feature) {
+        it.used_num = (int)it.feature_per_frame.size();
+        if (it.used_num < p_.TRACK_CNT) continue;
+        ++feature_index;
+        const int i = it.start_frame; int j = i - 1;
+        for (auto &f : it.feature_per_frame) {
+            j++;
+            if (i == j) continue;
+            obs_feat.push_back(feature_index); obs_i.push_back(i); obs_j.push_back(j);
+            obs_pts.insert(obs_pts.end(), { it.feature_per_frame[0].pt[0], it.feature_per_frame[0].pt[1], f.pt[0], f.pt[1] });
+        }
+    }
+    const int F = feature_index + 1;
+    const int feat_off[2] = { 0, F }, obs_off[2] = { 0, (int)obs_feat.size() };
+    int use_prior = 0;
+    if (first_refine >= p_.FINE_TIMES) use_prior = 1; else first_refine++;
+    const int flags[4] = { frame_count + 1, use_prior, p_.ESTIMATE_LASER == 0 ? 1 : 0, use_mono ? 1 : 0 };
+    std::vector<double> poses(77, 0.0), laser(240, 0.0);
+    for (int i = 0; i <= WINDOW_SIZE; i++) std::memcpy(&poses[7 * i], para_pose[i], 56);
+    for (int i = 0; i < frame_count; i++) {
+        double *c = &laser[24 * i];
+        std::memcpy(c, L0_R[i].m, 72); std::memcpy(c + 9, L0_R[i + 1].m, 72); std::memcpy(c + 18, L0_T[i].v, 24); std::memcpy(c + 21, L0_T[i + 1].v, 24);
+    }
+    double laser_info[36] = { 0 }, mono_info[4] = { p_.FACTOR_WEIGHT, 0, 0, p_.FACTOR_WEIGHT }, prior_w[2] = { p_.PRIOR_T, p_.PRIOR_R };
+    for (int k = 0; k < 6; k++) laser_info[k * 7] = p_.LASER_W * p_.FACTOR_WEIGHT;
+    lmono_ba_desc d{};
+    d.n_windows = 1; d.feat_off = feat_off; d.obs_off = obs_off; d.flags = flags; d.poses = poses.data(); d.ex = para_ex[0];
+    d.inv_depth = para_depth_inv.data(); d.obs_feat = obs_feat.data(); d.obs_i = obs_i.data(); d.obs_j = obs_j.data(); d.obs_pts = obs_pts.data();
+    d.laser_consts = laser.data(); d.prior_T = TLC; d.laser_info = laser_info; d.mono_info = mono_info; d.prior_w = prior_w;
+    lmono_ba_batch *b = lmono_ba_batch_create(hip_.get(), &d);
+    if (!b) throw std::runtime_error(std::string("lmono_ba_batch_create: ") + lmono_last_error(hip_.get()));
+    hip_.check(lmono_ba_solve(hip_.get(), b, p_.NUM_ITERATIONS), "lmono_ba_solve");
+    double summary[6];
+    std::vector<double> invd((size_t)std::max(F, 1));
+    hip_.check(lmono_ba_batch_read(hip_.get(), b, poses.data(), para_ex[0], invd.data(), summary), "lmono_ba_batch_read");
+    lmono_ba_batch_destroy(b);
+    for (int i = 0; i <= WINDOW_SIZE; i++) std::memcpy(para_pose[i], &poses[7 * i], 56);
+    if (use_mono) para_depth_inv.assign(invd.begin(), invd.begin() + F);
+    initial_cost = summary[0]; final_cost = summary[1]; iterations = (int)summary[2]; termination = (int)summary[3];
+    double2Matrix();
+    if (frame_count < WINDOW_SIZE) return false;
+    return termination == 0 || final_cost < 5e-3;            // Estimator.cc:1293
+}
+void Estimator::outliersRejection(std::set<int> &removeIndex, const double &error)
+{
+    std::vector<int> start, off; std::vector<double> pts, depth;
+    feature_manager.pack(start, off, pts, depth, true);
+    if (start.empty()) return;
+    const int feat_off[2] = { 0, (int)start.size() };
+    std::vector<double> R(99, 0.0), P(33, 0.0), score(start.size());
+    for (int i = 0; i <= WINDOW_SIZE; i++) { std::memcpy(&R[9 * i], Rs[i].m, 72); std::memcpy(&P[3 * i], Ps[i].v, 24); }
+    hip_.check(lmono_outlier_scores(hip_.get(), 1, feat_off, R.data(), P.data(), TLC, start.data(), off.data(), pts.data(), depth.data(),
+                                    p_.TRACK_CNT, p_.FACTOR_WEIGHT, score.data()), "lmono_outlier_scores");
+    size_t k = 0;
+    for (auto &it : feature_manager.feature) { if (score[k] >= 0 && score[k] > error) removeIndex.insert(it.feature_id); k++; }
+}
+void Estimator::slideWindow()
+{
+    if (marginalization_flag == MARGIN_OLD) {
+        back_R0 = Rs[0]; back_P0 = Ps[0];
+        if (frame_count == WINDOW_SIZE) {
+            for (int i = 0; i < frame_count; i++) { std::swap(Rs[i], Rs[i + 1]); std::swap(Ps[i], Ps[i + 1]); std::swap(L0_R[i], L0_R[i + 1]); std::swap(L0_T[i], L0_T[i + 1]); }
+            Rs[WINDOW_SIZE] = Rs[WINDOW_SIZE - 1]; Ps[WINDOW_SIZE] = Ps[WINDOW_SIZE - 1];
+            feature_manager.removeBackShiftDepth(back_R0, back_P0, Rs[0], Ps[0], TLC);     // slideWindowOld, stage INITED
+        }
+    } else if (frame_count == WINDOW_SIZE) {
+        Ps[frame_count - 1] = Ps[frame_count]; Rs[frame_count - 1] = Rs[frame_count];
+        L0_R[frame_count - 1] = L0_R[frame_count]; L0_T[frame_count - 1] = L0_T[frame_count];
+        feature_manager.removeFront(frame_count);                                          // slideWindowNew
+    }
+}
+
+// ---- A-LOAM nodes ---------------------------------------------------------------------------------------------------
+ScanRegistration::ScanRegistration(HipContext &hip, int n_scans_cap, int64_t points_cap, int N_SCANS, float MINIMUM_RANGE)
+    : hip_(hip), batch_(lmono_batch_create(hip.get(), n_scans_cap, points_cap)), N_SCANS_(N_SCANS), MINIMUM_RANGE_(MINIMUM_RANGE), cap_(points_cap)
+{
+    if (!batch_) throw std::runtime_error(std::string("lmono_batch_create: ") + lmono_last_error(hip.get()));
+}
+ScanRegistration::~ScanRegistration() { lmono_batch_destroy(batch_); }
+void ScanRegistration::laserCloudHandler(const float *xyzi_d, const int64_t *offsets_h, int n_scans)
+{
+    hip_.check(lmono_scanreg_batch(hip_.get(), batch_, xyzi_d, offsets_h, n_scans, N_SCANS_, MINIMUM_RANGE_), "lmono_scanreg_batch");
+    n_ = n_scans;
+}
+std::vector<float> ScanRegistration::cloud(int scan, int which)
+{
+    std::vector<float> out((size_t)cap_ * 4);
+    const int n = lmono_batch_get_cloud(hip_.get(), batch_, scan, which, out.data(), (int)cap_);
+    hip_.check(n, "lmono_batch_get_cloud");
+    out.resize((size_t)n * 4);
+    return out;
+}
+std::vector<double> LaserOdometry::process(ScanRegistration &reg, int n_chains, int lead)
+{
+    std::vector<double> poses((size_t)reg.n_scans() * 7);
+    hip_.check(lmono_odom_batch(hip_.get(), reg.batch(), n_chains, lead, nullptr, poses.data()), "lmono_odom_batch");
+    return poses;
+}
+
+} // namespace lmono_host

@@ -1,0 +1,131 @@
+// lmono_amd/host/lmono_host.hpp -- host-side C++ mirror of the reference call surface above the C ABI
+// (include/lmono_hip.h).  Same member names, argument meaning and state layout as the reference so that a maintainer
+// can swap the bodies in place:
+//   Estimator      /root/reference/mono_lidar_mapping/include/image_process/Estimator.h:110-173, .cc:1019-1305, :700-771
+//   FeatureManager /root/reference/mono_lidar_mapping/src/image_process/FeatureManager.cc:38-73, :75-255, :497-590
+//   ScanRegistration / LaserOdometry: the A-LOAM node handlers (source absent)
+// No Eigen / Ceres / ROS: plain arrays (row-major 3x3, x y z qx qy qz qw parameter blocks).  All numerics run in the
+// HIP library; this file only keeps the list / window bookkeeping that the reference keeps on the host.
+#pragma once
+#include <cstdint>
+#include <list>
+#include <set>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../include/lmono_hip.h"
+
+namespace lmono_host {
+
+constexpr int WINDOW_SIZE = 10;          // include/parameter.h:51
+constexpr double INIT_DEPTH = -1.0;
+
+struct Mat3 { double m[9]; };
+struct Vec3 { double v[3]; };
+
+struct Params {                           // config values used on the hot path (kitti_config_05.yaml)
+    double FACTOR_WEIGHT = 1500.0, LASER_W = 3.0, PRIOR_T = 1000.0, PRIOR_R = 1000.0, OUTLIER_T = 5.0;
+    int TRACK_CNT = 3, FINE_TIMES = 1, NUM_ITERATIONS = 30, ESTIMATE_LASER = 1;
+};
+
+class HipContext {
+public:
+    explicit HipContext(int device = 0) : ctx_(lmono_create(device))
+    {
+        if (!ctx_) throw std::runtime_error("lmono_create failed: no usable gfx950 device (there is no CPU fallback)");
+    }
+    ~HipContext() { lmono_destroy(ctx_); }
+    lmono_ctx *get() const { return ctx_; }
+    void check(int rc, const char *what) const
+    {
+        if (rc < 0) throw std::runtime_error(std::string(what) + ": " + lmono_last_error(ctx_));
+    }
+private:
+    lmono_ctx *ctx_;
+};
+
+// ---- FeatureManager (track store) ---------------------------------------------------------------------------------
+struct FeaturePerFrame { double pt[2]; };
+struct FeaturePerId {
+    int feature_id, start_frame;
+    std::vector<FeaturePerFrame> feature_per_frame;
+    int used_num = 0, solve_flag = 0;
+    double estimated_depth = INIT_DEPTH;
+    int endFrame() const { return start_frame + (int)feature_per_frame.size() - 1; }
+};
+
+class FeatureManager {
+public:
+    std::list<FeaturePerId> feature;
+    const Params *params = nullptr;
+    HipContext *hip = nullptr;
+
+    int getFeatureCount();                                   // FeatureManager.cc: tracks with used_num >= TRACK_CNT
+    std::vector<double> getDepthVector();                    // :58-73  (inverse depths)
+    void setDepth(const std::vector<double> &x);             // :38-56
+    void removeFailures();                                   // erase solve_flag == 2
+    void removeOutlier(const std::set<int> &ids);
+    void triangulate(int frameCnt, const Mat3 Rs[], const Vec3 Ps[], const double tlc[16]);   // :75-255 -> lmono_triangulate
+    void removeBackShiftDepth(const Mat3 &back_R0, const Vec3 &back_P0, const Mat3 &R1, const Vec3 &P1, const double tlc[16]);  // :540-590
+    void removeBack();                                       // :497-511
+    void removeFront(int frame_count);                       // :513-538
+    // packs tracks with used_num >= TRACK_CNT for the kernels: start, offsets, points (anchor first)
+    void pack(std::vector<int> &start, std::vector<int> &off, std::vector<double> &pts, std::vector<double> &depth, bool all_tracks);
+};
+
+// ---- Estimator ------------------------------------------------------------------------------------------------------
+class Estimator {
+public:
+    enum MarginalizationFlag { MARGIN_OLD = 0, MARGIN_SECOND_NEW = 1 };
+    Estimator(HipContext &hip, const Params &p);
+
+    // state, same names as Estimator.h:240-272
+    Mat3 Rs[WINDOW_SIZE + 1];
+    Vec3 Ps[WINDOW_SIZE + 1];
+    double TLC[16];                        // laser <- camera 4x4 row-major (TLC[0])
+    Mat3 L0_R[WINDOW_SIZE + 1];            // all_image_frame[i].second.L0_R / L0_T
+    Vec3 L0_T[WINDOW_SIZE + 1];
+    double para_pose[WINDOW_SIZE + 1][7], para_ex[1][7];
+    std::vector<double> para_depth_inv;
+    int frame_count = 0, first_refine = 0;
+    bool static_status = false;
+    MarginalizationFlag marginalization_flag = MARGIN_OLD;
+    FeatureManager feature_manager;
+    Mat3 back_R0; Vec3 back_P0;
+    double final_cost = 0, initial_cost = 0; int iterations = 0, termination = 0;
+
+    void matrix2Double();                  // Estimator.cc:1019-1057
+    void double2Matrix();                  // :1059-1122
+    bool optimization();                   // :1124-1305 (solve through lmono_ba_*; margin() is not part of the solve path)
+    void outliersRejection(std::set<int> &removeIndex, const double &error);   // :134-190
+    void slideWindow();                    // :700-771
+
+private:
+    HipContext &hip_;
+    Params p_;
+};
+
+// ---- A-LOAM nodes ---------------------------------------------------------------------------------------------------
+class ScanRegistration {                   // scanRegistration.cpp: laserCloudHandler
+public:
+    ScanRegistration(HipContext &hip, int n_scans_cap, int64_t points_cap, int N_SCANS = 64, float MINIMUM_RANGE = 5.0f);
+    ~ScanRegistration();
+    // xyzi_d: scans already staged in HBM; runs the batch (one call per queue flush)
+    void laserCloudHandler(const float *xyzi_d, const int64_t *offsets_h, int n_scans);
+    std::vector<float> cloud(int scan, int which);          // 0 velodyne_cloud_2, 1 sharp, 2 less_sharp, 3 flat, 4 less_flat
+    lmono_scan_batch *batch() const { return batch_; }
+    int n_scans() const { return n_; }
+private:
+    HipContext &hip_; lmono_scan_batch *batch_; int N_SCANS_; float MINIMUM_RANGE_; int n_ = 0; int64_t cap_;
+};
+
+class LaserOdometry {                      // laserOdometry.cpp main loop
+public:
+    explicit LaserOdometry(HipContext &hip) : hip_(hip) {}
+    // q_w_curr / t_w_curr of every scan: [n][7] = qx qy qz qw tx ty tz
+    std::vector<double> process(ScanRegistration &reg, int n_chains = 1, int lead = 0);
+private:
+    HipContext &hip_;
+};
+
+} // namespace lmono_host

@@ -1,0 +1,69 @@
+"""Host-side C++ mirror (lmono_amd/host: Estimator / FeatureManager over the C ABI) against the CPU oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import ba_cases as K
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "lmono_amd", "host", "host_test")
+
+
+def test_host_library_builds():
+    import __graft_entry__ as g
+    g.build()
+    assert os.path.exists(EXE) and os.path.exists(os.path.join(ROOT, "lmono_amd", "lib", "liblmono_host.a"))
+
+
+@pytest.mark.gpu
+def test_estimator_mirror_matches_oracle(oracle, tmp_path):
+    from oracle import ba_numpy as B
+    w = K.make_window(21)
+    n = len(w["poses"])
+    Rs = np.array([B.q_to_R(p[3:]) for p in w["poses"]]); Ps = w["poses"][:, :3].copy()
+    lc = w["laser_consts"]
+    L0_R = [lc[i][:9] for i in range(n - 1)] + [lc[n - 2][9:18]]
+    L0_T = [lc[i][18:21] for i in range(n - 1)] + [lc[n - 2][21:24]]
+    buf = [float(len(w["trk_start"]))]
+    for i in range(n):
+        buf += list(Rs[i].ravel()) + list(Ps[i])
+    for i in range(n):
+        buf += list(L0_R[i]) + list(L0_T[i])
+    buf += list(w["tlc"].ravel())
+    for f in range(len(w["trk_start"])):
+        a, b = w["trk_off"][f], w["trk_off"][f + 1]
+        buf += [float(w["trk_start"][f]), float(b - a), -1.0] + list(np.asarray(w["trk_pts"][a:b]).ravel())
+    fx = tmp_path / "window.bin"
+    np.array(buf, np.float64).tofile(fx)
+    out = subprocess.run([EXE, str(fx)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    lines = {ln.split()[0]: ln.split()[1:] for ln in out.stdout.strip().splitlines()}
+
+    # expected, step by step, from the oracle
+    d0, d1, flag = oracle.triangulate(Rs, Ps, w["tlc"], w["trk_start"], w["trk_off"], w["trk_pts"], -np.ones(len(w["trk_start"])))
+    tri = np.array(lines["TRI"], float)
+    assert np.abs(1 / tri - 1 / d1).max() < 1e-9
+    w2 = dict(w); w2["inv_depth"] = 1.0 / d1
+    poses, ex, invd, sm = oracle.ba_solve(w2)
+    conv, c0, c1, iters, term = lines["OPT"]
+    assert abs(float(c0) - sm.initial_cost) < 1e-9 * sm.initial_cost and abs(float(c1) - sm.final_cost) < 1e-6 * sm.final_cost
+    assert int(iters) == sm.iterations and int(term) == sm.termination
+    R_ref, P_ref = oracle.ba_reanchor(poses, Rs[0], Ps[0])      # double2Matrix
+    assert np.abs(np.array(lines["POS"], float).reshape(n, 3) - P_ref).max() < 1e-6
+    assert np.abs(np.array(lines["ROT"], float).reshape(n, 3, 3) - R_ref).max() < 1e-7
+    # outliersRejection + slideWindow bookkeeping
+    depth = 1.0 / invd
+    keep = ~((depth < 0.1) | (depth > 300))                      # removeFailures after setDepth
+    TLC = np.eye(4); TLC[:3, :3] = B.q_to_R(B.q_normalized(ex[3:])); TLC[:3, 3] = ex[:3]
+    sc = oracle.outlier_scores(R_ref.reshape(n, 9), P_ref, TLC, w["trk_start"], w["trk_off"], w["trk_pts"], depth)
+    n_out = int(((sc > 5.0) & keep).sum())
+    assert int(lines["OUT"][0]) == n_out
+    alive = keep & ~(sc > 5.0)
+    before = int(alive.sum())
+    lens = np.diff(w["trk_off"])
+    erased = alive & (w["trk_start"] == 0) & (lens < 3)
+    after = before - int(erased.sum())
+    anchored0 = int((alive & ~erased & (w["trk_start"] <= 1)).sum())
+    assert [int(v) for v in lines["SLD"]] == [before, after, anchored0]
