@@ -134,7 +134,7 @@ static double refine_eval(const double *Rs, const double *Ps, const double *tlc,
 void lo_depth_refine(const double *Rs, const double *Ps, const double *tlc, int n_feat, const int32_t *start_frame, const int32_t *obs_off,
                      const double *pts, double *depth, int32_t *solve_flag, int track_cnt, int window_size, double weight, int max_iter)
 {
-    double *x = (double *)malloc(sizeof(double) * (size_t)(n_feat + 1)), *cand = (double *)malloc(sizeof(double) * (size_t)(n_feat + 1));
+    double *x = (double *)calloc((size_t)(n_feat + 1), sizeof(double)), *cand = (double *)malloc(sizeof(double) * (size_t)(n_feat + 1));
     double *h = (double *)malloc(sizeof(double) * (size_t)(n_feat + 1)), *g = (double *)malloc(sizeof(double) * (size_t)(n_feat + 1));
     double *scale = (double *)malloc(sizeof(double) * (size_t)(n_feat + 1)), *diag = (double *)malloc(sizeof(double) * (size_t)(n_feat + 1));
     double *step = (double *)malloc(sizeof(double) * (size_t)(n_feat + 1));

@@ -345,3 +345,32 @@ def shift_depth(back_R0, back_P0, R1, P1, tlc, pt_i, depth):
     out = np.zeros(len(d))
     lib().lo_shift_depth(*[_fp(v, C.c_double) for v in a], C.c_int(len(d)), _fp(pt, C.c_double), _fp(d, C.c_double), _fp(out, C.c_double))
     return out
+
+
+def marginalize(w, pt_j_from="left"):
+    """MARGIN_OLD prior from a window dict (tests/ba_cases.make_window).  Returns (lin_J [66,66], lin_r [66], m, x0 [11,7])."""
+    sel = np.nonzero(np.asarray(w["obs_i"]) == 0)[0]
+    feats = sorted(set(int(f) for f in np.asarray(w["obs_feat"])[sel]))
+    remap = {f: k for k, f in enumerate(feats)}
+    obs_feat = np.array([remap[int(f)] for f in np.asarray(w["obs_feat"])[sel]], np.int32)
+    obs_j = np.ascontiguousarray(np.asarray(w["obs_j"])[sel], np.int32)
+    pts = np.ascontiguousarray(np.asarray(w["obs_pts"])[sel], np.float64)
+    invd = np.ascontiguousarray(np.asarray(w["inv_depth"])[feats], np.float64)
+    poses = np.ascontiguousarray(w["poses"], np.float64); ex = np.ascontiguousarray(w["ex"], np.float64)
+    lc = np.ascontiguousarray(w["laser_consts"][0], np.float64)
+    li = np.ascontiguousarray(w["laser_info"], np.float64); mi = np.ascontiguousarray(w["mono_info"], np.float64)
+    J = np.zeros((66, 66)); r = np.zeros(66); m = C.c_int(0)
+    lib().lo_marginalize(_fp(poses, C.c_double), _fp(ex, C.c_double), C.c_int(len(feats)), _fp(invd, C.c_double), C.c_int(len(sel)),
+                         _fp(obs_feat, C.c_int32), _fp(obs_j, C.c_int32), _fp(pts, C.c_double), _fp(lc, C.c_double), _fp(li, C.c_double),
+                         _fp(mi, C.c_double), _fp(J, C.c_double), _fp(r, C.c_double), C.byref(m))
+    x0 = np.concatenate([ex[None], poses[1:]], 0)
+    return J, r, m.value, x0, dict(feats=feats, obs_feat=obs_feat, obs_j=obs_j, pts=pts, invd=invd)
+
+
+def marg_evaluate(lin_J, lin_r, x0, x, want_jac=True):
+    lin_J = np.ascontiguousarray(lin_J, np.float64); lin_r = np.ascontiguousarray(lin_r, np.float64)
+    x0 = np.ascontiguousarray(x0, np.float64); x = np.ascontiguousarray(x, np.float64)
+    res = np.zeros(66); jac = np.zeros((11, 66, 7)) if want_jac else None
+    lib().lo_marg_evaluate(_fp(lin_J, C.c_double), _fp(lin_r, C.c_double), _fp(x0, C.c_double), _fp(x, C.c_double), _fp(res, C.c_double),
+                           _fp(jac, C.c_double) if want_jac else None)
+    return res, jac
