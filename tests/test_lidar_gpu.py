@@ -133,3 +133,16 @@ def test_pose_prefix_and_rebase_kernels(gpu_ctx):
     gpu_ctx.pose_rebase_d(d_b.data_ptr(), 3, d_pose.data_ptr(), n - 7)
     torch.cuda.synchronize()
     assert np.abs(d_pose.cpu().numpy() - sharding.rebase(bases, ref)).max() < 1e-12
+
+
+def test_two_rank_sharded_run_matches_unsharded():
+    """N > 1 path end to end on the GPU kernels: 2 processes (gloo rendezvous, both on cuda:0) vs one batch."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "scripts", "shard_check.py")]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.count("max |pose - unsharded|") == 2
