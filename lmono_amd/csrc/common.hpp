@@ -26,24 +26,40 @@ constexpr int kStatusIrregularLines = 4; // scan-line ids of a feature cloud too
 #define LM_PI 3.14159265358979323846
 #define LM_PI_2 1.57079632679489661923
 
-// Deterministic arctangent from IEEE +,-,*,/ and sqrt only (bit-identical to the CPU oracle's
-// restatement; the file is compiled with -ffp-contract=off).  Three half-angle reductions and a
-// 12-term odd Taylor series.
+// Deterministic arctangent from IEEE +,-,*,/ only (bit-identical to the CPU oracle's restatement; the file is compiled
+// with -ffp-contract=off): |x| > 1 -> 1/|x|, nearest breakpoint c = k/16, t = (a - c) / (1 + a c) with |t| <= 1/32,
+// atan(a) = atan(c) from a table of correctly rounded constants + odd Taylor series in t up to t^15 (two divisions).
+__device__ __constant__ const double kAtanTab[17] = {
+    0,
+    0.06241880999595735,
+    0.12435499454676144,
+    0.18534794999569476,
+    0.24497866312686414,
+    0.30288486837497142,
+    0.35877067027057225,
+    0.41241044159738732,
+    0.46364760900080609,
+    0.51238946031073773,
+    0.55859931534356244,
+    0.60228734613496415,
+    0.64350110879328437,
+    0.68231655487474807,
+    0.71882999962162453,
+    0.75315128096219441,
+    0.78539816339744828
+};
+
 __device__ __forceinline__ double det_atan(double x)
 {
     const bool neg = x < 0.0;
     double a = neg ? -x : x;
     const bool inv = a > 1.0;
     if (inv) a = 1.0 / a;
-    a = a / (1.0 + sqrt(1.0 + a * a));
-    a = a / (1.0 + sqrt(1.0 + a * a));
-    a = a / (1.0 + sqrt(1.0 + a * a));
-    const double z = a * a;
-    double s = 1.0 / 23.0;
-    s = 1.0 / 21.0 - z * s;
-    s = 1.0 / 19.0 - z * s;
-    s = 1.0 / 17.0 - z * s;
-    s = 1.0 / 15.0 - z * s;
+    const int k = (int)(a * 16.0 + 0.5);
+    const double c = (double)k * 0.0625;
+    const double t = (a - c) / (1.0 + a * c);
+    const double z = t * t;
+    double s = 1.0 / 15.0;
     s = 1.0 / 13.0 - z * s;
     s = 1.0 / 11.0 - z * s;
     s = 1.0 / 9.0 - z * s;
@@ -51,7 +67,7 @@ __device__ __forceinline__ double det_atan(double x)
     s = 1.0 / 5.0 - z * s;
     s = 1.0 / 3.0 - z * s;
     s = 1.0 - z * s;
-    double r = 8.0 * (a * s);
+    double r = kAtanTab[k] + t * s;
     if (inv) r = LM_PI_2 - r;
     return neg ? -r : r;
 }
@@ -128,22 +144,39 @@ __device__ __forceinline__ unsigned long long pack_fu(float f, unsigned int payl
     return ((unsigned long long)__float_as_uint(f) << 32) | payload;
 }
 
-// in-LDS bitonic sort of n (power of two) 64-bit keys by all threads of the block
+// in-LDS bitonic sort of n (power of two) 64-bit keys by the 4 waves of a 256-thread block.  Each wave owns a
+// contiguous quarter of the array; compare-exchange stages whose partner distance j stays inside a quarter need no
+// workgroup barrier (LDS operations of one wave execute in order), only the few stages with j >= n/4 do.
 __device__ __forceinline__ void bitonic_sort_u64(unsigned long long *keys, int n)
 {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int P = n >= 8 ? n / 4 : n;            // elements per wave (tiny arrays: wave 0 alone)
+    const int nw = n >= 8 ? 4 : 1;
     for (int k = 2; k <= n; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < n; i += blockDim.x) {
-                const int p = i ^ j;
-                if (p > i) {
+            if (j >= P) {
+                __syncthreads();
+                for (int q = threadIdx.x; q < n / 2; q += 256) {
+                    const int i = 2 * j * (q / j) + (q % j), p = i + j;
                     const unsigned long long a = keys[i], b = keys[p];
                     const bool asc = (i & k) == 0;
                     if ((a > b) == asc) { keys[i] = b; keys[p] = a; }
                 }
+                __syncthreads();
+            } else if (wave < nw) {
+                const int base = wave * P;
+                for (int q = lane; q < P / 2; q += 64) {
+                    const int i = base + 2 * j * (q / j) + (q % j), p = i + j;
+                    const unsigned long long a = keys[i], b = keys[p];
+                    const bool asc = (i & k) == 0;
+                    if ((a > b) == asc) { keys[i] = b; keys[p] = a; }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
-            __syncthreads();
         }
     }
+    __syncthreads();
 }
 
 __device__ __forceinline__ int next_pow2(int v)

@@ -328,9 +328,11 @@ __global__ __launch_bounds__(256) void k_select(BatchView b)
 
 // ------------------------------------------------------------------------------------------------
 // k_voxel: one workgroup per (scan, ring): pcl::VoxelGrid(0.2 m, all fields averaged) over the ring's less-flat
-// candidates (label <= 0 inside the sectors): bounding box, (cell, index) keys, in-LDS bitonic sort, run starts,
-// float centroids summed in (cell, index) order.
-constexpr int kVoxLds = kRingCap * 8 + 1024;
+// candidates (label <= 0 inside the sectors).  PCL sorts (cell, point) pairs and averages each cell's points in that
+// order.  Consecutive ring points mostly share a voxel, so the points are first run-length compressed into segments
+// (cell, first index); only the segments are sorted (u64 bitonic in LDS, typically 4x fewer keys than points), and a
+// voxel's centroid is the float sum over its segments in (cell, first index) order = (cell, point index) order.
+constexpr int kVoxLds = kRingCap * 8 + kRingCap * 4 + 1024;
 
 __global__ __launch_bounds__(256) void k_voxel(BatchView b)
 {
@@ -345,16 +347,31 @@ __global__ __launch_bounds__(256) void k_voxel(BatchView b)
         return;
     }
     extern __shared__ __align__(16) unsigned char smem[];
-    unsigned long long *keys = (unsigned long long *)smem;
-    int *scr = (int *)(smem + kRingCap * 8);   // 256 ints
+    unsigned long long *keys = (unsigned long long *)smem;                  // segment keys (cell << 32 | first index)
+    unsigned int *cellv = (unsigned int *)(smem + kRingCap * 8);            // cell of every ring point, ~0u = not a candidate
+    int *scr = (int *)(smem + kRingCap * 8 + kRingCap * 4);                 // 256 ints
     const signed char *label = (const signed char *)(b.label + off + rbeg);
     const float4 *cl = b.cloud + off + rbeg;
     const int c_lo = 5, c_hi = len - 7;   // sectors cover local [5, len-7]
     float mnx = FLT_MAX, mny = FLT_MAX, mnz = FLT_MAX, mxx = -FLT_MAX, mxy = -FLT_MAX, mxz = -FLT_MAX;
     int ncand = 0;
-    for (int i = c_lo + tid; i <= c_hi; i += 256) {
-        if (label[i] <= 0) {
-            const float4 p = cl[i];
+    // the ring's points stay in registers (point tid + 256 m in slot m): all loads are issued back to back, and the
+    // second pass (cell indices) needs no second trip to memory
+    constexpr int kSlots = kRingCap / 256;
+    float4 pr[kSlots];
+    unsigned int cand_mask = 0;
+#pragma unroll
+    for (int m = 0; m < kSlots; m++) {
+        const int i = tid + 256 * m;
+        signed char lb = 1;
+        pr[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < len) { lb = label[i]; pr[m] = cl[i]; }
+        if (i >= c_lo && i <= c_hi && lb <= 0) cand_mask |= 1u << m;
+    }
+#pragma unroll
+    for (int m = 0; m < kSlots; m++) {
+        if ((cand_mask >> m) & 1u) {
+            const float4 p = pr[m];
             mnx = fminf(mnx, p.x); mny = fminf(mny, p.y); mnz = fminf(mnz, p.z);
             mxx = fmaxf(mxx, p.x); mxy = fmaxf(mxy, p.y); mxz = fmaxf(mxz, p.z);
             ncand++;
@@ -387,49 +404,80 @@ __global__ __launch_bounds__(256) void k_voxel(BatchView b)
     const int minb0 = (int)floorf(mnx * inv_leaf), minb1 = (int)floorf(mny * inv_leaf), minb2 = (int)floorf(mnz * inv_leaf);
     const int div0 = (int)floorf(mxx * inv_leaf) - minb0 + 1, div1 = (int)floorf(mxy * inv_leaf) - minb1 + 1;
     const int mul1 = div0, mul2 = div0 * div1;
-    const int np2v = next_pow2(len);
     __syncthreads();
-    for (int i = tid; i < np2v; i += 256) {
-        unsigned long long key = ~0ull;
-        if (i >= c_lo && i <= c_hi && label[i] <= 0) {
-            const float4 p = cl[i];
+#pragma unroll
+    for (int m = 0; m < kSlots; m++) {
+        const int i = tid + 256 * m;
+        if (i >= len) continue;
+        unsigned int cell = ~0u;
+        if ((cand_mask >> m) & 1u) {
+            const float4 p = pr[m];
             const int i0 = (int)(floorf(p.x * inv_leaf) - (float)minb0);
             const int i1 = (int)(floorf(p.y * inv_leaf) - (float)minb1);
             const int i2 = (int)(floorf(p.z * inv_leaf) - (float)minb2);
-            const unsigned int cell = (unsigned int)(i0 + i1 * mul1 + i2 * mul2);
-            key = ((unsigned long long)cell << 32) | (unsigned int)i;
+            cell = (unsigned int)(i0 + i1 * mul1 + i2 * mul2);
         }
-        keys[i] = key;
+        cellv[i] = cell;
     }
     __syncthreads();
-    bitonic_sort_u64(keys, np2v);
-    // run starts -> output slots (block-wide exclusive scan over contiguous per-thread chunks)
-    const int chunk = (np2v + 255) / 256;
-    const int t_lo = tid * chunk, t_hi = min(t_lo + chunk, ncand);
-    int nstart = 0;
-    for (int t = t_lo; t < t_hi; t++) {
-        const unsigned int cell = (unsigned int)(keys[t] >> 32);
-        if (t == 0 || cell != (unsigned int)(keys[t - 1] >> 32)) nstart++;
+    // segment heads: a candidate whose predecessor in the ring is not a candidate of the same cell
+    const int chunk = (len + 255) / 256;
+    const int i_lo = tid * chunk, i_hi = min(i_lo + chunk, len);
+    int nhead = 0;
+    for (int i = i_lo; i < i_hi; i++) {
+        const unsigned int c = cellv[i];
+        if (c != ~0u && (i == 0 || cellv[i - 1] != c)) nhead++;
     }
-    const int incl = wave_scan_incl(nstart);
+    int incl = wave_scan_incl(nhead);
     if (lane == 63) scr[40 + wave] = incl;
     __syncthreads();
-    int base = incl - nstart;
+    int base = incl - nhead;
     for (int w = 0; w < wave; w++) base += scr[40 + w];
-    const int n_out = scr[40] + scr[41] + scr[42] + scr[43];
+    const int nseg = scr[40] + scr[41] + scr[42] + scr[43];
+    int np2 = next_pow2(nseg);
+    if (np2 < 2) np2 = 2;
+    __syncthreads();
+    {
+        int o = base;
+        for (int i = i_lo; i < i_hi; i++) {
+            const unsigned int c = cellv[i];
+            if (c != ~0u && (i == 0 || cellv[i - 1] != c)) keys[o++] = ((unsigned long long)c << 32) | (unsigned int)i;
+        }
+        for (int k = nseg + tid; k < np2; k += 256) keys[k] = ~0ull;
+    }
+    __syncthreads();
+    bitonic_sort_u64(keys, np2);
+    // runs of equal cell over the sorted segments -> output voxels
+    const int chunk2 = (np2 + 255) / 256;
+    const int t_lo = tid * chunk2, t_hi = min(t_lo + chunk2, nseg);
+    int nstart = 0;
+    for (int t = t_lo; t < t_hi; t++) {
+        const unsigned int c = (unsigned int)(keys[t] >> 32);
+        if (t == 0 || c != (unsigned int)(keys[t - 1] >> 32)) nstart++;
+    }
+    incl = wave_scan_incl(nstart);
+    __syncthreads();
+    if (lane == 63) scr[48 + wave] = incl;
+    __syncthreads();
+    base = incl - nstart;
+    for (int w = 0; w < wave; w++) base += scr[48 + w];
+    const int n_out = scr[48] + scr[49] + scr[50] + scr[51];
     float4 *outp = b.lf_tmp + off + rbeg;
     int o = base;
     for (int t = t_lo; t < t_hi; t++) {
-        const unsigned int cell = (unsigned int)(keys[t] >> 32);
-        if (t == 0 || cell != (unsigned int)(keys[t - 1] >> 32)) {
+        const unsigned int c = (unsigned int)(keys[t] >> 32);
+        if (t == 0 || c != (unsigned int)(keys[t - 1] >> 32)) {
             float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
-            int u = t;
-            for (; u < ncand && (unsigned int)(keys[u] >> 32) == cell; u++) {
-                const float4 p = cl[(int)(keys[u] & 0xffffffffull)];
-                sx += p.x; sy += p.y; sz += p.z; si += p.w;
+            int cnt = 0;
+            for (int u = t; u < nseg && (unsigned int)(keys[u] >> 32) == c; u++) {
+                for (int i = (int)(keys[u] & 0xffffffffull); i < len && cellv[i] == c; i++) {
+                    const float4 p = cl[i];
+                    sx += p.x; sy += p.y; sz += p.z; si += p.w;
+                    cnt++;
+                }
             }
-            const float cnt = (float)(u - t);
-            outp[o++] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
+            const float fc = (float)cnt;
+            outp[o++] = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
         }
     }
     if (tid == 0) b.lf_n[s * 64 + r] = n_out;

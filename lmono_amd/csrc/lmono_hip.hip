@@ -315,7 +315,7 @@ static int ensure_odom_ws(lmono_ctx *c, lmono_scan_batch *b, int n_chains)
     return LMONO_OK;
 }
 
-extern "C" int lmono_odom_batch_d(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, double *incr_d, double *poses_d)
+static int odom_run(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, double *incr_d, double *poses_d, bool want_poses)
 {
     if (!c || !b || !b->registered || lead < 0) return LMONO_EINVAL;
     const int n = b->n_scans;
@@ -358,7 +358,7 @@ extern "C" int lmono_odom_batch_d(lmono_ctx *c, lmono_scan_batch *b, int n_chain
         }
     }
     es.n_kev = ne;
-    hipLaunchKernelGGL(k_pose_prefix, dim3(1), dim3(64), 0, st, (const double *)b->incr, b->poses, 0, n);
+    if (want_poses) hipLaunchKernelGGL(k_pose_prefix, dim3(1), dim3(64), 0, st, (const double *)b->incr, b->poses, 0, n);
     HIP_TRY(c, hipEventRecord(c->ev[9], st));
     rc = check_launch(c, "odometry kernels");
     if (rc) return rc;
@@ -367,9 +367,14 @@ extern "C" int lmono_odom_batch_d(lmono_ctx *c, lmono_scan_batch *b, int n_chain
     return LMONO_OK;
 }
 
+extern "C" int lmono_odom_batch_d(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, double *incr_d, double *poses_d)
+{
+    return odom_run(c, b, n_chains, lead, incr_d, poses_d, poses_d != nullptr);
+}
+
 extern "C" int lmono_odom_batch(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, double *incr_h, double *poses_h)
 {
-    int rc = lmono_odom_batch_d(c, b, n_chains, lead, nullptr, nullptr);
+    int rc = odom_run(c, b, n_chains, lead, nullptr, nullptr, poses_h != nullptr);
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     const int n = b->n_scans;

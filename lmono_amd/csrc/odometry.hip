@@ -1021,30 +1021,57 @@ __global__ void k_odom_init(OdomView o)
     }
 }
 
-// poses[k - first] = incr[first] (+) incr[first+1] (+) ... (+) incr[k]  (t_w += q_w * t ; q_w = q_w * q), one lane,
-// sequential like the reference.  incr[0] is the identity, so first = 0 gives poses relative to scan 0; for
-// first > 0 the result is relative to scan first-1 (the previous rank's last scan).
-__global__ void k_pose_prefix(const double *incr, double *poses, int first, int n)
+// poses[k - first] = incr[first] (+) incr[first+1] (+) ... (+) incr[k]  (t_w += q_w * t ; q_w = q_w * q).
+// incr[0] is the identity, so first = 0 gives poses relative to scan 0; for first > 0 the result is relative to scan
+// first-1 (the previous rank's last scan).  One wave: every lane composes a contiguous segment, an inclusive wave scan
+// composes the segment totals, then every lane re-bases its segment (SE(3) composition is associative; the result
+// differs from the strictly sequential product only by rounding, ~1e-16).
+__device__ __forceinline__ void se3_compose(const double *a, const double *b, double *o)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double qw[4] = { 0, 0, 0, 1 }, tw[3] = { 0, 0, 0 };
+    double rx, ry, rz;
+    quat_rotate(a, b[4], b[5], b[6], rx, ry, rz);
+    const double ax = a[0], ay = a[1], az = a[2], aw = a[3];
+    const double bx = b[0], by = b[1], bz = b[2], bw = b[3];
+    const double t0 = a[4] + rx, t1 = a[5] + ry, t2 = a[6] + rz;
+    o[3] = aw * bw - ax * bx - ay * by - az * bz;
+    o[0] = aw * bx + ax * bw + ay * bz - az * by;
+    o[1] = aw * by + ay * bw + az * bx - ax * bz;
+    o[2] = aw * bz + az * bw + ax * by - ay * bx;
+    o[4] = t0; o[5] = t1; o[6] = t2;
+}
+
+__global__ __launch_bounds__(64) void k_pose_prefix(const double *incr, double *poses, int first, int n)
+{
+    const int lane = threadIdx.x;
     incr += (size_t)first * 7;
     n -= first;
-    for (int k = 0; k < n; k++) {
-        {
-            const double *q = incr + (size_t)k * 7, *t = q + 4;
-            double rx, ry, rz;
-            quat_rotate(qw, t[0], t[1], t[2], rx, ry, rz);
-            tw[0] += rx; tw[1] += ry; tw[2] += rz;
-            const double ax = qw[0], ay = qw[1], az = qw[2], aw = qw[3];
-            const double bx = q[0], by = q[1], bz = q[2], bw = q[3];
-            qw[3] = aw * bw - ax * bx - ay * by - az * bz;
-            qw[0] = aw * bx + ax * bw + ay * bz - az * by;
-            qw[1] = aw * by + ay * bw + az * bx - ax * bz;
-            qw[2] = aw * bz + az * bw + ax * by - ay * bx;
+    const int seg = (n + 63) / 64;
+    const int k0 = lane * seg, k1 = min(k0 + seg, n);
+    double acc[7] = { 0, 0, 0, 1, 0, 0, 0 };
+    for (int k = k0; k < k1; k++) {
+        double o[7];
+        se3_compose(acc, incr + (size_t)k * 7, o);
+        for (int i = 0; i < 7; i++) acc[i] = o[i];
+        for (int i = 0; i < 7; i++) poses[(size_t)k * 7 + i] = acc[i];
+    }
+    // inclusive scan of the segment totals over the lanes (Hillis-Steele with SE(3) composition, left operand = lower lanes)
+    double tot[7];
+    for (int i = 0; i < 7; i++) tot[i] = acc[i];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        double left[7], o[7];
+        for (int i = 0; i < 7; i++) left[i] = __shfl_up(tot[i], d);
+        if (lane >= d) { se3_compose(left, tot, o); for (int i = 0; i < 7; i++) tot[i] = o[i]; }
+    }
+    double base[7];
+    for (int i = 0; i < 7; i++) base[i] = __shfl_up(tot[i], 1);
+    if (lane > 0) {
+        for (int k = k0; k < k1; k++) {
+            double cur[7], o[7];
+            for (int i = 0; i < 7; i++) cur[i] = poses[(size_t)k * 7 + i];
+            se3_compose(base, cur, o);
+            for (int i = 0; i < 7; i++) poses[(size_t)k * 7 + i] = o[i];
         }
-        double *p = poses + (size_t)k * 7;
-        p[0] = qw[0]; p[1] = qw[1]; p[2] = qw[2]; p[3] = qw[3]; p[4] = tw[0]; p[5] = tw[1]; p[6] = tw[2];
     }
 }
 
