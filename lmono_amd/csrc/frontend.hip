@@ -214,18 +214,84 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
     return v;
 }
 
-// after a pick at ring-local index pind: how far the suppression reaches forward / backward (0..5); lanes 0..4 look
-// at the forward gaps, lanes 5..9 at the backward gaps, and the first gap whose squared length exceeds 0.05 stops it
-__device__ __forceinline__ void suppression_reach(const unsigned char *gap, int pind, int lane, int &lf, int &lb)
+// key of a sector element: (curvature bits, index, suppression reach).  Ordering by the key = ordering by
+// (curvature, index), so the arg-max / arg-min over keys reproduces the sort's tie order; the winner's reach rides along.
+__device__ __forceinline__ unsigned long long select_key(float c, int idx, unsigned int reach)
 {
-    const bool fwd = lane < 5;
-    const int l = fwd ? lane + 1 : lane - 4;
-    const int gi = fwd ? pind + l - 1 : pind - l;
-    const bool brk = lane < 10 ? (gap[gi] != 0) : false;
-    const unsigned long long mb = __ballot(brk);
-    const unsigned int mf = (unsigned int)(mb & 0x1full), mbk = (unsigned int)((mb >> 5) & 0x1full);
-    lf = mf ? (__ffs((int)mf) - 1) : 5;
-    lb = mbk ? (__ffs((int)mbk) - 1) : 5;
+    return ((unsigned long long)__float_as_uint(c) << 32) | ((unsigned int)idx << 8) | reach;
+}
+
+// one sector of one ring, M register slots per lane (element m of a lane is ring-local index sp + lane + 64 m)
+template <int M>
+__device__ __forceinline__ void select_sector(int lane, int j, int sp, int slen, int rbeg, const float *curv, unsigned char *picked,
+                                              signed char *label, const unsigned char *gap, int *sel_sh, int *sel_sh_n, int *sel_fl, int *sel_fl_n)
+{
+    unsigned long long key[M];
+    unsigned int dead = 0, big = 0, small = 0;     // bit m: suppressed / out of range; curvature > 0.1; < 0.1
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+        const int e = lane + 64 * m;
+        key[m] = 0ull;
+        if (e < slen) {
+            const int i = sp + e;
+            const float c = curv[i];
+            // suppression reach: the neighbour walk marks l = 1..5 forward while the gap before point i+l is short,
+            // and the same backward
+            int lf = 0, lb = 0;
+            while (lf < 5 && gap[i + lf] == 0) lf++;
+            while (lb < 5 && gap[i - lb - 1] == 0) lb++;
+            key[m] = select_key(c, i, (unsigned int)(lf | (lb << 4)));
+            if (picked[i]) dead |= 1u << m;
+            if ((double)c > 0.1) big |= 1u << m;
+            if ((double)c < 0.1) small |= 1u << m;
+        } else dead |= 1u << m;
+    }
+    // ---- largest curvature first: <= 2 sharp, <= 20 less sharp
+    int largest = 0;
+    while (true) {
+        unsigned long long best = 0ull;
+        const unsigned int live = big & ~dead;
+#pragma unroll
+        for (int m = 0; m < M; m++)
+            if ((live >> m) & 1u) best = key[m] > best ? key[m] : best;
+        best = wave_max_u64(best);
+        if (best == 0ull) break;
+        const unsigned int lo = (unsigned int)(best & 0xffffffffull);
+        const int pind = (int)(lo >> 8), lf = (int)(lo & 15u), lb = (int)((lo >> 4) & 15u);
+        largest++;
+        if (largest > 20) break;
+        if (lane == 0) { sel_sh[j * 20 + largest - 1] = rbeg + pind; label[pind] = largest <= 2 ? 2 : 1; }
+        if (lane <= lf + lb) picked[pind - lb + lane] = 1;
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            const int idx = sp + lane + 64 * m;
+            if (idx >= pind - lb && idx <= pind + lf) dead |= 1u << m;
+        }
+    }
+    if (lane == 0) sel_sh_n[j] = largest > 20 ? 20 : largest;
+    // ---- smallest curvature first: <= 4 flat
+    int smallest = 0;
+    while (true) {
+        unsigned long long best = ~0ull;
+        const unsigned int live = small & ~dead;
+#pragma unroll
+        for (int m = 0; m < M; m++)
+            if ((live >> m) & 1u) best = key[m] < best ? key[m] : best;
+        best = wave_min_u64(best);
+        if (best == ~0ull) break;
+        const unsigned int lo = (unsigned int)(best & 0xffffffffull);
+        const int pind = (int)(lo >> 8), lf = (int)(lo & 15u), lb = (int)((lo >> 4) & 15u);
+        if (lane == 0) { label[pind] = -1; sel_fl[j * 4 + smallest] = rbeg + pind; }
+        smallest++;
+        if (smallest >= 4) break;
+        if (lane <= lf + lb) picked[pind - lb + lane] = 1;
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            const int idx = sp + lane + 64 * m;
+            if (idx >= pind - lb && idx <= pind + lf) dead |= 1u << m;
+        }
+    }
+    if (lane == 0) sel_fl_n[j] = smallest;
 }
 
 __global__ __launch_bounds__(256) void k_select(BatchView b)
@@ -252,76 +318,14 @@ __global__ __launch_bounds__(256) void k_select(BatchView b)
     unsigned char *gap = picked + 2 * kRingCap;
     const float *curv = b.curv + off + rbeg;
     for (int i = lane; i < len; i += 64) { picked[i] = 0; label[i] = 0; gap[i] = b.gap[off + rbeg + i]; }
-
     const int span = E - S;
     for (int j = 0; j < kSectors; j++) {
         const int sp = 5 + span * j / 6;
         const int ep = 5 + span * (j + 1) / 6 - 1;
         const int slen = ep - sp + 1;
-        // register-resident sector: element m of this lane is ring-local index sp + lane + 64 m
-        float c[kSelMaxPerLane];
-        unsigned int dead = 0;     // bit m: element suppressed (picked) or out of range
-#pragma unroll
-        for (int m = 0; m < kSelMaxPerLane; m++) {
-            const int e = lane + 64 * m;
-            c[m] = 0.f;
-            if (e < slen) { c[m] = curv[sp + e]; if (picked[sp + e]) dead |= 1u << m; }
-            else dead |= 1u << m;
-        }
-        // ---- largest curvature first
-        int largest = 0;
-        while (true) {
-            unsigned long long key = 0ull;
-#pragma unroll
-            for (int m = 0; m < kSelMaxPerLane; m++) {
-                if (!((dead >> m) & 1u) && (double)c[m] > 0.1) {
-                    const unsigned long long kk = pack_fu(c[m], (unsigned int)(sp + lane + 64 * m));
-                    key = kk > key ? kk : key;
-                }
-            }
-            key = wave_max_u64(key);
-            if (key == 0ull) break;
-            const int pind = (int)(unsigned int)(key & 0xffffffffull);
-            largest++;
-            if (largest > 20) break;
-            if (lane == 0) { sel_sh[j * 20 + largest - 1] = rbeg + pind; label[pind] = largest <= 2 ? 2 : 1; }
-            int lf, lb;
-            suppression_reach(gap, pind, lane, lf, lb);
-            if (lane <= lf + lb) picked[pind - lb + lane] = 1;
-#pragma unroll
-            for (int m = 0; m < kSelMaxPerLane; m++) {
-                const int idx = sp + lane + 64 * m;
-                if (idx >= pind - lb && idx <= pind + lf) dead |= 1u << m;
-            }
-        }
-        if (lane == 0) sel_sh_n[j] = largest > 20 ? 20 : largest;
-        // ---- smallest curvature first
-        int smallest = 0;
-        while (true) {
-            unsigned long long key = ~0ull;
-#pragma unroll
-            for (int m = 0; m < kSelMaxPerLane; m++) {
-                if (!((dead >> m) & 1u) && (double)c[m] < 0.1) {
-                    const unsigned long long kk = pack_fu(c[m], (unsigned int)(sp + lane + 64 * m));
-                    key = kk < key ? kk : key;
-                }
-            }
-            key = wave_min_u64(key);
-            if (key == ~0ull) break;
-            const int pind = (int)(unsigned int)(key & 0xffffffffull);
-            if (lane == 0) { label[pind] = -1; sel_fl[j * 4 + smallest] = rbeg + pind; }
-            smallest++;
-            if (smallest >= 4) break;
-            int lf, lb;
-            suppression_reach(gap, pind, lane, lf, lb);
-            if (lane <= lf + lb) picked[pind - lb + lane] = 1;
-#pragma unroll
-            for (int m = 0; m < kSelMaxPerLane; m++) {
-                const int idx = sp + lane + 64 * m;
-                if (idx >= pind - lb && idx <= pind + lf) dead |= 1u << m;
-            }
-        }
-        if (lane == 0) sel_fl_n[j] = smallest;
+        // HDL-64-sized sectors (<= 384 points) take the 6-slot instantiation, longer rings the full one
+        if (slen <= 6 * 64) select_sector<6>(lane, j, sp, slen, rbeg, curv, picked, label, gap, sel_sh, sel_sh_n, sel_fl, sel_fl_n);
+        else select_sector<kSelMaxPerLane>(lane, j, sp, slen, rbeg, curv, picked, label, gap, sel_sh, sel_sh_n, sel_fl, sel_fl_n);
     }
     for (int i = lane; i < len; i += 64) b.label[off + rbeg + i] = label[i];
 }
