@@ -146,3 +146,68 @@ def test_two_rank_sharded_run_matches_unsharded():
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert out.stdout.count("max |pose - unsharded|") == 2
+
+
+def test_api_errors_and_limits(oracle, gpu_ctx, small_seq):
+    import torch
+    import lmono_amd
+    xyzi, off = small_seq["xyzi"], small_seq["off"]
+    dev = torch.from_numpy(xyzi).cuda()
+    b = lmono_amd.ScanBatch(gpu_ctx, 2, 10)                        # capacity: 2 scans, 10 points
+    with pytest.raises(lmono_amd.LmonoError):
+        b.scanreg(dev.data_ptr(), off[:3], 64, 5.0)                 # too many points -> LMONO_ECAPACITY
+    b = lmono_amd.ScanBatch(gpu_ctx, 8, len(xyzi))
+    with pytest.raises(lmono_amd.LmonoError):
+        b.odometry(1, 0)                                            # odometry before registration -> LMONO_EINVAL
+    with pytest.raises(lmono_amd.LmonoError):
+        b.scanreg(dev.data_ptr(), off, 48, 5.0)                     # n_lines must be 16 / 32 / 64
+    b.scanreg(dev.data_ptr(), off, 64, 5.0, keepalive=dev)
+    incr, poses = b.odometry(1000, 2)                               # n_chains is clamped to the number of scans
+    ref = oracle.run_sequence(xyzi, off, n_chains=len(off) - 1, lead=2)
+    assert np.abs(incr - ref["incr"]).max() < 1e-9
+    one = lmono_amd.ScanBatch(gpu_ctx, 1, len(xyzi))
+    one.scanreg(dev.data_ptr(), off[:2], 64, 5.0, keepalive=dev)
+    incr, poses = one.odometry(1, 0)                                # a single scan: identity
+    assert np.array_equal(incr, np.array([[0, 0, 0, 1, 0, 0, 0.0]])) and np.array_equal(poses, incr)
+
+
+def test_ring_longer_than_kernel_limit_is_flagged(gpu_ctx):
+    """A ring with more than LMONO_RING_CAP = 4096 points sets status bit 1 for that scan and contributes no features."""
+    import torch
+    import lmono_amd
+    n = 6000
+    az = np.linspace(-3.1, 3.1, n)
+    elev = np.deg2rad(-5.0)
+    pts = np.stack([20 * np.cos(elev) * np.cos(az), 20 * np.cos(elev) * np.sin(az), np.full(n, 20 * np.sin(elev)), np.zeros(n)], 1).astype(np.float32)
+    dev = torch.from_numpy(pts).cuda()
+    b = lmono_amd.ScanBatch(gpu_ctx, 1, n)
+    b.scanreg(dev.data_ptr(), np.array([0, n], np.int64), 64, 5.0, keepalive=dev)
+    cnt = b.counts()
+    assert cnt[0, 0] == n and cnt[0, 5] & 1 and cnt[0, 1] == 0 and cnt[0, 3] == 0
+
+
+def test_full_size_batch_properties(gpu_ctx, oracle):
+    """32 full-resolution scans (size-independent properties at bench scale): sharp is a prefix-subset of less_sharp per
+    sector, counts respect the per-sector caps, labels agree with the clouds, poses have unit quaternions."""
+    import torch
+    import lmono_amd
+    w = oracle.S1World()
+    xyzi, off = w.scans(w.trajectory(32, speed=8.0), scan_id0=1000)
+    dev = torch.from_numpy(xyzi).cuda()
+    b = lmono_amd.ScanBatch(gpu_ctx, 32, len(xyzi))
+    b.scanreg(dev.data_ptr(), off, keepalive=dev)
+    cnt = b.counts()
+    assert (cnt[:, 5] == 0).all()
+    assert (cnt[:, 1] <= 51 * 6 * 2).all() and (cnt[:, 2] <= 51 * 6 * 20).all() and (cnt[:, 3] <= 51 * 6 * 4).all()
+    for s in (0, 17, 31):
+        n = int(off[s + 1] - off[s])
+        cv, lb = b.curvature(s, n)
+        assert (lb == 2).sum() == cnt[s, 1] and ((lb == 2) | (lb == 1)).sum() == cnt[s, 2] and (lb == -1).sum() == cnt[s, 3]
+        assert (cv[lb > 0] > 0.1).all() and (cv[lb == -1] < 0.1).all()
+        sharp = b.cloud(s, 1, n); ls = b.cloud(s, 2, n)
+        keys = {p.tobytes() for p in ls}
+        assert all(p.tobytes() in keys for p in sharp)
+    incr, poses = b.odometry(4, 3)
+    assert np.abs(np.linalg.norm(poses[:, :4], axis=1) - 1).max() < 1e-9
+    fwd = incr[1:, 4]
+    assert (fwd > 0.5).all() and (fwd < 1.1).all()                  # ~0.8 m per scan
