@@ -151,6 +151,22 @@ int lmono_outlier_scores(lmono_ctx *, int n_windows, const int *feat_off_h, cons
 int lmono_shift_depth(lmono_ctx *, const double *back_R0, const double *back_P0, const double *R1, const double *P1, const double *tlc,
                       int n, const double *pt_i_h, const double *depth_h, double *depth_out_h);
 
+/* ---- marginalisation prior: the MARGIN_OLD branch of Estimator::margin() ----------------------------------- *
+ * Reference interfaces: Estimator::margin (src/image_process/Estimator.cc:1307-1405), MarginalizationInfo::
+ * {preMarginalize, marginalize} and Marginalization::Evaluate (src/factor/MarginalizationFactor.cc:109-131, :176-272,
+ * :309-373).  Factors: LASERFactor(pose0, pose1) and one MonoProjectionFactor + CauchyLoss(1) per observation of the
+ * tracks anchored at frame 0 (observations grouped by track; obs_j in 1..10; obs_pts = pt_i.xy, pt_j.xy -- the
+ * reference passes the never-initialised right_pt here).  Kept blocks, in this order: ex, pose1 .. pose10 (n = 66).
+ * lin_J_h [n_windows][66*66] = linearized_jacobians, lin_r_h [n_windows][66] = linearized_residuals (defined up to an
+ * orthogonal row transform: compare J^T J and J^T r); status_h bit 0: H_mm needed the eps = 1e-8 cut.
+ * lmono_marg_evaluate: residual = r0 + J dx with x0_h / x_h [n_windows][11][7] (ex, pose1..pose10).               */
+int lmono_marginalize(lmono_ctx *, int n_windows, const int *feat_off_h, const int *obs_off_h, const double *poses_h, const double *ex_h,
+                      const double *inv_depth_h, const int *obs_feat_h, const int *obs_j_h, const double *obs_pts_h,
+                      const double *laser01_h, const double *laser_info_h, const double *mono_info_h,
+                      double *lin_J_h, double *lin_r_h, int *status_h);
+int lmono_marg_evaluate(lmono_ctx *, int n_windows, const double *lin_J_h, const double *lin_r_h, const double *x0_h, const double *x_h,
+                        double *residual_h);
+
 /* ---- pose composition (laserOdometry: t_w_curr += q_w_curr * t_last_curr; q_w_curr *= q_last_curr) ------- *
  * lmono_pose_prefix_d: poses_d[k - first] = incr[first] (+) ... (+) incr[k] for k in [first, n) (incr[0] is the
  * identity: first = 0 gives poses relative to scan 0, first > 0 poses relative to scan first-1).  lmono_pose_rebase_d: poses[k] <- bases[0] (+) ... (+) bases[n_bases-1] (+) poses[k]; with scans

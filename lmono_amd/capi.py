@@ -13,7 +13,7 @@ SYMBOLS = [
     "lmono_batch_create", "lmono_batch_destroy", "lmono_scanreg_batch", "lmono_batch_counts", "lmono_batch_get_cloud",
     "lmono_batch_get_curvature", "lmono_odom_batch", "lmono_odom_batch_d", "lmono_odom_correspond", "lmono_timing_reset", "lmono_timing_read",
     "lmono_pose_prefix_d", "lmono_pose_rebase_d", "lmono_factor_eval", "lmono_factor_eval_d",
-    "lmono_triangulate", "lmono_outlier_scores", "lmono_shift_depth", "lmono_ba_batch_create", "lmono_ba_batch_destroy", "lmono_ba_solve", "lmono_ba_batch_reset", "lmono_ba_batch_read",
+    "lmono_triangulate", "lmono_outlier_scores", "lmono_shift_depth", "lmono_marginalize", "lmono_marg_evaluate", "lmono_ba_batch_create", "lmono_ba_batch_destroy", "lmono_ba_solve", "lmono_ba_batch_reset", "lmono_ba_batch_read",
 ]
 
 
@@ -58,6 +58,8 @@ def load_library():
     L.lmono_triangulate.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 9 + [C.c_int, C.c_int, C.c_double, C.c_int]
     L.lmono_outlier_scores.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_double, C.c_void_p]
     L.lmono_shift_depth.argtypes = [C.c_void_p] * 6 + [C.c_int] + [C.c_void_p] * 3
+    L.lmono_marginalize.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 14
+    L.lmono_marg_evaluate.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
     L.lmono_ba_batch_create.restype = C.c_void_p
     L.lmono_ba_batch_create.argtypes = [C.c_void_p, C.c_void_p]
     L.lmono_ba_batch_destroy.argtypes = [C.c_void_p]
@@ -160,6 +162,29 @@ class Context:
         pt = np.ascontiguousarray(pt_i, np.float64).reshape(-1, 2); d = np.ascontiguousarray(depth, np.float64); out = np.zeros(len(d))
         self.check(self.L.lmono_shift_depth(self.h, *[v.ctypes.data for v in a], len(d), pt.ctypes.data, d.ctypes.data, out.ctypes.data))
         return out
+
+    def marginalize(self, windows):
+        """windows: list of dicts(poses [11,7], ex [7], invd [F0], obs_feat, obs_j, pts [O,4], laser01 [24], laser_info, mono_info)."""
+        W = len(windows)
+        feat_off = np.concatenate([[0], np.cumsum([len(w["invd"]) for w in windows])]).astype(np.int32)
+        obs_off = np.concatenate([[0], np.cumsum([len(w["obs_j"]) for w in windows])]).astype(np.int32)
+        cat = lambda k, dt: np.ascontiguousarray(np.concatenate([np.asarray(w[k], dt).reshape(len(w[k]), -1) for w in windows]).ravel(), dt)
+        poses = np.ascontiguousarray([w["poses"] for w in windows], np.float64); ex = np.ascontiguousarray([w["ex"] for w in windows], np.float64)
+        invd = cat("invd", np.float64); of = cat("obs_feat", np.int32); oj = cat("obs_j", np.int32); pts = cat("pts", np.float64)
+        l01 = np.ascontiguousarray([w["laser01"] for w in windows], np.float64)
+        li = np.ascontiguousarray(windows[0]["laser_info"], np.float64); mi = np.ascontiguousarray(windows[0]["mono_info"], np.float64)
+        J = np.zeros((W, 66, 66)); r = np.zeros((W, 66)); st = np.zeros(W, np.int32)
+        self.check(self.L.lmono_marginalize(self.h, W, feat_off.ctypes.data, obs_off.ctypes.data, poses.ctypes.data, ex.ctypes.data, invd.ctypes.data,
+                                            of.ctypes.data, oj.ctypes.data, pts.ctypes.data, l01.ctypes.data, li.ctypes.data, mi.ctypes.data,
+                                            J.ctypes.data, r.ctypes.data, st.ctypes.data))
+        return J, r, st
+
+    def marg_evaluate(self, lin_J, lin_r, x0, x):
+        lin_J = np.ascontiguousarray(lin_J, np.float64); lin_r = np.ascontiguousarray(lin_r, np.float64)
+        x0 = np.ascontiguousarray(x0, np.float64); x = np.ascontiguousarray(x, np.float64)
+        W = len(lin_r); res = np.zeros((W, 66))
+        self.check(self.L.lmono_marg_evaluate(self.h, W, lin_J.ctypes.data, lin_r.ctypes.data, x0.ctypes.data, x.ctypes.data, res.ctypes.data))
+        return res
 
     def pose_prefix_d(self, incr_ptr, first, n, poses_ptr):
         self.check(self.L.lmono_pose_prefix_d(self.h, C.c_void_p(incr_ptr), first, n, C.c_void_p(poses_ptr)))

@@ -5,6 +5,7 @@
 #include "ba.hip"
 #include "ba_solve.hip"
 #include "feat.hip"
+#include "marg.hip"
 
 #include <string>
 #include <vector>
@@ -671,5 +672,70 @@ extern "C" int lmono_shift_depth(lmono_ctx *c, const double *back_R0, const doub
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(depth_out_h, o, sizeof(double) * n, hipMemcpyDeviceToHost));
+    return LMONO_OK;
+}
+
+// ---- marginalisation prior ----------------------------------------------------------------------------------------
+extern "C" int lmono_marginalize(lmono_ctx *c, int n_windows, const int *feat_off_h, const int *obs_off_h, const double *poses_h, const double *ex_h,
+                                 const double *inv_depth_h, const int *obs_feat_h, const int *obs_j_h, const double *obs_pts_h,
+                                 const double *laser01_h, const double *laser_info_h, const double *mono_info_h,
+                                 double *lin_J_h, double *lin_r_h, int *status_h)
+{
+    if (!c || n_windows <= 0 || !feat_off_h || !obs_off_h || !poses_h || !ex_h || !laser01_h || !laser_info_h || !mono_info_h || !lin_J_h || !lin_r_h) return LMONO_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int TF = feat_off_h[n_windows], TO = obs_off_h[n_windows];
+    std::vector<int> fo((size_t)TF + 1, 0);
+    for (int w = 0; w < n_windows; w++) {
+        if (feat_off_h[w + 1] - feat_off_h[w] > kMargMaxF0) { c->err = "lmono_marginalize: more than 128 tracks anchored at frame 0"; return LMONO_ECAPACITY; }
+        int o = obs_off_h[w];
+        for (int f = feat_off_h[w]; f < feat_off_h[w + 1]; f++) {
+            fo[f] = o;
+            while (o < obs_off_h[w + 1] && obs_feat_h[o] == f - feat_off_h[w]) {
+                if (obs_j_h[o] < 1 || obs_j_h[o] > 10) { c->err = "lmono_marginalize: observation frame must be 1..10"; return LMONO_EINVAL; }
+                o++;
+            }
+        }
+        if (o != obs_off_h[w + 1]) { c->err = "lmono_marginalize: observations are not grouped by track"; return LMONO_EINVAL; }
+    }
+    fo[TF] = TO;
+    double info[40];
+    memcpy(info, laser_info_h, 36 * sizeof(double)); memcpy(info + 36, mono_info_h, 4 * sizeof(double));
+    DevBuf db; bool ok = true;
+    MargBatch B{};
+    B.n_windows = n_windows;
+    B.feat_off = db.up(feat_off_h, (size_t)n_windows + 1, ok); B.obs_off = db.up(obs_off_h, (size_t)n_windows + 1, ok);
+    B.poses = db.up(poses_h, (size_t)n_windows * 77, ok); B.ex = db.up(ex_h, (size_t)n_windows * 7, ok);
+    B.inv_depth = db.up(inv_depth_h, (size_t)TF, ok); B.feat_obs_off = db.up(fo.data(), (size_t)TF + 1, ok);
+    B.obs_j = db.up(obs_j_h, (size_t)TO, ok); B.obs_pts = db.up(obs_pts_h, (size_t)TO * 4, ok);
+    B.laser01 = db.up(laser01_h, (size_t)n_windows * 24, ok); B.info = db.up(info, (size_t)40, ok);
+    B.lin_J = db.up((const double *)nullptr, (size_t)n_windows * kMargN * kMargN, ok); B.lin_r = db.up((const double *)nullptr, (size_t)n_windows * kMargN, ok);
+    B.status = db.up((const int *)nullptr, (size_t)n_windows, ok);
+    if (!ok) { c->err = "lmono_marginalize: device allocation / upload failed"; return LMONO_ENOMEM; }
+    static bool attr_set = false;
+    if (!attr_set) { HIP_TRY(c, hipFuncSetAttribute((const void *)k_marginalize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MargLds))); attr_set = true; }
+    hipLaunchKernelGGL(k_marginalize, dim3(n_windows), dim3(256), sizeof(MargLds), c->stream, B);
+    int rc = check_launch(c, "k_marginalize");
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(lin_J_h, B.lin_J, sizeof(double) * (size_t)n_windows * kMargN * kMargN, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(lin_r_h, B.lin_r, sizeof(double) * (size_t)n_windows * kMargN, hipMemcpyDeviceToHost));
+    if (status_h) HIP_TRY(c, hipMemcpy(status_h, B.status, sizeof(int) * (size_t)n_windows, hipMemcpyDeviceToHost));
+    return LMONO_OK;
+}
+
+extern "C" int lmono_marg_evaluate(lmono_ctx *c, int n_windows, const double *lin_J_h, const double *lin_r_h, const double *x0_h, const double *x_h, double *residual_h)
+{
+    if (!c || n_windows <= 0 || !lin_J_h || !lin_r_h || !x0_h || !x_h || !residual_h) return LMONO_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBuf db; bool ok = true;
+    const double *J = db.up(lin_J_h, (size_t)n_windows * kMargN * kMargN, ok), *r = db.up(lin_r_h, (size_t)n_windows * kMargN, ok);
+    const double *x0 = db.up(x0_h, (size_t)n_windows * 77, ok), *x = db.up(x_h, (size_t)n_windows * 77, ok);
+    double *res = db.up((const double *)nullptr, (size_t)n_windows * kMargN, ok);
+    if (!ok) { c->err = "lmono_marg_evaluate: device allocation / upload failed"; return LMONO_ENOMEM; }
+    hipLaunchKernelGGL(k_marg_evaluate, dim3(n_windows), dim3(128), 0, c->stream, n_windows, J, r, x0, x, res);
+    int rc = check_launch(c, "k_marg_evaluate");
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(residual_h, res, sizeof(double) * (size_t)n_windows * kMargN, hipMemcpyDeviceToHost));
     return LMONO_OK;
 }

@@ -1,0 +1,317 @@
+// lmono_amd/csrc/marg.hip -- marginalisation prior of lmono's Estimator on gfx950 (fp64), one workgroup per window.
+// Restates the MARGIN_OLD branch of Estimator::margin() (/root/reference/mono_lidar_mapping/src/image_process/
+// Estimator.cc:1307-1405) with ResidualBlockInfo::Evaluate, MarginalizationInfo::marginalize and
+// Marginalization::Evaluate (src/factor/MarginalizationFactor.cc:18-68, :176-272, :309-373).
+//
+// Blocks: m = [pose0 (6), inverse depths of the F0 tracks anchored at frame 0], n = [ex, pose1..pose10] = 66.
+// H_mm = [[A, B], [B^T, D]] with D diagonal (each MonoProjectionFactor touches one depth), so
+//   H' = H_rr - G^T S_A^+ G - W_d^T D^+ W_d,   G = W_p - B D^+ W_d,   S_A = A - B D^+ B^T   (6x6)
+// (W_p / W_d = pose0 / depth rows of H_mr).  The reference inverts the full H_mm through an eigen-decomposition with
+// an eps = 1e-8 cut; the structured form applies the same cut to D and to S_A and agrees with it to rounding whenever
+// H_mm has no eigenvalue near eps (every depth observed, pose0 held by the LASERFactor) -- the well-posed case the
+// parity tests cover; a degenerate H_mm is flagged in the status word.  The 66x66 eigen-decomposition of H' that
+// yields linearized_jacobians = sqrt(S) V^T and linearized_residuals = sqrt(S^-1) V^T b' is a parallel (round-robin)
+// Jacobi iteration in LDS.  As in the reference the result is a prior that Estimator::optimization never consumes
+// (MarginalizationInfo::valid stays false).
+#include "common.hpp"
+
+namespace lmono {
+
+constexpr int kMargN = 66;
+constexpr int kMargMaxF0 = 128;
+
+struct MargBatch {
+    int n_windows;
+    const int *feat_off;        // [W+1] tracks anchored at frame 0
+    const int *obs_off;         // [W+1]
+    const double *poses;        // [W][11][7]
+    const double *ex;           // [W][7]
+    const double *inv_depth;    // [total F0]
+    const int *feat_obs_off;    // [total F0 + 1]
+    const int *obs_j;           // [total O]
+    const double *obs_pts;      // [total O][4]
+    const double *laser01;      // [W][24]
+    const double *info;         // laser_info[36], mono_info[4]
+    double *lin_J;              // [W][66*66]
+    double *lin_r;              // [W][66]
+    int *status;                // [W] bit 0: H_mm degenerate (eps cut applied)
+};
+
+struct MargLds {
+    double Hrr[kMargN * kMargN];
+    double V[kMargN * kMargN];
+    double Wd[kMargMaxF0 * kMargN];     // depth rows of H_mr
+    double Wp[6 * kMargN];              // pose0 rows of H_mr, later G
+    double Y[6 * kMargN];
+    double B[6 * kMargMaxF0];
+    double D[kMargMaxF0], bd[kMargMaxF0];
+    double A[36], SAi[36], bp[6], u[6], br[kMargN];
+    double cs[2 * 33];
+    double red[8];
+    int flag;
+};
+
+__device__ __forceinline__ void marg_corrector(double *r, double *J, int nc, const double rho1, const double rho2)
+{
+    // ResidualBlockInfo::Evaluate / ceres::Corrector on one 2-row Jacobian block with leading dimension nc (in place, r untouched)
+    const double sq = r[0] * r[0] + r[1] * r[1];
+    const double sr = sqrt(rho1);
+    double alpha_sq = 0.0;
+    if (!(sq == 0.0 || rho2 <= 0.0)) { const double Dd = 1.0 + 2.0 * sq * rho2 / rho1; alpha_sq = (1.0 - sqrt(Dd)) / sq; }
+    for (int j = 0; j < nc; j++) {
+        const double rj = r[0] * J[j] + r[1] * J[nc + j];
+        J[j] = sr * (J[j] - alpha_sq * r[0] * rj);
+        J[nc + j] = sr * (J[nc + j] - alpha_sq * r[1] * rj);
+    }
+}
+
+// symmetric 6x6 pseudo-inverse with the eps cut (serial Jacobi, one thread)
+__device__ void pinv6(const double *Ain, double *out, double eps, int *degenerate)
+{
+    double M[36], Vv[36];
+    for (int i = 0; i < 36; i++) { M[i] = Ain[i]; Vv[i] = (i % 7 == 0) ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 40; sweep++) {
+        double offn = 0;
+        for (int p = 0; p < 6; p++) for (int q = p + 1; q < 6; q++) offn += M[p * 6 + q] * M[p * 6 + q];
+        if (offn < 1e-300) break;
+        for (int p = 0; p < 6; p++)
+            for (int q = p + 1; q < 6; q++) {
+                const double apq = M[p * 6 + q];
+                if (apq == 0.0) continue;
+                const double theta = (M[q * 6 + q] - M[p * 6 + p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 6; k++) { const double a = M[k * 6 + p], b = M[k * 6 + q]; M[k * 6 + p] = c * a - s * b; M[k * 6 + q] = s * a + c * b; }
+                for (int k = 0; k < 6; k++) { const double a = M[p * 6 + k], b = M[q * 6 + k]; M[p * 6 + k] = c * a - s * b; M[q * 6 + k] = s * a + c * b; }
+                for (int k = 0; k < 6; k++) { const double a = Vv[k * 6 + p], b = Vv[k * 6 + q]; Vv[k * 6 + p] = c * a - s * b; Vv[k * 6 + q] = s * a + c * b; }
+            }
+    }
+    for (int i = 0; i < 36; i++) out[i] = 0.0;
+    for (int k = 0; k < 6; k++) {
+        const double w = M[k * 6 + k];
+        if (!(w > eps)) { *degenerate = 1; continue; }
+        for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) out[i * 6 + j] += Vv[i * 6 + k] * Vv[j * 6 + k] / w;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_marginalize(MargBatch Bt)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    MargLds &L = *reinterpret_cast<MargLds *>(smem_raw);
+    const int w = blockIdx.x, tid = threadIdx.x;
+    const int f0 = Bt.feat_off[w], F0 = Bt.feat_off[w + 1] - f0;
+    const double *poses = Bt.poses + (size_t)w * 77, *ex = Bt.ex + (size_t)w * 7;
+    const double *laser_info = Bt.info, *mono_info = Bt.info + 36;
+    const double eps = 1e-8;
+    for (int k = tid; k < kMargN * kMargN; k += 256) { L.Hrr[k] = 0.0; L.V[k] = (k / kMargN == k % kMargN) ? 1.0 : 0.0; }
+    for (int k = tid; k < F0 * kMargN; k += 256) L.Wd[k] = 0.0;
+    for (int k = tid; k < 6 * kMargN; k += 256) L.Wp[k] = 0.0;
+    for (int k = tid; k < 6 * F0; k += 256) L.B[k] = 0.0;
+    for (int k = tid; k < F0; k += 256) { L.D[k] = 0.0; L.bd[k] = 0.0; }
+    if (tid < 36) L.A[tid] = 0.0;
+    if (tid < 6) L.bp[tid] = 0.0;
+    if (tid < kMargN) L.br[tid] = 0.0;
+    if (tid == 0) L.flag = 0;
+    __syncthreads();
+    // kept-block column of pose j (1..10) and of the extrinsic inside n
+    auto col_pose = [](int j) { return 6 + 6 * (j - 1); };
+    if (tid == 0) {
+        double prm[14], r[6], J[84];
+        for (int k = 0; k < 14; k++) prm[k] = poses[k];
+        ba::laser_factor(prm, Bt.laser01 + (size_t)w * 24, laser_info, r, J);
+        const int c1 = col_pose(1);
+        for (int a = 0; a < 6; a++) {
+            double g0 = 0, g1 = 0;
+            for (int k = 0; k < 6; k++) { g0 += J[k * 7 + a] * r[k]; g1 += J[42 + k * 7 + a] * r[k]; }
+            atomicAdd(&L.bp[a], g0); atomicAdd(&L.br[c1 + a], g1);
+            for (int bb = 0; bb < 6; bb++) {
+                double v00 = 0, v01 = 0, v11 = 0;
+                for (int k = 0; k < 6; k++) { v00 += J[k * 7 + a] * J[k * 7 + bb]; v01 += J[k * 7 + a] * J[42 + k * 7 + bb]; v11 += J[42 + k * 7 + a] * J[42 + k * 7 + bb]; }
+                atomicAdd(&L.A[a * 6 + bb], v00); atomicAdd(&L.Wp[a * kMargN + c1 + bb], v01); atomicAdd(&L.Hrr[(c1 + a) * kMargN + c1 + bb], v11);
+            }
+        }
+    }
+    for (int f = tid; f < F0; f += 256) {
+        double Df = 0, bdf = 0, Bf[6] = { 0, 0, 0, 0, 0, 0 }, Wx[6] = { 0, 0, 0, 0, 0, 0 };
+        for (int o = Bt.feat_obs_off[f0 + f]; o < Bt.feat_obs_off[f0 + f + 1]; o++) {
+            const int j = Bt.obs_j[o];
+            double prm[22], r[2], J[44];
+            for (int k = 0; k < 7; k++) { prm[k] = ex[k]; prm[7 + k] = poses[k]; prm[14 + k] = poses[7 * j + k]; }
+            prm[21] = Bt.inv_depth[f0 + f];
+            ba::mono_factor(prm, Bt.obs_pts + (size_t)o * 4, mono_info, r, J);
+            const double sq = r[0] * r[0] + r[1] * r[1];
+            const double inv = 1.0 / (1.0 + sq);
+            const double rho1 = inv > DBL_MIN ? inv : DBL_MIN, rho2 = -(inv * inv);
+            marg_corrector(r, J, 7, rho1, rho2); marg_corrector(r, J + 14, 7, rho1, rho2); marg_corrector(r, J + 28, 7, rho1, rho2); marg_corrector(r, J + 42, 1, rho1, rho2);
+            {   // residual scaling
+                const double sr = sqrt(rho1);
+                double scaling = sr;
+                if (!(sq == 0.0 || rho2 <= 0.0)) { const double Dd = 1.0 + 2.0 * sq * rho2 / rho1; scaling = sr / (1.0 - (1.0 - sqrt(Dd))); }
+                r[0] *= scaling; r[1] *= scaling;
+            }
+            const double *Jx = J, *J0 = J + 14, *Jj = J + 28, *Jd = J + 42;
+            const int cj = col_pose(j);
+            for (int a = 0; a < 6; a++) {
+                atomicAdd(&L.bp[a], J0[a] * r[0] + J0[7 + a] * r[1]);
+                atomicAdd(&L.br[a], Jx[a] * r[0] + Jx[7 + a] * r[1]);
+                atomicAdd(&L.br[cj + a], Jj[a] * r[0] + Jj[7 + a] * r[1]);
+                Bf[a] += J0[a] * Jd[0] + J0[7 + a] * Jd[1];
+                Wx[a] += Jd[0] * Jx[a] + Jd[1] * Jx[7 + a];
+                L.Wd[f * kMargN + cj + a] = Jd[0] * Jj[a] + Jd[1] * Jj[7 + a];     // frame j is observed once per track
+                for (int bb = 0; bb < 6; bb++) {
+                    atomicAdd(&L.A[a * 6 + bb], J0[a] * J0[bb] + J0[7 + a] * J0[7 + bb]);
+                    atomicAdd(&L.Wp[a * kMargN + bb], J0[a] * Jx[bb] + J0[7 + a] * Jx[7 + bb]);
+                    atomicAdd(&L.Wp[a * kMargN + cj + bb], J0[a] * Jj[bb] + J0[7 + a] * Jj[7 + bb]);
+                    atomicAdd(&L.Hrr[a * kMargN + bb], Jx[a] * Jx[bb] + Jx[7 + a] * Jx[7 + bb]);
+                    const double xj = Jx[a] * Jj[bb] + Jx[7 + a] * Jj[7 + bb];
+                    atomicAdd(&L.Hrr[a * kMargN + cj + bb], xj); atomicAdd(&L.Hrr[(cj + bb) * kMargN + a], xj);
+                    atomicAdd(&L.Hrr[(cj + a) * kMargN + cj + bb], Jj[a] * Jj[bb] + Jj[7 + a] * Jj[7 + bb]);
+                }
+            }
+            Df += Jd[0] * Jd[0] + Jd[1] * Jd[1];
+            bdf += Jd[0] * r[0] + Jd[1] * r[1];
+        }
+        L.D[f] = Df; L.bd[f] = bdf;
+        for (int a = 0; a < 6; a++) { L.B[a * kMargMaxF0 + f] = Bf[a]; L.Wd[f * kMargN + a] = Wx[a]; }
+    }
+    __syncthreads();
+    // D^+ (eps cut), S_A = A - B D^+ B^T, G = W_p - B D^+ W_d, u = bp - B D^+ bd
+    for (int f = tid; f < F0; f += 256) { const double d = L.D[f]; if (!(d > eps)) L.flag = 1; L.D[f] = d > eps ? 1.0 / d : 0.0; }
+    __syncthreads();
+    if (tid < 36) {
+        const int a = tid / 6, bb = tid % 6;
+        double acc = 0.5 * (L.A[a * 6 + bb] + L.A[bb * 6 + a]);
+        for (int f = 0; f < F0; f++) acc -= L.B[a * kMargMaxF0 + f] * L.D[f] * L.B[bb * kMargMaxF0 + f];
+        L.SAi[tid] = acc;
+    }
+    if (tid >= 64 && tid < 70) {
+        const int a = tid - 64;
+        double acc = L.bp[a];
+        for (int f = 0; f < F0; f++) acc -= L.B[a * kMargMaxF0 + f] * L.D[f] * L.bd[f];
+        L.u[a] = acc;
+    }
+    for (int k = tid; k < 6 * kMargN; k += 256) {
+        const int a = k / kMargN, cidx = k % kMargN;
+        double acc = L.Wp[k];
+        for (int f = 0; f < F0; f++) acc -= L.B[a * kMargMaxF0 + f] * L.D[f] * L.Wd[f * kMargN + cidx];
+        L.Y[k] = acc;      // G, staged in Y
+    }
+    __syncthreads();
+    for (int k = tid; k < 6 * kMargN; k += 256) L.Wp[k] = L.Y[k];
+    if (tid == 0) { double tmp[36]; int deg = 0; pinv6(L.SAi, tmp, eps, &deg); for (int i = 0; i < 36; i++) L.SAi[i] = tmp[i]; if (deg) L.flag = 1; }
+    __syncthreads();
+    for (int k = tid; k < 6 * kMargN; k += 256) {
+        const int a = k / kMargN, cidx = k % kMargN;
+        double acc = 0;
+        for (int q = 0; q < 6; q++) acc += L.SAi[a * 6 + q] * L.Wp[q * kMargN + cidx];
+        L.Y[k] = acc;
+    }
+    __syncthreads();
+    // H' = Hrr - G^T Y - Wd^T D^+ Wd ; b' = br - G^T SA^+ u - Wd^T D^+ bd
+    for (int k = tid; k < kMargN * kMargN; k += 256) {
+        const int a = k / kMargN, bb = k % kMargN;
+        double acc = L.Hrr[k];
+        for (int q = 0; q < 6; q++) acc -= L.Wp[q * kMargN + a] * L.Y[q * kMargN + bb];
+        for (int f = 0; f < F0; f++) acc -= L.Wd[f * kMargN + a] * L.D[f] * L.Wd[f * kMargN + bb];
+        L.V[k] = acc;      // H' staged in V
+    }
+    for (int a = tid; a < kMargN; a += 256) {
+        double acc = L.br[a];
+        for (int q = 0; q < 6; q++) { double su = 0; for (int p = 0; p < 6; p++) su += L.SAi[q * 6 + p] * L.u[p]; acc -= L.Wp[q * kMargN + a] * su; }
+        for (int f = 0; f < F0; f++) acc -= L.Wd[f * kMargN + a] * L.D[f] * L.bd[f];
+        L.br[a] = acc;
+    }
+    __syncthreads();
+    for (int k = tid; k < kMargN * kMargN; k += 256) { const int a = k / kMargN, bb = k % kMargN; L.Hrr[k] = 0.5 * (L.V[k] + L.V[bb * kMargN + a]); }
+    __syncthreads();
+    for (int k = tid; k < kMargN * kMargN; k += 256) L.V[k] = (k / kMargN == k % kMargN) ? 1.0 : 0.0;
+    __syncthreads();
+    // ---- parallel Jacobi eigen-decomposition of Hrr (66x66): 65 rounds of 33 disjoint rotations per sweep
+    for (int sweep = 0; sweep < 40; sweep++) {
+        double offn = 0, dia = 0;
+        for (int k = tid; k < kMargN * kMargN; k += 256) { const int a = k / kMargN, bb = k % kMargN; const double v = L.Hrr[k]; if (a == bb) dia += v * v; else if (a < bb) offn += v * v; }
+        offn = wave_sum_d(offn); dia = wave_sum_d(dia);
+        __syncthreads();
+        if ((tid & 63) == 0) { L.red[tid >> 6] = offn; L.red[4 + (tid >> 6)] = dia; }
+        __syncthreads();
+        offn = L.red[0] + L.red[1] + L.red[2] + L.red[3]; dia = L.red[4] + L.red[5] + L.red[6] + L.red[7];
+        if (offn <= 1e-30 * dia || offn == 0.0) break;
+        for (int rnd = 0; rnd < 65; rnd++) {
+            if (tid < 33) {
+                const int p0 = tid == 0 ? 65 : (rnd + tid) % 65, q0 = tid == 0 ? rnd : (rnd - tid + 65) % 65;
+                const int p = min(p0, q0), q = max(p0, q0);
+                const double apq = L.Hrr[p * kMargN + q];
+                double c = 1.0, s = 0.0;
+                if (apq != 0.0) {
+                    const double theta = (L.Hrr[q * kMargN + q] - L.Hrr[p * kMargN + p]) / (2.0 * apq);
+                    const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    c = 1.0 / sqrt(t * t + 1.0); s = t * c;
+                }
+                L.cs[2 * tid] = c; L.cs[2 * tid + 1] = s;
+            }
+            __syncthreads();
+            // columns: (H, V) <- (H, V) R
+            for (int k = tid; k < 33 * kMargN; k += 256) {
+                const int pr = k / kMargN, i = k % kMargN;
+                const int p0 = pr == 0 ? 65 : (rnd + pr) % 65, q0 = pr == 0 ? rnd : (rnd - pr + 65) % 65;
+                const int p = min(p0, q0), q = max(p0, q0);
+                const double c = L.cs[2 * pr], s = L.cs[2 * pr + 1];
+                const double a = L.Hrr[i * kMargN + p], bb = L.Hrr[i * kMargN + q];
+                L.Hrr[i * kMargN + p] = c * a - s * bb; L.Hrr[i * kMargN + q] = s * a + c * bb;
+                const double va = L.V[i * kMargN + p], vb = L.V[i * kMargN + q];
+                L.V[i * kMargN + p] = c * va - s * vb; L.V[i * kMargN + q] = s * va + c * vb;
+            }
+            __syncthreads();
+            // rows: H <- R^T H
+            for (int k = tid; k < 33 * kMargN; k += 256) {
+                const int pr = k / kMargN, i = k % kMargN;
+                const int p0 = pr == 0 ? 65 : (rnd + pr) % 65, q0 = pr == 0 ? rnd : (rnd - pr + 65) % 65;
+                const int p = min(p0, q0), q = max(p0, q0);
+                const double c = L.cs[2 * pr], s = L.cs[2 * pr + 1];
+                const double a = L.Hrr[p * kMargN + i], bb = L.Hrr[q * kMargN + i];
+                L.Hrr[p * kMargN + i] = c * a - s * bb; L.Hrr[q * kMargN + i] = s * a + c * bb;
+            }
+            __syncthreads();
+        }
+    }
+    // linearized_jacobians = sqrt(S) V^T, linearized_residuals = sqrt(S^-1) V^T b'
+    for (int k = tid; k < kMargN * kMargN; k += 256) {
+        const int e = k / kMargN, i = k % kMargN;
+        const double wv = L.Hrr[e * kMargN + e];
+        Bt.lin_J[(size_t)w * kMargN * kMargN + k] = (wv > eps ? sqrt(wv) : 0.0) * L.V[i * kMargN + e];
+    }
+    for (int e = tid; e < kMargN; e += 256) {
+        const double wv = L.Hrr[e * kMargN + e];
+        double vb = 0;
+        for (int i = 0; i < kMargN; i++) vb += L.V[i * kMargN + e] * L.br[i];
+        Bt.lin_r[(size_t)w * kMargN + e] = (wv > eps ? sqrt(1.0 / wv) : 0.0) * vb;
+    }
+    if (tid == 0) Bt.status[w] = L.flag;
+}
+
+// Marginalization::Evaluate: residual = r0 + J dx for the kept blocks x (11 x 7: ex, pose1..pose10); one thread per row
+__global__ __launch_bounds__(128) void k_marg_evaluate(int n_windows, const double *lin_J, const double *lin_r, const double *x0, const double *x, double *residual)
+{
+    const int w = blockIdx.x, e = threadIdx.x;
+    if (w >= n_windows) return;
+    __shared__ double dx[kMargN];
+    if (e < 11) {
+        const double *a = x + (size_t)w * 77 + 7 * e, *a0 = x0 + (size_t)w * 77 + 7 * e;
+        for (int k = 0; k < 3; k++) dx[6 * e + k] = a[k] - a0[k];
+        const double n2 = a0[3] * a0[3] + a0[4] * a0[4] + a0[5] * a0[5] + a0[6] * a0[6];
+        const double ix = -a0[3] / n2, iy = -a0[4] / n2, iz = -a0[5] / n2, iw = a0[6] / n2;
+        const double qx = a[3], qy = a[4], qz = a[5], qw = a[6];
+        const double rw = iw * qw - ix * qx - iy * qy - iz * qz;
+        double rx = iw * qx + ix * qw + iy * qz - iz * qy, ry = iw * qy + iy * qw + iz * qx - ix * qz, rz = iw * qz + iz * qw + ix * qy - iy * qx;
+        if (!(rw >= 0)) { rx = -rx; ry = -ry; rz = -rz; }
+        dx[6 * e + 3] = 2.0 * rx; dx[6 * e + 4] = 2.0 * ry; dx[6 * e + 5] = 2.0 * rz;
+    }
+    __syncthreads();
+    if (e < kMargN) {
+        double v = lin_r[(size_t)w * kMargN + e];
+        for (int k = 0; k < kMargN; k++) v += lin_J[(size_t)w * kMargN * kMargN + e * kMargN + k] * dx[k];
+        residual[(size_t)w * kMargN + e] = v;
+    }
+}
+
+} // namespace lmono

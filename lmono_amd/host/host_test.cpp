@@ -52,6 +52,15 @@ int main(int argc, char **argv)
         std::printf("\nROT");
         for (int i = 0; i <= WINDOW_SIZE; i++) for (int j = 0; j < 9; j++) std::printf(" %.17g", est.Rs[i].m[j]);
         std::printf("\n");
+        est.marginalization_flag = Estimator::MARGIN_OLD;
+        est.margin();
+        {
+            // gauge-invariant digest of the prior: trace(J^T J) and |J^T r|^2
+            const auto &J = est.last_marginalization_info.linearized_jacobians; const auto &r = est.last_marginalization_info.linearized_residuals;
+            double tr = 0, g2 = 0;
+            for (int c = 0; c < 66; c++) { double g = 0; for (int k = 0; k < 66; k++) { tr += J[k * 66 + c] * J[k * 66 + c]; g += J[k * 66 + c] * r[k]; } g2 += g * g; }
+            std::printf("MRG %d %.17g %.17g %d\n", est.last_marginalization_info.m, tr, g2, est.last_marginalization_info.status);
+        }
         std::set<int> rm;
         est.outliersRejection(rm, p.OUTLIER_T);
         std::printf("OUT %zu\n", rm.size());

@@ -220,6 +220,46 @@ void Estimator::outliersRejection(std::set<int> &removeIndex, const double &erro
     size_t k = 0;
     for (auto &it : feature_manager.feature) { if (score[k] >= 0 && score[k] > error) removeIndex.insert(it.feature_id); k++; }
 }
+void Estimator::margin()
+{
+    if (marginalization_flag != MARGIN_OLD) return;       // the MARGIN_SECOND_NEW branch only re-marginalises an existing prior
+    matrix2Double();
+    std::vector<int> obs_feat, obs_j; std::vector<double> obs_pts, invd;
+    int feature_index = -1, f0 = 0;
+    for (auto &it : feature_manager.feature) {
+        it.used_num = (int)it.feature_per_frame.size();
+        if (it.used_num < p_.TRACK_CNT) continue;
+        ++feature_index;
+        if (it.start_frame != 0) continue;
+        int j = -1;
+        for (auto &f : it.feature_per_frame) {
+            j++;
+            if (j == 0) continue;
+            obs_feat.push_back(f0); obs_j.push_back(j);
+            obs_pts.insert(obs_pts.end(), { it.feature_per_frame[0].pt[0], it.feature_per_frame[0].pt[1], f.pt[0], f.pt[1] });
+        }
+        invd.push_back(para_depth_inv[feature_index]);
+        f0++;
+    }
+    const int feat_off[2] = { 0, f0 }, obs_off[2] = { 0, (int)obs_feat.size() };
+    double poses[77], laser01[24], laser_info[36] = { 0 }, mono_info[4] = { p_.FACTOR_WEIGHT, 0, 0, p_.FACTOR_WEIGHT };
+    for (int i = 0; i <= WINDOW_SIZE; i++) std::memcpy(poses + 7 * i, para_pose[i], 56);
+    std::memcpy(laser01, L0_R[0].m, 72); std::memcpy(laser01 + 9, L0_R[1].m, 72); std::memcpy(laser01 + 18, L0_T[0].v, 24); std::memcpy(laser01 + 21, L0_T[1].v, 24);
+    for (int k = 0; k < 6; k++) laser_info[k * 7] = p_.LASER_W * p_.FACTOR_WEIGHT;
+    MarginalizationInfo &mi = last_marginalization_info;
+    mi.linearized_jacobians.assign(66 * 66, 0.0); mi.linearized_residuals.assign(66, 0.0);
+    const int dummy = 0; const double dzero = 0.0;
+    hip_.check(lmono_marginalize(hip_.get(), 1, feat_off, obs_off, poses, para_ex[0], invd.empty() ? &dzero : invd.data(),
+                                 obs_feat.empty() ? &dummy : obs_feat.data(), obs_j.empty() ? &dummy : obs_j.data(),
+                                 obs_pts.empty() ? &dzero : obs_pts.data(), laser01, laser_info, mono_info,
+                                 mi.linearized_jacobians.data(), mi.linearized_residuals.data(), &mi.status), "lmono_marginalize");
+    mi.m = 6 + f0; mi.n = 66;
+    mi.keep_block_data.assign(77, 0.0);
+    std::memcpy(mi.keep_block_data.data(), para_ex[0], 56);
+    for (int i = 1; i <= WINDOW_SIZE; i++) std::memcpy(mi.keep_block_data.data() + 7 * i, para_pose[i], 56);
+    mi.valid = false;      // never set by the reference either
+}
+
 void Estimator::slideWindow()
 {
     if (marginalization_flag == MARGIN_OLD) {

@@ -99,6 +99,17 @@ public:
     bool optimization();                   // :1124-1305 (solve through lmono_ba_*; margin() is not part of the solve path)
     void outliersRejection(std::set<int> &removeIndex, const double &error);   // :134-190
     void slideWindow();                    // :700-771
+    // :1307-1405, MARGIN_OLD branch.  Like the reference, the prior is computed but never fed back into
+    // optimization() (MarginalizationInfo::valid is never set).  The reference passes the mono
+    // pipeline's never-initialised right_pt as the second observation; the mirror passes the tracked point.
+    void margin();
+    struct MarginalizationInfo {           // include/factor/MarginalizationFactor.h:78-108 (fields used downstream)
+        int m = 0, n = 0;
+        std::vector<double> linearized_jacobians, linearized_residuals;   // [66*66], [66]
+        std::vector<double> keep_block_data;                               // [11][7]: ex, pose1..pose10 at linearisation
+        bool valid = false;
+        int status = 0;
+    } last_marginalization_info;
 
 private:
     HipContext &hip_;

@@ -53,6 +53,22 @@ def test_estimator_mirror_matches_oracle(oracle, tmp_path):
     R_ref, P_ref = oracle.ba_reanchor(poses, Rs[0], Ps[0])      # double2Matrix
     assert np.abs(np.array(lines["POS"], float).reshape(n, 3) - P_ref).max() < 1e-6
     assert np.abs(np.array(lines["ROT"], float).reshape(n, 3, 3) - R_ref).max() < 1e-7
+    # margin(): prior of the post-optimisation state (gauge-invariant digest), features surviving removeFailures
+    keep0 = ~((1.0 / invd < 0.1) | (1.0 / invd > 300))
+    w3 = dict(w)
+    w3["poses"] = np.concatenate([P_ref, np.array([B.R_to_q(R) for R in R_ref])], 1)
+    w3["ex"] = np.concatenate([ex[:3], B.R_to_q(B.q_to_R(B.q_normalized(ex[3:])))])
+    alive_feat = np.nonzero(keep0)[0]
+    remap = -np.ones(len(invd), int); remap[alive_feat] = np.arange(len(alive_feat))
+    sel = keep0[w["obs_feat"]]
+    w3["inv_depth"] = invd[alive_feat]; w3["obs_feat"] = remap[w["obs_feat"][sel]].astype(np.int32)
+    w3["obs_i"] = w["obs_i"][sel]; w3["obs_j"] = w["obs_j"][sel]; w3["obs_pts"] = w["obs_pts"][sel]
+    Jm, rm_, m_ref, _, _ = oracle.marginalize(w3)
+    m_got, tr, g2, st = lines["MRG"]
+    assert int(m_got) == m_ref and int(st) == 0
+    assert abs(float(tr) - np.trace(Jm.T @ Jm)) < 1e-6 * np.trace(Jm.T @ Jm)
+    gref = float(((Jm.T @ rm_) ** 2).sum())
+    assert abs(float(g2) - gref) < 1e-5 * gref + 1e-12
     # outliersRejection + slideWindow bookkeeping
     depth = 1.0 / invd
     keep = ~((depth < 0.1) | (depth > 300))                      # removeFailures after setDepth
