@@ -66,39 +66,56 @@ __global__ __launch_bounds__(1024) void k_grid_build(BatchView b)
     }
     __threadfence_block();
     __syncthreads();
-    for (int i = tid; i < n; i += 1024) {
-        const float4 p = src[i];
-        const unsigned long long k = cell_key((int)floorf(p.x * kInvCell), (int)floorf(p.y * kInvCell), (int)floorf(p.z * kInvCell));
-        unsigned int sl = hash_key(k) & mask;
-        while (true) {
-            const unsigned long long old = atomicCAS(&cell[sl].key, kEmptyKey, k);
-            if (old == kEmptyKey || old == k) break;
-            sl = (sl + 1) & mask;
+    // Each thread inserts a run of kRun consecutive points.  Feature clouds are ordered ring by ring and, inside a ring,
+    // by 0.2 m voxel, so consecutive points mostly fall into the same 1 m cell: one CAS + one counted atomicAdd per run
+    // of equal cells instead of two scattered L2 atomics per point (the atomics are what bounds this kernel).
+    constexpr int kRun = 8;
+    for (int i0 = tid * kRun; i0 < n; i0 += 1024 * kRun) {
+        const int i1 = min(i0 + kRun, n);
+        unsigned long long keys[kRun];
+#pragma unroll
+        for (int u = 0; u < kRun; u++) {
+            keys[u] = kEmptyKey;
+            if (i0 + u < i1) {
+                const float4 p = src[i0 + u];
+                keys[u] = cell_key((int)floorf(p.x * kInvCell), (int)floorf(p.y * kInvCell), (int)floorf(p.z * kInvCell));
+            }
         }
-        slot_of[i] = (int)sl;
-        rank_of[i] = atomicAdd(&cell[sl].cnt, 1);
+        int u = 0;
+        while (i0 + u < i1) {
+            int len = 1;
+            while (i0 + u + len < i1 && keys[u + len] == keys[u]) len++;
+            const unsigned long long k = keys[u];
+            unsigned int sl = hash_key(k) & mask;
+            while (true) {
+                const unsigned long long old = atomicCAS(&cell[sl].key, kEmptyKey, k);
+                if (old == kEmptyKey || old == k) break;
+                sl = (sl + 1) & mask;
+            }
+            const int base = atomicAdd(&cell[sl].cnt, len);
+            for (int v = 0; v < len; v++) { slot_of[i0 + u + v] = (int)sl; rank_of[i0 + u + v] = base + v; }
+            u += len;
+        }
     }
     __syncthreads();
     // The counts were produced by L2 atomics: invalidate this CU's L1 once (agent-scope acquire), then read them with
     // plain coalesced loads.  Exclusive prefix over the table in tiles of 1024 cells (wave scan + cross-wave carry).
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __shared__ int s_wsum[16];
-    __shared__ int s_carry;
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
+    __shared__ int s_wsum[2][16];
     const int lane = tid & 63, wave = tid >> 6;
-    for (int t0 = 0; t0 < T; t0 += 1024) {
+    int carry = 0;      // every thread tracks the running total itself: one barrier per tile, wave sums double-buffered
+    for (int t0 = 0, buf = 0; t0 < T; t0 += 1024, buf ^= 1) {
         const int c = cell[t0 + tid].cnt;
         const int incl = wave_scan_incl(c);
-        if (lane == 63) s_wsum[wave] = incl;
+        if (lane == 63) s_wsum[buf][wave] = incl;
         __syncthreads();
-        int base = s_carry;
-        for (int w = 0; w < wave; w++) base += s_wsum[w];
+        int base = carry, tile = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) { const int v = s_wsum[buf][w]; if (w < wave) base += v; tile += v; }
         cell[t0 + tid].start = base + incl - c;
-        __syncthreads();
-        if (tid == 1023) s_carry = base + incl;
-        __syncthreads();
+        carry += tile;
     }
+    __syncthreads();
     for (int i = tid; i < n; i += 1024) {
         const float4 p = src[i];
         const int ln = (int)p.w;
