@@ -55,7 +55,7 @@ struct BatchView {
     float4 *sg_pts;          // [total]
     float4 *lbc_pts;         // [n_scans][kMaxLessSharp] less_sharp sorted by (line, azimuth bin), .w = original index bits
     float4 *lbs_pts;         // [total] same for less_flat
-    int *lb_start;           // [n_scans][2][66*64+1] start of every (line, bin) bucket
+    int *lb_start;           // [n_scans][2][66*128+1] start of every (line, bin) bucket
     int *grid_mask;          // [n_scans][2] table size - 1 actually used (corner, surf): power of two >= 2 n
     int *sg_slot, *sg_rank;  // [total] scratch: table slot of each surf point / rank inside its cell
     int *cg_slot, *cg_rank;  // [n_scans][kMaxLessSharp] same for corner points

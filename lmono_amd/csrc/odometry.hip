@@ -306,7 +306,7 @@ __device__ __forceinline__ int chain_scan(const OdomView &o, int c, int step, in
 // within +-asin(5 / rho_xy) of its azimuth, and only on lines ra-2 .. ra+2.  k_line_index sorts a copy of every "last"
 // cloud by (line, azimuth bin) once per scan (counting sort in LDS), so that the walk of a feature is a handful of
 // short coalesced sweeps instead of a pass over five whole scan lines.
-constexpr int kAzBins = 64;
+constexpr int kAzBins = 128;
 constexpr int kLineKeys = 66 * kAzBins;
 
 __device__ __forceinline__ int az_bin(float x, float y)
@@ -372,93 +372,6 @@ __device__ __forceinline__ void walk_update(WalkBest &bst, float d, unsigned int
     bst.seq = better ? seq : bst.seq;
 }
 
-// Correspondence of one feature point: exact NN, then the scan-line walk over the (line, azimuth) index.
-__device__ __forceinline__ int4 correspond_indexed(const BatchView &b, int k, int qi, const double *x, int lane)
-{
-    const int n_sharp = b.feat_n[k * 4 + 0];
-    const bool edge = qi < n_sharp;
-    const float4 p = edge ? b.sharp[(size_t)k * kMaxSharp + qi] : b.flat[(size_t)k * kMaxFlat + (qi - n_sharp)];
-    double rx, ry, rz;
-    quat_rotate(x, (double)p.x, (double)p.y, (double)p.z, rx, ry, rz);
-    const float qx = (float)(rx + x[4]), qy = (float)(ry + x[5]), qz = (float)(rz + x[6]);
-    const int l = k - 1;
-    GridRef g;
-    const float4 *cloud, *lb_pts;
-    int n_last;
-    if (edge) {
-        g.cell = b.cg_cell + (size_t)l * kCornerTable; g.pts = b.cg_pts + (size_t)l * kMaxLessSharp; g.mask = b.grid_mask[l * 2 + 0];
-        cloud = b.less_sharp + (size_t)l * kMaxLessSharp; n_last = b.feat_n[l * 4 + 1];
-        lb_pts = b.lbc_pts + (size_t)l * kMaxLessSharp;
-    } else {
-        g.cell = b.sg_cell + (size_t)l * kSurfTable; g.pts = b.sg_pts + b.off[l]; g.mask = b.grid_mask[l * 2 + 1];
-        cloud = b.less_flat + b.off[l]; n_last = b.feat_n[l * 4 + 3];
-        lb_pts = b.lbs_pts + b.off[l];
-    }
-    int4 out = make_int4(-1, -1, -1, 0);
-    if (n_last == 0) return out;
-    const unsigned long long nn = wave_nn(g, qx, qy, qz, lane);
-    if (nn == ~0ull || !((double)__uint_as_float((unsigned int)(nn >> 32)) < 25.0)) return out;
-    const int closest = (int)(unsigned int)(nn & 0xffffffffull);
-    const int ra = line_of(cloud[closest].w);
-    const int cl = edge ? 0 : 1;
-    const int *fge = b.line_first_ge + (size_t)(l * 2 + cl) * 66;
-    const int *lle = b.line_last_le + (size_t)(l * 2 + cl) * 66;
-    const int *table = b.lb_start + (size_t)(l * 2 + cl) * (kLineKeys + 1);
-    const int w_lo = ra - 3 >= 0 ? lle[ra - 3] + 1 : 0;      // index window the reference loops can reach
-    const int w_hi = ra + 3 <= 65 ? fge[ra + 3] : n_last;
-    // arc of azimuth bins that can hold a point within 5 m of the query
-    const float rho = sqrtf(qx * qx + qy * qy);
-    int b_lo = 0, nb = kAzBins;
-    if (rho > 5.01f) {
-        const float alpha = asin_upper(5.0f / rho) + 1.5f * (6.28318531f / kAzBins);
-        const float th = atan2f(qy, qx) + 3.14159265f;
-        const int lo = (int)floorf((th - alpha) * (kAzBins / 6.28318531f));
-        const int hi = (int)floorf((th + alpha) * (kAzBins / 6.28318531f));
-        if (hi - lo + 1 < kAzBins) { b_lo = ((lo % kAzBins) + kAzBins) % kAzBins; nb = hi - lo + 1; }
-    }
-    const int b_end = b_lo + nb;
-    WalkBest bs = { 25.0f, 0u }, bo = { 25.0f, 0u };
-    // lanes 0..4 fetch the bucket bounds of lines ra-2..ra+2 (two runs when the arc wraps past bin 63)
-    int t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-    {
-        const int v = ra - 2 + lane;
-        if (lane < 5 && v >= 0 && v <= 65 && !(edge && v == ra)) {
-            const int *row = table + v * kAzBins;
-            t0 = row[b_lo]; t1 = row[min(b_end, kAzBins)];
-            if (b_end > kAzBins) { t2 = row[0]; t3 = row[b_end - kAzBins]; }
-        }
-    }
-    for (int vi = 0; vi < 5; vi++) {
-        const int v = ra - 2 + vi;
-        for (int part = 0; part < 2; part++) {
-            const int r0 = __shfl(part ? t2 : t0, vi), r1 = __shfl(part ? t3 : t1, vi);
-            for (int i = r0 + lane; i < r1; i += 64) {
-                const float4 c = lb_pts[i];
-                const int j = __float_as_int(c.w);
-                if (j == closest || j < w_lo || j >= w_hi) continue;
-                const bool fwd = j > closest;
-                const unsigned int seq = fwd ? (unsigned int)(j - closest - 1) : kSeqBack + (unsigned int)(closest - 1 - j);
-                const float d = dist2f(c.x, c.y, c.z, qx, qy, qz);
-                const bool is_other = fwd ? (v > ra) : (v < ra);
-                if (is_other) walk_update(bo, d, seq);
-                else if (!edge) walk_update(bs, d, seq);
-            }
-        }
-    }
-    const unsigned long long thr = pack_fu(25.0f, 0u);
-    unsigned long long same = bs.d < 25.0f ? pack_fu(bs.d, bs.seq) : thr;
-    unsigned long long other = bo.d < 25.0f ? pack_fu(bo.d, bo.seq) : thr;
-    same = wave_min_u64(same); other = wave_min_u64(other);
-    const int i_other = other < thr ? seq_to_index((unsigned int)(other & 0xffffffffull), closest) : -1;
-    if (edge) {
-        if (i_other >= 0) out = make_int4(closest, i_other, -1, 1);
-        return out;
-    }
-    const int i_same = same < thr ? seq_to_index((unsigned int)(same & 0xffffffffull), closest) : -1;
-    if (i_same >= 0 && i_other >= 0) out = make_int4(closest, i_same, i_other, 2);
-    return out;
-}
-
 // ---- half-wave (32-lane) groups: two feature points per wave --------------------------------------------------
 // The per-feature work is dominated by scalar-like instructions (hashing, probing, bookkeeping) and by chains of
 // dependent loads, so each feature gets 32 lanes (the 27 cells of shell 1 fit) and independent loads are issued in
@@ -504,6 +417,33 @@ __device__ __forceinline__ void walk_point(const float4 &cpt, int v, int ra, int
     else if (!edge) walk_update(bs, d, seq);
 }
 
+// sweep the cell runs (st, cn) held by the group's lanes, four non-empty cells per round: their first 32 points are
+// loaded back to back before any is consumed; nb accumulates the nearest point
+__device__ __forceinline__ void nn_sweep(const float4 *gpts, int st, int cn, int gl, int gbase, float qx, float qy, float qz, NnBest &nb)
+{
+    unsigned int m = group_ballot(cn > 0, gbase);
+    while (m) {
+        int s4[4], n4[4];
+        float4 v4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            n4[u] = 0; s4[u] = 0;
+            if (m) {
+                const int src = __ffs((int)m) - 1;
+                m &= m - 1;
+                s4[u] = __shfl(st, src, kGroup); n4[u] = __shfl(cn, src, kGroup);
+            }
+            v4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gl < n4[u]) v4[u] = gpts[s4[u] + gl];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (gl < n4[u]) nn_update(nb, v4[u], qx, qy, qz);
+            for (int i = gl + kGroup; i < n4[u]; i += kGroup) nn_update(nb, gpts[s4[u] + i], qx, qy, qz);
+        }
+    }
+}
+
 // gl = lane inside the 32-lane group, gbase = first wave lane of the group (0 or 32)
 __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi, const double *x, int gl, int gbase)
 {
@@ -524,10 +464,15 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
     if (n_last == 0) return out;
 
     // ---- exact NN, shell 1: lanes 0..26 probe one cell each
-    const int cqx = (int)floorf(qx * kInvCell), cqy = (int)floorf(qy * kInvCell), cqz = (int)floorf(qz * kInvCell);
+    const float fx = qx * kInvCell, fy = qy * kInvCell, fz = qz * kInvCell;
+    const int cqx = (int)floorf(fx), cqy = (int)floorf(fy), cqz = (int)floorf(fz);
     int st = 0, cn = 0;
+    bool near = false;
     if (gl < 27) {
         const int dx = gl % 3 - 1, dy = (gl / 3) % 3 - 1, dz = gl / 9 - 1;
+        // the 2x2x2 block of cells whose faces are all >= half a cell away from the query
+        const int sx = (fx - (float)cqx) >= 0.5f ? 1 : -1, sy = (fy - (float)cqy) >= 0.5f ? 1 : -1, sz = (fz - (float)cqz) >= 0.5f ? 1 : -1;
+        near = (dx == 0 || dx == sx) && (dy == 0 || dy == sy) && (dz == 0 || dz == sz);
         const unsigned long long kk = cell_key(cqx + dx, cqy + dy, cqz + dz);
         unsigned int sl = hash_key(kk) & mask;
         while (true) {
@@ -538,29 +483,16 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
         }
     }
     NnBest nb = { __uint_as_float(0x7f800000u), 0x7fffffff, 0 };
-    unsigned int m = group_ballot(cn > 0, gbase);
-    while (m) {
-        // four non-empty cells per round: their first 32 points are loaded back to back before any is consumed
-        int s4[4], n4[4];
-        float4 v4[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            n4[u] = 0; s4[u] = 0;
-            if (m) {
-                const int src = __ffs((int)m) - 1;
-                m &= m - 1;
-                s4[u] = __shfl(st, src, kGroup); n4[u] = __shfl(cn, src, kGroup);
-            }
-            v4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gl < n4[u]) v4[u] = gpts[s4[u] + gl];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (gl < n4[u]) nn_update(nb, v4[u], qx, qy, qz);
-            for (int i = gl + kGroup; i < n4[u]; i += kGroup) nn_update(nb, gpts[s4[u] + i], qx, qy, qz);
+    // near block first: any point outside it is farther than half a cell
+    nn_sweep(gpts, st, near ? cn : 0, gl, gbase, qx, qy, qz, nb);
+    unsigned long long best = group_min_u64(nb.idx == 0x7fffffff ? ~0ull : pack_fu(nb.d, (unsigned int)nb.idx));
+    {
+        const float bound_h = 0.5f * kCell * 0.9999f;
+        if (!(best != ~0ull && __uint_as_float((unsigned int)(best >> 32)) <= bound_h * bound_h)) {
+            nn_sweep(gpts, st, near ? 0 : cn, gl, gbase, qx, qy, qz, nb);
+            best = group_min_u64(nb.idx == 0x7fffffff ? ~0ull : pack_fu(nb.d, (unsigned int)nb.idx));
         }
     }
-    unsigned long long best = group_min_u64(nb.idx == 0x7fffffff ? ~0ull : pack_fu(nb.d, (unsigned int)nb.idx));
     {
         const float bound = kCell * 0.9999f;
         const bool settled = best != ~0ull && __uint_as_float((unsigned int)(best >> 32)) <= bound * bound;
@@ -606,55 +538,70 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
     const unsigned int wm = group_ballot(nb.idx == closest && pack_fu(nb.d, (unsigned int)nb.idx) == best, gbase);
     const int ra = __shfl(nb.line, __ffs((int)wm) - 1, kGroup);
 
-    // ---- scan-line walk over the (line, azimuth) index
+    // ---- scan-line walk over the (line, azimuth) index: lines ra-2 .. ra+2, index window (last_le[ra-3], first_ge[ra+3]).
+    // Two passes: first only the arc that can hold points within r1 = 0.5 m + 5 % of the range (the partners are
+    // nearly always on the neighbouring lines right next to the nearest point); minima found below r1 are final because
+    // every point outside the arc is farther than r1.  Otherwise the full 5 m arc is swept.
     const int *fge = b.line_first_ge + (size_t)(l * 2 + cl) * 66;
     const int *lle = b.line_last_le + (size_t)(l * 2 + cl) * 66;
     const int *table = b.lb_start + (size_t)(l * 2 + cl) * (kLineKeys + 1);
     const float rho = sqrtf(qx * qx + qy * qy);
-    int b_lo = 0, nbins = kAzBins;
-    if (rho > 5.01f) {
-        const float alpha = asin_upper(5.0f / rho) + 1.5f * (6.28318531f / kAzBins);
-        const float th = atan2f(qy, qx) + 3.14159265f;
-        const int lo = (int)floorf((th - alpha) * (kAzBins / 6.28318531f));
-        const int hi = (int)floorf((th + alpha) * (kAzBins / 6.28318531f));
-        if (hi - lo + 1 < kAzBins) { b_lo = ((lo % kAzBins) + kAzBins) % kAzBins; nbins = hi - lo + 1; }
-    }
-    const int b_end = b_lo + nbins;
-    // lanes 0..4: bucket bounds of lines ra-2..ra+2; lanes 5, 6: the index window
-    int t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-    {
-        const int v = ra - 2 + gl;
-        if (gl < 5 && v >= 0 && v <= 65 && !(edge && v == ra)) {
-            const int *row = table + v * kAzBins;
-            t0 = row[b_lo]; t1 = row[min(b_end, kAzBins)];
-            if (b_end > kAzBins) { t2 = row[0]; t3 = row[b_end - kAzBins]; }
-        }
-        if (gl == 5) t0 = ra - 3 >= 0 ? lle[ra - 3] + 1 : 0;
-        if (gl == 6) t0 = ra + 3 <= 65 ? fge[ra + 3] : n_last;
-    }
-    const int w_lo = __shfl(t0, 5, kGroup), w_hi = __shfl(t0, 6, kGroup);
-    WalkBest bs = { 25.0f, 0u }, bo = { 25.0f, 0u };
-    for (int part = 0; part < 2; part++) {
-        if (part == 1 && b_end <= kAzBins) break;
-        int r0[5], r1[5];
-        float4 v5[5];
-#pragma unroll
-        for (int vi = 0; vi < 5; vi++) {
-            r0[vi] = __shfl(part ? t2 : t0, vi, kGroup); r1[vi] = __shfl(part ? t3 : t1, vi, kGroup);
-            v5[vi] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-            if (r0[vi] + gl < r1[vi]) v5[vi] = lb_pts[r0[vi] + gl];
-        }
-#pragma unroll
-        for (int vi = 0; vi < 5; vi++) {
-            const int v = ra - 2 + vi;
-            if (r0[vi] + gl < r1[vi]) walk_point(v5[vi], v, ra, closest, w_lo, w_hi, edge, qx, qy, qz, bs, bo);
-            for (int i = r0[vi] + gl + kGroup; i < r1[vi]; i += kGroup) walk_point(lb_pts[i], v, ra, closest, w_lo, w_hi, edge, qx, qy, qz, bs, bo);
-        }
-    }
+    const float th = atan2f(qy, qx) + 3.14159265f;
+    const int w_lo = ra - 3 >= 0 ? lle[ra - 3] + 1 : 0;
+    const int w_hi = ra + 3 <= 65 ? fge[ra + 3] : n_last;
     const unsigned long long thr = pack_fu(25.0f, 0u);
-    unsigned long long same = bs.d < 25.0f ? pack_fu(bs.d, bs.seq) : thr;
-    unsigned long long other = bo.d < 25.0f ? pack_fu(bo.d, bo.seq) : thr;
-    same = group_min_u64(same); other = group_min_u64(other);
+    unsigned long long same = thr, other = thr;
+    const float r1 = 0.5f + 0.05f * rho;
+    for (int pass = (rho > 5.01f ? 0 : 1); pass < 2; pass++) {
+        int b_lo = 0, nbins = kAzBins;
+        if (rho > 5.01f) {
+            const float alpha = asin_upper((pass == 0 ? r1 : 5.0f) / rho) + 1.5f * (6.28318531f / kAzBins);
+            const int lo = (int)floorf((th - alpha) * (kAzBins / 6.28318531f));
+            const int hi = (int)floorf((th + alpha) * (kAzBins / 6.28318531f));
+            if (hi - lo + 1 < kAzBins) { b_lo = ((lo % kAzBins) + kAzBins) % kAzBins; nbins = hi - lo + 1; }
+        }
+        const int b_end = b_lo + nbins;
+        // lanes 0..4: bucket bounds of lines ra-2..ra+2 (two runs when the arc wraps past the last bin)
+        int r0a[5], r1a[5], r0b[5], r1b[5];
+        {
+            int u0 = 0, u1 = 0, u2 = 0, u3 = 0;
+            const int v = ra - 2 + gl;
+            if (gl < 5 && v >= 0 && v <= 65 && !(edge && v == ra)) {   // edges never use the nearest point's own line
+                const int *row = table + v * kAzBins;
+                u0 = row[b_lo]; u1 = row[min(b_end, kAzBins)];
+                if (b_end > kAzBins) { u2 = row[0]; u3 = row[b_end - kAzBins]; }
+            }
+#pragma unroll
+            for (int vi = 0; vi < 5; vi++) {
+                r0a[vi] = __shfl(u0, vi, kGroup); r1a[vi] = __shfl(u1, vi, kGroup);
+                r0b[vi] = __shfl(u2, vi, kGroup); r1b[vi] = __shfl(u3, vi, kGroup);
+            }
+        }
+        WalkBest bs = { 25.0f, 0u }, bo = { 25.0f, 0u };
+        for (int part = 0; part < 2; part++) {
+            if (part == 1 && b_end <= kAzBins) break;
+            float4 v5[5];
+#pragma unroll
+            for (int vi = 0; vi < 5; vi++) {
+                const int r0 = part ? r0b[vi] : r0a[vi], r1 = part ? r1b[vi] : r1a[vi];
+                v5[vi] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+                if (r0 + gl < r1) v5[vi] = lb_pts[r0 + gl];
+            }
+#pragma unroll
+            for (int vi = 0; vi < 5; vi++) {
+                const int r0 = part ? r0b[vi] : r0a[vi], r1 = part ? r1b[vi] : r1a[vi];
+                const int v = ra - 2 + vi;
+                if (r0 + gl < r1) walk_point(v5[vi], v, ra, closest, w_lo, w_hi, edge, qx, qy, qz, bs, bo);
+                for (int i = r0 + gl + kGroup; i < r1; i += kGroup) walk_point(lb_pts[i], v, ra, closest, w_lo, w_hi, edge, qx, qy, qz, bs, bo);
+            }
+        }
+        same = group_min_u64(bs.d < 25.0f ? pack_fu(bs.d, bs.seq) : thr);
+        other = group_min_u64(bo.d < 25.0f ? pack_fu(bo.d, bo.seq) : thr);
+        if (pass == 0) {
+            const unsigned long long lim = pack_fu(r1 * r1 * 0.998f, 0u);   // squared distance strictly inside the r1 ball
+            if (other < lim && (edge || same < lim)) break;
+        }
+    }
     const int i_other = other < thr ? seq_to_index((unsigned int)(other & 0xffffffffull), closest) : -1;
     if (edge) {
         if (i_other >= 0) out = make_int4(closest, i_other, -1, 1);
