@@ -489,7 +489,16 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
     {
         const float bound_h = 0.5f * kCell * 0.9999f;
         if (!(best != ~0ull && __uint_as_float((unsigned int)(best >> 32)) <= bound_h * bound_h)) {
-            nn_sweep(gpts, st, near ? 0 : cn, gl, gbase, qx, qy, qz, nb);
+            // remaining 19 cells, minus those whose box is farther than the best point found so far
+            int cn_far = near ? 0 : cn;
+            if (best != ~0ull && gl < 27) {
+                const float lx = (float)(cqx + gl % 3 - 1) * kCell, ly = (float)(cqy + (gl / 3) % 3 - 1) * kCell, lz = (float)(cqz + gl / 9 - 1) * kCell;
+                const float ex = fmaxf(fmaxf(lx - qx, qx - (lx + kCell)), 0.f), ey = fmaxf(fmaxf(ly - qy, qy - (ly + kCell)), 0.f), ez = fmaxf(fmaxf(lz - qz, qz - (lz + kCell)), 0.f);
+                // 1e-3 m slack: the cell of a point is floor(coordinate), exact, so only the float box arithmetic needs margin
+                const float eb = fmaxf(sqrtf(ex * ex + ey * ey + ez * ez) - 1e-3f, 0.f);
+                if (eb * eb > __uint_as_float((unsigned int)(best >> 32))) cn_far = 0;
+            }
+            nn_sweep(gpts, st, cn_far, gl, gbase, qx, qy, qz, nb);
             best = group_min_u64(nb.idx == 0x7fffffff ? ~0ull : pack_fu(nb.d, (unsigned int)nb.idx));
         }
     }
@@ -505,7 +514,15 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
                     int st2 = 0, cn2 = 0;
                     if (ci < ncell) {
                         const int dx = ci % side - sh, dy = (ci / side) % side - sh, dz = ci / (side * side) - sh;
-                        if (max(max(abs(dx), abs(dy)), abs(dz)) == sh) {
+                        bool want = max(max(abs(dx), abs(dy)), abs(dz)) == sh;
+                        if (want && best != ~0ull) {
+                            // skip cells whose box is farther than the best point of the previous shells
+                            const float lx = (float)(cqx + dx) * kCell, ly = (float)(cqy + dy) * kCell, lz = (float)(cqz + dz) * kCell;
+                            const float ex = fmaxf(fmaxf(lx - qx, qx - (lx + kCell)), 0.f), ey = fmaxf(fmaxf(ly - qy, qy - (ly + kCell)), 0.f), ez = fmaxf(fmaxf(lz - qz, qz - (lz + kCell)), 0.f);
+                            const float eb = fmaxf(sqrtf(ex * ex + ey * ey + ez * ez) - 1e-3f, 0.f);
+                            want = !(eb * eb > __uint_as_float((unsigned int)(best >> 32)));
+                        }
+                        if (want) {
                             const unsigned long long kk = cell_key(cqx + dx, cqy + dy, cqz + dz);
                             unsigned int sl = hash_key(kk) & mask;
                             while (true) {
@@ -516,13 +533,7 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
                             }
                         }
                     }
-                    unsigned int m2 = group_ballot(cn2 > 0, gbase);
-                    while (m2) {
-                        const int src = __ffs((int)m2) - 1;
-                        m2 &= m2 - 1;
-                        const int s0 = __shfl(st2, src, kGroup), n0 = __shfl(cn2, src, kGroup);
-                        for (int i = gl; i < n0; i += kGroup) nn_update(nb, gpts[s0 + i], qx, qy, qz);
-                    }
+                    nn_sweep(gpts, st2, cn2, gl, gbase, qx, qy, qz, nb);
                 }
                 best = group_min_u64(nb.idx == 0x7fffffff ? ~0ull : pack_fu(nb.d, (unsigned int)nb.idx));
                 if (best != ~0ull) {
