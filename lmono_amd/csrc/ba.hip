@@ -112,21 +112,21 @@ __device__ __forceinline__ void quat_matrix(const double *q, double sign, double
 }
 
 // params[14] pose_i, pose_j; consts[24] L0_Ri, L0_Rj (row-major), L0_Pi, L0_Pj; info 6x6.  J: [2][6*7] or null.
-__device__ void laser_factor(const double *params, const double *consts, const double *info, double *r, double *J)
+__device__ __forceinline__ void laser_factor(const double *params, const double *consts, const double *info, double *r, double *J)
 {
     const double *Ri0 = consts, *Rj0 = consts + 9, *Pi0 = consts + 18, *Pj0 = consts + 21;
     double RiT[9], Rrel[9], dq[4], dp[3], d[3];
     mT(Ri0, RiT); mm(RiT, Rj0, Rrel); R_to_q(Rrel, dq);
-    for (int k = 0; k < 3; k++) d[k] = Pj0[k] - Pi0[k];
+    _Pragma("unroll") for (int k = 0; k < 3; k++) d[k] = Pj0[k] - Pi0[k];
     mv(RiT, d, dp);
     const double *Pi = params, *Qi = params + 3, *Pj = params + 7, *Qj = params + 10;
     double Qi_inv[4], dPij[3], rp[3], dq_inv[4], qij[4], rq[4], res[6];
     q_inv(Qi, Qi_inv);
-    for (int k = 0; k < 3; k++) dPij[k] = Pj[k] - Pi[k];
+    _Pragma("unroll") for (int k = 0; k < 3; k++) dPij[k] = Pj[k] - Pi[k];
     q_rot(Qi_inv, dPij, rp);
     q_inv(dq, dq_inv); q_mul(Qi_inv, Qj, qij); q_mul(dq_inv, qij, rq);
-    for (int k = 0; k < 3; k++) { res[k] = rp[k] - dp[k]; res[3 + k] = 2 * rq[k]; }
-    for (int i = 0; i < 6; i++) { double s = 0; for (int k = 0; k < 6; k++) s += info[i * 6 + k] * res[k]; r[i] = s; }
+    _Pragma("unroll") for (int k = 0; k < 3; k++) { res[k] = rp[k] - dp[k]; res[3 + k] = 2 * rq[k]; }
+    _Pragma("unroll") for (int i = 0; i < 6; i++) { double s = 0; for (int k = 0; k < 6; k++) s += info[i * 6 + k] * res[k]; r[i] = s; }
     if (!J) return;
     double Rinv[9], S[9], Qj_inv[4], qa[4], L[16], Rm[16], qb[4], qc[4], L2[16];
     q_to_R(Qi_inv, Rinv); skew(rp, S);
@@ -134,21 +134,21 @@ __device__ void laser_factor(const double *params, const double *consts, const d
     quat_matrix(qa, 1.0, L); quat_matrix(dq, -1.0, Rm);
     q_mul(dq_inv, Qi_inv, qb); q_mul(qb, Qj, qc); quat_matrix(qc, 1.0, L2);
     double Ji[42], Jj[42];
-    for (int k = 0; k < 42; k++) { Ji[k] = 0.0; Jj[k] = 0.0; }
-    for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 3; j++) {
+    _Pragma("unroll") for (int k = 0; k < 42; k++) { Ji[k] = 0.0; Jj[k] = 0.0; }
+    _Pragma("unroll") for (int i = 0; i < 3; i++)
+        _Pragma("unroll") for (int j = 0; j < 3; j++) {
             double lr = 0;
-            for (int k = 0; k < 4; k++) lr += L[(1 + i) * 4 + k] * Rm[k * 4 + 1 + j];
+            _Pragma("unroll") for (int k = 0; k < 4; k++) lr += L[(1 + i) * 4 + k] * Rm[k * 4 + 1 + j];
             Ji[i * 7 + j] = -Rinv[i * 3 + j];
             Ji[i * 7 + 3 + j] = S[i * 3 + j];
             Ji[(3 + i) * 7 + 3 + j] = -lr;
             Jj[i * 7 + j] = Rinv[i * 3 + j];
             Jj[(3 + i) * 7 + 3 + j] = L2[(1 + i) * 4 + 1 + j];
         }
-    for (int i = 0; i < 6; i++)
-        for (int j = 0; j < 7; j++) {
+    _Pragma("unroll") for (int i = 0; i < 6; i++)
+        _Pragma("unroll") for (int j = 0; j < 7; j++) {
             double si = 0, sj = 0;
-            for (int k = 0; k < 6; k++) { si += info[i * 6 + k] * Ji[k * 7 + j]; sj += info[i * 6 + k] * Jj[k * 7 + j]; }
+            _Pragma("unroll") for (int k = 0; k < 6; k++) { si += info[i * 6 + k] * Ji[k * 7 + j]; sj += info[i * 6 + k] * Jj[k * 7 + j]; }
             J[i * 7 + j] = si; J[42 + i * 7 + j] = sj;
         }
 }
@@ -217,21 +217,21 @@ __device__ void mono_factor(const double *params, const double *consts, const do
 }
 
 // params[7] ex; consts[16] 4x4 transform; info[2] = PRIOR_T, PRIOR_R.  J: [6*7] or null.
-__device__ void prior_factor(const double *params, const double *consts, const double *info, double *r, double *J)
+__device__ __forceinline__ void prior_factor(const double *params, const double *consts, const double *info, double *r, double *J)
 {
     double Rm[9], rot[4], rinv[4], q[4], pos[3];
-    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) Rm[i * 3 + j] = consts[i * 4 + j]; pos[i] = consts[i * 4 + 3]; }
+    _Pragma("unroll") for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) Rm[i * 3 + j] = consts[i * 4 + j]; pos[i] = consts[i * 4 + 3]; }
     R_to_q(Rm, rot);
     const double *P = params, *Q = params + 3;
     q_inv(rot, rinv); q_mul(rinv, Q, q);
-    for (int k = 0; k < 3; k++) { r[k] = info[0] * (P[k] - pos[k]); r[3 + k] = info[1] * (2 * q[k]); }
+    _Pragma("unroll") for (int k = 0; k < 3; k++) { r[k] = info[0] * (P[k] - pos[k]); r[3 + k] = info[1] * (2 * q[k]); }
     if (!J) return;
     double Qinv[4], qa[4], L[16];
     q_inv(Q, Qinv); q_mul(Qinv, rot, qa); quat_matrix(qa, 1.0, L);
-    for (int k = 0; k < 42; k++) J[k] = 0.0;
-    for (int i = 0; i < 3; i++) {
+    _Pragma("unroll") for (int k = 0; k < 42; k++) J[k] = 0.0;
+    _Pragma("unroll") for (int i = 0; i < 3; i++) {
         J[i * 7 + i] = info[0];
-        for (int j = 0; j < 3; j++) J[(3 + i) * 7 + 3 + j] = info[1] * L[i * 4 + j];
+        _Pragma("unroll") for (int j = 0; j < 3; j++) J[(3 + i) * 7 + 3 + j] = info[1] * L[i * 4 + j];
     }
 }
 

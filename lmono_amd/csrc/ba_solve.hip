@@ -1,4 +1,4 @@
-// lmono_amd/csrc/ba_solve.hip -- sliding-window BA solve on gfx950 (fp64): one 256-thread workgroup per window,
+// lmono_amd/csrc/ba_solve.hip -- sliding-window BA solve on gfx950 (fp64): one 512-thread workgroup per window,
 // windows batched across the grid (independent sequences / streams; a window depends on its predecessor, so one
 // sequence alone cannot batch -- SURVEY.md 8e).
 //
@@ -8,20 +8,40 @@
 // SURVEY.md): Jacobi scaling, traditional dogleg on the elliptical trust region, Schur elimination of the 1-D inverse
 // depth blocks into the 72x72 reduced system, Cholesky, step acceptance and radius update.
 //
-// Data flow per iteration: one thread per feature evaluates its observations (ba::mono_factor) and keeps the depth
-// block (H_ff, g_f) private, camera blocks go into the LDS-resident 72x72 H_pp with LDS double atomics, the coupling
-// columns H_pf into an HBM scratch (72 x F, L2-resident); the Schur complement is accumulated from 32-feature tiles
-// staged through LDS; Cholesky and the triangular solves run column-parallel in LDS.  The 72x72 system is far too
-// small for MFMA to matter at one window per workgroup: plain fp64 FMA.
+// Data flow of one linearisation (ba_evaluate<true>):
+//   * every 3x3 product of MonoProjectionFactor::Evaluate (MonoProjectionFactor.cc:40-174) that depends only on the
+//     frame pair (i, j) and the extrinsic is computed once per pair (<= 110 pairs) instead of once per observation;
+//   * observations are visited in (i, j)-pair order, two threads each (one per residual row); the robustified Jacobian
+//     rows [J_i | J_j | J_ex | r] go to an LDS stage (192 observations per pass);
+//   * the camera part of J^T J is a sum of small GEMMs, one per frame pair: the 8 waves walk the staged rows four at a
+//     time with v_mfma_f64_16x16x4_f64 (A = B^T = the same staged value) and add the finished 16x16 blocks into the
+//     LDS-resident 72x72 H_pp once per pair -- no per-observation atomics;
+//   * depth blocks: H_ff, g_f by LDS atomics (2 per observation), the coupling rows H_fp (feature-major, 80 doubles)
+//     in an HBM/L2 scratch.
+// Schur complement S = H_pp - sum_f e_f e_f^T / h_ff: 64-feature tiles staged in LDS, 15 upper 16x16 tiles of S
+// accumulated in registers with the same f64 MFMA; blocked Cholesky (8-column panels) and the triangular solves in
+// LDS.  fp64 throughout; contraction to FMA is allowed in this file (the BA parity bar is a tolerance).
 #include "common.hpp"
+
+#pragma clang fp contract(fast)
 
 namespace lmono {
 
 constexpr int kBaMaxPoses = 11;
 constexpr int kBaP = 6 * (kBaMaxPoses + 1);      // 72
+constexpr int kBaPS = 80;                        // padded row of the coupling matrix: 5 MFMA tiles of 16
 constexpr int kBaMaxFeat = 448;
 constexpr int kBaN = kBaP + kBaMaxFeat;          // 520
-constexpr int kBaTile = 32;
+constexpr int kBaMaxPairs = kBaMaxPoses * (kBaMaxPoses - 1);
+constexpr int kBaChunk = 192;                    // observations staged per pass
+constexpr int kBaRow = 20;                       // staged row: J_i(6) J_j(6) J_ex(6) r pad
+constexpr int kBaFT = 64;                        // features per Schur tile
+constexpr int kBaSS = 73;                        // row stride of S in LDS (odd: conflict-free column walks)
+constexpr int kBaPairRec = 40;                   // T(9) tp(3) Cm(9) A(9) B(9) pad
+constexpr int kBaT = 512;                        // threads per workgroup (2 waves per SIMD)
+constexpr int kBaW = kBaT / 64;
+
+typedef double ba_d4 __attribute__((ext_vector_type(4)));
 
 struct BaBatch {
     int n_windows;
@@ -32,31 +52,45 @@ struct BaBatch {
     double *poses;              // [W][11][7]
     double *ex;                 // [W][7]
     double *inv_depth;          // [total F]
-    const int *obs_feat;        // [total O] window-local feature index, grouped by feature
-    const int *obs_i, *obs_j;   // [total O]
-    const double *obs_pts;      // [total O][4]
-    const int *feat_obs_off;    // [total F + 1] first observation of each feature (global index)
+    const int *feat_anchor;     // [total F] frame the feature is anchored in (-1: no observation)
+    const int *pair_off;        // [W+1] first (i, j) frame pair of each window
+    const int *pair_ij;         // [total pairs] i | j << 8
+    const int *pobs_off;        // [W+1] first slot of each window in the pair-ordered observation list
+    const int *slot_info;       // [total slots] feature | pair << 16 (both window-local); feature 0xffff = padding (pairs are padded to even length)
+    const double *slot_pts;     // [total slots][4] the observation's two normalised image points, in slot order
     const double *laser_consts; // [W][10][24]
     const double *prior_T;      // [W][16]
     const double *info;         // laser_info[36], mono_info[4], prior_w[2]
-    double *hpd;                // scratch [W][72][kBaMaxFeat]
-    double *cand;               // scratch [W][ (11+1)*7 + kBaMaxFeat ]
+    double *hpd;                // scratch [W][kBaMaxFeat][kBaPS] coupling rows, feature-major
+    double *pairdat;            // scratch [total pairs][kBaPairRec]
+    double *cand;               // scratch [W][kBaMaxFeat]
     double *summary;            // [W][6] initial_cost, final_cost, iterations, termination, successful, unsuccessful
 };
 
+struct BaSchurStage { double et[kBaFT * kBaPS]; double ic[kBaFT]; double gi[kBaFT]; };
+
 struct BaLds {
     double Hpp[kBaP * kBaP];
-    double S[kBaP * kBaP];
-    double tile[kBaP * kBaTile];
+    union {
+        double stage[kBaChunk * 2 * kBaRow];     // evaluate: staged Jacobian rows
+        BaSchurStage sch;                         // Schur: scaled coupling tile, 1 / h_ff
+        double S[(kBaP + 1) * kBaSS];             // reduced system / its Cholesky factor; row P = right-hand side
+    } u;
     double Hdd[kBaMaxFeat], gdd[kBaMaxFeat];
     double gp[kBaP];
-    double scale[kBaN], D[kBaN], D2[kBaN], gs[kBaN], gdv[kBaN], gn[kBaN], step[kBaN], tmp[kBaN], tmp2[kBaN];
-    double rhs[kBaP];
-    double red[8];
+    double scale[kBaN], D[kBaN], D2[kBaN], gs[kBaN], gdv[kBaN], gn[kBaN], va[kBaN], vb[kBaN], vw[kBaN];
+    double rhs[kBaPS];
+    double part[kBaW][kBaPS];
+    double red[3 * kBaW];
     double poses[kBaMaxPoses * 7], ex[7];
     double cposes[kBaMaxPoses * 7], cex[7];
+    double Rp[(kBaMaxPoses + 1) * 9];            // rotation matrices of the window poses, then R_lc
+    double vinv[kBaMaxFeat];                     // inverse depths of the state being evaluated
+    int pair_ij[kBaMaxPairs];
+    int spair[kBaChunk];                         // pair of every staged slot
     int ok;
 };
+static_assert(sizeof(BaLds) <= 160 * 1024, "BaLds exceeds the 160 KB LDS of a gfx950 CU");
 
 __device__ __forceinline__ double block_sum(double v, double *red)
 {
@@ -64,7 +98,20 @@ __device__ __forceinline__ double block_sum(double v, double *red)
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    return ((red[0] + red[1]) + red[2]) + red[3];
+    double s = 0;
+#pragma unroll
+    for (int w = 0; w < kBaW; w++) s += red[w];
+    return s;
+}
+__device__ __forceinline__ void block_sum3(double &a, double &b, double &c, double *red)
+{
+    a = wave_sum_d(a); b = wave_sum_d(b); c = wave_sum_d(c);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; red[w] = a; red[kBaW + w] = b; red[2 * kBaW + w] = c; }
+    __syncthreads();
+    a = 0; b = 0; c = 0;
+#pragma unroll
+    for (int w = 0; w < kBaW; w++) { a += red[w]; b += red[kBaW + w]; c += red[2 * kBaW + w]; }
 }
 __device__ __forceinline__ double block_max(double v, double *red)
 {
@@ -73,7 +120,10 @@ __device__ __forceinline__ double block_max(double v, double *red)
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    double m = red[0];
+#pragma unroll
+    for (int w = 1; w < kBaW; w++) m = fmax(m, red[w]);
+    return m;
 }
 
 __device__ __forceinline__ void lds_add_block(double *H, const double *Ja, int oa, const double *Jb, int ob, int nr)
@@ -82,205 +132,683 @@ __device__ __forceinline__ void lds_add_block(double *H, const double *Ja, int o
         for (int b = 0; b < 6; b++) {
             double v = 0;
             for (int r = 0; r < nr; r++) v += Ja[r * 7 + a] * Jb[r * 7 + b];
-            atomicAdd(&H[(oa + a) * kBaP + ob + b], v);
-            if (oa != ob) atomicAdd(&H[(ob + b) * kBaP + oa + a], v);
+            unsafeAtomicAdd(&H[(oa + a) * kBaP + ob + b], v);
+            if (oa != ob) unsafeAtomicAdd(&H[(ob + b) * kBaP + oa + a], v);
         }
 }
+
+#ifdef LMONO_BA_PROF
+__device__ long long g_prof[16];
+#define BA_TICK(i) { if (blockIdx.x == 0 && threadIdx.x == 0) g_prof[i] -= clock64(); }
+#define BA_TOCK(i) { if (blockIdx.x == 0 && threadIdx.x == 0) g_prof[i] += clock64(); }
+#else
+#define BA_TICK(i)
+#define BA_TOCK(i)
+#endif
 
 struct BaCtx {
     int n_poses, use_prior, ex_constant, use_mono, F, P, ex_off;
     int f0, o0;
+    int pp0, n_pairs;      // first pair / number of pairs of this window
+    int ps0, n_slots;      // first slot / number of slots of the pair-ordered observation list
 };
 __device__ __forceinline__ int ba_pose_off(const BaCtx &c, int i) { return (c.ex_off < 0 ? 0 : 6) + 6 * i; }
 
+// row vector times 3x3 (row-major)
+__device__ __forceinline__ void rowmul(const double *u, const double *M, double *o)
+{
+    o[0] = u[0] * M[0] + u[1] * M[3] + u[2] * M[6];
+    o[1] = u[0] * M[1] + u[1] * M[4] + u[2] * M[7];
+    o[2] = u[0] * M[2] + u[1] * M[5] + u[2] * M[8];
+}
+__device__ __forceinline__ void cross3(const double *a, const double *b, double *o)
+{
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// everything of MonoProjectionFactor::Evaluate that depends only on (pose_i, pose_j, extrinsic)
+__device__ __forceinline__ void ba_pair_record(const double *Ri, const double *Rj, const double *Rlc, const double *ti, const double *tj,
+                                               const double *tx, double *rec)
+{
+    double RlcT[9], RjT[9], G[9], A[9], Bm[9], T[9], Cm[9], v[3], v2[3];
+    ba::mT(Rlc, RlcT); ba::mT(Rj, RjT);
+    // (Rj^T Ri).normalized() is a Frobenius normalisation (MonoProjectionFactor.cc:125)
+    ba::mm(RjT, Ri, G);
+    double fro = 0;
+    for (int k = 0; k < 9; k++) fro += G[k] * G[k];
+    fro = sqrt(fro);
+    for (int k = 0; k < 9; k++) G[k] = G[k] / fro - ((k % 4 == 0) ? 1.0 : 0.0);
+    ba::mm(RlcT, G, Cm);
+    ba::mm(RlcT, RjT, A);
+    ba::mm(A, Ri, Bm);
+    ba::mm(Bm, Rlc, T);
+    ba::mv(Ri, tx, v);
+    for (int k = 0; k < 3; k++) v[k] = v[k] + ti[k] - tj[k];
+    ba::mv(RjT, v, v2);
+    for (int k = 0; k < 3; k++) v2[k] -= tx[k];
+    ba::mv(RlcT, v2, v);
+    for (int k = 0; k < 9; k++) { rec[k] = T[k]; rec[12 + k] = Cm[k]; rec[21 + k] = A[k]; rec[30 + k] = Bm[k]; }
+    for (int k = 0; k < 3; k++) rec[9 + k] = v[k];
+    rec[39] = 0.0;
+}
+
+// v + the value of the neighbouring lane (lane ^ 1): DPP quad_perm [1, 0, 3, 2], no LDS round trip
+__device__ __forceinline__ double pair_sum(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xF, 0xF, false);
+    return v + __hiloint2double(hi, lo);
+}
+// the scratch / index arrays of a window live in HBM: say so (a pointer loaded from the argument struct is generic,
+// and generic loads / atomics tie the LDS and the vector-memory counters together)
+typedef __attribute__((address_space(1))) double ba_gd;
+typedef __attribute__((address_space(1))) const double ba_gcd;
+typedef __attribute__((address_space(1))) const int ba_gci;
+__device__ __forceinline__ double gld(const double *p) { return *(ba_gcd *)p; }
+__device__ __forceinline__ int gldi(const int *p) { return *(ba_gci *)p; }
+__device__ __forceinline__ void gst(double *p, double v) { *(ba_gd *)p = v; }
+__device__ __forceinline__ void gatomic_add(double *p, double v) { (void)__builtin_amdgcn_global_atomic_fadd_f64((ba_gd *)p, v); }
+
+// LASERFactor chain and the extrinsic prior: a handful of residual blocks, one thread each.  The thread leaves its
+// residuals and Jacobians in LDS ([r(6) | J(84)] per block, block 10 = prior); the J^T J products are then spread over
+// the whole workgroup (ba_small_accumulate).  Kept out of line: its register-resident 6x14 Jacobian must not shape the
+// register allocation of the hot loops.
+constexpr int kBaSmallRec = 96;
+template <bool kJac>
+__device__ __noinline__ double ba_small_factors(const BaBatch &B, const BaCtx c, double *out, const double *poses, const double *ex, int t)
+{
+    double cost = 0.0;
+    const double *laser_info = B.info, *prior_w = B.info + 40;
+    if (t >= 0 && t < c.n_poses - 1) {
+        double prm[14], cst[24], inf[36], r[6], J[84];
+#pragma unroll
+        for (int k = 0; k < 7; k++) { prm[k] = poses[7 * t + k]; prm[7 + k] = poses[7 * (t + 1) + k]; }
+#pragma unroll
+        for (int k = 0; k < 24; k++) cst[k] = gld(B.laser_consts + ((size_t)blockIdx.x * 10 + t) * 24 + k);
+#pragma unroll
+        for (int k = 0; k < 36; k++) inf[k] = gld(laser_info + k);
+        ba::laser_factor(prm, cst, inf, r, kJac ? J : nullptr);
+#pragma unroll
+        for (int k = 0; k < 6; k++) cost += 0.5 * r[k] * r[k];
+        if (kJac) {
+            double *o = out + t * kBaSmallRec;
+#pragma unroll
+            for (int k = 0; k < 6; k++) o[k] = r[k];
+#pragma unroll
+            for (int k = 0; k < 84; k++) o[6 + k] = J[k];
+        }
+    }
+    if (t == 16 && c.use_prior && !c.ex_constant) {
+        double prm[7], cst[16], r[6], J[42];
+        const double pw[2] = { gld(prior_w), gld(prior_w + 1) };
+#pragma unroll
+        for (int k = 0; k < 7; k++) prm[k] = ex[k];
+#pragma unroll
+        for (int k = 0; k < 16; k++) cst[k] = gld(B.prior_T + (size_t)blockIdx.x * 16 + k);
+        ba::prior_factor(prm, cst, pw, r, kJac ? J : nullptr);
+#pragma unroll
+        for (int k = 0; k < 6; k++) cost += 0.5 * r[k] * r[k];
+        if (kJac) {
+            double *o = out + 10 * kBaSmallRec;
+#pragma unroll
+            for (int k = 0; k < 6; k++) o[k] = r[k];
+#pragma unroll
+            for (int k = 0; k < 42; k++) o[6 + k] = J[k];
+        }
+    }
+    return cost;
+}
+
+// J^T J and J^T r of the blocks left in LDS by ba_small_factors, one output entry per thread and round
+__device__ __forceinline__ void ba_small_accumulate(const BaCtx &c, BaLds &L, const double *in)
+{
+    const int nl = c.n_poses - 1;
+    for (int idx = threadIdx.x; idx < nl * 156; idx += kBaT) {
+        const int b = idx / 156, e = idx - b * 156;
+        const double *r = in + b * kBaSmallRec, *J = r + 6;
+        const int a = e < 144 ? e / 12 : e - 144, bb = e < 144 ? e % 12 : 0;
+        const double *Ja = J + (a < 6 ? a : 42 + a - 6);
+        const int ga = ba_pose_off(c, a < 6 ? b : b + 1) + (a < 6 ? a : a - 6);
+        double v = 0;
+        if (e < 144) {
+            const double *Jb = J + (bb < 6 ? bb : 42 + bb - 6);
+#pragma unroll
+            for (int k = 0; k < 6; k++) v += Ja[7 * k] * Jb[7 * k];
+            unsafeAtomicAdd(&L.Hpp[ga * kBaP + ba_pose_off(c, bb < 6 ? b : b + 1) + (bb < 6 ? bb : bb - 6)], v);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 6; k++) v += Ja[7 * k] * r[k];
+            unsafeAtomicAdd(&L.gp[ga], v);
+        }
+    }
+    if (c.use_prior && !c.ex_constant && threadIdx.x < 42) {
+        const double *r = in + 10 * kBaSmallRec, *J = r + 6;
+        const int e = threadIdx.x, a = e < 36 ? e / 6 : e - 36, bb = e < 36 ? e % 6 : 0;
+        double v = 0;
+        if (e < 36) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) v += J[7 * k + a] * J[7 * k + bb];
+            unsafeAtomicAdd(&L.Hpp[(c.ex_off + a) * kBaP + c.ex_off + bb], v);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 6; k++) v += J[7 * k + a] * r[k];
+            unsafeAtomicAdd(&L.gp[c.ex_off + a], v);
+        }
+    }
+}
+
+
 // cost (returned to every thread) and, when kJac, the unscaled normal equations: Hpp, gp, Hdd, gdd in LDS, Hpd in HBM
 template <bool kJac>
-__device__ double ba_evaluate(const BaBatch &B, const BaCtx &c, BaLds &L, const double *poses, const double *ex, const double *invd, double *hpd)
+__device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLds &L, const double *poses, const double *ex, const double *invd,
+                                              double *hpd, double *pairdat)
 {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __syncthreads();
+    BA_TICK(kJac ? 0 : 3)
+    if (tid <= c.n_poses) {
+        double qn[4];
+        ba::q_norm(tid == c.n_poses ? ex + 3 : poses + 7 * tid + 3, qn);
+        ba::q_to_R(qn, L.Rp + 9 * tid);
+    }
+    for (int f = tid; f < c.F; f += kBaT) L.vinv[f] = gld(invd + f);
     if (kJac) {
-        for (int k = tid; k < kBaP * kBaP; k += 256) L.Hpp[k] = 0.0;
-        for (int k = tid; k < kBaP; k += 256) L.gp[k] = 0.0;
-        for (int k = tid; k < c.F; k += 256) { L.Hdd[k] = 0.0; L.gdd[k] = 0.0; }
-        for (int k = tid; k < c.P * c.F; k += 256) hpd[(k / c.F) * kBaMaxFeat + (k % c.F)] = 0.0;
-        __syncthreads();
+        for (int k = tid; k < kBaP * kBaP; k += kBaT) L.Hpp[k] = 0.0;
+        for (int k = tid; k < kBaP; k += kBaT) L.gp[k] = 0.0;
+        for (int f = tid; f < c.F; f += kBaT) {
+            L.Hdd[f] = 0.0; L.gdd[f] = 0.0;
+            // the extrinsic and anchor-frame parts of a coupling row are sums over the feature's observations
+            const int anchor = gldi(B.feat_anchor + c.f0 + f);
+            double *row = hpd + (size_t)f * kBaPS;
+            for (int a = 0; a < 6; a++) {
+                if (c.ex_off >= 0) gst(row + c.ex_off + a, 0.0);
+                if (anchor >= 0) gst(row + ba_pose_off(c, anchor) + a, 0.0);
+            }
+        }
+    }
+    __syncthreads();
+    const double *Rlc = L.Rp + 9 * c.n_poses;
+    for (int p = tid; p < c.n_pairs; p += kBaT) {
+        const int ij = L.pair_ij[p], i = ij & 255, j = ij >> 8;
+        double rec[kBaPairRec];
+        ba_pair_record(L.Rp + 9 * i, L.Rp + 9 * j, Rlc, poses + 7 * i, poses + 7 * j, ex, rec);
+        double *dst = pairdat + (size_t)p * kBaPairRec;
+#pragma unroll
+        for (int k = 0; k < kBaPairRec; k++) gst(dst + k, rec[k]);
     }
     double cost = 0.0;
-    const double *laser_info = B.info, *mono_info = B.info + 36, *prior_w = B.info + 40;
-    if (tid < c.n_poses - 1) {
-        double prm[14], r[6], J[84];
-        for (int k = 0; k < 7; k++) { prm[k] = poses[7 * tid + k]; prm[7 + k] = poses[7 * (tid + 1) + k]; }
-        ba::laser_factor(prm, B.laser_consts + ((size_t)blockIdx.x * 10 + tid) * 24, laser_info, r, kJac ? J : nullptr);
-        for (int k = 0; k < 6; k++) cost += 0.5 * r[k] * r[k];
-        if (kJac) {
-            const int oi = ba_pose_off(c, tid), oj = ba_pose_off(c, tid + 1);
-            lds_add_block(L.Hpp, J, oi, J, oi, 6); lds_add_block(L.Hpp, J, oi, J + 42, oj, 6); lds_add_block(L.Hpp, J + 42, oj, J + 42, oj, 6);
-            for (int a = 0; a < 6; a++) {
-                double gi = 0, gj = 0;
-                for (int k = 0; k < 6; k++) { gi += J[k * 7 + a] * r[k]; gj += J[42 + k * 7 + a] * r[k]; }
-                atomicAdd(&L.gp[oi + a], gi); atomicAdd(&L.gp[oj + a], gj);
+    // wave 1: LASERFactor chain and prior, next to the pair records of wave 0
+    if (tid >= 64 && tid < 96) cost += ba_small_factors<kJac>(B, c, L.u.stage, poses, ex, tid - 64);
+    const double *mono_info = B.info + 36;
+    const double m00 = gld(mono_info), m01 = gld(mono_info + 1), m10 = gld(mono_info + 2), m11 = gld(mono_info + 3);
+    const int *sinfo = B.slot_info + c.ps0;
+    const double *spts = B.slot_pts + (size_t)c.ps0 * 4;
+    if (!kJac) {
+        __syncthreads();   // pair records are visible
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // four slots per thread and round: their index words and image points are requested before any is used
+        for (int s0 = tid; s0 < c.n_slots; s0 += 4 * kBaT) {
+            int info[4];
+            double2 pa[4], pb[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int s = s0 + kBaT * u;
+                info[u] = -1;
+                if (s < c.n_slots) {
+                    info[u] = gldi(sinfo + s);
+                    pa[u] = make_double2(gld(spts + (size_t)s * 4), gld(spts + (size_t)s * 4 + 1)); pb[u] = make_double2(gld(spts + (size_t)s * 4 + 2), gld(spts + (size_t)s * 4 + 3));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (info[u] < 0 || (info[u] & 0xffff) == 0xffff) continue;
+                const double *rec = pairdat + (size_t)(info[u] >> 16) * kBaPairRec;
+                const double depth = 1.0 / L.vinv[info[u] & 0xffff];
+                const double pc[3] = { depth * pa[u].x, depth * pa[u].y, depth };
+                double Tt[12], pcj[3];
+#pragma unroll
+                for (int k = 0; k < 12; k++) Tt[k] = gld(rec + k);
+                ba::mv(Tt, pc, pcj);
+                for (int k = 0; k < 3; k++) pcj[k] += Tt[9 + k];
+                const double inv = 1.0 / pcj[2];
+                const double e0 = pcj[0] * inv - pb[u].x, e1 = pcj[1] * inv - pb[u].y;
+                const double r0 = m00 * e0 + m01 * e1, r1 = m10 * e0 + m11 * e1;
+                cost += 0.5 * log(1.0 + (r0 * r0 + r1 * r1));   // ceres::CauchyLoss(1)
             }
         }
+        cost = block_sum(cost, L.red);
+        BA_TOCK(3)
+        return cost;
     }
-    if (tid == 32 && c.use_prior && !c.ex_constant) {
-        double r[6], J[42];
-        ba::prior_factor(ex, B.prior_T + (size_t)blockIdx.x * 16, prior_w, r, kJac ? J : nullptr);
-        for (int k = 0; k < 6; k++) cost += 0.5 * r[k] * r[k];
-        if (kJac) {
-            lds_add_block(L.Hpp, J, c.ex_off, J, c.ex_off, 6);
-            for (int a = 0; a < 6; a++) { double g = 0; for (int k = 0; k < 6; k++) g += J[k * 7 + a] * r[k]; atomicAdd(&L.gp[c.ex_off + a], g); }
-        }
+
+    __syncthreads();   // pair records and zeroed coupling rows are visible
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    ba_small_accumulate(c, L, L.u.stage);
+    __syncthreads();   // the stage is free for the first pass
+    BA_TOCK(0)
+    // two threads per observation: thread q of the pair owns residual row q.  Slot data of the next pass are requested
+    // before the MFMA phase of the current one.
+    const int q = tid & 1, so = tid >> 1;        // row, slot inside the pass
+    double xx44 = 0, xx45 = 0, xx55 = 0, gx4 = 0, gx5 = 0;
+    int info_n = -1;
+    double2 pa_n = { 0, 0 }, pb_n = { 0, 0 };
+    if (so < min(kBaChunk, c.n_slots)) {
+        info_n = gldi(sinfo + so);
+        pa_n = make_double2(gld(spts + (size_t)so * 4), gld(spts + (size_t)so * 4 + 1)); pb_n = make_double2(gld(spts + (size_t)so * 4 + 2), gld(spts + (size_t)so * 4 + 3));
     }
-    // one thread per feature: its observations are contiguous
-    for (int f = tid; f < c.F; f += 256) {
-        const int ob = B.feat_obs_off[c.f0 + f], oe = B.feat_obs_off[c.f0 + f + 1];
-        double hff = 0.0, gf = 0.0, hx[6] = { 0, 0, 0, 0, 0, 0 }, hi[6] = { 0, 0, 0, 0, 0, 0 };
-        int anchor = -1;
-        for (int o = ob; o < oe; o++) {
-            const int i = B.obs_i[o], j = B.obs_j[o];
-            anchor = i;
-            double prm[22], r[2], J[44];
-            for (int k = 0; k < 7; k++) { prm[k] = ex[k]; prm[7 + k] = poses[7 * i + k]; prm[14 + k] = poses[7 * j + k]; }
-            prm[21] = invd[f];
-            ba::mono_factor(prm, B.obs_pts + (size_t)o * 4, mono_info, r, kJac ? J : nullptr);
-            const double sq = r[0] * r[0] + r[1] * r[1];
-            // ceres::CauchyLoss(1): rho = log(1 + s), rho' = 1 / (1 + s), rho'' < 0 -> corrector scales by sqrt(rho')
-            cost += 0.5 * log(1.0 + sq);
-            if (!kJac) continue;
-            const double inv = 1.0 / (1.0 + sq);
-            const double sr = sqrt(inv > DBL_MIN ? inv : DBL_MIN);
-            for (int k = 0; k < 44; k++) J[k] *= sr;
-            r[0] *= sr; r[1] *= sr;
-            const int oi = ba_pose_off(c, i), oj = ba_pose_off(c, j);
-            const double *Jx = J, *Ji = J + 14, *Jj = J + 28, *Jd = J + 42;
-            if (c.ex_off >= 0) { lds_add_block(L.Hpp, Jx, c.ex_off, Jx, c.ex_off, 2); lds_add_block(L.Hpp, Jx, c.ex_off, Ji, oi, 2); lds_add_block(L.Hpp, Jx, c.ex_off, Jj, oj, 2); }
-            lds_add_block(L.Hpp, Ji, oi, Ji, oi, 2); lds_add_block(L.Hpp, Ji, oi, Jj, oj, 2); lds_add_block(L.Hpp, Jj, oj, Jj, oj, 2);
-            for (int a = 0; a < 6; a++) {
-                if (c.ex_off >= 0) { atomicAdd(&L.gp[c.ex_off + a], Jx[a] * r[0] + Jx[7 + a] * r[1]); hx[a] += Jx[a] * Jd[0] + Jx[7 + a] * Jd[1]; }
-                atomicAdd(&L.gp[oi + a], Ji[a] * r[0] + Ji[7 + a] * r[1]);
-                atomicAdd(&L.gp[oj + a], Jj[a] * r[0] + Jj[7 + a] * r[1]);
-                hi[a] += Ji[a] * Jd[0] + Ji[7 + a] * Jd[1];
-                hpd[(size_t)(oj + a) * kBaMaxFeat + f] = Jj[a] * Jd[0] + Jj[7 + a] * Jd[1];   // frame j is observed once per feature
+    for (int c0 = 0; c0 < c.n_slots; c0 += kBaChunk) {
+        const int nslot = min(kBaChunk, c.n_slots - c0);   // even: pairs are padded to even length
+        BA_TICK(1)
+        const int info = info_n;
+        const double2 pa = pa_n, pb = pb_n;
+        {
+            const int sn = c0 + kBaChunk + so;
+            info_n = -1;
+            if (so < kBaChunk && sn < c.n_slots) {
+                info_n = gldi(sinfo + sn);
+                pa_n = make_double2(gld(spts + (size_t)sn * 4), gld(spts + (size_t)sn * 4 + 1)); pb_n = make_double2(gld(spts + (size_t)sn * 4 + 2), gld(spts + (size_t)sn * 4 + 3));
             }
-            hff += Jd[0] * Jd[0] + Jd[1] * Jd[1];
-            gf += Jd[0] * r[0] + Jd[1] * r[1];
         }
-        if (kJac) {
-            L.Hdd[f] = hff; L.gdd[f] = gf;
-            if (anchor >= 0) {
-                const int oi = ba_pose_off(c, anchor);
-                for (int a = 0; a < 6; a++) {
-                    if (c.ex_off >= 0) hpd[(size_t)(c.ex_off + a) * kBaMaxFeat + f] = hx[a];
-                    hpd[(size_t)(oi + a) * kBaMaxFeat + f] = hi[a];
+        if (so < nslot) {
+            double *row = L.u.stage + (size_t)(2 * so + q) * kBaRow;
+            const int pr = info >> 16, f = info & 0xffff;
+            if (q == 0) L.spair[so] = pr;
+            if (f == 0xffff) {
+                for (int k = 0; k < kBaRow; k++) row[k] = 0.0;   // padding slot of its pair
+            } else {
+                const int ij = L.pair_ij[pr], fi = ij & 255, fj = ij >> 8;
+                // the whole pair record is requested at once (one round trip); the lanes of a pair read the same lines
+                double rec[kBaPairRec - 1];
+                {
+                    const double *rp = pairdat + (size_t)pr * kBaPairRec;
+#pragma unroll
+                    for (int k = 0; k < kBaPairRec - 1; k++) rec[k] = gld(rp + k);
+                }
+                const double *T = rec, *Cm = rec + 12, *A = rec + 21, *Bm = rec + 30;
+                const double depth = 1.0 / L.vinv[f];
+                const double pc[3] = { depth * pa.x, depth * pa.y, depth };
+                double Tp[3], pcj[3], uT[3], u[3];
+                ba::mv(T, pc, Tp);
+                for (int k = 0; k < 3; k++) pcj[k] = Tp[k] + rec[9 + k];
+                const double inv = 1.0 / pcj[2];
+                const double e0 = pcj[0] * inv - pb.x, e1 = pcj[1] * inv - pb.y;
+                const double r0 = m00 * e0 + m01 * e1, r1 = m10 * e0 + m11 * e1;
+                const double sq = r0 * r0 + r1 * r1;
+                if (q == 0) cost += 0.5 * log(1.0 + sq);
+                // ceres::CauchyLoss(1): rho' = 1 / (1 + s), rho'' < 0 -> the corrector scales rows by sqrt(rho')
+                const double rho1 = 1.0 / (1.0 + sq);
+                const double sr = sqrt(rho1 > DBL_MIN ? rho1 : DBL_MIN);
+                const double rq = (q ? r1 : r0) * sr;
+                // row q of sqrt_info * [[1/z, 0, -x/z^2], [0, 1/z, -y/z^2]], robustified
+                const double ma = q ? m10 : m00, mb = q ? m11 : m01;
+                u[0] = sr * ma * inv; u[1] = sr * mb * inv; u[2] = -sr * (ma * pcj[0] + mb * pcj[1]) * inv * inv;
+                rowmul(u, T, uT);
+                // inverse depth: -u (T p_i) depth^2 = -u (T pc) depth
+                const double Jd = -(u[0] * Tp[0] + u[1] * Tp[1] + u[2] * Tp[2]) * depth;
+                double Jx[6], Ji[6], Jj[6], c1[3], c2[3];
+                // extrinsic block: position u Cm, rotation -(uT) x pc + u x pcj   (u skew(v) = u x v)
+                if (c.ex_off >= 0) {
+                    rowmul(u, Cm, Jx);
+                    cross3(uT, pc, c1); cross3(u, pcj, c2);
+                    for (int k = 0; k < 3; k++) Jx[3 + k] = c2[k] - c1[k];
+                    xx44 += Jx[4] * Jx[4]; xx45 += Jx[4] * Jx[5]; xx55 += Jx[5] * Jx[5];
+                    gx4 += Jx[4] * rq; gx5 += Jx[5] * rq;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 6; k++) Jx[k] = 0.0;
+                }
+                // pose i: position u A, rotation -(u B) x pl;  pose j: position -u A, rotation (u Rlc^T) x plj
+                {
+                    double uB[3], uR[3], pl[3], plj[3];
+                    rowmul(u, A, Ji);
+                    for (int k = 0; k < 3; k++) Jj[k] = -Ji[k];
+                    ba::mv(Rlc, pc, pl);
+                    for (int k = 0; k < 3; k++) pl[k] += ex[k];
+                    rowmul(u, Bm, uB); cross3(uB, pl, c1);
+                    for (int k = 0; k < 3; k++) Ji[3 + k] = -c1[k];
+                    ba::mv(Rlc, pcj, plj);
+                    for (int k = 0; k < 3; k++) plj[k] += ex[k];
+                    uR[0] = u[0] * Rlc[0] + u[1] * Rlc[1] + u[2] * Rlc[2];
+                    uR[1] = u[0] * Rlc[3] + u[1] * Rlc[4] + u[2] * Rlc[5];
+                    uR[2] = u[0] * Rlc[6] + u[1] * Rlc[7] + u[2] * Rlc[8];
+                    cross3(uR, plj, c1);
+                    for (int k = 0; k < 3; k++) Jj[3 + k] = c1[k];
+                }
+#pragma unroll
+                for (int k = 0; k < 6; k++) { row[k] = Ji[k]; row[6 + k] = Jj[k]; row[12 + k] = Jx[k]; }
+                row[18] = rq; row[19] = 0.0;
+                // depth block and coupling row: the two rows of the observation are summed across the lane pair, lane q = 0
+                // issues the atomics -- after every load of this pass, so that nothing waits on their completion
+                double hx[6], hi[6], hj[6];
+#pragma unroll
+                for (int k = 0; k < 6; k++) { hx[k] = pair_sum(Jx[k] * Jd); hi[k] = pair_sum(Ji[k] * Jd); hj[k] = pair_sum(Jj[k] * Jd); }
+                const double hdd = pair_sum(Jd * Jd), gd = pair_sum(Jd * rq);
+                if (q == 0) {
+                    double *hrow = hpd + (size_t)f * kBaPS;
+                    const int oi = ba_pose_off(c, fi), oj = ba_pose_off(c, fj);
+                    unsafeAtomicAdd(&L.Hdd[f], hdd); unsafeAtomicAdd(&L.gdd[f], gd);
+#pragma unroll
+                    for (int k = 0; k < 6; k++) {
+                        if (c.ex_off >= 0) gatomic_add(hrow + c.ex_off + k, hx[k]);
+                        gatomic_add(hrow + oi + k, hi[k]);
+                        gst(hrow + oj + k, hj[k]);                              // frame j sees a feature once
+                    }
                 }
             }
         }
+        __syncthreads();
+        BA_TOCK(1)
+        BA_TICK(2)
+        // J^T [J r] of the staged rows: four rows (two observations of one pair) per MFMA step
+        {
+            const int nk = nslot >> 1;
+            const int k_begin = wave * nk / kBaW, k_end = (wave + 1) * nk / kBaW;
+            const int col = lane & 15, kq = lane >> 4;
+            int cur = -1;
+            ba_d4 aa = { 0, 0, 0, 0 }, ab = { 0, 0, 0, 0 };
+            auto flush = [&](int pr) {
+                const int ij = L.pair_ij[pr];
+                const int oi = ba_pose_off(c, ij & 255), oj = ba_pose_off(c, ij >> 8);
+                auto gidx = [&](int m) { return m < 6 ? oi + m : (m < 12 ? oj + m - 6 : (c.ex_off < 0 ? -1 : c.ex_off + m - 12)); };
+                const int gn_ = gidx(col);
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    const int gm = gidx(kq + 4 * v);
+                    if (gm < 0) continue;
+                    if (gn_ >= 0) unsafeAtomicAdd(&L.Hpp[gm * kBaP + gn_], aa[v]);
+                    if (col < 2) {
+                        if (c.ex_off >= 0) {
+                            const int xc = c.ex_off + 4 + col;
+                            unsafeAtomicAdd(&L.Hpp[gm * kBaP + xc], ab[v]);
+                            unsafeAtomicAdd(&L.Hpp[xc * kBaP + gm], ab[v]);
+                        }
+                    } else if (col == 2) {
+                        unsafeAtomicAdd(&L.gp[gm], ab[v]);
+                    }
+                }
+            };
+            for (int ks = k_begin; ks < k_end; ks++) {
+                const int pr = L.spair[2 * ks];
+                if (pr != cur) {
+                    if (cur >= 0) flush(cur);
+                    aa = ba_d4{ 0, 0, 0, 0 }; ab = ba_d4{ 0, 0, 0, 0 };
+                    cur = pr;
+                }
+                const double *rowp = L.u.stage + (size_t)(4 * ks + kq) * kBaRow;
+                const double a = rowp[col];
+                const double b = col < 4 ? rowp[16 + col] : 0.0;
+                aa = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, aa, 0, 0, 0);
+                ab = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, ab, 0, 0, 0);
+            }
+            if (cur >= 0) flush(cur);
+        }
+        __syncthreads();
+        BA_TOCK(2)
     }
-    return block_sum(cost, L.red);
+    if (c.ex_off >= 0 && c.n_slots > 0) {
+        xx44 = wave_sum_d(xx44); xx45 = wave_sum_d(xx45); xx55 = wave_sum_d(xx55); gx4 = wave_sum_d(gx4); gx5 = wave_sum_d(gx5);
+        if (lane == 0) {
+            const int x4 = c.ex_off + 4, x5 = c.ex_off + 5;
+            unsafeAtomicAdd(&L.Hpp[x4 * kBaP + x4], xx44); unsafeAtomicAdd(&L.Hpp[x5 * kBaP + x5], xx55);
+            unsafeAtomicAdd(&L.Hpp[x4 * kBaP + x5], xx45); unsafeAtomicAdd(&L.Hpp[x5 * kBaP + x4], xx45);
+            unsafeAtomicAdd(&L.gp[x4], gx4); unsafeAtomicAdd(&L.gp[x5], gx5);
+        }
+    }
+    cost = block_sum(cost, L.red);
+    // the coupling rows were accumulated by L2 atomics: drop this CU's L1 copies before they are read with plain loads
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return cost;
 }
 
 // y = Hs v (Jacobi-scaled), v and y in LDS arrays of length N
-__device__ void ba_hs_mul(const BaCtx &c, BaLds &L, const double *hpd, const double *v, double *y)
+__device__ __noinline__ void ba_hs_mul(const BaCtx c, BaLds &L, const double *hpd, const double *v, double *y)
 {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P = c.P, F = c.F, N = P + F;
     __syncthreads();
-    for (int a = tid; a < c.P; a += 256) {
+    BA_TICK(4)
+    for (int k = tid; k < N; k += kBaT) L.vw[k] = L.scale[k] * v[k];
+    __syncthreads();
+    // camera rows: wave w sums the features f = w (mod 8); lanes own the parameter columns (coalesced 640-B rows),
+    // eight feature rows in flight
+    {
+        double a0 = 0, a1 = 0;
+        for (int f = wave; f < F; f += 8 * kBaW) {
+            double r0[8], r1[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int fu = f + kBaW * u;
+                const double *row = hpd + (size_t)fu * kBaPS;
+                r0[u] = fu < F ? gld(row + lane) : 0.0;
+                r1[u] = (fu < F && lane < kBaPS - 64) ? gld(row + 64 + lane) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int fu = f + kBaW * u;
+                const double w = fu < F ? L.vw[P + fu] : 0.0;
+                a0 += r0[u] * w; a1 += r1[u] * w;
+            }
+        }
+        L.part[wave][lane] = a0;
+        if (lane < kBaPS - 64) L.part[wave][64 + lane] = a1;
+    }
+    // depth rows: four lanes per feature, the 18 entries of a lane requested together
+    for (int f = tid >> 2; f < F; f += kBaT / 4) {
+        const double *row = hpd + (size_t)f * kBaPS;
+        double rv[18];
+#pragma unroll
+        for (int k = 0; k < 18; k++) { const int a = (tid & 3) + 4 * k; rv[k] = a < P ? gld(row + a) : 0.0; }
         double acc = 0;
-        for (int b = 0; b < c.P; b++) acc += L.Hpp[a * kBaP + b] * L.scale[b] * v[b];
-        for (int f = 0; f < c.F; f++) acc += hpd[(size_t)a * kBaMaxFeat + f] * L.scale[c.P + f] * v[c.P + f];
-        y[a] = acc * L.scale[a];
-    }
-    for (int f = tid; f < c.F; f += 256) {
-        double acc = L.Hdd[f] * L.scale[c.P + f] * v[c.P + f];
-        for (int a = 0; a < c.P; a++) acc += hpd[(size_t)a * kBaMaxFeat + f] * L.scale[a] * v[a];
-        y[c.P + f] = acc * L.scale[c.P + f];
+#pragma unroll
+        for (int k = 0; k < 18; k++) { const int a = (tid & 3) + 4 * k; acc += rv[k] * (a < P ? L.vw[a] : 0.0); }
+        acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 2);
+        if ((tid & 3) == 0) y[P + f] = (acc + L.Hdd[f] * L.vw[P + f]) * L.scale[P + f];
     }
     __syncthreads();
+    if (tid < P) {
+        double acc = 0;
+#pragma unroll
+        for (int w = 0; w < kBaW; w++) acc += L.part[w][tid];
+        for (int b = 0; b < P; b++) acc += L.Hpp[b * kBaP + tid] * L.vw[b];   // H_pp is symmetric: column walk, no bank conflicts
+        y[tid] = acc * L.scale[tid];
+    }
+    __syncthreads();
+    BA_TOCK(4)
+}
+
+__constant__ int kBaTileM[16] = { 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 3, 3, 4, -1 };
+__constant__ int kBaTileN[16] = { 0, 1, 2, 3, 4, 1, 2, 3, 4, 2, 3, 4, 3, 4, 4, -1 };
+
+__device__ __forceinline__ double readlane_d(double v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
 }
 
 // solve (Hs + mu diag(D2)) x = gs by Schur elimination of the depth columns; result in L.gn; returns success to all
-__device__ bool ba_schur_solve(const BaCtx &c, BaLds &L, const double *hpd, double mu)
+__device__ __noinline__ bool ba_schur_solve(const BaCtx c, BaLds &L, const double *hpd, double mu)
 {
-    const int tid = threadIdx.x, P = c.P, F = c.F;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, P = c.P, F = c.F;
+    const int col = lane & 15, kq = lane >> 4;
     __syncthreads();
-    for (int k = tid; k < P * P; k += 256) {
-        const int a = k / P, b = k % P;
-        L.S[a * kBaP + b] = L.Hpp[a * kBaP + b] * L.scale[a] * L.scale[b] + (a == b ? mu * L.D2[a] : 0.0);
-    }
-    for (int a = tid; a < P; a += 256) L.rhs[a] = L.gs[a];
+    BA_TICK(5)
+    for (int a = tid; a < kBaPS; a += kBaT) L.rhs[a] = a < P ? L.gs[a] : 0.0;
     if (tid == 0) L.ok = 1;
-    __syncthreads();
-    for (int f0 = 0; f0 < F; f0 += kBaTile) {
-        const int nf = min(kBaTile, F - f0);
-        // tile[a][t] = scaled coupling of camera parameter a with feature f0 + t
-        for (int k = tid; k < P * kBaTile; k += 256) {
-            const int a = k / kBaTile, t = k % kBaTile;
-            L.tile[k] = t < nf ? hpd[(size_t)a * kBaMaxFeat + f0 + t] * L.scale[a] * L.scale[P + f0 + t] : 0.0;
-        }
+    // upper 16x16 tiles of E diag(1 / h_ff) E^T: tiles 2 wave and 2 wave + 1
+    ba_d4 acc[2];
+    int tm[2], tn[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        acc[u] = ba_d4{ 0, 0, 0, 0 };
+        tm[u] = kBaTileM[2 * wave + u]; tn[u] = kBaTileN[2 * wave + u];
+    }
+    for (int f0 = 0; f0 < F; f0 += kBaFT) {
+        const int nf = min(kBaFT, F - f0);
         __syncthreads();
-        for (int k = tid; k < P * P; k += 256) {
-            const int a = k / P, b = k % P;
-            double acc = 0;
-            for (int t = 0; t < nf; t++) {
-                const double hff = L.Hdd[f0 + t] * L.scale[P + f0 + t] * L.scale[P + f0 + t] + mu * L.D2[P + f0 + t];
-                acc += L.tile[a * kBaTile + t] * L.tile[b * kBaTile + t] / hff;
+        {
+            // 64 x 80 coupling entries, 10 per thread, all requested before the first is used
+            double v[10];
+#pragma unroll
+            for (int qq = 0; qq < 10; qq++) {
+                const int k = tid + kBaT * qq, t = k / kBaPS, a = k - t * kBaPS;
+                v[qq] = (t < nf && a < P) ? gld(hpd + (size_t)(f0 + t) * kBaPS + a) : 0.0;
             }
-            L.S[a * kBaP + b] -= acc;
+#pragma unroll
+            for (int qq = 0; qq < 10; qq++) {
+                const int k = tid + kBaT * qq, t = k / kBaPS, a = k - t * kBaPS;
+                L.u.sch.et[k] = (t < nf && a < P) ? v[qq] * L.scale[a] * L.scale[P + f0 + t] : 0.0;
+            }
         }
-        for (int a = tid; a < P; a += 256) {
-            double acc = 0;
-            for (int t = 0; t < nf; t++) {
-                const double hff = L.Hdd[f0 + t] * L.scale[P + f0 + t] * L.scale[P + f0 + t] + mu * L.D2[P + f0 + t];
+        if (tid < kBaFT) {
+            double ic = 0.0, gi = 0.0;
+            if (tid < nf) {
+                const double s = L.scale[P + f0 + tid];
+                const double hff = L.Hdd[f0 + tid] * s * s + mu * L.D2[P + f0 + tid];
                 if (!(hff > 0.0)) L.ok = 0;
-                acc += L.tile[a * kBaTile + t] * L.gs[P + f0 + t] / hff;
+                ic = 1.0 / hff;
+                gi = L.gs[P + f0 + tid] * ic;
             }
-            L.rhs[a] -= acc;
+            L.u.sch.ic[tid] = ic; L.u.sch.gi[tid] = gi;
         }
         __syncthreads();
-    }
-    // in-place lower Cholesky of S (column by column), then forward / backward substitution, all in LDS
-    for (int j = 0; j < P; j++) {
-        if (tid == 0) {
-            double s = L.S[j * kBaP + j];
-            for (int k = 0; k < j; k++) s -= L.S[j * kBaP + k] * L.S[j * kBaP + k];
-            if (!(s > 0.0)) { L.ok = 0; s = 1.0; }
-            L.S[j * kBaP + j] = sqrt(s);
+        // right-hand side: thread (a, part) sums a quarter of the tile's features
+        if (tid < 4 * kBaPS) {
+            const int a = tid % kBaPS, part = tid / kBaPS;
+            double s = 0;
+#pragma unroll 4
+            for (int t = part * (kBaFT / 4); t < (part + 1) * (kBaFT / 4); t++) s += L.u.sch.et[t * kBaPS + a] * L.u.sch.gi[t];
+            L.part[part][a] = s;
+        }
+        const int nks = (nf + 3) >> 2;
+        for (int ks = 0; ks < nks; ks++) {
+            const int t = 4 * ks + kq;
+            const double *er = L.u.sch.et + t * kBaPS;
+            const double icv = L.u.sch.ic[t];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                if (tm[u] < 0) continue;
+                const double a = er[16 * tm[u] + col];
+                const double b = er[16 * tn[u] + col] * icv;
+                acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[u], 0, 0, 0);
+            }
         }
         __syncthreads();
-        for (int i = j + 1 + tid; i < P; i += 256) {
-            double s = L.S[i * kBaP + j];
-            for (int k = 0; k < j; k++) s -= L.S[i * kBaP + k] * L.S[j * kBaP + k];
-            L.S[i * kBaP + j] = s / L.S[j * kBaP + j];
+        if (tid < P) L.rhs[tid] -= ((L.part[0][tid] + L.part[1][tid]) + L.part[2][tid]) + L.part[3][tid];
+    }
+    __syncthreads();   // the staged tile is dead: S takes its place
+    double *S = L.u.S;
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        if (tm[u] < 0) continue;
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const int m = 16 * tm[u] + kq + 4 * v, n = 16 * tn[u] + col;
+            if (m < P && n < P) {
+                const double val = L.Hpp[m * kBaP + n] * L.scale[m] * L.scale[n] + (m == n ? mu * L.D2[m] : 0.0) - acc[u][v];
+                S[m * kBaSS + n] = val;
+                if (tm[u] != tn[u]) S[n * kBaSS + m] = val;
+            }
         }
-        __syncthreads();
     }
-    for (int k = 0; k < P; k++) {
-        if (tid == 0) L.rhs[k] = L.rhs[k] / L.S[k * kBaP + k];
-        __syncthreads();
-        for (int i = k + 1 + tid; i < P; i += 256) L.rhs[i] -= L.S[i * kBaP + k] * L.rhs[k];
-        __syncthreads();
-    }
-    for (int k = P - 1; k >= 0; k--) {
-        if (tid == 0) L.rhs[k] = L.rhs[k] / L.S[k * kBaP + k];
-        __syncthreads();
-        for (int i = tid; i < k; i += 256) L.rhs[i] -= L.S[k * kBaP + i] * L.rhs[k];
-        __syncthreads();
-    }
-    for (int a = tid; a < P; a += 256) { L.gn[a] = L.rhs[a]; if (!isfinite(L.rhs[a])) L.ok = 0; }
     __syncthreads();
-    for (int f = tid; f < F; f += 256) {
-        const double hff = L.Hdd[f] * L.scale[P + f] * L.scale[P + f] + mu * L.D2[P + f];
-        double acc = L.gs[P + f];
-        for (int a = 0; a < P; a++) acc -= hpd[(size_t)a * kBaMaxFeat + f] * L.scale[a] * L.scale[P + f] * L.gn[a];
-        const double x = acc / hff;
-        L.gn[P + f] = x;
-        if (!isfinite(x)) L.ok = 0;
+    // the right-hand side rides along as row P of the matrix: its factor entries are the forward substitution L y = b
+    if (tid < P) S[P * kBaSS + tid] = L.rhs[tid];
+    __syncthreads();
+    BA_TOCK(5)
+    BA_TICK(6)
+    // blocked in-place lower Cholesky: 8-column panels factored in the registers of wave 0 (lane = row, the pivot row
+    // broadcast with v_readlane), trailing update by all
+    for (int p0 = 0; p0 < P; p0 += 8) {
+        const int pw = min(8, P - p0);
+        if (wave == 0) {
+            const int i0 = p0 + lane, i1 = p0 + 64 + lane;      // rows of this lane (row P = right-hand side)
+            double a[8], b[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                a[k] = (i0 <= P && k < pw) ? S[i0 * kBaSS + p0 + k] : 0.0;
+                b[k] = (i1 <= P && k < pw) ? S[i1 * kBaSS + p0 + k] : 0.0;
+            }
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++) {
+                if (jj < pw) {
+                    double s0 = a[jj], s1 = b[jj];
+#pragma unroll
+                    for (int k = 0; k < jj; k++) {
+                        const double ljk = readlane_d(a[k], jj);
+                        s0 -= a[k] * ljk; s1 -= b[k] * ljk;
+                    }
+                    double d = readlane_d(s0, jj);
+                    if (!(d > 0.0)) { if (lane == 0) L.ok = 0; d = 1.0; }
+                    d = sqrt(d);
+                    a[jj] = lane == jj ? d : s0 / d;
+                    b[jj] = s1 / d;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (k < pw && i0 <= P && lane >= k) S[i0 * kBaSS + p0 + k] = a[k];
+                if (k < pw && i1 <= P) S[i1 * kBaSS + p0 + k] = b[k];
+            }
+        }
+        __syncthreads();
+        const int r0 = p0 + pw, n = P + 1 - r0;   // rows r0 .. P (n <= 65), columns r0 .. P - 1
+        for (int idx = tid; idx < 64 * n; idx += kBaT) {
+            const int i = idx >> 6, k = idx & 63;
+            if (k > i || r0 + k >= P) continue;
+            const double *ri = S + (r0 + i) * kBaSS + p0, *rk = S + (r0 + k) * kBaSS + p0;
+            double s = 0;
+            for (int qq = 0; qq < pw; qq++) s += ri[qq] * rk[qq];
+            S[(r0 + i) * kBaSS + r0 + k] -= s;
+        }
+        __syncthreads();
+    }
+    BA_TOCK(6)
+    BA_TICK(7)
+    // backward substitution L^T x = y by wave 0 (y = row P of the factor), rows lane and 64 + lane in registers
+    if (wave == 0) {
+        double y0 = lane < P ? S[P * kBaSS + lane] : 0.0, y1 = 64 + lane < P ? S[P * kBaSS + 64 + lane] : 0.0;
+        for (int k = P - 1; k >= 0; k--) {
+            const double lk0 = lane < k ? S[k * kBaSS + lane] : 0.0, lk1 = 64 + lane < k ? S[k * kBaSS + 64 + lane] : 0.0;
+            const double num = k < 64 ? readlane_d(y0, k) : readlane_d(y1, k - 64);
+            const double xk = num / S[k * kBaSS + k];
+            if (lane == (k & 63)) { if (k < 64) y0 = xk; else y1 = xk; }
+            y0 -= lk0 * xk; y1 -= lk1 * xk;
+        }
+        if (lane < P) { L.gn[lane] = y0; if (!isfinite(y0)) L.ok = 0; }
+        if (64 + lane < P) { L.gn[64 + lane] = y1; if (!isfinite(y1)) L.ok = 0; }
     }
     __syncthreads();
+    BA_TOCK(7)
+    BA_TICK(8)
+    for (int k = tid; k < P; k += kBaT) L.vw[k] = L.scale[k] * L.gn[k];
+    __syncthreads();
+    for (int f = tid >> 2; f < F; f += kBaT / 4) {
+        const double *row = hpd + (size_t)f * kBaPS;
+        double rv[18];
+#pragma unroll
+        for (int k = 0; k < 18; k++) { const int a = (tid & 3) + 4 * k; rv[k] = a < P ? gld(row + a) : 0.0; }
+        double acc = 0;
+#pragma unroll
+        for (int k = 0; k < 18; k++) { const int a = (tid & 3) + 4 * k; acc += rv[k] * (a < P ? L.vw[a] : 0.0); }
+        acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 2);
+        if ((tid & 3) == 0) {
+            const double s = L.scale[P + f];
+            const double hff = L.Hdd[f] * s * s + mu * L.D2[P + f];
+            const double x = (L.gs[P + f] - acc * s) / hff;
+            L.gn[P + f] = x;
+            if (!isfinite(x)) L.ok = 0;
+        }
+    }
+    __syncthreads();
+    BA_TOCK(8)
     return L.ok != 0;
 }
 
-__global__ __launch_bounds__(256) void k_ba_solve(BaBatch B)
+__global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     BaLds &L = *reinterpret_cast<BaLds *>(smem_raw);
@@ -291,12 +819,16 @@ __global__ __launch_bounds__(256) void k_ba_solve(BaBatch B)
     c.F = c.use_mono ? B.feat_off[w + 1] - c.f0 : 0;
     c.ex_off = c.ex_constant ? -1 : 0;
     c.P = 6 * c.n_poses + (c.ex_constant ? 0 : 6);
+    c.pp0 = B.pair_off[w]; c.n_pairs = c.use_mono ? B.pair_off[w + 1] - c.pp0 : 0;
+    c.ps0 = B.pobs_off[w]; c.n_slots = c.use_mono ? B.pobs_off[w + 1] - c.ps0 : 0;
     const int P = c.P, F = c.F, N = P + F;
     double *gposes = B.poses + (size_t)w * kBaMaxPoses * 7, *gex = B.ex + (size_t)w * 7, *ginvd = B.inv_depth + c.f0;
-    double *hpd = B.hpd + (size_t)w * kBaP * kBaMaxFeat;
+    double *hpd = B.hpd + (size_t)w * kBaMaxFeat * kBaPS;
+    double *pairdat = B.pairdat + (size_t)c.pp0 * kBaPairRec;
     double *cinvd = B.cand + (size_t)w * kBaMaxFeat;
-    for (int k = tid; k < c.n_poses * 7; k += 256) L.poses[k] = gposes[k];
+    for (int k = tid; k < c.n_poses * 7; k += kBaT) L.poses[k] = gposes[k];
     if (tid < 7) L.ex[tid] = gex[tid];
+    for (int k = tid; k < c.n_pairs; k += kBaT) L.pair_ij[k] = B.pair_ij[c.pp0 + k];
     __syncthreads();
 
     const double function_tol = 1e-6, gradient_tol = 1e-10, parameter_tol = 1e-8, min_rel_decrease = 1e-3;
@@ -306,82 +838,90 @@ __global__ __launch_bounds__(256) void k_ba_solve(BaBatch B)
     bool reuse = false;
     int invalid = 0, iter = 0, termination = 1, n_succ = 0, n_unsucc = 0;
 
-    double x_cost = ba_evaluate<true>(B, c, L, L.poses, L.ex, ginvd, hpd);
-    const double initial_cost = x_cost;
-    auto global_norm = [&](const double *poses, const double *ex, const double *invd) {
-        double q = 0;
-        if (c.ex_off >= 0 && tid < 7) q += ex[tid] * ex[tid];
-        for (int k = tid; k < 7 * c.n_poses; k += 256) q += poses[k] * poses[k];
-        for (int f = tid; f < F; f += 256) q += invd[f] * invd[f];
-        return sqrt(block_sum(q, L.red));
-    };
-    double x_norm = global_norm(L.poses, L.ex, ginvd);
-    for (int a = tid; a < P; a += 256) L.scale[a] = 1.0 / (1.0 + sqrt(L.Hpp[a * kBaP + a]));
-    for (int f = tid; f < F; f += 256) L.scale[P + f] = 1.0 / (1.0 + sqrt(L.Hdd[f]));
-    auto grad_max = [&]() {
-        double g = 0;
-        for (int a = tid; a < P; a += 256) g = fmax(g, fabs(L.gp[a]));
-        for (int f = tid; f < F; f += 256) g = fmax(g, fabs(L.gdd[f]));
-        return block_max(g, L.red);
-    };
-    double gmax = grad_max();
-    if (gmax <= gradient_tol) termination = 0;
-    else while (iter < B.max_iter) {
+    double x_cost = 0.0, initial_cost = 0.0, x_norm = 0.0;
+    bool linearise = true, first = true;
+    BA_TICK(9)
+    // one call site per phase (the phases are inlined: LDS addressing, no register-file round trips through a call)
+    for (;;) {
+        if (linearise) {
+            x_cost = ba_evaluate<true>(B, c, L, L.poses, L.ex, ginvd, hpd, pairdat);
+            double q = 0, g = 0;
+            if (c.ex_off >= 0 && tid < 7) q += L.ex[tid] * L.ex[tid];
+            for (int k = tid; k < 7 * c.n_poses; k += kBaT) q += L.poses[k] * L.poses[k];
+            for (int f = tid; f < F; f += kBaT) { q += L.vinv[f] * L.vinv[f]; g = fmax(g, fabs(L.gdd[f])); }
+            for (int a = tid; a < P; a += kBaT) g = fmax(g, fabs(L.gp[a]));
+            x_norm = sqrt(block_sum(q, L.red));
+            const double gmax = block_max(g, L.red);
+            if (first) {
+                initial_cost = x_cost;
+                // Jacobi scaling from the first linearisation (ceres jacobi_scaling)
+                for (int a = tid; a < P; a += kBaT) L.scale[a] = 1.0 / (1.0 + sqrt(L.Hpp[a * kBaP + a]));
+                for (int f = tid; f < F; f += kBaT) L.scale[P + f] = 1.0 / (1.0 + sqrt(L.Hdd[f]));
+                first = false;
+            }
+            linearise = false; reuse = false;
+            if (gmax <= gradient_tol) { termination = 0; break; }
+        }
+        if (radius <= min_radius) { termination = 0; break; }
+        if (iter >= B.max_iter) break;
         iter++;
         bool ok = true;
-        if (!reuse) {
-            __syncthreads();
-            for (int k = tid; k < N; k += 256) {
-                const double h = k < P ? L.Hpp[k * kBaP + k] : L.Hdd[k - P];
-                const double g = k < P ? L.gp[k] : L.gdd[k - P];
-                L.gs[k] = g * L.scale[k];
-                double d = h * L.scale[k] * L.scale[k];
-                d = d < min_diag ? min_diag : (d > max_diag ? max_diag : d);
-                L.D2[k] = d; L.D[k] = sqrt(d);
-                L.gdv[k] = L.gs[k] / L.D[k];
-                L.tmp[k] = L.gdv[k] / L.D[k];
-            }
-            ba_hs_mul(c, L, hpd, L.tmp, L.tmp2);
-            double g2 = 0, jg2 = 0;
-            for (int k = tid; k < N; k += 256) { g2 += L.gdv[k] * L.gdv[k]; jg2 += L.tmp[k] * L.tmp2[k]; }
-            g2 = block_sum(g2, L.red); jg2 = block_sum(jg2, L.red);
-            alpha = g2 / jg2;
-            ok = false;
-            while (mu < max_mu) {
-                if (ba_schur_solve(c, L, hpd, mu)) { ok = true; break; }
-                mu *= mu_inc;
-            }
-            if (ok) {
-                mu = fmax(min_mu, 2.0 * mu / mu_inc);
-                for (int k = tid; k < N; k += 256) L.gn[k] *= -L.D[k];
-            }
-            __syncthreads();
-        }
         double model_change = 0.0;
-        if (ok) {
-            double a2 = 0, b2 = 0, ab = 0;
-            for (int k = tid; k < N; k += 256) { a2 += L.gn[k] * L.gn[k]; b2 += L.gdv[k] * L.gdv[k]; ab += L.gdv[k] * L.gn[k]; }
-            const double gn_norm = sqrt(block_sum(a2, L.red)), g_norm = sqrt(block_sum(b2, L.red));
-            ab = block_sum(ab, L.red);
-            double ca, cb;   // step = ca * gdv + cb * gn
-            if (gn_norm <= radius) { ca = 0.0; cb = 1.0; dogleg_norm = gn_norm; }
-            else if (alpha * g_norm >= radius) { ca = -(radius / g_norm); cb = 0.0; dogleg_norm = radius; }
-            else {
-                const double b_dot_a = -alpha * ab;
-                const double aa = alpha * alpha * g_norm * g_norm;
-                const double bma2 = aa - 2 * b_dot_a + gn_norm * gn_norm;
-                const double cc = b_dot_a - aa;
-                const double d = sqrt(cc * cc + bma2 * (radius * radius - aa));
-                const double beta = (cc <= 0) ? (d - cc) / bma2 : (radius * radius - aa) / (d + cc);
-                ca = -alpha * (1.0 - beta); cb = beta; dogleg_norm = radius;
-            }
+        for (int pass = reuse ? 1 : 0; pass < 2; pass++) {
             __syncthreads();
-            for (int k = tid; k < N; k += 256) L.step[k] = (ca * L.gdv[k] + cb * L.gn[k]) / L.D[k];
-            ba_hs_mul(c, L, hpd, L.step, L.tmp);
-            double dg = 0, dHd = 0;
-            for (int k = tid; k < N; k += 256) { dg += L.step[k] * L.gs[k]; dHd += L.step[k] * L.tmp[k]; }
-            dg = block_sum(dg, L.red); dHd = block_sum(dHd, L.red);
-            model_change = -(dg + 0.5 * dHd);
+            if (pass == 0) {
+                for (int k = tid; k < N; k += kBaT) {
+                    const double h = k < P ? L.Hpp[k * kBaP + k] : L.Hdd[k - P];
+                    const double g = k < P ? L.gp[k] : L.gdd[k - P];
+                    L.gs[k] = g * L.scale[k];
+                    double d = h * L.scale[k] * L.scale[k];
+                    d = d < min_diag ? min_diag : (d > max_diag ? max_diag : d);
+                    L.D2[k] = d; L.D[k] = sqrt(d);
+                    L.gdv[k] = L.gs[k] / L.D[k];
+                    L.va[k] = L.gdv[k] / L.D[k];
+                }
+            } else {
+                if (!ok) break;
+                double a2 = 0, b2 = 0, ab = 0;
+                for (int k = tid; k < N; k += kBaT) { a2 += L.gn[k] * L.gn[k]; b2 += L.gdv[k] * L.gdv[k]; ab += L.gdv[k] * L.gn[k]; }
+                block_sum3(a2, b2, ab, L.red);
+                const double gn_norm = sqrt(a2), g_norm = sqrt(b2);
+                double ca, cb;   // step = ca * gdv + cb * gn
+                if (gn_norm <= radius) { ca = 0.0; cb = 1.0; dogleg_norm = gn_norm; }
+                else if (alpha * g_norm >= radius) { ca = -(radius / g_norm); cb = 0.0; dogleg_norm = radius; }
+                else {
+                    const double b_dot_a = -alpha * ab;
+                    const double aa = alpha * alpha * g_norm * g_norm;
+                    const double bma2 = aa - 2 * b_dot_a + gn_norm * gn_norm;
+                    const double cc = b_dot_a - aa;
+                    const double d = sqrt(cc * cc + bma2 * (radius * radius - aa));
+                    const double beta = (cc <= 0) ? (d - cc) / bma2 : (radius * radius - aa) / (d + cc);
+                    ca = -alpha * (1.0 - beta); cb = beta; dogleg_norm = radius;
+                }
+                __syncthreads();
+                for (int k = tid; k < N; k += kBaT) L.va[k] = (ca * L.gdv[k] + cb * L.gn[k]) / L.D[k];   // the step
+            }
+            ba_hs_mul(c, L, hpd, L.va, L.vb);
+            if (pass == 0) {
+                double g2 = 0, jg2 = 0, zero = 0;
+                for (int k = tid; k < N; k += kBaT) { g2 += L.gdv[k] * L.gdv[k]; jg2 += L.va[k] * L.vb[k]; }
+                block_sum3(g2, jg2, zero, L.red);
+                alpha = g2 / jg2;
+                ok = false;
+                while (mu < max_mu) {
+                    if (ba_schur_solve(c, L, hpd, mu)) { ok = true; break; }
+                    mu *= mu_inc;
+                }
+                if (ok) {
+                    mu = fmax(min_mu, 2.0 * mu / mu_inc);
+                    for (int k = tid; k < N; k += kBaT) L.gn[k] *= -L.D[k];
+                }
+            } else {
+                double dg = 0, dHd = 0, zero = 0;
+                for (int k = tid; k < N; k += kBaT) { dg += L.va[k] * L.gs[k]; dHd += L.va[k] * L.vb[k]; }
+                block_sum3(dg, dHd, zero, L.red);
+                model_change = -(dg + 0.5 * dHd);
+            }
         }
         if (!ok || !(model_change > 0.0)) {
             if (++invalid >= 5) { termination = 2; break; }
@@ -396,46 +936,45 @@ __global__ __launch_bounds__(256) void k_ba_solve(BaBatch B)
             if (!is_ex || c.ex_off >= 0) {
                 const int off = is_ex ? c.ex_off : ba_pose_off(c, tid);
                 double d6[6];
-                for (int a = 0; a < 6; a++) d6[a] = L.step[off + a] * L.scale[off + a];
+                for (int a = 0; a < 6; a++) d6[a] = L.va[off + a] * L.scale[off + a];
                 ba::pose_plus(is_ex ? L.ex : L.poses + 7 * tid, d6, is_ex ? L.cex : L.cposes + 7 * tid);
             } else {
                 for (int k = 0; k < 7; k++) L.cex[k] = L.ex[k];
             }
         }
-        for (int f = tid; f < F; f += 256) cinvd[f] = ginvd[f] + L.step[P + f] * L.scale[P + f];
+        for (int f = tid; f < F; f += kBaT) cinvd[f] = ginvd[f] + L.va[P + f] * L.scale[P + f];
         __syncthreads();
-        const double cand_cost = ba_evaluate<false>(B, c, L, L.cposes, L.cex, cinvd, hpd);
+        const double cand_cost = ba_evaluate<false>(B, c, L, L.cposes, L.cex, cinvd, hpd, pairdat);
         double dq = 0;
         if (c.ex_off >= 0 && tid < 7) dq += (L.ex[tid] - L.cex[tid]) * (L.ex[tid] - L.cex[tid]);
-        for (int k = tid; k < 7 * c.n_poses; k += 256) dq += (L.poses[k] - L.cposes[k]) * (L.poses[k] - L.cposes[k]);
-        for (int f = tid; f < F; f += 256) dq += (ginvd[f] - cinvd[f]) * (ginvd[f] - cinvd[f]);
+        for (int k = tid; k < 7 * c.n_poses; k += kBaT) dq += (L.poses[k] - L.cposes[k]) * (L.poses[k] - L.cposes[k]);
+        for (int f = tid; f < F; f += kBaT) dq += (ginvd[f] - cinvd[f]) * (ginvd[f] - cinvd[f]);
         const double sn = sqrt(block_sum(dq, L.red));
         if (sn <= parameter_tol * (x_norm + parameter_tol)) { termination = 0; break; }
         if (fabs(x_cost - cand_cost) <= function_tol * x_cost) { termination = 0; break; }
         const double rel = (x_cost - cand_cost) / model_change;
         if (rel > min_rel_decrease) {
             __syncthreads();
-            for (int k = tid; k < 7 * c.n_poses; k += 256) L.poses[k] = L.cposes[k];
+            for (int k = tid; k < 7 * c.n_poses; k += kBaT) L.poses[k] = L.cposes[k];
             if (tid < 7) L.ex[tid] = L.cex[tid];
-            for (int f = tid; f < F; f += 256) ginvd[f] = cinvd[f];
+            for (int f = tid; f < F; f += kBaT) ginvd[f] = cinvd[f];
             __syncthreads();
-            x_norm = global_norm(L.poses, L.ex, ginvd);
-            x_cost = ba_evaluate<true>(B, c, L, L.poses, L.ex, ginvd, hpd);
             n_succ++;
             if (rel < 0.25) radius *= 0.5;
             if (rel > 0.75) radius = fmax(radius, 3.0 * dogleg_norm);
             if (radius > max_radius) radius = max_radius;
-            reuse = false;
-            gmax = grad_max();
-            if (gmax <= gradient_tol) { termination = 0; break; }
+            linearise = true;
         } else {
             radius *= 0.5; reuse = true;
             n_unsucc++;
         }
-        if (radius <= min_radius) { termination = 0; break; }
     }
     __syncthreads();
-    for (int k = tid; k < c.n_poses * 7; k += 256) gposes[k] = L.poses[k];
+    BA_TOCK(9)
+#ifdef LMONO_BA_PROF
+    if (w == 0 && tid == 0) printf("PROF total %lld | lin: prologue %lld eval %lld mfma %lld | cost %lld | hs %lld | schur: stage+mfma %lld chol %lld subst %lld depth %lld | iters %d\n", g_prof[9], g_prof[0], g_prof[1], g_prof[2], g_prof[3], g_prof[4], g_prof[5], g_prof[6], g_prof[7], g_prof[8], iter);
+#endif
+    for (int k = tid; k < c.n_poses * 7; k += kBaT) gposes[k] = L.poses[k];
     if (tid < 7) gex[tid] = L.ex[tid];
     if (tid == 0) {
         double *sm = B.summary + (size_t)w * 6;
@@ -444,3 +983,5 @@ __global__ __launch_bounds__(256) void k_ba_solve(BaBatch B)
 }
 
 } // namespace lmono
+
+#pragma clang fp contract(off)

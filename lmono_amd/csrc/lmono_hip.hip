@@ -481,6 +481,7 @@ static bool ba_upload(lmono_ba_batch *b, T *&dst, const T *src, size_t count)
     b->allocs.push_back(q);
     dst = (T *)q;
     if (src && count > 0 && hipMemcpy(q, src, count * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return false;
+    if (!src && hipMemset(q, 0, (count > 0 ? count : 1) * sizeof(T)) != hipSuccess) return false;   // scratch starts zeroed
     return true;
 }
 
@@ -520,28 +521,56 @@ extern "C" lmono_ba_batch *lmono_ba_batch_create(lmono_ctx *c, const lmono_ba_de
         }
         fo[TF] = TO;
     }
+    // frame pairs of every window and the pair-ordered (padded to even length per pair) observation list
+    std::vector<int> pair_off((size_t)W + 1, 0), pair_ij, pobs_off((size_t)W + 1, 0), slot_info, anchor((size_t)TF, -1);
+    std::vector<double> slot_pts;
+    for (int w = 0; w < W; w++) {
+        pair_off[w] = (int)pair_ij.size(); pobs_off[w] = (int)slot_info.size();
+        const int f0 = d->feat_off[w], f1 = d->feat_off[w + 1];
+        for (int f = f0; f < f1; f++) if (fo[f + 1] > fo[f]) anchor[f] = d->obs_i[fo[f]];
+        if (!d->flags[4 * w + 3]) continue;   // use_mono == 0: the projection factors are not part of the problem
+        std::vector<std::vector<int>> by_pair((size_t)kBaMaxPoses * kBaMaxPoses);
+        for (int o = d->obs_off[w]; o < d->obs_off[w + 1]; o++) by_pair[(size_t)d->obs_i[o] * kBaMaxPoses + d->obs_j[o]].push_back(o);
+        int local = 0;
+        for (int key = 0; key < kBaMaxPoses * kBaMaxPoses; key++) {
+            const std::vector<int> &v = by_pair[(size_t)key];
+            if (v.empty()) continue;
+            pair_ij.push_back((key / kBaMaxPoses) | ((key % kBaMaxPoses) << 8));
+            for (int o : v) {
+                slot_info.push_back(d->obs_feat[o] | (local << 16));
+                for (int k = 0; k < 4; k++) slot_pts.push_back(d->obs_pts[(size_t)o * 4 + k]);
+            }
+            if (v.size() & 1) { slot_info.push_back(0xffff | (local << 16)); for (int k = 0; k < 4; k++) slot_pts.push_back(0.0); }
+            local++;
+        }
+    }
+    pair_off[W] = (int)pair_ij.size(); pobs_off[W] = (int)slot_info.size();
     lmono_ba_batch *b = new lmono_ba_batch();
     b->ctx = c; b->n_windows = W; b->total_feat = TF; b->total_obs = TO;
     BaBatch &v = b->v;
     v.n_windows = W; v.max_iter = 30;
     double info[42];
     memcpy(info, d->laser_info, 36 * sizeof(double)); memcpy(info + 36, d->mono_info, 4 * sizeof(double)); memcpy(info + 40, d->prior_w, 2 * sizeof(double));
-    int *feat_off = nullptr, *obs_off = nullptr, *flags = nullptr, *obs_feat = nullptr, *obs_i = nullptr, *obs_j = nullptr, *fobs = nullptr;
-    double *obs_pts = nullptr, *laser = nullptr, *prior = nullptr, *infod = nullptr;
+    int *feat_off = nullptr, *obs_off = nullptr, *flags = nullptr, *anch = nullptr, *poff = nullptr, *pij = nullptr, *psoff = nullptr, *sinfo_d = nullptr;
+    double *spts_d = nullptr, *laser = nullptr, *prior = nullptr, *infod = nullptr;
     bool ok = ba_upload(b, feat_off, d->feat_off, (size_t)W + 1) && ba_upload(b, obs_off, d->obs_off, (size_t)W + 1) &&
               ba_upload(b, flags, d->flags, (size_t)W * 4) && ba_upload(b, v.poses, d->poses, (size_t)W * kBaMaxPoses * 7) &&
               ba_upload(b, v.ex, d->ex, (size_t)W * 7) && ba_upload(b, v.inv_depth, d->inv_depth, (size_t)TF) &&
-              ba_upload(b, obs_feat, d->obs_feat, (size_t)TO) && ba_upload(b, obs_i, d->obs_i, (size_t)TO) && ba_upload(b, obs_j, d->obs_j, (size_t)TO) &&
-              ba_upload(b, obs_pts, d->obs_pts, (size_t)TO * 4) && ba_upload(b, fobs, fo.data(), (size_t)TF + 1) &&
+              ba_upload(b, anch, anchor.data(), (size_t)TF) &&
+              ba_upload(b, poff, pair_off.data(), (size_t)W + 1) && ba_upload(b, pij, pair_ij.data(), pair_ij.size()) &&
+              ba_upload(b, psoff, pobs_off.data(), (size_t)W + 1) && ba_upload(b, sinfo_d, slot_info.data(), slot_info.size()) &&
+              ba_upload(b, spts_d, slot_pts.data(), slot_pts.size()) &&
               ba_upload(b, laser, d->laser_consts, (size_t)W * 10 * 24) && ba_upload(b, prior, d->prior_T, (size_t)W * 16) &&
               ba_upload(b, infod, info, (size_t)42) &&
               ba_upload(b, b->poses0, d->poses, (size_t)W * kBaMaxPoses * 7) && ba_upload(b, b->ex0, d->ex, (size_t)W * 7) &&
               ba_upload(b, b->invd0, d->inv_depth, (size_t)TF) &&
-              ba_upload(b, v.hpd, (const double *)nullptr, (size_t)W * kBaP * kBaMaxFeat) &&
+              ba_upload(b, v.hpd, (const double *)nullptr, (size_t)W * kBaMaxFeat * kBaPS) &&
+              ba_upload(b, v.pairdat, (const double *)nullptr, pair_ij.size() * kBaPairRec) &&
               ba_upload(b, v.cand, (const double *)nullptr, (size_t)W * kBaMaxFeat) && ba_upload(b, v.summary, (const double *)nullptr, (size_t)W * 6);
     if (!ok) { c->err = "lmono_ba_batch_create: device allocation / upload failed"; lmono_ba_batch_destroy(b); return nullptr; }
-    v.feat_off = feat_off; v.obs_off = obs_off; v.flags = flags; v.obs_feat = obs_feat; v.obs_i = obs_i; v.obs_j = obs_j;
-    v.obs_pts = obs_pts; v.feat_obs_off = fobs; v.laser_consts = laser; v.prior_T = prior; v.info = infod;
+    v.feat_off = feat_off; v.obs_off = obs_off; v.flags = flags; v.feat_anchor = anch;
+    v.pair_off = poff; v.pair_ij = pij; v.pobs_off = psoff; v.slot_info = sinfo_d; v.slot_pts = spts_d;
+    v.laser_consts = laser; v.prior_T = prior; v.info = infod;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)k_ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BaLds)) != hipSuccess) {
@@ -557,7 +586,7 @@ extern "C" int lmono_ba_solve(lmono_ctx *c, lmono_ba_batch *b, int max_iteration
     if (!c || !b || max_iterations < 0) return LMONO_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
     b->v.max_iter = max_iterations;
-    hipLaunchKernelGGL(k_ba_solve, dim3(b->n_windows), dim3(256), sizeof(BaLds), c->stream, b->v);
+    hipLaunchKernelGGL(k_ba_solve, dim3(b->n_windows), dim3(kBaT), sizeof(BaLds), c->stream, b->v);
     return check_launch(c, "k_ba_solve");
 }
 

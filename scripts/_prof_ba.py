@@ -1,0 +1,9 @@
+import sys, numpy as np
+sys.path.insert(0, '.')
+import lmono_amd
+from tests import ba_cases as K
+ctx = lmono_amd.Context(0)
+base = [K.make_window(s) for s in range(16)]
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+b = lmono_amd.BaBatch(ctx, [base[k % 16] for k in range(n)])
+b.solve(30); ctx.synchronize()
