@@ -68,13 +68,14 @@ struct BaBatch {
 };
 
 struct BaSchurStage { double et[kBaFT * kBaPS]; double ic[kBaFT]; double gi[kBaFT]; };
+struct BaFactor { double S[(kBaP + 1) * kBaSS]; double idiag[kBaP]; };   // reduced system / its Cholesky factor (row P = right-hand side), 1 / diagonal
 
 struct BaLds {
     double Hpp[kBaP * kBaP];
     union {
         double stage[kBaChunk * 2 * kBaRow];     // evaluate: staged Jacobian rows
         BaSchurStage sch;                         // Schur: scaled coupling tile, 1 / h_ff
-        double S[(kBaP + 1) * kBaSS];             // reduced system / its Cholesky factor; row P = right-hand side
+        BaFactor fac;
     } u;
     double Hdd[kBaMaxFeat], gdd[kBaMaxFeat];
     double gp[kBaP];
@@ -699,7 +700,7 @@ __device__ __noinline__ bool ba_schur_solve(const BaCtx c, BaLds &L, const doubl
         if (tid < P) L.rhs[tid] -= ((L.part[0][tid] + L.part[1][tid]) + L.part[2][tid]) + L.part[3][tid];
     }
     __syncthreads();   // the staged tile is dead: S takes its place
-    double *S = L.u.S;
+    double *S = L.u.fac.S;
 #pragma unroll
     for (int u = 0; u < 2; u++) {
         if (tm[u] < 0) continue;
@@ -742,9 +743,10 @@ __device__ __noinline__ bool ba_schur_solve(const BaCtx c, BaLds &L, const doubl
                     }
                     double d = readlane_d(s0, jj);
                     if (!(d > 0.0)) { if (lane == 0) L.ok = 0; d = 1.0; }
-                    d = sqrt(d);
-                    a[jj] = lane == jj ? d : s0 / d;
-                    b[jj] = s1 / d;
+                    const double id_ = rsqrt(d);
+                    if (lane == jj) L.u.fac.idiag[p0 + jj] = id_;
+                    a[jj] = lane == jj ? d * id_ : s0 * id_;
+                    b[jj] = s1 * id_;
                 }
             }
 #pragma unroll
@@ -773,7 +775,7 @@ __device__ __noinline__ bool ba_schur_solve(const BaCtx c, BaLds &L, const doubl
         for (int k = P - 1; k >= 0; k--) {
             const double lk0 = lane < k ? S[k * kBaSS + lane] : 0.0, lk1 = 64 + lane < k ? S[k * kBaSS + 64 + lane] : 0.0;
             const double num = k < 64 ? readlane_d(y0, k) : readlane_d(y1, k - 64);
-            const double xk = num / S[k * kBaSS + k];
+            const double xk = num * L.u.fac.idiag[k];
             if (lane == (k & 63)) { if (k < 64) y0 = xk; else y1 = xk; }
             y0 -= lk0 * xk; y1 -= lk1 * xk;
         }
@@ -834,7 +836,7 @@ __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B)
     const double function_tol = 1e-6, gradient_tol = 1e-10, parameter_tol = 1e-8, min_rel_decrease = 1e-3;
     const double min_diag = 1e-6, max_diag = 1e32, max_radius = 1e16, min_radius = 1e-32;
     const double min_mu = 1e-8, max_mu = 1.0, mu_inc = 10.0;
-    double radius = 1e4, mu = min_mu, alpha = 0.0, dogleg_norm = 0.0;
+    double radius = 1e4, mu = min_mu, mu_used = min_mu, alpha = 0.0, dogleg_norm = 0.0;
     bool reuse = false;
     int invalid = 0, iter = 0, termination = 1, n_succ = 0, n_unsucc = 0;
 
@@ -867,61 +869,63 @@ __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B)
         iter++;
         bool ok = true;
         double model_change = 0.0;
-        for (int pass = reuse ? 1 : 0; pass < 2; pass++) {
+        if (!reuse) {
             __syncthreads();
-            if (pass == 0) {
-                for (int k = tid; k < N; k += kBaT) {
-                    const double h = k < P ? L.Hpp[k * kBaP + k] : L.Hdd[k - P];
-                    const double g = k < P ? L.gp[k] : L.gdd[k - P];
-                    L.gs[k] = g * L.scale[k];
-                    double d = h * L.scale[k] * L.scale[k];
-                    d = d < min_diag ? min_diag : (d > max_diag ? max_diag : d);
-                    L.D2[k] = d; L.D[k] = sqrt(d);
-                    L.gdv[k] = L.gs[k] / L.D[k];
-                    L.va[k] = L.gdv[k] / L.D[k];
-                }
-            } else {
-                if (!ok) break;
-                double a2 = 0, b2 = 0, ab = 0;
-                for (int k = tid; k < N; k += kBaT) { a2 += L.gn[k] * L.gn[k]; b2 += L.gdv[k] * L.gdv[k]; ab += L.gdv[k] * L.gn[k]; }
-                block_sum3(a2, b2, ab, L.red);
-                const double gn_norm = sqrt(a2), g_norm = sqrt(b2);
-                double ca, cb;   // step = ca * gdv + cb * gn
-                if (gn_norm <= radius) { ca = 0.0; cb = 1.0; dogleg_norm = gn_norm; }
-                else if (alpha * g_norm >= radius) { ca = -(radius / g_norm); cb = 0.0; dogleg_norm = radius; }
-                else {
-                    const double b_dot_a = -alpha * ab;
-                    const double aa = alpha * alpha * g_norm * g_norm;
-                    const double bma2 = aa - 2 * b_dot_a + gn_norm * gn_norm;
-                    const double cc = b_dot_a - aa;
-                    const double d = sqrt(cc * cc + bma2 * (radius * radius - aa));
-                    const double beta = (cc <= 0) ? (d - cc) / bma2 : (radius * radius - aa) / (d + cc);
-                    ca = -alpha * (1.0 - beta); cb = beta; dogleg_norm = radius;
-                }
-                __syncthreads();
-                for (int k = tid; k < N; k += kBaT) L.va[k] = (ca * L.gdv[k] + cb * L.gn[k]) / L.D[k];   // the step
+            for (int k = tid; k < N; k += kBaT) {
+                const double h = k < P ? L.Hpp[k * kBaP + k] : L.Hdd[k - P];
+                const double g = k < P ? L.gp[k] : L.gdd[k - P];
+                L.gs[k] = g * L.scale[k];
+                double d = h * L.scale[k] * L.scale[k];
+                d = d < min_diag ? min_diag : (d > max_diag ? max_diag : d);
+                L.D2[k] = d; L.D[k] = sqrt(d);
+                L.gdv[k] = L.gs[k] / L.D[k];
+                L.va[k] = L.gdv[k] / L.D[k];
             }
-            ba_hs_mul(c, L, hpd, L.va, L.vb);
-            if (pass == 0) {
-                double g2 = 0, jg2 = 0, zero = 0;
-                for (int k = tid; k < N; k += kBaT) { g2 += L.gdv[k] * L.gdv[k]; jg2 += L.va[k] * L.vb[k]; }
-                block_sum3(g2, jg2, zero, L.red);
-                alpha = g2 / jg2;
-                ok = false;
-                while (mu < max_mu) {
-                    if (ba_schur_solve(c, L, hpd, mu)) { ok = true; break; }
-                    mu *= mu_inc;
-                }
-                if (ok) {
-                    mu = fmax(min_mu, 2.0 * mu / mu_inc);
-                    for (int k = tid; k < N; k += kBaT) L.gn[k] *= -L.D[k];
-                }
-            } else {
-                double dg = 0, dHd = 0, zero = 0;
-                for (int k = tid; k < N; k += kBaT) { dg += L.va[k] * L.gs[k]; dHd += L.va[k] * L.vb[k]; }
-                block_sum3(dg, dHd, zero, L.red);
-                model_change = -(dg + 0.5 * dHd);
+            ba_hs_mul(c, L, hpd, L.va, L.vb);      // vb = Hs (gs / D^2): kept until the next linearisation
+            double g2 = 0, jg2 = 0, zero = 0;
+            for (int k = tid; k < N; k += kBaT) { g2 += L.gdv[k] * L.gdv[k]; jg2 += L.va[k] * L.vb[k]; }
+            block_sum3(g2, jg2, zero, L.red);
+            alpha = g2 / jg2;
+            ok = false;
+            while (mu < max_mu) {
+                if (ba_schur_solve(c, L, hpd, mu)) { ok = true; break; }
+                mu *= mu_inc;
             }
+            if (ok) {
+                mu_used = mu;
+                mu = fmax(min_mu, 2.0 * mu / mu_inc);
+                for (int k = tid; k < N; k += kBaT) L.gn[k] *= -L.D[k];
+            }
+            __syncthreads();
+        }
+        if (ok) {
+            double a2 = 0, b2 = 0, ab = 0;
+            for (int k = tid; k < N; k += kBaT) { a2 += L.gn[k] * L.gn[k]; b2 += L.gdv[k] * L.gdv[k]; ab += L.gdv[k] * L.gn[k]; }
+            block_sum3(a2, b2, ab, L.red);
+            const double gn_norm = sqrt(a2), g_norm = sqrt(b2);
+            double ca, cb;   // step = ca * gdv + cb * gn
+            if (gn_norm <= radius) { ca = 0.0; cb = 1.0; dogleg_norm = gn_norm; }
+            else if (alpha * g_norm >= radius) { ca = -(radius / g_norm); cb = 0.0; dogleg_norm = radius; }
+            else {
+                const double b_dot_a = -alpha * ab;
+                const double aa = alpha * alpha * g_norm * g_norm;
+                const double bma2 = aa - 2 * b_dot_a + gn_norm * gn_norm;
+                const double cc = b_dot_a - aa;
+                const double d = sqrt(cc * cc + bma2 * (radius * radius - aa));
+                const double beta = (cc <= 0) ? (d - cc) / bma2 : (radius * radius - aa) / (d + cc);
+                ca = -alpha * (1.0 - beta); cb = beta; dogleg_norm = radius;
+            }
+            // step = ca gs / D^2 - cb x with (Hs + mu D2) x = gs (x = -gn / D), hence
+            // Hs step = ca vb - cb (gs + mu D2 gn / D): the model decrease needs no second product with Hs
+            double dg = 0, dHd = 0, zero = 0;
+            for (int k = tid; k < N; k += kBaT) {
+                const double st = (ca * L.gdv[k] + cb * L.gn[k]) / L.D[k];
+                const double hs = ca * L.vb[k] - cb * (L.gs[k] + mu_used * L.D2[k] * L.gn[k] / L.D[k]);
+                L.va[k] = st;
+                dg += st * L.gs[k]; dHd += st * hs;
+            }
+            block_sum3(dg, dHd, zero, L.red);
+            model_change = -(dg + 0.5 * dHd);
         }
         if (!ok || !(model_change > 0.0)) {
             if (++invalid >= 5) { termination = 2; break; }
