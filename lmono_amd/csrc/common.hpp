@@ -147,7 +147,7 @@ __device__ __forceinline__ unsigned long long pack_fu(float f, unsigned int payl
 // in-LDS bitonic sort of n (power of two) 64-bit keys by the 4 waves of a 256-thread block.  Each wave owns a
 // contiguous quarter of the array; compare-exchange stages whose partner distance j stays inside a quarter need no
 // workgroup barrier (LDS operations of one wave execute in order), only the few stages with j >= n/4 do.
-__device__ __forceinline__ void bitonic_sort_u64(unsigned long long *keys, int n)
+__device__ __forceinline__ void bitonic_sort_u64_lds(unsigned long long *keys, int n)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int P = n >= 8 ? n / 4 : n;            // elements per wave (tiny arrays: wave 0 alone)
@@ -177,6 +177,74 @@ __device__ __forceinline__ void bitonic_sort_u64(unsigned long long *keys, int n
         }
     }
     __syncthreads();
+}
+
+// Register-resident variant for n = 256 R keys (R = 1, 2, 4, 8): every wave keeps its quarter of the array in registers
+// (lane l holds elements base + 64 r + l).  Of the log2(n) (log2(n) + 1) / 2 compare-exchange stages only three have a
+// partner in another wave (through LDS, with barriers); partner distances 64..n/8 are register swaps inside a lane and
+// distances < 64 are lane exchanges (ds_bpermute) -- no LDS addressing, no bank conflicts, no barriers.
+template <int R>
+__device__ __forceinline__ void bitonic_sort_u64_reg(unsigned long long *keys)
+{
+    constexpr int P = 64 * R, n = 4 * P;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, base = wave * P;
+    unsigned long long v[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) v[r] = keys[base + 64 * r + lane];
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= P) {
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < R; r++) keys[base + 64 * r + lane] = v[r];
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int i = base + 64 * r + lane;
+                    const unsigned long long o = keys[i ^ j];
+                    const bool keep_min = ((i & j) == 0) == ((i & k) == 0);
+                    v[r] = keep_min ? (o < v[r] ? o : v[r]) : (o > v[r] ? o : v[r]);
+                }
+            } else if (j >= 64) {
+#pragma unroll
+                for (int dr = R / 2; dr >= 1; dr >>= 1) {
+                    if (j != 64 * dr) continue;
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        if (r & dr) continue;
+                        const bool asc = ((base + 64 * r + lane) & k) == 0;
+                        const unsigned long long a = v[r], b = v[r | dr];
+                        const bool sw = (a > b) == asc;
+                        v[r] = sw ? b : a; v[r | dr] = sw ? a : b;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int i = base + 64 * r + lane;
+                    const unsigned long long o = __shfl_xor(v[r], j);
+                    const bool keep_min = ((lane & j) == 0) == ((i & k) == 0);
+                    v[r] = keep_min ? (o < v[r] ? o : v[r]) : (o > v[r] ? o : v[r]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; r++) keys[base + 64 * r + lane] = v[r];
+    __syncthreads();
+}
+
+// sort n (power of two, <= 2048) 64-bit keys in LDS with the 256 threads of the block
+__device__ __forceinline__ void bitonic_sort_u64(unsigned long long *keys, int n)
+{
+    switch (n) {
+    case 256: bitonic_sort_u64_reg<1>(keys); break;
+    case 512: bitonic_sort_u64_reg<2>(keys); break;
+    case 1024: bitonic_sort_u64_reg<4>(keys); break;
+    case 2048: bitonic_sort_u64_reg<8>(keys); break;
+    default: bitonic_sort_u64_lds(keys, n); break;
+    }
 }
 
 __device__ __forceinline__ int next_pow2(int v)

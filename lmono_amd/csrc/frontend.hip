@@ -337,12 +337,21 @@ __global__ __launch_bounds__(256) void k_select(BatchView b)
 // (cell, first index); only the segments are sorted (u64 bitonic in LDS, typically 4x fewer keys than points), and a
 // voxel's centroid is the float sum over its segments in (cell, first index) order = (cell, point index) order.
 constexpr int kVoxLds = kRingCap * 8 + kRingCap * 4 + 1024;
+#ifdef LMONO_VOX_PROF
+#define VT(i) { if (blockIdx.x == 20 && blockIdx.y == 3 && threadIdx.x == 0) vt[i] = clock64(); }
+#else
+#define VT(i)
+#endif
 
 __global__ __launch_bounds__(256) void k_voxel(BatchView b)
 {
     const int r = blockIdx.x, s = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t off = b.off[s];
+#ifdef LMONO_VOX_PROF
+    long long vt[8];
+#endif
+    VT(0)
     const int *rb = b.ring_begin + s * 65;
     const int rbeg = rb[r], rend = rb[r + 1], len = rend - rbeg;
     const int S = rbeg + 5, E = rend - 6;
@@ -381,6 +390,7 @@ __global__ __launch_bounds__(256) void k_voxel(BatchView b)
             ncand++;
         }
     }
+    VT(1)
     float *fs = (float *)scr;   // [4 waves][6] + counts
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -424,6 +434,7 @@ __global__ __launch_bounds__(256) void k_voxel(BatchView b)
         cellv[i] = cell;
     }
     __syncthreads();
+    VT(2)
     // segment heads: a candidate whose predecessor in the ring is not a candidate of the same cell
     const int chunk = (len + 255) / 256;
     const int i_lo = tid * chunk, i_hi = min(i_lo + chunk, len);
@@ -450,7 +461,9 @@ __global__ __launch_bounds__(256) void k_voxel(BatchView b)
         for (int k = nseg + tid; k < np2; k += 256) keys[k] = ~0ull;
     }
     __syncthreads();
+    VT(3)
     bitonic_sort_u64(keys, np2);
+    VT(4)
     // runs of equal cell over the sorted segments -> output voxels
     const int chunk2 = (np2 + 255) / 256;
     const int t_lo = tid * chunk2, t_hi = min(t_lo + chunk2, nseg);
@@ -468,22 +481,34 @@ __global__ __launch_bounds__(256) void k_voxel(BatchView b)
     const int n_out = scr[48] + scr[49] + scr[50] + scr[51];
     float4 *outp = b.lf_tmp + off + rbeg;
     int o = base;
+    VT(5)
     for (int t = t_lo; t < t_hi; t++) {
         const unsigned int c = (unsigned int)(keys[t] >> 32);
         if (t == 0 || c != (unsigned int)(keys[t - 1] >> 32)) {
             float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
             int cnt = 0;
             for (int u = t; u < nseg && (unsigned int)(keys[u] >> 32) == c; u++) {
-                for (int i = (int)(keys[u] & 0xffffffffull); i < len && cellv[i] == c; i++) {
-                    const float4 p = cl[i];
-                    sx += p.x; sy += p.y; sz += p.z; si += p.w;
-                    cnt++;
+                const int i0 = (int)(keys[u] & 0xffffffffull);
+                int rl = 1;
+                while (i0 + rl < len && cellv[i0 + rl] == c) rl++;
+                // the run's points are requested four at a time, then added in index order (PCL's summation order)
+                for (int b4 = 0; b4 < rl; b4 += 4) {
+                    float4 q4[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) q4[k] = b4 + k < rl ? cl[i0 + b4 + k] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) if (b4 + k < rl) { sx += q4[k].x; sy += q4[k].y; sz += q4[k].z; si += q4[k].w; }
                 }
+                cnt += rl;
             }
             const float fc = (float)cnt;
             outp[o++] = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
         }
     }
+    VT(6)
+#ifdef LMONO_VOX_PROF
+    if (blockIdx.x == 20 && blockIdx.y == 3 && tid == 0) printf("VOX len %d nseg %d nout %d | load %lld bbox+cell %lld heads+keys %lld sort %lld runs %lld accum %lld\n", len, nseg, n_out, vt[1]-vt[0], vt[2]-vt[1], vt[3]-vt[2], vt[4]-vt[3], vt[5]-vt[4], vt[6]-vt[5]);
+#endif
     if (tid == 0) b.lf_n[s * 64 + r] = n_out;
 }
 
