@@ -5,8 +5,8 @@
 namespace lmono {
 
 // hash grid over a "last" feature cloud (cell edge 1 m)
-constexpr int kCornerTable = 16384;   // >= 2 * kMaxLessSharp
-constexpr int kSurfTable = 131072;    // surf cloud capacity = kSurfTable / 2 points
+constexpr int kCornerTable = 16384;   // > kMaxLessSharp
+constexpr int kSurfTable = 131072;    // surf cloud capacity = kSurfTable - 1 points
 constexpr unsigned long long kEmptyKey = ~0ull;
 
 // one hash-grid slot: 16 B so that a probe is a single dwordx4 load
@@ -56,7 +56,7 @@ struct BatchView {
     float4 *lbc_pts;         // [n_scans][kMaxLessSharp] less_sharp sorted by (line, azimuth bin), .w = original index bits
     float4 *lbs_pts;         // [total] same for less_flat
     int *lb_start;           // [n_scans][2][66*128+1] start of every (line, bin) bucket
-    int *grid_mask;          // [n_scans][2] table size - 1 actually used (corner, surf): power of two >= 2 n
+    int *grid_mask;          // [n_scans][2] table size - 1 actually used (corner, surf): power of two > n
     int *sg_slot, *sg_rank;  // [total] scratch: table slot of each surf point / rank inside its cell
     int *cg_slot, *cg_rank;  // [n_scans][kMaxLessSharp] same for corner points
 };

@@ -41,14 +41,24 @@ struct GridRef {
 };
 
 // ------------------------------------------------------------------------------------------------
+#ifdef LMONO_GRID_PROF
+#define GT(i) { if (blockIdx.x == 3 && threadIdx.x == 0) gt[i] = clock64(); }
+#else
+#define GT(i)
+#endif
 __global__ __launch_bounds__(1024) void k_grid_build(BatchView b)
 {
+#ifdef LMONO_GRID_PROF
+    long long gt[6];
+#endif
     const int s = blockIdx.x;
     const bool surf = blockIdx.y == 1;
     const int tid = threadIdx.x;
     const int n = b.feat_n[s * 4 + (surf ? 3 : 1)];
     const int Tcap = surf ? kSurfTable : kCornerTable;
-    int T = next_pow2(2 * n);
+    // occupied slots = distinct 1 m cells, typically n / 3: a table of >= n + 1 slots keeps the load near 0.3 and always
+    // has an empty slot to end the probe sequence of an absent key; clearing and scanning it is most of this kernel's traffic
+    int T = next_pow2(n + 1);
     if (T < 1024) T = 1024;
     const bool overflow = T > Tcap;
     if (overflow) T = 1024;
@@ -59,6 +69,7 @@ __global__ __launch_bounds__(1024) void k_grid_build(BatchView b)
     float4 *dst = surf ? b.sg_pts + b.off[s] : b.cg_pts + (size_t)s * kMaxLessSharp;
     int *slot_of = surf ? b.sg_slot + b.off[s] : b.cg_slot + (size_t)s * kMaxLessSharp;
     int *rank_of = surf ? b.sg_rank + b.off[s] : b.cg_rank + (size_t)s * kMaxLessSharp;
+    GT(0)
     for (int i = tid; i < T; i += 1024) { GridCell e; e.key = kEmptyKey; e.start = 0; e.cnt = 0; cell[i] = e; }
     if (overflow) {
         if (tid == 0) atomicOr(&b.status[s], kStatusGridOverflow);
@@ -66,63 +77,119 @@ __global__ __launch_bounds__(1024) void k_grid_build(BatchView b)
     }
     __threadfence_block();
     __syncthreads();
-    // Each thread inserts a run of kRun consecutive points.  Feature clouds are ordered ring by ring and, inside a ring,
-    // by 0.2 m voxel, so consecutive points mostly fall into the same 1 m cell: one CAS + one counted atomicAdd per run
-    // of equal cells instead of two scattered L2 atomics per point (the atomics are what bounds this kernel).
-    constexpr int kRun = 8;
-    for (int i0 = tid * kRun; i0 < n; i0 += 1024 * kRun) {
-        const int i1 = min(i0 + kRun, n);
-        unsigned long long keys[kRun];
+    GT(1)
+    // Insertion, 256 consecutive points per wave and round (lane l owns points t0 + 64 q + l, q = 0..3).  Feature clouds
+    // are ordered ring by ring and, inside a ring, by 0.2 m voxel, so neighbouring points mostly share a 1 m cell: runs
+    // of equal cells are found with a lane shift and a ballot, the head lane of a run does ONE atomicCAS on the cell key
+    // and ONE counted atomicAdd, and hands (slot, first rank) to the run with a lane read.  The four sub-tiles give every
+    // lane four independent atomic chains in flight; all loads and stores are coalesced.
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int t0 = wave * 256; t0 < n; t0 += 16 * 256) {
+        unsigned long long key[4];
+        int hl[4], len[4];
+        bool head[4];
 #pragma unroll
-        for (int u = 0; u < kRun; u++) {
-            keys[u] = kEmptyKey;
-            if (i0 + u < i1) {
-                const float4 p = src[i0 + u];
-                keys[u] = cell_key((int)floorf(p.x * kInvCell), (int)floorf(p.y * kInvCell), (int)floorf(p.z * kInvCell));
+        for (int q = 0; q < 4; q++) {
+            const int i = t0 + 64 * q + lane;
+            key[q] = kEmptyKey;
+            if (i < n) {
+                const float4 p = src[i];
+                key[q] = cell_key((int)floorf(p.x * kInvCell), (int)floorf(p.y * kInvCell), (int)floorf(p.z * kInvCell));
             }
         }
-        int u = 0;
-        while (i0 + u < i1) {
-            int len = 1;
-            while (i0 + u + len < i1 && keys[u + len] == keys[u]) len++;
-            const unsigned long long k = keys[u];
-            unsigned int sl = hash_key(k) & mask;
-            while (true) {
-                const unsigned long long old = atomicCAS(&cell[sl].key, kEmptyKey, k);
-                if (old == kEmptyKey || old == k) break;
-                sl = (sl + 1) & mask;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int i = t0 + 64 * q + lane;
+            const unsigned long long prev = __shfl_up(key[q], 1);
+            head[q] = i < n && (lane == 0 || key[q] != prev);
+            const unsigned long long hm = __ballot(head[q]);
+            const int nv = min(64, max(0, n - (t0 + 64 * q)));                       // valid lanes of the sub-tile
+            hl[q] = 63 - __clzll((long long)(hm & ((2ull << lane) - 1ull)));          // head lane of this lane's run
+            const unsigned long long rest = lane < 63 ? hm >> (lane + 1) : 0ull;
+            len[q] = (rest ? lane + __ffsll((long long)rest) : nv) - lane;           // run length (meaningful on head lanes)
+        }
+        unsigned int sl[4];
+        int base[4];
+        // first probe of the four chains back to back, then the (rare) collisions
+        unsigned long long old[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            sl[q] = hash_key(key[q]) & mask;
+            old[q] = head[q] ? atomicCAS(&cell[sl[q]].key, kEmptyKey, key[q]) : kEmptyKey;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (head[q]) {
+                unsigned long long o = old[q];
+                while (!(o == kEmptyKey || o == key[q])) {
+                    sl[q] = (sl[q] + 1) & mask;
+                    o = atomicCAS(&cell[sl[q]].key, kEmptyKey, key[q]);
+                }
             }
-            const int base = atomicAdd(&cell[sl].cnt, len);
-            for (int v = 0; v < len; v++) { slot_of[i0 + u + v] = (int)sl; rank_of[i0 + u + v] = base + v; }
-            u += len;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) base[q] = head[q] ? atomicAdd(&cell[sl[q]].cnt, len[q]) : 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int i = t0 + 64 * q + lane;
+            const int h = max(hl[q], 0);
+            const int s_run = __shfl((int)sl[q], h), b_run = __shfl(base[q], h);
+            if (i < n) { slot_of[i] = s_run; rank_of[i] = b_run + (lane - h); }
         }
     }
     __syncthreads();
+    GT(2)
     // The counts were produced by L2 atomics: invalidate this CU's L1 once (agent-scope acquire), then read them with
-    // plain coalesced loads.  Exclusive prefix over the table in tiles of 1024 cells (wave scan + cross-wave carry).
+    // plain loads.  Exclusive prefix over the table in tiles of 4096 cells: four consecutive cells per thread, wave scan,
+    // cross-wave carry kept per thread (one barrier per tile, wave sums double-buffered).
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __shared__ int s_wsum[2][16];
-    const int lane = tid & 63, wave = tid >> 6;
-    int carry = 0;      // every thread tracks the running total itself: one barrier per tile, wave sums double-buffered
-    for (int t0 = 0, buf = 0; t0 < T; t0 += 1024, buf ^= 1) {
-        const int c = cell[t0 + tid].cnt;
-        const int incl = wave_scan_incl(c);
+    int carry = 0;
+    for (int t0 = 0, buf = 0; t0 < T; t0 += 4096, buf ^= 1) {
+        const int c0 = t0 + 4 * tid;
+        int c[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) c[q] = c0 + q < T ? cell[c0 + q].cnt : 0;
+        const int sum = (c[0] + c[1]) + (c[2] + c[3]);
+        const int incl = wave_scan_incl(sum);
         if (lane == 63) s_wsum[buf][wave] = incl;
         __syncthreads();
         int base = carry, tile = 0;
 #pragma unroll
         for (int w = 0; w < 16; w++) { const int v = s_wsum[buf][w]; if (w < wave) base += v; tile += v; }
-        cell[t0 + tid].start = base + incl - c;
+        int run = base + incl - sum;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { if (c0 + q < T) cell[c0 + q].start = run; run += c[q]; }
         carry += tile;
     }
     __syncthreads();
-    for (int i = tid; i < n; i += 1024) {
-        const float4 p = src[i];
-        const int ln = (int)p.w;
-        dst[cell[slot_of[i]].start + rank_of[i]] = make_float4(p.x, p.y, p.z, __int_as_float(i | ((ln < 0 ? 0 : (ln > 65 ? 65 : ln)) << 24)));
+    GT(3)
+    // cell-sorted copy: four points per thread and round, the dependent gathers issued together
+    for (int i0 = tid; i0 < n; i0 += 4 * 1024) {
+        float4 p[4];
+        int so[4], ro[4], st[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int i = i0 + 1024 * q;
+            so[q] = 0; ro[q] = 0; p[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < n) { p[q] = src[i]; so[q] = slot_of[i]; ro[q] = rank_of[i]; }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) st[q] = i0 + 1024 * q < n ? cell[so[q]].start : 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int i = i0 + 1024 * q;
+            if (i < n) {
+                const int ln = (int)p[q].w;
+                dst[st[q] + ro[q]] = make_float4(p[q].x, p[q].y, p[q].z, __int_as_float(i | ((ln < 0 ? 0 : (ln > 65 ? 65 : ln)) << 24)));
+            }
+        }
     }
+    GT(4)
+#ifdef LMONO_GRID_PROF
+    if (blockIdx.x == 3 && tid == 0) printf("GRID surf %d n %d T %d | clear %lld insert %lld scan %lld scatter %lld\n", (int)surf, n, T, gt[1]-gt[0], gt[2]-gt[1], gt[3]-gt[2], gt[4]-gt[3]);
+#endif
 }
-
 // ------------------------------------------------------------------------------------------------
 struct OdomView {
     int n_scans, n_chains, lead;
@@ -629,7 +696,7 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
 // grid / index / point data of a chain's "last" scan then stay in that XCD's L2 for its 1836 features.
 constexpr int kCorrBlocks = kMaxQueries / 8;
 
-__global__ __launch_bounds__(256) void k_correspond(BatchView b, OdomView o, int step)
+__global__ __launch_bounds__(256, 6) void k_correspond(BatchView b, OdomView o, int step)
 {
     const int xcd = blockIdx.x & 7, u = blockIdx.x >> 3;
     const int c = (u / kCorrBlocks) * 8 + xcd;
