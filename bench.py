@@ -195,8 +195,15 @@ def main():
         # every chain by half a scan (2 launches per scan-to-scan step)
         scans_per_launch = n_local if dom != "k_correspond" else chains * 0.5
         ach = alg[dom] * scans_per_launch / (ms_launch * 1e-3) / 1e9
+        # HBM bytes per launch of the dominant kernel from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE and
+        # WRITE_SIZE in separate passes, gfx950 correction applied; scripts/profile_round.sh); null if not collected for it
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "r1", "pmc_%s.json" % dom)
+        if os.path.exists(pmc_path) and chains == 256:
+            with open(pmc_path) as fh:
+                traffic = json.load(fh)["hbm_bytes_per_launch"]
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "ms_per_launch": round(ms_launch, 4), "launches_per_step": round(launches_per_step[dom], 1),
                     "frontend_fused_frac": round(37 * N * n_local / (groups["frontend_total"] / max(n_reg, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                     "group_ms_per_step": {k: round(v / max(args.steps, 1), 3) for k, v in groups.items() if k != "odometry_launch_pairs"}}
