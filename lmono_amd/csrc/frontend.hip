@@ -39,8 +39,17 @@ __device__ __forceinline__ bool point_valid(const float4 &p, float mr2)
 }
 
 // ------------------------------------------------------------------------------------------------
+#ifdef LMONO_RS_PROF
+#define RT(i) { if (blockIdx.x == 3 && threadIdx.x == 0) rt[i] = clock64(); }
+#else
+#define RT(i)
+#endif
 __global__ __launch_bounds__(1024) void k_ring_sort(BatchView b)
 {
+#ifdef LMONO_RS_PROF
+    long long rt[6];
+#endif
+    RT(0)
     const int s = blockIdx.x;
     const int64_t off = b.off[s];
     const int n = (int)(b.off[s + 1] - off);
@@ -48,20 +57,34 @@ __global__ __launch_bounds__(1024) void k_ring_sort(BatchView b)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __shared__ int s_first, s_last, s_half;
     __shared__ int s_cnt[64], s_base[64], s_tile[64];
-    __shared__ int s_wcnt[16][64];
+    __shared__ int s_wcnt[4][16][64];
     __shared__ float s_ori[2];
     if (tid < 64) s_cnt[tid] = 0;
     if (tid == 0) { s_first = INT_MAX; s_last = -1; s_half = INT_MAX; }
     __syncthreads();
     const float mr2 = b.min_range * b.min_range;
+    // first / last valid point (they define the sweep's start and end azimuth): almost always inside the first and the
+    // last 1024 points, so only those are read; the full pass runs when one of the two tiles holds no valid point
     int lf = INT_MAX, ll = -1;
-    for (int i = tid; i < n; i += 1024) {
-        const float4 p = in[i];
-        if (point_valid(p, mr2)) { lf = min(lf, i); ll = max(ll, i); }
+    {
+        const int i0 = tid, i1 = n - 1 - tid;
+        if (i0 < n && point_valid(in[i0], mr2)) lf = i0;
+        if (i1 >= 0 && point_valid(in[i1], mr2)) ll = i1;
     }
     lf = wave_min_i(lf); ll = wave_max_i(ll);
     if (lane == 0) { atomicMin(&s_first, lf); atomicMax(&s_last, ll); }
     __syncthreads();
+    if (s_first == INT_MAX || s_last < 0) {
+        __syncthreads();
+        lf = INT_MAX; ll = -1;
+        for (int i = tid; i < n; i += 1024) {
+            const float4 p = in[i];
+            if (point_valid(p, mr2)) { lf = min(lf, i); ll = max(ll, i); }
+        }
+        lf = wave_min_i(lf); ll = wave_max_i(ll);
+        if (lane == 0) { atomicMin(&s_first, lf); atomicMax(&s_last, ll); }
+        __syncthreads();
+    }
     int *rb = b.ring_begin + s * 65;
     if (s_last < 0) {
         if (tid < 65) rb[tid] = 0;
@@ -77,29 +100,39 @@ __global__ __launch_bounds__(1024) void k_ring_sort(BatchView b)
         s_ori[0] = startOri; s_ori[1] = endOri;
     }
     __syncthreads();
+    RT(1)
     const float startOri = s_ori[0], endOri = s_ori[1];
     const int n_lines = b.n_lines;
     int lh = INT_MAX;
-    for (int i = tid; i < n; i += 1024) {
-        const float4 p = in[i];
-        int id = -1;
-        float ori = 0.f;
-        if (point_valid(p, mr2)) {
-            const float angle = (float)(det_atan((double)p.z / sqrt((double)(p.x * p.x + p.y * p.y))) * 180.0 / LM_PI);
-            bool discard;
-            const int r = ring_of(angle, n_lines, discard);
-            if (!discard) {
-                id = r;
-                ori = (float)(-det_atan2((double)p.y, (double)p.x));
-                float o1 = ori;
-                if ((double)o1 < (double)startOri - LM_PI / 2.0) o1 = (float)((double)o1 + 2.0 * LM_PI);
-                else if ((double)o1 > (double)startOri + LM_PI * 3.0 / 2.0) o1 = (float)((double)o1 - 2.0 * LM_PI);
-                if ((double)(o1 - startOri) > LM_PI) lh = min(lh, i);
-                atomicAdd(&s_cnt[id], 1);
+    // four points per thread and round: their loads are in flight together (the sweep is bandwidth-bound)
+    for (int i0 = tid; i0 < n; i0 += 4 * 1024) {
+        float4 pq[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const int i = i0 + 1024 * q; pq[q] = i < n ? in[i] : make_float4(NAN, 0.f, 0.f, 0.f); }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int i = i0 + 1024 * q;
+            if (i >= n) continue;
+            const float4 p = pq[q];
+            int id = -1;
+            float ori = 0.f;
+            if (point_valid(p, mr2)) {
+                const float angle = (float)(det_atan((double)p.z / sqrt((double)(p.x * p.x + p.y * p.y))) * 180.0 / LM_PI);
+                bool discard;
+                const int r = ring_of(angle, n_lines, discard);
+                if (!discard) {
+                    id = r;
+                    ori = (float)(-det_atan2((double)p.y, (double)p.x));
+                    float o1 = ori;
+                    if ((double)o1 < (double)startOri - LM_PI / 2.0) o1 = (float)((double)o1 + 2.0 * LM_PI);
+                    else if ((double)o1 > (double)startOri + LM_PI * 3.0 / 2.0) o1 = (float)((double)o1 - 2.0 * LM_PI);
+                    if ((double)(o1 - startOri) > LM_PI) lh = min(lh, i);
+                    atomicAdd(&s_cnt[id], 1);
+                }
             }
+            b.ring_tmp[off + i] = (int8_t)id;
+            b.ori_tmp[off + i] = ori;
         }
-        b.ring_tmp[off + i] = (int8_t)id;
-        b.ori_tmp[off + i] = ori;
     }
     lh = wave_min_i(lh);
     if (lane == 0 && lh != INT_MAX) atomicMin(&s_half, lh);
@@ -112,46 +145,72 @@ __global__ __launch_bounds__(1024) void k_ring_sort(BatchView b)
     }
     __syncthreads();
     const int half = s_half;
-    for (int t0 = 0; t0 < n; t0 += 1024) {
-        const int i = t0 + tid;
-        const int id = (i < n) ? (int)b.ring_tmp[off + i] : -1;
-        int rank = 0;
-        s_wcnt[wave][lane] = 0;
-        unsigned long long rem = __ballot(id >= 0);
-        while (rem) {
-            const int src = __ffsll((long long)rem) - 1;
-            const int k = __shfl(id, src);
-            const unsigned long long m = __ballot(id == k);
-            if (id == k) rank = __popcll(m & ((1ull << lane) - 1ull));
-            if (lane == src) s_wcnt[wave][k] = __popcll(m);
-            rem &= ~m;
+    RT(2)
+    // stable scatter in super-tiles of 4096 points (sub-tile q = points t0 + 1024 q + tid): one round of barriers per
+    // super-tile, the four sub-tiles' loads in flight together
+    for (int t0 = 0; t0 < n; t0 += 4 * 1024) {
+        int id[4], rank[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const int i = t0 + 1024 * q + tid; id[q] = (i < n) ? (int)b.ring_tmp[off + i] : -1; }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            rank[q] = 0;
+            s_wcnt[q][wave][lane] = 0;
+            unsigned long long rem = __ballot(id[q] >= 0);
+            while (rem) {
+                const int src = __ffsll((long long)rem) - 1;
+                const int k = __shfl(id[q], src);
+                const unsigned long long m = __ballot(id[q] == k);
+                if (id[q] == k) rank[q] = __popcll(m & ((1ull << lane) - 1ull));
+                if (lane == src) s_wcnt[q][wave][k] = __popcll(m);
+                rem &= ~m;
+            }
         }
         __syncthreads();
         if (tid < 64) {
+            // exclusive prefix over (sub-tile, wave) for ring tid: input order = sub-tile major, then wave, then lane
             int acc = 0;
-            for (int w = 0; w < 16; w++) { const int c = s_wcnt[w][tid]; s_wcnt[w][tid] = acc; acc += c; }
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                for (int w = 0; w < 16; w++) { const int c = s_wcnt[q][w][tid]; s_wcnt[q][w][tid] = acc; acc += c; }
             s_tile[tid] = acc;
         }
         __syncthreads();
-        if (id >= 0) {
-            const float4 p = in[i];
-            float ori = b.ori_tmp[off + i];
-            if (i <= half) {
-                if ((double)ori < (double)startOri - LM_PI / 2.0) ori = (float)((double)ori + 2.0 * LM_PI);
-                else if ((double)ori > (double)startOri + LM_PI * 3.0 / 2.0) ori = (float)((double)ori - 2.0 * LM_PI);
-            } else {
-                ori = (float)((double)ori + 2.0 * LM_PI);
-                if ((double)ori < (double)endOri - LM_PI * 3.0 / 2.0) ori = (float)((double)ori + 2.0 * LM_PI);
-                else if ((double)ori > (double)endOri + LM_PI / 2.0) ori = (float)((double)ori - 2.0 * LM_PI);
+        float4 pq[4];
+        float oq[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int i = t0 + 1024 * q + tid;
+            pq[q] = make_float4(0.f, 0.f, 0.f, 0.f); oq[q] = 0.f;
+            if (id[q] >= 0) { pq[q] = in[i]; oq[q] = b.ori_tmp[off + i]; }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int i = t0 + 1024 * q + tid;
+            if (id[q] >= 0) {
+                const float4 p = pq[q];
+                float ori = oq[q];
+                if (i <= half) {
+                    if ((double)ori < (double)startOri - LM_PI / 2.0) ori = (float)((double)ori + 2.0 * LM_PI);
+                    else if ((double)ori > (double)startOri + LM_PI * 3.0 / 2.0) ori = (float)((double)ori - 2.0 * LM_PI);
+                } else {
+                    ori = (float)((double)ori + 2.0 * LM_PI);
+                    if ((double)ori < (double)endOri - LM_PI * 3.0 / 2.0) ori = (float)((double)ori + 2.0 * LM_PI);
+                    else if ((double)ori > (double)endOri + LM_PI / 2.0) ori = (float)((double)ori - 2.0 * LM_PI);
+                }
+                const float relTime = (ori - startOri) / (endOri - startOri);
+                const float inten = (float)((double)id[q] + 0.1 * (double)relTime);
+                const int dst = s_base[id[q]] + s_wcnt[q][wave][id[q]] + rank[q];
+                b.cloud[off + dst] = make_float4(p.x, p.y, p.z, inten);
             }
-            const float relTime = (ori - startOri) / (endOri - startOri);
-            const float inten = (float)((double)id + 0.1 * (double)relTime);
-            const int dst = s_base[id] + s_wcnt[wave][id] + rank;
-            b.cloud[off + dst] = make_float4(p.x, p.y, p.z, inten);
         }
         __syncthreads();
         if (tid < 64) s_base[tid] += s_tile[tid];
     }
+    RT(3)
+#ifdef LMONO_RS_PROF
+    if (blockIdx.x == 3 && tid == 0) printf("RSORT n %d | first/last %lld ring+ori %lld scatter %lld\n", n, rt[1]-rt[0], rt[2]-rt[1], rt[3]-rt[2]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
