@@ -79,6 +79,7 @@ extern "C" lmono_ctx *lmono_create(int device)
     // the selection kernel needs ~62 KB of dynamic LDS
     if (hipFuncSetAttribute((const void *)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kSelWaveLds) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_voxel, hipFuncAttributeMaxDynamicSharedMemorySize, kVoxLds) != hipSuccess) { delete c; return nullptr; }
+    if (hipFuncSetAttribute((const void *)k_lm_solve, hipFuncAttributeMaxDynamicSharedMemorySize, kLmRecLds) != hipSuccess) { delete c; return nullptr; }
     return c;
 }
 
@@ -354,7 +355,7 @@ static int odom_run(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, d
             if (e0 && e1 && e2) (void)hipEventRecord(e0, st);
             hipLaunchKernelGGL(k_correspond, dim3(8 * ((n_chains + 7) / 8) * kCorrBlocks), dim3(256), 0, st, b->v, o, step);
             if (e0 && e1 && e2) (void)hipEventRecord(e1, st);
-            hipLaunchKernelGGL(k_lm_solve, dim3(n_chains), dim3(256), 0, st, b->v, o, step, outer);
+            hipLaunchKernelGGL(k_lm_solve, dim3(n_chains), dim3(kLmT), kLmRecLds, st, b->v, o, step, outer);
             if (e0 && e1 && e2) { (void)hipEventRecord(e2, st); ne += 3; }
         }
     }

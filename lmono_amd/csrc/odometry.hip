@@ -753,6 +753,8 @@ __global__ __launch_bounds__(256, 6) void k_correspond(BatchView b, OdomView o, 
 // ------------------------------------------------------------------------------------------------
 // Residual blocks.  lp = q * cp + t (Eigen _transformVector polynomial); edge r = ((lp-a) x (lp-b)) / |a-b| (3 rows),
 // plane r = (lp - j) . n (1 row).  d r / d lp is constant: [b-a]_x / |a-b| and n^T.
+constexpr int kLmT = 256;   // threads per chain in k_lm_solve (512 measured slower: the serial trust-region part dominates)
+constexpr int kLmW = kLmT / 64;
 struct LmAcc { double H[21]; double g[6]; double cost; };
 
 __device__ __forceinline__ void accumulate_row(LmAcc &a, const double *J, double r)
@@ -778,9 +780,8 @@ __device__ __forceinline__ void huber(double s, double &rho0, double &rho1)
 }
 
 template <bool kJac>
-__device__ __forceinline__ void eval_block(const float4 *rec, const double *x, const double *Jp, LmAcc &acc)
+__device__ __forceinline__ void eval_block(const float4 cp, const float4 A, const float4 B, const float4 Cc, const double *x, const double *Jp, LmAcc &acc)
 {
-    const float4 cp = rec[0], A = rec[1], B = rec[2];
     const int kind = __float_as_int(cp.w);
     if (kind == 0) return;
     const bool edge = kind == 1;
@@ -806,7 +807,6 @@ __device__ __forceinline__ void eval_block(const float4 *rec, const double *x, c
         }
         nr = 3;
     } else {
-        const float4 Cc = rec[3];
         const double jx = (double)A.x, jy = (double)A.y, jz = (double)A.z;
         const double ux = jx - (double)B.x, uy = jy - (double)B.y, uz = jz - (double)B.z;
         const double wx = jx - (double)Cc.x, wy = jy - (double)Cc.y, wz = jz - (double)Cc.z;
@@ -858,10 +858,11 @@ __device__ __forceinline__ void eval_block(const float4 *rec, const double *x, c
     }
 }
 
-// Sum over all residual blocks of a chain by the 256 threads of its workgroup; every thread returns the same sums
-// (wave butterfly, then the four wave partials are added in fixed order).
+// Sum over all residual blocks of a chain by the kLmT threads of its workgroup; every thread returns the same sums
+// (wave butterfly, then the wave partials are added in fixed order).  srec = the chain's records in LDS, one
+// plane of kMaxQueries float4 per record field (conflict-free 16-B reads).
 template <bool kJac>
-__device__ __forceinline__ void evaluate_block(const float4 *crec, int nq, const double *x, LmAcc &acc, double (*s_red)[28])
+__device__ __forceinline__ void evaluate_block(const float4 *srec, int nq, const double *x, LmAcc &acc, double (*s_red)[28])
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double Jp[12];
@@ -876,7 +877,8 @@ __device__ __forceinline__ void evaluate_block(const float4 *crec, int nq, const
 #pragma unroll
         for (int i = 0; i < 6; i++) acc.g[i] = 0.0;
     }
-    for (int qi = tid; qi < nq; qi += 256) eval_block<kJac>(crec + (size_t)qi * 4, x, Jp, acc);
+    for (int qi = tid; qi < nq; qi += kLmT)
+        eval_block<kJac>(srec[qi], srec[kMaxQueries + qi], srec[2 * kMaxQueries + qi], srec[3 * kMaxQueries + qi], x, Jp, acc);
     acc.cost = wave_sum_d(acc.cost);
     if (kJac) {
 #pragma unroll
@@ -893,10 +895,12 @@ __device__ __forceinline__ void evaluate_block(const float4 *crec, int nq, const
         }
     }
     __syncthreads();
-    acc.cost = ((s_red[0][27] + s_red[1][27]) + s_red[2][27]) + s_red[3][27];
+    acc.cost = 0.0;
+#pragma unroll
+    for (int w = 0; w < kLmW; w++) acc.cost += s_red[w][27];
     if (kJac) {
-        for (int i = 0; i < 21; i++) acc.H[i] = ((s_red[0][i] + s_red[1][i]) + s_red[2][i]) + s_red[3][i];
-        for (int i = 0; i < 6; i++) acc.g[i] = ((s_red[0][21 + i] + s_red[1][21 + i]) + s_red[2][21 + i]) + s_red[3][21 + i];
+        for (int i = 0; i < 21; i++) { double t = 0.0; for (int w = 0; w < kLmW; w++) t += s_red[w][i]; acc.H[i] = t; }
+        for (int i = 0; i < 6; i++) { double t = 0.0; for (int w = 0; w < kLmW; w++) t += s_red[w][21 + i]; acc.g[i] = t; }
     }
 }
 
@@ -946,19 +950,39 @@ __device__ __forceinline__ void unpack_sym(const double *Hu, double *H)
         for (int j = i; j < 6; j++) { H[i * 6 + j] = Hu[t]; H[j * 6 + i] = Hu[t]; t++; }
 }
 
-// One 256-thread workgroup per chain.  Every thread runs the (uniform) trust-region control flow redundantly on the
+constexpr int kLmRecLds = 4 * kMaxQueries * 16;   // the chain's records in LDS
+
+// One kLmT-thread workgroup per chain.  Every thread runs the (uniform) trust-region control flow redundantly on the
 // block-reduced sums; residual blocks come from the 64-B records written by k_correspond.
-__global__ __launch_bounds__(256) void k_lm_solve(BatchView b, OdomView o, int step, int outer)
+__global__ __launch_bounds__(kLmT) void k_lm_solve(BatchView b, OdomView o, int step, int outer)
 {
     const int c = blockIdx.x;
     int s;
     const int k = chain_scan(o, c, step, s);
     if (k < 0) return;
-    __shared__ double s_red[4][28];
-    __shared__ int s_used[4];
+    __shared__ double s_red[kLmW][28];
+    __shared__ int s_used[kLmW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nq = b.feat_n[k * 4 + 0] + b.feat_n[k * 4 + 2];
     const float4 *crec = o.crec + (size_t)c * kMaxQueries * 4;
+    // the chain's residual-block records (64 B each, <= 144 KB) are read once and stay in LDS for the up to nine
+    // evaluations of this launch; eight 16-B loads per thread in flight
+    extern __shared__ __align__(16) float4 s_rec[];
+    int n_used = 0;
+    for (int i0 = tid; i0 < nq * 4; i0 += 8 * kLmT) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int idx = i0 + kLmT * u; v[u] = idx < nq * 4 ? crec[idx] : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int idx = i0 + kLmT * u;
+            if (idx < nq * 4) {
+                s_rec[(idx & 3) * kMaxQueries + (idx >> 2)] = v[u];
+                if ((idx & 3) == 0) n_used += __float_as_int(v[u].w) != 0;
+            }
+        }
+    }
+    __syncthreads();
     double x[7];
     for (int i = 0; i < 7; i++) x[i] = o.state[c * 8 + i];
 
@@ -969,17 +993,16 @@ __global__ __launch_bounds__(256) void k_lm_solve(BatchView b, OdomView o, int s
     bool reuse_diagonal = false;
     int invalid_steps = 0, iter = 0;
     LmAcc acc;
-    evaluate_block<true>(crec, nq, x, acc, s_red);
+    evaluate_block<true>(s_rec, nq, x, acc, s_red);
     double x_cost = acc.cost;
     double H[36], g[6], scale[6], diag[6];
     unpack_sym(acc.H, H);
     for (int i = 0; i < 6; i++) g[i] = acc.g[i];
-    int n_used = 0;
-    for (int qi = tid; qi < nq; qi += 256) n_used += __float_as_int(crec[(size_t)qi * 4].w) != 0;
     n_used = wave_sum_i(n_used);
     if (lane == 0) s_used[wave] = n_used;
     __syncthreads();
-    n_used = s_used[0] + s_used[1] + s_used[2] + s_used[3];
+    n_used = 0;
+    for (int w = 0; w < kLmW; w++) n_used += s_used[w];
     double gmax = 0.0;
     for (int i = 0; i < 6; i++) gmax = fmax(gmax, fabs(g[i]));
     if (n_used > 0 && gmax > gradient_tol) {
@@ -1012,7 +1035,7 @@ __global__ __launch_bounds__(256) void k_lm_solve(BatchView b, OdomView o, int s
             for (int i = 0; i < 6; i++) delta[i] = stepv[i] * scale[i];
             manifold_plus(x, delta, cand);
             LmAcc ca;
-            evaluate_block<false>(crec, nq, cand, ca, s_red);
+            evaluate_block<false>(s_rec, nq, cand, ca, s_red);
             const double cand_cost = ca.cost;
             double sn = 0.0;
             for (int i = 0; i < 7; i++) sn += (x[i] - cand[i]) * (x[i] - cand[i]);
@@ -1023,7 +1046,7 @@ __global__ __launch_bounds__(256) void k_lm_solve(BatchView b, OdomView o, int s
             if (rel > min_rel_decrease) {
                 for (int i = 0; i < 7; i++) x[i] = cand[i];
                 x_norm = norm7(x);
-                evaluate_block<true>(crec, nq, x, acc, s_red);
+                evaluate_block<true>(s_rec, nq, x, acc, s_red);
                 x_cost = acc.cost;
                 unpack_sym(acc.H, H);
                 for (int i = 0; i < 6; i++) g[i] = acc.g[i];
