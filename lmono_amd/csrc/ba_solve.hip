@@ -33,8 +33,8 @@ constexpr int kBaPS = 80;                        // padded row of the coupling m
 constexpr int kBaMaxFeat = 448;
 constexpr int kBaN = kBaP + kBaMaxFeat;          // 520
 constexpr int kBaMaxPairs = kBaMaxPoses * (kBaMaxPoses - 1);
-constexpr int kBaChunk = 192;                    // observations staged per pass
-constexpr int kBaRow = 20;                       // staged row: J_i(6) J_j(6) J_ex(6) r pad
+constexpr int kBaRound = 32;                     // observations a wave stages per round (two lanes each)
+constexpr int kBaRow = 19;                       // staged row: J_i(6) J_j(6) J_ex(6) r (odd stride: few bank conflicts)
 constexpr int kBaFT = 64;                        // features per Schur tile
 constexpr int kBaSS = 73;                        // row stride of S in LDS (odd: conflict-free column walks)
 constexpr int kBaPairRec = 40;                   // T(9) tp(3) Cm(9) A(9) B(9) pad
@@ -56,7 +56,8 @@ struct BaBatch {
     const int *pair_off;        // [W+1] first (i, j) frame pair of each window
     const int *pair_ij;         // [total pairs] i | j << 8
     const int *pobs_off;        // [W+1] first slot of each window in the pair-ordered observation list
-    const int *slot_info;       // [total slots] feature | pair << 16 (both window-local); feature 0xffff = padding (pairs are padded to even length)
+    const int *pair_slot;       // [total pairs + W] per window n_pairs + 1 window-local slot offsets; pairs sorted by descending size
+    const int *slot_info;       // [total slots] feature | pair << 16 (both window-local), slots ordered by pair
     const double *slot_pts;     // [total slots][4] the observation's two normalised image points, in slot order
     const double *laser_consts; // [W][10][24]
     const double *prior_T;      // [W][16]
@@ -67,28 +68,29 @@ struct BaBatch {
     double *summary;            // [W][6] initial_cost, final_cost, iterations, termination, successful, unsuccessful
 };
 
-struct BaSchurStage { double et[kBaFT * kBaPS]; double ic[kBaFT]; double gi[kBaFT]; };
+struct BaSchurStage { double et[kBaFT * kBaPS]; double ic[kBaFT]; double gi[kBaFT]; double part[4][kBaPS]; };
 struct BaFactor { double S[(kBaP + 1) * kBaSS]; double idiag[kBaP]; };   // reduced system / its Cholesky factor (row P = right-hand side), 1 / diagonal
 
 struct BaLds {
     double Hpp[kBaP * kBaP];
     union {
-        double stage[kBaChunk * 2 * kBaRow];     // evaluate: staged Jacobian rows
+        double stage[kBaW * 2 * kBaRound * kBaRow];   // evaluate: every wave's staged Jacobian rows
+        double hs_part[kBaW][kBaPS];                  // Hs v: per-wave partial sums of the camera rows
         BaSchurStage sch;                         // Schur: scaled coupling tile, 1 / h_ff
         BaFactor fac;
     } u;
     double Hdd[kBaMaxFeat], gdd[kBaMaxFeat];
     double gp[kBaP];
-    double scale[kBaN], D[kBaN], D2[kBaN], gs[kBaN], gdv[kBaN], gn[kBaN], va[kBaN], vb[kBaN], vw[kBaN];
+    double scale[kBaN], D[kBaN], gs[kBaN], gn[kBaN], va[kBaN], vb[kBaN];
     double rhs[kBaPS];
-    double part[kBaW][kBaPS];
     double red[3 * kBaW];
     double poses[kBaMaxPoses * 7], ex[7];
     double cposes[kBaMaxPoses * 7], cex[7];
     double Rp[(kBaMaxPoses + 1) * 9];            // rotation matrices of the window poses, then R_lc
     double vinv[kBaMaxFeat];                     // inverse depths of the state being evaluated
     int pair_ij[kBaMaxPairs];
-    int spair[kBaChunk];                         // pair of every staged slot
+    int pair_slot[kBaMaxPairs + 1];              // first slot of every pair (pairs in descending size)
+    int next_pair;                               // work counter of the linearisation
     int ok;
 };
 static_assert(sizeof(BaLds) <= 160 * 1024, "BaLds exceeds the 160 KB LDS of a gfx950 CU");
@@ -214,7 +216,7 @@ __device__ __forceinline__ void gatomic_add(double *p, double v) { (void)__built
 
 // LASERFactor chain and the extrinsic prior: a handful of residual blocks, one thread each.  The thread leaves its
 // residuals and Jacobians in LDS ([r(6) | J(84)] per block, block 10 = prior); the J^T J products are then spread over
-// the whole workgroup (ba_small_accumulate).  Kept out of line: its register-resident 6x14 Jacobian must not shape the
+// one wave (ba_small_accumulate_wave).  Kept out of line: its register-resident 6x14 Jacobian must not shape the
 // register allocation of the hot loops.
 constexpr int kBaSmallRec = 96;
 template <bool kJac>
@@ -262,11 +264,11 @@ __device__ __noinline__ double ba_small_factors(const BaBatch &B, const BaCtx c,
     return cost;
 }
 
-// J^T J and J^T r of the blocks left in LDS by ba_small_factors, one output entry per thread and round
-__device__ __forceinline__ void ba_small_accumulate(const BaCtx &c, BaLds &L, const double *in)
+// J^T J and J^T r of the blocks left in LDS by ba_small_factors, by one wave (one output entry per lane and round)
+__device__ __forceinline__ void ba_small_accumulate_wave(const BaCtx &c, BaLds &L, const double *in, int lane)
 {
     const int nl = c.n_poses - 1;
-    for (int idx = threadIdx.x; idx < nl * 156; idx += kBaT) {
+    for (int idx = lane; idx < nl * 156; idx += 64) {
         const int b = idx / 156, e = idx - b * 156;
         const double *r = in + b * kBaSmallRec, *J = r + 6;
         const int a = e < 144 ? e / 12 : e - 144, bb = e < 144 ? e % 12 : 0;
@@ -284,9 +286,9 @@ __device__ __forceinline__ void ba_small_accumulate(const BaCtx &c, BaLds &L, co
             unsafeAtomicAdd(&L.gp[ga], v);
         }
     }
-    if (c.use_prior && !c.ex_constant && threadIdx.x < 42) {
+    if (c.use_prior && !c.ex_constant && lane < 42) {
         const double *r = in + 10 * kBaSmallRec, *J = r + 6;
-        const int e = threadIdx.x, a = e < 36 ? e / 6 : e - 36, bb = e < 36 ? e % 6 : 0;
+        const int e = lane, a = e < 36 ? e / 6 : e - 36, bb = e < 36 ? e % 6 : 0;
         double v = 0;
         if (e < 36) {
 #pragma unroll
@@ -298,8 +300,9 @@ __device__ __forceinline__ void ba_small_accumulate(const BaCtx &c, BaLds &L, co
             unsafeAtomicAdd(&L.gp[c.ex_off + a], v);
         }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();    // the slice becomes the wave's Jacobian stage
 }
-
 
 // cost (returned to every thread) and, when kJac, the unscaled normal equations: Hpp, gp, Hdd, gdd in LDS, Hpd in HBM
 template <bool kJac>
@@ -341,7 +344,8 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
     }
     double cost = 0.0;
     // wave 1: LASERFactor chain and prior, next to the pair records of wave 0
-    if (tid >= 64 && tid < 96) cost += ba_small_factors<kJac>(B, c, L.u.stage, poses, ex, tid - 64);
+    if (tid >= 64 && tid < 96) cost += ba_small_factors<kJac>(B, c, L.u.stage + (size_t)1 * 2 * kBaRound * kBaRow, poses, ex, tid - 64);
+    if (tid == 0) L.next_pair = 0;
     const double *mono_info = B.info + 36;
     const double m00 = gld(mono_info), m01 = gld(mono_info + 1), m10 = gld(mono_info + 2), m11 = gld(mono_info + 3);
     const int *sinfo = B.slot_info + c.ps0;
@@ -386,55 +390,46 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
 
     __syncthreads();   // pair records and zeroed coupling rows are visible
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    ba_small_accumulate(c, L, L.u.stage);
-    __syncthreads();   // the stage is free for the first pass
     BA_TOCK(0)
-    // two threads per observation: thread q of the pair owns residual row q.  Slot data of the next pass are requested
-    // before the MFMA phase of the current one.
-    const int q = tid & 1, so = tid >> 1;        // row, slot inside the pass
+    BA_TICK(1)
+    // Every wave works on whole frame pairs, taken from a work counter in descending size: 32 observations per round,
+    // two lanes each (lane q of the pair owns residual row q), the 64 rows staged in the wave's own LDS slice and
+    // multiplied right away -- no workgroup barrier inside the loop.
+    double *wstage = L.u.stage + (size_t)wave * 2 * kBaRound * kBaRow;
+    if (wave == 1) ba_small_accumulate_wave(c, L, wstage, lane);     // LASERFactor chain / prior left there by wave 1
+    const int q = lane & 1, lo = lane >> 1, col = lane & 15, kq = lane >> 4;
     double xx44 = 0, xx45 = 0, xx55 = 0, gx4 = 0, gx5 = 0;
-    int info_n = -1;
-    double2 pa_n = { 0, 0 }, pb_n = { 0, 0 };
-    if (so < min(kBaChunk, c.n_slots)) {
-        info_n = gldi(sinfo + so);
-        pa_n = make_double2(gld(spts + (size_t)so * 4), gld(spts + (size_t)so * 4 + 1)); pb_n = make_double2(gld(spts + (size_t)so * 4 + 2), gld(spts + (size_t)so * 4 + 3));
-    }
-    for (int c0 = 0; c0 < c.n_slots; c0 += kBaChunk) {
-        const int nslot = min(kBaChunk, c.n_slots - c0);   // even: pairs are padded to even length
-        BA_TICK(1)
-        const int info = info_n;
-        const double2 pa = pa_n, pb = pb_n;
+    for (;;) {
+        int pr = 0;
+        if (lane == 0) pr = atomicAdd(&L.next_pair, 1);
+        pr = __builtin_amdgcn_readfirstlane(pr);
+        if (pr >= c.n_pairs) break;
+        const int ij = L.pair_ij[pr], fi = ij & 255, fj = ij >> 8;
+        const int s_begin = L.pair_slot[pr], s_end = L.pair_slot[pr + 1];
+        const int oi = ba_pose_off(c, fi), oj = ba_pose_off(c, fj);
+        // the pair record: one (broadcast) request per value, kept in registers for all rounds of the pair
+        double rec[kBaPairRec - 1];
         {
-            const int sn = c0 + kBaChunk + so;
-            info_n = -1;
-            if (so < kBaChunk && sn < c.n_slots) {
-                info_n = gldi(sinfo + sn);
-                pa_n = make_double2(gld(spts + (size_t)sn * 4), gld(spts + (size_t)sn * 4 + 1)); pb_n = make_double2(gld(spts + (size_t)sn * 4 + 2), gld(spts + (size_t)sn * 4 + 3));
-            }
-        }
-        if (so < nslot) {
-            double *row = L.u.stage + (size_t)(2 * so + q) * kBaRow;
-            const int pr = info >> 16, f = info & 0xffff;
-            if (q == 0) L.spair[so] = pr;
-            if (f == 0xffff) {
-                for (int k = 0; k < kBaRow; k++) row[k] = 0.0;   // padding slot of its pair
-            } else {
-                const int ij = L.pair_ij[pr], fi = ij & 255, fj = ij >> 8;
-                // the whole pair record is requested at once (one round trip); the lanes of a pair read the same lines
-                double rec[kBaPairRec - 1];
-                {
-                    const double *rp = pairdat + (size_t)pr * kBaPairRec;
+            const double *rp = pairdat + (size_t)pr * kBaPairRec;
 #pragma unroll
-                    for (int k = 0; k < kBaPairRec - 1; k++) rec[k] = gld(rp + k);
-                }
-                const double *T = rec, *Cm = rec + 12, *A = rec + 21, *Bm = rec + 30;
+            for (int k = 0; k < kBaPairRec - 1; k++) rec[k] = gld(rp + k);
+        }
+        const double *T = rec, *Cm = rec + 12, *A = rec + 21, *Bm = rec + 30;
+        ba_d4 aa = { 0, 0, 0, 0 }, ab = { 0, 0, 0, 0 };
+        for (int base = s_begin; base < s_end; base += kBaRound) {
+            const int so = base + lo;
+            double *row = wstage + (size_t)lane * kBaRow;
+            if (so < s_end) {
+                const int f = gldi(sinfo + so) & 0xffff;
+                const double pax = gld(spts + (size_t)so * 4), pay = gld(spts + (size_t)so * 4 + 1);
+                const double pbx = gld(spts + (size_t)so * 4 + 2), pby = gld(spts + (size_t)so * 4 + 3);
                 const double depth = 1.0 / L.vinv[f];
-                const double pc[3] = { depth * pa.x, depth * pa.y, depth };
+                const double pc[3] = { depth * pax, depth * pay, depth };
                 double Tp[3], pcj[3], uT[3], u[3];
                 ba::mv(T, pc, Tp);
                 for (int k = 0; k < 3; k++) pcj[k] = Tp[k] + rec[9 + k];
                 const double inv = 1.0 / pcj[2];
-                const double e0 = pcj[0] * inv - pb.x, e1 = pcj[1] * inv - pb.y;
+                const double e0 = pcj[0] * inv - pbx, e1 = pcj[1] * inv - pby;
                 const double r0 = m00 * e0 + m01 * e1, r1 = m10 * e0 + m11 * e1;
                 const double sq = r0 * r0 + r1 * r1;
                 if (q == 0) cost += 0.5 * log(1.0 + sq);
@@ -479,16 +474,15 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
                 }
 #pragma unroll
                 for (int k = 0; k < 6; k++) { row[k] = Ji[k]; row[6 + k] = Jj[k]; row[12 + k] = Jx[k]; }
-                row[18] = rq; row[19] = 0.0;
-                // depth block and coupling row: the two rows of the observation are summed across the lane pair, lane q = 0
-                // issues the atomics -- after every load of this pass, so that nothing waits on their completion
+                row[18] = rq;
+                // depth block and coupling row: the two rows of the observation are summed across the lane pair, lane
+                // q = 0 issues the atomics
                 double hx[6], hi[6], hj[6];
 #pragma unroll
                 for (int k = 0; k < 6; k++) { hx[k] = pair_sum(Jx[k] * Jd); hi[k] = pair_sum(Ji[k] * Jd); hj[k] = pair_sum(Jj[k] * Jd); }
                 const double hdd = pair_sum(Jd * Jd), gd = pair_sum(Jd * rq);
                 if (q == 0) {
                     double *hrow = hpd + (size_t)f * kBaPS;
-                    const int oi = ba_pose_off(c, fi), oj = ba_pose_off(c, fj);
                     unsafeAtomicAdd(&L.Hdd[f], hdd); unsafeAtomicAdd(&L.gdd[f], gd);
 #pragma unroll
                     for (int k = 0; k < 6; k++) {
@@ -497,57 +491,47 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
                         gst(hrow + oj + k, hj[k]);                              // frame j sees a feature once
                     }
                 }
-            }
-        }
-        __syncthreads();
-        BA_TOCK(1)
-        BA_TICK(2)
-        // J^T [J r] of the staged rows: four rows (two observations of one pair) per MFMA step
-        {
-            const int nk = nslot >> 1;
-            const int k_begin = wave * nk / kBaW, k_end = (wave + 1) * nk / kBaW;
-            const int col = lane & 15, kq = lane >> 4;
-            int cur = -1;
-            ba_d4 aa = { 0, 0, 0, 0 }, ab = { 0, 0, 0, 0 };
-            auto flush = [&](int pr) {
-                const int ij = L.pair_ij[pr];
-                const int oi = ba_pose_off(c, ij & 255), oj = ba_pose_off(c, ij >> 8);
-                auto gidx = [&](int m) { return m < 6 ? oi + m : (m < 12 ? oj + m - 6 : (c.ex_off < 0 ? -1 : c.ex_off + m - 12)); };
-                const int gn_ = gidx(col);
+            } else {
 #pragma unroll
-                for (int v = 0; v < 4; v++) {
-                    const int gm = gidx(kq + 4 * v);
-                    if (gm < 0) continue;
-                    if (gn_ >= 0) unsafeAtomicAdd(&L.Hpp[gm * kBaP + gn_], aa[v]);
-                    if (col < 2) {
-                        if (c.ex_off >= 0) {
-                            const int xc = c.ex_off + 4 + col;
-                            unsafeAtomicAdd(&L.Hpp[gm * kBaP + xc], ab[v]);
-                            unsafeAtomicAdd(&L.Hpp[xc * kBaP + gm], ab[v]);
-                        }
-                    } else if (col == 2) {
-                        unsafeAtomicAdd(&L.gp[gm], ab[v]);
-                    }
-                }
-            };
-            for (int ks = k_begin; ks < k_end; ks++) {
-                const int pr = L.spair[2 * ks];
-                if (pr != cur) {
-                    if (cur >= 0) flush(cur);
-                    aa = ba_d4{ 0, 0, 0, 0 }; ab = ba_d4{ 0, 0, 0, 0 };
-                    cur = pr;
-                }
-                const double *rowp = L.u.stage + (size_t)(4 * ks + kq) * kBaRow;
-                const double a = rowp[col];
-                const double b = col < 4 ? rowp[16 + col] : 0.0;
-                aa = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, aa, 0, 0, 0);
-                ab = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, ab, 0, 0, 0);
+                for (int k = 0; k < kBaRow; k++) row[k] = 0.0;
             }
-            if (cur >= 0) flush(cur);
+            // the wave's rows are in LDS (its LDS operations execute in order): J^T [J r], four rows per MFMA step
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int nrow = 2 * min(kBaRound, s_end - base);
+            for (int ks = 0; 4 * ks < nrow; ks++) {
+                const double *rowp = wstage + (size_t)(4 * ks + kq) * kBaRow;
+                const double a = rowp[col];
+                const double bq = col < 3 ? rowp[16 + col] : 0.0;
+                aa = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, aa, 0, 0, 0);
+                ab = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, ab, 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();   // the slice is rewritten by the next round
         }
-        __syncthreads();
-        BA_TOCK(2)
+        // add the pair's blocks to H_pp / g_p
+        {
+            auto gidx = [&](int m) { return m < 6 ? oi + m : (m < 12 ? oj + m - 6 : (c.ex_off < 0 ? -1 : c.ex_off + m - 12)); };
+            const int gn_ = gidx(col);
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const int gm = gidx(kq + 4 * v);
+                if (gm < 0) continue;
+                if (gn_ >= 0) unsafeAtomicAdd(&L.Hpp[gm * kBaP + gn_], aa[v]);
+                if (col < 2) {
+                    if (c.ex_off >= 0) {
+                        const int xc = c.ex_off + 4 + col;
+                        unsafeAtomicAdd(&L.Hpp[gm * kBaP + xc], ab[v]);
+                        unsafeAtomicAdd(&L.Hpp[xc * kBaP + gm], ab[v]);
+                    }
+                } else if (col == 2) {
+                    unsafeAtomicAdd(&L.gp[gm], ab[v]);
+                }
+            }
+        }
     }
+    BA_TOCK(1)
+    __syncthreads();
     if (c.ex_off >= 0 && c.n_slots > 0) {
         xx44 = wave_sum_d(xx44); xx45 = wave_sum_d(xx45); xx55 = wave_sum_d(xx55); gx4 = wave_sum_d(gx4); gx5 = wave_sum_d(gx5);
         if (lane == 0) {
@@ -563,14 +547,14 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
     return cost;
 }
 
-// y = Hs v (Jacobi-scaled), v and y in LDS arrays of length N
+// y = Hs v (Jacobi-scaled), v and y in LDS arrays of length N.  L.gn is used as scratch (it is dead until the next solve).
 __device__ __noinline__ void ba_hs_mul(const BaCtx c, BaLds &L, const double *hpd, const double *v, double *y)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = c.P, F = c.F, N = P + F;
     __syncthreads();
     BA_TICK(4)
-    for (int k = tid; k < N; k += kBaT) L.vw[k] = L.scale[k] * v[k];
+    for (int k = tid; k < N; k += kBaT) L.gn[k] = L.scale[k] * v[k];
     __syncthreads();
     // camera rows: wave w sums the features f = w (mod 8); lanes own the parameter columns (coalesced 640-B rows),
     // eight feature rows in flight
@@ -588,12 +572,12 @@ __device__ __noinline__ void ba_hs_mul(const BaCtx c, BaLds &L, const double *hp
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const int fu = f + kBaW * u;
-                const double w = fu < F ? L.vw[P + fu] : 0.0;
+                const double w = fu < F ? L.gn[P + fu] : 0.0;
                 a0 += r0[u] * w; a1 += r1[u] * w;
             }
         }
-        L.part[wave][lane] = a0;
-        if (lane < kBaPS - 64) L.part[wave][64 + lane] = a1;
+        L.u.hs_part[wave][lane] = a0;
+        if (lane < kBaPS - 64) L.u.hs_part[wave][64 + lane] = a1;
     }
     // depth rows: four lanes per feature, the 18 entries of a lane requested together
     for (int f = tid >> 2; f < F; f += kBaT / 4) {
@@ -603,17 +587,17 @@ __device__ __noinline__ void ba_hs_mul(const BaCtx c, BaLds &L, const double *hp
         for (int k = 0; k < 18; k++) { const int a = (tid & 3) + 4 * k; rv[k] = a < P ? gld(row + a) : 0.0; }
         double acc = 0;
 #pragma unroll
-        for (int k = 0; k < 18; k++) { const int a = (tid & 3) + 4 * k; acc += rv[k] * (a < P ? L.vw[a] : 0.0); }
+        for (int k = 0; k < 18; k++) { const int a = (tid & 3) + 4 * k; acc += rv[k] * (a < P ? L.gn[a] : 0.0); }
         acc += __shfl_xor(acc, 1);
         acc += __shfl_xor(acc, 2);
-        if ((tid & 3) == 0) y[P + f] = (acc + L.Hdd[f] * L.vw[P + f]) * L.scale[P + f];
+        if ((tid & 3) == 0) y[P + f] = (acc + L.Hdd[f] * L.gn[P + f]) * L.scale[P + f];
     }
     __syncthreads();
     if (tid < P) {
         double acc = 0;
 #pragma unroll
-        for (int w = 0; w < kBaW; w++) acc += L.part[w][tid];
-        for (int b = 0; b < P; b++) acc += L.Hpp[b * kBaP + tid] * L.vw[b];   // H_pp is symmetric: column walk, no bank conflicts
+        for (int w = 0; w < kBaW; w++) acc += L.u.hs_part[w][tid];
+        for (int b = 0; b < P; b++) acc += L.Hpp[b * kBaP + tid] * L.gn[b];   // H_pp is symmetric: column walk, no bank conflicts
         y[tid] = acc * L.scale[tid];
     }
     __syncthreads();
@@ -667,7 +651,7 @@ __device__ __noinline__ bool ba_schur_solve(const BaCtx c, BaLds &L, const doubl
             double ic = 0.0, gi = 0.0;
             if (tid < nf) {
                 const double s = L.scale[P + f0 + tid];
-                const double hff = L.Hdd[f0 + tid] * s * s + mu * L.D2[P + f0 + tid];
+                const double hff = L.Hdd[f0 + tid] * s * s + mu * L.D[P + f0 + tid] * L.D[P + f0 + tid];
                 if (!(hff > 0.0)) L.ok = 0;
                 ic = 1.0 / hff;
                 gi = L.gs[P + f0 + tid] * ic;
@@ -681,7 +665,7 @@ __device__ __noinline__ bool ba_schur_solve(const BaCtx c, BaLds &L, const doubl
             double s = 0;
 #pragma unroll 4
             for (int t = part * (kBaFT / 4); t < (part + 1) * (kBaFT / 4); t++) s += L.u.sch.et[t * kBaPS + a] * L.u.sch.gi[t];
-            L.part[part][a] = s;
+            L.u.sch.part[part][a] = s;
         }
         const int nks = (nf + 3) >> 2;
         for (int ks = 0; ks < nks; ks++) {
@@ -697,7 +681,7 @@ __device__ __noinline__ bool ba_schur_solve(const BaCtx c, BaLds &L, const doubl
             }
         }
         __syncthreads();
-        if (tid < P) L.rhs[tid] -= ((L.part[0][tid] + L.part[1][tid]) + L.part[2][tid]) + L.part[3][tid];
+        if (tid < P) L.rhs[tid] -= ((L.u.sch.part[0][tid] + L.u.sch.part[1][tid]) + L.u.sch.part[2][tid]) + L.u.sch.part[3][tid];
     }
     __syncthreads();   // the staged tile is dead: S takes its place
     double *S = L.u.fac.S;
@@ -708,7 +692,7 @@ __device__ __noinline__ bool ba_schur_solve(const BaCtx c, BaLds &L, const doubl
         for (int v = 0; v < 4; v++) {
             const int m = 16 * tm[u] + kq + 4 * v, n = 16 * tn[u] + col;
             if (m < P && n < P) {
-                const double val = L.Hpp[m * kBaP + n] * L.scale[m] * L.scale[n] + (m == n ? mu * L.D2[m] : 0.0) - acc[u][v];
+                const double val = L.Hpp[m * kBaP + n] * L.scale[m] * L.scale[n] + (m == n ? mu * L.D[m] * L.D[m] : 0.0) - acc[u][v];
                 S[m * kBaSS + n] = val;
                 if (tm[u] != tn[u]) S[n * kBaSS + m] = val;
             }
@@ -785,7 +769,7 @@ __device__ __noinline__ bool ba_schur_solve(const BaCtx c, BaLds &L, const doubl
     __syncthreads();
     BA_TOCK(7)
     BA_TICK(8)
-    for (int k = tid; k < P; k += kBaT) L.vw[k] = L.scale[k] * L.gn[k];
+    for (int k = tid; k < P; k += kBaT) L.rhs[k] = L.scale[k] * L.gn[k];
     __syncthreads();
     for (int f = tid >> 2; f < F; f += kBaT / 4) {
         const double *row = hpd + (size_t)f * kBaPS;
@@ -794,12 +778,12 @@ __device__ __noinline__ bool ba_schur_solve(const BaCtx c, BaLds &L, const doubl
         for (int k = 0; k < 18; k++) { const int a = (tid & 3) + 4 * k; rv[k] = a < P ? gld(row + a) : 0.0; }
         double acc = 0;
 #pragma unroll
-        for (int k = 0; k < 18; k++) { const int a = (tid & 3) + 4 * k; acc += rv[k] * (a < P ? L.vw[a] : 0.0); }
+        for (int k = 0; k < 18; k++) { const int a = (tid & 3) + 4 * k; acc += rv[k] * (a < P ? L.rhs[a] : 0.0); }
         acc += __shfl_xor(acc, 1);
         acc += __shfl_xor(acc, 2);
         if ((tid & 3) == 0) {
             const double s = L.scale[P + f];
-            const double hff = L.Hdd[f] * s * s + mu * L.D2[P + f];
+            const double hff = L.Hdd[f] * s * s + mu * L.D[P + f] * L.D[P + f];
             const double x = (L.gs[P + f] - acc * s) / hff;
             L.gn[P + f] = x;
             if (!isfinite(x)) L.ok = 0;
@@ -831,6 +815,7 @@ __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B)
     for (int k = tid; k < c.n_poses * 7; k += kBaT) L.poses[k] = gposes[k];
     if (tid < 7) L.ex[tid] = gex[tid];
     for (int k = tid; k < c.n_pairs; k += kBaT) L.pair_ij[k] = B.pair_ij[c.pp0 + k];
+    for (int k = tid; k <= c.n_pairs; k += kBaT) L.pair_slot[k] = B.pair_slot[c.pp0 + w + k];
     __syncthreads();
 
     const double function_tol = 1e-6, gradient_tol = 1e-10, parameter_tol = 1e-8, min_rel_decrease = 1e-3;
@@ -877,13 +862,12 @@ __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B)
                 L.gs[k] = g * L.scale[k];
                 double d = h * L.scale[k] * L.scale[k];
                 d = d < min_diag ? min_diag : (d > max_diag ? max_diag : d);
-                L.D2[k] = d; L.D[k] = sqrt(d);
-                L.gdv[k] = L.gs[k] / L.D[k];
-                L.va[k] = L.gdv[k] / L.D[k];
+                L.D[k] = sqrt(d);
+                L.va[k] = L.gs[k] / d;
             }
             ba_hs_mul(c, L, hpd, L.va, L.vb);      // vb = Hs (gs / D^2): kept until the next linearisation
             double g2 = 0, jg2 = 0, zero = 0;
-            for (int k = tid; k < N; k += kBaT) { g2 += L.gdv[k] * L.gdv[k]; jg2 += L.va[k] * L.vb[k]; }
+            for (int k = tid; k < N; k += kBaT) { const double gd = L.gs[k] / L.D[k]; g2 += gd * gd; jg2 += L.va[k] * L.vb[k]; }
             block_sum3(g2, jg2, zero, L.red);
             alpha = g2 / jg2;
             ok = false;
@@ -900,7 +884,7 @@ __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B)
         }
         if (ok) {
             double a2 = 0, b2 = 0, ab = 0;
-            for (int k = tid; k < N; k += kBaT) { a2 += L.gn[k] * L.gn[k]; b2 += L.gdv[k] * L.gdv[k]; ab += L.gdv[k] * L.gn[k]; }
+            for (int k = tid; k < N; k += kBaT) { const double gd = L.gs[k] / L.D[k]; a2 += L.gn[k] * L.gn[k]; b2 += gd * gd; ab += gd * L.gn[k]; }
             block_sum3(a2, b2, ab, L.red);
             const double gn_norm = sqrt(a2), g_norm = sqrt(b2);
             double ca, cb;   // step = ca * gdv + cb * gn
@@ -919,8 +903,8 @@ __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B)
             // Hs step = ca vb - cb (gs + mu D2 gn / D): the model decrease needs no second product with Hs
             double dg = 0, dHd = 0, zero = 0;
             for (int k = tid; k < N; k += kBaT) {
-                const double st = (ca * L.gdv[k] + cb * L.gn[k]) / L.D[k];
-                const double hs = ca * L.vb[k] - cb * (L.gs[k] + mu_used * L.D2[k] * L.gn[k] / L.D[k]);
+                const double st = (ca * (L.gs[k] / L.D[k]) + cb * L.gn[k]) / L.D[k];
+                const double hs = ca * L.vb[k] - cb * (L.gs[k] + mu_used * L.D[k] * L.gn[k]);
                 L.va[k] = st;
                 dg += st * L.gs[k]; dHd += st * hs;
             }

@@ -9,6 +9,7 @@
 
 #include <string>
 #include <vector>
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 
@@ -522,28 +523,33 @@ extern "C" lmono_ba_batch *lmono_ba_batch_create(lmono_ctx *c, const lmono_ba_de
         }
         fo[TF] = TO;
     }
-    // frame pairs of every window and the pair-ordered (padded to even length per pair) observation list
-    std::vector<int> pair_off((size_t)W + 1, 0), pair_ij, pobs_off((size_t)W + 1, 0), slot_info, anchor((size_t)TF, -1);
+    // frame pairs of every window (descending observation count: the waves take them from a work counter) and the
+    // pair-ordered observation list
+    std::vector<int> pair_off((size_t)W + 1, 0), pair_ij, pair_slot, pobs_off((size_t)W + 1, 0), slot_info, anchor((size_t)TF, -1);
     std::vector<double> slot_pts;
     for (int w = 0; w < W; w++) {
         pair_off[w] = (int)pair_ij.size(); pobs_off[w] = (int)slot_info.size();
         const int f0 = d->feat_off[w], f1 = d->feat_off[w + 1];
         for (int f = f0; f < f1; f++) if (fo[f + 1] > fo[f]) anchor[f] = d->obs_i[fo[f]];
-        if (!d->flags[4 * w + 3]) continue;   // use_mono == 0: the projection factors are not part of the problem
-        std::vector<std::vector<int>> by_pair((size_t)kBaMaxPoses * kBaMaxPoses);
-        for (int o = d->obs_off[w]; o < d->obs_off[w + 1]; o++) by_pair[(size_t)d->obs_i[o] * kBaMaxPoses + d->obs_j[o]].push_back(o);
-        int local = 0;
-        for (int key = 0; key < kBaMaxPoses * kBaMaxPoses; key++) {
-            const std::vector<int> &v = by_pair[(size_t)key];
-            if (v.empty()) continue;
-            pair_ij.push_back((key / kBaMaxPoses) | ((key % kBaMaxPoses) << 8));
-            for (int o : v) {
-                slot_info.push_back(d->obs_feat[o] | (local << 16));
-                for (int k = 0; k < 4; k++) slot_pts.push_back(d->obs_pts[(size_t)o * 4 + k]);
+        if (d->flags[4 * w + 3]) {   // use_mono == 0: the projection factors are not part of the problem
+            std::vector<std::vector<int>> by_pair((size_t)kBaMaxPoses * kBaMaxPoses);
+            for (int o = d->obs_off[w]; o < d->obs_off[w + 1]; o++) by_pair[(size_t)d->obs_i[o] * kBaMaxPoses + d->obs_j[o]].push_back(o);
+            std::vector<int> order;
+            for (int key = 0; key < kBaMaxPoses * kBaMaxPoses; key++) if (!by_pair[(size_t)key].empty()) order.push_back(key);
+            std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return by_pair[(size_t)x].size() > by_pair[(size_t)y].size(); });
+            int local = 0;
+            for (int key : order) {
+                const std::vector<int> &v = by_pair[(size_t)key];
+                pair_ij.push_back((key / kBaMaxPoses) | ((key % kBaMaxPoses) << 8));
+                pair_slot.push_back((int)slot_info.size() - pobs_off[w]);
+                for (int o : v) {
+                    slot_info.push_back(d->obs_feat[o] | (local << 16));
+                    for (int k = 0; k < 4; k++) slot_pts.push_back(d->obs_pts[(size_t)o * 4 + k]);
+                }
+                local++;
             }
-            if (v.size() & 1) { slot_info.push_back(0xffff | (local << 16)); for (int k = 0; k < 4; k++) slot_pts.push_back(0.0); }
-            local++;
         }
+        pair_slot.push_back((int)slot_info.size() - pobs_off[w]);   // n_pairs + 1 entries per window
     }
     pair_off[W] = (int)pair_ij.size(); pobs_off[W] = (int)slot_info.size();
     lmono_ba_batch *b = new lmono_ba_batch();
@@ -552,7 +558,7 @@ extern "C" lmono_ba_batch *lmono_ba_batch_create(lmono_ctx *c, const lmono_ba_de
     v.n_windows = W; v.max_iter = 30;
     double info[42];
     memcpy(info, d->laser_info, 36 * sizeof(double)); memcpy(info + 36, d->mono_info, 4 * sizeof(double)); memcpy(info + 40, d->prior_w, 2 * sizeof(double));
-    int *feat_off = nullptr, *obs_off = nullptr, *flags = nullptr, *anch = nullptr, *poff = nullptr, *pij = nullptr, *psoff = nullptr, *sinfo_d = nullptr;
+    int *feat_off = nullptr, *obs_off = nullptr, *flags = nullptr, *anch = nullptr, *poff = nullptr, *pij = nullptr, *psoff = nullptr, *sinfo_d = nullptr, *pslot_d = nullptr;
     double *spts_d = nullptr, *laser = nullptr, *prior = nullptr, *infod = nullptr;
     bool ok = ba_upload(b, feat_off, d->feat_off, (size_t)W + 1) && ba_upload(b, obs_off, d->obs_off, (size_t)W + 1) &&
               ba_upload(b, flags, d->flags, (size_t)W * 4) && ba_upload(b, v.poses, d->poses, (size_t)W * kBaMaxPoses * 7) &&
@@ -560,7 +566,7 @@ extern "C" lmono_ba_batch *lmono_ba_batch_create(lmono_ctx *c, const lmono_ba_de
               ba_upload(b, anch, anchor.data(), (size_t)TF) &&
               ba_upload(b, poff, pair_off.data(), (size_t)W + 1) && ba_upload(b, pij, pair_ij.data(), pair_ij.size()) &&
               ba_upload(b, psoff, pobs_off.data(), (size_t)W + 1) && ba_upload(b, sinfo_d, slot_info.data(), slot_info.size()) &&
-              ba_upload(b, spts_d, slot_pts.data(), slot_pts.size()) &&
+              ba_upload(b, spts_d, slot_pts.data(), slot_pts.size()) && ba_upload(b, pslot_d, pair_slot.data(), pair_slot.size()) &&
               ba_upload(b, laser, d->laser_consts, (size_t)W * 10 * 24) && ba_upload(b, prior, d->prior_T, (size_t)W * 16) &&
               ba_upload(b, infod, info, (size_t)42) &&
               ba_upload(b, b->poses0, d->poses, (size_t)W * kBaMaxPoses * 7) && ba_upload(b, b->ex0, d->ex, (size_t)W * 7) &&
@@ -570,7 +576,7 @@ extern "C" lmono_ba_batch *lmono_ba_batch_create(lmono_ctx *c, const lmono_ba_de
               ba_upload(b, v.cand, (const double *)nullptr, (size_t)W * kBaMaxFeat) && ba_upload(b, v.summary, (const double *)nullptr, (size_t)W * 6);
     if (!ok) { c->err = "lmono_ba_batch_create: device allocation / upload failed"; lmono_ba_batch_destroy(b); return nullptr; }
     v.feat_off = feat_off; v.obs_off = obs_off; v.flags = flags; v.feat_anchor = anch;
-    v.pair_off = poff; v.pair_ij = pij; v.pobs_off = psoff; v.slot_info = sinfo_d; v.slot_pts = spts_d;
+    v.pair_off = poff; v.pair_ij = pij; v.pobs_off = psoff; v.slot_info = sinfo_d; v.slot_pts = spts_d; v.pair_slot = pslot_d;
     v.laser_consts = laser; v.prior_T = prior; v.info = infod;
     static bool attr_set = false;
     if (!attr_set) {
