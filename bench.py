@@ -28,9 +28,7 @@ def bench_ba(args):
     initial state (<= 30 dogleg iterations).  Reported separately from the headline scans/s."""
     import torch
     import lmono_amd
-    from oracle import oracle as O
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from tests import ba_cases as K
+    from workloads import s2 as K        # synthetic S2 windows (input plumbing)
     assert torch.cuda.is_available()
     ctx = lmono_amd.Context(0)
     base = [K.make_window(s) for s in range(16)]
@@ -45,6 +43,8 @@ def bench_ba(args):
     ctx.synchronize()
     el = time.perf_counter() - t0
     poses, ex, invd, sm = b.read()
+    # ---- cpu_baseline leg: the only place the oracle is touched
+    from oracle import oracle as O
     t0 = time.time()
     ref = [O.ba_solve(w) for w in base]
     cpu_s = (time.time() - t0) / len(base)
@@ -90,7 +90,7 @@ def main():
     import torch.distributed as dist
     import lmono_amd
     from lmono_amd import sharding
-    from oracle import oracle as O   # synthetic generator (input plumbing) + cpu_baseline leg only
+    from workloads import s1 as S1       # synthetic S1 scans (input plumbing)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -109,7 +109,7 @@ def main():
     n_local = own_end - load_begin
 
     t0 = time.time()
-    w = O.S1World(n_az=args.az)
+    w = S1.S1World(n_az=args.az)
     traj = w.trajectory(n_total)
     xyzi, off = w.scans(traj[load_begin:own_end], scan_id0=load_begin)
     gen_s = time.time() - t0
@@ -220,6 +220,8 @@ def main():
             "roofline": roofline,
         }
         if sample is not None:
+            # ---- cpu_baseline leg: the only place the oracle is touched
+            from oracle import oracle as O
             sx, so = sample
             m = len(so) - 1
             t0 = time.time()

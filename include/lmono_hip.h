@@ -51,6 +51,11 @@ void              lmono_batch_destroy(lmono_scan_batch *);
  * point offsets of each scan.  n_lines in {16,32,64}; min_range = A-LOAM `minimum_range`.    */
 int lmono_scanreg_batch(lmono_ctx *, lmono_scan_batch *, const float *xyzi_d, const int64_t *offsets_h,
                         int n_scans, int n_lines, float min_range);
+/* Same with the scans in HOST memory (what the reference's node callback receives in a sensor_msgs/PointCloud2, or a
+ * KITTI .bin file read from disk): the points are staged into a batch-owned HBM buffer on the context stream first.
+ * This is the PCIe-inclusive entry; the resident-in-HBM one above is what bench.py times.                       */
+int lmono_scanreg_batch_h(lmono_ctx *, lmono_scan_batch *, const float *xyzi_h, const int64_t *offsets_h,
+                          int n_scans, int n_lines, float min_range);
 
 /* counts_h: [n_scans][6] = n_cloud, n_sharp, n_less_sharp, n_flat, n_less_flat, status          */
 int lmono_batch_counts(lmono_ctx *, lmono_scan_batch *, int32_t *counts_h);

@@ -10,7 +10,7 @@ MAX_QUERIES = 64 * 6 * 2 + 64 * 6 * 4
 # every symbol include/lmono_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "lmono_create", "lmono_destroy", "lmono_last_error", "lmono_set_stream", "lmono_synchronize", "lmono_version",
-    "lmono_batch_create", "lmono_batch_destroy", "lmono_scanreg_batch", "lmono_batch_counts", "lmono_batch_get_cloud",
+    "lmono_batch_create", "lmono_batch_destroy", "lmono_scanreg_batch", "lmono_scanreg_batch_h", "lmono_batch_counts", "lmono_batch_get_cloud",
     "lmono_batch_get_curvature", "lmono_odom_batch", "lmono_odom_batch_d", "lmono_odom_correspond", "lmono_timing_reset", "lmono_timing_read",
     "lmono_pose_prefix_d", "lmono_pose_rebase_d", "lmono_factor_eval", "lmono_factor_eval_d",
     "lmono_triangulate", "lmono_outlier_scores", "lmono_shift_depth", "lmono_marginalize", "lmono_marg_evaluate", "lmono_ba_batch_create", "lmono_ba_batch_destroy", "lmono_ba_solve", "lmono_ba_batch_reset", "lmono_ba_batch_read",
@@ -48,6 +48,7 @@ def load_library():
     L.lmono_batch_create.argtypes = [C.c_void_p, C.c_int, C.c_int64]
     L.lmono_batch_destroy.argtypes = [C.c_void_p]
     L.lmono_scanreg_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float]
+    L.lmono_scanreg_batch_h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float]
     L.lmono_batch_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.lmono_batch_get_cloud.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
     L.lmono_batch_get_curvature.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
@@ -222,6 +223,15 @@ class ScanBatch:
         self._keep = keepalive
         self.ctx.check(self.ctx.L.lmono_scanreg_batch(self.ctx.h, self.h, C.c_void_p(xyzi_dev_ptr), offsets.ctypes.data,
                                                        self.n_scans, int(n_lines), float(min_range)))
+
+    def scanreg_host(self, xyzi, offsets, n_lines=64, min_range=5.0):
+        """xyzi: [total,4] float32 numpy array in host memory (KITTI .bin layout): staged to HBM by the library."""
+        xyzi = np.ascontiguousarray(xyzi, np.float32)
+        offsets = np.ascontiguousarray(offsets, np.int64)
+        self.n_scans = len(offsets) - 1
+        self._keep = xyzi
+        self.ctx.check(self.ctx.L.lmono_scanreg_batch_h(self.ctx.h, self.h, xyzi.ctypes.data, offsets.ctypes.data,
+                                                         self.n_scans, int(n_lines), float(min_range)))
 
     def counts(self):
         out = np.zeros((self.n_scans, 6), np.int32)

@@ -52,6 +52,7 @@ struct lmono_scan_batch {
     std::vector<void *> allocs;
     BatchView v{};
     int64_t *off_d = nullptr;
+    float *in_owned = nullptr;     // staging buffer of lmono_scanreg_batch_h (pts_cap points), allocated on first use
     // odometry workspace
     int chains_cap = 0;
     double *state = nullptr, *incr = nullptr, *poses = nullptr, *xq = nullptr;
@@ -164,6 +165,27 @@ static int check_launch(lmono_ctx *c, const char *what)
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { c->err = std::string(what) + ": " + hipGetErrorString(e); return LMONO_ENODEV; }
     return LMONO_OK;
+}
+
+extern "C" int lmono_scanreg_batch(lmono_ctx *c, lmono_scan_batch *b, const float *xyzi_d, const int64_t *offsets_h,
+                                   int n_scans, int n_lines, float min_range);
+
+extern "C" int lmono_scanreg_batch_h(lmono_ctx *c, lmono_scan_batch *b, const float *xyzi_h, const int64_t *offsets_h,
+                                     int n_scans, int n_lines, float min_range)
+{
+    if (!c || !b || !xyzi_h || !offsets_h || n_scans <= 0) return LMONO_EINVAL;
+    if (offsets_h[0] != 0) { c->err = "offsets must start at 0"; return LMONO_EINVAL; }
+    const int64_t total = offsets_h[n_scans];
+    if (total < 0 || total > b->pts_cap) { c->err = "batch: too many points"; return LMONO_ECAPACITY; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!b->in_owned) {
+        void *q = nullptr;
+        HIP_TRY(c, hipMalloc(&q, (size_t)(b->pts_cap > 0 ? b->pts_cap : 1) * 16));
+        b->allocs.push_back(q);
+        b->in_owned = (float *)q;
+    }
+    if (total > 0) HIP_TRY(c, hipMemcpyAsync(b->in_owned, xyzi_h, (size_t)total * 16, hipMemcpyHostToDevice, c->stream));
+    return lmono_scanreg_batch(c, b, b->in_owned, offsets_h, n_scans, n_lines, min_range);
 }
 
 extern "C" int lmono_scanreg_batch(lmono_ctx *c, lmono_scan_batch *b, const float *xyzi_d, const int64_t *offsets_h,

@@ -288,6 +288,11 @@ void ScanRegistration::laserCloudHandler(const float *xyzi_d, const int64_t *off
     hip_.check(lmono_scanreg_batch(hip_.get(), batch_, xyzi_d, offsets_h, n_scans, N_SCANS_, MINIMUM_RANGE_), "lmono_scanreg_batch");
     n_ = n_scans;
 }
+void ScanRegistration::laserCloudHandlerHost(const float *xyzi_h, const int64_t *offsets_h, int n_scans)
+{
+    hip_.check(lmono_scanreg_batch_h(hip_.get(), batch_, xyzi_h, offsets_h, n_scans, N_SCANS_, MINIMUM_RANGE_), "lmono_scanreg_batch_h");
+    n_ = n_scans;
+}
 std::vector<float> ScanRegistration::cloud(int scan, int which)
 {
     std::vector<float> out((size_t)cap_ * 4);

@@ -123,6 +123,8 @@ public:
     ~ScanRegistration();
     // xyzi_d: scans already staged in HBM; runs the batch (one call per queue flush)
     void laserCloudHandler(const float *xyzi_d, const int64_t *offsets_h, int n_scans);
+    // same with the scans in host memory (a decoded PointCloud2 / a KITTI .bin): staged to HBM by the library
+    void laserCloudHandlerHost(const float *xyzi_h, const int64_t *offsets_h, int n_scans);
     std::vector<float> cloud(int scan, int which);          // 0 velodyne_cloud_2, 1 sharp, 2 less_sharp, 3 flat, 4 less_flat
     lmono_scan_batch *batch() const { return batch_; }
     int n_scans() const { return n_; }

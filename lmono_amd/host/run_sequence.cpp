@@ -1,0 +1,45 @@
+// lmono_amd/host/run_sequence.cpp -- KITTI-layout sequence -> scanRegistration + laserOdometry on the GPU -> trajectory
+// file in the reference's "loam_odometry" format (Estimator.cc:270).  The C++ counterpart of examples/run_sequence.py:
+//   run_sequence <sequence_dir> <out_trajectory> [first] [count] [n_chains] [lead]
+#include "kitti_io.hpp"
+#include "lmono_host.hpp"
+
+#include <cstdio>
+#include <cstdlib>
+
+using namespace lmono_host;
+
+int main(int argc, char **argv)
+{
+    if (argc < 3) { std::fprintf(stderr, "usage: run_sequence <sequence_dir> <out_trajectory> [first] [count] [n_chains] [lead]\n"); return 2; }
+    const std::string seq = argv[1], out = argv[2];
+    const int first = argc > 3 ? std::atoi(argv[3]) : 0;
+    int count = argc > 4 ? std::atoi(argv[4]) : -1;
+    const int n_chains = argc > 5 ? std::atoi(argv[5]) : 1, lead = argc > 6 ? std::atoi(argv[6]) : 0;
+    try {
+        std::vector<double> stamps;
+        if (!read_times(seq + "/times.txt", stamps)) { std::fprintf(stderr, "%s/times.txt unreadable\n", seq.c_str()); return 1; }
+        if (count < 0 || first + count > (int)stamps.size()) count = (int)stamps.size() - first;
+        if (count <= 0) { std::fprintf(stderr, "no scans\n"); return 1; }
+        std::vector<float> xyzi;
+        std::vector<int64_t> off(1, 0);
+        for (int k = 0; k < count; k++) {
+            const long n = read_velodyne_bin(velodyne_path(seq, first + k), xyzi);
+            if (n < 0) { std::fprintf(stderr, "%s unreadable\n", velodyne_path(seq, first + k).c_str()); return 1; }
+            off.push_back(off.back() + n);
+        }
+        HipContext hip(0);
+        ScanRegistration reg(hip, count, off.back());
+        reg.laserCloudHandlerHost(xyzi.data(), off.data(), count);
+        LaserOdometry odo(hip);
+        const std::vector<double> poses = odo.process(reg, n_chains, lead);
+        TrajectoryWriter w(out, 1);
+        if (!w.ok()) { std::fprintf(stderr, "cannot write %s\n", out.c_str()); return 1; }
+        for (int k = 0; k < count; k++) w.write(stamps[(size_t)(first + k)], &poses[(size_t)k * 7 + 4], &poses[(size_t)k * 7]);
+        std::printf("DONE %d scans %lld points\n", count, (long long)off.back());
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "run_sequence: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

@@ -68,19 +68,9 @@ int lo_odom_step(const lo_pt *sharp, int n_sharp, const lo_pt *flat, int n_flat,
 void lo_pose_accumulate(double q_w[4], double t_w[3], const double q[4], const double t[3]);
 
 /* ---- synthetic HDL-64 generator S1 ---- */
-typedef struct {
-    int n_boxes;   const double *boxes;     /* [n_boxes][6]  xmin ymin zmin xmax ymax zmax */
-    int n_cyls;    const double *cyls;      /* [n_cyls][4]   cx cy radius height(top z)     */
-    double ground_z;
-    int n_rings;   const double *elev_rad;  /* [n_rings] elevation angles                  */
-    int n_az;                               /* azimuth steps per ring                       */
-    double range_sigma, dropout, max_range;
-    uint64_t seed;
-} lo_world;
 
-/* pose: sensor position (x,y,z) and yaw.  Writes up to n_rings*n_az points (ring-major,
- * azimuth ascending in firing order) as xyzi float32; returns the number written. */
-int lo_synth_scan(const lo_world *w, const double pose_xyzyaw[4], uint64_t scan_id, float *xyzi_out);
+
+
 
 #ifdef __cplusplus
 }

@@ -50,3 +50,16 @@ def test_product_does_not_import_oracle():
                 txt = open(os.path.join(dp, f)).read()
                 assert "oracle/" not in txt.replace("CPU oracle", "") or "#include" not in txt.split("oracle/")[0][-40:], f
                 assert "from oracle" not in txt and "import oracle" not in txt and "liblmono_oracle" not in txt, f
+
+
+def test_bench_touches_oracle_only_in_cpu_baseline_leg():
+    """bench.py may use oracle/ only as the cpu_baseline (and the parity figures reported with it); inputs come from
+    workloads/, which must not depend on the oracle either."""
+    src = open(os.path.join(ROOT, "bench.py")).read().split("\n")
+    for k, line in enumerate(src):
+        if "from oracle" in line or "import oracle" in line:
+            assert "cpu_baseline leg" in src[k - 1], "oracle import outside the cpu_baseline leg: line %d" % (k + 1)
+    for f in os.listdir(os.path.join(ROOT, "workloads")):
+        if f.endswith((".py", ".c", ".h")):
+            txt = open(os.path.join(ROOT, "workloads", f)).read()
+            assert "from oracle" not in txt and "import oracle" not in txt and "lo_oracle.h" not in txt, f

@@ -1,0 +1,58 @@
+"""BASELINE configs[0] plumbing on the GPU: a KITTI-layout sequence on disk -> host-buffer entry of the C ABI
+(lmono_scanreg_batch_h) -> laserOdometry -> trajectory file in the reference's format, through the Python wrapper and
+through the C++ host mirror (lmono_amd/host/run_sequence), both against the CPU oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from lmono_amd import kitti_io as IO
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "lmono_amd", "host")
+
+
+@pytest.fixture(scope="module")
+def sequence_on_disk(oracle, tmp_path_factory):
+    root = tmp_path_factory.mktemp("kitti_seq")
+    w = oracle.S1World(n_az=500)
+    xyzi, off = w.scans(w.trajectory(6))
+    os.makedirs(root / "velodyne")
+    for k in range(6):
+        IO.write_velodyne_bin(IO.velodyne_path(str(root), k), xyzi[off[k]:off[k + 1]])
+    np.savetxt(root / "times.txt", 100.0 + 0.1 * np.arange(6), fmt="%.6f")
+    ref = oracle.run_sequence(xyzi, off, threads=1)
+    return str(root), xyzi, off, ref
+
+
+def test_host_buffer_entry_matches_device_pointer_entry_and_oracle(sequence_on_disk, gpu_ctx):
+    import torch
+    import lmono_amd
+    root, xyzi, off, ref = sequence_on_disk
+    x2, o2, stamps = IO.load_scans(root)
+    assert np.array_equal(x2, xyzi) and np.array_equal(o2, off)
+    b1 = lmono_amd.ScanBatch(gpu_ctx, 6, len(xyzi))
+    b1.scanreg_host(x2, o2, 64, 5.0)
+    _, p1 = b1.odometry(n_chains=1, lead=0)
+    xd = torch.from_numpy(xyzi).cuda()
+    b2 = lmono_amd.ScanBatch(gpu_ctx, 6, len(xyzi))
+    b2.scanreg(xd.data_ptr(), off, 64, 5.0, keepalive=xd)
+    _, p2 = b2.odometry(n_chains=1, lead=0)
+    assert np.array_equal(p1, p2)                       # same kernels, same data: bit-identical
+    assert np.abs(p1 - ref["poses"]).max() < 1e-6       # and the CPU oracle's trajectory
+
+
+def test_cpp_run_sequence_writes_the_reference_format(sequence_on_disk, tmp_path):
+    root, xyzi, off, ref = sequence_on_disk
+    subprocess.check_call(["make", "-s", "-C", HOST, "run_sequence"])
+    out = tmp_path / "loam_odometry.txt"
+    txt = subprocess.check_output([os.path.join(HOST, "run_sequence"), root, str(out)], text=True)
+    assert txt.startswith("DONE 6 scans")
+    lines = out.read_text().split("\n")
+    assert len(lines) == 7 and all(line.endswith(" ") for line in lines[:6])      # Estimator.cc:270: blank before \n
+    traj = IO.read_trajectory(str(out))
+    assert np.allclose(traj[:, 0], 100.0 + 0.1 * np.arange(6))
+    # six printed decimals of the oracle's poses (t then q)
+    assert np.abs(traj[:, 1:4] - ref["poses"][:, 4:7]).max() < 2e-6 and np.abs(traj[:, 4:8] - ref["poses"][:, 0:4]).max() < 2e-6

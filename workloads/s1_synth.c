@@ -1,12 +1,12 @@
 /*
- * oracle/lo_synth.c -- TEST INFRASTRUCTURE.  Synthetic HDL-64 scan generator "S1"
+ * workloads/s1_synth.c -- INPUT PLUMBING (not the hot path, not the oracle).  Synthetic HDL-64 scan generator "S1"
  * (SURVEY.md 8d): ground plane + axis-aligned boxes + vertical cylinders, ring-major point order
  * like KITTI velodyne .bin files (float32 x y z reflectance), one clockwise sweep per ring starting
  * at the rear of the vehicle, Gaussian range noise, random drop-outs, no motion distortion
  * (KITTI scans are already de-skewed; A-LOAM runs them with DISTORTION 0).
  * This is input plumbing shared by tests and bench.py; it is not part of the hot path.
  */
-#include "lo_oracle.h"
+#include "s1_synth.h"
 #include <math.h>
 #include <stdlib.h>
 

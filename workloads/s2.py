@@ -1,0 +1,123 @@
+"""workloads/s2.py -- synthetic workload S2: one Estimator sliding window as optimization() sees it
+(KITTI-05 intrinsics / extrinsic / weights, <= 150 tracks per frame).  Input plumbing for tests and bench.py."""
+import numpy as np
+
+
+def quat_R(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+# laser_to_camera0 of kitti_config_05.yaml (mono_lidar_mapping/config/kitti_config_05.yaml:27-30)
+def kitti_extrinsic():
+    T = np.eye(4)
+    T[:3, :3] = np.array([[0.0, 0.0, 1.0], [-1.0, 0.0, 0.0], [0.0, -1.0, 0.0]])   # camera z forward -> lidar x forward
+    T[:3, 3] = [0.27, 0.0, -0.08]
+    return T
+
+
+def R_to_q(m):
+    """Eigen Quaternion(Matrix3) constructor: xyzw."""
+    t = m[0, 0] + m[1, 1] + m[2, 2]
+    q = np.zeros(4)
+    if t > 0:
+        t = np.sqrt(t + 1.0)
+        q[3] = 0.5 * t
+        t = 0.5 / t
+        q[0] = (m[2, 1] - m[1, 2]) * t
+        q[1] = (m[0, 2] - m[2, 0]) * t
+        q[2] = (m[1, 0] - m[0, 1]) * t
+    else:
+        i = 0
+        if m[1, 1] > m[0, 0]:
+            i = 1
+        if m[2, 2] > m[i, i]:
+            i = 2
+        j = (i + 1) % 3
+        k = (j + 1) % 3
+        t = np.sqrt(m[i, i] - m[j, j] - m[k, k] + 1.0)
+        q[i] = 0.5 * t
+        t = 0.5 / t
+        q[3] = (m[k, j] - m[j, k]) * t
+        q[j] = (m[j, i] + m[i, j]) * t
+        q[k] = (m[k, i] + m[i, k]) * t
+    return q
+
+
+FX, FY, CX, CY, W_IMG, H_IMG = 707.0912, 707.0912, 601.8873, 183.1104, 1241, 376
+
+
+def make_window(seed=0, n_frames=11, n_landmarks=4000, max_tracks=150, pix_sigma=0.5, odo_sigma_t=0.01, odo_sigma_r=np.deg2rad(0.05),
+                track_cnt=3, use_prior=True, perturb=True):
+    """One Estimator window as optimization() sees it (Estimator.cc:1124-1215): state, feature tracks, LiDAR increments."""
+    rng = np.random.default_rng(20241 + seed)
+    T = kitti_extrinsic()                       # laser <- camera
+    Rlc, tlc = T[:3, :3], T[:3, 3]
+    # LiDAR ground-truth poses in the LiDAR odometry frame: forward 0.8 m / frame, gentle yaw
+    L0_R, L0_P = [], []
+    yaw, pos = 0.0, np.zeros(3)
+    for k in range(n_frames):
+        c, s = np.cos(yaw), np.sin(yaw)
+        L0_R.append(np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])); L0_P.append(pos.copy())
+        pos = pos + L0_R[-1] @ np.array([0.8, 0, 0]); yaw += rng.normal(0.01, 0.005)
+    # Estimator world: Rs = Rlc^T L0_R, Ps = Rlc^T (L0_P - tlc)   (Estimator.cc:995-996)
+    Rs = [Rlc.T @ R for R in L0_R]; Ps = [Rlc.T @ (P - tlc) for P in L0_P]
+    cam_R = [Rs[k] @ Rlc for k in range(n_frames)]; cam_P = [Ps[k] + Rs[k] @ tlc for k in range(n_frames)]
+    # landmarks in a corridor ahead of the path, expressed in the Estimator world (camera-aligned: z forward, y down)
+    lm_l = np.stack([rng.uniform(2, 120, n_landmarks), rng.uniform(-20, 20, n_landmarks), rng.uniform(-1.5, 6.5, n_landmarks)], 1)
+    lm = (Rlc.T @ (lm_l - tlc).T).T
+    tracks = {}
+    alive = []
+    for k in range(n_frames):
+        pc = (cam_R[k].T @ (lm - cam_P[k]).T).T
+        z = pc[:, 2]
+        u = FX * pc[:, 0] / z + CX; v = FY * pc[:, 1] / z + CY
+        vis = (z > 1.0) & (u > 0) & (u < W_IMG) & (v > 0) & (v < H_IMG)
+        alive = [t for t in alive if vis[t] and rng.uniform() > 0.1]
+        cand = [t for t in np.nonzero(vis)[0] if t not in tracks]
+        rng.shuffle(cand)
+        taken = [(u[t], v[t]) for t in alive]
+        for t in cand:
+            if len(alive) >= max_tracks:
+                break
+            if all((u[t] - a) ** 2 + (v[t] - b) ** 2 > 30 ** 2 for a, b in taken):
+                alive.append(t); taken.append((u[t], v[t])); tracks[t] = (k, [])
+        for t in alive:
+            un = (u[t] + rng.normal(0, pix_sigma) - CX) / FX; vn = (v[t] + rng.normal(0, pix_sigma) - CY) / FY
+            tracks[t][1].append((un, vn))
+    feat_depth, obs_feat, obs_i, obs_j, obs_pts = [], [], [], [], []
+    trk_start, trk_off, trk_pts, trk_true = [], [0], [], []
+    for t, (k0, obs) in sorted(tracks.items(), key=lambda kv: (kv[1][0], kv[0])):
+        if len(obs) < track_cnt:
+            continue
+        f = len(feat_depth)
+        trk_start.append(k0); trk_pts.extend(obs); trk_off.append(trk_off[-1] + len(obs))
+        trk_true.append((cam_R[k0].T @ (lm[t] - cam_P[k0]))[2])
+        z0 = (cam_R[k0].T @ (lm[t] - cam_P[k0]))[2]
+        feat_depth.append(z0 * (1 + rng.normal(0, 0.05)))
+        for d, (un, vn) in enumerate(obs):
+            if d == 0:
+                continue
+            obs_feat.append(f); obs_i.append(k0); obs_j.append(k0 + d); obs_pts.append([obs[0][0], obs[0][1], un, vn])
+    # LiDAR odometry input: ground truth + noise; LASERFactor consts are (L0_Ri, L0_Rj, L0_Pi, L0_Pj)
+    nR = [R @ quat_R(np.concatenate([rng.normal(0, odo_sigma_r / 2, 3), [1.0]]) / 1.0) for R in L0_R]
+    nP = [P + rng.normal(0, odo_sigma_t, 3) for P in L0_P]
+    laser = np.array([np.concatenate([nR[k].ravel(), nR[k + 1].ravel(), nP[k], nP[k + 1]]) for k in range(n_frames - 1)])
+    # window state: ground truth, newest frame one motion behind (slideWindow keeps the previous newest pose), small noise
+    poses = []
+    for k in range(n_frames):
+        kk = k if (k < n_frames - 1 or not perturb) else k - 1
+        q = R_to_q(Rs[kk]); p = Ps[kk].copy()
+        if perturb:
+            p = p + rng.normal(0, 0.01, 3)
+        poses.append(np.concatenate([p, q]))
+    ex = np.concatenate([tlc, R_to_q(Rlc)])
+    return dict(poses=np.array(poses), ex=ex, inv_depth=1.0 / np.array(feat_depth),
+                obs_feat=np.array(obs_feat, np.int32), obs_i=np.array(obs_i, np.int32), obs_j=np.array(obs_j, np.int32),
+                obs_pts=np.array(obs_pts), laser_consts=laser, laser_info=(3.0 * 1500.0) * np.eye(6), mono_info=1500.0 * np.eye(2),
+                prior_T=T.copy(), prior_w=np.array([1000.0, 1000.0]), use_prior=use_prior, ex_constant=False, use_mono=True,
+                gt_Rs=np.array(Rs), gt_Ps=np.array(Ps), tlc=T.copy(),
+                trk_start=np.array(trk_start, np.int32), trk_off=np.array(trk_off, np.int32), trk_pts=np.array(trk_pts),
+                trk_true_depth=np.array(trk_true))
