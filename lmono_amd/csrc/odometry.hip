@@ -640,37 +640,31 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
         }
         const int b_end = b_lo + nbins;
         // lanes 0..4: bucket bounds of lines ra-2..ra+2 (two runs when the arc wraps past the last bin)
-        int r0a[5], r1a[5], r0b[5], r1b[5];
+        int u0 = 0, u1 = 0, u2 = 0, u3 = 0;
         {
-            int u0 = 0, u1 = 0, u2 = 0, u3 = 0;
             const int v = ra - 2 + gl;
             if (gl < 5 && v >= 0 && v <= 65 && !(edge && v == ra)) {   // edges never use the nearest point's own line
                 const int *row = table + v * kAzBins;
                 u0 = row[b_lo]; u1 = row[min(b_end, kAzBins)];
                 if (b_end > kAzBins) { u2 = row[0]; u3 = row[b_end - kAzBins]; }
             }
-#pragma unroll
-            for (int vi = 0; vi < 5; vi++) {
-                r0a[vi] = __shfl(u0, vi, kGroup); r1a[vi] = __shfl(u1, vi, kGroup);
-                r0b[vi] = __shfl(u2, vi, kGroup); r1b[vi] = __shfl(u3, vi, kGroup);
-            }
         }
         WalkBest bs = { 25.0f, 0u }, bo = { 25.0f, 0u };
         for (int part = 0; part < 2; part++) {
             if (part == 1 && b_end <= kAzBins) break;
+            int r0[5], r1[5];
             float4 v5[5];
 #pragma unroll
             for (int vi = 0; vi < 5; vi++) {
-                const int r0 = part ? r0b[vi] : r0a[vi], r1 = part ? r1b[vi] : r1a[vi];
+                r0[vi] = __shfl(part ? u2 : u0, vi, kGroup); r1[vi] = __shfl(part ? u3 : u1, vi, kGroup);
                 v5[vi] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-                if (r0 + gl < r1) v5[vi] = lb_pts[r0 + gl];
+                if (r0[vi] + gl < r1[vi]) v5[vi] = lb_pts[r0[vi] + gl];
             }
 #pragma unroll
             for (int vi = 0; vi < 5; vi++) {
-                const int r0 = part ? r0b[vi] : r0a[vi], r1 = part ? r1b[vi] : r1a[vi];
                 const int v = ra - 2 + vi;
-                if (r0 + gl < r1) walk_point(v5[vi], v, ra, closest, w_lo, w_hi, edge, qx, qy, qz, bs, bo);
-                for (int i = r0 + gl + kGroup; i < r1; i += kGroup) walk_point(lb_pts[i], v, ra, closest, w_lo, w_hi, edge, qx, qy, qz, bs, bo);
+                if (r0[vi] + gl < r1[vi]) walk_point(v5[vi], v, ra, closest, w_lo, w_hi, edge, qx, qy, qz, bs, bo);
+                for (int i = r0[vi] + gl + kGroup; i < r1[vi]; i += kGroup) walk_point(lb_pts[i], v, ra, closest, w_lo, w_hi, edge, qx, qy, qz, bs, bo);
             }
         }
         same = group_min_u64(bs.d < 25.0f ? pack_fu(bs.d, bs.seq) : thr);
