@@ -652,19 +652,29 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
         WalkBest bs = { 25.0f, 0u }, bo = { 25.0f, 0u };
         for (int part = 0; part < 2; part++) {
             if (part == 1 && b_end <= kAzBins) break;
-            int r0[5], r1[5];
-            float4 v5[5];
+            // rows in two sub-batches (3 + 2): the loads of a sub-batch are issued back to back
 #pragma unroll
-            for (int vi = 0; vi < 5; vi++) {
-                r0[vi] = __shfl(part ? u2 : u0, vi, kGroup); r1[vi] = __shfl(part ? u3 : u1, vi, kGroup);
-                v5[vi] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-                if (r0[vi] + gl < r1[vi]) v5[vi] = lb_pts[r0[vi] + gl];
-            }
+            for (int v0 = 0; v0 < 5; v0 += 3) {
+                int r0[3], r1[3];
+                float4 v3[3];
 #pragma unroll
-            for (int vi = 0; vi < 5; vi++) {
-                const int v = ra - 2 + vi;
-                if (r0[vi] + gl < r1[vi]) walk_point(v5[vi], v, ra, closest, w_lo, w_hi, edge, qx, qy, qz, bs, bo);
-                for (int i = r0[vi] + gl + kGroup; i < r1[vi]; i += kGroup) walk_point(lb_pts[i], v, ra, closest, w_lo, w_hi, edge, qx, qy, qz, bs, bo);
+                for (int w = 0; w < 3; w++) {
+                    const int vi = v0 + w;
+                    r0[w] = 0; r1[w] = 0;
+                    v3[w] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+                    if (vi < 5) {
+                        r0[w] = __shfl(part ? u2 : u0, vi, kGroup); r1[w] = __shfl(part ? u3 : u1, vi, kGroup);
+                        if (r0[w] + gl < r1[w]) v3[w] = lb_pts[r0[w] + gl];
+                    }
+                }
+#pragma unroll
+                for (int w = 0; w < 3; w++) {
+                    const int vi = v0 + w;
+                    if (vi >= 5) continue;
+                    const int v = ra - 2 + vi;
+                    if (r0[w] + gl < r1[w]) walk_point(v3[w], v, ra, closest, w_lo, w_hi, edge, qx, qy, qz, bs, bo);
+                    for (int i = r0[w] + gl + kGroup; i < r1[w]; i += kGroup) walk_point(lb_pts[i], v, ra, closest, w_lo, w_hi, edge, qx, qy, qz, bs, bo);
+                }
             }
         }
         same = group_min_u64(bs.d < 25.0f ? pack_fu(bs.d, bs.seq) : thr);
@@ -690,7 +700,7 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
 // grid / index / point data of a chain's "last" scan then stay in that XCD's L2 for its 1836 features.
 constexpr int kCorrBlocks = kMaxQueries / 8;
 
-__global__ __launch_bounds__(256, 6) void k_correspond(BatchView b, OdomView o, int step)
+__global__ __launch_bounds__(256, 7) void k_correspond(BatchView b, OdomView o, int step)
 {
     const int xcd = blockIdx.x & 7, u = blockIdx.x >> 3;
     const int c = (u / kCorrBlocks) * 8 + xcd;
