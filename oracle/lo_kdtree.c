@@ -131,6 +131,43 @@ int lo_kdtree_nn(const lo_kdtree *t, float qx, float qy, float qz, float *d2)
     return bi;
 }
 
+/* ---- k nearest (pcl::KdTreeFLANN::nearestKSearch(k) as used by laserMapping with k = 5): exact, ascending
+ * (distance, index); a bounded insertion list stands in for FLANN's result set ---- */
+typedef struct { int k, n; int *idx; float *d2; } knn_set;
+static inline float knn_worst(const knn_set *s) { return s->n < s->k ? FLT_MAX : s->d2[s->n - 1]; }
+static void knn_push(knn_set *s, float d, int pi)
+{
+    if (s->n == s->k) {
+        const float wd = s->d2[s->n - 1]; const int wi = s->idx[s->n - 1];
+        if (!(d < wd || (d == wd && pi < wi))) return;
+        s->n--;
+    }
+    int j = s->n++;
+    while (j > 0 && (s->d2[j - 1] > d || (s->d2[j - 1] == d && s->idx[j - 1] > pi))) { s->d2[j] = s->d2[j - 1]; s->idx[j] = s->idx[j - 1]; j--; }
+    s->d2[j] = d; s->idx[j] = pi;
+}
+static void search_k(const lo_kdtree *t, int id, float qx, float qy, float qz, knn_set *s)
+{
+    const kd_node *nd = &t->nodes[id];
+    if (nd->left < 0) {
+        for (int i = nd->lo; i < nd->hi; i++) { const int pi = t->perm[i]; knn_push(s, dist2(&t->pts[pi], qx, qy, qz), pi); }
+        return;
+    }
+    const float qv = nd->dim == 0 ? qx : (nd->dim == 1 ? qy : qz);
+    const float dl = qv - nd->split_lo, dr = nd->split_hi - qv;
+    const int first = dl < dr ? nd->left : nd->right;
+    const int second = first == nd->left ? nd->right : nd->left;
+    search_k(t, first, qx, qy, qz, s);
+    const float gap = second == nd->left ? dl : dr;
+    if (gap <= 0.f || gap * gap <= knn_worst(s)) search_k(t, second, qx, qy, qz, s);
+}
+int lo_kdtree_knn(const lo_kdtree *t, float qx, float qy, float qz, int k, int *idx, float *d2)
+{
+    knn_set s = { k, 0, idx, d2 };
+    if (t->n > 0 && k > 0) search_k(t, 0, qx, qy, qz, &s);
+    return s.n;
+}
+
 int lo_brute_nn(const lo_pt *pts, int n, float qx, float qy, float qz, float *d2)
 {
     float best = FLT_MAX; int bi = -1;

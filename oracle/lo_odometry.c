@@ -81,11 +81,9 @@ static void jet_transform(const double x[7], const float cp[3], jet lp[3])
 }
 
 /* ---------- correspondences ---------- */
-typedef struct {
-    int kind;      /* 1 edge, 2 plane */
-    float cp[3];
-    double a[3], b[3];   /* edge: lpa, lpb ; plane: lpj in a, unit normal in b */
-} corr;
+/* lo_corr (lo_oracle.h): kind 1 edge (a, b = the two line points), 2 plane (a = point j, b = unit normal),
+ * 3 plane-norm of laserMapping (b = unit normal, a[0] = negative_OA_dot_norm: r = n . lp + d) */
+typedef lo_corr corr;
 
 /* EigenQuaternionParameterization::ComputeJacobian (4x3, rows x,y,z,w) */
 static void quat_local_jac(const double q[4], double J[12])
@@ -142,8 +140,12 @@ static double evaluate(const corr *cs, int nc, const double x[7], double *H, dou
             double den = sqrt(dex * dex + dey * dey + dez * dez);
             double r0 = nux / den, r1 = nuy / den, r2 = nuz / den;
             sq = r0 * r0 + r1 * r1 + r2 * r2;
-        } else {
+        } else if (cs[c].kind == 2) {
             double r0 = (lp[0] - cs[c].a[0]) * cs[c].b[0] + (lp[1] - cs[c].a[1]) * cs[c].b[1] + (lp[2] - cs[c].a[2]) * cs[c].b[2];
+            sq = r0 * r0;
+        } else {
+            /* LidarPlaneNormFactor: norm.dot(point_w) + negative_OA_dot_norm */
+            double r0 = (cs[c].b[0] * lp[0] + cs[c].b[1] * lp[1] + cs[c].b[2] * lp[2]) + cs[c].a[0];
             sq = r0 * r0;
         }
         double rho[3];
@@ -168,9 +170,12 @@ static double evaluate(const corr *cs, int nc, const double x[7], double *H, dou
             /* value path uses a true division like Jet / Jet */
             res[0].v = nux.v / den; res[1].v = nuy.v / den; res[2].v = nuz.v / den;
             nr = 3;
-        } else {
+        } else if (cs[c].kind == 2) {
             jet dx = jsub(lp[0], jc(cs[c].a[0])), dy = jsub(lp[1], jc(cs[c].a[1])), dz = jsub(lp[2], jc(cs[c].a[2]));
             res[0] = jadd(jadd(jscale(dx, cs[c].b[0]), jscale(dy, cs[c].b[1])), jscale(dz, cs[c].b[2]));
+            nr = 1;
+        } else {
+            res[0] = jadd(jadd(jadd(jscale(lp[0], cs[c].b[0]), jscale(lp[1], cs[c].b[1])), jscale(lp[2], cs[c].b[2])), jc(cs[c].a[0]));
             nr = 1;
         }
         double sq = 0.0;
@@ -229,7 +234,7 @@ static int chol_solve6(const double *A, const double *b, double *x)
 static double norm7(const double *x) { double s = 0; for (int i = 0; i < 7; i++) s += x[i] * x[i]; return sqrt(s); }
 
 /* ceres::Solve restated (TrustRegionMinimizer, LEVENBERG_MARQUARDT, max_num_iterations = 4) */
-static int lm_solve(const corr *cs, int nc, double x[7], double *cost0, double *cost1)
+int lo_lm_solve(const lo_corr *cs, int nc, double x[7], double *cost0, double *cost1)
 {
     const int max_iter = 4;
     const double function_tol = 1e-6, gradient_tol = 1e-10, parameter_tol = 1e-8;
@@ -402,7 +407,7 @@ int lo_odom_step(const lo_pt *sharp, int n_sharp, const lo_pt *flat, int n_flat,
             }
         }
         double c0, c1;
-        int it = lm_solve(cs, nc, x, &c0, &c1);
+        int it = lo_lm_solve(cs, nc, x, &c0, &c1);
         if (stats) {
             stats->n_corner_corr[opti] = n_edge; stats->n_plane_corr[opti] = n_plane;
             stats->lm_iters[opti] = it; stats->initial_cost[opti] = c0; stats->final_cost[opti] = c1;

@@ -46,6 +46,18 @@ void lo_kdtree_free(lo_kdtree *t);
 int lo_kdtree_nn(const lo_kdtree *t, float qx, float qy, float qz, float *d2);
 int lo_brute_nn(const lo_pt *pts, int n, float qx, float qy, float qz, float *d2);
 
+/* k nearest neighbours in ascending (distance, index) order; returns the number found (< k only when n < k) */
+int lo_kdtree_knn(const lo_kdtree *t, float qx, float qy, float qz, int k, int *idx, float *d2);
+
+/* pcl::VoxelGrid restated (cubic leaf, inv_leaf = 1.0f / leaf); out has capacity n; returns the output size */
+int lo_voxel_filter(const lo_pt *in, int n, float inv_leaf, lo_pt *out);
+
+/* residual block of the LiDAR solves: kind 1 edge (a, b = line points), 2 plane (a = point j, b = unit normal),
+ * 3 plane-norm of laserMapping (b = unit normal, a[0] = negative_OA_dot_norm) */
+typedef struct { int kind; float cp[3]; double a[3], b[3]; } lo_corr;
+/* ceres::Solve restated (trust-region LM, <= 4 iterations, Huber 0.1); x = q(xyzw), t in/out; returns iterations */
+int lo_lm_solve(const lo_corr *cs, int nc, double x[7], double *cost0, double *cost1);
+
 /* ---- laserOdometry (A-LOAM laserOdometry.cpp main loop) ---- */
 typedef struct {
     int n_corner_corr[2];   /* correspondences per outer iteration */
@@ -71,6 +83,31 @@ void lo_pose_accumulate(double q_w[4], double t_w[3], const double q[4], const d
 
 
 
+
+/* ---- laserMapping (A-LOAM laserMapping.cpp process()) ---- */
+typedef struct lo_map lo_map;
+typedef struct {
+    int n_corner_stack, n_surf_stack;     /* down-sampled scan clouds                         */
+    int n_corner_map, n_surf_map;         /* map points in the 5 x 5 x 3 cube neighbourhood   */
+    int n_edge[2], n_plane[2];            /* residual blocks per outer iteration              */
+    int lm_iters[2];
+    double final_cost[2];
+} lo_map_stats;
+lo_map *lo_map_create(float line_res, float plane_res);     /* HDL-64 launch: 0.4, 0.8 */
+void lo_map_free(lo_map *);
+/* One frame: corner_last / surf_last = the scan's less-sharp / less-flat clouds (sensor frame), q_wodom / t_wodom =
+ * laserOdometry's pose of the scan.  Writes the refined pose (aft_mapped_to_init) and updates the map. */
+int lo_map_process(lo_map *, const lo_pt *corner_last, int n_corner, const lo_pt *surf_last, int n_surf,
+                   const double q_wodom[4], const double t_wodom[3], double q_w_curr[4], double t_w_curr[3], lo_map_stats *);
+/* introspection for the tests: cube (i, j, k) of the 21 x 21 x 11 arrays; which = 0 corner, 1 surf */
+int lo_map_cube(const lo_map *, int which, int i, int j, int k, const lo_pt **pts);
+void lo_map_centre(const lo_map *, int cen[3]);
+int lo_run_mapping(const float *xyzi, const int64_t *offsets, int n_scans, int n_lines, float min_range,
+                   float line_res, float plane_res, int threads, const double *poses_odom, double *poses_mapped,
+                   lo_map_stats *stats, double *stage_ms);
+/* building blocks (exposed for the tests): ascending eigen-decomposition of a symmetric 3x3, and the 5-point plane fit */
+void lo_sym_eig3(const double A[9], double evals[3], double evecs[9] /* columns = eigenvectors */);
+int lo_plane_fit5(const double pts[15], double norm[3], double *negative_OA_dot_norm);
 
 #ifdef __cplusplus
 }

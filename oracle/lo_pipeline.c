@@ -95,3 +95,42 @@ int lo_run_sequence(const float *xyzi, const int64_t *offsets, int n_scans, int 
     free(F);
     return rc;
 }
+
+/* laserMapping over a sequence: scanRegistration of every scan, then lo_map_process frame by frame with
+ * the given laserOdometry poses poses_odom[n][7] (q xyzw, t).  poses_mapped: [n][7]; stats: [n] or NULL;
+ * stage_ms: [2] wall-clock scanreg, mapping. */
+int lo_run_mapping(const float *xyzi, const int64_t *offsets, int n_scans, int n_lines, float min_range,
+                   float line_res, float plane_res, int threads, const double *poses_odom, double *poses_mapped,
+                   lo_map_stats *stats, double *stage_ms)
+{
+    if (n_scans <= 0) return 0;
+    if (threads < 1) threads = 1;
+    scan_feats *F = (scan_feats *)calloc((size_t)n_scans, sizeof(scan_feats));
+    int rc = 0;
+    double t0 = now_ms();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+    for (int s = 0; s < n_scans; s++) {
+        int n = (int)(offsets[s + 1] - offsets[s]);
+        size_t cap = (size_t)(n > 0 ? n : 1);
+        lo_pt *cloud = (lo_pt *)malloc(sizeof(lo_pt) * cap);
+        float *curv = (float *)malloc(sizeof(float) * cap);
+        int32_t *label = (int32_t *)malloc(sizeof(int32_t) * cap);
+        lo_pt *ls = (lo_pt *)malloc(sizeof(lo_pt) * cap), *lf = (lo_pt *)malloc(sizeof(lo_pt) * cap);
+        lo_pt *sh = (lo_pt *)malloc(sizeof(lo_pt) * cap), *fl = (lo_pt *)malloc(sizeof(lo_pt) * cap);
+        int r = lo_scanreg(xyzi + 4 * offsets[s], n, n_lines, min_range, cloud, curv, label, sh, ls, fl, lf, &F[s].info);
+        if (r != 0) rc = r;
+        F[s].less_sharp = ls; F[s].less_flat = lf;
+        free(cloud); free(curv); free(label); free(sh); free(fl);
+    }
+    double t1 = now_ms();
+    lo_map *m = lo_map_create(line_res, plane_res);
+    for (int k = 0; k < n_scans; k++)
+        lo_map_process(m, F[k].less_sharp, F[k].info.n_less_sharp, F[k].less_flat, F[k].info.n_less_flat,
+                       poses_odom + 7 * k, poses_odom + 7 * k + 4, poses_mapped + 7 * k, poses_mapped + 7 * k + 4, stats ? stats + k : NULL);
+    lo_map_free(m);
+    double t2 = now_ms();
+    if (stage_ms) { stage_ms[0] = t1 - t0; stage_ms[1] = t2 - t1; }
+    for (int s = 0; s < n_scans; s++) { free(F[s].less_sharp); free(F[s].less_flat); }
+    free(F);
+    return rc;
+}

@@ -73,10 +73,11 @@ static int cmp_vox(const void *a, const void *b)
     if (x->cell != y->cell) return x->cell < y->cell ? -1 : 1;
     return (x->idx > y->idx) - (x->idx < y->idx);
 }
-static int voxel_downsample(const lo_pt *in, int n, lo_pt *out)
+/* pcl::VoxelGrid with a cubic leaf (inverse_leaf_size_ = 1.0f / leaf as PCL computes it), all fields averaged, output in
+ * ascending cell index, the points of a cell summed in index order */
+int lo_voxel_filter(const lo_pt *in, int n, float inv_leaf, lo_pt *out)
 {
     if (n == 0) return 0;
-    const float inv_leaf = 5.0f; /* 1.0f / 0.2f rounds to 5.0f */
     float mn[3] = { in[0].x, in[0].y, in[0].z }, mx[3] = { in[0].x, in[0].y, in[0].z };
     for (int i = 1; i < n; i++) {
         const float p[3] = { in[i].x, in[i].y, in[i].z };
@@ -118,6 +119,7 @@ static int voxel_downsample(const lo_pt *in, int n, lo_pt *out)
     free(keys);
     return n_out;
 }
+static int voxel_downsample(const lo_pt *in, int n, lo_pt *out) { return lo_voxel_filter(in, n, 5.0f /* 1.0f / 0.2f rounds to 5.0f */, out); }
 
 int lo_scanreg(const float *xyzi, int n, int n_scans, float min_range,
                lo_pt *cloud, float *curvature, int32_t *label,

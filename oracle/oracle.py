@@ -127,6 +127,104 @@ def run_sequence(xyzi, offsets, n_lines=64, min_range=5.0, n_chains=1, lead=0, u
     return dict(incr=incr, poses=poses, feat_counts=counts, stage_ms=ms)
 
 
+# --------------------------------------------------------------------------------------------
+# laserMapping
+# --------------------------------------------------------------------------------------------
+class MapStats(C.Structure):
+    _fields_ = [("n_corner_stack", C.c_int), ("n_surf_stack", C.c_int), ("n_corner_map", C.c_int), ("n_surf_map", C.c_int),
+                ("n_edge", C.c_int * 2), ("n_plane", C.c_int * 2), ("lm_iters", C.c_int * 2), ("final_cost", C.c_double * 2)]
+
+
+class Map:
+    """A-LOAM laserMapping state (21 x 21 x 11 cubes of 50 m); process() = one frame."""
+
+    def __init__(self, line_res=0.4, plane_res=0.8):
+        L = lib()
+        L.lo_map_create.restype = C.c_void_p
+        L.lo_map_create.argtypes = [C.c_float, C.c_float]
+        L.lo_map_free.argtypes = [C.c_void_p]
+        L.lo_map_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.lo_map_cube.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.lo_map_centre.argtypes = [C.c_void_p, C.c_void_p]
+        self.h = L.lo_map_create(line_res, plane_res)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().lo_map_free(self.h)
+            self.h = None
+
+    def process(self, corner_last, surf_last, q_wodom, t_wodom):
+        """corner_last / surf_last: [n,4] float32 (less-sharp / less-flat clouds).  Returns (q_w_curr, t_w_curr, MapStats)."""
+        c = np.ascontiguousarray(corner_last, np.float32).reshape(-1, 4); s = np.ascontiguousarray(surf_last, np.float32).reshape(-1, 4)
+        q = np.ascontiguousarray(q_wodom, np.float64); t = np.ascontiguousarray(t_wodom, np.float64)
+        qo = np.zeros(4); to = np.zeros(3); st = MapStats()
+        lib().lo_map_process(self.h, c.ctypes.data, len(c), s.ctypes.data, len(s), q.ctypes.data, t.ctypes.data,
+                             qo.ctypes.data, to.ctypes.data, C.byref(st))
+        return qo, to, st
+
+    def cube(self, which, i, j, k):
+        ptr = C.c_void_p()
+        n = lib().lo_map_cube(self.h, which, i, j, k, C.byref(ptr))
+        if n == 0:
+            return np.zeros((0, 4), np.float32)
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), (n, 4)).copy()
+
+    def centre(self):
+        cen = np.zeros(3, np.int32)
+        lib().lo_map_centre(self.h, cen.ctypes.data)
+        return cen
+
+    def all_points(self, which):
+        out = [self.cube(which, i, j, k) for k in range(11) for j in range(21) for i in range(21)]
+        return np.concatenate(out) if out else np.zeros((0, 4), np.float32)
+
+
+def run_mapping(xyzi, offsets, poses_odom, n_lines=64, min_range=5.0, line_res=0.4, plane_res=0.8, threads=1):
+    """scanRegistration + laserMapping over a sequence with the given laserOdometry poses [n,7].  Returns dict(poses[n,7],
+    stats[n], stage_ms[2])."""
+    xyzi = np.ascontiguousarray(xyzi, np.float32).reshape(-1, 4)
+    offsets = np.ascontiguousarray(offsets, np.int64)
+    po = np.ascontiguousarray(poses_odom, np.float64)
+    n = len(offsets) - 1
+    out = np.zeros((n, 7)); ms = np.zeros(2)
+    stats = (MapStats * n)()
+    rc = lib().lo_run_mapping(_fp(xyzi, C.c_float), _fp(offsets, C.c_int64), C.c_int(n), C.c_int(n_lines), C.c_float(min_range),
+                              C.c_float(line_res), C.c_float(plane_res), C.c_int(threads), _fp(po, C.c_double), _fp(out, C.c_double),
+                              stats, _fp(ms, C.c_double))
+    if rc != 0:
+        raise RuntimeError("lo_run_mapping failed: %d" % rc)
+    return dict(poses=out, stats=list(stats), stage_ms=ms)
+
+
+def knn(pts, q, k):
+    """k nearest neighbours of q in pts [n,4] through the kd-tree: (indices, squared distances)."""
+    pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 4)
+    L = lib()
+    L.lo_kdtree_build.restype = C.c_void_p
+    L.lo_kdtree_build.argtypes = [C.c_void_p, C.c_int]
+    L.lo_kdtree_free.argtypes = [C.c_void_p]
+    L.lo_kdtree_knn.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
+    t = L.lo_kdtree_build(pts.ctypes.data, len(pts))
+    idx = np.zeros(k, np.int32); d2 = np.zeros(k, np.float32)
+    n = L.lo_kdtree_knn(t, float(q[0]), float(q[1]), float(q[2]), k, idx.ctypes.data, d2.ctypes.data)
+    L.lo_kdtree_free(t)
+    return idx[:n], d2[:n]
+
+
+def sym_eig3(A):
+    A = np.ascontiguousarray(A, np.float64).reshape(9)
+    ev = np.zeros(3); vec = np.zeros(9)
+    lib().lo_sym_eig3(A.ctypes.data_as(C.c_void_p), ev.ctypes.data_as(C.c_void_p), vec.ctypes.data_as(C.c_void_p))
+    return ev, vec.reshape(3, 3)
+
+
+def plane_fit5(pts):
+    P = np.ascontiguousarray(pts, np.float64).reshape(15)
+    n = np.zeros(3); d = C.c_double()
+    ok = lib().lo_plane_fit5(P.ctypes.data_as(C.c_void_p), n.ctypes.data_as(C.c_void_p), C.byref(d))
+    return bool(ok), n, d.value
+
+
 # Synthetic workload S1 lives in workloads/s1.py (input plumbing, not part of the oracle); re-exported for the tests.
 from workloads.s1 import S1World, hdl64_elevations_rad  # noqa: E402,F401
 
