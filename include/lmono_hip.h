@@ -172,6 +172,21 @@ int lmono_marginalize(lmono_ctx *, int n_windows, const int *feat_off_h, const i
 int lmono_marg_evaluate(lmono_ctx *, int n_windows, const double *lin_J_h, const double *lin_r_h, const double *x0_h, const double *x_h,
                         double *residual_h);
 
+/* ---- laserMapping, optimisation step -------------------------------------------------------------------
+ * Replaces the `for iterCount < 2 { 5-NN in the corner / surf map kd-trees; PCA line test -> LidarEdgeFactor; 5-point
+ * plane fit -> LidarPlaneNormFactor; ceres::Solve }` block of A-LOAM laserMapping.cpp process() (source absent from the
+ * reference tree; behavioural spec SURVEY.md Appendix A.4), batched over n_streams independent sequences.
+ * *_map_h: the map clouds of each stream's 5 x 5 x 3 cube neighbourhood, *_stack_h: its voxel-filtered scan clouds
+ * ([total][4] float32 x y z intensity, host memory; *_off: [n_streams + 1] point offsets).  pose_qt: [n_streams][7]
+ * q_w_curr (x y z w), t_w_curr -- initial guess in, refined pose out.  stats (optional): [n_streams][8] = edge blocks of
+ * the two outer iterations, plane blocks of the two, LM iterations of the two, 0, 0.  nn_out (optional):
+ * [total stack points][5] neighbour indices of the last outer iteration (corner points first; -1 = no residual block).
+ * The cube-map bookkeeping and the voxel filters of process() are not behind this ABI yet.                            */
+int lmono_map_refine(lmono_ctx *, int n_streams,
+                     const float *corner_map_h, const int64_t *corner_map_off, const float *surf_map_h, const int64_t *surf_map_off,
+                     const float *corner_stack_h, const int64_t *corner_stack_off, const float *surf_stack_h, const int64_t *surf_stack_off,
+                     double *pose_qt, int32_t *stats, int32_t *nn_out);
+
 /* ---- pose composition (laserOdometry: t_w_curr += q_w_curr * t_last_curr; q_w_curr *= q_last_curr) ------- *
  * lmono_pose_prefix_d: poses_d[k - first] = incr[first] (+) ... (+) incr[k] for k in [first, n) (incr[0] is the
  * identity: first = 0 gives poses relative to scan 0, first > 0 poses relative to scan first-1).  lmono_pose_rebase_d: poses[k] <- bases[0] (+) ... (+) bases[n_bases-1] (+) poses[k]; with scans

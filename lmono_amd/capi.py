@@ -12,7 +12,7 @@ SYMBOLS = [
     "lmono_create", "lmono_destroy", "lmono_last_error", "lmono_set_stream", "lmono_synchronize", "lmono_version",
     "lmono_batch_create", "lmono_batch_destroy", "lmono_scanreg_batch", "lmono_scanreg_batch_h", "lmono_batch_counts", "lmono_batch_get_cloud",
     "lmono_batch_get_curvature", "lmono_odom_batch", "lmono_odom_batch_d", "lmono_odom_correspond", "lmono_timing_reset", "lmono_timing_read",
-    "lmono_pose_prefix_d", "lmono_pose_rebase_d", "lmono_factor_eval", "lmono_factor_eval_d",
+    "lmono_pose_prefix_d", "lmono_pose_rebase_d", "lmono_map_refine", "lmono_factor_eval", "lmono_factor_eval_d",
     "lmono_triangulate", "lmono_outlier_scores", "lmono_shift_depth", "lmono_marginalize", "lmono_marg_evaluate", "lmono_ba_batch_create", "lmono_ba_batch_destroy", "lmono_ba_solve", "lmono_ba_batch_reset", "lmono_ba_batch_read",
 ]
 
@@ -204,6 +204,27 @@ class Context:
         except Exception:
             pass
 
+
+    def map_refine(self, corner_maps, surf_maps, corner_stacks, surf_stacks, poses_qt, want_nn=False):
+        """Scan-to-map optimisation step of laserMapping for a batch of independent streams: lists of [n,4] float32 clouds
+        per stream, poses_qt [n_streams,7] (q xyzw, t) initial guesses.  Returns (poses [n_streams,7], stats
+        [n_streams,8], nn [total stack points,5] or None)."""
+        ns = len(corner_maps)
+
+        def cat(lst):
+            arrs = [np.ascontiguousarray(a, np.float32).reshape(-1, 4) for a in lst]
+            off = np.zeros(ns + 1, np.int64)
+            off[1:] = np.cumsum([len(a) for a in arrs])
+            return (np.concatenate(arrs) if off[-1] > 0 else np.zeros((0, 4), np.float32)), off
+        cm, cmo = cat(corner_maps); sm, smo = cat(surf_maps); cs, cso = cat(corner_stacks); ss, sso = cat(surf_stacks)
+        poses = np.ascontiguousarray(poses_qt, np.float64).reshape(ns, 7).copy()
+        stats = np.zeros((ns, 8), np.int32)
+        nn = np.zeros((int(cso[-1] + sso[-1]), 5), np.int32) if want_nn else None
+        self.L.lmono_map_refine.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 11
+        self.check(self.L.lmono_map_refine(self.h, ns, cm.ctypes.data, cmo.ctypes.data, sm.ctypes.data, smo.ctypes.data,
+                                           cs.ctypes.data, cso.ctypes.data, ss.ctypes.data, sso.ctypes.data,
+                                           poses.ctypes.data, stats.ctypes.data, nn.ctypes.data if want_nn else None))
+        return poses, stats, nn
 
 class ScanBatch:
     """Device-resident working set of a batch of scans (lmono_scan_batch)."""

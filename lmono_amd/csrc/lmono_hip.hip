@@ -2,6 +2,7 @@
 // the kernel files are included so that one `hipcc -shared` produces liblmono_hip.so.
 #include "frontend.hip"
 #include "odometry.hip"
+#include "mapping.hip"
 #include "ba.hip"
 #include "ba_solve.hip"
 #include "feat.hip"
@@ -797,3 +798,84 @@ extern "C" int lmono_marg_evaluate(lmono_ctx *c, int n_windows, const double *li
     HIP_TRY(c, hipMemcpy(residual_h, res, sizeof(double) * (size_t)n_windows * kMargN, hipMemcpyDeviceToHost));
     return LMONO_OK;
 }
+
+// ---- scan-to-map optimisation step of laserMapping, batched over independent streams ------------------------
+extern "C" int lmono_map_refine(lmono_ctx *c, int n_streams,
+                                const float *corner_map_h, const int64_t *corner_map_off, const float *surf_map_h, const int64_t *surf_map_off,
+                                const float *corner_stack_h, const int64_t *corner_stack_off, const float *surf_stack_h, const int64_t *surf_stack_off,
+                                double *pose_qt, int32_t *stats_h, int32_t *nn_out_h)
+{
+    if (!c || n_streams <= 0 || !corner_map_off || !surf_map_off || !corner_stack_off || !surf_stack_off || !pose_qt) return LMONO_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int64_t tot[4] = { corner_map_off[n_streams], surf_map_off[n_streams], corner_stack_off[n_streams], surf_stack_off[n_streams] };
+    const float *src_h[4] = { corner_map_h, surf_map_h, corner_stack_h, surf_stack_h };
+    for (int k = 0; k < 4; k++) if (tot[k] < 0 || (tot[k] > 0 && !src_h[k])) return LMONO_EINVAL;
+    DevBuf db;
+    bool ok = true;
+    float4 *cloud_d[4];
+    for (int k = 0; k < 4; k++) cloud_d[k] = (float4 *)db.up(src_h[k], (size_t)tot[k] * 4, ok);
+    // hash tables, cell-sorted copies and scratch of the 2 n_streams map clouds
+    std::vector<int64_t> toff((size_t)2 * n_streams + 1, 0);
+    for (int s = 0; s < n_streams; s++)
+        for (int w = 0; w < 2; w++) {
+            const int64_t n = (w ? surf_map_off : corner_map_off)[s + 1] - (w ? surf_map_off : corner_map_off)[s];
+            if (n < 0 || n > (1 << 24) - 2) { c->err = "lmono_map_refine: bad map cloud size"; return LMONO_EINVAL; }
+            int T = 1024;
+            while (T < n + 1) T <<= 1;
+            toff[(size_t)2 * s + w + 1] = toff[(size_t)2 * s + w] + T;
+        }
+    GridCell *cells = (GridCell *)db.up((const char *)nullptr, (size_t)toff.back() * sizeof(GridCell), ok);
+    float4 *sorted[2] = { (float4 *)db.up((const float *)nullptr, (size_t)tot[0] * 4, ok), (float4 *)db.up((const float *)nullptr, (size_t)tot[1] * 4, ok) };
+    int *slot[2] = { db.up((const int *)nullptr, (size_t)tot[0], ok), db.up((const int *)nullptr, (size_t)tot[1], ok) };
+    int *rank[2] = { db.up((const int *)nullptr, (size_t)tot[0], ok), db.up((const int *)nullptr, (size_t)tot[1], ok) };
+    int *masks = db.up((const int *)nullptr, (size_t)2 * n_streams, ok);
+    const int64_t nq_total = tot[2] + tot[3];
+    MapRec *rec = (MapRec *)db.up((const char *)nullptr, (size_t)(nq_total > 0 ? nq_total : 1) * sizeof(MapRec), ok);
+    int *nn_d = nn_out_h ? db.up((const int *)nullptr, (size_t)(nq_total > 0 ? nq_total : 1) * 5, ok) : nullptr;
+    std::vector<double> xh((size_t)n_streams * 8, 0.0);
+    for (int s = 0; s < n_streams; s++) for (int k = 0; k < 7; k++) xh[(size_t)s * 8 + k] = pose_qt[(size_t)s * 7 + k];
+    double *x_d = db.up(xh.data(), xh.size(), ok);
+    std::vector<int> zero((size_t)n_streams * 8, 0);
+    int *stats_d = db.up(zero.data(), zero.size(), ok);
+    if (!ok) { c->err = "lmono_map_refine: device allocation / upload failed"; return LMONO_ENOMEM; }
+    std::vector<CloudJob> jobs((size_t)2 * n_streams);
+    std::vector<MapStream> st((size_t)n_streams);
+    int max_nq = 0;
+    int64_t rec_at = 0;
+    for (int s = 0; s < n_streams; s++) {
+        MapStream &S = st[(size_t)s];
+        for (int w = 0; w < 2; w++) {
+            const int64_t *moff = w ? surf_map_off : corner_map_off, *soff = w ? surf_stack_off : corner_stack_off;
+            CloudJob &J = jobs[(size_t)2 * s + w];
+            J.src = cloud_d[w] + moff[s]; J.n = (int)(moff[s + 1] - moff[s]);
+            J.cell = cells + toff[(size_t)2 * s + w]; J.tcap = (int)(toff[(size_t)2 * s + w + 1] - toff[(size_t)2 * s + w]);
+            J.sorted = sorted[w] + moff[s]; J.slot_of = slot[w] + moff[s]; J.rank_of = rank[w] + moff[s];
+            J.mask_out = masks + 2 * s + w;
+            S.cell[w] = J.cell; S.sorted[w] = J.sorted; S.cloud[w] = J.src; S.mask[w] = J.mask_out; S.n_map[w] = J.n;
+            S.stack[w] = cloud_d[2 + w] + soff[s]; S.n_stack[w] = (int)(soff[s + 1] - soff[s]);
+        }
+        S.rec = rec + rec_at; S.x = x_d + (size_t)s * 8; S.stats = stats_d + (size_t)s * 8;
+        S.nn_out = nn_d ? nn_d + rec_at * 5 : nullptr;
+        const int nq = S.n_stack[0] + S.n_stack[1];
+        rec_at += nq;
+        max_nq = nq > max_nq ? nq : max_nq;
+    }
+    CloudJob *jobs_d = db.up(jobs.data(), jobs.size(), ok);
+    MapStream *st_d = db.up(st.data(), st.size(), ok);
+    if (!ok) { c->err = "lmono_map_refine: device allocation / upload failed"; return LMONO_ENOMEM; }
+    hipStream_t stream = c->stream;
+    hipLaunchKernelGGL(k_cloud_grid, dim3(2 * n_streams), dim3(1024), 0, stream, (const CloudJob *)jobs_d);
+    for (int outer = 0; outer < 2; outer++) {
+        if (max_nq > 0) hipLaunchKernelGGL(k_map_correspond, dim3((max_nq + 7) / 8, n_streams), dim3(256), 0, stream, (const MapStream *)st_d, outer);
+        hipLaunchKernelGGL(k_map_solve, dim3(n_streams), dim3(1024), 0, stream, (const MapStream *)st_d, outer);
+    }
+    int rc = check_launch(c, "map refine kernels");
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(stream));
+    HIP_TRY(c, hipMemcpy(xh.data(), x_d, sizeof(double) * xh.size(), hipMemcpyDeviceToHost));
+    for (int s = 0; s < n_streams; s++) for (int k = 0; k < 7; k++) pose_qt[(size_t)s * 7 + k] = xh[(size_t)s * 8 + k];
+    if (stats_h) HIP_TRY(c, hipMemcpy(stats_h, stats_d, sizeof(int) * (size_t)n_streams * 8, hipMemcpyDeviceToHost));
+    if (nn_out_h && nq_total > 0) HIP_TRY(c, hipMemcpy(nn_out_h, nn_d, sizeof(int) * (size_t)nq_total * 5, hipMemcpyDeviceToHost));
+    return LMONO_OK;
+}
+

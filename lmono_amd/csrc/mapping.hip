@@ -1,0 +1,486 @@
+// lmono_amd/csrc/mapping.hip -- gfx950 kernels of the scan-to-map optimisation step of A-LOAM laserMapping (SURVEY.md
+// Appendix A.4, row 8f-1; source absent from the reference tree, /root/reference/.gitmodules:1-3), batched over
+// independent streams:
+//   k_cloud_grid   one workgroup per (stream, cloud): 1 m hash grid over an arbitrary float4 cloud (the map clouds of the
+//                  cube neighbourhood), same structure as the odometry grids (16-B cells, cell-sorted copy)
+//   k_map_correspond  32 lanes per down-sampled scan point: pointAssociateToMap, exact 5-NN among the 27 cells around it
+//                  (every neighbour that can pass the "5th distance^2 < 1" test lies inside them), then per point the
+//                  line test (covariance of the 5 neighbours, Jacobi eigen-decomposition, largest > 3 x middle) or the
+//                  plane fit (column-pivoted Householder least squares, all five within 0.2) -> an 80-B double record
+//   k_map_solve    one workgroup per stream: ceres::Solve restated (trust-region LM, <= 4 iterations, Huber 0.1) over
+//                  the records (LidarEdgeFactor / LidarPlaneNormFactor, closed-form Jacobians)
+// The map bookkeeping (cube array, voxel re-filtering) is not part of this file yet.
+#include "batch.hpp"
+
+namespace lmono {
+
+struct CloudJob {
+    const float4 *src;     // the cloud
+    int n;                 // its size
+    GridCell *cell;        // hash table (capacity tcap slots)
+    int tcap;
+    float4 *sorted;        // cell-sorted copy, .w = original index bits
+    int *slot_of, *rank_of;
+    int *mask_out;         // table size - 1 actually used (0: table unusable -> no correspondences)
+};
+
+__global__ __launch_bounds__(1024) void k_cloud_grid(const CloudJob *jobs)
+{
+    const CloudJob J = jobs[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = J.n;
+    int T = next_pow2(n + 1);
+    if (T < 1024) T = 1024;
+    if (T > J.tcap) { if (tid == 0) *J.mask_out = 0; return; }
+    const int mask = T - 1;
+    if (tid == 0) *J.mask_out = mask;
+    GridCell *cell = J.cell;
+    for (int i = tid; i < T; i += 1024) { GridCell e; e.key = kEmptyKey; e.start = 0; e.cnt = 0; cell[i] = e; }
+    __threadfence_block();
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        const float4 p = J.src[i];
+        const unsigned long long key = cell_key((int)floorf(p.x * kInvCell), (int)floorf(p.y * kInvCell), (int)floorf(p.z * kInvCell));
+        unsigned int sl = hash_key(key) & mask;
+        while (true) {
+            const unsigned long long old = atomicCAS(&cell[sl].key, kEmptyKey, key);
+            if (old == kEmptyKey || old == key) break;
+            sl = (sl + 1) & mask;
+        }
+        J.slot_of[i] = (int)sl;
+        J.rank_of[i] = atomicAdd(&cell[sl].cnt, 1);
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __shared__ int s_wsum[2][16];
+    int carry = 0;
+    for (int t0 = 0, buf = 0; t0 < T; t0 += 1024, buf ^= 1) {
+        const int c = cell[t0 + tid].cnt;
+        const int incl = wave_scan_incl(c);
+        if (lane == 63) s_wsum[buf][wave] = incl;
+        __syncthreads();
+        int base = carry, tile = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) { const int v = s_wsum[buf][w]; if (w < wave) base += v; tile += v; }
+        cell[t0 + tid].start = base + incl - c;
+        carry += tile;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        const float4 p = J.src[i];
+        J.sorted[cell[J.slot_of[i]].start + J.rank_of[i]] = make_float4(p.x, p.y, p.z, __int_as_float(i));
+    }
+}
+
+// ---- small dense pieces, same arithmetic as oracle/lo_mapping.c --------------------------------------------------
+// ascending eigenvalues / eigenvectors (columns) of a symmetric 3x3: cyclic Jacobi
+__device__ void sym_eig3(const double *A, double *evals, double *evecs)
+{
+    double a[9], v[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+    for (int k = 0; k < 9; k++) a[k] = A[k];
+    for (int sweep = 0; sweep < 60; sweep++) {
+        const double off = a[1] * a[1] + a[2] * a[2] + a[5] * a[5];
+        const double dia = a[0] * a[0] + a[4] * a[4] + a[8] * a[8];
+        if (off <= 1e-40 * (dia > 0 ? dia : 1.0) || off == 0.0) break;
+        for (int p = 0; p < 2; p++)
+            for (int q = p + 1; q < 3; q++) {
+                const double apq = a[p * 3 + q];
+                if (apq == 0.0) continue;
+                const double theta = (a[q * 3 + q] - a[p * 3 + p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 3; k++) {
+                    const double akp = a[k * 3 + p], akq = a[k * 3 + q];
+                    a[k * 3 + p] = c * akp - s * akq; a[k * 3 + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 3; k++) {
+                    const double apk = a[p * 3 + k], aqk = a[q * 3 + k];
+                    a[p * 3 + k] = c * apk - s * aqk; a[q * 3 + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; k++) {
+                    const double vkp = v[k * 3 + p], vkq = v[k * 3 + q];
+                    v[k * 3 + p] = c * vkp - s * vkq; v[k * 3 + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    int ord[3] = { 0, 1, 2 };
+    const double d[3] = { a[0], a[4], a[8] };
+    for (int i = 0; i < 2; i++) for (int j = i + 1; j < 3; j++) if (d[ord[j]] < d[ord[i]]) { const int t = ord[i]; ord[i] = ord[j]; ord[j] = t; }
+    for (int c = 0; c < 3; c++) { evals[c] = d[ord[c]]; for (int k = 0; k < 3; k++) evecs[k * 3 + c] = v[k * 3 + ord[c]]; }
+}
+
+// norm = argmin |A norm + 1| over the 5 rows (matA0.colPivHouseholderQr().solve(matB0)); true when all five points are
+// within 0.2 of the plane
+__device__ bool plane_fit5(const double *pts, double *norm, double &negative_OA_dot_norm)
+{
+    double A[15], b[5] = { -1, -1, -1, -1, -1 };
+    for (int k = 0; k < 15; k++) A[k] = pts[k];
+    int perm[3] = { 0, 1, 2 };
+    for (int k = 0; k < 3; k++) {
+        int piv = k; double best = -1.0;
+        for (int c = k; c < 3; c++) { double s = 0; for (int r = k; r < 5; r++) s += A[r * 3 + c] * A[r * 3 + c]; if (s > best) { best = s; piv = c; } }
+        if (piv != k) { for (int r = 0; r < 5; r++) { const double t = A[r * 3 + k]; A[r * 3 + k] = A[r * 3 + piv]; A[r * 3 + piv] = t; } const int t = perm[k]; perm[k] = perm[piv]; perm[piv] = t; }
+        double nrm = 0; for (int r = k; r < 5; r++) nrm += A[r * 3 + k] * A[r * 3 + k];
+        nrm = sqrt(nrm);
+        if (nrm == 0.0) continue;
+        const double alpha = A[k * 3 + k] > 0 ? -nrm : nrm;
+        double v[5] = { 0, 0, 0, 0, 0 };
+        for (int r = k; r < 5; r++) v[r] = A[r * 3 + k];
+        v[k] -= alpha;
+        double vv = 0; for (int r = k; r < 5; r++) vv += v[r] * v[r];
+        if (vv == 0.0) continue;
+        for (int c = k; c < 3; c++) {
+            double dot = 0; for (int r = k; r < 5; r++) dot += v[r] * A[r * 3 + c];
+            const double f = 2.0 * dot / vv;
+            for (int r = k; r < 5; r++) A[r * 3 + c] -= f * v[r];
+        }
+        double dot = 0; for (int r = k; r < 5; r++) dot += v[r] * b[r];
+        const double f = 2.0 * dot / vv;
+        for (int r = k; r < 5; r++) b[r] -= f * v[r];
+    }
+    double y[3];
+    for (int k = 2; k >= 0; k--) {
+        double s = b[k];
+        for (int c = k + 1; c < 3; c++) s -= A[k * 3 + c] * y[c];
+        y[k] = A[k * 3 + k] != 0.0 ? s / A[k * 3 + k] : 0.0;
+    }
+    for (int k = 0; k < 3; k++) norm[perm[k]] = y[k];
+    const double nn = sqrt(norm[0] * norm[0] + norm[1] * norm[1] + norm[2] * norm[2]);
+    negative_OA_dot_norm = 1.0 / nn;
+    for (int k = 0; k < 3; k++) norm[k] /= nn;
+    for (int j = 0; j < 5; j++)
+        if (fabs(norm[0] * pts[j * 3] + norm[1] * pts[j * 3 + 1] + norm[2] * pts[j * 3 + 2] + negative_OA_dot_norm) > 0.2) return false;
+    return true;
+}
+
+// ---- correspondences ------------------------------------------------------------------------------------------------
+struct MapRec { double cp[3]; double a[3]; double b[3]; int kind; int pad; };   // kind 0 none, 1 edge, 3 plane-norm
+
+struct MapStream {
+    // map clouds (grids built by k_cloud_grid) and down-sampled scan clouds of one stream
+    const GridCell *cell[2]; const float4 *sorted[2]; const float4 *cloud[2]; const int *mask[2]; int n_map[2];
+    const float4 *stack[2]; int n_stack[2];
+    MapRec *rec;           // [n_stack[0] + n_stack[1]]
+    double *x;             // [8] q(xyzw), t
+    int *stats;            // [8] n_edge[2], n_plane[2], lm_iters[2], pad
+    int *nn_out;           // optional [n][5] neighbour indices of the last outer iteration (-1: rejected)
+};
+
+// sorted insertion of (d, idx) into a lane-local ascending top-5
+__device__ __forceinline__ void top5_insert(float *td, int *ti, float d, int idx)
+{
+    if (!(d < td[4] || (d == td[4] && idx < ti[4]))) return;
+    td[4] = d; ti[4] = idx;
+#pragma unroll
+    for (int k = 4; k > 0; k--) {
+        const bool sw = td[k] < td[k - 1] || (td[k] == td[k - 1] && ti[k] < ti[k - 1]);
+        const float fd = td[k]; const int fi = ti[k];
+        td[k] = sw ? td[k - 1] : td[k]; ti[k] = sw ? ti[k - 1] : ti[k];
+        td[k - 1] = sw ? fd : td[k - 1]; ti[k - 1] = sw ? fi : ti[k - 1];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_map_correspond(const MapStream *streams, int outer)
+{
+    const MapStream S = streams[blockIdx.y];
+    const int nq = S.n_stack[0] + S.n_stack[1];
+    const int qi = blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (qi >= nq) return;
+    const int lane = threadIdx.x & 63, gl = threadIdx.x & 31, gbase = lane & ~31;
+    const int which = qi < S.n_stack[0] ? 0 : 1;
+    const float4 p = S.stack[which][which ? qi - S.n_stack[0] : qi];
+    MapRec *rec = S.rec + qi;
+    int kind = 0;
+    int nn[5] = { -1, -1, -1, -1, -1 };
+    const unsigned int mask = (unsigned int)*S.mask[which];
+    // the solve is skipped altogether unless the map holds > 10 corner and > 50 surf points (laserMapping.cpp)
+    if (S.n_map[0] > 10 && S.n_map[1] > 50 && mask != 0) {
+        // pointAssociateToMap: double transform, stored in a float point
+        const double *x = S.x;
+        double rx, ry, rz;
+        quat_rotate(x, (double)p.x, (double)p.y, (double)p.z, rx, ry, rz);
+        const float qx = (float)(rx + x[4]), qy = (float)(ry + x[5]), qz = (float)(rz + x[6]);
+        const int cqx = (int)floorf(qx * kInvCell), cqy = (int)floorf(qy * kInvCell), cqz = (int)floorf(qz * kInvCell);
+        int st = 0, cn = 0;
+        if (gl < 27) {
+            const unsigned long long kk = cell_key(cqx + gl % 3 - 1, cqy + (gl / 3) % 3 - 1, cqz + gl / 9 - 1);
+            unsigned int sl = hash_key(kk) & mask;
+            while (true) {
+                const GridCell e = S.cell[which][sl];
+                if (e.key == kk) { st = e.start; cn = e.cnt; break; }
+                if (e.key == kEmptyKey) break;
+                sl = (sl + 1) & mask;
+            }
+        }
+        float td[5]; int ti[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) { td[k] = __uint_as_float(0x7f800000u); ti[k] = 0x7fffffff; }
+        unsigned int m = group_ballot(cn > 0, gbase);
+        while (m) {
+            const int src = __ffs((int)m) - 1;
+            m &= m - 1;
+            const int s0 = __shfl(st, src, kGroup), n0 = __shfl(cn, src, kGroup);
+            for (int i = gl; i < n0; i += kGroup) {
+                const float4 c = S.sorted[which][s0 + i];
+                top5_insert(td, ti, dist2f(c.x, c.y, c.z, qx, qy, qz), __float_as_int(c.w));
+            }
+        }
+        // merge the lanes' lists: five rounds of "smallest head wins, its lane pops"
+        float d5 = 0.f;
+        bool full = true;
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+            const unsigned long long head = ti[0] == 0x7fffffff ? ~0ull : pack_fu(td[0], (unsigned int)ti[0]);
+            const unsigned long long best = group_min_u64(head);
+            if (best == ~0ull) { full = false; break; }
+            nn[r] = (int)(unsigned int)(best & 0xffffffffull);
+            d5 = __uint_as_float((unsigned int)(best >> 32));
+            if (head == best) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) { td[k] = td[k + 1]; ti[k] = ti[k + 1]; }
+                td[4] = __uint_as_float(0x7f800000u); ti[4] = 0x7fffffff;
+            }
+        }
+        if (full && (double)d5 < 1.0) {
+            // every lane evaluates the (group-uniform) small dense problem: no divergence, lane 0 writes
+            double P[15];
+            for (int j = 0; j < 5; j++) { const float4 c = S.cloud[which][nn[j]]; P[j * 3] = (double)c.x; P[j * 3 + 1] = (double)c.y; P[j * 3 + 2] = (double)c.z; }
+            double ra[3] = { 0, 0, 0 }, rb[3] = { 0, 0, 0 };
+            if (which == 0) {
+                double c[3] = { 0, 0, 0 };
+                for (int j = 0; j < 5; j++) { c[0] += P[j * 3]; c[1] += P[j * 3 + 1]; c[2] += P[j * 3 + 2]; }
+                for (int k = 0; k < 3; k++) c[k] = c[k] / 5.0;
+                double cov[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+                for (int j = 0; j < 5; j++) {
+                    const double z[3] = { P[j * 3] - c[0], P[j * 3 + 1] - c[1], P[j * 3 + 2] - c[2] };
+                    for (int a = 0; a < 3; a++) for (int bb = 0; bb < 3; bb++) cov[a * 3 + bb] += z[a] * z[bb];
+                }
+                double ev[3], evec[9];
+                sym_eig3(cov, ev, evec);
+                if (ev[2] > 3.0 * ev[1]) {
+                    kind = 1;
+                    for (int k = 0; k < 3; k++) { ra[k] = 0.1 * evec[k * 3 + 2] + c[k]; rb[k] = -0.1 * evec[k * 3 + 2] + c[k]; }
+                }
+            } else {
+                double nrm[3], d;
+                if (plane_fit5(P, nrm, d)) { kind = 3; ra[0] = d; for (int k = 0; k < 3; k++) rb[k] = nrm[k]; }
+            }
+            if (gl == 0 && kind != 0) {
+                rec->cp[0] = (double)p.x; rec->cp[1] = (double)p.y; rec->cp[2] = (double)p.z;
+                for (int k = 0; k < 3; k++) { rec->a[k] = ra[k]; rec->b[k] = rb[k]; }
+            }
+        }
+    }
+    if (gl == 0) {
+        rec->kind = kind;
+        if (kind == 1) atomicAdd(&S.stats[outer], 1);
+        if (kind == 3) atomicAdd(&S.stats[2 + outer], 1);
+        if (S.nn_out) for (int k = 0; k < 5; k++) S.nn_out[(size_t)qi * 5 + k] = kind != 0 ? nn[k] : -1;
+    }
+}
+
+// ---- solve -----------------------------------------------------------------------------------------------------------
+template <bool kJac>
+__device__ __forceinline__ void map_eval_block(const MapRec &R, const double *x, const double *Jp, LmAcc &acc)
+{
+    if (R.kind == 0) return;
+    const bool edge = R.kind == 1;
+    const double vx = R.cp[0], vy = R.cp[1], vz = R.cp[2];
+    double lx, ly, lz;
+    quat_rotate(x, vx, vy, vz, lx, ly, lz);
+    lx += x[4]; ly += x[5]; lz += x[6];
+    double res[3], D[3][3];
+    int nr;
+    if (edge) {
+        const double ax = lx - R.a[0], ay = ly - R.a[1], az = lz - R.a[2];
+        const double bx = lx - R.b[0], by = ly - R.b[1], bz = lz - R.b[2];
+        const double nux = ay * bz - az * by, nuy = az * bx - ax * bz, nuz = ax * by - ay * bx;
+        const double ex = R.a[0] - R.b[0], ey = R.a[1] - R.b[1], ez = R.a[2] - R.b[2];
+        const double den = sqrt(ex * ex + ey * ey + ez * ez);
+        res[0] = nux / den; res[1] = nuy / den; res[2] = nuz / den;
+        if (kJac) {
+            const double inv = 1.0 / den;
+            D[0][0] = 0.0;       D[0][1] = ez * inv;  D[0][2] = -ey * inv;
+            D[1][0] = -ez * inv; D[1][1] = 0.0;       D[1][2] = ex * inv;
+            D[2][0] = ey * inv;  D[2][1] = -ex * inv; D[2][2] = 0.0;
+        }
+        nr = 3;
+    } else {
+        // LidarPlaneNormFactor: norm . point_w + negative_OA_dot_norm
+        res[0] = (R.b[0] * lx + R.b[1] * ly + R.b[2] * lz) + R.a[0];
+        if (kJac) { D[0][0] = R.b[0]; D[0][1] = R.b[1]; D[0][2] = R.b[2]; }
+        nr = 1;
+    }
+    double sq = 0.0;
+    for (int r = 0; r < nr; r++) sq += res[r] * res[r];
+    double rho0, rho1;
+    huber(sq, rho0, rho1);
+    acc.cost += 0.5 * rho0;
+    if (!kJac) return;
+    const double sr = sqrt(rho1);
+    const double ux = x[0], uy = x[1], uz = x[2], w = x[3];
+    const double cxv = uy * vz - uz * vy, cyv = uz * vx - ux * vz, czv = ux * vy - uy * vx;
+    double G[3][4];
+    const double V[3][3] = { { 0, -vz, vy }, { vz, 0, -vx }, { -vy, vx, 0 } };
+    const double U[3][3] = { { 0, -uz, uy }, { uz, 0, -ux }, { -uy, ux, 0 } };
+    const double Cx[3][3] = { { 0, -czv, cyv }, { czv, 0, -cxv }, { -cyv, cxv, 0 } };
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const double uv = U[i][0] * V[0][j] + U[i][1] * V[1][j] + U[i][2] * V[2][j];
+            G[i][j] = -2.0 * w * V[i][j] - 2.0 * Cx[i][j] - 2.0 * uv;
+        }
+    G[0][3] = 2.0 * cxv; G[1][3] = 2.0 * cyv; G[2][3] = 2.0 * czv;
+    double Gl[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            Gl[i][j] = G[i][0] * Jp[j] + G[i][1] * Jp[3 + j] + G[i][2] * Jp[6 + j] + G[i][3] * Jp[9 + j];
+    for (int r = 0; r < nr; r++) {
+        double J[6];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            J[j] = (D[r][0] * Gl[0][j] + D[r][1] * Gl[1][j] + D[r][2] * Gl[2][j]) * sr;
+            J[3 + j] = D[r][j] * sr;
+        }
+        accumulate_row(acc, J, res[r] * sr);
+    }
+}
+
+template <bool kJac>
+__device__ __forceinline__ void map_evaluate(const MapRec *rec, int nq, const double *x, LmAcc &acc, double (*s_red)[28])
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double Jp[12];
+    Jp[0] = x[3];  Jp[1] = x[2];   Jp[2] = -x[1];
+    Jp[3] = -x[2]; Jp[4] = x[3];   Jp[5] = x[0];
+    Jp[6] = x[1];  Jp[7] = -x[0];  Jp[8] = x[3];
+    Jp[9] = -x[0]; Jp[10] = -x[1]; Jp[11] = -x[2];
+    acc.cost = 0.0;
+    if (kJac) {
+#pragma unroll
+        for (int i = 0; i < 21; i++) acc.H[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) acc.g[i] = 0.0;
+    }
+    for (int qi = tid; qi < nq; qi += 1024) map_eval_block<kJac>(rec[qi], x, Jp, acc);
+    acc.cost = wave_sum_d(acc.cost);
+    if (kJac) {
+#pragma unroll
+        for (int i = 0; i < 21; i++) acc.H[i] = wave_sum_d(acc.H[i]);
+#pragma unroll
+        for (int i = 0; i < 6; i++) acc.g[i] = wave_sum_d(acc.g[i]);
+    }
+    __syncthreads();
+    if (lane == 0) {
+        s_red[wave][27] = acc.cost;
+        if (kJac) {
+            for (int i = 0; i < 21; i++) s_red[wave][i] = acc.H[i];
+            for (int i = 0; i < 6; i++) s_red[wave][21 + i] = acc.g[i];
+        }
+    }
+    __syncthreads();
+    acc.cost = 0.0;
+    for (int w = 0; w < 16; w++) acc.cost += s_red[w][27];
+    if (kJac) {
+        for (int i = 0; i < 21; i++) { double t = 0.0; for (int w = 0; w < 16; w++) t += s_red[w][i]; acc.H[i] = t; }
+        for (int i = 0; i < 6; i++) { double t = 0.0; for (int w = 0; w < 16; w++) t += s_red[w][21 + i]; acc.g[i] = t; }
+    }
+}
+
+// One 1024-thread workgroup per stream (a frame has ~8 k residual blocks); the trust-region control flow runs redundantly
+// in every thread on the block-reduced sums, exactly like k_lm_solve.
+__global__ __launch_bounds__(1024) void k_map_solve(const MapStream *streams, int outer)
+{
+    const MapStream S = streams[blockIdx.x];
+    __shared__ double s_red[16][28];
+    const int tid = threadIdx.x;
+    const int nq = S.n_stack[0] + S.n_stack[1];
+    const int n_used = S.stats[outer] + S.stats[2 + outer];
+    double x[7];
+    for (int i = 0; i < 7; i++) x[i] = S.x[i];
+    const int max_iter = 4;
+    const double function_tol = 1e-6, gradient_tol = 1e-10, parameter_tol = 1e-8;
+    const double min_rel_decrease = 1e-3, min_diag = 1e-6, max_diag = 1e32, max_radius = 1e16, min_radius = 1e-32;
+    double radius = 1e4, decrease_factor = 2.0;
+    bool reuse_diagonal = false;
+    int invalid_steps = 0, iter = 0;
+    if (n_used > 0) {
+        LmAcc acc;
+        map_evaluate<true>(S.rec, nq, x, acc, s_red);
+        double x_cost = acc.cost;
+        double H[36], g[6], scale[6], diag[6];
+        unpack_sym(acc.H, H);
+        for (int i = 0; i < 6; i++) g[i] = acc.g[i];
+        double gmax = 0.0;
+        for (int i = 0; i < 6; i++) gmax = fmax(gmax, fabs(g[i]));
+        if (gmax > gradient_tol) {
+            double x_norm = norm7(x);
+            for (int i = 0; i < 6; i++) scale[i] = 1.0 / (1.0 + sqrt(H[i * 6 + i]));
+            while (iter < max_iter) {
+                iter++;
+                double Hs[36], gs[6], A[36], stepv[6];
+                for (int i = 0; i < 6; i++) { gs[i] = g[i] * scale[i]; for (int j = 0; j < 6; j++) Hs[i * 6 + j] = H[i * 6 + j] * scale[i] * scale[j]; }
+                if (!reuse_diagonal)
+                    for (int i = 0; i < 6; i++) { double d = Hs[i * 6 + i]; d = d < min_diag ? min_diag : d; d = d > max_diag ? max_diag : d; diag[i] = d; }
+                for (int i = 0; i < 36; i++) A[i] = Hs[i];
+                for (int i = 0; i < 6; i++) A[i * 6 + i] += diag[i] / radius;
+                bool ok = chol_solve6(A, gs, stepv);
+                for (int i = 0; i < 6; i++) if (!isfinite(stepv[i])) ok = false;
+                double model_change = 0.0;
+                if (ok) {
+                    for (int i = 0; i < 6; i++) stepv[i] = -stepv[i];
+                    double dg = 0.0, dHd = 0.0;
+                    for (int i = 0; i < 6; i++) { dg += stepv[i] * gs[i]; for (int j = 0; j < 6; j++) dHd += stepv[i] * Hs[i * 6 + j] * stepv[j]; }
+                    model_change = -(dg + 0.5 * dHd);
+                }
+                if (!ok || !(model_change > 0.0)) {
+                    if (++invalid_steps >= 5) break;
+                    radius *= 0.5; reuse_diagonal = true;
+                    continue;
+                }
+                invalid_steps = 0;
+                double delta[6], cand[7];
+                for (int i = 0; i < 6; i++) delta[i] = stepv[i] * scale[i];
+                manifold_plus(x, delta, cand);
+                LmAcc ca;
+                map_evaluate<false>(S.rec, nq, cand, ca, s_red);
+                const double cand_cost = ca.cost;
+                double sn = 0.0;
+                for (int i = 0; i < 7; i++) sn += (x[i] - cand[i]) * (x[i] - cand[i]);
+                sn = sqrt(sn);
+                if (sn <= parameter_tol * (x_norm + parameter_tol)) break;
+                if (fabs(x_cost - cand_cost) <= function_tol * x_cost) break;
+                const double rel = (x_cost - cand_cost) / model_change;
+                if (rel > min_rel_decrease) {
+                    for (int i = 0; i < 7; i++) x[i] = cand[i];
+                    x_norm = norm7(x);
+                    map_evaluate<true>(S.rec, nq, x, acc, s_red);
+                    x_cost = acc.cost;
+                    unpack_sym(acc.H, H);
+                    for (int i = 0; i < 6; i++) g[i] = acc.g[i];
+                    const double tt = 2.0 * rel - 1.0;
+                    double den = 1.0 - tt * tt * tt;
+                    if (den < 1.0 / 3.0) den = 1.0 / 3.0;
+                    radius = radius / den;
+                    if (radius > max_radius) radius = max_radius;
+                    decrease_factor = 2.0; reuse_diagonal = false;
+                    gmax = 0.0;
+                    for (int i = 0; i < 6; i++) gmax = fmax(gmax, fabs(g[i]));
+                    if (gmax <= gradient_tol) break;
+                } else {
+                    radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
+                }
+                if (radius <= min_radius) break;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int i = 0; i < 7; i++) S.x[i] = x[i];
+        S.stats[4 + outer] = iter;
+    }
+}
+
+} // namespace lmono

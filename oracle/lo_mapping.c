@@ -189,44 +189,14 @@ static void shift_axis(lo_map *m, int axis, int dir)
     }
 }
 
-int lo_map_process(lo_map *m, const lo_pt *corner_last, int n_corner, const lo_pt *surf_last, int n_surf,
-                   const double q_wodom[4], const double t_wodom[3], double q_w_curr[4], double t_w_curr[3], lo_map_stats *st)
+/* The optimisation part of one frame: 2 x [5-NN of every stack point in the map clouds -> line / plane tests -> factors ->
+ * ceres::Solve].  x = q_w_curr (xyzw), t_w_curr in/out.  corr_out (optional): the residual blocks of the LAST outer
+ * iteration (capacity n_cs + n_ss), *n_corr_out their number. */
+int lo_map_refine(const lo_pt *cmap, int n_cmap, const lo_pt *smap, int n_smap, const lo_pt *cstack, int n_cs,
+                  const lo_pt *sstack, int n_ss, double x[7], lo_map_stats *st, lo_corr *corr_out, int *n_corr_out)
 {
-    if (st) memset(st, 0, sizeof(*st));
-    /* transformAssociateToMap */
-    double tmp[3];
-    q_mul(m->q_wmap_wodom, q_wodom, q_w_curr);
-    q_rot(m->q_wmap_wodom, t_wodom, tmp);
-    for (int k = 0; k < 3; k++) t_w_curr[k] = tmp[k] + m->t_wmap_wodom[k];
-
-    int ci = cube_of(t_w_curr[0], m->cen_w), cj = cube_of(t_w_curr[1], m->cen_h), ck = cube_of(t_w_curr[2], m->cen_d);
-    while (ci < 3) { shift_axis(m, 0, +1); ci++; m->cen_w++; }
-    while (ci >= MW - 3) { shift_axis(m, 0, -1); ci--; m->cen_w--; }
-    while (cj < 3) { shift_axis(m, 1, +1); cj++; m->cen_h++; }
-    while (cj >= MH - 3) { shift_axis(m, 1, -1); cj--; m->cen_h--; }
-    while (ck < 3) { shift_axis(m, 2, +1); ck++; m->cen_d++; }
-    while (ck >= MD - 3) { shift_axis(m, 2, -1); ck--; m->cen_d--; }
-
-    int valid[125], n_valid = 0;
-    for (int i = ci - 2; i <= ci + 2; i++)
-        for (int j = cj - 2; j <= cj + 2; j++)
-            for (int k = ck - 1; k <= ck + 1; k++)
-                if (i >= 0 && i < MW && j >= 0 && j < MH && k >= 0 && k < MD) valid[n_valid++] = i + MW * j + MW * MH * k;
-    int n_cmap = 0, n_smap = 0;
-    for (int v = 0; v < n_valid; v++) { n_cmap += m->corner[valid[v]].n; n_smap += m->surf[valid[v]].n; }
-    lo_pt *cmap = (lo_pt *)malloc(sizeof(lo_pt) * (size_t)(n_cmap + 1)), *smap = (lo_pt *)malloc(sizeof(lo_pt) * (size_t)(n_smap + 1));
-    n_cmap = 0; n_smap = 0;
-    for (int v = 0; v < n_valid; v++) {
-        memcpy(cmap + n_cmap, m->corner[valid[v]].p, sizeof(lo_pt) * (size_t)m->corner[valid[v]].n); n_cmap += m->corner[valid[v]].n;
-        memcpy(smap + n_smap, m->surf[valid[v]].p, sizeof(lo_pt) * (size_t)m->surf[valid[v]].n); n_smap += m->surf[valid[v]].n;
-    }
-    lo_pt *cstack = (lo_pt *)malloc(sizeof(lo_pt) * (size_t)(n_corner + 1)), *sstack = (lo_pt *)malloc(sizeof(lo_pt) * (size_t)(n_surf + 1));
-    const int n_cs = lo_voxel_filter(corner_last, n_corner, m->inv_line, cstack);
-    const int n_ss = lo_voxel_filter(surf_last, n_surf, m->inv_plane, sstack);
-    if (st) { st->n_corner_stack = n_cs; st->n_surf_stack = n_ss; st->n_corner_map = n_cmap; st->n_surf_map = n_smap; }
-
-    double x[7] = { q_w_curr[0], q_w_curr[1], q_w_curr[2], q_w_curr[3], t_w_curr[0], t_w_curr[1], t_w_curr[2] };
-    if (n_cmap > 10 && n_smap > 50) {
+    if (n_corr_out) *n_corr_out = 0;
+    if (!(n_cmap > 10 && n_smap > 50)) return 0;
         lo_kdtree *kc = lo_kdtree_build(cmap, n_cmap), *ks = lo_kdtree_build(smap, n_smap);
         lo_corr *cs = (lo_corr *)malloc(sizeof(lo_corr) * (size_t)(n_cs + n_ss + 1));
         for (int it = 0; it < 2; it++) {
@@ -272,11 +242,52 @@ int lo_map_process(lo_map *m, const lo_pt *corner_last, int n_corner, const lo_p
                 n_plane++;
             }
             double c0, c1;
+            if (corr_out && it == 1) { memcpy(corr_out, cs, sizeof(lo_corr) * (size_t)nc); if (n_corr_out) *n_corr_out = nc; }
             const int iters = lo_lm_solve(cs, nc, x, &c0, &c1);
             if (st) { st->n_edge[it] = n_edge; st->n_plane[it] = n_plane; st->lm_iters[it] = iters; st->final_cost[it] = c1; }
         }
         free(cs); lo_kdtree_free(kc); lo_kdtree_free(ks);
+    return 0;
+}
+
+int lo_map_process(lo_map *m, const lo_pt *corner_last, int n_corner, const lo_pt *surf_last, int n_surf,
+                   const double q_wodom[4], const double t_wodom[3], double q_w_curr[4], double t_w_curr[3], lo_map_stats *st)
+{
+    if (st) memset(st, 0, sizeof(*st));
+    /* transformAssociateToMap */
+    double tmp[3];
+    q_mul(m->q_wmap_wodom, q_wodom, q_w_curr);
+    q_rot(m->q_wmap_wodom, t_wodom, tmp);
+    for (int k = 0; k < 3; k++) t_w_curr[k] = tmp[k] + m->t_wmap_wodom[k];
+
+    int ci = cube_of(t_w_curr[0], m->cen_w), cj = cube_of(t_w_curr[1], m->cen_h), ck = cube_of(t_w_curr[2], m->cen_d);
+    while (ci < 3) { shift_axis(m, 0, +1); ci++; m->cen_w++; }
+    while (ci >= MW - 3) { shift_axis(m, 0, -1); ci--; m->cen_w--; }
+    while (cj < 3) { shift_axis(m, 1, +1); cj++; m->cen_h++; }
+    while (cj >= MH - 3) { shift_axis(m, 1, -1); cj--; m->cen_h--; }
+    while (ck < 3) { shift_axis(m, 2, +1); ck++; m->cen_d++; }
+    while (ck >= MD - 3) { shift_axis(m, 2, -1); ck--; m->cen_d--; }
+
+    int valid[125], n_valid = 0;
+    for (int i = ci - 2; i <= ci + 2; i++)
+        for (int j = cj - 2; j <= cj + 2; j++)
+            for (int k = ck - 1; k <= ck + 1; k++)
+                if (i >= 0 && i < MW && j >= 0 && j < MH && k >= 0 && k < MD) valid[n_valid++] = i + MW * j + MW * MH * k;
+    int n_cmap = 0, n_smap = 0;
+    for (int v = 0; v < n_valid; v++) { n_cmap += m->corner[valid[v]].n; n_smap += m->surf[valid[v]].n; }
+    lo_pt *cmap = (lo_pt *)malloc(sizeof(lo_pt) * (size_t)(n_cmap + 1)), *smap = (lo_pt *)malloc(sizeof(lo_pt) * (size_t)(n_smap + 1));
+    n_cmap = 0; n_smap = 0;
+    for (int v = 0; v < n_valid; v++) {
+        memcpy(cmap + n_cmap, m->corner[valid[v]].p, sizeof(lo_pt) * (size_t)m->corner[valid[v]].n); n_cmap += m->corner[valid[v]].n;
+        memcpy(smap + n_smap, m->surf[valid[v]].p, sizeof(lo_pt) * (size_t)m->surf[valid[v]].n); n_smap += m->surf[valid[v]].n;
     }
+    lo_pt *cstack = (lo_pt *)malloc(sizeof(lo_pt) * (size_t)(n_corner + 1)), *sstack = (lo_pt *)malloc(sizeof(lo_pt) * (size_t)(n_surf + 1));
+    const int n_cs = lo_voxel_filter(corner_last, n_corner, m->inv_line, cstack);
+    const int n_ss = lo_voxel_filter(surf_last, n_surf, m->inv_plane, sstack);
+    if (st) { st->n_corner_stack = n_cs; st->n_surf_stack = n_ss; st->n_corner_map = n_cmap; st->n_surf_map = n_smap; }
+
+    double x[7] = { q_w_curr[0], q_w_curr[1], q_w_curr[2], q_w_curr[3], t_w_curr[0], t_w_curr[1], t_w_curr[2] };
+    lo_map_refine(cmap, n_cmap, smap, n_smap, cstack, n_cs, sstack, n_ss, x, st, NULL, NULL);
     for (int k = 0; k < 4; k++) q_w_curr[k] = x[k];
     for (int k = 0; k < 3; k++) t_w_curr[k] = x[4 + k];
     /* transformUpdate: q_wmap_wodom = q_w_curr * q_wodom^-1, t_wmap_wodom = t_w_curr - q_wmap_wodom * t_wodom */

@@ -99,6 +99,10 @@ void lo_map_free(lo_map *);
  * laserOdometry's pose of the scan.  Writes the refined pose (aft_mapped_to_init) and updates the map. */
 int lo_map_process(lo_map *, const lo_pt *corner_last, int n_corner, const lo_pt *surf_last, int n_surf,
                    const double q_wodom[4], const double t_wodom[3], double q_w_curr[4], double t_w_curr[3], lo_map_stats *);
+/* the optimisation part of one frame on explicit clouds (map clouds of the cube neighbourhood, down-sampled scan clouds);
+ * x = q(xyzw), t in/out; corr_out / n_corr_out (optional): residual blocks of the last outer iteration */
+int lo_map_refine(const lo_pt *cmap, int n_cmap, const lo_pt *smap, int n_smap, const lo_pt *cstack, int n_cs,
+                  const lo_pt *sstack, int n_ss, double x[7], lo_map_stats *st, lo_corr *corr_out, int *n_corr_out);
 /* introspection for the tests: cube (i, j, k) of the 21 x 21 x 11 arrays; which = 0 corner, 1 surf */
 int lo_map_cube(const lo_map *, int which, int i, int j, int k, const lo_pt **pts);
 void lo_map_centre(const lo_map *, int cen[3]);

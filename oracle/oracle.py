@@ -196,6 +196,35 @@ def run_mapping(xyzi, offsets, poses_odom, n_lines=64, min_range=5.0, line_res=0
     return dict(poses=out, stats=list(stats), stage_ms=ms)
 
 
+class Corr(C.Structure):
+    _fields_ = [("kind", C.c_int), ("cp", C.c_float * 3), ("a", C.c_double * 3), ("b", C.c_double * 3)]
+
+
+def voxel_filter(pts, leaf):
+    """pcl::VoxelGrid restated: [n,4] float32 -> centroids in ascending cell order."""
+    pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 4)
+    out = np.zeros_like(pts)
+    L = lib()
+    L.lo_voxel_filter.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p]
+    n = L.lo_voxel_filter(pts.ctypes.data, len(pts), C.c_float(np.float32(1.0) / np.float32(leaf)), out.ctypes.data)
+    return out[:n].copy()
+
+
+def map_refine(cmap, smap, cstack, sstack, x):
+    """Optimisation part of one laserMapping frame on explicit clouds.  Returns (x [7], MapStats, list of Corr of the last
+    outer iteration)."""
+    cm = np.ascontiguousarray(cmap, np.float32).reshape(-1, 4); sm = np.ascontiguousarray(smap, np.float32).reshape(-1, 4)
+    cs = np.ascontiguousarray(cstack, np.float32).reshape(-1, 4); ss = np.ascontiguousarray(sstack, np.float32).reshape(-1, 4)
+    xo = np.ascontiguousarray(x, np.float64).copy()
+    st = MapStats(); n_out = C.c_int(0)
+    corr = (Corr * (len(cs) + len(ss) + 1))()
+    L = lib()
+    L.lo_map_refine.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.lo_map_refine(cm.ctypes.data, len(cm), sm.ctypes.data, len(sm), cs.ctypes.data, len(cs), ss.ctypes.data, len(ss),
+                    xo.ctypes.data, C.byref(st), corr, C.byref(n_out))
+    return xo, st, list(corr[:n_out.value])
+
+
 def knn(pts, q, k):
     """k nearest neighbours of q in pts [n,4] through the kd-tree: (indices, squared distances)."""
     pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 4)
