@@ -179,7 +179,8 @@ int lmono_marg_evaluate(lmono_ctx *, int n_windows, const double *lin_J_h, const
  * *_map_h: the map clouds of each stream's 5 x 5 x 3 cube neighbourhood, *_stack_h: its voxel-filtered scan clouds
  * ([total][4] float32 x y z intensity, host memory; *_off: [n_streams + 1] point offsets).  pose_qt: [n_streams][7]
  * q_w_curr (x y z w), t_w_curr -- initial guess in, refined pose out.  stats (optional): [n_streams][8] = edge blocks of
- * the two outer iterations, plane blocks of the two, LM iterations of the two, 0, 0.  nn_out (optional):
+ * the two outer iterations, plane blocks of the two, LM iterations of the two, then the device time of the whole batch in
+ * microseconds: grid build, optimisation (2 x [correspond + solve]).  nn_out (optional):
  * [total stack points][5] neighbour indices of the last outer iteration (corner points first; -1 = no residual block).
  * The cube-map bookkeeping and the voxel filters of process() are not behind this ABI yet.                            */
 int lmono_map_refine(lmono_ctx *, int n_streams,

@@ -864,17 +864,29 @@ extern "C" int lmono_map_refine(lmono_ctx *c, int n_streams,
     MapStream *st_d = db.up(st.data(), st.size(), ok);
     if (!ok) { c->err = "lmono_map_refine: device allocation / upload failed"; return LMONO_ENOMEM; }
     hipStream_t stream = c->stream;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess || hipEventCreate(&ev2) != hipSuccess) { c->err = "hipEventCreate failed"; return LMONO_ENODEV; }
+    (void)hipEventRecord(ev0, stream);
     hipLaunchKernelGGL(k_cloud_grid, dim3(2 * n_streams), dim3(1024), 0, stream, (const CloudJob *)jobs_d);
+    (void)hipEventRecord(ev1, stream);
     for (int outer = 0; outer < 2; outer++) {
         if (max_nq > 0) hipLaunchKernelGGL(k_map_correspond, dim3((max_nq + 7) / 8, n_streams), dim3(256), 0, stream, (const MapStream *)st_d, outer);
         hipLaunchKernelGGL(k_map_solve, dim3(n_streams), dim3(1024), 0, stream, (const MapStream *)st_d, outer);
     }
+    (void)hipEventRecord(ev2, stream);
     int rc = check_launch(c, "map refine kernels");
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(stream));
+    float ms_grid = 0.f, ms_opt = 0.f;
+    (void)hipEventElapsedTime(&ms_grid, ev0, ev1); (void)hipEventElapsedTime(&ms_opt, ev1, ev2);
+    (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); (void)hipEventDestroy(ev2);
     HIP_TRY(c, hipMemcpy(xh.data(), x_d, sizeof(double) * xh.size(), hipMemcpyDeviceToHost));
     for (int s = 0; s < n_streams; s++) for (int k = 0; k < 7; k++) pose_qt[(size_t)s * 7 + k] = xh[(size_t)s * 8 + k];
-    if (stats_h) HIP_TRY(c, hipMemcpy(stats_h, stats_d, sizeof(int) * (size_t)n_streams * 8, hipMemcpyDeviceToHost));
+    if (stats_h) {
+        HIP_TRY(c, hipMemcpy(stats_h, stats_d, sizeof(int) * (size_t)n_streams * 8, hipMemcpyDeviceToHost));
+        // device time of the whole batch in microseconds: grid build, then the two correspond + solve rounds
+        for (int s = 0; s < n_streams; s++) { stats_h[(size_t)s * 8 + 6] = (int)(ms_grid * 1e3f); stats_h[(size_t)s * 8 + 7] = (int)(ms_opt * 1e3f); }
+    }
     if (nn_out_h && nq_total > 0) HIP_TRY(c, hipMemcpy(nn_out_h, nn_d, sizeof(int) * (size_t)nq_total * 5, hipMemcpyDeviceToHost));
     return LMONO_OK;
 }
