@@ -12,6 +12,7 @@
 #include <set>
 #include <stdexcept>
 #include <string>
+#include <array>
 #include <vector>
 #include "../../include/lmono_hip.h"
 
@@ -139,6 +140,31 @@ public:
     std::vector<double> process(ScanRegistration &reg, int n_chains = 1, int lead = 0);
 private:
     HipContext &hip_;
+};
+
+// laserMapping.cpp process(): the cube-array bookkeeping and the pcl::VoxelGrid filters stay host-side like in the
+// reference node (std::vector clouds instead of pcl::PointCloud), the optimisation block runs on the GPU through
+// lmono_map_refine.  SURVEY.md Appendix A.4 / row 8f-1.
+class LaserMapping {
+public:
+    typedef std::array<float, 4> Point;            // x y z intensity
+    LaserMapping(HipContext &hip, float lineRes = 0.4f, float planeRes = 0.8f);
+    // laserCloudCornerLast / laserCloudSurfLast: [n][4] float32 less-sharp / less-flat clouds of the scan;
+    // q_wodom_curr (x y z w), t_wodom_curr: laserOdometry's pose.  Writes q_w_curr / t_w_curr (aft_mapped_to_init).
+    void process(const std::vector<float> &laserCloudCornerLast, const std::vector<float> &laserCloudSurfLast,
+                 const double q_wodom_curr[4], const double t_wodom_curr[3], double q_w_curr[4], double t_w_curr[3]);
+    // pcl::VoxelGrid (cubic leaf, all fields averaged, ascending cell index, index-order sums)
+    static std::vector<Point> voxelGrid(const std::vector<Point> &in, float leaf);
+    int stats[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };     // of the last frame: edge / plane blocks and LM iterations per outer iteration
+    static constexpr int laserCloudWidth = 21, laserCloudHeight = 21, laserCloudDepth = 11;
+    static constexpr int laserCloudNum = laserCloudWidth * laserCloudHeight * laserCloudDepth;
+    int laserCloudCenWidth = 10, laserCloudCenHeight = 10, laserCloudCenDepth = 5;
+    std::vector<std::vector<Point>> laserCloudCornerArray, laserCloudSurfArray;
+private:
+    void shift(int axis, int dir);
+    HipContext &hip_;
+    float lineRes_, planeRes_;
+    double q_wmap_wodom_[4] = { 0, 0, 0, 1 }, t_wmap_wodom_[3] = { 0, 0, 0 };
 };
 
 } // namespace lmono_host

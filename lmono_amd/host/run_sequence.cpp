@@ -1,6 +1,7 @@
 // lmono_amd/host/run_sequence.cpp -- KITTI-layout sequence -> scanRegistration + laserOdometry on the GPU -> trajectory
 // file in the reference's "loam_odometry" format (Estimator.cc:270).  The C++ counterpart of examples/run_sequence.py:
-//   run_sequence <sequence_dir> <out_trajectory> [first] [count] [n_chains] [lead]
+//   run_sequence <sequence_dir> <out_trajectory> [first] [count] [n_chains] [lead] [out_mapped_trajectory]
+// With the last argument laserMapping refines every pose (scan-to-map) and its trajectory is written too.
 #include "kitti_io.hpp"
 #include "lmono_host.hpp"
 
@@ -16,6 +17,7 @@ int main(int argc, char **argv)
     const int first = argc > 3 ? std::atoi(argv[3]) : 0;
     int count = argc > 4 ? std::atoi(argv[4]) : -1;
     const int n_chains = argc > 5 ? std::atoi(argv[5]) : 1, lead = argc > 6 ? std::atoi(argv[6]) : 0;
+    const std::string out_mapped = argc > 7 ? argv[7] : "";
     try {
         std::vector<double> stamps;
         if (!read_times(seq + "/times.txt", stamps)) { std::fprintf(stderr, "%s/times.txt unreadable\n", seq.c_str()); return 1; }
@@ -36,6 +38,18 @@ int main(int argc, char **argv)
         TrajectoryWriter w(out, 1);
         if (!w.ok()) { std::fprintf(stderr, "cannot write %s\n", out.c_str()); return 1; }
         for (int k = 0; k < count; k++) w.write(stamps[(size_t)(first + k)], &poses[(size_t)k * 7 + 4], &poses[(size_t)k * 7]);
+        if (!out_mapped.empty()) {
+            LaserMapping mapping(hip);
+            TrajectoryWriter wm(out_mapped, 1);
+            if (!wm.ok()) { std::fprintf(stderr, "cannot write %s\n", out_mapped.c_str()); return 1; }
+            for (int k = 0; k < count; k++) {
+                double q[4], t[3];
+                mapping.process(reg.cloud(k, 2), reg.cloud(k, 4), &poses[(size_t)k * 7], &poses[(size_t)k * 7 + 4], q, t);
+                wm.write(stamps[(size_t)(first + k)], t, q);
+                std::printf("MAP %d edges %d %d planes %d %d iters %d %d\n", k, mapping.stats[0], mapping.stats[1], mapping.stats[2], mapping.stats[3],
+                            mapping.stats[4], mapping.stats[5]);
+            }
+        }
         std::printf("DONE %d scans %lld points\n", count, (long long)off.back());
     } catch (const std::exception &e) {
         std::fprintf(stderr, "run_sequence: %s\n", e.what());

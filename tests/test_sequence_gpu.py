@@ -56,3 +56,25 @@ def test_cpp_run_sequence_writes_the_reference_format(sequence_on_disk, tmp_path
     assert np.allclose(traj[:, 0], 100.0 + 0.1 * np.arange(6))
     # six printed decimals of the oracle's poses (t then q)
     assert np.abs(traj[:, 1:4] - ref["poses"][:, 4:7]).max() < 2e-6 and np.abs(traj[:, 4:8] - ref["poses"][:, 0:4]).max() < 2e-6
+
+
+def test_cpp_laser_mapping_matches_the_oracle_trajectory(oracle, sequence_on_disk, tmp_path):
+    """Host mirror LaserMapping (cube bookkeeping and voxel filters host-side as in the reference node, optimisation on
+    the GPU) over the sequence on disk against oracle.run_mapping."""
+    root, xyzi, off, ref = sequence_on_disk
+    subprocess.check_call(["make", "-s", "-C", HOST, "run_sequence"])
+    out = tmp_path / "loam_odometry.txt"; mapped = tmp_path / "aft_mapped.txt"
+    txt = subprocess.check_output([os.path.join(HOST, "run_sequence"), root, str(out), "0", "-1", "1", "0", str(mapped)], text=True)
+    want = oracle.run_mapping(xyzi, off, ref["poses"])
+    lines = [line.split() for line in txt.split("\n") if line.startswith("MAP ")]
+    assert len(lines) == 6
+    for k, line in enumerate(lines):
+        st = want["stats"][k]
+        assert [int(v) for v in (line[3], line[4], line[6], line[7], line[9], line[10])] == \
+            [st.n_edge[0], st.n_edge[1], st.n_plane[0], st.n_plane[1], st.lm_iters[0], st.lm_iters[1]], k
+    assert want["stats"][-1].n_plane[1] > 500
+    traj = IO.read_trajectory(str(mapped))
+    assert np.abs(traj[:, 1:4] - want["poses"][:, 4:7]).max() < 3e-6 and np.abs(traj[:, 4:8] - want["poses"][:, 0:4]).max() < 3e-6
+    # and the refinement did something: it differs from the odometry trajectory
+    odo = IO.read_trajectory(str(out))
+    assert np.abs(traj[:, 1:4] - odo[:, 1:4]).max() > 1e-4
