@@ -188,6 +188,14 @@ int lmono_map_refine(lmono_ctx *, int n_streams,
                      const float *corner_stack_h, const int64_t *corner_stack_off, const float *surf_stack_h, const int64_t *surf_stack_off,
                      double *pose_qt, int32_t *stats, int32_t *nn_out);
 
+/* pcl::VoxelGrid (cubic leaf, every field averaged) on n_clouds independent clouds in one call: laserMapping's
+ * downSizeFilterCorner / downSizeFilterSurf on the scan clouds and on the cubes of the neighbourhood (A-LOAM
+ * laserMapping.cpp process()).  xyzi_h: [total][4] float32, off: [n_clouds + 1], leaf_h:
+ * [n_clouds] leaf size in metres (<= 65536 points per cloud).  out_h: capacity total points; out_off: [n_clouds + 1]
+ * offsets of the filtered clouds (centroids in ascending cell index, the points of a cell summed in index order).  */
+int lmono_voxel_filter(lmono_ctx *, int n_clouds, const float *xyzi_h, const int64_t *off, const float *leaf_h,
+                       float *out_h, int64_t *out_off);
+
 /* ---- pose composition (laserOdometry: t_w_curr += q_w_curr * t_last_curr; q_w_curr *= q_last_curr) ------- *
  * lmono_pose_prefix_d: poses_d[k - first] = incr[first] (+) ... (+) incr[k] for k in [first, n) (incr[0] is the
  * identity: first = 0 gives poses relative to scan 0, first > 0 poses relative to scan first-1).  lmono_pose_rebase_d: poses[k] <- bases[0] (+) ... (+) bases[n_bases-1] (+) poses[k]; with scans

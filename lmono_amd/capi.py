@@ -12,7 +12,7 @@ SYMBOLS = [
     "lmono_create", "lmono_destroy", "lmono_last_error", "lmono_set_stream", "lmono_synchronize", "lmono_version",
     "lmono_batch_create", "lmono_batch_destroy", "lmono_scanreg_batch", "lmono_scanreg_batch_h", "lmono_batch_counts", "lmono_batch_get_cloud",
     "lmono_batch_get_curvature", "lmono_odom_batch", "lmono_odom_batch_d", "lmono_odom_correspond", "lmono_timing_reset", "lmono_timing_read",
-    "lmono_pose_prefix_d", "lmono_pose_rebase_d", "lmono_map_refine", "lmono_factor_eval", "lmono_factor_eval_d",
+    "lmono_pose_prefix_d", "lmono_pose_rebase_d", "lmono_map_refine", "lmono_voxel_filter", "lmono_factor_eval", "lmono_factor_eval_d",
     "lmono_triangulate", "lmono_outlier_scores", "lmono_shift_depth", "lmono_marginalize", "lmono_marg_evaluate", "lmono_ba_batch_create", "lmono_ba_batch_destroy", "lmono_ba_solve", "lmono_ba_batch_reset", "lmono_ba_batch_read",
 ]
 
@@ -204,6 +204,19 @@ class Context:
         except Exception:
             pass
 
+
+    def voxel_filter(self, clouds, leafs):
+        """pcl::VoxelGrid on a list of [n,4] float32 clouds (one leaf size each): list of filtered clouds."""
+        arrs = [np.ascontiguousarray(a, np.float32).reshape(-1, 4) for a in clouds]
+        off = np.zeros(len(arrs) + 1, np.int64)
+        off[1:] = np.cumsum([len(a) for a in arrs])
+        cat = np.concatenate(arrs) if off[-1] > 0 else np.zeros((0, 4), np.float32)
+        leaf = np.ascontiguousarray(leafs, np.float32)
+        out = np.zeros_like(cat) if len(cat) else np.zeros((1, 4), np.float32)
+        oo = np.zeros(len(arrs) + 1, np.int64)
+        self.L.lmono_voxel_filter.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
+        self.check(self.L.lmono_voxel_filter(self.h, len(arrs), cat.ctypes.data, off.ctypes.data, leaf.ctypes.data, out.ctypes.data, oo.ctypes.data))
+        return [out[oo[k]:oo[k + 1]].copy() for k in range(len(arrs))]
 
     def map_refine(self, corner_maps, surf_maps, corner_stacks, surf_stacks, poses_qt, want_nn=False):
         """Scan-to-map optimisation step of laserMapping for a batch of independent streams: lists of [n,4] float32 clouds

@@ -891,3 +891,48 @@ extern "C" int lmono_map_refine(lmono_ctx *c, int n_streams,
     return LMONO_OK;
 }
 
+// ---- pcl::VoxelGrid on arbitrary clouds (laserMapping's scan and cube filters), a batch of clouds per call -----------------
+extern "C" int lmono_voxel_filter(lmono_ctx *c, int n_clouds, const float *xyzi_h, const int64_t *off, const float *leaf_h,
+                                  float *out_h, int64_t *out_off)
+{
+    if (!c || n_clouds <= 0 || !off || !leaf_h || !out_h || !out_off) return LMONO_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int64_t total = off[n_clouds];
+    if (off[0] != 0 || total < 0 || (total > 0 && !xyzi_h)) return LMONO_EINVAL;
+    for (int k = 0; k < n_clouds; k++) {
+        const int64_t n = off[k + 1] - off[k];
+        if (n < 0 || n > kVoxCloudMax) { c->err = "lmono_voxel_filter: a cloud holds more than 65536 points"; return LMONO_ECAPACITY; }
+        if (!(leaf_h[k] > 0.f)) { c->err = "lmono_voxel_filter: leaf size must be positive"; return LMONO_EINVAL; }
+    }
+    DevBuf db;
+    bool ok = true;
+    float4 *in_d = (float4 *)db.up(xyzi_h, (size_t)total * 4, ok);
+    float4 *out_d = (float4 *)db.up((const float *)nullptr, (size_t)total * 4, ok);
+    unsigned int *ka = db.up((const unsigned int *)nullptr, (size_t)total, ok), *kb = db.up((const unsigned int *)nullptr, (size_t)total, ok);
+    int *ia = db.up((const int *)nullptr, (size_t)total, ok), *ib = db.up((const int *)nullptr, (size_t)total, ok);
+    int *nout_d = db.up((const int *)nullptr, (size_t)n_clouds, ok);
+    std::vector<VoxJob> jobs((size_t)n_clouds);
+    for (int k = 0; k < n_clouds; k++) {
+        VoxJob &J = jobs[(size_t)k];
+        J.in = in_d + off[k]; J.n = (int)(off[k + 1] - off[k]); J.inv_leaf = 1.0f / leaf_h[k];
+        J.out = out_d + off[k]; J.n_out = nout_d + k;
+        J.key_a = ka + off[k]; J.key_b = kb + off[k]; J.idx_a = ia + off[k]; J.idx_b = ib + off[k];
+    }
+    VoxJob *jobs_d = db.up(jobs.data(), jobs.size(), ok);
+    if (!ok) { c->err = "lmono_voxel_filter: device allocation / upload failed"; return LMONO_ENOMEM; }
+    hipLaunchKernelGGL(k_voxel_cloud, dim3(n_clouds), dim3(1024), 0, c->stream, (const VoxJob *)jobs_d);
+    int rc = check_launch(c, "k_voxel_cloud");
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::vector<int> nout((size_t)n_clouds);
+    HIP_TRY(c, hipMemcpy(nout.data(), nout_d, sizeof(int) * (size_t)n_clouds, hipMemcpyDeviceToHost));
+    out_off[0] = 0;
+    for (int k = 0; k < n_clouds; k++) {
+        if (nout[(size_t)k] < 0) { c->err = "lmono_voxel_filter: kernel rejected a cloud"; return LMONO_ECAPACITY; }
+        out_off[k + 1] = out_off[k] + nout[(size_t)k];
+        if (nout[(size_t)k] > 0)
+            HIP_TRY(c, hipMemcpy(out_h + 4 * out_off[k], out_d + off[k], sizeof(float) * 4 * (size_t)nout[(size_t)k], hipMemcpyDeviceToHost));
+    }
+    return LMONO_OK;
+}
+

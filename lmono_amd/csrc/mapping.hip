@@ -484,3 +484,138 @@ __global__ __launch_bounds__(1024) void k_map_solve(const MapStream *streams, in
 }
 
 } // namespace lmono
+
+// ---- pcl::VoxelGrid on an arbitrary cloud (laserMapping's downSizeFilterCorner / downSizeFilterSurf) -------
+// One 1024-thread workgroup per cloud (<= kVoxCloudMax points): bounding box -> PCL's linear cell index -> stable LSD
+// radix sort of (cell, point index) by cell, 4 bits per pass (per-thread digit counts over contiguous chunks keep equal
+// cells in index order) -> one thread per run of equal cells sums its points in that order (PCL's float summation order)
+// and writes the centroids in ascending cell order.  Bit-exact against oracle/lo_scanreg.c lo_voxel_filter.
+namespace lmono {
+
+constexpr int kVoxCloudMax = 65536;
+
+struct VoxJob {
+    const float4 *in; int n;
+    float inv_leaf;
+    float4 *out;           // capacity n
+    int *n_out;
+    unsigned int *key_a, *key_b;   // scratch [n] cell keys (ping-pong)
+    int *idx_a, *idx_b;            // scratch [n] point indices (ping-pong)
+};
+
+__global__ __launch_bounds__(1024) void k_voxel_cloud(const VoxJob *jobs)
+{
+    const VoxJob J = jobs[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = J.n;
+    if (n <= 0 || n > kVoxCloudMax) { if (tid == 0) *J.n_out = n <= 0 ? 0 : -1; return; }
+    __shared__ float s_box[16][6];
+    __shared__ int s_cnt[16][1024];      // digit-major counts / offsets of one radix pass
+    __shared__ int s_wsum[16];
+    __shared__ int s_total;
+    // bounding box
+    float mn[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, mx[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+    for (int i = tid; i < n; i += 1024) {
+        const float4 p = J.in[i];
+        mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+        mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int k = 0; k < 3; k++) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], o)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], o)); }
+    if (lane == 0) for (int k = 0; k < 3; k++) { s_box[wave][k] = mn[k]; s_box[wave][3 + k] = mx[k]; }
+    __syncthreads();
+    for (int w = 0; w < 16; w++) for (int k = 0; k < 3; k++) { mn[k] = fminf(mn[k], s_box[w][k]); mx[k] = fmaxf(mx[k], s_box[w][3 + k]); }
+    const float inv = J.inv_leaf;
+    const int minb0 = (int)floorf(mn[0] * inv), minb1 = (int)floorf(mn[1] * inv), minb2 = (int)floorf(mn[2] * inv);
+    const int div0 = (int)floorf(mx[0] * inv) - minb0 + 1, div1 = (int)floorf(mx[1] * inv) - minb1 + 1, div2 = (int)floorf(mx[2] * inv) - minb2 + 1;
+    const int mul1 = div0, mul2 = div0 * div1;
+    // highest cell index decides how many 4-bit passes are needed
+    const unsigned int max_cell = (unsigned int)((div0 - 1) + (div1 - 1) * mul1 + (div2 - 1) * mul2);
+    int bits = 0;
+    while (bits < 32 && (max_cell >> bits) != 0u) bits++;
+    const int passes = (bits + 3) / 4 > 0 ? (bits + 3) / 4 : 1;
+    // contiguous chunk of every thread
+    const int chunk = (n + 1023) / 1024;
+    const int c_lo = min(tid * chunk, n), c_hi = min(c_lo + chunk, n);
+    for (int i = c_lo; i < c_hi; i++) {
+        const float4 p = J.in[i];
+        const int i0 = (int)(floorf(p.x * inv) - (float)minb0);
+        const int i1 = (int)(floorf(p.y * inv) - (float)minb1);
+        const int i2 = (int)(floorf(p.z * inv) - (float)minb2);
+        J.key_a[i] = (unsigned int)(i0 + i1 * mul1 + i2 * mul2);
+        J.idx_a[i] = i;
+    }
+    __syncthreads();
+    unsigned int *ka = J.key_a, *kb = J.key_b;
+    int *ia = J.idx_a, *ib = J.idx_b;
+    for (int pass = 0; pass < passes; pass++) {
+        const int sh = 4 * pass;
+        int cnt[16];
+#pragma unroll
+        for (int d = 0; d < 16; d++) cnt[d] = 0;
+        for (int i = c_lo; i < c_hi; i++) {
+            const int dgt = (int)((ka[i] >> sh) & 15u);
+#pragma unroll
+            for (int d = 0; d < 16; d++) cnt[d] += dgt == d;
+        }
+#pragma unroll
+        for (int d = 0; d < 16; d++) s_cnt[d][tid] = cnt[d];
+        __syncthreads();
+        // exclusive prefix over the 16 x 1024 counts in (digit, thread) order: thread t owns entries 16 t .. 16 t + 15 of
+        // the flattened array
+        int *flat = &s_cnt[0][0];
+        int local = 0, v16[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) { v16[q] = flat[16 * tid + q]; local += v16[q]; }
+        const int incl = wave_scan_incl(local);
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        int run = incl - local;
+        for (int w = 0; w < wave; w++) run += s_wsum[w];
+#pragma unroll
+        for (int q = 0; q < 16; q++) { flat[16 * tid + q] = run; run += v16[q]; }
+        __syncthreads();
+        int off[16];
+#pragma unroll
+        for (int d = 0; d < 16; d++) off[d] = s_cnt[d][tid];
+        for (int i = c_lo; i < c_hi; i++) {
+            const unsigned int k = ka[i];
+            const int dgt = (int)((k >> sh) & 15u);
+            int dst = 0;
+#pragma unroll
+            for (int d = 0; d < 16; d++) if (dgt == d) { dst = off[d]; off[d]++; }
+            kb[dst] = k; ib[dst] = ia[i];
+        }
+        __threadfence_block();
+        __syncthreads();
+        unsigned int *tk = ka; ka = kb; kb = tk;
+        int *ti = ia; ia = ib; ib = ti;
+    }
+    // runs of equal cells -> centroids
+    int heads = 0;
+    for (int i = c_lo; i < c_hi; i++) heads += (i == 0 || ka[i] != ka[i - 1]);
+    const int incl = wave_scan_incl(heads);
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    int o = incl - heads;
+    for (int w = 0; w < wave; w++) o += s_wsum[w];
+    if (tid == 1023) s_total = o + heads;
+    for (int i = c_lo; i < c_hi; i++) {
+        if (!(i == 0 || ka[i] != ka[i - 1])) continue;
+        const unsigned int c = ka[i];
+        float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+        int cnt = 0;
+        for (int u = i; u < n && ka[u] == c; u++) {
+            const float4 p = J.in[ia[u]];
+            sx += p.x; sy += p.y; sz += p.z; si += p.w;
+            cnt++;
+        }
+        const float fc = (float)cnt;
+        J.out[o++] = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
+    }
+    __syncthreads();
+    if (tid == 0) *J.n_out = s_total;
+}
+
+} // namespace lmono

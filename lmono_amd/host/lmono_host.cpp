@@ -336,33 +336,20 @@ int cubeIndex(double v, int cen)
 LaserMapping::LaserMapping(HipContext &hip, float lineRes, float planeRes)
     : laserCloudCornerArray((size_t)laserCloudNum), laserCloudSurfArray((size_t)laserCloudNum), hip_(hip), lineRes_(lineRes), planeRes_(planeRes) {}
 
-std::vector<LaserMapping::Point> LaserMapping::voxelGrid(const std::vector<Point> &in, float leaf)
+// pcl::VoxelGrid on a batch of clouds through the C ABI (lmono_voxel_filter): one call, one workgroup per cloud
+std::vector<std::vector<LaserMapping::Point>> LaserMapping::voxelGrid(const std::vector<const std::vector<Point> *> &in, const std::vector<float> &leaf)
 {
-    std::vector<Point> out;
+    std::vector<std::vector<Point>> out(in.size());
     if (in.empty()) return out;
-    const float inv = 1.0f / leaf;
-    float mn[3] = { in[0][0], in[0][1], in[0][2] }, mx[3] = { in[0][0], in[0][1], in[0][2] };
-    for (const Point &p : in)
-        for (int k = 0; k < 3; k++) { if (p[(size_t)k] < mn[k]) mn[k] = p[(size_t)k]; if (p[(size_t)k] > mx[k]) mx[k] = p[(size_t)k]; }
-    int min_b[3], div_b[3];
-    for (int k = 0; k < 3; k++) { min_b[k] = (int)std::floor(mn[k] * inv); div_b[k] = (int)std::floor(mx[k] * inv) - min_b[k] + 1; }
-    const int mul1 = div_b[0], mul2 = div_b[0] * div_b[1];
-    std::vector<std::pair<unsigned int, int>> keys(in.size());
-    for (size_t i = 0; i < in.size(); i++) {
-        const int i0 = (int)(std::floor(in[i][0] * inv) - (float)min_b[0]);
-        const int i1 = (int)(std::floor(in[i][1] * inv) - (float)min_b[1]);
-        const int i2 = (int)(std::floor(in[i][2] * inv) - (float)min_b[2]);
-        keys[i] = { (unsigned int)(i0 + i1 * mul1 + i2 * mul2), (int)i };
-    }
-    std::sort(keys.begin(), keys.end());
-    for (size_t s = 0; s < keys.size();) {
-        size_t e = s + 1;
-        while (e < keys.size() && keys[e].first == keys[s].first) e++;
-        float sum[4] = { 0.f, 0.f, 0.f, 0.f };
-        for (size_t k = s; k < e; k++) for (int c = 0; c < 4; c++) sum[c] += in[(size_t)keys[k].second][(size_t)c];
-        const float cnt = (float)(e - s);
-        out.push_back({ sum[0] / cnt, sum[1] / cnt, sum[2] / cnt, sum[3] / cnt });
-        s = e;
+    std::vector<int64_t> off(in.size() + 1, 0), out_off(in.size() + 1, 0);
+    for (size_t k = 0; k < in.size(); k++) off[k + 1] = off[k] + (int64_t)in[k]->size();
+    std::vector<float> cat((size_t)off.back() * 4 + 4), res((size_t)off.back() * 4 + 4);
+    for (size_t k = 0; k < in.size(); k++)
+        if (!in[k]->empty()) std::memcpy(cat.data() + 4 * off[k], (*in[k])[0].data(), sizeof(float) * 4 * in[k]->size());
+    hip_.check(lmono_voxel_filter(hip_.get(), (int)in.size(), cat.data(), off.data(), leaf.data(), res.data(), out_off.data()), "lmono_voxel_filter");
+    for (size_t k = 0; k < in.size(); k++) {
+        out[k].resize((size_t)(out_off[k + 1] - out_off[k]));
+        if (!out[k].empty()) std::memcpy(out[k][0].data(), res.data() + 4 * out_off[k], sizeof(float) * 4 * out[k].size());
     }
     return out;
 }
@@ -420,7 +407,9 @@ void LaserMapping::process(const std::vector<float> &cornerLast, const std::vect
         for (size_t i = 0; i < o.size(); i++) o[i] = { v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3] };
         return o;
     };
-    const std::vector<Point> cornerStack = voxelGrid(to_points(cornerLast), lineRes_), surfStack = voxelGrid(to_points(surfLast), planeRes_);
+    const std::vector<Point> cornerLastPts = to_points(cornerLast), surfLastPts = to_points(surfLast);
+    const std::vector<std::vector<Point>> stacks = voxelGrid({ &cornerLastPts, &surfLastPts }, { lineRes_, planeRes_ });
+    const std::vector<Point> &cornerStack = stacks[0], &surfStack = stacks[1];
 
     // the optimisation block (2 x [5-NN, line / plane tests, ceres::Solve]) on the GPU
     double pose[7] = { q_w_curr[0], q_w_curr[1], q_w_curr[2], q_w_curr[3], t_w_curr[0], t_w_curr[1], t_w_curr[2] };
@@ -458,9 +447,19 @@ void LaserMapping::process(const std::vector<float> &cornerLast, const std::vect
     };
     insert(cornerStack, laserCloudCornerArray);
     insert(surfStack, laserCloudSurfArray);
-    for (int ind : laserCloudValidInd) {
-        laserCloudCornerArray[(size_t)ind] = voxelGrid(laserCloudCornerArray[(size_t)ind], lineRes_);
-        laserCloudSurfArray[(size_t)ind] = voxelGrid(laserCloudSurfArray[(size_t)ind], planeRes_);
+    // downSizeFilterCorner / downSizeFilterSurf over the cubes of the neighbourhood: one batched call
+    {
+        std::vector<const std::vector<Point> *> in;
+        std::vector<float> leaf;
+        for (int ind : laserCloudValidInd) {
+            in.push_back(&laserCloudCornerArray[(size_t)ind]); leaf.push_back(lineRes_);
+            in.push_back(&laserCloudSurfArray[(size_t)ind]); leaf.push_back(planeRes_);
+        }
+        std::vector<std::vector<Point>> filtered = voxelGrid(in, leaf);
+        for (size_t v = 0; v < laserCloudValidInd.size(); v++) {
+            laserCloudCornerArray[(size_t)laserCloudValidInd[v]] = std::move(filtered[2 * v]);
+            laserCloudSurfArray[(size_t)laserCloudValidInd[v]] = std::move(filtered[2 * v + 1]);
+        }
     }
 }
 

@@ -142,9 +142,9 @@ private:
     HipContext &hip_;
 };
 
-// laserMapping.cpp process(): the cube-array bookkeeping and the pcl::VoxelGrid filters stay host-side like in the
-// reference node (std::vector clouds instead of pcl::PointCloud), the optimisation block runs on the GPU through
-// lmono_map_refine.  SURVEY.md Appendix A.4 / row 8f-1.
+// laserMapping.cpp process(): the cube-array bookkeeping (which cloud belongs to which cube, shifts) stays host-side like
+// in the reference node (std::vector clouds instead of pcl::PointCloud); the numerics run on the GPU: the VoxelGrid
+// filters through lmono_voxel_filter, the optimisation block through lmono_map_refine.  SURVEY.md Appendix A.4 / row 8f-1.
 class LaserMapping {
 public:
     typedef std::array<float, 4> Point;            // x y z intensity
@@ -153,8 +153,8 @@ public:
     // q_wodom_curr (x y z w), t_wodom_curr: laserOdometry's pose.  Writes q_w_curr / t_w_curr (aft_mapped_to_init).
     void process(const std::vector<float> &laserCloudCornerLast, const std::vector<float> &laserCloudSurfLast,
                  const double q_wodom_curr[4], const double t_wodom_curr[3], double q_w_curr[4], double t_w_curr[3]);
-    // pcl::VoxelGrid (cubic leaf, all fields averaged, ascending cell index, index-order sums)
-    static std::vector<Point> voxelGrid(const std::vector<Point> &in, float leaf);
+    // pcl::VoxelGrid (cubic leaf, all fields averaged, ascending cell index, index-order sums) on a batch of clouds: GPU
+    std::vector<std::vector<Point>> voxelGrid(const std::vector<const std::vector<Point> *> &in, const std::vector<float> &leaf);
     int stats[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };     // of the last frame: edge / plane blocks and LM iterations per outer iteration
     static constexpr int laserCloudWidth = 21, laserCloudHeight = 21, laserCloudDepth = 11;
     static constexpr int laserCloudNum = laserCloudWidth * laserCloudHeight * laserCloudDepth;

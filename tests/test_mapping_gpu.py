@@ -102,3 +102,22 @@ def test_empty_map_leaves_the_pose_alone(gpu_ctx, frames):
     f = frames[0]
     poses, stats, _ = gpu_ctx.map_refine([np.zeros((0, 4), np.float32)], [np.zeros((0, 4), np.float32)], [f["cstack"]], [f["sstack"]], f["x0"][None])
     assert np.array_equal(poses[0], f["x0"]) and not stats[:, :6].any()
+
+
+def test_voxel_filter_is_bit_exact(oracle, gpu_ctx, frames):
+    """lmono_voxel_filter (stable radix sort by PCL cell index, index-order sums) against oracle.voxel_filter."""
+    rng = np.random.default_rng(11)
+    f = frames[0]
+    clouds = [f["cmap"], f["smap"], f["cstack"], f["sstack"]]
+    leafs = [0.4, 0.8, 0.4, 0.8]
+    big = np.zeros((60000, 4), np.float32); big[:, :3] = rng.uniform(-40, 40, (60000, 3)); big[:, 3] = rng.uniform(0, 64, 60000)
+    clouds += [big, big[:1], big[:2] * 0 + np.float32(-3.3), np.zeros((0, 4), np.float32), rng.normal(0, 0.05, (500, 4)).astype(np.float32)]
+    leafs += [0.8, 0.4, 0.2, 0.4, 0.2]
+    out = gpu_ctx.voxel_filter(clouds, leafs)
+    for c, leaf, o in zip(clouds, leafs, out):
+        want = oracle.voxel_filter(c, leaf) if len(c) else np.zeros((0, 4), np.float32)
+        assert o.shape == want.shape, (len(c), leaf, o.shape, want.shape)
+        assert np.array_equal(o.view(np.uint32), want.view(np.uint32))
+    assert len(out[4]) > 20000
+    with pytest.raises(Exception):
+        gpu_ctx.voxel_filter([np.zeros((70000, 4), np.float32)], [0.4])
