@@ -196,6 +196,22 @@ int lmono_map_refine(lmono_ctx *, int n_streams,
 int lmono_voxel_filter(lmono_ctx *, int n_clouds, const float *xyzi_h, const int64_t *off, const float *leaf_h,
                        float *out_h, int64_t *out_off);
 
+/* laserMapping with a device-resident map: the 21 x 21 x 11 array of 50 m cubes of laserMapping.cpp (laserCloudCornerArray /
+ * laserCloudSurfArray) lives in HBM, the library keeps only (offset, count) per cube on the host.  One call = one
+ * process() of the node for scan `scan` of a registered batch (its less-sharp / less-flat clouds are read in place):
+ * transformAssociateToMap, cube shifts, VoxelGrid of the scan clouds (mapping_line_resolution / _plane_resolution),
+ * the optimisation block, transformUpdate, insertion of the scan into the cubes and re-filtering of the 5 x 5 x 3
+ * neighbourhood.  q_wodom / t_wodom: laserOdometry's pose of the scan; q_w_curr / t_w_curr: aft_mapped_to_init.
+ * stats (optional, [8]): edge blocks of the two outer iterations, plane blocks, LM iterations, 0, 0.
+ * A-LOAM laserMapping.cpp process(), source absent from the reference tree.          */
+typedef struct lmono_mapper lmono_mapper;
+lmono_mapper *lmono_mapper_create(lmono_ctx *, float line_res, float plane_res);      /* HDL-64 launch file: 0.4, 0.8 */
+void          lmono_mapper_destroy(lmono_mapper *);
+int lmono_mapper_process(lmono_ctx *, lmono_mapper *, lmono_scan_batch *, int scan, const double q_wodom[4], const double t_wodom[3],
+                         double q_w_curr[4], double t_w_curr[3], int32_t *stats);
+/* cube (i, j, k) of the corner (which = 0) / surf (1) array: returns its size; copies the points when out_h != NULL */
+int lmono_mapper_cube(lmono_ctx *, lmono_mapper *, int which, int i, int j, int k, float *out_h, int cap);
+
 /* ---- pose composition (laserOdometry: t_w_curr += q_w_curr * t_last_curr; q_w_curr *= q_last_curr) ------- *
  * lmono_pose_prefix_d: poses_d[k - first] = incr[first] (+) ... (+) incr[k] for k in [first, n) (incr[0] is the
  * identity: first = 0 gives poses relative to scan 0, first > 0 poses relative to scan first-1).  lmono_pose_rebase_d: poses[k] <- bases[0] (+) ... (+) bases[n_bases-1] (+) poses[k]; with scans

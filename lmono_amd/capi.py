@@ -12,7 +12,7 @@ SYMBOLS = [
     "lmono_create", "lmono_destroy", "lmono_last_error", "lmono_set_stream", "lmono_synchronize", "lmono_version",
     "lmono_batch_create", "lmono_batch_destroy", "lmono_scanreg_batch", "lmono_scanreg_batch_h", "lmono_batch_counts", "lmono_batch_get_cloud",
     "lmono_batch_get_curvature", "lmono_odom_batch", "lmono_odom_batch_d", "lmono_odom_correspond", "lmono_timing_reset", "lmono_timing_read",
-    "lmono_pose_prefix_d", "lmono_pose_rebase_d", "lmono_map_refine", "lmono_voxel_filter", "lmono_factor_eval", "lmono_factor_eval_d",
+    "lmono_pose_prefix_d", "lmono_pose_rebase_d", "lmono_map_refine", "lmono_voxel_filter", "lmono_mapper_create", "lmono_mapper_destroy", "lmono_mapper_process", "lmono_mapper_cube", "lmono_factor_eval", "lmono_factor_eval_d",
     "lmono_triangulate", "lmono_outlier_scores", "lmono_shift_depth", "lmono_marginalize", "lmono_marg_evaluate", "lmono_ba_batch_create", "lmono_ba_batch_destroy", "lmono_ba_solve", "lmono_ba_batch_reset", "lmono_ba_batch_read",
 ]
 
@@ -372,3 +372,46 @@ class BaBatch:
             self.close()
         except Exception:
             pass
+
+
+class Mapper:
+    """laserMapping with a device-resident cube map (lmono_mapper_*): process(batch, scan, q_wodom, t_wodom) per frame."""
+
+    def __init__(self, ctx, line_res=0.4, plane_res=0.8):
+        self.ctx = ctx
+        L = ctx.L
+        L.lmono_mapper_create.restype = C.c_void_p
+        L.lmono_mapper_create.argtypes = [C.c_void_p, C.c_float, C.c_float]
+        L.lmono_mapper_destroy.argtypes = [C.c_void_p]
+        L.lmono_mapper_process.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 5
+        L.lmono_mapper_cube.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        self.h = L.lmono_mapper_create(ctx.h, line_res, plane_res)
+        if not self.h:
+            raise LmonoError("lmono_mapper_create failed: " + ctx.last_error())
+
+    def process(self, batch, scan, q_wodom, t_wodom):
+        q = np.ascontiguousarray(q_wodom, np.float64); t = np.ascontiguousarray(t_wodom, np.float64)
+        qo = np.zeros(4); to = np.zeros(3); st = np.zeros(8, np.int32)
+        self.ctx.check(self.ctx.L.lmono_mapper_process(self.ctx.h, self.h, batch.h, int(scan), q.ctypes.data, t.ctypes.data,
+                                                       qo.ctypes.data, to.ctypes.data, st.ctypes.data))
+        return qo, to, st
+
+    def cube(self, which, i, j, k):
+        n = self.ctx.L.lmono_mapper_cube(self.ctx.h, self.h, which, i, j, k, None, 0)
+        self.ctx.check(min(n, 0))
+        out = np.zeros((max(n, 1), 4), np.float32)
+        if n > 0:
+            self.ctx.check(min(self.ctx.L.lmono_mapper_cube(self.ctx.h, self.h, which, i, j, k, out.ctypes.data, n), 0))
+        return out[:n]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.L.lmono_mapper_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+

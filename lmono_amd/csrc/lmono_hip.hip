@@ -936,3 +936,335 @@ extern "C" int lmono_voxel_filter(lmono_ctx *c, int n_clouds, const float *xyzi_
     return LMONO_OK;
 }
 
+// ---- laserMapping with a device-resident cube map -------------------------------------------------------------
+// The 21 x 21 x 11 cube array of laserMapping.cpp lives in two HBM arenas (corner, surf); the host keeps, per cube, only
+// (offset, count).  Per frame the scan's feature clouds are taken from the scan batch in HBM, every numeric step runs in
+// the kernels above, and what crosses PCIe is the pose (56 B), the cube index of every down-sampled scan point and the
+// sizes of the re-filtered cubes.
+namespace {
+constexpr int kMapW = 21, kMapH = 21, kMapD = 11, kMapCubes = kMapW * kMapH * kMapD;
+constexpr int64_t kMapArena = 6 << 20;        // points per arena half
+constexpr int kMapNeighMax = 1 << 20;         // map points of the cube neighbourhood handed to one optimisation
+constexpr int kMapStackMax = kVoxCloudMax;
+struct Seg { int64_t off = 0; int n = 0; };
+}
+struct lmono_mapper {
+    lmono_ctx *ctx = nullptr;
+    float leaf[2] = { 0.4f, 0.8f };
+    int cen[3] = { 10, 10, 5 };
+    double q_wmap_wodom[4] = { 0, 0, 0, 1 }, t_wmap_wodom[3] = { 0, 0, 0 };
+    std::vector<Seg> cube[2];
+    std::vector<void *> allocs;
+    float4 *arena[2][2] = { { nullptr, nullptr }, { nullptr, nullptr } };   // [type][half]
+    int half[2] = { 0, 0 };
+    int64_t bump[2] = { 0, 0 };
+    // per-frame workspace
+    float4 *stack[2] = { nullptr, nullptr }, *newpts[2] = { nullptr, nullptr }, *neigh[2] = { nullptr, nullptr }, *sorted[2] = { nullptr, nullptr }, *cat[2] = { nullptr, nullptr };
+    unsigned int *vk[2] = { nullptr, nullptr };
+    int *vi[2] = { nullptr, nullptr }, *slot[2] = { nullptr, nullptr }, *rank[2] = { nullptr, nullptr }, *cube_of[2] = { nullptr, nullptr }, *pos[2] = { nullptr, nullptr };
+    GridCell *cells[2] = { nullptr, nullptr };
+    int tcap = 0;
+    int *masks = nullptr, *nout = nullptr, *stats = nullptr;
+    double *x = nullptr;
+    MapRec *rec = nullptr;
+    void *jobs = nullptr;           // device scratch for job arrays
+    size_t jobs_bytes = 0;
+    MapStream *stream_d = nullptr;
+};
+
+template <typename T> static bool mp_alloc(lmono_mapper *m, T *&p, size_t n)
+{
+    void *q = nullptr;
+    if (hipMalloc(&q, (n > 0 ? n : 1) * sizeof(T)) != hipSuccess) return false;
+    m->allocs.push_back(q);
+    p = (T *)q;
+    return true;
+}
+
+extern "C" void lmono_mapper_destroy(lmono_mapper *m)
+{
+    if (!m) return;
+    for (void *q : m->allocs) (void)hipFree(q);
+    delete m;
+}
+
+extern "C" lmono_mapper *lmono_mapper_create(lmono_ctx *c, float line_res, float plane_res)
+{
+    if (!c || !(line_res > 0.f) || !(plane_res > 0.f)) return nullptr;
+    if (hipSetDevice(c->device) != hipSuccess) return nullptr;
+    lmono_mapper *m = new lmono_mapper();
+    m->ctx = c; m->leaf[0] = line_res; m->leaf[1] = plane_res;
+    m->cube[0].assign((size_t)kMapCubes, Seg()); m->cube[1].assign((size_t)kMapCubes, Seg());
+    m->tcap = 1;
+    while (m->tcap < kMapNeighMax + 1) m->tcap <<= 1;
+    bool ok = true;
+    for (int t = 0; t < 2 && ok; t++) {
+        ok = ok && mp_alloc(m, m->arena[t][0], (size_t)kMapArena) && mp_alloc(m, m->arena[t][1], (size_t)kMapArena) &&
+             mp_alloc(m, m->stack[t], (size_t)kMapStackMax) && mp_alloc(m, m->newpts[t], (size_t)kMapStackMax) &&
+             mp_alloc(m, m->neigh[t], (size_t)kMapNeighMax) && mp_alloc(m, m->sorted[t], (size_t)kMapNeighMax) &&
+             mp_alloc(m, m->cat[t], (size_t)kMapNeighMax + kMapStackMax) &&
+             mp_alloc(m, m->vk[t], (size_t)2 * (kMapNeighMax + kMapStackMax)) && mp_alloc(m, m->vi[t], (size_t)2 * (kMapNeighMax + kMapStackMax)) &&
+             mp_alloc(m, m->slot[t], (size_t)kMapNeighMax) && mp_alloc(m, m->rank[t], (size_t)kMapNeighMax) &&
+             mp_alloc(m, m->cube_of[t], (size_t)kMapStackMax) && mp_alloc(m, m->pos[t], (size_t)kMapStackMax) &&
+             mp_alloc(m, m->cells[t], (size_t)m->tcap);
+    }
+    m->jobs_bytes = 1 << 20;
+    ok = ok && mp_alloc(m, m->masks, 2) && mp_alloc(m, m->nout, 2 * 256) && mp_alloc(m, m->stats, 8) && mp_alloc(m, m->x, 8) &&
+         mp_alloc(m, m->rec, (size_t)2 * kMapStackMax) && mp_alloc(m, (char *&)m->jobs, m->jobs_bytes) && mp_alloc(m, m->stream_d, 1);
+    if (!ok) { c->err = "lmono_mapper_create: device allocation failed"; lmono_mapper_destroy(m); return nullptr; }
+    return m;
+}
+
+// compaction: copy every live segment of one type into the other arena half
+static int mapper_compact(lmono_mapper *m, int t)
+{
+    lmono_ctx *c = m->ctx;
+    std::vector<CopyJob> jobs;
+    const int nh = m->half[t] ^ 1;
+    int64_t at = 0;
+    for (Seg &s : m->cube[(size_t)t]) {
+        if (s.n == 0) continue;
+        jobs.push_back({ m->arena[t][m->half[t]] + s.off, m->arena[t][nh] + at, s.n });
+        s.off = at; at += s.n;
+    }
+    if (jobs.size() * sizeof(CopyJob) > m->jobs_bytes) { c->err = "lmono_mapper: job scratch too small"; return LMONO_ECAPACITY; }
+    if (!jobs.empty()) {
+        HIP_TRY(c, hipMemcpyAsync(m->jobs, jobs.data(), jobs.size() * sizeof(CopyJob), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_copy_jobs, dim3((unsigned)jobs.size()), dim3(256), 0, c->stream, (const CopyJob *)m->jobs);
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    m->half[t] = nh; m->bump[t] = at;
+    return LMONO_OK;
+}
+
+extern "C" int lmono_mapper_process(lmono_ctx *c, lmono_mapper *m, lmono_scan_batch *b, int scan, const double q_wodom[4], const double t_wodom[3],
+                                    double q_w_curr[4], double t_w_curr[3], int32_t *stats_h)
+{
+    if (!c || !m || !b || !b->registered || scan < 0 || scan >= b->n_scans || !q_wodom || !t_wodom || !q_w_curr || !t_w_curr) return LMONO_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    auto qrot = [](const double *q, const double *v, double *o) {
+        const double ux = q[0], uy = q[1], uz = q[2], w = q[3];
+        const double uvx = 2.0 * (uy * v[2] - uz * v[1]), uvy = 2.0 * (uz * v[0] - ux * v[2]), uvz = 2.0 * (ux * v[1] - uy * v[0]);
+        o[0] = v[0] + w * uvx + (uy * uvz - uz * uvy); o[1] = v[1] + w * uvy + (uz * uvx - ux * uvz); o[2] = v[2] + w * uvz + (ux * uvy - uy * uvx);
+    };
+    auto qmul = [](const double *a, const double *bq, double *o) {
+        o[3] = a[3] * bq[3] - a[0] * bq[0] - a[1] * bq[1] - a[2] * bq[2];
+        o[0] = a[3] * bq[0] + a[0] * bq[3] + a[1] * bq[2] - a[2] * bq[1];
+        o[1] = a[3] * bq[1] + a[1] * bq[3] + a[2] * bq[0] - a[0] * bq[2];
+        o[2] = a[3] * bq[2] + a[2] * bq[3] + a[0] * bq[1] - a[1] * bq[0];
+    };
+    auto cube_of = [](double v, int cen) { int q = (int)((v + 25.0) / 50.0) + cen; if (v + 25.0 < 0) q--; return q; };
+    // transformAssociateToMap
+    double tmp[3], x[8] = { 0, 0, 0, 1, 0, 0, 0, 0 };
+    qmul(m->q_wmap_wodom, q_wodom, x);
+    qrot(m->q_wmap_wodom, t_wodom, tmp);
+    for (int k = 0; k < 3; k++) x[4 + k] = tmp[k] + m->t_wmap_wodom[k];
+    // centre cube and shifts of the (offset, count) tables
+    int ci = cube_of(x[4], m->cen[0]), cj = cube_of(x[5], m->cen[1]), ck = cube_of(x[6], m->cen[2]);
+    auto shift = [&](int axis, int dir) {
+        const int n[3] = { kMapW, kMapH, kMapD }, stride[3] = { 1, kMapW, kMapW * kMapH };
+        const int a1 = (axis + 1) % 3, a2 = (axis + 2) % 3;
+        for (int t = 0; t < 2; t++)
+            for (int u = 0; u < n[a1]; u++)
+                for (int v = 0; v < n[a2]; v++) {
+                    const int base = u * stride[a1] + v * stride[a2];
+                    std::vector<Seg> &arr = m->cube[(size_t)t];
+                    if (dir > 0) { for (int i = n[axis] - 1; i >= 1; i--) arr[(size_t)(base + i * stride[axis])] = arr[(size_t)(base + (i - 1) * stride[axis])]; arr[(size_t)base] = Seg(); }
+                    else { for (int i = 0; i < n[axis] - 1; i++) arr[(size_t)(base + i * stride[axis])] = arr[(size_t)(base + (i + 1) * stride[axis])]; arr[(size_t)(base + (n[axis] - 1) * stride[axis])] = Seg(); }
+                }
+    };
+    while (ci < 3) { shift(0, +1); ci++; m->cen[0]++; }
+    while (ci >= kMapW - 3) { shift(0, -1); ci--; m->cen[0]--; }
+    while (cj < 3) { shift(1, +1); cj++; m->cen[1]++; }
+    while (cj >= kMapH - 3) { shift(1, -1); cj--; m->cen[1]--; }
+    while (ck < 3) { shift(2, +1); ck++; m->cen[2]++; }
+    while (ck >= kMapD - 3) { shift(2, -1); ck--; m->cen[2]--; }
+    std::vector<int> valid;
+    for (int i = ci - 2; i <= ci + 2; i++)
+        for (int j = cj - 2; j <= cj + 2; j++)
+            for (int k = ck - 1; k <= ck + 1; k++)
+                if (i >= 0 && i < kMapW && j >= 0 && j < kMapH && k >= 0 && k < kMapD) valid.push_back(i + kMapW * j + kMapW * kMapH * k);
+    // scan clouds (HBM-resident in the batch) -> stacks
+    int fn[4];
+    HIP_TRY(c, hipMemcpyAsync(fn, b->v.feat_n + scan * 4, sizeof(fn), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    const float4 *last[2] = { b->v.less_sharp + (size_t)scan * kMaxLessSharp, b->v.less_flat + b->off_h[(size_t)scan] };
+    const int n_last[2] = { fn[1], fn[3] };
+    if (n_last[0] > kMapStackMax || n_last[1] > kMapStackMax) { c->err = "lmono_mapper: scan cloud too large"; return LMONO_ECAPACITY; }
+    char *jobs_h_bytes = nullptr; (void)jobs_h_bytes;
+    {
+        VoxJob vj[2];
+        for (int t = 0; t < 2; t++) {
+            vj[t].in = last[t]; vj[t].n = n_last[t]; vj[t].inv_leaf = 1.0f / m->leaf[t]; vj[t].out = m->stack[t]; vj[t].n_out = m->nout + t;
+            vj[t].key_a = m->vk[t]; vj[t].key_b = m->vk[t] + kMapStackMax; vj[t].idx_a = m->vi[t]; vj[t].idx_b = m->vi[t] + kMapStackMax;
+        }
+        HIP_TRY(c, hipMemcpyAsync(m->jobs, vj, sizeof(vj), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_voxel_cloud, dim3(2), dim3(1024), 0, st, (const VoxJob *)m->jobs);
+    }
+    int n_stack[2];
+    HIP_TRY(c, hipMemcpyAsync(n_stack, m->nout, sizeof(n_stack), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    if (n_stack[0] < 0 || n_stack[1] < 0) { c->err = "lmono_mapper: voxel filter rejected a scan cloud"; return LMONO_ECAPACITY; }
+    // map clouds of the neighbourhood, concatenated in validInd order
+    int n_map[2] = { 0, 0 };
+    {
+        std::vector<CopyJob> jobs;
+        for (int t = 0; t < 2; t++)
+            for (int ind : valid) {
+                const Seg &s = m->cube[(size_t)t][(size_t)ind];
+                if (s.n == 0) continue;
+                if (n_map[t] + s.n > kMapNeighMax) { c->err = "lmono_mapper: neighbourhood holds more than 1 Mi points"; return LMONO_ECAPACITY; }
+                jobs.push_back({ m->arena[t][m->half[t]] + s.off, m->neigh[t] + n_map[t], s.n });
+                n_map[t] += s.n;
+            }
+        if (!jobs.empty()) {
+            HIP_TRY(c, hipMemcpyAsync(m->jobs, jobs.data(), jobs.size() * sizeof(CopyJob), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_copy_jobs, dim3((unsigned)jobs.size()), dim3(256), 0, st, (const CopyJob *)m->jobs);
+            HIP_TRY(c, hipStreamSynchronize(st));    // the job array is reused below
+        }
+    }
+    // optimisation: grids, 2 x [correspond + solve]
+    int32_t stats[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    HIP_TRY(c, hipMemcpyAsync(m->x, x, sizeof(double) * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemsetAsync(m->stats, 0, sizeof(int) * 8, st));
+    if (n_map[0] > 10 && n_map[1] > 50) {
+        CloudJob cj2[2];
+        MapStream S;
+        for (int t = 0; t < 2; t++) {
+            cj2[t].src = m->neigh[t]; cj2[t].n = n_map[t]; cj2[t].cell = m->cells[t]; cj2[t].tcap = m->tcap; cj2[t].sorted = m->sorted[t];
+            cj2[t].slot_of = m->slot[t]; cj2[t].rank_of = m->rank[t]; cj2[t].mask_out = m->masks + t;
+            S.cell[t] = m->cells[t]; S.sorted[t] = m->sorted[t]; S.cloud[t] = m->neigh[t]; S.mask[t] = m->masks + t; S.n_map[t] = n_map[t];
+            S.stack[t] = m->stack[t]; S.n_stack[t] = n_stack[t];
+        }
+        S.rec = m->rec; S.x = m->x; S.stats = m->stats; S.nn_out = nullptr;
+        HIP_TRY(c, hipMemcpyAsync(m->jobs, cj2, sizeof(cj2), hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipMemcpyAsync(m->stream_d, &S, sizeof(S), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_cloud_grid, dim3(2), dim3(1024), 0, st, (const CloudJob *)m->jobs);
+        const int nq = n_stack[0] + n_stack[1];
+        for (int outer = 0; outer < 2; outer++) {
+            if (nq > 0) hipLaunchKernelGGL(k_map_correspond, dim3((nq + 7) / 8, 1), dim3(256), 0, st, (const MapStream *)m->stream_d, outer);
+            hipLaunchKernelGGL(k_map_solve, dim3(1), dim3(1024), 0, st, (const MapStream *)m->stream_d, outer);
+        }
+        HIP_TRY(c, hipMemcpyAsync(x, m->x, sizeof(double) * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipMemcpyAsync(stats, m->stats, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+    }
+    for (int k = 0; k < 4; k++) q_w_curr[k] = x[k];
+    for (int k = 0; k < 3; k++) t_w_curr[k] = x[4 + k];
+    if (stats_h) for (int k = 0; k < 8; k++) stats_h[k] = k < 6 ? stats[k] : 0;
+    // transformUpdate
+    {
+        const double n2 = q_wodom[0] * q_wodom[0] + q_wodom[1] * q_wodom[1] + q_wodom[2] * q_wodom[2] + q_wodom[3] * q_wodom[3];
+        const double qi[4] = { -q_wodom[0] / n2, -q_wodom[1] / n2, -q_wodom[2] / n2, q_wodom[3] / n2 };
+        qmul(x, qi, m->q_wmap_wodom);
+        qrot(m->q_wmap_wodom, t_wodom, tmp);
+        for (int k = 0; k < 3; k++) m->t_wmap_wodom[k] = x[4 + k] - tmp[k];
+    }
+    // the scan joins the cubes: transformed points and their cube on the device, the per-cube placement on the host
+    HIP_TRY(c, hipMemcpyAsync(m->x, x, sizeof(double) * 8, hipMemcpyHostToDevice, st));
+    std::vector<int> cube_h[2];
+    for (int t = 0; t < 2; t++) {
+        cube_h[t].assign((size_t)(n_stack[t] > 0 ? n_stack[t] : 1), -1);
+        if (n_stack[t] > 0) {
+            hipLaunchKernelGGL(k_map_assign, dim3((n_stack[t] + 255) / 256), dim3(256), 0, st, (const float4 *)m->stack[t], n_stack[t], (const double *)m->x,
+                               m->cen[0], m->cen[1], m->cen[2], m->newpts[t], m->cube_of[t]);
+            HIP_TRY(c, hipMemcpyAsync(cube_h[t].data(), m->cube_of[t], sizeof(int) * (size_t)n_stack[t], hipMemcpyDeviceToHost, st));
+        }
+    }
+    HIP_TRY(c, hipStreamSynchronize(st));
+    std::vector<char> is_valid((size_t)kMapCubes, 0);
+    for (int ind : valid) is_valid[(size_t)ind] = 1;
+    for (int t = 0; t < 2; t++) {
+        // cubes touched by this frame: those of the neighbourhood (re-filtered even without new points) and those that
+        // receive points; `cat` holds, per touched cube, [old points | new points in stack order]
+        std::vector<int> add((size_t)kMapCubes, 0);
+        for (int i = 0; i < n_stack[t]; i++) if (cube_h[t][(size_t)i] >= 0) add[(size_t)cube_h[t][(size_t)i]]++;
+        std::vector<int> touched;
+        for (int ind = 0; ind < kMapCubes; ind++) if ((is_valid[(size_t)ind] && m->cube[(size_t)t][(size_t)ind].n + add[(size_t)ind] > 0) || (!is_valid[(size_t)ind] && add[(size_t)ind] > 0)) touched.push_back(ind);
+        std::vector<int64_t> cat_off((size_t)kMapCubes, -1);
+        int64_t at = 0;
+        std::vector<CopyJob> copy;
+        for (int ind : touched) {
+            const Seg &s = m->cube[(size_t)t][(size_t)ind];
+            cat_off[(size_t)ind] = at;
+            if (s.n > 0) copy.push_back({ m->arena[t][m->half[t]] + s.off, m->cat[t] + at, s.n });
+            at += s.n + add[(size_t)ind];
+        }
+        if (at > (int64_t)kMapNeighMax + kMapStackMax) { c->err = "lmono_mapper: frame touches more points than the workspace holds"; return LMONO_ECAPACITY; }
+        std::vector<int> fill((size_t)kMapCubes, 0), pos_h((size_t)(n_stack[t] > 0 ? n_stack[t] : 1), -1);
+        for (int i = 0; i < n_stack[t]; i++) {
+            const int ind = cube_h[t][(size_t)i];
+            if (ind < 0) continue;
+            pos_h[(size_t)i] = (int)(cat_off[(size_t)ind] + m->cube[(size_t)t][(size_t)ind].n + fill[(size_t)ind]++);
+        }
+        if (!copy.empty()) {
+            HIP_TRY(c, hipMemcpyAsync(m->jobs, copy.data(), copy.size() * sizeof(CopyJob), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_copy_jobs, dim3((unsigned)copy.size()), dim3(256), 0, st, (const CopyJob *)m->jobs);
+        }
+        if (n_stack[t] > 0) {
+            HIP_TRY(c, hipMemcpyAsync(m->pos[t], pos_h.data(), sizeof(int) * (size_t)n_stack[t], hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_scatter_pos, dim3((n_stack[t] + 255) / 256), dim3(256), 0, st, (const float4 *)m->newpts[t], (const int *)m->pos[t], n_stack[t], m->cat[t]);
+        }
+        HIP_TRY(c, hipStreamSynchronize(st));   // job array and pos_h are reused
+        // arena space for the outputs (an output is never larger than its input)
+        if (m->bump[t] + at > kMapArena) {
+            int rc = mapper_compact(m, t);
+            if (rc) return rc;
+            // the copy jobs above read the old half: redo them against the compacted one is unnecessary -- `cat` is already built
+            if (m->bump[t] + at > kMapArena) { c->err = "lmono_mapper: map arena exhausted"; return LMONO_ECAPACITY; }
+        }
+        // neighbourhood cubes are re-filtered, the others just keep [old | new]
+        std::vector<VoxJob> vox;
+        std::vector<CopyJob> keep;
+        std::vector<int> vox_ind;
+        std::vector<Seg> new_seg((size_t)kMapCubes);
+        for (int ind : touched) {
+            const int n_in = m->cube[(size_t)t][(size_t)ind].n + add[(size_t)ind];
+            float4 *dst = m->arena[t][m->half[t]] + m->bump[t];
+            new_seg[(size_t)ind].off = m->bump[t];
+            if (is_valid[(size_t)ind]) {
+                if (n_in > kVoxCloudMax) { c->err = "lmono_mapper: a cube holds more than 65536 points"; return LMONO_ECAPACITY; }
+                VoxJob J;
+                J.in = m->cat[t] + cat_off[(size_t)ind]; J.n = n_in; J.inv_leaf = 1.0f / m->leaf[t]; J.out = dst; J.n_out = m->nout + (int)vox.size();
+                J.key_a = m->vk[t] + 2 * cat_off[(size_t)ind]; J.key_b = J.key_a + n_in; J.idx_a = m->vi[t] + 2 * cat_off[(size_t)ind]; J.idx_b = J.idx_a + n_in;
+                vox.push_back(J); vox_ind.push_back(ind);
+            } else {
+                keep.push_back({ m->cat[t] + cat_off[(size_t)ind], dst, n_in });
+                new_seg[(size_t)ind].n = n_in;
+            }
+            m->bump[t] += n_in;
+        }
+        if (vox.size() > 256) { c->err = "lmono_mapper: too many cubes in one frame"; return LMONO_ECAPACITY; }
+        std::vector<int> nout_h(vox.size() > 0 ? vox.size() : 1, 0);
+        if (!vox.empty()) {
+            HIP_TRY(c, hipMemcpyAsync(m->jobs, vox.data(), vox.size() * sizeof(VoxJob), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_voxel_cloud, dim3((unsigned)vox.size()), dim3(1024), 0, st, (const VoxJob *)m->jobs);
+            HIP_TRY(c, hipMemcpyAsync(nout_h.data(), m->nout, sizeof(int) * vox.size(), hipMemcpyDeviceToHost, st));
+            HIP_TRY(c, hipStreamSynchronize(st));
+        }
+        if (!keep.empty()) {
+            HIP_TRY(c, hipMemcpyAsync(m->jobs, keep.data(), keep.size() * sizeof(CopyJob), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_copy_jobs, dim3((unsigned)keep.size()), dim3(256), 0, st, (const CopyJob *)m->jobs);
+            HIP_TRY(c, hipStreamSynchronize(st));
+        }
+        for (size_t v = 0; v < vox.size(); v++) {
+            if (nout_h[v] < 0) { c->err = "lmono_mapper: voxel filter rejected a cube"; return LMONO_ECAPACITY; }
+            new_seg[(size_t)vox_ind[v]].n = nout_h[v];
+        }
+        for (int ind : touched) m->cube[(size_t)t][(size_t)ind] = new_seg[(size_t)ind];
+    }
+    return check_launch(c, "mapper kernels");
+}
+
+extern "C" int lmono_mapper_cube(lmono_ctx *c, lmono_mapper *m, int which, int i, int j, int k, float *out_h, int cap)
+{
+    if (!c || !m || which < 0 || which > 1 || i < 0 || i >= kMapW || j < 0 || j >= kMapH || k < 0 || k >= kMapD) return LMONO_EINVAL;
+    const Seg &s = m->cube[(size_t)which][(size_t)(i + kMapW * j + kMapW * kMapH * k)];
+    if (!out_h) return s.n;
+    if (s.n > cap) return LMONO_ECAPACITY;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (s.n > 0) HIP_TRY(c, hipMemcpy(out_h, m->arena[which][m->half[which]] + s.off, sizeof(float) * 4 * (size_t)s.n, hipMemcpyDeviceToHost));
+    return s.n;
+}
+

@@ -121,3 +121,45 @@ def test_voxel_filter_is_bit_exact(oracle, gpu_ctx, frames):
     assert len(out[4]) > 20000
     with pytest.raises(Exception):
         gpu_ctx.voxel_filter([np.zeros((70000, 4), np.float32)], [0.4])
+
+
+def test_device_resident_mapper_follows_the_oracle(oracle, gpu_ctx):
+    """lmono_mapper_process frame by frame (scan clouds taken in place from the scan batch, cube map in HBM) against
+    oracle.run_mapping fed with the same odometry poses."""
+    import torch
+    import lmono_amd
+    w = oracle.S1World(n_az=500)
+    traj = w.trajectory(12)
+    x, off = w.scans(traj)
+    xd = torch.from_numpy(x).cuda()
+    batch = lmono_amd.ScanBatch(gpu_ctx, 12, len(x))
+    batch.scanreg(xd.data_ptr(), off, 64, 5.0, keepalive=xd)
+    _, odo = batch.odometry(n_chains=1, lead=0)
+    want = oracle.run_mapping(x, off, odo)
+    mapper = lmono_amd.Mapper(gpu_ctx)
+    got = np.zeros((12, 7))
+    for k in range(12):
+        q, t, st = mapper.process(batch, k, odo[k, :4], odo[k, 4:])
+        got[k, :4] = q; got[k, 4:] = t
+        ws = want["stats"][k]
+        assert list(st[:6]) == [ws.n_edge[0], ws.n_edge[1], ws.n_plane[0], ws.n_plane[1], ws.lm_iters[0], ws.lm_iters[1]], k
+    assert np.abs(got - want["poses"]).max() < 1e-7
+    assert want["stats"][-1].n_plane[1] > 1000 and oracle.ate(got, oracle.gt_relative(traj)) < oracle.ate(odo, oracle.gt_relative(traj))
+    # the map itself: replay the oracle frame by frame and compare every cube
+    m = oracle.Map()
+    import ctypes as C
+    for k in range(12):
+        ls, lf = _scan_clouds(oracle, x, off, k)
+        m.process(ls, lf, odo[k, :4], odo[k, 4:])
+    n_pts = 0
+    for which in (0, 1):
+        for i in range(21):
+            for j in range(21):
+                for kk in range(11):
+                    a = m.cube(which, i, j, kk)
+                    bq = mapper.cube(which, i, j, kk)
+                    assert a.shape == bq.shape, (which, i, j, kk)
+                    if len(a):
+                        assert np.abs(a - bq).max() < 1e-4
+                        n_pts += len(a)
+    assert n_pts > 20000
