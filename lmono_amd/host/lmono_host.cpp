@@ -309,158 +309,25 @@ std::vector<double> LaserOdometry::process(ScanRegistration &reg, int n_chains, 
 }
 
 // ---- laserMapping ---------------------------------------------------------------------------------------------------
-namespace {
-void q_rot(const double q[4], const double v[3], double o[3])
+LaserMapping::LaserMapping(HipContext &hip, float lineRes, float planeRes) : hip_(hip), mapper_(lmono_mapper_create(hip.get(), lineRes, planeRes))
 {
-    const double ux = q[0], uy = q[1], uz = q[2], w = q[3];
-    const double uvx = 2.0 * (uy * v[2] - uz * v[1]), uvy = 2.0 * (uz * v[0] - ux * v[2]), uvz = 2.0 * (ux * v[1] - uy * v[0]);
-    o[0] = v[0] + w * uvx + (uy * uvz - uz * uvy);
-    o[1] = v[1] + w * uvy + (uz * uvx - ux * uvz);
-    o[2] = v[2] + w * uvz + (ux * uvy - uy * uvx);
+    if (!mapper_) throw std::runtime_error(std::string("lmono_mapper_create: ") + lmono_last_error(hip.get()));
 }
-void q_mul(const double a[4], const double b[4], double o[4])
+LaserMapping::~LaserMapping() { lmono_mapper_destroy(mapper_); }
+void LaserMapping::process(ScanRegistration &reg, int scan, const double q_wodom_curr[4], const double t_wodom_curr[3], double q_w_curr[4], double t_w_curr[3])
 {
-    o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
-    o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
-    o[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
-    o[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
-}
-int cubeIndex(double v, int cen)
-{
-    int c = (int)((v + 25.0) / 50.0) + cen;
-    if (v + 25.0 < 0) c--;
-    return c;
-}
-}
-
-LaserMapping::LaserMapping(HipContext &hip, float lineRes, float planeRes)
-    : laserCloudCornerArray((size_t)laserCloudNum), laserCloudSurfArray((size_t)laserCloudNum), hip_(hip), lineRes_(lineRes), planeRes_(planeRes) {}
-
-// pcl::VoxelGrid on a batch of clouds through the C ABI (lmono_voxel_filter): one call, one workgroup per cloud
-std::vector<std::vector<LaserMapping::Point>> LaserMapping::voxelGrid(const std::vector<const std::vector<Point> *> &in, const std::vector<float> &leaf)
-{
-    std::vector<std::vector<Point>> out(in.size());
-    if (in.empty()) return out;
-    std::vector<int64_t> off(in.size() + 1, 0), out_off(in.size() + 1, 0);
-    for (size_t k = 0; k < in.size(); k++) off[k + 1] = off[k] + (int64_t)in[k]->size();
-    std::vector<float> cat((size_t)off.back() * 4 + 4), res((size_t)off.back() * 4 + 4);
-    for (size_t k = 0; k < in.size(); k++)
-        if (!in[k]->empty()) std::memcpy(cat.data() + 4 * off[k], (*in[k])[0].data(), sizeof(float) * 4 * in[k]->size());
-    hip_.check(lmono_voxel_filter(hip_.get(), (int)in.size(), cat.data(), off.data(), leaf.data(), res.data(), out_off.data()), "lmono_voxel_filter");
-    for (size_t k = 0; k < in.size(); k++) {
-        out[k].resize((size_t)(out_off[k + 1] - out_off[k]));
-        if (!out[k].empty()) std::memcpy(out[k][0].data(), res.data() + 4 * out_off[k], sizeof(float) * 4 * out[k].size());
-    }
-    return out;
-}
-
-void LaserMapping::shift(int axis, int dir)
-{
-    const int n[3] = { laserCloudWidth, laserCloudHeight, laserCloudDepth };
-    const int stride[3] = { 1, laserCloudWidth, laserCloudWidth * laserCloudHeight };
-    const int a1 = (axis + 1) % 3, a2 = (axis + 2) % 3;
-    for (auto *arr : { &laserCloudCornerArray, &laserCloudSurfArray })
-        for (int u = 0; u < n[a1]; u++)
-            for (int v = 0; v < n[a2]; v++) {
-                const int base = u * stride[a1] + v * stride[a2];
-                if (dir > 0) {
-                    for (int i = n[axis] - 1; i >= 1; i--) std::swap((*arr)[(size_t)(base + i * stride[axis])], (*arr)[(size_t)(base + (i - 1) * stride[axis])]);
-                    (*arr)[(size_t)base].clear();
-                } else {
-                    for (int i = 0; i < n[axis] - 1; i++) std::swap((*arr)[(size_t)(base + i * stride[axis])], (*arr)[(size_t)(base + (i + 1) * stride[axis])]);
-                    (*arr)[(size_t)(base + (n[axis] - 1) * stride[axis])].clear();
-                }
-            }
-}
-
-void LaserMapping::process(const std::vector<float> &cornerLast, const std::vector<float> &surfLast,
-                           const double q_wodom_curr[4], const double t_wodom_curr[3], double q_w_curr[4], double t_w_curr[3])
-{
-    // transformAssociateToMap
-    double tmp[3];
-    q_mul(q_wmap_wodom_, q_wodom_curr, q_w_curr);
-    q_rot(q_wmap_wodom_, t_wodom_curr, tmp);
-    for (int k = 0; k < 3; k++) t_w_curr[k] = tmp[k] + t_wmap_wodom_[k];
-
-    int centerCubeI = cubeIndex(t_w_curr[0], laserCloudCenWidth), centerCubeJ = cubeIndex(t_w_curr[1], laserCloudCenHeight),
-        centerCubeK = cubeIndex(t_w_curr[2], laserCloudCenDepth);
-    while (centerCubeI < 3) { shift(0, +1); centerCubeI++; laserCloudCenWidth++; }
-    while (centerCubeI >= laserCloudWidth - 3) { shift(0, -1); centerCubeI--; laserCloudCenWidth--; }
-    while (centerCubeJ < 3) { shift(1, +1); centerCubeJ++; laserCloudCenHeight++; }
-    while (centerCubeJ >= laserCloudHeight - 3) { shift(1, -1); centerCubeJ--; laserCloudCenHeight--; }
-    while (centerCubeK < 3) { shift(2, +1); centerCubeK++; laserCloudCenDepth++; }
-    while (centerCubeK >= laserCloudDepth - 3) { shift(2, -1); centerCubeK--; laserCloudCenDepth--; }
-
-    std::vector<int> laserCloudValidInd;
-    for (int i = centerCubeI - 2; i <= centerCubeI + 2; i++)
-        for (int j = centerCubeJ - 2; j <= centerCubeJ + 2; j++)
-            for (int k = centerCubeK - 1; k <= centerCubeK + 1; k++)
-                if (i >= 0 && i < laserCloudWidth && j >= 0 && j < laserCloudHeight && k >= 0 && k < laserCloudDepth)
-                    laserCloudValidInd.push_back(i + laserCloudWidth * j + laserCloudWidth * laserCloudHeight * k);
-    std::vector<Point> cornerFromMap, surfFromMap;
-    for (int ind : laserCloudValidInd) {
-        cornerFromMap.insert(cornerFromMap.end(), laserCloudCornerArray[(size_t)ind].begin(), laserCloudCornerArray[(size_t)ind].end());
-        surfFromMap.insert(surfFromMap.end(), laserCloudSurfArray[(size_t)ind].begin(), laserCloudSurfArray[(size_t)ind].end());
-    }
-    auto to_points = [](const std::vector<float> &v) {
-        std::vector<Point> o(v.size() / 4);
-        for (size_t i = 0; i < o.size(); i++) o[i] = { v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3] };
-        return o;
-    };
-    const std::vector<Point> cornerLastPts = to_points(cornerLast), surfLastPts = to_points(surfLast);
-    const std::vector<std::vector<Point>> stacks = voxelGrid({ &cornerLastPts, &surfLastPts }, { lineRes_, planeRes_ });
-    const std::vector<Point> &cornerStack = stacks[0], &surfStack = stacks[1];
-
-    // the optimisation block (2 x [5-NN, line / plane tests, ceres::Solve]) on the GPU
-    double pose[7] = { q_w_curr[0], q_w_curr[1], q_w_curr[2], q_w_curr[3], t_w_curr[0], t_w_curr[1], t_w_curr[2] };
-    const int64_t cm_off[2] = { 0, (int64_t)cornerFromMap.size() }, sm_off[2] = { 0, (int64_t)surfFromMap.size() };
-    const int64_t cs_off[2] = { 0, (int64_t)cornerStack.size() }, ss_off[2] = { 0, (int64_t)surfStack.size() };
     int32_t st[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-    hip_.check(lmono_map_refine(hip_.get(), 1, cornerFromMap.empty() ? nullptr : cornerFromMap[0].data(), cm_off,
-                                surfFromMap.empty() ? nullptr : surfFromMap[0].data(), sm_off,
-                                cornerStack.empty() ? nullptr : cornerStack[0].data(), cs_off,
-                                surfStack.empty() ? nullptr : surfStack[0].data(), ss_off, pose, st, nullptr), "lmono_map_refine");
+    hip_.check(lmono_mapper_process(hip_.get(), mapper_, reg.batch(), scan, q_wodom_curr, t_wodom_curr, q_w_curr, t_w_curr, st), "lmono_mapper_process");
     for (int k = 0; k < 8; k++) stats[k] = st[k];
-    for (int k = 0; k < 4; k++) q_w_curr[k] = pose[k];
-    for (int k = 0; k < 3; k++) t_w_curr[k] = pose[4 + k];
-
-    // transformUpdate
-    {
-        const double n2 = q_wodom_curr[0] * q_wodom_curr[0] + q_wodom_curr[1] * q_wodom_curr[1] + q_wodom_curr[2] * q_wodom_curr[2] + q_wodom_curr[3] * q_wodom_curr[3];
-        const double qi[4] = { -q_wodom_curr[0] / n2, -q_wodom_curr[1] / n2, -q_wodom_curr[2] / n2, q_wodom_curr[3] / n2 };
-        q_mul(q_w_curr, qi, q_wmap_wodom_);
-        q_rot(q_wmap_wodom_, t_wodom_curr, tmp);
-        for (int k = 0; k < 3; k++) t_wmap_wodom_[k] = t_w_curr[k] - tmp[k];
-    }
-    // the scan joins the cubes, which are then re-filtered
-    auto insert = [&](const std::vector<Point> &stack, std::vector<std::vector<Point>> &arr) {
-        for (const Point &p : stack) {
-            const double v[3] = { (double)p[0], (double)p[1], (double)p[2] };
-            double r[3];
-            q_rot(pose, v, r);
-            const Point sel = { (float)(r[0] + pose[4]), (float)(r[1] + pose[5]), (float)(r[2] + pose[6]), p[3] };
-            const int cubeI = cubeIndex((double)sel[0], laserCloudCenWidth), cubeJ = cubeIndex((double)sel[1], laserCloudCenHeight),
-                      cubeK = cubeIndex((double)sel[2], laserCloudCenDepth);
-            if (cubeI >= 0 && cubeI < laserCloudWidth && cubeJ >= 0 && cubeJ < laserCloudHeight && cubeK >= 0 && cubeK < laserCloudDepth)
-                arr[(size_t)(cubeI + laserCloudWidth * cubeJ + laserCloudWidth * laserCloudHeight * cubeK)].push_back(sel);
-        }
-    };
-    insert(cornerStack, laserCloudCornerArray);
-    insert(surfStack, laserCloudSurfArray);
-    // downSizeFilterCorner / downSizeFilterSurf over the cubes of the neighbourhood: one batched call
-    {
-        std::vector<const std::vector<Point> *> in;
-        std::vector<float> leaf;
-        for (int ind : laserCloudValidInd) {
-            in.push_back(&laserCloudCornerArray[(size_t)ind]); leaf.push_back(lineRes_);
-            in.push_back(&laserCloudSurfArray[(size_t)ind]); leaf.push_back(planeRes_);
-        }
-        std::vector<std::vector<Point>> filtered = voxelGrid(in, leaf);
-        for (size_t v = 0; v < laserCloudValidInd.size(); v++) {
-            laserCloudCornerArray[(size_t)laserCloudValidInd[v]] = std::move(filtered[2 * v]);
-            laserCloudSurfArray[(size_t)laserCloudValidInd[v]] = std::move(filtered[2 * v + 1]);
-        }
-    }
+}
+std::vector<float> LaserMapping::cube(int which, int i, int j, int k)
+{
+    const int n = lmono_mapper_cube(hip_.get(), mapper_, which, i, j, k, nullptr, 0);
+    hip_.check(n < 0 ? n : 0, "lmono_mapper_cube");
+    std::vector<float> out((size_t)(n > 0 ? n : 1) * 4);
+    if (n > 0) hip_.check(lmono_mapper_cube(hip_.get(), mapper_, which, i, j, k, out.data(), n) < 0 ? -1 : 0, "lmono_mapper_cube");
+    out.resize((size_t)n * 4);
+    return out;
 }
 
 } // namespace lmono_host

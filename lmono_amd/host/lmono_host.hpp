@@ -142,29 +142,23 @@ private:
     HipContext &hip_;
 };
 
-// laserMapping.cpp process(): the cube-array bookkeeping (which cloud belongs to which cube, shifts) stays host-side like
-// in the reference node (std::vector clouds instead of pcl::PointCloud); the numerics run on the GPU: the VoxelGrid
-// filters through lmono_voxel_filter, the optimisation block through lmono_map_refine.  SURVEY.md Appendix A.4 / row 8f-1.
+// laserMapping.cpp process(): the 21 x 21 x 11 cube array (laserCloudCornerArray /
+// laserCloudSurfArray) lives in HBM behind lmono_mapper_*; one call per scan of a registered batch.
 class LaserMapping {
 public:
-    typedef std::array<float, 4> Point;            // x y z intensity
-    LaserMapping(HipContext &hip, float lineRes = 0.4f, float planeRes = 0.8f);
-    // laserCloudCornerLast / laserCloudSurfLast: [n][4] float32 less-sharp / less-flat clouds of the scan;
-    // q_wodom_curr (x y z w), t_wodom_curr: laserOdometry's pose.  Writes q_w_curr / t_w_curr (aft_mapped_to_init).
-    void process(const std::vector<float> &laserCloudCornerLast, const std::vector<float> &laserCloudSurfLast,
-                 const double q_wodom_curr[4], const double t_wodom_curr[3], double q_w_curr[4], double t_w_curr[3]);
-    // pcl::VoxelGrid (cubic leaf, all fields averaged, ascending cell index, index-order sums) on a batch of clouds: GPU
-    std::vector<std::vector<Point>> voxelGrid(const std::vector<const std::vector<Point> *> &in, const std::vector<float> &leaf);
+    LaserMapping(HipContext &hip, float lineRes = 0.4f, float planeRes = 0.8f);   // mapping_line_resolution / _plane_resolution
+    ~LaserMapping();
+    LaserMapping(const LaserMapping &) = delete;
+    LaserMapping &operator=(const LaserMapping &) = delete;
+    // q_wodom_curr (x y z w), t_wodom_curr: laserOdometry's pose of scan `scan`.  Writes q_w_curr / t_w_curr
+    // (aft_mapped_to_init) and updates the map.
+    void process(ScanRegistration &reg, int scan, const double q_wodom_curr[4], const double t_wodom_curr[3], double q_w_curr[4], double t_w_curr[3]);
+    // cube (i, j, k) of the corner (which = 0) / surf (1) array: [n][4] float32
+    std::vector<float> cube(int which, int i, int j, int k);
     int stats[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };     // of the last frame: edge / plane blocks and LM iterations per outer iteration
-    static constexpr int laserCloudWidth = 21, laserCloudHeight = 21, laserCloudDepth = 11;
-    static constexpr int laserCloudNum = laserCloudWidth * laserCloudHeight * laserCloudDepth;
-    int laserCloudCenWidth = 10, laserCloudCenHeight = 10, laserCloudCenDepth = 5;
-    std::vector<std::vector<Point>> laserCloudCornerArray, laserCloudSurfArray;
 private:
-    void shift(int axis, int dir);
     HipContext &hip_;
-    float lineRes_, planeRes_;
-    double q_wmap_wodom_[4] = { 0, 0, 0, 1 }, t_wmap_wodom_[3] = { 0, 0, 0 };
+    lmono_mapper *mapper_;
 };
 
 } // namespace lmono_host

@@ -44,7 +44,7 @@ int main(int argc, char **argv)
             if (!wm.ok()) { std::fprintf(stderr, "cannot write %s\n", out_mapped.c_str()); return 1; }
             for (int k = 0; k < count; k++) {
                 double q[4], t[3];
-                mapping.process(reg.cloud(k, 2), reg.cloud(k, 4), &poses[(size_t)k * 7], &poses[(size_t)k * 7 + 4], q, t);
+                mapping.process(reg, k, &poses[(size_t)k * 7], &poses[(size_t)k * 7 + 4], q, t);
                 wm.write(stamps[(size_t)(first + k)], t, q);
                 std::printf("MAP %d edges %d %d planes %d %d iters %d %d\n", k, mapping.stats[0], mapping.stats[1], mapping.stats[2], mapping.stats[3],
                             mapping.stats[4], mapping.stats[5]);

@@ -59,8 +59,8 @@ def test_cpp_run_sequence_writes_the_reference_format(sequence_on_disk, tmp_path
 
 
 def test_cpp_laser_mapping_matches_the_oracle_trajectory(oracle, sequence_on_disk, tmp_path):
-    """Host mirror LaserMapping (cube bookkeeping and voxel filters host-side as in the reference node, optimisation on
-    the GPU) over the sequence on disk against oracle.run_mapping."""
+    """Host mirror LaserMapping (device-resident cube map behind lmono_mapper_*) over the sequence on disk against
+    oracle.run_mapping."""
     root, xyzi, off, ref = sequence_on_disk
     subprocess.check_call(["make", "-s", "-C", HOST, "run_sequence"])
     out = tmp_path / "loam_odometry.txt"; mapped = tmp_path / "aft_mapped.txt"
