@@ -69,6 +69,58 @@ def bench_ba(args):
     print(json.dumps(out), flush=True)
 
 
+def bench_map(args):
+    """Tertiary workload: laserMapping with the device-resident cube map over a synthetic S1 sequence, one
+    stream.  One step = every scan of the sequence through lmono_mapper_process once (fresh map per step)."""
+    import torch
+    import lmono_amd
+    from workloads import s1 as S1
+    assert torch.cuda.is_available()
+    n = min(args.scans, 256)
+    w = S1.S1World(n_az=args.az)
+    traj = w.trajectory(n)
+    x, off = w.scans(traj)
+    ctx = lmono_amd.Context(0)
+    xd = torch.from_numpy(x).cuda()
+    batch = lmono_amd.ScanBatch(ctx, n, len(x))
+    batch.scanreg(xd.data_ptr(), off, 64, 5.0, keepalive=xd)
+    _, odo = batch.odometry(n_chains=1, lead=0)
+
+    def run():
+        mapper = lmono_amd.Mapper(ctx)
+        out = np.zeros((n, 7))
+        for k in range(n):
+            q, t, _ = mapper.process(batch, k, odo[k, :4], odo[k, 4:])
+            out[k, :4] = q; out[k, 4:] = t
+        mapper.close()
+        return out
+    for _ in range(args.warmup):
+        run()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        got = run()
+    ctx.synchronize()
+    el = time.perf_counter() - t0
+    # ---- cpu_baseline leg: the only place the oracle is touched
+    from oracle import oracle as O
+    ref = O.run_mapping(x, off, odo)
+    gt = O.gt_relative(traj)
+    out = {"metric": "laserMapping frames/sec (scan-to-map refinement, device-resident cube map, one stream)",
+           "value": round(n * args.steps / el, 1), "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32 clouds / f64 solve", "data": "synthetic",
+           "config": {"workload": "S1 HDL-64 sequence, %d scans, laserMapping after laserOdometry (SURVEY 8f-1)" % n, "streams": 1},
+           "roofline": {"bound": "hbm", "kernel": "per-frame kernel chain (k_voxel_cloud, k_cloud_grid, k_map_correspond, k_map_solve)",
+                        "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                        "note": "one stream: a frame is a chain of small dependent launches with host round trips; not a roofline measurement yet"},
+           "cpu_baseline": {"value": round(n / (ref["stage_ms"][1] * 1e-3), 2), "unit": "frames/s", "cores": 1, "kind": "port",
+                            "sample": "the same %d scans, oracle/lo_mapping.c (-O3), 1 thread, mapping stage only" % n},
+           "max_pose_diff_vs_cpu": float(np.abs(got - ref["poses"]).max()),
+           "ate_vs_truth_m": {"odometry": round(O.ate(odo, gt), 4), "mapped": round(O.ate(got, gt), 4)}}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,12 +131,15 @@ def main():
     ap.add_argument("--lead", type=int, default=5, help="lead-in scans of a chain that does not start at scan 0")
     ap.add_argument("--az", type=int, default=2000, help="azimuth steps per ring (2000 = HDL-64 at 10 Hz)")
     ap.add_argument("--cpu-sample", type=int, default=384, help="scans of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--workload", default="lidar", choices=["lidar", "ba"],
-                    help="lidar = headline (BASELINE configs[1]); ba = configs[2]-shaped sliding-window BA solves (secondary)")
+    ap.add_argument("--workload", default="lidar", choices=["lidar", "ba", "map"],
+                    help="lidar = headline (BASELINE configs[1]); ba = configs[2]-shaped sliding-window BA solves (secondary); "
+                         "map = laserMapping over a synthetic sequence, one stream (SURVEY 8f-1)")
     ap.add_argument("--windows", type=int, default=1024, help="ba: independent windows per GPU")
     args = ap.parse_args()
     if args.workload == "ba":
         return bench_ba(args)
+    if args.workload == "map":
+        return bench_map(args)
 
     import torch
     import torch.distributed as dist
