@@ -209,6 +209,10 @@ lmono_mapper *lmono_mapper_create(lmono_ctx *, float line_res, float plane_res);
 void          lmono_mapper_destroy(lmono_mapper *);
 int lmono_mapper_process(lmono_ctx *, lmono_mapper *, lmono_scan_batch *, int scan, const double q_wodom[4], const double t_wodom[3],
                          double q_w_curr[4], double t_w_curr[3], int32_t *stats);
+/* n independent streams advanced by one frame each, every phase one launch for all of them: mappers[n] (distinct),
+ * batches[n], scans[n], q_wodom [n][4], t_wodom [n][3] -> q_w_curr [n][4], t_w_curr [n][3], stats [n][8] (optional) */
+int lmono_mapper_process_batch(lmono_ctx *, int n, lmono_mapper *const *mappers, lmono_scan_batch *const *batches, const int *scans,
+                               const double *q_wodom, const double *t_wodom, double *q_w_curr, double *t_w_curr, int32_t *stats);
 /* cube (i, j, k) of the corner (which = 0) / surf (1) array: returns its size; copies the points when out_h != NULL */
 int lmono_mapper_cube(lmono_ctx *, lmono_mapper *, int which, int i, int j, int k, float *out_h, int cap);
 

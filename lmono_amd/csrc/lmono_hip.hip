@@ -965,6 +965,8 @@ struct lmono_mapper {
     GridCell *cells[2] = { nullptr, nullptr };
     int tcap = 0;
     int *masks = nullptr, *nout = nullptr, *stats = nullptr;
+    int *nout_big = nullptr;        // output sizes of the cube filter jobs of a batched call (owned by the first mapper)
+    size_t nout_cap = 0;
     double *x = nullptr;
     MapRec *rec = nullptr;
     void *jobs = nullptr;           // device scratch for job arrays
@@ -1009,7 +1011,8 @@ extern "C" lmono_mapper *lmono_mapper_create(lmono_ctx *c, float line_res, float
              mp_alloc(m, m->cells[t], (size_t)m->tcap);
     }
     m->jobs_bytes = 1 << 20;
-    ok = ok && mp_alloc(m, m->masks, 2) && mp_alloc(m, m->nout, 2 * 256) && mp_alloc(m, m->stats, 8) && mp_alloc(m, m->x, 8) &&
+    m->nout_cap = 1024;
+    ok = ok && mp_alloc(m, m->masks, 2) && mp_alloc(m, m->nout, 2 * 256) && mp_alloc(m, m->nout_big, m->nout_cap) && mp_alloc(m, m->stats, 8) && mp_alloc(m, m->x, 8) &&
          mp_alloc(m, m->rec, (size_t)2 * kMapStackMax) && mp_alloc(m, (char *&)m->jobs, m->jobs_bytes) && mp_alloc(m, m->stream_d, 1);
     if (!ok) { c->err = "lmono_mapper_create: device allocation failed"; lmono_mapper_destroy(m); return nullptr; }
     return m;
@@ -1037,224 +1040,332 @@ static int mapper_compact(lmono_mapper *m, int t)
     return LMONO_OK;
 }
 
+namespace {
+// job tables of one phase for every stream go through one pinned-free staging path: a scratch device buffer owned by the
+// first mapper of the call, grown on demand
+struct JobScratch {
+    lmono_mapper *owner;
+    int upload(lmono_ctx *c, const void *src, size_t bytes, hipStream_t st)
+    {
+        if (bytes > owner->jobs_bytes) {
+            void *q = nullptr;
+            size_t nb = owner->jobs_bytes;
+            while (nb < bytes) nb <<= 1;
+            if (hipMalloc(&q, nb) != hipSuccess) { c->err = "lmono_mapper: job scratch allocation failed"; return LMONO_ENOMEM; }
+            owner->allocs.push_back(q);
+            owner->jobs = q; owner->jobs_bytes = nb;
+        }
+        if (bytes > 0 && hipMemcpyAsync(owner->jobs, src, bytes, hipMemcpyHostToDevice, st) != hipSuccess) { c->err = "lmono_mapper: job upload failed"; return LMONO_ENODEV; }
+        return LMONO_OK;
+    }
+};
+void mp_qrot(const double *q, const double *v, double *o)
+{
+    const double ux = q[0], uy = q[1], uz = q[2], w = q[3];
+    const double uvx = 2.0 * (uy * v[2] - uz * v[1]), uvy = 2.0 * (uz * v[0] - ux * v[2]), uvz = 2.0 * (ux * v[1] - uy * v[0]);
+    o[0] = v[0] + w * uvx + (uy * uvz - uz * uvy); o[1] = v[1] + w * uvy + (uz * uvx - ux * uvz); o[2] = v[2] + w * uvz + (ux * uvy - uy * uvx);
+}
+void mp_qmul(const double *a, const double *bq, double *o)
+{
+    o[3] = a[3] * bq[3] - a[0] * bq[0] - a[1] * bq[1] - a[2] * bq[2];
+    o[0] = a[3] * bq[0] + a[0] * bq[3] + a[1] * bq[2] - a[2] * bq[1];
+    o[1] = a[3] * bq[1] + a[1] * bq[3] + a[2] * bq[0] - a[0] * bq[2];
+    o[2] = a[3] * bq[2] + a[2] * bq[3] + a[0] * bq[1] - a[1] * bq[0];
+}
+int mp_cube_of(double v, int cen) { int q = (int)((v + 25.0) / 50.0) + cen; if (v + 25.0 < 0) q--; return q; }
+void mp_shift(lmono_mapper *m, int axis, int dir)
+{
+    const int n[3] = { kMapW, kMapH, kMapD }, stride[3] = { 1, kMapW, kMapW * kMapH };
+    const int a1 = (axis + 1) % 3, a2 = (axis + 2) % 3;
+    for (int t = 0; t < 2; t++)
+        for (int u = 0; u < n[a1]; u++)
+            for (int v = 0; v < n[a2]; v++) {
+                const int base = u * stride[a1] + v * stride[a2];
+                std::vector<Seg> &arr = m->cube[(size_t)t];
+                if (dir > 0) { for (int i = n[axis] - 1; i >= 1; i--) arr[(size_t)(base + i * stride[axis])] = arr[(size_t)(base + (i - 1) * stride[axis])]; arr[(size_t)base] = Seg(); }
+                else { for (int i = 0; i < n[axis] - 1; i++) arr[(size_t)(base + i * stride[axis])] = arr[(size_t)(base + (i + 1) * stride[axis])]; arr[(size_t)(base + (n[axis] - 1) * stride[axis])] = Seg(); }
+            }
+}
+struct FrameState {            // one stream's frame
+    double x[8];
+    std::vector<int> valid;
+    int n_last[2], n_stack[2], n_map[2];
+    bool solve;
+    std::vector<int> cube_h[2];
+};
+}
+
+// n mappers (independent streams), each advanced by one frame: every phase is one launch for all streams
+extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *const *ms, lmono_scan_batch *const *bs, const int *scans,
+                                          const double *q_wodom, const double *t_wodom, double *q_w_curr, double *t_w_curr, int32_t *stats_h)
+{
+    if (!c || n <= 0 || !ms || !bs || !scans || !q_wodom || !t_wodom || !q_w_curr || !t_w_curr) return LMONO_EINVAL;
+    for (int s = 0; s < n; s++) {
+        if (!ms[s] || !bs[s] || !bs[s]->registered || scans[s] < 0 || scans[s] >= bs[s]->n_scans) return LMONO_EINVAL;
+        for (int u = 0; u < s; u++) if (ms[u] == ms[s]) { c->err = "lmono_mapper_process_batch: a mapper appears twice"; return LMONO_EINVAL; }
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    JobScratch js{ ms[0] };
+    std::vector<FrameState> F((size_t)n);
+    int rc;
+    // ---- phase 1 (host): transformAssociateToMap, centre cube, shifts, neighbourhood; scan cloud sizes
+    std::vector<int> fn((size_t)n * 4);
+    for (int s = 0; s < n; s++) HIP_TRY(c, hipMemcpyAsync(&fn[(size_t)s * 4], bs[s]->v.feat_n + scans[s] * 4, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    for (int s = 0; s < n; s++) {
+        lmono_mapper *m = ms[s];
+        FrameState &f = F[(size_t)s];
+        double tmp[3];
+        for (int k = 0; k < 8; k++) f.x[k] = 0.0;
+        mp_qmul(m->q_wmap_wodom, q_wodom + 4 * s, f.x);
+        mp_qrot(m->q_wmap_wodom, t_wodom + 3 * s, tmp);
+        for (int k = 0; k < 3; k++) f.x[4 + k] = tmp[k] + m->t_wmap_wodom[k];
+        int ci = mp_cube_of(f.x[4], m->cen[0]), cj = mp_cube_of(f.x[5], m->cen[1]), ck = mp_cube_of(f.x[6], m->cen[2]);
+        while (ci < 3) { mp_shift(m, 0, +1); ci++; m->cen[0]++; }
+        while (ci >= kMapW - 3) { mp_shift(m, 0, -1); ci--; m->cen[0]--; }
+        while (cj < 3) { mp_shift(m, 1, +1); cj++; m->cen[1]++; }
+        while (cj >= kMapH - 3) { mp_shift(m, 1, -1); cj--; m->cen[1]--; }
+        while (ck < 3) { mp_shift(m, 2, +1); ck++; m->cen[2]++; }
+        while (ck >= kMapD - 3) { mp_shift(m, 2, -1); ck--; m->cen[2]--; }
+        for (int i = ci - 2; i <= ci + 2; i++)
+            for (int j = cj - 2; j <= cj + 2; j++)
+                for (int k = ck - 1; k <= ck + 1; k++)
+                    if (i >= 0 && i < kMapW && j >= 0 && j < kMapH && k >= 0 && k < kMapD) f.valid.push_back(i + kMapW * j + kMapW * kMapH * k);
+        f.n_last[0] = fn[(size_t)s * 4 + 1]; f.n_last[1] = fn[(size_t)s * 4 + 3];
+        if (f.n_last[0] > kMapStackMax || f.n_last[1] > kMapStackMax) { c->err = "lmono_mapper: scan cloud too large"; return LMONO_ECAPACITY; }
+    }
+    // ---- phase 2: VoxelGrid of the scan clouds (read in place from the scan batches)
+    {
+        std::vector<VoxJob> vj((size_t)2 * n);
+        for (int s = 0; s < n; s++)
+            for (int t = 0; t < 2; t++) {
+                lmono_mapper *m = ms[s];
+                VoxJob &J = vj[(size_t)2 * s + t];
+                J.in = t ? bs[s]->v.less_flat + bs[s]->off_h[(size_t)scans[s]] : bs[s]->v.less_sharp + (size_t)scans[s] * kMaxLessSharp;
+                J.n = F[(size_t)s].n_last[t]; J.inv_leaf = 1.0f / m->leaf[t]; J.out = m->stack[t]; J.n_out = m->nout + t;
+                J.key_a = m->vk[t]; J.key_b = m->vk[t] + kMapStackMax; J.idx_a = m->vi[t]; J.idx_b = m->vi[t] + kMapStackMax;
+            }
+        if ((rc = js.upload(c, vj.data(), vj.size() * sizeof(VoxJob), st))) return rc;
+        hipLaunchKernelGGL(k_voxel_cloud, dim3(2 * n), dim3(1024), 0, st, (const VoxJob *)js.owner->jobs);
+        for (int s = 0; s < n; s++) HIP_TRY(c, hipMemcpyAsync(F[(size_t)s].n_stack, ms[s]->nout, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        for (int s = 0; s < n; s++) if (F[(size_t)s].n_stack[0] < 0 || F[(size_t)s].n_stack[1] < 0) { c->err = "lmono_mapper: voxel filter rejected a scan cloud"; return LMONO_ECAPACITY; }
+    }
+    // ---- phase 3: map clouds of the neighbourhoods, concatenated in validInd order
+    {
+        std::vector<CopyJob> jobs;
+        for (int s = 0; s < n; s++) {
+            lmono_mapper *m = ms[s];
+            FrameState &f = F[(size_t)s];
+            for (int t = 0; t < 2; t++) {
+                f.n_map[t] = 0;
+                for (int ind : f.valid) {
+                    const Seg &sg = m->cube[(size_t)t][(size_t)ind];
+                    if (sg.n == 0) continue;
+                    if (f.n_map[t] + sg.n > kMapNeighMax) { c->err = "lmono_mapper: neighbourhood holds more than 1 Mi points"; return LMONO_ECAPACITY; }
+                    jobs.push_back({ m->arena[t][m->half[t]] + sg.off, m->neigh[t] + f.n_map[t], sg.n });
+                    f.n_map[t] += sg.n;
+                }
+            }
+            f.solve = f.n_map[0] > 10 && f.n_map[1] > 50;
+        }
+        if (!jobs.empty()) {
+            if ((rc = js.upload(c, jobs.data(), jobs.size() * sizeof(CopyJob), st))) return rc;
+            hipLaunchKernelGGL(k_copy_jobs, dim3((unsigned)jobs.size()), dim3(256), 0, st, (const CopyJob *)js.owner->jobs);
+            HIP_TRY(c, hipStreamSynchronize(st));    // the job scratch is reused below
+        }
+    }
+    // ---- phase 4: optimisation (grids, 2 x [correspond + solve]) for the streams whose map is large enough
+    std::vector<int32_t> stats((size_t)n * 8, 0);
+    {
+        std::vector<int> act;
+        for (int s = 0; s < n; s++) if (F[(size_t)s].solve) act.push_back(s);
+        for (int s = 0; s < n; s++) {
+            HIP_TRY(c, hipMemcpyAsync(ms[s]->x, F[(size_t)s].x, sizeof(double) * 8, hipMemcpyHostToDevice, st));
+            HIP_TRY(c, hipMemsetAsync(ms[s]->stats, 0, sizeof(int) * 8, st));
+        }
+        if (!act.empty()) {
+            std::vector<CloudJob> cj((size_t)2 * act.size());
+            std::vector<MapStream> S(act.size());
+            int max_nq = 0;
+            for (size_t a = 0; a < act.size(); a++) {
+                lmono_mapper *m = ms[act[a]];
+                FrameState &f = F[(size_t)act[a]];
+                for (int t = 0; t < 2; t++) {
+                    CloudJob &J = cj[2 * a + (size_t)t];
+                    J.src = m->neigh[t]; J.n = f.n_map[t]; J.cell = m->cells[t]; J.tcap = m->tcap; J.sorted = m->sorted[t];
+                    J.slot_of = m->slot[t]; J.rank_of = m->rank[t]; J.mask_out = m->masks + t;
+                    S[a].cell[t] = m->cells[t]; S[a].sorted[t] = m->sorted[t]; S[a].cloud[t] = m->neigh[t]; S[a].mask[t] = m->masks + t; S[a].n_map[t] = f.n_map[t];
+                    S[a].stack[t] = m->stack[t]; S[a].n_stack[t] = f.n_stack[t];
+                }
+                S[a].rec = m->rec; S[a].x = m->x; S[a].stats = m->stats; S[a].nn_out = nullptr;
+                max_nq = std::max(max_nq, f.n_stack[0] + f.n_stack[1]);
+            }
+            // job table = [CloudJob x 2 act | MapStream x act] in one upload
+            std::vector<char> blob(cj.size() * sizeof(CloudJob) + S.size() * sizeof(MapStream));
+            memcpy(blob.data(), cj.data(), cj.size() * sizeof(CloudJob));
+            memcpy(blob.data() + cj.size() * sizeof(CloudJob), S.data(), S.size() * sizeof(MapStream));
+            if ((rc = js.upload(c, blob.data(), blob.size(), st))) return rc;
+            const CloudJob *cj_d = (const CloudJob *)js.owner->jobs;
+            const MapStream *S_d = (const MapStream *)((const char *)js.owner->jobs + cj.size() * sizeof(CloudJob));
+            hipLaunchKernelGGL(k_cloud_grid, dim3((unsigned)cj.size()), dim3(1024), 0, st, cj_d);
+            for (int outer = 0; outer < 2; outer++) {
+                if (max_nq > 0) hipLaunchKernelGGL(k_map_correspond, dim3((max_nq + 7) / 8, (unsigned)act.size()), dim3(256), 0, st, S_d, outer);
+                hipLaunchKernelGGL(k_map_solve, dim3((unsigned)act.size()), dim3(1024), 0, st, S_d, outer);
+            }
+            for (int s : act) {
+                HIP_TRY(c, hipMemcpyAsync(F[(size_t)s].x, ms[s]->x, sizeof(double) * 8, hipMemcpyDeviceToHost, st));
+                HIP_TRY(c, hipMemcpyAsync(&stats[(size_t)s * 8], ms[s]->stats, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
+            }
+            HIP_TRY(c, hipStreamSynchronize(st));
+        }
+    }
+    // ---- phase 5 (host): results, transformUpdate; then pointAssociateToMap + cube index of every stack point on the device
+    for (int s = 0; s < n; s++) {
+        lmono_mapper *m = ms[s];
+        FrameState &f = F[(size_t)s];
+        for (int k = 0; k < 4; k++) q_w_curr[4 * s + k] = f.x[k];
+        for (int k = 0; k < 3; k++) t_w_curr[3 * s + k] = f.x[4 + k];
+        if (stats_h) for (int k = 0; k < 8; k++) stats_h[(size_t)s * 8 + k] = k < 6 ? stats[(size_t)s * 8 + k] : 0;
+        const double *qo = q_wodom + 4 * s, *to = t_wodom + 3 * s;
+        const double n2 = qo[0] * qo[0] + qo[1] * qo[1] + qo[2] * qo[2] + qo[3] * qo[3];
+        const double qi[4] = { -qo[0] / n2, -qo[1] / n2, -qo[2] / n2, qo[3] / n2 };
+        double tmp[3];
+        mp_qmul(f.x, qi, m->q_wmap_wodom);
+        mp_qrot(m->q_wmap_wodom, to, tmp);
+        for (int k = 0; k < 3; k++) m->t_wmap_wodom[k] = f.x[4 + k] - tmp[k];
+        HIP_TRY(c, hipMemcpyAsync(m->x, f.x, sizeof(double) * 8, hipMemcpyHostToDevice, st));
+        for (int t = 0; t < 2; t++) {
+            f.cube_h[t].assign((size_t)(f.n_stack[t] > 0 ? f.n_stack[t] : 1), -1);
+            if (f.n_stack[t] > 0) {
+                hipLaunchKernelGGL(k_map_assign, dim3((f.n_stack[t] + 255) / 256), dim3(256), 0, st, (const float4 *)m->stack[t], f.n_stack[t], (const double *)m->x,
+                                   m->cen[0], m->cen[1], m->cen[2], m->newpts[t], m->cube_of[t]);
+                HIP_TRY(c, hipMemcpyAsync(f.cube_h[t].data(), m->cube_of[t], sizeof(int) * (size_t)f.n_stack[t], hipMemcpyDeviceToHost, st));
+            }
+        }
+    }
+    HIP_TRY(c, hipStreamSynchronize(st));
+    // ---- phase 6: the scans join the cubes.  Host: per touched cube [old points | new points in stack order]; device: build
+    // them, re-filter the cubes of the neighbourhoods into fresh arena space, the other touched cubes keep [old | new]
+    struct Touched { int s, t, ind, n_in; int64_t cat_off; bool filter; };
+    std::vector<Touched> touched;
+    std::vector<CopyJob> copy;
+    std::vector<std::vector<int>> pos_h((size_t)2 * n);
+    for (int s = 0; s < n; s++) {
+        lmono_mapper *m = ms[s];
+        FrameState &f = F[(size_t)s];
+        std::vector<char> is_valid((size_t)kMapCubes, 0);
+        for (int ind : f.valid) is_valid[(size_t)ind] = 1;
+        for (int t = 0; t < 2; t++) {
+            std::vector<int> add((size_t)kMapCubes, 0);
+            for (int i = 0; i < f.n_stack[t]; i++) if (f.cube_h[t][(size_t)i] >= 0) add[(size_t)f.cube_h[t][(size_t)i]]++;
+            std::vector<int64_t> cat_off((size_t)kMapCubes, -1);
+            int64_t at = 0;
+            for (int ind = 0; ind < kMapCubes; ind++) {
+                const Seg &sg = m->cube[(size_t)t][(size_t)ind];
+                const bool v = is_valid[(size_t)ind] != 0;
+                if (!((v && sg.n + add[(size_t)ind] > 0) || (!v && add[(size_t)ind] > 0))) continue;
+                cat_off[(size_t)ind] = at;
+                if (sg.n > 0) copy.push_back({ m->arena[t][m->half[t]] + sg.off, m->cat[t] + at, sg.n });
+                const int n_in = sg.n + add[(size_t)ind];
+                if (v && n_in > kVoxCloudMax) { c->err = "lmono_mapper: a cube holds more than 65536 points"; return LMONO_ECAPACITY; }
+                touched.push_back({ s, t, ind, n_in, at, v });
+                at += n_in;
+            }
+            if (at > (int64_t)kMapNeighMax + kMapStackMax) { c->err = "lmono_mapper: frame touches more points than the workspace holds"; return LMONO_ECAPACITY; }
+            std::vector<int> fill((size_t)kMapCubes, 0);
+            std::vector<int> &ph = pos_h[(size_t)2 * s + t];
+            ph.assign((size_t)(f.n_stack[t] > 0 ? f.n_stack[t] : 1), -1);
+            for (int i = 0; i < f.n_stack[t]; i++) {
+                const int ind = f.cube_h[t][(size_t)i];
+                if (ind >= 0) ph[(size_t)i] = (int)(cat_off[(size_t)ind] + m->cube[(size_t)t][(size_t)ind].n + fill[(size_t)ind]++);
+            }
+        }
+    }
+    if (!copy.empty()) {
+        if ((rc = js.upload(c, copy.data(), copy.size() * sizeof(CopyJob), st))) return rc;
+        hipLaunchKernelGGL(k_copy_jobs, dim3((unsigned)copy.size()), dim3(256), 0, st, (const CopyJob *)js.owner->jobs);
+    }
+    for (int s = 0; s < n; s++)
+        for (int t = 0; t < 2; t++) {
+            lmono_mapper *m = ms[s];
+            const int ns = F[(size_t)s].n_stack[t];
+            if (ns <= 0) continue;
+            HIP_TRY(c, hipMemcpyAsync(m->pos[t], pos_h[(size_t)2 * s + t].data(), sizeof(int) * (size_t)ns, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_scatter_pos, dim3((ns + 255) / 256), dim3(256), 0, st, (const float4 *)m->newpts[t], (const int *)m->pos[t], ns, m->cat[t]);
+        }
+    HIP_TRY(c, hipStreamSynchronize(st));   // `cat` is complete; the job scratch and pos_h are free again
+    // arena space (an output is never larger than its input); compaction reads only the tables, `cat` is already built
+    {
+        std::vector<int64_t> need((size_t)2 * n, 0);
+        for (const Touched &T : touched) need[(size_t)2 * T.s + T.t] += T.n_in;
+        for (int s = 0; s < n; s++)
+            for (int t = 0; t < 2; t++)
+                if (ms[s]->bump[t] + need[(size_t)2 * s + t] > kMapArena) {
+                    if ((rc = mapper_compact(ms[s], t))) return rc;
+                    if (ms[s]->bump[t] + need[(size_t)2 * s + t] > kMapArena) { c->err = "lmono_mapper: map arena exhausted"; return LMONO_ECAPACITY; }
+                }
+    }
+    std::vector<VoxJob> vox;
+    std::vector<CopyJob> keep;
+    std::vector<size_t> vox_t;
+    std::vector<int64_t> new_off(touched.size());
+    for (size_t k = 0; k < touched.size(); k++) {
+        const Touched &T = touched[k];
+        lmono_mapper *m = ms[T.s];
+        float4 *dst = m->arena[T.t][m->half[T.t]] + m->bump[T.t];
+        new_off[k] = m->bump[T.t];
+        if (T.filter) {
+            VoxJob J;
+            J.in = m->cat[T.t] + T.cat_off; J.n = T.n_in; J.inv_leaf = 1.0f / m->leaf[T.t]; J.out = dst; J.n_out = nullptr;
+            J.key_a = m->vk[T.t] + 2 * T.cat_off; J.key_b = J.key_a + T.n_in; J.idx_a = m->vi[T.t] + 2 * T.cat_off; J.idx_b = J.idx_a + T.n_in;
+            vox.push_back(J); vox_t.push_back(k);
+        } else {
+            keep.push_back({ m->cat[T.t] + T.cat_off, dst, T.n_in });
+        }
+        m->bump[T.t] += T.n_in;
+    }
+    // output sizes of the filter jobs land in one array owned by the first mapper (grown on demand)
+    std::vector<int> nout_h(vox.size() > 0 ? vox.size() : 1, 0);
+    if (!vox.empty()) {
+        if (vox.size() > ms[0]->nout_cap) {
+            int *q = nullptr;
+            size_t cap = ms[0]->nout_cap;
+            while (cap < vox.size()) cap <<= 1;
+            if (!mp_alloc(ms[0], q, cap)) { c->err = "lmono_mapper: allocation failed"; return LMONO_ENOMEM; }
+            ms[0]->nout_big = q; ms[0]->nout_cap = cap;
+        }
+        for (size_t k = 0; k < vox.size(); k++) vox[k].n_out = ms[0]->nout_big + k;
+        if ((rc = js.upload(c, vox.data(), vox.size() * sizeof(VoxJob), st))) return rc;
+        hipLaunchKernelGGL(k_voxel_cloud, dim3((unsigned)vox.size()), dim3(1024), 0, st, (const VoxJob *)js.owner->jobs);
+        HIP_TRY(c, hipMemcpyAsync(nout_h.data(), ms[0]->nout_big, sizeof(int) * vox.size(), hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+    }
+    if (!keep.empty()) {
+        if ((rc = js.upload(c, keep.data(), keep.size() * sizeof(CopyJob), st))) return rc;
+        hipLaunchKernelGGL(k_copy_jobs, dim3((unsigned)keep.size()), dim3(256), 0, st, (const CopyJob *)js.owner->jobs);
+        HIP_TRY(c, hipStreamSynchronize(st));
+    }
+    for (size_t k = 0; k < touched.size(); k++) {
+        const Touched &T = touched[k];
+        Seg &sg = ms[T.s]->cube[(size_t)T.t][(size_t)T.ind];
+        sg.off = new_off[k];
+        sg.n = T.n_in;
+    }
+    for (size_t v = 0; v < vox.size(); v++) {
+        if (nout_h[v] < 0) { c->err = "lmono_mapper: voxel filter rejected a cube"; return LMONO_ECAPACITY; }
+        const Touched &T = touched[vox_t[v]];
+        ms[T.s]->cube[(size_t)T.t][(size_t)T.ind].n = nout_h[v];
+    }
+    return check_launch(c, "mapper kernels");
+}
+
 extern "C" int lmono_mapper_process(lmono_ctx *c, lmono_mapper *m, lmono_scan_batch *b, int scan, const double q_wodom[4], const double t_wodom[3],
                                     double q_w_curr[4], double t_w_curr[3], int32_t *stats_h)
 {
-    if (!c || !m || !b || !b->registered || scan < 0 || scan >= b->n_scans || !q_wodom || !t_wodom || !q_w_curr || !t_w_curr) return LMONO_EINVAL;
-    HIP_TRY(c, hipSetDevice(c->device));
-    hipStream_t st = c->stream;
-    auto qrot = [](const double *q, const double *v, double *o) {
-        const double ux = q[0], uy = q[1], uz = q[2], w = q[3];
-        const double uvx = 2.0 * (uy * v[2] - uz * v[1]), uvy = 2.0 * (uz * v[0] - ux * v[2]), uvz = 2.0 * (ux * v[1] - uy * v[0]);
-        o[0] = v[0] + w * uvx + (uy * uvz - uz * uvy); o[1] = v[1] + w * uvy + (uz * uvx - ux * uvz); o[2] = v[2] + w * uvz + (ux * uvy - uy * uvx);
-    };
-    auto qmul = [](const double *a, const double *bq, double *o) {
-        o[3] = a[3] * bq[3] - a[0] * bq[0] - a[1] * bq[1] - a[2] * bq[2];
-        o[0] = a[3] * bq[0] + a[0] * bq[3] + a[1] * bq[2] - a[2] * bq[1];
-        o[1] = a[3] * bq[1] + a[1] * bq[3] + a[2] * bq[0] - a[0] * bq[2];
-        o[2] = a[3] * bq[2] + a[2] * bq[3] + a[0] * bq[1] - a[1] * bq[0];
-    };
-    auto cube_of = [](double v, int cen) { int q = (int)((v + 25.0) / 50.0) + cen; if (v + 25.0 < 0) q--; return q; };
-    // transformAssociateToMap
-    double tmp[3], x[8] = { 0, 0, 0, 1, 0, 0, 0, 0 };
-    qmul(m->q_wmap_wodom, q_wodom, x);
-    qrot(m->q_wmap_wodom, t_wodom, tmp);
-    for (int k = 0; k < 3; k++) x[4 + k] = tmp[k] + m->t_wmap_wodom[k];
-    // centre cube and shifts of the (offset, count) tables
-    int ci = cube_of(x[4], m->cen[0]), cj = cube_of(x[5], m->cen[1]), ck = cube_of(x[6], m->cen[2]);
-    auto shift = [&](int axis, int dir) {
-        const int n[3] = { kMapW, kMapH, kMapD }, stride[3] = { 1, kMapW, kMapW * kMapH };
-        const int a1 = (axis + 1) % 3, a2 = (axis + 2) % 3;
-        for (int t = 0; t < 2; t++)
-            for (int u = 0; u < n[a1]; u++)
-                for (int v = 0; v < n[a2]; v++) {
-                    const int base = u * stride[a1] + v * stride[a2];
-                    std::vector<Seg> &arr = m->cube[(size_t)t];
-                    if (dir > 0) { for (int i = n[axis] - 1; i >= 1; i--) arr[(size_t)(base + i * stride[axis])] = arr[(size_t)(base + (i - 1) * stride[axis])]; arr[(size_t)base] = Seg(); }
-                    else { for (int i = 0; i < n[axis] - 1; i++) arr[(size_t)(base + i * stride[axis])] = arr[(size_t)(base + (i + 1) * stride[axis])]; arr[(size_t)(base + (n[axis] - 1) * stride[axis])] = Seg(); }
-                }
-    };
-    while (ci < 3) { shift(0, +1); ci++; m->cen[0]++; }
-    while (ci >= kMapW - 3) { shift(0, -1); ci--; m->cen[0]--; }
-    while (cj < 3) { shift(1, +1); cj++; m->cen[1]++; }
-    while (cj >= kMapH - 3) { shift(1, -1); cj--; m->cen[1]--; }
-    while (ck < 3) { shift(2, +1); ck++; m->cen[2]++; }
-    while (ck >= kMapD - 3) { shift(2, -1); ck--; m->cen[2]--; }
-    std::vector<int> valid;
-    for (int i = ci - 2; i <= ci + 2; i++)
-        for (int j = cj - 2; j <= cj + 2; j++)
-            for (int k = ck - 1; k <= ck + 1; k++)
-                if (i >= 0 && i < kMapW && j >= 0 && j < kMapH && k >= 0 && k < kMapD) valid.push_back(i + kMapW * j + kMapW * kMapH * k);
-    // scan clouds (HBM-resident in the batch) -> stacks
-    int fn[4];
-    HIP_TRY(c, hipMemcpyAsync(fn, b->v.feat_n + scan * 4, sizeof(fn), hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
-    const float4 *last[2] = { b->v.less_sharp + (size_t)scan * kMaxLessSharp, b->v.less_flat + b->off_h[(size_t)scan] };
-    const int n_last[2] = { fn[1], fn[3] };
-    if (n_last[0] > kMapStackMax || n_last[1] > kMapStackMax) { c->err = "lmono_mapper: scan cloud too large"; return LMONO_ECAPACITY; }
-    char *jobs_h_bytes = nullptr; (void)jobs_h_bytes;
-    {
-        VoxJob vj[2];
-        for (int t = 0; t < 2; t++) {
-            vj[t].in = last[t]; vj[t].n = n_last[t]; vj[t].inv_leaf = 1.0f / m->leaf[t]; vj[t].out = m->stack[t]; vj[t].n_out = m->nout + t;
-            vj[t].key_a = m->vk[t]; vj[t].key_b = m->vk[t] + kMapStackMax; vj[t].idx_a = m->vi[t]; vj[t].idx_b = m->vi[t] + kMapStackMax;
-        }
-        HIP_TRY(c, hipMemcpyAsync(m->jobs, vj, sizeof(vj), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_voxel_cloud, dim3(2), dim3(1024), 0, st, (const VoxJob *)m->jobs);
-    }
-    int n_stack[2];
-    HIP_TRY(c, hipMemcpyAsync(n_stack, m->nout, sizeof(n_stack), hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
-    if (n_stack[0] < 0 || n_stack[1] < 0) { c->err = "lmono_mapper: voxel filter rejected a scan cloud"; return LMONO_ECAPACITY; }
-    // map clouds of the neighbourhood, concatenated in validInd order
-    int n_map[2] = { 0, 0 };
-    {
-        std::vector<CopyJob> jobs;
-        for (int t = 0; t < 2; t++)
-            for (int ind : valid) {
-                const Seg &s = m->cube[(size_t)t][(size_t)ind];
-                if (s.n == 0) continue;
-                if (n_map[t] + s.n > kMapNeighMax) { c->err = "lmono_mapper: neighbourhood holds more than 1 Mi points"; return LMONO_ECAPACITY; }
-                jobs.push_back({ m->arena[t][m->half[t]] + s.off, m->neigh[t] + n_map[t], s.n });
-                n_map[t] += s.n;
-            }
-        if (!jobs.empty()) {
-            HIP_TRY(c, hipMemcpyAsync(m->jobs, jobs.data(), jobs.size() * sizeof(CopyJob), hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(k_copy_jobs, dim3((unsigned)jobs.size()), dim3(256), 0, st, (const CopyJob *)m->jobs);
-            HIP_TRY(c, hipStreamSynchronize(st));    // the job array is reused below
-        }
-    }
-    // optimisation: grids, 2 x [correspond + solve]
-    int32_t stats[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-    HIP_TRY(c, hipMemcpyAsync(m->x, x, sizeof(double) * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemsetAsync(m->stats, 0, sizeof(int) * 8, st));
-    if (n_map[0] > 10 && n_map[1] > 50) {
-        CloudJob cj2[2];
-        MapStream S;
-        for (int t = 0; t < 2; t++) {
-            cj2[t].src = m->neigh[t]; cj2[t].n = n_map[t]; cj2[t].cell = m->cells[t]; cj2[t].tcap = m->tcap; cj2[t].sorted = m->sorted[t];
-            cj2[t].slot_of = m->slot[t]; cj2[t].rank_of = m->rank[t]; cj2[t].mask_out = m->masks + t;
-            S.cell[t] = m->cells[t]; S.sorted[t] = m->sorted[t]; S.cloud[t] = m->neigh[t]; S.mask[t] = m->masks + t; S.n_map[t] = n_map[t];
-            S.stack[t] = m->stack[t]; S.n_stack[t] = n_stack[t];
-        }
-        S.rec = m->rec; S.x = m->x; S.stats = m->stats; S.nn_out = nullptr;
-        HIP_TRY(c, hipMemcpyAsync(m->jobs, cj2, sizeof(cj2), hipMemcpyHostToDevice, st));
-        HIP_TRY(c, hipMemcpyAsync(m->stream_d, &S, sizeof(S), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_cloud_grid, dim3(2), dim3(1024), 0, st, (const CloudJob *)m->jobs);
-        const int nq = n_stack[0] + n_stack[1];
-        for (int outer = 0; outer < 2; outer++) {
-            if (nq > 0) hipLaunchKernelGGL(k_map_correspond, dim3((nq + 7) / 8, 1), dim3(256), 0, st, (const MapStream *)m->stream_d, outer);
-            hipLaunchKernelGGL(k_map_solve, dim3(1), dim3(1024), 0, st, (const MapStream *)m->stream_d, outer);
-        }
-        HIP_TRY(c, hipMemcpyAsync(x, m->x, sizeof(double) * 8, hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipMemcpyAsync(stats, m->stats, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipStreamSynchronize(st));
-    }
-    for (int k = 0; k < 4; k++) q_w_curr[k] = x[k];
-    for (int k = 0; k < 3; k++) t_w_curr[k] = x[4 + k];
-    if (stats_h) for (int k = 0; k < 8; k++) stats_h[k] = k < 6 ? stats[k] : 0;
-    // transformUpdate
-    {
-        const double n2 = q_wodom[0] * q_wodom[0] + q_wodom[1] * q_wodom[1] + q_wodom[2] * q_wodom[2] + q_wodom[3] * q_wodom[3];
-        const double qi[4] = { -q_wodom[0] / n2, -q_wodom[1] / n2, -q_wodom[2] / n2, q_wodom[3] / n2 };
-        qmul(x, qi, m->q_wmap_wodom);
-        qrot(m->q_wmap_wodom, t_wodom, tmp);
-        for (int k = 0; k < 3; k++) m->t_wmap_wodom[k] = x[4 + k] - tmp[k];
-    }
-    // the scan joins the cubes: transformed points and their cube on the device, the per-cube placement on the host
-    HIP_TRY(c, hipMemcpyAsync(m->x, x, sizeof(double) * 8, hipMemcpyHostToDevice, st));
-    std::vector<int> cube_h[2];
-    for (int t = 0; t < 2; t++) {
-        cube_h[t].assign((size_t)(n_stack[t] > 0 ? n_stack[t] : 1), -1);
-        if (n_stack[t] > 0) {
-            hipLaunchKernelGGL(k_map_assign, dim3((n_stack[t] + 255) / 256), dim3(256), 0, st, (const float4 *)m->stack[t], n_stack[t], (const double *)m->x,
-                               m->cen[0], m->cen[1], m->cen[2], m->newpts[t], m->cube_of[t]);
-            HIP_TRY(c, hipMemcpyAsync(cube_h[t].data(), m->cube_of[t], sizeof(int) * (size_t)n_stack[t], hipMemcpyDeviceToHost, st));
-        }
-    }
-    HIP_TRY(c, hipStreamSynchronize(st));
-    std::vector<char> is_valid((size_t)kMapCubes, 0);
-    for (int ind : valid) is_valid[(size_t)ind] = 1;
-    for (int t = 0; t < 2; t++) {
-        // cubes touched by this frame: those of the neighbourhood (re-filtered even without new points) and those that
-        // receive points; `cat` holds, per touched cube, [old points | new points in stack order]
-        std::vector<int> add((size_t)kMapCubes, 0);
-        for (int i = 0; i < n_stack[t]; i++) if (cube_h[t][(size_t)i] >= 0) add[(size_t)cube_h[t][(size_t)i]]++;
-        std::vector<int> touched;
-        for (int ind = 0; ind < kMapCubes; ind++) if ((is_valid[(size_t)ind] && m->cube[(size_t)t][(size_t)ind].n + add[(size_t)ind] > 0) || (!is_valid[(size_t)ind] && add[(size_t)ind] > 0)) touched.push_back(ind);
-        std::vector<int64_t> cat_off((size_t)kMapCubes, -1);
-        int64_t at = 0;
-        std::vector<CopyJob> copy;
-        for (int ind : touched) {
-            const Seg &s = m->cube[(size_t)t][(size_t)ind];
-            cat_off[(size_t)ind] = at;
-            if (s.n > 0) copy.push_back({ m->arena[t][m->half[t]] + s.off, m->cat[t] + at, s.n });
-            at += s.n + add[(size_t)ind];
-        }
-        if (at > (int64_t)kMapNeighMax + kMapStackMax) { c->err = "lmono_mapper: frame touches more points than the workspace holds"; return LMONO_ECAPACITY; }
-        std::vector<int> fill((size_t)kMapCubes, 0), pos_h((size_t)(n_stack[t] > 0 ? n_stack[t] : 1), -1);
-        for (int i = 0; i < n_stack[t]; i++) {
-            const int ind = cube_h[t][(size_t)i];
-            if (ind < 0) continue;
-            pos_h[(size_t)i] = (int)(cat_off[(size_t)ind] + m->cube[(size_t)t][(size_t)ind].n + fill[(size_t)ind]++);
-        }
-        if (!copy.empty()) {
-            HIP_TRY(c, hipMemcpyAsync(m->jobs, copy.data(), copy.size() * sizeof(CopyJob), hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(k_copy_jobs, dim3((unsigned)copy.size()), dim3(256), 0, st, (const CopyJob *)m->jobs);
-        }
-        if (n_stack[t] > 0) {
-            HIP_TRY(c, hipMemcpyAsync(m->pos[t], pos_h.data(), sizeof(int) * (size_t)n_stack[t], hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(k_scatter_pos, dim3((n_stack[t] + 255) / 256), dim3(256), 0, st, (const float4 *)m->newpts[t], (const int *)m->pos[t], n_stack[t], m->cat[t]);
-        }
-        HIP_TRY(c, hipStreamSynchronize(st));   // job array and pos_h are reused
-        // arena space for the outputs (an output is never larger than its input)
-        if (m->bump[t] + at > kMapArena) {
-            int rc = mapper_compact(m, t);
-            if (rc) return rc;
-            // the copy jobs above read the old half: redo them against the compacted one is unnecessary -- `cat` is already built
-            if (m->bump[t] + at > kMapArena) { c->err = "lmono_mapper: map arena exhausted"; return LMONO_ECAPACITY; }
-        }
-        // neighbourhood cubes are re-filtered, the others just keep [old | new]
-        std::vector<VoxJob> vox;
-        std::vector<CopyJob> keep;
-        std::vector<int> vox_ind;
-        std::vector<Seg> new_seg((size_t)kMapCubes);
-        for (int ind : touched) {
-            const int n_in = m->cube[(size_t)t][(size_t)ind].n + add[(size_t)ind];
-            float4 *dst = m->arena[t][m->half[t]] + m->bump[t];
-            new_seg[(size_t)ind].off = m->bump[t];
-            if (is_valid[(size_t)ind]) {
-                if (n_in > kVoxCloudMax) { c->err = "lmono_mapper: a cube holds more than 65536 points"; return LMONO_ECAPACITY; }
-                VoxJob J;
-                J.in = m->cat[t] + cat_off[(size_t)ind]; J.n = n_in; J.inv_leaf = 1.0f / m->leaf[t]; J.out = dst; J.n_out = m->nout + (int)vox.size();
-                J.key_a = m->vk[t] + 2 * cat_off[(size_t)ind]; J.key_b = J.key_a + n_in; J.idx_a = m->vi[t] + 2 * cat_off[(size_t)ind]; J.idx_b = J.idx_a + n_in;
-                vox.push_back(J); vox_ind.push_back(ind);
-            } else {
-                keep.push_back({ m->cat[t] + cat_off[(size_t)ind], dst, n_in });
-                new_seg[(size_t)ind].n = n_in;
-            }
-            m->bump[t] += n_in;
-        }
-        if (vox.size() > 256) { c->err = "lmono_mapper: too many cubes in one frame"; return LMONO_ECAPACITY; }
-        std::vector<int> nout_h(vox.size() > 0 ? vox.size() : 1, 0);
-        if (!vox.empty()) {
-            HIP_TRY(c, hipMemcpyAsync(m->jobs, vox.data(), vox.size() * sizeof(VoxJob), hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(k_voxel_cloud, dim3((unsigned)vox.size()), dim3(1024), 0, st, (const VoxJob *)m->jobs);
-            HIP_TRY(c, hipMemcpyAsync(nout_h.data(), m->nout, sizeof(int) * vox.size(), hipMemcpyDeviceToHost, st));
-            HIP_TRY(c, hipStreamSynchronize(st));
-        }
-        if (!keep.empty()) {
-            HIP_TRY(c, hipMemcpyAsync(m->jobs, keep.data(), keep.size() * sizeof(CopyJob), hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(k_copy_jobs, dim3((unsigned)keep.size()), dim3(256), 0, st, (const CopyJob *)m->jobs);
-            HIP_TRY(c, hipStreamSynchronize(st));
-        }
-        for (size_t v = 0; v < vox.size(); v++) {
-            if (nout_h[v] < 0) { c->err = "lmono_mapper: voxel filter rejected a cube"; return LMONO_ECAPACITY; }
-            new_seg[(size_t)vox_ind[v]].n = nout_h[v];
-        }
-        for (int ind : touched) m->cube[(size_t)t][(size_t)ind] = new_seg[(size_t)ind];
-    }
-    return check_launch(c, "mapper kernels");
+    if (!m || !b) return LMONO_EINVAL;
+    return lmono_mapper_process_batch(c, 1, &m, &b, &scan, q_wodom, t_wodom, q_w_curr, t_w_curr, stats_h);
 }
 
 extern "C" int lmono_mapper_cube(lmono_ctx *c, lmono_mapper *m, int which, int i, int j, int k, float *out_h, int cap)

@@ -163,3 +163,30 @@ def test_device_resident_mapper_follows_the_oracle(oracle, gpu_ctx):
                         assert np.abs(a - bq).max() < 1e-4
                         n_pts += len(a)
     assert n_pts > 20000
+
+
+def test_batched_streams_match_their_single_stream_oracles(oracle, gpu_ctx):
+    """lmono_mapper_process_batch: three independent streams (two different worlds, one of them twice) advanced in
+    lock-step, each against oracle.run_mapping of its own sequence."""
+    import torch
+    import lmono_amd
+    seqs = []
+    for seed in (20240, 777):
+        w = oracle.S1World(seed=seed, n_az=500)
+        traj = w.trajectory(8)
+        x, off = w.scans(traj)
+        xd = torch.from_numpy(x).cuda()
+        batch = lmono_amd.ScanBatch(gpu_ctx, 8, len(x))
+        batch.scanreg(xd.data_ptr(), off, 64, 5.0, keepalive=xd)
+        _, odo = batch.odometry(n_chains=1, lead=0)
+        seqs.append(dict(batch=batch, odo=odo, want=oracle.run_mapping(x, off, odo)))
+    streams = [seqs[0], seqs[1], seqs[0]]
+    mappers = [lmono_amd.Mapper(gpu_ctx) for _ in streams]
+    for k in range(8):
+        q, t, st = lmono_amd.Mapper.process_batch(gpu_ctx, mappers, [s["batch"] for s in streams], [k] * 3,
+                                                  np.array([s["odo"][k, :4] for s in streams]), np.array([s["odo"][k, 4:] for s in streams]))
+        for i, s in enumerate(streams):
+            ws = s["want"]["stats"][k]
+            assert list(st[i, :6]) == [ws.n_edge[0], ws.n_edge[1], ws.n_plane[0], ws.n_plane[1], ws.lm_iters[0], ws.lm_iters[1]], (k, i)
+            assert np.abs(np.concatenate([q[i], t[i]]) - s["want"]["poses"][k]).max() < 1e-7, (k, i)
+    assert np.array_equal(mappers[0].cube(1, 10, 10, 5), mappers[2].cube(1, 10, 10, 5)) and len(mappers[0].cube(1, 10, 10, 5)) > 100
