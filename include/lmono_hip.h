@@ -207,6 +207,7 @@ int lmono_voxel_filter(lmono_ctx *, int n_clouds, const float *xyzi_h, const int
 typedef struct lmono_mapper lmono_mapper;
 lmono_mapper *lmono_mapper_create(lmono_ctx *, float line_res, float plane_res);      /* HDL-64 launch file: 0.4, 0.8 */
 void          lmono_mapper_destroy(lmono_mapper *);
+int           lmono_mapper_reset(lmono_ctx *, lmono_mapper *);                        /* empty map, identity correction */
 int lmono_mapper_process(lmono_ctx *, lmono_mapper *, lmono_scan_batch *, int scan, const double q_wodom[4], const double t_wodom[3],
                          double q_w_curr[4], double t_w_curr[3], int32_t *stats);
 /* n independent streams advanced by one frame each, every phase one launch for all of them: mappers[n] (distinct),

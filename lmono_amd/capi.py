@@ -12,7 +12,7 @@ SYMBOLS = [
     "lmono_create", "lmono_destroy", "lmono_last_error", "lmono_set_stream", "lmono_synchronize", "lmono_version",
     "lmono_batch_create", "lmono_batch_destroy", "lmono_scanreg_batch", "lmono_scanreg_batch_h", "lmono_batch_counts", "lmono_batch_get_cloud",
     "lmono_batch_get_curvature", "lmono_odom_batch", "lmono_odom_batch_d", "lmono_odom_correspond", "lmono_timing_reset", "lmono_timing_read",
-    "lmono_pose_prefix_d", "lmono_pose_rebase_d", "lmono_map_refine", "lmono_voxel_filter", "lmono_mapper_create", "lmono_mapper_destroy", "lmono_mapper_process", "lmono_mapper_process_batch", "lmono_mapper_cube", "lmono_factor_eval", "lmono_factor_eval_d",
+    "lmono_pose_prefix_d", "lmono_pose_rebase_d", "lmono_map_refine", "lmono_voxel_filter", "lmono_mapper_create", "lmono_mapper_destroy", "lmono_mapper_reset", "lmono_mapper_process", "lmono_mapper_process_batch", "lmono_mapper_cube", "lmono_factor_eval", "lmono_factor_eval_d",
     "lmono_triangulate", "lmono_outlier_scores", "lmono_shift_depth", "lmono_marginalize", "lmono_marg_evaluate", "lmono_ba_batch_create", "lmono_ba_batch_destroy", "lmono_ba_solve", "lmono_ba_batch_reset", "lmono_ba_batch_read",
 ]
 
@@ -395,6 +395,10 @@ class Mapper:
         self.ctx.check(self.ctx.L.lmono_mapper_process(self.ctx.h, self.h, batch.h, int(scan), q.ctypes.data, t.ctypes.data,
                                                        qo.ctypes.data, to.ctypes.data, st.ctypes.data))
         return qo, to, st
+
+    def reset(self):
+        self.ctx.L.lmono_mapper_reset.argtypes = [C.c_void_p, C.c_void_p]
+        self.ctx.check(self.ctx.L.lmono_mapper_reset(self.ctx.h, self.h))
 
     @staticmethod
     def process_batch(ctx, mappers, batches, scans, q_wodom, t_wodom):

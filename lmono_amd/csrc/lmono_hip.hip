@@ -10,6 +10,7 @@
 
 #include <string>
 #include <vector>
+#include <chrono>
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -54,6 +55,7 @@ struct lmono_scan_batch {
     BatchView v{};
     int64_t *off_d = nullptr;
     float *in_owned = nullptr;     // staging buffer of lmono_scanreg_batch_h (pts_cap points), allocated on first use
+    std::vector<int> feat_h;       // host copy of feat_n [n_scans][4], fetched on first use after a registration
     // odometry workspace
     int chains_cap = 0;
     double *state = nullptr, *incr = nullptr, *poses = nullptr, *xq = nullptr;
@@ -207,6 +209,7 @@ extern "C" int lmono_scanreg_batch(lmono_ctx *c, lmono_scan_batch *b, const floa
     HIP_TRY(c, hipSetDevice(c->device));
     b->off_h.assign(offsets_h, offsets_h + n_scans + 1);
     b->n_scans = n_scans; b->total = total; b->max_pts = (int)max_pts; b->registered = false;
+    b->feat_h.clear();
     BatchView &v = b->v;
     v.in = (const float4 *)xyzi_d; v.n_scans = n_scans; v.n_lines = n_lines; v.min_range = min_range;
     hipStream_t st = c->stream;
@@ -967,6 +970,10 @@ struct lmono_mapper {
     int *masks = nullptr, *nout = nullptr, *stats = nullptr;
     int *nout_big = nullptr;        // output sizes of the cube filter jobs of a batched call (owned by the first mapper)
     size_t nout_cap = 0;
+    // contiguous mail boxes of a batched call (owned by the first mapper, grown on demand): poses, counters, cube indices /
+    // placements of all streams travel in one copy per phase
+    double *xbuf = nullptr; int *ibuf = nullptr; int *cubebuf = nullptr; int *posbuf = nullptr;
+    size_t xbuf_cap = 0, ibuf_cap = 0, cubebuf_cap = 0, posbuf_cap = 0;
     double *x = nullptr;
     MapRec *rec = nullptr;
     void *jobs = nullptr;           // device scratch for job arrays
@@ -1018,6 +1025,17 @@ extern "C" lmono_mapper *lmono_mapper_create(lmono_ctx *c, float line_res, float
     return m;
 }
 
+extern "C" int lmono_mapper_reset(lmono_ctx *c, lmono_mapper *m)
+{
+    if (!c || !m) return LMONO_EINVAL;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int t = 0; t < 2; t++) { m->cube[(size_t)t].assign((size_t)kMapCubes, Seg()); m->half[t] = 0; m->bump[t] = 0; }
+    m->cen[0] = 10; m->cen[1] = 10; m->cen[2] = 5;
+    m->q_wmap_wodom[0] = m->q_wmap_wodom[1] = m->q_wmap_wodom[2] = 0.0; m->q_wmap_wodom[3] = 1.0;
+    m->t_wmap_wodom[0] = m->t_wmap_wodom[1] = m->t_wmap_wodom[2] = 0.0;
+    return LMONO_OK;
+}
+
 // compaction: copy every live segment of one type into the other arena half
 static int mapper_compact(lmono_mapper *m, int t)
 {
@@ -1041,6 +1059,16 @@ static int mapper_compact(lmono_mapper *m, int t)
 }
 
 namespace {
+template <typename T> int mp_grow(lmono_ctx *c, lmono_mapper *m, T *&p, size_t &cap, size_t need)
+{
+    if (need <= cap) return LMONO_OK;
+    size_t nc = cap ? cap : 1024;
+    while (nc < need) nc <<= 1;
+    T *q = nullptr;
+    if (!mp_alloc(m, q, nc)) { c->err = "lmono_mapper: allocation failed"; return LMONO_ENOMEM; }
+    p = q; cap = nc;
+    return LMONO_OK;
+}
 // job tables of one phase for every stream go through one pinned-free staging path: a scratch device buffer owned by the
 // first mapper of the call, grown on demand
 struct JobScratch {
@@ -1109,10 +1137,21 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
     JobScratch js{ ms[0] };
     std::vector<FrameState> F((size_t)n);
     int rc;
+    const bool prof = getenv("LMONO_MAP_PROF") != nullptr;
+    auto tnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tp[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    tp[0] = tnow();
     // ---- phase 1 (host): transformAssociateToMap, centre cube, shifts, neighbourhood; scan cloud sizes
     std::vector<int> fn((size_t)n * 4);
-    for (int s = 0; s < n; s++) HIP_TRY(c, hipMemcpyAsync(&fn[(size_t)s * 4], bs[s]->v.feat_n + scans[s] * 4, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
+    for (int s = 0; s < n; s++) {
+        lmono_scan_batch *b = bs[s];
+        if (b->feat_h.empty()) {
+            b->feat_h.assign((size_t)b->n_scans * 4, 0);
+            HIP_TRY(c, hipStreamSynchronize(st));
+            HIP_TRY(c, hipMemcpy(b->feat_h.data(), b->v.feat_n, sizeof(int) * 4 * (size_t)b->n_scans, hipMemcpyDeviceToHost));
+        }
+        for (int k = 0; k < 4; k++) fn[(size_t)s * 4 + k] = b->feat_h[(size_t)scans[s] * 4 + k];
+    }
     for (int s = 0; s < n; s++) {
         lmono_mapper *m = ms[s];
         FrameState &f = F[(size_t)s];
@@ -1135,23 +1174,28 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
         f.n_last[0] = fn[(size_t)s * 4 + 1]; f.n_last[1] = fn[(size_t)s * 4 + 3];
         if (f.n_last[0] > kMapStackMax || f.n_last[1] > kMapStackMax) { c->err = "lmono_mapper: scan cloud too large"; return LMONO_ECAPACITY; }
     }
+    tp[1] = tnow();
     // ---- phase 2: VoxelGrid of the scan clouds (read in place from the scan batches)
     {
+        if ((rc = mp_grow(c, ms[0], ms[0]->ibuf, ms[0]->ibuf_cap, (size_t)10 * n)) || (rc = mp_grow(c, ms[0], ms[0]->xbuf, ms[0]->xbuf_cap, (size_t)8 * n))) return rc;
         std::vector<VoxJob> vj((size_t)2 * n);
         for (int s = 0; s < n; s++)
             for (int t = 0; t < 2; t++) {
                 lmono_mapper *m = ms[s];
                 VoxJob &J = vj[(size_t)2 * s + t];
                 J.in = t ? bs[s]->v.less_flat + bs[s]->off_h[(size_t)scans[s]] : bs[s]->v.less_sharp + (size_t)scans[s] * kMaxLessSharp;
-                J.n = F[(size_t)s].n_last[t]; J.inv_leaf = 1.0f / m->leaf[t]; J.out = m->stack[t]; J.n_out = m->nout + t;
+                J.n = F[(size_t)s].n_last[t]; J.inv_leaf = 1.0f / m->leaf[t]; J.out = m->stack[t]; J.n_out = ms[0]->ibuf + 2 * s + t;
                 J.key_a = m->vk[t]; J.key_b = m->vk[t] + kMapStackMax; J.idx_a = m->vi[t]; J.idx_b = m->vi[t] + kMapStackMax;
             }
         if ((rc = js.upload(c, vj.data(), vj.size() * sizeof(VoxJob), st))) return rc;
         hipLaunchKernelGGL(k_voxel_cloud, dim3(2 * n), dim3(1024), 0, st, (const VoxJob *)js.owner->jobs);
-        for (int s = 0; s < n; s++) HIP_TRY(c, hipMemcpyAsync(F[(size_t)s].n_stack, ms[s]->nout, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
+        std::vector<int> ns_h((size_t)2 * n);
+        HIP_TRY(c, hipMemcpyAsync(ns_h.data(), ms[0]->ibuf, sizeof(int) * 2 * (size_t)n, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
+        for (int s = 0; s < n; s++) { F[(size_t)s].n_stack[0] = ns_h[(size_t)2 * s]; F[(size_t)s].n_stack[1] = ns_h[(size_t)2 * s + 1]; }
         for (int s = 0; s < n; s++) if (F[(size_t)s].n_stack[0] < 0 || F[(size_t)s].n_stack[1] < 0) { c->err = "lmono_mapper: voxel filter rejected a scan cloud"; return LMONO_ECAPACITY; }
     }
+    tp[2] = tnow();
     // ---- phase 3: map clouds of the neighbourhoods, concatenated in validInd order
     {
         std::vector<CopyJob> jobs;
@@ -1176,15 +1220,17 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
             HIP_TRY(c, hipStreamSynchronize(st));    // the job scratch is reused below
         }
     }
+    tp[3] = tnow();
     // ---- phase 4: optimisation (grids, 2 x [correspond + solve]) for the streams whose map is large enough
     std::vector<int32_t> stats((size_t)n * 8, 0);
     {
         std::vector<int> act;
         for (int s = 0; s < n; s++) if (F[(size_t)s].solve) act.push_back(s);
-        for (int s = 0; s < n; s++) {
-            HIP_TRY(c, hipMemcpyAsync(ms[s]->x, F[(size_t)s].x, sizeof(double) * 8, hipMemcpyHostToDevice, st));
-            HIP_TRY(c, hipMemsetAsync(ms[s]->stats, 0, sizeof(int) * 8, st));
-        }
+        std::vector<double> xh((size_t)8 * n);
+        for (int s = 0; s < n; s++) for (int k = 0; k < 8; k++) xh[(size_t)8 * s + k] = F[(size_t)s].x[k];
+        int *statbuf = ms[0]->ibuf + 2 * n;      // [n][8] behind the n_stack pairs
+        HIP_TRY(c, hipMemcpyAsync(ms[0]->xbuf, xh.data(), sizeof(double) * 8 * (size_t)n, hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipMemsetAsync(statbuf, 0, sizeof(int) * 8 * (size_t)n, st));
         if (!act.empty()) {
             std::vector<CloudJob> cj((size_t)2 * act.size());
             std::vector<MapStream> S(act.size());
@@ -1199,7 +1245,7 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
                     S[a].cell[t] = m->cells[t]; S[a].sorted[t] = m->sorted[t]; S[a].cloud[t] = m->neigh[t]; S[a].mask[t] = m->masks + t; S[a].n_map[t] = f.n_map[t];
                     S[a].stack[t] = m->stack[t]; S[a].n_stack[t] = f.n_stack[t];
                 }
-                S[a].rec = m->rec; S[a].x = m->x; S[a].stats = m->stats; S[a].nn_out = nullptr;
+                S[a].rec = m->rec; S[a].x = ms[0]->xbuf + 8 * act[a]; S[a].stats = statbuf + 8 * act[a]; S[a].nn_out = nullptr;
                 max_nq = std::max(max_nq, f.n_stack[0] + f.n_stack[1]);
             }
             // job table = [CloudJob x 2 act | MapStream x act] in one upload
@@ -1214,13 +1260,13 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
                 if (max_nq > 0) hipLaunchKernelGGL(k_map_correspond, dim3((max_nq + 7) / 8, (unsigned)act.size()), dim3(256), 0, st, S_d, outer);
                 hipLaunchKernelGGL(k_map_solve, dim3((unsigned)act.size()), dim3(1024), 0, st, S_d, outer);
             }
-            for (int s : act) {
-                HIP_TRY(c, hipMemcpyAsync(F[(size_t)s].x, ms[s]->x, sizeof(double) * 8, hipMemcpyDeviceToHost, st));
-                HIP_TRY(c, hipMemcpyAsync(&stats[(size_t)s * 8], ms[s]->stats, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
-            }
+            HIP_TRY(c, hipMemcpyAsync(xh.data(), ms[0]->xbuf, sizeof(double) * 8 * (size_t)n, hipMemcpyDeviceToHost, st));
+            HIP_TRY(c, hipMemcpyAsync(stats.data(), statbuf, sizeof(int) * 8 * (size_t)n, hipMemcpyDeviceToHost, st));
             HIP_TRY(c, hipStreamSynchronize(st));
+            for (int s : act) for (int k = 0; k < 8; k++) F[(size_t)s].x[k] = xh[(size_t)8 * s + k];
         }
     }
+    tp[4] = tnow();
     // ---- phase 5 (host): results, transformUpdate; then pointAssociateToMap + cube index of every stack point on the device
     for (int s = 0; s < n; s++) {
         lmono_mapper *m = ms[s];
@@ -1235,17 +1281,38 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
         mp_qmul(f.x, qi, m->q_wmap_wodom);
         mp_qrot(m->q_wmap_wodom, to, tmp);
         for (int k = 0; k < 3; k++) m->t_wmap_wodom[k] = f.x[4 + k] - tmp[k];
-        HIP_TRY(c, hipMemcpyAsync(m->x, f.x, sizeof(double) * 8, hipMemcpyHostToDevice, st));
-        for (int t = 0; t < 2; t++) {
-            f.cube_h[t].assign((size_t)(f.n_stack[t] > 0 ? f.n_stack[t] : 1), -1);
-            if (f.n_stack[t] > 0) {
-                hipLaunchKernelGGL(k_map_assign, dim3((f.n_stack[t] + 255) / 256), dim3(256), 0, st, (const float4 *)m->stack[t], f.n_stack[t], (const double *)m->x,
-                                   m->cen[0], m->cen[1], m->cen[2], m->newpts[t], m->cube_of[t]);
-                HIP_TRY(c, hipMemcpyAsync(f.cube_h[t].data(), m->cube_of[t], sizeof(int) * (size_t)f.n_stack[t], hipMemcpyDeviceToHost, st));
-            }
-        }
     }
-    HIP_TRY(c, hipStreamSynchronize(st));
+    {
+        // refined poses back to the device in one copy; one launch transforms every stack and finds its cubes
+        std::vector<double> xh((size_t)8 * n);
+        for (int s = 0; s < n; s++) for (int k = 0; k < 8; k++) xh[(size_t)8 * s + k] = F[(size_t)s].x[k];
+        HIP_TRY(c, hipMemcpyAsync(ms[0]->xbuf, xh.data(), sizeof(double) * 8 * (size_t)n, hipMemcpyHostToDevice, st));
+        size_t total = 0;
+        int max_n = 0;
+        std::vector<size_t> at((size_t)2 * n);
+        for (int s = 0; s < n; s++) for (int t = 0; t < 2; t++) { at[(size_t)2 * s + t] = total; total += (size_t)F[(size_t)s].n_stack[t]; max_n = std::max(max_n, F[(size_t)s].n_stack[t]); }
+        if ((rc = mp_grow(c, ms[0], ms[0]->cubebuf, ms[0]->cubebuf_cap, total + 1)) || (rc = mp_grow(c, ms[0], ms[0]->posbuf, ms[0]->posbuf_cap, total + 1))) return rc;
+        std::vector<AssignJob> aj((size_t)2 * n);
+        for (int s = 0; s < n; s++)
+            for (int t = 0; t < 2; t++) {
+                lmono_mapper *m = ms[s];
+                aj[(size_t)2 * s + t] = { m->stack[t], F[(size_t)s].n_stack[t], ms[0]->xbuf + 8 * s, m->cen[0], m->cen[1], m->cen[2], m->newpts[t], ms[0]->cubebuf + at[(size_t)2 * s + t] };
+            }
+        std::vector<int> cube_all(total + 1, -1);
+        if (max_n > 0) {
+            if ((rc = js.upload(c, aj.data(), aj.size() * sizeof(AssignJob), st))) return rc;
+            hipLaunchKernelGGL(k_map_assign, dim3((max_n + 255) / 256, 2 * n), dim3(256), 0, st, (const AssignJob *)js.owner->jobs);
+            HIP_TRY(c, hipMemcpyAsync(cube_all.data(), ms[0]->cubebuf, sizeof(int) * total, hipMemcpyDeviceToHost, st));
+        }
+        HIP_TRY(c, hipStreamSynchronize(st));
+        for (int s = 0; s < n; s++)
+            for (int t = 0; t < 2; t++) {
+                const int ns = F[(size_t)s].n_stack[t];
+                F[(size_t)s].cube_h[t].assign(cube_all.begin() + (long)at[(size_t)2 * s + t], cube_all.begin() + (long)at[(size_t)2 * s + t] + ns);
+                if (ns == 0) F[(size_t)s].cube_h[t].assign(1, -1);
+            }
+    }
+    tp[5] = tnow();
     // ---- phase 6: the scans join the cubes.  Host: per touched cube [old points | new points in stack order]; device: build
     // them, re-filter the cubes of the neighbourhoods into fresh arena space, the other touched cubes keep [old | new]
     struct Touched { int s, t, ind, n_in; int64_t cat_off; bool filter; };
@@ -1287,14 +1354,26 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
         if ((rc = js.upload(c, copy.data(), copy.size() * sizeof(CopyJob), st))) return rc;
         hipLaunchKernelGGL(k_copy_jobs, dim3((unsigned)copy.size()), dim3(256), 0, st, (const CopyJob *)js.owner->jobs);
     }
-    for (int s = 0; s < n; s++)
-        for (int t = 0; t < 2; t++) {
-            lmono_mapper *m = ms[s];
-            const int ns = F[(size_t)s].n_stack[t];
-            if (ns <= 0) continue;
-            HIP_TRY(c, hipMemcpyAsync(m->pos[t], pos_h[(size_t)2 * s + t].data(), sizeof(int) * (size_t)ns, hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(k_scatter_pos, dim3((ns + 255) / 256), dim3(256), 0, st, (const float4 *)m->newpts[t], (const int *)m->pos[t], ns, m->cat[t]);
+    {
+        size_t total = 0;
+        int max_n = 0;
+        std::vector<size_t> at((size_t)2 * n);
+        for (int s = 0; s < n; s++) for (int t = 0; t < 2; t++) { at[(size_t)2 * s + t] = total; total += (size_t)F[(size_t)s].n_stack[t]; max_n = std::max(max_n, F[(size_t)s].n_stack[t]); }
+        std::vector<int> pos_all(total + 1, -1);
+        std::vector<ScatterJob> sj((size_t)2 * n);
+        for (int s = 0; s < n; s++)
+            for (int t = 0; t < 2; t++) {
+                const int ns = F[(size_t)s].n_stack[t];
+                for (int i = 0; i < ns; i++) pos_all[at[(size_t)2 * s + t] + (size_t)i] = pos_h[(size_t)2 * s + t][(size_t)i];
+                sj[(size_t)2 * s + t] = { ms[s]->newpts[t], ms[0]->posbuf + at[(size_t)2 * s + t], ns, ms[s]->cat[t] };
+            }
+        if (max_n > 0) {
+            HIP_TRY(c, hipStreamSynchronize(st));    // the copy jobs still read the job scratch
+            HIP_TRY(c, hipMemcpyAsync(ms[0]->posbuf, pos_all.data(), sizeof(int) * total, hipMemcpyHostToDevice, st));
+            if ((rc = js.upload(c, sj.data(), sj.size() * sizeof(ScatterJob), st))) return rc;
+            hipLaunchKernelGGL(k_scatter_pos, dim3((max_n + 255) / 256, 2 * n), dim3(256), 0, st, (const ScatterJob *)js.owner->jobs);
         }
+    }
     HIP_TRY(c, hipStreamSynchronize(st));   // `cat` is complete; the job scratch and pos_h are free again
     // arena space (an output is never larger than its input); compaction reads only the tables, `cat` is already built
     {
@@ -1358,6 +1437,8 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
         const Touched &T = touched[vox_t[v]];
         ms[T.s]->cube[(size_t)T.t][(size_t)T.ind].n = nout_h[v];
     }
+    tp[6] = tnow();
+    if (prof) fprintf(stderr, "MAPPROF n=%d ms: host1 %.2f voxel %.2f gather %.2f optimise %.2f assign %.2f update %.2f\n", n, tp[1] - tp[0], tp[2] - tp[1], tp[3] - tp[2], tp[4] - tp[3], tp[5] - tp[4], tp[6] - tp[5]);
     return check_launch(c, "mapper kernels");
 }
 

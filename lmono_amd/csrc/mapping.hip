@@ -633,29 +633,36 @@ __global__ __launch_bounds__(256) void k_copy_jobs(const CopyJob *jobs)
 }
 
 // pointAssociateToMap of every down-sampled scan point with the refined pose (double transform stored in a float point,
-// intensity kept) and the cube it falls into: cube = int((v + 25) / 50) + cen, one lower when v + 25 < 0
-__global__ __launch_bounds__(256) void k_map_assign(const float4 *stack, int n, const double *x, int cen_w, int cen_h, int cen_d,
-                                                    float4 *out, int *cube)
+// intensity kept) and the cube it falls into: cube = int((v + 25) / 50) + cen, one lower when v + 25 < 0.
+// One job per (stream, cloud type); blockIdx.y = job.
+struct AssignJob { const float4 *stack; int n; const double *x; int cen_w, cen_h, cen_d; float4 *out; int *cube; };
+
+__global__ __launch_bounds__(256) void k_map_assign(const AssignJob *jobs)
 {
+    const AssignJob J = jobs[blockIdx.y];
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float4 p = stack[i];
+    if (i >= J.n) return;
+    const float4 p = J.stack[i];
+    const double *x = J.x;
     double rx, ry, rz;
     quat_rotate(x, (double)p.x, (double)p.y, (double)p.z, rx, ry, rz);
     const float4 s = make_float4((float)(rx + x[4]), (float)(ry + x[5]), (float)(rz + x[6]), p.w);
-    out[i] = s;
-    int ci = (int)(((double)s.x + 25.0) / 50.0) + cen_w, cj = (int)(((double)s.y + 25.0) / 50.0) + cen_h, ck = (int)(((double)s.z + 25.0) / 50.0) + cen_d;
+    J.out[i] = s;
+    int ci = (int)(((double)s.x + 25.0) / 50.0) + J.cen_w, cj = (int)(((double)s.y + 25.0) / 50.0) + J.cen_h, ck = (int)(((double)s.z + 25.0) / 50.0) + J.cen_d;
     if ((double)s.x + 25.0 < 0) ci--;
     if ((double)s.y + 25.0 < 0) cj--;
     if ((double)s.z + 25.0 < 0) ck--;
-    cube[i] = (ci >= 0 && ci < 21 && cj >= 0 && cj < 21 && ck >= 0 && ck < 11) ? ci + 21 * cj + 441 * ck : -1;
+    J.cube[i] = (ci >= 0 && ci < 21 && cj >= 0 && cj < 21 && ck >= 0 && ck < 11) ? ci + 21 * cj + 441 * ck : -1;
 }
 
-// dst[pos[i]] = src[i] for pos[i] >= 0
-__global__ __launch_bounds__(256) void k_scatter_pos(const float4 *src, const int *pos, int n, float4 *dst)
+// dst[pos[i]] = src[i] for pos[i] >= 0; one job per (stream, cloud type); blockIdx.y = job
+struct ScatterJob { const float4 *src; const int *pos; int n; float4 *dst; };
+
+__global__ __launch_bounds__(256) void k_scatter_pos(const ScatterJob *jobs)
 {
+    const ScatterJob J = jobs[blockIdx.y];
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n && pos[i] >= 0) dst[pos[i]] = src[i];
+    if (i < J.n && J.pos[i] >= 0) J.dst[J.pos[i]] = J.src[i];
 }
 
 } // namespace lmono
