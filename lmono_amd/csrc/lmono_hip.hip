@@ -835,6 +835,7 @@ extern "C" int lmono_map_refine(lmono_ctx *c, int n_streams,
     const int64_t nq_total = tot[2] + tot[3];
     MapRec *rec = (MapRec *)db.up((const char *)nullptr, (size_t)(nq_total > 0 ? nq_total : 1) * sizeof(MapRec), ok);
     int *nn_d = nn_out_h ? db.up((const int *)nullptr, (size_t)(nq_total > 0 ? nq_total : 1) * 5, ok) : nullptr;
+    int *nn_tmp_d = db.up((const int *)nullptr, (size_t)(nq_total > 0 ? nq_total : 1) * 5, ok);
     std::vector<double> xh((size_t)n_streams * 8, 0.0);
     for (int s = 0; s < n_streams; s++) for (int k = 0; k < 7; k++) xh[(size_t)s * 8 + k] = pose_qt[(size_t)s * 7 + k];
     double *x_d = db.up(xh.data(), xh.size(), ok);
@@ -859,6 +860,7 @@ extern "C" int lmono_map_refine(lmono_ctx *c, int n_streams,
         }
         S.rec = rec + rec_at; S.x = x_d + (size_t)s * 8; S.stats = stats_d + (size_t)s * 8;
         S.nn_out = nn_d ? nn_d + rec_at * 5 : nullptr;
+        S.nn_tmp = nn_tmp_d + rec_at * 5;
         const int nq = S.n_stack[0] + S.n_stack[1];
         rec_at += nq;
         max_nq = nq > max_nq ? nq : max_nq;
@@ -873,7 +875,10 @@ extern "C" int lmono_map_refine(lmono_ctx *c, int n_streams,
     hipLaunchKernelGGL(k_cloud_grid, dim3(2 * n_streams), dim3(1024), 0, stream, (const CloudJob *)jobs_d);
     (void)hipEventRecord(ev1, stream);
     for (int outer = 0; outer < 2; outer++) {
-        if (max_nq > 0) hipLaunchKernelGGL(k_map_correspond, dim3((max_nq + 7) / 8, n_streams), dim3(256), 0, stream, (const MapStream *)st_d, outer);
+        if (max_nq > 0) {
+            hipLaunchKernelGGL(k_map_correspond, dim3((max_nq + 7) / 8, n_streams), dim3(256), 0, stream, (const MapStream *)st_d, outer);
+            hipLaunchKernelGGL(k_map_factor, dim3((max_nq + 63) / 64, n_streams), dim3(64), 0, stream, (const MapStream *)st_d, outer);
+        }
         hipLaunchKernelGGL(k_map_solve, dim3(n_streams), dim3(1024), 0, stream, (const MapStream *)st_d, outer);
     }
     (void)hipEventRecord(ev2, stream);
@@ -976,6 +981,7 @@ struct lmono_mapper {
     size_t xbuf_cap = 0, ibuf_cap = 0, cubebuf_cap = 0, posbuf_cap = 0;
     double *x = nullptr;
     MapRec *rec = nullptr;
+    int *nn_tmp = nullptr;          // [2 kMapStackMax][5]
     void *jobs = nullptr;           // device scratch for job arrays
     size_t jobs_bytes = 0;
     MapStream *stream_d = nullptr;
@@ -1020,7 +1026,7 @@ extern "C" lmono_mapper *lmono_mapper_create(lmono_ctx *c, float line_res, float
     m->jobs_bytes = 1 << 20;
     m->nout_cap = 1024;
     ok = ok && mp_alloc(m, m->masks, 2) && mp_alloc(m, m->nout, 2 * 256) && mp_alloc(m, m->nout_big, m->nout_cap) && mp_alloc(m, m->stats, 8) && mp_alloc(m, m->x, 8) &&
-         mp_alloc(m, m->rec, (size_t)2 * kMapStackMax) && mp_alloc(m, (char *&)m->jobs, m->jobs_bytes) && mp_alloc(m, m->stream_d, 1);
+         mp_alloc(m, m->rec, (size_t)2 * kMapStackMax) && mp_alloc(m, m->nn_tmp, (size_t)10 * kMapStackMax) && mp_alloc(m, (char *&)m->jobs, m->jobs_bytes) && mp_alloc(m, m->stream_d, 1);
     if (!ok) { c->err = "lmono_mapper_create: device allocation failed"; lmono_mapper_destroy(m); return nullptr; }
     return m;
 }
@@ -1245,7 +1251,7 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
                     S[a].cell[t] = m->cells[t]; S[a].sorted[t] = m->sorted[t]; S[a].cloud[t] = m->neigh[t]; S[a].mask[t] = m->masks + t; S[a].n_map[t] = f.n_map[t];
                     S[a].stack[t] = m->stack[t]; S[a].n_stack[t] = f.n_stack[t];
                 }
-                S[a].rec = m->rec; S[a].x = ms[0]->xbuf + 8 * act[a]; S[a].stats = statbuf + 8 * act[a]; S[a].nn_out = nullptr;
+                S[a].rec = m->rec; S[a].x = ms[0]->xbuf + 8 * act[a]; S[a].stats = statbuf + 8 * act[a]; S[a].nn_out = nullptr; S[a].nn_tmp = m->nn_tmp;
                 max_nq = std::max(max_nq, f.n_stack[0] + f.n_stack[1]);
             }
             // job table = [CloudJob x 2 act | MapStream x act] in one upload
@@ -1257,7 +1263,10 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
             const MapStream *S_d = (const MapStream *)((const char *)js.owner->jobs + cj.size() * sizeof(CloudJob));
             hipLaunchKernelGGL(k_cloud_grid, dim3((unsigned)cj.size()), dim3(1024), 0, st, cj_d);
             for (int outer = 0; outer < 2; outer++) {
-                if (max_nq > 0) hipLaunchKernelGGL(k_map_correspond, dim3((max_nq + 7) / 8, (unsigned)act.size()), dim3(256), 0, st, S_d, outer);
+                if (max_nq > 0) {
+                    hipLaunchKernelGGL(k_map_correspond, dim3((max_nq + 7) / 8, (unsigned)act.size()), dim3(256), 0, st, S_d, outer);
+                    hipLaunchKernelGGL(k_map_factor, dim3((max_nq + 63) / 64, (unsigned)act.size()), dim3(64), 0, st, S_d, outer);
+                }
                 hipLaunchKernelGGL(k_map_solve, dim3((unsigned)act.size()), dim3(1024), 0, st, S_d, outer);
             }
             HIP_TRY(c, hipMemcpyAsync(xh.data(), ms[0]->xbuf, sizeof(double) * 8 * (size_t)n, hipMemcpyDeviceToHost, st));

@@ -4,9 +4,10 @@
 //   k_cloud_grid   one workgroup per (stream, cloud): 1 m hash grid over an arbitrary float4 cloud (the map clouds of the
 //                  cube neighbourhood), same structure as the odometry grids (16-B cells, cell-sorted copy)
 //   k_map_correspond  32 lanes per down-sampled scan point: pointAssociateToMap, exact 5-NN among the 27 cells around it
-//                  (every neighbour that can pass the "5th distance^2 < 1" test lies inside them), then per point the
-//                  line test (covariance of the 5 neighbours, Jacobi eigen-decomposition, largest > 3 x middle) or the
-//                  plane fit (column-pivoted Householder least squares, all five within 0.2) -> an 80-B double record
+//                  (every neighbour that can pass the "5th distance^2 < 1" test lies inside them)
+//   k_map_factor   one thread per point: the line test (covariance of the 5 neighbours, Jacobi eigen-decomposition,
+//                  largest > 3 x middle) or the plane fit (column-pivoted Householder least squares, all five within
+//                  0.2) -> an 80-B double record
 //   k_map_solve    one workgroup per stream: ceres::Solve restated (trust-region LM, <= 4 iterations, Huber 0.1) over
 //                  the records (LidarEdgeFactor / LidarPlaneNormFactor, closed-form Jacobians)
 // The map bookkeeping (cube array, voxel re-filtering) is not part of this file yet.
@@ -162,7 +163,8 @@ struct MapStream {
     MapRec *rec;           // [n_stack[0] + n_stack[1]]
     double *x;             // [8] q(xyzw), t
     int *stats;            // [8] n_edge[2], n_plane[2], lm_iters[2], pad
-    int *nn_out;           // optional [n][5] neighbour indices of the last outer iteration (-1: rejected)
+    int *nn_tmp;           // [n][5] neighbour indices of the current outer iteration (-1: the 5-NN test failed)
+    int *nn_out;           // optional [n][5] neighbour indices of the accepted blocks of the last outer iteration (-1: none)
 };
 
 // sorted insertion of (d, idx) into a lane-local ascending top-5
@@ -188,9 +190,8 @@ __global__ __launch_bounds__(256) void k_map_correspond(const MapStream *streams
     const int lane = threadIdx.x & 63, gl = threadIdx.x & 31, gbase = lane & ~31;
     const int which = qi < S.n_stack[0] ? 0 : 1;
     const float4 p = S.stack[which][which ? qi - S.n_stack[0] : qi];
-    MapRec *rec = S.rec + qi;
-    int kind = 0;
     int nn[5] = { -1, -1, -1, -1, -1 };
+    bool accepted = false;
     const unsigned int mask = (unsigned int)*S.mask[which];
     // the solve is skipped altogether unless the map holds > 10 corner and > 50 surf points (laserMapping.cpp)
     if (S.n_map[0] > 10 && S.n_map[1] > 50 && mask != 0) {
@@ -240,42 +241,66 @@ __global__ __launch_bounds__(256) void k_map_correspond(const MapStream *streams
                 td[4] = __uint_as_float(0x7f800000u); ti[4] = 0x7fffffff;
             }
         }
-        if (full && (double)d5 < 1.0) {
-            // every lane evaluates the (group-uniform) small dense problem: no divergence, lane 0 writes
-            double P[15];
-            for (int j = 0; j < 5; j++) { const float4 c = S.cloud[which][nn[j]]; P[j * 3] = (double)c.x; P[j * 3 + 1] = (double)c.y; P[j * 3 + 2] = (double)c.z; }
-            double ra[3] = { 0, 0, 0 }, rb[3] = { 0, 0, 0 };
-            if (which == 0) {
-                double c[3] = { 0, 0, 0 };
-                for (int j = 0; j < 5; j++) { c[0] += P[j * 3]; c[1] += P[j * 3 + 1]; c[2] += P[j * 3 + 2]; }
-                for (int k = 0; k < 3; k++) c[k] = c[k] / 5.0;
-                double cov[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-                for (int j = 0; j < 5; j++) {
-                    const double z[3] = { P[j * 3] - c[0], P[j * 3 + 1] - c[1], P[j * 3 + 2] - c[2] };
-                    for (int a = 0; a < 3; a++) for (int bb = 0; bb < 3; bb++) cov[a * 3 + bb] += z[a] * z[bb];
-                }
-                double ev[3], evec[9];
-                sym_eig3(cov, ev, evec);
-                if (ev[2] > 3.0 * ev[1]) {
-                    kind = 1;
-                    for (int k = 0; k < 3; k++) { ra[k] = 0.1 * evec[k * 3 + 2] + c[k]; rb[k] = -0.1 * evec[k * 3 + 2] + c[k]; }
-                }
-            } else {
-                double nrm[3], d;
-                if (plane_fit5(P, nrm, d)) { kind = 3; ra[0] = d; for (int k = 0; k < 3; k++) rb[k] = nrm[k]; }
+        accepted = full && (double)d5 < 1.0;
+    }
+    // the five neighbours (or -1) go to the per-point scratch; k_map_factor turns them into a residual block
+    if (gl == 0) {
+        int *o = S.nn_tmp + (size_t)qi * 5;
+#pragma unroll
+        for (int k = 0; k < 5; k++) o[k] = accepted ? nn[k] : -1;
+    }
+}
+
+// One thread per down-sampled scan point: the line test (covariance of the five neighbours, eigen-decomposition, largest
+// > 3 x middle -> LidarEdgeFactor against centre +- 0.1 dir) or the plane fit (all five within 0.2 ->
+// LidarPlaneNormFactor), written as an 80-B fp64 record.
+__global__ __launch_bounds__(64) void k_map_factor(const MapStream *streams, int outer)
+{
+    const MapStream S = streams[blockIdx.y];
+    const int nq = S.n_stack[0] + S.n_stack[1];
+    const int qi = blockIdx.x * 64 + threadIdx.x;
+    if (qi >= nq) return;
+    const int which = qi < S.n_stack[0] ? 0 : 1;
+    const int *nn = S.nn_tmp + (size_t)qi * 5;
+    MapRec *rec = S.rec + qi;
+    int kind = 0;
+    if (nn[0] >= 0) {
+        const float4 p = S.stack[which][which ? qi - S.n_stack[0] : qi];
+        double P[15];
+        for (int j = 0; j < 5; j++) { const float4 c = S.cloud[which][nn[j]]; P[j * 3] = (double)c.x; P[j * 3 + 1] = (double)c.y; P[j * 3 + 2] = (double)c.z; }
+        double ra[3] = { 0, 0, 0 }, rb[3] = { 0, 0, 0 };
+        if (which == 0) {
+            double c[3] = { 0, 0, 0 };
+            for (int j = 0; j < 5; j++) { c[0] += P[j * 3]; c[1] += P[j * 3 + 1]; c[2] += P[j * 3 + 2]; }
+            for (int k = 0; k < 3; k++) c[k] = c[k] / 5.0;
+            double cov[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+            for (int j = 0; j < 5; j++) {
+                const double z[3] = { P[j * 3] - c[0], P[j * 3 + 1] - c[1], P[j * 3 + 2] - c[2] };
+                for (int a = 0; a < 3; a++) for (int bb = 0; bb < 3; bb++) cov[a * 3 + bb] += z[a] * z[bb];
             }
-            if (gl == 0 && kind != 0) {
-                rec->cp[0] = (double)p.x; rec->cp[1] = (double)p.y; rec->cp[2] = (double)p.z;
-                for (int k = 0; k < 3; k++) { rec->a[k] = ra[k]; rec->b[k] = rb[k]; }
+            double ev[3], evec[9];
+            sym_eig3(cov, ev, evec);
+            if (ev[2] > 3.0 * ev[1]) {
+                kind = 1;
+                for (int k = 0; k < 3; k++) { ra[k] = 0.1 * evec[k * 3 + 2] + c[k]; rb[k] = -0.1 * evec[k * 3 + 2] + c[k]; }
             }
+        } else {
+            double nrm[3], d;
+            if (plane_fit5(P, nrm, d)) { kind = 3; ra[0] = d; for (int k = 0; k < 3; k++) rb[k] = nrm[k]; }
+        }
+        if (kind != 0) {
+            rec->cp[0] = (double)p.x; rec->cp[1] = (double)p.y; rec->cp[2] = (double)p.z;
+            for (int k = 0; k < 3; k++) { rec->a[k] = ra[k]; rec->b[k] = rb[k]; }
         }
     }
-    if (gl == 0) {
-        rec->kind = kind;
-        if (kind == 1) atomicAdd(&S.stats[outer], 1);
-        if (kind == 3) atomicAdd(&S.stats[2 + outer], 1);
-        if (S.nn_out) for (int k = 0; k < 5; k++) S.nn_out[(size_t)qi * 5 + k] = kind != 0 ? nn[k] : -1;
+    rec->kind = kind;
+    // block counts: one atomic per wave and kind
+    const unsigned long long m1 = __ballot(kind == 1), m3 = __ballot(kind == 3);
+    if (threadIdx.x == 0) {
+        if (m1) atomicAdd(&S.stats[outer], __popcll(m1));
+        if (m3) atomicAdd(&S.stats[2 + outer], __popcll(m3));
     }
+    if (S.nn_out) for (int k = 0; k < 5; k++) S.nn_out[(size_t)qi * 5 + k] = kind != 0 ? nn[k] : -1;
 }
 
 // ---- solve -----------------------------------------------------------------------------------------------------------
