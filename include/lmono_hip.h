@@ -217,6 +217,41 @@ int lmono_mapper_process_batch(lmono_ctx *, int n, lmono_mapper *const *mappers,
 /* cube (i, j, k) of the corner (which = 0) / surf (1) array: returns its size; copies the points when out_h != NULL */
 int lmono_mapper_cube(lmono_ctx *, lmono_mapper *, int which, int i, int j, int k, float *out_h, int cap);
 
+/* ---- colour projection of the map builder ------------------------------------------------------------
+ * Replaces MapBuilder::associateToMap + MapBuilder::depthFill (mono_lidar_mapping/src/map_builder/Map_Builder.cc:213-403)
+ * and the accumulation of MapBuilder::processMapping (:8-90): a LiDAR scan is moved into the camera frame (the
+ * pcl::transformPointCloud of map_build_node.cc:216-225, passed as `transform`), projected with camodocal's pinhole model
+ * (camera_models/src/camera_models/PinholeCamera.cc:450-545), splatted into an 8-bit depth image (100 - z), hole-filled
+ * (dilate / close / dilate 7 + fill / median 5 / bilateral or Gaussian), and every pixel with 0 < depth < 70 m is lifted
+ * back to a coloured 3-D point, in row-major pixel order, in the camera frame (topic rgb_points) and in the world frame
+ * (q_wc, t_wc = the Q, T arguments of associateToMap), the latter appended to the device-resident rgb_map.
+ * The display products (HSV overlay :244, JET heat map :255) are not produced.                                          */
+typedef struct {
+    int width, height;                       /* image size (config image_width / image_height)                         */
+    double fx, fy, cx, cy, k1, k2, p1, p2;   /* PINHOLE projection_parameters / distortion_parameters of the cam yaml   */
+    int kernel_size;                         /* kernel_size (odd, <= 11)                                                */
+    int kernel_type;                         /* kernel_type: 0 "FULL" (rect), 1 "CROSS", 2 anything else (ellipse)       */
+    int blur_type;                           /* blur_type: 0 "bilateral", 1 anything else (Gaussian)                     */
+} lmono_camera;
+typedef struct { float x, y, z; uint32_t bgra; } lmono_point_rgb;   /* pcl::PointXYZRGB payload: b | g << 8 | r << 16 | 255 << 24 */
+typedef struct lmono_map_builder lmono_map_builder;
+/* max_cloud_points: largest scan of the host-buffer entry; map_capacity_points: capacity of rgb_map (>= width * height) */
+lmono_map_builder *lmono_map_builder_create(lmono_ctx *, const lmono_camera *, int max_cloud_points, int64_t map_capacity_points);
+void               lmono_map_builder_destroy(lmono_map_builder *);
+/* One associateToMap: xyzi_h [n_points][4] float32 scan (LiDAR frame), transform: row-major 4 x 4 LiDAR -> camera,
+ * bgr_h: [height][width][3] uint8 (cv::Mat BGR8), q_wc (x y z w) / t_wc: camera pose.  n_out: size of the coloured cloud. */
+int lmono_associate_to_map(lmono_ctx *, lmono_map_builder *, const float *xyzi_h, int n_points, const double transform[16],
+                           const uint8_t *bgr_h, const double q_wc[4], const double t_wc[3], int *n_out);
+/* n_streams independent map builders advanced by one frame each, scans and images already resident in HBM (xyzi_d[s],
+ * bgr_d[s] device pointers; transforms [n][16], q_wc [n][4], t_wc [n][3], n_out [n] host arrays); four launches in all. */
+int lmono_associate_to_map_batch(lmono_ctx *, int n_streams, lmono_map_builder *const *mbs, const float *const *xyzi_d, const int *n_points,
+                                 const double *transforms, const uint8_t *const *bgr_d, const double *q_wc, const double *t_wc, int *n_out);
+int lmono_map_builder_depth(lmono_ctx *, lmono_map_builder *, uint8_t *depth_h);       /* filled depth map of the last frame */
+/* coloured cloud of the last frame: which = 0 camera frame, 1 world frame; returns its size (copies when out_h != NULL)  */
+int lmono_map_builder_cloud(lmono_ctx *, lmono_map_builder *, int which, lmono_point_rgb *out_h, int cap);
+int64_t lmono_map_builder_map(lmono_ctx *, lmono_map_builder *, lmono_point_rgb *out_h, int64_t cap);   /* rgb_map; returns its size */
+int lmono_map_builder_clear(lmono_ctx *, lmono_map_builder *);                         /* rgb_map->clear()                    */
+
 /* ---- pose composition (laserOdometry: t_w_curr += q_w_curr * t_last_curr; q_w_curr *= q_last_curr) ------- *
  * lmono_pose_prefix_d: poses_d[k - first] = incr[first] (+) ... (+) incr[k] for k in [first, n) (incr[0] is the
  * identity: first = 0 gives poses relative to scan 0, first > 0 poses relative to scan first-1).  lmono_pose_rebase_d: poses[k] <- bases[0] (+) ... (+) bases[n_bases-1] (+) poses[k]; with scans

@@ -12,7 +12,9 @@ SYMBOLS = [
     "lmono_create", "lmono_destroy", "lmono_last_error", "lmono_set_stream", "lmono_synchronize", "lmono_version",
     "lmono_batch_create", "lmono_batch_destroy", "lmono_scanreg_batch", "lmono_scanreg_batch_h", "lmono_batch_counts", "lmono_batch_get_cloud",
     "lmono_batch_get_curvature", "lmono_odom_batch", "lmono_odom_batch_d", "lmono_odom_correspond", "lmono_timing_reset", "lmono_timing_read",
-    "lmono_pose_prefix_d", "lmono_pose_rebase_d", "lmono_map_refine", "lmono_voxel_filter", "lmono_mapper_create", "lmono_mapper_destroy", "lmono_mapper_reset", "lmono_mapper_process", "lmono_mapper_process_batch", "lmono_mapper_cube", "lmono_factor_eval", "lmono_factor_eval_d",
+    "lmono_pose_prefix_d", "lmono_pose_rebase_d", "lmono_map_refine", "lmono_voxel_filter", "lmono_mapper_create", "lmono_mapper_destroy", "lmono_mapper_reset", "lmono_mapper_process", "lmono_mapper_process_batch", "lmono_mapper_cube",
+    "lmono_map_builder_create", "lmono_map_builder_destroy", "lmono_associate_to_map", "lmono_associate_to_map_batch", "lmono_map_builder_depth",
+    "lmono_map_builder_cloud", "lmono_map_builder_map", "lmono_map_builder_clear", "lmono_factor_eval", "lmono_factor_eval_d",
     "lmono_triangulate", "lmono_outlier_scores", "lmono_shift_depth", "lmono_marginalize", "lmono_marg_evaluate", "lmono_ba_batch_create", "lmono_ba_batch_destroy", "lmono_ba_solve", "lmono_ba_batch_reset", "lmono_ba_batch_read",
 ]
 
@@ -90,6 +92,9 @@ class Context:
         if rc < 0:
             raise LmonoError("lmono error %d: %s" % (rc, self.L.lmono_last_error(self.h).decode()))
         return rc
+
+    def last_error(self):
+        return self.L.lmono_last_error(self.h).decode()
 
     def set_stream(self, raw_stream):
         self.check(self.L.lmono_set_stream(self.h, C.c_void_p(raw_stream)))
@@ -432,3 +437,105 @@ class Mapper:
         except Exception:
             pass
 
+
+
+class Camera(C.Structure):
+    """lmono_camera: PINHOLE intrinsics of the cam yaml + kernel_size / kernel_type / blur_type of the map config."""
+    _fields_ = [("width", C.c_int), ("height", C.c_int),
+                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("k1", C.c_double), ("k2", C.c_double), ("p1", C.c_double), ("p2", C.c_double),
+                ("kernel_size", C.c_int), ("kernel_type", C.c_int), ("blur_type", C.c_int)]
+
+
+POINT_RGB = np.dtype([("x", np.float32), ("y", np.float32), ("z", np.float32), ("bgra", np.uint32)])
+
+
+def lidar_to_camera(rlc, tlc):
+    """The 4 x 4 of map_build_node.cc:216-220: [rlc^T | -rlc^T tlc]."""
+    rlc = np.asarray(rlc, np.float64).reshape(3, 3); tlc = np.asarray(tlc, np.float64).reshape(3)
+    M = np.eye(4)
+    M[:3, :3] = rlc.T
+    M[:3, 3] = (-1.0 * rlc.T) @ tlc
+    return M
+
+
+class MapBuilder:
+    """MapBuilder::associateToMap / depthFill / rgb_map accumulation on the device (lmono_map_builder_*)."""
+
+    def __init__(self, ctx, camera, max_cloud_points=1 << 18, map_capacity_points=None):
+        self.ctx = ctx
+        self.cam = camera
+        L = ctx.L
+        L.lmono_map_builder_create.restype = C.c_void_p
+        L.lmono_map_builder_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64]
+        L.lmono_map_builder_destroy.argtypes = [C.c_void_p]
+        L.lmono_associate_to_map.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 5
+        L.lmono_associate_to_map_batch.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8
+        L.lmono_map_builder_depth.argtypes = [C.c_void_p] * 3
+        L.lmono_map_builder_cloud.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.lmono_map_builder_map.restype = C.c_int64
+        L.lmono_map_builder_map.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+        L.lmono_map_builder_clear.argtypes = [C.c_void_p, C.c_void_p]
+        if map_capacity_points is None:
+            map_capacity_points = 10 * camera.width * camera.height      # processMapping flushes every 10 frames
+        self.h = L.lmono_map_builder_create(ctx.h, C.byref(camera), int(max_cloud_points), int(map_capacity_points))
+        if not self.h:
+            raise LmonoError("lmono_map_builder_create failed: " + ctx.last_error())
+
+    def associate(self, xyzi, transform, bgr, q_wc, t_wc):
+        """One associateToMap on host buffers; returns the size of the coloured cloud."""
+        xyzi = np.ascontiguousarray(xyzi, np.float32).reshape(-1, 4); M = np.ascontiguousarray(transform, np.float64).reshape(16)
+        bgr = np.ascontiguousarray(bgr, np.uint8)
+        if bgr.shape != (self.cam.height, self.cam.width, 3):
+            raise LmonoError("image must be [height][width][3] uint8")
+        q = np.ascontiguousarray(q_wc, np.float64).reshape(4); t = np.ascontiguousarray(t_wc, np.float64).reshape(3)
+        n = C.c_int(0)
+        self.ctx.check(self.ctx.L.lmono_associate_to_map(self.ctx.h, self.h, xyzi.ctypes.data, len(xyzi), M.ctypes.data, bgr.ctypes.data,
+                                                         q.ctypes.data, t.ctypes.data, C.addressof(n)))
+        return n.value
+
+    @staticmethod
+    def associate_batch(ctx, builders, xyzi_ptrs, n_points, transforms, bgr_ptrs, q_wc, t_wc):
+        """One frame of several independent builders; xyzi_ptrs / bgr_ptrs are device pointers (ints).  Returns sizes [n]."""
+        n = len(builders)
+        mh = (C.c_void_p * n)(*[b.h for b in builders])
+        xp = (C.c_void_p * n)(*[int(p) for p in xyzi_ptrs]); bp = (C.c_void_p * n)(*[int(p) for p in bgr_ptrs])
+        npt = np.ascontiguousarray(n_points, np.int32)
+        M = np.ascontiguousarray(transforms, np.float64).reshape(n, 16)
+        q = np.ascontiguousarray(q_wc, np.float64).reshape(n, 4); t = np.ascontiguousarray(t_wc, np.float64).reshape(n, 3)
+        out = np.zeros(n, np.int32)
+        ctx.check(ctx.L.lmono_associate_to_map_batch(ctx.h, n, mh, xp, npt.ctypes.data, M.ctypes.data, bp, q.ctypes.data, t.ctypes.data, out.ctypes.data))
+        return out
+
+    def depth(self):
+        d = np.zeros((self.cam.height, self.cam.width), np.uint8)
+        self.ctx.check(self.ctx.L.lmono_map_builder_depth(self.ctx.h, self.h, d.ctypes.data))
+        return d
+
+    def cloud(self, which=0):
+        n = self.ctx.L.lmono_map_builder_cloud(self.ctx.h, self.h, which, None, 0)
+        self.ctx.check(min(n, 0))
+        out = np.zeros(max(n, 1), POINT_RGB)
+        self.ctx.check(min(self.ctx.L.lmono_map_builder_cloud(self.ctx.h, self.h, which, out.ctypes.data, n), 0))
+        return out[:n]
+
+    def map(self):
+        n = self.ctx.L.lmono_map_builder_map(self.ctx.h, self.h, None, 0)
+        self.ctx.check(min(n, 0))
+        out = np.zeros(max(n, 1), POINT_RGB)
+        self.ctx.check(min(self.ctx.L.lmono_map_builder_map(self.ctx.h, self.h, out.ctypes.data, n), 0))
+        return out[:n]
+
+    def clear(self):
+        self.ctx.check(self.ctx.L.lmono_map_builder_clear(self.ctx.h, self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.L.lmono_map_builder_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1469,3 +1469,4 @@ extern "C" int lmono_mapper_cube(lmono_ctx *c, lmono_mapper *m, int which, int i
     return s.n;
 }
 
+#include "colour_abi.hip"

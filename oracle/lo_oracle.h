@@ -113,6 +113,35 @@ int lo_run_mapping(const float *xyzi, const int64_t *offsets, int n_scans, int n
 void lo_sym_eig3(const double A[9], double evals[3], double evecs[9] /* columns = eigenvectors */);
 int lo_plane_fit5(const double pts[15], double norm[3], double *negative_OA_dot_norm);
 
+/* ---- colour projection (MapBuilder::associateToMap + depthFill, mono_lidar_mapping/src/map_builder/Map_Builder.cc:213-403;
+ * SURVEY row 8f-3).  The morphology / median / bilateral / Gaussian stages restate the documented OpenCV definitions
+ * (OpenCV is an un-vendored dependency of the reference and absent here: those stages are UNPINNED). ---- */
+typedef struct {
+    int width, height;
+    double fx, fy, cx, cy, k1, k2, p1, p2;   /* camodocal PINHOLE parameters (config/kitti00_cam.yaml)              */
+    int kernel_size;                         /* KERNEL_SIZE (odd)                                                  */
+    int kernel_type;                         /* KERNEL_TYPE: 0 FULL (rect), 1 CROSS, 2 anything else (ellipse)      */
+    int blur_type;                           /* BLUR_TYPE: 0 bilateral, 1 anything else (Gaussian)                  */
+} lo_cam;
+typedef struct { float x, y, z; uint32_t bgra; } lo_pt_rgb;   /* pcl::PointXYZRGB payload: b | g << 8 | r << 16 | a << 24 */
+
+void lo_structuring_element(int type, int k, uint8_t *mask /* k x k */);
+/* op 0 dilate, 1 erode (cv::dilate / cv::erode with the default border: outside pixels do not take part) */
+void lo_morph(const uint8_t *src, uint8_t *dst, int w, int h, const uint8_t *mask, int k, int op);
+void lo_median5(const uint8_t *src, uint8_t *dst, int w, int h);                 /* cv::medianBlur(.., 5)               */
+void lo_bilateral5(const uint8_t *src, uint8_t *dst, int w, int h, double sigma_color, double sigma_space); /* d = 5     */
+void lo_gauss5(const uint8_t *src, uint8_t *dst, int w, int h);                  /* cv::GaussianBlur(.., (5,5), 0)      */
+void lo_depth_fill(const lo_cam *, uint8_t *depth /* in/out */);
+/* transform (row-major 4x4, pcl::transformPointCloud) + projection + 8-bit depth splat; depth must be zeroed by the caller */
+void lo_depth_splat(const lo_cam *, const float *xyzi, int n, const double M[16], uint8_t *depth);
+int lo_backproject(const lo_cam *, const uint8_t *depth, const uint8_t *bgr, lo_pt_rgb *out);
+void lo_transform_rgb(const lo_pt_rgb *in, int n, const double q[4] /* xyzw */, const double t[3], lo_pt_rgb *out);
+/* whole associateToMap: depth_out (w*h, optional) = the filled depth map, cam_out / world_out capacity w*h; returns the cloud size */
+int lo_associate_to_map(const lo_cam *, const float *xyzi, int n, const double M[16], const uint8_t *bgr,
+                        const double q[4], const double t[3], uint8_t *depth_out, lo_pt_rgb *cam_out, lo_pt_rgb *world_out);
+void lo_lift_projective(const lo_cam *, double u, double v, double ray[3]);
+int lo_space_to_plane(const lo_cam *, const double P[3], double p[2]);
+
 #ifdef __cplusplus
 }
 #endif

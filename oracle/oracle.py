@@ -420,3 +420,99 @@ def marg_evaluate(lin_J, lin_r, x0, x, want_jac=True):
     lib().lo_marg_evaluate(_fp(lin_J, C.c_double), _fp(lin_r, C.c_double), _fp(x0, C.c_double), _fp(x, C.c_double), _fp(res, C.c_double),
                            _fp(jac, C.c_double) if want_jac else None)
     return res, jac
+
+
+# ---- colour projection (MapBuilder::associateToMap / depthFill; lo_colour.c) ----
+class Cam(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int),
+                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("k1", C.c_double), ("k2", C.c_double), ("p1", C.c_double), ("p2", C.c_double),
+                ("kernel_size", C.c_int), ("kernel_type", C.c_int), ("blur_type", C.c_int)]
+
+
+PT_RGB = np.dtype([("x", np.float32), ("y", np.float32), ("z", np.float32), ("bgra", np.uint32)])
+
+
+def kitti00_cam(width=1241, height=376, kernel_size=5, kernel_type=0, blur_type=0, dist=(0.0, 0.0, 0.0, 0.0)):
+    """config/kitti00_cam.yaml + config/kitti_map_config_00.yaml (FULL kernel, bilateral blur, kernel_size 5)."""
+    return Cam(width, height, 718.856, 718.856, 607.1928, 185.2157, dist[0], dist[1], dist[2], dist[3], kernel_size, kernel_type, blur_type)
+
+
+def structuring_element(kind, k):
+    m = np.zeros((k, k), np.uint8)
+    lib().lo_structuring_element(C.c_int(kind), C.c_int(k), _fp(m, C.c_uint8))
+    return m
+
+
+def morph(img, mask, op):
+    img = np.ascontiguousarray(img, np.uint8); mask = np.ascontiguousarray(mask, np.uint8)
+    out = np.empty_like(img)
+    lib().lo_morph(_fp(img, C.c_uint8), _fp(out, C.c_uint8), C.c_int(img.shape[1]), C.c_int(img.shape[0]), _fp(mask, C.c_uint8),
+                   C.c_int(mask.shape[0]), C.c_int(op))
+    return out
+
+
+def _img_op(name, img, *extra):
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.empty_like(img)
+    getattr(lib(), name)(_fp(img, C.c_uint8), _fp(out, C.c_uint8), C.c_int(img.shape[1]), C.c_int(img.shape[0]), *extra)
+    return out
+
+
+def median5(img):
+    return _img_op("lo_median5", img)
+
+
+def bilateral5(img, sigma_color=1.5, sigma_space=2.0):
+    return _img_op("lo_bilateral5", img, C.c_double(sigma_color), C.c_double(sigma_space))
+
+
+def gauss5(img):
+    return _img_op("lo_gauss5", img)
+
+
+def depth_fill(cam, depth):
+    d = np.array(depth, np.uint8, copy=True, order="C")
+    assert d.shape == (cam.height, cam.width)
+    lib().lo_depth_fill(C.byref(cam), _fp(d, C.c_uint8))
+    return d
+
+
+def depth_splat(cam, xyzi, M):
+    xyzi = np.ascontiguousarray(xyzi, np.float32).reshape(-1, 4); M = np.ascontiguousarray(M, np.float64).reshape(16)
+    d = np.zeros((cam.height, cam.width), np.uint8)
+    lib().lo_depth_splat(C.byref(cam), _fp(xyzi, C.c_float), C.c_int(len(xyzi)), _fp(M, C.c_double), _fp(d, C.c_uint8))
+    return d
+
+
+def backproject(cam, depth, bgr):
+    depth = np.ascontiguousarray(depth, np.uint8); bgr = np.ascontiguousarray(bgr, np.uint8)
+    out = np.zeros(cam.width * cam.height, PT_RGB)
+    lib().lo_backproject.restype = C.c_int
+    n = lib().lo_backproject(C.byref(cam), _fp(depth, C.c_uint8), _fp(bgr, C.c_uint8), out.ctypes.data_as(C.c_void_p))
+    return out[:n].copy()
+
+
+def associate_to_map(cam, xyzi, M, bgr, q, t):
+    """-> (filled depth map [h, w] u8, camera-frame cloud, world-frame cloud) of one associateToMap call."""
+    xyzi = np.ascontiguousarray(xyzi, np.float32).reshape(-1, 4); M = np.ascontiguousarray(M, np.float64).reshape(16)
+    bgr = np.ascontiguousarray(bgr, np.uint8); q = np.ascontiguousarray(q, np.float64); t = np.ascontiguousarray(t, np.float64)
+    assert bgr.shape == (cam.height, cam.width, 3)
+    d = np.zeros((cam.height, cam.width), np.uint8)
+    a = np.zeros(cam.width * cam.height, PT_RGB); b = np.zeros(cam.width * cam.height, PT_RGB)
+    lib().lo_associate_to_map.restype = C.c_int
+    n = lib().lo_associate_to_map(C.byref(cam), _fp(xyzi, C.c_float), C.c_int(len(xyzi)), _fp(M, C.c_double), _fp(bgr, C.c_uint8),
+                                  _fp(q, C.c_double), _fp(t, C.c_double), _fp(d, C.c_uint8), a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p))
+    return d, a[:n].copy(), b[:n].copy()
+
+
+def lift_projective(cam, u, v):
+    r = np.zeros(3)
+    lib().lo_lift_projective(C.byref(cam), C.c_double(u), C.c_double(v), _fp(r, C.c_double))
+    return r
+
+
+def space_to_plane(cam, P):
+    P = np.ascontiguousarray(P, np.float64); p = np.zeros(2)
+    lib().lo_space_to_plane(C.byref(cam), _fp(P, C.c_double), _fp(p, C.c_double))
+    return p
