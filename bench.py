@@ -128,6 +128,87 @@ def bench_map(args):
     print(json.dumps(out), flush=True)
 
 
+def bench_colour(args):
+    """Workload of SURVEY config 5 / row 8f-3: colour projection (MapBuilder::associateToMap + depthFill + rgb_map
+    accumulation) of S3 scans (32 rings x 1800 azimuth steps) into 1241 x 376 noise images, `--streams` independent map
+    builders advanced in lock-step.  One step = `--frames` frames per stream; rgb_map is cleared every 10 frames as
+    processMapping does.  Scans and images are resident in HBM before the timed region."""
+    import torch
+    import lmono_amd
+    from workloads import s1 as S1
+    assert torch.cuda.is_available()
+    W, H = 1241, 376
+    n_distinct = 16
+    w = S1.S1World(n_rings=32, n_az=1800)
+    traj = w.trajectory(n_distinct)
+    x, off = w.scans(traj)
+    rng = np.random.default_rng(5)
+    imgs = [rng.integers(0, 256, (H, W, 3), dtype=np.uint8) for _ in range(n_distinct)]
+    ctx = lmono_amd.Context(0)
+    cam = lmono_amd.Camera(W, H, 718.856, 718.856, 607.1928, 185.2157, 0, 0, 0, 0, 5, 0, 0)    # kitti00_cam.yaml + kitti_map_config_00.yaml
+    M = lmono_amd.lidar_to_camera([[0, 0, 1], [-1, 0, 0], [0, -1, 0]], [0.27, 0.0, -0.08])
+    B = max(1, args.streams)
+    F = max(1, args.frames)
+    mbs = [lmono_amd.MapBuilder(ctx, cam, max_cloud_points=16) for _ in range(B)]
+    dx = [torch.from_numpy(x[off[k]:off[k + 1]]).cuda() for k in range(n_distinct)]
+    di = [torch.from_numpy(im).cuda() for im in imgs]
+    npts = [int(off[k + 1] - off[k]) for k in range(n_distinct)]
+    yaw = traj[:, 3]
+    qs = np.stack([np.zeros(n_distinct), -np.sin(yaw / 2), np.zeros(n_distinct), np.cos(yaw / 2)], 1)     # camera y axis points down
+    ts = np.stack([-traj[:, 1], np.zeros(n_distinct), traj[:, 0]], 1)
+    sizes = np.zeros(n_distinct, np.int64)
+
+    def run():
+        for f in range(F):
+            if f % 10 == 0:
+                for m in mbs:
+                    m.clear()
+            ks = [(s + f) % n_distinct for s in range(B)]
+            n = lmono_amd.MapBuilder.associate_batch(ctx, mbs, [dx[k].data_ptr() for k in ks], [npts[k] for k in ks], [M] * B,
+                                                     [di[k].data_ptr() for k in ks], qs[ks], ts[ks])
+            for s, k in enumerate(ks):
+                sizes[k] = n[s]
+    for _ in range(args.warmup):
+        run()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    ctx.synchronize()
+    el = time.perf_counter() - t0
+    frames = B * F * args.steps
+    # algorithmic bytes of one frame: scan in (16 B / point), image in (3 B / pixel), depth map out (1 B / pixel), camera-frame
+    # and world-frame coloured clouds out (16 B / point each)
+    ks_all = [(s + f) % n_distinct for f in range(F) for s in range(B)]
+    alg = float(np.mean([16 * npts[k] + 4 * W * H + 32 * sizes[k] for k in ks_all]))
+    # ---- cpu_baseline leg: the only place the oracle is touched
+    from oracle import oracle as O
+    oc = O.kitti00_cam()
+    t1 = time.perf_counter()
+    n_cpu = 0
+    while n_cpu < n_distinct and (n_cpu < 4 or time.perf_counter() - t1 < 10.0):
+        k = n_cpu
+        d, a, b = O.associate_to_map(oc, x[off[k]:off[k + 1]], M, imgs[k], qs[k], ts[k])
+        assert len(a) == sizes[k] or sizes[k] == 0, (k, len(a), sizes[k])
+        n_cpu += 1
+    cpu_s = time.perf_counter() - t1
+    same = bool((mbs[0].depth() == O.associate_to_map(oc, x[off[(F - 1) % n_distinct]:off[(F - 1) % n_distinct + 1]], M, imgs[(F - 1) % n_distinct],
+                                                      qs[(F - 1) % n_distinct], ts[(F - 1) % n_distinct])[0]).all())
+    out = {"metric": "colour-projection frames/sec (associateToMap + depthFill + rgb_map accumulation, independent streams in lock-step)",
+           "value": round(frames / el, 1), "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "u8 image ops / f64 projection", "data": "synthetic",
+           "config": {"workload": "S3 VLP-32-shaped scans (32 x 1800) into 1241 x 376 RGB noise images, colour projection (SURVEY 8f-3, config 5)",
+                      "streams": B, "frames_per_step": F, "mean_points_in": round(float(np.mean(npts)), 1), "mean_points_out": round(float(np.mean(sizes[sizes > 0])), 1)},
+           "roofline": {"bound": "hbm", "kernel": "frame chain: k_colour_splat, k_depth_fill<5>, k_colour_count, k_colour_lift (wall clock incl. the host round trip per batch)",
+                        "achieved": round(alg * frames / el / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg * frames / el / 1e9 / HBM_PEAK_GBS, 4),
+                        "traffic": None, "algorithmic_bytes_per_frame": round(alg, 1)},
+           "cpu_baseline": {"value": round(n_cpu / cpu_s, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+                            "sample": "%d of the same frames, oracle/lo_colour.c (-O3), 1 thread" % n_cpu},
+           "depth_map_equals_cpu": same}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,16 +219,19 @@ def main():
     ap.add_argument("--lead", type=int, default=5, help="lead-in scans of a chain that does not start at scan 0")
     ap.add_argument("--az", type=int, default=2000, help="azimuth steps per ring (2000 = HDL-64 at 10 Hz)")
     ap.add_argument("--cpu-sample", type=int, default=384, help="scans of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--workload", default="lidar", choices=["lidar", "ba", "map"],
+    ap.add_argument("--workload", default="lidar", choices=["lidar", "ba", "map", "colour"],
                     help="lidar = headline (BASELINE configs[1]); ba = configs[2]-shaped sliding-window BA solves (secondary); "
                          "map = laserMapping over a synthetic sequence, one stream (SURVEY 8f-1)")
     ap.add_argument("--windows", type=int, default=1024, help="ba: independent windows per GPU")
-    ap.add_argument("--streams", type=int, default=64, help="map: independent mapping streams advanced in lock-step")
+    ap.add_argument("--streams", type=int, default=64, help="map / colour: independent streams advanced in lock-step")
+    ap.add_argument("--frames", type=int, default=20, help="colour: frames per stream and step")
     args = ap.parse_args()
     if args.workload == "ba":
         return bench_ba(args)
     if args.workload == "map":
         return bench_map(args)
+    if args.workload == "colour":
+        return bench_colour(args)
 
     import torch
     import torch.distributed as dist

@@ -1,6 +1,8 @@
 // lmono_amd/host/io_test.cpp -- file-format round trip driver (tests/test_kitti_io.py): reads a KITTI-layout sequence
 // directory, echoes what it found, and writes the trajectory / timing files in the reference's formats.
-//   io_test <sequence_dir> <poses_file> <out_dir>
+//   io_test <sequence_dir> <poses_file> <out_dir> [points.bin]
+// With points.bin ([n] records x y z float32 + bgra uint32) it also writes <out_dir>/rgb_map10.ply (the colour map format
+// of MapBuilder::processMapping), reads it back and writes <out_dir>/mapping_recorder.txt.
 #include "kitti_io.hpp"
 
 #include <cmath>
@@ -34,6 +36,21 @@ int main(int argc, char **argv)
             loam_odometry.write(stamps[k], p, q);
             times.write(stamps[k], 0.001 * (double)k, 0.002, 0.5 + (double)k);
         }
+    }
+    if (argc > 4) {
+        FILE *f = std::fopen(argv[4], "rb");
+        if (!f) return 1;
+        std::vector<PointRgb> pts, back;
+        PointRgb p;
+        while (std::fread(&p, sizeof p, 1, f) == 1) pts.push_back(p);
+        std::fclose(f);
+        const std::string ply = rgb_map_path(out, 10);
+        if (!write_ply_binary(ply, pts.data(), pts.size()) || !read_ply_binary(ply, back) || back.size() != pts.size()) return 1;
+        size_t same = 0;
+        for (size_t i = 0; i < pts.size(); i++) same += back[i].x == pts[i].x && back[i].y == pts[i].y && back[i].z == pts[i].z && (back[i].bgra & 0xffffffu) == (pts[i].bgra & 0xffffffu);
+        std::printf("PLY %zu %zu\n", pts.size(), same);
+        MappingLog rec(out + "/mapping_recorder.txt");
+        rec.write(1.5, 2.25); rec.write(2.5, 0.125);
     }
     // a file that is not a whole number of 16-byte records is rejected
     std::vector<float> bad;

@@ -1,5 +1,6 @@
 // lmono_amd/host/lmono_host.cpp -- see lmono_host.hpp.  Window / track bookkeeping on the host, numerics in the HIP library.
 #include "lmono_host.hpp"
+#include "kitti_io.hpp"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -328,6 +329,68 @@ std::vector<float> LaserMapping::cube(int which, int i, int j, int k)
     if (n > 0) hip_.check(lmono_mapper_cube(hip_.get(), mapper_, which, i, j, k, out.data(), n) < 0 ? -1 : 0, "lmono_mapper_cube");
     out.resize((size_t)n * 4);
     return out;
+}
+
+// ---- map builder (colour projection) -----------------------------------------------------------------------------------
+MapBuilder::MapBuilder(HipContext &hip, const lmono_camera &camera, bool save_map, const std::string &map_dir, int max_cloud_points)
+    : hip_(hip), mb_(lmono_map_builder_create(hip.get(), &camera, max_cloud_points, (int64_t)10 * camera.width * camera.height)), cam_(camera),
+      save_map_(save_map), map_dir_(map_dir)
+{
+    if (!mb_) throw std::runtime_error(std::string("lmono_map_builder_create: ") + lmono_last_error(hip.get()));
+}
+MapBuilder::~MapBuilder() { lmono_map_builder_destroy(mb_); }
+int MapBuilder::associateToMap(const double Q[4], const double T[3], const float *xyzi, int n_points, const double rlc[9], const double tlc[3],
+                               const uint8_t *frame, double)
+{
+    // map_build_node.cc:216-220: transformation = [rlc^T | (-1) * rlc^T * tlc]
+    double M[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1 };
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) M[4 * i + j] = rlc[3 * j + i];
+        M[4 * i + 3] = (-1.0 * rlc[i]) * tlc[0] + (-1.0 * rlc[3 + i]) * tlc[1] + (-1.0 * rlc[6 + i]) * tlc[2];
+    }
+    int n = 0;
+    hip_.check(lmono_associate_to_map(hip_.get(), mb_, xyzi, n_points, M, frame, Q, T, &n), "lmono_associate_to_map");
+    pending_ = true;
+    return n;
+}
+std::string MapBuilder::processMapping()
+{
+    std::string written;
+    if (!pending_) return written;
+    pending_ = false;
+    map_index++;                                                        // Map_Builder.cc:64
+    if (map_index > 0 && map_index % 10 == 0) {                         // :72
+        if (save_map_) {
+            const std::vector<lmono_point_rgb> m = rgbMap();
+            written = rgb_map_path(map_dir_, map_index);
+            static_assert(sizeof(PointRgb) == sizeof(lmono_point_rgb), "point layout");
+            if (!write_ply_binary(written, reinterpret_cast<const PointRgb *>(m.data()), m.size())) throw std::runtime_error("cannot write " + written);
+        }
+        hip_.check(lmono_map_builder_clear(hip_.get(), mb_), "lmono_map_builder_clear");   // :81
+    }
+    return written;
+}
+std::vector<lmono_point_rgb> MapBuilder::rgbCloud(int which)
+{
+    const int n = lmono_map_builder_cloud(hip_.get(), mb_, which, nullptr, 0);
+    hip_.check(n < 0 ? n : 0, "lmono_map_builder_cloud");
+    std::vector<lmono_point_rgb> out((size_t)n);
+    if (n > 0) hip_.check(lmono_map_builder_cloud(hip_.get(), mb_, which, out.data(), n) < 0 ? -1 : 0, "lmono_map_builder_cloud");
+    return out;
+}
+std::vector<lmono_point_rgb> MapBuilder::rgbMap()
+{
+    const int64_t n = lmono_map_builder_map(hip_.get(), mb_, nullptr, 0);
+    hip_.check(n < 0 ? (int)n : 0, "lmono_map_builder_map");
+    std::vector<lmono_point_rgb> out((size_t)n);
+    if (n > 0) hip_.check(lmono_map_builder_map(hip_.get(), mb_, out.data(), n) < 0 ? -1 : 0, "lmono_map_builder_map");
+    return out;
+}
+std::vector<uint8_t> MapBuilder::depthMap()
+{
+    std::vector<uint8_t> d((size_t)cam_.width * cam_.height);
+    hip_.check(lmono_map_builder_depth(hip_.get(), mb_, d.data()), "lmono_map_builder_depth");
+    return d;
 }
 
 } // namespace lmono_host

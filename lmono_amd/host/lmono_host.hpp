@@ -161,4 +161,34 @@ private:
     lmono_mapper *mapper_;
 };
 
+// MapBuilder (include/map_builder/Map_Builder.h, src/map_builder/Map_Builder.cc): colour projection of a
+// LiDAR scan into the camera image and accumulation of the coloured world-frame map, on the device behind lmono_map_builder_*.
+class MapBuilder {
+public:
+    // camera: PINHOLE intrinsics + kernel_size / kernel_type / blur_type of the map config; save_map / map_dir: SAVE_MAP and the
+    // directory of "rgb_map<index>.ply" (hard-coded "/home/bo/raw_data/map" in the reference, Map_Builder.cc:75)
+    MapBuilder(HipContext &hip, const lmono_camera &camera, bool save_map = false, const std::string &map_dir = ".", int max_cloud_points = 1 << 18);
+    ~MapBuilder();
+    MapBuilder(const MapBuilder &) = delete;
+    MapBuilder &operator=(const MapBuilder &) = delete;
+    // Map_Builder.cc:213 with the cloud transform of map_build_node.cc:216-225 folded in: Q (x y z w), T = camera pose,
+    // xyzi = the scan in the LiDAR frame, rlc / tlc = camera-from-LiDAR extrinsic (p_l = rlc p_c + tlc), frame = BGR8 image,
+    // t = stamp.  Returns the size of the coloured cloud; the world-frame cloud is queued for processMapping().
+    int associateToMap(const double Q[4], const double T[3], const float *xyzi, int n_points, const double rlc[9], const double tlc[3],
+                       const uint8_t *frame, double t);
+    // one pass of the body of MapBuilder::processMapping (Map_Builder.cc:12-86) for the frame queued last: rgb_map += cloud,
+    // map_index++, and every 10th frame the map is written (when save_map) and cleared.  Returns the path written, or "".
+    std::string processMapping();
+    std::vector<lmono_point_rgb> rgbCloud(int which);        // last frame: 0 camera frame (topic rgb_points), 1 world frame
+    std::vector<lmono_point_rgb> rgbMap();                   // rgb_map
+    std::vector<uint8_t> depthMap();                         // filled depth map of the last frame (topic depth_map before COLORMAP_JET)
+    int map_index = 0;
+private:
+    HipContext &hip_;
+    lmono_map_builder *mb_;
+    lmono_camera cam_;
+    bool save_map_, pending_ = false;
+    std::string map_dir_;
+};
+
 } // namespace lmono_host

@@ -67,3 +67,54 @@ def read_trajectory(path):
 
 def format_timing_line(stamp, track_time, laser_decode_time, pred_time):
     return "%f %f %f %f\n" % (stamp, track_time, laser_decode_time, pred_time)
+
+
+POINT_RGB = np.dtype([("x", np.float32), ("y", np.float32), ("z", np.float32), ("bgra", np.uint32)])
+_PLY_CAMERA = ["view_px", "view_py", "view_pz", "x_axisx", "x_axisy", "x_axisz", "y_axisx", "y_axisy", "y_axisz",
+               "z_axisx", "z_axisy", "z_axisz", "focal", "scalex", "scaley", "centerx", "centery"]
+_PLY_VERTEX = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("red", "u1"), ("green", "u1"), ("blue", "u1")])
+
+
+def rgb_map_path(directory, map_index):
+    """Map_Builder.cc:75: "<dir>/rgb_map<index>.ply"."""
+    return os.path.join(directory, "rgb_map%d.ply" % map_index)
+
+
+def write_ply_binary(path, pts):
+    """pcl::io::savePLYFileBinary of an unorganised PointXYZRGB cloud (Map_Builder.cc:76): vertex x y z float + red green
+    blue uchar, then PCL's one-record camera element.  pts: POINT_RGB records (bgra = b | g << 8 | r << 16 | a << 24)."""
+    pts = np.ascontiguousarray(pts, POINT_RGB)
+    n = len(pts)
+    head = "ply\nformat binary_little_endian 1.0\ncomment PCL generated\nelement vertex %d\n" % n
+    head += "property float x\nproperty float y\nproperty float z\nproperty uchar red\nproperty uchar green\nproperty uchar blue\n"
+    head += "element camera 1\n" + "".join("property float %s\n" % p for p in _PLY_CAMERA)
+    head += "property int viewportx\nproperty int viewporty\nproperty float k1\nproperty float k2\nend_header\n"
+    v = np.zeros(n, _PLY_VERTEX)
+    v["x"], v["y"], v["z"] = pts["x"], pts["y"], pts["z"]
+    v["red"] = (pts["bgra"] >> 16) & 0xff; v["green"] = (pts["bgra"] >> 8) & 0xff; v["blue"] = pts["bgra"] & 0xff
+    with open(path, "wb") as f:
+        f.write(head.encode("ascii"))
+        f.write(v.tobytes())
+        f.write(np.array([0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 0, 0], "<f4").tobytes())
+        f.write(np.array([n, 1], "<i4").tobytes())
+        f.write(np.array([0, 0], "<f4").tobytes())
+
+
+def read_ply_binary(path):
+    with open(path, "rb") as f:
+        raw = f.read()
+    end = raw.index(b"end_header\n") + len(b"end_header\n")
+    head = raw[:end].decode("ascii").split("\n")
+    if "format binary_little_endian 1.0" not in head:
+        raise ValueError("not a binary little-endian PLY: " + path)
+    n = [int(l.split()[2]) for l in head if l.startswith("element vertex")][0]
+    v = np.frombuffer(raw, _PLY_VERTEX, n, end)
+    out = np.zeros(n, POINT_RGB)
+    out["x"], out["y"], out["z"] = v["x"], v["y"], v["z"]
+    out["bgra"] = v["blue"].astype(np.uint32) | v["green"].astype(np.uint32) << 8 | v["red"].astype(np.uint32) << 16 | 0xff000000
+    return out
+
+
+def format_mapping_line(stamp, toc_ms):
+    """map_build_node.cc:230: fprintf(mapping_recorder, "%f %f \\n", stamp, toc)."""
+    return "%f %f \n" % (stamp, toc_ms)

@@ -118,3 +118,47 @@ def test_accumulation_clear_batch_and_capacity(oracle, gpu_ctx):
         lmono_amd.MapBuilder(gpu_ctx, lmono_amd.Camera(320, 96, 100.0, 100.0, 160.0, 48.0, 0, 0, 0, 0, 4, 0, 0))    # even kernel
     for m in mbs + [mb]:
         m.close()
+
+
+def test_cpp_map_build_writes_the_colour_map(oracle, tmp_path):
+    """Host mirror MapBuilder (associateToMap + processMapping) over a sequence on disk through lmono_amd/host/map_build:
+    rgb_map10.ply holds the world clouds of frames 0..9 (then the map is cleared), the last frame's products match the oracle."""
+    import os
+    import subprocess
+    from lmono_amd import kitti_io as IO
+    host = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lmono_amd", "host")
+    subprocess.check_call(["make", "-s", "-C", host, "map_build"])
+    W, H = 320, 96
+    oc = oracle.kitti00_cam(W, H)
+    oc.fx = oc.fy = 185.0; oc.cx = 156.5; oc.cy = 47.25
+    seq = tmp_path / "seq"; out = tmp_path / "out"
+    os.makedirs(seq / "velodyne"); os.makedirs(seq / "image_bgr"); os.makedirs(out)
+    n = 11
+    M = CC.lidar_to_camera()
+    rng = np.random.default_rng(8)
+    stamps = 50.0 + 0.1 * np.arange(n)
+    qt = np.zeros((n, 7)); acc = []; ref_last = None
+    for k in range(n):
+        cloud = CC.s1_scan(n_rings=32, n_az=600, k=k)
+        bgr = CC.noise_image(H, W, seed=100 + k)
+        IO.write_velodyne_bin(IO.velodyne_path(str(seq), k), cloud)
+        (seq / "image_bgr" / ("%06d.bgr" % k)).write_bytes(bgr.tobytes())
+        # poses with exactly six decimals so that the text file carries them losslessly
+        q = np.round(np.array([0.01 * k, -0.02, np.sin(0.05 * k), np.cos(0.05 * k)]), 6); t = np.round(rng.normal(0, 5, 3), 6)
+        qt[k, :4] = q; qt[k, 4:] = t
+        ref = oracle.associate_to_map(oc, cloud, M, bgr, q, t)
+        if k < 10:
+            acc.append(ref[2])
+        ref_last = ref
+    IO.write_trajectory(str(tmp_path / "traj.txt"), stamps, qt)
+    txt = subprocess.check_output([os.path.join(host, "map_build"), str(seq), str(tmp_path / "traj.txt"), str(out), str(n), str(W), str(H),
+                                   repr(oc.fx), repr(oc.fy), repr(oc.cx), repr(oc.cy)], text=True).strip().split("\n")
+    assert len(txt) == n and txt[9].endswith("wrote " + IO.rgb_map_path(str(out), 10)) and "wrote" not in txt[10]
+    ply = IO.read_ply_binary(IO.rgb_map_path(str(out), 10))
+    want = np.concatenate(acc)
+    assert ply.tobytes() == want.tobytes()
+    d, a, b = ref_last
+    assert (np.frombuffer((out / "depth_last.u8").read_bytes(), np.uint8).reshape(H, W) == d).all()
+    assert (out / "cloud_cam_last.bin").read_bytes() == a.tobytes() and (out / "cloud_world_last.bin").read_bytes() == b.tobytes()
+    rec = (out / "mapping_recorder.txt").read_text().split("\n")
+    assert len(rec) == n + 1 and all(line.endswith(" ") and line.startswith("%f" % stamps[k]) for k, line in enumerate(rec[:n]))

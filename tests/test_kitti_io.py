@@ -71,3 +71,33 @@ def test_cpp_reader_and_writers_match_numpy(tmp_path):
     assert (out / "new_odometry.txt").read_text() == exp_new
     assert (out / "loam_odometry.txt").read_text() == exp_loam
     assert (out / "times_recorder.txt").read_text() == exp_t
+
+
+def test_ply_colour_map_format(tmp_path):
+    """rgb_map<index>.ply (MapBuilder::processMapping, Map_Builder.cc:72-77): the C++ and the Python writer emit the same
+    bytes, the PCL-style header is in place, and both readers return the points."""
+    subprocess.check_call(["make", "-s", "-C", HOST, "io_test"])
+    seq, poses_file, clouds, stamps, poses = _make_sequence(tmp_path)
+    rng = np.random.default_rng(2)
+    pts = np.zeros(1000, IO.POINT_RGB)
+    pts["x"], pts["y"], pts["z"] = rng.normal(0, 30, (3, 1000)).astype(np.float32)
+    pts["bgra"] = rng.integers(0, 1 << 24, 1000).astype(np.uint32) | 0xff000000
+    (tmp_path / "pts.bin").write_bytes(pts.tobytes())
+    out = tmp_path / "out2"
+    out.mkdir()
+    txt = subprocess.check_output([os.path.join(HOST, "io_test"), seq, poses_file, str(out), str(tmp_path / "pts.bin")], text=True)
+    assert "PLY 1000 1000" in txt
+    IO.write_ply_binary(str(tmp_path / "py.ply"), pts)
+    raw = (out / "rgb_map10.ply").read_bytes()
+    assert raw == (tmp_path / "py.ply").read_bytes()
+    assert IO.rgb_map_path(str(out), 10) == str(out / "rgb_map10.ply")
+    head = raw[:raw.index(b"end_header\n")].decode().split("\n")
+    assert head[:4] == ["ply", "format binary_little_endian 1.0", "comment PCL generated", "element vertex 1000"]
+    assert head[4:10] == ["property float x", "property float y", "property float z", "property uchar red", "property uchar green", "property uchar blue"]
+    assert head[10] == "element camera 1" and len(head) == 33 and head[-1] == ""
+    assert len(raw) == raw.index(b"end_header\n") + 11 + 1000 * 15 + 21 * 4
+    assert (IO.read_ply_binary(str(out / "rgb_map10.ply")) == pts).all()
+    assert (out / "mapping_recorder.txt").read_text() == IO.format_mapping_line(1.5, 2.25) + IO.format_mapping_line(2.5, 0.125)
+    empty = np.zeros(0, IO.POINT_RGB)
+    IO.write_ply_binary(str(tmp_path / "e.ply"), empty)
+    assert len(IO.read_ply_binary(str(tmp_path / "e.ply"))) == 0
