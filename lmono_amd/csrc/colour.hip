@@ -17,6 +17,7 @@
 // All of it is HBM / LDS bound byte work; nothing here is reshaped for the matrix cores.
 #pragma once
 #include "common.hpp"
+#include "median_net.hpp"
 
 namespace lmono {
 
@@ -32,6 +33,7 @@ struct ColourCam {
     double ik11, ik13, ik22, ik23;     // PinholeCamera.cc:292-295
     int distort;                       // PinholeCamera.cc:278-289
     int ksize, blur;
+    int mask_rect;                     // every element of mask set (KERNEL_TYPE FULL): the separable path applies
     unsigned char mask[kMaxMorphK * kMaxMorphK];
 };
 
@@ -139,18 +141,22 @@ __global__ __launch_bounds__(kColT) void k_depth_fill(const ColourJob *jobs, con
         sA[ry * P + rx] = (unsigned char)v;
     });
     __syncthreads();
-    // S1 = dilate(S0, KERNEL_TYPE element), :359-360
-    fill_region<P, RH, A, A>([&](int rx, int ry) {
-        int v = 0;
-        for (int i = 0; i < K; i++)
+    // S1 = dilate(S0, KERNEL_TYPE element), :359-360.  FULL is separable; the general element walks its mask.
+    if (j.cam.mask_rect) {
+        fill_rect<P, RH, 0, A, false>(sA, sC, sB, ox, oy, w, h, 0);
+    } else {
+        fill_region<P, RH, A, A>([&](int rx, int ry) {
+            int v = 0;
+            for (int i = 0; i < K; i++)
 #pragma unroll
-            for (int jj = 0; jj < K; jj++)
-                if (j.cam.mask[i * K + jj]) v = max(v, (int)sA[(ry + i - A) * P + rx + jj - A]);
-        const int gx = ox + rx, gy = oy + ry;
-        if (gx < 0 || gx >= w || gy < 0 || gy >= h) v = 0;
-        sB[ry * P + rx] = (unsigned char)v;
-    });
-    __syncthreads();
+                for (int jj = 0; jj < K; jj++)
+                    if (j.cam.mask[i * K + jj]) v = max(v, (int)sA[(ry + i - A) * P + rx + jj - A]);
+            const int gx = ox + rx, gy = oy + ry;
+            if (gx < 0 || gx >= w || gy < 0 || gy >= h) v = 0;
+            sB[ry * P + rx] = (unsigned char)v;
+        });
+        __syncthreads();
+    }
     fill_rect<P, RH, A, A, false>(sB, sC, sA, ox, oy, w, h, 255);        // :364 close = dilate ...
     fill_rect<P, RH, 2 * A, A, true>(sA, sC, sB, ox, oy, w, h, 0);       //      ... then erode: sB = hole_fill
     fill_rect<P, RH, 3 * A, 3, false>(sB, sC, sA, ox, oy, w, h, 0);      // :365 dilate 7 x 7
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(kColT) void k_depth_fill(const ColourJob *jobs, con
         if (s != 0) sA[ry * P + rx] = (unsigned char)s;
     });
     __syncthreads();
-    // median 5 x 5, BORDER_REPLICATE (:393): the smallest v with 13 or more window values <= v
+    // median 5 x 5, BORDER_REPLICATE (:393), by the min / max / med3 network of median_net.hpp
     fill_region<P, RH, 3 * A + 5, 3 * A + 5>([&](int rx, int ry) {
         const int gx = ox + rx, gy = oy + ry;
         if (gx < 0 || gx >= w || gy < 0 || gy >= h) return;
@@ -170,15 +176,7 @@ __global__ __launch_bounds__(kColT) void k_depth_fill(const ColourJob *jobs, con
 #pragma unroll
             for (int jj = 0; jj < 5; jj++) val[i * 5 + jj] = sA[yy * P + min(max(gx + jj - 2, 0), w - 1) - ox];
         }
-        int lo = 0, hi = 255;
-#pragma unroll
-        for (int it = 0; it < 8; it++) {
-            const int mid = (lo + hi) >> 1;
-            int c = 0;
-#pragma unroll
-            for (int k = 0; k < 25; k++) c += val[k] <= mid ? 1 : 0;
-            if (c >= 13) hi = mid; else lo = mid + 1;
-        }
+        const int lo = mednet::median25(val);
         sC[ry * P + rx] = (unsigned char)lo;
     });
     __syncthreads();
@@ -188,19 +186,32 @@ __global__ __launch_bounds__(kColT) void k_depth_fill(const ColourJob *jobs, con
         if (gx >= w || gy >= h) return;
         int out;
         if (j.cam.blur == 0) {
-            float sum = 0.f, wsum = 0.f;
-            const int val0 = sC[ry * P + rx];
+            // taps of the radius-2 disc in row-major order (the order cv::bilateralFilter accumulates in)
+            constexpr int kDi[13] = { -2, -1, -1, -1, 0, 0, 0, 0, 0, 1, 1, 1, 2 }, kDj[13] = { 0, -1, 0, 1, -2, -1, 0, 1, 2, -1, 0, 1, 0 };
+            int rowo[5], colo[5];
 #pragma unroll
-            for (int k = 0; k < 13; k++) {
-                int yy = gy + tab->di[k], xx = gx + tab->dj[k];
+            for (int d = 0; d < 5; d++) {
+                int yy = gy + d - 2, xx = gx + d - 2;
                 yy = yy < 0 ? -yy : yy; yy = yy >= h ? 2 * h - 2 - yy : yy;
                 xx = xx < 0 ? -xx : xx; xx = xx >= w ? 2 * w - 2 - xx : xx;
-                const int val = sC[(yy - oy) * P + xx - ox];
-                const float wt = tab->space[k] * s_cw[abs(val - val0)];
-                sum += (float)val * wt;
-                wsum += wt;
+                rowo[d] = (yy - oy) * P; colo[d] = xx - ox;
             }
-            out = (int)rintf(sum / wsum);
+            int val[13];
+            const int val0 = sC[ry * P + rx];
+            bool flat = true;
+#pragma unroll
+            for (int k = 0; k < 13; k++) { val[k] = sC[rowo[kDi[k] + 2] + colo[kDj[k] + 2]]; flat = flat && val[k] == val0; }
+            out = val0;                  // a constant window: sum / wsum = val0 up to float rounding, far inside cvRound's half
+            if (!flat) {
+                float sum = 0.f, wsum = 0.f;
+#pragma unroll
+                for (int k = 0; k < 13; k++) {
+                    const float wt = tab->space[k] * s_cw[abs(val[k] - val0)];
+                    sum += (float)val[k] * wt;
+                    wsum += wt;
+                }
+                out = (int)rintf(sum / wsum);
+            }
         } else {
             int s = 0;
 #pragma unroll

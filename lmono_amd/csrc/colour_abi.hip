@@ -71,6 +71,8 @@ extern "C" lmono_map_builder *lmono_map_builder_create(lmono_ctx *c, const lmono
             }
             for (int j = 0; j < K; j++) k.mask[i * K + j] = (j >= j1 && j < j2) ? 1 : 0;
         }
+        k.mask_rect = 1;
+        for (int i = 0; i < K * K; i++) if (!k.mask[i]) k.mask_rect = 0;
     }
     m->max_pts = max_cloud_points;
     m->map_cap = map_capacity_points;
