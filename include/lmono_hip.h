@@ -252,6 +252,32 @@ int lmono_map_builder_cloud(lmono_ctx *, lmono_map_builder *, int which, lmono_p
 int64_t lmono_map_builder_map(lmono_ctx *, lmono_map_builder *, lmono_point_rgb *out_h, int64_t cap);   /* rgb_map; returns its size */
 int lmono_map_builder_clear(lmono_ctx *, lmono_map_builder *);                         /* rgb_map->clear()                    */
 
+/* ---- loop-closure pose graph -- NEW FEATURE, no counterpart in the reference --------------------------
+ * The reference detects loops and publishes loop_info = relative_t, relative_q (w x y z), relative_yaw
+ * (mono_lidar_mapping/src/loop_detection/KeyFrame.cc:570-633) and re-anchors the window rigidly (Estimator.cc:309-365); it never
+ * optimises a graph and only carries the unused 4-DoF helpers of include/loop_detection/Loop_Detector.h:99-168.  This entry is
+ * the 4-DoF (yaw, x, y, z; degrees) keyframe graph those helpers belong to: odometry edges to the four previous keyframes,
+ * one Huber(0.1) edge per loop (yaw residual / 10), keyframe 0 fixed, Ceres-style Levenberg-Marquardt with a block-banded
+ * Cholesky in reverse Cuthill-McKee order.
+ * poses_tq_h: [n][7] keyframe poses t (x y z), q (x y z w); loops_h: [n_loops][2] (old keyframe, current keyframe);
+ * loop_info_h: [n_loops][8] in the layout above.
+ * Multi-GPU: every rank creates the same graph; per round each rank calls lmono_pose_graph_linearise(rank, world) -- the
+ * normal equations of the edges it owns --, the fp64 buffer lmono_pose_graph_reduce_buffer (reduce_count doubles) is summed
+ * over ranks with one all-reduce (RCCL), and lmono_pose_graph_step takes the identical trust-region step on every rank.   */
+typedef struct lmono_pose_graph lmono_pose_graph;
+lmono_pose_graph *lmono_pose_graph_create(lmono_ctx *, int n, const double *poses_tq_h, int n_loops, const int32_t *loops_h, const double *loop_info_h);
+void              lmono_pose_graph_destroy(lmono_pose_graph *);
+int   lmono_pose_graph_info(lmono_pose_graph *, int64_t *reduce_count, int *bandwidth_blocks, int *n_edges);
+void *lmono_pose_graph_reduce_buffer(lmono_pose_graph *);                         /* device pointer, reduce_count doubles */
+/* use a caller-owned device buffer of reduce_count doubles instead (e.g. the storage of the tensor handed to the all-reduce) */
+int   lmono_pose_graph_set_reduce_buffer(lmono_pose_graph *, void *buffer_d);
+int   lmono_pose_graph_linearise(lmono_ctx *, lmono_pose_graph *, int rank, int world);
+int   lmono_pose_graph_step(lmono_ctx *, lmono_pose_graph *, int max_iter, int *done);   /* done (optional) synchronises   */
+int   lmono_pose_graph_optimize(lmono_ctx *, lmono_pose_graph *, int max_iter);          /* one GPU: the loop of the two   */
+/* poses_tq_h: [n][7] optimised keyframes; stats (optional, [6]): LM iterations, initial cost, final cost, half bandwidth
+ * (blocks), accepted steps, rejected steps */
+int   lmono_pose_graph_result(lmono_ctx *, lmono_pose_graph *, double *poses_tq_h, double *stats);
+
 /* ---- pose composition (laserOdometry: t_w_curr += q_w_curr * t_last_curr; q_w_curr *= q_last_curr) ------- *
  * lmono_pose_prefix_d: poses_d[k - first] = incr[first] (+) ... (+) incr[k] for k in [first, n) (incr[0] is the
  * identity: first = 0 gives poses relative to scan 0, first > 0 poses relative to scan first-1).  lmono_pose_rebase_d: poses[k] <- bases[0] (+) ... (+) bases[n_bases-1] (+) poses[k]; with scans

@@ -14,7 +14,9 @@ SYMBOLS = [
     "lmono_batch_get_curvature", "lmono_odom_batch", "lmono_odom_batch_d", "lmono_odom_correspond", "lmono_timing_reset", "lmono_timing_read",
     "lmono_pose_prefix_d", "lmono_pose_rebase_d", "lmono_map_refine", "lmono_voxel_filter", "lmono_mapper_create", "lmono_mapper_destroy", "lmono_mapper_reset", "lmono_mapper_process", "lmono_mapper_process_batch", "lmono_mapper_cube",
     "lmono_map_builder_create", "lmono_map_builder_destroy", "lmono_associate_to_map", "lmono_associate_to_map_batch", "lmono_map_builder_depth",
-    "lmono_map_builder_cloud", "lmono_map_builder_map", "lmono_map_builder_clear", "lmono_factor_eval", "lmono_factor_eval_d",
+    "lmono_map_builder_cloud", "lmono_map_builder_map", "lmono_map_builder_clear",
+    "lmono_pose_graph_create", "lmono_pose_graph_destroy", "lmono_pose_graph_info", "lmono_pose_graph_reduce_buffer", "lmono_pose_graph_set_reduce_buffer", "lmono_pose_graph_linearise",
+    "lmono_pose_graph_step", "lmono_pose_graph_optimize", "lmono_pose_graph_result", "lmono_factor_eval", "lmono_factor_eval_d",
     "lmono_triangulate", "lmono_outlier_scores", "lmono_shift_depth", "lmono_marginalize", "lmono_marg_evaluate", "lmono_ba_batch_create", "lmono_ba_batch_destroy", "lmono_ba_solve", "lmono_ba_batch_reset", "lmono_ba_batch_read",
 ]
 
@@ -532,6 +534,75 @@ class MapBuilder:
     def close(self):
         if getattr(self, "h", None):
             self.ctx.L.lmono_map_builder_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PoseGraph:
+    """Loop-closure pose graph (lmono_pose_graph_*; a new feature): 4-DoF keyframe graph over odometry poses and
+    loop_info records.  optimize() on one GPU; linearise() / reduce_buffer / step() for the multi-GPU round (sharding.py)."""
+
+    def __init__(self, ctx, poses_tq, loops, loop_info):
+        self.ctx = ctx
+        L = ctx.L
+        L.lmono_pose_graph_create.restype = C.c_void_p
+        L.lmono_pose_graph_create.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.lmono_pose_graph_destroy.argtypes = [C.c_void_p]
+        L.lmono_pose_graph_info.argtypes = [C.c_void_p] * 4
+        L.lmono_pose_graph_reduce_buffer.restype = C.c_void_p
+        L.lmono_pose_graph_reduce_buffer.argtypes = [C.c_void_p]
+        L.lmono_pose_graph_linearise.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.lmono_pose_graph_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.lmono_pose_graph_optimize.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.lmono_pose_graph_result.argtypes = [C.c_void_p] * 4
+        P = np.ascontiguousarray(poses_tq, np.float64).reshape(-1, 7)
+        lp = np.ascontiguousarray(loops, np.int32).reshape(-1, 2); li = np.ascontiguousarray(loop_info, np.float64).reshape(-1, 8)
+        if len(lp) != len(li):
+            raise LmonoError("loops and loop_info differ in length")
+        self.n = len(P)
+        self.h = L.lmono_pose_graph_create(ctx.h, self.n, P.ctypes.data, len(lp), lp.ctypes.data, li.ctypes.data)
+        if not self.h:
+            raise LmonoError("lmono_pose_graph_create failed: " + ctx.last_error())
+        rc = C.c_int64(0); bw = C.c_int(0); ne = C.c_int(0)
+        L.lmono_pose_graph_info(self.h, C.addressof(rc), C.addressof(bw), C.addressof(ne))
+        self.reduce_count, self.bandwidth, self.n_edges = rc.value, bw.value, ne.value
+        self.reduce_ptr = L.lmono_pose_graph_reduce_buffer(self.h)
+
+    def use_reduce_tensor(self, tensor):
+        """Make a caller-owned contiguous fp64 device tensor of reduce_count elements the buffer linearise() fills and step()
+        reads (the tensor handed to torch.distributed.all_reduce)."""
+        if tensor.numel() != self.reduce_count or tensor.element_size() != 8 or not tensor.is_contiguous():
+            raise LmonoError("reduce tensor must be contiguous fp64 with %d elements" % self.reduce_count)
+        self.ctx.L.lmono_pose_graph_set_reduce_buffer.argtypes = [C.c_void_p, C.c_void_p]
+        self.ctx.check(self.ctx.L.lmono_pose_graph_set_reduce_buffer(self.h, tensor.data_ptr()))
+        self.reduce_tensor = tensor
+        self.reduce_ptr = tensor.data_ptr()
+
+    def linearise(self, rank=0, world=1):
+        self.ctx.check(self.ctx.L.lmono_pose_graph_linearise(self.ctx.h, self.h, rank, world))
+
+    def step(self, max_iter=5):
+        done = C.c_int(0)
+        self.ctx.check(self.ctx.L.lmono_pose_graph_step(self.ctx.h, self.h, max_iter, C.addressof(done)))
+        return bool(done.value)
+
+    def optimize(self, max_iter=5):
+        self.ctx.check(self.ctx.L.lmono_pose_graph_optimize(self.ctx.h, self.h, max_iter))
+        return self.result()
+
+    def result(self):
+        out = np.zeros((self.n, 7)); st = np.zeros(6)
+        self.ctx.check(self.ctx.L.lmono_pose_graph_result(self.ctx.h, self.h, out.ctypes.data, st.ctypes.data))
+        return out, dict(iterations=int(st[0]), initial_cost=st[1], final_cost=st[2], bandwidth=int(st[3]), accepted=int(st[4]), rejected=int(st[5]))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.L.lmono_pose_graph_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -1470,3 +1470,4 @@ extern "C" int lmono_mapper_cube(lmono_ctx *c, lmono_mapper *m, int which, int i
 }
 
 #include "colour_abi.hip"
+#include "posegraph_abi.hip"

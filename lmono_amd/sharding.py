@@ -68,3 +68,23 @@ def gather_bases(my_base, group=None):
     out = torch.empty(world * 7, dtype=torch.float64, device=my_base.device)
     dist.all_gather_into_tensor(out, my_base.contiguous().reshape(7), group=group)
     return out.view(world, 7)
+
+
+def pose_graph_rounds(graph, rank, world, max_iter=5, all_reduce=None):
+    """Loop-closure pose graph over `world` ranks: every rank holds the same graph object (lmono_amd.PoseGraph
+    on a GPU; anything with linearise(rank, world) / reduce_tensor / step(max_iter) works), linearises the edges it owns, ONE
+    all-reduce sums the normal equations [H | g | cost] (RCCL over xGMI with the nccl backend), and every rank takes the same
+    trust-region step.  Returns the number of rounds run."""
+    rounds = 0
+    for _ in range(max_iter + 1):
+        graph.linearise(rank, world)
+        if world > 1:
+            if all_reduce is None:
+                import torch.distributed as dist
+                dist.all_reduce(graph.reduce_tensor)
+            else:
+                all_reduce(graph.reduce_tensor)
+        rounds += 1
+        if graph.step(max_iter):
+            break
+    return rounds

@@ -142,6 +142,20 @@ int lo_associate_to_map(const lo_cam *, const float *xyzi, int n, const double M
 void lo_lift_projective(const lo_cam *, double u, double v, double ray[3]);
 int lo_space_to_plane(const lo_cam *, const double P[3], double p[2]);
 
+/* ---- loop-closure pose graph: NEW FEATURE, no parity target -- see lo_posegraph.c ---- */
+void lo_pg_q2ypr(const double q_xyzw[4], double ypr_deg[3]);     /* mathutils::R2ypr, math_utils.h:187-202 */
+void lo_pg_ypr2q(const double ypr_deg[3], double q_xyzw[4]);     /* YawPitchRollToRotationMatrix, Loop_Detector.h:129-147 */
+typedef struct lo_pg lo_pg;
+lo_pg *lo_pg_create(int n, const double *poses_tq, int n_loops, const int32_t *loops, const double *loop_info, int ordering);
+void lo_pg_free(lo_pg *);
+int64_t lo_pg_reduce_count(const lo_pg *);
+int lo_pg_bandwidth(const lo_pg *);
+void lo_pg_linearise(lo_pg *, int rank, int world, double *buf);       /* this rank's [H band | g | cost] */
+int lo_pg_step(lo_pg *, const double *summed_buf, int max_iter);        /* 1 when finished */
+void lo_pg_result(const lo_pg *, double *out_tq, double *stats);
+int lo_pose_graph_optimize(int n, const double *poses_tq, int n_loops, const int32_t *loops, const double *loop_info,
+                           int max_iter, int ordering, double *out_tq, double *stats);
+
 #ifdef __cplusplus
 }
 #endif

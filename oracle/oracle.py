@@ -516,3 +516,64 @@ def space_to_plane(cam, P):
     P = np.ascontiguousarray(P, np.float64); p = np.zeros(2)
     lib().lo_space_to_plane(C.byref(cam), _fp(P, C.c_double), _fp(p, C.c_double))
     return p
+
+
+# ---- loop-closure pose graph (new feature; lo_posegraph.c) ----
+def pose_graph_optimize(poses_tq, loops, loop_info, max_iter=5, ordering=0):
+    """poses_tq [n,7] (t, q xyzw), loops [L,2] (old, current), loop_info [L,8] (KeyFrame.cc:630-633 layout).
+    -> (optimised poses [n,7], dict(iterations, initial_cost, final_cost, bandwidth))."""
+    P = np.ascontiguousarray(poses_tq, np.float64).reshape(-1, 7)
+    lp = np.ascontiguousarray(loops, np.int32).reshape(-1, 2); li = np.ascontiguousarray(loop_info, np.float64).reshape(-1, 8)
+    out = np.zeros_like(P); st = np.zeros(6)
+    lib().lo_pose_graph_optimize.restype = C.c_int
+    rc = lib().lo_pose_graph_optimize(C.c_int(len(P)), _fp(P, C.c_double), C.c_int(len(lp)), _fp(lp, C.c_int32), _fp(li, C.c_double),
+                                      C.c_int(max_iter), C.c_int(ordering), _fp(out, C.c_double), _fp(st, C.c_double))
+    if rc != 0:
+        raise ValueError("lo_pose_graph_optimize failed")
+    return out, dict(iterations=int(st[0]), initial_cost=st[1], final_cost=st[2], bandwidth=int(st[3]), accepted=int(st[4]), rejected=int(st[5]))
+
+
+def q2ypr(q):
+    q = np.ascontiguousarray(q, np.float64); o = np.zeros(3)
+    lib().lo_pg_q2ypr(_fp(q, C.c_double), _fp(o, C.c_double))
+    return o
+
+
+def ypr2q(ypr):
+    y = np.ascontiguousarray(ypr, np.float64); o = np.zeros(4)
+    lib().lo_pg_ypr2q(_fp(y, C.c_double), _fp(o, C.c_double))
+    return o
+
+
+class PoseGraph:
+    """The oracle's pose graph in the rounds the product runs (linearise a rank's share -> sum over ranks -> step)."""
+
+    def __init__(self, poses_tq, loops, loop_info, ordering=0):
+        P = np.ascontiguousarray(poses_tq, np.float64).reshape(-1, 7)
+        lp = np.ascontiguousarray(loops, np.int32).reshape(-1, 2); li = np.ascontiguousarray(loop_info, np.float64).reshape(-1, 8)
+        L = lib()
+        L.lo_pg_create.restype = C.c_void_p
+        L.lo_pg_reduce_count.restype = C.c_int64
+        self.n = len(P)
+        self.h = C.c_void_p(L.lo_pg_create(C.c_int(self.n), _fp(P, C.c_double), C.c_int(len(lp)), _fp(lp, C.c_int32), _fp(li, C.c_double), C.c_int(ordering)))
+        if not self.h:
+            raise ValueError("lo_pg_create failed")
+        self.reduce_count = L.lo_pg_reduce_count(self.h)
+        self.bandwidth = L.lo_pg_bandwidth(self.h)
+        self.reduce_tensor = np.zeros(self.reduce_count)
+
+    def linearise(self, rank=0, world=1):
+        lib().lo_pg_linearise(self.h, C.c_int(rank), C.c_int(world), _fp(self.reduce_tensor, C.c_double))
+
+    def step(self, max_iter=5):
+        return bool(lib().lo_pg_step(self.h, _fp(self.reduce_tensor, C.c_double), C.c_int(max_iter)))
+
+    def result(self):
+        out = np.zeros((self.n, 7)); st = np.zeros(6)
+        lib().lo_pg_result(self.h, _fp(out, C.c_double), _fp(st, C.c_double))
+        return out, dict(iterations=int(st[0]), initial_cost=st[1], final_cost=st[2], bandwidth=int(st[3]), accepted=int(st[4]), rejected=int(st[5]))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().lo_pg_free(self.h)
+            self.h = None
