@@ -209,6 +209,76 @@ def bench_colour(args):
     print(json.dumps(out), flush=True)
 
 
+def bench_posegraph(args):
+    """Workload of SURVEY config 4 / row 8f-2 (a new feature: the reference has no pose graph): one S4 loop-closure graph of
+    `--keyframes` keyframes (KITTI-00 has 4541 scans) optimised with 5 LM iterations per step.  With --gpus N every rank holds the
+    graph, linearises the edges of its keyframe range, and ONE all-reduce per round sums the normal equations (RCCL); the
+    factorisation is replicated, so N > 1 shards only the linearisation ("strong" scaling of one fixed graph)."""
+    import torch
+    import lmono_amd
+    from lmono_amd import sharding
+    from workloads import s4
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available() and world == args.gpus
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl")
+    g = s4.make_graph(n=args.keyframes, laps=2.2)
+    ctx = lmono_amd.Context(local)
+    pg = lmono_amd.PoseGraph(ctx, g["odom"], g["loops"], g["loop_info"])
+    buf = torch.zeros(pg.reduce_count, dtype=torch.float64, device="cuda:%d" % local)
+    pg.use_reduce_tensor(buf)
+
+    def run():
+        pg.reset()
+        return sharding.pose_graph_rounds(pg, rank, world, max_iter=5)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        run()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rounds = run()
+    fence()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda:%d" % local)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    el = float(el.item())
+    out, st = pg.result()
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    # ---- cpu_baseline leg: the only place the oracle is touched
+    from oracle import oracle as O
+    t1 = time.perf_counter()
+    ref, rs = O.pose_graph_optimize(g["odom"], g["loops"], g["loop_info"], max_iter=5)
+    cpu_s = time.perf_counter() - t1
+    w = pg.bandwidth
+    # the factorisation sweeps the (w+1) x (w+1) block window once per keyframe: read + write of ~ (w+1)^2 / 2 blocks of 128 B
+    alg = args.keyframes * (w + 1) * (w + 1) * 128.0 * st["iterations"]
+    res = {"metric": "loop-closure pose-graph optimisations/sec (4-DoF keyframe graph, 5 LM iterations)", "value": round(args.steps / el, 3), "unit": "graphs/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "S4 loop-closure graph (new feature, SURVEY 8f-2 / config 4 shape)", "keyframes": args.keyframes, "loops": int(len(g["loops"])),
+                      "edges": pg.n_edges, "half_bandwidth_blocks": w, "lm_iterations": st["iterations"], "rounds": rounds,
+                      "all_reduce_bytes_per_round": 8 * pg.reduce_count},
+           "roofline": {"bound": "hbm", "kernel": "k_pg_step (one workgroup: in-place block-banded Cholesky through L2, latency bound by construction)",
+                        "achieved": round(alg * args.steps / el / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg * args.steps / el / 1e9 / HBM_PEAK_GBS, 5),
+                        "traffic": None},
+           "cpu_baseline": {"value": round(1.0 / cpu_s, 3), "unit": "graphs/s", "cores": 1, "kind": "port", "sample": "the same graph, oracle/lo_posegraph.c (-O3), 1 thread"},
+           "max_keyframe_diff_vs_cpu_m": float(np.abs(out[:, :3] - ref[:, :3]).max()),
+           "ate_vs_truth_m": {"odometry": round(s4.ate(g["odom"], g["truth"]), 4), "optimised": round(s4.ate(out, g["truth"]), 4)}}
+    print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -219,12 +289,13 @@ def main():
     ap.add_argument("--lead", type=int, default=5, help="lead-in scans of a chain that does not start at scan 0")
     ap.add_argument("--az", type=int, default=2000, help="azimuth steps per ring (2000 = HDL-64 at 10 Hz)")
     ap.add_argument("--cpu-sample", type=int, default=384, help="scans of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--workload", default="lidar", choices=["lidar", "ba", "map", "colour"],
+    ap.add_argument("--workload", default="lidar", choices=["lidar", "ba", "map", "colour", "posegraph"],
                     help="lidar = headline (BASELINE configs[1]); ba = configs[2]-shaped sliding-window BA solves (secondary); "
                          "map = laserMapping over a synthetic sequence, one stream (SURVEY 8f-1)")
     ap.add_argument("--windows", type=int, default=1024, help="ba: independent windows per GPU")
     ap.add_argument("--streams", type=int, default=64, help="map / colour: independent streams advanced in lock-step")
     ap.add_argument("--frames", type=int, default=20, help="colour: frames per stream and step")
+    ap.add_argument("--keyframes", type=int, default=4541, help="posegraph: keyframes of the graph")
     args = ap.parse_args()
     if args.workload == "ba":
         return bench_ba(args)
@@ -232,6 +303,8 @@ def main():
         return bench_map(args)
     if args.workload == "colour":
         return bench_colour(args)
+    if args.workload == "posegraph":
+        return bench_posegraph(args)
 
     import torch
     import torch.distributed as dist

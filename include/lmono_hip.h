@@ -267,6 +267,7 @@ int lmono_map_builder_clear(lmono_ctx *, lmono_map_builder *);                  
 typedef struct lmono_pose_graph lmono_pose_graph;
 lmono_pose_graph *lmono_pose_graph_create(lmono_ctx *, int n, const double *poses_tq_h, int n_loops, const int32_t *loops_h, const double *loop_info_h);
 void              lmono_pose_graph_destroy(lmono_pose_graph *);
+int   lmono_pose_graph_reset(lmono_ctx *, lmono_pose_graph *);                    /* back to the odometry poses, same graph */
 int   lmono_pose_graph_info(lmono_pose_graph *, int64_t *reduce_count, int *bandwidth_blocks, int *n_edges);
 void *lmono_pose_graph_reduce_buffer(lmono_pose_graph *);                         /* device pointer, reduce_count doubles */
 /* use a caller-owned device buffer of reduce_count doubles instead (e.g. the storage of the tensor handed to the all-reduce) */

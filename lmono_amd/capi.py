@@ -15,7 +15,7 @@ SYMBOLS = [
     "lmono_pose_prefix_d", "lmono_pose_rebase_d", "lmono_map_refine", "lmono_voxel_filter", "lmono_mapper_create", "lmono_mapper_destroy", "lmono_mapper_reset", "lmono_mapper_process", "lmono_mapper_process_batch", "lmono_mapper_cube",
     "lmono_map_builder_create", "lmono_map_builder_destroy", "lmono_associate_to_map", "lmono_associate_to_map_batch", "lmono_map_builder_depth",
     "lmono_map_builder_cloud", "lmono_map_builder_map", "lmono_map_builder_clear",
-    "lmono_pose_graph_create", "lmono_pose_graph_destroy", "lmono_pose_graph_info", "lmono_pose_graph_reduce_buffer", "lmono_pose_graph_set_reduce_buffer", "lmono_pose_graph_linearise",
+    "lmono_pose_graph_create", "lmono_pose_graph_destroy", "lmono_pose_graph_reset", "lmono_pose_graph_info", "lmono_pose_graph_reduce_buffer", "lmono_pose_graph_set_reduce_buffer", "lmono_pose_graph_linearise",
     "lmono_pose_graph_step", "lmono_pose_graph_optimize", "lmono_pose_graph_result", "lmono_factor_eval", "lmono_factor_eval_d",
     "lmono_triangulate", "lmono_outlier_scores", "lmono_shift_depth", "lmono_marginalize", "lmono_marg_evaluate", "lmono_ba_batch_create", "lmono_ba_batch_destroy", "lmono_ba_solve", "lmono_ba_batch_reset", "lmono_ba_batch_read",
 ]
@@ -572,6 +572,10 @@ class PoseGraph:
         L.lmono_pose_graph_info(self.h, C.addressof(rc), C.addressof(bw), C.addressof(ne))
         self.reduce_count, self.bandwidth, self.n_edges = rc.value, bw.value, ne.value
         self.reduce_ptr = L.lmono_pose_graph_reduce_buffer(self.h)
+
+    def reset(self):
+        self.ctx.L.lmono_pose_graph_reset.argtypes = [C.c_void_p, C.c_void_p]
+        self.ctx.check(self.ctx.L.lmono_pose_graph_reset(self.ctx.h, self.h))
 
     def use_reduce_tensor(self, tensor):
         """Make a caller-owned contiguous fp64 device tensor of reduce_count elements the buffer linearise() fills and step()

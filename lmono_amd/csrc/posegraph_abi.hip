@@ -13,7 +13,7 @@ struct lmono_pose_graph {
     int n = 0, n_edges = 0, w = 0;
     int64_t reduce_count = 0;
     std::vector<void *> allocs;
-    std::vector<double> pitch_h, roll_h;
+    std::vector<double> pitch_h, roll_h, x0_h;
 };
 
 template <typename T> static bool pg_upload(lmono_pose_graph *g, const T *&dst, const std::vector<T> &src)
@@ -160,8 +160,17 @@ extern "C" lmono_pose_graph *lmono_pose_graph_create(lmono_ctx *c, int n, const 
               pg_alloc(g, v.cur, (size_t)g->reduce_count) && pg_alloc(g, v.Aw, hsz) && pg_alloc(g, v.scale, (size_t)n * 4) && pg_alloc(g, v.diag, (size_t)n * 4) &&
               pg_alloc(g, v.gs, (size_t)n * 4) && pg_alloc(g, v.sol, (size_t)n * 4) && pg_alloc(g, v.st, 1);
     ok = ok && hipMemcpy(v.x, x.data(), x.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+    g->x0_h = x;
     if (!ok) { c->err = "lmono_pose_graph_create: device allocation failed"; lmono_pose_graph_destroy(g); return nullptr; }
     return g;
+}
+
+extern "C" int lmono_pose_graph_reset(lmono_ctx *c, lmono_pose_graph *g)
+{
+    if (!c || !g || g->ctx != c) return LMONO_EINVAL;
+    HIP_TRY(c, hipMemcpyAsync(g->v.x, g->x0_h.data(), g->x0_h.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(g->v.st, 0, sizeof(PgState), c->stream));
+    return LMONO_OK;
 }
 
 extern "C" int lmono_pose_graph_info(lmono_pose_graph *g, int64_t *reduce_count, int *bandwidth, int *n_edges)

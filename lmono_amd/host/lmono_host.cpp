@@ -393,4 +393,25 @@ std::vector<uint8_t> MapBuilder::depthMap()
     return d;
 }
 
+// ---- loop-closure pose graph (new feature) ------------------------------------------------------------------------------
+int PoseGraph::optimize4DoF(std::vector<double> &poses_tq, const std::vector<Loop> &loops, int max_iter)
+{
+    const int n = (int)(poses_tq.size() / 7);
+    std::vector<int32_t> idx(loops.size() * 2);
+    std::vector<double> info(loops.size() * 8);
+    for (size_t k = 0; k < loops.size(); k++) {
+        idx[2 * k] = loops[k].old_index; idx[2 * k + 1] = loops[k].cur_index;
+        for (int q = 0; q < 8; q++) info[8 * k + (size_t)q] = loops[k].loop_info[q];
+    }
+    lmono_pose_graph *g = lmono_pose_graph_create(hip_.get(), n, poses_tq.data(), (int)loops.size(), idx.data(), info.data());
+    if (!g) throw std::runtime_error(std::string("lmono_pose_graph_create: ") + lmono_last_error(hip_.get()));
+    double st[6] = { 0, 0, 0, 0, 0, 0 };
+    int rc = lmono_pose_graph_optimize(hip_.get(), g, max_iter);
+    if (rc == 0) rc = lmono_pose_graph_result(hip_.get(), g, poses_tq.data(), st);
+    lmono_pose_graph_destroy(g);
+    hip_.check(rc, "lmono_pose_graph_optimize");
+    initial_cost = st[1]; final_cost = st[2]; bandwidth = (int)st[3];
+    return (int)st[0];
+}
+
 } // namespace lmono_host

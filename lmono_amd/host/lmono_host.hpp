@@ -191,4 +191,19 @@ private:
     std::string map_dir_;
 };
 
+// Loop-closure pose graph -- NEW FEATURE: the reference's LoopDetector declares t_optimization / optimize_buf
+// (include/loop_detection/Loop_Detector.h:85-86) but never optimises.  This is the 4-DoF graph its leftover helpers
+// (Loop_Detector.h:99-168) belong to, behind lmono_pose_graph_*.
+class PoseGraph {
+public:
+    struct Loop { int old_index, cur_index; double loop_info[8]; };   // loop_info as KeyFrame::findConnection fills it (KeyFrame.cc:630-633)
+    explicit PoseGraph(HipContext &hip) : hip_(hip) {}
+    // keyframe poses [n][7] = t (x y z), q (x y z w) in, optimised poses out; returns the LM iterations run
+    int optimize4DoF(std::vector<double> &poses_tq, const std::vector<Loop> &loops, int max_iter = 5);
+    double initial_cost = 0, final_cost = 0;
+    int bandwidth = 0;
+private:
+    HipContext &hip_;
+};
+
 } // namespace lmono_host

@@ -562,11 +562,15 @@ class PoseGraph:
         self.bandwidth = L.lo_pg_bandwidth(self.h)
         self.reduce_tensor = np.zeros(self.reduce_count)
 
+    def _buf(self):
+        t = self.reduce_tensor
+        return t if isinstance(t, np.ndarray) else t.numpy()       # a CPU torch tensor shares its memory with the array
+
     def linearise(self, rank=0, world=1):
-        lib().lo_pg_linearise(self.h, C.c_int(rank), C.c_int(world), _fp(self.reduce_tensor, C.c_double))
+        lib().lo_pg_linearise(self.h, C.c_int(rank), C.c_int(world), _fp(self._buf(), C.c_double))
 
     def step(self, max_iter=5):
-        return bool(lib().lo_pg_step(self.h, _fp(self.reduce_tensor, C.c_double), C.c_int(max_iter)))
+        return bool(lib().lo_pg_step(self.h, _fp(self._buf(), C.c_double), C.c_int(max_iter)))
 
     def result(self):
         out = np.zeros((self.n, 7)); st = np.zeros(6)

@@ -60,3 +60,43 @@ def test_shard_ranges_cover_sequence():
             assert ob == prev_end and lb == max(ob - lead, 0)
             prev_end = oe
         assert prev_end == n
+
+
+def _pg_worker(rank, world, port, graph, max_iter, ret):
+    """One rank of the pose-graph rounds: the product's driver (lmono_amd.sharding.pose_graph_rounds) over gloo, with the CPU
+    oracle's graph object standing in for the GPU one (same linearise / reduce_tensor / step interface)."""
+    sys.path.insert(0, ROOT)
+    from lmono_amd import sharding
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pg = O.PoseGraph(graph["odom"], graph["loops"], graph["loop_info"])
+    pg.reduce_tensor = torch.from_numpy(pg.reduce_tensor)          # shares memory with the array the oracle fills / reads
+    calls = []
+
+    def all_reduce(t):
+        calls.append(t.numel())
+        dist.all_reduce(t)
+    rounds = sharding.pose_graph_rounds(pg, rank, world, max_iter=max_iter, all_reduce=all_reduce)
+    out, st = pg.result()
+    ret[rank] = (out, st, rounds, calls, float(pg.reduce_tensor.abs().sum()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_pose_graph_rounds_equal_single_process():
+    """edges sharded by keyframe range, ONE all-reduce of the normal equations per round."""
+    from oracle import oracle as O
+    from workloads import s4
+    g = s4.make_graph(n=160, loop_gap=30)
+    ref, st = O.pose_graph_optimize(g["odom"], g["loops"], g["loop_info"], max_iter=5)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_pg_worker, args=(2, 29531, g, 5, ret), nprocs=2, join=True)
+    for rank in range(2):
+        out, s2, rounds, calls, _ = ret[rank]
+        assert s2["iterations"] == st["iterations"] and abs(s2["final_cost"] - st["final_cost"]) < 1e-12
+        assert np.abs(out - ref).max() < 1e-9
+        assert len(calls) == rounds and rounds <= 6 and all(c == calls[0] for c in calls)      # one all-reduce per round
+    assert np.array_equal(ret[0][0], ret[1][0])                     # both ranks hold bit-identical keyframes
