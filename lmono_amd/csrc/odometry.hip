@@ -471,6 +471,16 @@ __device__ __forceinline__ void nn_update(NnBest &bst, const float4 &p, float qx
     bst.line = better ? (w >> 24) : bst.line;
 }
 
+__device__ __forceinline__ void nn_update_line(NnBest &bst, const float4 &p, int line, float qx, float qy, float qz)
+{
+    const float d = dist2f(p.x, p.y, p.z, qx, qy, qz);
+    const int idx = __float_as_int(p.w);
+    const bool better = d < bst.d || (d == bst.d && idx < bst.idx);
+    bst.d = better ? d : bst.d;
+    bst.idx = better ? idx : bst.idx;
+    bst.line = better ? line : bst.line;
+}
+
 __device__ __forceinline__ void walk_point(const float4 &cpt, int v, int ra, int closest, int w_lo, int w_hi, bool edge,
                                            float qx, float qy, float qz, WalkBest &bs, WalkBest &bo)
 {
@@ -507,6 +517,33 @@ __device__ __forceinline__ void nn_sweep(const float4 *gpts, int st, int cn, int
         for (int u = 0; u < 4; u++) {
             if (gl < n4[u]) nn_update(nb, v4[u], qx, qy, qz);
             for (int i = gl + kGroup; i < n4[u]; i += kGroup) nn_update(nb, gpts[s4[u] + i], qx, qy, qz);
+        }
+    }
+}
+
+// the same over runs of the (line, azimuth-bin) index: lane i of the group holds the run (st, cn) of scan line v0 + i; the
+// points of the index carry their cloud index in .w and the line is the row
+__device__ __forceinline__ void nn_sweep_rows(const float4 *lpts, int st, int cn, int v0, int gl, int gbase, float qx, float qy, float qz, NnBest &nb)
+{
+    unsigned int m = group_ballot(cn > 0, gbase);
+    while (m) {
+        int s4[4], n4[4], l4[4];
+        float4 v4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            n4[u] = 0; s4[u] = 0; l4[u] = 0;
+            if (m) {
+                const int src = __ffs((int)m) - 1;
+                m &= m - 1;
+                s4[u] = __shfl(st, src, kGroup); n4[u] = __shfl(cn, src, kGroup); l4[u] = v0 + src;
+            }
+            v4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gl < n4[u]) v4[u] = lpts[s4[u] + gl];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (gl < n4[u]) nn_update_line(nb, v4[u], l4[u], qx, qy, qz);
+            for (int i = gl + kGroup; i < n4[u]; i += kGroup) nn_update_line(nb, lpts[s4[u] + i], l4[u], qx, qy, qz);
         }
     }
 }
@@ -549,6 +586,9 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
             sl = (sl + 1) & mask;
         }
     }
+    const int *table = b.lb_start + (size_t)(l * 2 + cl) * (kLineKeys + 1);
+    const float rho = sqrtf(qx * qx + qy * qy);
+    const float th = atan2f(qy, qx) + 3.14159265f;
     NnBest nb = { __uint_as_float(0x7f800000u), 0x7fffffff, 0 };
     // near block first: any point outside it is farther than half a cell
     nn_sweep(gpts, st, near ? cn : 0, gl, gbase, qx, qy, qz, nb);
@@ -573,41 +613,33 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
         const float bound = kCell * 0.9999f;
         const bool settled = best != ~0ull && __uint_as_float((unsigned int)(best >> 32)) <= bound * bound;
         if (!settled) {
-            // rare: shells 2..6 with the generic (slower) cooperative search over the group's 32 lanes
-            for (int sh = 2; sh <= kMaxShell; sh++) {
-                const int side = 2 * sh + 1, ncell = side * side * side;
-                for (int base = 0; base < ncell; base += kGroup) {
-                    const int ci = base + gl;
-                    int st2 = 0, cn2 = 0;
-                    if (ci < ncell) {
-                        const int dx = ci % side - sh, dy = (ci / side) % side - sh, dz = ci / (side * side) - sh;
-                        bool want = max(max(abs(dx), abs(dy)), abs(dz)) == sh;
-                        if (want && best != ~0ull) {
-                            // skip cells whose box is farther than the best point of the previous shells
-                            const float lx = (float)(cqx + dx) * kCell, ly = (float)(cqy + dy) * kCell, lz = (float)(cqz + dz) * kCell;
-                            const float ex = fmaxf(fmaxf(lx - qx, qx - (lx + kCell)), 0.f), ey = fmaxf(fmaxf(ly - qy, qy - (ly + kCell)), 0.f), ez = fmaxf(fmaxf(lz - qz, qz - (lz + kCell)), 0.f);
-                            const float eb = fmaxf(sqrtf(ex * ex + ey * ey + ez * ez) - 1e-3f, 0.f);
-                            want = !(eb * eb > __uint_as_float((unsigned int)(best >> 32)));
-                        }
-                        if (want) {
-                            const unsigned long long kk = cell_key(cqx + dx, cqy + dy, cqz + dz);
-                            unsigned int sl = hash_key(kk) & mask;
-                            while (true) {
-                                const GridCell e = cell[sl];
-                                if (e.key == kk) { st2 = e.start; cn2 = e.cnt; break; }
-                                if (e.key == kEmptyKey) break;
-                                sl = (sl + 1) & mask;
-                            }
-                        }
-                    }
-                    nn_sweep(gpts, st2, cn2, gl, gbase, qx, qy, qz, nb);
-                }
-                best = group_min_u64(nb.idx == 0x7fffffff ? ~0ull : pack_fu(nb.d, (unsigned int)nb.idx));
-                if (best != ~0ull) {
-                    const float bound2 = (float)sh * kCell * 0.9999f;
-                    if (__uint_as_float((unsigned int)(best >> 32)) <= bound2 * bound2) break;
-                }
+            // rare (~2 % of the features): the nearest point is not provably inside shell 1.  Instead of probing the
+            // hash cells of shells 2..6 (up to ~150 rounds of dependent probes for a feature without any neighbour),
+            // sweep the (line, azimuth-bin) index: every point closer than rr to the query lies within
+            // +-asin(rr / rho) of its azimuth, so the candidates are one contiguous run per scan line (two when the
+            // arc wraps) -- a few dozen independent coalesced loads.  rr = the best distance of shell 1, or 5 m.
+            const float bd = best != ~0ull ? __uint_as_float((unsigned int)(best >> 32)) : 25.0f;
+            const float rr = bd < 25.0f ? sqrtf(bd) * 1.0005f + 1e-3f : 5.0f;
+            int b_lo = 0, nbins = kAzBins;
+            if (rho > rr * 1.002f) {
+                const float alpha = asin_upper(rr / rho) + 1.5f * (6.28318531f / kAzBins);
+                const int lo = (int)floorf((th - alpha) * (kAzBins / 6.28318531f));
+                const int hi = (int)floorf((th + alpha) * (kAzBins / 6.28318531f));
+                if (hi - lo + 1 < kAzBins) { b_lo = ((lo % kAzBins) + kAzBins) % kAzBins; nbins = hi - lo + 1; }
             }
+            const int b_end = b_lo + nbins;
+            for (int v0 = 0; v0 < 66; v0 += kGroup) {
+                const int v = v0 + gl;
+                int s0 = 0, c0 = 0, s1 = 0, c1 = 0;
+                if (v < 66) {
+                    const int *row = table + v * kAzBins;
+                    s0 = row[b_lo]; c0 = row[min(b_end, kAzBins)] - s0;
+                    if (b_end > kAzBins) { s1 = row[0]; c1 = row[b_end - kAzBins] - s1; }
+                }
+                nn_sweep_rows(lb_pts, s0, c0, v0, gl, gbase, qx, qy, qz, nb);
+                if (b_end > kAzBins) nn_sweep_rows(lb_pts, s1, c1, v0, gl, gbase, qx, qy, qz, nb);
+            }
+            best = group_min_u64(nb.idx == 0x7fffffff ? ~0ull : pack_fu(nb.d, (unsigned int)nb.idx));
         }
     }
     if (best == ~0ull || !((double)__uint_as_float((unsigned int)(best >> 32)) < 25.0)) return out;
@@ -622,9 +654,6 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
     // every point outside the arc is farther than r1.  Otherwise the full 5 m arc is swept.
     const int *fge = b.line_first_ge + (size_t)(l * 2 + cl) * 66;
     const int *lle = b.line_last_le + (size_t)(l * 2 + cl) * 66;
-    const int *table = b.lb_start + (size_t)(l * 2 + cl) * (kLineKeys + 1);
-    const float rho = sqrtf(qx * qx + qy * qy);
-    const float th = atan2f(qy, qx) + 3.14159265f;
     const int w_lo = ra - 3 >= 0 ? lle[ra - 3] + 1 : 0;
     const int w_hi = ra + 3 <= 65 ? fge[ra + 3] : n_last;
     const unsigned long long thr = pack_fu(25.0f, 0u);
