@@ -119,6 +119,49 @@ __device__ __forceinline__ double wave_sum_d(double v)
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+// ---- DPP reductions with a wave-uniform result (no LDS crossbar, one VALU instruction per stage): row_shr 1/2/4/8 inside
+// every 16-lane row, row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2-3; lane 63 then holds the reduction of the
+// wave and lane 31 that of lanes 0..31.  max / min are idempotent, so lanes without a source simply keep their own value.
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ unsigned int dpp_mov_u32(unsigned int v)
+{
+    return (unsigned int)__builtin_amdgcn_update_dpp((int)v, (int)v, kCtrl, kRowMask, 0xf, false);
+}
+__device__ __forceinline__ unsigned int wave_max_u32_uniform(unsigned int v)
+{
+    v = max(v, dpp_mov_u32<0x111, 0xf>(v));
+    v = max(v, dpp_mov_u32<0x112, 0xf>(v));
+    v = max(v, dpp_mov_u32<0x114, 0xf>(v));
+    v = max(v, dpp_mov_u32<0x118, 0xf>(v));
+    v = max(v, dpp_mov_u32<0x142, 0xa>(v));
+    v = max(v, dpp_mov_u32<0x143, 0xc>(v));
+    return (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned int wave_min_u32_uniform(unsigned int v)
+{
+    v = min(v, dpp_mov_u32<0x111, 0xf>(v));
+    v = min(v, dpp_mov_u32<0x112, 0xf>(v));
+    v = min(v, dpp_mov_u32<0x114, 0xf>(v));
+    v = min(v, dpp_mov_u32<0x118, 0xf>(v));
+    v = min(v, dpp_mov_u32<0x142, 0xa>(v));
+    v = min(v, dpp_mov_u32<0x143, 0xc>(v));
+    return (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
+}
+// arg-max / arg-min of a (hi, lo) key in lexicographic order, two 32-bit reductions; identity: (0, 0) / (~0, ~0)
+__device__ __forceinline__ unsigned long long wave_max_key_uniform(unsigned long long k)
+{
+    const unsigned int hi = (unsigned int)(k >> 32), lo = (unsigned int)k;
+    const unsigned int mh = wave_max_u32_uniform(hi);
+    const unsigned int ml = wave_max_u32_uniform(hi == mh ? lo : 0u);
+    return ((unsigned long long)mh << 32) | ml;
+}
+__device__ __forceinline__ unsigned long long wave_min_key_uniform(unsigned long long k)
+{
+    const unsigned int hi = (unsigned int)(k >> 32), lo = (unsigned int)k;
+    const unsigned int mh = wave_min_u32_uniform(hi);
+    const unsigned int ml = wave_min_u32_uniform(hi == mh ? lo : ~0u);
+    return ((unsigned long long)mh << 32) | ml;
+}
 // inclusive prefix sum across the wave
 __device__ __forceinline__ int wave_scan_incl(int v)
 {

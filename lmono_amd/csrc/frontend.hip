@@ -313,7 +313,7 @@ __device__ __forceinline__ void select_sector(int lane, int j, int sp, int slen,
 #pragma unroll
         for (int m = 0; m < M; m++)
             if ((live >> m) & 1u) best = key[m] > best ? key[m] : best;
-        best = wave_max_u64(best);
+        best = wave_max_key_uniform(best);
         if (best == 0ull) break;
         const unsigned int lo = (unsigned int)(best & 0xffffffffull);
         const int pind = (int)(lo >> 8), lf = (int)(lo & 15u), lb = (int)((lo >> 4) & 15u);
@@ -336,7 +336,7 @@ __device__ __forceinline__ void select_sector(int lane, int j, int sp, int slen,
 #pragma unroll
         for (int m = 0; m < M; m++)
             if ((live >> m) & 1u) best = key[m] < best ? key[m] : best;
-        best = wave_min_u64(best);
+        best = wave_min_key_uniform(best);
         if (best == ~0ull) break;
         const unsigned int lo = (unsigned int)(best & 0xffffffffull);
         const int pind = (int)(lo >> 8), lf = (int)(lo & 15u), lb = (int)((lo >> 4) & 15u);
