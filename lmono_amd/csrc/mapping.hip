@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void k_map_correspond(const MapStream *streams
 #pragma unroll
         for (int r = 0; r < 5; r++) {
             const unsigned long long head = ti[0] == 0x7fffffff ? ~0ull : pack_fu(td[0], (unsigned int)ti[0]);
-            const unsigned long long best = group_min_u64(head);
+            const unsigned long long best = group_min_u64(head, gbase);
             if (best == ~0ull) { full = false; break; }
             nn[r] = (int)(unsigned int)(best & 0xffffffffull);
             d5 = __uint_as_float((unsigned int)(best >> 32));

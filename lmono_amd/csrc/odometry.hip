@@ -449,14 +449,24 @@ __device__ __forceinline__ unsigned int group_ballot(bool pred, int gbase)
 {
     return (unsigned int)((__ballot(pred) >> gbase) & 0xffffffffull);
 }
-__device__ __forceinline__ unsigned long long group_min_u64(unsigned long long v)
+// minimum of a (hi, lo) key over the lanes of each 32-lane group, returned to every lane of the group: two 32-bit DPP
+// reductions (row_shr 1/2/4/8, row_bcast:15 into rows 1 and 3 leave the group minima in lanes 31 and 63)
+__device__ __forceinline__ unsigned int group_min_u32(unsigned int v, int gbase)
 {
-#pragma unroll
-    for (int o = kGroup / 2; o > 0; o >>= 1) {
-        const unsigned long long w = __shfl_xor(v, o, kGroup);
-        v = w < v ? w : v;
-    }
-    return v;
+    v = min(v, dpp_mov_u32<0x111, 0xf>(v));
+    v = min(v, dpp_mov_u32<0x112, 0xf>(v));
+    v = min(v, dpp_mov_u32<0x114, 0xf>(v));
+    v = min(v, dpp_mov_u32<0x118, 0xf>(v));
+    v = min(v, dpp_mov_u32<0x142, 0xa>(v));
+    const unsigned int g0 = (unsigned int)__builtin_amdgcn_readlane((int)v, 31), g1 = (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
+    return gbase ? g1 : g0;
+}
+__device__ __forceinline__ unsigned long long group_min_u64(unsigned long long k, int gbase)
+{
+    const unsigned int hi = (unsigned int)(k >> 32), lo = (unsigned int)k;
+    const unsigned int mh = group_min_u32(hi, gbase);
+    const unsigned int ml = group_min_u32(hi == mh ? lo : ~0u, gbase);
+    return ((unsigned long long)mh << 32) | ml;
 }
 
 struct NnBest { float d; int idx; int line; };
@@ -592,7 +602,7 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
     NnBest nb = { __uint_as_float(0x7f800000u), 0x7fffffff, 0 };
     // near block first: any point outside it is farther than half a cell
     nn_sweep(gpts, st, near ? cn : 0, gl, gbase, qx, qy, qz, nb);
-    unsigned long long best = group_min_u64(nb.idx == 0x7fffffff ? ~0ull : pack_fu(nb.d, (unsigned int)nb.idx));
+    unsigned long long best = group_min_u64(nb.idx == 0x7fffffff ? ~0ull : pack_fu(nb.d, (unsigned int)nb.idx), gbase);
     {
         const float bound_h = 0.5f * kCell * 0.9999f;
         if (!(best != ~0ull && __uint_as_float((unsigned int)(best >> 32)) <= bound_h * bound_h)) {
@@ -606,7 +616,7 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
                 if (eb * eb > __uint_as_float((unsigned int)(best >> 32))) cn_far = 0;
             }
             nn_sweep(gpts, st, cn_far, gl, gbase, qx, qy, qz, nb);
-            best = group_min_u64(nb.idx == 0x7fffffff ? ~0ull : pack_fu(nb.d, (unsigned int)nb.idx));
+            best = group_min_u64(nb.idx == 0x7fffffff ? ~0ull : pack_fu(nb.d, (unsigned int)nb.idx), gbase);
         }
     }
     {
@@ -639,7 +649,7 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
                 nn_sweep_rows(lb_pts, s0, c0, v0, gl, gbase, qx, qy, qz, nb);
                 if (b_end > kAzBins) nn_sweep_rows(lb_pts, s1, c1, v0, gl, gbase, qx, qy, qz, nb);
             }
-            best = group_min_u64(nb.idx == 0x7fffffff ? ~0ull : pack_fu(nb.d, (unsigned int)nb.idx));
+            best = group_min_u64(nb.idx == 0x7fffffff ? ~0ull : pack_fu(nb.d, (unsigned int)nb.idx), gbase);
         }
     }
     if (best == ~0ull || !((double)__uint_as_float((unsigned int)(best >> 32)) < 25.0)) return out;
@@ -706,8 +716,8 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
                 }
             }
         }
-        same = group_min_u64(bs.d < 25.0f ? pack_fu(bs.d, bs.seq) : thr);
-        other = group_min_u64(bo.d < 25.0f ? pack_fu(bo.d, bo.seq) : thr);
+        same = group_min_u64(bs.d < 25.0f ? pack_fu(bs.d, bs.seq) : thr, gbase);
+        other = group_min_u64(bo.d < 25.0f ? pack_fu(bo.d, bo.seq) : thr, gbase);
         if (pass == 0) {
             const unsigned long long lim = pack_fu(r1 * r1 * 0.998f, 0u);   // squared distance strictly inside the r1 ball
             if (other < lim && (edge || same < lim)) break;
