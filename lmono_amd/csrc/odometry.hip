@@ -181,7 +181,7 @@ __global__ __launch_bounds__(1024) void k_grid_build(BatchView b)
             const int i = i0 + 1024 * q;
             if (i < n) {
                 const int ln = (int)p[q].w;
-                dst[st[q] + ro[q]] = make_float4(p[q].x, p[q].y, p[q].z, __int_as_float(i | ((ln < 0 ? 0 : (ln > 65 ? 65 : ln)) << 24)));
+                dst[st[q] + ro[q]] = make_float4(p[q].x, p[q].y, p[q].z, __int_as_float((i << 7) | (ln < 0 ? 0 : (ln > 65 ? 65 : ln))));
             }
         }
     }
@@ -251,7 +251,7 @@ __device__ __forceinline__ unsigned long long wave_nn(const GridRef &g, float qx
                 const int s0 = __shfl(st, src), n0 = __shfl(cn, src);
                 for (int i = lane; i < n0; i += 64) {
                     const float4 p = g.pts[s0 + i];
-                    const unsigned long long cand = pack_fu(dist2f(p.x, p.y, p.z, qx, qy, qz), (unsigned int)__float_as_int(p.w) & 0xffffffu);
+                    const unsigned long long cand = pack_fu(dist2f(p.x, p.y, p.z, qx, qy, qz), (unsigned int)__float_as_int(p.w) >> 7);
                     best = cand < best ? cand : best;
                 }
             }
@@ -431,12 +431,13 @@ __global__ __launch_bounds__(256) void k_line_index(BatchView b)
 // asin(x) <= x (1 + 0.5708 x^2) on [0, 1] (equality at 0 and 1): conservative arc half-width without libm
 __device__ __forceinline__ float asin_upper(float x) { return x * (1.0f + 0.5708f * x * x); }
 
-struct WalkBest { float d; unsigned int seq; };
+// walk candidate as one u64 key: (float bits of d2) << 32 | rank in the reference's visiting order; starts at (25.0, 0),
+// so only candidates with d2 < 25 ever replace it
+typedef unsigned long long WalkBest;
 __device__ __forceinline__ void walk_update(WalkBest &bst, float d, unsigned int seq)
 {
-    const bool better = d < bst.d || (d == bst.d && seq < bst.seq);
-    bst.d = better ? d : bst.d;
-    bst.seq = better ? seq : bst.seq;
+    const WalkBest k = ((unsigned long long)__float_as_uint(d) << 32) | seq;
+    bst = k < bst ? k : bst;
 }
 
 // ---- half-wave (32-lane) groups: two feature points per wave --------------------------------------------------
@@ -469,26 +470,24 @@ __device__ __forceinline__ unsigned long long group_min_u64(unsigned long long k
     return ((unsigned long long)mh << 32) | ml;
 }
 
-struct NnBest { float d; int idx; int line; };
+// Nearest-point candidate as ONE u64 key: (float bits of d2) << 32 | index << 7 | line.  d2 >= 0, so the unsigned order
+// of the key is the (d2, index) order of the reference's tie rule and the line rides along; ~0 = no candidate yet.
+// The cell-sorted point copy carries index << 7 | line in .w (k_grid_build).
+typedef unsigned long long NnBest;
+constexpr NnBest kNnNone = ~0ull;
 __device__ __forceinline__ void nn_update(NnBest &bst, const float4 &p, float qx, float qy, float qz)
 {
     const float d = dist2f(p.x, p.y, p.z, qx, qy, qz);
-    const int w = __float_as_int(p.w);
-    const int idx = w & 0xffffff;
-    const bool better = d < bst.d || (d == bst.d && idx < bst.idx);
-    bst.d = better ? d : bst.d;
-    bst.idx = better ? idx : bst.idx;
-    bst.line = better ? (w >> 24) : bst.line;
+    const NnBest k = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)__float_as_int(p.w);
+    bst = k < bst ? k : bst;
 }
 
+// the same for a point of the (line, azimuth-bin) index, whose .w is the plain cloud index
 __device__ __forceinline__ void nn_update_line(NnBest &bst, const float4 &p, int line, float qx, float qy, float qz)
 {
     const float d = dist2f(p.x, p.y, p.z, qx, qy, qz);
-    const int idx = __float_as_int(p.w);
-    const bool better = d < bst.d || (d == bst.d && idx < bst.idx);
-    bst.d = better ? d : bst.d;
-    bst.idx = better ? idx : bst.idx;
-    bst.line = better ? line : bst.line;
+    const NnBest k = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)((__float_as_int(p.w) << 7) | line);
+    bst = k < bst ? k : bst;
 }
 
 __device__ __forceinline__ void walk_point(const float4 &cpt, int v, int ra, int closest, int w_lo, int w_hi, bool edge,
@@ -599,10 +598,10 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
     const int *table = b.lb_start + (size_t)(l * 2 + cl) * (kLineKeys + 1);
     const float rho = sqrtf(qx * qx + qy * qy);
     const float th = atan2f(qy, qx) + 3.14159265f;
-    NnBest nb = { __uint_as_float(0x7f800000u), 0x7fffffff, 0 };
+    NnBest nb = kNnNone;
     // near block first: any point outside it is farther than half a cell
     nn_sweep(gpts, st, near ? cn : 0, gl, gbase, qx, qy, qz, nb);
-    unsigned long long best = group_min_u64(nb.idx == 0x7fffffff ? ~0ull : pack_fu(nb.d, (unsigned int)nb.idx), gbase);
+    unsigned long long best = group_min_u64(nb, gbase);
     {
         const float bound_h = 0.5f * kCell * 0.9999f;
         if (!(best != ~0ull && __uint_as_float((unsigned int)(best >> 32)) <= bound_h * bound_h)) {
@@ -616,7 +615,7 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
                 if (eb * eb > __uint_as_float((unsigned int)(best >> 32))) cn_far = 0;
             }
             nn_sweep(gpts, st, cn_far, gl, gbase, qx, qy, qz, nb);
-            best = group_min_u64(nb.idx == 0x7fffffff ? ~0ull : pack_fu(nb.d, (unsigned int)nb.idx), gbase);
+            best = group_min_u64(nb, gbase);
         }
     }
     {
@@ -649,14 +648,12 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
                 nn_sweep_rows(lb_pts, s0, c0, v0, gl, gbase, qx, qy, qz, nb);
                 if (b_end > kAzBins) nn_sweep_rows(lb_pts, s1, c1, v0, gl, gbase, qx, qy, qz, nb);
             }
-            best = group_min_u64(nb.idx == 0x7fffffff ? ~0ull : pack_fu(nb.d, (unsigned int)nb.idx), gbase);
+            best = group_min_u64(nb, gbase);
         }
     }
     if (best == ~0ull || !((double)__uint_as_float((unsigned int)(best >> 32)) < 25.0)) return out;
-    const int closest = (int)(unsigned int)(best & 0xffffffffull);
-    // the lane that holds the winner knows its line
-    const unsigned int wm = group_ballot(nb.idx == closest && pack_fu(nb.d, (unsigned int)nb.idx) == best, gbase);
-    const int ra = __shfl(nb.line, __ffs((int)wm) - 1, kGroup);
+    const int closest = (int)((unsigned int)(best & 0xffffffffull) >> 7);
+    const int ra = (int)(best & 127ull);
 
     // ---- scan-line walk over the (line, azimuth) index: lines ra-2 .. ra+2, index window (last_le[ra-3], first_ge[ra+3]).
     // Two passes: first only the arc that can hold points within r1 = 0.5 m + 5 % of the range (the partners are
@@ -688,7 +685,7 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
                 if (b_end > kAzBins) { u2 = row[0]; u3 = row[b_end - kAzBins]; }
             }
         }
-        WalkBest bs = { 25.0f, 0u }, bo = { 25.0f, 0u };
+        WalkBest bs = thr, bo = thr;
         for (int part = 0; part < 2; part++) {
             if (part == 1 && b_end <= kAzBins) break;
             // rows in two sub-batches (3 + 2): the loads of a sub-batch are issued back to back
@@ -716,8 +713,8 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
                 }
             }
         }
-        same = group_min_u64(bs.d < 25.0f ? pack_fu(bs.d, bs.seq) : thr, gbase);
-        other = group_min_u64(bo.d < 25.0f ? pack_fu(bo.d, bo.seq) : thr, gbase);
+        same = group_min_u64(bs, gbase);
+        other = group_min_u64(bo, gbase);
         if (pass == 0) {
             const unsigned long long lim = pack_fu(r1 * r1 * 0.998f, 0u);   // squared distance strictly inside the r1 ball
             if (other < lim && (edge || same < lim)) break;
