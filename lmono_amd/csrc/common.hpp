@@ -21,6 +21,7 @@ constexpr int kMaxQueries = kMaxSharp + kMaxFlat;
 constexpr int kStatusRingOverflow = 1;   // a ring holds more than kRingCap points
 constexpr int kStatusGridOverflow = 2;   // a "last" cloud does not fit its hash grid
 constexpr int kStatusWalkOverflow = 8;    // more than 256 features share one scan line (walk truncated)
+constexpr int kStatusDenseCell = 16;     // a 1 m grid cell of a "last" cloud holds > 32767 points (generic search path used)
 constexpr int kStatusIrregularLines = 4; // scan-line ids of a feature cloud too disordered for the windowed walk (array-order walk used)
 
 #define LM_PI 3.14159265358979323846
@@ -122,29 +123,31 @@ __device__ __forceinline__ double wave_sum_d(double v)
 // ---- DPP reductions with a wave-uniform result (no LDS crossbar, one VALU instruction per stage): row_shr 1/2/4/8 inside
 // every 16-lane row, row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2-3; lane 63 then holds the reduction of the
 // wave and lane 31 that of lanes 0..31.  max / min are idempotent, so lanes without a source simply keep their own value.
+// lanes without a source (or outside kRowMask) receive `ident`, the identity of the reduction, which lets the compiler
+// fold the move into the consuming v_min_u32 / v_max_u32 as a DPP operand
 template <int kCtrl, int kRowMask>
-__device__ __forceinline__ unsigned int dpp_mov_u32(unsigned int v)
+__device__ __forceinline__ unsigned int dpp_mov_u32(unsigned int v, unsigned int ident)
 {
-    return (unsigned int)__builtin_amdgcn_update_dpp((int)v, (int)v, kCtrl, kRowMask, 0xf, false);
+    return (unsigned int)__builtin_amdgcn_update_dpp((int)ident, (int)v, kCtrl, kRowMask, 0xf, false);
 }
 __device__ __forceinline__ unsigned int wave_max_u32_uniform(unsigned int v)
 {
-    v = max(v, dpp_mov_u32<0x111, 0xf>(v));
-    v = max(v, dpp_mov_u32<0x112, 0xf>(v));
-    v = max(v, dpp_mov_u32<0x114, 0xf>(v));
-    v = max(v, dpp_mov_u32<0x118, 0xf>(v));
-    v = max(v, dpp_mov_u32<0x142, 0xa>(v));
-    v = max(v, dpp_mov_u32<0x143, 0xc>(v));
+    v = max(v, dpp_mov_u32<0x111, 0xf>(v, 0u));
+    v = max(v, dpp_mov_u32<0x112, 0xf>(v, 0u));
+    v = max(v, dpp_mov_u32<0x114, 0xf>(v, 0u));
+    v = max(v, dpp_mov_u32<0x118, 0xf>(v, 0u));
+    v = max(v, dpp_mov_u32<0x142, 0xa>(v, 0u));
+    v = max(v, dpp_mov_u32<0x143, 0xc>(v, 0u));
     return (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ unsigned int wave_min_u32_uniform(unsigned int v)
 {
-    v = min(v, dpp_mov_u32<0x111, 0xf>(v));
-    v = min(v, dpp_mov_u32<0x112, 0xf>(v));
-    v = min(v, dpp_mov_u32<0x114, 0xf>(v));
-    v = min(v, dpp_mov_u32<0x118, 0xf>(v));
-    v = min(v, dpp_mov_u32<0x142, 0xa>(v));
-    v = min(v, dpp_mov_u32<0x143, 0xc>(v));
+    v = min(v, dpp_mov_u32<0x111, 0xf>(v, ~0u));
+    v = min(v, dpp_mov_u32<0x112, 0xf>(v, ~0u));
+    v = min(v, dpp_mov_u32<0x114, 0xf>(v, ~0u));
+    v = min(v, dpp_mov_u32<0x118, 0xf>(v, ~0u));
+    v = min(v, dpp_mov_u32<0x142, 0xa>(v, ~0u));
+    v = min(v, dpp_mov_u32<0x143, 0xc>(v, ~0u));
     return (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
 }
 // arg-max / arg-min of a (hi, lo) key in lexicographic order, two 32-bit reductions; identity: (0, 0) / (~0, ~0)

@@ -18,6 +18,9 @@ constexpr float kCell = 1.0f;          // grid edge (m)
 constexpr float kInvCell = 1.0f;
 constexpr int kMaxShell = 6;           // shells 1..5 cover 5 m up to float slop; shell 6 makes d2 < 25 exact
 constexpr int kCoordOff = 1 << 20;
+// k_correspond moves a run of points between lanes as ONE register: start (17 bits: a cloud holds < 2^17 points) | count << 17
+constexpr int kRunMaxCount = 32767;
+__device__ __forceinline__ int pack_run(int start, int count) { return start | (count << 17); }
 
 __device__ __forceinline__ unsigned long long cell_key(int cx, int cy, int cz)
 {
@@ -150,6 +153,7 @@ __global__ __launch_bounds__(1024) void k_grid_build(BatchView b)
         int c[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) c[q] = c0 + q < T ? cell[c0 + q].cnt : 0;
+        if (max(max(c[0], c[1]), max(c[2], c[3])) > kRunMaxCount) atomicOr(&b.status[s], kStatusDenseCell);
         const int sum = (c[0] + c[1]) + (c[2] + c[3]);
         const int incl = wave_scan_incl(sum);
         if (lane == 63) s_wsum[buf][wave] = incl;
@@ -454,11 +458,11 @@ __device__ __forceinline__ unsigned int group_ballot(bool pred, int gbase)
 // reductions (row_shr 1/2/4/8, row_bcast:15 into rows 1 and 3 leave the group minima in lanes 31 and 63)
 __device__ __forceinline__ unsigned int group_min_u32(unsigned int v, int gbase)
 {
-    v = min(v, dpp_mov_u32<0x111, 0xf>(v));
-    v = min(v, dpp_mov_u32<0x112, 0xf>(v));
-    v = min(v, dpp_mov_u32<0x114, 0xf>(v));
-    v = min(v, dpp_mov_u32<0x118, 0xf>(v));
-    v = min(v, dpp_mov_u32<0x142, 0xa>(v));
+    v = min(v, dpp_mov_u32<0x111, 0xf>(v, ~0u));
+    v = min(v, dpp_mov_u32<0x112, 0xf>(v, ~0u));
+    v = min(v, dpp_mov_u32<0x114, 0xf>(v, ~0u));
+    v = min(v, dpp_mov_u32<0x118, 0xf>(v, ~0u));
+    v = min(v, dpp_mov_u32<0x142, 0xa>(v, ~0u));
     const unsigned int g0 = (unsigned int)__builtin_amdgcn_readlane((int)v, 31), g1 = (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
     return gbase ? g1 : g0;
 }
@@ -505,20 +509,21 @@ __device__ __forceinline__ void walk_point(const float4 &cpt, int v, int ra, int
 
 // sweep the cell runs (st, cn) held by the group's lanes, four non-empty cells per round: their first 32 points are
 // loaded back to back before any is consumed; nb accumulates the nearest point
-__device__ __forceinline__ void nn_sweep(const float4 *gpts, int st, int cn, int gl, int gbase, float qx, float qy, float qz, NnBest &nb)
+__device__ __forceinline__ void nn_sweep(const float4 *gpts, int run, int gl, int gbase, float qx, float qy, float qz, NnBest &nb)
 {
-    unsigned int m = group_ballot(cn > 0, gbase);
+    unsigned int m = group_ballot(run >= (1 << 17), gbase);
     while (m) {
         int s4[4], n4[4];
         float4 v4[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            n4[u] = 0; s4[u] = 0;
+            int rv = 0;
             if (m) {
                 const int src = __ffs((int)m) - 1;
                 m &= m - 1;
-                s4[u] = __shfl(st, src, kGroup); n4[u] = __shfl(cn, src, kGroup);
+                rv = __shfl(run, src, kGroup);
             }
+            s4[u] = rv & 0x1ffff; n4[u] = rv >> 17;
             v4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (gl < n4[u]) v4[u] = gpts[s4[u] + gl];
         }
@@ -532,20 +537,22 @@ __device__ __forceinline__ void nn_sweep(const float4 *gpts, int st, int cn, int
 
 // the same over runs of the (line, azimuth-bin) index: lane i of the group holds the run (st, cn) of scan line v0 + i; the
 // points of the index carry their cloud index in .w and the line is the row
-__device__ __forceinline__ void nn_sweep_rows(const float4 *lpts, int st, int cn, int v0, int gl, int gbase, float qx, float qy, float qz, NnBest &nb)
+__device__ __forceinline__ void nn_sweep_rows(const float4 *lpts, int run, int v0, int gl, int gbase, float qx, float qy, float qz, NnBest &nb)
 {
-    unsigned int m = group_ballot(cn > 0, gbase);
+    unsigned int m = group_ballot(run >= (1 << 17), gbase);
     while (m) {
         int s4[4], n4[4], l4[4];
         float4 v4[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            n4[u] = 0; s4[u] = 0; l4[u] = 0;
+            int rv = 0;
+            l4[u] = 0;
             if (m) {
                 const int src = __ffs((int)m) - 1;
                 m &= m - 1;
-                s4[u] = __shfl(st, src, kGroup); n4[u] = __shfl(cn, src, kGroup); l4[u] = v0 + src;
+                rv = __shfl(run, src, kGroup); l4[u] = v0 + src;
             }
+            s4[u] = rv & 0x1ffff; n4[u] = rv >> 17;
             v4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (gl < n4[u]) v4[u] = lpts[s4[u] + gl];
         }
@@ -579,7 +586,7 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
     // ---- exact NN, shell 1: lanes 0..26 probe one cell each
     const float fx = qx * kInvCell, fy = qy * kInvCell, fz = qz * kInvCell;
     const int cqx = (int)floorf(fx), cqy = (int)floorf(fy), cqz = (int)floorf(fz);
-    int st = 0, cn = 0;
+    int run = 0;          // pack_run(start, count) of this lane's cell, 0 = empty
     bool near = false;
     if (gl < 27) {
         const int dx = gl % 3 - 1, dy = (gl / 3) % 3 - 1, dz = gl / 9 - 1;
@@ -590,7 +597,7 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
         unsigned int sl = hash_key(kk) & mask;
         while (true) {
             const GridCell e = cell[sl];
-            if (e.key == kk) { st = e.start; cn = e.cnt; break; }
+            if (e.key == kk) { run = pack_run(e.start, e.cnt); break; }
             if (e.key == kEmptyKey) break;
             sl = (sl + 1) & mask;
         }
@@ -600,21 +607,21 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
     const float th = atan2f(qy, qx) + 3.14159265f;
     NnBest nb = kNnNone;
     // near block first: any point outside it is farther than half a cell
-    nn_sweep(gpts, st, near ? cn : 0, gl, gbase, qx, qy, qz, nb);
+    nn_sweep(gpts, near ? run : 0, gl, gbase, qx, qy, qz, nb);
     unsigned long long best = group_min_u64(nb, gbase);
     {
         const float bound_h = 0.5f * kCell * 0.9999f;
         if (!(best != ~0ull && __uint_as_float((unsigned int)(best >> 32)) <= bound_h * bound_h)) {
             // remaining 19 cells, minus those whose box is farther than the best point found so far
-            int cn_far = near ? 0 : cn;
+            int run_far = near ? 0 : run;
             if (best != ~0ull && gl < 27) {
                 const float lx = (float)(cqx + gl % 3 - 1) * kCell, ly = (float)(cqy + (gl / 3) % 3 - 1) * kCell, lz = (float)(cqz + gl / 9 - 1) * kCell;
                 const float ex = fmaxf(fmaxf(lx - qx, qx - (lx + kCell)), 0.f), ey = fmaxf(fmaxf(ly - qy, qy - (ly + kCell)), 0.f), ez = fmaxf(fmaxf(lz - qz, qz - (lz + kCell)), 0.f);
                 // 1e-3 m slack: the cell of a point is floor(coordinate), exact, so only the float box arithmetic needs margin
                 const float eb = fmaxf(sqrtf(ex * ex + ey * ey + ez * ez) - 1e-3f, 0.f);
-                if (eb * eb > __uint_as_float((unsigned int)(best >> 32))) cn_far = 0;
+                if (eb * eb > __uint_as_float((unsigned int)(best >> 32))) run_far = 0;
             }
-            nn_sweep(gpts, st, cn_far, gl, gbase, qx, qy, qz, nb);
+            nn_sweep(gpts, run_far, gl, gbase, qx, qy, qz, nb);
             best = group_min_u64(nb, gbase);
         }
     }
@@ -639,14 +646,15 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
             const int b_end = b_lo + nbins;
             for (int v0 = 0; v0 < 66; v0 += kGroup) {
                 const int v = v0 + gl;
-                int s0 = 0, c0 = 0, s1 = 0, c1 = 0;
+                int run0 = 0, run1 = 0;
                 if (v < 66) {
                     const int *row = table + v * kAzBins;
-                    s0 = row[b_lo]; c0 = row[min(b_end, kAzBins)] - s0;
-                    if (b_end > kAzBins) { s1 = row[0]; c1 = row[b_end - kAzBins] - s1; }
+                    const int s0 = row[b_lo];
+                    run0 = pack_run(s0, row[min(b_end, kAzBins)] - s0);
+                    if (b_end > kAzBins) { const int s1 = row[0]; run1 = pack_run(s1, row[b_end - kAzBins] - s1); }
                 }
-                nn_sweep_rows(lb_pts, s0, c0, v0, gl, gbase, qx, qy, qz, nb);
-                if (b_end > kAzBins) nn_sweep_rows(lb_pts, s1, c1, v0, gl, gbase, qx, qy, qz, nb);
+                nn_sweep_rows(lb_pts, run0, v0, gl, gbase, qx, qy, qz, nb);
+                if (b_end > kAzBins) nn_sweep_rows(lb_pts, run1, v0, gl, gbase, qx, qy, qz, nb);
             }
             best = group_min_u64(nb, gbase);
         }
@@ -676,13 +684,14 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
         }
         const int b_end = b_lo + nbins;
         // lanes 0..4: bucket bounds of lines ra-2..ra+2 (two runs when the arc wraps past the last bin)
-        int u0 = 0, u1 = 0, u2 = 0, u3 = 0;
+        int ua = 0, ub = 0;    // pack_run(start, count) of the arc on this lane's line; ub = the part past the last bin
         {
             const int v = ra - 2 + gl;
             if (gl < 5 && v >= 0 && v <= 65 && !(edge && v == ra)) {   // edges never use the nearest point's own line
                 const int *row = table + v * kAzBins;
-                u0 = row[b_lo]; u1 = row[min(b_end, kAzBins)];
-                if (b_end > kAzBins) { u2 = row[0]; u3 = row[b_end - kAzBins]; }
+                const int u0 = row[b_lo];
+                ua = pack_run(u0, row[min(b_end, kAzBins)] - u0);
+                if (b_end > kAzBins) { const int u2 = row[0]; ub = pack_run(u2, row[b_end - kAzBins] - u2); }
             }
         }
         WalkBest bs = thr, bo = thr;
@@ -699,7 +708,8 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
                     r0[w] = 0; r1[w] = 0;
                     v3[w] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
                     if (vi < 5) {
-                        r0[w] = __shfl(part ? u2 : u0, vi, kGroup); r1[w] = __shfl(part ? u3 : u1, vi, kGroup);
+                        const int rv = __shfl(part ? ub : ua, vi, kGroup);
+                        r0[w] = rv & 0x1ffff; r1[w] = r0[w] + (rv >> 17);
                         if (r0[w] + gl < r1[w]) v3[w] = lb_pts[r0[w] + gl];
                     }
                 }
@@ -752,7 +762,7 @@ __global__ __launch_bounds__(256, 7) void k_correspond(BatchView b, OdomView o, 
     const double *x = o.state + c * 8;
     int4 *corr = (int4 *)o.corr + (size_t)c * kMaxQueries;
     const int l = k - 1;
-    if (b.status[l] & kStatusIrregularLines) {
+    if (b.status[l] & (kStatusIrregularLines | kStatusDenseCell)) {
         // rare: array-order walk with the whole wave, the wave's two features one after the other
         for (int t = 0; t < 2; t++) {
             const int qi = qblock * 8 + (threadIdx.x >> 6) * 2 + t;
