@@ -602,9 +602,6 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
             sl = (sl + 1) & mask;
         }
     }
-    const int *table = b.lb_start + (size_t)(l * 2 + cl) * (kLineKeys + 1);
-    const float rho = sqrtf(qx * qx + qy * qy);
-    const float th = atan2f(qy, qx) + 3.14159265f;
     NnBest nb = kNnNone;
     // near block first: any point outside it is farther than half a cell
     nn_sweep(gpts, near ? run : 0, gl, gbase, qx, qy, qz, nb);
@@ -634,6 +631,9 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
             // sweep the (line, azimuth-bin) index: every point closer than rr to the query lies within
             // +-asin(rr / rho) of its azimuth, so the candidates are one contiguous run per scan line (two when the
             // arc wraps) -- a few dozen independent coalesced loads.  rr = the best distance of shell 1, or 5 m.
+            const int *table = b.lb_start + (size_t)(l * 2 + cl) * (kLineKeys + 1);
+            const float rho = sqrtf(qx * qx + qy * qy);
+            const float th = atan2f(qy, qx) + 3.14159265f;
             const float bd = best != ~0ull ? __uint_as_float((unsigned int)(best >> 32)) : 25.0f;
             const float rr = bd < 25.0f ? sqrtf(bd) * 1.0005f + 1e-3f : 5.0f;
             int b_lo = 0, nbins = kAzBins;
@@ -669,6 +669,9 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
     // every point outside the arc is farther than r1.  Otherwise the full 5 m arc is swept.
     const int *fge = b.line_first_ge + (size_t)(l * 2 + cl) * 66;
     const int *lle = b.line_last_le + (size_t)(l * 2 + cl) * 66;
+    const int *table = b.lb_start + (size_t)(l * 2 + cl) * (kLineKeys + 1);
+    const float rho = sqrtf(qx * qx + qy * qy);
+    const float th = atan2f(qy, qx) + 3.14159265f;
     const int w_lo = ra - 3 >= 0 ? lle[ra - 3] + 1 : 0;
     const int w_hi = ra + 3 <= 65 ? fge[ra + 3] : n_last;
     const unsigned long long thr = pack_fu(25.0f, 0u);
@@ -746,7 +749,7 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
 // grid / index / point data of a chain's "last" scan then stay in that XCD's L2 for its 1836 features.
 constexpr int kCorrBlocks = kMaxQueries / 8;
 
-__global__ __launch_bounds__(256, 7) void k_correspond(BatchView b, OdomView o, int step)
+__global__ __launch_bounds__(256, 8) void k_correspond(BatchView b, OdomView o, int step)
 {
     const int xcd = blockIdx.x & 7, u = blockIdx.x >> 3;
     const int c = (u / kCorrBlocks) * 8 + xcd;
