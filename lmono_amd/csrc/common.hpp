@@ -225,6 +225,39 @@ __device__ __forceinline__ void bitonic_sort_u64_lds(unsigned long long *keys, i
     __syncthreads();
 }
 
+// value of lane (l ^ J), J = 1, 2, 4, 8, 16, 32.  Partner distances 1, 2 and 8 are one DPP move per dword (quad_perm,
+// row_ror:8), 4 is two (row_half_mirror then the quad reversed); 16 and 32 leave the row and go through ds_bpermute.
+template <int kCtrl>
+__device__ __forceinline__ unsigned long long dpp_perm_u64(unsigned long long v)
+{
+    const int l = (int)(unsigned int)v, h = (int)(unsigned int)(v >> 32);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_update_dpp(l, l, kCtrl, 0xf, 0xf, false);   // every lane has a source
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_update_dpp(h, h, kCtrl, 0xf, 0xf, false);
+    return ((unsigned long long)hi << 32) | lo;
+}
+template <int J>
+__device__ __forceinline__ unsigned long long lane_xor_u64(unsigned long long v)
+{
+    if constexpr (J == 1) return dpp_perm_u64<0xB1>(v);                          // quad_perm [1,0,3,2]
+    else if constexpr (J == 2) return dpp_perm_u64<0x4E>(v);                     // quad_perm [2,3,0,1]
+    else if constexpr (J == 4) return dpp_perm_u64<0x1B>(dpp_perm_u64<0x141>(v));  // row_half_mirror (i -> 7 - i), then quad_perm [3,2,1,0]
+    else if constexpr (J == 8) return dpp_perm_u64<0x128>(v);                    // row_ror:8
+    else return __shfl_xor(v, J);
+}
+// one compare-exchange stage of the register bitonic sort with partner distance J < 64 (lane exchange)
+template <int R, int J>
+__device__ __forceinline__ void bitonic_lane_stage(unsigned long long (&v)[R], int base, int lane, int k)
+{
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int i = base + 64 * r + lane;
+        const unsigned long long o = lane_xor_u64<J>(v[r]);
+        const bool keep_min = ((lane & J) == 0) == ((i & k) == 0);
+        // keep the smaller of (own, partner) on the low side: one 64-bit compare decides (equal keys: either)
+        v[r] = ((o < v[r]) == keep_min) ? o : v[r];
+    }
+}
+
 // Register-resident variant for n = 256 R keys (R = 1, 2, 4, 8): every wave keeps its quarter of the array in registers
 // (lane l holds elements base + 64 r + l).  Of the log2(n) (log2(n) + 1) / 2 compare-exchange stages only three have a
 // partner in another wave (through LDS, with barriers); partner distances 64..n/8 are register swaps inside a lane and
@@ -249,7 +282,7 @@ __device__ __forceinline__ void bitonic_sort_u64_reg(unsigned long long *keys)
                     const int i = base + 64 * r + lane;
                     const unsigned long long o = keys[i ^ j];
                     const bool keep_min = ((i & j) == 0) == ((i & k) == 0);
-                    v[r] = keep_min ? (o < v[r] ? o : v[r]) : (o > v[r] ? o : v[r]);
+                    v[r] = ((o < v[r]) == keep_min) ? o : v[r];
                 }
             } else if (j >= 64) {
 #pragma unroll
@@ -265,12 +298,13 @@ __device__ __forceinline__ void bitonic_sort_u64_reg(unsigned long long *keys)
                     }
                 }
             } else {
-#pragma unroll
-                for (int r = 0; r < R; r++) {
-                    const int i = base + 64 * r + lane;
-                    const unsigned long long o = __shfl_xor(v[r], j);
-                    const bool keep_min = ((lane & j) == 0) == ((i & k) == 0);
-                    v[r] = keep_min ? (o < v[r] ? o : v[r]) : (o > v[r] ? o : v[r]);
+                switch (j) {
+                case 1: bitonic_lane_stage<R, 1>(v, base, lane, k); break;
+                case 2: bitonic_lane_stage<R, 2>(v, base, lane, k); break;
+                case 4: bitonic_lane_stage<R, 4>(v, base, lane, k); break;
+                case 8: bitonic_lane_stage<R, 8>(v, base, lane, k); break;
+                case 16: bitonic_lane_stage<R, 16>(v, base, lane, k); break;
+                default: bitonic_lane_stage<R, 32>(v, base, lane, k); break;
                 }
             }
         }
