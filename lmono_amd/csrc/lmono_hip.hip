@@ -85,6 +85,7 @@ extern "C" lmono_ctx *lmono_create(int device)
     if (hipFuncSetAttribute((const void *)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kSelWaveLds) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_voxel, hipFuncAttributeMaxDynamicSharedMemorySize, kVoxLds) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_lm_solve, hipFuncAttributeMaxDynamicSharedMemorySize, kLmRecLds) != hipSuccess) { delete c; return nullptr; }
+    if (hipFuncSetAttribute((const void *)k_grid_build, hipFuncAttributeMaxDynamicSharedMemorySize, kGridLds) != hipSuccess) { delete c; return nullptr; }
     return c;
 }
 
@@ -230,7 +231,7 @@ extern "C" int lmono_scanreg_batch(lmono_ctx *c, lmono_scan_batch *b, const floa
     HIP_TRY(c, hipEventRecord(c->ev[4], st));
     hipLaunchKernelGGL(k_compact, dim3(n_scans), dim3(256), 0, st, v);
     HIP_TRY(c, hipEventRecord(c->ev[5], st));
-    hipLaunchKernelGGL(k_grid_build, dim3(n_scans, 2), dim3(1024), 0, st, v);
+    hipLaunchKernelGGL(k_grid_build, dim3(n_scans, 1 + kGridPar), dim3(1024), kGridLds, st, v);
     HIP_TRY(c, hipEventRecord(c->ev[6], st));
     hipLaunchKernelGGL(k_line_index, dim3(n_scans, 2), dim3(256), 0, st, v);
     HIP_TRY(c, hipEventRecord(c->ev[7], st));

@@ -44,155 +44,183 @@ struct GridRef {
 };
 
 // ------------------------------------------------------------------------------------------------
-#ifdef LMONO_GRID_PROF
-#define GT(i) { if (blockIdx.x == 3 && threadIdx.x == 0) gt[i] = clock64(); }
-#else
-#define GT(i)
-#endif
+// k_grid_build: 1 m hash grid of a "last" cloud, built page by page in LDS.
+//
+// The table of T = 2^k > n slots is cut into pages of kGridPage slots; a cell lives in the page its hash selects
+// (initial slot = hash & (T - 1)) and linear probing wraps INSIDE the page (grid_next), so a page is a closed open-addressing
+// table that fits LDS: keys (32-bit cell code) and one counter per slot (count, then write cursor), 128 KB.  One workgroup builds one page at a time:
+//   pass 1  every point of the cloud: cell, hash, page; points of other pages are only counted (lower pages = this page's first
+//           output position); runs of consecutive points in the same cell (feature clouds are ring / voxel ordered) are
+//           merged by shift + ballot and their head lane does ONE LDS atomicCAS on the key and ONE counted LDS atomicAdd
+//   scan    exclusive prefix of the page's counts, in place -> cursors
+//   pass 2  the page's points again: read-only probe, counted atomicAdd on the cursor, coalesced-source scatter of the
+//           cell-sorted copy (.w = index << 7 | line); the order of the points inside a cell is arbitrary, the searches
+//           take minima over (distance, index) keys
+//   write   the finished page streams out as 16-B GridCell records (every slot written: no clear pass over the table);
+//           after pass 2 a cursor is the end of its cell = the start of the next slot's, so start and count follow from neighbours
+// HBM sees the cloud (read), the copy and the table (written once); the random read-modify-write traffic of the old
+// global-memory table (8.6 MB per scan) stays in LDS.  Surf pages of one scan are built by kGridPar workgroups in parallel.
+constexpr int kGridPage = 16384;
+constexpr int kGridPar = 2;
+constexpr int kGridLds = kGridPage * 8;
+constexpr unsigned int kEmptyKey32 = 0xffffffffu;
+
+__device__ __forceinline__ unsigned int grid_next(unsigned int sl, unsigned int pmask) { return (sl & ~pmask) | ((sl + 1) & pmask); }
+
+// 32-bit cell code of the LDS table: 11 + 11 + 10 bits (|cx|, |cy| < 1024 cells, -512 <= cz < 511); never kEmptyKey32
+__device__ __forceinline__ bool cell_key32(int cx, int cy, int cz, unsigned int &k)
+{
+    const unsigned int ux = (unsigned int)(cx + 1024), uy = (unsigned int)(cy + 1024), uz = (unsigned int)(cz + 512);
+    k = ux | (uy << 11) | (uz << 22);
+    return ux < 2048u && uy < 2048u && uz < 1023u;
+}
+__device__ __forceinline__ unsigned long long key32_to_64(unsigned int k)
+{
+    return cell_key((int)(k & 2047u) - 1024, (int)((k >> 11) & 2047u) - 1024, (int)(k >> 22) - 512);
+}
+
 __global__ __launch_bounds__(1024) void k_grid_build(BatchView b)
 {
-#ifdef LMONO_GRID_PROF
-    long long gt[6];
-#endif
     const int s = blockIdx.x;
-    const bool surf = blockIdx.y == 1;
-    const int tid = threadIdx.x;
+    const bool surf = blockIdx.y > 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = b.feat_n[s * 4 + (surf ? 3 : 1)];
     const int Tcap = surf ? kSurfTable : kCornerTable;
-    // occupied slots = distinct 1 m cells, typically n / 3: a table of >= n + 1 slots keeps the load near 0.3 and always
-    // has an empty slot to end the probe sequence of an absent key; clearing and scanning it is most of this kernel's traffic
+    // occupied slots = distinct 1 m cells, typically n / 3: a table of >= n + 1 slots keeps the load near 0.3
     int T = next_pow2(n + 1);
     if (T < 1024) T = 1024;
-    const bool overflow = T > Tcap;
-    if (overflow) T = 1024;
-    const int mask = T - 1;
-    if (tid == 0) b.grid_mask[s * 2 + (surf ? 1 : 0)] = mask;
     GridCell *cell = surf ? b.sg_cell + (size_t)s * kSurfTable : b.cg_cell + (size_t)s * kCornerTable;
+    const int p0 = surf ? (int)blockIdx.y - 1 : 0, pstep = surf ? kGridPar : 1;
+    if (T > Tcap) {
+        // the cloud does not fit its table: empty table, no correspondences for the next scan, flagged in status
+        if (p0 == 0) {
+            for (int i = tid; i < 1024; i += 1024) { GridCell e; e.key = kEmptyKey; e.start = 0; e.cnt = 0; cell[i] = e; }
+            if (tid == 0) { b.grid_mask[s * 2 + (surf ? 1 : 0)] = 1023; atomicOr(&b.status[s], kStatusGridOverflow); }
+        }
+        return;
+    }
+    const int P = T < kGridPage ? T : kGridPage, n_pages = T / P, pshift = __ffs(P) - 1;
+    if (p0 >= n_pages) return;
+    if (tid == 0 && p0 == 0) b.grid_mask[s * 2 + (surf ? 1 : 0)] = T - 1;
     const float4 *src = surf ? b.less_flat + b.off[s] : b.less_sharp + (size_t)s * kMaxLessSharp;
     float4 *dst = surf ? b.sg_pts + b.off[s] : b.cg_pts + (size_t)s * kMaxLessSharp;
-    int *slot_of = surf ? b.sg_slot + b.off[s] : b.cg_slot + (size_t)s * kMaxLessSharp;
-    int *rank_of = surf ? b.sg_rank + b.off[s] : b.cg_rank + (size_t)s * kMaxLessSharp;
-    GT(0)
-    for (int i = tid; i < T; i += 1024) { GridCell e; e.key = kEmptyKey; e.start = 0; e.cnt = 0; cell[i] = e; }
-    if (overflow) {
-        if (tid == 0) atomicOr(&b.status[s], kStatusGridOverflow);
-        return;   // table stays empty: no correspondences for the next scan, flagged in status
-    }
-    __threadfence_block();
-    __syncthreads();
-    GT(1)
-    // Insertion, 256 consecutive points per wave and round (lane l owns points t0 + 64 q + l, q = 0..3).  Feature clouds
-    // are ordered ring by ring and, inside a ring, by 0.2 m voxel, so neighbouring points mostly share a 1 m cell: runs
-    // of equal cells are found with a lane shift and a ballot, the head lane of a run does ONE atomicCAS on the cell key
-    // and ONE counted atomicAdd, and hands (slot, first rank) to the run with a lane read.  The four sub-tiles give every
-    // lane four independent atomic chains in flight; all loads and stores are coalesced.
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int t0 = wave * 256; t0 < n; t0 += 16 * 256) {
-        unsigned long long key[4];
-        int hl[4], len[4];
-        bool head[4];
+    extern __shared__ __align__(16) unsigned int g_lds[];
+    unsigned int *keys = g_lds;
+    int *cnt = (int *)(g_lds + kGridPage);      // pass 1: points per cell; after the scan: write cursor
+    __shared__ int s_wsum[16], s_before, s_fail;
+    const unsigned int pm = (unsigned int)(P - 1);
+
+    for (int p = p0; p < n_pages; p += pstep) {
+        for (int i = tid; i < P; i += 1024) { keys[i] = kEmptyKey32; cnt[i] = 0; }
+        if (tid == 0) { s_before = 0; s_fail = 0; }
+        __syncthreads();
+        for (int pass = 0; pass < 2; pass++) {
+            int before = 0;
+            bool fail = false;
+            // 256 consecutive points per wave and round (lane l owns points t0 + 64 q + l, q = 0..3): four independent chains
+            for (int t0 = wave * 256; t0 < n; t0 += 16 * 256) {
+                unsigned long long key[4];
+                unsigned int k32[4], sl[4];
+                float4 pt[4];
+                bool mine[4], head[4];
+                int hl[4], len[4], base[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int i = t0 + 64 * q + lane;
-            key[q] = kEmptyKey;
-            if (i < n) {
-                const float4 p = src[i];
-                key[q] = cell_key((int)floorf(p.x * kInvCell), (int)floorf(p.y * kInvCell), (int)floorf(p.z * kInvCell));
-            }
-        }
+                for (int q = 0; q < 4; q++) {
+                    const int i = t0 + 64 * q + lane;
+                    pt[q] = i < n ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int i = t0 + 64 * q + lane;
-            const unsigned long long prev = __shfl_up(key[q], 1);
-            head[q] = i < n && (lane == 0 || key[q] != prev);
-            const unsigned long long hm = __ballot(head[q]);
-            const int nv = min(64, max(0, n - (t0 + 64 * q)));                       // valid lanes of the sub-tile
-            hl[q] = 63 - __clzll((long long)(hm & ((2ull << lane) - 1ull)));          // head lane of this lane's run
-            const unsigned long long rest = lane < 63 ? hm >> (lane + 1) : 0ull;
-            len[q] = (rest ? lane + __ffsll((long long)rest) : nv) - lane;           // run length (meaningful on head lanes)
-        }
-        unsigned int sl[4];
-        int base[4];
-        // first probe of the four chains back to back, then the (rare) collisions
-        unsigned long long old[4];
+                for (int q = 0; q < 4; q++) {
+                    const int i = t0 + 64 * q + lane;
+                    const int cx = (int)floorf(pt[q].x * kInvCell), cy = (int)floorf(pt[q].y * kInvCell), cz = (int)floorf(pt[q].z * kInvCell);
+                    key[q] = cell_key(cx, cy, cz);
+                    const bool ok = cell_key32(cx, cy, cz, k32[q]);
+                    const unsigned int h = hash_key(key[q]) & (unsigned int)(T - 1);
+                    const int pg = (int)(h >> pshift);
+                    sl[q] = h & pm;
+                    mine[q] = i < n && pg == p;
+                    if (i < n && pg < p) before++;
+                    if (mine[q] && !ok) { fail = true; mine[q] = false; }
+                }
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            sl[q] = hash_key(key[q]) & mask;
-            old[q] = head[q] ? atomicCAS(&cell[sl[q]].key, kEmptyKey, key[q]) : kEmptyKey;
-        }
+                for (int q = 0; q < 4; q++) {
+                    const unsigned long long prev = __shfl_up(key[q], 1);
+                    const unsigned long long mm = __ballot(mine[q]);
+                    head[q] = mine[q] && (lane == 0 || !((mm >> (lane - 1)) & 1ull) || key[q] != prev);
+                    const unsigned long long hm = __ballot(head[q]);
+                    hl[q] = 63 - __clzll((long long)(hm & ((2ull << lane) - 1ull)));          // head lane of this lane's run
+                    const unsigned long long stop = hm | ~mm;                                  // a run ends before the next head / foreign point
+                    const unsigned long long rest = lane < 63 ? stop >> (lane + 1) : 0ull;
+                    len[q] = rest ? __ffsll((long long)rest) : 64 - lane;                      // run length (meaningful on head lanes)
+                }
+                // probe chains of the four sub-tiles back to back (LDS): pass 0 inserts, pass 1 only looks the slot up
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            if (head[q]) {
-                unsigned long long o = old[q];
-                while (!(o == kEmptyKey || o == key[q])) {
-                    sl[q] = (sl[q] + 1) & mask;
-                    o = atomicCAS(&cell[sl[q]].key, kEmptyKey, key[q]);
+                for (int q = 0; q < 4; q++) {
+                    if (head[q]) {
+                        int tries = 0;
+                        while (true) {
+                            const unsigned int o = pass == 0 ? atomicCAS(&keys[sl[q]], kEmptyKey32, k32[q]) : keys[sl[q]];
+                            if (o == k32[q] || (pass == 0 && o == kEmptyKey32)) break;
+                            if (++tries >= P || (pass == 1 && o == kEmptyKey32)) { fail = true; head[q] = false; break; }
+                            sl[q] = (sl[q] + 1) & pm;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) base[q] = head[q] ? atomicAdd(&cnt[sl[q]], len[q]) : -1;
+                if (pass == 1) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int i = t0 + 64 * q + lane;
+                        const int h = max(hl[q], 0);
+                        const int b_run = __shfl(base[q], h);
+                        if (mine[q] && b_run >= 0) {
+                            const int ln = (int)pt[q].w;
+                            dst[b_run + (lane - h)] = make_float4(pt[q].x, pt[q].y, pt[q].z, __int_as_float((i << 7) | (ln < 0 ? 0 : (ln > 65 ? 65 : ln))));
+                        }
+                    }
                 }
             }
-        }
+            if (pass == 0) {
+                before = wave_sum_i(before);
+                if (lane == 0 && before) atomicAdd(&s_before, before);
+            }
+            if (fail) s_fail = 1;
+            __syncthreads();
+            if (pass == 0) {
+                // exclusive prefix of the page's counts -> cursors (first output position of every cell)
+                const int per = P >> 10;                       // 1 .. 16 consecutive slots per thread
+                int c[16], sum = 0;
 #pragma unroll
-        for (int q = 0; q < 4; q++) base[q] = head[q] ? atomicAdd(&cell[sl[q]].cnt, len[q]) : 0;
+                for (int q = 0; q < 16; q++) { c[q] = q < per ? cnt[tid * per + q] : 0; sum += c[q]; }
+                const int incl = wave_scan_incl(sum);
+                if (lane == 63) s_wsum[wave] = incl;
+                __syncthreads();
+                int run = s_before + incl - sum;
+                for (int w = 0; w < wave; w++) run += s_wsum[w];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int i = t0 + 64 * q + lane;
-            const int h = max(hl[q], 0);
-            const int s_run = __shfl((int)sl[q], h), b_run = __shfl(base[q], h);
-            if (i < n) { slot_of[i] = s_run; rank_of[i] = b_run + (lane - h); }
-        }
-    }
-    __syncthreads();
-    GT(2)
-    // The counts were produced by L2 atomics: invalidate this CU's L1 once (agent-scope acquire), then read them with
-    // plain loads.  Exclusive prefix over the table in tiles of 4096 cells: four consecutive cells per thread, wave scan,
-    // cross-wave carry kept per thread (one barrier per tile, wave sums double-buffered).
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __shared__ int s_wsum[2][16];
-    int carry = 0;
-    for (int t0 = 0, buf = 0; t0 < T; t0 += 4096, buf ^= 1) {
-        const int c0 = t0 + 4 * tid;
-        int c[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) c[q] = c0 + q < T ? cell[c0 + q].cnt : 0;
-        if (max(max(c[0], c[1]), max(c[2], c[3])) > kRunMaxCount) atomicOr(&b.status[s], kStatusDenseCell);
-        const int sum = (c[0] + c[1]) + (c[2] + c[3]);
-        const int incl = wave_scan_incl(sum);
-        if (lane == 63) s_wsum[buf][wave] = incl;
-        __syncthreads();
-        int base = carry, tile = 0;
-#pragma unroll
-        for (int w = 0; w < 16; w++) { const int v = s_wsum[buf][w]; if (w < wave) base += v; tile += v; }
-        int run = base + incl - sum;
-#pragma unroll
-        for (int q = 0; q < 4; q++) { if (c0 + q < T) cell[c0 + q].start = run; run += c[q]; }
-        carry += tile;
-    }
-    __syncthreads();
-    GT(3)
-    // cell-sorted copy: four points per thread and round, the dependent gathers issued together
-    for (int i0 = tid; i0 < n; i0 += 4 * 1024) {
-        float4 p[4];
-        int so[4], ro[4], st[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int i = i0 + 1024 * q;
-            so[q] = 0; ro[q] = 0; p[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < n) { p[q] = src[i]; so[q] = slot_of[i]; ro[q] = rank_of[i]; }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; q++) st[q] = i0 + 1024 * q < n ? cell[so[q]].start : 0;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int i = i0 + 1024 * q;
-            if (i < n) {
-                const int ln = (int)p[q].w;
-                dst[st[q] + ro[q]] = make_float4(p[q].x, p[q].y, p[q].z, __int_as_float((i << 7) | (ln < 0 ? 0 : (ln > 65 ? 65 : ln))));
+                for (int q = 0; q < 16; q++) { if (q < per) { cnt[tid * per + q] = run; run += c[q]; } }
+                __syncthreads();
             }
         }
+        // the finished page streams out; a failed page (cell code out of range, page full) is written empty and flagged
+        const bool bad = s_fail != 0;
+        bool dense = false;
+        for (int j = tid; j < P; j += 1024) {
+            const unsigned int k = keys[j];
+            const int end = cnt[j], start = j > 0 ? cnt[j - 1] : s_before;
+            const int c = end - start;
+            GridCell e;
+            e.key = (k == kEmptyKey32 || bad) ? kEmptyKey : key32_to_64(k);
+            e.cnt = bad ? 0 : c;
+            e.start = bad ? 0 : start;
+            cell[(size_t)p * P + j] = e;
+            dense = dense || c > kRunMaxCount;
+        }
+        if (tid == 0 && bad) atomicOr(&b.status[s], kStatusGridOverflow);
+        if (dense) atomicOr(&b.status[s], kStatusDenseCell);
+        __syncthreads();
     }
-    GT(4)
-#ifdef LMONO_GRID_PROF
-    if (blockIdx.x == 3 && tid == 0) printf("GRID surf %d n %d T %d | clear %lld insert %lld scan %lld scatter %lld\n", (int)surf, n, T, gt[1]-gt[0], gt[2]-gt[1], gt[3]-gt[2], gt[4]-gt[3]);
-#endif
 }
 // ------------------------------------------------------------------------------------------------
 struct OdomView {
@@ -239,11 +267,12 @@ __device__ __forceinline__ unsigned long long wave_nn(const GridRef &g, float qx
                 if (sh == 1 || max(max(abs(dx), abs(dy)), abs(dz)) == sh) {
                     const unsigned long long k = cell_key(cqx + dx, cqy + dy, cqz + dz);
                     unsigned int sl = hash_key(k) & g.mask;
+                    const unsigned int pmask = min((unsigned int)g.mask, (unsigned int)(kGridPage - 1));
                     while (true) {
                         const GridCell e = g.cell[sl];
                         if (e.key == k) { st = e.start; cn = e.cnt; break; }
                         if (e.key == kEmptyKey) break;
-                        sl = (sl + 1) & g.mask;
+                        sl = grid_next(sl, pmask);
                     }
                 }
             }
@@ -579,7 +608,7 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
     const float4 *gpts = edge ? b.cg_pts + (size_t)l * kMaxLessSharp : b.sg_pts + b.off[l];
     const float4 *lb_pts = edge ? b.lbc_pts + (size_t)l * kMaxLessSharp : b.lbs_pts + b.off[l];
     const int n_last = b.feat_n[l * 4 + (edge ? 1 : 3)];
-    const unsigned int mask = (unsigned int)b.grid_mask[l * 2 + cl];
+    const unsigned int mask = (unsigned int)b.grid_mask[l * 2 + cl], pmask = min(mask, (unsigned int)(kGridPage - 1));
     int4 out = make_int4(-1, -1, -1, 0);
     if (n_last == 0) return out;
 
@@ -599,7 +628,7 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
             const GridCell e = cell[sl];
             if (e.key == kk) { run = pack_run(e.start, e.cnt); break; }
             if (e.key == kEmptyKey) break;
-            sl = (sl + 1) & mask;
+            sl = grid_next(sl, pmask);
         }
     }
     NnBest nb = kNnNone;
