@@ -57,8 +57,6 @@ struct BatchView {
     float4 *lbs_pts;         // [total] same for less_flat
     int *lb_start;           // [n_scans][2][66*128+1] start of every (line, bin) bucket
     int *grid_mask;          // [n_scans][2] table size - 1 actually used (corner, surf): power of two > n
-    int *sg_slot, *sg_rank;  // [total] scratch: table slot of each surf point / rank inside its cell
-    int *cg_slot, *cg_rank;  // [n_scans][kMaxLessSharp] same for corner points
 };
 
 } // namespace lmono

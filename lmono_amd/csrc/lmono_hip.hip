@@ -150,9 +150,7 @@ extern "C" lmono_scan_batch *lmono_batch_create(lmono_ctx *c, int n_cap, int64_t
     ok = ok && dalloc(b, v.feat_n, N * 4) && dalloc(b, v.line_first_ge, N * 2 * 66) && dalloc(b, v.line_last_le, N * 2 * 66);
     ok = ok && dalloc(b, v.cg_cell, N * kCornerTable) && dalloc(b, v.sg_cell, N * kSurfTable);
     ok = ok && dalloc(b, v.cg_pts, N * kMaxLessSharp) && dalloc(b, v.sg_pts, T) && dalloc(b, v.grid_mask, N * 2);
-    ok = ok && dalloc(b, v.sg_slot, T) && dalloc(b, v.sg_rank, T);
     ok = ok && dalloc(b, v.lbc_pts, N * kMaxLessSharp) && dalloc(b, v.lbs_pts, T) && dalloc(b, v.lb_start, N * 2 * (kLineKeys + 1));
-    ok = ok && dalloc(b, v.cg_slot, N * kMaxLessSharp) && dalloc(b, v.cg_rank, N * kMaxLessSharp);
     ok = ok && dalloc(b, b->incr, N * 7) && dalloc(b, b->poses, N * 7) && dalloc(b, b->xq, 8);
     ok = ok && dalloc(b, b->corr_pair, (size_t)kMaxQueries * 4) && dalloc(b, b->crec_pair, (size_t)kMaxQueries * 4);
     if (!ok) {

@@ -118,6 +118,9 @@ __global__ __launch_bounds__(1024) void k_grid_build(BatchView b)
             int before = 0;
             bool fail = false;
             // 256 consecutive points per wave and round (lane l owns points t0 + 64 q + l, q = 0..3): four independent chains
+            float4 nxt[4];     // the next round's points are requested before this round's atomics are waited for
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const int i = wave * 256 + 64 * q + lane; nxt[q] = i < n ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
             for (int t0 = wave * 256; t0 < n; t0 += 16 * 256) {
                 unsigned long long key[4];
                 unsigned int k32[4], sl[4];
@@ -126,8 +129,9 @@ __global__ __launch_bounds__(1024) void k_grid_build(BatchView b)
                 int hl[4], len[4], base[4];
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    const int i = t0 + 64 * q + lane;
-                    pt[q] = i < n ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    pt[q] = nxt[q];
+                    const int i = t0 + 16 * 256 + 64 * q + lane;
+                    nxt[q] = i < n ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
