@@ -74,6 +74,13 @@ __device__ __forceinline__ bool cell_key32(int cx, int cy, int cz, unsigned int 
     k = ux | (uy << 11) | (uz << 22);
     return ux < 2048u && uy < 2048u && uz < 1023u;
 }
+// hash_key(cell_key(cx, cy, cz)) without building the 64-bit key (coordinates inside the 32-bit code's range)
+__device__ __forceinline__ unsigned int hash_cell(int cx, int cy, int cz)
+{
+    unsigned int h = ((unsigned int)(cx + kCoordOff) * 73856093u) ^ ((unsigned int)(cy + kCoordOff) * 19349663u) ^ ((unsigned int)(cz + kCoordOff) * 83492791u);
+    h ^= h >> 15;
+    return h;
+}
 __device__ __forceinline__ unsigned long long key32_to_64(unsigned int k)
 {
     return cell_key((int)(k & 2047u) - 1024, (int)((k >> 11) & 2047u) - 1024, (int)(k >> 22) - 512);
@@ -122,7 +129,6 @@ __global__ __launch_bounds__(1024) void k_grid_build(BatchView b)
 #pragma unroll
             for (int q = 0; q < 4; q++) { const int i = wave * 256 + 64 * q + lane; nxt[q] = i < n ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
             for (int t0 = wave * 256; t0 < n; t0 += 16 * 256) {
-                unsigned long long key[4];
                 unsigned int k32[4], sl[4];
                 float4 pt[4];
                 bool mine[4], head[4];
@@ -137,9 +143,8 @@ __global__ __launch_bounds__(1024) void k_grid_build(BatchView b)
                 for (int q = 0; q < 4; q++) {
                     const int i = t0 + 64 * q + lane;
                     const int cx = (int)floorf(pt[q].x * kInvCell), cy = (int)floorf(pt[q].y * kInvCell), cz = (int)floorf(pt[q].z * kInvCell);
-                    key[q] = cell_key(cx, cy, cz);
                     const bool ok = cell_key32(cx, cy, cz, k32[q]);
-                    const unsigned int h = hash_key(key[q]) & (unsigned int)(T - 1);
+                    const unsigned int h = hash_cell(cx, cy, cz) & (unsigned int)(T - 1);
                     const int pg = (int)(h >> pshift);
                     sl[q] = h & pm;
                     mine[q] = i < n && pg == p;
@@ -148,9 +153,9 @@ __global__ __launch_bounds__(1024) void k_grid_build(BatchView b)
                 }
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    const unsigned long long prev = __shfl_up(key[q], 1);
+                    const unsigned int prev = (unsigned int)__shfl_up((int)k32[q], 1);
                     const unsigned long long mm = __ballot(mine[q]);
-                    head[q] = mine[q] && (lane == 0 || !((mm >> (lane - 1)) & 1ull) || key[q] != prev);
+                    head[q] = mine[q] && (lane == 0 || !((mm >> (lane - 1)) & 1ull) || k32[q] != prev);
                     const unsigned long long hm = __ballot(head[q]);
                     hl[q] = 63 - __clzll((long long)(hm & ((2ull << lane) - 1ull)));          // head lane of this lane's run
                     const unsigned long long stop = hm | ~mm;                                  // a run ends before the next head / foreign point
