@@ -396,6 +396,9 @@ __global__ __launch_bounds__(256) void k_select(BatchView b)
 // (cell, first index); only the segments are sorted (u64 bitonic in LDS, typically 4x fewer keys than points), and a
 // voxel's centroid is the float sum over its segments in (cell, first index) order = (cell, point index) order.
 constexpr int kVoxLds = kRingCap * 8 + kRingCap * 4 + 1024;
+// bucket sort of the segment keys: keys[0 .. 1024) | scattered copy [1024 .. 2048) | 4096 bucket counters in the upper half of the key region
+constexpr int kVoxBucketSegs = 1024, kVoxBucketBits = 12, kVoxBuckets = 1 << kVoxBucketBits;
+static_assert(2 * kVoxBucketSegs * 8 + kVoxBuckets * 4 <= kRingCap * 8, "bucket sort scratch must fit the key region");
 #ifdef LMONO_VOX_PROF
 #define VT(i) { if (blockIdx.x == 20 && blockIdx.y == 3 && threadIdx.x == 0) vt[i] = clock64(); }
 #else
@@ -473,10 +476,17 @@ __global__ __launch_bounds__(256) void k_voxel(BatchView b)
     mnz = fminf(fminf(fs[2], fs[8]), fminf(fs[14], fs[20]));
     mxx = fmaxf(fmaxf(fs[3], fs[9]), fmaxf(fs[15], fs[21]));
     mxy = fmaxf(fmaxf(fs[4], fs[10]), fmaxf(fs[16], fs[22]));
+    mxz = fmaxf(fmaxf(fs[5], fs[11]), fmaxf(fs[17], fs[23]));
     const float inv_leaf = 5.0f;
     const int minb0 = (int)floorf(mnx * inv_leaf), minb1 = (int)floorf(mny * inv_leaf), minb2 = (int)floorf(mnz * inv_leaf);
     const int div0 = (int)floorf(mxx * inv_leaf) - minb0 + 1, div1 = (int)floorf(mxy * inv_leaf) - minb1 + 1;
     const int mul1 = div0, mul2 = div0 * div1;
+    // bucket of a cell for the bucket sort below: its index shifted so that at most kVoxBuckets buckets cover the bounding box
+    const unsigned long long ncell = (unsigned long long)div0 * (unsigned long long)div1 * (unsigned long long)((int)floorf(mxz * inv_leaf) - minb2 + 1);
+    const int cell_bits = ncell > 1ull ? 64 - __clzll((long long)(ncell - 1ull)) : 0;
+    const int bshift = cell_bits > kVoxBucketBits ? cell_bits - kVoxBucketBits : 0;
+    int *hist = (int *)(keys + 2 * kVoxBucketSegs);
+    for (int i = tid; i < kVoxBuckets; i += 256) hist[i] = 0;
     __syncthreads();
 #pragma unroll
     for (int m = 0; m < kSlots; m++) {
@@ -510,18 +520,57 @@ __global__ __launch_bounds__(256) void k_voxel(BatchView b)
     const int nseg = scr[40] + scr[41] + scr[42] + scr[43];
     int np2 = next_pow2(nseg);
     if (np2 < 2) np2 = 2;
+    const bool bucket_path = nseg <= kVoxBucketSegs && ncell <= 0xffffffffull;
     __syncthreads();
     {
         int o = base;
         for (int i = i_lo; i < i_hi; i++) {
             const unsigned int c = cellv[i];
-            if (c != ~0u && (i == 0 || cellv[i - 1] != c)) keys[o++] = ((unsigned long long)c << 32) | (unsigned int)i;
+            if (c != ~0u && (i == 0 || cellv[i - 1] != c)) {
+                keys[o++] = ((unsigned long long)c << 32) | (unsigned int)i;
+                if (bucket_path) atomicAdd(&hist[c >> bshift], 1);
+            }
         }
-        for (int k = nseg + tid; k < np2; k += 256) keys[k] = ~0ull;
+        if (!bucket_path) for (int k = nseg + tid; k < np2; k += 256) keys[k] = ~0ull;
     }
     __syncthreads();
     VT(3)
-    bitonic_sort_u64(keys, np2);
+    if (bucket_path) {
+        // Bucket sort of the <= 1024 segment keys (the usual case; replaces 55 compare-exchange stages): buckets = cell index
+        // shifted down to <= 4096 values, histogram -> exclusive prefix -> cursors; the keys are scattered bucket by bucket
+        // (arrival order), then every key counts the smaller keys of its bucket (typically 1-3 members) and takes that
+        // place: the result is the exact (cell, first index) order whatever the arrival order was.
+        unsigned long long *tmp = keys + kVoxBucketSegs;
+        constexpr int kPer = kVoxBuckets / 256;
+        int c[kPer], sum = 0;
+#pragma unroll
+        for (int q = 0; q < kPer; q++) { c[q] = hist[tid * kPer + q]; sum += c[q]; }
+        const int incl_b = wave_scan_incl(sum);
+        if (lane == 63) scr[44 + wave] = incl_b;
+        __syncthreads();
+        int run = incl_b - sum;
+        for (int w = 0; w < wave; w++) run += scr[44 + w];
+#pragma unroll
+        for (int q = 0; q < kPer; q++) { hist[tid * kPer + q] = run; run += c[q]; }
+        __syncthreads();
+        for (int t = tid; t < nseg; t += 256) {
+            const unsigned long long k = keys[t];
+            tmp[atomicAdd(&hist[(unsigned int)(k >> 32) >> bshift], 1)] = k;
+        }
+        __syncthreads();
+        // a cursor is now the end of its bucket = the start of the next one
+        for (int t = tid; t < nseg; t += 256) {
+            const unsigned long long k = tmp[t];
+            const int bk = (int)((unsigned int)(k >> 32) >> bshift);
+            const int lo = bk > 0 ? hist[bk - 1] : 0, hi = hist[bk];
+            int less = 0;
+            for (int u = lo; u < hi; u++) less += tmp[u] < k ? 1 : 0;
+            keys[lo + less] = k;
+        }
+        __syncthreads();
+    } else {
+        bitonic_sort_u64(keys, np2);
+    }
     VT(4)
     // runs of equal cell over the sorted segments -> output voxels
     const int chunk2 = (np2 + 255) / 256;
