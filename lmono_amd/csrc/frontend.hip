@@ -393,17 +393,40 @@ __global__ __launch_bounds__(256) void k_select(BatchView b)
 // k_voxel: one workgroup per (scan, ring): pcl::VoxelGrid(0.2 m, all fields averaged) over the ring's less-flat
 // candidates (label <= 0 inside the sectors).  PCL sorts (cell, point) pairs and averages each cell's points in that
 // order.  Consecutive ring points mostly share a voxel, so the points are first run-length compressed into segments
-// (cell, first index); only the segments are sorted (u64 bitonic in LDS, typically 4x fewer keys than points), and a
-// voxel's centroid is the float sum over its segments in (cell, first index) order = (cell, point index) order.
-constexpr int kVoxLds = kRingCap * 8 + kRingCap * 4 + 1024;
-// bucket sort of the segment keys: keys[0 .. 1024) | scattered copy [1024 .. 2048) | 4096 bucket counters in the upper half of the key region
+// (cell, first index); only the segments are sorted and a voxel's centroid is the float sum over its segments in
+// (cell, first index) order = (cell, point index) order.
+//
+// Layout: point i = tid + 256 m of the ring sits in register slot m of thread tid, so wave w of slot m holds 64
+// consecutive points and a ballot over the wave is a 64-bit piece of a per-ring bitmap (word i >> 6).  Segment heads,
+// their count and their positions come from ballots and a 32-entry prefix over (slot, wave); "point i continues the run
+// of point i - 1" is kept as a bitmap, which is all the accumulation needs to know about run lengths.
+// Sort: rings of <= 1024 segments (the usual case) use a bucket sort -- bucket = cell index shifted down to <= 4096 values,
+// histogram -> exclusive prefix -> cursors, keys scattered bucket by bucket in arrival order, then every key counts the
+// smaller keys of its bucket (typically 1-3 members) and takes that place: the exact (cell, first index) order whatever the
+// arrival order was.  Longer rings fall back to the register bitonic network.
 constexpr int kVoxBucketSegs = 1024, kVoxBucketBits = 12, kVoxBuckets = 1 << kVoxBucketBits;
+constexpr int kVoxSlots = kRingCap / 256;
+// LDS: key region (sorted keys | scattered copy | bucket counters, or kRingCap keys for the bitonic fallback), scratch ints
+constexpr int kVoxLds = kRingCap * 8 + 1024 + kVoxSlots * 4 * 8 + kVoxSlots * 4 * 4;
 static_assert(2 * kVoxBucketSegs * 8 + kVoxBuckets * 4 <= kRingCap * 8, "bucket sort scratch must fit the key region");
 #ifdef LMONO_VOX_PROF
 #define VT(i) { if (blockIdx.x == 20 && blockIdx.y == 3 && threadIdx.x == 0) vt[i] = clock64(); }
 #else
 #define VT(i)
 #endif
+
+__device__ __forceinline__ float wave_min_f(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_max_f(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
 
 __global__ __launch_bounds__(256) void k_voxel(BatchView b)
 {
@@ -422,21 +445,20 @@ __global__ __launch_bounds__(256) void k_voxel(BatchView b)
         return;
     }
     extern __shared__ __align__(16) unsigned char smem[];
-    unsigned long long *keys = (unsigned long long *)smem;                  // segment keys (cell << 32 | first index)
-    unsigned int *cellv = (unsigned int *)(smem + kRingCap * 8);            // cell of every ring point, ~0u = not a candidate
-    int *scr = (int *)(smem + kRingCap * 8 + kRingCap * 4);                 // 256 ints
+    unsigned long long *keys = (unsigned long long *)smem;                  // sorted segment keys (cell << 32 | first index)
+    int *scr = (int *)(smem + kRingCap * 8);                                // 256 ints
+    unsigned long long *contw = (unsigned long long *)(smem + kRingCap * 8 + 1024);   // [kVoxSlots * 4] run-continuation bitmap
+    unsigned int *lastc = (unsigned int *)(contw + kVoxSlots * 4);          // [kVoxSlots * 4] cell of lane 63 of every (slot, wave)
     const signed char *label = (const signed char *)(b.label + off + rbeg);
     const float4 *cl = b.cloud + off + rbeg;
     const int c_lo = 5, c_hi = len - 7;   // sectors cover local [5, len-7]
     float mnx = FLT_MAX, mny = FLT_MAX, mnz = FLT_MAX, mxx = -FLT_MAX, mxy = -FLT_MAX, mxz = -FLT_MAX;
     int ncand = 0;
-    // the ring's points stay in registers (point tid + 256 m in slot m): all loads are issued back to back, and the
-    // second pass (cell indices) needs no second trip to memory
-    constexpr int kSlots = kRingCap / 256;
-    float4 pr[kSlots];
+    // the ring's points stay in registers: all loads are issued back to back, and the cell pass needs no second trip
+    float4 pr[kVoxSlots];
     unsigned int cand_mask = 0;
 #pragma unroll
-    for (int m = 0; m < kSlots; m++) {
+    for (int m = 0; m < kVoxSlots; m++) {
         const int i = tid + 256 * m;
         signed char lb = 1;
         pr[m] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -444,7 +466,7 @@ __global__ __launch_bounds__(256) void k_voxel(BatchView b)
         if (i >= c_lo && i <= c_hi && lb <= 0) cand_mask |= 1u << m;
     }
 #pragma unroll
-    for (int m = 0; m < kSlots; m++) {
+    for (int m = 0; m < kVoxSlots; m++) {
         if ((cand_mask >> m) & 1u) {
             const float4 p = pr[m];
             mnx = fminf(mnx, p.x); mny = fminf(mny, p.y); mnz = fminf(mnz, p.z);
@@ -454,11 +476,8 @@ __global__ __launch_bounds__(256) void k_voxel(BatchView b)
     }
     VT(1)
     float *fs = (float *)scr;   // [4 waves][6] + counts
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        mnx = fminf(mnx, __shfl_xor(mnx, o)); mny = fminf(mny, __shfl_xor(mny, o)); mnz = fminf(mnz, __shfl_xor(mnz, o));
-        mxx = fmaxf(mxx, __shfl_xor(mxx, o)); mxy = fmaxf(mxy, __shfl_xor(mxy, o)); mxz = fmaxf(mxz, __shfl_xor(mxz, o));
-    }
+    mnx = wave_min_f(mnx); mny = wave_min_f(mny); mnz = wave_min_f(mnz);
+    mxx = wave_max_f(mxx); mxy = wave_max_f(mxy); mxz = wave_max_f(mxz);
     ncand = wave_sum_i(ncand);
     if (lane == 0) {
         fs[wave * 6 + 0] = mnx; fs[wave * 6 + 1] = mny; fs[wave * 6 + 2] = mnz;
@@ -481,17 +500,14 @@ __global__ __launch_bounds__(256) void k_voxel(BatchView b)
     const int minb0 = (int)floorf(mnx * inv_leaf), minb1 = (int)floorf(mny * inv_leaf), minb2 = (int)floorf(mnz * inv_leaf);
     const int div0 = (int)floorf(mxx * inv_leaf) - minb0 + 1, div1 = (int)floorf(mxy * inv_leaf) - minb1 + 1;
     const int mul1 = div0, mul2 = div0 * div1;
-    // bucket of a cell for the bucket sort below: its index shifted so that at most kVoxBuckets buckets cover the bounding box
+    // bucket of a cell for the bucket sort: its index shifted so that at most kVoxBuckets buckets cover the bounding box
     const unsigned long long ncell = (unsigned long long)div0 * (unsigned long long)div1 * (unsigned long long)((int)floorf(mxz * inv_leaf) - minb2 + 1);
     const int cell_bits = ncell > 1ull ? 64 - __clzll((long long)(ncell - 1ull)) : 0;
     const int bshift = cell_bits > kVoxBucketBits ? cell_bits - kVoxBucketBits : 0;
-    int *hist = (int *)(keys + 2 * kVoxBucketSegs);
-    for (int i = tid; i < kVoxBuckets; i += 256) hist[i] = 0;
-    __syncthreads();
+    // ---- cells (registers), cell of the last lane of every (slot, wave) for the neighbour test across waves
+    unsigned int cellr[kVoxSlots];
 #pragma unroll
-    for (int m = 0; m < kSlots; m++) {
-        const int i = tid + 256 * m;
-        if (i >= len) continue;
+    for (int m = 0; m < kVoxSlots; m++) {
         unsigned int cell = ~0u;
         if ((cand_mask >> m) & 1u) {
             const float4 p = pr[m];
@@ -500,46 +516,52 @@ __global__ __launch_bounds__(256) void k_voxel(BatchView b)
             const int i2 = (int)(floorf(p.z * inv_leaf) - (float)minb2);
             cell = (unsigned int)(i0 + i1 * mul1 + i2 * mul2);
         }
-        cellv[i] = cell;
+        cellr[m] = cell;
+        if (lane == 63) lastc[m * 4 + wave] = cell;
     }
-    __syncthreads();
+    int *hist = (int *)(keys + 2 * kVoxBucketSegs);
+    __syncthreads();            // fs / scr[32..35] are read, lastc is written
     VT(2)
-    // segment heads: a candidate whose predecessor in the ring is not a candidate of the same cell
-    const int chunk = (len + 255) / 256;
-    const int i_lo = tid * chunk, i_hi = min(i_lo + chunk, len);
-    int nhead = 0;
-    for (int i = i_lo; i < i_hi; i++) {
-        const unsigned int c = cellv[i];
-        if (c != ~0u && (i == 0 || cellv[i - 1] != c)) nhead++;
+    // ---- segment heads: a candidate whose predecessor in the ring is not a candidate of the same cell
+    unsigned int head_mask = 0;
+    int nhead_w = 0;            // heads of this wave over all slots (wave-uniform)
+#pragma unroll
+    for (int m = 0; m < kVoxSlots; m++) {
+        const int i = tid + 256 * m;
+        unsigned int prev = (unsigned int)__shfl_up((int)cellr[m], 1);
+        if (lane == 0) prev = wave > 0 ? lastc[m * 4 + wave - 1] : (m > 0 ? lastc[(m - 1) * 4 + 3] : ~0u);
+        const bool cand = cellr[m] != ~0u;
+        const bool cont = cand && i > 0 && prev == cellr[m];
+        const bool head = cand && !cont;
+        const unsigned long long hm = __ballot(head), cm = __ballot(cont);
+        if (lane == 0) { contw[m * 4 + wave] = cm; scr[64 + m * 4 + wave] = __popcll(hm); }
+        if (head) head_mask |= 1u << m;
+        nhead_w += __popcll(hm);
     }
-    int incl = wave_scan_incl(nhead);
-    if (lane == 63) scr[40 + wave] = incl;
     __syncthreads();
-    int base = incl - nhead;
-    for (int w = 0; w < wave; w++) base += scr[40 + w];
-    const int nseg = scr[40] + scr[41] + scr[42] + scr[43];
+    // position of a head in ring order = heads of the earlier (slot, wave) pairs + heads below it in its own ballot
+    int nseg = 0;
+    int hbase[kVoxSlots];
+#pragma unroll
+    for (int m = 0; m < kVoxSlots; m++) {
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const int c = scr[64 + m * 4 + w];
+            if (w == wave) hbase[m] = nseg;
+            nseg += c;
+        }
+    }
     int np2 = next_pow2(nseg);
     if (np2 < 2) np2 = 2;
     const bool bucket_path = nseg <= kVoxBucketSegs && ncell <= 0xffffffffull;
-    __syncthreads();
-    {
-        int o = base;
-        for (int i = i_lo; i < i_hi; i++) {
-            const unsigned int c = cellv[i];
-            if (c != ~0u && (i == 0 || cellv[i - 1] != c)) {
-                keys[o++] = ((unsigned long long)c << 32) | (unsigned int)i;
-                if (bucket_path) atomicAdd(&hist[c >> bshift], 1);
-            }
-        }
-        if (!bucket_path) for (int k = nseg + tid; k < np2; k += 256) keys[k] = ~0ull;
-    }
-    __syncthreads();
-    VT(3)
     if (bucket_path) {
-        // Bucket sort of the <= 1024 segment keys (the usual case; replaces 55 compare-exchange stages): buckets = cell index
-        // shifted down to <= 4096 values, histogram -> exclusive prefix -> cursors; the keys are scattered bucket by bucket
-        // (arrival order), then every key counts the smaller keys of its bucket (typically 1-3 members) and takes that
-        // place: the result is the exact (cell, first index) order whatever the arrival order was.
+        for (int i = tid; i < kVoxBuckets; i += 256) hist[i] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < kVoxSlots; m++)
+            if ((head_mask >> m) & 1u) atomicAdd(&hist[cellr[m] >> bshift], 1);
+        __syncthreads();
+        VT(3)
         unsigned long long *tmp = keys + kVoxBucketSegs;
         constexpr int kPer = kVoxBuckets / 256;
         int c[kPer], sum = 0;
@@ -553,10 +575,10 @@ __global__ __launch_bounds__(256) void k_voxel(BatchView b)
 #pragma unroll
         for (int q = 0; q < kPer; q++) { hist[tid * kPer + q] = run; run += c[q]; }
         __syncthreads();
-        for (int t = tid; t < nseg; t += 256) {
-            const unsigned long long k = keys[t];
-            tmp[atomicAdd(&hist[(unsigned int)(k >> 32) >> bshift], 1)] = k;
-        }
+#pragma unroll
+        for (int m = 0; m < kVoxSlots; m++)
+            if ((head_mask >> m) & 1u)
+                tmp[atomicAdd(&hist[cellr[m] >> bshift], 1)] = ((unsigned long long)cellr[m] << 32) | (unsigned int)(tid + 256 * m);
         __syncthreads();
         // a cursor is now the end of its bucket = the start of the next one
         for (int t = tid; t < nseg; t += 256) {
@@ -569,37 +591,59 @@ __global__ __launch_bounds__(256) void k_voxel(BatchView b)
         }
         __syncthreads();
     } else {
+#pragma unroll
+        for (int m = 0; m < kVoxSlots; m++) {
+            const unsigned long long hm = __ballot((head_mask >> m) & 1u);
+            if ((head_mask >> m) & 1u)
+                keys[hbase[m] + __popcll(hm & ((1ull << lane) - 1ull))] = ((unsigned long long)cellr[m] << 32) | (unsigned int)(tid + 256 * m);
+        }
+        for (int k = nseg + tid; k < np2; k += 256) keys[k] = ~0ull;
+        __syncthreads();
+        VT(3)
         bitonic_sort_u64(keys, np2);
     }
     VT(4)
-    // runs of equal cell over the sorted segments -> output voxels
-    const int chunk2 = (np2 + 255) / 256;
-    const int t_lo = tid * chunk2, t_hi = min(t_lo + chunk2, nseg);
-    int nstart = 0;
-    for (int t = t_lo; t < t_hi; t++) {
-        const unsigned int c = (unsigned int)(keys[t] >> 32);
-        if (t == 0 || c != (unsigned int)(keys[t - 1] >> 32)) nstart++;
+    // ---- runs of equal cell over the sorted segments -> output voxels; vstart[o] = first sorted segment of voxel o
+    int *vstart = bucket_path ? (int *)(keys + kVoxBucketSegs) : nullptr;   // the scattered copy is dead now
+    int n_out = 0, obase[(kRingCap + 255) / 256];
+    {
+        const int rounds = (nseg + 255) / 256;
+        // voxel starts per round and wave -> prefix in sorted order (round, wave, lane)
+        for (int j = 0; j < rounds; j++) {
+            const int t = tid + 256 * j;
+            const bool st = t < nseg && (t == 0 || (unsigned int)(keys[t] >> 32) != (unsigned int)(keys[t - 1] >> 32));
+            const unsigned long long sm = __ballot(st);
+            if (lane == 0) scr[128 + ((j * 4 + wave) & 127)] = __popcll(sm);
+        }
     }
-    incl = wave_scan_incl(nstart);
     __syncthreads();
-    if (lane == 63) scr[48 + wave] = incl;
-    __syncthreads();
-    base = incl - nstart;
-    for (int w = 0; w < wave; w++) base += scr[48 + w];
-    const int n_out = scr[48] + scr[49] + scr[50] + scr[51];
     float4 *outp = b.lf_tmp + off + rbeg;
-    int o = base;
     VT(5)
-    for (int t = t_lo; t < t_hi; t++) {
-        const unsigned int c = (unsigned int)(keys[t] >> 32);
-        if (t == 0 || c != (unsigned int)(keys[t - 1] >> 32)) {
+    if (bucket_path) {
+        // nseg <= 1024: at most 4 rounds
+        const int rounds = (nseg + 255) / 256;
+        int total = 0;
+        for (int j = 0; j < rounds; j++)
+            for (int w = 0; w < 4; w++) { if (j * 4 + w < 16) { if (w == wave) obase[j & 3] = total; total += scr[128 + j * 4 + w]; } }
+        n_out = total;
+        for (int j = 0; j < rounds; j++) {
+            const int t = tid + 256 * j;
+            const bool st = t < nseg && (t == 0 || (unsigned int)(keys[t] >> 32) != (unsigned int)(keys[t - 1] >> 32));
+            const unsigned long long sm = __ballot(st);
+            if (st) vstart[obase[j & 3] + __popcll(sm & ((1ull << lane) - 1ull))] = t;
+        }
+        __syncthreads();
+        // one voxel per thread and round: its segments in sorted order, every segment's points in index order
+        for (int v = tid; v < n_out; v += 256) {
+            const int t = vstart[v];
+            const unsigned int c = (unsigned int)(keys[t] >> 32);
             float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
             int cnt = 0;
             for (int u = t; u < nseg && (unsigned int)(keys[u] >> 32) == c; u++) {
                 const int i0 = (int)(keys[u] & 0xffffffffull);
+                // run length from the continuation bitmap: points i0+1 .. while their bit is set
                 int rl = 1;
-                while (i0 + rl < len && cellv[i0 + rl] == c) rl++;
-                // the run's points are requested four at a time, then added in index order (PCL's summation order)
+                while (i0 + rl < len && ((contw[(i0 + rl) >> 6] >> ((i0 + rl) & 63)) & 1ull)) rl++;
                 for (int b4 = 0; b4 < rl; b4 += 4) {
                     float4 q4[4];
 #pragma unroll
@@ -610,12 +654,51 @@ __global__ __launch_bounds__(256) void k_voxel(BatchView b)
                 cnt += rl;
             }
             const float fc = (float)cnt;
-            outp[o++] = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
+            outp[v] = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
+        }
+    } else {
+        // long rings: contiguous ranges of sorted segments per thread (serial prefix of the voxel starts)
+        const int chunk2 = (np2 + 255) / 256;
+        const int t_lo = tid * chunk2, t_hi = min(t_lo + chunk2, nseg);
+        int nstart = 0;
+        for (int t = t_lo; t < t_hi; t++) {
+            const unsigned int c = (unsigned int)(keys[t] >> 32);
+            if (t == 0 || c != (unsigned int)(keys[t - 1] >> 32)) nstart++;
+        }
+        const int incl = wave_scan_incl(nstart);
+        __syncthreads();
+        if (lane == 63) scr[48 + wave] = incl;
+        __syncthreads();
+        int base = incl - nstart;
+        for (int w = 0; w < wave; w++) base += scr[48 + w];
+        n_out = scr[48] + scr[49] + scr[50] + scr[51];
+        int o = base;
+        for (int t = t_lo; t < t_hi; t++) {
+            const unsigned int c = (unsigned int)(keys[t] >> 32);
+            if (t == 0 || c != (unsigned int)(keys[t - 1] >> 32)) {
+                float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+                int cnt = 0;
+                for (int u = t; u < nseg && (unsigned int)(keys[u] >> 32) == c; u++) {
+                    const int i0 = (int)(keys[u] & 0xffffffffull);
+                    int rl = 1;
+                    while (i0 + rl < len && ((contw[(i0 + rl) >> 6] >> ((i0 + rl) & 63)) & 1ull)) rl++;
+                    for (int b4 = 0; b4 < rl; b4 += 4) {
+                        float4 q4[4];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) q4[k] = b4 + k < rl ? cl[i0 + b4 + k] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                        for (int k = 0; k < 4; k++) if (b4 + k < rl) { sx += q4[k].x; sy += q4[k].y; sz += q4[k].z; si += q4[k].w; }
+                    }
+                    cnt += rl;
+                }
+                const float fc = (float)cnt;
+                outp[o++] = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
+            }
         }
     }
     VT(6)
 #ifdef LMONO_VOX_PROF
-    if (blockIdx.x == 20 && blockIdx.y == 3 && tid == 0) printf("VOX len %d nseg %d nout %d | load %lld bbox+cell %lld heads+keys %lld sort %lld runs %lld accum %lld\n", len, nseg, n_out, vt[1]-vt[0], vt[2]-vt[1], vt[3]-vt[2], vt[4]-vt[3], vt[5]-vt[4], vt[6]-vt[5]);
+    if (blockIdx.x == 20 && blockIdx.y == 3 && tid == 0) printf("VOX len %d nseg %d nout %d | load %lld bbox+cell %lld heads %lld sort %lld runs %lld accum %lld\n", len, nseg, n_out, vt[1]-vt[0], vt[2]-vt[1], vt[3]-vt[2], vt[4]-vt[3], vt[5]-vt[4], vt[6]-vt[5]);
 #endif
     if (tid == 0) b.lf_n[s * 64 + r] = n_out;
 }
