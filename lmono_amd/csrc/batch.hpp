@@ -40,6 +40,7 @@ struct BatchView {
     int *sel_flat_n;         // [n_scans][64][6]
     float4 *lf_tmp;          // [total] voxel-filtered less-flat points in ring slots
     int *lf_n;               // [n_scans][64]
+    int *vox_todo;           // [1 + n_scans * 64] work list of k_voxel's second instantiation: count, then (scan << 6 | ring)
     // ---- final feature clouds
     float4 *sharp;           // [n_scans][kMaxSharp]
     float4 *less_sharp;      // [n_scans][kMaxLessSharp]

@@ -404,11 +404,24 @@ __global__ __launch_bounds__(256) void k_select(BatchView b)
 // histogram -> exclusive prefix -> cursors, keys scattered bucket by bucket in arrival order, then every key counts the
 // smaller keys of its bucket (typically 1-3 members) and takes that place: the exact (cell, first index) order whatever the
 // arrival order was.  Longer rings fall back to the register bitonic network.
-constexpr int kVoxBucketSegs = 1024, kVoxBucketBits = 12, kVoxBuckets = 1 << kVoxBucketBits;
-constexpr int kVoxSlots = kRingCap / 256;
-// LDS: key region (sorted keys | scattered copy | bucket counters, or kRingCap keys for the bitonic fallback), scratch ints
-constexpr int kVoxLds = kRingCap * 8 + 1024 + kVoxSlots * 4 * 8 + kVoxSlots * 4 * 4;
-static_assert(2 * kVoxBucketSegs * 8 + kVoxBuckets * 4 <= kRingCap * 8, "bucket sort scratch must fit the key region");
+//
+// Two instantiations run back to back: <9 slots, 2048 buckets> takes the rings of <= 2304 points (every HDL-64 ring: ~80 VGPRs,
+// 27 KB of LDS, 6 workgroups per CU) and appends a ring it cannot take (more points, or > 1024 segments: bitonic network) to a
+// work list; <16 slots, 4096 buckets> runs as a small fixed grid over that list (normally empty).
+constexpr int kVoxBucketSegs = 1024;
+constexpr int kVoxSmallSlots = 9, kVoxSmallBits = 11;
+constexpr int kVoxBigSlots = kRingCap / 256, kVoxBigBits = 12;
+constexpr int kVoxBigGrid = 512;    // workgroups of the second instantiation; each walks the work list with this stride
+// LDS: key region (sorted keys | scattered copy | bucket counters; the big variant: kRingCap keys for the bitonic fallback),
+// 256 scratch ints, the continuation bitmap and the last cells
+template <int kSlots, int kBits, bool kSmall>
+struct VoxCfg {
+    static constexpr int kKeyBytes = kSmall ? 2 * kVoxBucketSegs * 8 + (1 << kBits) * 4 : kRingCap * 8;
+    static constexpr int kLds = kKeyBytes + 1024 + kSlots * 4 * 8 + kSlots * 4 * 4;
+};
+constexpr int kVoxLdsSmall = VoxCfg<kVoxSmallSlots, kVoxSmallBits, true>::kLds;
+constexpr int kVoxLdsBig = VoxCfg<kVoxBigSlots, kVoxBigBits, false>::kLds;
+static_assert(2 * kVoxBucketSegs * 8 + (1 << kVoxBigBits) * 4 <= kRingCap * 8, "bucket sort scratch must fit the key region");
 #ifdef LMONO_VOX_PROF
 #define VT(i) { if (blockIdx.x == 20 && blockIdx.y == 3 && threadIdx.x == 0) vt[i] = clock64(); }
 #else
@@ -428,9 +441,29 @@ __device__ __forceinline__ float wave_max_f(float v)
     return v;
 }
 
+template <int kVoxSlots, int kVoxBucketBits, bool kSmall>
+__device__ __forceinline__ void voxel_ring(BatchView &b, int r, int s);
+
+template <int kVoxSlots, int kVoxBucketBits, bool kSmall>
 __global__ __launch_bounds__(256) void k_voxel(BatchView b)
 {
-    const int r = blockIdx.x, s = blockIdx.y;
+    if (kSmall) voxel_ring<kVoxSlots, kVoxBucketBits, kSmall>(b, blockIdx.x, blockIdx.y);
+    else {
+        const int n_todo = b.vox_todo[0];
+        for (int k = blockIdx.x; k < n_todo; k += gridDim.x) {
+            const int e = b.vox_todo[1 + k];
+            voxel_ring<kVoxSlots, kVoxBucketBits, kSmall>(b, e & 63, e >> 6);
+            __syncthreads();
+        }
+    }
+}
+
+template <int kVoxSlots, int kVoxBucketBits, bool kSmall>
+__device__ __forceinline__ void voxel_ring(BatchView &b, int r, int s)
+{
+    constexpr int kVoxBuckets = 1 << kVoxBucketBits;
+    constexpr int kCap = 256 * kVoxSlots;
+    constexpr int kKeyBytes = VoxCfg<kVoxSlots, kVoxBucketBits, kSmall>::kKeyBytes;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t off = b.off[s];
 #ifdef LMONO_VOX_PROF
@@ -440,14 +473,18 @@ __global__ __launch_bounds__(256) void k_voxel(BatchView b)
     const int *rb = b.ring_begin + s * 65;
     const int rbeg = rb[r], rend = rb[r + 1], len = rend - rbeg;
     const int S = rbeg + 5, E = rend - 6;
+    if (kSmall && len > kCap && len <= kRingCap && E - S >= 6) {
+        if (tid == 0) b.vox_todo[1 + atomicAdd(&b.vox_todo[0], 1)] = (s << 6) | r;    // the big instantiation's ring
+        return;
+    }
     if (E - S < 6 || len > kRingCap) {
         if (tid == 0) b.lf_n[s * 64 + r] = 0;
         return;
     }
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned long long *keys = (unsigned long long *)smem;                  // sorted segment keys (cell << 32 | first index)
-    int *scr = (int *)(smem + kRingCap * 8);                                // 256 ints
-    unsigned long long *contw = (unsigned long long *)(smem + kRingCap * 8 + 1024);   // [kVoxSlots * 4] run-continuation bitmap
+    int *scr = (int *)(smem + kKeyBytes);                                   // 256 ints
+    unsigned long long *contw = (unsigned long long *)(smem + kKeyBytes + 1024);   // [kVoxSlots * 4] run-continuation bitmap
     unsigned int *lastc = (unsigned int *)(contw + kVoxSlots * 4);          // [kVoxSlots * 4] cell of lane 63 of every (slot, wave)
     const signed char *label = (const signed char *)(b.label + off + rbeg);
     const float4 *cl = b.cloud + off + rbeg;
@@ -554,6 +591,10 @@ __global__ __launch_bounds__(256) void k_voxel(BatchView b)
     int np2 = next_pow2(nseg);
     if (np2 < 2) np2 = 2;
     const bool bucket_path = nseg <= kVoxBucketSegs && ncell <= 0xffffffffull;
+    if (kSmall && !bucket_path) {
+        if (tid == 0) b.vox_todo[1 + atomicAdd(&b.vox_todo[0], 1)] = (s << 6) | r;    // needs the bitonic network: big instantiation
+        return;
+    }
     if (bucket_path) {
         for (int i = tid; i < kVoxBuckets; i += 256) hist[i] = 0;
         __syncthreads();
@@ -590,7 +631,7 @@ __global__ __launch_bounds__(256) void k_voxel(BatchView b)
             keys[lo + less] = k;
         }
         __syncthreads();
-    } else {
+    } else if (!kSmall) {
 #pragma unroll
         for (int m = 0; m < kVoxSlots; m++) {
             const unsigned long long hm = __ballot((head_mask >> m) & 1u);
@@ -605,7 +646,7 @@ __global__ __launch_bounds__(256) void k_voxel(BatchView b)
     VT(4)
     // ---- runs of equal cell over the sorted segments -> output voxels; vstart[o] = first sorted segment of voxel o
     int *vstart = bucket_path ? (int *)(keys + kVoxBucketSegs) : nullptr;   // the scattered copy is dead now
-    int n_out = 0, obase[(kRingCap + 255) / 256];
+    int n_out = 0, obase[4];
     {
         const int rounds = (nseg + 255) / 256;
         // voxel starts per round and wave -> prefix in sorted order (round, wave, lane)
@@ -656,7 +697,7 @@ __global__ __launch_bounds__(256) void k_voxel(BatchView b)
             const float fc = (float)cnt;
             outp[v] = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
         }
-    } else {
+    } else if (!kSmall) {
         // long rings: contiguous ranges of sorted segments per thread (serial prefix of the voxel starts)
         const int chunk2 = (np2 + 255) / 256;
         const int t_lo = tid * chunk2, t_hi = min(t_lo + chunk2, nseg);

@@ -83,7 +83,8 @@ extern "C" lmono_ctx *lmono_create(int device)
     c->device = device;
     // the selection kernel needs ~62 KB of dynamic LDS
     if (hipFuncSetAttribute((const void *)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kSelWaveLds) != hipSuccess) { delete c; return nullptr; }
-    if (hipFuncSetAttribute((const void *)k_voxel, hipFuncAttributeMaxDynamicSharedMemorySize, kVoxLds) != hipSuccess) { delete c; return nullptr; }
+    if (hipFuncSetAttribute((const void *)k_voxel<kVoxSmallSlots, kVoxSmallBits, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kVoxLdsSmall) != hipSuccess) { delete c; return nullptr; }
+    if (hipFuncSetAttribute((const void *)k_voxel<kVoxBigSlots, kVoxBigBits, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kVoxLdsBig) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_lm_solve, hipFuncAttributeMaxDynamicSharedMemorySize, kLmRecLds) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_grid_build, hipFuncAttributeMaxDynamicSharedMemorySize, kGridLds) != hipSuccess) { delete c; return nullptr; }
     return c;
@@ -144,7 +145,7 @@ extern "C" lmono_scan_batch *lmono_batch_create(lmono_ctx *c, int n_cap, int64_t
     ok = ok && dalloc(b, v.ring_begin, N * 65) && dalloc(b, v.n_cloud, N) && dalloc(b, v.status, N);
     ok = ok && dalloc(b, v.sel_sharp, N * 64 * 6 * 20) && dalloc(b, v.sel_sharp_n, N * 64 * 6);
     ok = ok && dalloc(b, v.sel_flat, N * 64 * 6 * 4) && dalloc(b, v.sel_flat_n, N * 64 * 6);
-    ok = ok && dalloc(b, v.lf_tmp, T) && dalloc(b, v.lf_n, N * 64);
+    ok = ok && dalloc(b, v.lf_tmp, T) && dalloc(b, v.lf_n, N * 64) && dalloc(b, v.vox_todo, N * 64 + 1);
     ok = ok && dalloc(b, v.sharp, N * kMaxSharp) && dalloc(b, v.less_sharp, N * kMaxLessSharp);
     ok = ok && dalloc(b, v.flat, N * kMaxFlat) && dalloc(b, v.less_flat, T);
     ok = ok && dalloc(b, v.feat_n, N * 4) && dalloc(b, v.line_first_ge, N * 2 * 66) && dalloc(b, v.line_last_le, N * 2 * 66);
@@ -217,6 +218,7 @@ extern "C" int lmono_scanreg_batch(lmono_ctx *c, lmono_scan_batch *b, const floa
     c->sets[c->n_sets - 1].reg = true;
     HIP_TRY(c, hipMemcpyAsync(b->off_d, b->off_h.data(), sizeof(int64_t) * (n_scans + 1), hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemsetAsync(v.status, 0, sizeof(int) * n_scans, st));
+    HIP_TRY(c, hipMemsetAsync(v.vox_todo, 0, sizeof(int), st));
     HIP_TRY(c, hipEventRecord(c->ev[0], st));
     hipLaunchKernelGGL(k_ring_sort, dim3(n_scans), dim3(1024), 0, st, v);
     HIP_TRY(c, hipEventRecord(c->ev[1], st));
@@ -225,7 +227,8 @@ extern "C" int lmono_scanreg_batch(lmono_ctx *c, lmono_scan_batch *b, const floa
     HIP_TRY(c, hipEventRecord(c->ev[2], st));
     hipLaunchKernelGGL(k_select, dim3(kMaxRings / 4, n_scans), dim3(256), 4 * kSelWaveLds, st, v);
     HIP_TRY(c, hipEventRecord(c->ev[3], st));
-    hipLaunchKernelGGL(k_voxel, dim3(kMaxRings, n_scans), dim3(256), kVoxLds, st, v);
+    hipLaunchKernelGGL((k_voxel<kVoxSmallSlots, kVoxSmallBits, true>), dim3(kMaxRings, n_scans), dim3(256), kVoxLdsSmall, st, v);
+    hipLaunchKernelGGL((k_voxel<kVoxBigSlots, kVoxBigBits, false>), dim3(kVoxBigGrid), dim3(256), kVoxLdsBig, st, v);
     HIP_TRY(c, hipEventRecord(c->ev[4], st));
     hipLaunchKernelGGL(k_compact, dim3(n_scans), dim3(256), 0, st, v);
     HIP_TRY(c, hipEventRecord(c->ev[5], st));

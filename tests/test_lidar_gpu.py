@@ -70,6 +70,23 @@ def test_scanreg_other_sensors(oracle, gpu_ctx, n_lines):
     _check_scanreg(oracle, batch, xyzi, off, n_lines, 0.5)
 
 
+def test_scanreg_long_rings_take_the_second_voxel_kernel(oracle, gpu_ctx):
+    """Rings of more than 2304 points (azimuth step 0.12 deg) and rings with more than 1024 voxel segments (points scattered
+    over many 0.2 m cells) are handed to k_voxel's second instantiation (work list, bitonic network): still bit-exact."""
+    w = oracle.S1World(n_az=3000)
+    xyzi, off = w.scans(w.trajectory(2))
+    a = xyzi[off[0]:off[1]].copy()
+    b = xyzi[off[1]:off[2]].copy()
+    # scan b: radial jitter of +-3 m on every second point: neighbouring ring points fall into different voxels
+    rng = np.random.default_rng(11)
+    scale = 1.0 + (rng.uniform(-0.15, 0.15, len(b)) * (np.arange(len(b)) % 2)).astype(np.float32)
+    b[:, :3] *= scale[:, None]
+    cat = np.concatenate([a, b], 0)
+    o = np.array([0, len(a), len(a) + len(b)], np.int64)
+    batch = _register(gpu_ctx, cat, o)
+    _check_scanreg(oracle, batch, cat, o)
+
+
 def test_correspondences_match_oracle(oracle, gpu_ctx, small_seq):
     xyzi, off = small_seq["xyzi"], small_seq["off"]
     batch = _register(gpu_ctx, xyzi, off)
