@@ -163,6 +163,9 @@ extern "C" lmono_scan_batch *lmono_batch_create(lmono_ctx *c, int n_cap, int64_t
     return b;
 }
 
+// rings a sensor can produce (scanRegistration keeps rings 0..50 of a 64-line sensor): grids of the per-ring kernels
+static int rings_used(int n_lines) { return n_lines == 64 ? 51 : n_lines; }
+
 static int check_launch(lmono_ctx *c, const char *what)
 {
     hipError_t e = hipGetLastError();
@@ -225,9 +228,14 @@ extern "C" int lmono_scanreg_batch(lmono_ctx *c, lmono_scan_batch *b, const floa
     const int tiles = (int)((max_pts + kCurvTile - 1) / kCurvTile);
     if (tiles > 0) hipLaunchKernelGGL(k_curvature, dim3(tiles, n_scans), dim3(256), 0, st, v);
     HIP_TRY(c, hipEventRecord(c->ev[2], st));
-    hipLaunchKernelGGL(k_select, dim3(kMaxRings / 4, n_scans), dim3(256), 4 * kSelWaveLds, st, v);
+    // the kernels below run one workgroup per ring of the sensor; the counters of the rings it cannot produce stay zero
+    const int n_rings = rings_used(n_lines);
+    HIP_TRY(c, hipMemsetAsync(v.sel_sharp_n, 0, sizeof(int) * (size_t)n_scans * 64 * 6, st));
+    HIP_TRY(c, hipMemsetAsync(v.sel_flat_n, 0, sizeof(int) * (size_t)n_scans * 64 * 6, st));
+    HIP_TRY(c, hipMemsetAsync(v.lf_n, 0, sizeof(int) * (size_t)n_scans * 64, st));
+    hipLaunchKernelGGL(k_select, dim3((n_rings + 3) / 4, n_scans), dim3(256), 4 * kSelWaveLds, st, v);
     HIP_TRY(c, hipEventRecord(c->ev[3], st));
-    hipLaunchKernelGGL((k_voxel<kVoxSmallSlots, kVoxSmallBits, true>), dim3(kMaxRings, n_scans), dim3(256), kVoxLdsSmall, st, v);
+    hipLaunchKernelGGL((k_voxel<kVoxSmallSlots, kVoxSmallBits, true>), dim3(n_rings, n_scans), dim3(256), kVoxLdsSmall, st, v);
     hipLaunchKernelGGL((k_voxel<kVoxBigSlots, kVoxBigBits, false>), dim3(kVoxBigGrid), dim3(256), kVoxLdsBig, st, v);
     HIP_TRY(c, hipEventRecord(c->ev[4], st));
     hipLaunchKernelGGL(k_compact, dim3(n_scans), dim3(256), 0, st, v);

@@ -785,6 +785,7 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
 // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an XCD and its 4 MB L2), so
 // the 1-D grid is decoded such that all blocks of a chain run on ONE XCD, one chain after the other: the ~2 MB of
 // grid / index / point data of a chain's "last" scan then stay in that XCD's L2 for its 1836 features.
+// (sizing the grid to the sensor's feature bound, 230 instead of 288 workgroups per chain for an HDL-64, measured 3 % slower)
 constexpr int kCorrBlocks = kMaxQueries / 8;
 
 __global__ __launch_bounds__(256, 8) void k_correspond(BatchView b, OdomView o, int step)
