@@ -871,8 +871,31 @@ __device__ __forceinline__ void huber(double s, double &rho0, double &rho1)
     } else { rho0 = s; rho1 = 1.0; }
 }
 
+// A staged residual block (64 B in LDS, planes of 16 B): (cp, kind) as float4, then six doubles that do not depend on the pose and
+// are computed once per launch instead of once per evaluation (up to nine per launch):
+//   edge   a, e^ = (a - b) / |a - b|:          r = (lp - a) x e^   [= ((lp - a) x (lp - b)) / |a - b| since (lp - a) x (lp - a) = 0],  d r / d lp = -[e^]_x
+//   plane  j, n = normalised((j - l) x (j - m)):  r = (lp - j) . n,  d r / d lp = n^T
+__device__ __forceinline__ void stage_block(const float4 cp, const float4 A, const float4 B, const float4 Cc, double *P)
+{
+    const int kind = __float_as_int(cp.w);
+    if (kind == 1) {
+        const double ex = (double)A.x - (double)B.x, ey = (double)A.y - (double)B.y, ez = (double)A.z - (double)B.z;
+        const double inv = 1.0 / sqrt(ex * ex + ey * ey + ez * ez);
+        P[0] = (double)A.x; P[1] = (double)A.y; P[2] = (double)A.z;
+        P[3] = ex * inv; P[4] = ey * inv; P[5] = ez * inv;
+    } else {
+        const double jx = (double)A.x, jy = (double)A.y, jz = (double)A.z;
+        const double ux = jx - (double)B.x, uy = jy - (double)B.y, uz = jz - (double)B.z;
+        const double wx = jx - (double)Cc.x, wy = jy - (double)Cc.y, wz = jz - (double)Cc.z;
+        double nx = uy * wz - uz * wy, ny = uz * wx - ux * wz, nz = ux * wy - uy * wx;
+        const double nn = sqrt(nx * nx + ny * ny + nz * nz);
+        if (nn > 0.0) { nx /= nn; ny /= nn; nz /= nn; }
+        P[0] = jx; P[1] = jy; P[2] = jz; P[3] = nx; P[4] = ny; P[5] = nz;
+    }
+}
+
 template <bool kJac>
-__device__ __forceinline__ void eval_block(const float4 cp, const float4 A, const float4 B, const float4 Cc, const double *x, const double *Jp, LmAcc &acc)
+__device__ __forceinline__ void eval_block(const float4 cp, const double2 P01, const double2 P23, const double2 P45, const double *x, const double *Jp, LmAcc &acc)
 {
     const int kind = __float_as_int(cp.w);
     if (kind == 0) return;
@@ -883,30 +906,19 @@ __device__ __forceinline__ void eval_block(const float4 cp, const float4 A, cons
     lx += x[4]; ly += x[5]; lz += x[6];
     double res[3], D[3][3];   // D = d res / d lp
     int nr;
+    const double dx = lx - P01.x, dy = ly - P01.y, dz = lz - P23.x;     // lp - a  /  lp - j
+    const double qx = P23.y, qy = P45.x, qz = P45.y;                    // e^      /  n
     if (edge) {
-        const double ax = lx - (double)A.x, ay = ly - (double)A.y, az = lz - (double)A.z;
-        const double bx = lx - (double)B.x, by = ly - (double)B.y, bz = lz - (double)B.z;
-        const double nux = ay * bz - az * by, nuy = az * bx - ax * bz, nuz = ax * by - ay * bx;
-        const double ex = (double)A.x - (double)B.x, ey = (double)A.y - (double)B.y, ez = (double)A.z - (double)B.z;
-        const double den = sqrt(ex * ex + ey * ey + ez * ez);
-        res[0] = nux / den; res[1] = nuy / den; res[2] = nuz / den;
+        res[0] = dy * qz - dz * qy; res[1] = dz * qx - dx * qz; res[2] = dx * qy - dy * qx;
         if (kJac) {
-            const double inv = 1.0 / den;
-            // [b - a]_x with (b - a) = -e
-            D[0][0] = 0.0;       D[0][1] = ez * inv;  D[0][2] = -ey * inv;
-            D[1][0] = -ez * inv; D[1][1] = 0.0;       D[1][2] = ex * inv;
-            D[2][0] = ey * inv;  D[2][1] = -ex * inv; D[2][2] = 0.0;
+            D[0][0] = 0.0; D[0][1] = qz;  D[0][2] = -qy;
+            D[1][0] = -qz; D[1][1] = 0.0; D[1][2] = qx;
+            D[2][0] = qy;  D[2][1] = -qx; D[2][2] = 0.0;
         }
         nr = 3;
     } else {
-        const double jx = (double)A.x, jy = (double)A.y, jz = (double)A.z;
-        const double ux = jx - (double)B.x, uy = jy - (double)B.y, uz = jz - (double)B.z;
-        const double wx = jx - (double)Cc.x, wy = jy - (double)Cc.y, wz = jz - (double)Cc.z;
-        double nx = uy * wz - uz * wy, ny = uz * wx - ux * wz, nz = ux * wy - uy * wx;
-        const double nn = sqrt(nx * nx + ny * ny + nz * nz);
-        if (nn > 0.0) { nx /= nn; ny /= nn; nz /= nn; }
-        res[0] = (lx - jx) * nx + (ly - jy) * ny + (lz - jz) * nz;
-        if (kJac) { D[0][0] = nx; D[0][1] = ny; D[0][2] = nz; }
+        res[0] = dx * qx + dy * qy + dz * qz;
+        if (kJac) { D[0][0] = qx; D[0][1] = qy; D[0][2] = qz; }
         nr = 1;
     }
     double sq = 0.0;
@@ -970,7 +982,10 @@ __device__ __forceinline__ void evaluate_block(const float4 *srec, int nq, const
         for (int i = 0; i < 6; i++) acc.g[i] = 0.0;
     }
     for (int qi = tid; qi < nq; qi += kLmT)
-        eval_block<kJac>(srec[qi], srec[kMaxQueries + qi], srec[2 * kMaxQueries + qi], srec[3 * kMaxQueries + qi], x, Jp, acc);
+    {
+        const double2 *sp = (const double2 *)srec;
+        eval_block<kJac>(srec[qi], sp[kMaxQueries + qi], sp[2 * kMaxQueries + qi], sp[3 * kMaxQueries + qi], x, Jp, acc);
+    }
     acc.cost = wave_sum_d(acc.cost);
     if (kJac) {
 #pragma unroll
@@ -1061,17 +1076,18 @@ __global__ __launch_bounds__(kLmT) void k_lm_solve(BatchView b, OdomView o, int 
     // evaluations of this launch; eight 16-B loads per thread in flight
     extern __shared__ __align__(16) float4 s_rec[];
     int n_used = 0;
-    for (int i0 = tid; i0 < nq * 4; i0 += 8 * kLmT) {
-        float4 v[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) { const int idx = i0 + kLmT * u; v[u] = idx < nq * 4 ? crec[idx] : make_float4(0.f, 0.f, 0.f, 0.f); }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int idx = i0 + kLmT * u;
-            if (idx < nq * 4) {
-                s_rec[(idx & 3) * kMaxQueries + (idx >> 2)] = v[u];
-                if ((idx & 3) == 0) n_used += __float_as_int(v[u].w) != 0;
-            }
+    {
+        // one record per thread and round: its four 16-B quarters are requested together, the pose-independent part of the
+        // residual block is computed once (stage_block) and the block goes to LDS as (cp, kind) + six doubles
+        double2 *sp = (double2 *)s_rec;
+        for (int qi = tid; qi < nq; qi += kLmT) {
+            const float4 cp = crec[qi * 4], A = crec[qi * 4 + 1], B = crec[qi * 4 + 2], Cc = crec[qi * 4 + 3];
+            double P[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
+            if (__float_as_int(cp.w) != 0) { stage_block(cp, A, B, Cc, P); n_used++; }
+            s_rec[qi] = cp;
+            sp[kMaxQueries + qi] = make_double2(P[0], P[1]);
+            sp[2 * kMaxQueries + qi] = make_double2(P[2], P[3]);
+            sp[3 * kMaxQueries + qi] = make_double2(P[4], P[5]);
         }
     }
     __syncthreads();
