@@ -545,30 +545,32 @@ __device__ __forceinline__ void walk_point(const float4 &cpt, int v, int ra, int
     else if (!edge) walk_update(bs, d, seq);
 }
 
-// sweep the cell runs (st, cn) held by the group's lanes, four non-empty cells per round: their first 32 points are
-// loaded back to back before any is consumed; nb accumulates the nearest point
+// sweep the cell runs held by the group's lanes (pack_run), four non-empty cells per round, ONE CELL PER 8-LANE SUB-GROUP:
+// 1 m cells of a 0.2 m-voxelised cloud hold ~10 points (corner cells 1-3), so a 32-lane load per cell leaves most lanes
+// idle while every wave instruction costs the same; with four cells side by side a round is one or two load + update
+// steps instead of four.  Two steps are requested back to back.
 __device__ __forceinline__ void nn_sweep(const float4 *gpts, int run, int gl, int gbase, float qx, float qy, float qz, NnBest &nb)
 {
     unsigned int m = group_ballot(run >= (1 << 17), gbase);
+    const int sub = gl >> 3, sl = gl & 7;
     while (m) {
-        int s4[4], n4[4];
-        float4 v4[4];
+        int src = -1;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            int rv = 0;
-            if (m) {
-                const int src = __ffs((int)m) - 1;
-                m &= m - 1;
-                rv = __shfl(run, src, kGroup);
-            }
-            s4[u] = rv & 0x1ffff; n4[u] = rv >> 17;
-            v4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gl < n4[u]) v4[u] = gpts[s4[u] + gl];
+            const int f = __ffs((int)m) - 1;      // -1 when no cell is left
+            if (u == sub) src = f;
+            m &= m - 1;
         }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (gl < n4[u]) nn_update(nb, v4[u], qx, qy, qz);
-            for (int i = gl + kGroup; i < n4[u]; i += kGroup) nn_update(nb, gpts[s4[u] + i], qx, qy, qz);
+        const int rv = __shfl(run, max(src, 0), kGroup);
+        const int st = rv & 0x1ffff, cn = src >= 0 ? rv >> 17 : 0;
+        int i = sl;
+        while (__any(i < cn)) {
+            float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+            if (i < cn) v0 = gpts[st + i];
+            if (i + 8 < cn) v1 = gpts[st + i + 8];
+            if (i < cn) nn_update(nb, v0, qx, qy, qz);
+            if (i + 8 < cn) nn_update(nb, v1, qx, qy, qz);
+            i += 16;
         }
     }
 }
@@ -736,32 +738,22 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
             }
         }
         WalkBest bs = thr, bo = thr;
+        // the five lines side by side, one per 6-lane sub-group (lanes 30, 31 idle): the arcs hold few points per line
+        // (~17 surf, ~4 corner in the narrow arc), so a 32-lane load per line would leave most lanes idle
+        const int wsub = gl / 6, wsl = gl - 6 * wsub;
+        const int wv = ra - 2 + wsub;
         for (int part = 0; part < 2; part++) {
             if (part == 1 && b_end <= kAzBins) break;
-            // rows in two sub-batches (3 + 2): the loads of a sub-batch are issued back to back
-#pragma unroll
-            for (int v0 = 0; v0 < 5; v0 += 3) {
-                int r0[3], r1[3];
-                float4 v3[3];
-#pragma unroll
-                for (int w = 0; w < 3; w++) {
-                    const int vi = v0 + w;
-                    r0[w] = 0; r1[w] = 0;
-                    v3[w] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-                    if (vi < 5) {
-                        const int rv = __shfl(part ? ub : ua, vi, kGroup);
-                        r0[w] = rv & 0x1ffff; r1[w] = r0[w] + (rv >> 17);
-                        if (r0[w] + gl < r1[w]) v3[w] = lb_pts[r0[w] + gl];
-                    }
-                }
-#pragma unroll
-                for (int w = 0; w < 3; w++) {
-                    const int vi = v0 + w;
-                    if (vi >= 5) continue;
-                    const int v = ra - 2 + vi;
-                    if (r0[w] + gl < r1[w]) walk_point(v3[w], v, ra, closest, w_lo, w_hi, edge, qx, qy, qz, bs, bo);
-                    for (int i = r0[w] + gl + kGroup; i < r1[w]; i += kGroup) walk_point(lb_pts[i], v, ra, closest, w_lo, w_hi, edge, qx, qy, qz, bs, bo);
-                }
+            const int rv = __shfl(part ? ub : ua, min(wsub, 4), kGroup);
+            const int r0 = rv & 0x1ffff, cnw = wsub < 5 ? rv >> 17 : 0;
+            int i = wsl;
+            while (__any(i < cnw)) {
+                float4 v0 = make_float4(0.f, 0.f, 0.f, __int_as_float(-1)), v1 = v0;
+                if (i < cnw) v0 = lb_pts[r0 + i];
+                if (i + 6 < cnw) v1 = lb_pts[r0 + i + 6];
+                if (i < cnw) walk_point(v0, wv, ra, closest, w_lo, w_hi, edge, qx, qy, qz, bs, bo);
+                if (i + 6 < cnw) walk_point(v1, wv, ra, closest, w_lo, w_hi, edge, qx, qy, qz, bs, bo);
+                i += 12;
             }
         }
         same = group_min_u64(bs, gbase);
