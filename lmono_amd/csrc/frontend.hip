@@ -789,10 +789,33 @@ __global__ __launch_bounds__(256) void k_compact(BatchView b)
     __shared__ int pre_sh[NE + 1], pre_ls[NE + 1], pre_fl[NE + 1], pre_lf[kMaxRings + 1];
     const int *nsh = b.sel_sharp_n + s * NE;
     const int *nfl = b.sel_flat_n + s * NE;
-    if (tid == 0) { int a = 0; for (int e = 0; e < NE; e++) { pre_sh[e] = a; a += min(nsh[e], 2); } pre_sh[NE] = a; }
-    if (tid == 64) { int a = 0; for (int e = 0; e < NE; e++) { pre_ls[e] = a; a += nsh[e]; } pre_ls[NE] = a; }
-    if (tid == 128) { int a = 0; for (int e = 0; e < NE; e++) { pre_fl[e] = a; a += nfl[e]; } pre_fl[NE] = a; }
-    if (tid == 192) { int a = 0; for (int r = 0; r < kMaxRings; r++) { pre_lf[r] = a; a += b.lf_n[s * 64 + r]; } pre_lf[kMaxRings] = a; }
+    // four exclusive prefixes, one per wave: (ring, sector) counts of sharp (<= 2), less sharp, flat; ring counts of less flat
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        constexpr int kPer = NE / 64;   // 6 consecutive entries per lane
+        int c[kPer], sum = 0;
+#pragma unroll
+        for (int q = 0; q < kPer; q++) {
+            const int e = lane * kPer + q;
+            int v = 0;
+            if (wave == 0) v = min(nsh[e], 2);
+            else if (wave == 1) v = nsh[e];
+            else if (wave == 2) v = nfl[e];
+            else if (e < kMaxRings) v = b.lf_n[s * 64 + e];
+            c[q] = v; sum += v;
+        }
+        const int incl = wave_scan_incl(sum);
+        int run = incl - sum;
+        int *dst = wave == 0 ? pre_sh : (wave == 1 ? pre_ls : (wave == 2 ? pre_fl : pre_lf));
+        const int n_e = wave == 3 ? kMaxRings : NE;
+#pragma unroll
+        for (int q = 0; q < kPer; q++) {
+            const int e = lane * kPer + q;
+            if (e < n_e) dst[e] = run;
+            run += c[q];
+        }
+        if (lane == 63) dst[n_e] = run;
+    }
     __syncthreads();
     const float4 *cl = b.cloud + off;
     float4 *sharp = b.sharp + (size_t)s * kMaxSharp;
@@ -801,32 +824,77 @@ __global__ __launch_bounds__(256) void k_compact(BatchView b)
     float4 *lf = b.less_flat + off;
     const int *ssel = b.sel_sharp + (size_t)s * NE * 20;
     const int *fsel = b.sel_flat + (size_t)s * NE * 4;
+    // line tables of the two "last" clouds are gathered while the points pass through (first / last index of every line)
+    __shared__ int s_first[2][66], s_last[2][66], s_flag[2], s_rb[kMaxRings + 1];
+    if (tid < 66) { s_first[0][tid] = INT_MAX; s_last[0][tid] = -1; s_first[1][tid] = INT_MAX; s_last[1][tid] = -1; }
+    if (tid < 2) s_flag[tid] = 0;
+    if (tid >= 128 && tid < 128 + kMaxRings + 1) s_rb[tid - 128] = b.ring_begin[s * 65 + tid - 128];
+    __syncthreads();
     for (int x = tid; x < NE * 20; x += 256) {
         const int e = x / 20, k = x % 20;
         if (k < nsh[e]) {
             const float4 p = cl[ssel[x]];
-            ls[pre_ls[e] + k] = p;
+            const int pos = pre_ls[e] + k;
+            ls[pos] = p;
             if (k < 2) sharp[pre_sh[e] + k] = p;
+            int v = (int)p.w;
+            v = v < 0 ? 0 : (v > 65 ? 65 : v);
+            atomicMin(&s_first[0][v], pos);
+            atomicMax(&s_last[0][v], pos);
         }
     }
     for (int x = tid; x < NE * 4; x += 256) {
         const int e = x / 4, k = x % 4;
         if (k < nfl[e]) flat[pre_fl[e] + k] = cl[fsel[x]];
     }
-    const int *rb = b.ring_begin + s * 65;
-    for (int r = 0; r < kMaxRings; r++) {
-        const int cnt = pre_lf[r + 1] - pre_lf[r];
-        const float4 *src = b.lf_tmp + off + rb[r];
-        for (int i = tid; i < cnt; i += 256) lf[pre_lf[r] + i] = src[i];
+    // less-flat cloud = the rings' voxel outputs back to back: every thread finds the ring of its output index by a binary
+    // search over the ring prefix (all loads independent, four per thread in flight)
+    const int n_lf = pre_lf[kMaxRings];
+    for (int j0 = tid; j0 < n_lf; j0 += 4 * 256) {
+        float4 v4[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int j = j0 + 256 * q;
+            v4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j < n_lf) {
+                int lo = 0, hi = kMaxRings;
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pre_lf[mid] <= j) lo = mid; else hi = mid; }
+                v4[q] = b.lf_tmp[off + s_rb[lo] + (j - pre_lf[lo])];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int j = j0 + 256 * q;
+            if (j < n_lf) {
+                lf[j] = v4[q];
+                int v = (int)v4[q].w;
+                v = v < 0 ? 0 : (v > 65 ? 65 : v);
+                atomicMin(&s_first[1][v], j);
+                atomicMax(&s_last[1][v], j);
+            }
+        }
     }
     if (tid == 0) {
         b.feat_n[s * 4 + 0] = pre_sh[NE]; b.feat_n[s * 4 + 1] = pre_ls[NE];
-        b.feat_n[s * 4 + 2] = pre_fl[NE]; b.feat_n[s * 4 + 3] = pre_lf[kMaxRings];
+        b.feat_n[s * 4 + 2] = pre_fl[NE]; b.feat_n[s * 4 + 3] = n_lf;
     }
     __syncthreads();
-    __shared__ int s_first[66], s_last[66], s_flag;
-    line_tables(ls, pre_ls[NE], b.line_first_ge + (size_t)(s * 2 + 0) * 66, b.line_last_le + (size_t)(s * 2 + 0) * 66, b.status + s, tid, s_first, s_last, &s_flag);
-    line_tables(lf, pre_lf[kMaxRings], b.line_first_ge + (size_t)(s * 2 + 1) * 66, b.line_last_le + (size_t)(s * 2 + 1) * 66, b.status + s, tid, s_first, s_last, &s_flag);
+    // irregular iff some line a >= b + 3 starts before line b ends (see line_tables)
+    for (int x = tid; x < 2 * 66 * 66; x += 256) {
+        const int cld = x / (66 * 66), y = x % (66 * 66), a = y / 66, bb = y % 66;
+        if (a >= bb + 3 && s_first[cld][a] < s_last[cld][bb]) s_flag[cld] = 1;
+    }
+    __syncthreads();
+    if (tid == 0 || tid == 64) {
+        const int cld = tid >> 6;
+        const int n = cld ? n_lf : pre_ls[NE];
+        int *first_ge = b.line_first_ge + (size_t)(s * 2 + cld) * 66, *last_le = b.line_last_le + (size_t)(s * 2 + cld) * 66;
+        int m = n;
+        for (int t = 65; t >= 0; t--) { m = min(m, s_first[cld][t] == INT_MAX ? n : s_first[cld][t]); first_ge[t] = m; }
+        int M = -1;
+        for (int t = 0; t <= 65; t++) { M = max(M, s_last[cld][t]); last_le[t] = M; }
+        if (s_flag[cld]) atomicOr(b.status + s, kStatusIrregularLines);
+    }
 }
 
 } // namespace lmono
