@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256) void k_select(BatchView b)
 // Two instantiations run back to back: <9 slots, 2048 buckets> takes the rings of <= 2304 points (every HDL-64 ring: ~80 VGPRs,
 // 27 KB of LDS, 6 workgroups per CU) and appends a ring it cannot take (more points, or > 1024 segments: bitonic network) to a
 // work list; <16 slots, 4096 buckets> runs as a small fixed grid over that list (normally empty).
-constexpr int kVoxBucketSegs = 1024;
+constexpr int kVoxBucketSegsBig = 1024;   // bucket-sort capacity (segments) of the big instantiation; the small one takes its whole ring
 constexpr int kVoxSmallSlots = 9, kVoxSmallBits = 11;
 constexpr int kVoxBigSlots = kRingCap / 256, kVoxBigBits = 12;
 constexpr int kVoxBigGrid = 512;    // workgroups of the second instantiation; each walks the work list with this stride
@@ -416,12 +416,13 @@ constexpr int kVoxBigGrid = 512;    // workgroups of the second instantiation; e
 // 256 scratch ints, the continuation bitmap and the last cells
 template <int kSlots, int kBits, bool kSmall>
 struct VoxCfg {
-    static constexpr int kKeyBytes = kSmall ? 2 * kVoxBucketSegs * 8 + (1 << kBits) * 4 : kRingCap * 8;
+    static constexpr int kSegCap = kSmall ? 256 * kSlots : kVoxBucketSegsBig;
+    static constexpr int kKeyBytes = kSmall ? 2 * kSegCap * 8 + (1 << kBits) * 4 : kRingCap * 8;
     static constexpr int kLds = kKeyBytes + 1024 + kSlots * 4 * 8 + kSlots * 4 * 4;
 };
 constexpr int kVoxLdsSmall = VoxCfg<kVoxSmallSlots, kVoxSmallBits, true>::kLds;
 constexpr int kVoxLdsBig = VoxCfg<kVoxBigSlots, kVoxBigBits, false>::kLds;
-static_assert(2 * kVoxBucketSegs * 8 + (1 << kVoxBigBits) * 4 <= kRingCap * 8, "bucket sort scratch must fit the key region");
+static_assert(2 * kVoxBucketSegsBig * 8 + (1 << kVoxBigBits) * 4 <= kRingCap * 8, "bucket sort scratch must fit the key region");
 #ifdef LMONO_VOX_PROF
 #define VT(i) { if (blockIdx.x == 20 && blockIdx.y == 3 && threadIdx.x == 0) vt[i] = clock64(); }
 #else
@@ -464,6 +465,7 @@ __device__ __forceinline__ void voxel_ring(BatchView &b, int r, int s)
     constexpr int kVoxBuckets = 1 << kVoxBucketBits;
     constexpr int kCap = 256 * kVoxSlots;
     constexpr int kKeyBytes = VoxCfg<kVoxSlots, kVoxBucketBits, kSmall>::kKeyBytes;
+    constexpr int kVoxBucketSegs = VoxCfg<kVoxSlots, kVoxBucketBits, kSmall>::kSegCap;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t off = b.off[s];
 #ifdef LMONO_VOX_PROF
@@ -646,7 +648,8 @@ __device__ __forceinline__ void voxel_ring(BatchView &b, int r, int s)
     VT(4)
     // ---- runs of equal cell over the sorted segments -> output voxels; vstart[o] = first sorted segment of voxel o
     int *vstart = bucket_path ? (int *)(keys + kVoxBucketSegs) : nullptr;   // the scattered copy is dead now
-    int n_out = 0, obase[4];
+    constexpr int kRounds = (kVoxBucketSegs + 255) / 256;
+    int n_out = 0, obase[kRounds];
     {
         const int rounds = (nseg + 255) / 256;
         // voxel starts per round and wave -> prefix in sorted order (round, wave, lane)
@@ -661,17 +664,19 @@ __device__ __forceinline__ void voxel_ring(BatchView &b, int r, int s)
     float4 *outp = b.lf_tmp + off + rbeg;
     VT(5)
     if (bucket_path) {
-        // nseg <= 1024: at most 4 rounds
         const int rounds = (nseg + 255) / 256;
         int total = 0;
-        for (int j = 0; j < rounds; j++)
-            for (int w = 0; w < 4; w++) { if (j * 4 + w < 16) { if (w == wave) obase[j & 3] = total; total += scr[128 + j * 4 + w]; } }
+#pragma unroll
+        for (int j = 0; j < kRounds; j++)
+            for (int w = 0; w < 4; w++) { if (j < rounds) { if (w == wave) obase[j] = total; total += scr[128 + j * 4 + w]; } }
         n_out = total;
-        for (int j = 0; j < rounds; j++) {
+#pragma unroll
+        for (int j = 0; j < kRounds; j++) {
+            if (j >= rounds) break;
             const int t = tid + 256 * j;
             const bool st = t < nseg && (t == 0 || (unsigned int)(keys[t] >> 32) != (unsigned int)(keys[t - 1] >> 32));
             const unsigned long long sm = __ballot(st);
-            if (st) vstart[obase[j & 3] + __popcll(sm & ((1ull << lane) - 1ull))] = t;
+            if (st) vstart[obase[j] + __popcll(sm & ((1ull << lane) - 1ull))] = t;
         }
         __syncthreads();
         // one voxel per thread and round: its segments in sorted order, every segment's points in index order
