@@ -382,8 +382,9 @@ __global__ __launch_bounds__(256) void k_select(BatchView b)
         const int sp = 5 + span * j / 6;
         const int ep = 5 + span * (j + 1) / 6 - 1;
         const int slen = ep - sp + 1;
-        // HDL-64-sized sectors (<= 384 points) take the 6-slot instantiation, longer rings the full one
-        if (slen <= 6 * 64) select_sector<6>(lane, j, sp, slen, rbeg, curv, picked, label, gap, sel_sh, sel_sh_n, sel_fl, sel_fl_n);
+        // HDL-64-sized sectors (<= 320 / <= 384 points) take the 5- / 6-slot instantiations, longer rings the full one
+        if (slen <= 5 * 64) select_sector<5>(lane, j, sp, slen, rbeg, curv, picked, label, gap, sel_sh, sel_sh_n, sel_fl, sel_fl_n);
+        else if (slen <= 6 * 64) select_sector<6>(lane, j, sp, slen, rbeg, curv, picked, label, gap, sel_sh, sel_sh_n, sel_fl, sel_fl_n);
         else select_sector<kSelMaxPerLane>(lane, j, sp, slen, rbeg, curv, picked, label, gap, sel_sh, sel_sh_n, sel_fl, sel_fl_n);
     }
     for (int i = lane; i < len; i += 64) b.label[off + rbeg + i] = label[i];
