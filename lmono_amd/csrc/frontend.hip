@@ -56,10 +56,9 @@ __global__ __launch_bounds__(1024) void k_ring_sort(BatchView b)
     const float4 *in = b.in + off;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __shared__ int s_first, s_last, s_half;
-    __shared__ int s_cnt[64], s_base[64], s_tile[64];
-    __shared__ int s_wcnt[4][16][64];
+    __shared__ int s_cnt[64], s_base[64];
+    __shared__ int s_hist[16][64];      // pass 1: points per (wave, ring); pass 2: next output position of (wave, ring)
     __shared__ float s_ori[2];
-    if (tid < 64) s_cnt[tid] = 0;
     if (tid == 0) { s_first = INT_MAX; s_last = -1; s_half = INT_MAX; }
     __syncthreads();
     const float mr2 = b.min_range * b.min_range;
@@ -104,19 +103,25 @@ __global__ __launch_bounds__(1024) void k_ring_sort(BatchView b)
     const float startOri = s_ori[0], endOri = s_ori[1];
     const int n_lines = b.n_lines;
     int lh = INT_MAX;
+    // Every wave owns one contiguous chunk of the scan in BOTH passes: pass 1 leaves a per-(wave, ring) histogram, a prefix
+    // over (ring, wave) turns it into the first output position of every (wave, ring), and pass 2 is then a barrier-free
+    // stable multisplit: a wave walks its chunk in input order with its own running counters.
+    const int chunk = (((n + 15) / 16) + 255) & ~255;          // points per wave, a multiple of the 256-point round
+    const int c_lo = wave * chunk, c_hi = min(c_lo + chunk, n);
+    for (int i = tid; i < 16 * 64; i += 1024) (&s_hist[0][0])[i] = 0;
+    __syncthreads();
     // four points per thread and round: their loads are in flight together (the sweep is bandwidth-bound)
-    for (int i0 = tid; i0 < n; i0 += 4 * 1024) {
+    for (int t0 = c_lo; t0 < c_hi; t0 += 256) {
         float4 pq[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) { const int i = i0 + 1024 * q; pq[q] = i < n ? in[i] : make_float4(NAN, 0.f, 0.f, 0.f); }
+        for (int q = 0; q < 4; q++) { const int i = t0 + 64 * q + lane; pq[q] = i < c_hi ? in[i] : make_float4(NAN, 0.f, 0.f, 0.f); }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int i = i0 + 1024 * q;
-            if (i >= n) continue;
+            const int i = t0 + 64 * q + lane;
             const float4 p = pq[q];
             int id = -1;
             float ori = 0.f;
-            if (point_valid(p, mr2)) {
+            if (i < c_hi && point_valid(p, mr2)) {
                 const float angle = (float)(det_atan((double)p.z / sqrt((double)(p.x * p.x + p.y * p.y))) * 180.0 / LM_PI);
                 bool discard;
                 const int r = ring_of(angle, n_lines, discard);
@@ -127,15 +132,29 @@ __global__ __launch_bounds__(1024) void k_ring_sort(BatchView b)
                     if ((double)o1 < (double)startOri - LM_PI / 2.0) o1 = (float)((double)o1 + 2.0 * LM_PI);
                     else if ((double)o1 > (double)startOri + LM_PI * 3.0 / 2.0) o1 = (float)((double)o1 - 2.0 * LM_PI);
                     if ((double)(o1 - startOri) > LM_PI) lh = min(lh, i);
-                    atomicAdd(&s_cnt[id], 1);
                 }
             }
-            b.ring_tmp[off + i] = (int8_t)id;
-            b.ori_tmp[off + i] = ori;
+            if (i < c_hi) { b.ring_tmp[off + i] = (int8_t)id; b.ori_tmp[off + i] = ori; }
+            // histogram of the sub-tile by ballot matching (ring-major input: one or two rings per 64 points)
+            unsigned long long rem = __ballot(id >= 0);
+            while (rem) {
+                const int src = __ffsll((long long)rem) - 1;
+                const int k = __shfl(id, src);
+                const unsigned long long m = __ballot(id == k);
+                if (lane == src) s_hist[wave][k] += __popcll(m);
+                rem &= ~m;
+            }
         }
     }
     lh = wave_min_i(lh);
     if (lane == 0 && lh != INT_MAX) atomicMin(&s_half, lh);
+    __syncthreads();
+    // ring totals -> ring_begin; first output position of every (wave, ring)
+    if (tid < 64) {
+        int t = 0;
+        for (int w = 0; w < 16; w++) t += s_hist[w][tid];
+        s_cnt[tid] = t;
+    }
     __syncthreads();
     if (tid == 0) {
         int t = 0;
@@ -144,49 +163,46 @@ __global__ __launch_bounds__(1024) void k_ring_sort(BatchView b)
         b.n_cloud[s] = t;
     }
     __syncthreads();
+    {
+        const int w = tid >> 6, r = tid & 63;      // one (wave, ring) per thread
+        int before = s_base[r];
+        for (int w2 = 0; w2 < w; w2++) before += s_hist[w2][r];
+        __syncthreads();
+        s_hist[w][r] = before;
+    }
+    __syncthreads();
     const int half = s_half;
     RT(2)
-    // stable scatter in super-tiles of 4096 points (sub-tile q = points t0 + 1024 q + tid): one round of barriers per
-    // super-tile, the four sub-tiles' loads in flight together
-    for (int t0 = 0; t0 < n; t0 += 4 * 1024) {
-        int id[4], rank[4];
+    for (int t0 = c_lo; t0 < c_hi; t0 += 256) {
+        int id[4], dstp[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) { const int i = t0 + 1024 * q + tid; id[q] = (i < n) ? (int)b.ring_tmp[off + i] : -1; }
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            rank[q] = 0;
-            s_wcnt[q][wave][lane] = 0;
-            unsigned long long rem = __ballot(id[q] >= 0);
-            while (rem) {
-                const int src = __ffsll((long long)rem) - 1;
-                const int k = __shfl(id[q], src);
-                const unsigned long long m = __ballot(id[q] == k);
-                if (id[q] == k) rank[q] = __popcll(m & ((1ull << lane) - 1ull));
-                if (lane == src) s_wcnt[q][wave][k] = __popcll(m);
-                rem &= ~m;
-            }
-        }
-        __syncthreads();
-        if (tid < 64) {
-            // exclusive prefix over (sub-tile, wave) for ring tid: input order = sub-tile major, then wave, then lane
-            int acc = 0;
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-                for (int w = 0; w < 16; w++) { const int c = s_wcnt[q][w][tid]; s_wcnt[q][w][tid] = acc; acc += c; }
-            s_tile[tid] = acc;
-        }
-        __syncthreads();
+        for (int q = 0; q < 4; q++) { const int i = t0 + 64 * q + lane; id[q] = (i < c_hi) ? (int)b.ring_tmp[off + i] : -1; }
         float4 pq[4];
         float oq[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int i = t0 + 1024 * q + tid;
+            const int i = t0 + 64 * q + lane;
             pq[q] = make_float4(0.f, 0.f, 0.f, 0.f); oq[q] = 0.f;
             if (id[q] >= 0) { pq[q] = in[i]; oq[q] = b.ori_tmp[off + i]; }
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int i = t0 + 1024 * q + tid;
+            dstp[q] = 0;
+            unsigned long long rem = __ballot(id[q] >= 0);
+            while (rem) {
+                const int src = __ffsll((long long)rem) - 1;
+                const int k = __shfl(id[q], src);
+                const unsigned long long m = __ballot(id[q] == k);
+                int base = 0;
+                if (lane == src) { base = s_hist[wave][k]; s_hist[wave][k] = base + __popcll(m); }
+                base = __shfl(base, src);
+                if (id[q] == k) dstp[q] = base + __popcll(m & ((1ull << lane) - 1ull));
+                rem &= ~m;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int i = t0 + 64 * q + lane;
             if (id[q] >= 0) {
                 const float4 p = pq[q];
                 float ori = oq[q];
@@ -200,12 +216,9 @@ __global__ __launch_bounds__(1024) void k_ring_sort(BatchView b)
                 }
                 const float relTime = (ori - startOri) / (endOri - startOri);
                 const float inten = (float)((double)id[q] + 0.1 * (double)relTime);
-                const int dst = s_base[id[q]] + s_wcnt[q][wave][id[q]] + rank[q];
-                b.cloud[off + dst] = make_float4(p.x, p.y, p.z, inten);
+                b.cloud[off + dstp[q]] = make_float4(p.x, p.y, p.z, inten);
             }
         }
-        __syncthreads();
-        if (tid < 64) s_base[tid] += s_tile[tid];
     }
     RT(3)
 #ifdef LMONO_RS_PROF
