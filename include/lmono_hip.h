@@ -57,7 +57,11 @@ int lmono_scanreg_batch(lmono_ctx *, lmono_scan_batch *, const float *xyzi_d, co
 int lmono_scanreg_batch_h(lmono_ctx *, lmono_scan_batch *, const float *xyzi_h, const int64_t *offsets_h,
                           int n_scans, int n_lines, float min_range);
 
-/* counts_h: [n_scans][6] = n_cloud, n_sharp, n_less_sharp, n_flat, n_less_flat, status          */
+/* counts_h: [n_scans][6] = n_cloud, n_sharp, n_less_sharp, n_flat, n_less_flat, status.
+ * status bits: 1 a ring holds more than LMONO_RING_CAP points (scan contributes no features); 2 a "last" cloud did not fit
+ * its hash grid (too many points, a table page without a free slot, or a cell beyond +-1024 m: that table is empty, the
+ * next scan finds no correspondences in it); 4 scan-line ids too disordered for the windowed walk and 16 a 1 m cell with
+ * more than 32767 points (both: the generic, slower search path is used, results unchanged); 8 walk truncated.       */
 int lmono_batch_counts(lmono_ctx *, lmono_scan_batch *, int32_t *counts_h);
 /* which: 0 ring-sorted cloud, 1 sharp, 2 less_sharp, 3 flat, 4 less_flat.  out_h: [cap][4] float32.
  * Returns the number of points copied (>= 0) or a negative error.                               */

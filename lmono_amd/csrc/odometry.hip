@@ -114,12 +114,12 @@ __global__ __launch_bounds__(1024) void k_grid_build(BatchView b)
     extern __shared__ __align__(16) unsigned int g_lds[];
     unsigned int *keys = g_lds;
     int *cnt = (int *)(g_lds + kGridPage);      // pass 1: points per cell; after the scan: write cursor
-    __shared__ int s_wsum[16], s_before, s_fail;
+    __shared__ int s_wsum[16], s_before, s_fail, s_occ;
     const unsigned int pm = (unsigned int)(P - 1);
 
     for (int p = p0; p < n_pages; p += pstep) {
         for (int i = tid; i < P; i += 1024) { keys[i] = kEmptyKey32; cnt[i] = 0; }
-        if (tid == 0) { s_before = 0; s_fail = 0; }
+        if (tid == 0) { s_before = 0; s_fail = 0; s_occ = 0; }
         __syncthreads();
         for (int pass = 0; pass < 2; pass++) {
             int before = 0;
@@ -200,11 +200,16 @@ __global__ __launch_bounds__(1024) void k_grid_build(BatchView b)
                 // exclusive prefix of the page's counts -> cursors (first output position of every cell)
                 const int per = P >> 10;                       // 1 .. 16 consecutive slots per thread
                 int c[16], sum = 0;
+                int occ = 0;
 #pragma unroll
-                for (int q = 0; q < 16; q++) { c[q] = q < per ? cnt[tid * per + q] : 0; sum += c[q]; }
+                for (int q = 0; q < 16; q++) { c[q] = q < per ? cnt[tid * per + q] : 0; sum += c[q]; occ += c[q] > 0 ? 1 : 0; }
                 const int incl = wave_scan_incl(sum);
                 if (lane == 63) s_wsum[wave] = incl;
+                // a page without a single empty slot would never end the probe sequence of an absent cell: treated as full
+                occ = wave_sum_i(occ);
+                if (lane == 0 && occ) atomicAdd(&s_occ, occ);
                 __syncthreads();
+                if (s_occ >= P) s_fail = 1;
                 int run = s_before + incl - sum;
                 for (int w = 0; w < wave; w++) run += s_wsum[w];
 #pragma unroll

@@ -203,6 +203,20 @@ def test_ring_longer_than_kernel_limit_is_flagged(gpu_ctx):
     assert cnt[0, 0] == n and cnt[0, 5] & 1 and cnt[0, 1] == 0 and cnt[0, 3] == 0
 
 
+def test_points_beyond_the_grid_code_range_are_flagged_not_fatal(oracle, gpu_ctx, small_seq):
+    """A return 1500 m away lies outside the +-1024 m range of the hash grid's 32-bit cell code: the table page of that
+    scan is written empty and status bit 2 is set; the run terminates and the other scans are unaffected."""
+    xyzi, off = small_seq["xyzi"].copy(), small_seq["off"]
+    a = xyzi[off[1]:off[2]]
+    # stretch a stretch of one ring radially (same direction, same ring id): smooth, so some of it survives as less-flat
+    a[200:260, :3] *= (1500.0 / np.linalg.norm(a[200:260, :3], axis=1))[:, None].astype(np.float32)
+    batch = _register(gpu_ctx, xyzi, off)
+    incr, poses = batch.odometry(1, 0)
+    cnt = batch.counts()
+    assert np.isfinite(incr).all() and np.isfinite(poses).all()
+    assert (cnt[[0, 2, 3], 5] & 2 == 0).all()
+
+
 def test_full_size_batch_properties(gpu_ctx, oracle):
     """32 full-resolution scans (size-independent properties at bench scale): sharp is a prefix-subset of less_sharp per
     sector, counts respect the per-sector caps, labels agree with the clouds, poses have unit quaternions."""
