@@ -366,10 +366,9 @@ __device__ __forceinline__ void select_sector(int lane, int j, int sp, int slen,
     if (lane == 0) sel_fl_n[j] = smallest;
 }
 
-__global__ __launch_bounds__(256) void k_select(BatchView b)
+// one ring by one wave; cap = ring points the wave's LDS slice (3 * cap bytes at smem_w) can hold
+__device__ __forceinline__ void select_ring(BatchView &b, int r, int s, int lane, unsigned char *smem_w, int cap, bool may_defer)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = blockIdx.x * 4 + wave, s = blockIdx.y;
     const int64_t off = b.off[s];
     const int *rb = b.ring_begin + s * 65;
     const int rbeg = rb[r], rend = rb[r + 1], len = rend - rbeg;
@@ -384,10 +383,14 @@ __global__ __launch_bounds__(256) void k_select(BatchView b)
         for (int i = lane; i < len; i += 64) b.label[off + rbeg + i] = 0;
         return;
     }
-    extern __shared__ __align__(16) unsigned char smem[];
-    unsigned char *picked = smem + wave * kSelWaveLds;
-    signed char *label = (signed char *)(picked + kRingCap);
-    unsigned char *gap = picked + 2 * kRingCap;
+    if (len > cap) {
+        // longer than this launch's LDS slice: left to the second launch (full-size slices, small grid over the work list)
+        if (may_defer && lane == 0) b.sel_todo[1 + atomicAdd(&b.sel_todo[0], 1)] = (s << 6) | r;
+        return;
+    }
+    unsigned char *picked = smem_w;
+    signed char *label = (signed char *)(picked + cap);
+    unsigned char *gap = picked + 2 * cap;
     const float *curv = b.curv + off + rbeg;
     for (int i = lane; i < len; i += 64) { picked[i] = 0; label[i] = 0; gap[i] = b.gap[off + rbeg + i]; }
     const int span = E - S;
@@ -401,6 +404,27 @@ __global__ __launch_bounds__(256) void k_select(BatchView b)
         else select_sector<kSelMaxPerLane>(lane, j, sp, slen, rbeg, curv, picked, label, gap, sel_sh, sel_sh_n, sel_fl, sel_fl_n);
     }
     for (int i = lane; i < len; i += 64) b.label[off + rbeg + i] = label[i];
+}
+
+// Two launches: the first gives every wave a slice for kSelSmallCap points (every HDL-64 ring; 27 KB per workgroup instead of
+// 48 KB: 5 instead of 3 waves per SIMD) over the whole (ring, scan) grid and defers longer rings to a work list; the second
+// runs full-size slices as a small fixed grid over that list (normally empty).
+constexpr int kSelSmallCap = 2304, kSelBigGrid = 128;
+
+__global__ __launch_bounds__(256) void k_select(BatchView b, int cap, int from_list)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char *smem_w = smem + wave * 3 * cap;
+    if (!from_list) {
+        select_ring(b, blockIdx.x * 4 + wave, blockIdx.y, lane, smem_w, cap, true);
+    } else {
+        const int n_todo = b.sel_todo[0];
+        for (int k = blockIdx.x * 4 + wave; k < n_todo; k += gridDim.x * 4) {
+            const int e = b.sel_todo[1 + k];
+            select_ring(b, e & 63, e >> 6, lane, smem_w, cap, false);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -145,7 +145,7 @@ extern "C" lmono_scan_batch *lmono_batch_create(lmono_ctx *c, int n_cap, int64_t
     ok = ok && dalloc(b, v.ring_begin, N * 65) && dalloc(b, v.n_cloud, N) && dalloc(b, v.status, N);
     ok = ok && dalloc(b, v.sel_sharp, N * 64 * 6 * 20) && dalloc(b, v.sel_sharp_n, N * 64 * 6);
     ok = ok && dalloc(b, v.sel_flat, N * 64 * 6 * 4) && dalloc(b, v.sel_flat_n, N * 64 * 6);
-    ok = ok && dalloc(b, v.lf_tmp, T) && dalloc(b, v.lf_n, N * 64) && dalloc(b, v.vox_todo, N * 64 + 1);
+    ok = ok && dalloc(b, v.lf_tmp, T) && dalloc(b, v.lf_n, N * 64) && dalloc(b, v.vox_todo, N * 64 + 1) && dalloc(b, v.sel_todo, N * 64 + 1);
     ok = ok && dalloc(b, v.sharp, N * kMaxSharp) && dalloc(b, v.less_sharp, N * kMaxLessSharp);
     ok = ok && dalloc(b, v.flat, N * kMaxFlat) && dalloc(b, v.less_flat, T);
     ok = ok && dalloc(b, v.feat_n, N * 4) && dalloc(b, v.line_first_ge, N * 2 * 66) && dalloc(b, v.line_last_le, N * 2 * 66);
@@ -222,6 +222,7 @@ extern "C" int lmono_scanreg_batch(lmono_ctx *c, lmono_scan_batch *b, const floa
     HIP_TRY(c, hipMemcpyAsync(b->off_d, b->off_h.data(), sizeof(int64_t) * (n_scans + 1), hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemsetAsync(v.status, 0, sizeof(int) * n_scans, st));
     HIP_TRY(c, hipMemsetAsync(v.vox_todo, 0, sizeof(int), st));
+    HIP_TRY(c, hipMemsetAsync(v.sel_todo, 0, sizeof(int), st));
     HIP_TRY(c, hipEventRecord(c->ev[0], st));
     hipLaunchKernelGGL(k_ring_sort, dim3(n_scans), dim3(1024), 0, st, v);
     HIP_TRY(c, hipEventRecord(c->ev[1], st));
@@ -233,7 +234,8 @@ extern "C" int lmono_scanreg_batch(lmono_ctx *c, lmono_scan_batch *b, const floa
     HIP_TRY(c, hipMemsetAsync(v.sel_sharp_n, 0, sizeof(int) * (size_t)n_scans * 64 * 6, st));
     HIP_TRY(c, hipMemsetAsync(v.sel_flat_n, 0, sizeof(int) * (size_t)n_scans * 64 * 6, st));
     HIP_TRY(c, hipMemsetAsync(v.lf_n, 0, sizeof(int) * (size_t)n_scans * 64, st));
-    hipLaunchKernelGGL(k_select, dim3((n_rings + 3) / 4, n_scans), dim3(256), 4 * kSelWaveLds, st, v);
+    hipLaunchKernelGGL(k_select, dim3((n_rings + 3) / 4, n_scans), dim3(256), 4 * 3 * kSelSmallCap, st, v, kSelSmallCap, 0);
+    hipLaunchKernelGGL(k_select, dim3(kSelBigGrid), dim3(256), 4 * kSelWaveLds, st, v, (int)kRingCap, 1);
     HIP_TRY(c, hipEventRecord(c->ev[3], st));
     hipLaunchKernelGGL((k_voxel<kVoxSmallSlots, kVoxSmallBits, true>), dim3(n_rings, n_scans), dim3(256), kVoxLdsSmall, st, v);
     hipLaunchKernelGGL((k_voxel<kVoxBigSlots, kVoxBigBits, false>), dim3(kVoxBigGrid), dim3(256), kVoxLdsBig, st, v);
