@@ -334,10 +334,11 @@ __device__ __forceinline__ void select_sector(int lane, int j, int sp, int slen,
         if (largest > 20) break;
         if (lane == 0) { sel_sh[j * 20 + largest - 1] = rbeg + pind; label[pind] = largest <= 2 ? 2 : 1; }
         if (lane <= lf + lb) picked[pind - lb + lane] = 1;
-#pragma unroll
-        for (int m = 0; m < M; m++) {
-            const int idx = sp + lane + 64 * m;
-            if (idx >= pind - lb && idx <= pind + lf) dead |= 1u << m;
+        {
+            // the suppressed range [pind - lb, pind + lf] is shorter than 64, so it meets at most one slot of this lane
+            const int a = pind - lb - sp - lane;                 // slot m is hit iff a <= 64 m <= a + lb + lf
+            const int m0 = (a + 63) >> 6;
+            if (m0 >= 0 && m0 < M && 64 * m0 <= a + lb + lf) dead |= 1u << m0;
         }
     }
     if (lane == 0) sel_sh_n[j] = largest > 20 ? 20 : largest;
@@ -357,10 +358,11 @@ __device__ __forceinline__ void select_sector(int lane, int j, int sp, int slen,
         smallest++;
         if (smallest >= 4) break;
         if (lane <= lf + lb) picked[pind - lb + lane] = 1;
-#pragma unroll
-        for (int m = 0; m < M; m++) {
-            const int idx = sp + lane + 64 * m;
-            if (idx >= pind - lb && idx <= pind + lf) dead |= 1u << m;
+        {
+            // the suppressed range [pind - lb, pind + lf] is shorter than 64, so it meets at most one slot of this lane
+            const int a = pind - lb - sp - lane;                 // slot m is hit iff a <= 64 m <= a + lb + lf
+            const int m0 = (a + 63) >> 6;
+            if (m0 >= 0 && m0 < M && 64 * m0 <= a + lb + lf) dead |= 1u << m0;
         }
     }
     if (lane == 0) sel_fl_n[j] = smallest;
