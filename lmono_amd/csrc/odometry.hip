@@ -444,8 +444,8 @@ __global__ __launch_bounds__(256) void k_line_index(BatchView b)
     const float4 *src = surf ? b.less_flat + b.off[s] : b.less_sharp + (size_t)s * kMaxLessSharp;
     float4 *dst = surf ? b.lbs_pts + b.off[s] : b.lbc_pts + (size_t)s * kMaxLessSharp;
     int *table = b.lb_start + (size_t)(s * 2 + (surf ? 1 : 0)) * (kLineKeys + 1);
-    __shared__ int s_cnt[kLineKeys], s_fill[kLineKeys], s_wsum[4];
-    for (int i = tid; i < kLineKeys; i += 256) { s_cnt[i] = 0; s_fill[i] = 0; }
+    __shared__ int s_cnt[kLineKeys], s_wsum[4];      // points per (line, bin); after the prefix: write cursor of the bucket
+    for (int i = tid; i < kLineKeys; i += 256) s_cnt[i] = 0;
     __syncthreads();
     for (int i = tid; i < n; i += 256) {
         const float4 p = src[i];
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256) void k_line_index(BatchView b)
     for (int i = tid; i < n; i += 256) {
         const float4 p = src[i];
         const int key = line_of(p.w) * kAzBins + az_bin(p.x, p.y);
-        const int d = s_cnt[key] + atomicAdd(&s_fill[key], 1);
+        const int d = atomicAdd(&s_cnt[key], 1);
         dst[d] = make_float4(p.x, p.y, p.z, __int_as_float(i));
     }
 }
