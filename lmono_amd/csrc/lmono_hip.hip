@@ -244,7 +244,7 @@ extern "C" int lmono_scanreg_batch(lmono_ctx *c, lmono_scan_batch *b, const floa
     HIP_TRY(c, hipEventRecord(c->ev[5], st));
     hipLaunchKernelGGL(k_grid_build, dim3(n_scans, 1 + kGridPar), dim3(1024), kGridLds, st, v);
     HIP_TRY(c, hipEventRecord(c->ev[6], st));
-    hipLaunchKernelGGL(k_line_index, dim3(n_scans, 2), dim3(256), 0, st, v);
+    hipLaunchKernelGGL(k_line_index, dim3(n_scans, 2), dim3(kLiT), 0, st, v);
     HIP_TRY(c, hipEventRecord(c->ev[7], st));
     int rc = check_launch(c, "scanreg kernels");
     if (rc) return rc;

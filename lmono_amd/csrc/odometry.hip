@@ -435,7 +435,8 @@ __device__ __forceinline__ int line_of(float w)
     return v < 0 ? 0 : (v > 65 ? 65 : v);
 }
 
-__global__ __launch_bounds__(256) void k_line_index(BatchView b)
+constexpr int kLiT = 512;     // threads of k_line_index
+__global__ __launch_bounds__(kLiT) void k_line_index(BatchView b)
 {
     const int s = blockIdx.x;
     const bool surf = blockIdx.y == 1;
@@ -444,16 +445,21 @@ __global__ __launch_bounds__(256) void k_line_index(BatchView b)
     const float4 *src = surf ? b.less_flat + b.off[s] : b.less_sharp + (size_t)s * kMaxLessSharp;
     float4 *dst = surf ? b.lbs_pts + b.off[s] : b.lbc_pts + (size_t)s * kMaxLessSharp;
     int *table = b.lb_start + (size_t)(s * 2 + (surf ? 1 : 0)) * (kLineKeys + 1);
-    __shared__ int s_cnt[kLineKeys], s_wsum[4];      // points per (line, bin); after the prefix: write cursor of the bucket
-    for (int i = tid; i < kLineKeys; i += 256) s_cnt[i] = 0;
+    __shared__ int s_cnt[kLineKeys], s_wsum[kLiT / 64];      // points per (line, bin); after the prefix: write cursor of the bucket
+    for (int i = tid; i < kLineKeys; i += kLiT) s_cnt[i] = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += 256) {
-        const float4 p = src[i];
-        atomicAdd(&s_cnt[line_of(p.w) * kAzBins + az_bin(p.x, p.y)], 1);
+    // four points per thread and round, their loads in flight together
+    for (int i0 = tid; i0 < n; i0 += 4 * kLiT) {
+        float4 p[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const int i = i0 + kLiT * q; p[q] = i < n ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (i0 + kLiT * q < n) atomicAdd(&s_cnt[line_of(p[q].w) * kAzBins + az_bin(p[q].x, p[q].y)], 1);
     }
     __syncthreads();
-    // exclusive prefix over kLineKeys = 4224 counters: 17 per thread (last thread padded)
-    constexpr int kPer = (kLineKeys + 255) / 256;
+    // exclusive prefix over the kLineKeys = 8448 counters: 17 consecutive counters per thread (last threads padded)
+    constexpr int kPer = (kLineKeys + kLiT - 1) / kLiT;
     int local = 0;
     for (int i = 0; i < kPer; i++) { const int idx = tid * kPer + i; if (idx < kLineKeys) local += s_cnt[idx]; }
     const int incl = wave_scan_incl(local);
@@ -465,13 +471,21 @@ __global__ __launch_bounds__(256) void k_line_index(BatchView b)
         const int idx = tid * kPer + i;
         if (idx < kLineKeys) { const int cnt = s_cnt[idx]; s_cnt[idx] = run; table[idx] = run; run += cnt; }
     }
-    if (tid == 255) table[kLineKeys] = n;
+    if (tid == kLiT - 1) table[kLineKeys] = n;
     __syncthreads();
-    for (int i = tid; i < n; i += 256) {
-        const float4 p = src[i];
-        const int key = line_of(p.w) * kAzBins + az_bin(p.x, p.y);
-        const int d = atomicAdd(&s_cnt[key], 1);
-        dst[d] = make_float4(p.x, p.y, p.z, __int_as_float(i));
+    for (int i0 = tid; i0 < n; i0 += 4 * kLiT) {
+        float4 p[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const int i = i0 + kLiT * q; p[q] = i < n ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int i = i0 + kLiT * q;
+            if (i < n) {
+                const int key = line_of(p[q].w) * kAzBins + az_bin(p[q].x, p[q].y);
+                const int d = atomicAdd(&s_cnt[key], 1);
+                dst[d] = make_float4(p[q].x, p[q].y, p[q].z, __int_as_float(i));
+            }
+        }
     }
 }
 
