@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256) void k_select(BatchView b, int cap, int from_l
 // 27 KB of LDS, 6 workgroups per CU) and appends a ring it cannot take (more points, or > 1024 segments: bitonic network) to a
 // work list; <16 slots, 4096 buckets> runs as a small fixed grid over that list (normally empty).
 constexpr int kVoxBucketSegsBig = 1024;   // bucket-sort capacity (segments) of the big instantiation; the small one takes its whole ring
-constexpr int kVoxSmallSlots = 9, kVoxSmallBits = 11;
+constexpr int kVoxSmallSlots = 9, kVoxSmallBits = 10;
 constexpr int kVoxBigSlots = kRingCap / 256, kVoxBigBits = 12;
 constexpr int kVoxBigGrid = 512;    // workgroups of the second instantiation; each walks the work list with this stride
 // LDS: key region (sorted keys | scattered copy | bucket counters; the big variant: kRingCap keys for the bitonic fallback),
@@ -457,7 +457,9 @@ constexpr int kVoxBigGrid = 512;    // workgroups of the second instantiation; e
 template <int kSlots, int kBits, bool kSmall>
 struct VoxCfg {
     static constexpr int kSegCap = kSmall ? 256 * kSlots : kVoxBucketSegsBig;
-    static constexpr int kKeyBytes = kSmall ? 2 * kSegCap * 8 + (1 << kBits) * 4 : kRingCap * 8;
+    // small: scattered keys (u64) | sorted order as u16 positions into them | bucket counters, later the voxel starts (u16)
+    static constexpr int kHistBytes = (1 << kBits) * 4 > kSegCap * 2 ? (1 << kBits) * 4 : kSegCap * 2;
+    static constexpr int kKeyBytes = kSmall ? kSegCap * 8 + kSegCap * 2 + kHistBytes : kRingCap * 8;
     static constexpr int kLds = kKeyBytes + 1024 + kSlots * 4 * 8 + kSlots * 4 * 4;
 };
 constexpr int kVoxLdsSmall = VoxCfg<kVoxSmallSlots, kVoxSmallBits, true>::kLds;
@@ -598,7 +600,12 @@ __device__ __forceinline__ void voxel_ring(BatchView &b, int r, int s)
         cellr[m] = cell;
         if (lane == 63) lastc[m * 4 + wave] = cell;
     }
-    int *hist = (int *)(keys + 2 * kVoxBucketSegs);
+    // small instantiation: the sorted order is a u16 index into the scattered keys (28 KB of LDS in all: 5 workgroups per CU;
+    // the kernel is bound by resident workgroups -- 3 per CU at 46 KB measured 6.2 ms, 2 per CU 8.8 ms)
+    unsigned long long *tmp = kSmall ? keys : keys + kVoxBucketSegs;
+    unsigned short *pos = (unsigned short *)(keys + kVoxBucketSegs);                       // small only
+    int *hist = kSmall ? (int *)((unsigned char *)keys + kVoxBucketSegs * 10) : (int *)(keys + 2 * kVoxBucketSegs);
+    auto skey = [&](int t) -> unsigned long long { return kSmall ? tmp[pos[t]] : keys[t]; };
     __syncthreads();            // fs / scr[32..35] are read, lastc is written
     VT(2)
     // ---- segment heads: a candidate whose predecessor in the ring is not a candidate of the same cell
@@ -645,7 +652,6 @@ __device__ __forceinline__ void voxel_ring(BatchView &b, int r, int s)
             if ((head_mask >> m) & 1u) atomicAdd(&hist[cellr[m] >> bshift], 1);
         __syncthreads();
         VT(3)
-        unsigned long long *tmp = keys + kVoxBucketSegs;
         constexpr int kPer = kVoxBuckets / 256;
         int c[kPer], sum = 0;
 #pragma unroll
@@ -670,7 +676,7 @@ __device__ __forceinline__ void voxel_ring(BatchView &b, int r, int s)
             const int lo = bk > 0 ? hist[bk - 1] : 0, hi = hist[bk];
             int less = 0;
             for (int u = lo; u < hi; u++) less += tmp[u] < k ? 1 : 0;
-            keys[lo + less] = k;
+            if (kSmall) pos[lo + less] = (unsigned short)t; else keys[lo + less] = k;
         }
         __syncthreads();
     } else if (!kSmall) {
@@ -687,7 +693,8 @@ __device__ __forceinline__ void voxel_ring(BatchView &b, int r, int s)
     }
     VT(4)
     // ---- runs of equal cell over the sorted segments -> output voxels; vstart[o] = first sorted segment of voxel o
-    int *vstart = bucket_path ? (int *)(keys + kVoxBucketSegs) : nullptr;   // the scattered copy is dead now
+    int *vstart = bucket_path && !kSmall ? (int *)(keys + kVoxBucketSegs) : nullptr;   // big: the scattered copy is dead now
+    unsigned short *vstart16 = (unsigned short *)hist;                                 // small: the bucket counters are dead after the ranking
     constexpr int kRounds = (kVoxBucketSegs + 255) / 256;
     int n_out = 0, obase[kRounds];
     {
@@ -695,7 +702,7 @@ __device__ __forceinline__ void voxel_ring(BatchView &b, int r, int s)
         // voxel starts per round and wave -> prefix in sorted order (round, wave, lane)
         for (int j = 0; j < rounds; j++) {
             const int t = tid + 256 * j;
-            const bool st = t < nseg && (t == 0 || (unsigned int)(keys[t] >> 32) != (unsigned int)(keys[t - 1] >> 32));
+            const bool st = t < nseg && (t == 0 || (unsigned int)(skey(t) >> 32) != (unsigned int)(skey(t - 1) >> 32));
             const unsigned long long sm = __ballot(st);
             if (lane == 0) scr[128 + ((j * 4 + wave) & 127)] = __popcll(sm);
         }
@@ -714,19 +721,21 @@ __device__ __forceinline__ void voxel_ring(BatchView &b, int r, int s)
         for (int j = 0; j < kRounds; j++) {
             if (j >= rounds) break;
             const int t = tid + 256 * j;
-            const bool st = t < nseg && (t == 0 || (unsigned int)(keys[t] >> 32) != (unsigned int)(keys[t - 1] >> 32));
+            const bool st = t < nseg && (t == 0 || (unsigned int)(skey(t) >> 32) != (unsigned int)(skey(t - 1) >> 32));
             const unsigned long long sm = __ballot(st);
-            if (st) vstart[obase[j] + __popcll(sm & ((1ull << lane) - 1ull))] = t;
+            if (st) { const int o = obase[j] + __popcll(sm & ((1ull << lane) - 1ull)); if (kSmall) vstart16[o] = (unsigned short)t; else vstart[o] = t; }
         }
         __syncthreads();
         // one voxel per thread and round: its segments in sorted order, every segment's points in index order
         for (int v = tid; v < n_out; v += 256) {
-            const int t = vstart[v];
-            const unsigned int c = (unsigned int)(keys[t] >> 32);
+            const int t = kSmall ? (int)vstart16[v] : vstart[v];
+            const unsigned int c = (unsigned int)(skey(t) >> 32);
             float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
             int cnt = 0;
-            for (int u = t; u < nseg && (unsigned int)(keys[u] >> 32) == c; u++) {
-                const int i0 = (int)(keys[u] & 0xffffffffull);
+            for (int u = t; u < nseg; u++) {
+                const unsigned long long ku = skey(u);
+                if ((unsigned int)(ku >> 32) != c) break;
+                const int i0 = (int)(ku & 0xffffffffull);
                 // run length from the continuation bitmap: points i0+1 .. while their bit is set
                 int rl = 1;
                 while (i0 + rl < len && ((contw[(i0 + rl) >> 6] >> ((i0 + rl) & 63)) & 1ull)) rl++;
