@@ -59,7 +59,7 @@ struct lmono_scan_batch {
     // odometry workspace
     int chains_cap = 0;
     double *state = nullptr, *incr = nullptr, *poses = nullptr, *xq = nullptr;
-    int *corr = nullptr, *lm_info = nullptr, *corr_pair = nullptr;
+    int *corr = nullptr, *lm_info = nullptr, *corr_pair = nullptr, *seed = nullptr;
     float4 *crec = nullptr, *crec_pair = nullptr;
 };
 
@@ -350,7 +350,8 @@ static int ensure_odom_ws(lmono_ctx *c, lmono_scan_batch *b, int n_chains)
     if (n_chains <= b->chains_cap) return LMONO_OK;
     // (re)allocate; old buffers stay in allocs and are freed with the batch
     bool ok = dalloc(b, b->state, (size_t)n_chains * 8) && dalloc(b, b->corr, (size_t)n_chains * kMaxQueries * 4) &&
-              dalloc(b, b->lm_info, (size_t)n_chains * 4) && dalloc(b, b->crec, (size_t)n_chains * kMaxQueries * 4);
+              dalloc(b, b->lm_info, (size_t)n_chains * 4) && dalloc(b, b->crec, (size_t)n_chains * kMaxQueries * 4) &&
+              dalloc(b, b->seed, (size_t)n_chains * kMaxQueries);
     if (!ok) { c->err = "odometry workspace: hipMalloc failed"; return LMONO_ENOMEM; }
     b->chains_cap = n_chains;
     return LMONO_OK;
@@ -367,7 +368,7 @@ static int odom_run(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, d
     if (rc) return rc;
     OdomView o;
     o.n_scans = n; o.n_chains = n_chains; o.lead = lead; o.fixed_k = -1;
-    o.state = b->state; o.corr = b->corr; o.incr = b->incr; o.lm_info = b->lm_info; o.crec = b->crec;
+    o.state = b->state; o.corr = b->corr; o.incr = b->incr; o.lm_info = b->lm_info; o.crec = b->crec; o.seed = b->seed;
     int max_steps = 0;
     for (int ch = 0; ch < n_chains; ch++) {
         const int s = (int)((long long)ch * n / n_chains), e = (int)((long long)(ch + 1) * n / n_chains);
@@ -392,7 +393,7 @@ static int odom_run(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, d
         for (int outer = 0; outer < 2; outer++) {
             hipEvent_t e0 = kev(ne), e1 = kev(ne + 1), e2 = kev(ne + 2);
             if (e0 && e1 && e2) (void)hipEventRecord(e0, st);
-            hipLaunchKernelGGL(k_correspond, dim3(8 * ((n_chains + 7) / 8) * kCorrBlocks), dim3(256), 0, st, b->v, o, step);
+            hipLaunchKernelGGL(k_correspond, dim3(8 * ((n_chains + 7) / 8) * kCorrBlocks), dim3(256), 0, st, b->v, o, step, outer);
             if (e0 && e1 && e2) (void)hipEventRecord(e1, st);
             hipLaunchKernelGGL(k_lm_solve, dim3(n_chains), dim3(kLmT), kLmRecLds, st, b->v, o, step, outer);
             if (e0 && e1 && e2) { (void)hipEventRecord(e2, st); ne += 3; }
@@ -438,8 +439,8 @@ extern "C" int lmono_odom_correspond(lmono_ctx *c, lmono_scan_batch *b, int scan
     if (nq > cap) { c->err = "odom_correspond: output capacity too small"; return LMONO_ECAPACITY; }
     OdomView o;
     o.n_scans = b->n_scans; o.n_chains = 1; o.lead = 0; o.fixed_k = scan;
-    o.state = b->xq; o.corr = b->corr_pair; o.incr = nullptr; o.lm_info = nullptr; o.crec = b->crec_pair;
-    hipLaunchKernelGGL(k_correspond, dim3(8 * kCorrBlocks), dim3(256), 0, c->stream, b->v, o, 0);
+    o.state = b->xq; o.corr = b->corr_pair; o.incr = nullptr; o.lm_info = nullptr; o.crec = b->crec_pair; o.seed = nullptr;
+    hipLaunchKernelGGL(k_correspond, dim3(8 * kCorrBlocks), dim3(256), 0, c->stream, b->v, o, 0, 0);
     int rc = check_launch(c, "k_correspond");
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));

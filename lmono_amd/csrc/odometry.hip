@@ -245,6 +245,7 @@ struct OdomView {
     float4 *crec;         // [n_chains][kMaxQueries][4] residual-block records: (cp, kind), a, b, c
     double *incr;         // [n_scans][7]
     int *lm_info;         // [n_chains][4]
+    int *seed;            // [n_chains][kMaxQueries] nearest point found by the previous outer iteration of the same scan pair (-1: none)
 };
 
 __device__ __forceinline__ void chain_bounds(int n_scans, int n_chains, int c, int &s, int &e)
@@ -624,8 +625,9 @@ __device__ __forceinline__ void nn_sweep_rows(const float4 *lpts, int run, int v
 }
 
 // gl = lane inside the 32-lane group, gbase = first wave lane of the group (0 or 32)
-__device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi, const double *x, int gl, int gbase)
+__device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi, const double *x, int gl, int gbase, int seed, int &closest_out)
 {
+    closest_out = -1;
     const int n_sharp = b.feat_n[k * 4 + 0];
     const bool edge = qi < n_sharp;
     const float4 p = edge ? b.sharp[(size_t)k * kMaxSharp + qi] : b.flat[(size_t)k * kMaxFlat + (qi - n_sharp)];
@@ -647,24 +649,52 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
     const int cqx = (int)floorf(fx), cqy = (int)floorf(fy), cqz = (int)floorf(fz);
     int run = 0;          // pack_run(start, count) of this lane's cell, 0 = empty
     bool near = false;
+    // Second outer iteration of a scan pair: the nearest point of the first one, seen from the updated pose, is a real
+    // candidate; when it lies inside shell 1 only the cells whose box comes closer than it can hold the nearest point,
+    // typically one or two of the 27 -- one sweep round settles the search exactly.
+    NnBest nb = kNnNone;
+    bool seeded = false;
+    float sd = 0.f;
+    if (seed >= 0 && seed < n_last) {
+        const float4 pp = (edge ? b.less_sharp + (size_t)l * kMaxLessSharp : b.less_flat + b.off[l])[seed];
+        const float d = dist2f(pp.x, pp.y, pp.z, qx, qy, qz);
+        const int ln = (int)pp.w;
+        if (d <= (kCell * 0.9999f) * (kCell * 0.9999f)) {
+            seeded = true; sd = d;
+            nb = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)((seed << 7) | (ln < 0 ? 0 : (ln > 65 ? 65 : ln)));
+        }
+    }
     if (gl < 27) {
         const int dx = gl % 3 - 1, dy = (gl / 3) % 3 - 1, dz = gl / 9 - 1;
         // the 2x2x2 block of cells whose faces are all >= half a cell away from the query
         const int sx = (fx - (float)cqx) >= 0.5f ? 1 : -1, sy = (fy - (float)cqy) >= 0.5f ? 1 : -1, sz = (fz - (float)cqz) >= 0.5f ? 1 : -1;
         near = (dx == 0 || dx == sx) && (dy == 0 || dy == sy) && (dz == 0 || dz == sz);
-        const unsigned long long kk = cell_key(cqx + dx, cqy + dy, cqz + dz);
-        unsigned int sl = hash_key(kk) & mask;
-        while (true) {
-            const GridCell e = cell[sl];
-            if (e.key == kk) { run = pack_run(e.start, e.cnt); break; }
-            if (e.key == kEmptyKey) break;
-            sl = grid_next(sl, pmask);
+        bool wanted = true;
+        if (seeded) {
+            const float lx = (float)(cqx + dx) * kCell, ly = (float)(cqy + dy) * kCell, lz = (float)(cqz + dz) * kCell;
+            const float ex = fmaxf(fmaxf(lx - qx, qx - (lx + kCell)), 0.f), ey = fmaxf(fmaxf(ly - qy, qy - (ly + kCell)), 0.f), ez = fmaxf(fmaxf(lz - qz, qz - (lz + kCell)), 0.f);
+            const float eb = fmaxf(sqrtf(ex * ex + ey * ey + ez * ez) - 1e-3f, 0.f);
+            wanted = !(eb * eb > sd);
+        }
+        if (wanted) {
+            const unsigned long long kk = cell_key(cqx + dx, cqy + dy, cqz + dz);
+            unsigned int sl = hash_key(kk) & mask;
+            while (true) {
+                const GridCell e = cell[sl];
+                if (e.key == kk) { run = pack_run(e.start, e.cnt); break; }
+                if (e.key == kEmptyKey) break;
+                sl = grid_next(sl, pmask);
+            }
         }
     }
-    NnBest nb = kNnNone;
+    unsigned long long best;
+    if (seeded) {
+        nn_sweep(gpts, run, gl, gbase, qx, qy, qz, nb);
+        best = group_min_u64(nb, gbase);
+    } else {
     // near block first: any point outside it is farther than half a cell
     nn_sweep(gpts, near ? run : 0, gl, gbase, qx, qy, qz, nb);
-    unsigned long long best = group_min_u64(nb, gbase);
+    best = group_min_u64(nb, gbase);
     {
         const float bound_h = 0.5f * kCell * 0.9999f;
         if (!(best != ~0ull && __uint_as_float((unsigned int)(best >> 32)) <= bound_h * bound_h)) {
@@ -680,6 +710,7 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
             nn_sweep(gpts, run_far, gl, gbase, qx, qy, qz, nb);
             best = group_min_u64(nb, gbase);
         }
+    }
     }
     {
         const float bound = kCell * 0.9999f;
@@ -721,6 +752,7 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
     if (best == ~0ull || !((double)__uint_as_float((unsigned int)(best >> 32)) < 25.0)) return out;
     const int closest = (int)((unsigned int)(best & 0xffffffffull) >> 7);
     const int ra = (int)(best & 127ull);
+    closest_out = closest;
 
     // ---- scan-line walk over the (line, azimuth) index: lines ra-2 .. ra+2, index window (last_le[ra-3], first_ge[ra+3]).
     // Two passes: first only the arc that can hold points within r1 = 0.5 m + 5 % of the range (the partners are
@@ -799,7 +831,7 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
 // (sizing the grid to the sensor's feature bound, 230 instead of 288 workgroups per chain for an HDL-64, measured 3 % slower)
 constexpr int kCorrBlocks = kMaxQueries / 8;
 
-__global__ __launch_bounds__(256, 8) void k_correspond(BatchView b, OdomView o, int step)
+__global__ __launch_bounds__(256, 8) void k_correspond(BatchView b, OdomView o, int step, int outer)
 {
     const int xcd = blockIdx.x & 7, u = blockIdx.x >> 3;
     const int c = (u / kCorrBlocks) * 8 + xcd;
@@ -835,8 +867,10 @@ __global__ __launch_bounds__(256, 8) void k_correspond(BatchView b, OdomView o, 
     }
     const int qi = qblock * 8 + (threadIdx.x >> 5);
     if (qi >= nq) return;
-    const int4 r = correspond_g32(b, k, qi, x, gl, gbase);
-    if (gl == 0) corr[qi] = r;
+    int *seed_c = o.seed ? o.seed + (size_t)c * kMaxQueries : nullptr;
+    int closest;
+    const int4 r = correspond_g32(b, k, qi, x, gl, gbase, (outer == 1 && seed_c) ? seed_c[qi] : -1, closest);
+    if (gl == 0) { corr[qi] = r; if (outer == 0 && seed_c) seed_c[qi] = closest; }
     // residual-block record for the solver: the feature point and its 2 (edge) or 3 (plane) partners, 64 B
     if (gl < 4) {
         const bool edge = qi < n_sharp;
