@@ -1187,8 +1187,12 @@ __global__ __launch_bounds__(kLmT) void k_lm_solve(BatchView b, OdomView o, int 
             double delta[6], cand[7];
             for (int i = 0; i < 6; i++) delta[i] = stepv[i] * scale[i];
             manifold_plus(x, delta, cand);
+            // The candidate is evaluated WITH its Jacobian (it is accepted almost always, and then this is the linearisation of
+            // the next iteration -- the same numbers a separate pass would give); the last iteration only needs the cost.
+            const bool last = iter == max_iter;
             LmAcc ca;
-            evaluate_block<false>(s_rec, nq, cand, ca, s_red);
+            if (last) evaluate_block<false>(s_rec, nq, cand, ca, s_red);
+            else evaluate_block<true>(s_rec, nq, cand, ca, s_red);
             const double cand_cost = ca.cost;
             double sn = 0.0;
             for (int i = 0; i < 7; i++) sn += (x[i] - cand[i]) * (x[i] - cand[i]);
@@ -1198,11 +1202,11 @@ __global__ __launch_bounds__(kLmT) void k_lm_solve(BatchView b, OdomView o, int 
             const double rel = (x_cost - cand_cost) / model_change;
             if (rel > min_rel_decrease) {
                 for (int i = 0; i < 7; i++) x[i] = cand[i];
+                if (last) break;                 // nothing after the last accepted step is used
                 x_norm = norm7(x);
-                evaluate_block<true>(s_rec, nq, x, acc, s_red);
-                x_cost = acc.cost;
-                unpack_sym(acc.H, H);
-                for (int i = 0; i < 6; i++) g[i] = acc.g[i];
+                x_cost = ca.cost;
+                unpack_sym(ca.H, H);
+                for (int i = 0; i < 6; i++) g[i] = ca.g[i];
                 const double tt = 2.0 * rel - 1.0;
                 double den = 1.0 - tt * tt * tt;
                 if (den < 1.0 / 3.0) den = 1.0 / 3.0;
