@@ -469,8 +469,11 @@ __global__ __launch_bounds__(1024) void k_map_solve(const MapStream *streams, in
                 double delta[6], cand[7];
                 for (int i = 0; i < 6; i++) delta[i] = stepv[i] * scale[i];
                 manifold_plus(x, delta, cand);
+                // candidate evaluated with its Jacobian (reused as the next linearisation); the last iteration needs the cost only
+                const bool last = iter == max_iter;
                 LmAcc ca;
-                map_evaluate<false>(S.rec, nq, cand, ca, s_red);
+                if (last) map_evaluate<false>(S.rec, nq, cand, ca, s_red);
+                else map_evaluate<true>(S.rec, nq, cand, ca, s_red);
                 const double cand_cost = ca.cost;
                 double sn = 0.0;
                 for (int i = 0; i < 7; i++) sn += (x[i] - cand[i]) * (x[i] - cand[i]);
@@ -480,11 +483,11 @@ __global__ __launch_bounds__(1024) void k_map_solve(const MapStream *streams, in
                 const double rel = (x_cost - cand_cost) / model_change;
                 if (rel > min_rel_decrease) {
                     for (int i = 0; i < 7; i++) x[i] = cand[i];
+                    if (last) break;
                     x_norm = norm7(x);
-                    map_evaluate<true>(S.rec, nq, x, acc, s_red);
-                    x_cost = acc.cost;
-                    unpack_sym(acc.H, H);
-                    for (int i = 0; i < 6; i++) g[i] = acc.g[i];
+                    x_cost = ca.cost;
+                    unpack_sym(ca.H, H);
+                    for (int i = 0; i < 6; i++) g[i] = ca.g[i];
                     const double tt = 2.0 * rel - 1.0;
                     double den = 1.0 - tt * tt * tt;
                     if (den < 1.0 / 3.0) den = 1.0 / 3.0;
