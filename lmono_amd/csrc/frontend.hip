@@ -1,13 +1,16 @@
 // lmono_amd/csrc/frontend.hip -- gfx950 kernels of the LiDAR front end (A-LOAM scanRegistration;
 // source absent from the reference tree, behavioural spec SURVEY.md Appendix A.1).
 //
-// Four kernels per batch of scans, every one a coalesced sweep over HBM-resident SoA/float4 pools:
-//   k_ring_sort  one workgroup per scan: filter, ring id, azimuth, stable counting sort into ring-major order
+// Five kernel stages per batch of scans over HBM-resident SoA/float4 pools:
+//   k_ring_sort  one workgroup per scan: filter, ring id, azimuth, stable counting sort into ring-major order (per-wave
+//                multisplit: every wave owns a contiguous chunk in both passes, no barriers inside the passes)
 //   k_curvature  one workgroup per 1024-point tile: LDS tile with +-5 halo, curvature and neighbour-gap flags
-//   k_select     one wave per (scan, ring): per-sector edge/planar selection as repeated 64-lane arg-max/arg-min
-//                over register-resident (curvature, index) keys with neighbour suppression (no sort needed)
-//   k_voxel      one workgroup per (scan, ring): voxel-grid down-sampling of the less-flat points (LDS bitonic sort)
-//   k_compact    one workgroup per scan: prefix sums over (ring, sector) and compaction of the four clouds
+//   k_select     one wave per (scan, ring): per-sector edge/planar selection as repeated 64-lane arg-max/arg-min (DPP
+//                reductions) over register-resident (curvature, index) keys with neighbour suppression (no sort needed);
+//                rings longer than the small LDS slice go through a work list to a second launch
+//   k_voxel      one workgroup per (scan, ring): voxel-grid down-sampling of the less-flat points (run-length segments from
+//                ballots, bucket sort of the segment keys in LDS; <9 slots> / <16 slots> instantiations + work list)
+//   k_compact    one workgroup per scan: prefix sums over (ring, sector), compaction of the four clouds, line tables
 // Arithmetic is float/double exactly as the CPU restatement evaluates it (compiled with -ffp-contract=off).
 #include "batch.hpp"
 

@@ -2,13 +2,16 @@
 // loop + lidarFactor.hpp + the ceres::Solve call it makes; source absent from the reference tree,
 // behavioural spec SURVEY.md Appendix A.2/A.3/B).
 //
-//   k_grid_build  one workgroup per (scan, cloud): 1 m hash grid over less_sharp / less_flat (the "last" clouds
-//                 of the next scan).  Exact 1-NN needs only neighbours closer than 5 m (DISTANCE_SQ_THRESHOLD).
+//   k_grid_build  one workgroup per (scan, table page): 1 m hash grid over less_sharp / less_flat (the "last" clouds
+//                 of the next scan), built page by page in LDS.  Exact 1-NN needs only neighbours closer than 5 m
+//                 (DISTANCE_SQ_THRESHOLD).
 //   k_line_index  one workgroup per (scan, cloud): copy of the cloud counting-sorted by (scan line, azimuth bin)
-//   k_correspond  one wave per feature point: de-skew transform (fp64), exact 1-NN by growing cell shells, then the
-//                 reference's scan-line walk restricted to the lines ra-2..ra+2 and the azimuth arc within 5 m
-//   k_lm_solve    one wave per chain: <= 4 Levenberg-Marquardt iterations restating Ceres' trust-region loop,
-//                 closed-form edge/plane Jacobians, wave-shuffle reduction into the 6x6 normal equations (fp64)
+//   k_correspond  32 lanes per feature point: de-skew transform (fp64), exact 1-NN over the 27 cells around the point
+//                 (candidates as u64 keys, four cells per round in 8-lane sub-groups; arc sweep of the line index for the
+//                 rare far cases), then the reference's scan-line walk restricted to the lines ra-2..ra+2 and the azimuth
+//                 arc within 5 m (the five lines side by side in 6-lane sub-groups)
+//   k_lm_solve    one workgroup per chain: <= 4 Levenberg-Marquardt iterations restating Ceres' trust-region loop,
+//                 closed-form edge/plane Jacobians, reduction into the 6x6 normal equations (fp64)
 //   k_pose_prefix sequential pose accumulation
 #include "batch.hpp"
 

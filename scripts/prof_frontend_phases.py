@@ -1,3 +1,5 @@
+"""Per-phase cycle counts of one k_voxel workgroup on an idle GPU: build the library with -DLMONO_VOX_PROF first
+(hipcc ... -DLMONO_VOX_PROF -o lmono_amd/lib/liblmono_hip.so lmono_amd/csrc/lmono_hip.hip), run this, rebuild clean."""
 import sys, numpy as np, torch
 sys.path.insert(0, '.')
 import lmono_amd
