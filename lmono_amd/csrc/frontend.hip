@@ -279,16 +279,6 @@ __global__ __launch_bounds__(256) void k_curvature(BatchView b)
 constexpr int kSelMaxPerLane = (kRingCap / 6 + 1 + 63) / 64;   // 11 elements per lane for the largest legal sector
 constexpr int kSelWaveLds = 3 * kRingCap;                      // picked, label, gap bytes of one ring
 
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long w = __shfl_xor(v, o);
-        v = w > v ? w : v;
-    }
-    return v;
-}
-
 // key of a sector element: (curvature bits, index, suppression reach).  Ordering by the key = ordering by
 // (curvature, index), so the arg-max / arg-min over keys reproduces the sort's tie order; the winner's reach rides along.
 __device__ __forceinline__ unsigned long long select_key(float c, int idx, unsigned int reach)
@@ -613,7 +603,6 @@ __device__ __forceinline__ void voxel_ring(BatchView &b, int r, int s)
     VT(2)
     // ---- segment heads: a candidate whose predecessor in the ring is not a candidate of the same cell
     unsigned int head_mask = 0;
-    int nhead_w = 0;            // heads of this wave over all slots (wave-uniform)
 #pragma unroll
     for (int m = 0; m < kVoxSlots; m++) {
         const int i = tid + 256 * m;
@@ -625,7 +614,6 @@ __device__ __forceinline__ void voxel_ring(BatchView &b, int r, int s)
         const unsigned long long hm = __ballot(head), cm = __ballot(cont);
         if (lane == 0) { contw[m * 4 + wave] = cm; scr[64 + m * 4 + wave] = __popcll(hm); }
         if (head) head_mask |= 1u << m;
-        nhead_w += __popcll(hm);
     }
     __syncthreads();
     // position of a head in ring order = heads of the earlier (slot, wave) pairs + heads below it in its own ballot
@@ -807,35 +795,6 @@ __device__ __forceinline__ void voxel_ring(BatchView &b, int r, int s)
 // The odometry walk around a nearest point of line ra visits exactly the index window (last_le[ra-3], first_ge[ra+3])
 // provided no point precedes a point whose line is >= 3 lower ("regular"); irregular clouds are flagged and walked
 // in array order instead.  Lines are not monotone in general: A-LOAM's relTime can be negative (line = ring - 1).
-__device__ __forceinline__ void line_tables(const float4 *pts, int n, int *first_ge, int *last_le, int *status, int tid,
-                                            int *s_first, int *s_last, int *s_flag)
-{
-    if (tid < 66) { s_first[tid] = INT_MAX; s_last[tid] = -1; }
-    if (tid == 0) *s_flag = 0;
-    __syncthreads();
-    for (int j = tid; j < n; j += 256) {
-        int v = (int)pts[j].w;
-        v = v < 0 ? 0 : (v > 65 ? 65 : v);
-        atomicMin(&s_first[v], j);
-        atomicMax(&s_last[v], j);
-    }
-    __syncthreads();
-    // irregular iff some line a >= b + 3 starts before line b ends
-    for (int x = tid; x < 66 * 66; x += 256) {
-        const int a = x / 66, bb = x % 66;
-        if (a >= bb + 3 && s_first[a] < s_last[bb]) *s_flag = 1;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        int m = n;
-        for (int t = 65; t >= 0; t--) { m = min(m, s_first[t] == INT_MAX ? n : s_first[t]); first_ge[t] = m; }
-        int M = -1;
-        for (int t = 0; t <= 65; t++) { M = max(M, s_last[t]); last_le[t] = M; }
-        if (*s_flag) atomicOr(status, kStatusIrregularLines);
-    }
-    __syncthreads();
-}
-
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_compact(BatchView b)
 {
@@ -936,7 +895,7 @@ __global__ __launch_bounds__(256) void k_compact(BatchView b)
         b.feat_n[s * 4 + 2] = pre_fl[NE]; b.feat_n[s * 4 + 3] = n_lf;
     }
     __syncthreads();
-    // irregular iff some line a >= b + 3 starts before line b ends (see line_tables)
+    // irregular iff some line a >= b + 3 starts before line b ends (see above)
     for (int x = tid; x < 2 * 66 * 66; x += 256) {
         const int cld = x / (66 * 66), y = x % (66 * 66), a = y / 66, bb = y % 66;
         if (a >= bb + 3 && s_first[cld][a] < s_last[cld][bb]) s_flag[cld] = 1;
