@@ -47,7 +47,8 @@ __device__ __forceinline__ bool point_valid(const float4 &p, float mr2)
 #else
 #define RT(i)
 #endif
-__global__ __launch_bounds__(1024) void k_ring_sort(BatchView b)
+constexpr int kRsT = 256, kRsW = kRsT / 64;    // threads / waves of k_ring_sort (1024 / 512 / 256 / 128 measured 9.5 / 8.7 / 8.4 / 9.5 ms)
+__global__ __launch_bounds__(kRsT) void k_ring_sort(BatchView b)
 {
 #ifdef LMONO_RS_PROF
     long long rt[6];
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(1024) void k_ring_sort(BatchView b)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __shared__ int s_first, s_last, s_half;
     __shared__ int s_cnt[64], s_base[64];
-    __shared__ int s_hist[16][64];      // pass 1: points per (wave, ring); pass 2: next output position of (wave, ring)
+    __shared__ int s_hist[kRsW][64];      // pass 1: points per (wave, ring); pass 2: next output position of (wave, ring)
     __shared__ float s_ori[2];
     if (tid == 0) { s_first = INT_MAX; s_last = -1; s_half = INT_MAX; }
     __syncthreads();
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(1024) void k_ring_sort(BatchView b)
     if (s_first == INT_MAX || s_last < 0) {
         __syncthreads();
         lf = INT_MAX; ll = -1;
-        for (int i = tid; i < n; i += 1024) {
+        for (int i = tid; i < n; i += kRsT) {
             const float4 p = in[i];
             if (point_valid(p, mr2)) { lf = min(lf, i); ll = max(ll, i); }
         }
@@ -109,9 +110,9 @@ __global__ __launch_bounds__(1024) void k_ring_sort(BatchView b)
     // Every wave owns one contiguous chunk of the scan in BOTH passes: pass 1 leaves a per-(wave, ring) histogram, a prefix
     // over (ring, wave) turns it into the first output position of every (wave, ring), and pass 2 is then a barrier-free
     // stable multisplit: a wave walks its chunk in input order with its own running counters.
-    const int chunk = (((n + 15) / 16) + 255) & ~255;          // points per wave, a multiple of the 256-point round
+    const int chunk = (((n + kRsW - 1) / kRsW) + 255) & ~255;          // points per wave, a multiple of the 256-point round
     const int c_lo = wave * chunk, c_hi = min(c_lo + chunk, n);
-    for (int i = tid; i < 16 * 64; i += 1024) (&s_hist[0][0])[i] = 0;
+    for (int i = tid; i < kRsW * 64; i += kRsT) (&s_hist[0][0])[i] = 0;
     __syncthreads();
     // four points per thread and round: their loads are in flight together (the sweep is bandwidth-bound)
     for (int t0 = c_lo; t0 < c_hi; t0 += 256) {
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(1024) void k_ring_sort(BatchView b)
     // ring totals -> ring_begin; first output position of every (wave, ring)
     if (tid < 64) {
         int t = 0;
-        for (int w = 0; w < 16; w++) t += s_hist[w][tid];
+        for (int w = 0; w < kRsW; w++) t += s_hist[w][tid];
         s_cnt[tid] = t;
     }
     __syncthreads();

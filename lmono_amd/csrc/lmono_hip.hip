@@ -224,7 +224,7 @@ extern "C" int lmono_scanreg_batch(lmono_ctx *c, lmono_scan_batch *b, const floa
     HIP_TRY(c, hipMemsetAsync(v.vox_todo, 0, sizeof(int), st));
     HIP_TRY(c, hipMemsetAsync(v.sel_todo, 0, sizeof(int), st));
     HIP_TRY(c, hipEventRecord(c->ev[0], st));
-    hipLaunchKernelGGL(k_ring_sort, dim3(n_scans), dim3(1024), 0, st, v);
+    hipLaunchKernelGGL(k_ring_sort, dim3(n_scans), dim3(kRsT), 0, st, v);
     HIP_TRY(c, hipEventRecord(c->ev[1], st));
     const int tiles = (int)((max_pts + kCurvTile - 1) / kCurvTile);
     if (tiles > 0) hipLaunchKernelGGL(k_curvature, dim3(tiles, n_scans), dim3(256), 0, st, v);
