@@ -451,9 +451,10 @@ constexpr int kVoxBigGrid = 512;    // workgroups of the second instantiation; e
 template <int kSlots, int kBits, bool kSmall>
 struct VoxCfg {
     static constexpr int kSegCap = kSmall ? 256 * kSlots : kVoxBucketSegsBig;
-    // small: scattered keys (u64) | sorted order as u16 positions into them | bucket counters, later the voxel starts (u16)
+    // small: scattered keys as (cell u32 | first index u16) | sorted order as u16 positions into them | bucket counters, later
+    // the voxel starts (u16)
     static constexpr int kHistBytes = (1 << kBits) * 4 > kSegCap * 2 ? (1 << kBits) * 4 : kSegCap * 2;
-    static constexpr int kKeyBytes = kSmall ? kSegCap * 8 + kSegCap * 2 + kHistBytes : kRingCap * 8;
+    static constexpr int kKeyBytes = kSmall ? kSegCap * 4 + kSegCap * 2 + kSegCap * 2 + kHistBytes : kRingCap * 8;
     static constexpr int kLds = kKeyBytes + 1024 + kSlots * 4 * 8 + kSlots * 4 * 4;
 };
 constexpr int kVoxLdsSmall = VoxCfg<kVoxSmallSlots, kVoxSmallBits, true>::kLds;
@@ -596,10 +597,15 @@ __device__ __forceinline__ void voxel_ring(BatchView &b, int r, int s)
     }
     // small instantiation: the sorted order is a u16 index into the scattered keys (28 KB of LDS in all: 5 workgroups per CU;
     // the kernel is bound by resident workgroups -- 3 per CU at 46 KB measured 6.2 ms, 2 per CU 8.8 ms)
-    unsigned long long *tmp = kSmall ? keys : keys + kVoxBucketSegs;
-    unsigned short *pos = (unsigned short *)(keys + kVoxBucketSegs);                       // small only
-    int *hist = kSmall ? (int *)((unsigned char *)keys + kVoxBucketSegs * 10) : (int *)(keys + 2 * kVoxBucketSegs);
-    auto skey = [&](int t) -> unsigned long long { return kSmall ? tmp[pos[t]] : keys[t]; };
+    unsigned long long *tmp = keys + kVoxBucketSegs;                                        // big only: scattered keys
+    unsigned int *cellt = (unsigned int *)keys;                                             // small only: scattered (cell,
+    unsigned short *idxt = (unsigned short *)((unsigned char *)keys + kVoxBucketSegs * 4);  //             first index)
+    unsigned short *pos = (unsigned short *)((unsigned char *)keys + kVoxBucketSegs * 6);   // small only: sorted order
+    int *hist = kSmall ? (int *)((unsigned char *)keys + kVoxBucketSegs * 8) : (int *)(keys + 2 * kVoxBucketSegs);
+    auto skey = [&](int t) -> unsigned long long {
+        if (kSmall) { const int q = pos[t]; return ((unsigned long long)cellt[q] << 32) | idxt[q]; }
+        return keys[t];
+    };
     __syncthreads();            // fs / scr[32..35] are read, lastc is written
     VT(2)
     // ---- segment heads: a candidate whose predecessor in the ring is not a candidate of the same cell
@@ -659,15 +665,19 @@ __device__ __forceinline__ void voxel_ring(BatchView &b, int r, int s)
 #pragma unroll
         for (int m = 0; m < kVoxSlots; m++)
             if ((head_mask >> m) & 1u)
-                tmp[atomicAdd(&hist[cellr[m] >> bshift], 1)] = ((unsigned long long)cellr[m] << 32) | (unsigned int)(tid + 256 * m);
+            {
+                const int q = atomicAdd(&hist[cellr[m] >> bshift], 1);
+                if (kSmall) { cellt[q] = cellr[m]; idxt[q] = (unsigned short)(tid + 256 * m); }
+                else tmp[q] = ((unsigned long long)cellr[m] << 32) | (unsigned int)(tid + 256 * m);
+            }
         __syncthreads();
         // a cursor is now the end of its bucket = the start of the next one
         for (int t = tid; t < nseg; t += 256) {
-            const unsigned long long k = tmp[t];
+            const unsigned long long k = kSmall ? (((unsigned long long)cellt[t] << 32) | idxt[t]) : tmp[t];
             const int bk = (int)((unsigned int)(k >> 32) >> bshift);
             const int lo = bk > 0 ? hist[bk - 1] : 0, hi = hist[bk];
             int less = 0;
-            for (int u = lo; u < hi; u++) less += tmp[u] < k ? 1 : 0;
+            for (int u = lo; u < hi; u++) less += (kSmall ? (((unsigned long long)cellt[u] << 32) | idxt[u]) : tmp[u]) < k ? 1 : 0;
             if (kSmall) pos[lo + less] = (unsigned short)t; else keys[lo + less] = k;
         }
         __syncthreads();
