@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void k_curvature(BatchView b)
 // keeps its sector elements (curvature, suppressed flag) in registers and a pick is one 64-lane arg-max / arg-min
 // over the packed key (curvature bits, index), which also reproduces the (curvature, index) tie order of the sort.
 constexpr int kSelMaxPerLane = (kRingCap / 6 + 1 + 63) / 64;   // 11 elements per lane for the largest legal sector
-constexpr int kSelWaveLds = 3 * kRingCap;                      // picked, label, gap bytes of one ring
+constexpr int kSelWaveLds = 2 * kRingCap;                      // picked, gap bytes of one ring
 
 // key of a sector element: (curvature bits, index, suppression reach).  Ordering by the key = ordering by
 // (curvature, index), so the arg-max / arg-min over keys reproduces the sort's tie order; the winner's reach rides along.
@@ -362,7 +362,7 @@ __device__ __forceinline__ void select_sector(int lane, int j, int sp, int slen,
     if (lane == 0) sel_fl_n[j] = smallest;
 }
 
-// one ring by one wave; cap = ring points the wave's LDS slice (3 * cap bytes at smem_w) can hold
+// one ring by one wave; cap = ring points the wave's LDS slice (2 * cap bytes at smem_w) can hold
 __device__ __forceinline__ void select_ring(BatchView &b, int r, int s, int lane, unsigned char *smem_w, int cap, bool may_defer)
 {
     const int64_t off = b.off[s];
@@ -384,9 +384,11 @@ __device__ __forceinline__ void select_ring(BatchView &b, int r, int s, int lane
         if (may_defer && lane == 0) b.sel_todo[1 + atomicAdd(&b.sel_todo[0], 1)] = (s << 6) | r;
         return;
     }
+    // labels go straight to HBM (zeroed here, ~144 single-byte stores per ring afterwards): the LDS slice only holds the
+    // picked and gap bytes, 2 * cap per wave
     unsigned char *picked = smem_w;
-    signed char *label = (signed char *)(picked + cap);
-    unsigned char *gap = picked + 2 * cap;
+    signed char *label = (signed char *)(b.label + off + rbeg);
+    unsigned char *gap = picked + cap;
     const float *curv = b.curv + off + rbeg;
     for (int i = lane; i < len; i += 64) { picked[i] = 0; label[i] = 0; gap[i] = b.gap[off + rbeg + i]; }
     const int span = E - S;
@@ -399,11 +401,10 @@ __device__ __forceinline__ void select_ring(BatchView &b, int r, int s, int lane
         else if (slen <= 6 * 64) select_sector<6>(lane, j, sp, slen, rbeg, curv, picked, label, gap, sel_sh, sel_sh_n, sel_fl, sel_fl_n);
         else select_sector<kSelMaxPerLane>(lane, j, sp, slen, rbeg, curv, picked, label, gap, sel_sh, sel_sh_n, sel_fl, sel_fl_n);
     }
-    for (int i = lane; i < len; i += 64) b.label[off + rbeg + i] = label[i];
 }
 
-// Two launches: the first gives every wave a slice for kSelSmallCap points (every HDL-64 ring; 27 KB per workgroup instead of
-// 48 KB: 5 instead of 3 waves per SIMD) over the whole (ring, scan) grid and defers longer rings to a work list; the second
+// Two launches: the first gives every wave a slice for kSelSmallCap points (every HDL-64 ring; 18 KB per workgroup instead of
+// 32 KB) over the whole (ring, scan) grid and defers longer rings to a work list; the second
 // runs full-size slices as a small fixed grid over that list (normally empty).
 constexpr int kSelSmallCap = 2304, kSelBigGrid = 128;
 
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(256) void k_select(BatchView b, int cap, int from_l
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     extern __shared__ __align__(16) unsigned char smem[];
-    unsigned char *smem_w = smem + wave * 3 * cap;
+    unsigned char *smem_w = smem + wave * 2 * cap;
     if (!from_list) {
         select_ring(b, blockIdx.x * 4 + wave, blockIdx.y, lane, smem_w, cap, true);
     } else {

@@ -234,7 +234,7 @@ extern "C" int lmono_scanreg_batch(lmono_ctx *c, lmono_scan_batch *b, const floa
     HIP_TRY(c, hipMemsetAsync(v.sel_sharp_n, 0, sizeof(int) * (size_t)n_scans * 64 * 6, st));
     HIP_TRY(c, hipMemsetAsync(v.sel_flat_n, 0, sizeof(int) * (size_t)n_scans * 64 * 6, st));
     HIP_TRY(c, hipMemsetAsync(v.lf_n, 0, sizeof(int) * (size_t)n_scans * 64, st));
-    hipLaunchKernelGGL(k_select, dim3((n_rings + 3) / 4, n_scans), dim3(256), 4 * 3 * kSelSmallCap, st, v, kSelSmallCap, 0);
+    hipLaunchKernelGGL(k_select, dim3((n_rings + 3) / 4, n_scans), dim3(256), 4 * 2 * kSelSmallCap, st, v, kSelSmallCap, 0);
     hipLaunchKernelGGL(k_select, dim3(kSelBigGrid), dim3(256), 4 * kSelWaveLds, st, v, (int)kRingCap, 1);
     HIP_TRY(c, hipEventRecord(c->ev[3], st));
     hipLaunchKernelGGL((k_voxel<kVoxSmallSlots, kVoxSmallBits, true>), dim3(n_rings, n_scans), dim3(256), kVoxLdsSmall, st, v);
