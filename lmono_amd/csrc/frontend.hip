@@ -408,7 +408,7 @@ __device__ __forceinline__ void select_ring(BatchView &b, int r, int s, int lane
 // runs full-size slices as a small fixed grid over that list (normally empty).
 constexpr int kSelSmallCap = 2304, kSelBigGrid = 128;
 
-__global__ __launch_bounds__(256) void k_select(BatchView b, int cap, int from_list)
+__global__ __launch_bounds__(256, 8) void k_select(BatchView b, int cap, int from_list)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     extern __shared__ __align__(16) unsigned char smem[];
