@@ -165,16 +165,21 @@ __global__ __launch_bounds__(1024) void k_grid_build(BatchView b)
                     const unsigned long long rest = lane < 63 ? stop >> (lane + 1) : 0ull;
                     len[q] = rest ? __ffsll((long long)rest) : 64 - lane;                      // run length (meaningful on head lanes)
                 }
-                // probe chains of the four sub-tiles back to back (LDS): pass 0 inserts, pass 1 only looks the slot up
+                // first probe of the four sub-tiles back to back (four LDS operations in flight), then the (rare) collisions;
+                // pass 0 inserts, pass 1 only looks the slot up
+                unsigned int o4[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    o4[q] = head[q] ? (pass == 0 ? atomicCAS(&keys[sl[q]], kEmptyKey32, k32[q]) : keys[sl[q]]) : k32[q];
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     if (head[q]) {
+                        unsigned int o = o4[q];
                         int tries = 0;
-                        while (true) {
-                            const unsigned int o = pass == 0 ? atomicCAS(&keys[sl[q]], kEmptyKey32, k32[q]) : keys[sl[q]];
-                            if (o == k32[q] || (pass == 0 && o == kEmptyKey32)) break;
+                        while (!(o == k32[q] || (pass == 0 && o == kEmptyKey32))) {
                             if (++tries >= P || (pass == 1 && o == kEmptyKey32)) { fail = true; head[q] = false; break; }
                             sl[q] = (sl[q] + 1) & pm;
+                            o = pass == 0 ? atomicCAS(&keys[sl[q]], kEmptyKey32, k32[q]) : keys[sl[q]];
                         }
                     }
                 }
