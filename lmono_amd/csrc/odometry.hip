@@ -124,7 +124,8 @@ __global__ __launch_bounds__(1024) void k_grid_build(BatchView b)
         for (int i = tid; i < P; i += 1024) { keys[i] = kEmptyKey32; cnt[i] = 0; }
         if (tid == 0) { s_before = 0; s_fail = 0; s_occ = 0; }
         __syncthreads();
-        for (int pass = 0; pass < 2; pass++) {
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++) {       // unrolled: two specialised copies (insert / look up and scatter)
             int before = 0;
             bool fail = false;
             // 256 consecutive points per wave and round (lane l owns points t0 + 64 q + l, q = 0..3): four independent chains
