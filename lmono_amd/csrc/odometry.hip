@@ -634,11 +634,12 @@ __device__ __forceinline__ void nn_sweep_rows(const float4 *lpts, int run, int v
 }
 
 // gl = lane inside the 32-lane group, gbase = first wave lane of the group (0 or 32)
+template <bool kEdge>     // edge (corner cloud) and plane (surf cloud) features as two specialised copies: no per-lane pointer selects
 __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi, const double *x, int gl, int gbase, int seed, int &closest_out)
 {
     closest_out = -1;
     const int n_sharp = b.feat_n[k * 4 + 0];
-    const bool edge = qi < n_sharp;
+    constexpr bool edge = kEdge;
     const float4 p = edge ? b.sharp[(size_t)k * kMaxSharp + qi] : b.flat[(size_t)k * kMaxFlat + (qi - n_sharp)];
     double rx, ry, rz;
     quat_rotate(x, (double)p.x, (double)p.y, (double)p.z, rx, ry, rz);
@@ -878,7 +879,8 @@ __global__ __launch_bounds__(256, 8) void k_correspond(BatchView b, OdomView o, 
     if (qi >= nq) return;
     int *seed_c = o.seed ? o.seed + (size_t)c * kMaxQueries : nullptr;
     int closest;
-    const int4 r = correspond_g32(b, k, qi, x, gl, gbase, (outer == 1 && seed_c) ? seed_c[qi] : -1, closest);
+    const int seed = (outer == 1 && seed_c) ? seed_c[qi] : -1;
+    const int4 r = qi < n_sharp ? correspond_g32<true>(b, k, qi, x, gl, gbase, seed, closest) : correspond_g32<false>(b, k, qi, x, gl, gbase, seed, closest);
     if (gl == 0) { corr[qi] = r; if (outer == 0 && seed_c) seed_c[qi] = closest; }
     // residual-block record for the solver: the feature point and its 2 (edge) or 3 (plane) partners, 64 B
     if (gl < 4) {
