@@ -594,14 +594,16 @@ __device__ __forceinline__ void nn_sweep(const float4 *gpts, int run, int gl, in
         const int st = rv & 0x1ffff, cn = src >= 0 ? rv >> 17 : 0;
         int i = sl;
         while (__any(i < cn)) {
-            float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0, v2 = v0;
+            float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0, v2 = v0, v3 = v0;
             if (i < cn) v0 = gpts[st + i];
             if (i + 8 < cn) v1 = gpts[st + i + 8];
             if (i + 16 < cn) v2 = gpts[st + i + 16];
+            if (i + 24 < cn) v3 = gpts[st + i + 24];
             if (i < cn) nn_update(nb, v0, qx, qy, qz);
             if (i + 8 < cn) nn_update(nb, v1, qx, qy, qz);
             if (i + 16 < cn) nn_update(nb, v2, qx, qy, qz);
-            i += 24;
+            if (i + 24 < cn) nn_update(nb, v3, qx, qy, qz);
+            i += 32;
         }
     }
 }
@@ -811,14 +813,16 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
             const int r0 = rv & 0x1ffff, cnw = wsub < 5 ? rv >> 17 : 0;
             int i = wsl;
             while (__any(i < cnw)) {
-                float4 v0 = make_float4(0.f, 0.f, 0.f, __int_as_float(-1)), v1 = v0, v2 = v0;
+                float4 v0 = make_float4(0.f, 0.f, 0.f, __int_as_float(-1)), v1 = v0, v2 = v0, v3 = v0;
                 if (i < cnw) v0 = lb_pts[r0 + i];
                 if (i + 6 < cnw) v1 = lb_pts[r0 + i + 6];
                 if (i + 12 < cnw) v2 = lb_pts[r0 + i + 12];
+                if (i + 18 < cnw) v3 = lb_pts[r0 + i + 18];
                 if (i < cnw) walk_point(v0, wv, ra, closest, w_lo, w_hi, edge, qx, qy, qz, bs, bo);
                 if (i + 6 < cnw) walk_point(v1, wv, ra, closest, w_lo, w_hi, edge, qx, qy, qz, bs, bo);
                 if (i + 12 < cnw) walk_point(v2, wv, ra, closest, w_lo, w_hi, edge, qx, qy, qz, bs, bo);
-                i += 18;
+                if (i + 18 < cnw) walk_point(v3, wv, ra, closest, w_lo, w_hi, edge, qx, qy, qz, bs, bo);
+                i += 24;
             }
         }
         same = group_min_u64(bs, gbase);
