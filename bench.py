@@ -279,16 +279,85 @@ def bench_posegraph(args):
         dist.destroy_process_group()
 
 
+GOLDEN = os.path.join(ROOT, "tests", "golden", "s1_seq00_oracle.npz")
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as fresh child processes (the
+    driver's own command line: torch.distributed.run, one rank per GPU) BEFORE anything in this process touches the GPU,
+    and exit with the children's code.  The parent imports neither torch nor the HIP library."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def probe_ranks(args):
+    """--probe-ranks: the launcher check used by the CPU tests -- every rank joins a gloo group, the ranks are counted with
+    one all-reduce and rank 0 prints the count.  No GPU call."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.ones(1, dtype=torch.int64)
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"probe": "ranks", "n_gpus": world, "ranks_seen": int(t.item()), "requested": args.gpus}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def ba_secondary(ctx, windows=1024, steps=3):
+    """BASELINE configs[2] shape beside the headline (VERDICT r1 item 7): batched Estimator::optimization() solves and the
+    batch-1 latency the reference's own operating point (one sequence, one window per frame) sees."""
+    import lmono_amd
+    from workloads import s2 as K
+    base = [K.make_window(s) for s in range(16)]
+    b = lmono_amd.BaBatch(ctx, [base[k % 16] for k in range(windows)])
+    b.reset(); b.solve(30); ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        b.reset(); b.solve(30)
+    ctx.synchronize()
+    el = (time.perf_counter() - t0) / steps
+    _, _, _, sm = b.read()
+    n_obs = float(np.mean([len(w["obs_feat"]) for w in base])); iters = float(sm[:, 2].mean())
+    flops = (2.0e3 * n_obs + 72.0 ** 3 / 3.0) * iters * windows
+    one = lmono_amd.BaBatch(ctx, [base[0]])
+    one.reset(); one.solve(30); ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        one.reset(); one.solve(30)
+    ctx.synchronize()
+    lat = (time.perf_counter() - t0) / 10
+    return {"workload": "S2 11-frame windows (configs[2] shape), Estimator::optimization() solve, <= 30 dogleg iterations",
+            "windows_per_s": round(windows / el, 1), "batch": windows, "single_window_latency_ms": round(lat * 1e3, 3),
+            "mean_iterations": iters, "fp64_tflops": round(flops / el / 1e12, 3), "fp64_frac": round(flops / el / 1e12 / FP64_PEAK_TFLOPS, 5)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scans", type=int, default=4541, help="scans per GPU (KITTI seq 00 = 4541)")
-    ap.add_argument("--chains", type=int, default=256, help="concurrent odometry chains per GPU")
-    ap.add_argument("--lead", type=int, default=5, help="lead-in scans of a chain that does not start at scan 0")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scans", type=int, default=4541, help="scans per GPU (weak) or in total (strong); KITTI seq 00 = 4541")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank gets --scans scans of one long trajectory; strong: --scans scans in total, sharded "
+                         "over the ranks (BASELINE configs[3]: seq 00 sharded across 8)")
+    ap.add_argument("--chains", type=int, default=256, help="concurrent odometry chains per GPU (strong scaling: in total)")
+    ap.add_argument("--lead", type=int, default=8, help="lead-in scans of a chain that does not start at scan 0")
     ap.add_argument("--az", type=int, default=2000, help="azimuth steps per ring (2000 = HDL-64 at 10 Hz)")
     ap.add_argument("--cpu-sample", type=int, default=384, help="scans of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (sequential run, BA secondary)")
+    ap.add_argument("--probe-ranks", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--workload", default="lidar", choices=["lidar", "ba", "map", "colour", "posegraph"],
                     help="lidar = headline (BASELINE configs[1]); ba = configs[2]-shaped sliding-window BA solves (secondary); "
                          "map = laserMapping over a synthetic sequence, one stream (SURVEY 8f-1)")
@@ -297,6 +366,10 @@ def main():
     ap.add_argument("--frames", type=int, default=20, help="colour: frames per stream and step")
     ap.add_argument("--keyframes", type=int, default=4541, help="posegraph: keyframes of the graph")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    if args.probe_ranks:
+        return probe_ranks(args)
     if args.workload == "ba":
         return bench_ba(args)
     if args.workload == "map":
@@ -309,12 +382,13 @@ def main():
     import torch
     import torch.distributed as dist
     import lmono_amd
-    from lmono_amd import sharding
+    from lmono_amd import sharding, trajectory
     from workloads import s1 as S1       # synthetic S1 scans (input plumbing)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "--gpus %d but the launcher started %d ranks" % (args.gpus, world)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -322,11 +396,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    n = args.scans
-    n_total = n * world
+    strong = args.scaling == "strong"
+    n_total = args.scans if strong else args.scans * world
     load_begin, own_begin, own_end = sharding.shard_range(n_total, world, rank, args.lead)
     lead_r = own_begin - load_begin
     n_local = own_end - load_begin
+    n_own = own_end - own_begin
 
     t0 = time.time()
     w = S1.S1World(n_az=args.az)
@@ -349,8 +424,8 @@ def main():
 
     batch = lmono_amd.ScanBatch(ctx, n_local, total_pts)
     incr_d = torch.zeros((n_local, 7), dtype=torch.float64, device=dev)
-    poses_d = torch.zeros((n_local - lead_r, 7), dtype=torch.float64, device=dev)
-    chains = min(args.chains, n_local)
+    poses_d = torch.zeros((n_own, 7), dtype=torch.float64, device=dev)
+    chains = max(1, min(args.chains // world if strong else args.chains, n_local))
 
     def step():
         batch.scanreg(xyzi_d.data_ptr(), off, 64, 5.0, keepalive=xyzi_d)
@@ -359,7 +434,7 @@ def main():
         if world > 1:
             bases = sharding.gather_bases(poses_d[-1].clone())
             # the first owned increment composes onto the previous rank's last pose
-            ctx.pose_rebase_d(bases.data_ptr(), rank, poses_d.data_ptr(), n_local - lead_r)
+            ctx.pose_rebase_d(bases.data_ptr(), rank, poses_d.data_ptr(), n_own)
 
     def barrier():
         if world > 1:
@@ -385,6 +460,36 @@ def main():
     status_or = int(np.bitwise_or.reduce(cnt[:, 5]))
     n_cloud_mean = float(cnt[:, 0].mean())
     gpu_incr = incr_d.cpu().numpy()
+    gpu_poses = poses_d.cpu().numpy()
+
+    # ---- tolerance of the timed run: its poses against the committed trajectory of the strictly sequential CPU path over
+    # the WHOLE sequence (tests/golden/s1_seq00_oracle.npz: data, not the oracle), every owned scan the fixture covers
+    parity = None
+    if args.az == 2000 and os.path.exists(GOLDEN):
+        gold = np.load(GOLDEN)
+        gp, gi, gc = gold["poses"], gold["incr"], gold["feat_counts"]
+        hi = min(own_end, len(gp))
+        sums = np.zeros(6)
+        if hi > own_begin:
+            m = hi - own_begin
+            s2, cnt_a = trajectory.ate_sums(gpu_poses[:m], gp[own_begin:hi])
+            st, sr, cnt_r = trajectory.rpe_from_relative(gpu_incr[lead_r:lead_r + m], gi[own_begin:hi])
+            feat_equal = float((cnt[lead_r:lead_r + m, 1:5] == gc[own_begin:hi]).all())
+            sums = np.array([s2, cnt_a, st, sr, cnt_r, 1.0 - feat_equal])
+        if world > 1:
+            ts = torch.from_numpy(sums).to(dev)
+            dist.all_reduce(ts)
+            sums = ts.cpu().numpy()
+        if sums[1] > 0:
+            parity = {"reference": "tests/golden/s1_seq00_oracle.npz (sequential CPU oracle, n_chains 1, lead 0)",
+                      "scans_compared": int(sums[1]),
+                      "ate_vs_cpu_m": round(float(np.sqrt(sums[0] / sums[1])), 6),
+                      "rpe_vs_cpu": {"delta_scans": 1, "trans_rmse_m": round(float(np.sqrt(sums[2] / sums[4])), 7),
+                                     "rot_rmse_deg": round(float(np.degrees(np.sqrt(sums[3] / sums[4]))), 7)},
+                      "feature_counts_equal": bool(sums[5] == 0)}
+            if world == 1:
+                r100 = trajectory.rpe(gpu_poses[:hi], gp[:hi], delta=100)
+                parity["rpe_vs_cpu_100"] = {"delta_scans": 100, "trans_rmse_m": round(r100["trans_rmse_m"], 6), "rot_rmse_deg": round(r100["rot_rmse_deg"], 6)}
 
     if rank == 0:
         scans_per_s = n_total * args.steps / elapsed
@@ -418,27 +523,60 @@ def main():
         # HBM bytes per launch of the dominant kernel from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE and
         # WRITE_SIZE in separate passes, gfx950 correction applied; scripts/profile_round.sh); null if not collected for it
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r1", "pmc_%s.json" % dom)
-        if os.path.exists(pmc_path) and chains == 256:
-            with open(pmc_path) as fh:
-                traffic = json.load(fh)["hbm_bytes_per_launch"]
+        for rnd in ("r2", "r1"):
+            pmc_path = os.path.join(ROOT, "profiles", rnd, "pmc_%s.json" % dom)
+            if os.path.exists(pmc_path) and chains == 256:
+                with open(pmc_path) as fh:
+                    traffic = json.load(fh)["hbm_bytes_per_launch"]
+                break
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "ms_per_launch": round(ms_launch, 4), "launches_per_step": round(launches_per_step[dom], 1),
                     "frontend_fused_frac": round(37 * N * n_local / (groups["frontend_total"] / max(n_reg, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "whole_step_frac": round((37 * N + 0.77e6) * n_local / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
                     "group_ms_per_step": {k: round(v / max(args.steps, 1), 3) for k, v in groups.items() if k != "odometry_launch_pairs"}}
         out = {
             "metric": "KITTI HDL-64 scans/sec (scanRegistration + laserOdometry)", "value": round(scans_per_s, 1),
             "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32 features / f64 solve", "data": "synthetic",
             "config": {"workload": "KITTI-seq-00-shaped synthetic S1 HDL-64, laserOdometry-only (configs[1])",
-                       "scans_per_gpu": n, "points_per_scan": round(N), "azimuth_steps": args.az,
-                       "odometry_chains": chains, "chain_lead_in": args.lead, "parallelism": "scan-range shard x%d" % world,
-                       "status_or": status_or, "gen_s": round(gen_s, 1), "h2d_s": round(h2d_s, 2),
+                       "scans_total": n_total, "scans_per_gpu": n_own, "points_per_scan": round(N), "azimuth_steps": args.az,
+                       "odometry_chains_per_gpu": chains, "chain_lead_in": args.lead,
+                       "parallelism": "scan-range shard x%d, one RCCL all-gather of 7 doubles per rank" % world,
+                       "collective_ranks": world, "status_or": status_or, "gen_s": round(gen_s, 1), "h2d_s": round(h2d_s, 2),
                        "h2d_GBps": round(total_pts * 16 / h2d_s / 1e9, 1)},
             "roofline": roofline,
         }
+        if parity is not None:
+            out["ate_vs_cpu_m"] = parity["ate_vs_cpu_m"]
+            out["rpe_vs_cpu"] = parity["rpe_vs_cpu"]
+            out["parity"] = parity
+        m_gt = min(n_own, len(traj))
+        out["ate_vs_truth_m"] = round(trajectory.ate(gpu_poses[:m_gt], _gt_relative(traj[:m_gt])), 4) if rank == 0 and own_begin == 0 else None
+        if world == 1 and not args.no_extras:
+            # ---- untimed extras.  (1) A-LOAM's own schedule: ONE chain, no lead-in (every scan pair warm-started from the
+            # previous increment) -- the run whose poses must EQUAL the CPU path's, and the throughput of that schedule
+            seq_incr = torch.zeros((n_local, 7), dtype=torch.float64, device=dev)
+            seq_poses = torch.zeros((n_local, 7), dtype=torch.float64, device=dev)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            batch.odometry_d(1, 0, seq_incr.data_ptr(), None)
+            ctx.pose_prefix_d(seq_incr.data_ptr(), 0, n_local, seq_poses.data_ptr())
+            torch.cuda.synchronize()
+            seq_s = time.perf_counter() - t0
+            out["sequential"] = {"schedule": "n_chains 1, lead 0 (the reference's: strictly sequential warm starts), odometry stage only",
+                                 "odometry_scans_per_s": round(n_local / seq_s, 1)}
+            if parity is not None:
+                sp = seq_poses.cpu().numpy()
+                hi = min(n_local, len(gp))
+                out["sequential"]["max_abs_pose_diff_vs_cpu"] = float(np.abs(sp[:hi] - gp[:hi]).max())
+                out["sequential"]["ate_vs_cpu_m"] = round(trajectory.ate(sp[:hi], gp[:hi]), 9)
+            # (2) the Estimator half beside the headline
+            try:
+                out["secondary"] = {"ba": ba_secondary(ctx)}
+            except Exception as e:       # the secondary line must never take the headline down
+                out["secondary"] = {"ba": {"error": repr(e)}}
         if sample is not None:
             # ---- cpu_baseline leg: the only place the oracle is touched
             from oracle import oracle as O
@@ -447,8 +585,6 @@ def main():
             t0 = time.time()
             ref = O.run_sequence(sx, so, threads=1)
             cpu_s = time.time() - t0
-            # parity of the timed GPU run against the CPU path on the sample: chain-sharded GPU vs strictly sequential CPU
-            gp = sharding.prefix(gpu_incr[:m])
             out["cpu_baseline"] = {"value": round(m / cpu_s, 2), "unit": "scans/s", "cores": 1, "kind": "port",
                                    "sample": "first %d scans of the same sequence, oracle/ C restatement (-O3, kd-tree), 1 thread: scanreg %.0f ms + odometry %.0f ms"
                                              % (m, ref["stage_ms"][0], ref["stage_ms"][1])}
@@ -463,11 +599,21 @@ def main():
                 out["cpu_baseline_all_cores"] = {"value": round(m / cpu_mt, 2), "unit": "scans/s", "cores": cores, "kind": "port",
                                                  "sample": "the same %d scans, OpenMP over scans / %d odometry chains with lead-in %d: scanreg %.0f ms + odometry %.0f ms"
                                                            % (m, cores, args.lead, ref_mt["stage_ms"][0], ref_mt["stage_ms"][1])}
-            out["ate_vs_cpu_m"] = round(O.ate(gp, ref["poses"]), 6)
-            out["ate_vs_truth_m"] = round(O.ate(gp, O.gt_relative(traj[:m])), 4)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def _gt_relative(poses):
+    """Ground-truth sensor poses relative to scan 0 as [n,7] (q xyzw, t): the planar S1 trajectory (x, y, z, yaw)."""
+    out = np.zeros((len(poses), 7))
+    x0, y0, z0, yaw0 = poses[0]
+    c, s = np.cos(-yaw0), np.sin(-yaw0)
+    dx, dy = poses[:, 0] - x0, poses[:, 1] - y0
+    out[:, 4] = c * dx - s * dy; out[:, 5] = s * dx + c * dy; out[:, 6] = poses[:, 2] - z0
+    half = 0.5 * (poses[:, 3] - yaw0)
+    out[:, 2] = np.sin(half); out[:, 3] = np.cos(half)
+    return out
 
 
 if __name__ == "__main__":

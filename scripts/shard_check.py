@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import lmono_amd                      # noqa: E402
 from lmono_amd import sharding        # noqa: E402
-from oracle import oracle as O        # noqa: E402  (synthetic generator only)
+from workloads import s1 as O         # noqa: E402  (synthetic generator)
 
 
 def main():

@@ -1,0 +1,66 @@
+"""The headline configuration checked at its tolerance over the WHOLE configs[1] sequence: 4541 S1 scans,
+the bench's (chains, lead), against the committed trajectory of the strictly sequential CPU oracle
+(tests/golden/s1_seq00_oracle.npz, generator tests/golden/make_s1_trajectory.py).  Also: the GPU's own sequential schedule
+(n_chains 1, lead 0) reproduces that trajectory, and the front end's feature counts are equal for every scan."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _bench_defaults():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    chains = int(re.search(r'"--chains", type=int, default=(\d+)', src).group(1))
+    lead = int(re.search(r'"--lead", type=int, default=(\d+)', src).group(1))
+    return chains, lead
+
+
+@pytest.fixture(scope="module")
+def seq00(gpu_ctx):
+    import torch
+    import lmono_amd
+    from workloads import s1 as S1
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "s1_seq00_oracle.npz"))
+    n = len(gold["poses"])
+    w = S1.S1World(n_az=2000)
+    traj = w.trajectory(n)
+    xyzi, off = w.scans(traj)
+    assert (np.diff(off) == gold["n_points"]).all(), "the S1 generator no longer produces the fixture's scans"
+    xd = torch.from_numpy(xyzi).cuda()
+    del xyzi
+    batch = lmono_amd.ScanBatch(gpu_ctx, n, int(off[-1]))
+    batch.scanreg(xd.data_ptr(), off, 64, 5.0, keepalive=xd)
+    return dict(batch=batch, gold=gold, n=n)
+
+
+def test_front_end_feature_counts_equal_over_4541_scans(seq00):
+    cnt = seq00["batch"].counts()
+    assert (cnt[:, 5] == 0).all()
+    assert (cnt[:, 1:5] == seq00["gold"]["feat_counts"]).all()
+
+
+def test_sequential_schedule_reproduces_the_cpu_trajectory(seq00):
+    incr, poses = seq00["batch"].odometry(1, 0)
+    g = seq00["gold"]
+    assert np.abs(incr - g["incr"]).max() < 1e-7
+    assert np.abs(poses - g["poses"]).max() < 1e-5          # 4540 composed increments
+    from lmono_amd import trajectory
+    assert trajectory.ate(poses, g["poses"]) < 1e-6
+
+
+def test_bench_schedule_meets_the_1cm_bar_over_the_whole_sequence(seq00):
+    from lmono_amd import trajectory
+    chains, lead = _bench_defaults()
+    incr, poses = seq00["batch"].odometry(chains, lead)
+    g = seq00["gold"]
+    ate = trajectory.ate(poses, g["poses"])
+    r1 = trajectory.rpe(poses, g["poses"], 1)
+    r100 = trajectory.rpe(poses, g["poses"], 100)
+    print("chains %d lead %d: ATE %.5f m, RPE(1) %.2e m / %.2e deg, RPE(100) %.2e m / %.2e deg"
+          % (chains, lead, ate, r1["trans_rmse_m"], r1["rot_rmse_deg"], r100["trans_rmse_m"], r100["rot_rmse_deg"]))
+    assert ate <= 0.01                                     # north_star: ATE within 1 cm of the reference path
+    assert r1["trans_rmse_m"] <= 1e-3 and r1["rot_rmse_deg"] <= 1e-3
