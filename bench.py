@@ -353,7 +353,7 @@ def main():
                     help="weak: every rank gets --scans scans of one long trajectory; strong: --scans scans in total, sharded "
                          "over the ranks (BASELINE configs[3]: seq 00 sharded across 8)")
     ap.add_argument("--chains", type=int, default=256, help="concurrent odometry chains per GPU (strong scaling: in total)")
-    ap.add_argument("--lead", type=int, default=8, help="lead-in scans of a chain that does not start at scan 0")
+    ap.add_argument("--lead", type=int, default=7, help="lead-in scans of a chain that does not start at scan 0")
     ap.add_argument("--az", type=int, default=2000, help="azimuth steps per ring (2000 = HDL-64 at 10 Hz)")
     ap.add_argument("--cpu-sample", type=int, default=384, help="scans of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (sequential run, BA secondary)")
