@@ -37,6 +37,12 @@ void        lmono_destroy(lmono_ctx *);
 const char *lmono_last_error(const lmono_ctx *);
 int         lmono_set_stream(lmono_ctx *, void *hip_stream); /* hipStream_t; NULL = default  */
 int         lmono_synchronize(lmono_ctx *);
+/* Tuning / test switches of a context (no reference counterpart).  LMONO_OPT_CORR_TILE: 1 (default) = the laserOdometry
+ * correspondence search runs from LDS-staged azimuth sectors (k_corr_tile) with the global-memory search (k_correspond_list) for
+ * the feature points it defers; 0 = every feature point through the global-memory search (k_correspond).  Results are identical. */
+#define LMONO_OPT_CORR_TILE 0
+#define LMONO_OPT_COUNT     1
+int         lmono_set_option(lmono_ctx *, int key, int value);
 const char *lmono_version(void);
 
 /* ---- LiDAR front end: A-LOAM scanRegistration::laserCloudHandler ------------------------ *

@@ -9,7 +9,7 @@ MAX_QUERIES = 64 * 6 * 2 + 64 * 6 * 4
 
 # every symbol include/lmono_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "lmono_create", "lmono_destroy", "lmono_last_error", "lmono_set_stream", "lmono_synchronize", "lmono_version",
+    "lmono_create", "lmono_destroy", "lmono_last_error", "lmono_set_stream", "lmono_set_option", "lmono_synchronize", "lmono_version",
     "lmono_batch_create", "lmono_batch_destroy", "lmono_scanreg_batch", "lmono_scanreg_batch_h", "lmono_batch_counts", "lmono_batch_get_cloud",
     "lmono_batch_get_curvature", "lmono_odom_batch", "lmono_odom_batch_d", "lmono_odom_correspond", "lmono_timing_reset", "lmono_timing_read",
     "lmono_pose_prefix_d", "lmono_pose_rebase_d", "lmono_map_refine", "lmono_voxel_filter", "lmono_mapper_create", "lmono_mapper_destroy", "lmono_mapper_reset", "lmono_mapper_process", "lmono_mapper_process_batch", "lmono_mapper_cube",
@@ -48,6 +48,7 @@ def load_library():
     L.lmono_version.restype = C.c_char_p
     L.lmono_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     L.lmono_synchronize.argtypes = [C.c_void_p]
+    L.lmono_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.lmono_batch_create.restype = C.c_void_p
     L.lmono_batch_create.argtypes = [C.c_void_p, C.c_int, C.c_int64]
     L.lmono_batch_destroy.argtypes = [C.c_void_p]
@@ -89,6 +90,8 @@ class Context:
         if not self.h:
             raise LmonoError("lmono_create(%d) failed: no usable HIP device" % device)
         self.device = device
+        if os.environ.get("LMONO_CORR_TILE") is not None:       # A/B switch for measurements (default: tile search on)
+            self.L.lmono_set_option(self.h, 0, int(os.environ["LMONO_CORR_TILE"]))
 
     def check(self, rc):
         if rc < 0:
@@ -104,16 +107,21 @@ class Context:
     def synchronize(self):
         self.check(self.L.lmono_synchronize(self.h))
 
+    OPT_CORR_TILE = 0
+
+    def set_option(self, key, value):
+        self.check(self.L.lmono_set_option(self.h, int(key), int(value)))
+
     def timing_reset(self):
         self.check(self.L.lmono_timing_reset(self.h))
 
     def timing(self):
         """Summed device ms per kernel group since timing_reset(): dict + call counts."""
-        ms = np.zeros(12)
+        ms = np.zeros(13)
         nr, no = C.c_int(0), C.c_int(0)
-        self.check(self.L.lmono_timing_read(self.h, ms.ctypes.data, 12, C.byref(nr), C.byref(no)))
+        self.check(self.L.lmono_timing_read(self.h, ms.ctypes.data, 13, C.byref(nr), C.byref(no)))
         names = ["frontend_total", "odometry_total", "k_ring_sort", "k_curvature", "k_select", "k_voxel", "k_compact",
-                 "k_grid_build", "k_line_index", "k_correspond", "k_lm_solve", "odometry_launch_pairs"]
+                 "k_grid_build", "k_line_index", "k_correspond", "k_lm_solve", "odometry_launch_pairs", "deferred_features"]
         return dict(zip(names, ms.tolist())), nr.value, no.value
 
     FACTOR_DIMS = {0: (14, 24, 36, 6, 84), 1: (22, 4, 4, 2, 44), 2: (7, 16, 2, 6, 42), 3: (1, 44, 1, 2, 2)}

@@ -2,6 +2,7 @@
 // the kernel files are included so that one `hipcc -shared` produces liblmono_hip.so.
 #include "frontend.hip"
 #include "odometry.hip"
+#include "corr_tile.hip"
 #include "mapping.hip"
 #include "ba.hip"
 #include "ba_solve.hip"
@@ -15,6 +16,8 @@
 #include <cstdio>
 #include <cstring>
 
+constexpr int kListGrid = 1024;      // workgroups of k_correspond_list (fixed: the work list's length is only known on the device)
+
 using namespace lmono;
 
 struct EvSet { hipEvent_t e[10]; bool reg = false, odom = false; std::vector<hipEvent_t> kev; int n_kev = 0; };  // kev: (begin, mid, end) per odometry launch pair
@@ -26,6 +29,8 @@ struct lmono_ctx {
     std::vector<EvSet> sets;   // one event set per scanreg/odometry call since the last lmono_timing_reset
     int n_sets = 0;
     hipEvent_t *ev = nullptr;  // events of the current call
+    int opt[LMONO_OPT_COUNT] = { 1 };   // LMONO_OPT_CORR_TILE on by default
+    unsigned long long *stats_d = nullptr;   // [0] feature points deferred by the tile search since the last lmono_timing_reset
 
     hipEvent_t *next_set()
     {
@@ -61,6 +66,8 @@ struct lmono_scan_batch {
     double *state = nullptr, *incr = nullptr, *poses = nullptr, *xq = nullptr;
     int *corr = nullptr, *lm_info = nullptr, *corr_pair = nullptr, *seed = nullptr;
     float4 *crec = nullptr, *crec_pair = nullptr;
+    unsigned int *wl = nullptr;            // work list of feature points the LDS tile search defers: [0] = count
+    size_t wl_cap = 0;
 };
 
 #define HIP_TRY(ctx, expr)                                                                   \
@@ -81,12 +88,15 @@ extern "C" lmono_ctx *lmono_create(int device)
     if (hipSetDevice(device) != hipSuccess) return nullptr;
     lmono_ctx *c = new lmono_ctx();
     c->device = device;
+    if (hipMalloc((void **)&c->stats_d, 16) != hipSuccess || hipMemset(c->stats_d, 0, 16) != hipSuccess) { delete c; return nullptr; }
     // the selection kernel needs ~62 KB of dynamic LDS
     if (hipFuncSetAttribute((const void *)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kSelWaveLds) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_voxel<kVoxSmallSlots, kVoxSmallBits, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kVoxLdsSmall) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_voxel<kVoxBigSlots, kVoxBigBits, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kVoxLdsBig) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_lm_solve, hipFuncAttributeMaxDynamicSharedMemorySize, kLmRecLds) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_grid_build, hipFuncAttributeMaxDynamicSharedMemorySize, kGridLds) != hipSuccess) { delete c; return nullptr; }
+    if (hipFuncSetAttribute((const void *)k_line_index, hipFuncAttributeMaxDynamicSharedMemorySize, kLiLds) != hipSuccess) { delete c; return nullptr; }
+    if (hipFuncSetAttribute((const void *)k_corr_tile, hipFuncAttributeMaxDynamicSharedMemorySize, kTileLds) != hipSuccess) { delete c; return nullptr; }
     return c;
 }
 
@@ -94,6 +104,7 @@ extern "C" void lmono_destroy(lmono_ctx *c)
 {
     if (!c) return;
     for (auto &s : c->sets) { for (auto &e : s.e) (void)hipEventDestroy(e); for (auto &e : s.kev) (void)hipEventDestroy(e); }
+    if (c->stats_d) (void)hipFree(c->stats_d);
     delete c;
 }
 
@@ -103,6 +114,13 @@ extern "C" int lmono_set_stream(lmono_ctx *c, void *s)
 {
     if (!c) return LMONO_EINVAL;
     c->stream = (hipStream_t)s;
+    return LMONO_OK;
+}
+
+extern "C" int lmono_set_option(lmono_ctx *c, int key, int value)
+{
+    if (!c || key < 0 || key >= LMONO_OPT_COUNT) return LMONO_EINVAL;
+    c->opt[key] = value;
     return LMONO_OK;
 }
 
@@ -151,7 +169,7 @@ extern "C" lmono_scan_batch *lmono_batch_create(lmono_ctx *c, int n_cap, int64_t
     ok = ok && dalloc(b, v.feat_n, N * 4) && dalloc(b, v.line_first_ge, N * 2 * 66) && dalloc(b, v.line_last_le, N * 2 * 66);
     ok = ok && dalloc(b, v.cg_cell, N * kCornerTable) && dalloc(b, v.sg_cell, N * kSurfTable);
     ok = ok && dalloc(b, v.cg_pts, N * kMaxLessSharp) && dalloc(b, v.sg_pts, T) && dalloc(b, v.grid_mask, N * 2);
-    ok = ok && dalloc(b, v.lbc_pts, N * kMaxLessSharp) && dalloc(b, v.lbs_pts, T) && dalloc(b, v.lb_start, N * 2 * (kLineKeys + 1));
+    ok = ok && dalloc(b, v.lbc_pts, N * kMaxLessSharp) && dalloc(b, v.lbs_pts, T) && dalloc(b, v.lb_start, N * 2 * (kLineKeys + 1)) && dalloc(b, v.lb_elev, N * 2 * 66);
     ok = ok && dalloc(b, b->incr, N * 7) && dalloc(b, b->poses, N * 7) && dalloc(b, b->xq, 8);
     ok = ok && dalloc(b, b->corr_pair, (size_t)kMaxQueries * 4) && dalloc(b, b->crec_pair, (size_t)kMaxQueries * 4);
     if (!ok) {
@@ -244,7 +262,7 @@ extern "C" int lmono_scanreg_batch(lmono_ctx *c, lmono_scan_batch *b, const floa
     HIP_TRY(c, hipEventRecord(c->ev[5], st));
     hipLaunchKernelGGL(k_grid_build, dim3(n_scans, 1 + kGridPar), dim3(1024), kGridLds, st, v);
     HIP_TRY(c, hipEventRecord(c->ev[6], st));
-    hipLaunchKernelGGL(k_line_index, dim3(n_scans, 2), dim3(kLiT), 0, st, v);
+    hipLaunchKernelGGL(k_line_index, dim3(n_scans, 2), dim3(kLiT), kLiLds, st, v);
     HIP_TRY(c, hipEventRecord(c->ev[7], st));
     int rc = check_launch(c, "scanreg kernels");
     if (rc) return rc;
@@ -256,6 +274,7 @@ extern "C" int lmono_timing_reset(lmono_ctx *c)
 {
     if (!c) return LMONO_EINVAL;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemset(c->stats_d, 0, 16));
     c->n_sets = 0;
     return LMONO_OK;
 }
@@ -264,7 +283,7 @@ extern "C" int lmono_timing_read(lmono_ctx *c, double *ms, int cap, int *n_scanr
 {
     if (!c || !ms) return LMONO_EINVAL;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    double sum[12] = { 0 };
+    double sum[13] = { 0 };
     int nr = 0, no = 0;
     float t;
     for (int i = 0; i < c->n_sets; i++) {
@@ -286,7 +305,12 @@ extern "C" int lmono_timing_read(lmono_ctx *c, double *ms, int cap, int *n_scanr
             }
         }
     }
-    for (int i = 0; i < cap && i < 12; i++) ms[i] = sum[i];
+    {
+        unsigned long long st[2] = { 0, 0 };
+        HIP_TRY(c, hipMemcpy(st, c->stats_d, 16, hipMemcpyDeviceToHost));
+        sum[12] = (double)st[0];
+    }
+    for (int i = 0; i < cap && i < 13; i++) ms[i] = sum[i];
     if (n_scanreg_calls) *n_scanreg_calls = nr;
     if (n_odom_calls) *n_odom_calls = no;
     return LMONO_OK;
@@ -351,7 +375,7 @@ static int ensure_odom_ws(lmono_ctx *c, lmono_scan_batch *b, int n_chains)
     // (re)allocate; old buffers stay in allocs and are freed with the batch
     bool ok = dalloc(b, b->state, (size_t)n_chains * 8) && dalloc(b, b->corr, (size_t)n_chains * kMaxQueries * 4) &&
               dalloc(b, b->lm_info, (size_t)n_chains * 4) && dalloc(b, b->crec, (size_t)n_chains * kMaxQueries * 4) &&
-              dalloc(b, b->seed, (size_t)n_chains * kMaxQueries);
+              dalloc(b, b->seed, (size_t)n_chains * kMaxQueries) && dalloc(b, b->wl, (size_t)n_chains * kMaxQueries + 1);
     if (!ok) { c->err = "odometry workspace: hipMalloc failed"; return LMONO_ENOMEM; }
     b->chains_cap = n_chains;
     return LMONO_OK;
@@ -383,6 +407,8 @@ static int odom_run(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, d
     HIP_TRY(c, hipEventRecord(c->ev[8], st));
     const int ninit = n > n_chains ? n : n_chains;
     hipLaunchKernelGGL(k_odom_init, dim3((ninit + 255) / 256), dim3(256), 0, st, o);
+    const bool tile = c->opt[LMONO_OPT_CORR_TILE] != 0;
+    if (tile) HIP_TRY(c, hipMemsetAsync(b->wl, 0, sizeof(unsigned int), st));
     EvSet &es = c->sets[c->n_sets - 1];
     auto kev = [&](int i) -> hipEvent_t {
         while ((int)es.kev.size() <= i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; es.kev.push_back(e); }
@@ -393,9 +419,13 @@ static int odom_run(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, d
         for (int outer = 0; outer < 2; outer++) {
             hipEvent_t e0 = kev(ne), e1 = kev(ne + 1), e2 = kev(ne + 2);
             if (e0 && e1 && e2) (void)hipEventRecord(e0, st);
-            hipLaunchKernelGGL(k_correspond, dim3(8 * ((n_chains + 7) / 8) * kCorrBlocks), dim3(256), 0, st, b->v, o, step, outer);
+            if (tile) {
+                hipLaunchKernelGGL(k_corr_tile, dim3(8 * ((n_chains + 7) / 8) * kTSect), dim3(kTT), kTileLds, st, b->v, o, step, outer, b->wl);
+                hipLaunchKernelGGL(k_correspond_list, dim3(kListGrid), dim3(256), 0, st, b->v, o, step, outer, (const unsigned int *)b->wl, c->stats_d);
+            } else
+                hipLaunchKernelGGL(k_correspond, dim3(8 * ((n_chains + 7) / 8) * kCorrBlocks), dim3(256), 0, st, b->v, o, step, outer);
             if (e0 && e1 && e2) (void)hipEventRecord(e1, st);
-            hipLaunchKernelGGL(k_lm_solve, dim3(n_chains), dim3(kLmT), kLmRecLds, st, b->v, o, step, outer);
+            hipLaunchKernelGGL(k_lm_solve, dim3(n_chains), dim3(kLmT), kLmRecLds, st, b->v, o, step, outer, tile ? b->wl : (unsigned int *)nullptr);
             if (e0 && e1 && e2) { (void)hipEventRecord(e2, st); ne += 3; }
         }
     }
@@ -440,8 +470,16 @@ extern "C" int lmono_odom_correspond(lmono_ctx *c, lmono_scan_batch *b, int scan
     OdomView o;
     o.n_scans = b->n_scans; o.n_chains = 1; o.lead = 0; o.fixed_k = scan;
     o.state = b->xq; o.corr = b->corr_pair; o.incr = nullptr; o.lm_info = nullptr; o.crec = b->crec_pair; o.seed = nullptr;
-    hipLaunchKernelGGL(k_correspond, dim3(8 * kCorrBlocks), dim3(256), 0, c->stream, b->v, o, 0, 0);
-    int rc = check_launch(c, "k_correspond");
+    int rc;
+    if (c->opt[LMONO_OPT_CORR_TILE]) {
+        rc = ensure_odom_ws(c, b, 1);
+        if (rc) return rc;
+        HIP_TRY(c, hipMemsetAsync(b->wl, 0, sizeof(unsigned int), c->stream));
+        hipLaunchKernelGGL(k_corr_tile, dim3(8 * kTSect), dim3(kTT), kTileLds, c->stream, b->v, o, 0, 0, b->wl);
+        hipLaunchKernelGGL(k_correspond_list, dim3(kListGrid), dim3(256), 0, c->stream, b->v, o, 0, 0, (const unsigned int *)b->wl, c->stats_d);
+    } else
+        hipLaunchKernelGGL(k_correspond, dim3(8 * kCorrBlocks), dim3(256), 0, c->stream, b->v, o, 0, 0);
+    rc = check_launch(c, "k_correspond");
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (nq > 0) HIP_TRY(c, hipMemcpy(corr_h, b->corr_pair, sizeof(int) * 4 * nq, hipMemcpyDeviceToHost));

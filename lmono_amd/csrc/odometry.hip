@@ -430,7 +430,7 @@ __device__ __forceinline__ int chain_scan(const OdomView &o, int c, int step, in
 // within +-asin(5 / rho_xy) of its azimuth, and only on lines ra-2 .. ra+2.  k_line_index sorts a copy of every "last"
 // cloud by (line, azimuth bin) once per scan (counting sort in LDS), so that the walk of a feature is a handful of
 // short coalesced sweeps instead of a pass over five whole scan lines.
-constexpr int kAzBins = 128;
+constexpr int kAzBins = 384;           // 0.9375 deg: about one point of a 0.2 m-voxelised cloud per bin and line at 12 m
 constexpr int kLineKeys = 66 * kAzBins;
 
 __device__ __forceinline__ int az_bin(float x, float y)
@@ -444,8 +444,14 @@ __device__ __forceinline__ int line_of(float w)
     const int v = (int)w;
     return v < 0 ? 0 : (v > 65 ? 65 : v);
 }
+// elevation angle of a point as the index sees it (only ever compared with margins: no exactness requirement on atan2f)
+__device__ __forceinline__ float elev_of(float x, float y, float z) { return atan2f(z, sqrtf(x * x + y * y)); }
+// order-preserving float <-> int map for LDS atomicMin / atomicMax
+__device__ __forceinline__ int f2ord(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
+__device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
 
-constexpr int kLiT = 512;     // threads of k_line_index
+constexpr int kLiT = 1024;     // threads of k_line_index
+constexpr int kLiLds = kLineKeys * 4;   // dynamic LDS: one counter per (line, bin)
 __global__ __launch_bounds__(kLiT) void k_line_index(BatchView b)
 {
     const int s = blockIdx.x;
@@ -455,20 +461,43 @@ __global__ __launch_bounds__(kLiT) void k_line_index(BatchView b)
     const float4 *src = surf ? b.less_flat + b.off[s] : b.less_sharp + (size_t)s * kMaxLessSharp;
     float4 *dst = surf ? b.lbs_pts + b.off[s] : b.lbc_pts + (size_t)s * kMaxLessSharp;
     int *table = b.lb_start + (size_t)(s * 2 + (surf ? 1 : 0)) * (kLineKeys + 1);
-    __shared__ int s_cnt[kLineKeys], s_wsum[kLiT / 64];      // points per (line, bin); after the prefix: write cursor of the bucket
+    extern __shared__ __align__(16) int s_cnt[];      // points per (line, bin); after the prefix: write cursor of the bucket
+    __shared__ int s_wsum[kLiT / 64], s_emin[66], s_emax[66];
     for (int i = tid; i < kLineKeys; i += kLiT) s_cnt[i] = 0;
+    if (tid < 66) { s_emin[tid] = INT_MAX; s_emax[tid] = INT_MIN; }
     __syncthreads();
-    // four points per thread and round, their loads in flight together
-    for (int i0 = tid; i0 < n; i0 += 4 * kLiT) {
+    // four points per thread and round, their loads in flight together.  A wave holds 64 consecutive points, which nearly always
+    // share one scan line: their elevation bounds are reduced in the wave (DPP) and leave as ONE pair of LDS atomics
+    for (int base = 0; base < n; base += 4 * kLiT) {      // uniform trip count: the wave reductions need every lane
         float4 p[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) { const int i = i0 + kLiT * q; p[q] = i < n ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
+        for (int q = 0; q < 4; q++) { const int i = base + tid + kLiT * q; p[q] = i < n ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
 #pragma unroll
-        for (int q = 0; q < 4; q++)
-            if (i0 + kLiT * q < n) atomicAdd(&s_cnt[line_of(p[q].w) * kAzBins + az_bin(p[q].x, p[q].y)], 1);
+        for (int q = 0; q < 4; q++) {
+            const bool ok = base + tid + kLiT * q < n;
+            const int ln = line_of(p[q].w);
+            if (ok) atomicAdd(&s_cnt[ln * kAzBins + az_bin(p[q].x, p[q].y)], 1);
+            const unsigned long long act = __ballot(ok);
+            if (act == 0ull) continue;
+            const int eo = f2ord(elev_of(p[q].x, p[q].y, p[q].z));
+            const int ln0 = __shfl(ln, __ffsll((long long)act) - 1);
+            if (__ballot(ok && ln != ln0) == 0ull) {
+                const unsigned int lo = wave_min_u32_uniform(ok ? (unsigned int)eo ^ 0x80000000u : ~0u);
+                const unsigned int hi = wave_max_u32_uniform(ok ? (unsigned int)eo ^ 0x80000000u : 0u);
+                if (lane == 0) { atomicMin(&s_emin[ln0], (int)(lo ^ 0x80000000u)); atomicMax(&s_emax[ln0], (int)(hi ^ 0x80000000u)); }
+            } else if (ok) {
+                atomicMin(&s_emin[ln], eo);
+                atomicMax(&s_emax[ln], eo);
+            }
+        }
     }
     __syncthreads();
-    // exclusive prefix over the kLineKeys = 8448 counters: 17 consecutive counters per thread (last threads padded)
+    // per-line elevation bounds of the cloud (empty line: lo > hi), used by the tile search to bound the lines a ball can meet
+    if (tid < 66) {
+        float2 *el = b.lb_elev + (size_t)(s * 2 + (surf ? 1 : 0)) * 66;
+        el[tid] = s_emin[tid] == INT_MAX ? make_float2(1e30f, -1e30f) : make_float2(ord2f(s_emin[tid]), ord2f(s_emax[tid]));
+    }
+    // exclusive prefix over the kLineKeys counters: kPer consecutive counters per thread (last threads padded)
     constexpr int kPer = (kLineKeys + kLiT - 1) / kLiT;
     int local = 0;
     for (int i = 0; i < kPer; i++) { const int idx = tid * kPer + i; if (idx < kLineKeys) local += s_cnt[idx]; }
@@ -842,6 +871,54 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
     return out;
 }
 
+// one feature point served by a 32-lane group: search, correspondence indices, seed of the second outer iteration and the
+// 64-B residual-block record of the solver
+__device__ __forceinline__ void correspond_group(const BatchView &b, const OdomView &o, int c, int k, int qi, int outer, int gl, int gbase)
+{
+    const int n_sharp = b.feat_n[k * 4 + 0];
+    const int l = k - 1;
+    int4 *corr = (int4 *)o.corr + (size_t)c * kMaxQueries;
+    int *seed_c = o.seed ? o.seed + (size_t)c * kMaxQueries : nullptr;
+    int closest;
+    const int seed = (outer == 1 && seed_c) ? seed_c[qi] : -1;
+    const double *x = o.state + c * 8;
+    const int4 r = qi < n_sharp ? correspond_g32<true>(b, k, qi, x, gl, gbase, seed, closest) : correspond_g32<false>(b, k, qi, x, gl, gbase, seed, closest);
+    if (gl == 0) { corr[qi] = r; if (outer == 0 && seed_c) seed_c[qi] = closest; }
+    // residual-block record for the solver: the feature point and its 2 (edge) or 3 (plane) partners, 64 B
+    if (gl < 4) {
+        const bool edge = qi < n_sharp;
+        const float4 *cloud = edge ? b.less_sharp + (size_t)l * kMaxLessSharp : b.less_flat + b.off[l];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gl == 0) {
+            v = edge ? b.sharp[(size_t)k * kMaxSharp + qi] : b.flat[(size_t)k * kMaxFlat + (qi - n_sharp)];
+            v.w = __int_as_float(r.w);
+        } else if (r.w != 0) {
+            const int idx = gl == 1 ? r.x : (gl == 2 ? r.y : r.z);
+            if (idx >= 0) v = cloud[idx];
+        }
+        o.crec[((size_t)c * kMaxQueries + qi) * 4 + gl] = v;
+    }
+}
+
+// the generic path (array-order walk) for one feature point, whole wave
+__device__ __forceinline__ void correspond_wave(const BatchView &b, const OdomView &o, int c, int k, int qi, int lane)
+{
+    const int n_sharp = b.feat_n[k * 4 + 0];
+    const int l = k - 1;
+    int4 *corr = (int4 *)o.corr + (size_t)c * kMaxQueries;
+    const double *x = o.state + c * 8;
+    const int4 r = correspond_one(b, k, qi, x, lane);
+    if (lane == 0) { corr[qi] = r; if (o.seed) o.seed[(size_t)c * kMaxQueries + qi] = -1; }
+    if (lane < 4) {
+        const bool edge = qi < n_sharp;
+        const float4 *cloud = edge ? b.less_sharp + (size_t)l * kMaxLessSharp : b.less_flat + b.off[l];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane == 0) { v = edge ? b.sharp[(size_t)k * kMaxSharp + qi] : b.flat[(size_t)k * kMaxFlat + (qi - n_sharp)]; v.w = __int_as_float(r.w); }
+        else if (r.w != 0) { const int idx = lane == 1 ? r.x : (lane == 2 ? r.y : r.z); if (idx >= 0) v = cloud[idx]; }
+        o.crec[((size_t)c * kMaxQueries + qi) * 4 + lane] = v;
+    }
+}
+
 // step t of every chain: one 32-lane group per feature point of the chain's current scan (8 features per workgroup).
 // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an XCD and its 4 MB L2), so
 // the 1-D grid is decoded such that all blocks of a chain run on ONE XCD, one chain after the other: the ~2 MB of
@@ -870,39 +947,39 @@ __global__ __launch_bounds__(256, 8) void k_correspond(BatchView b, OdomView o, 
         for (int t = 0; t < 2; t++) {
             const int qi = qblock * 8 + (threadIdx.x >> 6) * 2 + t;
             if (qi >= nq) break;
-            const int4 r = correspond_one(b, k, qi, x, lane);
-            if (lane == 0) corr[qi] = r;
-            if (lane < 4) {
-                const bool edge = qi < n_sharp;
-                const float4 *cloud = edge ? b.less_sharp + (size_t)l * kMaxLessSharp : b.less_flat + b.off[l];
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (lane == 0) { v = edge ? b.sharp[(size_t)k * kMaxSharp + qi] : b.flat[(size_t)k * kMaxFlat + (qi - n_sharp)]; v.w = __int_as_float(r.w); }
-                else if (r.w != 0) { const int idx = lane == 1 ? r.x : (lane == 2 ? r.y : r.z); if (idx >= 0) v = cloud[idx]; }
-                o.crec[((size_t)c * kMaxQueries + qi) * 4 + lane] = v;
-            }
+            correspond_wave(b, o, c, k, qi, lane);
         }
         return;
     }
     const int qi = qblock * 8 + (threadIdx.x >> 5);
     if (qi >= nq) return;
-    int *seed_c = o.seed ? o.seed + (size_t)c * kMaxQueries : nullptr;
-    int closest;
-    const int seed = (outer == 1 && seed_c) ? seed_c[qi] : -1;
-    const int4 r = qi < n_sharp ? correspond_g32<true>(b, k, qi, x, gl, gbase, seed, closest) : correspond_g32<false>(b, k, qi, x, gl, gbase, seed, closest);
-    if (gl == 0) { corr[qi] = r; if (outer == 0 && seed_c) seed_c[qi] = closest; }
-    // residual-block record for the solver: the feature point and its 2 (edge) or 3 (plane) partners, 64 B
-    if (gl < 4) {
-        const bool edge = qi < n_sharp;
-        const float4 *cloud = edge ? b.less_sharp + (size_t)l * kMaxLessSharp : b.less_flat + b.off[l];
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gl == 0) {
-            v = edge ? b.sharp[(size_t)k * kMaxSharp + qi] : b.flat[(size_t)k * kMaxFlat + (qi - n_sharp)];
-            v.w = __int_as_float(r.w);
-        } else if (r.w != 0) {
-            const int idx = gl == 1 ? r.x : (gl == 2 ? r.y : r.z);
-            if (idx >= 0) v = cloud[idx];
-        }
-        o.crec[((size_t)c * kMaxQueries + qi) * 4 + gl] = v;
+    correspond_group(b, o, c, k, qi, outer, gl, gbase);
+}
+
+// The same search for the feature points of a device work list ([0] = count, then chain << 12 | feature index): the points the
+// LDS tile search (corr_tile.hip) defers.  Phase 1 serves them with 32-lane groups; phase 2 (scan pairs flagged irregular / dense:
+// rare) with the whole-wave array-order walk.  Fixed grid, items strided over it.
+__global__ __launch_bounds__(256, 4) void k_correspond_list(BatchView b, OdomView o, int step, int outer, const unsigned int *wl, unsigned long long *stats)
+{
+    const unsigned int n = wl[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && stats) stats[0] += n;
+    const int lane = threadIdx.x & 63;
+    const int gl = threadIdx.x & (kGroup - 1), gbase = lane & ~(kGroup - 1);
+    for (unsigned int it = blockIdx.x * 8 + (threadIdx.x >> 5); it < n; it += gridDim.x * 8) {
+        const unsigned int e = wl[1 + it];
+        const int c = (int)(e >> 12), qi = (int)(e & 4095u);
+        int own;
+        const int k = chain_scan(o, c, step, own);
+        if (k < 0 || (b.status[k - 1] & (kStatusIrregularLines | kStatusDenseCell))) continue;
+        correspond_group(b, o, c, k, qi, outer, gl, gbase);
+    }
+    for (unsigned int it = blockIdx.x * 4 + (threadIdx.x >> 6); it < n; it += gridDim.x * 4) {
+        const unsigned int e = wl[1 + it];
+        const int c = (int)(e >> 12), qi = (int)(e & 4095u);
+        int own;
+        const int k = chain_scan(o, c, step, own);
+        if (k < 0 || !(b.status[k - 1] & (kStatusIrregularLines | kStatusDenseCell))) continue;
+        correspond_wave(b, o, c, k, qi, lane);
     }
 }
 
@@ -1125,9 +1202,10 @@ constexpr int kLmRecLds = 4 * kMaxQueries * 16;   // the chain's records in LDS
 
 // One kLmT-thread workgroup per chain.  Every thread runs the (uniform) trust-region control flow redundantly on the
 // block-reduced sums; residual blocks come from the 64-B records written by k_correspond.
-__global__ __launch_bounds__(kLmT) void k_lm_solve(BatchView b, OdomView o, int step, int outer)
+__global__ __launch_bounds__(kLmT) void k_lm_solve(BatchView b, OdomView o, int step, int outer, unsigned int *wl_reset)
 {
     const int c = blockIdx.x;
+    if (wl_reset && c == 0 && threadIdx.x == 0) wl_reset[0] = 0u;      // the work list of the next correspondence launch starts empty
     int s;
     const int k = chain_scan(o, c, step, s);
     if (k < 0) return;

@@ -99,6 +99,42 @@ def test_correspondences_match_oracle(oracle, gpu_ctx, small_seq):
         assert np.array_equal(got, corr[0]), "correspondence indices differ at scan %d" % k
 
 
+def test_tile_search_equals_global_search(oracle, gpu_ctx, full_seq):
+    """The LDS tile search (k_corr_tile + the deferred list) and the global-memory search (k_correspond) return the same
+    correspondence indices for good and bad warm starts, and the same odometry bit for bit (same residual blocks, same solve)."""
+    xyzi, off = full_seq["xyzi"], full_seq["off"]
+    batch = _register(gpu_ctx, xyzi, off)
+    poses = [(np.array([0.0, 0.0, 0.0, 1.0]), np.array([0.0, 0.0, 0.0])),            # identity: 0.8 m off, wide searches
+             (np.array([0.0, 0.0, 0.01, 1.0]), np.array([0.7, 0.02, 0.0])),
+             (np.array([0.002, -0.001, 0.02, 1.0]), np.array([0.85, -0.05, 0.01])),
+             (np.array([0.0, 0.0, 0.3, 1.0]), np.array([3.0, 2.0, 0.5]))]            # far off: many features without partners
+    try:
+        for k in (1, 2):
+            for q, t in poses:
+                q = q / np.linalg.norm(q)
+                gpu_ctx.set_option(gpu_ctx.OPT_CORR_TILE, 0)
+                ref = batch.correspond(k, q, t)
+                gpu_ctx.set_option(gpu_ctx.OPT_CORR_TILE, 1)
+                gpu_ctx.timing_reset()
+                got = batch.correspond(k, q, t)
+                deferred = gpu_ctx.timing()[0]["deferred_features"]
+                print("scan %d t=%s: %d features, %d deferred to the global search" % (k, t, len(ref), deferred))
+                assert np.array_equal(got, ref)
+        gpu_ctx.set_option(gpu_ctx.OPT_CORR_TILE, 0)
+        i0, p0 = batch.odometry(1, 0)
+        gpu_ctx.set_option(gpu_ctx.OPT_CORR_TILE, 1)
+        i1, p1 = batch.odometry(1, 0)
+        assert np.array_equal(i0, i1) and np.array_equal(p0, p1)
+    finally:
+        gpu_ctx.set_option(gpu_ctx.OPT_CORR_TILE, 1)
+    # against the oracle as well (index-exact), at full resolution
+    f = [oracle.scanreg(xyzi[off[s]:off[s + 1]]) for s in range(3)]
+    q, t = poses[1]
+    q = q / np.linalg.norm(q)
+    _, _, _, corr = oracle.odom_step(f[2]["sharp"], f[2]["flat"], f[1]["less_sharp"], f[1]["less_flat"], q, t, want_corr=True)
+    assert np.array_equal(batch.correspond(2, q, t), corr[0])
+
+
 def test_odometry_sequential_matches_oracle(oracle, gpu_ctx, small_seq):
     xyzi, off = small_seq["xyzi"], small_seq["off"]
     batch = _register(gpu_ctx, xyzi, off)
