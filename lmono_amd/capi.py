@@ -26,7 +26,8 @@ class LmonoError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "liblmono_hip.so")
+    # LMONO_HIP_LIB: a diagnostic build of the same sources (scripts/prof_tile.py); the product path is the in-tree library
+    return os.environ.get("LMONO_HIP_LIB") or os.path.join(_HERE, "lib", "liblmono_hip.so")
 
 
 _lib = None
@@ -117,9 +118,10 @@ class Context:
 
     def timing(self):
         """Summed device ms per kernel group since timing_reset(): dict + call counts."""
-        ms = np.zeros(13)
+        ms = np.zeros(28)
         nr, no = C.c_int(0), C.c_int(0)
-        self.check(self.L.lmono_timing_read(self.h, ms.ctypes.data, 13, C.byref(nr), C.byref(no)))
+        self.check(self.L.lmono_timing_read(self.h, ms.ctypes.data, 28, C.byref(nr), C.byref(no)))
+        self.diag = ms[13:].copy()
         names = ["frontend_total", "odometry_total", "k_ring_sort", "k_curvature", "k_select", "k_voxel", "k_compact",
                  "k_grid_build", "k_line_index", "k_correspond", "k_lm_solve", "odometry_launch_pairs", "deferred_features"]
         return dict(zip(names, ms.tolist())), nr.value, no.value

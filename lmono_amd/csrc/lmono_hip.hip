@@ -88,7 +88,7 @@ extern "C" lmono_ctx *lmono_create(int device)
     if (hipSetDevice(device) != hipSuccess) return nullptr;
     lmono_ctx *c = new lmono_ctx();
     c->device = device;
-    if (hipMalloc((void **)&c->stats_d, 16) != hipSuccess || hipMemset(c->stats_d, 0, 16) != hipSuccess) { delete c; return nullptr; }
+    if (hipMalloc((void **)&c->stats_d, 128) != hipSuccess || hipMemset(c->stats_d, 0, 128) != hipSuccess) { delete c; return nullptr; }
     // the selection kernel needs ~62 KB of dynamic LDS
     if (hipFuncSetAttribute((const void *)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kSelWaveLds) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_voxel<kVoxSmallSlots, kVoxSmallBits, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kVoxLdsSmall) != hipSuccess) { delete c; return nullptr; }
@@ -274,7 +274,7 @@ extern "C" int lmono_timing_reset(lmono_ctx *c)
 {
     if (!c) return LMONO_EINVAL;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemset(c->stats_d, 0, 16));
+    HIP_TRY(c, hipMemset(c->stats_d, 0, 128));
     c->n_sets = 0;
     return LMONO_OK;
 }
@@ -306,9 +306,10 @@ extern "C" int lmono_timing_read(lmono_ctx *c, double *ms, int cap, int *n_scanr
         }
     }
     {
-        unsigned long long st[2] = { 0, 0 };
-        HIP_TRY(c, hipMemcpy(st, c->stats_d, 16, hipMemcpyDeviceToHost));
+        unsigned long long st[16] = { 0 };
+        HIP_TRY(c, hipMemcpy(st, c->stats_d, 128, hipMemcpyDeviceToHost));
         sum[12] = (double)st[0];
+        for (int i = 1; i < 16 && 12 + i < cap; i++) ms[12 + i] = (double)st[i];     // diagnostic words (LMONO_TILE_PROF builds)
     }
     for (int i = 0; i < cap && i < 13; i++) ms[i] = sum[i];
     if (n_scanreg_calls) *n_scanreg_calls = nr;
@@ -420,7 +421,7 @@ static int odom_run(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, d
             hipEvent_t e0 = kev(ne), e1 = kev(ne + 1), e2 = kev(ne + 2);
             if (e0 && e1 && e2) (void)hipEventRecord(e0, st);
             if (tile) {
-                hipLaunchKernelGGL(k_corr_tile, dim3(8 * ((n_chains + 7) / 8) * kTSect), dim3(kTT), kTileLds, st, b->v, o, step, outer, b->wl);
+                hipLaunchKernelGGL(k_corr_tile, dim3(8 * ((n_chains + 7) / 8) * kTSect), dim3(kTT), kTileLds, st, b->v, o, step, outer, b->wl, c->stats_d);
                 hipLaunchKernelGGL(k_correspond_list, dim3(kListGrid), dim3(256), 0, st, b->v, o, step, outer, (const unsigned int *)b->wl, c->stats_d);
             } else
                 hipLaunchKernelGGL(k_correspond, dim3(8 * ((n_chains + 7) / 8) * kCorrBlocks), dim3(256), 0, st, b->v, o, step, outer);
@@ -475,7 +476,7 @@ extern "C" int lmono_odom_correspond(lmono_ctx *c, lmono_scan_batch *b, int scan
         rc = ensure_odom_ws(c, b, 1);
         if (rc) return rc;
         HIP_TRY(c, hipMemsetAsync(b->wl, 0, sizeof(unsigned int), c->stream));
-        hipLaunchKernelGGL(k_corr_tile, dim3(8 * kTSect), dim3(kTT), kTileLds, c->stream, b->v, o, 0, 0, b->wl);
+        hipLaunchKernelGGL(k_corr_tile, dim3(8 * kTSect), dim3(kTT), kTileLds, c->stream, b->v, o, 0, 0, b->wl, c->stats_d);
         hipLaunchKernelGGL(k_correspond_list, dim3(kListGrid), dim3(256), 0, c->stream, b->v, o, 0, 0, (const unsigned int *)b->wl, c->stats_d);
     } else
         hipLaunchKernelGGL(k_correspond, dim3(8 * kCorrBlocks), dim3(256), 0, c->stream, b->v, o, 0, 0);
