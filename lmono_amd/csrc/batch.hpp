@@ -58,7 +58,7 @@ struct BatchView {
     float4 *lbc_pts;         // [n_scans][kMaxLessSharp] less_sharp sorted by (line, azimuth bin), .w = original index bits
     float4 *lbs_pts;         // [total] same for less_flat
     int *lb_start;           // [n_scans][2][66*384+1] start of every (line, bin) bucket
-    float2 *lb_elev;         // [n_scans][2][66] (min, max) elevation angle of every line's points (empty line: min > max)
+    float4 *lb_elev;         // [n_scans][2][66] elevation angles of every line's points: (min, max, min over lines <= v, max over lines >= v)
     int *grid_mask;          // [n_scans][2] table size - 1 actually used (corner, surf): power of two > n
 };
 

@@ -285,7 +285,8 @@ __global__ __launch_bounds__(kTT) void k_corr_tile(BatchView b, OdomView o, int 
         const bool wrap_hi = ue > kAzBins;
         if (wrap_hi) ue -= kAzBins;
         const int G = tg[0], tK = tg[kAzBins], tA = tg[gb], tE = tg[ue];       // four independent loads
-        const float2 ev = b.lb_elev[(size_t)(l * 2 + cl) * 66 + v];
+        const float4 ev4 = b.lb_elev[(size_t)(l * 2 + cl) * 66 + v];
+        const float2 ev = make_float2(ev4.x, ev4.y);
         const int fge = b.line_first_ge[(size_t)(l * 2 + cl) * 66 + v], lle = b.line_last_le[(size_t)(l * 2 + cl) * 66 + v];
         const int N = tK - G;
         const int F0 = tA - G - (g0 < 0 ? N : 0);

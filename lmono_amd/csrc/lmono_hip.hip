@@ -3,6 +3,8 @@
 #include "frontend.hip"
 #include "odometry.hip"
 #include "corr_tile.hip"
+#include "corr_thread.hip"
+#include "corr_flat.hip"
 #include "mapping.hip"
 #include "ba.hip"
 #include "ba_solve.hip"
@@ -29,7 +31,7 @@ struct lmono_ctx {
     std::vector<EvSet> sets;   // one event set per scanreg/odometry call since the last lmono_timing_reset
     int n_sets = 0;
     hipEvent_t *ev = nullptr;  // events of the current call
-    int opt[LMONO_OPT_COUNT] = { 1 };   // LMONO_OPT_CORR_TILE on by default
+    int opt[LMONO_OPT_COUNT] = { 3 };   // LMONO_OPT_CORR_TILE: 3 = flattened sweeps (default), 2 = thread per feature, 1 = LDS sector tiles, 0 = 32-lane groups
     unsigned long long *stats_d = nullptr;   // [0] feature points deferred by the tile search since the last lmono_timing_reset
 
     hipEvent_t *next_set()
@@ -408,7 +410,7 @@ static int odom_run(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, d
     HIP_TRY(c, hipEventRecord(c->ev[8], st));
     const int ninit = n > n_chains ? n : n_chains;
     hipLaunchKernelGGL(k_odom_init, dim3((ninit + 255) / 256), dim3(256), 0, st, o);
-    const bool tile = c->opt[LMONO_OPT_CORR_TILE] != 0;
+    const int tile = c->opt[LMONO_OPT_CORR_TILE];
     if (tile) HIP_TRY(c, hipMemsetAsync(b->wl, 0, sizeof(unsigned int), st));
     EvSet &es = c->sets[c->n_sets - 1];
     auto kev = [&](int i) -> hipEvent_t {
@@ -420,7 +422,13 @@ static int odom_run(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, d
         for (int outer = 0; outer < 2; outer++) {
             hipEvent_t e0 = kev(ne), e1 = kev(ne + 1), e2 = kev(ne + 2);
             if (e0 && e1 && e2) (void)hipEventRecord(e0, st);
-            if (tile) {
+            if (tile == 3) {
+                hipLaunchKernelGGL(k_corr_flat, dim3(8 * ((n_chains + 7) / 8) * kCfBlocks), dim3(kCfT), 0, st, b->v, o, step, outer, b->wl);
+                hipLaunchKernelGGL(k_correspond_list, dim3(kListGrid), dim3(256), 0, st, b->v, o, step, outer, (const unsigned int *)b->wl, c->stats_d);
+            } else if (tile == 2) {
+                hipLaunchKernelGGL(k_corr_thread, dim3(8 * ((n_chains + 7) / 8) * kCtBlocks), dim3(kCtT), 0, st, b->v, o, step, outer, b->wl);
+                hipLaunchKernelGGL(k_correspond_list, dim3(kListGrid), dim3(256), 0, st, b->v, o, step, outer, (const unsigned int *)b->wl, c->stats_d);
+            } else if (tile) {
                 hipLaunchKernelGGL(k_corr_tile, dim3(8 * ((n_chains + 7) / 8) * kTSect), dim3(kTT), kTileLds, st, b->v, o, step, outer, b->wl, c->stats_d);
                 hipLaunchKernelGGL(k_correspond_list, dim3(kListGrid), dim3(256), 0, st, b->v, o, step, outer, (const unsigned int *)b->wl, c->stats_d);
             } else
@@ -476,7 +484,9 @@ extern "C" int lmono_odom_correspond(lmono_ctx *c, lmono_scan_batch *b, int scan
         rc = ensure_odom_ws(c, b, 1);
         if (rc) return rc;
         HIP_TRY(c, hipMemsetAsync(b->wl, 0, sizeof(unsigned int), c->stream));
-        hipLaunchKernelGGL(k_corr_tile, dim3(8 * kTSect), dim3(kTT), kTileLds, c->stream, b->v, o, 0, 0, b->wl, c->stats_d);
+        if (c->opt[LMONO_OPT_CORR_TILE] == 3) hipLaunchKernelGGL(k_corr_flat, dim3(8 * kCfBlocks), dim3(kCfT), 0, c->stream, b->v, o, 0, 0, b->wl);
+        else if (c->opt[LMONO_OPT_CORR_TILE] == 2) hipLaunchKernelGGL(k_corr_thread, dim3(8 * kCtBlocks), dim3(kCtT), 0, c->stream, b->v, o, 0, 0, b->wl);
+        else hipLaunchKernelGGL(k_corr_tile, dim3(8 * kTSect), dim3(kTT), kTileLds, c->stream, b->v, o, 0, 0, b->wl, c->stats_d);
         hipLaunchKernelGGL(k_correspond_list, dim3(kListGrid), dim3(256), 0, c->stream, b->v, o, 0, 0, (const unsigned int *)b->wl, c->stats_d);
     } else
         hipLaunchKernelGGL(k_correspond, dim3(8 * kCorrBlocks), dim3(256), 0, c->stream, b->v, o, 0, 0);

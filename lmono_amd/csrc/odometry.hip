@@ -492,10 +492,15 @@ __global__ __launch_bounds__(kLiT) void k_line_index(BatchView b)
         }
     }
     __syncthreads();
-    // per-line elevation bounds of the cloud (empty line: lo > hi), used by the tile search to bound the lines a ball can meet
+    // per-line elevation bounds of the cloud (empty line: lo > hi), used by the searches to bound the lines a ball can meet:
+    // (lo, hi, A = min of lo over lines <= v, B = max of hi over lines >= v).  A and B are monotone (non-increasing in v) whatever
+    // the sensor, so the lines that can meet an elevation window [a, b] lie between the first v with A_v <= b and the last with B_v >= a
     if (tid < 66) {
-        float2 *el = b.lb_elev + (size_t)(s * 2 + (surf ? 1 : 0)) * 66;
-        el[tid] = s_emin[tid] == INT_MAX ? make_float2(1e30f, -1e30f) : make_float2(ord2f(s_emin[tid]), ord2f(s_emax[tid]));
+        float4 *el = b.lb_elev + (size_t)(s * 2 + (surf ? 1 : 0)) * 66;
+        float A = 1e30f, B = -1e30f;
+        for (int v = 0; v <= tid; v++) if (s_emin[v] != INT_MAX) A = fminf(A, ord2f(s_emin[v]));
+        for (int v = tid; v < 66; v++) if (s_emin[v] != INT_MAX) B = fmaxf(B, ord2f(s_emax[v]));
+        el[tid] = s_emin[tid] == INT_MAX ? make_float4(1e30f, -1e30f, A, B) : make_float4(ord2f(s_emin[tid]), ord2f(s_emax[tid]), A, B);
     }
     // exclusive prefix over the kLineKeys counters: kPer consecutive counters per thread (last threads padded)
     constexpr int kPer = (kLineKeys + kLiT - 1) / kLiT;

@@ -114,19 +114,21 @@ def test_tile_search_equals_global_search(oracle, gpu_ctx, full_seq):
                 q = q / np.linalg.norm(q)
                 gpu_ctx.set_option(gpu_ctx.OPT_CORR_TILE, 0)
                 ref = batch.correspond(k, q, t)
-                gpu_ctx.set_option(gpu_ctx.OPT_CORR_TILE, 1)
-                gpu_ctx.timing_reset()
-                got = batch.correspond(k, q, t)
-                deferred = gpu_ctx.timing()[0]["deferred_features"]
-                print("scan %d t=%s: %d features, %d deferred to the global search" % (k, t, len(ref), deferred))
-                assert np.array_equal(got, ref)
+                for mode in (1, 2, 3):       # 1: LDS sector tiles, 2: thread per feature, 3: flattened sweeps (default)
+                    gpu_ctx.set_option(gpu_ctx.OPT_CORR_TILE, mode)
+                    gpu_ctx.timing_reset()
+                    got = batch.correspond(k, q, t)
+                    deferred = gpu_ctx.timing()[0]["deferred_features"]
+                    print("scan %d t=%s mode %d: %d features, %d deferred to the list kernel" % (k, t, mode, len(ref), deferred))
+                    assert np.array_equal(got, ref)
         gpu_ctx.set_option(gpu_ctx.OPT_CORR_TILE, 0)
         i0, p0 = batch.odometry(1, 0)
-        gpu_ctx.set_option(gpu_ctx.OPT_CORR_TILE, 1)
-        i1, p1 = batch.odometry(1, 0)
-        assert np.array_equal(i0, i1) and np.array_equal(p0, p1)
+        for mode in (1, 2, 3):
+            gpu_ctx.set_option(gpu_ctx.OPT_CORR_TILE, mode)
+            i1, p1 = batch.odometry(1, 0)
+            assert np.array_equal(i0, i1) and np.array_equal(p0, p1)
     finally:
-        gpu_ctx.set_option(gpu_ctx.OPT_CORR_TILE, 1)
+        gpu_ctx.set_option(gpu_ctx.OPT_CORR_TILE, 3)
     # against the oracle as well (index-exact), at full resolution
     f = [oracle.scanreg(xyzi[off[s]:off[s + 1]]) for s in range(3)]
     q, t = poses[1]
