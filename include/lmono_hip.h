@@ -37,9 +37,11 @@ void        lmono_destroy(lmono_ctx *);
 const char *lmono_last_error(const lmono_ctx *);
 int         lmono_set_stream(lmono_ctx *, void *hip_stream); /* hipStream_t; NULL = default  */
 int         lmono_synchronize(lmono_ctx *);
-/* Tuning / test switches of a context (no reference counterpart).  LMONO_OPT_CORR_TILE: 1 (default) = the laserOdometry
- * correspondence search runs from LDS-staged azimuth sectors (k_corr_tile) with the global-memory search (k_correspond_list) for
- * the feature points it defers; 0 = every feature point through the global-memory search (k_correspond).  Results are identical. */
+/* Tuning / test switches of a context (no reference counterpart).  LMONO_OPT_CORR_TILE selects the laserOdometry correspondence
+ * search: 0 (default) = 32 lanes per feature point on the global hash grid + line index (k_correspond); 1 = LDS-staged azimuth
+ * sectors, 16 lanes per feature (k_corr_tile); 2 = one thread per feature (k_corr_thread); 3 = flattened candidate sweeps
+ * (k_corr_flat); 1..3 hand the features they do not answer to k_correspond_list.  All four return identical results
+ * (tests/test_lidar_gpu.py::test_tile_search_equals_global_search); measured rates: profiles/r2/NOTES.md.                      */
 #define LMONO_OPT_CORR_TILE 0
 #define LMONO_OPT_COUNT     1
 int         lmono_set_option(lmono_ctx *, int key, int value);

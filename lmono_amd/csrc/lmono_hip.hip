@@ -31,7 +31,7 @@ struct lmono_ctx {
     std::vector<EvSet> sets;   // one event set per scanreg/odometry call since the last lmono_timing_reset
     int n_sets = 0;
     hipEvent_t *ev = nullptr;  // events of the current call
-    int opt[LMONO_OPT_COUNT] = { 3 };   // LMONO_OPT_CORR_TILE: 3 = flattened sweeps (default), 2 = thread per feature, 1 = LDS sector tiles, 0 = 32-lane groups
+    int opt[LMONO_OPT_COUNT] = { 0 };   // LMONO_OPT_CORR_TILE: 0 = 32-lane groups (default, fastest measured), 1 = LDS sector tiles, 2 = thread per feature, 3 = flattened sweeps
     unsigned long long *stats_d = nullptr;   // [0] feature points deferred by the tile search since the last lmono_timing_reset
 
     hipEvent_t *next_set()

@@ -128,7 +128,7 @@ def test_tile_search_equals_global_search(oracle, gpu_ctx, full_seq):
             i1, p1 = batch.odometry(1, 0)
             assert np.array_equal(i0, i1) and np.array_equal(p0, p1)
     finally:
-        gpu_ctx.set_option(gpu_ctx.OPT_CORR_TILE, 3)
+        gpu_ctx.set_option(gpu_ctx.OPT_CORR_TILE, 0)
     # against the oracle as well (index-exact), at full resolution
     f = [oracle.scanreg(xyzi[off[s]:off[s + 1]]) for s in range(3)]
     q, t = poses[1]
