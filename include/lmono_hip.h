@@ -168,7 +168,7 @@ int lmono_outlier_scores(lmono_ctx *, int n_windows, const int *feat_off_h, cons
 int lmono_shift_depth(lmono_ctx *, const double *back_R0, const double *back_P0, const double *R1, const double *P1, const double *tlc,
                       int n, const double *pt_i_h, const double *depth_h, double *depth_out_h);
 
-/* ---- marginalisation prior: the MARGIN_OLD branch of Estimator::margin() ----------------------------------- *
+/* ---- marginalisation prior: Estimator::margin(), MARGIN_OLD branch first ------------------------------------ *
  * Reference interfaces: Estimator::margin (src/image_process/Estimator.cc:1307-1405), MarginalizationInfo::
  * {preMarginalize, marginalize} and Marginalization::Evaluate (src/factor/MarginalizationFactor.cc:109-131, :176-272,
  * :309-373).  Factors: LASERFactor(pose0, pose1) and one MonoProjectionFactor + CauchyLoss(1) per observation of the
@@ -183,6 +183,15 @@ int lmono_marginalize(lmono_ctx *, int n_windows, const int *feat_off_h, const i
                       double *lin_J_h, double *lin_r_h, int *status_h);
 int lmono_marg_evaluate(lmono_ctx *, int n_windows, const double *lin_J_h, const double *lin_r_h, const double *x0_h, const double *x_h,
                         double *residual_h);
+/* The MARGIN_SECOND_NEW branch of Estimator::margin() (Estimator.cc:1406-1470): the only factor is the previous prior itself
+ * (`Marginalization(last_marginalization_info)`, MarginalizationFactor.cc:300-373) over its n_blocks parameter blocks (7 doubles
+ * each, 6 local; <= 11), evaluated at the current values x_h [n_windows][n_blocks][7] (linearisation point x0_h), and the block
+ * drop_block (the one aliasing para_pose[WINDOW_SIZE - 1]) is eliminated: H = J^T J, b = J^T r, eigen pseudo-inverse of the 6x6
+ * H_mm with the eps = 1e-8 cut, Schur complement, second eigen-decomposition.  lin_J_h [n_windows][n0*n0], lin_r_h [n_windows][n0],
+ * n0 = 6 n_blocks; outputs over the kept blocks in their old order: lin_J_out_h [n_windows][n*n], lin_r_out_h [n_windows][n],
+ * n = n0 - 6; the new linearisation point is x_h without the dropped block.  status_h bit 0: H_mm needed the eps cut.          */
+int lmono_marg_second_new(lmono_ctx *, int n_windows, int n_blocks, int drop_block, const double *lin_J_h, const double *lin_r_h,
+                          const double *x0_h, const double *x_h, double *lin_J_out_h, double *lin_r_out_h, int *status_h);
 
 /* ---- laserMapping, optimisation step -------------------------------------------------------------------
  * Replaces the `for iterCount < 2 { 5-NN in the corner / surf map kd-trees; PCA line test -> LidarEdgeFactor; 5-point

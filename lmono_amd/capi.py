@@ -17,7 +17,7 @@ SYMBOLS = [
     "lmono_map_builder_cloud", "lmono_map_builder_map", "lmono_map_builder_clear",
     "lmono_pose_graph_create", "lmono_pose_graph_destroy", "lmono_pose_graph_reset", "lmono_pose_graph_info", "lmono_pose_graph_reduce_buffer", "lmono_pose_graph_set_reduce_buffer", "lmono_pose_graph_linearise",
     "lmono_pose_graph_step", "lmono_pose_graph_optimize", "lmono_pose_graph_result", "lmono_factor_eval", "lmono_factor_eval_d",
-    "lmono_triangulate", "lmono_outlier_scores", "lmono_shift_depth", "lmono_marginalize", "lmono_marg_evaluate", "lmono_ba_batch_create", "lmono_ba_batch_destroy", "lmono_ba_solve", "lmono_ba_batch_reset", "lmono_ba_batch_read",
+    "lmono_triangulate", "lmono_outlier_scores", "lmono_shift_depth", "lmono_marginalize", "lmono_marg_evaluate", "lmono_marg_second_new", "lmono_ba_batch_create", "lmono_ba_batch_destroy", "lmono_ba_solve", "lmono_ba_batch_reset", "lmono_ba_batch_read",
 ]
 
 
@@ -67,6 +67,7 @@ def load_library():
     L.lmono_shift_depth.argtypes = [C.c_void_p] * 6 + [C.c_int] + [C.c_void_p] * 3
     L.lmono_marginalize.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 14
     L.lmono_marg_evaluate.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
+    L.lmono_marg_second_new.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7
     L.lmono_ba_batch_create.restype = C.c_void_p
     L.lmono_ba_batch_create.argtypes = [C.c_void_p, C.c_void_p]
     L.lmono_ba_batch_destroy.argtypes = [C.c_void_p]
@@ -203,6 +204,17 @@ class Context:
         W = len(lin_r); res = np.zeros((W, 66))
         self.check(self.L.lmono_marg_evaluate(self.h, W, lin_J.ctypes.data, lin_r.ctypes.data, x0.ctypes.data, x.ctypes.data, res.ctypes.data))
         return res
+
+    def marg_second_new(self, lin_J, lin_r, x0, x, drop_block):
+        """MARGIN_SECOND_NEW: lin_J [W, n0, n0], lin_r [W, n0], x0 / x [W, nb, 7] -> (J [W, n, n], r [W, n], status [W]), n = n0 - 6."""
+        lin_J = np.ascontiguousarray(lin_J, np.float64); lin_r = np.ascontiguousarray(lin_r, np.float64)
+        x0 = np.ascontiguousarray(x0, np.float64); x = np.ascontiguousarray(x, np.float64)
+        W, nb = x.shape[0], x.shape[1]
+        n = 6 * nb - 6
+        J = np.zeros((W, n, n)); r = np.zeros((W, n)); st = np.zeros(W, np.int32)
+        self.check(self.L.lmono_marg_second_new(self.h, W, nb, int(drop_block), lin_J.ctypes.data, lin_r.ctypes.data, x0.ctypes.data, x.ctypes.data,
+                                                J.ctypes.data, r.ctypes.data, st.ctypes.data))
+        return J, r, st
 
     def pose_prefix_d(self, incr_ptr, first, n, poses_ptr):
         self.check(self.L.lmono_pose_prefix_d(self.h, C.c_void_p(incr_ptr), first, n, C.c_void_p(poses_ptr)))

@@ -99,6 +99,10 @@ extern "C" lmono_ctx *lmono_create(int device)
     if (hipFuncSetAttribute((const void *)k_grid_build, hipFuncAttributeMaxDynamicSharedMemorySize, kGridLds) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_line_index, hipFuncAttributeMaxDynamicSharedMemorySize, kLiLds) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_corr_tile, hipFuncAttributeMaxDynamicSharedMemorySize, kTileLds) != hipSuccess) { delete c; return nullptr; }
+    // the BA-side kernels with large dynamic LDS: per device, so per context (a second context on another GPU needs them too)
+    if (hipFuncSetAttribute((const void *)k_ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BaLds)) != hipSuccess) { delete c; return nullptr; }
+    if (hipFuncSetAttribute((const void *)k_marginalize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MargLds)) != hipSuccess) { delete c; return nullptr; }
+    if (hipFuncSetAttribute((const void *)k_marg_second_new, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Marg2Lds)) != hipSuccess) { delete c; return nullptr; }
     return c;
 }
 
@@ -666,13 +670,6 @@ extern "C" lmono_ba_batch *lmono_ba_batch_create(lmono_ctx *c, const lmono_ba_de
     v.feat_off = feat_off; v.obs_off = obs_off; v.flags = flags; v.feat_anchor = anch;
     v.pair_off = poff; v.pair_ij = pij; v.pobs_off = psoff; v.slot_info = sinfo_d; v.slot_pts = spts_d; v.pair_slot = pslot_d;
     v.laser_consts = laser; v.prior_T = prior; v.info = infod;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)k_ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BaLds)) != hipSuccess) {
-            c->err = "k_ba_solve: cannot reserve LDS"; lmono_ba_batch_destroy(b); return nullptr;
-        }
-        attr_set = true;
-    }
     return b;
 }
 
@@ -810,7 +807,7 @@ extern "C" int lmono_marginalize(lmono_ctx *c, int n_windows, const int *feat_of
     const int TF = feat_off_h[n_windows], TO = obs_off_h[n_windows];
     std::vector<int> fo((size_t)TF + 1, 0);
     for (int w = 0; w < n_windows; w++) {
-        if (feat_off_h[w + 1] - feat_off_h[w] > kMargMaxF0) { c->err = "lmono_marginalize: more than 128 tracks anchored at frame 0"; return LMONO_ECAPACITY; }
+        if (feat_off_h[w + 1] - feat_off_h[w] > kMargMaxF0) { c->err = "lmono_marginalize: more than 160 tracks anchored at frame 0"; return LMONO_ECAPACITY; }
         int o = obs_off_h[w];
         for (int f = feat_off_h[w]; f < feat_off_h[w + 1]; f++) {
             fo[f] = o;
@@ -835,8 +832,6 @@ extern "C" int lmono_marginalize(lmono_ctx *c, int n_windows, const int *feat_of
     B.lin_J = db.up((const double *)nullptr, (size_t)n_windows * kMargN * kMargN, ok); B.lin_r = db.up((const double *)nullptr, (size_t)n_windows * kMargN, ok);
     B.status = db.up((const int *)nullptr, (size_t)n_windows, ok);
     if (!ok) { c->err = "lmono_marginalize: device allocation / upload failed"; return LMONO_ENOMEM; }
-    static bool attr_set = false;
-    if (!attr_set) { HIP_TRY(c, hipFuncSetAttribute((const void *)k_marginalize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MargLds))); attr_set = true; }
     hipLaunchKernelGGL(k_marginalize, dim3(n_windows), dim3(256), sizeof(MargLds), c->stream, B);
     int rc = check_launch(c, "k_marginalize");
     if (rc) return rc;
@@ -861,6 +856,33 @@ extern "C" int lmono_marg_evaluate(lmono_ctx *c, int n_windows, const double *li
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(residual_h, res, sizeof(double) * (size_t)n_windows * kMargN, hipMemcpyDeviceToHost));
+    return LMONO_OK;
+}
+
+
+// MARGIN_SECOND_NEW (Estimator.cc:1406-1470): the previous prior loses one of its blocks.
+extern "C" int lmono_marg_second_new(lmono_ctx *c, int n_windows, int n_blocks, int drop_block, const double *lin_J_h, const double *lin_r_h,
+                                     const double *x0_h, const double *x_h, double *lin_J_out_h, double *lin_r_out_h, int *status_h)
+{
+    if (!c || n_windows <= 0 || n_blocks < 2 || n_blocks > 11 || drop_block < 0 || drop_block >= n_blocks || !lin_J_h || !lin_r_h || !x0_h || !x_h ||
+        !lin_J_out_h || !lin_r_out_h) return LMONO_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n0 = 6 * (size_t)n_blocks, n = n0 - 6, W = (size_t)n_windows;
+    DevBuf db; bool ok = true;
+    Marg2Batch B{};
+    B.n_windows = n_windows; B.nb = n_blocks; B.drop = drop_block;
+    B.lin_J = db.up(lin_J_h, W * n0 * n0, ok); B.lin_r = db.up(lin_r_h, W * n0, ok);
+    B.x0 = db.up(x0_h, W * n_blocks * 7, ok); B.x = db.up(x_h, W * n_blocks * 7, ok);
+    B.out_J = db.up((const double *)nullptr, W * n * n, ok); B.out_r = db.up((const double *)nullptr, W * n, ok);
+    B.status = db.up((const int *)nullptr, W, ok);
+    if (!ok) { c->err = "lmono_marg_second_new: device allocation / upload failed"; return LMONO_ENOMEM; }
+    hipLaunchKernelGGL(k_marg_second_new, dim3(n_windows), dim3(256), sizeof(Marg2Lds), c->stream, B);
+    int rc = check_launch(c, "k_marg_second_new");
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(lin_J_out_h, B.out_J, sizeof(double) * W * n * n, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(lin_r_out_h, B.out_r, sizeof(double) * W * n, hipMemcpyDeviceToHost));
+    if (status_h) HIP_TRY(c, hipMemcpy(status_h, B.status, sizeof(int) * W, hipMemcpyDeviceToHost));
     return LMONO_OK;
 }
 

@@ -18,7 +18,7 @@
 namespace lmono {
 
 constexpr int kMargN = 66;
-constexpr int kMargMaxF0 = 128;
+constexpr int kMargMaxF0 = 160;        // >= the tracker's MAX_CNT = 150 features per frame (FeatureTracker.cc:21), all of which can be anchored at frame 0
 
 struct MargBatch {
     int n_windows;
@@ -39,8 +39,10 @@ struct MargBatch {
 
 struct MargLds {
     double Hrr[kMargN * kMargN];
-    double V[kMargN * kMargN];
-    double Wd[kMargMaxF0 * kMargN];     // depth rows of H_mr
+    union {                             // the eigenvectors are only formed after the last use of W_d
+        double Wd[kMargMaxF0 * kMargN]; // depth rows of H_mr
+        double V[kMargN * kMargN];
+    };
     double Wp[6 * kMargN];              // pose0 rows of H_mr, later G
     double Y[6 * kMargN];
     double B[6 * kMargMaxF0];
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(256) void k_marginalize(MargBatch Bt)
     const double *poses = Bt.poses + (size_t)w * 77, *ex = Bt.ex + (size_t)w * 7;
     const double *laser_info = Bt.info, *mono_info = Bt.info + 36;
     const double eps = 1e-8;
-    for (int k = tid; k < kMargN * kMargN; k += 256) { L.Hrr[k] = 0.0; L.V[k] = (k / kMargN == k % kMargN) ? 1.0 : 0.0; }
+    for (int k = tid; k < kMargN * kMargN; k += 256) L.Hrr[k] = 0.0;
     for (int k = tid; k < F0 * kMargN; k += 256) L.Wd[k] = 0.0;
     for (int k = tid; k < 6 * kMargN; k += 256) L.Wp[k] = 0.0;
     for (int k = tid; k < 6 * F0; k += 256) L.B[k] = 0.0;
@@ -207,13 +209,13 @@ __global__ __launch_bounds__(256) void k_marginalize(MargBatch Bt)
         L.Y[k] = acc;
     }
     __syncthreads();
-    // H' = Hrr - G^T Y - Wd^T D^+ Wd ; b' = br - G^T SA^+ u - Wd^T D^+ bd
+    // H' = Hrr - G^T Y - Wd^T D^+ Wd ; b' = br - G^T SA^+ u - Wd^T D^+ bd   (H' in place: every element only reads itself of Hrr)
     for (int k = tid; k < kMargN * kMargN; k += 256) {
         const int a = k / kMargN, bb = k % kMargN;
         double acc = L.Hrr[k];
         for (int q = 0; q < 6; q++) acc -= L.Wp[q * kMargN + a] * L.Y[q * kMargN + bb];
         for (int f = 0; f < F0; f++) acc -= L.Wd[f * kMargN + a] * L.D[f] * L.Wd[f * kMargN + bb];
-        L.V[k] = acc;      // H' staged in V
+        L.Hrr[k] = acc;
     }
     for (int a = tid; a < kMargN; a += 256) {
         double acc = L.br[a];
@@ -222,8 +224,11 @@ __global__ __launch_bounds__(256) void k_marginalize(MargBatch Bt)
         L.br[a] = acc;
     }
     __syncthreads();
-    for (int k = tid; k < kMargN * kMargN; k += 256) { const int a = k / kMargN, bb = k % kMargN; L.Hrr[k] = 0.5 * (L.V[k] + L.V[bb * kMargN + a]); }
-    __syncthreads();
+    // symmetrise in place (one thread per unordered pair), then V (which shares W_d's memory) becomes the identity
+    for (int k = tid; k < kMargN * kMargN; k += 256) {
+        const int a = k / kMargN, bb = k % kMargN;
+        if (a < bb) { const double v = 0.5 * (L.Hrr[k] + L.Hrr[bb * kMargN + a]); L.Hrr[k] = v; L.Hrr[bb * kMargN + a] = v; }
+    }
     for (int k = tid; k < kMargN * kMargN; k += 256) L.V[k] = (k / kMargN == k % kMargN) ? 1.0 : 0.0;
     __syncthreads();
     // ---- parallel Jacobi eigen-decomposition of Hrr (66x66): 65 rounds of 33 disjoint rotations per sweep
@@ -312,6 +317,157 @@ __global__ __launch_bounds__(128) void k_marg_evaluate(int n_windows, const doub
         for (int k = 0; k < kMargN; k++) v += lin_J[(size_t)w * kMargN * kMargN + e * kMargN + k] * dx[k];
         residual[(size_t)w * kMargN + e] = v;
     }
+}
+
+
+// ---- MARGIN_SECOND_NEW (Estimator.cc:1406-1470): the previous prior, as the only factor (Marginalization::Evaluate at the current
+// parameter values, MarginalizationFactor.cc:309-373), loses the block that aliases para_pose[WINDOW_SIZE - 1].
+// One workgroup per window: dx, r = r0 + J0 dx, H = J0^T J0 and b = J0^T r with the dropped block's six columns first, eigen
+// pseudo-inverse of the 6x6 H_mm (eps cut), Schur complement, parallel Jacobi eigen-decomposition of the (n0 - 6)-square H',
+// linearized_jacobians = sqrt(S) V^T, linearized_residuals = sqrt(S^-1) V^T b'.  Kept blocks stay in their old order.
+struct Marg2Batch {
+    int n_windows, nb, drop;     // blocks of the previous prior (<= 11), index of the dropped one
+    const double *lin_J;         // [W][n0*n0], n0 = 6 nb
+    const double *lin_r;         // [W][n0]
+    const double *x0;            // [W][nb][7] linearisation point of the previous prior
+    const double *x;             // [W][nb][7] current values
+    double *out_J;               // [W][n*n], n = n0 - 6
+    double *out_r;               // [W][n]
+    int *status;                 // [W] bit 0: H_mm degenerate (eps cut applied)
+};
+struct Marg2Lds {
+    double A[kMargN * kMargN];   // J0, later the eigenvectors V
+    double H[kMargN * kMargN];
+    double T[kMargN * 6];
+    double r[kMargN], b[kMargN], dx[kMargN], br[kMargN];
+    double Hmm[36], Hinv[36];
+    double cs[2 * 33], red[8];
+    int perm[kMargN], flag;
+};
+
+__global__ __launch_bounds__(256) void k_marg_second_new(Marg2Batch Bt)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw2[];
+    Marg2Lds &L = *reinterpret_cast<Marg2Lds *>(smem_raw2);
+    const int w = blockIdx.x, tid = threadIdx.x;
+    const int nb = Bt.nb, n0 = 6 * nb, n = n0 - 6, drop = Bt.drop;
+    const double eps = 1e-8;
+    const double *J0 = Bt.lin_J + (size_t)w * n0 * n0;
+    for (int k = tid; k < n0 * n0; k += 256) L.A[k] = J0[k];
+    if (tid < nb) {
+        const double *a = Bt.x + ((size_t)w * nb + tid) * 7, *a0 = Bt.x0 + ((size_t)w * nb + tid) * 7;
+        for (int k = 0; k < 3; k++) L.dx[6 * tid + k] = a[k] - a0[k];
+        const double n2 = a0[3] * a0[3] + a0[4] * a0[4] + a0[5] * a0[5] + a0[6] * a0[6];
+        const double ix = -a0[3] / n2, iy = -a0[4] / n2, iz = -a0[5] / n2, iw = a0[6] / n2;
+        const double qx = a[3], qy = a[4], qz = a[5], qw = a[6];
+        const double rw = iw * qw - ix * qx - iy * qy - iz * qz;
+        double rx = iw * qx + ix * qw + iy * qz - iz * qy, ry = iw * qy + iy * qw + iz * qx - ix * qz, rz = iw * qz + iz * qw + ix * qy - iy * qx;
+        if (!(rw >= 0)) { rx = -rx; ry = -ry; rz = -rz; }
+        L.dx[6 * tid + 3] = 2.0 * rx; L.dx[6 * tid + 4] = 2.0 * ry; L.dx[6 * tid + 5] = 2.0 * rz;
+    }
+    if (tid < n0) {
+        // dropped block first, then the kept blocks in order
+        int src;
+        if (tid < 6) src = 6 * drop + tid;
+        else { const int kb = (tid - 6) / 6, c = (tid - 6) % 6; src = 6 * (kb < drop ? kb : kb + 1) + c; }
+        L.perm[tid] = src;
+    }
+    if (tid == 0) L.flag = 0;
+    __syncthreads();
+    if (tid < n0) { double v = Bt.lin_r[(size_t)w * n0 + tid]; for (int k = 0; k < n0; k++) v += L.A[tid * n0 + k] * L.dx[k]; L.r[tid] = v; }
+    __syncthreads();
+    for (int k = tid; k < n0 * n0; k += 256) {
+        const int i = k / n0, j = k % n0, pi = L.perm[i], pj = L.perm[j];
+        double v = 0;
+        for (int q = 0; q < n0; q++) v += L.A[q * n0 + pi] * L.A[q * n0 + pj];
+        L.H[k] = v;
+    }
+    if (tid < n0) { const int pi = L.perm[tid]; double v = 0; for (int q = 0; q < n0; q++) v += L.A[q * n0 + pi] * L.r[q]; L.b[tid] = v; }
+    __syncthreads();
+    if (tid < 36) { const int i = tid / 6, j = tid % 6; L.Hmm[tid] = 0.5 * (L.H[i * n0 + j] + L.H[j * n0 + i]); }
+    __syncthreads();
+    if (tid == 0) { int deg = 0; pinv6(L.Hmm, L.Hinv, eps, &deg); if (deg) L.flag = 1; }
+    __syncthreads();
+    for (int k = tid; k < n * 6; k += 256) {
+        const int i = k / 6, j = k % 6;
+        double v = 0;
+        for (int q = 0; q < 6; q++) v += L.H[(6 + i) * n0 + q] * L.Hinv[q * 6 + j];
+        L.T[k] = v;
+    }
+    __syncthreads();
+    // H' (n x n, leading dimension n) into A; b'
+    for (int k = tid; k < n * n; k += 256) {
+        const int i = k / n, j = k % n;
+        double v = 0;
+        for (int q = 0; q < 6; q++) v += L.T[i * 6 + q] * L.H[q * n0 + 6 + j];
+        L.A[k] = L.H[(6 + i) * n0 + 6 + j] - v;
+    }
+    if (tid < n) { double v = 0; for (int q = 0; q < 6; q++) v += L.T[tid * 6 + q] * L.b[q]; L.br[tid] = L.b[6 + tid] - v; }
+    __syncthreads();
+    // move H' to H (ld n), V = identity in A
+    for (int k = tid; k < n * n; k += 256) L.H[k] = L.A[k];
+    __syncthreads();
+    for (int k = tid; k < n * n; k += 256) L.A[k] = (k / n == k % n) ? 1.0 : 0.0;
+    __syncthreads();
+    // parallel Jacobi (round-robin tournament over n = even): n - 1 rounds of n / 2 disjoint rotations per sweep
+    const int N1 = n - 1, half = n / 2;
+    for (int sweep = 0; sweep < 40; sweep++) {
+        double offn = 0, dia = 0;
+        for (int k = tid; k < n * n; k += 256) { const int a = k / n, bb = k % n; const double v = L.H[k]; if (a == bb) dia += v * v; else if (a < bb) offn += v * v; }
+        offn = wave_sum_d(offn); dia = wave_sum_d(dia);
+        __syncthreads();
+        if ((tid & 63) == 0) { L.red[tid >> 6] = offn; L.red[4 + (tid >> 6)] = dia; }
+        __syncthreads();
+        offn = L.red[0] + L.red[1] + L.red[2] + L.red[3]; dia = L.red[4] + L.red[5] + L.red[6] + L.red[7];
+        if (offn <= 1e-30 * dia || offn == 0.0) break;
+        for (int rnd = 0; rnd < N1; rnd++) {
+            if (tid < half) {
+                const int p0 = tid == 0 ? N1 : (rnd + tid) % N1, q0 = tid == 0 ? rnd : (rnd - tid + N1) % N1;
+                const int p = min(p0, q0), q = max(p0, q0);
+                const double apq = L.H[p * n + q];
+                double c = 1.0, s = 0.0;
+                if (apq != 0.0) {
+                    const double theta = (L.H[q * n + q] - L.H[p * n + p]) / (2.0 * apq);
+                    const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    c = 1.0 / sqrt(t * t + 1.0); s = t * c;
+                }
+                L.cs[2 * tid] = c; L.cs[2 * tid + 1] = s;
+            }
+            __syncthreads();
+            for (int k = tid; k < half * n; k += 256) {
+                const int pr = k / n, i = k % n;
+                const int p0 = pr == 0 ? N1 : (rnd + pr) % N1, q0 = pr == 0 ? rnd : (rnd - pr + N1) % N1;
+                const int p = min(p0, q0), q = max(p0, q0);
+                const double c = L.cs[2 * pr], s = L.cs[2 * pr + 1];
+                const double a = L.H[i * n + p], bb = L.H[i * n + q];
+                L.H[i * n + p] = c * a - s * bb; L.H[i * n + q] = s * a + c * bb;
+                const double va = L.A[i * n + p], vb = L.A[i * n + q];
+                L.A[i * n + p] = c * va - s * vb; L.A[i * n + q] = s * va + c * vb;
+            }
+            __syncthreads();
+            for (int k = tid; k < half * n; k += 256) {
+                const int pr = k / n, i = k % n;
+                const int p0 = pr == 0 ? N1 : (rnd + pr) % N1, q0 = pr == 0 ? rnd : (rnd - pr + N1) % N1;
+                const int p = min(p0, q0), q = max(p0, q0);
+                const double c = L.cs[2 * pr], s = L.cs[2 * pr + 1];
+                const double a = L.H[p * n + i], bb = L.H[q * n + i];
+                L.H[p * n + i] = c * a - s * bb; L.H[q * n + i] = s * a + c * bb;
+            }
+            __syncthreads();
+        }
+    }
+    for (int k = tid; k < n * n; k += 256) {
+        const int e = k / n, i = k % n;
+        const double wv = L.H[e * n + e];
+        Bt.out_J[(size_t)w * n * n + k] = (wv > eps ? sqrt(wv) : 0.0) * L.A[i * n + e];
+    }
+    for (int e = tid; e < n; e += 256) {
+        const double wv = L.H[e * n + e];
+        double vb = 0;
+        for (int i = 0; i < n; i++) vb += L.A[i * n + e] * L.br[i];
+        Bt.out_r[(size_t)w * n + e] = (wv > eps ? sqrt(1.0 / wv) : 0.0) * vb;
+    }
+    if (tid == 0) Bt.status[w] = L.flag;
 }
 
 } // namespace lmono

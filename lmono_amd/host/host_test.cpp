@@ -30,6 +30,7 @@ int main(int argc, char **argv)
         Estimator est(hip, p);
         const int n_tracks = (int)d[k++];
         est.frame_count = WINDOW_SIZE; est.first_refine = p.FINE_TIMES;     // prior active, as after the first solve
+        est.stage_flag = Estimator::INITED;
         for (int i = 0; i <= WINDOW_SIZE; i++) { for (int j = 0; j < 9; j++) est.Rs[i].m[j] = d[k++]; for (int j = 0; j < 3; j++) est.Ps[i].v[j] = d[k++]; }
         for (int i = 0; i <= WINDOW_SIZE; i++) { for (int j = 0; j < 9; j++) est.L0_R[i].m[j] = d[k++]; for (int j = 0; j < 3; j++) est.L0_T[i].v[j] = d[k++]; }
         for (int j = 0; j < 16; j++) est.TLC[j] = d[k++];

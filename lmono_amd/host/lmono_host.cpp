@@ -122,6 +122,48 @@ void FeatureManager::removeFront(int frame_count)
     }
 }
 
+void FeatureManager::clearDepth()
+{
+    for (auto &it : feature) { it.solve_flag = 0; it.estimated_depth = INIT_DEPTH; }
+}
+double FeatureManager::computeParallax(const FeaturePerId &it_per_id, int frame_count) const
+{
+    const FeaturePerFrame &frame_i = it_per_id.feature_per_frame[frame_count - 2 - it_per_id.start_frame];
+    const FeaturePerFrame &frame_j = it_per_id.feature_per_frame[frame_count - 1 - it_per_id.start_frame];
+    const double du = frame_i.uv[0] - frame_j.uv[0], dv = frame_i.uv[1] - frame_j.uv[1];
+    return std::max(0.0, std::sqrt(du * du + dv * dv));
+}
+bool FeatureManager::featureCheck(int frame_count, const Image &image, double)
+{
+    double parallax_sum = 0;
+    int parallax_num = 0;
+    last_track_num = 0; long_track_num = 0; new_feature_num = 0;
+    for (const auto &id_pts : image) {
+        FeaturePerFrame f_per_fra;
+        f_per_fra.pt[0] = id_pts.second[0]; f_per_fra.pt[1] = id_pts.second[1]; f_per_fra.uv[0] = id_pts.second[2]; f_per_fra.uv[1] = id_pts.second[3];
+        const int feature_id = id_pts.first;
+        auto it = std::find_if(feature.begin(), feature.end(), [feature_id](const FeaturePerId &f) { return f.feature_id == feature_id; });
+        if (it == feature.end()) {
+            FeaturePerId f; f.feature_id = feature_id; f.start_frame = frame_count;
+            f.feature_per_frame.push_back(f_per_fra);
+            feature.push_back(f);
+            new_feature_num++;
+        } else {
+            it->feature_per_frame.push_back(f_per_fra);
+            last_track_num++;
+            if ((int)it->feature_per_frame.size() >= params->TRACK_CNT) long_track_num++;
+        }
+    }
+    if (frame_count < 2 || last_track_num < 20 || new_feature_num > 0.5 * last_track_num) return true;
+    for (auto &it : feature)
+        if (it.start_frame <= frame_count - 2 && it.start_frame + (int)it.feature_per_frame.size() - 1 >= frame_count - 1) {
+            parallax_sum += computeParallax(it, frame_count);
+            parallax_num++;
+        }
+    if (parallax_num == 0) return true;
+    return parallax_sum / parallax_num >= params->FEATURE_THRESHOLD;
+}
+
 // ---- Estimator ----------------------------------------------------------------------------------------------------
 Estimator::Estimator(HipContext &hip, const Params &p) : hip_(hip), p_(p)
 {
@@ -157,6 +199,7 @@ void Estimator::double2Matrix()
     for (int i = 0; i < 3; i++) { TLC[i * 4 + 3] = para_ex[0][i]; for (int j = 0; j < 3; j++) TLC[i * 4 + j] = Rx[i * 3 + j]; }
     feature_manager.setDepth(para_depth_inv);
     feature_manager.removeFailures();
+    loop_closure = false;                                   // :1111-1120
 }
 bool Estimator::optimization()
 {
@@ -206,6 +249,7 @@ bool Estimator::optimization()
     initial_cost = summary[0]; final_cost = summary[1]; iterations = (int)summary[2]; termination = (int)summary[3];
     double2Matrix();
     if (frame_count < WINDOW_SIZE) return false;
+    if (p_.ESTIMATE_LASER) margin();                         // Estimator.cc:1288-1291
     return termination == 0 || final_cost < 5e-3;            // Estimator.cc:1293
 }
 void Estimator::outliersRejection(std::set<int> &removeIndex, const double &error)
@@ -223,7 +267,29 @@ void Estimator::outliersRejection(std::set<int> &removeIndex, const double &erro
 }
 void Estimator::margin()
 {
-    if (marginalization_flag != MARGIN_OLD) return;       // the MARGIN_SECOND_NEW branch only re-marginalises an existing prior
+    if (marginalization_flag != MARGIN_OLD) {
+        // :1406-1470: the previous prior, as the only factor, loses the block that aliases para_pose[WINDOW_SIZE - 1]
+        MarginalizationInfo &mi = last_marginalization_info;
+        if (!mi.present) return;
+        const auto it = std::find(mi.parameter_blocks.begin(), mi.parameter_blocks.end(), WINDOW_SIZE - 1);
+        if (it == mi.parameter_blocks.end()) return;
+        const int drop = (int)(it - mi.parameter_blocks.begin()), nb = (int)mi.parameter_blocks.size();
+        matrix2Double();
+        std::vector<double> x((size_t)nb * 7);
+        for (int k = 0; k < nb; k++) std::memcpy(&x[7 * (size_t)k], mi.parameter_blocks[k] < 0 ? para_ex[0] : para_pose[mi.parameter_blocks[k]], 56);
+        const int n = 6 * (nb - 1);
+        std::vector<double> J((size_t)n * n), r((size_t)n);
+        int status = 0;
+        hip_.check(lmono_marg_second_new(hip_.get(), 1, nb, drop, mi.linearized_jacobians.data(), mi.linearized_residuals.data(),
+                                         mi.keep_block_data.data(), x.data(), J.data(), r.data(), &status), "lmono_marg_second_new");
+        mi.linearized_jacobians.swap(J); mi.linearized_residuals.swap(r);
+        x.erase(x.begin() + 7 * (size_t)drop, x.begin() + 7 * (size_t)(drop + 1));
+        mi.keep_block_data.swap(x);                            // parameter_block_data: the values at this marginalisation
+        mi.parameter_blocks.erase(mi.parameter_blocks.begin() + drop);   // addr_shift :1442-1455: pose i -> pose i (i < 9), pose 10 -> pose 9 is not a block
+        mi.m = 6; mi.n = n; mi.status = status; mi.valid = false;
+        margin_calls[1]++;
+        return;
+    }
     matrix2Double();
     std::vector<int> obs_feat, obs_j; std::vector<double> obs_pts, invd;
     int feature_index = -1, f0 = 0;
@@ -258,7 +324,12 @@ void Estimator::margin()
     mi.keep_block_data.assign(77, 0.0);
     std::memcpy(mi.keep_block_data.data(), para_ex[0], 56);
     for (int i = 1; i <= WINDOW_SIZE; i++) std::memcpy(mi.keep_block_data.data() + 7 * i, para_pose[i], 56);
+    // addr_shift :1390-1396: the kept blocks ex, pose1 .. pose10 alias para_ex[0], para_pose[0] .. para_pose[9] from now on
+    mi.parameter_blocks.assign(1, -1);
+    for (int i = 0; i < WINDOW_SIZE; i++) mi.parameter_blocks.push_back(i);
+    mi.present = true;
     mi.valid = false;      // never set by the reference either
+    margin_calls[0]++;
 }
 
 void Estimator::slideWindow()
@@ -266,15 +337,117 @@ void Estimator::slideWindow()
     if (marginalization_flag == MARGIN_OLD) {
         back_R0 = Rs[0]; back_P0 = Ps[0];
         if (frame_count == WINDOW_SIZE) {
-            for (int i = 0; i < frame_count; i++) { std::swap(Rs[i], Rs[i + 1]); std::swap(Ps[i], Ps[i + 1]); std::swap(L0_R[i], L0_R[i + 1]); std::swap(L0_T[i], L0_T[i + 1]); }
-            Rs[WINDOW_SIZE] = Rs[WINDOW_SIZE - 1]; Ps[WINDOW_SIZE] = Ps[WINDOW_SIZE - 1];
-            feature_manager.removeBackShiftDepth(back_R0, back_P0, Rs[0], Ps[0], TLC);     // slideWindowOld, stage INITED
+            for (int i = 0; i < frame_count; i++) {
+                Header[i] = Header[i + 1];
+                std::swap(Rs[i], Rs[i + 1]); std::swap(Ps[i], Ps[i + 1]);
+                std::swap(L0_R[i], L0_R[i + 1]); std::swap(L0_T[i], L0_T[i + 1]);     // all_image_frame.erase(begin()): slot 10 is rewritten by the next frame
+            }
+            Rs[WINDOW_SIZE] = Rs[WINDOW_SIZE - 1]; Ps[WINDOW_SIZE] = Ps[WINDOW_SIZE - 1]; Header[WINDOW_SIZE] = Header[WINDOW_SIZE - 1];
+            if (stage_flag == NOT_INITED) feature_manager.removeBack();                    // slideWindowOld :744-768
+            else feature_manager.removeBackShiftDepth(back_R0, back_P0, Rs[0], Ps[0], TLC);
         }
     } else if (frame_count == WINDOW_SIZE) {
+        Header[frame_count - 1] = Header[frame_count];
         Ps[frame_count - 1] = Ps[frame_count]; Rs[frame_count - 1] = Rs[frame_count];
-        L0_R[frame_count - 1] = L0_R[frame_count]; L0_T[frame_count - 1] = L0_T[frame_count];
+        // all_image_frame.erase(all_image_frame.end() - 1) (:735) removes the LAST element -- the newest frame's LiDAR pose -- while slot
+        // WINDOW_SIZE - 1 takes the newest Ps / Rs / Header.  Reproduced as written: L0_R / L0_T[WINDOW_SIZE - 1] keep the second-newest
+        // frame's pose and slot WINDOW_SIZE is rewritten by the next frame.
         feature_manager.removeFront(frame_count);                                          // slideWindowNew
     }
+}
+
+// ---- frame loop -------------------------------------------------------------------------------------------------------
+void Estimator::processCompactData(const double L0_Pos[16])
+{
+    const double d[3] = { L0_Pos[3] - last_laser_t.v[0], L0_Pos[7] - last_laser_t.v[1], L0_Pos[11] - last_laser_t.v[2] };
+    static_status = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) < 0.1;             // :259-265
+    last_laser_t.v[0] = L0_Pos[3]; last_laser_t.v[1] = L0_Pos[7]; last_laser_t.v[2] = L0_Pos[11];
+}
+bool Estimator::runInitialization()
+{
+    // :986-1012 (the structure-from-motion block above it is commented out in the reference)
+    double rlcT[9], tlc[3] = { TLC[3], TLC[7], TLC[11] };
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) rlcT[i * 3 + j] = TLC[j * 4 + i];
+    for (int i = 0; i <= frame_count; i++) {
+        mat_mul(rlcT, L0_R[i].m, Rs[i].m);
+        const double dv[3] = { L0_T[i].v[0] - tlc[0], L0_T[i].v[1] - tlc[1], L0_T[i].v[2] - tlc[2] };
+        mat_vec(rlcT, dv, Ps[i].v);
+    }
+    feature_manager.clearDepth();
+    feature_manager.triangulate(frame_count, Rs, Ps, TLC);
+    std::set<int> removeIndex;
+    outliersRejection(removeIndex, 100.0);
+    feature_manager.removeOutlier(removeIndex);
+    return true;
+}
+void Estimator::loopCorrection()
+{
+    if (loop_buf.empty()) return;
+    const LoopFrame lf = loop_buf.back();                 // the while loop of :312-317 keeps the last one
+    loop_buf.clear();
+    int idx = -1;
+    for (int i = 0; i < WINDOW_SIZE; i++) if (lf.loop_time_stamp == Header[i]) idx = i;
+    if (idx < 0) return;
+    loop_closure = true;
+    // Eigen::Quaterniond(w, x, y, z).toRotationMatrix(): the message's quaternion as it is (not normalised)
+    const double w = lf.correct_Q[0], x = lf.correct_Q[1], y = lf.correct_Q[2], z = lf.correct_Q[3];
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z, twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    const double Rc[9] = { 1 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1 - (txx + tzz), tyz - twx, txz - twy, tyz + twx, 1 - (txx + tyy) };
+    const Mat3 Ri = Rs[idx]; const Vec3 Pi = Ps[idx];
+    double RiT[9];
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) RiT[a * 3 + b] = Ri.m[b * 3 + a];
+    for (int i = 0; i <= WINDOW_SIZE; i++) {
+        if (i == idx) continue;
+        double rel_r[9], rel_t[3], rt[3];
+        mat_mul(RiT, Rs[i].m, rel_r);
+        const double dp[3] = { Pi.v[0] - Ps[i].v[0], Pi.v[1] - Ps[i].v[1], Pi.v[2] - Ps[i].v[2] };
+        mat_vec(RiT, dp, rel_t);
+        mat_mul(Rc, rel_r, Rs[i].m);
+        mat_vec(Rc, rel_t, rt);
+        for (int k = 0; k < 3; k++) Ps[i].v[k] = lf.correct_T[k] - rt[k];
+    }
+    std::memcpy(Rs[idx].m, Rc, 72);
+    for (int k = 0; k < 3; k++) Ps[idx].v[k] = lf.correct_T[k];
+}
+bool Estimator::processImage(double header, const FeatureManager::Image &image, const double transform_to_init[16])
+{
+    processCompactData(transform_to_init);
+    const bool keyframe = feature_manager.featureCheck(frame_count, image, header);       // :383-394
+    marginalization_flag = keyframe ? MARGIN_OLD : MARGIN_SECOND_NEW;
+    Header[frame_count] = header;
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) L0_R[frame_count].m[i * 3 + j] = transform_to_init[i * 4 + j]; L0_T[frame_count].v[i] = transform_to_init[i * 4 + 3]; }   // all_image_frame.push_back
+    if (stage_flag == NOT_INITED) {
+        if (frame_count == WINDOW_SIZE) {
+            if (p_.ESTIMATE_LASER != 2 && runInitialization()) {
+                optimization();
+                stage_flag = INITED;
+                std::set<int> removeIndex;
+                outliersRejection(removeIndex, 3);
+                feature_manager.removeOutlier(removeIndex);
+                slideWindow();
+            } else slideWindow();
+        }
+        if (frame_count < WINDOW_SIZE) {
+            frame_count++;
+            Ps[frame_count] = Ps[frame_count - 1]; Rs[frame_count] = Rs[frame_count - 1]; Header[frame_count] = Header[frame_count - 1];
+        }
+    } else {
+        loopCorrection();
+        feature_manager.triangulate(frame_count, Rs, Ps, TLC);
+        std::set<int> removeIndex;
+        optimization();
+        outliersRejection(removeIndex, p_.OUTLIER_T);
+        feature_manager.removeOutlier(removeIndex);
+        slideWindow();
+    }
+    if (stage_flag == INITED) {                             // new_odometry.txt row, :634-645
+        std::array<double, 8> row;
+        row[0] = Header[WINDOW_SIZE];
+        for (int k = 0; k < 3; k++) row[1 + k] = Ps[WINDOW_SIZE].v[k];
+        R_to_q(Rs[WINDOW_SIZE].m, &row[4]);
+        new_odometry.push_back(row);
+    }
+    return keyframe;
 }
 
 // ---- A-LOAM nodes ---------------------------------------------------------------------------------------------------

@@ -9,6 +9,7 @@
 #pragma once
 #include <cstdint>
 #include <list>
+#include <map>
 #include <set>
 #include <stdexcept>
 #include <string>
@@ -27,6 +28,7 @@ struct Vec3 { double v[3]; };
 struct Params {                           // config values used on the hot path (kitti_config_05.yaml)
     double FACTOR_WEIGHT = 1500.0, LASER_W = 3.0, PRIOR_T = 1000.0, PRIOR_R = 1000.0, OUTLIER_T = 5.0;
     int TRACK_CNT = 3, FINE_TIMES = 1, NUM_ITERATIONS = 30, ESTIMATE_LASER = 1;
+    double FEATURE_THRESHOLD = 10.0;      // feature_threshold (pixels of parallax that make a keyframe)
 };
 
 class HipContext {
@@ -46,7 +48,7 @@ private:
 };
 
 // ---- FeatureManager (track store) ---------------------------------------------------------------------------------
-struct FeaturePerFrame { double pt[2]; };
+struct FeaturePerFrame { double pt[2]; double uv[2] = { 0, 0 }; };   // normalised point, pixel (FeatureManager.h FeaturePerFrame)
 struct FeaturePerId {
     int feature_id, start_frame;
     std::vector<FeaturePerFrame> feature_per_frame;
@@ -70,6 +72,13 @@ public:
     void removeBackShiftDepth(const Mat3 &back_R0, const Vec3 &back_P0, const Mat3 &R1, const Vec3 &P1, const double tlc[16]);  // :540-590
     void removeBack();                                       // :497-511
     void removeFront(int frame_count);                       // :513-538
+    // one observation of the tracker per feature id: x_n, y_n, u, v (the first four of the reference's 6-vector)
+    typedef std::map<int, std::array<double, 4>> Image;
+    bool featureCheck(int frame_count, const Image &image, double td);   // :315-400: appends the observations, true = keyframe
+    double computeParallax(const FeaturePerId &it_per_id, int frame_count) const;   // :279-313
+    void clearDepth();                                       // :29-36
+    void clearState() { feature.clear(); }
+    int last_track_num = 0, long_track_num = 0, new_feature_num = 0;
     // packs tracks with used_num >= TRACK_CNT for the kernels: start, offsets, points (anchor first)
     void pack(std::vector<int> &start, std::vector<int> &off, std::vector<double> &pts, std::vector<double> &depth, bool all_tracks);
 };
@@ -95,22 +104,42 @@ public:
     Mat3 back_R0; Vec3 back_P0;
     double final_cost = 0, initial_cost = 0; int iterations = 0, termination = 0;
 
+    // ---- frame loop (Estimator.cc:236-273, :309-365, :367-499, :852-1017)
+    enum StageFlag { NOT_INITED = 0, INITED = 1 };
+    StageFlag stage_flag = NOT_INITED;
+    double Header[WINDOW_SIZE + 1] = { 0 };
+    Vec3 last_laser_t = { { 0, 0, 0 } };
+    bool loop_closure = false;
+    struct LoopFrame { double loop_time_stamp; double old_T[3], old_Q[4], correct_T[3], correct_Q[4]; };   // quaternions w x y z (Estimator.h:60-104)
+    std::vector<LoopFrame> loop_buf;
+    std::vector<std::array<double, 8>> new_odometry;     // trajectory of record (:634-645): header, P, q x y z w
+    // L0_Pos of processCompactData: 4x4 row-major LiDAR pose (topic LASER_ODOM_TOPIC); sets static_status
+    void processCompactData(const double L0_Pos[16]);
+    // one pass of processEstimation without ROS / the image tracker: `image` is FeatureTracker::trackImage's output
+    bool processImage(double header, const FeatureManager::Image &image, const double transform_to_init[16]);
+    bool runInitialization();
+    void loopCorrection();
+    void setLoopFrame(const LoopFrame &f) { loop_buf.push_back(f); }
+
     void matrix2Double();                  // Estimator.cc:1019-1057
     void double2Matrix();                  // :1059-1122
     bool optimization();                   // :1124-1305 (solve through lmono_ba_*; margin() is not part of the solve path)
     void outliersRejection(std::set<int> &removeIndex, const double &error);   // :134-190
     void slideWindow();                    // :700-771
-    // :1307-1405, MARGIN_OLD branch.  Like the reference, the prior is computed but never fed back into
-    // optimization() (MarginalizationInfo::valid is never set).  The reference passes the mono
-    // pipeline's never-initialised right_pt as the second observation; the mirror passes the tracked point.
+    // :1307-1470, both branches.  Like the reference, the prior is computed but never fed back into optimization()
+    // (MarginalizationInfo::valid is never set).  The reference passes the mono pipeline's
+    // never-initialised right_pt as the second observation; the mirror passes the tracked point.
     void margin();
     struct MarginalizationInfo {           // include/factor/MarginalizationFactor.h:78-108 (fields used downstream)
         int m = 0, n = 0;
-        std::vector<double> linearized_jacobians, linearized_residuals;   // [66*66], [66]
-        std::vector<double> keep_block_data;                               // [11][7]: ex, pose1..pose10 at linearisation
-        bool valid = false;
+        std::vector<double> linearized_jacobians, linearized_residuals;   // [n*n], [n]
+        std::vector<double> keep_block_data;                               // [blocks][7] at linearisation
+        // last_marginalization_parameter_blocks as window slots: -1 = para_ex[0], i = para_pose[i] (after the address shift)
+        std::vector<int> parameter_blocks;
+        bool valid = false, present = false;
         int status = 0;
     } last_marginalization_info;
+    int margin_calls[2] = { 0, 0 };        // MARGIN_OLD priors built, MARGIN_SECOND_NEW eliminations done
 
 private:
     HipContext &hip_;

@@ -150,3 +150,66 @@ void lo_marg_evaluate(const double *lin_J, const double *lin_r, const double *x0
         for (int bk = 0; bk < 11; bk++)
             for (int i = 0; i < 66; i++) { for (int c = 0; c < 6; c++) jac[(size_t)bk * 462 + i * 7 + c] = lin_J[i * 66 + 6 * bk + c]; jac[(size_t)bk * 462 + i * 7 + 6] = 0.0; }
 }
+
+/* MARGIN_SECOND_NEW branch of Estimator::margin() (Estimator.cc:1406-1470): the only factor is the previous prior itself,
+ * `Marginalization(last_marginalization_info)` over last_marginalization_parameter_blocks (MarginalizationFactor.cc:300-373),
+ * with the block that aliases para_pose[WINDOW_SIZE - 1] in the drop set.  preMarginalize evaluates it at the CURRENT parameter
+ * values (residual = r0 + J0 dx, Jacobian blocks = columns of J0) and keeps those values as the new linearisation point;
+ * marginalize then eliminates the dropped block's 6 local dimensions (H = J^T J, b = J^T r, eigen pseudo-inverse of H_mm with the
+ * eps cut, Schur complement, second eigen-decomposition -> linearized_jacobians / linearized_residuals).
+ *   nb blocks of the previous prior (7 doubles each, 6 local), x0 / x [nb][7] at its linearisation point / now, drop = block index.
+ *   lin_J [6nb x 6nb] row-major, lin_r [6nb].  Outputs over the nb - 1 kept blocks in their old order: out_J [n x n], out_r [n],
+ *   n = 6 (nb - 1).  Block order is implementation defined in the reference (unordered_map iteration); any order gives the same
+ *   prior up to a permutation. */
+int lo_marg_second_new(int nb, int drop, const double *lin_J, const double *lin_r, const double *x0, const double *x, double *out_J, double *out_r)
+{
+    const int n0 = 6 * nb, n = n0 - 6, m = 6;
+    const double eps = 1e-8;
+    if (nb < 2 || nb > 11 || drop < 0 || drop >= nb) return -1;
+    double dx[66], r[66];
+    for (int bk = 0; bk < nb; bk++) {
+        const double *a = x + 7 * bk, *a0 = x0 + 7 * bk;
+        for (int k = 0; k < 3; k++) dx[6 * bk + k] = a[k] - a0[k];
+        const double n2 = a0[3] * a0[3] + a0[4] * a0[4] + a0[5] * a0[5] + a0[6] * a0[6];
+        const double ix = -a0[3] / n2, iy = -a0[4] / n2, iz = -a0[5] / n2, iw = a0[6] / n2;
+        const double qx = a[3], qy = a[4], qz = a[5], qw = a[6];
+        const double rw = iw * qw - ix * qx - iy * qy - iz * qz;
+        double rx = iw * qx + ix * qw + iy * qz - iz * qy, ry = iw * qy + iy * qw + iz * qx - ix * qz, rz = iw * qz + iz * qw + ix * qy - iy * qx;
+        if (!(rw >= 0)) { rx = -rx; ry = -ry; rz = -rz; }
+        dx[6 * bk + 3] = 2.0 * rx; dx[6 * bk + 4] = 2.0 * ry; dx[6 * bk + 5] = 2.0 * rz;
+    }
+    for (int i = 0; i < n0; i++) { double v = lin_r[i]; for (int k = 0; k < n0; k++) v += lin_J[i * n0 + k] * dx[k]; r[i] = v; }
+    /* permutation: dropped block first, then the kept blocks in order */
+    int perm[66];
+    for (int c = 0; c < 6; c++) perm[c] = 6 * drop + c;
+    for (int bk = 0, p = 6; bk < nb; bk++) { if (bk == drop) continue; for (int c = 0; c < 6; c++) perm[p++] = 6 * bk + c; }
+    double *H = (double *)calloc((size_t)n0 * n0, sizeof(double)), b[66];
+    for (int i = 0; i < n0; i++) {
+        for (int j = 0; j < n0; j++) { double v = 0; for (int k = 0; k < n0; k++) v += lin_J[k * n0 + perm[i]] * lin_J[k * n0 + perm[j]]; H[i * n0 + j] = v; }
+        double v = 0; for (int k = 0; k < n0; k++) v += lin_J[k * n0 + perm[i]] * r[k];
+        b[i] = v;
+    }
+    double Hmm[36], w[66], Vm[36], Hinv[36] = { 0 };
+    for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) Hmm[i * m + j] = 0.5 * (H[i * n0 + j] + H[j * n0 + i]);
+    jacobi_eig(Hmm, m, w, Vm);
+    for (int k = 0; k < m; k++) {
+        if (!(w[k] > eps)) continue;
+        for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) Hinv[i * m + j] += Vm[i * m + k] / w[k] * Vm[j * m + k];
+    }
+    double *T = (double *)malloc(sizeof(double) * (size_t)n * m), *Hr = (double *)malloc(sizeof(double) * (size_t)n * n), *V = (double *)malloc(sizeof(double) * (size_t)n * n), br[66];
+    for (int i = 0; i < n; i++) for (int j = 0; j < m; j++) { double v = 0; for (int k = 0; k < m; k++) v += H[(m + i) * n0 + k] * Hinv[k * m + j]; T[i * m + j] = v; }
+    for (int i = 0; i < n; i++) {
+        for (int j = 0; j < n; j++) { double v = 0; for (int k = 0; k < m; k++) v += T[i * m + k] * H[k * n0 + m + j]; Hr[i * n + j] = H[(m + i) * n0 + m + j] - v; }
+        double v = 0; for (int k = 0; k < m; k++) v += T[i * m + k] * b[k];
+        br[i] = b[m + i] - v;
+    }
+    jacobi_eig(Hr, n, w, V);
+    for (int k = 0; k < n; k++) {
+        const double S = w[k] > eps ? w[k] : 0.0, Si = w[k] > eps ? 1.0 / w[k] : 0.0;
+        double vb = 0;
+        for (int i = 0; i < n; i++) { out_J[k * n + i] = sqrt(S) * V[i * n + k]; vb += V[i * n + k] * br[i]; }
+        out_r[k] = sqrt(Si) * vb;
+    }
+    free(H); free(T); free(Hr); free(V);
+    return 0;
+}

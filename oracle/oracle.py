@@ -422,6 +422,37 @@ def marg_evaluate(lin_J, lin_r, x0, x, want_jac=True):
     return res, jac
 
 
+def marg_second_new(lin_J, lin_r, x0, x, drop_block):
+    """MARGIN_SECOND_NEW: previous prior (lin_J [n0,n0], lin_r [n0], x0 [nb,7]) evaluated at x [nb,7], block drop_block eliminated.
+    -> (J [n,n], r [n]), n = n0 - 6, kept blocks in their old order."""
+    lin_J = np.ascontiguousarray(lin_J, np.float64); lin_r = np.ascontiguousarray(lin_r, np.float64)
+    x0 = np.ascontiguousarray(x0, np.float64); x = np.ascontiguousarray(x, np.float64)
+    nb = len(x); n = 6 * nb - 6
+    J = np.zeros((n, n)); r = np.zeros(n)
+    rc = lib().lo_marg_second_new(C.c_int(nb), C.c_int(drop_block), _fp(lin_J, C.c_double), _fp(lin_r, C.c_double), _fp(x0, C.c_double), _fp(x, C.c_double),
+                                  _fp(J, C.c_double), _fp(r, C.c_double))
+    if rc != 0:
+        raise ValueError("lo_marg_second_new failed")
+    return J, r
+
+
+def prior_dx(x0, x):
+    """dx of Marginalization::Evaluate (MarginalizationFactor.cc:323-343) for any number of 7-wide blocks: numpy, for the tests."""
+    x0 = np.asarray(x0, np.float64).reshape(-1, 7); x = np.asarray(x, np.float64).reshape(-1, 7)
+    out = np.zeros((len(x), 6))
+    out[:, :3] = x[:, :3] - x0[:, :3]
+    for k in range(len(x)):
+        a0 = x0[k, 3:]; a = x[k, 3:]
+        n2 = (a0 ** 2).sum()
+        i = np.array([-a0[0], -a0[1], -a0[2], a0[3]]) / n2
+        rw = i[3] * a[3] - i[0] * a[0] - i[1] * a[1] - i[2] * a[2]
+        rv = np.array([i[3] * a[0] + i[0] * a[3] + i[1] * a[2] - i[2] * a[1],
+                       i[3] * a[1] + i[1] * a[3] + i[2] * a[0] - i[0] * a[2],
+                       i[3] * a[2] + i[2] * a[3] + i[0] * a[1] - i[1] * a[0]])
+        out[k, 3:] = 2.0 * (rv if rw >= 0 else -rv)
+    return out.ravel()
+
+
 # ---- colour projection (MapBuilder::associateToMap / depthFill; lo_colour.c) ----
 class Cam(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int),

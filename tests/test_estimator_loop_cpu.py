@@ -1,0 +1,82 @@
+"""The Estimator frame loop restated in the oracle (oracle/estimator_ref.py): state machine, keyframe decision, static frames,
+marginalisation branches, loop re-anchoring, trajectory of record.  CPU only."""
+import numpy as np
+
+from tests import estimator_stream as S
+
+
+def test_state_machine_and_trajectory(oracle):
+    from workloads import s2
+    from oracle import estimator_ref as E
+    st = s2.make_stream(48, seed=1, stops=(30, 31))
+    est, log = S.replay_oracle(st)
+    stages = [r[1] for r in log]
+    assert stages[:10] == [E.NOT_INITED] * 10 and all(s == E.INITED for s in stages[10:])          # INITED with the 11th frame (:442-459)
+    tr = np.array(est.trajectory)
+    assert tr.shape == (38, 8)                                                                    # one new_odometry row per INITED frame
+    assert np.allclose(tr[:, 0], st["headers"][10:])                                              # Header[WINDOW_SIZE] = the newest frame
+    # not exactly unit: Rs = rlc^T L0_R with the 8-digit laser_to_camera0 of the YAML, whose 3x3 block is a rotation to ~1e-8 only
+    assert np.abs(np.linalg.norm(tr[:, 4:], axis=1) - 1).max() < 1e-7
+    # static_status exactly on the frames where the LiDAR moved < 0.1 m (:259-265), and those solves still terminate
+    static = [r[2] for r in log]
+    assert [k for k, v in enumerate(static) if v] == [0, 30, 31]                                   # frame 0: |t - 0| < 0.1
+    # both marginalisation branches ran; a MARGIN_SECOND_NEW elimination leaves [ex, pose0..pose8]
+    kinds = [m for m in est.marg_log]
+    assert any(f == E.MARGIN_OLD for f, _ in kinds) and any(f == E.MARGIN_SECOND_NEW and nb == 10 for f, nb in kinds)
+    keyframes = [r[0] for r in log]
+    assert 0 < sum(keyframes[10:]) < len(keyframes[10:])                                          # keyframes and non-keyframes both occur
+    # the fused trajectory follows the ground truth (LiDAR increments with 1 cm / 0.05 deg noise chained over 38 frames)
+    err = np.linalg.norm(tr[:, 1:4] - st["gt_P"][10:], axis=1)
+    assert err.max() < 1.0 and err[:5].max() < 0.1
+    # window bookkeeping invariants: every track starts inside the window and ends at most at the newest frame
+    for f in est.feature:
+        assert 0 <= f.start_frame <= E.WINDOW_SIZE and f.end_frame() <= E.WINDOW_SIZE and len(f.obs) >= 1
+
+
+def test_second_new_drops_the_newest_lidar_frame_as_written(oracle):
+    """all_image_frame.erase(end() - 1) (Estimator.cc:735) removes the newest frame's LiDAR pose on a non-keyframe: the restatement keeps
+    that behaviour, so after such a slide the window holds 10 image frames whose last one is the SECOND-newest."""
+    from workloads import s2
+    from oracle import estimator_ref as E
+    st = s2.make_stream(48, seed=1, stops=(30, 31))
+    seen = []
+
+    def on_frame(k, est):
+        if est.stage_flag == E.INITED and est.marginalization_flag == E.MARGIN_SECOND_NEW:
+            seen.append((k, len(est.frames), est.frames[-1][0], st["headers"][k - 1]))
+    S.replay_oracle(st, on_frame=on_frame)
+    assert seen, "the stream must contain a non-keyframe after initialisation"
+    for k, n, last_header, prev_header in seen:
+        assert n == 10 and last_header != st["headers"][k]
+
+
+def test_loop_correction_reanchors_the_window_rigidly(oracle):
+    """loopCorrection (:309-365): every window pose keeps its pose relative to the matched frame, which takes the corrected pose."""
+    from workloads import s2
+    from oracle import estimator_ref as E
+    st = s2.make_stream(24, seed=2)
+    e = S.loop_event(st, 18)
+    snap = {}
+
+    def on_frame(k, est):
+        if k == 17:
+            snap["Rs"] = [R.copy() for R in est.Rs]; snap["Ps"] = [P.copy() for P in est.Ps]; snap["H"] = list(est.Header)
+    est = E.EstimatorRef(st["tlc"])
+    est0, _ = S.replay_oracle(st, on_frame=on_frame)          # no loop: reference run
+    est1, _ = S.replay_oracle(st, loops=[e])
+    assert e["stamp"] in snap["H"][:E.WINDOW_SIZE]
+    # the runs agree before the loop frame and differ after it
+    t0 = np.array(est0.trajectory); t1 = np.array(est1.trajectory)
+    assert np.array_equal(t0[:7], t1[:7]) and np.abs(t0[8:, 1:4] - t1[8:, 1:4]).max() > 1e-3
+    # rigidity of the correction itself, on a copy of the window before frame 18
+    est2 = E.EstimatorRef(st["tlc"])
+    est2.Rs = [R.copy() for R in snap["Rs"]]; est2.Ps = [P.copy() for P in snap["Ps"]]; est2.Header = list(snap["H"])
+    est2.setLoopFrame(e["stamp"], e["old_T"], e["old_Q"], e["correct_T"], e["correct_Q"])
+    est2.loopCorrection()
+    i = snap["H"].index(e["stamp"])
+    assert np.allclose(est2.Ps[i], e["correct_T"])
+    for j in range(E.WINDOW_SIZE + 1):
+        rel_before = snap["Rs"][i].T @ (snap["Ps"][j] - snap["Ps"][i]); rel_after = est2.Rs[i].T @ (est2.Ps[j] - est2.Ps[i])
+        # to the orthonormality of the window rotations (~1e-8: they inherit the YAML extrinsic's 8 digits)
+        assert np.abs(rel_before - rel_after).max() < 1e-6
+        assert np.abs(snap["Rs"][i].T @ snap["Rs"][j] - est2.Rs[i].T @ est2.Rs[j]).max() < 1e-6

@@ -1,0 +1,76 @@
+"""the Estimator frame loop of the host mirror (lmono_amd/host: processImage -> featureCheck ->
+[runInitialization | loopCorrection -> triangulate] -> optimization (+ margin) -> outliersRejection -> slideWindow, all numerics
+on the GPU through the C ABI) replays >= 101 frames of the S2 stream and reproduces the CPU oracle's trajectory of record
+(new_odometry, Estimator.cc:642) and its per-frame decisions."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import estimator_stream as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "lmono_amd", "host", "estimator_seq")
+pytestmark = pytest.mark.gpu
+
+
+def _run(st, loops, tmp_path, name):
+    fx = tmp_path / (name + ".bin")
+    S.write_stream(fx, st, loops)
+    out = subprocess.run([EXE, str(fx), str(tmp_path / (name + ".txt"))], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    frm = [ln.split()[1:] for ln in out.stdout.splitlines() if ln.startswith("FRM")]
+    odo = np.array([[float(v) for v in ln.split()[1:]] for ln in out.stdout.splitlines() if ln.startswith("ODO")])
+    ext = np.array([float(v) for v in [ln for ln in out.stdout.splitlines() if ln.startswith("EXT")][0].split()[1:]]).reshape(4, 4)
+    tim = [ln for ln in out.stdout.splitlines() if ln.startswith("TIM")][0].split()
+    return frm, odo, ext, float(tim[2])
+
+
+def test_120_frames_match_the_oracle(oracle, tmp_path):
+    from workloads import s2
+    # seed 2: a stream on which every solve is well conditioned (final costs < 3e3; scan in profiles/r2/NOTES.md)
+    st = s2.make_stream(120, seed=2, stops=(40, 41, 77))
+    loops = [S.loop_event(st, 60), S.loop_event(st, 95, shift=(-0.03, 0.01, 0.06), yaw=-0.003)]
+    est, log = S.replay_oracle(st, loops)                 # fills the loop events' corrected poses from the oracle's own window
+    frm, odo, ext, ms = _run(st, loops, tmp_path, "s2_120")
+    assert len(frm) == 120 and odo.shape == (110, 8)
+    ref = np.array(est.trajectory)
+    # per-frame decisions: keyframe, stage, static, solver iterations / termination, marginalisation counters, surviving tracks
+    for k, (row, r) in enumerate(zip(frm, log)):
+        got = (int(row[1]), int(row[2]), int(row[3]))
+        assert got == (r[0], r[1], r[2]), "frame %d: keyframe / stage / static differ: %s vs %s" % (k, got, r[:3])
+        if r[1] == 1:
+            assert (int(row[4]), int(row[5])) == (r[3], r[4]), "frame %d: iterations / termination differ" % k
+            assert abs(float(row[6]) - r[5]) <= 1e-4 * max(r[5], 1.0)      # 30 unconverged iterations: costs agree to ~1e-6..1e-5, poses to 1e-8
+        assert (int(row[7]), int(row[8])) == (r[6], r[7]), "frame %d: marginalisation counters differ" % k
+        assert int(row[9]) == r[8], "frame %d: track counts differ" % k
+    # the trajectory of record, every INITED frame
+    assert np.array_equal(odo[:, 0], ref[:, 0])
+    assert np.abs(odo[:, 1:4] - ref[:, 1:4]).max() < 1e-6
+    assert np.abs(odo[:, 4:] - ref[:, 4:]).max() < 1e-7
+    assert np.abs(ext - est.TLC).max() < 1e-7             # the refined extrinsic (ESTIMATE_LASER = 1)
+    # both marginalisation branches and both loop events were exercised
+    assert log[-1][6] > 50 and log[-1][7] >= 3
+    print("120-frame replay: %.2f ms per INITED frame on the GPU path, max |dP| vs oracle %.2e" % (ms, np.abs(odo[:, 1:4] - ref[:, 1:4]).max()))
+    # the new_odometry.txt written by the mirror has the reference's layout (8 %f columns, Estimator.cc:642-644)
+    txt = np.loadtxt(str(tmp_path / "s2_120.txt"))
+    assert txt.shape == (110, 8) and np.abs(txt[:, 1:4] - ref[:, 1:4]).max() < 1e-5
+
+
+def test_ill_conditioned_frames_stay_close(oracle, tmp_path):
+    """Seed 3 contains two frames (17, 18) whose solves start from a cost of ~1e7 (a badly triangulated track) and stop after 1 resp.
+    10 iterations on a function-tolerance knife edge: there the GPU's and the oracle's trust-region traces may part (Appendix B of
+    SURVEY.md: parity is on converged states, not traces).  The decisions of the loop must still agree and the trajectories stay
+    within 1 mm."""
+    from workloads import s2
+    st = s2.make_stream(60, seed=3)
+    est, log = S.replay_oracle(st, [])
+    frm, odo, ext, ms = _run(st, [], tmp_path, "s2_seed3")
+    ref = np.array(est.trajectory)
+    assert odo.shape == ref.shape
+    for k, (row, r) in enumerate(zip(frm, log)):
+        assert (int(row[1]), int(row[2]), int(row[3])) == (r[0], r[1], r[2]), "frame %d" % k
+        assert (int(row[7]), int(row[8])) == (r[6], r[7]) and int(row[9]) == r[8], "frame %d" % k
+    assert np.abs(odo[:7, 1:4] - ref[:7, 1:4]).max() < 1e-6          # identical up to the knife edge
+    assert np.abs(odo[:, 1:4] - ref[:, 1:4]).max() < 1e-3

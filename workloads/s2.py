@@ -10,12 +10,17 @@ def quat_R(q):
                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
 
 
-# laser_to_camera0 of kitti_config_05.yaml (mono_lidar_mapping/config/kitti_config_05.yaml:27-30)
+# laser_to_camera0 of kitti_config_05.yaml (mono_lidar_mapping/config/kitti_config_05.yaml:27-30), digits as in the file.  The 3x3
+# block is a rotation to ~1e-8 only (8 printed digits); the Estimator goes through Eigen::Quaterniond(TLC.block<3,3>) and
+# q.normalized().toRotationMatrix() (matrix2Double / double2Matrix), which this module mirrors where an exact rotation is needed.
+LASER_TO_CAM0 = np.array([[-0.00185773, -0.00648143, 0.99997727, 0.3308678],
+                          [-0.99996595, 0.00805187, -0.00180552, 0.05505896],
+                          [-0.00803998, -0.99994658, -0.00649617, -0.07543742],
+                          [0.0, 0.0, 0.0, 1.0]])
+
+
 def kitti_extrinsic():
-    T = np.eye(4)
-    T[:3, :3] = np.array([[0.0, 0.0, 1.0], [-1.0, 0.0, 0.0], [0.0, -1.0, 0.0]])   # camera z forward -> lidar x forward
-    T[:3, 3] = [0.27, 0.0, -0.08]
-    return T
+    return LASER_TO_CAM0.copy()
 
 
 def R_to_q(m):
@@ -121,3 +126,62 @@ def make_window(seed=0, n_frames=11, n_landmarks=4000, max_tracks=150, pix_sigma
                 gt_Rs=np.array(Rs), gt_Ps=np.array(Ps), tlc=T.copy(),
                 trk_start=np.array(trk_start, np.int32), trk_off=np.array(trk_off, np.int32), trk_pts=np.array(trk_pts),
                 trk_true_depth=np.array(trk_true))
+
+
+def make_stream(n_frames=120, seed=0, n_landmarks=None, max_tracks=150, pix_sigma=0.5, odo_sigma_t=0.01, odo_sigma_r=np.deg2rad(0.05),
+                death=0.1, min_dist=30.0, speed=0.8, stops=()):
+    """BASELINE configs[2] as a frame STREAM (what Estimator::processEstimation consumes frame by frame, Estimator.cc:528-553):
+    per frame the LiDAR odometry pose (ground truth + noise; topic /aft_mapped_to_init) and the tracker's output
+    {feature id: (x_n, y_n, u, v)} (FeatureTracker::trackImage, <= max_tracks features, min_dist pixels apart, a track dies
+    with probability `death` per frame).  Landmarks fill a corridor along the whole path.  `stops`: frame indices at which the
+    vehicle stands still for that frame (static_status, Estimator.cc:259-265).
+    Returns dict(headers [n], L0 [n,4,4], feats (list of dicts), gt_R [n,3,3], gt_P [n,3] in the Estimator world, tlc)."""
+    rng = np.random.default_rng(20241 + 7919 * seed)
+    T = kitti_extrinsic()
+    Rlc, tlc = quat_R(R_to_q(T[:3, :3]) / np.linalg.norm(R_to_q(T[:3, :3]))), T[:3, 3]
+    L0_R, L0_P = [], []
+    yaw, pos = 0.0, np.zeros(3)
+    for k in range(n_frames):
+        c, s = np.cos(yaw), np.sin(yaw)
+        L0_R.append(np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])); L0_P.append(pos.copy())
+        if k + 1 not in stops:
+            pos = pos + L0_R[-1] @ np.array([speed, 0, 0]); yaw += rng.normal(0.01, 0.005)
+    Rs = [Rlc.T @ R for R in L0_R]; Ps = [Rlc.T @ (P - tlc) for P in L0_P]
+    cam_R = [Rs[k] @ Rlc for k in range(n_frames)]; cam_P = [Ps[k] + Rs[k] @ tlc for k in range(n_frames)]
+    # landmarks around the whole path (LiDAR frame: x forward, y left, z up), ~33 per metre of path as in make_window
+    path = np.array(L0_P)
+    if n_landmarks is None:
+        n_landmarks = int(33 * (np.linalg.norm(np.diff(path, axis=0), axis=1).sum() + 120))
+    a = rng.uniform(0, 1, n_landmarks)
+    idx = np.minimum((a * (n_frames - 1)).astype(int), n_frames - 1)
+    base = path[idx]; head = np.array([L0_R[i][:, 0] for i in idx]); left = np.array([L0_R[i][:, 1] for i in idx])
+    lm_l = base + head * rng.uniform(2, 120, n_landmarks)[:, None] + left * rng.uniform(-20, 20, n_landmarks)[:, None]
+    lm_l[:, 2] = rng.uniform(-1.5, 6.5, n_landmarks)
+    lm = (Rlc.T @ (lm_l - tlc).T).T
+    feats, alive, seen = [], [], set()
+    for k in range(n_frames):
+        pc = (cam_R[k].T @ (lm - cam_P[k]).T).T
+        z = pc[:, 2]
+        zs = np.where(z > 1e-6, z, 1.0)
+        u = FX * pc[:, 0] / zs + CX; v = FY * pc[:, 1] / zs + CY
+        vis = (z > 1.0) & (u > 0) & (u < W_IMG) & (v > 0) & (v < H_IMG)
+        alive = [t for t in alive if vis[t] and rng.uniform() > death]
+        cand = [t for t in np.nonzero(vis)[0] if t not in seen]
+        rng.shuffle(cand)
+        taken = np.array([(u[t], v[t]) for t in alive]).reshape(-1, 2)
+        for t in cand:
+            if len(alive) >= max_tracks:
+                break
+            if len(taken) == 0 or ((taken[:, 0] - u[t]) ** 2 + (taken[:, 1] - v[t]) ** 2).min() > min_dist ** 2:
+                alive.append(t); seen.add(t); taken = np.concatenate([taken, [[u[t], v[t]]]])
+        fr = {}
+        for t in alive:
+            uu = u[t] + rng.normal(0, pix_sigma); vv = v[t] + rng.normal(0, pix_sigma)
+            fr[int(t)] = ((uu - CX) / FX, (vv - CY) / FY, uu, vv)
+        feats.append(fr)
+    L0 = np.zeros((n_frames, 4, 4))
+    for k in range(n_frames):
+        L0[k] = np.eye(4)
+        L0[k, :3, :3] = L0_R[k] @ quat_R(np.concatenate([rng.normal(0, odo_sigma_r / 2, 3), [1.0]]))
+        L0[k, :3, 3] = L0_P[k] + rng.normal(0, odo_sigma_t, 3)
+    return dict(headers=0.1 * np.arange(n_frames), L0=L0, feats=feats, gt_R=np.array(Rs), gt_P=np.array(Ps), tlc=T)
