@@ -116,6 +116,14 @@ int lmono_factor_eval(lmono_ctx *, int kind, int count, const double *params_h, 
                       const double *info_h, double *r_h, double *J_h);
 int lmono_factor_eval_d(lmono_ctx *, int kind, int count, const double *params_d, const double *consts_d,
                         const double *info_d, double *r_d, double *J_d);
+/* The same with ceres::CostFunction::Evaluate's per-block contract (LaserFactor.h:45, MonoProjectionFactor.cc:40: any jacobians[k]
+ * may be NULL): block_mask [count] holds one byte per residual block, bit k set = the Jacobian of parameter block k is wanted
+ * (LASER: pose_i, pose_j; MONO: ex, pose_i, pose_j, inv_depth; PRIOR: ex; REPROJ: inv_depth).  Blocks whose bit is clear are left
+ * untouched in J; a zero byte is `jacobians == NULL` for that residual block.  block_mask NULL = every block.                     */
+int lmono_factor_eval_blocks(lmono_ctx *, int kind, int count, const double *params_h, const double *consts_h,
+                             const double *info_h, double *r_h, double *J_h, const unsigned char *block_mask_h);
+int lmono_factor_eval_blocks_d(lmono_ctx *, int kind, int count, const double *params_d, const double *consts_d,
+                               const double *info_d, double *r_d, double *J_d, const unsigned char *block_mask_d);
 
 /* ---- lmono sliding-window BA: Estimator::optimization()'s solve, batched over independent windows ------------ *
  * Reference interface: Estimator::optimization() -> ceres::Solve(DENSE_SCHUR, DOGLEG, max_num_iterations = NUM_ITERATIONS)

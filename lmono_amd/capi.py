@@ -16,7 +16,7 @@ SYMBOLS = [
     "lmono_map_builder_create", "lmono_map_builder_destroy", "lmono_associate_to_map", "lmono_associate_to_map_batch", "lmono_map_builder_depth",
     "lmono_map_builder_cloud", "lmono_map_builder_map", "lmono_map_builder_clear",
     "lmono_pose_graph_create", "lmono_pose_graph_destroy", "lmono_pose_graph_reset", "lmono_pose_graph_info", "lmono_pose_graph_reduce_buffer", "lmono_pose_graph_set_reduce_buffer", "lmono_pose_graph_linearise",
-    "lmono_pose_graph_step", "lmono_pose_graph_optimize", "lmono_pose_graph_result", "lmono_factor_eval", "lmono_factor_eval_d",
+    "lmono_pose_graph_step", "lmono_pose_graph_optimize", "lmono_pose_graph_result", "lmono_factor_eval", "lmono_factor_eval_d", "lmono_factor_eval_blocks", "lmono_factor_eval_blocks_d",
     "lmono_triangulate", "lmono_outlier_scores", "lmono_shift_depth", "lmono_marginalize", "lmono_marg_evaluate", "lmono_marg_second_new", "lmono_ba_batch_create", "lmono_ba_batch_destroy", "lmono_ba_solve", "lmono_ba_batch_reset", "lmono_ba_batch_read",
 ]
 
@@ -76,6 +76,8 @@ def load_library():
     L.lmono_ba_batch_read.argtypes = [C.c_void_p] * 6
     L.lmono_factor_eval.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
     L.lmono_factor_eval_d.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
+    L.lmono_factor_eval_blocks.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6
+    L.lmono_factor_eval_blocks_d.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6
     L.lmono_pose_prefix_d.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.lmono_pose_rebase_d.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     L.lmono_timing_read.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
@@ -139,6 +141,21 @@ class Context:
         r = np.zeros((n, nres)); J = np.zeros((n, njac)) if want_jac else None
         self.check(self.L.lmono_factor_eval(self.h, kind, n, params.ctypes.data, consts.ctypes.data, info.ctypes.data,
                                             r.ctypes.data, J.ctypes.data if want_jac else None))
+        return r, J
+
+    def factor_eval_blocks(self, kind, params, consts, info, block_mask, J_init=None):
+        """Evaluate with ceres' per-block contract: block_mask [n] uint8, bit k = jacobians[k] != NULL.  J starts as J_init (or NaN) so
+        that the caller can see which blocks were written."""
+        npar, ncon, ninf, nres, njac = self.FACTOR_DIMS[kind]
+        params = np.ascontiguousarray(params, np.float64).reshape(-1, npar)
+        consts = np.ascontiguousarray(consts, np.float64).reshape(-1, ncon)
+        info = np.ascontiguousarray(info, np.float64).reshape(ninf)
+        n = len(params)
+        mask = np.ascontiguousarray(block_mask, np.uint8).reshape(n)
+        r = np.zeros((n, nres))
+        J = np.full((n, njac), np.nan) if J_init is None else np.ascontiguousarray(J_init, np.float64).copy()
+        self.check(self.L.lmono_factor_eval_blocks(self.h, kind, n, params.ctypes.data, consts.ctypes.data, info.ctypes.data,
+                                                   r.ctypes.data, J.ctypes.data, mask.ctypes.data))
         return r, J
 
     def factor_eval_d(self, kind, count, params_ptr, consts_ptr, info_ptr, r_ptr, J_ptr=None):

@@ -286,8 +286,23 @@ __host__ __device__ inline FactorDims factor_dims(int kind)
     }
 }
 
+// first Jacobian element of parameter block k of a factor kind, in doubles; entry n_blocks = total (the packed layout of lmono_hip.h)
+__device__ __forceinline__ int factor_block_begin(int kind, int k)
+{
+    switch (kind) {
+    case 0: return k == 0 ? 0 : (k == 1 ? 42 : 84);                          // LASER: J_i [6x7], J_j [6x7]
+    case 1: return k == 0 ? 0 : (k == 1 ? 14 : (k == 2 ? 28 : (k == 3 ? 42 : 44)));   // MONO: J_ex, J_i, J_j [2x7], J_depth [2x1]
+    case 2: return k == 0 ? 0 : 42;                                          // PRIOR: J_ex [6x7]
+    default: return k == 0 ? 0 : 2;                                          // REPROJ: J_depth [2x1]
+    }
+}
+__device__ __forceinline__ int factor_blocks(int kind) { return kind == 0 ? 2 : (kind == 1 ? 4 : 1); }
+
+// block_mask (optional, one byte per residual block): bit k set = the caller wants the Jacobian of parameter block k, as
+// ceres::CostFunction::Evaluate is called with jacobians[k] != NULL; the other blocks of J are left untouched.  mask == 0 for a
+// residual block = jacobians == NULL for it.
 __global__ __launch_bounds__(64) void k_factor_eval(int kind, int count, const double *params, const double *consts, const double *info,
-                                                    double *r, double *J)
+                                                    double *r, double *J, const unsigned char *block_mask)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
@@ -296,7 +311,8 @@ __global__ __launch_bounds__(64) void k_factor_eval(int kind, int count, const d
     for (int k = 0; k < d.np; k++) p[k] = params[(size_t)i * d.np + k];
     for (int k = 0; k < d.nc; k++) c[k] = consts[(size_t)i * d.nc + k];
     for (int k = 0; k < d.ni; k++) inf[k] = info[k];
-    double *jp = J ? jo : nullptr;
+    const unsigned int mask = block_mask ? block_mask[i] : 0xffu;
+    double *jp = (J && mask) ? jo : nullptr;
     switch (kind) {
     case 0: ba::laser_factor(p, c, inf, ro, jp); break;
     case 1: ba::mono_factor(p, c, inf, ro, jp); break;
@@ -304,7 +320,10 @@ __global__ __launch_bounds__(64) void k_factor_eval(int kind, int count, const d
     default: ba::reproj_factor(p, c, inf, ro, jp); break;
     }
     for (int k = 0; k < d.nr; k++) r[(size_t)i * d.nr + k] = ro[k];
-    if (J) for (int k = 0; k < d.nj; k++) J[(size_t)i * d.nj + k] = jo[k];
+    if (jp)
+        for (int bk = 0; bk < factor_blocks(kind); bk++)
+            if (mask & (1u << bk))
+                for (int k = factor_block_begin(kind, bk); k < factor_block_begin(kind, bk + 1); k++) J[(size_t)i * d.nj + k] = jo[k];
 }
 
 } // namespace lmono

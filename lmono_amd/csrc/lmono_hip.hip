@@ -518,36 +518,49 @@ extern "C" int lmono_pose_rebase_d(lmono_ctx *c, const double *bases_d, int n_ba
 }
 
 // ---- BA factors -------------------------------------------------------------------------------------------------
-extern "C" int lmono_factor_eval_d(lmono_ctx *c, int kind, int count, const double *params_d, const double *consts_d,
-                                   const double *info_d, double *r_d, double *J_d)
+extern "C" int lmono_factor_eval_blocks_d(lmono_ctx *c, int kind, int count, const double *params_d, const double *consts_d,
+                                          const double *info_d, double *r_d, double *J_d, const unsigned char *block_mask_d)
 {
     if (!c || kind < 0 || kind > 3 || count < 0 || !params_d || !consts_d || !info_d || !r_d) return LMONO_EINVAL;
     if (count == 0) return LMONO_OK;
     HIP_TRY(c, hipSetDevice(c->device));
-    hipLaunchKernelGGL(k_factor_eval, dim3((count + 63) / 64), dim3(64), 0, c->stream, kind, count, params_d, consts_d, info_d, r_d, J_d);
+    hipLaunchKernelGGL(k_factor_eval, dim3((count + 63) / 64), dim3(64), 0, c->stream, kind, count, params_d, consts_d, info_d, r_d, J_d, block_mask_d);
     return check_launch(c, "k_factor_eval");
 }
 
-extern "C" int lmono_factor_eval(lmono_ctx *c, int kind, int count, const double *params_h, const double *consts_h,
-                                 const double *info_h, double *r_h, double *J_h)
+extern "C" int lmono_factor_eval_d(lmono_ctx *c, int kind, int count, const double *params_d, const double *consts_d,
+                                   const double *info_d, double *r_d, double *J_d)
+{
+    return lmono_factor_eval_blocks_d(c, kind, count, params_d, consts_d, info_d, r_d, J_d, nullptr);
+}
+
+extern "C" int lmono_factor_eval_blocks(lmono_ctx *c, int kind, int count, const double *params_h, const double *consts_h,
+                                        const double *info_h, double *r_h, double *J_h, const unsigned char *block_mask_h)
 {
     if (!c || kind < 0 || kind > 3 || count < 0 || !params_h || !consts_h || !info_h || !r_h) return LMONO_EINVAL;
     if (count == 0) return LMONO_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     const FactorDims d = factor_dims(kind);
     double *p = nullptr, *cn = nullptr, *inf = nullptr, *r = nullptr, *J = nullptr;
+    unsigned char *mk = nullptr;
     int rc = LMONO_OK;
-    auto cleanup = [&]() { (void)hipFree(p); (void)hipFree(cn); (void)hipFree(inf); (void)hipFree(r); (void)hipFree(J); };
+    auto cleanup = [&]() { (void)hipFree(p); (void)hipFree(cn); (void)hipFree(inf); (void)hipFree(r); (void)hipFree(J); (void)hipFree(mk); };
 #define TRYF(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { c->err = std::string(#expr) + ": " + hipGetErrorString(e_); cleanup(); return LMONO_ENODEV; } } while (0)
     TRYF(hipMalloc((void **)&p, sizeof(double) * d.np * count));
     TRYF(hipMalloc((void **)&cn, sizeof(double) * d.nc * count));
     TRYF(hipMalloc((void **)&inf, sizeof(double) * d.ni));
     TRYF(hipMalloc((void **)&r, sizeof(double) * d.nr * count));
     if (J_h) TRYF(hipMalloc((void **)&J, sizeof(double) * d.nj * count));
+    if (J_h && block_mask_h) {
+        TRYF(hipMalloc((void **)&mk, (size_t)count));
+        TRYF(hipMemcpy(mk, block_mask_h, (size_t)count, hipMemcpyHostToDevice));
+        // blocks the caller did not ask for keep the caller's bytes: start from the caller's J
+        TRYF(hipMemcpy(J, J_h, sizeof(double) * d.nj * count, hipMemcpyHostToDevice));
+    }
     TRYF(hipMemcpy(p, params_h, sizeof(double) * d.np * count, hipMemcpyHostToDevice));
     TRYF(hipMemcpy(cn, consts_h, sizeof(double) * d.nc * count, hipMemcpyHostToDevice));
     TRYF(hipMemcpy(inf, info_h, sizeof(double) * d.ni, hipMemcpyHostToDevice));
-    rc = lmono_factor_eval_d(c, kind, count, p, cn, inf, r, J);
+    rc = lmono_factor_eval_blocks_d(c, kind, count, p, cn, inf, r, J, mk);
     if (rc == LMONO_OK) {
         TRYF(hipStreamSynchronize(c->stream));
         TRYF(hipMemcpy(r_h, r, sizeof(double) * d.nr * count, hipMemcpyDeviceToHost));
@@ -556,6 +569,12 @@ extern "C" int lmono_factor_eval(lmono_ctx *c, int kind, int count, const double
 #undef TRYF
     cleanup();
     return rc;
+}
+
+extern "C" int lmono_factor_eval(lmono_ctx *c, int kind, int count, const double *params_h, const double *consts_h,
+                                 const double *info_h, double *r_h, double *J_h)
+{
+    return lmono_factor_eval_blocks(c, kind, count, params_h, consts_h, info_h, r_h, J_h, nullptr);
 }
 
 // ---- BA window solve ---------------------------------------------------------------------------------------------

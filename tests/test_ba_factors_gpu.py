@@ -50,3 +50,26 @@ def test_factor_eval_device_resident_large_batch(oracle, gpu_ctx):
     assert torch.equal(r2, 2 * r1) and torch.equal(J2, 2 * J1)
     ro, Jo = oracle.factor_eval(1, P, Cn, info)
     assert _rel(r1[:2000].cpu().numpy(), ro) < 1e-12 and _rel(J1[-2000:].cpu().numpy(), Jo) < 1e-12
+
+
+def test_per_block_null_jacobians(oracle, gpu_ctx):
+    """ceres::CostFunction::Evaluate may be handed jacobians[k] == NULL for any subset of the parameter blocks (LaserFactor.h:45,
+    MonoProjectionFactor.cc:40): lmono_factor_eval_blocks writes exactly the requested blocks and leaves the others untouched."""
+    from tests import ba_cases as K
+    bounds = {0: [0, 42, 84], 1: [0, 14, 28, 42, 44], 2: [0, 42], 3: [0, 2]}
+    cases = {0: K.laser_cases(12), 1: K.mono_cases(12), 2: K.prior_cases(12), 3: K.reproj_cases(12)}
+    rng = np.random.default_rng(4)
+    for kind, (P, Cn, info) in cases.items():
+        r_ref, J_ref = oracle.factor_eval(kind, P, Cn, info)
+        nb = len(bounds[kind]) - 1
+        mask = rng.integers(0, 1 << nb, len(P)).astype(np.uint8)
+        mask[0] = 0; mask[1] = (1 << nb) - 1
+        r, J = gpu_ctx.factor_eval_blocks(kind, P, Cn, info, mask)
+        assert np.abs(r - r_ref).max() <= 1e-12 * (np.abs(r_ref).max() + 1)
+        for i in range(len(P)):
+            for b in range(nb):
+                blk = slice(bounds[kind][b], bounds[kind][b + 1])
+                if mask[i] >> b & 1:
+                    assert np.abs(J[i, blk] - J_ref[i, blk]).max() <= 1e-12 * (np.abs(J_ref[i]).max() + 1)
+                else:
+                    assert np.isnan(J[i, blk]).all(), "block %d of residual %d was written although jacobians[%d] == NULL" % (b, i, b)

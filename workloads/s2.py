@@ -59,6 +59,8 @@ def make_window(seed=0, n_frames=11, n_landmarks=4000, max_tracks=150, pix_sigma
     """One Estimator window as optimization() sees it (Estimator.cc:1124-1215): state, feature tracks, LiDAR increments."""
     rng = np.random.default_rng(20241 + seed)
     T = kitti_extrinsic()                       # laser <- camera
+    q = R_to_q(T[:3, :3])
+    T[:3, :3] = quat_R(q / np.linalg.norm(q))   # the exact rotation the Estimator works with (Quaterniond(TLC).normalized(), matrix2Double)
     Rlc, tlc = T[:3, :3], T[:3, 3]
     # LiDAR ground-truth poses in the LiDAR odometry frame: forward 0.8 m / frame, gentle yaw
     L0_R, L0_P = [], []
