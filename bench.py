@@ -69,6 +69,62 @@ def bench_ba(args):
     print(json.dumps(out), flush=True)
 
 
+def bench_ba_seq(args):
+    """BASELINE configs[2] as a SEQUENCE: KITTI-05-shaped S2 frame stream (2761 frames: LiDAR odometry pose +
+    tracker output per frame) through the host mirror's Estimator::processImage loop (lmono_amd/host/estimator_seq: featureCheck ->
+    triangulate -> optimization + margin -> outliersRejection -> slideWindow, every numeric step on the GPU through the C ABI), one
+    frame after the other as the reference runs (batch 1: window k depends on window k - 1).  Reports frames/s of the INITED
+    frames, the fused trajectory's ATE against ground truth and against the CPU oracle's replay of a bounded prefix."""
+    import subprocess
+    import tempfile
+    from lmono_amd import trajectory
+    from workloads import s2 as K
+    n = args.frames_seq
+    t0 = time.time()
+    st = K.make_stream(n, seed=2, stops=(400, 401, 1500) if n > 1500 else ())
+    gen_s = time.time() - t0
+    d = tempfile.mkdtemp()
+    fx = os.path.join(d, "stream.bin")
+    K.write_stream(fx, st)
+    exe = os.path.join(ROOT, "lmono_amd", "host", "estimator_seq")
+    t0 = time.perf_counter()
+    out = subprocess.run([exe, fx], capture_output=True, text=True)          # the child owns the GPU; this process never touches it
+    wall = time.perf_counter() - t0
+    if out.returncode != 0:
+        raise RuntimeError("estimator_seq failed: " + out.stderr[-1000:])
+    odo = np.array([[float(v) for v in ln.split()[1:]] for ln in out.stdout.splitlines() if ln.startswith("ODO")])
+    tim = [ln for ln in out.stdout.splitlines() if ln.startswith("TIM")][0].split()
+    n_inited, ms_frame = int(tim[1]), float(tim[2])
+    gt = np.concatenate([np.zeros((len(odo), 4)), st["gt_P"][10:10 + len(odo)]], 1)
+    est = np.concatenate([np.zeros((len(odo), 4)), odo[:, 1:4]], 1)
+    # ---- cpu_baseline leg: the only place the oracle is touched
+    from oracle import estimator_ref as E
+    m = min(args.cpu_sample if args.cpu_sample > 0 else 0, n)
+    res = {"metric": "Estimator frames/sec (sliding-window BA frame loop, S2 synthetic stream)", "value": round(1e3 / ms_frame, 2), "unit": "frames/s",
+           "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": round(ms_frame * n_inited, 1), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "S2 frame stream, KITTI-05 shape (configs[2]): %d frames, <= 150 tracks / frame, batch 1 (one sequence)" % n,
+                      "frames": n, "inited_frames": n_inited, "ms_per_frame": round(ms_frame, 3), "wall_s": round(wall, 1), "gen_s": round(gen_s, 1),
+                      "note": "a frame = processImage of the C++ mirror: triangulate + <= 30 dogleg iterations + marginalisation + outlier "
+                              "rejection + window slide; each numeric step is one C-ABI call with its own allocation / upload (PCIe-inclusive)"},
+           "roofline": {"bound": "mfma", "kernel": "k_ba_solve (one window per launch: one of 256 CUs busy)", "achieved": None, "peak": FP64_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": None, "traffic": None,
+                        "note": "batch 1 is latency bound by construction (SURVEY 8d): the reference's own operating point; the batched rate is the `ba` workload"},
+           "ate_vs_truth_m": round(trajectory.ate(est, gt), 4)}
+    if m > 20:
+        sub = {k: (v[:m] if k != "tlc" else v) for k, v in st.items()}
+        t0 = time.time()
+        ref_est = E.EstimatorRef(sub["tlc"])
+        for k in range(m):
+            ref_est.process(sub["headers"][k], sub["L0"][k], sub["feats"][k])
+        cpu_s = time.time() - t0
+        ref = np.array(ref_est.trajectory)
+        res["cpu_baseline"] = {"value": round((m - 10) / cpu_s, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+                               "sample": "first %d frames of the same stream, oracle/estimator_ref.py over the C oracle (-O3), 1 thread" % m}
+        res["max_pos_diff_vs_cpu_m"] = float(np.abs(odo[:len(ref), 1:4] - ref[:, 1:4]).max())
+    print(json.dumps(res), flush=True)
+
+
 def bench_map(args):
     """Tertiary workload: laserMapping with the device-resident cube map over a synthetic S1 sequence, one
     stream.  One step = every scan of the sequence through lmono_mapper_process once (fresh map per step)."""
@@ -358,10 +414,11 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=384, help="scans of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (sequential run, BA secondary)")
     ap.add_argument("--probe-ranks", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--workload", default="lidar", choices=["lidar", "ba", "map", "colour", "posegraph"],
+    ap.add_argument("--workload", default="lidar", choices=["lidar", "ba", "ba-seq", "map", "colour", "posegraph"],
                     help="lidar = headline (BASELINE configs[1]); ba = configs[2]-shaped sliding-window BA solves (secondary); "
                          "map = laserMapping over a synthetic sequence, one stream (SURVEY 8f-1)")
     ap.add_argument("--windows", type=int, default=1024, help="ba: independent windows per GPU")
+    ap.add_argument("--frames-seq", type=int, default=2761, help="ba-seq: frames of the stream (KITTI seq 05 = 2761)")
     ap.add_argument("--streams", type=int, default=64, help="map / colour: independent streams advanced in lock-step")
     ap.add_argument("--frames", type=int, default=20, help="colour: frames per stream and step")
     ap.add_argument("--keyframes", type=int, default=4541, help="posegraph: keyframes of the graph")
@@ -372,6 +429,8 @@ def main():
         return probe_ranks(args)
     if args.workload == "ba":
         return bench_ba(args)
+    if args.workload == "ba-seq":
+        return bench_ba_seq(args)
     if args.workload == "map":
         return bench_map(args)
     if args.workload == "colour":

@@ -10,22 +10,7 @@ def loop_event(st, frame, old_T=(1.0, 2.0, 3.0), shift=(0.05, -0.02, 0.03), yaw=
                 shift=np.array(shift), yaw=yaw)
 
 
-def write_stream(path, st, loops=()):
-    by_frame = {e["frame"]: e for e in loops}
-    buf = [float(len(st["headers"]))] + list(np.asarray(st["tlc"], np.float64).ravel())
-    for k in range(len(st["headers"])):
-        buf += [float(st["headers"][k])] + list(st["L0"][k].ravel())
-        e = by_frame.get(k)
-        if e is None:
-            buf.append(0.0)
-        else:
-            buf.append(1.0)
-            buf += [e["stamp"]] + list(e["old_T"]) + list(e["old_Q"]) + list(e["correct_T"]) + list(e["correct_Q"])
-        fr = st["feats"][k]
-        buf.append(float(len(fr)))
-        for fid in sorted(fr):
-            buf += [float(fid)] + list(fr[fid])
-    np.array(buf, np.float64).tofile(str(path))
+from workloads.s2 import write_stream  # noqa: E402,F401  (the stream file writer is input plumbing)
 
 
 def replay_oracle(st, loops=(), on_frame=None):

@@ -29,7 +29,7 @@ def _run(st, loops, tmp_path, name):
 
 def test_120_frames_match_the_oracle(oracle, tmp_path):
     from workloads import s2
-    # seed 2: a stream on which every solve is well conditioned (final costs < 3e3; scan in profiles/r2/NOTES.md)
+    # seed 2: a stream on which every solve is well conditioned (final costs < 1e3; seeds 0..5 scanned with the oracle)
     st = s2.make_stream(120, seed=2, stops=(40, 41, 77))
     loops = [S.loop_event(st, 60), S.loop_event(st, 95, shift=(-0.03, 0.01, 0.06), yaw=-0.003)]
     est, log = S.replay_oracle(st, loops)                 # fills the loop events' corrected poses from the oracle's own window
@@ -59,12 +59,11 @@ def test_120_frames_match_the_oracle(oracle, tmp_path):
 
 
 def test_ill_conditioned_frames_stay_close(oracle, tmp_path):
-    """Seed 3 contains two frames (17, 18) whose solves start from a cost of ~1e7 (a badly triangulated track) and stop after 1 resp.
-    10 iterations on a function-tolerance knife edge: there the GPU's and the oracle's trust-region traces may part (Appendix B of
-    SURVEY.md: parity is on converged states, not traces).  The decisions of the loop must still agree and the trajectories stay
-    within 1 mm."""
+    """Seed 0 contains a frame (19) whose solve starts from a cost of ~6e6 (a badly triangulated track) and stops after a few iterations
+    on a function-tolerance knife edge: there the GPU's and the oracle's trust-region traces may part (Appendix B of SURVEY.md: parity
+    is on converged states, not traces).  The decisions of the loop must still agree and the trajectories stay within 1 mm."""
     from workloads import s2
-    st = s2.make_stream(60, seed=3)
+    st = s2.make_stream(60, seed=0)
     est, log = S.replay_oracle(st, [])
     frm, odo, ext, ms = _run(st, [], tmp_path, "s2_seed3")
     ref = np.array(est.trajectory)
@@ -72,5 +71,5 @@ def test_ill_conditioned_frames_stay_close(oracle, tmp_path):
     for k, (row, r) in enumerate(zip(frm, log)):
         assert (int(row[1]), int(row[2]), int(row[3])) == (r[0], r[1], r[2]), "frame %d" % k
         assert (int(row[7]), int(row[8])) == (r[6], r[7]) and int(row[9]) == r[8], "frame %d" % k
-    assert np.abs(odo[:7, 1:4] - ref[:7, 1:4]).max() < 1e-6          # identical up to the knife edge
+    assert np.abs(odo[:8, 1:4] - ref[:8, 1:4]).max() < 1e-6          # identical up to the knife edge
     assert np.abs(odo[:, 1:4] - ref[:, 1:4]).max() < 1e-3

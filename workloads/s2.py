@@ -131,12 +131,14 @@ def make_window(seed=0, n_frames=11, n_landmarks=4000, max_tracks=150, pix_sigma
 
 
 def make_stream(n_frames=120, seed=0, n_landmarks=None, max_tracks=150, pix_sigma=0.5, odo_sigma_t=0.01, odo_sigma_r=np.deg2rad(0.05),
-                death=0.1, min_dist=30.0, speed=0.8, stops=()):
+                death=0.1, min_dist=30.0, speed=0.8, stops=(), lidar_gt=None, lidar_meas=None):
     """BASELINE configs[2] as a frame STREAM (what Estimator::processEstimation consumes frame by frame, Estimator.cc:528-553):
     per frame the LiDAR odometry pose (ground truth + noise; topic /aft_mapped_to_init) and the tracker's output
     {feature id: (x_n, y_n, u, v)} (FeatureTracker::trackImage, <= max_tracks features, min_dist pixels apart, a track dies
     with probability `death` per frame).  Landmarks fill a corridor along the whole path.  `stops`: frame indices at which the
-    vehicle stands still for that frame (static_status, Estimator.cc:259-265).
+    vehicle stands still for that frame (static_status, Estimator.cc:259-265).  lidar_gt = (R [n,3,3], P [n,3]): ground-truth LiDAR
+    poses to use instead of the built-in path (e.g. the S1 trajectory); lidar_meas [n,4,4]: the LiDAR odometry to hand to the
+    Estimator instead of ground truth + noise (e.g. the output of the GPU laserOdometry / laserMapping on S1 scans: configs[0]).
     Returns dict(headers [n], L0 [n,4,4], feats (list of dicts), gt_R [n,3,3], gt_P [n,3] in the Estimator world, tlc)."""
     rng = np.random.default_rng(20241 + 7919 * seed)
     T = kitti_extrinsic()
@@ -148,6 +150,8 @@ def make_stream(n_frames=120, seed=0, n_landmarks=None, max_tracks=150, pix_sigm
         L0_R.append(np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])); L0_P.append(pos.copy())
         if k + 1 not in stops:
             pos = pos + L0_R[-1] @ np.array([speed, 0, 0]); yaw += rng.normal(0.01, 0.005)
+    if lidar_gt is not None:
+        L0_R = [np.asarray(R, np.float64) for R in lidar_gt[0][:n_frames]]; L0_P = [np.asarray(P, np.float64) for P in lidar_gt[1][:n_frames]]
     Rs = [Rlc.T @ R for R in L0_R]; Ps = [Rlc.T @ (P - tlc) for P in L0_P]
     cam_R = [Rs[k] @ Rlc for k in range(n_frames)]; cam_P = [Ps[k] + Rs[k] @ tlc for k in range(n_frames)]
     # landmarks around the whole path (LiDAR frame: x forward, y left, z up), ~33 per metre of path as in make_window
@@ -160,18 +164,24 @@ def make_stream(n_frames=120, seed=0, n_landmarks=None, max_tracks=150, pix_sigm
     lm_l = base + head * rng.uniform(2, 120, n_landmarks)[:, None] + left * rng.uniform(-20, 20, n_landmarks)[:, None]
     lm_l[:, 2] = rng.uniform(-1.5, 6.5, n_landmarks)
     lm = (Rlc.T @ (lm_l - tlc).T).T
+    # landmarks sorted by the path index they hang on: a frame only looks at those within [-20, +200] frames of itself
+    # (up to ~160 m ahead), which keeps the generator linear in the number of frames
+    order = np.argsort(idx, kind="stable")
+    lm = lm[order]; idx = idx[order]
     feats, alive, seen = [], [], set()
     for k in range(n_frames):
-        pc = (cam_R[k].T @ (lm - cam_P[k]).T).T
+        lo, hi = np.searchsorted(idx, k - 20, "left"), np.searchsorted(idx, k + 200, "right")
+        pc = (cam_R[k].T @ (lm[lo:hi] - cam_P[k]).T).T
         z = pc[:, 2]
         zs = np.where(z > 1e-6, z, 1.0)
-        u = FX * pc[:, 0] / zs + CX; v = FY * pc[:, 1] / zs + CY
-        vis = (z > 1.0) & (u > 0) & (u < W_IMG) & (v > 0) & (v < H_IMG)
+        u = np.full(len(lm), -1.0); v = np.full(len(lm), -1.0); vis = np.zeros(len(lm), bool)
+        u[lo:hi] = FX * pc[:, 0] / zs + CX; v[lo:hi] = FY * pc[:, 1] / zs + CY
+        vis[lo:hi] = (z > 1.0) & (u[lo:hi] > 0) & (u[lo:hi] < W_IMG) & (v[lo:hi] > 0) & (v[lo:hi] < H_IMG)
         alive = [t for t in alive if vis[t] and rng.uniform() > death]
-        cand = [t for t in np.nonzero(vis)[0] if t not in seen]
+        cand = [t for t in (lo + np.nonzero(vis[lo:hi])[0]) if t not in seen]
         rng.shuffle(cand)
         taken = np.array([(u[t], v[t]) for t in alive]).reshape(-1, 2)
-        for t in cand:
+        for t in cand[:500]:                      # goodFeaturesToTrack looks at a bounded number of corners
             if len(alive) >= max_tracks:
                 break
             if len(taken) == 0 or ((taken[:, 0] - u[t]) ** 2 + (taken[:, 1] - v[t]) ** 2).min() > min_dist ** 2:
@@ -186,4 +196,26 @@ def make_stream(n_frames=120, seed=0, n_landmarks=None, max_tracks=150, pix_sigm
         L0[k] = np.eye(4)
         L0[k, :3, :3] = L0_R[k] @ quat_R(np.concatenate([rng.normal(0, odo_sigma_r / 2, 3), [1.0]]))
         L0[k, :3, 3] = L0_P[k] + rng.normal(0, odo_sigma_t, 3)
+    if lidar_meas is not None:
+        L0 = np.asarray(lidar_meas, np.float64)[:n_frames].copy()
     return dict(headers=0.1 * np.arange(n_frames), L0=L0, feats=feats, gt_R=np.array(Rs), gt_P=np.array(Ps), tlc=T)
+
+
+def write_stream(path, st, loops=()):
+    """The frame stream in the binary layout lmono_amd/host/estimator_seq reads (doubles): n_frames, TLC[16], then per frame: header,
+    L0_Pos[16], n_loop (0/1) [stamp, old_T[3], old_Q[4] w x y z, correct_T[3], correct_Q[4] w x y z], n_features, n x (id, x_n, y_n, u, v)."""
+    by_frame = {e["frame"]: e for e in loops}
+    buf = [float(len(st["headers"]))] + list(np.asarray(st["tlc"], np.float64).ravel())
+    for k in range(len(st["headers"])):
+        buf += [float(st["headers"][k])] + list(st["L0"][k].ravel())
+        e = by_frame.get(k)
+        if e is None:
+            buf.append(0.0)
+        else:
+            buf.append(1.0)
+            buf += [e["stamp"]] + list(e["old_T"]) + list(e["old_Q"]) + list(e["correct_T"]) + list(e["correct_Q"])
+        fr = st["feats"][k]
+        buf.append(float(len(fr)))
+        for fid in sorted(fr):
+            buf += [float(fid)] + list(fr[fid])
+    np.array(buf, np.float64).tofile(str(path))
