@@ -38,12 +38,16 @@ const char *lmono_last_error(const lmono_ctx *);
 int         lmono_set_stream(lmono_ctx *, void *hip_stream); /* hipStream_t; NULL = default  */
 int         lmono_synchronize(lmono_ctx *);
 /* Tuning / test switches of a context (no reference counterpart).  LMONO_OPT_CORR_TILE selects the laserOdometry correspondence
- * search: 0 (default) = 32 lanes per feature point on the global hash grid + line index (k_correspond); 1 = LDS-staged azimuth
- * sectors, 16 lanes per feature (k_corr_tile); 2 = one thread per feature (k_corr_thread); 3 = flattened candidate sweeps
- * (k_corr_flat); 1..3 hand the features they do not answer to k_correspond_list.  All four return identical results
+ * search: 3 (default) = flattened candidate sweeps over the (scan line, azimuth bin) index (k_corr_flat; needs no hash grid, so
+ * lmono_scanreg_batch skips k_grid_build and the grids are built on demand); 0 = 32 lanes per feature point on the hash grid + line
+ * index (k_correspond); 1 = LDS-staged azimuth sectors, 4 lanes per feature (k_corr_tile); 2 = one thread per feature
+ * (k_corr_thread); 1..3 hand the features they do not answer to k_correspond_list.  All four return identical results
  * (tests/test_lidar_gpu.py::test_tile_search_equals_global_search); measured rates: profiles/r2/NOTES.md.                      */
 #define LMONO_OPT_CORR_TILE 0
-#define LMONO_OPT_COUNT     1
+/* test hook: n > 0 makes the default search (mode 3) hand every n-th feature point to its fall-back kernel (k_correspond_list), which
+ * then runs without hash grids; results must not change.  0 = off.                                                              */
+#define LMONO_OPT_DEFER_EVERY 1
+#define LMONO_OPT_COUNT     2
 int         lmono_set_option(lmono_ctx *, int key, int value);
 const char *lmono_version(void);
 

@@ -112,6 +112,7 @@ class Context:
         self.check(self.L.lmono_synchronize(self.h))
 
     OPT_CORR_TILE = 0
+    OPT_DEFER_EVERY = 1
 
     def set_option(self, key, value):
         self.check(self.L.lmono_set_option(self.h, int(key), int(value)))
@@ -121,9 +122,9 @@ class Context:
 
     def timing(self):
         """Summed device ms per kernel group since timing_reset(): dict + call counts."""
-        ms = np.zeros(28)
+        ms = np.zeros(52)
         nr, no = C.c_int(0), C.c_int(0)
-        self.check(self.L.lmono_timing_read(self.h, ms.ctypes.data, 28, C.byref(nr), C.byref(no)))
+        self.check(self.L.lmono_timing_read(self.h, ms.ctypes.data, 52, C.byref(nr), C.byref(no)))
         self.diag = ms[13:].copy()
         names = ["frontend_total", "odometry_total", "k_ring_sort", "k_curvature", "k_select", "k_voxel", "k_compact",
                  "k_grid_build", "k_line_index", "k_correspond", "k_lm_solve", "odometry_launch_pairs", "deferred_features"]

@@ -22,6 +22,7 @@ struct BatchView {
     const int64_t *off;      // [n_scans + 1] point offsets (device copy)
     int n_scans;
     int n_lines;
+    int has_grid;            // the hash grids (cg_* / sg_*) of this registration have been built (k_grid_build runs on demand)
     float min_range;
     // ---- ring-sorted cloud (same offsets as the input; n_cloud[s] valid points)
     float4 *cloud;           // [total] x y z (ring + 0.1 relTime)

@@ -69,7 +69,7 @@ __device__ __forceinline__ void cf_arc(float r, float rho, float th, CfArc &a)
     constexpr float kb = kAzBins / 6.28318531f;
     a.a0 = 0; a.a1 = kAzBins; a.w1 = 0;
     if (!(rho > r * 1.002f)) return;                      // the ball reaches the sensor axis: every azimuth
-    const float alpha = asin_upper(r / rho) + 1.5f / kb;
+    const float alpha = asin_upper(r / rho) + kArcSlackBins / kb;
     const int lo = (int)floorf((th - alpha) * kb), hi = (int)floorf((th + alpha) * kb);
     const int n = hi - lo + 1;
     if (n >= kAzBins) return;
@@ -210,7 +210,7 @@ __device__ __forceinline__ void cf_sweep(CfLds &L, const int *tg_c, const int *t
 
 // step `step`, outer iteration `outer` of every chain: kCfBlocks workgroups of 256 feature points per chain, decoded onto ONE XCD
 // per chain (blocks b and b + 8 share an XCD): the chain's index and tables are fetched into one L2 only.
-__global__ __launch_bounds__(kCfT) void k_corr_flat(BatchView b, OdomView o, int step, int outer, unsigned int *wl)
+__global__ __launch_bounds__(kCfT) void k_corr_flat(BatchView b, OdomView o, int step, int outer, unsigned int *wl, int defer_every)
 {
     __shared__ CfLds L;
     const int xcd = blockIdx.x & 7, u = blockIdx.x >> 3;
@@ -267,6 +267,7 @@ __global__ __launch_bounds__(kCfT) void k_corr_flat(BatchView b, OdomView o, int
     const unsigned char tag_cl = edge ? 0 : 0x80;
     bool alive = qi < nq && n_last > 0;       // still looking for its nearest point
     bool deferred = false;
+    if (defer_every > 0 && qi < nq && qi % defer_every == 0) { alive = false; deferred = true; }      // test hook: exercise the fall-back kernel
     float r = sd >= 0.f ? sqrtf(sd) * 1.0005f + 1e-3f : kCfR0;
     __syncthreads();
 
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(kCfT) void k_corr_flat(BatchView b, OdomView o, int
         L.whi[tid] = ra + 3 <= 65 ? L.fge[cl][ra + 3] : n_last;
     }
     // radii: the neighbouring lines right next to the nearest point; the ring gap of far ground points (rho^2 dtheta / h); 5 m
-    const float rad[3] = { 0.5f + 0.05f * rho, fminf(5.0f, 1.0f + 0.0045f * rho2), 5.0f };
+    const float rad[4] = { walk_radius(0, rho), walk_radius(1, rho), walk_radius(2, rho), walk_radius(3, rho) };
     int wpass = 0;
     unsigned long long same = thr, other = thr;
     for (int round = 0; round < 64; round++) {
@@ -347,8 +348,8 @@ __global__ __launch_bounds__(kCfT) void k_corr_flat(BatchView b, OdomView o, int
         __syncthreads();
         bool posted = false;
         if (walking) {
-            while (wpass > 0 && wpass < 3 && rad[wpass] <= rad[wpass - 1]) wpass++;
-            if (wpass >= 3) walking = false;
+            while (wpass > 0 && wpass < 4 && rad[wpass] <= rad[wpass - 1]) wpass++;
+            if (wpass >= 4) walking = false;
         }
         if (walking) {
             CfArc a;

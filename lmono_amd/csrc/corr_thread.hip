@@ -46,7 +46,7 @@ __device__ __forceinline__ bool ct_arc(float r, float rho, float th, CtArc &a)
     constexpr float kb = kAzBins / 6.28318531f;
     a.a0 = 0; a.a1 = kAzBins; a.w1 = 0; a.nb = kAzBins;
     if (!(rho > r * 1.002f)) return true;                 // the ball reaches the sensor axis: every azimuth
-    const float alpha = asin_upper(r / rho) + 1.5f / kb;
+    const float alpha = asin_upper(r / rho) + kArcSlackBins / kb;
     const int lo = (int)floorf((th - alpha) * kb), hi = (int)floorf((th + alpha) * kb);
     const int n = hi - lo + 1;
     if (n >= kAzBins) return true;
@@ -147,9 +147,9 @@ __device__ __forceinline__ bool thread_search(const CtLds &L, const int *tg, con
     WalkBest same = thr, other = thr;
     int spos = -1, opos = -1;
     // radii: the neighbouring lines right next to the nearest point; the ring gap of far ground points (rho^2 dtheta / h); 5 m
-    const float rad[3] = { 0.5f + 0.05f * rho, fminf(5.0f, 1.0f + 0.0045f * rho2), 5.0f };
+    const float rad[4] = { walk_radius(0, rho), walk_radius(1, rho), walk_radius(2, rho), walk_radius(3, rho) };
 #pragma unroll
-    for (int pass = 0; pass < 3; pass++) {
+    for (int pass = 0; pass < 4; pass++) {
         if (pass > 0 && rad[pass] <= rad[pass - 1]) continue;
         CtArc a;
         ct_arc(rad[pass], rho, th, a);

@@ -31,7 +31,7 @@ struct lmono_ctx {
     std::vector<EvSet> sets;   // one event set per scanreg/odometry call since the last lmono_timing_reset
     int n_sets = 0;
     hipEvent_t *ev = nullptr;  // events of the current call
-    int opt[LMONO_OPT_COUNT] = { 0 };   // LMONO_OPT_CORR_TILE: 0 = 32-lane groups (default, fastest measured), 1 = LDS sector tiles, 2 = thread per feature, 3 = flattened sweeps
+    int opt[LMONO_OPT_COUNT] = { 3, 0 };   // LMONO_OPT_CORR_TILE: 3 = flattened sweeps (default: as fast as 0 and needs no hash grid), 0 = 32-lane groups, 1 = LDS sector tiles, 2 = thread per feature
     unsigned long long *stats_d = nullptr;   // [0] feature points deferred by the tile search since the last lmono_timing_reset
 
     hipEvent_t *next_set()
@@ -57,6 +57,7 @@ struct lmono_scan_batch {
     int64_t total = 0;
     int max_pts = 0;
     bool registered = false;
+    bool grid_built = false;       // k_grid_build has run for this registration
     std::vector<int64_t> off_h;
     std::vector<void *> allocs;
     BatchView v{};
@@ -90,7 +91,7 @@ extern "C" lmono_ctx *lmono_create(int device)
     if (hipSetDevice(device) != hipSuccess) return nullptr;
     lmono_ctx *c = new lmono_ctx();
     c->device = device;
-    if (hipMalloc((void **)&c->stats_d, 128) != hipSuccess || hipMemset(c->stats_d, 0, 128) != hipSuccess) { delete c; return nullptr; }
+    if (hipMalloc((void **)&c->stats_d, 320) != hipSuccess || hipMemset(c->stats_d, 0, 320) != hipSuccess) { delete c; return nullptr; }
     // the selection kernel needs ~62 KB of dynamic LDS
     if (hipFuncSetAttribute((const void *)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kSelWaveLds) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_voxel<kVoxSmallSlots, kVoxSmallBits, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kVoxLdsSmall) != hipSuccess) { delete c; return nullptr; }
@@ -235,10 +236,10 @@ extern "C" int lmono_scanreg_batch(lmono_ctx *c, lmono_scan_batch *b, const floa
     if (total > b->pts_cap) { c->err = "batch: too many points"; return LMONO_ECAPACITY; }
     HIP_TRY(c, hipSetDevice(c->device));
     b->off_h.assign(offsets_h, offsets_h + n_scans + 1);
-    b->n_scans = n_scans; b->total = total; b->max_pts = (int)max_pts; b->registered = false;
+    b->n_scans = n_scans; b->total = total; b->max_pts = (int)max_pts; b->registered = false; b->grid_built = false;
     b->feat_h.clear();
     BatchView &v = b->v;
-    v.in = (const float4 *)xyzi_d; v.n_scans = n_scans; v.n_lines = n_lines; v.min_range = min_range;
+    v.in = (const float4 *)xyzi_d; v.n_scans = n_scans; v.n_lines = n_lines; v.min_range = min_range; v.has_grid = 0;
     hipStream_t st = c->stream;
     c->ev = c->next_set();
     if (!c->ev) { c->err = "hipEventCreate failed"; return LMONO_ENODEV; }
@@ -266,7 +267,12 @@ extern "C" int lmono_scanreg_batch(lmono_ctx *c, lmono_scan_batch *b, const floa
     HIP_TRY(c, hipEventRecord(c->ev[4], st));
     hipLaunchKernelGGL(k_compact, dim3(n_scans), dim3(256), 0, st, v);
     HIP_TRY(c, hipEventRecord(c->ev[5], st));
-    hipLaunchKernelGGL(k_grid_build, dim3(n_scans, 1 + kGridPar), dim3(1024), kGridLds, st, v);
+    // the hash grids serve the 32-lane-group search (LMONO_OPT_CORR_TILE 0) and the deferred lists of modes 1 and 2; the default
+    // (flattened sweeps) works on the line index alone, so the grids are built on demand (ensure_grid)
+    if (c->opt[LMONO_OPT_CORR_TILE] != 3) {
+        hipLaunchKernelGGL(k_grid_build, dim3(n_scans, 1 + kGridPar), dim3(1024), kGridLds, st, v);
+        b->grid_built = true; v.has_grid = 1;
+    }
     HIP_TRY(c, hipEventRecord(c->ev[6], st));
     hipLaunchKernelGGL(k_line_index, dim3(n_scans, 2), dim3(kLiT), kLiLds, st, v);
     HIP_TRY(c, hipEventRecord(c->ev[7], st));
@@ -280,7 +286,7 @@ extern "C" int lmono_timing_reset(lmono_ctx *c)
 {
     if (!c) return LMONO_EINVAL;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemset(c->stats_d, 0, 128));
+    HIP_TRY(c, hipMemset(c->stats_d, 0, 320));
     c->n_sets = 0;
     return LMONO_OK;
 }
@@ -312,10 +318,10 @@ extern "C" int lmono_timing_read(lmono_ctx *c, double *ms, int cap, int *n_scanr
         }
     }
     {
-        unsigned long long st[16] = { 0 };
-        HIP_TRY(c, hipMemcpy(st, c->stats_d, 128, hipMemcpyDeviceToHost));
+        unsigned long long st[40] = { 0 };
+        HIP_TRY(c, hipMemcpy(st, c->stats_d, 320, hipMemcpyDeviceToHost));
         sum[12] = (double)st[0];
-        for (int i = 1; i < 16 && 12 + i < cap; i++) ms[12 + i] = (double)st[i];     // diagnostic words (LMONO_TILE_PROF builds)
+        for (int i = 1; i < 40 && 12 + i < cap; i++) ms[12 + i] = (double)st[i];     // diagnostic words (LMONO_TILE_PROF builds)
     }
     for (int i = 0; i < cap && i < 13; i++) ms[i] = sum[i];
     if (n_scanreg_calls) *n_scanreg_calls = nr;
@@ -388,6 +394,17 @@ static int ensure_odom_ws(lmono_ctx *c, lmono_scan_batch *b, int n_chains)
     return LMONO_OK;
 }
 
+// hash grids of a registered batch, for the searches that use them
+static int ensure_grid(lmono_ctx *c, lmono_scan_batch *b)
+{
+    if (b->grid_built) return LMONO_OK;
+    hipLaunchKernelGGL(k_grid_build, dim3(b->n_scans, 1 + kGridPar), dim3(1024), kGridLds, c->stream, b->v);
+    int rc = check_launch(c, "k_grid_build");
+    if (rc) return rc;
+    b->grid_built = true; b->v.has_grid = 1;
+    return LMONO_OK;
+}
+
 static int odom_run(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, double *incr_d, double *poses_d, bool want_poses)
 {
     if (!c || !b || !b->registered || lead < 0) return LMONO_EINVAL;
@@ -415,6 +432,7 @@ static int odom_run(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, d
     const int ninit = n > n_chains ? n : n_chains;
     hipLaunchKernelGGL(k_odom_init, dim3((ninit + 255) / 256), dim3(256), 0, st, o);
     const int tile = c->opt[LMONO_OPT_CORR_TILE];
+    if (tile != 3) { rc = ensure_grid(c, b); if (rc) return rc; }
     if (tile) HIP_TRY(c, hipMemsetAsync(b->wl, 0, sizeof(unsigned int), st));
     EvSet &es = c->sets[c->n_sets - 1];
     auto kev = [&](int i) -> hipEvent_t {
@@ -427,7 +445,7 @@ static int odom_run(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, d
             hipEvent_t e0 = kev(ne), e1 = kev(ne + 1), e2 = kev(ne + 2);
             if (e0 && e1 && e2) (void)hipEventRecord(e0, st);
             if (tile == 3) {
-                hipLaunchKernelGGL(k_corr_flat, dim3(8 * ((n_chains + 7) / 8) * kCfBlocks), dim3(kCfT), 0, st, b->v, o, step, outer, b->wl);
+                hipLaunchKernelGGL(k_corr_flat, dim3(8 * ((n_chains + 7) / 8) * kCfBlocks), dim3(kCfT), 0, st, b->v, o, step, outer, b->wl, c->opt[LMONO_OPT_DEFER_EVERY]);
                 hipLaunchKernelGGL(k_correspond_list, dim3(kListGrid), dim3(256), 0, st, b->v, o, step, outer, (const unsigned int *)b->wl, c->stats_d);
             } else if (tile == 2) {
                 hipLaunchKernelGGL(k_corr_thread, dim3(8 * ((n_chains + 7) / 8) * kCtBlocks), dim3(kCtT), 0, st, b->v, o, step, outer, b->wl);
@@ -484,11 +502,12 @@ extern "C" int lmono_odom_correspond(lmono_ctx *c, lmono_scan_batch *b, int scan
     o.n_scans = b->n_scans; o.n_chains = 1; o.lead = 0; o.fixed_k = scan;
     o.state = b->xq; o.corr = b->corr_pair; o.incr = nullptr; o.lm_info = nullptr; o.crec = b->crec_pair; o.seed = nullptr;
     int rc;
+    if (c->opt[LMONO_OPT_CORR_TILE] != 3) { rc = ensure_grid(c, b); if (rc) return rc; }
     if (c->opt[LMONO_OPT_CORR_TILE]) {
         rc = ensure_odom_ws(c, b, 1);
         if (rc) return rc;
         HIP_TRY(c, hipMemsetAsync(b->wl, 0, sizeof(unsigned int), c->stream));
-        if (c->opt[LMONO_OPT_CORR_TILE] == 3) hipLaunchKernelGGL(k_corr_flat, dim3(8 * kCfBlocks), dim3(kCfT), 0, c->stream, b->v, o, 0, 0, b->wl);
+        if (c->opt[LMONO_OPT_CORR_TILE] == 3) hipLaunchKernelGGL(k_corr_flat, dim3(8 * kCfBlocks), dim3(kCfT), 0, c->stream, b->v, o, 0, 0, b->wl, c->opt[LMONO_OPT_DEFER_EVERY]);
         else if (c->opt[LMONO_OPT_CORR_TILE] == 2) hipLaunchKernelGGL(k_corr_thread, dim3(8 * kCtBlocks), dim3(kCtT), 0, c->stream, b->v, o, 0, 0, b->wl);
         else hipLaunchKernelGGL(k_corr_tile, dim3(8 * kTSect), dim3(kTT), kTileLds, c->stream, b->v, o, 0, 0, b->wl, c->stats_d);
         hipLaunchKernelGGL(k_correspond_list, dim3(kListGrid), dim3(256), 0, c->stream, b->v, o, 0, 0, (const unsigned int *)b->wl, c->stats_d);

@@ -322,6 +322,19 @@ __device__ __forceinline__ unsigned long long wave_nn(const GridRef &g, float qx
     return best;
 }
 
+// the same without a grid: every lane sweeps the whole cloud (only the generic path of flagged scans can get here, and only when the
+// grids were not built because the default search does not use them)
+__device__ __forceinline__ unsigned long long wave_nn_brute(const float4 *cloud, int n, float qx, float qy, float qz, int lane)
+{
+    unsigned long long best = ~0ull;
+    for (int i = lane; i < n; i += 64) {
+        const float4 p = cloud[i];
+        const unsigned long long cand = pack_fu(dist2f(p.x, p.y, p.z, qx, qy, qz), (unsigned int)i);
+        best = cand < best ? cand : best;
+    }
+    return wave_min_u64(best);
+}
+
 constexpr unsigned int kSeqBack = 1u << 24;   // backward candidates rank after every forward candidate
 
 // Wave-parallel restatement of the reference's two index walks around the nearest point `closest` of a feature
@@ -394,7 +407,7 @@ __device__ __forceinline__ int4 correspond_one(const BatchView &b, int k, int qi
     }
     int4 out = make_int4(-1, -1, -1, 0);
     if (n_last == 0) return out;
-    const unsigned long long nn = wave_nn(g, qx, qy, qz, lane);
+    const unsigned long long nn = b.has_grid ? wave_nn(g, qx, qy, qz, lane) : wave_nn_brute(cloud, n_last, qx, qy, qz, lane);
     if (nn == ~0ull) return out;
     const float d2 = __uint_as_float((unsigned int)(nn >> 32));
     if (!((double)d2 < 25.0)) return out;
@@ -531,6 +544,19 @@ __global__ __launch_bounds__(kLiT) void k_line_index(BatchView b)
             }
         }
     }
+}
+
+// Slack of an azimuth arc in bins.  A point within r of the feature differs from it by at most asin(r / rho) in azimuth; both bins come
+// from the same atan2f (error ~1e-6 rad = 6e-5 bins) and asin_upper bounds asin from above, so only float rounding needs cover.
+// (1.5 bins until round 2: that alone made every arc 3 bins = 2.8 deg wider than the ball it serves.)
+constexpr float kArcSlackBins = 0.05f;
+// Radii of the scan-line walk's passes: a minimum found strictly inside the ball of a pass is final (every point outside the arc is
+// farther).  0: the neighbouring lines right next to the nearest point (line spacing ~0.006-0.009 rho, voxel spacing 0.2 m);
+// 1: 0.5 m + 5 % of the range; 2: the ring gap of far ground points (rho^2 dtheta / h); 3: DISTANCE_SQ_THRESHOLD.  Non-increasing
+// entries are skipped by the callers.
+__device__ __forceinline__ float walk_radius(int pass, float rho)
+{
+    return pass == 0 ? 0.2f + 0.012f * rho : (pass == 1 ? 0.5f + 0.05f * rho : (pass == 2 ? fminf(5.0f, 1.0f + 0.0045f * rho * rho) : 5.0f));
 }
 
 // asin(x) <= x (1 + 0.5708 x^2) on [0, 1] (equality at 0 and 1): conservative arc half-width without libm
@@ -712,7 +738,7 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
             nb = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)((seed << 7) | (ln < 0 ? 0 : (ln > 65 ? 65 : ln)));
         }
     }
-    if (gl < 27) {
+    if (gl < 27 && b.has_grid) {       // without grids (not built: the default search does not use them) the arc sweep below finds the nearest point
         const int dx = gl % 3 - 1, dy = (gl / 3) % 3 - 1, dz = gl / 9 - 1;
         // the 2x2x2 block of cells whose faces are all >= half a cell away from the query
         const int sx = (fx - (float)cqx) >= 0.5f ? 1 : -1, sy = (fy - (float)cqy) >= 0.5f ? 1 : -1, sz = (fz - (float)cqz) >= 0.5f ? 1 : -1;
@@ -762,7 +788,8 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
     }
     {
         const float bound = kCell * 0.9999f;
-        const bool settled = best != ~0ull && __uint_as_float((unsigned int)(best >> 32)) <= bound * bound;
+        // without grids nothing has been swept yet: the arc sweep below does the whole search (its radius is the seed's distance, or 5 m)
+        const bool settled = b.has_grid && best != ~0ull && __uint_as_float((unsigned int)(best >> 32)) <= bound * bound;
         if (!settled) {
             // rare (~2 % of the features): the nearest point is not provably inside shell 1.  Instead of probing the
             // hash cells of shells 2..6 (up to ~150 rounds of dependent probes for a feature without any neighbour),
@@ -776,7 +803,7 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
             const float rr = bd < 25.0f ? sqrtf(bd) * 1.0005f + 1e-3f : 5.0f;
             int b_lo = 0, nbins = kAzBins;
             if (rho > rr * 1.002f) {
-                const float alpha = asin_upper(rr / rho) + 1.5f * (6.28318531f / kAzBins);
+                const float alpha = asin_upper(rr / rho) + kArcSlackBins * (6.28318531f / kAzBins);
                 const int lo = (int)floorf((th - alpha) * (kAzBins / 6.28318531f));
                 const int hi = (int)floorf((th + alpha) * (kAzBins / 6.28318531f));
                 if (hi - lo + 1 < kAzBins) { b_lo = ((lo % kAzBins) + kAzBins) % kAzBins; nbins = hi - lo + 1; }
@@ -803,9 +830,8 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
     closest_out = closest;
 
     // ---- scan-line walk over the (line, azimuth) index: lines ra-2 .. ra+2, index window (last_le[ra-3], first_ge[ra+3]).
-    // Two passes: first only the arc that can hold points within r1 = 0.5 m + 5 % of the range (the partners are
-    // nearly always on the neighbouring lines right next to the nearest point); minima found below r1 are final because
-    // every point outside the arc is farther than r1.  Otherwise the full 5 m arc is swept.
+    // Passes of growing radius (walk_radius): first only the arc that can hold the neighbouring lines' points right next to the
+    // nearest point; minima found strictly inside a pass's ball are final because every point outside the arc is farther.
     const int *fge = b.line_first_ge + (size_t)(l * 2 + cl) * 66;
     const int *lle = b.line_last_le + (size_t)(l * 2 + cl) * 66;
     const int *table = b.lb_start + (size_t)(l * 2 + cl) * (kLineKeys + 1);
@@ -815,11 +841,14 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
     const int w_hi = ra + 3 <= 65 ? fge[ra + 3] : n_last;
     const unsigned long long thr = pack_fu(25.0f, 0u);
     unsigned long long same = thr, other = thr;
-    const float r1 = 0.5f + 0.05f * rho;
-    for (int pass = (rho > 5.01f ? 0 : 1); pass < 2; pass++) {
+    float rprev = 0.f;
+    for (int pass = (rho > 5.01f ? 0 : 3); pass < 4; pass++) {
+        const float rw = walk_radius(pass, rho);
+        if (rw <= rprev) continue;                  // this pass would not widen the arc
+        rprev = rw;
         int b_lo = 0, nbins = kAzBins;
         if (rho > 5.01f) {
-            const float alpha = asin_upper((pass == 0 ? r1 : 5.0f) / rho) + 1.5f * (6.28318531f / kAzBins);
+            const float alpha = asin_upper(rw / rho) + kArcSlackBins * (6.28318531f / kAzBins);
             const int lo = (int)floorf((th - alpha) * (kAzBins / 6.28318531f));
             const int hi = (int)floorf((th + alpha) * (kAzBins / 6.28318531f));
             if (hi - lo + 1 < kAzBins) { b_lo = ((lo % kAzBins) + kAzBins) % kAzBins; nbins = hi - lo + 1; }
@@ -861,10 +890,9 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
         }
         same = group_min_u64(bs, gbase);
         other = group_min_u64(bo, gbase);
-        if (pass == 0) {
-            const unsigned long long lim = pack_fu(r1 * r1 * 0.998f, 0u);   // squared distance strictly inside the r1 ball
-            if (other < lim && (edge || same < lim)) break;
-        }
+        if (rw >= 5.0f) break;
+        const unsigned long long lim = pack_fu(rw * rw * 0.998f, 0u);   // squared distance strictly inside this pass's ball
+        if (other < lim && (edge || same < lim)) break;
     }
     const int i_other = other < thr ? seq_to_index((unsigned int)(other & 0xffffffffull), closest) : -1;
     if (edge) {

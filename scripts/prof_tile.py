@@ -34,7 +34,7 @@ batch.odometry_d(chains, lead, incr.data_ptr(), None)
 groups, _, _ = ctx.timing()
 d = ctx.diag
 wgs = max(d[0], 1)
-names = ["line geometry", "line prefix", "bucket table", "point copy", "feature binning", "search"]
+names = ["requests + geometry", "prefix + tables", "bucket table", "point copy", "feature binning", "search"]
 print("workgroups %d, features served per workgroup %.1f, deferred %d of %d launches-pairs %d" % (wgs, d[14] / wgs, groups["deferred_features"], d[14], groups["odometry_launch_pairs"]))
 tot = sum(d[1:7])
 for i, nm in enumerate(names):
@@ -43,4 +43,10 @@ print("  total %.0f cycles / workgroup" % (tot / wgs))
 reasons = ["?", "nn: seeded arc outside window", "nn: first arc outside window", "nn: grown arc outside window", "walk r1 outside", "walk r2 outside", "walk 5 m outside"]
 for i, nm in enumerate(reasons):
     print("  deferred %-32s %d" % (nm, d[7 + i]))
+for nm, o in (("edge", 15), ("plane", 21)):
+    nqd = max(d[o + 5], 1)
+    print("  %-5s features %d: NN passes %.2f, NN lines %.1f, NN candidates %.1f, walk passes %.2f, walk candidates %.1f (per feature)" %
+          (nm, d[o + 5], d[o + 0] / nqd, d[o + 4] / nqd, d[o + 1] / nqd, d[o + 2] / nqd, d[o + 3] / nqd))
+hist = d[27:37]
+print('  walk distance needed / r1 (quarters; last = no partner):', [round(float(x) / max(hist.sum(), 1), 3) for x in hist])
 print({k: round(v, 3) for k, v in groups.items()})

@@ -112,7 +112,7 @@ def test_tile_search_equals_global_search(oracle, gpu_ctx, full_seq):
         for k in (1, 2):
             for q, t in poses:
                 q = q / np.linalg.norm(q)
-                gpu_ctx.set_option(gpu_ctx.OPT_CORR_TILE, 0)
+                gpu_ctx.set_option(gpu_ctx.OPT_CORR_TILE, 3)
                 ref = batch.correspond(k, q, t)
                 for mode in (1, 2, 3):       # 1: LDS sector tiles, 2: thread per feature, 3: flattened sweeps (default)
                     gpu_ctx.set_option(gpu_ctx.OPT_CORR_TILE, mode)
@@ -121,14 +121,32 @@ def test_tile_search_equals_global_search(oracle, gpu_ctx, full_seq):
                     deferred = gpu_ctx.timing()[0]["deferred_features"]
                     print("scan %d t=%s mode %d: %d features, %d deferred to the list kernel" % (k, t, mode, len(ref), deferred))
                     assert np.array_equal(got, ref)
-        gpu_ctx.set_option(gpu_ctx.OPT_CORR_TILE, 0)
+        # a batch registered under the default mode has no hash grids; the deferred-list kernel then searches through the line index alone
+        gpu_ctx.set_option(gpu_ctx.OPT_CORR_TILE, 3)
         i0, p0 = batch.odometry(1, 0)
         for mode in (1, 2, 3):
             gpu_ctx.set_option(gpu_ctx.OPT_CORR_TILE, mode)
             i1, p1 = batch.odometry(1, 0)
             assert np.array_equal(i0, i1) and np.array_equal(p0, p1)
     finally:
-        gpu_ctx.set_option(gpu_ctx.OPT_CORR_TILE, 0)
+        gpu_ctx.set_option(gpu_ctx.OPT_CORR_TILE, 3)
+    # the fall-back of the default search on a batch WITHOUT hash grids (registered under mode 3): every 5th feature is forced through
+    # k_correspond_list, which then finds the nearest point by the arc sweep alone; same indices, same odometry
+    fresh = _register(gpu_ctx, xyzi, off)
+    try:
+        gpu_ctx.set_option(gpu_ctx.OPT_DEFER_EVERY, 5)
+        for q, t in poses[:3]:
+            q = q / np.linalg.norm(q)
+            gpu_ctx.timing_reset()
+            got = fresh.correspond(2, q, t)
+            assert gpu_ctx.timing()[0]["deferred_features"] >= len(got) // 5
+            gpu_ctx.set_option(gpu_ctx.OPT_DEFER_EVERY, 0)
+            assert np.array_equal(got, fresh.correspond(2, q, t))
+            gpu_ctx.set_option(gpu_ctx.OPT_DEFER_EVERY, 5)
+        i5, p5 = fresh.odometry(1, 0)
+        assert np.array_equal(i5, i0) and np.array_equal(p5, p0)
+    finally:
+        gpu_ctx.set_option(gpu_ctx.OPT_DEFER_EVERY, 0)
     # against the oracle as well (index-exact), at full resolution
     f = [oracle.scanreg(xyzi[off[s]:off[s + 1]]) for s in range(3)]
     q, t = poses[1]
