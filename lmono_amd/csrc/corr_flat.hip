@@ -28,19 +28,31 @@
 
 namespace lmono {
 
-constexpr int kCfT = 256;                     // threads per workgroup = feature points per workgroup
+#ifndef LMONO_CF_T
+#define LMONO_CF_T 128
+#endif
+constexpr int kCfT = LMONO_CF_T;               // threads per workgroup = feature points per workgroup
 constexpr int kCfBlocks = kMaxQueries / kCfT; // workgroups per chain
 static_assert(kMaxQueries % kCfT == 0, "feature capacity must be a multiple of the workgroup size");
-constexpr int kCfPer = 8;                     // runs per lane and round
+#ifndef LMONO_CF_PER
+#define LMONO_CF_PER 8
+#endif
+#ifndef LMONO_CF_U
+#define LMONO_CF_U 4
+#endif
+#ifndef LMONO_CF_WAVES
+#define LMONO_CF_WAVES 1
+#endif
+constexpr int kCfPer = LMONO_CF_PER;           // runs per lane and round
 constexpr int kCfPool = kCfT * kCfPer;        // run descriptors per round
 constexpr float kCfR0 = 0.3f;                 // first search radius of an unseeded feature (m)
-constexpr int kCfU = 8;                       // gathers in flight per lane
+constexpr int kCfU = LMONO_CF_U;               // gathers in flight per lane
 
 struct CfRun {
     unsigned int start;                       // request: table entry of the first bin; resolved: first point of the run
     unsigned int pre;                         // request: table entry behind the last bin; resolved: candidates before this run
     unsigned short len;
-    unsigned char owner;                      // feature (lane) the run belongs to
+    unsigned char owner;                      // feature (lane) the run belongs to (kCfT <= 256)
     unsigned char tag;                        // bit 7: surf cloud; low bits: scan line (nearest point) / line offset 0..4 (walk)
 };
 static_assert(sizeof(CfRun) == 12, "run descriptor layout");
@@ -96,8 +108,14 @@ __device__ __forceinline__ int cf_last_line(const float4 *el, float elo)
 
 // stages 1b and 2 of a round, executed by the whole workgroup.  kWalk = false: nearest point (minimum into L.best);
 // kWalk = true: scan-line walk (minima into L.same / L.other).
+#ifdef LMONO_TILE_PROF
+#define CF_STAMP(v) { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); (v) += t_ - cf_t; cf_t = t_; } }
+#else
+#define CF_STAMP(v)
+#endif
+
 template <bool kWalk>
-__device__ __forceinline__ void cf_sweep(CfLds &L, const int *tg_c, const int *tg_s, const float4 *pts_c, const float4 *pts_s)
+__device__ __forceinline__ void cf_sweep(CfLds &L, const int *tg_c, const int *tg_s, const float4 *pts_c, const float4 *pts_s, unsigned long long &cf_t, unsigned long long *cf_acc)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_pool = min(L.n_pool, kCfPool);
@@ -133,6 +151,7 @@ __device__ __forceinline__ void cf_sweep(CfLds &L, const int *tg_c, const int *t
         run += (int)(en[j] - st[j]);
     }
     __syncthreads();
+    CF_STAMP(cf_acc[1])
     // ---- 2: this lane's contiguous chunk of the candidate index space
     const int T = L.n_cand;
     if (T <= 0 || n_pool <= 0) return;
@@ -208,9 +227,10 @@ __device__ __forceinline__ void cf_sweep(CfLds &L, const int *tg_c, const int *t
     flush();
 }
 
-// step `step`, outer iteration `outer` of every chain: kCfBlocks workgroups of 256 feature points per chain, decoded onto ONE XCD
+// step `step`, outer iteration `outer` of every chain: kCfBlocks workgroups of kCfT feature points per chain (measured: 256 threads
+// 30.0 ms of correspondence search per bench step, 128 threads 26.6, 64 threads 31.4; 4 or 8 gathers in flight make no difference), decoded onto ONE XCD
 // per chain (blocks b and b + 8 share an XCD): the chain's index and tables are fetched into one L2 only.
-__global__ __launch_bounds__(kCfT) void k_corr_flat(BatchView b, OdomView o, int step, int outer, unsigned int *wl, int defer_every)
+__global__ __launch_bounds__(kCfT, LMONO_CF_WAVES) void k_corr_flat(BatchView b, OdomView o, int step, int outer, unsigned int *wl, int defer_every, unsigned long long *stats)
 {
     __shared__ CfLds L;
     const int xcd = blockIdx.x & 7, u = blockIdx.x >> 3;
@@ -224,8 +244,10 @@ __global__ __launch_bounds__(kCfT) void k_corr_flat(BatchView b, OdomView o, int
     const int l = k - 1;
     const int n_sharp = b.feat_n[k * 4 + 0];
     const int nq = n_sharp + b.feat_n[k * 4 + 2];
-    if (qb * kCfT >= nq) return;
-    const int qi = qb * kCfT + tid;
+    if (qb >= nq) return;
+    // the chain's features are dealt round-robin over its kCfBlocks workgroups: every workgroup gets the same share of edge and plane
+    // features (blocks of consecutive features gave workgroups of very different weight, and an almost empty last one)
+    const int qi = tid * kCfBlocks + qb;
     if (b.status[l] & (kStatusIrregularLines | kStatusDenseCell)) {
         if (qi < nq) cf_defer(wl, c, qi);       // rare: the whole scan pair goes to the generic search
         return;
@@ -240,8 +262,8 @@ __global__ __launch_bounds__(kCfT) void k_corr_flat(BatchView b, OdomView o, int
         fp = edge ? b.sharp[(size_t)k * kMaxSharp + qi] : b.flat[(size_t)k * kMaxFlat + (qi - n_sharp)];
         if (outer == 1 && seed_c) sidx = seed_c[qi];
     }
-    if (tid < 2 * 66) {
-        const int tc = tid / 66, v = tid % 66;
+    for (int xx = tid; xx < 2 * 66; xx += kCfT) {
+        const int tc = xx / 66, v = xx % 66;
         L.elev[tc][v] = b.lb_elev[(size_t)(l * 2 + tc) * 66 + v];
         L.fge[tc][v] = b.line_first_ge[(size_t)(l * 2 + tc) * 66 + v];
         L.lle[tc][v] = b.line_last_le[(size_t)(l * 2 + tc) * 66 + v];
@@ -265,12 +287,17 @@ __global__ __launch_bounds__(kCfT) void k_corr_flat(BatchView b, OdomView o, int
     const float th = atan2f(qy, qx) + 3.14159265f;
     const float eq = elev_of(qx, qy, qz);
     const unsigned char tag_cl = edge ? 0 : 0x80;
+    unsigned long long cf_t = 0, cf_acc[10] = { 0 };      // diagnostic build: cycles per stage (1a, 1b, 2, 3, setup, epilogue), rounds, candidates
+#ifdef LMONO_TILE_PROF
+    if (tid == 0) cf_t = __builtin_amdgcn_s_memtime();
+#endif
     bool alive = qi < nq && n_last > 0;       // still looking for its nearest point
     bool deferred = false;
     if (defer_every > 0 && qi < nq && qi % defer_every == 0) { alive = false; deferred = true; }      // test hook: exercise the fall-back kernel
     float r = sd >= 0.f ? sqrtf(sd) * 1.0005f + 1e-3f : kCfR0;
     __syncthreads();
 
+    CF_STAMP(cf_acc[4])
     // ================= nearest point =================
     for (int round = 0; round < 64; round++) {
         if (tid == 0) L.n_pool = 0;
@@ -310,8 +337,13 @@ __global__ __launch_bounds__(kCfT) void k_corr_flat(BatchView b, OdomView o, int
             }
         }
         __syncthreads();
-        cf_sweep<false>(L, tg_c, tg_s, pts_c, pts_s);
+        CF_STAMP(cf_acc[0])
+        cf_sweep<false>(L, tg_c, tg_s, pts_c, pts_s, cf_t, cf_acc);
         __syncthreads();
+        CF_STAMP(cf_acc[2])
+#ifdef LMONO_TILE_PROF
+        if (tid == 0) { cf_acc[6] += 1; cf_acc[8] += (unsigned long long)L.n_cand; }
+#endif
         // ---- 3: owners decide
         if (alive && posted) {
             const unsigned long long best = L.best[tid];
@@ -324,6 +356,7 @@ __global__ __launch_bounds__(kCfT) void k_corr_flat(BatchView b, OdomView o, int
                 else r = rr * 2.5f;
             }
         }
+        CF_STAMP(cf_acc[3])
         if (!__syncthreads_or(alive ? 1 : 0)) break;
     }
     if (alive) { alive = false; deferred = true; }            // round budget exhausted (never observed): list kernel
@@ -376,8 +409,13 @@ __global__ __launch_bounds__(kCfT) void k_corr_flat(BatchView b, OdomView o, int
                 for (; slot < kCfPool; slot++) { CfRun rq; rq.start = 0; rq.pre = 0; rq.len = 0; rq.owner = (unsigned char)tid; rq.tag = 0; L.pool[slot] = rq; }
         }
         __syncthreads();
-        cf_sweep<true>(L, tg_c, tg_s, pts_c, pts_s);
+        CF_STAMP(cf_acc[0])
+        cf_sweep<true>(L, tg_c, tg_s, pts_c, pts_s, cf_t, cf_acc);
         __syncthreads();
+        CF_STAMP(cf_acc[2])
+#ifdef LMONO_TILE_PROF
+        if (tid == 0) { cf_acc[7] += 1; cf_acc[9] += (unsigned long long)L.n_cand; }
+#endif
         if (walking && posted) {
             same = L.same[tid]; other = L.other[tid];
             if (rad[wpass] >= 5.0f) walking = false;
@@ -386,8 +424,12 @@ __global__ __launch_bounds__(kCfT) void k_corr_flat(BatchView b, OdomView o, int
                 if (other < lim && (edge || same < lim)) walking = false; else wpass++;
             }
         }
+        CF_STAMP(cf_acc[3])
         if (!__syncthreads_or(walking ? 1 : 0)) break;
     }
+#ifdef LMONO_TILE_PROF
+    if (tid == 0 && stats) { atomicAdd(&stats[1], 1ull); for (int i = 0; i < 10; i++) atomicAdd(&stats[2 + i], cf_acc[i]); }
+#endif
     if (qi >= nq) return;
     if (deferred || walking) { cf_defer(wl, c, qi); return; }
     int4 rres = make_int4(-1, -1, -1, 0);

@@ -104,6 +104,13 @@ extern "C" lmono_ctx *lmono_create(int device)
     if (hipFuncSetAttribute((const void *)k_ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BaLds)) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_marginalize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MargLds)) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_marg_second_new, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Marg2Lds)) != hipSuccess) { delete c; return nullptr; }
+#ifdef LMONO_TILE_PROF
+    {
+        int nb = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_corr_flat, kCfT, 0);
+        std::fprintf(stderr, "[lmono diag] k_corr_flat: %d workgroups of %d threads per CU by the occupancy query, static LDS %zu B\n", nb, kCfT, sizeof(CfLds));
+    }
+#endif
     return c;
 }
 
@@ -445,7 +452,7 @@ static int odom_run(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, d
             hipEvent_t e0 = kev(ne), e1 = kev(ne + 1), e2 = kev(ne + 2);
             if (e0 && e1 && e2) (void)hipEventRecord(e0, st);
             if (tile == 3) {
-                hipLaunchKernelGGL(k_corr_flat, dim3(8 * ((n_chains + 7) / 8) * kCfBlocks), dim3(kCfT), 0, st, b->v, o, step, outer, b->wl, c->opt[LMONO_OPT_DEFER_EVERY]);
+                hipLaunchKernelGGL(k_corr_flat, dim3(8 * ((n_chains + 7) / 8) * kCfBlocks), dim3(kCfT), 0, st, b->v, o, step, outer, b->wl, c->opt[LMONO_OPT_DEFER_EVERY], c->stats_d);
                 hipLaunchKernelGGL(k_correspond_list, dim3(kListGrid), dim3(256), 0, st, b->v, o, step, outer, (const unsigned int *)b->wl, c->stats_d);
             } else if (tile == 2) {
                 hipLaunchKernelGGL(k_corr_thread, dim3(8 * ((n_chains + 7) / 8) * kCtBlocks), dim3(kCtT), 0, st, b->v, o, step, outer, b->wl);
@@ -507,7 +514,7 @@ extern "C" int lmono_odom_correspond(lmono_ctx *c, lmono_scan_batch *b, int scan
         rc = ensure_odom_ws(c, b, 1);
         if (rc) return rc;
         HIP_TRY(c, hipMemsetAsync(b->wl, 0, sizeof(unsigned int), c->stream));
-        if (c->opt[LMONO_OPT_CORR_TILE] == 3) hipLaunchKernelGGL(k_corr_flat, dim3(8 * kCfBlocks), dim3(kCfT), 0, c->stream, b->v, o, 0, 0, b->wl, c->opt[LMONO_OPT_DEFER_EVERY]);
+        if (c->opt[LMONO_OPT_CORR_TILE] == 3) hipLaunchKernelGGL(k_corr_flat, dim3(8 * kCfBlocks), dim3(kCfT), 0, c->stream, b->v, o, 0, 0, b->wl, c->opt[LMONO_OPT_DEFER_EVERY], c->stats_d);
         else if (c->opt[LMONO_OPT_CORR_TILE] == 2) hipLaunchKernelGGL(k_corr_thread, dim3(8 * kCtBlocks), dim3(kCtT), 0, c->stream, b->v, o, 0, 0, b->wl);
         else hipLaunchKernelGGL(k_corr_tile, dim3(8 * kTSect), dim3(kTT), kTileLds, c->stream, b->v, o, 0, 0, b->wl, c->stats_d);
         hipLaunchKernelGGL(k_correspond_list, dim3(kListGrid), dim3(256), 0, c->stream, b->v, o, 0, 0, (const unsigned int *)b->wl, c->stats_d);
