@@ -576,8 +576,10 @@ def main():
         dom = max(ms_step, key=lambda k: ms_step[k])
         ms_launch = ms_step[dom] / launches_per_step[dom]
         # scans handled by one launch: every front-end kernel sees all local scans; a k_correspond launch advances
-        # every chain by half a scan (2 launches per scan-to-scan step)
-        scans_per_launch = n_local if dom != "k_correspond" else chains * 0.5
+        # every chain of ITS chain group by half a scan (2 launches per scan-to-scan step).  The timed launches are
+        # group 0's (they carry the events); the other G-1 groups run the same kernels beside them on their own streams
+        chain_groups = ctx.odom_chain_groups(chains)
+        scans_per_launch = n_local if dom != "k_correspond" else chains / chain_groups * 0.5
         ach = alg[dom] * scans_per_launch / (ms_launch * 1e-3) / 1e9
         # HBM bytes per launch of the dominant kernel from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE and
         # WRITE_SIZE in separate passes, gfx950 correction applied; scripts/profile_round.sh); null if not collected for it
@@ -586,11 +588,16 @@ def main():
             pmc_path = os.path.join(ROOT, "profiles", rnd, "pmc_%s.json" % dom)
             if os.path.exists(pmc_path) and chains == 256:
                 with open(pmc_path) as fh:
-                    traffic = json.load(fh)["hbm_bytes_per_launch"]
-                break
+                    pmc = json.load(fh)
+                if dom != "k_correspond" or pmc.get("chain_groups", 1) == chain_groups:     # counters of a launch of this size only
+                    traffic = pmc["hbm_bytes_per_launch"]
+                    break
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "ms_per_launch": round(ms_launch, 4), "launches_per_step": round(launches_per_step[dom], 1),
+                    # the G groups' launches run side by side, each on its share of the CUs: one launch's bytes over its own
+                    # duration (achieved, as rocprof sees it) understates the chip by about G; G launches' bytes over that duration:
+                    "chain_groups": chain_groups, "achieved_all_groups": round(ach * (chain_groups if dom == "k_correspond" else 1), 2),
                     "frontend_fused_frac": round(37 * N * n_local / (groups["frontend_total"] / max(n_reg, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                     "whole_step_frac": round((37 * N + 0.77e6) * n_local / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
                     "group_ms_per_step": {k: round(v / max(args.steps, 1), 3) for k, v in groups.items() if k != "odometry_launch_pairs"}}
@@ -601,7 +608,7 @@ def main():
             "vs_baseline": None, "dtype": "f32 features / f64 solve", "data": "synthetic",
             "config": {"workload": "KITTI-seq-00-shaped synthetic S1 HDL-64, laserOdometry-only (configs[1])",
                        "scans_total": n_total, "scans_per_gpu": n_own, "points_per_scan": round(N), "azimuth_steps": args.az,
-                       "odometry_chains_per_gpu": chains, "chain_lead_in": args.lead,
+                       "odometry_chains_per_gpu": chains, "chain_lead_in": args.lead, "odometry_chain_groups": ctx.odom_chain_groups(chains),
                        "parallelism": "scan-range shard x%d, one RCCL all-gather of 7 doubles per rank" % world,
                        "collective_ranks": world, "status_or": status_or, "gen_s": round(gen_s, 1), "h2d_s": round(h2d_s, 2),
                        "h2d_GBps": round(total_pts * 16 / h2d_s / 1e9, 1)},

@@ -47,8 +47,12 @@ int         lmono_synchronize(lmono_ctx *);
 /* test hook: n > 0 makes the default search (mode 3) hand every n-th feature point to its fall-back kernel (k_correspond_list), which
  * then runs without hash grids; results must not change.  0 = off.                                                              */
 #define LMONO_OPT_DEFER_EVERY 1
-#define LMONO_OPT_COUNT     2
+/* chain groups of lmono_odom_batch[_d]: G = 1 .. 8 groups of chains advance on G HIP streams side by side (results unchanged).
+ * Default 4 (one per hardware queue); reduced until every group holds at least 32 chains, so a 1-chain call is ungrouped.   */
+#define LMONO_OPT_ODOM_STREAMS 2
+#define LMONO_OPT_COUNT     3
 int         lmono_set_option(lmono_ctx *, int key, int value);
+int         lmono_get_option(lmono_ctx *, int key);                 /* the configured value, or LMONO_EINVAL */
 const char *lmono_version(void);
 
 /* ---- LiDAR front end: A-LOAM scanRegistration::laserCloudHandler ------------------------ *

@@ -9,7 +9,7 @@ MAX_QUERIES = 64 * 6 * 2 + 64 * 6 * 4
 
 # every symbol include/lmono_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "lmono_create", "lmono_destroy", "lmono_last_error", "lmono_set_stream", "lmono_set_option", "lmono_synchronize", "lmono_version",
+    "lmono_create", "lmono_destroy", "lmono_last_error", "lmono_set_stream", "lmono_set_option", "lmono_get_option", "lmono_synchronize", "lmono_version",
     "lmono_batch_create", "lmono_batch_destroy", "lmono_scanreg_batch", "lmono_scanreg_batch_h", "lmono_batch_counts", "lmono_batch_get_cloud",
     "lmono_batch_get_curvature", "lmono_odom_batch", "lmono_odom_batch_d", "lmono_odom_correspond", "lmono_timing_reset", "lmono_timing_read",
     "lmono_pose_prefix_d", "lmono_pose_rebase_d", "lmono_map_refine", "lmono_voxel_filter", "lmono_mapper_create", "lmono_mapper_destroy", "lmono_mapper_reset", "lmono_mapper_process", "lmono_mapper_process_batch", "lmono_mapper_cube",
@@ -50,6 +50,7 @@ def load_library():
     L.lmono_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     L.lmono_synchronize.argtypes = [C.c_void_p]
     L.lmono_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.lmono_get_option.argtypes = [C.c_void_p, C.c_int]
     L.lmono_batch_create.restype = C.c_void_p
     L.lmono_batch_create.argtypes = [C.c_void_p, C.c_int, C.c_int64]
     L.lmono_batch_destroy.argtypes = [C.c_void_p]
@@ -94,8 +95,10 @@ class Context:
         if not self.h:
             raise LmonoError("lmono_create(%d) failed: no usable HIP device" % device)
         self.device = device
-        if os.environ.get("LMONO_CORR_TILE") is not None:       # A/B switch for measurements (default: tile search on)
+        if os.environ.get("LMONO_CORR_TILE") is not None:       # A/B switches for measurements
             self.L.lmono_set_option(self.h, 0, int(os.environ["LMONO_CORR_TILE"]))
+        if os.environ.get("LMONO_ODOM_STREAMS") is not None:
+            self.L.lmono_set_option(self.h, 2, int(os.environ["LMONO_ODOM_STREAMS"]))
 
     def check(self, rc):
         if rc < 0:
@@ -113,9 +116,22 @@ class Context:
 
     OPT_CORR_TILE = 0
     OPT_DEFER_EVERY = 1
+    OPT_ODOM_STREAMS = 2
 
     def set_option(self, key, value):
         self.check(self.L.lmono_set_option(self.h, int(key), int(value)))
+
+    def get_option(self, key):
+        return self.check(self.L.lmono_get_option(self.h, int(key)))
+
+    def odom_chain_groups(self, n_chains):
+        """Chain groups (HIP streams) an odometry call with n_chains chains runs on: the rule of odom_run in lmono_hip.hip."""
+        g = max(1, min(8, self.get_option(self.OPT_ODOM_STREAMS)))
+        if self.get_option(self.OPT_CORR_TILE) != 3:
+            return 1
+        while g > 1 and n_chains // g < 32:
+            g -= 1
+        return g
 
     def timing_reset(self):
         self.check(self.L.lmono_timing_reset(self.h))

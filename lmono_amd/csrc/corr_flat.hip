@@ -234,9 +234,9 @@ __global__ __launch_bounds__(kCfT, LMONO_CF_WAVES) void k_corr_flat(BatchView b,
 {
     __shared__ CfLds L;
     const int xcd = blockIdx.x & 7, u = blockIdx.x >> 3;
-    const int c = (u / kCfBlocks) * 8 + xcd;
+    const int c = o.chain0 + (u / kCfBlocks) * 8 + xcd;
     const int qb = u % kCfBlocks;
-    if (c >= o.n_chains) return;
+    if (c >= o.chain1) return;
     int own;
     const int k = chain_scan(o, c, step, own);
     if (k < 0) return;

@@ -205,9 +205,9 @@ __global__ __launch_bounds__(kCtT) void k_corr_thread(BatchView b, OdomView o, i
 {
     __shared__ CtLds L;
     const int xcd = blockIdx.x & 7, u = blockIdx.x >> 3;
-    const int c = (u / kCtBlocks) * 8 + xcd;
+    const int c = o.chain0 + (u / kCtBlocks) * 8 + xcd;
     const int qb = u % kCtBlocks;
-    if (c >= o.n_chains) return;
+    if (c >= o.chain1) return;
     int own;
     const int k = chain_scan(o, c, step, own);
     if (k < 0) return;

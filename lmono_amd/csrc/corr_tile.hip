@@ -232,9 +232,9 @@ __global__ __launch_bounds__(kTT) void k_corr_tile(BatchView b, OdomView o, int 
     extern __shared__ __align__(16) unsigned char t_raw[];
     TileLds &L = *reinterpret_cast<TileLds *>(t_raw);
     const int xcd = blockIdx.x & 7, u = blockIdx.x >> 3;
-    const int c = (u / kTSect) * 8 + xcd;
+    const int c = o.chain0 + (u / kTSect) * 8 + xcd;
     const int t = u % kTSect;
-    if (c >= o.n_chains) return;
+    if (c >= o.chain1) return;
     int own;
     const int k = chain_scan(o, c, step, own);
     if (k < 0) return;

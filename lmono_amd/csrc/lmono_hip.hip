@@ -31,7 +31,9 @@ struct lmono_ctx {
     std::vector<EvSet> sets;   // one event set per scanreg/odometry call since the last lmono_timing_reset
     int n_sets = 0;
     hipEvent_t *ev = nullptr;  // events of the current call
-    int opt[LMONO_OPT_COUNT] = { 3, 0 };   // LMONO_OPT_CORR_TILE: 3 = flattened sweeps (default: as fast as 0 and needs no hash grid), 0 = 32-lane groups, 1 = LDS sector tiles, 2 = thread per feature
+    int opt[LMONO_OPT_COUNT] = { 3, 0, 4 };   // LMONO_OPT_CORR_TILE: 3 = flattened sweeps (default: as fast as 0 and needs no hash grid), 0 = 32-lane groups, 1 = LDS sector tiles, 2 = thread per feature
+    hipStream_t gstream[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };   // streams of the odometry's chain groups (LMONO_OPT_ODOM_STREAMS > 1)
+    hipEvent_t gev[9] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     unsigned long long *stats_d = nullptr;   // [0] feature points deferred by the tile search since the last lmono_timing_reset
 
     hipEvent_t *next_set()
@@ -119,6 +121,8 @@ extern "C" void lmono_destroy(lmono_ctx *c)
     if (!c) return;
     for (auto &s : c->sets) { for (auto &e : s.e) (void)hipEventDestroy(e); for (auto &e : s.kev) (void)hipEventDestroy(e); }
     if (c->stats_d) (void)hipFree(c->stats_d);
+    for (auto &s : c->gstream) if (s) (void)hipStreamDestroy(s);
+    for (auto &e : c->gev) if (e) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -136,6 +140,12 @@ extern "C" int lmono_set_option(lmono_ctx *c, int key, int value)
     if (!c || key < 0 || key >= LMONO_OPT_COUNT) return LMONO_EINVAL;
     c->opt[key] = value;
     return LMONO_OK;
+}
+
+extern "C" int lmono_get_option(lmono_ctx *c, int key)
+{
+    if (!c || key < 0 || key >= LMONO_OPT_COUNT) return LMONO_EINVAL;
+    return c->opt[key];
 }
 
 extern "C" int lmono_synchronize(lmono_ctx *c)
@@ -395,7 +405,7 @@ static int ensure_odom_ws(lmono_ctx *c, lmono_scan_batch *b, int n_chains)
     // (re)allocate; old buffers stay in allocs and are freed with the batch
     bool ok = dalloc(b, b->state, (size_t)n_chains * 8) && dalloc(b, b->corr, (size_t)n_chains * kMaxQueries * 4) &&
               dalloc(b, b->lm_info, (size_t)n_chains * 4) && dalloc(b, b->crec, (size_t)n_chains * kMaxQueries * 4) &&
-              dalloc(b, b->seed, (size_t)n_chains * kMaxQueries) && dalloc(b, b->wl, (size_t)n_chains * kMaxQueries + 1);
+              dalloc(b, b->seed, (size_t)n_chains * kMaxQueries) && dalloc(b, b->wl, 8 * ((size_t)n_chains * kMaxQueries + 1));
     if (!ok) { c->err = "odometry workspace: hipMalloc failed"; return LMONO_ENOMEM; }
     b->chains_cap = n_chains;
     return LMONO_OK;
@@ -422,7 +432,7 @@ static int odom_run(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, d
     int rc = ensure_odom_ws(c, b, n_chains);
     if (rc) return rc;
     OdomView o;
-    o.n_scans = n; o.n_chains = n_chains; o.lead = lead; o.fixed_k = -1;
+    o.n_scans = n; o.n_chains = n_chains; o.lead = lead; o.fixed_k = -1; o.chain0 = 0; o.chain1 = n_chains;
     o.state = b->state; o.corr = b->corr; o.incr = b->incr; o.lm_info = b->lm_info; o.crec = b->crec; o.seed = b->seed;
     int max_steps = 0;
     for (int ch = 0; ch < n_chains; ch++) {
@@ -447,26 +457,52 @@ static int odom_run(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, d
         return es.kev[i];
     };
     int ne = 0;
+    // Chain groups: with LMONO_OPT_ODOM_STREAMS = G > 1 the chains are cut into G groups, each advancing on its own stream, so that
+    // one group's solve (one workgroup per chain: a quarter of the CUs' wave slots at most) and the ragged tail of its search kernel
+    // run beside the other groups' searches.  Group 0 uses the context stream and carries the per-kernel events.
+    constexpr int kMinChainsPerGroup = 32;
+    int G = c->opt[LMONO_OPT_ODOM_STREAMS];
+    G = G < 1 ? 1 : (G > 8 ? 8 : G);
+    while (G > 1 && n_chains / G < kMinChainsPerGroup) G--;      // a group below 32 chains cannot fill its share of the CUs
+    if (tile != 3) G = 1;                       // only the default search is grouped
+    const size_t wl_stride = (size_t)n_chains * kMaxQueries + 1;
+    if (G > 1) {
+        for (int g = 1; g < G; g++) if (!c->gstream[g]) HIP_TRY(c, hipStreamCreateWithFlags(&c->gstream[g], hipStreamNonBlocking));
+        for (int g = 0; g <= G && g < 9; g++) if (!c->gev[g]) HIP_TRY(c, hipEventCreateWithFlags(&c->gev[g], hipEventDisableTiming));
+        for (int g = 1; g < G; g++) HIP_TRY(c, hipMemsetAsync(b->wl + g * wl_stride, 0, sizeof(unsigned int), st));
+        HIP_TRY(c, hipEventRecord(c->gev[0], st));
+        for (int g = 1; g < G; g++) HIP_TRY(c, hipStreamWaitEvent(c->gstream[g], c->gev[0], 0));
+    }
     for (int step = 0; step < max_steps; step++) {
         for (int outer = 0; outer < 2; outer++) {
-            hipEvent_t e0 = kev(ne), e1 = kev(ne + 1), e2 = kev(ne + 2);
-            if (e0 && e1 && e2) (void)hipEventRecord(e0, st);
-            if (tile == 3) {
-                hipLaunchKernelGGL(k_corr_flat, dim3(8 * ((n_chains + 7) / 8) * kCfBlocks), dim3(kCfT), 0, st, b->v, o, step, outer, b->wl, c->opt[LMONO_OPT_DEFER_EVERY], c->stats_d);
-                hipLaunchKernelGGL(k_correspond_list, dim3(kListGrid), dim3(256), 0, st, b->v, o, step, outer, (const unsigned int *)b->wl, c->stats_d);
-            } else if (tile == 2) {
-                hipLaunchKernelGGL(k_corr_thread, dim3(8 * ((n_chains + 7) / 8) * kCtBlocks), dim3(kCtT), 0, st, b->v, o, step, outer, b->wl);
-                hipLaunchKernelGGL(k_correspond_list, dim3(kListGrid), dim3(256), 0, st, b->v, o, step, outer, (const unsigned int *)b->wl, c->stats_d);
-            } else if (tile) {
-                hipLaunchKernelGGL(k_corr_tile, dim3(8 * ((n_chains + 7) / 8) * kTSect), dim3(kTT), kTileLds, st, b->v, o, step, outer, b->wl, c->stats_d);
-                hipLaunchKernelGGL(k_correspond_list, dim3(kListGrid), dim3(256), 0, st, b->v, o, step, outer, (const unsigned int *)b->wl, c->stats_d);
-            } else
-                hipLaunchKernelGGL(k_correspond, dim3(8 * ((n_chains + 7) / 8) * kCorrBlocks), dim3(256), 0, st, b->v, o, step, outer);
-            if (e0 && e1 && e2) (void)hipEventRecord(e1, st);
-            hipLaunchKernelGGL(k_lm_solve, dim3(n_chains), dim3(kLmT), kLmRecLds, st, b->v, o, step, outer, tile ? b->wl : (unsigned int *)nullptr);
-            if (e0 && e1 && e2) { (void)hipEventRecord(e2, st); ne += 3; }
+            for (int g = 0; g < G; g++) {
+                hipStream_t sg = g == 0 ? st : c->gstream[g];
+                OdomView og = o;
+                og.chain0 = (int)((long long)g * n_chains / G); og.chain1 = (int)((long long)(g + 1) * n_chains / G);
+                const int ng = og.chain1 - og.chain0;
+                unsigned int *wlg = b->wl + g * wl_stride;
+                hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+                if (g == 0) { e0 = kev(ne); e1 = kev(ne + 1); e2 = kev(ne + 2); }
+                if (e0 && e1 && e2) (void)hipEventRecord(e0, sg);
+                if (tile == 3) {
+                    hipLaunchKernelGGL(k_corr_flat, dim3(8 * ((ng + 7) / 8) * kCfBlocks), dim3(kCfT), 0, sg, b->v, og, step, outer, wlg, c->opt[LMONO_OPT_DEFER_EVERY], c->stats_d);
+                    hipLaunchKernelGGL(k_correspond_list, dim3(kListGrid), dim3(256), 0, sg, b->v, og, step, outer, (const unsigned int *)wlg, c->stats_d);
+                } else if (tile == 2) {
+                    hipLaunchKernelGGL(k_corr_thread, dim3(8 * ((ng + 7) / 8) * kCtBlocks), dim3(kCtT), 0, sg, b->v, og, step, outer, wlg);
+                    hipLaunchKernelGGL(k_correspond_list, dim3(kListGrid), dim3(256), 0, sg, b->v, og, step, outer, (const unsigned int *)wlg, c->stats_d);
+                } else if (tile) {
+                    hipLaunchKernelGGL(k_corr_tile, dim3(8 * ((ng + 7) / 8) * kTSect), dim3(kTT), kTileLds, sg, b->v, og, step, outer, wlg, c->stats_d);
+                    hipLaunchKernelGGL(k_correspond_list, dim3(kListGrid), dim3(256), 0, sg, b->v, og, step, outer, (const unsigned int *)wlg, c->stats_d);
+                } else
+                    hipLaunchKernelGGL(k_correspond, dim3(8 * ((ng + 7) / 8) * kCorrBlocks), dim3(256), 0, sg, b->v, og, step, outer);
+                if (e0 && e1 && e2) (void)hipEventRecord(e1, sg);
+                hipLaunchKernelGGL(k_lm_solve, dim3(ng), dim3(kLmT), kLmRecLds, sg, b->v, og, step, outer, tile ? wlg : (unsigned int *)nullptr);
+                if (e0 && e1 && e2) { (void)hipEventRecord(e2, sg); ne += 3; }
+            }
         }
     }
+    if (G > 1)
+        for (int g = 1; g < G; g++) { HIP_TRY(c, hipEventRecord(c->gev[g], c->gstream[g])); HIP_TRY(c, hipStreamWaitEvent(st, c->gev[g], 0)); }
     es.n_kev = ne;
     if (want_poses) hipLaunchKernelGGL(k_pose_prefix, dim3(1), dim3(64), 0, st, (const double *)b->incr, b->poses, 0, n);
     HIP_TRY(c, hipEventRecord(c->ev[9], st));
@@ -506,7 +542,7 @@ extern "C" int lmono_odom_correspond(lmono_ctx *c, lmono_scan_batch *b, int scan
     const int nq = fn[0] + fn[2];
     if (nq > cap) { c->err = "odom_correspond: output capacity too small"; return LMONO_ECAPACITY; }
     OdomView o;
-    o.n_scans = b->n_scans; o.n_chains = 1; o.lead = 0; o.fixed_k = scan;
+    o.n_scans = b->n_scans; o.n_chains = 1; o.lead = 0; o.fixed_k = scan; o.chain0 = 0; o.chain1 = 1;
     o.state = b->xq; o.corr = b->corr_pair; o.incr = nullptr; o.lm_info = nullptr; o.crec = b->crec_pair; o.seed = nullptr;
     int rc;
     if (c->opt[LMONO_OPT_CORR_TILE] != 3) { rc = ensure_grid(c, b); if (rc) return rc; }

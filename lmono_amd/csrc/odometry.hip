@@ -248,6 +248,7 @@ __global__ __launch_bounds__(1024) void k_grid_build(BatchView b)
 // ------------------------------------------------------------------------------------------------
 struct OdomView {
     int n_scans, n_chains, lead;
+    int chain0, chain1;   // the chains this launch advances: [chain0, chain1) (groups of chains run on their own streams)
     int fixed_k;          // >= 0: single-pair debug view, every chain works on this scan
     double *state;        // [n_chains][8]  q(xyzw), t, pad
     int *corr;            // [n_chains][kMaxQueries][4]
@@ -962,9 +963,9 @@ constexpr int kCorrBlocks = kMaxQueries / 8;
 __global__ __launch_bounds__(256, 8) void k_correspond(BatchView b, OdomView o, int step, int outer)
 {
     const int xcd = blockIdx.x & 7, u = blockIdx.x >> 3;
-    const int c = (u / kCorrBlocks) * 8 + xcd;
+    const int c = o.chain0 + (u / kCorrBlocks) * 8 + xcd;
     const int qblock = u % kCorrBlocks;
-    if (c >= o.n_chains) return;
+    if (c >= o.chain1) return;
     const int lane = threadIdx.x & 63;
     const int gl = threadIdx.x & (kGroup - 1), gbase = lane & ~(kGroup - 1);
     int own;
@@ -1237,8 +1238,8 @@ constexpr int kLmRecLds = 4 * kMaxQueries * 16;   // the chain's records in LDS
 // block-reduced sums; residual blocks come from the 64-B records written by k_correspond.
 __global__ __launch_bounds__(kLmT) void k_lm_solve(BatchView b, OdomView o, int step, int outer, unsigned int *wl_reset)
 {
-    const int c = blockIdx.x;
-    if (wl_reset && c == 0 && threadIdx.x == 0) wl_reset[0] = 0u;      // the work list of the next correspondence launch starts empty
+    const int c = o.chain0 + blockIdx.x;
+    if (wl_reset && blockIdx.x == 0 && threadIdx.x == 0) wl_reset[0] = 0u;      // the work list of the next correspondence launch starts empty
     int s;
     const int k = chain_scan(o, c, step, s);
     if (k < 0) return;

@@ -175,6 +175,20 @@ def test_odometry_chain_sharded_matches_oracle(oracle, gpu_ctx, small_seq):
     assert np.abs(poses - ref["poses"]).max() < 1e-8
 
 
+def test_chain_groups_on_streams_change_nothing(gpu_ctx, small_seq):
+    """LMONO_OPT_ODOM_STREAMS: the chains advance in 2 or 4 groups on their own HIP streams; same increments bit for bit."""
+    xyzi, off = small_seq["xyzi"], small_seq["off"]
+    batch = _register(gpu_ctx, xyzi, off)
+    ref_i, ref_p = batch.odometry(6, 2)
+    try:
+        for g in (2, 4):
+            gpu_ctx.set_option(gpu_ctx.OPT_ODOM_STREAMS, g)
+            i, p = batch.odometry(6, 2)
+            assert np.array_equal(i, ref_i) and np.array_equal(p, ref_p)
+    finally:
+        gpu_ctx.set_option(gpu_ctx.OPT_ODOM_STREAMS, 1)
+
+
 def test_odometry_full_resolution(oracle, gpu_ctx, full_seq):
     xyzi, off = full_seq["xyzi"], full_seq["off"]
     batch = _register(gpu_ctx, xyzi, off)
