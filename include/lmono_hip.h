@@ -159,6 +159,9 @@ typedef struct {
 } lmono_ba_desc;
 lmono_ba_batch *lmono_ba_batch_create(lmono_ctx *, const lmono_ba_desc *);
 void            lmono_ba_batch_destroy(lmono_ba_batch *);
+/* load another problem into an existing batch, reusing its device arrays (Estimator::optimization() of the next frame: the
+ * reference rebuilds its ceres::Problem per call, Estimator.cc:1017; here the frame loop allocates nothing in steady state)  */
+int             lmono_ba_batch_update(lmono_ctx *, lmono_ba_batch *, const lmono_ba_desc *);
 int lmono_ba_solve(lmono_ctx *, lmono_ba_batch *, int max_iterations);   /* asynchronous on the context stream    */
 int lmono_ba_batch_reset(lmono_ctx *, lmono_ba_batch *);                 /* restore the state given at creation   */
 /* poses_h [n][11][7], ex_h [n][7], inv_depth_h [F total], summary_h [n][6] = initial_cost, final_cost, iterations,

@@ -17,7 +17,7 @@ SYMBOLS = [
     "lmono_map_builder_cloud", "lmono_map_builder_map", "lmono_map_builder_clear",
     "lmono_pose_graph_create", "lmono_pose_graph_destroy", "lmono_pose_graph_reset", "lmono_pose_graph_info", "lmono_pose_graph_reduce_buffer", "lmono_pose_graph_set_reduce_buffer", "lmono_pose_graph_linearise",
     "lmono_pose_graph_step", "lmono_pose_graph_optimize", "lmono_pose_graph_result", "lmono_factor_eval", "lmono_factor_eval_d", "lmono_factor_eval_blocks", "lmono_factor_eval_blocks_d",
-    "lmono_triangulate", "lmono_outlier_scores", "lmono_shift_depth", "lmono_marginalize", "lmono_marg_evaluate", "lmono_marg_second_new", "lmono_ba_batch_create", "lmono_ba_batch_destroy", "lmono_ba_solve", "lmono_ba_batch_reset", "lmono_ba_batch_read",
+    "lmono_triangulate", "lmono_outlier_scores", "lmono_shift_depth", "lmono_marginalize", "lmono_marg_evaluate", "lmono_marg_second_new", "lmono_ba_batch_create", "lmono_ba_batch_update", "lmono_ba_batch_destroy", "lmono_ba_solve", "lmono_ba_batch_reset", "lmono_ba_batch_read",
 ]
 
 
@@ -72,6 +72,7 @@ def load_library():
     L.lmono_ba_batch_create.restype = C.c_void_p
     L.lmono_ba_batch_create.argtypes = [C.c_void_p, C.c_void_p]
     L.lmono_ba_batch_destroy.argtypes = [C.c_void_p]
+    L.lmono_ba_batch_update.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.lmono_ba_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.lmono_ba_batch_reset.argtypes = [C.c_void_p, C.c_void_p]
     L.lmono_ba_batch_read.argtypes = [C.c_void_p] * 6
@@ -387,6 +388,17 @@ class BaBatch:
 
     def __init__(self, ctx, windows):
         self.ctx = ctx
+        d = self._desc(windows)
+        self.h = ctx.L.lmono_ba_batch_create(ctx.h, C.byref(d))
+        if not self.h:
+            raise LmonoError("lmono_ba_batch_create failed: %s" % ctx.L.lmono_last_error(ctx.h).decode())
+
+    def update(self, windows):
+        """Load another set of windows into the same device arrays (lmono_ba_batch_update)."""
+        d = self._desc(windows)
+        self.ctx.check(self.ctx.L.lmono_ba_batch_update(self.ctx.h, self.h, C.byref(d)))
+
+    def _desc(self, windows):
         W = len(windows)
         self.W = W
         self.n_poses = [len(w["poses"]) for w in windows]
@@ -410,9 +422,7 @@ class BaBatch:
         d = BaDesc(W, *[k[n].ctypes.data for n in ("feat_off", "obs_off", "flags", "poses", "ex", "inv_depth", "obs_feat", "obs_i",
                                                     "obs_j", "obs_pts", "laser", "prior", "li", "mi", "pw")])
         self.feat_off = feat_off
-        self.h = ctx.L.lmono_ba_batch_create(ctx.h, C.byref(d))
-        if not self.h:
-            raise LmonoError("lmono_ba_batch_create failed: %s" % ctx.L.lmono_last_error(ctx.h).decode())
+        return d
 
     def solve(self, max_iter=30):
         self.ctx.check(self.ctx.L.lmono_ba_solve(self.ctx.h, self.h, max_iter))

@@ -232,7 +232,11 @@ extern "C" int lmono_scanreg_batch_h(lmono_ctx *c, lmono_scan_batch *b, const fl
         b->allocs.push_back(q);
         b->in_owned = (float *)q;
     }
-    if (total > 0) HIP_TRY(c, hipMemcpyAsync(b->in_owned, xyzi_h, (size_t)total * 16, hipMemcpyHostToDevice, c->stream));
+    if (total > 0) {
+        // staged: the caller's (pageable) buffer is free again when this returns
+        HIP_TRY(c, hipMemcpyAsync(b->in_owned, xyzi_h, (size_t)total * 16, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
     return lmono_scanreg_batch(c, b, b->in_owned, offsets_h, n_scans, n_lines, min_range);
 }
 
@@ -642,40 +646,60 @@ extern "C" int lmono_factor_eval(lmono_ctx *c, int kind, int count, const double
 // ---- BA window solve ---------------------------------------------------------------------------------------------
 struct lmono_ba_batch {
     lmono_ctx *ctx = nullptr;
-    std::vector<void *> allocs;
+    // device arrays in the fixed order ba_fill asks for them; lmono_ba_batch_update reuses every slot that is large enough
+    struct Slot { void *p; size_t bytes; };
+    std::vector<Slot> slots;
+    size_t next_slot = 0;
+    std::vector<void *> retired;          // outgrown slots, freed with the batch
     BaBatch v{};
     int n_windows = 0, total_feat = 0, total_obs = 0;
     double *poses0 = nullptr, *ex0 = nullptr, *invd0 = nullptr;   // initial state for lmono_ba_batch_reset
 };
 
+// next slot of the batch: at least `count` elements, filled from `src` (or zeroed: scratch starts zeroed).  Copies are ordered on
+// the context stream and waited for by ba_fill before the host staging vectors go away.
 template <typename T>
 static bool ba_upload(lmono_ba_batch *b, T *&dst, const T *src, size_t count)
 {
-    void *q = nullptr;
-    if (hipMalloc(&q, (count > 0 ? count : 1) * sizeof(T)) != hipSuccess) return false;
-    b->allocs.push_back(q);
-    dst = (T *)q;
-    if (src && count > 0 && hipMemcpy(q, src, count * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return false;
-    if (!src && hipMemset(q, 0, (count > 0 ? count : 1) * sizeof(T)) != hipSuccess) return false;   // scratch starts zeroed
+    const size_t bytes = (count > 0 ? count : 1) * sizeof(T);
+    hipStream_t st = b->ctx->stream;
+    if (b->next_slot == b->slots.size()) b->slots.push_back({ nullptr, 0 });
+    lmono_ba_batch::Slot &s = b->slots[b->next_slot++];
+    if (s.bytes < bytes) {
+        void *q = nullptr;
+        size_t cap = s.bytes ? s.bytes : bytes;
+        while (cap < bytes) cap <<= 1;
+        if (hipMalloc(&q, cap) != hipSuccess) return false;
+        if (s.p) b->retired.push_back(s.p);
+        s.p = q; s.bytes = cap;
+    }
+    dst = (T *)s.p;
+    if (src && count > 0 && hipMemcpyAsync(s.p, src, count * sizeof(T), hipMemcpyHostToDevice, st) != hipSuccess) return false;
+    if (!src && hipMemsetAsync(s.p, 0, bytes, st) != hipSuccess) return false;
     return true;
 }
 
 extern "C" void lmono_ba_batch_destroy(lmono_ba_batch *b)
 {
     if (!b) return;
-    for (void *p : b->allocs) (void)hipFree(p);
+    if (b->ctx) (void)hipStreamSynchronize(b->ctx->stream);
+    for (auto &s : b->slots) if (s.p) (void)hipFree(s.p);
+    for (void *p : b->retired) (void)hipFree(p);
     delete b;
 }
 
-extern "C" lmono_ba_batch *lmono_ba_batch_create(lmono_ctx *c, const lmono_ba_desc *d)
+// validate the descriptor, build the pair-ordered tables and (re)load every device array of the batch
+static int ba_fill(lmono_ctx *c, lmono_ba_batch *b, const lmono_ba_desc *d)
 {
-    if (!c || !d || d->n_windows <= 0 || !d->feat_off || !d->obs_off || !d->flags || !d->poses || !d->ex) return nullptr;
-    if (hipSetDevice(c->device) != hipSuccess) return nullptr;
+    if (!d || d->n_windows <= 0 || !d->feat_off || !d->obs_off || !d->flags || !d->poses || !d->ex) { c->err = "lmono_ba_batch: bad descriptor"; return LMONO_EINVAL; }
+    if (!d->laser_info || !d->mono_info || !d->prior_w || !d->laser_consts || !d->prior_T || (d->feat_off[d->n_windows] > 0 && !d->inv_depth)) { c->err = "lmono_ba_batch_create: a descriptor array is NULL"; return LMONO_EINVAL; }
+    if (d->obs_off[d->n_windows] > 0 && (!d->obs_feat || !d->obs_i || !d->obs_j || !d->obs_pts)) { c->err = "lmono_ba_batch_create: observation arrays are NULL"; return LMONO_EINVAL; }
+    HIP_TRY(c, hipSetDevice(c->device));
     const int W = d->n_windows;
     const int TF = d->feat_off[W], TO = d->obs_off[W];
     for (int w = 0; w < W; w++) {
-        if (d->feat_off[w + 1] - d->feat_off[w] > kBaMaxFeat) { c->err = "lmono_ba_batch_create: more than 448 features in a window"; return nullptr; }
-        if (d->flags[4 * w] < 2 || d->flags[4 * w] > kBaMaxPoses) { c->err = "lmono_ba_batch_create: n_poses must be 2..11"; return nullptr; }
+        if (d->feat_off[w + 1] - d->feat_off[w] > kBaMaxFeat) { c->err = "lmono_ba_batch_create: more than 448 features in a window"; return LMONO_ECAPACITY; }
+        if (d->flags[4 * w] < 2 || d->flags[4 * w] > kBaMaxPoses) { c->err = "lmono_ba_batch_create: n_poses must be 2..11"; return LMONO_EINVAL; }
     }
     // first observation of every feature: observations must be grouped by (window, feature) in ascending order
     std::vector<int> fo((size_t)TF + 1, 0);
@@ -688,11 +712,11 @@ extern "C" lmono_ba_batch *lmono_ba_batch_create(lmono_ctx *c, const lmono_ba_de
                 fo[f] = o;
                 while (o < oe && d->obs_feat[o] == f - f0) {
                     const int np = d->flags[4 * w];
-                    if (d->obs_i[o] < 0 || d->obs_i[o] >= np || d->obs_j[o] < 0 || d->obs_j[o] >= np || d->obs_i[o] == d->obs_j[o]) { c->err = "lmono_ba_batch_create: bad observation frame"; return nullptr; }
+                    if (d->obs_i[o] < 0 || d->obs_i[o] >= np || d->obs_j[o] < 0 || d->obs_j[o] >= np || d->obs_i[o] == d->obs_j[o]) { c->err = "lmono_ba_batch_create: bad observation frame"; return LMONO_EINVAL; }
                     o++;
                 }
             }
-            if (o != oe) { c->err = "lmono_ba_batch_create: observations are not grouped by feature"; return nullptr; }
+            if (o != oe) { c->err = "lmono_ba_batch_create: observations are not grouped by feature"; return LMONO_EINVAL; }
         }
         fo[TF] = TO;
     }
@@ -725,8 +749,8 @@ extern "C" lmono_ba_batch *lmono_ba_batch_create(lmono_ctx *c, const lmono_ba_de
         pair_slot.push_back((int)slot_info.size() - pobs_off[w]);   // n_pairs + 1 entries per window
     }
     pair_off[W] = (int)pair_ij.size(); pobs_off[W] = (int)slot_info.size();
-    lmono_ba_batch *b = new lmono_ba_batch();
     b->ctx = c; b->n_windows = W; b->total_feat = TF; b->total_obs = TO;
+    b->next_slot = 0;
     BaBatch &v = b->v;
     v.n_windows = W; v.max_iter = 30;
     double info[42];
@@ -747,16 +771,38 @@ extern "C" lmono_ba_batch *lmono_ba_batch_create(lmono_ctx *c, const lmono_ba_de
               ba_upload(b, v.hpd, (const double *)nullptr, (size_t)W * kBaMaxFeat * kBaPS) &&
               ba_upload(b, v.pairdat, (const double *)nullptr, pair_ij.size() * kBaPairRec) &&
               ba_upload(b, v.cand, (const double *)nullptr, (size_t)W * kBaMaxFeat) && ba_upload(b, v.summary, (const double *)nullptr, (size_t)W * 6);
-    if (!ok) { c->err = "lmono_ba_batch_create: device allocation / upload failed"; lmono_ba_batch_destroy(b); return nullptr; }
+    if (!ok) { (void)hipStreamSynchronize(c->stream); c->err = "lmono_ba_batch_create: device allocation / upload failed"; return LMONO_ENOMEM; }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));      // the staging vectors above end here
     v.feat_off = feat_off; v.obs_off = obs_off; v.flags = flags; v.feat_anchor = anch;
     v.pair_off = poff; v.pair_ij = pij; v.pobs_off = psoff; v.slot_info = sinfo_d; v.slot_pts = spts_d; v.pair_slot = pslot_d;
     v.laser_consts = laser; v.prior_T = prior; v.info = infod;
+    return LMONO_OK;
+}
+
+extern "C" lmono_ba_batch *lmono_ba_batch_create(lmono_ctx *c, const lmono_ba_desc *d)
+{
+    if (!c) return nullptr;
+    lmono_ba_batch *b = new lmono_ba_batch();
+    b->ctx = c;
+    if (ba_fill(c, b, d) != LMONO_OK) { lmono_ba_batch_destroy(b); return nullptr; }
     return b;
+}
+
+// Load another set of windows into an existing batch (the Estimator's next frame): device arrays are reused where they are large
+// enough, so a steady-state frame loop allocates nothing.  On error the batch holds no valid problem until the next update.
+extern "C" int lmono_ba_batch_update(lmono_ctx *c, lmono_ba_batch *b, const lmono_ba_desc *d)
+{
+    if (!c || !b || b->ctx != c) return LMONO_EINVAL;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));      // a solve of the previous problem may still read the arrays
+    const int rc = ba_fill(c, b, d);
+    if (rc != LMONO_OK) b->n_windows = 0;
+    return rc;
 }
 
 extern "C" int lmono_ba_solve(lmono_ctx *c, lmono_ba_batch *b, int max_iterations)
 {
     if (!c || !b || max_iterations < 0) return LMONO_EINVAL;
+    if (b->n_windows <= 0) { c->err = "lmono_ba_solve: the batch holds no problem (failed update)"; return LMONO_EINVAL; }
     HIP_TRY(c, hipSetDevice(c->device));
     b->v.max_iter = max_iterations;
     hipLaunchKernelGGL(k_ba_solve, dim3(b->n_windows), dim3(kBaT), sizeof(BaLds), c->stream, b->v);
@@ -1034,8 +1080,12 @@ extern "C" int lmono_map_refine(lmono_ctx *c, int n_streams,
     MapStream *st_d = db.up(st.data(), st.size(), ok);
     if (!ok) { c->err = "lmono_map_refine: device allocation / upload failed"; return LMONO_ENOMEM; }
     hipStream_t stream = c->stream;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
-    if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess || hipEventCreate(&ev2) != hipSuccess) { c->err = "hipEventCreate failed"; return LMONO_ENODEV; }
+    struct Events {             // destroyed on every return path
+        hipEvent_t e[3] = { nullptr, nullptr, nullptr };
+        ~Events() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); }
+    } evs;
+    for (hipEvent_t &x : evs.e) if (hipEventCreate(&x) != hipSuccess) { c->err = "hipEventCreate failed"; return LMONO_ENODEV; }
+    const hipEvent_t ev0 = evs.e[0], ev1 = evs.e[1], ev2 = evs.e[2];
     (void)hipEventRecord(ev0, stream);
     hipLaunchKernelGGL(k_cloud_grid, dim3(2 * n_streams), dim3(1024), 0, stream, (const CloudJob *)jobs_d);
     (void)hipEventRecord(ev1, stream);
@@ -1052,7 +1102,6 @@ extern "C" int lmono_map_refine(lmono_ctx *c, int n_streams,
     HIP_TRY(c, hipStreamSynchronize(stream));
     float ms_grid = 0.f, ms_opt = 0.f;
     (void)hipEventElapsedTime(&ms_grid, ev0, ev1); (void)hipEventElapsedTime(&ms_opt, ev1, ev2);
-    (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); (void)hipEventDestroy(ev2);
     HIP_TRY(c, hipMemcpy(xh.data(), x_d, sizeof(double) * xh.size(), hipMemcpyDeviceToHost));
     for (int s = 0; s < n_streams; s++) for (int k = 0; k < 7; k++) pose_qt[(size_t)s * 7 + k] = xh[(size_t)s * 8 + k];
     if (stats_h) {
@@ -1285,6 +1334,32 @@ void mp_shift(lmono_mapper *m, int axis, int dir)
                 else { for (int i = 0; i < n[axis] - 1; i++) arr[(size_t)(base + i * stride[axis])] = arr[(size_t)(base + (i + 1) * stride[axis])]; arr[(size_t)(base + (n[axis] - 1) * stride[axis])] = Seg(); }
             }
 }
+// Host state of a mapper that lmono_mapper_process_batch changes; put back when the call fails after changing it.  The device
+// side needs no undo: new points only ever land in free arena space (behind `bump`, or in the idle half during compaction).
+struct MapperUndo {
+    lmono_mapper *m;
+    std::vector<Seg> cube[2];
+    int cen[3], half[2];
+    int64_t bump[2];
+    double q[4], t[3];
+    explicit MapperUndo(lmono_mapper *mp) : m(mp)
+    {
+        for (int k = 0; k < 2; k++) { cube[k] = m->cube[(size_t)k]; half[k] = m->half[k]; bump[k] = m->bump[k]; }
+        for (int k = 0; k < 3; k++) { cen[k] = m->cen[k]; t[k] = m->t_wmap_wodom[k]; }
+        for (int k = 0; k < 4; k++) q[k] = m->q_wmap_wodom[k];
+    }
+    void restore()
+    {
+        for (int k = 0; k < 2; k++) { m->cube[(size_t)k].swap(cube[k]); m->half[k] = half[k]; m->bump[k] = bump[k]; }
+        for (int k = 0; k < 3; k++) { m->cen[k] = cen[k]; m->t_wmap_wodom[k] = t[k]; }
+        for (int k = 0; k < 4; k++) m->q_wmap_wodom[k] = q[k];
+    }
+};
+struct MapperUndoAll {
+    std::vector<MapperUndo> u;
+    bool committed = false;
+    ~MapperUndoAll() { if (!committed) for (MapperUndo &x : u) x.restore(); }
+};
 struct FrameState {            // one stream's frame
     double x[8];
     std::vector<int> valid;
@@ -1308,6 +1383,13 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
     JobScratch js{ ms[0] };
     std::vector<FrameState> F((size_t)n);
     int rc;
+    MapperUndoAll undo;                      // every error return below leaves the mappers as they were on entry
+    undo.u.reserve((size_t)n);
+    for (int s = 0; s < n; s++) undo.u.emplace_back(ms[s]);
+    // staging vectors of asynchronous copies live until the function returns (every path syncs the stream before that)
+    std::vector<double> xh_opt;
+    std::vector<int> pos_all;
+    std::vector<ScatterJob> sj;
     const bool prof = getenv("LMONO_MAP_PROF") != nullptr;
     auto tnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tp[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -1397,7 +1479,8 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
     {
         std::vector<int> act;
         for (int s = 0; s < n; s++) if (F[(size_t)s].solve) act.push_back(s);
-        std::vector<double> xh((size_t)8 * n);
+        std::vector<double> &xh = xh_opt;
+        xh.assign((size_t)8 * n, 0.0);
         for (int s = 0; s < n; s++) for (int k = 0; k < 8; k++) xh[(size_t)8 * s + k] = F[(size_t)s].x[k];
         int *statbuf = ms[0]->ibuf + 2 * n;      // [n][8] behind the n_stack pairs
         HIP_TRY(c, hipMemcpyAsync(ms[0]->xbuf, xh.data(), sizeof(double) * 8 * (size_t)n, hipMemcpyHostToDevice, st));
@@ -1533,8 +1616,8 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
         int max_n = 0;
         std::vector<size_t> at((size_t)2 * n);
         for (int s = 0; s < n; s++) for (int t = 0; t < 2; t++) { at[(size_t)2 * s + t] = total; total += (size_t)F[(size_t)s].n_stack[t]; max_n = std::max(max_n, F[(size_t)s].n_stack[t]); }
-        std::vector<int> pos_all(total + 1, -1);
-        std::vector<ScatterJob> sj((size_t)2 * n);
+        pos_all.assign(total + 1, -1);
+        sj.resize((size_t)2 * n);
         for (int s = 0; s < n; s++)
             for (int t = 0; t < 2; t++) {
                 const int ns = F[(size_t)s].n_stack[t];
@@ -1612,8 +1695,11 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
         ms[T.s]->cube[(size_t)T.t][(size_t)T.ind].n = nout_h[v];
     }
     tp[6] = tnow();
+    rc = check_launch(c, "mapper kernels");
+    if (rc) return rc;
+    undo.committed = true;
     if (prof) fprintf(stderr, "MAPPROF n=%d ms: host1 %.2f voxel %.2f gather %.2f optimise %.2f assign %.2f update %.2f\n", n, tp[1] - tp[0], tp[2] - tp[1], tp[3] - tp[2], tp[4] - tp[3], tp[5] - tp[4], tp[6] - tp[5]);
-    return check_launch(c, "mapper kernels");
+    return LMONO_OK;
 }
 
 extern "C" int lmono_mapper_process(lmono_ctx *c, lmono_mapper *m, lmono_scan_batch *b, int scan, const double q_wodom[4], const double t_wodom[3],

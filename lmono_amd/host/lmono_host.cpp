@@ -172,6 +172,7 @@ Estimator::Estimator(HipContext &hip, const Params &p) : hip_(hip), p_(p)
     std::memset(TLC, 0, sizeof(TLC)); TLC[0] = TLC[5] = TLC[10] = TLC[15] = 1.0;
     feature_manager.params = &p_; feature_manager.hip = &hip_;
 }
+Estimator::~Estimator() { if (ba_batch_) lmono_ba_batch_destroy(ba_batch_); }
 void Estimator::matrix2Double()
 {
     for (int i = 0; i <= WINDOW_SIZE; i++) { std::memcpy(para_pose[i], Ps[i].v, 24); R_to_q(Rs[i].m, para_pose[i] + 3); }
@@ -237,13 +238,18 @@ bool Estimator::optimization()
     d.n_windows = 1; d.feat_off = feat_off; d.obs_off = obs_off; d.flags = flags; d.poses = poses.data(); d.ex = para_ex[0];
     d.inv_depth = para_depth_inv.data(); d.obs_feat = obs_feat.data(); d.obs_i = obs_i.data(); d.obs_j = obs_j.data(); d.obs_pts = obs_pts.data();
     d.laser_consts = laser.data(); d.prior_T = TLC; d.laser_info = laser_info; d.mono_info = mono_info; d.prior_w = prior_w;
-    lmono_ba_batch *b = lmono_ba_batch_create(hip_.get(), &d);
-    if (!b) throw std::runtime_error(std::string("lmono_ba_batch_create: ") + lmono_last_error(hip_.get()));
+    // the reference builds a new ceres::Problem per call (Estimator.cc:1017); here the device arrays of the previous frame's
+    // problem are loaded again in place, so the steady-state frame loop does not allocate
+    if (!ba_batch_) {
+        ba_batch_ = lmono_ba_batch_create(hip_.get(), &d);
+        if (!ba_batch_) throw std::runtime_error(std::string("lmono_ba_batch_create: ") + lmono_last_error(hip_.get()));
+    } else
+        hip_.check(lmono_ba_batch_update(hip_.get(), ba_batch_, &d), "lmono_ba_batch_update");
+    lmono_ba_batch *b = ba_batch_;
     hip_.check(lmono_ba_solve(hip_.get(), b, p_.NUM_ITERATIONS), "lmono_ba_solve");
     double summary[6];
     std::vector<double> invd((size_t)std::max(F, 1));
     hip_.check(lmono_ba_batch_read(hip_.get(), b, poses.data(), para_ex[0], invd.data(), summary), "lmono_ba_batch_read");
-    lmono_ba_batch_destroy(b);
     for (int i = 0; i <= WINDOW_SIZE; i++) std::memcpy(para_pose[i], &poses[7 * i], 56);
     if (use_mono) para_depth_inv.assign(invd.begin(), invd.begin() + F);
     initial_cost = summary[0]; final_cost = summary[1]; iterations = (int)summary[2]; termination = (int)summary[3];

@@ -88,6 +88,9 @@ class Estimator {
 public:
     enum MarginalizationFlag { MARGIN_OLD = 0, MARGIN_SECOND_NEW = 1 };
     Estimator(HipContext &hip, const Params &p);
+    ~Estimator();
+    Estimator(const Estimator &) = delete;
+    Estimator &operator=(const Estimator &) = delete;
 
     // state, same names as Estimator.h:240-272
     Mat3 Rs[WINDOW_SIZE + 1];
@@ -143,6 +146,7 @@ public:
 
 private:
     HipContext &hip_;
+    lmono_ba_batch *ba_batch_ = nullptr;       // the window problem's device arrays, kept from frame to frame
     Params p_;
 };
 

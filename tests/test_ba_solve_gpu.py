@@ -58,3 +58,28 @@ def test_large_batch_cost_decreases_everywhere(gpu_ctx):
     b, (poses, ex, invd, sm) = _solve_gpu(gpu_ctx, windows)
     assert (sm[:, 1] < 1e-3 * sm[:, 0]).all() and (sm[:, 3] <= 1).all()
     assert np.abs(np.linalg.norm(poses[:, :, 3:], axis=2) - 1).max() < 1e-12
+
+
+def test_update_reuses_the_batch_and_changes_nothing(oracle, gpu_ctx):
+    """lmono_ba_batch_update: the next frame's problem loaded into the previous frame's device arrays (smaller, then larger than
+    what the arrays were created for, then a different number of windows) solves exactly like a freshly created batch."""
+    import lmono_amd
+    small = [K.make_window(21, n_landmarks=400)]
+    large = [K.make_window(22, n_landmarks=2500)]
+    two = [K.make_window(23), K.make_window(24, n_frames=6)]
+    b = lmono_amd.BaBatch(gpu_ctx, [K.make_window(20)])
+    b.solve(30)
+    b.read()
+    for windows in (small, large, two, small):
+        b.update(windows)
+        b.solve(30)
+        got = b.read()
+        _, want = _solve_gpu(gpu_ctx, windows)
+        assert (got[3][:, 0] == want[3][:, 0]).all()                       # initial cost: no atomics yet, bit-equal
+        assert (got[3][:, 2:4] == want[3][:, 2:4]).all()                   # iterations, termination
+        assert np.abs(got[3][:, 1] - want[3][:, 1]).max() <= 1e-6 * want[3][:, 1].max() + 1e-12
+        for k, w in enumerate(windows):
+            n = len(w["poses"])
+            R1, P1 = oracle.ba_reanchor(got[0][k, :n], w["gt_Rs"][0], w["gt_Ps"][0])
+            R2, P2 = oracle.ba_reanchor(want[0][k, :n], w["gt_Rs"][0], w["gt_Ps"][0])
+            assert np.abs(P1 - P2).max() < 1e-7 and np.abs(R1 - R2).max() < 1e-8
