@@ -75,7 +75,7 @@ def test_update_reuses_the_batch_and_changes_nothing(oracle, gpu_ctx):
         b.solve(30)
         got = b.read()
         _, want = _solve_gpu(gpu_ctx, windows)
-        assert (got[3][:, 0] == want[3][:, 0]).all()                       # initial cost: no atomics yet, bit-equal
+        assert np.abs(got[3][:, 0] - want[3][:, 0]).max() <= 1e-12 * want[3][:, 0].max()      # initial cost (summed by atomics)
         assert (got[3][:, 2:4] == want[3][:, 2:4]).all()                   # iterations, termination
         assert np.abs(got[3][:, 1] - want[3][:, 1]).max() <= 1e-6 * want[3][:, 1].max() + 1e-12
         for k, w in enumerate(windows):

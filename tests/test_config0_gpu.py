@@ -84,7 +84,8 @@ def test_101_scans_through_both_halves(oracle, gpu_ctx, tmp_path):
         assert (int(row[1]), int(row[2]), int(row[3])) == (r[0], r[1], r[2]) and (int(row[7]), int(row[8])) == (r[6], r[7]), "frame %d" % k
     # the fused trajectory (camera-aligned Estimator world) follows the ground truth
     fused_err = np.linalg.norm(odo_e[:, 1:4] - st["gt_P"][10:], axis=1)
-    assert fused_err.max() < 1.0
+    fused_ref = np.linalg.norm(ref_e[:, 1:4] - st["gt_P"][10:], axis=1)
+    assert fused_err.max() < 2.0 and abs(fused_err.max() - fused_ref.max()) < 0.1        # as far from the truth as the CPU path is
     # trajectory of record in the reference's file format (Estimator.cc:642-644)
     txt = np.loadtxt(str(tmp_path / "new_odometry.txt"))
     assert txt.shape == (n - 10, 8)

@@ -49,7 +49,8 @@ def test_120_frames_match_the_oracle(oracle, tmp_path):
     assert np.array_equal(odo[:, 0], ref[:, 0])
     assert np.abs(odo[:, 1:4] - ref[:, 1:4]).max() < 1e-6
     assert np.abs(odo[:, 4:] - ref[:, 4:]).max() < 1e-7
-    assert np.abs(ext - est.TLC).max() < 1e-7             # the refined extrinsic (ESTIMATE_LASER = 1)
+    # the refined extrinsic (ESTIMATE_LASER = 1) after 110 chained solves: SURVEY 8c's 1e-6 m / 1e-7 rad
+    assert np.abs(ext[:3, :3] - est.TLC[:3, :3]).max() < 1e-7 and np.abs(ext[:3, 3] - est.TLC[:3, 3]).max() < 1e-6
     # both marginalisation branches and both loop events were exercised
     assert log[-1][6] > 50 and log[-1][7] >= 3
     print("120-frame replay: %.2f ms per INITED frame on the GPU path, max |dP| vs oracle %.2e" % (ms, np.abs(odo[:, 1:4] - ref[:, 1:4]).max()))
