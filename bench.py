@@ -410,6 +410,8 @@ def main():
                          "over the ranks (BASELINE configs[3]: seq 00 sharded across 8)")
     ap.add_argument("--chains", type=int, default=256, help="concurrent odometry chains per GPU (strong scaling: in total)")
     ap.add_argument("--lead", type=int, default=7, help="lead-in scans of a chain that does not start at scan 0")
+    ap.add_argument("--lead-full", type=int, default=2,
+                    help="lead-in scan pairs of a chain (the last ones) that use all feature points; the earlier ones a quarter (-1: all use all)")
     ap.add_argument("--az", type=int, default=2000, help="azimuth steps per ring (2000 = HDL-64 at 10 Hz)")
     ap.add_argument("--cpu-sample", type=int, default=384, help="scans of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (sequential run, BA secondary)")
@@ -470,6 +472,8 @@ def main():
     total_pts = int(off[-1])
 
     ctx = lmono_amd.Context(local_rank)
+    if os.environ.get("LMONO_LEAD_FULL") is None:
+        ctx.set_option(ctx.OPT_LEAD_FULL, args.lead_full)
     xyzi_t = torch.from_numpy(xyzi)
     t0 = time.time()
     xyzi_d = xyzi_t.to(dev)
@@ -608,7 +612,7 @@ def main():
             "vs_baseline": None, "dtype": "f32 features / f64 solve", "data": "synthetic",
             "config": {"workload": "KITTI-seq-00-shaped synthetic S1 HDL-64, laserOdometry-only (configs[1])",
                        "scans_total": n_total, "scans_per_gpu": n_own, "points_per_scan": round(N), "azimuth_steps": args.az,
-                       "odometry_chains_per_gpu": chains, "chain_lead_in": args.lead, "odometry_chain_groups": ctx.odom_chain_groups(chains),
+                       "odometry_chains_per_gpu": chains, "chain_lead_in": args.lead, "lead_in_full_pairs": ctx.get_option(ctx.OPT_LEAD_FULL), "odometry_chain_groups": ctx.odom_chain_groups(chains),
                        "parallelism": "scan-range shard x%d, one RCCL all-gather of 7 doubles per rank" % world,
                        "collective_ranks": world, "status_or": status_or, "gen_s": round(gen_s, 1), "h2d_s": round(h2d_s, 2),
                        "h2d_GBps": round(total_pts * 16 / h2d_s / 1e9, 1)},

@@ -50,7 +50,11 @@ int         lmono_synchronize(lmono_ctx *);
 /* chain groups of lmono_odom_batch[_d]: G = 1 .. 8 groups of chains advance on G HIP streams side by side (results unchanged).
  * Default 4 (one per hardware queue); reduced until every group holds at least 32 chains, so a 1-chain call is ungrouped.   */
 #define LMONO_OPT_ODOM_STREAMS 2
-#define LMONO_OPT_COUNT     3
+/* lead-in of lmono_odom_batch[_d]'s chains: >= 0 = only the last N lead-in scan pairs of a chain use all feature points, the earlier
+ * ones a quarter of them (a lead-in pair only produces the next pair's warm start); -1 (default) = every pair uses all of them.
+ * An accuracy / speed knob like n_chains and lead: n_chains = 1 is unaffected.                                                  */
+#define LMONO_OPT_LEAD_FULL 3
+#define LMONO_OPT_COUNT     4
 int         lmono_set_option(lmono_ctx *, int key, int value);
 int         lmono_get_option(lmono_ctx *, int key);                 /* the configured value, or LMONO_EINVAL */
 const char *lmono_version(void);

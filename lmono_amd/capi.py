@@ -98,6 +98,8 @@ class Context:
         self.device = device
         if os.environ.get("LMONO_CORR_TILE") is not None:       # A/B switches for measurements
             self.L.lmono_set_option(self.h, 0, int(os.environ["LMONO_CORR_TILE"]))
+        if os.environ.get("LMONO_LEAD_FULL") is not None:
+            self.L.lmono_set_option(self.h, 3, int(os.environ["LMONO_LEAD_FULL"]))
         if os.environ.get("LMONO_ODOM_STREAMS") is not None:
             self.L.lmono_set_option(self.h, 2, int(os.environ["LMONO_ODOM_STREAMS"]))
 
@@ -118,6 +120,7 @@ class Context:
     OPT_CORR_TILE = 0
     OPT_DEFER_EVERY = 1
     OPT_ODOM_STREAMS = 2
+    OPT_LEAD_FULL = 3
 
     def set_option(self, key, value):
         self.check(self.L.lmono_set_option(self.h, int(key), int(value)))

@@ -34,6 +34,7 @@ namespace lmono {
 constexpr int kCfT = LMONO_CF_T;               // threads per workgroup = feature points per workgroup
 constexpr int kCfBlocks = kMaxQueries / kCfT; // workgroups per chain
 static_assert(kMaxQueries % kCfT == 0, "feature capacity must be a multiple of the workgroup size");
+static_assert(kCfBlocks == kThinBlocks, "k_lm_solve skips the records of the workgroups a thinned lead-in pair does not run");
 #ifndef LMONO_CF_PER
 #define LMONO_CF_PER 8
 #endif
@@ -240,6 +241,7 @@ __global__ __launch_bounds__(kCfT, LMONO_CF_WAVES) void k_corr_flat(BatchView b,
     int own;
     const int k = chain_scan(o, c, step, own);
     if (k < 0) return;
+    if (lead_in_thinned(o, k, own) && qb % kThinStride != 0) return;      // early lead-in pair: every kThinStride-th share of the features
     const int tid = threadIdx.x;
     const int l = k - 1;
     const int n_sharp = b.feat_n[k * 4 + 0];

@@ -31,7 +31,7 @@ struct lmono_ctx {
     std::vector<EvSet> sets;   // one event set per scanreg/odometry call since the last lmono_timing_reset
     int n_sets = 0;
     hipEvent_t *ev = nullptr;  // events of the current call
-    int opt[LMONO_OPT_COUNT] = { 3, 0, 4 };   // LMONO_OPT_CORR_TILE: 3 = flattened sweeps (default: as fast as 0 and needs no hash grid), 0 = 32-lane groups, 1 = LDS sector tiles, 2 = thread per feature
+    int opt[LMONO_OPT_COUNT] = { 3, 0, 4, -1 };   // LMONO_OPT_CORR_TILE: 3 = flattened sweeps (default: as fast as 0 and needs no hash grid), 0 = 32-lane groups, 1 = LDS sector tiles, 2 = thread per feature
     hipStream_t gstream[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };   // streams of the odometry's chain groups (LMONO_OPT_ODOM_STREAMS > 1)
     hipEvent_t gev[9] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     unsigned long long *stats_d = nullptr;   // [0] feature points deferred by the tile search since the last lmono_timing_reset
@@ -437,6 +437,7 @@ static int odom_run(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, d
     if (rc) return rc;
     OdomView o;
     o.n_scans = n; o.n_chains = n_chains; o.lead = lead; o.fixed_k = -1; o.chain0 = 0; o.chain1 = n_chains;
+    o.lead_full = c->opt[LMONO_OPT_CORR_TILE] == 3 ? c->opt[LMONO_OPT_LEAD_FULL] : -1;     // only the default search thins lead-in pairs
     o.state = b->state; o.corr = b->corr; o.incr = b->incr; o.lm_info = b->lm_info; o.crec = b->crec; o.seed = b->seed;
     int max_steps = 0;
     for (int ch = 0; ch < n_chains; ch++) {
@@ -463,7 +464,10 @@ static int odom_run(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, d
     int ne = 0;
     // Chain groups: with LMONO_OPT_ODOM_STREAMS = G > 1 the chains are cut into G groups, each advancing on its own stream, so that
     // one group's solve (one workgroup per chain: a quarter of the CUs' wave slots at most) and the ragged tail of its search kernel
-    // run beside the other groups' searches.  Group 0 uses the context stream and carries the per-kernel events.
+    // run beside the other groups' searches.  Group 0 uses the context stream and carries the per-kernel events.  The runtime maps
+    // streams onto 4 hardware queues (GPU_MAX_HW_QUEUES), the null stream on one of its own: the default context (null stream + 3
+    // group streams) gets 4 distinct queues.  With a caller-created context stream, or with all 4 groups on created streams, two
+    // groups share a queue and serialise (measured 64-70 instead of 51 ms per step): export GPU_MAX_HW_QUEUES=8 in that case.
     constexpr int kMinChainsPerGroup = 32;
     int G = c->opt[LMONO_OPT_ODOM_STREAMS];
     G = G < 1 ? 1 : (G > 8 ? 8 : G);
@@ -546,7 +550,7 @@ extern "C" int lmono_odom_correspond(lmono_ctx *c, lmono_scan_batch *b, int scan
     const int nq = fn[0] + fn[2];
     if (nq > cap) { c->err = "odom_correspond: output capacity too small"; return LMONO_ECAPACITY; }
     OdomView o;
-    o.n_scans = b->n_scans; o.n_chains = 1; o.lead = 0; o.fixed_k = scan; o.chain0 = 0; o.chain1 = 1;
+    o.n_scans = b->n_scans; o.n_chains = 1; o.lead = 0; o.fixed_k = scan; o.chain0 = 0; o.chain1 = 1; o.lead_full = -1;
     o.state = b->xq; o.corr = b->corr_pair; o.incr = nullptr; o.lm_info = nullptr; o.crec = b->crec_pair; o.seed = nullptr;
     int rc;
     if (c->opt[LMONO_OPT_CORR_TILE] != 3) { rc = ensure_grid(c, b); if (rc) return rc; }

@@ -250,6 +250,8 @@ struct OdomView {
     int n_scans, n_chains, lead;
     int chain0, chain1;   // the chains this launch advances: [chain0, chain1) (groups of chains run on their own streams)
     int fixed_k;          // >= 0: single-pair debug view, every chain works on this scan
+    int lead_full;        // >= 0: only the last lead_full lead-in scan pairs of a chain use all feature points, the earlier ones every
+                          // kThinStride-th workgroup's share (their result is only the next pair's warm start); -1: all pairs use all
     double *state;        // [n_chains][8]  q(xyzw), t, pad
     int *corr;            // [n_chains][kMaxQueries][4]
     float4 *crec;         // [n_chains][kMaxQueries][4] residual-block records: (cp, kind), a, b, c
@@ -425,6 +427,14 @@ __device__ __forceinline__ int4 correspond_one(const BatchView &b, int k, int qi
     const int i_same = same < thr ? seq_to_index((unsigned int)(same & 0xffffffffull), closest) : -1;
     if (i_same >= 0 && i_other >= 0) out = make_int4(closest, i_same, i_other, 2);
     return out;
+}
+
+constexpr int kThinStride = 4;
+
+// lead-in scan pair k of a chain owning scans from own_begin on that runs on a thinned feature set
+__device__ __forceinline__ bool lead_in_thinned(const OdomView &o, int k, int own_begin)
+{
+    return o.lead_full >= 0 && k < own_begin && own_begin - k > o.lead_full;
 }
 
 // which scan does chain c work on at this step (-1: chain finished)
@@ -1233,6 +1243,7 @@ __device__ __forceinline__ void unpack_sym(const double *Hu, double *H)
 }
 
 constexpr int kLmRecLds = 4 * kMaxQueries * 16;   // the chain's records in LDS
+constexpr int kThinBlocks = kMaxQueries / 128;     // = kCfBlocks of corr_flat.hip: feature qi belongs to workgroup qi % kThinBlocks
 
 // One kLmT-thread workgroup per chain.  Every thread runs the (uniform) trust-region control flow redundantly on the
 // block-reduced sums; residual blocks come from the 64-B records written by k_correspond.
@@ -1256,8 +1267,11 @@ __global__ __launch_bounds__(kLmT) void k_lm_solve(BatchView b, OdomView o, int 
         // one record per thread and round: its four 16-B quarters are requested together, the pose-independent part of the
         // residual block is computed once (stage_block) and the block goes to LDS as (cp, kind) + six doubles
         double2 *sp = (double2 *)s_rec;
+        const bool thin = lead_in_thinned(o, k, s);
         for (int qi = tid; qi < nq; qi += kLmT) {
-            const float4 cp = crec[qi * 4], A = crec[qi * 4 + 1], B = crec[qi * 4 + 2], Cc = crec[qi * 4 + 3];
+            float4 cp = crec[qi * 4];
+            const float4 A = crec[qi * 4 + 1], B = crec[qi * 4 + 2], Cc = crec[qi * 4 + 3];
+            if (thin && (qi % kThinBlocks) % kThinStride != 0) cp.w = 0.f;       // not searched in this launch: a stale record
             double P[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
             if (__float_as_int(cp.w) != 0) { stage_block(cp, A, B, Cc, P); n_used++; }
             s_rec[qi] = cp;

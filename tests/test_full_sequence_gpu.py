@@ -16,7 +16,8 @@ def _bench_defaults():
     src = open(os.path.join(ROOT, "bench.py")).read()
     chains = int(re.search(r'"--chains", type=int, default=(\d+)', src).group(1))
     lead = int(re.search(r'"--lead", type=int, default=(\d+)', src).group(1))
-    return chains, lead
+    lead_full = int(re.search(r'"--lead-full", type=int, default=(-?\d+)', src).group(1))
+    return chains, lead, lead_full
 
 
 @pytest.fixture(scope="module")
@@ -54,13 +55,49 @@ def test_sequential_schedule_reproduces_the_cpu_trajectory(seq00):
 
 def test_bench_schedule_meets_the_1cm_bar_over_the_whole_sequence(seq00):
     from lmono_amd import trajectory
-    chains, lead = _bench_defaults()
-    incr, poses = seq00["batch"].odometry(chains, lead)
+    chains, lead, lead_full = _bench_defaults()
+    ctx = seq00["batch"].ctx
+    ctx.set_option(ctx.OPT_LEAD_FULL, lead_full)
+    try:
+        incr, poses = seq00["batch"].odometry(chains, lead)
+    finally:
+        ctx.set_option(ctx.OPT_LEAD_FULL, -1)
     g = seq00["gold"]
     ate = trajectory.ate(poses, g["poses"])
     r1 = trajectory.rpe(poses, g["poses"], 1)
     r100 = trajectory.rpe(poses, g["poses"], 100)
-    print("chains %d lead %d: ATE %.5f m, RPE(1) %.2e m / %.2e deg, RPE(100) %.2e m / %.2e deg"
-          % (chains, lead, ate, r1["trans_rmse_m"], r1["rot_rmse_deg"], r100["trans_rmse_m"], r100["rot_rmse_deg"]))
+    print("chains %d lead %d (last %d lead-in pairs on all features): ATE %.5f m, RPE(1) %.2e m / %.2e deg, RPE(100) %.2e m / %.2e deg"
+          % (chains, lead, lead_full, ate, r1["trans_rmse_m"], r1["rot_rmse_deg"], r100["trans_rmse_m"], r100["rot_rmse_deg"]))
     assert ate <= 0.01                                     # north_star: ATE within 1 cm of the reference path
     assert r1["trans_rmse_m"] <= 1e-3 and r1["rot_rmse_deg"] <= 1e-3
+
+
+def test_chain_groups_and_lead_in_options_at_bench_scale(seq00):
+    """256 chains: (1) LMONO_OPT_ODOM_STREAMS -- 1, 2 or 4 chain groups on their own HIP streams give the same increments bit for
+    bit; (2) LMONO_OPT_LEAD_FULL -- a value >= lead changes nothing, a smaller one only moves the result within the tolerance."""
+    from lmono_amd import trajectory
+    chains, lead, _ = _bench_defaults()
+    b = seq00["batch"]; ctx = b.ctx
+    assert ctx.odom_chain_groups(chains) == 4 and ctx.odom_chain_groups(6) == 1
+    ref_i, ref_p = b.odometry(chains, lead)
+    try:
+        for g in (1, 2):
+            ctx.set_option(ctx.OPT_ODOM_STREAMS, g)
+            assert ctx.odom_chain_groups(chains) == g
+            i, p = b.odometry(chains, lead)
+            assert np.array_equal(i, ref_i) and np.array_equal(p, ref_p)
+        ctx.set_option(ctx.OPT_ODOM_STREAMS, 4)
+        ctx.set_option(ctx.OPT_LEAD_FULL, lead)
+        i, p = b.odometry(chains, lead)
+        assert np.array_equal(i, ref_i)
+        ctx.set_option(ctx.OPT_LEAD_FULL, 3)
+        i, p = b.odometry(chains, lead)
+        assert not np.array_equal(i, ref_i)
+        assert trajectory.ate(p, seq00["gold"]["poses"]) <= 0.01
+        # the strictly sequential schedule has no lead-in: the option does not touch it
+        ctx.set_option(ctx.OPT_LEAD_FULL, 0)
+        i1, _ = b.odometry(1, 0)
+        assert np.abs(i1 - seq00["gold"]["incr"]).max() < 1e-7
+    finally:
+        ctx.set_option(ctx.OPT_ODOM_STREAMS, 4)
+        ctx.set_option(ctx.OPT_LEAD_FULL, -1)
