@@ -264,6 +264,9 @@ __global__ __launch_bounds__(kCfT, LMONO_CF_WAVES) void k_corr_flat(BatchView b,
         fp = edge ? b.sharp[(size_t)k * kMaxSharp + qi] : b.flat[(size_t)k * kMaxFlat + (qi - n_sharp)];
         if (outer == 1 && seed_c) sidx = seed_c[qi];
     }
+    // second outer iteration: the partners the walk found in the first one bound its radius (below)
+    int4 prev = make_int4(-1, -1, -1, 0);
+    if (qi < nq && outer == 1 && seed_c && sidx >= 0) prev = ((const int4 *)o.corr + (size_t)c * kMaxQueries)[qi];
     for (int xx = tid; xx < 2 * 66; xx += kCfT) {
         const int tc = xx / 66, v = xx % 66;
         L.elev[tc][v] = b.lb_elev[(size_t)(l * 2 + tc) * 66 + v];
@@ -378,6 +381,17 @@ __global__ __launch_bounds__(kCfT, LMONO_CF_WAVES) void k_corr_flat(BatchView b,
     const float rad[4] = { walk_radius(0, rho), walk_radius(1, rho), walk_radius(2, rho), walk_radius(3, rho) };
     int wpass = 0;
     unsigned long long same = thr, other = thr;
+    // Seeded walk: when the nearest point is the one of the first outer iteration, the partners found then are still admissible
+    // candidates, so the new minima are no farther than they are: ONE pass with the ball that just holds them is exact (their own
+    // keys are strictly inside it).  Otherwise, and if that pass does not settle, the radius ladder below runs as usual.
+    float r_seed = -1.0f;
+    if (walking && prev.w != 0 && prev.x == closest) {
+        const int i_o = edge ? prev.y : prev.z;
+        const float4 po = cloud[i_o];
+        float d = dist2f(po.x, po.y, po.z, qx, qy, qz);
+        if (!edge) { const float4 ps = cloud[prev.y]; d = fmaxf(d, dist2f(ps.x, ps.y, ps.z, qx, qy, qz)); }
+        if (d < 24.0f) r_seed = sqrtf(d) * 1.002f + 1e-3f;
+    }
     for (int round = 0; round < 64; round++) {
         if (tid == 0) L.n_pool = 0;
         __syncthreads();
@@ -386,9 +400,11 @@ __global__ __launch_bounds__(kCfT, LMONO_CF_WAVES) void k_corr_flat(BatchView b,
             while (wpass > 0 && wpass < 4 && rad[wpass] <= rad[wpass - 1]) wpass++;
             if (wpass >= 4) walking = false;
         }
+        const bool seeded = r_seed > 0.0f;
+        const float r_now = seeded ? r_seed : rad[wpass < 4 ? wpass : 3];
         if (walking) {
             CfArc a;
-            cf_arc(rad[wpass], rho, th, a);
+            cf_arc(r_now, rho, th, a);
             int nl = 0;
 #pragma unroll
             for (int j = 0; j < 5; j++) { const int v = ra - 2 + j; nl += (v >= 0 && v <= 65 && !(edge && j == 2)) ? 1 : 0; }
@@ -420,10 +436,12 @@ __global__ __launch_bounds__(kCfT, LMONO_CF_WAVES) void k_corr_flat(BatchView b,
 #endif
         if (walking && posted) {
             same = L.same[tid]; other = L.other[tid];
-            if (rad[wpass] >= 5.0f) walking = false;
+            if (!seeded && r_now >= 5.0f) walking = false;
             else {
-                const unsigned long long lim = pack_fu(rad[wpass] * rad[wpass] * 0.998f, 0u);     // strictly inside the ball of this pass
-                if (other < lim && (edge || same < lim)) walking = false; else wpass++;
+                const unsigned long long lim = pack_fu(r_now * r_now * 0.998f, 0u);     // strictly inside the ball of this pass
+                if (other < lim && (edge || same < lim)) walking = false;
+                else if (seeded) r_seed = -1.0f;          // (not expected) back to the ladder
+                else wpass++;
             }
         }
         CF_STAMP(cf_acc[3])

@@ -187,7 +187,7 @@ def test_chain_groups_on_streams_change_nothing(gpu_ctx, small_seq):
             i, p = batch.odometry(6, 2)
             assert np.array_equal(i, ref_i) and np.array_equal(p, ref_p)
     finally:
-        gpu_ctx.set_option(gpu_ctx.OPT_ODOM_STREAMS, 1)
+        gpu_ctx.set_option(gpu_ctx.OPT_ODOM_STREAMS, 4)       # the library default
 
 
 def test_odometry_full_resolution(oracle, gpu_ctx, full_seq):
