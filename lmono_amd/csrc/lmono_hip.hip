@@ -18,7 +18,7 @@
 #include <cstdio>
 #include <cstring>
 
-constexpr int kListGrid = 1024;      // workgroups of k_correspond_list (fixed: the work list's length is only known on the device)
+constexpr int kListGrid = 256;       // workgroups of k_correspond_list (fixed: the work list's length is only known on the device; almost always empty)
 
 using namespace lmono;
 
