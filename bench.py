@@ -324,7 +324,7 @@ def bench_posegraph(args):
            "config": {"workload": "S4 loop-closure graph (new feature, SURVEY 8f-2 / config 4 shape)", "keyframes": args.keyframes, "loops": int(len(g["loops"])),
                       "edges": pg.n_edges, "half_bandwidth_blocks": w, "lm_iterations": st["iterations"], "rounds": rounds,
                       "all_reduce_bytes_per_round": 8 * pg.reduce_count},
-           "roofline": {"bound": "hbm", "kernel": "k_pg_step (one workgroup: in-place block-banded Cholesky through L2, latency bound by construction)",
+           "roofline": {"bound": "hbm", "kernel": "k_pg_step (one workgroup: block-banded Cholesky, 8-column panels in LDS, trailing window on f64 MFMA; bound by the dependent chain of 4541 pivots)",
                         "achieved": round(alg * args.steps / el / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg * args.steps / el / 1e9 / HBM_PEAK_GBS, 5),
                         "traffic": None},
            "cpu_baseline": {"value": round(1.0 / cpu_s, 3), "unit": "graphs/s", "cores": 1, "kind": "port", "sample": "the same graph, oracle/lo_posegraph.c (-O3), 1 thread"},

@@ -172,99 +172,181 @@ __device__ __forceinline__ double pg_block_max(double v, double *s_red)
     return t;
 }
 
+// ---- panelled band solver ------------------------------------------------------------------------------------------------
 // In-place right-looking Cholesky of the block band Aw (lower triangle, block (p, p - d) at Aw[(p (w+1) + d) 16], row-major) fused
 // with the forward substitution of sol, then the backward substitution.  Returns false when a pivot is not positive.
-__device__ bool pg_band_solve(const PgView &v, double *s_col, double *s_d, int *s_flag)
+//
+// Round 1 factored one block column at a time with the (w+1)^2-block trailing window read and written through L2 for EVERY
+// keyframe (54.8 ms at 4541 keyframes / w = 67).  Here P block columns form a panel that lives in LDS while it is factored
+// (the same three barriers per keyframe, but between them only LDS is touched), and the trailing window is then updated ONCE
+// per panel as a rank-4P product on the matrix cores (v_mfma_f64_16x16x4_f64: one instruction per 16 x 16 output tile and panel
+// column, operands read from the LDS panel, where blocks outside the band are stored as zeros so that no operand needs a mask).
+// The window traffic falls by P; the backward substitution is panelled the same way.  Measured: 37.5 ms per round -- the round is
+// now bound by the dependent chains inside a panel (a 32 x 32 dense factorisation is 32 sequential pivots whatever executes it;
+// a one-wave register version with lane-to-lane broadcasts and independent row solves was tried: 50 ms).
+typedef double pg_d4 __attribute__((ext_vector_type(4)));
+__host__ __device__ inline int pg_panel_width(int w) { return w <= 120 ? 8 : 4; }     // the panel must fit LDS
+__host__ __device__ inline size_t pg_panel_doubles(int w) { const int P = pg_panel_width(w); return (size_t)(w + P + 4) * P * 16 + (size_t)(w + P + 4) * 4; }
+
+__device__ bool pg_band_solve(const PgView &v, double *s_pan, double *s_d, int *s_flag)
 {
-    const int n = v.n, w = v.w, bs = (w + 1) * 16, tid = threadIdx.x;
+    const int n = v.n, w = v.w, bs = (w + 1) * 16, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P = pg_panel_width(w), rows_cap = w + P + 4;
     double *A = v.Aw, *y = v.sol;
+    double *s_y = s_pan + (size_t)rows_cap * P * 16;          // right-hand side rows of the panel's window
     if (tid == 0) *s_flag = 1;
     __syncthreads();
-    for (int p = 0; p < n; p++) {
-        const int m = min(w, n - 1 - p);
-        if (tid == 0) {
-            double *D = A + (size_t)p * bs;                       // Cholesky of the 4 x 4 diagonal block, y_p = L^-1 b_p
-            double L[16];
-            bool ok = true;
+    for (int p0 = 0; p0 < n; p0 += P) {
+        const int Pw = min(P, n - p0);
+        const int R = min(Pw - 1 + w, n - 1 - p0) + 1;        // block rows p0 .. p0 + R - 1 are touched by this panel
+        // ---- load: block (p0 + row, p0 + k) -> s_pan[(row P + k) 16]; zeros outside the band and below row R
+        for (int t = tid; t < rows_cap * P * 16; t += kPgT) {
+            const int e = t & 15, k = (t >> 4) % P, row = (t >> 4) / P;
+            double a = 0.0;
+            if (row < R && k < Pw && row >= k && row - k <= w) a = A[(size_t)(p0 + row) * bs + (size_t)(row - k) * 16 + e];
+            s_pan[t] = a;
+        }
+        for (int t = tid; t < rows_cap * 4; t += kPgT) s_y[t] = t < R * 4 ? y[4 * p0 + t] : 0.0;
+        __syncthreads();
+        // ---- factor the panel inside LDS, one block column after the other
+        for (int k = 0; k < Pw; k++) {
+            const int m = min(w, n - 1 - (p0 + k));            // block rows below the pivot
+            if (tid == 0) {
+                double *D = s_pan + (size_t)(k * P + k) * 16;
+                double L[16];
+                bool ok = true;
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+                for (int i = 0; i < 4; i++)
 #pragma unroll
-                for (int j = 0; j <= i; j++) {
-                    double s = D[4 * i + j];
+                    for (int j = 0; j <= i; j++) {
+                        double s = D[4 * i + j];
 #pragma unroll
-                    for (int k = 0; k < j; k++) s -= L[4 * i + k] * L[4 * j + k];
-                    if (i == j) { ok = ok && s > 0.0; L[4 * i + i] = sqrt(s); }
-                    else L[4 * i + j] = s / L[4 * j + j];
+                        for (int q = 0; q < j; q++) s -= L[4 * i + q] * L[4 * j + q];
+                        if (i == j) { ok = ok && s > 0.0; L[4 * i + i] = sqrt(s); }
+                        else L[4 * i + j] = s / L[4 * j + j];
+                    }
+                if (!ok) *s_flag = 0;
+                double yy[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    double s = s_y[4 * k + i];
+#pragma unroll
+                    for (int q = 0; q < i; q++) s -= L[4 * i + q] * yy[q];
+                    yy[i] = s / L[4 * i + i];
+                    s_y[4 * k + i] = yy[i];
+                    s_d[16 + i] = yy[i];
                 }
-            if (!ok) *s_flag = 0;
-            double yy[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                double s = y[4 * p + i];
+                for (int i = 0; i < 4; i++)
 #pragma unroll
-                for (int k = 0; k < i; k++) s -= L[4 * i + k] * yy[k];
-                yy[i] = s / L[4 * i + i];
-                y[4 * p + i] = yy[i];
-                s_d[16 + i] = yy[i];
+                    for (int j = 0; j < 4; j++) { const double l = j <= i ? L[4 * i + j] : 0.0; D[4 * i + j] = l; s_d[4 * i + j] = l; }
             }
+            __syncthreads();
+            if (!*s_flag) return false;
+            // block column k below the pivot: L_ik = A_ik L_kk^-T (one scalar row per thread), b_i -= L_ik y_k
+            for (int t = tid; t < 4 * m; t += kPgT) {
+                const int io = t >> 2, r = t & 3, row = k + 1 + io;
+                double *blk = s_pan + (size_t)(row * P + k) * 16 + 4 * r;
+                double l[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+                for (int c = 0; c < 4; c++) {
+                    double s = blk[c];
 #pragma unroll
-                for (int j = 0; j < 4; j++) { const double l = j <= i ? L[4 * i + j] : 0.0; D[4 * i + j] = l; s_d[4 * i + j] = l; }
-        }
-        __syncthreads();
-        if (!*s_flag) return false;
-        // block column p: L_ip = A_ip L_pp^-T (one scalar row per thread), b_i -= L_ip y_p
-        for (int t = tid; t < 4 * m; t += kPgT) {
-            const int io = t >> 2, r = t & 3, i = p + 1 + io;
-            double *blk = A + (size_t)i * bs + (size_t)(io + 1) * 16 + 4 * r;
-            double l[4];
+                    for (int q = 0; q < c; q++) s -= l[q] * s_d[4 * c + q];
+                    l[c] = s / s_d[4 * c + c];
+                }
+                double dot = 0.0;
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                double s = blk[c];
-#pragma unroll
-                for (int k = 0; k < c; k++) s -= l[k] * s_d[4 * c + k];
-                l[c] = s / s_d[4 * c + c];
+                for (int c = 0; c < 4; c++) { blk[c] = l[c]; dot += l[c] * s_d[16 + c]; }
+                s_y[4 * row + r] -= dot;
             }
-            double dot = 0.0;
+            __syncthreads();
+            // the later columns of the panel: A_(row, k2) -= L_(row, k) L_(k2, k)^T for k < k2 < Pw, k2 <= row <= k + m
+            const int nk2 = Pw - 1 - k;
+            for (int t = tid; t < nk2 * m * 4; t += kPgT) {
+                const int r = t & 3, io = (t >> 2) % m, k2 = k + 1 + (t >> 2) / m, row = k + 1 + io;
+                if (row < k2) continue;
+                const double *li = s_pan + (size_t)(row * P + k) * 16 + 4 * r, *lj = s_pan + (size_t)(k2 * P + k) * 16;
+                double *blk = s_pan + (size_t)(row * P + k2) * 16 + 4 * r;
 #pragma unroll
-            for (int c = 0; c < 4; c++) { blk[c] = l[c]; s_col[io * 16 + 4 * r + c] = l[c]; dot += l[c] * s_d[16 + c]; }
-            y[4 * i + r] -= dot;
+                for (int c = 0; c < 4; c++) blk[c] -= li[0] * lj[4 * c] + li[1] * lj[4 * c + 1] + li[2] * lj[4 * c + 2] + li[3] * lj[4 * c + 3];
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        // trailing update A_ij -= L_ip L_jp^T for p < j <= i <= p + m, one scalar row of a block per work item
-        const int items = m * m * 4;
-        for (int t = tid; t < items; t += kPgT) {
-            const int io = t / (4 * m), rem = t - io * 4 * m, jo = rem >> 2, r = rem & 3;
-            if (jo > io) continue;
-            double *blk = A + (size_t)(p + 1 + io) * bs + (size_t)(io - jo) * 16 + 4 * r;
-            const double *li = s_col + io * 16 + 4 * r, *lj = s_col + jo * 16;
+        // ---- the factored panel and the window's right-hand side go back
+        for (int t = tid; t < R * P * 16; t += kPgT) {
+            const int e = t & 15, k = (t >> 4) % P, row = (t >> 4) / P;
+            if (k < Pw && row >= k && row - k <= w) A[(size_t)(p0 + row) * bs + (size_t)(row - k) * 16 + e] = s_pan[t];
+        }
+        for (int t = tid; t < R * 4; t += kPgT) y[4 * p0 + t] = s_y[t];
+        // ---- trailing window: A_(row, col) -= sum_k L_(row, k) L_(col, k)^T for Pw <= col <= row < R, 16 x 16 tiles on the matrix cores
+        const int Tn = (R - Pw + 3) >> 2;
+        for (int tile = wave; tile < Tn * (Tn + 1) / 2; tile += kPgT / kWave) {
+            int a = 0;
+            while ((a + 1) * (a + 2) / 2 <= tile) a++;           // tile (a, b), b <= a, in row-major order of the lower triangle
+            const int b = tile - a * (a + 1) / 2;
+            const int cq = lane >> 4, cc = lane & 15;            // this lane: tile rows 4 v + cq (v = register), tile column cc
+            const int col = Pw + 4 * b + (cc >> 2), c = cc & 3;
+            pg_d4 acc;
+            bool valid[4];
 #pragma unroll
-            for (int c = 0; c < 4; c++) blk[c] -= li[0] * lj[4 * c] + li[1] * lj[4 * c + 1] + li[2] * lj[4 * c + 2] + li[3] * lj[4 * c + 3];
+            for (int vv = 0; vv < 4; vv++) {
+                const int row = Pw + 4 * a + vv;
+                valid[vv] = row < R && col <= row;
+                acc[vv] = valid[vv] ? A[(size_t)(p0 + row) * bs + (size_t)(row - col) * 16 + 4 * cq + c] : 0.0;
+            }
+            // operands: A[i][kk] = -L[(row_i, r_i), (k, kk)], B[kk][j] = L[(col_j, c_j), (k, kk)]; lane = (i or j) + 16 kk
+            const int orow = Pw + 4 * a + (cc >> 2), orr = cc & 3, kk = cq;
+            const double *pa = s_pan + (size_t)orow * P * 16 + 4 * orr + kk, *pb = s_pan + (size_t)col * P * 16 + 4 * c + kk;
+            for (int k = 0; k < Pw; k++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[k * 16], pb[k * 16], acc, 0, 0, 0);
+#pragma unroll
+            for (int vv = 0; vv < 4; vv++) {
+                const int row = Pw + 4 * a + vv;
+                if (valid[vv]) A[(size_t)(p0 + row) * bs + (size_t)(row - col) * 16 + 4 * cq + c] = acc[vv];
+            }
         }
         __syncthreads();
     }
-    // backward substitution: x_i = L_ii^-T y_i, then y_j -= L_ij^T x_i for the w block rows above
-    for (int i = n - 1; i >= 0; i--) {
+    // ---- backward substitution, panel by panel from the bottom: x_i = L_ii^-T (y_i - sum_(j > i) L_ji^T x_j)
+    for (int i0 = ((n - 1) / P) * P; i0 >= 0; i0 -= P) {
+        const int Pw = min(P, n - i0);
+        // block rows i0 .. i0 + Pw - 1 of L: s_pan[(ii (w+1) + d) 16] = block (i0 + ii, i0 + ii - d)
+        for (int t = tid; t < Pw * bs; t += kPgT) {
+            const int ii = t / bs, d = (t - ii * bs) >> 4;
+            s_pan[t] = i0 + ii - d >= 0 ? A[(size_t)(i0 + ii) * bs + (t - ii * bs)] : 0.0;
+        }
+        for (int t = tid; t < Pw * 4; t += kPgT) s_y[t] = y[4 * i0 + t];
+        __syncthreads();
         if (tid == 0) {
-            const double *L = A + (size_t)i * bs;
-            double xx[4];
+            for (int ii = Pw - 1; ii >= 0; ii--) {
+                const double *L = s_pan + (size_t)ii * bs;
+                double xx[4];
 #pragma unroll
-            for (int c = 3; c >= 0; c--) {
-                double s = y[4 * i + c];
+                for (int c = 3; c >= 0; c--) {
+                    double s = s_y[4 * ii + c];
 #pragma unroll
-                for (int k = c + 1; k < 4; k++) s -= L[4 * k + c] * xx[k];
-                xx[c] = s / L[4 * c + c];
-                y[4 * i + c] = xx[c];
-                s_d[c] = xx[c];
+                    for (int q = c + 1; q < 4; q++) s -= L[4 * q + c] * xx[q];
+                    xx[c] = s / L[4 * c + c];
+                    s_y[4 * ii + c] = xx[c];
+                }
+                for (int d = 1; d <= ii && d <= w; d++) {       // the rows above it inside the panel
+                    const double *blk = L + d * 16;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) s_y[4 * (ii - d) + c] -= blk[c] * xx[0] + blk[4 + c] * xx[1] + blk[8 + c] * xx[2] + blk[12 + c] * xx[3];
+                }
             }
         }
         __syncthreads();
-        const int m = min(w, i);
-        for (int t = tid; t < 4 * m; t += kPgT) {
-            const int d = (t >> 2) + 1, c = t & 3;
-            const double *blk = A + (size_t)i * bs + (size_t)d * 16;
-            y[4 * (i - d) + c] -= blk[c] * s_d[0] + blk[4 + c] * s_d[1] + blk[8 + c] * s_d[2] + blk[12 + c] * s_d[3];
+        for (int t = tid; t < Pw * 4; t += kPgT) y[4 * i0 + t] = s_y[t];
+        // rows above the panel: y_J -= sum_ii L_(i0 + ii, J)^T x_ii for J = i0 - dd, dd = 1 .. w
+        for (int t = tid; t < 4 * min(w, i0); t += kPgT) {
+            const int dd = (t >> 2) + 1, c = t & 3;
+            double s = 0.0;
+            for (int ii = 0; ii < Pw && ii + dd <= w; ii++) {
+                const double *blk = s_pan + (size_t)ii * bs + (size_t)(ii + dd) * 16;
+                s += blk[c] * s_y[4 * ii] + blk[4 + c] * s_y[4 * ii + 1] + blk[8 + c] * s_y[4 * ii + 2] + blk[12 + c] * s_y[4 * ii + 3];
+            }
+            y[4 * (i0 - dd) + c] -= s;
         }
         __syncthreads();
     }
@@ -275,7 +357,7 @@ __device__ bool pg_band_solve(const PgView &v, double *s_col, double *s_d, int *
 // v.lin (initial point or last candidate), decide, solve for the next candidate.
 __global__ __launch_bounds__(kPgT) void k_pg_step(PgView v, int max_iter)
 {
-    __shared__ double s_col[kPgMaxW * 16];
+    extern __shared__ __align__(16) double s_pan[];          // pg_panel_doubles(w): the panel of the band solver
     __shared__ double s_d[20];
     __shared__ double s_red[kPgT / kWave];
     __shared__ int s_flag;
@@ -340,20 +422,25 @@ __global__ __launch_bounds__(kPgT) void k_pg_step(PgView v, int max_iter)
         if (tid == 0) s.iter++;
         const double radius = s.radius;
         const bool reuse = s.reuse_diag != 0;
-        for (size_t i = tid; i < hsz; i += kPgT) {
-            const int p = (int)(i / bs), rem = (int)(i - (size_t)p * bs), d = rem >> 4, r = (rem >> 2) & 3, c = rem & 3;
-            const int col = 4 * (p - d) + c;
-            double a = 0.0;
-            if (p - d >= 0 && !(d == 0 && c > r)) a = v.cur[i] * v.scale[4 * p + r] * v.scale[col];
-            if (d == 0 && c == r) {
-                if (!reuse) v.diag[4 * p + r] = fmin(fmax(a, min_diag), max_diag);
-                a += v.diag[4 * p + r] / radius;
+        // one wave per block row at a time (no 64-bit division per element)
+        for (int p = tid >> 6; p < n; p += kPgT / kWave) {
+            const double *src = v.cur + (size_t)p * bs;
+            double *dst = v.Aw + (size_t)p * bs;
+            for (int rem = tid & 63; rem < bs; rem += kWave) {
+                const int d = rem >> 4, r = (rem >> 2) & 3, c = rem & 3;
+                const int col = 4 * (p - d) + c;
+                double a = 0.0;
+                if (p - d >= 0 && !(d == 0 && c > r)) a = src[rem] * v.scale[4 * p + r] * v.scale[col];
+                if (d == 0 && c == r) {
+                    if (!reuse) v.diag[4 * p + r] = fmin(fmax(a, min_diag), max_diag);
+                    a += v.diag[4 * p + r] / radius;
+                }
+                dst[rem] = a;
             }
-            v.Aw[i] = a;
         }
         for (int i = tid; i < n4; i += kPgT) { const double g = v.cur[hsz + i] * v.scale[i]; v.gs[i] = g; v.sol[i] = g; }
         __syncthreads();
-        bool ok = pg_band_solve(v, s_col, s_d, &s_flag);
+        bool ok = pg_band_solve(v, s_pan, s_d, &s_flag);
         double dg = 0.0, dd = 0.0, bad = 0.0;
         if (ok)
             for (int i = tid; i < n4; i += kPgT) {

@@ -149,6 +149,10 @@ extern "C" lmono_pose_graph *lmono_pose_graph_create(lmono_ctx *c, int n, const 
     for (int e = 0; e < ne; e++) w = std::max(w, std::abs(pos[(size_t)ea[(size_t)e]] - pos[(size_t)eb[(size_t)e]]));
     if (w > kPgMaxW) { c->err = "lmono_pose_graph_create: graph bandwidth " + std::to_string(w) + " blocks exceeds " + std::to_string(kPgMaxW); delete g; return nullptr; }
     g->w = w;
+    // the band solver's panel lives in dynamic LDS (83 KB at w = 67, <= 143 KB at the widest band); per device, so set per graph
+    if (hipFuncSetAttribute((const void *)k_pg_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(std::max(pg_panel_doubles(120), pg_panel_doubles(kPgMaxW)) * sizeof(double))) != hipSuccess) {      // the largest any graph can ask for
+        c->err = "lmono_pose_graph_create: cannot reserve the band solver's LDS panel"; delete g; return nullptr;
+    }
     const size_t hsz = (size_t)n * (size_t)(w + 1) * 16;
     g->reduce_count = (int64_t)(hsz + 5 * (size_t)n);
     PgView &v = g->v;
@@ -203,7 +207,7 @@ extern "C" int lmono_pose_graph_linearise(lmono_ctx *c, lmono_pose_graph *g, int
 extern "C" int lmono_pose_graph_step(lmono_ctx *c, lmono_pose_graph *g, int max_iter, int *done)
 {
     if (!c || !g || g->ctx != c || max_iter < 0) return LMONO_EINVAL;
-    k_pg_step<<<1, kPgT, 0, c->stream>>>(g->v, max_iter);
+    k_pg_step<<<1, kPgT, pg_panel_doubles(g->w) * sizeof(double), c->stream>>>(g->v, max_iter);
     if (int rc = check_launch(c, "k_pg_step")) return rc;
     if (done) {
         PgState s;
