@@ -48,7 +48,8 @@ int         lmono_synchronize(lmono_ctx *);
  * then runs without hash grids; results must not change.  0 = off.                                                              */
 #define LMONO_OPT_DEFER_EVERY 1
 /* chain groups of lmono_odom_batch[_d]: G = 1 .. 8 groups of chains advance on G HIP streams side by side (results unchanged).
- * Default 4 (one per hardware queue); reduced until every group holds at least 32 chains, so a 1-chain call is ungrouped.   */
+ * Default 4 (one per hardware queue); at most 3 for a context on a caller-created stream (the runtime keeps one queue for the null
+ * stream); reduced until every group holds at least 32 chains, so a 1-chain call is ungrouped.                                */
 #define LMONO_OPT_ODOM_STREAMS 2
 /* lead-in of lmono_odom_batch[_d]'s chains: >= 0 = only the last N lead-in scan pairs of a chain use all feature points, the earlier
  * ones a quarter of them (a lead-in pair only produces the next pair's warm start); -1 (default) = every pair uses all of them.

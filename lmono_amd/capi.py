@@ -92,6 +92,7 @@ class Context:
 
     def __init__(self, device=0):
         self.L = load_library()
+        self._own_stream = False          # the context starts on the null stream
         self.h = self.L.lmono_create(int(device))
         if not self.h:
             raise LmonoError("lmono_create(%d) failed: no usable HIP device" % device)
@@ -113,6 +114,7 @@ class Context:
 
     def set_stream(self, raw_stream):
         self.check(self.L.lmono_set_stream(self.h, C.c_void_p(raw_stream)))
+        self._own_stream = bool(raw_stream)
 
     def synchronize(self):
         self.check(self.L.lmono_synchronize(self.h))
@@ -133,6 +135,8 @@ class Context:
         g = max(1, min(8, self.get_option(self.OPT_ODOM_STREAMS)))
         if self.get_option(self.OPT_CORR_TILE) != 3:
             return 1
+        if self._own_stream:
+            g = min(g, 3)
         while g > 1 and n_chains // g < 32:
             g -= 1
         return g

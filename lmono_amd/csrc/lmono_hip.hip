@@ -464,27 +464,31 @@ static int odom_run(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, d
     int ne = 0;
     // Chain groups: with LMONO_OPT_ODOM_STREAMS = G > 1 the chains are cut into G groups, each advancing on its own stream, so that
     // one group's solve (one workgroup per chain: a quarter of the CUs' wave slots at most) and the ragged tail of its search kernel
-    // run beside the other groups' searches.  Group 0 uses the context stream and carries the per-kernel events.  The runtime maps
-    // streams onto 4 hardware queues (GPU_MAX_HW_QUEUES), the null stream on one of its own: the default context (null stream + 3
-    // group streams) gets 4 distinct queues.  With a caller-created context stream, or with all 4 groups on created streams, two
-    // groups share a queue and serialise (measured 64-70 instead of 51 ms per step): export GPU_MAX_HW_QUEUES=8 in that case.
+    // run beside the other groups' searches.  Group 0 carries the per-kernel events.  The runtime maps streams onto 4 hardware queues
+    // (GPU_MAX_HW_QUEUES): the null stream on one of its own, created streams round-robin on the other three.  So the default context
+    // (null stream) runs group 0 on the null stream + 3 group streams = 4 distinct queues; a context on a caller-created stream runs
+    // at most 3 groups, all on the library's own streams (4 created streams would put two groups on one queue: 64-70 instead of 51 ms
+    // per step measured), and the caller's stream only forks and joins.
     constexpr int kMinChainsPerGroup = 32;
     int G = c->opt[LMONO_OPT_ODOM_STREAMS];
     G = G < 1 ? 1 : (G > 8 ? 8 : G);
+    const bool null_stream = c->stream == nullptr;
+    if (!null_stream && G > 3) G = 3;
     while (G > 1 && n_chains / G < kMinChainsPerGroup) G--;      // a group below 32 chains cannot fill its share of the CUs
+    const int g_own = null_stream ? 1 : 0;                        // first group that runs on a stream of the library
     if (tile != 3) G = 1;                       // only the default search is grouped
     const size_t wl_stride = (size_t)n_chains * kMaxQueries + 1;
     if (G > 1) {
-        for (int g = 1; g < G; g++) if (!c->gstream[g]) HIP_TRY(c, hipStreamCreateWithFlags(&c->gstream[g], hipStreamNonBlocking));
+        for (int g = g_own; g < G; g++) if (!c->gstream[g]) HIP_TRY(c, hipStreamCreateWithFlags(&c->gstream[g], hipStreamNonBlocking));
         for (int g = 0; g <= G && g < 9; g++) if (!c->gev[g]) HIP_TRY(c, hipEventCreateWithFlags(&c->gev[g], hipEventDisableTiming));
         for (int g = 1; g < G; g++) HIP_TRY(c, hipMemsetAsync(b->wl + g * wl_stride, 0, sizeof(unsigned int), st));
         HIP_TRY(c, hipEventRecord(c->gev[0], st));
-        for (int g = 1; g < G; g++) HIP_TRY(c, hipStreamWaitEvent(c->gstream[g], c->gev[0], 0));
+        for (int g = g_own; g < G; g++) HIP_TRY(c, hipStreamWaitEvent(c->gstream[g], c->gev[0], 0));
     }
     for (int step = 0; step < max_steps; step++) {
         for (int outer = 0; outer < 2; outer++) {
             for (int g = 0; g < G; g++) {
-                hipStream_t sg = g == 0 ? st : c->gstream[g];
+                hipStream_t sg = (G == 1 || g < g_own) ? st : c->gstream[g];
                 OdomView og = o;
                 og.chain0 = (int)((long long)g * n_chains / G); og.chain1 = (int)((long long)(g + 1) * n_chains / G);
                 const int ng = og.chain1 - og.chain0;
@@ -510,7 +514,7 @@ static int odom_run(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, d
         }
     }
     if (G > 1)
-        for (int g = 1; g < G; g++) { HIP_TRY(c, hipEventRecord(c->gev[g], c->gstream[g])); HIP_TRY(c, hipStreamWaitEvent(st, c->gev[g], 0)); }
+        for (int g = g_own; g < G; g++) { HIP_TRY(c, hipEventRecord(c->gev[g + 1], c->gstream[g])); HIP_TRY(c, hipStreamWaitEvent(st, c->gev[g + 1], 0)); }
     es.n_kev = ne;
     if (want_poses) hipLaunchKernelGGL(k_pose_prefix, dim3(1), dim3(64), 0, st, (const double *)b->incr, b->poses, 0, n);
     HIP_TRY(c, hipEventRecord(c->ev[9], st));
