@@ -175,6 +175,45 @@ def test_odometry_chain_sharded_matches_oracle(oracle, gpu_ctx, small_seq):
     assert np.abs(poses - ref["poses"]).max() < 1e-8
 
 
+@pytest.mark.parametrize("n_lines,min_range", [(16, 0.5), (32, 0.5), (64, 0.5)])
+def test_odometry_other_sensors_and_near_points(oracle, gpu_ctx, n_lines, min_range):
+    """The (scan line, azimuth bin) search on 16- / 32-line sensors and with points from 0.5 m on (feature points close to the sensor
+    axis: their search balls cover every azimuth): correspondences of every search mode and the sequential odometry against the oracle."""
+    w = oracle.S1World(n_az=600, n_rings=n_lines)
+    xyzi, off = w.scans(w.trajectory(5))
+    batch = _register(gpu_ctx, xyzi, off, n_lines, min_range)
+    f = [oracle.scanreg(xyzi[off[s]:off[s + 1]], n_lines, min_range) for s in range(3)]
+    q = np.array([0.0, 0.0, 0.008, 1.0]); q /= np.linalg.norm(q)
+    t = np.array([0.75, -0.01, 0.0])
+    for k in (1, 2):
+        _, _, _, corr = oracle.odom_step(f[k]["sharp"], f[k]["flat"], f[k - 1]["less_sharp"], f[k - 1]["less_flat"], q, t, want_corr=True)
+        try:
+            for mode in (3, 0, 1, 2):
+                gpu_ctx.set_option(gpu_ctx.OPT_CORR_TILE, mode)
+                assert np.array_equal(batch.correspond(k, q, t), corr[0]), "mode %d, scan %d" % (mode, k)
+        finally:
+            gpu_ctx.set_option(gpu_ctx.OPT_CORR_TILE, 3)
+    incr, poses = batch.odometry(1, 0)
+    ref = oracle.run_sequence(xyzi, off, n_lines, min_range)
+    assert np.abs(incr - ref["incr"]).max() < 1e-9 and np.abs(poses - ref["poses"]).max() < 1e-8
+
+
+def test_odometry_dense_rings(oracle, gpu_ctx):
+    """3000 azimuth steps per ring (rings beyond the small-slice kernels' 2304 points, denser azimuth bins): sequential odometry and the
+    correspondences of the default search against the oracle."""
+    w = oracle.S1World(n_az=3000)
+    xyzi, off = w.scans(w.trajectory(3))
+    batch = _register(gpu_ctx, xyzi, off)
+    assert (batch.counts()[:, 5] == 0).all()
+    incr, poses = batch.odometry(1, 0)
+    ref = oracle.run_sequence(xyzi, off)
+    assert np.abs(incr - ref["incr"]).max() < 1e-9 and np.abs(poses - ref["poses"]).max() < 1e-8
+    f = [oracle.scanreg(xyzi[off[s]:off[s + 1]]) for s in range(2)]
+    q = np.array([0.0, 0.0, 0.0, 1.0]); t = np.array([0.0, 0.0, 0.0])      # identity warm start: the largest search radii
+    _, _, _, corr = oracle.odom_step(f[1]["sharp"], f[1]["flat"], f[0]["less_sharp"], f[0]["less_flat"], q, t, want_corr=True)
+    assert np.array_equal(batch.correspond(1, q, t), corr[0])
+
+
 def test_chain_groups_on_streams_change_nothing(gpu_ctx, small_seq):
     """LMONO_OPT_ODOM_STREAMS on a small batch: groups need >= 32 chains each, so 6 chains stay on one stream whatever the option
     says (the grouped path itself is checked at 256 chains in test_full_sequence_gpu.py); same increments bit for bit."""
