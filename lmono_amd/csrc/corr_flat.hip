@@ -46,7 +46,10 @@ static_assert(kCfBlocks == kThinBlocks, "k_lm_solve skips the records of the wor
 #endif
 constexpr int kCfPer = LMONO_CF_PER;           // runs per lane and round
 constexpr int kCfPool = kCfT * kCfPer;        // run descriptors per round
-constexpr float kCfR0 = 0.3f;                 // first search radius of an unseeded feature (m)
+// first search radius of an unseeded feature (m): the less-sharp cloud is sparse (<= 20 points per ring and sector), the 0.2 m-voxelised
+// less-flat cloud dense.  Any value is exact; measured per bench step: (0.3, 0.3) 49.0 ms, (0.5, 0.3) 48.8, (0.5, 0.2) 48.1, (0.5, 0.15) 47.8,
+// (0.5, 0.1) 48.4, (0.8, 0.3) 49.0; a term proportional to the range did not help.
+constexpr float kCfR0Edge = 0.5f, kCfR0Plane = 0.15f;
 constexpr int kCfU = LMONO_CF_U;               // gathers in flight per lane
 
 struct CfRun {
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(kCfT, LMONO_CF_WAVES) void k_corr_flat(BatchView b,
     bool alive = qi < nq && n_last > 0;       // still looking for its nearest point
     bool deferred = false;
     if (defer_every > 0 && qi < nq && qi % defer_every == 0) { alive = false; deferred = true; }      // test hook: exercise the fall-back kernel
-    float r = sd >= 0.f ? sqrtf(sd) * 1.0005f + 1e-3f : kCfR0;
+    float r = sd >= 0.f ? sqrtf(sd) * 1.0005f + 1e-3f : (edge ? kCfR0Edge : kCfR0Plane);
     __syncthreads();
 
     CF_STAMP(cf_acc[4])
