@@ -57,7 +57,7 @@ int         lmono_synchronize(lmono_ctx *);
 #define LMONO_OPT_LEAD_FULL 3
 #define LMONO_OPT_COUNT     4
 int         lmono_set_option(lmono_ctx *, int key, int value);
-int         lmono_get_option(lmono_ctx *, int key);                 /* the configured value, or LMONO_EINVAL */
+int         lmono_get_option(lmono_ctx *, int key, int *value);     /* the configured value (option values may be negative) */
 const char *lmono_version(void);
 
 /* ---- LiDAR front end: A-LOAM scanRegistration::laserCloudHandler ------------------------ *

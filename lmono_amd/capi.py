@@ -50,7 +50,7 @@ def load_library():
     L.lmono_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     L.lmono_synchronize.argtypes = [C.c_void_p]
     L.lmono_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int]
-    L.lmono_get_option.argtypes = [C.c_void_p, C.c_int]
+    L.lmono_get_option.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.lmono_batch_create.restype = C.c_void_p
     L.lmono_batch_create.argtypes = [C.c_void_p, C.c_int, C.c_int64]
     L.lmono_batch_destroy.argtypes = [C.c_void_p]
@@ -128,7 +128,9 @@ class Context:
         self.check(self.L.lmono_set_option(self.h, int(key), int(value)))
 
     def get_option(self, key):
-        return self.check(self.L.lmono_get_option(self.h, int(key)))
+        v = C.c_int(0)
+        self.check(self.L.lmono_get_option(self.h, int(key), C.byref(v)))
+        return int(v.value)
 
     def odom_chain_groups(self, n_chains):
         """Chain groups (HIP streams) an odometry call with n_chains chains runs on: the rule of odom_run in lmono_hip.hip."""

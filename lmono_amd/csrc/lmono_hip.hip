@@ -142,10 +142,11 @@ extern "C" int lmono_set_option(lmono_ctx *c, int key, int value)
     return LMONO_OK;
 }
 
-extern "C" int lmono_get_option(lmono_ctx *c, int key)
+extern "C" int lmono_get_option(lmono_ctx *c, int key, int *value)
 {
-    if (!c || key < 0 || key >= LMONO_OPT_COUNT) return LMONO_EINVAL;
-    return c->opt[key];
+    if (!c || !value || key < 0 || key >= LMONO_OPT_COUNT) return LMONO_EINVAL;
+    *value = c->opt[key];
+    return LMONO_OK;
 }
 
 extern "C" int lmono_synchronize(lmono_ctx *c)
