@@ -138,6 +138,11 @@ extern "C" int lmono_set_stream(lmono_ctx *c, void *s)
 extern "C" int lmono_set_option(lmono_ctx *c, int key, int value)
 {
     if (!c || key < 0 || key >= LMONO_OPT_COUNT) return LMONO_EINVAL;
+    const bool ok = key == LMONO_OPT_CORR_TILE ? (value >= 0 && value <= 3)
+                  : key == LMONO_OPT_DEFER_EVERY ? value >= 0
+                  : key == LMONO_OPT_ODOM_STREAMS ? (value >= 1 && value <= 8)
+                  : value >= -1;                                     // LMONO_OPT_LEAD_FULL
+    if (!ok) { c->err = "lmono_set_option: value out of range for this option"; return LMONO_EINVAL; }
     c->opt[key] = value;
     return LMONO_OK;
 }

@@ -296,6 +296,15 @@ def test_api_errors_and_limits(oracle, gpu_ctx, small_seq):
     one.scanreg(dev.data_ptr(), off[:2], 64, 5.0, keepalive=dev)
     incr, poses = one.odometry(1, 0)                                # a single scan: identity
     assert np.array_equal(incr, np.array([[0, 0, 0, 1, 0, 0, 0.0]])) and np.array_equal(poses, incr)
+    # options: values are range-checked, a rejected value leaves the option as it was, values may be negative
+    for key, bad in ((gpu_ctx.OPT_CORR_TILE, 4), (gpu_ctx.OPT_CORR_TILE, -1), (gpu_ctx.OPT_ODOM_STREAMS, 0), (gpu_ctx.OPT_ODOM_STREAMS, 9),
+                     (gpu_ctx.OPT_DEFER_EVERY, -1), (gpu_ctx.OPT_LEAD_FULL, -2), (17, 0)):
+        before = gpu_ctx.get_option(key) if key < 4 else None
+        with pytest.raises(lmono_amd.LmonoError):
+            gpu_ctx.set_option(key, bad)
+        if before is not None:
+            assert gpu_ctx.get_option(key) == before
+    assert gpu_ctx.get_option(gpu_ctx.OPT_LEAD_FULL) == -1
 
 
 def test_ring_longer_than_kernel_limit_is_flagged(gpu_ctx):
