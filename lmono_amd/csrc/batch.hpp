@@ -42,6 +42,7 @@ struct BatchView {
     float4 *lf_tmp;          // [total] voxel-filtered less-flat points in ring slots
     int *lf_n;               // [n_scans][64]
     int *sel_todo;           // [1 + n_scans * 64] work list of k_select's second launch (rings longer than the small LDS slice)
+    int *li_todo;            // [1 + n_scans * 2] work list of k_line_index's full-width launch: count, then scan * 2 + cloud
     int *vox_todo;           // [1 + n_scans * 64] work list of k_voxel's second instantiation: count, then (scan << 6 | ring)
     // ---- final feature clouds
     float4 *sharp;           // [n_scans][kMaxSharp]

@@ -100,7 +100,8 @@ extern "C" lmono_ctx *lmono_create(int device)
     if (hipFuncSetAttribute((const void *)k_voxel<kVoxBigSlots, kVoxBigBits, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kVoxLdsBig) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_lm_solve, hipFuncAttributeMaxDynamicSharedMemorySize, kLmRecLds) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_grid_build, hipFuncAttributeMaxDynamicSharedMemorySize, kGridLds) != hipSuccess) { delete c; return nullptr; }
-    if (hipFuncSetAttribute((const void *)k_line_index, hipFuncAttributeMaxDynamicSharedMemorySize, kLiLds) != hipSuccess) { delete c; return nullptr; }
+    if (hipFuncSetAttribute((const void *)k_line_index<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLiLdsHalf) != hipSuccess) { delete c; return nullptr; }
+    if (hipFuncSetAttribute((const void *)k_line_index<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLiLdsFull) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_corr_tile, hipFuncAttributeMaxDynamicSharedMemorySize, kTileLds) != hipSuccess) { delete c; return nullptr; }
     // the BA-side kernels with large dynamic LDS: per device, so per context (a second context on another GPU needs them too)
     if (hipFuncSetAttribute((const void *)k_ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BaLds)) != hipSuccess) { delete c; return nullptr; }
@@ -193,7 +194,7 @@ extern "C" lmono_scan_batch *lmono_batch_create(lmono_ctx *c, int n_cap, int64_t
     ok = ok && dalloc(b, v.ring_begin, N * 65) && dalloc(b, v.n_cloud, N) && dalloc(b, v.status, N);
     ok = ok && dalloc(b, v.sel_sharp, N * 64 * 6 * 20) && dalloc(b, v.sel_sharp_n, N * 64 * 6);
     ok = ok && dalloc(b, v.sel_flat, N * 64 * 6 * 4) && dalloc(b, v.sel_flat_n, N * 64 * 6);
-    ok = ok && dalloc(b, v.lf_tmp, T) && dalloc(b, v.lf_n, N * 64) && dalloc(b, v.vox_todo, N * 64 + 1) && dalloc(b, v.sel_todo, N * 64 + 1);
+    ok = ok && dalloc(b, v.lf_tmp, T) && dalloc(b, v.lf_n, N * 64) && dalloc(b, v.vox_todo, N * 64 + 1) && dalloc(b, v.sel_todo, N * 64 + 1) && dalloc(b, v.li_todo, N * 2 + 1);
     ok = ok && dalloc(b, v.sharp, N * kMaxSharp) && dalloc(b, v.less_sharp, N * kMaxLessSharp);
     ok = ok && dalloc(b, v.flat, N * kMaxFlat) && dalloc(b, v.less_flat, T);
     ok = ok && dalloc(b, v.feat_n, N * 4) && dalloc(b, v.line_first_ge, N * 2 * 66) && dalloc(b, v.line_last_le, N * 2 * 66);
@@ -275,6 +276,7 @@ extern "C" int lmono_scanreg_batch(lmono_ctx *c, lmono_scan_batch *b, const floa
     HIP_TRY(c, hipMemsetAsync(v.status, 0, sizeof(int) * n_scans, st));
     HIP_TRY(c, hipMemsetAsync(v.vox_todo, 0, sizeof(int), st));
     HIP_TRY(c, hipMemsetAsync(v.sel_todo, 0, sizeof(int), st));
+    HIP_TRY(c, hipMemsetAsync(v.li_todo, 0, sizeof(int), st));
     HIP_TRY(c, hipEventRecord(c->ev[0], st));
     hipLaunchKernelGGL(k_ring_sort, dim3(n_scans), dim3(kRsT), 0, st, v);
     HIP_TRY(c, hipEventRecord(c->ev[1], st));
@@ -301,7 +303,8 @@ extern "C" int lmono_scanreg_batch(lmono_ctx *c, lmono_scan_batch *b, const floa
         b->grid_built = true; v.has_grid = 1;
     }
     HIP_TRY(c, hipEventRecord(c->ev[6], st));
-    hipLaunchKernelGGL(k_line_index, dim3(n_scans, 2), dim3(kLiT), kLiLds, st, v);
+    hipLaunchKernelGGL(k_line_index<true>, dim3(n_scans, 2), dim3(kLiT), kLiLdsHalf, st, v);
+    hipLaunchKernelGGL(k_line_index<false>, dim3(kLiBigGrid), dim3(kLiT), kLiLdsFull, st, v);
     HIP_TRY(c, hipEventRecord(c->ev[7], st));
     int rc = check_launch(c, "scanreg kernels");
     if (rc) return rc;

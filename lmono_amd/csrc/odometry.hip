@@ -475,19 +475,30 @@ __device__ __forceinline__ int f2ord(float f) { const int i = __float_as_int(f);
 __device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
 
 constexpr int kLiT = 1024;     // threads of k_line_index
-constexpr int kLiLds = kLineKeys * 4;   // dynamic LDS: one counter per (line, bin)
-__global__ __launch_bounds__(kLiT) void k_line_index(BatchView b)
+constexpr int kLiLdsHalf = kLineKeys * 2, kLiLdsFull = kLineKeys * 4;   // dynamic LDS: one 16-bit / 32-bit counter per (line, bin)
+constexpr int kLiBigGrid = 64;
+
+// One (scan, cloud): copy of the cloud counting-sorted by (line, azimuth bin), the (line, bin) start table, per-line elevation bounds.
+// kHalf: the counters are 16-bit halves of 32-bit LDS words (50 KB instead of 101 KB: three workgroups per CU instead of one --
+// the kernel is bound by its own dependent rounds, not by bytes); a cloud of more than 65535 points cannot be counted in 16 bits
+// and goes through the work list `li_todo` to the full-width launch (small fixed grid, normally empty).
+template <bool kHalf>
+__device__ __forceinline__ void line_index_cloud(const BatchView &b, int s, bool surf, int *s_cnt, int *s_wsum, int *s_emin, int *s_emax)
 {
-    const int s = blockIdx.x;
-    const bool surf = blockIdx.y == 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = b.feat_n[s * 4 + (surf ? 3 : 1)];
     const float4 *src = surf ? b.less_flat + b.off[s] : b.less_sharp + (size_t)s * kMaxLessSharp;
     float4 *dst = surf ? b.lbs_pts + b.off[s] : b.lbc_pts + (size_t)s * kMaxLessSharp;
     int *table = b.lb_start + (size_t)(s * 2 + (surf ? 1 : 0)) * (kLineKeys + 1);
-    extern __shared__ __align__(16) int s_cnt[];      // points per (line, bin); after the prefix: write cursor of the bucket
-    __shared__ int s_wsum[kLiT / 64], s_emin[66], s_emax[66];
-    for (int i = tid; i < kLineKeys; i += kLiT) s_cnt[i] = 0;
+    unsigned int *s_c32 = (unsigned int *)s_cnt;
+    constexpr int kWords = kHalf ? kLineKeys / 2 : kLineKeys;
+    static_assert(kLineKeys % 2 == 0, "two 16-bit counters per LDS word");
+    // counter `key`: add one, return the old value
+    auto bump = [&](int key) -> int {
+        if (kHalf) { const int sh = (key & 1) * 16; return (int)((atomicAdd(&s_c32[key >> 1], 1u << sh) >> sh) & 0xffffu); }
+        return atomicAdd(&s_cnt[key], 1);
+    };
+    for (int i = tid; i < kWords; i += kLiT) s_cnt[i] = 0;
     if (tid < 66) { s_emin[tid] = INT_MAX; s_emax[tid] = INT_MIN; }
     __syncthreads();
     // four points per thread and round, their loads in flight together.  A wave holds 64 consecutive points, which nearly always
@@ -500,7 +511,7 @@ __global__ __launch_bounds__(kLiT) void k_line_index(BatchView b)
         for (int q = 0; q < 4; q++) {
             const bool ok = base + tid + kLiT * q < n;
             const int ln = line_of(p[q].w);
-            if (ok) atomicAdd(&s_cnt[ln * kAzBins + az_bin(p[q].x, p[q].y)], 1);
+            if (ok) (void)bump(ln * kAzBins + az_bin(p[q].x, p[q].y));
             const unsigned long long act = __ballot(ok);
             if (act == 0ull) continue;
             const int eo = f2ord(elev_of(p[q].x, p[q].y, p[q].z));
@@ -526,18 +537,33 @@ __global__ __launch_bounds__(kLiT) void k_line_index(BatchView b)
         for (int v = tid; v < 66; v++) if (s_emin[v] != INT_MAX) B = fmaxf(B, ord2f(s_emax[v]));
         el[tid] = s_emin[tid] == INT_MAX ? make_float4(1e30f, -1e30f, A, B) : make_float4(ord2f(s_emin[tid]), ord2f(s_emax[tid]), A, B);
     }
-    // exclusive prefix over the kLineKeys counters: kPer consecutive counters per thread (last threads padded)
-    constexpr int kPer = (kLineKeys + kLiT - 1) / kLiT;
+    // exclusive prefix over the kLineKeys counters: kPer consecutive counters per thread (kPer even: whole LDS words; last threads padded)
+    constexpr int kPer = (((kLineKeys + kLiT - 1) / kLiT) + 1) & ~1;
+    auto get = [&](int idx) -> int { return kHalf ? (int)((s_c32[idx >> 1] >> ((idx & 1) * 16)) & 0xffffu) : s_cnt[idx]; };
     int local = 0;
-    for (int i = 0; i < kPer; i++) { const int idx = tid * kPer + i; if (idx < kLineKeys) local += s_cnt[idx]; }
+    for (int i = 0; i < kPer; i++) { const int idx = tid * kPer + i; if (idx < kLineKeys) local += get(idx); }
     const int incl = wave_scan_incl(local);
     if (lane == 63) s_wsum[wave] = incl;
     __syncthreads();
     int run = incl - local;
     for (int w = 0; w < wave; w++) run += s_wsum[w];
-    for (int i = 0; i < kPer; i++) {
-        const int idx = tid * kPer + i;
-        if (idx < kLineKeys) { const int cnt = s_cnt[idx]; s_cnt[idx] = run; table[idx] = run; run += cnt; }
+    if (kHalf) {
+        // a thread owns whole words (kPer is even): no other thread touches them here.  Cursors are < n <= 65535.
+        for (int i = 0; i < kPer; i += 2) {
+            const int idx = tid * kPer + i;
+            if (idx < kLineKeys) {
+                const unsigned int wv = s_c32[idx >> 1];
+                const int c0 = (int)(wv & 0xffffu), c1 = (int)(wv >> 16);
+                table[idx] = run; table[idx + 1] = run + c0;
+                s_c32[idx >> 1] = (unsigned int)run | ((unsigned int)(run + c0) << 16);
+                run += c0 + c1;
+            }
+        }
+    } else {
+        for (int i = 0; i < kPer; i++) {
+            const int idx = tid * kPer + i;
+            if (idx < kLineKeys) { const int cnt = s_cnt[idx]; s_cnt[idx] = run; table[idx] = run; run += cnt; }
+        }
     }
     if (tid == kLiT - 1) table[kLineKeys] = n;
     __syncthreads();
@@ -549,10 +575,33 @@ __global__ __launch_bounds__(kLiT) void k_line_index(BatchView b)
         for (int q = 0; q < 4; q++) {
             const int i = i0 + kLiT * q;
             if (i < n) {
-                const int key = line_of(p[q].w) * kAzBins + az_bin(p[q].x, p[q].y);
-                const int d = atomicAdd(&s_cnt[key], 1);
+                const int d = bump(line_of(p[q].w) * kAzBins + az_bin(p[q].x, p[q].y));
                 dst[d] = make_float4(p[q].x, p[q].y, p[q].z, __int_as_float(i));
             }
+        }
+    }
+}
+
+// from_list = 0: grid (n_scans, 2), 16-bit counters, clouds of more than 65535 points deferred; 1: kLiBigGrid workgroups over the list
+template <bool kHalf>
+__global__ __launch_bounds__(kLiT) void k_line_index(BatchView b)
+{
+    extern __shared__ __align__(16) int s_cnt[];      // points per (line, bin); after the prefix: write cursor of the bucket
+    __shared__ int s_wsum[kLiT / 64], s_emin[66], s_emax[66];
+    if (kHalf) {
+        const int s = blockIdx.x;
+        const bool surf = blockIdx.y == 1;
+        if (b.feat_n[s * 4 + (surf ? 3 : 1)] > 65535) {
+            if (threadIdx.x == 0) b.li_todo[1 + atomicAdd(&b.li_todo[0], 1)] = s * 2 + (surf ? 1 : 0);
+            return;
+        }
+        line_index_cloud<true>(b, s, surf, s_cnt, s_wsum, s_emin, s_emax);
+    } else {
+        const int n_todo = b.li_todo[0];
+        for (int k = blockIdx.x; k < n_todo; k += gridDim.x) {
+            const int e = b.li_todo[1 + k];
+            __syncthreads();                            // the previous cloud's scatter is done with the counters
+            line_index_cloud<false>(b, e >> 1, (e & 1) != 0, s_cnt, s_wsum, s_emin, s_emax);
         }
     }
 }

@@ -214,6 +214,24 @@ def test_odometry_dense_rings(oracle, gpu_ctx):
     assert np.array_equal(batch.correspond(1, q, t), corr[0])
 
 
+def test_line_index_full_width_counters_for_huge_clouds(oracle, gpu_ctx, full_seq):
+    """k_line_index counts in 16-bit halves; a less-flat cloud of more than 65535 points goes through its work list to the 32-bit
+    launch.  Scans stretched by 4 (0.2 m voxels merge almost nothing any more) have such clouds: same correspondences and odometry."""
+    xyzi = full_seq["xyzi"].copy(); off = full_seq["off"]
+    xyzi[:, :3] *= 4.0
+    batch = _register(gpu_ctx, xyzi, off)
+    cnt = batch.counts()
+    assert (cnt[:, 4] > 65535).all(), cnt[:, 4]
+    f = [oracle.scanreg(xyzi[off[s]:off[s + 1]]) for s in range(2)]
+    q = np.array([0.0, 0.0, 0.004, 1.0]); q /= np.linalg.norm(q)
+    t = np.array([2.9, 0.0, 0.0])
+    _, _, _, corr = oracle.odom_step(f[1]["sharp"], f[1]["flat"], f[0]["less_sharp"], f[0]["less_flat"], q, t, want_corr=True)
+    assert np.array_equal(batch.correspond(1, q, t), corr[0])
+    incr, poses = batch.odometry(1, 0)
+    ref = oracle.run_sequence(xyzi, off)
+    assert np.abs(incr - ref["incr"]).max() < 1e-8
+
+
 def test_chain_groups_on_streams_change_nothing(gpu_ctx, small_seq):
     """LMONO_OPT_ODOM_STREAMS on a small batch: groups need >= 32 chains each, so 6 chains stay on one stream whatever the option
     says (the grouped path itself is checked at 256 chains in test_full_sequence_gpu.py); same increments bit for bit."""
