@@ -73,4 +73,6 @@ def test_ill_conditioned_frames_stay_close(oracle, tmp_path):
         assert (int(row[1]), int(row[2]), int(row[3])) == (r[0], r[1], r[2]), "frame %d" % k
         assert (int(row[7]), int(row[8])) == (r[6], r[7]) and int(row[9]) == r[8], "frame %d" % k
     assert np.abs(odo[:8, 1:4] - ref[:8, 1:4]).max() < 1e-6          # identical up to the knife edge
-    assert np.abs(odo[:, 1:4] - ref[:, 1:4]).max() < 1e-3
+    d = np.abs(odo[:, 1:4] - ref[:, 1:4]).max()
+    print("ill-conditioned stream: max |dP| vs oracle %.2e m" % d)
+    assert d < 1e-3
