@@ -305,7 +305,7 @@ __global__ __launch_bounds__(64) void k_map_factor(const MapStream *streams, int
 
 // ---- solve -----------------------------------------------------------------------------------------------------------
 template <bool kJac>
-__device__ __forceinline__ void map_eval_block(const MapRec &R, const double *x, const double *Jp, LmAcc &acc)
+__device__ __forceinline__ void map_eval_block(const MapRec &R, const double *x, LmAcc &acc)
 {
     if (R.kind == 0) return;
     const bool edge = R.kind == 1;
@@ -342,26 +342,10 @@ __device__ __forceinline__ void map_eval_block(const MapRec &R, const double *x,
     acc.cost += 0.5 * rho0;
     if (!kJac) return;
     const double sr = sqrt(rho1);
-    const double ux = x[0], uy = x[1], uz = x[2], w = x[3];
-    const double cxv = uy * vz - uz * vy, cyv = uz * vx - ux * vz, czv = ux * vy - uy * vx;
-    double G[3][4];
-    const double V[3][3] = { { 0, -vz, vy }, { vz, 0, -vx }, { -vy, vx, 0 } };
-    const double U[3][3] = { { 0, -uz, uy }, { uz, 0, -ux }, { -uy, ux, 0 } };
-    const double Cx[3][3] = { { 0, -czv, cyv }, { czv, 0, -cxv }, { -cyv, cxv, 0 } };
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const double uv = U[i][0] * V[0][j] + U[i][1] * V[1][j] + U[i][2] * V[2][j];
-            G[i][j] = -2.0 * w * V[i][j] - 2.0 * Cx[i][j] - 2.0 * uv;
-        }
-    G[0][3] = 2.0 * cxv; G[1][3] = 2.0 * cyv; G[2][3] = 2.0 * czv;
-    double Gl[3][3];
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++)
-            Gl[i][j] = G[i][0] * Jp[j] + G[i][1] * Jp[3 + j] + G[i][2] * Jp[6 + j] + G[i][3] * Jp[9 + j];
+    // d lp / d(local rotation) = -2 [R v]_x: the product of the polynomial's 3 x 4 Jacobian with the plus-Jacobian of
+    // ceres::EigenQuaternionParameterization, to rounding (see eval_block in odometry.hip)
+    const double rx = lx - x[4], ry = ly - x[5], rz = lz - x[6];
+    const double Gl[3][3] = { { 0.0, 2.0 * rz, -2.0 * ry }, { -2.0 * rz, 0.0, 2.0 * rx }, { 2.0 * ry, -2.0 * rx, 0.0 } };
     for (int r = 0; r < nr; r++) {
         double J[6];
 #pragma unroll
@@ -377,11 +361,6 @@ template <bool kJac>
 __device__ __forceinline__ void map_evaluate(const MapRec *rec, int nq, const double *x, LmAcc &acc, double (*s_red)[28])
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double Jp[12];
-    Jp[0] = x[3];  Jp[1] = x[2];   Jp[2] = -x[1];
-    Jp[3] = -x[2]; Jp[4] = x[3];   Jp[5] = x[0];
-    Jp[6] = x[1];  Jp[7] = -x[0];  Jp[8] = x[3];
-    Jp[9] = -x[0]; Jp[10] = -x[1]; Jp[11] = -x[2];
     acc.cost = 0.0;
     if (kJac) {
 #pragma unroll
@@ -389,7 +368,7 @@ __device__ __forceinline__ void map_evaluate(const MapRec *rec, int nq, const do
 #pragma unroll
         for (int i = 0; i < 6; i++) acc.g[i] = 0.0;
     }
-    for (int qi = tid; qi < nq; qi += 1024) map_eval_block<kJac>(rec[qi], x, Jp, acc);
+    for (int qi = tid; qi < nq; qi += 1024) map_eval_block<kJac>(rec[qi], x, acc);
     acc.cost = wave_sum_d(acc.cost);
     if (kJac) {
 #pragma unroll
