@@ -1079,7 +1079,7 @@ __global__ __launch_bounds__(256, 4) void k_correspond_list(BatchView b, OdomVie
 // ------------------------------------------------------------------------------------------------
 // Residual blocks.  lp = q * cp + t (Eigen _transformVector polynomial); edge r = ((lp-a) x (lp-b)) / |a-b| (3 rows),
 // plane r = (lp - j) . n (1 row).  d r / d lp is constant: [b-a]_x / |a-b| and n^T.
-constexpr int kLmT = 256;   // threads per chain in k_lm_solve (512 measured slower: the serial trust-region part dominates)
+constexpr int kLmT = 256;   // threads per chain in k_lm_solve (512 measured slower, with and without register spills: reductions and the serial trust-region part dominate)
 constexpr int kLmW = kLmT / 64;
 struct LmAcc { double H[21]; double g[6]; double cost; };
 
@@ -1180,13 +1180,15 @@ __device__ __forceinline__ void eval_block(const float4 cp, const double2 P01, c
     }
 }
 
-// Sum over all residual blocks of a chain by the kLmT threads of its workgroup; every thread returns the same sums
-// (wave butterfly, then the wave partials are added in fixed order).  srec = the chain's records in LDS, one
-// plane of kMaxQueries float4 per record field (conflict-free 16-B reads).
+// Sum over all residual blocks of a chain by the kLmT threads of its workgroup (wave butterfly, then the wave partials are added in
+// fixed order); the sums -- H (21, upper triangle row by row), g (6), cost -- are left in LDS (s_sum) for every thread to read: the
+// trust-region code below keeps no copy of them in registers.  srec = the chain's records in LDS, one plane of kMaxQueries float4
+// per record field (conflict-free 16-B reads).
 template <bool kJac>
-__device__ __forceinline__ void evaluate_block(const float4 *srec, int nq, const double *x, LmAcc &acc, double (*s_red)[28])
+__device__ __forceinline__ void evaluate_block(const float4 *srec, int nq, const double *x, double (*s_red)[28], double *s_sum)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    LmAcc acc;
     acc.cost = 0.0;
     if (kJac) {
 #pragma unroll
@@ -1215,14 +1217,16 @@ __device__ __forceinline__ void evaluate_block(const float4 *srec, int nq, const
         }
     }
     __syncthreads();
-    acc.cost = 0.0;
-#pragma unroll
-    for (int w = 0; w < kLmW; w++) acc.cost += s_red[w][27];
-    if (kJac) {
-        for (int i = 0; i < 21; i++) { double t = 0.0; for (int w = 0; w < kLmW; w++) t += s_red[w][i]; acc.H[i] = t; }
-        for (int i = 0; i < 6; i++) { double t = 0.0; for (int w = 0; w < kLmW; w++) t += s_red[w][21 + i]; acc.g[i] = t; }
+    if (tid < 28 && (kJac || tid == 27)) {
+        double t = 0.0;
+        for (int w = 0; w < kLmW; w++) t += s_red[w][tid];
+        s_sum[tid] = t;
     }
+    __syncthreads();
 }
+
+// entry (i, j) of a symmetric 6 x 6 matrix stored as its upper triangle row by row (the order of accumulate_row)
+__device__ __forceinline__ int sym6(int i, int j) { const int a = i < j ? i : j, b = i < j ? j : i; return a * 6 - a * (a - 1) / 2 + (b - a); }
 
 __device__ __forceinline__ bool chol_solve6(const double *A, const double *bvec, double *xo)
 {
@@ -1238,6 +1242,38 @@ __device__ __forceinline__ bool chol_solve6(const double *A, const double *bvec,
     double y[6];
     for (int i = 0; i < 6; i++) { double s = bvec[i]; for (int k = 0; k < i; k++) s -= L[i * 6 + k] * y[k]; y[i] = s / L[i * 6 + i]; }
     for (int i = 5; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < 6; k++) s -= L[k * 6 + i] * xo[k]; xo[i] = s / L[i * 6 + i]; }
+    return true;
+}
+
+// The same factorisation and substitutions on the LOWER triangle stored row by row (entry (i, j), j <= i, at i (i + 1) / 2 + j),
+// in place: 21 doubles instead of two 6 x 6 arrays, same operations in the same order.
+__device__ __forceinline__ bool chol_solve6_packed(double *L, const double *bvec, double *xo)
+{
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++) {
+            double s = L[i * (i + 1) / 2 + j];
+#pragma unroll
+            for (int k = 0; k < j; k++) s -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
+            if (i == j) { if (!(s > 0.0)) return false; L[i * (i + 1) / 2 + i] = sqrt(s); }
+            else L[i * (i + 1) / 2 + j] = s / L[j * (j + 1) / 2 + j];
+        }
+    double y[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        double s = bvec[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) s -= L[i * (i + 1) / 2 + k] * y[k];
+        y[i] = s / L[i * (i + 1) / 2 + i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; i--) {
+        double s = y[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; k++) s -= L[k * (k + 1) / 2 + i] * xo[k];
+        xo[i] = s / L[i * (i + 1) / 2 + i];
+    }
     return true;
 }
 
@@ -1282,7 +1318,7 @@ __global__ __launch_bounds__(kLmT) void k_lm_solve(BatchView b, OdomView o, int 
     int s;
     const int k = chain_scan(o, c, step, s);
     if (k < 0) return;
-    __shared__ double s_red[kLmW][28];
+    __shared__ double s_red[kLmW][28], s_sum[28], s_cur[28];
     __shared__ int s_used[kLmW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nq = b.feat_n[k * 4 + 0] + b.feat_n[k * 4 + 2];
@@ -1318,37 +1354,44 @@ __global__ __launch_bounds__(kLmT) void k_lm_solve(BatchView b, OdomView o, int 
     double radius = 1e4, decrease_factor = 2.0;
     bool reuse_diagonal = false;
     int invalid_steps = 0, iter = 0;
-    LmAcc acc;
-    evaluate_block<true>(s_rec, nq, x, acc, s_red);
-    double x_cost = acc.cost;
-    double H[36], g[6], scale[6], diag[6];
-    unpack_sym(acc.H, H);
-    for (int i = 0; i < 6; i++) g[i] = acc.g[i];
+    // The accepted linearisation (H, g, cost) lives in LDS (s_cur), a candidate's in s_sum: every thread runs the uniform trust-region
+    // arithmetic on the same LDS numbers, and only the scaled, damped system of the current iteration is ever in registers -- with
+    // H, Hs, a second matrix for the factor and two accumulator sets per thread the kernel needed ~350 registers and could not run
+    // two waves per SIMD.
+    evaluate_block<true>(s_rec, nq, x, s_red, s_sum);
+    if (tid < 28) s_cur[tid] = s_sum[tid];
     n_used = wave_sum_i(n_used);
     if (lane == 0) s_used[wave] = n_used;
     __syncthreads();
+    double x_cost = s_cur[27];
+    double scale[6], diag[6];
     n_used = 0;
     for (int w = 0; w < kLmW; w++) n_used += s_used[w];
     double gmax = 0.0;
-    for (int i = 0; i < 6; i++) gmax = fmax(gmax, fabs(g[i]));
+    for (int i = 0; i < 6; i++) gmax = fmax(gmax, fabs(s_cur[21 + i]));
     if (n_used > 0 && gmax > gradient_tol) {
         double x_norm = norm7(x);
-        for (int i = 0; i < 6; i++) scale[i] = 1.0 / (1.0 + sqrt(H[i * 6 + i]));
+        for (int i = 0; i < 6; i++) scale[i] = 1.0 / (1.0 + sqrt(s_cur[sym6(i, i)]));
         while (iter < max_iter) {
             iter++;
-            double Hs[36], gs[6], A[36], stepv[6];
-            for (int i = 0; i < 6; i++) { gs[i] = g[i] * scale[i]; for (int j = 0; j < 6; j++) Hs[i * 6 + j] = H[i * 6 + j] * scale[i] * scale[j]; }
+            double gs[6], A[21], stepv[6];
+            // lower triangle of A = Hs = H scale_i scale_j, then + diag / radius on the diagonal
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                gs[i] = s_cur[21 + i] * scale[i];
+#pragma unroll
+                for (int j = 0; j <= i; j++) A[i * (i + 1) / 2 + j] = s_cur[sym6(i, j)] * scale[i] * scale[j];
+            }
             if (!reuse_diagonal)
-                for (int i = 0; i < 6; i++) { double d = Hs[i * 6 + i]; d = d < min_diag ? min_diag : d; d = d > max_diag ? max_diag : d; diag[i] = d; }
-            for (int i = 0; i < 36; i++) A[i] = Hs[i];
-            for (int i = 0; i < 6; i++) A[i * 6 + i] += diag[i] / radius;
-            bool ok = chol_solve6(A, gs, stepv);
+                for (int i = 0; i < 6; i++) { double d = A[i * (i + 1) / 2 + i]; d = d < min_diag ? min_diag : d; d = d > max_diag ? max_diag : d; diag[i] = d; }
+            for (int i = 0; i < 6; i++) A[i * (i + 1) / 2 + i] += diag[i] / radius;
+            bool ok = chol_solve6_packed(A, gs, stepv);
             for (int i = 0; i < 6; i++) if (!isfinite(stepv[i])) ok = false;
             double model_change = 0.0;
             if (ok) {
                 for (int i = 0; i < 6; i++) stepv[i] = -stepv[i];
                 double dg = 0.0, dHd = 0.0;
-                for (int i = 0; i < 6; i++) { dg += stepv[i] * gs[i]; for (int j = 0; j < 6; j++) dHd += stepv[i] * Hs[i * 6 + j] * stepv[j]; }
+                for (int i = 0; i < 6; i++) { dg += stepv[i] * gs[i]; for (int j = 0; j < 6; j++) dHd += stepv[i] * (s_cur[sym6(i, j)] * scale[i] * scale[j]) * stepv[j]; }
                 model_change = -(dg + 0.5 * dHd);
             }
             if (!ok || !(model_change > 0.0)) {
@@ -1361,12 +1404,12 @@ __global__ __launch_bounds__(kLmT) void k_lm_solve(BatchView b, OdomView o, int 
             for (int i = 0; i < 6; i++) delta[i] = stepv[i] * scale[i];
             manifold_plus(x, delta, cand);
             // The candidate is evaluated WITH its Jacobian (it is accepted almost always, and then this is the linearisation of
-            // the next iteration -- the same numbers a separate pass would give); the last iteration only needs the cost.
+            // the next iteration -- the same numbers a separate pass would give).  The last iteration only needs the cost, but a
+            // second, cost-only copy of the sweep inside this loop costs the kernel its second wave per SIMD (81 spilled registers).
             const bool last = iter == max_iter;
-            LmAcc ca;
-            if (last) evaluate_block<false>(s_rec, nq, cand, ca, s_red);
-            else evaluate_block<true>(s_rec, nq, cand, ca, s_red);
-            const double cand_cost = ca.cost;
+            if (last) evaluate_block<false>(s_rec, nq, cand, s_red, s_sum);
+            else evaluate_block<true>(s_rec, nq, cand, s_red, s_sum);
+            const double cand_cost = s_sum[27];
             double sn = 0.0;
             for (int i = 0; i < 7; i++) sn += (x[i] - cand[i]) * (x[i] - cand[i]);
             sn = sqrt(sn);
@@ -1377,9 +1420,10 @@ __global__ __launch_bounds__(kLmT) void k_lm_solve(BatchView b, OdomView o, int 
                 for (int i = 0; i < 7; i++) x[i] = cand[i];
                 if (last) break;                 // nothing after the last accepted step is used
                 x_norm = norm7(x);
-                x_cost = ca.cost;
-                unpack_sym(ca.H, H);
-                for (int i = 0; i < 6; i++) g[i] = ca.g[i];
+                x_cost = cand_cost;
+                __syncthreads();                 // every thread has read the old linearisation
+                if (tid < 28) s_cur[tid] = s_sum[tid];
+                __syncthreads();
                 const double tt = 2.0 * rel - 1.0;
                 double den = 1.0 - tt * tt * tt;
                 if (den < 1.0 / 3.0) den = 1.0 / 3.0;
@@ -1387,7 +1431,7 @@ __global__ __launch_bounds__(kLmT) void k_lm_solve(BatchView b, OdomView o, int 
                 if (radius > max_radius) radius = max_radius;
                 decrease_factor = 2.0; reuse_diagonal = false;
                 gmax = 0.0;
-                for (int i = 0; i < 6; i++) gmax = fmax(gmax, fabs(g[i]));
+                for (int i = 0; i < 6; i++) gmax = fmax(gmax, fabs(s_cur[21 + i]));
                 if (gmax <= gradient_tol) break;
             } else {
                 radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
