@@ -165,6 +165,41 @@ def test_device_resident_mapper_follows_the_oracle(oracle, gpu_ctx):
     assert n_pts > 20000
 
 
+def test_failed_frame_leaves_the_mapper_as_it_was(oracle, gpu_ctx, full_seq):
+    """A frame that fails AFTER the cube array was shifted (a scan cloud beyond the 65536-point stack, offered at a pose 300 m away) must not
+    change the mapper: the following frames give the poses, bit for bit, of a mapper that never saw the failing call."""
+    import torch
+    import lmono_amd
+    w = oracle.S1World(n_az=500)
+    traj = w.trajectory(6)
+    x, off = w.scans(traj)
+    xd = torch.from_numpy(x).cuda()
+    batch = lmono_amd.ScanBatch(gpu_ctx, 6, len(x))
+    batch.scanreg(xd.data_ptr(), off, 64, 5.0, keepalive=xd)
+    _, odo = batch.odometry(n_chains=1, lead=0)
+    big = full_seq["xyzi"][full_seq["off"][0]:full_seq["off"][1]].copy()
+    big[:, :3] *= 4.0                                   # less-flat cloud > 65536 points (test_lidar_gpu.py)
+    bd = torch.from_numpy(big).cuda()
+    bad = lmono_amd.ScanBatch(gpu_ctx, 1, len(big))
+    bad.scanreg(bd.data_ptr(), np.array([0, len(big)], np.int64), 64, 5.0, keepalive=bd)
+    assert bad.counts()[0, 4] > 65536
+    ref, tst = lmono_amd.Mapper(gpu_ctx), lmono_amd.Mapper(gpu_ctx)
+    out = {id(ref): [], id(tst): []}
+    for k in range(6):
+        for m in (ref, tst):
+            q, t, st = m.process(batch, k, odo[k, :4], odo[k, 4:])
+            out[id(m)].append(np.concatenate([q, t]))
+        if k == 2:
+            with pytest.raises(lmono_amd.LmonoError):
+                tst.process(bad, 0, np.array([0.0, 0.0, 0.0, 1.0]), np.array([300.0, -200.0, 0.0]))
+    assert np.array_equal(np.array(out[id(ref)]), np.array(out[id(tst)]))
+    for which in (0, 1):
+        for i in (9, 10, 11):
+            for j in (9, 10, 11):
+                a, bq = ref.cube(which, i, j, 5), tst.cube(which, i, j, 5)
+                assert a.shape == bq.shape and np.array_equal(a, bq)
+
+
 def test_batched_streams_match_their_single_stream_oracles(oracle, gpu_ctx):
     """lmono_mapper_process_batch: three independent streams (two different worlds, one of them twice) advanced in
     lock-step, each against oracle.run_mapping of its own sequence."""
