@@ -1083,8 +1083,25 @@ constexpr int kLmT = 256;   // threads per chain in k_lm_solve (512 measured slo
 constexpr int kLmW = kLmT / 64;
 struct LmAcc { double H[21]; double g[6]; double cost; };
 
+// The LM solve below (accumulate_row .. k_lm_solve) allows contraction to FMA: its parity bar is a tolerance (1e-9 against the oracle's
+// loop), and with -ffp-contract=off every a * b + c of the 6 x 6 normal equations is two dependent instructions on the one wave per
+// SIMD that runs a chain's solve.  The de-skew transform of the SEARCH (quat_rotate in the correspondence kernels) stays uncontracted:
+// its float result must equal the oracle's bit for bit.
+__device__ __forceinline__ void quat_rotate_fma(const double *q, double vx, double vy, double vz, double &ox, double &oy, double &oz)
+{
+#pragma clang fp contract(fast)
+    const double ux = q[0], uy = q[1], uz = q[2], w = q[3];
+    const double uvx = 2.0 * (uy * vz - uz * vy);
+    const double uvy = 2.0 * (uz * vx - ux * vz);
+    const double uvz = 2.0 * (ux * vy - uy * vx);
+    ox = vx + w * uvx + (uy * uvz - uz * uvy);
+    oy = vy + w * uvy + (uz * uvx - ux * uvz);
+    oz = vz + w * uvz + (ux * uvy - uy * uvx);
+}
+
 __device__ __forceinline__ void accumulate_row(LmAcc &a, const double *J, double r)
 {
+#pragma clang fp contract(fast)
     int t = 0;
 #pragma unroll
     for (int i = 0; i < 6; i++) {
@@ -1128,56 +1145,48 @@ __device__ __forceinline__ void stage_block(const float4 cp, const float4 A, con
     }
 }
 
-template <bool kJac>
-__device__ __forceinline__ void eval_block(const float4 cp, const double2 P01, const double2 P23, const double2 P45, const double *x, LmAcc &acc)
+// One Jacobian row of a residual block: d r / d lp = d (3-vector), scaled by sr.  d lp / d(local rotation) = -2 [R v]_x: the reference
+// differentiates the polynomial lp = v + 2 w (u x v) + 2 u x (u x v) with respect to the four quaternion components and multiplies by
+// the 4 x 3 plus-Jacobian of ceres::EigenQuaternionParameterization (x_new = (delta, 1) (x) x, a rotation by 2 |delta| in front of R);
+// along those tangent directions the product is the derivative of the rotation itself -- the same numbers to rounding (7e-15 on entries
+// of magnitude 20).  So the rotation part of the row is d^T (-2 [rv]_x) = 2 (rv x d), the translation part d.
+__device__ __forceinline__ void lm_row(LmAcc &acc, double d0, double d1, double d2, double rvx, double rvy, double rvz, double res, double sr)
 {
-    const int kind = __float_as_int(cp.w);
-    if (kind == 0) return;
-    const bool edge = kind == 1;
+#pragma clang fp contract(fast)
+    double J[6];
+    const double s2 = 2.0 * sr;
+    J[0] = (rvy * d2 - rvz * d1) * s2; J[1] = (rvz * d0 - rvx * d2) * s2; J[2] = (rvx * d1 - rvy * d0) * s2;
+    J[3] = d0 * sr; J[4] = d1 * sr; J[5] = d2 * sr;
+    accumulate_row(acc, J, res * sr);
+}
+
+// One residual block at the pose (Rm = rotation matrix of x's quaternion, row-major; x[4..6] = translation), as straight-line code per
+// kind: the generic form (a rows loop of run-time length over a 3 x 3 derivative array) cost ~300 instructions per plane and ~460 per
+// edge on the one wave per SIMD that runs a chain's solve.
+template <bool kJac, bool kEdge>
+__device__ __forceinline__ void eval_block(const float4 cp, const double2 P01, const double2 P23, const double2 P45, const double *Rm, const double *x, LmAcc &acc)
+{
+#pragma clang fp contract(fast)
+    if (__float_as_int(cp.w) == 0) return;
     const double vx = (double)cp.x, vy = (double)cp.y, vz = (double)cp.z;
-    double lx, ly, lz;
-    quat_rotate(x, vx, vy, vz, lx, ly, lz);
-    lx += x[4]; ly += x[5]; lz += x[6];
-    double res[3], D[3][3];   // D = d res / d lp
-    int nr;
-    const double dx = lx - P01.x, dy = ly - P01.y, dz = lz - P23.x;     // lp - a  /  lp - j
-    const double qx = P23.y, qy = P45.x, qz = P45.y;                    // e^      /  n
-    if (edge) {
-        res[0] = dy * qz - dz * qy; res[1] = dz * qx - dx * qz; res[2] = dx * qy - dy * qx;
-        if (kJac) {
-            D[0][0] = 0.0; D[0][1] = qz;  D[0][2] = -qy;
-            D[1][0] = -qz; D[1][1] = 0.0; D[1][2] = qx;
-            D[2][0] = qy;  D[2][1] = -qx; D[2][2] = 0.0;
-        }
-        nr = 3;
-    } else {
-        res[0] = dx * qx + dy * qy + dz * qz;
-        if (kJac) { D[0][0] = qx; D[0][1] = qy; D[0][2] = qz; }
-        nr = 1;
-    }
-    double sq = 0.0;
-    for (int r = 0; r < nr; r++) sq += res[r] * res[r];
+    const double rvx = Rm[0] * vx + Rm[1] * vy + Rm[2] * vz, rvy = Rm[3] * vx + Rm[4] * vy + Rm[5] * vz, rvz = Rm[6] * vx + Rm[7] * vy + Rm[8] * vz;
+    const double dx = rvx + x[4] - P01.x, dy = rvy + x[5] - P01.y, dz = rvz + x[6] - P23.x;     // lp - a  /  lp - j
+    const double qx = P23.y, qy = P45.x, qz = P45.y;                                            // e^      /  n
+    double r0, r1 = 0.0, r2 = 0.0, sq;
+    if (kEdge) { r0 = dy * qz - dz * qy; r1 = dz * qx - dx * qz; r2 = dx * qy - dy * qx; sq = r0 * r0 + r1 * r1 + r2 * r2; }
+    else { r0 = dx * qx + dy * qy + dz * qz; sq = r0 * r0; }
     double rho0, rho1;
     huber(sq, rho0, rho1);
     acc.cost += 0.5 * rho0;
     if (!kJac) return;
     const double sr = rho1 == 1.0 ? 1.0 : sqrt(rho1);      // inliers: sqrt(1) = 1 exactly, without the 25-instruction fp64 square root
-    // d lp / d(local rotation).  The reference differentiates the polynomial lp = v + 2 w (u x v) + 2 u x (u x v) with respect to the four
-    // quaternion components and multiplies by the 4 x 3 plus-Jacobian of ceres::EigenQuaternionParameterization (x_new = (delta, 1) (x) x,
-    // a rotation by 2 |delta| in front of R): 63 multiply-adds per residual block and evaluation.  Along those tangent directions the
-    // product is the derivative of the rotation itself, d ((I + 2 [delta]_x) R v) / d delta = -2 [R v]_x -- the same numbers to rounding
-    // (7e-15 on entries of magnitude 20), from the rotated point that is already there.
-    const double rx = lx - x[4], ry = ly - x[5], rz = lz - x[6];          // R v
-    const double Gl[3][3] = { { 0.0, 2.0 * rz, -2.0 * ry }, { -2.0 * rz, 0.0, 2.0 * rx }, { 2.0 * ry, -2.0 * rx, 0.0 } };
-    for (int r = 0; r < nr; r++) {
-        double J[6];
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            J[j] = (D[r][0] * Gl[0][j] + D[r][1] * Gl[1][j] + D[r][2] * Gl[2][j]) * sr;
-            J[3 + j] = D[r][j] * sr;
-        }
-        accumulate_row(acc, J, res[r] * sr);
-    }
+    if (kEdge) {
+        // rows of d r / d lp = -[e^]_x
+        lm_row(acc, 0.0, qz, -qy, rvx, rvy, rvz, r0, sr);
+        lm_row(acc, -qz, 0.0, qx, rvx, rvy, rvz, r1, sr);
+        lm_row(acc, qy, -qx, 0.0, rvx, rvy, rvz, r2, sr);
+    } else
+        lm_row(acc, qx, qy, qz, rvx, rvy, rvz, r0, sr);
 }
 
 // Sum over all residual blocks of a chain by the kLmT threads of its workgroup (wave butterfly, then the wave partials are added in
@@ -1185,7 +1194,7 @@ __device__ __forceinline__ void eval_block(const float4 cp, const double2 P01, c
 // trust-region code below keeps no copy of them in registers.  srec = the chain's records in LDS, one plane of kMaxQueries float4
 // per record field (conflict-free 16-B reads).
 template <bool kJac>
-__device__ __forceinline__ void evaluate_block(const float4 *srec, int nq, const double *x, double (*s_red)[28], double *s_sum)
+__device__ __forceinline__ void evaluate_block(const float4 *srec, int n_edge, int nq, const double *x, double (*s_red)[28], double *s_sum)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     LmAcc acc;
@@ -1196,11 +1205,23 @@ __device__ __forceinline__ void evaluate_block(const float4 *srec, int nq, const
 #pragma unroll
         for (int i = 0; i < 6; i++) acc.g[i] = 0.0;
     }
-    for (int qi = tid; qi < nq; qi += kLmT)
+    // rotation matrix of the pose's quaternion (uniform; once per sweep instead of a quaternion rotation per block)
+    double Rm[9];
     {
-        const double2 *sp = (const double2 *)srec;
-        eval_block<kJac>(srec[qi], sp[kMaxQueries + qi], sp[2 * kMaxQueries + qi], sp[3 * kMaxQueries + qi], x, acc);
+#pragma clang fp contract(fast)
+        const double ux = x[0], uy = x[1], uz = x[2], w = x[3];
+        Rm[0] = 1.0 - 2.0 * (uy * uy + uz * uz); Rm[1] = 2.0 * (ux * uy - w * uz);       Rm[2] = 2.0 * (ux * uz + w * uy);
+        Rm[3] = 2.0 * (ux * uy + w * uz);       Rm[4] = 1.0 - 2.0 * (ux * ux + uz * uz); Rm[5] = 2.0 * (uy * uz - w * ux);
+        Rm[6] = 2.0 * (ux * uz - w * uy);       Rm[7] = 2.0 * (uy * uz + w * ux);       Rm[8] = 1.0 - 2.0 * (ux * ux + uy * uy);
     }
+    // a thread visits its blocks in ascending order as before (edge blocks are the first n_edge of a chain's list), but every loop body
+    // is one kind: no divergence inside a wave except at unused blocks
+    const double2 *sp = (const double2 *)srec;
+    int qi = tid;
+    for (; qi < n_edge; qi += kLmT)
+        eval_block<kJac, true>(srec[qi], sp[kMaxQueries + qi], sp[2 * kMaxQueries + qi], sp[3 * kMaxQueries + qi], Rm, x, acc);
+    for (; qi < nq; qi += kLmT)
+        eval_block<kJac, false>(srec[qi], sp[kMaxQueries + qi], sp[2 * kMaxQueries + qi], sp[3 * kMaxQueries + qi], Rm, x, acc);
     acc.cost = wave_sum_d(acc.cost);
     if (kJac) {
 #pragma unroll
@@ -1249,6 +1270,7 @@ __device__ __forceinline__ bool chol_solve6(const double *A, const double *bvec,
 // in place: 21 doubles instead of two 6 x 6 arrays, same operations in the same order.
 __device__ __forceinline__ bool chol_solve6_packed(double *L, const double *bvec, double *xo)
 {
+#pragma clang fp contract(fast)
 #pragma unroll
     for (int i = 0; i < 6; i++)
 #pragma unroll
@@ -1321,7 +1343,7 @@ __global__ __launch_bounds__(kLmT) void k_lm_solve(BatchView b, OdomView o, int 
     __shared__ double s_red[kLmW][28], s_sum[28], s_cur[28];
     __shared__ int s_used[kLmW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nq = b.feat_n[k * 4 + 0] + b.feat_n[k * 4 + 2];
+    const int n_edge = b.feat_n[k * 4 + 0], nq = n_edge + b.feat_n[k * 4 + 2];
     const float4 *crec = o.crec + (size_t)c * kMaxQueries * 4;
     // the chain's residual-block records (64 B each, <= 144 KB) are read once and stay in LDS for the up to nine
     // evaluations of this launch; eight 16-B loads per thread in flight
@@ -1358,7 +1380,7 @@ __global__ __launch_bounds__(kLmT) void k_lm_solve(BatchView b, OdomView o, int 
     // arithmetic on the same LDS numbers, and only the scaled, damped system of the current iteration is ever in registers -- with
     // H, Hs, a second matrix for the factor and two accumulator sets per thread the kernel needed ~350 registers and could not run
     // two waves per SIMD.
-    evaluate_block<true>(s_rec, nq, x, s_red, s_sum);
+    evaluate_block<true>(s_rec, n_edge, nq, x, s_red, s_sum);
     if (tid < 28) s_cur[tid] = s_sum[tid];
     n_used = wave_sum_i(n_used);
     if (lane == 0) s_used[wave] = n_used;
@@ -1407,8 +1429,8 @@ __global__ __launch_bounds__(kLmT) void k_lm_solve(BatchView b, OdomView o, int 
             // the next iteration -- the same numbers a separate pass would give).  The last iteration only needs the cost, but a
             // second, cost-only copy of the sweep inside this loop costs the kernel its second wave per SIMD (81 spilled registers).
             const bool last = iter == max_iter;
-            if (last) evaluate_block<false>(s_rec, nq, cand, s_red, s_sum);
-            else evaluate_block<true>(s_rec, nq, cand, s_red, s_sum);
+            if (last) evaluate_block<false>(s_rec, n_edge, nq, cand, s_red, s_sum);
+            else evaluate_block<true>(s_rec, n_edge, nq, cand, s_red, s_sum);
             const double cand_cost = s_sum[27];
             double sn = 0.0;
             for (int i = 0; i < 7; i++) sn += (x[i] - cand[i]) * (x[i] - cand[i]);
