@@ -304,63 +304,58 @@ __global__ __launch_bounds__(64) void k_map_factor(const MapStream *streams, int
 }
 
 // ---- solve -----------------------------------------------------------------------------------------------------------
-template <bool kJac>
-__device__ __forceinline__ void map_eval_block(const MapRec &R, const double *x, LmAcc &acc)
+// Same structure as k_lm_solve (odometry.hip): straight-line edge / plane-norm blocks over a per-sweep rotation matrix, the rotation
+// part of a Jacobian row as 2 (Rv x d), the accepted / candidate sums in LDS, packed in-place Cholesky.  No FMA contraction here: the
+// tests compare this kernel's LM iteration counts with the oracle's, and a contracted trace can stop one iteration apart on a knife edge.
+__device__ __forceinline__ void map_row(LmAcc &acc, double d0, double d1, double d2, double rvx, double rvy, double rvz, double res, double sr)
+{
+    double J[6];
+    const double s2 = 2.0 * sr;
+    J[0] = (rvy * d2 - rvz * d1) * s2; J[1] = (rvz * d0 - rvx * d2) * s2; J[2] = (rvx * d1 - rvy * d0) * s2;
+    J[3] = d0 * sr; J[4] = d1 * sr; J[5] = d2 * sr;
+    accumulate_row(acc, J, res * sr);
+}
+
+template <bool kJac, bool kEdge>
+__device__ __forceinline__ void map_eval_block(const MapRec &R, const double *Rm, const double *x, LmAcc &acc)
 {
     if (R.kind == 0) return;
-    const bool edge = R.kind == 1;
     const double vx = R.cp[0], vy = R.cp[1], vz = R.cp[2];
-    double lx, ly, lz;
-    quat_rotate(x, vx, vy, vz, lx, ly, lz);
-    lx += x[4]; ly += x[5]; lz += x[6];
-    double res[3], D[3][3];
-    int nr;
-    if (edge) {
+    const double rvx = Rm[0] * vx + Rm[1] * vy + Rm[2] * vz, rvy = Rm[3] * vx + Rm[4] * vy + Rm[5] * vz, rvz = Rm[6] * vx + Rm[7] * vy + Rm[8] * vz;
+    const double lx = rvx + x[4], ly = rvy + x[5], lz = rvz + x[6];
+    double r0, r1 = 0.0, r2 = 0.0, sq, e0 = 0.0, e1 = 0.0, e2 = 0.0;
+    if (kEdge) {
         const double ax = lx - R.a[0], ay = ly - R.a[1], az = lz - R.a[2];
         const double bx = lx - R.b[0], by = ly - R.b[1], bz = lz - R.b[2];
-        const double nux = ay * bz - az * by, nuy = az * bx - ax * bz, nuz = ax * by - ay * bx;
         const double ex = R.a[0] - R.b[0], ey = R.a[1] - R.b[1], ez = R.a[2] - R.b[2];
         const double den = sqrt(ex * ex + ey * ey + ez * ez);
-        res[0] = nux / den; res[1] = nuy / den; res[2] = nuz / den;
-        if (kJac) {
-            const double inv = 1.0 / den;
-            D[0][0] = 0.0;       D[0][1] = ez * inv;  D[0][2] = -ey * inv;
-            D[1][0] = -ez * inv; D[1][1] = 0.0;       D[1][2] = ex * inv;
-            D[2][0] = ey * inv;  D[2][1] = -ex * inv; D[2][2] = 0.0;
-        }
-        nr = 3;
+        r0 = (ay * bz - az * by) / den; r1 = (az * bx - ax * bz) / den; r2 = (ax * by - ay * bx) / den;
+        sq = r0 * r0 + r1 * r1 + r2 * r2;
+        if (kJac) { const double inv = 1.0 / den; e0 = ex * inv; e1 = ey * inv; e2 = ez * inv; }
     } else {
         // LidarPlaneNormFactor: norm . point_w + negative_OA_dot_norm
-        res[0] = (R.b[0] * lx + R.b[1] * ly + R.b[2] * lz) + R.a[0];
-        if (kJac) { D[0][0] = R.b[0]; D[0][1] = R.b[1]; D[0][2] = R.b[2]; }
-        nr = 1;
+        r0 = (R.b[0] * lx + R.b[1] * ly + R.b[2] * lz) + R.a[0];
+        sq = r0 * r0;
     }
-    double sq = 0.0;
-    for (int r = 0; r < nr; r++) sq += res[r] * res[r];
     double rho0, rho1;
     huber(sq, rho0, rho1);
     acc.cost += 0.5 * rho0;
     if (!kJac) return;
     const double sr = rho1 == 1.0 ? 1.0 : sqrt(rho1);      // inliers: sqrt(1) = 1 exactly, without the 25-instruction fp64 square root
-    // d lp / d(local rotation) = -2 [R v]_x: the product of the polynomial's 3 x 4 Jacobian with the plus-Jacobian of
-    // ceres::EigenQuaternionParameterization, to rounding (see eval_block in odometry.hip)
-    const double rx = lx - x[4], ry = ly - x[5], rz = lz - x[6];
-    const double Gl[3][3] = { { 0.0, 2.0 * rz, -2.0 * ry }, { -2.0 * rz, 0.0, 2.0 * rx }, { 2.0 * ry, -2.0 * rx, 0.0 } };
-    for (int r = 0; r < nr; r++) {
-        double J[6];
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            J[j] = (D[r][0] * Gl[0][j] + D[r][1] * Gl[1][j] + D[r][2] * Gl[2][j]) * sr;
-            J[3 + j] = D[r][j] * sr;
-        }
-        accumulate_row(acc, J, res[r] * sr);
-    }
+    if (kEdge) {
+        map_row(acc, 0.0, e2, -e1, rvx, rvy, rvz, r0, sr);
+        map_row(acc, -e2, 0.0, e0, rvx, rvy, rvz, r1, sr);
+        map_row(acc, e1, -e0, 0.0, rvx, rvy, rvz, r2, sr);
+    } else
+        map_row(acc, R.b[0], R.b[1], R.b[2], rvx, rvy, rvz, r0, sr);
 }
 
+// sums of all residual blocks of a stream into LDS (s_sum: H 21 | g 6 | cost); blocks [0, n_edge) are the corner points' (edges)
 template <bool kJac>
-__device__ __forceinline__ void map_evaluate(const MapRec *rec, int nq, const double *x, LmAcc &acc, double (*s_red)[28])
+__device__ __forceinline__ void map_evaluate(const MapRec *rec, int n_edge, int nq, const double *x, double (*s_red)[28], double *s_sum)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    LmAcc acc;
     acc.cost = 0.0;
     if (kJac) {
 #pragma unroll
@@ -368,7 +363,16 @@ __device__ __forceinline__ void map_evaluate(const MapRec *rec, int nq, const do
 #pragma unroll
         for (int i = 0; i < 6; i++) acc.g[i] = 0.0;
     }
-    for (int qi = tid; qi < nq; qi += 1024) map_eval_block<kJac>(rec[qi], x, acc);
+    double Rm[9];
+    {
+        const double ux = x[0], uy = x[1], uz = x[2], w = x[3];
+        Rm[0] = 1.0 - 2.0 * (uy * uy + uz * uz); Rm[1] = 2.0 * (ux * uy - w * uz);       Rm[2] = 2.0 * (ux * uz + w * uy);
+        Rm[3] = 2.0 * (ux * uy + w * uz);       Rm[4] = 1.0 - 2.0 * (ux * ux + uz * uz); Rm[5] = 2.0 * (uy * uz - w * ux);
+        Rm[6] = 2.0 * (ux * uz - w * uy);       Rm[7] = 2.0 * (uy * uz + w * ux);       Rm[8] = 1.0 - 2.0 * (ux * ux + uy * uy);
+    }
+    int qi = tid;
+    for (; qi < n_edge; qi += 1024) map_eval_block<kJac, true>(rec[qi], Rm, x, acc);
+    for (; qi < nq; qi += 1024) map_eval_block<kJac, false>(rec[qi], Rm, x, acc);
     acc.cost = wave_sum_d(acc.cost);
     if (kJac) {
 #pragma unroll
@@ -385,22 +389,22 @@ __device__ __forceinline__ void map_evaluate(const MapRec *rec, int nq, const do
         }
     }
     __syncthreads();
-    acc.cost = 0.0;
-    for (int w = 0; w < 16; w++) acc.cost += s_red[w][27];
-    if (kJac) {
-        for (int i = 0; i < 21; i++) { double t = 0.0; for (int w = 0; w < 16; w++) t += s_red[w][i]; acc.H[i] = t; }
-        for (int i = 0; i < 6; i++) { double t = 0.0; for (int w = 0; w < 16; w++) t += s_red[w][21 + i]; acc.g[i] = t; }
+    if (tid < 28 && (kJac || tid == 27)) {
+        double t = 0.0;
+        for (int w = 0; w < 16; w++) t += s_red[w][tid];
+        s_sum[tid] = t;
     }
+    __syncthreads();
 }
 
 // One 1024-thread workgroup per stream (a frame has ~8 k residual blocks); the trust-region control flow runs redundantly
-// in every thread on the block-reduced sums, exactly like k_lm_solve.
+// in every thread on the block-reduced sums in LDS, exactly like k_lm_solve.
 __global__ __launch_bounds__(1024) void k_map_solve(const MapStream *streams, int outer)
 {
     const MapStream S = streams[blockIdx.x];
-    __shared__ double s_red[16][28];
+    __shared__ double s_red[16][28], s_sum[28], s_cur[28];
     const int tid = threadIdx.x;
-    const int nq = S.n_stack[0] + S.n_stack[1];
+    const int n_edge = S.n_stack[0], nq = S.n_stack[0] + S.n_stack[1];
     const int n_used = S.stats[outer] + S.stats[2 + outer];
     double x[7];
     for (int i = 0; i < 7; i++) x[i] = S.x[i];
@@ -411,32 +415,35 @@ __global__ __launch_bounds__(1024) void k_map_solve(const MapStream *streams, in
     bool reuse_diagonal = false;
     int invalid_steps = 0, iter = 0;
     if (n_used > 0) {
-        LmAcc acc;
-        map_evaluate<true>(S.rec, nq, x, acc, s_red);
-        double x_cost = acc.cost;
-        double H[36], g[6], scale[6], diag[6];
-        unpack_sym(acc.H, H);
-        for (int i = 0; i < 6; i++) g[i] = acc.g[i];
+        map_evaluate<true>(S.rec, n_edge, nq, x, s_red, s_sum);
+        if (tid < 28) s_cur[tid] = s_sum[tid];
+        __syncthreads();
+        double x_cost = s_cur[27];
+        double scale[6], diag[6];
         double gmax = 0.0;
-        for (int i = 0; i < 6; i++) gmax = fmax(gmax, fabs(g[i]));
+        for (int i = 0; i < 6; i++) gmax = fmax(gmax, fabs(s_cur[21 + i]));
         if (gmax > gradient_tol) {
             double x_norm = norm7(x);
-            for (int i = 0; i < 6; i++) scale[i] = 1.0 / (1.0 + sqrt(H[i * 6 + i]));
+            for (int i = 0; i < 6; i++) scale[i] = 1.0 / (1.0 + sqrt(s_cur[sym6(i, i)]));
             while (iter < max_iter) {
                 iter++;
-                double Hs[36], gs[6], A[36], stepv[6];
-                for (int i = 0; i < 6; i++) { gs[i] = g[i] * scale[i]; for (int j = 0; j < 6; j++) Hs[i * 6 + j] = H[i * 6 + j] * scale[i] * scale[j]; }
+                double gs[6], A[21], stepv[6];
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    gs[i] = s_cur[21 + i] * scale[i];
+#pragma unroll
+                    for (int j = 0; j <= i; j++) A[i * (i + 1) / 2 + j] = s_cur[sym6(i, j)] * scale[i] * scale[j];
+                }
                 if (!reuse_diagonal)
-                    for (int i = 0; i < 6; i++) { double d = Hs[i * 6 + i]; d = d < min_diag ? min_diag : d; d = d > max_diag ? max_diag : d; diag[i] = d; }
-                for (int i = 0; i < 36; i++) A[i] = Hs[i];
-                for (int i = 0; i < 6; i++) A[i * 6 + i] += diag[i] / radius;
-                bool ok = chol_solve6(A, gs, stepv);
+                    for (int i = 0; i < 6; i++) { double d = A[i * (i + 1) / 2 + i]; d = d < min_diag ? min_diag : d; d = d > max_diag ? max_diag : d; diag[i] = d; }
+                for (int i = 0; i < 6; i++) A[i * (i + 1) / 2 + i] += diag[i] / radius;
+                bool ok = chol_solve6_packed(A, gs, stepv);
                 for (int i = 0; i < 6; i++) if (!isfinite(stepv[i])) ok = false;
                 double model_change = 0.0;
                 if (ok) {
                     for (int i = 0; i < 6; i++) stepv[i] = -stepv[i];
                     double dg = 0.0, dHd = 0.0;
-                    for (int i = 0; i < 6; i++) { dg += stepv[i] * gs[i]; for (int j = 0; j < 6; j++) dHd += stepv[i] * Hs[i * 6 + j] * stepv[j]; }
+                    for (int i = 0; i < 6; i++) { dg += stepv[i] * gs[i]; for (int j = 0; j < 6; j++) dHd += stepv[i] * (s_cur[sym6(i, j)] * scale[i] * scale[j]) * stepv[j]; }
                     model_change = -(dg + 0.5 * dHd);
                 }
                 if (!ok || !(model_change > 0.0)) {
@@ -450,10 +457,9 @@ __global__ __launch_bounds__(1024) void k_map_solve(const MapStream *streams, in
                 manifold_plus(x, delta, cand);
                 // candidate evaluated with its Jacobian (reused as the next linearisation); the last iteration needs the cost only
                 const bool last = iter == max_iter;
-                LmAcc ca;
-                if (last) map_evaluate<false>(S.rec, nq, cand, ca, s_red);
-                else map_evaluate<true>(S.rec, nq, cand, ca, s_red);
-                const double cand_cost = ca.cost;
+                if (last) map_evaluate<false>(S.rec, n_edge, nq, cand, s_red, s_sum);
+                else map_evaluate<true>(S.rec, n_edge, nq, cand, s_red, s_sum);
+                const double cand_cost = s_sum[27];
                 double sn = 0.0;
                 for (int i = 0; i < 7; i++) sn += (x[i] - cand[i]) * (x[i] - cand[i]);
                 sn = sqrt(sn);
@@ -464,9 +470,10 @@ __global__ __launch_bounds__(1024) void k_map_solve(const MapStream *streams, in
                     for (int i = 0; i < 7; i++) x[i] = cand[i];
                     if (last) break;
                     x_norm = norm7(x);
-                    x_cost = ca.cost;
-                    unpack_sym(ca.H, H);
-                    for (int i = 0; i < 6; i++) g[i] = ca.g[i];
+                    x_cost = cand_cost;
+                    __syncthreads();             // every thread has read the old linearisation
+                    if (tid < 28) s_cur[tid] = s_sum[tid];
+                    __syncthreads();
                     const double tt = 2.0 * rel - 1.0;
                     double den = 1.0 - tt * tt * tt;
                     if (den < 1.0 / 3.0) den = 1.0 / 3.0;
@@ -474,7 +481,7 @@ __global__ __launch_bounds__(1024) void k_map_solve(const MapStream *streams, in
                     if (radius > max_radius) radius = max_radius;
                     decrease_factor = 2.0; reuse_diagonal = false;
                     gmax = 0.0;
-                    for (int i = 0; i < 6; i++) gmax = fmax(gmax, fabs(g[i]));
+                    for (int i = 0; i < 6; i++) gmax = fmax(gmax, fabs(s_cur[21 + i]));
                     if (gmax <= gradient_tol) break;
                 } else {
                     radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
