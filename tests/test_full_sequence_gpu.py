@@ -101,3 +101,33 @@ def test_chain_groups_and_lead_in_options_at_bench_scale(seq00):
     finally:
         ctx.set_option(ctx.OPT_ODOM_STREAMS, 4)
         ctx.set_option(ctx.OPT_LEAD_FULL, -1)
+
+
+def test_context_on_a_caller_stream_gives_the_same_increments(seq00):
+    """A context moved onto a caller-created stream runs at most 3 chain groups, all on the library's own streams (lmono_hip.hip:
+    odom_run); the increments are the null-stream context's bit for bit."""
+    import torch
+    import lmono_amd
+    from workloads import s1 as S1
+    chains, lead, _ = _bench_defaults()
+    n = 1024                                            # a quarter of the sequence is enough to run 3 groups of 85 chains
+    w = S1.S1World(n_az=2000)
+    xyzi, off = w.scans(w.trajectory(n))
+    xd = torch.from_numpy(xyzi).cuda()
+    del xyzi
+    out = []
+    for own_stream in (False, True):
+        ctx = lmono_amd.Context(0)
+        if own_stream:
+            st = torch.cuda.Stream()
+            ctx.set_stream(st.cuda_stream)
+            assert ctx.odom_chain_groups(chains) == 3
+        else:
+            assert ctx.odom_chain_groups(chains) == 4
+        b = lmono_amd.ScanBatch(ctx, n, int(off[-1]))
+        torch.cuda.synchronize()
+        b.scanreg(xd.data_ptr(), off, 64, 5.0, keepalive=xd)
+        i, p = b.odometry(chains, lead)
+        out.append((i, p))
+        b.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
