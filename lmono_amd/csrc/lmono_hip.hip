@@ -84,7 +84,7 @@ struct lmono_scan_batch {
         }                                                                                    \
     } while (0)
 
-extern "C" const char *lmono_version(void) { return "lmono-hip 0.1 (gfx950)"; }
+extern "C" const char *lmono_version(void) { return "lmono-hip 0.2 (gfx950)"; }
 
 extern "C" lmono_ctx *lmono_create(int device)
 {
