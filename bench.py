@@ -335,7 +335,7 @@ def bench_posegraph(args):
         dist.destroy_process_group()
 
 
-GOLDEN = os.path.join(ROOT, "tests", "golden", "s1_seq00_oracle.npz")
+GOLDEN = os.path.join(ROOT, "tests", "golden", "s1_seq%02d_oracle.npz")
 
 
 def spawn_ranks(args):
@@ -409,11 +409,12 @@ def main():
                     help="weak: every rank gets --scans scans of one long trajectory; strong: --scans scans in total, sharded "
                          "over the ranks (BASELINE configs[3]: seq 00 sharded across 8)")
     ap.add_argument("--chains", type=int, default=256, help="concurrent odometry chains per GPU (strong scaling: in total)")
-    ap.add_argument("--lead", type=int, default=7, help="lead-in scans of a chain that does not start at scan 0")
+    ap.add_argument("--lead", type=int, default=5, help="lead-in scans of a chain that does not start at scan 0")
     ap.add_argument("--lead-full", type=int, default=2,
                     help="lead-in scan pairs of a chain (the last ones) that use all feature points; the earlier ones a quarter (-1: all use all)")
+    ap.add_argument("--seq", type=int, default=0, choices=[0, 1], help="0: the S1 figure-8 sequence (headline); 1: the held-out sequence (other world, clover trajectory)")
     ap.add_argument("--az", type=int, default=2000, help="azimuth steps per ring (2000 = HDL-64 at 10 Hz)")
-    ap.add_argument("--cpu-sample", type=int, default=384, help="scans of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=128, help="scans of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (sequential run, BA secondary)")
     ap.add_argument("--probe-ranks", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--workload", default="lidar", choices=["lidar", "ba", "ba-seq", "map", "colour", "posegraph"],
@@ -449,7 +450,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "--gpus %d but the launcher started %d ranks" % (args.gpus, world)
+    if world != args.gpus:
+        if args.gpus == 1:
+            args.gpus = world              # started by a launcher without --gpus: adopt its world size
+        else:
+            sys.exit("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -465,8 +470,12 @@ def main():
     n_own = own_end - own_begin
 
     t0 = time.time()
-    w = S1.S1World(n_az=args.az)
-    traj = w.trajectory(n_total)
+    if args.seq == 0:
+        w = S1.S1World(n_az=args.az)
+        traj = w.trajectory(n_total)
+    else:           # the held-out sequence: another world, another trajectory (tests/golden/s1_seq01_oracle.npz)
+        w = S1.S1World(seed=777, n_az=args.az)
+        traj = w.trajectory_clover(n_total)
     xyzi, off = w.scans(traj[load_begin:own_end], scan_id0=load_begin)
     gen_s = time.time() - t0
     total_pts = int(off[-1])
@@ -490,9 +499,18 @@ def main():
     poses_d = torch.zeros((n_own, 7), dtype=torch.float64, device=dev)
     chains = max(1, min(args.chains // world if strong else args.chains, n_local))
 
+    boundary, shard_rounds = [], [0]
+
     def step():
         batch.scanreg(xyzi_d.data_ptr(), off, 64, 5.0, keepalive=xyzi_d)
-        batch.odometry_d(chains, args.lead, incr_d.data_ptr(), None)
+        if world == 1:
+            batch.odometry_d(chains, args.lead, incr_d.data_ptr(), None)
+        else:
+            # the rank's chains run over its owned scans (chain 0's lead-in = the previous rank's last scans); then the rank boundaries
+            # are validated like the chain boundaries inside a rank: one all-gather of every rank's last increment per round
+            batch.odometry_shard_d(chains, args.lead, lead_r, incr_d.data_ptr())
+            shard_rounds[0] = sharding.validate_rank_boundaries(lambda: incr_d[-1], lambda prev: batch.shard_validate(prev, incr_d.data_ptr()), rank, world)
+        boundary.append(batch.boundary_report())
         ctx.pose_prefix_d(incr_d.data_ptr(), lead_r, n_local, poses_d.data_ptr())
         if world > 1:
             bases = sharding.gather_bases(poses_d[-1].clone())
@@ -508,6 +526,7 @@ def main():
         step()
     barrier()
     ctx.timing_reset()
+    del boundary[:]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -528,8 +547,8 @@ def main():
     # ---- tolerance of the timed run: its poses against the committed trajectory of the strictly sequential CPU path over
     # the WHOLE sequence (tests/golden/s1_seq00_oracle.npz: data, not the oracle), every owned scan the fixture covers
     parity = None
-    if args.az == 2000 and os.path.exists(GOLDEN):
-        gold = np.load(GOLDEN)
+    if args.az == 2000 and os.path.exists(GOLDEN % args.seq):
+        gold = np.load(GOLDEN % args.seq)
         gp, gi, gc = gold["poses"], gold["incr"], gold["feat_counts"]
         hi = min(own_end, len(gp))
         sums = np.zeros(6)
@@ -544,7 +563,7 @@ def main():
             dist.all_reduce(ts)
             sums = ts.cpu().numpy()
         if sums[1] > 0:
-            parity = {"reference": "tests/golden/s1_seq00_oracle.npz (sequential CPU oracle, n_chains 1, lead 0)",
+            parity = {"reference": "tests/golden/s1_seq%02d_oracle.npz (sequential CPU oracle, n_chains 1, lead 0)" % args.seq,
                       "scans_compared": int(sums[1]),
                       "ate_vs_cpu_m": round(float(np.sqrt(sums[0] / sums[1])), 6),
                       "rpe_vs_cpu": {"delta_scans": 1, "trans_rmse_m": round(float(np.sqrt(sums[2] / sums[4])), 7),
@@ -618,6 +637,15 @@ def main():
                        "h2d_GBps": round(total_pts * 16 / h2d_s / 1e9, 1)},
             "roofline": roofline,
         }
+        # the chained schedule validated itself in every timed step (LMONO_OPT_BOUNDARY_TOL; rank 0's chains): per step
+        rep = boundary[-1]
+        out["boundaries_rerun"] = rep["chains_rerun"]
+        out["boundary_validation"] = {"tol": rep["tol"], "boundaries": rep["n_chains"] - 1, "flagged": rep["flagged"], "chains_rerun": rep["chains_rerun"],
+                                      "pairs_rerun": rep["pairs_rerun"], "rounds": rep["rounds"], "unresolved": rep["unresolved"],
+                                      "max_residual": float(rep["max_resid"]), "residual_q50_q90_q99": [float(v) for v in np.quantile(rep["resid"][1:], [0.5, 0.9, 0.99])] if rep["n_chains"] > 1 else None,
+                                      "repair_ms_per_step": round(float(np.mean([b["repair_ms"] for b in boundary])), 3),
+                                      "rank_boundary_rounds": shard_rounds[0] if world > 1 else None,
+                                      "residual": "max(|dq_i|, 0.1 |dt_i| / m) between a chain's own lead-in estimate of the pair before its first owned one and its predecessor's increment for that pair"}
         if parity is not None:
             out["ate_vs_cpu_m"] = parity["ate_vs_cpu_m"]
             out["rpe_vs_cpu"] = parity["rpe_vs_cpu"]

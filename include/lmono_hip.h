@@ -55,7 +55,14 @@ int         lmono_synchronize(lmono_ctx *);
  * ones a quarter of them (a lead-in pair only produces the next pair's warm start); -1 (default) = every pair uses all of them.
  * An accuracy / speed knob like n_chains and lead: n_chains = 1 is unaffected.                                                  */
 #define LMONO_OPT_LEAD_FULL 3
-#define LMONO_OPT_COUNT     4
+/* boundary validation of lmono_odom_batch[_d]'s chained schedule (n_chains > 1), in units of 1e-9: after the chains have run, the warm
+ * start every chain used for its first owned scan pair (its own lead-in's estimate) is compared on the device with the increment the
+ * strictly sequential schedule warm-starts from (the predecessor chain's last one): residual = max(|dq_i|, 0.1 |dt_i| / m).  Chains
+ * above the tolerance are re-started from the sequential warm start and re-run until their increments agree with the stored ones
+ * within it (everything behind stands), in rounds until no boundary is flagged; lmono_odom_boundary_report tells what happened.
+ * Default 1000 (1e-6: 2e-6 rad, 1e-5 m); 0 = no validation (and no synchronisation inside lmono_odom_batch_d).                    */
+#define LMONO_OPT_BOUNDARY_TOL 4
+#define LMONO_OPT_COUNT     5
 int         lmono_set_option(lmono_ctx *, int key, int value);
 int         lmono_get_option(lmono_ctx *, int key, int *value);     /* the configured value (option values may be negative) */
 const char *lmono_version(void);
@@ -101,6 +108,28 @@ int lmono_batch_get_curvature(lmono_ctx *, lmono_scan_batch *, int scan, float *
 int lmono_odom_batch(lmono_ctx *, lmono_scan_batch *, int n_chains, int lead, double *incr_h, double *poses_h);
 /* Same, results stay on the device: incr_d, poses_d [n_scans][7] float64 (may be NULL).       */
 int lmono_odom_batch_d(lmono_ctx *, lmono_scan_batch *, int n_chains, int lead, double *incr_d, double *poses_d);
+
+/* What the boundary validation of the last lmono_odom_batch[_d] / lmono_odom_shard_* call on this batch did (LMONO_OPT_BOUNDARY_TOL).
+ * resid_h [n_chains] (may be NULL): residual of every chain's warm start at the first check (entry 0: 0, or the shard's external
+ * boundary); rerun_h [n_chains] (may be NULL): scan pairs re-run per chain.  No reference counterpart (the reference is sequential). */
+typedef struct {
+    int n_chains;
+    int flagged;        /* boundaries above the tolerance, summed over the rounds                                   */
+    int chains_rerun;   /* distinct chains re-started                                                              */
+    int pairs_rerun;    /* scan pairs re-run by them                                                               */
+    int rounds;         /* check + repair rounds (a repair that reaches its chain's end can flag the next boundary) */
+    int unresolved;     /* always 0 on return: boundaries still above the tolerance                                */
+    double tol, max_resid, repair_ms;
+} lmono_boundary_report;
+int lmono_odom_boundary_report(lmono_ctx *, lmono_scan_batch *, lmono_boundary_report *rep, double *resid_h, int32_t *rerun_h, int cap);
+
+/* Scan-range sharding over the GPUs of a node: the batch holds scans [first_owned - lead', n) of a longer sequence, the
+ * first `first_owned` of them are the previous rank's (chain 0's lead-in; their increments are not produced).  lmono_odom_shard_d runs
+ * the chains over the owned scans; after ONE all-gather of every rank's last increment (incr_d[n - 1]), lmono_odom_shard_validate
+ * checks chain 0's warm start against the previous rank's last increment prev_incr_h[7] exactly like an inner boundary and repairs;
+ * *changed_last = 1 when this rank's own last increment changed (the next rank must validate again).  incr_d [n][7] as above.     */
+int lmono_odom_shard_d(lmono_ctx *, lmono_scan_batch *, int n_chains, int lead, int first_owned, double *incr_d);
+int lmono_odom_shard_validate(lmono_ctx *, lmono_scan_batch *, const double *prev_incr_h, double *incr_d, int *changed_last);
 
 /* Debug/parity view of one odometry step: correspondences of outer iteration `outer` (0/1) for the scan
  * pair (scan-1, scan) evaluated at pose q,t: corr_h [n_sharp + n_flat][4] = (a, b, c, kind).       */

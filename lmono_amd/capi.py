@@ -11,7 +11,7 @@ MAX_QUERIES = 64 * 6 * 2 + 64 * 6 * 4
 SYMBOLS = [
     "lmono_create", "lmono_destroy", "lmono_last_error", "lmono_set_stream", "lmono_set_option", "lmono_get_option", "lmono_synchronize", "lmono_version",
     "lmono_batch_create", "lmono_batch_destroy", "lmono_scanreg_batch", "lmono_scanreg_batch_h", "lmono_batch_counts", "lmono_batch_get_cloud",
-    "lmono_batch_get_curvature", "lmono_odom_batch", "lmono_odom_batch_d", "lmono_odom_correspond", "lmono_timing_reset", "lmono_timing_read",
+    "lmono_batch_get_curvature", "lmono_odom_batch", "lmono_odom_batch_d", "lmono_odom_shard_d", "lmono_odom_shard_validate", "lmono_odom_boundary_report", "lmono_odom_correspond", "lmono_timing_reset", "lmono_timing_read",
     "lmono_pose_prefix_d", "lmono_pose_rebase_d", "lmono_map_refine", "lmono_voxel_filter", "lmono_mapper_create", "lmono_mapper_destroy", "lmono_mapper_reset", "lmono_mapper_process", "lmono_mapper_process_batch", "lmono_mapper_cube",
     "lmono_map_builder_create", "lmono_map_builder_destroy", "lmono_associate_to_map", "lmono_associate_to_map_batch", "lmono_map_builder_depth",
     "lmono_map_builder_cloud", "lmono_map_builder_map", "lmono_map_builder_clear",
@@ -61,6 +61,9 @@ def load_library():
     L.lmono_batch_get_curvature.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
     L.lmono_odom_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.lmono_odom_batch_d.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.lmono_odom_shard_d.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.lmono_odom_shard_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.lmono_odom_boundary_report.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.lmono_odom_correspond.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.lmono_timing_reset.argtypes = [C.c_void_p]
     L.lmono_triangulate.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 9 + [C.c_int, C.c_int, C.c_double, C.c_int]
@@ -103,6 +106,8 @@ class Context:
             self.L.lmono_set_option(self.h, 3, int(os.environ["LMONO_LEAD_FULL"]))
         if os.environ.get("LMONO_ODOM_STREAMS") is not None:
             self.L.lmono_set_option(self.h, 2, int(os.environ["LMONO_ODOM_STREAMS"]))
+        if os.environ.get("LMONO_BOUNDARY_TOL") is not None:
+            self.L.lmono_set_option(self.h, 4, int(os.environ["LMONO_BOUNDARY_TOL"]))
 
     def check(self, rc):
         if rc < 0:
@@ -123,6 +128,7 @@ class Context:
     OPT_DEFER_EVERY = 1
     OPT_ODOM_STREAMS = 2
     OPT_LEAD_FULL = 3
+    OPT_BOUNDARY_TOL = 4
 
     def set_option(self, key, value):
         self.check(self.L.lmono_set_option(self.h, int(key), int(value)))
@@ -312,6 +318,12 @@ class Context:
                                            poses.ctypes.data, stats.ctypes.data, nn.ctypes.data if want_nn else None))
         return poses, stats, nn
 
+class BoundaryReport(C.Structure):
+    """lmono_boundary_report (include/lmono_hip.h)"""
+    _fields_ = [("n_chains", C.c_int), ("flagged", C.c_int), ("chains_rerun", C.c_int), ("pairs_rerun", C.c_int), ("rounds", C.c_int),
+                ("unresolved", C.c_int), ("tol", C.c_double), ("max_resid", C.c_double), ("repair_ms", C.c_double)]
+
+
 class ScanBatch:
     """Device-resident working set of a batch of scans (lmono_scan_batch)."""
 
@@ -365,6 +377,28 @@ class ScanBatch:
     def odometry_d(self, n_chains, lead, incr_ptr=None, poses_ptr=None):
         self.ctx.check(self.ctx.L.lmono_odom_batch_d(self.ctx.h, self.h, n_chains, lead,
                                                       C.c_void_p(incr_ptr or 0), C.c_void_p(poses_ptr or 0)))
+
+    def odometry_shard_d(self, n_chains, lead, first_owned, incr_ptr=None):
+        """Rank-local odometry of a scan-range shard: the first `first_owned` scans of the batch are the previous rank's (lead-in)."""
+        self.ctx.check(self.ctx.L.lmono_odom_shard_d(self.ctx.h, self.h, n_chains, lead, int(first_owned), C.c_void_p(incr_ptr or 0)))
+
+    def shard_validate(self, prev_incr, incr_ptr=None):
+        """Checks / repairs chain 0's warm start against the previous rank's last increment; True when this rank's last one changed."""
+        prev = np.ascontiguousarray(prev_incr, np.float64).reshape(7)
+        ch = C.c_int(0)
+        self.ctx.check(self.ctx.L.lmono_odom_shard_validate(self.ctx.h, self.h, prev.ctypes.data, C.c_void_p(incr_ptr or 0), C.byref(ch)))
+        return bool(ch.value)
+
+    def boundary_report(self):
+        """What the boundary validation of the last odometry call did: dict + per-chain residuals and re-run pair counts."""
+        rep = BoundaryReport()
+        self.ctx.check(self.ctx.L.lmono_odom_boundary_report(self.ctx.h, self.h, C.byref(rep), None, None, 0))
+        n = rep.n_chains
+        resid = np.zeros(max(n, 1)); rerun = np.zeros(max(n, 1), np.int32)
+        self.ctx.check(self.ctx.L.lmono_odom_boundary_report(self.ctx.h, self.h, C.byref(rep), resid.ctypes.data, rerun.ctypes.data, n))
+        d = {k: getattr(rep, k) for k, _ in BoundaryReport._fields_}
+        d["resid"] = resid[:n]; d["rerun"] = rerun[:n]
+        return d
 
     def correspond(self, scan, q, t):
         q = np.ascontiguousarray(q, np.float64); t = np.ascontiguousarray(t, np.float64)

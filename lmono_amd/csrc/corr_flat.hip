@@ -238,9 +238,10 @@ __global__ __launch_bounds__(kCfT, LMONO_CF_WAVES) void k_corr_flat(BatchView b,
 {
     __shared__ CfLds L;
     const int xcd = blockIdx.x & 7, u = blockIdx.x >> 3;
-    const int c = o.chain0 + (u / kCfBlocks) * 8 + xcd;
+    const int ci = o.chain0 + (u / kCfBlocks) * 8 + xcd;
     const int qb = u % kCfBlocks;
-    if (c >= o.chain1) return;
+    if (ci >= o.chain1) return;
+    const int c = o.clist ? o.clist[ci] : ci;
     int own;
     const int k = chain_scan(o, c, step, own);
     if (k < 0) return;

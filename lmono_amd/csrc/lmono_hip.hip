@@ -31,7 +31,7 @@ struct lmono_ctx {
     std::vector<EvSet> sets;   // one event set per scanreg/odometry call since the last lmono_timing_reset
     int n_sets = 0;
     hipEvent_t *ev = nullptr;  // events of the current call
-    int opt[LMONO_OPT_COUNT] = { 3, 0, 4, -1 };   // LMONO_OPT_CORR_TILE: 3 = flattened sweeps (default: as fast as 0 and needs no hash grid), 0 = 32-lane groups, 1 = LDS sector tiles, 2 = thread per feature
+    int opt[LMONO_OPT_COUNT] = { 3, 0, 4, -1, 1000 };   // LMONO_OPT_CORR_TILE: 3 = flattened sweeps (default: as fast as 0 and needs no hash grid), 0 = 32-lane groups, 1 = LDS sector tiles, 2 = thread per feature
     hipStream_t gstream[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };   // streams of the odometry's chain groups (LMONO_OPT_ODOM_STREAMS > 1)
     hipEvent_t gev[9] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     unsigned long long *stats_d = nullptr;   // [0] feature points deferred by the tile search since the last lmono_timing_reset
@@ -73,6 +73,15 @@ struct lmono_scan_batch {
     float4 *crec = nullptr, *crec_pair = nullptr;
     unsigned int *wl = nullptr;            // work list of feature points the LDS tile search defers: [0] = count
     size_t wl_cap = 0;
+    // boundary validation of the chained schedule
+    double *ws = nullptr, *resid_d = nullptr;
+    int *rstat = nullptr;
+    unsigned int *rcount = nullptr;
+    hipEvent_t rep_ev[2] = { nullptr, nullptr };
+    lmono_boundary_report brep{};
+    std::vector<double> resid_h;
+    std::vector<int> rerun_h;
+    int last_chains = 0, last_lead = 0, last_first = 0;
 };
 
 #define HIP_TRY(ctx, expr)                                                                   \
@@ -142,6 +151,7 @@ extern "C" int lmono_set_option(lmono_ctx *c, int key, int value)
     const bool ok = key == LMONO_OPT_CORR_TILE ? (value >= 0 && value <= 3)
                   : key == LMONO_OPT_DEFER_EVERY ? value >= 0
                   : key == LMONO_OPT_ODOM_STREAMS ? (value >= 1 && value <= 8)
+                  : key == LMONO_OPT_BOUNDARY_TOL ? value >= 0
                   : value >= -1;                                     // LMONO_OPT_LEAD_FULL
     if (!ok) { c->err = "lmono_set_option: value out of range for this option"; return LMONO_EINVAL; }
     c->opt[key] = value;
@@ -176,6 +186,7 @@ extern "C" void lmono_batch_destroy(lmono_scan_batch *b)
 {
     if (!b) return;
     for (void *p : b->allocs) (void)hipFree(p);
+    for (auto &e : b->rep_ev) if (e) (void)hipEventDestroy(e);
     delete b;
 }
 
@@ -418,7 +429,9 @@ static int ensure_odom_ws(lmono_ctx *c, lmono_scan_batch *b, int n_chains)
     // (re)allocate; old buffers stay in allocs and are freed with the batch
     bool ok = dalloc(b, b->state, (size_t)n_chains * 8) && dalloc(b, b->corr, (size_t)n_chains * kMaxQueries * 4) &&
               dalloc(b, b->lm_info, (size_t)n_chains * 4) && dalloc(b, b->crec, (size_t)n_chains * kMaxQueries * 4) &&
-              dalloc(b, b->seed, (size_t)n_chains * kMaxQueries) && dalloc(b, b->wl, 8 * ((size_t)n_chains * kMaxQueries + 1));
+              dalloc(b, b->seed, (size_t)n_chains * kMaxQueries) && dalloc(b, b->wl, 8 * ((size_t)n_chains * kMaxQueries + 1)) &&
+              dalloc(b, b->ws, (size_t)n_chains * 8) && dalloc(b, b->resid_d, (size_t)n_chains) && dalloc(b, b->rstat, (size_t)n_chains * 4) &&
+              dalloc(b, b->rcount, (size_t)n_chains + 2);
     if (!ok) { c->err = "odometry workspace: hipMalloc failed"; return LMONO_ENOMEM; }
     b->chains_cap = n_chains;
     return LMONO_OK;
@@ -435,75 +448,83 @@ static int ensure_grid(lmono_ctx *c, lmono_scan_batch *b)
     return LMONO_OK;
 }
 
-static int odom_run(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, double *incr_d, double *poses_d, bool want_poses)
-{
-    if (!c || !b || !b->registered || lead < 0) return LMONO_EINVAL;
-    const int n = b->n_scans;
-    if (n_chains < 1) n_chains = 1;
-    if (n_chains > n) n_chains = n;
-    HIP_TRY(c, hipSetDevice(c->device));
-    int rc = ensure_odom_ws(c, b, n_chains);
-    if (rc) return rc;
-    OdomView o;
-    o.n_scans = n; o.n_chains = n_chains; o.lead = lead; o.fixed_k = -1; o.chain0 = 0; o.chain1 = n_chains;
-    o.lead_full = c->opt[LMONO_OPT_CORR_TILE] == 3 ? c->opt[LMONO_OPT_LEAD_FULL] : -1;     // only the default search thins lead-in pairs
-    o.state = b->state; o.corr = b->corr; o.incr = b->incr; o.lm_info = b->lm_info; o.crec = b->crec; o.seed = b->seed;
-    int max_steps = 0;
-    for (int ch = 0; ch < n_chains; ch++) {
-        const int s = (int)((long long)ch * n / n_chains), e = (int)((long long)(ch + 1) * n / n_chains);
-        const int begin = s - lead > 0 ? s - lead : 0;
-        const int steps = e - begin - 1;
-        max_steps = steps > max_steps ? steps : max_steps;
+// Chain-group streams of a context: forks the library's group streams off the context stream, joins them again on every exit path.
+struct GroupFork {
+    lmono_ctx *c; int G, g_own; bool forked = false;
+    GroupFork(lmono_ctx *c_, int G_, int g_own_) : c(c_), G(G_), g_own(g_own_) {}
+    int fork()
+    {
+        if (G <= 1) return LMONO_OK;
+        for (int g = g_own; g < G; g++) if (!c->gstream[g]) HIP_TRY(c, hipStreamCreateWithFlags(&c->gstream[g], hipStreamNonBlocking));
+        for (int g = 0; g <= G && g < 9; g++) if (!c->gev[g]) HIP_TRY(c, hipEventCreateWithFlags(&c->gev[g], hipEventDisableTiming));
+        HIP_TRY(c, hipEventRecord(c->gev[0], c->stream));
+        forked = true;                           // from here on the group streams may carry work: join() must run
+        for (int g = g_own; g < G; g++) HIP_TRY(c, hipStreamWaitEvent(c->gstream[g], c->gev[0], 0));
+        return LMONO_OK;
     }
-    hipStream_t st = c->stream;
-    if (c->n_sets == 0 || c->sets[c->n_sets - 1].odom) c->ev = c->next_set();
-    if (!c->ev) { c->err = "hipEventCreate failed"; return LMONO_ENODEV; }
-    c->sets[c->n_sets - 1].odom = true;
-    HIP_TRY(c, hipEventRecord(c->ev[8], st));
-    const int ninit = n > n_chains ? n : n_chains;
-    hipLaunchKernelGGL(k_odom_init, dim3((ninit + 255) / 256), dim3(256), 0, st, o);
-    const int tile = c->opt[LMONO_OPT_CORR_TILE];
-    if (tile != 3) { rc = ensure_grid(c, b); if (rc) return rc; }
-    if (tile) HIP_TRY(c, hipMemsetAsync(b->wl, 0, sizeof(unsigned int), st));
-    EvSet &es = c->sets[c->n_sets - 1];
-    auto kev = [&](int i) -> hipEvent_t {
-        while ((int)es.kev.size() <= i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; es.kev.push_back(e); }
-        return es.kev[i];
-    };
-    int ne = 0;
-    // Chain groups: with LMONO_OPT_ODOM_STREAMS = G > 1 the chains are cut into G groups, each advancing on its own stream, so that
-    // one group's solve (one workgroup per chain: a quarter of the CUs' wave slots at most) and the ragged tail of its search kernel
-    // run beside the other groups' searches.  Group 0 carries the per-kernel events.  The runtime maps streams onto 4 hardware queues
-    // (GPU_MAX_HW_QUEUES): the null stream on one of its own, created streams round-robin on the other three.  So the default context
-    // (null stream) runs group 0 on the null stream + 3 group streams = 4 distinct queues; a context on a caller-created stream runs
-    // at most 3 groups, all on the library's own streams (4 created streams would put two groups on one queue: 64-70 instead of 51 ms
-    // per step measured), and the caller's stream only forks and joins.
+    // every forked stream is waited on by the context stream; if recording / waiting itself fails, the stream is synchronised instead,
+    // so that nothing enqueued later (or the destruction of the batch) can overtake the group's kernels
+    int join()
+    {
+        if (!forked) return LMONO_OK;
+        forked = false;
+        int rc = LMONO_OK;
+        for (int g = g_own; g < G; g++) {
+            if (hipEventRecord(c->gev[g + 1], c->gstream[g]) != hipSuccess || hipStreamWaitEvent(c->stream, c->gev[g + 1], 0) != hipSuccess) {
+                (void)hipStreamSynchronize(c->gstream[g]);
+                c->err = "odometry: joining a chain-group stream failed"; rc = LMONO_ENODEV;
+            }
+        }
+        return rc;
+    }
+    ~GroupFork() { (void)join(); }
+};
+
+// number of chain groups a launch sequence over n_ch chains uses on this context
+static int odom_groups(const lmono_ctx *c, int n_ch)
+{
     constexpr int kMinChainsPerGroup = 32;
     int G = c->opt[LMONO_OPT_ODOM_STREAMS];
     G = G < 1 ? 1 : (G > 8 ? 8 : G);
-    const bool null_stream = c->stream == nullptr;
-    if (!null_stream && G > 3) G = 3;
-    while (G > 1 && n_chains / G < kMinChainsPerGroup) G--;      // a group below 32 chains cannot fill its share of the CUs
-    const int g_own = null_stream ? 1 : 0;                        // first group that runs on a stream of the library
-    if (tile != 3) G = 1;                       // only the default search is grouped
-    const size_t wl_stride = (size_t)n_chains * kMaxQueries + 1;
-    if (G > 1) {
-        for (int g = g_own; g < G; g++) if (!c->gstream[g]) HIP_TRY(c, hipStreamCreateWithFlags(&c->gstream[g], hipStreamNonBlocking));
-        for (int g = 0; g <= G && g < 9; g++) if (!c->gev[g]) HIP_TRY(c, hipEventCreateWithFlags(&c->gev[g], hipEventDisableTiming));
-        for (int g = 1; g < G; g++) HIP_TRY(c, hipMemsetAsync(b->wl + g * wl_stride, 0, sizeof(unsigned int), st));
-        HIP_TRY(c, hipEventRecord(c->gev[0], st));
-        for (int g = g_own; g < G; g++) HIP_TRY(c, hipStreamWaitEvent(c->gstream[g], c->gev[0], 0));
-    }
-    for (int step = 0; step < max_steps; step++) {
+    if (c->stream != nullptr && G > 3) G = 3;
+    while (G > 1 && n_ch / G < kMinChainsPerGroup) G--;      // a group below 32 chains cannot fill its share of the CUs
+    if (c->opt[LMONO_OPT_CORR_TILE] != 3) G = 1;            // only the default search is grouped
+    return G;
+}
+
+// Steps [step_a, step_b) x 2 outer iterations of the chains [0, n_ch) of view o (o.clist set: of the listed chains), in G chain groups.
+// Chain groups: with LMONO_OPT_ODOM_STREAMS = G > 1 the chains are cut into G groups, each advancing on its own stream, so that
+// one group's solve (one workgroup per chain: a quarter of the CUs' wave slots at most) and the ragged tail of its search kernel
+// run beside the other groups' searches.  Group 0 carries the per-kernel events.  The runtime maps streams onto 4 hardware queues
+// (GPU_MAX_HW_QUEUES): the null stream on one of its own, created streams round-robin on the other three.  So the default context
+// (null stream) runs group 0 on the null stream + 3 group streams = 4 distinct queues; a context on a caller-created stream runs
+// at most 3 groups, all on the library's own streams (4 created streams would put two groups on one queue: 64-70 instead of 51 ms
+// per step measured), and the caller's stream only forks and joins.
+static int odom_launch_steps(lmono_ctx *c, lmono_scan_batch *b, const OdomView &o, int n_ch, int step_a, int step_b, int G, EvSet *es, int *ne)
+{
+    const int tile = c->opt[LMONO_OPT_CORR_TILE];
+    hipStream_t st = c->stream;
+    const int g_own = st == nullptr ? 1 : 0;                  // first group that runs on a stream of the library
+    const size_t wl_stride = (size_t)b->chains_cap * kMaxQueries + 1;
+    auto kev = [&](int i) -> hipEvent_t {
+        if (!es) return nullptr;
+        while ((int)es->kev.size() <= i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; es->kev.push_back(e); }
+        return es->kev[i];
+    };
+    GroupFork fork(c, G, g_own);
+    int rc = fork.fork();
+    if (rc) return rc;
+    for (int step = step_a; step < step_b; step++) {
         for (int outer = 0; outer < 2; outer++) {
             for (int g = 0; g < G; g++) {
                 hipStream_t sg = (G == 1 || g < g_own) ? st : c->gstream[g];
                 OdomView og = o;
-                og.chain0 = (int)((long long)g * n_chains / G); og.chain1 = (int)((long long)(g + 1) * n_chains / G);
+                og.chain0 = (int)((long long)g * n_ch / G); og.chain1 = (int)((long long)(g + 1) * n_ch / G);
                 const int ng = og.chain1 - og.chain0;
+                if (ng <= 0) continue;
                 unsigned int *wlg = b->wl + g * wl_stride;
                 hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
-                if (g == 0) { e0 = kev(ne); e1 = kev(ne + 1); e2 = kev(ne + 2); }
+                if (g == 0 && es) { e0 = kev(*ne); e1 = kev(*ne + 1); e2 = kev(*ne + 2); }
                 if (e0 && e1 && e2) (void)hipEventRecord(e0, sg);
                 if (tile == 3) {
                     hipLaunchKernelGGL(k_corr_flat, dim3(8 * ((ng + 7) / 8) * kCfBlocks), dim3(kCfT), 0, sg, b->v, og, step, outer, wlg, c->opt[LMONO_OPT_DEFER_EVERY], c->stats_d);
@@ -518,30 +539,176 @@ static int odom_run(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, d
                     hipLaunchKernelGGL(k_correspond, dim3(8 * ((ng + 7) / 8) * kCorrBlocks), dim3(256), 0, sg, b->v, og, step, outer);
                 if (e0 && e1 && e2) (void)hipEventRecord(e1, sg);
                 hipLaunchKernelGGL(k_lm_solve, dim3(ng), dim3(kLmT), kLmRecLds, sg, b->v, og, step, outer, tile ? wlg : (unsigned int *)nullptr);
-                if (e0 && e1 && e2) { (void)hipEventRecord(e2, sg); ne += 3; }
+                if (e0 && e1 && e2) { (void)hipEventRecord(e2, sg); *ne += 3; }
             }
         }
     }
-    if (G > 1)
-        for (int g = g_own; g < G; g++) { HIP_TRY(c, hipEventRecord(c->gev[g + 1], c->gstream[g])); HIP_TRY(c, hipStreamWaitEvent(st, c->gev[g + 1], 0)); }
+    return fork.join();
+}
+
+// Boundary validation + repair rounds of the chained schedule ("self-validating chains").  ext: incr[first - 1]
+// was supplied by the caller (previous rank's last increment).  Synchronises the context stream (the flagged count decides what is
+// launched).  Results in b->brep / b->resid_h / b->rerun_h.
+static int odom_validate(lmono_ctx *c, lmono_scan_batch *b, OdomView o, bool ext, bool first_call)
+{
+    hipStream_t st = c->stream;
+    const int n_chains = o.n_chains;
+    lmono_boundary_report &R = b->brep;
+    if (first_call) {
+        R = lmono_boundary_report{};
+        R.n_chains = n_chains; R.tol = o.tol;
+        b->resid_h.assign(n_chains, 0.0); b->rerun_h.assign(n_chains, 0);
+    }
+    if (!b->rep_ev[0]) for (auto &e : b->rep_ev) HIP_TRY(c, hipEventCreate(&e));
+    HIP_TRY(c, hipEventRecord(b->rep_ev[0], st));
+    int max_len = 0;
+    for (int ch = 0; ch < n_chains; ch++) { int s, e; chain_bounds(o.first, o.n_scans, n_chains, ch, s, e); max_len = e - s > max_len ? e - s : max_len; }
+    const int tile = c->opt[LMONO_OPT_CORR_TILE];
+    std::vector<int> rs((size_t)n_chains * 4);
+    for (int round = 0; round < n_chains + 1; round++) {
+        const bool very_first = first_call && round == 0;
+        hipLaunchKernelGGL(k_boundary_check, dim3(1), dim3(256), 0, st, o, very_first ? b->resid_d : (double *)nullptr, very_first ? 1 : 0, ext ? 1 : 0);
+        unsigned int cnt[2] = { 0, 0 };
+        HIP_TRY(c, hipMemcpyAsync(cnt, b->rcount, sizeof(cnt), hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        if (very_first) {
+            HIP_TRY(c, hipMemcpy(b->resid_h.data(), b->resid_d, sizeof(double) * n_chains, hipMemcpyDeviceToHost));
+            for (int ch = 0; ch < n_chains; ch++) R.max_resid = b->resid_h[ch] > R.max_resid ? b->resid_h[ch] : R.max_resid;
+        }
+        const int nf = (int)cnt[0];
+        if (nf == 0) break;
+        R.flagged += nf; R.rounds += 1;
+        OdomView orp = o;
+        orp.repair = 1; orp.clist = (const int *)(b->rcount + 2); orp.lead_full = -1;
+        const int G = odom_groups(c, nf);
+        if (tile) for (int g = 0; g < G; g++) HIP_TRY(c, hipMemsetAsync(b->wl + g * ((size_t)b->chains_cap * kMaxQueries + 1), 0, sizeof(unsigned int), st));
+        // a repair chain usually agrees with the stored increments after a few pairs: launch in chunks, ask the device how many still run
+        int done = 0, chunk = 2;
+        while (done < max_len) {
+            const int upto = done + chunk < max_len ? done + chunk : max_len;
+            orp.step0 = 0;
+            int rc = odom_launch_steps(c, b, orp, nf, done, upto, G, nullptr, nullptr);
+            if (rc) return rc;
+            done = upto;
+            HIP_TRY(c, hipMemcpyAsync(cnt, b->rcount, sizeof(cnt), hipMemcpyDeviceToHost, st));
+            HIP_TRY(c, hipStreamSynchronize(st));
+            if (cnt[1] == 0) break;
+            chunk = chunk < 8 ? chunk * 2 : 8;
+        }
+    }
+    HIP_TRY(c, hipEventRecord(b->rep_ev[1], st));
+    HIP_TRY(c, hipMemcpyAsync(rs.data(), b->rstat, sizeof(int) * 4 * n_chains, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, b->rep_ev[0], b->rep_ev[1]) == hipSuccess) R.repair_ms += ms;
+    R.pairs_rerun = 0; R.chains_rerun = 0; R.unresolved = 0;
+    for (int ch = 0; ch < n_chains; ch++) {
+        b->rerun_h[ch] = rs[ch * 4 + 1];
+        R.pairs_rerun += rs[ch * 4 + 1]; R.chains_rerun += rs[ch * 4 + 3] > 0 ? 1 : 0;
+        R.unresolved += rs[ch * 4 + 2] && !rs[ch * 4] ? 1 : 0;
+    }
+    return check_launch(c, "boundary validation");
+}
+
+static OdomView odom_view(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, int first)
+{
+    OdomView o{};
+    o.n_scans = b->n_scans; o.n_chains = n_chains; o.lead = lead; o.first = first; o.fixed_k = -1; o.chain0 = 0; o.chain1 = n_chains;
+    o.lead_full = c->opt[LMONO_OPT_CORR_TILE] == 3 ? c->opt[LMONO_OPT_LEAD_FULL] : -1;     // only the default search thins lead-in pairs
+    o.state = b->state; o.corr = b->corr; o.incr = b->incr; o.lm_info = b->lm_info; o.crec = b->crec; o.seed = b->seed;
+    o.ws = b->ws; o.repair = 0; o.step0 = 0; o.clist = nullptr; o.rstat = b->rstat; o.rcount = b->rcount;
+    o.tol = 1e-9 * (double)c->opt[LMONO_OPT_BOUNDARY_TOL];
+    return o;
+}
+
+static int odom_run(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, int first, double *incr_d, double *poses_d, bool want_poses)
+{
+    if (!c || !b || !b->registered || lead < 0 || first < 0 || first >= b->n_scans) return LMONO_EINVAL;
+    const int n = b->n_scans;
+    if (n_chains < 1) n_chains = 1;
+    if (n_chains > n - first) n_chains = n - first;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = ensure_odom_ws(c, b, n_chains);
+    if (rc) return rc;
+    OdomView o = odom_view(c, b, n_chains, lead, first);
+    b->last_chains = n_chains; b->last_lead = lead; b->last_first = first;
+    int max_steps = 0;
+    for (int ch = 0; ch < n_chains; ch++) {
+        int s, e;
+        chain_bounds(first, n, n_chains, ch, s, e);
+        const int begin = s - lead > 0 ? s - lead : 0;
+        const int steps = e - begin - 1;
+        max_steps = steps > max_steps ? steps : max_steps;
+    }
+    hipStream_t st = c->stream;
+    if (c->n_sets == 0 || c->sets[c->n_sets - 1].odom) c->ev = c->next_set();
+    if (!c->ev) { c->err = "hipEventCreate failed"; return LMONO_ENODEV; }
+    c->sets[c->n_sets - 1].odom = true;
+    HIP_TRY(c, hipEventRecord(c->ev[8], st));
+    const int ninit = n > n_chains ? n : n_chains;
+    hipLaunchKernelGGL(k_odom_init, dim3((ninit + 255) / 256), dim3(256), 0, st, o);
+    const int tile = c->opt[LMONO_OPT_CORR_TILE];
+    if (tile != 3) { rc = ensure_grid(c, b); if (rc) return rc; }
+    const int G = odom_groups(c, n_chains);
+    if (tile) for (int g = 0; g < G; g++) HIP_TRY(c, hipMemsetAsync(b->wl + g * ((size_t)b->chains_cap * kMaxQueries + 1), 0, sizeof(unsigned int), st));
+    EvSet &es = c->sets[c->n_sets - 1];
+    int ne = 0;
+    rc = odom_launch_steps(c, b, o, n_chains, 0, max_steps, G, &es, &ne);
+    if (rc) return rc;
     es.n_kev = ne;
-    if (want_poses) hipLaunchKernelGGL(k_pose_prefix, dim3(1), dim3(64), 0, st, (const double *)b->incr, b->poses, 0, n);
+    // the chained schedule validates itself: every chain's warm start against its predecessor's last increment, repair where they differ
+    b->brep = lmono_boundary_report{};
+    b->brep.n_chains = n_chains;
+    if (o.tol > 0.0 && n_chains > 1) { rc = odom_validate(c, b, o, false, true); if (rc) return rc; }
+    if (want_poses) hipLaunchKernelGGL(k_pose_prefix, dim3(1), dim3(64), 0, st, (const double *)b->incr, b->poses, first, n);
     HIP_TRY(c, hipEventRecord(c->ev[9], st));
     rc = check_launch(c, "odometry kernels");
     if (rc) return rc;
     if (incr_d) HIP_TRY(c, hipMemcpyAsync(incr_d, b->incr, sizeof(double) * 7 * n, hipMemcpyDeviceToDevice, st));
-    if (poses_d) HIP_TRY(c, hipMemcpyAsync(poses_d, b->poses, sizeof(double) * 7 * n, hipMemcpyDeviceToDevice, st));
+    if (poses_d) HIP_TRY(c, hipMemcpyAsync(poses_d, b->poses, sizeof(double) * 7 * (n - first), hipMemcpyDeviceToDevice, st));
     return LMONO_OK;
 }
 
 extern "C" int lmono_odom_batch_d(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, double *incr_d, double *poses_d)
 {
-    return odom_run(c, b, n_chains, lead, incr_d, poses_d, poses_d != nullptr);
+    return odom_run(c, b, n_chains, lead, 0, incr_d, poses_d, poses_d != nullptr);
+}
+
+extern "C" int lmono_odom_shard_d(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, int first_owned, double *incr_d)
+{
+    return odom_run(c, b, n_chains, lead, first_owned, incr_d, nullptr, false);
+}
+
+extern "C" int lmono_odom_shard_validate(lmono_ctx *c, lmono_scan_batch *b, const double *prev_incr_h, double *incr_d, int *changed_last)
+{
+    if (!c || !b || !b->registered || !prev_incr_h || b->last_chains < 1 || b->last_first < 1) return LMONO_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    OdomView o = odom_view(c, b, b->last_chains, b->last_lead, b->last_first);
+    const int n = b->n_scans;
+    double before[7], after[7];
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(before, b->incr + (size_t)(n - 1) * 7, sizeof(before), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(b->incr + (size_t)(o.first - 1) * 7, prev_incr_h, sizeof(double) * 7, hipMemcpyHostToDevice));
+    if (o.tol > 0.0) { int rc = odom_validate(c, b, o, true, false); if (rc) return rc; }
+    HIP_TRY(c, hipMemcpy(after, b->incr + (size_t)(n - 1) * 7, sizeof(after), hipMemcpyDeviceToHost));
+    if (changed_last) *changed_last = std::memcmp(before, after, sizeof(before)) != 0 ? 1 : 0;
+    if (incr_d) HIP_TRY(c, hipMemcpyAsync(incr_d, b->incr, sizeof(double) * 7 * n, hipMemcpyDeviceToDevice, c->stream));
+    return LMONO_OK;
+}
+
+extern "C" int lmono_odom_boundary_report(lmono_ctx *c, lmono_scan_batch *b, lmono_boundary_report *rep, double *resid_h, int32_t *rerun_h, int cap)
+{
+    if (!c || !b || !rep) return LMONO_EINVAL;
+    *rep = b->brep;
+    const int n = b->brep.n_chains;
+    if ((resid_h || rerun_h) && cap < n) { c->err = "boundary_report: output capacity too small"; return LMONO_ECAPACITY; }
+    for (int i = 0; i < n && i < (int)b->resid_h.size(); i++) { if (resid_h) resid_h[i] = b->resid_h[i]; if (rerun_h) rerun_h[i] = b->rerun_h[i]; }
+    return LMONO_OK;
 }
 
 extern "C" int lmono_odom_batch(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, double *incr_h, double *poses_h)
 {
-    int rc = odom_run(c, b, n_chains, lead, nullptr, nullptr, poses_h != nullptr);
+    int rc = odom_run(c, b, n_chains, lead, 0, nullptr, nullptr, poses_h != nullptr);
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     const int n = b->n_scans;
@@ -562,7 +729,7 @@ extern "C" int lmono_odom_correspond(lmono_ctx *c, lmono_scan_batch *b, int scan
     HIP_TRY(c, hipMemcpy(fn, b->v.feat_n + scan * 4, sizeof(fn), hipMemcpyDeviceToHost));
     const int nq = fn[0] + fn[2];
     if (nq > cap) { c->err = "odom_correspond: output capacity too small"; return LMONO_ECAPACITY; }
-    OdomView o;
+    OdomView o{};
     o.n_scans = b->n_scans; o.n_chains = 1; o.lead = 0; o.fixed_k = scan; o.chain0 = 0; o.chain1 = 1; o.lead_full = -1;
     o.state = b->xq; o.corr = b->corr_pair; o.incr = nullptr; o.lm_info = nullptr; o.crec = b->crec_pair; o.seed = nullptr;
     int rc;

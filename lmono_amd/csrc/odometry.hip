@@ -248,6 +248,7 @@ __global__ __launch_bounds__(1024) void k_grid_build(BatchView b)
 // ------------------------------------------------------------------------------------------------
 struct OdomView {
     int n_scans, n_chains, lead;
+    int first;            // first owned scan of the batch (> 0: the scans before it are the lead-in of chain 0, results discarded)
     int chain0, chain1;   // the chains this launch advances: [chain0, chain1) (groups of chains run on their own streams)
     int fixed_k;          // >= 0: single-pair debug view, every chain works on this scan
     int lead_full;        // >= 0: only the last lead_full lead-in scan pairs of a chain use all feature points, the earlier ones every
@@ -258,12 +259,23 @@ struct OdomView {
     double *incr;         // [n_scans][7]
     int *lm_info;         // [n_chains][4]
     int *seed;            // [n_chains][kMaxQueries] nearest point found by the previous outer iteration of the same scan pair (-1: none)
+    // ---- boundary validation of the chained schedule (k_boundary_check, repair launches; lmono_hip.hip: odom_run)
+    double *ws;           // [n_chains][8] the warm start chain c used for its first owned scan pair: the result of its last lead-in pair
+                          // (identity without a lead-in); after a repair, the increment it was re-started from
+    int repair;           // 1: repair launch -- chain slot c re-runs its OWN pairs from scan s_c on (no lead-in: state = incr[s_c - 1]),
+                          // compares every new increment with the stored one and stops at the first that agrees within tol
+    int step0;            // repair: pairs of the chain already re-run by earlier launches of this repair round
+    const int *clist;     // repair: the launch's chains are clist[chain0 .. chain1) (flagged boundaries); nullptr: chains chain0 .. chain1
+    int *rstat;           // [n_chains][4] repair state: [0] stopped (agreement or end of chain), [1] pairs re-run in total, [2] flagged in the current round, [3] times flagged
+    unsigned int *rcount; // [0] chains flagged by k_boundary_check, [1] repair chains still running, then the flagged chain ids (clist)
+    double tol;           // agreement bound of boundary_residual()
 };
 
-__device__ __forceinline__ void chain_bounds(int n_scans, int n_chains, int c, int &s, int &e)
+// scans [first, n_scans) are cut into n_chains ranges; scans before `first` are an external lead-in (the previous rank's scans)
+__device__ __host__ __forceinline__ void chain_bounds(int first, int n_scans, int n_chains, int c, int &s, int &e)
 {
-    s = (int)((long long)c * n_scans / n_chains);
-    e = (int)((long long)(c + 1) * n_scans / n_chains);
+    s = first + (int)((long long)c * (n_scans - first) / n_chains);
+    e = first + (int)((long long)(c + 1) * (n_scans - first) / n_chains);
 }
 
 __device__ __forceinline__ void quat_rotate(const double *q, double vx, double vy, double vz, double &ox, double &oy, double &oz)
@@ -430,6 +442,7 @@ __device__ __forceinline__ int4 correspond_one(const BatchView &b, int k, int qi
 }
 
 constexpr int kThinStride = 4;
+static_assert(kMaxQueries <= 4096, "the work lists pack (chain << 12 | feature index)");
 
 // lead-in scan pair k of a chain owning scans from own_begin on that runs on a thinned feature set
 __device__ __forceinline__ bool lead_in_thinned(const OdomView &o, int k, int own_begin)
@@ -442,11 +455,25 @@ __device__ __forceinline__ int chain_scan(const OdomView &o, int c, int step, in
 {
     if (o.fixed_k >= 0) { own_begin = 0; return o.fixed_k; }
     int s, e;
-    chain_bounds(o.n_scans, o.n_chains, c, s, e);
+    chain_bounds(o.first, o.n_scans, o.n_chains, c, s, e);
     own_begin = s;
+    if (o.repair) {
+        const int k = s + o.step0 + step;
+        return (k < e && !o.rstat[c * 4]) ? k : -1;
+    }
     const int begin = max(s - o.lead, 0);
     const int k = begin + 1 + step;
     return k < e ? k : -1;
+}
+
+// Distance of two scan-pair increments (q xyzw, t): max(|dq_i| with the signs aligned, 0.1 |dt_i| / m) -- 1e-6 = 2e-6 rad, 1e-5 m.
+__device__ __forceinline__ double boundary_residual(const double *a, const double *b)
+{
+    const double sg = (a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]) < 0.0 ? -1.0 : 1.0;
+    double r = 0.0;
+    for (int i = 0; i < 4; i++) r = fmax(r, fabs(a[i] - sg * b[i]));
+    for (int i = 4; i < 7; i++) r = fmax(r, 0.1 * fabs(a[i] - b[i]));
+    return r == r ? r : 1e300;            // a NaN never agrees
 }
 
 // ---- (line, azimuth-bin) index of a feature cloud -------------------------------------------------------------
@@ -1055,7 +1082,7 @@ __global__ __launch_bounds__(256, 8) void k_correspond(BatchView b, OdomView o, 
 __global__ __launch_bounds__(256, 4) void k_correspond_list(BatchView b, OdomView o, int step, int outer, const unsigned int *wl, unsigned long long *stats)
 {
     const unsigned int n = wl[0];
-    if (blockIdx.x == 0 && threadIdx.x == 0 && stats) stats[0] += n;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && stats && n) atomicAdd(&stats[0], (unsigned long long)n);       // chain groups run this kernel concurrently
     const int lane = threadIdx.x & 63;
     const int gl = threadIdx.x & (kGroup - 1), gbase = lane & ~(kGroup - 1);
     for (unsigned int it = blockIdx.x * 8 + (threadIdx.x >> 5); it < n; it += gridDim.x * 8) {
@@ -1335,7 +1362,7 @@ constexpr int kThinBlocks = kMaxQueries / 128;     // = kCfBlocks of corr_flat.h
 // block-reduced sums; residual blocks come from the 64-B records written by k_correspond.
 __global__ __launch_bounds__(kLmT) void k_lm_solve(BatchView b, OdomView o, int step, int outer, unsigned int *wl_reset)
 {
-    const int c = o.chain0 + blockIdx.x;
+    const int c = o.clist ? o.clist[o.chain0 + blockIdx.x] : o.chain0 + (int)blockIdx.x;
     if (wl_reset && blockIdx.x == 0 && threadIdx.x == 0) wl_reset[0] = 0u;      // the work list of the next correspondence launch starts empty
     int s;
     const int k = chain_scan(o, c, step, s);
@@ -1463,10 +1490,65 @@ __global__ __launch_bounds__(kLmT) void k_lm_solve(BatchView b, OdomView o, int 
     }
     if (tid == 0) {
         for (int i = 0; i < 7; i++) o.state[c * 8 + i] = x[i];
-        if (o.incr && outer == 1 && k >= s)
+        if (o.repair && outer == 1) {
+            // repair chain: the pair's stored increment came from a warm start that failed the boundary check (or from a chain
+            // re-started behind one).  Replace it; once the new one agrees with the stored one the rest of the chain stands.
+            int e0, e1;
+            chain_bounds(o.first, o.n_scans, o.n_chains, c, e0, e1);
+            const double res = boundary_residual(x, o.incr + (size_t)k * 7);
             for (int i = 0; i < 7; i++) o.incr[(size_t)k * 7 + i] = x[i];
+            o.rstat[c * 4 + 1] += 1;
+            if (res <= o.tol || k + 1 >= e1) { o.rstat[c * 4] = 1; atomicSub(&o.rcount[1], 1u); }
+        } else if (o.incr && outer == 1 && k >= s)
+            for (int i = 0; i < 7; i++) o.incr[(size_t)k * 7 + i] = x[i];
+        if (o.ws && !o.repair && outer == 1 && k == s - 1)
+            for (int i = 0; i < 7; i++) o.ws[c * 8 + i] = x[i];       // the warm start of the chain's first owned pair
         if (o.lm_info) { o.lm_info[c * 4 + outer] = iter; o.lm_info[c * 4 + 2 + outer] = n_used; }
     }
+}
+
+// Boundary validation of the chained schedule.  Chain c > 0 warm-starts its first owned pair (s_c - 1, s_c) from ws[c] (its own
+// lead-in's estimate of the pair before), the strictly sequential schedule from incr[s_c - 1], which chain c - 1 owns.  Where the two
+// agree within tol chain c's increments are the sequential schedule's (to the sensitivity of one pair to its warm start); where they
+// do not, the chain is flagged: its slot is re-started from incr[s_c - 1] (state, ws) and listed in rcount[2..] for the repair
+// launches.  One workgroup; the list is in chain order.  resid (may be null): [n_chains] residual of this check per boundary.
+// ext: incr[first - 1] holds the previous rank's last increment, so chain 0's boundary is checked as well.
+__global__ __launch_bounds__(256) void k_boundary_check(OdomView o, double *resid, int first_round, int ext)
+{
+    __shared__ int s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    for (int base = 0; base < o.n_chains; base += 256) {
+        const int c = base + threadIdx.x;
+        bool flag = false;
+        if (c < o.n_chains) {
+            int s, e;
+            chain_bounds(o.first, o.n_scans, o.n_chains, c, s, e);
+            double res = 0.0;
+            if ((c > 0 || ext) && s > 0) res = boundary_residual(o.ws + c * 8, o.incr + (size_t)(s - 1) * 7);
+            if (resid) resid[c] = res;
+            flag = res > o.tol;
+            if (first_round) { o.rstat[c * 4 + 1] = 0; o.rstat[c * 4 + 3] = 0; }
+            o.rstat[c * 4] = flag ? 0 : 1;
+            o.rstat[c * 4 + 2] = flag ? 1 : 0;
+            if (flag) {
+                o.rstat[c * 4 + 3] += 1;
+                for (int i = 0; i < 7; i++) { const double v = o.incr[(size_t)(s - 1) * 7 + i]; o.state[c * 8 + i] = v; o.ws[c * 8 + i] = v; }
+            }
+        }
+        // ordered compaction: wave ballots + a running base
+        const unsigned long long m = __ballot(flag);
+        __shared__ int s_w[4];
+        if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = __popcll(m);
+        __syncthreads();
+        int pre = s_n;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); w++) pre += s_w[w];
+        if (flag) o.rcount[2 + pre + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = (unsigned int)c;
+        __syncthreads();
+        if (threadIdx.x == 0) s_n += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { o.rcount[0] = (unsigned int)s_n; o.rcount[1] = (unsigned int)s_n; }
 }
 
 __global__ void k_odom_init(OdomView o)
@@ -1475,6 +1557,7 @@ __global__ void k_odom_init(OdomView o)
     if (i < o.n_chains) {
         double *st = o.state + i * 8;
         st[0] = st[1] = st[2] = 0.0; st[3] = 1.0; st[4] = st[5] = st[6] = 0.0; st[7] = 0.0;
+        if (o.ws) { double *w = o.ws + i * 8; w[0] = w[1] = w[2] = 0.0; w[3] = 1.0; w[4] = w[5] = w[6] = 0.0; w[7] = 0.0; }
     }
     if (i < o.n_scans) {
         double *r = o.incr + (size_t)i * 7;

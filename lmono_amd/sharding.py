@@ -70,6 +70,31 @@ def gather_bases(my_base, group=None):
     return out.view(world, 7)
 
 
+def validate_rank_boundaries(last_incr, validate, rank, world, group=None, max_rounds=None):
+    """The rank boundaries of a scan-range shard checked like the chain boundaries inside a rank (lmono_odom_shard_validate): every rank
+    publishes its LAST increment (one all-gather of 7 doubles), rank r > 0 hands rank r-1's to `validate(prev_incr [7] numpy) -> bool`
+    (True when its own last increment changed by the repair), and the round repeats while any rank reports a change (one all-reduce of a
+    flag) -- a repair rarely reaches the end of a rank's range, so this is one round in practice.  last_incr() -> torch tensor [7]
+    float64, the rank's current last increment (on the GPU for RCCL, on the CPU for gloo).  Returns the number of rounds."""
+    import torch
+    import torch.distributed as dist
+    rounds = 0
+    limit = max_rounds if max_rounds is not None else world
+    while rounds < limit:
+        mine = last_incr().contiguous().reshape(7)
+        last = torch.empty(world * 7, dtype=torch.float64, device=mine.device)
+        dist.all_gather_into_tensor(last, mine, group=group)
+        changed = False
+        if rank > 0:
+            changed = bool(validate(last.view(world, 7)[rank - 1].cpu().numpy()))
+        flag = torch.tensor([1.0 if changed else 0.0], dtype=torch.float64, device=mine.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        rounds += 1
+        if float(flag.item()) == 0.0:
+            break
+    return rounds
+
+
 def pose_graph_rounds(graph, rank, world, max_iter=5, all_reduce=None):
     """Loop-closure pose graph over `world` ranks: every rank holds the same graph object (lmono_amd.PoseGraph
     on a GPU; anything with linearise(rank, world) / reduce_tensor / step(max_iter) works), linearises the edges it owns, ONE

@@ -9,7 +9,11 @@ Contents: poses [4541,7] f64 (q xyzw, t; laserOdometry's q_w_curr / t_w_curr), i
 feat_counts [4541,4] i32 (sharp, less sharp, flat, less flat), n_points [4541] i32 (raw returns per scan: pins the
 generator), meta.  Takes ~3 min on 8 cores (front end in parallel over scans, odometry sequential).
 
-    python tests/golden/make_s1_trajectory.py [n_scans]
+    python tests/golden/make_s1_trajectory.py [n_scans] [seq]
+
+seq 1 = the HELD-OUT sequence tests/golden/s1_seq01_oracle.npz: another world (S1World(seed=777): other boxes and poles) and another
+trajectory (S1World.trajectory_clover: three-leaf clover at 4 .. 10 m/s).  The chain schedule's parameters were never tuned on it;
+tests/test_chain_validation_gpu.py runs every chain layout on both sequences.
 """
 import os
 import sys
@@ -25,20 +29,23 @@ from oracle import oracle as O          # noqa: E402
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 4541
+    seq = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     S1.build(); O.build()
-    w = S1.S1World(n_az=2000)
-    traj = w.trajectory(n)
+    w = S1.S1World(n_az=2000) if seq == 0 else S1.S1World(seed=777, n_az=2000)
+    traj = w.trajectory(n) if seq == 0 else w.trajectory_clover(n)
     t0 = time.time()
     xyzi, off = w.scans(traj)
     print("generated %d scans, %d points in %.1f s" % (n, off[-1], time.time() - t0), flush=True)
     t0 = time.time()
     ref = O.run_sequence(xyzi, off, n_chains=1, lead=0, threads=len(os.sched_getaffinity(0)))
     print("oracle: %.1f s (scanreg %.0f ms, odometry %.0f ms)" % (time.time() - t0, ref["stage_ms"][0], ref["stage_ms"][1]), flush=True)
-    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "s1_seq00_oracle.npz" if n == 4541 else "s1_seq00_oracle_%d.npz" % n)
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), ("s1_seq%02d_oracle.npz" % seq) if n == 4541 else "s1_seq%02d_oracle_%d.npz" % (seq, n))
     np.savez_compressed(out, poses=ref["poses"], incr=ref["incr"], feat_counts=ref["feat_counts"],
                         n_points=np.diff(off).astype(np.int32),
-                        meta=np.array("S1World(seed=20240, n_az=2000, n_rings=64), trajectory(%d), n_lines=64, min_range=5.0, "
-                                      "oracle n_chains=1 lead=0 kd-tree" % n))
+                        meta=np.array(("S1World(seed=20240, n_az=2000, n_rings=64), trajectory(%d), n_lines=64, min_range=5.0, "
+                                       "oracle n_chains=1 lead=0 kd-tree" if seq == 0 else
+                                       "S1World(seed=777, n_az=2000, n_rings=64), trajectory_clover(%d), n_lines=64, min_range=5.0, "
+                                       "oracle n_chains=1 lead=0 kd-tree") % n))
     print("wrote", out, os.path.getsize(out), "bytes")
 
 

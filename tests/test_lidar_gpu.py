@@ -167,12 +167,21 @@ def test_odometry_sequential_matches_oracle(oracle, gpu_ctx, small_seq):
 
 
 def test_odometry_chain_sharded_matches_oracle(oracle, gpu_ctx, small_seq):
+    """The oracle's chained schedule is the plain one (lead-in from the identity, nothing validated): compared with the boundary
+    validation off.  With it on (default) the same layout is repaired to the strictly sequential result."""
     xyzi, off = small_seq["xyzi"], small_seq["off"]
     batch = _register(gpu_ctx, xyzi, off)
-    incr, poses = batch.odometry(3, 2)
+    gpu_ctx.set_option(gpu_ctx.OPT_BOUNDARY_TOL, 0)
+    try:
+        incr, poses = batch.odometry(3, 2)
+    finally:
+        gpu_ctx.set_option(gpu_ctx.OPT_BOUNDARY_TOL, 1000)
     ref = oracle.run_sequence(xyzi, off, n_chains=3, lead=2)
     assert np.abs(incr - ref["incr"]).max() < 1e-9
     assert np.abs(poses - ref["poses"]).max() < 1e-8
+    incr_v, _ = batch.odometry(3, 2)
+    seq = oracle.run_sequence(xyzi, off)
+    assert np.abs(incr_v - seq["incr"]).max() < 1e-4 and np.abs(incr - seq["incr"]).max() > 1e-4
 
 
 @pytest.mark.parametrize("n_lines,min_range", [(16, 0.5), (32, 0.5), (64, 0.5)])
@@ -307,7 +316,9 @@ def test_api_errors_and_limits(oracle, gpu_ctx, small_seq):
     with pytest.raises(lmono_amd.LmonoError):
         b.scanreg(dev.data_ptr(), off, 48, 5.0)                     # n_lines must be 16 / 32 / 64
     b.scanreg(dev.data_ptr(), off, 64, 5.0, keepalive=dev)
+    gpu_ctx.set_option(gpu_ctx.OPT_BOUNDARY_TOL, 0)                 # the oracle's chained schedule validates nothing
     incr, poses = b.odometry(1000, 2)                               # n_chains is clamped to the number of scans
+    gpu_ctx.set_option(gpu_ctx.OPT_BOUNDARY_TOL, 1000)
     ref = oracle.run_sequence(xyzi, off, n_chains=len(off) - 1, lead=2)
     assert np.abs(incr - ref["incr"]).max() < 1e-9
     one = lmono_amd.ScanBatch(gpu_ctx, 1, len(xyzi))
@@ -316,8 +327,8 @@ def test_api_errors_and_limits(oracle, gpu_ctx, small_seq):
     assert np.array_equal(incr, np.array([[0, 0, 0, 1, 0, 0, 0.0]])) and np.array_equal(poses, incr)
     # options: values are range-checked, a rejected value leaves the option as it was, values may be negative
     for key, bad in ((gpu_ctx.OPT_CORR_TILE, 4), (gpu_ctx.OPT_CORR_TILE, -1), (gpu_ctx.OPT_ODOM_STREAMS, 0), (gpu_ctx.OPT_ODOM_STREAMS, 9),
-                     (gpu_ctx.OPT_DEFER_EVERY, -1), (gpu_ctx.OPT_LEAD_FULL, -2), (17, 0)):
-        before = gpu_ctx.get_option(key) if key < 4 else None
+                     (gpu_ctx.OPT_DEFER_EVERY, -1), (gpu_ctx.OPT_LEAD_FULL, -2), (gpu_ctx.OPT_BOUNDARY_TOL, -1), (17, 0)):
+        before = gpu_ctx.get_option(key) if key < 5 else None
         with pytest.raises(lmono_amd.LmonoError):
             gpu_ctx.set_option(key, bad)
         if before is not None:

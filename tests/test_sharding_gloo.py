@@ -100,3 +100,43 @@ def test_two_rank_pose_graph_rounds_equal_single_process():
         assert np.abs(out - ref).max() < 1e-9
         assert len(calls) == rounds and rounds <= 6 and all(c == calls[0] for c in calls)      # one all-reduce per round
     assert np.array_equal(ret[0][0], ret[1][0])                     # both ranks hold bit-identical keyframes
+
+
+def _vb_worker(rank, world, port, ret):
+    """Rank-boundary validation rounds (lmono_amd.sharding.validate_rank_boundaries) over gloo with a stand-in for the GPU batch:
+    `ws` = the rank's own lead-in estimate of the previous rank's last increment, a repair adopts the published one, and on rank 1 the
+    repair reaches the end of the rank's range (its last increment changes -> rank 2 must validate again)."""
+    sys.path.insert(0, ROOT)
+    from lmono_amd import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tol = 1e-6
+    st = {"last": np.array([0, 0, 0, 1, 0.8 + 0.01 * rank, 0, 0.0]), "ws": np.array([0, 0, 0, 1, 0.8 + 0.01 * (rank - 1) + 1e-4, 0, 0.0]), "calls": 0, "repairs": 0}
+
+    def validate(prev):
+        st["calls"] += 1
+        if np.abs(prev - st["ws"]).max() <= tol:
+            return False
+        st["ws"] = prev.copy(); st["repairs"] += 1
+        if rank == 1 and st["repairs"] == 1:
+            st["last"] = st["last"] + 1e-3          # the repair ran to the end of this rank's range
+            return True
+        return False
+    rounds = sharding.validate_rank_boundaries(lambda: torch.from_numpy(st["last"].copy()), validate, rank, world)
+    ret[rank] = (rounds, st["calls"], st["repairs"], st["ws"], st["last"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rank_boundary_validation_rounds_over_gloo():
+    world = 3
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_vb_worker, args=(world, 29541, ret), nprocs=world, join=True)
+    rounds = [ret[r][0] for r in range(world)]
+    assert rounds == [2, 2, 2]                       # round 1 repairs ranks 1 and 2, rank 1's change sends rank 2 round again
+    assert ret[0][1] == 0 and ret[1][1] == 2 and ret[2][1] == 2
+    assert ret[1][2] == 1 and ret[2][2] == 2
+    for r in (1, 2):
+        assert np.array_equal(ret[r][3], ret[r - 1][4])      # every rank's warm start is its predecessor's final last increment

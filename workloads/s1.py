@@ -95,6 +95,26 @@ class S1World:
         yaw = np.unwrap(np.arctan2(dy, dx))
         return np.stack([xk, yk, np.zeros(n_scans), yaw], 1)
 
+    def trajectory_clover(self, n_scans, dt=0.1):
+        """Held-out trajectory (not the one the chain schedule was tuned on): a three-leaf clover r = 60 + 18 cos(3 phi) driven at a
+        varying speed v(t) = 7 + 3 sin(2 pi t / 37 s) m/s (4 .. 10 m/s; the figure-8 runs at a constant 8), yaw along the tangent."""
+        u = np.linspace(0, 2 * np.pi, 40001)
+        r = 60.0 + 18.0 * np.cos(3 * u)
+        x = r * np.cos(u); y = r * np.sin(u)
+        ds = np.hypot(np.diff(x), np.diff(y))
+        s = np.concatenate([[0], np.cumsum(ds)])
+        total = s[-1]
+        t = np.arange(n_scans) * dt
+        # distance driven: integral of v(t)
+        sk = (7.0 * t + 3.0 * 37.0 / (2 * np.pi) * (1.0 - np.cos(2 * np.pi * t / 37.0))) % total
+        uk = np.interp(sk, s, u)
+        rk = 60.0 + 18.0 * np.cos(3 * uk)
+        xk = rk * np.cos(uk); yk = rk * np.sin(uk)
+        drk = -54.0 * np.sin(3 * uk)
+        dx = drk * np.cos(uk) - rk * np.sin(uk); dy = drk * np.sin(uk) + rk * np.cos(uk)
+        yaw = np.unwrap(np.arctan2(dy, dx))
+        return np.stack([xk, yk, np.zeros(n_scans), yaw], 1)
+
     def scans(self, poses, scan_id0=0):
         """Returns (xyzi [N,4] float32 concatenated, offsets int64 [n+1])."""
         poses = np.ascontiguousarray(poses, np.float64)
