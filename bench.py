@@ -99,7 +99,7 @@ def bench_ba_seq(args):
     est = np.concatenate([np.zeros((len(odo), 4)), odo[:, 1:4]], 1)
     # ---- cpu_baseline leg: the only place the oracle is touched
     from oracle import estimator_ref as E
-    m = min(args.cpu_sample if args.cpu_sample > 0 else 0, n)
+    m = n if args.cpu_frames < 0 else min(args.cpu_frames, n)            # default: the whole stream (2761 frames: ~20 s on one core)
     res = {"metric": "Estimator frames/sec (sliding-window BA frame loop, S2 synthetic stream)", "value": round(1e3 / ms_frame, 2), "unit": "frames/s",
            "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": round(ms_frame * n_inited, 1), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -122,6 +122,9 @@ def bench_ba_seq(args):
         res["cpu_baseline"] = {"value": round((m - 10) / cpu_s, 2), "unit": "frames/s", "cores": 1, "kind": "port",
                                "sample": "first %d frames of the same stream, oracle/estimator_ref.py over the C oracle (-O3), 1 thread" % m}
         res["max_pos_diff_vs_cpu_m"] = float(np.abs(odo[:len(ref), 1:4] - ref[:, 1:4]).max())
+        k = min(len(ref), len(odo))
+        res["ate_vs_cpu_m"] = round(float(np.sqrt(np.mean(np.sum((odo[:k, 1:4] - ref[:k, 1:4]) ** 2, axis=1)))), 6)
+        res["frames_compared_vs_cpu"] = k
     print(json.dumps(res), flush=True)
 
 
@@ -415,6 +418,7 @@ def main():
     ap.add_argument("--seq", type=int, default=0, choices=[0, 1], help="0: the S1 figure-8 sequence (headline); 1: the held-out sequence (other world, clover trajectory)")
     ap.add_argument("--az", type=int, default=2000, help="azimuth steps per ring (2000 = HDL-64 at 10 Hz)")
     ap.add_argument("--cpu-sample", type=int, default=128, help="scans of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=-1, help="ba-seq: frames of the CPU oracle's replay (-1 = the whole stream)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (sequential run, BA secondary)")
     ap.add_argument("--probe-ranks", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--workload", default="lidar", choices=["lidar", "ba", "ba-seq", "map", "colour", "posegraph"],

@@ -16,8 +16,10 @@
 //   * the camera part of J^T J is a sum of small GEMMs, one per frame pair: the 8 waves walk the staged rows four at a
 //     time with v_mfma_f64_16x16x4_f64 (A = B^T = the same staged value) and add the finished 16x16 blocks into the
 //     LDS-resident 72x72 H_pp once per pair -- no per-observation atomics;
-//   * depth blocks: H_ff, g_f by LDS atomics (2 per observation), the coupling rows H_fp (feature-major, 80 doubles)
-//     in an HBM/L2 scratch.
+//   * depth blocks H_ff, g_f and the coupling rows H_fp (feature-major, 80 doubles, in an HBM/L2 scratch): every observation
+//     leaves its shares in its own 128-B record, one pass per feature sums them in observation order.
+// Every sum of the linearisation is formed in an order fixed by the problem alone (static pair schedule, turn-ordered block
+// additions, per-feature passes): two runs of the same problem give the same bits.
 // Schur complement S = H_pp - sum_f e_f e_f^T / h_ff: 64-feature tiles staged in LDS, 15 upper 16x16 tiles of S
 // accumulated in registers with the same f64 MFMA; blocked Cholesky (8-column panels) and the triangular solves in
 // LDS.  fp64 throughout; contraction to FMA is allowed in this file (the BA parity bar is a tolerance).
@@ -37,7 +39,7 @@ constexpr int kBaRound = 32;                     // observations a wave stages p
 constexpr int kBaRow = 19;                       // staged row: J_i(6) J_j(6) J_ex(6) r (odd stride: few bank conflicts)
 constexpr int kBaFT = 64;                        // features per Schur tile
 constexpr int kBaSS = 73;                        // row stride of S in LDS (odd: conflict-free column walks)
-constexpr int kBaPairRec = 40;                   // T(9) tp(3) Cm(9) A(9) B(9) pad
+constexpr int kBaPairRec = 52;                   // Tres(9) tres(3) Cm(9) A(9) B(9) Tn(9) tn(3) pad
 constexpr int kBaT = 512;                        // threads per workgroup (2 waves per SIMD)
 constexpr int kBaW = kBaT / 64;
 
@@ -64,6 +66,10 @@ struct BaBatch {
     const double *info;         // laser_info[36], mono_info[4], prior_w[2]
     double *hpd;                // scratch [W][kBaMaxFeat][kBaPS] coupling rows, feature-major
     double *pairdat;            // scratch [total pairs][kBaPairRec]
+    const int *feat_obs_off;    // [total F + 1] first observation of every feature (observations grouped by feature, host order)
+    const int *slot_obs;        // [total slots] observation (host order, global index) behind every slot
+    double *obsc;               // scratch [total obs][16]: per-observation depth / coupling contributions (hdd, gd, hx[6], hi[6]),
+                                // in host observation order = grouped by feature: a feature's records are contiguous
     double *cand;               // scratch [W][kBaMaxFeat]
     double *summary;            // [W][6] initial_cost, final_cost, iterations, termination, successful, unsuccessful
 };
@@ -86,11 +92,17 @@ struct BaLds {
     double red[3 * kBaW];
     double poses[kBaMaxPoses * 7], ex[7];
     double cposes[kBaMaxPoses * 7], cex[7];
-    double Rp[(kBaMaxPoses + 1) * 9];            // rotation matrices of the window poses, then R_lc
+    double Rp[(kBaMaxPoses + 1) * 9];            // rotation matrices of the window poses, then R_lc (normalised quaternions: Jacobians)
+    double Mq[(kBaMaxPoses + 1) * 18 + 9];       // per pose and for the extrinsic: M(q), M(q^-1) of the RAW quaternion (residual path); then M(qx^-1)^-1
     double vinv[kBaMaxFeat];                     // inverse depths of the state being evaluated
     int pair_ij[kBaMaxPairs];
     int pair_slot[kBaMaxPairs + 1];              // first slot of every pair (pairs in descending size)
-    int next_pair;                               // work counter of the linearisation
+    // static schedule of the linearisation (ba_schedule, once per launch): which wave takes which frame pairs, and the order
+    // in which the pairs' blocks are added to H_pp -- fixed by the pair sizes alone, so the sums are the same in every run
+    short wlist[kBaMaxPairs];                    // pairs in wave order
+    short woff[kBaW + 1];                        // first entry of every wave in wlist
+    short pair_turn[kBaMaxPairs];                // position of the pair in the add order
+    int turn;                                    // next position allowed to add (-1: the small factors are still being added)
     int ok;
 };
 static_assert(sizeof(BaLds) <= 160 * 1024, "BaLds exceeds the 160 KB LDS of a gfx950 CU");
@@ -129,17 +141,6 @@ __device__ __forceinline__ double block_max(double v, double *red)
     return m;
 }
 
-__device__ __forceinline__ void lds_add_block(double *H, const double *Ja, int oa, const double *Jb, int ob, int nr)
-{
-    for (int a = 0; a < 6; a++)
-        for (int b = 0; b < 6; b++) {
-            double v = 0;
-            for (int r = 0; r < nr; r++) v += Ja[r * 7 + a] * Jb[r * 7 + b];
-            unsafeAtomicAdd(&H[(oa + a) * kBaP + ob + b], v);
-            if (oa != ob) unsafeAtomicAdd(&H[(ob + b) * kBaP + oa + a], v);
-        }
-}
-
 #ifdef LMONO_BA_PROF
 __device__ long long g_prof[16];
 #define BA_TICK(i) { if (blockIdx.x == 0 && threadIdx.x == 0) g_prof[i] -= clock64(); }
@@ -171,9 +172,14 @@ __device__ __forceinline__ void cross3(const double *a, const double *b, double 
     o[2] = a[0] * b[1] - a[1] * b[0];
 }
 
-// everything of MonoProjectionFactor::Evaluate that depends only on (pose_i, pose_j, extrinsic)
-__device__ __forceinline__ void ba_pair_record(const double *Ri, const double *Rj, const double *Rlc, const double *ti, const double *tj,
-                                               const double *tx, double *rec)
+// everything of MonoProjectionFactor::Evaluate that depends only on (pose_i, pose_j, extrinsic).  The reference forms the RESIDUAL with
+// the parameter quaternions as they are (Eigen's q * v and q.inverse() * v, MonoProjectionFactor.cc:64-69: for |q| != 1 the map
+// v -> v + 2 w (u x v) + 2 u x (u x v) is linear but not a rotation) and the JACOBIANS with normalised rotation matrices (:58-60).  The
+// window's quaternions come out of matrix2Double un-normalised in the 9th digit, so the two are kept apart:
+//   Tres, tres   p_cj = Tres (depth p_i) + tres, from M(q) = q_to_R of the raw quaternion and M(q^-1)
+//   Tn, tn, Cm, A, Bm   the normalised products of the Jacobian blocks
+__device__ __forceinline__ void ba_pair_record(const double *Ri, const double *Rj, const double *Rlc, const double *Mi, const double *Mjinv,
+                                               const double *Mx, const double *Mxinv, const double *ti, const double *tj, const double *tx, double *rec)
 {
     double RlcT[9], RjT[9], G[9], A[9], Bm[9], T[9], Cm[9], v[3], v2[3];
     ba::mT(Rlc, RlcT); ba::mT(Rj, RjT);
@@ -192,9 +198,29 @@ __device__ __forceinline__ void ba_pair_record(const double *Ri, const double *R
     ba::mv(RjT, v, v2);
     for (int k = 0; k < 3; k++) v2[k] -= tx[k];
     ba::mv(RlcT, v2, v);
-    for (int k = 0; k < 9; k++) { rec[k] = T[k]; rec[12 + k] = Cm[k]; rec[21 + k] = A[k]; rec[30 + k] = Bm[k]; }
+    for (int k = 0; k < 9; k++) { rec[39 + k] = T[k]; rec[12 + k] = Cm[k]; rec[21 + k] = A[k]; rec[30 + k] = Bm[k]; }
+    for (int k = 0; k < 3; k++) rec[48 + k] = v[k];
+    // residual path: p_cj = Mxinv (Mjinv (Mi (Mx pc + tx) + ti - tj) - tx)
+    double P1[9], P2[9];
+    ba::mm(Mxinv, Mjinv, P1); ba::mm(P1, Mi, P2); ba::mm(P2, Mx, T);
+    ba::mv(Mi, tx, v);
+    for (int k = 0; k < 3; k++) v[k] = v[k] + ti[k] - tj[k];
+    ba::mv(Mjinv, v, v2);
+    for (int k = 0; k < 3; k++) v2[k] -= tx[k];
+    ba::mv(Mxinv, v2, v);
+    for (int k = 0; k < 9; k++) rec[k] = T[k];
     for (int k = 0; k < 3; k++) rec[9 + k] = v[k];
-    rec[39] = 0.0;
+    rec[51] = 0.0;
+}
+
+// inverse of a 3x3 matrix (row-major) by the adjugate
+__device__ __forceinline__ void inv3(const double *m, double *o)
+{
+    const double c0 = m[4] * m[8] - m[5] * m[7], c1 = m[5] * m[6] - m[3] * m[8], c2 = m[3] * m[7] - m[4] * m[6];
+    const double id = 1.0 / (m[0] * c0 + m[1] * c1 + m[2] * c2);
+    o[0] = c0 * id; o[1] = (m[2] * m[7] - m[1] * m[8]) * id; o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+    o[3] = c1 * id; o[4] = (m[0] * m[8] - m[2] * m[6]) * id; o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+    o[6] = c2 * id; o[7] = (m[1] * m[6] - m[0] * m[7]) * id; o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
 }
 
 // v + the value of the neighbouring lane (lane ^ 1): DPP quad_perm [1, 0, 3, 2], no LDS round trip
@@ -212,7 +238,6 @@ typedef __attribute__((address_space(1))) const int ba_gci;
 __device__ __forceinline__ double gld(const double *p) { return *(ba_gcd *)p; }
 __device__ __forceinline__ int gldi(const int *p) { return *(ba_gci *)p; }
 __device__ __forceinline__ void gst(double *p, double v) { *(ba_gd *)p = v; }
-__device__ __forceinline__ void gatomic_add(double *p, double v) { (void)__builtin_amdgcn_global_atomic_fadd_f64((ba_gd *)p, v); }
 
 // LASERFactor chain and the extrinsic prior: a handful of residual blocks, one thread each.  The thread leaves its
 // residuals and Jacobians in LDS ([r(6) | J(84)] per block, block 10 = prior); the J^T J products are then spread over
@@ -264,27 +289,35 @@ __device__ __noinline__ double ba_small_factors(const BaBatch &B, const BaCtx c,
     return cost;
 }
 
-// J^T J and J^T r of the blocks left in LDS by ba_small_factors, by one wave (one output entry per lane and round)
+// J^T J and J^T r of the blocks left in LDS by ba_small_factors, by one wave (one output entry per lane and round).  Neighbouring
+// LASER blocks share a pose: the even blocks are added first, then the odd ones (within a phase every entry has one writer), so the
+// sums are formed in a fixed order with plain LDS read-modify-writes.  Nothing else touches H_pp meanwhile (L.turn == -1).
 __device__ __forceinline__ void ba_small_accumulate_wave(const BaCtx &c, BaLds &L, const double *in, int lane)
 {
     const int nl = c.n_poses - 1;
-    for (int idx = lane; idx < nl * 156; idx += 64) {
-        const int b = idx / 156, e = idx - b * 156;
-        const double *r = in + b * kBaSmallRec, *J = r + 6;
-        const int a = e < 144 ? e / 12 : e - 144, bb = e < 144 ? e % 12 : 0;
-        const double *Ja = J + (a < 6 ? a : 42 + a - 6);
-        const int ga = ba_pose_off(c, a < 6 ? b : b + 1) + (a < 6 ? a : a - 6);
-        double v = 0;
-        if (e < 144) {
-            const double *Jb = J + (bb < 6 ? bb : 42 + bb - 6);
+    for (int par = 0; par < 2; par++) {
+        const int nb = (nl - par + 1) / 2;                       // blocks par, par + 2, ...
+        for (int idx = lane; idx < nb * 156; idx += 64) {
+            const int b = 2 * (idx / 156) + par, e = idx % 156;
+            const double *r = in + b * kBaSmallRec, *J = r + 6;
+            const int a = e < 144 ? e / 12 : e - 144, bb = e < 144 ? e % 12 : 0;
+            const double *Ja = J + (a < 6 ? a : 42 + a - 6);
+            const int ga = ba_pose_off(c, a < 6 ? b : b + 1) + (a < 6 ? a : a - 6);
+            double v = 0;
+            if (e < 144) {
+                const double *Jb = J + (bb < 6 ? bb : 42 + bb - 6);
 #pragma unroll
-            for (int k = 0; k < 6; k++) v += Ja[7 * k] * Jb[7 * k];
-            unsafeAtomicAdd(&L.Hpp[ga * kBaP + ba_pose_off(c, bb < 6 ? b : b + 1) + (bb < 6 ? bb : bb - 6)], v);
-        } else {
+                for (int k = 0; k < 6; k++) v += Ja[7 * k] * Jb[7 * k];
+                L.Hpp[ga * kBaP + ba_pose_off(c, bb < 6 ? b : b + 1) + (bb < 6 ? bb : bb - 6)] += v;
+            } else {
 #pragma unroll
-            for (int k = 0; k < 6; k++) v += Ja[7 * k] * r[k];
-            unsafeAtomicAdd(&L.gp[ga], v);
+                for (int k = 0; k < 6; k++) v += Ja[7 * k] * r[k];
+                L.gp[ga] += v;
+            }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     if (c.use_prior && !c.ex_constant && lane < 42) {
         const double *r = in + 10 * kBaSmallRec, *J = r + 6;
@@ -293,11 +326,11 @@ __device__ __forceinline__ void ba_small_accumulate_wave(const BaCtx &c, BaLds &
         if (e < 36) {
 #pragma unroll
             for (int k = 0; k < 6; k++) v += J[7 * k + a] * J[7 * k + bb];
-            unsafeAtomicAdd(&L.Hpp[(c.ex_off + a) * kBaP + c.ex_off + bb], v);
+            L.Hpp[(c.ex_off + a) * kBaP + c.ex_off + bb] += v;
         } else {
 #pragma unroll
             for (int k = 0; k < 6; k++) v += J[7 * k + a] * r[k];
-            unsafeAtomicAdd(&L.gp[c.ex_off + a], v);
+            L.gp[c.ex_off + a] += v;
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -314,45 +347,44 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
     BA_TICK(kJac ? 0 : 3)
     if (tid <= c.n_poses) {
         double qn[4];
-        ba::q_norm(tid == c.n_poses ? ex + 3 : poses + 7 * tid + 3, qn);
+        const double *qraw = tid == c.n_poses ? ex + 3 : poses + 7 * tid + 3;
+        ba::q_norm(qraw, qn);
         ba::q_to_R(qn, L.Rp + 9 * tid);
+        double qi[4];
+        ba::q_to_R(qraw, L.Mq + 18 * tid);
+        ba::q_inv(qraw, qi);
+        ba::q_to_R(qi, L.Mq + 18 * tid + 9);
+        if (tid == c.n_poses) inv3(L.Mq + 18 * tid + 9, L.Mq + 18 * (kBaMaxPoses + 1));
     }
     for (int f = tid; f < c.F; f += kBaT) L.vinv[f] = gld(invd + f);
     if (kJac) {
         for (int k = tid; k < kBaP * kBaP; k += kBaT) L.Hpp[k] = 0.0;
         for (int k = tid; k < kBaP; k += kBaT) L.gp[k] = 0.0;
-        for (int f = tid; f < c.F; f += kBaT) {
-            L.Hdd[f] = 0.0; L.gdd[f] = 0.0;
-            // the extrinsic and anchor-frame parts of a coupling row are sums over the feature's observations
-            const int anchor = gldi(B.feat_anchor + c.f0 + f);
-            double *row = hpd + (size_t)f * kBaPS;
-            for (int a = 0; a < 6; a++) {
-                if (c.ex_off >= 0) gst(row + c.ex_off + a, 0.0);
-                if (anchor >= 0) gst(row + ba_pose_off(c, anchor) + a, 0.0);
-            }
-        }
     }
     __syncthreads();
     const double *Rlc = L.Rp + 9 * c.n_poses;
     for (int p = tid; p < c.n_pairs; p += kBaT) {
         const int ij = L.pair_ij[p], i = ij & 255, j = ij >> 8;
         double rec[kBaPairRec];
-        ba_pair_record(L.Rp + 9 * i, L.Rp + 9 * j, Rlc, poses + 7 * i, poses + 7 * j, ex, rec);
+        ba_pair_record(L.Rp + 9 * i, L.Rp + 9 * j, Rlc, L.Mq + 18 * i, L.Mq + 18 * j + 9, L.Mq + 18 * c.n_poses, L.Mq + 18 * c.n_poses + 9,
+                       poses + 7 * i, poses + 7 * j, ex, rec);
         double *dst = pairdat + (size_t)p * kBaPairRec;
 #pragma unroll
         for (int k = 0; k < kBaPairRec; k++) gst(dst + k, rec[k]);
     }
     double cost = 0.0;
     // wave 1: LASERFactor chain and prior, next to the pair records of wave 0
-    if (tid >= 64 && tid < 96) cost += ba_small_factors<kJac>(B, c, L.u.stage + (size_t)1 * 2 * kBaRound * kBaRow, poses, ex, tid - 64);
-    if (tid == 0) L.next_pair = 0;
+    // (their residuals / Jacobians wait in gn | va | vb, which are dead during a linearisation, until the pair blocks are in)
+    static_assert(3 * kBaN >= 11 * kBaSmallRec, "small-factor records must fit gn | va | vb");
+    if (tid >= 64 && tid < 96) cost += ba_small_factors<kJac>(B, c, L.gn, poses, ex, tid - 64);
+    if (tid == 0) L.turn = 0;
     const double *mono_info = B.info + 36;
     const double m00 = gld(mono_info), m01 = gld(mono_info + 1), m10 = gld(mono_info + 2), m11 = gld(mono_info + 3);
     const int *sinfo = B.slot_info + c.ps0;
     const double *spts = B.slot_pts + (size_t)c.ps0 * 4;
     if (!kJac) {
         __syncthreads();   // pair records are visible
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         // four slots per thread and round: their index words and image points are requested before any is used
         for (int s0 = tid; s0 < c.n_slots; s0 += 4 * kBaT) {
             int info[4];
@@ -389,21 +421,17 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
     }
 
     __syncthreads();   // pair records and zeroed coupling rows are visible
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     BA_TOCK(0)
     BA_TICK(1)
     // Every wave works on whole frame pairs, taken from a work counter in descending size: 32 observations per round,
     // two lanes each (lane q of the pair owns residual row q), the 64 rows staged in the wave's own LDS slice and
     // multiplied right away -- no workgroup barrier inside the loop.
     double *wstage = L.u.stage + (size_t)wave * 2 * kBaRound * kBaRow;
-    if (wave == 1) ba_small_accumulate_wave(c, L, wstage, lane);     // LASERFactor chain / prior left there by wave 1
     const int q = lane & 1, lo = lane >> 1, col = lane & 15, kq = lane >> 4;
     double xx44 = 0, xx45 = 0, xx55 = 0, gx4 = 0, gx5 = 0;
-    for (;;) {
-        int pr = 0;
-        if (lane == 0) pr = atomicAdd(&L.next_pair, 1);
-        pr = __builtin_amdgcn_readfirstlane(pr);
-        if (pr >= c.n_pairs) break;
+    for (int wi = L.woff[wave]; wi < L.woff[wave + 1]; wi++) {
+        const int pr = L.wlist[wi];
         const int ij = L.pair_ij[pr], fi = ij & 255, fj = ij >> 8;
         const int s_begin = L.pair_slot[pr], s_end = L.pair_slot[pr + 1];
         const int oi = ba_pose_off(c, fi), oj = ba_pose_off(c, fj);
@@ -414,20 +442,24 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
 #pragma unroll
             for (int k = 0; k < kBaPairRec - 1; k++) rec[k] = gld(rp + k);
         }
-        const double *T = rec, *Cm = rec + 12, *A = rec + 21, *Bm = rec + 30;
+        const double *T = rec, *Cm = rec + 12, *A = rec + 21, *Bm = rec + 30, *Tn = rec + 39;
+        const double *Mx = L.Mq + 18 * c.n_poses, *Mxi = L.Mq + 18 * (kBaMaxPoses + 1);
         ba_d4 aa = { 0, 0, 0, 0 }, ab = { 0, 0, 0, 0 };
         for (int base = s_begin; base < s_end; base += kBaRound) {
             const int so = base + lo;
             double *row = wstage + (size_t)lane * kBaRow;
             if (so < s_end) {
                 const int f = gldi(sinfo + so) & 0xffff;
+                const int ob = gldi(B.slot_obs + c.ps0 + so);
                 const double pax = gld(spts + (size_t)so * 4), pay = gld(spts + (size_t)so * 4 + 1);
                 const double pbx = gld(spts + (size_t)so * 4 + 2), pby = gld(spts + (size_t)so * 4 + 3);
                 const double depth = 1.0 / L.vinv[f];
                 const double pc[3] = { depth * pax, depth * pay, depth };
-                double Tp[3], pcj[3], uT[3], u[3];
+                double Tp[3], pcj[3], pcn[3], uT[3], u[3];
                 ba::mv(T, pc, Tp);
-                for (int k = 0; k < 3; k++) pcj[k] = Tp[k] + rec[9 + k];
+                for (int k = 0; k < 3; k++) pcj[k] = Tp[k] + rec[9 + k];     // the residual's p_cj (raw quaternions)
+                ba::mv(Tn, pc, Tp);                                          // from here on Tp = Tn pc: the Jacobians' normalised product
+                for (int k = 0; k < 3; k++) pcn[k] = Tp[k] + rec[48 + k];
                 const double inv = 1.0 / pcj[2];
                 const double e0 = pcj[0] * inv - pbx, e1 = pcj[1] * inv - pby;
                 const double r0 = m00 * e0 + m01 * e1, r1 = m10 * e0 + m11 * e1;
@@ -440,14 +472,14 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
                 // row q of sqrt_info * [[1/z, 0, -x/z^2], [0, 1/z, -y/z^2]], robustified
                 const double ma = q ? m10 : m00, mb = q ? m11 : m01;
                 u[0] = sr * ma * inv; u[1] = sr * mb * inv; u[2] = -sr * (ma * pcj[0] + mb * pcj[1]) * inv * inv;
-                rowmul(u, T, uT);
-                // inverse depth: -u (T p_i) depth^2 = -u (T pc) depth
+                rowmul(u, Tn, uT);
+                // inverse depth: -u (Tn p_i) depth^2 = -u (Tn pc) depth
                 const double Jd = -(u[0] * Tp[0] + u[1] * Tp[1] + u[2] * Tp[2]) * depth;
                 double Jx[6], Ji[6], Jj[6], c1[3], c2[3];
-                // extrinsic block: position u Cm, rotation -(uT) x pc + u x pcj   (u skew(v) = u x v)
+                // extrinsic block: position u Cm, rotation -(uT) x pc + u x (Tn pc + tn)   (u skew(v) = u x v; :127-130: all normalised)
                 if (c.ex_off >= 0) {
                     rowmul(u, Cm, Jx);
-                    cross3(uT, pc, c1); cross3(u, pcj, c2);
+                    cross3(uT, pc, c1); cross3(u, pcn, c2);
                     for (int k = 0; k < 3; k++) Jx[3 + k] = c2[k] - c1[k];
                     xx44 += Jx[4] * Jx[4]; xx45 += Jx[4] * Jx[5]; xx55 += Jx[5] * Jx[5];
                     gx4 += Jx[4] * rq; gx5 += Jx[5] * rq;
@@ -455,16 +487,17 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
 #pragma unroll
                     for (int k = 0; k < 6; k++) Jx[k] = 0.0;
                 }
-                // pose i: position u A, rotation -(u B) x pl;  pose j: position -u A, rotation (u Rlc^T) x plj
+                // pose i: position u A, rotation -(u B) x pl;  pose j: position -u A, rotation (u Rlc^T) x plj, with the residual
+                // path's own points pl = pts_laser_i = Qx pc + tx and plj = pt_l_j = M(qx^-1)^-1 p_cj + tx (:66-68, :145, :158)
                 {
                     double uB[3], uR[3], pl[3], plj[3];
                     rowmul(u, A, Ji);
                     for (int k = 0; k < 3; k++) Jj[k] = -Ji[k];
-                    ba::mv(Rlc, pc, pl);
+                    ba::mv(Mx, pc, pl);
                     for (int k = 0; k < 3; k++) pl[k] += ex[k];
                     rowmul(u, Bm, uB); cross3(uB, pl, c1);
                     for (int k = 0; k < 3; k++) Ji[3 + k] = -c1[k];
-                    ba::mv(Rlc, pcj, plj);
+                    ba::mv(Mxi, pcj, plj);
                     for (int k = 0; k < 3; k++) plj[k] += ex[k];
                     uR[0] = u[0] * Rlc[0] + u[1] * Rlc[1] + u[2] * Rlc[2];
                     uR[1] = u[0] * Rlc[3] + u[1] * Rlc[4] + u[2] * Rlc[5];
@@ -481,15 +514,21 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
 #pragma unroll
                 for (int k = 0; k < 6; k++) { hx[k] = pair_sum(Jx[k] * Jd); hi[k] = pair_sum(Ji[k] * Jd); hj[k] = pair_sum(Jj[k] * Jd); }
                 const double hdd = pair_sum(Jd * Jd), gd = pair_sum(Jd * rq);
+                // The observation's shares of H_ff, g_f and of the extrinsic / anchor parts of the coupling row are sums over the
+                // feature's observations, which sit in different pairs (waves): they go to the observation's own scratch record and
+                // are summed per feature in observation order afterwards (ba_feature_sums) -- no atomics, the same bits every run.
+                double *sc = B.obsc + (size_t)ob * 16;
                 if (q == 0) {
                     double *hrow = hpd + (size_t)f * kBaPS;
-                    unsafeAtomicAdd(&L.Hdd[f], hdd); unsafeAtomicAdd(&L.gdd[f], gd);
+                    gst(sc, hdd); gst(sc + 1, gd);
 #pragma unroll
                     for (int k = 0; k < 6; k++) {
-                        if (c.ex_off >= 0) gatomic_add(hrow + c.ex_off + k, hx[k]);
-                        gatomic_add(hrow + oi + k, hi[k]);
+                        gst(sc + 2 + k, hx[k]);
                         gst(hrow + oj + k, hj[k]);                              // frame j sees a feature once
                     }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 6; k++) gst(sc + 8 + k, hi[k]);
                 }
             } else {
 #pragma unroll
@@ -509,41 +548,88 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
             }
             __builtin_amdgcn_wave_barrier();   // the slice is rewritten by the next round
         }
-        // add the pair's blocks to H_pp / g_p
+        // add the pair's blocks to H_pp / g_p when it is this pair's turn: the order of the additions is the static one of
+        // ba_schedule (simulated finish order), so waves rarely wait and every entry is summed in the same order in every run
         {
+            const int my_turn = L.pair_turn[pr];
+            if (lane == 0) while (__hip_atomic_load(&L.turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != my_turn) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             auto gidx = [&](int m) { return m < 6 ? oi + m : (m < 12 ? oj + m - 6 : (c.ex_off < 0 ? -1 : c.ex_off + m - 12)); };
             const int gn_ = gidx(col);
+            // entries of one tile are distinct (m, n) pairs, except the mirrored extrinsic columns 4, 5, which go second
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const int gm = gidx(kq + 4 * v);
+                if (gm >= 0 && gn_ >= 0) L.Hpp[gm * kBaP + gn_] += aa[v];
+            }
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int v = 0; v < 4; v++) {
                 const int gm = gidx(kq + 4 * v);
                 if (gm < 0) continue;
-                if (gn_ >= 0) unsafeAtomicAdd(&L.Hpp[gm * kBaP + gn_], aa[v]);
                 if (col < 2) {
-                    if (c.ex_off >= 0) {
-                        const int xc = c.ex_off + 4 + col;
-                        unsafeAtomicAdd(&L.Hpp[gm * kBaP + xc], ab[v]);
-                        unsafeAtomicAdd(&L.Hpp[xc * kBaP + gm], ab[v]);
-                    }
+                    if (c.ex_off >= 0) { const int xc = c.ex_off + 4 + col; L.Hpp[gm * kBaP + xc] += ab[v]; }
                 } else if (col == 2) {
-                    unsafeAtomicAdd(&L.gp[gm], ab[v]);
+                    L.gp[gm] += ab[v];
                 }
             }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const int gm = gidx(kq + 4 * v);
+                if (gm >= 0 && col < 2 && c.ex_off >= 0) { const int xc = c.ex_off + 4 + col; L.Hpp[xc * kBaP + gm] += ab[v]; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __hip_atomic_store(&L.turn, my_turn + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
     BA_TOCK(1)
+    // the waves' shares of the (4..5, 4..5) extrinsic corner and its gradient: summed in wave order
+    xx44 = wave_sum_d(xx44); xx45 = wave_sum_d(xx45); xx55 = wave_sum_d(xx55); gx4 = wave_sum_d(gx4); gx5 = wave_sum_d(gx5);
+    if (lane == 0) { double *r5 = L.rhs + 5 * wave; r5[0] = xx44; r5[1] = xx45; r5[2] = xx55; r5[3] = gx4; r5[4] = gx5; }   // L.rhs is dead outside the Schur solve
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // the observation records are written
     __syncthreads();
-    if (c.ex_off >= 0 && c.n_slots > 0) {
-        xx44 = wave_sum_d(xx44); xx45 = wave_sum_d(xx45); xx55 = wave_sum_d(xx55); gx4 = wave_sum_d(gx4); gx5 = wave_sum_d(gx5);
-        if (lane == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");       // ... and read below by other waves: drop this CU's L1 copies
+    if (wave == 1) {
+        // every pair block is in H_pp: wave 1 adds the LASERFactor chain / prior it left in gn | va | vb, then the waves' shares of
+        // the extrinsic corner in wave order -- after the pair blocks in every run
+        ba_small_accumulate_wave(c, L, L.gn, lane);
+        if (c.ex_off >= 0 && c.n_slots > 0 && lane == 0) {
+            double t[5] = { 0, 0, 0, 0, 0 };
+            for (int w = 0; w < kBaW; w++) for (int k = 0; k < 5; k++) t[k] += L.rhs[5 * w + k];
             const int x4 = c.ex_off + 4, x5 = c.ex_off + 5;
-            unsafeAtomicAdd(&L.Hpp[x4 * kBaP + x4], xx44); unsafeAtomicAdd(&L.Hpp[x5 * kBaP + x5], xx55);
-            unsafeAtomicAdd(&L.Hpp[x4 * kBaP + x5], xx45); unsafeAtomicAdd(&L.Hpp[x5 * kBaP + x4], xx45);
-            unsafeAtomicAdd(&L.gp[x4], gx4); unsafeAtomicAdd(&L.gp[x5], gx5);
+            L.Hpp[x4 * kBaP + x4] += t[0]; L.Hpp[x5 * kBaP + x5] += t[2];
+            L.Hpp[x4 * kBaP + x5] += t[1]; L.Hpp[x5 * kBaP + x4] += t[1];
+            L.gp[x4] += t[3]; L.gp[x5] += t[4];
+        }
+    } else {
+        // H_ff, g_f and the extrinsic / anchor parts of the coupling rows, by the other seven waves: 16 lanes per feature, lane k sums
+        // entry k of the feature's observation records (contiguous, at most 10: one per other frame of the window) in observation
+        // order; the loads are independent and requested together
+        const int k = lane & 15, t7 = (wave == 0 ? 0 : wave - 1) * 4 + (lane >> 4);
+        for (int f = t7; f < c.F; f += 28) {
+            const int o0 = gldi(B.feat_obs_off + c.f0 + f), o1 = gldi(B.feat_obs_off + c.f0 + f + 1);
+            double acc = 0.0;
+            for (int ob = o0; ob < o1; ob += 10) {
+                double v[10];
+#pragma unroll
+                for (int u = 0; u < 10; u++) v[u] = ob + u < o1 ? gld(B.obsc + (size_t)(ob + u) * 16 + k) : 0.0;
+#pragma unroll
+                for (int u = 0; u < 10; u++) acc += v[u];
+            }
+            if (k == 0) L.Hdd[f] = acc;
+            else if (k == 1) L.gdd[f] = acc;
+            else if (k < 14) {
+                double *hrow = hpd + (size_t)f * kBaPS;
+                if (k < 8) { if (c.ex_off >= 0) gst(hrow + c.ex_off + k - 2, acc); }
+                else { const int anchor = gldi(B.feat_anchor + c.f0 + f); if (anchor >= 0) gst(hrow + ba_pose_off(c, anchor) + k - 8, acc); }
+            }
         }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     cost = block_sum(cost, L.red);
-    // the coupling rows were accumulated by L2 atomics: drop this CU's L1 copies before they are read with plain loads
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // the coupling rows were written through L2: drop this CU's L1 copies before they are read with plain loads
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     return cost;
 }
 
@@ -794,6 +880,47 @@ __device__ __noinline__ bool ba_schur_solve(const BaCtx c, BaLds &L, const doubl
     return L.ok != 0;
 }
 
+// Static schedule of the linearisation's frame pairs (sizes descending): longest-processing-time assignment to the 8 waves, and the
+// order in which the pairs' blocks enter H_pp = the order in which a wave-time model (one unit per 32-observation round + one per
+// pair) says they finish, ties by pair index.  A wave's own pairs are in that order too, so the turn-taking cannot deadlock, and
+// because the model is close to the real timing, waves seldom wait for their turn.  Depends on the pair sizes only.
+__device__ __noinline__ void ba_schedule(const BaCtx c, BaLds &L)
+{
+    const int tid = threadIdx.x;
+    int *fin = (int *)L.u.stage;                          // [n_pairs] modelled finish time, then [n_pairs] wave
+    __syncthreads();
+    if (tid == 0) {
+        int load[kBaW];
+        for (int w = 0; w < kBaW; w++) load[w] = 0;
+        for (int p = 0; p < c.n_pairs; p++) {
+            int w = 0;
+            for (int u = 1; u < kBaW; u++) if (load[u] < load[w]) w = u;
+            load[w] += 1 + (L.pair_slot[p + 1] - L.pair_slot[p] + kBaRound - 1) / kBaRound;
+            fin[p] = load[w]; fin[kBaMaxPairs + p] = w;
+        }
+    }
+    __syncthreads();
+    for (int p = tid; p < c.n_pairs; p += kBaT) {
+        int rank = 0, pos = 0;
+        const int w = fin[kBaMaxPairs + p];
+        for (int q = 0; q < c.n_pairs; q++) {
+            const bool before = fin[q] < fin[p] || (fin[q] == fin[p] && q < p);
+            rank += before ? 1 : 0;
+            pos += (before && fin[kBaMaxPairs + q] == w) ? 1 : 0;
+        }
+        L.pair_turn[p] = (short)rank;
+        fin[2 * kBaMaxPairs + p] = pos;                     // position among its wave's pairs
+    }
+    if (tid <= kBaW) {
+        int n = 0;
+        for (int q = 0; q < c.n_pairs; q++) n += fin[kBaMaxPairs + q] < tid ? 1 : 0;
+        L.woff[tid] = (short)n;
+    }
+    __syncthreads();
+    for (int p = tid; p < c.n_pairs; p += kBaT) L.wlist[L.woff[fin[kBaMaxPairs + p]] + fin[2 * kBaMaxPairs + p]] = (short)p;
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -817,6 +944,7 @@ __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B)
     for (int k = tid; k < c.n_pairs; k += kBaT) L.pair_ij[k] = B.pair_ij[c.pp0 + k];
     for (int k = tid; k <= c.n_pairs; k += kBaT) L.pair_slot[k] = B.pair_slot[c.pp0 + w + k];
     __syncthreads();
+    ba_schedule(c, L);
 
     const double function_tol = 1e-6, gradient_tol = 1e-10, parameter_tol = 1e-8, min_rel_decrease = 1e-3;
     const double min_diag = 1e-6, max_diag = 1e32, max_radius = 1e16, min_radius = 1e-32;

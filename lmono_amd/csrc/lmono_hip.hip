@@ -908,6 +908,8 @@ static int ba_fill(lmono_ctx *c, lmono_ba_batch *b, const lmono_ba_desc *d)
     // pair-ordered observation list
     std::vector<int> pair_off((size_t)W + 1, 0), pair_ij, pair_slot, pobs_off((size_t)W + 1, 0), slot_info, anchor((size_t)TF, -1);
     std::vector<double> slot_pts;
+    std::vector<int> slot_obs;                      // the observation (host order) behind every slot: its scratch record is indexed by observation,
+                                                    // so a feature's records are contiguous for the per-feature sums of k_ba_solve
     for (int w = 0; w < W; w++) {
         pair_off[w] = (int)pair_ij.size(); pobs_off[w] = (int)slot_info.size();
         const int f0 = d->feat_off[w], f1 = d->feat_off[w + 1];
@@ -924,6 +926,7 @@ static int ba_fill(lmono_ctx *c, lmono_ba_batch *b, const lmono_ba_desc *d)
                 pair_ij.push_back((key / kBaMaxPoses) | ((key % kBaMaxPoses) << 8));
                 pair_slot.push_back((int)slot_info.size() - pobs_off[w]);
                 for (int o : v) {
+                    slot_obs.push_back(o);
                     slot_info.push_back(d->obs_feat[o] | (local << 16));
                     for (int k = 0; k < 4; k++) slot_pts.push_back(d->obs_pts[(size_t)o * 4 + k]);
                 }
@@ -940,6 +943,7 @@ static int ba_fill(lmono_ctx *c, lmono_ba_batch *b, const lmono_ba_desc *d)
     double info[42];
     memcpy(info, d->laser_info, 36 * sizeof(double)); memcpy(info + 36, d->mono_info, 4 * sizeof(double)); memcpy(info + 40, d->prior_w, 2 * sizeof(double));
     int *feat_off = nullptr, *obs_off = nullptr, *flags = nullptr, *anch = nullptr, *poff = nullptr, *pij = nullptr, *psoff = nullptr, *sinfo_d = nullptr, *pslot_d = nullptr;
+    int *fobs_d = nullptr, *oslot_d = nullptr;
     double *spts_d = nullptr, *laser = nullptr, *prior = nullptr, *infod = nullptr;
     bool ok = ba_upload(b, feat_off, d->feat_off, (size_t)W + 1) && ba_upload(b, obs_off, d->obs_off, (size_t)W + 1) &&
               ba_upload(b, flags, d->flags, (size_t)W * 4) && ba_upload(b, v.poses, d->poses, (size_t)W * kBaMaxPoses * 7) &&
@@ -952,6 +956,8 @@ static int ba_fill(lmono_ctx *c, lmono_ba_batch *b, const lmono_ba_desc *d)
               ba_upload(b, infod, info, (size_t)42) &&
               ba_upload(b, b->poses0, d->poses, (size_t)W * kBaMaxPoses * 7) && ba_upload(b, b->ex0, d->ex, (size_t)W * 7) &&
               ba_upload(b, b->invd0, d->inv_depth, (size_t)TF) &&
+              ba_upload(b, fobs_d, fo.data(), (size_t)TF + 1) && ba_upload(b, oslot_d, slot_obs.data(), slot_obs.size()) &&
+              ba_upload(b, v.obsc, (const double *)nullptr, (size_t)TO * 16) &&
               ba_upload(b, v.hpd, (const double *)nullptr, (size_t)W * kBaMaxFeat * kBaPS) &&
               ba_upload(b, v.pairdat, (const double *)nullptr, pair_ij.size() * kBaPairRec) &&
               ba_upload(b, v.cand, (const double *)nullptr, (size_t)W * kBaMaxFeat) && ba_upload(b, v.summary, (const double *)nullptr, (size_t)W * 6);
@@ -960,6 +966,7 @@ static int ba_fill(lmono_ctx *c, lmono_ba_batch *b, const lmono_ba_desc *d)
     v.feat_off = feat_off; v.obs_off = obs_off; v.flags = flags; v.feat_anchor = anch;
     v.pair_off = poff; v.pair_ij = pij; v.pobs_off = psoff; v.slot_info = sinfo_d; v.slot_pts = spts_d; v.pair_slot = pslot_d;
     v.laser_consts = laser; v.prior_T = prior; v.info = infod;
+    v.feat_obs_off = fobs_d; v.slot_obs = oslot_d;
     return LMONO_OK;
 }
 
@@ -979,7 +986,7 @@ extern "C" int lmono_ba_batch_update(lmono_ctx *c, lmono_ba_batch *b, const lmon
     if (!c || !b || b->ctx != c) return LMONO_EINVAL;
     HIP_TRY(c, hipStreamSynchronize(c->stream));      // a solve of the previous problem may still read the arrays
     const int rc = ba_fill(c, b, d);
-    if (rc != LMONO_OK) b->n_windows = 0;
+    if (rc != LMONO_OK) { b->n_windows = 0; b->total_feat = 0; b->total_obs = 0; }     // no problem: solve / reset / read refuse
     return rc;
 }
 
@@ -996,6 +1003,7 @@ extern "C" int lmono_ba_solve(lmono_ctx *c, lmono_ba_batch *b, int max_iteration
 extern "C" int lmono_ba_batch_reset(lmono_ctx *c, lmono_ba_batch *b)
 {
     if (!c || !b) return LMONO_EINVAL;
+    if (b->n_windows <= 0) { c->err = "lmono_ba_batch_reset: the batch holds no problem (failed update)"; return LMONO_EINVAL; }
     HIP_TRY(c, hipMemcpyAsync(b->v.poses, b->poses0, sizeof(double) * (size_t)b->n_windows * kBaMaxPoses * 7, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(b->v.ex, b->ex0, sizeof(double) * (size_t)b->n_windows * 7, hipMemcpyDeviceToDevice, c->stream));
     if (b->total_feat > 0) HIP_TRY(c, hipMemcpyAsync(b->v.inv_depth, b->invd0, sizeof(double) * (size_t)b->total_feat, hipMemcpyDeviceToDevice, c->stream));
@@ -1005,6 +1013,7 @@ extern "C" int lmono_ba_batch_reset(lmono_ctx *c, lmono_ba_batch *b)
 extern "C" int lmono_ba_batch_read(lmono_ctx *c, lmono_ba_batch *b, double *poses_h, double *ex_h, double *inv_depth_h, double *summary_h)
 {
     if (!c || !b) return LMONO_EINVAL;
+    if (b->n_windows <= 0) { c->err = "lmono_ba_batch_read: the batch holds no problem (failed update)"; return LMONO_EINVAL; }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (poses_h) HIP_TRY(c, hipMemcpy(poses_h, b->v.poses, sizeof(double) * (size_t)b->n_windows * kBaMaxPoses * 7, hipMemcpyDeviceToHost));
     if (ex_h) HIP_TRY(c, hipMemcpy(ex_h, b->v.ex, sizeof(double) * (size_t)b->n_windows * 7, hipMemcpyDeviceToHost));

@@ -227,6 +227,12 @@ class EstimatorRef:
         w["use_mono"] = bool(self.p.ESTIMATE_LASER) and not self.static_status
         poses, ex, invd, sm = O.ba_solve(w, max_iter=self.p.NUM_ITERATIONS)
         self.solve_log.append((sm.iterations, sm.termination, sm.final_cost))
+        if getattr(self, "capture", None) is not None:
+            # test hook: the window problem exactly as it went into the solve, and what came out (teacher-forced parity of a frame loop)
+            import copy
+            self.capture.append(dict(window=copy.deepcopy(w), poses=np.array(poses), ex=np.array(ex), inv_depth=np.array(invd),
+                                     iterations=sm.iterations, termination=sm.termination, initial_cost=sm.initial_cost, final_cost=sm.final_cost,
+                                     R0=self.Rs[0].copy(), P0=self.Ps[0].copy()))
         # double2Matrix
         R_new, P_new = O.ba_reanchor(poses, self.Rs[0], self.Ps[0])
         for i in range(WINDOW_SIZE + 1):

@@ -13,10 +13,12 @@ def loop_event(st, frame, old_T=(1.0, 2.0, 3.0), shift=(0.05, -0.02, 0.03), yaw=
 from workloads.s2 import write_stream  # noqa: E402,F401  (the stream file writer is input plumbing)
 
 
-def replay_oracle(st, loops=(), on_frame=None):
+def replay_oracle(st, loops=(), on_frame=None, capture=False):
     """-> (EstimatorRef after the stream, per-frame log rows (keyframe, stage, static, iterations, termination, final_cost, n_old, n_new, n_feat))."""
     from oracle import estimator_ref as E
     est = E.EstimatorRef(st["tlc"])
+    if capture:
+        est.capture = []
     by_frame = {e["frame"]: e for e in loops}
     log = []
     n_old = n_new = 0

@@ -42,13 +42,13 @@ def test_reset_and_resolve_is_repeatable(oracle, gpu_ctx):
     b, first = _solve_gpu(gpu_ctx, windows)
     b.reset(); b.solve(30)
     second = b.read()
-    # LDS atomics make the summation order vary run to run, and the problem has a free 6-DoF gauge (no block is held
-    # constant, Estimator.cc:1150): compare the gauge-fixed (re-anchored, double2Matrix) poses, equal to rounding
-    for k, w in enumerate(windows):
-        R1, P1 = oracle.ba_reanchor(first[0][k], w["gt_Rs"][0], w["gt_Ps"][0])
-        R2, P2 = oracle.ba_reanchor(second[0][k], w["gt_Rs"][0], w["gt_Ps"][0])
-        assert np.abs(P1 - P2).max() < 1e-7 and np.abs(R1 - R2).max() < 1e-8
-    assert np.abs(first[3][:, 1] - second[3][:, 1]).max() < 1e-6 * first[3][:, 1].max()
+    # every sum of k_ba_solve is formed in an order fixed by the problem (static pair schedule, turn-ordered block additions,
+    # per-feature passes -- no floating-point atomics): two solves of the same problem give the same BYTES
+    for a, c in zip(first, second):
+        assert a.tobytes() == c.tobytes()
+    # ... also from a different batch object and beside other windows (another grid position, other L2 scratch addresses)
+    b2, third = _solve_gpu(gpu_ctx, [K.make_window(3)] + windows)
+    assert third[0][1:].tobytes() == first[0].tobytes() and third[1][1:].tobytes() == first[1].tobytes() and third[3][1:].tobytes() == first[3].tobytes()
 
 
 def test_large_batch_cost_decreases_everywhere(gpu_ctx):
@@ -75,9 +75,8 @@ def test_update_reuses_the_batch_and_changes_nothing(oracle, gpu_ctx):
         b.solve(30)
         got = b.read()
         _, want = _solve_gpu(gpu_ctx, windows)
-        assert np.abs(got[3][:, 0] - want[3][:, 0]).max() <= 1e-12 * want[3][:, 0].max()      # initial cost (summed by atomics)
-        assert (got[3][:, 2:4] == want[3][:, 2:4]).all()                   # iterations, termination
-        assert np.abs(got[3][:, 1] - want[3][:, 1]).max() <= 1e-6 * want[3][:, 1].max() + 1e-12
+        for a, c in zip(got, want):
+            assert a.tobytes() == c.tobytes()                               # the solve is order-deterministic: same problem, same bytes
         for k, w in enumerate(windows):
             n = len(w["poses"])
             R1, P1 = oracle.ba_reanchor(got[0][k, :n], w["gt_Rs"][0], w["gt_Ps"][0])

@@ -53,11 +53,51 @@ def test_101_scans_through_both_halves(oracle, gpu_ctx, tmp_path):
     gt_R = np.array([_pose44(g[:4], g[4:])[:3, :3] for g in gt]); gt_P = gt[:, 4:]
     L0 = np.array([_pose44(m[:4], m[4:]) for m in mapped])
     st = s2.make_stream(n, seed=5, lidar_gt=(gt_R, gt_P), lidar_meas=L0)
-    est, log = S.replay_oracle(st)
+    est, log = S.replay_oracle(st, capture=True)
+    # ---- (1) teacher-forced parity: EVERY window problem of the sequence exactly as the oracle's frame loop handed it to its solve,
+    # solved on the GPU from that same state (one batch of 91 independent windows) -- the statement "same inputs, same results" for
+    # Estimator::optimization() over configs[0], free of the frame loop's own sensitivity (below)
+    caps = est.capture
+    assert len(caps) >= n - 10
+    gb = lmono_amd.BaBatch(gpu_ctx, [c["window"] for c in caps])
+    gb.solve(30)
+    g_poses, g_ex, g_invd, g_sm = gb.read()
+    worst_p = worst_r = 0.0
+    split, per_window = [], []
+    for k, c in enumerate(caps):
+        np_ = len(c["window"]["poses"])
+        assert abs(g_sm[k, 0] - c["initial_cost"]) <= 1e-9 * max(c["initial_cost"], 1.0), "window %d: initial cost" % k
+        if (int(g_sm[k, 2]), int(g_sm[k, 3])) != (c["iterations"], c["termination"]):
+            split.append(k)                     # a termination test on a knife edge: the traces part, compare nothing further
+            continue
+        R1, P1 = oracle.ba_reanchor(g_poses[k, :np_], c["R0"], c["P0"])
+        R2, P2 = oracle.ba_reanchor(c["poses"], c["R0"], c["P0"])
+        worst_p = max(worst_p, np.abs(P1 - P2).max()); worst_r = max(worst_r, np.abs(R1 - R2).max())
+        per_window.append((k, np.abs(P1 - P2).max(), np.abs(R1 - R2).max(), g_sm[k, 1], c["final_cost"], c["iterations"]))
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        with open(os.path.join(ROOT, "gpurun_out", "config0_windows.txt"), "w") as fh:
+            for row in per_window:
+                fh.write("%d dP %.3e dR %.3e cost %.12g / %.12g it %d\n" % row)
+    print("configs[0], %d windows solved from the oracle's own pre-solve state: max |dP| %.2e m, max |dR| %.2e; %d window(s) stop at a different iteration %s"
+          % (len(caps), worst_p, worst_r, len(split), split))
+    dps = sorted(r[1] for r in per_window); drs = sorted(r[2] for r in per_window)
+    assert dps[-3] < 1e-7 and drs[-3] < 1e-8                   # every window but (at most) two: far inside SURVEY 8c's 1e-6 m / 1e-7
+    assert worst_p < 5e-6 and worst_r < 1e-6                   # the ill-conditioned window(s) after frame 60 amplify rounding 1e6-fold inside ONE solve
+    assert len(split) <= 2
+    # ---- (2) the free-running frame loop.  Its sensitivity first: the ORACLE against itself with the LiDAR translations moved by 1e-12 m
+    st_p = dict(st); st_p["L0"] = st["L0"].copy(); st_p["L0"][:, :3, 3] += 1e-12 * np.random.default_rng(0).standard_normal((n, 3))
+    est_p, _ = S.replay_oracle(st_p)
+    d_self = np.abs(np.array(est_p.trajectory)[:, 1:4] - np.array(est.trajectory)[:, 1:4]).max()
     fx = tmp_path / "config0.bin"
     s2.write_stream(fx, st)
     out = subprocess.run([EXE, str(fx), str(tmp_path / "new_odometry.txt")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
+    # the GPU frame loop is reproducible: a second run of the same binary on the same stream prints the same trajectory and decisions
+    out2 = subprocess.run([EXE, str(fx), str(tmp_path / "new_odometry_2.txt")], capture_output=True, text=True, timeout=600)
+    assert out2.returncode == 0, out2.stderr[-2000:]
+    keep = lambda txt: [ln for ln in txt.splitlines() if ln.startswith(("ODO", "FRM", "EXT"))]       # (TIM lines carry wall time)
+    assert keep(out.stdout) == keep(out2.stdout), "two runs of estimator_seq differ"
+    assert open(tmp_path / "new_odometry.txt").read() == open(tmp_path / "new_odometry_2.txt").read()
     odo_e = np.array([[float(v) for v in ln.split()[1:]] for ln in out.stdout.splitlines() if ln.startswith("ODO")])
     ref_e = np.array(est.trajectory)
     assert odo_e.shape == ref_e.shape == (n - 10, 8)
@@ -72,15 +112,17 @@ def test_101_scans_through_both_halves(oracle, gpu_ctx, tmp_path):
                 dp = np.abs(odo_e[k - 10, 1:4] - ref_e[k - 10, 1:4]).max() if k >= 10 else 0.0
                 fh.write("%d kf %s/%d st %s/%d it %s/%d term %s/%d cost %.9g/%.9g marg %s,%s/%d,%d feat %s/%d dP %.2e\n" %
                          (k, row[1], r[0], row[3], r[2], row[4], r[3], row[5], r[4], float(row[6]), r[5], row[7], row[8], r[6], r[7], row[9], r[8], dp))
-    print("configs[0]: LiDAR ATE odometry %.3f m -> mapped %.3f m; Estimator GPU vs oracle max |dP| %.2e m (max final cost %.3g)" % (ate_odo, ate_map, d, costs.max()))
-    # Frame k starts from frame k - 1's result and a solve is 30 unconverged dogleg iterations, so the rounding-level difference of the two
-    # implementations (1e-9 at the first window) grows along the sequence and jumps where a termination test falls on a knife edge
-    # (parity is defined on converged states, not on traces); k_ba_solve accumulates with fp64 atomics, so the size of
-    # the late difference also varies from run to run (4.8, 5.5, 6.0, 10.2 and 25.8 mm seen over five runs of the same binary).  Bars: 1e-6 m
-    # over the first 40 windows, 20 cm overall (a fifth of the fused trajectory's own 1.2 m error against the truth), identical keyframe /
-    # marginalisation decisions throughout, and the same distance from the truth as the CPU path (below).
+    print("configs[0]: LiDAR ATE odometry %.3f m -> mapped %.3f m; Estimator free-running GPU vs oracle max |dP| %.2e m; oracle vs oracle with the "
+          "LiDAR input moved by 1e-12 m: %.2e m (max final cost %.3g)" % (ate_odo, ate_map, d, d_self, costs.max()))
+    # Frame k starts from frame k - 1's result and a solve is 30 unconverged dogleg iterations (termination NO_CONVERGENCE on most frames), so a
+    # rounding-level difference (1e-9 at the first window) grows along the sequence (x 1.3 per frame, x 3-4 on the ill-conditioned stretch after
+    # frame 60) and jumps where a termination test falls on a knife edge (parity is defined on converged states, not on
+    # traces).  The GPU path is bit-reproducible (above), so what remains is the frame loop's own conditioning, measured by d_self: the CPU oracle
+    # moves by that much when its input moves in the 12th digit (3.8 mm on this stream; the GPU path is 1.7 mm from the oracle since k_ba_solve
+    # forms its residuals with the raw parameter quaternions like the reference, round 3).  Bars: 1e-6 m over the first 40 windows; 1 cm overall
+    # (north_star); identical keyframe / marginalisation decisions throughout; the same distance from the truth as the CPU path (below).
     assert np.abs(odo_e[:40, 1:4] - ref_e[:40, 1:4]).max() < 1e-6
-    assert d < 0.2
+    assert d < 0.01                                            # north_star's bar (the oracle's own sensitivity d_self is printed beside it)
     for k, (row, r) in enumerate(zip(frm, log)):
         assert (int(row[1]), int(row[2]), int(row[3])) == (r[0], r[1], r[2]) and (int(row[7]), int(row[8])) == (r[6], r[7]), "frame %d" % k
     # the fused trajectory (camera-aligned Estimator world) follows the ground truth
