@@ -62,7 +62,14 @@ int         lmono_synchronize(lmono_ctx *);
  * within it (everything behind stands), in rounds until no boundary is flagged; lmono_odom_boundary_report tells what happened.
  * Default 1000 (1e-6: 2e-6 rad, 1e-5 m); 0 = no validation (and no synchronisation inside lmono_odom_batch_d).                    */
 #define LMONO_OPT_BOUNDARY_TOL 4
-#define LMONO_OPT_COUNT     5
+/* schedule of lmono_odom_batch[_d] with the default search: 0 (default) = one launch per phase and outer iteration for all chains
+ * (k_corr_flat / k_correspond_list / k_lm_solve, LMONO_OPT_ODOM_STREAMS chain groups); 1 = one persistent 1024-thread workgroup per chain
+ * runs all of the chain's scan pairs in ONE launch (k_odom_chain: search by wave tasks, solve by the whole workgroup, no launch-wide
+ * barriers).  Same correspondences; increments equal to rounding (the solve's reductions run over 1024 instead of 256 threads).
+ * Measured (profiles/r3/NOTES.md): 1 is slower -- a chain confined to one CU pays its search and its solve one after the other
+ * (27.5 ms against 21.8 ms per pass over 4541 scans) -- and is kept as a measured alternative.                                      */
+#define LMONO_OPT_ODOM_PERSIST 5
+#define LMONO_OPT_COUNT     6
 int         lmono_set_option(lmono_ctx *, int key, int value);
 int         lmono_get_option(lmono_ctx *, int key, int *value);     /* the configured value (option values may be negative) */
 const char *lmono_version(void);
@@ -130,6 +137,23 @@ int lmono_odom_boundary_report(lmono_ctx *, lmono_scan_batch *, lmono_boundary_r
  * *changed_last = 1 when this rank's own last increment changed (the next rank must validate again).  incr_d [n][7] as above.     */
 int lmono_odom_shard_d(lmono_ctx *, lmono_scan_batch *, int n_chains, int lead, int first_owned, double *incr_d);
 int lmono_odom_shard_validate(lmono_ctx *, lmono_scan_batch *, const double *prev_incr_h, double *incr_d, int *changed_last);
+
+/* Online form: ONE scan per call, as the reference's nodes run (ROS callbacks laserCloudHandler -> laserOdometry at sensor rate; lmono
+ * consumes the result per frame: mono_lidar_mapping/src/image_process/MeasurementManager.cc:17-24, config/kitti_config_00.yaml:7-8).
+ * A stream keeps the previous scan's feature clouds and search index on the device ("last") and A-LOAM's para_q / para_t between calls
+ * (SURVEY.md A.2): lmono_odom_step registers the new scan (scanRegistration), runs the scan pair (2 x [correspondences -> <= 4 LM
+ * iterations]) warm-started from the previous increment and returns q_last_curr / t_last_curr and the accumulated q_w_curr / t_w_curr
+ * -- the same numbers lmono_odom_batch(n_chains 1, lead 0) gives for the same scans, bit for bit.  xyzi: [n_points][4] float32, host
+ * (on_device 0) or HBM (1).  use_warm_start != 0: q_last_curr / t_last_curr are read as the pair's warm start instead of the stream's
+ * own.  info [8] (may be NULL): n_cloud, n_sharp, n_less_sharp, n_flat, n_less_flat, status, LM iterations (outer 0 << 8 | outer 1),
+ * residual blocks of the last solve.  history >= 1 slots of scans are kept (the slots are reused cyclically).  Synchronous.         */
+typedef struct lmono_odom_stream lmono_odom_stream;
+lmono_odom_stream *lmono_odom_stream_create(lmono_ctx *, int max_points_per_scan, int n_lines, float min_range, int history);
+void lmono_odom_stream_destroy(lmono_odom_stream *);
+int lmono_odom_step(lmono_ctx *, lmono_odom_stream *, const float *xyzi, int n_points, int on_device, int use_warm_start,
+                    double *q_last_curr, double *t_last_curr, double *q_w_curr, double *t_w_curr, int32_t *info);
+/* the batch / scan index holding the stream's newest scan: for lmono_batch_get_cloud and lmono_mapper_process (laserMapping behind it) */
+int lmono_odom_stream_scan(lmono_odom_stream *, lmono_scan_batch **batch, int *scan);
 
 /* Debug/parity view of one odometry step: correspondences of outer iteration `outer` (0/1) for the scan
  * pair (scan-1, scan) evaluated at pose q,t: corr_h [n_sharp + n_flat][4] = (a, b, c, kind).       */

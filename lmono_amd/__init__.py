@@ -5,4 +5,4 @@ hand-written HIP kernels in lmono_amd/csrc/.  This Python package is plumbing on
 ctypes and uses torch for device buffers / streams / torch.distributed.  There is no CPU fallback: every entry
 point raises when the HIP library or a GPU is missing.
 """
-from .capi import LmonoError, Context, ScanBatch, BaBatch, Mapper, MapBuilder, PoseGraph, Camera, lidar_to_camera, lib_path, load_library  # noqa: F401
+from .capi import LmonoError, Context, ScanBatch, OdomStream, BaBatch, Mapper, MapBuilder, PoseGraph, Camera, lidar_to_camera, lib_path, load_library  # noqa: F401

@@ -11,7 +11,7 @@ MAX_QUERIES = 64 * 6 * 2 + 64 * 6 * 4
 SYMBOLS = [
     "lmono_create", "lmono_destroy", "lmono_last_error", "lmono_set_stream", "lmono_set_option", "lmono_get_option", "lmono_synchronize", "lmono_version",
     "lmono_batch_create", "lmono_batch_destroy", "lmono_scanreg_batch", "lmono_scanreg_batch_h", "lmono_batch_counts", "lmono_batch_get_cloud",
-    "lmono_batch_get_curvature", "lmono_odom_batch", "lmono_odom_batch_d", "lmono_odom_shard_d", "lmono_odom_shard_validate", "lmono_odom_boundary_report", "lmono_odom_correspond", "lmono_timing_reset", "lmono_timing_read",
+    "lmono_batch_get_curvature", "lmono_odom_batch", "lmono_odom_batch_d", "lmono_odom_shard_d", "lmono_odom_shard_validate", "lmono_odom_boundary_report", "lmono_odom_stream_create", "lmono_odom_stream_destroy", "lmono_odom_step", "lmono_odom_stream_scan", "lmono_odom_correspond", "lmono_timing_reset", "lmono_timing_read",
     "lmono_pose_prefix_d", "lmono_pose_rebase_d", "lmono_map_refine", "lmono_voxel_filter", "lmono_mapper_create", "lmono_mapper_destroy", "lmono_mapper_reset", "lmono_mapper_process", "lmono_mapper_process_batch", "lmono_mapper_cube",
     "lmono_map_builder_create", "lmono_map_builder_destroy", "lmono_associate_to_map", "lmono_associate_to_map_batch", "lmono_map_builder_depth",
     "lmono_map_builder_cloud", "lmono_map_builder_map", "lmono_map_builder_clear",
@@ -64,6 +64,11 @@ def load_library():
     L.lmono_odom_shard_d.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.lmono_odom_shard_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.lmono_odom_boundary_report.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.lmono_odom_stream_create.restype = C.c_void_p
+    L.lmono_odom_stream_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int]
+    L.lmono_odom_stream_destroy.argtypes = [C.c_void_p]
+    L.lmono_odom_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5
+    L.lmono_odom_stream_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.lmono_odom_correspond.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.lmono_timing_reset.argtypes = [C.c_void_p]
     L.lmono_triangulate.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 9 + [C.c_int, C.c_int, C.c_double, C.c_int]
@@ -106,6 +111,8 @@ class Context:
             self.L.lmono_set_option(self.h, 3, int(os.environ["LMONO_LEAD_FULL"]))
         if os.environ.get("LMONO_ODOM_STREAMS") is not None:
             self.L.lmono_set_option(self.h, 2, int(os.environ["LMONO_ODOM_STREAMS"]))
+        if os.environ.get("LMONO_ODOM_PERSIST") is not None:
+            self.L.lmono_set_option(self.h, 5, int(os.environ["LMONO_ODOM_PERSIST"]))
         if os.environ.get("LMONO_BOUNDARY_TOL") is not None:
             self.L.lmono_set_option(self.h, 4, int(os.environ["LMONO_BOUNDARY_TOL"]))
 
@@ -129,6 +136,7 @@ class Context:
     OPT_ODOM_STREAMS = 2
     OPT_LEAD_FULL = 3
     OPT_BOUNDARY_TOL = 4
+    OPT_ODOM_PERSIST = 5
 
     def set_option(self, key, value):
         self.check(self.L.lmono_set_option(self.h, int(key), int(value)))
@@ -317,6 +325,55 @@ class Context:
                                            cs.ctypes.data, cso.ctypes.data, ss.ctypes.data, sso.ctypes.data,
                                            poses.ctypes.data, stats.ctypes.data, nn.ctypes.data if want_nn else None))
         return poses, stats, nn
+
+class OdomStream:
+    """Online laserOdometry (lmono_odom_stream): one scan per step(), the previous scan's features stay on the device."""
+
+    def __init__(self, ctx, max_points, n_lines=64, min_range=5.0, history=8):
+        self.ctx = ctx
+        self.h = ctx.L.lmono_odom_stream_create(ctx.h, int(max_points), int(n_lines), float(min_range), int(history))
+        if not self.h:
+            raise LmonoError("lmono_odom_stream_create failed: %s" % ctx.L.lmono_last_error(ctx.h).decode())
+
+    def step(self, xyzi=None, dev_ptr=None, n_points=None, warm_start=None):
+        """xyzi: [n,4] float32 host array, or dev_ptr + n_points for a scan resident in HBM.  Returns (incr [7] = q_last_curr xyzw +
+        t_last_curr, pose [7] = q_w_curr + t_w_curr, info [8])."""
+        incr = np.zeros(7); pose = np.zeros(7); info = np.zeros(8, np.int32)
+        use = 0
+        if warm_start is not None:
+            incr[:] = np.asarray(warm_start, np.float64); use = 1
+        if dev_ptr is None:
+            xyzi = np.ascontiguousarray(xyzi, np.float32)
+            ptr, n, on_dev = xyzi.ctypes.data, len(xyzi), 0
+        else:
+            ptr, n, on_dev = dev_ptr, int(n_points), 1
+        self.ctx.check(self.ctx.L.lmono_odom_step(self.ctx.h, self.h, C.c_void_p(ptr), n, on_dev, use, incr.ctypes.data, incr.ctypes.data + 32,
+                                                  pose.ctypes.data, pose.ctypes.data + 32, info.ctypes.data))
+        return incr, pose, info
+
+    def scan(self):
+        """(raw lmono_scan_batch handle, scan index) of the newest scan, for Mapper.process_raw / cloud()."""
+        bh = C.c_void_p(0); sc = C.c_int(0)
+        self.ctx.check(self.ctx.L.lmono_odom_stream_scan(self.h, C.byref(bh), C.byref(sc)))
+        return bh.value, sc.value
+
+    def cloud(self, which, cap):
+        bh, sc = self.scan()
+        out = np.zeros((max(cap, 1), 4), np.float32)
+        n = self.ctx.check(self.ctx.L.lmono_batch_get_cloud(self.ctx.h, C.c_void_p(bh), sc, which, out.ctypes.data, cap))
+        return out[:n]
+
+    def close(self):
+        if self.h:
+            self.ctx.L.lmono_odom_stream_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
 
 class BoundaryReport(C.Structure):
     """lmono_boundary_report (include/lmono_hip.h)"""

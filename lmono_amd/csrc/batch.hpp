@@ -21,6 +21,7 @@ struct BatchView {
     const float4 *in;        // [total] raw x y z reflectance
     const int64_t *off;      // [n_scans + 1] point offsets (device copy)
     int n_scans;
+    int scan0;               // first scan of this launch (the per-scan kernels' grids cover scans scan0 .. scan0 + grid - 1; 0 for a whole batch)
     int n_lines;
     int has_grid;            // the hash grids (cg_* / sg_*) of this registration have been built (k_grid_build runs on demand)
     float min_range;

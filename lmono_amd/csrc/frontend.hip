@@ -54,7 +54,7 @@ __global__ __launch_bounds__(kRsT) void k_ring_sort(BatchView b)
     long long rt[6];
 #endif
     RT(0)
-    const int s = blockIdx.x;
+    const int s = b.scan0 + blockIdx.x;
     const int64_t off = b.off[s];
     const int n = (int)(b.off[s + 1] - off);
     const float4 *in = b.in + off;
@@ -235,7 +235,7 @@ constexpr int kCurvTile = 1024;
 
 __global__ __launch_bounds__(256) void k_curvature(BatchView b)
 {
-    const int s = blockIdx.y;
+    const int s = b.scan0 + blockIdx.y;
     const int n = b.n_cloud[s];
     const int t0 = blockIdx.x * kCurvTile;
     if (t0 >= n) return;
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256, 8) void k_select(BatchView b, int cap, int fro
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char *smem_w = smem + wave * 2 * cap;
     if (!from_list) {
-        select_ring(b, blockIdx.x * 4 + wave, blockIdx.y, lane, smem_w, cap, true);
+        select_ring(b, blockIdx.x * 4 + wave, b.scan0 + blockIdx.y, lane, smem_w, cap, true);
     } else {
         const int n_todo = b.sel_todo[0];
         for (int k = blockIdx.x * 4 + wave; k < n_todo; k += gridDim.x * 4) {
@@ -486,7 +486,7 @@ __device__ __forceinline__ void voxel_ring(BatchView &b, int r, int s);
 template <int kVoxSlots, int kVoxBucketBits, bool kSmall>
 __global__ __launch_bounds__(256) void k_voxel(BatchView b)
 {
-    if (kSmall) voxel_ring<kVoxSlots, kVoxBucketBits, kSmall>(b, blockIdx.x, blockIdx.y);
+    if (kSmall) voxel_ring<kVoxSlots, kVoxBucketBits, kSmall>(b, blockIdx.x, b.scan0 + blockIdx.y);
     else {
         const int n_todo = b.vox_todo[0];
         for (int k = blockIdx.x; k < n_todo; k += gridDim.x) {
@@ -810,7 +810,7 @@ __device__ __forceinline__ void voxel_ring(BatchView &b, int r, int s)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_compact(BatchView b)
 {
-    const int s = blockIdx.x;
+    const int s = b.scan0 + blockIdx.x;
     const int tid = threadIdx.x;
     const int64_t off = b.off[s];
     constexpr int NE = kMaxRings * kSectors;   // 384

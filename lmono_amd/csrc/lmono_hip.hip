@@ -5,6 +5,7 @@
 #include "corr_tile.hip"
 #include "corr_thread.hip"
 #include "corr_flat.hip"
+#include "odom_chain.hip"
 #include "mapping.hip"
 #include "ba.hip"
 #include "ba_solve.hip"
@@ -31,7 +32,7 @@ struct lmono_ctx {
     std::vector<EvSet> sets;   // one event set per scanreg/odometry call since the last lmono_timing_reset
     int n_sets = 0;
     hipEvent_t *ev = nullptr;  // events of the current call
-    int opt[LMONO_OPT_COUNT] = { 3, 0, 4, -1, 1000 };   // LMONO_OPT_CORR_TILE: 3 = flattened sweeps (default: as fast as 0 and needs no hash grid), 0 = 32-lane groups, 1 = LDS sector tiles, 2 = thread per feature
+    int opt[LMONO_OPT_COUNT] = { 3, 0, 4, -1, 1000, 0 };   // LMONO_OPT_CORR_TILE: 3 = flattened sweeps (default: as fast as 0 and needs no hash grid), 0 = 32-lane groups, 1 = LDS sector tiles, 2 = thread per feature
     hipStream_t gstream[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };   // streams of the odometry's chain groups (LMONO_OPT_ODOM_STREAMS > 1)
     hipEvent_t gev[9] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     unsigned long long *stats_d = nullptr;   // [0] feature points deferred by the tile search since the last lmono_timing_reset
@@ -108,6 +109,7 @@ extern "C" lmono_ctx *lmono_create(int device)
     if (hipFuncSetAttribute((const void *)k_voxel<kVoxSmallSlots, kVoxSmallBits, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kVoxLdsSmall) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_voxel<kVoxBigSlots, kVoxBigBits, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kVoxLdsBig) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_lm_solve, hipFuncAttributeMaxDynamicSharedMemorySize, kLmRecLds) != hipSuccess) { delete c; return nullptr; }
+    if (hipFuncSetAttribute((const void *)k_odom_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(OcLds)) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_grid_build, hipFuncAttributeMaxDynamicSharedMemorySize, kGridLds) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_line_index<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLiLdsHalf) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_line_index<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLiLdsFull) != hipSuccess) { delete c; return nullptr; }
@@ -152,6 +154,7 @@ extern "C" int lmono_set_option(lmono_ctx *c, int key, int value)
                   : key == LMONO_OPT_DEFER_EVERY ? value >= 0
                   : key == LMONO_OPT_ODOM_STREAMS ? (value >= 1 && value <= 8)
                   : key == LMONO_OPT_BOUNDARY_TOL ? value >= 0
+                  : key == LMONO_OPT_ODOM_PERSIST ? (value == 0 || value == 1)
                   : value >= -1;                                     // LMONO_OPT_LEAD_FULL
     if (!ok) { c->err = "lmono_set_option: value out of range for this option"; return LMONO_EINVAL; }
     c->opt[key] = value;
@@ -233,6 +236,52 @@ static int check_launch(lmono_ctx *c, const char *what)
     return LMONO_OK;
 }
 
+// The front end (scanRegistration) over scans scan0 .. scan0 + n_scans - 1 of the batch: the per-scan kernels' grids cover n_scans scans, the
+// batch view tells them where they start.  A whole-batch registration is (0, n); the online stream registers one slot at a time.
+static int scanreg_launch(lmono_ctx *c, lmono_scan_batch *b, int scan0, int n_scans, int64_t max_pts)
+{
+    BatchView v = b->v;
+    v.scan0 = scan0;
+    hipStream_t st = c->stream;
+    c->ev = c->next_set();
+    if (!c->ev) { c->err = "hipEventCreate failed"; return LMONO_ENODEV; }
+    c->sets[c->n_sets - 1].reg = true;
+    HIP_TRY(c, hipMemsetAsync(v.status + scan0, 0, sizeof(int) * n_scans, st));
+    HIP_TRY(c, hipMemsetAsync(v.vox_todo, 0, sizeof(int), st));
+    HIP_TRY(c, hipMemsetAsync(v.sel_todo, 0, sizeof(int), st));
+    HIP_TRY(c, hipMemsetAsync(v.li_todo, 0, sizeof(int), st));
+    HIP_TRY(c, hipEventRecord(c->ev[0], st));
+    hipLaunchKernelGGL(k_ring_sort, dim3(n_scans), dim3(kRsT), 0, st, v);
+    HIP_TRY(c, hipEventRecord(c->ev[1], st));
+    const int tiles = (int)((max_pts + kCurvTile - 1) / kCurvTile);
+    if (tiles > 0) hipLaunchKernelGGL(k_curvature, dim3(tiles, n_scans), dim3(256), 0, st, v);
+    HIP_TRY(c, hipEventRecord(c->ev[2], st));
+    // the kernels below run one workgroup per ring of the sensor; the counters of the rings it cannot produce stay zero
+    const int n_rings = rings_used(b->v.n_lines);
+    HIP_TRY(c, hipMemsetAsync(v.sel_sharp_n + (size_t)scan0 * 64 * 6, 0, sizeof(int) * (size_t)n_scans * 64 * 6, st));
+    HIP_TRY(c, hipMemsetAsync(v.sel_flat_n + (size_t)scan0 * 64 * 6, 0, sizeof(int) * (size_t)n_scans * 64 * 6, st));
+    HIP_TRY(c, hipMemsetAsync(v.lf_n + (size_t)scan0 * 64, 0, sizeof(int) * (size_t)n_scans * 64, st));
+    hipLaunchKernelGGL(k_select, dim3((n_rings + 3) / 4, n_scans), dim3(256), 4 * 2 * kSelSmallCap, st, v, kSelSmallCap, 0);
+    hipLaunchKernelGGL(k_select, dim3(kSelBigGrid), dim3(256), 4 * kSelWaveLds, st, v, (int)kRingCap, 1);
+    HIP_TRY(c, hipEventRecord(c->ev[3], st));
+    hipLaunchKernelGGL((k_voxel<kVoxSmallSlots, kVoxSmallBits, true>), dim3(n_rings, n_scans), dim3(256), kVoxLdsSmall, st, v);
+    hipLaunchKernelGGL((k_voxel<kVoxBigSlots, kVoxBigBits, false>), dim3(kVoxBigGrid), dim3(256), kVoxLdsBig, st, v);
+    HIP_TRY(c, hipEventRecord(c->ev[4], st));
+    hipLaunchKernelGGL(k_compact, dim3(n_scans), dim3(256), 0, st, v);
+    HIP_TRY(c, hipEventRecord(c->ev[5], st));
+    // the hash grids serve the 32-lane-group search (LMONO_OPT_CORR_TILE 0) and the deferred lists of modes 1 and 2; the default
+    // (flattened sweeps) works on the line index alone, so the grids are built on demand (ensure_grid)
+    if (c->opt[LMONO_OPT_CORR_TILE] != 3) {
+        hipLaunchKernelGGL(k_grid_build, dim3(n_scans, 1 + kGridPar), dim3(1024), kGridLds, st, v);
+        b->grid_built = true; v.has_grid = 1; b->v.has_grid = 1;
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[6], st));
+    hipLaunchKernelGGL(k_line_index<true>, dim3(n_scans, 2), dim3(kLiT), kLiLdsHalf, st, v);
+    hipLaunchKernelGGL(k_line_index<false>, dim3(kLiBigGrid), dim3(kLiT), kLiLdsFull, st, v);
+    HIP_TRY(c, hipEventRecord(c->ev[7], st));
+    return check_launch(c, "scanreg kernels");
+}
+
 extern "C" int lmono_scanreg_batch(lmono_ctx *c, lmono_scan_batch *b, const float *xyzi_d, const int64_t *offsets_h,
                                    int n_scans, int n_lines, float min_range);
 
@@ -278,46 +327,9 @@ extern "C" int lmono_scanreg_batch(lmono_ctx *c, lmono_scan_batch *b, const floa
     b->n_scans = n_scans; b->total = total; b->max_pts = (int)max_pts; b->registered = false; b->grid_built = false;
     b->feat_h.clear();
     BatchView &v = b->v;
-    v.in = (const float4 *)xyzi_d; v.n_scans = n_scans; v.n_lines = n_lines; v.min_range = min_range; v.has_grid = 0;
-    hipStream_t st = c->stream;
-    c->ev = c->next_set();
-    if (!c->ev) { c->err = "hipEventCreate failed"; return LMONO_ENODEV; }
-    c->sets[c->n_sets - 1].reg = true;
-    HIP_TRY(c, hipMemcpyAsync(b->off_d, b->off_h.data(), sizeof(int64_t) * (n_scans + 1), hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemsetAsync(v.status, 0, sizeof(int) * n_scans, st));
-    HIP_TRY(c, hipMemsetAsync(v.vox_todo, 0, sizeof(int), st));
-    HIP_TRY(c, hipMemsetAsync(v.sel_todo, 0, sizeof(int), st));
-    HIP_TRY(c, hipMemsetAsync(v.li_todo, 0, sizeof(int), st));
-    HIP_TRY(c, hipEventRecord(c->ev[0], st));
-    hipLaunchKernelGGL(k_ring_sort, dim3(n_scans), dim3(kRsT), 0, st, v);
-    HIP_TRY(c, hipEventRecord(c->ev[1], st));
-    const int tiles = (int)((max_pts + kCurvTile - 1) / kCurvTile);
-    if (tiles > 0) hipLaunchKernelGGL(k_curvature, dim3(tiles, n_scans), dim3(256), 0, st, v);
-    HIP_TRY(c, hipEventRecord(c->ev[2], st));
-    // the kernels below run one workgroup per ring of the sensor; the counters of the rings it cannot produce stay zero
-    const int n_rings = rings_used(n_lines);
-    HIP_TRY(c, hipMemsetAsync(v.sel_sharp_n, 0, sizeof(int) * (size_t)n_scans * 64 * 6, st));
-    HIP_TRY(c, hipMemsetAsync(v.sel_flat_n, 0, sizeof(int) * (size_t)n_scans * 64 * 6, st));
-    HIP_TRY(c, hipMemsetAsync(v.lf_n, 0, sizeof(int) * (size_t)n_scans * 64, st));
-    hipLaunchKernelGGL(k_select, dim3((n_rings + 3) / 4, n_scans), dim3(256), 4 * 2 * kSelSmallCap, st, v, kSelSmallCap, 0);
-    hipLaunchKernelGGL(k_select, dim3(kSelBigGrid), dim3(256), 4 * kSelWaveLds, st, v, (int)kRingCap, 1);
-    HIP_TRY(c, hipEventRecord(c->ev[3], st));
-    hipLaunchKernelGGL((k_voxel<kVoxSmallSlots, kVoxSmallBits, true>), dim3(n_rings, n_scans), dim3(256), kVoxLdsSmall, st, v);
-    hipLaunchKernelGGL((k_voxel<kVoxBigSlots, kVoxBigBits, false>), dim3(kVoxBigGrid), dim3(256), kVoxLdsBig, st, v);
-    HIP_TRY(c, hipEventRecord(c->ev[4], st));
-    hipLaunchKernelGGL(k_compact, dim3(n_scans), dim3(256), 0, st, v);
-    HIP_TRY(c, hipEventRecord(c->ev[5], st));
-    // the hash grids serve the 32-lane-group search (LMONO_OPT_CORR_TILE 0) and the deferred lists of modes 1 and 2; the default
-    // (flattened sweeps) works on the line index alone, so the grids are built on demand (ensure_grid)
-    if (c->opt[LMONO_OPT_CORR_TILE] != 3) {
-        hipLaunchKernelGGL(k_grid_build, dim3(n_scans, 1 + kGridPar), dim3(1024), kGridLds, st, v);
-        b->grid_built = true; v.has_grid = 1;
-    }
-    HIP_TRY(c, hipEventRecord(c->ev[6], st));
-    hipLaunchKernelGGL(k_line_index<true>, dim3(n_scans, 2), dim3(kLiT), kLiLdsHalf, st, v);
-    hipLaunchKernelGGL(k_line_index<false>, dim3(kLiBigGrid), dim3(kLiT), kLiLdsFull, st, v);
-    HIP_TRY(c, hipEventRecord(c->ev[7], st));
-    int rc = check_launch(c, "scanreg kernels");
+    v.in = (const float4 *)xyzi_d; v.n_scans = n_scans; v.scan0 = 0; v.n_lines = n_lines; v.min_range = min_range; v.has_grid = 0;
+    HIP_TRY(c, hipMemcpyAsync(b->off_d, b->off_h.data(), sizeof(int64_t) * (n_scans + 1), hipMemcpyHostToDevice, c->stream));
+    int rc = scanreg_launch(c, b, 0, n_scans, max_pts);
     if (rc) return rc;
     b->registered = true;
     return LMONO_OK;
@@ -546,6 +558,30 @@ static int odom_launch_steps(lmono_ctx *c, lmono_scan_batch *b, const OdomView &
     return fork.join();
 }
 
+// The persistent schedule: ONE launch, one 1024-thread workgroup per chain of view o (o.clist set: per listed chain) runs up to max_steps
+// scan pairs of its chain.  es / ne: group-0 style events around the launch (the whole odometry is one "correspondence" interval).
+static int odom_launch_chains(lmono_ctx *c, lmono_scan_batch *b, const OdomView &o, int n_ch, int max_steps, EvSet *es, int *ne)
+{
+    if (n_ch <= 0 || max_steps <= 0) return LMONO_OK;
+    hipStream_t st = c->stream;
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    if (es) {
+        auto kev = [&](int i) -> hipEvent_t {
+            while ((int)es->kev.size() <= i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; es->kev.push_back(e); }
+            return es->kev[i];
+        };
+        e0 = kev(*ne); e1 = kev(*ne + 1); e2 = kev(*ne + 2);
+    }
+    OdomView og = o;
+    og.chain0 = 0; og.chain1 = n_ch;
+    if (e0 && e1 && e2) (void)hipEventRecord(e0, st);
+    hipLaunchKernelGGL(k_odom_chain, dim3(n_ch), dim3(kOcT), sizeof(OcLds), st, b->v, og, max_steps, b->wl, c->opt[LMONO_OPT_DEFER_EVERY], c->stats_d);
+    if (e0 && e1 && e2) { (void)hipEventRecord(e1, st); (void)hipEventRecord(e2, st); *ne += 3; }
+    return check_launch(c, "k_odom_chain");
+}
+
+static bool odom_persistent(const lmono_ctx *c) { return c->opt[LMONO_OPT_CORR_TILE] == 3 && c->opt[LMONO_OPT_ODOM_PERSIST] != 0; }
+
 // Boundary validation + repair rounds of the chained schedule ("self-validating chains").  ext: incr[first - 1]
 // was supplied by the caller (previous rank's last increment).  Synchronises the context stream (the flagged count decides what is
 // launched).  Results in b->brep / b->resid_h / b->rerun_h.
@@ -580,6 +616,12 @@ static int odom_validate(lmono_ctx *c, lmono_scan_batch *b, OdomView o, bool ext
         R.flagged += nf; R.rounds += 1;
         OdomView orp = o;
         orp.repair = 1; orp.clist = (const int *)(b->rcount + 2); orp.lead_full = -1;
+        if (odom_persistent(c)) {
+            // a repair chain stops by itself at the first pair whose increment agrees with the stored one
+            int rc = odom_launch_chains(c, b, orp, nf, max_len, nullptr, nullptr);
+            if (rc) return rc;
+            continue;
+        }
         const int G = odom_groups(c, nf);
         if (tile) for (int g = 0; g < G; g++) HIP_TRY(c, hipMemsetAsync(b->wl + g * ((size_t)b->chains_cap * kMaxQueries + 1), 0, sizeof(unsigned int), st));
         // a repair chain usually agrees with the stored increments after a few pairs: launch in chunks, ask the device how many still run
@@ -653,7 +695,8 @@ static int odom_run(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, i
     if (tile) for (int g = 0; g < G; g++) HIP_TRY(c, hipMemsetAsync(b->wl + g * ((size_t)b->chains_cap * kMaxQueries + 1), 0, sizeof(unsigned int), st));
     EvSet &es = c->sets[c->n_sets - 1];
     int ne = 0;
-    rc = odom_launch_steps(c, b, o, n_chains, 0, max_steps, G, &es, &ne);
+    if (odom_persistent(c)) rc = odom_launch_chains(c, b, o, n_chains, max_steps, &es, &ne);
+    else rc = odom_launch_steps(c, b, o, n_chains, 0, max_steps, G, &es, &ne);
     if (rc) return rc;
     es.n_kev = ne;
     // the chained schedule validates itself: every chain's warm start against its predecessor's last increment, repair where they differ
@@ -714,6 +757,147 @@ extern "C" int lmono_odom_batch(lmono_ctx *c, lmono_scan_batch *b, int n_chains,
     const int n = b->n_scans;
     if (incr_h) HIP_TRY(c, hipMemcpy(incr_h, b->incr, sizeof(double) * 7 * n, hipMemcpyDeviceToHost));
     if (poses_h) HIP_TRY(c, hipMemcpy(poses_h, b->poses, sizeof(double) * 7 * n, hipMemcpyDeviceToHost));
+    return LMONO_OK;
+}
+
+// ---- online laserOdometry: one scan per call (A-LOAM's node callbacks) -------------------------------------------------------------
+// A stream owns a batch of history + 1 fixed-size slots.  Scan t is registered into the slot behind scan t - 1's (the raw points are
+// copied into the slot, the rest of the slot is NaN: scanRegistration drops NaN points first), so "last" = the previous slot keeps its
+// feature clouds and (line, azimuth bin) index from the previous call; one chain, pinned to the new slot, runs the scan pair from the
+// stream's para_q / para_t.  When the slots run out, the last slot's "last" data move to slot 0 and the cycle restarts at slot 1.
+struct lmono_odom_stream {
+    lmono_ctx *ctx = nullptr;
+    lmono_scan_batch *batch = nullptr;
+    float *in_d = nullptr;
+    int cap_pts = 0, n_slots = 0, slot = 0;
+    long long frame = 0;
+    double para[8] = { 0, 0, 0, 1, 0, 0, 0, 0 };       // q_last_curr (x y z w), t_last_curr
+    double q_w[4] = { 0, 0, 0, 1 }, t_w[3] = { 0, 0, 0 };
+};
+
+extern "C" void lmono_odom_stream_destroy(lmono_odom_stream *s)
+{
+    if (!s) return;
+    if (s->batch) lmono_batch_destroy(s->batch);
+    if (s->in_d) (void)hipFree(s->in_d);
+    delete s;
+}
+
+extern "C" lmono_odom_stream *lmono_odom_stream_create(lmono_ctx *c, int max_points, int n_lines, float min_range, int history)
+{
+    if (!c || max_points <= 0 || history < 1 || (n_lines != 16 && n_lines != 32 && n_lines != 64)) return nullptr;
+    if (c->opt[LMONO_OPT_CORR_TILE] != 3) { c->err = "lmono_odom_stream: needs the default correspondence search (LMONO_OPT_CORR_TILE 3)"; return nullptr; }
+    if (hipSetDevice(c->device) != hipSuccess) return nullptr;
+    lmono_odom_stream *s = new lmono_odom_stream();
+    s->ctx = c; s->cap_pts = max_points; s->n_slots = history + 1;
+    s->batch = lmono_batch_create(c, s->n_slots, (int64_t)s->n_slots * max_points);
+    if (!s->batch || hipMalloc((void **)&s->in_d, (size_t)s->n_slots * max_points * 16) != hipSuccess) { c->err = "lmono_odom_stream_create: allocation failed"; lmono_odom_stream_destroy(s); return nullptr; }
+    lmono_scan_batch *b = s->batch;
+    b->off_h.resize(s->n_slots + 1);
+    for (int i = 0; i <= s->n_slots; i++) b->off_h[i] = (int64_t)i * max_points;
+    b->n_scans = s->n_slots; b->total = (int64_t)s->n_slots * max_points; b->max_pts = max_points;
+    BatchView &v = b->v;
+    v.in = (const float4 *)s->in_d; v.n_scans = s->n_slots; v.scan0 = 0; v.n_lines = n_lines; v.min_range = min_range; v.has_grid = 0;
+    bool ok = hipMemcpy(b->off_d, b->off_h.data(), sizeof(int64_t) * (s->n_slots + 1), hipMemcpyHostToDevice) == hipSuccess;
+    // empty slots: no points, no features
+    ok = ok && hipMemset(s->in_d, 0xff, (size_t)s->n_slots * max_points * 16) == hipSuccess;
+    ok = ok && hipMemset(v.n_cloud, 0, sizeof(int) * s->n_slots) == hipSuccess && hipMemset(v.feat_n, 0, sizeof(int) * 4 * s->n_slots) == hipSuccess;
+    ok = ok && hipMemset(v.status, 0, sizeof(int) * s->n_slots) == hipSuccess;
+    ok = ok && ensure_odom_ws(c, b, 1) == LMONO_OK;
+    if (!ok) { c->err = "lmono_odom_stream_create: initialisation failed"; lmono_odom_stream_destroy(s); return nullptr; }
+    b->registered = true;
+    return s;
+}
+
+// everything of slot `from` that a scan pair reads of its "last" scan, copied to slot `to`
+static int stream_copy_last(lmono_ctx *c, lmono_scan_batch *b, int from, int to)
+{
+    hipStream_t st = c->stream;
+    BatchView &v = b->v;
+    const int64_t of = b->off_h[from], ot = b->off_h[to];
+    const size_t P = (size_t)(b->off_h[1] - b->off_h[0]);
+#define CP(arr, stride, off_from, off_to) HIP_TRY(c, hipMemcpyAsync((arr) + (off_to), (arr) + (off_from), sizeof(*(arr)) * (stride), hipMemcpyDeviceToDevice, st))
+    CP(v.feat_n, 4, (size_t)from * 4, (size_t)to * 4);
+    CP(v.n_cloud, 1, (size_t)from, (size_t)to);
+    CP(v.status, 1, (size_t)from, (size_t)to);
+    CP(v.less_sharp, kMaxLessSharp, (size_t)from * kMaxLessSharp, (size_t)to * kMaxLessSharp);
+    CP(v.less_flat, P, (size_t)of, (size_t)ot);
+    CP(v.lbc_pts, kMaxLessSharp, (size_t)from * kMaxLessSharp, (size_t)to * kMaxLessSharp);
+    CP(v.lbs_pts, P, (size_t)of, (size_t)ot);
+    CP(v.lb_start, 2 * (kLineKeys + 1), (size_t)from * 2 * (kLineKeys + 1), (size_t)to * 2 * (kLineKeys + 1));
+    CP(v.lb_elev, 2 * 66, (size_t)from * 2 * 66, (size_t)to * 2 * 66);
+    CP(v.line_first_ge, 2 * 66, (size_t)from * 2 * 66, (size_t)to * 2 * 66);
+    CP(v.line_last_le, 2 * 66, (size_t)from * 2 * 66, (size_t)to * 2 * 66);
+#undef CP
+    return LMONO_OK;
+}
+
+extern "C" int lmono_odom_step(lmono_ctx *c, lmono_odom_stream *s, const float *xyzi, int n_points, int on_device, int use_warm_start,
+                               double *q_last_curr, double *t_last_curr, double *q_w_curr, double *t_w_curr, int32_t *info)
+{
+    if (!c || !s || s->ctx != c || !xyzi || n_points < 0) return LMONO_EINVAL;
+    if (n_points > s->cap_pts) { c->err = "lmono_odom_step: more points than the stream's slots hold"; return LMONO_ECAPACITY; }
+    if (use_warm_start && (!q_last_curr || !t_last_curr)) return LMONO_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    lmono_scan_batch *b = s->batch;
+    hipStream_t st = c->stream;
+    int next = s->frame == 0 ? 1 : s->slot + 1;
+    if (next >= s->n_slots) {
+        int rc = stream_copy_last(c, b, s->slot, 0);
+        if (rc) return rc;
+        next = 1;
+    }
+    float *dst = s->in_d + (size_t)next * s->cap_pts * 4;
+    if (n_points > 0) HIP_TRY(c, hipMemcpyAsync(dst, xyzi, (size_t)n_points * 16, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    if (n_points < s->cap_pts) HIP_TRY(c, hipMemsetAsync(dst + (size_t)n_points * 4, 0xff, (size_t)(s->cap_pts - n_points) * 16, st));
+    int rc = scanreg_launch(c, b, next, 1, n_points);
+    if (rc) return rc;
+    b->feat_h.clear();
+    int iters[4] = { 0, 0, 0, 0 };
+    if (s->frame > 0) {
+        if (use_warm_start) { for (int i = 0; i < 4; i++) s->para[i] = q_last_curr[i]; for (int i = 0; i < 3; i++) s->para[4 + i] = t_last_curr[i]; }
+        HIP_TRY(c, hipMemcpyAsync(b->state, s->para, sizeof(double) * 8, hipMemcpyHostToDevice, st));
+        OdomView o = odom_view(c, b, 1, 0, 0);
+        o.fixed_k = next; o.ws = nullptr; o.lead_full = -1;
+        HIP_TRY(c, hipMemsetAsync(b->wl, 0, sizeof(unsigned int), st));
+        rc = odom_launch_steps(c, b, o, 1, 0, 1, 1, nullptr, nullptr);
+        if (rc) return rc;
+        HIP_TRY(c, hipMemcpyAsync(s->para, b->state, sizeof(double) * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipMemcpyAsync(iters, b->lm_info, sizeof(iters), hipMemcpyDeviceToHost, st));
+    }
+    int fn[6] = { 0, 0, 0, 0, 0, 0 };
+    HIP_TRY(c, hipMemcpyAsync(fn, b->v.n_cloud + next, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(fn + 1, b->v.feat_n + next * 4, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(fn + 5, b->v.status + next, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    if (s->frame > 0) {
+        // laserOdometry's accumulation: t_w_curr += q_w_curr * t_last_curr; q_w_curr = q_w_curr * q_last_curr
+        const double *q = s->para, *t = s->para + 4;
+        const double ux = s->q_w[0], uy = s->q_w[1], uz = s->q_w[2], w = s->q_w[3];
+        const double uvx = 2.0 * (uy * t[2] - uz * t[1]), uvy = 2.0 * (uz * t[0] - ux * t[2]), uvz = 2.0 * (ux * t[1] - uy * t[0]);
+        s->t_w[0] += t[0] + w * uvx + (uy * uvz - uz * uvy);
+        s->t_w[1] += t[1] + w * uvy + (uz * uvx - ux * uvz);
+        s->t_w[2] += t[2] + w * uvz + (ux * uvy - uy * uvx);
+        const double bx = q[0], by = q[1], bz = q[2], bw = q[3];
+        const double nw = w * bw - ux * bx - uy * by - uz * bz, nx = w * bx + ux * bw + uy * bz - uz * by;
+        const double ny = w * by + uy * bw + uz * bx - ux * bz, nz = w * bz + uz * bw + ux * by - uy * bx;
+        s->q_w[0] = nx; s->q_w[1] = ny; s->q_w[2] = nz; s->q_w[3] = nw;
+    }
+    if (q_last_curr) for (int i = 0; i < 4; i++) q_last_curr[i] = s->para[i];
+    if (t_last_curr) for (int i = 0; i < 3; i++) t_last_curr[i] = s->para[4 + i];
+    if (q_w_curr) for (int i = 0; i < 4; i++) q_w_curr[i] = s->q_w[i];
+    if (t_w_curr) for (int i = 0; i < 3; i++) t_w_curr[i] = s->t_w[i];
+    if (info) { for (int i = 0; i < 6; i++) info[i] = fn[i]; info[6] = (iters[0] << 8) | iters[1]; info[7] = iters[3]; }
+    s->slot = next; s->frame++;
+    if (fn[5] & kStatusRingOverflow) { c->err = "lmono_odom_step: a ring holds more than LMONO_RING_CAP points"; return LMONO_ESCAN; }
+    return LMONO_OK;
+}
+
+extern "C" int lmono_odom_stream_scan(lmono_odom_stream *s, lmono_scan_batch **batch, int *scan)
+{
+    if (!s || s->frame == 0) return LMONO_EINVAL;
+    if (batch) *batch = s->batch;
+    if (scan) *scan = s->slot;
     return LMONO_OK;
 }
 

@@ -91,7 +91,7 @@ __device__ __forceinline__ unsigned long long key32_to_64(unsigned int k)
 
 __global__ __launch_bounds__(1024) void k_grid_build(BatchView b)
 {
-    const int s = blockIdx.x;
+    const int s = b.scan0 + blockIdx.x;
     const bool surf = blockIdx.y > 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = b.feat_n[s * 4 + (surf ? 3 : 1)];
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(kLiT) void k_line_index(BatchView b)
     extern __shared__ __align__(16) int s_cnt[];      // points per (line, bin); after the prefix: write cursor of the bucket
     __shared__ int s_wsum[kLiT / 64], s_emin[66], s_emax[66];
     if (kHalf) {
-        const int s = blockIdx.x;
+        const int s = b.scan0 + blockIdx.x;
         const bool surf = blockIdx.y == 1;
         if (b.feat_n[s * 4 + (surf ? 3 : 1)] > 65535) {
             if (threadIdx.x == 0) b.li_todo[1 + atomicAdd(&b.li_todo[0], 1)] = s * 2 + (surf ? 1 : 0);
@@ -1360,62 +1360,35 @@ constexpr int kThinBlocks = kMaxQueries / 128;     // = kCfBlocks of corr_flat.h
 
 // One kLmT-thread workgroup per chain.  Every thread runs the (uniform) trust-region control flow redundantly on the
 // block-reduced sums; residual blocks come from the 64-B records written by k_correspond.
-__global__ __launch_bounds__(kLmT) void k_lm_solve(BatchView b, OdomView o, int step, int outer, unsigned int *wl_reset)
-{
-    const int c = o.clist ? o.clist[o.chain0 + blockIdx.x] : o.chain0 + (int)blockIdx.x;
-    if (wl_reset && blockIdx.x == 0 && threadIdx.x == 0) wl_reset[0] = 0u;      // the work list of the next correspondence launch starts empty
-    int s;
-    const int k = chain_scan(o, c, step, s);
-    if (k < 0) return;
-    __shared__ double s_red[kLmW][28], s_sum[28], s_cur[28];
-    __shared__ int s_used[kLmW];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n_edge = b.feat_n[k * 4 + 0], nq = n_edge + b.feat_n[k * 4 + 2];
-    const float4 *crec = o.crec + (size_t)c * kMaxQueries * 4;
-    // the chain's residual-block records (64 B each, <= 144 KB) are read once and stay in LDS for the up to nine
-    // evaluations of this launch; eight 16-B loads per thread in flight
-    extern __shared__ __align__(16) float4 s_rec[];
-    int n_used = 0;
-    {
-        // one record per thread and round: its four 16-B quarters are requested together, the pose-independent part of the
-        // residual block is computed once (stage_block) and the block goes to LDS as (cp, kind) + six doubles
-        double2 *sp = (double2 *)s_rec;
-        const bool thin = lead_in_thinned(o, k, s);
-        for (int qi = tid; qi < nq; qi += kLmT) {
-            float4 cp = crec[qi * 4];
-            const float4 A = crec[qi * 4 + 1], B = crec[qi * 4 + 2], Cc = crec[qi * 4 + 3];
-            if (thin && (qi % kThinBlocks) % kThinStride != 0) cp.w = 0.f;       // not searched in this launch: a stale record
-            double P[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
-            if (__float_as_int(cp.w) != 0) { stage_block(cp, A, B, Cc, P); n_used++; }
-            s_rec[qi] = cp;
-            sp[kMaxQueries + qi] = make_double2(P[0], P[1]);
-            sp[2 * kMaxQueries + qi] = make_double2(P[2], P[3]);
-            sp[3 * kMaxQueries + qi] = make_double2(P[4], P[5]);
-        }
-    }
-    __syncthreads();
-    double x[7];
-    for (int i = 0; i < 7; i++) x[i] = o.state[c * 8 + i];
+// k_lm_solve's evaluation: the chain's records staged in LDS
+struct LmRecEval {
+    const float4 *srec; int n_edge, nq; double (*s_red)[28]; double *s_sum;
+    template <bool kJac> __device__ __forceinline__ void run(const double *x) const { evaluate_block<kJac>(srec, n_edge, nq, x, s_red, s_sum); }
+};
 
+// Ceres' trust-region loop (Levenberg-Marquardt, DENSE_QR restated on the 6 x 6 normal equations, <= 4 iterations) over
+// an evaluation functor: ev.run<kJac>(pose) leaves the sums H (21), g (6), cost in s_sum (with the workgroup barriers that takes).  On
+// entry s_sum holds the linearisation at x; on return x is the accepted pose, the same in every thread.  Shared by k_lm_solve
+// (records in LDS, 256 threads) and k_odom_chain (records in registers, 1024 threads).
+template <class Eval>
+__device__ __forceinline__ void lm_trust_region(const Eval &ev, double *x, double *s_cur, double *s_sum, int n_used, int &iter)
+{
+    const int tid = threadIdx.x;
     const int max_iter = 4;
     const double function_tol = 1e-6, gradient_tol = 1e-10, parameter_tol = 1e-8;
     const double min_rel_decrease = 1e-3, min_diag = 1e-6, max_diag = 1e32, max_radius = 1e16, min_radius = 1e-32;
     double radius = 1e4, decrease_factor = 2.0;
     bool reuse_diagonal = false;
-    int invalid_steps = 0, iter = 0;
+    int invalid_steps = 0;
+    iter = 0;
     // The accepted linearisation (H, g, cost) lives in LDS (s_cur), a candidate's in s_sum: every thread runs the uniform trust-region
     // arithmetic on the same LDS numbers, and only the scaled, damped system of the current iteration is ever in registers -- with
     // H, Hs, a second matrix for the factor and two accumulator sets per thread the kernel needed ~350 registers and could not run
     // two waves per SIMD.
-    evaluate_block<true>(s_rec, n_edge, nq, x, s_red, s_sum);
     if (tid < 28) s_cur[tid] = s_sum[tid];
-    n_used = wave_sum_i(n_used);
-    if (lane == 0) s_used[wave] = n_used;
     __syncthreads();
     double x_cost = s_cur[27];
     double scale[6], diag[6];
-    n_used = 0;
-    for (int w = 0; w < kLmW; w++) n_used += s_used[w];
     double gmax = 0.0;
     for (int i = 0; i < 6; i++) gmax = fmax(gmax, fabs(s_cur[21 + i]));
     if (n_used > 0 && gmax > gradient_tol) {
@@ -1456,8 +1429,8 @@ __global__ __launch_bounds__(kLmT) void k_lm_solve(BatchView b, OdomView o, int 
             // the next iteration -- the same numbers a separate pass would give).  The last iteration only needs the cost, but a
             // second, cost-only copy of the sweep inside this loop costs the kernel its second wave per SIMD (81 spilled registers).
             const bool last = iter == max_iter;
-            if (last) evaluate_block<false>(s_rec, n_edge, nq, cand, s_red, s_sum);
-            else evaluate_block<true>(s_rec, n_edge, nq, cand, s_red, s_sum);
+            if (last) ev.template run<false>(cand);
+            else ev.template run<true>(cand);
             const double cand_cost = s_sum[27];
             double sn = 0.0;
             for (int i = 0; i < 7; i++) sn += (x[i] - cand[i]) * (x[i] - cand[i]);
@@ -1488,6 +1461,54 @@ __global__ __launch_bounds__(kLmT) void k_lm_solve(BatchView b, OdomView o, int 
             if (radius <= min_radius) break;
         }
     }
+}
+
+__global__ __launch_bounds__(kLmT) void k_lm_solve(BatchView b, OdomView o, int step, int outer, unsigned int *wl_reset)
+{
+    const int c = o.clist ? o.clist[o.chain0 + blockIdx.x] : o.chain0 + (int)blockIdx.x;
+    if (wl_reset && blockIdx.x == 0 && threadIdx.x == 0) wl_reset[0] = 0u;      // the work list of the next correspondence launch starts empty
+    int s;
+    const int k = chain_scan(o, c, step, s);
+    if (k < 0) return;
+    __shared__ double s_red[kLmW][28], s_sum[28], s_cur[28];
+    __shared__ int s_used[kLmW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_edge = b.feat_n[k * 4 + 0], nq = n_edge + b.feat_n[k * 4 + 2];
+    const float4 *crec = o.crec + (size_t)c * kMaxQueries * 4;
+    // the chain's residual-block records (64 B each, <= 144 KB) are read once and stay in LDS for the up to nine
+    // evaluations of this launch; eight 16-B loads per thread in flight
+    extern __shared__ __align__(16) float4 s_rec[];
+    int n_used = 0;
+    {
+        // one record per thread and round: its four 16-B quarters are requested together, the pose-independent part of the
+        // residual block is computed once (stage_block) and the block goes to LDS as (cp, kind) + six doubles
+        double2 *sp = (double2 *)s_rec;
+        const bool thin = lead_in_thinned(o, k, s);
+        for (int qi = tid; qi < nq; qi += kLmT) {
+            float4 cp = crec[qi * 4];
+            const float4 A = crec[qi * 4 + 1], B = crec[qi * 4 + 2], Cc = crec[qi * 4 + 3];
+            if (thin && (qi % kThinBlocks) % kThinStride != 0) cp.w = 0.f;       // not searched in this launch: a stale record
+            double P[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
+            if (__float_as_int(cp.w) != 0) { stage_block(cp, A, B, Cc, P); n_used++; }
+            s_rec[qi] = cp;
+            sp[kMaxQueries + qi] = make_double2(P[0], P[1]);
+            sp[2 * kMaxQueries + qi] = make_double2(P[2], P[3]);
+            sp[3 * kMaxQueries + qi] = make_double2(P[4], P[5]);
+        }
+    }
+    __syncthreads();
+    double x[7];
+    for (int i = 0; i < 7; i++) x[i] = o.state[c * 8 + i];
+
+    LmRecEval ev{ s_rec, n_edge, nq, s_red, s_sum };
+    int iter = 0;
+    ev.run<true>(x);
+    n_used = wave_sum_i(n_used);
+    if (lane == 0) s_used[wave] = n_used;
+    __syncthreads();
+    n_used = 0;
+    for (int w = 0; w < kLmW; w++) n_used += s_used[w];
+    lm_trust_region(ev, x, s_cur, s_sum, n_used, iter);
     if (tid == 0) {
         for (int i = 0; i < 7; i++) o.state[c * 8 + i] = x[i];
         if (o.repair && outer == 1) {

@@ -390,3 +390,36 @@ def test_full_size_batch_properties(gpu_ctx, oracle):
     assert np.abs(np.linalg.norm(poses[:, :4], axis=1) - 1).max() < 1e-9
     fwd = incr[1:, 4]
     assert (fwd > 0.5).all() and (fwd < 1.1).all()                  # ~0.8 m per scan
+
+
+def test_persistent_chain_kernel_equals_launch_per_phase_schedule(oracle, gpu_ctx, small_seq):
+    """LMONO_OPT_ODOM_PERSIST: one workgroup per chain running all its scan pairs in one launch (k_odom_chain) against one
+    launch per phase (k_corr_flat + k_correspond_list + k_lm_solve, the default): same correspondences, increments equal to the rounding of the
+    solve's reductions (1024 vs 256 threads) -- sequential, chained with a thinned lead-in, with the fall-back searches forced
+    (LMONO_OPT_DEFER_EVERY) and with the boundary validation repairing chains in both schedules."""
+    xyzi, off = small_seq["xyzi"], small_seq["off"]
+    batch = _register(gpu_ctx, xyzi, off)
+    ref = oracle.run_sequence(xyzi, off)
+    out = {}
+    try:
+        for persist in (1, 0):
+            gpu_ctx.set_option(gpu_ctx.OPT_ODOM_PERSIST, persist)
+            res = [batch.odometry(1, 0)[0]]
+            gpu_ctx.set_option(gpu_ctx.OPT_LEAD_FULL, 1)
+            res.append(batch.odometry(3, 2)[0])
+            gpu_ctx.set_option(gpu_ctx.OPT_BOUNDARY_TOL, 0)
+            res.append(batch.odometry(3, 2)[0])
+            gpu_ctx.set_option(gpu_ctx.OPT_BOUNDARY_TOL, 1000)
+            gpu_ctx.set_option(gpu_ctx.OPT_LEAD_FULL, -1)
+            gpu_ctx.set_option(gpu_ctx.OPT_DEFER_EVERY, 3)
+            res.append(batch.odometry(1, 0)[0])
+            gpu_ctx.set_option(gpu_ctx.OPT_DEFER_EVERY, 0)
+            out[persist] = res
+    finally:
+        gpu_ctx.set_option(gpu_ctx.OPT_ODOM_PERSIST, 0)
+        gpu_ctx.set_option(gpu_ctx.OPT_LEAD_FULL, -1)
+        gpu_ctx.set_option(gpu_ctx.OPT_BOUNDARY_TOL, 1000)
+        gpu_ctx.set_option(gpu_ctx.OPT_DEFER_EVERY, 0)
+    for a, b_ in zip(out[1], out[0]):
+        assert np.abs(a - b_).max() < 1e-10
+    assert np.abs(out[1][0] - ref["incr"]).max() < 1e-9 and np.abs(out[1][3] - ref["incr"]).max() < 1e-9
