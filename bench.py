@@ -402,6 +402,131 @@ def ba_secondary(ctx, windows=1024, steps=3):
             "mean_iterations": iters, "fp64_tflops": round(flops / el / 1e12, 3), "fp64_frac": round(flops / el / 1e12 / FP64_PEAK_TFLOPS, 5)}
 
 
+def streamed_extra(ctx, off, xyzi_d, args, gold_poses):
+    """PCIe-inclusive operation (SURVEY 8d "PCIe H2D floor"): the sequence sits in PINNED host memory and streams through
+    two device working sets in n_chunks scan ranges -- lmono_batch_stage_h copies range j + 1 on the library's copy stream while range j is
+    registered and its chains run (scan-range shard with a lead-in, the range boundary validated like a rank boundary).  Reports the
+    streamed rate, the copy-only and compute-only times of the same ranges, and how much of the shorter one was hidden."""
+    import torch
+    import lmono_amd
+    from lmono_amd import trajectory
+    n = len(off) - 1
+    lead = args.lead
+    n_chunks = max(1, min(args.stream_chunks, n // 8))
+    total_bytes = int(off[-1]) * 16
+    pinned = ctx.host_alloc(total_bytes)
+    torch.from_numpy(pinned.view(np.float32).reshape(-1, 4)).copy_(xyzi_d)          # the sequence back in (pinned) host memory
+    base = pinned.ctypes.data
+    ranges = []
+    for j in range(n_chunks):
+        s, e = j * n // n_chunks, (j + 1) * n // n_chunks
+        lb = max(s - lead, 0)
+        ranges.append((lb, s, e))
+    max_scans = max(e - lb for lb, s, e in ranges)
+    max_pts = max(int(off[e] - off[lb]) for lb, s, e in ranges)
+    batches = [lmono_amd.ScanBatch(ctx, max_scans, max_pts) for _ in range(2)]
+    chains = max(1, args.stream_chains if args.stream_chains > 0 else args.chains // n_chunks)
+    incr_all = torch.zeros((n, 7), dtype=torch.float64, device=xyzi_d.device)
+    incr_all[:, 3] = 1.0
+    incr_loc = torch.zeros((max_scans, 7), dtype=torch.float64, device=xyzi_d.device)
+    poses = torch.zeros((n, 7), dtype=torch.float64, device=xyzi_d.device)
+
+    def stage(j):
+        lb, s, e = ranges[j]
+        batches[j % 2].stage_host(base + int(off[lb]) * 16, int(off[e] - off[lb]), keepalive=pinned)
+
+    def compute(j, staged):
+        lb, s, e = ranges[j]
+        b = batches[j % 2]
+        o = (off[lb:e + 1] - off[lb]).astype(np.int64)
+        if staged:
+            b.scanreg_staged(o, 64, 5.0)
+        else:
+            b.scanreg(xyzi_d.data_ptr() + int(off[lb]) * 16, o, 64, 5.0, keepalive=xyzi_d)
+        b.odometry_shard_d(chains, lead, s - lb, incr_loc.data_ptr())
+        if j > 0:
+            b.shard_validate(incr_all[s - 1].cpu().numpy(), incr_loc.data_ptr())
+        else:
+            ctx.synchronize()
+        incr_all[s:e] = incr_loc[s - lb:e - lb]
+
+    def run_streamed():
+        stage(0)
+        for j in range(n_chunks):
+            if j + 1 < n_chunks:
+                stage(j + 1)
+            compute(j, True)
+        torch.cuda.synchronize()
+
+    def run_compute_only():
+        for j in range(n_chunks):
+            compute(j, False)
+        torch.cuda.synchronize()
+
+    def timed(fn, reps=2):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        return (time.perf_counter() - t0) / reps
+
+    t_compute = timed(run_compute_only)
+    t_stream = timed(run_streamed)
+    ctx.pose_prefix_d(incr_all.data_ptr(), 0, n, poses.data_ptr())
+    torch.cuda.synchronize()
+    p = poses.cpu().numpy()
+    # copy-only: the same stage calls, then wait for the device (hipDeviceSynchronize covers the copy stream)
+    def run_copy():
+        for j in range(n_chunks):
+            stage(j)
+        torch.cuda.synchronize()
+    t_copy = timed(run_copy)
+    out = {"scans_per_s": round(n / t_stream, 1), "ms_per_pass": round(t_stream * 1e3, 2), "chunks": n_chunks, "chains_per_chunk": chains,
+           "h2d_GBps": round(total_bytes / t_copy / 1e9, 1), "copy_only_ms": round(t_copy * 1e3, 2), "compute_only_ms": round(t_compute * 1e3, 2),
+           "overlap_frac": round((t_copy + t_compute - t_stream) / min(t_copy, t_compute), 3),
+           "pcie_floor_scans_per_s": round(n / t_copy, 1),
+           "note": "pinned host memory -> two device working sets; H2D of range j + 1 under scanRegistration + laserOdometry of range j; "
+                   "overlap_frac 1 = the shorter of (copy, compute) fully hidden"}
+    if gold_poses is not None and len(gold_poses) >= n:
+        out["ate_vs_cpu_m"] = round(trajectory.ate(p, gold_poses[:n]), 6)
+    for b in batches:
+        b.close()
+    ctx.host_free(pinned)
+    return out
+
+
+def latency_extra(ctx, xyzi_d, off, n_steps=64):
+    """One scan per call (lmono_odom_step): wall time of a callback for a scan already in HBM -- scanRegistration of ONE scan plus ONE scan
+    pair of laserOdometry -- and of the scanRegistration part alone (a 1-scan batch)."""
+    import torch
+    import lmono_amd
+    cap = int(np.diff(off[:n_steps + 2]).max())
+    st = lmono_amd.OdomStream(ctx, cap, 64, 5.0, history=8)
+    ts = []
+    for k in range(n_steps + 1):
+        a, e = int(off[k]), int(off[k + 1])
+        t0 = time.perf_counter()
+        st.step(dev_ptr=xyzi_d.data_ptr() + a * 16, n_points=e - a)
+        ts.append(time.perf_counter() - t0)
+    st.close()
+    ts = np.array(ts[1:]) * 1e3
+    b1 = lmono_amd.ScanBatch(ctx, 1, cap)
+    tr = []
+    for k in range(1, 17):
+        a, e = int(off[k]), int(off[k + 1])
+        o = np.array([0, e - a], np.int64)
+        t0 = time.perf_counter()
+        b1.scanreg(xyzi_d.data_ptr() + a * 16, o, 64, 5.0, keepalive=xyzi_d)
+        ctx.synchronize()
+        tr.append(time.perf_counter() - t0)
+    b1.close()
+    reg = float(np.median(tr[2:])) * 1e3
+    return {"online_step_ms": round(float(np.median(ts)), 3), "online_step_p99_ms": round(float(np.quantile(ts, 0.99)), 3),
+            "scanreg_ms": round(reg, 3), "odom_pair_ms": round(float(np.median(ts)) - reg, 3), "steps": n_steps,
+            "note": "lmono_odom_step on a scan resident in HBM: scanRegistration of one scan + one scan pair (2 x [search + <= 4 LM iterations]), "
+                    "host-synchronous; scanreg_ms = the front end of one scan alone"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -419,6 +544,9 @@ def main():
     ap.add_argument("--az", type=int, default=2000, help="azimuth steps per ring (2000 = HDL-64 at 10 Hz)")
     ap.add_argument("--cpu-sample", type=int, default=128, help="scans of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-frames", type=int, default=-1, help="ba-seq: frames of the CPU oracle's replay (-1 = the whole stream)")
+    ap.add_argument("--stream-chunks", type=int, default=8, help="streamed extra: scan ranges the sequence streams through two working sets in")
+    ap.add_argument("--stream-chains", type=int, default=64, help="streamed extra: chains per range (0 = --chains / --stream-chunks)")
+    ap.add_argument("--only-streamed", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (sequential run, BA secondary)")
     ap.add_argument("--probe-ranks", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--workload", default="lidar", choices=["lidar", "ba", "ba-seq", "map", "colour", "posegraph"],
@@ -674,7 +802,17 @@ def main():
                 hi = min(n_local, len(gp))
                 out["sequential"]["max_abs_pose_diff_vs_cpu"] = float(np.abs(sp[:hi] - gp[:hi]).max())
                 out["sequential"]["ate_vs_cpu_m"] = round(trajectory.ate(sp[:hi], gp[:hi]), 9)
-            # (2) the Estimator half beside the headline
+            # (2) one scan per call: the latency of a callback
+            try:
+                out["latency"] = latency_extra(ctx, xyzi_d, off)
+            except Exception as e:
+                out["latency"] = {"error": repr(e)}
+            # (3) PCIe-inclusive streaming of the whole sequence from pinned host memory
+            try:
+                out["streamed"] = streamed_extra(ctx, off, xyzi_d, args, gp if parity is not None else None)
+            except Exception as e:
+                out["streamed"] = {"error": repr(e)}
+            # (4) the Estimator half beside the headline
             try:
                 out["secondary"] = {"ba": ba_secondary(ctx)}
             except Exception as e:       # the secondary line must never take the headline down

@@ -10,6 +10,7 @@
 #ifndef LMONO_HIP_H
 #define LMONO_HIP_H
 #include <stdint.h>
+#include <stddef.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -91,6 +92,16 @@ int lmono_scanreg_batch(lmono_ctx *, lmono_scan_batch *, const float *xyzi_d, co
  * This is the PCIe-inclusive entry; the resident-in-HBM one above is what bench.py times.                       */
 int lmono_scanreg_batch_h(lmono_ctx *, lmono_scan_batch *, const float *xyzi_h, const int64_t *offsets_h,
                           int n_scans, int n_lines, float min_range);
+
+/* Streamed input (PCIe-inclusive operation): lmono_batch_stage_h enqueues the H2D copy of a working set's points into the batch's own
+ * staging buffer on the library's copy stream and returns at once (xyzi_h should be pinned: lmono_host_alloc, or hipHostRegister'ed by the
+ * caller); lmono_scanreg_batch_staged makes the compute stream wait for that copy ON THE DEVICE and registers the staged scans.  With two
+ * batches the copy of working set i + 1 runs under the compute of working set i; a batch's staging buffer is not overwritten before its
+ * front end has read it.  No reference counterpart (the reference receives one message at a time in host memory).                    */
+void *lmono_host_alloc(lmono_ctx *, size_t bytes);
+void  lmono_host_free(lmono_ctx *, void *);
+int lmono_batch_stage_h(lmono_ctx *, lmono_scan_batch *, const float *xyzi_h, int64_t total_points);
+int lmono_scanreg_batch_staged(lmono_ctx *, lmono_scan_batch *, const int64_t *offsets_h, int n_scans, int n_lines, float min_range);
 
 /* counts_h: [n_scans][6] = n_cloud, n_sharp, n_less_sharp, n_flat, n_less_flat, status.
  * status bits: 1 a ring holds more than LMONO_RING_CAP points (scan contributes no features); 2 a "last" cloud did not fit

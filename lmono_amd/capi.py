@@ -10,7 +10,7 @@ MAX_QUERIES = 64 * 6 * 2 + 64 * 6 * 4
 # every symbol include/lmono_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "lmono_create", "lmono_destroy", "lmono_last_error", "lmono_set_stream", "lmono_set_option", "lmono_get_option", "lmono_synchronize", "lmono_version",
-    "lmono_batch_create", "lmono_batch_destroy", "lmono_scanreg_batch", "lmono_scanreg_batch_h", "lmono_batch_counts", "lmono_batch_get_cloud",
+    "lmono_batch_create", "lmono_batch_destroy", "lmono_scanreg_batch", "lmono_scanreg_batch_h", "lmono_host_alloc", "lmono_host_free", "lmono_batch_stage_h", "lmono_scanreg_batch_staged", "lmono_batch_counts", "lmono_batch_get_cloud",
     "lmono_batch_get_curvature", "lmono_odom_batch", "lmono_odom_batch_d", "lmono_odom_shard_d", "lmono_odom_shard_validate", "lmono_odom_boundary_report", "lmono_odom_stream_create", "lmono_odom_stream_destroy", "lmono_odom_step", "lmono_odom_stream_scan", "lmono_odom_correspond", "lmono_timing_reset", "lmono_timing_read",
     "lmono_pose_prefix_d", "lmono_pose_rebase_d", "lmono_map_refine", "lmono_voxel_filter", "lmono_mapper_create", "lmono_mapper_destroy", "lmono_mapper_reset", "lmono_mapper_process", "lmono_mapper_process_batch", "lmono_mapper_cube",
     "lmono_map_builder_create", "lmono_map_builder_destroy", "lmono_associate_to_map", "lmono_associate_to_map_batch", "lmono_map_builder_depth",
@@ -56,6 +56,11 @@ def load_library():
     L.lmono_batch_destroy.argtypes = [C.c_void_p]
     L.lmono_scanreg_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float]
     L.lmono_scanreg_batch_h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float]
+    L.lmono_host_alloc.restype = C.c_void_p
+    L.lmono_host_alloc.argtypes = [C.c_void_p, C.c_size_t]
+    L.lmono_host_free.argtypes = [C.c_void_p, C.c_void_p]
+    L.lmono_batch_stage_h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    L.lmono_scanreg_batch_staged.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float]
     L.lmono_batch_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.lmono_batch_get_cloud.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
     L.lmono_batch_get_curvature.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
@@ -156,6 +161,21 @@ class Context:
         while g > 1 and n_chains // g < 32:
             g -= 1
         return g
+
+    def host_alloc(self, nbytes):
+        """Pinned host memory from the library (lmono_host_alloc) as a numpy uint8 array; free with host_free(array)."""
+        p = self.L.lmono_host_alloc(self.h, int(nbytes))
+        if not p:
+            raise LmonoError("lmono_host_alloc(%d) failed: %s" % (nbytes, self.last_error()))
+        arr = np.ctypeslib.as_array((C.c_uint8 * int(nbytes)).from_address(p))
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p
+        return arr
+
+    def host_free(self, arr):
+        p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
+        if p:
+            self.L.lmono_host_free(self.h, C.c_void_p(p))
 
     def timing_reset(self):
         self.check(self.L.lmono_timing_reset(self.h))
@@ -408,6 +428,16 @@ class ScanBatch:
         self._keep = xyzi
         self.ctx.check(self.ctx.L.lmono_scanreg_batch_h(self.ctx.h, self.h, xyzi.ctypes.data, offsets.ctypes.data,
                                                          self.n_scans, int(n_lines), float(min_range)))
+
+    def stage_host(self, host_ptr, total_points, keepalive=None):
+        """Asynchronous H2D of a working set (pinned host memory at raw address host_ptr) into this batch's staging buffer."""
+        self._keep = keepalive
+        self.ctx.check(self.ctx.L.lmono_batch_stage_h(self.ctx.h, self.h, C.c_void_p(host_ptr), int(total_points)))
+
+    def scanreg_staged(self, offsets, n_lines=64, min_range=5.0):
+        offsets = np.ascontiguousarray(offsets, np.int64)
+        self.n_scans = len(offsets) - 1
+        self.ctx.check(self.ctx.L.lmono_scanreg_batch_staged(self.ctx.h, self.h, offsets.ctypes.data, self.n_scans, int(n_lines), float(min_range)))
 
     def counts(self):
         out = np.zeros((self.n_scans, 6), np.int32)

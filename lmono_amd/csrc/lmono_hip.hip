@@ -36,6 +36,7 @@ struct lmono_ctx {
     hipStream_t gstream[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };   // streams of the odometry's chain groups (LMONO_OPT_ODOM_STREAMS > 1)
     hipEvent_t gev[9] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     unsigned long long *stats_d = nullptr;   // [0] feature points deferred by the tile search since the last lmono_timing_reset
+    hipStream_t copy_stream = nullptr;       // H2D staging of lmono_batch_stage_h (runs beside the compute stream)
 
     hipEvent_t *next_set()
     {
@@ -66,6 +67,8 @@ struct lmono_scan_batch {
     BatchView v{};
     int64_t *off_d = nullptr;
     float *in_owned = nullptr;     // staging buffer of lmono_scanreg_batch_h (pts_cap points), allocated on first use
+    hipEvent_t staged_ev = nullptr, in_free_ev = nullptr;   // lmono_batch_stage_h: copy finished / the front end has read the staging buffer
+    int64_t staged_points = -1;
     std::vector<int> feat_h;       // host copy of feat_n [n_scans][4], fetched on first use after a registration
     // odometry workspace
     int chains_cap = 0;
@@ -134,6 +137,7 @@ extern "C" void lmono_destroy(lmono_ctx *c)
     for (auto &s : c->sets) { for (auto &e : s.e) (void)hipEventDestroy(e); for (auto &e : s.kev) (void)hipEventDestroy(e); }
     if (c->stats_d) (void)hipFree(c->stats_d);
     for (auto &s : c->gstream) if (s) (void)hipStreamDestroy(s);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (auto &e : c->gev) if (e) (void)hipEventDestroy(e);
     delete c;
 }
@@ -190,6 +194,8 @@ extern "C" void lmono_batch_destroy(lmono_scan_batch *b)
     if (!b) return;
     for (void *p : b->allocs) (void)hipFree(p);
     for (auto &e : b->rep_ev) if (e) (void)hipEventDestroy(e);
+    if (b->staged_ev) (void)hipEventDestroy(b->staged_ev);
+    if (b->in_free_ev) (void)hipEventDestroy(b->in_free_ev);
     delete b;
 }
 
@@ -333,6 +339,50 @@ extern "C" int lmono_scanreg_batch(lmono_ctx *c, lmono_scan_batch *b, const floa
     if (rc) return rc;
     b->registered = true;
     return LMONO_OK;
+}
+
+// ---- streamed input: H2D of the next working set beside the compute of the current one ---------------------------------------------
+extern "C" void *lmono_host_alloc(lmono_ctx *c, size_t bytes)
+{
+    if (!c || bytes == 0 || hipSetDevice(c->device) != hipSuccess) return nullptr;
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { c->err = "lmono_host_alloc: hipHostMalloc failed"; return nullptr; }
+    return p;
+}
+extern "C" void lmono_host_free(lmono_ctx *c, void *p) { if (c && p) (void)hipHostFree(p); }
+
+extern "C" int lmono_batch_stage_h(lmono_ctx *c, lmono_scan_batch *b, const float *xyzi_h, int64_t total_points)
+{
+    if (!c || !b || !xyzi_h || total_points < 0) return LMONO_EINVAL;
+    if (total_points > b->pts_cap) { c->err = "batch: too many points"; return LMONO_ECAPACITY; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->copy_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    if (!b->in_owned) {
+        void *q = nullptr;
+        HIP_TRY(c, hipMalloc(&q, (size_t)(b->pts_cap > 0 ? b->pts_cap : 1) * 16));
+        b->allocs.push_back(q);
+        b->in_owned = (float *)q;
+    }
+    if (!b->staged_ev) HIP_TRY(c, hipEventCreateWithFlags(&b->staged_ev, hipEventDisableTiming));
+    if (!b->in_free_ev) HIP_TRY(c, hipEventCreateWithFlags(&b->in_free_ev, hipEventDisableTiming));
+    // the front end of this batch's previous registration may still read the staging buffer
+    else HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, b->in_free_ev, 0));
+    if (total_points > 0) HIP_TRY(c, hipMemcpyAsync(b->in_owned, xyzi_h, (size_t)total_points * 16, hipMemcpyHostToDevice, c->copy_stream));
+    HIP_TRY(c, hipEventRecord(b->staged_ev, c->copy_stream));
+    b->staged_points = total_points;
+    return LMONO_OK;
+}
+
+extern "C" int lmono_scanreg_batch_staged(lmono_ctx *c, lmono_scan_batch *b, const int64_t *offsets_h, int n_scans, int n_lines, float min_range)
+{
+    if (!c || !b || !offsets_h || n_scans <= 0) return LMONO_EINVAL;
+    if (b->staged_points < 0 || !b->in_owned) { c->err = "lmono_scanreg_batch_staged: nothing staged (lmono_batch_stage_h first)"; return LMONO_EINVAL; }
+    if (offsets_h[n_scans] != b->staged_points) { c->err = "lmono_scanreg_batch_staged: offsets do not match the staged points"; return LMONO_EINVAL; }
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, b->staged_ev, 0));          // the device waits for the copy, the host does not
+    const int rc = lmono_scanreg_batch(c, b, b->in_owned, offsets_h, n_scans, n_lines, min_range);
+    HIP_TRY(c, hipEventRecord(b->in_free_ev, c->stream));
+    b->staged_points = -1;
+    return rc;
 }
 
 extern "C" int lmono_timing_reset(lmono_ctx *c)

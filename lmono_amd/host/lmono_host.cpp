@@ -488,6 +488,31 @@ std::vector<double> LaserOdometry::process(ScanRegistration &reg, int n_chains, 
     return poses;
 }
 
+LaserOdometryNode::LaserOdometryNode(HipContext &hip, int max_points_per_scan, int n_lines, float minimum_range, int history)
+    : hip_(hip), stream_(lmono_odom_stream_create(hip.get(), max_points_per_scan, n_lines, minimum_range, history))
+{
+    if (!stream_) throw std::runtime_error(std::string("lmono_odom_stream_create: ") + lmono_last_error(hip.get()));
+}
+LaserOdometryNode::~LaserOdometryNode() { lmono_odom_stream_destroy(stream_); }
+void LaserOdometryNode::laserCloudHandler(const float *xyzi, int n_points)
+{
+    int32_t st[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    hip_.check(lmono_odom_step(hip_.get(), stream_, xyzi, n_points, 0, 0, q_last_curr, t_last_curr, q_w_curr, t_w_curr, st), "lmono_odom_step");
+    for (int k = 0; k < 8; k++) info[k] = st[k];
+}
+lmono_scan_batch *LaserOdometryNode::batch() const
+{
+    lmono_scan_batch *b = nullptr;
+    (void)lmono_odom_stream_scan(stream_, &b, nullptr);
+    return b;
+}
+int LaserOdometryNode::scan() const
+{
+    int s = -1;
+    (void)lmono_odom_stream_scan(stream_, nullptr, &s);
+    return s;
+}
+
 // ---- laserMapping ---------------------------------------------------------------------------------------------------
 LaserMapping::LaserMapping(HipContext &hip, float lineRes, float planeRes) : hip_(hip), mapper_(lmono_mapper_create(hip.get(), lineRes, planeRes))
 {
@@ -498,6 +523,12 @@ void LaserMapping::process(ScanRegistration &reg, int scan, const double q_wodom
 {
     int32_t st[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     hip_.check(lmono_mapper_process(hip_.get(), mapper_, reg.batch(), scan, q_wodom_curr, t_wodom_curr, q_w_curr, t_w_curr, st), "lmono_mapper_process");
+    for (int k = 0; k < 8; k++) stats[k] = st[k];
+}
+void LaserMapping::process(LaserOdometryNode &node, double q_w_curr[4], double t_w_curr[3])
+{
+    int32_t st[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    hip_.check(lmono_mapper_process(hip_.get(), mapper_, node.batch(), node.scan(), node.q_w_curr, node.t_w_curr, q_w_curr, t_w_curr, st), "lmono_mapper_process");
     for (int k = 0; k < 8; k++) stats[k] = st[k];
 }
 std::vector<float> LaserMapping::cube(int which, int i, int j, int k)

@@ -175,6 +175,28 @@ private:
     HipContext &hip_;
 };
 
+// The same two nodes as they run online: one /velodyne_points message per callback.  laserCloudHandler registers the scan, process()
+// runs the scan pair against the previous scan's clouds (kept on the device) from para_q / para_t, which persist between callbacks
+// like A-LOAM's globals; q_w_curr / t_w_curr accumulate.  Same numbers as LaserOdometry::process(reg, 1, 0).
+class LaserOdometryNode {
+public:
+    LaserOdometryNode(HipContext &hip, int max_points_per_scan, int n_lines = 64, float minimum_range = 5.0f, int history = 8);
+    ~LaserOdometryNode();
+    LaserOdometryNode(const LaserOdometryNode &) = delete;
+    LaserOdometryNode &operator=(const LaserOdometryNode &) = delete;
+    // xyzi: [n][4] float32 in host memory (a sensor_msgs/PointCloud2 payload, a KITTI .bin file)
+    void laserCloudHandler(const float *xyzi, int n_points);
+    double q_last_curr[4] = { 0, 0, 0, 1 }, t_last_curr[3] = { 0, 0, 0 };     // para_q, para_t
+    double q_w_curr[4] = { 0, 0, 0, 1 }, t_w_curr[3] = { 0, 0, 0 };
+    int info[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };     // n_cloud, n_sharp, n_less_sharp, n_flat, n_less_flat, status, LM iterations, residual blocks
+    // the device-resident scan for laserMapping behind this node
+    lmono_scan_batch *batch() const;
+    int scan() const;
+private:
+    HipContext &hip_;
+    lmono_odom_stream *stream_;
+};
+
 // laserMapping.cpp process(): the 21 x 21 x 11 cube array (laserCloudCornerArray /
 // laserCloudSurfArray) lives in HBM behind lmono_mapper_*; one call per scan of a registered batch.
 class LaserMapping {
@@ -186,6 +208,8 @@ public:
     // q_wodom_curr (x y z w), t_wodom_curr: laserOdometry's pose of scan `scan`.  Writes q_w_curr / t_w_curr
     // (aft_mapped_to_init) and updates the map.
     void process(ScanRegistration &reg, int scan, const double q_wodom_curr[4], const double t_wodom_curr[3], double q_w_curr[4], double t_w_curr[3]);
+    // the same behind the online node: the scan it has just registered
+    void process(LaserOdometryNode &node, double q_w_curr[4], double t_w_curr[3]);
     // cube (i, j, k) of the corner (which = 0) / surf (1) array: [n][4] float32
     std::vector<float> cube(int which, int i, int j, int k);
     int stats[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };     // of the last frame: edge / plane blocks and LM iterations per outer iteration

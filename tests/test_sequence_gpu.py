@@ -78,3 +78,17 @@ def test_cpp_laser_mapping_matches_the_oracle_trajectory(oracle, sequence_on_dis
     # and the refinement did something: it differs from the odometry trajectory
     odo = IO.read_trajectory(str(out))
     assert np.abs(traj[:, 1:4] - odo[:, 1:4]).max() > 1e-4
+
+
+def test_cpp_online_nodes_write_the_same_trajectories(sequence_on_disk, tmp_path):
+    """run_sequence with n_chains = 0: LaserOdometryNode::laserCloudHandler per scan (lmono_odom_step) and laserMapping behind it per scan,
+    against the batch form of the same program: the same files, byte for byte."""
+    root, xyzi, off, ref = sequence_on_disk
+    subprocess.check_call(["make", "-s", "-C", HOST, "run_sequence"])
+    exe = os.path.join(HOST, "run_sequence")
+    a, am, b, bm = (tmp_path / n for n in ("odo_batch.txt", "map_batch.txt", "odo_online.txt", "map_online.txt"))
+    subprocess.check_output([exe, root, str(a), "0", "-1", "1", "0", str(am)], text=True)
+    txt = subprocess.check_output([exe, root, str(b), "0", "-1", "0", "0", str(bm)], text=True)
+    assert a.read_text() == b.read_text() and am.read_text() == bm.read_text()
+    lat = [float(line.split()[2]) for line in txt.split("\n") if line.startswith("LAT ")]
+    assert len(lat) == 6 and all(v > 0 for v in lat)
