@@ -76,3 +76,26 @@ def test_ill_conditioned_frames_stay_close(oracle, tmp_path):
     d = np.abs(odo[:, 1:4] - ref[:, 1:4]).max()
     print("ill-conditioned stream: max |dP| vs oracle %.2e m" % d)
     assert d < 1e-3
+
+
+def test_600_frames_match_the_oracle(oracle, tmp_path):
+    """configs[2]-shaped stream at length: 600 frames, three static stretches, four loop events; the GPU frame loop stays
+    within SURVEY 8c's 1e-6 m / 1e-7 of the oracle's replay on every INITED frame, with identical decisions, and two runs are identical."""
+    from workloads import s2
+    st = s2.make_stream(600, seed=2, stops=(40, 41, 77, 300, 301, 302, 555))
+    loops = [S.loop_event(st, f, shift=(0.02 * (-1) ** i, 0.01, 0.03), yaw=0.002 * (-1) ** i) for i, f in enumerate((60, 200, 380, 520))]
+    est, log = S.replay_oracle(st, loops)
+    frm, odo, ext, ms = _run(st, loops, tmp_path, "s2_600")
+    frm2, odo2, ext2, _ = _run(st, loops, tmp_path, "s2_600b")
+    assert frm == frm2 and np.array_equal(odo, odo2) and np.array_equal(ext, ext2)          # bit-reproducible (deterministic k_ba_solve)
+    ref = np.array(est.trajectory)
+    assert len(frm) == 600 and odo.shape == ref.shape == (590, 8)
+    for k, (row, r) in enumerate(zip(frm, log)):
+        assert (int(row[1]), int(row[2]), int(row[3])) == (r[0], r[1], r[2]), "frame %d" % k
+        if r[1] == 1:
+            assert (int(row[4]), int(row[5])) == (r[3], r[4]), "frame %d: iterations / termination differ" % k
+        assert (int(row[7]), int(row[8])) == (r[6], r[7]) and int(row[9]) == r[8], "frame %d" % k
+    dp = np.abs(odo[:, 1:4] - ref[:, 1:4]).max(); dq = np.abs(odo[:, 4:] - ref[:, 4:]).max()
+    print("600-frame replay: %.2f ms per INITED frame, max |dP| %.2e m, max |dq| %.2e vs the oracle" % (ms, dp, dq))
+    assert dp < 1e-6 and dq < 1e-7
+    assert log[-1][6] > 300 and log[-1][7] >= 5                       # both marginalisation branches, many times
