@@ -540,6 +540,8 @@ def main():
     ap.add_argument("--lead", type=int, default=5, help="lead-in scans of a chain that does not start at scan 0")
     ap.add_argument("--lead-full", type=int, default=2,
                     help="lead-in scan pairs of a chain (the last ones) that use all feature points; the earlier ones a quarter (-1: all use all)")
+    ap.add_argument("--kitti-dir", default="", help="read the scans of a KITTI-layout sequence directory (velodyne/%%06d.bin + times.txt, e.g. "
+                    "dataset/sequences/00: /root/reference/README.md:48-60) instead of generating S1 scans; --scans caps the count")
     ap.add_argument("--seq", type=int, default=0, choices=[0, 1], help="0: the S1 figure-8 sequence (headline); 1: the held-out sequence (other world, clover trajectory)")
     ap.add_argument("--az", type=int, default=2000, help="azimuth steps per ring (2000 = HDL-64 at 10 Hz)")
     ap.add_argument("--cpu-sample", type=int, default=128, help="scans of the CPU baseline sample (0 = skip)")
@@ -594,6 +596,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
+    kitti_stamps = None
+    if args.kitti_dir:
+        from lmono_amd import kitti_io
+        kitti_stamps = kitti_io.read_times(os.path.join(args.kitti_dir, "times.txt"))
+        args.scans = min(args.scans, len(kitti_stamps)) if world == 1 or args.scaling == "strong" else min(args.scans, len(kitti_stamps) // world)
+        if args.scaling != "strong" and world > 1:
+            pass                                   # weak scaling: every rank takes the next --scans scans of the sequence
     strong = args.scaling == "strong"
     n_total = args.scans if strong else args.scans * world
     load_begin, own_begin, own_end = sharding.shard_range(n_total, world, rank, args.lead)
@@ -602,13 +611,17 @@ def main():
     n_own = own_end - own_begin
 
     t0 = time.time()
-    if args.seq == 0:
-        w = S1.S1World(n_az=args.az)
-        traj = w.trajectory(n_total)
-    else:           # the held-out sequence: another world, another trajectory (tests/golden/s1_seq01_oracle.npz)
-        w = S1.S1World(seed=777, n_az=args.az)
-        traj = w.trajectory_clover(n_total)
-    xyzi, off = w.scans(traj[load_begin:own_end], scan_id0=load_begin)
+    traj = None
+    if args.kitti_dir:
+        xyzi, off, _ = kitti_io.load_scans(args.kitti_dir, load_begin, own_end - load_begin)
+    else:
+        if args.seq == 0:
+            w = S1.S1World(n_az=args.az)
+            traj = w.trajectory(n_total)
+        else:           # the held-out sequence: another world, another trajectory (tests/golden/s1_seq01_oracle.npz)
+            w = S1.S1World(seed=777, n_az=args.az)
+            traj = w.trajectory_clover(n_total)
+        xyzi, off = w.scans(traj[load_begin:own_end], scan_id0=load_begin)
     gen_s = time.time() - t0
     total_pts = int(off[-1])
 
@@ -679,7 +692,7 @@ def main():
     # ---- tolerance of the timed run: its poses against the committed trajectory of the strictly sequential CPU path over
     # the WHOLE sequence (tests/golden/s1_seq00_oracle.npz: data, not the oracle), every owned scan the fixture covers
     parity = None
-    if args.az == 2000 and os.path.exists(GOLDEN % args.seq):
+    if not args.kitti_dir and args.az == 2000 and os.path.exists(GOLDEN % args.seq):
         gold = np.load(GOLDEN % args.seq)
         gp, gi, gc = gold["poses"], gold["incr"], gold["feat_counts"]
         hi = min(own_end, len(gp))
@@ -782,8 +795,12 @@ def main():
             out["ate_vs_cpu_m"] = parity["ate_vs_cpu_m"]
             out["rpe_vs_cpu"] = parity["rpe_vs_cpu"]
             out["parity"] = parity
-        m_gt = min(n_own, len(traj))
-        out["ate_vs_truth_m"] = round(trajectory.ate(gpu_poses[:m_gt], _gt_relative(traj[:m_gt])), 4) if rank == 0 and own_begin == 0 else None
+        if traj is not None:
+            m_gt = min(n_own, len(traj))
+            out["ate_vs_truth_m"] = round(trajectory.ate(gpu_poses[:m_gt], _gt_relative(traj[:m_gt])), 4) if rank == 0 and own_begin == 0 else None
+        else:
+            out["data"] = "KITTI-layout sequence " + args.kitti_dir
+            out["config"]["workload"] = "KITTI-layout sequence on disk, laserOdometry-only (configs[1])"
         if world == 1 and not args.no_extras:
             # ---- untimed extras.  (1) A-LOAM's own schedule: ONE chain, no lead-in (every scan pair warm-started from the
             # previous increment) -- the run whose poses must EQUAL the CPU path's, and the throughput of that schedule

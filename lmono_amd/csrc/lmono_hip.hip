@@ -2,8 +2,10 @@
 // the kernel files are included so that one `hipcc -shared` produces liblmono_hip.so.
 #include "frontend.hip"
 #include "odometry.hip"
-#include "corr_tile.hip"
+#ifdef LMONO_DIAG_SEARCH
+#include "corr_tile.hip"      // measured alternatives of the correspondence search (profiles/r2/NOTES.md): diagnostic build only
 #include "corr_thread.hip"
+#endif
 #include "corr_flat.hip"
 #include "odom_chain.hip"
 #include "mapping.hip"
@@ -97,7 +99,11 @@ struct lmono_scan_batch {
         }                                                                                    \
     } while (0)
 
-extern "C" const char *lmono_version(void) { return "lmono-hip 0.2 (gfx950)"; }
+#ifdef LMONO_DIAG_SEARCH
+extern "C" const char *lmono_version(void) { return "lmono-hip 0.3 (gfx950, diagnostic build: search alternatives)"; }
+#else
+extern "C" const char *lmono_version(void) { return "lmono-hip 0.3 (gfx950)"; }
+#endif
 
 extern "C" lmono_ctx *lmono_create(int device)
 {
@@ -113,10 +119,12 @@ extern "C" lmono_ctx *lmono_create(int device)
     if (hipFuncSetAttribute((const void *)k_voxel<kVoxBigSlots, kVoxBigBits, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kVoxLdsBig) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_lm_solve, hipFuncAttributeMaxDynamicSharedMemorySize, kLmRecLds) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_odom_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(OcLds)) != hipSuccess) { delete c; return nullptr; }
+#ifdef LMONO_DIAG_SEARCH
     if (hipFuncSetAttribute((const void *)k_grid_build, hipFuncAttributeMaxDynamicSharedMemorySize, kGridLds) != hipSuccess) { delete c; return nullptr; }
+    if (hipFuncSetAttribute((const void *)k_corr_tile, hipFuncAttributeMaxDynamicSharedMemorySize, kTileLds) != hipSuccess) { delete c; return nullptr; }
+#endif
     if (hipFuncSetAttribute((const void *)k_line_index<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLiLdsHalf) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_line_index<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLiLdsFull) != hipSuccess) { delete c; return nullptr; }
-    if (hipFuncSetAttribute((const void *)k_corr_tile, hipFuncAttributeMaxDynamicSharedMemorySize, kTileLds) != hipSuccess) { delete c; return nullptr; }
     // the BA-side kernels with large dynamic LDS: per device, so per context (a second context on another GPU needs them too)
     if (hipFuncSetAttribute((const void *)k_ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BaLds)) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_marginalize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MargLds)) != hipSuccess) { delete c; return nullptr; }
@@ -154,7 +162,12 @@ extern "C" int lmono_set_stream(lmono_ctx *c, void *s)
 extern "C" int lmono_set_option(lmono_ctx *c, int key, int value)
 {
     if (!c || key < 0 || key >= LMONO_OPT_COUNT) return LMONO_EINVAL;
-    const bool ok = key == LMONO_OPT_CORR_TILE ? (value >= 0 && value <= 3)
+#ifdef LMONO_DIAG_SEARCH
+    const int corr_lo = 0;
+#else
+    const int corr_lo = 3;           // the measured alternatives 0 .. 2 are compiled into the diagnostic build only
+#endif
+    const bool ok = key == LMONO_OPT_CORR_TILE ? (value >= corr_lo && value <= 3)
                   : key == LMONO_OPT_DEFER_EVERY ? value >= 0
                   : key == LMONO_OPT_ODOM_STREAMS ? (value >= 1 && value <= 8)
                   : key == LMONO_OPT_BOUNDARY_TOL ? value >= 0
@@ -277,10 +290,12 @@ static int scanreg_launch(lmono_ctx *c, lmono_scan_batch *b, int scan0, int n_sc
     HIP_TRY(c, hipEventRecord(c->ev[5], st));
     // the hash grids serve the 32-lane-group search (LMONO_OPT_CORR_TILE 0) and the deferred lists of modes 1 and 2; the default
     // (flattened sweeps) works on the line index alone, so the grids are built on demand (ensure_grid)
+#ifdef LMONO_DIAG_SEARCH
     if (c->opt[LMONO_OPT_CORR_TILE] != 3) {
         hipLaunchKernelGGL(k_grid_build, dim3(n_scans, 1 + kGridPar), dim3(1024), kGridLds, st, v);
         b->grid_built = true; v.has_grid = 1; b->v.has_grid = 1;
     }
+#endif
     HIP_TRY(c, hipEventRecord(c->ev[6], st));
     hipLaunchKernelGGL(k_line_index<true>, dim3(n_scans, 2), dim3(kLiT), kLiLdsHalf, st, v);
     hipLaunchKernelGGL(k_line_index<false>, dim3(kLiBigGrid), dim3(kLiT), kLiLdsFull, st, v);
@@ -503,11 +518,16 @@ static int ensure_odom_ws(lmono_ctx *c, lmono_scan_batch *b, int n_chains)
 static int ensure_grid(lmono_ctx *c, lmono_scan_batch *b)
 {
     if (b->grid_built) return LMONO_OK;
+#ifdef LMONO_DIAG_SEARCH
     hipLaunchKernelGGL(k_grid_build, dim3(b->n_scans, 1 + kGridPar), dim3(1024), kGridLds, c->stream, b->v);
     int rc = check_launch(c, "k_grid_build");
     if (rc) return rc;
     b->grid_built = true; b->v.has_grid = 1;
     return LMONO_OK;
+#else
+    c->err = "the hash-grid searches exist in the diagnostic build only (-DLMONO_DIAG_SEARCH)";
+    return LMONO_EINVAL;
+#endif
 }
 
 // Chain-group streams of a context: forks the library's group streams off the context stream, joins them again on every exit path.
@@ -591,7 +611,9 @@ static int odom_launch_steps(lmono_ctx *c, lmono_scan_batch *b, const OdomView &
                 if (tile == 3) {
                     hipLaunchKernelGGL(k_corr_flat, dim3(8 * ((ng + 7) / 8) * kCfBlocks), dim3(kCfT), 0, sg, b->v, og, step, outer, wlg, c->opt[LMONO_OPT_DEFER_EVERY], c->stats_d);
                     hipLaunchKernelGGL(k_correspond_list, dim3(kListGrid), dim3(256), 0, sg, b->v, og, step, outer, (const unsigned int *)wlg, c->stats_d);
-                } else if (tile == 2) {
+                }
+#ifdef LMONO_DIAG_SEARCH
+                else if (tile == 2) {
                     hipLaunchKernelGGL(k_corr_thread, dim3(8 * ((ng + 7) / 8) * kCtBlocks), dim3(kCtT), 0, sg, b->v, og, step, outer, wlg);
                     hipLaunchKernelGGL(k_correspond_list, dim3(kListGrid), dim3(256), 0, sg, b->v, og, step, outer, (const unsigned int *)wlg, c->stats_d);
                 } else if (tile) {
@@ -599,6 +621,7 @@ static int odom_launch_steps(lmono_ctx *c, lmono_scan_batch *b, const OdomView &
                     hipLaunchKernelGGL(k_correspond_list, dim3(kListGrid), dim3(256), 0, sg, b->v, og, step, outer, (const unsigned int *)wlg, c->stats_d);
                 } else
                     hipLaunchKernelGGL(k_correspond, dim3(8 * ((ng + 7) / 8) * kCorrBlocks), dim3(256), 0, sg, b->v, og, step, outer);
+#endif
                 if (e0 && e1 && e2) (void)hipEventRecord(e1, sg);
                 hipLaunchKernelGGL(k_lm_solve, dim3(ng), dim3(kLmT), kLmRecLds, sg, b->v, og, step, outer, tile ? wlg : (unsigned int *)nullptr);
                 if (e0 && e1 && e2) { (void)hipEventRecord(e2, sg); *ne += 3; }
@@ -973,11 +996,16 @@ extern "C" int lmono_odom_correspond(lmono_ctx *c, lmono_scan_batch *b, int scan
         if (rc) return rc;
         HIP_TRY(c, hipMemsetAsync(b->wl, 0, sizeof(unsigned int), c->stream));
         if (c->opt[LMONO_OPT_CORR_TILE] == 3) hipLaunchKernelGGL(k_corr_flat, dim3(8 * kCfBlocks), dim3(kCfT), 0, c->stream, b->v, o, 0, 0, b->wl, c->opt[LMONO_OPT_DEFER_EVERY], c->stats_d);
+#ifdef LMONO_DIAG_SEARCH
         else if (c->opt[LMONO_OPT_CORR_TILE] == 2) hipLaunchKernelGGL(k_corr_thread, dim3(8 * kCtBlocks), dim3(kCtT), 0, c->stream, b->v, o, 0, 0, b->wl);
         else hipLaunchKernelGGL(k_corr_tile, dim3(8 * kTSect), dim3(kTT), kTileLds, c->stream, b->v, o, 0, 0, b->wl, c->stats_d);
+#endif
         hipLaunchKernelGGL(k_correspond_list, dim3(kListGrid), dim3(256), 0, c->stream, b->v, o, 0, 0, (const unsigned int *)b->wl, c->stats_d);
-    } else
+    }
+#ifdef LMONO_DIAG_SEARCH
+    else
         hipLaunchKernelGGL(k_correspond, dim3(8 * kCorrBlocks), dim3(256), 0, c->stream, b->v, o, 0, 0);
+#endif
     rc = check_launch(c, "k_correspond");
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));

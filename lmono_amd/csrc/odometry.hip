@@ -89,6 +89,7 @@ __device__ __forceinline__ unsigned long long key32_to_64(unsigned int k)
     return cell_key((int)(k & 2047u) - 1024, (int)((k >> 11) & 2047u) - 1024, (int)(k >> 22) - 512);
 }
 
+#ifdef LMONO_DIAG_SEARCH
 __global__ __launch_bounds__(1024) void k_grid_build(BatchView b)
 {
     const int s = b.scan0 + blockIdx.x;
@@ -245,6 +246,7 @@ __global__ __launch_bounds__(1024) void k_grid_build(BatchView b)
         __syncthreads();
     }
 }
+#endif // LMONO_DIAG_SEARCH
 // ------------------------------------------------------------------------------------------------
 struct OdomView {
     int n_scans, n_chains, lead;
@@ -1046,6 +1048,7 @@ __device__ __forceinline__ void correspond_wave(const BatchView &b, const OdomVi
 // (sizing the grid to the sensor's feature bound, 230 instead of 288 workgroups per chain for an HDL-64, measured 3 % slower)
 constexpr int kCorrBlocks = kMaxQueries / 8;
 
+#ifdef LMONO_DIAG_SEARCH
 __global__ __launch_bounds__(256, 8) void k_correspond(BatchView b, OdomView o, int step, int outer)
 {
     const int xcd = blockIdx.x & 7, u = blockIdx.x >> 3;
@@ -1075,6 +1078,7 @@ __global__ __launch_bounds__(256, 8) void k_correspond(BatchView b, OdomView o, 
     if (qi >= nq) return;
     correspond_group(b, o, c, k, qi, outer, gl, gbase);
 }
+#endif // LMONO_DIAG_SEARCH
 
 // The same search for the feature points of a device work list ([0] = count, then chain << 12 | feature index): the points the
 // LDS tile search (corr_tile.hip) defers.  Phase 1 serves them with 32-lane groups; phase 2 (scan pairs flagged irregular / dense:

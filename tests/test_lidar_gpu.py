@@ -99,60 +99,23 @@ def test_correspondences_match_oracle(oracle, gpu_ctx, small_seq):
         assert np.array_equal(got, corr[0]), "correspondence indices differ at scan %d" % k
 
 
-def test_tile_search_equals_global_search(oracle, gpu_ctx, full_seq):
-    """The LDS tile search (k_corr_tile + the deferred list) and the global-memory search (k_correspond) return the same
-    correspondence indices for good and bad warm starts, and the same odometry bit for bit (same residual blocks, same solve)."""
-    xyzi, off = full_seq["xyzi"], full_seq["off"]
-    batch = _register(gpu_ctx, xyzi, off)
-    poses = [(np.array([0.0, 0.0, 0.0, 1.0]), np.array([0.0, 0.0, 0.0])),            # identity: 0.8 m off, wide searches
-             (np.array([0.0, 0.0, 0.01, 1.0]), np.array([0.7, 0.02, 0.0])),
-             (np.array([0.002, -0.001, 0.02, 1.0]), np.array([0.85, -0.05, 0.01])),
-             (np.array([0.0, 0.0, 0.3, 1.0]), np.array([3.0, 2.0, 0.5]))]            # far off: many features without partners
-    try:
-        for k in (1, 2):
-            for q, t in poses:
-                q = q / np.linalg.norm(q)
-                gpu_ctx.set_option(gpu_ctx.OPT_CORR_TILE, 3)
-                ref = batch.correspond(k, q, t)
-                for mode in (1, 2, 3):       # 1: LDS sector tiles, 2: thread per feature, 3: flattened sweeps (default)
-                    gpu_ctx.set_option(gpu_ctx.OPT_CORR_TILE, mode)
-                    gpu_ctx.timing_reset()
-                    got = batch.correspond(k, q, t)
-                    deferred = gpu_ctx.timing()[0]["deferred_features"]
-                    print("scan %d t=%s mode %d: %d features, %d deferred to the list kernel" % (k, t, mode, len(ref), deferred))
-                    assert np.array_equal(got, ref)
-        # a batch registered under the default mode has no hash grids; the deferred-list kernel then searches through the line index alone
-        gpu_ctx.set_option(gpu_ctx.OPT_CORR_TILE, 3)
-        i0, p0 = batch.odometry(1, 0)
-        for mode in (1, 2, 3):
-            gpu_ctx.set_option(gpu_ctx.OPT_CORR_TILE, mode)
-            i1, p1 = batch.odometry(1, 0)
-            assert np.array_equal(i0, i1) and np.array_equal(p0, p1)
-    finally:
-        gpu_ctx.set_option(gpu_ctx.OPT_CORR_TILE, 3)
-    # the fall-back of the default search on a batch WITHOUT hash grids (registered under mode 3): every 5th feature is forced through
-    # k_correspond_list, which then finds the nearest point by the arc sweep alone; same indices, same odometry
-    fresh = _register(gpu_ctx, xyzi, off)
-    try:
-        gpu_ctx.set_option(gpu_ctx.OPT_DEFER_EVERY, 5)
-        for q, t in poses[:3]:
-            q = q / np.linalg.norm(q)
-            gpu_ctx.timing_reset()
-            got = fresh.correspond(2, q, t)
-            assert gpu_ctx.timing()[0]["deferred_features"] >= len(got) // 5
-            gpu_ctx.set_option(gpu_ctx.OPT_DEFER_EVERY, 0)
-            assert np.array_equal(got, fresh.correspond(2, q, t))
-            gpu_ctx.set_option(gpu_ctx.OPT_DEFER_EVERY, 5)
-        i5, p5 = fresh.odometry(1, 0)
-        assert np.array_equal(i5, i0) and np.array_equal(p5, p0)
-    finally:
-        gpu_ctx.set_option(gpu_ctx.OPT_DEFER_EVERY, 0)
-    # against the oracle as well (index-exact), at full resolution
-    f = [oracle.scanreg(xyzi[off[s]:off[s + 1]]) for s in range(3)]
-    q, t = poses[1]
-    q = q / np.linalg.norm(q)
-    _, _, _, corr = oracle.odom_step(f[2]["sharp"], f[2]["flat"], f[1]["less_sharp"], f[1]["less_flat"], q, t, want_corr=True)
-    assert np.array_equal(batch.correspond(2, q, t), corr[0])
+def test_search_formulations_agree_in_the_diagnostic_build(gpu_ctx):
+    """The product library compiles the default search only (LMONO_OPT_CORR_TILE 0 .. 2 are refused); the four-way equality of the search
+    formulations runs against the diagnostic build of the same sources in a child process (tests/diag_search_modes.py)."""
+    import os
+    import subprocess
+    import sys
+    import lmono_amd
+    with pytest.raises(lmono_amd.LmonoError):
+        gpu_ctx.set_option(gpu_ctx.OPT_CORR_TILE, 0)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    diag = os.path.join(root, "lmono_amd", "lib", "liblmono_hip_diag.so")
+    assert os.path.exists(diag), "run __graft_entry__.build() first: it also builds the diagnostic library"
+    env = dict(os.environ, LMONO_HIP_LIB=diag)
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "diag_search_modes.py"), "-m", "gpu", "-x", "-q"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "4 passed" in out.stdout
 
 
 def test_odometry_sequential_matches_oracle(oracle, gpu_ctx, small_seq):
@@ -197,7 +160,7 @@ def test_odometry_other_sensors_and_near_points(oracle, gpu_ctx, n_lines, min_ra
     for k in (1, 2):
         _, _, _, corr = oracle.odom_step(f[k]["sharp"], f[k]["flat"], f[k - 1]["less_sharp"], f[k - 1]["less_flat"], q, t, want_corr=True)
         try:
-            for mode in (3, 0, 1, 2):
+            for mode in (3,):          # the other formulations: tests/diag_search_modes.py (diagnostic build)
                 gpu_ctx.set_option(gpu_ctx.OPT_CORR_TILE, mode)
                 assert np.array_equal(batch.correspond(k, q, t), corr[0]), "mode %d, scan %d" % (mode, k)
         finally:
@@ -326,7 +289,7 @@ def test_api_errors_and_limits(oracle, gpu_ctx, small_seq):
     incr, poses = one.odometry(1, 0)                                # a single scan: identity
     assert np.array_equal(incr, np.array([[0, 0, 0, 1, 0, 0, 0.0]])) and np.array_equal(poses, incr)
     # options: values are range-checked, a rejected value leaves the option as it was, values may be negative
-    for key, bad in ((gpu_ctx.OPT_CORR_TILE, 4), (gpu_ctx.OPT_CORR_TILE, -1), (gpu_ctx.OPT_ODOM_STREAMS, 0), (gpu_ctx.OPT_ODOM_STREAMS, 9),
+    for key, bad in ((gpu_ctx.OPT_CORR_TILE, 4), (gpu_ctx.OPT_CORR_TILE, -1), (gpu_ctx.OPT_CORR_TILE, 1), (gpu_ctx.OPT_ODOM_STREAMS, 0), (gpu_ctx.OPT_ODOM_STREAMS, 9),
                      (gpu_ctx.OPT_DEFER_EVERY, -1), (gpu_ctx.OPT_LEAD_FULL, -2), (gpu_ctx.OPT_BOUNDARY_TOL, -1), (17, 0)):
         before = gpu_ctx.get_option(key) if key < 5 else None
         with pytest.raises(lmono_amd.LmonoError):
