@@ -40,6 +40,7 @@ constexpr int kBaRow = 19;                       // staged row: J_i(6) J_j(6) J_
 constexpr int kBaFT = 64;                        // features per Schur tile
 constexpr int kBaSS = 73;                        // row stride of S in LDS (odd: conflict-free column walks)
 constexpr int kBaPairRec = 52;                   // Tres(9) tres(3) Cm(9) A(9) B(9) Tn(9) tn(3) pad
+constexpr int kBaPairTile = 320;                 // 16 x 16 tile + 16 x 4 side tile of a frame pair
 constexpr int kBaT = 512;                        // threads per workgroup (2 waves per SIMD)
 constexpr int kBaW = kBaT / 64;
 
@@ -70,6 +71,7 @@ struct BaBatch {
     const int *slot_obs;        // [total slots] observation (host order, global index) behind every slot
     double *obsc;               // scratch [total obs][16]: per-observation depth / coupling contributions (hdd, gd, hx[6], hi[6]),
                                 // in host observation order = grouped by feature: a feature's records are contiguous
+    double *pairH;              // scratch [total pairs][kBaPairTile]: every pair's J^T [J r] tile (16 x 16 + 16 x 4), summed by ba_reduce_pairs
     double *cand;               // scratch [W][kBaMaxFeat]
     double *summary;            // [W][6] initial_cost, final_cost, iterations, termination, successful, unsuccessful
 };
@@ -101,8 +103,9 @@ struct BaLds {
     // in which the pairs' blocks are added to H_pp -- fixed by the pair sizes alone, so the sums are the same in every run
     short wlist[kBaMaxPairs];                    // pairs in wave order
     short woff[kBaW + 1];                        // first entry of every wave in wlist
-    short pair_turn[kBaMaxPairs];                // position of the pair in the add order
-    int turn;                                    // next position allowed to add (-1: the small factors are still being added)
+    short pair_of[kBaMaxPoses * kBaMaxPoses];    // pair (anchor i, observer j) -> index in the window's pair list, -1: none
+    unsigned short fobs[kBaMaxFeat + 1];         // first observation of every feature, relative to the window's first (host order: grouped by feature)
+    signed char fanchor[kBaMaxFeat];             // the frame a feature is anchored in (-1: no observation)
     int ok;
 };
 static_assert(sizeof(BaLds) <= 160 * 1024, "BaLds exceeds the 160 KB LDS of a gfx950 CU");
@@ -337,6 +340,75 @@ __device__ __forceinline__ void ba_small_accumulate_wave(const BaCtx &c, BaLds &
     __builtin_amdgcn_wave_barrier();    // the slice becomes the wave's Jacobian stage
 }
 
+// H_pp and g_p as ordered sums of the frame pairs' tiles (ba_evaluate leaves one record per pair in the L2 scratch): every entry is owned
+// by one thread, which adds the tiles that touch it in a fixed order -- the pairs (f, j) by ascending j, then the pairs (i, f) by
+// ascending i for an entry of frame f's rows / columns; all pairs by index for the extrinsic block -- so the sums are the same bits in
+// every run whatever the waves' timing was.  Entries nothing touches become zero: the pass replaces clearing H_pp.
+__device__ __forceinline__ void ba_reduce_pairs(const BaBatch &B, const BaCtx c, BaLds &L)
+{
+    const int tid = threadIdx.x, P = c.P, np_ = c.n_poses;
+    const double *tiles = B.pairH + (size_t)c.pp0 * kBaPairTile;
+    // block of a parameter index: -1 = extrinsic, else the frame; offset inside the block
+    auto blk = [&](int g, int &o) { if (c.ex_off >= 0 && g < 6) { o = g; return -1; } const int q = g - (c.ex_off >= 0 ? 6 : 0); o = q % 6; return q / 6; };
+    // position of (row r, column q) of a pair's record; rows / columns 0..5 = frame i, 6..11 = frame j, 12..15 = extrinsic 0..3 (the 16 x 16
+    // tile), column 16 / 17 = extrinsic 4 / 5 and column 18 = the residual (the 16 x 4 side tile); the tile is symmetric
+    auto pos = [](int r, int q) { return q < 16 ? (r < 16 ? r * 16 + q : 256 + q * 4 + (r - 16)) : 256 + r * 4 + (q - 16); };
+    for (int e = tid; e < P * P + P; e += kBaT) {
+        const bool is_g = e >= P * P;
+        const int gm = is_g ? e - P * P : e / P, gn = is_g ? -1 : e % P;
+        int om, on = 0;
+        const int bm = blk(gm, om), bn = is_g ? -2 : blk(gn, on);
+        const bool m_x = bm == -1, n_x = bn == -1;
+        double acc = 0.0;
+        if (is_g ? m_x : (m_x && n_x)) {
+            // extrinsic block / extrinsic gradient: every pair contributes the same position of its record.  The (4..5, 4..5) corner and
+            // g_x4, g_x5 are the waves' own sums (added by wave 1 afterwards)
+            if (!(om >= 4 && (is_g || on >= 4))) {
+                const int o = is_g ? pos(12 + om, 18) : pos(12 + om, 12 + on);
+                for (int p0 = 0; p0 < c.n_pairs; p0 += 8) {
+                    double v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) v[u] = p0 + u < c.n_pairs ? gld(tiles + (size_t)(p0 + u) * kBaPairTile + o) : 0.0;
+#pragma unroll
+                    for (int u = 0; u < 8; u++) acc += v[u];
+                }
+            }
+        } else if (!is_g && !m_x && !n_x && bm != bn) {
+            // two different frames: the one pair (or, for a caller that anchors tracks at a later frame, the two) that holds both
+            const int i = bm < bn ? bm : bn, j = bm < bn ? bn : bm;
+            const int p1 = L.pair_of[i * kBaMaxPoses + j], p2 = L.pair_of[j * kBaMaxPoses + i];
+            const int r1 = bm == i ? om : 6 + om, q1 = bn == i ? on : 6 + on;       // in pair (i, j)
+            const int r2 = bm == j ? om : 6 + om, q2 = bn == j ? on : 6 + on;       // in pair (j, i)
+            const double v1 = p1 >= 0 ? gld(tiles + (size_t)p1 * kBaPairTile + pos(r1, q1)) : 0.0;
+            const double v2 = p2 >= 0 ? gld(tiles + (size_t)p2 * kBaPairTile + pos(r2, q2)) : 0.0;
+            acc = v1 + v2;
+        } else {
+            // one frame f (with itself, with the extrinsic, or its gradient): the pairs (f, j) by ascending j, then the pairs (i, f) by
+            // ascending i; f sits in rows 0..5 of the former and 6..11 of the latter.  All loads are requested before the first is used.
+            const int f = m_x ? bn : bm;
+            int oi_, oj_;            // positions in a pair where f is the anchor / the observer
+            if (is_g) { oi_ = pos(om, 18); oj_ = pos(6 + om, 18); }
+            else if (m_x) { oi_ = pos(12 + om, on); oj_ = pos(12 + om, 6 + on); }
+            else if (n_x) { oi_ = pos(om, 12 + on); oj_ = pos(6 + om, 12 + on); }
+            else { oi_ = pos(om, on); oj_ = pos(6 + om, 6 + on); }
+            double va[kBaMaxPoses], vb[kBaMaxPoses];
+#pragma unroll
+            for (int k = 0; k < kBaMaxPoses; k++) {
+                const int pa = (k < np_ && k != f) ? L.pair_of[f * kBaMaxPoses + k] : -1;
+                const int pb = (k < np_ && k != f) ? L.pair_of[k * kBaMaxPoses + f] : -1;
+                va[k] = pa >= 0 ? gld(tiles + (size_t)pa * kBaPairTile + oi_) : 0.0;
+                vb[k] = pb >= 0 ? gld(tiles + (size_t)pb * kBaPairTile + oj_) : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < kBaMaxPoses; k++) acc += va[k];
+#pragma unroll
+            for (int k = 0; k < kBaMaxPoses; k++) acc += vb[k];
+        }
+        if (is_g) L.gp[gm] = acc; else L.Hpp[gm * kBaP + gn] = acc;
+    }
+    __syncthreads();
+}
+
 // cost (returned to every thread) and, when kJac, the unscaled normal equations: Hpp, gp, Hdd, gdd in LDS, Hpd in HBM
 template <bool kJac>
 __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLds &L, const double *poses, const double *ex, const double *invd,
@@ -357,10 +429,6 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
         if (tid == c.n_poses) inv3(L.Mq + 18 * tid + 9, L.Mq + 18 * (kBaMaxPoses + 1));
     }
     for (int f = tid; f < c.F; f += kBaT) L.vinv[f] = gld(invd + f);
-    if (kJac) {
-        for (int k = tid; k < kBaP * kBaP; k += kBaT) L.Hpp[k] = 0.0;
-        for (int k = tid; k < kBaP; k += kBaT) L.gp[k] = 0.0;
-    }
     __syncthreads();
     const double *Rlc = L.Rp + 9 * c.n_poses;
     for (int p = tid; p < c.n_pairs; p += kBaT) {
@@ -377,7 +445,6 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
     // (their residuals / Jacobians wait in gn | va | vb, which are dead during a linearisation, until the pair blocks are in)
     static_assert(3 * kBaN >= 11 * kBaSmallRec, "small-factor records must fit gn | va | vb");
     if (tid >= 64 && tid < 96) cost += ba_small_factors<kJac>(B, c, L.gn, poses, ex, tid - 64);
-    if (tid == 0) L.turn = 0;
     const double *mono_info = B.info + 36;
     const double m00 = gld(mono_info), m01 = gld(mono_info + 1), m10 = gld(mono_info + 2), m11 = gld(mono_info + 3);
     const int *sinfo = B.slot_info + c.ps0;
@@ -548,48 +615,26 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
             }
             __builtin_amdgcn_wave_barrier();   // the slice is rewritten by the next round
         }
-        // add the pair's blocks to H_pp / g_p when it is this pair's turn: the order of the additions is the static one of
-        // ba_schedule (simulated finish order), so waves rarely wait and every entry is summed in the same order in every run
+        // the pair's tile [J_i J_j J_x0..3]^T [J_i J_j J_x0..3 | J_x4 J_x5 r] goes to the pair's own record in the L2 scratch (plain stores,
+        // no other wave touches it); ba_reduce_pairs sums the records into H_pp / g_p in a fixed order afterwards
         {
-            const int my_turn = L.pair_turn[pr];
-            if (lane == 0) while (__hip_atomic_load(&L.turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != my_turn) __builtin_amdgcn_s_sleep(1);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            auto gidx = [&](int m) { return m < 6 ? oi + m : (m < 12 ? oj + m - 6 : (c.ex_off < 0 ? -1 : c.ex_off + m - 12)); };
-            const int gn_ = gidx(col);
-            // entries of one tile are distinct (m, n) pairs, except the mirrored extrinsic columns 4, 5, which go second
+            double *tile = B.pairH + (size_t)(c.pp0 + pr) * kBaPairTile;
 #pragma unroll
             for (int v = 0; v < 4; v++) {
-                const int gm = gidx(kq + 4 * v);
-                if (gm >= 0 && gn_ >= 0) L.Hpp[gm * kBaP + gn_] += aa[v];
+                gst(tile + (kq + 4 * v) * 16 + col, aa[v]);
+                if (col < 3) gst(tile + 256 + (kq + 4 * v) * 4 + col, ab[v]);
             }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int v = 0; v < 4; v++) {
-                const int gm = gidx(kq + 4 * v);
-                if (gm < 0) continue;
-                if (col < 2) {
-                    if (c.ex_off >= 0) { const int xc = c.ex_off + 4 + col; L.Hpp[gm * kBaP + xc] += ab[v]; }
-                } else if (col == 2) {
-                    L.gp[gm] += ab[v];
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int v = 0; v < 4; v++) {
-                const int gm = gidx(kq + 4 * v);
-                if (gm >= 0 && col < 2 && c.ex_off >= 0) { const int xc = c.ex_off + 4 + col; L.Hpp[xc * kBaP + gm] += ab[v]; }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0) __hip_atomic_store(&L.turn, my_turn + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
     BA_TOCK(1)
+    BA_TICK(11)
     // the waves' shares of the (4..5, 4..5) extrinsic corner and its gradient: summed in wave order
     xx44 = wave_sum_d(xx44); xx45 = wave_sum_d(xx45); xx55 = wave_sum_d(xx55); gx4 = wave_sum_d(gx4); gx5 = wave_sum_d(gx5);
     if (lane == 0) { double *r5 = L.rhs + 5 * wave; r5[0] = xx44; r5[1] = xx45; r5[2] = xx55; r5[3] = gx4; r5[4] = gx5; }   // L.rhs is dead outside the Schur solve
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // the observation records are written
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");       // ... and read below by other waves: drop this CU's L1 copies
+    ba_reduce_pairs(B, c, L);
     if (wave == 1) {
         // every pair block is in H_pp: wave 1 adds the LASERFactor chain / prior it left in gn | va | vb, then the waves' shares of
         // the extrinsic corner in wave order -- after the pair blocks in every run
@@ -608,7 +653,7 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
         // order; the loads are independent and requested together
         const int k = lane & 15, t7 = (wave == 0 ? 0 : wave - 1) * 4 + (lane >> 4);
         for (int f = t7; f < c.F; f += 28) {
-            const int o0 = gldi(B.feat_obs_off + c.f0 + f), o1 = gldi(B.feat_obs_off + c.f0 + f + 1);
+            const int o0 = c.o0 + L.fobs[f], o1 = c.o0 + L.fobs[f + 1];
             double acc = 0.0;
             for (int ob = o0; ob < o1; ob += 10) {
                 double v[10];
@@ -622,12 +667,13 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
             else if (k < 14) {
                 double *hrow = hpd + (size_t)f * kBaPS;
                 if (k < 8) { if (c.ex_off >= 0) gst(hrow + c.ex_off + k - 2, acc); }
-                else { const int anchor = gldi(B.feat_anchor + c.f0 + f); if (anchor >= 0) gst(hrow + ba_pose_off(c, anchor) + k - 8, acc); }
+                else { const int anchor = L.fanchor[f]; if (anchor >= 0) gst(hrow + ba_pose_off(c, anchor) + k - 8, acc); }
             }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     cost = block_sum(cost, L.red);
+    BA_TOCK(11)
     // the coupling rows were written through L2: drop this CU's L1 copies before they are read with plain loads
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     return cost;
@@ -827,13 +873,29 @@ __device__ __noinline__ bool ba_schur_solve(const BaCtx c, BaLds &L, const doubl
         }
         __syncthreads();
         const int r0 = p0 + pw, n = P + 1 - r0;   // rows r0 .. P (n <= 65), columns r0 .. P - 1
-        for (int idx = tid; idx < 64 * n; idx += kBaT) {
-            const int i = idx >> 6, k = idx & 63;
-            if (k > i || r0 + k >= P) continue;
-            const double *ri = S + (r0 + i) * kBaSS + p0, *rk = S + (r0 + k) * kBaSS + p0;
-            double s = 0;
-            for (int qq = 0; qq < pw; qq++) s += ri[qq] * rk[qq];
-            S[(r0 + i) * kBaSS + r0 + k] -= s;
+        // trailing update S -= L_panel L_panel^T on the matrix cores: 16 x 16 tiles (ti >= tk) of the remaining rows, the panel's 8 columns
+        // as two k-steps of v_mfma_f64_16x16x4_f64; a tile belongs to one wave (whole tiles: entries above the diagonal are never read)
+        {
+            const int nt = (n + 15) >> 4;                         // tile rows (<= 5)
+            for (int t = wave; t < nt * (nt + 1) / 2; t += kBaW) {
+                int ti = 0, rem = t;
+                while (rem > ti) { rem -= ti + 1; ti++; }
+                const int tk = rem;
+                const int ra = r0 + 16 * ti + col, rb = r0 + 16 * tk + col;       // operand rows of this lane
+                ba_d4 acc4 = { 0, 0, 0, 0 };
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++) {
+                    const int q = 4 * ks + kq;
+                    const double a = (ra <= P && q < pw) ? S[ra * kBaSS + p0 + q] : 0.0;
+                    const double bq = (rb <= P && q < pw) ? S[rb * kBaSS + p0 + q] : 0.0;
+                    acc4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, acc4, 0, 0, 0);
+                }
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    const int m = r0 + 16 * ti + kq + 4 * v, nn = r0 + 16 * tk + col;
+                    if (m <= P && nn < P && nn <= m) S[m * kBaSS + nn] -= acc4[v];
+                }
+            }
         }
         __syncthreads();
     }
@@ -884,7 +946,7 @@ __device__ __noinline__ bool ba_schur_solve(const BaCtx c, BaLds &L, const doubl
 // order in which the pairs' blocks enter H_pp = the order in which a wave-time model (one unit per 32-observation round + one per
 // pair) says they finish, ties by pair index.  A wave's own pairs are in that order too, so the turn-taking cannot deadlock, and
 // because the model is close to the real timing, waves seldom wait for their turn.  Depends on the pair sizes only.
-__device__ __noinline__ void ba_schedule(const BaCtx c, BaLds &L)
+__device__ __noinline__ void ba_schedule(const BaBatch &B, const BaCtx c, BaLds &L)
 {
     const int tid = threadIdx.x;
     int *fin = (int *)L.u.stage;                          // [n_pairs] modelled finish time, then [n_pairs] wave
@@ -908,7 +970,6 @@ __device__ __noinline__ void ba_schedule(const BaCtx c, BaLds &L)
             rank += before ? 1 : 0;
             pos += (before && fin[kBaMaxPairs + q] == w) ? 1 : 0;
         }
-        L.pair_turn[p] = (short)rank;
         fin[2 * kBaMaxPairs + p] = pos;                     // position among its wave's pairs
     }
     if (tid <= kBaW) {
@@ -918,6 +979,11 @@ __device__ __noinline__ void ba_schedule(const BaCtx c, BaLds &L)
     }
     __syncthreads();
     for (int p = tid; p < c.n_pairs; p += kBaT) L.wlist[L.woff[fin[kBaMaxPairs + p]] + fin[2 * kBaMaxPairs + p]] = (short)p;
+    for (int k = tid; k < kBaMaxPoses * kBaMaxPoses; k += kBaT) L.pair_of[k] = -1;
+    for (int f = tid; f <= c.F; f += kBaT) L.fobs[f] = (unsigned short)(B.feat_obs_off[c.f0 + f] - c.o0);      // <= 448 x 10 observations per window
+    for (int f = tid; f < c.F; f += kBaT) L.fanchor[f] = (signed char)B.feat_anchor[c.f0 + f];
+    __syncthreads();
+    for (int p = tid; p < c.n_pairs; p += kBaT) { const int ij = L.pair_ij[p]; L.pair_of[(ij & 255) * kBaMaxPoses + (ij >> 8)] = (short)p; }
     __syncthreads();
 }
 
@@ -944,7 +1010,7 @@ __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B)
     for (int k = tid; k < c.n_pairs; k += kBaT) L.pair_ij[k] = B.pair_ij[c.pp0 + k];
     for (int k = tid; k <= c.n_pairs; k += kBaT) L.pair_slot[k] = B.pair_slot[c.pp0 + w + k];
     __syncthreads();
-    ba_schedule(c, L);
+    ba_schedule(B, c, L);
 
     const double function_tol = 1e-6, gradient_tol = 1e-10, parameter_tol = 1e-8, min_rel_decrease = 1e-3;
     const double min_diag = 1e-6, max_diag = 1e32, max_radius = 1e16, min_radius = 1e-32;
@@ -1088,7 +1154,7 @@ __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B)
     __syncthreads();
     BA_TOCK(9)
 #ifdef LMONO_BA_PROF
-    if (w == 0 && tid == 0) printf("PROF total %lld | lin: prologue %lld eval %lld mfma %lld | cost %lld | hs %lld | schur: stage+mfma %lld chol %lld subst %lld depth %lld | iters %d\n", g_prof[9], g_prof[0], g_prof[1], g_prof[2], g_prof[3], g_prof[4], g_prof[5], g_prof[6], g_prof[7], g_prof[8], iter);
+    if (w == 0 && tid == 0) printf("PROF total %lld | lin: prologue %lld eval %lld mfma %lld | cost %lld | hs %lld | schur: stage+mfma %lld chol %lld subst %lld depth %lld | iters %d | wave-0 turn wait %lld, feature pass + small factors %lld\n", g_prof[9], g_prof[0], g_prof[1], g_prof[2], g_prof[3], g_prof[4], g_prof[5], g_prof[6], g_prof[7], g_prof[8], iter, g_prof[10], g_prof[11]);
 #endif
     for (int k = tid; k < c.n_poses * 7; k += kBaT) gposes[k] = L.poses[k];
     if (tid < 7) gex[tid] = L.ex[tid];

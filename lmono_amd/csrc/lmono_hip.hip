@@ -1222,6 +1222,7 @@ static int ba_fill(lmono_ctx *c, lmono_ba_batch *b, const lmono_ba_desc *d)
               ba_upload(b, v.obsc, (const double *)nullptr, (size_t)TO * 16) &&
               ba_upload(b, v.hpd, (const double *)nullptr, (size_t)W * kBaMaxFeat * kBaPS) &&
               ba_upload(b, v.pairdat, (const double *)nullptr, pair_ij.size() * kBaPairRec) &&
+              ba_upload(b, v.pairH, (const double *)nullptr, pair_ij.size() * kBaPairTile) &&
               ba_upload(b, v.cand, (const double *)nullptr, (size_t)W * kBaMaxFeat) && ba_upload(b, v.summary, (const double *)nullptr, (size_t)W * 6);
     if (!ok) { (void)hipStreamSynchronize(c->stream); c->err = "lmono_ba_batch_create: device allocation / upload failed"; return LMONO_ENOMEM; }
     HIP_TRY(c, hipStreamSynchronize(c->stream));      // the staging vectors above end here
