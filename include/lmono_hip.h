@@ -70,7 +70,12 @@ int         lmono_synchronize(lmono_ctx *);
  * Measured (profiles/r3/NOTES.md): 1 is slower -- a chain confined to one CU pays its search and its solve one after the other
  * (27.5 ms against 21.8 ms per pass over 4541 scans) -- and is kept as a measured alternative.                                      */
 #define LMONO_OPT_ODOM_PERSIST 5
-#define LMONO_OPT_COUNT     6
+/* correspondence search of the launch-per-phase schedule: 1 = sector-staged (k_corr_sect: the feature points of one azimuth sector per
+ * workgroup, the sector's window of the "last" clouds and their start tables staged in LDS, every candidate read from LDS; features whose
+ * search ball leaves the window go through k_corr_flat's list mode); 0 = k_corr_flat over global memory for every feature.  Identical
+ * correspondences and increments.                                                                                                  */
+#define LMONO_OPT_CORR_SECT 6
+#define LMONO_OPT_COUNT     7
 int         lmono_set_option(lmono_ctx *, int key, int value);
 int         lmono_get_option(lmono_ctx *, int key, int *value);     /* the configured value (option values may be negative) */
 const char *lmono_version(void);

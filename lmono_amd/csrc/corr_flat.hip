@@ -234,7 +234,9 @@ __device__ __forceinline__ void cf_sweep(CfLds &L, const int *tg_c, const int *t
 // step `step`, outer iteration `outer` of every chain: kCfBlocks workgroups of kCfT feature points per chain (measured: 256 threads
 // 30.0 ms of correspondence search per bench step, 128 threads 26.6, 64 threads 31.4; 4 or 8 gathers in flight make no difference), decoded onto ONE XCD
 // per chain (blocks b and b + 8 share an XCD): the chain's index and tables are fetched into one L2 only.
-__global__ __launch_bounds__(kCfT, LMONO_CF_WAVES) void k_corr_flat(BatchView b, OdomView o, int step, int outer, unsigned int *wl, int defer_every, unsigned long long *stats)
+// list_mode != 0: the workgroups serve the chain's deferred list (o.dl / o.dl_cnt, left by the sector-staged search of corr_sect.hip)
+// instead of dealing all feature points: workgroup qb takes entries qb, qb + kCfBlocks, ...
+__global__ __launch_bounds__(kCfT, LMONO_CF_WAVES) void k_corr_flat(BatchView b, OdomView o, int step, int outer, unsigned int *wl, int defer_every, unsigned long long *stats, int list_mode)
 {
     __shared__ CfLds L;
     const int xcd = blockIdx.x & 7, u = blockIdx.x >> 3;
@@ -245,15 +247,18 @@ __global__ __launch_bounds__(kCfT, LMONO_CF_WAVES) void k_corr_flat(BatchView b,
     int own;
     const int k = chain_scan(o, c, step, own);
     if (k < 0) return;
-    if (lead_in_thinned(o, k, own) && qb % kThinStride != 0) return;      // early lead-in pair: every kThinStride-th share of the features
+    if (!list_mode && lead_in_thinned(o, k, own) && qb % kThinStride != 0) return;      // early lead-in pair: every kThinStride-th share of the features
     const int tid = threadIdx.x;
     const int l = k - 1;
     const int n_sharp = b.feat_n[k * 4 + 0];
     const int nq = n_sharp + b.feat_n[k * 4 + 2];
-    if (qb >= nq) return;
+    int n_list = 0;
+    if (list_mode) { n_list = o.dl_cnt[c]; if (qb == 0 && tid == 0 && stats && n_list) atomicAdd(&stats[1], (unsigned long long)n_list); if (qb >= n_list) return; }
+    else if (qb >= nq) return;
     // the chain's features are dealt round-robin over its kCfBlocks workgroups: every workgroup gets the same share of edge and plane
     // features (blocks of consecutive features gave workgroups of very different weight, and an almost empty last one)
-    const int qi = tid * kCfBlocks + qb;
+    // (list mode: the deferred features are the expensive ones -- wide balls -- so they are dealt round-robin over the workgroups as well)
+    const int qi = list_mode ? (tid * kCfBlocks + qb < n_list ? (int)o.dl[(size_t)c * kMaxQueries + tid * kCfBlocks + qb] : nq) : tid * kCfBlocks + qb;
     if (b.status[l] & (kStatusIrregularLines | kStatusDenseCell)) {
         if (qi < nq) cf_defer(wl, c, qi);       // rare: the whole scan pair goes to the generic search
         return;
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(kCfT, LMONO_CF_WAVES) void k_corr_flat(BatchView b,
 #endif
     bool alive = qi < nq && n_last > 0;       // still looking for its nearest point
     bool deferred = false;
-    if (defer_every > 0 && qi < nq && qi % defer_every == 0) { alive = false; deferred = true; }      // test hook: exercise the fall-back kernel
+    if (!list_mode && defer_every > 0 && qi < nq && qi % defer_every == 0) { alive = false; deferred = true; }      // test hook: exercise the fall-back kernel
     float r = sd >= 0.f ? sqrtf(sd) * 1.0005f + 1e-3f : (edge ? kCfR0Edge : kCfR0Plane);
     __syncthreads();
 

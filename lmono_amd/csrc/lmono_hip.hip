@@ -7,6 +7,7 @@
 #include "corr_thread.hip"
 #endif
 #include "corr_flat.hip"
+#include "corr_sect.hip"
 #include "odom_chain.hip"
 #include "mapping.hip"
 #include "ba.hip"
@@ -34,7 +35,7 @@ struct lmono_ctx {
     std::vector<EvSet> sets;   // one event set per scanreg/odometry call since the last lmono_timing_reset
     int n_sets = 0;
     hipEvent_t *ev = nullptr;  // events of the current call
-    int opt[LMONO_OPT_COUNT] = { 3, 0, 4, -1, 1000, 0 };   // LMONO_OPT_CORR_TILE: 3 = flattened sweeps (default: as fast as 0 and needs no hash grid), 0 = 32-lane groups, 1 = LDS sector tiles, 2 = thread per feature
+    int opt[LMONO_OPT_COUNT] = { 3, 0, 4, -1, 1000, 0, 0 };   // LMONO_OPT_CORR_TILE: 3 = flattened sweeps (default: as fast as 0 and needs no hash grid), 0 = 32-lane groups, 1 = LDS sector tiles, 2 = thread per feature
     hipStream_t gstream[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };   // streams of the odometry's chain groups (LMONO_OPT_ODOM_STREAMS > 1)
     hipEvent_t gev[9] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     unsigned long long *stats_d = nullptr;   // [0] feature points deferred by the tile search since the last lmono_timing_reset
@@ -88,6 +89,8 @@ struct lmono_scan_batch {
     std::vector<double> resid_h;
     std::vector<int> rerun_h;
     int last_chains = 0, last_lead = 0, last_first = 0;
+    unsigned short *fs_list = nullptr, *dl = nullptr;       // sector-staged search: sorted feature lists, deferred lists
+    int *fs_off = nullptr, *dl_cnt = nullptr;
 };
 
 #define HIP_TRY(ctx, expr)                                                                   \
@@ -119,6 +122,7 @@ extern "C" lmono_ctx *lmono_create(int device)
     if (hipFuncSetAttribute((const void *)k_voxel<kVoxBigSlots, kVoxBigBits, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kVoxLdsBig) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_lm_solve, hipFuncAttributeMaxDynamicSharedMemorySize, kLmRecLds) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_odom_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(OcLds)) != hipSuccess) { delete c; return nullptr; }
+    if (hipFuncSetAttribute((const void *)k_corr_sect, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CsLds)) != hipSuccess) { delete c; return nullptr; }
 #ifdef LMONO_DIAG_SEARCH
     if (hipFuncSetAttribute((const void *)k_grid_build, hipFuncAttributeMaxDynamicSharedMemorySize, kGridLds) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_corr_tile, hipFuncAttributeMaxDynamicSharedMemorySize, kTileLds) != hipSuccess) { delete c; return nullptr; }
@@ -172,6 +176,7 @@ extern "C" int lmono_set_option(lmono_ctx *c, int key, int value)
                   : key == LMONO_OPT_ODOM_STREAMS ? (value >= 1 && value <= 8)
                   : key == LMONO_OPT_BOUNDARY_TOL ? value >= 0
                   : key == LMONO_OPT_ODOM_PERSIST ? (value == 0 || value == 1)
+                  : key == LMONO_OPT_CORR_SECT ? (value == 0 || value == 1)
                   : value >= -1;                                     // LMONO_OPT_LEAD_FULL
     if (!ok) { c->err = "lmono_set_option: value out of range for this option"; return LMONO_EINVAL; }
     c->opt[key] = value;
@@ -508,7 +513,9 @@ static int ensure_odom_ws(lmono_ctx *c, lmono_scan_batch *b, int n_chains)
               dalloc(b, b->lm_info, (size_t)n_chains * 4) && dalloc(b, b->crec, (size_t)n_chains * kMaxQueries * 4) &&
               dalloc(b, b->seed, (size_t)n_chains * kMaxQueries) && dalloc(b, b->wl, 8 * ((size_t)n_chains * kMaxQueries + 1)) &&
               dalloc(b, b->ws, (size_t)n_chains * 8) && dalloc(b, b->resid_d, (size_t)n_chains) && dalloc(b, b->rstat, (size_t)n_chains * 4) &&
-              dalloc(b, b->rcount, (size_t)n_chains + 2);
+              dalloc(b, b->rcount, (size_t)n_chains + 2) &&
+              dalloc(b, b->fs_list, (size_t)n_chains * kMaxQueries) && dalloc(b, b->dl, (size_t)n_chains * kMaxQueries) &&
+              dalloc(b, b->fs_off, (size_t)n_chains * (kCsSect + 1)) && dalloc(b, b->dl_cnt, (size_t)n_chains);
     if (!ok) { c->err = "odometry workspace: hipMalloc failed"; return LMONO_ENOMEM; }
     b->chains_cap = n_chains;
     return LMONO_OK;
@@ -593,6 +600,12 @@ static int odom_launch_steps(lmono_ctx *c, lmono_scan_batch *b, const OdomView &
         while ((int)es->kev.size() <= i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; es->kev.push_back(e); }
         return es->kev[i];
     };
+    if (o.fs_list) {
+        // the features of every chain's first search of this launch sequence, sorted by sector (later ones: k_lm_solve's tail)
+        OdomView of = o;
+        of.chain0 = 0; of.chain1 = n_ch;
+        hipLaunchKernelGGL(k_feat_sectors, dim3(n_ch), dim3(256), 0, st, b->v, of, step_a);
+    }
     GroupFork fork(c, G, g_own);
     int rc = fork.fork();
     if (rc) return rc;
@@ -608,8 +621,12 @@ static int odom_launch_steps(lmono_ctx *c, lmono_scan_batch *b, const OdomView &
                 hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
                 if (g == 0 && es) { e0 = kev(*ne); e1 = kev(*ne + 1); e2 = kev(*ne + 2); }
                 if (e0 && e1 && e2) (void)hipEventRecord(e0, sg);
-                if (tile == 3) {
-                    hipLaunchKernelGGL(k_corr_flat, dim3(8 * ((ng + 7) / 8) * kCfBlocks), dim3(kCfT), 0, sg, b->v, og, step, outer, wlg, c->opt[LMONO_OPT_DEFER_EVERY], c->stats_d);
+                if (tile == 3 && og.fs_list) {
+                    hipLaunchKernelGGL(k_corr_sect, dim3(8 * ((ng + 7) / 8) * kCsSect), dim3(kCsT), sizeof(CsLds), sg, b->v, og, step, outer, c->opt[LMONO_OPT_DEFER_EVERY], c->stats_d);
+                    hipLaunchKernelGGL(k_corr_flat, dim3(8 * ((ng + 7) / 8) * kCfBlocks), dim3(kCfT), 0, sg, b->v, og, step, outer, wlg, 0, c->stats_d, 1);
+                    hipLaunchKernelGGL(k_correspond_list, dim3(kListGrid), dim3(256), 0, sg, b->v, og, step, outer, (const unsigned int *)wlg, c->stats_d);
+                } else if (tile == 3) {
+                    hipLaunchKernelGGL(k_corr_flat, dim3(8 * ((ng + 7) / 8) * kCfBlocks), dim3(kCfT), 0, sg, b->v, og, step, outer, wlg, c->opt[LMONO_OPT_DEFER_EVERY], c->stats_d, 0);
                     hipLaunchKernelGGL(k_correspond_list, dim3(kListGrid), dim3(256), 0, sg, b->v, og, step, outer, (const unsigned int *)wlg, c->stats_d);
                 }
 #ifdef LMONO_DIAG_SEARCH
@@ -733,6 +750,8 @@ static OdomView odom_view(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int l
     o.state = b->state; o.corr = b->corr; o.incr = b->incr; o.lm_info = b->lm_info; o.crec = b->crec; o.seed = b->seed;
     o.ws = b->ws; o.repair = 0; o.step0 = 0; o.clist = nullptr; o.rstat = b->rstat; o.rcount = b->rcount;
     o.tol = 1e-9 * (double)c->opt[LMONO_OPT_BOUNDARY_TOL];
+    const bool sect = c->opt[LMONO_OPT_CORR_TILE] == 3 && c->opt[LMONO_OPT_CORR_SECT] != 0 && !odom_persistent(c);
+    o.fs_list = sect ? b->fs_list : nullptr; o.fs_off = b->fs_off; o.dl = b->dl; o.dl_cnt = b->dl_cnt;
     return o;
 }
 
@@ -995,7 +1014,7 @@ extern "C" int lmono_odom_correspond(lmono_ctx *c, lmono_scan_batch *b, int scan
         rc = ensure_odom_ws(c, b, 1);
         if (rc) return rc;
         HIP_TRY(c, hipMemsetAsync(b->wl, 0, sizeof(unsigned int), c->stream));
-        if (c->opt[LMONO_OPT_CORR_TILE] == 3) hipLaunchKernelGGL(k_corr_flat, dim3(8 * kCfBlocks), dim3(kCfT), 0, c->stream, b->v, o, 0, 0, b->wl, c->opt[LMONO_OPT_DEFER_EVERY], c->stats_d);
+        if (c->opt[LMONO_OPT_CORR_TILE] == 3) hipLaunchKernelGGL(k_corr_flat, dim3(8 * kCfBlocks), dim3(kCfT), 0, c->stream, b->v, o, 0, 0, b->wl, c->opt[LMONO_OPT_DEFER_EVERY], c->stats_d, 0);
 #ifdef LMONO_DIAG_SEARCH
         else if (c->opt[LMONO_OPT_CORR_TILE] == 2) hipLaunchKernelGGL(k_corr_thread, dim3(8 * kCtBlocks), dim3(kCtT), 0, c->stream, b->v, o, 0, 0, b->wl);
         else hipLaunchKernelGGL(k_corr_tile, dim3(8 * kTSect), dim3(kTT), kTileLds, c->stream, b->v, o, 0, 0, b->wl, c->stats_d);

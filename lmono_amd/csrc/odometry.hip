@@ -271,6 +271,11 @@ struct OdomView {
     int *rstat;           // [n_chains][4] repair state: [0] stopped (agreement or end of chain), [1] pairs re-run in total, [2] flagged in the current round, [3] times flagged
     unsigned int *rcount; // [0] chains flagged by k_boundary_check, [1] repair chains still running, then the flagged chain ids (clist)
     double tol;           // agreement bound of boundary_residual()
+    // ---- sector-staged search (corr_sect.hip)
+    unsigned short *fs_list;  // [n_chains][kMaxQueries] feature indices of the chain's NEXT search, sorted by azimuth sector (feat_sectors)
+    int *fs_off;              // [n_chains][kCsSect + 1]
+    unsigned short *dl;       // [n_chains][kMaxQueries] features the staged search hands to k_corr_flat's list mode
+    int *dl_cnt;              // [n_chains]
 };
 
 // scans [first, n_scans) are cut into n_chains ranges; scans before `first` are an external lead-in (the previous rank's scans)
@@ -1467,6 +1472,9 @@ __device__ __forceinline__ void lm_trust_region(const Eval &ev, double *x, doubl
     }
 }
 
+constexpr int kCsSectFwd = 32;
+__device__ __forceinline__ void feat_sectors(const BatchView &b, const OdomView &o, int c, int k, const double *x, bool thin, int *s_cnt);
+
 __global__ __launch_bounds__(kLmT) void k_lm_solve(BatchView b, OdomView o, int step, int outer, unsigned int *wl_reset)
 {
     const int c = o.clist ? o.clist[o.chain0 + blockIdx.x] : o.chain0 + (int)blockIdx.x;
@@ -1529,6 +1537,15 @@ __global__ __launch_bounds__(kLmT) void k_lm_solve(BatchView b, OdomView o, int 
         if (o.ws && !o.repair && outer == 1 && k == s - 1)
             for (int i = 0; i < 7; i++) o.ws[c * 8 + i] = x[i];       // the warm start of the chain's first owned pair
         if (o.lm_info) { o.lm_info[c * 4 + outer] = iter; o.lm_info[c * 4 + 2 + outer] = n_used; }
+    }
+    if (o.fs_list) {
+        // the sector-staged search of the chain's next launch (outer 1 of this pair, or outer 0 of the next pair) wants the features
+        // sorted by the azimuth sector of their position at THIS pose; its deferred list starts empty
+        __shared__ int s_sect[kCsSectFwd + 1];
+        int own2;
+        const int kn = outer == 0 ? k : chain_scan(o, c, step + 1, own2);
+        if (tid == 0) o.dl_cnt[c] = 0;
+        if (kn >= 0) feat_sectors(b, o, c, kn, x, lead_in_thinned(o, kn, s), s_sect);
     }
 }
 

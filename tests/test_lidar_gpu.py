@@ -386,3 +386,39 @@ def test_persistent_chain_kernel_equals_launch_per_phase_schedule(oracle, gpu_ct
     for a, b_ in zip(out[1], out[0]):
         assert np.abs(a - b_).max() < 1e-10
     assert np.abs(out[1][0] - ref["incr"]).max() < 1e-9 and np.abs(out[1][3] - ref["incr"]).max() < 1e-9
+
+
+@pytest.mark.parametrize("n_lines,n_az,min_range", [(64, 500, 5.0), (64, 2000, 5.0), (32, 1800, 0.5), (16, 600, 0.5)])
+def test_sector_staged_search_equals_flat_search(oracle, gpu_ctx, n_lines, n_az, min_range):
+    """LMONO_OPT_CORR_SECT: the sector-staged search (k_corr_sect: candidates and tables read from an LDS-staged azimuth window, features
+    whose ball leaves the window through k_corr_flat's list mode) against k_corr_flat over global memory for every feature: the same
+    correspondences, hence bit-identical increments -- sequential, chained with a thinned lead-in and repairs, from bad warm starts (the
+    first pair of every chain starts from the identity), with the fall-back hook on."""
+    w = oracle.S1World(n_az=n_az, n_rings=n_lines)
+    xyzi, off = w.scans(w.trajectory(8))
+    batch = _register(gpu_ctx, xyzi, off, n_lines, min_range)
+    out = {}
+    try:
+        for sect in (0, 1):
+            gpu_ctx.set_option(gpu_ctx.OPT_CORR_SECT, sect)
+            res = [batch.odometry(1, 0)[0]]
+            gpu_ctx.set_option(gpu_ctx.OPT_LEAD_FULL, 1)
+            res.append(batch.odometry(4, 2)[0])
+            gpu_ctx.set_option(gpu_ctx.OPT_LEAD_FULL, -1)
+            gpu_ctx.set_option(gpu_ctx.OPT_DEFER_EVERY, 7)
+            gpu_ctx.timing_reset()
+            res.append(batch.odometry(2, 3)[0])
+            gpu_ctx.timing()
+            res.append(float(gpu_ctx.diag[0]))
+            assert gpu_ctx.diag[1] == 0 and gpu_ctx.diag[2] == 0          # the kernels' index guards never had to act
+            gpu_ctx.set_option(gpu_ctx.OPT_DEFER_EVERY, 0)
+            out[sect] = res
+    finally:
+        gpu_ctx.set_option(gpu_ctx.OPT_CORR_SECT, 0)
+        gpu_ctx.set_option(gpu_ctx.OPT_LEAD_FULL, -1)
+        gpu_ctx.set_option(gpu_ctx.OPT_DEFER_EVERY, 0)
+    for a, b_ in zip(out[0][:3], out[1][:3]):
+        assert np.array_equal(a, b_)
+    assert out[1][3] > 0                      # the hook sent features through the list mode
+    ref = oracle.run_sequence(xyzi, off, n_lines, min_range)
+    assert np.abs(out[1][0] - ref["incr"]).max() < 1e-9
