@@ -537,7 +537,7 @@ def main():
                     help="weak: every rank gets --scans scans of one long trajectory; strong: --scans scans in total, sharded "
                          "over the ranks (BASELINE configs[3]: seq 00 sharded across 8)")
     ap.add_argument("--chains", type=int, default=256, help="concurrent odometry chains per GPU (strong scaling: in total)")
-    ap.add_argument("--lead", type=int, default=5, help="lead-in scans of a chain that does not start at scan 0")
+    ap.add_argument("--lead", type=int, default=4, help="lead-in scans of a chain that does not start at scan 0")
     ap.add_argument("--lead-full", type=int, default=2,
                     help="lead-in scan pairs of a chain (the last ones) that use all feature points; the earlier ones a quarter (-1: all use all)")
     ap.add_argument("--kitti-dir", default="", help="read the scans of a KITTI-layout sequence directory (velodyne/%%06d.bin + times.txt, e.g. "
@@ -752,7 +752,7 @@ def main():
         # HBM bytes per launch of the dominant kernel from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE and
         # WRITE_SIZE in separate passes, gfx950 correction applied; scripts/profile_round.sh); null if not collected for it
         traffic = None
-        for rnd in ("r2", "r1"):
+        for rnd in ("r3", "r2", "r1"):
             pmc_path = os.path.join(ROOT, "profiles", rnd, "pmc_%s.json" % dom)
             if os.path.exists(pmc_path) and chains == 256:
                 with open(pmc_path) as fh:

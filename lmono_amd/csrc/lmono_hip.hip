@@ -675,7 +675,7 @@ static bool odom_persistent(const lmono_ctx *c) { return c->opt[LMONO_OPT_CORR_T
 // Boundary validation + repair rounds of the chained schedule ("self-validating chains").  ext: incr[first - 1]
 // was supplied by the caller (previous rank's last increment).  Synchronises the context stream (the flagged count decides what is
 // launched).  Results in b->brep / b->resid_h / b->rerun_h.
-static int odom_validate(lmono_ctx *c, lmono_scan_batch *b, OdomView o, bool ext, bool first_call)
+static int odom_validate(lmono_ctx *c, lmono_scan_batch *b, OdomView o, bool ext, bool first_call, EvSet *es = nullptr, int *ne = nullptr)
 {
     hipStream_t st = c->stream;
     const int n_chains = o.n_chains;
@@ -708,7 +708,7 @@ static int odom_validate(lmono_ctx *c, lmono_scan_batch *b, OdomView o, bool ext
         orp.repair = 1; orp.clist = (const int *)(b->rcount + 2); orp.lead_full = -1;
         if (odom_persistent(c)) {
             // a repair chain stops by itself at the first pair whose increment agrees with the stored one
-            int rc = odom_launch_chains(c, b, orp, nf, max_len, nullptr, nullptr);
+            int rc = odom_launch_chains(c, b, orp, nf, max_len, es, ne);
             if (rc) return rc;
             continue;
         }
@@ -719,7 +719,7 @@ static int odom_validate(lmono_ctx *c, lmono_scan_batch *b, OdomView o, bool ext
         while (done < max_len) {
             const int upto = done + chunk < max_len ? done + chunk : max_len;
             orp.step0 = 0;
-            int rc = odom_launch_steps(c, b, orp, nf, done, upto, G, nullptr, nullptr);
+            int rc = odom_launch_steps(c, b, orp, nf, done, upto, G, es, ne);      // group 0's repair launches are timed like the main pass's
             if (rc) return rc;
             done = upto;
             HIP_TRY(c, hipMemcpyAsync(cnt, b->rcount, sizeof(cnt), hipMemcpyDeviceToHost, st));
@@ -794,6 +794,8 @@ static int odom_run(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, i
     // the chained schedule validates itself: every chain's warm start against its predecessor's last increment, repair where they differ
     b->brep = lmono_boundary_report{};
     b->brep.n_chains = n_chains;
+    // (the repair launches carry no per-kernel events: the correspondence / solve sums of lmono_timing_read are the main pass's; the
+    // repair's device time is lmono_boundary_report.repair_ms)
     if (o.tol > 0.0 && n_chains > 1) { rc = odom_validate(c, b, o, false, true); if (rc) return rc; }
     if (want_poses) hipLaunchKernelGGL(k_pose_prefix, dim3(1), dim3(64), 0, st, (const double *)b->incr, b->poses, first, n);
     HIP_TRY(c, hipEventRecord(c->ev[9], st));

@@ -688,7 +688,10 @@ __global__ __launch_bounds__(kOcT) void k_odom_chain(BatchView b, OdomView o, in
                         const double res = boundary_residual(x, o.incr + (size_t)k * 7);
                         for (int i = 0; i < 7; i++) o.incr[(size_t)k * 7 + i] = x[i];
                         o.rstat[c * 4 + 1] += 1;
-                        if (res <= o.tol || k + 1 >= e_own) { o.rstat[c * 4] = 1; S.stop = 1; }
+                        int agree = o.rstat[c * 4 + 2] >> 1;
+                        agree = res <= o.tol ? agree + 1 : 0;
+                        o.rstat[c * 4 + 2] = 1 | (agree << 1);
+                        if (agree >= kRepairAgree || k + 1 >= e_own) { o.rstat[c * 4] = 1; S.stop = 1; }
                     } else {
                         if (o.incr && k >= s_own) for (int i = 0; i < 7; i++) o.incr[(size_t)k * 7 + i] = x[i];
                         if (o.ws && k == s_own - 1) for (int i = 0; i < 7; i++) o.ws[c * 8 + i] = x[i];

@@ -83,6 +83,27 @@ def test_every_layout_meets_the_1cm_bar_without_tuning(seq):
         ctx.set_option(ctx.OPT_LEAD_FULL, -1)
 
 
+def test_thinner_lead_ins_stay_inside_the_bar(seq):
+    """LMONO_OPT_LEAD_FULL 1 and 0 (less accurate warm starts: every boundary is flagged).  With LEAD_FULL 1 the held-out sequence once came
+    out 11 mm off although every boundary had passed: a repair chain had stopped at the first pair that agreed within the tolerance, and the
+    NEXT pair amplified that 1e-6 difference to 1.9e-4 rad (a correspondence set on a knife edge).  A repair chain now has to reproduce two
+    consecutive pairs (kRepairAgree, odometry.hip) before the rest of its chain stands."""
+    from lmono_amd import trajectory
+    lead, _ = _bench_defaults()
+    b = seq["batch"]; ctx = b.ctx
+    try:
+        for lead_full in (1, 0):
+            ctx.set_option(ctx.OPT_LEAD_FULL, lead_full)
+            for ld in (lead, lead + 1):
+                _, poses = b.odometry(256, ld)
+                rep = b.boundary_report()
+                ate = trajectory.ate(poses, seq["gold"]["poses"])
+                print("seq %d, 256 chains, lead %d, LEAD_FULL %d: ATE %.6f m, %d chains re-run, %d pairs" % (seq["id"], ld, lead_full, ate, rep["chains_rerun"], rep["pairs_rerun"]))
+                assert rep["unresolved"] == 0 and ate <= 0.002
+    finally:
+        ctx.set_option(ctx.OPT_LEAD_FULL, -1)
+
+
 def test_validation_off_is_the_round2_schedule_and_on_only_improves(seq):
     """tol 0 = no check (the round-2 behaviour: 224 chains x lead 7 missed the bar on seq 0 by one unlucky boundary)."""
     from lmono_amd import trajectory
