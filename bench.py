@@ -603,6 +603,8 @@ def main():
         args.scans = min(args.scans, len(kitti_stamps)) if world == 1 or args.scaling == "strong" else min(args.scans, len(kitti_stamps) // world)
         if args.scaling != "strong" and world > 1:
             pass                                   # weak scaling: every rank takes the next --scans scans of the sequence
+    if world > 1 and args.lead < 1:
+        sys.exit("bench.py: --gpus > 1 needs --lead >= 1 (a rank's first owned scan pair needs the scan before it, which the lead-in loads)")
     strong = args.scaling == "strong"
     n_total = args.scans if strong else args.scans * world
     load_begin, own_begin, own_end = sharding.shard_range(n_total, world, rank, args.lead)
