@@ -87,14 +87,21 @@ def bench_ba_seq(args):
     fx = os.path.join(d, "stream.bin")
     K.write_stream(fx, st)
     exe = os.path.join(ROOT, "lmono_amd", "host", "estimator_seq")
-    t0 = time.perf_counter()
-    out = subprocess.run([exe, fx], capture_output=True, text=True)          # the child owns the GPU; this process never touches it
-    wall = time.perf_counter() - t0
-    if out.returncode != 0:
-        raise RuntimeError("estimator_seq failed: " + out.stderr[-1000:])
-    odo = np.array([[float(v) for v in ln.split()[1:]] for ln in out.stdout.splitlines() if ln.startswith("ODO")])
-    tim = [ln for ln in out.stdout.splitlines() if ln.startswith("TIM")][0].split()
-    n_inited, ms_frame = int(tim[1]), float(tim[2])
+    # two replays: marginalisation inline (the reference's order) and overlapped with the next frame on a second context / stream /
+    # host thread (Estimator::setAsyncMargin -- the timed configuration); every printed quantity must be the same bytes
+    runs = {}
+    for mode in ("sync", "async"):
+        t0 = time.perf_counter()
+        out = subprocess.run([exe, fx, "-", mode], capture_output=True, text=True)  # the child owns the GPU; this process never touches it
+        wall = time.perf_counter() - t0
+        if out.returncode != 0:
+            raise RuntimeError("estimator_seq failed: " + out.stderr[-1000:])
+        lines = out.stdout.splitlines()
+        tim = [ln for ln in lines if ln.startswith("TIM")][0].split()
+        runs[mode] = {"lines": [ln for ln in lines if not ln.startswith("TIM")], "n_inited": int(tim[1]), "ms_frame": float(tim[2]), "wall": wall}
+    identical = runs["sync"]["lines"] == runs["async"]["lines"]
+    odo = np.array([[float(v) for v in ln.split()[1:]] for ln in runs["async"]["lines"] if ln.startswith("ODO")])
+    n_inited, ms_frame, wall = runs["async"]["n_inited"], runs["async"]["ms_frame"], runs["async"]["wall"]
     gt = np.concatenate([np.zeros((len(odo), 4)), st["gt_P"][10:10 + len(odo)]], 1)
     est = np.concatenate([np.zeros((len(odo), 4)), odo[:, 1:4]], 1)
     # ---- cpu_baseline leg: the only place the oracle is touched
@@ -105,8 +112,11 @@ def bench_ba_seq(args):
            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": "S2 frame stream, KITTI-05 shape (configs[2]): %d frames, <= 150 tracks / frame, batch 1 (one sequence)" % n,
                       "frames": n, "inited_frames": n_inited, "ms_per_frame": round(ms_frame, 3), "wall_s": round(wall, 1), "gen_s": round(gen_s, 1),
+                      "marginalisation": "overlapped with the next frame (second context, own HIP stream, host thread)",
+                      "inline_marginalisation": {"ms_per_frame": round(runs["sync"]["ms_frame"], 3), "frames_per_s": round(1e3 / runs["sync"]["ms_frame"], 2),
+                                                 "output_identical_to_overlapped": identical},
                       "note": "a frame = processImage of the C++ mirror: triangulate + <= 30 dogleg iterations + marginalisation + outlier "
-                              "rejection + window slide; each numeric step is one C-ABI call with its own allocation / upload (PCIe-inclusive)"},
+                              "rejection + window slide; each numeric step is one C-ABI call with its own upload / download (PCIe-inclusive; scratch from the context arena)"},
            "roofline": {"bound": "mfma", "kernel": "k_ba_solve (one window per launch: one of 256 CUs busy)", "achieved": None, "peak": FP64_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": None, "traffic": None,
                         "note": "batch 1 is latency bound by construction (SURVEY 8d): the reference's own operating point; the batched rate is the `ba` workload"},

@@ -37,6 +37,11 @@ lmono_ctx  *lmono_create(int device);           /* NULL when HIP / the device is
 void        lmono_destroy(lmono_ctx *);
 const char *lmono_last_error(const lmono_ctx *);
 int         lmono_set_stream(lmono_ctx *, void *hip_stream); /* hipStream_t; NULL = default  */
+/* Run this context on a non-blocking stream the library creates (and destroys with the context).  No reference counterpart: the
+ * reference runs marginalisation inline (Estimator.cc:1280-1470); the host mirror uses a second context on its own stream so that it
+ * overlaps the next frame's solve.  A context is used by one host thread at a time; two contexts on two threads do not serialise
+ * (the host-array entry points carve their scratch from a per-context arena and copy on the context stream only). */
+int         lmono_use_own_stream(lmono_ctx *);
 int         lmono_synchronize(lmono_ctx *);
 /* Tuning / test switches of a context (no reference counterpart).  LMONO_OPT_CORR_TILE selects the laserOdometry correspondence
  * search: 3 (default) = flattened candidate sweeps over the (scan line, azimuth bin) index (k_corr_flat; needs no hash grid, so

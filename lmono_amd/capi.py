@@ -9,7 +9,7 @@ MAX_QUERIES = 64 * 6 * 2 + 64 * 6 * 4
 
 # every symbol include/lmono_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "lmono_create", "lmono_destroy", "lmono_last_error", "lmono_set_stream", "lmono_set_option", "lmono_get_option", "lmono_synchronize", "lmono_version",
+    "lmono_create", "lmono_destroy", "lmono_last_error", "lmono_set_stream", "lmono_use_own_stream", "lmono_set_option", "lmono_get_option", "lmono_synchronize", "lmono_version",
     "lmono_batch_create", "lmono_batch_destroy", "lmono_scanreg_batch", "lmono_scanreg_batch_h", "lmono_host_alloc", "lmono_host_free", "lmono_batch_stage_h", "lmono_scanreg_batch_staged", "lmono_batch_counts", "lmono_batch_get_cloud",
     "lmono_batch_get_curvature", "lmono_odom_batch", "lmono_odom_batch_d", "lmono_odom_shard_d", "lmono_odom_shard_validate", "lmono_odom_boundary_report", "lmono_odom_stream_create", "lmono_odom_stream_destroy", "lmono_odom_step", "lmono_odom_stream_scan", "lmono_odom_correspond", "lmono_timing_reset", "lmono_timing_read",
     "lmono_pose_prefix_d", "lmono_pose_rebase_d", "lmono_map_refine", "lmono_voxel_filter", "lmono_mapper_create", "lmono_mapper_destroy", "lmono_mapper_reset", "lmono_mapper_process", "lmono_mapper_process_batch", "lmono_mapper_cube",
@@ -48,6 +48,7 @@ def load_library():
     L.lmono_last_error.argtypes = [C.c_void_p]
     L.lmono_version.restype = C.c_char_p
     L.lmono_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.lmono_use_own_stream.argtypes = [C.c_void_p]
     L.lmono_synchronize.argtypes = [C.c_void_p]
     L.lmono_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.lmono_get_option.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
@@ -134,6 +135,11 @@ class Context:
     def set_stream(self, raw_stream):
         self.check(self.L.lmono_set_stream(self.h, C.c_void_p(raw_stream)))
         self._own_stream = bool(raw_stream)
+
+    def use_own_stream(self):
+        """Run on a non-blocking stream of the library's (two contexts on two host threads then overlap)."""
+        self.check(self.L.lmono_use_own_stream(self.h))
+        self._own_stream = True
 
     def synchronize(self):
         self.check(self.L.lmono_synchronize(self.h))

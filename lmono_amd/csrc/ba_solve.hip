@@ -346,65 +346,84 @@ __device__ __forceinline__ void ba_small_accumulate_wave(const BaCtx &c, BaLds &
 // every run whatever the waves' timing was.  Entries nothing touches become zero: the pass replaces clearing H_pp.
 __device__ __forceinline__ void ba_reduce_pairs(const BaBatch &B, const BaCtx c, BaLds &L)
 {
-    const int tid = threadIdx.x, P = c.P, np_ = c.n_poses;
+    const int tid = threadIdx.x, np_ = c.n_poses;
     const double *tiles = B.pairH + (size_t)c.pp0 * kBaPairTile;
-    // block of a parameter index: -1 = extrinsic, else the frame; offset inside the block
-    auto blk = [&](int g, int &o) { if (c.ex_off >= 0 && g < 6) { o = g; return -1; } const int q = g - (c.ex_off >= 0 ? 6 : 0); o = q % 6; return q / 6; };
     // position of (row r, column q) of a pair's record; rows / columns 0..5 = frame i, 6..11 = frame j, 12..15 = extrinsic 0..3 (the 16 x 16
     // tile), column 16 / 17 = extrinsic 4 / 5 and column 18 = the residual (the 16 x 4 side tile); the tile is symmetric
     auto pos = [](int r, int q) { return q < 16 ? (r < 16 ? r * 16 + q : 256 + q * 4 + (r - 16)) : 256 + r * 4 + (q - 16); };
-    for (int e = tid; e < P * P + P; e += kBaT) {
-        const bool is_g = e >= P * P;
-        const int gm = is_g ? e - P * P : e / P, gn = is_g ? -1 : e % P;
-        int om, on = 0;
-        const int bm = blk(gm, om), bn = is_g ? -2 : blk(gn, on);
-        const bool m_x = bm == -1, n_x = bn == -1;
-        double acc = 0.0;
-        if (is_g ? m_x : (m_x && n_x)) {
-            // extrinsic block / extrinsic gradient: every pair contributes the same position of its record.  The (4..5, 4..5) corner and
-            // g_x4, g_x5 are the waves' own sums (added by wave 1 afterwards)
-            if (!(om >= 4 && (is_g || on >= 4))) {
-                const int o = is_g ? pos(12 + om, 18) : pos(12 + om, 12 + on);
-                for (int p0 = 0; p0 < c.n_pairs; p0 += 8) {
-                    double v[8];
+    const int x0 = c.ex_off;                                   // first extrinsic index (-1: extrinsic constant)
+    // (A) entries coupling two DIFFERENT frames: the one pair that holds both (a caller may anchor tracks at a later frame: both orders).
+    //     Four entries per thread and turn: their loads are in flight together.
+    for (int t0 = tid; t0 < np_ * np_ * 36; t0 += 4 * kBaT) {
+        double v1[4], v2[4];
+        int dst[4];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) v[u] = p0 + u < c.n_pairs ? gld(tiles + (size_t)(p0 + u) * kBaPairTile + o) : 0.0;
-#pragma unroll
-                    for (int u = 0; u < 8; u++) acc += v[u];
+        for (int u = 0; u < 4; u++) {
+            const int t = t0 + u * kBaT;
+            dst[u] = -1; v1[u] = 0.0; v2[u] = 0.0;
+            if (t < np_ * np_ * 36) {
+                const int bm = t / (np_ * 36), r = t % (np_ * 36), bn = r / 36, om = (r % 36) / 6, on = r % 6;
+                if (bm != bn) {
+                    const int i = bm < bn ? bm : bn, j = bm < bn ? bn : bm;
+                    const int p1 = L.pair_of[i * kBaMaxPoses + j], p2 = L.pair_of[j * kBaMaxPoses + i];
+                    if (p1 >= 0) v1[u] = gld(tiles + (size_t)p1 * kBaPairTile + pos(bm == i ? om : 6 + om, bn == i ? on : 6 + on));
+                    if (p2 >= 0) v2[u] = gld(tiles + (size_t)p2 * kBaPairTile + pos(bm == j ? om : 6 + om, bn == j ? on : 6 + on));
+                    dst[u] = (ba_pose_off(c, bm) + om) * kBaP + ba_pose_off(c, bn) + on;
                 }
             }
-        } else if (!is_g && !m_x && !n_x && bm != bn) {
-            // two different frames: the one pair (or, for a caller that anchors tracks at a later frame, the two) that holds both
-            const int i = bm < bn ? bm : bn, j = bm < bn ? bn : bm;
-            const int p1 = L.pair_of[i * kBaMaxPoses + j], p2 = L.pair_of[j * kBaMaxPoses + i];
-            const int r1 = bm == i ? om : 6 + om, q1 = bn == i ? on : 6 + on;       // in pair (i, j)
-            const int r2 = bm == j ? om : 6 + om, q2 = bn == j ? on : 6 + on;       // in pair (j, i)
-            const double v1 = p1 >= 0 ? gld(tiles + (size_t)p1 * kBaPairTile + pos(r1, q1)) : 0.0;
-            const double v2 = p2 >= 0 ? gld(tiles + (size_t)p2 * kBaPairTile + pos(r2, q2)) : 0.0;
-            acc = v1 + v2;
-        } else {
-            // one frame f (with itself, with the extrinsic, or its gradient): the pairs (f, j) by ascending j, then the pairs (i, f) by
-            // ascending i; f sits in rows 0..5 of the former and 6..11 of the latter.  All loads are requested before the first is used.
-            const int f = m_x ? bn : bm;
-            int oi_, oj_;            // positions in a pair where f is the anchor / the observer
-            if (is_g) { oi_ = pos(om, 18); oj_ = pos(6 + om, 18); }
-            else if (m_x) { oi_ = pos(12 + om, on); oj_ = pos(12 + om, 6 + on); }
-            else if (n_x) { oi_ = pos(om, 12 + on); oj_ = pos(6 + om, 12 + on); }
-            else { oi_ = pos(om, on); oj_ = pos(6 + om, 6 + on); }
-            double va[kBaMaxPoses], vb[kBaMaxPoses];
-#pragma unroll
-            for (int k = 0; k < kBaMaxPoses; k++) {
-                const int pa = (k < np_ && k != f) ? L.pair_of[f * kBaMaxPoses + k] : -1;
-                const int pb = (k < np_ && k != f) ? L.pair_of[k * kBaMaxPoses + f] : -1;
-                va[k] = pa >= 0 ? gld(tiles + (size_t)pa * kBaPairTile + oi_) : 0.0;
-                vb[k] = pb >= 0 ? gld(tiles + (size_t)pb * kBaPairTile + oj_) : 0.0;
-            }
-#pragma unroll
-            for (int k = 0; k < kBaMaxPoses; k++) acc += va[k];
-#pragma unroll
-            for (int k = 0; k < kBaMaxPoses; k++) acc += vb[k];
         }
-        if (is_g) L.gp[gm] = acc; else L.Hpp[gm * kBaP + gn] = acc;
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (dst[u] >= 0) L.Hpp[dst[u]] = v1[u] + v2[u];
+    }
+    // (B) entries of ONE frame f -- with itself (36), with the extrinsic (2 x 36) and its gradient (6): the pairs (f, j) by ascending j, then
+    //     the pairs (i, f) by ascending i; f sits in rows 0..5 of the former and 6..11 of the latter.  22 loads in flight per entry.
+    const int per_f = 36 + (x0 >= 0 ? 72 : 0) + 6;
+    for (int t = tid; t < np_ * per_f; t += kBaT) {
+        const int f = t / per_f, r = t % per_f;
+        int oi_, oj_, dst, dst2 = -1;
+        bool is_g = false;
+        if (r < 36) { const int om = r / 6, on = r % 6; oi_ = pos(om, on); oj_ = pos(6 + om, 6 + on); dst = (ba_pose_off(c, f) + om) * kBaP + ba_pose_off(c, f) + on; }
+        else if (r >= per_f - 6) { const int om = r - (per_f - 6); oi_ = pos(om, 18); oj_ = pos(6 + om, 18); dst = ba_pose_off(c, f) + om; is_g = true; }
+        else {
+            // (frame row om, extrinsic column ox) and its mirror: the tile is symmetric, one sum serves both
+            const int q = r - 36, om = (q % 36) / 6, ox = q % 6;
+            oi_ = pos(om, 12 + ox); oj_ = pos(6 + om, 12 + ox);
+            dst = (ba_pose_off(c, f) + om) * kBaP + x0 + ox; dst2 = (x0 + ox) * kBaP + ba_pose_off(c, f) + om;
+            if (q >= 36) continue;                              // the mirror is written with its twin
+        }
+        double va[kBaMaxPoses], vb[kBaMaxPoses];
+#pragma unroll
+        for (int k = 0; k < kBaMaxPoses; k++) {
+            const int pa = (k < np_ && k != f) ? L.pair_of[f * kBaMaxPoses + k] : -1;
+            const int pb = (k < np_ && k != f) ? L.pair_of[k * kBaMaxPoses + f] : -1;
+            va[k] = pa >= 0 ? gld(tiles + (size_t)pa * kBaPairTile + oi_) : 0.0;
+            vb[k] = pb >= 0 ? gld(tiles + (size_t)pb * kBaPairTile + oj_) : 0.0;
+        }
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < kBaMaxPoses; k++) acc += va[k];
+#pragma unroll
+        for (int k = 0; k < kBaMaxPoses; k++) acc += vb[k];
+        if (is_g) L.gp[dst] = acc;
+        else { L.Hpp[dst] = acc; if (dst2 >= 0) L.Hpp[dst2] = acc; }
+    }
+    // (C) the extrinsic block and gradient from the waves' partial sums (wave order); the (4..5, 4..5) corner and g_x4, g_x5 are added by
+    //     wave 1 afterwards and start at zero
+    if (x0 >= 0 && tid < 42) {
+        double acc = 0.0;
+        int dst;
+        if (tid < 36) {
+            const int om = tid / 6, on = tid % 6;
+            dst = (x0 + om) * kBaP + x0 + on;
+            if (om < 4 && on < 4) { for (int w = 0; w < kBaW; w++) acc += L.D[w * 40 + om * 4 + on]; }
+            else if (om < 4) { for (int w = 0; w < kBaW; w++) acc += L.D[w * 40 + 16 + om * 3 + (on - 4)]; }
+            else if (on < 4) { for (int w = 0; w < kBaW; w++) acc += L.D[w * 40 + 16 + on * 3 + (om - 4)]; }
+            L.Hpp[dst] = acc;
+        } else {
+            const int om = tid - 36;
+            if (om < 4) for (int w = 0; w < kBaW; w++) acc += L.D[w * 40 + 16 + om * 3 + 2];
+            L.gp[x0 + om] = acc;
+        }
     }
     __syncthreads();
 }
@@ -497,6 +516,7 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
     double *wstage = L.u.stage + (size_t)wave * 2 * kBaRound * kBaRow;
     const int q = lane & 1, lo = lane >> 1, col = lane & 15, kq = lane >> 4;
     double xx44 = 0, xx45 = 0, xx55 = 0, gx4 = 0, gx5 = 0;
+    double xa = 0, xb = 0;      // this lane's entry of the extrinsic rows 12..15 of the tiles, summed over the wave's pairs (all pairs touch them)
     for (int wi = L.woff[wave]; wi < L.woff[wave + 1]; wi++) {
         const int pr = L.wlist[wi];
         const int ij = L.pair_ij[pr], fi = ij & 255, fj = ij >> 8;
@@ -624,8 +644,13 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
                 gst(tile + (kq + 4 * v) * 16 + col, aa[v]);
                 if (col < 3) gst(tile + 256 + (kq + 4 * v) * 4 + col, ab[v]);
             }
+            xa += aa[3]; xb += ab[3];        // rows 12 + kq (extrinsic 0..3): columns col of the tile / of the side tile
         }
     }
+    // the extrinsic block and gradient get a contribution from EVERY pair: each wave leaves the sums over its own pairs (static order) in
+    // LDS (L.D is dead during a linearisation), ba_reduce_pairs adds the eight in wave order -- no all-pairs loop over the L2 records
+    if (col >= 12) L.D[wave * 40 + kq * 4 + (col - 12)] = xa;
+    if (col < 3) L.D[wave * 40 + 16 + kq * 3 + col] = xb;
     BA_TOCK(1)
     BA_TICK(11)
     // the waves' shares of the (4..5, 4..5) extrinsic corner and its gradient: summed in wave order

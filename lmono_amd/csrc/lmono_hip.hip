@@ -40,6 +40,12 @@ struct lmono_ctx {
     hipEvent_t gev[9] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     unsigned long long *stats_d = nullptr;   // [0] feature points deferred by the tile search since the last lmono_timing_reset
     hipStream_t copy_stream = nullptr;       // H2D staging of lmono_batch_stage_h (runs beside the compute stream)
+    hipStream_t own_stream = nullptr;        // lmono_use_own_stream: a stream of the library's that this context runs on
+    // scratch arena of the small host-array entry points (triangulate, outlier scores, marginalise ...): chunks are allocated once and
+    // reused by every later call -- no hipMalloc / hipFree (both synchronise the device) in a steady-state frame loop
+    struct Chunk { char *base; size_t cap; };
+    std::vector<Chunk> arena;
+    size_t arena_chunk = 0, arena_off = 0;
 
     hipEvent_t *next_set()
     {
@@ -150,6 +156,8 @@ extern "C" void lmono_destroy(lmono_ctx *c)
     if (c->stats_d) (void)hipFree(c->stats_d);
     for (auto &s : c->gstream) if (s) (void)hipStreamDestroy(s);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    for (auto &ch : c->arena) (void)hipFree(ch.base);
     for (auto &e : c->gev) if (e) (void)hipEventDestroy(e);
     delete c;
 }
@@ -160,6 +168,15 @@ extern "C" int lmono_set_stream(lmono_ctx *c, void *s)
 {
     if (!c) return LMONO_EINVAL;
     c->stream = (hipStream_t)s;
+    return LMONO_OK;
+}
+
+extern "C" int lmono_use_own_stream(lmono_ctx *c)
+{
+    if (!c) return LMONO_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->own_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
     return LMONO_OK;
 }
 
@@ -1298,28 +1315,48 @@ extern "C" int lmono_ba_batch_read(lmono_ctx *c, lmono_ba_batch *b, double *pose
 {
     if (!c || !b) return LMONO_EINVAL;
     if (b->n_windows <= 0) { c->err = "lmono_ba_batch_read: the batch holds no problem (failed update)"; return LMONO_EINVAL; }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (poses_h) HIP_TRY(c, hipMemcpy(poses_h, b->v.poses, sizeof(double) * (size_t)b->n_windows * kBaMaxPoses * 7, hipMemcpyDeviceToHost));
-    if (ex_h) HIP_TRY(c, hipMemcpy(ex_h, b->v.ex, sizeof(double) * (size_t)b->n_windows * 7, hipMemcpyDeviceToHost));
-    if (inv_depth_h && b->total_feat > 0) HIP_TRY(c, hipMemcpy(inv_depth_h, b->v.inv_depth, sizeof(double) * (size_t)b->total_feat, hipMemcpyDeviceToHost));
-    if (summary_h) HIP_TRY(c, hipMemcpy(summary_h, b->v.summary, sizeof(double) * (size_t)b->n_windows * 6, hipMemcpyDeviceToHost));
+    if (poses_h) HIP_TRY(c, hipMemcpyAsync(poses_h, b->v.poses, sizeof(double) * (size_t)b->n_windows * kBaMaxPoses * 7, hipMemcpyDeviceToHost, c->stream));
+    if (ex_h) HIP_TRY(c, hipMemcpyAsync(ex_h, b->v.ex, sizeof(double) * (size_t)b->n_windows * 7, hipMemcpyDeviceToHost, c->stream));
+    if (inv_depth_h && b->total_feat > 0) HIP_TRY(c, hipMemcpyAsync(inv_depth_h, b->v.inv_depth, sizeof(double) * (size_t)b->total_feat, hipMemcpyDeviceToHost, c->stream));
+    if (summary_h) HIP_TRY(c, hipMemcpyAsync(summary_h, b->v.summary, sizeof(double) * (size_t)b->n_windows * 6, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));      // stream-ordered behind the solve; nothing goes through the null stream
     return LMONO_OK;
 }
 
 // ---- per-feature kernels (triangulation, depth refinement, outlier scores, depth shift) ---------------------------
 namespace {
+// Scratch of one ABI call, carved from the context's arena (released when the scope ends; the chunks stay).  Uploads are asynchronous on
+// the context stream: nothing here touches the null stream or synchronises the device, so two contexts on two host threads overlap.
 struct DevBuf {
-    std::vector<void *> p;
-    ~DevBuf() { for (void *q : p) (void)hipFree(q); }
+    lmono_ctx *c;
+    size_t chunk0, off0;
+    bool used = false;
+    explicit DevBuf(lmono_ctx *c_) : c(c_), chunk0(c_ ? c_->arena_chunk : 0), off0(c_ ? c_->arena_off : 0) {}
+    // the scratch goes back to the arena only once nothing queued on the stream can still touch it (a no-op wait on the normal path,
+    // where the call has already waited for its results; it matters on the early error returns)
+    ~DevBuf() { if (c) { if (used) (void)hipStreamSynchronize(c->stream); c->arena_chunk = chunk0; c->arena_off = off0; } }
     template <typename T> T *up(const T *src, size_t n, bool &ok)
     {
-        void *q = nullptr;
-        if (!ok || hipMalloc(&q, (n > 0 ? n : 1) * sizeof(T)) != hipSuccess) { ok = false; return nullptr; }
-        p.push_back(q);
-        if (src && n > 0 && hipMemcpy(q, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) ok = false;
+        if (!ok || !c) { ok = false; return nullptr; }
+        used = true;
+        const size_t bytes = (((n > 0 ? n : 1) * sizeof(T)) + 255) & ~(size_t)255;
+        while (c->arena_chunk < c->arena.size() && c->arena_off + bytes > c->arena[c->arena_chunk].cap) { c->arena_chunk++; c->arena_off = 0; }
+        if (c->arena_chunk == c->arena.size()) {
+            size_t cap = c->arena.empty() ? (size_t)1 << 20 : 2 * c->arena.back().cap;
+            while (cap < bytes) cap <<= 1;
+            void *q = nullptr;
+            if (hipMalloc(&q, cap) != hipSuccess) { ok = false; return nullptr; }
+            c->arena.push_back({ (char *)q, cap });
+            c->arena_off = 0;
+        }
+        char *q = c->arena[c->arena_chunk].base + c->arena_off;
+        c->arena_off += bytes;
+        if (src && n > 0 && hipMemcpyAsync(q, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream) != hipSuccess) ok = false;
         return (T *)q;
     }
 };
+// result back to a host array: on the context stream (a blocking hipMemcpy would go through the null stream and wait for other contexts)
+template <typename T> hipError_t dl_async(lmono_ctx *c, T *dst_h, const T *src_d, size_t n) { return hipMemcpyAsync(dst_h, src_d, n * sizeof(T), hipMemcpyDeviceToHost, c->stream); }
 }
 
 static int feat_setup(lmono_ctx *c, DevBuf &db, FeatBatch &B, int n_windows, const int *feat_off, const double *Rs, const double *Ps, const double *tlc,
@@ -1346,7 +1383,7 @@ extern "C" int lmono_triangulate(lmono_ctx *c, int n_windows, const int *feat_of
                                  const int *start_frame_h, const int *obs_off_h, const double *pts_h, double *depth_h, int *solve_flag_h,
                                  int track_cnt, int window_size, double factor_weight, int refine_max_iter)
 {
-    DevBuf db; FeatBatch B{};
+    DevBuf db(c); FeatBatch B{};
     int rc = feat_setup(c, db, B, n_windows, feat_off_h, Rs_h, Ps_h, tlc_h, start_frame_h, obs_off_h, pts_h, depth_h);
     if (rc) return rc;
     B.track_cnt = track_cnt; B.window_size = window_size; B.weight = factor_weight; B.max_iter = refine_max_iter;
@@ -1356,9 +1393,9 @@ extern "C" int lmono_triangulate(lmono_ctx *c, int n_windows, const int *feat_of
     if (refine_max_iter >= 0) hipLaunchKernelGGL(k_depth_refine, dim3(n_windows), dim3(256), 0, c->stream, B);
     rc = check_launch(c, "k_triangulate_init/k_depth_refine");
     if (rc) return rc;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpy(depth_h, B.depth, sizeof(double) * F, hipMemcpyDeviceToHost));
-    if (solve_flag_h && refine_max_iter >= 0) HIP_TRY(c, hipMemcpy(solve_flag_h, B.solve_flag, sizeof(int) * F, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpyAsync(depth_h, B.depth, sizeof(double) * F, hipMemcpyDeviceToHost, c->stream));
+    if (solve_flag_h && refine_max_iter >= 0) HIP_TRY(c, hipMemcpyAsync(solve_flag_h, B.solve_flag, sizeof(int) * F, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));      // the results are in the caller's arrays
     return LMONO_OK;
 }
 
@@ -1367,7 +1404,7 @@ extern "C" int lmono_outlier_scores(lmono_ctx *c, int n_windows, const int *feat
                                     int track_cnt, double factor_weight, double *score_h)
 {
     if (!score_h) return LMONO_EINVAL;
-    DevBuf db; FeatBatch B{};
+    DevBuf db(c); FeatBatch B{};
     int rc = feat_setup(c, db, B, n_windows, feat_off_h, Rs_h, Ps_h, tlc_h, start_frame_h, obs_off_h, pts_h, depth_h);
     if (rc) return rc;
     B.track_cnt = track_cnt; B.window_size = 0; B.weight = factor_weight; B.max_iter = 0;
@@ -1376,8 +1413,8 @@ extern "C" int lmono_outlier_scores(lmono_ctx *c, int n_windows, const int *feat
     hipLaunchKernelGGL(k_outlier_scores, dim3((F + 127) / 128), dim3(128), 0, c->stream, B);
     rc = check_launch(c, "k_outlier_scores");
     if (rc) return rc;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpy(score_h, B.score, sizeof(double) * F, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpyAsync(score_h, B.score, sizeof(double) * F, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));      // the results are in the caller's arrays
     return LMONO_OK;
 }
 
@@ -1389,14 +1426,14 @@ extern "C" int lmono_shift_depth(lmono_ctx *c, const double *back_R0, const doub
     HIP_TRY(c, hipSetDevice(c->device));
     double poses[40];
     memcpy(poses, back_R0, 72); memcpy(poses + 9, back_P0, 24); memcpy(poses + 12, R1, 72); memcpy(poses + 21, P1, 24); memcpy(poses + 24, tlc, 128);
-    DevBuf db; bool ok = true;
+    DevBuf db(c); bool ok = true;
     double *pd = db.up(poses, 40, ok), *pt = db.up(pt_i_h, (size_t)n * 2, ok), *d = db.up(depth_h, (size_t)n, ok), *o = db.up((const double *)nullptr, (size_t)n, ok);
     if (!ok) { c->err = "lmono_shift_depth: device allocation / upload failed"; return LMONO_ENOMEM; }
     hipLaunchKernelGGL(k_shift_depth, dim3((n + 127) / 128), dim3(128), 0, c->stream, (const double *)pd, n, (const double *)pt, (const double *)d, o);
     int rc = check_launch(c, "k_shift_depth");
     if (rc) return rc;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpy(depth_out_h, o, sizeof(double) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpyAsync(depth_out_h, o, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));      // the results are in the caller's arrays
     return LMONO_OK;
 }
 
@@ -1425,7 +1462,7 @@ extern "C" int lmono_marginalize(lmono_ctx *c, int n_windows, const int *feat_of
     fo[TF] = TO;
     double info[40];
     memcpy(info, laser_info_h, 36 * sizeof(double)); memcpy(info + 36, mono_info_h, 4 * sizeof(double));
-    DevBuf db; bool ok = true;
+    DevBuf db(c); bool ok = true;
     MargBatch B{};
     B.n_windows = n_windows;
     B.feat_off = db.up(feat_off_h, (size_t)n_windows + 1, ok); B.obs_off = db.up(obs_off_h, (size_t)n_windows + 1, ok);
@@ -1439,10 +1476,10 @@ extern "C" int lmono_marginalize(lmono_ctx *c, int n_windows, const int *feat_of
     hipLaunchKernelGGL(k_marginalize, dim3(n_windows), dim3(256), sizeof(MargLds), c->stream, B);
     int rc = check_launch(c, "k_marginalize");
     if (rc) return rc;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpy(lin_J_h, B.lin_J, sizeof(double) * (size_t)n_windows * kMargN * kMargN, hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemcpy(lin_r_h, B.lin_r, sizeof(double) * (size_t)n_windows * kMargN, hipMemcpyDeviceToHost));
-    if (status_h) HIP_TRY(c, hipMemcpy(status_h, B.status, sizeof(int) * (size_t)n_windows, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpyAsync(lin_J_h, B.lin_J, sizeof(double) * (size_t)n_windows * kMargN * kMargN, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(lin_r_h, B.lin_r, sizeof(double) * (size_t)n_windows * kMargN, hipMemcpyDeviceToHost, c->stream));
+    if (status_h) HIP_TRY(c, hipMemcpyAsync(status_h, B.status, sizeof(int) * (size_t)n_windows, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));      // the results are in the caller's arrays
     return LMONO_OK;
 }
 
@@ -1450,7 +1487,7 @@ extern "C" int lmono_marg_evaluate(lmono_ctx *c, int n_windows, const double *li
 {
     if (!c || n_windows <= 0 || !lin_J_h || !lin_r_h || !x0_h || !x_h || !residual_h) return LMONO_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
-    DevBuf db; bool ok = true;
+    DevBuf db(c); bool ok = true;
     const double *J = db.up(lin_J_h, (size_t)n_windows * kMargN * kMargN, ok), *r = db.up(lin_r_h, (size_t)n_windows * kMargN, ok);
     const double *x0 = db.up(x0_h, (size_t)n_windows * 77, ok), *x = db.up(x_h, (size_t)n_windows * 77, ok);
     double *res = db.up((const double *)nullptr, (size_t)n_windows * kMargN, ok);
@@ -1458,8 +1495,8 @@ extern "C" int lmono_marg_evaluate(lmono_ctx *c, int n_windows, const double *li
     hipLaunchKernelGGL(k_marg_evaluate, dim3(n_windows), dim3(128), 0, c->stream, n_windows, J, r, x0, x, res);
     int rc = check_launch(c, "k_marg_evaluate");
     if (rc) return rc;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpy(residual_h, res, sizeof(double) * (size_t)n_windows * kMargN, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpyAsync(residual_h, res, sizeof(double) * (size_t)n_windows * kMargN, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));      // the results are in the caller's arrays
     return LMONO_OK;
 }
 
@@ -1472,7 +1509,7 @@ extern "C" int lmono_marg_second_new(lmono_ctx *c, int n_windows, int n_blocks, 
         !lin_J_out_h || !lin_r_out_h) return LMONO_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t n0 = 6 * (size_t)n_blocks, n = n0 - 6, W = (size_t)n_windows;
-    DevBuf db; bool ok = true;
+    DevBuf db(c); bool ok = true;
     Marg2Batch B{};
     B.n_windows = n_windows; B.nb = n_blocks; B.drop = drop_block;
     B.lin_J = db.up(lin_J_h, W * n0 * n0, ok); B.lin_r = db.up(lin_r_h, W * n0, ok);
@@ -1483,10 +1520,10 @@ extern "C" int lmono_marg_second_new(lmono_ctx *c, int n_windows, int n_blocks, 
     hipLaunchKernelGGL(k_marg_second_new, dim3(n_windows), dim3(256), sizeof(Marg2Lds), c->stream, B);
     int rc = check_launch(c, "k_marg_second_new");
     if (rc) return rc;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpy(lin_J_out_h, B.out_J, sizeof(double) * W * n * n, hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemcpy(lin_r_out_h, B.out_r, sizeof(double) * W * n, hipMemcpyDeviceToHost));
-    if (status_h) HIP_TRY(c, hipMemcpy(status_h, B.status, sizeof(int) * W, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpyAsync(lin_J_out_h, B.out_J, sizeof(double) * W * n * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(lin_r_out_h, B.out_r, sizeof(double) * W * n, hipMemcpyDeviceToHost, c->stream));
+    if (status_h) HIP_TRY(c, hipMemcpyAsync(status_h, B.status, sizeof(int) * W, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));      // the results are in the caller's arrays
     return LMONO_OK;
 }
 
@@ -1501,7 +1538,7 @@ extern "C" int lmono_map_refine(lmono_ctx *c, int n_streams,
     const int64_t tot[4] = { corner_map_off[n_streams], surf_map_off[n_streams], corner_stack_off[n_streams], surf_stack_off[n_streams] };
     const float *src_h[4] = { corner_map_h, surf_map_h, corner_stack_h, surf_stack_h };
     for (int k = 0; k < 4; k++) if (tot[k] < 0 || (tot[k] > 0 && !src_h[k])) return LMONO_EINVAL;
-    DevBuf db;
+    DevBuf db(c);
     bool ok = true;
     float4 *cloud_d[4];
     for (int k = 0; k < 4; k++) cloud_d[k] = (float4 *)db.up(src_h[k], (size_t)tot[k] * 4, ok);
@@ -1603,7 +1640,7 @@ extern "C" int lmono_voxel_filter(lmono_ctx *c, int n_clouds, const float *xyzi_
         if (n < 0 || n > kVoxCloudMax) { c->err = "lmono_voxel_filter: a cloud holds more than 65536 points"; return LMONO_ECAPACITY; }
         if (!(leaf_h[k] > 0.f)) { c->err = "lmono_voxel_filter: leaf size must be positive"; return LMONO_EINVAL; }
     }
-    DevBuf db;
+    DevBuf db(c);
     bool ok = true;
     float4 *in_d = (float4 *)db.up(xyzi_h, (size_t)total * 4, ok);
     float4 *out_d = (float4 *)db.up((const float *)nullptr, (size_t)total * 4, ok);

@@ -4,10 +4,13 @@
 //
 // Stream file (doubles): n_frames, TLC[16], then per frame: header, L0_Pos[16], n_loop (0/1) [loop_time_stamp, old_T[3],
 // old_Q[4] w x y z, correct_T[3], correct_Q[4] w x y z], n_features, n_features x (id, x_n, y_n, u, v).
-// Usage: estimator_seq <stream.bin> [new_odometry.txt]
+// Usage: estimator_seq <stream.bin> [new_odometry.txt | -] [async]
+// "async": marginalisation overlapped with the next frame (Estimator::setAsyncMargin); the PRI line (digest of the last prior) and
+// everything else must come out the same bytes as without it.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 #include "lmono_host.hpp"
 
@@ -34,6 +37,7 @@ int main(int argc, char **argv)
         HipContext hip(0);
         Params p;
         Estimator est(hip, p);
+        if (argc > 3 && std::string(argv[3]) == "async") est.setAsyncMargin(true);
         for (int j = 0; j < 16; j++) est.TLC[j] = d[k++];
         double solve_ms = 0; int solves = 0;
         for (int f = 0; f < n_frames; f++) {
@@ -61,10 +65,18 @@ int main(int argc, char **argv)
         }
         for (const auto &r : est.new_odometry)
             std::printf("ODO %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
+        est.marginWait();
+        {
+            const auto &mi = est.last_marginalization_info;
+            double sj = 0, sr = 0;
+            for (double v : mi.linearized_jacobians) sj += v * v;
+            for (double v : mi.linearized_residuals) sr += v * v;
+            std::printf("PRI %d %d %d %zu %.17g %.17g\n", mi.m, mi.n, mi.status, mi.parameter_blocks.size(), sj, sr);
+        }
         std::printf("EXT");
         for (int j = 0; j < 16; j++) std::printf(" %.17g", est.TLC[j]);
         std::printf("\nTIM %d %.6f\n", solves, solves ? solve_ms / solves : 0.0);
-        if (argc > 2) {
+        if (argc > 2 && std::string(argv[2]) != "-") {
             FILE *fo = std::fopen(argv[2], "w");
             if (!fo) { std::perror(argv[2]); return 2; }
             for (const auto &r : est.new_odometry) std::fprintf(fo, "%f %f %f %f %f %f %f %f\n", r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);   // Estimator.cc:642

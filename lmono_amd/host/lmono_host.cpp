@@ -172,7 +172,18 @@ Estimator::Estimator(HipContext &hip, const Params &p) : hip_(hip), p_(p)
     std::memset(TLC, 0, sizeof(TLC)); TLC[0] = TLC[5] = TLC[10] = TLC[15] = 1.0;
     feature_manager.params = &p_; feature_manager.hip = &hip_;
 }
-Estimator::~Estimator() { if (ba_batch_) lmono_ba_batch_destroy(ba_batch_); }
+Estimator::~Estimator()
+{
+    try { marginWait(); } catch (...) {}
+    if (ba_batch_) lmono_ba_batch_destroy(ba_batch_);
+}
+void Estimator::marginWait() { if (margin_job_.valid()) margin_job_.get(); }     // rethrows what the worker threw
+void Estimator::setAsyncMargin(bool on)
+{
+    marginWait();
+    if (on && !margin_hip_) { margin_hip_.reset(new HipContext(hip_.device())); margin_hip_->useOwnStream(); }
+    async_margin_ = on;
+}
 void Estimator::matrix2Double()
 {
     for (int i = 0; i <= WINDOW_SIZE; i++) { std::memcpy(para_pose[i], Ps[i].v, 24); R_to_q(Rs[i].m, para_pose[i] + 3); }
@@ -273,9 +284,11 @@ void Estimator::outliersRejection(std::set<int> &removeIndex, const double &erro
 }
 void Estimator::margin()
 {
+    marginWait();                                             // the previous prior is this call's input (and its storage is reused)
+    HipContext *h = async_margin_ ? margin_hip_.get() : &hip_;
+    MarginalizationInfo &mi = last_marginalization_info;
     if (marginalization_flag != MARGIN_OLD) {
         // :1406-1470: the previous prior, as the only factor, loses the block that aliases para_pose[WINDOW_SIZE - 1]
-        MarginalizationInfo &mi = last_marginalization_info;
         if (!mi.present) return;
         const auto it = std::find(mi.parameter_blocks.begin(), mi.parameter_blocks.end(), WINDOW_SIZE - 1);
         if (it == mi.parameter_blocks.end()) return;
@@ -283,22 +296,30 @@ void Estimator::margin()
         matrix2Double();
         std::vector<double> x((size_t)nb * 7);
         for (int k = 0; k < nb; k++) std::memcpy(&x[7 * (size_t)k], mi.parameter_blocks[k] < 0 ? para_ex[0] : para_pose[mi.parameter_blocks[k]], 56);
-        const int n = 6 * (nb - 1);
-        std::vector<double> J((size_t)n * n), r((size_t)n);
-        int status = 0;
-        hip_.check(lmono_marg_second_new(hip_.get(), 1, nb, drop, mi.linearized_jacobians.data(), mi.linearized_residuals.data(),
-                                         mi.keep_block_data.data(), x.data(), J.data(), r.data(), &status), "lmono_marg_second_new");
-        mi.linearized_jacobians.swap(J); mi.linearized_residuals.swap(r);
-        x.erase(x.begin() + 7 * (size_t)drop, x.begin() + 7 * (size_t)(drop + 1));
-        mi.keep_block_data.swap(x);                            // parameter_block_data: the values at this marginalisation
-        mi.parameter_blocks.erase(mi.parameter_blocks.begin() + drop);   // addr_shift :1442-1455: pose i -> pose i (i < 9), pose 10 -> pose 9 is not a block
-        mi.m = 6; mi.n = n; mi.status = status; mi.valid = false;
         margin_calls[1]++;
+        auto job = [h, &mi, drop, nb, x]() mutable {
+            const int n = 6 * (nb - 1);
+            std::vector<double> J((size_t)n * n), r((size_t)n);
+            int status = 0;
+            h->check(lmono_marg_second_new(h->get(), 1, nb, drop, mi.linearized_jacobians.data(), mi.linearized_residuals.data(),
+                                           mi.keep_block_data.data(), x.data(), J.data(), r.data(), &status), "lmono_marg_second_new");
+            mi.linearized_jacobians.swap(J); mi.linearized_residuals.swap(r);
+            x.erase(x.begin() + 7 * (size_t)drop, x.begin() + 7 * (size_t)(drop + 1));
+            mi.keep_block_data.swap(x);                            // parameter_block_data: the values at this marginalisation
+            mi.parameter_blocks.erase(mi.parameter_blocks.begin() + drop);   // addr_shift :1442-1455: pose i -> pose i (i < 9), pose 10 -> pose 9 is not a block
+            mi.m = 6; mi.n = n; mi.status = status; mi.valid = false;
+        };
+        if (async_margin_) margin_job_ = std::async(std::launch::async, std::move(job)); else job();
         return;
     }
     matrix2Double();
-    std::vector<int> obs_feat, obs_j; std::vector<double> obs_pts, invd;
-    int feature_index = -1, f0 = 0;
+    struct Pack {
+        std::vector<int> obs_feat, obs_j; std::vector<double> obs_pts, invd;
+        int f0 = 0;
+        double poses[77], ex[7], laser01[24], laser_info[36] = { 0 }, mono_info[4];
+    };
+    auto pk = std::make_shared<Pack>();
+    int feature_index = -1;
     for (auto &it : feature_manager.feature) {
         it.used_num = (int)it.feature_per_frame.size();
         if (it.used_num < p_.TRACK_CNT) continue;
@@ -308,34 +329,38 @@ void Estimator::margin()
         for (auto &f : it.feature_per_frame) {
             j++;
             if (j == 0) continue;
-            obs_feat.push_back(f0); obs_j.push_back(j);
-            obs_pts.insert(obs_pts.end(), { it.feature_per_frame[0].pt[0], it.feature_per_frame[0].pt[1], f.pt[0], f.pt[1] });
+            pk->obs_feat.push_back(pk->f0); pk->obs_j.push_back(j);
+            pk->obs_pts.insert(pk->obs_pts.end(), { it.feature_per_frame[0].pt[0], it.feature_per_frame[0].pt[1], f.pt[0], f.pt[1] });
         }
-        invd.push_back(para_depth_inv[feature_index]);
-        f0++;
+        pk->invd.push_back(para_depth_inv[feature_index]);
+        pk->f0++;
     }
-    const int feat_off[2] = { 0, f0 }, obs_off[2] = { 0, (int)obs_feat.size() };
-    double poses[77], laser01[24], laser_info[36] = { 0 }, mono_info[4] = { p_.FACTOR_WEIGHT, 0, 0, p_.FACTOR_WEIGHT };
-    for (int i = 0; i <= WINDOW_SIZE; i++) std::memcpy(poses + 7 * i, para_pose[i], 56);
-    std::memcpy(laser01, L0_R[0].m, 72); std::memcpy(laser01 + 9, L0_R[1].m, 72); std::memcpy(laser01 + 18, L0_T[0].v, 24); std::memcpy(laser01 + 21, L0_T[1].v, 24);
-    for (int k = 0; k < 6; k++) laser_info[k * 7] = p_.LASER_W * p_.FACTOR_WEIGHT;
-    MarginalizationInfo &mi = last_marginalization_info;
-    mi.linearized_jacobians.assign(66 * 66, 0.0); mi.linearized_residuals.assign(66, 0.0);
-    const int dummy = 0; const double dzero = 0.0;
-    hip_.check(lmono_marginalize(hip_.get(), 1, feat_off, obs_off, poses, para_ex[0], invd.empty() ? &dzero : invd.data(),
-                                 obs_feat.empty() ? &dummy : obs_feat.data(), obs_j.empty() ? &dummy : obs_j.data(),
-                                 obs_pts.empty() ? &dzero : obs_pts.data(), laser01, laser_info, mono_info,
-                                 mi.linearized_jacobians.data(), mi.linearized_residuals.data(), &mi.status), "lmono_marginalize");
-    mi.m = 6 + f0; mi.n = 66;
-    mi.keep_block_data.assign(77, 0.0);
-    std::memcpy(mi.keep_block_data.data(), para_ex[0], 56);
-    for (int i = 1; i <= WINDOW_SIZE; i++) std::memcpy(mi.keep_block_data.data() + 7 * i, para_pose[i], 56);
-    // addr_shift :1390-1396: the kept blocks ex, pose1 .. pose10 alias para_ex[0], para_pose[0] .. para_pose[9] from now on
-    mi.parameter_blocks.assign(1, -1);
-    for (int i = 0; i < WINDOW_SIZE; i++) mi.parameter_blocks.push_back(i);
-    mi.present = true;
-    mi.valid = false;      // never set by the reference either
+    for (int i = 0; i <= WINDOW_SIZE; i++) std::memcpy(pk->poses + 7 * i, para_pose[i], 56);
+    std::memcpy(pk->ex, para_ex[0], 56);
+    std::memcpy(pk->laser01, L0_R[0].m, 72); std::memcpy(pk->laser01 + 9, L0_R[1].m, 72);
+    std::memcpy(pk->laser01 + 18, L0_T[0].v, 24); std::memcpy(pk->laser01 + 21, L0_T[1].v, 24);
+    for (int k = 0; k < 6; k++) pk->laser_info[k * 7] = p_.LASER_W * p_.FACTOR_WEIGHT;
+    pk->mono_info[0] = pk->mono_info[3] = p_.FACTOR_WEIGHT; pk->mono_info[1] = pk->mono_info[2] = 0;
     margin_calls[0]++;
+    auto job = [h, &mi, pk]() {
+        const int feat_off[2] = { 0, pk->f0 }, obs_off[2] = { 0, (int)pk->obs_feat.size() };
+        mi.linearized_jacobians.assign(66 * 66, 0.0); mi.linearized_residuals.assign(66, 0.0);
+        const int dummy = 0; const double dzero = 0.0;
+        h->check(lmono_marginalize(h->get(), 1, feat_off, obs_off, pk->poses, pk->ex, pk->invd.empty() ? &dzero : pk->invd.data(),
+                                   pk->obs_feat.empty() ? &dummy : pk->obs_feat.data(), pk->obs_j.empty() ? &dummy : pk->obs_j.data(),
+                                   pk->obs_pts.empty() ? &dzero : pk->obs_pts.data(), pk->laser01, pk->laser_info, pk->mono_info,
+                                   mi.linearized_jacobians.data(), mi.linearized_residuals.data(), &mi.status), "lmono_marginalize");
+        mi.m = 6 + pk->f0; mi.n = 66;
+        mi.keep_block_data.assign(77, 0.0);
+        std::memcpy(mi.keep_block_data.data(), pk->ex, 56);
+        for (int i = 1; i <= WINDOW_SIZE; i++) std::memcpy(mi.keep_block_data.data() + 7 * i, pk->poses + 7 * i, 56);
+        // addr_shift :1390-1396: the kept blocks ex, pose1 .. pose10 alias para_ex[0], para_pose[0] .. para_pose[9] from now on
+        mi.parameter_blocks.assign(1, -1);
+        for (int i = 0; i < WINDOW_SIZE; i++) mi.parameter_blocks.push_back(i);
+        mi.present = true;
+        mi.valid = false;      // never set by the reference either
+    };
+    if (async_margin_) margin_job_ = std::async(std::launch::async, std::move(job)); else job();
 }
 
 void Estimator::slideWindow()

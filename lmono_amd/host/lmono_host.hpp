@@ -8,7 +8,9 @@
 // HIP library; this file only keeps the list / window bookkeeping that the reference keeps on the host.
 #pragma once
 #include <cstdint>
+#include <future>
 #include <list>
+#include <memory>
 #include <map>
 #include <set>
 #include <stdexcept>
@@ -33,18 +35,21 @@ struct Params {                           // config values used on the hot path 
 
 class HipContext {
 public:
-    explicit HipContext(int device = 0) : ctx_(lmono_create(device))
+    explicit HipContext(int device = 0) : ctx_(lmono_create(device)), device_(device)
     {
         if (!ctx_) throw std::runtime_error("lmono_create failed: no usable gfx950 device (there is no CPU fallback)");
     }
     ~HipContext() { lmono_destroy(ctx_); }
     lmono_ctx *get() const { return ctx_; }
+    int device() const { return device_; }
+    void useOwnStream() { check(lmono_use_own_stream(ctx_), "lmono_use_own_stream"); }   // a non-blocking stream of the library's
     void check(int rc, const char *what) const
     {
         if (rc < 0) throw std::runtime_error(std::string(what) + ": " + lmono_last_error(ctx_));
     }
 private:
     lmono_ctx *ctx_;
+    int device_;
 };
 
 // ---- FeatureManager (track store) ---------------------------------------------------------------------------------
@@ -133,6 +138,13 @@ public:
     // (MarginalizationInfo::valid is never set).  The reference passes the mono pipeline's
     // never-initialised right_pt as the second observation; the mirror passes the tracked point.
     void margin();
+    // Marginalisation overlapped with the next frame (off by default = the reference's inline order).  When on, margin() packs its
+    // inputs and hands the kernel call to a second context on its own HIP stream and a host thread; processImage returns without
+    // waiting and the next frame's solve runs beside it.  Results are the same bytes: nothing reads the prior before the next
+    // margin() (MarginalizationInfo::valid is never set), which waits for the pending one first.  Call marginWait()
+    // before reading last_marginalization_info from outside.
+    void setAsyncMargin(bool on);
+    void marginWait();
     struct MarginalizationInfo {           // include/factor/MarginalizationFactor.h:78-108 (fields used downstream)
         int m = 0, n = 0;
         std::vector<double> linearized_jacobians, linearized_residuals;   // [n*n], [n]
@@ -147,6 +159,9 @@ public:
 private:
     HipContext &hip_;
     lmono_ba_batch *ba_batch_ = nullptr;       // the window problem's device arrays, kept from frame to frame
+    std::unique_ptr<HipContext> margin_hip_;   // setAsyncMargin: the context marginalisation runs on
+    std::future<void> margin_job_;
+    bool async_margin_ = false;
     Params p_;
 };
 

@@ -99,3 +99,28 @@ def test_600_frames_match_the_oracle(oracle, tmp_path):
     print("600-frame replay: %.2f ms per INITED frame, max |dP| %.2e m, max |dq| %.2e vs the oracle" % (ms, dp, dq))
     assert dp < 1e-6 and dq < 1e-7
     assert log[-1][6] > 300 and log[-1][7] >= 5                       # both marginalisation branches, many times
+
+
+def test_overlapped_marginalisation_is_the_same_bytes(oracle, tmp_path):
+    """Estimator::setAsyncMargin: marginalisation on a second context / HIP stream / host thread, overlapped with the next frame.  Every
+    printed quantity (decisions, costs, trajectory, extrinsic) and the digest of the LAST prior -- the end of a chain of MARGIN_OLD /
+    MARGIN_SECOND_NEW steps each consuming the one before -- equal the inline run's bytes; the digest also matches the oracle's prior."""
+    from workloads import s2
+    st = s2.make_stream(200, seed=2, stops=(40, 41, 77))
+    fx = tmp_path / "s2_async.bin"
+    S.write_stream(fx, st, [])
+    runs = []
+    for mode in ("sync", "async"):
+        out = subprocess.run([EXE, str(fx), "-", mode], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        runs.append(out.stdout.splitlines())
+    keep = lambda lines: [ln for ln in lines if not ln.startswith("TIM")]
+    assert keep(runs[0]) == keep(runs[1])
+    pri = [ln for ln in runs[1] if ln.startswith("PRI")][0].split()
+    est, log = S.replay_oracle(st, [])
+    lm = est.last_marg
+    assert int(pri[1]) == lm["m"] and int(pri[4]) == len(lm["blocks"])
+    sj, sr = float((lm["J"] ** 2).sum()), float((lm["r"] ** 2).sum())             # trace(J^T J), b^T A^-1 b: gauge invariant
+    assert abs(float(pri[5]) - sj) <= 1e-6 * sj and abs(float(pri[6]) - sr) <= 1e-6 * max(sr, 1e-12)
+    ms = [float([ln for ln in r if ln.startswith("TIM")][0].split()[2]) for r in runs]
+    print("200-frame replay: %.2f ms per INITED frame inline, %.2f ms with marginalisation overlapped" % (ms[0], ms[1]))
