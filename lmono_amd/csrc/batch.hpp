@@ -31,7 +31,10 @@ struct BatchView {
     int8_t *label;           // [total]
     uint8_t *gap;            // [total] gap[i] = |p[i+1]-p[i]|^2 > 0.05
     int8_t *ring_tmp;        // [total] ring id per input point (-1 = discarded)
-    float *ori_tmp;          // [total] -atan2(y, x) per input point
+    int *seg_hist;           // [(total >> 10) + n_scans + 1][64] ring histogram of every 1024-point segment, then its exclusive prefix within the scan
+    int *scan_ends;          // [n_scans][2] first / last valid input point (-1: none)
+    int *scan_half;          // [n_scans] first input point past the half sweep (INT_MAX: none)
+    float *scan_ori;         // [n_scans][2] start / end azimuth of the sweep
     int *ring_begin;         // [n_scans][65]
     int *n_cloud;            // [n_scans]
     int *status;             // [n_scans]

@@ -2,8 +2,8 @@
 // source absent from the reference tree, behavioural spec SURVEY.md Appendix A.1).
 //
 // Five kernel stages per batch of scans over HBM-resident SoA/float4 pools:
-//   k_ring_sort  one workgroup per scan: filter, ring id, azimuth, stable counting sort into ring-major order (per-wave
-//                multisplit: every wave owns a contiguous chunk in both passes, no barriers inside the passes)
+//   k_ring_*     filter, ring id, azimuth, stable counting sort into ring-major order: four tile-parallel launches (ends, tag,
+//                offsets, scatter); every wave owns a 1024-point segment in both passes, no barriers inside the passes
 //   k_curvature  one workgroup per 1024-point tile: LDS tile with +-5 halo, curvature and neighbour-gap flags
 //   k_select     one wave per (scan, ring): per-sector edge/planar selection as repeated 64-lane arg-max/arg-min (DPP
 //                reductions) over register-resident (curvature, index) keys with neighbour suppression (no sort needed);
@@ -42,103 +42,123 @@ __device__ __forceinline__ bool point_valid(const float4 &p, float mr2)
 }
 
 // ------------------------------------------------------------------------------------------------
-#ifdef LMONO_RS_PROF
-#define RT(i) { if (blockIdx.x == 3 && threadIdx.x == 0) rt[i] = clock64(); }
-#else
-#define RT(i)
-#endif
-constexpr int kRsT = 256, kRsW = kRsT / 64;    // threads / waves of k_ring_sort (1024 / 512 / 256 / 128 measured 9.5 / 8.7 / 8.4 / 9.5 ms)
-__global__ __launch_bounds__(kRsT) void k_ring_sort(BatchView b)
+// Ring sort = stable counting sort of a scan's valid points into ring-major order, as four tile-parallel launches (round 3: one
+// workgroup per scan kept ~2 long workgroups per wave slot -- a third of the launch was its tail -- and made one scan alone take 1.1 ms):
+//   k_ring_ends     per scan: first / last valid point -> start / end azimuth of the sweep
+//   k_ring_tag      per 4096-point tile: ring id of every point, a [64]-ring histogram per 1024-point wave segment, the first point
+//                   past the half sweep, the last valid point
+//   k_ring_offsets  per scan: exclusive prefix of the segment histograms in segment order (= input order) per ring, ring_begin
+//   k_ring_scatter  per tile: every wave walks its segment in input order with its own running counters (barrier-free multisplit)
+// Segment g of scan s lives in row (off[s] >> 10) + s + g of seg_hist: rows of different scans never collide and need no table.
+constexpr int kRtT = 256, kRtW = kRtT / 64;    // threads / waves of a tile workgroup
+constexpr int kRtSeg = 1024;                   // points per wave segment (4 rounds of 256)
+constexpr int kRtTile = kRtSeg * kRtW;
+constexpr float kRingGuardDeg = 2e-3f;         // 20x the single-precision angle's error bound
+constexpr float kHalfGuardRad = 4e-5f;         // 20x (the float subtractions near 3 pi / 2 round to 5e-7)
+
+__global__ __launch_bounds__(256) void k_ring_ends(BatchView b)
 {
-#ifdef LMONO_RS_PROF
-    long long rt[6];
-#endif
-    RT(0)
     const int s = b.scan0 + blockIdx.x;
     const int64_t off = b.off[s];
     const int n = (int)(b.off[s + 1] - off);
     const float4 *in = b.in + off;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    __shared__ int s_first, s_last, s_half;
-    __shared__ int s_cnt[64], s_base[64];
-    __shared__ int s_hist[kRsW][64];      // pass 1: points per (wave, ring); pass 2: next output position of (wave, ring)
-    __shared__ float s_ori[2];
-    if (tid == 0) { s_first = INT_MAX; s_last = -1; s_half = INT_MAX; }
+    const int tid = threadIdx.x, lane = tid & 63;
+    __shared__ int s_first;
+    if (tid == 0) s_first = INT_MAX;
     __syncthreads();
     const float mr2 = b.min_range * b.min_range;
-    // first / last valid point (they define the sweep's start and end azimuth): almost always inside the first and the
-    // last 1024 points, so only those are read; the full pass runs when one of the two tiles holds no valid point
-    int lf = INT_MAX, ll = -1;
-    {
-        const int i0 = tid, i1 = n - 1 - tid;
-        if (i0 < n && point_valid(in[i0], mr2)) lf = i0;
-        if (i1 >= 0 && point_valid(in[i1], mr2)) ll = i1;
-    }
-    lf = wave_min_i(lf); ll = wave_max_i(ll);
-    if (lane == 0) { atomicMin(&s_first, lf); atomicMax(&s_last, ll); }
-    __syncthreads();
-    if (s_first == INT_MAX || s_last < 0) {
+    // first valid point (it defines the sweep's start azimuth): forward in 256-point chunks until one holds a valid point -- almost always
+    // the first.  The LAST valid point is found by k_ring_tag on its way through the scan (the low rings of a 64-line sensor end a scan with
+    // thousands of points inside min_range; looking for it from here cost a full read of every scan, 1.9 ms of the round-3 front end).
+    for (int c0 = 0; c0 < n; c0 += 256) {
+        const int i = c0 + tid;
+        int lf = (i < n && point_valid(in[i], mr2)) ? i : INT_MAX;
+        lf = wave_min_i(lf);
+        if (lane == 0 && lf != INT_MAX) atomicMin(&s_first, lf);
         __syncthreads();
-        lf = INT_MAX; ll = -1;
-        for (int i = tid; i < n; i += kRsT) {
-            const float4 p = in[i];
-            if (point_valid(p, mr2)) { lf = min(lf, i); ll = max(ll, i); }
-        }
-        lf = wave_min_i(lf); ll = wave_max_i(ll);
-        if (lane == 0) { atomicMin(&s_first, lf); atomicMax(&s_last, ll); }
-        __syncthreads();
+        const int f = s_first;
+        __syncthreads();                   // nobody is in the next chunk's atomicMin before everybody has read this one's result
+        if (f != INT_MAX) break;
     }
-    int *rb = b.ring_begin + s * 65;
-    if (s_last < 0) {
+    if (s_first == INT_MAX) {
+        int *rb = b.ring_begin + s * 65;
         if (tid < 65) rb[tid] = 0;
-        if (tid == 0) b.n_cloud[s] = 0;
+        if (tid == 0) { b.n_cloud[s] = 0; b.scan_ends[s * 2] = -1; b.scan_ends[s * 2 + 1] = -1; b.scan_half[s] = INT_MAX; }
         return;
     }
     if (tid == 0) {
-        const float4 p0 = in[s_first], p1 = in[s_last];
-        const float startOri = (float)(-det_atan2((double)p0.y, (double)p0.x));
-        float endOri = (float)((double)(float)(-det_atan2((double)p1.y, (double)p1.x)) + 2.0 * LM_PI);
-        if ((double)(endOri - startOri) > 3.0 * LM_PI) endOri = (float)((double)endOri - 2.0 * LM_PI);
-        else if ((double)(endOri - startOri) < LM_PI) endOri = (float)((double)endOri + 2.0 * LM_PI);
-        s_ori[0] = startOri; s_ori[1] = endOri;
+        const float4 p0 = in[s_first];
+        b.scan_ori[s * 2] = (float)(-det_atan2((double)p0.y, (double)p0.x));
+        b.scan_ends[s * 2] = s_first; b.scan_ends[s * 2 + 1] = -1;
+        b.scan_half[s] = INT_MAX;
     }
+}
+
+__global__ __launch_bounds__(kRtT) void k_ring_tag(BatchView b)
+{
+    const int s = b.scan0 + blockIdx.y;
+    const int64_t off = b.off[s];
+    const int n = (int)(b.off[s + 1] - off);
+    const int t0 = blockIdx.x * kRtTile;
+    if (t0 >= n || b.scan_ends[s * 2] < 0) return;
+    const float4 *in = b.in + off;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ int s_hist[kRtW][64];
+    s_hist[wave][lane] = 0;
     __syncthreads();
-    RT(1)
-    const float startOri = s_ori[0], endOri = s_ori[1];
+    const float mr2 = b.min_range * b.min_range;
+    const float startOri = b.scan_ori[s * 2];
     const int n_lines = b.n_lines;
-    int lh = INT_MAX;
-    // Every wave owns one contiguous chunk of the scan in BOTH passes: pass 1 leaves a per-(wave, ring) histogram, a prefix
-    // over (ring, wave) turns it into the first output position of every (wave, ring), and pass 2 is then a barrier-free
-    // stable multisplit: a wave walks its chunk in input order with its own running counters.
-    const int chunk = (((n + kRsW - 1) / kRsW) + 255) & ~255;          // points per wave, a multiple of the 256-point round
-    const int c_lo = wave * chunk, c_hi = min(c_lo + chunk, n);
-    for (int i = tid; i < kRsW * 64; i += kRsT) (&s_hist[0][0])[i] = 0;
-    __syncthreads();
-    // four points per thread and round: their loads are in flight together (the sweep is bandwidth-bound)
-    for (int t0 = c_lo; t0 < c_hi; t0 += 256) {
+    int lh = INT_MAX, ll = -1;
+    const int c_lo = t0 + wave * kRtSeg, c_hi = min(c_lo + kRtSeg, n);
+    // four points per thread and round: their loads are in flight together
+    for (int r0 = c_lo; r0 < c_hi; r0 += 256) {
         float4 pq[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) { const int i = t0 + 64 * q + lane; pq[q] = i < c_hi ? in[i] : make_float4(NAN, 0.f, 0.f, 0.f); }
+        for (int q = 0; q < 4; q++) { const int i = r0 + 64 * q + lane; pq[q] = i < c_hi ? in[i] : make_float4(NAN, 0.f, 0.f, 0.f); }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int i = t0 + 64 * q + lane;
+            const int i = r0 + 64 * q + lane;
             const float4 p = pq[q];
             int id = -1;
-            float ori = 0.f;
             if (i < c_hi && point_valid(p, mr2)) {
-                const float angle = (float)(det_atan((double)p.z / sqrt((double)(p.x * p.x + p.y * p.y))) * 180.0 / LM_PI);
-                bool discard;
-                const int r = ring_of(angle, n_lines, discard);
-                if (!discard) {
-                    id = r;
-                    ori = (float)(-det_atan2((double)p.y, (double)p.x));
-                    float o1 = ori;
-                    if ((double)o1 < (double)startOri - LM_PI / 2.0) o1 = (float)((double)o1 + 2.0 * LM_PI);
-                    else if ((double)o1 > (double)startOri + LM_PI * 3.0 / 2.0) o1 = (float)((double)o1 - 2.0 * LM_PI);
-                    if ((double)(o1 - startOri) > LM_PI) lh = min(lh, i);
+                ll = i;                        // i grows with q and r0: the lane's last valid point so far
+                // Ring id and the half-sweep test decide between alternatives, so single-precision angles settle them whenever the
+                // answer is the same over the whole error interval (ring_of is monotone in the angle; the half test has three
+                // thresholds); the fp64 forms run only for the points that fall inside a guard band (and for x = y = 0).
+                const float q2 = p.x * p.x + p.y * p.y;
+                bool exact = !(q2 > 1e-30f);
+                bool discard = false, past_half = false;
+                if (!exact) {
+                    const float af = atanf(p.z * __frsqrt_rn(q2)) * 57.29577951308232f;      // |error| < 1e-4 deg (2 ulp atanf, 1 ulp rsqrt)
+                    bool d0, d1;
+                    const int r0i = ring_of(af - kRingGuardDeg, n_lines, d0), r1i = ring_of(af + kRingGuardDeg, n_lines, d1);
+                    if (d0 != d1 || (!d0 && r0i != r1i)) exact = true;
+                    else { discard = d0; id = d0 ? -1 : r0i; }
                 }
+                if (!exact && !discard) {
+                    const float dr = -atan2f(p.y, p.x) - startOri;                               // |error| < 2e-6 rad
+                    float dw = dr;
+                    if (dr < -(float)LM_PI_2) dw = dr + 2.0f * (float)LM_PI;
+                    else if (dr > 1.5f * (float)LM_PI) dw = dr - 2.0f * (float)LM_PI;
+                    if (fabsf(dr + (float)LM_PI_2) < kHalfGuardRad || fabsf(dr - 1.5f * (float)LM_PI) < kHalfGuardRad || fabsf(dw - (float)LM_PI) < kHalfGuardRad) exact = true;
+                    else past_half = dw > (float)LM_PI;
+                }
+                if (exact) {
+                    const float angle = (float)(det_atan((double)p.z / sqrt((double)(p.x * p.x + p.y * p.y))) * 180.0 / LM_PI);
+                    const int r = ring_of(angle, n_lines, discard);
+                    id = -1; past_half = false;
+                    if (!discard) {
+                        id = r;
+                        float o1 = (float)(-det_atan2((double)p.y, (double)p.x));
+                        if ((double)o1 < (double)startOri - LM_PI / 2.0) o1 = (float)((double)o1 + 2.0 * LM_PI);
+                        else if ((double)o1 > (double)startOri + LM_PI * 3.0 / 2.0) o1 = (float)((double)o1 - 2.0 * LM_PI);
+                        past_half = (double)(o1 - startOri) > LM_PI;
+                    }
+                }
+                if (past_half) lh = min(lh, i);
             }
-            if (i < c_hi) { b.ring_tmp[off + i] = (int8_t)id; b.ori_tmp[off + i] = ori; }
+            if (i < c_hi) b.ring_tmp[off + i] = (int8_t)id;
             // histogram of the sub-tile by ballot matching (ring-major input: one or two rings per 64 points)
             unsigned long long rem = __ballot(id >= 0);
             while (rem) {
@@ -150,44 +170,73 @@ __global__ __launch_bounds__(kRsT) void k_ring_sort(BatchView b)
             }
         }
     }
-    lh = wave_min_i(lh);
-    if (lane == 0 && lh != INT_MAX) atomicMin(&s_half, lh);
+    lh = wave_min_i(lh); ll = wave_max_i(ll);
+    if (lane == 0 && lh != INT_MAX) atomicMin(&b.scan_half[s], lh);
+    if (lane == 0 && ll >= 0) atomicMax(&b.scan_ends[s * 2 + 1], ll);
     __syncthreads();
-    // ring totals -> ring_begin; first output position of every (wave, ring)
-    if (tid < 64) {
-        int t = 0;
-        for (int w = 0; w < kRsW; w++) t += s_hist[w][tid];
-        s_cnt[tid] = t;
+    if (c_lo < n) b.seg_hist[((size_t)(off >> 10) + (size_t)s + (size_t)(c_lo >> 10)) * 64 + lane] = s_hist[wave][lane];
+}
+
+__global__ __launch_bounds__(64) void k_ring_offsets(BatchView b)
+{
+    const int s = b.scan0 + blockIdx.x;
+    if (b.scan_ends[s * 2] < 0) return;
+    const int64_t off = b.off[s];
+    const int n = (int)(b.off[s + 1] - off);
+    const int nseg = (n + kRtSeg - 1) / kRtSeg, r = threadIdx.x;
+    if (r == 0) {                                  // end azimuth of the sweep from the last valid point k_ring_tag found
+        const float4 p1 = b.in[off + b.scan_ends[s * 2 + 1]];
+        const float startOri = b.scan_ori[s * 2];
+        float endOri = (float)((double)(float)(-det_atan2((double)p1.y, (double)p1.x)) + 2.0 * LM_PI);
+        if ((double)(endOri - startOri) > 3.0 * LM_PI) endOri = (float)((double)endOri - 2.0 * LM_PI);
+        else if ((double)(endOri - startOri) < LM_PI) endOri = (float)((double)endOri + 2.0 * LM_PI);
+        b.scan_ori[s * 2 + 1] = endOri;
     }
-    __syncthreads();
-    if (tid == 0) {
-        int t = 0;
-        for (int r = 0; r < 64; r++) { rb[r] = t; s_base[r] = t; t += s_cnt[r]; }
-        rb[64] = t;
-        b.n_cloud[s] = t;
+    int *h = b.seg_hist + ((size_t)(off >> 10) + (size_t)s) * 64 + r;
+    int run = 0;
+    int g = 0;
+    for (; g + 8 <= nseg; g += 8) {              // eight rows in flight per round trip
+        int t[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) t[u] = h[(size_t)(g + u) * 64];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { h[(size_t)(g + u) * 64] = run; run += t[u]; }
     }
+    for (; g < nseg; g++) { const int t = h[(size_t)g * 64]; h[(size_t)g * 64] = run; run += t; }
+    // exclusive scan of the ring totals over the 64 lanes
+    int incl = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (r >= o) incl += v; }
+    int *rb = b.ring_begin + s * 65;
+    rb[r] = incl - run;
+    if (r == 63) { rb[64] = incl; b.n_cloud[s] = incl; }
+}
+
+__global__ __launch_bounds__(kRtT) void k_ring_scatter(BatchView b)
+{
+    const int s = b.scan0 + blockIdx.y;
+    const int64_t off = b.off[s];
+    const int n = (int)(b.off[s + 1] - off);
+    const int t0 = blockIdx.x * kRtTile;
+    if (t0 >= n || b.scan_ends[s * 2] < 0) return;
+    const float4 *in = b.in + off;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ int s_pos[kRtW][64];            // next output position of (wave, ring)
+    const int c_lo = t0 + wave * kRtSeg, c_hi = min(c_lo + kRtSeg, n);
+    s_pos[wave][lane] = c_lo < n ? b.seg_hist[((size_t)(off >> 10) + (size_t)s + (size_t)(c_lo >> 10)) * 64 + lane] + b.ring_begin[s * 65 + lane] : 0;
     __syncthreads();
-    {
-        const int w = tid >> 6, r = tid & 63;      // one (wave, ring) per thread
-        int before = s_base[r];
-        for (int w2 = 0; w2 < w; w2++) before += s_hist[w2][r];
-        __syncthreads();
-        s_hist[w][r] = before;
-    }
-    __syncthreads();
-    const int half = s_half;
-    RT(2)
-    for (int t0 = c_lo; t0 < c_hi; t0 += 256) {
+    const float startOri = b.scan_ori[s * 2], endOri = b.scan_ori[s * 2 + 1];
+    const int half = b.scan_half[s];
+    for (int r0 = c_lo; r0 < c_hi; r0 += 256) {
         int id[4], dstp[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) { const int i = t0 + 64 * q + lane; id[q] = (i < c_hi) ? (int)b.ring_tmp[off + i] : -1; }
+        for (int q = 0; q < 4; q++) { const int i = r0 + 64 * q + lane; id[q] = (i < c_hi) ? (int)b.ring_tmp[off + i] : -1; }
         float4 pq[4];
-        float oq[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int i = t0 + 64 * q + lane;
-            pq[q] = make_float4(0.f, 0.f, 0.f, 0.f); oq[q] = 0.f;
-            if (id[q] >= 0) { pq[q] = in[i]; oq[q] = b.ori_tmp[off + i]; }
+            const int i = r0 + 64 * q + lane;
+            pq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (id[q] >= 0) pq[q] = in[i];
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -198,7 +247,7 @@ __global__ __launch_bounds__(kRsT) void k_ring_sort(BatchView b)
                 const int k = __shfl(id[q], src);
                 const unsigned long long m = __ballot(id[q] == k);
                 int base = 0;
-                if (lane == src) { base = s_hist[wave][k]; s_hist[wave][k] = base + __popcll(m); }
+                if (lane == src) { base = s_pos[wave][k]; s_pos[wave][k] = base + __popcll(m); }
                 base = __shfl(base, src);
                 if (id[q] == k) dstp[q] = base + __popcll(m & ((1ull << lane) - 1ull));
                 rem &= ~m;
@@ -206,10 +255,10 @@ __global__ __launch_bounds__(kRsT) void k_ring_sort(BatchView b)
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int i = t0 + 64 * q + lane;
+            const int i = r0 + 64 * q + lane;
             if (id[q] >= 0) {
                 const float4 p = pq[q];
-                float ori = oq[q];
+                float ori = (float)(-det_atan2((double)p.y, (double)p.x));      // the azimuth itself is a result (relTime): always the fp64 form
                 if (i <= half) {
                     if ((double)ori < (double)startOri - LM_PI / 2.0) ori = (float)((double)ori + 2.0 * LM_PI);
                     else if ((double)ori > (double)startOri + LM_PI * 3.0 / 2.0) ori = (float)((double)ori - 2.0 * LM_PI);
@@ -224,10 +273,6 @@ __global__ __launch_bounds__(kRsT) void k_ring_sort(BatchView b)
             }
         }
     }
-    RT(3)
-#ifdef LMONO_RS_PROF
-    if (blockIdx.x == 3 && tid == 0) printf("RSORT n %d | first/last %lld ring+ori %lld scatter %lld\n", n, rt[1]-rt[0], rt[2]-rt[1], rt[3]-rt[2]);
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -245,7 +245,8 @@ extern "C" lmono_scan_batch *lmono_batch_create(lmono_ctx *c, int n_cap, int64_t
     bool ok = true;
     ok = ok && dalloc(b, b->off_d, N + 1);
     ok = ok && dalloc(b, v.cloud, T) && dalloc(b, v.curv, T) && dalloc(b, v.label, T) && dalloc(b, v.gap, T);
-    ok = ok && dalloc(b, v.ring_tmp, T) && dalloc(b, v.ori_tmp, T);
+    ok = ok && dalloc(b, v.ring_tmp, T);
+    ok = ok && dalloc(b, v.seg_hist, ((T >> 10) + N + 1) * 64) && dalloc(b, v.scan_ends, N * 2) && dalloc(b, v.scan_half, N) && dalloc(b, v.scan_ori, N * 2);
     ok = ok && dalloc(b, v.ring_begin, N * 65) && dalloc(b, v.n_cloud, N) && dalloc(b, v.status, N);
     ok = ok && dalloc(b, v.sel_sharp, N * 64 * 6 * 20) && dalloc(b, v.sel_sharp_n, N * 64 * 6);
     ok = ok && dalloc(b, v.sel_flat, N * 64 * 6 * 4) && dalloc(b, v.sel_flat_n, N * 64 * 6);
@@ -292,7 +293,11 @@ static int scanreg_launch(lmono_ctx *c, lmono_scan_batch *b, int scan0, int n_sc
     HIP_TRY(c, hipMemsetAsync(v.sel_todo, 0, sizeof(int), st));
     HIP_TRY(c, hipMemsetAsync(v.li_todo, 0, sizeof(int), st));
     HIP_TRY(c, hipEventRecord(c->ev[0], st));
-    hipLaunchKernelGGL(k_ring_sort, dim3(n_scans), dim3(kRsT), 0, st, v);
+    const int rt_tiles = (int)((max_pts + kRtTile - 1) / kRtTile);
+    hipLaunchKernelGGL(k_ring_ends, dim3(n_scans), dim3(256), 0, st, v);
+    if (rt_tiles > 0) hipLaunchKernelGGL(k_ring_tag, dim3(rt_tiles, n_scans), dim3(kRtT), 0, st, v);
+    hipLaunchKernelGGL(k_ring_offsets, dim3(n_scans), dim3(64), 0, st, v);
+    if (rt_tiles > 0) hipLaunchKernelGGL(k_ring_scatter, dim3(rt_tiles, n_scans), dim3(kRtT), 0, st, v);
     HIP_TRY(c, hipEventRecord(c->ev[1], st));
     const int tiles = (int)((max_pts + kCurvTile - 1) / kCurvTile);
     if (tiles > 0) hipLaunchKernelGGL(k_curvature, dim3(tiles, n_scans), dim3(256), 0, st, v);
