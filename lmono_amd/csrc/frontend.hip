@@ -325,24 +325,23 @@ __global__ __launch_bounds__(256) void k_curvature(BatchView b)
 constexpr int kSelMaxPerLane = (kRingCap / 6 + 1 + 63) / 64;   // 11 elements per lane for the largest legal sector
 constexpr int kSelWaveLds = 2 * kRingCap;                      // picked, gap bytes of one ring
 
-// key of a sector element: (curvature bits, index, suppression reach).  Ordering by the key = ordering by
+// key of a sector element: hi = curvature bits, lo = (index << 8 | suppression reach).  Ordering by (hi, lo) = ordering by
 // (curvature, index), so the arg-max / arg-min over keys reproduces the sort's tie order; the winner's reach rides along.
-__device__ __forceinline__ unsigned long long select_key(float c, int idx, unsigned int reach)
-{
-    return ((unsigned long long)__float_as_uint(c) << 32) | ((unsigned int)idx << 8) | reach;
-}
+// A pick is ONE 32-bit wave reduction: the curvature decides; the winner's low word is read from its lane when a single lane holds the
+// extremum (the rule: equal curvatures in two lanes are rare), a second reduction over the low words settles the ties otherwise.
+__device__ __forceinline__ unsigned int select_lo(int idx, unsigned int reach) { return ((unsigned int)idx << 8) | reach; }
 
 // one sector of one ring, M register slots per lane (element m of a lane is ring-local index sp + lane + 64 m)
 template <int M>
 __device__ __forceinline__ void select_sector(int lane, int j, int sp, int slen, int rbeg, const float *curv, unsigned char *picked,
                                               signed char *label, const unsigned char *gap, int *sel_sh, int *sel_sh_n, int *sel_fl, int *sel_fl_n)
 {
-    unsigned long long key[M];
+    unsigned int kh[M], kl[M];
     unsigned int dead = 0, big = 0, small = 0;     // bit m: suppressed / out of range; curvature > 0.1; < 0.1
 #pragma unroll
     for (int m = 0; m < M; m++) {
         const int e = lane + 64 * m;
-        key[m] = 0ull;
+        kh[m] = 0u; kl[m] = 0u;
         if (e < slen) {
             const int i = sp + e;
             const float c = curv[i];
@@ -351,7 +350,7 @@ __device__ __forceinline__ void select_sector(int lane, int j, int sp, int slen,
             int lf = 0, lb = 0;
             while (lf < 5 && gap[i + lf] == 0) lf++;
             while (lb < 5 && gap[i - lb - 1] == 0) lb++;
-            key[m] = select_key(c, i, (unsigned int)(lf | (lb << 4)));
+            kh[m] = __float_as_uint(c); kl[m] = select_lo(i, (unsigned int)(lf | (lb << 4)));
             if (picked[i]) dead |= 1u << m;
             if ((double)c > 0.1) big |= 1u << m;
             if ((double)c < 0.1) small |= 1u << m;
@@ -360,14 +359,21 @@ __device__ __forceinline__ void select_sector(int lane, int j, int sp, int slen,
     // ---- largest curvature first: <= 2 sharp, <= 20 less sharp
     int largest = 0;
     while (true) {
-        unsigned long long best = 0ull;
         const unsigned int live = big & ~dead;
+        // the lane's own best: slots ascend in index, so ">=" keeps the larger index among equal curvatures (live curvatures are > 0.1: 0 = none)
+        unsigned int bh = 0u, bl = 0u;
 #pragma unroll
-        for (int m = 0; m < M; m++)
-            if ((live >> m) & 1u) best = key[m] > best ? key[m] : best;
-        best = wave_max_key_uniform(best);
-        if (best == 0ull) break;
-        const unsigned int lo = (unsigned int)(best & 0xffffffffull);
+        for (int m = 0; m < M; m++) {
+            const unsigned int h = kh[m] & (unsigned int)((int)(live << (31 - m)) >> 31);
+            const bool t = h >= bh;
+            bh = t ? h : bh; bl = t ? kl[m] : bl;
+        }
+        const unsigned int mh = wave_max_u32_uniform(bh);
+        if (mh == 0u) break;
+        const unsigned long long who = __ballot(bh == mh);
+        unsigned int lo;
+        if ((who & (who - 1ull)) == 0ull) lo = (unsigned int)__builtin_amdgcn_readlane((int)bl, __ffsll((long long)who) - 1);
+        else lo = wave_max_u32_uniform(bh == mh ? bl : 0u);
         const int pind = (int)(lo >> 8), lf = (int)(lo & 15u), lb = (int)((lo >> 4) & 15u);
         largest++;
         if (largest > 20) break;
@@ -384,14 +390,21 @@ __device__ __forceinline__ void select_sector(int lane, int j, int sp, int slen,
     // ---- smallest curvature first: <= 4 flat
     int smallest = 0;
     while (true) {
-        unsigned long long best = ~0ull;
         const unsigned int live = small & ~dead;
+        // "<" keeps the smaller index among equal curvatures; a dead slot reads as ~0 (a live curvature is < 0.1)
+        unsigned int bh = ~0u, bl = ~0u;
 #pragma unroll
-        for (int m = 0; m < M; m++)
-            if ((live >> m) & 1u) best = key[m] < best ? key[m] : best;
-        best = wave_min_key_uniform(best);
-        if (best == ~0ull) break;
-        const unsigned int lo = (unsigned int)(best & 0xffffffffull);
+        for (int m = 0; m < M; m++) {
+            const unsigned int h = kh[m] | ~(unsigned int)((int)(live << (31 - m)) >> 31);
+            const bool t = h < bh;
+            bh = t ? h : bh; bl = t ? kl[m] : bl;
+        }
+        const unsigned int mh = wave_min_u32_uniform(bh);
+        if (mh == ~0u) break;
+        const unsigned long long who = __ballot(bh == mh);
+        unsigned int lo;
+        if ((who & (who - 1ull)) == 0ull) lo = (unsigned int)__builtin_amdgcn_readlane((int)bl, __ffsll((long long)who) - 1);
+        else lo = wave_min_u32_uniform(bh == mh ? bl : ~0u);
         const int pind = (int)(lo >> 8), lf = (int)(lo & 15u), lb = (int)((lo >> 4) & 15u);
         if (lane == 0) { label[pind] = -1; sel_fl[j * 4 + smallest] = rbeg + pind; }
         smallest++;
@@ -407,17 +420,27 @@ __device__ __forceinline__ void select_sector(int lane, int j, int sp, int slen,
     if (lane == 0) sel_fl_n[j] = smallest;
 }
 
+// wave-uniform values as scalars (the compiler cannot prove uniformity of what is loaded through a per-wave index)
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ long long uni64(long long v)
+{
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)v), hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)((unsigned long long)v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+template <typename T> __device__ __forceinline__ T *uni_ptr(T *p) { return (T *)uni64((long long)p); }
+
 // one ring by one wave; cap = ring points the wave's LDS slice (2 * cap bytes at smem_w) can hold
 __device__ __forceinline__ void select_ring(BatchView &b, int r, int s, int lane, unsigned char *smem_w, int cap, bool may_defer)
 {
-    const int64_t off = b.off[s];
+    r = uni(r); s = uni(s);
+    const int64_t off = uni64(b.off[s]);
     const int *rb = b.ring_begin + s * 65;
-    const int rbeg = rb[r], rend = rb[r + 1], len = rend - rbeg;
+    const int rbeg = uni(rb[r]), rend = uni(rb[r + 1]), len = rend - rbeg;
     const int S = rbeg + 5, E = rend - 6;
-    int *sel_sh = b.sel_sharp + (size_t)((s * 64 + r) * kSectors) * 20;
-    int *sel_sh_n = b.sel_sharp_n + (s * 64 + r) * kSectors;
-    int *sel_fl = b.sel_flat + (size_t)((s * 64 + r) * kSectors) * 4;
-    int *sel_fl_n = b.sel_flat_n + (s * 64 + r) * kSectors;
+    int *sel_sh = uni_ptr(b.sel_sharp + (size_t)((s * 64 + r) * kSectors) * 20);
+    int *sel_sh_n = uni_ptr(b.sel_sharp_n + (s * 64 + r) * kSectors);
+    int *sel_fl = uni_ptr(b.sel_flat + (size_t)((s * 64 + r) * kSectors) * 4);
+    int *sel_fl_n = uni_ptr(b.sel_flat_n + (s * 64 + r) * kSectors);
     if (E - S < 6 || len > kRingCap) {
         if (lane < kSectors) { sel_sh_n[lane] = 0; sel_fl_n[lane] = 0; }
         if (lane == 0 && len > kRingCap) atomicOr(&b.status[s], kStatusRingOverflow);
@@ -432,9 +455,9 @@ __device__ __forceinline__ void select_ring(BatchView &b, int r, int s, int lane
     // labels go straight to HBM (zeroed here, ~144 single-byte stores per ring afterwards): the LDS slice only holds the
     // picked and gap bytes, 2 * cap per wave
     unsigned char *picked = smem_w;
-    signed char *label = (signed char *)(b.label + off + rbeg);
+    signed char *label = uni_ptr((signed char *)(b.label + off + rbeg));
     unsigned char *gap = picked + cap;
-    const float *curv = b.curv + off + rbeg;
+    const float *curv = uni_ptr(b.curv + off + rbeg);
     for (int i = lane; i < len; i += 64) { picked[i] = 0; label[i] = 0; gap[i] = b.gap[off + rbeg + i]; }
     const int span = E - S;
     for (int j = 0; j < kSectors; j++) {
@@ -455,7 +478,9 @@ constexpr int kSelSmallCap = 2304, kSelBigGrid = 128;
 
 __global__ __launch_bounds__(256, 8) void k_select(BatchView b, int cap, int from_list)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the wave index as a scalar: ring, scan, the ring's bounds and every output pointer derived from it stay in SGPRs (as VGPRs they
+    // pushed the 64-register budget of 8 waves / SIMD over and the pick loop reloaded a spilled pointer on every pick)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char *smem_w = smem + wave * 2 * cap;
     if (!from_list) {
