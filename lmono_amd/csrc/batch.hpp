@@ -23,6 +23,7 @@ struct BatchView {
     int n_scans;
     int scan0;               // first scan of this launch (the per-scan kernels' grids cover scans scan0 .. scan0 + grid - 1; 0 for a whole batch)
     int n_lines;
+    int n_limit;             // > 0: the ring sort reads only the first n_limit points of a scan's slot (one-scan launches of the online stream)
     int has_grid;            // the hash grids (cg_* / sg_*) of this registration have been built (k_grid_build runs on demand)
     float min_range;
     // ---- ring-sorted cloud (same offsets as the input; n_cloud[s] valid points)

@@ -56,11 +56,19 @@ constexpr int kRtTile = kRtSeg * kRtW;
 constexpr float kRingGuardDeg = 2e-3f;         // 20x the single-precision angle's error bound
 constexpr float kHalfGuardRad = 4e-5f;         // 20x (the float subtractions near 3 pi / 2 round to 5e-7)
 
+// points of scan s the ring sort looks at: the scan's slot, or the first n_limit of it (one-scan launches of the online stream: the rest of
+// the slot is padding)
+__device__ __forceinline__ int ring_scan_points(const BatchView &b, int s, int64_t off)
+{
+    const int n = (int)(b.off[s + 1] - off);
+    return b.n_limit > 0 && b.n_limit < n ? b.n_limit : n;
+}
+
 __global__ __launch_bounds__(256) void k_ring_ends(BatchView b)
 {
     const int s = b.scan0 + blockIdx.x;
     const int64_t off = b.off[s];
-    const int n = (int)(b.off[s + 1] - off);
+    const int n = ring_scan_points(b, s, off);
     const float4 *in = b.in + off;
     const int tid = threadIdx.x, lane = tid & 63;
     __shared__ int s_first;
@@ -98,7 +106,7 @@ __global__ __launch_bounds__(kRtT) void k_ring_tag(BatchView b)
 {
     const int s = b.scan0 + blockIdx.y;
     const int64_t off = b.off[s];
-    const int n = (int)(b.off[s + 1] - off);
+    const int n = ring_scan_points(b, s, off);
     const int t0 = blockIdx.x * kRtTile;
     if (t0 >= n || b.scan_ends[s * 2] < 0) return;
     const float4 *in = b.in + off;
@@ -182,7 +190,7 @@ __global__ __launch_bounds__(64) void k_ring_offsets(BatchView b)
     const int s = b.scan0 + blockIdx.x;
     if (b.scan_ends[s * 2] < 0) return;
     const int64_t off = b.off[s];
-    const int n = (int)(b.off[s + 1] - off);
+    const int n = ring_scan_points(b, s, off);
     const int nseg = (n + kRtSeg - 1) / kRtSeg, r = threadIdx.x;
     if (r == 0) {                                  // end azimuth of the sweep from the last valid point k_ring_tag found
         const float4 p1 = b.in[off + b.scan_ends[s * 2 + 1]];
@@ -216,7 +224,7 @@ __global__ __launch_bounds__(kRtT) void k_ring_scatter(BatchView b)
 {
     const int s = b.scan0 + blockIdx.y;
     const int64_t off = b.off[s];
-    const int n = (int)(b.off[s + 1] - off);
+    const int n = ring_scan_points(b, s, off);
     const int t0 = blockIdx.x * kRtTile;
     if (t0 >= n || b.scan_ends[s * 2] < 0) return;
     const float4 *in = b.in + off;

@@ -280,10 +280,10 @@ static int check_launch(lmono_ctx *c, const char *what)
 
 // The front end (scanRegistration) over scans scan0 .. scan0 + n_scans - 1 of the batch: the per-scan kernels' grids cover n_scans scans, the
 // batch view tells them where they start.  A whole-batch registration is (0, n); the online stream registers one slot at a time.
-static int scanreg_launch(lmono_ctx *c, lmono_scan_batch *b, int scan0, int n_scans, int64_t max_pts)
+static int scanreg_launch(lmono_ctx *c, lmono_scan_batch *b, int scan0, int n_scans, int64_t max_pts, int n_limit = 0)
 {
     BatchView v = b->v;
-    v.scan0 = scan0;
+    v.scan0 = scan0; v.n_limit = n_limit;
     hipStream_t st = c->stream;
     c->ev = c->next_set();
     if (!c->ev) { c->err = "hipEventCreate failed"; return LMONO_ENODEV; }
@@ -966,7 +966,7 @@ extern "C" int lmono_odom_step(lmono_ctx *c, lmono_odom_stream *s, const float *
     float *dst = s->in_d + (size_t)next * s->cap_pts * 4;
     if (n_points > 0) HIP_TRY(c, hipMemcpyAsync(dst, xyzi, (size_t)n_points * 16, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     if (n_points < s->cap_pts) HIP_TRY(c, hipMemsetAsync(dst + (size_t)n_points * 4, 0xff, (size_t)(s->cap_pts - n_points) * 16, st));
-    int rc = scanreg_launch(c, b, next, 1, n_points);
+    int rc = scanreg_launch(c, b, next, 1, n_points, n_points > 0 ? n_points : 1);
     if (rc) return rc;
     b->feat_h.clear();
     int iters[4] = { 0, 0, 0, 0 };
