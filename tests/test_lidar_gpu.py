@@ -62,6 +62,61 @@ def test_scanreg_edge_cases(oracle, gpu_ctx, small_seq):
     _check_scanreg(oracle, batch, cat, o)
 
 
+def _boundary_scan(n_lines, rng, base):
+    """Points placed ON and next to every decision threshold of the ring sort: the elevation angles at which ring_of changes its answer
+    (and the discard limits), azimuths at the three half-sweep thresholds relative to the scan's first point, x = y = 0, and points whose
+    first / last 300 are invalid.  Offsets from 0 to 3e-3 deg / 1e-4 rad straddle the guard bands (2e-3 deg, 4e-5 rad) of k_ring_tag, so
+    both the single-precision decisions and the fp64 forms run."""
+    if n_lines == 64:
+        edges = [2.0 - (k - 0.5) / 3.0 for k in range(0, 34)] + [-8.83 - (k - 0.5) / 2.0 for k in range(0, 34)] + [2.0, -24.33, -8.83]
+    elif n_lines == 32:
+        edges = [(k + 0.0) * 4.0 / 3.0 - 92.0 / 3.0 for k in range(-1, 34)]
+    else:
+        edges = [(k - 0.5) * 2.0 - 15.0 for k in range(-1, 18)]
+    deltas = np.array([0.0, 1e-7, 1e-6, 1e-5, 1e-4, 5e-4, 1.5e-3, 2.5e-3, 3e-3])
+    ang = np.array([e + sgn * d for e in edges for d in deltas for sgn in (-1.0, 1.0)])
+    ang = np.repeat(ang, 3)
+    az = rng.uniform(-np.pi, np.pi, len(ang))
+    rho = rng.uniform(6.0, 60.0, len(ang))
+    pts = np.stack([rho * np.cos(az), rho * np.sin(az), rho * np.tan(np.radians(ang)), rng.uniform(0, 1, len(ang))], 1).astype(np.float32)
+    # azimuth thresholds: ori = -atan2(y, x); start azimuth = that of the scan's first valid point (base[0] after the invalid head)
+    x0, y0 = float(base[0, 0]), float(base[0, 1])
+    start = -np.arctan2(y0, x0)
+    d_az = np.array([0.0, 1e-7, 1e-6, 1e-5, 3e-5, 5e-5, 1e-4])
+    oris = np.array([start + t + sgn * d for t in (np.pi, -np.pi / 2, 1.5 * np.pi, -np.pi, 0.5 * np.pi) for d in d_az for sgn in (-1.0, 1.0)])
+    oris = np.repeat(oris, 4)
+    rho2 = rng.uniform(8.0, 40.0, len(oris))
+    el = np.radians(rng.uniform(-20.0, 1.5, len(oris)) if n_lines == 64 else rng.uniform(-14.0, 14.0, len(oris)))
+    thr = np.stack([rho2 * np.cos(-oris), rho2 * np.sin(-oris), rho2 * np.tan(el), rng.uniform(0, 1, len(oris))], 1).astype(np.float32)
+    axis = np.array([[0, 0, 7.0, 0.5], [0, 0, -9.0, 0.5], [0.0, 1e-20, 8.0, 0.1]], np.float32)        # x = y = 0 (and a denormal radius)
+    dead = np.tile(np.array([[0.5, 0.2, -0.1, 0.0]], np.float32), (300, 1))                           # inside min_range
+    mid = np.concatenate([base[1:], pts, thr, axis], 0)
+    rng.shuffle(mid, axis=0)
+    return np.concatenate([dead, base[:1], mid, dead], 0)
+
+
+@pytest.mark.parametrize("n_lines", [64, 32, 16])
+def test_scanreg_at_the_ring_and_half_sweep_thresholds(oracle, gpu_ctx, n_lines):
+    """k_ring_tag decides ring id and half sweep from single-precision angles inside proven margins and from the fp64 forms next to a
+    threshold: a scan made of threshold points (plus an invalid head and tail, so that the first / last valid point are far from the ends)
+    must still come out bit for bit as the oracle's."""
+    rng = np.random.default_rng(64 + n_lines)
+    w = oracle.S1World(n_az=500, n_rings=n_lines)
+    xyzi, off = w.scans(w.trajectory(2))
+    mr = 5.0 if n_lines == 64 else 0.5
+    scans = []
+    for s in range(2):
+        base = xyzi[off[s]:off[s + 1]]
+        r2 = (base[:, :3].astype(np.float64) ** 2).sum(1)
+        base = base[r2 > (mr + 1.0) ** 2]
+        scans.append(_boundary_scan(n_lines, rng, base))
+    cat = np.concatenate(scans, 0)
+    o = np.concatenate([[0], np.cumsum([len(p) for p in scans])]).astype(np.int64)
+    batch = _register(gpu_ctx, cat, o, n_lines, mr)
+    _check_scanreg(oracle, batch, cat, o, n_lines, mr)
+    assert batch.counts()[:, 0].min() > 1000
+
+
 @pytest.mark.parametrize("n_lines", [16, 32])
 def test_scanreg_other_sensors(oracle, gpu_ctx, n_lines):
     w = oracle.S1World(n_az=600, n_rings=n_lines)
