@@ -1,6 +1,7 @@
 """ctypes binding of include/lmono_hip.h (the drop-in C ABI).  Fails loudly when the library is absent."""
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -107,6 +108,9 @@ class Context:
     def __init__(self, device=0):
         self.L = load_library()
         self._own_stream = False          # the context starts on the null stream
+        # objects created on this context (batches, streams, mappers ...): closed before the context whatever order the
+        # interpreter drops them in -- their destroy calls touch the context's stream
+        self._children = weakref.WeakSet()
         self.h = self.L.lmono_create(int(device))
         if not self.h:
             raise LmonoError("lmono_create(%d) failed: no usable HIP device" % device)
@@ -310,7 +314,9 @@ class Context:
         self.check(self.L.lmono_pose_rebase_d(self.h, C.c_void_p(bases_ptr or 0), n_bases, C.c_void_p(poses_ptr), n))
 
     def close(self):
-        if self.h:
+        if getattr(self, "h", None):
+            for child in list(self._children):
+                child.close()
             self.L.lmono_destroy(self.h)
             self.h = None
 
@@ -360,6 +366,7 @@ class OdomStream:
 
     def __init__(self, ctx, max_points, n_lines=64, min_range=5.0, history=8):
         self.ctx = ctx
+        ctx._children.add(self)
         self.h = ctx.L.lmono_odom_stream_create(ctx.h, int(max_points), int(n_lines), float(min_range), int(history))
         if not self.h:
             raise LmonoError("lmono_odom_stream_create failed: %s" % ctx.L.lmono_last_error(ctx.h).decode())
@@ -393,7 +400,7 @@ class OdomStream:
         return out[:n]
 
     def close(self):
-        if self.h:
+        if getattr(self, "h", None):
             self.ctx.L.lmono_odom_stream_destroy(self.h)
             self.h = None
 
@@ -415,6 +422,7 @@ class ScanBatch:
 
     def __init__(self, ctx, n_scans_cap, total_points_cap):
         self.ctx = ctx
+        ctx._children.add(self)
         self.h = ctx.L.lmono_batch_create(ctx.h, int(n_scans_cap), int(total_points_cap))
         if not self.h:
             raise LmonoError("lmono_batch_create failed: %s" % ctx.L.lmono_last_error(ctx.h).decode())
@@ -503,7 +511,7 @@ class ScanBatch:
         return out[:n]
 
     def close(self):
-        if self.h:
+        if getattr(self, "h", None):
             self.ctx.L.lmono_batch_destroy(self.h)
             self.h = None
 
@@ -527,6 +535,7 @@ class BaBatch:
 
     def __init__(self, ctx, windows):
         self.ctx = ctx
+        ctx._children.add(self)
         d = self._desc(windows)
         self.h = ctx.L.lmono_ba_batch_create(ctx.h, C.byref(d))
         if not self.h:
@@ -575,7 +584,7 @@ class BaBatch:
         return poses, ex, invd, sm
 
     def close(self):
-        if self.h:
+        if getattr(self, "h", None):
             self.ctx.L.lmono_ba_batch_destroy(self.h)
             self.h = None
 
@@ -591,6 +600,7 @@ class Mapper:
 
     def __init__(self, ctx, line_res=0.4, plane_res=0.8):
         self.ctx = ctx
+        ctx._children.add(self)
         L = ctx.L
         L.lmono_mapper_create.restype = C.c_void_p
         L.lmono_mapper_create.argtypes = [C.c_void_p, C.c_float, C.c_float]
@@ -671,6 +681,7 @@ class MapBuilder:
 
     def __init__(self, ctx, camera, max_cloud_points=1 << 18, map_capacity_points=None):
         self.ctx = ctx
+        ctx._children.add(self)
         self.cam = camera
         L = ctx.L
         L.lmono_map_builder_create.restype = C.c_void_p
@@ -754,6 +765,7 @@ class PoseGraph:
 
     def __init__(self, ctx, poses_tq, loops, loop_info):
         self.ctx = ctx
+        ctx._children.add(self)
         L = ctx.L
         L.lmono_pose_graph_create.restype = C.c_void_p
         L.lmono_pose_graph_create.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
