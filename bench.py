@@ -665,8 +665,10 @@ def main():
         else:
             # the rank's chains run over its owned scans (chain 0's lead-in = the previous rank's last scans); then the rank boundaries
             # are validated like the chain boundaries inside a rank: one all-gather of every rank's last increment per round
-            batch.odometry_shard_d(chains, args.lead, lead_r, incr_d.data_ptr())
-            shard_rounds[0] = sharding.validate_rank_boundaries(lambda: incr_d[-1], lambda prev: batch.shard_validate(prev, incr_d.data_ptr()), rank, world)
+            # main pass, then ONE all-gather of every rank's last increment, then one validation of all the rank's boundaries -- the chain
+            # boundaries inside it and the one to the previous rank -- in the same repair rounds
+            batch.odometry_shard_main_d(chains, args.lead, lead_r, incr_d.data_ptr())
+            shard_rounds[0] = sharding.validate_rank_boundaries(lambda: incr_d[-1], lambda prev: batch.shard_validate(prev, incr_d.data_ptr()), rank, world, deferred=True)
         boundary.append(batch.boundary_report())
         ctx.pose_prefix_d(incr_d.data_ptr(), lead_r, n_local, poses_d.data_ptr())
         if world > 1:

@@ -155,8 +155,12 @@ int lmono_odom_boundary_report(lmono_ctx *, lmono_scan_batch *, lmono_boundary_r
  * first `first_owned` of them are the previous rank's (chain 0's lead-in; their increments are not produced).  lmono_odom_shard_d runs
  * the chains over the owned scans; after ONE all-gather of every rank's last increment (incr_d[n - 1]), lmono_odom_shard_validate
  * checks chain 0's warm start against the previous rank's last increment prev_incr_h[7] exactly like an inner boundary and repairs;
- * *changed_last = 1 when this rank's own last increment changed (the next rank must validate again).  incr_d [n][7] as above.     */
+ * *changed_last = 1 when this rank's own last increment changed (the next rank must validate again).  incr_d [n][7] as above.
+ * lmono_odom_shard_main_d is lmono_odom_shard_d WITHOUT the validation of the boundaries inside the rank: the caller exchanges the last
+ * increments right after the main pass and lmono_odom_shard_validate then validates every boundary of the rank -- the external one too --
+ * in one set of repair rounds (prev_incr_h = NULL on the rank that owns the sequence's first scan: inner boundaries only).               */
 int lmono_odom_shard_d(lmono_ctx *, lmono_scan_batch *, int n_chains, int lead, int first_owned, double *incr_d);
+int lmono_odom_shard_main_d(lmono_ctx *, lmono_scan_batch *, int n_chains, int lead, int first_owned, double *incr_d);
 int lmono_odom_shard_validate(lmono_ctx *, lmono_scan_batch *, const double *prev_incr_h, double *incr_d, int *changed_last);
 
 /* Online form: ONE scan per call, as the reference's nodes run (ROS callbacks laserCloudHandler -> laserOdometry at sensor rate; lmono

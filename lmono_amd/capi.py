@@ -12,7 +12,7 @@ MAX_QUERIES = 64 * 6 * 2 + 64 * 6 * 4
 SYMBOLS = [
     "lmono_create", "lmono_destroy", "lmono_last_error", "lmono_set_stream", "lmono_use_own_stream", "lmono_set_option", "lmono_get_option", "lmono_synchronize", "lmono_version",
     "lmono_batch_create", "lmono_batch_destroy", "lmono_scanreg_batch", "lmono_scanreg_batch_h", "lmono_host_alloc", "lmono_host_free", "lmono_batch_stage_h", "lmono_scanreg_batch_staged", "lmono_batch_counts", "lmono_batch_get_cloud",
-    "lmono_batch_get_curvature", "lmono_odom_batch", "lmono_odom_batch_d", "lmono_odom_shard_d", "lmono_odom_shard_validate", "lmono_odom_boundary_report", "lmono_odom_stream_create", "lmono_odom_stream_destroy", "lmono_odom_step", "lmono_odom_stream_scan", "lmono_odom_correspond", "lmono_timing_reset", "lmono_timing_read",
+    "lmono_batch_get_curvature", "lmono_odom_batch", "lmono_odom_batch_d", "lmono_odom_shard_d", "lmono_odom_shard_main_d", "lmono_odom_shard_validate", "lmono_odom_boundary_report", "lmono_odom_stream_create", "lmono_odom_stream_destroy", "lmono_odom_step", "lmono_odom_stream_scan", "lmono_odom_correspond", "lmono_timing_reset", "lmono_timing_read",
     "lmono_pose_prefix_d", "lmono_pose_rebase_d", "lmono_map_refine", "lmono_voxel_filter", "lmono_mapper_create", "lmono_mapper_destroy", "lmono_mapper_reset", "lmono_mapper_process", "lmono_mapper_process_batch", "lmono_mapper_cube",
     "lmono_map_builder_create", "lmono_map_builder_destroy", "lmono_associate_to_map", "lmono_associate_to_map_batch", "lmono_map_builder_depth",
     "lmono_map_builder_cloud", "lmono_map_builder_map", "lmono_map_builder_clear",
@@ -69,6 +69,7 @@ def load_library():
     L.lmono_odom_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.lmono_odom_batch_d.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.lmono_odom_shard_d.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.lmono_odom_shard_main_d.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.lmono_odom_shard_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.lmono_odom_boundary_report.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.lmono_odom_stream_create.restype = C.c_void_p
@@ -486,11 +487,17 @@ class ScanBatch:
         """Rank-local odometry of a scan-range shard: the first `first_owned` scans of the batch are the previous rank's (lead-in)."""
         self.ctx.check(self.ctx.L.lmono_odom_shard_d(self.ctx.h, self.h, n_chains, lead, int(first_owned), C.c_void_p(incr_ptr or 0)))
 
+    def odometry_shard_main_d(self, n_chains, lead, first_owned, incr_ptr=None):
+        """odometry_shard_d without the validation of the rank's inner boundaries: shard_validate (after the exchange of the last
+        increments) then validates every boundary of the rank, the external one too, in one set of repair rounds."""
+        self.ctx.check(self.ctx.L.lmono_odom_shard_main_d(self.ctx.h, self.h, n_chains, lead, int(first_owned), C.c_void_p(incr_ptr or 0)))
+
     def shard_validate(self, prev_incr, incr_ptr=None):
-        """Checks / repairs chain 0's warm start against the previous rank's last increment; True when this rank's last one changed."""
-        prev = np.ascontiguousarray(prev_incr, np.float64).reshape(7)
+        """Checks / repairs chain 0's warm start against the previous rank's last increment (None: the rank owns the sequence's first scan;
+        only valid as the deferred validation after odometry_shard_main_d); True when this rank's last increment changed."""
+        prev = None if prev_incr is None else np.ascontiguousarray(prev_incr, np.float64).reshape(7)
         ch = C.c_int(0)
-        self.ctx.check(self.ctx.L.lmono_odom_shard_validate(self.ctx.h, self.h, prev.ctypes.data, C.c_void_p(incr_ptr or 0), C.byref(ch)))
+        self.ctx.check(self.ctx.L.lmono_odom_shard_validate(self.ctx.h, self.h, None if prev is None else prev.ctypes.data, C.c_void_p(incr_ptr or 0), C.byref(ch)))
         return bool(ch.value)
 
     def boundary_report(self):

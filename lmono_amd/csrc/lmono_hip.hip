@@ -72,6 +72,7 @@ struct lmono_scan_batch {
     bool registered = false;
     bool grid_built = false;       // k_grid_build has run for this registration
     std::vector<int64_t> off_h;
+    bool validation_pending = false;   // lmono_odom_shard_main_d ran: lmono_odom_shard_validate is the batch's first (whole) validation
     std::vector<void *> allocs;
     BatchView v{};
     int64_t *off_d = nullptr;
@@ -777,7 +778,7 @@ static OdomView odom_view(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int l
     return o;
 }
 
-static int odom_run(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, int first, double *incr_d, double *poses_d, bool want_poses)
+static int odom_run(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, int first, double *incr_d, double *poses_d, bool want_poses, bool validate = true)
 {
     if (!c || !b || !b->registered || lead < 0 || first < 0 || first >= b->n_scans) return LMONO_EINVAL;
     const int n = b->n_scans;
@@ -818,7 +819,8 @@ static int odom_run(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, i
     b->brep.n_chains = n_chains;
     // (the repair launches carry no per-kernel events: the correspondence / solve sums of lmono_timing_read are the main pass's; the
     // repair's device time is lmono_boundary_report.repair_ms)
-    if (o.tol > 0.0 && n_chains > 1) { rc = odom_validate(c, b, o, false, true); if (rc) return rc; }
+    b->validation_pending = !validate;
+    if (validate && o.tol > 0.0 && n_chains > 1) { rc = odom_validate(c, b, o, false, true); if (rc) return rc; }
     if (want_poses) hipLaunchKernelGGL(k_pose_prefix, dim3(1), dim3(64), 0, st, (const double *)b->incr, b->poses, first, n);
     HIP_TRY(c, hipEventRecord(c->ev[9], st));
     rc = check_launch(c, "odometry kernels");
@@ -838,17 +840,28 @@ extern "C" int lmono_odom_shard_d(lmono_ctx *c, lmono_scan_batch *b, int n_chain
     return odom_run(c, b, n_chains, lead, first_owned, incr_d, nullptr, false);
 }
 
+extern "C" int lmono_odom_shard_main_d(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, int first_owned, double *incr_d)
+{
+    return odom_run(c, b, n_chains, lead, first_owned, incr_d, nullptr, false, false);
+}
+
 extern "C" int lmono_odom_shard_validate(lmono_ctx *c, lmono_scan_batch *b, const double *prev_incr_h, double *incr_d, int *changed_last)
 {
-    if (!c || !b || !b->registered || !prev_incr_h || b->last_chains < 1 || b->last_first < 1) return LMONO_EINVAL;
+    if (!c || !b || !b->registered || b->last_chains < 1 || (prev_incr_h && b->last_first < 1)) return LMONO_EINVAL;
+    if (!prev_incr_h && !b->validation_pending) return LMONO_EINVAL;     // without an external boundary there is only the deferred validation to run
     HIP_TRY(c, hipSetDevice(c->device));
     OdomView o = odom_view(c, b, b->last_chains, b->last_lead, b->last_first);
     const int n = b->n_scans;
     double before[7], after[7];
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(before, b->incr + (size_t)(n - 1) * 7, sizeof(before), hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemcpy(b->incr + (size_t)(o.first - 1) * 7, prev_incr_h, sizeof(double) * 7, hipMemcpyHostToDevice));
-    if (o.tol > 0.0) { int rc = odom_validate(c, b, o, true, false); if (rc) return rc; }
+    if (prev_incr_h) HIP_TRY(c, hipMemcpy(b->incr + (size_t)(o.first - 1) * 7, prev_incr_h, sizeof(double) * 7, hipMemcpyHostToDevice));
+    // after lmono_odom_shard_main_d this is the batch's ONE validation: the rank boundary (chain 0) goes through the same repair rounds as the
+    // chain boundaries inside the rank instead of a second tail of sequential steps behind them
+    const bool first_call = b->validation_pending;
+    b->validation_pending = false;
+    if (first_call) { b->brep = lmono_boundary_report{}; b->brep.n_chains = b->last_chains; }
+    if (o.tol > 0.0 && (prev_incr_h || b->last_chains > 1)) { int rc = odom_validate(c, b, o, prev_incr_h != nullptr, first_call); if (rc) return rc; }
     HIP_TRY(c, hipMemcpy(after, b->incr + (size_t)(n - 1) * 7, sizeof(after), hipMemcpyDeviceToHost));
     if (changed_last) *changed_last = std::memcmp(before, after, sizeof(before)) != 0 ? 1 : 0;
     if (incr_d) HIP_TRY(c, hipMemcpyAsync(incr_d, b->incr, sizeof(double) * 7 * n, hipMemcpyDeviceToDevice, c->stream));

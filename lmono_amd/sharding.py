@@ -70,12 +70,14 @@ def gather_bases(my_base, group=None):
     return out.view(world, 7)
 
 
-def validate_rank_boundaries(last_incr, validate, rank, world, group=None, max_rounds=None):
+def validate_rank_boundaries(last_incr, validate, rank, world, group=None, max_rounds=None, deferred=False):
     """The rank boundaries of a scan-range shard checked like the chain boundaries inside a rank (lmono_odom_shard_validate): every rank
     publishes its LAST increment (one all-gather of 7 doubles), rank r > 0 hands rank r-1's to `validate(prev_incr [7] numpy) -> bool`
     (True when its own last increment changed by the repair), and the round repeats while any rank reports a change (one all-reduce of a
     flag) -- a repair rarely reaches the end of a rank's range, so this is one round in practice.  last_incr() -> torch tensor [7]
-    float64, the rank's current last increment (on the GPU for RCCL, on the CPU for gloo).  Returns the number of rounds."""
+    float64, the rank's current last increment (on the GPU for RCCL, on the CPU for gloo).  deferred: the ranks ran the main pass only
+    (lmono_odom_shard_main_d); the first round's validate() is then every rank's WHOLE validation -- rank 0 calls validate(None) -- so that the
+    rank boundary is repaired in the same rounds as the chain boundaries inside the rank.  Returns the number of rounds."""
     import torch
     import torch.distributed as dist
     rounds = 0
@@ -87,6 +89,8 @@ def validate_rank_boundaries(last_incr, validate, rank, world, group=None, max_r
         changed = False
         if rank > 0:
             changed = bool(validate(last.view(world, 7)[rank - 1].cpu().numpy()))
+        elif deferred and rounds == 0:
+            changed = bool(validate(None))
         flag = torch.tensor([1.0 if changed else 0.0], dtype=torch.float64, device=mine.device)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
         rounds += 1

@@ -31,9 +31,9 @@ def main():
         b = lmono_amd.ScanBatch(ctx, hi - lo, len(xyzi))
         b.scanreg(d.data_ptr(), off, keepalive=d)
         incr = torch.zeros((hi - lo, 7), dtype=torch.float64, device=dev)
-        b.odometry_shard_d(2, lead, first, incr.data_ptr())
+        b.odometry_shard_main_d(2, lead, first, incr.data_ptr())
         torch.cuda.synchronize()
-        rounds = sharding.validate_rank_boundaries(lambda: incr[-1].cpu(), lambda prev: b.shard_validate(prev, incr.data_ptr()), rank, world)
+        rounds = sharding.validate_rank_boundaries(lambda: incr[-1].cpu(), lambda prev: b.shard_validate(prev, incr.data_ptr()), rank, world, deferred=True)
         rep = b.boundary_report()
         print("rank %d: %d rank-boundary round(s), %d chain(s) re-run, %d pair(s)" % (rank, rounds, rep["chains_rerun"], rep["pairs_rerun"]), flush=True)
         poses = torch.zeros((hi - lo - first, 7), dtype=torch.float64, device=dev)

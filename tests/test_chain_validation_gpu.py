@@ -184,6 +184,24 @@ def test_shard_entry_validates_the_external_boundary(gpu_ctx):
               % (rep["flagged"], rep["pairs_rerun"], np.abs(before - ref_incr[cut:]).max(), np.abs(after - ref_incr[cut:]).max(), changed))
         assert np.abs(after - ref_incr[cut:]).max() < 1e-7
         assert rep["unresolved"] == 0
+        # the deferred flow of bench.py --gpus N: main pass, (exchange,) ONE validation of the three inner boundaries and the external one
+        incr_d.zero_()
+        shard.odometry_shard_main_d(4, lead, lead, incr_d.data_ptr())
+        shard.shard_validate(ref_incr[cut - 1], incr_d.data_ptr())
+        gpu_ctx.synchronize()
+        rep2 = shard.boundary_report()
+        deferred = incr_d.cpu().numpy()[lead:]
+        print("shard, deferred validation: flagged %d of %d chains, pairs re-run %d, rounds %d; max |incr - unsharded| %.2e"
+              % (rep2["flagged"], rep2["n_chains"], rep2["pairs_rerun"], rep2["rounds"], np.abs(deferred - ref_incr[cut:]).max()))
+        assert np.abs(deferred - ref_incr[cut:]).max() < 1e-7 and rep2["unresolved"] == 0
+        print("   per chain: residual", rep2["resid"], "pairs re-run", rep2["rerun"], "| two-step flow:", rep["resid"], rep["rerun"])
+        assert rep2["rounds"] <= rep["rounds"] + 1 and rep2["chains_rerun"] >= 1
+        # the rank that owns the first scan: inner boundaries only; and without a pending validation a NULL boundary is refused
+        shard.odometry_shard_main_d(4, 3, 0, incr_d.data_ptr())
+        shard.shard_validate(None, incr_d.data_ptr())
+        assert shard.boundary_report()["unresolved"] == 0
+        with pytest.raises(lmono_amd.LmonoError):
+            shard.shard_validate(None, incr_d.data_ptr())
     finally:
         gpu_ctx.set_option(gpu_ctx.OPT_BOUNDARY_TOL, 1000)
         shard.close()

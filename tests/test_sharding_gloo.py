@@ -102,7 +102,7 @@ def test_two_rank_pose_graph_rounds_equal_single_process():
     assert np.array_equal(ret[0][0], ret[1][0])                     # both ranks hold bit-identical keyframes
 
 
-def _vb_worker(rank, world, port, ret):
+def _vb_worker(rank, world, port, ret, deferred=False):
     """Rank-boundary validation rounds (lmono_amd.sharding.validate_rank_boundaries) over gloo with a stand-in for the GPU batch:
     `ws` = the rank's own lead-in estimate of the previous rank's last increment, a repair adopts the published one, and on rank 1 the
     repair reaches the end of the rank's range (its last increment changes -> rank 2 must validate again)."""
@@ -116,6 +116,9 @@ def _vb_worker(rank, world, port, ret):
 
     def validate(prev):
         st["calls"] += 1
+        if prev is None:                            # deferred flow, rank 0: the rank's inner boundaries only
+            st["inner_only"] = st.get("inner_only", 0) + 1
+            return False
         if np.abs(prev - st["ws"]).max() <= tol:
             return False
         st["ws"] = prev.copy(); st["repairs"] += 1
@@ -123,8 +126,8 @@ def _vb_worker(rank, world, port, ret):
             st["last"] = st["last"] + 1e-3          # the repair ran to the end of this rank's range
             return True
         return False
-    rounds = sharding.validate_rank_boundaries(lambda: torch.from_numpy(st["last"].copy()), validate, rank, world)
-    ret[rank] = (rounds, st["calls"], st["repairs"], st["ws"], st["last"])
+    rounds = sharding.validate_rank_boundaries(lambda: torch.from_numpy(st["last"].copy()), validate, rank, world, deferred=deferred)
+    ret[rank] = (rounds, st["calls"], st["repairs"], st["ws"], st["last"], st.get("inner_only", 0))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -140,3 +143,17 @@ def test_rank_boundary_validation_rounds_over_gloo():
     assert ret[1][2] == 1 and ret[2][2] == 2
     for r in (1, 2):
         assert np.array_equal(ret[r][3], ret[r - 1][4])      # every rank's warm start is its predecessor's final last increment
+
+
+def test_deferred_rank_boundary_validation_calls_every_rank_once():
+    """Deferred flow (lmono_odom_shard_main_d): the first round's validate() is every rank's whole validation -- rank 0 gets prev = None
+    exactly once -- and the later rounds are the rank boundaries' as before."""
+    world = 3
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_vb_worker, args=(world, 29543, ret, True), nprocs=world, join=True)
+    assert [ret[r][0] for r in range(world)] == [2, 2, 2]
+    assert ret[0][1] == 1 and ret[0][5] == 1 and ret[0][2] == 0          # rank 0: one call, with None, no repair of an external boundary
+    assert ret[1][1] == 2 and ret[2][1] == 2 and ret[1][5] == 0 and ret[2][5] == 0
+    for r in (1, 2):
+        assert np.array_equal(ret[r][3], ret[r - 1][4])
