@@ -599,9 +599,18 @@ def main():
             args.gpus = world              # started by a launcher without --gpus: adopt its world size
         else:
             sys.exit("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
+    # LMONO_BENCH_REHEARSE=1: every rank on cuda:0 and the collectives over gloo on CPU copies -- the multi-rank step of this file run end to
+    # end on a one-GPU box (tests/test_lidar_gpu.py); never a measurement
+    rehearse = world > 1 and os.environ.get("LMONO_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    coll = (lambda t: t.cpu()) if rehearse else (lambda t: t)        # the tensor a collective runs on
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -668,11 +677,11 @@ def main():
             # main pass, then ONE all-gather of every rank's last increment, then one validation of all the rank's boundaries -- the chain
             # boundaries inside it and the one to the previous rank -- in the same repair rounds
             batch.odometry_shard_main_d(chains, args.lead, lead_r, incr_d.data_ptr())
-            shard_rounds[0] = sharding.validate_rank_boundaries(lambda: incr_d[-1], lambda prev: batch.shard_validate(prev, incr_d.data_ptr()), rank, world, deferred=True)
+            shard_rounds[0] = sharding.validate_rank_boundaries(lambda: coll(incr_d[-1]), lambda prev: batch.shard_validate(prev, incr_d.data_ptr()), rank, world, deferred=True)
         boundary.append(batch.boundary_report())
         ctx.pose_prefix_d(incr_d.data_ptr(), lead_r, n_local, poses_d.data_ptr())
         if world > 1:
-            bases = sharding.gather_bases(poses_d[-1].clone())
+            bases = sharding.gather_bases(coll(poses_d[-1].clone())).to(dev)
             # the first owned increment composes onto the previous rank's last pose
             ctx.pose_rebase_d(bases.data_ptr(), rank, poses_d.data_ptr(), n_own)
 
@@ -692,7 +701,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        te = coll(torch.tensor([elapsed], dtype=torch.float64, device=dev))
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
     groups, n_reg, n_odo = ctx.timing()
@@ -718,7 +727,7 @@ def main():
             feat_equal = float((cnt[lead_r:lead_r + m, 1:5] == gc[own_begin:hi]).all())
             sums = np.array([s2, cnt_a, st, sr, cnt_r, 1.0 - feat_equal])
         if world > 1:
-            ts = torch.from_numpy(sums).to(dev)
+            ts = coll(torch.from_numpy(sums).to(dev))
             dist.all_reduce(ts)
             sums = ts.cpu().numpy()
         if sums[1] > 0:

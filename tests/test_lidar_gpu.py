@@ -320,6 +320,30 @@ def test_two_rank_sharded_run_matches_unsharded():
     assert out.stdout.count("max |pose - unsharded|") == 2
 
 
+def test_bench_multi_rank_step_rehearsed_on_one_gpu():
+    """bench.py's N > 1 step end to end -- scan-range shards, the deferred rank-boundary validation, the pose exchange, the reductions of
+    time and tolerance -- with two ranks on cuda:0 and the collectives over gloo (LMONO_BENCH_REHEARSE=1).  The run checks itself against the
+    committed trajectory of the sequential CPU path; here: it finishes, reports two ranks and stays within the tolerance."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LMONO_BENCH_REHEARSE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29537",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--scans", "96", "--chains", "8", "--steps", "2", "--warmup", "1", "--no-extras", "--cpu-sample", "0"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["scans_total"] == 192 and d["scaling"] == "weak"
+    assert d["parity"]["scans_compared"] == 192 and d["parity"]["feature_counts_equal"]
+    assert d["ate_vs_cpu_m"] < 1e-3, d["ate_vs_cpu_m"]
+    assert d["boundary_validation"]["unresolved"] == 0 and d["boundary_validation"]["rank_boundary_rounds"] >= 1
+    print("2-rank rehearsal: %.0f scans/s (not a measurement), ATE vs CPU %.2e m, rank-boundary rounds %s"
+          % (d["value"], d["ate_vs_cpu_m"], d["boundary_validation"]["rank_boundary_rounds"]))
+
+
 def test_api_errors_and_limits(oracle, gpu_ctx, small_seq):
     import torch
     import lmono_amd
