@@ -721,7 +721,8 @@ static int odom_validate(lmono_ctx *c, lmono_scan_batch *b, OdomView o, bool ext
         HIP_TRY(c, hipMemcpyAsync(cnt, b->rcount, sizeof(cnt), hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
         if (very_first) {
-            HIP_TRY(c, hipMemcpy(b->resid_h.data(), b->resid_d, sizeof(double) * n_chains, hipMemcpyDeviceToHost));
+            HIP_TRY(c, hipMemcpyAsync(b->resid_h.data(), b->resid_d, sizeof(double) * n_chains, hipMemcpyDeviceToHost, st));     // on the context
+            HIP_TRY(c, hipStreamSynchronize(st));                                                                                  // stream, not the null one
             for (int ch = 0; ch < n_chains; ch++) R.max_resid = b->resid_h[ch] > R.max_resid ? b->resid_h[ch] : R.max_resid;
         }
         const int nf = (int)cnt[0];
@@ -853,16 +854,18 @@ extern "C" int lmono_odom_shard_validate(lmono_ctx *c, lmono_scan_batch *b, cons
     OdomView o = odom_view(c, b, b->last_chains, b->last_lead, b->last_first);
     const int n = b->n_scans;
     double before[7], after[7];
+    // every copy below is ordered on the context stream (a blocking hipMemcpy would wait for whatever another context has queued on the null stream)
+    HIP_TRY(c, hipMemcpyAsync(before, b->incr + (size_t)(n - 1) * 7, sizeof(before), hipMemcpyDeviceToHost, c->stream));
+    if (prev_incr_h) HIP_TRY(c, hipMemcpyAsync(b->incr + (size_t)(o.first - 1) * 7, prev_incr_h, sizeof(double) * 7, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpy(before, b->incr + (size_t)(n - 1) * 7, sizeof(before), hipMemcpyDeviceToHost));
-    if (prev_incr_h) HIP_TRY(c, hipMemcpy(b->incr + (size_t)(o.first - 1) * 7, prev_incr_h, sizeof(double) * 7, hipMemcpyHostToDevice));
     // after lmono_odom_shard_main_d this is the batch's ONE validation: the rank boundary (chain 0) goes through the same repair rounds as the
     // chain boundaries inside the rank instead of a second tail of sequential steps behind them
     const bool first_call = b->validation_pending;
     b->validation_pending = false;
     if (first_call) { b->brep = lmono_boundary_report{}; b->brep.n_chains = b->last_chains; }
     if (o.tol > 0.0 && (prev_incr_h || b->last_chains > 1)) { int rc = odom_validate(c, b, o, prev_incr_h != nullptr, first_call); if (rc) return rc; }
-    HIP_TRY(c, hipMemcpy(after, b->incr + (size_t)(n - 1) * 7, sizeof(after), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpyAsync(after, b->incr + (size_t)(n - 1) * 7, sizeof(after), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (changed_last) *changed_last = std::memcmp(before, after, sizeof(before)) != 0 ? 1 : 0;
     if (incr_d) HIP_TRY(c, hipMemcpyAsync(incr_d, b->incr, sizeof(double) * 7 * n, hipMemcpyDeviceToDevice, c->stream));
     return LMONO_OK;
