@@ -49,7 +49,11 @@ constexpr int kCfPool = kCfT * kCfPer;        // run descriptors per round
 // first search radius of an unseeded feature (m): the less-sharp cloud is sparse (<= 20 points per ring and sector), the 0.2 m-voxelised
 // less-flat cloud dense.  Any value is exact; measured per bench step: (0.3, 0.3) 49.0 ms, (0.5, 0.3) 48.8, (0.5, 0.2) 48.1, (0.5, 0.15) 47.8,
 // (0.5, 0.1) 48.4, (0.8, 0.3) 49.0; a term proportional to the range did not help.
-constexpr float kCfR0Edge = 0.5f, kCfR0Plane = 0.15f;
+#ifndef LMONO_R0_PLANE
+#define LMONO_R0_PLANE 0.15f
+#define LMONO_R0_EDGE 0.5f
+#endif
+constexpr float kCfR0Edge = LMONO_R0_EDGE, kCfR0Plane = LMONO_R0_PLANE;
 constexpr int kCfU = LMONO_CF_U;               // gathers in flight per lane
 
 struct CfRun {

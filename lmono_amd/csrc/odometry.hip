@@ -650,9 +650,17 @@ constexpr float kArcSlackBins = 0.05f;
 // farther).  0: the neighbouring lines right next to the nearest point (line spacing ~0.006-0.009 rho, voxel spacing 0.2 m);
 // 1: 0.5 m + 5 % of the range; 2: the ring gap of far ground points (rho^2 dtheta / h); 3: DISTANCE_SQ_THRESHOLD.  Non-increasing
 // entries are skipped by the callers.
+// Radii of the walk's passes (a search strategy, not a result: any ascending ladder that ends at 5 m finds the same partners; scripts/ladder_sweep.sh
+// re-measures variants with the index-exact tests in the loop).  Round 3: 0.2 + 0.012 rho / 0.5 + 0.05 rho -> 0.3 + 0.03 rho / 1 + 0.1 rho (-1..2 % of the pass).
+#ifndef LMONO_WR_A0
+#define LMONO_WR_A0 0.3f
+#define LMONO_WR_B0 0.03f
+#define LMONO_WR_A1 1.0f
+#define LMONO_WR_B1 0.1f
+#endif
 __device__ __forceinline__ float walk_radius(int pass, float rho)
 {
-    return pass == 0 ? 0.2f + 0.012f * rho : (pass == 1 ? 0.5f + 0.05f * rho : (pass == 2 ? fminf(5.0f, 1.0f + 0.0045f * rho * rho) : 5.0f));
+    return pass == 0 ? LMONO_WR_A0 + LMONO_WR_B0 * rho : (pass == 1 ? LMONO_WR_A1 + LMONO_WR_B1 * rho : (pass == 2 ? fminf(5.0f, 1.0f + 0.0045f * rho * rho) : 5.0f));
 }
 
 // asin(x) <= x (1 + 0.5708 x^2) on [0, 1] (equality at 0 and 1): conservative arc half-width without libm
