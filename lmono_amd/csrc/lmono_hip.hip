@@ -1151,45 +1151,60 @@ extern "C" int lmono_factor_eval(lmono_ctx *c, int kind, int count, const double
 // ---- BA window solve ---------------------------------------------------------------------------------------------
 struct lmono_ba_batch {
     lmono_ctx *ctx = nullptr;
-    // device arrays in the fixed order ba_fill asks for them; lmono_ba_batch_update reuses every slot that is large enough
-    struct Slot { void *p; size_t bytes; };
-    std::vector<Slot> slots;
-    size_t next_slot = 0;
-    std::vector<void *> retired;          // outgrown slots, freed with the batch
+    // ONE device allocation holds every array of the problem: [uploaded arrays | scratch that starts zeroed], each 256-B aligned, laid out
+    // anew by every ba_fill; ONE pinned host buffer stages the uploaded part.  A frame loop (lmono_ba_batch_update per frame) therefore costs
+    // one H2D copy and one memset per frame instead of 21 pageable copies and 6 memsets, and allocates nothing in steady state.
+    char *blob = nullptr; size_t blob_cap = 0;
+    char *stage = nullptr; size_t stage_cap = 0;
     BaBatch v{};
     int n_windows = 0, total_feat = 0, total_obs = 0;
     double *poses0 = nullptr, *ex0 = nullptr, *invd0 = nullptr;   // initial state for lmono_ba_batch_reset
 };
 
-// next slot of the batch: at least `count` elements, filled from `src` (or zeroed: scratch starts zeroed).  Copies are ordered on
-// the context stream and waited for by ba_fill before the host staging vectors go away.
-template <typename T>
-static bool ba_upload(lmono_ba_batch *b, T *&dst, const T *src, size_t count)
-{
-    const size_t bytes = (count > 0 ? count : 1) * sizeof(T);
-    hipStream_t st = b->ctx->stream;
-    if (b->next_slot == b->slots.size()) b->slots.push_back({ nullptr, 0 });
-    lmono_ba_batch::Slot &s = b->slots[b->next_slot++];
-    if (s.bytes < bytes) {
-        void *q = nullptr;
-        size_t cap = s.bytes ? s.bytes : bytes;
-        while (cap < bytes) cap <<= 1;
-        if (hipMalloc(&q, cap) != hipSuccess) return false;
-        if (s.p) b->retired.push_back(s.p);
-        s.p = q; s.bytes = cap;
+// the arrays of one ba_fill: laid out first (add), then staged / placed in one go (commit)
+struct BaPack {
+    struct Item { void **dst; const void *src; size_t bytes, off; };
+    std::vector<Item> items;
+    size_t up = 0, zero = 0;
+    template <typename T> void add(T *&dst, const T *src, size_t count)
+    {
+        const size_t bytes = (count > 0 ? count : 1) * sizeof(T), al = (bytes + 255) & ~(size_t)255;
+        items.push_back({ (void **)&dst, (const void *)src, src ? count * sizeof(T) : 0, src ? up : zero });
+        (src ? up : zero) += al;
     }
-    dst = (T *)s.p;
-    if (src && count > 0 && hipMemcpyAsync(s.p, src, count * sizeof(T), hipMemcpyHostToDevice, st) != hipSuccess) return false;
-    if (!src && hipMemsetAsync(s.p, 0, bytes, st) != hipSuccess) return false;
-    return true;
-}
+    int commit(lmono_ctx *c, lmono_ba_batch *b)
+    {
+        const size_t total = up + zero;
+        if (b->blob_cap < total) {
+            if (b->blob) HIP_TRY(c, hipFree(b->blob));
+            b->blob = nullptr; b->blob_cap = 0;
+            const size_t cap = total + total / 2;
+            HIP_TRY(c, hipMalloc((void **)&b->blob, cap));
+            b->blob_cap = cap;
+        }
+        if (b->stage_cap < up) {
+            if (b->stage) HIP_TRY(c, hipHostFree(b->stage));
+            b->stage = nullptr; b->stage_cap = 0;
+            const size_t cap = up + up / 2;
+            HIP_TRY(c, hipHostMalloc((void **)&b->stage, cap, hipHostMallocDefault));
+            b->stage_cap = cap;
+        }
+        for (const Item &it : items) {
+            if (it.src) { memcpy(b->stage + it.off, it.src, it.bytes); *it.dst = b->blob + it.off; }
+            else *it.dst = b->blob + up + it.off;
+        }
+        if (up) HIP_TRY(c, hipMemcpyAsync(b->blob, b->stage, up, hipMemcpyHostToDevice, c->stream));
+        if (zero) HIP_TRY(c, hipMemsetAsync(b->blob + up, 0, zero, c->stream));
+        return LMONO_OK;
+    }
+};
 
 extern "C" void lmono_ba_batch_destroy(lmono_ba_batch *b)
 {
     if (!b) return;
     if (b->ctx) (void)hipStreamSynchronize(b->ctx->stream);
-    for (auto &s : b->slots) if (s.p) (void)hipFree(s.p);
-    for (void *p : b->retired) (void)hipFree(p);
+    if (b->blob) (void)hipFree(b->blob);
+    if (b->stage) (void)hipHostFree(b->stage);
     delete b;
 }
 
@@ -1258,7 +1273,6 @@ static int ba_fill(lmono_ctx *c, lmono_ba_batch *b, const lmono_ba_desc *d)
     }
     pair_off[W] = (int)pair_ij.size(); pobs_off[W] = (int)slot_info.size();
     b->ctx = c; b->n_windows = W; b->total_feat = TF; b->total_obs = TO;
-    b->next_slot = 0;
     BaBatch &v = b->v;
     v.n_windows = W; v.max_iter = 30;
     double info[42];
@@ -1266,25 +1280,27 @@ static int ba_fill(lmono_ctx *c, lmono_ba_batch *b, const lmono_ba_desc *d)
     int *feat_off = nullptr, *obs_off = nullptr, *flags = nullptr, *anch = nullptr, *poff = nullptr, *pij = nullptr, *psoff = nullptr, *sinfo_d = nullptr, *pslot_d = nullptr;
     int *fobs_d = nullptr, *oslot_d = nullptr;
     double *spts_d = nullptr, *laser = nullptr, *prior = nullptr, *infod = nullptr;
-    bool ok = ba_upload(b, feat_off, d->feat_off, (size_t)W + 1) && ba_upload(b, obs_off, d->obs_off, (size_t)W + 1) &&
-              ba_upload(b, flags, d->flags, (size_t)W * 4) && ba_upload(b, v.poses, d->poses, (size_t)W * kBaMaxPoses * 7) &&
-              ba_upload(b, v.ex, d->ex, (size_t)W * 7) && ba_upload(b, v.inv_depth, d->inv_depth, (size_t)TF) &&
-              ba_upload(b, anch, anchor.data(), (size_t)TF) &&
-              ba_upload(b, poff, pair_off.data(), (size_t)W + 1) && ba_upload(b, pij, pair_ij.data(), pair_ij.size()) &&
-              ba_upload(b, psoff, pobs_off.data(), (size_t)W + 1) && ba_upload(b, sinfo_d, slot_info.data(), slot_info.size()) &&
-              ba_upload(b, spts_d, slot_pts.data(), slot_pts.size()) && ba_upload(b, pslot_d, pair_slot.data(), pair_slot.size()) &&
-              ba_upload(b, laser, d->laser_consts, (size_t)W * 10 * 24) && ba_upload(b, prior, d->prior_T, (size_t)W * 16) &&
-              ba_upload(b, infod, info, (size_t)42) &&
-              ba_upload(b, b->poses0, d->poses, (size_t)W * kBaMaxPoses * 7) && ba_upload(b, b->ex0, d->ex, (size_t)W * 7) &&
-              ba_upload(b, b->invd0, d->inv_depth, (size_t)TF) &&
-              ba_upload(b, fobs_d, fo.data(), (size_t)TF + 1) && ba_upload(b, oslot_d, slot_obs.data(), slot_obs.size()) &&
-              ba_upload(b, v.obsc, (const double *)nullptr, (size_t)TO * 16) &&
-              ba_upload(b, v.hpd, (const double *)nullptr, (size_t)W * kBaMaxFeat * kBaPS) &&
-              ba_upload(b, v.pairdat, (const double *)nullptr, pair_ij.size() * kBaPairRec) &&
-              ba_upload(b, v.pairH, (const double *)nullptr, pair_ij.size() * kBaPairTile) &&
-              ba_upload(b, v.cand, (const double *)nullptr, (size_t)W * kBaMaxFeat) && ba_upload(b, v.summary, (const double *)nullptr, (size_t)W * 6);
-    if (!ok) { (void)hipStreamSynchronize(c->stream); c->err = "lmono_ba_batch_create: device allocation / upload failed"; return LMONO_ENOMEM; }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));      // the staging vectors above end here
+    const int izero = 0; const double dzero = 0.0;       // a present (non-NULL) source for arrays that may be empty
+    BaPack pk;
+    pk.add(feat_off, d->feat_off, (size_t)W + 1); pk.add(obs_off, d->obs_off, (size_t)W + 1);
+    pk.add(flags, d->flags, (size_t)W * 4); pk.add(v.poses, d->poses, (size_t)W * kBaMaxPoses * 7);
+    pk.add(v.ex, d->ex, (size_t)W * 7); pk.add(v.inv_depth, TF ? d->inv_depth : &dzero, (size_t)TF);
+    pk.add(anch, TF ? anchor.data() : &izero, (size_t)TF);
+    pk.add(poff, pair_off.data(), (size_t)W + 1); pk.add(pij, pair_ij.empty() ? &izero : pair_ij.data(), pair_ij.size());
+    pk.add(psoff, pobs_off.data(), (size_t)W + 1); pk.add(sinfo_d, slot_info.empty() ? &izero : slot_info.data(), slot_info.size());
+    pk.add(spts_d, slot_pts.empty() ? &dzero : slot_pts.data(), slot_pts.size()); pk.add(pslot_d, pair_slot.data(), pair_slot.size());
+    pk.add(laser, d->laser_consts, (size_t)W * 10 * 24); pk.add(prior, d->prior_T, (size_t)W * 16);
+    pk.add(infod, (const double *)info, (size_t)42);
+    pk.add(b->poses0, d->poses, (size_t)W * kBaMaxPoses * 7); pk.add(b->ex0, d->ex, (size_t)W * 7);
+    pk.add(b->invd0, TF ? d->inv_depth : &dzero, (size_t)TF);
+    pk.add(fobs_d, (const int *)fo.data(), (size_t)TF + 1); pk.add(oslot_d, slot_obs.empty() ? &izero : slot_obs.data(), slot_obs.size());
+    pk.add(v.obsc, (const double *)nullptr, (size_t)TO * 16);
+    pk.add(v.hpd, (const double *)nullptr, (size_t)W * kBaMaxFeat * kBaPS);
+    pk.add(v.pairdat, (const double *)nullptr, pair_ij.size() * kBaPairRec);
+    pk.add(v.pairH, (const double *)nullptr, pair_ij.size() * kBaPairTile);
+    pk.add(v.cand, (const double *)nullptr, (size_t)W * kBaMaxFeat); pk.add(v.summary, (const double *)nullptr, (size_t)W * 6);
+    // everything is staged in the batch's pinned buffer: the vectors above may go, and nothing waits here
+    { const int rc = pk.commit(c, b); if (rc) { c->err = "lmono_ba_batch_create: device allocation / upload failed"; return LMONO_ENOMEM; } }
     v.feat_off = feat_off; v.obs_off = obs_off; v.flags = flags; v.feat_anchor = anch;
     v.pair_off = poff; v.pair_ij = pij; v.pobs_off = psoff; v.slot_info = sinfo_d; v.slot_pts = spts_d; v.pair_slot = pslot_d;
     v.laser_consts = laser; v.prior_T = prior; v.info = infod;
