@@ -792,6 +792,10 @@ def main():
                     "frontend_fused_frac": round(37 * N * n_local / (groups["frontend_total"] / max(n_reg, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                     "whole_step_frac": round((37 * N + 0.77e6) * n_local / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
                     "group_ms_per_step": {k: round(v / max(args.steps, 1), 3) for k, v in groups.items() if k != "odometry_launch_pairs"}}
+        if dom == "k_correspond":
+            roofline["note"] = ("exact nearest-neighbour + scan-line walk over a (line, azimuth-bin) index: 16-B gathers of ~2-point runs; the kernel is bound by "
+                                "the CUs' L1 (TCP busy 70 % of a launch, ~2400 line accesses per workgroup and round; profiles/r2/NOTES.md, profiles/r3/NOTES.md 13), "
+                                "not by HBM -- the HBM fraction is reported because SURVEY 8d prices the path in bytes")
         out = {
             "metric": "KITTI HDL-64 scans/sec (scanRegistration + laserOdometry)", "value": round(scans_per_s, 1),
             "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
