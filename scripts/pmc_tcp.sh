@@ -11,7 +11,7 @@ for grp in "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_T
            "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TA_DATA_STALL_CYCLES_sum GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   LMONO_ODOM_STREAMS=1 timeout -k 10 200 rocprofv3 --pmc $grp --output-format csv -d $OUT/g$i -- python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-extras > $OUT/g$i.out 2> $OUT/g$i.err || { echo "group $i failed"; tail -3 $OUT/g$i.err; }
-  python3 scripts/pmc_summary.py $OUT/g$i 2>&1 | grep -E "k_corr_flat|k_ring_sort|k_lm_solve" > $OUT/g$i.summary
+  python3 scripts/pmc_summary.py $OUT/g$i 2>&1 | grep -E "k_corr_flat|k_ring_tag|k_ring_scatter|k_select|k_voxel<9|k_lm_solve" > $OUT/g$i.summary
   cat $OUT/g$i.summary
   rm -rf $OUT/g$i
 done
