@@ -199,12 +199,17 @@ __device__ __forceinline__ void cf_sweep(CfLds &L, const int *tg_c, const int *t
                 off++;
             }
         }
+        // UNCONDITIONAL gathers (an unused slot reads entry 0 of the corner copy, which always exists): behind a branch the compiler sank the first
+        // use of every point into its load's block and waited for each gather in turn (s_waitcnt vmcnt(0) after every global_load_dwordx4 --
+        // rounds 2 and 3 ran with ONE gather in flight per lane whatever kCfU said)
         float4 p[kCfU];
 #pragma unroll
         for (int u = 0; u < kCfU; u++) {
-            p[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (addr[u] != 0xffffffffu) p[u] = ((meta[u] & 0x80) ? pts_s : pts_c)[addr[u]];
+            const bool live = addr[u] != 0xffffffffu;
+            const float4 *src = (live && (meta[u] & 0x80)) ? pts_s : pts_c;
+            p[u] = src[live ? addr[u] : 0u];
         }
+        __builtin_amdgcn_sched_barrier(0);          // the arithmetic below stays below the loads
 #pragma unroll
         for (int u = 0; u < kCfU; u++) {
             if (addr[u] == 0xffffffffu) continue;
