@@ -109,6 +109,11 @@ struct BaLds {
     int ok;
 };
 static_assert(sizeof(BaLds) <= 160 * 1024, "BaLds exceeds the 160 KB LDS of a gfx950 CU");
+// The workgroup's state is a STATIC LDS object (gfx950 takes 160 KB of it).  As dynamic LDS, every out-of-line phase of k_ba_solve found its base through
+// llvm.amdgcn.dynlds.offset.table -- a global_load + s_waitcnt vmcnt(0) that the compiler, short of registers, repeated in front of LDS stores all over
+// the linearisation; a module-scope __shared__ object sits at a link-time address and every access is a ds_ instruction with an immediate.
+__shared__ BaLds g_ba_lds;
+#define BA_BIND_LDS(arg) (void)arg; BaLds &L = g_ba_lds;
 
 __device__ __forceinline__ double block_sum(double v, double *red)
 {
@@ -430,9 +435,10 @@ __device__ __forceinline__ void ba_reduce_pairs(const BaBatch &B, const BaCtx c,
 
 // cost (returned to every thread) and, when kJac, the unscaled normal equations: Hpp, gp, Hdd, gdd in LDS, Hpd in HBM
 template <bool kJac>
-__device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLds &L, const double *poses, const double *ex, const double *invd,
+__device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLds &L_arg, const double *poses, const double *ex, const double *invd,
                                               double *hpd, double *pairdat)
 {
+    BA_BIND_LDS(L_arg)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __syncthreads();
     BA_TICK(kJac ? 0 : 3)
@@ -705,8 +711,9 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
 }
 
 // y = Hs v (Jacobi-scaled), v and y in LDS arrays of length N.  L.gn is used as scratch (it is dead until the next solve).
-__device__ __noinline__ void ba_hs_mul(const BaCtx c, BaLds &L, const double *hpd, const double *v, double *y)
+__device__ __noinline__ void ba_hs_mul(const BaCtx c, BaLds &L_arg, const double *hpd, const double *v, double *y)
 {
+    BA_BIND_LDS(L_arg)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = c.P, F = c.F, N = P + F;
     __syncthreads();
@@ -771,8 +778,9 @@ __device__ __forceinline__ double readlane_d(double v, int l)
 }
 
 // solve (Hs + mu diag(D2)) x = gs by Schur elimination of the depth columns; result in L.gn; returns success to all
-__device__ __noinline__ bool ba_schur_solve(const BaCtx c, BaLds &L, const double *hpd, double mu)
+__device__ __noinline__ bool ba_schur_solve(const BaCtx c, BaLds &L_arg, const double *hpd, double mu)
 {
+    BA_BIND_LDS(L_arg)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, P = c.P, F = c.F;
     const int col = lane & 15, kq = lane >> 4;
     __syncthreads();
@@ -971,8 +979,9 @@ __device__ __noinline__ bool ba_schur_solve(const BaCtx c, BaLds &L, const doubl
 // order in which the pairs' blocks enter H_pp = the order in which a wave-time model (one unit per 32-observation round + one per
 // pair) says they finish, ties by pair index.  A wave's own pairs are in that order too, so the turn-taking cannot deadlock, and
 // because the model is close to the real timing, waves seldom wait for their turn.  Depends on the pair sizes only.
-__device__ __noinline__ void ba_schedule(const BaBatch &B, const BaCtx c, BaLds &L)
+__device__ __noinline__ void ba_schedule(const BaBatch &B, const BaCtx c, BaLds &L_arg)
 {
+    BA_BIND_LDS(L_arg)
     const int tid = threadIdx.x;
     int *fin = (int *)L.u.stage;                          // [n_pairs] modelled finish time, then [n_pairs] wave
     __syncthreads();
@@ -1014,8 +1023,7 @@ __device__ __noinline__ void ba_schedule(const BaBatch &B, const BaCtx c, BaLds 
 
 __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B)
 {
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    BaLds &L = *reinterpret_cast<BaLds *>(smem_raw);
+    BaLds &L = g_ba_lds;
     const int w = blockIdx.x, tid = threadIdx.x;
     BaCtx c;
     c.n_poses = B.flags[w * 4 + 0]; c.use_prior = B.flags[w * 4 + 1]; c.ex_constant = B.flags[w * 4 + 2]; c.use_mono = B.flags[w * 4 + 3];

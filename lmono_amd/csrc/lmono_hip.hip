@@ -137,7 +137,6 @@ extern "C" lmono_ctx *lmono_create(int device)
     if (hipFuncSetAttribute((const void *)k_line_index<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLiLdsHalf) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_line_index<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLiLdsFull) != hipSuccess) { delete c; return nullptr; }
     // the BA-side kernels with large dynamic LDS: per device, so per context (a second context on another GPU needs them too)
-    if (hipFuncSetAttribute((const void *)k_ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BaLds)) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_marginalize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MargLds)) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_marg_second_new, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Marg2Lds)) != hipSuccess) { delete c; return nullptr; }
 #ifdef LMONO_TILE_PROF
@@ -1334,7 +1333,7 @@ extern "C" int lmono_ba_solve(lmono_ctx *c, lmono_ba_batch *b, int max_iteration
     if (b->n_windows <= 0) { c->err = "lmono_ba_solve: the batch holds no problem (failed update)"; return LMONO_EINVAL; }
     HIP_TRY(c, hipSetDevice(c->device));
     b->v.max_iter = max_iterations;
-    hipLaunchKernelGGL(k_ba_solve, dim3(b->n_windows), dim3(kBaT), sizeof(BaLds), c->stream, b->v);
+    hipLaunchKernelGGL(k_ba_solve, dim3(b->n_windows), dim3(kBaT), 0, c->stream, b->v);          // its LDS is static (g_ba_lds)
     return check_launch(c, "k_ba_solve");
 }
 
