@@ -151,12 +151,15 @@ __device__ __forceinline__ void oc_sweep(OcWave &L, const int *tg_c, const int *
                 off++;
             }
         }
+        // unconditional gathers, as in cf_sweep (behind a branch the compiler waits for every gather in turn)
         float4 p[kCfU];
 #pragma unroll
         for (int u = 0; u < kCfU; u++) {
-            p[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (addr[u] != 0xffffffffu) p[u] = ((meta[u] & 0x80) ? pts_s : pts_c)[addr[u]];
+            const bool live = addr[u] != 0xffffffffu;
+            const float4 *src = (live && (meta[u] & 0x80)) ? pts_s : pts_c;
+            p[u] = src[live ? addr[u] : 0u];
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < kCfU; u++) {
             if (addr[u] == 0xffffffffu) continue;
