@@ -15,10 +15,11 @@ g=d["roofline"]["group_ms_per_step"]
 print("[$flags] tests rc=$rc |", d["value"], d["ms_per_step"], "ate", d["ate_vs_cpu_m"], "corr", g["k_correspond"], "odo", g["odometry_total"], "ms/launch", d["roofline"]["ms_per_launch"])
 PY
 done <<'VAR'
--DLMONO_WR_A0=0.3f -DLMONO_WR_B0=0.03f -DLMONO_WR_A1=1.0f -DLMONO_WR_B1=0.1f -DLMONO_R0_PLANE=0.12f -DLMONO_R0_EDGE=0.4f
--DLMONO_WR_A0=0.4f -DLMONO_WR_B0=0.04f -DLMONO_WR_A1=1.5f -DLMONO_WR_B1=0.15f
--DLMONO_WR_A0=0.3f -DLMONO_WR_B0=0.03f -DLMONO_WR_A1=1.5f -DLMONO_WR_B1=0.12f
--DLMONO_WR_A0=0.25f -DLMONO_WR_B0=0.03f -DLMONO_WR_A1=1.0f -DLMONO_WR_B1=0.1f -DLMONO_R0_PLANE=0.1f -DLMONO_R0_EDGE=0.35f
--DLMONO_WR_A0=0.3f -DLMONO_WR_B0=0.04f -DLMONO_WR_A1=1.0f -DLMONO_WR_B1=0.12f
+-DLMONO_WR_A0=0.3f -DLMONO_WR_B0=0.03f -DLMONO_WR_A1=1.0f -DLMONO_WR_B1=0.1f
+-DLMONO_WR_A0=0.5f -DLMONO_WR_B0=0.05f -DLMONO_WR_A1=1.5f -DLMONO_WR_B1=0.15f
+-DLMONO_WR_A0=0.4f -DLMONO_WR_B0=0.06f -DLMONO_WR_A1=2.0f -DLMONO_WR_B1=0.15f
+-DLMONO_WR_A0=0.3f -DLMONO_WR_B0=0.03f -DLMONO_WR_A1=1.0f -DLMONO_WR_B1=0.1f -DLMONO_R0_PLANE=0.25f -DLMONO_R0_EDGE=0.7f
+-DLMONO_WR_A0=0.3f -DLMONO_WR_B0=0.03f -DLMONO_WR_A1=1.0f -DLMONO_WR_B1=0.1f -DLMONO_R0_PLANE=0.1f -DLMONO_R0_EDGE=0.4f
+-DLMONO_WR_A0=0.3f -DLMONO_WR_B0=0.03f -DLMONO_WR_A1=1.0f -DLMONO_WR_B1=0.1f -DLMONO_CF_U=8 -DLMONO_CF_PER=12
 VAR
 cp gpurun_out/ladder/keep.so lmono_amd/lib/liblmono_hip.so; rm gpurun_out/ladder/keep.so
