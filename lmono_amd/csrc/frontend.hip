@@ -435,7 +435,12 @@ __device__ __forceinline__ long long uni64(long long v)
     const unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)v), hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)((unsigned long long)v >> 32));
     return (long long)(((unsigned long long)hi << 32) | lo);
 }
-template <typename T> __device__ __forceinline__ T *uni_ptr(T *p) { return (T *)uni64((long long)p); }
+// (through address space 1: the integer round trip would otherwise leave a generic pointer and flat_ loads / stores behind)
+template <typename T> __device__ __forceinline__ T *uni_ptr(T *p)
+{
+    typedef __attribute__((address_space(1))) T GT;
+    return (T *)(GT *)uni64((long long)p);
+}
 
 // one ring by one wave; cap = ring points the wave's LDS slice (2 * cap bytes at smem_w) can hold
 __device__ __forceinline__ void select_ring(BatchView &b, int r, int s, int lane, unsigned char *smem_w, int cap, bool may_defer)
