@@ -50,7 +50,8 @@ __device__ __constant__ const double kAtanTab[17] = {
     0.78539816339744828
 };
 
-__device__ __forceinline__ double det_atan(double x)
+// tab: kAtanTab, or a copy of it in LDS (a per-lane look-up in the constant table is a global load that is waited for on the spot)
+__device__ __forceinline__ double det_atan(double x, const double *tab = kAtanTab)
 {
     const bool neg = x < 0.0;
     double a = neg ? -x : x;
@@ -68,16 +69,16 @@ __device__ __forceinline__ double det_atan(double x)
     s = 1.0 / 5.0 - z * s;
     s = 1.0 / 3.0 - z * s;
     s = 1.0 - z * s;
-    double r = kAtanTab[k] + t * s;
+    double r = tab[k] + t * s;
     if (inv) r = LM_PI_2 - r;
     return neg ? -r : r;
 }
 
-__device__ __forceinline__ double det_atan2(double y, double x)
+__device__ __forceinline__ double det_atan2(double y, double x, const double *tab = kAtanTab)
 {
-    if (x > 0.0) return det_atan(y / x);
+    if (x > 0.0) return det_atan(y / x, tab);
     if (x < 0.0) {
-        const double r = det_atan(y / x);
+        const double r = det_atan(y / x, tab);
         return (y >= 0.0) ? r + LM_PI : r - LM_PI;
     }
     if (y > 0.0) return LM_PI_2;

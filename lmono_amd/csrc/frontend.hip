@@ -230,6 +230,8 @@ __global__ __launch_bounds__(kRtT) void k_ring_scatter(BatchView b)
     const float4 *in = b.in + off;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __shared__ int s_pos[kRtW][64];            // next output position of (wave, ring)
+    __shared__ double s_atan[17];              // kAtanTab in LDS: the azimuth of every kept point looks it up per lane
+    if (tid < 17) s_atan[tid] = kAtanTab[tid];
     const int c_lo = t0 + wave * kRtSeg, c_hi = min(c_lo + kRtSeg, n);
     s_pos[wave][lane] = c_lo < n ? b.seg_hist[((size_t)(off >> 10) + (size_t)s + (size_t)(c_lo >> 10)) * 64 + lane] + b.ring_begin[s * 65 + lane] : 0;
     __syncthreads();
@@ -237,8 +239,12 @@ __global__ __launch_bounds__(kRtT) void k_ring_scatter(BatchView b)
     const int half = b.scan_half[s];
     for (int r0 = c_lo; r0 < c_hi; r0 += 256) {
         int id[4], dstp[4];
+        // unconditional loads (index clamped into the segment): behind their guards the four byte loads were waited for one by one
+        signed char idb[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) { const int i = r0 + 64 * q + lane; id[q] = (i < c_hi) ? (int)b.ring_tmp[off + i] : -1; }
+        for (int q = 0; q < 4; q++) { const int i = r0 + 64 * q + lane; idb[q] = b.ring_tmp[off + min(i, c_hi - 1)]; }
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const int i = r0 + 64 * q + lane; id[q] = (i < c_hi) ? (int)idb[q] : -1; }
         float4 pq[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -266,7 +272,7 @@ __global__ __launch_bounds__(kRtT) void k_ring_scatter(BatchView b)
             const int i = r0 + 64 * q + lane;
             if (id[q] >= 0) {
                 const float4 p = pq[q];
-                float ori = (float)(-det_atan2((double)p.y, (double)p.x));      // the azimuth itself is a result (relTime): always the fp64 form
+                float ori = (float)(-det_atan2((double)p.y, (double)p.x, s_atan));      // the azimuth itself is a result (relTime): always the fp64 form
                 if (i <= half) {
                     if ((double)ori < (double)startOri - LM_PI / 2.0) ori = (float)((double)ori + 2.0 * LM_PI);
                     else if ((double)ori > (double)startOri + LM_PI * 3.0 / 2.0) ori = (float)((double)ori - 2.0 * LM_PI);
