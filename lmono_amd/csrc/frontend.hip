@@ -911,15 +911,19 @@ __global__ __launch_bounds__(256) void k_compact(BatchView b)
         const int lane = tid & 63, wave = tid >> 6;
         constexpr int kPer = NE / 64;   // 6 consecutive entries per lane
         int c[kPer], sum = 0;
+        // one source array per wave, six unconditional loads per lane in flight together
+        const int *srcp = wave <= 1 ? nsh : (wave == 2 ? nfl : b.lf_n + s * 64);
 #pragma unroll
         for (int q = 0; q < kPer; q++) {
             const int e = lane * kPer + q;
-            int v = 0;
-            if (wave == 0) v = min(nsh[e], 2);
-            else if (wave == 1) v = nsh[e];
-            else if (wave == 2) v = nfl[e];
-            else if (e < kMaxRings) v = b.lf_n[s * 64 + e];
-            c[q] = v; sum += v;
+            const bool on = wave < 3 || e < kMaxRings;
+            c[q] = srcp[on ? e : 0];
+            if (!on) c[q] = 0;
+        }
+#pragma unroll
+        for (int q = 0; q < kPer; q++) {
+            if (wave == 0) c[q] = min(c[q], 2);
+            sum += c[q];
         }
         const int incl = wave_scan_incl(sum);
         int run = incl - sum;
@@ -947,22 +951,47 @@ __global__ __launch_bounds__(256) void k_compact(BatchView b)
     if (tid < 2) s_flag[tid] = 0;
     if (tid >= 128 && tid < 128 + kMaxRings + 1) s_rb[tid - 128] = b.ring_begin[s * 65 + tid - 128];
     __syncthreads();
-    for (int x = tid; x < NE * 20; x += 256) {
-        const int e = x / 20, k = x % 20;
-        if (k < nsh[e]) {
-            const float4 p = cl[ssel[x]];
-            const int pos = pre_ls[e] + k;
-            ls[pos] = p;
+    // four selection slots per thread and turn: the counts come from the LDS prefixes, the index loads and then the point gathers are issued
+    // together (behind per-slot guards the compiler waits for every load in turn: three dependent round trips per slot, 30 slots per thread)
+    for (int x0 = tid; x0 < NE * 20; x0 += 4 * 256) {
+        int pos[4], idx[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int x = x0 + 256 * q, e = x / 20, k = x % 20;
+            pos[q] = (x < NE * 20 && k < pre_ls[e + 1] - pre_ls[e]) ? pre_ls[e] + k : -1;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) idx[q] = ssel[pos[q] >= 0 ? x0 + 256 * q : 0];
+        float4 p4[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const float4 *src = pos[q] >= 0 ? cl + idx[q] : b.cloud; p4[q] = *src; }      // (an unused slot reads the batch's first point)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (pos[q] < 0) continue;
+            const int x = x0 + 256 * q, e = x / 20, k = x % 20;
+            const float4 p = p4[q];
+            ls[pos[q]] = p;
             if (k < 2) sharp[pre_sh[e] + k] = p;
             int v = (int)p.w;
             v = v < 0 ? 0 : (v > 65 ? 65 : v);
-            atomicMin(&s_first[0][v], pos);
-            atomicMax(&s_last[0][v], pos);
+            atomicMin(&s_first[0][v], pos[q]);
+            atomicMax(&s_last[0][v], pos[q]);
         }
     }
-    for (int x = tid; x < NE * 4; x += 256) {
-        const int e = x / 4, k = x % 4;
-        if (k < nfl[e]) flat[pre_fl[e] + k] = cl[fsel[x]];
+    for (int x0 = tid; x0 < NE * 4; x0 += 2 * 256) {
+        int pos[2], idx[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int x = x0 + 256 * q, e = x / 4, k = x % 4;
+            pos[q] = (x < NE * 4 && k < pre_fl[e + 1] - pre_fl[e]) ? pre_fl[e] + k : -1;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; q++) idx[q] = fsel[pos[q] >= 0 ? x0 + 256 * q : 0];
+        float4 p2[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) { const float4 *src = pos[q] >= 0 ? cl + idx[q] : b.cloud; p2[q] = *src; }
+#pragma unroll
+        for (int q = 0; q < 2; q++) if (pos[q] >= 0) flat[pos[q]] = p2[q];
     }
     // less-flat cloud = the rings' voxel outputs back to back: every thread finds the ring of its output index by a binary
     // search over the ring prefix (all loads independent, four per thread in flight)
