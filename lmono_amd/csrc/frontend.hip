@@ -623,13 +623,21 @@ __device__ __forceinline__ void voxel_ring(BatchView &b, int r, int s)
     // the ring's points stay in registers: all loads are issued back to back, and the cell pass needs no second trip
     float4 pr[kVoxSlots];
     unsigned int cand_mask = 0;
+    {
+        // every slot's label and point are requested before the first label is looked at (index clamped into the ring: len >= 12 here);
+        // with the candidate test next to its load the compiler waited for one label byte after the other -- 9 round trips instead of 1
+        signed char lbs[kVoxSlots];
 #pragma unroll
-    for (int m = 0; m < kVoxSlots; m++) {
-        const int i = tid + 256 * m;
-        signed char lb = 1;
-        pr[m] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < len) { lb = label[i]; pr[m] = cl[i]; }
-        if (i >= c_lo && i <= c_hi && lb <= 0) cand_mask |= 1u << m;
+        for (int m = 0; m < kVoxSlots; m++) {
+            const int i = tid + 256 * m, ic = i < len ? i : len - 1;
+            lbs[m] = label[ic]; pr[m] = cl[ic];
+        }
+#pragma unroll
+        for (int m = 0; m < kVoxSlots; m++) {
+            const int i = tid + 256 * m;
+            if (i >= len) pr[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i >= c_lo && i <= c_hi && i < len && lbs[m] <= 0) cand_mask |= 1u << m;
+        }
     }
 #pragma unroll
     for (int m = 0; m < kVoxSlots; m++) {
