@@ -542,7 +542,7 @@ __device__ __forceinline__ void line_index_cloud(const BatchView &b, int s, bool
     for (int base = 0; base < n; base += 4 * kLiT) {      // uniform trip count: the wave reductions need every lane
         float4 p[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) { const int i = base + tid + kLiT * q; p[q] = i < n ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
+        for (int q = 0; q < 4; q++) { const int i = base + tid + kLiT * q; p[q] = src[i < n ? i : 0]; }      // unconditional (clamped): really four in flight
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const bool ok = base + tid + kLiT * q < n;
@@ -606,7 +606,7 @@ __device__ __forceinline__ void line_index_cloud(const BatchView &b, int s, bool
     for (int i0 = tid; i0 < n; i0 += 4 * kLiT) {
         float4 p[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) { const int i = i0 + kLiT * q; p[q] = i < n ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
+        for (int q = 0; q < 4; q++) { const int i = i0 + kLiT * q; p[q] = src[i < n ? i : 0]; }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int i = i0 + kLiT * q;
