@@ -549,29 +549,54 @@ __global__ __launch_bounds__(1024) void k_voxel_cloud(const VoxJob *jobs)
     int bits = 0;
     while (bits < 32 && (max_cell >> bits) != 0u) bits++;
     const int passes = (bits + 3) / 4 > 0 ? (bits + 3) / 4 : 1;
+    // The job's arrays as GLOBAL pointers (loaded from the job struct they are generic: flat_ loads that also tie up the LDS counter), and every
+    // per-chunk loop in blocks of kB elements whose loads are unconditional (clamped index) and therefore in flight together: the kernel is ONE
+    // workgroup per cloud, its time is the sum of its memory round trips -- one at a time it spent ~375 of them per 25 k-point cloud.
+    typedef __attribute__((address_space(1))) const float4 GF4;
+    typedef __attribute__((address_space(1))) unsigned int GU;
+    typedef __attribute__((address_space(1))) int GI;
+    const float4 *gin = (const float4 *)(GF4 *)J.in;          // generic again for float4's operators; the compiler keeps the address space it came through
+    constexpr int kB = 8;
     // contiguous chunk of every thread
     const int chunk = (n + 1023) / 1024;
     const int c_lo = min(tid * chunk, n), c_hi = min(c_lo + chunk, n);
-    for (int i = c_lo; i < c_hi; i++) {
-        const float4 p = J.in[i];
-        const int i0 = (int)(floorf(p.x * inv) - (float)minb0);
-        const int i1 = (int)(floorf(p.y * inv) - (float)minb1);
-        const int i2 = (int)(floorf(p.z * inv) - (float)minb2);
-        J.key_a[i] = (unsigned int)(i0 + i1 * mul1 + i2 * mul2);
-        J.idx_a[i] = i;
+    {
+        GU *ka0 = (GU *)J.key_a; GI *ia0 = (GI *)J.idx_a;
+        for (int i0 = c_lo; i0 < c_hi; i0 += kB) {
+            float4 p[kB];
+#pragma unroll
+            for (int u = 0; u < kB; u++) p[u] = gin[min(i0 + u, c_hi - 1)];
+#pragma unroll
+            for (int u = 0; u < kB; u++) {
+                const int i = i0 + u;
+                if (i >= c_hi) break;
+                const int i0c = (int)(floorf(p[u].x * inv) - (float)minb0);
+                const int i1c = (int)(floorf(p[u].y * inv) - (float)minb1);
+                const int i2c = (int)(floorf(p[u].z * inv) - (float)minb2);
+                ka0[i] = (unsigned int)(i0c + i1c * mul1 + i2c * mul2);
+                ia0[i] = i;
+            }
+        }
     }
     __syncthreads();
-    unsigned int *ka = J.key_a, *kb = J.key_b;
-    int *ia = J.idx_a, *ib = J.idx_b;
+    GU *ka = (GU *)J.key_a, *kb = (GU *)J.key_b;
+    GI *ia = (GI *)J.idx_a, *ib = (GI *)J.idx_b;
     for (int pass = 0; pass < passes; pass++) {
         const int sh = 4 * pass;
         int cnt[16];
 #pragma unroll
         for (int d = 0; d < 16; d++) cnt[d] = 0;
-        for (int i = c_lo; i < c_hi; i++) {
-            const int dgt = (int)((ka[i] >> sh) & 15u);
+        for (int i0 = c_lo; i0 < c_hi; i0 += kB) {
+            unsigned int kk[kB];
 #pragma unroll
-            for (int d = 0; d < 16; d++) cnt[d] += dgt == d;
+            for (int u = 0; u < kB; u++) kk[u] = ka[min(i0 + u, c_hi - 1)];
+#pragma unroll
+            for (int u = 0; u < kB; u++) {
+                if (i0 + u >= c_hi) break;
+                const int dgt = (int)((kk[u] >> sh) & 15u);
+#pragma unroll
+                for (int d = 0; d < 16; d++) cnt[d] += dgt == d;
+            }
         }
 #pragma unroll
         for (int d = 0; d < 16; d++) s_cnt[d][tid] = cnt[d];
@@ -593,40 +618,79 @@ __global__ __launch_bounds__(1024) void k_voxel_cloud(const VoxJob *jobs)
         int off[16];
 #pragma unroll
         for (int d = 0; d < 16; d++) off[d] = s_cnt[d][tid];
-        for (int i = c_lo; i < c_hi; i++) {
-            const unsigned int k = ka[i];
-            const int dgt = (int)((k >> sh) & 15u);
-            int dst = 0;
+        for (int i0 = c_lo; i0 < c_hi; i0 += kB) {
+            unsigned int kk[kB];
+            int ii[kB];
 #pragma unroll
-            for (int d = 0; d < 16; d++) if (dgt == d) { dst = off[d]; off[d]++; }
-            kb[dst] = k; ib[dst] = ia[i];
+            for (int u = 0; u < kB; u++) { const int ic = min(i0 + u, c_hi - 1); kk[u] = ka[ic]; ii[u] = ia[ic]; }
+#pragma unroll
+            for (int u = 0; u < kB; u++) {
+                if (i0 + u >= c_hi) break;
+                const int dgt = (int)((kk[u] >> sh) & 15u);
+                int dst = 0;
+#pragma unroll
+                for (int d = 0; d < 16; d++) if (dgt == d) { dst = off[d]; off[d]++; }
+                kb[dst] = kk[u]; ib[dst] = ii[u];
+            }
         }
         __threadfence_block();
         __syncthreads();
-        unsigned int *tk = ka; ka = kb; kb = tk;
-        int *ti = ia; ia = ib; ib = ti;
+        GU *tk = ka; ka = kb; kb = tk;
+        GI *ti = ia; ia = ib; ib = ti;
     }
     // runs of equal cells -> centroids
     int heads = 0;
-    for (int i = c_lo; i < c_hi; i++) heads += (i == 0 || ka[i] != ka[i - 1]);
+    unsigned int kprev = c_lo > 0 && c_lo < c_hi ? ka[c_lo - 1] : 0u;
+    {
+        unsigned int kp = kprev;
+        for (int i0 = c_lo; i0 < c_hi; i0 += kB) {
+            unsigned int kk[kB];
+#pragma unroll
+            for (int u = 0; u < kB; u++) kk[u] = ka[min(i0 + u, c_hi - 1)];
+#pragma unroll
+            for (int u = 0; u < kB; u++) {
+                const int i = i0 + u;
+                if (i >= c_hi) break;
+                heads += (i == 0 || kk[u] != kp);
+                kp = kk[u];
+            }
+        }
+    }
     const int incl = wave_scan_incl(heads);
     if (lane == 63) s_wsum[wave] = incl;
     __syncthreads();
     int o = incl - heads;
     for (int w = 0; w < wave; w++) o += s_wsum[w];
     if (tid == 1023) s_total = o + heads;
+    typedef __attribute__((address_space(1))) float4 GF4W;
+    float4 *gout = (float4 *)(GF4W *)J.out;
+    unsigned int kp = kprev;
     for (int i = c_lo; i < c_hi; i++) {
-        if (!(i == 0 || ka[i] != ka[i - 1])) continue;
         const unsigned int c = ka[i];
+        const bool head = i == 0 || c != kp;
+        kp = c;
+        if (!head) continue;
         float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
         int cnt = 0;
-        for (int u = i; u < n && ka[u] == c; u++) {
-            const float4 p = J.in[ia[u]];
-            sx += p.x; sy += p.y; sz += p.z; si += p.w;
-            cnt++;
+        // a run's points, four at a time: keys and indices first, then the points (clamped past the end of the cloud; a slot past the run is skipped)
+        for (int u0 = i; u0 < n; u0 += 4) {
+            unsigned int k4[4]; int j4[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int uc = min(u0 + u, n - 1); k4[u] = ka[uc]; j4[u] = ia[uc]; }
+            float4 p4[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) p4[u] = gin[j4[u]];
+            bool more = true;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (!more || u0 + u >= n || k4[u] != c) { more = false; continue; }
+                sx += p4[u].x; sy += p4[u].y; sz += p4[u].z; si += p4[u].w;
+                cnt++;
+            }
+            if (!more) break;
         }
         const float fc = (float)cnt;
-        J.out[o++] = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
+        gout[o++] = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
     }
     __syncthreads();
     if (tid == 0) *J.n_out = s_total;
