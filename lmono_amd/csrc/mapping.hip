@@ -517,21 +517,36 @@ struct VoxJob {
     int *idx_a, *idx_b;            // scratch [n] point indices (ping-pong)
 };
 
+// Round 3: the sort works on COALESCED streams.  Every wave owns a contiguous segment of the array and walks it 64 consecutive elements at a time
+// (lane = element), digit counts and ranks come from ballots, a (digit, wave) prefix gives every wave its first output position per digit: order by
+// (wave segment, round, lane) = index order, so the sort stays stable.  (Until then every THREAD owned a contiguous chunk: 64 cache lines per wave
+// load, one load at a time through generic pointers -- 0.4 ms per 25 k-point cloud, 40 % of a laserMapping frame.)
 __global__ __launch_bounds__(1024) void k_voxel_cloud(const VoxJob *jobs)
 {
     const VoxJob J = jobs[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = J.n;
     if (n <= 0 || n > kVoxCloudMax) { if (tid == 0) *J.n_out = n <= 0 ? 0 : -1; return; }
     __shared__ float s_box[16][6];
-    __shared__ int s_cnt[16][1024];      // digit-major counts / offsets of one radix pass
-    __shared__ int s_wsum[16];
+    __shared__ int s_cnt[16][16];        // [digit][wave] counts, then first output positions
+    __shared__ int s_heads[16];
     __shared__ int s_total;
-    // bounding box
+    typedef __attribute__((address_space(1))) const float4 GF4;
+    typedef __attribute__((address_space(1))) float4 GF4W;
+    typedef __attribute__((address_space(1))) unsigned int GU;
+    typedef __attribute__((address_space(1))) int GI;
+    const float4 *gin = (const float4 *)(GF4 *)J.in;          // generic again for float4's operators; the compiler keeps the address space it came through
+    float4 *gout = (float4 *)(GF4W *)J.out;
+    // bounding box (four points per thread in flight)
     float mn[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, mx[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
-    for (int i = tid; i < n; i += 1024) {
-        const float4 p = J.in[i];
-        mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
-        mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+    for (int i0 = tid; i0 < n; i0 += 4 * 1024) {
+        float4 p[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) p[u] = gin[min(i0 + 1024 * u, n - 1)];          // a clamped slot repeats the last point: harmless for min / max
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            mn[0] = fminf(mn[0], p[u].x); mn[1] = fminf(mn[1], p[u].y); mn[2] = fminf(mn[2], p[u].z);
+            mx[0] = fmaxf(mx[0], p[u].x); mx[1] = fmaxf(mx[1], p[u].y); mx[2] = fmaxf(mx[2], p[u].z);
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1)
@@ -549,88 +564,83 @@ __global__ __launch_bounds__(1024) void k_voxel_cloud(const VoxJob *jobs)
     int bits = 0;
     while (bits < 32 && (max_cell >> bits) != 0u) bits++;
     const int passes = (bits + 3) / 4 > 0 ? (bits + 3) / 4 : 1;
-    // The job's arrays as GLOBAL pointers (loaded from the job struct they are generic: flat_ loads that also tie up the LDS counter), and every
-    // per-chunk loop in blocks of kB elements whose loads are unconditional (clamped index) and therefore in flight together: the kernel is ONE
-    // workgroup per cloud, its time is the sum of its memory round trips -- one at a time it spent ~375 of them per 25 k-point cloud.
-    typedef __attribute__((address_space(1))) const float4 GF4;
-    typedef __attribute__((address_space(1))) unsigned int GU;
-    typedef __attribute__((address_space(1))) int GI;
-    const float4 *gin = (const float4 *)(GF4 *)J.in;          // generic again for float4's operators; the compiler keeps the address space it came through
-    constexpr int kB = 8;
-    // contiguous chunk of every thread
-    const int chunk = (n + 1023) / 1024;
-    const int c_lo = min(tid * chunk, n), c_hi = min(c_lo + chunk, n);
-    {
-        GU *ka0 = (GU *)J.key_a; GI *ia0 = (GI *)J.idx_a;
-        for (int i0 = c_lo; i0 < c_hi; i0 += kB) {
-            float4 p[kB];
-#pragma unroll
-            for (int u = 0; u < kB; u++) p[u] = gin[min(i0 + u, c_hi - 1)];
-#pragma unroll
-            for (int u = 0; u < kB; u++) {
-                const int i = i0 + u;
-                if (i >= c_hi) break;
-                const int i0c = (int)(floorf(p[u].x * inv) - (float)minb0);
-                const int i1c = (int)(floorf(p[u].y * inv) - (float)minb1);
-                const int i2c = (int)(floorf(p[u].z * inv) - (float)minb2);
-                ka0[i] = (unsigned int)(i0c + i1c * mul1 + i2c * mul2);
-                ia0[i] = i;
-            }
-        }
-    }
-    __syncthreads();
     GU *ka = (GU *)J.key_a, *kb = (GU *)J.key_b;
     GI *ia = (GI *)J.idx_a, *ib = (GI *)J.idx_b;
+    // keys in index order
+    for (int i0 = tid; i0 < n; i0 += 4 * 1024) {
+        float4 p[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) p[u] = gin[min(i0 + 1024 * u, n - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + 1024 * u;
+            if (i >= n) break;
+            const int i0c = (int)(floorf(p[u].x * inv) - (float)minb0);
+            const int i1c = (int)(floorf(p[u].y * inv) - (float)minb1);
+            const int i2c = (int)(floorf(p[u].z * inv) - (float)minb2);
+            ka[i] = (unsigned int)(i0c + i1c * mul1 + i2c * mul2);
+            ia[i] = i;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // the wave's segment: a multiple of 64 elements
+    const int seg = (((n + 15) / 16) + 63) & ~63;
+    const int w_lo = min(wave * seg, n), w_hi = min(w_lo + seg, n);
+    const unsigned long long lt = (1ull << lane) - 1ull;
     for (int pass = 0; pass < passes; pass++) {
         const int sh = 4 * pass;
         int cnt[16];
 #pragma unroll
         for (int d = 0; d < 16; d++) cnt[d] = 0;
-        for (int i0 = c_lo; i0 < c_hi; i0 += kB) {
-            unsigned int kk[kB];
+        for (int r0 = w_lo; r0 < w_hi; r0 += 4 * 64) {
+            unsigned int kk[4];
 #pragma unroll
-            for (int u = 0; u < kB; u++) kk[u] = ka[min(i0 + u, c_hi - 1)];
+            for (int u = 0; u < 4; u++) kk[u] = ka[min(r0 + 64 * u + lane, n - 1)];
 #pragma unroll
-            for (int u = 0; u < kB; u++) {
-                if (i0 + u >= c_hi) break;
+            for (int u = 0; u < 4; u++) {
+                const bool ok = r0 + 64 * u + lane < w_hi;
                 const int dgt = (int)((kk[u] >> sh) & 15u);
 #pragma unroll
-                for (int d = 0; d < 16; d++) cnt[d] += dgt == d;
+                for (int d = 0; d < 16; d++) cnt[d] += __popcll(__ballot(ok && dgt == d));
             }
         }
+        if (lane == 0) {
 #pragma unroll
-        for (int d = 0; d < 16; d++) s_cnt[d][tid] = cnt[d];
+            for (int d = 0; d < 16; d++) s_cnt[d][wave] = cnt[d];
+        }
         __syncthreads();
-        // exclusive prefix over the 16 x 1024 counts in (digit, thread) order: thread t owns entries 16 t .. 16 t + 15 of
-        // the flattened array
-        int *flat = &s_cnt[0][0];
-        int local = 0, v16[16];
+        // exclusive prefix over the 256 counts in (digit, wave) order by wave 0: four consecutive entries per lane
+        if (wave == 0) {
+            int *flat = &s_cnt[0][0];
+            int v4[4], local = 0;
 #pragma unroll
-        for (int q = 0; q < 16; q++) { v16[q] = flat[16 * tid + q]; local += v16[q]; }
-        const int incl = wave_scan_incl(local);
-        if (lane == 63) s_wsum[wave] = incl;
-        __syncthreads();
-        int run = incl - local;
-        for (int w = 0; w < wave; w++) run += s_wsum[w];
+            for (int q = 0; q < 4; q++) { v4[q] = flat[4 * lane + q]; local += v4[q]; }
+            int run = wave_scan_incl(local) - local;
 #pragma unroll
-        for (int q = 0; q < 16; q++) { flat[16 * tid + q] = run; run += v16[q]; }
+            for (int q = 0; q < 4; q++) { flat[4 * lane + q] = run; run += v4[q]; }
+        }
         __syncthreads();
         int off[16];
 #pragma unroll
-        for (int d = 0; d < 16; d++) off[d] = s_cnt[d][tid];
-        for (int i0 = c_lo; i0 < c_hi; i0 += kB) {
-            unsigned int kk[kB];
-            int ii[kB];
+        for (int d = 0; d < 16; d++) off[d] = s_cnt[d][wave];
+        for (int r0 = w_lo; r0 < w_hi; r0 += 4 * 64) {
+            unsigned int kk[4];
+            int ii[4];
 #pragma unroll
-            for (int u = 0; u < kB; u++) { const int ic = min(i0 + u, c_hi - 1); kk[u] = ka[ic]; ii[u] = ia[ic]; }
+            for (int u = 0; u < 4; u++) { const int ic = min(r0 + 64 * u + lane, n - 1); kk[u] = ka[ic]; ii[u] = ia[ic]; }
 #pragma unroll
-            for (int u = 0; u < kB; u++) {
-                if (i0 + u >= c_hi) break;
+            for (int u = 0; u < 4; u++) {
+                const bool ok = r0 + 64 * u + lane < w_hi;
                 const int dgt = (int)((kk[u] >> sh) & 15u);
                 int dst = 0;
 #pragma unroll
-                for (int d = 0; d < 16; d++) if (dgt == d) { dst = off[d]; off[d]++; }
-                kb[dst] = kk[u]; ib[dst] = ii[u];
+                for (int d = 0; d < 16; d++) {
+                    const unsigned long long m = __ballot(ok && dgt == d);
+                    if (dgt == d) dst = off[d] + __popcll(m & lt);
+                    off[d] += __popcll(m);
+                }
+                if (ok) { kb[dst] = kk[u]; ib[dst] = ii[u]; }
             }
         }
         __threadfence_block();
@@ -638,59 +648,66 @@ __global__ __launch_bounds__(1024) void k_voxel_cloud(const VoxJob *jobs)
         GU *tk = ka; ka = kb; kb = tk;
         GI *ti = ia; ia = ib; ib = ti;
     }
-    // runs of equal cells -> centroids
+    // runs of equal cells -> centroids, in ascending cell order.  Heads of the wave's segment first (count), then every head lane sums its run
     int heads = 0;
-    unsigned int kprev = c_lo > 0 && c_lo < c_hi ? ka[c_lo - 1] : 0u;
-    {
-        unsigned int kp = kprev;
-        for (int i0 = c_lo; i0 < c_hi; i0 += kB) {
-            unsigned int kk[kB];
-#pragma unroll
-            for (int u = 0; u < kB; u++) kk[u] = ka[min(i0 + u, c_hi - 1)];
-#pragma unroll
-            for (int u = 0; u < kB; u++) {
-                const int i = i0 + u;
-                if (i >= c_hi) break;
-                heads += (i == 0 || kk[u] != kp);
-                kp = kk[u];
-            }
-        }
+    for (int r0 = w_lo; r0 < w_hi; r0 += 64) {
+        const int i = r0 + lane;
+        const bool ok = i < w_hi;
+        const unsigned int k = ka[min(i, n - 1)], kp = ka[max(min(i, n - 1) - 1, 0)];
+        heads += __popcll(__ballot(ok && (i == 0 || k != kp)));
     }
-    const int incl = wave_scan_incl(heads);
-    if (lane == 63) s_wsum[wave] = incl;
+    if (lane == 0) s_heads[wave] = heads;
     __syncthreads();
-    int o = incl - heads;
-    for (int w = 0; w < wave; w++) o += s_wsum[w];
+    int o = 0;
+    for (int w = 0; w < wave; w++) o += s_heads[w];
     if (tid == 1023) s_total = o + heads;
-    typedef __attribute__((address_space(1))) float4 GF4W;
-    float4 *gout = (float4 *)(GF4W *)J.out;
-    unsigned int kp = kprev;
-    for (int i = c_lo; i < c_hi; i++) {
-        const unsigned int c = ka[i];
-        const bool head = i == 0 || c != kp;
-        kp = c;
-        if (!head) continue;
-        float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
-        int cnt = 0;
-        // a run's points, four at a time: keys and indices first, then the points (clamped past the end of the cloud; a slot past the run is skipped)
-        for (int u0 = i; u0 < n; u0 += 4) {
-            unsigned int k4[4]; int j4[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const int uc = min(u0 + u, n - 1); k4[u] = ka[uc]; j4[u] = ia[uc]; }
-            float4 p4[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) p4[u] = gin[j4[u]];
-            bool more = true;
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                if (!more || u0 + u >= n || k4[u] != c) { more = false; continue; }
-                sx += p4[u].x; sy += p4[u].y; sz += p4[u].z; si += p4[u].w;
-                cnt++;
-            }
-            if (!more) break;
+    // Every lane fetches ITS element (key, index: coalesced; point: gathered) -- all of a round's memory traffic in one go --, a head lane then collects
+    // the rest of its run from the lanes behind it with shuffles, in run order (PCL's float summation order); only a run that leaves the 64-element block
+    // goes on through memory.
+    for (int r0 = w_lo; r0 < w_hi; r0 += 64) {
+        const int i = r0 + lane;
+        const bool ok = i < w_hi;
+        const int ic = min(i, n - 1);
+        const unsigned int c = ka[ic], kp = ka[max(ic - 1, 0)];
+        const float4 pt = gin[ia[ic]];
+        const bool head = ok && (i == 0 || c != kp);
+        const unsigned long long hm = __ballot(head);
+        // lanes that continue the run of the lane before them, inside this block and inside the array
+        const unsigned long long cm = __ballot(i < n && lane > 0 && c == kp);
+        // run length behind a head inside the block: consecutive continuation bits after its lane
+        const unsigned long long after = lane < 63 ? (cm >> (lane + 1)) : 0ull;
+        const int rl = head ? (int)__builtin_ctzll(~after | (1ull << 63)) : 0;
+        const int rl_max = (int)wave_max_i(rl);
+        float sx = pt.x, sy = pt.y, sz = pt.z, si = pt.w;
+        for (int t = 1; t <= rl_max; t++) {
+            const float vx = __shfl_down(pt.x, t), vy = __shfl_down(pt.y, t), vz = __shfl_down(pt.z, t), vw = __shfl_down(pt.w, t);
+            if (t <= rl) { sx += vx; sy += vy; sz += vz; si += vw; }
         }
-        const float fc = (float)cnt;
-        gout[o++] = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
+        if (head) {
+            int cnt = 1 + rl;
+            // the run reaches the end of the block: the rest comes from memory, four at a time (keys and indices first, then the points)
+            if (lane + rl == 63) {
+                for (int u0 = r0 + 64; u0 < n; u0 += 4) {
+                    unsigned int k4[4]; int j4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { const int uc = min(u0 + u, n - 1); k4[u] = ka[uc]; j4[u] = ia[uc]; }
+                    float4 p4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) p4[u] = gin[j4[u]];
+                    bool more = true;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (!more || u0 + u >= n || k4[u] != c) { more = false; continue; }
+                        sx += p4[u].x; sy += p4[u].y; sz += p4[u].z; si += p4[u].w;
+                        cnt++;
+                    }
+                    if (!more) break;
+                }
+            }
+            const float fc = (float)cnt;
+            gout[o + __popcll(hm & lt)] = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
+        }
+        o += __popcll(hm);
     }
     __syncthreads();
     if (tid == 0) *J.n_out = s_total;
