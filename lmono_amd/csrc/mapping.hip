@@ -34,41 +34,100 @@ __global__ __launch_bounds__(1024) void k_cloud_grid(const CloudJob *jobs)
     if (T > J.tcap) { if (tid == 0) *J.mask_out = 0; return; }
     const int mask = T - 1;
     if (tid == 0) *J.mask_out = mask;
-    GridCell *cell = J.cell;
+    // the job's arrays as global pointers (through the job struct they are generic: flat_ loads and flat atomics); four points per thread and turn --
+    // the kernel is ONE workgroup per cloud and a returning global atomic is a ~1 us round trip: one point at a time it was three of them per point
+    typedef __attribute__((address_space(1))) const float4 GF4;
+    typedef __attribute__((address_space(1))) float4 GF4W;
+    typedef __attribute__((address_space(1))) GridCell GCell;
+    typedef __attribute__((address_space(1))) int GI;
+    GridCell *cell = (GridCell *)(GCell *)J.cell;
+    const float4 *gsrc = (const float4 *)(GF4 *)J.src;
+    float4 *gsorted = (float4 *)(GF4W *)J.sorted;
+    GI *slot_of = (GI *)J.slot_of, *rank_of = (GI *)J.rank_of;
     for (int i = tid; i < T; i += 1024) { GridCell e; e.key = kEmptyKey; e.start = 0; e.cnt = 0; cell[i] = e; }
     __threadfence_block();
     __syncthreads();
-    for (int i = tid; i < n; i += 1024) {
-        const float4 p = J.src[i];
-        const unsigned long long key = cell_key((int)floorf(p.x * kInvCell), (int)floorf(p.y * kInvCell), (int)floorf(p.z * kInvCell));
-        unsigned int sl = hash_key(key) & mask;
-        while (true) {
-            const unsigned long long old = atomicCAS(&cell[sl].key, kEmptyKey, key);
-            if (old == kEmptyKey || old == key) break;
-            sl = (sl + 1) & mask;
+    for (int i0 = tid; i0 < n; i0 += 4 * 1024) {
+        float4 p[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) p[u] = gsrc[min(i0 + 1024 * u, n - 1)];
+        unsigned long long key[4];
+        unsigned int sl[4];
+        bool open[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            key[u] = cell_key((int)floorf(p[u].x * kInvCell), (int)floorf(p[u].y * kInvCell), (int)floorf(p[u].z * kInvCell));
+            sl[u] = hash_key(key[u]) & mask;
+            open[u] = i0 + 1024 * u < n;
         }
-        J.slot_of[i] = (int)sl;
-        J.rank_of[i] = atomicAdd(&cell[sl].cnt, 1);
+        // probe rounds: the compare-and-swaps of the four points are issued together
+        while (open[0] || open[1] || open[2] || open[3]) {
+            unsigned long long old[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) old[u] = open[u] ? atomicCAS(&cell[sl[u]].key, kEmptyKey, key[u]) : key[u];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (!open[u]) continue;
+                if (old[u] == kEmptyKey || old[u] == key[u]) open[u] = false;
+                else sl[u] = (sl[u] + 1) & mask;
+            }
+        }
+        int rk[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) rk[u] = i0 + 1024 * u < n ? atomicAdd(&cell[sl[u]].cnt, 1) : 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (i0 + 1024 * u < n) { slot_of[i0 + 1024 * u] = (int)sl[u]; rank_of[i0 + 1024 * u] = rk[u]; }
     }
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __shared__ int s_wsum[2][16];
-    int carry = 0;
-    for (int t0 = 0, buf = 0; t0 < T; t0 += 1024, buf ^= 1) {
-        const int c = cell[t0 + tid].cnt;
-        const int incl = wave_scan_incl(c);
-        if (lane == 63) s_wsum[buf][wave] = incl;
-        __syncthreads();
-        int base = carry, tile = 0;
+    // exclusive prefix of the cell counts -> cell starts.  Every wave owns T / 16 consecutive cells and walks them 64 at a time (coalesced), four rounds in
+    // flight: its total first, ONE barrier, then the starts (a barrier per 1024-cell tile before: up to 128 of them, each behind a load and a store)
+    __shared__ int s_wtot[16];
+    const int wseg = T / 16;                     // T is a power of two >= 1024: a multiple of 64
+    const int cw0 = wave * wseg;
+    {
+        int tot = 0;
+        for (int r0 = 0; r0 < wseg; r0 += 4 * 64) {
+            int c4[4];
 #pragma unroll
-        for (int w = 0; w < 16; w++) { const int v = s_wsum[buf][w]; if (w < wave) base += v; tile += v; }
-        cell[t0 + tid].start = base + incl - c;
-        carry += tile;
+            for (int u = 0; u < 4; u++) c4[u] = r0 + 64 * u < wseg ? cell[cw0 + r0 + 64 * u + lane].cnt : 0;
+#pragma unroll
+            for (int u = 0; u < 4; u++) tot += c4[u];
+        }
+        tot = wave_sum_i(tot);
+        if (lane == 0) s_wtot[wave] = tot;
     }
     __syncthreads();
-    for (int i = tid; i < n; i += 1024) {
-        const float4 p = J.src[i];
-        J.sorted[cell[J.slot_of[i]].start + J.rank_of[i]] = make_float4(p.x, p.y, p.z, __int_as_float(i));
+    {
+        int run = 0;
+        for (int w = 0; w < wave; w++) run += s_wtot[w];
+        for (int r0 = 0; r0 < wseg; r0 += 4 * 64) {
+            int c4[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) c4[u] = r0 + 64 * u < wseg ? cell[cw0 + r0 + 64 * u + lane].cnt : 0;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (r0 + 64 * u >= wseg) break;
+                const int incl = wave_scan_incl(c4[u]);
+                cell[cw0 + r0 + 64 * u + lane].start = run + incl - c4[u];
+                run += __shfl(incl, 63);
+            }
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int i0 = tid; i0 < n; i0 += 4 * 1024) {
+        float4 p[4];
+        int so[4], ro[4], st[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int ic = min(i0 + 1024 * u, n - 1); p[u] = gsrc[ic]; so[u] = slot_of[ic]; ro[u] = rank_of[ic]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) st[u] = cell[so[u]].start;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + 1024 * u;
+            if (i < n) gsorted[st[u] + ro[u]] = make_float4(p[u].x, p[u].y, p[u].z, __int_as_float(i));
+        }
     }
 }
 
