@@ -1644,7 +1644,7 @@ extern "C" int lmono_map_refine(lmono_ctx *c, int n_streams,
             hipLaunchKernelGGL(k_map_correspond, dim3((max_nq + 7) / 8, n_streams), dim3(256), 0, stream, (const MapStream *)st_d, outer);
             hipLaunchKernelGGL(k_map_factor, dim3((max_nq + 63) / 64, n_streams), dim3(64), 0, stream, (const MapStream *)st_d, outer);
         }
-        hipLaunchKernelGGL(k_map_solve, dim3(n_streams), dim3(1024), 0, stream, (const MapStream *)st_d, outer);
+        hipLaunchKernelGGL(k_map_solve, dim3(n_streams), dim3(kMsT), 0, stream, (const MapStream *)st_d, outer);
     }
     (void)hipEventRecord(ev2, stream);
     int rc = check_launch(c, "map refine kernels");
@@ -2065,7 +2065,7 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
                     hipLaunchKernelGGL(k_map_correspond, dim3((max_nq + 7) / 8, (unsigned)act.size()), dim3(256), 0, st, S_d, outer);
                     hipLaunchKernelGGL(k_map_factor, dim3((max_nq + 63) / 64, (unsigned)act.size()), dim3(64), 0, st, S_d, outer);
                 }
-                hipLaunchKernelGGL(k_map_solve, dim3((unsigned)act.size()), dim3(1024), 0, st, S_d, outer);
+                hipLaunchKernelGGL(k_map_solve, dim3((unsigned)act.size()), dim3(kMsT), 0, st, S_d, outer);
             }
             HIP_TRY(c, hipMemcpyAsync(xh.data(), ms[0]->xbuf, sizeof(double) * 8 * (size_t)n, hipMemcpyDeviceToHost, st));
             HIP_TRY(c, hipMemcpyAsync(stats.data(), statbuf, sizeof(int) * 8 * (size_t)n, hipMemcpyDeviceToHost, st));

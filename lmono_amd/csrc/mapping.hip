@@ -409,6 +409,11 @@ __device__ __forceinline__ void map_eval_block(const MapRec &R, const double *Rm
         map_row(acc, R.b[0], R.b[1], R.b[2], rvx, rvy, rvz, r0, sr);
 }
 
+// threads of k_map_solve: 1024 / 512 / 256 measured 1.65 / 1.50 / 1.55 ms per laserMapping frame (at 1024 the 128-register budget spills 152 VGPRs)
+#ifndef LMONO_MS_T
+#define LMONO_MS_T 512
+#endif
+constexpr int kMsT = LMONO_MS_T;
 // sums of all residual blocks of a stream into LDS (s_sum: H 21 | g 6 | cost); blocks [0, n_edge) are the corner points' (edges)
 template <bool kJac>
 __device__ __forceinline__ void map_evaluate(const MapRec *rec, int n_edge, int nq, const double *x, double (*s_red)[28], double *s_sum)
@@ -430,8 +435,8 @@ __device__ __forceinline__ void map_evaluate(const MapRec *rec, int n_edge, int 
         Rm[6] = 2.0 * (ux * uz - w * uy);       Rm[7] = 2.0 * (uy * uz + w * ux);       Rm[8] = 1.0 - 2.0 * (ux * ux + uy * uy);
     }
     int qi = tid;
-    for (; qi < n_edge; qi += 1024) map_eval_block<kJac, true>(rec[qi], Rm, x, acc);
-    for (; qi < nq; qi += 1024) map_eval_block<kJac, false>(rec[qi], Rm, x, acc);
+    for (; qi < n_edge; qi += kMsT) map_eval_block<kJac, true>(rec[qi], Rm, x, acc);
+    for (; qi < nq; qi += kMsT) map_eval_block<kJac, false>(rec[qi], Rm, x, acc);
     acc.cost = wave_sum_d(acc.cost);
     if (kJac) {
 #pragma unroll
@@ -450,18 +455,18 @@ __device__ __forceinline__ void map_evaluate(const MapRec *rec, int n_edge, int 
     __syncthreads();
     if (tid < 28 && (kJac || tid == 27)) {
         double t = 0.0;
-        for (int w = 0; w < 16; w++) t += s_red[w][tid];
+        for (int w = 0; w < kMsT / 64; w++) t += s_red[w][tid];
         s_sum[tid] = t;
     }
     __syncthreads();
 }
 
-// One 1024-thread workgroup per stream (a frame has ~8 k residual blocks); the trust-region control flow runs redundantly
+// One kMsT-thread workgroup per stream (a frame has ~8 k residual blocks); the trust-region control flow runs redundantly
 // in every thread on the block-reduced sums in LDS, exactly like k_lm_solve.
-__global__ __launch_bounds__(1024) void k_map_solve(const MapStream *streams, int outer)
+__global__ __launch_bounds__(kMsT) void k_map_solve(const MapStream *streams, int outer)
 {
     const MapStream S = streams[blockIdx.x];
-    __shared__ double s_red[16][28], s_sum[28], s_cur[28];
+    __shared__ double s_red[kMsT / 64][28], s_sum[28], s_cur[28];
     const int tid = threadIdx.x;
     const int n_edge = S.n_stack[0], nq = S.n_stack[0] + S.n_stack[1];
     const int n_used = S.stats[outer] + S.stats[2 + outer];
