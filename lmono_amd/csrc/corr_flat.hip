@@ -36,7 +36,7 @@ constexpr int kCfBlocks = kMaxQueries / kCfT; // workgroups per chain
 static_assert(kMaxQueries % kCfT == 0, "feature capacity must be a multiple of the workgroup size");
 static_assert(kCfBlocks == kThinBlocks, "k_lm_solve skips the records of the workgroups a thinned lead-in pair does not run");
 #ifndef LMONO_CF_PER
-#define LMONO_CF_PER 8
+#define LMONO_CF_PER 10         // after the gather fix of round 3: 6 / 7 / 8 / 10 / 12 / 14 runs per lane -> 42.36 / 42.23 / 41.89 / 41.57 / 42.07 / 44.62 ms per pass
 #endif
 #ifndef LMONO_CF_U
 #define LMONO_CF_U 4

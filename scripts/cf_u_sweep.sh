@@ -15,10 +15,9 @@ g=d["roofline"]["group_ms_per_step"]
 print("[$flags] tests rc=$rc |", d["value"], d["ms_per_step"], "ate", d["ate_vs_cpu_m"], "corr", g["k_correspond"], "odo", g["odometry_total"], "ms/launch", d["roofline"]["ms_per_launch"])
 PY
 done <<'VAR'
--DLMONO_CF_U=4
--DLMONO_CF_U=8
--DLMONO_CF_U=6
--DLMONO_CF_U=8 -DLMONO_CF_PER=6
--DLMONO_CF_U=2
+-DLMONO_CF_PER=12
+-DLMONO_CF_PER=14
+-DLMONO_CF_PER=16
+-DLMONO_CF_PER=12 -DLMONO_CF_U=8
 VAR
 cp gpurun_out/cfu/keep.so lmono_amd/lib/liblmono_hip.so; rm gpurun_out/cfu/keep.so
