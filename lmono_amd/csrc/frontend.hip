@@ -119,11 +119,17 @@ __global__ __launch_bounds__(kRtT) void k_ring_tag(BatchView b)
     const int n_lines = b.n_lines;
     int lh = INT_MAX, ll = -1;
     const int c_lo = t0 + wave * kRtSeg, c_hi = min(c_lo + kRtSeg, n);
-    // four points per thread and round: their loads are in flight together
+    // four points per thread and round, and the NEXT round's four requested before this round's are worked on (unconditional loads, index clamped
+    // into the segment): a wave's segment is four rounds, each a load latency + ~450 instructions of angle work -- one behind the other they added up
+    float4 nx[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) nx[q] = in[min(c_lo + 64 * q + lane, n - 1)];
     for (int r0 = c_lo; r0 < c_hi; r0 += 256) {
         float4 pq[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) { const int i = r0 + 64 * q + lane; pq[q] = i < c_hi ? in[i] : make_float4(NAN, 0.f, 0.f, 0.f); }
+        for (int q = 0; q < 4; q++) pq[q] = nx[q];
+#pragma unroll
+        for (int q = 0; q < 4; q++) nx[q] = in[min(r0 + 256 + 64 * q + lane, n - 1)];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int i = r0 + 64 * q + lane;
