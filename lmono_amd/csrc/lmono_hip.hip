@@ -738,7 +738,7 @@ static int odom_validate(lmono_ctx *c, lmono_scan_batch *b, OdomView o, bool ext
         const int G = odom_groups(c, nf);
         if (tile) for (int g = 0; g < G; g++) HIP_TRY(c, hipMemsetAsync(b->wl + g * ((size_t)b->chains_cap * kMaxQueries + 1), 0, sizeof(unsigned int), st));
         // a repair chain usually agrees with the stored increments after a few pairs: launch in chunks, ask the device how many still run
-        int done = 0, chunk = 2;
+        int done = 0, chunk = 3;          // 3, 6, 8, 8 ...: most chains agree after 2-4 pairs, the slowest after ~9 (2, 4, 8 launched 14 steps for those 9)
         while (done < max_len) {
             const int upto = done + chunk < max_len ? done + chunk : max_len;
             orp.step0 = 0;
