@@ -44,11 +44,12 @@ int         lmono_set_stream(lmono_ctx *, void *hip_stream); /* hipStream_t; NUL
 int         lmono_use_own_stream(lmono_ctx *);
 int         lmono_synchronize(lmono_ctx *);
 /* Tuning / test switches of a context (no reference counterpart).  LMONO_OPT_CORR_TILE selects the laserOdometry correspondence
- * search: 3 (default) = flattened candidate sweeps over the (scan line, azimuth bin) index (k_corr_flat; needs no hash grid, so
- * lmono_scanreg_batch skips k_grid_build and the grids are built on demand); 0 = 32 lanes per feature point on the hash grid + line
- * index (k_correspond); 1 = LDS-staged azimuth sectors, 4 lanes per feature (k_corr_tile); 2 = one thread per feature
- * (k_corr_thread); 1..3 hand the features they do not answer to k_correspond_list.  All four return identical results
- * (tests/test_lidar_gpu.py::test_tile_search_equals_global_search); measured rates: profiles/r2/NOTES.md.                      */
+ * search: 3 (default) = flattened candidate sweeps over the (azimuth bin, scan line) index (k_corr_flat; needs no hash grid);
+ * 0 = 32 lanes per feature point on a 1 m hash grid (k_correspond + k_grid_build: the round-1 search, compiled into the diagnostic
+ * build liblmono_hip_diag.so only, where the two are checked against each other -- tests/diag_search_modes.py).  The product library
+ * refuses every value but 3.  (Rounds 2-3 carried four more formulations -- LDS sector tiles, thread per feature, a sector-staged
+ * flat search, one persistent workgroup per chain; all measured slower, profiles/r2/NOTES.md, profiles/r3/NOTES.md sections 2-3 --
+ * they were removed in round 4 and live in the history at commit d914e8c.)                                                        */
 #define LMONO_OPT_CORR_TILE 0
 /* test hook: n > 0 makes the default search (mode 3) hand every n-th feature point to its fall-back kernel (k_correspond_list), which
  * then runs without hash grids; results must not change.  0 = off.                                                              */
@@ -68,18 +69,9 @@ int         lmono_synchronize(lmono_ctx *);
  * within it (everything behind stands), in rounds until no boundary is flagged; lmono_odom_boundary_report tells what happened.
  * Default 1000 (1e-6: 2e-6 rad, 1e-5 m); 0 = no validation (and no synchronisation inside lmono_odom_batch_d).                    */
 #define LMONO_OPT_BOUNDARY_TOL 4
-/* schedule of lmono_odom_batch[_d] with the default search: 0 (default) = one launch per phase and outer iteration for all chains
- * (k_corr_flat / k_correspond_list / k_lm_solve, LMONO_OPT_ODOM_STREAMS chain groups); 1 = one persistent 1024-thread workgroup per chain
- * runs all of the chain's scan pairs in ONE launch (k_odom_chain: search by wave tasks, solve by the whole workgroup, no launch-wide
- * barriers).  Same correspondences; increments equal to rounding (the solve's reductions run over 1024 instead of 256 threads).
- * Measured (profiles/r3/NOTES.md): 1 is slower -- a chain confined to one CU pays its search and its solve one after the other
- * (27.5 ms against 21.8 ms per pass over 4541 scans) -- and is kept as a measured alternative.                                      */
-#define LMONO_OPT_ODOM_PERSIST 5
-/* correspondence search of the launch-per-phase schedule: 1 = sector-staged (k_corr_sect: the feature points of one azimuth sector per
- * workgroup, the sector's window of the "last" clouds and their start tables staged in LDS, every candidate read from LDS; features whose
- * search ball leaves the window go through k_corr_flat's list mode); 0 = k_corr_flat over global memory for every feature.  Identical
- * correspondences and increments.                                                                                                  */
-#define LMONO_OPT_CORR_SECT 6
+/* 5, 6: round 3's LMONO_OPT_ODOM_PERSIST / LMONO_OPT_CORR_SECT (schedules measured slower and removed); only 0 is accepted */
+#define LMONO_OPT_RESERVED5 5
+#define LMONO_OPT_RESERVED6 6
 #define LMONO_OPT_COUNT     7
 int         lmono_set_option(lmono_ctx *, int key, int value);
 int         lmono_get_option(lmono_ctx *, int key, int *value);     /* the configured value (option values may be negative) */

@@ -122,10 +122,6 @@ class Context:
             self.L.lmono_set_option(self.h, 3, int(os.environ["LMONO_LEAD_FULL"]))
         if os.environ.get("LMONO_ODOM_STREAMS") is not None:
             self.L.lmono_set_option(self.h, 2, int(os.environ["LMONO_ODOM_STREAMS"]))
-        if os.environ.get("LMONO_CORR_SECT") is not None:
-            self.L.lmono_set_option(self.h, 6, int(os.environ["LMONO_CORR_SECT"]))
-        if os.environ.get("LMONO_ODOM_PERSIST") is not None:
-            self.L.lmono_set_option(self.h, 5, int(os.environ["LMONO_ODOM_PERSIST"]))
         if os.environ.get("LMONO_BOUNDARY_TOL") is not None:
             self.L.lmono_set_option(self.h, 4, int(os.environ["LMONO_BOUNDARY_TOL"]))
 
@@ -154,8 +150,6 @@ class Context:
     OPT_ODOM_STREAMS = 2
     OPT_LEAD_FULL = 3
     OPT_BOUNDARY_TOL = 4
-    OPT_ODOM_PERSIST = 5
-    OPT_CORR_SECT = 6
 
     def set_option(self, key, value):
         self.check(self.L.lmono_set_option(self.h, int(key), int(value)))

@@ -3,27 +3,33 @@
 // Same results as k_correspond (odometry.hip): the exact nearest point (float distance, lowest index on ties) of every de-skewed
 // feature point in the previous scan's less-sharp / less-flat cloud, then the reference's scan-line walk.
 //
-// Measured (profiles/r2/NOTES.md): giving a feature point 32 lanes (k_correspond), 16 lanes over an LDS tile (k_corr_tile) or 4
-// lanes all cost ~440 vector instructions per feature -- the lanes idle while a few dozen candidates are visited in short, ragged
-// runs -- and one lane per feature with its own loops (k_corr_thread) is bound by chains of dependent loads and by the slowest
-// lane.  Here the ragged work of 256 feature points is flattened through LDS, so that every lane always has a candidate:
+// Measured (profiles/r2/NOTES.md): giving a feature point 32 lanes (k_correspond), 16 lanes over an LDS tile or 4 lanes all cost ~440
+// vector instructions per feature -- the lanes idle while a few dozen candidates are visited in short, ragged runs -- and one lane per
+// feature with its own loops is bound by chains of dependent loads and by the slowest lane.  Here the ragged work of a workgroup's
+// feature points is flattened through LDS, so that every lane always has a candidate:
 //
-//   round   1a  each feature's lane (the "owner") turns its search ball into run REQUESTS: one per scan line of the elevation
-//               window, (row, first bin, last bin) of the (line, azimuth bin)-sorted copy of the cloud (k_line_index)
-//           1b  the workgroup resolves all requests together (every lane 8 requests: 16 independent table loads in flight) into
-//               runs (start, length) and takes the exclusive prefix of the lengths
-//           2   the candidates of ALL runs are one index space [0, T): every lane takes a contiguous chunk of T / 256 candidates
-//               (8 independent 16-B gathers in flight), keeps the running minimum of the feature its chunk is in and posts it with
-//               one LDS atomic min per feature it touches.  A feature with 2000 candidates is spread over 40 lanes; one with 20
-//               shares a lane with its neighbours
+//   round   1a  each feature's lane (the "owner") turns its search ball into run REQUESTS: one per azimuth bin of the ball's arc,
+//               (bin, first line, last line) of the (azimuth bin, scan line)-sorted copy of the cloud (k_line_index) -- the lines
+//               v1 .. v2 the ball's elevation window admits are contiguous inside a bin; a request is ONE packed 32-bit word
+//           1b  the workgroup resolves all requests together (every lane kCfPer requests: 2 kCfPer independent table loads in
+//               flight) into runs (start, length), cuts every run into CHUNKS of kCfC = 4 consecutive points and takes the
+//               exclusive prefix of the chunk counts
+//           2   the chunks of ALL runs are one index space [0, C): every lane takes a contiguous range of chunks.  A chunk is 64
+//               contiguous bytes: ONE address and four 16-B loads at immediate offsets, one owner, four distance tests -- the run
+//               walk, the owner test and the address arithmetic are paid per chunk, not per candidate (round 3 dealt single
+//               CANDIDATES to lanes: ~65 vector instructions per candidate, and the kernel is bound by instruction issue -- 53 M
+//               VALU + 26 M SALU wave instructions per 256-chain launch, profiles/r4/NOTES.md).  The next chunk's descriptor walk
+//               (LDS) runs while the current chunk's loads are in flight.  Every lane keeps the running minimum of the feature
+//               its chunks belong to and posts it with one LDS atomic min per feature it touches
 //           3   the owners read their minimum: settled (d <= r), or the radius grows and the feature joins the next round
-//   then the same machinery runs the scan-line walk (lines ra-2 .. ra+2, growing arcs, two minima per feature).
+//   then the same machinery runs the scan-line walk (lines ra-2 .. ra+2 of every bin of growing arcs, two minima per feature).
 //
 // Exactness: a point p with |p - q| <= r lies within asin(r / rho_xy(q)) of q's azimuth and within asin(r / |q|) of q's elevation
-// angle; lb_elev holds every line's elevation range and its monotone envelopes, so the lines a ball can meet are an interval found
-// by two binary searches, each line tested against its own range.  A search of radius r is exact when its minimum is <= r.
-// Features whose requests do not fit the round's pool are served in the next round; a feature whose single ball needs more runs
-// than the whole pool goes to the device work list of k_correspond_list.
+// angle; lb_elev holds every line's elevation range and its monotone envelopes, so the lines a ball can meet lie inside an interval
+// v1 .. v2 found by two binary searches (lines inside the interval that the ball cannot meet ride along: extra candidates can only
+// confirm the minimum).  A search of radius r is exact when its minimum is <= r.  Features whose requests do not fit the round's pool
+// are served in the next round; a feature whose single ball needs more runs than the whole pool goes to the device work list of
+// k_correspond_list.
 #include "batch.hpp"
 
 namespace lmono {
@@ -36,10 +42,7 @@ constexpr int kCfBlocks = kMaxQueries / kCfT; // workgroups per chain
 static_assert(kMaxQueries % kCfT == 0, "feature capacity must be a multiple of the workgroup size");
 static_assert(kCfBlocks == kThinBlocks, "k_lm_solve skips the records of the workgroups a thinned lead-in pair does not run");
 #ifndef LMONO_CF_PER
-#define LMONO_CF_PER 10         // after the gather fix of round 3: 6 / 7 / 8 / 10 / 12 / 14 runs per lane -> 42.36 / 42.23 / 41.89 / 41.57 / 42.07 / 44.62 ms per pass
-#endif
-#ifndef LMONO_CF_U
-#define LMONO_CF_U 4
+#define LMONO_CF_PER 6          // runs per lane and round (round 3, one run per LINE: 10)
 #endif
 #ifndef LMONO_CF_WAVES
 #define LMONO_CF_WAVES 1
@@ -54,14 +57,25 @@ constexpr int kCfPool = kCfT * kCfPer;        // run descriptors per round
 #define LMONO_R0_EDGE 0.5f
 #endif
 constexpr float kCfR0Edge = LMONO_R0_EDGE, kCfR0Plane = LMONO_R0_PLANE;
-constexpr int kCfU = LMONO_CF_U;               // gathers in flight per lane
+constexpr int kCfC = 4;                        // points per chunk = loads in flight per lane (64 contiguous bytes)
+static_assert(kCfC - 1 <= kLbPad, "a chunk's loads may run kCfC - 1 points past its run: the index copies are padded");
+#ifndef LMONO_WALK_TIGHT
+#define LMONO_WALK_TIGHT 1      // a walk pass that SAW its partners outside its ball continues with the ball that just holds them, not with the next rung
+#endif
 
-struct CfRun {
-    unsigned int start;                       // request: table entry of the first bin; resolved: first point of the run
-    unsigned int pre;                         // request: table entry behind the last bin; resolved: candidates before this run
-    unsigned short len;
-    unsigned char owner;                      // feature (lane) the run belongs to (kCfT <= 256)
-    unsigned char tag;                        // bit 7: surf cloud; low bits: scan line (nearest point) / line offset 0..4 (walk)
+// run request, one word: bin (9 bits) | first line (7) << 9 | last line + 1 (7) << 16 | owner (8) << 23 | surf cloud << 31
+__device__ __forceinline__ unsigned int cf_request(int v1, int v2p1, int owner, bool surf)
+{
+    return ((unsigned int)v1 << 9) | ((unsigned int)v2p1 << 16) | ((unsigned int)owner << 23) | (surf ? 0x80000000u : 0u);
+}
+static_assert(kCfT <= 256 && kAzBins <= 512, "request packing");
+
+struct CfRun {                                // resolved run
+    unsigned int start;                       // first point of the run in its index copy
+    unsigned int pre;                         // chunks before this run
+    unsigned short len;                       // points
+    unsigned char owner;                      // feature (lane) the run belongs to
+    unsigned char tag;                        // bit 7: surf cloud
 };
 static_assert(sizeof(CfRun) == 12, "run descriptor layout");
 
@@ -69,9 +83,10 @@ struct CfLds {
     float4 elev[2][66];                       // lb_elev of the two "last" clouds
     int fge[2][66], lle[2][66];
     float4 q[kCfT];                           // de-skewed feature points
-    unsigned long long best[kCfT];            // nearest point: (d2 bits) << 32 | index << 7 | line
+    unsigned long long best[kCfT];            // nearest point: (d2 bits) << 32 | index << 7 | line (the low word is the index copy's .w)
     unsigned long long same[kCfT], other[kCfT];
     int closest[kCfT], wlo[kCfT], whi[kCfT], ra[kCfT];
+    unsigned int req[kCfPool];
     CfRun pool[kCfPool];
     int n_pool, n_cand, wsum[kCfT / 64];
 };
@@ -82,21 +97,25 @@ __device__ __forceinline__ void cf_defer(unsigned int *wl, int c, int qi)
     wl[1 + slot] = ((unsigned int)c << 12) | (unsigned int)qi;
 }
 
-// azimuth arc of radius r around the feature as one or two bin ranges of a table row: [a0, a1) and [0, w1) (w1 = 0: no wrap)
-struct CfArc { int a0, a1, w1; };
+// azimuth arc of radius r around the feature: nb bins from bin a0 on, wrapping past the last bin
+struct CfArc { int a0, nb; };
 __device__ __forceinline__ void cf_arc(float r, float rho, float th, CfArc &a)
 {
     constexpr float kb = kAzBins / 6.28318531f;
-    a.a0 = 0; a.a1 = kAzBins; a.w1 = 0;
+    a.a0 = 0; a.nb = kAzBins;
     if (!(rho > r * 1.002f)) return;                      // the ball reaches the sensor axis: every azimuth
     const float alpha = asin_upper(r / rho) + kArcSlackBins / kb;
     const int lo = (int)floorf((th - alpha) * kb), hi = (int)floorf((th + alpha) * kb);
     const int n = hi - lo + 1;
     if (n >= kAzBins) return;
-    const int b0 = ((lo % kAzBins) + kAzBins) % kAzBins;
-    a.a0 = b0;
-    if (b0 + n <= kAzBins) a.a1 = b0 + n;
-    else { a.a1 = kAzBins; a.w1 = b0 + n - kAzBins; }
+    a.a0 = ((lo % kAzBins) + kAzBins) % kAzBins;
+    a.nb = n;
+}
+// the owner's requests: one per bin of the arc (lines v1 .. v2p1 - 1), from slot on
+__device__ __forceinline__ void cf_post(unsigned int *req, int slot, const CfArc &a, unsigned int rq0)
+{
+    int bn = a.a0;
+    for (int t = 0; t < a.nb; t++) { req[slot + t] = rq0 | (unsigned int)bn; bn = bn + 1 == kAzBins ? 0 : bn + 1; }
 }
 
 // first line whose envelope A (min of lo over lines <= v, non-increasing) is <= ehi; 66 when none
@@ -118,8 +137,12 @@ __device__ __forceinline__ int cf_last_line(const float4 *el, float elo)
 // kWalk = true: scan-line walk (minima into L.same / L.other).
 #ifdef LMONO_TILE_PROF
 #define CF_STAMP(v) { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); (v) += t_ - cf_t; cf_t = t_; } }
+#define CF_WAIT_VM() __builtin_amdgcn_s_waitcnt(0x0F70);     /* vmcnt(0): the stamp behind it sees the gathers arrive */
+#define CF_COUNT(v) { if (threadIdx.x == 0) (v) += 1; }
 #else
 #define CF_STAMP(v)
+#define CF_WAIT_VM()
+#define CF_COUNT(v)
 #endif
 
 template <bool kWalk>
@@ -127,21 +150,22 @@ __device__ __forceinline__ void cf_sweep(CfLds &L, const int *tg_c, const int *t
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_pool = min(L.n_pool, kCfPool);
-    // ---- 1b: resolve this lane's kCfPer consecutive requests (all table loads in flight together), prefix of the lengths
-    unsigned int st[kCfPer], en[kCfPer];
+    // ---- 1b: resolve this lane's kCfPer consecutive requests (all table loads in flight together), prefix of the chunk counts
+    unsigned int st[kCfPer], en[kCfPer], rq[kCfPer];
 #pragma unroll
     for (int j = 0; j < kCfPer; j++) {
         const int i = tid * kCfPer + j;
-        st[j] = 0; en[j] = 0;
+        st[j] = 0; en[j] = 0; rq[j] = 0;
         if (i < n_pool) {
-            const CfRun rq = L.pool[i];
-            const int *tg = (rq.tag & 0x80) ? tg_s : tg_c;
-            st[j] = (unsigned int)tg[rq.start]; en[j] = (unsigned int)tg[rq.pre];
+            rq[j] = L.req[i];
+            const int *tg = (rq[j] & 0x80000000u) ? tg_s : tg_c;
+            const int row = (int)(rq[j] & 511u) * 66;
+            st[j] = (unsigned int)tg[row + (int)((rq[j] >> 9) & 127u)]; en[j] = (unsigned int)tg[row + (int)((rq[j] >> 16) & 127u)];
         }
     }
     int sum = 0;
 #pragma unroll
-    for (int j = 0; j < kCfPer; j++) sum += (int)(en[j] - st[j]);
+    for (int j = 0; j < kCfPer; j++) { en[j] = min(en[j] - st[j], 65535u); sum += (int)((en[j] + kCfC - 1) / kCfC); }      // en = length from here on
     const int incl = wave_scan_incl(sum);
     if (lane == 63) L.wsum[wave] = incl;
     __syncthreads();
@@ -152,100 +176,104 @@ __device__ __forceinline__ void cf_sweep(CfLds &L, const int *tg_c, const int *t
     for (int j = 0; j < kCfPer; j++) {
         const int i = tid * kCfPer + j;
         if (i < n_pool) {
-            L.pool[i].start = st[j];
-            L.pool[i].pre = (unsigned int)run;
-            L.pool[i].len = (unsigned short)min(en[j] - st[j], 65535u);
+            CfRun d;
+            d.start = st[j]; d.pre = (unsigned int)run; d.len = (unsigned short)en[j];
+            d.owner = (unsigned char)((rq[j] >> 23) & 255u); d.tag = (unsigned char)(rq[j] >> 31 ? 0x80 : 0);
+            L.pool[i] = d;
         }
-        run += (int)(en[j] - st[j]);
+        run += (int)((en[j] + kCfC - 1) / kCfC);
     }
     __syncthreads();
     CF_STAMP(cf_acc[1])
-    // ---- 2: this lane's contiguous chunk of the candidate index space
-    const int T = L.n_cand;
-    if (T <= 0 || n_pool <= 0) return;
-    const int ch = (T + kCfT - 1) / kCfT;
-    int j0 = tid * ch;
-    const int j1 = min(j0 + ch, T);
-    if (j0 >= j1) return;
-    // run that holds candidate j0: last run with pre <= j0 (runs of length 0 share their pre with the next run)
+    // ---- 2: this lane's contiguous range of chunks
+    const int C = L.n_cand;
+    if (C <= 0 || n_pool <= 0) return;
+    const int ch = (C + kCfT - 1) / kCfT;
+    int j = tid * ch;
+    const int j1 = min(j + ch, C);
+    if (j >= j1) return;
+    // run that holds chunk j: last run with pre <= j (runs without chunks share their pre with the next run)
     int seg;
     {
         int lo = 0, hi = n_pool - 1;
-        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((int)L.pool[mid].pre <= j0) lo = mid; else hi = mid - 1; }
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((int)L.pool[mid].pre <= j) lo = mid; else hi = mid - 1; }
         seg = lo;
     }
     CfRun cur = L.pool[seg];
-    int off = j0 - (int)cur.pre;
+    int off = (j - (int)cur.pre) * kCfC;           // first point of the chunk inside its run
+    CF_STAMP(cf_acc[10])
     int owner = -1;
     float qx = 0.f, qy = 0.f, qz = 0.f;
     unsigned long long m0 = ~0ull, m1 = ~0ull;      // running minima of the current owner (nearest / same, other)
-    int closest = 0, w_lo = 0, w_hi = 0;
+    int closest = 0, w_lo = 0, ra = 0;
+    unsigned int w_span = 0;
     auto flush = [&]() {
         if (owner < 0) return;
         if (!kWalk) { if (m0 != ~0ull) atomicMin(&L.best[owner], m0); }
         else { if (m0 != ~0ull) atomicMin(&L.same[owner], m0); if (m1 != ~0ull) atomicMin(&L.other[owner], m1); }
     };
-    while (j0 < j1) {
-        // up to kCfU candidates: addresses first (LDS only), then the gathers together, then the arithmetic
-        unsigned int addr[kCfU];
-        unsigned short meta[kCfU];            // owner << 8 | tag
+    // the chunk (first point, live points, owner) the loop body works on; the NEXT one is prepared while its loads are in flight
+    const float4 *pp; int n, ow;
+    auto next_chunk = [&](const float4 *&pp_, int &n_, int &ow_) {
+        while (off >= (int)cur.len) { seg++; cur = L.pool[seg]; off = 0; }
+        pp_ = ((cur.tag & 0x80) ? pts_s : pts_c) + cur.start + off;
+        n_ = (int)cur.len - off; ow_ = cur.owner;
+        off += kCfC;
+    };
+    next_chunk(pp, n, ow);
+    for (;;) {
+        // four UNCONDITIONAL loads at immediate offsets (the copies are padded: a chunk may run up to three points past its run; the
+        // points behind the run's end are masked below).  Behind a branch the compiler would wait for each load in turn (round 3).
+        float4 p[kCfC];
 #pragma unroll
-        for (int u = 0; u < kCfU; u++) {
-            addr[u] = 0xffffffffu; meta[u] = 0;
-            if (j0 + u < j1) {
-                while (off >= (int)cur.len) { off -= (int)cur.len; seg++; cur = L.pool[seg]; }
-                addr[u] = cur.start + (unsigned int)off;
-                meta[u] = (unsigned short)(((unsigned int)cur.owner << 8) | cur.tag);
-                off++;
-            }
+        for (int u = 0; u < kCfC; u++) p[u] = pp[u];
+        __builtin_amdgcn_sched_barrier(0);          // everything below stays below the loads
+        CF_STAMP(cf_acc[11])
+        j++;
+        const bool more = j < j1;
+        const float4 *pp_n = pp; int n_n = 0, ow_n = ow;
+        if (more) next_chunk(pp_n, n_n, ow_n);
+        if (ow != owner) {
+            CF_COUNT(cf_acc[16])
+            flush();
+            owner = ow; m0 = ~0ull; m1 = ~0ull;
+            const float4 qq = L.q[ow];
+            qx = qq.x; qy = qq.y; qz = qq.z;
+            if (kWalk) { closest = L.closest[ow]; w_lo = L.wlo[ow]; w_span = (unsigned int)(L.whi[ow] - w_lo); ra = L.ra[ow]; }
         }
-        // UNCONDITIONAL gathers (an unused slot reads entry 0 of the corner copy, which always exists): behind a branch the compiler sank the first
-        // use of every point into its load's block and waited for each gather in turn (s_waitcnt vmcnt(0) after every global_load_dwordx4 --
-        // rounds 2 and 3 ran with ONE gather in flight per lane whatever kCfU said)
-        float4 p[kCfU];
+        CF_WAIT_VM()
+        CF_STAMP(cf_acc[12])
+        CF_COUNT(cf_acc[15])
 #pragma unroll
-        for (int u = 0; u < kCfU; u++) {
-            const bool live = addr[u] != 0xffffffffu;
-            const float4 *src = (live && (meta[u] & 0x80)) ? pts_s : pts_c;
-            p[u] = src[live ? addr[u] : 0u];
-        }
-        __builtin_amdgcn_sched_barrier(0);          // the arithmetic below stays below the loads
-#pragma unroll
-        for (int u = 0; u < kCfU; u++) {
-            if (addr[u] == 0xffffffffu) continue;
-            const int ow = meta[u] >> 8, tag = meta[u] & 0x7f;
-            if (ow != owner) {
-                flush();
-                owner = ow; m0 = ~0ull; m1 = ~0ull;
-                const float4 qq = L.q[ow];
-                qx = qq.x; qy = qq.y; qz = qq.z;
-                if (kWalk) { closest = L.closest[ow]; w_lo = L.wlo[ow]; w_hi = L.whi[ow]; }
-            }
+        for (int u = 0; u < kCfC; u++) {
             const float d = dist2f(p[u].x, p[u].y, p[u].z, qx, qy, qz);
+            const int pw = __float_as_int(p[u].w);      // cloud index << 7 | line
+            const bool live = u < n;
             if (!kWalk) {
-                const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)((__float_as_int(p[u].w) << 7) | tag);
-                m0 = key < m0 ? key : m0;
+                const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)pw;
+                m0 = (live & (key < m0)) ? key : m0;
             } else {
-                const int jj = __float_as_int(p[u].w);
-                if (jj == closest || jj < w_lo || jj >= w_hi) continue;
-                const bool fwd = jj > closest;
-                const unsigned int seq = fwd ? (unsigned int)(jj - closest - 1) : kSeqBack + (unsigned int)(closest - 1 - jj);
+                const int jj = pw >> 7, dv = (pw & 127) - ra, sj = jj - closest;
+                const bool ok = live & (sj != 0) & ((unsigned int)(jj - w_lo) < w_span);          // inside the window the reference's loops can reach
+                const unsigned int seq = sj > 0 ? (unsigned int)(sj - 1) : kSeqBack + (unsigned int)(-1 - sj);
                 const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | seq;
-                const bool is_other = fwd ? (tag > 2) : (tag < 2);          // tag = line offset 0..4, 2 = the nearest point's own line
-                if (is_other) m1 = key < m1 ? key : m1; else m0 = key < m0 ? key : m0;
+                const bool is_other = sj > 0 ? (dv > 0) : (dv < 0);       // ra = the nearest point's own line (an edge feature's "same" minimum is never read)
+                m1 = (ok & is_other & (key < m1)) ? key : m1;
+                m0 = (ok & !is_other & (key < m0)) ? key : m0;
             }
         }
-        j0 += kCfU;
+        CF_STAMP(cf_acc[13])
+        if (!more) break;
+        pp = pp_n; n = n_n; ow = ow_n;
     }
     flush();
+    CF_STAMP(cf_acc[14])
 }
 
 // step `step`, outer iteration `outer` of every chain: kCfBlocks workgroups of kCfT feature points per chain (measured: 256 threads
 // 30.0 ms of correspondence search per bench step, 128 threads 26.6, 64 threads 31.4; 4 or 8 gathers in flight make no difference), decoded onto ONE XCD
 // per chain (blocks b and b + 8 share an XCD): the chain's index and tables are fetched into one L2 only.
-// list_mode != 0: the workgroups serve the chain's deferred list (o.dl / o.dl_cnt, left by the sector-staged search of corr_sect.hip)
-// instead of dealing all feature points: workgroup qb takes entries qb, qb + kCfBlocks, ...
-__global__ __launch_bounds__(kCfT, LMONO_CF_WAVES) void k_corr_flat(BatchView b, OdomView o, int step, int outer, unsigned int *wl, int defer_every, unsigned long long *stats, int list_mode)
+__global__ __launch_bounds__(kCfT, LMONO_CF_WAVES) void k_corr_flat(BatchView b, OdomView o, int step, int outer, unsigned int *wl, int defer_every, unsigned long long *stats)
 {
     __shared__ CfLds L;
     const int xcd = blockIdx.x & 7, u = blockIdx.x >> 3;
@@ -256,18 +284,15 @@ __global__ __launch_bounds__(kCfT, LMONO_CF_WAVES) void k_corr_flat(BatchView b,
     int own;
     const int k = chain_scan(o, c, step, own);
     if (k < 0) return;
-    if (!list_mode && lead_in_thinned(o, k, own) && qb % kThinStride != 0) return;      // early lead-in pair: every kThinStride-th share of the features
+    if (lead_in_thinned(o, k, own) && qb % kThinStride != 0) return;      // early lead-in pair: every kThinStride-th share of the features
     const int tid = threadIdx.x;
     const int l = k - 1;
     const int n_sharp = b.feat_n[k * 4 + 0];
     const int nq = n_sharp + b.feat_n[k * 4 + 2];
-    int n_list = 0;
-    if (list_mode) { n_list = o.dl_cnt[c]; if (qb == 0 && tid == 0 && stats && n_list) atomicAdd(&stats[1], (unsigned long long)n_list); if (qb >= n_list) return; }
-    else if (qb >= nq) return;
+    if (qb >= nq) return;
     // the chain's features are dealt round-robin over its kCfBlocks workgroups: every workgroup gets the same share of edge and plane
     // features (blocks of consecutive features gave workgroups of very different weight, and an almost empty last one)
-    // (list mode: the deferred features are the expensive ones -- wide balls -- so they are dealt round-robin over the workgroups as well)
-    const int qi = list_mode ? (tid * kCfBlocks + qb < n_list ? (int)o.dl[(size_t)c * kMaxQueries + tid * kCfBlocks + qb] : nq) : tid * kCfBlocks + qb;
+    const int qi = tid * kCfBlocks + qb;
     if (b.status[l] & (kStatusIrregularLines | kStatusDenseCell)) {
         if (qi < nq) cf_defer(wl, c, qi);       // rare: the whole scan pair goes to the generic search
         return;
@@ -309,14 +334,13 @@ __global__ __launch_bounds__(kCfT, LMONO_CF_WAVES) void k_corr_flat(BatchView b,
     const float rho2 = qx * qx + qy * qy, rho = sqrtf(rho2), R = sqrtf(rho2 + qz * qz);
     const float th = atan2f(qy, qx) + 3.14159265f;
     const float eq = elev_of(qx, qy, qz);
-    const unsigned char tag_cl = edge ? 0 : 0x80;
-    unsigned long long cf_t = 0, cf_acc[10] = { 0 };      // diagnostic build: cycles per stage (1a, 1b, 2, 3, setup, epilogue), rounds, candidates
+    unsigned long long cf_t = 0, cf_acc[20] = { 0 };      // diagnostic build: cycles per stage (1a, 1b, 2, 3, setup, epilogue), rounds, candidates
 #ifdef LMONO_TILE_PROF
     if (tid == 0) cf_t = __builtin_amdgcn_s_memtime();
 #endif
     bool alive = qi < nq && n_last > 0;       // still looking for its nearest point
     bool deferred = false;
-    if (!list_mode && defer_every > 0 && qi < nq && qi % defer_every == 0) { alive = false; deferred = true; }      // test hook: exercise the fall-back kernel
+    if (defer_every > 0 && qi < nq && qi % defer_every == 0) { alive = false; deferred = true; }      // test hook: exercise the fall-back kernel
     float r = sd >= 0.f ? sqrtf(sd) * 1.0005f + 1e-3f : (edge ? kCfR0Edge : kCfR0Plane);
     __syncthreads();
 
@@ -335,27 +359,18 @@ __global__ __launch_bounds__(kCfT, LMONO_CF_WAVES) void k_corr_flat(BatchView b,
             const float beta = R > rr ? asin_upper(rr / R) + 5e-4f : 4.0f;
             const float elo = eq - beta, ehi = eq + beta;
             const int v1 = cf_first_line(el, ehi), v2 = cf_last_line(el, elo);
-            int nl = 0;
-            for (int v = v1; v <= v2; v++) { const float4 ev = el[v]; nl += !(ev.y < elo || ev.x > ehi) ? 1 : 0; }
-            const int nreq = nl * (a.w1 ? 2 : 1);
+            // one run per azimuth bin of the arc: its lines v1 .. v2
+            const int nreq = v1 > v2 ? 0 : a.nb;
             if (nreq > kCfPool) { alive = false; deferred = true; }       // a single ball larger than the pool: list kernel
             else {
-                int slot = nreq > 0 ? atomicAdd(&L.n_pool, nreq) : 0;
+                const int slot = nreq > 0 ? atomicAdd(&L.n_pool, nreq) : 0;
                 if (slot + nreq <= kCfPool) {
                     posted = true;
-                    for (int v = v1; v <= v2; v++) {
-                        const float4 ev = el[v];
-                        if (ev.y < elo || ev.x > ehi) continue;
-                        CfRun rq;
-                        rq.start = (unsigned int)(v * kAzBins + a.a0); rq.pre = (unsigned int)(v * kAzBins + a.a1);
-                        rq.len = 0; rq.owner = (unsigned char)tid; rq.tag = (unsigned char)(tag_cl | v);
-                        L.pool[slot++] = rq;
-                        if (a.w1) { rq.start = (unsigned int)(v * kAzBins); rq.pre = (unsigned int)(v * kAzBins + a.w1); L.pool[slot++] = rq; }
-                    }
+                    if (nreq > 0) cf_post(L.req, slot, a, cf_request(v1, v2 + 1, tid, !edge));
                 } else {
                     // the pool of this round is full: the feature posts again in the next round; the part of its reservation that
                     // lies inside the pool becomes empty runs
-                    for (; slot < kCfPool; slot++) { CfRun rq; rq.start = 0; rq.pre = 0; rq.len = 0; rq.owner = (unsigned char)tid; rq.tag = 0; L.pool[slot] = rq; }
+                    for (int t = slot; t < kCfPool; t++) L.req[t] = 0u;
                 }
             }
         }
@@ -391,7 +406,7 @@ __global__ __launch_bounds__(kCfT, LMONO_CF_WAVES) void k_corr_flat(BatchView b,
     const int closest = (int)((unsigned int)(nn & 0xffffffffull) >> 7);
     const int ra = (int)(nn & 127ull);
     if (walking) {
-        L.closest[tid] = closest;
+        L.closest[tid] = closest; L.ra[tid] = ra;
         L.wlo[tid] = ra - 3 >= 0 ? L.lle[cl][ra - 3] + 1 : 0;
         L.whi[tid] = ra + 3 <= 65 ? L.fge[cl][ra + 3] : n_last;
     }
@@ -423,26 +438,15 @@ __global__ __launch_bounds__(kCfT, LMONO_CF_WAVES) void k_corr_flat(BatchView b,
         if (walking) {
             CfArc a;
             cf_arc(r_now, rho, th, a);
-            int nl = 0;
-#pragma unroll
-            for (int j = 0; j < 5; j++) { const int v = ra - 2 + j; nl += (v >= 0 && v <= 65 && !(edge && j == 2)) ? 1 : 0; }
-            const int nreq = nl * (a.w1 ? 2 : 1);
-            int slot = nreq > 0 ? atomicAdd(&L.n_pool, nreq) : 0;
+            // one run per azimuth bin of the arc: the lines ra-2 .. ra+2 (an edge feature's own line rides along: its "same" minimum is not read)
+            const int nreq = a.nb;
+            const int slot = atomicAdd(&L.n_pool, nreq);
             if (slot + nreq <= kCfPool) {
                 posted = true;
                 L.same[tid] = thr; L.other[tid] = thr;
-#pragma unroll
-                for (int j = 0; j < 5; j++) {
-                    const int v = ra - 2 + j;
-                    if (!(v >= 0 && v <= 65 && !(edge && j == 2))) continue;      // edges never use the nearest point's own line
-                    CfRun rq;
-                    rq.start = (unsigned int)(v * kAzBins + a.a0); rq.pre = (unsigned int)(v * kAzBins + a.a1);
-                    rq.len = 0; rq.owner = (unsigned char)tid; rq.tag = (unsigned char)(tag_cl | j);
-                    L.pool[slot++] = rq;
-                    if (a.w1) { rq.start = (unsigned int)(v * kAzBins); rq.pre = (unsigned int)(v * kAzBins + a.w1); L.pool[slot++] = rq; }
-                }
+                cf_post(L.req, slot, a, cf_request(max(ra - 2, 0), min(ra + 2, 65) + 1, tid, !edge));
             } else
-                for (; slot < kCfPool; slot++) { CfRun rq; rq.start = 0; rq.pre = 0; rq.len = 0; rq.owner = (unsigned char)tid; rq.tag = 0; L.pool[slot] = rq; }
+                for (int t = slot; t < kCfPool; t++) L.req[t] = 0u;
         }
         __syncthreads();
         CF_STAMP(cf_acc[0])
@@ -459,14 +463,26 @@ __global__ __launch_bounds__(kCfT, LMONO_CF_WAVES) void k_corr_flat(BatchView b,
                 const unsigned long long lim = pack_fu(r_now * r_now * 0.998f, 0u);     // strictly inside the ball of this pass
                 if (other < lim && (edge || same < lim)) walking = false;
                 else if (seeded) r_seed = -1.0f;          // (not expected) back to the ladder
-                else wpass++;
+                else {
+                    wpass++;
+                    while (wpass < 4 && rad[wpass] <= rad[wpass - 1]) wpass++;
+#if LMONO_WALK_TIGHT
+                    // the pass SAW the partners it needs, but outside its ball (its arc's bins hold more than the ball): the ball that just holds
+                    // them settles the walk exactly -- every point outside it is farther -- and is usually much smaller than the next rung's
+                    if (other < thr && (edge || same < thr)) {
+                        const float d = edge ? __uint_as_float((unsigned int)(other >> 32)) : fmaxf(__uint_as_float((unsigned int)(other >> 32)), __uint_as_float((unsigned int)(same >> 32)));
+                        const float rt = sqrtf(d) * 1.002f + 1e-3f;
+                        if (wpass < 4 && rt < rad[wpass] && d < 24.0f) r_seed = rt;
+                    }
+#endif
+                }
             }
         }
         CF_STAMP(cf_acc[3])
         if (!__syncthreads_or(walking ? 1 : 0)) break;
     }
 #ifdef LMONO_TILE_PROF
-    if (tid == 0 && stats) { atomicAdd(&stats[1], 1ull); for (int i = 0; i < 10; i++) atomicAdd(&stats[2 + i], cf_acc[i]); }
+    if (tid == 0 && stats) { atomicAdd(&stats[1], 1ull); for (int i = 0; i < 20; i++) atomicAdd(&stats[2 + i], cf_acc[i]); }
 #endif
     if (qi >= nq) return;
     if (deferred || walking) { cf_defer(wl, c, qi); return; }

@@ -2,13 +2,7 @@
 // the kernel files are included so that one `hipcc -shared` produces liblmono_hip.so.
 #include "frontend.hip"
 #include "odometry.hip"
-#ifdef LMONO_DIAG_SEARCH
-#include "corr_tile.hip"      // measured alternatives of the correspondence search (profiles/r2/NOTES.md): diagnostic build only
-#include "corr_thread.hip"
-#endif
 #include "corr_flat.hip"
-#include "corr_sect.hip"
-#include "odom_chain.hip"
 #include "mapping.hip"
 #include "ba.hip"
 #include "ba_solve.hip"
@@ -35,7 +29,7 @@ struct lmono_ctx {
     std::vector<EvSet> sets;   // one event set per scanreg/odometry call since the last lmono_timing_reset
     int n_sets = 0;
     hipEvent_t *ev = nullptr;  // events of the current call
-    int opt[LMONO_OPT_COUNT] = { 3, 0, 4, -1, 1000, 0, 0 };   // LMONO_OPT_CORR_TILE: 3 = flattened sweeps (default: as fast as 0 and needs no hash grid), 0 = 32-lane groups, 1 = LDS sector tiles, 2 = thread per feature
+    int opt[LMONO_OPT_COUNT] = { 3, 0, 4, -1, 1000, 0, 0 };   // LMONO_OPT_CORR_TILE: 3 = flattened sweeps (default, needs no hash grid), 0 = 32-lane groups on the hash grid (diagnostic build)
     hipStream_t gstream[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };   // streams of the odometry's chain groups (LMONO_OPT_ODOM_STREAMS > 1)
     hipEvent_t gev[9] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     unsigned long long *stats_d = nullptr;   // [0] feature points deferred by the tile search since the last lmono_timing_reset
@@ -96,8 +90,6 @@ struct lmono_scan_batch {
     std::vector<double> resid_h;
     std::vector<int> rerun_h;
     int last_chains = 0, last_lead = 0, last_first = 0;
-    unsigned short *fs_list = nullptr, *dl = nullptr;       // sector-staged search: sorted feature lists, deferred lists
-    int *fs_off = nullptr, *dl_cnt = nullptr;
 };
 
 #define HIP_TRY(ctx, expr)                                                                   \
@@ -110,9 +102,9 @@ struct lmono_scan_batch {
     } while (0)
 
 #ifdef LMONO_DIAG_SEARCH
-extern "C" const char *lmono_version(void) { return "lmono-hip 0.3 (gfx950, diagnostic build: search alternatives)"; }
+extern "C" const char *lmono_version(void) { return "lmono-hip 0.4 (gfx950, diagnostic build: + hash-grid search)"; }
 #else
-extern "C" const char *lmono_version(void) { return "lmono-hip 0.3 (gfx950)"; }
+extern "C" const char *lmono_version(void) { return "lmono-hip 0.4 (gfx950)"; }
 #endif
 
 extern "C" lmono_ctx *lmono_create(int device)
@@ -128,11 +120,8 @@ extern "C" lmono_ctx *lmono_create(int device)
     if (hipFuncSetAttribute((const void *)k_voxel<kVoxSmallSlots, kVoxSmallBits, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kVoxLdsSmall) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_voxel<kVoxBigSlots, kVoxBigBits, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kVoxLdsBig) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_lm_solve, hipFuncAttributeMaxDynamicSharedMemorySize, kLmRecLds) != hipSuccess) { delete c; return nullptr; }
-    if (hipFuncSetAttribute((const void *)k_odom_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(OcLds)) != hipSuccess) { delete c; return nullptr; }
-    if (hipFuncSetAttribute((const void *)k_corr_sect, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CsLds)) != hipSuccess) { delete c; return nullptr; }
 #ifdef LMONO_DIAG_SEARCH
     if (hipFuncSetAttribute((const void *)k_grid_build, hipFuncAttributeMaxDynamicSharedMemorySize, kGridLds) != hipSuccess) { delete c; return nullptr; }
-    if (hipFuncSetAttribute((const void *)k_corr_tile, hipFuncAttributeMaxDynamicSharedMemorySize, kTileLds) != hipSuccess) { delete c; return nullptr; }
 #endif
     if (hipFuncSetAttribute((const void *)k_line_index<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLiLdsHalf) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_line_index<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLiLdsFull) != hipSuccess) { delete c; return nullptr; }
@@ -184,16 +173,15 @@ extern "C" int lmono_set_option(lmono_ctx *c, int key, int value)
 {
     if (!c || key < 0 || key >= LMONO_OPT_COUNT) return LMONO_EINVAL;
 #ifdef LMONO_DIAG_SEARCH
-    const int corr_lo = 0;
+    const bool grid_search = true;
 #else
-    const int corr_lo = 3;           // the measured alternatives 0 .. 2 are compiled into the diagnostic build only
+    const bool grid_search = false;  // the round-1 hash-grid search (0) is compiled into the diagnostic build only
 #endif
-    const bool ok = key == LMONO_OPT_CORR_TILE ? (value >= corr_lo && value <= 3)
+    const bool ok = key == LMONO_OPT_CORR_TILE ? (value == 3 || (value == 0 && grid_search))
                   : key == LMONO_OPT_DEFER_EVERY ? value >= 0
                   : key == LMONO_OPT_ODOM_STREAMS ? (value >= 1 && value <= 8)
                   : key == LMONO_OPT_BOUNDARY_TOL ? value >= 0
-                  : key == LMONO_OPT_ODOM_PERSIST ? (value == 0 || value == 1)
-                  : key == LMONO_OPT_CORR_SECT ? (value == 0 || value == 1)
+                  : (key == LMONO_OPT_RESERVED5 || key == LMONO_OPT_RESERVED6) ? value == 0      // round 3's shelved schedules (removed)
                   : value >= -1;                                     // LMONO_OPT_LEAD_FULL
     if (!ok) { c->err = "lmono_set_option: value out of range for this option"; return LMONO_EINVAL; }
     c->opt[key] = value;
@@ -256,7 +244,7 @@ extern "C" lmono_scan_batch *lmono_batch_create(lmono_ctx *c, int n_cap, int64_t
     ok = ok && dalloc(b, v.feat_n, N * 4) && dalloc(b, v.line_first_ge, N * 2 * 66) && dalloc(b, v.line_last_le, N * 2 * 66);
     ok = ok && dalloc(b, v.cg_cell, N * kCornerTable) && dalloc(b, v.sg_cell, N * kSurfTable);
     ok = ok && dalloc(b, v.cg_pts, N * kMaxLessSharp) && dalloc(b, v.sg_pts, T) && dalloc(b, v.grid_mask, N * 2);
-    ok = ok && dalloc(b, v.lbc_pts, N * kMaxLessSharp) && dalloc(b, v.lbs_pts, T) && dalloc(b, v.lb_start, N * 2 * (kLineKeys + 1)) && dalloc(b, v.lb_elev, N * 2 * 66);
+    ok = ok && dalloc(b, v.lbc_pts, N * kMaxLessSharp + kLbPad) && dalloc(b, v.lbs_pts, T + kLbPad) && dalloc(b, v.lb_start, N * 2 * (kLineKeys + 1)) && dalloc(b, v.lb_elev, N * 2 * 66);
     ok = ok && dalloc(b, b->incr, N * 7) && dalloc(b, b->poses, N * 7) && dalloc(b, b->xq, 8);
     ok = ok && dalloc(b, b->corr_pair, (size_t)kMaxQueries * 4) && dalloc(b, b->crec_pair, (size_t)kMaxQueries * 4);
     if (!ok) {
@@ -535,9 +523,7 @@ static int ensure_odom_ws(lmono_ctx *c, lmono_scan_batch *b, int n_chains)
               dalloc(b, b->lm_info, (size_t)n_chains * 4) && dalloc(b, b->crec, (size_t)n_chains * kMaxQueries * 4) &&
               dalloc(b, b->seed, (size_t)n_chains * kMaxQueries) && dalloc(b, b->wl, 8 * ((size_t)n_chains * kMaxQueries + 1)) &&
               dalloc(b, b->ws, (size_t)n_chains * 8) && dalloc(b, b->resid_d, (size_t)n_chains) && dalloc(b, b->rstat, (size_t)n_chains * 4) &&
-              dalloc(b, b->rcount, (size_t)n_chains + 2) &&
-              dalloc(b, b->fs_list, (size_t)n_chains * kMaxQueries) && dalloc(b, b->dl, (size_t)n_chains * kMaxQueries) &&
-              dalloc(b, b->fs_off, (size_t)n_chains * (kCsSect + 1)) && dalloc(b, b->dl_cnt, (size_t)n_chains);
+              dalloc(b, b->rcount, (size_t)n_chains + 2);
     if (!ok) { c->err = "odometry workspace: hipMalloc failed"; return LMONO_ENOMEM; }
     b->chains_cap = n_chains;
     return LMONO_OK;
@@ -622,12 +608,6 @@ static int odom_launch_steps(lmono_ctx *c, lmono_scan_batch *b, const OdomView &
         while ((int)es->kev.size() <= i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; es->kev.push_back(e); }
         return es->kev[i];
     };
-    if (o.fs_list) {
-        // the features of every chain's first search of this launch sequence, sorted by sector (later ones: k_lm_solve's tail)
-        OdomView of = o;
-        of.chain0 = 0; of.chain1 = n_ch;
-        hipLaunchKernelGGL(k_feat_sectors, dim3(n_ch), dim3(256), 0, st, b->v, of, step_a);
-    }
     GroupFork fork(c, G, g_own);
     int rc = fork.fork();
     if (rc) return rc;
@@ -643,22 +623,12 @@ static int odom_launch_steps(lmono_ctx *c, lmono_scan_batch *b, const OdomView &
                 hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
                 if (g == 0 && es) { e0 = kev(*ne); e1 = kev(*ne + 1); e2 = kev(*ne + 2); }
                 if (e0 && e1 && e2) (void)hipEventRecord(e0, sg);
-                if (tile == 3 && og.fs_list) {
-                    hipLaunchKernelGGL(k_corr_sect, dim3(8 * ((ng + 7) / 8) * kCsSect), dim3(kCsT), sizeof(CsLds), sg, b->v, og, step, outer, c->opt[LMONO_OPT_DEFER_EVERY], c->stats_d);
-                    hipLaunchKernelGGL(k_corr_flat, dim3(8 * ((ng + 7) / 8) * kCfBlocks), dim3(kCfT), 0, sg, b->v, og, step, outer, wlg, 0, c->stats_d, 1);
-                    hipLaunchKernelGGL(k_correspond_list, dim3(kListGrid), dim3(256), 0, sg, b->v, og, step, outer, (const unsigned int *)wlg, c->stats_d);
-                } else if (tile == 3) {
-                    hipLaunchKernelGGL(k_corr_flat, dim3(8 * ((ng + 7) / 8) * kCfBlocks), dim3(kCfT), 0, sg, b->v, og, step, outer, wlg, c->opt[LMONO_OPT_DEFER_EVERY], c->stats_d, 0);
+                if (tile == 3) {
+                    hipLaunchKernelGGL(k_corr_flat, dim3(8 * ((ng + 7) / 8) * kCfBlocks), dim3(kCfT), 0, sg, b->v, og, step, outer, wlg, c->opt[LMONO_OPT_DEFER_EVERY], c->stats_d);
                     hipLaunchKernelGGL(k_correspond_list, dim3(kListGrid), dim3(256), 0, sg, b->v, og, step, outer, (const unsigned int *)wlg, c->stats_d);
                 }
 #ifdef LMONO_DIAG_SEARCH
-                else if (tile == 2) {
-                    hipLaunchKernelGGL(k_corr_thread, dim3(8 * ((ng + 7) / 8) * kCtBlocks), dim3(kCtT), 0, sg, b->v, og, step, outer, wlg);
-                    hipLaunchKernelGGL(k_correspond_list, dim3(kListGrid), dim3(256), 0, sg, b->v, og, step, outer, (const unsigned int *)wlg, c->stats_d);
-                } else if (tile) {
-                    hipLaunchKernelGGL(k_corr_tile, dim3(8 * ((ng + 7) / 8) * kTSect), dim3(kTT), kTileLds, sg, b->v, og, step, outer, wlg, c->stats_d);
-                    hipLaunchKernelGGL(k_correspond_list, dim3(kListGrid), dim3(256), 0, sg, b->v, og, step, outer, (const unsigned int *)wlg, c->stats_d);
-                } else
+                else
                     hipLaunchKernelGGL(k_correspond, dim3(8 * ((ng + 7) / 8) * kCorrBlocks), dim3(256), 0, sg, b->v, og, step, outer);
 #endif
                 if (e0 && e1 && e2) (void)hipEventRecord(e1, sg);
@@ -669,30 +639,6 @@ static int odom_launch_steps(lmono_ctx *c, lmono_scan_batch *b, const OdomView &
     }
     return fork.join();
 }
-
-// The persistent schedule: ONE launch, one 1024-thread workgroup per chain of view o (o.clist set: per listed chain) runs up to max_steps
-// scan pairs of its chain.  es / ne: group-0 style events around the launch (the whole odometry is one "correspondence" interval).
-static int odom_launch_chains(lmono_ctx *c, lmono_scan_batch *b, const OdomView &o, int n_ch, int max_steps, EvSet *es, int *ne)
-{
-    if (n_ch <= 0 || max_steps <= 0) return LMONO_OK;
-    hipStream_t st = c->stream;
-    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
-    if (es) {
-        auto kev = [&](int i) -> hipEvent_t {
-            while ((int)es->kev.size() <= i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; es->kev.push_back(e); }
-            return es->kev[i];
-        };
-        e0 = kev(*ne); e1 = kev(*ne + 1); e2 = kev(*ne + 2);
-    }
-    OdomView og = o;
-    og.chain0 = 0; og.chain1 = n_ch;
-    if (e0 && e1 && e2) (void)hipEventRecord(e0, st);
-    hipLaunchKernelGGL(k_odom_chain, dim3(n_ch), dim3(kOcT), sizeof(OcLds), st, b->v, og, max_steps, b->wl, c->opt[LMONO_OPT_DEFER_EVERY], c->stats_d);
-    if (e0 && e1 && e2) { (void)hipEventRecord(e1, st); (void)hipEventRecord(e2, st); *ne += 3; }
-    return check_launch(c, "k_odom_chain");
-}
-
-static bool odom_persistent(const lmono_ctx *c) { return c->opt[LMONO_OPT_CORR_TILE] == 3 && c->opt[LMONO_OPT_ODOM_PERSIST] != 0; }
 
 // Boundary validation + repair rounds of the chained schedule ("self-validating chains").  ext: incr[first - 1]
 // was supplied by the caller (previous rank's last increment).  Synchronises the context stream (the flagged count decides what is
@@ -729,12 +675,6 @@ static int odom_validate(lmono_ctx *c, lmono_scan_batch *b, OdomView o, bool ext
         R.flagged += nf; R.rounds += 1;
         OdomView orp = o;
         orp.repair = 1; orp.clist = (const int *)(b->rcount + 2); orp.lead_full = -1;
-        if (odom_persistent(c)) {
-            // a repair chain stops by itself at the first pair whose increment agrees with the stored one
-            int rc = odom_launch_chains(c, b, orp, nf, max_len, es, ne);
-            if (rc) return rc;
-            continue;
-        }
         const int G = odom_groups(c, nf);
         if (tile) for (int g = 0; g < G; g++) HIP_TRY(c, hipMemsetAsync(b->wl + g * ((size_t)b->chains_cap * kMaxQueries + 1), 0, sizeof(unsigned int), st));
         // a repair chain usually agrees with the stored increments after a few pairs: launch in chunks, ask the device how many still run
@@ -773,8 +713,6 @@ static OdomView odom_view(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int l
     o.state = b->state; o.corr = b->corr; o.incr = b->incr; o.lm_info = b->lm_info; o.crec = b->crec; o.seed = b->seed;
     o.ws = b->ws; o.repair = 0; o.step0 = 0; o.clist = nullptr; o.rstat = b->rstat; o.rcount = b->rcount;
     o.tol = 1e-9 * (double)c->opt[LMONO_OPT_BOUNDARY_TOL];
-    const bool sect = c->opt[LMONO_OPT_CORR_TILE] == 3 && c->opt[LMONO_OPT_CORR_SECT] != 0 && !odom_persistent(c);
-    o.fs_list = sect ? b->fs_list : nullptr; o.fs_off = b->fs_off; o.dl = b->dl; o.dl_cnt = b->dl_cnt;
     return o;
 }
 
@@ -810,8 +748,7 @@ static int odom_run(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, i
     if (tile) for (int g = 0; g < G; g++) HIP_TRY(c, hipMemsetAsync(b->wl + g * ((size_t)b->chains_cap * kMaxQueries + 1), 0, sizeof(unsigned int), st));
     EvSet &es = c->sets[c->n_sets - 1];
     int ne = 0;
-    if (odom_persistent(c)) rc = odom_launch_chains(c, b, o, n_chains, max_steps, &es, &ne);
-    else rc = odom_launch_steps(c, b, o, n_chains, 0, max_steps, G, &es, &ne);
+    rc = odom_launch_steps(c, b, o, n_chains, 0, max_steps, G, &es, &ne);
     if (rc) return rc;
     es.n_kev = ne;
     // the chained schedule validates itself: every chain's warm start against its predecessor's last increment, repair where they differ
@@ -1053,11 +990,7 @@ extern "C" int lmono_odom_correspond(lmono_ctx *c, lmono_scan_batch *b, int scan
         rc = ensure_odom_ws(c, b, 1);
         if (rc) return rc;
         HIP_TRY(c, hipMemsetAsync(b->wl, 0, sizeof(unsigned int), c->stream));
-        if (c->opt[LMONO_OPT_CORR_TILE] == 3) hipLaunchKernelGGL(k_corr_flat, dim3(8 * kCfBlocks), dim3(kCfT), 0, c->stream, b->v, o, 0, 0, b->wl, c->opt[LMONO_OPT_DEFER_EVERY], c->stats_d, 0);
-#ifdef LMONO_DIAG_SEARCH
-        else if (c->opt[LMONO_OPT_CORR_TILE] == 2) hipLaunchKernelGGL(k_corr_thread, dim3(8 * kCtBlocks), dim3(kCtT), 0, c->stream, b->v, o, 0, 0, b->wl);
-        else hipLaunchKernelGGL(k_corr_tile, dim3(8 * kTSect), dim3(kTT), kTileLds, c->stream, b->v, o, 0, 0, b->wl, c->stats_d);
-#endif
+        hipLaunchKernelGGL(k_corr_flat, dim3(8 * kCfBlocks), dim3(kCfT), 0, c->stream, b->v, o, 0, 0, b->wl, c->opt[LMONO_OPT_DEFER_EVERY], c->stats_d);
         hipLaunchKernelGGL(k_correspond_list, dim3(kListGrid), dim3(256), 0, c->stream, b->v, o, 0, 0, (const unsigned int *)b->wl, c->stats_d);
     }
 #ifdef LMONO_DIAG_SEARCH

@@ -271,11 +271,6 @@ struct OdomView {
     int *rstat;           // [n_chains][4] repair state: [0] stopped (agreement or end of chain), [1] pairs re-run in total, [2] flagged in the current round, [3] times flagged
     unsigned int *rcount; // [0] chains flagged by k_boundary_check, [1] repair chains still running, then the flagged chain ids (clist)
     double tol;           // agreement bound of boundary_residual()
-    // ---- sector-staged search (corr_sect.hip)
-    unsigned short *fs_list;  // [n_chains][kMaxQueries] feature indices of the chain's NEXT search, sorted by azimuth sector (feat_sectors)
-    int *fs_off;              // [n_chains][kCsSect + 1]
-    unsigned short *dl;       // [n_chains][kMaxQueries] features the staged search hands to k_corr_flat's list mode
-    int *dl_cnt;              // [n_chains]
 };
 
 // scans [first, n_scans) are cut into n_chains ranges; scans before `first` are an external lead-in (the previous rank's scans)
@@ -485,13 +480,17 @@ __device__ __forceinline__ double boundary_residual(const double *a, const doubl
     return r == r ? r : 1e300;            // a NaN never agrees
 }
 
-// ---- (line, azimuth-bin) index of a feature cloud -------------------------------------------------------------
-// The reference's scan-line walk only ever accepts candidates closer than 5 m to the (transformed) feature point, i.e.
-// within +-asin(5 / rho_xy) of its azimuth, and only on lines ra-2 .. ra+2.  k_line_index sorts a copy of every "last"
-// cloud by (line, azimuth bin) once per scan (counting sort in LDS), so that the walk of a feature is a handful of
-// short coalesced sweeps instead of a pass over five whole scan lines.
+// ---- (azimuth-bin, line) index of a feature cloud -------------------------------------------------------------
+// Every candidate the searches ever accept lies closer than 5 m to the (transformed) feature point, i.e. within +-asin(r / rho_xy)
+// of its azimuth and within a few scan lines of its elevation.  k_line_index sorts a copy of every "last" cloud by
+// (azimuth bin, scan line) once per scan (counting sort in LDS) and keeps the start of every (bin, line) bucket: the candidates of a
+// ball are then ONE contiguous run per azimuth bin of its arc, covering the lines v1 .. v2 its elevation window admits (round 4; until
+// then the copy was (line, bin)-major and a ball was one ~2-point run per line: every 16-B candidate gather was its own 128-B L1 access).
+// A point of the copy carries (cloud index << 7 | line) in .w.
 constexpr int kAzBins = 384;           // 0.9375 deg: about one point of a 0.2 m-voxelised cloud per bin and line at 12 m
 constexpr int kLineKeys = 66 * kAzBins;
+__device__ __forceinline__ int lb_key(int bin, int line) { return bin * 66 + line; }
+constexpr int kLbPad = 4;              // entries behind the index copies: k_corr_flat's 64-B chunks may read up to three points past a run
 
 __device__ __forceinline__ int az_bin(float x, float y)
 {
@@ -514,7 +513,7 @@ constexpr int kLiT = 1024;     // threads of k_line_index
 constexpr int kLiLdsHalf = kLineKeys * 2, kLiLdsFull = kLineKeys * 4;   // dynamic LDS: one 16-bit / 32-bit counter per (line, bin)
 constexpr int kLiBigGrid = 64;
 
-// One (scan, cloud): copy of the cloud counting-sorted by (line, azimuth bin), the (line, bin) start table, per-line elevation bounds.
+// One (scan, cloud): copy of the cloud counting-sorted by (azimuth bin, line), the (bin, line) start table, per-line elevation bounds.
 // kHalf: the counters are 16-bit halves of 32-bit LDS words (50 KB instead of 101 KB: three workgroups per CU instead of one --
 // the kernel is bound by its own dependent rounds, not by bytes); a cloud of more than 65535 points cannot be counted in 16 bits
 // and goes through the work list `li_todo` to the full-width launch (small fixed grid, normally empty).
@@ -547,7 +546,7 @@ __device__ __forceinline__ void line_index_cloud(const BatchView &b, int s, bool
         for (int q = 0; q < 4; q++) {
             const bool ok = base + tid + kLiT * q < n;
             const int ln = line_of(p[q].w);
-            if (ok) (void)bump(ln * kAzBins + az_bin(p[q].x, p[q].y));
+            if (ok) (void)bump(lb_key(az_bin(p[q].x, p[q].y), ln));
             const unsigned long long act = __ballot(ok);
             if (act == 0ull) continue;
             const int eo = f2ord(elev_of(p[q].x, p[q].y, p[q].z));
@@ -611,8 +610,9 @@ __device__ __forceinline__ void line_index_cloud(const BatchView &b, int s, bool
         for (int q = 0; q < 4; q++) {
             const int i = i0 + kLiT * q;
             if (i < n) {
-                const int d = bump(line_of(p[q].w) * kAzBins + az_bin(p[q].x, p[q].y));
-                dst[d] = make_float4(p[q].x, p[q].y, p[q].z, __int_as_float(i));
+                const int ln = line_of(p[q].w);
+                const int d = bump(lb_key(az_bin(p[q].x, p[q].y), ln));
+                dst[d] = make_float4(p[q].x, p[q].y, p[q].z, __int_as_float((i << 7) | ln));
             }
         }
     }
@@ -717,19 +717,13 @@ __device__ __forceinline__ void nn_update(NnBest &bst, const float4 &p, float qx
     bst = k < bst ? k : bst;
 }
 
-// the same for a point of the (line, azimuth-bin) index, whose .w is the plain cloud index
-__device__ __forceinline__ void nn_update_line(NnBest &bst, const float4 &p, int line, float qx, float qy, float qz)
-{
-    const float d = dist2f(p.x, p.y, p.z, qx, qy, qz);
-    const NnBest k = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)((__float_as_int(p.w) << 7) | line);
-    bst = k < bst ? k : bst;
-}
-
-__device__ __forceinline__ void walk_point(const float4 &cpt, int v, int ra, int closest, int w_lo, int w_hi, bool edge,
+// walk candidate from the (azimuth bin, line) index: .w = cloud index << 7 | line; only lines ra-2 .. ra+2 take part
+__device__ __forceinline__ void walk_point(const float4 &cpt, int ra, int closest, int w_lo, int w_hi, bool edge,
                                            float qx, float qy, float qz, WalkBest &bs, WalkBest &bo)
 {
-    const int j = __float_as_int(cpt.w);
-    if (j == closest || j < w_lo || j >= w_hi) return;
+    const int w = __float_as_int(cpt.w);
+    const int j = w >> 7, v = w & 127;
+    if (v < ra - 2 || v > ra + 2 || j == closest || j < w_lo || j >= w_hi) return;
     const bool fwd = j > closest;
     const unsigned int seq = fwd ? (unsigned int)(j - closest - 1) : kSeqBack + (unsigned int)(closest - 1 - j);
     const float d = dist2f(cpt.x, cpt.y, cpt.z, qx, qy, qz);
@@ -772,32 +766,15 @@ __device__ __forceinline__ void nn_sweep(const float4 *gpts, int run, int gl, in
     }
 }
 
-// the same over runs of the (line, azimuth-bin) index: lane i of the group holds the run (st, cn) of scan line v0 + i; the
-// points of the index carry their cloud index in .w and the line is the row
-__device__ __forceinline__ void nn_sweep_rows(const float4 *lpts, int run, int v0, int gl, int gbase, float qx, float qy, float qz, NnBest &nb)
+// the group sweeps one contiguous run of the (azimuth bin, line) index (all lines of an arc of bins), four loads per lane in flight
+__device__ __forceinline__ void nn_sweep_arc(const float4 *lpts, int st, int cn, int gl, float qx, float qy, float qz, NnBest &nb)
 {
-    unsigned int m = group_ballot(run >= (1 << 17), gbase);
-    while (m) {
-        int s4[4], n4[4], l4[4];
+    for (int i = gl; i < cn; i += 4 * kGroup) {
         float4 v4[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            int rv = 0;
-            l4[u] = 0;
-            if (m) {
-                const int src = __ffs((int)m) - 1;
-                m &= m - 1;
-                rv = __shfl(run, src, kGroup); l4[u] = v0 + src;
-            }
-            s4[u] = rv & 0x1ffff; n4[u] = rv >> 17;
-            v4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gl < n4[u]) v4[u] = lpts[s4[u] + gl];
-        }
+        for (int u = 0; u < 4; u++) v4[u] = lpts[st + min(i + u * kGroup, cn - 1)];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (gl < n4[u]) nn_update_line(nb, v4[u], l4[u], qx, qy, qz);
-            for (int i = gl + kGroup; i < n4[u]; i += kGroup) nn_update_line(nb, lpts[s4[u] + i], l4[u], qx, qy, qz);
-        }
+        for (int u = 0; u < 4; u++) if (i + u * kGroup < cn) nn_update(nb, v4[u], qx, qy, qz);
     }
 }
 
@@ -913,17 +890,11 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
                 if (hi - lo + 1 < kAzBins) { b_lo = ((lo % kAzBins) + kAzBins) % kAzBins; nbins = hi - lo + 1; }
             }
             const int b_end = b_lo + nbins;
-            for (int v0 = 0; v0 < 66; v0 += kGroup) {
-                const int v = v0 + gl;
-                int run0 = 0, run1 = 0;
-                if (v < 66) {
-                    const int *row = table + v * kAzBins;
-                    const int s0 = row[b_lo];
-                    run0 = pack_run(s0, row[min(b_end, kAzBins)] - s0);
-                    if (b_end > kAzBins) { const int s1 = row[0]; run1 = pack_run(s1, row[b_end - kAzBins] - s1); }
-                }
-                nn_sweep_rows(lb_pts, run0, v0, gl, gbase, qx, qy, qz, nb);
-                if (b_end > kAzBins) nn_sweep_rows(lb_pts, run1, v0, gl, gbase, qx, qy, qz, nb);
+            // all lines of the arc's bins are ONE contiguous run of the (bin, line)-major copy (two when the arc wraps)
+            {
+                const int s0 = table[lb_key(b_lo, 0)];
+                nn_sweep_arc(lb_pts, s0, table[lb_key(min(b_end, kAzBins), 0)] - s0, gl, qx, qy, qz, nb);
+                if (b_end > kAzBins) nn_sweep_arc(lb_pts, table[0], table[lb_key(b_end - kAzBins, 0)] - table[0], gl, qx, qy, qz, nb);
             }
             best = group_min_u64(nb, gbase);
         }
@@ -958,38 +929,19 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
             if (hi - lo + 1 < kAzBins) { b_lo = ((lo % kAzBins) + kAzBins) % kAzBins; nbins = hi - lo + 1; }
         }
         const int b_end = b_lo + nbins;
-        // lanes 0..4: bucket bounds of lines ra-2..ra+2 (two runs when the arc wraps past the last bin)
-        int ua = 0, ub = 0;    // pack_run(start, count) of the arc on this lane's line; ub = the part past the last bin
-        {
-            const int v = ra - 2 + gl;
-            if (gl < 5 && v >= 0 && v <= 65 && !(edge && v == ra)) {   // edges never use the nearest point's own line
-                const int *row = table + v * kAzBins;
-                const int u0 = row[b_lo];
-                ua = pack_run(u0, row[min(b_end, kAzBins)] - u0);
-                if (b_end > kAzBins) { const int u2 = row[0]; ub = pack_run(u2, row[b_end - kAzBins] - u2); }
-            }
-        }
+        // the arc's bins with all their lines are one contiguous run (two when the arc wraps); the lines ra-2 .. ra+2 are picked out by
+        // walk_point (this is the fall-back kernel: simple beats fast)
         WalkBest bs = thr, bo = thr;
-        // the five lines side by side, one per 6-lane sub-group (lanes 30, 31 idle): the arcs hold few points per line
-        // (~17 surf, ~4 corner in the narrow arc), so a 32-lane load per line would leave most lanes idle
-        const int wsub = gl / 6, wsl = gl - 6 * wsub;
-        const int wv = ra - 2 + wsub;
         for (int part = 0; part < 2; part++) {
             if (part == 1 && b_end <= kAzBins) break;
-            const int rv = __shfl(part ? ub : ua, min(wsub, 4), kGroup);
-            const int r0 = rv & 0x1ffff, cnw = wsub < 5 ? rv >> 17 : 0;
-            int i = wsl;
-            while (__any(i < cnw)) {
-                float4 v0 = make_float4(0.f, 0.f, 0.f, __int_as_float(-1)), v1 = v0, v2 = v0, v3 = v0;
-                if (i < cnw) v0 = lb_pts[r0 + i];
-                if (i + 6 < cnw) v1 = lb_pts[r0 + i + 6];
-                if (i + 12 < cnw) v2 = lb_pts[r0 + i + 12];
-                if (i + 18 < cnw) v3 = lb_pts[r0 + i + 18];
-                if (i < cnw) walk_point(v0, wv, ra, closest, w_lo, w_hi, edge, qx, qy, qz, bs, bo);
-                if (i + 6 < cnw) walk_point(v1, wv, ra, closest, w_lo, w_hi, edge, qx, qy, qz, bs, bo);
-                if (i + 12 < cnw) walk_point(v2, wv, ra, closest, w_lo, w_hi, edge, qx, qy, qz, bs, bo);
-                if (i + 18 < cnw) walk_point(v3, wv, ra, closest, w_lo, w_hi, edge, qx, qy, qz, bs, bo);
-                i += 24;
+            const int r0 = part ? table[0] : table[lb_key(b_lo, 0)];
+            const int cnw = (part ? table[lb_key(b_end - kAzBins, 0)] : table[lb_key(min(b_end, kAzBins), 0)]) - r0;
+            for (int i = gl; i < cnw; i += 4 * kGroup) {
+                float4 v4[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) v4[u] = lb_pts[r0 + min(i + u * kGroup, cnw - 1)];
+#pragma unroll
+                for (int u = 0; u < 4; u++) if (i + u * kGroup < cnw) walk_point(v4[u], ra, closest, w_lo, w_hi, edge, qx, qy, qz, bs, bo);
             }
         }
         same = group_min_u64(bs, gbase);
@@ -1482,9 +1434,6 @@ __device__ __forceinline__ void lm_trust_region(const Eval &ev, double *x, doubl
     }
 }
 
-constexpr int kCsSectFwd = 32;
-__device__ __forceinline__ void feat_sectors(const BatchView &b, const OdomView &o, int c, int k, const double *x, bool thin, int *s_cnt);
-
 __global__ __launch_bounds__(kLmT) void k_lm_solve(BatchView b, OdomView o, int step, int outer, unsigned int *wl_reset)
 {
     const int c = o.clist ? o.clist[o.chain0 + blockIdx.x] : o.chain0 + (int)blockIdx.x;
@@ -1552,15 +1501,6 @@ __global__ __launch_bounds__(kLmT) void k_lm_solve(BatchView b, OdomView o, int 
         if (o.ws && !o.repair && outer == 1 && k == s - 1)
             for (int i = 0; i < 7; i++) o.ws[c * 8 + i] = x[i];       // the warm start of the chain's first owned pair
         if (o.lm_info) { o.lm_info[c * 4 + outer] = iter; o.lm_info[c * 4 + 2 + outer] = n_used; }
-    }
-    if (o.fs_list) {
-        // the sector-staged search of the chain's next launch (outer 1 of this pair, or outer 0 of the next pair) wants the features
-        // sorted by the azimuth sector of their position at THIS pose; its deferred list starts empty
-        __shared__ int s_sect[kCsSectFwd + 1];
-        int own2;
-        const int kn = outer == 0 ? k : chain_scan(o, c, step + 1, own2);
-        if (tid == 0) o.dl_cnt[c] = 0;
-        if (kn >= 0) feat_sectors(b, o, c, kn, x, lead_in_thinned(o, kn, s), s_sect);
     }
 }
 

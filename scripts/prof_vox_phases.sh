@@ -2,8 +2,8 @@
 # Phase cycles of one k_voxel workgroup (ring 20 of scan 3) in a -DLMONO_VOX_PROF build made on the box; idle GPU (8 scans) and loaded (512 scans).
 set -e
 mkdir -p gpurun_out/vox_prof
-cp lmono_amd/lib/liblmono_hip.so gpurun_out/vox_prof/keep.so
-hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -std=c++17 -DLMONO_VOX_PROF -o lmono_amd/lib/liblmono_hip.so lmono_amd/csrc/lmono_hip.hip 2>/dev/null
+hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -std=c++17 -DLMONO_VOX_PROF -o gpurun_out/vox_prof/prof.so lmono_amd/csrc/lmono_hip.hip 2>/dev/null
+export LMONO_HIP_LIB=$PWD/gpurun_out/vox_prof/prof.so      # a scratch library: the product library is never overwritten
 timeout -k 10 120 python - <<'PY' | tee gpurun_out/vox_prof/phases.txt
 import sys, numpy as np, torch
 sys.path.insert(0, '.')
@@ -17,4 +17,4 @@ for n in (8, 512):
     for _ in range(2):
         b.scanreg(xd.data_ptr(), off, 64, 5.0, keepalive=xd); ctx.synchronize()
 PY
-cp gpurun_out/vox_prof/keep.so lmono_amd/lib/liblmono_hip.so; rm gpurun_out/vox_prof/keep.so
+rm -f gpurun_out/vox_prof/prof.so

@@ -1,7 +1,7 @@
 """Run by tests/test_lidar_gpu.py::test_search_formulations_agree_in_the_diagnostic_build in a child process whose LMONO_HIP_LIB points at
-lmono_amd/lib/liblmono_hip_diag.so (-DLMONO_DIAG_SEARCH): the product library holds the default search only; its three measured
-alternatives (k_correspond on hash grids, k_corr_tile, k_corr_thread; profiles/r2/NOTES.md) live in the diagnostic build, where this
-four-way equality is the strongest check each formulation has."""
+lmono_amd/lib/liblmono_hip_diag.so (-DLMONO_DIAG_SEARCH): the product library holds the default search only (k_corr_flat over the
+(azimuth bin, scan line) index); the round-1 search (k_correspond on 1 m hash grids, an independent formulation of the same exact search) lives
+in the diagnostic build, where the two are checked against each other and against the oracle."""
 import numpy as np
 import pytest
 
@@ -20,7 +20,7 @@ def _register(ctx, xyzi, off, n_lines=64, min_range=5.0):
 def test_tile_search_equals_global_search(oracle, gpu_ctx, full_seq):
     import lmono_amd
     assert b"diagnostic build" in lmono_amd.load_library().lmono_version()
-    """The LDS tile search (k_corr_tile + the deferred list) and the global-memory search (k_correspond) return the same
+    """The flat search (k_corr_flat + the deferred list) and the hash-grid search (k_correspond) return the same
     correspondence indices for good and bad warm starts, and the same odometry bit for bit (same residual blocks, same solve)."""
     xyzi, off = full_seq["xyzi"], full_seq["off"]
     batch = _register(gpu_ctx, xyzi, off)
@@ -34,7 +34,7 @@ def test_tile_search_equals_global_search(oracle, gpu_ctx, full_seq):
                 q = q / np.linalg.norm(q)
                 gpu_ctx.set_option(gpu_ctx.OPT_CORR_TILE, 3)
                 ref = batch.correspond(k, q, t)
-                for mode in (1, 2, 3):       # 1: LDS sector tiles, 2: thread per feature, 3: flattened sweeps (default)
+                for mode in (0, 3):          # 0: 32 lanes per feature on the hash grid, 3: flattened sweeps (default)
                     gpu_ctx.set_option(gpu_ctx.OPT_CORR_TILE, mode)
                     gpu_ctx.timing_reset()
                     got = batch.correspond(k, q, t)
@@ -44,7 +44,7 @@ def test_tile_search_equals_global_search(oracle, gpu_ctx, full_seq):
         # a batch registered under the default mode has no hash grids; the deferred-list kernel then searches through the line index alone
         gpu_ctx.set_option(gpu_ctx.OPT_CORR_TILE, 3)
         i0, p0 = batch.odometry(1, 0)
-        for mode in (1, 2, 3):
+        for mode in (0, 3):
             gpu_ctx.set_option(gpu_ctx.OPT_CORR_TILE, mode)
             i1, p1 = batch.odometry(1, 0)
             assert np.array_equal(i0, i1) and np.array_equal(p0, p1)
@@ -90,7 +90,7 @@ def test_odometry_other_sensors_and_near_points(oracle, gpu_ctx, n_lines, min_ra
     for k in (1, 2):
         _, _, _, corr = oracle.odom_step(f[k]["sharp"], f[k]["flat"], f[k - 1]["less_sharp"], f[k - 1]["less_flat"], q, t, want_corr=True)
         try:
-            for mode in (3, 0, 1, 2):
+            for mode in (3, 0):
                 gpu_ctx.set_option(gpu_ctx.OPT_CORR_TILE, mode)
                 assert np.array_equal(batch.correspond(k, q, t), corr[0]), "mode %d, scan %d" % (mode, k)
         finally:

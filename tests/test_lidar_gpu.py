@@ -155,8 +155,8 @@ def test_correspondences_match_oracle(oracle, gpu_ctx, small_seq):
 
 
 def test_search_formulations_agree_in_the_diagnostic_build(gpu_ctx):
-    """The product library compiles the default search only (LMONO_OPT_CORR_TILE 0 .. 2 are refused); the four-way equality of the search
-    formulations runs against the diagnostic build of the same sources in a child process (tests/diag_search_modes.py)."""
+    """The product library compiles the default search only (every LMONO_OPT_CORR_TILE but 3 is refused); its equality with the round-1
+    hash-grid search runs against the diagnostic build of the same sources in a child process (tests/diag_search_modes.py)."""
     import os
     import subprocess
     import sys
@@ -368,7 +368,7 @@ def test_api_errors_and_limits(oracle, gpu_ctx, small_seq):
     incr, poses = one.odometry(1, 0)                                # a single scan: identity
     assert np.array_equal(incr, np.array([[0, 0, 0, 1, 0, 0, 0.0]])) and np.array_equal(poses, incr)
     # options: values are range-checked, a rejected value leaves the option as it was, values may be negative
-    for key, bad in ((gpu_ctx.OPT_CORR_TILE, 4), (gpu_ctx.OPT_CORR_TILE, -1), (gpu_ctx.OPT_CORR_TILE, 1), (gpu_ctx.OPT_ODOM_STREAMS, 0), (gpu_ctx.OPT_ODOM_STREAMS, 9),
+    for key, bad in ((gpu_ctx.OPT_CORR_TILE, 4), (gpu_ctx.OPT_CORR_TILE, -1), (gpu_ctx.OPT_CORR_TILE, 1), (5, 1), (6, 1), (gpu_ctx.OPT_ODOM_STREAMS, 0), (gpu_ctx.OPT_ODOM_STREAMS, 9),
                      (gpu_ctx.OPT_DEFER_EVERY, -1), (gpu_ctx.OPT_LEAD_FULL, -2), (gpu_ctx.OPT_BOUNDARY_TOL, -1), (17, 0)):
         before = gpu_ctx.get_option(key) if key < 5 else None
         with pytest.raises(lmono_amd.LmonoError):
@@ -434,70 +434,32 @@ def test_full_size_batch_properties(gpu_ctx, oracle):
     assert (fwd > 0.5).all() and (fwd < 1.1).all()                  # ~0.8 m per scan
 
 
-def test_persistent_chain_kernel_equals_launch_per_phase_schedule(oracle, gpu_ctx, small_seq):
-    """LMONO_OPT_ODOM_PERSIST: one workgroup per chain running all its scan pairs in one launch (k_odom_chain) against one
-    launch per phase (k_corr_flat + k_correspond_list + k_lm_solve, the default): same correspondences, increments equal to the rounding of the
-    solve's reductions (1024 vs 256 threads) -- sequential, chained with a thinned lead-in, with the fall-back searches forced
-    (LMONO_OPT_DEFER_EVERY) and with the boundary validation repairing chains in both schedules."""
-    xyzi, off = small_seq["xyzi"], small_seq["off"]
-    batch = _register(gpu_ctx, xyzi, off)
-    ref = oracle.run_sequence(xyzi, off)
-    out = {}
-    try:
-        for persist in (1, 0):
-            gpu_ctx.set_option(gpu_ctx.OPT_ODOM_PERSIST, persist)
-            res = [batch.odometry(1, 0)[0]]
-            gpu_ctx.set_option(gpu_ctx.OPT_LEAD_FULL, 1)
-            res.append(batch.odometry(3, 2)[0])
-            gpu_ctx.set_option(gpu_ctx.OPT_BOUNDARY_TOL, 0)
-            res.append(batch.odometry(3, 2)[0])
-            gpu_ctx.set_option(gpu_ctx.OPT_BOUNDARY_TOL, 1000)
-            gpu_ctx.set_option(gpu_ctx.OPT_LEAD_FULL, -1)
-            gpu_ctx.set_option(gpu_ctx.OPT_DEFER_EVERY, 3)
-            res.append(batch.odometry(1, 0)[0])
-            gpu_ctx.set_option(gpu_ctx.OPT_DEFER_EVERY, 0)
-            out[persist] = res
-    finally:
-        gpu_ctx.set_option(gpu_ctx.OPT_ODOM_PERSIST, 0)
-        gpu_ctx.set_option(gpu_ctx.OPT_LEAD_FULL, -1)
-        gpu_ctx.set_option(gpu_ctx.OPT_BOUNDARY_TOL, 1000)
-        gpu_ctx.set_option(gpu_ctx.OPT_DEFER_EVERY, 0)
-    for a, b_ in zip(out[1], out[0]):
-        assert np.abs(a - b_).max() < 1e-10
-    assert np.abs(out[1][0] - ref["incr"]).max() < 1e-9 and np.abs(out[1][3] - ref["incr"]).max() < 1e-9
-
-
 @pytest.mark.parametrize("n_lines,n_az,min_range", [(64, 500, 5.0), (64, 2000, 5.0), (32, 1800, 0.5), (16, 600, 0.5)])
-def test_sector_staged_search_equals_flat_search(oracle, gpu_ctx, n_lines, n_az, min_range):
-    """LMONO_OPT_CORR_SECT: the sector-staged search (k_corr_sect: candidates and tables read from an LDS-staged azimuth window, features
-    whose ball leaves the window through k_corr_flat's list mode) against k_corr_flat over global memory for every feature: the same
-    correspondences, hence bit-identical increments -- sequential, chained with a thinned lead-in and repairs, from bad warm starts (the
-    first pair of every chain starts from the identity), with the fall-back hook on."""
+def test_fall_back_search_changes_nothing_in_any_schedule(oracle, gpu_ctx, n_lines, n_az, min_range):
+    """LMONO_OPT_DEFER_EVERY hands every n-th feature point of the default search to its fall-back kernel (k_correspond_list on the same
+    (azimuth bin, scan line) index, no hash grid): bit-identical increments -- sequential, chained with a thinned lead-in and repairs, and
+    from bad warm starts (the first pair of every chain starts from the identity)."""
     w = oracle.S1World(n_az=n_az, n_rings=n_lines)
     xyzi, off = w.scans(w.trajectory(8))
     batch = _register(gpu_ctx, xyzi, off, n_lines, min_range)
     out = {}
     try:
-        for sect in (0, 1):
-            gpu_ctx.set_option(gpu_ctx.OPT_CORR_SECT, sect)
+        for every in (0, 3, 7):
+            gpu_ctx.set_option(gpu_ctx.OPT_DEFER_EVERY, every)
+            gpu_ctx.timing_reset()
             res = [batch.odometry(1, 0)[0]]
             gpu_ctx.set_option(gpu_ctx.OPT_LEAD_FULL, 1)
             res.append(batch.odometry(4, 2)[0])
             gpu_ctx.set_option(gpu_ctx.OPT_LEAD_FULL, -1)
-            gpu_ctx.set_option(gpu_ctx.OPT_DEFER_EVERY, 7)
-            gpu_ctx.timing_reset()
             res.append(batch.odometry(2, 3)[0])
-            gpu_ctx.timing()
-            res.append(float(gpu_ctx.diag[0]))
-            assert gpu_ctx.diag[1] == 0 and gpu_ctx.diag[2] == 0          # the kernels' index guards never had to act
-            gpu_ctx.set_option(gpu_ctx.OPT_DEFER_EVERY, 0)
-            out[sect] = res
+            deferred = gpu_ctx.timing()[0]["deferred_features"]
+            assert (deferred > 0) == (every > 0)
+            out[every] = res
     finally:
-        gpu_ctx.set_option(gpu_ctx.OPT_CORR_SECT, 0)
         gpu_ctx.set_option(gpu_ctx.OPT_LEAD_FULL, -1)
         gpu_ctx.set_option(gpu_ctx.OPT_DEFER_EVERY, 0)
-    for a, b_ in zip(out[0][:3], out[1][:3]):
-        assert np.array_equal(a, b_)
-    assert out[1][3] > 0                      # the hook sent features through the list mode
+    for every in (3, 7):
+        for a, b_ in zip(out[0], out[every]):
+            assert np.array_equal(a, b_)
     ref = oracle.run_sequence(xyzi, off, n_lines, min_range)
-    assert np.abs(out[1][0] - ref["incr"]).max() < 1e-9
+    assert np.abs(out[0][0] - ref["incr"]).max() < 1e-9
