@@ -547,8 +547,8 @@ def main():
                     help="weak: every rank gets --scans scans of one long trajectory; strong: --scans scans in total, sharded "
                          "over the ranks (BASELINE configs[3]: seq 00 sharded across 8)")
     ap.add_argument("--chains", type=int, default=256, help="concurrent odometry chains per GPU (strong scaling: in total)")
-    ap.add_argument("--lead", type=int, default=4, help="lead-in scans of a chain that does not start at scan 0")
-    ap.add_argument("--lead-full", type=int, default=2,
+    ap.add_argument("--lead", type=int, default=6, help="lead-in scans of a chain that does not start at scan 0")
+    ap.add_argument("--lead-full", type=int, default=3,
                     help="lead-in scan pairs of a chain (the last ones) that use all feature points; the earlier ones a quarter (-1: all use all)")
     ap.add_argument("--kitti-dir", default="", help="read the scans of a KITTI-layout sequence directory (velodyne/%%06d.bin + times.txt, e.g. "
                     "dataset/sequences/00: /root/reference/README.md:48-60) instead of generating S1 scans; --scans caps the count")
@@ -663,7 +663,13 @@ def main():
     batch = lmono_amd.ScanBatch(ctx, n_local, total_pts)
     incr_d = torch.zeros((n_local, 7), dtype=torch.float64, device=dev)
     poses_d = torch.zeros((n_own, 7), dtype=torch.float64, device=dev)
-    chains = max(1, min(args.chains // world if strong else args.chains, n_local))
+    # chains of this rank.  Weak scaling: --chains per rank.  Strong scaling: a rank's share of the scans is cut by RULE, not by --chains // world:
+    # as many chains as keep a chain at least 4 lead-ins long (the speculative lead-in pairs stay below a quarter of a chain's own), at most
+    # --chains; with 4541 scans and lead 4 that gives 256 / 141 / 70 / 35 chains per rank at 1 / 2 / 4 / 8 ranks
+    chains = args.chains
+    if strong and world > 1:
+        chains = min(args.chains, max(1, n_own // (4 * max(args.lead, 1))))
+    chains = max(1, min(chains, n_local))
 
     boundary, shard_rounds = [], [0]
 

@@ -53,22 +53,25 @@ constexpr int kCfPool = kCfT * kCfPer;        // run descriptors per round
 // less-flat cloud dense.  Any value is exact; measured per bench step: (0.3, 0.3) 49.0 ms, (0.5, 0.3) 48.8, (0.5, 0.2) 48.1, (0.5, 0.15) 47.8,
 // (0.5, 0.1) 48.4, (0.8, 0.3) 49.0; a term proportional to the range did not help.
 #ifndef LMONO_R0_PLANE
-#define LMONO_R0_PLANE 0.15f
-#define LMONO_R0_EDGE 0.5f
+#define LMONO_R0_PLANE 0.25f
+#define LMONO_R0_EDGE 0.7f
 #endif
 constexpr float kCfR0Edge = LMONO_R0_EDGE, kCfR0Plane = LMONO_R0_PLANE;
-constexpr int kCfC = 4;                        // points per chunk = loads in flight per lane (64 contiguous bytes)
+constexpr int kCfC = 4;                        // points per chunk (64 contiguous bytes)
+#ifndef LMONO_CF_B
+#define LMONO_CF_B 2
+#endif
+constexpr int kCfB = LMONO_CF_B;               // chunks per lane in flight (kCfB x kCfC 16-B loads)
 static_assert(kCfC - 1 <= kLbPad, "a chunk's loads may run kCfC - 1 points past its run: the index copies are padded");
 #ifndef LMONO_WALK_TIGHT
 #define LMONO_WALK_TIGHT 1      // a walk pass that SAW its partners outside its ball continues with the ball that just holds them, not with the next rung
 #endif
 
-// run request, one word: bin (9 bits) | first line (7) << 9 | last line + 1 (7) << 16 | owner (8) << 23 | surf cloud << 31
-__device__ __forceinline__ unsigned int cf_request(int v1, int v2p1, int owner, bool surf)
-{
-    return ((unsigned int)v1 << 9) | ((unsigned int)v2p1 << 16) | ((unsigned int)owner << 23) | (surf ? 0x80000000u : 0u);
-}
-static_assert(kCfT <= 256 && kAzBins <= 512, "request packing");
+// run request, one word.  (bin, line)-major copy: bin (9 bits) | first line (7) << 9 | last line + 1 (7) << 16 | owner (7) << 23;
+// (line, bin)-major copy: line (7 bits) | first bin (9) << 7 | bins (9) << 16 | owner (7) << 25.  The cloud follows from the owner.
+__device__ __forceinline__ unsigned int cf_request(int v1, int v2p1, int owner) { return ((unsigned int)v1 << 9) | ((unsigned int)v2p1 << 16) | ((unsigned int)owner << 23); }
+__device__ __forceinline__ unsigned int cf_request_line(int line, int b0, int nb, int owner) { return (unsigned int)line | ((unsigned int)b0 << 7) | ((unsigned int)nb << 16) | ((unsigned int)owner << 25); }
+static_assert(kCfT <= 128 && kAzBins <= 511, "request packing");
 
 struct CfRun {                                // resolved run
     unsigned int start;                       // first point of the run in its index copy
@@ -117,6 +120,14 @@ __device__ __forceinline__ void cf_post(unsigned int *req, int slot, const CfArc
     int bn = a.a0;
     for (int t = 0; t < a.nb; t++) { req[slot + t] = rq0 | (unsigned int)bn; bn = bn + 1 == kAzBins ? 0 : bn + 1; }
 }
+// (line, bin)-major copy: the arc on one line is one run, two when it wraps past the last bin
+__device__ __forceinline__ int cf_arc_pieces(const CfArc &a) { return a.a0 + a.nb > kAzBins ? 2 : 1; }
+__device__ __forceinline__ void cf_post_line(unsigned int *req, int &slot, const CfArc &a, int line, int owner)
+{
+    const int n0 = min(a.nb, kAzBins - a.a0);
+    req[slot++] = cf_request_line(line, a.a0, n0, owner);
+    if (n0 < a.nb) req[slot++] = cf_request_line(line, 0, a.nb - n0, owner);
+}
 
 // first line whose envelope A (min of lo over lines <= v, non-increasing) is <= ehi; 66 when none
 __device__ __forceinline__ int cf_first_line(const float4 *el, float ehi)
@@ -146,21 +157,28 @@ __device__ __forceinline__ int cf_last_line(const float4 *el, float elo)
 #endif
 
 template <bool kWalk>
-__device__ __forceinline__ void cf_sweep(CfLds &L, const int *tg_c, const int *tg_s, const float4 *pts_c, const float4 *pts_s, unsigned long long &cf_t, unsigned long long *cf_acc)
+__device__ __forceinline__ void cf_sweep(CfLds &L, int n_edge_owner, const int *tg_c, const int *tg_s, const float4 *pts_c, const float4 *pts_s, unsigned long long &cf_t, unsigned long long *cf_acc)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_pool = min(L.n_pool, kCfPool);
     // ---- 1b: resolve this lane's kCfPer consecutive requests (all table loads in flight together), prefix of the chunk counts
-    unsigned int st[kCfPer], en[kCfPer], rq[kCfPer];
+    unsigned int st[kCfPer], en[kCfPer];
+    int own[kCfPer];
 #pragma unroll
     for (int j = 0; j < kCfPer; j++) {
         const int i = tid * kCfPer + j;
-        st[j] = 0; en[j] = 0; rq[j] = 0;
+        st[j] = 0; en[j] = 0; own[j] = 0;
         if (i < n_pool) {
-            rq[j] = L.req[i];
-            const int *tg = (rq[j] & 0x80000000u) ? tg_s : tg_c;
-            const int row = (int)(rq[j] & 511u) * 66;
-            st[j] = (unsigned int)tg[row + (int)((rq[j] >> 9) & 127u)]; en[j] = (unsigned int)tg[row + (int)((rq[j] >> 16) & 127u)];
+            const unsigned int rq = L.req[i];
+            own[j] = (int)(rq >> (kLbLineMajor ? 25 : 23)) & 127;
+            const int *tg = own[j] >= n_edge_owner ? tg_s : tg_c;
+            if (kLbLineMajor) {
+                const int e0 = (int)(rq & 127u) * kAzBins + (int)((rq >> 7) & 511u);
+                st[j] = (unsigned int)tg[e0]; en[j] = (unsigned int)tg[e0 + (int)((rq >> 16) & 511u)];
+            } else {
+                const int row = (int)(rq & 511u) * 66;
+                st[j] = (unsigned int)tg[row + (int)((rq >> 9) & 127u)]; en[j] = (unsigned int)tg[row + (int)((rq >> 16) & 127u)];
+            }
         }
     }
     int sum = 0;
@@ -178,7 +196,7 @@ __device__ __forceinline__ void cf_sweep(CfLds &L, const int *tg_c, const int *t
         if (i < n_pool) {
             CfRun d;
             d.start = st[j]; d.pre = (unsigned int)run; d.len = (unsigned short)en[j];
-            d.owner = (unsigned char)((rq[j] >> 23) & 255u); d.tag = (unsigned char)(rq[j] >> 31 ? 0x80 : 0);
+            d.owner = (unsigned char)own[j]; d.tag = (unsigned char)(own[j] >= n_edge_owner ? 0x80 : 0);
             L.pool[i] = d;
         }
         run += (int)((en[j] + kCfC - 1) / kCfC);
@@ -212,59 +230,73 @@ __device__ __forceinline__ void cf_sweep(CfLds &L, const int *tg_c, const int *t
         if (!kWalk) { if (m0 != ~0ull) atomicMin(&L.best[owner], m0); }
         else { if (m0 != ~0ull) atomicMin(&L.same[owner], m0); if (m1 != ~0ull) atomicMin(&L.other[owner], m1); }
     };
-    // the chunk (first point, live points, owner) the loop body works on; the NEXT one is prepared while its loads are in flight
-    const float4 *pp; int n, ow;
-    auto next_chunk = [&](const float4 *&pp_, int &n_, int &ow_) {
-        while (off >= (int)cur.len) { seg++; cur = L.pool[seg]; off = 0; }
-        pp_ = ((cur.tag & 0x80) ? pts_s : pts_c) + cur.start + off;
-        n_ = (int)cur.len - off; ow_ = cur.owner;
-        off += kCfC;
-    };
-    next_chunk(pp, n, ow);
-    for (;;) {
-        // four UNCONDITIONAL loads at immediate offsets (the copies are padded: a chunk may run up to three points past its run; the
-        // points behind the run's end are masked below).  Behind a branch the compiler would wait for each load in turn (round 3).
-        float4 p[kCfC];
+    // the kCfB chunks (first point, live points, owner) the loop body works on; the NEXT ones are prepared while these loads are in flight
+    const float4 *pp[kCfB]; int n[kCfB], ow[kCfB];
 #pragma unroll
-        for (int u = 0; u < kCfC; u++) p[u] = pp[u];
+    for (int bb = 0; bb < kCfB; bb++) { pp[bb] = pts_c; n[bb] = 0; ow[bb] = -1; }
+    auto next_chunks = [&]() {
+#pragma unroll
+        for (int bb = 0; bb < kCfB; bb++) {
+            n[bb] = 0;                                    // no chunk left: the loads read a valid dummy, nothing is live
+            if (j < j1) {
+                while (off >= (int)cur.len) { seg++; cur = L.pool[seg]; off = 0; }
+                pp[bb] = ((cur.tag & 0x80) ? pts_s : pts_c) + cur.start + off;
+                n[bb] = (int)cur.len - off; ow[bb] = cur.owner;
+                off += kCfC; j++;
+            }
+        }
+    };
+    next_chunks();
+    for (;;) {
+        // UNCONDITIONAL loads at immediate offsets (the copies are padded: a chunk may run up to three points past its run; the
+        // points behind the run's end are masked below).  Behind a branch the compiler would wait for each load in turn (round 3).
+        float4 p[kCfB][kCfC];
+#pragma unroll
+        for (int bb = 0; bb < kCfB; bb++)
+#pragma unroll
+            for (int u = 0; u < kCfC; u++) p[bb][u] = pp[bb][u];
         __builtin_amdgcn_sched_barrier(0);          // everything below stays below the loads
         CF_STAMP(cf_acc[11])
-        j++;
+        int n_c[kCfB], ow_c[kCfB];
+#pragma unroll
+        for (int bb = 0; bb < kCfB; bb++) { n_c[bb] = n[bb]; ow_c[bb] = ow[bb]; }
         const bool more = j < j1;
-        const float4 *pp_n = pp; int n_n = 0, ow_n = ow;
-        if (more) next_chunk(pp_n, n_n, ow_n);
-        if (ow != owner) {
-            CF_COUNT(cf_acc[16])
-            flush();
-            owner = ow; m0 = ~0ull; m1 = ~0ull;
-            const float4 qq = L.q[ow];
-            qx = qq.x; qy = qq.y; qz = qq.z;
-            if (kWalk) { closest = L.closest[ow]; w_lo = L.wlo[ow]; w_span = (unsigned int)(L.whi[ow] - w_lo); ra = L.ra[ow]; }
-        }
+        if (more) next_chunks();
         CF_WAIT_VM()
         CF_STAMP(cf_acc[12])
         CF_COUNT(cf_acc[15])
 #pragma unroll
-        for (int u = 0; u < kCfC; u++) {
-            const float d = dist2f(p[u].x, p[u].y, p[u].z, qx, qy, qz);
-            const int pw = __float_as_int(p[u].w);      // cloud index << 7 | line
-            const bool live = u < n;
-            if (!kWalk) {
-                const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)pw;
-                m0 = (live & (key < m0)) ? key : m0;
-            } else {
-                const int jj = pw >> 7, dv = (pw & 127) - ra, sj = jj - closest;
-                const bool ok = live & (sj != 0) & ((unsigned int)(jj - w_lo) < w_span);          // inside the window the reference's loops can reach
-                const unsigned int seq = sj > 0 ? (unsigned int)(sj - 1) : kSeqBack + (unsigned int)(-1 - sj);
-                const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | seq;
-                const bool is_other = sj > 0 ? (dv > 0) : (dv < 0);       // ra = the nearest point's own line (an edge feature's "same" minimum is never read)
-                m1 = (ok & is_other & (key < m1)) ? key : m1;
-                m0 = (ok & !is_other & (key < m0)) ? key : m0;
+        for (int bb = 0; bb < kCfB; bb++) {
+            if (n_c[bb] > 0 && ow_c[bb] != owner) {
+                CF_COUNT(cf_acc[16])
+                flush();
+                owner = ow_c[bb]; m0 = ~0ull; m1 = ~0ull;
+                const float4 qq = L.q[owner];
+                qx = qq.x; qy = qq.y; qz = qq.z;
+                if (kWalk) { closest = L.closest[owner]; w_lo = L.wlo[owner]; w_span = (unsigned int)(L.whi[owner] - w_lo); ra = L.ra[owner]; }
+            }
+#pragma unroll
+            for (int u = 0; u < kCfC; u++) {
+                const float4 pt = p[bb][u];
+                const float d = dist2f(pt.x, pt.y, pt.z, qx, qy, qz);
+                const int pw = __float_as_int(pt.w);      // cloud index << 7 | line
+                const bool live = u < n_c[bb];
+                if (!kWalk) {
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)pw;
+                    m0 = (live & (key < m0)) ? key : m0;
+                } else {
+                    const int jj = pw >> 7, dv = (pw & 127) - ra, sj = jj - closest;
+                    const bool ok = live & (sj != 0) & ((unsigned int)(jj - w_lo) < w_span);          // inside the window the reference's loops can reach
+                    const unsigned int seq = sj > 0 ? (unsigned int)(sj - 1) : kSeqBack + (unsigned int)(-1 - sj);
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | seq;
+                    const bool is_other = sj > 0 ? (dv > 0) : (dv < 0);       // ra = the nearest point's own line (an edge feature's "same" minimum is never read)
+                    m1 = (ok & is_other & (key < m1)) ? key : m1;
+                    m0 = (ok & !is_other & (key < m0)) ? key : m0;
+                }
             }
         }
         CF_STAMP(cf_acc[13])
         if (!more) break;
-        pp = pp_n; n = n_n; ow = ow_n;
     }
     flush();
     CF_STAMP(cf_acc[14])
@@ -300,6 +332,7 @@ __global__ __launch_bounds__(kCfT, LMONO_CF_WAVES) void k_corr_flat(BatchView b,
     // the feature point and its seed are requested before the small tables are staged
     const bool edge = qi < n_sharp;
     const int cl = edge ? 0 : 1;
+    const int n_edge_owner = n_sharp > qb ? (n_sharp - qb + kCfBlocks - 1) / kCfBlocks : 0;      // owners (lanes) below it hold edge features
     float4 fp = make_float4(0.f, 0.f, 0.f, 0.f);
     int *seed_c = o.seed ? o.seed + (size_t)c * kMaxQueries : nullptr;
     int sidx = -1;
@@ -359,14 +392,22 @@ __global__ __launch_bounds__(kCfT, LMONO_CF_WAVES) void k_corr_flat(BatchView b,
             const float beta = R > rr ? asin_upper(rr / R) + 5e-4f : 4.0f;
             const float elo = eq - beta, ehi = eq + beta;
             const int v1 = cf_first_line(el, ehi), v2 = cf_last_line(el, elo);
-            // one run per azimuth bin of the arc: its lines v1 .. v2
-            const int nreq = v1 > v2 ? 0 : a.nb;
+            // bin-major copy: one run per azimuth bin of the arc, its lines v1 .. v2; line-major copy: one run (two when the arc wraps) per line
+            // of v1 .. v2 that the ball can meet
+            int nreq = v1 > v2 ? 0 : a.nb;
+            if (kLbLineMajor) {
+                int nl = 0;
+                for (int v = v1; v <= v2; v++) { const float4 ev = el[v]; nl += !(ev.y < elo || ev.x > ehi) ? 1 : 0; }
+                nreq = nl * cf_arc_pieces(a);
+            }
             if (nreq > kCfPool) { alive = false; deferred = true; }       // a single ball larger than the pool: list kernel
             else {
-                const int slot = nreq > 0 ? atomicAdd(&L.n_pool, nreq) : 0;
+                int slot = nreq > 0 ? atomicAdd(&L.n_pool, nreq) : 0;
                 if (slot + nreq <= kCfPool) {
                     posted = true;
-                    if (nreq > 0) cf_post(L.req, slot, a, cf_request(v1, v2 + 1, tid, !edge));
+                    if (kLbLineMajor) {
+                        for (int v = v1; v <= v2; v++) { const float4 ev = el[v]; if (!(ev.y < elo || ev.x > ehi)) cf_post_line(L.req, slot, a, v, tid); }
+                    } else if (nreq > 0) cf_post(L.req, slot, a, cf_request(v1, v2 + 1, tid));
                 } else {
                     // the pool of this round is full: the feature posts again in the next round; the part of its reservation that
                     // lies inside the pool becomes empty runs
@@ -376,7 +417,7 @@ __global__ __launch_bounds__(kCfT, LMONO_CF_WAVES) void k_corr_flat(BatchView b,
         }
         __syncthreads();
         CF_STAMP(cf_acc[0])
-        cf_sweep<false>(L, tg_c, tg_s, pts_c, pts_s, cf_t, cf_acc);
+        cf_sweep<false>(L, n_edge_owner, tg_c, tg_s, pts_c, pts_s, cf_t, cf_acc);
         __syncthreads();
         CF_STAMP(cf_acc[2])
 #ifdef LMONO_TILE_PROF
@@ -438,19 +479,23 @@ __global__ __launch_bounds__(kCfT, LMONO_CF_WAVES) void k_corr_flat(BatchView b,
         if (walking) {
             CfArc a;
             cf_arc(r_now, rho, th, a);
-            // one run per azimuth bin of the arc: the lines ra-2 .. ra+2 (an edge feature's own line rides along: its "same" minimum is not read)
-            const int nreq = a.nb;
-            const int slot = atomicAdd(&L.n_pool, nreq);
+            // bin-major copy: one run per azimuth bin of the arc, the lines ra-2 .. ra+2 (an edge feature's own line rides along: its "same"
+            // minimum is not read); line-major copy: one run (two when the arc wraps) per line, without an edge feature's own line
+            const int wv1 = max(ra - 2, 0), wv2 = min(ra + 2, 65);
+            const int nreq = kLbLineMajor ? (wv2 - wv1 + 1 - (edge ? 1 : 0)) * cf_arc_pieces(a) : a.nb;
+            int slot = atomicAdd(&L.n_pool, nreq);
             if (slot + nreq <= kCfPool) {
                 posted = true;
                 L.same[tid] = thr; L.other[tid] = thr;
-                cf_post(L.req, slot, a, cf_request(max(ra - 2, 0), min(ra + 2, 65) + 1, tid, !edge));
+                if (kLbLineMajor) {
+                    for (int v = wv1; v <= wv2; v++) if (!(edge && v == ra)) cf_post_line(L.req, slot, a, v, tid);
+                } else cf_post(L.req, slot, a, cf_request(wv1, wv2 + 1, tid));
             } else
                 for (int t = slot; t < kCfPool; t++) L.req[t] = 0u;
         }
         __syncthreads();
         CF_STAMP(cf_acc[0])
-        cf_sweep<true>(L, tg_c, tg_s, pts_c, pts_s, cf_t, cf_acc);
+        cf_sweep<true>(L, n_edge_owner, tg_c, tg_s, pts_c, pts_s, cf_t, cf_acc);
         __syncthreads();
         CF_STAMP(cf_acc[2])
 #ifdef LMONO_TILE_PROF

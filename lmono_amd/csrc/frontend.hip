@@ -352,16 +352,24 @@ constexpr int kSelWaveLds = 2 * kRingCap;                      // picked, gap by
 __device__ __forceinline__ unsigned int select_lo(int idx, unsigned int reach) { return ((unsigned int)idx << 8) | reach; }
 
 // one sector of one ring, M register slots per lane (element m of a lane is ring-local index sp + lane + 64 m)
+#ifndef LMONO_SEL_COMPACT
+#define LMONO_SEL_COMPACT 1
+#endif
+constexpr int kSelScratch = 64 * 8;      // per wave: one (curvature bits, index | reach) pair per lane, the compacted candidates of a sector
+
 template <int M>
 __device__ __forceinline__ void select_sector(int lane, int j, int sp, int slen, int rbeg, const float *curv, unsigned char *picked,
-                                              signed char *label, const unsigned char *gap, int *sel_sh, int *sel_sh_n, int *sel_fl, int *sel_fl_n)
+                                              signed char *label, const unsigned char *gap, int *sel_sh, int *sel_sh_n, int *sel_fl, int *sel_fl_n,
+                                              unsigned int *scratch)
 {
     unsigned int kh[M], kl[M];
     unsigned int dead = 0, big = 0, small = 0;     // bit m: suppressed / out of range; curvature > 0.1; < 0.1
+    int n_big = 0;                                 // live points with c > 0.1 (wave-uniform), compacted into `scratch` as they are loaded
 #pragma unroll
     for (int m = 0; m < M; m++) {
         const int e = lane + 64 * m;
         kh[m] = 0u; kl[m] = 0u;
+        bool cand = false;
         if (e < slen) {
             const int i = sp + e;
             const float c = curv[i];
@@ -371,14 +379,58 @@ __device__ __forceinline__ void select_sector(int lane, int j, int sp, int slen,
             while (lf < 5 && gap[i + lf] == 0) lf++;
             while (lb < 5 && gap[i - lb - 1] == 0) lb++;
             kh[m] = __float_as_uint(c); kl[m] = select_lo(i, (unsigned int)(lf | (lb << 4)));
-            if (picked[i]) dead |= 1u << m;
-            if ((double)c > 0.1) big |= 1u << m;
+            const bool pk = picked[i] != 0;
+            if (pk) dead |= 1u << m;
+            if ((double)c > 0.1) { big |= 1u << m; cand = !pk; }
             if ((double)c < 0.1) small |= 1u << m;
         } else dead |= 1u << m;
+#if LMONO_SEL_COMPACT
+        {
+            const unsigned long long mk = __ballot(cand);
+            const int pos = n_big + __popcll(mk & ((1ull << lane) - 1ull));
+            if (cand && pos < 64) { scratch[2 * pos] = kh[m]; scratch[2 * pos + 1] = kl[m]; }
+            n_big += __popcll(mk);
+        }
+#endif
     }
     // ---- largest curvature first: <= 2 sharp, <= 20 less sharp
     int largest = 0;
+#if LMONO_SEL_COMPACT
+    // Only the points with c > 0.1 that are not suppressed yet can be picked here -- a few dozen of a sector's ~300.  When they fit one per lane
+    // they are compacted (ballot ranks, through 512 B of LDS): a pick then costs one comparison per lane + the wave reduction instead of a pass
+    // over the lane's M slots.  Same live set, same (curvature, index) order: the same picks.  The slot bitmask `dead` is kept up to date for the
+    // flat picks below.
+    const bool compact = n_big <= 64;
+    if (compact) {
+        __builtin_amdgcn_wave_barrier();           // one wave: its LDS operations execute in order; the barrier keeps the compiler from reordering them
+        unsigned int ch = 0u, cl = 0u;
+        if (lane < n_big) { ch = scratch[2 * lane]; cl = scratch[2 * lane + 1]; }
+        __builtin_amdgcn_wave_barrier();           // the next sector's writes stay behind these reads
+        while (true) {
+            const unsigned int mh = wave_max_u32_uniform(ch);
+            if (mh == 0u) break;
+            const unsigned long long who = __ballot(ch == mh);
+            unsigned int lo;
+            if ((who & (who - 1ull)) == 0ull) lo = (unsigned int)__builtin_amdgcn_readlane((int)cl, __ffsll((long long)who) - 1);
+            else lo = wave_max_u32_uniform(ch == mh ? cl : 0u);
+            const int pind = (int)(lo >> 8), lf = (int)(lo & 15u), lb = (int)((lo >> 4) & 15u);
+            largest++;
+            if (largest > 20) break;
+            if (lane == 0) { sel_sh[j * 20 + largest - 1] = rbeg + pind; label[pind] = largest <= 2 ? 2 : 1; }
+            if (lane <= lf + lb) picked[pind - lb + lane] = 1;
+            // the compacted candidate of this lane is suppressed iff its index lies in [pind - lb, pind + lf]
+            if ((unsigned int)((int)(cl >> 8) - (pind - lb)) <= (unsigned int)(lb + lf)) ch = 0u;
+            {
+                const int a = pind - lb - sp - lane;                 // slot m is hit iff a <= 64 m <= a + lb + lf
+                const int m0 = (a + 63) >> 6;
+                if (m0 >= 0 && m0 < M && 64 * m0 <= a + lb + lf) dead |= 1u << m0;
+            }
+        }
+    }
+    while (!compact) {
+#else
     while (true) {
+#endif
         const unsigned int live = big & ~dead;
         // the lane's own best: slots ascend in index, so ">=" keeps the larger index among equal curvatures (live curvatures are > 0.1: 0 = none)
         unsigned int bh = 0u, bl = 0u;
@@ -455,7 +507,7 @@ template <typename T> __device__ __forceinline__ T *uni_ptr(T *p)
 }
 
 // one ring by one wave; cap = ring points the wave's LDS slice (2 * cap bytes at smem_w) can hold
-__device__ __forceinline__ void select_ring(BatchView &b, int r, int s, int lane, unsigned char *smem_w, int cap, bool may_defer)
+__device__ __forceinline__ void select_ring(BatchView &b, int r, int s, int lane, unsigned char *smem_w, int cap, bool may_defer, unsigned int *scratch)
 {
     r = uni(r); s = uni(s);
     const int64_t off = uni64(b.off[s]);
@@ -490,9 +542,9 @@ __device__ __forceinline__ void select_ring(BatchView &b, int r, int s, int lane
         const int ep = 5 + span * (j + 1) / 6 - 1;
         const int slen = ep - sp + 1;
         // HDL-64-sized sectors (<= 320 / <= 384 points) take the 5- / 6-slot instantiations, longer rings the full one
-        if (slen <= 5 * 64) select_sector<5>(lane, j, sp, slen, rbeg, curv, picked, label, gap, sel_sh, sel_sh_n, sel_fl, sel_fl_n);
-        else if (slen <= 6 * 64) select_sector<6>(lane, j, sp, slen, rbeg, curv, picked, label, gap, sel_sh, sel_sh_n, sel_fl, sel_fl_n);
-        else select_sector<kSelMaxPerLane>(lane, j, sp, slen, rbeg, curv, picked, label, gap, sel_sh, sel_sh_n, sel_fl, sel_fl_n);
+        if (slen <= 5 * 64) select_sector<5>(lane, j, sp, slen, rbeg, curv, picked, label, gap, sel_sh, sel_sh_n, sel_fl, sel_fl_n, scratch);
+        else if (slen <= 6 * 64) select_sector<6>(lane, j, sp, slen, rbeg, curv, picked, label, gap, sel_sh, sel_sh_n, sel_fl, sel_fl_n, scratch);
+        else select_sector<kSelMaxPerLane>(lane, j, sp, slen, rbeg, curv, picked, label, gap, sel_sh, sel_sh_n, sel_fl, sel_fl_n, scratch);
     }
 }
 
@@ -508,13 +560,14 @@ __global__ __launch_bounds__(256, 8) void k_select(BatchView b, int cap, int fro
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char *smem_w = smem + wave * 2 * cap;
+    unsigned int *scratch = (unsigned int *)(smem + 4 * 2 * cap + wave * kSelScratch);      // behind the four slices (2 * cap is a multiple of 4)
     if (!from_list) {
-        select_ring(b, blockIdx.x * 4 + wave, b.scan0 + blockIdx.y, lane, smem_w, cap, true);
+        select_ring(b, blockIdx.x * 4 + wave, b.scan0 + blockIdx.y, lane, smem_w, cap, true, scratch);
     } else {
         const int n_todo = b.sel_todo[0];
         for (int k = blockIdx.x * 4 + wave; k < n_todo; k += gridDim.x * 4) {
             const int e = b.sel_todo[1 + k];
-            select_ring(b, e & 63, e >> 6, lane, smem_w, cap, false);
+            select_ring(b, e & 63, e >> 6, lane, smem_w, cap, false, scratch);
         }
     }
 }

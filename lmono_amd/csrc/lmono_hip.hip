@@ -116,7 +116,7 @@ extern "C" lmono_ctx *lmono_create(int device)
     c->device = device;
     if (hipMalloc((void **)&c->stats_d, 320) != hipSuccess || hipMemset(c->stats_d, 0, 320) != hipSuccess) { delete c; return nullptr; }
     // the selection kernel needs ~62 KB of dynamic LDS
-    if (hipFuncSetAttribute((const void *)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kSelWaveLds) != hipSuccess) { delete c; return nullptr; }
+    if (hipFuncSetAttribute((const void *)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kSelWaveLds + 4 * kSelScratch) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_voxel<kVoxSmallSlots, kVoxSmallBits, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kVoxLdsSmall) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_voxel<kVoxBigSlots, kVoxBigBits, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kVoxLdsBig) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_lm_solve, hipFuncAttributeMaxDynamicSharedMemorySize, kLmRecLds) != hipSuccess) { delete c; return nullptr; }
@@ -295,8 +295,8 @@ static int scanreg_launch(lmono_ctx *c, lmono_scan_batch *b, int scan0, int n_sc
     HIP_TRY(c, hipMemsetAsync(v.sel_sharp_n + (size_t)scan0 * 64 * 6, 0, sizeof(int) * (size_t)n_scans * 64 * 6, st));
     HIP_TRY(c, hipMemsetAsync(v.sel_flat_n + (size_t)scan0 * 64 * 6, 0, sizeof(int) * (size_t)n_scans * 64 * 6, st));
     HIP_TRY(c, hipMemsetAsync(v.lf_n + (size_t)scan0 * 64, 0, sizeof(int) * (size_t)n_scans * 64, st));
-    hipLaunchKernelGGL(k_select, dim3((n_rings + 3) / 4, n_scans), dim3(256), 4 * 2 * kSelSmallCap, st, v, kSelSmallCap, 0);
-    hipLaunchKernelGGL(k_select, dim3(kSelBigGrid), dim3(256), 4 * kSelWaveLds, st, v, (int)kRingCap, 1);
+    hipLaunchKernelGGL(k_select, dim3((n_rings + 3) / 4, n_scans), dim3(256), 4 * 2 * kSelSmallCap + 4 * kSelScratch, st, v, kSelSmallCap, 0);
+    hipLaunchKernelGGL(k_select, dim3(kSelBigGrid), dim3(256), 4 * kSelWaveLds + 4 * kSelScratch, st, v, (int)kRingCap, 1);
     HIP_TRY(c, hipEventRecord(c->ev[3], st));
     hipLaunchKernelGGL((k_voxel<kVoxSmallSlots, kVoxSmallBits, true>), dim3(n_rings, n_scans), dim3(256), kVoxLdsSmall, st, v);
     hipLaunchKernelGGL((k_voxel<kVoxBigSlots, kVoxBigBits, false>), dim3(kVoxBigGrid), dim3(256), kVoxLdsBig, st, v);

@@ -489,7 +489,30 @@ __device__ __forceinline__ double boundary_residual(const double *a, const doubl
 // A point of the copy carries (cloud index << 7 | line) in .w.
 constexpr int kAzBins = 384;           // 0.9375 deg: about one point of a 0.2 m-voxelised cloud per bin and line at 12 m
 constexpr int kLineKeys = 66 * kAzBins;
-__device__ __forceinline__ int lb_key(int bin, int line) { return bin * 66 + line; }
+#ifndef LMONO_LB_ORDER
+#define LMONO_LB_ORDER 1               // 1 (default): (line, azimuth bin)-major copy; 0: (azimuth bin, line)-major -- measured side by side (profiles/r4/NOTES.md): with
+                                       // the chunked sweep of corr_flat.hip the two searches are within 5 %, and the line-major copy is 0.8 ms per pass cheaper to build
+#endif
+constexpr bool kLbLineMajor = LMONO_LB_ORDER != 0;
+__device__ __forceinline__ int lb_key(int bin, int line) { return kLbLineMajor ? line * kAzBins + bin : bin * 66 + line; }
+// the runs of the copy that hold the lines va .. vb of the bins [b_lo, b_lo + nbins) (wrapping past the last bin): f(first point, count).
+// Fall-back kernels only: simple beats fast.
+template <class F>
+__device__ __forceinline__ void lb_for_runs(const int *table, int b_lo, int nbins, int va, int vb, F f)
+{
+    const int b_end = b_lo + nbins;
+    for (int part = 0; part < 2; part++) {
+        if (part == 1 && b_end <= kAzBins) break;
+        const int p0 = part ? 0 : b_lo, p1 = part ? b_end - kAzBins : min(b_end, kAzBins);
+        if (kLbLineMajor) {
+            for (int v = va; v <= vb; v++) { const int s0 = table[v * kAzBins + p0]; f(s0, table[v * kAzBins + p1] - s0); }
+        } else if (va == 0 && vb == 65) {
+            const int s0 = table[p0 * 66]; f(s0, table[p1 * 66] - s0);
+        } else {
+            for (int bn = p0; bn < p1; bn++) { const int s0 = table[bn * 66 + va]; f(s0, table[bn * 66 + vb + 1] - s0); }
+        }
+    }
+}
 constexpr int kLbPad = 4;              // entries behind the index copies: k_corr_flat's 64-B chunks may read up to three points past a run
 
 __device__ __forceinline__ int az_bin(float x, float y)
@@ -653,8 +676,8 @@ constexpr float kArcSlackBins = 0.05f;
 // Radii of the walk's passes (a search strategy, not a result: any ascending ladder that ends at 5 m finds the same partners; scripts/ladder_sweep.sh
 // re-measures variants with the index-exact tests in the loop).  Round 3: 0.2 + 0.012 rho / 0.5 + 0.05 rho -> 0.3 + 0.03 rho / 1 + 0.1 rho (-1..2 % of the pass).
 #ifndef LMONO_WR_A0
-#define LMONO_WR_A0 0.3f
-#define LMONO_WR_B0 0.03f
+#define LMONO_WR_A0 0.25f
+#define LMONO_WR_B0 0.02f
 #define LMONO_WR_A1 1.0f
 #define LMONO_WR_B1 0.1f
 #endif
@@ -889,13 +912,7 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
                 const int hi = (int)floorf((th + alpha) * (kAzBins / 6.28318531f));
                 if (hi - lo + 1 < kAzBins) { b_lo = ((lo % kAzBins) + kAzBins) % kAzBins; nbins = hi - lo + 1; }
             }
-            const int b_end = b_lo + nbins;
-            // all lines of the arc's bins are ONE contiguous run of the (bin, line)-major copy (two when the arc wraps)
-            {
-                const int s0 = table[lb_key(b_lo, 0)];
-                nn_sweep_arc(lb_pts, s0, table[lb_key(min(b_end, kAzBins), 0)] - s0, gl, qx, qy, qz, nb);
-                if (b_end > kAzBins) nn_sweep_arc(lb_pts, table[0], table[lb_key(b_end - kAzBins, 0)] - table[0], gl, qx, qy, qz, nb);
-            }
+            lb_for_runs(table, b_lo, nbins, 0, 65, [&](int s0, int cn) { nn_sweep_arc(lb_pts, s0, cn, gl, qx, qy, qz, nb); });
             best = group_min_u64(nb, gbase);
         }
     }
@@ -928,14 +945,8 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
             const int hi = (int)floorf((th + alpha) * (kAzBins / 6.28318531f));
             if (hi - lo + 1 < kAzBins) { b_lo = ((lo % kAzBins) + kAzBins) % kAzBins; nbins = hi - lo + 1; }
         }
-        const int b_end = b_lo + nbins;
-        // the arc's bins with all their lines are one contiguous run (two when the arc wraps); the lines ra-2 .. ra+2 are picked out by
-        // walk_point (this is the fall-back kernel: simple beats fast)
         WalkBest bs = thr, bo = thr;
-        for (int part = 0; part < 2; part++) {
-            if (part == 1 && b_end <= kAzBins) break;
-            const int r0 = part ? table[0] : table[lb_key(b_lo, 0)];
-            const int cnw = (part ? table[lb_key(b_end - kAzBins, 0)] : table[lb_key(min(b_end, kAzBins), 0)]) - r0;
+        lb_for_runs(table, b_lo, nbins, max(ra - 2, 0), min(ra + 2, 65), [&](int r0, int cnw) {
             for (int i = gl; i < cnw; i += 4 * kGroup) {
                 float4 v4[4];
 #pragma unroll
@@ -943,7 +954,7 @@ __device__ __forceinline__ int4 correspond_g32(const BatchView &b, int k, int qi
 #pragma unroll
                 for (int u = 0; u < 4; u++) if (i + u * kGroup < cnw) walk_point(v4[u], ra, closest, w_lo, w_hi, edge, qx, qy, qz, bs, bo);
             }
-        }
+        });
         same = group_min_u64(bs, gbase);
         other = group_min_u64(bo, gbase);
         if (rw >= 5.0f) break;

@@ -30,6 +30,15 @@ def test_matches_oracle_on_a_two_lap_graph(oracle, gpu_ctx):
     assert np.abs(out[0] - g["odom"][0]).max() < 1e-12
 
 
+def test_configs3_graph_at_its_size(oracle, gpu_ctx):
+    """BASELINE configs[3]'s graph at its named size: 4541 keyframes (KITTI seq 00), the graph `bench.py --workload posegraph` measures
+    (2.2 laps, half bandwidth ~67 blocks) against oracle/lo_posegraph.c -- same accepted / rejected steps, costs to 1e-9, keyframes to 1e-7."""
+    g = s4.make_graph(n=4541, laps=2.2)
+    out, st = _compare(oracle, gpu_ctx, g)
+    assert st["bandwidth"] > 40 and len(g["loops"]) > 100
+    assert s4.ate(out, g["truth"]) < 0.5 * s4.ate(g["odom"], g["truth"])
+
+
 def test_more_iterations_outliers_and_short_graphs(oracle, gpu_ctx):
     _compare(oracle, gpu_ctx, s4.make_graph(n=300, outliers=3), max_iter=12)
     _compare(oracle, gpu_ctx, s4.make_graph(n=120, loop_gap=30, seed=3), max_iter=8)
