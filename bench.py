@@ -189,7 +189,7 @@ def bench_map(args):
            "config": {"workload": "S1 HDL-64 sequence, %d scans, laserMapping after laserOdometry (SURVEY 8f-1)" % n, "streams": B},
            "roofline": {"bound": "hbm", "kernel": "per-frame kernel chain (k_voxel_cloud, k_cloud_grid, k_map_correspond, k_map_solve)",
                         "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                        "note": "a frame is a chain of dependent launches with host round trips (cube tables live on the host); not a roofline measurement yet"},
+                        "note": "a frame is a chain of dependent single-workgroup launches (k_voxel_cloud 0.32 ms x 2, k_cloud_grid 0.26 ms, k_map_solve 0.13 ms x 2: profiles/r4/map_kernel_stats_1stream.csv) with four host read-backs (cube tables live on the host); latency of that chain, not a roofline measurement"},
            "cpu_baseline": {"value": round(n / (ref["stage_ms"][1] * 1e-3), 2), "unit": "frames/s", "cores": 1, "kind": "port",
                             "sample": "the same %d scans, oracle/lo_mapping.c (-O3), 1 thread, mapping stage only" % n},
            "max_pose_diff_vs_cpu": float(np.abs(got - ref["poses"]).max()),
@@ -781,7 +781,7 @@ def main():
         # HBM bytes per launch of the dominant kernel from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE and
         # WRITE_SIZE in separate passes, gfx950 correction applied; scripts/profile_round.sh); null if not collected for it
         traffic = None
-        for rnd in ("r3", "r2", "r1"):
+        for rnd in ("r4", "r3", "r2", "r1"):
             pmc_path = os.path.join(ROOT, "profiles", rnd, "pmc_%s.json" % dom)
             if os.path.exists(pmc_path) and chains == 256:
                 with open(pmc_path) as fh:
@@ -799,9 +799,10 @@ def main():
                     "whole_step_frac": round((37 * N + 0.77e6) * n_local / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
                     "group_ms_per_step": {k: round(v / max(args.steps, 1), 3) for k, v in groups.items() if k != "odometry_launch_pairs"}}
         if dom == "k_correspond":
-            roofline["note"] = ("exact nearest-neighbour + scan-line walk over a (line, azimuth-bin) index: 16-B gathers of ~2-point runs; the kernel is bound by "
-                                "the CUs' L1 (TCP busy 70 % of a launch, ~2400 line accesses per workgroup and round; profiles/r2/NOTES.md, profiles/r3/NOTES.md 13), "
-                                "not by HBM -- the HBM fraction is reported because SURVEY 8d prices the path in bytes")
+            roofline["note"] = ("exact nearest-neighbour + scan-line walk over a (line, azimuth-bin) index, candidates swept as 64-byte chunks; the kernel is bound by "
+                                "instruction issue and by the dependent rounds of its slowest workgroup, not by HBM or the L1 (46 M VALU + 19 M SALU wave instructions per 256-chain "
+                                "launch, VALU ~80 % busy while the CUs are full, UTCL1 misses 0.04 %; profiles/r4/NOTES.md) -- the HBM fraction is reported because SURVEY 8d prices "
+                                "the path in bytes")
         out = {
             "metric": "KITTI HDL-64 scans/sec (scanRegistration + laserOdometry)", "value": round(scans_per_s, 1),
             "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -138,7 +138,8 @@ typedef struct {
     int chains_rerun;   /* distinct chains re-started                                                              */
     int pairs_rerun;    /* scan pairs re-run by them                                                               */
     int rounds;         /* check + repair rounds (a repair that reaches its chain's end can flag the next boundary) */
-    int unresolved;     /* always 0 on return: boundaries still above the tolerance                                */
+    int unresolved;     /* boundaries still above the tolerance behind the last repair round (counted by one more check when the
+                         * round cap n_chains + 1 ends the loop; 0 otherwise)                                       */
     double tol, max_resid, repair_ms;
 } lmono_boundary_report;
 int lmono_odom_boundary_report(lmono_ctx *, lmono_scan_batch *, lmono_boundary_report *rep, double *resid_h, int32_t *rerun_h, int cap);
@@ -213,7 +214,13 @@ int lmono_factor_eval_blocks_d(lmono_ctx *, int kind, int count, const double *p
  * (mono_lidar_mapping/src/image_process/Estimator.cc:1124-1305) over para_pose[11][7], para_ex[1][7],
  * para_depth_inv[F][1] (Estimator.h:255-257) with PriorFactor / LASERFactor / MonoProjectionFactor+CauchyLoss(1).
  * A window depends on its predecessor, so a batch holds windows of independent sequences.  All arrays are host
- * pointers; lmono_ba_batch_create copies them into HBM once, lmono_ba_solve runs one workgroup per window.     */
+ * pointers; lmono_ba_batch_create copies them into HBM once, lmono_ba_solve runs one workgroup per window.
+ * Supported maximum: LMONO_BA_MAX_FEATURES = 448 inverse-depth blocks per window (the reference sizes para_depth_inv[10000],
+ * Estimator.h:256; its tracker caps a frame at 150 new tracks, FeatureTracker.cc:21, of which the ones tracked >= TRACK_CNT frames
+ * enter a solve -- 100-300 on the S2 streams).  The bound is the workgroup's LDS budget: the per-feature
+ * vectors of the dogleg step (scale, D, gs, gn, va, vb, H_ff, g_f: 8 doubles per feature) live in LDS beside the 72 x 72 reduced system.
+ * A window above it is refused with LMONO_ECAPACITY by lmono_ba_batch_create / _update -- nothing is truncated.                        */
+#define LMONO_BA_MAX_FEATURES 448
 typedef struct lmono_ba_batch lmono_ba_batch;
 typedef struct {
     int n_windows;

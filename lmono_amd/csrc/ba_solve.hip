@@ -32,7 +32,7 @@ namespace lmono {
 constexpr int kBaMaxPoses = 11;
 constexpr int kBaP = 6 * (kBaMaxPoses + 1);      // 72
 constexpr int kBaPS = 80;                        // padded row of the coupling matrix: 5 MFMA tiles of 16
-constexpr int kBaMaxFeat = 448;
+constexpr int kBaMaxFeat = LMONO_BA_MAX_FEATURES;      // include/lmono_hip.h states the bound and why
 constexpr int kBaN = kBaP + kBaMaxFeat;          // 520
 constexpr int kBaMaxPairs = kBaMaxPoses * (kBaMaxPoses - 1);
 constexpr int kBaRound = 32;                     // observations a wave stages per round (two lanes each)

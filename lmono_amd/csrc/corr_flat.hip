@@ -63,6 +63,13 @@ constexpr int kCfC = 4;                        // points per chunk (64 contiguou
 #endif
 constexpr int kCfB = LMONO_CF_B;               // chunks per lane in flight (kCfB x kCfC 16-B loads)
 static_assert(kCfC - 1 <= kLbPad, "a chunk's loads may run kCfC - 1 points past its run: the index copies are padded");
+// Round budgets of the two phases: a workgroup runs as many rounds as its SLOWEST feature needs, and a launch lasts as long as its slowest
+// workgroup; a feature that has not settled within the budget goes to the device work list of k_correspond_list (exact as well).
+#ifndef LMONO_CF_NN_ROUNDS
+#define LMONO_CF_NN_ROUNDS 64
+#define LMONO_CF_WALK_ROUNDS 64
+#endif
+constexpr int kCfNnRounds = LMONO_CF_NN_ROUNDS, kCfWalkRounds = LMONO_CF_WALK_ROUNDS;
 #ifndef LMONO_WALK_TIGHT
 #define LMONO_WALK_TIGHT 1      // a walk pass that SAW its partners outside its ball continues with the ball that just holds them, not with the next rung
 #endif
@@ -379,7 +386,7 @@ __global__ __launch_bounds__(kCfT, LMONO_CF_WAVES) void k_corr_flat(BatchView b,
 
     CF_STAMP(cf_acc[4])
     // ================= nearest point =================
-    for (int round = 0; round < 64; round++) {
+    for (int round = 0; round < kCfNnRounds; round++) {
         if (tid == 0) L.n_pool = 0;
         __syncthreads();
         // ---- 1a: run requests of the features still searching
@@ -466,7 +473,7 @@ __global__ __launch_bounds__(kCfT, LMONO_CF_WAVES) void k_corr_flat(BatchView b,
         if (!edge) { const float4 ps = cloud[prev.y]; d = fmaxf(d, dist2f(ps.x, ps.y, ps.z, qx, qy, qz)); }
         if (d < 24.0f) r_seed = sqrtf(d) * 1.002f + 1e-3f;
     }
-    for (int round = 0; round < 64; round++) {
+    for (int round = 0; round < kCfWalkRounds; round++) {
         if (tid == 0) L.n_pool = 0;
         __syncthreads();
         bool posted = false;

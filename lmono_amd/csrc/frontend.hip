@@ -359,7 +359,7 @@ constexpr int kSelScratch = 64 * 8;      // per wave: one (curvature bits, index
 
 template <int M>
 __device__ __forceinline__ void select_sector(int lane, int j, int sp, int slen, int rbeg, const float *curv, unsigned char *picked,
-                                              signed char *label, const unsigned char *gap, int *sel_sh, int *sel_sh_n, int *sel_fl, int *sel_fl_n,
+                                              signed char *label, const unsigned long long *gap, int *sel_sh, int *sel_sh_n, int *sel_fl, int *sel_fl_n,
                                               unsigned int *scratch)
 {
     unsigned int kh[M], kl[M];
@@ -373,11 +373,15 @@ __device__ __forceinline__ void select_sector(int lane, int j, int sp, int slen,
         if (e < slen) {
             const int i = sp + e;
             const float c = curv[i];
-            // suppression reach: the neighbour walk marks l = 1..5 forward while the gap before point i+l is short,
-            // and the same backward
-            int lf = 0, lb = 0;
-            while (lf < 5 && gap[i + lf] == 0) lf++;
-            while (lb < 5 && gap[i - lb - 1] == 0) lb++;
+            // suppression reach: the neighbour walk marks l = 1..5 forward while the gap before point i+l is short, and the same backward --
+            // the zero runs above / below bit i of the ring's gap BIT mask (two independent 8-byte LDS reads; as bytes the two walks were up to
+            // ten dependent single-byte reads per element, the latency that bound the kernel).  i >= 5 inside a sector.
+            const int jw = i - 5;
+            const unsigned long long wa = gap[jw >> 6], wb = gap[(jw >> 6) + 1];
+            const int sh = jw & 63;
+            const unsigned int win = (unsigned int)((wa >> sh) | (sh ? wb << (64 - sh) : 0ull));      // bit k = gap flag of point i - 5 + k
+            const int lf = min(5, __ffs((int)((win >> 5) | 32u)) - 1);
+            const int lb = min(5, __clz((int)((win & 31u) << 27)));
             kh[m] = __float_as_uint(c); kl[m] = select_lo(i, (unsigned int)(lf | (lb << 4)));
             const bool pk = picked[i] != 0;
             if (pk) dead |= 1u << m;
@@ -533,9 +537,17 @@ __device__ __forceinline__ void select_ring(BatchView &b, int r, int s, int lane
     // picked and gap bytes, 2 * cap per wave
     unsigned char *picked = smem_w;
     signed char *label = uni_ptr((signed char *)(b.label + off + rbeg));
-    unsigned char *gap = picked + cap;
+    // gap flags of the ring as a bit mask, one 64-bit word per 64 points (+ one word of padding read by the last elements' windows)
+    unsigned long long *gap = (unsigned long long *)(picked + cap);
     const float *curv = uni_ptr(b.curv + off + rbeg);
-    for (int i = lane; i < len; i += 64) { picked[i] = 0; label[i] = 0; gap[i] = b.gap[off + rbeg + i]; }
+    for (int i0 = 0; i0 < len + 64; i0 += 64) {
+        const int i = i0 + lane;
+        unsigned char g = 0;
+        if (i < len) { picked[i] = 0; label[i] = 0; g = b.gap[off + rbeg + i]; }
+        const unsigned long long mk = __ballot(g != 0);
+        if (lane == 0) gap[i0 >> 6] = mk;
+    }
+    __builtin_amdgcn_wave_barrier();
     const int span = E - S;
     for (int j = 0; j < kSectors; j++) {
         const int sp = 5 + span * j / 6;
@@ -964,7 +976,13 @@ __device__ __forceinline__ void voxel_ring(BatchView &b, int r, int s)
 // provided no point precedes a point whose line is >= 3 lower ("regular"); irregular clouds are flagged and walked
 // in array order instead.  Lines are not monotone in general: A-LOAM's relTime can be negative (line = ring - 1).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_compact(BatchView b)
+#ifndef LMONO_COMPACT_T
+#define LMONO_COMPACT_T 256
+#endif
+constexpr int kCompT = LMONO_COMPACT_T;      // threads per scan; 256 / 512 / 1024 measured the same 2.0 ms per pass (profiles/r4: the kernel is bound by its traffic)
+static_assert(kCompT >= 256 && kCompT % 64 == 0, "the four prefixes take one wave each");
+
+__global__ __launch_bounds__(kCompT) void k_compact(BatchView b)
 {
     const int s = b.scan0 + blockIdx.x;
     const int tid = threadIdx.x;
@@ -978,6 +996,7 @@ __global__ __launch_bounds__(256) void k_compact(BatchView b)
         const int lane = tid & 63, wave = tid >> 6;
         constexpr int kPer = NE / 64;   // 6 consecutive entries per lane
         int c[kPer], sum = 0;
+        if (wave < 4) {
         // one source array per wave, six unconditional loads per lane in flight together
         const int *srcp = wave <= 1 ? nsh : (wave == 2 ? nfl : b.lf_n + s * 64);
 #pragma unroll
@@ -1003,6 +1022,7 @@ __global__ __launch_bounds__(256) void k_compact(BatchView b)
             run += c[q];
         }
         if (lane == 63) dst[n_e] = run;
+        }
     }
     __syncthreads();
     const float4 *cl = b.cloud + off;
@@ -1020,22 +1040,22 @@ __global__ __launch_bounds__(256) void k_compact(BatchView b)
     __syncthreads();
     // four selection slots per thread and turn: the counts come from the LDS prefixes, the index loads and then the point gathers are issued
     // together (behind per-slot guards the compiler waits for every load in turn: three dependent round trips per slot, 30 slots per thread)
-    for (int x0 = tid; x0 < NE * 20; x0 += 4 * 256) {
+    for (int x0 = tid; x0 < NE * 20; x0 += 4 * kCompT) {
         int pos[4], idx[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int x = x0 + 256 * q, e = x / 20, k = x % 20;
+            const int x = x0 + kCompT * q, e = x / 20, k = x % 20;
             pos[q] = (x < NE * 20 && k < pre_ls[e + 1] - pre_ls[e]) ? pre_ls[e] + k : -1;
         }
 #pragma unroll
-        for (int q = 0; q < 4; q++) idx[q] = ssel[pos[q] >= 0 ? x0 + 256 * q : 0];
+        for (int q = 0; q < 4; q++) idx[q] = ssel[pos[q] >= 0 ? x0 + kCompT * q : 0];
         float4 p4[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) { const float4 *src = pos[q] >= 0 ? cl + idx[q] : b.cloud; p4[q] = *src; }      // (an unused slot reads the batch's first point)
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             if (pos[q] < 0) continue;
-            const int x = x0 + 256 * q, e = x / 20, k = x % 20;
+            const int x = x0 + kCompT * q, e = x / 20, k = x % 20;
             const float4 p = p4[q];
             ls[pos[q]] = p;
             if (k < 2) sharp[pre_sh[e] + k] = p;
@@ -1045,15 +1065,15 @@ __global__ __launch_bounds__(256) void k_compact(BatchView b)
             atomicMax(&s_last[0][v], pos[q]);
         }
     }
-    for (int x0 = tid; x0 < NE * 4; x0 += 2 * 256) {
+    for (int x0 = tid; x0 < NE * 4; x0 += 2 * kCompT) {
         int pos[2], idx[2];
 #pragma unroll
         for (int q = 0; q < 2; q++) {
-            const int x = x0 + 256 * q, e = x / 4, k = x % 4;
+            const int x = x0 + kCompT * q, e = x / 4, k = x % 4;
             pos[q] = (x < NE * 4 && k < pre_fl[e + 1] - pre_fl[e]) ? pre_fl[e] + k : -1;
         }
 #pragma unroll
-        for (int q = 0; q < 2; q++) idx[q] = fsel[pos[q] >= 0 ? x0 + 256 * q : 0];
+        for (int q = 0; q < 2; q++) idx[q] = fsel[pos[q] >= 0 ? x0 + kCompT * q : 0];
         float4 p2[2];
 #pragma unroll
         for (int q = 0; q < 2; q++) { const float4 *src = pos[q] >= 0 ? cl + idx[q] : b.cloud; p2[q] = *src; }
@@ -1063,11 +1083,11 @@ __global__ __launch_bounds__(256) void k_compact(BatchView b)
     // less-flat cloud = the rings' voxel outputs back to back: every thread finds the ring of its output index by a binary
     // search over the ring prefix (all loads independent, four per thread in flight)
     const int n_lf = pre_lf[kMaxRings];
-    for (int j0 = tid; j0 < n_lf; j0 += 4 * 256) {
+    for (int j0 = tid; j0 < n_lf; j0 += 4 * kCompT) {
         float4 v4[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int j = j0 + 256 * q;
+            const int j = j0 + kCompT * q;
             v4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (j < n_lf) {
                 int lo = 0, hi = kMaxRings;
@@ -1077,7 +1097,7 @@ __global__ __launch_bounds__(256) void k_compact(BatchView b)
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int j = j0 + 256 * q;
+            const int j = j0 + kCompT * q;
             if (j < n_lf) {
                 lf[j] = v4[q];
                 int v = (int)v4[q].w;
@@ -1093,7 +1113,7 @@ __global__ __launch_bounds__(256) void k_compact(BatchView b)
     }
     __syncthreads();
     // irregular iff some line a >= b + 3 starts before line b ends (see above)
-    for (int x = tid; x < 2 * 66 * 66; x += 256) {
+    for (int x = tid; x < 2 * 66 * 66; x += kCompT) {
         const int cld = x / (66 * 66), y = x % (66 * 66), a = y / 66, bb = y % 66;
         if (a >= bb + 3 && s_first[cld][a] < s_last[cld][bb]) s_flag[cld] = 1;
     }

@@ -301,7 +301,7 @@ static int scanreg_launch(lmono_ctx *c, lmono_scan_batch *b, int scan0, int n_sc
     hipLaunchKernelGGL((k_voxel<kVoxSmallSlots, kVoxSmallBits, true>), dim3(n_rings, n_scans), dim3(256), kVoxLdsSmall, st, v);
     hipLaunchKernelGGL((k_voxel<kVoxBigSlots, kVoxBigBits, false>), dim3(kVoxBigGrid), dim3(256), kVoxLdsBig, st, v);
     HIP_TRY(c, hipEventRecord(c->ev[4], st));
-    hipLaunchKernelGGL(k_compact, dim3(n_scans), dim3(256), 0, st, v);
+    hipLaunchKernelGGL(k_compact, dim3(n_scans), dim3(kCompT), 0, st, v);
     HIP_TRY(c, hipEventRecord(c->ev[5], st));
     // the hash grids serve the 32-lane-group search (LMONO_OPT_CORR_TILE 0) and the deferred lists of modes 1 and 2; the default
     // (flattened sweeps) works on the line index alone, so the grids are built on demand (ensure_grid)
@@ -659,19 +659,24 @@ static int odom_validate(lmono_ctx *c, lmono_scan_batch *b, OdomView o, bool ext
     for (int ch = 0; ch < n_chains; ch++) { int s, e; chain_bounds(o.first, o.n_scans, n_chains, ch, s, e); max_len = e - s > max_len ? e - s : max_len; }
     const int tile = c->opt[LMONO_OPT_CORR_TILE];
     std::vector<int> rs((size_t)n_chains * 4);
-    for (int round = 0; round < n_chains + 1; round++) {
+    const int max_rounds = n_chains + 1;
+    int still_flagged = 0;               // boundaries the LAST check of the loop flagged (non-zero only when the round cap ends the loop)
+    for (int round = 0; round <= max_rounds; round++) {
         const bool very_first = first_call && round == 0;
         hipLaunchKernelGGL(k_boundary_check, dim3(1), dim3(256), 0, st, o, very_first ? b->resid_d : (double *)nullptr, very_first ? 1 : 0, ext ? 1 : 0);
         unsigned int cnt[2] = { 0, 0 };
         HIP_TRY(c, hipMemcpyAsync(cnt, b->rcount, sizeof(cnt), hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipStreamSynchronize(st));
+        if (very_first) HIP_TRY(c, hipMemcpyAsync(b->resid_h.data(), b->resid_d, sizeof(double) * n_chains, hipMemcpyDeviceToHost, st));     // both copies on the
+        HIP_TRY(c, hipStreamSynchronize(st));                                                                                                 // context stream, one wait
         if (very_first) {
-            HIP_TRY(c, hipMemcpyAsync(b->resid_h.data(), b->resid_d, sizeof(double) * n_chains, hipMemcpyDeviceToHost, st));     // on the context
-            HIP_TRY(c, hipStreamSynchronize(st));                                                                                  // stream, not the null one
             for (int ch = 0; ch < n_chains; ch++) R.max_resid = b->resid_h[ch] > R.max_resid ? b->resid_h[ch] : R.max_resid;
+            // boundary_residual() answers 1e300 for a NaN increment: no repair can make such a boundary agree -- report it instead of re-running
+            // its chain in every round
+            if (R.max_resid >= 1e299) { c->err = "odometry: a chain boundary holds a NaN increment (a scan pair without a usable solution)"; return LMONO_ESCAN; }
         }
         const int nf = (int)cnt[0];
-        if (nf == 0) break;
+        still_flagged = nf;
+        if (nf == 0 || round == max_rounds) break;      // the check behind the last allowed round only counts what is left
         R.flagged += nf; R.rounds += 1;
         OdomView orp = o;
         orp.repair = 1; orp.clist = (const int *)(b->rcount + 2); orp.lead_full = -1;
@@ -696,11 +701,11 @@ static int odom_validate(lmono_ctx *c, lmono_scan_batch *b, OdomView o, bool ext
     HIP_TRY(c, hipStreamSynchronize(st));
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, b->rep_ev[0], b->rep_ev[1]) == hipSuccess) R.repair_ms += ms;
-    R.pairs_rerun = 0; R.chains_rerun = 0; R.unresolved = 0;
+    R.pairs_rerun = 0; R.chains_rerun = 0;
+    R.unresolved = still_flagged;        // boundaries above the tolerance after the last round (0 unless the round cap ended the loop)
     for (int ch = 0; ch < n_chains; ch++) {
         b->rerun_h[ch] = rs[ch * 4 + 1];
         R.pairs_rerun += rs[ch * 4 + 1]; R.chains_rerun += rs[ch * 4 + 3] > 0 ? 1 : 0;
-        R.unresolved += rs[ch * 4 + 2] && !rs[ch * 4] ? 1 : 0;
     }
     return check_launch(c, "boundary validation");
 }
@@ -754,6 +759,7 @@ static int odom_run(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, i
     // the chained schedule validates itself: every chain's warm start against its predecessor's last increment, repair where they differ
     b->brep = lmono_boundary_report{};
     b->brep.n_chains = n_chains;
+    b->resid_h.assign((size_t)n_chains, 0.0); b->rerun_h.assign((size_t)n_chains, 0);      // a run without validation reports zeros, not the previous layout's values
     // (the repair launches carry no per-kernel events: the correspondence / solve sums of lmono_timing_read are the main pass's; the
     // repair's device time is lmono_boundary_report.repair_ms)
     b->validation_pending = !validate;
@@ -798,7 +804,7 @@ extern "C" int lmono_odom_shard_validate(lmono_ctx *c, lmono_scan_batch *b, cons
     // chain boundaries inside the rank instead of a second tail of sequential steps behind them
     const bool first_call = b->validation_pending;
     b->validation_pending = false;
-    if (first_call) { b->brep = lmono_boundary_report{}; b->brep.n_chains = b->last_chains; }
+    if (first_call) { b->brep = lmono_boundary_report{}; b->brep.n_chains = b->last_chains; b->resid_h.assign((size_t)b->last_chains, 0.0); b->rerun_h.assign((size_t)b->last_chains, 0); }
     if (o.tol > 0.0 && (prev_incr_h || b->last_chains > 1)) { int rc = odom_validate(c, b, o, prev_incr_h != nullptr, first_call); if (rc) return rc; }
     HIP_TRY(c, hipMemcpyAsync(after, b->incr + (size_t)(n - 1) * 7, sizeof(after), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1743,6 +1749,7 @@ extern "C" int lmono_mapper_reset(lmono_ctx *c, lmono_mapper *m)
 static int mapper_compact(lmono_mapper *m, int t)
 {
     lmono_ctx *c = m->ctx;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));      // rare path: the frame's tables in the job scratch are done with before it is overwritten
     std::vector<CopyJob> jobs;
     const int nh = m->half[t] ^ 1;
     int64_t at = 0;
@@ -1774,19 +1781,27 @@ template <typename T> int mp_grow(lmono_ctx *c, lmono_mapper *m, T *&p, size_t &
 }
 // job tables of one phase for every stream go through one pinned-free staging path: a scratch device buffer owned by the
 // first mapper of the call, grown on demand
+// Every table of a call gets its OWN piece of the scratch (bump allocation, 256-B aligned): no phase waits for the previous phase's
+// kernels to be done with "the" job table before it uploads its own (round 4: four stream synchronisations per frame less).  A scratch
+// that runs out is replaced by a larger one; the old one stays allocated (kernels in flight still read it) until the mapper is destroyed.
 struct JobScratch {
     lmono_mapper *owner;
+    size_t used = 0;
+    void *last = nullptr;        // device address of the table uploaded last
     int upload(lmono_ctx *c, const void *src, size_t bytes, hipStream_t st)
     {
-        if (bytes > owner->jobs_bytes) {
+        used = (used + 255) & ~(size_t)255;
+        if (used + bytes > owner->jobs_bytes) {
             void *q = nullptr;
             size_t nb = owner->jobs_bytes;
-            while (nb < bytes) nb <<= 1;
+            while (nb < bytes || nb < 2 * (used + bytes)) nb <<= 1;
             if (hipMalloc(&q, nb) != hipSuccess) { c->err = "lmono_mapper: job scratch allocation failed"; return LMONO_ENOMEM; }
             owner->allocs.push_back(q);
-            owner->jobs = q; owner->jobs_bytes = nb;
+            owner->jobs = q; owner->jobs_bytes = nb; used = 0;
         }
-        if (bytes > 0 && hipMemcpyAsync(owner->jobs, src, bytes, hipMemcpyHostToDevice, st) != hipSuccess) { c->err = "lmono_mapper: job upload failed"; return LMONO_ENODEV; }
+        last = (char *)owner->jobs + used;
+        if (bytes > 0 && hipMemcpyAsync(last, src, bytes, hipMemcpyHostToDevice, st) != hipSuccess) { c->err = "lmono_mapper: job upload failed"; return LMONO_ENODEV; }
+        used += bytes;
         return LMONO_OK;
     }
 };
@@ -1864,6 +1879,7 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
     JobScratch js{ ms[0] };
+    HIP_TRY(c, hipStreamSynchronize(st));        // the previous frame's kernels are done with the job scratch (normally a no-op: a frame ends with a read-back)
     std::vector<FrameState> F((size_t)n);
     int rc;
     MapperUndoAll undo;                      // every error return below leaves the mappers as they were on entry
@@ -1924,7 +1940,7 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
                 J.key_a = m->vk[t]; J.key_b = m->vk[t] + kMapStackMax; J.idx_a = m->vi[t]; J.idx_b = m->vi[t] + kMapStackMax;
             }
         if ((rc = js.upload(c, vj.data(), vj.size() * sizeof(VoxJob), st))) return rc;
-        hipLaunchKernelGGL(k_voxel_cloud, dim3(2 * n), dim3(1024), 0, st, (const VoxJob *)js.owner->jobs);
+        hipLaunchKernelGGL(k_voxel_cloud, dim3(2 * n), dim3(1024), 0, st, (const VoxJob *)js.last);
         std::vector<int> ns_h((size_t)2 * n);
         HIP_TRY(c, hipMemcpyAsync(ns_h.data(), ms[0]->ibuf, sizeof(int) * 2 * (size_t)n, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
@@ -1952,8 +1968,7 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
         }
         if (!jobs.empty()) {
             if ((rc = js.upload(c, jobs.data(), jobs.size() * sizeof(CopyJob), st))) return rc;
-            hipLaunchKernelGGL(k_copy_jobs, dim3((unsigned)jobs.size()), dim3(256), 0, st, (const CopyJob *)js.owner->jobs);
-            HIP_TRY(c, hipStreamSynchronize(st));    // the job scratch is reused below
+            hipLaunchKernelGGL(k_copy_jobs, dim3((unsigned)jobs.size()), dim3(256), 0, st, (const CopyJob *)js.last);
         }
     }
     tp[3] = tnow();
@@ -1990,8 +2005,8 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
             memcpy(blob.data(), cj.data(), cj.size() * sizeof(CloudJob));
             memcpy(blob.data() + cj.size() * sizeof(CloudJob), S.data(), S.size() * sizeof(MapStream));
             if ((rc = js.upload(c, blob.data(), blob.size(), st))) return rc;
-            const CloudJob *cj_d = (const CloudJob *)js.owner->jobs;
-            const MapStream *S_d = (const MapStream *)((const char *)js.owner->jobs + cj.size() * sizeof(CloudJob));
+            const CloudJob *cj_d = (const CloudJob *)js.last;
+            const MapStream *S_d = (const MapStream *)((const char *)js.last + cj.size() * sizeof(CloudJob));
             hipLaunchKernelGGL(k_cloud_grid, dim3((unsigned)cj.size()), dim3(1024), 0, st, cj_d);
             for (int outer = 0; outer < 2; outer++) {
                 if (max_nq > 0) {
@@ -2041,7 +2056,7 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
         std::vector<int> cube_all(total + 1, -1);
         if (max_n > 0) {
             if ((rc = js.upload(c, aj.data(), aj.size() * sizeof(AssignJob), st))) return rc;
-            hipLaunchKernelGGL(k_map_assign, dim3((max_n + 255) / 256, 2 * n), dim3(256), 0, st, (const AssignJob *)js.owner->jobs);
+            hipLaunchKernelGGL(k_map_assign, dim3((max_n + 255) / 256, 2 * n), dim3(256), 0, st, (const AssignJob *)js.last);
             HIP_TRY(c, hipMemcpyAsync(cube_all.data(), ms[0]->cubebuf, sizeof(int) * total, hipMemcpyDeviceToHost, st));
         }
         HIP_TRY(c, hipStreamSynchronize(st));
@@ -2092,7 +2107,7 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
     }
     if (!copy.empty()) {
         if ((rc = js.upload(c, copy.data(), copy.size() * sizeof(CopyJob), st))) return rc;
-        hipLaunchKernelGGL(k_copy_jobs, dim3((unsigned)copy.size()), dim3(256), 0, st, (const CopyJob *)js.owner->jobs);
+        hipLaunchKernelGGL(k_copy_jobs, dim3((unsigned)copy.size()), dim3(256), 0, st, (const CopyJob *)js.last);
     }
     {
         size_t total = 0;
@@ -2108,13 +2123,11 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
                 sj[(size_t)2 * s + t] = { ms[s]->newpts[t], ms[0]->posbuf + at[(size_t)2 * s + t], ns, ms[s]->cat[t] };
             }
         if (max_n > 0) {
-            HIP_TRY(c, hipStreamSynchronize(st));    // the copy jobs still read the job scratch
             HIP_TRY(c, hipMemcpyAsync(ms[0]->posbuf, pos_all.data(), sizeof(int) * total, hipMemcpyHostToDevice, st));
             if ((rc = js.upload(c, sj.data(), sj.size() * sizeof(ScatterJob), st))) return rc;
-            hipLaunchKernelGGL(k_scatter_pos, dim3((max_n + 255) / 256, 2 * n), dim3(256), 0, st, (const ScatterJob *)js.owner->jobs);
+            hipLaunchKernelGGL(k_scatter_pos, dim3((max_n + 255) / 256, 2 * n), dim3(256), 0, st, (const ScatterJob *)js.last);
         }
     }
-    HIP_TRY(c, hipStreamSynchronize(st));   // `cat` is complete; the job scratch and pos_h are free again
     // arena space (an output is never larger than its input); compaction reads only the tables, `cat` is already built
     {
         std::vector<int64_t> need((size_t)2 * n, 0);
@@ -2157,15 +2170,14 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
         }
         for (size_t k = 0; k < vox.size(); k++) vox[k].n_out = ms[0]->nout_big + k;
         if ((rc = js.upload(c, vox.data(), vox.size() * sizeof(VoxJob), st))) return rc;
-        hipLaunchKernelGGL(k_voxel_cloud, dim3((unsigned)vox.size()), dim3(1024), 0, st, (const VoxJob *)js.owner->jobs);
+        hipLaunchKernelGGL(k_voxel_cloud, dim3((unsigned)vox.size()), dim3(1024), 0, st, (const VoxJob *)js.last);
         HIP_TRY(c, hipMemcpyAsync(nout_h.data(), ms[0]->nout_big, sizeof(int) * vox.size(), hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipStreamSynchronize(st));
     }
     if (!keep.empty()) {
         if ((rc = js.upload(c, keep.data(), keep.size() * sizeof(CopyJob), st))) return rc;
-        hipLaunchKernelGGL(k_copy_jobs, dim3((unsigned)keep.size()), dim3(256), 0, st, (const CopyJob *)js.owner->jobs);
-        HIP_TRY(c, hipStreamSynchronize(st));
+        hipLaunchKernelGGL(k_copy_jobs, dim3((unsigned)keep.size()), dim3(256), 0, st, (const CopyJob *)js.last);
     }
+    HIP_TRY(c, hipStreamSynchronize(st));       // ONE wait for the frame's map update: filter sizes are back, `cat` and the job tables are free
     for (size_t k = 0; k < touched.size(); k++) {
         const Touched &T = touched[k];
         Seg &sg = ms[T.s]->cube[(size_t)T.t][(size_t)T.ind];

@@ -344,10 +344,10 @@ def test_bench_multi_rank_step_rehearsed_on_one_gpu():
           % (d["value"], d["ate_vs_cpu_m"], d["boundary_validation"]["rank_boundary_rounds"]))
 
 
-def test_bench_strong_scaling_step_rehearsed_with_five_ranks():
-    """`bench.py --gpus N --scaling strong` as the driver's SCALE tier launches it, rehearsed with FIVE ranks on cuda:0 over gloo (the GPU box
-    admits six GPU processes of ours at once, and this pytest process is one of them: 8 ranks cannot be rehearsed on one card): the 4541 scans of
-    configs[1] sharded into five scan ranges, four rank boundaries validated through the deferred rank-boundary validation, chains per rank by
+def test_bench_strong_scaling_step_rehearsed_with_four_ranks():
+    """`bench.py --gpus N --scaling strong` as the driver's SCALE tier launches it, rehearsed with FOUR ranks on cuda:0 over gloo (the GPU box
+    admits six GPU processes of ours at once; this pytest process and the launcher are two of them, so 8 ranks cannot be rehearsed on one card): the
+    4541 scans of configs[1] sharded into four scan ranges, three rank boundaries validated through the deferred rank-boundary validation, chains per rank by
     the rule of bench.py (chain length >= 4 x lead), parity against the committed sequential trajectory over ALL 4541 scans."""
     import json
     import os
@@ -355,16 +355,16 @@ def test_bench_strong_scaling_step_rehearsed_with_five_ranks():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, LMONO_BENCH_REHEARSE="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "5", "--master-addr", "127.0.0.1", "--master-port", "29541",
-           os.path.join(root, "bench.py"), "--gpus", "5", "--scaling", "strong", "--steps", "2", "--warmup", "1", "--no-extras", "--cpu-sample", "0"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1", "--master-port", "29541",
+           os.path.join(root, "bench.py"), "--gpus", "4", "--scaling", "strong", "--steps", "2", "--warmup", "1", "--no-extras", "--cpu-sample", "0"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
-    assert d["n_gpus"] == 5 and d["scaling"] == "strong" and d["config"]["scans_total"] == 4541
+    assert d["n_gpus"] == 4 and d["scaling"] == "strong" and d["config"]["scans_total"] == 4541
     assert d["parity"]["scans_compared"] == 4541 and d["parity"]["feature_counts_equal"]
     assert d["ate_vs_cpu_m"] < 1e-3, d["ate_vs_cpu_m"]                   # the 1 cm bar of north_star with a factor 10 in hand
     assert d["boundary_validation"]["unresolved"] == 0 and d["boundary_validation"]["rank_boundary_rounds"] >= 1
-    print("5-rank strong-scaling rehearsal on one GPU: ATE vs CPU %.2e m over %d scans, chains per rank %s, rank-boundary rounds %s"
+    print("4-rank strong-scaling rehearsal on one GPU: ATE vs CPU %.2e m over %d scans, chains per rank %s, rank-boundary rounds %s"
           % (d["ate_vs_cpu_m"], d["parity"]["scans_compared"], d["config"].get("odometry_chains_per_gpu"), d["boundary_validation"]["rank_boundary_rounds"]))
 
 
