@@ -664,11 +664,11 @@ def main():
     incr_d = torch.zeros((n_local, 7), dtype=torch.float64, device=dev)
     poses_d = torch.zeros((n_own, 7), dtype=torch.float64, device=dev)
     # chains of this rank.  Weak scaling: --chains per rank.  Strong scaling: a rank's share of the scans is cut by RULE, not by --chains // world:
-    # as many chains as keep a chain at least 4 lead-ins long (the speculative lead-in pairs stay below a quarter of a chain's own), at most
-    # --chains; with 4541 scans and lead 4 that gives 256 / 141 / 70 / 35 chains per rank at 1 / 2 / 4 / 8 ranks
+    # as many chains as keep a chain at least 3 lead-ins long -- the length the single-GPU layout was tuned to (4541 scans / 256 chains = 17.7 scans at
+    # lead 6) --, at most --chains; with 4541 scans and lead 6 that gives 256 / 126 / 63 / 31 chains per rank at 1 / 2 / 4 / 8 ranks
     chains = args.chains
     if strong and world > 1:
-        chains = min(args.chains, max(1, n_own // (4 * max(args.lead, 1))))
+        chains = min(args.chains, max(1, n_own // (3 * max(args.lead, 1))))
     chains = max(1, min(chains, n_local))
 
     boundary, shard_rounds = [], [0]

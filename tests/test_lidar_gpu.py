@@ -348,7 +348,7 @@ def test_bench_strong_scaling_step_rehearsed_with_four_ranks():
     """`bench.py --gpus N --scaling strong` as the driver's SCALE tier launches it, rehearsed with FOUR ranks on cuda:0 over gloo (the GPU box
     admits six GPU processes of ours at once; this pytest process and the launcher are two of them, so 8 ranks cannot be rehearsed on one card): the
     4541 scans of configs[1] sharded into four scan ranges, three rank boundaries validated through the deferred rank-boundary validation, chains per rank by
-    the rule of bench.py (chain length >= 4 x lead), parity against the committed sequential trajectory over ALL 4541 scans."""
+    the rule of bench.py (chain length >= 3 x lead), parity against the committed sequential trajectory over ALL 4541 scans."""
     import json
     import os
     import subprocess
