@@ -1277,9 +1277,13 @@ __device__ __forceinline__ bool chol_solve6(const double *A, const double *bvec,
 
 // The same factorisation and substitutions on the LOWER triangle stored row by row (entry (i, j), j <= i, at i (i + 1) / 2 + j),
 // in place: 21 doubles instead of two 6 x 6 arrays, same operations in the same order.
+// Round 4: the 27 divisions by the factor's diagonal are multiplications by its six reciprocals (an fp64 division is ~35 instructions on the one wave
+// per SIMD that runs a chain's solve, and every thread of the workgroup runs this redundantly four times per launch: ~24 k of a launch's ~126 k cycles).
+// Same factorisation to rounding; the solve's parity bar is 1e-9 against the oracle's loop.
 __device__ __forceinline__ bool chol_solve6_packed(double *L, const double *bvec, double *xo)
 {
 #pragma clang fp contract(fast)
+    double inv[6];
 #pragma unroll
     for (int i = 0; i < 6; i++)
 #pragma unroll
@@ -1287,8 +1291,8 @@ __device__ __forceinline__ bool chol_solve6_packed(double *L, const double *bvec
             double s = L[i * (i + 1) / 2 + j];
 #pragma unroll
             for (int k = 0; k < j; k++) s -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
-            if (i == j) { if (!(s > 0.0)) return false; L[i * (i + 1) / 2 + i] = sqrt(s); }
-            else L[i * (i + 1) / 2 + j] = s / L[j * (j + 1) / 2 + j];
+            if (i == j) { if (!(s > 0.0)) return false; const double d = sqrt(s); L[i * (i + 1) / 2 + i] = d; inv[i] = 1.0 / d; }
+            else L[i * (i + 1) / 2 + j] = s * inv[j];
         }
     double y[6];
 #pragma unroll
@@ -1296,14 +1300,14 @@ __device__ __forceinline__ bool chol_solve6_packed(double *L, const double *bvec
         double s = bvec[i];
 #pragma unroll
         for (int k = 0; k < i; k++) s -= L[i * (i + 1) / 2 + k] * y[k];
-        y[i] = s / L[i * (i + 1) / 2 + i];
+        y[i] = s * inv[i];
     }
 #pragma unroll
     for (int i = 5; i >= 0; i--) {
         double s = y[i];
 #pragma unroll
         for (int k = i + 1; k < 6; k++) s -= L[k * (k + 1) / 2 + i] * xo[k];
-        xo[i] = s / L[i * (i + 1) / 2 + i];
+        xo[i] = s * inv[i];
     }
     return true;
 }
@@ -1338,7 +1342,10 @@ __device__ __forceinline__ void unpack_sym(const double *Hu, double *H)
 }
 
 constexpr int kLmRecLds = 4 * kMaxQueries * 16;   // the chain's records in LDS
-constexpr int kThinBlocks = kMaxQueries / 128;     // = kCfBlocks of corr_flat.hip: feature qi belongs to workgroup qi % kThinBlocks
+#ifndef LMONO_CF_T
+#define LMONO_CF_T 128
+#endif
+constexpr int kThinBlocks = kMaxQueries / LMONO_CF_T;     // = kCfBlocks of corr_flat.hip: feature qi belongs to workgroup qi % kThinBlocks
 
 // One kLmT-thread workgroup per chain.  Every thread runs the (uniform) trust-region control flow redundantly on the
 // block-reduced sums; residual blocks come from the 64-B records written by k_correspond.
@@ -1388,7 +1395,7 @@ __device__ __forceinline__ void lm_trust_region(const Eval &ev, double *x, doubl
             }
             if (!reuse_diagonal)
                 for (int i = 0; i < 6; i++) { double d = A[i * (i + 1) / 2 + i]; d = d < min_diag ? min_diag : d; d = d > max_diag ? max_diag : d; diag[i] = d; }
-            for (int i = 0; i < 6; i++) A[i * (i + 1) / 2 + i] += diag[i] / radius;
+            { const double ir = 1.0 / radius; for (int i = 0; i < 6; i++) A[i * (i + 1) / 2 + i] += diag[i] * ir; }
             bool ok = chol_solve6_packed(A, gs, stepv);
             for (int i = 0; i < 6; i++) if (!isfinite(stepv[i])) ok = false;
             double model_change = 0.0;
