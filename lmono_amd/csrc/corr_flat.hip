@@ -386,9 +386,15 @@ __global__ __launch_bounds__(kCfT, LMONO_CF_WAVES) void k_corr_flat(BatchView b,
 
     CF_STAMP(cf_acc[4])
     // ================= nearest point =================
+#ifdef LMONO_TILE_PROF
+    int my_rounds = 0;          // rounds THIS feature took part in (nearest point + walk): the workgroup runs max(nearest) + max(walk), a merged loop would run max of the sums
+#endif
     for (int round = 0; round < kCfNnRounds; round++) {
         if (tid == 0) L.n_pool = 0;
         __syncthreads();
+#ifdef LMONO_TILE_PROF
+        my_rounds += alive ? 1 : 0;
+#endif
         // ---- 1a: run requests of the features still searching
         const float rr = fminf(r, 5.0f);                    // d2 < 25 means d < 5: a 5 m ball holds every admissible point
         bool posted = false;
@@ -476,6 +482,9 @@ __global__ __launch_bounds__(kCfT, LMONO_CF_WAVES) void k_corr_flat(BatchView b,
     for (int round = 0; round < kCfWalkRounds; round++) {
         if (tid == 0) L.n_pool = 0;
         __syncthreads();
+#ifdef LMONO_TILE_PROF
+        my_rounds += walking ? 1 : 0;
+#endif
         bool posted = false;
         if (walking) {
             while (wpass > 0 && wpass < 4 && rad[wpass] <= rad[wpass - 1]) wpass++;
@@ -534,6 +543,15 @@ __global__ __launch_bounds__(kCfT, LMONO_CF_WAVES) void k_corr_flat(BatchView b,
         if (!__syncthreads_or(walking ? 1 : 0)) break;
     }
 #ifdef LMONO_TILE_PROF
+    {
+        const int mr = __syncthreads_or(0) * 0 + my_rounds;
+        __shared__ int s_maxr, s_sumr;
+        if (tid == 0) { s_maxr = 0; s_sumr = 0; }
+        __syncthreads();
+        atomicMax(&s_maxr, mr); atomicAdd(&s_sumr, mr);
+        __syncthreads();
+        if (tid == 0) { cf_acc[17] = (unsigned long long)s_maxr; cf_acc[18] = (unsigned long long)s_sumr; }
+    }
     if (tid == 0 && stats) { atomicAdd(&stats[1], 1ull); for (int i = 0; i < 20; i++) atomicAdd(&stats[2 + i], cf_acc[i]); }
 #endif
     if (qi >= nq) return;

@@ -33,4 +33,6 @@ fine = ["2: chunk search", "2: addresses (LDS)", "2: gathers in flight", "2: ari
 for i, nm in enumerate(fine):
     print("    %-24s %9.0f" % (nm, d[11 + i] / wgs))
 print("    gather batches per workgroup (thread 0) %.1f, owner switches %.1f" % (d[16] / wgs, d[17] / wgs))
+print("    rounds per workgroup as run (max nearest + max walk) %.2f; max over its features of (nearest + walk) %.2f; mean per feature %.2f" %
+      ((d[7] + d[8]) / wgs, d[18] / wgs, d[19] / wgs / 128.0))
 print({k: round(v, 3) for k, v in groups.items()})

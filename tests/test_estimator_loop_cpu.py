@@ -80,3 +80,29 @@ def test_loop_correction_reanchors_the_window_rigidly(oracle):
         # to the orthonormality of the window rotations (~1e-8: they inherit the YAML extrinsic's 8 digits)
         assert np.abs(rel_before - rel_after).max() < 1e-6
         assert np.abs(snap["Rs"][i].T @ snap["Rs"][j] - est2.Rs[i].T @ est2.Rs[j]).max() < 1e-6
+
+
+def test_cxx_mirror_over_the_c_oracle_prints_the_python_replays_trajectory(oracle, tmp_path):
+    """The C++ host mirror (lmono_amd/host/lmono_host.cpp, the code the product's frame loop runs) linked against the C oracle through
+    oracle/cpu_shim.cpp instead of the HIP library -- oracle/estimator_seq_cpu, `bench.py --workload ba-seq`'s CPU baseline -- against the
+    Python replay of the same oracle: the same decisions on every frame and the same trajectory (two host-side orchestrations of the same C
+    numerics; they differ in nothing but the order of a few double additions)."""
+    import os
+    import subprocess
+    from workloads import s2
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "estimator_seq_cpu"])
+    st = s2.make_stream(120, seed=0, stops=(60, 61))
+    est, log = S.replay_oracle(st)
+    fx = tmp_path / "stream.bin"
+    s2.write_stream(fx, st)
+    out = subprocess.run([os.path.join(root, "oracle", "estimator_seq_cpu"), str(fx), "-"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    odo = np.array([[float(v) for v in ln.split()[1:]] for ln in out.stdout.splitlines() if ln.startswith("ODO")])
+    ref = np.array(est.trajectory)
+    assert odo.shape == ref.shape
+    assert np.abs(odo[:, 1:4] - ref[:, 1:4]).max() < 1e-6 and np.abs(np.abs(odo[:, 4:8]) - np.abs(ref[:, 4:8])).max() < 1e-7
+    frm = [ln.split()[1:] for ln in out.stdout.splitlines() if ln.startswith("FRM")]
+    assert len(frm) == len(log)
+    for k, (row, r) in enumerate(zip(frm, log)):
+        assert (int(row[1]), int(row[2]), int(row[3])) == (r[0], r[1], r[2]) and (int(row[7]), int(row[8])) == (r[6], r[7]), "frame %d" % k
