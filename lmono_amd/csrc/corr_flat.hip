@@ -8,9 +8,9 @@
 // feature with its own loops is bound by chains of dependent loads and by the slowest lane.  Here the ragged work of a workgroup's
 // feature points is flattened through LDS, so that every lane always has a candidate:
 //
-//   round   1a  each feature's lane (the "owner") turns its search ball into run REQUESTS: one per azimuth bin of the ball's arc,
-//               (bin, first line, last line) of the (azimuth bin, scan line)-sorted copy of the cloud (k_line_index) -- the lines
-//               v1 .. v2 the ball's elevation window admits are contiguous inside a bin; a request is ONE packed 32-bit word
+//   round   1a  each feature's lane (the "owner") turns its search ball into run REQUESTS: one per scan line the ball's elevation window
+//               admits, (line, first bin, bins) of the (scan line, azimuth bin)-sorted copy of the cloud (k_line_index); a request is ONE
+//               packed 32-bit word
 //           1b  the workgroup resolves all requests together (every lane kCfPer requests: 2 kCfPer independent table loads in
 //               flight) into runs (start, length), cuts every run into CHUNKS of kCfC = 4 consecutive points and takes the
 //               exclusive prefix of the chunk counts
@@ -22,12 +22,11 @@
 //               (LDS) runs while the current chunk's loads are in flight.  Every lane keeps the running minimum of the feature
 //               its chunks belong to and posts it with one LDS atomic min per feature it touches
 //           3   the owners read their minimum: settled (d <= r), or the radius grows and the feature joins the next round
-//   then the same machinery runs the scan-line walk (lines ra-2 .. ra+2 of every bin of growing arcs, two minima per feature).
+//   then the same machinery runs the scan-line walk (lines ra-2 .. ra+2, growing arcs, two minima per feature).
 //
 // Exactness: a point p with |p - q| <= r lies within asin(r / rho_xy(q)) of q's azimuth and within asin(r / |q|) of q's elevation
 // angle; lb_elev holds every line's elevation range and its monotone envelopes, so the lines a ball can meet lie inside an interval
-// v1 .. v2 found by two binary searches (lines inside the interval that the ball cannot meet ride along: extra candidates can only
-// confirm the minimum).  A search of radius r is exact when its minimum is <= r.  Features whose requests do not fit the round's pool
+// v1 .. v2 found by two binary searches, each line tested against its own range.  A search of radius r is exact when its minimum is <= r.  Features whose requests do not fit the round's pool
 // are served in the next round; a feature whose single ball needs more runs than the whole pool goes to the device work list of
 // k_correspond_list.
 #include "batch.hpp"
@@ -74,11 +73,9 @@ constexpr int kCfNnRounds = LMONO_CF_NN_ROUNDS, kCfWalkRounds = LMONO_CF_WALK_RO
 #define LMONO_WALK_TIGHT 1      // a walk pass that SAW its partners outside its ball continues with the ball that just holds them, not with the next rung
 #endif
 
-// run request, one word.  (bin, line)-major copy: bin (9 bits) | first line (7) << 9 | last line + 1 (7) << 16 | owner (7) << 23;
-// (line, bin)-major copy: line (7 bits) | first bin (9) << 7 | bins (9) << 16 | owner (7) << 25.  The cloud follows from the owner.
-__device__ __forceinline__ unsigned int cf_request(int v1, int v2p1, int owner) { return ((unsigned int)v1 << 9) | ((unsigned int)v2p1 << 16) | ((unsigned int)owner << 23); }
+// run request, one word: line (7 bits) | first bin (9) << 7 | bins (9) << 16 | owner (7) << 25.  The cloud follows from the owner.
 __device__ __forceinline__ unsigned int cf_request_line(int line, int b0, int nb, int owner) { return (unsigned int)line | ((unsigned int)b0 << 7) | ((unsigned int)nb << 16) | ((unsigned int)owner << 25); }
-static_assert(kCfT <= 128 && kAzBins <= 511, "request packing");
+static_assert(kCfT <= 128 && kAzBins <= 511, "request packing");       // (owner 7 bits, bins 9 bits)
 
 struct CfRun {                                // resolved run
     unsigned int start;                       // first point of the run in its index copy
@@ -121,13 +118,7 @@ __device__ __forceinline__ void cf_arc(float r, float rho, float th, CfArc &a)
     a.a0 = ((lo % kAzBins) + kAzBins) % kAzBins;
     a.nb = n;
 }
-// the owner's requests: one per bin of the arc (lines v1 .. v2p1 - 1), from slot on
-__device__ __forceinline__ void cf_post(unsigned int *req, int slot, const CfArc &a, unsigned int rq0)
-{
-    int bn = a.a0;
-    for (int t = 0; t < a.nb; t++) { req[slot + t] = rq0 | (unsigned int)bn; bn = bn + 1 == kAzBins ? 0 : bn + 1; }
-}
-// (line, bin)-major copy: the arc on one line is one run, two when it wraps past the last bin
+// the arc on one line is one run, two when it wraps past the last bin
 __device__ __forceinline__ int cf_arc_pieces(const CfArc &a) { return a.a0 + a.nb > kAzBins ? 2 : 1; }
 __device__ __forceinline__ void cf_post_line(unsigned int *req, int &slot, const CfArc &a, int line, int owner)
 {
@@ -177,15 +168,10 @@ __device__ __forceinline__ void cf_sweep(CfLds &L, int n_edge_owner, const int *
         st[j] = 0; en[j] = 0; own[j] = 0;
         if (i < n_pool) {
             const unsigned int rq = L.req[i];
-            own[j] = (int)(rq >> (kLbLineMajor ? 25 : 23)) & 127;
+            own[j] = (int)(rq >> 25) & 127;
             const int *tg = own[j] >= n_edge_owner ? tg_s : tg_c;
-            if (kLbLineMajor) {
-                const int e0 = (int)(rq & 127u) * kAzBins + (int)((rq >> 7) & 511u);
-                st[j] = (unsigned int)tg[e0]; en[j] = (unsigned int)tg[e0 + (int)((rq >> 16) & 511u)];
-            } else {
-                const int row = (int)(rq & 511u) * 66;
-                st[j] = (unsigned int)tg[row + (int)((rq >> 9) & 127u)]; en[j] = (unsigned int)tg[row + (int)((rq >> 16) & 127u)];
-            }
+            const int e0 = (int)(rq & 127u) * kAzBins + (int)((rq >> 7) & 511u);
+            st[j] = (unsigned int)tg[e0]; en[j] = (unsigned int)tg[e0 + (int)((rq >> 16) & 511u)];
         }
     }
     int sum = 0;
@@ -405,22 +391,16 @@ __global__ __launch_bounds__(kCfT, LMONO_CF_WAVES) void k_corr_flat(BatchView b,
             const float beta = R > rr ? asin_upper(rr / R) + 5e-4f : 4.0f;
             const float elo = eq - beta, ehi = eq + beta;
             const int v1 = cf_first_line(el, ehi), v2 = cf_last_line(el, elo);
-            // bin-major copy: one run per azimuth bin of the arc, its lines v1 .. v2; line-major copy: one run (two when the arc wraps) per line
-            // of v1 .. v2 that the ball can meet
-            int nreq = v1 > v2 ? 0 : a.nb;
-            if (kLbLineMajor) {
-                int nl = 0;
-                for (int v = v1; v <= v2; v++) { const float4 ev = el[v]; nl += !(ev.y < elo || ev.x > ehi) ? 1 : 0; }
-                nreq = nl * cf_arc_pieces(a);
-            }
+            // one run (two when the arc wraps) per line of v1 .. v2 that the ball can meet
+            int nl = 0;
+            for (int v = v1; v <= v2; v++) { const float4 ev = el[v]; nl += !(ev.y < elo || ev.x > ehi) ? 1 : 0; }
+            const int nreq = nl * cf_arc_pieces(a);
             if (nreq > kCfPool) { alive = false; deferred = true; }       // a single ball larger than the pool: list kernel
             else {
                 int slot = nreq > 0 ? atomicAdd(&L.n_pool, nreq) : 0;
                 if (slot + nreq <= kCfPool) {
                     posted = true;
-                    if (kLbLineMajor) {
-                        for (int v = v1; v <= v2; v++) { const float4 ev = el[v]; if (!(ev.y < elo || ev.x > ehi)) cf_post_line(L.req, slot, a, v, tid); }
-                    } else if (nreq > 0) cf_post(L.req, slot, a, cf_request(v1, v2 + 1, tid));
+                    for (int v = v1; v <= v2; v++) { const float4 ev = el[v]; if (!(ev.y < elo || ev.x > ehi)) cf_post_line(L.req, slot, a, v, tid); }
                 } else {
                     // the pool of this round is full: the feature posts again in the next round; the part of its reservation that
                     // lies inside the pool becomes empty runs
@@ -495,17 +475,14 @@ __global__ __launch_bounds__(kCfT, LMONO_CF_WAVES) void k_corr_flat(BatchView b,
         if (walking) {
             CfArc a;
             cf_arc(r_now, rho, th, a);
-            // bin-major copy: one run per azimuth bin of the arc, the lines ra-2 .. ra+2 (an edge feature's own line rides along: its "same"
-            // minimum is not read); line-major copy: one run (two when the arc wraps) per line, without an edge feature's own line
+            // one run (two when the arc wraps) per line of ra-2 .. ra+2, without an edge feature's own line
             const int wv1 = max(ra - 2, 0), wv2 = min(ra + 2, 65);
-            const int nreq = kLbLineMajor ? (wv2 - wv1 + 1 - (edge ? 1 : 0)) * cf_arc_pieces(a) : a.nb;
+            const int nreq = (wv2 - wv1 + 1 - (edge ? 1 : 0)) * cf_arc_pieces(a);
             int slot = atomicAdd(&L.n_pool, nreq);
             if (slot + nreq <= kCfPool) {
                 posted = true;
                 L.same[tid] = thr; L.other[tid] = thr;
-                if (kLbLineMajor) {
-                    for (int v = wv1; v <= wv2; v++) if (!(edge && v == ra)) cf_post_line(L.req, slot, a, v, tid);
-                } else cf_post(L.req, slot, a, cf_request(wv1, wv2 + 1, tid));
+                for (int v = wv1; v <= wv2; v++) if (!(edge && v == ra)) cf_post_line(L.req, slot, a, v, tid);
             } else
                 for (int t = slot; t < kCfPool; t++) L.req[t] = 0u;
         }

@@ -35,6 +35,7 @@ struct lmono_ctx {
     unsigned long long *stats_d = nullptr;   // [0] feature points deferred by the tile search since the last lmono_timing_reset
     hipStream_t copy_stream = nullptr;       // H2D staging of lmono_batch_stage_h (runs beside the compute stream)
     hipStream_t own_stream = nullptr;        // lmono_use_own_stream: a stream of the library's that this context runs on
+    bool odom_prio = false, many_queues = false;     // measurement switches read from the environment at creation (LMONO_ODOM_STREAM_PRIORITY, GPU_MAX_HW_QUEUES >= 8)
     // scratch arena of the small host-array entry points (triangulate, outlier scores, marginalise ...): chunks are allocated once and
     // reused by every later call -- no hipMalloc / hipFree (both synchronise the device) in a steady-state frame loop
     struct Chunk { char *base; size_t cap; };
@@ -114,6 +115,8 @@ extern "C" lmono_ctx *lmono_create(int device)
     if (hipSetDevice(device) != hipSuccess) return nullptr;
     lmono_ctx *c = new lmono_ctx();
     c->device = device;
+    if (const char *e = getenv("LMONO_ODOM_STREAM_PRIORITY")) c->odom_prio = atoi(e) != 0;
+    if (const char *e = getenv("GPU_MAX_HW_QUEUES")) c->many_queues = atoi(e) >= 8;
     if (hipMalloc((void **)&c->stats_d, 320) != hipSuccess || hipMemset(c->stats_d, 0, 320) != hipSuccess) { delete c; return nullptr; }
     // the selection kernel needs ~62 KB of dynamic LDS
     if (hipFuncSetAttribute((const void *)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kSelWaveLds + 4 * kSelScratch) != hipSuccess) { delete c; return nullptr; }
@@ -552,7 +555,14 @@ struct GroupFork {
     int fork()
     {
         if (G <= 1) return LMONO_OK;
-        for (int g = g_own; g < G; g++) if (!c->gstream[g]) HIP_TRY(c, hipStreamCreateWithFlags(&c->gstream[g], hipStreamNonBlocking));
+        for (int g = g_own; g < G; g++)
+            if (!c->gstream[g]) {
+                // LMONO_ODOM_STREAM_PRIORITY=1 (measurement switch): the chain groups' streams at the highest priority, so that their short dependent
+                // launches are dispatched ahead of another context's wide grids (a front end running beside the odometry)
+                int lo = 0, hi = 0;
+                if (c->odom_prio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess) HIP_TRY(c, hipStreamCreateWithPriority(&c->gstream[g], hipStreamNonBlocking, hi));
+                else HIP_TRY(c, hipStreamCreateWithFlags(&c->gstream[g], hipStreamNonBlocking));
+            }
         for (int g = 0; g <= G && g < 9; g++) if (!c->gev[g]) HIP_TRY(c, hipEventCreateWithFlags(&c->gev[g], hipEventDisableTiming));
         HIP_TRY(c, hipEventRecord(c->gev[0], c->stream));
         forked = true;                           // from here on the group streams may carry work: join() must run
@@ -583,7 +593,7 @@ static int odom_groups(const lmono_ctx *c, int n_ch)
     constexpr int kMinChainsPerGroup = 32;
     int G = c->opt[LMONO_OPT_ODOM_STREAMS];
     G = G < 1 ? 1 : (G > 8 ? 8 : G);
-    if (c->stream != nullptr && G > 3) G = 3;
+    if (c->stream != nullptr && G > 3 && !c->many_queues) G = 3;      // (GPU_MAX_HW_QUEUES >= 8 in the environment: one hardware queue per stream anyway)
     while (G > 1 && n_ch / G < kMinChainsPerGroup) G--;      // a group below 32 chains cannot fill its share of the CUs
     if (c->opt[LMONO_OPT_CORR_TILE] != 3) G = 1;            // only the default search is grouped
     return G;

@@ -480,21 +480,19 @@ __device__ __forceinline__ double boundary_residual(const double *a, const doubl
     return r == r ? r : 1e300;            // a NaN never agrees
 }
 
-// ---- (azimuth-bin, line) index of a feature cloud -------------------------------------------------------------
+// ---- (line, azimuth-bin) index of a feature cloud -------------------------------------------------------------
 // Every candidate the searches ever accept lies closer than 5 m to the (transformed) feature point, i.e. within +-asin(r / rho_xy)
-// of its azimuth and within a few scan lines of its elevation.  k_line_index sorts a copy of every "last" cloud by
-// (azimuth bin, scan line) once per scan (counting sort in LDS) and keeps the start of every (bin, line) bucket: the candidates of a
-// ball are then ONE contiguous run per azimuth bin of its arc, covering the lines v1 .. v2 its elevation window admits (round 4; until
-// then the copy was (line, bin)-major and a ball was one ~2-point run per line: every 16-B candidate gather was its own 128-B L1 access).
-// A point of the copy carries (cloud index << 7 | line) in .w.
+// of its azimuth and within a few scan lines of its elevation.  k_line_index sorts a copy of every "last" cloud by (scan line,
+// azimuth bin) once per scan (counting sort in LDS) and keeps the start of every (line, bin) bucket: the candidates of a ball are ONE
+// contiguous run per scan line -- a handful of short coalesced sweeps instead of a pass over whole scan lines.  A point of the copy carries
+// (cloud index << 7 | line) in .w, the low word of the searches' u64 keys.
+// Round 4 measured the (bin, line)-major order beside this one (commit 9c24d9d holds both behind LMONO_LB_ORDER; profiles/r4/NOTES.md section 1):
+// equal for the chunked search (0.250 against 0.236 ms per launch), 3.0 instead of 2.2 ms per pass to build (a ring's consecutive points land 66
+// buckets apart: scattered 16-B writes).  Removed again.
 constexpr int kAzBins = 384;           // 0.9375 deg: about one point of a 0.2 m-voxelised cloud per bin and line at 12 m
 constexpr int kLineKeys = 66 * kAzBins;
-#ifndef LMONO_LB_ORDER
-#define LMONO_LB_ORDER 1               // 1 (default): (line, azimuth bin)-major copy; 0: (azimuth bin, line)-major -- measured side by side (profiles/r4/NOTES.md): with
-                                       // the chunked sweep of corr_flat.hip the two searches are within 5 %, and the line-major copy is 0.8 ms per pass cheaper to build
-#endif
-constexpr bool kLbLineMajor = LMONO_LB_ORDER != 0;
-__device__ __forceinline__ int lb_key(int bin, int line) { return kLbLineMajor ? line * kAzBins + bin : bin * 66 + line; }
+__device__ __forceinline__ int lb_key(int bin, int line) { return line * kAzBins + bin; }
+constexpr int kLbPad = 4;              // entries behind the index copies: k_corr_flat's 64-B chunks may read up to three points past a run
 // the runs of the copy that hold the lines va .. vb of the bins [b_lo, b_lo + nbins) (wrapping past the last bin): f(first point, count).
 // Fall-back kernels only: simple beats fast.
 template <class F>
@@ -504,16 +502,9 @@ __device__ __forceinline__ void lb_for_runs(const int *table, int b_lo, int nbin
     for (int part = 0; part < 2; part++) {
         if (part == 1 && b_end <= kAzBins) break;
         const int p0 = part ? 0 : b_lo, p1 = part ? b_end - kAzBins : min(b_end, kAzBins);
-        if (kLbLineMajor) {
-            for (int v = va; v <= vb; v++) { const int s0 = table[v * kAzBins + p0]; f(s0, table[v * kAzBins + p1] - s0); }
-        } else if (va == 0 && vb == 65) {
-            const int s0 = table[p0 * 66]; f(s0, table[p1 * 66] - s0);
-        } else {
-            for (int bn = p0; bn < p1; bn++) { const int s0 = table[bn * 66 + va]; f(s0, table[bn * 66 + vb + 1] - s0); }
-        }
+        for (int v = va; v <= vb; v++) { const int s0 = table[v * kAzBins + p0]; f(s0, table[v * kAzBins + p1] - s0); }
     }
 }
-constexpr int kLbPad = 4;              // entries behind the index copies: k_corr_flat's 64-B chunks may read up to three points past a run
 
 __device__ __forceinline__ int az_bin(float x, float y)
 {
@@ -536,7 +527,7 @@ constexpr int kLiT = 1024;     // threads of k_line_index
 constexpr int kLiLdsHalf = kLineKeys * 2, kLiLdsFull = kLineKeys * 4;   // dynamic LDS: one 16-bit / 32-bit counter per (line, bin)
 constexpr int kLiBigGrid = 64;
 
-// One (scan, cloud): copy of the cloud counting-sorted by (azimuth bin, line), the (bin, line) start table, per-line elevation bounds.
+// One (scan, cloud): copy of the cloud counting-sorted by (line, azimuth bin), the (line, bin) start table, per-line elevation bounds.
 // kHalf: the counters are 16-bit halves of 32-bit LDS words (50 KB instead of 101 KB: three workgroups per CU instead of one --
 // the kernel is bound by its own dependent rounds, not by bytes); a cloud of more than 65535 points cannot be counted in 16 bits
 // and goes through the work list `li_todo` to the full-width launch (small fixed grid, normally empty).

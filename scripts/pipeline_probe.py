@@ -10,7 +10,7 @@ from workloads import s1 as S1
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4541
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-chains, lead = 256, 7
+chains, lead = 256, 6
 w = S1.S1World(n_az=2000)
 traj = w.trajectory(n)
 xyzi, off = w.scans(traj, scan_id0=0)
@@ -22,6 +22,7 @@ del xyzi
 def run(pipelined):
     sF, sO = torch.cuda.Stream(), torch.cuda.Stream()
     cF, cO = lmono_amd.Context(0), lmono_amd.Context(0)
+    cO.set_option(cO.OPT_LEAD_FULL, 3)
     cF.set_stream(sF.cuda_stream)
     cO.set_stream(sO.cuda_stream if pipelined else sF.cuda_stream)
     nb = 2 if pipelined else 1
