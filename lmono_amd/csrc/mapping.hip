@@ -591,7 +591,8 @@ __global__ __launch_bounds__(1024) void k_voxel_cloud(const VoxJob *jobs)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = J.n;
     if (n <= 0 || n > kVoxCloudMax) { if (tid == 0) *J.n_out = n <= 0 ? 0 : -1; return; }
     __shared__ float s_box[16][6];
-    __shared__ int s_cnt[16][16];        // [digit][wave] counts, then first output positions
+    __shared__ int s_cnt[16][256];       // [wave][digit] counts of a pass, then first output positions (running cursors during the scatter)
+    __shared__ int s_wtot[16];
     __shared__ int s_heads[16];
     __shared__ int s_total;
     typedef __attribute__((address_space(1))) const float4 GF4;
@@ -623,11 +624,11 @@ __global__ __launch_bounds__(1024) void k_voxel_cloud(const VoxJob *jobs)
     const int minb0 = (int)floorf(mn[0] * inv), minb1 = (int)floorf(mn[1] * inv), minb2 = (int)floorf(mn[2] * inv);
     const int div0 = (int)floorf(mx[0] * inv) - minb0 + 1, div1 = (int)floorf(mx[1] * inv) - minb1 + 1, div2 = (int)floorf(mx[2] * inv) - minb2 + 1;
     const int mul1 = div0, mul2 = div0 * div1;
-    // highest cell index decides how many 4-bit passes are needed
+    // highest cell index decides how many 8-bit passes are needed
     const unsigned int max_cell = (unsigned int)((div0 - 1) + (div1 - 1) * mul1 + (div2 - 1) * mul2);
     int bits = 0;
     while (bits < 32 && (max_cell >> bits) != 0u) bits++;
-    const int passes = (bits + 3) / 4 > 0 ? (bits + 3) / 4 : 1;
+    const int passes = (bits + 7) / 8 > 0 ? (bits + 7) / 8 : 1;
     GU *ka = (GU *)J.key_a, *kb = (GU *)J.key_b;
     GI *ia = (GI *)J.idx_a, *ib = (GI *)J.idx_b;
     // keys in index order
@@ -652,11 +653,23 @@ __global__ __launch_bounds__(1024) void k_voxel_cloud(const VoxJob *jobs)
     const int seg = (((n + 15) / 16) + 63) & ~63;
     const int w_lo = min(wave * seg, n), w_hi = min(w_lo + seg, n);
     const unsigned long long lt = (1ull << lane) - 1ull;
-    for (int pass = 0; pass < passes; pass++) {
-        const int sh = 4 * pass;
-        int cnt[16];
+    // Round 4: 8-bit digits (three passes for a 20..24-bit cell index instead of six 4-bit ones).  The lanes of a 64-element block that hold the same digit
+    // find each other with eight ballots (one per digit bit); the lowest of them owns the wave's counter / cursor of that digit for the block, the others
+    // take their rank behind it: still the order (wave segment, block, lane) = index order inside a digit, so every pass is stable.
+    auto peers_of = [&](bool ok, unsigned int dgt) -> unsigned long long {
+        unsigned long long pm = __ballot(ok);
 #pragma unroll
-        for (int d = 0; d < 16; d++) cnt[d] = 0;
+        for (int bq = 0; bq < 8; bq++) {
+            const unsigned long long m = __ballot(ok && ((dgt >> bq) & 1u));
+            pm &= ((dgt >> bq) & 1u) ? m : ~m;
+        }
+        return ok ? pm : 0ull;
+    };
+    for (int pass = 0; pass < passes; pass++) {
+        const int sh = 8 * pass;
+        int *flat = &s_cnt[0][0];
+        for (int i = tid; i < 16 * 256; i += 1024) flat[i] = 0;
+        __syncthreads();
         for (int r0 = w_lo; r0 < w_hi; r0 += 4 * 64) {
             unsigned int kk[4];
 #pragma unroll
@@ -664,30 +677,26 @@ __global__ __launch_bounds__(1024) void k_voxel_cloud(const VoxJob *jobs)
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const bool ok = r0 + 64 * u + lane < w_hi;
-                const int dgt = (int)((kk[u] >> sh) & 15u);
-#pragma unroll
-                for (int d = 0; d < 16; d++) cnt[d] += __popcll(__ballot(ok && dgt == d));
+                const unsigned int dgt = (kk[u] >> sh) & 255u;
+                const unsigned long long pm = peers_of(ok, dgt);
+                if (ok && (pm & lt) == 0ull) s_cnt[wave][dgt] += __popcll(pm);        // the digit's lowest lane; one wave, one row: plain read-modify-write, in block order
             }
         }
-        if (lane == 0) {
-#pragma unroll
-            for (int d = 0; d < 16; d++) s_cnt[d][wave] = cnt[d];
-        }
         __syncthreads();
-        // exclusive prefix over the 256 counts in (digit, wave) order by wave 0: four consecutive entries per lane
-        if (wave == 0) {
-            int *flat = &s_cnt[0][0];
+        // exclusive prefix over the 4096 counts in (digit, wave) order: four consecutive entries per thread
+        {
             int v4[4], local = 0;
 #pragma unroll
-            for (int q = 0; q < 4; q++) { v4[q] = flat[4 * lane + q]; local += v4[q]; }
-            int run = wave_scan_incl(local) - local;
+            for (int q = 0; q < 4; q++) { const int e = 4 * tid + q; v4[q] = s_cnt[e & 15][e >> 4]; local += v4[q]; }
+            const int incl = wave_scan_incl(local);
+            if (lane == 63) s_wtot[wave] = incl;
+            __syncthreads();
+            int run = incl - local;
+            for (int w = 0; w < wave; w++) run += s_wtot[w];
 #pragma unroll
-            for (int q = 0; q < 4; q++) { flat[4 * lane + q] = run; run += v4[q]; }
+            for (int q = 0; q < 4; q++) { const int e = 4 * tid + q; s_cnt[e & 15][e >> 4] = run; run += v4[q]; }
         }
         __syncthreads();
-        int off[16];
-#pragma unroll
-        for (int d = 0; d < 16; d++) off[d] = s_cnt[d][wave];
         for (int r0 = w_lo; r0 < w_hi; r0 += 4 * 64) {
             unsigned int kk[4];
             int ii[4];
@@ -696,15 +705,13 @@ __global__ __launch_bounds__(1024) void k_voxel_cloud(const VoxJob *jobs)
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const bool ok = r0 + 64 * u + lane < w_hi;
-                const int dgt = (int)((kk[u] >> sh) & 15u);
-                int dst = 0;
-#pragma unroll
-                for (int d = 0; d < 16; d++) {
-                    const unsigned long long m = __ballot(ok && dgt == d);
-                    if (dgt == d) dst = off[d] + __popcll(m & lt);
-                    off[d] += __popcll(m);
-                }
-                if (ok) { kb[dst] = kk[u]; ib[dst] = ii[u]; }
+                const unsigned int dgt = (kk[u] >> sh) & 255u;
+                const unsigned long long pm = peers_of(ok, dgt);
+                const bool lead = ok && (pm & lt) == 0ull;
+                int base = 0;
+                if (lead) { base = s_cnt[wave][dgt]; s_cnt[wave][dgt] = base + __popcll(pm); }
+                base = __shfl(base, ok ? __ffsll((long long)pm) - 1 : lane);
+                if (ok) { const int dst = base + __popcll(pm & lt); kb[dst] = kk[u]; ib[dst] = ii[u]; }
             }
         }
         __threadfence_block();

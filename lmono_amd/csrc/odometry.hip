@@ -1354,7 +1354,10 @@ template <class Eval>
 __device__ __forceinline__ void lm_trust_region(const Eval &ev, double *x, double *s_cur, double *s_sum, int n_used, int &iter)
 {
     const int tid = threadIdx.x;
-    const int max_iter = 4;
+#ifndef LMONO_LM_MAX_ITER
+#define LMONO_LM_MAX_ITER 4          // ceres max_num_iterations of laserOdometry (any other value is a TIMING experiment: results change)
+#endif
+    const int max_iter = LMONO_LM_MAX_ITER;
     const double function_tol = 1e-6, gradient_tol = 1e-10, parameter_tol = 1e-8;
     const double min_rel_decrease = 1e-3, min_diag = 1e-6, max_diag = 1e32, max_radius = 1e16, min_radius = 1e-32;
     double radius = 1e4, decrease_factor = 2.0;
