@@ -1541,7 +1541,7 @@ extern "C" int lmono_map_refine(lmono_ctx *c, int n_streams,
     float4 *sorted[2] = { (float4 *)db.up((const float *)nullptr, (size_t)tot[0] * 4, ok), (float4 *)db.up((const float *)nullptr, (size_t)tot[1] * 4, ok) };
     int *slot[2] = { db.up((const int *)nullptr, (size_t)tot[0], ok), db.up((const int *)nullptr, (size_t)tot[1], ok) };
     int *rank[2] = { db.up((const int *)nullptr, (size_t)tot[0], ok), db.up((const int *)nullptr, (size_t)tot[1], ok) };
-    int *masks = db.up((const int *)nullptr, (size_t)2 * n_streams, ok);
+    int *masks = db.up((const int *)nullptr, (size_t)4 * n_streams, ok);     // [2 n] masks, [2 n] run allocators
     const int64_t nq_total = tot[2] + tot[3];
     MapRec *rec = (MapRec *)db.up((const char *)nullptr, (size_t)(nq_total > 0 ? nq_total : 1) * sizeof(MapRec), ok);
     int *nn_d = nn_out_h ? db.up((const int *)nullptr, (size_t)(nq_total > 0 ? nq_total : 1) * 5, ok) : nullptr;
@@ -1554,7 +1554,7 @@ extern "C" int lmono_map_refine(lmono_ctx *c, int n_streams,
     if (!ok) { c->err = "lmono_map_refine: device allocation / upload failed"; return LMONO_ENOMEM; }
     std::vector<CloudJob> jobs((size_t)2 * n_streams);
     std::vector<MapStream> st((size_t)n_streams);
-    int max_nq = 0;
+    int max_nq = 0, max_nmap = 0;
     int64_t rec_at = 0;
     for (int s = 0; s < n_streams; s++) {
         MapStream &S = st[(size_t)s];
@@ -1562,9 +1562,10 @@ extern "C" int lmono_map_refine(lmono_ctx *c, int n_streams,
             const int64_t *moff = w ? surf_map_off : corner_map_off, *soff = w ? surf_stack_off : corner_stack_off;
             CloudJob &J = jobs[(size_t)2 * s + w];
             J.src = cloud_d[w] + moff[s]; J.n = (int)(moff[s + 1] - moff[s]);
+            max_nmap = std::max(max_nmap, J.n);
             J.cell = cells + toff[(size_t)2 * s + w]; J.tcap = (int)(toff[(size_t)2 * s + w + 1] - toff[(size_t)2 * s + w]);
             J.sorted = sorted[w] + moff[s]; J.slot_of = slot[w] + moff[s]; J.rank_of = rank[w] + moff[s];
-            J.mask_out = masks + 2 * s + w;
+            J.mask_out = masks + 2 * s + w; J.bump = masks + 2 * n_streams + 2 * s + w;
             S.cell[w] = J.cell; S.sorted[w] = J.sorted; S.cloud[w] = J.src; S.mask[w] = J.mask_out; S.n_map[w] = J.n;
             S.stack[w] = cloud_d[2 + w] + soff[s]; S.n_stack[w] = (int)(soff[s + 1] - soff[s]);
         }
@@ -1586,7 +1587,7 @@ extern "C" int lmono_map_refine(lmono_ctx *c, int n_streams,
     for (hipEvent_t &x : evs.e) if (hipEventCreate(&x) != hipSuccess) { c->err = "hipEventCreate failed"; return LMONO_ENODEV; }
     const hipEvent_t ev0 = evs.e[0], ev1 = evs.e[1], ev2 = evs.e[2];
     (void)hipEventRecord(ev0, stream);
-    hipLaunchKernelGGL(k_cloud_grid, dim3(2 * n_streams), dim3(1024), 0, stream, (const CloudJob *)jobs_d);
+    launch_cloud_grids(stream, (const CloudJob *)jobs_d, 2 * n_streams, max_nmap);
     (void)hipEventRecord(ev1, stream);
     for (int outer = 0; outer < 2; outer++) {
         if (max_nq > 0) {
@@ -1738,7 +1739,7 @@ extern "C" lmono_mapper *lmono_mapper_create(lmono_ctx *c, float line_res, float
     }
     m->jobs_bytes = 1 << 20;
     m->nout_cap = 1024;
-    ok = ok && mp_alloc(m, m->masks, 2) && mp_alloc(m, m->nout, 2 * 256) && mp_alloc(m, m->nout_big, m->nout_cap) && mp_alloc(m, m->stats, 8) && mp_alloc(m, m->x, 8) &&
+    ok = ok && mp_alloc(m, m->masks, 4) && mp_alloc(m, m->nout, 2 * 256) && mp_alloc(m, m->nout_big, m->nout_cap) && mp_alloc(m, m->stats, 8) && mp_alloc(m, m->x, 8) &&
          mp_alloc(m, m->rec, (size_t)2 * kMapStackMax) && mp_alloc(m, m->nn_tmp, (size_t)10 * kMapStackMax) && mp_alloc(m, (char *&)m->jobs, m->jobs_bytes) && mp_alloc(m, m->stream_d, 1);
     if (!ok) { c->err = "lmono_mapper_create: device allocation failed"; lmono_mapper_destroy(m); return nullptr; }
     return m;
@@ -1996,14 +1997,15 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
         if (!act.empty()) {
             std::vector<CloudJob> cj((size_t)2 * act.size());
             std::vector<MapStream> S(act.size());
-            int max_nq = 0;
+            int max_nq = 0, max_nmap = 0;
             for (size_t a = 0; a < act.size(); a++) {
                 lmono_mapper *m = ms[act[a]];
                 FrameState &f = F[(size_t)act[a]];
                 for (int t = 0; t < 2; t++) {
                     CloudJob &J = cj[2 * a + (size_t)t];
                     J.src = m->neigh[t]; J.n = f.n_map[t]; J.cell = m->cells[t]; J.tcap = m->tcap; J.sorted = m->sorted[t];
-                    J.slot_of = m->slot[t]; J.rank_of = m->rank[t]; J.mask_out = m->masks + t;
+                    J.slot_of = m->slot[t]; J.rank_of = m->rank[t]; J.mask_out = m->masks + t; J.bump = m->masks + 2 + t;
+                    max_nmap = std::max(max_nmap, f.n_map[t]);
                     S[a].cell[t] = m->cells[t]; S[a].sorted[t] = m->sorted[t]; S[a].cloud[t] = m->neigh[t]; S[a].mask[t] = m->masks + t; S[a].n_map[t] = f.n_map[t];
                     S[a].stack[t] = m->stack[t]; S[a].n_stack[t] = f.n_stack[t];
                 }
@@ -2017,7 +2019,7 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
             if ((rc = js.upload(c, blob.data(), blob.size(), st))) return rc;
             const CloudJob *cj_d = (const CloudJob *)js.last;
             const MapStream *S_d = (const MapStream *)((const char *)js.last + cj.size() * sizeof(CloudJob));
-            hipLaunchKernelGGL(k_cloud_grid, dim3((unsigned)cj.size()), dim3(1024), 0, st, cj_d);
+            launch_cloud_grids(st, cj_d, (int)cj.size(), max_nmap);
             for (int outer = 0; outer < 2; outer++) {
                 if (max_nq > 0) {
                     hipLaunchKernelGGL(k_map_correspond, dim3((max_nq + 7) / 8, (unsigned)act.size()), dim3(256), 0, st, S_d, outer);

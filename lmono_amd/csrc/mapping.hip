@@ -1,8 +1,8 @@
 // lmono_amd/csrc/mapping.hip -- gfx950 kernels of the scan-to-map optimisation step of A-LOAM laserMapping (SURVEY.md
 // Appendix A.4, row 8f-1; source absent from the reference tree, /root/reference/.gitmodules:1-3), batched over
 // independent streams:
-//   k_cloud_grid   one workgroup per (stream, cloud): 1 m hash grid over an arbitrary float4 cloud (the map clouds of the
-//                  cube neighbourhood), same structure as the odometry grids (16-B cells, cell-sorted copy)
+//   k_grid_clear / _insert / _starts / _fill   1 m hash grid over an arbitrary float4 cloud (the map clouds of the cube
+//                  neighbourhood), many workgroups per (stream, cloud); 16-B cells, cell-sorted copy
 //   k_map_correspond  32 lanes per down-sampled scan point: pointAssociateToMap, exact 5-NN among the 27 cells around it
 //                  (every neighbour that can pass the "5th distance^2 < 1" test lies inside them)
 //   k_map_factor   one thread per point: the line test (covariance of the 5 neighbours, Jacobi eigen-decomposition,
@@ -23,112 +23,129 @@ struct CloudJob {
     float4 *sorted;        // cell-sorted copy, .w = original index bits
     int *slot_of, *rank_of;
     int *mask_out;         // table size - 1 actually used (0: table unusable -> no correspondences)
+    int *bump;             // the job's run allocator inside `sorted` (zeroed by k_grid_clear)
 };
 
-__global__ __launch_bounds__(1024) void k_cloud_grid(const CloudJob *jobs)
+// Round 4: the grid of one cloud is built by MANY workgroups (blockIdx.y = job, blockIdx.x strides over the job's cells / points) in four launches --
+// clear | insert | starts | fill -- instead of one 1024-thread workgroup per cloud (0.26 ms per frame for the ~100 k-point neighbourhood clouds, a
+// chain of ~1 us global round trips on one CU).  The cells no longer sit in slot order inside `sorted`: a cell's run starts where an atomic bump of
+// the job's counter put it.  Nothing reads the order of the runs (k_map_correspond ranks candidates by (distance, original index)).
+__device__ __forceinline__ int cloud_grid_size(const CloudJob &J)
 {
-    const CloudJob J = jobs[blockIdx.x];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = J.n;
-    int T = next_pow2(n + 1);
+    int T = next_pow2(J.n + 1);
     if (T < 1024) T = 1024;
-    if (T > J.tcap) { if (tid == 0) *J.mask_out = 0; return; }
-    const int mask = T - 1;
-    if (tid == 0) *J.mask_out = mask;
-    // the job's arrays as global pointers (through the job struct they are generic: flat_ loads and flat atomics); four points per thread and turn --
-    // the kernel is ONE workgroup per cloud and a returning global atomic is a ~1 us round trip: one point at a time it was three of them per point
+    return T > J.tcap ? 0 : T;
+}
+
+constexpr int kCgT = 256;      // threads per workgroup of the four kernels
+
+__global__ __launch_bounds__(kCgT) void k_grid_clear(const CloudJob *jobs)
+{
+    const CloudJob J = jobs[blockIdx.y];
+    const int T = cloud_grid_size(J);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *J.mask_out = T ? T - 1 : 0; *J.bump = 0; }
+    typedef __attribute__((address_space(1))) GridCell GCell;
+    GridCell *cell = (GridCell *)(GCell *)J.cell;
+    for (int i = blockIdx.x * kCgT + threadIdx.x; i < T; i += gridDim.x * kCgT) { GridCell e; e.key = kEmptyKey; e.start = 0; e.cnt = 0; cell[i] = e; }
+}
+
+__global__ __launch_bounds__(kCgT) void k_grid_insert(const CloudJob *jobs)
+{
+    const CloudJob J = jobs[blockIdx.y];
+    const int T = cloud_grid_size(J), n = J.n;
+    if (T == 0) return;
+    const unsigned int mask = (unsigned int)(T - 1);
     typedef __attribute__((address_space(1))) const float4 GF4;
-    typedef __attribute__((address_space(1))) float4 GF4W;
     typedef __attribute__((address_space(1))) GridCell GCell;
     typedef __attribute__((address_space(1))) int GI;
     GridCell *cell = (GridCell *)(GCell *)J.cell;
     const float4 *gsrc = (const float4 *)(GF4 *)J.src;
-    float4 *gsorted = (float4 *)(GF4W *)J.sorted;
     GI *slot_of = (GI *)J.slot_of, *rank_of = (GI *)J.rank_of;
-    for (int i = tid; i < T; i += 1024) { GridCell e; e.key = kEmptyKey; e.start = 0; e.cnt = 0; cell[i] = e; }
-    __threadfence_block();
-    __syncthreads();
-    for (int i0 = tid; i0 < n; i0 += 4 * 1024) {
-        float4 p[4];
+    const int stride = gridDim.x * kCgT;
+    for (int i0 = blockIdx.x * kCgT + threadIdx.x; i0 < n; i0 += 2 * stride) {
+        float4 p[2];
 #pragma unroll
-        for (int u = 0; u < 4; u++) p[u] = gsrc[min(i0 + 1024 * u, n - 1)];
-        unsigned long long key[4];
-        unsigned int sl[4];
-        bool open[4];
+        for (int u = 0; u < 2; u++) p[u] = gsrc[min(i0 + stride * u, n - 1)];
+        unsigned long long key[2];
+        unsigned int sl[2];
+        bool open[2];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < 2; u++) {
             key[u] = cell_key((int)floorf(p[u].x * kInvCell), (int)floorf(p[u].y * kInvCell), (int)floorf(p[u].z * kInvCell));
             sl[u] = hash_key(key[u]) & mask;
-            open[u] = i0 + 1024 * u < n;
+            open[u] = i0 + stride * u < n;
         }
-        // probe rounds: the compare-and-swaps of the four points are issued together
-        while (open[0] || open[1] || open[2] || open[3]) {
-            unsigned long long old[4];
+        while (open[0] || open[1]) {
+            unsigned long long old[2];
 #pragma unroll
-            for (int u = 0; u < 4; u++) old[u] = open[u] ? atomicCAS(&cell[sl[u]].key, kEmptyKey, key[u]) : key[u];
+            for (int u = 0; u < 2; u++) old[u] = open[u] ? atomicCAS(&cell[sl[u]].key, kEmptyKey, key[u]) : key[u];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < 2; u++) {
                 if (!open[u]) continue;
                 if (old[u] == kEmptyKey || old[u] == key[u]) open[u] = false;
                 else sl[u] = (sl[u] + 1) & mask;
             }
         }
-        int rk[4];
+        int rk[2];
 #pragma unroll
-        for (int u = 0; u < 4; u++) rk[u] = i0 + 1024 * u < n ? atomicAdd(&cell[sl[u]].cnt, 1) : 0;
+        for (int u = 0; u < 2; u++) rk[u] = i0 + stride * u < n ? atomicAdd(&cell[sl[u]].cnt, 1) : 0;
 #pragma unroll
-        for (int u = 0; u < 4; u++) if (i0 + 1024 * u < n) { slot_of[i0 + 1024 * u] = (int)sl[u]; rank_of[i0 + 1024 * u] = rk[u]; }
+        for (int u = 0; u < 2; u++) if (i0 + stride * u < n) { slot_of[i0 + stride * u] = (int)sl[u]; rank_of[i0 + stride * u] = rk[u]; }
     }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    // exclusive prefix of the cell counts -> cell starts.  Every wave owns T / 16 consecutive cells and walks them 64 at a time (coalesced), four rounds in
-    // flight: its total first, ONE barrier, then the starts (a barrier per 1024-cell tile before: up to 128 of them, each behind a load and a store)
-    __shared__ int s_wtot[16];
-    const int wseg = T / 16;                     // T is a power of two >= 1024: a multiple of 64
-    const int cw0 = wave * wseg;
-    {
-        int tot = 0;
-        for (int r0 = 0; r0 < wseg; r0 += 4 * 64) {
-            int c4[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) c4[u] = r0 + 64 * u < wseg ? cell[cw0 + r0 + 64 * u + lane].cnt : 0;
-#pragma unroll
-            for (int u = 0; u < 4; u++) tot += c4[u];
-        }
-        tot = wave_sum_i(tot);
-        if (lane == 0) s_wtot[wave] = tot;
+}
+
+// every occupied cell takes its run of `sorted`: one bump of the job's counter per wave and turn
+__global__ __launch_bounds__(kCgT) void k_grid_starts(const CloudJob *jobs)
+{
+    const CloudJob J = jobs[blockIdx.y];
+    const int T = cloud_grid_size(J);
+    typedef __attribute__((address_space(1))) GridCell GCell;
+    GridCell *cell = (GridCell *)(GCell *)J.cell;
+    const int lane = threadIdx.x & 63;
+    for (int i0 = blockIdx.x * kCgT + (threadIdx.x & ~63); i0 < T; i0 += gridDim.x * kCgT) {       // T is a multiple of 64: whole waves
+        const int cnt = cell[i0 + lane].cnt;
+        const int incl = wave_scan_incl(cnt);
+        const int tot = __shfl(incl, 63);
+        if (tot == 0) continue;
+        int base = 0;
+        if (lane == 63) base = atomicAdd(J.bump, tot);
+        base = __shfl(base, 63);
+        if (cnt > 0) cell[i0 + lane].start = base + incl - cnt;
     }
-    __syncthreads();
-    {
-        int run = 0;
-        for (int w = 0; w < wave; w++) run += s_wtot[w];
-        for (int r0 = 0; r0 < wseg; r0 += 4 * 64) {
-            int c4[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) c4[u] = r0 + 64 * u < wseg ? cell[cw0 + r0 + 64 * u + lane].cnt : 0;
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                if (r0 + 64 * u >= wseg) break;
-                const int incl = wave_scan_incl(c4[u]);
-                cell[cw0 + r0 + 64 * u + lane].start = run + incl - c4[u];
-                run += __shfl(incl, 63);
-            }
-        }
+}
+
+__global__ __launch_bounds__(kCgT) void k_grid_fill(const CloudJob *jobs)
+{
+    const CloudJob J = jobs[blockIdx.y];
+    const int T = cloud_grid_size(J), n = J.n;
+    if (T == 0) return;
+    typedef __attribute__((address_space(1))) const float4 GF4;
+    typedef __attribute__((address_space(1))) float4 GF4W;
+    typedef __attribute__((address_space(1))) const GridCell GCell;
+    typedef __attribute__((address_space(1))) const int GI;
+    const GridCell *cell = (const GridCell *)(GCell *)J.cell;
+    const float4 *gsrc = (const float4 *)(GF4 *)J.src;
+    float4 *gsorted = (float4 *)(GF4W *)J.sorted;
+    GI *slot_of = (GI *)J.slot_of, *rank_of = (GI *)J.rank_of;
+    for (int i = blockIdx.x * kCgT + threadIdx.x; i < n; i += gridDim.x * kCgT) {
+        const float4 p = gsrc[i];
+        const int st = cell[slot_of[i]].start;
+        gsorted[st + rank_of[i]] = make_float4(p.x, p.y, p.z, __int_as_float(i));
     }
-    __threadfence_block();
-    __syncthreads();
-    for (int i0 = tid; i0 < n; i0 += 4 * 1024) {
-        float4 p[4];
-        int so[4], ro[4], st[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) { const int ic = min(i0 + 1024 * u, n - 1); p[u] = gsrc[ic]; so[u] = slot_of[ic]; ro[u] = rank_of[ic]; }
-#pragma unroll
-        for (int u = 0; u < 4; u++) st[u] = cell[so[u]].start;
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int i = i0 + 1024 * u;
-            if (i < n) gsorted[st[u] + ro[u]] = make_float4(p[u].x, p[u].y, p[u].z, __int_as_float(i));
-        }
-    }
+}
+
+// the four launches of a table of cloud jobs; max_n = the largest cloud among them
+static inline void launch_cloud_grids(hipStream_t st, const CloudJob *jobs_d, int n_jobs, int max_n)
+{
+    if (n_jobs <= 0) return;
+    int T = 1024;
+    while (T < max_n + 1) T <<= 1;
+    const int per = 2048 / (n_jobs < 16 ? 1 : 4);           // elements per workgroup: few jobs -> more workgroups per job
+    const unsigned bc = (unsigned)std::min(512, std::max(1, (T + per - 1) / per)), bp = (unsigned)std::min(512, std::max(1, (max_n + per - 1) / per));
+    hipLaunchKernelGGL(k_grid_clear, dim3(bc, (unsigned)n_jobs), dim3(kCgT), 0, st, jobs_d);
+    hipLaunchKernelGGL(k_grid_insert, dim3(bp, (unsigned)n_jobs), dim3(kCgT), 0, st, jobs_d);
+    hipLaunchKernelGGL(k_grid_starts, dim3(bc, (unsigned)n_jobs), dim3(kCgT), 0, st, jobs_d);
+    hipLaunchKernelGGL(k_grid_fill, dim3(bp, (unsigned)n_jobs), dim3(kCgT), 0, st, jobs_d);
 }
 
 // ---- small dense pieces, same arithmetic as oracle/lo_mapping.c --------------------------------------------------
@@ -216,7 +233,7 @@ __device__ bool plane_fit5(const double *pts, double *norm, double &negative_OA_
 struct MapRec { double cp[3]; double a[3]; double b[3]; int kind; int pad; };   // kind 0 none, 1 edge, 3 plane-norm
 
 struct MapStream {
-    // map clouds (grids built by k_cloud_grid) and down-sampled scan clouds of one stream
+    // map clouds (grids built by the k_grid_* kernels) and down-sampled scan clouds of one stream
     const GridCell *cell[2]; const float4 *sorted[2]; const float4 *cloud[2]; const int *mask[2]; int n_map[2];
     const float4 *stack[2]; int n_stack[2];
     MapRec *rec;           // [n_stack[0] + n_stack[1]]
@@ -565,7 +582,7 @@ __global__ __launch_bounds__(kMsT) void k_map_solve(const MapStream *streams, in
 
 // ---- pcl::VoxelGrid on an arbitrary cloud (laserMapping's downSizeFilterCorner / downSizeFilterSurf) -------
 // One 1024-thread workgroup per cloud (<= kVoxCloudMax points): bounding box -> PCL's linear cell index -> stable LSD
-// radix sort of (cell, point index) by cell, 4 bits per pass (per-thread digit counts over contiguous chunks keep equal
+// radix sort of (cell, point index) by cell, 8 bits per pass (wave segments walked in index order keep equal
 // cells in index order) -> one thread per run of equal cells sums its points in that order (PCL's float summation order)
 // and writes the centroids in ascending cell order.  Bit-exact against oracle/lo_scanreg.c lo_voxel_filter.
 namespace lmono {
