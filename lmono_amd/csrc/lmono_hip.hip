@@ -1549,8 +1549,10 @@ extern "C" int lmono_map_refine(lmono_ctx *c, int n_streams,
     std::vector<double> xh((size_t)n_streams * 8, 0.0);
     for (int s = 0; s < n_streams; s++) for (int k = 0; k < 7; k++) xh[(size_t)s * 8 + k] = pose_qt[(size_t)s * 7 + k];
     double *x_d = db.up(xh.data(), xh.size(), ok);
-    std::vector<int> zero((size_t)n_streams * 8, 0);
-    int *stats_d = db.up(zero.data(), zero.size(), ok);
+    std::vector<int> zero((size_t)n_streams * 16, 0);
+    int *stats_d = db.up(zero.data(), (size_t)n_streams * 8, ok);
+    unsigned int *bar_d = (unsigned int *)db.up(zero.data(), (size_t)n_streams * 16, ok);          // cluster barriers of the two solves, zeroed
+    double *part_d = db.up((const double *)nullptr, (size_t)n_streams * kMsEvals * kMsMaxK * 28, ok);
     if (!ok) { c->err = "lmono_map_refine: device allocation / upload failed"; return LMONO_ENOMEM; }
     std::vector<CloudJob> jobs((size_t)2 * n_streams);
     std::vector<MapStream> st((size_t)n_streams);
@@ -1570,6 +1572,7 @@ extern "C" int lmono_map_refine(lmono_ctx *c, int n_streams,
             S.stack[w] = cloud_d[2 + w] + soff[s]; S.n_stack[w] = (int)(soff[s + 1] - soff[s]);
         }
         S.rec = rec + rec_at; S.x = x_d + (size_t)s * 8; S.stats = stats_d + (size_t)s * 8;
+        S.part = part_d + (size_t)s * kMsEvals * kMsMaxK * 28; S.bar = bar_d + (size_t)s * 16;
         S.nn_out = nn_d ? nn_d + rec_at * 5 : nullptr;
         S.nn_tmp = nn_tmp_d + rec_at * 5;
         const int nq = S.n_stack[0] + S.n_stack[1];
@@ -1594,7 +1597,7 @@ extern "C" int lmono_map_refine(lmono_ctx *c, int n_streams,
             hipLaunchKernelGGL(k_map_correspond, dim3((max_nq + 7) / 8, n_streams), dim3(256), 0, stream, (const MapStream *)st_d, outer);
             hipLaunchKernelGGL(k_map_factor, dim3((max_nq + 63) / 64, n_streams), dim3(64), 0, stream, (const MapStream *)st_d, outer);
         }
-        hipLaunchKernelGGL(k_map_solve, dim3(n_streams), dim3(kMsT), 0, stream, (const MapStream *)st_d, outer);
+        launch_map_solve(stream, (const MapStream *)st_d, n_streams, outer);
     }
     (void)hipEventRecord(ev2, stream);
     int rc = check_launch(c, "map refine kernels");
@@ -1604,6 +1607,11 @@ extern "C" int lmono_map_refine(lmono_ctx *c, int n_streams,
     (void)hipEventElapsedTime(&ms_grid, ev0, ev1); (void)hipEventElapsedTime(&ms_opt, ev1, ev2);
     HIP_TRY(c, hipMemcpy(xh.data(), x_d, sizeof(double) * xh.size(), hipMemcpyDeviceToHost));
     for (int s = 0; s < n_streams; s++) for (int k = 0; k < 7; k++) pose_qt[(size_t)s * 7 + k] = xh[(size_t)s * 8 + k];
+    {
+        std::vector<int> sh((size_t)n_streams * 8);
+        HIP_TRY(c, hipMemcpy(sh.data(), stats_d, sizeof(int) * sh.size(), hipMemcpyDeviceToHost));
+        for (int s = 0; s < n_streams; s++) if (sh[(size_t)s * 8 + 6]) { c->err = "lmono_map_refine: a solve's cluster barrier timed out"; return LMONO_ENODEV; }
+    }
     if (stats_h) {
         HIP_TRY(c, hipMemcpy(stats_h, stats_d, sizeof(int) * (size_t)n_streams * 8, hipMemcpyDeviceToHost));
         // device time of the whole batch in microseconds: grid build, then the two correspond + solve rounds
@@ -1633,17 +1641,25 @@ extern "C" int lmono_voxel_filter(lmono_ctx *c, int n_clouds, const float *xyzi_
     unsigned int *ka = db.up((const unsigned int *)nullptr, (size_t)total, ok), *kb = db.up((const unsigned int *)nullptr, (size_t)total, ok);
     int *ia = db.up((const int *)nullptr, (size_t)total, ok), *ib = db.up((const int *)nullptr, (size_t)total, ok);
     int *nout_d = db.up((const int *)nullptr, (size_t)n_clouds, ok);
+    size_t ws_total = 0;
+    for (int k = 0; k < n_clouds; k++) ws_total += vox_ws_ints(off[k + 1] - off[k]);
+    int *ws_d = db.up((const int *)nullptr, ws_total, ok);
     std::vector<VoxJob> jobs((size_t)n_clouds);
+    size_t ws_at = 0;
     for (int k = 0; k < n_clouds; k++) {
         VoxJob &J = jobs[(size_t)k];
+        J.ws = ws_d + ws_at; ws_at += vox_ws_ints(off[k + 1] - off[k]);
         J.in = in_d + off[k]; J.n = (int)(off[k + 1] - off[k]); J.inv_leaf = 1.0f / leaf_h[k];
         J.out = out_d + off[k]; J.n_out = nout_d + k;
         J.key_a = ka + off[k]; J.key_b = kb + off[k]; J.idx_a = ia + off[k]; J.idx_b = ib + off[k];
     }
     VoxJob *jobs_d = db.up(jobs.data(), jobs.size(), ok);
+    std::vector<int> tab;
+    vox_tile_table(jobs.data(), jobs.size(), tab);
+    int *tab_d = db.up(tab.data(), tab.size(), ok);
     if (!ok) { c->err = "lmono_voxel_filter: device allocation / upload failed"; return LMONO_ENOMEM; }
-    hipLaunchKernelGGL(k_voxel_cloud, dim3(n_clouds), dim3(1024), 0, c->stream, (const VoxJob *)jobs_d);
-    int rc = check_launch(c, "k_voxel_cloud");
+    launch_voxel_jobs(c->stream, (const VoxJob *)jobs_d, tab_d, (int)tab.size(), 4);
+    int rc = check_launch(c, "voxel filter kernels");
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     std::vector<int> nout((size_t)n_clouds);
@@ -1683,6 +1699,11 @@ struct lmono_mapper {
     // per-frame workspace
     float4 *stack[2] = { nullptr, nullptr }, *newpts[2] = { nullptr, nullptr }, *neigh[2] = { nullptr, nullptr }, *sorted[2] = { nullptr, nullptr }, *cat[2] = { nullptr, nullptr };
     unsigned int *vk[2] = { nullptr, nullptr };
+    hipStream_t side = nullptr;                 // second stream of a frame: the neighbourhood gather + grids run beside the scan clouds' voxel filter
+    hipEvent_t ev_side = nullptr;
+    double *solve_part = nullptr;               // k_map_solve's cluster: partial sums [kMsEvals][kMsMaxK][28]
+    int *vws[2] = { nullptr, nullptr };         // voxel filter workspace (vox_ws_ints per job), vws_cap ints each
+    size_t vws_cap = 0;
     int *vi[2] = { nullptr, nullptr }, *slot[2] = { nullptr, nullptr }, *rank[2] = { nullptr, nullptr }, *cube_of[2] = { nullptr, nullptr }, *pos[2] = { nullptr, nullptr };
     GridCell *cells[2] = { nullptr, nullptr };
     int tcap = 0;
@@ -1713,6 +1734,8 @@ template <typename T> static bool mp_alloc(lmono_mapper *m, T *&p, size_t n)
 extern "C" void lmono_mapper_destroy(lmono_mapper *m)
 {
     if (!m) return;
+    if (m->side) { (void)hipStreamSynchronize(m->side); (void)hipStreamDestroy(m->side); }
+    if (m->ev_side) (void)hipEventDestroy(m->ev_side);
     for (void *q : m->allocs) (void)hipFree(q);
     delete m;
 }
@@ -1725,6 +1748,7 @@ extern "C" lmono_mapper *lmono_mapper_create(lmono_ctx *c, float line_res, float
     m->ctx = c; m->leaf[0] = line_res; m->leaf[1] = plane_res;
     m->cube[0].assign((size_t)kMapCubes, Seg()); m->cube[1].assign((size_t)kMapCubes, Seg());
     m->tcap = 1;
+    m->vws_cap = (size_t)128 * kVxHdr + (size_t)((kMapNeighMax + kMapStackMax) / kVxTile + 128) * kVxWsTile;     // <= 75 cube jobs per type and frame
     while (m->tcap < kMapNeighMax + 1) m->tcap <<= 1;
     bool ok = true;
     for (int t = 0; t < 2 && ok; t++) {
@@ -1735,12 +1759,14 @@ extern "C" lmono_mapper *lmono_mapper_create(lmono_ctx *c, float line_res, float
              mp_alloc(m, m->vk[t], (size_t)2 * (kMapNeighMax + kMapStackMax)) && mp_alloc(m, m->vi[t], (size_t)2 * (kMapNeighMax + kMapStackMax)) &&
              mp_alloc(m, m->slot[t], (size_t)kMapNeighMax) && mp_alloc(m, m->rank[t], (size_t)kMapNeighMax) &&
              mp_alloc(m, m->cube_of[t], (size_t)kMapStackMax) && mp_alloc(m, m->pos[t], (size_t)kMapStackMax) &&
-             mp_alloc(m, m->cells[t], (size_t)m->tcap);
+             mp_alloc(m, m->cells[t], (size_t)m->tcap) && mp_alloc(m, m->vws[t], m->vws_cap);
     }
     m->jobs_bytes = 1 << 20;
     m->nout_cap = 1024;
     ok = ok && mp_alloc(m, m->masks, 4) && mp_alloc(m, m->nout, 2 * 256) && mp_alloc(m, m->nout_big, m->nout_cap) && mp_alloc(m, m->stats, 8) && mp_alloc(m, m->x, 8) &&
-         mp_alloc(m, m->rec, (size_t)2 * kMapStackMax) && mp_alloc(m, m->nn_tmp, (size_t)10 * kMapStackMax) && mp_alloc(m, (char *&)m->jobs, m->jobs_bytes) && mp_alloc(m, m->stream_d, 1);
+         mp_alloc(m, m->rec, (size_t)2 * kMapStackMax) && mp_alloc(m, m->nn_tmp, (size_t)10 * kMapStackMax) && mp_alloc(m, (char *&)m->jobs, m->jobs_bytes) && mp_alloc(m, m->stream_d, 1) &&
+         mp_alloc(m, m->solve_part, (size_t)kMsEvals * kMsMaxK * 28);
+    ok = ok && hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&m->ev_side, hipEventDisableTiming) == hipSuccess;
     if (!ok) { c->err = "lmono_mapper_create: device allocation failed"; lmono_mapper_destroy(m); return nullptr; }
     return m;
 }
@@ -1816,6 +1842,16 @@ struct JobScratch {
         return LMONO_OK;
     }
 };
+// a voxel job table and its tile table in one upload: [VoxJob x n | int x tiles]; `blob` is the staging buffer (alive until the stream is waited for)
+int upload_vox_jobs(lmono_ctx *c, JobScratch &js, const std::vector<VoxJob> &jobs, std::vector<char> &blob, hipStream_t st)
+{
+    std::vector<int> tab;
+    vox_tile_table(jobs.data(), jobs.size(), tab);
+    blob.resize(jobs.size() * sizeof(VoxJob) + tab.size() * sizeof(int));
+    memcpy(blob.data(), jobs.data(), jobs.size() * sizeof(VoxJob));
+    memcpy(blob.data() + jobs.size() * sizeof(VoxJob), tab.data(), tab.size() * sizeof(int));
+    return js.upload(c, blob.data(), blob.size(), st);
+}
 void mp_qrot(const double *q, const double *v, double *o)
 {
     const double ux = q[0], uy = q[1], uz = q[2], w = q[3];
@@ -1900,6 +1936,7 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
     std::vector<double> xh_opt;
     std::vector<int> pos_all;
     std::vector<ScatterJob> sj;
+    std::vector<char> vox_blob;
     const bool prof = getenv("LMONO_MAP_PROF") != nullptr;
     auto tnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tp[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -1938,9 +1975,10 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
         if (f.n_last[0] > kMapStackMax || f.n_last[1] > kMapStackMax) { c->err = "lmono_mapper: scan cloud too large"; return LMONO_ECAPACITY; }
     }
     tp[1] = tnow();
-    // ---- phase 2: VoxelGrid of the scan clouds (read in place from the scan batches)
+    // ---- phase 2: VoxelGrid of the scan clouds (read in place from the scan batches), on the main stream; its sizes are waited for below
+    std::vector<int> ns_h((size_t)2 * n);
     {
-        if ((rc = mp_grow(c, ms[0], ms[0]->ibuf, ms[0]->ibuf_cap, (size_t)10 * n)) || (rc = mp_grow(c, ms[0], ms[0]->xbuf, ms[0]->xbuf_cap, (size_t)8 * n))) return rc;
+        if ((rc = mp_grow(c, ms[0], ms[0]->ibuf, ms[0]->ibuf_cap, (size_t)26 * n)) || (rc = mp_grow(c, ms[0], ms[0]->xbuf, ms[0]->xbuf_cap, (size_t)8 * n))) return rc;
         std::vector<VoxJob> vj((size_t)2 * n);
         for (int s = 0; s < n; s++)
             for (int t = 0; t < 2; t++) {
@@ -1949,17 +1987,21 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
                 J.in = t ? bs[s]->v.less_flat + bs[s]->off_h[(size_t)scans[s]] : bs[s]->v.less_sharp + (size_t)scans[s] * kMaxLessSharp;
                 J.n = F[(size_t)s].n_last[t]; J.inv_leaf = 1.0f / m->leaf[t]; J.out = m->stack[t]; J.n_out = ms[0]->ibuf + 2 * s + t;
                 J.key_a = m->vk[t]; J.key_b = m->vk[t] + kMapStackMax; J.idx_a = m->vi[t]; J.idx_b = m->vi[t] + kMapStackMax;
+                J.ws = m->vws[t];
             }
-        if ((rc = js.upload(c, vj.data(), vj.size() * sizeof(VoxJob), st))) return rc;
-        hipLaunchKernelGGL(k_voxel_cloud, dim3(2 * n), dim3(1024), 0, st, (const VoxJob *)js.last);
-        std::vector<int> ns_h((size_t)2 * n);
+        if ((rc = upload_vox_jobs(c, js, vj, vox_blob, st))) return rc;
+        launch_voxel_jobs(st, (const VoxJob *)js.last, (const int *)((const char *)js.last + vj.size() * sizeof(VoxJob)), (int)((vox_blob.size() - vj.size() * sizeof(VoxJob)) / sizeof(int)), 4);
         HIP_TRY(c, hipMemcpyAsync(ns_h.data(), ms[0]->ibuf, sizeof(int) * 2 * (size_t)n, hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipStreamSynchronize(st));
-        for (int s = 0; s < n; s++) { F[(size_t)s].n_stack[0] = ns_h[(size_t)2 * s]; F[(size_t)s].n_stack[1] = ns_h[(size_t)2 * s + 1]; }
-        for (int s = 0; s < n; s++) if (F[(size_t)s].n_stack[0] < 0 || F[(size_t)s].n_stack[1] < 0) { c->err = "lmono_mapper: voxel filter rejected a scan cloud"; return LMONO_ECAPACITY; }
     }
-    tp[2] = tnow();
-    // ---- phase 3: map clouds of the neighbourhoods, concatenated in validInd order
+    // ---- phase 3, on the side stream (round 4: both are chains of short launches that leave most of the chip idle, and neither needs the other): map
+    // clouds of the neighbourhoods, concatenated in validInd order, and their grids for the streams whose map is large enough
+    hipStream_t side = ms[0]->side;
+    struct SideGuard {            // no return path leaves work on the side stream behind
+        hipStream_t s;
+        ~SideGuard() { (void)hipStreamSynchronize(s); }
+    } side_guard{ side };
+    std::vector<int> act;
+    const CloudJob *cj_d = nullptr;
     {
         std::vector<CopyJob> jobs;
         for (int s = 0; s < n; s++) {
@@ -1976,28 +2018,15 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
                 }
             }
             f.solve = f.n_map[0] > 10 && f.n_map[1] > 50;
+            if (f.solve) act.push_back(s);
         }
         if (!jobs.empty()) {
-            if ((rc = js.upload(c, jobs.data(), jobs.size() * sizeof(CopyJob), st))) return rc;
-            hipLaunchKernelGGL(k_copy_jobs, dim3((unsigned)jobs.size()), dim3(256), 0, st, (const CopyJob *)js.last);
+            if ((rc = js.upload(c, jobs.data(), jobs.size() * sizeof(CopyJob), side))) return rc;
+            hipLaunchKernelGGL(k_copy_jobs, dim3((unsigned)jobs.size()), dim3(256), 0, side, (const CopyJob *)js.last);
         }
-    }
-    tp[3] = tnow();
-    // ---- phase 4: optimisation (grids, 2 x [correspond + solve]) for the streams whose map is large enough
-    std::vector<int32_t> stats((size_t)n * 8, 0);
-    {
-        std::vector<int> act;
-        for (int s = 0; s < n; s++) if (F[(size_t)s].solve) act.push_back(s);
-        std::vector<double> &xh = xh_opt;
-        xh.assign((size_t)8 * n, 0.0);
-        for (int s = 0; s < n; s++) for (int k = 0; k < 8; k++) xh[(size_t)8 * s + k] = F[(size_t)s].x[k];
-        int *statbuf = ms[0]->ibuf + 2 * n;      // [n][8] behind the n_stack pairs
-        HIP_TRY(c, hipMemcpyAsync(ms[0]->xbuf, xh.data(), sizeof(double) * 8 * (size_t)n, hipMemcpyHostToDevice, st));
-        HIP_TRY(c, hipMemsetAsync(statbuf, 0, sizeof(int) * 8 * (size_t)n, st));
         if (!act.empty()) {
             std::vector<CloudJob> cj((size_t)2 * act.size());
-            std::vector<MapStream> S(act.size());
-            int max_nq = 0, max_nmap = 0;
+            int max_nmap = 0;
             for (size_t a = 0; a < act.size(); a++) {
                 lmono_mapper *m = ms[act[a]];
                 FrameState &f = F[(size_t)act[a]];
@@ -2006,30 +2035,57 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
                     J.src = m->neigh[t]; J.n = f.n_map[t]; J.cell = m->cells[t]; J.tcap = m->tcap; J.sorted = m->sorted[t];
                     J.slot_of = m->slot[t]; J.rank_of = m->rank[t]; J.mask_out = m->masks + t; J.bump = m->masks + 2 + t;
                     max_nmap = std::max(max_nmap, f.n_map[t]);
+                }
+            }
+            if ((rc = js.upload(c, cj.data(), cj.size() * sizeof(CloudJob), side))) return rc;
+            cj_d = (const CloudJob *)js.last;
+            launch_cloud_grids(side, cj_d, (int)cj.size(), max_nmap);
+        }
+        HIP_TRY(c, hipEventRecord(ms[0]->ev_side, side));
+    }
+    HIP_TRY(c, hipStreamSynchronize(st));
+    for (int s = 0; s < n; s++) { F[(size_t)s].n_stack[0] = ns_h[(size_t)2 * s]; F[(size_t)s].n_stack[1] = ns_h[(size_t)2 * s + 1]; }
+    for (int s = 0; s < n; s++) if (F[(size_t)s].n_stack[0] < 0 || F[(size_t)s].n_stack[1] < 0) { c->err = "lmono_mapper: voxel filter rejected a scan cloud"; return LMONO_ECAPACITY; }
+    tp[2] = tnow();
+    tp[3] = tp[2];
+    // ---- phase 4: optimisation (2 x [correspond + solve]) behind both streams
+    std::vector<int32_t> stats((size_t)n * 8, 0);
+    {
+        std::vector<double> &xh = xh_opt;
+        xh.assign((size_t)8 * n, 0.0);
+        for (int s = 0; s < n; s++) for (int k = 0; k < 8; k++) xh[(size_t)8 * s + k] = F[(size_t)s].x[k];
+        int *statbuf = ms[0]->ibuf + 2 * n;      // [n][8] behind the n_stack pairs, then the solves' cluster barriers [n][16]
+        unsigned int *barbuf = (unsigned int *)(statbuf + 8 * n);
+        HIP_TRY(c, hipMemcpyAsync(ms[0]->xbuf, xh.data(), sizeof(double) * 8 * (size_t)n, hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipMemsetAsync(statbuf, 0, sizeof(int) * 24 * (size_t)n, st));
+        HIP_TRY(c, hipStreamWaitEvent(st, ms[0]->ev_side, 0));
+        if (!act.empty()) {
+            std::vector<MapStream> S(act.size());
+            int max_nq = 0;
+            for (size_t a = 0; a < act.size(); a++) {
+                lmono_mapper *m = ms[act[a]];
+                FrameState &f = F[(size_t)act[a]];
+                for (int t = 0; t < 2; t++) {
                     S[a].cell[t] = m->cells[t]; S[a].sorted[t] = m->sorted[t]; S[a].cloud[t] = m->neigh[t]; S[a].mask[t] = m->masks + t; S[a].n_map[t] = f.n_map[t];
                     S[a].stack[t] = m->stack[t]; S[a].n_stack[t] = f.n_stack[t];
                 }
                 S[a].rec = m->rec; S[a].x = ms[0]->xbuf + 8 * act[a]; S[a].stats = statbuf + 8 * act[a]; S[a].nn_out = nullptr; S[a].nn_tmp = m->nn_tmp;
+                S[a].part = m->solve_part; S[a].bar = barbuf + 16 * act[a];
                 max_nq = std::max(max_nq, f.n_stack[0] + f.n_stack[1]);
             }
-            // job table = [CloudJob x 2 act | MapStream x act] in one upload
-            std::vector<char> blob(cj.size() * sizeof(CloudJob) + S.size() * sizeof(MapStream));
-            memcpy(blob.data(), cj.data(), cj.size() * sizeof(CloudJob));
-            memcpy(blob.data() + cj.size() * sizeof(CloudJob), S.data(), S.size() * sizeof(MapStream));
-            if ((rc = js.upload(c, blob.data(), blob.size(), st))) return rc;
-            const CloudJob *cj_d = (const CloudJob *)js.last;
-            const MapStream *S_d = (const MapStream *)((const char *)js.last + cj.size() * sizeof(CloudJob));
-            launch_cloud_grids(st, cj_d, (int)cj.size(), max_nmap);
+            if ((rc = js.upload(c, S.data(), S.size() * sizeof(MapStream), st))) return rc;
+            const MapStream *S_d = (const MapStream *)js.last;
             for (int outer = 0; outer < 2; outer++) {
                 if (max_nq > 0) {
                     hipLaunchKernelGGL(k_map_correspond, dim3((max_nq + 7) / 8, (unsigned)act.size()), dim3(256), 0, st, S_d, outer);
                     hipLaunchKernelGGL(k_map_factor, dim3((max_nq + 63) / 64, (unsigned)act.size()), dim3(64), 0, st, S_d, outer);
                 }
-                hipLaunchKernelGGL(k_map_solve, dim3((unsigned)act.size()), dim3(kMsT), 0, st, S_d, outer);
+                launch_map_solve(st, S_d, (int)act.size(), outer);
             }
             HIP_TRY(c, hipMemcpyAsync(xh.data(), ms[0]->xbuf, sizeof(double) * 8 * (size_t)n, hipMemcpyDeviceToHost, st));
             HIP_TRY(c, hipMemcpyAsync(stats.data(), statbuf, sizeof(int) * 8 * (size_t)n, hipMemcpyDeviceToHost, st));
             HIP_TRY(c, hipStreamSynchronize(st));
+            for (int s : act) if (stats[(size_t)s * 8 + 6]) { c->err = "lmono_mapper: a solve's cluster barrier timed out"; return LMONO_ENODEV; }
             for (int s : act) for (int k = 0; k < 8; k++) F[(size_t)s].x[k] = xh[(size_t)8 * s + k];
         }
     }
@@ -2155,6 +2211,8 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
     std::vector<CopyJob> keep;
     std::vector<size_t> vox_t;
     std::vector<int64_t> new_off(touched.size());
+    std::vector<size_t> ws_at((size_t)2 * n, 0);
+    int cube_passes = 1;
     for (size_t k = 0; k < touched.size(); k++) {
         const Touched &T = touched[k];
         lmono_mapper *m = ms[T.s];
@@ -2164,6 +2222,16 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
             VoxJob J;
             J.in = m->cat[T.t] + T.cat_off; J.n = T.n_in; J.inv_leaf = 1.0f / m->leaf[T.t]; J.out = dst; J.n_out = nullptr;
             J.key_a = m->vk[T.t] + 2 * T.cat_off; J.key_b = J.key_a + T.n_in; J.idx_a = m->vi[T.t] + 2 * T.cat_off; J.idx_b = J.idx_a + T.n_in;
+            size_t &wa = ws_at[(size_t)2 * T.s + T.t];
+            if (wa + vox_ws_ints(T.n_in) > m->vws_cap) { c->err = "lmono_mapper: voxel workspace exhausted"; return LMONO_ECAPACITY; }
+            J.ws = m->vws[T.t] + wa; wa += vox_ws_ints(T.n_in);
+            // a cube is a 50 m box: at most 50 / leaf + 3 cells per axis, whatever it holds -> the passes its keys can need
+            {
+                const double per_axis = 50.0 / (double)m->leaf[T.t] + 3.0;
+                int bits = 1;
+                while (bits < 32 && std::ldexp(1.0, bits) < per_axis * per_axis * per_axis) bits++;
+                cube_passes = std::max(cube_passes, std::min(4, (bits + 8) / 9));
+            }
             vox.push_back(J); vox_t.push_back(k);
         } else {
             keep.push_back({ m->cat[T.t] + T.cat_off, dst, T.n_in });
@@ -2181,8 +2249,8 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
             ms[0]->nout_big = q; ms[0]->nout_cap = cap;
         }
         for (size_t k = 0; k < vox.size(); k++) vox[k].n_out = ms[0]->nout_big + k;
-        if ((rc = js.upload(c, vox.data(), vox.size() * sizeof(VoxJob), st))) return rc;
-        hipLaunchKernelGGL(k_voxel_cloud, dim3((unsigned)vox.size()), dim3(1024), 0, st, (const VoxJob *)js.last);
+        if ((rc = upload_vox_jobs(c, js, vox, vox_blob, st))) return rc;
+        launch_voxel_jobs(st, (const VoxJob *)js.last, (const int *)((const char *)js.last + vox.size() * sizeof(VoxJob)), (int)((vox_blob.size() - vox.size() * sizeof(VoxJob)) / sizeof(int)), cube_passes);
         HIP_TRY(c, hipMemcpyAsync(nout_h.data(), ms[0]->nout_big, sizeof(int) * vox.size(), hipMemcpyDeviceToHost, st));
     }
     if (!keep.empty()) {
@@ -2206,6 +2274,12 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
     if (rc) return rc;
     undo.committed = true;
     if (prof) fprintf(stderr, "MAPPROF n=%d ms: host1 %.2f voxel %.2f gather %.2f optimise %.2f assign %.2f update %.2f\n", n, tp[1] - tp[0], tp[2] - tp[1], tp[3] - tp[2], tp[4] - tp[3], tp[5] - tp[4], tp[6] - tp[5]);
+    if (prof) {
+        int mx = 0, n_small = 0; long sum = 0;
+        for (const VoxJob &J : vox) { mx = std::max(mx, J.n); sum += J.n; n_small += J.n <= 2048; }
+        fprintf(stderr, "MAPSIZES scan %d %d -> %d %d  map %d %d  cube jobs %zu (<= 2048: %d) max %d sum %ld kept %zu\n", F[0].n_last[0], F[0].n_last[1], F[0].n_stack[0], F[0].n_stack[1],
+                F[0].n_map[0], F[0].n_map[1], vox.size(), n_small, mx, sum, keep.size());
+    }
     return LMONO_OK;
 }
 

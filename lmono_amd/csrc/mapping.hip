@@ -241,7 +241,11 @@ struct MapStream {
     int *stats;            // [8] n_edge[2], n_plane[2], lm_iters[2], pad
     int *nn_tmp;           // [n][5] neighbour indices of the current outer iteration (-1: the 5-NN test failed)
     int *nn_out;           // optional [n][5] neighbour indices of the accepted blocks of the last outer iteration (-1: none)
+    // k_map_solve as a cluster of K workgroups: partial sums [kMsEvals][K][28] and arrival counters [2 outer][kMsEvals] (zeroed by the host per frame)
+    double *part; unsigned int *bar;
 };
+constexpr int kMsEvals = 5;        // evaluations of one solve at most: the start + one per LM iteration (max 4)
+constexpr int kMsMaxK = 8;
 
 // sorted insertion of (d, idx) into a lane-local ascending top-5
 __device__ __forceinline__ void top5_insert(float *td, int *ti, float d, int idx)
@@ -431,9 +435,35 @@ __device__ __forceinline__ void map_eval_block(const MapRec &R, const double *Rm
 #define LMONO_MS_T 512
 #endif
 constexpr int kMsT = LMONO_MS_T;
+// (records per thread in flight 1 / 2 / 4, round 4: 1253 / 1174 / 1220 frames/s -- the evaluation is bound by its fp64 work on one CU, not by the loads)
 // sums of all residual blocks of a stream into LDS (s_sum: H 21 | g 6 | cost); blocks [0, n_edge) are the corner points' (edges)
+// Round 4: one stream's solve is a CLUSTER of K workgroups on one XCD (block b runs on XCD b mod 8).  Every workgroup runs the whole trust-region
+// control flow on the same sums, so they all take the same branches; an evaluation is split between them (chunks of kMsT blocks in turn), each leaves
+// its 28 partial sums in L2, ONE cluster barrier (an arrival counter per evaluation, agent-scope release / acquire), and everybody adds the K partials in
+// rank order.  One workgroup alone was bound by the fp64 work of ~11 k residual blocks x <= 5 evaluations on a single CU (0.13 ms, twice per frame).
+struct MsCluster { int K, rank, eval; double *part; unsigned int *bar; int *fail; };
+
+__device__ __forceinline__ void ms_cluster_barrier(MsCluster &cl)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // this workgroup's partial sums are visible device-wide before the arrival
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int *ctr = cl.bar + cl.eval;
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        // every workgroup of the cluster is resident by construction (the host keeps clusters x K within half the CUs); the spin is bounded all the
+        // same -- a wave that never finishes can take the whole GPU down: after a few seconds the solve is marked failed and the barrier opens
+        int spins = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)cl.K) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 26)) { *cl.fail = 1; break; }
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       // the other workgroups' partial sums are read with plain loads
+}
+
 template <bool kJac>
-__device__ __forceinline__ void map_evaluate(const MapRec *rec, int n_edge, int nq, const double *x, double (*s_red)[28], double *s_sum)
+__device__ __forceinline__ void map_evaluate(const MapRec *rec, int n_edge, int nq, const double *x, double (*s_red)[28], double *s_sum, MsCluster &cl)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     LmAcc acc;
@@ -451,9 +481,13 @@ __device__ __forceinline__ void map_evaluate(const MapRec *rec, int n_edge, int 
         Rm[3] = 2.0 * (ux * uy + w * uz);       Rm[4] = 1.0 - 2.0 * (ux * ux + uz * uz); Rm[5] = 2.0 * (uy * uz - w * ux);
         Rm[6] = 2.0 * (ux * uz - w * uy);       Rm[7] = 2.0 * (uy * uz + w * ux);       Rm[8] = 1.0 - 2.0 * (ux * ux + uy * uy);
     }
-    int qi = tid;
-    for (; qi < n_edge; qi += kMsT) map_eval_block<kJac, true>(rec[qi], Rm, x, acc);
-    for (; qi < nq; qi += kMsT) map_eval_block<kJac, false>(rec[qi], Rm, x, acc);
+    // chunks of kMsT consecutive blocks are dealt to the cluster's workgroups in turn
+    for (int q0 = cl.rank * kMsT; q0 < nq; q0 += cl.K * kMsT) {
+        const int qi = q0 + tid;
+        if (qi >= nq) break;
+        if (qi < n_edge) map_eval_block<kJac, true>(rec[qi], Rm, x, acc);
+        else map_eval_block<kJac, false>(rec[qi], Rm, x, acc);
+    }
     acc.cost = wave_sum_d(acc.cost);
     if (kJac) {
 #pragma unroll
@@ -473,16 +507,31 @@ __device__ __forceinline__ void map_evaluate(const MapRec *rec, int n_edge, int 
     if (tid < 28 && (kJac || tid == 27)) {
         double t = 0.0;
         for (int w = 0; w < kMsT / 64; w++) t += s_red[w][tid];
-        s_sum[tid] = t;
+        if (cl.K > 1) cl.part[(cl.eval * cl.K + cl.rank) * 28 + tid] = t;
+        else s_sum[tid] = t;
     }
+    if (cl.K > 1) {
+        ms_cluster_barrier(cl);
+        if (tid < 28 && (kJac || tid == 27)) {
+            double t = 0.0;
+            for (int w = 0; w < cl.K; w++) t += cl.part[(cl.eval * cl.K + w) * 28 + tid];
+            s_sum[tid] = t;
+        }
+    }
+    cl.eval++;
     __syncthreads();
 }
 
 // One kMsT-thread workgroup per stream (a frame has ~8 k residual blocks); the trust-region control flow runs redundantly
 // in every thread on the block-reduced sums in LDS, exactly like k_lm_solve.
-__global__ __launch_bounds__(kMsT) void k_map_solve(const MapStream *streams, int outer)
+// grid: ceil(n_streams / 8) x 8 K blocks; block b = 8 K g + 8 rank + j works on stream 8 g + j: the K workgroups of a stream are 8 blocks apart
+__global__ __launch_bounds__(kMsT) void k_map_solve(const MapStream *streams, int n_streams, int K, int outer)
 {
-    const MapStream S = streams[blockIdx.x];
+    const int sidx = (int)(blockIdx.x / (8 * K)) * 8 + (int)(blockIdx.x % 8);
+    if (sidx >= n_streams) return;
+    const MapStream S = streams[sidx];
+    MsCluster cl;
+    cl.K = K; cl.rank = (int)(blockIdx.x % (8 * K)) / 8; cl.eval = 0; cl.part = S.part; cl.bar = S.bar + outer * 8; cl.fail = S.stats + 6;
     __shared__ double s_red[kMsT / 64][28], s_sum[28], s_cur[28];
     const int tid = threadIdx.x;
     const int n_edge = S.n_stack[0], nq = S.n_stack[0] + S.n_stack[1];
@@ -496,7 +545,7 @@ __global__ __launch_bounds__(kMsT) void k_map_solve(const MapStream *streams, in
     bool reuse_diagonal = false;
     int invalid_steps = 0, iter = 0;
     if (n_used > 0) {
-        map_evaluate<true>(S.rec, n_edge, nq, x, s_red, s_sum);
+        map_evaluate<true>(S.rec, n_edge, nq, x, s_red, s_sum, cl);
         if (tid < 28) s_cur[tid] = s_sum[tid];
         __syncthreads();
         double x_cost = s_cur[27];
@@ -538,8 +587,8 @@ __global__ __launch_bounds__(kMsT) void k_map_solve(const MapStream *streams, in
                 manifold_plus(x, delta, cand);
                 // candidate evaluated with its Jacobian (reused as the next linearisation); the last iteration needs the cost only
                 const bool last = iter == max_iter;
-                if (last) map_evaluate<false>(S.rec, n_edge, nq, cand, s_red, s_sum);
-                else map_evaluate<true>(S.rec, n_edge, nq, cand, s_red, s_sum);
+                if (last) map_evaluate<false>(S.rec, n_edge, nq, cand, s_red, s_sum, cl);
+                else map_evaluate<true>(S.rec, n_edge, nq, cand, s_red, s_sum, cl);
                 const double cand_cost = s_sum[27];
                 double sn = 0.0;
                 for (int i = 0; i < 7; i++) sn += (x[i] - cand[i]) * (x[i] - cand[i]);
@@ -572,63 +621,102 @@ __global__ __launch_bounds__(kMsT) void k_map_solve(const MapStream *streams, in
         }
     }
     __syncthreads();
-    if (tid == 0) {
+    if (tid == 0 && cl.rank == 0) {
         for (int i = 0; i < 7; i++) S.x[i] = x[i];
         S.stats[4 + outer] = iter;
     }
 }
 
+// workgroups per stream: as many as keep clusters x K within half the chip's 256 CUs (every workgroup of a cluster must be resident while it spins)
+static inline int map_solve_cluster(int n_streams)
+{
+    static const int forced = [] { const char *e = getenv("LMONO_MAP_SOLVE_K"); return e ? atoi(e) : 0; }();        // measurement switch
+    int K = forced > 0 ? forced : kMsMaxK;
+    if (K > kMsMaxK) K = kMsMaxK;
+    const int groups = (n_streams + 7) / 8;
+    while (K > 1 && groups * 8 * K > 128) K--;
+    return K;
+}
+static inline void launch_map_solve(hipStream_t st, const MapStream *S_d, int n_streams, int outer)
+{
+    const int K = map_solve_cluster(n_streams);
+    hipLaunchKernelGGL(k_map_solve, dim3((unsigned)(((n_streams + 7) / 8) * 8 * K)), dim3(kMsT), 0, st, S_d, n_streams, K, outer);
+}
+
 } // namespace lmono
 
 // ---- pcl::VoxelGrid on an arbitrary cloud (laserMapping's downSizeFilterCorner / downSizeFilterSurf) -------
-// One 1024-thread workgroup per cloud (<= kVoxCloudMax points): bounding box -> PCL's linear cell index -> stable LSD
-// radix sort of (cell, point index) by cell, 8 bits per pass (wave segments walked in index order keep equal
-// cells in index order) -> one thread per run of equal cells sums its points in that order (PCL's float summation order)
-// and writes the centroids in ascending cell order.  Bit-exact against oracle/lo_scanreg.c lo_voxel_filter.
+// bounding box -> PCL's linear cell index -> stable LSD radix sort of (cell, point index) by cell -> one lane per run of equal cells sums its points
+// in index order (PCL's float summation order) and writes the centroids in ascending cell order.  Bit-exact against oracle/lo_scanreg.c
+// lo_voxel_filter.
+//
+// Round 4: a cloud is worked on by ceil(n / 2048) workgroups (a "tile" each) in a chain of short launches
+//     k_vox_box | k_vox_keys | k_vox_pass x passes | k_vox_heads | k_vox_centroids
+// instead of one 1024-thread workgroup per cloud walking it end to end (0.32 ms per 25 k-point cloud in round 3, 0.23 ms with 8-bit digits: a chain of
+// ~1 us global round trips on ONE compute unit, twice per laserMapping frame).  What makes the sort work across workgroups without a counting launch
+// per pass: a pass scatters its elements to their final positions of that pass, so it knows the TILE each of them lands in and adds it to that tile's
+// digit counts of the NEXT pass (global atomics, no return value).  A pass then reads the (tile, digit) counts of all tiles of its cloud (<= 32 x 512),
+// turns them into its own first output position per digit, and ranks its 2048 elements by (wave, block of 64, lane) = index order: stable.
+// The digit width adapts to the key: passes = ceil(bits / 9), width = ceil(bits / passes) (26-bit scan-cloud keys: three passes of 9 bits).
 namespace lmono {
 
 constexpr int kVoxCloudMax = 65536;
+constexpr int kVxT = 256;                                // threads per workgroup
+constexpr int kVxTile = 2048;                            // elements per workgroup: 8 per thread, 8 blocks of 64 per wave
+constexpr int kVxBlocks = kVxTile / kVxT;                // blocks of 64 per wave
+constexpr int kVxMaxTiles = kVoxCloudMax / kVxTile;      // 32
+constexpr int kVxMaxDigit = 512;                         // 9-bit digits at most
+constexpr int kVxHdr = 16;                               // ints of a job's header in its workspace
+constexpr int kVxWsTile = 16 + 3 * kVxMaxDigit;          // ints of workspace per tile: box[8], heads[1] (+7 pad), three digit-count rows
 
 struct VoxJob {
     const float4 *in; int n;
     float inv_leaf;
     float4 *out;           // capacity n
-    int *n_out;
+    int *n_out;            // number of centroids; -1: cloud rejected (too large, or more passes than were launched)
     unsigned int *key_a, *key_b;   // scratch [n] cell keys (ping-pong)
     int *idx_a, *idx_b;            // scratch [n] point indices (ping-pong)
+    int *ws;               // workspace: kVxHdr + tiles * kVxWsTile ints (vox_ws_ints)
 };
 
-// Round 3: the sort works on COALESCED streams.  Every wave owns a contiguous segment of the array and walks it 64 consecutive elements at a time
-// (lane = element), digit counts and ranks come from ballots, a (digit, wave) prefix gives every wave its first output position per digit: order by
-// (wave segment, round, lane) = index order, so the sort stays stable.  (Until then every THREAD owned a contiguous chunk: 64 cache lines per wave
-// load, one load at a time through generic pointers -- 0.4 ms per 25 k-point cloud, 40 % of a laserMapping frame.)
-__global__ __launch_bounds__(1024) void k_voxel_cloud(const VoxJob *jobs)
+static inline size_t vox_ws_ints(int64_t n) { return (size_t)kVxHdr + (size_t)((n + kVxTile - 1) / kVxTile > 0 ? (n + kVxTile - 1) / kVxTile : 1) * kVxWsTile; }
+
+struct VoxView {           // a job's workspace
+    int *hdr;              // minb[3], mul1, mul2, passes, width
+    float *box;            // [tiles][8]
+    int *heads;            // [tiles][8] (first used)
+    int *hist;             // [3][tiles][kVxMaxDigit]
+    int tiles;
+};
+
+__device__ __forceinline__ VoxView vox_view(const VoxJob &J)
 {
-    const VoxJob J = jobs[blockIdx.x];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = J.n;
-    if (n <= 0 || n > kVoxCloudMax) { if (tid == 0) *J.n_out = n <= 0 ? 0 : -1; return; }
-    __shared__ float s_box[16][6];
-    __shared__ int s_cnt[16][256];       // [wave][digit] counts of a pass, then first output positions (running cursors during the scatter)
-    __shared__ int s_wtot[16];
-    __shared__ int s_heads[16];
-    __shared__ int s_total;
+    VoxView V;
+    V.tiles = (J.n + kVxTile - 1) / kVxTile;
+    V.hdr = J.ws; V.box = (float *)(J.ws + kVxHdr); V.heads = J.ws + kVxHdr + 8 * V.tiles; V.hist = J.ws + kVxHdr + 16 * V.tiles;
+    return V;
+}
+
+// per-tile bounding boxes
+__global__ __launch_bounds__(kVxT) void k_vox_box(const VoxJob *jobs, const int *tile_tab)
+{
+    const int entry = tile_tab[blockIdx.x];
+    const VoxJob J = jobs[entry >> 6];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = J.n, tile = entry & 63;
+    if (n <= 0 || n > kVoxCloudMax) { if (tile == 0 && tid == 0) *J.n_out = n <= 0 ? 0 : -1; return; }
+    const VoxView V = vox_view(J);
+    if (tile >= V.tiles) return;
     typedef __attribute__((address_space(1))) const float4 GF4;
-    typedef __attribute__((address_space(1))) float4 GF4W;
-    typedef __attribute__((address_space(1))) unsigned int GU;
-    typedef __attribute__((address_space(1))) int GI;
-    const float4 *gin = (const float4 *)(GF4 *)J.in;          // generic again for float4's operators; the compiler keeps the address space it came through
-    float4 *gout = (float4 *)(GF4W *)J.out;
-    // bounding box (four points per thread in flight)
+    const float4 *gin = (const float4 *)(GF4 *)J.in;
+    __shared__ float s_box[4][6];
     float mn[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, mx[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
-    for (int i0 = tid; i0 < n; i0 += 4 * 1024) {
-        float4 p[4];
+    float4 p[kVxBlocks];
 #pragma unroll
-        for (int u = 0; u < 4; u++) p[u] = gin[min(i0 + 1024 * u, n - 1)];          // a clamped slot repeats the last point: harmless for min / max
+    for (int u = 0; u < kVxBlocks; u++) p[u] = gin[min(tile * kVxTile + kVxT * u + tid, n - 1)];          // a clamped slot repeats the last point: harmless for min / max
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            mn[0] = fminf(mn[0], p[u].x); mn[1] = fminf(mn[1], p[u].y); mn[2] = fminf(mn[2], p[u].z);
-            mx[0] = fmaxf(mx[0], p[u].x); mx[1] = fmaxf(mx[1], p[u].y); mx[2] = fmaxf(mx[2], p[u].z);
-        }
+    for (int u = 0; u < kVxBlocks; u++) {
+        mn[0] = fminf(mn[0], p[u].x); mn[1] = fminf(mn[1], p[u].y); mn[2] = fminf(mn[2], p[u].z);
+        mx[0] = fmaxf(mx[0], p[u].x); mx[1] = fmaxf(mx[1], p[u].y); mx[2] = fmaxf(mx[2], p[u].z);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1)
@@ -636,169 +724,323 @@ __global__ __launch_bounds__(1024) void k_voxel_cloud(const VoxJob *jobs)
         for (int k = 0; k < 3; k++) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], o)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], o)); }
     if (lane == 0) for (int k = 0; k < 3; k++) { s_box[wave][k] = mn[k]; s_box[wave][3 + k] = mx[k]; }
     __syncthreads();
-    for (int w = 0; w < 16; w++) for (int k = 0; k < 3; k++) { mn[k] = fminf(mn[k], s_box[w][k]); mx[k] = fmaxf(mx[k], s_box[w][3 + k]); }
+    if (tid < 6) {
+        float v = s_box[0][tid];
+        for (int w = 1; w < 4; w++) v = tid < 3 ? fminf(v, s_box[w][tid]) : fmaxf(v, s_box[w][tid]);
+        V.box[tile * 8 + tid] = v;
+    }
+}
+
+// cell keys in index order + the tile's digit counts of pass 0
+__global__ __launch_bounds__(kVxT) void k_vox_keys(const VoxJob *jobs, const int *tile_tab)
+{
+    const int entry = tile_tab[blockIdx.x];
+    const VoxJob J = jobs[entry >> 6];
+    const int tid = threadIdx.x, n = J.n, tile = entry & 63;
+    if (n <= 0 || n > kVoxCloudMax) return;
+    const VoxView V = vox_view(J);
+    if (tile >= V.tiles) return;
+    typedef __attribute__((address_space(1))) const float4 GF4;
+    typedef __attribute__((address_space(1))) unsigned int GU;
+    typedef __attribute__((address_space(1))) int GI;
+    const float4 *gin = (const float4 *)(GF4 *)J.in;
+    GU *ka = (GU *)J.key_a;
+    GI *ia = (GI *)J.idx_a;
+    __shared__ float s_box[6];
+    __shared__ int s_h[kVxMaxDigit];
+    float4 p[kVxBlocks];
+#pragma unroll
+    for (int u = 0; u < kVxBlocks; u++) p[u] = gin[min(tile * kVxTile + kVxT * u + tid, n - 1)];
+    if (tid < 64) {                                   // the cloud's box from the tiles' boxes (<= 32 of them)
+        float v[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) v[k] = V.box[min(tid, V.tiles - 1) * 8 + k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int k = 0; k < 6; k++) v[k] = k < 3 ? fminf(v[k], __shfl_xor(v[k], o)) : fmaxf(v[k], __shfl_xor(v[k], o));
+        if (tid == 0) for (int k = 0; k < 6; k++) s_box[k] = v[k];
+    }
+    for (int d = tid; d < kVxMaxDigit; d += kVxT) s_h[d] = 0;
+    __syncthreads();
     const float inv = J.inv_leaf;
-    const int minb0 = (int)floorf(mn[0] * inv), minb1 = (int)floorf(mn[1] * inv), minb2 = (int)floorf(mn[2] * inv);
-    const int div0 = (int)floorf(mx[0] * inv) - minb0 + 1, div1 = (int)floorf(mx[1] * inv) - minb1 + 1, div2 = (int)floorf(mx[2] * inv) - minb2 + 1;
+    const int minb0 = (int)floorf(s_box[0] * inv), minb1 = (int)floorf(s_box[1] * inv), minb2 = (int)floorf(s_box[2] * inv);
+    const int div0 = (int)floorf(s_box[3] * inv) - minb0 + 1, div1 = (int)floorf(s_box[4] * inv) - minb1 + 1, div2 = (int)floorf(s_box[5] * inv) - minb2 + 1;
     const int mul1 = div0, mul2 = div0 * div1;
-    // highest cell index decides how many 8-bit passes are needed
+    // the highest cell index decides the passes and the digit width
     const unsigned int max_cell = (unsigned int)((div0 - 1) + (div1 - 1) * mul1 + (div2 - 1) * mul2);
     int bits = 0;
     while (bits < 32 && (max_cell >> bits) != 0u) bits++;
-    const int passes = (bits + 7) / 8 > 0 ? (bits + 7) / 8 : 1;
-    GU *ka = (GU *)J.key_a, *kb = (GU *)J.key_b;
-    GI *ia = (GI *)J.idx_a, *ib = (GI *)J.idx_b;
-    // keys in index order
-    for (int i0 = tid; i0 < n; i0 += 4 * 1024) {
-        float4 p[4];
+    if (bits < 1) bits = 1;
+    const int passes = (bits + 8) / 9, width = (bits + passes - 1) / passes;
+    if (tile == 0 && tid == 0) { V.hdr[0] = passes; V.hdr[1] = width; }
+    const unsigned int dmask = (1u << width) - 1u;
 #pragma unroll
-        for (int u = 0; u < 4; u++) p[u] = gin[min(i0 + 1024 * u, n - 1)];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int i = i0 + 1024 * u;
-            if (i >= n) break;
-            const int i0c = (int)(floorf(p[u].x * inv) - (float)minb0);
-            const int i1c = (int)(floorf(p[u].y * inv) - (float)minb1);
-            const int i2c = (int)(floorf(p[u].z * inv) - (float)minb2);
-            ka[i] = (unsigned int)(i0c + i1c * mul1 + i2c * mul2);
-            ia[i] = i;
-        }
+    for (int u = 0; u < kVxBlocks; u++) {
+        const int i = tile * kVxTile + kVxT * u + tid;
+        if (i >= n) break;
+        const int i0c = (int)(floorf(p[u].x * inv) - (float)minb0);
+        const int i1c = (int)(floorf(p[u].y * inv) - (float)minb1);
+        const int i2c = (int)(floorf(p[u].z * inv) - (float)minb2);
+        const unsigned int key = (unsigned int)(i0c + i1c * mul1 + i2c * mul2);
+        ka[i] = key;
+        ia[i] = i;
+        atomicAdd(&s_h[key & dmask], 1);
     }
-    __threadfence_block();
     __syncthreads();
-    // the wave's segment: a multiple of 64 elements
-    const int seg = (((n + 15) / 16) + 63) & ~63;
-    const int w_lo = min(wave * seg, n), w_hi = min(w_lo + seg, n);
+    // table 0: this tile's counts; table 1 (filled by pass 0): cleared
+    for (int d = tid; d < kVxMaxDigit; d += kVxT) { V.hist[(0 * V.tiles + tile) * kVxMaxDigit + d] = s_h[d]; V.hist[(1 * V.tiles + tile) * kVxMaxDigit + d] = 0; }
+}
+
+// one stable pass over one tile
+__global__ __launch_bounds__(kVxT) void k_vox_pass(const VoxJob *jobs, const int *tile_tab, int pass)
+{
+    const int entry = tile_tab[blockIdx.x];
+    const VoxJob J = jobs[entry >> 6];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = J.n, tile = entry & 63;
+    if (n <= 0 || n > kVoxCloudMax) return;
+    const VoxView V = vox_view(J);
+    if (tile >= V.tiles) return;
+    const int passes = V.hdr[0], width = V.hdr[1];
+    if (pass >= passes) return;
+    typedef __attribute__((address_space(1))) unsigned int GU;
+    typedef __attribute__((address_space(1))) int GI;
+    GU *ka = (GU *)((pass & 1) ? J.key_b : J.key_a), *kb = (GU *)((pass & 1) ? J.key_a : J.key_b);
+    GI *ia = (GI *)((pass & 1) ? J.idx_b : J.idx_a), *ib = (GI *)((pass & 1) ? J.idx_a : J.idx_b);
+    const int sh = pass * width, D = 1 << width;
+    const unsigned int dmask = (unsigned int)D - 1u;
+    const bool more = pass + 1 < passes;
+    const int *h_cur = V.hist + (size_t)((pass % 3) * V.tiles) * kVxMaxDigit;
+    int *h_nxt = V.hist + (size_t)(((pass + 1) % 3) * V.tiles) * kVxMaxDigit;
+    int *h_clr = V.hist + (size_t)(((pass + 2) % 3) * V.tiles + tile) * kVxMaxDigit;
+    __shared__ int s_cnt[4][kVxMaxDigit];       // [wave][digit]: counts, then cursors
+    __shared__ int s_wtot[4];
+    // the wave's eight blocks of 64 consecutive elements
+    const int w_lo = tile * kVxTile + wave * (kVxTile / 4), w_hi = min(w_lo + kVxTile / 4, n);
+    unsigned int kk[kVxBlocks];
+    int ii[kVxBlocks];
+#pragma unroll
+    for (int u = 0; u < kVxBlocks; u++) { const int ic = min(w_lo + 64 * u + lane, n - 1); kk[u] = ka[ic]; ii[u] = ia[ic]; }
+    for (int d = tid; d < 4 * kVxMaxDigit; d += kVxT) (&s_cnt[0][0])[d] = 0;
+    // first output position of every digit for this tile: (all tiles' counts of smaller digits) + (earlier tiles' counts of this digit)
+    const int per = D > kVxT ? 2 : 1;                 // digits per thread: 2 tid, 2 tid + 1 for 9-bit digits
+    int tot[2] = { 0, 0 }, before[2] = { 0, 0 };
+    for (int q = 0; q < per; q++) {
+        const int d = per * tid + q;
+        if (d < D)
+            for (int t0 = 0; t0 < V.tiles; t0 += 8) {                  // eight tiles' counts in flight (one at a time it was a ~1 us round trip per tile)
+                int cth[8];
+#pragma unroll
+                for (int v = 0; v < 8; v++) cth[v] = h_cur[min(t0 + v, V.tiles - 1) * kVxMaxDigit + d];
+#pragma unroll
+                for (int v = 0; v < 8; v++) { const int t = t0 + v; tot[q] += t < V.tiles ? cth[v] : 0; before[q] += t < tile ? cth[v] : 0; }
+            }
+    }
+    __syncthreads();
     const unsigned long long lt = (1ull << lane) - 1ull;
-    // Round 4: 8-bit digits (three passes for a 20..24-bit cell index instead of six 4-bit ones).  The lanes of a 64-element block that hold the same digit
-    // find each other with eight ballots (one per digit bit); the lowest of them owns the wave's counter / cursor of that digit for the block, the others
-    // take their rank behind it: still the order (wave segment, block, lane) = index order inside a digit, so every pass is stable.
     auto peers_of = [&](bool ok, unsigned int dgt) -> unsigned long long {
         unsigned long long pm = __ballot(ok);
-#pragma unroll
-        for (int bq = 0; bq < 8; bq++) {
+        for (int bq = 0; bq < width; bq++) {
             const unsigned long long m = __ballot(ok && ((dgt >> bq) & 1u));
             pm &= ((dgt >> bq) & 1u) ? m : ~m;
         }
         return ok ? pm : 0ull;
     };
-    for (int pass = 0; pass < passes; pass++) {
-        const int sh = 8 * pass;
-        int *flat = &s_cnt[0][0];
-        for (int i = tid; i < 16 * 256; i += 1024) flat[i] = 0;
-        __syncthreads();
-        for (int r0 = w_lo; r0 < w_hi; r0 += 4 * 64) {
-            unsigned int kk[4];
+    unsigned long long pm[kVxBlocks];
 #pragma unroll
-            for (int u = 0; u < 4; u++) kk[u] = ka[min(r0 + 64 * u + lane, n - 1)];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const bool ok = r0 + 64 * u + lane < w_hi;
-                const unsigned int dgt = (kk[u] >> sh) & 255u;
-                const unsigned long long pm = peers_of(ok, dgt);
-                if (ok && (pm & lt) == 0ull) s_cnt[wave][dgt] += __popcll(pm);        // the digit's lowest lane; one wave, one row: plain read-modify-write, in block order
-            }
-        }
-        __syncthreads();
-        // exclusive prefix over the 4096 counts in (digit, wave) order: four consecutive entries per thread
-        {
-            int v4[4], local = 0;
-#pragma unroll
-            for (int q = 0; q < 4; q++) { const int e = 4 * tid + q; v4[q] = s_cnt[e & 15][e >> 4]; local += v4[q]; }
-            const int incl = wave_scan_incl(local);
-            if (lane == 63) s_wtot[wave] = incl;
-            __syncthreads();
-            int run = incl - local;
-            for (int w = 0; w < wave; w++) run += s_wtot[w];
-#pragma unroll
-            for (int q = 0; q < 4; q++) { const int e = 4 * tid + q; s_cnt[e & 15][e >> 4] = run; run += v4[q]; }
-        }
-        __syncthreads();
-        for (int r0 = w_lo; r0 < w_hi; r0 += 4 * 64) {
-            unsigned int kk[4];
-            int ii[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const int ic = min(r0 + 64 * u + lane, n - 1); kk[u] = ka[ic]; ii[u] = ia[ic]; }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const bool ok = r0 + 64 * u + lane < w_hi;
-                const unsigned int dgt = (kk[u] >> sh) & 255u;
-                const unsigned long long pm = peers_of(ok, dgt);
-                const bool lead = ok && (pm & lt) == 0ull;
-                int base = 0;
-                if (lead) { base = s_cnt[wave][dgt]; s_cnt[wave][dgt] = base + __popcll(pm); }
-                base = __shfl(base, ok ? __ffsll((long long)pm) - 1 : lane);
-                if (ok) { const int dst = base + __popcll(pm & lt); kb[dst] = kk[u]; ib[dst] = ii[u]; }
-            }
-        }
-        __threadfence_block();
-        __syncthreads();
-        GU *tk = ka; ka = kb; kb = tk;
-        GI *ti = ia; ia = ib; ib = ti;
+    for (int u = 0; u < kVxBlocks; u++) {
+        const bool ok = w_lo + 64 * u + lane < w_hi;
+        const unsigned int dgt = (kk[u] >> sh) & dmask;
+        pm[u] = peers_of(ok, dgt);
+        if (ok && (pm[u] & lt) == 0ull) s_cnt[wave][dgt] += __popcll(pm[u]);        // the digit's lowest lane of the block; one wave, one row, block order
     }
-    // runs of equal cells -> centroids, in ascending cell order.  Heads of the wave's segment first (count), then every head lane sums its run
-    int heads = 0;
-    for (int r0 = w_lo; r0 < w_hi; r0 += 64) {
-        const int i = r0 + lane;
-        const bool ok = i < w_hi;
-        const unsigned int k = ka[min(i, n - 1)], kp = ka[max(min(i, n - 1) - 1, 0)];
-        heads += __popcll(__ballot(ok && (i == 0 || k != kp)));
+    {
+        const int local = tot[0] + tot[1];
+        const int incl = wave_scan_incl(local);
+        if (lane == 63) s_wtot[wave] = incl;
+        __syncthreads();
+        int run = incl - local;
+        for (int w = 0; w < wave; w++) run += s_wtot[w];
+        for (int q = 0; q < per; q++) {
+            const int d = per * tid + q;
+            if (d < D) {
+                int cur = run + before[q];
+                for (int w = 0; w < 4; w++) { const int cw = s_cnt[w][d]; s_cnt[w][d] = cur; cur += cw; }
+            }
+            run += tot[q];
+        }
     }
-    if (lane == 0) s_heads[wave] = heads;
     __syncthreads();
-    int o = 0;
-    for (int w = 0; w < wave; w++) o += s_heads[w];
-    if (tid == 1023) s_total = o + heads;
-    // Every lane fetches ITS element (key, index: coalesced; point: gathered) -- all of a round's memory traffic in one go --, a head lane then collects
-    // the rest of its run from the lanes behind it with shuffles, in run order (PCL's float summation order); only a run that leaves the 64-element block
-    // goes on through memory.
-    for (int r0 = w_lo; r0 < w_hi; r0 += 64) {
+#pragma unroll
+    for (int u = 0; u < kVxBlocks; u++) {
+        const bool ok = w_lo + 64 * u + lane < w_hi;
+        const unsigned int dgt = (kk[u] >> sh) & dmask;
+        const bool lead = ok && (pm[u] & lt) == 0ull;
+        int base = 0;
+        if (lead) { base = s_cnt[wave][dgt]; s_cnt[wave][dgt] = base + __popcll(pm[u]); }
+        base = __shfl(base, ok ? __ffsll((long long)pm[u]) - 1 : lane);
+        const int dst = base + __popcll(pm[u] & lt);
+        if (ok && (unsigned int)dst < (unsigned int)n) {       // (the counts add up to n: the bound only keeps a corrupted workspace from becoming a stray write)
+            kb[dst] = kk[u]; ib[dst] = ii[u];
+#ifndef LMONO_VOX_TIMING_NO_ATOMICS        // (timing experiment only: wrong results without them)
+            if (more) atomicAdd(&h_nxt[(dst / kVxTile) * kVxMaxDigit + ((kk[u] >> (sh + width)) & dmask)], 1);
+#endif
+        }
+    }
+    for (int d = tid; d < D; d += kVxT) h_clr[d] = 0;             // (the rows start out as the keys kernel left them: whole rows of table 1 cleared, tables 0 / 2 written before they are read)
+}
+
+// run heads of a tile
+__global__ __launch_bounds__(kVxT) void k_vox_heads(const VoxJob *jobs, const int *tile_tab, int max_passes)
+{
+    const int entry = tile_tab[blockIdx.x];
+    const VoxJob J = jobs[entry >> 6];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = J.n, tile = entry & 63;
+    if (n <= 0 || n > kVoxCloudMax) return;
+    const VoxView V = vox_view(J);
+    if (tile >= V.tiles) return;
+    const int passes = V.hdr[0];
+    if (passes > max_passes) return;
+    typedef __attribute__((address_space(1))) const unsigned int GU;
+    GU *ka = (GU *)((passes & 1) ? J.key_b : J.key_a);
+    __shared__ int s_h[4];
+    int heads = 0;
+    unsigned int k[kVxBlocks], kp[kVxBlocks];
+#pragma unroll
+    for (int u = 0; u < kVxBlocks; u++) { const int ic = min(tile * kVxTile + kVxT * u + tid, n - 1); k[u] = ka[ic]; kp[u] = ka[max(ic - 1, 0)]; }
+#pragma unroll
+    for (int u = 0; u < kVxBlocks; u++) { const int i = tile * kVxTile + kVxT * u + tid; heads += (i < n && (i == 0 || k[u] != kp[u])) ? 1 : 0; }
+    heads = wave_sum_i(heads);
+    if (lane == 0) s_h[wave] = heads;
+    __syncthreads();
+    if (tid == 0) V.heads[tile * 8] = s_h[0] + s_h[1] + s_h[2] + s_h[3];
+}
+
+// runs of equal cells -> centroids, in ascending cell order
+__global__ __launch_bounds__(kVxT) void k_vox_centroids(const VoxJob *jobs, const int *tile_tab, int max_passes)
+{
+    const int entry = tile_tab[blockIdx.x];
+    const VoxJob J = jobs[entry >> 6];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = J.n, tile = entry & 63;
+    if (n <= 0 || n > kVoxCloudMax) return;
+    const VoxView V = vox_view(J);
+    if (tile >= V.tiles) return;
+    const int passes = V.hdr[0];
+    if (passes > max_passes) { if (tile == 0 && tid == 0) *J.n_out = -1; return; }
+    typedef __attribute__((address_space(1))) const float4 GF4;
+    typedef __attribute__((address_space(1))) float4 GF4W;
+    typedef __attribute__((address_space(1))) const unsigned int GU;
+    typedef __attribute__((address_space(1))) const int GI;
+    const float4 *gin = (const float4 *)(GF4 *)J.in;
+    float4 *gout = (float4 *)(GF4W *)J.out;
+    GU *ka = (GU *)((passes & 1) ? J.key_b : J.key_a);
+    GI *ia = (GI *)((passes & 1) ? J.idx_b : J.idx_a);
+    __shared__ int s_h[4];
+    const int w_lo = tile * kVxTile + wave * (kVxTile / 4), w_hi = min(w_lo + kVxTile / 4, n);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    // every lane fetches ITS elements of the wave's eight blocks (key, key before, index: coalesced; point: gathered), all in flight together
+    unsigned int c[kVxBlocks], kp[kVxBlocks];
+    int jx[kVxBlocks];
+#pragma unroll
+    for (int u = 0; u < kVxBlocks; u++) { const int ic = min(w_lo + 64 * u + lane, n - 1); c[u] = ka[ic]; kp[u] = ka[max(ic - 1, 0)]; jx[u] = ia[ic]; }
+    int before = 0;
+    for (int t = lane; t < tile; t += 64) before += V.heads[t * 8];
+    float4 pt[kVxBlocks];
+#pragma unroll
+    for (int u = 0; u < kVxBlocks; u++) pt[u] = gin[min((unsigned int)jx[u], (unsigned int)(n - 1))];
+    before = wave_sum_i(before);
+    int heads = 0;
+#pragma unroll
+    for (int u = 0; u < kVxBlocks; u++) { const int i = w_lo + 64 * u + lane; heads += __popcll(__ballot(i < w_hi && (i == 0 || c[u] != kp[u]))); }
+    if (lane == 0) s_h[wave] = heads;
+    __syncthreads();
+    int o = before;
+    for (int w = 0; w < wave; w++) o += s_h[w];
+    if (tile == V.tiles - 1 && tid == kVxT - 1) *J.n_out = o + heads;
+    // a head lane collects the rest of its run from the lanes behind it with shuffles, in run order (PCL's float summation order).  A run that leaves its
+    // 64-element block goes on in the registers of the wave's next blocks (their leading lanes, read one by one in order); only a run that leaves the
+    // wave's 512 elements goes on through memory.
+    unsigned long long cmf[kVxBlocks];          // lanes that continue the run of the element before them (lane 0: the run of the previous block)
+#pragma unroll
+    for (int u = 0; u < kVxBlocks; u++) { const int i = w_lo + 64 * u + lane; cmf[u] = __ballot(i < w_hi && i > 0 && c[u] == kp[u]); }
+    const unsigned int k_next = ka[min(w_hi, n - 1)];       // the key behind the wave's segment
+#pragma unroll
+    for (int u = 0; u < kVxBlocks; u++) {
+        const int r0 = w_lo + 64 * u;
+        if (r0 >= w_hi) break;
         const int i = r0 + lane;
-        const bool ok = i < w_hi;
-        const int ic = min(i, n - 1);
-        const unsigned int c = ka[ic], kp = ka[max(ic - 1, 0)];
-        const float4 pt = gin[ia[ic]];
-        const bool head = ok && (i == 0 || c != kp);
+        const bool head = i < w_hi && !((cmf[u] >> lane) & 1ull);
         const unsigned long long hm = __ballot(head);
-        // lanes that continue the run of the lane before them, inside this block and inside the array
-        const unsigned long long cm = __ballot(i < n && lane > 0 && c == kp);
         // run length behind a head inside the block: consecutive continuation bits after its lane
-        const unsigned long long after = lane < 63 ? (cm >> (lane + 1)) : 0ull;
+        const unsigned long long after = lane < 63 ? (cmf[u] >> (lane + 1)) : 0ull;
         const int rl = head ? (int)__builtin_ctzll(~after | (1ull << 63)) : 0;
         const int rl_max = (int)wave_max_i(rl);
-        float sx = pt.x, sy = pt.y, sz = pt.z, si = pt.w;
+        float sx = pt[u].x, sy = pt[u].y, sz = pt[u].z, si = pt[u].w;
         for (int t = 1; t <= rl_max; t++) {
-            const float vx = __shfl_down(pt.x, t), vy = __shfl_down(pt.y, t), vz = __shfl_down(pt.z, t), vw = __shfl_down(pt.w, t);
+            const float vx = __shfl_down(pt[u].x, t), vy = __shfl_down(pt[u].y, t), vz = __shfl_down(pt[u].z, t), vw = __shfl_down(pt[u].w, t);
             if (t <= rl) { sx += vx; sy += vy; sz += vz; si += vw; }
         }
-        if (head) {
-            int cnt = 1 + rl;
-            // the run reaches the end of the block: the rest comes from memory, four at a time (keys and indices first, then the points)
-            if (lane + rl == 63) {
-                for (int u0 = r0 + 64; u0 < n; u0 += 4) {
-                    unsigned int k4[4]; int j4[4];
+        int cnt = 1 + rl;
+        bool open = head && lane + rl == 63 && r0 + 64 < n;          // at most one lane: its run reaches the block's end
 #pragma unroll
-                    for (int u = 0; u < 4; u++) { const int uc = min(u0 + u, n - 1); k4[u] = ka[uc]; j4[u] = ia[uc]; }
-                    float4 p4[4];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) p4[u] = gin[j4[u]];
-                    bool more = true;
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        if (!more || u0 + u >= n || k4[u] != c) { more = false; continue; }
-                        sx += p4[u].x; sy += p4[u].y; sz += p4[u].z; si += p4[u].w;
-                        cnt++;
-                    }
-                    if (!more) break;
-                }
+        for (int v = u + 1; v < kVxBlocks; v++) {
+            if (__ballot(open) == 0ull) break;
+            const int lead = cmf[v] == ~0ull ? 64 : (int)__builtin_ctzll(~cmf[v]);       // leading lanes of block v that continue the run
+            for (int t = 0; t < lead; t++) {
+                const float vx = __shfl(pt[v].x, t), vy = __shfl(pt[v].y, t), vz = __shfl(pt[v].z, t), vw = __shfl(pt[v].w, t);
+                if (open) { sx += vx; sy += vy; sz += vz; si += vw; cnt++; }
             }
+            if (lead < 64) open = false;
+        }
+        // still open behind the wave's last block: the rest comes from memory, four at a time (keys and indices first, then the points)
+        if (open && w_lo + kVxTile / 4 < n && k_next == c[u]) {
+            for (int u0 = w_lo + kVxTile / 4; u0 < n; u0 += 4) {
+                unsigned int k4[4]; int j4[4];
+#pragma unroll
+                for (int v = 0; v < 4; v++) { const int uc = min(u0 + v, n - 1); k4[v] = ka[uc]; j4[v] = ia[uc]; }
+                float4 p4[4];
+#pragma unroll
+                for (int v = 0; v < 4; v++) p4[v] = gin[min((unsigned int)j4[v], (unsigned int)(n - 1))];
+                bool go = true;
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    if (!go || u0 + v >= n || k4[v] != c[u]) { go = false; continue; }
+                    sx += p4[v].x; sy += p4[v].y; sz += p4[v].z; si += p4[v].w;
+                    cnt++;
+                }
+                if (!go) break;
+            }
+        }
+        if (head) {
             const float fc = (float)cnt;
             gout[o + __popcll(hm & lt)] = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
         }
         o += __popcll(hm);
     }
-    __syncthreads();
-    if (tid == 0) *J.n_out = s_total;
+}
+
+// One workgroup per entry of the tile table: (job << 6) | tile, every tile of every job (a job without points keeps one entry: its count must be
+// written).  Built on the host next to the job table and uploaded with it.
+static inline void vox_tile_table(const VoxJob *jobs, size_t n_jobs, std::vector<int> &tab)
+{
+    tab.clear();
+    for (size_t j = 0; j < n_jobs; j++) {
+        const int tiles = jobs[j].n > 0 && jobs[j].n <= kVoxCloudMax ? (jobs[j].n + kVxTile - 1) / kVxTile : 1;
+        for (int t = 0; t < tiles; t++) tab.push_back((int)(j << 6) | t);
+    }
+}
+
+// the launches of a table of voxel jobs; max_passes = the passes to launch (4 covers every 32-bit key; a job that needs more than were launched
+// comes back rejected)
+static inline void launch_voxel_jobs(hipStream_t st, const VoxJob *jobs_d, const int *tab_d, int n_tiles, int max_passes)
+{
+    if (n_tiles <= 0) return;
+    const dim3 g((unsigned)n_tiles), b(kVxT);
+    hipLaunchKernelGGL(k_vox_box, g, b, 0, st, jobs_d, tab_d);
+    hipLaunchKernelGGL(k_vox_keys, g, b, 0, st, jobs_d, tab_d);
+    for (int pass = 0; pass < max_passes; pass++) hipLaunchKernelGGL(k_vox_pass, g, b, 0, st, jobs_d, tab_d, pass);
+    hipLaunchKernelGGL(k_vox_heads, g, b, 0, st, jobs_d, tab_d, max_passes);
+    hipLaunchKernelGGL(k_vox_centroids, g, b, 0, st, jobs_d, tab_d, max_passes);
 }
 
 } // namespace lmono

@@ -123,6 +123,36 @@ def test_voxel_filter_is_bit_exact(oracle, gpu_ctx, frames):
         gpu_ctx.voxel_filter([np.zeros((70000, 4), np.float32)], [0.4])
 
 
+def test_voxel_filter_tile_edges_long_runs_and_every_pass_count(oracle, gpu_ctx):
+    """The filter works in 2048-point tiles, one workgroup each, 1..4 radix passes of 1..9 bits: sizes around the tile edges, the largest cloud,
+    runs of one cell that span several tiles, and key widths that need 1, 2, 3 and 4 passes."""
+    rng = np.random.default_rng(12)
+    def cloud(n, span, z_span=None):
+        c = np.zeros((n, 4), np.float32)
+        c[:, :3] = rng.uniform(-span, span, (n, 3))
+        if z_span is not None:
+            c[:, 2] = rng.uniform(-z_span, z_span, n)
+        c[:, 3] = rng.uniform(0, 64, n)
+        return c
+    clouds, leafs = [], []
+    for n in (63, 64, 65, 511, 512, 513, 2047, 2048, 2049, 4096, 4097, 6143, 65535, 65536):
+        clouds.append(cloud(n, 30.0)); leafs.append(0.5)
+    # long runs: 5000 points in one cell, then a mixture where a third of the points share three cells (runs across tile and wave boundaries)
+    one = cloud(5000, 0.05); one[:, :3] += np.float32(10.2)
+    clouds.append(one); leafs.append(0.4)
+    mix = cloud(30000, 20.0); mix[::3, :3] = np.float32(0.1) + rng.integers(0, 3, (10000, 1)).astype(np.float32) + rng.uniform(0, 0.1, (10000, 3)).astype(np.float32)
+    clouds.append(mix); leafs.append(0.4)
+    # key widths: ~3 bits (1 pass), ~15 bits (2 passes), ~26 bits (3 x 9), ~29 bits (4 x 8)
+    clouds += [cloud(3000, 0.9), cloud(20000, 6.0), cloud(40000, 90.0, 20.0), cloud(40000, 40.0)]
+    leafs += [1.0, 0.4, 0.4, 0.1]
+    out = gpu_ctx.voxel_filter(clouds, leafs)
+    for c, leaf, o in zip(clouds, leafs, out):
+        want = oracle.voxel_filter(c, leaf)
+        assert o.shape == want.shape, (len(c), leaf, o.shape, want.shape)
+        assert np.array_equal(o.view(np.uint32), want.view(np.uint32)), (len(c), leaf)
+    assert len(out[14]) == 1
+
+
 def test_device_resident_mapper_follows_the_oracle(oracle, gpu_ctx):
     """lmono_mapper_process frame by frame (scan clouds taken in place from the scan batch, cube map in HBM) against
     oracle.run_mapping fed with the same odometry poses."""
