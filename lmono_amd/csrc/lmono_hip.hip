@@ -1693,6 +1693,9 @@ struct lmono_mapper {
     double q_wmap_wodom[4] = { 0, 0, 0, 1 }, t_wmap_wodom[3] = { 0, 0, 0 };
     std::vector<Seg> cube[2];
     std::vector<void *> allocs;
+    std::vector<void *> pinned;                 // hipHostMalloc'ed mail boxes
+    int *pin_i = nullptr; double *pin_x = nullptr; int *pin_cube = nullptr; int *pin_nout = nullptr;
+    size_t pin_i_cap = 0, pin_x_cap = 0, pin_cube_cap = 0, pin_nout_cap = 0;
     float4 *arena[2][2] = { { nullptr, nullptr }, { nullptr, nullptr } };   // [type][half]
     int half[2] = { 0, 0 };
     int64_t bump[2] = { 0, 0 };
@@ -1700,7 +1703,7 @@ struct lmono_mapper {
     float4 *stack[2] = { nullptr, nullptr }, *newpts[2] = { nullptr, nullptr }, *neigh[2] = { nullptr, nullptr }, *sorted[2] = { nullptr, nullptr }, *cat[2] = { nullptr, nullptr };
     unsigned int *vk[2] = { nullptr, nullptr };
     hipStream_t side = nullptr;                 // second stream of a frame: the neighbourhood gather + grids run beside the scan clouds' voxel filter
-    hipEvent_t ev_side = nullptr;
+    hipEvent_t ev_side = nullptr, ev_sizes = nullptr;
     double *solve_part = nullptr;               // k_map_solve's cluster: partial sums [kMsEvals][kMsMaxK][28]
     int *vws[2] = { nullptr, nullptr };         // voxel filter workspace (vox_ws_ints per job), vws_cap ints each
     size_t vws_cap = 0;
@@ -1736,7 +1739,9 @@ extern "C" void lmono_mapper_destroy(lmono_mapper *m)
     if (!m) return;
     if (m->side) { (void)hipStreamSynchronize(m->side); (void)hipStreamDestroy(m->side); }
     if (m->ev_side) (void)hipEventDestroy(m->ev_side);
+    if (m->ev_sizes) (void)hipEventDestroy(m->ev_sizes);
     for (void *q : m->allocs) (void)hipFree(q);
+    for (void *q : m->pinned) (void)hipHostFree(q);
     delete m;
 }
 
@@ -1766,7 +1771,8 @@ extern "C" lmono_mapper *lmono_mapper_create(lmono_ctx *c, float line_res, float
     ok = ok && mp_alloc(m, m->masks, 4) && mp_alloc(m, m->nout, 2 * 256) && mp_alloc(m, m->nout_big, m->nout_cap) && mp_alloc(m, m->stats, 8) && mp_alloc(m, m->x, 8) &&
          mp_alloc(m, m->rec, (size_t)2 * kMapStackMax) && mp_alloc(m, m->nn_tmp, (size_t)10 * kMapStackMax) && mp_alloc(m, (char *&)m->jobs, m->jobs_bytes) && mp_alloc(m, m->stream_d, 1) &&
          mp_alloc(m, m->solve_part, (size_t)kMsEvals * kMsMaxK * 28);
-    ok = ok && hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&m->ev_side, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&m->ev_side, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&m->ev_sizes, hipEventDisableTiming) == hipSuccess;
     if (!ok) { c->err = "lmono_mapper_create: device allocation failed"; lmono_mapper_destroy(m); return nullptr; }
     return m;
 }
@@ -1814,6 +1820,19 @@ template <typename T> int mp_grow(lmono_ctx *c, lmono_mapper *m, T *&p, size_t &
     T *q = nullptr;
     if (!mp_alloc(m, q, nc)) { c->err = "lmono_mapper: allocation failed"; return LMONO_ENOMEM; }
     p = q; cap = nc;
+    return LMONO_OK;
+}
+// pinned host mail boxes of the frame's read-backs (a copy into pageable memory holds the calling thread until it is done; into pinned memory it is
+// asynchronous -- the host goes on enqueueing): grown on demand, freed with the mapper
+template <typename T> int pin_grow(lmono_ctx *c, lmono_mapper *m, T *&p, size_t &cap, size_t need)
+{
+    if (need <= cap) return LMONO_OK;
+    size_t nc = cap ? cap : 1024;
+    while (nc < need) nc <<= 1;
+    void *q = nullptr;
+    if (hipHostMalloc(&q, nc * sizeof(T), hipHostMallocDefault) != hipSuccess) { c->err = "lmono_mapper: pinned allocation failed"; return LMONO_ENOMEM; }
+    m->pinned.push_back(q);
+    p = (T *)q; cap = nc;
     return LMONO_OK;
 }
 // job tables of one phase for every stream go through one pinned-free staging path: a scratch device buffer owned by the
@@ -1933,7 +1952,6 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
     undo.u.reserve((size_t)n);
     for (int s = 0; s < n; s++) undo.u.emplace_back(ms[s]);
     // staging vectors of asynchronous copies live until the function returns (every path syncs the stream before that)
-    std::vector<double> xh_opt;
     std::vector<int> pos_all;
     std::vector<ScatterJob> sj;
     std::vector<char> vox_blob;
@@ -1975,10 +1993,17 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
         if (f.n_last[0] > kMapStackMax || f.n_last[1] > kMapStackMax) { c->err = "lmono_mapper: scan cloud too large"; return LMONO_ECAPACITY; }
     }
     tp[1] = tnow();
-    // ---- phase 2: VoxelGrid of the scan clouds (read in place from the scan batches), on the main stream; its sizes are waited for below
-    std::vector<int> ns_h((size_t)2 * n);
+    // Round 4: the frame's first half is enqueued in one go -- the host does not wait for the voxel filter's counts before it launches the optimisation
+    // (the kernels read them from the device, their launches are sized by the clouds' sizes before the filter and stride), it learns them from an event
+    // while the optimisation runs, enqueues the cube assignment behind the solve, and waits ONCE for poses, statistics and cube indices.
+    // ---- phase 2: VoxelGrid of the scan clouds (read in place from the scan batches), on the main stream
+    int *statbuf = nullptr;
+    if ((rc = pin_grow(c, ms[0], ms[0]->pin_i, ms[0]->pin_i_cap, (size_t)10 * n)) || (rc = pin_grow(c, ms[0], ms[0]->pin_x, ms[0]->pin_x_cap, (size_t)8 * n))) return rc;
+    int *ns_h = ms[0]->pin_i, *stats = ms[0]->pin_i + 2 * n;           // pinned: [n][2] filter counts, [n][8] statistics
+    double *xh = ms[0]->pin_x;
     {
         if ((rc = mp_grow(c, ms[0], ms[0]->ibuf, ms[0]->ibuf_cap, (size_t)26 * n)) || (rc = mp_grow(c, ms[0], ms[0]->xbuf, ms[0]->xbuf_cap, (size_t)8 * n))) return rc;
+        statbuf = ms[0]->ibuf + 2 * n;           // [n][8] behind the n_stack pairs, then the solves' cluster barriers [n][16]
         std::vector<VoxJob> vj((size_t)2 * n);
         for (int s = 0; s < n; s++)
             for (int t = 0; t < 2; t++) {
@@ -1991,17 +2016,17 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
             }
         if ((rc = upload_vox_jobs(c, js, vj, vox_blob, st))) return rc;
         launch_voxel_jobs(st, (const VoxJob *)js.last, (const int *)((const char *)js.last + vj.size() * sizeof(VoxJob)), (int)((vox_blob.size() - vj.size() * sizeof(VoxJob)) / sizeof(int)), 4);
-        HIP_TRY(c, hipMemcpyAsync(ns_h.data(), ms[0]->ibuf, sizeof(int) * 2 * (size_t)n, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipMemcpyAsync(ns_h, ms[0]->ibuf, sizeof(int) * 2 * (size_t)n, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipEventRecord(ms[0]->ev_sizes, st));
     }
-    // ---- phase 3, on the side stream (round 4: both are chains of short launches that leave most of the chip idle, and neither needs the other): map
-    // clouds of the neighbourhoods, concatenated in validInd order, and their grids for the streams whose map is large enough
+    // ---- phase 3, on the side stream (both are chains of short launches that leave most of the chip idle, and neither needs the other): map clouds of
+    // the neighbourhoods, concatenated in validInd order, and their grids for the streams whose map is large enough
     hipStream_t side = ms[0]->side;
     struct SideGuard {            // no return path leaves work on the side stream behind
         hipStream_t s;
         ~SideGuard() { (void)hipStreamSynchronize(s); }
     } side_guard{ side };
     std::vector<int> act;
-    const CloudJob *cj_d = nullptr;
     {
         std::vector<CopyJob> jobs;
         for (int s = 0; s < n; s++) {
@@ -2020,77 +2045,108 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
             f.solve = f.n_map[0] > 10 && f.n_map[1] > 50;
             if (f.solve) act.push_back(s);
         }
-        if (!jobs.empty()) {
-            if ((rc = js.upload(c, jobs.data(), jobs.size() * sizeof(CopyJob), side))) return rc;
-            hipLaunchKernelGGL(k_copy_jobs, dim3((unsigned)jobs.size()), dim3(256), 0, side, (const CopyJob *)js.last);
-        }
-        if (!act.empty()) {
-            std::vector<CloudJob> cj((size_t)2 * act.size());
-            int max_nmap = 0;
-            for (size_t a = 0; a < act.size(); a++) {
-                lmono_mapper *m = ms[act[a]];
-                FrameState &f = F[(size_t)act[a]];
-                for (int t = 0; t < 2; t++) {
-                    CloudJob &J = cj[2 * a + (size_t)t];
-                    J.src = m->neigh[t]; J.n = f.n_map[t]; J.cell = m->cells[t]; J.tcap = m->tcap; J.sorted = m->sorted[t];
-                    J.slot_of = m->slot[t]; J.rank_of = m->rank[t]; J.mask_out = m->masks + t; J.bump = m->masks + 2 + t;
-                    max_nmap = std::max(max_nmap, f.n_map[t]);
-                }
+        // one upload: [CopyJob x jobs | CloudJob x 2 act]
+        std::vector<CloudJob> cj((size_t)2 * act.size());
+        int max_nmap = 0;
+        for (size_t a = 0; a < act.size(); a++) {
+            lmono_mapper *m = ms[act[a]];
+            FrameState &f = F[(size_t)act[a]];
+            for (int t = 0; t < 2; t++) {
+                CloudJob &J = cj[2 * a + (size_t)t];
+                J.src = m->neigh[t]; J.n = f.n_map[t]; J.cell = m->cells[t]; J.tcap = m->tcap; J.sorted = m->sorted[t];
+                J.slot_of = m->slot[t]; J.rank_of = m->rank[t]; J.mask_out = m->masks + t; J.bump = m->masks + 2 + t;
+                max_nmap = std::max(max_nmap, f.n_map[t]);
             }
-            if ((rc = js.upload(c, cj.data(), cj.size() * sizeof(CloudJob), side))) return rc;
-            cj_d = (const CloudJob *)js.last;
-            launch_cloud_grids(side, cj_d, (int)cj.size(), max_nmap);
+        }
+        if (!jobs.empty() || !cj.empty()) {
+            const size_t cj_at = (jobs.size() * sizeof(CopyJob) + 15) & ~(size_t)15;
+            std::vector<char> blob(cj_at + cj.size() * sizeof(CloudJob));
+            if (!jobs.empty()) memcpy(blob.data(), jobs.data(), jobs.size() * sizeof(CopyJob));
+            if (!cj.empty()) memcpy(blob.data() + cj_at, cj.data(), cj.size() * sizeof(CloudJob));
+            if ((rc = js.upload(c, blob.data(), blob.size(), side))) return rc;
+            if (!jobs.empty()) hipLaunchKernelGGL(k_copy_jobs, dim3((unsigned)jobs.size()), dim3(256), 0, side, (const CopyJob *)js.last);
+            if (!cj.empty()) launch_cloud_grids(side, (const CloudJob *)((const char *)js.last + cj_at), (int)cj.size(), max_nmap);
         }
         HIP_TRY(c, hipEventRecord(ms[0]->ev_side, side));
     }
-    HIP_TRY(c, hipStreamSynchronize(st));
-    for (int s = 0; s < n; s++) { F[(size_t)s].n_stack[0] = ns_h[(size_t)2 * s]; F[(size_t)s].n_stack[1] = ns_h[(size_t)2 * s + 1]; }
-    for (int s = 0; s < n; s++) if (F[(size_t)s].n_stack[0] < 0 || F[(size_t)s].n_stack[1] < 0) { c->err = "lmono_mapper: voxel filter rejected a scan cloud"; return LMONO_ECAPACITY; }
     tp[2] = tnow();
     tp[3] = tp[2];
-    // ---- phase 4: optimisation (2 x [correspond + solve]) behind both streams
-    std::vector<int32_t> stats((size_t)n * 8, 0);
+    // ---- phase 4: optimisation (2 x [correspond + solve]) behind both streams, enqueued at once
+    for (size_t k = 0; k < (size_t)8 * n; k++) stats[k] = 0;
     {
-        std::vector<double> &xh = xh_opt;
-        xh.assign((size_t)8 * n, 0.0);
         for (int s = 0; s < n; s++) for (int k = 0; k < 8; k++) xh[(size_t)8 * s + k] = F[(size_t)s].x[k];
-        int *statbuf = ms[0]->ibuf + 2 * n;      // [n][8] behind the n_stack pairs, then the solves' cluster barriers [n][16]
         unsigned int *barbuf = (unsigned int *)(statbuf + 8 * n);
-        HIP_TRY(c, hipMemcpyAsync(ms[0]->xbuf, xh.data(), sizeof(double) * 8 * (size_t)n, hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipMemcpyAsync(ms[0]->xbuf, xh, sizeof(double) * 8 * (size_t)n, hipMemcpyHostToDevice, st));
         HIP_TRY(c, hipMemsetAsync(statbuf, 0, sizeof(int) * 24 * (size_t)n, st));
         HIP_TRY(c, hipStreamWaitEvent(st, ms[0]->ev_side, 0));
         if (!act.empty()) {
             std::vector<MapStream> S(act.size());
-            int max_nq = 0;
+            int max_nq = 0;        // upper bound: the clouds before the filter
             for (size_t a = 0; a < act.size(); a++) {
                 lmono_mapper *m = ms[act[a]];
                 FrameState &f = F[(size_t)act[a]];
                 for (int t = 0; t < 2; t++) {
                     S[a].cell[t] = m->cells[t]; S[a].sorted[t] = m->sorted[t]; S[a].cloud[t] = m->neigh[t]; S[a].mask[t] = m->masks + t; S[a].n_map[t] = f.n_map[t];
-                    S[a].stack[t] = m->stack[t]; S[a].n_stack[t] = f.n_stack[t];
+                    S[a].stack[t] = m->stack[t]; S[a].n_stack[t] = 0;
                 }
+                S[a].n_stack_d = ms[0]->ibuf + 2 * act[a];
                 S[a].rec = m->rec; S[a].x = ms[0]->xbuf + 8 * act[a]; S[a].stats = statbuf + 8 * act[a]; S[a].nn_out = nullptr; S[a].nn_tmp = m->nn_tmp;
                 S[a].part = m->solve_part; S[a].bar = barbuf + 16 * act[a];
-                max_nq = std::max(max_nq, f.n_stack[0] + f.n_stack[1]);
+                max_nq = std::max(max_nq, f.n_last[0] + f.n_last[1]);
             }
             if ((rc = js.upload(c, S.data(), S.size() * sizeof(MapStream), st))) return rc;
             const MapStream *S_d = (const MapStream *)js.last;
+            // the filter keeps a fraction of a scan cloud: a quarter of the bound's blocks (at least 256 per stream while few streams run) stride over the rest
+            const int per_stream = std::max(1, std::max((max_nq + 31) / 32, std::min((max_nq + 7) / 8, (int)(2048 / act.size()))));
             for (int outer = 0; outer < 2; outer++) {
                 if (max_nq > 0) {
-                    hipLaunchKernelGGL(k_map_correspond, dim3((max_nq + 7) / 8, (unsigned)act.size()), dim3(256), 0, st, S_d, outer);
-                    hipLaunchKernelGGL(k_map_factor, dim3((max_nq + 63) / 64, (unsigned)act.size()), dim3(64), 0, st, S_d, outer);
+                    hipLaunchKernelGGL(k_map_correspond, dim3((unsigned)per_stream, (unsigned)act.size()), dim3(256), 0, st, S_d, outer);
+                    hipLaunchKernelGGL(k_map_factor, dim3((unsigned)std::max(1, (per_stream + 7) / 8), (unsigned)act.size()), dim3(64), 0, st, S_d, outer);
                 }
                 launch_map_solve(st, S_d, (int)act.size(), outer);
             }
-            HIP_TRY(c, hipMemcpyAsync(xh.data(), ms[0]->xbuf, sizeof(double) * 8 * (size_t)n, hipMemcpyDeviceToHost, st));
-            HIP_TRY(c, hipMemcpyAsync(stats.data(), statbuf, sizeof(int) * 8 * (size_t)n, hipMemcpyDeviceToHost, st));
-            HIP_TRY(c, hipStreamSynchronize(st));
-            for (int s : act) if (stats[(size_t)s * 8 + 6]) { c->err = "lmono_mapper: a solve's cluster barrier timed out"; return LMONO_ENODEV; }
-            for (int s : act) for (int k = 0; k < 8; k++) F[(size_t)s].x[k] = xh[(size_t)8 * s + k];
         }
     }
-    tp[4] = tnow();
-    // ---- phase 5 (host): results, transformUpdate; then pointAssociateToMap + cube index of every stack point on the device
+    // the filter's counts (the optimisation is running): exact sizes for the assignment and the copies back
+    HIP_TRY(c, hipEventSynchronize(ms[0]->ev_sizes));
+    for (int s = 0; s < n; s++) { F[(size_t)s].n_stack[0] = ns_h[(size_t)2 * s]; F[(size_t)s].n_stack[1] = ns_h[(size_t)2 * s + 1]; }
+    for (int s = 0; s < n; s++) if (F[(size_t)s].n_stack[0] < 0 || F[(size_t)s].n_stack[1] < 0) { c->err = "lmono_mapper: voxel filter rejected a scan cloud"; return LMONO_ECAPACITY; }
+    // ---- phase 5: pointAssociateToMap + cube index of every stack point with the refined pose, behind the solve; then the one wait
+    {
+        size_t total = 0;
+        int max_n = 0;
+        std::vector<size_t> at((size_t)2 * n);
+        for (int s = 0; s < n; s++) for (int t = 0; t < 2; t++) { at[(size_t)2 * s + t] = total; total += (size_t)F[(size_t)s].n_stack[t]; max_n = std::max(max_n, F[(size_t)s].n_stack[t]); }
+        if ((rc = mp_grow(c, ms[0], ms[0]->cubebuf, ms[0]->cubebuf_cap, total + 1)) || (rc = mp_grow(c, ms[0], ms[0]->posbuf, ms[0]->posbuf_cap, total + 1))) return rc;
+        std::vector<AssignJob> aj((size_t)2 * n);
+        for (int s = 0; s < n; s++)
+            for (int t = 0; t < 2; t++) {
+                lmono_mapper *m = ms[s];
+                aj[(size_t)2 * s + t] = { m->stack[t], F[(size_t)s].n_stack[t], nullptr, ms[0]->xbuf + 8 * s, m->cen[0], m->cen[1], m->cen[2], m->newpts[t], ms[0]->cubebuf + at[(size_t)2 * s + t] };
+            }
+        if ((rc = pin_grow(c, ms[0], ms[0]->pin_cube, ms[0]->pin_cube_cap, total + 1))) return rc;
+        int *cube_all = ms[0]->pin_cube;
+        if (max_n > 0) {
+            if ((rc = js.upload(c, aj.data(), aj.size() * sizeof(AssignJob), st))) return rc;
+            hipLaunchKernelGGL(k_map_assign, dim3((max_n + 255) / 256, 2 * n), dim3(256), 0, st, (const AssignJob *)js.last);
+            HIP_TRY(c, hipMemcpyAsync(cube_all, ms[0]->cubebuf, sizeof(int) * total, hipMemcpyDeviceToHost, st));
+        }
+        if (!act.empty()) {
+            HIP_TRY(c, hipMemcpyAsync(xh, ms[0]->xbuf, sizeof(double) * 8 * (size_t)n, hipMemcpyDeviceToHost, st));
+            HIP_TRY(c, hipMemcpyAsync(stats, statbuf, sizeof(int) * 8 * (size_t)n, hipMemcpyDeviceToHost, st));
+        }
+        HIP_TRY(c, hipStreamSynchronize(st));
+        tp[4] = tnow();
+        for (int s : act) if (stats[(size_t)s * 8 + 6]) { c->err = "lmono_mapper: a solve's cluster barrier timed out"; return LMONO_ENODEV; }
+        for (int s : act) for (int k = 0; k < 8; k++) F[(size_t)s].x[k] = xh[(size_t)8 * s + k];
+        for (int s = 0; s < n; s++)
+            for (int t = 0; t < 2; t++) {
+                const int ns = F[(size_t)s].n_stack[t];
+                F[(size_t)s].cube_h[t].assign(cube_all + at[(size_t)2 * s + t], cube_all + at[(size_t)2 * s + t] + ns);
+                if (ns == 0) F[(size_t)s].cube_h[t].assign(1, -1);
+            }
+    }
+    // results, transformUpdate (host)
     for (int s = 0; s < n; s++) {
         lmono_mapper *m = ms[s];
         FrameState &f = F[(size_t)s];
@@ -2104,36 +2160,6 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
         mp_qmul(f.x, qi, m->q_wmap_wodom);
         mp_qrot(m->q_wmap_wodom, to, tmp);
         for (int k = 0; k < 3; k++) m->t_wmap_wodom[k] = f.x[4 + k] - tmp[k];
-    }
-    {
-        // refined poses back to the device in one copy; one launch transforms every stack and finds its cubes
-        std::vector<double> xh((size_t)8 * n);
-        for (int s = 0; s < n; s++) for (int k = 0; k < 8; k++) xh[(size_t)8 * s + k] = F[(size_t)s].x[k];
-        HIP_TRY(c, hipMemcpyAsync(ms[0]->xbuf, xh.data(), sizeof(double) * 8 * (size_t)n, hipMemcpyHostToDevice, st));
-        size_t total = 0;
-        int max_n = 0;
-        std::vector<size_t> at((size_t)2 * n);
-        for (int s = 0; s < n; s++) for (int t = 0; t < 2; t++) { at[(size_t)2 * s + t] = total; total += (size_t)F[(size_t)s].n_stack[t]; max_n = std::max(max_n, F[(size_t)s].n_stack[t]); }
-        if ((rc = mp_grow(c, ms[0], ms[0]->cubebuf, ms[0]->cubebuf_cap, total + 1)) || (rc = mp_grow(c, ms[0], ms[0]->posbuf, ms[0]->posbuf_cap, total + 1))) return rc;
-        std::vector<AssignJob> aj((size_t)2 * n);
-        for (int s = 0; s < n; s++)
-            for (int t = 0; t < 2; t++) {
-                lmono_mapper *m = ms[s];
-                aj[(size_t)2 * s + t] = { m->stack[t], F[(size_t)s].n_stack[t], ms[0]->xbuf + 8 * s, m->cen[0], m->cen[1], m->cen[2], m->newpts[t], ms[0]->cubebuf + at[(size_t)2 * s + t] };
-            }
-        std::vector<int> cube_all(total + 1, -1);
-        if (max_n > 0) {
-            if ((rc = js.upload(c, aj.data(), aj.size() * sizeof(AssignJob), st))) return rc;
-            hipLaunchKernelGGL(k_map_assign, dim3((max_n + 255) / 256, 2 * n), dim3(256), 0, st, (const AssignJob *)js.last);
-            HIP_TRY(c, hipMemcpyAsync(cube_all.data(), ms[0]->cubebuf, sizeof(int) * total, hipMemcpyDeviceToHost, st));
-        }
-        HIP_TRY(c, hipStreamSynchronize(st));
-        for (int s = 0; s < n; s++)
-            for (int t = 0; t < 2; t++) {
-                const int ns = F[(size_t)s].n_stack[t];
-                F[(size_t)s].cube_h[t].assign(cube_all.begin() + (long)at[(size_t)2 * s + t], cube_all.begin() + (long)at[(size_t)2 * s + t] + ns);
-                if (ns == 0) F[(size_t)s].cube_h[t].assign(1, -1);
-            }
     }
     tp[5] = tnow();
     // ---- phase 6: the scans join the cubes.  Host: per touched cube [old points | new points in stack order]; device: build
@@ -2239,7 +2265,8 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
         m->bump[T.t] += T.n_in;
     }
     // output sizes of the filter jobs land in one array owned by the first mapper (grown on demand)
-    std::vector<int> nout_h(vox.size() > 0 ? vox.size() : 1, 0);
+    if ((rc = pin_grow(c, ms[0], ms[0]->pin_nout, ms[0]->pin_nout_cap, vox.size() + 1))) return rc;
+    int *nout_h = ms[0]->pin_nout;
     if (!vox.empty()) {
         if (vox.size() > ms[0]->nout_cap) {
             int *q = nullptr;
@@ -2251,7 +2278,7 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
         for (size_t k = 0; k < vox.size(); k++) vox[k].n_out = ms[0]->nout_big + k;
         if ((rc = upload_vox_jobs(c, js, vox, vox_blob, st))) return rc;
         launch_voxel_jobs(st, (const VoxJob *)js.last, (const int *)((const char *)js.last + vox.size() * sizeof(VoxJob)), (int)((vox_blob.size() - vox.size() * sizeof(VoxJob)) / sizeof(int)), cube_passes);
-        HIP_TRY(c, hipMemcpyAsync(nout_h.data(), ms[0]->nout_big, sizeof(int) * vox.size(), hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipMemcpyAsync(nout_h, ms[0]->nout_big, sizeof(int) * vox.size(), hipMemcpyDeviceToHost, st));
     }
     if (!keep.empty()) {
         if ((rc = js.upload(c, keep.data(), keep.size() * sizeof(CopyJob), st))) return rc;

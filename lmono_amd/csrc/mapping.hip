@@ -236,6 +236,7 @@ struct MapStream {
     // map clouds (grids built by the k_grid_* kernels) and down-sampled scan clouds of one stream
     const GridCell *cell[2]; const float4 *sorted[2]; const float4 *cloud[2]; const int *mask[2]; int n_map[2];
     const float4 *stack[2]; int n_stack[2];
+    const int *n_stack_d;  // when set: the two sizes are read from the device (the voxel filter's counts, still in flight when the table is built); < 0 counts as 0
     MapRec *rec;           // [n_stack[0] + n_stack[1]]
     double *x;             // [8] q(xyzw), t
     int *stats;            // [8] n_edge[2], n_plane[2], lm_iters[2], pad
@@ -246,6 +247,12 @@ struct MapStream {
 };
 constexpr int kMsEvals = 5;        // evaluations of one solve at most: the start + one per LM iteration (max 4)
 constexpr int kMsMaxK = 8;
+
+__device__ __forceinline__ void map_stack_sizes(const MapStream &S, int &n0, int &n1)
+{
+    n0 = S.n_stack[0]; n1 = S.n_stack[1];
+    if (S.n_stack_d) { n0 = S.n_stack_d[0]; n1 = S.n_stack_d[1]; n0 = n0 < 0 ? 0 : n0; n1 = n1 < 0 ? 0 : n1; }
+}
 
 // sorted insertion of (d, idx) into a lane-local ascending top-5
 __device__ __forceinline__ void top5_insert(float *td, int *ti, float d, int idx)
@@ -264,12 +271,14 @@ __device__ __forceinline__ void top5_insert(float *td, int *ti, float d, int idx
 __global__ __launch_bounds__(256) void k_map_correspond(const MapStream *streams, int outer)
 {
     const MapStream S = streams[blockIdx.y];
-    const int nq = S.n_stack[0] + S.n_stack[1];
-    const int qi = blockIdx.x * 8 + (threadIdx.x >> 5);
-    if (qi >= nq) return;
+    int ns0, ns1;
+    map_stack_sizes(S, ns0, ns1);
+    const int nq = ns0 + ns1;
+    // (grid-stride over the points: the launch may be sized before the voxel filter's counts are known to the host)
+    for (int qi = blockIdx.x * 8 + (threadIdx.x >> 5); qi < nq; qi += gridDim.x * 8) {
     const int lane = threadIdx.x & 63, gl = threadIdx.x & 31, gbase = lane & ~31;
-    const int which = qi < S.n_stack[0] ? 0 : 1;
-    const float4 p = S.stack[which][which ? qi - S.n_stack[0] : qi];
+    const int which = qi < ns0 ? 0 : 1;
+    const float4 p = S.stack[which][which ? qi - ns0 : qi];
     int nn[5] = { -1, -1, -1, -1, -1 };
     bool accepted = false;
     const unsigned int mask = (unsigned int)*S.mask[which];
@@ -329,6 +338,7 @@ __global__ __launch_bounds__(256) void k_map_correspond(const MapStream *streams
 #pragma unroll
         for (int k = 0; k < 5; k++) o[k] = accepted ? nn[k] : -1;
     }
+    }
 }
 
 // One thread per down-sampled scan point: the line test (covariance of the five neighbours, eigen-decomposition, largest
@@ -337,15 +347,16 @@ __global__ __launch_bounds__(256) void k_map_correspond(const MapStream *streams
 __global__ __launch_bounds__(64) void k_map_factor(const MapStream *streams, int outer)
 {
     const MapStream S = streams[blockIdx.y];
-    const int nq = S.n_stack[0] + S.n_stack[1];
-    const int qi = blockIdx.x * 64 + threadIdx.x;
-    if (qi >= nq) return;
-    const int which = qi < S.n_stack[0] ? 0 : 1;
+    int ns0, ns1;
+    map_stack_sizes(S, ns0, ns1);
+    const int nq = ns0 + ns1;
+    for (int qi = blockIdx.x * 64 + threadIdx.x; qi < nq; qi += gridDim.x * 64) {
+    const int which = qi < ns0 ? 0 : 1;
     const int *nn = S.nn_tmp + (size_t)qi * 5;
     MapRec *rec = S.rec + qi;
     int kind = 0;
     if (nn[0] >= 0) {
-        const float4 p = S.stack[which][which ? qi - S.n_stack[0] : qi];
+        const float4 p = S.stack[which][which ? qi - ns0 : qi];
         double P[15];
         for (int j = 0; j < 5; j++) { const float4 c = S.cloud[which][nn[j]]; P[j * 3] = (double)c.x; P[j * 3 + 1] = (double)c.y; P[j * 3 + 2] = (double)c.z; }
         double ra[3] = { 0, 0, 0 }, rb[3] = { 0, 0, 0 };
@@ -381,6 +392,7 @@ __global__ __launch_bounds__(64) void k_map_factor(const MapStream *streams, int
         if (m3) atomicAdd(&S.stats[2 + outer], __popcll(m3));
     }
     if (S.nn_out) for (int k = 0; k < 5; k++) S.nn_out[(size_t)qi * 5 + k] = kind != 0 ? nn[k] : -1;
+    }
 }
 
 // ---- solve -----------------------------------------------------------------------------------------------------------
@@ -534,7 +546,9 @@ __global__ __launch_bounds__(kMsT) void k_map_solve(const MapStream *streams, in
     cl.K = K; cl.rank = (int)(blockIdx.x % (8 * K)) / 8; cl.eval = 0; cl.part = S.part; cl.bar = S.bar + outer * 8; cl.fail = S.stats + 6;
     __shared__ double s_red[kMsT / 64][28], s_sum[28], s_cur[28];
     const int tid = threadIdx.x;
-    const int n_edge = S.n_stack[0], nq = S.n_stack[0] + S.n_stack[1];
+    int ns0, ns1;
+    map_stack_sizes(S, ns0, ns1);
+    const int n_edge = ns0, nq = ns0 + ns1;
     const int n_used = S.stats[outer] + S.stats[2 + outer];
     double x[7];
     for (int i = 0; i < 7; i++) x[i] = S.x[i];
@@ -1060,13 +1074,13 @@ __global__ __launch_bounds__(256) void k_copy_jobs(const CopyJob *jobs)
 // pointAssociateToMap of every down-sampled scan point with the refined pose (double transform stored in a float point,
 // intensity kept) and the cube it falls into: cube = int((v + 25) / 50) + cen, one lower when v + 25 < 0.
 // One job per (stream, cloud type); blockIdx.y = job.
-struct AssignJob { const float4 *stack; int n; const double *x; int cen_w, cen_h, cen_d; float4 *out; int *cube; };
+struct AssignJob { const float4 *stack; int n; const int *n_d; const double *x; int cen_w, cen_h, cen_d; float4 *out; int *cube; };   // n_d set: the size is read from the device
 
 __global__ __launch_bounds__(256) void k_map_assign(const AssignJob *jobs)
 {
     const AssignJob J = jobs[blockIdx.y];
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= J.n) return;
+    if (i >= (J.n_d ? *J.n_d : J.n)) return;
     const float4 p = J.stack[i];
     const double *x = J.x;
     double rx, ry, rz;
