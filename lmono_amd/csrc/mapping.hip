@@ -61,19 +61,32 @@ __global__ __launch_bounds__(kCgT) void k_grid_insert(const CloudJob *jobs)
     GridCell *cell = (GridCell *)(GCell *)J.cell;
     const float4 *gsrc = (const float4 *)(GF4 *)J.src;
     GI *slot_of = (GI *)J.slot_of, *rank_of = (GI *)J.rank_of;
-    const int stride = gridDim.x * kCgT;
-    for (int i0 = blockIdx.x * kCgT + threadIdx.x; i0 < n; i0 += 2 * stride) {
+    const int stride = gridDim.x * kCgT, lane = threadIdx.x & 63;
+    // The map clouds are voxel-filter outputs, cube by cube in ascending voxel order: neighbours in the cloud are often neighbours in space.  Lanes
+    // whose points follow each other INTO THE SAME CELL form a run; the run's first lane claims the cell and takes the ranks for all of them (one
+    // compare-and-swap chain and one add per run instead of per point: device-scope atomics are what bounds this kernel).
+    for (int i0 = blockIdx.x * kCgT + (threadIdx.x & ~63); i0 < n; i0 += 2 * stride) {
         float4 p[2];
 #pragma unroll
-        for (int u = 0; u < 2; u++) p[u] = gsrc[min(i0 + stride * u, n - 1)];
-        unsigned long long key[2];
+        for (int u = 0; u < 2; u++) p[u] = gsrc[min(i0 + stride * u + lane, n - 1)];
+        unsigned long long key[2], hm[2];
         unsigned int sl[2];
-        bool open[2];
+        bool open[2], valid[2];
+        int rl[2];
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             key[u] = cell_key((int)floorf(p[u].x * kInvCell), (int)floorf(p[u].y * kInvCell), (int)floorf(p[u].z * kInvCell));
             sl[u] = hash_key(key[u]) & mask;
-            open[u] = i0 + stride * u < n;
+            valid[u] = i0 + stride * u + lane < n;
+            const unsigned long long prev = __shfl_up(key[u], 1);
+            const bool head = valid[u] && (lane == 0 || key[u] != prev);
+            hm[u] = __ballot(head);
+            const unsigned long long vm = __ballot(valid[u]);
+            // run length of a head: up to the next head or the last valid lane
+            const unsigned long long after = lane < 63 ? (hm[u] >> (lane + 1)) : 0ull;
+            const int nxt = after ? lane + 1 + (int)__builtin_ctzll(after) : (int)__popcll(vm);
+            rl[u] = head ? nxt - lane : 0;
+            open[u] = head;
         }
         while (open[0] || open[1]) {
             unsigned long long old[2];
@@ -88,29 +101,42 @@ __global__ __launch_bounds__(kCgT) void k_grid_insert(const CloudJob *jobs)
         }
         int rk[2];
 #pragma unroll
-        for (int u = 0; u < 2; u++) rk[u] = i0 + stride * u < n ? atomicAdd(&cell[sl[u]].cnt, 1) : 0;
+        for (int u = 0; u < 2; u++) rk[u] = rl[u] > 0 ? atomicAdd(&cell[sl[u]].cnt, rl[u]) : 0;
 #pragma unroll
-        for (int u = 0; u < 2; u++) if (i0 + stride * u < n) { slot_of[i0 + stride * u] = (int)sl[u]; rank_of[i0 + stride * u] = rk[u]; }
+        for (int u = 0; u < 2; u++) {
+            // every lane takes slot and first rank from its run's head: the highest head at or below it
+            const unsigned long long below = hm[u] & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+            const int lead = below ? 63 - (int)__builtin_clzll(below) : 0;
+            const int s_run = __shfl((int)sl[u], lead), r_run = __shfl(rk[u], lead);
+            if (valid[u]) { slot_of[i0 + stride * u + lane] = s_run; rank_of[i0 + stride * u + lane] = r_run + (lane - lead); }
+        }
     }
 }
 
-// every occupied cell takes its run of `sorted`: one bump of the job's counter per wave and turn
+// every occupied cell takes its run of `sorted`: one bump of the job's counter per workgroup and turn (2048 cells)
 __global__ __launch_bounds__(kCgT) void k_grid_starts(const CloudJob *jobs)
 {
     const CloudJob J = jobs[blockIdx.y];
     const int T = cloud_grid_size(J);
     typedef __attribute__((address_space(1))) GridCell GCell;
     GridCell *cell = (GridCell *)(GCell *)J.cell;
-    const int lane = threadIdx.x & 63;
-    for (int i0 = blockIdx.x * kCgT + (threadIdx.x & ~63); i0 < T; i0 += gridDim.x * kCgT) {       // T is a multiple of 64: whole waves
-        const int cnt = cell[i0 + lane].cnt;
-        const int incl = wave_scan_incl(cnt);
-        const int tot = __shfl(incl, 63);
-        if (tot == 0) continue;
-        int base = 0;
-        if (lane == 63) base = atomicAdd(J.bump, tot);
-        base = __shfl(base, 63);
-        if (cnt > 0) cell[i0 + lane].start = base + incl - cnt;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ int s_w[kCgT / 64], s_base;
+    for (int c0 = blockIdx.x * 8 * kCgT; c0 < T; c0 += gridDim.x * 8 * kCgT) {        // T is a multiple of 1024, >= 1024
+        int cnt[8], local = 0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int ci = c0 + 8 * tid + u; cnt[u] = ci < T ? cell[ci].cnt : 0; local += cnt[u]; }
+        const int incl = wave_scan_incl(local);
+        if (lane == 63) s_w[wave] = incl;
+        __syncthreads();
+        int run = incl - local, tot = 0;
+        for (int w = 0; w < kCgT / 64; w++) { run += w < wave ? s_w[w] : 0; tot += s_w[w]; }
+        if (tid == 0) s_base = tot > 0 ? atomicAdd(J.bump, tot) : 0;
+        __syncthreads();
+        run += s_base;
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int ci = c0 + 8 * tid + u; if (ci < T && cnt[u] > 0) cell[ci].start = run; run += cnt[u]; }
+        __syncthreads();
     }
 }
 
@@ -144,7 +170,7 @@ static inline void launch_cloud_grids(hipStream_t st, const CloudJob *jobs_d, in
     const unsigned bc = (unsigned)std::min(512, std::max(1, (T + per - 1) / per)), bp = (unsigned)std::min(512, std::max(1, (max_n + per - 1) / per));
     hipLaunchKernelGGL(k_grid_clear, dim3(bc, (unsigned)n_jobs), dim3(kCgT), 0, st, jobs_d);
     hipLaunchKernelGGL(k_grid_insert, dim3(bp, (unsigned)n_jobs), dim3(kCgT), 0, st, jobs_d);
-    hipLaunchKernelGGL(k_grid_starts, dim3(bc, (unsigned)n_jobs), dim3(kCgT), 0, st, jobs_d);
+    hipLaunchKernelGGL(k_grid_starts, dim3((unsigned)std::min(512, std::max(1, T / (8 * kCgT))), (unsigned)n_jobs), dim3(kCgT), 0, st, jobs_d);
     hipLaunchKernelGGL(k_grid_fill, dim3(bp, (unsigned)n_jobs), dim3(kCgT), 0, st, jobs_d);
 }
 
@@ -665,12 +691,13 @@ static inline void launch_map_solve(hipStream_t st, const MapStream *S_d, int n_
 // lo_voxel_filter.
 //
 // Round 4: a cloud is worked on by ceil(n / 2048) workgroups (a "tile" each) in a chain of short launches
-//     k_vox_box | k_vox_keys | k_vox_pass x passes | k_vox_heads | k_vox_centroids
+//     k_vox_box | k_vox_keys (+ counts of pass 0) | [k_vox_count |] k_vox_pass  x passes | k_vox_heads | k_vox_centroids
 // instead of one 1024-thread workgroup per cloud walking it end to end (0.32 ms per 25 k-point cloud in round 3, 0.23 ms with 8-bit digits: a chain of
-// ~1 us global round trips on ONE compute unit, twice per laserMapping frame).  What makes the sort work across workgroups without a counting launch
-// per pass: a pass scatters its elements to their final positions of that pass, so it knows the TILE each of them lands in and adds it to that tile's
-// digit counts of the NEXT pass (global atomics, no return value).  A pass then reads the (tile, digit) counts of all tiles of its cloud (<= 32 x 512),
-// turns them into its own first output position per digit, and ranks its 2048 elements by (wave, block of 64, lane) = index order: stable.
+// ~1 us global round trips on ONE compute unit, twice per laserMapping frame).  A pass reads the (tile, digit) counts of all tiles of its cloud
+// (<= 32 x 512), turns them into its own first output position per digit, and ranks its 2048 elements by (wave, block of 64, lane) = index order:
+// stable.  (A pass that added its scattered elements to the NEXT pass's counts with global atomics -- it knows the tile each of them lands in -- saved the
+// counting launches but was slower: 17 us instead of 9 us per pass on one stream, bound by the atomics' rate over 64 streams; device-scope atomics
+// are resolved beyond the XCDs' L2s.)
 // The digit width adapts to the key: passes = ceil(bits / 9), width = ceil(bits / passes) (26-bit scan-cloud keys: three passes of 9 bits).
 namespace lmono {
 
@@ -681,7 +708,7 @@ constexpr int kVxBlocks = kVxTile / kVxT;                // blocks of 64 per wav
 constexpr int kVxMaxTiles = kVoxCloudMax / kVxTile;      // 32
 constexpr int kVxMaxDigit = 512;                         // 9-bit digits at most
 constexpr int kVxHdr = 16;                               // ints of a job's header in its workspace
-constexpr int kVxWsTile = 16 + 3 * kVxMaxDigit;          // ints of workspace per tile: box[8], heads[1] (+7 pad), three digit-count rows
+constexpr int kVxWsTile = 16 + kVxMaxDigit;              // ints of workspace per tile: box[8], heads[1] (+7 pad), one row of digit counts
 
 struct VoxJob {
     const float4 *in; int n;
@@ -699,7 +726,7 @@ struct VoxView {           // a job's workspace
     int *hdr;              // minb[3], mul1, mul2, passes, width
     float *box;            // [tiles][8]
     int *heads;            // [tiles][8] (first used)
-    int *hist;             // [3][tiles][kVxMaxDigit]
+    int *hist;             // [tiles][kVxMaxDigit]: the tiles' digit counts of the pass at hand
     int tiles;
 };
 
@@ -802,8 +829,36 @@ __global__ __launch_bounds__(kVxT) void k_vox_keys(const VoxJob *jobs, const int
         atomicAdd(&s_h[key & dmask], 1);
     }
     __syncthreads();
-    // table 0: this tile's counts; table 1 (filled by pass 0): cleared
-    for (int d = tid; d < kVxMaxDigit; d += kVxT) { V.hist[(0 * V.tiles + tile) * kVxMaxDigit + d] = s_h[d]; V.hist[(1 * V.tiles + tile) * kVxMaxDigit + d] = 0; }
+    // this tile's digit counts of pass 0
+    for (int d = tid; d < kVxMaxDigit; d += kVxT) V.hist[tile * kVxMaxDigit + d] = s_h[d];
+}
+
+// digit counts of one tile for pass `pass` (pass 0's come from k_vox_keys)
+__global__ __launch_bounds__(kVxT) void k_vox_count(const VoxJob *jobs, const int *tile_tab, int pass)
+{
+    const int entry = tile_tab[blockIdx.x];
+    const VoxJob J = jobs[entry >> 6];
+    const int tid = threadIdx.x, n = J.n, tile = entry & 63;
+    if (n <= 0 || n > kVoxCloudMax) return;
+    const VoxView V = vox_view(J);
+    if (tile >= V.tiles) return;
+    const int passes = V.hdr[0], width = V.hdr[1];
+    if (pass >= passes) return;
+    typedef __attribute__((address_space(1))) const unsigned int GU;
+    GU *ka = (GU *)((pass & 1) ? J.key_b : J.key_a);
+    __shared__ int s_h[kVxMaxDigit];
+    unsigned int kk[kVxBlocks];
+#pragma unroll
+    for (int u = 0; u < kVxBlocks; u++) kk[u] = ka[min(tile * kVxTile + kVxT * u + tid, n - 1)];
+    for (int d = tid; d < kVxMaxDigit; d += kVxT) s_h[d] = 0;
+    __syncthreads();
+    const int sh = pass * width;
+    const unsigned int dmask = (1u << width) - 1u;
+#pragma unroll
+    for (int u = 0; u < kVxBlocks; u++) if (tile * kVxTile + kVxT * u + tid < n) atomicAdd(&s_h[(kk[u] >> sh) & dmask], 1);
+    __syncthreads();
+    int *row = V.hist + (size_t)tile * kVxMaxDigit;
+    for (int d = tid; d < (1 << width); d += kVxT) row[d] = s_h[d];
 }
 
 // one stable pass over one tile
@@ -823,10 +878,7 @@ __global__ __launch_bounds__(kVxT) void k_vox_pass(const VoxJob *jobs, const int
     GI *ia = (GI *)((pass & 1) ? J.idx_b : J.idx_a), *ib = (GI *)((pass & 1) ? J.idx_a : J.idx_b);
     const int sh = pass * width, D = 1 << width;
     const unsigned int dmask = (unsigned int)D - 1u;
-    const bool more = pass + 1 < passes;
-    const int *h_cur = V.hist + (size_t)((pass % 3) * V.tiles) * kVxMaxDigit;
-    int *h_nxt = V.hist + (size_t)(((pass + 1) % 3) * V.tiles) * kVxMaxDigit;
-    int *h_clr = V.hist + (size_t)(((pass + 2) % 3) * V.tiles + tile) * kVxMaxDigit;
+    const int *h_cur = V.hist;
     __shared__ int s_cnt[4][kVxMaxDigit];       // [wave][digit]: counts, then cursors
     __shared__ int s_wtot[4];
     // the wave's eight blocks of 64 consecutive elements
@@ -896,12 +948,8 @@ __global__ __launch_bounds__(kVxT) void k_vox_pass(const VoxJob *jobs, const int
         const int dst = base + __popcll(pm[u] & lt);
         if (ok && (unsigned int)dst < (unsigned int)n) {       // (the counts add up to n: the bound only keeps a corrupted workspace from becoming a stray write)
             kb[dst] = kk[u]; ib[dst] = ii[u];
-#ifndef LMONO_VOX_TIMING_NO_ATOMICS        // (timing experiment only: wrong results without them)
-            if (more) atomicAdd(&h_nxt[(dst / kVxTile) * kVxMaxDigit + ((kk[u] >> (sh + width)) & dmask)], 1);
-#endif
         }
     }
-    for (int d = tid; d < D; d += kVxT) h_clr[d] = 0;             // (the rows start out as the keys kernel left them: whole rows of table 1 cleared, tables 0 / 2 written before they are read)
 }
 
 // run heads of a tile
@@ -1052,7 +1100,10 @@ static inline void launch_voxel_jobs(hipStream_t st, const VoxJob *jobs_d, const
     const dim3 g((unsigned)n_tiles), b(kVxT);
     hipLaunchKernelGGL(k_vox_box, g, b, 0, st, jobs_d, tab_d);
     hipLaunchKernelGGL(k_vox_keys, g, b, 0, st, jobs_d, tab_d);
-    for (int pass = 0; pass < max_passes; pass++) hipLaunchKernelGGL(k_vox_pass, g, b, 0, st, jobs_d, tab_d, pass);
+    for (int pass = 0; pass < max_passes; pass++) {
+        if (pass > 0) hipLaunchKernelGGL(k_vox_count, g, b, 0, st, jobs_d, tab_d, pass);
+        hipLaunchKernelGGL(k_vox_pass, g, b, 0, st, jobs_d, tab_d, pass);
+    }
     hipLaunchKernelGGL(k_vox_heads, g, b, 0, st, jobs_d, tab_d, max_passes);
     hipLaunchKernelGGL(k_vox_centroids, g, b, 0, st, jobs_d, tab_d, max_passes);
 }
