@@ -1715,8 +1715,8 @@ struct lmono_mapper {
     size_t nout_cap = 0;
     // contiguous mail boxes of a batched call (owned by the first mapper, grown on demand): poses, counters, cube indices /
     // placements of all streams travel in one copy per phase
-    double *xbuf = nullptr; int *ibuf = nullptr; int *cubebuf = nullptr; int *posbuf = nullptr;
-    size_t xbuf_cap = 0, ibuf_cap = 0, cubebuf_cap = 0, posbuf_cap = 0;
+    double *xbuf = nullptr; int *ibuf = nullptr; int *cubebuf = nullptr;
+    size_t xbuf_cap = 0, ibuf_cap = 0, cubebuf_cap = 0;
     double *x = nullptr;
     MapRec *rec = nullptr;
     int *nn_tmp = nullptr;          // [2 kMapStackMax][5]
@@ -1844,6 +1844,27 @@ struct JobScratch {
     lmono_mapper *owner;
     size_t used = 0;
     void *last = nullptr;        // device address of the table uploaded last
+    // space for a table whose entries point into the table itself: place() it (its device address is `last`), fill it, send() it
+    int place(lmono_ctx *c, size_t bytes)
+    {
+        used = (used + 255) & ~(size_t)255;
+        if (used + bytes > owner->jobs_bytes) {
+            void *q = nullptr;
+            size_t nb = owner->jobs_bytes;
+            while (nb < bytes || nb < 2 * (used + bytes)) nb <<= 1;
+            if (hipMalloc(&q, nb) != hipSuccess) { c->err = "lmono_mapper: job scratch allocation failed"; return LMONO_ENOMEM; }
+            owner->allocs.push_back(q);
+            owner->jobs = q; owner->jobs_bytes = nb; used = 0;
+        }
+        last = (char *)owner->jobs + used;
+        used += bytes;
+        return LMONO_OK;
+    }
+    int send(lmono_ctx *c, const void *src, size_t bytes, hipStream_t st)
+    {
+        if (bytes > 0 && hipMemcpyAsync(last, src, bytes, hipMemcpyHostToDevice, st) != hipSuccess) { c->err = "lmono_mapper: job upload failed"; return LMONO_ENODEV; }
+        return LMONO_OK;
+    }
     int upload(lmono_ctx *c, const void *src, size_t bytes, hipStream_t st)
     {
         used = (used + 255) & ~(size_t)255;
@@ -2117,7 +2138,7 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
         int max_n = 0;
         std::vector<size_t> at((size_t)2 * n);
         for (int s = 0; s < n; s++) for (int t = 0; t < 2; t++) { at[(size_t)2 * s + t] = total; total += (size_t)F[(size_t)s].n_stack[t]; max_n = std::max(max_n, F[(size_t)s].n_stack[t]); }
-        if ((rc = mp_grow(c, ms[0], ms[0]->cubebuf, ms[0]->cubebuf_cap, total + 1)) || (rc = mp_grow(c, ms[0], ms[0]->posbuf, ms[0]->posbuf_cap, total + 1))) return rc;
+        if ((rc = mp_grow(c, ms[0], ms[0]->cubebuf, ms[0]->cubebuf_cap, total + 1))) return rc;
         std::vector<AssignJob> aj((size_t)2 * n);
         for (int s = 0; s < n; s++)
             for (int t = 0; t < 2; t++) {
@@ -2167,59 +2188,52 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
     struct Touched { int s, t, ind, n_in; int64_t cat_off; bool filter; };
     std::vector<Touched> touched;
     std::vector<CopyJob> copy;
-    std::vector<std::vector<int>> pos_h((size_t)2 * n);
-    for (int s = 0; s < n; s++) {
-        lmono_mapper *m = ms[s];
-        FrameState &f = F[(size_t)s];
-        std::vector<char> is_valid((size_t)kMapCubes, 0);
-        for (int ind : f.valid) is_valid[(size_t)ind] = 1;
-        for (int t = 0; t < 2; t++) {
-            std::vector<int> add((size_t)kMapCubes, 0);
-            for (int i = 0; i < f.n_stack[t]; i++) if (f.cube_h[t][(size_t)i] >= 0) add[(size_t)f.cube_h[t][(size_t)i]]++;
-            std::vector<int64_t> cat_off((size_t)kMapCubes, -1);
-            int64_t at = 0;
-            for (int ind = 0; ind < kMapCubes; ind++) {
-                const Seg &sg = m->cube[(size_t)t][(size_t)ind];
-                const bool v = is_valid[(size_t)ind] != 0;
-                if (!((v && sg.n + add[(size_t)ind] > 0) || (!v && add[(size_t)ind] > 0))) continue;
-                cat_off[(size_t)ind] = at;
-                if (sg.n > 0) copy.push_back({ m->arena[t][m->half[t]] + sg.off, m->cat[t] + at, sg.n });
-                const int n_in = sg.n + add[(size_t)ind];
-                if (v && n_in > kVoxCloudMax) { c->err = "lmono_mapper: a cube holds more than 65536 points"; return LMONO_ECAPACITY; }
-                touched.push_back({ s, t, ind, n_in, at, v });
-                at += n_in;
-            }
-            if (at > (int64_t)kMapNeighMax + kMapStackMax) { c->err = "lmono_mapper: frame touches more points than the workspace holds"; return LMONO_ECAPACITY; }
-            std::vector<int> fill((size_t)kMapCubes, 0);
-            std::vector<int> &ph = pos_h[(size_t)2 * s + t];
-            ph.assign((size_t)(f.n_stack[t] > 0 ? f.n_stack[t] : 1), -1);
-            for (int i = 0; i < f.n_stack[t]; i++) {
-                const int ind = f.cube_h[t][(size_t)i];
-                if (ind >= 0) ph[(size_t)i] = (int)(cat_off[(size_t)ind] + m->cube[(size_t)t][(size_t)ind].n + fill[(size_t)ind]++);
-            }
-        }
-    }
-    if (!copy.empty()) {
-        if ((rc = js.upload(c, copy.data(), copy.size() * sizeof(CopyJob), st))) return rc;
-        hipLaunchKernelGGL(k_copy_jobs, dim3((unsigned)copy.size()), dim3(256), 0, st, (const CopyJob *)js.last);
-    }
+    // (the per-cube tables are allocated once per call and only the entries a stream touched are reset: 64 streams x 2 types x 4851 cubes of
+    // fresh vectors were a millisecond of host time per batched frame)
+    size_t pos_total = 0;
+    int max_ns = 0;
+    std::vector<size_t> pos_at((size_t)2 * n);
+    for (int s = 0; s < n; s++) for (int t = 0; t < 2; t++) { pos_at[(size_t)2 * s + t] = pos_total; pos_total += (size_t)F[(size_t)s].n_stack[t]; max_ns = std::max(max_ns, F[(size_t)s].n_stack[t]); }
+    pos_all.assign(pos_total + 1, -1);
+    sj.resize((size_t)2 * n);
     {
-        size_t total = 0;
-        int max_n = 0;
-        std::vector<size_t> at((size_t)2 * n);
-        for (int s = 0; s < n; s++) for (int t = 0; t < 2; t++) { at[(size_t)2 * s + t] = total; total += (size_t)F[(size_t)s].n_stack[t]; max_n = std::max(max_n, F[(size_t)s].n_stack[t]); }
-        pos_all.assign(total + 1, -1);
-        sj.resize((size_t)2 * n);
-        for (int s = 0; s < n; s++)
+        std::vector<char> is_valid((size_t)kMapCubes, 0);
+        std::vector<int> add((size_t)kMapCubes, 0), fill((size_t)kMapCubes, 0), cand;
+        std::vector<int64_t> cat_off((size_t)kMapCubes, -1);
+        for (int s = 0; s < n; s++) {
+            lmono_mapper *m = ms[s];
+            FrameState &f = F[(size_t)s];
+            for (int ind : f.valid) is_valid[(size_t)ind] = 1;
             for (int t = 0; t < 2; t++) {
-                const int ns = F[(size_t)s].n_stack[t];
-                for (int i = 0; i < ns; i++) pos_all[at[(size_t)2 * s + t] + (size_t)i] = pos_h[(size_t)2 * s + t][(size_t)i];
-                sj[(size_t)2 * s + t] = { ms[s]->newpts[t], ms[0]->posbuf + at[(size_t)2 * s + t], ns, ms[s]->cat[t] };
+                // candidates in ascending cube order: the neighbourhood and every other cube a new point falls into
+                cand.assign(f.valid.begin(), f.valid.end());
+                for (int i = 0; i < f.n_stack[t]; i++) {
+                    const int ind = f.cube_h[t][(size_t)i];
+                    if (ind >= 0 && add[(size_t)ind]++ == 0 && !is_valid[(size_t)ind]) cand.push_back(ind);
+                }
+                std::sort(cand.begin(), cand.end());
+                int64_t at = 0;
+                for (int ind : cand) {
+                    const Seg &sg = m->cube[(size_t)t][(size_t)ind];
+                    const bool v = is_valid[(size_t)ind] != 0;
+                    if (!((v && sg.n + add[(size_t)ind] > 0) || (!v && add[(size_t)ind] > 0))) continue;
+                    cat_off[(size_t)ind] = at;
+                    if (sg.n > 0) copy.push_back({ m->arena[t][m->half[t]] + sg.off, m->cat[t] + at, sg.n });
+                    const int n_in = sg.n + add[(size_t)ind];
+                    if (v && n_in > kVoxCloudMax) { c->err = "lmono_mapper: a cube holds more than 65536 points"; return LMONO_ECAPACITY; }
+                    touched.push_back({ s, t, ind, n_in, at, v });
+                    at += n_in;
+                }
+                if (at > (int64_t)kMapNeighMax + kMapStackMax) { c->err = "lmono_mapper: frame touches more points than the workspace holds"; return LMONO_ECAPACITY; }
+                int *ph = pos_all.data() + pos_at[(size_t)2 * s + t];
+                for (int i = 0; i < f.n_stack[t]; i++) {
+                    const int ind = f.cube_h[t][(size_t)i];
+                    if (ind >= 0) ph[i] = (int)(cat_off[(size_t)ind] + m->cube[(size_t)t][(size_t)ind].n + fill[(size_t)ind]++);
+                }
+                for (int ind : cand) { add[(size_t)ind] = 0; fill[(size_t)ind] = 0; cat_off[(size_t)ind] = -1; }
+                sj[(size_t)2 * s + t] = { m->newpts[t], nullptr, f.n_stack[t], m->cat[t] };       // .pos: set when the blob is placed
             }
-        if (max_n > 0) {
-            HIP_TRY(c, hipMemcpyAsync(ms[0]->posbuf, pos_all.data(), sizeof(int) * total, hipMemcpyHostToDevice, st));
-            if ((rc = js.upload(c, sj.data(), sj.size() * sizeof(ScatterJob), st))) return rc;
-            hipLaunchKernelGGL(k_scatter_pos, dim3((max_n + 255) / 256, 2 * n), dim3(256), 0, st, (const ScatterJob *)js.last);
+            for (int ind : f.valid) is_valid[(size_t)ind] = 0;
         }
     }
     // arena space (an output is never larger than its input); compaction reads only the tables, `cat` is already built
@@ -2276,13 +2290,32 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
             ms[0]->nout_big = q; ms[0]->nout_cap = cap;
         }
         for (size_t k = 0; k < vox.size(); k++) vox[k].n_out = ms[0]->nout_big + k;
-        if ((rc = upload_vox_jobs(c, js, vox, vox_blob, st))) return rc;
-        launch_voxel_jobs(st, (const VoxJob *)js.last, (const int *)((const char *)js.last + vox.size() * sizeof(VoxJob)), (int)((vox_blob.size() - vox.size() * sizeof(VoxJob)) / sizeof(int)), cube_passes);
-        HIP_TRY(c, hipMemcpyAsync(nout_h, ms[0]->nout_big, sizeof(int) * vox.size(), hipMemcpyDeviceToHost, st));
     }
-    if (!keep.empty()) {
-        if ((rc = js.upload(c, keep.data(), keep.size() * sizeof(CopyJob), st))) return rc;
-        hipLaunchKernelGGL(k_copy_jobs, dim3((unsigned)keep.size()), dim3(256), 0, st, (const CopyJob *)js.last);
+    // ONE upload for the whole update: [CopyJob x copy | pos | ScatterJob x 2 n | VoxJob x vox | tile table | CopyJob x keep]
+    {
+        std::vector<int> tab;
+        vox_tile_table(vox.data(), vox.size(), tab);
+        auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
+        const size_t o_copy = 0, o_pos = al(o_copy + copy.size() * sizeof(CopyJob)), o_sj = al(o_pos + pos_total * sizeof(int)), o_vox = al(o_sj + sj.size() * sizeof(ScatterJob)),
+                     o_tab = al(o_vox + vox.size() * sizeof(VoxJob)), o_keep = al(o_tab + tab.size() * sizeof(int)), bytes = o_keep + keep.size() * sizeof(CopyJob);
+        if ((rc = js.place(c, bytes))) return rc;
+        const char *base = (const char *)js.last;
+        for (int s = 0; s < n; s++) for (int t = 0; t < 2; t++) sj[(size_t)2 * s + t].pos = (const int *)(base + o_pos) + pos_at[(size_t)2 * s + t];
+        vox_blob.resize(bytes);
+        if (!copy.empty()) memcpy(vox_blob.data() + o_copy, copy.data(), copy.size() * sizeof(CopyJob));
+        if (pos_total) memcpy(vox_blob.data() + o_pos, pos_all.data(), pos_total * sizeof(int));
+        memcpy(vox_blob.data() + o_sj, sj.data(), sj.size() * sizeof(ScatterJob));
+        if (!vox.empty()) memcpy(vox_blob.data() + o_vox, vox.data(), vox.size() * sizeof(VoxJob));
+        if (!tab.empty()) memcpy(vox_blob.data() + o_tab, tab.data(), tab.size() * sizeof(int));
+        if (!keep.empty()) memcpy(vox_blob.data() + o_keep, keep.data(), keep.size() * sizeof(CopyJob));
+        if ((rc = js.send(c, vox_blob.data(), bytes, st))) return rc;
+        if (!copy.empty()) hipLaunchKernelGGL(k_copy_jobs, dim3((unsigned)copy.size()), dim3(256), 0, st, (const CopyJob *)(base + o_copy));
+        if (max_ns > 0) hipLaunchKernelGGL(k_scatter_pos, dim3((max_ns + 255) / 256, 2 * n), dim3(256), 0, st, (const ScatterJob *)(base + o_sj));
+        if (!vox.empty()) {
+            launch_voxel_jobs(st, (const VoxJob *)(base + o_vox), (const int *)(base + o_tab), (int)tab.size(), cube_passes);
+            HIP_TRY(c, hipMemcpyAsync(nout_h, ms[0]->nout_big, sizeof(int) * vox.size(), hipMemcpyDeviceToHost, st));
+        }
+        if (!keep.empty()) hipLaunchKernelGGL(k_copy_jobs, dim3((unsigned)keep.size()), dim3(256), 0, st, (const CopyJob *)(base + o_keep));
     }
     HIP_TRY(c, hipStreamSynchronize(st));       // ONE wait for the frame's map update: filter sizes are back, `cat` and the job tables are free
     for (size_t k = 0; k < touched.size(); k++) {

@@ -1026,6 +1026,27 @@ __global__ __launch_bounds__(kVxT) void k_vox_centroids(const VoxJob *jobs, cons
 #pragma unroll
     for (int u = 0; u < kVxBlocks; u++) { const int i = w_lo + 64 * u + lane; cmf[u] = __ballot(i < w_hi && i > 0 && c[u] == kp[u]); }
     const unsigned int k_next = ka[min(w_hi, n - 1)];       // the key behind the wave's segment
+    // the in-block part of every run, the eight blocks side by side (a run is summed in order, one shuffle round per element: alone, a block's
+    // rounds are a chain of dependent LDS round trips as long as its longest run)
+    float sx[kVxBlocks], sy[kVxBlocks], sz[kVxBlocks], si[kVxBlocks];
+    int rlen[kVxBlocks], rl_all = 0;
+#pragma unroll
+    for (int u = 0; u < kVxBlocks; u++) {
+        const bool head = w_lo + 64 * u + lane < w_hi && !((cmf[u] >> lane) & 1ull);
+        // run length behind a head inside the block: consecutive continuation bits after its lane
+        const unsigned long long after = lane < 63 ? (cmf[u] >> (lane + 1)) : 0ull;
+        rlen[u] = head ? (int)__builtin_ctzll(~after | (1ull << 63)) : 0;
+        rl_all = max(rl_all, rlen[u]);
+        sx[u] = pt[u].x; sy[u] = pt[u].y; sz[u] = pt[u].z; si[u] = pt[u].w;
+    }
+    rl_all = (int)wave_max_i(rl_all);
+    for (int t = 1; t <= rl_all; t++) {
+#pragma unroll
+        for (int u = 0; u < kVxBlocks; u++) {
+            const float vx = __shfl_down(pt[u].x, t), vy = __shfl_down(pt[u].y, t), vz = __shfl_down(pt[u].z, t), vw = __shfl_down(pt[u].w, t);
+            if (t <= rlen[u]) { sx[u] += vx; sy[u] += vy; sz[u] += vz; si[u] += vw; }
+        }
+    }
 #pragma unroll
     for (int u = 0; u < kVxBlocks; u++) {
         const int r0 = w_lo + 64 * u;
@@ -1033,15 +1054,7 @@ __global__ __launch_bounds__(kVxT) void k_vox_centroids(const VoxJob *jobs, cons
         const int i = r0 + lane;
         const bool head = i < w_hi && !((cmf[u] >> lane) & 1ull);
         const unsigned long long hm = __ballot(head);
-        // run length behind a head inside the block: consecutive continuation bits after its lane
-        const unsigned long long after = lane < 63 ? (cmf[u] >> (lane + 1)) : 0ull;
-        const int rl = head ? (int)__builtin_ctzll(~after | (1ull << 63)) : 0;
-        const int rl_max = (int)wave_max_i(rl);
-        float sx = pt[u].x, sy = pt[u].y, sz = pt[u].z, si = pt[u].w;
-        for (int t = 1; t <= rl_max; t++) {
-            const float vx = __shfl_down(pt[u].x, t), vy = __shfl_down(pt[u].y, t), vz = __shfl_down(pt[u].z, t), vw = __shfl_down(pt[u].w, t);
-            if (t <= rl) { sx += vx; sy += vy; sz += vz; si += vw; }
-        }
+        const int rl = rlen[u];
         int cnt = 1 + rl;
         bool open = head && lane + rl == 63 && r0 + 64 < n;          // at most one lane: its run reaches the block's end
 #pragma unroll
@@ -1050,7 +1063,7 @@ __global__ __launch_bounds__(kVxT) void k_vox_centroids(const VoxJob *jobs, cons
             const int lead = cmf[v] == ~0ull ? 64 : (int)__builtin_ctzll(~cmf[v]);       // leading lanes of block v that continue the run
             for (int t = 0; t < lead; t++) {
                 const float vx = __shfl(pt[v].x, t), vy = __shfl(pt[v].y, t), vz = __shfl(pt[v].z, t), vw = __shfl(pt[v].w, t);
-                if (open) { sx += vx; sy += vy; sz += vz; si += vw; cnt++; }
+                if (open) { sx[u] += vx; sy[u] += vy; sz[u] += vz; si[u] += vw; cnt++; }
             }
             if (lead < 64) open = false;
         }
@@ -1067,7 +1080,7 @@ __global__ __launch_bounds__(kVxT) void k_vox_centroids(const VoxJob *jobs, cons
 #pragma unroll
                 for (int v = 0; v < 4; v++) {
                     if (!go || u0 + v >= n || k4[v] != c[u]) { go = false; continue; }
-                    sx += p4[v].x; sy += p4[v].y; sz += p4[v].z; si += p4[v].w;
+                    sx[u] += p4[v].x; sy[u] += p4[v].y; sz[u] += p4[v].z; si[u] += p4[v].w;
                     cnt++;
                 }
                 if (!go) break;
@@ -1075,7 +1088,7 @@ __global__ __launch_bounds__(kVxT) void k_vox_centroids(const VoxJob *jobs, cons
         }
         if (head) {
             const float fc = (float)cnt;
-            gout[o + __popcll(hm & lt)] = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
+            gout[o + __popcll(hm & lt)] = make_float4(sx[u] / fc, sy[u] / fc, sz[u] / fc, si[u] / fc);
         }
         o += __popcll(hm);
     }
