@@ -208,9 +208,9 @@ def bench_map(args):
            "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32 clouds / f64 solve", "data": "synthetic",
            "config": {"workload": "S1 HDL-64 sequence, %d scans, laserMapping after laserOdometry (SURVEY 8f-1)" % n, "streams": B},
-           "roofline": {"bound": "hbm", "kernel": "per-frame kernel chain (k_voxel_cloud, k_cloud_grid, k_map_correspond, k_map_solve)",
+           "roofline": {"bound": "hbm", "kernel": "per-frame kernel chain (k_vox_* filter chain, k_grid_*, k_map_correspond, k_map_factor, k_map_solve)",
                         "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                        "note": "a frame is a chain of dependent single-workgroup launches (k_voxel_cloud 0.32 ms x 2, k_cloud_grid 0.26 ms, k_map_solve 0.13 ms x 2: profiles/r4/map_kernel_stats_1stream.csv) with four host read-backs (cube tables live on the host); latency of that chain, not a roofline measurement"},
+                        "note": "a frame is a chain of ~40 short dependent launches (k_map_solve 0.10 ms x 2, the two voxel filter chains 0.15 ms, correspond + factor 0.07 ms: profiles/r4/map_kernel_stats_1stream_end_of_round.csv) with two host waits (the cube tables live on the host); latency of that chain, not a roofline measurement"},
            "cpu_baseline": {"value": round(n / (ref["stage_ms"][1] * 1e-3), 2), "unit": "frames/s", "cores": 1, "kind": "port",
                             "sample": "the same %d scans, oracle/lo_mapping.c (-O3), 1 thread, mapping stage only" % n},
            "max_pose_diff_vs_cpu": float(np.abs(got - ref["poses"]).max()),
