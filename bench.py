@@ -183,13 +183,16 @@ def bench_map(args):
     batches = [batch] * B
     qs = [np.tile(odo[k, :4], (B, 1)) for k in range(n)]; ts = [np.tile(odo[k, 4:], (B, 1)) for k in range(n)]
 
+    sizes = np.zeros((n, 2), np.int64)     # per frame: map points of the neighbourhood, points of the cubes the update rebuilt
+
     def run():
         for m in mappers:
             m.reset()                      # fresh map per step
         out = np.zeros((n, 7))
         for k in range(n):
-            q, t, _ = lmono_amd.Mapper.process_batch(ctx, mappers, batches, [k] * B, qs[k], ts[k])
+            q, t, st = lmono_amd.Mapper.process_batch(ctx, mappers, batches, [k] * B, qs[k], ts[k])
             out[k, :4] = q[-1]; out[k, 4:] = t[-1]
+            sizes[k] = st[-1][6:8]
         return out
     for _ in range(args.warmup):
         run()
@@ -203,14 +206,20 @@ def bench_map(args):
     from oracle import oracle as O
     ref = O.run_mapping(x, off, odo)
     gt = O.gt_relative(traj)
+    # frame-level algorithmic bytes: every cloud element a frame has to move once -- scan clouds into the filter (16 B), neighbourhood
+    # gathered (16 B in + 16 B out), touched cubes rebuilt (16 B in + 16 B out); whole chain, not one kernel
+    cnt = batch.counts()
+    alg = 16.0 * (cnt[:n, 2].sum() + cnt[:n, 4].sum()) + 32.0 * sizes[:, 0].sum() + 32.0 * sizes[:, 1].sum()
+    gbs = alg * B * args.steps / el / 1e9
     out = {"metric": "laserMapping frames/sec (scan-to-map refinement, device-resident cube maps, independent streams in lock-step)",
            "value": round(n * B * args.steps / el, 1), "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32 clouds / f64 solve", "data": "synthetic",
            "config": {"workload": "S1 HDL-64 sequence, %d scans, laserMapping after laserOdometry (SURVEY 8f-1)" % n, "streams": B},
            "roofline": {"bound": "hbm", "kernel": "per-frame kernel chain (k_vox_* filter chain, k_grid_*, k_map_correspond, k_map_factor, k_map_solve)",
-                        "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                        "note": "a frame is a chain of ~40 short dependent launches (k_map_solve 0.10 ms x 2, the two voxel filter chains 0.15 ms, correspond + factor 0.07 ms: profiles/r4/map_kernel_stats_1stream_end_of_round.csv) with two host waits (the cube tables live on the host); latency of that chain, not a roofline measurement"},
+                        "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None,
+                        "algorithmic_bytes_per_frame": round(alg / n),
+                        "note": "whole-chain figure (bytes every cloud element must move once per frame / frame time), not one kernel's: a frame is a chain of ~40 short dependent launches (k_map_solve 0.10 ms x 2, the two voxel filter chains 0.15 ms, correspond + factor 0.07 ms: profiles/r4/map_kernel_stats_1stream_end_of_round.csv) with two host waits (the cube tables live on the host); latency of that chain, not a roofline measurement"},
            "cpu_baseline": {"value": round(n / (ref["stage_ms"][1] * 1e-3), 2), "unit": "frames/s", "cores": 1, "kind": "port",
                             "sample": "the same %d scans, oracle/lo_mapping.c (-O3), 1 thread, mapping stage only" % n},
            "max_pose_diff_vs_cpu": float(np.abs(got - ref["poses"]).max()),

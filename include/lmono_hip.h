@@ -324,7 +324,8 @@ int lmono_voxel_filter(lmono_ctx *, int n_clouds, const float *xyzi_h, const int
  * transformAssociateToMap, cube shifts, VoxelGrid of the scan clouds (mapping_line_resolution / _plane_resolution),
  * the optimisation block, transformUpdate, insertion of the scan into the cubes and re-filtering of the 5 x 5 x 3
  * neighbourhood.  q_wodom / t_wodom: laserOdometry's pose of the scan; q_w_curr / t_w_curr: aft_mapped_to_init.
- * stats (optional, [8]): edge blocks of the two outer iterations, plane blocks, LM iterations, 0, 0.
+ * stats (optional, [8]): edge blocks of the two outer iterations, plane blocks, LM iterations, then two sizes of the frame (for traffic
+ * accounting): map points of the 5 x 5 x 3 neighbourhood handed to the optimisation, points of the cubes the map update rebuilt.
  * A-LOAM laserMapping.cpp process(), source absent from the reference tree.          */
 typedef struct lmono_mapper lmono_mapper;
 lmono_mapper *lmono_mapper_create(lmono_ctx *, float line_res, float plane_res);      /* HDL-64 launch file: 0.4, 0.8 */

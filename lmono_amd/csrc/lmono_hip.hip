@@ -2173,7 +2173,11 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
         FrameState &f = F[(size_t)s];
         for (int k = 0; k < 4; k++) q_w_curr[4 * s + k] = f.x[k];
         for (int k = 0; k < 3; k++) t_w_curr[3 * s + k] = f.x[4 + k];
-        if (stats_h) for (int k = 0; k < 8; k++) stats_h[(size_t)s * 8 + k] = k < 6 ? stats[(size_t)s * 8 + k] : 0;
+        if (stats_h) {
+            for (int k = 0; k < 6; k++) stats_h[(size_t)s * 8 + k] = stats[(size_t)s * 8 + k];
+            stats_h[(size_t)s * 8 + 6] = f.n_map[0] + f.n_map[1];       // map points of the neighbourhood
+            stats_h[(size_t)s * 8 + 7] = 0;                             // points of the cubes the update rebuilds: added below
+        }
         const double *qo = q_wodom + 4 * s, *to = t_wodom + 3 * s;
         const double n2 = qo[0] * qo[0] + qo[1] * qo[1] + qo[2] * qo[2] + qo[3] * qo[3];
         const double qi[4] = { -qo[0] / n2, -qo[1] / n2, -qo[2] / n2, qo[3] / n2 };
@@ -2236,6 +2240,7 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
             for (int ind : f.valid) is_valid[(size_t)ind] = 0;
         }
     }
+    if (stats_h) for (const Touched &T : touched) stats_h[(size_t)T.s * 8 + 7] += T.n_in;
     // arena space (an output is never larger than its input); compaction reads only the tables, `cat` is already built
     {
         std::vector<int64_t> need((size_t)2 * n, 0);
