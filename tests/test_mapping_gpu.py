@@ -68,6 +68,23 @@ def test_refine_matches_oracle_blocks_and_pose(oracle, gpu_ctx, frames):
     assert np.array_equal(stack[acc, :3], np.array([[c.cp[0], c.cp[1], c.cp[2]] for c in corr], np.float32))
 
 
+def test_solve_cluster_sizes_agree(oracle, gpu_ctx, frames):
+    """k_map_solve runs as a cluster of K workgroups per stream, K chosen by the number of streams (8 for <= 16 streams down to 1 beyond 64): the
+    same frame as 1, 20, 40 and 72 streams must give the oracle's block counts, iteration counts and pose in every stream."""
+    f = frames[1]
+    xr, st, _ = oracle.map_refine(f["cmap"], f["smap"], f["cstack"], f["sstack"], f["x0"])
+    want = [st.n_edge[0], st.n_edge[1], st.n_plane[0], st.n_plane[1], st.lm_iters[0], st.lm_iters[1]]
+    first = None
+    for n in (1, 20, 40, 72):
+        poses, stats, _ = gpu_ctx.map_refine([f["cmap"]] * n, [f["smap"]] * n, [f["cstack"]] * n, [f["sstack"]] * n, np.tile(f["x0"], (n, 1)))
+        for s in range(n):
+            assert list(stats[s, :6]) == want, (n, s)
+        assert np.abs(poses - xr).max() < 1e-9, n
+        assert (poses == poses[0]).all(), n                 # every stream of a launch adds the same partial sums in the same order
+        first = poses[0] if first is None else first
+        assert np.abs(poses[0] - first).max() < 1e-12       # cluster sizes differ in summation order only
+
+
 def test_neighbours_are_the_exact_five_nearest(oracle, gpu_ctx, frames):
     f = frames[0]
     # zero LM effect on the check: compare against brute force at the FINAL pose by refining from the converged pose
