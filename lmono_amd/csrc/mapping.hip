@@ -297,6 +297,7 @@ __device__ __forceinline__ void top5_insert(float *td, int *ti, float d, int idx
 __global__ __launch_bounds__(256) void k_map_correspond(const MapStream *streams, int outer)
 {
     const MapStream S = streams[blockIdx.y];
+    __shared__ int s_pre[8][kGroup], s_cst[8][kGroup];
     int ns0, ns1;
     map_stack_sizes(S, ns0, ns1);
     const int nq = ns0 + ns1;
@@ -330,16 +331,35 @@ __global__ __launch_bounds__(256) void k_map_correspond(const MapStream *streams
         float td[5]; int ti[5];
 #pragma unroll
         for (int k = 0; k < 5; k++) { td[k] = __uint_as_float(0x7f800000u); ti[k] = 0x7fffffff; }
-        unsigned int m = group_ballot(cn > 0, gbase);
-        while (m) {
-            const int src = __ffs((int)m) - 1;
-            m &= m - 1;
-            const int s0 = __shfl(st, src, kGroup), n0 = __shfl(cn, src, kGroup);
-            for (int i = gl; i < n0; i += kGroup) {
-                const float4 c = S.sorted[which][s0 + i];
-                top5_insert(td, ti, dist2f(c.x, c.y, c.z, qx, qy, qz), __float_as_int(c.w));
+        // The candidates of the 27 cells as ONE list (round 4): an inclusive prefix of the cells' counts over the group's lanes, then lane l takes
+        // candidates l, l + 32, ... and finds each one's cell by bisection over the prefix (in LDS).  Cell by cell -- 32 lanes on a cell of 2 (surf,
+        // 0.8 m voxels) to 15 (corner) points -- a query was 27 dependent load rounds with most lanes idle; the list is 2 to 10.  Same candidates,
+        // and the top-5 order is by (distance, index): same neighbours.
+        int incl = cn;
+#pragma unroll
+        for (int o = 1; o < kGroup; o <<= 1) { const int v = __shfl_up(incl, o, kGroup); if (gl >= o) incl += v; }
+        const int total = __shfl(incl, kGroup - 1, kGroup);
+        int *pre = s_pre[threadIdx.x >> 5], *cst = s_cst[threadIdx.x >> 5];
+        pre[gl] = incl; cst[gl] = st - (incl - cn);          // candidate j of cell c sits at cst[c] + j
+        __builtin_amdgcn_wave_barrier();                     // one wave: its LDS operations execute in order
+        for (int j0 = gl; j0 < total; j0 += 2 * kGroup) {
+            int at[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int j = min(j0 + u * kGroup, total - 1);
+                int lo = 0;                                  // smallest cell whose inclusive prefix exceeds j
+#pragma unroll
+                for (int step = 16; step > 0; step >>= 1) lo += (lo + step <= 26 && pre[lo + step - 1] <= j) ? step : 0;
+                at[u] = cst[lo] + j;
             }
+            float4 cpt[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) cpt[u] = S.sorted[which][at[u]];
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+                if (j0 + u * kGroup < total) top5_insert(td, ti, dist2f(cpt[u].x, cpt[u].y, cpt[u].z, qx, qy, qz), __float_as_int(cpt[u].w));
         }
+        __builtin_amdgcn_wave_barrier();                     // the next query's prefix is written behind these reads
         // merge the lanes' lists: five rounds of "smallest head wins, its lane pops"
         float d5 = 0.f;
         bool full = true;
