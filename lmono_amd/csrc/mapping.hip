@@ -501,22 +501,23 @@ constexpr int kMsT = LMONO_MS_T;
 // rank order.  One workgroup alone was bound by the fp64 work of ~11 k residual blocks x <= 5 evaluations on a single CU (0.13 ms, twice per frame).
 struct MsCluster { int K, rank, eval; double *part; unsigned int *bar; int *fail; };
 
-__device__ __forceinline__ void ms_cluster_barrier(MsCluster &cl)
+// The barrier is wave 0's business alone: its lanes 0..27 hold the workgroup's partial sums, so only that wave releases (one L2 write-back, not
+// eight), lane 0 arrives and polls with RELAXED loads (an acquire per poll is a cache invalidate per poll), one acquire behind the loop, and the rest of
+// the workgroup waits at the workgroup barrier that follows in map_evaluate.
+__device__ __forceinline__ void ms_cluster_barrier_wave0(MsCluster &cl)
 {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // this workgroup's partial sums are visible device-wide before the arrival
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // the partial sums are visible device-wide before the arrival
     if (threadIdx.x == 0) {
         unsigned int *ctr = cl.bar + cl.eval;
-        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // every workgroup of the cluster is resident by construction (the host keeps clusters x K within half the CUs); the spin is bounded all the
         // same -- a wave that never finishes can take the whole GPU down: after a few seconds the solve is marked failed and the barrier opens
         int spins = 0;
-        while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)cl.K) {
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)cl.K) {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > (1 << 26)) { *cl.fail = 1; break; }
         }
     }
-    __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       // the other workgroups' partial sums are read with plain loads
 }
 
@@ -562,19 +563,17 @@ __device__ __forceinline__ void map_evaluate(const MapRec *rec, int n_edge, int 
         }
     }
     __syncthreads();
-    if (tid < 28 && (kJac || tid == 27)) {
+    if (wave == 0) {
+        const bool mine = tid < 28 && (kJac || tid == 27);
         double t = 0.0;
-        for (int w = 0; w < kMsT / 64; w++) t += s_red[w][tid];
-        if (cl.K > 1) cl.part[(cl.eval * cl.K + cl.rank) * 28 + tid] = t;
-        else s_sum[tid] = t;
-    }
-    if (cl.K > 1) {
-        ms_cluster_barrier(cl);
-        if (tid < 28 && (kJac || tid == 27)) {
-            double t = 0.0;
-            for (int w = 0; w < cl.K; w++) t += cl.part[(cl.eval * cl.K + w) * 28 + tid];
-            s_sum[tid] = t;
+        if (mine) for (int w = 0; w < kMsT / 64; w++) t += s_red[w][tid];
+        if (cl.K > 1) {
+            if (mine) cl.part[(cl.eval * cl.K + cl.rank) * 28 + tid] = t;
+            ms_cluster_barrier_wave0(cl);
+            t = 0.0;
+            if (mine) for (int w = 0; w < cl.K; w++) t += cl.part[(cl.eval * cl.K + w) * 28 + tid];
         }
+        if (mine) s_sum[tid] = t;
     }
     cl.eval++;
     __syncthreads();
@@ -691,7 +690,7 @@ __global__ __launch_bounds__(kMsT) void k_map_solve(const MapStream *streams, in
 static inline int map_solve_cluster(int n_streams)
 {
     static const int forced = [] { const char *e = getenv("LMONO_MAP_SOLVE_K"); return e ? atoi(e) : 0; }();        // measurement switch
-    int K = forced > 0 ? forced : kMsMaxK;
+    int K = forced > 0 ? forced : 4;          // one stream, K = 1 / 2 / 4 / 8: 1.57 / 1.71 / 1.98 / 1.83 k frames/s (3 .. 6 within noise of each other)
     if (K > kMsMaxK) K = kMsMaxK;
     const int groups = (n_streams + 7) / 8;
     while (K > 1 && groups * 8 * K > 128) K--;
