@@ -219,7 +219,7 @@ def bench_map(args):
            "roofline": {"bound": "hbm", "kernel": "per-frame kernel chain (k_vox_* filter chain, k_grid_*, k_map_correspond, k_map_factor, k_map_solve)",
                         "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None,
                         "algorithmic_bytes_per_frame": round(alg / n),
-                        "note": "whole-chain figure (bytes every cloud element must move once per frame / frame time), not one kernel's: a frame is a chain of ~40 short dependent launches (k_map_solve 0.10 ms x 2, the two voxel filter chains 0.15 ms, correspond + factor 0.07 ms: profiles/r4/map_kernel_stats_1stream_end_of_round.csv) with two host waits (the cube tables live on the host); latency of that chain, not a roofline measurement"},
+                        "note": "whole-chain figure (bytes every cloud element must move once per frame / frame time), not one kernel's: a frame is a chain of ~40 short dependent launches (k_map_solve 0.08 ms x 2, the two voxel filter chains 0.16 ms, correspond + factor 0.08 ms: profiles/r4/map_kernel_stats_1stream_end_of_round.csv) with two host waits (the cube tables live on the host); latency of that chain, not a roofline measurement"},
            "cpu_baseline": {"value": round(n / (ref["stage_ms"][1] * 1e-3), 2), "unit": "frames/s", "cores": 1, "kind": "port",
                             "sample": "the same %d scans, oracle/lo_mapping.c (-O3), 1 thread, mapping stage only" % n},
            "max_pose_diff_vs_cpu": float(np.abs(got - ref["poses"]).max()),
