@@ -1882,6 +1882,12 @@ struct JobScratch {
         return LMONO_OK;
     }
 };
+// a copy of n points as jobs of at most kCopyChunk points: one workgroup per job, and a 16 k-point cube in one workgroup was a 12-us kernel
+constexpr int kCopyChunk = 4096;
+static inline void push_copy(std::vector<CopyJob> &jobs, const float4 *src, float4 *dst, int n)
+{
+    for (int at = 0; at < n; at += kCopyChunk) jobs.push_back({ src + at, dst + at, std::min(kCopyChunk, n - at) });
+}
 // a voxel job table and its tile table in one upload: [VoxJob x n | int x tiles]; `blob` is the staging buffer (alive until the stream is waited for)
 int upload_vox_jobs(lmono_ctx *c, JobScratch &js, const std::vector<VoxJob> &jobs, std::vector<char> &blob, hipStream_t st)
 {
@@ -2059,7 +2065,7 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
                     const Seg &sg = m->cube[(size_t)t][(size_t)ind];
                     if (sg.n == 0) continue;
                     if (f.n_map[t] + sg.n > kMapNeighMax) { c->err = "lmono_mapper: neighbourhood holds more than 1 Mi points"; return LMONO_ECAPACITY; }
-                    jobs.push_back({ m->arena[t][m->half[t]] + sg.off, m->neigh[t] + f.n_map[t], sg.n });
+                    push_copy(jobs, m->arena[t][m->half[t]] + sg.off, m->neigh[t] + f.n_map[t], sg.n);
                     f.n_map[t] += sg.n;
                 }
             }
@@ -2222,7 +2228,7 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
                     const bool v = is_valid[(size_t)ind] != 0;
                     if (!((v && sg.n + add[(size_t)ind] > 0) || (!v && add[(size_t)ind] > 0))) continue;
                     cat_off[(size_t)ind] = at;
-                    if (sg.n > 0) copy.push_back({ m->arena[t][m->half[t]] + sg.off, m->cat[t] + at, sg.n });
+                    if (sg.n > 0) push_copy(copy, m->arena[t][m->half[t]] + sg.off, m->cat[t] + at, sg.n);
                     const int n_in = sg.n + add[(size_t)ind];
                     if (v && n_in > kVoxCloudMax) { c->err = "lmono_mapper: a cube holds more than 65536 points"; return LMONO_ECAPACITY; }
                     touched.push_back({ s, t, ind, n_in, at, v });
@@ -2279,7 +2285,7 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
             }
             vox.push_back(J); vox_t.push_back(k);
         } else {
-            keep.push_back({ m->cat[T.t] + T.cat_off, dst, T.n_in });
+            push_copy(keep, m->cat[T.t] + T.cat_off, dst, T.n_in);
         }
         m->bump[T.t] += T.n_in;
     }
