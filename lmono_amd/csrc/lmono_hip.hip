@@ -1867,19 +1867,8 @@ struct JobScratch {
     }
     int upload(lmono_ctx *c, const void *src, size_t bytes, hipStream_t st)
     {
-        used = (used + 255) & ~(size_t)255;
-        if (used + bytes > owner->jobs_bytes) {
-            void *q = nullptr;
-            size_t nb = owner->jobs_bytes;
-            while (nb < bytes || nb < 2 * (used + bytes)) nb <<= 1;
-            if (hipMalloc(&q, nb) != hipSuccess) { c->err = "lmono_mapper: job scratch allocation failed"; return LMONO_ENOMEM; }
-            owner->allocs.push_back(q);
-            owner->jobs = q; owner->jobs_bytes = nb; used = 0;
-        }
-        last = (char *)owner->jobs + used;
-        if (bytes > 0 && hipMemcpyAsync(last, src, bytes, hipMemcpyHostToDevice, st) != hipSuccess) { c->err = "lmono_mapper: job upload failed"; return LMONO_ENODEV; }
-        used += bytes;
-        return LMONO_OK;
+        const int rc = place(c, bytes);
+        return rc ? rc : send(c, src, bytes, st);
     }
 };
 // a copy of n points as jobs of at most kCopyChunk points: one workgroup per job, and a 16 k-point cube in one workgroup was a 12-us kernel
