@@ -1715,8 +1715,8 @@ struct lmono_mapper {
     size_t nout_cap = 0;
     // contiguous mail boxes of a batched call (owned by the first mapper, grown on demand): poses, counters, cube indices /
     // placements of all streams travel in one copy per phase
-    double *xbuf = nullptr; int *ibuf = nullptr; int *cubebuf = nullptr;
-    size_t xbuf_cap = 0, ibuf_cap = 0, cubebuf_cap = 0;
+    int *cubebuf = nullptr;
+    size_t cubebuf_cap = 0;
     double *x = nullptr;
     MapRec *rec = nullptr;
     int *nn_tmp = nullptr;          // [2 kMapStackMax][5]
@@ -2011,32 +2011,10 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
     tp[1] = tnow();
     // Round 4: the frame's first half is enqueued in one go -- the host does not wait for the voxel filter's counts before it launches the optimisation
     // (the kernels read them from the device, their launches are sized by the clouds' sizes before the filter and stride), it learns them from an event
-    // while the optimisation runs, enqueues the cube assignment behind the solve, and waits ONCE for poses, statistics and cube indices.
-    // ---- phase 2: VoxelGrid of the scan clouds (read in place from the scan batches), on the main stream
-    int *statbuf = nullptr;
-    if ((rc = pin_grow(c, ms[0], ms[0]->pin_i, ms[0]->pin_i_cap, (size_t)10 * n)) || (rc = pin_grow(c, ms[0], ms[0]->pin_x, ms[0]->pin_x_cap, (size_t)8 * n))) return rc;
-    int *ns_h = ms[0]->pin_i, *stats = ms[0]->pin_i + 2 * n;           // pinned: [n][2] filter counts, [n][8] statistics
-    double *xh = ms[0]->pin_x;
-    {
-        if ((rc = mp_grow(c, ms[0], ms[0]->ibuf, ms[0]->ibuf_cap, (size_t)26 * n)) || (rc = mp_grow(c, ms[0], ms[0]->xbuf, ms[0]->xbuf_cap, (size_t)8 * n))) return rc;
-        statbuf = ms[0]->ibuf + 2 * n;           // [n][8] behind the n_stack pairs, then the solves' cluster barriers [n][16]
-        std::vector<VoxJob> vj((size_t)2 * n);
-        for (int s = 0; s < n; s++)
-            for (int t = 0; t < 2; t++) {
-                lmono_mapper *m = ms[s];
-                VoxJob &J = vj[(size_t)2 * s + t];
-                J.in = t ? bs[s]->v.less_flat + bs[s]->off_h[(size_t)scans[s]] : bs[s]->v.less_sharp + (size_t)scans[s] * kMaxLessSharp;
-                J.n = F[(size_t)s].n_last[t]; J.inv_leaf = 1.0f / m->leaf[t]; J.out = m->stack[t]; J.n_out = ms[0]->ibuf + 2 * s + t;
-                J.key_a = m->vk[t]; J.key_b = m->vk[t] + kMapStackMax; J.idx_a = m->vi[t]; J.idx_b = m->vi[t] + kMapStackMax;
-                J.ws = m->vws[t];
-            }
-        if ((rc = upload_vox_jobs(c, js, vj, vox_blob, st))) return rc;
-        launch_voxel_jobs(st, (const VoxJob *)js.last, (const int *)((const char *)js.last + vj.size() * sizeof(VoxJob)), (int)((vox_blob.size() - vj.size() * sizeof(VoxJob)) / sizeof(int)), 4);
-        HIP_TRY(c, hipMemcpyAsync(ns_h, ms[0]->ibuf, sizeof(int) * 2 * (size_t)n, hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipEventRecord(ms[0]->ev_sizes, st));
-    }
-    // ---- phase 3, on the side stream (both are chains of short launches that leave most of the chip idle, and neither needs the other): map clouds of
-    // the neighbourhoods, concatenated in validInd order, and their grids for the streams whose map is large enough
+    // while the optimisation runs, enqueues the cube assignment behind the solve, and waits ONCE for poses, statistics and cube indices.  Everything the
+    // first half needs travels in ONE upload (the frame blob: poses, zeroed statistics and barrier counters, the filter's counts, all job tables).
+    // ---- phase 3 first, on the side stream (both are chains of short launches that leave most of the chip idle, and neither needs the other): map clouds
+    // of the neighbourhoods, concatenated in validInd order, and their grids for the streams whose map is large enough
     hipStream_t side = ms[0]->side;
     struct SideGuard {            // no return path leaves work on the side stream behind
         hipStream_t s;
@@ -2085,33 +2063,75 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
         }
         HIP_TRY(c, hipEventRecord(ms[0]->ev_side, side));
     }
-    tp[2] = tnow();
-    tp[3] = tp[2];
-    // ---- phase 4: optimisation (2 x [correspond + solve]) behind both streams, enqueued at once
+    // ---- the frame blob: [x 8n doubles | stats 8n | barriers 16n | filter counts 2n | VoxJob 2n | tile table | MapStream act | AssignJob 2n]
+    if ((rc = pin_grow(c, ms[0], ms[0]->pin_i, ms[0]->pin_i_cap, (size_t)2 * n)) || (rc = pin_grow(c, ms[0], ms[0]->pin_x, ms[0]->pin_x_cap, (size_t)12 * n))) return rc;
+    int *ns_h = ms[0]->pin_i;                                       // pinned: [n][2] filter counts
+    double *xh = ms[0]->pin_x;                                      // pinned: [n][8] poses, then [n][8] statistics (ints)
+    int *stats = (int *)(ms[0]->pin_x + (size_t)8 * n);
     for (size_t k = 0; k < (size_t)8 * n; k++) stats[k] = 0;
+    const double *x_d = nullptr;
+    const AssignJob *aj_d = nullptr;
+    int n_last_total = 0;
     {
-        for (int s = 0; s < n; s++) for (int k = 0; k < 8; k++) xh[(size_t)8 * s + k] = F[(size_t)s].x[k];
-        unsigned int *barbuf = (unsigned int *)(statbuf + 8 * n);
-        HIP_TRY(c, hipMemcpyAsync(ms[0]->xbuf, xh, sizeof(double) * 8 * (size_t)n, hipMemcpyHostToDevice, st));
-        HIP_TRY(c, hipMemsetAsync(statbuf, 0, sizeof(int) * 24 * (size_t)n, st));
+        std::vector<VoxJob> vj((size_t)2 * n);
+        std::vector<int> tab;
+        std::vector<MapStream> S(act.size());
+        std::vector<AssignJob> aj((size_t)2 * n);
+        for (int s = 0; s < n; s++) n_last_total += F[(size_t)s].n_last[0] + F[(size_t)s].n_last[1];
+        if ((rc = mp_grow(c, ms[0], ms[0]->cubebuf, ms[0]->cubebuf_cap, (size_t)n_last_total + 1))) return rc;
+        // sizes first: the tile table needs the jobs' sizes only
+        for (int s = 0; s < n; s++) for (int t = 0; t < 2; t++) vj[(size_t)2 * s + t].n = F[(size_t)s].n_last[t];
+        vox_tile_table(vj.data(), vj.size(), tab);
+        auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
+        const size_t o_x = 0, o_stats = o_x + sizeof(double) * 8 * (size_t)n, o_bar = o_stats + sizeof(int) * 8 * (size_t)n, o_ns = o_bar + sizeof(int) * 16 * (size_t)n,
+                     o_vox = al(o_ns + sizeof(int) * 2 * (size_t)n), o_tab = al(o_vox + vj.size() * sizeof(VoxJob)), o_S = al(o_tab + tab.size() * sizeof(int)),
+                     o_aj = al(o_S + S.size() * sizeof(MapStream)), bytes = o_aj + aj.size() * sizeof(AssignJob);
+        if ((rc = js.place(c, bytes))) return rc;
+        char *base = (char *)js.last;
+        double *xb = (double *)(base + o_x);
+        int *statbuf = (int *)(base + o_stats), *nsb = (int *)(base + o_ns);
+        unsigned int *barbuf = (unsigned int *)(base + o_bar);
+        x_d = xb; aj_d = (const AssignJob *)(base + o_aj);
+        for (int s = 0; s < n; s++)
+            for (int t = 0; t < 2; t++) {
+                lmono_mapper *m = ms[s];
+                VoxJob &J = vj[(size_t)2 * s + t];
+                J.in = t ? bs[s]->v.less_flat + bs[s]->off_h[(size_t)scans[s]] : bs[s]->v.less_sharp + (size_t)scans[s] * kMaxLessSharp;
+                J.inv_leaf = 1.0f / m->leaf[t]; J.out = m->stack[t]; J.n_out = nsb + 2 * s + t;
+                J.key_a = m->vk[t]; J.key_b = m->vk[t] + kMapStackMax; J.idx_a = m->vi[t]; J.idx_b = m->vi[t] + kMapStackMax;
+                J.ws = m->vws[t];
+                aj[(size_t)2 * s + t] = { m->stack[t], 0, nsb, 2 * s + t, xb + 8 * s, m->cen[0], m->cen[1], m->cen[2], m->newpts[t], ms[0]->cubebuf };
+            }
+        int max_nq = 0;        // upper bound: the clouds before the filter
+        for (size_t a = 0; a < act.size(); a++) {
+            lmono_mapper *m = ms[act[a]];
+            FrameState &f = F[(size_t)act[a]];
+            for (int t = 0; t < 2; t++) {
+                S[a].cell[t] = m->cells[t]; S[a].sorted[t] = m->sorted[t]; S[a].cloud[t] = m->neigh[t]; S[a].mask[t] = m->masks + t; S[a].n_map[t] = f.n_map[t];
+                S[a].stack[t] = m->stack[t]; S[a].n_stack[t] = 0;
+            }
+            S[a].n_stack_d = nsb + 2 * act[a];
+            S[a].rec = m->rec; S[a].x = xb + 8 * act[a]; S[a].stats = statbuf + 8 * act[a]; S[a].nn_out = nullptr; S[a].nn_tmp = m->nn_tmp;
+            S[a].part = m->solve_part; S[a].bar = barbuf + 16 * act[a];
+            max_nq = std::max(max_nq, f.n_last[0] + f.n_last[1]);
+        }
+        vox_blob.assign(bytes, 0);                                   // statistics, barrier counters and filter counts start at zero
+        for (int s = 0; s < n; s++) for (int k = 0; k < 8; k++) ((double *)(vox_blob.data() + o_x))[(size_t)8 * s + k] = F[(size_t)s].x[k];
+        memcpy(vox_blob.data() + o_vox, vj.data(), vj.size() * sizeof(VoxJob));
+        if (!tab.empty()) memcpy(vox_blob.data() + o_tab, tab.data(), tab.size() * sizeof(int));
+        if (!S.empty()) memcpy(vox_blob.data() + o_S, S.data(), S.size() * sizeof(MapStream));
+        memcpy(vox_blob.data() + o_aj, aj.data(), aj.size() * sizeof(AssignJob));
+        if ((rc = js.send(c, vox_blob.data(), bytes, st))) return rc;
+        // ---- phase 2: VoxelGrid of the scan clouds (read in place from the scan batches), on the main stream
+        launch_voxel_jobs(st, (const VoxJob *)(base + o_vox), (const int *)(base + o_tab), (int)tab.size(), 4);
+        HIP_TRY(c, hipMemcpyAsync(ns_h, nsb, sizeof(int) * 2 * (size_t)n, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipEventRecord(ms[0]->ev_sizes, st));
+        tp[2] = tnow();
+        tp[3] = tp[2];
+        // ---- phase 4: optimisation (2 x [correspond + solve]) behind both streams, enqueued at once
         HIP_TRY(c, hipStreamWaitEvent(st, ms[0]->ev_side, 0));
         if (!act.empty()) {
-            std::vector<MapStream> S(act.size());
-            int max_nq = 0;        // upper bound: the clouds before the filter
-            for (size_t a = 0; a < act.size(); a++) {
-                lmono_mapper *m = ms[act[a]];
-                FrameState &f = F[(size_t)act[a]];
-                for (int t = 0; t < 2; t++) {
-                    S[a].cell[t] = m->cells[t]; S[a].sorted[t] = m->sorted[t]; S[a].cloud[t] = m->neigh[t]; S[a].mask[t] = m->masks + t; S[a].n_map[t] = f.n_map[t];
-                    S[a].stack[t] = m->stack[t]; S[a].n_stack[t] = 0;
-                }
-                S[a].n_stack_d = ms[0]->ibuf + 2 * act[a];
-                S[a].rec = m->rec; S[a].x = ms[0]->xbuf + 8 * act[a]; S[a].stats = statbuf + 8 * act[a]; S[a].nn_out = nullptr; S[a].nn_tmp = m->nn_tmp;
-                S[a].part = m->solve_part; S[a].bar = barbuf + 16 * act[a];
-                max_nq = std::max(max_nq, f.n_last[0] + f.n_last[1]);
-            }
-            if ((rc = js.upload(c, S.data(), S.size() * sizeof(MapStream), st))) return rc;
-            const MapStream *S_d = (const MapStream *)js.last;
+            const MapStream *S_d = (const MapStream *)(base + o_S);
             // the filter keeps a fraction of a scan cloud: a quarter of the bound's blocks (at least 256 per stream while few streams run) stride over the rest
             const int per_stream = std::max(1, std::max((max_nq + 31) / 32, std::min((max_nq + 7) / 8, (int)(2048 / act.size()))));
             for (int outer = 0; outer < 2; outer++) {
@@ -2127,30 +2147,20 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
     HIP_TRY(c, hipEventSynchronize(ms[0]->ev_sizes));
     for (int s = 0; s < n; s++) { F[(size_t)s].n_stack[0] = ns_h[(size_t)2 * s]; F[(size_t)s].n_stack[1] = ns_h[(size_t)2 * s + 1]; }
     for (int s = 0; s < n; s++) if (F[(size_t)s].n_stack[0] < 0 || F[(size_t)s].n_stack[1] < 0) { c->err = "lmono_mapper: voxel filter rejected a scan cloud"; return LMONO_ECAPACITY; }
-    // ---- phase 5: pointAssociateToMap + cube index of every stack point with the refined pose, behind the solve; then the one wait
+    // ---- phase 5: pointAssociateToMap + cube index of every stack point with the refined pose, behind the solve (its table went up with the blob: sizes
+    // and the dense layout of the cube indices come from the device-side counts); then the one wait
     {
         size_t total = 0;
         int max_n = 0;
         std::vector<size_t> at((size_t)2 * n);
         for (int s = 0; s < n; s++) for (int t = 0; t < 2; t++) { at[(size_t)2 * s + t] = total; total += (size_t)F[(size_t)s].n_stack[t]; max_n = std::max(max_n, F[(size_t)s].n_stack[t]); }
-        if ((rc = mp_grow(c, ms[0], ms[0]->cubebuf, ms[0]->cubebuf_cap, total + 1))) return rc;
-        std::vector<AssignJob> aj((size_t)2 * n);
-        for (int s = 0; s < n; s++)
-            for (int t = 0; t < 2; t++) {
-                lmono_mapper *m = ms[s];
-                aj[(size_t)2 * s + t] = { m->stack[t], F[(size_t)s].n_stack[t], nullptr, ms[0]->xbuf + 8 * s, m->cen[0], m->cen[1], m->cen[2], m->newpts[t], ms[0]->cubebuf + at[(size_t)2 * s + t] };
-            }
         if ((rc = pin_grow(c, ms[0], ms[0]->pin_cube, ms[0]->pin_cube_cap, total + 1))) return rc;
         int *cube_all = ms[0]->pin_cube;
         if (max_n > 0) {
-            if ((rc = js.upload(c, aj.data(), aj.size() * sizeof(AssignJob), st))) return rc;
-            hipLaunchKernelGGL(k_map_assign, dim3((max_n + 255) / 256, 2 * n), dim3(256), 0, st, (const AssignJob *)js.last);
+            hipLaunchKernelGGL(k_map_assign, dim3((max_n + 255) / 256, 2 * n), dim3(256), 0, st, aj_d);
             HIP_TRY(c, hipMemcpyAsync(cube_all, ms[0]->cubebuf, sizeof(int) * total, hipMemcpyDeviceToHost, st));
         }
-        if (!act.empty()) {
-            HIP_TRY(c, hipMemcpyAsync(xh, ms[0]->xbuf, sizeof(double) * 8 * (size_t)n, hipMemcpyDeviceToHost, st));
-            HIP_TRY(c, hipMemcpyAsync(stats, statbuf, sizeof(int) * 8 * (size_t)n, hipMemcpyDeviceToHost, st));
-        }
+        if (!act.empty()) HIP_TRY(c, hipMemcpyAsync(xh, x_d, sizeof(double) * 8 * (size_t)n + sizeof(int) * 8 * (size_t)n, hipMemcpyDeviceToHost, st));      // poses + statistics: adjacent in the blob
         HIP_TRY(c, hipStreamSynchronize(st));
         tp[4] = tnow();
         for (int s : act) if (stats[(size_t)s * 8 + 6]) { c->err = "lmono_mapper: a solve's cluster barrier timed out"; return LMONO_ENODEV; }

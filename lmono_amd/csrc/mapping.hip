@@ -1157,13 +1157,20 @@ __global__ __launch_bounds__(256) void k_copy_jobs(const CopyJob *jobs)
 // pointAssociateToMap of every down-sampled scan point with the refined pose (double transform stored in a float point,
 // intensity kept) and the cube it falls into: cube = int((v + 25) / 50) + cen, one lower when v + 25 < 0.
 // One job per (stream, cloud type); blockIdx.y = job.
-struct AssignJob { const float4 *stack; int n; const int *n_d; const double *x; int cen_w, cen_h, cen_d; float4 *out; int *cube; };   // n_d set: the size is read from the device
+// n_all set: the job's size is n_all[job] (read from the device: the voxel filter's counts) and its cube indices start at cube + sum of the sizes of
+// the jobs before it (dense, in job order); otherwise n and cube are used as they are
+struct AssignJob { const float4 *stack; int n; const int *n_all; int job; const double *x; int cen_w, cen_h, cen_d; float4 *out; int *cube; };
 
 __global__ __launch_bounds__(256) void k_map_assign(const AssignJob *jobs)
 {
     const AssignJob J = jobs[blockIdx.y];
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= (J.n_d ? *J.n_d : J.n)) return;
+    int n = J.n, base = 0;
+    if (J.n_all) {
+        n = J.n_all[J.job];
+        for (int j = 0; j < J.job; j++) base += max(J.n_all[j], 0);       // (uniform: scalar loads)
+    }
+    if (i >= n) return;
     const float4 p = J.stack[i];
     const double *x = J.x;
     double rx, ry, rz;
@@ -1174,7 +1181,7 @@ __global__ __launch_bounds__(256) void k_map_assign(const AssignJob *jobs)
     if ((double)s.x + 25.0 < 0) ci--;
     if ((double)s.y + 25.0 < 0) cj--;
     if ((double)s.z + 25.0 < 0) ck--;
-    J.cube[i] = (ci >= 0 && ci < 21 && cj >= 0 && cj < 21 && ck >= 0 && ck < 11) ? ci + 21 * cj + 441 * ck : -1;
+    J.cube[base + i] = (ci >= 0 && ci < 21 && cj >= 0 && cj < 21 && ck >= 0 && ck < 11) ? ci + 21 * cj + 441 * ck : -1;
 }
 
 // dst[pos[i]] = src[i] for pos[i] >= 0; one job per (stream, cloud type); blockIdx.y = job
