@@ -2209,16 +2209,31 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
         std::vector<char> is_valid((size_t)kMapCubes, 0);
         std::vector<int> add((size_t)kMapCubes, 0), fill((size_t)kMapCubes, 0), cand;
         std::vector<int64_t> cat_off((size_t)kMapCubes, -1);
+        struct Run { int ind, at, len; };
+        std::vector<Run> runs;
         for (int s = 0; s < n; s++) {
             lmono_mapper *m = ms[s];
             FrameState &f = F[(size_t)s];
             for (int ind : f.valid) is_valid[(size_t)ind] = 1;
             for (int t = 0; t < 2; t++) {
                 // candidates in ascending cube order: the neighbourhood and every other cube a new point falls into
+                // (the stack is in voxel order: neighbours in it mostly share a cube -- the per-point work is done per RUN of equal cube indices)
                 cand.assign(f.valid.begin(), f.valid.end());
-                for (int i = 0; i < f.n_stack[t]; i++) {
-                    const int ind = f.cube_h[t][(size_t)i];
-                    if (ind >= 0 && add[(size_t)ind]++ == 0 && !is_valid[(size_t)ind]) cand.push_back(ind);
+                runs.clear();
+                {
+                    const int *ch = f.cube_h[t].data();
+                    const int ns = f.n_stack[t];
+                    for (int i = 0; i < ns;) {
+                        const int ind = ch[i];
+                        int e = i + 1;
+                        while (e < ns && ch[e] == ind) e++;
+                        if (ind >= 0) {
+                            runs.push_back({ ind, i, e - i });
+                            if (add[(size_t)ind] == 0 && !is_valid[(size_t)ind]) cand.push_back(ind);
+                            add[(size_t)ind] += e - i;
+                        }
+                        i = e;
+                    }
                 }
                 std::sort(cand.begin(), cand.end());
                 int64_t at = 0;
@@ -2235,9 +2250,10 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
                 }
                 if (at > (int64_t)kMapNeighMax + kMapStackMax) { c->err = "lmono_mapper: frame touches more points than the workspace holds"; return LMONO_ECAPACITY; }
                 int *ph = pos_all.data() + pos_at[(size_t)2 * s + t];
-                for (int i = 0; i < f.n_stack[t]; i++) {
-                    const int ind = f.cube_h[t][(size_t)i];
-                    if (ind >= 0) ph[i] = (int)(cat_off[(size_t)ind] + m->cube[(size_t)t][(size_t)ind].n + fill[(size_t)ind]++);
+                for (const Run &r : runs) {
+                    const int p0 = (int)(cat_off[(size_t)r.ind] + m->cube[(size_t)t][(size_t)r.ind].n + fill[(size_t)r.ind]);
+                    fill[(size_t)r.ind] += r.len;
+                    for (int k = 0; k < r.len; k++) ph[r.at + k] = p0 + k;
                 }
                 for (int ind : cand) { add[(size_t)ind] = 0; fill[(size_t)ind] = 0; cat_off[(size_t)ind] = -1; }
                 sj[(size_t)2 * s + t] = { m->newpts[t], nullptr, f.n_stack[t], m->cat[t] };       // .pos: set when the blob is placed
@@ -2246,6 +2262,7 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
         }
     }
     if (stats_h) for (const Touched &T : touched) stats_h[(size_t)T.s * 8 + 7] += T.n_in;
+    const double tpa = tnow();
     // arena space (an output is never larger than its input); compaction reads only the tables, `cat` is already built
     {
         std::vector<int64_t> need((size_t)2 * n, 0);
@@ -2327,6 +2344,7 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
         }
         if (!keep.empty()) hipLaunchKernelGGL(k_copy_jobs, dim3((unsigned)keep.size()), dim3(256), 0, st, (const CopyJob *)(base + o_keep));
     }
+    const double tpb = tnow();
     HIP_TRY(c, hipStreamSynchronize(st));       // ONE wait for the frame's map update: filter sizes are back, `cat` and the job tables are free
     for (size_t k = 0; k < touched.size(); k++) {
         const Touched &T = touched[k];
@@ -2343,7 +2361,7 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
     rc = check_launch(c, "mapper kernels");
     if (rc) return rc;
     undo.committed = true;
-    if (prof) fprintf(stderr, "MAPPROF n=%d ms: host1 %.2f voxel %.2f gather %.2f optimise %.2f assign %.2f update %.2f\n", n, tp[1] - tp[0], tp[2] - tp[1], tp[3] - tp[2], tp[4] - tp[3], tp[5] - tp[4], tp[6] - tp[5]);
+    if (prof) fprintf(stderr, "MAPPROF n=%d ms: host1 %.2f voxel %.2f gather %.2f optimise %.2f assign %.2f update %.2f (plan %.2f tables+launch %.2f wait %.2f)\n", n, tp[1] - tp[0], tp[2] - tp[1], tp[3] - tp[2], tp[4] - tp[3], tp[5] - tp[4], tp[6] - tp[5], tpa - tp[5], tpb - tpa, tp[6] - tpb);
     if (prof) {
         int mx = 0, n_small = 0; long sum = 0;
         for (const VoxJob &J : vox) { mx = std::max(mx, J.n); sum += J.n; n_small += J.n <= 2048; }
