@@ -1694,8 +1694,8 @@ struct lmono_mapper {
     std::vector<Seg> cube[2];
     std::vector<void *> allocs;
     std::vector<void *> pinned;                 // hipHostMalloc'ed mail boxes
-    int *pin_i = nullptr; double *pin_x = nullptr; int *pin_cube = nullptr; int *pin_nout = nullptr;
-    size_t pin_i_cap = 0, pin_x_cap = 0, pin_cube_cap = 0, pin_nout_cap = 0;
+    int *pin_i = nullptr; double *pin_x = nullptr; int *pin_cube = nullptr; int *pin_nout = nullptr; char *pin_blob = nullptr;
+    size_t pin_i_cap = 0, pin_x_cap = 0, pin_cube_cap = 0, pin_nout_cap = 0, pin_blob_cap = 0;
     float4 *arena[2][2] = { { nullptr, nullptr }, { nullptr, nullptr } };   // [type][half]
     int half[2] = { 0, 0 };
     int64_t bump[2] = { 0, 0 };
@@ -1945,7 +1945,7 @@ struct FrameState {            // one stream's frame
     std::vector<int> valid;
     int n_last[2], n_stack[2], n_map[2];
     bool solve;
-    std::vector<int> cube_h[2];
+    const int *cube_h[2] = { nullptr, nullptr };       // cube index of every stack point: into the pinned read-back
 };
 }
 
@@ -1968,7 +1968,6 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
     undo.u.reserve((size_t)n);
     for (int s = 0; s < n; s++) undo.u.emplace_back(ms[s]);
     // staging vectors of asynchronous copies live until the function returns (every path syncs the stream before that)
-    std::vector<int> pos_all;
     std::vector<ScatterJob> sj;
     std::vector<char> vox_blob;
     const bool prof = getenv("LMONO_MAP_PROF") != nullptr;
@@ -2168,8 +2167,8 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
         for (int s = 0; s < n; s++)
             for (int t = 0; t < 2; t++) {
                 const int ns = F[(size_t)s].n_stack[t];
-                F[(size_t)s].cube_h[t].assign(cube_all + at[(size_t)2 * s + t], cube_all + at[(size_t)2 * s + t] + ns);
-                if (ns == 0) F[(size_t)s].cube_h[t].assign(1, -1);
+                (void)ns;
+                F[(size_t)s].cube_h[t] = cube_all + at[(size_t)2 * s + t];
             }
     }
     // results, transformUpdate (host)
@@ -2203,7 +2202,12 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
     int max_ns = 0;
     std::vector<size_t> pos_at((size_t)2 * n);
     for (int s = 0; s < n; s++) for (int t = 0; t < 2; t++) { pos_at[(size_t)2 * s + t] = pos_total; pos_total += (size_t)F[(size_t)s].n_stack[t]; max_ns = std::max(max_ns, F[(size_t)s].n_stack[t]); }
-    pos_all.assign(pos_total + 1, -1);
+    // the update's tables travel in ONE upload from a pinned staging buffer, the placements first (they are written straight into it):
+    // [pos | CopyJob x copy | ScatterJob x 2 n | VoxJob x vox | tile table | CopyJob x keep]; the tables behind the placements are bounded per stream
+    auto al16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t o_copy = al16((pos_total + 1) * sizeof(int)), tables_cap = (size_t)n * (96 << 10);
+    if ((rc = pin_grow(c, ms[0], ms[0]->pin_blob, ms[0]->pin_blob_cap, o_copy + tables_cap))) return rc;
+    int *pos_all = (int *)ms[0]->pin_blob;
     sj.resize((size_t)2 * n);
     {
         std::vector<char> is_valid((size_t)kMapCubes, 0);
@@ -2220,8 +2224,9 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
                 // (the stack is in voxel order: neighbours in it mostly share a cube -- the per-point work is done per RUN of equal cube indices)
                 cand.assign(f.valid.begin(), f.valid.end());
                 runs.clear();
+                int *ph = pos_all + pos_at[(size_t)2 * s + t];
                 {
-                    const int *ch = f.cube_h[t].data();
+                    const int *ch = f.cube_h[t];
                     const int ns = f.n_stack[t];
                     for (int i = 0; i < ns;) {
                         const int ind = ch[i];
@@ -2231,7 +2236,8 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
                             runs.push_back({ ind, i, e - i });
                             if (add[(size_t)ind] == 0 && !is_valid[(size_t)ind]) cand.push_back(ind);
                             add[(size_t)ind] += e - i;
-                        }
+                        } else
+                            for (int k = i; k < e; k++) ph[k] = -1;        // outside the cube array: not placed
                         i = e;
                     }
                 }
@@ -2249,7 +2255,6 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
                     at += n_in;
                 }
                 if (at > (int64_t)kMapNeighMax + kMapStackMax) { c->err = "lmono_mapper: frame touches more points than the workspace holds"; return LMONO_ECAPACITY; }
-                int *ph = pos_all.data() + pos_at[(size_t)2 * s + t];
                 for (const Run &r : runs) {
                     const int p0 = (int)(cat_off[(size_t)r.ind] + m->cube[(size_t)t][(size_t)r.ind].n + fill[(size_t)r.ind]);
                     fill[(size_t)r.ind] += r.len;
@@ -2318,24 +2323,24 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
         }
         for (size_t k = 0; k < vox.size(); k++) vox[k].n_out = ms[0]->nout_big + k;
     }
-    // ONE upload for the whole update: [CopyJob x copy | pos | ScatterJob x 2 n | VoxJob x vox | tile table | CopyJob x keep]
+    // ONE upload for the whole update (layout above)
     {
         std::vector<int> tab;
         vox_tile_table(vox.data(), vox.size(), tab);
-        auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
-        const size_t o_copy = 0, o_pos = al(o_copy + copy.size() * sizeof(CopyJob)), o_sj = al(o_pos + pos_total * sizeof(int)), o_vox = al(o_sj + sj.size() * sizeof(ScatterJob)),
+        auto al = al16;
+        const size_t o_pos = 0, o_sj = al(o_copy + copy.size() * sizeof(CopyJob)), o_vox = al(o_sj + sj.size() * sizeof(ScatterJob)),
                      o_tab = al(o_vox + vox.size() * sizeof(VoxJob)), o_keep = al(o_tab + tab.size() * sizeof(int)), bytes = o_keep + keep.size() * sizeof(CopyJob);
+        if (bytes > o_copy + tables_cap) { c->err = "lmono_mapper: the update's job tables exceed their staging bound"; return LMONO_ECAPACITY; }
         if ((rc = js.place(c, bytes))) return rc;
         const char *base = (const char *)js.last;
         for (int s = 0; s < n; s++) for (int t = 0; t < 2; t++) sj[(size_t)2 * s + t].pos = (const int *)(base + o_pos) + pos_at[(size_t)2 * s + t];
-        vox_blob.resize(bytes);
-        if (!copy.empty()) memcpy(vox_blob.data() + o_copy, copy.data(), copy.size() * sizeof(CopyJob));
-        if (pos_total) memcpy(vox_blob.data() + o_pos, pos_all.data(), pos_total * sizeof(int));
-        memcpy(vox_blob.data() + o_sj, sj.data(), sj.size() * sizeof(ScatterJob));
-        if (!vox.empty()) memcpy(vox_blob.data() + o_vox, vox.data(), vox.size() * sizeof(VoxJob));
-        if (!tab.empty()) memcpy(vox_blob.data() + o_tab, tab.data(), tab.size() * sizeof(int));
-        if (!keep.empty()) memcpy(vox_blob.data() + o_keep, keep.data(), keep.size() * sizeof(CopyJob));
-        if ((rc = js.send(c, vox_blob.data(), bytes, st))) return rc;
+        char *stage = ms[0]->pin_blob;
+        if (!copy.empty()) memcpy(stage + o_copy, copy.data(), copy.size() * sizeof(CopyJob));
+        memcpy(stage + o_sj, sj.data(), sj.size() * sizeof(ScatterJob));
+        if (!vox.empty()) memcpy(stage + o_vox, vox.data(), vox.size() * sizeof(VoxJob));
+        if (!tab.empty()) memcpy(stage + o_tab, tab.data(), tab.size() * sizeof(int));
+        if (!keep.empty()) memcpy(stage + o_keep, keep.data(), keep.size() * sizeof(CopyJob));
+        if ((rc = js.send(c, stage, bytes, st))) return rc;
         if (!copy.empty()) hipLaunchKernelGGL(k_copy_jobs, dim3((unsigned)copy.size()), dim3(256), 0, st, (const CopyJob *)(base + o_copy));
         if (max_ns > 0) hipLaunchKernelGGL(k_scatter_pos, dim3((max_ns + 255) / 256, 2 * n), dim3(256), 0, st, (const ScatterJob *)(base + o_sj));
         if (!vox.empty()) {
