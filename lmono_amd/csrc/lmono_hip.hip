@@ -41,6 +41,9 @@ struct lmono_ctx {
     struct Chunk { char *base; size_t cap; };
     std::vector<Chunk> arena;
     size_t arena_chunk = 0, arena_off = 0;
+    char *stage = nullptr;                   // pinned staging of DevBuf's small uploads (stage_all: every buffer ever allocated, freed with the context)
+    size_t stage_cap = 0;
+    std::vector<void *> stage_all;
 
     hipEvent_t *next_set()
     {
@@ -148,6 +151,7 @@ extern "C" void lmono_destroy(lmono_ctx *c)
     if (c->stats_d) (void)hipFree(c->stats_d);
     for (auto &s : c->gstream) if (s) (void)hipStreamDestroy(s);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    for (void *h : c->stage_all) (void)hipHostFree(h);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     for (auto &ch : c->arena) (void)hipFree(ch.base);
     for (auto &e : c->gev) if (e) (void)hipEventDestroy(e);
@@ -1312,11 +1316,27 @@ extern "C" int lmono_ba_batch_read(lmono_ctx *c, lmono_ba_batch *b, double *pose
 namespace {
 // Scratch of one ABI call, carved from the context's arena (released when the scope ends; the chunks stay).  Uploads are asynchronous on
 // the context stream: nothing here touches the null stream or synchronises the device, so two contexts on two host threads overlap.
+// Round 4: small uploads are STAGED -- copied into the context's pinned staging buffer at the same spacing as their device allocations and sent by
+// ready() as one copy per run of adjacent allocations (the per-feature calls of a frame made ~25 separate pageable uploads, each a staged, host-blocking
+// copy of its own).  Every user calls ready() behind its last up() and before its first launch.  A call's staged bytes are consumed before the call
+// returns (every call ends waiting for its results), so the next call may overwrite them.
 struct DevBuf {
     lmono_ctx *c;
     size_t chunk0, off0;
     bool used = false;
+    static constexpr size_t kStageMax = (size_t)256 << 10;      // larger uploads (clouds) go directly
+    char *run_dst = nullptr;         // device address of the pending run's first byte
+    size_t run_at = 0, run_bytes = 0, stage_used = 0;
     explicit DevBuf(lmono_ctx *c_) : c(c_), chunk0(c_ ? c_->arena_chunk : 0), off0(c_ ? c_->arena_off : 0) {}
+    bool send_run()
+    {
+        if (run_bytes == 0) return true;
+        const bool sent = hipMemcpyAsync(run_dst, c->stage + run_at, run_bytes, hipMemcpyHostToDevice, c->stream) == hipSuccess;
+        run_dst = nullptr; run_bytes = 0;
+        return sent;
+    }
+    // every staged upload is on its way (call once, behind the last up() and before the first launch)
+    void ready(bool &ok) { if (c && !send_run()) ok = false; }
     // the scratch goes back to the arena only once nothing queued on the stream can still touch it (a no-op wait on the normal path,
     // where the call has already waited for its results; it matters on the early error returns)
     ~DevBuf() { if (c) { if (used) (void)hipStreamSynchronize(c->stream); c->arena_chunk = chunk0; c->arena_off = off0; } }
@@ -1336,7 +1356,24 @@ struct DevBuf {
         }
         char *q = c->arena[c->arena_chunk].base + c->arena_off;
         c->arena_off += bytes;
-        if (src && n > 0 && hipMemcpyAsync(q, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream) != hipSuccess) ok = false;
+        if (!src || n == 0) { if (!send_run()) ok = false; return (T *)q; }        // scratch: the run of adjacent uploads ends here
+        if (bytes > kStageMax) {
+            if (!send_run() || hipMemcpyAsync(q, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream) != hipSuccess) ok = false;
+            return (T *)q;
+        }
+        if (stage_used + bytes > c->stage_cap) {
+            // grow: the old buffer may still be read by a copy in flight, so it is kept until the context is destroyed (a handful of doublings at most)
+            if (!send_run()) ok = false;
+            size_t cap = c->stage_cap ? 2 * c->stage_cap : (size_t)4 << 20;
+            while (cap < bytes) cap <<= 1;
+            void *h = nullptr;
+            if (hipHostMalloc(&h, cap, hipHostMallocDefault) != hipSuccess) { ok = false; return nullptr; }
+            c->stage_all.push_back(h); c->stage = (char *)h; c->stage_cap = cap; stage_used = 0;
+        }
+        if (run_bytes > 0 && q != run_dst + run_bytes) { if (!send_run()) ok = false; }       // not adjacent on the device (a new arena chunk)
+        if (run_bytes == 0) { run_dst = q; run_at = stage_used; }
+        memcpy(c->stage + stage_used, src, n * sizeof(T));
+        stage_used += bytes; run_bytes += bytes;
         return (T *)q;
     }
 };
@@ -1360,6 +1397,7 @@ static int feat_setup(lmono_ctx *c, DevBuf &db, FeatBatch &B, int n_windows, con
     B.depth = db.up(depth, (size_t)F, ok);
     B.solve_flag = db.up((const int *)nullptr, (size_t)F, ok); B.score = db.up((const double *)nullptr, (size_t)F, ok);
     B.x = nullptr; B.cand = nullptr;
+    db.ready(ok);
     if (!ok) { c->err = "per-feature kernels: device allocation / upload failed"; return LMONO_ENOMEM; }
     return LMONO_OK;
 }
@@ -1413,6 +1451,7 @@ extern "C" int lmono_shift_depth(lmono_ctx *c, const double *back_R0, const doub
     memcpy(poses, back_R0, 72); memcpy(poses + 9, back_P0, 24); memcpy(poses + 12, R1, 72); memcpy(poses + 21, P1, 24); memcpy(poses + 24, tlc, 128);
     DevBuf db(c); bool ok = true;
     double *pd = db.up(poses, 40, ok), *pt = db.up(pt_i_h, (size_t)n * 2, ok), *d = db.up(depth_h, (size_t)n, ok), *o = db.up((const double *)nullptr, (size_t)n, ok);
+    db.ready(ok);
     if (!ok) { c->err = "lmono_shift_depth: device allocation / upload failed"; return LMONO_ENOMEM; }
     hipLaunchKernelGGL(k_shift_depth, dim3((n + 127) / 128), dim3(128), 0, c->stream, (const double *)pd, n, (const double *)pt, (const double *)d, o);
     int rc = check_launch(c, "k_shift_depth");
@@ -1457,6 +1496,7 @@ extern "C" int lmono_marginalize(lmono_ctx *c, int n_windows, const int *feat_of
     B.laser01 = db.up(laser01_h, (size_t)n_windows * 24, ok); B.info = db.up(info, (size_t)40, ok);
     B.lin_J = db.up((const double *)nullptr, (size_t)n_windows * kMargN * kMargN, ok); B.lin_r = db.up((const double *)nullptr, (size_t)n_windows * kMargN, ok);
     B.status = db.up((const int *)nullptr, (size_t)n_windows, ok);
+    db.ready(ok);
     if (!ok) { c->err = "lmono_marginalize: device allocation / upload failed"; return LMONO_ENOMEM; }
     hipLaunchKernelGGL(k_marginalize, dim3(n_windows), dim3(256), sizeof(MargLds), c->stream, B);
     int rc = check_launch(c, "k_marginalize");
@@ -1476,6 +1516,7 @@ extern "C" int lmono_marg_evaluate(lmono_ctx *c, int n_windows, const double *li
     const double *J = db.up(lin_J_h, (size_t)n_windows * kMargN * kMargN, ok), *r = db.up(lin_r_h, (size_t)n_windows * kMargN, ok);
     const double *x0 = db.up(x0_h, (size_t)n_windows * 77, ok), *x = db.up(x_h, (size_t)n_windows * 77, ok);
     double *res = db.up((const double *)nullptr, (size_t)n_windows * kMargN, ok);
+    db.ready(ok);
     if (!ok) { c->err = "lmono_marg_evaluate: device allocation / upload failed"; return LMONO_ENOMEM; }
     hipLaunchKernelGGL(k_marg_evaluate, dim3(n_windows), dim3(128), 0, c->stream, n_windows, J, r, x0, x, res);
     int rc = check_launch(c, "k_marg_evaluate");
@@ -1501,6 +1542,7 @@ extern "C" int lmono_marg_second_new(lmono_ctx *c, int n_windows, int n_blocks, 
     B.x0 = db.up(x0_h, W * n_blocks * 7, ok); B.x = db.up(x_h, W * n_blocks * 7, ok);
     B.out_J = db.up((const double *)nullptr, W * n * n, ok); B.out_r = db.up((const double *)nullptr, W * n, ok);
     B.status = db.up((const int *)nullptr, W, ok);
+    db.ready(ok);
     if (!ok) { c->err = "lmono_marg_second_new: device allocation / upload failed"; return LMONO_ENOMEM; }
     hipLaunchKernelGGL(k_marg_second_new, dim3(n_windows), dim3(256), sizeof(Marg2Lds), c->stream, B);
     int rc = check_launch(c, "k_marg_second_new");
@@ -1553,6 +1595,7 @@ extern "C" int lmono_map_refine(lmono_ctx *c, int n_streams,
     int *stats_d = db.up(zero.data(), (size_t)n_streams * 8, ok);
     unsigned int *bar_d = (unsigned int *)db.up(zero.data(), (size_t)n_streams * 16, ok);          // cluster barriers of the two solves, zeroed
     double *part_d = db.up((const double *)nullptr, (size_t)n_streams * kMsEvals * kMsMaxK * 28, ok);
+    db.ready(ok);
     if (!ok) { c->err = "lmono_map_refine: device allocation / upload failed"; return LMONO_ENOMEM; }
     std::vector<CloudJob> jobs((size_t)2 * n_streams);
     std::vector<MapStream> st((size_t)n_streams);
@@ -1581,6 +1624,7 @@ extern "C" int lmono_map_refine(lmono_ctx *c, int n_streams,
     }
     CloudJob *jobs_d = db.up(jobs.data(), jobs.size(), ok);
     MapStream *st_d = db.up(st.data(), st.size(), ok);
+    db.ready(ok);
     if (!ok) { c->err = "lmono_map_refine: device allocation / upload failed"; return LMONO_ENOMEM; }
     hipStream_t stream = c->stream;
     struct Events {             // destroyed on every return path
@@ -1657,6 +1701,7 @@ extern "C" int lmono_voxel_filter(lmono_ctx *c, int n_clouds, const float *xyzi_
     std::vector<int> tab;
     vox_tile_table(jobs.data(), jobs.size(), tab);
     int *tab_d = db.up(tab.data(), tab.size(), ok);
+    db.ready(ok);
     if (!ok) { c->err = "lmono_voxel_filter: device allocation / upload failed"; return LMONO_ENOMEM; }
     launch_voxel_jobs(c->stream, (const VoxJob *)jobs_d, tab_d, (int)tab.size(), 4);
     int rc = check_launch(c, "voxel filter kernels");
