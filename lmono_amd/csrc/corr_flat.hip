@@ -92,7 +92,7 @@ struct CfLds {
     float4 q[kCfT];                           // de-skewed feature points
     unsigned long long best[kCfT];            // nearest point: (d2 bits) << 32 | index << 7 | line (the low word is the index copy's .w)
     unsigned long long same[kCfT], other[kCfT];
-    int closest[kCfT], wlo[kCfT], whi[kCfT], ra[kCfT];
+    int closest[kCfT], wlo[kCfT], whi[kCfT];  // closest: index << 7 | line of the nearest point (the walk's centre line rides in the low bits)
     unsigned int req[kCfPool];
     CfRun pool[kCfPool];
     int n_pool, n_cand, wsum[kCfT / 64];
@@ -266,7 +266,7 @@ __device__ __forceinline__ void cf_sweep(CfLds &L, int n_edge_owner, const int *
                 owner = ow_c[bb]; m0 = ~0ull; m1 = ~0ull;
                 const float4 qq = L.q[owner];
                 qx = qq.x; qy = qq.y; qz = qq.z;
-                if (kWalk) { closest = L.closest[owner]; w_lo = L.wlo[owner]; w_span = (unsigned int)(L.whi[owner] - w_lo); ra = L.ra[owner]; }
+                if (kWalk) { const int cr = L.closest[owner]; closest = cr >> 7; ra = cr & 127; w_lo = L.wlo[owner]; w_span = (unsigned int)(L.whi[owner] - w_lo); }
             }
 #pragma unroll
             for (int u = 0; u < kCfC; u++) {
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(kCfT, LMONO_CF_WAVES) void k_corr_flat(BatchView b,
     const int closest = (int)((unsigned int)(nn & 0xffffffffull) >> 7);
     const int ra = (int)(nn & 127ull);
     if (walking) {
-        L.closest[tid] = closest; L.ra[tid] = ra;
+        L.closest[tid] = (closest << 7) | ra;
         L.wlo[tid] = ra - 3 >= 0 ? L.lle[cl][ra - 3] + 1 : 0;
         L.whi[tid] = ra + 3 <= 65 ? L.fge[cl][ra + 3] : n_last;
     }
