@@ -208,27 +208,27 @@ __global__ __launch_bounds__(256) void k_depth_refine(FeatBatch B)
         model = bsum(model); bad = bmax(bad);
         if (bad > 0 || !(model > 0.0)) { if (++invalid >= 5) break; radius *= 0.5; reuse = true; continue; }
         invalid = 0;
-        double sn = 0, cc = 0;
+        // the candidate is evaluated WITH its Jacobian sums (round 4): an accepted step -- the usual case -- is the next linearisation, which was a
+        // second pass over the same observations computing the same residuals (same arithmetic: the cost, and with it every decision, is unchanged)
+        double sn = 0, cc = 0, hh[kSlots], gg[kSlots];
         for (int m = 0; m < kSlots; m++) {
             const int f = f0 + tid + 256 * m;
             cand[m] = x[m] + step[m] * scale[m];
+            hh[m] = 0; gg[m] = 0;
             if (act[m]) sn += (cand[m] - x[m]) * (cand[m] - x[m]);
-            double hh, gg;
-            if (f < f1) cc += refine_feature<false>(B, f, Rs, Ps, tlc, cand[m], hh, gg);
+            if (f < f1) cc += refine_feature<true>(B, f, Rs, Ps, tlc, cand[m], hh[m], gg[m]);
         }
         sn = sqrt(bsum(sn)); cc = bsum(cc);
         if (sn <= parameter_tol * (x_norm + parameter_tol)) break;
         if (fabs(x_cost - cc) <= function_tol * x_cost) break;
         const double rel = (x_cost - cc) / model;
         if (rel > min_rel) {
-            double c1 = 0; xn = 0; gm = 0;
+            xn = 0; gm = 0;
             for (int m = 0; m < kSlots; m++) {
-                const int f = f0 + tid + 256 * m;
-                x[m] = cand[m];
-                if (f < f1) c1 += refine_feature<true>(B, f, Rs, Ps, tlc, x[m], h[m], g[m]);
+                x[m] = cand[m]; h[m] = hh[m]; g[m] = gg[m];
                 if (act[m]) { xn += x[m] * x[m]; gm = fmax(gm, fabs(g[m])); }
             }
-            x_cost = bsum(c1); x_norm = sqrt(bsum(xn)); gmax = bmax(gm);
+            x_cost = cc; x_norm = sqrt(bsum(xn)); gmax = bmax(gm);
             const double t = 2.0 * rel - 1.0;
             double den = 1.0 - t * t * t; if (den < 1.0 / 3.0) den = 1.0 / 3.0;
             radius = radius / den; if (radius > 1e16) radius = 1e16;
