@@ -50,6 +50,7 @@ struct MargLds {
     double A[36], SAi[36], bp[6], u[6], br[kMargN];
     double cs[2 * 33];
     double red[8];
+    int pq[2 * 33];
     int flag;
 };
 
@@ -93,6 +94,61 @@ __device__ void pinv6(const double *Ain, double *out, double eps, int *degenerat
         const double w = M[k * 6 + k];
         if (!(w > eps)) { *degenerate = 1; continue; }
         for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) out[i * 6 + j] += Vv[i * 6 + k] * Vv[j * 6 + k] / w;
+    }
+}
+
+// Parallel (round-robin) Jacobi eigen-decomposition of the symmetric n x n matrix H (n even, leading dimension n) in LDS, eigenvectors accumulated
+// in V: n - 1 rounds of n / 2 disjoint rotations per sweep, until the off-diagonal mass is below 1e-30 of the diagonal's.  256 threads.
+// Round 4: a round is TWO phases instead of three -- the rotation angles, then every 2 x 2 block {p_a, q_a} x {p_b, q_b} of H takes pair b's column
+// rotation and pair a's row rotation in one go (column first, then row: the same operations in the same order as the two passes over the whole
+// matrix they replace, so the result is the same bit for bit), next to the column rotation of V.  One barrier and a third of the LDS traffic less.
+__device__ __forceinline__ void marg_jacobi(double *H, double *V, int n, double *cs, int *pq, double *red, int tid)
+{
+    const int N1 = n - 1, half = n / 2;
+    for (int sweep = 0; sweep < 40; sweep++) {
+        double offn = 0, dia = 0;
+        for (int k = tid; k < n * n; k += 256) { const int a = k / n, bb = k % n; const double v = H[k]; if (a == bb) dia += v * v; else if (a < bb) offn += v * v; }
+        offn = wave_sum_d(offn); dia = wave_sum_d(dia);
+        __syncthreads();
+        if ((tid & 63) == 0) { red[tid >> 6] = offn; red[4 + (tid >> 6)] = dia; }
+        __syncthreads();
+        offn = red[0] + red[1] + red[2] + red[3]; dia = red[4] + red[5] + red[6] + red[7];
+        if (offn <= 1e-30 * dia || offn == 0.0) break;
+        for (int rnd = 0; rnd < N1; rnd++) {
+            if (tid < half) {
+                const int p0 = tid == 0 ? N1 : (rnd + tid) % N1, q0 = tid == 0 ? rnd : (rnd - tid + N1) % N1;
+                const int p = min(p0, q0), q = max(p0, q0);
+                const double apq = H[p * n + q];
+                double c = 1.0, s = 0.0;
+                if (apq != 0.0) {
+                    const double theta = (H[q * n + q] - H[p * n + p]) / (2.0 * apq);
+                    const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    c = 1.0 / sqrt(t * t + 1.0); s = t * c;
+                }
+                cs[2 * tid] = c; cs[2 * tid + 1] = s;
+                pq[2 * tid] = p; pq[2 * tid + 1] = q;
+            }
+            __syncthreads();
+            // H <- R^T (H R), block by block
+            for (int k = tid; k < half * half; k += 256) {
+                const int a = k / half, b = k % half;
+                const int pa = pq[2 * a], qa = pq[2 * a + 1], pb = pq[2 * b], qb = pq[2 * b + 1];
+                const double ca = cs[2 * a], sa = cs[2 * a + 1], cb = cs[2 * b], sb = cs[2 * b + 1];
+                const double x0 = H[pa * n + pb], y0 = H[pa * n + qb], x1 = H[qa * n + pb], y1 = H[qa * n + qb];
+                const double t0 = cb * x0 - sb * y0, u0 = sb * x0 + cb * y0, t1 = cb * x1 - sb * y1, u1 = sb * x1 + cb * y1;      // columns p_b, q_b
+                H[pa * n + pb] = ca * t0 - sa * t1; H[qa * n + pb] = sa * t0 + ca * t1;                                            // rows p_a, q_a
+                H[pa * n + qb] = ca * u0 - sa * u1; H[qa * n + qb] = sa * u0 + ca * u1;
+            }
+            // V <- V R
+            for (int k = tid; k < half * n; k += 256) {
+                const int pr = k / n, i = k % n;
+                const int p = pq[2 * pr], q = pq[2 * pr + 1];
+                const double c = cs[2 * pr], s = cs[2 * pr + 1];
+                const double va = V[i * n + p], vb = V[i * n + q];
+                V[i * n + p] = c * va - s * vb; V[i * n + q] = s * va + c * vb;
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -232,53 +288,7 @@ __global__ __launch_bounds__(256) void k_marginalize(MargBatch Bt)
     for (int k = tid; k < kMargN * kMargN; k += 256) L.V[k] = (k / kMargN == k % kMargN) ? 1.0 : 0.0;
     __syncthreads();
     // ---- parallel Jacobi eigen-decomposition of Hrr (66x66): 65 rounds of 33 disjoint rotations per sweep
-    for (int sweep = 0; sweep < 40; sweep++) {
-        double offn = 0, dia = 0;
-        for (int k = tid; k < kMargN * kMargN; k += 256) { const int a = k / kMargN, bb = k % kMargN; const double v = L.Hrr[k]; if (a == bb) dia += v * v; else if (a < bb) offn += v * v; }
-        offn = wave_sum_d(offn); dia = wave_sum_d(dia);
-        __syncthreads();
-        if ((tid & 63) == 0) { L.red[tid >> 6] = offn; L.red[4 + (tid >> 6)] = dia; }
-        __syncthreads();
-        offn = L.red[0] + L.red[1] + L.red[2] + L.red[3]; dia = L.red[4] + L.red[5] + L.red[6] + L.red[7];
-        if (offn <= 1e-30 * dia || offn == 0.0) break;
-        for (int rnd = 0; rnd < 65; rnd++) {
-            if (tid < 33) {
-                const int p0 = tid == 0 ? 65 : (rnd + tid) % 65, q0 = tid == 0 ? rnd : (rnd - tid + 65) % 65;
-                const int p = min(p0, q0), q = max(p0, q0);
-                const double apq = L.Hrr[p * kMargN + q];
-                double c = 1.0, s = 0.0;
-                if (apq != 0.0) {
-                    const double theta = (L.Hrr[q * kMargN + q] - L.Hrr[p * kMargN + p]) / (2.0 * apq);
-                    const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                    c = 1.0 / sqrt(t * t + 1.0); s = t * c;
-                }
-                L.cs[2 * tid] = c; L.cs[2 * tid + 1] = s;
-            }
-            __syncthreads();
-            // columns: (H, V) <- (H, V) R
-            for (int k = tid; k < 33 * kMargN; k += 256) {
-                const int pr = k / kMargN, i = k % kMargN;
-                const int p0 = pr == 0 ? 65 : (rnd + pr) % 65, q0 = pr == 0 ? rnd : (rnd - pr + 65) % 65;
-                const int p = min(p0, q0), q = max(p0, q0);
-                const double c = L.cs[2 * pr], s = L.cs[2 * pr + 1];
-                const double a = L.Hrr[i * kMargN + p], bb = L.Hrr[i * kMargN + q];
-                L.Hrr[i * kMargN + p] = c * a - s * bb; L.Hrr[i * kMargN + q] = s * a + c * bb;
-                const double va = L.V[i * kMargN + p], vb = L.V[i * kMargN + q];
-                L.V[i * kMargN + p] = c * va - s * vb; L.V[i * kMargN + q] = s * va + c * vb;
-            }
-            __syncthreads();
-            // rows: H <- R^T H
-            for (int k = tid; k < 33 * kMargN; k += 256) {
-                const int pr = k / kMargN, i = k % kMargN;
-                const int p0 = pr == 0 ? 65 : (rnd + pr) % 65, q0 = pr == 0 ? rnd : (rnd - pr + 65) % 65;
-                const int p = min(p0, q0), q = max(p0, q0);
-                const double c = L.cs[2 * pr], s = L.cs[2 * pr + 1];
-                const double a = L.Hrr[p * kMargN + i], bb = L.Hrr[q * kMargN + i];
-                L.Hrr[p * kMargN + i] = c * a - s * bb; L.Hrr[q * kMargN + i] = s * a + c * bb;
-            }
-            __syncthreads();
-        }
-    }
+    marg_jacobi(L.Hrr, L.V, kMargN, L.cs, L.pq, L.red, tid);
     // linearized_jacobians = sqrt(S) V^T, linearized_residuals = sqrt(S^-1) V^T b'
     for (int k = tid; k < kMargN * kMargN; k += 256) {
         const int e = k / kMargN, i = k % kMargN;
@@ -342,7 +352,7 @@ struct Marg2Lds {
     double r[kMargN], b[kMargN], dx[kMargN], br[kMargN];
     double Hmm[36], Hinv[36];
     double cs[2 * 33], red[8];
-    int perm[kMargN], flag;
+    int perm[kMargN], pq[2 * 33], flag;
 };
 
 __global__ __launch_bounds__(256) void k_marg_second_new(Marg2Batch Bt)
@@ -410,52 +420,7 @@ __global__ __launch_bounds__(256) void k_marg_second_new(Marg2Batch Bt)
     for (int k = tid; k < n * n; k += 256) L.A[k] = (k / n == k % n) ? 1.0 : 0.0;
     __syncthreads();
     // parallel Jacobi (round-robin tournament over n = even): n - 1 rounds of n / 2 disjoint rotations per sweep
-    const int N1 = n - 1, half = n / 2;
-    for (int sweep = 0; sweep < 40; sweep++) {
-        double offn = 0, dia = 0;
-        for (int k = tid; k < n * n; k += 256) { const int a = k / n, bb = k % n; const double v = L.H[k]; if (a == bb) dia += v * v; else if (a < bb) offn += v * v; }
-        offn = wave_sum_d(offn); dia = wave_sum_d(dia);
-        __syncthreads();
-        if ((tid & 63) == 0) { L.red[tid >> 6] = offn; L.red[4 + (tid >> 6)] = dia; }
-        __syncthreads();
-        offn = L.red[0] + L.red[1] + L.red[2] + L.red[3]; dia = L.red[4] + L.red[5] + L.red[6] + L.red[7];
-        if (offn <= 1e-30 * dia || offn == 0.0) break;
-        for (int rnd = 0; rnd < N1; rnd++) {
-            if (tid < half) {
-                const int p0 = tid == 0 ? N1 : (rnd + tid) % N1, q0 = tid == 0 ? rnd : (rnd - tid + N1) % N1;
-                const int p = min(p0, q0), q = max(p0, q0);
-                const double apq = L.H[p * n + q];
-                double c = 1.0, s = 0.0;
-                if (apq != 0.0) {
-                    const double theta = (L.H[q * n + q] - L.H[p * n + p]) / (2.0 * apq);
-                    const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                    c = 1.0 / sqrt(t * t + 1.0); s = t * c;
-                }
-                L.cs[2 * tid] = c; L.cs[2 * tid + 1] = s;
-            }
-            __syncthreads();
-            for (int k = tid; k < half * n; k += 256) {
-                const int pr = k / n, i = k % n;
-                const int p0 = pr == 0 ? N1 : (rnd + pr) % N1, q0 = pr == 0 ? rnd : (rnd - pr + N1) % N1;
-                const int p = min(p0, q0), q = max(p0, q0);
-                const double c = L.cs[2 * pr], s = L.cs[2 * pr + 1];
-                const double a = L.H[i * n + p], bb = L.H[i * n + q];
-                L.H[i * n + p] = c * a - s * bb; L.H[i * n + q] = s * a + c * bb;
-                const double va = L.A[i * n + p], vb = L.A[i * n + q];
-                L.A[i * n + p] = c * va - s * vb; L.A[i * n + q] = s * va + c * vb;
-            }
-            __syncthreads();
-            for (int k = tid; k < half * n; k += 256) {
-                const int pr = k / n, i = k % n;
-                const int p0 = pr == 0 ? N1 : (rnd + pr) % N1, q0 = pr == 0 ? rnd : (rnd - pr + N1) % N1;
-                const int p = min(p0, q0), q = max(p0, q0);
-                const double c = L.cs[2 * pr], s = L.cs[2 * pr + 1];
-                const double a = L.H[p * n + i], bb = L.H[q * n + i];
-                L.H[p * n + i] = c * a - s * bb; L.H[q * n + i] = s * a + c * bb;
-            }
-            __syncthreads();
-        }
-    }
+    marg_jacobi(L.H, L.A, n, L.cs, L.pq, L.red, tid);
     for (int k = tid; k < n * n; k += 256) {
         const int e = k / n, i = k % n;
         const double wv = L.H[e * n + e];
