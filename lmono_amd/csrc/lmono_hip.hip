@@ -1498,7 +1498,7 @@ extern "C" int lmono_marginalize(lmono_ctx *c, int n_windows, const int *feat_of
     B.status = db.up((const int *)nullptr, (size_t)n_windows, ok);
     db.ready(ok);
     if (!ok) { c->err = "lmono_marginalize: device allocation / upload failed"; return LMONO_ENOMEM; }
-    hipLaunchKernelGGL(k_marginalize, dim3(n_windows), dim3(256), sizeof(MargLds), c->stream, B);
+    hipLaunchKernelGGL(k_marginalize, dim3(n_windows), dim3(kMgT), sizeof(MargLds), c->stream, B);
     int rc = check_launch(c, "k_marginalize");
     if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(lin_J_h, B.lin_J, sizeof(double) * (size_t)n_windows * kMargN * kMargN, hipMemcpyDeviceToHost, c->stream));
@@ -1544,7 +1544,7 @@ extern "C" int lmono_marg_second_new(lmono_ctx *c, int n_windows, int n_blocks, 
     B.status = db.up((const int *)nullptr, W, ok);
     db.ready(ok);
     if (!ok) { c->err = "lmono_marg_second_new: device allocation / upload failed"; return LMONO_ENOMEM; }
-    hipLaunchKernelGGL(k_marg_second_new, dim3(n_windows), dim3(256), sizeof(Marg2Lds), c->stream, B);
+    hipLaunchKernelGGL(k_marg_second_new, dim3(n_windows), dim3(kMgT), sizeof(Marg2Lds), c->stream, B);
     int rc = check_launch(c, "k_marg_second_new");
     if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(lin_J_out_h, B.out_J, sizeof(double) * W * n * n, hipMemcpyDeviceToHost, c->stream));

@@ -18,6 +18,10 @@
 namespace lmono {
 
 constexpr int kMargN = 66;
+#ifndef LMONO_MG_T
+#define LMONO_MG_T 512      // 256 / 512 / 1024: Estimator loop 283 / 287 / 287 frames/s with overlapped, 201 / 220 / 213 with inline marginalisation
+#endif
+constexpr int kMgT = LMONO_MG_T;       // threads of the two marginalisation kernels
 constexpr int kMargMaxF0 = 160;        // >= the tracker's MAX_CNT = 150 features per frame (FeatureTracker.cc:21), all of which can be anchored at frame 0
 
 struct MargBatch {
@@ -49,7 +53,7 @@ struct MargLds {
     double D[kMargMaxF0], bd[kMargMaxF0];
     double A[36], SAi[36], bp[6], u[6], br[kMargN];
     double cs[2 * 33];
-    double red[8];
+    double red[2 * 16];
     int pq[2 * 33];
     int flag;
 };
@@ -98,7 +102,7 @@ __device__ void pinv6(const double *Ain, double *out, double eps, int *degenerat
 }
 
 // Parallel (round-robin) Jacobi eigen-decomposition of the symmetric n x n matrix H (n even, leading dimension n) in LDS, eigenvectors accumulated
-// in V: n - 1 rounds of n / 2 disjoint rotations per sweep, until the off-diagonal mass is below 1e-30 of the diagonal's.  256 threads.
+// in V: n - 1 rounds of n / 2 disjoint rotations per sweep, until the off-diagonal mass is below 1e-30 of the diagonal's.  kMgT threads.
 // Round 4: a round is TWO phases instead of three -- the rotation angles, then every 2 x 2 block {p_a, q_a} x {p_b, q_b} of H takes pair b's column
 // rotation and pair a's row rotation in one go (column first, then row: the same operations in the same order as the two passes over the whole
 // matrix they replace, so the result is the same bit for bit), next to the column rotation of V.  One barrier and a third of the LDS traffic less.
@@ -107,12 +111,13 @@ __device__ __forceinline__ void marg_jacobi(double *H, double *V, int n, double 
     const int N1 = n - 1, half = n / 2;
     for (int sweep = 0; sweep < 40; sweep++) {
         double offn = 0, dia = 0;
-        for (int k = tid; k < n * n; k += 256) { const int a = k / n, bb = k % n; const double v = H[k]; if (a == bb) dia += v * v; else if (a < bb) offn += v * v; }
+        for (int k = tid; k < n * n; k += kMgT) { const int a = k / n, bb = k % n; const double v = H[k]; if (a == bb) dia += v * v; else if (a < bb) offn += v * v; }
         offn = wave_sum_d(offn); dia = wave_sum_d(dia);
         __syncthreads();
-        if ((tid & 63) == 0) { red[tid >> 6] = offn; red[4 + (tid >> 6)] = dia; }
+        if ((tid & 63) == 0) { red[tid >> 6] = offn; red[kMgT / 64 + (tid >> 6)] = dia; }
         __syncthreads();
-        offn = red[0] + red[1] + red[2] + red[3]; dia = red[4] + red[5] + red[6] + red[7];
+        offn = 0.0; dia = 0.0;
+        for (int wv = 0; wv < kMgT / 64; wv++) { offn += red[wv]; dia += red[kMgT / 64 + wv]; }
         if (offn <= 1e-30 * dia || offn == 0.0) break;
         for (int rnd = 0; rnd < N1; rnd++) {
             if (tid < half) {
@@ -130,7 +135,7 @@ __device__ __forceinline__ void marg_jacobi(double *H, double *V, int n, double 
             }
             __syncthreads();
             // H <- R^T (H R), block by block
-            for (int k = tid; k < half * half; k += 256) {
+            for (int k = tid; k < half * half; k += kMgT) {
                 const int a = k / half, b = k % half;
                 const int pa = pq[2 * a], qa = pq[2 * a + 1], pb = pq[2 * b], qb = pq[2 * b + 1];
                 const double ca = cs[2 * a], sa = cs[2 * a + 1], cb = cs[2 * b], sb = cs[2 * b + 1];
@@ -140,7 +145,7 @@ __device__ __forceinline__ void marg_jacobi(double *H, double *V, int n, double 
                 H[pa * n + qb] = ca * u0 - sa * u1; H[qa * n + qb] = sa * u0 + ca * u1;
             }
             // V <- V R
-            for (int k = tid; k < half * n; k += 256) {
+            for (int k = tid; k < half * n; k += kMgT) {
                 const int pr = k / n, i = k % n;
                 const int p = pq[2 * pr], q = pq[2 * pr + 1];
                 const double c = cs[2 * pr], s = cs[2 * pr + 1];
@@ -152,7 +157,7 @@ __device__ __forceinline__ void marg_jacobi(double *H, double *V, int n, double 
     }
 }
 
-__global__ __launch_bounds__(256) void k_marginalize(MargBatch Bt)
+__global__ __launch_bounds__(kMgT) void k_marginalize(MargBatch Bt)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     MargLds &L = *reinterpret_cast<MargLds *>(smem_raw);
@@ -161,11 +166,11 @@ __global__ __launch_bounds__(256) void k_marginalize(MargBatch Bt)
     const double *poses = Bt.poses + (size_t)w * 77, *ex = Bt.ex + (size_t)w * 7;
     const double *laser_info = Bt.info, *mono_info = Bt.info + 36;
     const double eps = 1e-8;
-    for (int k = tid; k < kMargN * kMargN; k += 256) L.Hrr[k] = 0.0;
-    for (int k = tid; k < F0 * kMargN; k += 256) L.Wd[k] = 0.0;
-    for (int k = tid; k < 6 * kMargN; k += 256) L.Wp[k] = 0.0;
-    for (int k = tid; k < 6 * F0; k += 256) L.B[k] = 0.0;
-    for (int k = tid; k < F0; k += 256) { L.D[k] = 0.0; L.bd[k] = 0.0; }
+    for (int k = tid; k < kMargN * kMargN; k += kMgT) L.Hrr[k] = 0.0;
+    for (int k = tid; k < F0 * kMargN; k += kMgT) L.Wd[k] = 0.0;
+    for (int k = tid; k < 6 * kMargN; k += kMgT) L.Wp[k] = 0.0;
+    for (int k = tid; k < 6 * F0; k += kMgT) L.B[k] = 0.0;
+    for (int k = tid; k < F0; k += kMgT) { L.D[k] = 0.0; L.bd[k] = 0.0; }
     if (tid < 36) L.A[tid] = 0.0;
     if (tid < 6) L.bp[tid] = 0.0;
     if (tid < kMargN) L.br[tid] = 0.0;
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(256) void k_marginalize(MargBatch Bt)
             }
         }
     }
-    for (int f = tid; f < F0; f += 256) {
+    for (int f = tid; f < F0; f += kMgT) {
         double Df = 0, bdf = 0, Bf[6] = { 0, 0, 0, 0, 0, 0 }, Wx[6] = { 0, 0, 0, 0, 0, 0 };
         for (int o = Bt.feat_obs_off[f0 + f]; o < Bt.feat_obs_off[f0 + f + 1]; o++) {
             const int j = Bt.obs_j[o];
@@ -234,7 +239,7 @@ __global__ __launch_bounds__(256) void k_marginalize(MargBatch Bt)
     }
     __syncthreads();
     // D^+ (eps cut), S_A = A - B D^+ B^T, G = W_p - B D^+ W_d, u = bp - B D^+ bd
-    for (int f = tid; f < F0; f += 256) { const double d = L.D[f]; if (!(d > eps)) L.flag = 1; L.D[f] = d > eps ? 1.0 / d : 0.0; }
+    for (int f = tid; f < F0; f += kMgT) { const double d = L.D[f]; if (!(d > eps)) L.flag = 1; L.D[f] = d > eps ? 1.0 / d : 0.0; }
     __syncthreads();
     if (tid < 36) {
         const int a = tid / 6, bb = tid % 6;
@@ -248,17 +253,17 @@ __global__ __launch_bounds__(256) void k_marginalize(MargBatch Bt)
         for (int f = 0; f < F0; f++) acc -= L.B[a * kMargMaxF0 + f] * L.D[f] * L.bd[f];
         L.u[a] = acc;
     }
-    for (int k = tid; k < 6 * kMargN; k += 256) {
+    for (int k = tid; k < 6 * kMargN; k += kMgT) {
         const int a = k / kMargN, cidx = k % kMargN;
         double acc = L.Wp[k];
         for (int f = 0; f < F0; f++) acc -= L.B[a * kMargMaxF0 + f] * L.D[f] * L.Wd[f * kMargN + cidx];
         L.Y[k] = acc;      // G, staged in Y
     }
     __syncthreads();
-    for (int k = tid; k < 6 * kMargN; k += 256) L.Wp[k] = L.Y[k];
+    for (int k = tid; k < 6 * kMargN; k += kMgT) L.Wp[k] = L.Y[k];
     if (tid == 0) { double tmp[36]; int deg = 0; pinv6(L.SAi, tmp, eps, &deg); for (int i = 0; i < 36; i++) L.SAi[i] = tmp[i]; if (deg) L.flag = 1; }
     __syncthreads();
-    for (int k = tid; k < 6 * kMargN; k += 256) {
+    for (int k = tid; k < 6 * kMargN; k += kMgT) {
         const int a = k / kMargN, cidx = k % kMargN;
         double acc = 0;
         for (int q = 0; q < 6; q++) acc += L.SAi[a * 6 + q] * L.Wp[q * kMargN + cidx];
@@ -266,14 +271,14 @@ __global__ __launch_bounds__(256) void k_marginalize(MargBatch Bt)
     }
     __syncthreads();
     // H' = Hrr - G^T Y - Wd^T D^+ Wd ; b' = br - G^T SA^+ u - Wd^T D^+ bd   (H' in place: every element only reads itself of Hrr)
-    for (int k = tid; k < kMargN * kMargN; k += 256) {
+    for (int k = tid; k < kMargN * kMargN; k += kMgT) {
         const int a = k / kMargN, bb = k % kMargN;
         double acc = L.Hrr[k];
         for (int q = 0; q < 6; q++) acc -= L.Wp[q * kMargN + a] * L.Y[q * kMargN + bb];
         for (int f = 0; f < F0; f++) acc -= L.Wd[f * kMargN + a] * L.D[f] * L.Wd[f * kMargN + bb];
         L.Hrr[k] = acc;
     }
-    for (int a = tid; a < kMargN; a += 256) {
+    for (int a = tid; a < kMargN; a += kMgT) {
         double acc = L.br[a];
         for (int q = 0; q < 6; q++) { double su = 0; for (int p = 0; p < 6; p++) su += L.SAi[q * 6 + p] * L.u[p]; acc -= L.Wp[q * kMargN + a] * su; }
         for (int f = 0; f < F0; f++) acc -= L.Wd[f * kMargN + a] * L.D[f] * L.bd[f];
@@ -281,21 +286,21 @@ __global__ __launch_bounds__(256) void k_marginalize(MargBatch Bt)
     }
     __syncthreads();
     // symmetrise in place (one thread per unordered pair), then V (which shares W_d's memory) becomes the identity
-    for (int k = tid; k < kMargN * kMargN; k += 256) {
+    for (int k = tid; k < kMargN * kMargN; k += kMgT) {
         const int a = k / kMargN, bb = k % kMargN;
         if (a < bb) { const double v = 0.5 * (L.Hrr[k] + L.Hrr[bb * kMargN + a]); L.Hrr[k] = v; L.Hrr[bb * kMargN + a] = v; }
     }
-    for (int k = tid; k < kMargN * kMargN; k += 256) L.V[k] = (k / kMargN == k % kMargN) ? 1.0 : 0.0;
+    for (int k = tid; k < kMargN * kMargN; k += kMgT) L.V[k] = (k / kMargN == k % kMargN) ? 1.0 : 0.0;
     __syncthreads();
     // ---- parallel Jacobi eigen-decomposition of Hrr (66x66): 65 rounds of 33 disjoint rotations per sweep
     marg_jacobi(L.Hrr, L.V, kMargN, L.cs, L.pq, L.red, tid);
     // linearized_jacobians = sqrt(S) V^T, linearized_residuals = sqrt(S^-1) V^T b'
-    for (int k = tid; k < kMargN * kMargN; k += 256) {
+    for (int k = tid; k < kMargN * kMargN; k += kMgT) {
         const int e = k / kMargN, i = k % kMargN;
         const double wv = L.Hrr[e * kMargN + e];
         Bt.lin_J[(size_t)w * kMargN * kMargN + k] = (wv > eps ? sqrt(wv) : 0.0) * L.V[i * kMargN + e];
     }
-    for (int e = tid; e < kMargN; e += 256) {
+    for (int e = tid; e < kMargN; e += kMgT) {
         const double wv = L.Hrr[e * kMargN + e];
         double vb = 0;
         for (int i = 0; i < kMargN; i++) vb += L.V[i * kMargN + e] * L.br[i];
@@ -351,11 +356,11 @@ struct Marg2Lds {
     double T[kMargN * 6];
     double r[kMargN], b[kMargN], dx[kMargN], br[kMargN];
     double Hmm[36], Hinv[36];
-    double cs[2 * 33], red[8];
+    double cs[2 * 33], red[2 * 16];
     int perm[kMargN], pq[2 * 33], flag;
 };
 
-__global__ __launch_bounds__(256) void k_marg_second_new(Marg2Batch Bt)
+__global__ __launch_bounds__(kMgT) void k_marg_second_new(Marg2Batch Bt)
 {
     extern __shared__ __align__(16) unsigned char smem_raw2[];
     Marg2Lds &L = *reinterpret_cast<Marg2Lds *>(smem_raw2);
@@ -363,7 +368,7 @@ __global__ __launch_bounds__(256) void k_marg_second_new(Marg2Batch Bt)
     const int nb = Bt.nb, n0 = 6 * nb, n = n0 - 6, drop = Bt.drop;
     const double eps = 1e-8;
     const double *J0 = Bt.lin_J + (size_t)w * n0 * n0;
-    for (int k = tid; k < n0 * n0; k += 256) L.A[k] = J0[k];
+    for (int k = tid; k < n0 * n0; k += kMgT) L.A[k] = J0[k];
     if (tid < nb) {
         const double *a = Bt.x + ((size_t)w * nb + tid) * 7, *a0 = Bt.x0 + ((size_t)w * nb + tid) * 7;
         for (int k = 0; k < 3; k++) L.dx[6 * tid + k] = a[k] - a0[k];
@@ -386,7 +391,7 @@ __global__ __launch_bounds__(256) void k_marg_second_new(Marg2Batch Bt)
     __syncthreads();
     if (tid < n0) { double v = Bt.lin_r[(size_t)w * n0 + tid]; for (int k = 0; k < n0; k++) v += L.A[tid * n0 + k] * L.dx[k]; L.r[tid] = v; }
     __syncthreads();
-    for (int k = tid; k < n0 * n0; k += 256) {
+    for (int k = tid; k < n0 * n0; k += kMgT) {
         const int i = k / n0, j = k % n0, pi = L.perm[i], pj = L.perm[j];
         double v = 0;
         for (int q = 0; q < n0; q++) v += L.A[q * n0 + pi] * L.A[q * n0 + pj];
@@ -398,7 +403,7 @@ __global__ __launch_bounds__(256) void k_marg_second_new(Marg2Batch Bt)
     __syncthreads();
     if (tid == 0) { int deg = 0; pinv6(L.Hmm, L.Hinv, eps, &deg); if (deg) L.flag = 1; }
     __syncthreads();
-    for (int k = tid; k < n * 6; k += 256) {
+    for (int k = tid; k < n * 6; k += kMgT) {
         const int i = k / 6, j = k % 6;
         double v = 0;
         for (int q = 0; q < 6; q++) v += L.H[(6 + i) * n0 + q] * L.Hinv[q * 6 + j];
@@ -406,7 +411,7 @@ __global__ __launch_bounds__(256) void k_marg_second_new(Marg2Batch Bt)
     }
     __syncthreads();
     // H' (n x n, leading dimension n) into A; b'
-    for (int k = tid; k < n * n; k += 256) {
+    for (int k = tid; k < n * n; k += kMgT) {
         const int i = k / n, j = k % n;
         double v = 0;
         for (int q = 0; q < 6; q++) v += L.T[i * 6 + q] * L.H[q * n0 + 6 + j];
@@ -415,18 +420,18 @@ __global__ __launch_bounds__(256) void k_marg_second_new(Marg2Batch Bt)
     if (tid < n) { double v = 0; for (int q = 0; q < 6; q++) v += L.T[tid * 6 + q] * L.b[q]; L.br[tid] = L.b[6 + tid] - v; }
     __syncthreads();
     // move H' to H (ld n), V = identity in A
-    for (int k = tid; k < n * n; k += 256) L.H[k] = L.A[k];
+    for (int k = tid; k < n * n; k += kMgT) L.H[k] = L.A[k];
     __syncthreads();
-    for (int k = tid; k < n * n; k += 256) L.A[k] = (k / n == k % n) ? 1.0 : 0.0;
+    for (int k = tid; k < n * n; k += kMgT) L.A[k] = (k / n == k % n) ? 1.0 : 0.0;
     __syncthreads();
     // parallel Jacobi (round-robin tournament over n = even): n - 1 rounds of n / 2 disjoint rotations per sweep
     marg_jacobi(L.H, L.A, n, L.cs, L.pq, L.red, tid);
-    for (int k = tid; k < n * n; k += 256) {
+    for (int k = tid; k < n * n; k += kMgT) {
         const int e = k / n, i = k % n;
         const double wv = L.H[e * n + e];
         Bt.out_J[(size_t)w * n * n + k] = (wv > eps ? sqrt(wv) : 0.0) * L.A[i * n + e];
     }
-    for (int e = tid; e < n; e += 256) {
+    for (int e = tid; e < n; e += kMgT) {
         const double wv = L.H[e * n + e];
         double vb = 0;
         for (int i = 0; i < n; i++) vb += L.A[i * n + e] * L.br[i];
