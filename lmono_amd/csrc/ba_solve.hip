@@ -435,13 +435,18 @@ __device__ __forceinline__ void ba_reduce_pairs(const BaBatch &B, const BaCtx c,
 
 // cost (returned to every thread) and, when kJac, the unscaled normal equations: Hpp, gp, Hdd, gdd in LDS, Hpd in HBM
 template <bool kJac>
+// records_valid: the pose matrices, the inverse depths in LDS and the pair records in HBM were computed by the previous call for the SAME parameter
+// values (the candidate evaluation of a step that was then accepted): a linearisation right behind it re-uses them instead of computing the same
+// numbers again
 __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLds &L_arg, const double *poses, const double *ex, const double *invd,
-                                              double *hpd, double *pairdat)
+                                              double *hpd, double *pairdat, bool records_valid = false)
 {
     BA_BIND_LDS(L_arg)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __syncthreads();
     BA_TICK(kJac ? 0 : 3)
+    const double *Rlc = L.Rp + 9 * c.n_poses;
+    if (!records_valid) {
     if (tid <= c.n_poses) {
         double qn[4];
         const double *qraw = tid == c.n_poses ? ex + 3 : poses + 7 * tid + 3;
@@ -455,7 +460,6 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
     }
     for (int f = tid; f < c.F; f += kBaT) L.vinv[f] = gld(invd + f);
     __syncthreads();
-    const double *Rlc = L.Rp + 9 * c.n_poses;
     for (int p = tid; p < c.n_pairs; p += kBaT) {
         const int ij = L.pair_ij[p], i = ij & 255, j = ij >> 8;
         double rec[kBaPairRec];
@@ -464,6 +468,7 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
         double *dst = pairdat + (size_t)p * kBaPairRec;
 #pragma unroll
         for (int k = 0; k < kBaPairRec; k++) gst(dst + k, rec[k]);
+    }
     }
     double cost = 0.0;
     // wave 1: LASERFactor chain and prior, next to the pair records of wave 0
@@ -1053,12 +1058,13 @@ __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B)
     int invalid = 0, iter = 0, termination = 1, n_succ = 0, n_unsucc = 0;
 
     double x_cost = 0.0, initial_cost = 0.0, x_norm = 0.0;
-    bool linearise = true, first = true;
+    bool linearise = true, first = true, records_valid = false;
     BA_TICK(9)
     // one call site per phase (the phases are inlined: LDS addressing, no register-file round trips through a call)
     for (;;) {
         if (linearise) {
-            x_cost = ba_evaluate<true>(B, c, L, L.poses, L.ex, ginvd, hpd, pairdat);
+            x_cost = ba_evaluate<true>(B, c, L, L.poses, L.ex, ginvd, hpd, pairdat, records_valid);
+            records_valid = false;
             double q = 0, g = 0;
             if (c.ex_off >= 0 && tid < 7) q += L.ex[tid] * L.ex[tid];
             for (int k = tid; k < 7 * c.n_poses; k += kBaT) q += L.poses[k] * L.poses[k];
@@ -1175,6 +1181,7 @@ __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B)
             for (int f = tid; f < F; f += kBaT) ginvd[f] = cinvd[f];
             __syncthreads();
             n_succ++;
+            records_valid = true;            // the candidate's records are the accepted state's
             if (rel < 0.25) radius *= 0.5;
             if (rel > 0.75) radius = fmax(radius, 3.0 * dogleg_norm);
             if (radius > max_radius) radius = max_radius;
