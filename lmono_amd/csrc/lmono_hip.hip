@@ -2014,7 +2014,7 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
     for (int s = 0; s < n; s++) undo.u.emplace_back(ms[s]);
     // staging vectors of asynchronous copies live until the function returns (every path syncs the stream before that)
     std::vector<ScatterJob> sj;
-    std::vector<char> vox_blob;
+    std::vector<char> vox_blob, side_blob;
     const bool prof = getenv("LMONO_MAP_PROF") != nullptr;
     auto tnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tp[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -2098,7 +2098,8 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
         }
         if (!jobs.empty() || !cj.empty()) {
             const size_t cj_at = (jobs.size() * sizeof(CopyJob) + 15) & ~(size_t)15;
-            std::vector<char> blob(cj_at + cj.size() * sizeof(CloudJob));
+            std::vector<char> &blob = side_blob;          // function scope: alive until every stream has been waited for
+            blob.resize(cj_at + cj.size() * sizeof(CloudJob));
             if (!jobs.empty()) memcpy(blob.data(), jobs.data(), jobs.size() * sizeof(CopyJob));
             if (!cj.empty()) memcpy(blob.data() + cj_at, cj.data(), cj.size() * sizeof(CloudJob));
             if ((rc = js.upload(c, blob.data(), blob.size(), side))) return rc;
