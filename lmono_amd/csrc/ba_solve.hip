@@ -300,12 +300,14 @@ __device__ __noinline__ double ba_small_factors(const BaBatch &B, const BaCtx c,
 // J^T J and J^T r of the blocks left in LDS by ba_small_factors, by one wave (one output entry per lane and round).  Neighbouring
 // LASER blocks share a pose: the even blocks are added first, then the odd ones (within a phase every entry has one writer), so the
 // sums are formed in a fixed order with plain LDS read-modify-writes.  Nothing else touches H_pp meanwhile (L.turn == -1).
-__device__ __forceinline__ void ba_small_accumulate_wave(const BaCtx &c, BaLds &L, const double *in, int lane)
+// Round 4: the LASER blocks are spread over the WHOLE workgroup (a barrier between the even and the odd blocks) -- one wave walking all 1560 entries
+// was the critical path of the phase (the other seven waves were done with the per-feature sums in half its time); same sums in the same order.
+__device__ __forceinline__ void ba_small_accumulate_block(const BaCtx &c, BaLds &L, const double *in, int tid)
 {
     const int nl = c.n_poses - 1;
     for (int par = 0; par < 2; par++) {
         const int nb = (nl - par + 1) / 2;                       // blocks par, par + 2, ...
-        for (int idx = lane; idx < nb * 156; idx += 64) {
+        for (int idx = tid; idx < nb * 156; idx += kBaT) {
             const int b = 2 * (idx / 156) + par, e = idx % 156;
             const double *r = in + b * kBaSmallRec, *J = r + 6;
             const int a = e < 144 ? e / 12 : e - 144, bb = e < 144 ? e % 12 : 0;
@@ -323,10 +325,12 @@ __device__ __forceinline__ void ba_small_accumulate_wave(const BaCtx &c, BaLds &
                 L.gp[ga] += v;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __syncthreads();
     }
+}
+// the extrinsic prior's block (entries nothing else has touched yet), by one wave
+__device__ __forceinline__ void ba_prior_accumulate_wave(const BaCtx &c, BaLds &L, const double *in, int lane)
+{
     if (c.use_prior && !c.ex_constant && lane < 42) {
         const double *r = in + 10 * kBaSmallRec, *J = r + 6;
         const int e = lane, a = e < 36 ? e / 6 : e - 36, bb = e < 36 ? e % 6 : 0;
@@ -434,10 +438,10 @@ __device__ __forceinline__ void ba_reduce_pairs(const BaBatch &B, const BaCtx c,
 }
 
 // cost (returned to every thread) and, when kJac, the unscaled normal equations: Hpp, gp, Hdd, gdd in LDS, Hpd in HBM
-template <bool kJac>
 // records_valid: the pose matrices, the inverse depths in LDS and the pair records in HBM were computed by the previous call for the SAME parameter
 // values (the candidate evaluation of a step that was then accepted): a linearisation right behind it re-uses them instead of computing the same
 // numbers again
+template <bool kJac>
 __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLds &L_arg, const double *poses, const double *ex, const double *invd,
                                               double *hpd, double *pairdat, bool records_valid = false)
 {
@@ -670,25 +674,15 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // the observation records are written
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");       // ... and read below by other waves: drop this CU's L1 copies
+    BA_TICK(12)
     ba_reduce_pairs(B, c, L);
-    if (wave == 1) {
-        // every pair block is in H_pp: wave 1 adds the LASERFactor chain / prior it left in gn | va | vb, then the waves' shares of
-        // the extrinsic corner in wave order -- after the pair blocks in every run
-        ba_small_accumulate_wave(c, L, L.gn, lane);
-        if (c.ex_off >= 0 && c.n_slots > 0 && lane == 0) {
-            double t[5] = { 0, 0, 0, 0, 0 };
-            for (int w = 0; w < kBaW; w++) for (int k = 0; k < 5; k++) t[k] += L.rhs[5 * w + k];
-            const int x4 = c.ex_off + 4, x5 = c.ex_off + 5;
-            L.Hpp[x4 * kBaP + x4] += t[0]; L.Hpp[x5 * kBaP + x5] += t[2];
-            L.Hpp[x4 * kBaP + x5] += t[1]; L.Hpp[x5 * kBaP + x4] += t[1];
-            L.gp[x4] += t[3]; L.gp[x5] += t[4];
-        }
-    } else {
-        // H_ff, g_f and the extrinsic / anchor parts of the coupling rows, by the other seven waves: 16 lanes per feature, lane k sums
-        // entry k of the feature's observation records (contiguous, at most 10: one per other frame of the window) in observation
-        // order; the loads are independent and requested together
-        const int k = lane & 15, t7 = (wave == 0 ? 0 : wave - 1) * 4 + (lane >> 4);
-        for (int f = t7; f < c.F; f += 28) {
+    BA_TOCK(12)
+    BA_TICK(13)
+    {
+        // H_ff, g_f and the extrinsic / anchor parts of the coupling rows: 16 lanes per feature, lane k sums entry k of the feature's observation
+        // records (contiguous, at most 10: one per other frame of the window) in observation order; the loads are independent and requested together
+        const int k = lane & 15, t8 = wave * 4 + (lane >> 4);
+        for (int f = t8; f < c.F; f += 4 * kBaW) {
             const int o0 = c.o0 + L.fobs[f], o1 = c.o0 + L.fobs[f + 1];
             double acc = 0.0;
             for (int ob = o0; ob < o1; ob += 10) {
@@ -705,6 +699,21 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
                 if (k < 8) { if (c.ex_off >= 0) gst(hrow + c.ex_off + k - 2, acc); }
                 else { const int anchor = L.fanchor[f]; if (anchor >= 0) gst(hrow + ba_pose_off(c, anchor) + k - 8, acc); }
             }
+        }
+    }
+    BA_TOCK(13)
+    // every pair block is in H_pp: the LASERFactor chain left in gn | va | vb is added by everybody, the prior and then the waves' shares of the
+    // extrinsic corner (in wave order) by wave 1 -- after the pair blocks in every run
+    ba_small_accumulate_block(c, L, L.gn, tid);
+    if (wave == 1) {
+        ba_prior_accumulate_wave(c, L, L.gn, lane);
+        if (c.ex_off >= 0 && c.n_slots > 0 && lane == 0) {
+            double t[5] = { 0, 0, 0, 0, 0 };
+            for (int w = 0; w < kBaW; w++) for (int k = 0; k < 5; k++) t[k] += L.rhs[5 * w + k];
+            const int x4 = c.ex_off + 4, x5 = c.ex_off + 5;
+            L.Hpp[x4 * kBaP + x4] += t[0]; L.Hpp[x5 * kBaP + x5] += t[2];
+            L.Hpp[x4 * kBaP + x5] += t[1]; L.Hpp[x5 * kBaP + x4] += t[1];
+            L.gp[x4] += t[3]; L.gp[x5] += t[4];
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1194,7 +1203,7 @@ __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B)
     __syncthreads();
     BA_TOCK(9)
 #ifdef LMONO_BA_PROF
-    if (w == 0 && tid == 0) printf("PROF total %lld | lin: prologue %lld eval %lld mfma %lld | cost %lld | hs %lld | schur: stage+mfma %lld chol %lld subst %lld depth %lld | iters %d | wave-0 turn wait %lld, feature pass + small factors %lld\n", g_prof[9], g_prof[0], g_prof[1], g_prof[2], g_prof[3], g_prof[4], g_prof[5], g_prof[6], g_prof[7], g_prof[8], iter, g_prof[10], g_prof[11]);
+    if (w == 0 && tid == 0) printf("PROF total %lld | lin: prologue %lld eval %lld mfma %lld | cost %lld | hs %lld | schur: stage+mfma %lld chol %lld subst %lld depth %lld | iters %d | wave-0 turn wait %lld, feature pass + small factors %lld (reduce pairs %lld, wave 0's features %lld)\n", g_prof[9], g_prof[0], g_prof[1], g_prof[2], g_prof[3], g_prof[4], g_prof[5], g_prof[6], g_prof[7], g_prof[8], iter, g_prof[10], g_prof[11], g_prof[12], g_prof[13]);
 #endif
     for (int k = tid; k < c.n_poses * 7; k += kBaT) gposes[k] = L.poses[k];
     if (tid < 7) gex[tid] = L.ex[tid];
