@@ -532,8 +532,22 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
     const int q = lane & 1, lo = lane >> 1, col = lane & 15, kq = lane >> 4;
     double xx44 = 0, xx45 = 0, xx55 = 0, gx4 = 0, gx5 = 0;
     double xa = 0, xb = 0;      // this lane's entry of the extrinsic rows 12..15 of the tiles, summed over the wave's pairs (all pairs touch them)
-    for (int wi = L.woff[wave]; wi < L.woff[wave + 1]; wi++) {
-        const int pr = L.wlist[wi];
+    // Round 4: two SMALL pairs share a round.  Most frame pairs of a window hold fewer than 16 observations (the Estimator's windows: ~14 on
+    // average), so a 32-observation round was half empty and a pair cost a whole round of ~15 k cycles whatever it held.  When a pair and the next one of
+    // the wave's list both fit 16 slots, lanes 0..31 take the first and lanes 32..63 the second: every lane reads ITS pair's record, the 64 staged rows
+    // are multiplied in two halves (MFMA steps 0..7 -> the first pair's tile, 8..15 -> the second's).  A pair's rows, their order and the order in
+    // which the wave adds its pairs' extrinsic rows are what they were; per-lane partial sums (cost, the extrinsic corner) meet different lanes.
+    constexpr int kBaHalf = kBaRound / 2;
+    for (int wi = L.woff[wave]; wi < L.woff[wave + 1];) {
+        const int pr0 = L.wlist[wi];
+        int pr1 = -1;
+        if (wi + 1 < L.woff[wave + 1] && L.pair_slot[pr0 + 1] - L.pair_slot[pr0] <= kBaHalf) {
+            const int cand = L.wlist[wi + 1];
+            if (L.pair_slot[cand + 1] - L.pair_slot[cand] <= kBaHalf) pr1 = cand;
+        }
+        const bool two = pr1 >= 0;
+        wi += two ? 2 : 1;
+        const int pr = two && lane >= 32 ? pr1 : pr0;       // this lane's pair
         const int ij = L.pair_ij[pr], fi = ij & 255, fj = ij >> 8;
         const int s_begin = L.pair_slot[pr], s_end = L.pair_slot[pr + 1];
         const int oi = ba_pose_off(c, fi), oj = ba_pose_off(c, fj);
@@ -547,8 +561,11 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
         const double *T = rec, *Cm = rec + 12, *A = rec + 21, *Bm = rec + 30, *Tn = rec + 39;
         const double *Mx = L.Mq + 18 * c.n_poses, *Mxi = L.Mq + 18 * (kBaMaxPoses + 1);
         ba_d4 aa = { 0, 0, 0, 0 }, ab = { 0, 0, 0, 0 };
-        for (int base = s_begin; base < s_end; base += kBaRound) {
-            const int so = base + lo;
+        // solo: rounds of 32 slots of the one pair; paired: ONE round, 16 slots of each pair (base = this lane's pair's first slot)
+        const int n_solo = L.pair_slot[pr0 + 1] - L.pair_slot[pr0];
+        for (int rb = 0; rb < (two ? 1 : n_solo); rb += kBaRound) {
+            const int base = s_begin + rb;
+            const int so = base + (two ? (lo & (kBaHalf - 1)) : lo);
             double *row = wstage + (size_t)lane * kBaRow;
             if (so < s_end) {
                 const int f = gldi(sinfo + so) & 0xffff;
@@ -640,20 +657,49 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const int nrow = 2 * min(kBaRound, s_end - base);
-            for (int ks = 0; 4 * ks < nrow; ks++) {
-                const double *rowp = wstage + (size_t)(4 * ks + kq) * kBaRow;
-                const double a = rowp[col];
-                const double bq = col < 3 ? rowp[16 + col] : 0.0;
-                aa = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, aa, 0, 0, 0);
-                ab = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, ab, 0, 0, 0);
+            if (!two) {
+                const int nrow = 2 * min(kBaRound, n_solo - rb);
+                for (int ks = 0; 4 * ks < nrow; ks++) {
+                    const double *rowp = wstage + (size_t)(4 * ks + kq) * kBaRow;
+                    const double a = rowp[col];
+                    const double bq = col < 3 ? rowp[16 + col] : 0.0;
+                    aa = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, aa, 0, 0, 0);
+                    ab = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, ab, 0, 0, 0);
+                }
+            } else {
+                // first pair: rows 0 .. 2 n0 - 1 -> its tile goes out, the accumulators start again for the second pair's rows 32 ..
+                const int n0 = n_solo, n1 = L.pair_slot[pr1 + 1] - L.pair_slot[pr1];
+                for (int ks = 0; 4 * ks < 2 * n0; ks++) {
+                    const double *rowp = wstage + (size_t)(4 * ks + kq) * kBaRow;
+                    const double a = rowp[col];
+                    const double bq = col < 3 ? rowp[16 + col] : 0.0;
+                    aa = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, aa, 0, 0, 0);
+                    ab = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, ab, 0, 0, 0);
+                }
+                {
+                    double *tile = B.pairH + (size_t)(c.pp0 + pr0) * kBaPairTile;
+#pragma unroll
+                    for (int v = 0; v < 4; v++) {
+                        gst(tile + (kq + 4 * v) * 16 + col, aa[v]);
+                        if (col < 3) gst(tile + 256 + (kq + 4 * v) * 4 + col, ab[v]);
+                    }
+                    xa += aa[3]; xb += ab[3];
+                }
+                aa = { 0, 0, 0, 0 }; ab = { 0, 0, 0, 0 };
+                for (int ks = 0; 4 * ks < 2 * n1; ks++) {
+                    const double *rowp = wstage + (size_t)(2 * kBaHalf + 4 * ks + kq) * kBaRow;
+                    const double a = rowp[col];
+                    const double bq = col < 3 ? rowp[16 + col] : 0.0;
+                    aa = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, aa, 0, 0, 0);
+                    ab = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, ab, 0, 0, 0);
+                }
             }
             __builtin_amdgcn_wave_barrier();   // the slice is rewritten by the next round
         }
         // the pair's tile [J_i J_j J_x0..3]^T [J_i J_j J_x0..3 | J_x4 J_x5 r] goes to the pair's own record in the L2 scratch (plain stores,
         // no other wave touches it); ba_reduce_pairs sums the records into H_pp / g_p in a fixed order afterwards
         {
-            double *tile = B.pairH + (size_t)(c.pp0 + pr) * kBaPairTile;
+            double *tile = B.pairH + (size_t)(c.pp0 + (two ? pr1 : pr0)) * kBaPairTile;      // (paired: the first pair's tile went out above)
 #pragma unroll
             for (int v = 0; v < 4; v++) {
                 gst(tile + (kq + 4 * v) * 16 + col, aa[v]);
