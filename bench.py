@@ -320,9 +320,12 @@ def bench_posegraph(args):
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available() and world == args.gpus
     torch.cuda.set_device(local)
-    if world > 1:
+    multi = world > 1 or os.environ.get("LMONO_BENCH_FORCE_COLLECTIVES") == "1"      # one rank through the RCCL all-reduce (tests/test_rccl_gpu.py)
+    if multi:
         import torch.distributed as dist
-        dist.init_process_group("nccl")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29573")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     g = s4.make_graph(n=args.keyframes, laps=2.2)
     ctx = lmono_amd.Context(local)
     pg = lmono_amd.PoseGraph(ctx, g["odom"], g["loops"], g["loop_info"])
@@ -331,10 +334,10 @@ def bench_posegraph(args):
 
     def run():
         pg.reset()
-        return sharding.pose_graph_rounds(pg, rank, world, max_iter=5)
+        return sharding.pose_graph_rounds(pg, rank, world, max_iter=5, force_collective=multi)
 
     def fence():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
     for _ in range(args.warmup):
@@ -345,12 +348,12 @@ def bench_posegraph(args):
         rounds = run()
     fence()
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda:%d" % local)
-    if world > 1:
+    if multi:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     el = float(el.item())
     out, st = pg.result()
     if rank != 0:
-        if world > 1:
+        if multi:
             dist.destroy_process_group()
         return
     # ---- cpu_baseline leg: the only place the oracle is touched
@@ -366,19 +369,35 @@ def bench_posegraph(args):
            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": "S4 loop-closure graph (new feature, SURVEY 8f-2 / config 4 shape)", "keyframes": args.keyframes, "loops": int(len(g["loops"])),
                       "edges": pg.n_edges, "half_bandwidth_blocks": w, "lm_iterations": st["iterations"], "rounds": rounds,
-                      "all_reduce_bytes_per_round": 8 * pg.reduce_count},
+                      "all_reduce_bytes_per_round": 8 * pg.reduce_count,
+                      "collective_backend": dist.get_backend() if multi else None, "collective_ranks": world if multi else 0,
+                      "collective_lib": _rccl_mapped() if multi else None},
            "roofline": {"bound": "hbm", "kernel": "k_pg_step (one workgroup: block-banded Cholesky, 8-column panels in LDS, trailing window on f64 MFMA; bound by the dependent chain of 4541 pivots)",
                         "achieved": round(alg * args.steps / el / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg * args.steps / el / 1e9 / HBM_PEAK_GBS, 5),
                         "traffic": None},
            "cpu_baseline": {"value": round(1.0 / cpu_s, 3), "unit": "graphs/s", "cores": 1, "kind": "port", "sample": "the same graph, oracle/lo_posegraph.c (-O3), 1 thread"},
            "max_keyframe_diff_vs_cpu_m": float(np.abs(out[:, :3] - ref[:, :3]).max()),
            "ate_vs_truth_m": {"odometry": round(s4.ate(g["odom"], g["truth"]), 4), "optimised": round(s4.ate(out, g["truth"]), 4)}}
+    if args.dump_poses:
+        np.savez(args.dump_poses, poses=out)
     print(json.dumps(res), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
 GOLDEN = os.path.join(ROOT, "tests", "golden", "s1_seq%02d_oracle.npz")
+
+
+def _rccl_mapped():
+    """The RCCL shared object mapped into this process (from /proc/self/maps), or None: evidence that a collective went through RCCL."""
+    try:
+        with open("/proc/self/maps") as fh:
+            for ln in fh:
+                if "librccl" in ln:
+                    return ln.split()[-1]
+    except OSError:
+        pass
+    return None
 
 
 def spawn_ranks(args):
@@ -591,6 +610,7 @@ def main():
     ap.add_argument("--only-streamed", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (sequential run, BA secondary)")
     ap.add_argument("--probe-ranks", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--dump-poses", default="", help=argparse.SUPPRESS)      # rank 0's poses / increments of the timed run as .npz (tests)
     ap.add_argument("--workload", default="lidar", choices=["lidar", "ba", "ba-seq", "map", "colour", "posegraph"],
                     help="lidar = headline (BASELINE configs[1]); ba = configs[2]-shaped sliding-window BA solves (secondary); "
                          "map = laserMapping over a synthetic sequence, one stream (SURVEY 8f-1)")
@@ -634,8 +654,12 @@ def main():
     rehearse = world > 1 and os.environ.get("LMONO_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = 0
-    if world > 1:
+    # LMONO_BENCH_FORCE_COLLECTIVES=1: a ONE-rank run takes the multi-rank step -- a world-1 "nccl" (RCCL) group, the all-gathers and
+    # all-reduces on device tensors -- so that the collective path runs on the one GPU a test box has (tests/test_rccl_gpu.py)
+    multi = world > 1 or os.environ.get("LMONO_BENCH_FORCE_COLLECTIVES") == "1"
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29571")
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -652,7 +676,7 @@ def main():
         args.scans = min(args.scans, len(kitti_stamps)) if world == 1 or args.scaling == "strong" else min(args.scans, len(kitti_stamps) // world)
         if args.scaling != "strong" and world > 1:
             pass                                   # weak scaling: every rank takes the next --scans scans of the sequence
-    if world > 1 and args.lead < 1:
+    if multi and args.lead < 1:
         sys.exit("bench.py: --gpus > 1 needs --lead >= 1 (a rank's first owned scan pair needs the scan before it, which the lead-in loads)")
     strong = args.scaling == "strong"
     n_total = args.scans if strong else args.scans * world
@@ -705,7 +729,7 @@ def main():
 
     def step():
         batch.scanreg(xyzi_d.data_ptr(), off, 64, 5.0, keepalive=xyzi_d)
-        if world == 1:
+        if not multi:
             batch.odometry_d(chains, args.lead, incr_d.data_ptr(), None)
         else:
             # the rank's chains run over its owned scans (chain 0's lead-in = the previous rank's last scans); then the rank boundaries
@@ -716,13 +740,13 @@ def main():
             shard_rounds[0] = sharding.validate_rank_boundaries(lambda: coll(incr_d[-1]), lambda prev: batch.shard_validate(prev, incr_d.data_ptr()), rank, world, deferred=True)
         boundary.append(batch.boundary_report())
         ctx.pose_prefix_d(incr_d.data_ptr(), lead_r, n_local, poses_d.data_ptr())
-        if world > 1:
+        if multi:
             bases = sharding.gather_bases(coll(poses_d[-1].clone())).to(dev)
             # the first owned increment composes onto the previous rank's last pose
             ctx.pose_rebase_d(bases.data_ptr(), rank, poses_d.data_ptr(), n_own)
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -736,7 +760,7 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         te = coll(torch.tensor([elapsed], dtype=torch.float64, device=dev))
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
@@ -762,7 +786,7 @@ def main():
             st, sr, cnt_r = trajectory.rpe_from_relative(gpu_incr[lead_r:lead_r + m], gi[own_begin:hi])
             feat_equal = float((cnt[lead_r:lead_r + m, 1:5] == gc[own_begin:hi]).all())
             sums = np.array([s2, cnt_a, st, sr, cnt_r, 1.0 - feat_equal])
-        if world > 1:
+        if multi:
             ts = coll(torch.from_numpy(sums).to(dev))
             dist.all_reduce(ts)
             sums = ts.cpu().numpy()
@@ -841,8 +865,10 @@ def main():
             "config": {"workload": "KITTI-seq-00-shaped synthetic S1 HDL-64, laserOdometry-only (configs[1])",
                        "scans_total": n_total, "scans_per_gpu": n_own, "points_per_scan": round(N), "azimuth_steps": args.az,
                        "odometry_chains_per_gpu": chains, "chain_lead_in": args.lead, "lead_in_full_pairs": ctx.get_option(ctx.OPT_LEAD_FULL), "odometry_chain_groups": ctx.odom_chain_groups(chains),
-                       "parallelism": "scan-range shard x%d, one RCCL all-gather of 7 doubles per rank" % world,
-                       "collective_ranks": world, "status_or": status_or, "gen_s": round(gen_s, 1), "h2d_s": round(h2d_s, 2),
+                       "parallelism": ("scan-range shard x%d, one %s all-gather of 7 doubles per rank per exchange" % (world, "gloo (rehearsal)" if rehearse else "RCCL"))
+                                      if multi else "no collective (1 rank)",
+                       "collective_ranks": world if multi else 0, "collective_backend": (dist.get_backend() if multi else None),
+                       "collective_lib": _rccl_mapped() if multi and not rehearse else None, "status_or": status_or, "gen_s": round(gen_s, 1), "h2d_s": round(h2d_s, 2),
                        "h2d_GBps": round(total_pts * 16 / h2d_s / 1e9, 1)},
             "roofline": roofline,
         }
@@ -853,7 +879,7 @@ def main():
                                       "pairs_rerun": rep["pairs_rerun"], "rounds": rep["rounds"], "unresolved": rep["unresolved"],
                                       "max_residual": float(rep["max_resid"]), "residual_q50_q90_q99": [float(v) for v in np.quantile(rep["resid"][1:], [0.5, 0.9, 0.99])] if rep["n_chains"] > 1 else None,
                                       "repair_ms_per_step": round(float(np.mean([b["repair_ms"] for b in boundary])), 3),
-                                      "rank_boundary_rounds": shard_rounds[0] if world > 1 else None,
+                                      "rank_boundary_rounds": shard_rounds[0] if multi else None,
                                       "residual": "max(|dq_i|, 0.1 |dt_i| / m) between a chain's own lead-in estimate of the pair before its first owned one and its predecessor's increment for that pair"}
         if parity is not None:
             out["ate_vs_cpu_m"] = parity["ate_vs_cpu_m"]
@@ -920,8 +946,10 @@ def main():
                 out["cpu_baseline_all_cores"] = {"value": round(m / cpu_mt, 2), "unit": "scans/s", "cores": cores, "kind": "port",
                                                  "sample": "the same %d scans, OpenMP over scans / %d odometry chains with lead-in %d: scanreg %.0f ms + odometry %.0f ms"
                                                            % (m, cores, args.lead, ref_mt["stage_ms"][0], ref_mt["stage_ms"][1])}
+        if args.dump_poses:
+            np.savez(args.dump_poses, poses=gpu_poses, incr=gpu_incr)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

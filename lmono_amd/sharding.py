@@ -99,15 +99,16 @@ def validate_rank_boundaries(last_incr, validate, rank, world, group=None, max_r
     return rounds
 
 
-def pose_graph_rounds(graph, rank, world, max_iter=5, all_reduce=None):
+def pose_graph_rounds(graph, rank, world, max_iter=5, all_reduce=None, force_collective=False):
     """Loop-closure pose graph over `world` ranks: every rank holds the same graph object (lmono_amd.PoseGraph
     on a GPU; anything with linearise(rank, world) / reduce_tensor / step(max_iter) works), linearises the edges it owns, ONE
     all-reduce sums the normal equations [H | g | cost] (RCCL over xGMI with the nccl backend), and every rank takes the same
-    trust-region step.  Returns the number of rounds run."""
+    trust-region step.  force_collective: run the all-reduce with one rank as well (the RCCL path on a one-GPU box; the sum over one
+    rank is the identity, so the result is the no-collective run's).  Returns the number of rounds run."""
     rounds = 0
     for _ in range(max_iter + 1):
         graph.linearise(rank, world)
-        if world > 1:
+        if world > 1 or force_collective:
             if all_reduce is None:
                 import torch.distributed as dist
                 dist.all_reduce(graph.reduce_tensor)

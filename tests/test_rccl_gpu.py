@@ -1,0 +1,54 @@
+"""The RCCL path on the one GPU a test box has: a world-1 "nccl" process group in a fresh child
+process, bench.py's MULTI-rank step (LMONO_BENCH_FORCE_COLLECTIVES=1: lmono_odom_shard_main_d, sharding.validate_rank_boundaries,
+sharding.gather_bases and the reductions of time and tolerance on DEVICE tensors) and the pose graph's all-reduce of the normal
+equations.  A sum / gather over one rank is the identity, so the poses must be the no-collective run's bytes."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(extra, tmp_path, name, force, port):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("LMONO_BENCH_REHEARSE", None)
+    if force:
+        env["LMONO_BENCH_FORCE_COLLECTIVES"] = "1"
+    else:
+        env.pop("LMONO_BENCH_FORCE_COLLECTIVES", None)
+    dump = str(tmp_path / (name + ".npz"))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--dump-poses", dump] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    return line, np.load(dump)
+
+
+@pytest.mark.gpu
+def test_lidar_step_through_a_world_1_rccl_group_is_the_same_bytes(tmp_path):
+    extra = ["--scans", "192", "--chains", "16", "--no-extras", "--cpu-sample", "0"]
+    a, pa = _bench(extra, tmp_path, "plain", False, 29581)
+    b, pb = _bench(extra, tmp_path, "rccl", True, 29583)
+    assert a["config"]["parallelism"] == "no collective (1 rank)" and a["config"]["collective_ranks"] == 0
+    assert b["config"]["collective_backend"] == "nccl" and b["config"]["collective_ranks"] == 1
+    assert b["config"]["collective_lib"] and "librccl" in b["config"]["collective_lib"], b["config"]
+    assert b["boundary_validation"]["rank_boundary_rounds"] >= 1 and b["boundary_validation"]["unresolved"] == 0
+    assert pa["poses"].tobytes() == pb["poses"].tobytes() and pa["incr"].tobytes() == pb["incr"].tobytes()
+    assert b["ate_vs_cpu_m"] == a["ate_vs_cpu_m"] and b["ate_vs_cpu_m"] < 1e-3
+    print("world-1 RCCL step: poses byte-equal to the no-collective run over %d scans (%s), ATE vs CPU %.2e m"
+          % (len(pa["poses"]), b["config"]["collective_lib"], b["ate_vs_cpu_m"]))
+
+
+@pytest.mark.gpu
+def test_pose_graph_all_reduce_through_rccl_is_the_same_bytes(tmp_path):
+    extra = ["--workload", "posegraph", "--keyframes", "600"]
+    a, pa = _bench(extra, tmp_path, "pg_plain", False, 29585)
+    b, pb = _bench(extra, tmp_path, "pg_rccl", True, 29587)
+    assert a["config"]["collective_backend"] is None
+    assert b["config"]["collective_backend"] == "nccl" and "librccl" in (b["config"]["collective_lib"] or "")
+    assert pa["poses"].tobytes() == pb["poses"].tobytes()
+    assert b["config"]["rounds"] == a["config"]["rounds"]
