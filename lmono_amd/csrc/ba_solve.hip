@@ -24,6 +24,7 @@
 // accumulated in registers with the same f64 MFMA; blocked Cholesky (8-column panels) and the triangular solves in
 // LDS.  fp64 throughout; contraction to FMA is allowed in this file (the BA parity bar is a tolerance).
 #include "common.hpp"
+#include <type_traits>
 
 #pragma clang fp contract(fast)
 
@@ -929,83 +930,217 @@ __device__ __noinline__ bool ba_schur_solve(const BaCtx c, BaLds &L_arg, const d
     __syncthreads();
     BA_TOCK(5)
     BA_TICK(6)
-    // blocked in-place lower Cholesky: 8-column panels factored in the registers of wave 0 (lane = row, the pivot row
-    // broadcast with v_readlane), trailing update by all
-    for (int p0 = 0; p0 < P; p0 += 8) {
-        const int pw = min(8, P - p0);
+    // Blocked in-place lower Cholesky with LOOK-AHEAD (round 5).  Wave 0 owns the panels: lane r carries rows r and 64 + r of the current 8-column
+    // panel in registers for the whole factorisation (a fixed lane <-> row map: no shuffles between panels), factors it right-looking (the pivot
+    // row is broadcast with v_readlane; only  readlane -> rsqrt -> scale -> readlane -> fma  is on the chain of a column, the LDS is not) and
+    // stores it; after the ONE workgroup barrier of the panel it fetches the next panel's columns and applies the panel it still holds in
+    // registers to them itself (64 broadcast multipliers), while waves 1..7 apply the panel to the rest of the trailing matrix on the matrix
+    // cores (16 x 16 tiles, the panel's 8 columns = two k-steps of v_mfma_f64_16x16x4_f64).  Round 4 had two barriers per panel, the whole
+    // trailing update between two panel factorisations and an LDS write + wait inside every column step: 52 k cycles per factorisation.
+    // A tile entry receives the panels in ascending order, as before; the next panel's entries receive panel p as ONE subtracted sum.
+    auto chol_tile = [&](int r0, int ti, int tk, int pc0) {
+        const int ra = r0 + 16 * ti + col, rb = r0 + 16 * tk + col;       // operand rows of this lane
+        ba_d4 acc4 = { 0, 0, 0, 0 };
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            const int q = 4 * ks + kq;
+            const double va = S[min(ra, P) * kBaSS + pc0 + q], vb = S[min(rb, P) * kBaSS + pc0 + q];
+            const double a = ra <= P ? va : 0.0;
+            const double bq = rb <= P ? vb : 0.0;
+            acc4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, acc4, 0, 0, 0);
+        }
+        // read-modify-write of the tile: the four reads go out together (unconditional, clamped), the writes are masked
+        const int nn = r0 + 16 * tk + col, nc = min(nn, kBaSS - 1);
+        double cur[4];
+#pragma unroll
+        for (int v = 0; v < 4; v++) cur[v] = S[min(r0 + 16 * ti + kq + 4 * v, P) * kBaSS + nc];
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const int m = r0 + 16 * ti + kq + 4 * v;
+            // columns r0 .. r0 + 7 are the next panel: wave 0 updates them in its registers
+            if (m <= P && nn < P && nn <= m && nn >= r0 + 8) S[m * kBaSS + nn] = cur[v] - acc4[v];
+        }
+    };
+    double cid0 = 0.0, cid1 = 0.0;                  // wave 0: 1 / l_rr of rows lane and 64 + lane (the backward substitution reads them)
+    {
+        // One wave alone issues a double-precision instruction every ~8 cycles, so the panel chain is priced in instructions.  Panels 0 and 1 reach
+        // past 64 rows (rows p0 .. P, P = 72): lane r carries rows r AND 64 + r (a, b).  From panel 2 on the remaining rows fit one register set:
+        // lane l carries row p0 + l (x), the pivot of column k sits in lane k, and the second set's multiply-adds are gone.
+        double a[8], b[8];                          // wave 0: the current panel; single-set panels use a[] only
+        bool bad = false;
+        const int ra_ = min(lane, P), rb_ = min(64 + lane, P);      // this lane's rows in the two-set map, clamped into the matrix
+        // 1 / sqrt(d): v_rsq_f64 and one third-order correction, y (1 + e / 2 + 3 e^2 / 8) with e = 1 - d y^2
+        auto rsqrt3 = [](double d) { double y = __builtin_amdgcn_rsq(d); const double e = __builtin_fma(-d * y, y, 1.0); return __builtin_fma(y * e, __builtin_fma(e, 0.375, 0.5), y); };
         if (wave == 0) {
-            const int i0 = p0 + lane, i1 = p0 + 64 + lane;      // rows of this lane (row P = right-hand side)
-            double a[8], b[8];
+            __builtin_amdgcn_s_setprio(3);
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                a[k] = (i0 <= P && k < pw) ? S[i0 * kBaSS + p0 + k] : 0.0;
-                b[k] = (i1 <= P && k < pw) ? S[i1 * kBaSS + p0 + k] : 0.0;
+                // unconditional LDS reads at clamped addresses + a select: a masked read is a branch with its own s_waitcnt, sixteen of them in a row
+                const double va = S[ra_ * kBaSS + k], vb = S[rb_ * kBaSS + k];
+                a[k] = lane <= P ? va : 0.0;
+                b[k] = 64 + lane <= P ? vb : 0.0;
             }
+        }
+        for (int p0 = 0; p0 < P; p0 += 8) {
+            const int pw = min(8, P - p0);
+            const bool two = p0 < 16;               // this panel is held as two register sets
+            if (wave == 0) {
+                BA_TICK(14)
+                if (two) {
 #pragma unroll
-            for (int jj = 0; jj < 8; jj++) {
-                if (jj < pw) {
-                    double s0 = a[jj], s1 = b[jj];
+                    for (int k = 0; k < 8; k++) {
+                        double d = readlane_d(a[k], p0 + k);
+                        if (!(d > 0.0)) { bad = true; d = 1.0; }
+                        const double y = rsqrt3(d);
+                        if (lane == p0 + k) cid0 = y;
+                        a[k] *= y; b[k] *= y;                      // the pivot row's own entry becomes d / sqrt(d)
 #pragma unroll
-                    for (int k = 0; k < jj; k++) {
-                        const double ljk = readlane_d(a[k], jj);
-                        s0 -= a[k] * ljk; s1 -= b[k] * ljk;
+                        for (int jj = k + 1; jj < 8; jj++) {
+                            const double ljk = readlane_d(a[k], p0 + jj);
+                            a[jj] -= a[k] * ljk; b[jj] -= b[k] * ljk;
+                        }
                     }
-                    double d = readlane_d(s0, jj);
-                    if (!(d > 0.0)) { if (lane == 0) L.ok = 0; d = 1.0; }
-                    const double id_ = rsqrt(d);
-                    if (lane == jj) L.u.fac.idiag[p0 + jj] = id_;
-                    a[jj] = lane == jj ? d * id_ : s0 * id_;
-                    b[jj] = s1 * id_;
-                }
-            }
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                if (k < pw && i0 <= P && lane >= k) S[i0 * kBaSS + p0 + k] = a[k];
-                if (k < pw && i1 <= P) S[i1 * kBaSS + p0 + k] = b[k];
+                    for (int k = 0; k < 8; k++) {
+                        if (lane <= P && lane >= p0 + k) S[lane * kBaSS + p0 + k] = a[k];
+                        if (64 + lane <= P) S[(64 + lane) * kBaSS + p0 + k] = b[k];
+                    }
+                } else {
+                    const int row = p0 + lane;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        double d = readlane_d(a[k], k);
+                        if (k >= pw) d = 1.0;                      // a column past the matrix (last panel of P = 66): zeros, never stored
+                        if (!(d > 0.0)) { bad = true; d = 1.0; }
+                        const double y = rsqrt3(d);
+                        if (lane == ((p0 + k) & 63)) { if (p0 + k >= 64) cid1 = y; else cid0 = y; }
+                        a[k] *= y;
+#pragma unroll
+                        for (int jj = k + 1; jj < 8; jj++) a[jj] -= a[k] * readlane_d(a[k], jj);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) if (k < pw && row <= P && lane >= k) S[row * kBaSS + p0 + k] = a[k];
+                }
+                BA_TOCK(14)
+            }
+            BA_TICK(15)
+            __syncthreads();
+            BA_TOCK(15)
+            const int r0 = p0 + 8;
+            if (r0 >= P) break;
+            if (wave == 0) {
+                BA_TICK(10)
+                // next panel: its columns (every earlier panel is in, the other waves finished theirs before the barrier) minus this panel's
+                // share.  The 64 multipliers l(r0 + c, p0 + k) come back from the LDS as broadcast reads (wave 0 stored the panel itself): the
+                // vector unit only runs the multiply-adds (a first version broadcast them with 128 v_readlane + 64 wait states).
+                if (r0 < 16) {
+                    double na[8], nb[8];
+#pragma unroll
+                    for (int c = 0; c < 8; c++) {
+                        const double va = S[ra_ * kBaSS + r0 + c], vb = S[rb_ * kBaSS + r0 + c];
+                        na[c] = lane <= P ? va : 0.0;
+                        nb[c] = 64 + lane <= P ? vb : 0.0;
+                    }
+#pragma unroll
+                    for (int h = 0; h < 4; h++) {
+                        double m[2][8];
+#pragma unroll
+                        for (int c = 0; c < 2; c++)
+#pragma unroll
+                            for (int k = 0; k < 8; k++) m[c][k] = S[(r0 + 2 * h + c) * kBaSS + p0 + k];
+#pragma unroll
+                        for (int c = 0; c < 2; c++) {
+                            double da = 0.0, db = 0.0;
+#pragma unroll
+                            for (int k = 0; k < 8; k++) { da += a[k] * m[c][k]; db += b[k] * m[c][k]; }
+                            na[2 * h + c] -= da; nb[2 * h + c] -= db;
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 8; c++) { a[c] = na[c]; b[c] = nb[c]; }
+                } else {
+                    // single set from here on: lane l takes row r0 + l; its entries of the panel just stored come back from the LDS as well
+                    const int row = r0 + lane, rc = min(row, P);
+                    double own[8], nx[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) own[k] = S[rc * kBaSS + p0 + k];
+#pragma unroll
+                    for (int c = 0; c < 8; c++) nx[c] = S[rc * kBaSS + min(r0 + c, P - 1)];
+#pragma unroll
+                    for (int h = 0; h < 4; h++) {
+                        double m[2][8];
+#pragma unroll
+                        for (int c = 0; c < 2; c++)
+#pragma unroll
+                            for (int k = 0; k < 8; k++) m[c][k] = S[min(r0 + 2 * h + c, P) * kBaSS + p0 + k];
+#pragma unroll
+                        for (int c = 0; c < 2; c++) {
+                            double da = 0.0;
+#pragma unroll
+                            for (int k = 0; k < 8; k++) da += own[k] * m[c][k];
+                            a[2 * h + c] = (row <= P && r0 + 2 * h + c < P) ? nx[2 * h + c] - da : 0.0;
+                        }
+                    }
+                }
+                BA_TOCK(10)
+            } else {
+                // (wave 4 shares its SIMD with wave 0, whose column chain is the critical path: it takes no tiles)
+                const int nt = (P + 1 - r0 + 15) >> 4;                            // tile rows of the trailing matrix (<= 5)
+                for (int t = wave < 4 ? wave - 1 : wave - 2; wave != 4 && t < nt * (nt + 1) / 2; t += kBaW - 2) {
+                    int ti = 0, rem = t;
+                    while (rem > ti) { rem -= ti + 1; ti++; }
+                    chol_tile(r0, ti, rem, p0);
+                }
             }
         }
-        __syncthreads();
-        const int r0 = p0 + pw, n = P + 1 - r0;   // rows r0 .. P (n <= 65), columns r0 .. P - 1
-        // trailing update S -= L_panel L_panel^T on the matrix cores: 16 x 16 tiles (ti >= tk) of the remaining rows, the panel's 8 columns
-        // as two k-steps of v_mfma_f64_16x16x4_f64; a tile belongs to one wave (whole tiles: entries above the diagonal are never read)
-        {
-            const int nt = (n + 15) >> 4;                         // tile rows (<= 5)
-            for (int t = wave; t < nt * (nt + 1) / 2; t += kBaW) {
-                int ti = 0, rem = t;
-                while (rem > ti) { rem -= ti + 1; ti++; }
-                const int tk = rem;
-                const int ra = r0 + 16 * ti + col, rb = r0 + 16 * tk + col;       // operand rows of this lane
-                ba_d4 acc4 = { 0, 0, 0, 0 };
-#pragma unroll
-                for (int ks = 0; ks < 2; ks++) {
-                    const int q = 4 * ks + kq;
-                    const double a = (ra <= P && q < pw) ? S[ra * kBaSS + p0 + q] : 0.0;
-                    const double bq = (rb <= P && q < pw) ? S[rb * kBaSS + p0 + q] : 0.0;
-                    acc4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, acc4, 0, 0, 0);
-                }
-#pragma unroll
-                for (int v = 0; v < 4; v++) {
-                    const int m = r0 + 16 * ti + kq + 4 * v, nn = r0 + 16 * tk + col;
-                    if (m <= P && nn < P && nn <= m) S[m * kBaSS + nn] -= acc4[v];
-                }
-            }
-        }
-        __syncthreads();
+        if (wave == 0 && bad && lane == 0) L.ok = 0;
     }
     BA_TOCK(6)
     BA_TICK(7)
-    // backward substitution L^T x = y by wave 0 (y = row P of the factor), rows lane and 64 + lane in registers
+    // Backward substitution L^T x = y by wave 0 (y = row P of the factor).  Lane j carries z_j = y_j / l_jj for rows j and 64 + j and the rows of
+    // L it reads are scaled by 1 / l_jj on the way in, so a step is  x_k = readlane(z, k);  z_j -= (l_kj / l_jj) x_k  -- the division and the LDS
+    // reads are off the dependent chain (round 4: a loop with a vector loop counter, masked LDS reads and an s_waitcnt per step: 360 cycles per step).
+    // Rows are requested eight at a time; every index is a compile-time constant after unrolling.
     if (wave == 0) {
-        double y0 = lane < P ? S[P * kBaSS + lane] : 0.0, y1 = 64 + lane < P ? S[P * kBaSS + 64 + lane] : 0.0;
-        for (int k = P - 1; k >= 0; k--) {
-            const double lk0 = lane < k ? S[k * kBaSS + lane] : 0.0, lk1 = 64 + lane < k ? S[k * kBaSS + 64 + lane] : 0.0;
-            const double num = k < 64 ? readlane_d(y0, k) : readlane_d(y1, k - 64);
-            const double xk = num * L.u.fac.idiag[k];
-            if (lane == (k & 63)) { if (k < 64) y0 = xk; else y1 = xk; }
-            y0 -= lk0 * xk; y1 -= lk1 * xk;
+        const double id0 = lane < P ? cid0 : 0.0, id1 = 64 + lane < P ? cid1 : 0.0;
+        // (unconditional reads of the 73-row LDS array + selects, see the panel loads)
+        const double y0 = S[P * kBaSS + lane], y1 = S[P * kBaSS + min(64 + lane, kBaSS - 1)];
+        double z0 = (lane < P ? y0 : 0.0) * id0, z1 = (64 + lane < P ? y1 : 0.0) * id1;
+        if (P > 64) {
+            double l0[8], l1[8];
+#pragma unroll
+            for (int kk = 0; kk < 8; kk++) {
+                const int k = 64 + kk;
+                const double v0 = S[k * kBaSS + lane], v1 = S[k * kBaSS + 64 + (lane & 7)];
+                l0[kk] = k < P ? v0 * id0 : 0.0;
+                l1[kk] = (k < P && lane < kk) ? v1 * id1 : 0.0;
+            }
+#pragma unroll
+            for (int kk = 7; kk >= 0; kk--) {
+                const double xk = readlane_d(z1, kk);          // rows >= P carry z = 0 and l = 0: no effect
+                z0 -= l0[kk] * xk; z1 -= l1[kk] * xk;
+            }
         }
-        if (lane < P) { L.gn[lane] = y0; if (!isfinite(y0)) L.ok = 0; }
-        if (64 + lane < P) { L.gn[64 + lane] = y1; if (!isfinite(y1)) L.ok = 0; }
+#pragma unroll
+        for (int kb = 56; kb >= 0; kb -= 8) {
+            if (kb < P) {
+                double l0[8];
+#pragma unroll
+                for (int kk = 0; kk < 8; kk++) {
+                    const int k = kb + kk;
+                    const double v0 = S[k * kBaSS + lane];
+                    l0[kk] = (k < P && lane < k) ? v0 * id0 : 0.0;
+                }
+#pragma unroll
+                for (int kk = 7; kk >= 0; kk--) {
+                    const double xk = readlane_d(z0, kb + kk);
+                    z0 -= l0[kk] * xk;
+                }
+            }
+        }
+        if (lane < P) { L.gn[lane] = z0; if (!isfinite(z0)) L.ok = 0; }
+        if (64 + lane < P) { L.gn[64 + lane] = z1; if (!isfinite(z1)) L.ok = 0; }
+        __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();
     BA_TOCK(7)
@@ -1249,7 +1384,7 @@ __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B)
     __syncthreads();
     BA_TOCK(9)
 #ifdef LMONO_BA_PROF
-    if (w == 0 && tid == 0) printf("PROF total %lld | lin: prologue %lld eval %lld mfma %lld | cost %lld | hs %lld | schur: stage+mfma %lld chol %lld subst %lld depth %lld | iters %d | wave-0 turn wait %lld, feature pass + small factors %lld (reduce pairs %lld, wave 0's features %lld)\n", g_prof[9], g_prof[0], g_prof[1], g_prof[2], g_prof[3], g_prof[4], g_prof[5], g_prof[6], g_prof[7], g_prof[8], iter, g_prof[10], g_prof[11], g_prof[12], g_prof[13]);
+    if (w == 0 && tid == 0) printf("PROF total %lld | lin: prologue %lld eval %lld mfma %lld | cost %lld | hs %lld | schur: stage+mfma %lld chol %lld subst %lld depth %lld | iters %d | wave-0 turn wait %lld, feature pass + small factors %lld (reduce pairs %lld, wave 0's features %lld) | chol: factor %lld barrier %lld next-panel %lld\n", g_prof[9], g_prof[0], g_prof[1], g_prof[2], g_prof[3], g_prof[4], g_prof[5], g_prof[6], g_prof[7], g_prof[8], iter, g_prof[10] * 0, g_prof[11], g_prof[12], g_prof[13], g_prof[14], g_prof[15], g_prof[10]);
 #endif
     for (int k = tid; k < c.n_poses * 7; k += kBaT) gposes[k] = L.poses[k];
     if (tid < 7) gex[tid] = L.ex[tid];
