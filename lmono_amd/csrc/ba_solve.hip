@@ -479,7 +479,9 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
     // wave 1: LASERFactor chain and prior, next to the pair records of wave 0
     // (their residuals / Jacobians wait in gn | va | vb, which are dead during a linearisation, until the pair blocks are in)
     static_assert(3 * kBaN >= 11 * kBaSmallRec, "small-factor records must fit gn | va | vb");
-    if (tid >= 64 && tid < 96) cost += ba_small_factors<kJac>(B, c, L.gn, poses, ex, tid - 64);
+    // (linearisation: wave 1 evaluates them at the head of its pair loop instead -- a single lane per block walks ~1000 double-precision instructions, and
+    // behind an accepted step, when the pair records are re-used, the whole workgroup used to wait for it here; ba_schedule gives wave 1 fewer pairs)
+    if (!kJac && tid >= 64 && tid < 96) cost += ba_small_factors<kJac>(B, c, L.gn, poses, ex, tid - 64);
     const double *mono_info = B.info + 36;
     const double m00 = gld(mono_info), m01 = gld(mono_info + 1), m10 = gld(mono_info + 2), m11 = gld(mono_info + 3);
     const int *sinfo = B.slot_info + c.ps0;
@@ -526,6 +528,7 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     BA_TOCK(0)
     BA_TICK(1)
+    if (kJac && tid >= 64 && tid < 96) cost += ba_small_factors<kJac>(B, c, L.gn, poses, ex, tid - 64);
     // Every wave works on whole frame pairs, taken from a work counter in descending size: 32 observations per round,
     // two lanes each (lane q of the pair owns residual row q), the 64 rows staged in the wave's own LDS slice and
     // multiplied right away -- no workgroup barrier inside the loop.
@@ -1182,7 +1185,7 @@ __device__ __noinline__ void ba_schedule(const BaBatch &B, const BaCtx c, BaLds 
     __syncthreads();
     if (tid == 0) {
         int load[kBaW];
-        for (int w = 0; w < kBaW; w++) load[w] = 0;
+        for (int w = 0; w < kBaW; w++) load[w] = w == 1 ? 1 : 0;      // wave 1 starts with the LASERFactor chain and the prior (about one round)
         for (int p = 0; p < c.n_pairs; p++) {
             int w = 0;
             for (int u = 1; u < kBaW; u++) if (load[u] < load[w]) w = u;
