@@ -41,7 +41,10 @@ constexpr int kBaRow = 19;                       // staged row: J_i(6) J_j(6) J_
 constexpr int kBaFT = 64;                        // features per Schur tile
 constexpr int kBaSS = 73;                        // row stride of S in LDS (odd: conflict-free column walks)
 constexpr int kBaPairRec = 52;                   // Tres(9) tres(3) Cm(9) A(9) B(9) Tn(9) tn(3) pad
-constexpr int kBaPairTile = 320;                 // 16 x 16 tile + 16 x 4 side tile of a frame pair
+constexpr int kBaPairTile = 320;                 // 16 x 16 tile + 16 x 4 side tile of a SEGMENT of a frame pair (column 3 of the side tile: the segment's scalar sums)
+constexpr int kBaSeg = 16;                       // observations of a segment: a frame pair's slots in runs of 16 (two lanes each: half a wave)
+constexpr int kBaMaxSeg = kBaMaxPairs + kBaMaxFeat * (kBaMaxPoses - 1) / kBaSeg;      // 110 + 280
+constexpr int kBaObsRec = 24;                    // per-observation record: hdd, gd, hx[6], hi[6], hj[6], oj
 constexpr int kBaT = 512;                        // threads per workgroup (2 waves per SIMD)
 constexpr int kBaW = kBaT / 64;
 
@@ -61,6 +64,10 @@ struct BaBatch {
     const int *pair_ij;         // [total pairs] i | j << 8
     const int *pobs_off;        // [W+1] first slot of each window in the pair-ordered observation list
     const int *pair_slot;       // [total pairs + W] per window n_pairs + 1 window-local slot offsets; pairs sorted by descending size
+    const int *seg_off;         // [W+1] first segment of each window
+    const unsigned short *seg_tab;  // [total segments] pair (window-local, 7 bits) | index of the segment inside its pair << 7
+    const int *pair_seg;        // [total pairs + W] per window n_pairs + 1 window-local first segments of the pairs
+    const int *n_multi;         // [W] pairs of more than one segment (they come first: the pairs are sorted by descending size)
     const int *slot_info;       // [total slots] feature | pair << 16 (both window-local), slots ordered by pair
     const double *slot_pts;     // [total slots][4] the observation's two normalised image points, in slot order
     const double *laser_consts; // [W][10][24]
@@ -70,9 +77,11 @@ struct BaBatch {
     double *pairdat;            // scratch [total pairs][kBaPairRec]
     const int *feat_obs_off;    // [total F + 1] first observation of every feature (observations grouped by feature, host order)
     const int *slot_obs;        // [total slots] observation (host order, global index) behind every slot
-    double *obsc;               // scratch [total obs][16]: per-observation depth / coupling contributions (hdd, gd, hx[6], hi[6]),
+    double *obsc;               // scratch [total obs][kBaObsRec]: per-observation depth / coupling contributions (hdd, gd, hx[6], hi[6], hj[6], oj),
                                 // in host observation order = grouped by feature: a feature's records are contiguous
-    double *pairH;              // scratch [total pairs][kBaPairTile]: every pair's J^T [J r] tile (16 x 16 + 16 x 4), summed by ba_reduce_pairs
+    double *pairH;              // scratch [total segments + total pairs][kBaPairTile], per window [its segments | its pairs]: every segment's J^T [J r] tile
+                                // (16 x 16 + 16 x 4) and scalar sums; a pair of several segments has their sum (segment order) in its own tile (ba_reduce_pairs)
+    double *cpart;              // scratch [total segments]: every segment's share of a candidate's cost
     double *cand;               // scratch [W][kBaMaxFeat]
     double *summary;            // [W][6] initial_cost, final_cost, iterations, termination, successful, unsuccessful
 };
@@ -99,11 +108,12 @@ struct BaLds {
     double Mq[(kBaMaxPoses + 1) * 18 + 9];       // per pose and for the extrinsic: M(q), M(q^-1) of the RAW quaternion (residual path); then M(qx^-1)^-1
     double vinv[kBaMaxFeat];                     // inverse depths of the state being evaluated
     int pair_ij[kBaMaxPairs];
-    int pair_slot[kBaMaxPairs + 1];              // first slot of every pair (pairs in descending size)
-    // static schedule of the linearisation (ba_schedule, once per launch): which wave takes which frame pairs, and the order
-    // in which the pairs' blocks are added to H_pp -- fixed by the pair sizes alone, so the sums are the same in every run
-    short wlist[kBaMaxPairs];                    // pairs in wave order
-    short woff[kBaW + 1];                        // first entry of every wave in wlist
+    short pair_slot[kBaMaxPairs + 1];            // first slot of every pair (pairs in descending size)
+    // The linearisation's unit of work is a SEGMENT: up to 16 consecutive slots of one frame pair (round 5).  Every sum that crosses observations is
+    // formed per segment (its J^T [J r] tile, its share of the cost and of the extrinsic corner) and the segments' results are added in segment
+    // order, so the bits depend neither on which wave takes a segment nor on how many workgroups share a window.
+    unsigned short seg[kBaMaxSeg];               // pair | index inside the pair << 7
+    short pair_seg[kBaMaxPairs + 1];             // first segment of every pair
     short pair_of[kBaMaxPoses * kBaMaxPoses];    // pair (anchor i, observer j) -> index in the window's pair list, -1: none
     unsigned short fobs[kBaMaxFeat + 1];         // first observation of every feature, relative to the window's first (host order: grouped by feature)
     signed char fanchor[kBaMaxFeat];             // the frame a feature is anchored in (-1: no observation)
@@ -164,6 +174,7 @@ struct BaCtx {
     int f0, o0;
     int pp0, n_pairs;      // first pair / number of pairs of this window
     int ps0, n_slots;      // first slot / number of slots of the pair-ordered observation list
+    int sg0, n_seg, n_multi;   // first segment / number of segments of this window; pairs of more than one segment
 };
 __device__ __forceinline__ int ba_pose_off(const BaCtx &c, int i) { return (c.ex_off < 0 ? 0 : 6) + 6 * i; }
 
@@ -350,34 +361,77 @@ __device__ __forceinline__ void ba_prior_accumulate_wave(const BaCtx &c, BaLds &
     __builtin_amdgcn_wave_barrier();    // the slice becomes the wave's Jacobian stage
 }
 
-// H_pp and g_p as ordered sums of the frame pairs' tiles (ba_evaluate leaves one record per pair in the L2 scratch): every entry is owned
-// by one thread, which adds the tiles that touch it in a fixed order -- the pairs (f, j) by ascending j, then the pairs (i, f) by
-// ascending i for an entry of frame f's rows / columns; all pairs by index for the extrinsic block -- so the sums are the same bits in
-// every run whatever the waves' timing was.  Entries nothing touches become zero: the pass replaces clearing H_pp.
+// H_pp and g_p as ordered sums of the segments' tiles (ba_evaluate leaves one record per segment in the L2 scratch): every entry is owned
+// by one thread, which adds the tiles that touch it in a fixed order -- a pair's segments in segment order, then the pairs (f, j) by ascending j and
+// the pairs (i, f) by ascending i for an entry of frame f's rows / columns; all segments by index for the extrinsic block -- so the sums are the same
+// bits in every run whatever the waves' timing was and whoever computed a segment.  Entries nothing touches become zero: the pass replaces clearing H_pp.
 __device__ __forceinline__ void ba_reduce_pairs(const BaBatch &B, const BaCtx c, BaLds &L)
 {
     const int tid = threadIdx.x, np_ = c.n_poses;
-    const double *tiles = B.pairH + (size_t)c.pp0 * kBaPairTile;
-    // position of (row r, column q) of a pair's record; rows / columns 0..5 = frame i, 6..11 = frame j, 12..15 = extrinsic 0..3 (the 16 x 16
+    // the window's tiles: one per segment, then one per pair (used by the pairs of several segments)
+    double *tiles = B.pairH + (size_t)(c.sg0 + c.pp0) * kBaPairTile;
+    double *ptile = tiles + (size_t)c.n_seg * kBaPairTile;
+    // (0) pairs of several segments (they come first: the pairs are sorted by size): their tiles summed in segment order into the pair's own tile
+    if (c.n_multi > 0) {
+        constexpr int kE = 4;                                   // entries per thread and turn
+        for (int e0 = tid; e0 < c.n_multi * kBaPairTile; e0 += kE * kBaT) {
+            double acc[kE];
+            int pe[kE], s0[kE], s1[kE], smax = 0;
+#pragma unroll
+            for (int u = 0; u < kE; u++) {
+                const int e = e0 + u * kBaT;
+                const bool in = e < c.n_multi * kBaPairTile;
+                pe[u] = in ? e : -1;
+                const int pq = in ? e / kBaPairTile : 0;
+                s0[u] = L.pair_seg[pq]; s1[u] = in ? (int)L.pair_seg[pq + 1] : s0[u];
+                smax = max(smax, s1[u] - s0[u]);
+                acc[u] = 0.0;
+            }
+            // eight segments of each entry in flight (a pair of up to 128 observations in one trip)
+            for (int b = 0; b < smax; b += 8) {
+                double v[kE][8];
+#pragma unroll
+                for (int u = 0; u < kE; u++)
+#pragma unroll
+                    for (int d = 0; d < 8; d++) {
+                        const int sgm = s0[u] + b + d;
+                        v[u][d] = sgm < s1[u] ? gld(tiles + (size_t)sgm * kBaPairTile + (pe[u] % kBaPairTile)) : 0.0;
+                    }
+#pragma unroll
+                for (int u = 0; u < kE; u++)
+#pragma unroll
+                    for (int d = 0; d < 8; d++) acc[u] += v[u][d];
+            }
+#pragma unroll
+            for (int u = 0; u < kE; u++) if (pe[u] >= 0) gst(ptile + pe[u], acc[u]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    // (L.pair_of holds a pair's TILE: its own for a pair of several segments, its only segment's otherwise)
+    auto tile_of = [&](int tix) -> const double * { return tiles + tix * kBaPairTile; };
+    // position of (row r, column q) of a tile; rows / columns 0..5 = frame i, 6..11 = frame j, 12..15 = extrinsic 0..3 (the 16 x 16
     // tile), column 16 / 17 = extrinsic 4 / 5 and column 18 = the residual (the 16 x 4 side tile); the tile is symmetric
     auto pos = [](int r, int q) { return q < 16 ? (r < 16 ? r * 16 + q : 256 + q * 4 + (r - 16)) : 256 + r * 4 + (q - 16); };
     const int x0 = c.ex_off;                                   // first extrinsic index (-1: extrinsic constant)
     // (A) entries coupling two DIFFERENT frames: the one pair that holds both (a caller may anchor tracks at a later frame: both orders).
     //     Four entries per thread and turn: their loads are in flight together.
-    for (int t0 = tid; t0 < np_ * np_ * 36; t0 += 4 * kBaT) {
+    //     (the index runs over all 11 x 11 frame blocks: divisions by constants; blocks of absent frames are skipped)
+    for (int t0 = tid; t0 < kBaMaxPoses * kBaMaxPoses * 36; t0 += 4 * kBaT) {
         double v1[4], v2[4];
         int dst[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int t = t0 + u * kBaT;
             dst[u] = -1; v1[u] = 0.0; v2[u] = 0.0;
-            if (t < np_ * np_ * 36) {
-                const int bm = t / (np_ * 36), r = t % (np_ * 36), bn = r / 36, om = (r % 36) / 6, on = r % 6;
-                if (bm != bn) {
+            if (t < kBaMaxPoses * kBaMaxPoses * 36) {
+                const int bm = t / (kBaMaxPoses * 36), r = t % (kBaMaxPoses * 36), bn = r / 36, om = (r % 36) / 6, on = r % 6;
+                if (bm != bn && bm < np_ && bn < np_) {
                     const int i = bm < bn ? bm : bn, j = bm < bn ? bn : bm;
                     const int p1 = L.pair_of[i * kBaMaxPoses + j], p2 = L.pair_of[j * kBaMaxPoses + i];
-                    if (p1 >= 0) v1[u] = gld(tiles + (size_t)p1 * kBaPairTile + pos(bm == i ? om : 6 + om, bn == i ? on : 6 + on));
-                    if (p2 >= 0) v2[u] = gld(tiles + (size_t)p2 * kBaPairTile + pos(bm == j ? om : 6 + om, bn == j ? on : 6 + on));
+                    if (p1 >= 0) v1[u] = gld(tile_of(p1) + pos(bm == i ? om : 6 + om, bn == i ? on : 6 + on));
+                    if (p2 >= 0) v2[u] = gld(tile_of(p2) + pos(bm == j ? om : 6 + om, bn == j ? on : 6 + on));
                     dst[u] = (ba_pose_off(c, bm) + om) * kBaP + ba_pose_off(c, bn) + on;
                 }
             }
@@ -406,8 +460,8 @@ __device__ __forceinline__ void ba_reduce_pairs(const BaBatch &B, const BaCtx c,
         for (int k = 0; k < kBaMaxPoses; k++) {
             const int pa = (k < np_ && k != f) ? L.pair_of[f * kBaMaxPoses + k] : -1;
             const int pb = (k < np_ && k != f) ? L.pair_of[k * kBaMaxPoses + f] : -1;
-            va[k] = pa >= 0 ? gld(tiles + (size_t)pa * kBaPairTile + oi_) : 0.0;
-            vb[k] = pb >= 0 ? gld(tiles + (size_t)pb * kBaPairTile + oj_) : 0.0;
+            va[k] = pa >= 0 ? gld(tile_of(pa) + oi_) : 0.0;
+            vb[k] = pb >= 0 ? gld(tile_of(pb) + oj_) : 0.0;
         }
         double acc = 0.0;
 #pragma unroll
@@ -417,25 +471,81 @@ __device__ __forceinline__ void ba_reduce_pairs(const BaBatch &B, const BaCtx c,
         if (is_g) L.gp[dst] = acc;
         else { L.Hpp[dst] = acc; if (dst2 >= 0) L.Hpp[dst2] = acc; }
     }
-    // (C) the extrinsic block and gradient from the waves' partial sums (wave order); the (4..5, 4..5) corner and g_x4, g_x5 are added by
-    //     wave 1 afterwards and start at zero
-    if (x0 >= 0 && tid < 42) {
-        double acc = 0.0;
-        int dst;
-        if (tid < 36) {
-            const int om = tid / 6, on = tid % 6;
-            dst = (x0 + om) * kBaP + x0 + on;
-            if (om < 4 && on < 4) { for (int w = 0; w < kBaW; w++) acc += L.D[w * 40 + om * 4 + on]; }
-            else if (om < 4) { for (int w = 0; w < kBaW; w++) acc += L.D[w * 40 + 16 + om * 3 + (on - 4)]; }
-            else if (on < 4) { for (int w = 0; w < kBaW; w++) acc += L.D[w * 40 + 16 + on * 3 + (om - 4)]; }
-            L.Hpp[dst] = acc;
-        } else {
-            const int om = tid - 36;
-            if (om < 4) for (int w = 0; w < kBaW; w++) acc += L.D[w * 40 + 16 + om * 3 + 2];
-            L.gp[x0 + om] = acc;
+    // (C) the extrinsic block and gradient get a share from EVERY segment: 33 values per segment (rows 12..15 of the tile and of the side tile, and
+    //     the five scalar sums of the (4..5, 4..5) corner); 15 threads per value add the segments s = g (mod 15) in ascending order into L.D (dead during
+    //     a linearisation), one thread per value then adds the 15 in order
+    if (x0 >= 0) {
+        constexpr int kG = 15;
+        if (tid < 33 * kG) {
+            const int e = tid % 33, g = tid / 33;
+            int off;
+            if (e < 16) off = (12 + e / 4) * 16 + 12 + e % 4;
+            else if (e < 28) off = 256 + (12 + (e - 16) / 3) * 4 + (e - 16) % 3;
+            else off = 256 + (e - 27) * 4 + 3;
+            double acc = 0.0;
+            for (int sg = g; sg < c.n_seg; sg += 4 * kG) {
+                double v[4];
+#pragma unroll
+                for (int d = 0; d < 4; d++) v[d] = sg + d * kG < c.n_seg ? gld(tiles + (size_t)(sg + d * kG) * kBaPairTile + off) : 0.0;
+#pragma unroll
+                for (int d = 0; d < 4; d++) acc += v[d];
+            }
+            L.D[g * 33 + e] = acc;
+        }
+        __syncthreads();
+        if (tid < 33) {
+            double tot = 0.0;
+#pragma unroll
+            for (int g = 0; g < kG; g++) tot += L.D[g * 33 + tid];
+            const int e = tid, x4 = x0 + 4, x5 = x0 + 5;
+            if (e < 16) L.Hpp[(x0 + e / 4) * kBaP + x0 + e % 4] = tot;
+            else if (e < 28) {
+                const int om = (e - 16) / 3, cc = (e - 16) % 3;
+                if (cc < 2) { L.Hpp[(x0 + om) * kBaP + x4 + cc] = tot; L.Hpp[(x4 + cc) * kBaP + x0 + om] = tot; }
+                else L.gp[x0 + om] = tot;
+            }
+            else if (e == 28) L.Hpp[x4 * kBaP + x4] = tot;
+            else if (e == 29) { L.Hpp[x4 * kBaP + x5] = tot; L.Hpp[x5 * kBaP + x4] = tot; }
+            else if (e == 30) L.Hpp[x5 * kBaP + x5] = tot;
+            else if (e == 31) L.gp[x4] = tot;
+            else L.gp[x5] = tot;
         }
     }
     __syncthreads();
+}
+
+// the segments' shares of a cost (one double per segment, `stride` apart), added in segment order by wave 0; the result is left in L.red[3 * kBaW - 1]
+// for everybody (read it behind the next workgroup barrier)
+__device__ __forceinline__ void ba_segment_cost(const BaCtx &c, BaLds &L, const double *part, int stride)
+{
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        double acc = 0.0;
+        for (int sg = tid; sg < c.n_seg; sg += 4 * 64) {
+            double v[4];
+#pragma unroll
+            for (int d = 0; d < 4; d++) v[d] = sg + 64 * d < c.n_seg ? gld(part + (size_t)(sg + 64 * d) * stride) : 0.0;
+#pragma unroll
+            for (int d = 0; d < 4; d++) acc += v[d];
+        }
+        acc = wave_sum_d(acc);
+        if (tid == 0) L.red[3 * kBaW - 1] = acc;
+    }
+}
+
+// sum over the 32 lanes of this lane's half of the wave (lanes 0..31 / 32..63), in every lane of the half
+__device__ __forceinline__ double half_sum_d(double v)
+{
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+// sum over the 16 lanes of this lane's quarter of the wave
+__device__ __forceinline__ double quarter_sum_d(double v)
+{
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
 }
 
 // cost (returned to every thread) and, when kJac, the unscaled normal equations: Hpp, gp, Hdd, gdd in LDS, Hpd in HBM
@@ -475,51 +585,60 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
         for (int k = 0; k < kBaPairRec; k++) gst(dst + k, rec[k]);
     }
     }
-    double cost = 0.0;
     // wave 1: LASERFactor chain and prior, next to the pair records of wave 0
     // (their residuals / Jacobians wait in gn | va | vb, which are dead during a linearisation, until the pair blocks are in)
     static_assert(3 * kBaN >= 11 * kBaSmallRec, "small-factor records must fit gn | va | vb");
     // (linearisation: wave 1 evaluates them at the head of its pair loop instead -- a single lane per block walks ~1000 double-precision instructions, and
-    // behind an accepted step, when the pair records are re-used, the whole workgroup used to wait for it here; ba_schedule gives wave 1 fewer pairs)
-    if (!kJac && tid >= 64 && tid < 96) cost += ba_small_factors<kJac>(B, c, L.gn, poses, ex, tid - 64);
+    // behind an accepted step, when the pair records are re-used, the whole workgroup used to wait for it here)
+    double small_cost = 0.0;
+    if (!kJac && tid >= 64 && tid < 96) small_cost = ba_small_factors<kJac>(B, c, L.gn, poses, ex, tid - 64);
     const double *mono_info = B.info + 36;
     const double m00 = gld(mono_info), m01 = gld(mono_info + 1), m10 = gld(mono_info + 2), m11 = gld(mono_info + 3);
     const int *sinfo = B.slot_info + c.ps0;
     const double *spts = B.slot_pts + (size_t)c.ps0 * 4;
+    const int gw = wave, GW = kBaW;                      // this wave among the waves that share the window's segments
     if (!kJac) {
         __syncthreads();   // pair records are visible
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        // four slots per thread and round: their index words and image points are requested before any is used
-        for (int s0 = tid; s0 < c.n_slots; s0 += 4 * kBaT) {
-            int info[4];
-            double2 pa[4], pb[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int s = s0 + kBaT * u;
-                info[u] = -1;
-                if (s < c.n_slots) {
-                    info[u] = gldi(sinfo + s);
-                    pa[u] = make_double2(gld(spts + (size_t)s * 4), gld(spts + (size_t)s * 4 + 1)); pb[u] = make_double2(gld(spts + (size_t)s * 4 + 2), gld(spts + (size_t)s * 4 + 3));
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                if (info[u] < 0 || (info[u] & 0xffff) == 0xffff) continue;
-                const double *rec = pairdat + (size_t)(info[u] >> 16) * kBaPairRec;
-                const double depth = 1.0 / L.vinv[info[u] & 0xffff];
-                const double pc[3] = { depth * pa[u].x, depth * pa[u].y, depth };
+        // one lane per slot, 16 lanes per segment, four segments per wave and round: a segment's share of the cost is the sum over its 16 lanes and
+        // goes to the segment's own cell; the cells are added in segment order below
+        double *cpart = B.cpart + c.sg0;
+        for (int s4 = 4 * gw; s4 < c.n_seg; s4 += 4 * GW) {
+            const int sg = s4 + (lane >> 4);
+            const bool seg_ok = sg < c.n_seg;
+            const unsigned int sv = L.seg[seg_ok ? sg : s4];
+            const int pr = sv & 127;
+            const int so = L.pair_slot[pr] + kBaSeg * (int)(sv >> 7) + (lane & 15);
+            double cst = 0.0;
+            if (seg_ok && so < L.pair_slot[pr + 1]) {
+                const int f = gldi(sinfo + so) & 0xffff;
+                const double pax = gld(spts + (size_t)so * 4), pay = gld(spts + (size_t)so * 4 + 1);
+                const double pbx = gld(spts + (size_t)so * 4 + 2), pby = gld(spts + (size_t)so * 4 + 3);
+                const double *rec = pairdat + (size_t)pr * kBaPairRec;
                 double Tt[12], pcj[3];
 #pragma unroll
                 for (int k = 0; k < 12; k++) Tt[k] = gld(rec + k);
+                const double depth = 1.0 / L.vinv[f];
+                const double pc[3] = { depth * pax, depth * pay, depth };
                 ba::mv(Tt, pc, pcj);
                 for (int k = 0; k < 3; k++) pcj[k] += Tt[9 + k];
                 const double inv = 1.0 / pcj[2];
-                const double e0 = pcj[0] * inv - pb[u].x, e1 = pcj[1] * inv - pb[u].y;
+                const double e0 = pcj[0] * inv - pbx, e1 = pcj[1] * inv - pby;
                 const double r0 = m00 * e0 + m01 * e1, r1 = m10 * e0 + m11 * e1;
-                cost += 0.5 * log(1.0 + (r0 * r0 + r1 * r1));   // ceres::CauchyLoss(1)
+                cst = 0.5 * log(1.0 + (r0 * r0 + r1 * r1));   // ceres::CauchyLoss(1)
             }
+            cst = quarter_sum_d(cst);
+            if (seg_ok && (lane & 15) == 0) gst(cpart + sg, cst);
         }
-        cost = block_sum(cost, L.red);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        ba_segment_cost(c, L, cpart, 1);
+        // the LASERFactor chain's and the prior's share: wave 1's lanes 0..31
+        if (wave == 1) { small_cost = wave_sum_d(small_cost); if (lane == 0) L.red[3 * kBaW - 2] = small_cost; }
+        __syncthreads();
+        const double cost = L.red[3 * kBaW - 1] + L.red[3 * kBaW - 2];
+        __syncthreads();
         BA_TOCK(3)
         return cost;
     }
@@ -528,34 +647,27 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     BA_TOCK(0)
     BA_TICK(1)
-    if (kJac && tid >= 64 && tid < 96) cost += ba_small_factors<kJac>(B, c, L.gn, poses, ex, tid - 64);
-    // Every wave works on whole frame pairs, taken from a work counter in descending size: 32 observations per round,
-    // two lanes each (lane q of the pair owns residual row q), the 64 rows staged in the wave's own LDS slice and
-    // multiplied right away -- no workgroup barrier inside the loop.
+    if (kJac && tid >= 64 && tid < 96) small_cost = ba_small_factors<kJac>(B, c, L.gn, poses, ex, tid - 64);
+    // Every wave takes SEGMENTS (up to 16 slots of one frame pair), two per round: lanes 0..31 the first, lanes 32..63 the second, two lanes per
+    // observation (lane q of the pair owns residual row q); the 64 rows are staged in the wave's own LDS slice and multiplied right away (MFMA steps
+    // 0..7 -> the first segment's tile, 8..15 -> the second's) -- no workgroup barrier inside the loop.  A segment's tile, its share of the cost and
+    // of the extrinsic (4..5, 4..5) corner go to the segment's own record: nothing is carried from one round to the next, so which wave (of which
+    // workgroup) takes a segment does not change a bit of the result.
     double *wstage = L.u.stage + (size_t)wave * 2 * kBaRound * kBaRow;
-    const int q = lane & 1, lo = lane >> 1, col = lane & 15, kq = lane >> 4;
-    double xx44 = 0, xx45 = 0, xx55 = 0, gx4 = 0, gx5 = 0;
-    double xa = 0, xb = 0;      // this lane's entry of the extrinsic rows 12..15 of the tiles, summed over the wave's pairs (all pairs touch them)
-    // Round 4: two SMALL pairs share a round.  Most frame pairs of a window hold fewer than 16 observations (the Estimator's windows: ~14 on
-    // average), so a 32-observation round was half empty and a pair cost a whole round of ~15 k cycles whatever it held.  When a pair and the next one of
-    // the wave's list both fit 16 slots, lanes 0..31 take the first and lanes 32..63 the second: every lane reads ITS pair's record, the 64 staged rows
-    // are multiplied in two halves (MFMA steps 0..7 -> the first pair's tile, 8..15 -> the second's).  A pair's rows, their order and the order in
-    // which the wave adds its pairs' extrinsic rows are what they were; per-lane partial sums (cost, the extrinsic corner) meet different lanes.
-    constexpr int kBaHalf = kBaRound / 2;
-    for (int wi = L.woff[wave]; wi < L.woff[wave + 1];) {
-        const int pr0 = L.wlist[wi];
-        int pr1 = -1;
-        if (wi + 1 < L.woff[wave + 1] && L.pair_slot[pr0 + 1] - L.pair_slot[pr0] <= kBaHalf) {
-            const int cand = L.wlist[wi + 1];
-            if (L.pair_slot[cand + 1] - L.pair_slot[cand] <= kBaHalf) pr1 = cand;
-        }
-        const bool two = pr1 >= 0;
-        wi += two ? 2 : 1;
-        const int pr = two && lane >= 32 ? pr1 : pr0;       // this lane's pair
-        const int ij = L.pair_ij[pr], fi = ij & 255, fj = ij >> 8;
-        const int s_begin = L.pair_slot[pr], s_end = L.pair_slot[pr + 1];
-        const int oi = ba_pose_off(c, fi), oj = ba_pose_off(c, fj);
-        // the pair record: one (broadcast) request per value, kept in registers for all rounds of the pair
+    double *tiles = B.pairH + (size_t)(c.sg0 + c.pp0) * kBaPairTile;
+    const int q = lane & 1, half = lane >> 5, lo = (lane & 31) >> 1, col = lane & 15, kq = lane >> 4;
+    const double *Mx = L.Mq + 18 * c.n_poses, *Mxi = L.Mq + 18 * (kBaMaxPoses + 1);
+    for (int sA = gw; sA < c.n_seg; sA += 2 * GW) {
+        const int sB = sA + GW;
+        const int sg = half ? sB : sA;                       // this lane's segment
+        const bool seg_ok = sg < c.n_seg;
+        const unsigned int sv = L.seg[seg_ok ? sg : sA];
+        const int pr = sv & 127;
+        const int s_begin = L.pair_slot[pr] + kBaSeg * (int)(sv >> 7), s_end = min(s_begin + kBaSeg, (int)L.pair_slot[pr + 1]);
+        const int so = s_begin + lo;
+        const int ij = L.pair_ij[pr], fj = ij >> 8;
+        const int oj = ba_pose_off(c, fj);
+        // the pair record: one request per value (at most two addresses per wave), kept in registers for the round
         double rec[kBaPairRec - 1];
         {
             const double *rp = pairdat + (size_t)pr * kBaPairRec;
@@ -563,165 +675,128 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
             for (int k = 0; k < kBaPairRec - 1; k++) rec[k] = gld(rp + k);
         }
         const double *T = rec, *Cm = rec + 12, *A = rec + 21, *Bm = rec + 30, *Tn = rec + 39;
-        const double *Mx = L.Mq + 18 * c.n_poses, *Mxi = L.Mq + 18 * (kBaMaxPoses + 1);
-        ba_d4 aa = { 0, 0, 0, 0 }, ab = { 0, 0, 0, 0 };
-        // solo: rounds of 32 slots of the one pair; paired: ONE round, 16 slots of each pair (base = this lane's pair's first slot)
-        const int n_solo = L.pair_slot[pr0 + 1] - L.pair_slot[pr0];
-        for (int rb = 0; rb < (two ? 1 : n_solo); rb += kBaRound) {
-            const int base = s_begin + rb;
-            const int so = base + (two ? (lo & (kBaHalf - 1)) : lo);
-            double *row = wstage + (size_t)lane * kBaRow;
-            if (so < s_end) {
-                const int f = gldi(sinfo + so) & 0xffff;
-                const int ob = gldi(B.slot_obs + c.ps0 + so);
-                const double pax = gld(spts + (size_t)so * 4), pay = gld(spts + (size_t)so * 4 + 1);
-                const double pbx = gld(spts + (size_t)so * 4 + 2), pby = gld(spts + (size_t)so * 4 + 3);
-                const double depth = 1.0 / L.vinv[f];
-                const double pc[3] = { depth * pax, depth * pay, depth };
-                double Tp[3], pcj[3], pcn[3], uT[3], u[3];
-                ba::mv(T, pc, Tp);
-                for (int k = 0; k < 3; k++) pcj[k] = Tp[k] + rec[9 + k];     // the residual's p_cj (raw quaternions)
-                ba::mv(Tn, pc, Tp);                                          // from here on Tp = Tn pc: the Jacobians' normalised product
-                for (int k = 0; k < 3; k++) pcn[k] = Tp[k] + rec[48 + k];
-                const double inv = 1.0 / pcj[2];
-                const double e0 = pcj[0] * inv - pbx, e1 = pcj[1] * inv - pby;
-                const double r0 = m00 * e0 + m01 * e1, r1 = m10 * e0 + m11 * e1;
-                const double sq = r0 * r0 + r1 * r1;
-                if (q == 0) cost += 0.5 * log(1.0 + sq);
-                // ceres::CauchyLoss(1): rho' = 1 / (1 + s), rho'' < 0 -> the corrector scales rows by sqrt(rho')
-                const double rho1 = 1.0 / (1.0 + sq);
-                const double sr = sqrt(rho1 > DBL_MIN ? rho1 : DBL_MIN);
-                const double rq = (q ? r1 : r0) * sr;
-                // row q of sqrt_info * [[1/z, 0, -x/z^2], [0, 1/z, -y/z^2]], robustified
-                const double ma = q ? m10 : m00, mb = q ? m11 : m01;
-                u[0] = sr * ma * inv; u[1] = sr * mb * inv; u[2] = -sr * (ma * pcj[0] + mb * pcj[1]) * inv * inv;
-                rowmul(u, Tn, uT);
-                // inverse depth: -u (Tn p_i) depth^2 = -u (Tn pc) depth
-                const double Jd = -(u[0] * Tp[0] + u[1] * Tp[1] + u[2] * Tp[2]) * depth;
-                double Jx[6], Ji[6], Jj[6], c1[3], c2[3];
-                // extrinsic block: position u Cm, rotation -(uT) x pc + u x (Tn pc + tn)   (u skew(v) = u x v; :127-130: all normalised)
-                if (c.ex_off >= 0) {
-                    rowmul(u, Cm, Jx);
-                    cross3(uT, pc, c1); cross3(u, pcn, c2);
-                    for (int k = 0; k < 3; k++) Jx[3 + k] = c2[k] - c1[k];
-                    xx44 += Jx[4] * Jx[4]; xx45 += Jx[4] * Jx[5]; xx55 += Jx[5] * Jx[5];
-                    gx4 += Jx[4] * rq; gx5 += Jx[5] * rq;
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 6; k++) Jx[k] = 0.0;
-                }
-                // pose i: position u A, rotation -(u B) x pl;  pose j: position -u A, rotation (u Rlc^T) x plj, with the residual
-                // path's own points pl = pts_laser_i = Qx pc + tx and plj = pt_l_j = M(qx^-1)^-1 p_cj + tx (:66-68, :145, :158)
-                {
-                    double uB[3], uR[3], pl[3], plj[3];
-                    rowmul(u, A, Ji);
-                    for (int k = 0; k < 3; k++) Jj[k] = -Ji[k];
-                    ba::mv(Mx, pc, pl);
-                    for (int k = 0; k < 3; k++) pl[k] += ex[k];
-                    rowmul(u, Bm, uB); cross3(uB, pl, c1);
-                    for (int k = 0; k < 3; k++) Ji[3 + k] = -c1[k];
-                    ba::mv(Mxi, pcj, plj);
-                    for (int k = 0; k < 3; k++) plj[k] += ex[k];
-                    uR[0] = u[0] * Rlc[0] + u[1] * Rlc[1] + u[2] * Rlc[2];
-                    uR[1] = u[0] * Rlc[3] + u[1] * Rlc[4] + u[2] * Rlc[5];
-                    uR[2] = u[0] * Rlc[6] + u[1] * Rlc[7] + u[2] * Rlc[8];
-                    cross3(uR, plj, c1);
-                    for (int k = 0; k < 3; k++) Jj[3 + k] = c1[k];
-                }
-#pragma unroll
-                for (int k = 0; k < 6; k++) { row[k] = Ji[k]; row[6 + k] = Jj[k]; row[12 + k] = Jx[k]; }
-                row[18] = rq;
-                // depth block and coupling row: the two rows of the observation are summed across the lane pair, lane
-                // q = 0 issues the atomics
-                double hx[6], hi[6], hj[6];
-#pragma unroll
-                for (int k = 0; k < 6; k++) { hx[k] = pair_sum(Jx[k] * Jd); hi[k] = pair_sum(Ji[k] * Jd); hj[k] = pair_sum(Jj[k] * Jd); }
-                const double hdd = pair_sum(Jd * Jd), gd = pair_sum(Jd * rq);
-                // The observation's shares of H_ff, g_f and of the extrinsic / anchor parts of the coupling row are sums over the
-                // feature's observations, which sit in different pairs (waves): they go to the observation's own scratch record and
-                // are summed per feature in observation order afterwards (ba_feature_sums) -- no atomics, the same bits every run.
-                double *sc = B.obsc + (size_t)ob * 16;
-                if (q == 0) {
-                    double *hrow = hpd + (size_t)f * kBaPS;
-                    gst(sc, hdd); gst(sc + 1, gd);
-#pragma unroll
-                    for (int k = 0; k < 6; k++) {
-                        gst(sc + 2 + k, hx[k]);
-                        gst(hrow + oj + k, hj[k]);                              // frame j sees a feature once
-                    }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 6; k++) gst(sc + 8 + k, hi[k]);
-                }
+        double cst = 0, xx44 = 0, xx45 = 0, xx55 = 0, gx4 = 0, gx5 = 0;       // this lane's share of its segment's scalar sums
+        double *row = wstage + (size_t)lane * kBaRow;
+        if (seg_ok && so < s_end) {
+            const int f = gldi(sinfo + so) & 0xffff;
+            const int ob = gldi(B.slot_obs + c.ps0 + so);
+            const double pax = gld(spts + (size_t)so * 4), pay = gld(spts + (size_t)so * 4 + 1);
+            const double pbx = gld(spts + (size_t)so * 4 + 2), pby = gld(spts + (size_t)so * 4 + 3);
+            const double depth = 1.0 / L.vinv[f];
+            const double pc[3] = { depth * pax, depth * pay, depth };
+            double Tp[3], pcj[3], pcn[3], uT[3], u[3];
+            ba::mv(T, pc, Tp);
+            for (int k = 0; k < 3; k++) pcj[k] = Tp[k] + rec[9 + k];     // the residual's p_cj (raw quaternions)
+            ba::mv(Tn, pc, Tp);                                          // from here on Tp = Tn pc: the Jacobians' normalised product
+            for (int k = 0; k < 3; k++) pcn[k] = Tp[k] + rec[48 + k];
+            const double inv = 1.0 / pcj[2];
+            const double e0 = pcj[0] * inv - pbx, e1 = pcj[1] * inv - pby;
+            const double r0 = m00 * e0 + m01 * e1, r1 = m10 * e0 + m11 * e1;
+            const double sq = r0 * r0 + r1 * r1;
+            if (q == 0) cst = 0.5 * log(1.0 + sq);
+            // ceres::CauchyLoss(1): rho' = 1 / (1 + s), rho'' < 0 -> the corrector scales rows by sqrt(rho')
+            const double rho1 = 1.0 / (1.0 + sq);
+            const double sr = sqrt(rho1 > DBL_MIN ? rho1 : DBL_MIN);
+            const double rq = (q ? r1 : r0) * sr;
+            // row q of sqrt_info * [[1/z, 0, -x/z^2], [0, 1/z, -y/z^2]], robustified
+            const double ma = q ? m10 : m00, mb = q ? m11 : m01;
+            u[0] = sr * ma * inv; u[1] = sr * mb * inv; u[2] = -sr * (ma * pcj[0] + mb * pcj[1]) * inv * inv;
+            rowmul(u, Tn, uT);
+            // inverse depth: -u (Tn p_i) depth^2 = -u (Tn pc) depth
+            const double Jd = -(u[0] * Tp[0] + u[1] * Tp[1] + u[2] * Tp[2]) * depth;
+            double Jx[6], Ji[6], Jj[6], c1[3], c2[3];
+            // extrinsic block: position u Cm, rotation -(uT) x pc + u x (Tn pc + tn)   (u skew(v) = u x v; :127-130: all normalised)
+            if (c.ex_off >= 0) {
+                rowmul(u, Cm, Jx);
+                cross3(uT, pc, c1); cross3(u, pcn, c2);
+                for (int k = 0; k < 3; k++) Jx[3 + k] = c2[k] - c1[k];
+                xx44 = Jx[4] * Jx[4]; xx45 = Jx[4] * Jx[5]; xx55 = Jx[5] * Jx[5];
+                gx4 = Jx[4] * rq; gx5 = Jx[5] * rq;
             } else {
 #pragma unroll
-                for (int k = 0; k < kBaRow; k++) row[k] = 0.0;
+                for (int k = 0; k < 6; k++) Jx[k] = 0.0;
             }
-            // the wave's rows are in LDS (its LDS operations execute in order): J^T [J r], four rows per MFMA step
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (!two) {
-                const int nrow = 2 * min(kBaRound, n_solo - rb);
-                for (int ks = 0; 4 * ks < nrow; ks++) {
-                    const double *rowp = wstage + (size_t)(4 * ks + kq) * kBaRow;
-                    const double a = rowp[col];
-                    const double bq = col < 3 ? rowp[16 + col] : 0.0;
-                    aa = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, aa, 0, 0, 0);
-                    ab = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, ab, 0, 0, 0);
-                }
+            // pose i: position u A, rotation -(u B) x pl;  pose j: position -u A, rotation (u Rlc^T) x plj, with the residual
+            // path's own points pl = pts_laser_i = Qx pc + tx and plj = pt_l_j = M(qx^-1)^-1 p_cj + tx (:66-68, :145, :158)
+            {
+                double uB[3], uR[3], pl[3], plj[3];
+                rowmul(u, A, Ji);
+                for (int k = 0; k < 3; k++) Jj[k] = -Ji[k];
+                ba::mv(Mx, pc, pl);
+                for (int k = 0; k < 3; k++) pl[k] += ex[k];
+                rowmul(u, Bm, uB); cross3(uB, pl, c1);
+                for (int k = 0; k < 3; k++) Ji[3 + k] = -c1[k];
+                ba::mv(Mxi, pcj, plj);
+                for (int k = 0; k < 3; k++) plj[k] += ex[k];
+                uR[0] = u[0] * Rlc[0] + u[1] * Rlc[1] + u[2] * Rlc[2];
+                uR[1] = u[0] * Rlc[3] + u[1] * Rlc[4] + u[2] * Rlc[5];
+                uR[2] = u[0] * Rlc[6] + u[1] * Rlc[7] + u[2] * Rlc[8];
+                cross3(uR, plj, c1);
+                for (int k = 0; k < 3; k++) Jj[3 + k] = c1[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 6; k++) { row[k] = Ji[k]; row[6 + k] = Jj[k]; row[12 + k] = Jx[k]; }
+            row[18] = rq;
+            // depth block and coupling row: the two rows of the observation are summed across the lane pair.  The observation's shares of H_ff, g_f and
+            // of its feature's coupling row go to the observation's own scratch record (host observation order: a feature's records are contiguous)
+            // and are summed / placed per feature afterwards -- no atomics, the same bits every run, and whoever evaluates the observation.
+            double hx[6], hi[6], hj[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) { hx[k] = pair_sum(Jx[k] * Jd); hi[k] = pair_sum(Ji[k] * Jd); hj[k] = pair_sum(Jj[k] * Jd); }
+            const double hdd = pair_sum(Jd * Jd), gd = pair_sum(Jd * rq);
+            double *sc = B.obsc + (size_t)ob * kBaObsRec;
+            if (q == 0) {
+                gst(sc, hdd); gst(sc + 1, gd);
+#pragma unroll
+                for (int k = 0; k < 6; k++) gst(sc + 2 + k, hx[k]);
+                gst(sc + 20, (double)(oj + 1)); gst(sc + 21, (double)f);   // where frame j's share goes: column + 1 (0: no record), row
             } else {
-                // first pair: rows 0 .. 2 n0 - 1 -> its tile goes out, the accumulators start again for the second pair's rows 32 ..
-                const int n0 = n_solo, n1 = L.pair_slot[pr1 + 1] - L.pair_slot[pr1];
-                for (int ks = 0; 4 * ks < 2 * n0; ks++) {
-                    const double *rowp = wstage + (size_t)(4 * ks + kq) * kBaRow;
+#pragma unroll
+                for (int k = 0; k < 6; k++) { gst(sc + 8 + k, hi[k]); gst(sc + 14 + k, hj[k]); }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kBaRow; k++) row[k] = 0.0;
+        }
+        // the segment's scalar sums: over the 32 lanes of this half
+        cst = half_sum_d(cst);
+        if (c.ex_off >= 0) { xx44 = half_sum_d(xx44); xx45 = half_sum_d(xx45); xx55 = half_sum_d(xx55); gx4 = half_sum_d(gx4); gx5 = half_sum_d(gx5); }
+        // the wave's rows are in LDS (its LDS operations execute in order): J^T [J r], four rows per MFMA step
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int nA = __builtin_amdgcn_readlane(s_end - s_begin, 0), nB = sB < c.n_seg ? __builtin_amdgcn_readlane(s_end - s_begin, 32) : 0;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int n = h ? nB : nA;
+            if (n > 0) {
+                ba_d4 aa = { 0, 0, 0, 0 }, ab = { 0, 0, 0, 0 };
+                for (int ks = 0; 4 * ks < 2 * n; ks++) {
+                    const double *rowp = wstage + (size_t)(2 * kBaSeg * h + 4 * ks + kq) * kBaRow;
                     const double a = rowp[col];
                     const double bq = col < 3 ? rowp[16 + col] : 0.0;
                     aa = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, aa, 0, 0, 0);
                     ab = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, ab, 0, 0, 0);
                 }
-                {
-                    double *tile = B.pairH + (size_t)(c.pp0 + pr0) * kBaPairTile;
+                // the segment's tile [J_i J_j J_x0..3]^T [J_i J_j J_x0..3 | J_x4 J_x5 r] and its scalar sums go to the segment's own record in the
+                // L2 scratch (plain stores, nobody else touches it); ba_reduce_pairs adds the records in a fixed order afterwards
+                double *tile = tiles + (size_t)(h ? sB : sA) * kBaPairTile;
 #pragma unroll
-                    for (int v = 0; v < 4; v++) {
-                        gst(tile + (kq + 4 * v) * 16 + col, aa[v]);
-                        if (col < 3) gst(tile + 256 + (kq + 4 * v) * 4 + col, ab[v]);
-                    }
-                    xa += aa[3]; xb += ab[3];
+                for (int v = 0; v < 4; v++) {
+                    gst(tile + (kq + 4 * v) * 16 + col, aa[v]);
+                    if (col < 3) gst(tile + 256 + (kq + 4 * v) * 4 + col, ab[v]);
                 }
-                aa = { 0, 0, 0, 0 }; ab = { 0, 0, 0, 0 };
-                for (int ks = 0; 4 * ks < 2 * n1; ks++) {
-                    const double *rowp = wstage + (size_t)(2 * kBaHalf + 4 * ks + kq) * kBaRow;
-                    const double a = rowp[col];
-                    const double bq = col < 3 ? rowp[16 + col] : 0.0;
-                    aa = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, aa, 0, 0, 0);
-                    ab = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, ab, 0, 0, 0);
+                if (lane == 32 * h) {
+                    gst(tile + 256 + 3, cst); gst(tile + 260 + 3, xx44); gst(tile + 264 + 3, xx45); gst(tile + 268 + 3, xx55);
+                    gst(tile + 272 + 3, gx4); gst(tile + 276 + 3, gx5);
                 }
             }
-            __builtin_amdgcn_wave_barrier();   // the slice is rewritten by the next round
         }
-        // the pair's tile [J_i J_j J_x0..3]^T [J_i J_j J_x0..3 | J_x4 J_x5 r] goes to the pair's own record in the L2 scratch (plain stores,
-        // no other wave touches it); ba_reduce_pairs sums the records into H_pp / g_p in a fixed order afterwards
-        {
-            double *tile = B.pairH + (size_t)(c.pp0 + (two ? pr1 : pr0)) * kBaPairTile;      // (paired: the first pair's tile went out above)
-#pragma unroll
-            for (int v = 0; v < 4; v++) {
-                gst(tile + (kq + 4 * v) * 16 + col, aa[v]);
-                if (col < 3) gst(tile + 256 + (kq + 4 * v) * 4 + col, ab[v]);
-            }
-            xa += aa[3]; xb += ab[3];        // rows 12 + kq (extrinsic 0..3): columns col of the tile / of the side tile
-        }
+        __builtin_amdgcn_wave_barrier();   // the slice is rewritten by the next round
     }
-    // the extrinsic block and gradient get a contribution from EVERY pair: each wave leaves the sums over its own pairs (static order) in
-    // LDS (L.D is dead during a linearisation), ba_reduce_pairs adds the eight in wave order -- no all-pairs loop over the L2 records
-    if (col >= 12) L.D[wave * 40 + kq * 4 + (col - 12)] = xa;
-    if (col < 3) L.D[wave * 40 + 16 + kq * 3 + col] = xb;
     BA_TOCK(1)
     BA_TICK(11)
-    // the waves' shares of the (4..5, 4..5) extrinsic corner and its gradient: summed in wave order
-    xx44 = wave_sum_d(xx44); xx45 = wave_sum_d(xx45); xx55 = wave_sum_d(xx55); gx4 = wave_sum_d(gx4); gx5 = wave_sum_d(gx5);
-    if (lane == 0) { double *r5 = L.rhs + 5 * wave; r5[0] = xx44; r5[1] = xx45; r5[2] = xx55; r5[3] = gx4; r5[4] = gx5; }   // L.rhs is dead outside the Schur solve
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // the observation records are written
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // the segment and observation records are written
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");       // ... and read below by other waves: drop this CU's L1 copies
     BA_TICK(12)
@@ -738,7 +813,7 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
             for (int ob = o0; ob < o1; ob += 10) {
                 double v[10];
 #pragma unroll
-                for (int u = 0; u < 10; u++) v[u] = ob + u < o1 ? gld(B.obsc + (size_t)(ob + u) * 16 + k) : 0.0;
+                for (int u = 0; u < 10; u++) v[u] = ob + u < o1 ? gld(B.obsc + (size_t)(ob + u) * kBaObsRec + k) : 0.0;
 #pragma unroll
                 for (int u = 0; u < 10; u++) acc += v[u];
             }
@@ -750,24 +825,40 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
                 else { const int anchor = L.fanchor[f]; if (anchor >= 0) gst(hrow + ba_pose_off(c, anchor) + k - 8, acc); }
             }
         }
+        // frame j's share of a coupling row (frame j sees a feature once) moves from the observation's record to its place: 8 lanes per observation, four
+        // observations of a lane in flight
+        const int n_obs = c.use_mono ? (int)L.fobs[c.F] : 0;
+        const int kk = tid & 7;
+        for (int ob0 = tid >> 3; ob0 < n_obs; ob0 += 4 * (kBaT / 8)) {
+            double vj[4], vo[4], vf[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int ob = ob0 + u * (kBaT / 8);
+                const double *rc = B.obsc + (size_t)(c.o0 + (ob < n_obs ? ob : ob0)) * kBaObsRec;
+                vj[u] = gld(rc + 14 + (kk < 6 ? kk : 0)); vo[u] = gld(rc + 20); vf[u] = gld(rc + 21);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int ob = ob0 + u * (kBaT / 8);
+                // (an observation outside the problem -- a feature below the track count -- has no record: its cells hold zeros and oj = 0 marks it)
+                if (ob < n_obs && kk < 6 && vo[u] > 0.0) gst(hpd + (size_t)(int)vf[u] * kBaPS + (int)vo[u] - 1 + kk, vj[u]);
+            }
+        }
     }
     BA_TOCK(13)
-    // every pair block is in H_pp: the LASERFactor chain left in gn | va | vb is added by everybody, the prior and then the waves' shares of the
-    // extrinsic corner (in wave order) by wave 1 -- after the pair blocks in every run
+    // every segment's block is in H_pp: the LASERFactor chain left in gn | va | vb is added by everybody, the prior by wave 1 -- after the pair
+    // blocks in every run
     ba_small_accumulate_block(c, L, L.gn, tid);
     if (wave == 1) {
         ba_prior_accumulate_wave(c, L, L.gn, lane);
-        if (c.ex_off >= 0 && c.n_slots > 0 && lane == 0) {
-            double t[5] = { 0, 0, 0, 0, 0 };
-            for (int w = 0; w < kBaW; w++) for (int k = 0; k < 5; k++) t[k] += L.rhs[5 * w + k];
-            const int x4 = c.ex_off + 4, x5 = c.ex_off + 5;
-            L.Hpp[x4 * kBaP + x4] += t[0]; L.Hpp[x5 * kBaP + x5] += t[2];
-            L.Hpp[x4 * kBaP + x5] += t[1]; L.Hpp[x5 * kBaP + x4] += t[1];
-            L.gp[x4] += t[3]; L.gp[x5] += t[4];
-        }
+        small_cost = wave_sum_d(small_cost);
+        if (lane == 0) L.red[3 * kBaW - 2] = small_cost;
     }
+    ba_segment_cost(c, L, tiles + 256 + 3, kBaPairTile);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    cost = block_sum(cost, L.red);
+    __syncthreads();
+    const double cost = L.red[3 * kBaW - 1] + L.red[3 * kBaW - 2];
+    __syncthreads();
     BA_TOCK(11)
     // the coupling rows were written through L2: drop this CU's L1 copies before they are read with plain loads
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -1173,49 +1264,22 @@ __device__ __noinline__ bool ba_schur_solve(const BaCtx c, BaLds &L_arg, const d
     return L.ok != 0;
 }
 
-// Static schedule of the linearisation's frame pairs (sizes descending): longest-processing-time assignment to the 8 waves, and the
-// order in which the pairs' blocks enter H_pp = the order in which a wave-time model (one unit per 32-observation round + one per
-// pair) says they finish, ties by pair index.  A wave's own pairs are in that order too, so the turn-taking cannot deadlock, and
-// because the model is close to the real timing, waves seldom wait for their turn.  Depends on the pair sizes only.
-__device__ __noinline__ void ba_schedule(const BaBatch &B, const BaCtx c, BaLds &L_arg)
+// Window tables that live in LDS for the whole solve: (anchor, observer) -> pair, the first observation and the anchor frame of every feature
+__device__ __noinline__ void ba_setup(const BaBatch &B, const BaCtx c, BaLds &L_arg)
 {
     BA_BIND_LDS(L_arg)
     const int tid = threadIdx.x;
-    int *fin = (int *)L.u.stage;                          // [n_pairs] modelled finish time, then [n_pairs] wave
     __syncthreads();
-    if (tid == 0) {
-        int load[kBaW];
-        for (int w = 0; w < kBaW; w++) load[w] = w == 1 ? 1 : 0;      // wave 1 starts with the LASERFactor chain and the prior (about one round)
-        for (int p = 0; p < c.n_pairs; p++) {
-            int w = 0;
-            for (int u = 1; u < kBaW; u++) if (load[u] < load[w]) w = u;
-            load[w] += 1 + (L.pair_slot[p + 1] - L.pair_slot[p] + kBaRound - 1) / kBaRound;
-            fin[p] = load[w]; fin[kBaMaxPairs + p] = w;
-        }
-    }
-    __syncthreads();
-    for (int p = tid; p < c.n_pairs; p += kBaT) {
-        int rank = 0, pos = 0;
-        const int w = fin[kBaMaxPairs + p];
-        for (int q = 0; q < c.n_pairs; q++) {
-            const bool before = fin[q] < fin[p] || (fin[q] == fin[p] && q < p);
-            rank += before ? 1 : 0;
-            pos += (before && fin[kBaMaxPairs + q] == w) ? 1 : 0;
-        }
-        fin[2 * kBaMaxPairs + p] = pos;                     // position among its wave's pairs
-    }
-    if (tid <= kBaW) {
-        int n = 0;
-        for (int q = 0; q < c.n_pairs; q++) n += fin[kBaMaxPairs + q] < tid ? 1 : 0;
-        L.woff[tid] = (short)n;
-    }
-    __syncthreads();
-    for (int p = tid; p < c.n_pairs; p += kBaT) L.wlist[L.woff[fin[kBaMaxPairs + p]] + fin[2 * kBaMaxPairs + p]] = (short)p;
     for (int k = tid; k < kBaMaxPoses * kBaMaxPoses; k += kBaT) L.pair_of[k] = -1;
     for (int f = tid; f <= c.F; f += kBaT) L.fobs[f] = (unsigned short)(B.feat_obs_off[c.f0 + f] - c.o0);      // <= 448 x 10 observations per window
     for (int f = tid; f < c.F; f += kBaT) L.fanchor[f] = (signed char)B.feat_anchor[c.f0 + f];
     __syncthreads();
-    for (int p = tid; p < c.n_pairs; p += kBaT) { const int ij = L.pair_ij[p]; L.pair_of[(ij & 255) * kBaMaxPoses + (ij >> 8)] = (short)p; }
+    // (anchor, observer) -> the pair's tile among the window's tiles [segments | pairs]: a pair of several segments has its own (ba_reduce_pairs sums
+    // its segments' tiles into it), any other pair's tile is its only segment's
+    for (int p = tid; p < c.n_pairs; p += kBaT) {
+        const int ij = L.pair_ij[p];
+        L.pair_of[(ij & 255) * kBaMaxPoses + (ij >> 8)] = (short)(p < c.n_multi ? c.n_seg + p : (int)L.pair_seg[p]);
+    }
     __syncthreads();
 }
 
@@ -1231,6 +1295,7 @@ __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B)
     c.P = 6 * c.n_poses + (c.ex_constant ? 0 : 6);
     c.pp0 = B.pair_off[w]; c.n_pairs = c.use_mono ? B.pair_off[w + 1] - c.pp0 : 0;
     c.ps0 = B.pobs_off[w]; c.n_slots = c.use_mono ? B.pobs_off[w + 1] - c.ps0 : 0;
+    c.sg0 = B.seg_off[w]; c.n_seg = c.use_mono ? B.seg_off[w + 1] - c.sg0 : 0; c.n_multi = c.use_mono ? B.n_multi[w] : 0;
     const int P = c.P, F = c.F, N = P + F;
     double *gposes = B.poses + (size_t)w * kBaMaxPoses * 7, *gex = B.ex + (size_t)w * 7, *ginvd = B.inv_depth + c.f0;
     double *hpd = B.hpd + (size_t)w * kBaMaxFeat * kBaPS;
@@ -1239,9 +1304,10 @@ __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B)
     for (int k = tid; k < c.n_poses * 7; k += kBaT) L.poses[k] = gposes[k];
     if (tid < 7) L.ex[tid] = gex[tid];
     for (int k = tid; k < c.n_pairs; k += kBaT) L.pair_ij[k] = B.pair_ij[c.pp0 + k];
-    for (int k = tid; k <= c.n_pairs; k += kBaT) L.pair_slot[k] = B.pair_slot[c.pp0 + w + k];
+    for (int k = tid; k <= c.n_pairs; k += kBaT) { L.pair_slot[k] = (short)B.pair_slot[c.pp0 + w + k]; L.pair_seg[k] = (short)B.pair_seg[c.pp0 + w + k]; }
+    for (int k = tid; k < c.n_seg; k += kBaT) L.seg[k] = B.seg_tab[c.sg0 + k];
     __syncthreads();
-    ba_schedule(B, c, L);
+    ba_setup(B, c, L);
 
     const double function_tol = 1e-6, gradient_tol = 1e-10, parameter_tol = 1e-8, min_rel_decrease = 1e-3;
     const double min_diag = 1e-6, max_diag = 1e32, max_radius = 1e16, min_radius = 1e-32;

@@ -1196,10 +1196,12 @@ static int ba_fill(lmono_ctx *c, lmono_ba_batch *b, const lmono_ba_desc *d)
     // pair-ordered observation list
     std::vector<int> pair_off((size_t)W + 1, 0), pair_ij, pair_slot, pobs_off((size_t)W + 1, 0), slot_info, anchor((size_t)TF, -1);
     std::vector<double> slot_pts;
+    std::vector<unsigned short> seg_tab;            // segments (<= 16 slots of one pair): pair (window-local) | index inside the pair << 7
+    std::vector<int> seg_off((size_t)W + 1, 0), pair_seg, n_multi((size_t)W, 0);
     std::vector<int> slot_obs;                      // the observation (host order) behind every slot: its scratch record is indexed by observation,
                                                     // so a feature's records are contiguous for the per-feature sums of k_ba_solve
     for (int w = 0; w < W; w++) {
-        pair_off[w] = (int)pair_ij.size(); pobs_off[w] = (int)slot_info.size();
+        pair_off[w] = (int)pair_ij.size(); pobs_off[w] = (int)slot_info.size(); seg_off[w] = (int)seg_tab.size();
         const int f0 = d->feat_off[w], f1 = d->feat_off[w + 1];
         for (int f = f0; f < f1; f++) if (fo[f + 1] > fo[f]) anchor[f] = d->obs_i[fo[f]];
         if (d->flags[4 * w + 3]) {   // use_mono == 0: the projection factors are not part of the problem
@@ -1213,6 +1215,10 @@ static int ba_fill(lmono_ctx *c, lmono_ba_batch *b, const lmono_ba_desc *d)
                 const std::vector<int> &v = by_pair[(size_t)key];
                 pair_ij.push_back((key / kBaMaxPoses) | ((key % kBaMaxPoses) << 8));
                 pair_slot.push_back((int)slot_info.size() - pobs_off[w]);
+                pair_seg.push_back((int)seg_tab.size() - seg_off[w]);
+                const int nseg = ((int)v.size() + kBaSeg - 1) / kBaSeg;
+                for (int sidx = 0; sidx < nseg; sidx++) seg_tab.push_back((unsigned short)(local | (sidx << 7)));
+                if (nseg > 1) n_multi[w]++;
                 for (int o : v) {
                     slot_obs.push_back(o);
                     slot_info.push_back(d->obs_feat[o] | (local << 16));
@@ -1222,15 +1228,18 @@ static int ba_fill(lmono_ctx *c, lmono_ba_batch *b, const lmono_ba_desc *d)
             }
         }
         pair_slot.push_back((int)slot_info.size() - pobs_off[w]);   // n_pairs + 1 entries per window
+        pair_seg.push_back((int)seg_tab.size() - seg_off[w]);
     }
-    pair_off[W] = (int)pair_ij.size(); pobs_off[W] = (int)slot_info.size();
+    pair_off[W] = (int)pair_ij.size(); pobs_off[W] = (int)slot_info.size(); seg_off[W] = (int)seg_tab.size();
     b->ctx = c; b->n_windows = W; b->total_feat = TF; b->total_obs = TO;
     BaBatch &v = b->v;
     v.n_windows = W; v.max_iter = 30;
     double info[42];
     memcpy(info, d->laser_info, 36 * sizeof(double)); memcpy(info + 36, d->mono_info, 4 * sizeof(double)); memcpy(info + 40, d->prior_w, 2 * sizeof(double));
     int *feat_off = nullptr, *obs_off = nullptr, *flags = nullptr, *anch = nullptr, *poff = nullptr, *pij = nullptr, *psoff = nullptr, *sinfo_d = nullptr, *pslot_d = nullptr;
-    int *fobs_d = nullptr, *oslot_d = nullptr;
+    int *fobs_d = nullptr, *oslot_d = nullptr, *segoff_d = nullptr, *pseg_d = nullptr, *nmulti_d = nullptr;
+    unsigned short *segtab_d = nullptr;
+    const unsigned short uzero = 0;
     double *spts_d = nullptr, *laser = nullptr, *prior = nullptr, *infod = nullptr;
     const int izero = 0; const double dzero = 0.0;       // a present (non-NULL) source for arrays that may be empty
     BaPack pk;
@@ -1246,10 +1255,13 @@ static int ba_fill(lmono_ctx *c, lmono_ba_batch *b, const lmono_ba_desc *d)
     pk.add(b->poses0, d->poses, (size_t)W * kBaMaxPoses * 7); pk.add(b->ex0, d->ex, (size_t)W * 7);
     pk.add(b->invd0, TF ? d->inv_depth : &dzero, (size_t)TF);
     pk.add(fobs_d, (const int *)fo.data(), (size_t)TF + 1); pk.add(oslot_d, slot_obs.empty() ? &izero : slot_obs.data(), slot_obs.size());
-    pk.add(v.obsc, (const double *)nullptr, (size_t)TO * 16);
+    pk.add(segoff_d, (const int *)seg_off.data(), (size_t)W + 1); pk.add(pseg_d, (const int *)pair_seg.data(), pair_seg.size());
+    pk.add(nmulti_d, (const int *)n_multi.data(), (size_t)W); pk.add(segtab_d, seg_tab.empty() ? &uzero : seg_tab.data(), seg_tab.size());
+    pk.add(v.obsc, (const double *)nullptr, (size_t)TO * kBaObsRec);
     pk.add(v.hpd, (const double *)nullptr, (size_t)W * kBaMaxFeat * kBaPS);
     pk.add(v.pairdat, (const double *)nullptr, pair_ij.size() * kBaPairRec);
-    pk.add(v.pairH, (const double *)nullptr, pair_ij.size() * kBaPairTile);
+    pk.add(v.pairH, (const double *)nullptr, (seg_tab.size() + pair_ij.size()) * kBaPairTile);
+    pk.add(v.cpart, (const double *)nullptr, seg_tab.size());
     pk.add(v.cand, (const double *)nullptr, (size_t)W * kBaMaxFeat); pk.add(v.summary, (const double *)nullptr, (size_t)W * 6);
     // everything is staged in the batch's pinned buffer: the vectors above may go, and nothing waits here
     { const int rc = pk.commit(c, b); if (rc) { c->err = "lmono_ba_batch_create: device allocation / upload failed"; return LMONO_ENOMEM; } }
@@ -1257,6 +1269,7 @@ static int ba_fill(lmono_ctx *c, lmono_ba_batch *b, const lmono_ba_desc *d)
     v.pair_off = poff; v.pair_ij = pij; v.pobs_off = psoff; v.slot_info = sinfo_d; v.slot_pts = spts_d; v.pair_slot = pslot_d;
     v.laser_consts = laser; v.prior_T = prior; v.info = infod;
     v.feat_obs_off = fobs_d; v.slot_obs = oslot_d;
+    v.seg_off = segoff_d; v.seg_tab = segtab_d; v.pair_seg = pseg_d; v.n_multi = nmulti_d;
     return LMONO_OK;
 }
 
