@@ -44,6 +44,8 @@ constexpr int kBaPairRec = 52;                   // Tres(9) tres(3) Cm(9) A(9) B
 constexpr int kBaPairTile = 320;                 // 16 x 16 tile + 16 x 4 side tile of a SEGMENT of a frame pair (column 3 of the side tile: the segment's scalar sums)
 constexpr int kBaSeg = 16;                       // observations of a segment: a frame pair's slots in runs of 16 (two lanes each: half a wave)
 constexpr int kBaMaxSeg = kBaMaxPairs + kBaMaxFeat * (kBaMaxPoses - 1) / kBaSeg;      // 110 + 280
+constexpr int kBaMbox = 96 + kBaMaxFeat;         // leader -> followers: [0] command, [1] re-use the records, [8..84] poses, [88..94] extrinsic, [96..] inverse depths
+constexpr int kBaMaxK = 8;                       // workgroups per window
 constexpr int kBaObsRec = 24;                    // per-observation record: hdd, gd, hx[6], hi[6], hj[6], oj
 constexpr int kBaT = 512;                        // threads per workgroup (2 waves per SIMD)
 constexpr int kBaW = kBaT / 64;
@@ -82,6 +84,12 @@ struct BaBatch {
     double *pairH;              // scratch [total segments + total pairs][kBaPairTile], per window [its segments | its pairs]: every segment's J^T [J r] tile
                                 // (16 x 16 + 16 x 4) and scalar sums; a pair of several segments has their sum (segment order) in its own tile (ba_reduce_pairs)
     double *cpart;              // scratch [total segments]: every segment's share of a candidate's cost
+    // several workgroups per window (k_ba_solve<true>): the leader's mail box [W][kBaMbox] (command, state to evaluate), flag words [W][16]
+    // (go, done of every follower; zeroed before every launch), a failure flag; pairdat then holds one copy per workgroup of a window
+    double *mbox;
+    unsigned int *bar;
+    int *fail;
+    int n_pairs_total;          // stride of the per-rank copies of pairdat
     double *cand;               // scratch [W][kBaMaxFeat]
     double *summary;            // [W][6] initial_cost, final_cost, iterations, termination, successful, unsuccessful
 };
@@ -112,12 +120,20 @@ struct BaLds {
     // The linearisation's unit of work is a SEGMENT: up to 16 consecutive slots of one frame pair (round 5).  Every sum that crosses observations is
     // formed per segment (its J^T [J r] tile, its share of the cost and of the extrinsic corner) and the segments' results are added in segment
     // order, so the bits depend neither on which wave takes a segment nor on how many workgroups share a window.
+#ifdef LMONO_BA_PROF
+    unsigned short seg[kBaMaxSeg - 64];          // (the profiling build's clock cells need the room; its windows hold fewer segments)
+#else
     unsigned short seg[kBaMaxSeg];               // pair | index inside the pair << 7
+#endif
     short pair_seg[kBaMaxPairs + 1];             // first segment of every pair
     short pair_of[kBaMaxPoses * kBaMaxPoses];    // pair (anchor i, observer j) -> index in the window's pair list, -1: none
     unsigned short fobs[kBaMaxFeat + 1];         // first observation of every feature, relative to the window's first (host order: grouped by feature)
     signed char fanchor[kBaMaxFeat];             // the frame a feature is anchored in (-1: no observation)
     int ok;
+    int eval_no, failed;        // several workgroups per window: evaluations handed out so far; a workgroup did not arrive
+#ifdef LMONO_BA_PROF
+    unsigned long long prof[24];
+#endif
 };
 static_assert(sizeof(BaLds) <= 160 * 1024, "BaLds exceeds the 160 KB LDS of a gfx950 CU");
 // The workgroup's state is a STATIC LDS object (gfx950 takes 160 KB of it).  As dynamic LDS, every out-of-line phase of k_ba_solve found its base through
@@ -161,9 +177,11 @@ __device__ __forceinline__ double block_max(double v, double *red)
 }
 
 #ifdef LMONO_BA_PROF
-__device__ long long g_prof[16];
-#define BA_TICK(i) { if (blockIdx.x == 0 && threadIdx.x == 0) g_prof[i] -= clock64(); }
-#define BA_TOCK(i) { if (blockIdx.x == 0 && threadIdx.x == 0) g_prof[i] += clock64(); }
+// phase clocks of window 0's leader: thread 0 adds to cells in LDS with no-return ds_add / ds_sub (a read-modify-write of a global cell made every probe
+// a ~500-cycle stall of wave 0: the phases with many probes looked twice as long as they are); copied out at the end of the solve
+__device__ long long g_prof[24];
+#define BA_TICK(i) { if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_fetch_sub(&g_ba_lds.prof[i], (unsigned long long)clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#define BA_TOCK(i) { if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(&g_ba_lds.prof[i], (unsigned long long)clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #else
 #define BA_TICK(i)
 #define BA_TOCK(i)
@@ -175,6 +193,8 @@ struct BaCtx {
     int pp0, n_pairs;      // first pair / number of pairs of this window
     int ps0, n_slots;      // first slot / number of slots of the pair-ordered observation list
     int sg0, n_seg, n_multi;   // first segment / number of segments of this window; pairs of more than one segment
+    int K, rank, GW;           // workgroups of this window, this workgroup among them (0 = the leader), waves that share the window's segments
+    int win;                   // the window
 };
 __device__ __forceinline__ int ba_pose_off(const BaCtx &c, int i) { return (c.ex_off < 0 ? 0 : 6) + 6 * i; }
 
@@ -258,6 +278,48 @@ typedef __attribute__((address_space(1))) const int ba_gci;
 __device__ __forceinline__ double gld(const double *p) { return *(ba_gcd *)p; }
 __device__ __forceinline__ int gldi(const int *p) { return *(ba_gci *)p; }
 __device__ __forceinline__ void gst(double *p, double v) { *(ba_gd *)p = v; }
+
+// this wave among the GW waves that take segments (-1: none).  One workgroup: its eight waves.  Several: the leader's wave 1 evaluates the LASERFactor
+// chain and the prior meanwhile and takes none.
+__device__ __forceinline__ int ba_worker(const BaCtx &c, int wave)
+{
+    if (c.K == 1) return wave;
+    if (c.rank == 0) return wave == 1 ? -1 : (wave == 0 ? 0 : wave - 1);
+    return kBaW - 1 + (c.rank - 1) * kBaW + wave;
+}
+// data that crosses workgroups (segment tiles, observation records, cost cells, the mail box): device-coherent stores and loads (sc1: they bypass the
+// CU's L1 and are ordered by the arrival counters; MI355X_MICROARCH.md, hand-off table) when several workgroups share a window, plain ones otherwise
+template <bool kCl> __device__ __forceinline__ double ld_sh(const double *p)
+{
+    if (kCl) return __hip_atomic_load((ba_gcd *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return gld(p);
+}
+template <bool kCl> __device__ __forceinline__ void st_sh(double *p, double v)
+{
+    if (kCl) __hip_atomic_store((ba_gd *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else gst(p, v);
+}
+// Hand-offs between the workgroups of a window are FLAG WORDS with one writer each (device-coherent stores, polled with device-coherent loads; no
+// read-modify-write: an agent-scope atomic add is resolved beyond the XCD's L2 and costs a microsecond before anybody can see it): the leader's "go"
+// word holds the number of evaluations it has published, follower r's "done" word the number it has answered.  B.bar: [W][16] words, [0] = go,
+// [r] = done of follower r (rank r >= 1).  Zeroed before every launch.
+__device__ __forceinline__ unsigned int ba_flag_load(const unsigned int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ba_flag_store(unsigned int *p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// lanes 0 .. n - 1 of ONE wave wait until flags[lane] >= target (bounded: a wave that never finishes can take the GPU down); false = gave up
+__device__ __forceinline__ bool ba_wait_flags(const unsigned int *flags, int n, unsigned int target, int *fail)
+{
+    const int lane = threadIdx.x & 63;
+    int spins = 0;
+    for (;;) {
+        const bool there = lane >= n || ba_flag_load(flags + (lane < n ? lane : 0)) >= target;
+        if (__all(there)) return true;
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 1023) == 0 && (spins > (1 << 23) || __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+    }
+}
 
 // LASERFactor chain and the extrinsic prior: a handful of residual blocks, one thread each.  The thread leaves its
 // residuals and Jacobians in LDS ([r(6) | J(84)] per block, block 10 = prior); the J^T J products are then spread over
@@ -365,6 +427,7 @@ __device__ __forceinline__ void ba_prior_accumulate_wave(const BaCtx &c, BaLds &
 // by one thread, which adds the tiles that touch it in a fixed order -- a pair's segments in segment order, then the pairs (f, j) by ascending j and
 // the pairs (i, f) by ascending i for an entry of frame f's rows / columns; all segments by index for the extrinsic block -- so the sums are the same
 // bits in every run whatever the waves' timing was and whoever computed a segment.  Entries nothing touches become zero: the pass replaces clearing H_pp.
+template <bool kCl>
 __device__ __forceinline__ void ba_reduce_pairs(const BaBatch &B, const BaCtx c, BaLds &L)
 {
     const int tid = threadIdx.x, np_ = c.n_poses;
@@ -395,7 +458,7 @@ __device__ __forceinline__ void ba_reduce_pairs(const BaBatch &B, const BaCtx c,
 #pragma unroll
                     for (int d = 0; d < 8; d++) {
                         const int sgm = s0[u] + b + d;
-                        v[u][d] = sgm < s1[u] ? gld(tiles + (size_t)sgm * kBaPairTile + (pe[u] % kBaPairTile)) : 0.0;
+                        v[u][d] = sgm < s1[u] ? ld_sh<kCl>(tiles + (size_t)sgm * kBaPairTile + (pe[u] % kBaPairTile)) : 0.0;
                     }
 #pragma unroll
                 for (int u = 0; u < kE; u++)
@@ -403,8 +466,9 @@ __device__ __forceinline__ void ba_reduce_pairs(const BaBatch &B, const BaCtx c,
                     for (int d = 0; d < 8; d++) acc[u] += v[u][d];
             }
 #pragma unroll
-            for (int u = 0; u < kE; u++) if (pe[u] >= 0) gst(ptile + pe[u], acc[u]);
+            for (int u = 0; u < kE; u++) if (pe[u] >= 0) st_sh<kCl>(ptile + pe[u], acc[u]);
         }
+        if (kCl) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -430,8 +494,8 @@ __device__ __forceinline__ void ba_reduce_pairs(const BaBatch &B, const BaCtx c,
                 if (bm != bn && bm < np_ && bn < np_) {
                     const int i = bm < bn ? bm : bn, j = bm < bn ? bn : bm;
                     const int p1 = L.pair_of[i * kBaMaxPoses + j], p2 = L.pair_of[j * kBaMaxPoses + i];
-                    if (p1 >= 0) v1[u] = gld(tile_of(p1) + pos(bm == i ? om : 6 + om, bn == i ? on : 6 + on));
-                    if (p2 >= 0) v2[u] = gld(tile_of(p2) + pos(bm == j ? om : 6 + om, bn == j ? on : 6 + on));
+                    if (p1 >= 0) v1[u] = ld_sh<kCl>(tile_of(p1) + pos(bm == i ? om : 6 + om, bn == i ? on : 6 + on));
+                    if (p2 >= 0) v2[u] = ld_sh<kCl>(tile_of(p2) + pos(bm == j ? om : 6 + om, bn == j ? on : 6 + on));
                     dst[u] = (ba_pose_off(c, bm) + om) * kBaP + ba_pose_off(c, bn) + on;
                 }
             }
@@ -460,8 +524,8 @@ __device__ __forceinline__ void ba_reduce_pairs(const BaBatch &B, const BaCtx c,
         for (int k = 0; k < kBaMaxPoses; k++) {
             const int pa = (k < np_ && k != f) ? L.pair_of[f * kBaMaxPoses + k] : -1;
             const int pb = (k < np_ && k != f) ? L.pair_of[k * kBaMaxPoses + f] : -1;
-            va[k] = pa >= 0 ? gld(tile_of(pa) + oi_) : 0.0;
-            vb[k] = pb >= 0 ? gld(tile_of(pb) + oj_) : 0.0;
+            va[k] = pa >= 0 ? ld_sh<kCl>(tile_of(pa) + oi_) : 0.0;
+            vb[k] = pb >= 0 ? ld_sh<kCl>(tile_of(pb) + oj_) : 0.0;
         }
         double acc = 0.0;
 #pragma unroll
@@ -486,7 +550,7 @@ __device__ __forceinline__ void ba_reduce_pairs(const BaBatch &B, const BaCtx c,
             for (int sg = g; sg < c.n_seg; sg += 4 * kG) {
                 double v[4];
 #pragma unroll
-                for (int d = 0; d < 4; d++) v[d] = sg + d * kG < c.n_seg ? gld(tiles + (size_t)(sg + d * kG) * kBaPairTile + off) : 0.0;
+                for (int d = 0; d < 4; d++) v[d] = sg + d * kG < c.n_seg ? ld_sh<kCl>(tiles + (size_t)(sg + d * kG) * kBaPairTile + off) : 0.0;
 #pragma unroll
                 for (int d = 0; d < 4; d++) acc += v[d];
             }
@@ -516,6 +580,7 @@ __device__ __forceinline__ void ba_reduce_pairs(const BaBatch &B, const BaCtx c,
 
 // the segments' shares of a cost (one double per segment, `stride` apart), added in segment order by wave 0; the result is left in L.red[3 * kBaW - 1]
 // for everybody (read it behind the next workgroup barrier)
+template <bool kCl>
 __device__ __forceinline__ void ba_segment_cost(const BaCtx &c, BaLds &L, const double *part, int stride)
 {
     const int tid = threadIdx.x;
@@ -524,7 +589,7 @@ __device__ __forceinline__ void ba_segment_cost(const BaCtx &c, BaLds &L, const 
         for (int sg = tid; sg < c.n_seg; sg += 4 * 64) {
             double v[4];
 #pragma unroll
-            for (int d = 0; d < 4; d++) v[d] = sg + 64 * d < c.n_seg ? gld(part + (size_t)(sg + 64 * d) * stride) : 0.0;
+            for (int d = 0; d < 4; d++) v[d] = sg + 64 * d < c.n_seg ? ld_sh<kCl>(part + (size_t)(sg + 64 * d) * stride) : 0.0;
 #pragma unroll
             for (int d = 0; d < 4; d++) acc += v[d];
         }
@@ -548,20 +613,13 @@ __device__ __forceinline__ double quarter_sum_d(double v)
     return v;
 }
 
-// cost (returned to every thread) and, when kJac, the unscaled normal equations: Hpp, gp, Hdd, gdd in LDS, Hpd in HBM
-// records_valid: the pose matrices, the inverse depths in LDS and the pair records in HBM were computed by the previous call for the SAME parameter
-// values (the candidate evaluation of a step that was then accepted): a linearisation right behind it re-uses them instead of computing the same
-// numbers again
-template <bool kJac>
-__device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLds &L_arg, const double *poses, const double *ex, const double *invd,
-                                              double *hpd, double *pairdat, bool records_valid = false)
+// pose matrices, inverse depths and pair records of the state (poses, ex, invd) -- every workgroup of a window computes its own (the followers read
+// the inverse depths from the leader's mail box)
+template <bool kSharedInvd>      // kSharedInvd: a follower (the inverse depths are in LDS already)
+__device__ __forceinline__ void ba_records(const BaCtx &c, BaLds &L, const double *poses, const double *ex, const double *invd, double *pairdat)
 {
-    BA_BIND_LDS(L_arg)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    __syncthreads();
-    BA_TICK(kJac ? 0 : 3)
+    const int tid = threadIdx.x;
     const double *Rlc = L.Rp + 9 * c.n_poses;
-    if (!records_valid) {
     if (tid <= c.n_poses) {
         double qn[4];
         const double *qraw = tid == c.n_poses ? ex + 3 : poses + 7 * tid + 3;
@@ -573,7 +631,7 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
         ba::q_to_R(qi, L.Mq + 18 * tid + 9);
         if (tid == c.n_poses) inv3(L.Mq + 18 * tid + 9, L.Mq + 18 * (kBaMaxPoses + 1));
     }
-    for (int f = tid; f < c.F; f += kBaT) L.vinv[f] = gld(invd + f);
+    if (!kSharedInvd) for (int f = tid; f < c.F; f += kBaT) L.vinv[f] = gld(invd + f);       // (a follower has read them from the mail box)
     __syncthreads();
     for (int p = tid; p < c.n_pairs; p += kBaT) {
         const int ij = L.pair_ij[p], i = ij & 255, j = ij >> 8;
@@ -584,24 +642,58 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
 #pragma unroll
         for (int k = 0; k < kBaPairRec; k++) gst(dst + k, rec[k]);
     }
+}
+
+// The leader hands the state to evaluate to the other workgroups of its window: mail box, then its go word.  cmd 1 = linearise (the followers take their
+// share of the segments and report), 2 = a candidate is being evaluated (the leader does that alone -- the shares are small and a hand-off costs more
+// than they save -- but the followers compute the candidate's records meanwhile: if the step is accepted the linearisation behind it re-uses them),
+// 3 = leave.  A follower acknowledges a mail box as soon as it has read it; the leader waits for those acknowledgements before it writes the next.
+__device__ __forceinline__ void ba_publish(const BaBatch &B, const BaCtx &c, BaLds &L, int cmd, const double *poses, const double *ex, const double *invd, bool reuse)
+{
+    const int tid = threadIdx.x;
+    unsigned int *flags = B.bar + (size_t)c.win * 16;
+    if (tid < 64 && L.eval_no > 0 && !L.failed) { if (!ba_wait_flags(flags + 1, c.K - 1, (unsigned int)L.eval_no, B.fail) && tid == 0) L.failed = 1; }
+    __syncthreads();
+    double *mb = B.mbox + (size_t)c.win * kBaMbox;
+    if (tid == 0) { st_sh<true>(mb, (double)cmd); st_sh<true>(mb + 1, reuse ? 1.0 : 0.0); }
+    if (!reuse && cmd != 3) {
+        for (int k = tid; k < 7 * c.n_poses; k += kBaT) st_sh<true>(mb + 8 + k, poses[k]);
+        if (tid < 7) st_sh<true>(mb + 88 + tid, ex[tid]);
+        for (int f = tid; f < c.F; f += kBaT) st_sh<true>(mb + 96 + f, gld(invd + f));
     }
-    // wave 1: LASERFactor chain and prior, next to the pair records of wave 0
-    // (their residuals / Jacobians wait in gn | va | vb, which are dead during a linearisation, until the pair blocks are in)
-    static_assert(3 * kBaN >= 11 * kBaSmallRec, "small-factor records must fit gn | va | vb");
-    // (linearisation: wave 1 evaluates them at the head of its pair loop instead -- a single lane per block walks ~1000 double-precision instructions, and
-    // behind an accepted step, when the pair records are re-used, the whole workgroup used to wait for it here)
-    double small_cost = 0.0;
-    if (!kJac && tid >= 64 && tid < 96) small_cost = ba_small_factors<kJac>(B, c, L.gn, poses, ex, tid - 64);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) ba_flag_store(flags, (unsigned int)(L.eval_no + 1));
+}
+// everybody's stores of a linearisation are out: the leader waits for the followers' done words, a follower sets its own
+template <bool kLeader>
+__device__ __forceinline__ void ba_done(const BaBatch &B, const BaCtx &c, BaLds &L)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned int *flags = B.bar + (size_t)c.win * 16;
+    if (kLeader) {
+        if (threadIdx.x < 64 && !L.failed) { if (!ba_wait_flags(flags + 1, c.K - 1, (unsigned int)(L.eval_no + 1), B.fail) && threadIdx.x == 0) L.failed = 1; }
+        __syncthreads();
+    } else if (threadIdx.x == 0) ba_flag_store(flags + c.rank, (unsigned int)(L.eval_no + 1));
+}
+
+// one workgroup's share of an evaluation: the segments gw, gw + GW, ... of the window (a linearisation takes two per round and wave, a cost evaluation
+// four).  Every result goes to the segment's / the observation's own record.
+template <bool kJac, bool kCl>
+__device__ __forceinline__ void ba_segments(const BaBatch &B, const BaCtx &c, BaLds &L, const double *ex, const double *pairdat)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double *Rlc = L.Rp + 9 * c.n_poses;
     const double *mono_info = B.info + 36;
     const double m00 = gld(mono_info), m01 = gld(mono_info + 1), m10 = gld(mono_info + 2), m11 = gld(mono_info + 3);
     const int *sinfo = B.slot_info + c.ps0;
     const double *spts = B.slot_pts + (size_t)c.ps0 * 4;
-    const int gw = wave, GW = kBaW;                      // this wave among the waves that share the window's segments
+    const int gw = ba_worker(c, wave), GW = c.GW;        // this wave among the waves that share the window's segments
+    if (gw < 0) return;
     if (!kJac) {
-        __syncthreads();   // pair records are visible
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         // one lane per slot, 16 lanes per segment, four segments per wave and round: a segment's share of the cost is the sum over its 16 lanes and
-        // goes to the segment's own cell; the cells are added in segment order below
+        // goes to the segment's own cell; the cells are added in segment order by the leader
         double *cpart = B.cpart + c.sg0;
         for (int s4 = 4 * gw; s4 < c.n_seg; s4 += 4 * GW) {
             const int sg = s4 + (lane >> 4);
@@ -628,26 +720,10 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
                 cst = 0.5 * log(1.0 + (r0 * r0 + r1 * r1));   // ceres::CauchyLoss(1)
             }
             cst = quarter_sum_d(cst);
-            if (seg_ok && (lane & 15) == 0) gst(cpart + sg, cst);
+            if (seg_ok && (lane & 15) == 0) st_sh<kCl>(cpart + sg, cst);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        ba_segment_cost(c, L, cpart, 1);
-        // the LASERFactor chain's and the prior's share: wave 1's lanes 0..31
-        if (wave == 1) { small_cost = wave_sum_d(small_cost); if (lane == 0) L.red[3 * kBaW - 2] = small_cost; }
-        __syncthreads();
-        const double cost = L.red[3 * kBaW - 1] + L.red[3 * kBaW - 2];
-        __syncthreads();
-        BA_TOCK(3)
-        return cost;
+        return;
     }
-
-    __syncthreads();   // pair records and zeroed coupling rows are visible
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    BA_TOCK(0)
-    BA_TICK(1)
-    if (kJac && tid >= 64 && tid < 96) small_cost = ba_small_factors<kJac>(B, c, L.gn, poses, ex, tid - 64);
     // Every wave takes SEGMENTS (up to 16 slots of one frame pair), two per round: lanes 0..31 the first, lanes 32..63 the second, two lanes per
     // observation (lane q of the pair owns residual row q); the 64 rows are staged in the wave's own LDS slice and multiplied right away (MFMA steps
     // 0..7 -> the first segment's tile, 8..15 -> the second's) -- no workgroup barrier inside the loop.  A segment's tile, its share of the cost and
@@ -746,13 +822,13 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
             const double hdd = pair_sum(Jd * Jd), gd = pair_sum(Jd * rq);
             double *sc = B.obsc + (size_t)ob * kBaObsRec;
             if (q == 0) {
-                gst(sc, hdd); gst(sc + 1, gd);
+                st_sh<kCl>(sc, hdd); st_sh<kCl>(sc + 1, gd);
 #pragma unroll
-                for (int k = 0; k < 6; k++) gst(sc + 2 + k, hx[k]);
-                gst(sc + 20, (double)(oj + 1)); gst(sc + 21, (double)f);   // where frame j's share goes: column + 1 (0: no record), row
+                for (int k = 0; k < 6; k++) st_sh<kCl>(sc + 2 + k, hx[k]);
+                st_sh<kCl>(sc + 20, (double)(oj + 1)); st_sh<kCl>(sc + 21, (double)f);   // where frame j's share goes: column + 1 (0: no record), row
             } else {
 #pragma unroll
-                for (int k = 0; k < 6; k++) { gst(sc + 8 + k, hi[k]); gst(sc + 14 + k, hj[k]); }
+                for (int k = 0; k < 6; k++) { st_sh<kCl>(sc + 8 + k, hi[k]); st_sh<kCl>(sc + 14 + k, hj[k]); }
             }
         } else {
 #pragma unroll
@@ -783,24 +859,80 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
                 double *tile = tiles + (size_t)(h ? sB : sA) * kBaPairTile;
 #pragma unroll
                 for (int v = 0; v < 4; v++) {
-                    gst(tile + (kq + 4 * v) * 16 + col, aa[v]);
-                    if (col < 3) gst(tile + 256 + (kq + 4 * v) * 4 + col, ab[v]);
+                    st_sh<kCl>(tile + (kq + 4 * v) * 16 + col, aa[v]);
+                    if (col < 3) st_sh<kCl>(tile + 256 + (kq + 4 * v) * 4 + col, ab[v]);
                 }
                 if (lane == 32 * h) {
-                    gst(tile + 256 + 3, cst); gst(tile + 260 + 3, xx44); gst(tile + 264 + 3, xx45); gst(tile + 268 + 3, xx55);
-                    gst(tile + 272 + 3, gx4); gst(tile + 276 + 3, gx5);
+                    st_sh<kCl>(tile + 256 + 3, cst); st_sh<kCl>(tile + 260 + 3, xx44); st_sh<kCl>(tile + 264 + 3, xx45); st_sh<kCl>(tile + 268 + 3, xx55);
+                    st_sh<kCl>(tile + 272 + 3, gx4); st_sh<kCl>(tile + 276 + 3, gx5);
                 }
             }
         }
         __builtin_amdgcn_wave_barrier();   // the slice is rewritten by the next round
     }
+}
+
+// cost (returned to every thread) and, when kJac, the unscaled normal equations: Hpp, gp, Hdd, gdd in LDS, Hpd in HBM -- the LEADER's view of an
+// evaluation (with several workgroups per window the others run ba_follow).
+// records_valid: the pose matrices, the inverse depths in LDS and the pair records in HBM were computed by the previous call for the SAME parameter
+// values (the candidate evaluation of a step that was then accepted): a linearisation right behind it re-uses them instead of computing the same
+// numbers again
+template <bool kJac, bool kCl>
+__device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLds &L_arg, const double *poses, const double *ex, const double *invd,
+                                              double *hpd, double *pairdat, bool records_valid = false)
+{
+    BA_BIND_LDS(L_arg)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __syncthreads();
+    BA_TICK(kJac ? 0 : 3)
+    if (kCl) ba_publish(B, c, L, kJac ? 1 : 2, poses, ex, invd, records_valid);
+    if (!records_valid) ba_records<false>(c, L, poses, ex, invd, pairdat);
+    // wave 1: LASERFactor chain and prior, next to the pair records of wave 0
+    // (their residuals / Jacobians wait in gn | va | vb, which are dead during a linearisation, until the pair blocks are in)
+    static_assert(3 * kBaN >= 11 * kBaSmallRec, "small-factor records must fit gn | va | vb");
+    // (linearisation: wave 1 evaluates them at the head of its pair loop instead -- a single lane per block walks ~1000 double-precision instructions, and
+    // behind an accepted step, when the pair records are re-used, the whole workgroup used to wait for it here)
+    double small_cost = 0.0;
+    if (!kJac && tid >= 64 && tid < 96) small_cost = ba_small_factors<kJac>(B, c, L.gn, poses, ex, tid - 64);
+    double *tiles = B.pairH + (size_t)(c.sg0 + c.pp0) * kBaPairTile;
+    if (!kJac) {
+        __syncthreads();   // pair records are visible
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // (the leader's eight waves take every segment of a candidate's cost, whatever K is)
+        BaCtx c1 = c;
+        c1.K = 1; c1.GW = kBaW;
+        ba_segments<false, false>(B, c1, L, ex, pairdat);
+        double *cpart = B.cpart + c.sg0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        ba_segment_cost<false>(c, L, cpart, 1);
+        // the LASERFactor chain's and the prior's share: wave 1's lanes 0..31
+        if (wave == 1) { small_cost = wave_sum_d(small_cost); if (lane == 0) L.red[3 * kBaW - 2] = small_cost; }
+        __syncthreads();
+        const double cost = L.red[3 * kBaW - 1] + L.red[3 * kBaW - 2];
+        __syncthreads();
+        if (kCl && tid == 0) L.eval_no++;
+        BA_TOCK(3)
+        return cost;
+    }
+
+    __syncthreads();   // pair records and zeroed coupling rows are visible
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    BA_TOCK(0)
+    BA_TICK(1)
+    if (kJac && tid >= 64 && tid < 96) small_cost = ba_small_factors<kJac>(B, c, L.gn, poses, ex, tid - 64);
+    ba_segments<true, kCl>(B, c, L, ex, pairdat);
     BA_TOCK(1)
     BA_TICK(11)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // the segment and observation records are written
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");       // ... and read below by other waves: drop this CU's L1 copies
+    if (kCl) ba_done<true>(B, c, L);                             // every workgroup's segment and observation records are written
+    else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // the segment and observation records are written
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");       // ... and read below by other waves: drop this CU's L1 copies
+    }
     BA_TICK(12)
-    ba_reduce_pairs(B, c, L);
+    ba_reduce_pairs<kCl>(B, c, L);
     BA_TOCK(12)
     BA_TICK(13)
     {
@@ -813,7 +945,7 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
             for (int ob = o0; ob < o1; ob += 10) {
                 double v[10];
 #pragma unroll
-                for (int u = 0; u < 10; u++) v[u] = ob + u < o1 ? gld(B.obsc + (size_t)(ob + u) * kBaObsRec + k) : 0.0;
+                for (int u = 0; u < 10; u++) v[u] = ob + u < o1 ? ld_sh<kCl>(B.obsc + (size_t)(ob + u) * kBaObsRec + k) : 0.0;
 #pragma unroll
                 for (int u = 0; u < 10; u++) acc += v[u];
             }
@@ -835,7 +967,7 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
             for (int u = 0; u < 4; u++) {
                 const int ob = ob0 + u * (kBaT / 8);
                 const double *rc = B.obsc + (size_t)(c.o0 + (ob < n_obs ? ob : ob0)) * kBaObsRec;
-                vj[u] = gld(rc + 14 + (kk < 6 ? kk : 0)); vo[u] = gld(rc + 20); vf[u] = gld(rc + 21);
+                vj[u] = ld_sh<kCl>(rc + 14 + (kk < 6 ? kk : 0)); vo[u] = ld_sh<kCl>(rc + 20); vf[u] = ld_sh<kCl>(rc + 21);
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -854,11 +986,12 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
         small_cost = wave_sum_d(small_cost);
         if (lane == 0) L.red[3 * kBaW - 2] = small_cost;
     }
-    ba_segment_cost(c, L, tiles + 256 + 3, kBaPairTile);
+    ba_segment_cost<kCl>(c, L, tiles + 256 + 3, kBaPairTile);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     const double cost = L.red[3 * kBaW - 1] + L.red[3 * kBaW - 2];
     __syncthreads();
+    if (kCl && tid == 0) L.eval_no++;
     BA_TOCK(11)
     // the coupling rows were written through L2: drop this CU's L1 copies before they are read with plain loads
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -1283,11 +1416,54 @@ __device__ __noinline__ void ba_setup(const BaBatch &B, const BaCtx c, BaLds &L_
     __syncthreads();
 }
 
-__global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B)
+// A follower workgroup of a window (rank > 0): waits for the leader's mail, computes its own copy of the state's records and, for a linearisation,
+// takes its share of the segments and reports; until the leader sends command 3.
+__device__ __noinline__ void ba_follow(const BaBatch &B, const BaCtx c, BaLds &L_arg, double *pairdat)
+{
+    BA_BIND_LDS(L_arg)
+    const int tid = threadIdx.x;
+    const double *mb = B.mbox + (size_t)c.win * kBaMbox;
+    unsigned int *flags = B.bar + (size_t)c.win * 16;
+    for (;;) {
+        if (tid < 64) { if (!ba_wait_flags(flags, 1, (unsigned int)(L.eval_no + 1), B.fail) && tid == 0) L.failed = 1; }
+        __syncthreads();
+        if (L.failed) return;
+        const int cmd = (int)ld_sh<true>(mb), reuse = (int)ld_sh<true>(mb + 1);
+        if (cmd == 3) return;
+        if (!reuse) {
+            for (int k = tid; k < 7 * c.n_poses; k += kBaT) L.cposes[k] = ld_sh<true>(mb + 8 + k);
+            if (tid < 7) L.cex[tid] = ld_sh<true>(mb + 88 + tid);
+            for (int f = tid; f < c.F; f += kBaT) L.vinv[f] = ld_sh<true>(mb + 96 + f);
+        }
+        __syncthreads();
+        // a candidate: the mail box is read -- acknowledge, then compute the records in the leader's shadow
+        if (cmd == 2 && tid == 0) ba_flag_store(flags + c.rank, (unsigned int)(L.eval_no + 1));
+        if (!reuse) ba_records<true>(c, L, L.cposes, L.cex, nullptr, pairdat);
+        __syncthreads();   // pair records are visible
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (cmd == 1) {
+            ba_segments<true, true>(B, c, L, L.cex, pairdat);
+            ba_done<false>(B, c, L);
+        }
+        if (tid == 0) L.eval_no++;
+        __syncthreads();
+    }
+}
+
+// K workgroups per window (kCl: K > 1): block b runs on XCD b mod 8 as dispatched today, so the K workgroups of a window are given the same b mod 8
+// (a shared L2 makes their exchange cheaper; nothing depends on it: every hand-off is device-coherent and ordered by the arrival counters)
+template <bool kCl>
+__global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B, int K)
 {
     BaLds &L = g_ba_lds;
-    const int w = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     BaCtx c;
+    c.K = kCl ? K : 1;
+    const int w = kCl ? ((int)blockIdx.x / 8 / K) * 8 + (int)blockIdx.x % 8 : (int)blockIdx.x;
+    c.rank = kCl ? ((int)blockIdx.x / 8) % K : 0;
+    c.GW = c.K == 1 ? kBaW : c.K * kBaW - 1;
+    c.win = w;
+    if (w >= B.n_windows) return;
     c.n_poses = B.flags[w * 4 + 0]; c.use_prior = B.flags[w * 4 + 1]; c.ex_constant = B.flags[w * 4 + 2]; c.use_mono = B.flags[w * 4 + 3];
     c.f0 = B.feat_off[w]; c.o0 = B.obs_off[w];
     c.F = c.use_mono ? B.feat_off[w + 1] - c.f0 : 0;
@@ -1299,8 +1475,12 @@ __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B)
     const int P = c.P, F = c.F, N = P + F;
     double *gposes = B.poses + (size_t)w * kBaMaxPoses * 7, *gex = B.ex + (size_t)w * 7, *ginvd = B.inv_depth + c.f0;
     double *hpd = B.hpd + (size_t)w * kBaMaxFeat * kBaPS;
-    double *pairdat = B.pairdat + (size_t)c.pp0 * kBaPairRec;
+    double *pairdat = B.pairdat + ((size_t)c.rank * B.n_pairs_total + c.pp0) * kBaPairRec;       // (one copy per workgroup of a window)
     double *cinvd = B.cand + (size_t)w * kBaMaxFeat;
+    if (tid == 0) { L.eval_no = 0; L.failed = 0; }
+#ifdef LMONO_BA_PROF
+    if (tid < 24) L.prof[tid] = 0;
+#endif
     for (int k = tid; k < c.n_poses * 7; k += kBaT) L.poses[k] = gposes[k];
     if (tid < 7) L.ex[tid] = gex[tid];
     for (int k = tid; k < c.n_pairs; k += kBaT) L.pair_ij[k] = B.pair_ij[c.pp0 + k];
@@ -1308,6 +1488,7 @@ __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B)
     for (int k = tid; k < c.n_seg; k += kBaT) L.seg[k] = B.seg_tab[c.sg0 + k];
     __syncthreads();
     ba_setup(B, c, L);
+    if (kCl && c.rank > 0) { ba_follow(B, c, L, pairdat); return; }
 
     const double function_tol = 1e-6, gradient_tol = 1e-10, parameter_tol = 1e-8, min_rel_decrease = 1e-3;
     const double min_diag = 1e-6, max_diag = 1e32, max_radius = 1e16, min_radius = 1e-32;
@@ -1322,8 +1503,9 @@ __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B)
     // one call site per phase (the phases are inlined: LDS addressing, no register-file round trips through a call)
     for (;;) {
         if (linearise) {
-            x_cost = ba_evaluate<true>(B, c, L, L.poses, L.ex, ginvd, hpd, pairdat, records_valid);
+            x_cost = ba_evaluate<true, kCl>(B, c, L, L.poses, L.ex, ginvd, hpd, pairdat, records_valid);
             records_valid = false;
+            BA_TICK(16)
             double q = 0, g = 0;
             if (c.ex_off >= 0 && tid < 7) q += L.ex[tid] * L.ex[tid];
             for (int k = tid; k < 7 * c.n_poses; k += kBaT) q += L.poses[k] * L.poses[k];
@@ -1357,12 +1539,15 @@ __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B)
                 L.D[k] = sqrt(d);
                 L.va[k] = L.gs[k] / d;
             }
+            BA_TOCK(16)
             ba_hs_mul(c, L, hpd, L.va, L.vb);      // vb = Hs (gs / D^2): kept until the next linearisation
+            BA_TICK(17)
             double g2 = 0, jg2 = 0, zero = 0;
             for (int k = tid; k < N; k += kBaT) { const double gd = L.gs[k] / L.D[k]; g2 += gd * gd; jg2 += L.va[k] * L.vb[k]; }
             block_sum3(g2, jg2, zero, L.red);
             alpha = g2 / jg2;
             ok = false;
+            BA_TOCK(17)
             while (mu < max_mu) {
                 if (ba_schur_solve(c, L, hpd, mu)) { ok = true; break; }
                 mu *= mu_inc;
@@ -1374,6 +1559,7 @@ __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B)
             }
             __syncthreads();
         }
+        BA_TICK(18)
         if (ok) {
             double a2 = 0, b2 = 0, ab = 0;
             for (int k = tid; k < N; k += kBaT) { const double gd = L.gs[k] / L.D[k]; a2 += L.gn[k] * L.gn[k]; b2 += gd * gd; ab += gd * L.gn[k]; }
@@ -1404,6 +1590,7 @@ __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B)
             model_change = -(dg + 0.5 * dHd);
         }
         if (!ok || !(model_change > 0.0)) {
+            BA_TOCK(18)
             if (++invalid >= 5) { termination = 2; break; }
             mu *= mu_inc; reuse = false;
             continue;
@@ -1424,7 +1611,9 @@ __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B)
         }
         for (int f = tid; f < F; f += kBaT) cinvd[f] = ginvd[f] + L.va[P + f] * L.scale[P + f];
         __syncthreads();
-        const double cand_cost = ba_evaluate<false>(B, c, L, L.cposes, L.cex, cinvd, hpd, pairdat);
+        BA_TOCK(18)
+        const double cand_cost = ba_evaluate<false, kCl>(B, c, L, L.cposes, L.cex, cinvd, hpd, pairdat);
+        BA_TICK(19)
         double dq = 0;
         if (c.ex_off >= 0 && tid < 7) dq += (L.ex[tid] - L.cex[tid]) * (L.ex[tid] - L.cex[tid]);
         for (int k = tid; k < 7 * c.n_poses; k += kBaT) dq += (L.poses[k] - L.cposes[k]) * (L.poses[k] - L.cposes[k]);
@@ -1449,17 +1638,21 @@ __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B)
             radius *= 0.5; reuse = true;
             n_unsucc++;
         }
+        BA_TOCK(19)
     }
     __syncthreads();
+    if (kCl) ba_publish(B, c, L, 3, L.poses, L.ex, ginvd, true);        // the followers leave
     BA_TOCK(9)
 #ifdef LMONO_BA_PROF
-    if (w == 0 && tid == 0) printf("PROF total %lld | lin: prologue %lld eval %lld mfma %lld | cost %lld | hs %lld | schur: stage+mfma %lld chol %lld subst %lld depth %lld | iters %d | wave-0 turn wait %lld, feature pass + small factors %lld (reduce pairs %lld, wave 0's features %lld) | chol: factor %lld barrier %lld next-panel %lld\n", g_prof[9], g_prof[0], g_prof[1], g_prof[2], g_prof[3], g_prof[4], g_prof[5], g_prof[6], g_prof[7], g_prof[8], iter, g_prof[10] * 0, g_prof[11], g_prof[12], g_prof[13], g_prof[14], g_prof[15], g_prof[10]);
+    if (w == 0 && tid < 24) g_prof[tid] += (long long)L.prof[tid];
+    __syncthreads();
+    if (w == 0 && tid == 0) printf("PROF total %lld | lin: prologue %lld eval %lld mfma %lld | cost %lld | hs %lld | schur: stage+mfma %lld chol %lld subst %lld depth %lld | iters %d | wave-0 turn wait %lld, feature pass + small factors %lld (reduce pairs %lld, wave 0's features %lld) | chol: factor %lld barrier %lld next-panel %lld | glue: norms+D %lld alpha %lld dogleg+candidate %lld decision %lld\n", g_prof[9], g_prof[0], g_prof[1], g_prof[2], g_prof[3], g_prof[4], g_prof[5], g_prof[6], g_prof[7], g_prof[8], iter, g_prof[10] * 0, g_prof[11], g_prof[12], g_prof[13], g_prof[14], g_prof[15], g_prof[10], g_prof[16], g_prof[17], g_prof[18], g_prof[19]);
 #endif
     for (int k = tid; k < c.n_poses * 7; k += kBaT) gposes[k] = L.poses[k];
     if (tid < 7) gex[tid] = L.ex[tid];
     if (tid == 0) {
         double *sm = B.summary + (size_t)w * 6;
-        sm[0] = initial_cost; sm[1] = x_cost; sm[2] = iter; sm[3] = termination; sm[4] = n_succ; sm[5] = n_unsucc;
+        sm[0] = initial_cost; sm[1] = x_cost; sm[2] = iter; sm[3] = (kCl && L.failed) ? 3 : termination; sm[4] = n_succ; sm[5] = n_unsucc;
     }
 }
 

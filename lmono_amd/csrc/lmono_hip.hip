@@ -188,7 +188,8 @@ extern "C" int lmono_set_option(lmono_ctx *c, int key, int value)
                   : key == LMONO_OPT_DEFER_EVERY ? value >= 0
                   : key == LMONO_OPT_ODOM_STREAMS ? (value >= 1 && value <= 8)
                   : key == LMONO_OPT_BOUNDARY_TOL ? value >= 0
-                  : (key == LMONO_OPT_RESERVED5 || key == LMONO_OPT_RESERVED6) ? value == 0      // round 3's shelved schedules (removed)
+                  : key == LMONO_OPT_BA_CLUSTER ? (value == 0 || value == 1 || value == 2 || value == 4 || value == 8)
+                  : key == LMONO_OPT_RESERVED6 ? value == 0                     // round 3's shelved schedule (removed)
                   : value >= -1;                                     // LMONO_OPT_LEAD_FULL
     if (!ok) { c->err = "lmono_set_option: value out of range for this option"; return LMONO_EINVAL; }
     c->opt[key] = value;
@@ -1110,6 +1111,7 @@ struct lmono_ba_batch {
     char *stage = nullptr; size_t stage_cap = 0;
     BaBatch v{};
     int n_windows = 0, total_feat = 0, total_obs = 0;
+    int cluster = 1;            // workgroups per window of the last fill (the scratch is sized for it)
     double *poses0 = nullptr, *ex0 = nullptr, *invd0 = nullptr;   // initial state for lmono_ba_batch_reset
 };
 
@@ -1259,7 +1261,22 @@ static int ba_fill(lmono_ctx *c, lmono_ba_batch *b, const lmono_ba_desc *d)
     pk.add(nmulti_d, (const int *)n_multi.data(), (size_t)W); pk.add(segtab_d, seg_tab.empty() ? &uzero : seg_tab.data(), seg_tab.size());
     pk.add(v.obsc, (const double *)nullptr, (size_t)TO * kBaObsRec);
     pk.add(v.hpd, (const double *)nullptr, (size_t)W * kBaMaxFeat * kBaPS);
-    pk.add(v.pairdat, (const double *)nullptr, pair_ij.size() * kBaPairRec);
+    // workgroups per window: several when the batch leaves most of the chip idle (every workgroup of a window must be resident while it polls: at most
+    // half the CUs).  LMONO_BA_CLUSTER = 1 / 2 / 4 forces it (measurement switch); the results do not depend on it, bit for bit.
+    {
+        static const int env = [] { const char *e = getenv("LMONO_BA_CLUSTER"); return e ? atoi(e) : 0; }();        // measurement switch
+        const int forced = c->opt[LMONO_OPT_BA_CLUSTER] > 0 ? c->opt[LMONO_OPT_BA_CLUSTER] : env;
+        int K = forced > 0 ? forced : kBaMaxK;
+        if (K > kBaMaxK) K = kBaMaxK;
+        if (K == 3) K = 2; else if (K > 4 && K < 8) K = 4;
+        while (K > 1 && ((W + 7) / 8) * 8 * K > 128) K >>= 1;
+        b->cluster = K;
+    }
+    pk.add(v.pairdat, (const double *)nullptr, (size_t)b->cluster * pair_ij.size() * kBaPairRec);
+    pk.add(v.mbox, (const double *)nullptr, (size_t)W * kBaMbox);
+    pk.add(v.bar, (const unsigned int *)nullptr, (size_t)W * 16);
+    pk.add(v.fail, (const int *)nullptr, (size_t)1);
+    v.n_pairs_total = (int)pair_ij.size();
     pk.add(v.pairH, (const double *)nullptr, (seg_tab.size() + pair_ij.size()) * kBaPairTile);
     pk.add(v.cpart, (const double *)nullptr, seg_tab.size());
     pk.add(v.cand, (const double *)nullptr, (size_t)W * kBaMaxFeat); pk.add(v.summary, (const double *)nullptr, (size_t)W * 6);
@@ -1299,7 +1316,12 @@ extern "C" int lmono_ba_solve(lmono_ctx *c, lmono_ba_batch *b, int max_iteration
     if (b->n_windows <= 0) { c->err = "lmono_ba_solve: the batch holds no problem (failed update)"; return LMONO_EINVAL; }
     HIP_TRY(c, hipSetDevice(c->device));
     b->v.max_iter = max_iterations;
-    hipLaunchKernelGGL(k_ba_solve, dim3(b->n_windows), dim3(kBaT), 0, c->stream, b->v);          // its LDS is static (g_ba_lds)
+    if (b->cluster > 1) {
+        // the arrival counters start at zero in every launch
+        HIP_TRY(c, hipMemsetAsync(b->v.bar, 0, (((sizeof(unsigned int) * (size_t)b->n_windows * 16) + 255) & ~(size_t)255) + 256, c->stream));   // (+ the failure flag behind them)
+        hipLaunchKernelGGL(k_ba_solve<true>, dim3(((b->n_windows + 7) / 8) * 8 * b->cluster), dim3(kBaT), 0, c->stream, b->v, b->cluster);
+    } else
+        hipLaunchKernelGGL(k_ba_solve<false>, dim3(b->n_windows), dim3(kBaT), 0, c->stream, b->v, 1);          // its LDS is static (g_ba_lds)
     return check_launch(c, "k_ba_solve");
 }
 
@@ -1321,7 +1343,10 @@ extern "C" int lmono_ba_batch_read(lmono_ctx *c, lmono_ba_batch *b, double *pose
     if (ex_h) HIP_TRY(c, hipMemcpyAsync(ex_h, b->v.ex, sizeof(double) * (size_t)b->n_windows * 7, hipMemcpyDeviceToHost, c->stream));
     if (inv_depth_h && b->total_feat > 0) HIP_TRY(c, hipMemcpyAsync(inv_depth_h, b->v.inv_depth, sizeof(double) * (size_t)b->total_feat, hipMemcpyDeviceToHost, c->stream));
     if (summary_h) HIP_TRY(c, hipMemcpyAsync(summary_h, b->v.summary, sizeof(double) * (size_t)b->n_windows * 6, hipMemcpyDeviceToHost, c->stream));
+    int failed = 0;
+    if (b->cluster > 1) HIP_TRY(c, hipMemcpyAsync(&failed, b->v.fail, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));      // stream-ordered behind the solve; nothing goes through the null stream
+    if (failed) { c->err = "k_ba_solve: a workgroup of a window's cluster did not arrive (not all resident?): the solve is void"; return LMONO_ENODEV; }
     return LMONO_OK;
 }
 

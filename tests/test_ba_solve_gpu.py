@@ -82,3 +82,31 @@ def test_update_reuses_the_batch_and_changes_nothing(oracle, gpu_ctx):
             R1, P1 = oracle.ba_reanchor(got[0][k, :n], w["gt_Rs"][0], w["gt_Ps"][0])
             R2, P2 = oracle.ba_reanchor(want[0][k, :n], w["gt_Rs"][0], w["gt_Ps"][0])
             assert np.abs(P1 - P2).max() < 1e-7 and np.abs(R1 - R2).max() < 1e-8
+
+
+def test_workgroups_per_window_do_not_change_a_bit(oracle, gpu_ctx):
+    """K = 1, 2, 4 or 8 workgroups share a window's linearisations and candidate costs (LMONO_OPT_BA_CLUSTER; default: 4 for small batches).  Every sum
+    that crosses observations is formed per 16-observation segment and the segments' results are added in segment order by the window's leader,
+    so the solve is the same BYTES whatever K is -- also for a window without projection factors, with a constant extrinsic, and while the window
+    still fills up -- and agrees with the CPU restatement like the one-workgroup solve."""
+    windows = [K.make_window(s) for s in (30, 31, 32)]
+    windows[1]["use_mono"] = False
+    windows[2]["ex_constant"] = True
+    windows.append(K.make_window(33, n_frames=5))
+    windows.append(K.make_window(34, n_landmarks=2500))       # many multi-segment frame pairs
+    got = {}
+    try:
+        for k in (1, 2, 4, 8):
+            gpu_ctx.set_option(gpu_ctx.OPT_BA_CLUSTER, k)
+            _, got[k] = _solve_gpu(gpu_ctx, windows)
+    finally:
+        gpu_ctx.set_option(gpu_ctx.OPT_BA_CLUSTER, 0)
+    _, got[0] = _solve_gpu(gpu_ctx, windows)                   # the default choice for a batch of five
+    for k in (2, 4, 8, 0):
+        for a, c in zip(got[1], got[k]):
+            assert a.tobytes() == c.tobytes(), "K = %d differs from K = 1" % k
+    sm = got[4][3]
+    for k, w in enumerate(windows):
+        rp, re, rd, rs = oracle.ba_solve(w)
+        assert abs(sm[k, 1] - rs.final_cost) <= 1e-6 * rs.final_cost + 1e-9
+        assert int(sm[k, 2]) == rs.iterations and int(sm[k, 3]) == rs.termination
