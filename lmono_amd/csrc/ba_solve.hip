@@ -46,6 +46,12 @@ constexpr int kBaSeg = 16;                       // observations of a segment: a
 constexpr int kBaMaxSeg = kBaMaxPairs + kBaMaxFeat * (kBaMaxPoses - 1) / kBaSeg;      // 110 + 280
 constexpr int kBaMbox = 96 + kBaMaxFeat;         // leader -> followers: [0] command, [1] re-use the records, [8..84] poses, [88..94] extrinsic, [96..] inverse depths
 constexpr int kBaMaxK = 8;                       // workgroups per window
+// ba_reduce_pairs' gather program (built once per solve: which tile cells an entry of H_pp / g_p is the sum of does not change between iterations):
+// part A = the 36 entries of every lower frame-block pair (two sources, written twice: the tiles are symmetric), part B = per frame the 21 lower
+// entries of its diagonal block, its 36 entries against the extrinsic and its 6 gradient entries (22 sources: the pairs (f, k), then the pairs (k, f))
+constexpr int kBaGaN = 2048;                     // part A items (55 block pairs x 36 = 1980, padded): fields source 1, source 2, destination, mirror
+constexpr int kBaGbN = 704;                      // part B items (11 frames x 63 = 693, padded): fields 22 sources, destination, mirror
+constexpr int kBaGprog = 4 * kBaGaN + 24 * kBaGbN;
 constexpr int kBaObsRec = 24;                    // per-observation record: hdd, gd, hx[6], hi[6], hj[6], oj
 constexpr int kBaT = 512;                        // threads per workgroup (2 waves per SIMD)
 constexpr int kBaW = kBaT / 64;
@@ -81,11 +87,12 @@ struct BaBatch {
     const int *slot_obs;        // [total slots] observation (host order, global index) behind every slot
     double *obsc;               // scratch [total obs][kBaObsRec]: per-observation depth / coupling contributions (hdd, gd, hx[6], hi[6], hj[6], oj),
                                 // in host observation order = grouped by feature: a feature's records are contiguous
-    double *pairH;              // scratch [total segments + total pairs][kBaPairTile], per window [its segments | its pairs]: every segment's J^T [J r] tile
+    double *pairH;              // scratch [total segments + total pairs + W][kBaPairTile], per window [its segments | its pairs | one tile of zeros]: every segment's J^T [J r] tile
                                 // (16 x 16 + 16 x 4) and scalar sums; a pair of several segments has their sum (segment order) in its own tile (ba_reduce_pairs)
     double *cpart;              // scratch [total segments]: every segment's share of a candidate's cost
     // several workgroups per window (k_ba_solve<true>): the leader's mail box [W][kBaMbox] (command, state to evaluate), flag words [W][16]
     // (go, done of every follower; zeroed before every launch), a failure flag; pairdat then holds one copy per workgroup of a window
+    int *gprog;                 // scratch [W][kBaGprog]: every window's gather program (see kBaGaN)
     double *mbox;
     unsigned int *bar;
     int *fail;
@@ -305,6 +312,10 @@ template <bool kCl> __device__ __forceinline__ void st_sh(double *p, double v)
 // [r] = done of follower r (rank r >= 1).  Zeroed before every launch.
 __device__ __forceinline__ unsigned int ba_flag_load(const unsigned int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void ba_flag_store(unsigned int *p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// the XCD this workgroup runs on (HW_REG_XCC_ID, bits 3:0).  Used for SPEED only: a follower on the leader's XCD shares its L2, so its plain
+// (write-through) stores are where the leader's device-coherent loads look first; a follower elsewhere stores device-coherently (sc1), which is right
+// on any placement and slower to read back
+__device__ __forceinline__ int ba_xcc_id() { return (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u); }
 // lanes 0 .. n - 1 of ONE wave wait until flags[lane] >= target (bounded: a wave that never finishes can take the GPU down); false = gave up
 __device__ __forceinline__ bool ba_wait_flags(const unsigned int *flags, int n, unsigned int target, int *fail)
 {
@@ -432,7 +443,7 @@ __device__ __forceinline__ void ba_reduce_pairs(const BaBatch &B, const BaCtx c,
 {
     const int tid = threadIdx.x, np_ = c.n_poses;
     // the window's tiles: one per segment, then one per pair (used by the pairs of several segments)
-    double *tiles = B.pairH + (size_t)(c.sg0 + c.pp0) * kBaPairTile;
+    double *tiles = B.pairH + (size_t)(c.sg0 + c.pp0 + c.win) * kBaPairTile;
     double *ptile = tiles + (size_t)c.n_seg * kBaPairTile;
     // (0) pairs of several segments (they come first: the pairs are sorted by size): their tiles summed in segment order into the pair's own tile
     if (c.n_multi > 0) {
@@ -473,67 +484,39 @@ __device__ __forceinline__ void ba_reduce_pairs(const BaBatch &B, const BaCtx c,
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
-    // (L.pair_of holds a pair's TILE: its own for a pair of several segments, its only segment's otherwise)
-    auto tile_of = [&](int tix) -> const double * { return tiles + tix * kBaPairTile; };
-    // position of (row r, column q) of a tile; rows / columns 0..5 = frame i, 6..11 = frame j, 12..15 = extrinsic 0..3 (the 16 x 16
-    // tile), column 16 / 17 = extrinsic 4 / 5 and column 18 = the residual (the 16 x 4 side tile); the tile is symmetric
-    auto pos = [](int r, int q) { return q < 16 ? (r < 16 ? r * 16 + q : 256 + q * 4 + (r - 16)) : 256 + r * 4 + (q - 16); };
+    // (A), (B): the entries of H_pp and g_p that are sums over frame pairs, by the window's gather program (ba_setup: the cells an entry is the sum of are
+    // the same in every iteration; looking them up anew -- pair tables in LDS, 64-bit address arithmetic, a branch per source -- was 400 instructions
+    // per entry).  An absent source points at the window's tile of zeros.  Part A: the two pairs that can hold a block of two different frames;
+    // part B: the pairs (f, k) by ascending k, then the pairs (k, f), for the entries of ONE frame f.  Sums in the order they always had.
     const int x0 = c.ex_off;                                   // first extrinsic index (-1: extrinsic constant)
-    // (A) entries coupling two DIFFERENT frames: the one pair that holds both (a caller may anchor tracks at a later frame: both orders).
-    //     Four entries per thread and turn: their loads are in flight together.
-    //     (the index runs over all 11 x 11 frame blocks: divisions by constants; blocks of absent frames are skipped)
-    for (int t0 = tid; t0 < kBaMaxPoses * kBaMaxPoses * 36; t0 += 4 * kBaT) {
+    const int *gp = B.gprog + (size_t)c.win * kBaGprog;
+    {
+        int o1[4], o2[4], d1[4], d2[4];
         double v1[4], v2[4];
-        int dst[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const int t = t0 + u * kBaT;
-            dst[u] = -1; v1[u] = 0.0; v2[u] = 0.0;
-            if (t < kBaMaxPoses * kBaMaxPoses * 36) {
-                const int bm = t / (kBaMaxPoses * 36), r = t % (kBaMaxPoses * 36), bn = r / 36, om = (r % 36) / 6, on = r % 6;
-                if (bm != bn && bm < np_ && bn < np_) {
-                    const int i = bm < bn ? bm : bn, j = bm < bn ? bn : bm;
-                    const int p1 = L.pair_of[i * kBaMaxPoses + j], p2 = L.pair_of[j * kBaMaxPoses + i];
-                    if (p1 >= 0) v1[u] = ld_sh<kCl>(tile_of(p1) + pos(bm == i ? om : 6 + om, bn == i ? on : 6 + on));
-                    if (p2 >= 0) v2[u] = ld_sh<kCl>(tile_of(p2) + pos(bm == j ? om : 6 + om, bn == j ? on : 6 + on));
-                    dst[u] = (ba_pose_off(c, bm) + om) * kBaP + ba_pose_off(c, bn) + on;
-                }
-            }
+            const int a = tid + u * kBaT;
+            o1[u] = gldi(gp + a); o2[u] = gldi(gp + kBaGaN + a); d1[u] = gldi(gp + 2 * kBaGaN + a); d2[u] = gldi(gp + 3 * kBaGaN + a);
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) if (dst[u] >= 0) L.Hpp[dst[u]] = v1[u] + v2[u];
+        for (int u = 0; u < 4; u++) { v1[u] = ld_sh<kCl>(tiles + o1[u]); v2[u] = ld_sh<kCl>(tiles + o2[u]); }
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (d1[u] >= 0) { const double sum = v1[u] + v2[u]; L.Hpp[d1[u]] = sum; L.Hpp[d2[u]] = sum; }
     }
-    // (B) entries of ONE frame f -- with itself (36), with the extrinsic (2 x 36) and its gradient (6): the pairs (f, j) by ascending j, then
-    //     the pairs (i, f) by ascending i; f sits in rows 0..5 of the former and 6..11 of the latter.  22 loads in flight per entry.
-    const int per_f = 36 + (x0 >= 0 ? 72 : 0) + 6;
-    for (int t = tid; t < np_ * per_f; t += kBaT) {
-        const int f = t / per_f, r = t % per_f;
-        int oi_, oj_, dst, dst2 = -1;
-        bool is_g = false;
-        if (r < 36) { const int om = r / 6, on = r % 6; oi_ = pos(om, on); oj_ = pos(6 + om, 6 + on); dst = (ba_pose_off(c, f) + om) * kBaP + ba_pose_off(c, f) + on; }
-        else if (r >= per_f - 6) { const int om = r - (per_f - 6); oi_ = pos(om, 18); oj_ = pos(6 + om, 18); dst = ba_pose_off(c, f) + om; is_g = true; }
-        else {
-            // (frame row om, extrinsic column ox) and its mirror: the tile is symmetric, one sum serves both
-            const int q = r - 36, om = (q % 36) / 6, ox = q % 6;
-            oi_ = pos(om, 12 + ox); oj_ = pos(6 + om, 12 + ox);
-            dst = (ba_pose_off(c, f) + om) * kBaP + x0 + ox; dst2 = (x0 + ox) * kBaP + ba_pose_off(c, f) + om;
-            if (q >= 36) continue;                              // the mirror is written with its twin
-        }
-        double va[kBaMaxPoses], vb[kBaMaxPoses];
+    const int *gb = gp + 4 * kBaGaN;
+    for (int t = tid; t < kBaGbN; t += kBaT) {
+        int off[22];
+        double v[22];
 #pragma unroll
-        for (int k = 0; k < kBaMaxPoses; k++) {
-            const int pa = (k < np_ && k != f) ? L.pair_of[f * kBaMaxPoses + k] : -1;
-            const int pb = (k < np_ && k != f) ? L.pair_of[k * kBaMaxPoses + f] : -1;
-            va[k] = pa >= 0 ? ld_sh<kCl>(tile_of(pa) + oi_) : 0.0;
-            vb[k] = pb >= 0 ? ld_sh<kCl>(tile_of(pb) + oj_) : 0.0;
-        }
+        for (int k = 0; k < 22; k++) off[k] = gldi(gb + k * kBaGbN + t);
+        const int dst = gldi(gb + 22 * kBaGbN + t), dst2 = gldi(gb + 23 * kBaGbN + t);
+#pragma unroll
+        for (int k = 0; k < 22; k++) v[k] = ld_sh<kCl>(tiles + off[k]);
         double acc = 0.0;
 #pragma unroll
-        for (int k = 0; k < kBaMaxPoses; k++) acc += va[k];
-#pragma unroll
-        for (int k = 0; k < kBaMaxPoses; k++) acc += vb[k];
-        if (is_g) L.gp[dst] = acc;
-        else { L.Hpp[dst] = acc; if (dst2 >= 0) L.Hpp[dst2] = acc; }
+        for (int k = 0; k < 22; k++) acc += v[k];
+        if (dst >= kBaP * kBaP) L.gp[dst - kBaP * kBaP] = acc;
+        else if (dst >= 0) { L.Hpp[dst] = acc; if (dst2 >= 0) L.Hpp[dst2] = acc; }
     }
     // (C) the extrinsic block and gradient get a share from EVERY segment: 33 values per segment (rows 12..15 of the tile and of the side tile, and
     //     the five scalar sums of the (4..5, 4..5) corner); 15 threads per value add the segments s = g (mod 15) in ascending order into L.D (dead during
@@ -655,7 +638,7 @@ __device__ __forceinline__ void ba_publish(const BaBatch &B, const BaCtx &c, BaL
     if (tid < 64 && L.eval_no > 0 && !L.failed) { if (!ba_wait_flags(flags + 1, c.K - 1, (unsigned int)L.eval_no, B.fail) && tid == 0) L.failed = 1; }
     __syncthreads();
     double *mb = B.mbox + (size_t)c.win * kBaMbox;
-    if (tid == 0) { st_sh<true>(mb, (double)cmd); st_sh<true>(mb + 1, reuse ? 1.0 : 0.0); }
+    if (tid == 0) { st_sh<true>(mb, (double)cmd); st_sh<true>(mb + 1, reuse ? 1.0 : 0.0); st_sh<true>(mb + 2, (double)ba_xcc_id()); }
     if (!reuse && cmd != 3) {
         for (int k = tid; k < 7 * c.n_poses; k += kBaT) st_sh<true>(mb + 8 + k, poses[k]);
         if (tid < 7) st_sh<true>(mb + 88 + tid, ex[tid]);
@@ -730,7 +713,7 @@ __device__ __forceinline__ void ba_segments(const BaBatch &B, const BaCtx &c, Ba
     // of the extrinsic (4..5, 4..5) corner go to the segment's own record: nothing is carried from one round to the next, so which wave (of which
     // workgroup) takes a segment does not change a bit of the result.
     double *wstage = L.u.stage + (size_t)wave * 2 * kBaRound * kBaRow;
-    double *tiles = B.pairH + (size_t)(c.sg0 + c.pp0) * kBaPairTile;
+    double *tiles = B.pairH + (size_t)(c.sg0 + c.pp0 + c.win) * kBaPairTile;
     const int q = lane & 1, half = lane >> 5, lo = (lane & 31) >> 1, col = lane & 15, kq = lane >> 4;
     const double *Mx = L.Mq + 18 * c.n_poses, *Mxi = L.Mq + 18 * (kBaMaxPoses + 1);
     for (int sA = gw; sA < c.n_seg; sA += 2 * GW) {
@@ -894,7 +877,7 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
     // behind an accepted step, when the pair records are re-used, the whole workgroup used to wait for it here)
     double small_cost = 0.0;
     if (!kJac && tid >= 64 && tid < 96) small_cost = ba_small_factors<kJac>(B, c, L.gn, poses, ex, tid - 64);
-    double *tiles = B.pairH + (size_t)(c.sg0 + c.pp0) * kBaPairTile;
+    double *tiles = B.pairH + (size_t)(c.sg0 + c.pp0 + c.win) * kBaPairTile;
     if (!kJac) {
         __syncthreads();   // pair records are visible
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -922,7 +905,7 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
     BA_TOCK(0)
     BA_TICK(1)
     if (kJac && tid >= 64 && tid < 96) small_cost = ba_small_factors<kJac>(B, c, L.gn, poses, ex, tid - 64);
-    ba_segments<true, kCl>(B, c, L, ex, pairdat);
+    ba_segments<true, false>(B, c, L, ex, pairdat);          // (the leader's own records: plain stores; it reads them back from the L2 like everybody's)
     BA_TOCK(1)
     BA_TICK(11)
     if (kCl) ba_done<true>(B, c, L);                             // every workgroup's segment and observation records are written
@@ -1414,6 +1397,61 @@ __device__ __noinline__ void ba_setup(const BaBatch &B, const BaCtx c, BaLds &L_
         L.pair_of[(ij & 255) * kBaMaxPoses + (ij >> 8)] = (short)(p < c.n_multi ? c.n_seg + p : (int)L.pair_seg[p]);
     }
     __syncthreads();
+    if (c.rank != 0) return;
+    // the gather program of ba_reduce_pairs (see kBaGaN); position of (row r, column q) of a tile: rows / columns 0..5 = frame i, 6..11 = frame j,
+    // 12..15 = extrinsic 0..3 (the 16 x 16 tile), column 16 / 17 = extrinsic 4 / 5 and column 18 = the residual (the 16 x 4 side tile)
+    auto pos = [](int r, int q) { return q < 16 ? (r < 16 ? r * 16 + q : 256 + q * 4 + (r - 16)) : 256 + r * 4 + (q - 16); };
+    const int zero = (c.n_seg + c.n_pairs) * kBaPairTile;          // the window's tile of zeros
+    int *gp = B.gprog + (size_t)c.win * kBaGprog;
+    const int np_ = c.n_poses, x0 = c.ex_off;
+    for (int a = tid; a < kBaGaN; a += kBaT) {
+        int o1 = zero, o2 = zero, d1 = -1, d2 = -1;
+        const int pb = a / 36, e = a % 36, om = e / 6, on = e % 6;
+        int bm = 1;
+        while (bm * (bm + 1) / 2 <= pb) bm++;                      // pb = bm (bm - 1) / 2 + bn, bn < bm
+        const int bn = pb - bm * (bm - 1) / 2;
+        if (bm < np_ && bm < kBaMaxPoses) {
+            // frame bn = i is the smaller one: the pair (i, j = bm) holds the block in rows 6.. / columns 0.., the pair (j, i) in rows 0.. / columns 6..
+            const int p1 = L.pair_of[bn * kBaMaxPoses + bm], p2 = L.pair_of[bm * kBaMaxPoses + bn];
+            if (p1 >= 0) o1 = p1 * kBaPairTile + pos(6 + om, on);
+            if (p2 >= 0) o2 = p2 * kBaPairTile + pos(om, 6 + on);
+            d1 = (ba_pose_off(c, bm) + om) * kBaP + ba_pose_off(c, bn) + on;
+            d2 = (ba_pose_off(c, bn) + on) * kBaP + ba_pose_off(c, bm) + om;
+        }
+        gp[a] = o1; gp[kBaGaN + a] = o2; gp[2 * kBaGaN + a] = d1; gp[3 * kBaGaN + a] = d2;
+    }
+    int *gb = gp + 4 * kBaGaN;
+    for (int t = tid; t < kBaGbN; t += kBaT) {
+        const int f = t / 63, r = t % 63;
+        int oi_ = 0, oj_ = 0, dst = -1, dst2 = -1;
+        bool on_ = f < np_ && f < kBaMaxPoses;
+        if (r < 21) {                                              // lower triangle of the frame's diagonal block, mirrored
+            int om = 0;
+            while ((om + 1) * (om + 2) / 2 <= r) om++;
+            const int on = r - om * (om + 1) / 2;
+            oi_ = pos(om, on); oj_ = pos(6 + om, 6 + on);
+            dst = (ba_pose_off(c, f) + om) * kBaP + ba_pose_off(c, f) + on; dst2 = om != on ? (ba_pose_off(c, f) + on) * kBaP + ba_pose_off(c, f) + om : -1;
+        } else if (r < 57) {                                       // (frame row om, extrinsic column ox) and its mirror
+            const int q = r - 21, om = q / 6, ox = q % 6;
+            oi_ = pos(om, 12 + ox); oj_ = pos(6 + om, 12 + ox);
+            dst = (ba_pose_off(c, f) + om) * kBaP + x0 + ox; dst2 = (x0 + ox) * kBaP + ba_pose_off(c, f) + om;
+            if (x0 < 0) on_ = false;
+        } else {                                                   // gradient
+            const int om = r - 57;
+            oi_ = pos(om, 18); oj_ = pos(6 + om, 18);
+            dst = kBaP * kBaP + ba_pose_off(c, f) + om;
+        }
+        for (int k = 0; k < kBaMaxPoses; k++) {
+            const int pa = (on_ && k < np_ && k != f) ? L.pair_of[f * kBaMaxPoses + k] : -1;
+            const int pb = (on_ && k < np_ && k != f) ? L.pair_of[k * kBaMaxPoses + f] : -1;
+            gb[k * kBaGbN + t] = pa >= 0 ? pa * kBaPairTile + oi_ : zero;
+            gb[(kBaMaxPoses + k) * kBaGbN + t] = pb >= 0 ? pb * kBaPairTile + oj_ : zero;
+        }
+        gb[22 * kBaGbN + t] = on_ ? dst : -1; gb[23 * kBaGbN + t] = on_ ? dst2 : -1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
 // A follower workgroup of a window (rank > 0): waits for the leader's mail, computes its own copy of the state's records and, for a linearisation,
@@ -1442,7 +1480,8 @@ __device__ __noinline__ void ba_follow(const BaBatch &B, const BaCtx c, BaLds &L
         __syncthreads();   // pair records are visible
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if (cmd == 1) {
-            ba_segments<true, true>(B, c, L, L.cex, pairdat);
+            if ((int)ld_sh<true>(mb + 2) == ba_xcc_id()) ba_segments<true, false>(B, c, L, L.cex, pairdat);      // the leader's XCD: plain stores stay in the shared L2
+            else ba_segments<true, true>(B, c, L, L.cex, pairdat);
             ba_done<false>(B, c, L);
         }
         if (tid == 0) L.eval_no++;
@@ -1452,15 +1491,17 @@ __device__ __noinline__ void ba_follow(const BaBatch &B, const BaCtx c, BaLds &L
 
 // K workgroups per window (kCl: K > 1): block b runs on XCD b mod 8 as dispatched today, so the K workgroups of a window are given the same b mod 8
 // (a shared L2 makes their exchange cheaper; nothing depends on it: every hand-off is device-coherent and ordered by the arrival counters)
+// spread (test hook, LMONO_BA_SPREAD=1): workgroup r of a window is given the residue (x + r) mod 8 instead, i.e. the K workgroups of a window land on K
+// different XCDs -- the placement the exchange must also be right on
 template <bool kCl>
-__global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B, int K)
+__global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B, int K, int spread)
 {
     BaLds &L = g_ba_lds;
     const int tid = threadIdx.x;
     BaCtx c;
     c.K = kCl ? K : 1;
-    const int w = kCl ? ((int)blockIdx.x / 8 / K) * 8 + (int)blockIdx.x % 8 : (int)blockIdx.x;
     c.rank = kCl ? ((int)blockIdx.x / 8) % K : 0;
+    const int w = kCl ? ((int)blockIdx.x / 8 / K) * 8 + (((int)blockIdx.x % 8) + (spread ? 8 - c.rank : 0)) % 8 : (int)blockIdx.x;
     c.GW = c.K == 1 ? kBaW : c.K * kBaW - 1;
     c.win = w;
     if (w >= B.n_windows) return;

@@ -1277,7 +1277,8 @@ static int ba_fill(lmono_ctx *c, lmono_ba_batch *b, const lmono_ba_desc *d)
     pk.add(v.bar, (const unsigned int *)nullptr, (size_t)W * 16);
     pk.add(v.fail, (const int *)nullptr, (size_t)1);
     v.n_pairs_total = (int)pair_ij.size();
-    pk.add(v.pairH, (const double *)nullptr, (seg_tab.size() + pair_ij.size()) * kBaPairTile);
+    pk.add(v.pairH, (const double *)nullptr, (seg_tab.size() + pair_ij.size() + (size_t)W) * kBaPairTile);
+    pk.add(v.gprog, (const int *)nullptr, (size_t)W * kBaGprog);
     pk.add(v.cpart, (const double *)nullptr, seg_tab.size());
     pk.add(v.cand, (const double *)nullptr, (size_t)W * kBaMaxFeat); pk.add(v.summary, (const double *)nullptr, (size_t)W * 6);
     // everything is staged in the batch's pinned buffer: the vectors above may go, and nothing waits here
@@ -1319,9 +1320,10 @@ extern "C" int lmono_ba_solve(lmono_ctx *c, lmono_ba_batch *b, int max_iteration
     if (b->cluster > 1) {
         // the arrival counters start at zero in every launch
         HIP_TRY(c, hipMemsetAsync(b->v.bar, 0, (((sizeof(unsigned int) * (size_t)b->n_windows * 16) + 255) & ~(size_t)255) + 256, c->stream));   // (+ the failure flag behind them)
-        hipLaunchKernelGGL(k_ba_solve<true>, dim3(((b->n_windows + 7) / 8) * 8 * b->cluster), dim3(kBaT), 0, c->stream, b->v, b->cluster);
+        static const int spread = [] { const char *e = getenv("LMONO_BA_SPREAD"); return e ? atoi(e) : 0; }();      // test hook: a window's workgroups on different XCDs
+        hipLaunchKernelGGL(k_ba_solve<true>, dim3(((b->n_windows + 7) / 8) * 8 * b->cluster), dim3(kBaT), 0, c->stream, b->v, b->cluster, spread);
     } else
-        hipLaunchKernelGGL(k_ba_solve<false>, dim3(b->n_windows), dim3(kBaT), 0, c->stream, b->v, 1);          // its LDS is static (g_ba_lds)
+        hipLaunchKernelGGL(k_ba_solve<false>, dim3(b->n_windows), dim3(kBaT), 0, c->stream, b->v, 1, 0);          // its LDS is static (g_ba_lds)
     return check_launch(c, "k_ba_solve");
 }
 

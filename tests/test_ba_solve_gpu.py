@@ -110,3 +110,31 @@ def test_workgroups_per_window_do_not_change_a_bit(oracle, gpu_ctx):
         rp, re, rd, rs = oracle.ba_solve(w)
         assert abs(sm[k, 1] - rs.final_cost) <= 1e-6 * rs.final_cost + 1e-9
         assert int(sm[k, 2]) == rs.iterations and int(sm[k, 3]) == rs.termination
+
+
+def test_workgroups_of_a_window_on_different_xcds(tmp_path):
+    """The exchange between a window's workgroups must be right on ANY placement (HIP promises none): LMONO_BA_SPREAD=1 deals the K workgroups of a
+    window to K different XCDs (other L2s: the followers then store device-coherently instead of through the shared L2).  A fresh process per
+    setting solves the same windows; the bytes must equal the one-workgroup solve's."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import numpy as np, lmono_amd\n"
+            "from tests import ba_cases as K\n"
+            "ctx = lmono_amd.Context(0)\n"
+            "ws = [K.make_window(s) for s in (40, 41)] + [K.make_window(42, n_landmarks=2500)]\n"
+            "b = lmono_amd.BaBatch(ctx, ws); b.solve(30); p, e, d, sm = b.read()\n"
+            "np.savez(sys.argv[1], p=p, e=e, d=d, sm=sm)\n") % root
+    out = {}
+    for name, env in (("k1", {"LMONO_BA_CLUSTER": "1"}), ("k8", {"LMONO_BA_CLUSTER": "8"}), ("k8_spread", {"LMONO_BA_CLUSTER": "8", "LMONO_BA_SPREAD": "1"}),
+                      ("k4_spread", {"LMONO_BA_CLUSTER": "4", "LMONO_BA_SPREAD": "1"})):
+        f = str(tmp_path / (name + ".npz"))
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[name] = np.load(f)
+    for name in ("k8", "k8_spread", "k4_spread"):
+        for key in ("p", "e", "d", "sm"):
+            assert out[name][key].tobytes() == out["k1"][key].tobytes(), "%s: %s differs from the one-workgroup solve" % (name, key)
+    assert (out["k1"]["sm"][:, 2] == 30).all()
