@@ -291,8 +291,10 @@ __device__ __forceinline__ void gst(double *p, double v) { *(ba_gd *)p = v; }
 __device__ __forceinline__ int ba_worker(const BaCtx &c, int wave)
 {
     if (c.K == 1) return wave;
-    if (c.rank == 0) return wave == 1 ? -1 : (wave == 0 ? 0 : wave - 1);
-    return kBaW - 1 + (c.rank - 1) * kBaW + wave;
+    // (the low ids get one segment more when the count does not divide: they go to the followers; the leader has the barrier, the sums and the
+    // LASERFactor chain on its hands)
+    if (c.rank == 0) return wave == 1 ? -1 : c.GW - (kBaW - 1) + (wave == 0 ? 0 : wave - 1);
+    return (c.rank - 1) * kBaW + wave;
 }
 // data that crosses workgroups (segment tiles, observation records, cost cells, the mail box): device-coherent stores and loads (sc1: they bypass the
 // CU's L1 and are ordered by the arrival counters; MI355X_MICROARCH.md, hand-off table) when several workgroups share a window, plain ones otherwise
@@ -596,13 +598,12 @@ __device__ __forceinline__ double quarter_sum_d(double v)
     return v;
 }
 
-// pose matrices, inverse depths and pair records of the state (poses, ex, invd) -- every workgroup of a window computes its own (the followers read
-// the inverse depths from the leader's mail box)
+// pose matrices and inverse depths of the state (poses, ex, invd) in LDS (ba_state), then its pair records in HBM (ba_pair_records) -- every workgroup
+// of a window computes its own (the followers read the inverse depths from the leader's mail box)
 template <bool kSharedInvd>      // kSharedInvd: a follower (the inverse depths are in LDS already)
-__device__ __forceinline__ void ba_records(const BaCtx &c, BaLds &L, const double *poses, const double *ex, const double *invd, double *pairdat)
+__device__ __forceinline__ void ba_state(const BaCtx &c, BaLds &L, const double *poses, const double *ex, const double *invd)
 {
     const int tid = threadIdx.x;
-    const double *Rlc = L.Rp + 9 * c.n_poses;
     if (tid <= c.n_poses) {
         double qn[4];
         const double *qraw = tid == c.n_poses ? ex + 3 : poses + 7 * tid + 3;
@@ -616,6 +617,11 @@ __device__ __forceinline__ void ba_records(const BaCtx &c, BaLds &L, const doubl
     }
     if (!kSharedInvd) for (int f = tid; f < c.F; f += kBaT) L.vinv[f] = gld(invd + f);       // (a follower has read them from the mail box)
     __syncthreads();
+}
+__device__ __forceinline__ void ba_pair_records(const BaCtx &c, BaLds &L, const double *poses, const double *ex, double *pairdat)
+{
+    const int tid = threadIdx.x;
+    const double *Rlc = L.Rp + 9 * c.n_poses;
     for (int p = tid; p < c.n_pairs; p += kBaT) {
         const int ij = L.pair_ij[p], i = ij & 255, j = ij >> 8;
         double rec[kBaPairRec];
@@ -869,14 +875,16 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
     __syncthreads();
     BA_TICK(kJac ? 0 : 3)
     if (kCl) ba_publish(B, c, L, kJac ? 1 : 2, poses, ex, invd, records_valid);
-    if (!records_valid) ba_records<false>(c, L, poses, ex, invd, pairdat);
+    if (!records_valid) ba_state<false>(c, L, poses, ex, invd);
     // wave 1: LASERFactor chain and prior, next to the pair records of wave 0
     // (their residuals / Jacobians wait in gn | va | vb, which are dead during a linearisation, until the pair blocks are in)
     static_assert(3 * kBaN >= 11 * kBaSmallRec, "small-factor records must fit gn | va | vb");
     // (linearisation: wave 1 evaluates them at the head of its pair loop instead -- a single lane per block walks ~1000 double-precision instructions, and
     // behind an accepted step, when the pair records are re-used, the whole workgroup used to wait for it here)
     double small_cost = 0.0;
+    // (cost evaluation: wave 1's LASERFactor chain runs beside wave 0's pair records)
     if (!kJac && tid >= 64 && tid < 96) small_cost = ba_small_factors<kJac>(B, c, L.gn, poses, ex, tid - 64);
+    if (!records_valid) ba_pair_records(c, L, poses, ex, pairdat);
     double *tiles = B.pairH + (size_t)(c.sg0 + c.pp0 + c.win) * kBaPairTile;
     if (!kJac) {
         __syncthreads();   // pair records are visible
@@ -1140,14 +1148,16 @@ __device__ __noinline__ bool ba_schur_solve(const BaCtx c, BaLds &L_arg, const d
     __syncthreads();
     BA_TOCK(5)
     BA_TICK(6)
-    // Blocked in-place lower Cholesky with LOOK-AHEAD (round 5).  Wave 0 owns the panels: lane r carries rows r and 64 + r of the current 8-column
-    // panel in registers for the whole factorisation (a fixed lane <-> row map: no shuffles between panels), factors it right-looking (the pivot
-    // row is broadcast with v_readlane; only  readlane -> rsqrt -> scale -> readlane -> fma  is on the chain of a column, the LDS is not) and
-    // stores it; after the ONE workgroup barrier of the panel it fetches the next panel's columns and applies the panel it still holds in
-    // registers to them itself (64 broadcast multipliers), while waves 1..7 apply the panel to the rest of the trailing matrix on the matrix
-    // cores (16 x 16 tiles, the panel's 8 columns = two k-steps of v_mfma_f64_16x16x4_f64).  Round 4 had two barriers per panel, the whole
-    // trailing update between two panel factorisations and an LDS write + wait inside every column step: 52 k cycles per factorisation.
-    // A tile entry receives the panels in ascending order, as before; the next panel's entries receive panel p as ONE subtracted sum.
+    // Blocked in-place lower Cholesky (round 5).  Wave 0 owns the 8-column panels: it holds the panel in registers (lane = row), factors it
+    // right-looking (the pivot row is broadcast with v_readlane; only  readlane -> rsqrt -> scale -> readlane -> fma  is on the chain of a column, the
+    // LDS is not) and stores it.  The trailing update S -= L_panel L_panel^T runs on the matrix cores as 16 x 16 tiles (the panel's 8 columns = two
+    // k-steps of v_mfma_f64_16x16x4_f64) in two parts: the first tile COLUMN -- it holds the next panel -- by waves 1..5 at once, one tile each, between
+    // two workgroup barriers; the other tiles by waves 1..7 while wave 0 already factors the next panel.  One wave alone issues a double-precision
+    // instruction every ~8 cycles, so the chain is priced in wave 0's instructions: ~270 per panel for the factorisation; a first version of this
+    // round applied the panel to the next one in wave 0's registers as well (+150 instructions per panel: 49 k cycles per factorisation; round 4,
+    // with the whole trailing update between two panels and an LDS write + wait in every column step: 52 k).
+    // Panels 0 and 1 reach past 64 rows (rows p0 .. P, P = 72): lane r carries rows r AND 64 + r (a, b).  From panel 2 on the remaining rows fit one
+    // register set: lane l carries row p0 + l, the pivot of column k sits in lane k.  A tile entry receives the panels in ascending order.
     auto chol_tile = [&](int r0, int ti, int tk, int pc0) {
         const int ra = r0 + 16 * ti + col, rb = r0 + 16 * tk + col;       // operand rows of this lane
         ba_d4 acc4 = { 0, 0, 0, 0 };
@@ -1167,36 +1177,40 @@ __device__ __noinline__ bool ba_schur_solve(const BaCtx c, BaLds &L_arg, const d
 #pragma unroll
         for (int v = 0; v < 4; v++) {
             const int m = r0 + 16 * ti + kq + 4 * v;
-            // columns r0 .. r0 + 7 are the next panel: wave 0 updates them in its registers
-            if (m <= P && nn < P && nn <= m && nn >= r0 + 8) S[m * kBaSS + nn] = cur[v] - acc4[v];
+            if (m <= P && nn < P && nn <= m) S[m * kBaSS + nn] = cur[v] - acc4[v];
         }
     };
     double cid0 = 0.0, cid1 = 0.0;                  // wave 0: 1 / l_rr of rows lane and 64 + lane (the backward substitution reads them)
     {
-        // One wave alone issues a double-precision instruction every ~8 cycles, so the panel chain is priced in instructions.  Panels 0 and 1 reach
-        // past 64 rows (rows p0 .. P, P = 72): lane r carries rows r AND 64 + r (a, b).  From panel 2 on the remaining rows fit one register set:
-        // lane l carries row p0 + l (x), the pivot of column k sits in lane k, and the second set's multiply-adds are gone.
         double a[8], b[8];                          // wave 0: the current panel; single-set panels use a[] only
         bool bad = false;
         const int ra_ = min(lane, P), rb_ = min(64 + lane, P);      // this lane's rows in the two-set map, clamped into the matrix
         // 1 / sqrt(d): v_rsq_f64 and one third-order correction, y (1 + e / 2 + 3 e^2 / 8) with e = 1 - d y^2
         auto rsqrt3 = [](double d) { double y = __builtin_amdgcn_rsq(d); const double e = __builtin_fma(-d * y, y, 1.0); return __builtin_fma(y * e, __builtin_fma(e, 0.375, 0.5), y); };
-        if (wave == 0) {
-            __builtin_amdgcn_s_setprio(3);
+        // the panel that starts at column q0: unconditional LDS reads at clamped addresses + a select (a masked read is a branch with its own s_waitcnt)
+        auto load_panel = [&](int q0) {
+            if (q0 < 16) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                // unconditional LDS reads at clamped addresses + a select: a masked read is a branch with its own s_waitcnt, sixteen of them in a row
-                const double va = S[ra_ * kBaSS + k], vb = S[rb_ * kBaSS + k];
-                a[k] = lane <= P ? va : 0.0;
-                b[k] = 64 + lane <= P ? vb : 0.0;
+                for (int k = 0; k < 8; k++) {
+                    const double va = S[ra_ * kBaSS + q0 + k], vb = S[rb_ * kBaSS + q0 + k];
+                    a[k] = lane <= P ? va : 0.0;
+                    b[k] = 64 + lane <= P ? vb : 0.0;
+                }
+            } else {
+                const int row = q0 + lane, rc = min(row, P);
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const double va = S[rc * kBaSS + min(q0 + k, P - 1)];
+                    a[k] = (row <= P && q0 + k < P) ? va : 0.0;
+                }
             }
-        }
+        };
+        if (wave == 0) { __builtin_amdgcn_s_setprio(3); load_panel(0); }
         for (int p0 = 0; p0 < P; p0 += 8) {
             const int pw = min(8, P - p0);
-            const bool two = p0 < 16;               // this panel is held as two register sets
             if (wave == 0) {
                 BA_TICK(14)
-                if (two) {
+                if (p0 < 16) {
 #pragma unroll
                     for (int k = 0; k < 8; k++) {
                         double d = readlane_d(a[k], p0 + k);
@@ -1234,72 +1248,23 @@ __device__ __noinline__ bool ba_schur_solve(const BaCtx c, BaLds &L_arg, const d
                 BA_TOCK(14)
             }
             BA_TICK(15)
+            __syncthreads();                                                   // the panel is in LDS
+            const int r0 = p0 + 8;
+            if (r0 >= P) { BA_TOCK(15) break; }
+            const int nt = (P + 1 - r0 + 15) >> 4;                            // tile rows of the trailing matrix (<= 5)
+            if (wave >= 1 && wave <= nt) chol_tile(r0, wave - 1, 0, p0);       // the first tile column: the next panel's (and the one after's) columns
             __syncthreads();
             BA_TOCK(15)
-            const int r0 = p0 + 8;
-            if (r0 >= P) break;
             if (wave == 0) {
                 BA_TICK(10)
-                // next panel: its columns (every earlier panel is in, the other waves finished theirs before the barrier) minus this panel's
-                // share.  The 64 multipliers l(r0 + c, p0 + k) come back from the LDS as broadcast reads (wave 0 stored the panel itself): the
-                // vector unit only runs the multiply-adds (a first version broadcast them with 128 v_readlane + 64 wait states).
-                if (r0 < 16) {
-                    double na[8], nb[8];
-#pragma unroll
-                    for (int c = 0; c < 8; c++) {
-                        const double va = S[ra_ * kBaSS + r0 + c], vb = S[rb_ * kBaSS + r0 + c];
-                        na[c] = lane <= P ? va : 0.0;
-                        nb[c] = 64 + lane <= P ? vb : 0.0;
-                    }
-#pragma unroll
-                    for (int h = 0; h < 4; h++) {
-                        double m[2][8];
-#pragma unroll
-                        for (int c = 0; c < 2; c++)
-#pragma unroll
-                            for (int k = 0; k < 8; k++) m[c][k] = S[(r0 + 2 * h + c) * kBaSS + p0 + k];
-#pragma unroll
-                        for (int c = 0; c < 2; c++) {
-                            double da = 0.0, db = 0.0;
-#pragma unroll
-                            for (int k = 0; k < 8; k++) { da += a[k] * m[c][k]; db += b[k] * m[c][k]; }
-                            na[2 * h + c] -= da; nb[2 * h + c] -= db;
-                        }
-                    }
-#pragma unroll
-                    for (int c = 0; c < 8; c++) { a[c] = na[c]; b[c] = nb[c]; }
-                } else {
-                    // single set from here on: lane l takes row r0 + l; its entries of the panel just stored come back from the LDS as well
-                    const int row = r0 + lane, rc = min(row, P);
-                    double own[8], nx[8];
-#pragma unroll
-                    for (int k = 0; k < 8; k++) own[k] = S[rc * kBaSS + p0 + k];
-#pragma unroll
-                    for (int c = 0; c < 8; c++) nx[c] = S[rc * kBaSS + min(r0 + c, P - 1)];
-#pragma unroll
-                    for (int h = 0; h < 4; h++) {
-                        double m[2][8];
-#pragma unroll
-                        for (int c = 0; c < 2; c++)
-#pragma unroll
-                            for (int k = 0; k < 8; k++) m[c][k] = S[min(r0 + 2 * h + c, P) * kBaSS + p0 + k];
-#pragma unroll
-                        for (int c = 0; c < 2; c++) {
-                            double da = 0.0;
-#pragma unroll
-                            for (int k = 0; k < 8; k++) da += own[k] * m[c][k];
-                            a[2 * h + c] = (row <= P && r0 + 2 * h + c < P) ? nx[2 * h + c] - da : 0.0;
-                        }
-                    }
-                }
+                load_panel(r0);
                 BA_TOCK(10)
             } else {
-                // (wave 4 shares its SIMD with wave 0, whose column chain is the critical path: it takes no tiles)
-                const int nt = (P + 1 - r0 + 15) >> 4;                            // tile rows of the trailing matrix (<= 5)
-                for (int t = wave < 4 ? wave - 1 : wave - 2; wave != 4 && t < nt * (nt + 1) / 2; t += kBaW - 2) {
-                    int ti = 0, rem = t;
-                    while (rem > ti) { rem -= ti + 1; ti++; }
-                    chol_tile(r0, ti, rem, p0);
+                // the other tile columns, while wave 0 factors (wave 4 shares its SIMD with wave 0, whose column chain is the critical path: it takes none)
+                for (int t = wave < 4 ? wave - 1 : wave - 2; wave != 4 && t < nt * (nt - 1) / 2; t += kBaW - 2) {
+                    int ti = 1, rem = t;                                          // tiles (ti, tk) with 1 <= tk <= ti
+                    while (rem >= ti) { rem -= ti; ti++; }
+                    chol_tile(r0, ti, rem + 1, p0);
                 }
             }
         }
@@ -1476,7 +1441,7 @@ __device__ __noinline__ void ba_follow(const BaBatch &B, const BaCtx c, BaLds &L
         __syncthreads();
         // a candidate: the mail box is read -- acknowledge, then compute the records in the leader's shadow
         if (cmd == 2 && tid == 0) ba_flag_store(flags + c.rank, (unsigned int)(L.eval_no + 1));
-        if (!reuse) ba_records<true>(c, L, L.cposes, L.cex, nullptr, pairdat);
+        if (!reuse) { ba_state<true>(c, L, L.cposes, L.cex, nullptr); ba_pair_records(c, L, L.cposes, L.cex, pairdat); }
         __syncthreads();   // pair records are visible
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if (cmd == 1) {

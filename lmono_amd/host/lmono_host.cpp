@@ -1,11 +1,38 @@
 // lmono_amd/host/lmono_host.cpp -- see lmono_host.hpp.  Window / track bookkeeping on the host, numerics in the HIP library.
 #include "lmono_host.hpp"
+#include <exception>
+#include <thread>
+#include <condition_variable>
+#include <mutex>
+#include <chrono>
+#include <cstdlib>
+#include <cstdio>
 #include "kitti_io.hpp"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
 
 namespace lmono_host {
+
+// host-side phase clocks of the INITED frame loop (LMONO_HOST_TIMING=1: printed to stderr by ~Estimator): where a frame's wall time goes beside the kernels
+namespace {
+struct PhaseClock {
+    double ms[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    long frames = 0;
+    const bool on = std::getenv("LMONO_HOST_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t0;
+    void start() { if (on) t0 = std::chrono::steady_clock::now(); }
+    void lap(int k) { if (on) { const auto t1 = std::chrono::steady_clock::now(); ms[k] += std::chrono::duration<double, std::milli>(t1 - t0).count(); t0 = t1; } }
+} g_clock;
+}
+void estimator_print_phase_clock()
+{
+    if (!g_clock.on || g_clock.frames == 0) return;
+    static const char *name[8] = { "featureCheck+loop", "triangulate", "pack+update", "solve+read", "double2Matrix+margin", "outliers", "slideWindow", "row" };
+    std::fprintf(stderr, "HOSTTIM frames %ld:", g_clock.frames);
+    for (int k = 0; k < 8; k++) std::fprintf(stderr, " %s %.4f", name[k], g_clock.ms[k] / g_clock.frames);
+    std::fprintf(stderr, " (ms per frame)\n");
+}
 
 static void mat_mul(const double *A, const double *B, double *C) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) C[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j]; }
 static void mat_vec(const double *A, const double *v, double *o) { for (int i = 0; i < 3; i++) o[i] = A[i * 3] * v[0] + A[i * 3 + 1] * v[1] + A[i * 3 + 2] * v[2]; }
@@ -172,12 +199,57 @@ Estimator::Estimator(HipContext &hip, const Params &p) : hip_(hip), p_(p)
     std::memset(TLC, 0, sizeof(TLC)); TLC[0] = TLC[5] = TLC[10] = TLC[15] = 1.0;
     feature_manager.params = &p_; feature_manager.hip = &hip_;
 }
+struct Estimator::MarginWorker {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<void()> job;          // pending job (empty: none)
+    bool busy = false, quit = false;
+    std::exception_ptr error;
+    std::thread th;
+    MarginWorker() : th([this] { run(); }) {}
+    ~MarginWorker() { { std::lock_guard<std::mutex> g(mu); quit = true; } cv.notify_all(); th.join(); }
+    void run()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [this] { return quit || (bool)job; });
+            if (!job) return;                                  // quit with nothing pending
+            std::function<void()> j;
+            j.swap(job);
+            lk.unlock();
+            std::exception_ptr e;
+            try { j(); } catch (...) { e = std::current_exception(); }
+            lk.lock();
+            if (e) error = e;
+            busy = false;
+            cv.notify_all();
+        }
+    }
+    void submit(std::function<void()> j)
+    {
+        { std::lock_guard<std::mutex> g(mu); job = std::move(j); busy = true; }
+        cv.notify_all();
+    }
+    void wait()                                                // rethrows what the job threw
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [this] { return !busy; });
+        if (error) { std::exception_ptr e = error; error = nullptr; std::rethrow_exception(e); }
+    }
+};
 Estimator::~Estimator()
 {
     try { marginWait(); } catch (...) {}
+    margin_worker_.reset();
     if (ba_batch_) lmono_ba_batch_destroy(ba_batch_);
 }
-void Estimator::marginWait() { if (margin_job_.valid()) margin_job_.get(); }     // rethrows what the worker threw
+void Estimator::marginWait() { if (margin_worker_) margin_worker_->wait(); }     // rethrows what the worker threw
+void Estimator::marginSubmit(std::function<void()> job)
+{
+    if (!async_margin_) { job(); return; }
+    if (!margin_worker_) margin_worker_.reset(new MarginWorker());
+    margin_worker_->submit(std::move(job));
+}
 void Estimator::setAsyncMargin(bool on)
 {
     marginWait();
@@ -256,17 +328,20 @@ bool Estimator::optimization()
         if (!ba_batch_) throw std::runtime_error(std::string("lmono_ba_batch_create: ") + lmono_last_error(hip_.get()));
     } else
         hip_.check(lmono_ba_batch_update(hip_.get(), ba_batch_, &d), "lmono_ba_batch_update");
+    g_clock.lap(2);
     lmono_ba_batch *b = ba_batch_;
     hip_.check(lmono_ba_solve(hip_.get(), b, p_.NUM_ITERATIONS), "lmono_ba_solve");
     double summary[6];
     std::vector<double> invd((size_t)std::max(F, 1));
     hip_.check(lmono_ba_batch_read(hip_.get(), b, poses.data(), para_ex[0], invd.data(), summary), "lmono_ba_batch_read");
+    g_clock.lap(3);
     for (int i = 0; i <= WINDOW_SIZE; i++) std::memcpy(para_pose[i], &poses[7 * i], 56);
     if (use_mono) para_depth_inv.assign(invd.begin(), invd.begin() + F);
     initial_cost = summary[0]; final_cost = summary[1]; iterations = (int)summary[2]; termination = (int)summary[3];
     double2Matrix();
     if (frame_count < WINDOW_SIZE) return false;
     if (p_.ESTIMATE_LASER) margin();                         // Estimator.cc:1288-1291
+    g_clock.lap(4);
     return termination == 0 || final_cost < 5e-3;            // Estimator.cc:1293
 }
 void Estimator::outliersRejection(std::set<int> &removeIndex, const double &error)
@@ -309,7 +384,7 @@ void Estimator::margin()
             mi.parameter_blocks.erase(mi.parameter_blocks.begin() + drop);   // addr_shift :1442-1455: pose i -> pose i (i < 9), pose 10 -> pose 9 is not a block
             mi.m = 6; mi.n = n; mi.status = status; mi.valid = false;
         };
-        if (async_margin_) margin_job_ = std::async(std::launch::async, std::move(job)); else job();
+        marginSubmit(std::move(job));
         return;
     }
     matrix2Double();
@@ -360,7 +435,7 @@ void Estimator::margin()
         mi.present = true;
         mi.valid = false;      // never set by the reference either
     };
-    if (async_margin_) margin_job_ = std::async(std::launch::async, std::move(job)); else job();
+    marginSubmit(std::move(job));
 }
 
 void Estimator::slideWindow()
@@ -442,6 +517,7 @@ void Estimator::loopCorrection()
 }
 bool Estimator::processImage(double header, const FeatureManager::Image &image, const double transform_to_init[16])
 {
+    g_clock.start();
     processCompactData(transform_to_init);
     const bool keyframe = feature_manager.featureCheck(frame_count, image, header);       // :383-394
     marginalization_flag = keyframe ? MARGIN_OLD : MARGIN_SECOND_NEW;
@@ -464,12 +540,17 @@ bool Estimator::processImage(double header, const FeatureManager::Image &image, 
         }
     } else {
         loopCorrection();
+        g_clock.lap(0);
         feature_manager.triangulate(frame_count, Rs, Ps, TLC);
+        g_clock.lap(1);
         std::set<int> removeIndex;
         optimization();
         outliersRejection(removeIndex, p_.OUTLIER_T);
         feature_manager.removeOutlier(removeIndex);
+        g_clock.lap(5);
         slideWindow();
+        g_clock.lap(6);
+        g_clock.frames++;
     }
     if (stage_flag == INITED) {                             // new_odometry.txt row, :634-645
         std::array<double, 8> row;

@@ -8,6 +8,7 @@
 // HIP library; this file only keeps the list / window bookkeeping that the reference keeps on the host.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <future>
 #include <list>
 #include <memory>
@@ -160,7 +161,11 @@ private:
     HipContext &hip_;
     lmono_ba_batch *ba_batch_ = nullptr;       // the window problem's device arrays, kept from frame to frame
     std::unique_ptr<HipContext> margin_hip_;   // setAsyncMargin: the context marginalisation runs on
-    std::future<void> margin_job_;
+    // the overlapped marginalisation's worker: ONE host thread for the Estimator's lifetime takes the jobs (a thread per frame -- std::async -- cost the
+    // frame loop ~70 us per frame); at most one job is pending
+    struct MarginWorker;
+    std::unique_ptr<MarginWorker> margin_worker_;
+    void marginSubmit(std::function<void()> job);
     bool async_margin_ = false;
     Params p_;
 };
@@ -277,5 +282,7 @@ public:
 private:
     HipContext &hip_;
 };
+
+void estimator_print_phase_clock();      // LMONO_HOST_TIMING=1: host-side phase times of the INITED frame loop, to stderr
 
 } // namespace lmono_host
