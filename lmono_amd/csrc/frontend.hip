@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void k_curvature(BatchView b)
 // keeps its sector elements (curvature, suppressed flag) in registers and a pick is one 64-lane arg-max / arg-min
 // over the packed key (curvature bits, index), which also reproduces the (curvature, index) tie order of the sort.
 constexpr int kSelMaxPerLane = (kRingCap / 6 + 1 + 63) / 64;   // 11 elements per lane for the largest legal sector
-constexpr int kSelWaveLds = 2 * kRingCap;                      // picked, gap bytes of one ring
+constexpr int kSelWaveLds = 2 * kRingCap;                      // picked, gap bytes of one ring (unfused flavour; sel_slice_bytes below)
 
 // key of a sector element: hi = curvature bits, lo = (index << 8 | suppression reach).  Ordering by (hi, lo) = ordering by
 // (curvature, index), so the arg-max / arg-min over keys reproduces the sort's tie order; the winner's reach rides along.
@@ -357,10 +357,13 @@ __device__ __forceinline__ unsigned int select_lo(int idx, unsigned int reach) {
 #endif
 constexpr int kSelScratch = 64 * 8;      // per wave: one (curvature bits, index | reach) pair per lane, the compacted candidates of a sector
 
-template <int M>
-__device__ __forceinline__ void select_sector(int lane, int j, int sp, int slen, int rbeg, const float *curv, unsigned char *picked,
+// kFused (LMONO_FUSE_CURV_SELECT, round 5): the curvature is computed here, from the sector's points staged in LDS (xs / ys / zs: staged index 0 =
+// ring point sp - 5), written to `curv` (the API returns it) instead of read from it, and `gap` is the SECTOR's bit mask (bit k = gap flag of ring
+// point sp - 5 + k) instead of the ring's.  Same expressions in the same order as k_curvature.
+template <int M, bool kFused>
+__device__ __forceinline__ void select_sector(int lane, int j, int sp, int slen, int rbeg, float *curv, unsigned char *picked,
                                               signed char *label, const unsigned long long *gap, int *sel_sh, int *sel_sh_n, int *sel_fl, int *sel_fl_n,
-                                              unsigned int *scratch)
+                                              unsigned int *scratch, const float *sx = nullptr, const float *sy = nullptr, const float *sz = nullptr)
 {
     unsigned int kh[M], kl[M];
     unsigned int dead = 0, big = 0, small = 0;     // bit m: suppressed / out of range; curvature > 0.1; < 0.1
@@ -372,11 +375,19 @@ __device__ __forceinline__ void select_sector(int lane, int j, int sp, int slen,
         bool cand = false;
         if (e < slen) {
             const int i = sp + e;
-            const float c = curv[i];
+            float c;
+            if (kFused) {
+                const int q = e + 5;
+                const float dx = sx[q - 5] + sx[q - 4] + sx[q - 3] + sx[q - 2] + sx[q - 1] - 10 * sx[q] + sx[q + 1] + sx[q + 2] + sx[q + 3] + sx[q + 4] + sx[q + 5];
+                const float dy = sy[q - 5] + sy[q - 4] + sy[q - 3] + sy[q - 2] + sy[q - 1] - 10 * sy[q] + sy[q + 1] + sy[q + 2] + sy[q + 3] + sy[q + 4] + sy[q + 5];
+                const float dz = sz[q - 5] + sz[q - 4] + sz[q - 3] + sz[q - 2] + sz[q - 1] - 10 * sz[q] + sz[q + 1] + sz[q + 2] + sz[q + 3] + sz[q + 4] + sz[q + 5];
+                c = dx * dx + dy * dy + dz * dz;
+                curv[i] = c;
+            } else c = curv[i];
             // suppression reach: the neighbour walk marks l = 1..5 forward while the gap before point i+l is short, and the same backward --
             // the zero runs above / below bit i of the ring's gap BIT mask (two independent 8-byte LDS reads; as bytes the two walks were up to
             // ten dependent single-byte reads per element, the latency that bound the kernel).  i >= 5 inside a sector.
-            const int jw = i - 5;
+            const int jw = kFused ? e : i - 5;
             const unsigned long long wa = gap[jw >> 6], wb = gap[(jw >> 6) + 1];
             const int sh = jw & 63;
             const unsigned int win = (unsigned int)((wa >> sh) | (sh ? wb << (64 - sh) : 0ull));      // bit k = gap flag of point i - 5 + k
@@ -510,9 +521,40 @@ template <typename T> __device__ __forceinline__ T *uni_ptr(T *p)
     return (T *)(GT *)uni64((long long)p);
 }
 
-// one ring by one wave; cap = ring points the wave's LDS slice (2 * cap bytes at smem_w) can hold
+#ifndef LMONO_FUSE_CURV_SELECT
+#define LMONO_FUSE_CURV_SELECT 0
+#endif
+// LDS slice of one wave for rings of up to `cap` points.  Unfused: picked bytes + the ring's gap bit mask (cap bytes reserved).  Fused with the
+// curvature: picked bytes + the staged x / y / z of one sector and its halo + the sector's gap words.
+__host__ __device__ constexpr int sel_sector_cap(int cap) { return cap / 6 + 2; }
+__host__ __device__ constexpr int sel_slice_bytes(int cap)
+{
+    return LMONO_FUSE_CURV_SELECT ? ((cap + 15) & ~15) + 3 * 4 * ((sel_sector_cap(cap) + 12 + 3) & ~3) + 8 * ((sel_sector_cap(cap) + 12) / 64 + 2) : 2 * cap;
+}
+// curvature of the cloud points first .. first + count - 1 of a scan straight from HBM (fused flavour: the points at a ring's ends, which no sector
+// holds, and rings that take no part in the selection) -- k_curvature's expressions
+__device__ __forceinline__ void curv_points_global(const float4 *c, float *curv, int n, int first, int count, int lane)
+{
+    for (int k = lane; k < count; k += 64) {
+        const int i = first + k;
+        float cv = 0.f;
+        if (i >= 5 && i < n - 5) {
+            float px[11], py[11], pz[11];
+#pragma unroll
+            for (int d = 0; d < 11; d++) { const float4 p = c[i - 5 + d]; px[d] = p.x; py[d] = p.y; pz[d] = p.z; }
+            const float dx = px[0] + px[1] + px[2] + px[3] + px[4] - 10 * px[5] + px[6] + px[7] + px[8] + px[9] + px[10];
+            const float dy = py[0] + py[1] + py[2] + py[3] + py[4] - 10 * py[5] + py[6] + py[7] + py[8] + py[9] + py[10];
+            const float dz = pz[0] + pz[1] + pz[2] + pz[3] + pz[4] - 10 * pz[5] + pz[6] + pz[7] + pz[8] + pz[9] + pz[10];
+            cv = dx * dx + dy * dy + dz * dz;
+        }
+        curv[i] = cv;
+    }
+}
+
+// one ring by one wave; cap = ring points the wave's LDS slice (sel_slice_bytes(cap) at smem_w) can hold
 __device__ __forceinline__ void select_ring(BatchView &b, int r, int s, int lane, unsigned char *smem_w, int cap, bool may_defer, unsigned int *scratch)
 {
+    constexpr bool kFused = LMONO_FUSE_CURV_SELECT != 0;
     r = uni(r); s = uni(s);
     const int64_t off = uni64(b.off[s]);
     const int *rb = b.ring_begin + s * 65;
@@ -522,10 +564,13 @@ __device__ __forceinline__ void select_ring(BatchView &b, int r, int s, int lane
     int *sel_sh_n = uni_ptr(b.sel_sharp_n + (s * 64 + r) * kSectors);
     int *sel_fl = uni_ptr(b.sel_flat + (size_t)((s * 64 + r) * kSectors) * 4);
     int *sel_fl_n = uni_ptr(b.sel_flat_n + (s * 64 + r) * kSectors);
+    const float4 *cl = uni_ptr(b.cloud + off);
+    const int n_cloud = kFused ? uni(b.n_cloud[s]) : 0;
     if (E - S < 6 || len > kRingCap) {
         if (lane < kSectors) { sel_sh_n[lane] = 0; sel_fl_n[lane] = 0; }
         if (lane == 0 && len > kRingCap) atomicOr(&b.status[s], kStatusRingOverflow);
         for (int i = lane; i < len; i += 64) b.label[off + rbeg + i] = 0;
+        if (kFused) curv_points_global(cl, uni_ptr(b.curv + off), n_cloud, rbeg, len, lane);
         return;
     }
     if (len > cap) {
@@ -534,29 +579,69 @@ __device__ __forceinline__ void select_ring(BatchView &b, int r, int s, int lane
         return;
     }
     // labels go straight to HBM (zeroed here, ~144 single-byte stores per ring afterwards): the LDS slice only holds the
-    // picked and gap bytes, 2 * cap per wave
+    // picked and gap bytes
     unsigned char *picked = smem_w;
     signed char *label = uni_ptr((signed char *)(b.label + off + rbeg));
-    // gap flags of the ring as a bit mask, one 64-bit word per 64 points (+ one word of padding read by the last elements' windows)
-    unsigned long long *gap = (unsigned long long *)(picked + cap);
-    const float *curv = uni_ptr(b.curv + off + rbeg);
-    for (int i0 = 0; i0 < len + 64; i0 += 64) {
-        const int i = i0 + lane;
-        unsigned char g = 0;
-        if (i < len) { picked[i] = 0; label[i] = 0; g = b.gap[off + rbeg + i]; }
-        const unsigned long long mk = __ballot(g != 0);
-        if (lane == 0) gap[i0 >> 6] = mk;
-    }
-    __builtin_amdgcn_wave_barrier();
+    float *curv = uni_ptr(b.curv + off + rbeg);
     const int span = E - S;
+    if (!kFused) {
+        // gap flags of the ring as a bit mask, one 64-bit word per 64 points (+ one word of padding read by the last elements' windows)
+        unsigned long long *gap = (unsigned long long *)(picked + cap);
+        for (int i0 = 0; i0 < len + 64; i0 += 64) {
+            const int i = i0 + lane;
+            unsigned char g = 0;
+            if (i < len) { picked[i] = 0; label[i] = 0; g = b.gap[off + rbeg + i]; }
+            const unsigned long long mk = __ballot(g != 0);
+            if (lane == 0) gap[i0 >> 6] = mk;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int j = 0; j < kSectors; j++) {
+            const int sp = 5 + span * j / 6;
+            const int ep = 5 + span * (j + 1) / 6 - 1;
+            const int slen = ep - sp + 1;
+            // HDL-64-sized sectors (<= 320 / <= 384 points) take the 5- / 6-slot instantiations, longer rings the full one
+            if (slen <= 5 * 64) select_sector<5, false>(lane, j, sp, slen, rbeg, curv, picked, label, gap, sel_sh, sel_sh_n, sel_fl, sel_fl_n, scratch);
+            else if (slen <= 6 * 64) select_sector<6, false>(lane, j, sp, slen, rbeg, curv, picked, label, gap, sel_sh, sel_sh_n, sel_fl, sel_fl_n, scratch);
+            else select_sector<kSelMaxPerLane, false>(lane, j, sp, slen, rbeg, curv, picked, label, gap, sel_sh, sel_sh_n, sel_fl, sel_fl_n, scratch);
+        }
+        return;
+    }
+    // ---- fused with the curvature (VERDICT r4 #2b): no k_curvature launch; a sector's points and their halo are staged in LDS, the curvature of its
+    // elements and the gap flags around them are computed from the stage
+    const int scap = (sel_sector_cap(cap) + 12 + 3) & ~3;
+    float *sx = (float *)(smem_w + ((cap + 15) & ~15)), *sy = sx + scap, *sz = sy + scap;
+    unsigned long long *gap = (unsigned long long *)(sz + scap);
+    for (int i = lane; i < len; i += 64) { picked[i] = 0; label[i] = 0; }
+    // the ring's end points belong to no sector: their curvature comes straight from HBM
+    curv_points_global(cl, uni_ptr(b.curv + off), n_cloud, rbeg, 5, lane);
+    curv_points_global(cl, uni_ptr(b.curv + off), n_cloud, rend - 6, 6, lane);
     for (int j = 0; j < kSectors; j++) {
         const int sp = 5 + span * j / 6;
         const int ep = 5 + span * (j + 1) / 6 - 1;
         const int slen = ep - sp + 1;
-        // HDL-64-sized sectors (<= 320 / <= 384 points) take the 5- / 6-slot instantiations, longer rings the full one
-        if (slen <= 5 * 64) select_sector<5>(lane, j, sp, slen, rbeg, curv, picked, label, gap, sel_sh, sel_sh_n, sel_fl, sel_fl_n, scratch);
-        else if (slen <= 6 * 64) select_sector<6>(lane, j, sp, slen, rbeg, curv, picked, label, gap, sel_sh, sel_sh_n, sel_fl, sel_fl_n, scratch);
-        else select_sector<kSelMaxPerLane>(lane, j, sp, slen, rbeg, curv, picked, label, gap, sel_sh, sel_sh_n, sel_fl, sel_fl_n, scratch);
+        __builtin_amdgcn_wave_barrier();               // the previous sector is done with the stage
+        // ring points sp - 5 .. ep + 6 (a point past the cloud reads as the origin: only its gap flag could use it, and that is forced to 0)
+        for (int k = lane; k < slen + 12; k += 64) {
+            const int ci = rbeg + sp - 5 + k;
+            float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ci < n_cloud) p = cl[ci];
+            sx[k] = p.x; sy[k] = p.y; sz[k] = p.z;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int k0 = 0; k0 < slen + 11 + 64; k0 += 64) {
+            const int k = k0 + lane;
+            bool g = false;
+            if (k < slen + 11 && rbeg + sp - 5 + k + 1 < n_cloud) {
+                const float gx = sx[k + 1] - sx[k], gy = sy[k + 1] - sy[k], gz = sz[k + 1] - sz[k];
+                g = (double)(gx * gx + gy * gy + gz * gz) > 0.05;
+            }
+            const unsigned long long mk = __ballot(g);
+            if (lane == 0) gap[k0 >> 6] = mk;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (slen <= 5 * 64) select_sector<5, true>(lane, j, sp, slen, rbeg, curv, picked, label, gap, sel_sh, sel_sh_n, sel_fl, sel_fl_n, scratch, sx, sy, sz);
+        else if (slen <= 6 * 64) select_sector<6, true>(lane, j, sp, slen, rbeg, curv, picked, label, gap, sel_sh, sel_sh_n, sel_fl, sel_fl_n, scratch, sx, sy, sz);
+        else select_sector<kSelMaxPerLane, true>(lane, j, sp, slen, rbeg, curv, picked, label, gap, sel_sh, sel_sh_n, sel_fl, sel_fl_n, scratch, sx, sy, sz);
     }
 }
 
@@ -571,8 +656,8 @@ __global__ __launch_bounds__(256, 8) void k_select(BatchView b, int cap, int fro
     // pushed the 64-register budget of 8 waves / SIMD over and the pick loop reloaded a spilled pointer on every pick)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     extern __shared__ __align__(16) unsigned char smem[];
-    unsigned char *smem_w = smem + wave * 2 * cap;
-    unsigned int *scratch = (unsigned int *)(smem + 4 * 2 * cap + wave * kSelScratch);      // behind the four slices (2 * cap is a multiple of 4)
+    unsigned char *smem_w = smem + wave * sel_slice_bytes(cap);
+    unsigned int *scratch = (unsigned int *)(smem + 4 * sel_slice_bytes(cap) + wave * kSelScratch);      // behind the four slices (a slice is a multiple of 8 bytes)
     if (!from_list) {
         select_ring(b, blockIdx.x * 4 + wave, b.scan0 + blockIdx.y, lane, smem_w, cap, true, scratch);
     } else {
@@ -979,12 +1064,14 @@ __device__ __forceinline__ void voxel_ring(BatchView &b, int r, int s)
 #ifndef LMONO_COMPACT_T
 #define LMONO_COMPACT_T 256
 #endif
-constexpr int kCompT = LMONO_COMPACT_T;      // threads per scan; 256 / 512 / 1024 measured the same 2.0 ms per pass (profiles/r4: the kernel is bound by its traffic)
+constexpr int kCompT = LMONO_COMPACT_T;      // threads per scan of the stand-alone kernel; 256 / 512 / 1024 measured the same 2.0 ms per pass (profiles/r4: bound by its traffic)
 static_assert(kCompT >= 256 && kCompT % 64 == 0, "the four prefixes take one wave each");
 
-__global__ __launch_bounds__(kCompT) void k_compact(BatchView b)
+// one scan's feature clouds compacted by kT threads (k_compact: kCompT; k_compact_index, odometry.hip: the line index's 1024); returns the sizes of the
+// two "last" clouds (less sharp, less flat) to every thread
+template <int kT>
+__device__ __forceinline__ void compact_scan(const BatchView &b, int s, int &n_ls_out, int &n_lf_out)
 {
-    const int s = b.scan0 + blockIdx.x;
     const int tid = threadIdx.x;
     const int64_t off = b.off[s];
     constexpr int NE = kMaxRings * kSectors;   // 384
@@ -1040,22 +1127,22 @@ __global__ __launch_bounds__(kCompT) void k_compact(BatchView b)
     __syncthreads();
     // four selection slots per thread and turn: the counts come from the LDS prefixes, the index loads and then the point gathers are issued
     // together (behind per-slot guards the compiler waits for every load in turn: three dependent round trips per slot, 30 slots per thread)
-    for (int x0 = tid; x0 < NE * 20; x0 += 4 * kCompT) {
+    for (int x0 = tid; x0 < NE * 20; x0 += 4 * kT) {
         int pos[4], idx[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int x = x0 + kCompT * q, e = x / 20, k = x % 20;
+            const int x = x0 + kT * q, e = x / 20, k = x % 20;
             pos[q] = (x < NE * 20 && k < pre_ls[e + 1] - pre_ls[e]) ? pre_ls[e] + k : -1;
         }
 #pragma unroll
-        for (int q = 0; q < 4; q++) idx[q] = ssel[pos[q] >= 0 ? x0 + kCompT * q : 0];
+        for (int q = 0; q < 4; q++) idx[q] = ssel[pos[q] >= 0 ? x0 + kT * q : 0];
         float4 p4[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) { const float4 *src = pos[q] >= 0 ? cl + idx[q] : b.cloud; p4[q] = *src; }      // (an unused slot reads the batch's first point)
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             if (pos[q] < 0) continue;
-            const int x = x0 + kCompT * q, e = x / 20, k = x % 20;
+            const int x = x0 + kT * q, e = x / 20, k = x % 20;
             const float4 p = p4[q];
             ls[pos[q]] = p;
             if (k < 2) sharp[pre_sh[e] + k] = p;
@@ -1065,15 +1152,15 @@ __global__ __launch_bounds__(kCompT) void k_compact(BatchView b)
             atomicMax(&s_last[0][v], pos[q]);
         }
     }
-    for (int x0 = tid; x0 < NE * 4; x0 += 2 * kCompT) {
+    for (int x0 = tid; x0 < NE * 4; x0 += 2 * kT) {
         int pos[2], idx[2];
 #pragma unroll
         for (int q = 0; q < 2; q++) {
-            const int x = x0 + kCompT * q, e = x / 4, k = x % 4;
+            const int x = x0 + kT * q, e = x / 4, k = x % 4;
             pos[q] = (x < NE * 4 && k < pre_fl[e + 1] - pre_fl[e]) ? pre_fl[e] + k : -1;
         }
 #pragma unroll
-        for (int q = 0; q < 2; q++) idx[q] = fsel[pos[q] >= 0 ? x0 + kCompT * q : 0];
+        for (int q = 0; q < 2; q++) idx[q] = fsel[pos[q] >= 0 ? x0 + kT * q : 0];
         float4 p2[2];
 #pragma unroll
         for (int q = 0; q < 2; q++) { const float4 *src = pos[q] >= 0 ? cl + idx[q] : b.cloud; p2[q] = *src; }
@@ -1083,11 +1170,11 @@ __global__ __launch_bounds__(kCompT) void k_compact(BatchView b)
     // less-flat cloud = the rings' voxel outputs back to back: every thread finds the ring of its output index by a binary
     // search over the ring prefix (all loads independent, four per thread in flight)
     const int n_lf = pre_lf[kMaxRings];
-    for (int j0 = tid; j0 < n_lf; j0 += 4 * kCompT) {
+    for (int j0 = tid; j0 < n_lf; j0 += 4 * kT) {
         float4 v4[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int j = j0 + kCompT * q;
+            const int j = j0 + kT * q;
             v4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (j < n_lf) {
                 int lo = 0, hi = kMaxRings;
@@ -1097,7 +1184,7 @@ __global__ __launch_bounds__(kCompT) void k_compact(BatchView b)
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int j = j0 + kCompT * q;
+            const int j = j0 + kT * q;
             if (j < n_lf) {
                 lf[j] = v4[q];
                 int v = (int)v4[q].w;
@@ -1113,7 +1200,7 @@ __global__ __launch_bounds__(kCompT) void k_compact(BatchView b)
     }
     __syncthreads();
     // irregular iff some line a >= b + 3 starts before line b ends (see above)
-    for (int x = tid; x < 2 * 66 * 66; x += kCompT) {
+    for (int x = tid; x < 2 * 66 * 66; x += kT) {
         const int cld = x / (66 * 66), y = x % (66 * 66), a = y / 66, bb = y % 66;
         if (a >= bb + 3 && s_first[cld][a] < s_last[cld][bb]) s_flag[cld] = 1;
     }
@@ -1128,6 +1215,13 @@ __global__ __launch_bounds__(kCompT) void k_compact(BatchView b)
         for (int t = 0; t <= 65; t++) { M = max(M, s_last[cld][t]); last_le[t] = M; }
         if (s_flag[cld]) atomicOr(b.status + s, kStatusIrregularLines);
     }
+    n_ls_out = pre_ls[NE]; n_lf_out = n_lf;
+}
+
+__global__ __launch_bounds__(kCompT) void k_compact(BatchView b)
+{
+    int n_ls, n_lf;
+    compact_scan<kCompT>(b, b.scan0 + blockIdx.x, n_ls, n_lf);
 }
 
 } // namespace lmono

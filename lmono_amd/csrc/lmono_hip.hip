@@ -122,7 +122,7 @@ extern "C" lmono_ctx *lmono_create(int device)
     if (const char *e = getenv("GPU_MAX_HW_QUEUES")) c->many_queues = atoi(e) >= 8;
     if (hipMalloc((void **)&c->stats_d, 320) != hipSuccess || hipMemset(c->stats_d, 0, 320) != hipSuccess) { delete c; return nullptr; }
     // the selection kernel needs ~62 KB of dynamic LDS
-    if (hipFuncSetAttribute((const void *)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kSelWaveLds + 4 * kSelScratch) != hipSuccess) { delete c; return nullptr; }
+    if (hipFuncSetAttribute((const void *)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * sel_slice_bytes(kRingCap) + 4 * kSelScratch) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_voxel<kVoxSmallSlots, kVoxSmallBits, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kVoxLdsSmall) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_voxel<kVoxBigSlots, kVoxBigBits, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kVoxLdsBig) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_lm_solve, hipFuncAttributeMaxDynamicSharedMemorySize, kLmRecLds) != hipSuccess) { delete c; return nullptr; }
@@ -130,6 +130,7 @@ extern "C" lmono_ctx *lmono_create(int device)
     if (hipFuncSetAttribute((const void *)k_grid_build, hipFuncAttributeMaxDynamicSharedMemorySize, kGridLds) != hipSuccess) { delete c; return nullptr; }
 #endif
     if (hipFuncSetAttribute((const void *)k_line_index<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLiLdsHalf) != hipSuccess) { delete c; return nullptr; }
+    if (hipFuncSetAttribute((const void *)k_compact_index, hipFuncAttributeMaxDynamicSharedMemorySize, kLiLdsHalf) != hipSuccess) { delete c; return nullptr; }
     if (hipFuncSetAttribute((const void *)k_line_index<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLiLdsFull) != hipSuccess) { delete c; return nullptr; }
     // the BA-side kernels with large dynamic LDS: per device, so per context (a second context on another GPU needs them too)
     if (hipFuncSetAttribute((const void *)k_marginalize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MargLds)) != hipSuccess) { delete c; return nullptr; }
@@ -296,20 +297,28 @@ static int scanreg_launch(lmono_ctx *c, lmono_scan_batch *b, int scan0, int n_sc
     if (rt_tiles > 0) hipLaunchKernelGGL(k_ring_scatter, dim3(rt_tiles, n_scans), dim3(kRtT), 0, st, v);
     HIP_TRY(c, hipEventRecord(c->ev[1], st));
     const int tiles = (int)((max_pts + kCurvTile - 1) / kCurvTile);
+#if !LMONO_FUSE_CURV_SELECT
     if (tiles > 0) hipLaunchKernelGGL(k_curvature, dim3(tiles, n_scans), dim3(256), 0, st, v);
+#else
+    (void)tiles;                                    // the curvature is computed inside k_select
+#endif
     HIP_TRY(c, hipEventRecord(c->ev[2], st));
     // the kernels below run one workgroup per ring of the sensor; the counters of the rings it cannot produce stay zero
     const int n_rings = rings_used(b->v.n_lines);
     HIP_TRY(c, hipMemsetAsync(v.sel_sharp_n + (size_t)scan0 * 64 * 6, 0, sizeof(int) * (size_t)n_scans * 64 * 6, st));
     HIP_TRY(c, hipMemsetAsync(v.sel_flat_n + (size_t)scan0 * 64 * 6, 0, sizeof(int) * (size_t)n_scans * 64 * 6, st));
     HIP_TRY(c, hipMemsetAsync(v.lf_n + (size_t)scan0 * 64, 0, sizeof(int) * (size_t)n_scans * 64, st));
-    hipLaunchKernelGGL(k_select, dim3((n_rings + 3) / 4, n_scans), dim3(256), 4 * 2 * kSelSmallCap + 4 * kSelScratch, st, v, kSelSmallCap, 0);
-    hipLaunchKernelGGL(k_select, dim3(kSelBigGrid), dim3(256), 4 * kSelWaveLds + 4 * kSelScratch, st, v, (int)kRingCap, 1);
+    hipLaunchKernelGGL(k_select, dim3((n_rings + 3) / 4, n_scans), dim3(256), 4 * sel_slice_bytes(kSelSmallCap) + 4 * kSelScratch, st, v, kSelSmallCap, 0);
+    hipLaunchKernelGGL(k_select, dim3(kSelBigGrid), dim3(256), 4 * sel_slice_bytes(kRingCap) + 4 * kSelScratch, st, v, (int)kRingCap, 1);
     HIP_TRY(c, hipEventRecord(c->ev[3], st));
     hipLaunchKernelGGL((k_voxel<kVoxSmallSlots, kVoxSmallBits, true>), dim3(n_rings, n_scans), dim3(256), kVoxLdsSmall, st, v);
     hipLaunchKernelGGL((k_voxel<kVoxBigSlots, kVoxBigBits, false>), dim3(kVoxBigGrid), dim3(256), kVoxLdsBig, st, v);
     HIP_TRY(c, hipEventRecord(c->ev[4], st));
+#if LMONO_FUSE_COMPACT_INDEX
+    hipLaunchKernelGGL(k_compact_index, dim3(n_scans), dim3(kLiT), kLiLdsHalf, st, v);       // compaction + (line, bin) index of the two "last" clouds
+#else
     hipLaunchKernelGGL(k_compact, dim3(n_scans), dim3(kCompT), 0, st, v);
+#endif
     HIP_TRY(c, hipEventRecord(c->ev[5], st));
     // the hash grids serve the 32-lane-group search (LMONO_OPT_CORR_TILE 0) and the deferred lists of modes 1 and 2; the default
     // (flattened sweeps) works on the line index alone, so the grids are built on demand (ensure_grid)
@@ -320,7 +329,9 @@ static int scanreg_launch(lmono_ctx *c, lmono_scan_batch *b, int scan0, int n_sc
     }
 #endif
     HIP_TRY(c, hipEventRecord(c->ev[6], st));
+#if !LMONO_FUSE_COMPACT_INDEX
     hipLaunchKernelGGL(k_line_index<true>, dim3(n_scans, 2), dim3(kLiT), kLiLdsHalf, st, v);
+#endif
     hipLaunchKernelGGL(k_line_index<false>, dim3(kLiBigGrid), dim3(kLiT), kLiLdsFull, st, v);
     HIP_TRY(c, hipEventRecord(c->ev[7], st));
     return check_launch(c, "scanreg kernels");
