@@ -601,7 +601,8 @@ def main():
                     help="lead-in scan pairs of a chain (the last ones) that use all feature points; the earlier ones a quarter (-1: all use all)")
     ap.add_argument("--kitti-dir", default="", help="read the scans of a KITTI-layout sequence directory (velodyne/%%06d.bin + times.txt, e.g. "
                     "dataset/sequences/00: /root/reference/README.md:48-60) instead of generating S1 scans; --scans caps the count")
-    ap.add_argument("--seq", type=int, default=0, choices=[0, 1], help="0: the S1 figure-8 sequence (headline); 1: the held-out sequence (other world, clover trajectory)")
+    ap.add_argument("--seq", type=int, default=0, choices=[0, 1, 2], help="0: the S1 figure-8 sequence (headline); 1: the held-out sequence (other world, clover trajectory); "
+                    "2: the stress sequence (cluttered world: small boxes, 20 %% stray returns, moving cylinders, dropped ring sectors)")
     ap.add_argument("--az", type=int, default=2000, help="azimuth steps per ring (2000 = HDL-64 at 10 Hz)")
     ap.add_argument("--cpu-sample", type=int, default=128, help="scans of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-frames", type=int, default=-1, help="ba-seq: frames of the CPU oracle's replay (-1 = the whole stream)")
@@ -693,9 +694,12 @@ def main():
         if args.seq == 0:
             w = S1.S1World(n_az=args.az)
             traj = w.trajectory(n_total)
-        else:           # the held-out sequence: another world, another trajectory (tests/golden/s1_seq01_oracle.npz)
+        elif args.seq == 1:           # the held-out sequence: another world, another trajectory (tests/golden/s1_seq01_oracle.npz)
             w = S1.S1World(seed=777, n_az=args.az)
             traj = w.trajectory_clover(n_total)
+        else:                         # the stress sequence: the cluttered world (tests/golden/s1_seq02_oracle.npz)
+            w = S1.S1World(seed=4242, n_az=args.az, clutter=True)
+            traj = w.trajectory(n_total)
         xyzi, off = w.scans(traj[load_begin:own_end], scan_id0=load_begin)
     gen_s = time.time() - t0
     total_pts = int(off[-1])

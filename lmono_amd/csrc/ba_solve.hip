@@ -34,7 +34,8 @@ constexpr int kBaMaxPoses = 11;
 constexpr int kBaP = 6 * (kBaMaxPoses + 1);      // 72
 constexpr int kBaPS = 80;                        // padded row of the coupling matrix: 5 MFMA tiles of 16
 constexpr int kBaMaxFeat = LMONO_BA_MAX_FEATURES;      // include/lmono_hip.h states the bound and why
-constexpr int kBaN = kBaP + kBaMaxFeat;          // 520
+constexpr int kBaLdsFeat = 448;                  // features whose dogleg vectors live in LDS; a window above it runs the kBig instantiation (vectors in an L2 scratch)
+constexpr int kBaN = kBaP + kBaLdsFeat;          // 520
 constexpr int kBaMaxPairs = kBaMaxPoses * (kBaMaxPoses - 1);
 constexpr int kBaRound = 32;                     // observations a wave stages per round (two lanes each)
 constexpr int kBaRow = 19;                       // staged row: J_i(6) J_j(6) J_ex(6) r (odd stride: few bank conflicts)
@@ -43,7 +44,7 @@ constexpr int kBaSS = 73;                        // row stride of S in LDS (odd:
 constexpr int kBaPairRec = 52;                   // Tres(9) tres(3) Cm(9) A(9) B(9) Tn(9) tn(3) pad
 constexpr int kBaPairTile = 320;                 // 16 x 16 tile + 16 x 4 side tile of a SEGMENT of a frame pair (column 3 of the side tile: the segment's scalar sums)
 constexpr int kBaSeg = 16;                       // observations of a segment: a frame pair's slots in runs of 16 (two lanes each: half a wave)
-constexpr int kBaMaxSeg = kBaMaxPairs + kBaMaxFeat * (kBaMaxPoses - 1) / kBaSeg;      // 110 + 280
+constexpr int kBaMaxSeg = kBaMaxPairs + kBaLdsFeat * (kBaMaxPoses - 1) / kBaSeg;      // 110 + 280 (segments whose table lives in LDS; kBig reads the table from HBM)
 constexpr int kBaMbox = 96 + kBaMaxFeat;         // leader -> followers: [0] command, [1] re-use the records, [8..84] poses, [88..94] extrinsic, [96..] inverse depths
 constexpr int kBaMaxK = 8;                       // workgroups per window
 // ba_reduce_pairs' gather program (built once per solve: which tile cells an entry of H_pp / g_p is the sum of does not change between iterations):
@@ -93,6 +94,8 @@ struct BaBatch {
     // several workgroups per window (k_ba_solve<true>): the leader's mail box [W][kBaMbox] (command, state to evaluate), flag words [W][16]
     // (go, done of every follower; zeroed before every launch), a failure flag; pairdat then holds one copy per workgroup of a window
     int *gprog;                 // scratch [W][kBaGprog]: every window's gather program (see kBaGaN)
+    int feat_cap;               // stride of the per-window feature arrays hpd / cand / mbox: kBaLdsFeat, or kBaMaxFeat when a window of the batch is larger
+    double *bigv;               // scratch [W][8][kBaMaxFeat] (kBig only): H_ff, g_f and the feature part of scale, D, gs, gn, va, vb
     double *mbox;
     unsigned int *bar;
     int *fail;
@@ -112,7 +115,7 @@ struct BaLds {
         BaSchurStage sch;                         // Schur: scaled coupling tile, 1 / h_ff
         BaFactor fac;
     } u;
-    double Hdd[kBaMaxFeat], gdd[kBaMaxFeat];
+    double Hdd[kBaLdsFeat], gdd[kBaLdsFeat];
     double gp[kBaP];
     double scale[kBaN], D[kBaN], gs[kBaN], gn[kBaN], va[kBaN], vb[kBaN];
     double rhs[kBaPS];
@@ -121,7 +124,7 @@ struct BaLds {
     double cposes[kBaMaxPoses * 7], cex[7];
     double Rp[(kBaMaxPoses + 1) * 9];            // rotation matrices of the window poses, then R_lc (normalised quaternions: Jacobians)
     double Mq[(kBaMaxPoses + 1) * 18 + 9];       // per pose and for the extrinsic: M(q), M(q^-1) of the RAW quaternion (residual path); then M(qx^-1)^-1
-    double vinv[kBaMaxFeat];                     // inverse depths of the state being evaluated
+    double vinv[kBaLdsFeat];                     // inverse depths of the state being evaluated
     int pair_ij[kBaMaxPairs];
     short pair_slot[kBaMaxPairs + 1];            // first slot of every pair (pairs in descending size)
     // The linearisation's unit of work is a SEGMENT: up to 16 consecutive slots of one frame pair (round 5).  Every sum that crosses observations is
@@ -134,8 +137,8 @@ struct BaLds {
 #endif
     short pair_seg[kBaMaxPairs + 1];             // first segment of every pair
     short pair_of[kBaMaxPoses * kBaMaxPoses];    // pair (anchor i, observer j) -> index in the window's pair list, -1: none
-    unsigned short fobs[kBaMaxFeat + 1];         // first observation of every feature, relative to the window's first (host order: grouped by feature)
-    signed char fanchor[kBaMaxFeat];             // the frame a feature is anchored in (-1: no observation)
+    unsigned short fobs[kBaLdsFeat + 1];         // first observation of every feature, relative to the window's first (host order: grouped by feature)
+    signed char fanchor[kBaLdsFeat];             // the frame a feature is anchored in (-1: no observation)
     int ok;
     int eval_no, failed;        // several workgroups per window: evaluations handed out so far; a workgroup did not arrive
 #ifdef LMONO_BA_PROF
@@ -308,6 +311,27 @@ template <bool kCl> __device__ __forceinline__ void st_sh(double *p, double v)
     if (kCl) __hip_atomic_store((ba_gd *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else gst(p, v);
 }
+// Per-feature vectors.  Up to kBaLdsFeat = 448 features they live in LDS (BaLds); a larger window (kBig: up to LMONO_BA_MAX_FEATURES = 1024, the
+// reference sizes para_depth_inv[10000]) keeps them in an L2 scratch of its own -- same arithmetic in the same order, every access a memory round trip
+// instead of an LDS read.  BA_F(name, f): feature f of H_ff / g_f; BA_V(name, k): entry k of a dogleg vector (k < P: pose part, always LDS).
+struct BaBig {
+    double *Hdd, *gdd, *scale, *D, *gs, *gn, *va, *vb;      // feature parts, [kBaMaxFeat] each
+    const double *vinv;                                     // inverse depths of the state being evaluated (the leader's array / the mail box)
+    const int *fobs;                                        // feat_obs_off of the window (global observation indices)
+    const int *fanchor;
+    const unsigned short *seg;
+    int o0;
+};
+template <bool kBig> __device__ __forceinline__ double &ba_fref(double *lds, double *glob, int f) { return kBig ? glob[f] : lds[f]; }
+template <bool kBig> __device__ __forceinline__ double &ba_vref(double *lds, double *glob, int k, int P) { return (kBig && k >= P) ? glob[k - P] : lds[k]; }
+#define BA_F(name, f) ba_fref<kBig>(L.name, G.name, (f))
+#define BA_V(name, k) ba_vref<kBig>(L.name, G.name, (k), c.P)
+// inverse depth of feature f of the state being evaluated; first observation of feature f (window-relative); anchor frame; segment word
+#define BA_VINV(f) (kBig ? ld_sh<kCl>(G.vinv + (f)) : L.vinv[(f)])
+#define BA_FOBS(f) (kBig ? G.fobs[(f)] - G.o0 : (int)L.fobs[(f)])
+#define BA_FANCHOR(f) (kBig ? G.fanchor[(f)] : (int)L.fanchor[(f)])
+#define BA_SEG(sg) (kBig ? (unsigned int)G.seg[(sg)] : (unsigned int)L.seg[(sg)])
+
 // Hand-offs between the workgroups of a window are FLAG WORDS with one writer each (device-coherent stores, polled with device-coherent loads; no
 // read-modify-write: an agent-scope atomic add is resolved beyond the XCD's L2 and costs a microsecond before anybody can see it): the leader's "go"
 // word holds the number of evaluations it has published, follower r's "done" word the number it has answered.  B.bar: [W][16] words, [0] = go,
@@ -600,7 +624,7 @@ __device__ __forceinline__ double quarter_sum_d(double v)
 
 // pose matrices and inverse depths of the state (poses, ex, invd) in LDS (ba_state), then its pair records in HBM (ba_pair_records) -- every workgroup
 // of a window computes its own (the followers read the inverse depths from the leader's mail box)
-template <bool kSharedInvd>      // kSharedInvd: a follower (the inverse depths are in LDS already)
+template <bool kSharedInvd, bool kBig>      // kSharedInvd: a follower (the inverse depths are in LDS already); kBig: they are read where they lie
 __device__ __forceinline__ void ba_state(const BaCtx &c, BaLds &L, const double *poses, const double *ex, const double *invd)
 {
     const int tid = threadIdx.x;
@@ -615,7 +639,7 @@ __device__ __forceinline__ void ba_state(const BaCtx &c, BaLds &L, const double 
         ba::q_to_R(qi, L.Mq + 18 * tid + 9);
         if (tid == c.n_poses) inv3(L.Mq + 18 * tid + 9, L.Mq + 18 * (kBaMaxPoses + 1));
     }
-    if (!kSharedInvd) for (int f = tid; f < c.F; f += kBaT) L.vinv[f] = gld(invd + f);       // (a follower has read them from the mail box)
+    if (!kSharedInvd && !kBig) for (int f = tid; f < c.F; f += kBaT) L.vinv[f] = gld(invd + f);       // (a follower has read them from the mail box)
     __syncthreads();
 }
 __device__ __forceinline__ void ba_pair_records(const BaCtx &c, BaLds &L, const double *poses, const double *ex, double *pairdat)
@@ -669,8 +693,8 @@ __device__ __forceinline__ void ba_done(const BaBatch &B, const BaCtx &c, BaLds 
 
 // one workgroup's share of an evaluation: the segments gw, gw + GW, ... of the window (a linearisation takes two per round and wave, a cost evaluation
 // four).  Every result goes to the segment's / the observation's own record.
-template <bool kJac, bool kCl>
-__device__ __forceinline__ void ba_segments(const BaBatch &B, const BaCtx &c, BaLds &L, const double *ex, const double *pairdat)
+template <bool kJac, bool kCl, bool kBig>
+__device__ __forceinline__ void ba_segments(const BaBatch &B, const BaCtx &c, BaLds &L, const BaBig &G, const double *ex, const double *pairdat)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double *Rlc = L.Rp + 9 * c.n_poses;
@@ -687,7 +711,7 @@ __device__ __forceinline__ void ba_segments(const BaBatch &B, const BaCtx &c, Ba
         for (int s4 = 4 * gw; s4 < c.n_seg; s4 += 4 * GW) {
             const int sg = s4 + (lane >> 4);
             const bool seg_ok = sg < c.n_seg;
-            const unsigned int sv = L.seg[seg_ok ? sg : s4];
+            const unsigned int sv = BA_SEG(seg_ok ? sg : s4);
             const int pr = sv & 127;
             const int so = L.pair_slot[pr] + kBaSeg * (int)(sv >> 7) + (lane & 15);
             double cst = 0.0;
@@ -699,7 +723,7 @@ __device__ __forceinline__ void ba_segments(const BaBatch &B, const BaCtx &c, Ba
                 double Tt[12], pcj[3];
 #pragma unroll
                 for (int k = 0; k < 12; k++) Tt[k] = gld(rec + k);
-                const double depth = 1.0 / L.vinv[f];
+                const double depth = 1.0 / BA_VINV(f);
                 const double pc[3] = { depth * pax, depth * pay, depth };
                 ba::mv(Tt, pc, pcj);
                 for (int k = 0; k < 3; k++) pcj[k] += Tt[9 + k];
@@ -726,7 +750,7 @@ __device__ __forceinline__ void ba_segments(const BaBatch &B, const BaCtx &c, Ba
         const int sB = sA + GW;
         const int sg = half ? sB : sA;                       // this lane's segment
         const bool seg_ok = sg < c.n_seg;
-        const unsigned int sv = L.seg[seg_ok ? sg : sA];
+        const unsigned int sv = BA_SEG(seg_ok ? sg : sA);
         const int pr = sv & 127;
         const int s_begin = L.pair_slot[pr] + kBaSeg * (int)(sv >> 7), s_end = min(s_begin + kBaSeg, (int)L.pair_slot[pr + 1]);
         const int so = s_begin + lo;
@@ -747,7 +771,7 @@ __device__ __forceinline__ void ba_segments(const BaBatch &B, const BaCtx &c, Ba
             const int ob = gldi(B.slot_obs + c.ps0 + so);
             const double pax = gld(spts + (size_t)so * 4), pay = gld(spts + (size_t)so * 4 + 1);
             const double pbx = gld(spts + (size_t)so * 4 + 2), pby = gld(spts + (size_t)so * 4 + 3);
-            const double depth = 1.0 / L.vinv[f];
+            const double depth = 1.0 / BA_VINV(f);
             const double pc[3] = { depth * pax, depth * pay, depth };
             double Tp[3], pcj[3], pcn[3], uT[3], u[3];
             ba::mv(T, pc, Tp);
@@ -866,8 +890,8 @@ __device__ __forceinline__ void ba_segments(const BaBatch &B, const BaCtx &c, Ba
 // records_valid: the pose matrices, the inverse depths in LDS and the pair records in HBM were computed by the previous call for the SAME parameter
 // values (the candidate evaluation of a step that was then accepted): a linearisation right behind it re-uses them instead of computing the same
 // numbers again
-template <bool kJac, bool kCl>
-__device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLds &L_arg, const double *poses, const double *ex, const double *invd,
+template <bool kJac, bool kCl, bool kBig>
+__device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLds &L_arg, BaBig G, const double *poses, const double *ex, const double *invd,
                                               double *hpd, double *pairdat, bool records_valid = false)
 {
     BA_BIND_LDS(L_arg)
@@ -875,7 +899,8 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
     __syncthreads();
     BA_TICK(kJac ? 0 : 3)
     if (kCl) ba_publish(B, c, L, kJac ? 1 : 2, poses, ex, invd, records_valid);
-    if (!records_valid) ba_state<false>(c, L, poses, ex, invd);
+    G.vinv = invd;
+    if (!records_valid) ba_state<false, kBig>(c, L, poses, ex, invd);
     // wave 1: LASERFactor chain and prior, next to the pair records of wave 0
     // (their residuals / Jacobians wait in gn | va | vb, which are dead during a linearisation, until the pair blocks are in)
     static_assert(3 * kBaN >= 11 * kBaSmallRec, "small-factor records must fit gn | va | vb");
@@ -892,7 +917,7 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
         // (the leader's eight waves take every segment of a candidate's cost, whatever K is)
         BaCtx c1 = c;
         c1.K = 1; c1.GW = kBaW;
-        ba_segments<false, false>(B, c1, L, ex, pairdat);
+        ba_segments<false, false, kBig>(B, c1, L, G, ex, pairdat);
         double *cpart = B.cpart + c.sg0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
@@ -913,7 +938,7 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
     BA_TOCK(0)
     BA_TICK(1)
     if (kJac && tid >= 64 && tid < 96) small_cost = ba_small_factors<kJac>(B, c, L.gn, poses, ex, tid - 64);
-    ba_segments<true, false>(B, c, L, ex, pairdat);          // (the leader's own records: plain stores; it reads them back from the L2 like everybody's)
+    ba_segments<true, false, kBig>(B, c, L, G, ex, pairdat);          // (the leader's own records: plain stores; it reads them back from the L2 like everybody's)
     BA_TOCK(1)
     BA_TICK(11)
     if (kCl) ba_done<true>(B, c, L);                             // every workgroup's segment and observation records are written
@@ -931,7 +956,7 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
         // records (contiguous, at most 10: one per other frame of the window) in observation order; the loads are independent and requested together
         const int k = lane & 15, t8 = wave * 4 + (lane >> 4);
         for (int f = t8; f < c.F; f += 4 * kBaW) {
-            const int o0 = c.o0 + L.fobs[f], o1 = c.o0 + L.fobs[f + 1];
+            const int o0 = c.o0 + BA_FOBS(f), o1 = c.o0 + BA_FOBS(f + 1);
             double acc = 0.0;
             for (int ob = o0; ob < o1; ob += 10) {
                 double v[10];
@@ -940,17 +965,17 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
 #pragma unroll
                 for (int u = 0; u < 10; u++) acc += v[u];
             }
-            if (k == 0) L.Hdd[f] = acc;
-            else if (k == 1) L.gdd[f] = acc;
+            if (k == 0) BA_F(Hdd, f) = acc;
+            else if (k == 1) BA_F(gdd, f) = acc;
             else if (k < 14) {
                 double *hrow = hpd + (size_t)f * kBaPS;
                 if (k < 8) { if (c.ex_off >= 0) gst(hrow + c.ex_off + k - 2, acc); }
-                else { const int anchor = L.fanchor[f]; if (anchor >= 0) gst(hrow + ba_pose_off(c, anchor) + k - 8, acc); }
+                else { const int anchor = BA_FANCHOR(f); if (anchor >= 0) gst(hrow + ba_pose_off(c, anchor) + k - 8, acc); }
             }
         }
         // frame j's share of a coupling row (frame j sees a feature once) moves from the observation's record to its place: 8 lanes per observation, four
         // observations of a lane in flight
-        const int n_obs = c.use_mono ? (int)L.fobs[c.F] : 0;
+        const int n_obs = c.use_mono ? BA_FOBS(c.F) : 0;
         const int kk = tid & 7;
         for (int ob0 = tid >> 3; ob0 < n_obs; ob0 += 4 * (kBaT / 8)) {
             double vj[4], vo[4], vf[4];
@@ -989,15 +1014,16 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
     return cost;
 }
 
-// y = Hs v (Jacobi-scaled), v and y in LDS arrays of length N.  L.gn is used as scratch (it is dead until the next solve).
-__device__ __noinline__ void ba_hs_mul(const BaCtx c, BaLds &L_arg, const double *hpd, const double *v, double *y)
+// vb = Hs va (Jacobi-scaled).  gn is used as scratch (it is dead until the next solve).
+template <bool kBig>
+__device__ __noinline__ void ba_hs_mul(const BaCtx c, BaLds &L_arg, const BaBig G, const double *hpd)
 {
     BA_BIND_LDS(L_arg)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = c.P, F = c.F, N = P + F;
     __syncthreads();
     BA_TICK(4)
-    for (int k = tid; k < N; k += kBaT) L.gn[k] = L.scale[k] * v[k];
+    for (int k = tid; k < N; k += kBaT) BA_V(gn, k) = BA_V(scale, k) * BA_V(va, k);
     __syncthreads();
     // camera rows: wave w sums the features f = w (mod 8); lanes own the parameter columns (coalesced 640-B rows),
     // eight feature rows in flight
@@ -1015,7 +1041,7 @@ __device__ __noinline__ void ba_hs_mul(const BaCtx c, BaLds &L_arg, const double
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const int fu = f + kBaW * u;
-                const double w = fu < F ? L.gn[P + fu] : 0.0;
+                const double w = fu < F ? BA_V(gn, P + fu) : 0.0;
                 a0 += r0[u] * w; a1 += r1[u] * w;
             }
         }
@@ -1030,18 +1056,18 @@ __device__ __noinline__ void ba_hs_mul(const BaCtx c, BaLds &L_arg, const double
         for (int k = 0; k < 18; k++) { const int a = (tid & 3) + 4 * k; rv[k] = a < P ? gld(row + a) : 0.0; }
         double acc = 0;
 #pragma unroll
-        for (int k = 0; k < 18; k++) { const int a = (tid & 3) + 4 * k; acc += rv[k] * (a < P ? L.gn[a] : 0.0); }
+        for (int k = 0; k < 18; k++) { const int a = (tid & 3) + 4 * k; acc += rv[k] * (a < P ? BA_V(gn, a) : 0.0); }
         acc += __shfl_xor(acc, 1);
         acc += __shfl_xor(acc, 2);
-        if ((tid & 3) == 0) y[P + f] = (acc + L.Hdd[f] * L.gn[P + f]) * L.scale[P + f];
+        if ((tid & 3) == 0) BA_V(vb, P + f) = (acc + BA_F(Hdd, f) * BA_V(gn, P + f)) * BA_V(scale, P + f);
     }
     __syncthreads();
     if (tid < P) {
         double acc = 0;
 #pragma unroll
         for (int w = 0; w < kBaW; w++) acc += L.u.hs_part[w][tid];
-        for (int b = 0; b < P; b++) acc += L.Hpp[b * kBaP + tid] * L.gn[b];   // H_pp is symmetric: column walk, no bank conflicts
-        y[tid] = acc * L.scale[tid];
+        for (int b = 0; b < P; b++) acc += L.Hpp[b * kBaP + tid] * BA_V(gn, b);   // H_pp is symmetric: column walk, no bank conflicts
+        BA_V(vb, tid) = acc * BA_V(scale, tid);
     }
     __syncthreads();
     BA_TOCK(4)
@@ -1057,14 +1083,15 @@ __device__ __forceinline__ double readlane_d(double v, int l)
 }
 
 // solve (Hs + mu diag(D2)) x = gs by Schur elimination of the depth columns; result in L.gn; returns success to all
-__device__ __noinline__ bool ba_schur_solve(const BaCtx c, BaLds &L_arg, const double *hpd, double mu)
+template <bool kBig>
+__device__ __noinline__ bool ba_schur_solve(const BaCtx c, BaLds &L_arg, const BaBig G, const double *hpd, double mu)
 {
     BA_BIND_LDS(L_arg)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, P = c.P, F = c.F;
     const int col = lane & 15, kq = lane >> 4;
     __syncthreads();
     BA_TICK(5)
-    for (int a = tid; a < kBaPS; a += kBaT) L.rhs[a] = a < P ? L.gs[a] : 0.0;
+    for (int a = tid; a < kBaPS; a += kBaT) L.rhs[a] = a < P ? BA_V(gs, a) : 0.0;
     if (tid == 0) L.ok = 1;
     // upper 16x16 tiles of E diag(1 / h_ff) E^T: tiles 2 wave and 2 wave + 1
     ba_d4 acc[2];
@@ -1088,17 +1115,17 @@ __device__ __noinline__ bool ba_schur_solve(const BaCtx c, BaLds &L_arg, const d
 #pragma unroll
             for (int qq = 0; qq < 10; qq++) {
                 const int k = tid + kBaT * qq, t = k / kBaPS, a = k - t * kBaPS;
-                L.u.sch.et[k] = (t < nf && a < P) ? v[qq] * L.scale[a] * L.scale[P + f0 + t] : 0.0;
+                L.u.sch.et[k] = (t < nf && a < P) ? v[qq] * BA_V(scale, a) * BA_V(scale, P + f0 + t) : 0.0;
             }
         }
         if (tid < kBaFT) {
             double ic = 0.0, gi = 0.0;
             if (tid < nf) {
-                const double s = L.scale[P + f0 + tid];
-                const double hff = L.Hdd[f0 + tid] * s * s + mu * L.D[P + f0 + tid] * L.D[P + f0 + tid];
+                const double s = BA_V(scale, P + f0 + tid);
+                const double hff = BA_F(Hdd, f0 + tid) * s * s + mu * BA_V(D, P + f0 + tid) * BA_V(D, P + f0 + tid);
                 if (!(hff > 0.0)) L.ok = 0;
                 ic = 1.0 / hff;
-                gi = L.gs[P + f0 + tid] * ic;
+                gi = BA_V(gs, P + f0 + tid) * ic;
             }
             L.u.sch.ic[tid] = ic; L.u.sch.gi[tid] = gi;
         }
@@ -1136,7 +1163,7 @@ __device__ __noinline__ bool ba_schur_solve(const BaCtx c, BaLds &L_arg, const d
         for (int v = 0; v < 4; v++) {
             const int m = 16 * tm[u] + kq + 4 * v, n = 16 * tn[u] + col;
             if (m < P && n < P) {
-                const double val = L.Hpp[m * kBaP + n] * L.scale[m] * L.scale[n] + (m == n ? mu * L.D[m] * L.D[m] : 0.0) - acc[u][v];
+                const double val = L.Hpp[m * kBaP + n] * BA_V(scale, m) * BA_V(scale, n) + (m == n ? mu * BA_V(D, m) * BA_V(D, m) : 0.0) - acc[u][v];
                 S[m * kBaSS + n] = val;
                 if (tm[u] != tn[u]) S[n * kBaSS + m] = val;
             }
@@ -1313,14 +1340,14 @@ __device__ __noinline__ bool ba_schur_solve(const BaCtx c, BaLds &L_arg, const d
                 }
             }
         }
-        if (lane < P) { L.gn[lane] = z0; if (!isfinite(z0)) L.ok = 0; }
-        if (64 + lane < P) { L.gn[64 + lane] = z1; if (!isfinite(z1)) L.ok = 0; }
+        if (lane < P) { BA_V(gn, lane) = z0; if (!isfinite(z0)) L.ok = 0; }
+        if (64 + lane < P) { BA_V(gn, 64 + lane) = z1; if (!isfinite(z1)) L.ok = 0; }
         __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();
     BA_TOCK(7)
     BA_TICK(8)
-    for (int k = tid; k < P; k += kBaT) L.rhs[k] = L.scale[k] * L.gn[k];
+    for (int k = tid; k < P; k += kBaT) L.rhs[k] = BA_V(scale, k) * BA_V(gn, k);
     __syncthreads();
     for (int f = tid >> 2; f < F; f += kBaT / 4) {
         const double *row = hpd + (size_t)f * kBaPS;
@@ -1333,10 +1360,10 @@ __device__ __noinline__ bool ba_schur_solve(const BaCtx c, BaLds &L_arg, const d
         acc += __shfl_xor(acc, 1);
         acc += __shfl_xor(acc, 2);
         if ((tid & 3) == 0) {
-            const double s = L.scale[P + f];
-            const double hff = L.Hdd[f] * s * s + mu * L.D[P + f] * L.D[P + f];
-            const double x = (L.gs[P + f] - acc * s) / hff;
-            L.gn[P + f] = x;
+            const double s = BA_V(scale, P + f);
+            const double hff = BA_F(Hdd, f) * s * s + mu * BA_V(D, P + f) * BA_V(D, P + f);
+            const double x = (BA_V(gs, P + f) - acc * s) / hff;
+            BA_V(gn, P + f) = x;
             if (!isfinite(x)) L.ok = 0;
         }
     }
@@ -1346,14 +1373,15 @@ __device__ __noinline__ bool ba_schur_solve(const BaCtx c, BaLds &L_arg, const d
 }
 
 // Window tables that live in LDS for the whole solve: (anchor, observer) -> pair, the first observation and the anchor frame of every feature
+template <bool kBig>
 __device__ __noinline__ void ba_setup(const BaBatch &B, const BaCtx c, BaLds &L_arg)
 {
     BA_BIND_LDS(L_arg)
     const int tid = threadIdx.x;
     __syncthreads();
     for (int k = tid; k < kBaMaxPoses * kBaMaxPoses; k += kBaT) L.pair_of[k] = -1;
-    for (int f = tid; f <= c.F; f += kBaT) L.fobs[f] = (unsigned short)(B.feat_obs_off[c.f0 + f] - c.o0);      // <= 448 x 10 observations per window
-    for (int f = tid; f < c.F; f += kBaT) L.fanchor[f] = (signed char)B.feat_anchor[c.f0 + f];
+    if (!kBig) for (int f = tid; f <= c.F; f += kBaT) L.fobs[f] = (unsigned short)(B.feat_obs_off[c.f0 + f] - c.o0);      // <= 448 x 10 observations per window
+    if (!kBig) for (int f = tid; f < c.F; f += kBaT) L.fanchor[f] = (signed char)B.feat_anchor[c.f0 + f];
     __syncthreads();
     // (anchor, observer) -> the pair's tile among the window's tiles [segments | pairs]: a pair of several segments has its own (ba_reduce_pairs sums
     // its segments' tiles into it), any other pair's tile is its only segment's
@@ -1421,12 +1449,14 @@ __device__ __noinline__ void ba_setup(const BaBatch &B, const BaCtx c, BaLds &L_
 
 // A follower workgroup of a window (rank > 0): waits for the leader's mail, computes its own copy of the state's records and, for a linearisation,
 // takes its share of the segments and reports; until the leader sends command 3.
-__device__ __noinline__ void ba_follow(const BaBatch &B, const BaCtx c, BaLds &L_arg, double *pairdat)
+template <bool kBig>
+__device__ __noinline__ void ba_follow(const BaBatch &B, const BaCtx c, BaLds &L_arg, BaBig G, double *pairdat)
 {
     BA_BIND_LDS(L_arg)
     const int tid = threadIdx.x;
     const double *mb = B.mbox + (size_t)c.win * kBaMbox;
     unsigned int *flags = B.bar + (size_t)c.win * 16;
+    G.vinv = mb + 96;                                   // (kBig: a follower reads the inverse depths straight from the mail box)
     for (;;) {
         if (tid < 64) { if (!ba_wait_flags(flags, 1, (unsigned int)(L.eval_no + 1), B.fail) && tid == 0) L.failed = 1; }
         __syncthreads();
@@ -1436,17 +1466,17 @@ __device__ __noinline__ void ba_follow(const BaBatch &B, const BaCtx c, BaLds &L
         if (!reuse) {
             for (int k = tid; k < 7 * c.n_poses; k += kBaT) L.cposes[k] = ld_sh<true>(mb + 8 + k);
             if (tid < 7) L.cex[tid] = ld_sh<true>(mb + 88 + tid);
-            for (int f = tid; f < c.F; f += kBaT) L.vinv[f] = ld_sh<true>(mb + 96 + f);
+            if (!kBig) for (int f = tid; f < c.F; f += kBaT) L.vinv[f] = ld_sh<true>(mb + 96 + f);
         }
         __syncthreads();
         // a candidate: the mail box is read -- acknowledge, then compute the records in the leader's shadow
         if (cmd == 2 && tid == 0) ba_flag_store(flags + c.rank, (unsigned int)(L.eval_no + 1));
-        if (!reuse) { ba_state<true>(c, L, L.cposes, L.cex, nullptr); ba_pair_records(c, L, L.cposes, L.cex, pairdat); }
+        if (!reuse) { ba_state<true, kBig>(c, L, L.cposes, L.cex, nullptr); ba_pair_records(c, L, L.cposes, L.cex, pairdat); }
         __syncthreads();   // pair records are visible
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if (cmd == 1) {
-            if ((int)ld_sh<true>(mb + 2) == ba_xcc_id()) ba_segments<true, false>(B, c, L, L.cex, pairdat);      // the leader's XCD: plain stores stay in the shared L2
-            else ba_segments<true, true>(B, c, L, L.cex, pairdat);
+            if ((int)ld_sh<true>(mb + 2) == ba_xcc_id()) ba_segments<true, false, kBig>(B, c, L, G, L.cex, pairdat);      // the leader's XCD: plain stores stay in the shared L2
+            else ba_segments<true, true, kBig>(B, c, L, G, L.cex, pairdat);
             ba_done<false>(B, c, L);
         }
         if (tid == 0) L.eval_no++;
@@ -1458,7 +1488,7 @@ __device__ __noinline__ void ba_follow(const BaBatch &B, const BaCtx c, BaLds &L
 // (a shared L2 makes their exchange cheaper; nothing depends on it: every hand-off is device-coherent and ordered by the arrival counters)
 // spread (test hook, LMONO_BA_SPREAD=1): workgroup r of a window is given the residue (x + r) mod 8 instead, i.e. the K workgroups of a window land on K
 // different XCDs -- the placement the exchange must also be right on
-template <bool kCl>
+template <bool kCl, bool kBig>
 __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B, int K, int spread)
 {
     BaLds &L = g_ba_lds;
@@ -1480,9 +1510,15 @@ __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B, int K, int spread)
     c.sg0 = B.seg_off[w]; c.n_seg = c.use_mono ? B.seg_off[w + 1] - c.sg0 : 0; c.n_multi = c.use_mono ? B.n_multi[w] : 0;
     const int P = c.P, F = c.F, N = P + F;
     double *gposes = B.poses + (size_t)w * kBaMaxPoses * 7, *gex = B.ex + (size_t)w * 7, *ginvd = B.inv_depth + c.f0;
-    double *hpd = B.hpd + (size_t)w * kBaMaxFeat * kBaPS;
+    double *hpd = B.hpd + (size_t)w * B.feat_cap * kBaPS;
     double *pairdat = B.pairdat + ((size_t)c.rank * B.n_pairs_total + c.pp0) * kBaPairRec;       // (one copy per workgroup of a window)
-    double *cinvd = B.cand + (size_t)w * kBaMaxFeat;
+    double *cinvd = B.cand + (size_t)w * B.feat_cap;
+    BaBig G;
+    {
+        double *gv = kBig ? B.bigv + (size_t)w * 8 * kBaMaxFeat : nullptr;
+        G.Hdd = gv; G.gdd = gv + kBaMaxFeat; G.scale = gv + 2 * kBaMaxFeat; G.D = gv + 3 * kBaMaxFeat; G.gs = gv + 4 * kBaMaxFeat; G.gn = gv + 5 * kBaMaxFeat;
+        G.va = gv + 6 * kBaMaxFeat; G.vb = gv + 7 * kBaMaxFeat; G.vinv = ginvd; G.fobs = B.feat_obs_off + c.f0; G.fanchor = B.feat_anchor + c.f0; G.seg = B.seg_tab + B.seg_off[w]; G.o0 = c.o0;
+    }
     if (tid == 0) { L.eval_no = 0; L.failed = 0; }
 #ifdef LMONO_BA_PROF
     if (tid < 24) L.prof[tid] = 0;
@@ -1491,10 +1527,10 @@ __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B, int K, int spread)
     if (tid < 7) L.ex[tid] = gex[tid];
     for (int k = tid; k < c.n_pairs; k += kBaT) L.pair_ij[k] = B.pair_ij[c.pp0 + k];
     for (int k = tid; k <= c.n_pairs; k += kBaT) { L.pair_slot[k] = (short)B.pair_slot[c.pp0 + w + k]; L.pair_seg[k] = (short)B.pair_seg[c.pp0 + w + k]; }
-    for (int k = tid; k < c.n_seg; k += kBaT) L.seg[k] = B.seg_tab[c.sg0 + k];
+    if (!kBig) for (int k = tid; k < c.n_seg; k += kBaT) L.seg[k] = B.seg_tab[c.sg0 + k];
     __syncthreads();
-    ba_setup(B, c, L);
-    if (kCl && c.rank > 0) { ba_follow(B, c, L, pairdat); return; }
+    ba_setup<kBig>(B, c, L);
+    if (kCl && c.rank > 0) { ba_follow<kBig>(B, c, L, G, pairdat); return; }
 
     const double function_tol = 1e-6, gradient_tol = 1e-10, parameter_tol = 1e-8, min_rel_decrease = 1e-3;
     const double min_diag = 1e-6, max_diag = 1e32, max_radius = 1e16, min_radius = 1e-32;
@@ -1509,21 +1545,21 @@ __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B, int K, int spread)
     // one call site per phase (the phases are inlined: LDS addressing, no register-file round trips through a call)
     for (;;) {
         if (linearise) {
-            x_cost = ba_evaluate<true, kCl>(B, c, L, L.poses, L.ex, ginvd, hpd, pairdat, records_valid);
+            x_cost = ba_evaluate<true, kCl, kBig>(B, c, L, G, L.poses, L.ex, ginvd, hpd, pairdat, records_valid);
             records_valid = false;
             BA_TICK(16)
             double q = 0, g = 0;
             if (c.ex_off >= 0 && tid < 7) q += L.ex[tid] * L.ex[tid];
             for (int k = tid; k < 7 * c.n_poses; k += kBaT) q += L.poses[k] * L.poses[k];
-            for (int f = tid; f < F; f += kBaT) { q += L.vinv[f] * L.vinv[f]; g = fmax(g, fabs(L.gdd[f])); }
+            for (int f = tid; f < F; f += kBaT) { { const double xv = kBig ? gld(ginvd + f) : L.vinv[f]; q += xv * xv; } g = fmax(g, fabs(BA_F(gdd, f))); }
             for (int a = tid; a < P; a += kBaT) g = fmax(g, fabs(L.gp[a]));
             x_norm = sqrt(block_sum(q, L.red));
             const double gmax = block_max(g, L.red);
             if (first) {
                 initial_cost = x_cost;
                 // Jacobi scaling from the first linearisation (ceres jacobi_scaling)
-                for (int a = tid; a < P; a += kBaT) L.scale[a] = 1.0 / (1.0 + sqrt(L.Hpp[a * kBaP + a]));
-                for (int f = tid; f < F; f += kBaT) L.scale[P + f] = 1.0 / (1.0 + sqrt(L.Hdd[f]));
+                for (int a = tid; a < P; a += kBaT) BA_V(scale, a) = 1.0 / (1.0 + sqrt(L.Hpp[a * kBaP + a]));
+                for (int f = tid; f < F; f += kBaT) BA_V(scale, P + f) = 1.0 / (1.0 + sqrt(BA_F(Hdd, f)));
                 first = false;
             }
             linearise = false; reuse = false;
@@ -1537,38 +1573,38 @@ __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B, int K, int spread)
         if (!reuse) {
             __syncthreads();
             for (int k = tid; k < N; k += kBaT) {
-                const double h = k < P ? L.Hpp[k * kBaP + k] : L.Hdd[k - P];
-                const double g = k < P ? L.gp[k] : L.gdd[k - P];
-                L.gs[k] = g * L.scale[k];
-                double d = h * L.scale[k] * L.scale[k];
+                const double h = k < P ? L.Hpp[k * kBaP + k] : BA_F(Hdd, k - P);
+                const double g = k < P ? L.gp[k] : BA_F(gdd, k - P);
+                BA_V(gs, k) = g * BA_V(scale, k);
+                double d = h * BA_V(scale, k) * BA_V(scale, k);
                 d = d < min_diag ? min_diag : (d > max_diag ? max_diag : d);
-                L.D[k] = sqrt(d);
-                L.va[k] = L.gs[k] / d;
+                BA_V(D, k) = sqrt(d);
+                BA_V(va, k) = BA_V(gs, k) / d;
             }
             BA_TOCK(16)
-            ba_hs_mul(c, L, hpd, L.va, L.vb);      // vb = Hs (gs / D^2): kept until the next linearisation
+            ba_hs_mul<kBig>(c, L, G, hpd);      // vb = Hs va = Hs (gs / D^2): kept until the next linearisation
             BA_TICK(17)
             double g2 = 0, jg2 = 0, zero = 0;
-            for (int k = tid; k < N; k += kBaT) { const double gd = L.gs[k] / L.D[k]; g2 += gd * gd; jg2 += L.va[k] * L.vb[k]; }
+            for (int k = tid; k < N; k += kBaT) { const double gd = BA_V(gs, k) / BA_V(D, k); g2 += gd * gd; jg2 += BA_V(va, k) * BA_V(vb, k); }
             block_sum3(g2, jg2, zero, L.red);
             alpha = g2 / jg2;
             ok = false;
             BA_TOCK(17)
             while (mu < max_mu) {
-                if (ba_schur_solve(c, L, hpd, mu)) { ok = true; break; }
+                if (ba_schur_solve<kBig>(c, L, G, hpd, mu)) { ok = true; break; }
                 mu *= mu_inc;
             }
             if (ok) {
                 mu_used = mu;
                 mu = fmax(min_mu, 2.0 * mu / mu_inc);
-                for (int k = tid; k < N; k += kBaT) L.gn[k] *= -L.D[k];
+                for (int k = tid; k < N; k += kBaT) BA_V(gn, k) *= -BA_V(D, k);
             }
             __syncthreads();
         }
         BA_TICK(18)
         if (ok) {
             double a2 = 0, b2 = 0, ab = 0;
-            for (int k = tid; k < N; k += kBaT) { const double gd = L.gs[k] / L.D[k]; a2 += L.gn[k] * L.gn[k]; b2 += gd * gd; ab += gd * L.gn[k]; }
+            for (int k = tid; k < N; k += kBaT) { const double gd = BA_V(gs, k) / BA_V(D, k); a2 += BA_V(gn, k) * BA_V(gn, k); b2 += gd * gd; ab += gd * BA_V(gn, k); }
             block_sum3(a2, b2, ab, L.red);
             const double gn_norm = sqrt(a2), g_norm = sqrt(b2);
             double ca, cb;   // step = ca * gdv + cb * gn
@@ -1587,10 +1623,10 @@ __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B, int K, int spread)
             // Hs step = ca vb - cb (gs + mu D2 gn / D): the model decrease needs no second product with Hs
             double dg = 0, dHd = 0, zero = 0;
             for (int k = tid; k < N; k += kBaT) {
-                const double st = (ca * (L.gs[k] / L.D[k]) + cb * L.gn[k]) / L.D[k];
-                const double hs = ca * L.vb[k] - cb * (L.gs[k] + mu_used * L.D[k] * L.gn[k]);
-                L.va[k] = st;
-                dg += st * L.gs[k]; dHd += st * hs;
+                const double st = (ca * (BA_V(gs, k) / BA_V(D, k)) + cb * BA_V(gn, k)) / BA_V(D, k);
+                const double hs = ca * BA_V(vb, k) - cb * (BA_V(gs, k) + mu_used * BA_V(D, k) * BA_V(gn, k));
+                BA_V(va, k) = st;
+                dg += st * BA_V(gs, k); dHd += st * hs;
             }
             block_sum3(dg, dHd, zero, L.red);
             model_change = -(dg + 0.5 * dHd);
@@ -1609,16 +1645,16 @@ __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B, int K, int spread)
             if (!is_ex || c.ex_off >= 0) {
                 const int off = is_ex ? c.ex_off : ba_pose_off(c, tid);
                 double d6[6];
-                for (int a = 0; a < 6; a++) d6[a] = L.va[off + a] * L.scale[off + a];
+                for (int a = 0; a < 6; a++) d6[a] = BA_V(va, off + a) * BA_V(scale, off + a);
                 ba::pose_plus(is_ex ? L.ex : L.poses + 7 * tid, d6, is_ex ? L.cex : L.cposes + 7 * tid);
             } else {
                 for (int k = 0; k < 7; k++) L.cex[k] = L.ex[k];
             }
         }
-        for (int f = tid; f < F; f += kBaT) cinvd[f] = ginvd[f] + L.va[P + f] * L.scale[P + f];
+        for (int f = tid; f < F; f += kBaT) cinvd[f] = ginvd[f] + BA_V(va, P + f) * BA_V(scale, P + f);
         __syncthreads();
         BA_TOCK(18)
-        const double cand_cost = ba_evaluate<false, kCl>(B, c, L, L.cposes, L.cex, cinvd, hpd, pairdat);
+        const double cand_cost = ba_evaluate<false, kCl, kBig>(B, c, L, G, L.cposes, L.cex, cinvd, hpd, pairdat);
         BA_TICK(19)
         double dq = 0;
         if (c.ex_off >= 0 && tid < 7) dq += (L.ex[tid] - L.cex[tid]) * (L.ex[tid] - L.cex[tid]);

@@ -1123,6 +1123,7 @@ struct lmono_ba_batch {
     BaBatch v{};
     int n_windows = 0, total_feat = 0, total_obs = 0;
     int cluster = 1;            // workgroups per window of the last fill (the scratch is sized for it)
+    bool big = false;           // a window of the last fill holds more than kBaLdsFeat features: the kBig kernels (per-feature vectors in an L2 scratch)
     double *poses0 = nullptr, *ex0 = nullptr, *invd0 = nullptr;   // initial state for lmono_ba_batch_reset
 };
 
@@ -1183,7 +1184,7 @@ static int ba_fill(lmono_ctx *c, lmono_ba_batch *b, const lmono_ba_desc *d)
     const int W = d->n_windows;
     const int TF = d->feat_off[W], TO = d->obs_off[W];
     for (int w = 0; w < W; w++) {
-        if (d->feat_off[w + 1] - d->feat_off[w] > kBaMaxFeat) { c->err = "lmono_ba_batch_create: more than 448 features in a window"; return LMONO_ECAPACITY; }
+        if (d->feat_off[w + 1] - d->feat_off[w] > kBaMaxFeat) { c->err = "lmono_ba_batch_create: more than LMONO_BA_MAX_FEATURES (1024) features in a window"; return LMONO_ECAPACITY; }
         if (d->flags[4 * w] < 2 || d->flags[4 * w] > kBaMaxPoses) { c->err = "lmono_ba_batch_create: n_poses must be 2..11"; return LMONO_EINVAL; }
     }
     // first observation of every feature: observations must be grouped by (window, feature) in ascending order
@@ -1271,7 +1272,11 @@ static int ba_fill(lmono_ctx *c, lmono_ba_batch *b, const lmono_ba_desc *d)
     pk.add(segoff_d, (const int *)seg_off.data(), (size_t)W + 1); pk.add(pseg_d, (const int *)pair_seg.data(), pair_seg.size());
     pk.add(nmulti_d, (const int *)n_multi.data(), (size_t)W); pk.add(segtab_d, seg_tab.empty() ? &uzero : seg_tab.data(), seg_tab.size());
     pk.add(v.obsc, (const double *)nullptr, (size_t)TO * kBaObsRec);
-    pk.add(v.hpd, (const double *)nullptr, (size_t)W * kBaMaxFeat * kBaPS);
+    b->big = false;
+    for (int w = 0; w < W; w++) if (d->feat_off[w + 1] - d->feat_off[w] > kBaLdsFeat) b->big = true;
+    v.feat_cap = b->big ? kBaMaxFeat : kBaLdsFeat;
+    pk.add(v.hpd, (const double *)nullptr, (size_t)W * v.feat_cap * kBaPS);
+    pk.add(v.bigv, (const double *)nullptr, b->big ? (size_t)W * 8 * kBaMaxFeat : (size_t)1);
     // workgroups per window: several when the batch leaves most of the chip idle (every workgroup of a window must be resident while it polls: at most
     // half the CUs).  LMONO_BA_CLUSTER = 1 / 2 / 4 forces it (measurement switch); the results do not depend on it, bit for bit.
     {
@@ -1291,7 +1296,7 @@ static int ba_fill(lmono_ctx *c, lmono_ba_batch *b, const lmono_ba_desc *d)
     pk.add(v.pairH, (const double *)nullptr, (seg_tab.size() + pair_ij.size() + (size_t)W) * kBaPairTile);
     pk.add(v.gprog, (const int *)nullptr, (size_t)W * kBaGprog);
     pk.add(v.cpart, (const double *)nullptr, seg_tab.size());
-    pk.add(v.cand, (const double *)nullptr, (size_t)W * kBaMaxFeat); pk.add(v.summary, (const double *)nullptr, (size_t)W * 6);
+    pk.add(v.cand, (const double *)nullptr, (size_t)W * v.feat_cap); pk.add(v.summary, (const double *)nullptr, (size_t)W * 6);
     // everything is staged in the batch's pinned buffer: the vectors above may go, and nothing waits here
     { const int rc = pk.commit(c, b); if (rc) { c->err = "lmono_ba_batch_create: device allocation / upload failed"; return LMONO_ENOMEM; } }
     v.feat_off = feat_off; v.obs_off = obs_off; v.flags = flags; v.feat_anchor = anch;
@@ -1332,9 +1337,14 @@ extern "C" int lmono_ba_solve(lmono_ctx *c, lmono_ba_batch *b, int max_iteration
         // the arrival counters start at zero in every launch
         HIP_TRY(c, hipMemsetAsync(b->v.bar, 0, (((sizeof(unsigned int) * (size_t)b->n_windows * 16) + 255) & ~(size_t)255) + 256, c->stream));   // (+ the failure flag behind them)
         static const int spread = [] { const char *e = getenv("LMONO_BA_SPREAD"); return e ? atoi(e) : 0; }();      // test hook: a window's workgroups on different XCDs
-        hipLaunchKernelGGL(k_ba_solve<true>, dim3(((b->n_windows + 7) / 8) * 8 * b->cluster), dim3(kBaT), 0, c->stream, b->v, b->cluster, spread);
+        const dim3 grid(((b->n_windows + 7) / 8) * 8 * b->cluster);
+        if (b->big) hipLaunchKernelGGL((k_ba_solve<true, true>), grid, dim3(kBaT), 0, c->stream, b->v, b->cluster, spread);
+        else hipLaunchKernelGGL((k_ba_solve<true, false>), grid, dim3(kBaT), 0, c->stream, b->v, b->cluster, spread);
     } else
-        hipLaunchKernelGGL(k_ba_solve<false>, dim3(b->n_windows), dim3(kBaT), 0, c->stream, b->v, 1, 0);          // its LDS is static (g_ba_lds)
+    {
+        if (b->big) hipLaunchKernelGGL((k_ba_solve<false, true>), dim3(b->n_windows), dim3(kBaT), 0, c->stream, b->v, 1, 0);
+        else hipLaunchKernelGGL((k_ba_solve<false, false>), dim3(b->n_windows), dim3(kBaT), 0, c->stream, b->v, 1, 0);          // its LDS is static (g_ba_lds)
+    }
     return check_launch(c, "k_ba_solve");
 }
 

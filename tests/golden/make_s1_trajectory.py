@@ -14,6 +14,10 @@ generator), meta.  Takes ~3 min on 8 cores (front end in parallel over scans, od
 seq 1 = the HELD-OUT sequence tests/golden/s1_seq01_oracle.npz: another world (S1World(seed=777): other boxes and poles) and another
 trajectory (S1World.trajectory_clover: three-leaf clover at 4 .. 10 m/s).  The chain schedule's parameters were never tuned on it;
 tests/test_chain_validation_gpu.py runs every chain layout on both sequences.
+
+seq 2 = the STRESS sequence tests/golden/s1_seq02_oracle.npz: S1World(seed=4242, clutter=True) -- 200 small boxes on top of the 40 + 60,
+20 % stray returns at random ranges, eight moving cylinders, 15 % of the rings with a dropped azimuth sector -- along the figure-8.  Nothing
+was tuned against it; it says whether the lead-in, the repair tolerance and the search's round budgets are properties of the tidy world.
 """
 import os
 import sys
@@ -31,8 +35,8 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 4541
     seq = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     S1.build(); O.build()
-    w = S1.S1World(n_az=2000) if seq == 0 else S1.S1World(seed=777, n_az=2000)
-    traj = w.trajectory(n) if seq == 0 else w.trajectory_clover(n)
+    w = S1.S1World(n_az=2000) if seq == 0 else (S1.S1World(seed=777, n_az=2000) if seq == 1 else S1.S1World(seed=4242, n_az=2000, clutter=True))
+    traj = w.trajectory_clover(n) if seq == 1 else w.trajectory(n)
     t0 = time.time()
     xyzi, off = w.scans(traj)
     print("generated %d scans, %d points in %.1f s" % (n, off[-1], time.time() - t0), flush=True)
@@ -45,6 +49,8 @@ def main():
                         meta=np.array(("S1World(seed=20240, n_az=2000, n_rings=64), trajectory(%d), n_lines=64, min_range=5.0, "
                                        "oracle n_chains=1 lead=0 kd-tree" if seq == 0 else
                                        "S1World(seed=777, n_az=2000, n_rings=64), trajectory_clover(%d), n_lines=64, min_range=5.0, "
+                                       "oracle n_chains=1 lead=0 kd-tree" if seq == 1 else
+                                       "S1World(seed=4242, n_az=2000, n_rings=64, clutter=True), trajectory(%d), n_lines=64, min_range=5.0, "
                                        "oracle n_chains=1 lead=0 kd-tree") % n))
     print("wrote", out, os.path.getsize(out), "bytes")
 

@@ -2,8 +2,9 @@
 chain's warm start is compared on the device with the increment the strictly sequential schedule would have warm-started from,
 chains above the tolerance are re-started from it and re-run until their increments agree with the stored ones, in rounds.
 Checked over chain layouts 128 .. 512 on BOTH bench-scale sequences -- the one the schedule was tuned on (seq 0, figure-8) and a
-held-out one (seq 1: other world, clover trajectory at 4-10 m/s; tests/golden/s1_seq01_oracle.npz) -- against the strictly
-sequential CPU oracle, with no per-layout tuning."""
+held-out one (seq 1: other world, clover trajectory at 4-10 m/s; tests/golden/s1_seq01_oracle.npz) -- and, from round 5, on the STRESS
+sequence (seq 2: a cluttered world -- 200 small boxes, 20 % stray returns at random ranges, moving cylinders, rings with dropped sectors;
+tests/golden/s1_seq02_oracle.npz) -- against the strictly sequential CPU oracle, with no per-layout tuning."""
 import os
 import re
 
@@ -27,11 +28,14 @@ def _scans(seq, n):
     if seq == 0:
         w = S1.S1World(n_az=2000)
         return w.scans(w.trajectory(n))
-    w = S1.S1World(seed=777, n_az=2000)
-    return w.scans(w.trajectory_clover(n))
+    if seq == 1:
+        w = S1.S1World(seed=777, n_az=2000)
+        return w.scans(w.trajectory_clover(n))
+    w = S1.S1World(seed=4242, n_az=2000, clutter=True)          # the stress sequence: nothing was tuned against it
+    return w.scans(w.trajectory(n))
 
 
-@pytest.fixture(scope="module", params=[0, 1], ids=["seq00_tuned", "seq01_held_out"])
+@pytest.fixture(scope="module", params=[0, 1, 2], ids=["seq00_tuned", "seq01_held_out", "seq02_clutter"])
 def seq(request, gpu_ctx):
     import torch
     import lmono_amd

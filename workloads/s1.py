@@ -43,7 +43,8 @@ class World(C.Structure):
                 ("n_rings", C.c_int), ("elev_rad", C.POINTER(C.c_double)),
                 ("n_az", C.c_int),
                 ("range_sigma", C.c_double), ("dropout", C.c_double), ("max_range", C.c_double),
-                ("seed", C.c_uint64)]
+                ("seed", C.c_uint64),
+                ("stray_frac", C.c_double), ("n_moving", C.c_int), ("moving", C.POINTER(C.c_double)), ("sector_drop", C.c_double)]
 
 
 def hdl64_elevations_rad():
@@ -56,7 +57,10 @@ def hdl64_elevations_rad():
 class S1World:
     """Ground plane z=-1.73 + 40 boxes + 60 poles in a 200 m x 200 m area, numpy default_rng(20240)."""
 
-    def __init__(self, seed=20240, n_az=2000, n_rings=64, range_sigma=0.02, dropout=0.05, max_range=120.0):
+    def __init__(self, seed=20240, n_az=2000, n_rings=64, range_sigma=0.02, dropout=0.05, max_range=120.0, clutter=False):
+        """clutter=True (the stress sequence, tests/golden/s1_seq02_oracle.npz): + 200 small boxes (0.3 .. 1.5 m: kerbs, bins, parked things), 20 % of
+        the returns at a random range in front of the surface, 8 cylinders moving at 1 .. 6 m/s, and 15 % of the (scan, ring)s lose an azimuth
+        sector of 5 .. 15 % -- nothing the chain schedule or the search budgets were ever tuned on."""
         rng = np.random.default_rng(seed)
         boxes = []
         for _ in range(40):
@@ -70,13 +74,28 @@ class S1World:
         for _ in range(60):
             cx, cy = rng.uniform(-95, 95, 2)
             cyls.append([cx, cy, 0.15, -1.73 + rng.uniform(3, 8)])
+        self.moving = np.zeros((0, 6))
+        stray, sector = 0.0, 0.0
+        if clutter:
+            for _ in range(200):
+                cx, cy = rng.uniform(-95, 95, 2)
+                sx, sy, h = rng.uniform(0.3, 1.5), rng.uniform(0.3, 1.5), rng.uniform(0.3, 1.8)
+                boxes.append([cx - sx / 2, cy - sy / 2, -1.73, cx + sx / 2, cy + sy / 2, -1.73 + h])
+            mv = []
+            for _ in range(8):
+                cx, cy = rng.uniform(-95, 95, 2)
+                sp, hd = rng.uniform(1, 6), rng.uniform(0, 2 * np.pi)
+                mv.append([cx, cy, sp * np.cos(hd), sp * np.sin(hd), rng.uniform(0.25, 0.9), -1.73 + rng.uniform(1.2, 3.0)])
+            self.moving = np.array(mv, np.float64)
+            stray, sector = 0.20, 0.15
         self.boxes = np.array(boxes, np.float64)
         self.cyls = np.array(cyls, np.float64)
         self.elev = hdl64_elevations_rad()[:n_rings].copy() if n_rings == 64 else np.deg2rad(np.linspace(15, -25, n_rings))
         self.n_az = n_az
         self.n_rings = n_rings
         self.w = World(len(boxes), _fp(self.boxes, C.c_double), len(cyls), _fp(self.cyls, C.c_double), -1.73,
-                       n_rings, _fp(self.elev, C.c_double), n_az, range_sigma, dropout, max_range, seed)
+                       n_rings, _fp(self.elev, C.c_double), n_az, range_sigma, dropout, max_range, seed,
+                       stray, len(self.moving), _fp(self.moving, C.c_double) if len(self.moving) else None, sector)
 
     def trajectory(self, n_scans, dt=0.1, speed=8.0):
         """Planar figure-8 (Gerono lemniscate scaled so that |yaw rate| <= 0.3 rad/s), keeping clear of boxes is

@@ -25,12 +25,12 @@ int lo_synth_scan(const lo_world *w, const double pose[4], uint64_t scan_id, flo
     const double cyaw = cos(yaw), syaw = sin(yaw);
     int n = 0;
     /* azimuth-binned culling: objects whose bounding circle can be hit by rays of each world-azimuth bin */
-    enum { NB = 720, MAXOBJ = 256 };
+    enum { NB = 720, MAXOBJ = 512 };
     const int nobj = w->n_boxes + w->n_cyls;
-    unsigned char *bins = NULL; short *bcount = NULL;
+    unsigned short *bins = NULL; short *bcount = NULL;
     const int use_bins = nobj <= MAXOBJ;
     if (use_bins) {
-        bins = (unsigned char *)malloc((size_t)NB * MAXOBJ);
+        bins = (unsigned short *)malloc(sizeof(unsigned short) * (size_t)NB * MAXOBJ);
         bcount = (short *)calloc(NB, sizeof(short));
         for (int o = 0; o < nobj; o++) {
             double cx, cy, R;
@@ -50,9 +50,20 @@ int lo_synth_scan(const lo_world *w, const double pose[4], uint64_t scan_id, flo
             }
             for (int bb = lo; bb <= hi; bb++) {
                 int bi = ((bb % NB) + NB) % NB;
-                bins[bi * MAXOBJ + bcount[bi]++] = (unsigned char)o;
+                bins[bi * MAXOBJ + bcount[bi]++] = (unsigned short)o;
             }
         }
+    }
+    /* moving cylinders at this scan's time (clutter; none in the tidy worlds) */
+    enum { MAXMOV = 16 };
+    double mov[MAXMOV][4];
+    const int n_mov = w->n_moving < MAXMOV ? w->n_moving : MAXMOV;
+    for (int m = 0; m < n_mov; m++) {
+        const double *M = w->moving + 6 * m;
+        const double t = (double)scan_id * 0.1;
+        double x = M[0] + M[2] * t, y = M[1] + M[3] * t;
+        x = fmod(fmod(x + 95.0, 190.0) + 190.0, 190.0) - 95.0; y = fmod(fmod(y + 95.0, 190.0) + 190.0, 190.0) - 95.0;
+        mov[m][0] = x; mov[m][1] = y; mov[m][2] = M[4]; mov[m][3] = M[5];
     }
     double *caz = (double *)malloc(sizeof(double) * 2 * (size_t)w->n_az);
     int *kbin = (int *)malloc(sizeof(int) * (size_t)w->n_az);
@@ -64,7 +75,18 @@ int lo_synth_scan(const lo_world *w, const double pose[4], uint64_t scan_id, flo
     }
     for (int r = 0; r < w->n_rings; r++) {
         const double ce = cos(w->elev_rad[r]), se = sin(w->elev_rad[r]);
+        /* a dropped azimuth sector of this ring (clutter) */
+        int drop0 = -1, drop1 = -1;
+        if (w->sector_drop > 0.0) {
+            const uint64_t hs = splitmix64(w->seed ^ 0xD509ull ^ splitmix64(scan_id * 0x9E3779B1ull + (uint64_t)r));
+            if (u01(hs) < w->sector_drop) {
+                const uint64_t hs2 = splitmix64(hs), hs3 = splitmix64(hs2);
+                drop0 = (int)(u01(hs2) * w->n_az);
+                drop1 = drop0 + (int)((0.05 + 0.10 * u01(hs3)) * w->n_az);
+            }
+        }
         for (int k = 0; k < w->n_az; k++) {
+            if (drop0 >= 0 && ((k >= drop0 && k < drop1) || (k + w->n_az >= drop0 && k + w->n_az < drop1))) continue;
             uint64_t h0 = splitmix64(w->seed ^ splitmix64(scan_id * 0x100000001B3ull + (uint64_t)r * 65536ull + (uint64_t)k));
             uint64_t h1 = splitmix64(h0), h2 = splitmix64(h1);
             if (u01(h0) < w->dropout) continue;
@@ -121,7 +143,25 @@ int lo_synth_scan(const lo_world *w, const double pose[4], uint64_t scan_id, flo
                 if (hz > C[3] || hz < w->ground_z) continue;
                 best = t;
             }
+            for (int m = 0; m < n_mov; m++) {
+                double cx = mov[m][0] - px, cy = mov[m][1] - py, R = mov[m][2];
+                double cr = cx * dy - cy * dx;
+                if (cr * cr > R * R * d2n) continue;
+                double bq = cx * dx + cy * dy;
+                double disc = bq * bq - d2n * (cx * cx + cy * cy - R * R);
+                if (disc < 0.0) continue;
+                double t = (bq - sqrt(disc)) / d2n;
+                if (t <= 0.0 || t >= best) continue;
+                double hz = pz + t * dz;
+                if (hz > mov[m][3] || hz < w->ground_z) continue;
+                best = t;
+            }
             if (!(best < w->max_range)) continue;
+            /* a stray return: a random range in front of the surface (clutter) */
+            if (w->stray_frac > 0.0) {
+                const uint64_t h3 = splitmix64(h2 ^ 0x5712A7ull), h4 = splitmix64(h3);
+                if (u01(h3) < w->stray_frac && best > 2.0) best = 2.0 + (best - 2.0) * u01(h4);
+            }
             /* Box-Muller range noise */
             double g = sqrt(-2.0 * log(u01(h1))) * cos(2.0 * M_PI * u01(h2));
             double rng = best + w->range_sigma * g;

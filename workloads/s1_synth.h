@@ -14,6 +14,13 @@ typedef struct {
     int n_az;                               /* azimuth steps per ring                       */
     double range_sigma, dropout, max_range;
     uint64_t seed;
+    /* clutter (all zero = the tidy S1 world; appended so that the old worlds generate the same scans bit for bit):
+     * stray_frac: fraction of the returns that come back at a RANDOM range between 2 m and the true one (dust, rain, multipath);
+     * moving[n_moving][6]: cylinders cx0 cy0 vx vy radius top_z that move with constant velocity (t = scan_id * 0.1 s, wrapping in +-95 m);
+     * sector_drop: probability that a (scan, ring) loses one azimuth sector of 5 .. 15 % of the ring (occlusion by the vehicle, a failing laser) */
+    double stray_frac;
+    int n_moving;  const double *moving;
+    double sector_drop;
 } lo_world;
 
 /* pose: sensor position (x,y,z) and yaw.  Writes up to n_rings*n_az points (ring-major,

@@ -55,7 +55,7 @@ FX, FY, CX, CY, W_IMG, H_IMG = 707.0912, 707.0912, 601.8873, 183.1104, 1241, 376
 
 
 def make_window(seed=0, n_frames=11, n_landmarks=4000, max_tracks=150, pix_sigma=0.5, odo_sigma_t=0.01, odo_sigma_r=np.deg2rad(0.05),
-                track_cnt=3, use_prior=True, perturb=True):
+                track_cnt=3, use_prior=True, perturb=True, min_dist=30):
     """One Estimator window as optimization() sees it (Estimator.cc:1124-1215): state, feature tracks, LiDAR increments."""
     rng = np.random.default_rng(20241 + seed)
     T = kitti_extrinsic()                       # laser <- camera
@@ -89,7 +89,7 @@ def make_window(seed=0, n_frames=11, n_landmarks=4000, max_tracks=150, pix_sigma
         for t in cand:
             if len(alive) >= max_tracks:
                 break
-            if all((u[t] - a) ** 2 + (v[t] - b) ** 2 > 30 ** 2 for a, b in taken):
+            if all((u[t] - a) ** 2 + (v[t] - b) ** 2 > min_dist ** 2 for a, b in taken):
                 alive.append(t); taken.append((u[t], v[t])); tracks[t] = (k, [])
         for t in alive:
             un = (u[t] + rng.normal(0, pix_sigma) - CX) / FX; vn = (v[t] + rng.normal(0, pix_sigma) - CY) / FY
