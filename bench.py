@@ -98,7 +98,9 @@ def bench_ba_seq(args):
             raise RuntimeError("estimator_seq failed: " + out.stderr[-1000:])
         lines = out.stdout.splitlines()
         tim = [ln for ln in lines if ln.startswith("TIM")][0].split()
-        runs[mode] = {"lines": [ln for ln in lines if not ln.startswith("TIM")], "n_inited": int(tim[1]), "ms_frame": float(tim[2]), "wall": wall}
+        flp = [ln for ln in lines if ln.startswith("FLP")]
+        runs[mode] = {"lines": [ln for ln in lines if not ln.startswith(("TIM", "FLP"))], "n_inited": int(tim[1]), "ms_frame": float(tim[2]), "wall": wall,
+                      "flops": float(flp[0].split()[1]) if flp else None, "obs": int(flp[0].split()[2]) if flp else None}
     identical = runs["sync"]["lines"] == runs["async"]["lines"]
     odo = np.array([[float(v) for v in ln.split()[1:]] for ln in runs["async"]["lines"] if ln.startswith("ODO")])
     n_inited, ms_frame, wall = runs["async"]["n_inited"], runs["async"]["ms_frame"], runs["async"]["wall"]
@@ -117,9 +119,12 @@ def bench_ba_seq(args):
                                                  "output_identical_to_overlapped": identical},
                       "note": "a frame = processImage of the C++ mirror: triangulate + <= 30 dogleg iterations + marginalisation + outlier "
                               "rejection + window slide; each numeric step is one C-ABI call with its own upload / download (PCIe-inclusive; scratch from the context arena)"},
-           "roofline": {"bound": "mfma", "kernel": "k_ba_solve (one window per launch: one of 256 CUs busy)", "achieved": None, "peak": FP64_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": None, "traffic": None,
-                        "note": "batch 1 is latency bound by construction (SURVEY 8d): the reference's own operating point; the batched rate is the `ba` workload"},
+           "roofline": {"bound": "mfma", "kernel": "k_ba_solve (one window per launch: up to 8 of 256 CUs busy)",
+                        "achieved": (round(runs["async"]["flops"] / (ms_frame * 1e-3 * n_inited) / 1e12, 5) if runs["async"]["flops"] else None), "peak": FP64_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": (round(runs["async"]["flops"] / (ms_frame * 1e-3 * n_inited) / 1e12 / FP64_PEAK_TFLOPS, 7) if runs["async"]["flops"] else None),
+                        "traffic": None, "algorithmic_flops": runs["async"]["flops"], "projection_blocks": runs["async"]["obs"],
+                        "note": "algorithmic flops of all window solves (SURVEY 8d: iterations x (2000 per projection block + 72^3 / 3)) over the WHOLE frame time; "
+                                "batch 1 is latency bound by construction: the reference's own operating point; the batched rate is the `ba` workload"},
            "ate_vs_truth_m": round(trajectory.ate(est, gt), 4)}
     if m > 20:
         sub = {k: (v[:m] if k != "tlc" else v) for k, v in st.items()}

@@ -120,25 +120,46 @@ __global__ __launch_bounds__(128) void k_triangulate_init(FeatBatch B)
     B.depth[f] = (z < 0.1) ? -1.0 : z;
 }
 
-// cost and (h, g) of one feature's ReprojectionFactor blocks at inverse depth xf
+// ReprojectionFactor::Evaluate (ba::reproj_factor, ba.hip) with the product T = Rlc^T Rj^T Ri Rlc of its Jacobian handed in: T depends on the frame
+// pair only, and the refinement evaluates every observation of every track in every iteration.  Same expressions in the same order: same bits.
+__device__ __forceinline__ void reproj_factor_T(double xf, const double *p_i2, const double *p_j2, const double *Ri, const double *Pi, const double *Rj, const double *Pj,
+                                                const double *Rlc, const double *Tlc, const double *T, double w, double *r, double *J)
+{
+    const double p_i[3] = { p_i2[0], p_i2[1], 1.0 }, p_j[3] = { p_j2[0], p_j2[1], 1.0 };
+    const double dep = 1.0 / xf;
+    const double pc[3] = { dep * p_i[0], dep * p_i[1], dep * p_i[2] };
+    double pl[3], pw[3], plj[3], pcj[3], tmp[3];
+    feat::mv3(Rlc, pc, pl); for (int k = 0; k < 3; k++) pl[k] += Tlc[k];
+    feat::mv3(Ri, pl, pw); for (int k = 0; k < 3; k++) pw[k] += Pi[k];
+    for (int k = 0; k < 3; k++) tmp[k] = pw[k] - Pj[k];
+    feat::mtv3(Rj, tmp, plj);
+    for (int k = 0; k < 3; k++) tmp[k] = plj[k] - Tlc[k];
+    feat::mtv3(Rlc, tmp, pcj);
+    const double d = pcj[2];
+    r[0] = w * (pcj[0] / d - p_j[0]);
+    r[1] = w * (pcj[1] / d - p_j[1]);
+    const double red[6] = { w * (1.0 / d), 0, w * (-pcj[0] / (d * d)), 0, w * (1.0 / d), w * (-pcj[1] / (d * d)) };
+    double v[3];
+    feat::mv3(T, p_i, v);
+    for (int a = 0; a < 2; a++) J[a] = -(red[a * 3] * v[0] + red[a * 3 + 1] * v[1] + red[a * 3 + 2] * v[2]) * dep * dep;
+}
+
+// cost and (h, g) of one feature's ReprojectionFactor blocks at inverse depth xf; sT: the window's T(i, j) = Rlc^T Rj^T Ri Rlc, [11][11][9] in LDS
 template <bool kJac>
-__device__ __forceinline__ double refine_feature(const FeatBatch &B, int f, const double *Rs, const double *Ps, const double *tlc, double xf, double &h, double &g)
+__device__ __forceinline__ double refine_feature(const FeatBatch &B, int f, const double *Rs, const double *Ps, const double *Rlc, const double *Tlc, const double *sT, double xf, double &h, double &g)
 {
     double cost = 0;
     h = 0; g = 0;
     const int nobs = B.obs_off[f + 1] - B.obs_off[f];
     if (nobs < B.track_cnt) return 0.0;
     const int i = B.start_frame[f];
+    const double *pi = B.pts + 2 * (size_t)B.obs_off[f];
     for (int o = 1; o < nobs; o++) {
         const int j = i + o;
         if (j == B.window_size) continue;
-        double c[44], r[2], J[2];
-        const double *pi = B.pts + 2 * (size_t)B.obs_off[f], *pj = B.pts + 2 * (size_t)(B.obs_off[f] + o);
-        c[0] = pi[0]; c[1] = pi[1]; c[2] = pj[0]; c[3] = pj[1];
-        for (int k = 0; k < 9; k++) { c[4 + k] = Rs[9 * i + k]; c[16 + k] = Rs[9 * j + k]; }
-        for (int k = 0; k < 3; k++) { c[13 + k] = Ps[3 * i + k]; c[25 + k] = Ps[3 * j + k]; }
-        for (int k = 0; k < 16; k++) c[28 + k] = tlc[k];
-        ba::reproj_factor(&xf, c, &B.weight, r, kJac ? J : nullptr);
+        double r[2], J[2];
+        const double *pj = B.pts + 2 * (size_t)(B.obs_off[f] + o);
+        reproj_factor_T(xf, pi, pj, Rs + 9 * i, Ps + 3 * i, Rs + 9 * j, Ps + 3 * j, Rlc, Tlc, sT + (i * 11 + j) * 9, B.weight, r, J);
         const double sq = r[0] * r[0] + r[1] * r[1];
         cost += 0.5 * log(1.0 + sq);
         if (kJac) { double rho1 = 1.0 / (1.0 + sq); rho1 = rho1 > DBL_MIN ? rho1 : DBL_MIN; h += rho1 * (J[0] * J[0] + J[1] * J[1]); g += rho1 * (J[0] * r[0] + J[1] * r[1]); }
@@ -150,8 +171,25 @@ __global__ __launch_bounds__(256) void k_depth_refine(FeatBatch B)
 {
     const int w = blockIdx.x, tid = threadIdx.x;
     const int f0 = B.feat_off[w], f1 = B.feat_off[w + 1];
-    const double *Rs = B.Rs + (size_t)w * 99, *Ps = B.Ps + (size_t)w * 33, *tlc = B.tlc + (size_t)w * 16;
+    const double *gRs = B.Rs + (size_t)w * 99, *gPs = B.Ps + (size_t)w * 33, *tlc = B.tlc + (size_t)w * 16;
     __shared__ double red[8];
+    // the window's poses, the extrinsic and the Jacobians' frame-pair products T(i, j) = Rlc^T Rj^T Ri Rlc in LDS (round 5: every observation of every
+    // iteration recomputed T with three 3 x 3 products -- 60 % of an evaluation; the products are formed exactly as ba::reproj_factor forms them)
+    __shared__ double Rs[99], Ps[33], sRlc[9], sTlc[3], sT[121 * 9];
+    if (tid < 99) Rs[tid] = gRs[tid];
+    if (tid < 33) Ps[tid] = gPs[tid];
+    if (tid < 9) sRlc[tid] = tlc[(tid / 3) * 4 + tid % 3];
+    if (tid < 3) sTlc[tid] = tlc[tid * 4 + 3];
+    __syncthreads();
+    if (tid < 121) {
+        const int i = tid / 11, j = tid % 11;
+        double RjT[9], RlcT[9], T[9];
+        ba::mT(Rs + 9 * j, RjT); ba::mT(sRlc, RlcT);
+        ba::mm(RlcT, RjT, T); ba::mm(T, Rs + 9 * i, T); ba::mm(T, sRlc, T);
+        for (int k = 0; k < 9; k++) sT[tid * 9 + k] = T[k];
+    }
+    __syncthreads();
+    const double *Rlc = sRlc, *Tlc = sTlc;
     // per-thread feature slots: features f0 + tid + 256 m, at most kSlots per thread
     constexpr int kSlots = 4;   // <= 1024 features per window
     double x[kSlots], h[kSlots], g[kSlots], scale[kSlots], diag[kSlots], step[kSlots], cand[kSlots];
@@ -188,7 +226,7 @@ __global__ __launch_bounds__(256) void k_depth_refine(FeatBatch B)
     double c0 = 0, xn = 0, gm = 0;
     for (int m = 0; m < kSlots; m++) {
         const int f = f0 + tid + 256 * m;
-        if (f < f1) c0 += refine_feature<true>(B, f, Rs, Ps, tlc, x[m], h[m], g[m]);
+        if (f < f1) c0 += refine_feature<true>(B, f, Rs, Ps, Rlc, Tlc, sT, x[m], h[m], g[m]);
         if (act[m]) { xn += x[m] * x[m]; scale[m] = 1.0 / (1.0 + sqrt(h[m])); gm = fmax(gm, fabs(g[m])); }
     }
     double x_cost = bsum(c0), x_norm = sqrt(bsum(xn)), gmax = bmax(gm);
@@ -216,7 +254,7 @@ __global__ __launch_bounds__(256) void k_depth_refine(FeatBatch B)
             cand[m] = x[m] + step[m] * scale[m];
             hh[m] = 0; gg[m] = 0;
             if (act[m]) sn += (cand[m] - x[m]) * (cand[m] - x[m]);
-            if (f < f1) cc += refine_feature<true>(B, f, Rs, Ps, tlc, cand[m], hh[m], gg[m]);
+            if (f < f1) cc += refine_feature<true>(B, f, Rs, Ps, Rlc, Tlc, sT, cand[m], hh[m], gg[m]);
         }
         sn = sqrt(bsum(sn)); cc = bsum(cc);
         if (sn <= parameter_tol * (x_norm + parameter_tol)) break;

@@ -76,6 +76,7 @@ int main(int argc, char **argv)
         std::printf("EXT");
         for (int j = 0; j < 16; j++) std::printf(" %.17g", est.TLC[j]);
         std::printf("\nTIM %d %.6f\n", solves, solves ? solve_ms / solves : 0.0);
+        std::printf("FLP %.17g %ld\n", est.solve_flops, est.solve_obs);     // algorithmic flops of all window solves, projection blocks in all
         lmono_host::estimator_print_phase_clock();
         if (argc > 2 && std::string(argv[2]) != "-") {
             FILE *fo = std::fopen(argv[2], "w");

@@ -338,6 +338,8 @@ bool Estimator::optimization()
     for (int i = 0; i <= WINDOW_SIZE; i++) std::memcpy(para_pose[i], &poses[7 * i], 56);
     if (use_mono) para_depth_inv.assign(invd.begin(), invd.begin() + F);
     initial_cost = summary[0]; final_cost = summary[1]; iterations = (int)summary[2]; termination = (int)summary[3];
+    solve_flops += (double)iterations * (2000.0 * (use_mono ? (double)obs_feat.size() : 0.0) + 72.0 * 72.0 * 72.0 / 3.0);
+    solve_obs += (long)obs_feat.size();
     double2Matrix();
     if (frame_count < WINDOW_SIZE) return false;
     if (p_.ESTIMATE_LASER) margin();                         // Estimator.cc:1288-1291

@@ -156,6 +156,9 @@ public:
         int status = 0;
     } last_marginalization_info;
     int margin_calls[2] = { 0, 0 };        // MARGIN_OLD priors built, MARGIN_SECOND_NEW eliminations done
+    // algorithmic flops of the window solves so far, SURVEY.md 8d: iterations x (2000 per projection block + 72^3 / 3) -- bench.py's roofline figure
+    double solve_flops = 0.0;
+    long solve_obs = 0;
 
 private:
     HipContext &hip_;
