@@ -69,6 +69,10 @@ static_assert(kCfC - 1 <= kLbPad, "a chunk's loads may run kCfC - 1 points past 
 #define LMONO_CF_WALK_ROUNDS 64
 #endif
 constexpr int kCfNnRounds = LMONO_CF_NN_ROUNDS, kCfWalkRounds = LMONO_CF_WALK_ROUNDS;
+#ifndef LMONO_CF_MERGED
+#define LMONO_CF_MERGED 0    // 1: nearest-point search and scan-line walk share their rounds (max of sums instead of sum of maxima: built in round 5, index-exact,
+                             // and SLOWER -- 0.295 against 0.239 ms per launch, profiles/r5: a round that mixes the two kinds of runs pays both inner loops)
+#endif
 #ifndef LMONO_WALK_TIGHT
 #define LMONO_WALK_TIGHT 1      // a walk pass that SAW its partners outside its ball continues with the ball that just holds them, not with the next rung
 #endif
@@ -96,6 +100,7 @@ struct CfLds {
     unsigned int req[kCfPool];
     CfRun pool[kCfPool];
     int n_pool, n_cand, wsum[kCfT / 64];
+    unsigned char wmode[kCfT];                // merged rounds: 1 = this owner's runs of the round belong to its scan-line walk, 0 = to its nearest-point search
 };
 
 __device__ __forceinline__ void cf_defer(unsigned int *wl, int c, int qi)
@@ -154,7 +159,7 @@ __device__ __forceinline__ int cf_last_line(const float4 *el, float elo)
 #define CF_COUNT(v)
 #endif
 
-template <bool kWalk>
+template <int kMode>
 __device__ __forceinline__ void cf_sweep(CfLds &L, int n_edge_owner, const int *tg_c, const int *tg_s, const float4 *pts_c, const float4 *pts_s, unsigned long long &cf_t, unsigned long long *cf_acc)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -218,9 +223,10 @@ __device__ __forceinline__ void cf_sweep(CfLds &L, int n_edge_owner, const int *
     unsigned long long m0 = ~0ull, m1 = ~0ull;      // running minima of the current owner (nearest / same, other)
     int closest = 0, w_lo = 0, ra = 0;
     unsigned int w_span = 0;
+    bool wk = kMode == 1;                           // the current owner's runs are walk runs (kMode 2: per owner)
     auto flush = [&]() {
         if (owner < 0) return;
-        if (!kWalk) { if (m0 != ~0ull) atomicMin(&L.best[owner], m0); }
+        if (!wk) { if (m0 != ~0ull) atomicMin(&L.best[owner], m0); }
         else { if (m0 != ~0ull) atomicMin(&L.same[owner], m0); if (m1 != ~0ull) atomicMin(&L.other[owner], m1); }
     };
     // the kCfB chunks (first point, live points, owner) the loop body works on; the NEXT ones are prepared while these loads are in flight
@@ -266,7 +272,8 @@ __device__ __forceinline__ void cf_sweep(CfLds &L, int n_edge_owner, const int *
                 owner = ow_c[bb]; m0 = ~0ull; m1 = ~0ull;
                 const float4 qq = L.q[owner];
                 qx = qq.x; qy = qq.y; qz = qq.z;
-                if (kWalk) { const int cr = L.closest[owner]; closest = cr >> 7; ra = cr & 127; w_lo = L.wlo[owner]; w_span = (unsigned int)(L.whi[owner] - w_lo); }
+                if (kMode == 2) wk = L.wmode[owner] != 0;
+                if (wk) { const int cr = L.closest[owner]; closest = cr >> 7; ra = cr & 127; w_lo = L.wlo[owner]; w_span = (unsigned int)(L.whi[owner] - w_lo); }
             }
 #pragma unroll
             for (int u = 0; u < kCfC; u++) {
@@ -274,7 +281,7 @@ __device__ __forceinline__ void cf_sweep(CfLds &L, int n_edge_owner, const int *
                 const float d = dist2f(pt.x, pt.y, pt.z, qx, qy, qz);
                 const int pw = __float_as_int(pt.w);      // cloud index << 7 | line
                 const bool live = u < n_c[bb];
-                if (!kWalk) {
+                if (!wk) {
                     const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)pw;
                     m0 = (live & (key < m0)) ? key : m0;
                 } else {
@@ -370,6 +377,136 @@ __global__ __launch_bounds__(kCfT, LMONO_CF_WAVES) void k_corr_flat(BatchView b,
     float r = sd >= 0.f ? sqrtf(sd) * 1.0005f + 1e-3f : (edge ? kCfR0Edge : kCfR0Plane);
     __syncthreads();
 
+#if LMONO_CF_MERGED
+    // ================= nearest point and scan-line walk in ONE loop of rounds (round 5, VERDICT r4 #3b) =================
+    // A workgroup used to run  max(nearest-point rounds) + max(walk rounds)  over its features: every feature waited for the slowest nearest-point
+    // search before any walk began.  Here a feature whose nearest point has settled posts its walk runs in the very next round, beside the
+    // searches still going on (L.wmode says which kind an owner's runs are): the workgroup runs  max over features of (search + walk rounds).
+    // Same balls, same candidates, same minima: the results are the index-exact ones.
+    const unsigned long long thr = pack_fu(25.0f, 0u);
+    const float rad[4] = { walk_radius(0, rho), walk_radius(1, rho), walk_radius(2, rho), walk_radius(3, rho) };
+    bool walking = false;
+    int closest = 0, ra = 0, wpass = 0;
+    unsigned long long nn = ~0ull, same = thr, other = thr;
+    float r_seed = -1.0f;
+#ifdef LMONO_TILE_PROF
+    int my_rounds = 0;
+#endif
+    CF_STAMP(cf_acc[4])
+    for (int round = 0; round < kCfNnRounds + kCfWalkRounds; round++) {
+        if (tid == 0) L.n_pool = 0;
+        __syncthreads();
+#ifdef LMONO_TILE_PROF
+        my_rounds += (alive || walking) ? 1 : 0;
+        if (tid == 0) cf_acc[6] += 1;
+#endif
+        // ---- 1a: run requests -- of the features still searching, and of those already walking
+        const float rr = fminf(r, 5.0f);                    // d2 < 25 means d < 5: a 5 m ball holds every admissible point
+        bool posted = false;
+        if (walking) {
+            while (wpass > 0 && wpass < 4 && rad[wpass] <= rad[wpass - 1]) wpass++;
+            if (wpass >= 4) walking = false;
+        }
+        const bool seeded = r_seed > 0.0f;
+        const float r_now = seeded ? r_seed : rad[wpass < 4 ? wpass : 3];
+        if (alive) {
+            const float4 *el = L.elev[cl];
+            CfArc a;
+            cf_arc(rr, rho, th, a);
+            const float beta = R > rr ? asin_upper(rr / R) + 5e-4f : 4.0f;
+            const float elo = eq - beta, ehi = eq + beta;
+            const int v1 = cf_first_line(el, ehi), v2 = cf_last_line(el, elo);
+            int nl = 0;
+            for (int v = v1; v <= v2; v++) { const float4 ev = el[v]; nl += !(ev.y < elo || ev.x > ehi) ? 1 : 0; }
+            const int nreq = nl * cf_arc_pieces(a);
+            if (nreq > kCfPool) { alive = false; deferred = true; }       // a single ball larger than the pool: list kernel
+            else {
+                int slot = nreq > 0 ? atomicAdd(&L.n_pool, nreq) : 0;
+                if (slot + nreq <= kCfPool) {
+                    posted = true;
+                    L.wmode[tid] = 0;
+                    for (int v = v1; v <= v2; v++) { const float4 ev = el[v]; if (!(ev.y < elo || ev.x > ehi)) cf_post_line(L.req, slot, a, v, tid); }
+                } else
+                    for (int t = slot; t < kCfPool; t++) L.req[t] = 0u;     // pool full: posts again next round; the reservation's part inside the pool becomes empty runs
+            }
+        } else if (walking) {
+            CfArc a;
+            cf_arc(r_now, rho, th, a);
+            // one run (two when the arc wraps) per line of ra-2 .. ra+2, without an edge feature's own line
+            const int wv1 = max(ra - 2, 0), wv2 = min(ra + 2, 65);
+            const int nreq = (wv2 - wv1 + 1 - (edge ? 1 : 0)) * cf_arc_pieces(a);
+            int slot = atomicAdd(&L.n_pool, nreq);
+            if (slot + nreq <= kCfPool) {
+                posted = true;
+                L.wmode[tid] = 1;
+                L.same[tid] = thr; L.other[tid] = thr;
+                for (int v = wv1; v <= wv2; v++) if (!(edge && v == ra)) cf_post_line(L.req, slot, a, v, tid);
+            } else
+                for (int t = slot; t < kCfPool; t++) L.req[t] = 0u;
+        }
+        __syncthreads();
+        CF_STAMP(cf_acc[0])
+        cf_sweep<2>(L, n_edge_owner, tg_c, tg_s, pts_c, pts_s, cf_t, cf_acc);
+        __syncthreads();
+        CF_STAMP(cf_acc[2])
+        // ---- 3: owners decide
+        if (alive && posted) {
+            const unsigned long long best = L.best[tid];
+            if (best != ~0ull) {
+                const float bd = __uint_as_float((unsigned int)(best >> 32));
+                if (bd <= (rr * 0.9999f) * (rr * 0.9999f) || rr >= 5.0f) alive = false;
+                else r = sqrtf(bd) * 1.0005f + 1e-3f;
+            } else {
+                if (rr >= 5.0f) alive = false;
+                else r = rr * 2.5f;
+            }
+            if (!alive) {
+                // the nearest point has settled: set the walk up, it posts from the next round on
+                nn = L.best[tid];
+                walking = qi < nq && n_last > 0 && !deferred && nn != ~0ull && (double)__uint_as_float((unsigned int)(nn >> 32)) < 25.0;
+                closest = (int)((unsigned int)(nn & 0xffffffffull) >> 7);
+                ra = (int)(nn & 127ull);
+                if (walking) {
+                    L.closest[tid] = (closest << 7) | ra;
+                    L.wlo[tid] = ra - 3 >= 0 ? L.lle[cl][ra - 3] + 1 : 0;
+                    L.whi[tid] = ra + 3 <= 65 ? L.fge[cl][ra + 3] : n_last;
+                    // seeded walk: when the nearest point is the one of the first outer iteration, the partners found then are still admissible candidates:
+                    // ONE pass with the ball that just holds them is exact; otherwise, and if that pass does not settle, the radius ladder runs as usual
+                    if (prev.w != 0 && prev.x == closest) {
+                        const int i_o = edge ? prev.y : prev.z;
+                        const float4 po = cloud[i_o];
+                        float d = dist2f(po.x, po.y, po.z, qx, qy, qz);
+                        if (!edge) { const float4 ps = cloud[prev.y]; d = fmaxf(d, dist2f(ps.x, ps.y, ps.z, qx, qy, qz)); }
+                        if (d < 24.0f) r_seed = sqrtf(d) * 1.002f + 1e-3f;
+                    }
+                }
+            }
+        } else if (walking && posted) {
+            same = L.same[tid]; other = L.other[tid];
+            if (!seeded && r_now >= 5.0f) walking = false;
+            else {
+                const unsigned long long lim = pack_fu(r_now * r_now * 0.998f, 0u);     // strictly inside the ball of this pass
+                if (other < lim && (edge || same < lim)) walking = false;
+                else if (seeded) r_seed = -1.0f;          // (not expected) back to the ladder
+                else {
+                    wpass++;
+                    while (wpass < 4 && rad[wpass] <= rad[wpass - 1]) wpass++;
+#if LMONO_WALK_TIGHT
+                    if (other < thr && (edge || same < thr)) {
+                        const float d = edge ? __uint_as_float((unsigned int)(other >> 32)) : fmaxf(__uint_as_float((unsigned int)(other >> 32)), __uint_as_float((unsigned int)(same >> 32)));
+                        const float rt = sqrtf(d) * 1.002f + 1e-3f;
+                        if (wpass < 4 && rt < rad[wpass] && d < 24.0f) r_seed = rt;
+                    }
+#endif
+                }
+            }
+        }
+        CF_STAMP(cf_acc[3])
+        if (!__syncthreads_or((alive || walking) ? 1 : 0)) break;
+    }
+    if (alive) { alive = false; deferred = true; }            // round budget exhausted (never observed): list kernel
+    if (nn == ~0ull) nn = L.best[tid];                        // (a feature that never settled keeps what it found: not used when deferred)
+#else
     CF_STAMP(cf_acc[4])
     // ================= nearest point =================
 #ifdef LMONO_TILE_PROF
@@ -410,7 +547,7 @@ __global__ __launch_bounds__(kCfT, LMONO_CF_WAVES) void k_corr_flat(BatchView b,
         }
         __syncthreads();
         CF_STAMP(cf_acc[0])
-        cf_sweep<false>(L, n_edge_owner, tg_c, tg_s, pts_c, pts_s, cf_t, cf_acc);
+        cf_sweep<0>(L, n_edge_owner, tg_c, tg_s, pts_c, pts_s, cf_t, cf_acc);
         __syncthreads();
         CF_STAMP(cf_acc[2])
 #ifdef LMONO_TILE_PROF
@@ -488,7 +625,7 @@ __global__ __launch_bounds__(kCfT, LMONO_CF_WAVES) void k_corr_flat(BatchView b,
         }
         __syncthreads();
         CF_STAMP(cf_acc[0])
-        cf_sweep<true>(L, n_edge_owner, tg_c, tg_s, pts_c, pts_s, cf_t, cf_acc);
+        cf_sweep<1>(L, n_edge_owner, tg_c, tg_s, pts_c, pts_s, cf_t, cf_acc);
         __syncthreads();
         CF_STAMP(cf_acc[2])
 #ifdef LMONO_TILE_PROF
@@ -519,6 +656,7 @@ __global__ __launch_bounds__(kCfT, LMONO_CF_WAVES) void k_corr_flat(BatchView b,
         CF_STAMP(cf_acc[3])
         if (!__syncthreads_or(walking ? 1 : 0)) break;
     }
+#endif
 #ifdef LMONO_TILE_PROF
     {
         const int mr = __syncthreads_or(0) * 0 + my_rounds;
