@@ -1292,11 +1292,12 @@ static int ba_fill(lmono_ctx *c, lmono_ba_batch *b, const lmono_ba_desc *d)
     pk.add(v.mbox, (const double *)nullptr, (size_t)W * kBaMbox);
     pk.add(v.bar, (const unsigned int *)nullptr, (size_t)W * 16);
     pk.add(v.fail, (const int *)nullptr, (size_t)1);
+    pk.add(v.summary, (const double *)nullptr, (size_t)W * 6);        // (right behind the failure flag: lmono_ba_batch_read fetches both in one copy)
     v.n_pairs_total = (int)pair_ij.size();
     pk.add(v.pairH, (const double *)nullptr, (seg_tab.size() + pair_ij.size() + (size_t)W) * kBaPairTile);
     pk.add(v.gprog, (const int *)nullptr, (size_t)W * kBaGprog);
     pk.add(v.cpart, (const double *)nullptr, seg_tab.size());
-    pk.add(v.cand, (const double *)nullptr, (size_t)W * v.feat_cap); pk.add(v.summary, (const double *)nullptr, (size_t)W * 6);
+    pk.add(v.cand, (const double *)nullptr, (size_t)W * v.feat_cap);
     // everything is staged in the batch's pinned buffer: the vectors above may go, and nothing waits here
     { const int rc = pk.commit(c, b); if (rc) { c->err = "lmono_ba_batch_create: device allocation / upload failed"; return LMONO_ENOMEM; } }
     v.feat_off = feat_off; v.obs_off = obs_off; v.flags = flags; v.feat_anchor = anch;
@@ -1362,13 +1363,32 @@ extern "C" int lmono_ba_batch_read(lmono_ctx *c, lmono_ba_batch *b, double *pose
 {
     if (!c || !b) return LMONO_EINVAL;
     if (b->n_windows <= 0) { c->err = "lmono_ba_batch_read: the batch holds no problem (failed update)"; return LMONO_EINVAL; }
-    if (poses_h) HIP_TRY(c, hipMemcpyAsync(poses_h, b->v.poses, sizeof(double) * (size_t)b->n_windows * kBaMaxPoses * 7, hipMemcpyDeviceToHost, c->stream));
-    if (ex_h) HIP_TRY(c, hipMemcpyAsync(ex_h, b->v.ex, sizeof(double) * (size_t)b->n_windows * 7, hipMemcpyDeviceToHost, c->stream));
-    if (inv_depth_h && b->total_feat > 0) HIP_TRY(c, hipMemcpyAsync(inv_depth_h, b->v.inv_depth, sizeof(double) * (size_t)b->total_feat, hipMemcpyDeviceToHost, c->stream));
-    if (summary_h) HIP_TRY(c, hipMemcpyAsync(summary_h, b->v.summary, sizeof(double) * (size_t)b->n_windows * 6, hipMemcpyDeviceToHost, c->stream));
+    // The state arrays (poses | ex | inverse depths) are neighbours in the batch's allocation, and so are (failure flag | summaries): a small batch --
+    // the Estimator's one window per frame -- comes back as TWO copies into the batch's pinned staging buffer (free between an upload and the next)
+    // instead of five copies into pageable memory, each of which the runtime stages and waits for on its own.
+    const size_t w = (size_t)b->n_windows;
+    const size_t bytes_a = (size_t)((const char *)(b->v.inv_depth + b->total_feat) - (const char *)b->v.poses);
+    const size_t bytes_b = (size_t)((const char *)(b->v.summary + w * 6) - (const char *)b->v.fail);
     int failed = 0;
-    if (b->cluster > 1) HIP_TRY(c, hipMemcpyAsync(&failed, b->v.fail, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));      // stream-ordered behind the solve; nothing goes through the null stream
+    if ((const char *)b->v.ex > (const char *)b->v.poses && (const char *)b->v.inv_depth > (const char *)b->v.ex && (const char *)b->v.summary > (const char *)b->v.fail &&
+        bytes_a + bytes_b + 256 <= b->stage_cap && bytes_a + bytes_b <= ((size_t)256 << 10)) {
+        char *sa = b->stage, *sb = b->stage + ((bytes_a + 255) & ~(size_t)255);
+        HIP_TRY(c, hipMemcpyAsync(sa, b->v.poses, bytes_a, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(sb, b->v.fail, bytes_b, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));      // stream-ordered behind the solve; nothing goes through the null stream
+        if (poses_h) memcpy(poses_h, sa, sizeof(double) * w * kBaMaxPoses * 7);
+        if (ex_h) memcpy(ex_h, sa + ((const char *)b->v.ex - (const char *)b->v.poses), sizeof(double) * w * 7);
+        if (inv_depth_h && b->total_feat > 0) memcpy(inv_depth_h, sa + ((const char *)b->v.inv_depth - (const char *)b->v.poses), sizeof(double) * (size_t)b->total_feat);
+        if (summary_h) memcpy(summary_h, sb + ((const char *)b->v.summary - (const char *)b->v.fail), sizeof(double) * w * 6);
+        if (b->cluster > 1) memcpy(&failed, sb, sizeof(int));
+    } else {
+        if (poses_h) HIP_TRY(c, hipMemcpyAsync(poses_h, b->v.poses, sizeof(double) * w * kBaMaxPoses * 7, hipMemcpyDeviceToHost, c->stream));
+        if (ex_h) HIP_TRY(c, hipMemcpyAsync(ex_h, b->v.ex, sizeof(double) * w * 7, hipMemcpyDeviceToHost, c->stream));
+        if (inv_depth_h && b->total_feat > 0) HIP_TRY(c, hipMemcpyAsync(inv_depth_h, b->v.inv_depth, sizeof(double) * (size_t)b->total_feat, hipMemcpyDeviceToHost, c->stream));
+        if (summary_h) HIP_TRY(c, hipMemcpyAsync(summary_h, b->v.summary, sizeof(double) * w * 6, hipMemcpyDeviceToHost, c->stream));
+        if (b->cluster > 1) HIP_TRY(c, hipMemcpyAsync(&failed, b->v.fail, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
     if (failed) { c->err = "k_ba_solve: a workgroup of a window's cluster did not arrive (not all resident?): the solve is void"; return LMONO_ENODEV; }
     return LMONO_OK;
 }
@@ -1398,6 +1418,38 @@ struct DevBuf {
     }
     // every staged upload is on its way (call once, behind the last up() and before the first launch)
     void ready(bool &ok) { if (c && !send_run()) ok = false; }
+    // Results come back the same way (round 5): small read-backs are queued into the pinned staging buffer -- device-adjacent ones as ONE copy -- and
+    // handed to the caller's (pageable) arrays by fetch(), which waits for the stream once.  A copy into pageable memory is staged by the runtime on
+    // its own and waited for one by one: ~20 us each in the Estimator's frame loop, four of them per frame.
+    struct Pending { char *dst; size_t at, bytes; };
+    std::vector<Pending> downs;
+    const char *drun_src = nullptr; size_t drun_at = 0, drun_bytes = 0;
+    bool flush_down()
+    {
+        if (drun_bytes == 0) return true;
+        const bool sent = hipMemcpyAsync(c->stage + drun_at, drun_src, drun_bytes, hipMemcpyDeviceToHost, c->stream) == hipSuccess;
+        drun_src = nullptr; drun_bytes = 0;
+        return sent;
+    }
+    bool down(void *dst, const void *src, size_t bytes)
+    {
+        const size_t al = (bytes + 255) & ~(size_t)255;
+        if (!c->stage || bytes > kStageMax || stage_used + al > c->stage_cap)
+            return flush_down() && hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream) == hipSuccess;
+        if (drun_bytes > 0 && (const char *)src != drun_src + drun_bytes && !flush_down()) return false;
+        if (drun_bytes == 0) { drun_src = (const char *)src; drun_at = stage_used; }
+        downs.push_back({ (char *)dst, stage_used, bytes });
+        stage_used += al; drun_bytes += al;
+        return true;
+    }
+    // every queued read-back is in the caller's arrays (waits for the stream)
+    bool fetch()
+    {
+        if (!flush_down() || hipStreamSynchronize(c->stream) != hipSuccess) return false;
+        for (const Pending &p : downs) memcpy(p.dst, c->stage + p.at, p.bytes);
+        downs.clear();
+        return true;
+    }
     // the scratch goes back to the arena only once nothing queued on the stream can still touch it (a no-op wait on the normal path,
     // where the call has already waited for its results; it matters on the early error returns)
     ~DevBuf() { if (c) { if (used) (void)hipStreamSynchronize(c->stream); c->arena_chunk = chunk0; c->arena_off = off0; } }
@@ -1477,9 +1529,9 @@ extern "C" int lmono_triangulate(lmono_ctx *c, int n_windows, const int *feat_of
     if (refine_max_iter >= 0) hipLaunchKernelGGL(k_depth_refine, dim3(n_windows), dim3(256), 0, c->stream, B);
     rc = check_launch(c, "k_triangulate_init/k_depth_refine");
     if (rc) return rc;
-    HIP_TRY(c, hipMemcpyAsync(depth_h, B.depth, sizeof(double) * F, hipMemcpyDeviceToHost, c->stream));
-    if (solve_flag_h && refine_max_iter >= 0) HIP_TRY(c, hipMemcpyAsync(solve_flag_h, B.solve_flag, sizeof(int) * F, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));      // the results are in the caller's arrays
+    bool ok = db.down(depth_h, B.depth, sizeof(double) * F);
+    if (solve_flag_h && refine_max_iter >= 0) ok = ok && db.down(solve_flag_h, B.solve_flag, sizeof(int) * F);
+    if (!ok || !db.fetch()) { c->err = "lmono_triangulate: read-back failed"; return LMONO_ENODEV; }      // the results are in the caller's arrays
     return LMONO_OK;
 }
 
@@ -1497,8 +1549,7 @@ extern "C" int lmono_outlier_scores(lmono_ctx *c, int n_windows, const int *feat
     hipLaunchKernelGGL(k_outlier_scores, dim3((F + 127) / 128), dim3(128), 0, c->stream, B);
     rc = check_launch(c, "k_outlier_scores");
     if (rc) return rc;
-    HIP_TRY(c, hipMemcpyAsync(score_h, B.score, sizeof(double) * F, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));      // the results are in the caller's arrays
+    if (!db.down(score_h, B.score, sizeof(double) * F) || !db.fetch()) { c->err = "lmono_outlier_scores: read-back failed"; return LMONO_ENODEV; }
     return LMONO_OK;
 }
 
@@ -1517,8 +1568,7 @@ extern "C" int lmono_shift_depth(lmono_ctx *c, const double *back_R0, const doub
     hipLaunchKernelGGL(k_shift_depth, dim3((n + 127) / 128), dim3(128), 0, c->stream, (const double *)pd, n, (const double *)pt, (const double *)d, o);
     int rc = check_launch(c, "k_shift_depth");
     if (rc) return rc;
-    HIP_TRY(c, hipMemcpyAsync(depth_out_h, o, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));      // the results are in the caller's arrays
+    if (!db.down(depth_out_h, o, sizeof(double) * n) || !db.fetch()) { c->err = "lmono_shift_depth: read-back failed"; return LMONO_ENODEV; }
     return LMONO_OK;
 }
 
