@@ -844,7 +844,7 @@ def main():
         # HBM bytes per launch of the dominant kernel from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE and
         # WRITE_SIZE in separate passes, gfx950 correction applied; scripts/profile_round.sh); null if not collected for it
         traffic = None
-        for rnd in ("r4", "r3", "r2", "r1"):
+        for rnd in ("r5", "r4", "r3", "r2", "r1"):
             pmc_path = os.path.join(ROOT, "profiles", rnd, "pmc_%s.json" % dom)
             if os.path.exists(pmc_path) and chains == 256:
                 with open(pmc_path) as fh:

@@ -1,0 +1,74 @@
+#!/bin/bash
+# Round-5 evidence (run on the GPU box through gpurun, AFTER the last kernel change of the round):
+#   1. headline (configs[1]): rocprofv3 kernel-trace summary of the default bench command, the same with the boundary validation off (main-pass
+#      launches only), the HBM traffic counters in their own passes (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass; never
+#      together with a trace), the plain bench lines of the three sequences (tidy, held-out, stress);
+#   2. BA half: single-window latency and Estimator loop rate for K = 1, 2, 4, 8 workgroups per window; kernel-trace summaries of the batched solve,
+#      of the single window and of the Estimator loop; MFMA / VALU / wait counters of k_ba_solve (single window, K = 8, and batched);
+#   3. laserMapping single stream (kernel-trace summary).
+# usage: bash scripts/profile_round5.sh <tag> [all|headline|ba]   (two gpurun calls of <= 20 minutes: headline, then ba)
+set -u
+TAG=${1:-final}; PART=${2:-all}
+OUT=$PWD/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+stats() { find $1 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $2; rm -rf $1; }
+# ---- 1. headline
+if [ "$PART" = all ] || [ "$PART" = headline ]; then
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 5 --warmup 1 --cpu-sample 0 --no-extras > $OUT/final_bench_under_rocprof.json 2> $OUT/trace.err
+stats $OUT/trace $OUT/final_kernel_stats_4541scans.csv
+LMONO_BOUNDARY_TOL=0 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace0 -- python3 bench.py --steps 5 --warmup 1 --cpu-sample 0 --no-extras > $OUT/final_bench_under_rocprof_no_validation.json 2> $OUT/trace0.err
+stats $OUT/trace0 $OUT/final_kernel_stats_4541scans_main_pass_only.csv
+: > $OUT/final_pmc_4541scans.txt
+for grp in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
+  tag=$(echo $grp | cut -d' ' -f1)
+  LMONO_BOUNDARY_TOL=0 timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_$tag -- python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-extras > $OUT/pmc_$tag.out 2> $OUT/pmc_$tag.err
+  echo "## $grp" >> $OUT/final_pmc_4541scans.txt
+  python3 scripts/pmc_summary.py $OUT/pmc_$tag >> $OUT/final_pmc_4541scans.txt 2>&1
+  rm -rf $OUT/pmc_$tag $OUT/pmc_$tag.out
+done
+echo "[1/3] headline traces and counters done"
+timeout -k 10 300 python3 bench.py > $OUT/final_bench_4541scans.json 2> $OUT/bench.err
+timeout -k 10 300 python3 bench.py --seq 1 --no-extras --cpu-sample 0 > $OUT/final_bench_seq1_held_out.json 2> $OUT/bench1.err
+timeout -k 10 300 python3 bench.py --seq 2 --no-extras --cpu-sample 0 > $OUT/final_bench_seq2_stress.json 2> $OUT/bench2.err
+fi
+# ---- 2. BA half
+if [ "$PART" = all ] || [ "$PART" = ba ]; then
+bash scripts/ba_ksweep.sh prof_$TAG > /dev/null 2>&1
+mv $OUT/ksweep.txt $OUT/ba_workgroups_per_window_K1_2_4_8.txt 2>/dev/null
+rm -f $OUT/ba1_k*.err $OUT/seq_k*.err $OUT/ba1_k[124].json $OUT/seq_k[124].json
+timeout -k 10 300 python3 bench.py --workload ba-seq > $OUT/final_bench_ba_seq_2761frames.json 2> $OUT/baseq.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_ba -- python3 bench.py --workload ba --windows 1024 --steps 3 --warmup 1 > $OUT/ba_bench_1024windows_under_rocprof.json 2> $OUT/trace_ba.err
+stats $OUT/trace_ba $OUT/ba_kernel_stats_1024windows.csv
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_ba1 -- python3 bench.py --workload ba --windows 1 --steps 20 --warmup 2 > $OUT/ba_bench_1window_under_rocprof.json 2> $OUT/trace_ba1.err
+stats $OUT/trace_ba1 $OUT/ba_kernel_stats_1window.csv
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_baseq -- python3 bench.py --workload ba-seq --frames-seq 600 --cpu-frames 0 > $OUT/ba_seq_bench_600frames_under_rocprof.json 2> $OUT/trace_baseq.err
+stats $OUT/trace_baseq $OUT/ba_seq_kernel_stats_600frames.csv
+: > $OUT/ba_pmc_k_ba_solve.txt
+for win in 1 1024; do
+  i=0
+  for grp in "SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_WAIT_ANY" \
+             "SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD"; do
+    i=$((i+1))
+    timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d $OUT/pmcba -- python3 bench.py --workload ba --windows $win --steps 1 --warmup 0 > /dev/null 2> $OUT/pmcba.err || echo "pmc group $i ($win windows) failed" >> $OUT/ba_pmc_k_ba_solve.txt
+    echo "## $win window(s), counter group $i" >> $OUT/ba_pmc_k_ba_solve.txt
+    python3 scripts/pmc_summary.py $OUT/pmcba 2>&1 | grep "k_ba_solve" >> $OUT/ba_pmc_k_ba_solve.txt
+    rm -rf $OUT/pmcba
+  done
+done
+echo "[2/3] BA done"
+# ---- 3. laserMapping
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_map -- python3 bench.py --workload map --scans 64 --streams 1 > $OUT/map_bench_1stream_under_rocprof.json 2> $OUT/trace_map.err
+stats $OUT/trace_map $OUT/map_kernel_stats_1stream.csv
+timeout -k 10 300 python3 bench.py --workload map --scans 64 --streams 1 > $OUT/map_bench_1stream.json 2>> $OUT/trace_map.err
+echo "[3/3] laserMapping done"
+fi
+find $OUT -name "*.err" -size 0 -delete
+head -8 $OUT/final_kernel_stats_4541scans.csv 2>/dev/null | cut -c1-200
+head -4 $OUT/final_kernel_stats_4541scans_main_pass_only.csv | cut -c1-200
+grep "corr_flat" $OUT/final_pmc_4541scans.txt
+cat $OUT/ba_workgroups_per_window_K1_2_4_8.txt
+head -4 $OUT/ba_seq_kernel_stats_600frames.csv | cut -c1-160
+cat $OUT/ba_pmc_k_ba_solve.txt | cut -c1-300
+tail -1 $OUT/final_bench_4541scans.json | cut -c1-300
