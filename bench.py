@@ -862,6 +862,8 @@ def main():
                     "whole_step_frac": round((37 * N + 0.77e6) * n_local / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
                     "group_ms_per_step": {k: round(v / max(args.steps, 1), 3) for k, v in groups.items() if k != "odometry_launch_pairs"}}
         if dom == "k_correspond":
+            # "k_correspond" is the library's timing group of the search; the kernel rocprofv3 lists under it is lmono::k_corr_flat
+            roofline["kernel_symbol"] = "lmono::k_corr_flat (+ k_correspond_list for deferred features: 0 here)"
             roofline["note"] = ("exact nearest-neighbour + scan-line walk over a (line, azimuth-bin) index, candidates swept as 64-byte chunks; the kernel is bound by "
                                 "instruction issue and by the dependent rounds of its slowest workgroup, not by HBM or the L1 (46 M VALU + 19 M SALU wave instructions per 256-chain "
                                 "launch, VALU ~80 % busy while the CUs are full, UTCL1 misses 0.04 %; profiles/r4/NOTES.md) -- the HBM fraction is reported because SURVEY 8d prices "

@@ -176,6 +176,9 @@ __global__ __launch_bounds__(kMgT) void k_marginalize(MargBatch Bt)
     if (tid < kMargN) L.br[tid] = 0.0;
     if (tid == 0) L.flag = 0;
     __syncthreads();
+#ifdef LMONO_MG_PROF
+    const unsigned long long mg_t0 = __builtin_readcyclecounter();
+#endif
     // kept-block column of pose j (1..10) and of the extrinsic inside n
     auto col_pose = [](int j) { return 6 + 6 * (j - 1); };
     if (tid == 0) {
@@ -238,6 +241,9 @@ __global__ __launch_bounds__(kMgT) void k_marginalize(MargBatch Bt)
         for (int a = 0; a < 6; a++) { L.B[a * kMargMaxF0 + f] = Bf[a]; L.Wd[f * kMargN + a] = Wx[a]; }
     }
     __syncthreads();
+#ifdef LMONO_MG_PROF
+    const unsigned long long mg_t1 = __builtin_readcyclecounter();
+#endif
     // D^+ (eps cut), S_A = A - B D^+ B^T, G = W_p - B D^+ W_d, u = bp - B D^+ bd
     for (int f = tid; f < F0; f += kMgT) { const double d = L.D[f]; if (!(d > eps)) L.flag = 1; L.D[f] = d > eps ? 1.0 / d : 0.0; }
     __syncthreads();
@@ -293,7 +299,13 @@ __global__ __launch_bounds__(kMgT) void k_marginalize(MargBatch Bt)
     for (int k = tid; k < kMargN * kMargN; k += kMgT) L.V[k] = (k / kMargN == k % kMargN) ? 1.0 : 0.0;
     __syncthreads();
     // ---- parallel Jacobi eigen-decomposition of Hrr (66x66): 65 rounds of 33 disjoint rotations per sweep
+#ifdef LMONO_MG_PROF
+    const unsigned long long mg_t2 = __builtin_readcyclecounter();
+#endif
     marg_jacobi(L.Hrr, L.V, kMargN, L.cs, L.pq, L.red, tid);
+#ifdef LMONO_MG_PROF
+    if (tid == 0) printf("MGPROF F0 %d obs %d factor %llu schur %llu jacobi %llu\n", F0, Bt.feat_obs_off[f0 + F0] - Bt.feat_obs_off[f0], mg_t1 - mg_t0, mg_t2 - mg_t1, (unsigned long long)__builtin_readcyclecounter() - mg_t2);
+#endif
     // linearized_jacobians = sqrt(S) V^T, linearized_residuals = sqrt(S^-1) V^T b'
     for (int k = tid; k < kMargN * kMargN; k += kMgT) {
         const int e = k / kMargN, i = k % kMargN;

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Phase cycles of k_marginalize on the Estimator's own windows: the -DLMONO_MG_PROF build replaces the in-tree library ON THE GPU BOX's copy of the tree
+# (estimator_seq loads it by rpath), 600 frames of the S2 stream; one line per call: tracks anchored at frame 0, their observations, cycles of the factor
+# pass / the Schur complement / the Jacobi eigen-decomposition (100 MHz constant clock x 24 = shader cycles at 2.4 GHz: the counter is s_memtime's).
+set -e
+O=gpurun_out/${1:-mg_prof}; mkdir -p $O
+hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -std=c++17 -DLMONO_MG_PROF -o lmono_amd/lib/liblmono_hip.so lmono_amd/csrc/lmono_hip.hip 2>/dev/null
+python3 - <<PY
+import sys
+sys.path.insert(0, '.')
+from workloads import s2 as K
+st = K.make_stream(600, seed=2, stops=())
+K.write_stream('$O/stream600.bin', st)
+PY
+lmono_amd/host/estimator_seq $O/stream600.bin - sync | grep "^MGPROF" > $O/marg_phases.txt
+rm -f $O/stream600.bin
+python3 - <<PY
+import re
+rows=[[int(x) for x in re.findall(r"\d+", l)] for l in open("$O/marg_phases.txt")]
+rows.sort(key=lambda r: r[0])
+n=len(rows)
+print("calls", n)
+for lo,hi in ((0,20),(20,60),(60,100),(100,140),(140,161)):
+    sel=[r for r in rows if lo<=r[0]<hi]
+    if sel:
+        m=lambda k: sum(r[k] for r in sel)/len(sel)
+        print("F0 in [%d,%d): %d calls, mean obs %.0f, factor %.0f schur %.0f jacobi %.0f cycles" % (lo,hi,len(sel),m(1),m(2),m(3),m(4)))
+PY
