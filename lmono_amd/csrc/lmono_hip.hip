@@ -1124,6 +1124,7 @@ struct lmono_ba_batch {
     int n_windows = 0, total_feat = 0, total_obs = 0;
     int cluster = 1;            // workgroups per window of the last fill (the scratch is sized for it)
     bool big = false;           // a window of the last fill holds more than kBaLdsFeat features: the kBig kernels (per-feature vectors in an L2 scratch)
+    bool flags_clean = false;   // the cluster's flag words and the failure flag are zero (a fill zeroes them; a solve dirties them)
     double *poses0 = nullptr, *ex0 = nullptr, *invd0 = nullptr;   // initial state for lmono_ba_batch_reset
 };
 
@@ -1161,6 +1162,7 @@ struct BaPack {
         }
         if (up) HIP_TRY(c, hipMemcpyAsync(b->blob, b->stage, up, hipMemcpyHostToDevice, c->stream));
         if (zero) HIP_TRY(c, hipMemsetAsync(b->blob + up, 0, zero, c->stream));
+        b->flags_clean = true;
         return LMONO_OK;
     }
 };
@@ -1335,8 +1337,9 @@ extern "C" int lmono_ba_solve(lmono_ctx *c, lmono_ba_batch *b, int max_iteration
     HIP_TRY(c, hipSetDevice(c->device));
     b->v.max_iter = max_iterations;
     if (b->cluster > 1) {
-        // the arrival counters start at zero in every launch
-        HIP_TRY(c, hipMemsetAsync(b->v.bar, 0, (((sizeof(unsigned int) * (size_t)b->n_windows * 16) + 255) & ~(size_t)255) + 256, c->stream));   // (+ the failure flag behind them)
+        // the flag words start at zero in every launch (the first solve after a fill finds them zeroed with the rest of the scratch)
+        if (!b->flags_clean) HIP_TRY(c, hipMemsetAsync(b->v.bar, 0, (((sizeof(unsigned int) * (size_t)b->n_windows * 16) + 255) & ~(size_t)255) + 256, c->stream));   // (+ the failure flag behind them)
+        b->flags_clean = false;
         static const int spread = [] { const char *e = getenv("LMONO_BA_SPREAD"); return e ? atoi(e) : 0; }();      // test hook: a window's workgroups on different XCDs
         const dim3 grid(((b->n_windows + 7) / 8) * 8 * b->cluster);
         if (b->big) hipLaunchKernelGGL((k_ba_solve<true, true>), grid, dim3(kBaT), 0, c->stream, b->v, b->cluster, spread);

@@ -686,7 +686,10 @@ __global__ __launch_bounds__(kMsT) void k_map_solve(const MapStream *streams, in
     }
 }
 
-// workgroups per stream: as many as keep clusters x K within half the chip's 256 CUs (every workgroup of a cluster must be resident while it spins)
+// workgroups per stream: K = 4 (measured best for one stream, below), lowered until clusters x K stay within half the chip's 256 CUs -- every workgroup
+// of a cluster must be resident while it spins; the spin is bounded (a cluster that is not resident sets stats[6] and the host returns LMONO_ENODEV).
+// A stream's partial sums are split by K, so its pose depends at rounding level (1e-12, tests/test_mapping_gpu.py::test_solve_cluster_sizes_agree) on
+// how many streams share the call; the budget assumes the card is not shared with another process's resident workgroups.
 static inline int map_solve_cluster(int n_streams)
 {
     static const int forced = [] { const char *e = getenv("LMONO_MAP_SOLVE_K"); return e ? atoi(e) : 0; }();        // measurement switch

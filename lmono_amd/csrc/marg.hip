@@ -41,6 +41,14 @@ struct MargBatch {
     int *status;                // [W] bit 0: H_mm degenerate (eps cut applied)
 };
 
+// Factor pass (round 5): every sum that many tracks share is reduced inside the wave (butterfly: deterministic) and added by ONE lane to the wave's own
+// slot array; the slots of the waves are added in wave order afterwards.  Until then those sums were LDS atomics on a few dozen addresses that every
+// lane of every wave hit at once: 3.5 M cycles for 43 tracks (`scripts/prof_marg.sh`), and an order of additions that depended on timing.
+// Slot layout per wave: common [90] = bp[6] | br_ex[6] | A (upper triangle, 21) | Wp_ex[36] | H_ex,ex (21); then per frame j = 1..10 [99] =
+// br_j[6] | Wp_j[36] | H_ex,j[36] | H_jj (21).
+constexpr int kMgAccC = 90, kMgAccJ = 99, kMgAcc = kMgAccC + 10 * kMgAccJ;
+constexpr int kMgAccWaves = (kMargMaxF0 + 63) / 64;
+
 struct MargLds {
     double Hrr[kMargN * kMargN];
     union {                             // the eigenvectors are only formed after the last use of W_d
@@ -48,15 +56,76 @@ struct MargLds {
         double V[kMargN * kMargN];
     };
     double Wp[6 * kMargN];              // pose0 rows of H_mr, later G
-    double Y[6 * kMargN];
     double B[6 * kMargMaxF0];
     double D[kMargMaxF0], bd[kMargMaxF0];
-    double A[36], SAi[36], bp[6], u[6], br[kMargN];
-    double cs[2 * 33];
-    double red[2 * 16];
-    int pq[2 * 33];
+    double A[36], bp[6], br[kMargN];
+    union {
+        struct {                        // Schur complement and eigen-decomposition
+            double Y[6 * kMargN];
+            double SAi[36], u[6];
+            double cs[2 * 33];
+            double red[2 * 16];
+            int pq[2 * 33];
+        };
+        struct {                        // factor pass
+            double acc[kMgAccWaves * kMgAcc];
+            double lz[120 + 90];        // LASERFactor(0, 1): g0[6] | g1[6] | J0^T J0 [36] | J0^T J1 [36] | J1^T J1 [36]; then its r[6] | J[84] while they are formed
+        };
+    };
     int flag;
 };
+static_assert(sizeof(MargLds) <= 160 * 1024, "k_marginalize: LDS");
+
+__device__ __forceinline__ int tri6(int a, int b) { const int lo = a < b ? a : b, hi = a < b ? b : a; return lo * (11 - lo) / 2 + hi; }
+// sum over the wave, valid in lane 63: row_shr 1 / 2 / 4 / 8 inside every 16-lane row, row_bcast 15 / 31 across the rows (VALU moves; the LDS-crossbar
+// butterfly of wave_sum_d cost the factor pass 160 k cycles per round of observations); a lane without a source adds 0
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ double dpp_mov_f64(double v)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)u, kCtrl, kRowMask, 0xf, false);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)(u >> 32), kCtrl, kRowMask, 0xf, false);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double wave_sum_d_lane63(double v)
+{
+    v += dpp_mov_f64<0x111, 0xf>(v);
+    v += dpp_mov_f64<0x112, 0xf>(v);
+    v += dpp_mov_f64<0x114, 0xf>(v);
+    v += dpp_mov_f64<0x118, 0xf>(v);
+    v += dpp_mov_f64<0x142, 0xa>(v);
+    v += dpp_mov_f64<0x143, 0xc>(v);
+    return v;
+}
+// the wave's sum of v goes to slot idx of the wave's array (one writer per array: the additions to a slot happen in program order)
+__device__ __forceinline__ void mg_acc(double *acc, int idx, double v, int lane)
+{
+    const double t = wave_sum_d_lane63(v);
+    if (lane == 63) atomicAdd(acc + idx, t);          // ds_add_f64 without a return value: nothing waits for it
+}
+// Jacobi rotation that annihilates a_pq: t = sgn(d) 2 a_pq / (|d| + sqrt(d^2 + 4 a_pq^2)) with d = a_qq - a_pp (the textbook tangent with numerator and
+// denominator multiplied by 2 |a_pq|: one square root and one reciprocal instead of a division, a square root and a division), c = 1 / sqrt(1 + t^2),
+// s = t c.  v_rsq_f64 / v_rcp_f64 with Newton corrections: accurate to rounding, not correctly rounded -- the iteration converges to the same
+// eigen-decomposition, and a round waits for 33 lanes to finish this chain.
+__device__ __forceinline__ double mg_rsqrt(double d)
+{
+    double y = __builtin_amdgcn_rsq(d);
+    const double e = __builtin_fma(-d * y, y, 1.0);
+    return __builtin_fma(y * e, __builtin_fma(e, 0.375, 0.5), y);
+}
+__device__ __forceinline__ void jacobi_cs(double app, double aqq, double apq, double &c, double &s)
+{
+    const double d = aqq - app, a2 = 2.0 * apq;
+    const double x = __builtin_fma(d, d, a2 * a2);
+    const double h = x * mg_rsqrt(x);
+    const double den = fabs(d) + h;
+    double r = __builtin_amdgcn_rcp(den);
+    r = r * __builtin_fma(-den, r, 2.0);
+    r = r * __builtin_fma(-den, r, 2.0);
+    const double t = (d >= 0 ? a2 : -a2) * r;
+    c = mg_rsqrt(__builtin_fma(t, t, 1.0));
+    s = t * c;
+}
 
 __device__ __forceinline__ void marg_corrector(double *r, double *J, int nc, const double rho1, const double rho2)
 {
@@ -72,46 +141,68 @@ __device__ __forceinline__ void marg_corrector(double *r, double *J, int nc, con
     }
 }
 
-// symmetric 6x6 pseudo-inverse with the eps cut (serial Jacobi, one thread)
+// symmetric 6x6 pseudo-inverse with the eps cut (serial Jacobi, one thread; every index is a compile-time constant after unrolling, so the two
+// matrices live in registers -- with run-time indices they lived in scratch memory: ~0.4 M cycles per call)
 __device__ void pinv6(const double *Ain, double *out, double eps, int *degenerate)
 {
     double M[36], Vv[36];
+#pragma unroll
     for (int i = 0; i < 36; i++) { M[i] = Ain[i]; Vv[i] = (i % 7 == 0) ? 1.0 : 0.0; }
     for (int sweep = 0; sweep < 40; sweep++) {
         double offn = 0;
-        for (int p = 0; p < 6; p++) for (int q = p + 1; q < 6; q++) offn += M[p * 6 + q] * M[p * 6 + q];
-        if (offn < 1e-300) break;
+#pragma unroll
         for (int p = 0; p < 6; p++)
+#pragma unroll
+            for (int q = p + 1; q < 6; q++) offn += M[p * 6 + q] * M[p * 6 + q];
+        if (offn < 1e-300) break;
+#pragma unroll
+        for (int p = 0; p < 6; p++)
+#pragma unroll
             for (int q = p + 1; q < 6; q++) {
                 const double apq = M[p * 6 + q];
-                if (apq == 0.0) continue;
-                const double theta = (M[q * 6 + q] - M[p * 6 + p]) / (2.0 * apq);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-                for (int k = 0; k < 6; k++) { const double a = M[k * 6 + p], b = M[k * 6 + q]; M[k * 6 + p] = c * a - s * b; M[k * 6 + q] = s * a + c * b; }
-                for (int k = 0; k < 6; k++) { const double a = M[p * 6 + k], b = M[q * 6 + k]; M[p * 6 + k] = c * a - s * b; M[q * 6 + k] = s * a + c * b; }
-                for (int k = 0; k < 6; k++) { const double a = Vv[k * 6 + p], b = Vv[k * 6 + q]; Vv[k * 6 + p] = c * a - s * b; Vv[k * 6 + q] = s * a + c * b; }
+                if (apq != 0.0) {
+                    double c, s;
+                    jacobi_cs(M[p * 6 + p], M[q * 6 + q], apq, c, s);
+#pragma unroll
+                    for (int k = 0; k < 6; k++) { const double a = M[k * 6 + p], b = M[k * 6 + q]; M[k * 6 + p] = c * a - s * b; M[k * 6 + q] = s * a + c * b; }
+#pragma unroll
+                    for (int k = 0; k < 6; k++) { const double a = M[p * 6 + k], b = M[q * 6 + k]; M[p * 6 + k] = c * a - s * b; M[q * 6 + k] = s * a + c * b; }
+#pragma unroll
+                    for (int k = 0; k < 6; k++) { const double a = Vv[k * 6 + p], b = Vv[k * 6 + q]; Vv[k * 6 + p] = c * a - s * b; Vv[k * 6 + q] = s * a + c * b; }
+                }
             }
     }
+#pragma unroll
     for (int i = 0; i < 36; i++) out[i] = 0.0;
+#pragma unroll
     for (int k = 0; k < 6; k++) {
         const double w = M[k * 6 + k];
         if (!(w > eps)) { *degenerate = 1; continue; }
-        for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) out[i * 6 + j] += Vv[i * 6 + k] * Vv[j * 6 + k] / w;
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = 0; j < 6; j++) out[i * 6 + j] += Vv[i * 6 + k] * Vv[j * 6 + k] / w;
     }
 }
 
 // Parallel (round-robin) Jacobi eigen-decomposition of the symmetric n x n matrix H (n even, leading dimension n) in LDS, eigenvectors accumulated
 // in V: n - 1 rounds of n / 2 disjoint rotations per sweep, until the off-diagonal mass is below 1e-30 of the diagonal's.  kMgT threads.
-// Round 4: a round is TWO phases instead of three -- the rotation angles, then every 2 x 2 block {p_a, q_a} x {p_b, q_b} of H takes pair b's column
-// rotation and pair a's row rotation in one go (column first, then row: the same operations in the same order as the two passes over the whole
-// matrix they replace, so the result is the same bit for bit), next to the column rotation of V.  One barrier and a third of the LDS traffic less.
+// A round is TWO phases -- the rotation angles, then every 2 x 2 block {p_a, q_a} x {p_b, q_b} of H takes pair b's column rotation and pair a's row
+// rotation in one go (column first, then row), next to the column rotation of V.
+// Round 5: a thread's share of a round is FIXED for the whole call -- pair a = tid / G with G = kMgT / (n / 2) threads per pair, which take the blocks
+// b = g, g + G, .. of the pair's block row of H and the rows g, g + G, .. of its two columns of V -- so the pair's indices and its (c, s) are read
+// once per round and nothing is divided inside the loops (the element loops used to spend ~150 instructions per element on k / n, k % n and the
+// index loads).
+constexpr int kJcB = (kMargN / 2 + kMgT / (kMargN / 2) - 1) / (kMgT / (kMargN / 2));      // blocks of a pair's block row per thread (n <= 66: 3 of 33 at 15 threads per pair)
+constexpr int kJcR = (kMargN + kMgT / (kMargN / 2) - 1) / (kMgT / (kMargN / 2));          // rows of V per thread (5 of 66)
 __device__ __forceinline__ void marg_jacobi(double *H, double *V, int n, double *cs, int *pq, double *red, int tid)
 {
     const int N1 = n - 1, half = n / 2;
+    const int G = kMgT / half, pa_i = tid / G, g = tid - pa_i * G;          // n <= kMargN: G >= kMgT / 33, so kJcB blocks and kJcR rows per thread cover every n
     for (int sweep = 0; sweep < 40; sweep++) {
         double offn = 0, dia = 0;
-        for (int k = tid; k < n * n; k += kMgT) { const int a = k / n, bb = k % n; const double v = H[k]; if (a == bb) dia += v * v; else if (a < bb) offn += v * v; }
+        for (int a = tid >> 6; a < n; a += kMgT / 64)             // a wave per row: no division
+            for (int bb = tid & 63; bb < n; bb += 64) { const double v = H[a * n + bb]; if (a == bb) dia += v * v; else if (a < bb) offn += v * v; }
         offn = wave_sum_d(offn); dia = wave_sum_d(dia);
         __syncthreads();
         if ((tid & 63) == 0) { red[tid >> 6] = offn; red[kMgT / 64 + (tid >> 6)] = dia; }
@@ -121,36 +212,48 @@ __device__ __forceinline__ void marg_jacobi(double *H, double *V, int n, double 
         if (offn <= 1e-30 * dia || offn == 0.0) break;
         for (int rnd = 0; rnd < N1; rnd++) {
             if (tid < half) {
-                const int p0 = tid == 0 ? N1 : (rnd + tid) % N1, q0 = tid == 0 ? rnd : (rnd - tid + N1) % N1;
+                int p0 = rnd + tid, q0 = rnd - tid + N1;
+                if (p0 >= N1) p0 -= N1;
+                if (q0 >= N1) q0 -= N1;
+                if (tid == 0) { p0 = N1; q0 = rnd; }
                 const int p = min(p0, q0), q = max(p0, q0);
                 const double apq = H[p * n + q];
+                const double app = H[p * n + p], aqq = H[q * n + q];
                 double c = 1.0, s = 0.0;
-                if (apq != 0.0) {
-                    const double theta = (H[q * n + q] - H[p * n + p]) / (2.0 * apq);
-                    const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                    c = 1.0 / sqrt(t * t + 1.0); s = t * c;
-                }
+                if (apq != 0.0) jacobi_cs(app, aqq, apq, c, s);
                 cs[2 * tid] = c; cs[2 * tid + 1] = s;
                 pq[2 * tid] = p; pq[2 * tid + 1] = q;
             }
             __syncthreads();
-            // H <- R^T (H R), block by block
-            for (int k = tid; k < half * half; k += kMgT) {
-                const int a = k / half, b = k % half;
-                const int pa = pq[2 * a], qa = pq[2 * a + 1], pb = pq[2 * b], qb = pq[2 * b + 1];
-                const double ca = cs[2 * a], sa = cs[2 * a + 1], cb = cs[2 * b], sb = cs[2 * b + 1];
-                const double x0 = H[pa * n + pb], y0 = H[pa * n + qb], x1 = H[qa * n + pb], y1 = H[qa * n + qb];
-                const double t0 = cb * x0 - sb * y0, u0 = sb * x0 + cb * y0, t1 = cb * x1 - sb * y1, u1 = sb * x1 + cb * y1;      // columns p_b, q_b
-                H[pa * n + pb] = ca * t0 - sa * t1; H[qa * n + pb] = sa * t0 + ca * t1;                                            // rows p_a, q_a
-                H[pa * n + qb] = ca * u0 - sa * u1; H[qa * n + qb] = sa * u0 + ca * u1;
-            }
-            // V <- V R
-            for (int k = tid; k < half * n; k += kMgT) {
-                const int pr = k / n, i = k % n;
-                const int p = pq[2 * pr], q = pq[2 * pr + 1];
-                const double c = cs[2 * pr], s = cs[2 * pr + 1];
-                const double va = V[i * n + p], vb = V[i * n + q];
-                V[i * n + p] = c * va - s * vb; V[i * n + q] = s * va + c * vb;
+            if (pa_i < half) {
+                const int pa = pq[2 * pa_i], qa = pq[2 * pa_i + 1];
+                const double ca = cs[2 * pa_i], sa = cs[2 * pa_i + 1];
+                double *Hp = H + pa * n, *Hq = H + qa * n;
+                // every operand of the thread's share is requested before the first result is stored (stores and loads of one array may alias as far as
+                // the compiler knows: element by element the loops were chains of LDS round trips, ~1.7 k cycles per round)
+                int pb[kJcB], qb[kJcB];
+                double cb[kJcB], sb[kJcB], x0[kJcB], y0[kJcB], x1[kJcB], y1[kJcB], va[kJcR], vb[kJcR];
+#pragma unroll
+                for (int u = 0; u < kJcB; u++) { const int b = min(g + u * G, half - 1); pb[u] = pq[2 * b]; qb[u] = pq[2 * b + 1]; cb[u] = cs[2 * b]; sb[u] = cs[2 * b + 1]; }
+#pragma unroll
+                for (int u = 0; u < kJcR; u++) { const int i = min(g + u * G, n - 1); va[u] = V[i * n + pa]; vb[u] = V[i * n + qa]; }
+#pragma unroll
+                for (int u = 0; u < kJcB; u++) { x0[u] = Hp[pb[u]]; y0[u] = Hp[qb[u]]; x1[u] = Hq[pb[u]]; y1[u] = Hq[qb[u]]; }
+                // H <- R^T (H R), block by block
+#pragma unroll
+                for (int u = 0; u < kJcB; u++) {
+                    if (g + u * G < half) {
+                        const double t0 = cb[u] * x0[u] - sb[u] * y0[u], u0 = sb[u] * x0[u] + cb[u] * y0[u], t1 = cb[u] * x1[u] - sb[u] * y1[u], u1 = sb[u] * x1[u] + cb[u] * y1[u];      // columns p_b, q_b
+                        Hp[pb[u]] = ca * t0 - sa * t1; Hq[pb[u]] = sa * t0 + ca * t1;                                                                                               // rows p_a, q_a
+                        Hp[qb[u]] = ca * u0 - sa * u1; Hq[qb[u]] = sa * u0 + ca * u1;
+                    }
+                }
+                // V <- V R
+#pragma unroll
+                for (int u = 0; u < kJcR; u++) {
+                    const int i = g + u * G;
+                    if (i < n) { V[i * n + pa] = ca * va[u] - sa * vb[u]; V[i * n + qa] = sa * va[u] + ca * vb[u]; }
+                }
             }
             __syncthreads();
         }
@@ -166,14 +269,10 @@ __global__ __launch_bounds__(kMgT) void k_marginalize(MargBatch Bt)
     const double *poses = Bt.poses + (size_t)w * 77, *ex = Bt.ex + (size_t)w * 7;
     const double *laser_info = Bt.info, *mono_info = Bt.info + 36;
     const double eps = 1e-8;
-    for (int k = tid; k < kMargN * kMargN; k += kMgT) L.Hrr[k] = 0.0;
     for (int k = tid; k < F0 * kMargN; k += kMgT) L.Wd[k] = 0.0;
-    for (int k = tid; k < 6 * kMargN; k += kMgT) L.Wp[k] = 0.0;
     for (int k = tid; k < 6 * F0; k += kMgT) L.B[k] = 0.0;
     for (int k = tid; k < F0; k += kMgT) { L.D[k] = 0.0; L.bd[k] = 0.0; }
-    if (tid < 36) L.A[tid] = 0.0;
-    if (tid < 6) L.bp[tid] = 0.0;
-    if (tid < kMargN) L.br[tid] = 0.0;
+    for (int k = tid; k < kMgAccWaves * kMgAcc; k += kMgT) L.acc[k] = 0.0;
     if (tid == 0) L.flag = 0;
     __syncthreads();
 #ifdef LMONO_MG_PROF
@@ -181,64 +280,143 @@ __global__ __launch_bounds__(kMgT) void k_marginalize(MargBatch Bt)
 #endif
     // kept-block column of pose j (1..10) and of the extrinsic inside n
     auto col_pose = [](int j) { return 6 + 6 * (j - 1); };
-    if (tid == 0) {
-        double prm[14], r[6], J[84];
-        for (int k = 0; k < 14; k++) prm[k] = poses[k];
-        ba::laser_factor(prm, Bt.laser01 + (size_t)w * 24, laser_info, r, J);
-        const int c1 = col_pose(1);
-        for (int a = 0; a < 6; a++) {
-            double g0 = 0, g1 = 0;
-            for (int k = 0; k < 6; k++) { g0 += J[k * 7 + a] * r[k]; g1 += J[42 + k * 7 + a] * r[k]; }
-            atomicAdd(&L.bp[a], g0); atomicAdd(&L.br[c1 + a], g1);
-            for (int bb = 0; bb < 6; bb++) {
-                double v00 = 0, v01 = 0, v11 = 0;
-                for (int k = 0; k < 6; k++) { v00 += J[k * 7 + a] * J[k * 7 + bb]; v01 += J[k * 7 + a] * J[42 + k * 7 + bb]; v11 += J[42 + k * 7 + a] * J[42 + k * 7 + bb]; }
-                atomicAdd(&L.A[a * 6 + bb], v00); atomicAdd(&L.Wp[a * kMargN + c1 + bb], v01); atomicAdd(&L.Hrr[(c1 + a) * kMargN + c1 + bb], v11);
-            }
+    const int lane = tid & 63;
+    if (tid >= kMgT - 64) {          // LASERFactor(pose0, pose1) on a wave that has no tracks: one lane evaluates it, the wave forms J^T J and J^T r
+        double *stage = L.lz + 120;  // r[6] | J[84]
+        if (tid == kMgT - 64) {
+            double prm[14], r[6], J[84];
+            for (int k = 0; k < 14; k++) prm[k] = poses[k];
+            ba::laser_factor(prm, Bt.laser01 + (size_t)w * 24, laser_info, r, J);
+            for (int k = 0; k < 6; k++) stage[k] = r[k];
+            for (int k = 0; k < 84; k++) stage[6 + k] = J[k];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const double *r = stage, *J = stage + 6;
+        for (int e = lane; e < 120; e += 64) {
+            double v = 0;
+            if (e < 12) { const int a = e % 6, o = e < 6 ? 0 : 42; for (int k = 0; k < 6; k++) v += J[o + k * 7 + a] * r[k]; }
+            else { const int blk = (e - 12) / 36, a = ((e - 12) % 36) / 6, bb = (e - 12) % 6, oa = blk == 2 ? 42 : 0, ob = blk == 0 ? 0 : 42;
+                   for (int k = 0; k < 6; k++) v += J[oa + k * 7 + a] * J[ob + k * 7 + bb]; }
+            L.lz[e] = v;
         }
     }
-    for (int f = tid; f < F0; f += kMgT) {
+    if (tid < kMgAccWaves * 64) {    // a track per lane; the o-th observations of a wave's tracks are evaluated together
+        double *acc = L.acc + (tid >> 6) * kMgAcc;
+        const int f = tid;
+        const bool has = f < F0;
+        const int o0 = has ? Bt.feat_obs_off[f0 + f] : 0, no = has ? Bt.feat_obs_off[f0 + f + 1] - o0 : 0;
+        const int nmax = wave_max_i(no);
         double Df = 0, bdf = 0, Bf[6] = { 0, 0, 0, 0, 0, 0 }, Wx[6] = { 0, 0, 0, 0, 0, 0 };
-        for (int o = Bt.feat_obs_off[f0 + f]; o < Bt.feat_obs_off[f0 + f + 1]; o++) {
-            const int j = Bt.obs_j[o];
-            double prm[22], r[2], J[44];
-            for (int k = 0; k < 7; k++) { prm[k] = ex[k]; prm[7 + k] = poses[k]; prm[14 + k] = poses[7 * j + k]; }
-            prm[21] = Bt.inv_depth[f0 + f];
-            ba::mono_factor(prm, Bt.obs_pts + (size_t)o * 4, mono_info, r, J);
-            const double sq = r[0] * r[0] + r[1] * r[1];
-            const double inv = 1.0 / (1.0 + sq);
-            const double rho1 = inv > DBL_MIN ? inv : DBL_MIN, rho2 = -(inv * inv);
-            marg_corrector(r, J, 7, rho1, rho2); marg_corrector(r, J + 14, 7, rho1, rho2); marg_corrector(r, J + 28, 7, rho1, rho2); marg_corrector(r, J + 42, 1, rho1, rho2);
-            {   // residual scaling
-                const double sr = sqrt(rho1);
-                double scaling = sr;
-                if (!(sq == 0.0 || rho2 <= 0.0)) { const double Dd = 1.0 + 2.0 * sq * rho2 / rho1; scaling = sr / (1.0 - (1.0 - sqrt(Dd))); }
-                r[0] *= scaling; r[1] *= scaling;
-            }
-            const double *Jx = J, *J0 = J + 14, *Jj = J + 28, *Jd = J + 42;
-            const int cj = col_pose(j);
-            for (int a = 0; a < 6; a++) {
-                atomicAdd(&L.bp[a], J0[a] * r[0] + J0[7 + a] * r[1]);
-                atomicAdd(&L.br[a], Jx[a] * r[0] + Jx[7 + a] * r[1]);
-                atomicAdd(&L.br[cj + a], Jj[a] * r[0] + Jj[7 + a] * r[1]);
-                Bf[a] += J0[a] * Jd[0] + J0[7 + a] * Jd[1];
-                Wx[a] += Jd[0] * Jx[a] + Jd[1] * Jx[7 + a];
-                L.Wd[f * kMargN + cj + a] = Jd[0] * Jj[a] + Jd[1] * Jj[7 + a];     // frame j is observed once per track
-                for (int bb = 0; bb < 6; bb++) {
-                    atomicAdd(&L.A[a * 6 + bb], J0[a] * J0[bb] + J0[7 + a] * J0[7 + bb]);
-                    atomicAdd(&L.Wp[a * kMargN + bb], J0[a] * Jx[bb] + J0[7 + a] * Jx[7 + bb]);
-                    atomicAdd(&L.Wp[a * kMargN + cj + bb], J0[a] * Jj[bb] + J0[7 + a] * Jj[7 + bb]);
-                    atomicAdd(&L.Hrr[a * kMargN + bb], Jx[a] * Jx[bb] + Jx[7 + a] * Jx[7 + bb]);
-                    const double xj = Jx[a] * Jj[bb] + Jx[7 + a] * Jj[7 + bb];
-                    atomicAdd(&L.Hrr[a * kMargN + cj + bb], xj); atomicAdd(&L.Hrr[(cj + bb) * kMargN + a], xj);
-                    atomicAdd(&L.Hrr[(cj + a) * kMargN + cj + bb], Jj[a] * Jj[bb] + Jj[7 + a] * Jj[7 + bb]);
+        for (int it = 0; it < nmax; it++) {
+            const bool act = it < no;
+            int j = 0;
+            double r[2] = { 0, 0 }, J[44];
+#pragma unroll
+            for (int k = 0; k < 44; k++) J[k] = 0.0;
+            if (act) {
+                const int o = o0 + it;
+                j = Bt.obs_j[o];
+                double prm[22];
+                for (int k = 0; k < 7; k++) { prm[k] = ex[k]; prm[7 + k] = poses[k]; prm[14 + k] = poses[7 * j + k]; }
+                prm[21] = Bt.inv_depth[f0 + f];
+                ba::mono_factor(prm, Bt.obs_pts + (size_t)o * 4, mono_info, r, J);
+                const double sq = r[0] * r[0] + r[1] * r[1];
+                const double inv = 1.0 / (1.0 + sq);
+                const double rho1 = inv > DBL_MIN ? inv : DBL_MIN, rho2 = -(inv * inv);
+                marg_corrector(r, J, 7, rho1, rho2); marg_corrector(r, J + 14, 7, rho1, rho2); marg_corrector(r, J + 28, 7, rho1, rho2); marg_corrector(r, J + 42, 1, rho1, rho2);
+                {   // residual scaling
+                    const double sr = sqrt(rho1);
+                    double scaling = sr;
+                    if (!(sq == 0.0 || rho2 <= 0.0)) { const double Dd = 1.0 + 2.0 * sq * rho2 / rho1; scaling = sr / (1.0 - (1.0 - sqrt(Dd))); }
+                    r[0] *= scaling; r[1] *= scaling;
                 }
             }
-            Df += Jd[0] * Jd[0] + Jd[1] * Jd[1];
-            bdf += Jd[0] * r[0] + Jd[1] * r[1];
+            const double *Jx = J, *J0 = J + 14, *Jj = J + 28, *Jd = J + 42;
+            // the track's own sums (one writer)
+            if (act) {
+                const int cj = col_pose(j);
+#pragma unroll
+                for (int a = 0; a < 6; a++) {
+                    Bf[a] += J0[a] * Jd[0] + J0[7 + a] * Jd[1];
+                    Wx[a] += Jd[0] * Jx[a] + Jd[1] * Jx[7 + a];
+                    L.Wd[f * kMargN + cj + a] = Jd[0] * Jj[a] + Jd[1] * Jj[7 + a];     // frame j is observed once per track
+                }
+                Df += Jd[0] * Jd[0] + Jd[1] * Jd[1];
+                bdf += Jd[0] * r[0] + Jd[1] * r[1];
+            }
+            // sums every track adds to: pose 0 and the extrinsic (an inactive lane's J and r are zero)
+#pragma unroll
+            for (int a = 0; a < 6; a++) {
+                mg_acc(acc, a, J0[a] * r[0] + J0[7 + a] * r[1], lane);
+                mg_acc(acc, 6 + a, Jx[a] * r[0] + Jx[7 + a] * r[1], lane);
+#pragma unroll
+                for (int bb = 0; bb < 6; bb++) {
+                    if (bb >= a) {
+                        mg_acc(acc, 12 + tri6(a, bb), J0[a] * J0[bb] + J0[7 + a] * J0[7 + bb], lane);
+                        mg_acc(acc, 69 + tri6(a, bb), Jx[a] * Jx[bb] + Jx[7 + a] * Jx[7 + bb], lane);
+                    }
+                    mg_acc(acc, 33 + a * 6 + bb, J0[a] * Jx[bb] + J0[7 + a] * Jx[7 + bb], lane);
+                }
+            }
+            // sums per observing frame: the frames the wave's tracks see in this round, one after the other (almost always one: a track anchored at
+            // frame 0 is seen in frames 1, 2, .. without a gap)
+            unsigned long long todo = __ballot(act);
+            while (todo != 0ull) {
+                const int jj = __shfl(j, (int)__ffsll((long long)todo) - 1);
+                const bool mine = act && j == jj;
+                todo &= ~__ballot(mine);
+                double *aj = acc + kMgAccC + (jj - 1) * kMgAccJ;
+                const double m = mine ? 1.0 : 0.0;
+#pragma unroll
+                for (int a = 0; a < 6; a++) {
+                    mg_acc(aj, a, m * (Jj[a] * r[0] + Jj[7 + a] * r[1]), lane);
+#pragma unroll
+                    for (int bb = 0; bb < 6; bb++) {
+                        mg_acc(aj, 6 + a * 6 + bb, m * (J0[a] * Jj[bb] + J0[7 + a] * Jj[7 + bb]), lane);
+                        mg_acc(aj, 42 + a * 6 + bb, m * (Jx[a] * Jj[bb] + Jx[7 + a] * Jj[7 + bb]), lane);
+                        if (bb >= a) mg_acc(aj, 78 + tri6(a, bb), m * (Jj[a] * Jj[bb] + Jj[7 + a] * Jj[7 + bb]), lane);
+                    }
+                }
+            }
         }
-        L.D[f] = Df; L.bd[f] = bdf;
-        for (int a = 0; a < 6; a++) { L.B[a * kMargMaxF0 + f] = Bf[a]; L.Wd[f * kMargN + a] = Wx[a]; }
+        if (has) {
+            L.D[f] = Df; L.bd[f] = bdf;
+            for (int a = 0; a < 6; a++) { L.B[a * kMargMaxF0 + f] = Bf[a]; L.Wd[f * kMargN + a] = Wx[a]; }
+        }
+    }
+    __syncthreads();
+    // the waves' slots, added in wave order, become A, bp, W_p, b_r and H_rr (+ the LASERFactor's blocks)
+    {
+        auto S = [&](int idx) { double v = L.acc[idx]; for (int wv = 1; wv < kMgAccWaves; wv++) v += L.acc[wv * kMgAcc + idx]; return v; };
+        for (int k = tid; k < kMargN * kMargN; k += kMgT) {
+            const int rr = k / kMargN, cc = k % kMargN;
+            double v = 0.0;
+            if (rr < 6 && cc < 6) v = S(69 + tri6(rr, cc));
+            else if (rr < 6) v = S(kMgAccC + ((cc - 6) / 6) * kMgAccJ + 42 + rr * 6 + (cc - 6) % 6);
+            else if (cc < 6) v = S(kMgAccC + ((rr - 6) / 6) * kMgAccJ + 42 + cc * 6 + (rr - 6) % 6);
+            else if ((rr - 6) / 6 == (cc - 6) / 6) {
+                const int jb = (rr - 6) / 6, a = (rr - 6) % 6, bb = (cc - 6) % 6;
+                v = S(kMgAccC + jb * kMgAccJ + 78 + tri6(a, bb));
+                if (jb == 0) v += L.lz[84 + a * 6 + bb];
+            }
+            L.Hrr[k] = v;
+        }
+        for (int k = tid; k < 6 * kMargN; k += kMgT) {
+            const int a = k / kMargN, cc = k % kMargN;
+            double v = cc < 6 ? S(33 + a * 6 + cc) : S(kMgAccC + ((cc - 6) / 6) * kMgAccJ + 6 + a * 6 + (cc - 6) % 6);
+            if (cc >= 6 && cc < 12) v += L.lz[48 + a * 6 + (cc - 6)];
+            L.Wp[k] = v;
+        }
+        if (tid >= 64 && tid < 64 + kMargN) {
+            const int cc = tid - 64;
+            double v = cc < 6 ? S(6 + cc) : S(kMgAccC + ((cc - 6) / 6) * kMgAccJ + (cc - 6) % 6);
+            if (cc >= 6 && cc < 12) v += L.lz[6 + (cc - 6)];
+            L.br[cc] = v;
+        }
+        if (tid < 36) L.A[tid] = S(12 + tri6(tid / 6, tid % 6)) + L.lz[12 + tid];
+        if (tid >= 36 && tid < 42) L.bp[tid - 36] = S(tid - 36) + L.lz[tid - 36];
     }
     __syncthreads();
 #ifdef LMONO_MG_PROF

@@ -16,11 +16,11 @@ lmono_amd/host/estimator_seq $O/stream600.bin - sync | grep "^MGPROF" > $O/marg_
 rm -f $O/stream600.bin
 python3 - <<PY
 import re
-rows=[[int(x) for x in re.findall(r"\d+", l)] for l in open("$O/marg_phases.txt")]
+rows=[[int(x) for x in re.findall(r"\d+", l)][1:] for l in open("$O/marg_phases.txt")]      # ([0] is the 0 of the label "F0")
 rows.sort(key=lambda r: r[0])
 n=len(rows)
-print("calls", n)
-for lo,hi in ((0,20),(20,60),(60,100),(100,140),(140,161)):
+print("calls", n, "mean cycles: factor %.0f schur %.0f jacobi %.0f, total %.0f, max %d" % (tuple(sum(r[k] for r in rows)/n for k in (2,3,4)) + (sum(r[2]+r[3]+r[4] for r in rows)/n, max(r[2]+r[3]+r[4] for r in rows))))
+for lo,hi in ((0,5),(5,10),(10,20),(20,40),(40,80),(80,161)):
     sel=[r for r in rows if lo<=r[0]<hi]
     if sel:
         m=lambda k: sum(r[k] for r in sel)/len(sel)
