@@ -198,6 +198,11 @@ def bench_map(args):
             m.reset()                      # fresh map per step
         out = np.zeros((n, 7))
         for k in range(n):
+            if B == 1:       # one stream: lmono_mapper_process (cube table on the device, one wait per frame)
+                q1, t1, st1 = mappers[0].process(batch, k, odo[k, :4], odo[k, 4:])
+                out[k, :4] = q1; out[k, 4:] = t1
+                sizes[k] = st1[6:8]
+                continue
             q, t, st = lmono_amd.Mapper.process_batch(ctx, mappers, batches, [k] * B, qs[k], ts[k])
             out[k, :4] = q[-1]; out[k, 4:] = t[-1]
             sizes[k] = st[-1][6:8]

@@ -1882,6 +1882,19 @@ struct lmono_mapper {
     void *jobs = nullptr;           // device scratch for job arrays
     size_t jobs_bytes = 0;
     MapStream *stream_d = nullptr;
+    // device-resident bookkeeping (lmono_mapper_process; the batched entry keeps the tables on the host and converts on entry)
+    bool dev_mode = false;
+    MapDev *dev = nullptr;
+    MapUpd *upd = nullptr;
+    char *fblob[2] = { nullptr, nullptr };      // a frame's control block + job tables on the device, by frame parity
+    char *fstage[2] = { nullptr, nullptr };     // their pinned staging buffers
+    int parity = 0;
+    unsigned int *vk_s[2] = { nullptr, nullptr };   // the scan filter's own workspace (it runs beside the previous frame's map update)
+    int *vi_s[2] = { nullptr, nullptr }, *vws_s[2] = { nullptr, nullptr };
+    int *cube_of_d = nullptr;
+    hipEvent_t ev_commit = nullptr, ev_assign = nullptr, ev_pose = nullptr, ev_solve = nullptr;
+    char *pin_back = nullptr;                   // pinned: the frame's read-back
+    int bump_seen[2] = { 0, 0 }, nmap_seen[2] = { 0, 0 };
 };
 
 template <typename T> static bool mp_alloc(lmono_mapper *m, T *&p, size_t n)
@@ -1896,9 +1909,11 @@ template <typename T> static bool mp_alloc(lmono_mapper *m, T *&p, size_t n)
 extern "C" void lmono_mapper_destroy(lmono_mapper *m)
 {
     if (!m) return;
+    if (m->ctx) (void)hipStreamSynchronize(m->ctx->stream);
     if (m->side) { (void)hipStreamSynchronize(m->side); (void)hipStreamDestroy(m->side); }
     if (m->ev_side) (void)hipEventDestroy(m->ev_side);
     if (m->ev_sizes) (void)hipEventDestroy(m->ev_sizes);
+    for (hipEvent_t e : { m->ev_commit, m->ev_assign, m->ev_pose, m->ev_solve }) if (e) (void)hipEventDestroy(e);
     for (void *q : m->allocs) (void)hipFree(q);
     for (void *q : m->pinned) (void)hipHostFree(q);
     delete m;
@@ -1932,6 +1947,16 @@ extern "C" lmono_mapper *lmono_mapper_create(lmono_ctx *c, float line_res, float
          mp_alloc(m, m->solve_part, (size_t)kMsEvals * kMsMaxK * 28);
     ok = ok && hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&m->ev_side, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&m->ev_sizes, hipEventDisableTiming) == hipSuccess;
+    constexpr size_t kFrameBlob = 4096;
+    ok = ok && mp_alloc(m, m->dev, 1) && mp_alloc(m, m->upd, 1) && mp_alloc(m, m->fblob[0], kFrameBlob) && mp_alloc(m, m->fblob[1], kFrameBlob) && mp_alloc(m, m->cube_of_d, (size_t)2 * kMapStackMax);
+    for (int t = 0; t < 2 && ok; t++)
+        ok = ok && mp_alloc(m, m->vk_s[t], (size_t)2 * kMapStackMax) && mp_alloc(m, m->vi_s[t], (size_t)2 * kMapStackMax) && mp_alloc(m, m->vws_s[t], vox_ws_ints(kMapStackMax));
+    for (hipEvent_t *e : { &m->ev_commit, &m->ev_assign, &m->ev_pose, &m->ev_solve }) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+    if (ok) {
+        void *q = nullptr;
+        ok = hipHostMalloc(&q, 2 * kFrameBlob + 256, hipHostMallocDefault) == hipSuccess;
+        if (ok) { m->pinned.push_back(q); m->fstage[0] = (char *)q; m->fstage[1] = (char *)q + kFrameBlob; m->pin_back = (char *)q + 2 * kFrameBlob; }
+    }
     if (!ok) { c->err = "lmono_mapper_create: device allocation failed"; lmono_mapper_destroy(m); return nullptr; }
     return m;
 }
@@ -1940,6 +1965,9 @@ extern "C" int lmono_mapper_reset(lmono_ctx *c, lmono_mapper *m)
 {
     if (!c || !m) return LMONO_EINVAL;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(m->side));
+    m->dev_mode = false;          // the (empty) table goes back to the device with the next lmono_mapper_process
+    m->bump_seen[0] = m->bump_seen[1] = 0; m->nmap_seen[0] = m->nmap_seen[1] = 0;
     for (int t = 0; t < 2; t++) { m->cube[(size_t)t].assign((size_t)kMapCubes, Seg()); m->half[t] = 0; m->bump[t] = 0; }
     m->cen[0] = 10; m->cen[1] = 10; m->cen[2] = 5;
     m->q_wmap_wodom[0] = m->q_wmap_wodom[1] = m->q_wmap_wodom[2] = 0.0; m->q_wmap_wodom[3] = 1.0;
@@ -2108,6 +2136,219 @@ struct FrameState {            // one stream's frame
 };
 }
 
+// ---- the cube table on the device (lmono_mapper_process) or on the host (lmono_mapper_process_batch, compaction): converted when the other side needs it
+static int mapper_tables_to_host(lmono_ctx *c, lmono_mapper *m)
+{
+    if (!m->dev_mode) return LMONO_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(m->side));
+    std::vector<int2> tab((size_t)2 * kMapCubes);
+    int tail[6];
+    HIP_TRY(c, hipMemcpy(tab.data(), &m->dev->tab[0][0], sizeof(int2) * tab.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(tail, &m->dev->bump[0], sizeof(tail), hipMemcpyDeviceToHost));
+    for (int t = 0; t < 2; t++) {
+        for (int k = 0; k < kMapCubes; k++) { Seg &sg = m->cube[(size_t)t][(size_t)k]; sg.off = tab[(size_t)t * kMapCubes + k].x; sg.n = tab[(size_t)t * kMapCubes + k].y; }
+        m->bump[t] = tail[t];
+    }
+    m->dev_mode = false;
+    if (tail[2]) { c->err = "lmono_mapper: a map update on the device was refused (capacity)"; return LMONO_ECAPACITY; }
+    return LMONO_OK;
+}
+static int mapper_tables_to_device(lmono_ctx *c, lmono_mapper *m)
+{
+    if (m->dev_mode) return LMONO_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::vector<int2> tab((size_t)2 * kMapCubes);
+    for (int t = 0; t < 2; t++)
+        for (int k = 0; k < kMapCubes; k++) { const Seg &sg = m->cube[(size_t)t][(size_t)k]; tab[(size_t)t * kMapCubes + k] = make_int2((int)sg.off, sg.n); }
+    HIP_TRY(c, hipMemcpy(&m->dev->tab[0][0], tab.data(), sizeof(int2) * tab.size(), hipMemcpyHostToDevice));
+    int tail[6] = { (int)m->bump[0], (int)m->bump[1], 0, 0, 0, 0 };
+    HIP_TRY(c, hipMemcpy(&m->dev->bump[0], tail, sizeof(tail), hipMemcpyHostToDevice));
+    CloudJob cj[2];
+    for (int t = 0; t < 2; t++) {
+        cj[t].src = m->neigh[t]; cj[t].n = 0; cj[t].cell = m->cells[t]; cj[t].tcap = m->tcap; cj[t].sorted = m->sorted[t];
+        cj[t].slot_of = m->slot[t]; cj[t].rank_of = m->rank[t]; cj[t].mask_out = m->masks + t; cj[t].bump = m->masks + 2 + t;
+    }
+    HIP_TRY(c, hipMemcpy(&m->dev->cj[0], cj, sizeof(cj), hipMemcpyHostToDevice));
+    m->bump_seen[0] = (int)m->bump[0]; m->bump_seen[1] = (int)m->bump[1];
+    m->dev_mode = true;
+    return LMONO_OK;
+}
+
+// One frame of one mapper with the bookkeeping on the device.  Streams: `side` takes the frame's upload, the scan clouds' voxel filter (beside the
+// previous frame's map update, which is still running on the main stream), then -- behind that update's commit -- the shift of the cube array, the
+// neighbourhood gather and its grids; the main stream takes the optimisation, hands the pose to the host, and goes on with the cube assignment, the
+// update's plan, its copies and filters and the commit while the caller already prepares the next frame.
+static int mapper_process_dev(lmono_ctx *c, lmono_mapper *m, lmono_scan_batch *b, int scan, const double *q_wodom, const double *t_wodom,
+                              double *q_w_curr, double *t_w_curr, int32_t *stats_h)
+{
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream, side = m->side;
+    if (b->feat_h.empty()) {
+        b->feat_h.assign((size_t)b->n_scans * 4, 0);
+        HIP_TRY(c, hipStreamSynchronize(st));
+        HIP_TRY(c, hipMemcpy(b->feat_h.data(), b->v.feat_n, sizeof(int) * 4 * (size_t)b->n_scans, hipMemcpyDeviceToHost));
+    }
+    const int n_last[2] = { b->feat_h[(size_t)scan * 4 + 1], b->feat_h[(size_t)scan * 4 + 3] };
+    if (n_last[0] > kMapStackMax || n_last[1] > kMapStackMax) { c->err = "lmono_mapper: scan cloud too large"; return LMONO_ECAPACITY; }
+    int rc;
+    // arena space: what the host saw last is two updates old; compact (on the host's copy of the table: rare) long before the bump pointer can reach the end
+    for (int t = 0; t < 2; t++)
+        if ((int64_t)m->bump_seen[t] + 2 * ((int64_t)m->nmap_seen[t] + 3 * kMapStackMax) + kMapStackMax > kMapArena) {
+            if ((rc = mapper_tables_to_host(c, m))) return rc;
+            if ((rc = mapper_compact(m, t))) return rc;
+        }
+    if ((rc = mapper_tables_to_device(c, m))) return rc;
+    // ---- host: transformAssociateToMap, centre cube, shifts (on copies: the mapper changes when the frame has succeeded)
+    double x[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tmp[3];
+    mp_qmul(m->q_wmap_wodom, q_wodom, x);
+    mp_qrot(m->q_wmap_wodom, t_wodom, tmp);
+    for (int k = 0; k < 3; k++) x[4 + k] = tmp[k] + m->t_wmap_wodom[k];
+    int cen[3] = { m->cen[0], m->cen[1], m->cen[2] };
+    int cc[3] = { mp_cube_of(x[4], cen[0]), mp_cube_of(x[5], cen[1]), mp_cube_of(x[6], cen[2]) };
+    const int dims[3] = { kMapW, kMapH, kMapD };
+    std::vector<std::pair<int, int>> shifts;
+    for (int a = 0; a < 3; a++) {
+        while (cc[a] < 3) { shifts.push_back({ a, +1 }); cc[a]++; cen[a]++; }
+        while (cc[a] >= dims[a] - 3) { shifts.push_back({ a, -1 }); cc[a]--; cen[a]--; }
+    }
+    // ---- the frame's block: [MapFrame | VoxJob x 2 | tile table | MapStream | AssignJob x 2]
+    const int par = m->parity;
+    char *blob = m->fblob[par], *stage = m->fstage[par];
+    auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    VoxJob vj[2];
+    vj[0].n = n_last[0]; vj[1].n = n_last[1];
+    std::vector<int> tab;
+    vox_tile_table(vj, 2, tab);
+    const size_t o_vox = al(sizeof(MapFrame)), o_tab = al(o_vox + 2 * sizeof(VoxJob)), o_S = al(o_tab + tab.size() * sizeof(int)), o_aj = al(o_S + sizeof(MapStream)),
+                 bytes = o_aj + 2 * sizeof(AssignJob);
+    if (bytes > 4096) { c->err = "lmono_mapper: frame block too large"; return LMONO_ECAPACITY; }
+    MapFrame *F_d = (MapFrame *)blob;
+    memset(stage, 0, bytes);
+    MapFrame *F = (MapFrame *)stage;
+    for (int k = 0; k < 8; k++) F->x[k] = x[k];
+    F->cen[0] = cen[0]; F->cen[1] = cen[1]; F->cen[2] = cen[2];
+    F->n_valid = 0;
+    for (int i = cc[0] - 2; i <= cc[0] + 2; i++)
+        for (int j = cc[1] - 2; j <= cc[1] + 2; j++)
+            for (int k = cc[2] - 1; k <= cc[2] + 1; k++)
+                if (i >= 0 && i < kMapW && j >= 0 && j < kMapH && k >= 0 && k < kMapD) F->valid[F->n_valid++] = i + kMapW * j + kMapW * kMapH * k;
+    for (int t = 0; t < 2; t++) {
+        VoxJob &J = vj[t];
+        J.in = t ? b->v.less_flat + b->off_h[(size_t)scan] : b->v.less_sharp + (size_t)scan * kMaxLessSharp;
+        J.inv_leaf = 1.0f / m->leaf[t]; J.out = m->stack[t]; J.n_out = &F_d->n_stack[t];
+        J.key_a = m->vk_s[t]; J.key_b = m->vk_s[t] + kMapStackMax; J.idx_a = m->vi_s[t]; J.idx_b = m->vi_s[t] + kMapStackMax; J.ws = m->vws_s[t];
+    }
+    memcpy(stage + o_vox, vj, sizeof(vj));
+    if (!tab.empty()) memcpy(stage + o_tab, tab.data(), tab.size() * sizeof(int));
+    MapStream S;
+    memset(&S, 0, sizeof(S));
+    for (int t = 0; t < 2; t++) {
+        S.cell[t] = m->cells[t]; S.sorted[t] = m->sorted[t]; S.cloud[t] = m->neigh[t]; S.mask[t] = m->masks + t; S.n_map[t] = 0;
+        S.stack[t] = m->stack[t]; S.n_stack[t] = 0;
+    }
+    S.n_stack_d = &F_d->n_stack[0]; S.rec = m->rec; S.x = &F_d->x[0]; S.stats = &F_d->stats[0]; S.nn_out = nullptr; S.nn_tmp = m->nn_tmp;
+    S.part = m->solve_part; S.bar = &F_d->bar[0];
+    memcpy(stage + o_S, &S, sizeof(S));
+    AssignJob aj[2];
+    for (int t = 0; t < 2; t++) aj[t] = { m->stack[t], 0, &F_d->n_stack[0], t, &F_d->x[0], cen[0], cen[1], cen[2], m->newpts[t], m->cube_of_d };
+    memcpy(stage + o_aj, aj, sizeof(aj));
+    MapDevCfg cfg;
+    cfg.dev = m->dev; cfg.frame = F_d; cfg.upd = m->upd; cfg.S = (MapStream *)(blob + o_S);
+    for (int t = 0; t < 2; t++) {
+        cfg.arena[t] = m->arena[t][m->half[t]]; cfg.neigh[t] = m->neigh[t]; cfg.cat[t] = m->cat[t]; cfg.newpts[t] = m->newpts[t];
+        cfg.vk[t] = m->vk[t]; cfg.vi[t] = m->vi[t]; cfg.vws[t] = m->vws[t]; cfg.inv_leaf[t] = 1.0f / m->leaf[t];
+    }
+    cfg.vws_cap = (int)m->vws_cap; cfg.cube_of = m->cube_of_d;
+    // ---- side stream: upload, scan filter (behind the previous frame's cube assignment: it reads the stack), then behind the previous commit: shifts, gather, grids
+    HIP_TRY(c, hipMemcpyAsync(blob, stage, bytes, hipMemcpyHostToDevice, side));
+    HIP_TRY(c, hipStreamWaitEvent(side, m->ev_assign, 0));
+    launch_voxel_jobs(side, (const VoxJob *)(blob + o_vox), (const int *)(blob + o_tab), (int)tab.size(), 4);
+    HIP_TRY(c, hipStreamWaitEvent(side, m->ev_commit, 0));
+    for (const std::pair<int, int> &sh : shifts) {
+        HIP_TRY(c, hipMemcpyAsync(&m->dev->tmp[0][0], &m->dev->tab[0][0], sizeof(int2) * 2 * kMapCubes, hipMemcpyDeviceToDevice, side));
+        hipLaunchKernelGGL(k_map_shift, dim3((2 * kMapCubes + 255) / 256), dim3(256), 0, side, m->dev, sh.first, sh.second);
+    }
+    hipLaunchKernelGGL(k_map_plan_gather, dim3(1), dim3(192), 0, side, cfg);
+    hipLaunchKernelGGL(k_copy_jobs_n, dim3(128), dim3(256), 0, side, (const CopyJob *)m->dev->gjobs, (const int *)&m->dev->n_gjobs);
+    {
+        const int est = std::max(65536, std::max(m->nmap_seen[0], m->nmap_seen[1]) * 5 / 4 + 32768);
+        launch_cloud_grids(side, (const CloudJob *)m->dev->cj, 2, est);
+    }
+    HIP_TRY(c, hipEventRecord(m->ev_side, side));
+    // ---- main stream: the optimisation
+    HIP_TRY(c, hipStreamWaitEvent(st, m->ev_side, 0));
+    {
+        const MapStream *S_d = (const MapStream *)(blob + o_S);
+        const int max_nq = n_last[0] + n_last[1];
+        const int per_stream = std::max(1, std::max((max_nq + 31) / 32, std::min((max_nq + 7) / 8, 2048)));
+        for (int outer = 0; outer < 2; outer++) {
+            if (max_nq > 0) {
+                hipLaunchKernelGGL(k_map_correspond, dim3((unsigned)per_stream, 1u), dim3(256), 0, st, S_d, outer);
+                hipLaunchKernelGGL(k_map_factor, dim3((unsigned)std::max(1, (per_stream + 7) / 8), 1u), dim3(64), 0, st, S_d, outer);
+            }
+            launch_map_solve(st, S_d, 1, outer);
+        }
+    }
+    HIP_TRY(c, hipEventRecord(m->ev_solve, st));
+    // the read-back leaves on the side stream (the main stream goes straight on): [x | stats | bar | n_stack | n_map] of the frame, [bump | err | . | last_sum] of the map
+    constexpr size_t kBackA = sizeof(double) * 8 + sizeof(int) * 8 + sizeof(unsigned int) * 16 + sizeof(int) * 4;
+    HIP_TRY(c, hipStreamWaitEvent(side, m->ev_solve, 0));
+    HIP_TRY(c, hipMemcpyAsync(m->pin_back, blob, kBackA, hipMemcpyDeviceToHost, side));
+    HIP_TRY(c, hipMemcpyAsync(m->pin_back + kBackA, &m->dev->bump[0], sizeof(int) * 6, hipMemcpyDeviceToHost, side));
+    HIP_TRY(c, hipEventRecord(m->ev_pose, side));
+    // ---- main stream: the scan joins the map
+    {
+        const int max_n = std::max(n_last[0], n_last[1]);
+        if (max_n > 0) hipLaunchKernelGGL(k_map_assign, dim3((max_n + 255) / 256, 2), dim3(256), 0, st, (const AssignJob *)(blob + o_aj));
+        HIP_TRY(c, hipEventRecord(m->ev_assign, st));
+        hipLaunchKernelGGL(k_map_plan_update, dim3(1), dim3(kMuT), 0, st, cfg);
+        hipLaunchKernelGGL(k_copy_jobs_n, dim3(128), dim3(256), 0, st, (const CopyJob *)m->upd->copy, (const int *)&m->upd->n_copy);
+        int cube_passes = 1;
+        for (int t = 0; t < 2; t++) {
+            const double per_axis = 50.0 / (double)m->leaf[t] + 3.0;
+            int bits = 1;
+            while (bits < 32 && std::ldexp(1.0, bits) < per_axis * per_axis * per_axis) bits++;
+            cube_passes = std::max(cube_passes, std::min(4, (bits + 8) / 9));
+        }
+        launch_voxel_jobs(st, (const VoxJob *)m->upd->vox, (const int *)m->upd->tiles, 160, cube_passes, (const int *)&m->upd->n_tiles);
+        hipLaunchKernelGGL(k_copy_jobs_n, dim3(32), dim3(256), 0, st, (const CopyJob *)m->upd->keep, (const int *)&m->upd->n_keep);
+        hipLaunchKernelGGL(k_map_commit, dim3(1), dim3(kMuH), 0, st, cfg);
+        HIP_TRY(c, hipEventRecord(m->ev_commit, st));
+    }
+    m->parity ^= 1;
+    m->cen[0] = cen[0]; m->cen[1] = cen[1]; m->cen[2] = cen[2];          // the device's table has moved: so has the mapper's centre, whatever the frame's fate
+    // ---- the one wait of the frame
+    HIP_TRY(c, hipEventSynchronize(m->ev_pose));
+    rc = check_launch(c, "mapper kernels");
+    if (rc) return rc;
+    const double *xb = (const double *)m->pin_back;
+    const int *sb = (const int *)(m->pin_back + sizeof(double) * 8);
+    const int *nb = (const int *)(m->pin_back + sizeof(double) * 8 + sizeof(int) * 8 + sizeof(unsigned int) * 16);
+    const int *mb = (const int *)(m->pin_back + kBackA);
+    if (sb[6]) { c->err = "lmono_mapper: a solve's cluster barrier timed out"; return LMONO_ENODEV; }
+    if (nb[0] < 0 || nb[1] < 0) { c->err = "lmono_mapper: voxel filter rejected a scan cloud"; return LMONO_ECAPACITY; }
+    if (mb[2]) { c->err = "lmono_mapper: the map update of an earlier frame was refused on the device (capacity)"; return LMONO_ECAPACITY; }
+    for (int k = 0; k < 4; k++) q_w_curr[k] = xb[k];
+    for (int k = 0; k < 3; k++) t_w_curr[k] = xb[4 + k];
+    if (stats_h) {
+        for (int k = 0; k < 6; k++) stats_h[k] = sb[k];
+        stats_h[6] = nb[2] + nb[3];           // map points of the neighbourhood
+        stats_h[7] = mb[4] + mb[5];           // points of the cubes the PREVIOUS frame's update rebuilt (this frame's update runs behind the return)
+    }
+    m->bump_seen[0] = mb[0]; m->bump_seen[1] = mb[1];
+    m->nmap_seen[0] = nb[2]; m->nmap_seen[1] = nb[3];
+    // transformUpdate; the shifts are the mapper's now
+    {
+        const double n2 = q_wodom[0] * q_wodom[0] + q_wodom[1] * q_wodom[1] + q_wodom[2] * q_wodom[2] + q_wodom[3] * q_wodom[3];
+        const double qi[4] = { -q_wodom[0] / n2, -q_wodom[1] / n2, -q_wodom[2] / n2, q_wodom[3] / n2 };
+        mp_qmul(xb, qi, m->q_wmap_wodom);
+        mp_qrot(m->q_wmap_wodom, t_wodom, tmp);
+        for (int k = 0; k < 3; k++) m->t_wmap_wodom[k] = xb[4 + k] - tmp[k];
+    }
+    return LMONO_OK;
+}
+
 // n mappers (independent streams), each advanced by one frame: every phase is one launch for all streams
 extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *const *ms, lmono_scan_batch *const *bs, const int *scans,
                                           const double *q_wodom, const double *t_wodom, double *q_w_curr, double *t_w_curr, int32_t *stats_h)
@@ -2118,6 +2359,7 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
         for (int u = 0; u < s; u++) if (ms[u] == ms[s]) { c->err = "lmono_mapper_process_batch: a mapper appears twice"; return LMONO_EINVAL; }
     }
     HIP_TRY(c, hipSetDevice(c->device));
+    for (int s = 0; s < n; s++) { const int rcv = mapper_tables_to_host(c, ms[s]); if (rcv) return rcv; }
     hipStream_t st = c->stream;
     JobScratch js{ ms[0] };
     HIP_TRY(c, hipStreamSynchronize(st));        // the previous frame's kernels are done with the job scratch (normally a no-op: a frame ends with a read-back)
@@ -2539,14 +2781,23 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
 extern "C" int lmono_mapper_process(lmono_ctx *c, lmono_mapper *m, lmono_scan_batch *b, int scan, const double q_wodom[4], const double t_wodom[3],
                                     double q_w_curr[4], double t_w_curr[3], int32_t *stats_h)
 {
-    if (!m || !b) return LMONO_EINVAL;
-    return lmono_mapper_process_batch(c, 1, &m, &b, &scan, q_wodom, t_wodom, q_w_curr, t_w_curr, stats_h);
+    if (!c || !m || !b || !q_wodom || !t_wodom || !q_w_curr || !t_w_curr) return LMONO_EINVAL;
+    if (!b->registered || scan < 0 || scan >= b->n_scans) return LMONO_EINVAL;
+    static const bool host_tables = getenv("LMONO_MAP_HOST_TABLES") != nullptr;       // measurement switch: the round-4 frame (cube table on the host, two waits)
+    if (host_tables) return lmono_mapper_process_batch(c, 1, &m, &b, &scan, q_wodom, t_wodom, q_w_curr, t_w_curr, stats_h);
+    return mapper_process_dev(c, m, b, scan, q_wodom, t_wodom, q_w_curr, t_w_curr, stats_h);
 }
 
 extern "C" int lmono_mapper_cube(lmono_ctx *c, lmono_mapper *m, int which, int i, int j, int k, float *out_h, int cap)
 {
     if (!c || !m || which < 0 || which > 1 || i < 0 || i >= kMapW || j < 0 || j >= kMapH || k < 0 || k >= kMapD) return LMONO_EINVAL;
-    const Seg &s = m->cube[(size_t)which][(size_t)(i + kMapW * j + kMapW * kMapH * k)];
+    Seg s = m->cube[(size_t)which][(size_t)(i + kMapW * j + kMapW * kMapH * k)];
+    if (m->dev_mode) {          // the table is on the device: behind the last frame's map update
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        int2 e;
+        HIP_TRY(c, hipMemcpy(&e, &m->dev->tab[which][i + kMapW * j + kMapW * kMapH * k], sizeof(e), hipMemcpyDeviceToHost));
+        s.off = e.x; s.n = e.y;
+    }
     if (!out_h) return s.n;
     if (s.n > cap) return LMONO_ECAPACITY;
     HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -761,9 +761,8 @@ __device__ __forceinline__ VoxView vox_view(const VoxJob &J)
 }
 
 // per-tile bounding boxes
-__global__ __launch_bounds__(kVxT) void k_vox_box(const VoxJob *jobs, const int *tile_tab)
+__device__ __forceinline__ void vox_box_tile(const VoxJob *jobs, const int entry)
 {
-    const int entry = tile_tab[blockIdx.x];
     const VoxJob J = jobs[entry >> 6];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = J.n, tile = entry & 63;
     if (n <= 0 || n > kVoxCloudMax) { if (tile == 0 && tid == 0) *J.n_out = n <= 0 ? 0 : -1; return; }
@@ -795,9 +794,8 @@ __global__ __launch_bounds__(kVxT) void k_vox_box(const VoxJob *jobs, const int 
 }
 
 // cell keys in index order + the tile's digit counts of pass 0
-__global__ __launch_bounds__(kVxT) void k_vox_keys(const VoxJob *jobs, const int *tile_tab)
+__device__ __forceinline__ void vox_keys_tile(const VoxJob *jobs, const int entry)
 {
-    const int entry = tile_tab[blockIdx.x];
     const VoxJob J = jobs[entry >> 6];
     const int tid = threadIdx.x, n = J.n, tile = entry & 63;
     if (n <= 0 || n > kVoxCloudMax) return;
@@ -856,9 +854,8 @@ __global__ __launch_bounds__(kVxT) void k_vox_keys(const VoxJob *jobs, const int
 }
 
 // digit counts of one tile for pass `pass` (pass 0's come from k_vox_keys)
-__global__ __launch_bounds__(kVxT) void k_vox_count(const VoxJob *jobs, const int *tile_tab, int pass)
+__device__ __forceinline__ void vox_count_tile(const VoxJob *jobs, const int entry, int pass)
 {
-    const int entry = tile_tab[blockIdx.x];
     const VoxJob J = jobs[entry >> 6];
     const int tid = threadIdx.x, n = J.n, tile = entry & 63;
     if (n <= 0 || n > kVoxCloudMax) return;
@@ -884,9 +881,8 @@ __global__ __launch_bounds__(kVxT) void k_vox_count(const VoxJob *jobs, const in
 }
 
 // one stable pass over one tile
-__global__ __launch_bounds__(kVxT) void k_vox_pass(const VoxJob *jobs, const int *tile_tab, int pass)
+__device__ __forceinline__ void vox_pass_tile(const VoxJob *jobs, const int entry, int pass)
 {
-    const int entry = tile_tab[blockIdx.x];
     const VoxJob J = jobs[entry >> 6];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = J.n, tile = entry & 63;
     if (n <= 0 || n > kVoxCloudMax) return;
@@ -975,9 +971,8 @@ __global__ __launch_bounds__(kVxT) void k_vox_pass(const VoxJob *jobs, const int
 }
 
 // run heads of a tile
-__global__ __launch_bounds__(kVxT) void k_vox_heads(const VoxJob *jobs, const int *tile_tab, int max_passes)
+__device__ __forceinline__ void vox_heads_tile(const VoxJob *jobs, const int entry, int max_passes)
 {
-    const int entry = tile_tab[blockIdx.x];
     const VoxJob J = jobs[entry >> 6];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = J.n, tile = entry & 63;
     if (n <= 0 || n > kVoxCloudMax) return;
@@ -1001,9 +996,8 @@ __global__ __launch_bounds__(kVxT) void k_vox_heads(const VoxJob *jobs, const in
 }
 
 // runs of equal cells -> centroids, in ascending cell order
-__global__ __launch_bounds__(kVxT) void k_vox_centroids(const VoxJob *jobs, const int *tile_tab, int max_passes)
+__device__ __forceinline__ void vox_centroids_tile(const VoxJob *jobs, const int entry, int max_passes)
 {
-    const int entry = tile_tab[blockIdx.x];
     const VoxJob J = jobs[entry >> 6];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = J.n, tile = entry & 63;
     if (n <= 0 || n > kVoxCloudMax) return;
@@ -1116,6 +1110,39 @@ __global__ __launch_bounds__(kVxT) void k_vox_centroids(const VoxJob *jobs, cons
     }
 }
 
+// The kernels: one workgroup per entry of the tile table -- or, when the table was written by the device (n_tiles_d: its length, the laserMapping frame's map
+// update), a fixed number of workgroups that stride over it.
+__global__ __launch_bounds__(kVxT) void k_vox_box(const VoxJob *jobs, const int *tile_tab, const int *n_tiles_d)
+{
+    if (!n_tiles_d) { vox_box_tile(jobs, tile_tab[blockIdx.x]); return; }
+    for (int t = blockIdx.x, nt = *n_tiles_d; t < nt; t += gridDim.x) { vox_box_tile(jobs, tile_tab[t]); __syncthreads(); }
+}
+__global__ __launch_bounds__(kVxT) void k_vox_keys(const VoxJob *jobs, const int *tile_tab, const int *n_tiles_d)
+{
+    if (!n_tiles_d) { vox_keys_tile(jobs, tile_tab[blockIdx.x]); return; }
+    for (int t = blockIdx.x, nt = *n_tiles_d; t < nt; t += gridDim.x) { vox_keys_tile(jobs, tile_tab[t]); __syncthreads(); }
+}
+__global__ __launch_bounds__(kVxT) void k_vox_count(const VoxJob *jobs, const int *tile_tab, int pass, const int *n_tiles_d)
+{
+    if (!n_tiles_d) { vox_count_tile(jobs, tile_tab[blockIdx.x], pass); return; }
+    for (int t = blockIdx.x, nt = *n_tiles_d; t < nt; t += gridDim.x) { vox_count_tile(jobs, tile_tab[t], pass); __syncthreads(); }
+}
+__global__ __launch_bounds__(kVxT) void k_vox_pass(const VoxJob *jobs, const int *tile_tab, int pass, const int *n_tiles_d)
+{
+    if (!n_tiles_d) { vox_pass_tile(jobs, tile_tab[blockIdx.x], pass); return; }
+    for (int t = blockIdx.x, nt = *n_tiles_d; t < nt; t += gridDim.x) { vox_pass_tile(jobs, tile_tab[t], pass); __syncthreads(); }
+}
+__global__ __launch_bounds__(kVxT) void k_vox_heads(const VoxJob *jobs, const int *tile_tab, int max_passes, const int *n_tiles_d)
+{
+    if (!n_tiles_d) { vox_heads_tile(jobs, tile_tab[blockIdx.x], max_passes); return; }
+    for (int t = blockIdx.x, nt = *n_tiles_d; t < nt; t += gridDim.x) { vox_heads_tile(jobs, tile_tab[t], max_passes); __syncthreads(); }
+}
+__global__ __launch_bounds__(kVxT) void k_vox_centroids(const VoxJob *jobs, const int *tile_tab, int max_passes, const int *n_tiles_d)
+{
+    if (!n_tiles_d) { vox_centroids_tile(jobs, tile_tab[blockIdx.x], max_passes); return; }
+    for (int t = blockIdx.x, nt = *n_tiles_d; t < nt; t += gridDim.x) { vox_centroids_tile(jobs, tile_tab[t], max_passes); __syncthreads(); }
+}
+
 // One workgroup per entry of the tile table: (job << 6) | tile, every tile of every job (a job without points keeps one entry: its count must be
 // written).  Built on the host next to the job table and uploaded with it.
 static inline void vox_tile_table(const VoxJob *jobs, size_t n_jobs, std::vector<int> &tab)
@@ -1129,18 +1156,18 @@ static inline void vox_tile_table(const VoxJob *jobs, size_t n_jobs, std::vector
 
 // the launches of a table of voxel jobs; max_passes = the passes to launch (4 covers every 32-bit key; a job that needs more than were launched
 // comes back rejected)
-static inline void launch_voxel_jobs(hipStream_t st, const VoxJob *jobs_d, const int *tab_d, int n_tiles, int max_passes)
+static inline void launch_voxel_jobs(hipStream_t st, const VoxJob *jobs_d, const int *tab_d, int n_tiles, int max_passes, const int *n_tiles_d = nullptr)
 {
     if (n_tiles <= 0) return;
     const dim3 g((unsigned)n_tiles), b(kVxT);
-    hipLaunchKernelGGL(k_vox_box, g, b, 0, st, jobs_d, tab_d);
-    hipLaunchKernelGGL(k_vox_keys, g, b, 0, st, jobs_d, tab_d);
+    hipLaunchKernelGGL(k_vox_box, g, b, 0, st, jobs_d, tab_d, n_tiles_d);
+    hipLaunchKernelGGL(k_vox_keys, g, b, 0, st, jobs_d, tab_d, n_tiles_d);
     for (int pass = 0; pass < max_passes; pass++) {
-        if (pass > 0) hipLaunchKernelGGL(k_vox_count, g, b, 0, st, jobs_d, tab_d, pass);
-        hipLaunchKernelGGL(k_vox_pass, g, b, 0, st, jobs_d, tab_d, pass);
+        if (pass > 0) hipLaunchKernelGGL(k_vox_count, g, b, 0, st, jobs_d, tab_d, pass, n_tiles_d);
+        hipLaunchKernelGGL(k_vox_pass, g, b, 0, st, jobs_d, tab_d, pass, n_tiles_d);
     }
-    hipLaunchKernelGGL(k_vox_heads, g, b, 0, st, jobs_d, tab_d, max_passes);
-    hipLaunchKernelGGL(k_vox_centroids, g, b, 0, st, jobs_d, tab_d, max_passes);
+    hipLaunchKernelGGL(k_vox_heads, g, b, 0, st, jobs_d, tab_d, max_passes, n_tiles_d);
+    hipLaunchKernelGGL(k_vox_centroids, g, b, 0, st, jobs_d, tab_d, max_passes, n_tiles_d);
 }
 
 } // namespace lmono
@@ -1195,6 +1222,353 @@ __global__ __launch_bounds__(256) void k_scatter_pos(const ScatterJob *jobs)
     const ScatterJob J = jobs[blockIdx.y];
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < J.n && J.pos[i] >= 0) J.dst[J.pos[i]] = J.src[i];
+}
+
+} // namespace lmono
+
+// ---- device-resident cube bookkeeping (round 5): the (offset, count) table of the 21 x 21 x 11 cubes, the neighbourhood gather and the plan of a frame's
+// map update on the device.  With the table on the host (rounds 2-4) a frame waited twice for the device: once for the cube index of every stack point
+// (the host planned the update from them), once for the sizes of the re-filtered cubes (the next frame's gather needs them).  Now the host enqueues the
+// whole frame, waits ONCE for the refined pose, and the map update runs behind that wait, beside the caller and the next frame's scan filter.
+namespace lmono {
+
+constexpr int kMdW = 21, kMdH = 21, kMdD = 11, kMdCubes = kMdW * kMdH * kMdD;
+constexpr int kMdValidMax = 75;              // 5 x 5 x 3 neighbourhood
+constexpr int kMdTouched = 256;              // cubes one frame's update may touch, per cloud type (the neighbourhood + cubes outside it that receive points)
+constexpr int kMdNeighMax = 1 << 20;         // = kMapNeighMax of the host side
+constexpr int kMdArena = 6 << 20;            // = kMapArena
+constexpr int kMdCatMax = kMdNeighMax + kVoxCloudMax;
+constexpr int kMdGJobs = 2 * (kMdNeighMax / 4096 + kMdValidMax);          // chunks of at most 4096 points
+constexpr int kMdCopy = 2 * (kMdNeighMax / 4096 + kMdTouched);
+constexpr int kMdKeep = 2 * (kVoxCloudMax / 4096 + kMdTouched);
+constexpr int kMdTiles = 2 * (kMdCatMax / kVxTile + kMdTouched);
+constexpr int kMdErrTouched = 1, kMdErrCat = 2, kMdErrCube = 4, kMdErrWs = 8, kMdErrArena = 16, kMdErrNeigh = 32, kMdErrFilter = 64, kMdErrTables = 128;
+
+struct MapDev {                              // one per mapper, lives as long as it does
+    int2 tab[2][kMdCubes];                   // (offset into the live arena half, points) of every cube
+    int2 tmp[2][kMdCubes];                   // the table before a shift
+    int bump[2];                             // first free point of the live half
+    int err;                                 // sticky error bits of the updates (kMdErr*)
+    int n_gjobs;
+    int last_sum[2];                         // points of the cubes the last update touched, per type   (bump .. last_sum: one read-back)
+    CopyJob gjobs[kMdGJobs];                 // the neighbourhood gather
+    CloudJob cj[2];                          // its grids (everything but n is constant)
+};
+struct MapFrame {                            // one per frame, uploaded by the host (two buffers, by frame parity)
+    double x[8];                             // in: predicted pose, out: refined pose (the solve's S.x)
+    int stats[8];
+    unsigned int bar[16];
+    int n_stack[2];                          // the scan filter's counts
+    int n_map[2];                            // out: sizes of the neighbourhood clouds
+    int cen[3], n_valid;
+    int valid[kMdValidMax + 1];
+};
+struct MapUpd {                              // tables of one frame's update, written by k_map_plan_update
+    int n_touched[2], sum_in[2];
+    int n_copy, n_vox, n_tiles, n_keep, err, pad[3];
+    int t_ind[2][kMdTouched], t_nin[2][kMdTouched], t_newoff[2][kMdTouched], t_job[2][kMdTouched];
+    int nout[2 * kMdTouched];
+    VoxJob vox[2 * kMdTouched];
+    int tiles[kMdTiles];
+    CopyJob copy[kMdCopy];
+    CopyJob keep[kMdKeep];
+};
+struct MapDevCfg {                           // kernel argument
+    MapDev *dev;
+    MapFrame *frame;
+    MapUpd *upd;
+    MapStream *S;
+    float4 *arena[2], *neigh[2], *cat[2], *newpts[2];
+    unsigned int *vk[2];
+    int *vi[2], *vws[2];
+    int vws_cap;
+    float inv_leaf[2];
+    const int *cube_of;                      // [n_stack[0] | n_stack[1]] cube index of every stack point (k_map_assign)
+};
+
+// the cube array moves by one cube along an axis (laserMapping's pointer rotation): tab[i] = tmp[i - dir]; the cubes that enter are empty
+__global__ __launch_bounds__(256) void k_map_shift(MapDev *dev, int axis, int dir)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * kMdCubes) return;
+    const int t = i / kMdCubes, c = i - t * kMdCubes;
+    int ijk[3] = { c % kMdW, (c / kMdW) % kMdH, c / (kMdW * kMdH) };
+    const int n[3] = { kMdW, kMdH, kMdD };
+    ijk[axis] -= dir;
+    int2 v = make_int2(0, 0);
+    if (ijk[axis] >= 0 && ijk[axis] < n[axis]) v = dev->tmp[t][ijk[0] + kMdW * ijk[1] + kMdW * kMdH * ijk[2]];
+    dev->tab[t][c] = v;
+}
+
+// the cubes of the neighbourhood, in validInd order, become the two map clouds: copy jobs, sizes for the grids and the optimisation
+__global__ __launch_bounds__(192) void k_map_plan_gather(MapDevCfg cfg)
+{
+    __shared__ int2 s_seg[2][kMdValidMax + 1];
+    MapDev *dev = cfg.dev;
+    const MapFrame *F = cfg.frame;
+    const int tid = threadIdx.x, nv = F->n_valid;
+    if (tid < 2 * kMdValidMax) {
+        const int t = tid / kMdValidMax, v = tid - t * kMdValidMax;
+        s_seg[t][v] = v < nv ? dev->tab[t][F->valid[v]] : make_int2(0, 0);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int nj = 0, err = 0;
+        for (int t = 0; t < 2; t++) {
+            int at = 0;
+            for (int v = 0; v < nv; v++) {
+                const int2 sg = s_seg[t][v];
+                if (sg.y <= 0) continue;
+                if (at + sg.y > kMdNeighMax) { err |= kMdErrNeigh; break; }
+                for (int o = 0; o < sg.y; o += 4096) {
+                    CopyJob J; J.src = cfg.arena[t] + sg.x + o; J.dst = cfg.neigh[t] + at + o; J.n = min(4096, sg.y - o);
+                    dev->gjobs[nj++] = J;
+                }
+                at += sg.y;
+            }
+            dev->cj[t].n = at;
+            cfg.S->n_map[t] = at;
+            cfg.frame->n_map[t] = at;
+        }
+        dev->n_gjobs = nj;
+        if (err) atomicOr(&dev->err, err);
+    }
+}
+
+// jobs[0 .. *n_jobs): dst[0..n) = src[0..n), the workgroups stride over the table
+__global__ __launch_bounds__(256) void k_copy_jobs_n(const CopyJob *jobs, const int *n_jobs)
+{
+    const int nj = *n_jobs;
+    for (int j = blockIdx.x; j < nj; j += gridDim.x) {
+        const CopyJob J = jobs[j];
+        for (int i = threadIdx.x; i < J.n; i += 256) J.dst[i] = J.src[i];
+    }
+}
+
+// The plan of a frame's map update, both cloud types in one workgroup (threads 0..511: corner, 512..1023: surf).  Per type: how many stack points
+// fall into every cube; the touched cubes in ascending cube order -- the neighbourhood's non-empty cubes and every other cube that receives points --;
+// [old points | new points in stack order] of every touched cube laid out in `cat` (the new points are placed here; the old ones by copy jobs);
+// fresh arena space behind the bump pointer; a voxel-filter job per touched cube of the neighbourhood, a plain copy for the others.
+constexpr int kMuT = 1024, kMuH = 512, kMuW = kMuH / 64;
+__global__ __launch_bounds__(kMuT) void k_map_plan_update(MapDevCfg cfg)
+{
+    __shared__ int s_add[2][kMdCubes];
+    __shared__ short s_slot[2][kMdCubes];
+    __shared__ unsigned char s_isv[kMdCubes];
+    __shared__ int s_ind[2][kMdTouched], s_nold[2][kMdTouched], s_nadd[2][kMdTouched], s_cat[2][kMdTouched], s_oldoff[2][kMdTouched];
+    __shared__ int s_base[2][kMdTouched][5];        // first copy job, filter job, tile, workspace int, keep job of every touched cube (type-local)
+    __shared__ int s_wh[2][kMuW][kMdTouched];
+    __shared__ int s_wtot[2][kMuW], s_nt[2], s_tot[2][6], s_err;
+    MapDev *dev = cfg.dev;
+    MapUpd *U = cfg.upd;
+    const MapFrame *F = cfg.frame;
+    const int tid = threadIdx.x, t = tid >> 9, lt = tid & (kMuH - 1), wv = lt >> 6, lane = tid & 63;
+    const int ns0 = max(F->n_stack[0], 0), ns1 = max(F->n_stack[1], 0);
+    const int n_st = t ? ns1 : ns0;
+    const int *cube = cfg.cube_of + (t ? ns0 : 0);
+    const unsigned long long ltm = (1ull << lane) - 1ull;
+    for (int k = tid; k < 2 * kMdCubes; k += kMuT) { (&s_add[0][0])[k] = 0; (&s_slot[0][0])[k] = (short)-1; }
+    for (int k = tid; k < kMdCubes; k += kMuT) s_isv[k] = 0;
+    for (int k = tid; k < 2 * kMuW * kMdTouched; k += kMuT) (&s_wh[0][0][0])[k] = 0;
+    if (tid == 0) s_err = 0;
+    __syncthreads();
+    if (tid < F->n_valid) s_isv[F->valid[tid]] = 1;
+    // 1. points per cube (lanes with the same cube add once)
+    for (int i0 = wv * 64; i0 < n_st; i0 += kMuH) {
+        const int i = i0 + lane, c = i < n_st ? cube[i] : -1;
+        unsigned long long todo = __ballot(c >= 0);
+        while (todo != 0ull) {
+            const int lead = (int)__ffsll((long long)todo) - 1, cc = __shfl(c, lead);
+            const unsigned long long m = __ballot(c == cc);
+            if (lane == lead) atomicAdd(&s_add[t][cc], (int)__popcll(m));
+            todo &= ~m;
+        }
+    }
+    __syncthreads();
+    // 2. the touched cubes, ascending: ten cubes per thread, their flags counted and placed through a scan of the type's 512 threads
+    {
+        const int c0 = lt * 10;
+        int2 seg[10];
+        int cnt = 0;
+        unsigned int fl = 0;
+#pragma unroll
+        for (int u = 0; u < 10; u++) {
+            const int c = c0 + u;
+            seg[u] = c < kMdCubes ? dev->tab[t][c] : make_int2(0, 0);
+            const int ad = c < kMdCubes ? s_add[t][c] : 0;
+            const bool need = c < kMdCubes && (s_isv[c] ? seg[u].y + ad > 0 : ad > 0);
+            if (need) { fl |= 1u << u; cnt++; }
+        }
+        const int incl = wave_scan_incl(cnt);
+        if (lane == 63) s_wtot[t][wv] = incl;
+        __syncthreads();
+        int at = incl - cnt;
+        for (int w = 0; w < wv; w++) at += s_wtot[t][w];
+        if (lt == kMuH - 1) s_nt[t] = at + cnt;
+#pragma unroll
+        for (int u = 0; u < 10; u++)
+            if (fl & (1u << u)) {
+                if (at < kMdTouched) { s_ind[t][at] = c0 + u; s_nold[t][at] = seg[u].y; s_nadd[t][at] = s_add[t][c0 + u]; s_oldoff[t][at] = seg[u].x; s_slot[t][c0 + u] = (short)at; }
+                at++;
+            }
+    }
+    __syncthreads();
+    if (lt == 0 && s_nt[t] > kMdTouched) atomicOr(&s_err, kMdErrTouched);
+    const int nt = min(s_nt[t], kMdTouched);
+    // 3. running sums over the touched cubes (wave 0 of the type, four cubes per lane): place in `cat`, copy jobs of the old points, filter jobs, tiles,
+    // workspace, plain copies
+    if (wv == 0) {
+        int nin[4], q[4][6], loc[6] = { 0, 0, 0, 0, 0, 0 };
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int k = 4 * lane + u;
+            const bool on = k < nt;
+            const int nold = on ? s_nold[t][k] : 0;
+            nin[u] = on ? nold + s_nadd[t][k] : 0;
+            const bool filt = on && s_isv[s_ind[t][k]] != 0;
+            if (filt && nin[u] > kVoxCloudMax) atomicOr(&s_err, kMdErrCube);
+            q[u][0] = nin[u];
+            q[u][1] = (nold + 4095) / 4096;
+            q[u][2] = filt ? 1 : 0;
+            q[u][3] = filt ? max(1, (nin[u] + kVxTile - 1) / kVxTile) : 0;
+            q[u][4] = filt ? kVxHdr + max(1, (nin[u] + kVxTile - 1) / kVxTile) * kVxWsTile : 0;
+            q[u][5] = (on && !filt) ? (nin[u] + 4095) / 4096 : 0;
+#pragma unroll
+            for (int z = 0; z < 6; z++) loc[z] += q[u][z];
+        }
+        int run[6];
+#pragma unroll
+        for (int z = 0; z < 6; z++) { const int incl = wave_scan_incl(loc[z]); run[z] = incl - loc[z]; if (lane == 63) s_tot[t][z] = incl; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int k = 4 * lane + u;
+            if (k < nt) {
+                s_base[t][k][0] = run[1]; s_base[t][k][1] = q[u][2] ? run[2] : -1; s_base[t][k][2] = run[3]; s_base[t][k][3] = run[4]; s_base[t][k][4] = run[5];
+                s_cat[t][k] = run[0];
+            }
+#pragma unroll
+            for (int z = 0; z < 6; z++) run[z] += q[u][z];
+        }
+    }
+    __syncthreads();
+    if (lt == 0) {
+        int e = 0;
+        if (s_tot[t][0] > kMdCatMax) e |= kMdErrCat;
+        if (s_tot[t][4] > cfg.vws_cap) e |= kMdErrWs;
+        if (dev->bump[t] + s_tot[t][0] > kMdArena) e |= kMdErrArena;
+        if (e) atomicOr(&s_err, e);
+    }
+    if (tid == 0) {
+        int e = 0;
+        if (s_tot[0][1] + s_tot[1][1] > kMdCopy || s_tot[0][5] + s_tot[1][5] > kMdKeep || s_tot[0][3] + s_tot[1][3] > kMdTiles) e |= kMdErrTables;
+        if (e) atomicOr(&s_err, e);
+    }
+    __syncthreads();
+    const int err = s_err;
+    if (err) {           // nothing of this update runs; the table keeps the map as it was
+        if (tid == 0) { U->n_touched[0] = U->n_touched[1] = 0; U->sum_in[0] = U->sum_in[1] = 0; U->n_copy = U->n_vox = U->n_tiles = U->n_keep = 0; U->err = err; atomicOr(&dev->err, err); }
+        return;
+    }
+    // 4. the tables
+    {
+        const int b_copy = t ? s_tot[0][1] : 0, b_vox = t ? s_tot[0][2] : 0, b_tile = t ? s_tot[0][3] : 0, b_keep = t ? s_tot[0][5] : 0;
+        const int bump = dev->bump[t];
+        for (int k = lt; k < nt; k += kMuH) {
+            const int ind = s_ind[t][k], nold = s_nold[t][k], nin = nold + s_nadd[t][k], coff = s_cat[t][k];
+            const int old_off = s_oldoff[t][k];
+            const int job = s_base[t][k][1] >= 0 ? b_vox + s_base[t][k][1] : -1;
+            U->t_ind[t][k] = ind; U->t_nin[t][k] = nin; U->t_newoff[t][k] = bump + coff; U->t_job[t][k] = job;
+            for (int o = 0, j = b_copy + s_base[t][k][0]; o < nold; o += 4096, j++) {
+                CopyJob J; J.src = cfg.arena[t] + old_off + o; J.dst = cfg.cat[t] + coff + o; J.n = min(4096, nold - o);
+                U->copy[j] = J;
+            }
+            float4 *dst = cfg.arena[t] + bump + coff;
+            if (job >= 0) {
+                VoxJob J;
+                J.in = cfg.cat[t] + coff; J.n = nin; J.inv_leaf = cfg.inv_leaf[t]; J.out = dst; J.n_out = U->nout + job;
+                J.key_a = cfg.vk[t] + 2 * coff; J.key_b = J.key_a + nin; J.idx_a = cfg.vi[t] + 2 * coff; J.idx_b = J.idx_a + nin;
+                J.ws = cfg.vws[t] + s_base[t][k][3];
+                U->vox[job] = J;
+                const int tiles = max(1, (nin + kVxTile - 1) / kVxTile);
+                for (int q = 0; q < tiles; q++) U->tiles[b_tile + s_base[t][k][2] + q] = (job << 6) | q;
+            } else {
+                for (int o = 0, j = b_keep + s_base[t][k][4]; o < nin; o += 4096, j++) {
+                    CopyJob J; J.src = cfg.cat[t] + coff + o; J.dst = dst + o; J.n = min(4096, nin - o);
+                    U->keep[j] = J;
+                }
+            }
+        }
+        if (lt == 0) { U->n_touched[t] = nt; U->sum_in[t] = s_tot[t][0]; }
+        if (tid == 0) { U->n_copy = s_tot[0][1] + s_tot[1][1]; U->n_vox = s_tot[0][2] + s_tot[1][2]; U->n_tiles = s_tot[0][3] + s_tot[1][3]; U->n_keep = s_tot[0][5] + s_tot[1][5]; U->err = 0; }
+    }
+    // 5. the new points behind their cube's old ones, in stack order: every wave counts a contiguous piece of the stack per touched cube, the pieces' counts
+    // become first positions (piece by piece: stack order), every wave places its piece
+    const int piece = ((n_st + kMuW - 1) / kMuW + 63) & ~63;
+    const int p_lo = min(wv * piece, n_st), p_hi = min(p_lo + piece, n_st);
+    for (int i0 = p_lo; i0 < p_hi; i0 += 64) {
+        const int i = i0 + lane, c = i < p_hi ? cube[i] : -1;
+        const int sl = c >= 0 ? (int)s_slot[t][c] : -1;
+        unsigned long long todo = __ballot(sl >= 0);
+        while (todo != 0ull) {
+            const int lead = (int)__ffsll((long long)todo) - 1, ss = __shfl(sl, lead);
+            const unsigned long long m = __ballot(sl == ss);
+            if (lane == lead) s_wh[t][wv][ss] += (int)__popcll(m);
+            todo &= ~m;
+        }
+    }
+    __syncthreads();
+    for (int k = lt; k < nt; k += kMuH) {
+        int run = s_cat[t][k] + s_nold[t][k];
+        for (int w = 0; w < kMuW; w++) { const int c = s_wh[t][w][k]; s_wh[t][w][k] = run; run += c; }
+    }
+    __syncthreads();
+    {
+        typedef __attribute__((address_space(1))) const float4 GF4;
+        const float4 *src = (const float4 *)(GF4 *)cfg.newpts[t];
+        float4 *cat = cfg.cat[t];
+        for (int i0 = p_lo; i0 < p_hi; i0 += 64) {
+            const int i = i0 + lane, c = i < p_hi ? cube[i] : -1;
+            const int sl = c >= 0 ? (int)s_slot[t][c] : -1;
+            const float4 p = src[min(i, n_st - 1)];
+            int pos = -1;
+            unsigned long long todo = __ballot(sl >= 0);
+            while (todo != 0ull) {
+                const int lead = (int)__ffsll((long long)todo) - 1, ss = __shfl(sl, lead);
+                const unsigned long long m = __ballot(sl == ss);
+                int cur = 0;
+                if (lane == lead) { cur = s_wh[t][wv][ss]; s_wh[t][wv][ss] = cur + (int)__popcll(m); }
+                cur = __shfl(cur, lead);
+                if (sl == ss) pos = cur + (int)__popcll(m & ltm);
+                todo &= ~m;
+            }
+            if (pos >= 0) cat[pos] = p;
+        }
+    }
+}
+
+// the touched cubes take their new place and size (a filtered cube: the filter's count); the bump pointers move on
+__global__ __launch_bounds__(kMuH) void k_map_commit(MapDevCfg cfg)
+{
+    MapDev *dev = cfg.dev;
+    const MapUpd *U = cfg.upd;
+    __shared__ int s_err;
+    if (threadIdx.x == 0) s_err = 0;
+    __syncthreads();
+    if (U->err == 0) {
+        for (int t = 0; t < 2; t++)
+            for (int k = threadIdx.x; k < U->n_touched[t]; k += kMuH) {
+                const int job = U->t_job[t][k];
+                const int n = job >= 0 ? U->nout[job] : U->t_nin[t][k];
+                if (n < 0) atomicOr(&s_err, kMdErrFilter);           // the cube keeps its old points
+                else dev->tab[t][U->t_ind[t][k]] = make_int2(U->t_newoff[t][k], n);
+            }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (U->err == 0) { dev->bump[0] += U->sum_in[0]; dev->bump[1] += U->sum_in[1]; }
+        if (s_err) atomicOr(&dev->err, s_err);
+        dev->last_sum[0] = U->sum_in[0]; dev->last_sum[1] = U->sum_in[1];
+    }
 }
 
 } // namespace lmono
