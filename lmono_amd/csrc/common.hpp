@@ -121,6 +121,26 @@ __device__ __forceinline__ double wave_sum_d(double v)
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+// sum over the wave, valid in lane 63: row_shr 1 / 2 / 4 / 8 inside every 16-lane row, row_bcast 15 / 31 across the rows (VALU moves; the LDS-crossbar
+// butterfly of wave_sum_d above is two ds_bpermute per stage: it cost k_marginalize's factor pass 160 k cycles per round of observations); a lane without a source adds 0
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ double dpp_mov_f64(double v)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)u, kCtrl, kRowMask, 0xf, false);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)(u >> 32), kCtrl, kRowMask, 0xf, false);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double wave_sum_d_lane63(double v)
+{
+    v += dpp_mov_f64<0x111, 0xf>(v);
+    v += dpp_mov_f64<0x112, 0xf>(v);
+    v += dpp_mov_f64<0x114, 0xf>(v);
+    v += dpp_mov_f64<0x118, 0xf>(v);
+    v += dpp_mov_f64<0x142, 0xa>(v);
+    v += dpp_mov_f64<0x143, 0xc>(v);
+    return v;
+}
 // ---- DPP reductions with a wave-uniform result (no LDS crossbar, one VALU instruction per stage): row_shr 1/2/4/8 inside
 // every 16-lane row, row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2-3; lane 63 then holds the reduction of the
 // wave and lane 31 that of lanes 0..31.  max / min are idempotent, so lanes without a source simply keep their own value.

@@ -547,15 +547,15 @@ __device__ __forceinline__ void map_evaluate(const MapRec *rec, int n_edge, int 
         if (qi < n_edge) map_eval_block<kJac, true>(rec[qi], Rm, x, acc);
         else map_eval_block<kJac, false>(rec[qi], Rm, x, acc);
     }
-    acc.cost = wave_sum_d(acc.cost);
+    acc.cost = wave_sum_d_lane63(acc.cost);
     if (kJac) {
 #pragma unroll
-        for (int i = 0; i < 21; i++) acc.H[i] = wave_sum_d(acc.H[i]);
+        for (int i = 0; i < 21; i++) acc.H[i] = wave_sum_d_lane63(acc.H[i]);
 #pragma unroll
-        for (int i = 0; i < 6; i++) acc.g[i] = wave_sum_d(acc.g[i]);
+        for (int i = 0; i < 6; i++) acc.g[i] = wave_sum_d_lane63(acc.g[i]);
     }
     __syncthreads();
-    if (lane == 0) {
+    if (lane == 63) {
         s_red[wave][27] = acc.cost;
         if (kJac) {
             for (int i = 0; i < 21; i++) s_red[wave][i] = acc.H[i];
@@ -603,80 +603,115 @@ __global__ __launch_bounds__(kMsT) void k_map_solve(const MapStream *streams, in
     double radius = 1e4, decrease_factor = 2.0;
     bool reuse_diagonal = false;
     int invalid_steps = 0, iter = 0;
+    // Round 5: the trust-region arithmetic between two evaluations (~1.5 k dependent fp64 instructions) runs on wave 0 alone -- every wave used to repeat it,
+    // two waves per SIMD taking turns at the issue port -- and hands the next candidate to the workgroup through LDS: ctl 0 = evaluate it with its Jacobian
+    // (the next linearisation when it is accepted), 1 = its cost only (the last iteration), 2 = finished.  Same arithmetic, same order of decisions.
+    __shared__ double s_xc[8];
+    __shared__ int s_ctl;
     if (n_used > 0) {
         map_evaluate<true>(S.rec, n_edge, nq, x, s_red, s_sum, cl);
-        if (tid < 28) s_cur[tid] = s_sum[tid];
-        __syncthreads();
-        double x_cost = s_cur[27];
-        double scale[6], diag[6];
-        double gmax = 0.0;
-        for (int i = 0; i < 6; i++) gmax = fmax(gmax, fabs(s_cur[21 + i]));
-        if (gmax > gradient_tol) {
-            double x_norm = norm7(x);
-            for (int i = 0; i < 6; i++) scale[i] = 1.0 / (1.0 + sqrt(s_cur[sym6(i, i)]));
-            while (iter < max_iter) {
-                iter++;
-                double gs[6], A[21], stepv[6];
-#pragma unroll
-                for (int i = 0; i < 6; i++) {
-                    gs[i] = s_cur[21 + i] * scale[i];
-#pragma unroll
-                    for (int j = 0; j <= i; j++) A[i * (i + 1) / 2 + j] = s_cur[sym6(i, j)] * scale[i] * scale[j];
-                }
-                if (!reuse_diagonal)
-                    for (int i = 0; i < 6; i++) { double d = A[i * (i + 1) / 2 + i]; d = d < min_diag ? min_diag : d; d = d > max_diag ? max_diag : d; diag[i] = d; }
-                for (int i = 0; i < 6; i++) A[i * (i + 1) / 2 + i] += diag[i] / radius;
-                bool ok = chol_solve6_packed(A, gs, stepv);
-                for (int i = 0; i < 6; i++) if (!isfinite(stepv[i])) ok = false;
-                double model_change = 0.0;
-                if (ok) {
-                    for (int i = 0; i < 6; i++) stepv[i] = -stepv[i];
-                    double dg = 0.0, dHd = 0.0;
-                    for (int i = 0; i < 6; i++) { dg += stepv[i] * gs[i]; for (int j = 0; j < 6; j++) dHd += stepv[i] * (s_cur[sym6(i, j)] * scale[i] * scale[j]) * stepv[j]; }
-                    model_change = -(dg + 0.5 * dHd);
-                }
-                if (!ok || !(model_change > 0.0)) {
-                    if (++invalid_steps >= 5) break;
-                    radius *= 0.5; reuse_diagonal = true;
-                    continue;
-                }
-                invalid_steps = 0;
-                double delta[6], cand[7];
-                for (int i = 0; i < 6; i++) delta[i] = stepv[i] * scale[i];
-                manifold_plus(x, delta, cand);
-                // candidate evaluated with its Jacobian (reused as the next linearisation); the last iteration needs the cost only
-                const bool last = iter == max_iter;
-                if (last) map_evaluate<false>(S.rec, n_edge, nq, cand, s_red, s_sum, cl);
-                else map_evaluate<true>(S.rec, n_edge, nq, cand, s_red, s_sum, cl);
-                const double cand_cost = s_sum[27];
-                double sn = 0.0;
-                for (int i = 0; i < 7; i++) sn += (x[i] - cand[i]) * (x[i] - cand[i]);
-                sn = sqrt(sn);
-                if (sn <= parameter_tol * (x_norm + parameter_tol)) break;
-                if (fabs(x_cost - cand_cost) <= function_tol * x_cost) break;
-                const double rel = (x_cost - cand_cost) / model_change;
-                if (rel > min_rel_decrease) {
-                    for (int i = 0; i < 7; i++) x[i] = cand[i];
-                    if (last) break;
-                    x_norm = norm7(x);
-                    x_cost = cand_cost;
-                    __syncthreads();             // every thread has read the old linearisation
+        const bool w0 = tid < 64;
+        bool first = true, last = false;
+        double x_cost = 0.0, x_norm = 0.0, model_change = 0.0, scale[6] = { 0, 0, 0, 0, 0, 0 }, diag[6] = { 0, 0, 0, 0, 0, 0 }, cand[7] = { 0, 0, 0, 0, 0, 0, 0 };
+        for (;;) {
+            if (w0) {
+                auto take_linearisation = [&]() {          // s_cur <- s_sum inside the wave (its LDS operations execute in order)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
                     if (tid < 28) s_cur[tid] = s_sum[tid];
-                    __syncthreads();
-                    const double tt = 2.0 * rel - 1.0;
-                    double den = 1.0 - tt * tt * tt;
-                    if (den < 1.0 / 3.0) den = 1.0 / 3.0;
-                    radius = radius / den;
-                    if (radius > max_radius) radius = max_radius;
-                    decrease_factor = 2.0; reuse_diagonal = false;
-                    gmax = 0.0;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                };
+                bool proceed = true;
+                if (first) {
+                    take_linearisation();
+                    x_cost = s_cur[27];
+                    double gmax = 0.0;
                     for (int i = 0; i < 6; i++) gmax = fmax(gmax, fabs(s_cur[21 + i]));
-                    if (gmax <= gradient_tol) break;
+                    if (gmax > gradient_tol) {
+                        x_norm = norm7(x);
+                        for (int i = 0; i < 6; i++) scale[i] = 1.0 / (1.0 + sqrt(s_cur[sym6(i, i)]));
+                    } else proceed = false;
                 } else {
-                    radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
+                    const double cand_cost = s_sum[27];
+                    double sn = 0.0;
+                    for (int i = 0; i < 7; i++) sn += (x[i] - cand[i]) * (x[i] - cand[i]);
+                    sn = sqrt(sn);
+                    if (sn <= parameter_tol * (x_norm + parameter_tol)) proceed = false;
+                    else if (fabs(x_cost - cand_cost) <= function_tol * x_cost) proceed = false;
+                    else {
+                        const double rel = (x_cost - cand_cost) / model_change;
+                        if (rel > min_rel_decrease) {
+                            for (int i = 0; i < 7; i++) x[i] = cand[i];
+                            if (last) proceed = false;
+                            else {
+                                x_norm = norm7(x);
+                                x_cost = cand_cost;
+                                take_linearisation();
+                                const double tt = 2.0 * rel - 1.0;
+                                double den = 1.0 - tt * tt * tt;
+                                if (den < 1.0 / 3.0) den = 1.0 / 3.0;
+                                radius = radius / den;
+                                if (radius > max_radius) radius = max_radius;
+                                decrease_factor = 2.0; reuse_diagonal = false;
+                                double gmax = 0.0;
+                                for (int i = 0; i < 6; i++) gmax = fmax(gmax, fabs(s_cur[21 + i]));
+                                if (gmax <= gradient_tol) proceed = false;
+                            }
+                        } else {
+                            radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
+                        }
+                        if (proceed && radius <= min_radius) proceed = false;
+                    }
                 }
-                if (radius <= min_radius) break;
+                int ctl = 2;
+                while (proceed) {
+                    if (iter >= max_iter) break;
+                    iter++;
+                    double gs[6], A[21], stepv[6];
+#pragma unroll
+                    for (int i = 0; i < 6; i++) {
+                        gs[i] = s_cur[21 + i] * scale[i];
+#pragma unroll
+                        for (int j = 0; j <= i; j++) A[i * (i + 1) / 2 + j] = s_cur[sym6(i, j)] * scale[i] * scale[j];
+                    }
+                    if (!reuse_diagonal)
+                        for (int i = 0; i < 6; i++) { double d = A[i * (i + 1) / 2 + i]; d = d < min_diag ? min_diag : d; d = d > max_diag ? max_diag : d; diag[i] = d; }
+                    for (int i = 0; i < 6; i++) A[i * (i + 1) / 2 + i] += diag[i] / radius;
+                    bool ok = chol_solve6_packed(A, gs, stepv);
+                    for (int i = 0; i < 6; i++) if (!isfinite(stepv[i])) ok = false;
+                    model_change = 0.0;
+                    if (ok) {
+                        for (int i = 0; i < 6; i++) stepv[i] = -stepv[i];
+                        double dg = 0.0, dHd = 0.0;
+                        for (int i = 0; i < 6; i++) { dg += stepv[i] * gs[i]; for (int j = 0; j < 6; j++) dHd += stepv[i] * (s_cur[sym6(i, j)] * scale[i] * scale[j]) * stepv[j]; }
+                        model_change = -(dg + 0.5 * dHd);
+                    }
+                    if (!ok || !(model_change > 0.0)) {
+                        if (++invalid_steps >= 5) break;
+                        radius *= 0.5; reuse_diagonal = true;
+                        continue;
+                    }
+                    invalid_steps = 0;
+                    double delta[6];
+                    for (int i = 0; i < 6; i++) delta[i] = stepv[i] * scale[i];
+                    manifold_plus(x, delta, cand);
+                    // candidate evaluated with its Jacobian (reused as the next linearisation); the last iteration needs the cost only
+                    last = iter == max_iter;
+                    ctl = last ? 1 : 0;
+                    break;
+                }
+                if (tid == 0) { s_ctl = ctl; for (int i = 0; i < 7; i++) s_xc[i] = cand[i]; }
             }
+            __syncthreads();
+            const int ctl = s_ctl;
+            if (ctl == 2) break;
+            double xc[7];
+            for (int i = 0; i < 7; i++) xc[i] = s_xc[i];
+            if (ctl == 1) map_evaluate<false>(S.rec, n_edge, nq, xc, s_red, s_sum, cl);
+            else map_evaluate<true>(S.rec, n_edge, nq, xc, s_red, s_sum, cl);
+            first = false;
         }
     }
     __syncthreads();
@@ -1312,19 +1347,17 @@ __global__ __launch_bounds__(192) void k_map_plan_gather(MapDevCfg cfg)
         s_seg[t][v] = v < nv ? dev->tab[t][F->valid[v]] : make_int2(0, 0);
     }
     __syncthreads();
-    if (tid == 0) {
+    __shared__ int s_at[2][kMdValidMax + 1], s_job[2][kMdValidMax + 1];
+    if (tid == 0) {          // running sums over at most 150 LDS entries; the jobs themselves are written by all threads below
         int nj = 0, err = 0;
         for (int t = 0; t < 2; t++) {
             int at = 0;
             for (int v = 0; v < nv; v++) {
-                const int2 sg = s_seg[t][v];
-                if (sg.y <= 0) continue;
-                if (at + sg.y > kMdNeighMax) { err |= kMdErrNeigh; break; }
-                for (int o = 0; o < sg.y; o += 4096) {
-                    CopyJob J; J.src = cfg.arena[t] + sg.x + o; J.dst = cfg.neigh[t] + at + o; J.n = min(4096, sg.y - o);
-                    dev->gjobs[nj++] = J;
-                }
-                at += sg.y;
+                int n = s_seg[t][v].y;
+                if (n < 0) n = 0;
+                if (at + n > kMdNeighMax) { err |= kMdErrNeigh; n = 0; s_seg[t][v].y = 0; }
+                s_at[t][v] = at; s_job[t][v] = nj;
+                at += n; nj += (n + 4095) / 4096;
             }
             dev->cj[t].n = at;
             cfg.S->n_map[t] = at;
@@ -1332,6 +1365,17 @@ __global__ __launch_bounds__(192) void k_map_plan_gather(MapDevCfg cfg)
         }
         dev->n_gjobs = nj;
         if (err) atomicOr(&dev->err, err);
+    }
+    __syncthreads();
+    if (tid < 2 * kMdValidMax) {
+        const int t = tid / kMdValidMax, v = tid - t * kMdValidMax;
+        if (v < nv) {
+            const int2 sg = s_seg[t][v];
+            for (int o = 0, j = s_job[t][v]; o < sg.y; o += 4096, j++) {
+                CopyJob J; J.src = cfg.arena[t] + sg.x + o; J.dst = cfg.neigh[t] + s_at[t][v] + o; J.n = min(4096, sg.y - o);
+                dev->gjobs[j] = J;
+            }
+        }
     }
 }
 
@@ -1373,15 +1417,22 @@ __global__ __launch_bounds__(kMuT) void k_map_plan_update(MapDevCfg cfg)
     if (tid == 0) s_err = 0;
     __syncthreads();
     if (tid < F->n_valid) s_isv[F->valid[tid]] = 1;
-    // 1. points per cube (lanes with the same cube add once)
-    for (int i0 = wv * 64; i0 < n_st; i0 += kMuH) {
-        const int i = i0 + lane, c = i < n_st ? cube[i] : -1;
-        unsigned long long todo = __ballot(c >= 0);
-        while (todo != 0ull) {
-            const int lead = (int)__ffsll((long long)todo) - 1, cc = __shfl(c, lead);
-            const unsigned long long m = __ballot(c == cc);
-            if (lane == lead) atomicAdd(&s_add[t][cc], (int)__popcll(m));
-            todo &= ~m;
+    // 1. points per cube (lanes with the same cube add once); eight rounds' cube indices are requested together -- one load per round was a chain of
+    // ~1.5 us global round trips, a dozen of them per frame
+    for (int r0 = 0; r0 * kMuH + wv * 64 < n_st; r0 += 8) {
+        int c8[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int i = (r0 + u) * kMuH + wv * 64 + lane; c8[u] = i < n_st ? cube[i] : -1; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int c = c8[u];
+            unsigned long long todo = __ballot(c >= 0);
+            while (todo != 0ull) {
+                const int lead = (int)__ffsll((long long)todo) - 1, cc = __shfl(c, lead);
+                const unsigned long long m = __ballot(c == cc);
+                if (lane == lead) atomicAdd(&s_add[t][cc], (int)__popcll(m));
+                todo &= ~m;
+            }
         }
     }
     __syncthreads();
@@ -1505,15 +1556,20 @@ __global__ __launch_bounds__(kMuT) void k_map_plan_update(MapDevCfg cfg)
     // become first positions (piece by piece: stack order), every wave places its piece
     const int piece = ((n_st + kMuW - 1) / kMuW + 63) & ~63;
     const int p_lo = min(wv * piece, n_st), p_hi = min(p_lo + piece, n_st);
-    for (int i0 = p_lo; i0 < p_hi; i0 += 64) {
-        const int i = i0 + lane, c = i < p_hi ? cube[i] : -1;
-        const int sl = c >= 0 ? (int)s_slot[t][c] : -1;
-        unsigned long long todo = __ballot(sl >= 0);
-        while (todo != 0ull) {
-            const int lead = (int)__ffsll((long long)todo) - 1, ss = __shfl(sl, lead);
-            const unsigned long long m = __ballot(sl == ss);
-            if (lane == lead) s_wh[t][wv][ss] += (int)__popcll(m);
-            todo &= ~m;
+    for (int i0 = p_lo; i0 < p_hi; i0 += 8 * 64) {
+        int c8[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int i = i0 + 64 * u + lane; c8[u] = i < p_hi ? cube[i] : -1; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int sl = c8[u] >= 0 ? (int)s_slot[t][c8[u]] : -1;
+            unsigned long long todo = __ballot(sl >= 0);
+            while (todo != 0ull) {
+                const int lead = (int)__ffsll((long long)todo) - 1, ss = __shfl(sl, lead);
+                const unsigned long long m = __ballot(sl == ss);
+                if (lane == lead) s_wh[t][wv][ss] += (int)__popcll(m);
+                todo &= ~m;
+            }
         }
     }
     __syncthreads();
@@ -1526,22 +1582,27 @@ __global__ __launch_bounds__(kMuT) void k_map_plan_update(MapDevCfg cfg)
         typedef __attribute__((address_space(1))) const float4 GF4;
         const float4 *src = (const float4 *)(GF4 *)cfg.newpts[t];
         float4 *cat = cfg.cat[t];
-        for (int i0 = p_lo; i0 < p_hi; i0 += 64) {
-            const int i = i0 + lane, c = i < p_hi ? cube[i] : -1;
-            const int sl = c >= 0 ? (int)s_slot[t][c] : -1;
-            const float4 p = src[min(i, n_st - 1)];
-            int pos = -1;
-            unsigned long long todo = __ballot(sl >= 0);
-            while (todo != 0ull) {
-                const int lead = (int)__ffsll((long long)todo) - 1, ss = __shfl(sl, lead);
-                const unsigned long long m = __ballot(sl == ss);
-                int cur = 0;
-                if (lane == lead) { cur = s_wh[t][wv][ss]; s_wh[t][wv][ss] = cur + (int)__popcll(m); }
-                cur = __shfl(cur, lead);
-                if (sl == ss) pos = cur + (int)__popcll(m & ltm);
-                todo &= ~m;
+        for (int i0 = p_lo; i0 < p_hi; i0 += 4 * 64) {
+            int c4[4];
+            float4 p4[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int i = i0 + 64 * u + lane; c4[u] = i < p_hi ? cube[i] : -1; p4[u] = src[min(i, n_st - 1)]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int sl = c4[u] >= 0 ? (int)s_slot[t][c4[u]] : -1;
+                int pos = -1;
+                unsigned long long todo = __ballot(sl >= 0);
+                while (todo != 0ull) {
+                    const int lead = (int)__ffsll((long long)todo) - 1, ss = __shfl(sl, lead);
+                    const unsigned long long m = __ballot(sl == ss);
+                    int cur = 0;
+                    if (lane == lead) { cur = s_wh[t][wv][ss]; s_wh[t][wv][ss] = cur + (int)__popcll(m); }
+                    cur = __shfl(cur, lead);
+                    if (sl == ss) pos = cur + (int)__popcll(m & ltm);
+                    todo &= ~m;
+                }
+                if (pos >= 0) cat[pos] = p4[u];
             }
-            if (pos >= 0) cat[pos] = p;
         }
     }
 }

@@ -77,26 +77,6 @@ struct MargLds {
 static_assert(sizeof(MargLds) <= 160 * 1024, "k_marginalize: LDS");
 
 __device__ __forceinline__ int tri6(int a, int b) { const int lo = a < b ? a : b, hi = a < b ? b : a; return lo * (11 - lo) / 2 + hi; }
-// sum over the wave, valid in lane 63: row_shr 1 / 2 / 4 / 8 inside every 16-lane row, row_bcast 15 / 31 across the rows (VALU moves; the LDS-crossbar
-// butterfly of wave_sum_d cost the factor pass 160 k cycles per round of observations); a lane without a source adds 0
-template <int kCtrl, int kRowMask>
-__device__ __forceinline__ double dpp_mov_f64(double v)
-{
-    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
-    const unsigned int lo = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)u, kCtrl, kRowMask, 0xf, false);
-    const unsigned int hi = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)(u >> 32), kCtrl, kRowMask, 0xf, false);
-    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-__device__ __forceinline__ double wave_sum_d_lane63(double v)
-{
-    v += dpp_mov_f64<0x111, 0xf>(v);
-    v += dpp_mov_f64<0x112, 0xf>(v);
-    v += dpp_mov_f64<0x114, 0xf>(v);
-    v += dpp_mov_f64<0x118, 0xf>(v);
-    v += dpp_mov_f64<0x142, 0xa>(v);
-    v += dpp_mov_f64<0x143, 0xc>(v);
-    return v;
-}
 // the wave's sum of v goes to slot idx of the wave's array (one writer per array: the additions to a slot happen in program order)
 __device__ __forceinline__ void mg_acc(double *acc, int idx, double v, int lane)
 {
