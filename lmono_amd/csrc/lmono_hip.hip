@@ -2251,7 +2251,7 @@ static int mapper_process_dev(lmono_ctx *c, lmono_mapper *m, lmono_scan_batch *b
     S.part = m->solve_part; S.bar = &F_d->bar[0];
     memcpy(stage + o_S, &S, sizeof(S));
     AssignJob aj[2];
-    for (int t = 0; t < 2; t++) aj[t] = { m->stack[t], 0, &F_d->n_stack[0], t, &F_d->x[0], cen[0], cen[1], cen[2], m->newpts[t], m->cube_of_d };
+    for (int t = 0; t < 2; t++) aj[t] = { m->stack[t], -1, &F_d->n_stack[0], t, &F_d->x[0], cen[0], cen[1], cen[2], m->newpts[t], m->cube_of_d + (size_t)t * kMapStackMax };      // (n = -1: the job's own array of cube indices)
     memcpy(stage + o_aj, aj, sizeof(aj));
     MapDevCfg cfg;
     cfg.dev = m->dev; cfg.frame = F_d; cfg.upd = m->upd; cfg.S = (MapStream *)(blob + o_S);
@@ -2259,7 +2259,7 @@ static int mapper_process_dev(lmono_ctx *c, lmono_mapper *m, lmono_scan_batch *b
         cfg.arena[t] = m->arena[t][m->half[t]]; cfg.neigh[t] = m->neigh[t]; cfg.cat[t] = m->cat[t]; cfg.newpts[t] = m->newpts[t];
         cfg.vk[t] = m->vk[t]; cfg.vi[t] = m->vi[t]; cfg.vws[t] = m->vws[t]; cfg.inv_leaf[t] = 1.0f / m->leaf[t];
     }
-    cfg.vws_cap = (int)m->vws_cap; cfg.cube_of = m->cube_of_d;
+    cfg.vws_cap = (int)m->vws_cap; cfg.cube_of[0] = m->cube_of_d; cfg.cube_of[1] = m->cube_of_d + kMapStackMax;
     // ---- side stream: upload, scan filter (behind the previous frame's cube assignment: it reads the stack), then behind the previous commit: shifts, gather, grids
     HIP_TRY(c, hipMemcpyAsync(blob, stage, bytes, hipMemcpyHostToDevice, side));
     HIP_TRY(c, hipStreamWaitEvent(side, m->ev_assign, 0));
@@ -2312,8 +2312,7 @@ static int mapper_process_dev(lmono_ctx *c, lmono_mapper *m, lmono_scan_batch *b
             cube_passes = std::max(cube_passes, std::min(4, (bits + 8) / 9));
         }
         launch_voxel_jobs(st, (const VoxJob *)m->upd->vox, (const int *)m->upd->tiles, 160, cube_passes, (const int *)&m->upd->n_tiles);
-        hipLaunchKernelGGL(k_copy_jobs_n, dim3(32), dim3(256), 0, st, (const CopyJob *)m->upd->keep, (const int *)&m->upd->n_keep);
-        hipLaunchKernelGGL(k_map_commit, dim3(1), dim3(kMuH), 0, st, cfg);
+        hipLaunchKernelGGL(k_map_commit, dim3(1 + 16), dim3(kMuH), 0, st, cfg);          // (workgroup 0 commits, the others do the plain copies)
         HIP_TRY(c, hipEventRecord(m->ev_commit, st));
     }
     m->parity ^= 1;

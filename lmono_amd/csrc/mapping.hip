@@ -721,14 +721,15 @@ __global__ __launch_bounds__(kMsT) void k_map_solve(const MapStream *streams, in
     }
 }
 
-// workgroups per stream: K = 4 (measured best for one stream, below), lowered until clusters x K stay within half the chip's 256 CUs -- every workgroup
+// workgroups per stream: K = 8 (measured best for one stream, below), lowered until clusters x K stay within half the chip's 256 CUs -- every workgroup
 // of a cluster must be resident while it spins; the spin is bounded (a cluster that is not resident sets stats[6] and the host returns LMONO_ENODEV).
 // A stream's partial sums are split by K, so its pose depends at rounding level (1e-12, tests/test_mapping_gpu.py::test_solve_cluster_sizes_agree) on
 // how many streams share the call; the budget assumes the card is not shared with another process's resident workgroups.
 static inline int map_solve_cluster(int n_streams)
 {
     static const int forced = [] { const char *e = getenv("LMONO_MAP_SOLVE_K"); return e ? atoi(e) : 0; }();        // measurement switch
-    int K = forced > 0 ? forced : 4;          // one stream, K = 1 / 2 / 4 / 8: 1.57 / 1.71 / 1.98 / 1.83 k frames/s (3 .. 6 within noise of each other)
+    int K = forced > 0 ? forced : 8;          // one stream, K = 2 / 4 / 6 / 8: 2.24 / 2.45 / 2.52 / 2.56 k frames/s (round 5, the trust-region step on one wave; round 4's
+                                              // kernel, where every wave repeated it, peaked at K = 4: 1.57 / 1.71 / 1.98 / 1.83 k for K = 1 / 2 / 4 / 8)
     if (K > kMsMaxK) K = kMsMaxK;
     const int groups = (n_streams + 7) / 8;
     while (K > 1 && groups * 8 * K > 128) K--;
@@ -1233,7 +1234,7 @@ __global__ __launch_bounds__(256) void k_map_assign(const AssignJob *jobs)
     int n = J.n, base = 0;
     if (J.n_all) {
         n = J.n_all[J.job];
-        for (int j = 0; j < J.job; j++) base += max(J.n_all[j], 0);       // (uniform: scalar loads)
+        if (J.n >= 0) for (int j = 0; j < J.job; j++) base += max(J.n_all[j], 0);       // (uniform: scalar loads)  n < 0: `cube` is the job's own array
     }
     if (i >= n) return;
     const float4 p = J.stack[i];
@@ -1318,7 +1319,7 @@ struct MapDevCfg {                           // kernel argument
     int *vi[2], *vws[2];
     int vws_cap;
     float inv_leaf[2];
-    const int *cube_of;                      // [n_stack[0] | n_stack[1]] cube index of every stack point (k_map_assign)
+    const int *cube_of[2];                   // cube index of every stack point, per cloud type (k_map_assign)
 };
 
 // the cube array moves by one cube along an axis (laserMapping's pointer rotation): tab[i] = tmp[i - dir]; the cubes that enter are empty
@@ -1347,31 +1348,36 @@ __global__ __launch_bounds__(192) void k_map_plan_gather(MapDevCfg cfg)
         s_seg[t][v] = v < nv ? dev->tab[t][F->valid[v]] : make_int2(0, 0);
     }
     __syncthreads();
-    __shared__ int s_at[2][kMdValidMax + 1], s_job[2][kMdValidMax + 1];
-    if (tid == 0) {          // running sums over at most 150 LDS entries; the jobs themselves are written by all threads below
-        int nj = 0, err = 0;
-        for (int t = 0; t < 2; t++) {
-            int at = 0;
-            for (int v = 0; v < nv; v++) {
-                int n = s_seg[t][v].y;
-                if (n < 0) n = 0;
-                if (at + n > kMdNeighMax) { err |= kMdErrNeigh; n = 0; s_seg[t][v].y = 0; }
-                s_at[t][v] = at; s_job[t][v] = nj;
-                at += n; nj += (n + 4095) / 4096;
-            }
-            dev->cj[t].n = at;
-            cfg.S->n_map[t] = at;
-            cfg.frame->n_map[t] = at;
-        }
-        dev->n_gjobs = nj;
-        if (err) atomicOr(&dev->err, err);
+    __shared__ int s_at[2][kMdValidMax + 1], s_job[2][kMdValidMax + 1], s_tot[2][2];
+    if (tid < 128) {         // wave t sums type t: two cubes per lane (75 <= 128), one scan for the points and one for the copy jobs
+        const int t = tid >> 6, lane = tid & 63;
+        int n[2], jn[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) { const int v = 2 * lane + u; n[u] = v < nv ? max(s_seg[t][v].y, 0) : 0; jn[u] = (n[u] + 4095) / 4096; }
+        const int in_n = wave_scan_incl(n[0] + n[1]), in_j = wave_scan_incl(jn[0] + jn[1]);
+        int at = in_n - n[0] - n[1], jb = in_j - jn[0] - jn[1];
+#pragma unroll
+        for (int u = 0; u < 2; u++) { const int v = 2 * lane + u; if (v < nv) { s_at[t][v] = at; s_job[t][v] = jb; } at += n[u]; jb += jn[u]; }
+        if (lane == 63) { s_tot[t][0] = in_n; s_tot[t][1] = in_j; }
     }
     __syncthreads();
+    const bool over = s_tot[0][0] > kMdNeighMax || s_tot[1][0] > kMdNeighMax;       // refused: the frame runs on an empty neighbourhood and reports it
+    if (tid < 2) {
+        const int at = over ? 0 : s_tot[tid][0];
+        dev->cj[tid].n = at;
+        cfg.S->n_map[tid] = at;
+        cfg.frame->n_map[tid] = at;
+    }
+    if (tid == 0) {
+        dev->n_gjobs = over ? 0 : s_tot[0][1] + s_tot[1][1];
+        if (over) atomicOr(&dev->err, kMdErrNeigh);
+    }
+    if (over) return;
     if (tid < 2 * kMdValidMax) {
         const int t = tid / kMdValidMax, v = tid - t * kMdValidMax;
         if (v < nv) {
             const int2 sg = s_seg[t][v];
-            for (int o = 0, j = s_job[t][v]; o < sg.y; o += 4096, j++) {
+            for (int o = 0, j = s_job[t][v] + (t ? s_tot[0][1] : 0); o < sg.y; o += 4096, j++) {
                 CopyJob J; J.src = cfg.arena[t] + sg.x + o; J.dst = cfg.neigh[t] + s_at[t][v] + o; J.n = min(4096, sg.y - o);
                 dev->gjobs[j] = J;
             }
@@ -1394,6 +1400,22 @@ __global__ __launch_bounds__(256) void k_copy_jobs_n(const CopyJob *jobs, const 
 // [old points | new points in stack order] of every touched cube laid out in `cat` (the new points are placed here; the old ones by copy jobs);
 // fresh arena space behind the bump pointer; a voxel-filter job per touched cube of the neighbourhood, a plain copy for the others.
 constexpr int kMuT = 1024, kMuH = 512, kMuW = kMuH / 64;
+constexpr int kMuStage = 12288;        // stack points per cloud type whose cube indices are staged in LDS (a 64-ring scan leaves 4-7 k after the filter)
+// runs of equal values among the wave's 64 lanes (v < 0: no value): true for the first lane of a run, len = the run's length.  One LDS add per RUN instead
+// of per lane: an LDS atomic serialises the lanes that share an address, and 16 waves of them cost the kernel ~10 k cycles per pass.
+__device__ __forceinline__ bool run_head(int v, int lane, int &len)
+{
+    const int prev = __shfl_up(v, 1);
+    const bool head = v >= 0 && (lane == 0 || prev != v);
+    const unsigned long long hm = __ballot(head), vm = __ballot(v >= 0);
+    // the run ends before the next head or the next lane without a value
+    const unsigned long long stop = (hm | ~vm) & (lane == 63 ? 0ull : (~0ull << (lane + 1)));
+    len = head ? (stop ? (int)__builtin_ctzll(stop) : 64) - lane : 0;
+    return head;
+}
+// value of lane `l` (the same l in every lane): v_readlane through a scalar register -- __shfl goes through the LDS crossbar (~130 cycles per hop of a
+// dependent chain; the three loops below were chains of them: 70 k of the kernel's 100 k cycles)
+__device__ __forceinline__ int lane_value(int v, int l) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(l)); }
 __global__ __launch_bounds__(kMuT) void k_map_plan_update(MapDevCfg cfg)
 {
     __shared__ int s_add[2][kMdCubes];
@@ -1403,49 +1425,66 @@ __global__ __launch_bounds__(kMuT) void k_map_plan_update(MapDevCfg cfg)
     __shared__ int s_base[2][kMdTouched][5];        // first copy job, filter job, tile, workspace int, keep job of every touched cube (type-local)
     __shared__ int s_wh[2][kMuW][kMdTouched];
     __shared__ int s_wtot[2][kMuW], s_nt[2], s_tot[2][6], s_err;
+    __shared__ unsigned short s_cube[2][kMuStage];      // the stack points' cube indices (0xffff: outside the array), read from memory once
     MapDev *dev = cfg.dev;
     MapUpd *U = cfg.upd;
     const MapFrame *F = cfg.frame;
+#ifdef LMONO_MU_PROF
+    unsigned long long mu_t[16];
+    mu_t[0] = __builtin_readcyclecounter();
+#endif
     const int tid = threadIdx.x, t = tid >> 9, lt = tid & (kMuH - 1), wv = lt >> 6, lane = tid & 63;
     const int ns0 = max(F->n_stack[0], 0), ns1 = max(F->n_stack[1], 0);
     const int n_st = t ? ns1 : ns0;
-    const int *cube = cfg.cube_of + (t ? ns0 : 0);
+    const int *cube = cfg.cube_of[t];
     const unsigned long long ltm = (1ull << lane) - 1ull;
+    // Everything this kernel reads was written by other kernels on other XCDs: every DEPENDENT round of global loads is a ~2 us trip to memory.  So:
+    // the table rows of step 2 and the bump pointer are requested here, the stack points' cube indices are read once (step 1) and kept in LDS for
+    // steps 5a / 5b, and the points themselves are requested one batch ahead of their use.
+    const int c0 = lt * 10;
+    int2 seg[10];
+#pragma unroll
+    for (int u = 0; u < 10; u++) seg[u] = c0 + u < kMdCubes ? dev->tab[t][c0 + u] : make_int2(0, 0);
+    const int bump = dev->bump[t];
+    const bool staged = n_st <= kMuStage;
+    // a wave's piece of the stack: contiguous, so that the pieces' counts become stack-order positions in step 5
+    const int piece = ((n_st + kMuW - 1) / kMuW + 63) & ~63;
+    const int p_lo = min(wv * piece, n_st), p_hi = min(p_lo + piece, n_st);
+    auto cube_at = [&](int i) -> int { if (staged) { const int v = (int)s_cube[t][i]; return v == 0xffff ? -1 : v; } return cube[i]; };
     for (int k = tid; k < 2 * kMdCubes; k += kMuT) { (&s_add[0][0])[k] = 0; (&s_slot[0][0])[k] = (short)-1; }
     for (int k = tid; k < kMdCubes; k += kMuT) s_isv[k] = 0;
-    for (int k = tid; k < 2 * kMuW * kMdTouched; k += kMuT) (&s_wh[0][0][0])[k] = 0;
     if (tid == 0) s_err = 0;
     __syncthreads();
+#ifdef LMONO_MU_PROF
+    if (tid == 0) mu_t[1] = __builtin_readcyclecounter();
+#endif
     if (tid < F->n_valid) s_isv[F->valid[tid]] = 1;
-    // 1. points per cube (lanes with the same cube add once); eight rounds' cube indices are requested together -- one load per round was a chain of
-    // ~1.5 us global round trips, a dozen of them per frame
-    for (int r0 = 0; r0 * kMuH + wv * 64 < n_st; r0 += 8) {
+    // 1. points per cube (lanes with the same cube add once), eight rounds of the wave's piece per trip to memory
+    for (int i0 = p_lo; i0 < p_hi; i0 += 8 * 64) {
         int c8[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { const int i = (r0 + u) * kMuH + wv * 64 + lane; c8[u] = i < n_st ? cube[i] : -1; }
+        for (int u = 0; u < 8; u++) { const int i = i0 + 64 * u + lane; c8[u] = i < p_hi ? cube[i] : -1; }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            const int c = c8[u];
-            unsigned long long todo = __ballot(c >= 0);
-            while (todo != 0ull) {
-                const int lead = (int)__ffsll((long long)todo) - 1, cc = __shfl(c, lead);
-                const unsigned long long m = __ballot(c == cc);
-                if (lane == lead) atomicAdd(&s_add[t][cc], (int)__popcll(m));
-                todo &= ~m;
-            }
+            const int c = c8[u], i = i0 + 64 * u + lane;
+            if (staged && i < p_hi) s_cube[t][i] = (unsigned short)(c < 0 ? 0xffff : c);
+            // (64 consecutive stack points -- voxel order: rows along x through the whole cloud -- fall into 5-10 different cubes: a loop over the distinct
+            // cubes of a round was ~250 cycles per cube)
+            int len;
+            if (run_head(c, lane, len)) atomicAdd(&s_add[t][c], len);
         }
     }
     __syncthreads();
+#ifdef LMONO_MU_PROF
+    if (tid == 0) mu_t[2] = __builtin_readcyclecounter();
+#endif
     // 2. the touched cubes, ascending: ten cubes per thread, their flags counted and placed through a scan of the type's 512 threads
     {
-        const int c0 = lt * 10;
-        int2 seg[10];
         int cnt = 0;
         unsigned int fl = 0;
 #pragma unroll
         for (int u = 0; u < 10; u++) {
             const int c = c0 + u;
-            seg[u] = c < kMdCubes ? dev->tab[t][c] : make_int2(0, 0);
             const int ad = c < kMdCubes ? s_add[t][c] : 0;
             const bool need = c < kMdCubes && (s_isv[c] ? seg[u].y + ad > 0 : ad > 0);
             if (need) { fl |= 1u << u; cnt++; }
@@ -1453,6 +1492,9 @@ __global__ __launch_bounds__(kMuT) void k_map_plan_update(MapDevCfg cfg)
         const int incl = wave_scan_incl(cnt);
         if (lane == 63) s_wtot[t][wv] = incl;
         __syncthreads();
+#ifdef LMONO_MU_PROF
+    if (tid == 0) mu_t[3] = __builtin_readcyclecounter();
+#endif
         int at = incl - cnt;
         for (int w = 0; w < wv; w++) at += s_wtot[t][w];
         if (lt == kMuH - 1) s_nt[t] = at + cnt;
@@ -1464,6 +1506,9 @@ __global__ __launch_bounds__(kMuT) void k_map_plan_update(MapDevCfg cfg)
             }
     }
     __syncthreads();
+#ifdef LMONO_MU_PROF
+    if (tid == 0) mu_t[4] = __builtin_readcyclecounter();
+#endif
     if (lt == 0 && s_nt[t] > kMdTouched) atomicOr(&s_err, kMdErrTouched);
     const int nt = min(s_nt[t], kMdTouched);
     // 3. running sums over the touched cubes (wave 0 of the type, four cubes per lane): place in `cat`, copy jobs of the old points, filter jobs, tiles,
@@ -1502,11 +1547,14 @@ __global__ __launch_bounds__(kMuT) void k_map_plan_update(MapDevCfg cfg)
         }
     }
     __syncthreads();
+#ifdef LMONO_MU_PROF
+    if (tid == 0) mu_t[5] = __builtin_readcyclecounter();
+#endif
     if (lt == 0) {
         int e = 0;
         if (s_tot[t][0] > kMdCatMax) e |= kMdErrCat;
         if (s_tot[t][4] > cfg.vws_cap) e |= kMdErrWs;
-        if (dev->bump[t] + s_tot[t][0] > kMdArena) e |= kMdErrArena;
+        if (bump + s_tot[t][0] > kMdArena) e |= kMdErrArena;
         if (e) atomicOr(&s_err, e);
     }
     if (tid == 0) {
@@ -1515,15 +1563,90 @@ __global__ __launch_bounds__(kMuT) void k_map_plan_update(MapDevCfg cfg)
         if (e) atomicOr(&s_err, e);
     }
     __syncthreads();
+#ifdef LMONO_MU_PROF
+    if (tid == 0) mu_t[6] = __builtin_readcyclecounter();
+#endif
     const int err = s_err;
     if (err) {           // nothing of this update runs; the table keeps the map as it was
         if (tid == 0) { U->n_touched[0] = U->n_touched[1] = 0; U->sum_in[0] = U->sum_in[1] = 0; U->n_copy = U->n_vox = U->n_tiles = U->n_keep = 0; U->err = err; atomicOr(&dev->err, err); }
         return;
     }
-    // 4. the tables
+    // 5. the new points behind their cube's old ones, in stack order: every wave counts a contiguous piece of the stack per touched cube, the pieces' counts
+    // become first positions (piece by piece: stack order), every wave places its piece
+    typedef __attribute__((address_space(1))) const float4 GF4;
+    const float4 *src = (const float4 *)(GF4 *)cfg.newpts[t];
+    for (int k = lane; k < kMdTouched; k += 64) s_wh[t][wv][k] = 0;          // (the wave's own row: its LDS operations execute in order)
+    for (int i0 = p_lo; i0 < p_hi; i0 += 8 * 64) {
+        int c8[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int i = i0 + 64 * u + lane; c8[u] = i < p_hi ? cube_at(i) : -1; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int sl = c8[u] >= 0 ? (int)s_slot[t][c8[u]] : -1;
+            int len;
+            if (run_head(sl, lane, len)) atomicAdd(&s_wh[t][wv][sl], len);
+        }
+    }
+    __syncthreads();
+#ifdef LMONO_MU_PROF
+    if (tid == 0) mu_t[7] = __builtin_readcyclecounter();
+#endif
+    for (int k = lt; k < nt; k += kMuH) {
+        int run = s_cat[t][k] + s_nold[t][k];
+        for (int w = 0; w < kMuW; w++) { const int c = s_wh[t][w][k]; s_wh[t][w][k] = run; run += c; }
+    }
+    __syncthreads();
+#ifdef LMONO_MU_PROF
+    if (tid == 0) mu_t[8] = __builtin_readcyclecounter();
+#endif
+    {
+        // 5b. positions of eight rounds (the peers of a lane's cube from ballots over the bits of its index among the touched cubes, the cube's cursor moved by the peers' lowest
+        // lane) while their points, requested together, are on their way; then the stores, together: a load / store pair per round made the compiler wait for every outstanding
+        // memory operation -- the previous round's store included -- before each store (~4 k cycles per round)
+        float4 *cat = cfg.cat[t];
+        int nbits = 1;
+        while ((1 << nbits) < nt) nbits++;          // (the pass is bound by its vector instructions: 16 waves on one compute unit)
+        for (int i0 = p_lo; i0 < p_hi; i0 += 8 * 64) {
+            float4 p8[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) p8[u] = src[max(min(i0 + 64 * u + lane, n_st - 1), 0)];
+            int pos[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = i0 + 64 * u + lane;
+                const int c = i < p_hi ? cube_at(i) : -1;
+                const int sl = c >= 0 ? (int)s_slot[t][c] : -1;
+                const bool ok = sl >= 0;
+                unsigned long long pm = __ballot(ok);
+#pragma unroll
+                for (int bq = 0; bq < 5; bq++) {
+                    const unsigned long long mb = __ballot(ok && ((sl >> bq) & 1));
+                    pm &= ((sl >> bq) & 1) ? mb : ~mb;
+                }
+                if (nbits > 5) {          // more than 32 touched cubes (uniform)
+#pragma unroll
+                    for (int bq = 5; bq < 8; bq++) {
+                        const unsigned long long mb = __ballot(ok && ((sl >> bq) & 1));
+                        pm &= ((sl >> bq) & 1) ? mb : ~mb;
+                    }
+                }
+                pm = ok ? pm : 0ull;
+                const int leader = ok ? (int)__ffsll((long long)pm) - 1 : lane;
+                int cur = 0;
+                if (ok && lane == leader) { cur = s_wh[t][wv][sl]; s_wh[t][wv][sl] = cur + (int)__popcll(pm); }
+                cur = __shfl(cur, leader);
+                pos[u] = ok ? cur + (int)__popcll(pm & ltm) : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) if (pos[u] >= 0) cat[pos[u]] = p8[u];
+        }
+    }
+#ifdef LMONO_MU_PROF
+    if (tid == 0) mu_t[10] = __builtin_readcyclecounter();
+#endif
+    // 4. the tables (last: their stores' acknowledgements are waited for by nobody but the end of the kernel)
     {
         const int b_copy = t ? s_tot[0][1] : 0, b_vox = t ? s_tot[0][2] : 0, b_tile = t ? s_tot[0][3] : 0, b_keep = t ? s_tot[0][5] : 0;
-        const int bump = dev->bump[t];
         for (int k = lt; k < nt; k += kMuH) {
             const int ind = s_ind[t][k], nold = s_nold[t][k], nin = nold + s_nadd[t][k], coff = s_cat[t][k];
             const int old_off = s_oldoff[t][k];
@@ -1552,59 +1675,9 @@ __global__ __launch_bounds__(kMuT) void k_map_plan_update(MapDevCfg cfg)
         if (lt == 0) { U->n_touched[t] = nt; U->sum_in[t] = s_tot[t][0]; }
         if (tid == 0) { U->n_copy = s_tot[0][1] + s_tot[1][1]; U->n_vox = s_tot[0][2] + s_tot[1][2]; U->n_tiles = s_tot[0][3] + s_tot[1][3]; U->n_keep = s_tot[0][5] + s_tot[1][5]; U->err = 0; }
     }
-    // 5. the new points behind their cube's old ones, in stack order: every wave counts a contiguous piece of the stack per touched cube, the pieces' counts
-    // become first positions (piece by piece: stack order), every wave places its piece
-    const int piece = ((n_st + kMuW - 1) / kMuW + 63) & ~63;
-    const int p_lo = min(wv * piece, n_st), p_hi = min(p_lo + piece, n_st);
-    for (int i0 = p_lo; i0 < p_hi; i0 += 8 * 64) {
-        int c8[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) { const int i = i0 + 64 * u + lane; c8[u] = i < p_hi ? cube[i] : -1; }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int sl = c8[u] >= 0 ? (int)s_slot[t][c8[u]] : -1;
-            unsigned long long todo = __ballot(sl >= 0);
-            while (todo != 0ull) {
-                const int lead = (int)__ffsll((long long)todo) - 1, ss = __shfl(sl, lead);
-                const unsigned long long m = __ballot(sl == ss);
-                if (lane == lead) s_wh[t][wv][ss] += (int)__popcll(m);
-                todo &= ~m;
-            }
-        }
-    }
-    __syncthreads();
-    for (int k = lt; k < nt; k += kMuH) {
-        int run = s_cat[t][k] + s_nold[t][k];
-        for (int w = 0; w < kMuW; w++) { const int c = s_wh[t][w][k]; s_wh[t][w][k] = run; run += c; }
-    }
-    __syncthreads();
-    {
-        typedef __attribute__((address_space(1))) const float4 GF4;
-        const float4 *src = (const float4 *)(GF4 *)cfg.newpts[t];
-        float4 *cat = cfg.cat[t];
-        for (int i0 = p_lo; i0 < p_hi; i0 += 4 * 64) {
-            int c4[4];
-            float4 p4[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const int i = i0 + 64 * u + lane; c4[u] = i < p_hi ? cube[i] : -1; p4[u] = src[min(i, n_st - 1)]; }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int sl = c4[u] >= 0 ? (int)s_slot[t][c4[u]] : -1;
-                int pos = -1;
-                unsigned long long todo = __ballot(sl >= 0);
-                while (todo != 0ull) {
-                    const int lead = (int)__ffsll((long long)todo) - 1, ss = __shfl(sl, lead);
-                    const unsigned long long m = __ballot(sl == ss);
-                    int cur = 0;
-                    if (lane == lead) { cur = s_wh[t][wv][ss]; s_wh[t][wv][ss] = cur + (int)__popcll(m); }
-                    cur = __shfl(cur, lead);
-                    if (sl == ss) pos = cur + (int)__popcll(m & ltm);
-                    todo &= ~m;
-                }
-                if (pos >= 0) cat[pos] = p4[u];
-            }
-        }
-    }
+#ifdef LMONO_MU_PROF
+    if (tid == 0) { mu_t[9] = __builtin_readcyclecounter(); printf("MUPROF n_st %d %d touched %d %d:", ns0, ns1, s_nt[0], s_nt[1]); for (int z = 1; z <= 9; z++) printf(" %llu", mu_t[z] - mu_t[z - 1]); printf(" | pass B %llu, tables %llu, rounds %d", mu_t[10] - mu_t[8], mu_t[9] - mu_t[10], (p_hi - p_lo + 63) / 64); printf("\n"); }
+#endif
 }
 
 // the touched cubes take their new place and size (a filtered cube: the filter's count); the bump pointers move on
@@ -1612,6 +1685,14 @@ __global__ __launch_bounds__(kMuH) void k_map_commit(MapDevCfg cfg)
 {
     MapDev *dev = cfg.dev;
     const MapUpd *U = cfg.upd;
+    if (blockIdx.x > 0) {        // workgroups 1.. : the plain copies [old | new] -> arena of the touched cubes outside the neighbourhood (normally none)
+        const int nj = U->n_keep;
+        for (int j = blockIdx.x - 1; j < nj; j += gridDim.x - 1) {
+            const CopyJob J = U->keep[j];
+            for (int i = threadIdx.x; i < J.n; i += kMuH) J.dst[i] = J.src[i];
+        }
+        return;
+    }
     __shared__ int s_err;
     if (threadIdx.x == 0) s_err = 0;
     __syncthreads();

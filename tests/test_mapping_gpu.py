@@ -69,9 +69,9 @@ def test_refine_matches_oracle_blocks_and_pose(oracle, gpu_ctx, frames):
 
 
 def test_solve_cluster_sizes_agree(oracle, gpu_ctx, frames):
-    """k_map_solve runs as a cluster of K workgroups per stream; map_solve_cluster (mapping.hip) starts from K = 4 and lowers it until
-    ceil(streams / 8) * 8 * K <= 128 workgroups: 1, 20, 40, 56 and 72 streams run K = 4, 4, 3, 2 and 1.  (K = 5..8 exist only behind the measurement
-    switch LMONO_MAP_SOLVE_K and are not shipped.)  The same frame in every stream must give the oracle's block counts, iteration counts and pose."""
+    """k_map_solve runs as a cluster of K workgroups per stream; map_solve_cluster (mapping.hip) starts from K = 8 and lowers it until
+    ceil(streams / 8) * 8 * K <= 128 workgroups: 1, 20, 40, 56 and 72 streams run K = 8, 5, 3, 2 and 1.  The same frame in every stream must give the
+    oracle's block counts, iteration counts and pose."""
     f = frames[1]
     xr, st, _ = oracle.map_refine(f["cmap"], f["smap"], f["cstack"], f["sstack"], f["x0"])
     want = [st.n_edge[0], st.n_edge[1], st.n_plane[0], st.n_plane[1], st.lm_iters[0], st.lm_iters[1]]
@@ -273,3 +273,54 @@ def test_batched_streams_match_their_single_stream_oracles(oracle, gpu_ctx):
             assert list(st[i, :6]) == [ws.n_edge[0], ws.n_edge[1], ws.n_plane[0], ws.n_plane[1], ws.lm_iters[0], ws.lm_iters[1]], (k, i)
             assert np.abs(np.concatenate([q[i], t[i]]) - s["want"]["poses"][k]).max() < 1e-7, (k, i)
     assert np.array_equal(mappers[0].cube(1, 10, 10, 5), mappers[2].cube(1, 10, 10, 5)) and len(mappers[0].cube(1, 10, 10, 5)) > 100
+
+
+def _all_cubes(mapper):
+    out = {}
+    for which in (0, 1):
+        for i in range(21):
+            for j in range(21):
+                for k in range(11):
+                    c = mapper.cube(which, i, j, k)
+                    if len(c):
+                        out[(which, i, j, k)] = c
+    return out
+
+
+def test_device_tables_follow_the_host_tables_through_shifts_and_mode_changes(oracle, gpu_ctx):
+    """lmono_mapper_process keeps the cube table on the device and plans the map update there (round 5); lmono_mapper_process_batch keeps it on the host.
+    Three mappers see the same 10 frames, the odometry stretched so that the vehicle crosses cube borders (the array shifts several times): one through
+    the device path only, one through the host path only (a batch of one), one alternating between the two (the table is converted on entry).  Poses,
+    statistics and every cube must be identical, bit for bit."""
+    import torch
+    import lmono_amd
+    w = oracle.S1World(n_az=500)
+    traj = w.trajectory(10)
+    x, off = w.scans(traj)
+    xd = torch.from_numpy(x).cuda()
+    batch = lmono_amd.ScanBatch(gpu_ctx, 10, len(x))
+    batch.scanreg(xd.data_ptr(), off, 64, 5.0, keepalive=xd)
+    _, odo = batch.odometry(n_chains=1, lead=0)
+    odo = odo.copy()
+    odo[:, 4] += np.arange(10) * 37.0            # 37 m per frame along x: the centre cube changes every other frame, the array shifts from frame 2 on
+    odo[:, 5] -= np.arange(10) * 21.0
+    dev, host, mixed = (lmono_amd.Mapper(gpu_ctx) for _ in range(3))
+    for k in range(10):
+        qd, td, sd = dev.process(batch, k, odo[k, :4], odo[k, 4:])
+        qh, th, sh = lmono_amd.Mapper.process_batch(gpu_ctx, [host], [batch], [k], odo[k:k + 1, :4], odo[k:k + 1, 4:])
+        if k % 3 == 1:
+            qm, tm, sm = lmono_amd.Mapper.process_batch(gpu_ctx, [mixed], [batch], [k], odo[k:k + 1, :4], odo[k:k + 1, 4:])
+            qm, tm, sm = qm[0], tm[0], sm[0]
+        else:
+            qm, tm, sm = mixed.process(batch, k, odo[k, :4], odo[k, 4:])
+        assert np.array_equal(qd, qh[0]) and np.array_equal(td, th[0]) and list(sd[:7]) == list(sh[0][:7]), k
+        assert np.array_equal(qd, qm) and np.array_equal(td, tm) and list(sd[:7]) == list(sm[:7]), k
+    cd, ch, cm = _all_cubes(dev), _all_cubes(host), _all_cubes(mixed)
+    assert len(cd) > 40 and cd.keys() == ch.keys() == cm.keys()
+    for key in cd:
+        assert np.array_equal(cd[key], ch[key]) and np.array_equal(cd[key], cm[key]), key
+    # a reset empties the device's table as well
+    dev.reset()
+    assert not _all_cubes(dev)
+    q0, t0, s0 = dev.process(batch, 0, odo[0, :4], odo[0, 4:])
+    assert not s0[:6].any() and s0[6] == 0
