@@ -167,6 +167,16 @@ def bench_ba_seq(args):
     print(json.dumps(res), flush=True)
 
 
+def _map_traffic(streams):
+    """HBM bytes per single-stream laserMapping frame from the committed counter summary (scripts/profile_round5.sh), or None."""
+    for rnd in ("r5",):
+        path = os.path.join(ROOT, "profiles", rnd, "pmc_map_frame.json")
+        if streams == 1 and os.path.exists(path):
+            with open(path) as fh:
+                return json.load(fh).get("hbm_bytes_per_frame")
+    return None
+
+
 def bench_map(args):
     """Tertiary workload: laserMapping with the device-resident cube map over a synthetic S1 sequence, one
     stream.  One step = every scan of the sequence through lmono_mapper_process once (fresh map per step)."""
@@ -230,9 +240,9 @@ def bench_map(args):
            "dtype": "f32 clouds / f64 solve", "data": "synthetic",
            "config": {"workload": "S1 HDL-64 sequence, %d scans, laserMapping after laserOdometry (SURVEY 8f-1)" % n, "streams": B},
            "roofline": {"bound": "hbm", "kernel": "per-frame kernel chain (k_vox_* filter chain, k_grid_*, k_map_correspond, k_map_factor, k_map_solve)",
-                        "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None,
+                        "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": _map_traffic(B),
                         "algorithmic_bytes_per_frame": round(alg / n),
-                        "note": "whole-chain figure (bytes every cloud element must move once per frame / frame time), not one kernel's: a frame is a chain of ~40 short dependent launches (k_map_solve 0.08 ms x 2, the two voxel filter chains 0.16 ms, correspond + factor 0.08 ms: profiles/r4/map_kernel_stats_1stream_end_of_round.csv) with two host waits (the cube tables live on the host); latency of that chain, not a roofline measurement"},
+                        "note": "whole-chain figure (bytes every cloud element must move once per frame / frame time), not one kernel's: a frame is a chain of ~35 short dependent launches (profiles/r5/map_kernel_stats_1stream.csv); one stream (lmono_mapper_process) keeps the cube table on the device and waits once per frame, several streams (lmono_mapper_process_batch) plan on the host and wait twice; latency of that chain, not a roofline measurement; traffic = FETCH_SIZE x 2 + WRITE_SIZE of all kernels of a single-stream frame (profiles/r5/pmc_map_frame.json)"},
            "cpu_baseline": {"value": round(n / (ref["stage_ms"][1] * 1e-3), 2), "unit": "frames/s", "cores": 1, "kind": "port",
                             "sample": "the same %d scans, oracle/lo_mapping.c (-O3), 1 thread, mapping stage only" % n},
            "max_pose_diff_vs_cpu": float(np.abs(got - ref["poses"]).max()),

@@ -329,8 +329,15 @@ int lmono_voxel_filter(lmono_ctx *, int n_clouds, const float *xyzi_h, const int
  * transformAssociateToMap, cube shifts, VoxelGrid of the scan clouds (mapping_line_resolution / _plane_resolution),
  * the optimisation block, transformUpdate, insertion of the scan into the cubes and re-filtering of the 5 x 5 x 3
  * neighbourhood.  q_wodom / t_wodom: laserOdometry's pose of the scan; q_w_curr / t_w_curr: aft_mapped_to_init.
- * stats (optional, [8]): edge blocks of the two outer iterations, plane blocks, LM iterations, then two sizes of the frame (for traffic
- * accounting): map points of the 5 x 5 x 3 neighbourhood handed to the optimisation, points of the cubes the map update rebuilt.
+ * stats (optional, [8]): edge blocks of the two outer iterations, plane blocks, LM iterations, then two sizes (for traffic
+ * accounting): map points of the 5 x 5 x 3 neighbourhood handed to the optimisation, points of the cubes a map update rebuilt.
+ * lmono_mapper_process keeps the (offset, count) table of the cubes ON THE DEVICE and plans the map update there: the call enqueues
+ * the whole frame, waits once for the refined pose and returns; the scan joins the map behind the return (stream order: the next
+ * call, lmono_mapper_cube and lmono_mapper_reset see the finished map).  Consequences for the caller: stats[7] is the PREVIOUS
+ * frame's update, and an update the device had to refuse (LMONO_ECAPACITY: more than 65536 points in a cube, workspace or arena
+ * exhausted) is reported by the next call on the mapper -- the map is then as it was before that update.
+ * lmono_mapper_process_batch keeps the table on the host (one planning pass for all streams, two waits per frame); a mapper may be
+ * used through both, the table is converted on entry.
  * A-LOAM laserMapping.cpp process(), source absent from the reference tree.          */
 typedef struct lmono_mapper lmono_mapper;
 lmono_mapper *lmono_mapper_create(lmono_ctx *, float line_res, float plane_res);      /* HDL-64 launch file: 0.4, 0.8 */

@@ -5,6 +5,7 @@ for row in csv.DictReader(open(f)):
     k = row["Kernel_Name"].split("(")[0]
     agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
     cnt[(k, row["Counter_Name"])] += 1
+total = "--sum" in sys.argv          # --sum: the counter summed over a kernel's launches instead of averaged
 for k, d in agg.items():
     if "lmono" in k:
-        print(k, {c: round(v / cnt[(k, c)]) for c, v in d.items()})
+        print(k, {c: round(v if total else v / cnt[(k, c)]) for c, v in d.items()})

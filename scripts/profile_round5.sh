@@ -62,6 +62,33 @@ echo "[2/3] BA done"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_map -- python3 bench.py --workload map --scans 64 --streams 1 > $OUT/map_bench_1stream_under_rocprof.json 2> $OUT/trace_map.err
 stats $OUT/trace_map $OUT/map_kernel_stats_1stream.csv
 timeout -k 10 300 python3 bench.py --workload map --scans 64 --streams 1 > $OUT/map_bench_1stream.json 2>> $OUT/trace_map.err
+timeout -k 10 300 python3 bench.py --workload map --scans 64 --streams 64 > $OUT/map_bench_64streams.json 2>> $OUT/trace_map.err
+LMONO_MAP_HOST_TABLES=1 timeout -k 10 300 python3 bench.py --workload map --scans 64 --streams 1 --cpu-sample 0 > $OUT/map_bench_1stream_host_tables.json 2>> $OUT/trace_map.err
+# HBM traffic of a single-stream frame: FETCH_SIZE and WRITE_SIZE in separate passes over one step of 64 frames (a fresh map: the front end's and the
+# odometry's kernels of the set-up are listed too, the frame's are k_map_* / k_vox_* / k_grid_* / k_copy_*)
+: > $OUT/map_pmc_1stream.txt
+for grp in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_map -- python3 bench.py --workload map --scans 64 --streams 1 --steps 1 --warmup 0 --cpu-sample 0 > /dev/null 2> $OUT/pmc_map.err
+  echo "## $grp (KB, summed over the launches of the run: 64 frames)" >> $OUT/map_pmc_1stream.txt
+  python3 scripts/pmc_summary.py $OUT/pmc_map --sum 2>&1 | grep -E "k_map|k_vox|k_grid|k_copy" >> $OUT/map_pmc_1stream.txt
+  rm -rf $OUT/pmc_map
+done
+python3 - <<PY
+import re, json
+tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
+cur = None
+for ln in open("$OUT/map_pmc_1stream.txt"):
+    if ln.startswith("## "): cur = ln.split()[1]; continue
+    m = re.search(r"'" + (cur or "x") + r"': (\d+)", ln)
+    if m: tot[cur] += float(m.group(1))
+frames = 64
+d = {"source": "profiles/r5/map_pmc_1stream.txt (scripts/profile_round5.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --workload map --scans 64 --streams 1 --steps 1 --warmup 0: every k_map_* / k_vox_* / k_grid_* / k_copy_* launch of 64 frames)",
+     "fetch_kb_total": tot["FETCH_SIZE"], "write_kb_total": tot["WRITE_SIZE"], "frames": frames,
+     "correction": "gfx950: FETCH_SIZE (KB) counts 128-B requests at 64 B -> doubled; WRITE_SIZE as is",
+     "hbm_bytes_per_frame": round((2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024 / frames)}
+open("$OUT/pmc_map_frame.json", "w").write(json.dumps(d, indent=1) + "\n")
+print("map frame traffic:", d["hbm_bytes_per_frame"], "B")
+PY
 echo "[3/3] laserMapping done"
 fi
 find $OUT -name "*.err" -size 0 -delete
