@@ -335,7 +335,7 @@ int lmono_voxel_filter(lmono_ctx *, int n_clouds, const float *xyzi_h, const int
  * the whole frame, waits once for the refined pose and returns; the scan joins the map behind the return (stream order: the next
  * call, lmono_mapper_cube and lmono_mapper_reset see the finished map).  Consequences for the caller: stats[7] is the PREVIOUS
  * frame's update, and an update the device had to refuse (LMONO_ECAPACITY: more than 65536 points in a cube, workspace or arena
- * exhausted) is reported by the next call on the mapper -- the map is then as it was before that update.
+ * exhausted) is reported by the following calls on the mapper until lmono_mapper_reset -- that update did not touch the map.
  * lmono_mapper_process_batch keeps the table on the host (one planning pass for all streams, two waits per frame); a mapper may be
  * used through both, the table is converted on entry.
  * A-LOAM laserMapping.cpp process(), source absent from the reference tree.          */

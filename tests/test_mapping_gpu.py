@@ -324,3 +324,34 @@ def test_device_tables_follow_the_host_tables_through_shifts_and_mode_changes(or
     assert not _all_cubes(dev)
     q0, t0, s0 = dev.process(batch, 0, odo[0, :4], odo[0, 4:])
     assert not s0[:6].any() and s0[6] == 0
+
+
+def test_update_refused_on_the_device_is_reported_by_the_next_call(oracle, gpu_ctx):
+    """With the cube table on the device the map update runs behind the call's return, so a capacity error found while it is planned (here: a cube that
+    would exceed the voxel filter's 65536 points, provoked with a 1 cm leaf that filters nothing away) cannot be returned by the call that caused it:
+    the NEXT call on the mapper reports it, the table keeps the map as it was before the refused update, and nothing hangs."""
+    import torch
+    import lmono_amd
+    w = oracle.S1World(n_az=2000)
+    traj = w.trajectory(6)
+    x, off = w.scans(traj)
+    xd = torch.from_numpy(x).cuda()
+    batch = lmono_amd.ScanBatch(gpu_ctx, 6, len(x))
+    batch.scanreg(xd.data_ptr(), off, 64, 5.0, keepalive=xd)
+    _, odo = batch.odometry(n_chains=1, lead=0)
+    m = lmono_amd.Mapper(gpu_ctx, 0.01, 0.01)
+    sizes, failed_at = [], None
+    for k in range(6):
+        try:
+            m.process(batch, k, odo[k, :4], odo[k, 4:])
+        except lmono_amd.LmonoError as e:
+            failed_at = k
+            assert "refused" in str(e) or "capacity" in str(e)
+            break
+        sizes.append(sum(len(m.cube(1, 10, 10, kk)) for kk in (4, 5, 6)))
+    assert failed_at is not None and failed_at >= 2, (failed_at, sizes)      # ~25 k less-flat points per scan around the start: the third or fourth update overflows
+    # the refused update left the table alone: the centre cubes hold what the last accepted update put there
+    assert sum(len(m.cube(1, 10, 10, kk)) for kk in (4, 5, 6)) == sizes[-1] or len(sizes) < 2
+    m.reset()
+    q, t, st = m.process(batch, 0, odo[0, :4], odo[0, 4:])           # usable again
+    assert not st[:6].any()
