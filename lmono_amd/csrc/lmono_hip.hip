@@ -1260,7 +1260,10 @@ static int ba_fill(lmono_ctx *c, lmono_ba_batch *b, const lmono_ba_desc *d)
     const int izero = 0; const double dzero = 0.0;       // a present (non-NULL) source for arrays that may be empty
     BaPack pk;
     pk.add(feat_off, d->feat_off, (size_t)W + 1); pk.add(obs_off, d->obs_off, (size_t)W + 1);
-    pk.add(flags, d->flags, (size_t)W * 4); pk.add(v.poses, d->poses, (size_t)W * kBaMaxPoses * 7);
+    std::vector<double> zsum((size_t)W * 6, 0.0);
+    pk.add(flags, d->flags, (size_t)W * 4);
+    pk.add(v.fail, &izero, (size_t)1); pk.add(v.summary, (const double *)zsum.data(), (size_t)W * 6);        // [failure flag | summaries | poses | ex | inverse depths]: the results, one read-back
+    pk.add(v.poses, d->poses, (size_t)W * kBaMaxPoses * 7);
     pk.add(v.ex, d->ex, (size_t)W * 7); pk.add(v.inv_depth, TF ? d->inv_depth : &dzero, (size_t)TF);
     pk.add(anch, TF ? anchor.data() : &izero, (size_t)TF);
     pk.add(poff, pair_off.data(), (size_t)W + 1); pk.add(pij, pair_ij.empty() ? &izero : pair_ij.data(), pair_ij.size());
@@ -1293,8 +1296,6 @@ static int ba_fill(lmono_ctx *c, lmono_ba_batch *b, const lmono_ba_desc *d)
     pk.add(v.pairdat, (const double *)nullptr, (size_t)b->cluster * pair_ij.size() * kBaPairRec);
     pk.add(v.mbox, (const double *)nullptr, (size_t)W * kBaMbox);
     pk.add(v.bar, (const unsigned int *)nullptr, (size_t)W * 16);
-    pk.add(v.fail, (const int *)nullptr, (size_t)1);
-    pk.add(v.summary, (const double *)nullptr, (size_t)W * 6);        // (right behind the failure flag: lmono_ba_batch_read fetches both in one copy)
     v.n_pairs_total = (int)pair_ij.size();
     pk.add(v.pairH, (const double *)nullptr, (seg_tab.size() + pair_ij.size() + (size_t)W) * kBaPairTile);
     pk.add(v.gprog, (const int *)nullptr, (size_t)W * kBaGprog);
@@ -1338,7 +1339,10 @@ extern "C" int lmono_ba_solve(lmono_ctx *c, lmono_ba_batch *b, int max_iteration
     b->v.max_iter = max_iterations;
     if (b->cluster > 1) {
         // the flag words start at zero in every launch (the first solve after a fill finds them zeroed with the rest of the scratch)
-        if (!b->flags_clean) HIP_TRY(c, hipMemsetAsync(b->v.bar, 0, (((sizeof(unsigned int) * (size_t)b->n_windows * 16) + 255) & ~(size_t)255) + 256, c->stream));   // (+ the failure flag behind them)
+        if (!b->flags_clean) {
+            HIP_TRY(c, hipMemsetAsync(b->v.bar, 0, sizeof(unsigned int) * (size_t)b->n_windows * 16, c->stream));
+            HIP_TRY(c, hipMemsetAsync(b->v.fail, 0, sizeof(int), c->stream));
+        }
         b->flags_clean = false;
         static const int spread = [] { const char *e = getenv("LMONO_BA_SPREAD"); return e ? atoi(e) : 0; }();      // test hook: a window's workgroups on different XCDs
         const dim3 grid(((b->n_windows + 7) / 8) * 8 * b->cluster);
@@ -1366,24 +1370,23 @@ extern "C" int lmono_ba_batch_read(lmono_ctx *c, lmono_ba_batch *b, double *pose
 {
     if (!c || !b) return LMONO_EINVAL;
     if (b->n_windows <= 0) { c->err = "lmono_ba_batch_read: the batch holds no problem (failed update)"; return LMONO_EINVAL; }
-    // The state arrays (poses | ex | inverse depths) are neighbours in the batch's allocation, and so are (failure flag | summaries): a small batch --
-    // the Estimator's one window per frame -- comes back as TWO copies into the batch's pinned staging buffer (free between an upload and the next)
-    // instead of five copies into pageable memory, each of which the runtime stages and waits for on its own.
+    // (failure flag | summaries | poses | ex | inverse depths) are neighbours in the batch's allocation: a small batch -- the Estimator's one window per
+    // frame -- comes back as ONE copy into the batch's pinned staging buffer (free between an upload and the next) instead of five copies into pageable
+    // memory, each of which the runtime stages and waits for on its own.
     const size_t w = (size_t)b->n_windows;
-    const size_t bytes_a = (size_t)((const char *)(b->v.inv_depth + b->total_feat) - (const char *)b->v.poses);
-    const size_t bytes_b = (size_t)((const char *)(b->v.summary + w * 6) - (const char *)b->v.fail);
+    const char *lo = (const char *)b->v.fail;
+    const size_t bytes = (size_t)((const char *)(b->v.inv_depth + b->total_feat) - lo);
     int failed = 0;
-    if ((const char *)b->v.ex > (const char *)b->v.poses && (const char *)b->v.inv_depth > (const char *)b->v.ex && (const char *)b->v.summary > (const char *)b->v.fail &&
-        bytes_a + bytes_b + 256 <= b->stage_cap && bytes_a + bytes_b <= ((size_t)256 << 10)) {
-        char *sa = b->stage, *sb = b->stage + ((bytes_a + 255) & ~(size_t)255);
-        HIP_TRY(c, hipMemcpyAsync(sa, b->v.poses, bytes_a, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(sb, b->v.fail, bytes_b, hipMemcpyDeviceToHost, c->stream));
+    if ((const char *)b->v.summary > lo && (const char *)b->v.poses > (const char *)b->v.summary && (const char *)b->v.ex > (const char *)b->v.poses &&
+        (const char *)b->v.inv_depth > (const char *)b->v.ex && bytes + 256 <= b->stage_cap && bytes <= ((size_t)256 << 10)) {
+        char *sa = b->stage;
+        HIP_TRY(c, hipMemcpyAsync(sa, lo, bytes, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));      // stream-ordered behind the solve; nothing goes through the null stream
-        if (poses_h) memcpy(poses_h, sa, sizeof(double) * w * kBaMaxPoses * 7);
-        if (ex_h) memcpy(ex_h, sa + ((const char *)b->v.ex - (const char *)b->v.poses), sizeof(double) * w * 7);
-        if (inv_depth_h && b->total_feat > 0) memcpy(inv_depth_h, sa + ((const char *)b->v.inv_depth - (const char *)b->v.poses), sizeof(double) * (size_t)b->total_feat);
-        if (summary_h) memcpy(summary_h, sb + ((const char *)b->v.summary - (const char *)b->v.fail), sizeof(double) * w * 6);
-        if (b->cluster > 1) memcpy(&failed, sb, sizeof(int));
+        if (poses_h) memcpy(poses_h, sa + ((const char *)b->v.poses - lo), sizeof(double) * w * kBaMaxPoses * 7);
+        if (ex_h) memcpy(ex_h, sa + ((const char *)b->v.ex - lo), sizeof(double) * w * 7);
+        if (inv_depth_h && b->total_feat > 0) memcpy(inv_depth_h, sa + ((const char *)b->v.inv_depth - lo), sizeof(double) * (size_t)b->total_feat);
+        if (summary_h) memcpy(summary_h, sa + ((const char *)b->v.summary - lo), sizeof(double) * w * 6);
+        if (b->cluster > 1) memcpy(&failed, sa, sizeof(int));
     } else {
         if (poses_h) HIP_TRY(c, hipMemcpyAsync(poses_h, b->v.poses, sizeof(double) * w * kBaMaxPoses * 7, hipMemcpyDeviceToHost, c->stream));
         if (ex_h) HIP_TRY(c, hipMemcpyAsync(ex_h, b->v.ex, sizeof(double) * w * 7, hipMemcpyDeviceToHost, c->stream));
