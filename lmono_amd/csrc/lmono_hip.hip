@@ -1618,10 +1618,10 @@ extern "C" int lmono_marginalize(lmono_ctx *c, int n_windows, const int *feat_of
     hipLaunchKernelGGL(k_marginalize, dim3(n_windows), dim3(kMgT), sizeof(MargLds), c->stream, B);
     int rc = check_launch(c, "k_marginalize");
     if (rc) return rc;
-    HIP_TRY(c, hipMemcpyAsync(lin_J_h, B.lin_J, sizeof(double) * (size_t)n_windows * kMargN * kMargN, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(lin_r_h, B.lin_r, sizeof(double) * (size_t)n_windows * kMargN, hipMemcpyDeviceToHost, c->stream));
-    if (status_h) HIP_TRY(c, hipMemcpyAsync(status_h, B.status, sizeof(int) * (size_t)n_windows, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));      // the results are in the caller's arrays
+    // (the three outputs are neighbours in the scratch: one copy through the pinned staging buffer)
+    bool got = db.down(lin_J_h, B.lin_J, sizeof(double) * (size_t)n_windows * kMargN * kMargN) && db.down(lin_r_h, B.lin_r, sizeof(double) * (size_t)n_windows * kMargN);
+    if (got && status_h) got = db.down(status_h, B.status, sizeof(int) * (size_t)n_windows);
+    if (!got || !db.fetch()) { c->err = "lmono_marginalize: read-back failed"; return LMONO_ENODEV; }      // the results are in the caller's arrays
     return LMONO_OK;
 }
 
@@ -1664,10 +1664,9 @@ extern "C" int lmono_marg_second_new(lmono_ctx *c, int n_windows, int n_blocks, 
     hipLaunchKernelGGL(k_marg_second_new, dim3(n_windows), dim3(kMgT), sizeof(Marg2Lds), c->stream, B);
     int rc = check_launch(c, "k_marg_second_new");
     if (rc) return rc;
-    HIP_TRY(c, hipMemcpyAsync(lin_J_out_h, B.out_J, sizeof(double) * W * n * n, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(lin_r_out_h, B.out_r, sizeof(double) * W * n, hipMemcpyDeviceToHost, c->stream));
-    if (status_h) HIP_TRY(c, hipMemcpyAsync(status_h, B.status, sizeof(int) * W, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));      // the results are in the caller's arrays
+    bool got = db.down(lin_J_out_h, B.out_J, sizeof(double) * W * n * n) && db.down(lin_r_out_h, B.out_r, sizeof(double) * W * n);
+    if (got && status_h) got = db.down(status_h, B.status, sizeof(int) * W);
+    if (!got || !db.fetch()) { c->err = "lmono_marg_second_new: read-back failed"; return LMONO_ENODEV; }      // the results are in the caller's arrays
     return LMONO_OK;
 }
 
