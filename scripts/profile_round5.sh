@@ -21,7 +21,7 @@ stats $OUT/trace $OUT/final_kernel_stats_4541scans.csv
 LMONO_BOUNDARY_TOL=0 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace0 -- python3 bench.py --steps 5 --warmup 1 --cpu-sample 0 --no-extras > $OUT/final_bench_under_rocprof_no_validation.json 2> $OUT/trace0.err
 stats $OUT/trace0 $OUT/final_kernel_stats_4541scans_main_pass_only.csv
 : > $OUT/final_pmc_4541scans.txt
-for grp in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
+for grp in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU"; do
   tag=$(echo $grp | cut -d' ' -f1)
   LMONO_BOUNDARY_TOL=0 timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_$tag -- python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-extras > $OUT/pmc_$tag.out 2> $OUT/pmc_$tag.err
   echo "## $grp" >> $OUT/final_pmc_4541scans.txt
