@@ -2195,8 +2195,10 @@ static int mapper_process_dev(lmono_ctx *c, lmono_mapper *m, lmono_scan_batch *b
     if (n_last[0] > kMapStackMax || n_last[1] > kMapStackMax) { c->err = "lmono_mapper: scan cloud too large"; return LMONO_ECAPACITY; }
     int rc;
     // arena space: what the host saw last is two updates old; compact (on the host's copy of the table: rare) long before the bump pointer can reach the end
+    static const int64_t compact_at = [] { const char *e = getenv("LMONO_MAP_COMPACT_AT"); return e ? (int64_t)atoll(e) : (int64_t)0; }();      // test hook: compact as soon as a
+                                                                                                                                              // bump pointer has passed this many points
     for (int t = 0; t < 2; t++)
-        if ((int64_t)m->bump_seen[t] + 2 * ((int64_t)m->nmap_seen[t] + 3 * kMapStackMax) + kMapStackMax > kMapArena) {
+        if ((int64_t)m->bump_seen[t] + 2 * ((int64_t)m->nmap_seen[t] + 3 * kMapStackMax) + kMapStackMax > kMapArena || (compact_at > 0 && m->bump_seen[t] > compact_at)) {
             if ((rc = mapper_tables_to_host(c, m))) return rc;
             if ((rc = mapper_compact(m, t))) return rc;
         }

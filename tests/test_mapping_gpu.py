@@ -355,3 +355,44 @@ def test_update_refused_on_the_device_is_reported_by_the_next_call(oracle, gpu_c
     m.reset()
     q, t, st = m.process(batch, 0, odo[0, :4], odo[0, 4:])           # usable again
     assert not st[:6].any()
+
+
+def test_arena_compaction_with_the_table_on_the_device(oracle, gpu_ctx):
+    """The arenas are compacted on the host's copy of the cube table (rare: the bump pointer has to come near 6 Mi points).  LMONO_MAP_COMPACT_AT (a test
+    hook, read once per process) makes it happen every other frame in a child process: table to the host, live cubes into the other arena half, table
+    back to the device -- the trajectory and the cubes must be those of this process, which never compacts."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, ".")
+import lmono_amd
+from oracle import oracle as O
+w = O.S1World(n_az=500)
+traj = w.trajectory(8)
+x, off = w.scans(traj)
+ctx = lmono_amd.Context(0)
+xd = torch.from_numpy(x).cuda()
+batch = lmono_amd.ScanBatch(ctx, 8, len(x))
+batch.scanreg(xd.data_ptr(), off, 64, 5.0, keepalive=xd)
+_, odo = batch.odometry(n_chains=1, lead=0)
+m = lmono_amd.Mapper(ctx)
+out = []
+for k in range(8):
+    q, t, st = m.process(batch, k, odo[k, :4], odo[k, 4:])
+    out.append(np.concatenate([q, t, st[:7].astype(np.float64)]))
+cubes = [m.cube(wh, 10, 10, 5) for wh in (0, 1)]
+np.savez(sys.argv[1], out=np.array(out), c0=cubes[0], c1=cubes[1])
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, env in (("plain", {}), ("compact", {"LMONO_MAP_COMPACT_AT": "20000"})):
+        path = os.path.join(root, "gpurun_out", "compact_%s.npz" % tag)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        e = dict(os.environ); e.update(env)
+        r = subprocess.run([sys.executable, "-c", code, path], cwd=root, env=e, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = np.load(path)
+    assert np.array_equal(res["plain"]["out"], res["compact"]["out"])
+    assert len(res["plain"]["c1"]) > 100 and np.array_equal(res["plain"]["c0"], res["compact"]["c0"]) and np.array_equal(res["plain"]["c1"], res["compact"]["c1"])
