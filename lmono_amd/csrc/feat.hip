@@ -287,6 +287,148 @@ __global__ __launch_bounds__(256) void k_depth_refine(FeatBatch B)
     }
 }
 
+// ---- k_depth_refine, one observation per thread (round 5).  The kernel above gives a track to a thread, which walks its <= 10 observations one after the
+// other in every evaluation: ~110 us per Estimator frame for ~150 tracks, a chain of ~3000 dependent fp64 instructions per thread and evaluation on a
+// fraction of one compute unit.  Here every (track, observation) pair of the window is an ITEM; an evaluation computes the items side by side on 1024
+// threads, leaves (cost, h, g) of each in LDS, and the track's thread adds its items in observation order -- the same terms in the same order as the walk,
+// so every sum, every decision and every result is the same bit for bit.  Windows above kDrItems items or 1024 tracks take the kernel above.
+constexpr int kDrT = 1024, kDrItems = 3072;
+__global__ __launch_bounds__(kDrT) void k_depth_refine_items(FeatBatch B)
+{
+    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int f0 = B.feat_off[w], f1 = B.feat_off[w + 1];
+    const double *gRs = B.Rs + (size_t)w * 99, *gPs = B.Ps + (size_t)w * 33, *tlc = B.tlc + (size_t)w * 16;
+    __shared__ double red[kDrT / 64];
+    __shared__ double Rs[99], Ps[33], sRlc[9], sTlc[3], sT[121 * 9];
+    __shared__ double s_x[kDrT];                       // the inverse depths an evaluation is made at
+    __shared__ double s_res[kDrItems][3];              // (cost, h, g) of every item
+    __shared__ unsigned short s_if[kDrItems];          // item -> track (thread index)
+    __shared__ unsigned char s_io[kDrItems];           // item -> observation
+    __shared__ int s_wtot[kDrT / 64], s_nitems;
+    if (tid < 99) Rs[tid] = gRs[tid];
+    if (tid < 33) Ps[tid] = gPs[tid];
+    if (tid < 9) sRlc[tid] = tlc[(tid / 3) * 4 + tid % 3];
+    if (tid < 3) sTlc[tid] = tlc[tid * 4 + 3];
+    __syncthreads();
+    if (tid < 121) {
+        const int i = tid / 11, j = tid % 11;
+        double RjT[9], RlcT[9], T[9];
+        ba::mT(Rs + 9 * j, RjT); ba::mT(sRlc, RlcT);
+        ba::mm(RlcT, RjT, T); ba::mm(T, Rs + 9 * i, T); ba::mm(T, sRlc, T);
+        for (int k = 0; k < 9; k++) sT[tid * 9 + k] = T[k];
+    }
+    // the track of this thread and its items
+    const int f = f0 + tid;
+    const bool has = f < f1;
+    const int ob0 = has ? B.obs_off[f] : 0, nobs = has ? B.obs_off[f + 1] - ob0 : 0, sf = has ? B.start_frame[f] : 0;
+    const bool cnt_ok = has && nobs >= B.track_cnt;
+    int nres = 0;
+    if (cnt_ok) for (int o = 1; o < nobs; o++) if (sf + o != B.window_size) nres++;
+    const bool act = nres > 0;
+    double x = has ? 1.0 / B.depth[f] : 0.0, h = 0, g = 0, scale = 1, diag = 1, step = 0, cand = 0;
+    int it0;
+    {
+        const int incl = wave_scan_incl(nres);
+        if (lane == 63) s_wtot[wave] = incl;
+        __syncthreads();
+        it0 = incl - nres;
+        for (int q = 0; q < wave; q++) it0 += s_wtot[q];
+        if (tid == kDrT - 1) s_nitems = it0 + nres;
+        if (cnt_ok) { int k = it0; for (int o = 1; o < nobs; o++) if (sf + o != B.window_size) { s_if[k] = (unsigned short)tid; s_io[k] = (unsigned char)o; k++; } }
+    }
+    __syncthreads();
+    const int n_items = s_nitems;
+    auto bsum = [&](double v) {
+        v = wave_sum_d(v);
+        __syncthreads();
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        // (the tracks of a window sit in the first waves: the order of this sum is the 256-thread kernel's -- ((w0 + w1) + w2) + w3 -- with zeros behind it)
+        double t = red[0];
+        for (int q = 1; q < kDrT / 64; q++) t += red[q];
+        return t;
+    };
+    auto bmax = [&](double v) {
+        for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+        __syncthreads();
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        double t = red[0];
+        for (int q = 1; q < kDrT / 64; q++) t = fmax(t, red[q]);
+        return t;
+    };
+    // cost of the track at xv, with (h, g): the items side by side, then the track's own items added in observation order
+    auto evaluate = [&](double xv, double &ho, double &go) -> double {
+        s_x[tid] = xv;
+        __syncthreads();
+        for (int k = tid; k < n_items; k += kDrT) {
+            const int ft = (int)s_if[k], o = (int)s_io[k], fg = f0 + ft;
+            const int i = B.start_frame[fg], j = i + o;
+            const double *pi = B.pts + 2 * (size_t)B.obs_off[fg], *pj = pi + 2 * (size_t)o;
+            double r[2], J[2];
+            reproj_factor_T(s_x[ft], pi, pj, Rs + 9 * i, Ps + 3 * i, Rs + 9 * j, Ps + 3 * j, sRlc, sTlc, sT + (i * 11 + j) * 9, B.weight, r, J);
+            const double sq = r[0] * r[0] + r[1] * r[1];
+            double rho1 = 1.0 / (1.0 + sq); rho1 = rho1 > DBL_MIN ? rho1 : DBL_MIN;
+            s_res[k][0] = 0.5 * log(1.0 + sq); s_res[k][1] = rho1 * (J[0] * J[0] + J[1] * J[1]); s_res[k][2] = rho1 * (J[0] * r[0] + J[1] * r[1]);
+        }
+        __syncthreads();
+        double cost = 0;
+        ho = 0; go = 0;
+        for (int k = it0; k < it0 + nres; k++) { cost += s_res[k][0]; ho += s_res[k][1]; go += s_res[k][2]; }
+        return cost;
+    };
+    const double function_tol = 1e-6, gradient_tol = 1e-10, parameter_tol = 1e-8, min_rel = 1e-3, min_diag = 1e-6, max_diag = 1e32;
+    double radius = 1e4, dec = 2.0;
+    bool reuse = false;
+    int invalid = 0, iter = 0;
+    double c0 = evaluate(x, h, g), xn = 0, gm = 0;
+    if (act) { xn = x * x; scale = 1.0 / (1.0 + sqrt(h)); gm = fabs(g); }
+    double x_cost = bsum(c0), x_norm = sqrt(bsum(xn)), gmax = bmax(gm);
+    if (gmax > gradient_tol) while (iter < B.max_iter) {
+        iter++;
+        double model = 0, bad = 0;
+        step = 0;
+        if (act) {
+            const double hs = h * scale * scale, gs = g * scale;
+            if (!reuse) { double d = hs; d = d < min_diag ? min_diag : (d > max_diag ? max_diag : d); diag = d; }
+            const double sv = -gs / (hs + diag / radius);
+            if (!isfinite(sv)) bad = 1;
+            step = sv;
+            model = -(sv * gs + 0.5 * sv * hs * sv);
+        }
+        model = bsum(model); bad = bmax(bad);
+        if (bad > 0 || !(model > 0.0)) { if (++invalid >= 5) break; radius *= 0.5; reuse = true; continue; }
+        invalid = 0;
+        cand = x + step * scale;
+        double hh = 0, gg = 0;
+        double sn = act ? (cand - x) * (cand - x) : 0.0;
+        double cc = evaluate(cand, hh, gg);
+        sn = sqrt(bsum(sn)); cc = bsum(cc);
+        if (sn <= parameter_tol * (x_norm + parameter_tol)) break;
+        if (fabs(x_cost - cc) <= function_tol * x_cost) break;
+        const double rel = (x_cost - cc) / model;
+        if (rel > min_rel) {
+            x = cand; h = hh; g = gg;
+            xn = act ? x * x : 0.0; gm = act ? fabs(g) : 0.0;
+            x_cost = cc; x_norm = sqrt(bsum(xn)); gmax = bmax(gm);
+            const double t = 2.0 * rel - 1.0;
+            double den = 1.0 - t * t * t; if (den < 1.0 / 3.0) den = 1.0 / 3.0;
+            radius = radius / den; if (radius > 1e16) radius = 1e16;
+            dec = 2.0; reuse = false;
+            if (gmax <= gradient_tol) break;
+        } else { radius /= dec; dec *= 2.0; reuse = true; }
+        if (radius <= 1e-32) break;
+    }
+    if (has) {
+        B.solve_flag[f] = 0;
+        if (nobs >= B.track_cnt) {
+            const double d = 1.0 / x;
+            B.depth[f] = d;
+            B.solve_flag[f] = (d < 0.1 || d > 300) ? 2 : 1;
+        }
+    }
+}
+
 __global__ __launch_bounds__(128) void k_outlier_scores(FeatBatch B)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
