@@ -171,7 +171,7 @@ def _map_traffic(streams):
     """HBM bytes per single-stream laserMapping frame from the committed counter summary (scripts/profile_round5.sh), or None."""
     for rnd in ("r5",):
         path = os.path.join(ROOT, "profiles", rnd, "pmc_map_frame.json")
-        if streams == 1 and os.path.exists(path):
+        if streams == 1 and os.path.exists(path) and not os.environ.get("LMONO_MAP_HOST_TABLES"):      # (the counters are the device-table frame's)
             with open(path) as fh:
                 return json.load(fh).get("hbm_bytes_per_frame")
     return None
