@@ -141,6 +141,44 @@ __device__ __forceinline__ double wave_sum_d_lane63(double v)
     v += dpp_mov_f64<0x143, 0xc>(v);
     return v;
 }
+// Jacobi rotation that annihilates a_pq: t = sgn(d) 2 a_pq / (|d| + sqrt(d^2 + 4 a_pq^2)) with d = a_qq - a_pp (the textbook tangent with numerator and
+// denominator multiplied by 2 |a_pq|: one square root and one reciprocal instead of a division, a square root and a division), c = 1 / sqrt(1 + t^2),
+// s = t c.  v_rsq_f64 / v_rcp_f64 with Newton corrections: accurate to rounding, not correctly rounded -- the iteration converges to the same
+// eigen-decomposition, and a round waits for 33 lanes to finish this chain.
+__device__ __forceinline__ double mg_rsqrt(double d)
+{
+    double y = __builtin_amdgcn_rsq(d);
+    const double e = __builtin_fma(-d * y, y, 1.0);
+    return __builtin_fma(y * e, __builtin_fma(e, 0.375, 0.5), y);
+}
+__device__ __forceinline__ void jacobi_cs(double app, double aqq, double apq, double &c, double &s)
+{
+    const double d = aqq - app, a2 = 2.0 * apq;
+    const double x = __builtin_fma(d, d, a2 * a2);
+    const double h = x * mg_rsqrt(x);
+    const double den = fabs(d) + h;
+    double r = __builtin_amdgcn_rcp(den);
+    r = r * __builtin_fma(-den, r, 2.0);
+    r = r * __builtin_fma(-den, r, 2.0);
+    const double t = (d >= 0 ? a2 : -a2) * r;
+    c = mg_rsqrt(__builtin_fma(t, t, 1.0));
+    s = t * c;
+}
+
+__device__ __forceinline__ void marg_corrector(double *r, double *J, int nc, const double rho1, const double rho2)
+{
+    // ResidualBlockInfo::Evaluate / ceres::Corrector on one 2-row Jacobian block with leading dimension nc (in place, r untouched)
+    const double sq = r[0] * r[0] + r[1] * r[1];
+    const double sr = sqrt(rho1);
+    double alpha_sq = 0.0;
+    if (!(sq == 0.0 || rho2 <= 0.0)) { const double Dd = 1.0 + 2.0 * sq * rho2 / rho1; alpha_sq = (1.0 - sqrt(Dd)) / sq; }
+    for (int j = 0; j < nc; j++) {
+        const double rj = r[0] * J[j] + r[1] * J[nc + j];
+        J[j] = sr * (J[j] - alpha_sq * r[0] * rj);
+        J[nc + j] = sr * (J[nc + j] - alpha_sq * r[1] * rj);
+    }
+}
+
 // ---- DPP reductions with a wave-uniform result (no LDS crossbar, one VALU instruction per stage): row_shr 1/2/4/8 inside
 // every 16-lane row, row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2-3; lane 63 then holds the reduction of the
 // wave and lane 31 that of lanes 0..31.  max / min are idempotent, so lanes without a source simply keep their own value.

@@ -175,6 +175,9 @@ static inline void launch_cloud_grids(hipStream_t st, const CloudJob *jobs_d, in
 }
 
 // ---- small dense pieces, same arithmetic as oracle/lo_mapping.c --------------------------------------------------
+#ifndef LMONO_MAP_FAST_ROT
+#define LMONO_MAP_FAST_ROT 0      // 1: the 3 x 3 Jacobi rotations from v_rsq / v_rcp (a measurement: the oracle's arithmetic is the default)
+#endif
 // ascending eigenvalues / eigenvectors (columns) of a symmetric 3x3: cyclic Jacobi
 __device__ void sym_eig3(const double *A, double *evals, double *evecs)
 {
@@ -188,9 +191,14 @@ __device__ void sym_eig3(const double *A, double *evals, double *evecs)
             for (int q = p + 1; q < 3; q++) {
                 const double apq = a[p * 3 + q];
                 if (apq == 0.0) continue;
+#if LMONO_MAP_FAST_ROT
+                double c, s;
+                jacobi_cs(a[p * 3 + p], a[q * 3 + q], apq, c, s);
+#else
                 const double theta = (a[q * 3 + q] - a[p * 3 + p]) / (2.0 * apq);
                 const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
                 const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#endif
                 for (int k = 0; k < 3; k++) {
                     const double akp = a[k * 3 + p], akq = a[k * 3 + q];
                     a[k * 3 + p] = c * akp - s * akq; a[k * 3 + q] = s * akp + c * akq;
