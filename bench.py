@@ -225,6 +225,23 @@ def bench_map(args):
         got = run()
     ctx.synchronize()
     el = time.perf_counter() - t0
+    host_tables = None
+    if B == 1:       # the same stream through lmono_mapper_process_batch (cube table on the host, two waits per frame: round 4's frame), untimed extra
+        hm = lmono_amd.Mapper(ctx)
+        def run_host():
+            hm.reset()
+            last = None
+            for k in range(n):
+                q, t, _ = lmono_amd.Mapper.process_batch(ctx, [hm], [batch], [k], odo[k:k + 1, :4], odo[k:k + 1, 4:])
+                last = np.concatenate([q[0], t[0]])
+            return last
+        run_host()
+        ctx.synchronize()
+        th = time.perf_counter()
+        for _ in range(max(1, args.steps // 4)):
+            last_h = run_host()
+        ctx.synchronize()
+        host_tables = {"frames_per_s": round(n * max(1, args.steps // 4) / (time.perf_counter() - th), 1), "last_pose_identical": bool(np.array_equal(last_h, got[-1]))}
     # ---- cpu_baseline leg: the only place the oracle is touched
     from oracle import oracle as O
     ref = O.run_mapping(x, off, odo)
@@ -238,7 +255,9 @@ def bench_map(args):
            "value": round(n * B * args.steps / el, 1), "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32 clouds / f64 solve", "data": "synthetic",
-           "config": {"workload": "S1 HDL-64 sequence, %d scans, laserMapping after laserOdometry (SURVEY 8f-1)" % n, "streams": B},
+           "config": {"workload": "S1 HDL-64 sequence, %d scans, laserMapping after laserOdometry (SURVEY 8f-1)" % n, "streams": B,
+                      "table": ("device (lmono_mapper_process: one wait per frame)" if B == 1 else "host (lmono_mapper_process_batch: two waits per frame)"),
+                      "same_stream_with_host_table": host_tables},
            "roofline": {"bound": "hbm", "kernel": "per-frame kernel chain (k_vox_* filter chain, k_grid_*, k_map_correspond, k_map_factor, k_map_solve)",
                         "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": _map_traffic(B),
                         "algorithmic_bytes_per_frame": round(alg / n),
