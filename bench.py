@@ -226,7 +226,7 @@ def bench_map(args):
     ctx.synchronize()
     el = time.perf_counter() - t0
     host_tables = None
-    if B == 1:       # the same stream through lmono_mapper_process_batch (cube table on the host, two waits per frame: round 4's frame), untimed extra
+    if B == 1 and not args.no_extras:       # the same stream through lmono_mapper_process_batch (cube table on the host, two waits per frame: round 4's frame), untimed extra
         hm = lmono_amd.Mapper(ctx)
         def run_host():
             hm.reset()

@@ -2,7 +2,7 @@
 # rocprofv3 kernel-trace summary of the single-stream laserMapping bench (run through gpurun).  usage: bash scripts/map_trace.sh <tag>
 O=$PWD/gpurun_out/${1:-map_tr}; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:-/root/repo}
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/t -- python3 bench.py --workload map --scans 64 --streams 1 --cpu-sample 0 > $O/b.json 2> $O/err.txt
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/t -- python3 bench.py --workload map --scans 64 --streams 1 --cpu-sample 0 --no-extras > $O/b.json 2> $O/err.txt
 find $O/t -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/stats.csv
 rm -rf $O/t
 python3 - <<PY

@@ -59,7 +59,7 @@ for win in 1 1024; do
 done
 echo "[2/3] BA done"
 # ---- 3. laserMapping
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_map -- python3 bench.py --workload map --scans 64 --streams 1 > $OUT/map_bench_1stream_under_rocprof.json 2> $OUT/trace_map.err
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_map -- python3 bench.py --workload map --scans 64 --streams 1 --no-extras > $OUT/map_bench_1stream_under_rocprof.json 2> $OUT/trace_map.err
 stats $OUT/trace_map $OUT/map_kernel_stats_1stream.csv
 timeout -k 10 300 python3 bench.py --workload map --scans 64 --streams 1 > $OUT/map_bench_1stream.json 2>> $OUT/trace_map.err
 timeout -k 10 300 python3 bench.py --workload map --scans 64 --streams 64 > $OUT/map_bench_64streams.json 2>> $OUT/trace_map.err
@@ -68,7 +68,7 @@ LMONO_MAP_HOST_TABLES=1 timeout -k 10 300 python3 bench.py --workload map --scan
 # odometry's kernels of the set-up are listed too, the frame's are k_map_* / k_vox_* / k_grid_* / k_copy_*)
 : > $OUT/map_pmc_1stream.txt
 for grp in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_map -- python3 bench.py --workload map --scans 64 --streams 1 --steps 1 --warmup 0 --cpu-sample 0 > /dev/null 2> $OUT/pmc_map.err
+  timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_map -- python3 bench.py --workload map --scans 64 --streams 1 --steps 1 --warmup 0 --cpu-sample 0 --no-extras > /dev/null 2> $OUT/pmc_map.err
   echo "## $grp (KB, summed over the launches of the run: 64 frames)" >> $OUT/map_pmc_1stream.txt
   python3 scripts/pmc_summary.py $OUT/pmc_map --sum 2>&1 | grep -E "k_map|k_vox|k_grid|k_copy" >> $OUT/map_pmc_1stream.txt
   rm -rf $OUT/pmc_map
@@ -82,7 +82,7 @@ for ln in open("$OUT/map_pmc_1stream.txt"):
     m = re.search(r"'" + (cur or "x") + r"': (\d+)", ln)
     if m: tot[cur] += float(m.group(1))
 frames = 64
-d = {"source": "profiles/r5/map_pmc_1stream.txt (scripts/profile_round5.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --workload map --scans 64 --streams 1 --steps 1 --warmup 0: every k_map_* / k_vox_* / k_grid_* / k_copy_* launch of 64 frames)",
+d = {"source": "profiles/r5/map_pmc_1stream.txt (scripts/profile_round5.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --workload map --scans 64 --streams 1 --steps 1 --warmup 0 --no-extras: every k_map_* / k_vox_* / k_grid_* / k_copy_* launch of 64 frames)",
      "fetch_kb_total": tot["FETCH_SIZE"], "write_kb_total": tot["WRITE_SIZE"], "frames": frames,
      "correction": "gfx950: FETCH_SIZE (KB) counts 128-B requests at 64 B -> doubled; WRITE_SIZE as is",
      "hbm_bytes_per_frame": round((2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024 / frames)}
