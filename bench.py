@@ -60,7 +60,7 @@ def bench_ba(args):
            "config": {"workload": "S2 11-frame windows, %d independent windows" % args.windows, "mean_obs": n_obs, "mean_features": n_f,
                       "mean_iterations": iters},
            "roofline": {"bound": "mfma", "kernel": "k_ba_solve", "achieved": round(tflops, 3), "peak": FP64_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(tflops / FP64_PEAK_TFLOPS, 5), "traffic": None,
+                        "unit": "TFLOP/s", "frac": round(tflops / FP64_PEAK_TFLOPS, 5), "traffic": _ba_traffic(args.windows),
                         "note": "fp64; J^T J and the Schur complement run on v_mfma_f64_16x16x4_f64, the rest of an iteration "
                                 "(72x72 Cholesky, triangular solves, reductions) is dependent-latency bound inside one workgroup per window"},
            "cpu_baseline": {"value": round(1.0 / cpu_s, 2), "unit": "windows/s", "cores": 1, "kind": "port",
@@ -165,6 +165,15 @@ def bench_ba_seq(args):
         res["ate_vs_cpu_m"] = round(float(np.sqrt(np.mean(np.sum((odo[:k, 1:4] - ref[:k, 1:4]) ** 2, axis=1)))), 6)
         res["frames_compared_vs_cpu"] = k
     print(json.dumps(res), flush=True)
+
+
+def _ba_traffic(windows):
+    """HBM bytes of one k_ba_solve launch from the committed counter summary (scripts/profile_round5.sh: 1 and 1024 windows), or None."""
+    path = os.path.join(ROOT, "profiles", "r5", "pmc_k_ba_solve.json")
+    if os.path.exists(path):
+        with open(path) as fh:
+            return json.load(fh).get("hbm_bytes_per_launch", {}).get(str(windows))
+    return None
 
 
 def _map_traffic(streams):

@@ -57,6 +57,35 @@ for win in 1 1024; do
     rm -rf $OUT/pmcba
   done
 done
+# HBM traffic of a k_ba_solve launch (1 and 1024 windows): FETCH_SIZE and WRITE_SIZE in separate passes
+python3 - <<PY > /dev/null
+import json; json.dump({}, open("$OUT/pmc_k_ba_solve.json", "w"))
+PY
+for win in 1 1024; do
+  for grp in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d $OUT/pmcba -- python3 bench.py --workload ba --windows $win --steps 1 --warmup 0 > /dev/null 2> $OUT/pmcba.err
+    echo "## $win window(s), $grp (KB per launch)" >> $OUT/ba_pmc_k_ba_solve.txt
+    python3 scripts/pmc_summary.py $OUT/pmcba 2>&1 | grep "k_ba_solve" >> $OUT/ba_pmc_k_ba_solve.txt
+    rm -rf $OUT/pmcba
+  done
+done
+python3 - <<PY
+import re, json
+cur = None; val = {}
+for ln in open("$OUT/ba_pmc_k_ba_solve.txt"):
+    m = re.match(r"## (\d+) window\(s\), (FETCH_SIZE|WRITE_SIZE)", ln)
+    if m: cur = (m.group(1), m.group(2)); continue
+    if cur:
+        k = re.search(r"'" + cur[1] + r"': (\d+)", ln)
+        if k: val[cur] = float(k.group(1)); cur = None
+out = {"source": "profiles/r5/ba_pmc_k_ba_solve.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --workload ba --windows 1 | 1024 --steps 1 --warmup 0; KB per launch)",
+       "correction": "gfx950: FETCH_SIZE (KB) counts 128-B requests at 64 B -> doubled; WRITE_SIZE as is", "hbm_bytes_per_launch": {}}
+for w in ("1", "1024"):
+    if (w, "FETCH_SIZE") in val and (w, "WRITE_SIZE") in val:
+        out["hbm_bytes_per_launch"][w] = round((2 * val[(w, "FETCH_SIZE")] + val[(w, "WRITE_SIZE")]) * 1024)
+json.dump(out, open("$OUT/pmc_k_ba_solve.json", "w"), indent=1)
+print("k_ba_solve traffic per launch:", out["hbm_bytes_per_launch"])
+PY
 echo "[2/3] BA done"
 # ---- 3. laserMapping
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_map -- python3 bench.py --workload map --scans 64 --streams 1 --no-extras > $OUT/map_bench_1stream_under_rocprof.json 2> $OUT/trace_map.err
