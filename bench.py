@@ -66,6 +66,10 @@ def bench_ba(args):
            "cpu_baseline": {"value": round(1.0 / cpu_s, 2), "unit": "windows/s", "cores": 1, "kind": "port",
                             "sample": "16 windows, oracle/lo_ba_solve.c (-O3), 1 thread"},
            "final_cost_rel_diff_vs_cpu": float(max(abs(sm[k, 1] - ref[k][3].final_cost) / ref[k][3].final_cost for k in range(min(len(base), args.windows))))}
+    if out["roofline"]["traffic"]:       # the counters' HBM traffic over this run's launch time (the scratch of many windows is not L2-resident)
+        gbps = out["roofline"]["traffic"] / (ms * 1e-3) / 1e9
+        out["roofline"]["hbm_traffic_GBps"] = round(gbps, 1)
+        out["roofline"]["hbm_frac"] = round(gbps / HBM_PEAK_GBS, 4)
     print(json.dumps(out), flush=True)
 
 
