@@ -71,7 +71,8 @@ int         lmono_synchronize(lmono_ctx *);
 #define LMONO_OPT_BOUNDARY_TOL 4
 /* workgroups per window of lmono_ba_solve (the K = 1 / 2 / 4 / 8 workgroups of a window share its linearisations and candidate costs; the sums are formed
  * per 16-observation segment and added in segment order, so the result is the same bit for bit whatever K is): 0 (default) = as many as keep the
- * batch within half the compute units (8 for up to 16 windows, 4 for up to 32, 2 for up to 64, else 1); 1, 2, 4, 8 = that many.  Takes effect at the next
+ * batch within half the compute units (8 for up to 16 windows, 4 for up to 32, 2 for up to 64, else 1; at most 4 when the windows average fewer than 64
+ * segments); 1, 2, 4, 8 = that many.  Takes effect at the next
  * lmono_ba_batch_create / _update of the context (the scratch is sized then).  (Slot 5 was round 3's LMONO_OPT_ODOM_PERSIST, removed in round 4.)   */
 #define LMONO_OPT_BA_CLUSTER 5
 /* 6: round 3's LMONO_OPT_CORR_SECT (a schedule measured slower and removed); only 0 is accepted */
