@@ -174,20 +174,23 @@ def bench_ba_seq(args):
 def _ba_traffic(windows):
     """HBM bytes of one k_ba_solve launch from the committed counter summary (scripts/profile_round5.sh: 1 and 1024 windows), or None."""
     path = os.path.join(ROOT, "profiles", "r5", "pmc_k_ba_solve.json")
-    if os.path.exists(path):
+    try:
         with open(path) as fh:
             return json.load(fh).get("hbm_bytes_per_launch", {}).get(str(windows))
-    return None
+    except (OSError, ValueError, AttributeError):          # no summary, or an unreadable one: the line carries null
+        return None
 
 
 def _map_traffic(streams):
     """HBM bytes per single-stream laserMapping frame from the committed counter summary (scripts/profile_round5.sh), or None."""
-    for rnd in ("r5",):
-        path = os.path.join(ROOT, "profiles", rnd, "pmc_map_frame.json")
-        if streams == 1 and os.path.exists(path) and not os.environ.get("LMONO_MAP_HOST_TABLES"):      # (the counters are the device-table frame's)
-            with open(path) as fh:
-                return json.load(fh).get("hbm_bytes_per_frame")
-    return None
+    path = os.path.join(ROOT, "profiles", "r5", "pmc_map_frame.json")
+    if streams != 1 or os.environ.get("LMONO_MAP_HOST_TABLES"):      # (the counters are the device-table frame's)
+        return None
+    try:
+        with open(path) as fh:
+            return json.load(fh).get("hbm_bytes_per_frame")
+    except (OSError, ValueError, AttributeError):
+        return None
 
 
 def bench_map(args):
@@ -897,11 +900,14 @@ def main():
         for rnd in ("r5", "r4", "r3", "r2", "r1"):
             pmc_path = os.path.join(ROOT, "profiles", rnd, "pmc_%s.json" % dom)
             if os.path.exists(pmc_path) and chains == 256:
-                with open(pmc_path) as fh:
-                    pmc = json.load(fh)
-                if dom != "k_correspond" or pmc.get("chain_groups", 1) == chain_groups:     # counters of a launch of this size only
-                    traffic = pmc["hbm_bytes_per_launch"]
-                    break
+                try:
+                    with open(pmc_path) as fh:
+                        pmc = json.load(fh)
+                    if dom != "k_correspond" or pmc.get("chain_groups", 1) == chain_groups:     # counters of a launch of this size only
+                        traffic = pmc["hbm_bytes_per_launch"]
+                        break
+                except (OSError, ValueError, KeyError, AttributeError):      # an unreadable summary: the line carries null
+                    pass
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "ms_per_launch": round(ms_launch, 4), "launches_per_step": round(launches_per_step[dom], 1),
