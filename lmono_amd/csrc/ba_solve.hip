@@ -327,7 +327,9 @@ template <bool kBig> __device__ __forceinline__ double &ba_vref(double *lds, dou
 #define BA_F(name, f) ba_fref<kBig>(L.name, G.name, (f))
 #define BA_V(name, k) ba_vref<kBig>(L.name, G.name, (k), c.P)
 // inverse depth of feature f of the state being evaluated; first observation of feature f (window-relative); anchor frame; segment word
-#define BA_VINV(f) (kBig ? ld_sh<kCl>(G.vinv + (f)) : L.vinv[(f)])
+// (kBig followers read them straight from the leader's mail box, which the leader rewrites with sc1 stores at every publish inside the same launch: the
+// read must bypass this CU's L1 on ANY placement -- kFol -- or a line cached during the previous linearisation answers with the old state)
+#define BA_VINV(f) (kBig ? ld_sh<kCl || kFol>(G.vinv + (f)) : L.vinv[(f)])
 #define BA_FOBS(f) (kBig ? G.fobs[(f)] - G.o0 : (int)L.fobs[(f)])
 #define BA_FANCHOR(f) (kBig ? G.fanchor[(f)] : (int)L.fanchor[(f)])
 #define BA_SEG(sg) (kBig ? (unsigned int)G.seg[(sg)] : (unsigned int)L.seg[(sg)])
@@ -351,7 +353,7 @@ __device__ __forceinline__ bool ba_wait_flags(const unsigned int *flags, int n, 
         const bool there = lane >= n || ba_flag_load(flags + (lane < n ? lane : 0)) >= target;
         if (__all(there)) return true;
         __builtin_amdgcn_s_sleep(1);
-        if ((++spins & 1023) == 0 && (spins > (1 << 23) || __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+        if ((++spins & 1023) == 0 && (spins > (1 << 19) || __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
             __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return false;
         }
@@ -693,7 +695,7 @@ __device__ __forceinline__ void ba_done(const BaBatch &B, const BaCtx &c, BaLds 
 
 // one workgroup's share of an evaluation: the segments gw, gw + GW, ... of the window (a linearisation takes two per round and wave, a cost evaluation
 // four).  Every result goes to the segment's / the observation's own record.
-template <bool kJac, bool kCl, bool kBig>
+template <bool kJac, bool kCl, bool kBig, bool kFol = false>      // kFol: a follower workgroup (its inverse depths are the leader's mail box)
 __device__ __forceinline__ void ba_segments(const BaBatch &B, const BaCtx &c, BaLds &L, const BaBig &G, const double *ex, const double *pairdat)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1475,8 +1477,8 @@ __device__ __noinline__ void ba_follow(const BaBatch &B, const BaCtx c, BaLds &L
         __syncthreads();   // pair records are visible
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if (cmd == 1) {
-            if ((int)ld_sh<true>(mb + 2) == ba_xcc_id()) ba_segments<true, false, kBig>(B, c, L, G, L.cex, pairdat);      // the leader's XCD: plain stores stay in the shared L2
-            else ba_segments<true, true, kBig>(B, c, L, G, L.cex, pairdat);
+            if ((int)ld_sh<true>(mb + 2) == ba_xcc_id()) ba_segments<true, false, kBig, true>(B, c, L, G, L.cex, pairdat);      // the leader's XCD: plain stores stay in the shared L2
+            else ba_segments<true, true, kBig, true>(B, c, L, G, L.cex, pairdat);
             ba_done<false>(B, c, L);
         }
         if (tid == 0) L.eval_no++;

@@ -41,6 +41,9 @@ struct lmono_ctx {
     struct Chunk { char *base; size_t cap; };
     std::vector<Chunk> arena;
     size_t arena_chunk = 0, arena_off = 0;
+    int n_cu = 0;                            // compute units of the device (hipDeviceProp_t::multiProcessorCount)
+    int map_budget = 0;
+    int cluster_budget = 0;                  // workgroups a cluster kernel (k_ba_solve<kCl>, k_map_solve) may keep resident while they poll each other: half the CUs
     char *stage = nullptr;                   // pinned staging of DevBuf's small uploads (stage_all: every buffer ever allocated, freed with the context)
     size_t stage_cap = 0;
     std::vector<void *> stage_all;
@@ -120,6 +123,19 @@ extern "C" lmono_ctx *lmono_create(int device)
     c->device = device;
     if (const char *e = getenv("LMONO_ODOM_STREAM_PRIORITY")) c->odom_prio = atoi(e) != 0;
     if (const char *e = getenv("GPU_MAX_HW_QUEUES")) c->many_queues = atoi(e) >= 8;
+    {
+        // residency budget of the cluster kernels: every workgroup of a cluster spins on its partners, so all of them must be resident at once.  k_ba_solve
+        // takes a whole CU's LDS (one workgroup per CU); half the CUs leaves room for whatever else the card runs (LMONO_CLUSTER_BUDGET overrides: CU masks,
+        // CPX partitions report their own multiProcessorCount and need no override)
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete c; return nullptr; }
+        c->n_cu = prop.multiProcessorCount;
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_ba_solve<true, false>, kBaT, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        c->cluster_budget = std::max(8, c->n_cu * per_cu / 2);
+        c->map_budget = std::max(8, c->n_cu / 2);         // k_map_solve: one workgroup per CU assumed, as measured (more fit, none are counted on)
+        if (const char *e = getenv("LMONO_CLUSTER_BUDGET")) { const int v = atoi(e); if (v >= 1) c->cluster_budget = c->map_budget = v; }
+    }
     if (hipMalloc((void **)&c->stats_d, 320) != hipSuccess || hipMemset(c->stats_d, 0, 320) != hipSuccess) { delete c; return nullptr; }
     // the selection kernel needs ~62 KB of dynamic LDS
     if (hipFuncSetAttribute((const void *)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * sel_slice_bytes(kRingCap) + 4 * kSelScratch) != hipSuccess) { delete c; return nullptr; }
@@ -1126,6 +1142,11 @@ struct lmono_ba_batch {
     bool big = false;           // a window of the last fill holds more than kBaLdsFeat features: the kBig kernels (per-feature vectors in an L2 scratch)
     bool flags_clean = false;   // the cluster's flag words and the failure flag are zero (a fill zeroes them; a solve dirties them)
     double *poses0 = nullptr, *ex0 = nullptr, *invd0 = nullptr;   // initial state for lmono_ba_batch_reset
+    // the state (poses | ex | inverse depths: neighbours in the blob) as it was before the last CLUSTER solve, and that solve's iteration cap: a cluster whose
+    // workgroups were not all resident gives up (bounded polls) and lmono_ba_batch_read runs the solve again with one workgroup per window from here
+    // -- same bytes by construction
+    char *pre = nullptr; size_t pre_bytes = 0;
+    int retries = 0;            // cluster solves that had to be run again (diagnosis; LMONO_BA_TEST_FAIL exercises the path)
 };
 
 // the arrays of one ba_fill: laid out first (add), then staged / placed in one go (commit)
@@ -1293,7 +1314,7 @@ static int ba_fill(lmono_ctx *c, lmono_ba_batch *b, const lmono_ba_desc *d)
         if (forced <= 0 && (int)seg_tab.size() < 64 * W) K = 4;
         if (K > kBaMaxK) K = kBaMaxK;
         if (K == 3) K = 2; else if (K > 4 && K < 8) K = 4;
-        while (K > 1 && ((W + 7) / 8) * 8 * K > 128) K >>= 1;
+        while (K > 1 && ((W + 7) / 8) * 8 * K > c->cluster_budget) K >>= 1;      // (256 CUs: 128 workgroups -- 8 for up to 16 windows ... 1 above 64)
         b->cluster = K;
     }
     pk.add(v.pairdat, (const double *)nullptr, (size_t)b->cluster * pair_ij.size() * kBaPairRec);
@@ -1304,6 +1325,11 @@ static int ba_fill(lmono_ctx *c, lmono_ba_batch *b, const lmono_ba_desc *d)
     pk.add(v.gprog, (const int *)nullptr, (size_t)W * kBaGprog);
     pk.add(v.cpart, (const double *)nullptr, seg_tab.size());
     pk.add(v.cand, (const double *)nullptr, (size_t)W * v.feat_cap);
+    {
+        auto al = [](size_t bytes) { return ((bytes ? bytes : 8) + 255) & ~(size_t)255; };
+        b->pre_bytes = al(sizeof(double) * (size_t)W * kBaMaxPoses * 7) + al(sizeof(double) * (size_t)W * 7) + al(sizeof(double) * (size_t)TF);
+        pk.add(b->pre, (const char *)nullptr, b->pre_bytes);
+    }
     // everything is staged in the batch's pinned buffer: the vectors above may go, and nothing waits here
     { const int rc = pk.commit(c, b); if (rc) { c->err = "lmono_ba_batch_create: device allocation / upload failed"; return LMONO_ENOMEM; } }
     v.feat_off = feat_off; v.obs_off = obs_off; v.flags = flags; v.feat_anchor = anch;
@@ -1334,6 +1360,13 @@ extern "C" int lmono_ba_batch_update(lmono_ctx *c, lmono_ba_batch *b, const lmon
     return rc;
 }
 
+static int ba_launch_single(lmono_ctx *c, lmono_ba_batch *b)
+{
+    if (b->big) hipLaunchKernelGGL((k_ba_solve<false, true>), dim3(b->n_windows), dim3(kBaT), 0, c->stream, b->v, 1, 0);
+    else hipLaunchKernelGGL((k_ba_solve<false, false>), dim3(b->n_windows), dim3(kBaT), 0, c->stream, b->v, 1, 0);          // its LDS is static (g_ba_lds)
+    return check_launch(c, "k_ba_solve");
+}
+
 extern "C" int lmono_ba_solve(lmono_ctx *c, lmono_ba_batch *b, int max_iterations)
 {
     if (!c || !b || max_iterations < 0) return LMONO_EINVAL;
@@ -1347,16 +1380,18 @@ extern "C" int lmono_ba_solve(lmono_ctx *c, lmono_ba_batch *b, int max_iteration
             HIP_TRY(c, hipMemsetAsync(b->v.fail, 0, sizeof(int), c->stream));
         }
         b->flags_clean = false;
+        // the state this solve starts from, for the one-workgroup re-run of a cluster that was not resident (lmono_ba_batch_read)
+        if ((const char *)(b->v.inv_depth + b->total_feat) - (const char *)b->v.poses <= (ptrdiff_t)b->pre_bytes && (const char *)b->v.ex > (const char *)b->v.poses)
+            HIP_TRY(c, hipMemcpyAsync(b->pre, b->v.poses, (size_t)((const char *)(b->v.inv_depth + b->total_feat) - (const char *)b->v.poses), hipMemcpyDeviceToDevice, c->stream));
+        static const int test_fail = [] { const char *e = getenv("LMONO_BA_TEST_FAIL"); return e ? atoi(e) : 0; }();   // test hook: the cluster gives up at its first poll
+        if (test_fail) HIP_TRY(c, hipMemsetAsync(b->v.fail, 1, 1, c->stream));
         static const int spread = [] { const char *e = getenv("LMONO_BA_SPREAD"); return e ? atoi(e) : 0; }();      // test hook: a window's workgroups on different XCDs
         const dim3 grid(((b->n_windows + 7) / 8) * 8 * b->cluster);
         if (b->big) hipLaunchKernelGGL((k_ba_solve<true, true>), grid, dim3(kBaT), 0, c->stream, b->v, b->cluster, spread);
         else hipLaunchKernelGGL((k_ba_solve<true, false>), grid, dim3(kBaT), 0, c->stream, b->v, b->cluster, spread);
-    } else
-    {
-        if (b->big) hipLaunchKernelGGL((k_ba_solve<false, true>), dim3(b->n_windows), dim3(kBaT), 0, c->stream, b->v, 1, 0);
-        else hipLaunchKernelGGL((k_ba_solve<false, false>), dim3(b->n_windows), dim3(kBaT), 0, c->stream, b->v, 1, 0);          // its LDS is static (g_ba_lds)
+        return check_launch(c, "k_ba_solve");
     }
-    return check_launch(c, "k_ba_solve");
+    return ba_launch_single(c, b);
 }
 
 extern "C" int lmono_ba_batch_reset(lmono_ctx *c, lmono_ba_batch *b)
@@ -1369,7 +1404,12 @@ extern "C" int lmono_ba_batch_reset(lmono_ctx *c, lmono_ba_batch *b)
     return LMONO_OK;
 }
 
+static int ba_read(lmono_ctx *c, lmono_ba_batch *b, double *poses_h, double *ex_h, double *inv_depth_h, double *summary_h, bool may_retry);
 extern "C" int lmono_ba_batch_read(lmono_ctx *c, lmono_ba_batch *b, double *poses_h, double *ex_h, double *inv_depth_h, double *summary_h)
+{
+    return ba_read(c, b, poses_h, ex_h, inv_depth_h, summary_h, true);
+}
+static int ba_read(lmono_ctx *c, lmono_ba_batch *b, double *poses_h, double *ex_h, double *inv_depth_h, double *summary_h, bool may_retry)
 {
     if (!c || !b) return LMONO_EINVAL;
     if (b->n_windows <= 0) { c->err = "lmono_ba_batch_read: the batch holds no problem (failed update)"; return LMONO_EINVAL; }
@@ -1397,6 +1437,19 @@ extern "C" int lmono_ba_batch_read(lmono_ctx *c, lmono_ba_batch *b, double *pose
         if (summary_h) HIP_TRY(c, hipMemcpyAsync(summary_h, b->v.summary, sizeof(double) * w * 6, hipMemcpyDeviceToHost, c->stream));
         if (b->cluster > 1) HIP_TRY(c, hipMemcpyAsync(&failed, b->v.fail, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    if (failed && may_retry && b->pre) {
+        // A workgroup of some window's cluster did not arrive within the poll bound (a CU mask, a partition, another process's resident workgroups: the
+        // residency budget is a guess about a card this context does not own).  Every window of the launch may have stopped early, so the whole solve runs
+        // again from the state it started from with ONE workgroup per window, which needs nobody resident but itself -- the same bytes (the sums are formed
+        // per segment in segment order whatever K is).
+        b->retries++;
+        const size_t range = (size_t)((const char *)(b->v.inv_depth + b->total_feat) - (const char *)b->v.poses);
+        HIP_TRY(c, hipMemcpyAsync(b->v.poses, b->pre, range, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipMemsetAsync(b->v.fail, 0, sizeof(int), c->stream));
+        const int rc = ba_launch_single(c, b);
+        if (rc) return rc;
+        return ba_read(c, b, poses_h, ex_h, inv_depth_h, summary_h, false);
     }
     if (failed) { c->err = "k_ba_solve: a workgroup of a window's cluster did not arrive (not all resident?): the solve is void"; return LMONO_ENODEV; }
     return LMONO_OK;
@@ -1770,7 +1823,7 @@ extern "C" int lmono_map_refine(lmono_ctx *c, int n_streams,
             hipLaunchKernelGGL(k_map_correspond, dim3((max_nq + 7) / 8, n_streams), dim3(256), 0, stream, (const MapStream *)st_d, outer);
             hipLaunchKernelGGL(k_map_factor, dim3((max_nq + 63) / 64, n_streams), dim3(64), 0, stream, (const MapStream *)st_d, outer);
         }
-        launch_map_solve(stream, (const MapStream *)st_d, n_streams, outer);
+        launch_map_solve(stream, (const MapStream *)st_d, n_streams, outer, c->map_budget);
     }
     (void)hipEventRecord(ev2, stream);
     int rc = check_launch(c, "map refine kernels");
@@ -2304,7 +2357,7 @@ static int mapper_process_dev(lmono_ctx *c, lmono_mapper *m, lmono_scan_batch *b
                 hipLaunchKernelGGL(k_map_correspond, dim3((unsigned)per_stream, 1u), dim3(256), 0, st, S_d, outer);
                 hipLaunchKernelGGL(k_map_factor, dim3((unsigned)std::max(1, (per_stream + 7) / 8), 1u), dim3(64), 0, st, S_d, outer);
             }
-            launch_map_solve(st, S_d, 1, outer);
+            launch_map_solve(st, S_d, 1, outer, c->map_budget);
         }
     }
     HIP_TRY(c, hipEventRecord(m->ev_solve, st));
@@ -2556,7 +2609,7 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
                     hipLaunchKernelGGL(k_map_correspond, dim3((unsigned)per_stream, (unsigned)act.size()), dim3(256), 0, st, S_d, outer);
                     hipLaunchKernelGGL(k_map_factor, dim3((unsigned)std::max(1, (per_stream + 7) / 8), (unsigned)act.size()), dim3(64), 0, st, S_d, outer);
                 }
-                launch_map_solve(st, S_d, (int)act.size(), outer);
+                launch_map_solve(st, S_d, (int)act.size(), outer, c->map_budget);
             }
         }
     }

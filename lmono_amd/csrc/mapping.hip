@@ -733,19 +733,19 @@ __global__ __launch_bounds__(kMsT) void k_map_solve(const MapStream *streams, in
 // of a cluster must be resident while it spins; the spin is bounded (a cluster that is not resident sets stats[6] and the host returns LMONO_ENODEV).
 // A stream's partial sums are split by K, so its pose depends at rounding level (1e-12, tests/test_mapping_gpu.py::test_solve_cluster_sizes_agree) on
 // how many streams share the call; the budget assumes the card is not shared with another process's resident workgroups.
-static inline int map_solve_cluster(int n_streams)
+static inline int map_solve_cluster(int n_streams, int budget)
 {
     static const int forced = [] { const char *e = getenv("LMONO_MAP_SOLVE_K"); return e ? atoi(e) : 0; }();        // measurement switch
     int K = forced > 0 ? forced : 8;          // one stream, K = 2 / 4 / 6 / 8: 2.24 / 2.45 / 2.52 / 2.56 k frames/s (round 5, the trust-region step on one wave; round 4's
                                               // kernel, where every wave repeated it, peaked at K = 4: 1.57 / 1.71 / 1.98 / 1.83 k for K = 1 / 2 / 4 / 8)
     if (K > kMsMaxK) K = kMsMaxK;
     const int groups = (n_streams + 7) / 8;
-    while (K > 1 && groups * 8 * K > 128) K--;
+    while (K > 1 && groups * 8 * K > budget) K--;          // budget: workgroups that may spin on each other at once (lmono_ctx::map_budget, from the device's CU count)
     return K;
 }
-static inline void launch_map_solve(hipStream_t st, const MapStream *S_d, int n_streams, int outer)
+static inline void launch_map_solve(hipStream_t st, const MapStream *S_d, int n_streams, int outer, int budget)
 {
-    const int K = map_solve_cluster(n_streams);
+    const int K = map_solve_cluster(n_streams, budget);
     hipLaunchKernelGGL(k_map_solve, dim3((unsigned)(((n_streams + 7) / 8) * 8 * K)), dim3(kMsT), 0, st, S_d, n_streams, K, outer);
 }
 

@@ -1,10 +1,11 @@
 #!/bin/bash
-# Phase cycles of k_marginalize on the Estimator's own windows: the -DLMONO_MG_PROF build replaces the in-tree library ON THE GPU BOX's copy of the tree
-# (estimator_seq loads it by rpath), 600 frames of the S2 stream; one line per call: tracks anchored at frame 0, their observations, cycles of the factor
+# Phase cycles of k_marginalize on the Estimator's own windows: the -DLMONO_MG_PROF build goes to a SCRATCH directory and is picked up through
+# LD_LIBRARY_PATH (estimator_seq carries a RUNPATH, which LD_LIBRARY_PATH precedes) -- the in-tree library is never replaced; 600 frames of the S2 stream; one line per call: tracks anchored at frame 0, their observations, cycles of the factor
 # pass / the Schur complement / the Jacobi eigen-decomposition (100 MHz constant clock x 24 = shader cycles at 2.4 GHz: the counter is s_memtime's).
 set -e
 O=gpurun_out/${1:-mg_prof}; mkdir -p $O
-hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -std=c++17 -DLMONO_MG_PROF -o lmono_amd/lib/liblmono_hip.so lmono_amd/csrc/lmono_hip.hip 2>/dev/null
+mkdir -p $O/lib
+hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -std=c++17 -DLMONO_MG_PROF -o $O/lib/liblmono_hip.so lmono_amd/csrc/lmono_hip.hip 2>/dev/null
 python3 - <<PY
 import sys
 sys.path.insert(0, '.')
@@ -12,8 +13,8 @@ from workloads import s2 as K
 st = K.make_stream(600, seed=2, stops=())
 K.write_stream('$O/stream600.bin', st)
 PY
-lmono_amd/host/estimator_seq $O/stream600.bin - sync | grep "^MGPROF" > $O/marg_phases.txt
-rm -f $O/stream600.bin
+LD_LIBRARY_PATH=$PWD/$O/lib:$LD_LIBRARY_PATH lmono_amd/host/estimator_seq $O/stream600.bin - sync | grep "^MGPROF" > $O/marg_phases.txt
+rm -rf $O/stream600.bin $O/lib
 python3 - <<PY
 import re
 rows=[[int(x) for x in re.findall(r"\d+", l)][1:] for l in open("$O/marg_phases.txt")]      # ([0] is the 0 of the label "F0")

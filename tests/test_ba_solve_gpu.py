@@ -176,3 +176,56 @@ def test_window_of_900_features_matches_the_oracle(oracle, gpu_ctx):
     assert len(too_big["inv_depth"]) > 1024
     with pytest.raises(lmono_amd.LmonoError):
         lmono_amd.BaBatch(gpu_ctx, [too_big])
+
+
+def test_large_window_cluster_repeats_give_one_workgroups_bytes(gpu_ctx):
+    """in the kBig instantiation a follower reads the inverse depths straight from the leader's mail box, which the leader rewrites at
+    every publish of the same launch; that read must bypass the follower's L1 on every placement (a line cached during the previous linearisation would
+    answer with the old state -- silently, and only when the L1 happened not to evict it).  The K = 8 solve of an ~870-feature window, repeated on one batch
+    (accepted steps: the state moves 30 times per solve), must give the one-workgroup solve's bytes every time."""
+    import lmono_amd
+    big = K.make_window(53, n_landmarks=20000, max_tracks=560, min_dist=14)
+    assert len(big["inv_depth"]) > 448
+    try:
+        gpu_ctx.set_option(gpu_ctx.OPT_BA_CLUSTER, 1)
+        _, want = _solve_gpu(gpu_ctx, [big])
+        assert want[3][0, 4] >= 10                                     # successful steps: the inverse depths did move
+        gpu_ctx.set_option(gpu_ctx.OPT_BA_CLUSTER, 8)
+        b = lmono_amd.BaBatch(gpu_ctx, [big])
+        for rep in range(12):
+            b.reset(); b.solve(30)
+            got = b.read()
+            for a, c in zip(want, got):
+                assert a.tobytes() == c.tobytes(), "repeat %d of the K = 8 solve differs from K = 1" % rep
+    finally:
+        gpu_ctx.set_option(gpu_ctx.OPT_BA_CLUSTER, 0)
+
+
+def test_cluster_that_gives_up_is_solved_again_with_one_workgroup(tmp_path):
+    """every workgroup of a cluster must be resident while it polls; the budget (half the device's CUs, from
+    hipDeviceProp_t::multiProcessorCount) is a guess about a card the context does not own.  When a poll runs out, the failure flag comes back set and
+    lmono_ba_batch_read re-runs the whole solve from the state it started from with ONE workgroup per window (same bytes by construction) instead of
+    failing the Estimator's frame.  LMONO_BA_TEST_FAIL=1 sets the flag before the launch; LMONO_CLUSTER_BUDGET=16 shows the budget is honoured."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import numpy as np, lmono_amd\n"
+            "from tests import ba_cases as K\n"
+            "ctx = lmono_amd.Context(0)\n"
+            "ws = [K.make_window(s) for s in (60, 61)] + [K.make_window(62, n_landmarks=2500)]\n"
+            "b = lmono_amd.BaBatch(ctx, ws); b.solve(30); p, e, d, sm = b.read()\n"
+            "b.solve(30); p2, e2, d2, sm2 = b.read()\n"                 # a second solve continues from the first one's result: the snapshot is per solve
+            "np.savez(sys.argv[1], p=p, e=e, d=d, sm=sm, p2=p2, e2=e2, d2=d2, sm2=sm2)\n") % root
+    out = {}
+    for name, env in (("k1", {"LMONO_BA_CLUSTER": "1"}), ("k8_fail", {"LMONO_BA_CLUSTER": "8", "LMONO_BA_TEST_FAIL": "1"}),
+                      ("budget16", {"LMONO_CLUSTER_BUDGET": "16"})):
+        f = str(tmp_path / (name + ".npz"))
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[name] = np.load(f)
+    for name in ("k8_fail", "budget16"):
+        for key in ("p", "e", "d", "sm", "p2", "e2", "d2", "sm2"):
+            assert out[name][key].tobytes() == out["k1"][key].tobytes(), "%s: %s differs from the one-workgroup solve" % (name, key)
+    assert (out["k1"]["sm"][:, 3] <= 1).all()
