@@ -274,6 +274,11 @@ int lmono_outlier_scores(lmono_ctx *, int n_windows, const int *feat_off_h, cons
                          int track_cnt, double factor_weight, double *score_h);
 int lmono_shift_depth(lmono_ctx *, const double *back_R0, const double *back_P0, const double *R1, const double *P1, const double *tlc,
                       int n, const double *pt_i_h, const double *depth_h, double *depth_out_h);
+/* The same for n_windows independent Estimators in one call (EstimatorBatch: N sequences stepped in lock-step, SURVEY.md 8e "parallel only across
+ * independent sequences"): frames_h [n_windows][40] = back_R0 (9), back_P0 (3), R1 (9), P1 (3), TLC (16, row-major 4 x 4) of each window;
+ * track_off_h [n_windows + 1] offsets of the windows' tracks in pt_i_h / depth_h / depth_out_h.  A window's results are the single call's, bit for bit. */
+int lmono_shift_depth_batch(lmono_ctx *, int n_windows, const double *frames_h, const int *track_off_h,
+                            const double *pt_i_h, const double *depth_h, double *depth_out_h);
 
 /* ---- marginalisation prior: Estimator::margin(), MARGIN_OLD branch first ------------------------------------ *
  * Reference interfaces: Estimator::margin (src/image_process/Estimator.cc:1307-1405), MarginalizationInfo::

@@ -18,7 +18,7 @@ SYMBOLS = [
     "lmono_map_builder_cloud", "lmono_map_builder_map", "lmono_map_builder_clear",
     "lmono_pose_graph_create", "lmono_pose_graph_destroy", "lmono_pose_graph_reset", "lmono_pose_graph_info", "lmono_pose_graph_reduce_buffer", "lmono_pose_graph_set_reduce_buffer", "lmono_pose_graph_linearise",
     "lmono_pose_graph_step", "lmono_pose_graph_optimize", "lmono_pose_graph_result", "lmono_factor_eval", "lmono_factor_eval_d", "lmono_factor_eval_blocks", "lmono_factor_eval_blocks_d",
-    "lmono_triangulate", "lmono_outlier_scores", "lmono_shift_depth", "lmono_marginalize", "lmono_marg_evaluate", "lmono_marg_second_new", "lmono_ba_batch_create", "lmono_ba_batch_update", "lmono_ba_batch_destroy", "lmono_ba_solve", "lmono_ba_batch_reset", "lmono_ba_batch_read",
+    "lmono_triangulate", "lmono_outlier_scores", "lmono_shift_depth", "lmono_shift_depth_batch", "lmono_marginalize", "lmono_marg_evaluate", "lmono_marg_second_new", "lmono_ba_batch_create", "lmono_ba_batch_update", "lmono_ba_batch_destroy", "lmono_ba_solve", "lmono_ba_batch_reset", "lmono_ba_batch_read",
 ]
 
 
@@ -82,6 +82,7 @@ def load_library():
     L.lmono_triangulate.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 9 + [C.c_int, C.c_int, C.c_double, C.c_int]
     L.lmono_outlier_scores.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_double, C.c_void_p]
     L.lmono_shift_depth.argtypes = [C.c_void_p] * 6 + [C.c_int] + [C.c_void_p] * 3
+    L.lmono_shift_depth_batch.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
     L.lmono_marginalize.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 14
     L.lmono_marg_evaluate.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
     L.lmono_marg_second_new.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7
@@ -268,6 +269,16 @@ class Context:
         pt = np.ascontiguousarray(pt_i, np.float64).reshape(-1, 2); d = np.ascontiguousarray(depth, np.float64); out = np.zeros(len(d))
         self.check(self.L.lmono_shift_depth(self.h, *[v.ctypes.data for v in a], len(d), pt.ctypes.data, d.ctypes.data, out.ctypes.data))
         return out
+
+    def shift_depth_batch(self, frames, pt_i_list, depth_list):
+        """frames: [n][40] (back_R0, back_P0, R1, P1, TLC per window); pt_i_list / depth_list: per window arrays.  Returns the list of shifted depths."""
+        fr = np.ascontiguousarray(frames, np.float64).reshape(-1, 40)
+        off = np.concatenate([[0], np.cumsum([len(d) for d in depth_list])]).astype(np.int32)
+        pt = np.ascontiguousarray(np.concatenate([np.asarray(p, np.float64).reshape(-1, 2) for p in pt_i_list]) if off[-1] else np.zeros((0, 2)), np.float64)
+        d = np.ascontiguousarray(np.concatenate([np.asarray(v, np.float64).ravel() for v in depth_list]) if off[-1] else np.zeros(0), np.float64)
+        out = np.zeros(len(d))
+        self.check(self.L.lmono_shift_depth_batch(self.h, len(fr), fr.ctypes.data, off.ctypes.data, pt.ctypes.data, d.ctypes.data, out.ctypes.data))
+        return [out[off[k]:off[k + 1]] for k in range(len(fr))]
 
     def marginalize(self, windows):
         """windows: list of dicts(poses [11,7], ex [7], invd [F0], obs_feat, obs_j, pts [O,4], laser01 [24], laser_info, mono_info)."""

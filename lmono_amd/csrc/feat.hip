@@ -459,11 +459,13 @@ __global__ __launch_bounds__(128) void k_outlier_scores(FeatBatch B)
     B.score[f] = (err / cnt) * B.weight;
 }
 
-// poses: [0..8] back_R0, [9..11] back_P0, [12..20] Rs[0] after the slide, [21..23] Ps[0], [24..39] TLC
-__global__ __launch_bounds__(128) void k_shift_depth(const double *poses, int n, const double *pt_i, const double *depth, double *depth_out)
+// poses: [0..8] back_R0, [9..11] back_P0, [12..20] Rs[0] after the slide, [21..23] Ps[0], [24..39] TLC -- one such record per window, win[f] = the
+// window of track f (nullptr: one window)
+__global__ __launch_bounds__(128) void k_shift_depth(const double *poses, int n, const double *pt_i, const double *depth, double *depth_out, const int *win)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n) return;
+    if (win) poses += (size_t)40 * win[f];
     const double *tlc = poses + 24;
     double Rlc[9], Tlc[3], R0[9], R1[9], P0[3], P1[3], tmp[3];
     for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) Rlc[i * 3 + j] = tlc[i * 4 + j]; Tlc[i] = tlc[i * 4 + 3]; }

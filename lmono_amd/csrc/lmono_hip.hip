@@ -1637,10 +1637,37 @@ extern "C" int lmono_shift_depth(lmono_ctx *c, const double *back_R0, const doub
     double *pd = db.up(poses, 40, ok), *pt = db.up(pt_i_h, (size_t)n * 2, ok), *d = db.up(depth_h, (size_t)n, ok), *o = db.up((const double *)nullptr, (size_t)n, ok);
     db.ready(ok);
     if (!ok) { c->err = "lmono_shift_depth: device allocation / upload failed"; return LMONO_ENOMEM; }
-    hipLaunchKernelGGL(k_shift_depth, dim3((n + 127) / 128), dim3(128), 0, c->stream, (const double *)pd, n, (const double *)pt, (const double *)d, o);
+    hipLaunchKernelGGL(k_shift_depth, dim3((n + 127) / 128), dim3(128), 0, c->stream, (const double *)pd, n, (const double *)pt, (const double *)d, o, (const int *)nullptr);
     int rc = check_launch(c, "k_shift_depth");
     if (rc) return rc;
     if (!db.down(depth_out_h, o, sizeof(double) * n) || !db.fetch()) { c->err = "lmono_shift_depth: read-back failed"; return LMONO_ENODEV; }
+    return LMONO_OK;
+}
+
+extern "C" int lmono_shift_depth_batch(lmono_ctx *c, int n_windows, const double *frames_h, const int *track_off_h,
+                                       const double *pt_i_h, const double *depth_h, double *depth_out_h)
+{
+    if (!c || n_windows <= 0 || !frames_h || !track_off_h) return LMONO_EINVAL;
+    const int n = track_off_h[n_windows];
+    if (n < 0 || track_off_h[0] != 0) return LMONO_EINVAL;
+    if (n == 0) return LMONO_OK;
+    if (!pt_i_h || !depth_h || !depth_out_h) return LMONO_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    std::vector<int> win((size_t)n);
+    for (int w = 0; w < n_windows; w++) {
+        if (track_off_h[w + 1] < track_off_h[w]) { c->err = "lmono_shift_depth_batch: track offsets must ascend"; return LMONO_EINVAL; }
+        for (int f = track_off_h[w]; f < track_off_h[w + 1]; f++) win[(size_t)f] = w;
+    }
+    DevBuf db(c); bool ok = true;
+    double *pd = db.up(frames_h, (size_t)n_windows * 40, ok), *pt = db.up(pt_i_h, (size_t)n * 2, ok), *d = db.up(depth_h, (size_t)n, ok);
+    int *wd = db.up(win.data(), (size_t)n, ok);
+    double *o = db.up((const double *)nullptr, (size_t)n, ok);
+    db.ready(ok);
+    if (!ok) { c->err = "lmono_shift_depth_batch: device allocation / upload failed"; return LMONO_ENOMEM; }
+    hipLaunchKernelGGL(k_shift_depth, dim3((n + 127) / 128), dim3(128), 0, c->stream, (const double *)pd, n, (const double *)pt, (const double *)d, o, (const int *)wd);
+    int rc = check_launch(c, "k_shift_depth");
+    if (rc) return rc;
+    if (!db.down(depth_out_h, o, sizeof(double) * n) || !db.fetch()) { c->err = "lmono_shift_depth_batch: read-back failed"; return LMONO_ENODEV; }
     return LMONO_OK;
 }
 

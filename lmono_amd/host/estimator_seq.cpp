@@ -4,12 +4,17 @@
 //
 // Stream file (doubles): n_frames, TLC[16], then per frame: header, L0_Pos[16], n_loop (0/1) [loop_time_stamp, old_T[3],
 // old_Q[4] w x y z, correct_T[3], correct_Q[4] w x y z], n_features, n_features x (id, x_n, y_n, u, v).
-// Usage: estimator_seq <stream.bin> [new_odometry.txt | -] [async]
+// Usage: estimator_seq <stream.bin> [new_odometry.txt | -] [sync | async] [streams=N [digest] [more stream files ...]]
 // "async": marginalisation overlapped with the next frame (Estimator::setAsyncMargin); the PRI line (digest of the last prior) and
 // everything else must come out the same bytes as without it.
+// "streams=N": N independent Estimators stepped in lock-step by EstimatorBatch (one batched C-ABI call per numeric step); stream s replays
+// file s mod (number of files given).  Every stream's lines are printed behind a "STR s" line and are, byte for byte, the lines of the
+// single-stream run of its file (and "DIG s <hash>" = FNV-1a of those lines; "digest": print only the DIG lines -- 256 streams x 2761 frames
+// of text is 70 MB).  The single-stream run prints its own "DIG 0 <hash>" over the same lines.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 #include "lmono_host.hpp"
@@ -27,63 +32,164 @@ static std::vector<double> read_all(const char *path)
     return v;
 }
 
+struct Frame {
+    double header; double L0[16];
+    bool has_loop = false; Estimator::LoopFrame loop;
+    FeatureManager::Image image;
+};
+struct Stream { double TLC[16]; std::vector<Frame> frames; };
+
+static Stream parse_stream(const char *path)
+{
+    const std::vector<double> d = read_all(path);
+    size_t k = 0;
+    Stream st;
+    const int n_frames = (int)d[k++];
+    for (int j = 0; j < 16; j++) st.TLC[j] = d[k++];
+    st.frames.resize((size_t)n_frames);
+    for (int f = 0; f < n_frames; f++) {
+        Frame &fr = st.frames[(size_t)f];
+        fr.header = d[k++];
+        for (int j = 0; j < 16; j++) fr.L0[j] = d[k++];
+        if ((int)d[k++]) {
+            fr.has_loop = true;
+            Estimator::LoopFrame &lf = fr.loop;
+            lf.loop_time_stamp = d[k++];
+            for (int j = 0; j < 3; j++) lf.old_T[j] = d[k++];
+            for (int j = 0; j < 4; j++) lf.old_Q[j] = d[k++];
+            for (int j = 0; j < 3; j++) lf.correct_T[j] = d[k++];
+            for (int j = 0; j < 4; j++) lf.correct_Q[j] = d[k++];
+        }
+        const int nf = (int)d[k++];
+        for (int j = 0; j < nf; j++) { const int id = (int)d[k]; fr.image[id] = { d[k + 1], d[k + 2], d[k + 3], d[k + 4] }; k += 5; }
+    }
+    return st;
+}
+
+// the lines of one stream (FRM per frame, then ODO / PRI / EXT) and their running digest
+struct Lines {
+    std::string text;
+    unsigned long long h = 1469598103934665603ull;
+    bool keep = true;
+    void add(const char *s)
+    {
+        for (const char *p = s; *p; p++) { h ^= (unsigned char)*p; h *= 1099511628211ull; }
+        if (keep) text += s;
+    }
+};
+static void frm_line(Lines &out, int f, bool keyframe, const Estimator &est)
+{
+    char buf[256];
+    std::snprintf(buf, sizeof buf, "FRM %d %d %d %d %d %d %.17g %d %d %zu\n", f, keyframe ? 1 : 0, (int)est.stage_flag, est.static_status ? 1 : 0, est.iterations, est.termination,
+                  est.final_cost, est.margin_calls[0], est.margin_calls[1], est.feature_manager.feature.size());
+    out.add(buf);
+}
+static void tail_lines(Lines &out, const Estimator &est)
+{
+    char buf[1024];
+    for (const auto &r : est.new_odometry) {
+        std::snprintf(buf, sizeof buf, "ODO %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
+        out.add(buf);
+    }
+    const auto &mi = est.last_marginalization_info;
+    double sj = 0, sr = 0;
+    for (double v : mi.linearized_jacobians) sj += v * v;
+    for (double v : mi.linearized_residuals) sr += v * v;
+    std::snprintf(buf, sizeof buf, "PRI %d %d %d %zu %.17g %.17g\n", mi.m, mi.n, mi.status, mi.parameter_blocks.size(), sj, sr);
+    out.add(buf);
+    std::string e = "EXT";
+    for (int j = 0; j < 16; j++) { std::snprintf(buf, sizeof buf, " %.17g", est.TLC[j]); e += buf; }
+    e += "\n";
+    out.add(e.c_str());
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 2) return 2;
     try {
-        const std::vector<double> d = read_all(argv[1]);
-        size_t k = 0;
-        const int n_frames = (int)d[k++];
+        int n_streams = 0; bool digest_only = false, async = false;
+        std::vector<const char *> files{ argv[1] };
+        for (int a = 3; a < argc; a++) {
+            const std::string s = argv[a];
+            if (s == "async") async = true;
+            else if (s == "sync") async = false;
+            else if (s.rfind("streams=", 0) == 0) n_streams = std::atoi(s.c_str() + 8);
+            else if (s == "digest") digest_only = true;
+            else files.push_back(argv[a]);
+        }
         HipContext hip(0);
         Params p;
-        Estimator est(hip, p);
-        if (argc > 3 && std::string(argv[3]) == "async") est.setAsyncMargin(true);
-        for (int j = 0; j < 16; j++) est.TLC[j] = d[k++];
-        double solve_ms = 0; int solves = 0;
-        for (int f = 0; f < n_frames; f++) {
-            const double header = d[k++];
-            const double *L0 = &d[k]; k += 16;
-            if ((int)d[k++]) {
-                Estimator::LoopFrame lf;
-                lf.loop_time_stamp = d[k++];
-                for (int j = 0; j < 3; j++) lf.old_T[j] = d[k++];
-                for (int j = 0; j < 4; j++) lf.old_Q[j] = d[k++];
-                for (int j = 0; j < 3; j++) lf.correct_T[j] = d[k++];
-                for (int j = 0; j < 4; j++) lf.correct_Q[j] = d[k++];
-                est.setLoopFrame(lf);
+        if (n_streams <= 0) {
+            const Stream st = parse_stream(argv[1]);
+            Estimator est(hip, p);
+            if (async) est.setAsyncMargin(true);
+            std::memcpy(est.TLC, st.TLC, sizeof(st.TLC));
+            Lines out;
+            double solve_ms = 0; int solves = 0;
+            for (size_t f = 0; f < st.frames.size(); f++) {
+                const Frame &fr = st.frames[f];
+                if (fr.has_loop) est.setLoopFrame(fr.loop);
+                const bool was_inited = est.stage_flag == Estimator::INITED;
+                const auto t0 = std::chrono::steady_clock::now();
+                const bool keyframe = est.processImage(fr.header, fr.image, fr.L0);
+                const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                if (was_inited) { solve_ms += ms; solves++; }
+                frm_line(out, (int)f, keyframe, est);
             }
-            const int nf = (int)d[k++];
-            FeatureManager::Image image;
-            for (int j = 0; j < nf; j++) { const int id = (int)d[k]; image[id] = { d[k + 1], d[k + 2], d[k + 3], d[k + 4] }; k += 5; }
-            const bool was_inited = est.stage_flag == Estimator::INITED;
+            est.marginWait();
+            tail_lines(out, est);
+            std::fputs(out.text.c_str(), stdout);
+            std::printf("DIG 0 %016llx\n", out.h);
+            std::printf("TIM %d %.6f\n", solves, solves ? solve_ms / solves : 0.0);
+            std::printf("FLP %.17g %ld\n", est.solve_flops, est.solve_obs);     // algorithmic flops of all window solves, projection blocks in all
+            lmono_host::estimator_print_phase_clock();
+            if (argc > 2 && std::string(argv[2]) != "-") {
+                FILE *fo = std::fopen(argv[2], "w");
+                if (!fo) { std::perror(argv[2]); return 2; }
+                for (const auto &r : est.new_odometry) std::fprintf(fo, "%f %f %f %f %f %f %f %f\n", r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);   // Estimator.cc:642
+                std::fclose(fo);
+            }
+            return 0;
+        }
+        // ---- N streams in lock-step
+        std::vector<Stream> src;
+        for (const char *f : files) src.push_back(parse_stream(f));
+        const size_t n_frames = src[0].frames.size();
+        for (const Stream &s : src) if (s.frames.size() != n_frames) { std::fprintf(stderr, "estimator_seq: the stream files must hold the same number of frames\n"); return 2; }
+        const int N = n_streams;
+        EstimatorBatch eb(hip, p, N);
+        if (async) eb.setAsyncMargin(true);
+        std::vector<Lines> out((size_t)N);
+        for (int s = 0; s < N; s++) { std::memcpy(eb.stream(s).TLC, src[(size_t)s % src.size()].TLC, 128); out[(size_t)s].keep = !digest_only; }
+        std::vector<double> headers((size_t)N);
+        std::vector<FeatureManager::Image> images((size_t)N);
+        std::vector<std::array<double, 16>> L0((size_t)N);
+        std::unique_ptr<bool[]> kf(new bool[(size_t)N]);
+        double solve_ms = 0; int solves = 0;
+        for (size_t f = 0; f < n_frames; f++) {
+            for (int s = 0; s < N; s++) {
+                const Frame &fr = src[(size_t)s % src.size()].frames[f];
+                headers[(size_t)s] = fr.header; images[(size_t)s] = fr.image; std::memcpy(L0[(size_t)s].data(), fr.L0, 128);
+                if (fr.has_loop) eb.stream(s).setLoopFrame(fr.loop);
+            }
+            const bool was_inited = eb.stream(0).stage_flag == Estimator::INITED;
             const auto t0 = std::chrono::steady_clock::now();
-            const bool keyframe = est.processImage(header, image, L0);
+            eb.processImage(headers.data(), images.data(), reinterpret_cast<const double (*)[16]>(L0.data()), kf.get());
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             if (was_inited) { solve_ms += ms; solves++; }
-            std::printf("FRM %d %d %d %d %d %d %.17g %d %d %zu\n", f, keyframe ? 1 : 0, (int)est.stage_flag, est.static_status ? 1 : 0, est.iterations, est.termination,
-                        est.final_cost, est.margin_calls[0], est.margin_calls[1], est.feature_manager.feature.size());
+            for (int s = 0; s < N; s++) frm_line(out[(size_t)s], (int)f, kf[(size_t)s], eb.stream(s));
         }
-        for (const auto &r : est.new_odometry)
-            std::printf("ODO %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
-        est.marginWait();
-        {
-            const auto &mi = est.last_marginalization_info;
-            double sj = 0, sr = 0;
-            for (double v : mi.linearized_jacobians) sj += v * v;
-            for (double v : mi.linearized_residuals) sr += v * v;
-            std::printf("PRI %d %d %d %zu %.17g %.17g\n", mi.m, mi.n, mi.status, mi.parameter_blocks.size(), sj, sr);
+        eb.marginWait();
+        double flops = 0; long obs = 0;
+        for (int s = 0; s < N; s++) {
+            tail_lines(out[(size_t)s], eb.stream(s));
+            if (!digest_only) { std::printf("STR %d\n", s); std::fputs(out[(size_t)s].text.c_str(), stdout); }
+            std::printf("DIG %d %016llx\n", s, out[(size_t)s].h);
+            flops += eb.stream(s).solve_flops; obs += eb.stream(s).solve_obs;
         }
-        std::printf("EXT");
-        for (int j = 0; j < 16; j++) std::printf(" %.17g", est.TLC[j]);
-        std::printf("\nTIM %d %.6f\n", solves, solves ? solve_ms / solves : 0.0);
-        std::printf("FLP %.17g %ld\n", est.solve_flops, est.solve_obs);     // algorithmic flops of all window solves, projection blocks in all
-        lmono_host::estimator_print_phase_clock();
-        if (argc > 2 && std::string(argv[2]) != "-") {
-            FILE *fo = std::fopen(argv[2], "w");
-            if (!fo) { std::perror(argv[2]); return 2; }
-            for (const auto &r : est.new_odometry) std::fprintf(fo, "%f %f %f %f %f %f %f %f\n", r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);   // Estimator.cc:642
-            std::fclose(fo);
-        }
+        // TIM: lock-step frames timed (INITED), milliseconds per lock-step frame (= N stream frames), streams
+        std::printf("TIM %d %.6f %d\n", solves, solves ? solve_ms / solves : 0.0, N);
+        std::printf("FLP %.17g %ld\n", flops, obs);
         return 0;
     } catch (const std::exception &e) {
         std::fprintf(stderr, "estimator_seq: %s\n", e.what());

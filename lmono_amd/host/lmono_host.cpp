@@ -111,15 +111,20 @@ void FeatureManager::triangulate(int, const Mat3 Rs[], const Vec3 Ps[], const do
     std::vector<int> flag(start.size(), 0);
     hip->check(lmono_triangulate(hip->get(), 1, feat_off, R.data(), P.data(), tlc, start.data(), off.data(), pts.data(), depth.data(), flag.data(),
                                  params->TRACK_CNT, WINDOW_SIZE, params->FACTOR_WEIGHT, 50), "lmono_triangulate");
+    triangulateApply(depth.data(), flag.data());
+}
+void FeatureManager::triangulateApply(const double *depth, const int *flag)
+{
     size_t k = 0;
     for (auto &it : feature) { it.estimated_depth = depth[k]; if (it.used_num >= params->TRACK_CNT) it.solve_flag = flag[k]; k++; }
 }
-void FeatureManager::removeBackShiftDepth(const Mat3 &R0, const Vec3 &P0, const Mat3 &R1, const Vec3 &P1, const double tlc[16])
+void FeatureManager::shiftDepthPack(std::vector<double> &pt, std::vector<double> &dep) const
 {
-    std::vector<double> pt, dep;
+    pt.clear(); dep.clear();
     for (auto &it : feature) if (it.start_frame == 0 && it.feature_per_frame.size() >= 3) { pt.push_back(it.feature_per_frame[0].pt[0]); pt.push_back(it.feature_per_frame[0].pt[1]); dep.push_back(it.estimated_depth); }
-    std::vector<double> out(dep.size());
-    if (!dep.empty()) hip->check(lmono_shift_depth(hip->get(), R0.m, P0.v, R1.m, P1.v, tlc, (int)dep.size(), pt.data(), dep.data(), out.data()), "lmono_shift_depth");
+}
+void FeatureManager::shiftDepthApply(const double *out)
+{
     size_t k = 0;
     for (auto it = feature.begin(); it != feature.end();) {
         if (it->start_frame != 0) { it->start_frame--; ++it; continue; }
@@ -129,6 +134,14 @@ void FeatureManager::removeBackShiftDepth(const Mat3 &R0, const Vec3 &P0, const 
         it->estimated_depth = out[k++];
         ++it;
     }
+}
+void FeatureManager::removeBackShiftDepth(const Mat3 &R0, const Vec3 &P0, const Mat3 &R1, const Vec3 &P1, const double tlc[16])
+{
+    std::vector<double> pt, dep;
+    shiftDepthPack(pt, dep);
+    std::vector<double> out(dep.size());
+    if (!dep.empty()) hip->check(lmono_shift_depth(hip->get(), R0.m, P0.v, R1.m, P1.v, tlc, (int)dep.size(), pt.data(), dep.data(), out.data()), "lmono_shift_depth");
+    shiftDepthApply(out.data());
 }
 void FeatureManager::removeBack()
 {
@@ -199,7 +212,8 @@ Estimator::Estimator(HipContext &hip, const Params &p) : hip_(hip), p_(p)
     std::memset(TLC, 0, sizeof(TLC)); TLC[0] = TLC[5] = TLC[10] = TLC[15] = 1.0;
     feature_manager.params = &p_; feature_manager.hip = &hip_;
 }
-struct Estimator::MarginWorker {
+class MarginWorker {
+public:
     std::mutex mu;
     std::condition_variable cv;
     std::function<void()> job;          // pending job (empty: none)
@@ -285,12 +299,12 @@ void Estimator::double2Matrix()
     feature_manager.removeFailures();
     loop_closure = false;                                   // :1111-1120
 }
-bool Estimator::optimization()
+void Estimator::packSolve(SolvePack &sp)
 {
     matrix2Double();
     // residual blocks exactly as Estimator.cc:1155-1215 adds them
-    std::vector<int> obs_feat, obs_i, obs_j; std::vector<double> obs_pts;
-    const bool use_mono = p_.ESTIMATE_LASER && !static_status;
+    sp.obs_feat.clear(); sp.obs_i.clear(); sp.obs_j.clear(); sp.obs_pts.clear();
+    sp.use_mono = p_.ESTIMATE_LASER && !static_status;
     int feature_index = -1;
     for (auto &it : feature_manager.feature) {
         it.used_num = (int)it.feature_per_frame.size();
@@ -300,27 +314,50 @@ bool Estimator::optimization()
         for (auto &f : it.feature_per_frame) {
             j++;
             if (i == j) continue;
-            obs_feat.push_back(feature_index); obs_i.push_back(i); obs_j.push_back(j);
-            obs_pts.insert(obs_pts.end(), { it.feature_per_frame[0].pt[0], it.feature_per_frame[0].pt[1], f.pt[0], f.pt[1] });
+            sp.obs_feat.push_back(feature_index); sp.obs_i.push_back(i); sp.obs_j.push_back(j);
+            sp.obs_pts.insert(sp.obs_pts.end(), { it.feature_per_frame[0].pt[0], it.feature_per_frame[0].pt[1], f.pt[0], f.pt[1] });
         }
     }
-    const int F = feature_index + 1;
-    const int feat_off[2] = { 0, F }, obs_off[2] = { 0, (int)obs_feat.size() };
+    sp.F = feature_index + 1;
     int use_prior = 0;
     if (first_refine >= p_.FINE_TIMES) use_prior = 1; else first_refine++;
-    const int flags[4] = { frame_count + 1, use_prior, p_.ESTIMATE_LASER == 0 ? 1 : 0, use_mono ? 1 : 0 };
-    std::vector<double> poses(77, 0.0), laser(240, 0.0);
-    for (int i = 0; i <= WINDOW_SIZE; i++) std::memcpy(&poses[7 * i], para_pose[i], 56);
+    sp.flags[0] = frame_count + 1; sp.flags[1] = use_prior; sp.flags[2] = p_.ESTIMATE_LASER == 0 ? 1 : 0; sp.flags[3] = sp.use_mono ? 1 : 0;
+    std::memset(sp.poses, 0, sizeof(sp.poses)); std::memset(sp.laser, 0, sizeof(sp.laser));
+    for (int i = 0; i <= WINDOW_SIZE; i++) std::memcpy(&sp.poses[7 * i], para_pose[i], 56);
     for (int i = 0; i < frame_count; i++) {
-        double *c = &laser[24 * i];
+        double *c = &sp.laser[24 * i];
         std::memcpy(c, L0_R[i].m, 72); std::memcpy(c + 9, L0_R[i + 1].m, 72); std::memcpy(c + 18, L0_T[i].v, 24); std::memcpy(c + 21, L0_T[i + 1].v, 24);
     }
-    double laser_info[36] = { 0 }, mono_info[4] = { p_.FACTOR_WEIGHT, 0, 0, p_.FACTOR_WEIGHT }, prior_w[2] = { p_.PRIOR_T, p_.PRIOR_R };
-    for (int k = 0; k < 6; k++) laser_info[k * 7] = p_.LASER_W * p_.FACTOR_WEIGHT;
+}
+void Estimator::unpackSolve(const SolvePack &sp, const double *poses77, const double *ex7, const double *invd, const double *summary)
+{
+    for (int i = 0; i <= WINDOW_SIZE; i++) std::memcpy(para_pose[i], &poses77[7 * i], 56);
+    std::memcpy(para_ex[0], ex7, 56);
+    if (sp.use_mono) para_depth_inv.assign(invd, invd + sp.F);
+    initial_cost = summary[0]; final_cost = summary[1]; iterations = (int)summary[2]; termination = (int)summary[3];
+    solve_flops += (double)iterations * (2000.0 * (sp.use_mono ? (double)sp.obs_feat.size() : 0.0) + 72.0 * 72.0 * 72.0 / 3.0);
+    solve_obs += (long)sp.obs_feat.size();
+    double2Matrix();
+}
+// the sqrt_info statics of Estimator::setParameter (Estimator.cc:94-95) and the PriorFactor weights, as the C ABI takes them
+static void solve_infos(const Params &p, double laser_info[36], double mono_info[4], double prior_w[2])
+{
+    std::memset(laser_info, 0, 36 * sizeof(double));
+    for (int k = 0; k < 6; k++) laser_info[k * 7] = p.LASER_W * p.FACTOR_WEIGHT;
+    mono_info[0] = mono_info[3] = p.FACTOR_WEIGHT; mono_info[1] = mono_info[2] = 0;
+    prior_w[0] = p.PRIOR_T; prior_w[1] = p.PRIOR_R;
+}
+bool Estimator::optimization()
+{
+    SolvePack sp;
+    packSolve(sp);
+    const int feat_off[2] = { 0, sp.F }, obs_off[2] = { 0, (int)sp.obs_feat.size() };
+    double laser_info[36], mono_info[4], prior_w[2];
+    solve_infos(p_, laser_info, mono_info, prior_w);
     lmono_ba_desc d{};
-    d.n_windows = 1; d.feat_off = feat_off; d.obs_off = obs_off; d.flags = flags; d.poses = poses.data(); d.ex = para_ex[0];
-    d.inv_depth = para_depth_inv.data(); d.obs_feat = obs_feat.data(); d.obs_i = obs_i.data(); d.obs_j = obs_j.data(); d.obs_pts = obs_pts.data();
-    d.laser_consts = laser.data(); d.prior_T = TLC; d.laser_info = laser_info; d.mono_info = mono_info; d.prior_w = prior_w;
+    d.n_windows = 1; d.feat_off = feat_off; d.obs_off = obs_off; d.flags = sp.flags; d.poses = sp.poses; d.ex = para_ex[0];
+    d.inv_depth = para_depth_inv.data(); d.obs_feat = sp.obs_feat.data(); d.obs_i = sp.obs_i.data(); d.obs_j = sp.obs_j.data(); d.obs_pts = sp.obs_pts.data();
+    d.laser_consts = sp.laser; d.prior_T = TLC; d.laser_info = laser_info; d.mono_info = mono_info; d.prior_w = prior_w;
     // the reference builds a new ceres::Problem per call (Estimator.cc:1017); here the device arrays of the previous frame's
     // problem are loaded again in place, so the steady-state frame loop does not allocate
     if (!ba_batch_) {
@@ -331,71 +368,57 @@ bool Estimator::optimization()
     g_clock.lap(2);
     lmono_ba_batch *b = ba_batch_;
     hip_.check(lmono_ba_solve(hip_.get(), b, p_.NUM_ITERATIONS), "lmono_ba_solve");
-    double summary[6];
-    std::vector<double> invd((size_t)std::max(F, 1));
-    hip_.check(lmono_ba_batch_read(hip_.get(), b, poses.data(), para_ex[0], invd.data(), summary), "lmono_ba_batch_read");
+    double summary[6], poses[77], ex[7];
+    std::vector<double> invd((size_t)std::max(sp.F, 1));
+    hip_.check(lmono_ba_batch_read(hip_.get(), b, poses, ex, invd.data(), summary), "lmono_ba_batch_read");
     g_clock.lap(3);
-    for (int i = 0; i <= WINDOW_SIZE; i++) std::memcpy(para_pose[i], &poses[7 * i], 56);
-    if (use_mono) para_depth_inv.assign(invd.begin(), invd.begin() + F);
-    initial_cost = summary[0]; final_cost = summary[1]; iterations = (int)summary[2]; termination = (int)summary[3];
-    solve_flops += (double)iterations * (2000.0 * (use_mono ? (double)obs_feat.size() : 0.0) + 72.0 * 72.0 * 72.0 / 3.0);
-    solve_obs += (long)obs_feat.size();
-    double2Matrix();
+    unpackSolve(sp, poses, ex, invd.data(), summary);
     if (frame_count < WINDOW_SIZE) return false;
     if (p_.ESTIMATE_LASER) margin();                         // Estimator.cc:1288-1291
     g_clock.lap(4);
     return termination == 0 || final_cost < 5e-3;            // Estimator.cc:1293
 }
-void Estimator::outliersRejection(std::set<int> &removeIndex, const double &error)
+bool Estimator::packTracks(TrackPack &tp)
 {
-    std::vector<int> start, off; std::vector<double> pts, depth;
-    feature_manager.pack(start, off, pts, depth, true);
-    if (start.empty()) return;
-    const int feat_off[2] = { 0, (int)start.size() };
-    std::vector<double> R(99, 0.0), P(33, 0.0), score(start.size());
-    for (int i = 0; i <= WINDOW_SIZE; i++) { std::memcpy(&R[9 * i], Rs[i].m, 72); std::memcpy(&P[3 * i], Ps[i].v, 24); }
-    hip_.check(lmono_outlier_scores(hip_.get(), 1, feat_off, R.data(), P.data(), TLC, start.data(), off.data(), pts.data(), depth.data(),
-                                    p_.TRACK_CNT, p_.FACTOR_WEIGHT, score.data()), "lmono_outlier_scores");
+    feature_manager.pack(tp.start, tp.off, tp.pts, tp.depth, true);      // tracks below TRACK_CNT are skipped inside the kernels
+    std::memset(tp.R, 0, sizeof(tp.R)); std::memset(tp.P, 0, sizeof(tp.P));
+    for (int i = 0; i <= WINDOW_SIZE; i++) { std::memcpy(&tp.R[9 * i], Rs[i].m, 72); std::memcpy(&tp.P[3 * i], Ps[i].v, 24); }
+    return !tp.start.empty();
+}
+void Estimator::applyOutlierScores(const double *score, double error, std::set<int> &removeIndex)
+{
     size_t k = 0;
     for (auto &it : feature_manager.feature) { if (score[k] >= 0 && score[k] > error) removeIndex.insert(it.feature_id); k++; }
 }
-void Estimator::margin()
+void Estimator::outliersRejection(std::set<int> &removeIndex, const double &error)
 {
-    marginWait();                                             // the previous prior is this call's input (and its storage is reused)
-    HipContext *h = async_margin_ ? margin_hip_.get() : &hip_;
+    TrackPack tp;
+    if (!packTracks(tp)) return;
+    const int feat_off[2] = { 0, (int)tp.start.size() };
+    std::vector<double> score(tp.start.size());
+    hip_.check(lmono_outlier_scores(hip_.get(), 1, feat_off, tp.R, tp.P, TLC, tp.start.data(), tp.off.data(), tp.pts.data(), tp.depth.data(),
+                                    p_.TRACK_CNT, p_.FACTOR_WEIGHT, score.data()), "lmono_outlier_scores");
+    applyOutlierScores(score.data(), error, removeIndex);
+}
+void Estimator::packMargin(MargPack &mp)
+{
     MarginalizationInfo &mi = last_marginalization_info;
+    mp = MargPack();
     if (marginalization_flag != MARGIN_OLD) {
         // :1406-1470: the previous prior, as the only factor, loses the block that aliases para_pose[WINDOW_SIZE - 1]
         if (!mi.present) return;
         const auto it = std::find(mi.parameter_blocks.begin(), mi.parameter_blocks.end(), WINDOW_SIZE - 1);
         if (it == mi.parameter_blocks.end()) return;
-        const int drop = (int)(it - mi.parameter_blocks.begin()), nb = (int)mi.parameter_blocks.size();
+        mp.kind = 2;
+        mp.drop = (int)(it - mi.parameter_blocks.begin()); mp.nb = (int)mi.parameter_blocks.size();
         matrix2Double();
-        std::vector<double> x((size_t)nb * 7);
-        for (int k = 0; k < nb; k++) std::memcpy(&x[7 * (size_t)k], mi.parameter_blocks[k] < 0 ? para_ex[0] : para_pose[mi.parameter_blocks[k]], 56);
+        mp.x.resize((size_t)mp.nb * 7);
+        for (int k = 0; k < mp.nb; k++) std::memcpy(&mp.x[7 * (size_t)k], mi.parameter_blocks[k] < 0 ? para_ex[0] : para_pose[mi.parameter_blocks[k]], 56);
         margin_calls[1]++;
-        auto job = [h, &mi, drop, nb, x]() mutable {
-            const int n = 6 * (nb - 1);
-            std::vector<double> J((size_t)n * n), r((size_t)n);
-            int status = 0;
-            h->check(lmono_marg_second_new(h->get(), 1, nb, drop, mi.linearized_jacobians.data(), mi.linearized_residuals.data(),
-                                           mi.keep_block_data.data(), x.data(), J.data(), r.data(), &status), "lmono_marg_second_new");
-            mi.linearized_jacobians.swap(J); mi.linearized_residuals.swap(r);
-            x.erase(x.begin() + 7 * (size_t)drop, x.begin() + 7 * (size_t)(drop + 1));
-            mi.keep_block_data.swap(x);                            // parameter_block_data: the values at this marginalisation
-            mi.parameter_blocks.erase(mi.parameter_blocks.begin() + drop);   // addr_shift :1442-1455: pose i -> pose i (i < 9), pose 10 -> pose 9 is not a block
-            mi.m = 6; mi.n = n; mi.status = status; mi.valid = false;
-        };
-        marginSubmit(std::move(job));
         return;
     }
     matrix2Double();
-    struct Pack {
-        std::vector<int> obs_feat, obs_j; std::vector<double> obs_pts, invd;
-        int f0 = 0;
-        double poses[77], ex[7], laser01[24], laser_info[36] = { 0 }, mono_info[4];
-    };
-    auto pk = std::make_shared<Pack>();
+    mp.kind = 1;
     int feature_index = -1;
     for (auto &it : feature_manager.feature) {
         it.used_num = (int)it.feature_per_frame.size();
@@ -406,41 +429,78 @@ void Estimator::margin()
         for (auto &f : it.feature_per_frame) {
             j++;
             if (j == 0) continue;
-            pk->obs_feat.push_back(pk->f0); pk->obs_j.push_back(j);
-            pk->obs_pts.insert(pk->obs_pts.end(), { it.feature_per_frame[0].pt[0], it.feature_per_frame[0].pt[1], f.pt[0], f.pt[1] });
+            mp.obs_feat.push_back(mp.f0); mp.obs_j.push_back(j);
+            mp.obs_pts.insert(mp.obs_pts.end(), { it.feature_per_frame[0].pt[0], it.feature_per_frame[0].pt[1], f.pt[0], f.pt[1] });
         }
-        pk->invd.push_back(para_depth_inv[feature_index]);
-        pk->f0++;
+        mp.invd.push_back(para_depth_inv[feature_index]);
+        mp.f0++;
     }
-    for (int i = 0; i <= WINDOW_SIZE; i++) std::memcpy(pk->poses + 7 * i, para_pose[i], 56);
-    std::memcpy(pk->ex, para_ex[0], 56);
-    std::memcpy(pk->laser01, L0_R[0].m, 72); std::memcpy(pk->laser01 + 9, L0_R[1].m, 72);
-    std::memcpy(pk->laser01 + 18, L0_T[0].v, 24); std::memcpy(pk->laser01 + 21, L0_T[1].v, 24);
-    for (int k = 0; k < 6; k++) pk->laser_info[k * 7] = p_.LASER_W * p_.FACTOR_WEIGHT;
-    pk->mono_info[0] = pk->mono_info[3] = p_.FACTOR_WEIGHT; pk->mono_info[1] = pk->mono_info[2] = 0;
+    for (int i = 0; i <= WINDOW_SIZE; i++) std::memcpy(mp.poses + 7 * i, para_pose[i], 56);
+    std::memcpy(mp.ex, para_ex[0], 56);
+    std::memcpy(mp.laser01, L0_R[0].m, 72); std::memcpy(mp.laser01 + 9, L0_R[1].m, 72);
+    std::memcpy(mp.laser01 + 18, L0_T[0].v, 24); std::memcpy(mp.laser01 + 21, L0_T[1].v, 24);
     margin_calls[0]++;
-    auto job = [h, &mi, pk]() {
-        const int feat_off[2] = { 0, pk->f0 }, obs_off[2] = { 0, (int)pk->obs_feat.size() };
-        mi.linearized_jacobians.assign(66 * 66, 0.0); mi.linearized_residuals.assign(66, 0.0);
+}
+void Estimator::applyMarginOld(const MargPack &mp, const double *lin_J, const double *lin_r, int status)
+{
+    MarginalizationInfo &mi = last_marginalization_info;
+    mi.linearized_jacobians.assign(lin_J, lin_J + 66 * 66); mi.linearized_residuals.assign(lin_r, lin_r + 66);
+    mi.status = status;
+    mi.m = 6 + mp.f0; mi.n = 66;
+    mi.keep_block_data.assign(77, 0.0);
+    std::memcpy(mi.keep_block_data.data(), mp.ex, 56);
+    for (int i = 1; i <= WINDOW_SIZE; i++) std::memcpy(mi.keep_block_data.data() + 7 * i, mp.poses + 7 * i, 56);
+    // addr_shift :1390-1396: the kept blocks ex, pose1 .. pose10 alias para_ex[0], para_pose[0] .. para_pose[9] from now on
+    mi.parameter_blocks.assign(1, -1);
+    for (int i = 0; i < WINDOW_SIZE; i++) mi.parameter_blocks.push_back(i);
+    mi.present = true;
+    mi.valid = false;      // never set by the reference either
+}
+void Estimator::applyMarginSecond(MargPack &mp, const double *lin_J, const double *lin_r, int status)
+{
+    MarginalizationInfo &mi = last_marginalization_info;
+    const int n = 6 * (mp.nb - 1);
+    mi.linearized_jacobians.assign(lin_J, lin_J + (size_t)n * n); mi.linearized_residuals.assign(lin_r, lin_r + n);
+    mp.x.erase(mp.x.begin() + 7 * (size_t)mp.drop, mp.x.begin() + 7 * (size_t)(mp.drop + 1));
+    mi.keep_block_data.swap(mp.x);                             // parameter_block_data: the values at this marginalisation
+    mi.parameter_blocks.erase(mi.parameter_blocks.begin() + mp.drop);   // addr_shift :1442-1455: pose i -> pose i (i < 9), pose 10 -> pose 9 is not a block
+    mi.m = 6; mi.n = n; mi.status = status; mi.valid = false;
+}
+void Estimator::margin()
+{
+    marginWait();                                             // the previous prior is this call's input (and its storage is reused)
+    HipContext *h = async_margin_ ? margin_hip_.get() : &hip_;
+    auto mp = std::make_shared<MargPack>();
+    packMargin(*mp);
+    if (mp->kind == 0) return;
+    double laser_info[36], mono_info[4], prior_w[2];
+    solve_infos(p_, laser_info, mono_info, prior_w);
+    std::array<double, 40> info;
+    std::memcpy(info.data(), laser_info, 36 * sizeof(double)); std::memcpy(info.data() + 36, mono_info, 4 * sizeof(double));
+    auto job = [this, h, mp, info]() {
+        MarginalizationInfo &mi = last_marginalization_info;
+        int status = 0;
+        if (mp->kind == 2) {
+            const int n = 6 * (mp->nb - 1);
+            std::vector<double> J((size_t)n * n), r((size_t)n);
+            h->check(lmono_marg_second_new(h->get(), 1, mp->nb, mp->drop, mi.linearized_jacobians.data(), mi.linearized_residuals.data(),
+                                           mi.keep_block_data.data(), mp->x.data(), J.data(), r.data(), &status), "lmono_marg_second_new");
+            applyMarginSecond(*mp, J.data(), r.data(), status);
+            return;
+        }
+        const int feat_off[2] = { 0, mp->f0 }, obs_off[2] = { 0, (int)mp->obs_feat.size() };
+        std::vector<double> J(66 * 66, 0.0), r(66, 0.0);
         const int dummy = 0; const double dzero = 0.0;
-        h->check(lmono_marginalize(h->get(), 1, feat_off, obs_off, pk->poses, pk->ex, pk->invd.empty() ? &dzero : pk->invd.data(),
-                                   pk->obs_feat.empty() ? &dummy : pk->obs_feat.data(), pk->obs_j.empty() ? &dummy : pk->obs_j.data(),
-                                   pk->obs_pts.empty() ? &dzero : pk->obs_pts.data(), pk->laser01, pk->laser_info, pk->mono_info,
-                                   mi.linearized_jacobians.data(), mi.linearized_residuals.data(), &mi.status), "lmono_marginalize");
-        mi.m = 6 + pk->f0; mi.n = 66;
-        mi.keep_block_data.assign(77, 0.0);
-        std::memcpy(mi.keep_block_data.data(), pk->ex, 56);
-        for (int i = 1; i <= WINDOW_SIZE; i++) std::memcpy(mi.keep_block_data.data() + 7 * i, pk->poses + 7 * i, 56);
-        // addr_shift :1390-1396: the kept blocks ex, pose1 .. pose10 alias para_ex[0], para_pose[0] .. para_pose[9] from now on
-        mi.parameter_blocks.assign(1, -1);
-        for (int i = 0; i < WINDOW_SIZE; i++) mi.parameter_blocks.push_back(i);
-        mi.present = true;
-        mi.valid = false;      // never set by the reference either
+        h->check(lmono_marginalize(h->get(), 1, feat_off, obs_off, mp->poses, mp->ex, mp->invd.empty() ? &dzero : mp->invd.data(),
+                                   mp->obs_feat.empty() ? &dummy : mp->obs_feat.data(), mp->obs_j.empty() ? &dummy : mp->obs_j.data(),
+                                   mp->obs_pts.empty() ? &dzero : mp->obs_pts.data(), mp->laser01, info.data(), info.data() + 36,
+                                   J.data(), r.data(), &status), "lmono_marginalize");
+        applyMarginOld(*mp, J.data(), r.data(), status);
     };
     marginSubmit(std::move(job));
 }
 
-void Estimator::slideWindow()
+bool Estimator::slideWindowBegin(ShiftPack &sp)
 {
     if (marginalization_flag == MARGIN_OLD) {
         back_R0 = Rs[0]; back_P0 = Ps[0];
@@ -452,7 +512,12 @@ void Estimator::slideWindow()
             }
             Rs[WINDOW_SIZE] = Rs[WINDOW_SIZE - 1]; Ps[WINDOW_SIZE] = Ps[WINDOW_SIZE - 1]; Header[WINDOW_SIZE] = Header[WINDOW_SIZE - 1];
             if (stage_flag == NOT_INITED) feature_manager.removeBack();                    // slideWindowOld :744-768
-            else feature_manager.removeBackShiftDepth(back_R0, back_P0, Rs[0], Ps[0], TLC);
+            else {
+                feature_manager.shiftDepthPack(sp.pt, sp.dep);                             // removeBackShiftDepth(back_R0, back_P0, Rs[0], Ps[0]) with TLC
+                std::memcpy(sp.frames, back_R0.m, 72); std::memcpy(sp.frames + 9, back_P0.v, 24); std::memcpy(sp.frames + 12, Rs[0].m, 72);
+                std::memcpy(sp.frames + 21, Ps[0].v, 24); std::memcpy(sp.frames + 24, TLC, 128);
+                return true;
+            }
         }
     } else if (frame_count == WINDOW_SIZE) {
         Header[frame_count - 1] = Header[frame_count];
@@ -462,6 +527,18 @@ void Estimator::slideWindow()
         // frame's pose and slot WINDOW_SIZE is rewritten by the next frame.
         feature_manager.removeFront(frame_count);                                          // slideWindowNew
     }
+    return false;
+}
+void Estimator::slideWindowFinish(const double *depth_out) { feature_manager.shiftDepthApply(depth_out); }
+void Estimator::slideWindow()
+{
+    ShiftPack sp;
+    if (!slideWindowBegin(sp)) return;
+    std::vector<double> out(sp.dep.size());
+    if (!sp.dep.empty())
+        hip_.check(lmono_shift_depth(hip_.get(), sp.frames, sp.frames + 9, sp.frames + 12, sp.frames + 21, sp.frames + 24, (int)sp.dep.size(), sp.pt.data(),
+                                     sp.dep.data(), out.data()), "lmono_shift_depth");
+    slideWindowFinish(out.data());
 }
 
 // ---- frame loop -------------------------------------------------------------------------------------------------------
@@ -471,9 +548,8 @@ void Estimator::processCompactData(const double L0_Pos[16])
     static_status = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) < 0.1;             // :259-265
     last_laser_t.v[0] = L0_Pos[3]; last_laser_t.v[1] = L0_Pos[7]; last_laser_t.v[2] = L0_Pos[11];
 }
-bool Estimator::runInitialization()
+void Estimator::initialPoses()
 {
-    // :986-1012 (the structure-from-motion block above it is commented out in the reference)
     double rlcT[9], tlc[3] = { TLC[3], TLC[7], TLC[11] };
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) rlcT[i * 3 + j] = TLC[j * 4 + i];
     for (int i = 0; i <= frame_count; i++) {
@@ -482,6 +558,11 @@ bool Estimator::runInitialization()
         mat_vec(rlcT, dv, Ps[i].v);
     }
     feature_manager.clearDepth();
+}
+bool Estimator::runInitialization()
+{
+    // :986-1012 (the structure-from-motion block above it is commented out in the reference)
+    initialPoses();
     feature_manager.triangulate(frame_count, Rs, Ps, TLC);
     std::set<int> removeIndex;
     outliersRejection(removeIndex, 100.0);
@@ -517,14 +598,28 @@ void Estimator::loopCorrection()
     std::memcpy(Rs[idx].m, Rc, 72);
     for (int k = 0; k < 3; k++) Ps[idx].v[k] = lf.correct_T[k];
 }
-bool Estimator::processImage(double header, const FeatureManager::Image &image, const double transform_to_init[16])
+void Estimator::preFrame(double header, const FeatureManager::Image &image, const double transform_to_init[16], bool *keyframe_out)
 {
-    g_clock.start();
     processCompactData(transform_to_init);
     const bool keyframe = feature_manager.featureCheck(frame_count, image, header);       // :383-394
     marginalization_flag = keyframe ? MARGIN_OLD : MARGIN_SECOND_NEW;
     Header[frame_count] = header;
     for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) L0_R[frame_count].m[i * 3 + j] = transform_to_init[i * 4 + j]; L0_T[frame_count].v[i] = transform_to_init[i * 4 + 3]; }   // all_image_frame.push_back
+    if (keyframe_out) *keyframe_out = keyframe;
+}
+void Estimator::pushOdometryRow()
+{
+    std::array<double, 8> row;
+    row[0] = Header[WINDOW_SIZE];
+    for (int k = 0; k < 3; k++) row[1 + k] = Ps[WINDOW_SIZE].v[k];
+    R_to_q(Rs[WINDOW_SIZE].m, &row[4]);
+    new_odometry.push_back(row);
+}
+bool Estimator::processImage(double header, const FeatureManager::Image &image, const double transform_to_init[16])
+{
+    g_clock.start();
+    bool keyframe = false;
+    preFrame(header, image, transform_to_init, &keyframe);
     if (stage_flag == NOT_INITED) {
         if (frame_count == WINDOW_SIZE) {
             if (p_.ESTIMATE_LASER != 2 && runInitialization()) {
@@ -554,14 +649,338 @@ bool Estimator::processImage(double header, const FeatureManager::Image &image, 
         g_clock.lap(6);
         g_clock.frames++;
     }
-    if (stage_flag == INITED) {                             // new_odometry.txt row, :634-645
-        std::array<double, 8> row;
-        row[0] = Header[WINDOW_SIZE];
-        for (int k = 0; k < 3; k++) row[1 + k] = Ps[WINDOW_SIZE].v[k];
-        R_to_q(Rs[WINDOW_SIZE].m, &row[4]);
-        new_odometry.push_back(row);
-    }
+    if (stage_flag == INITED) pushOdometryRow();             // new_odometry.txt row, :634-645
     return keyframe;
+}
+
+// ---- EstimatorBatch: N Estimators in lock-step ---------------------------------------------------------------------------
+// worker threads for the per-stream host halves (pack / unpack: list walks, a few hundred microseconds per stream and frame in all)
+class HostPool {
+public:
+    explicit HostPool(int n_threads)
+    {
+        for (int t = 1; t < n_threads; t++) th_.emplace_back([this] { work(); });
+    }
+    ~HostPool()
+    {
+        { std::lock_guard<std::mutex> g(mu_); quit_ = true; gen_++; }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    // fn(i) for i in [0, n), the caller takes part; rethrows the first exception
+    void run(int n, const std::function<void(int)> &fn)
+    {
+        if (n <= 0) return;
+        if (th_.empty() || n == 1) { for (int i = 0; i < n; i++) fn(i); return; }
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            fn_ = &fn; n_ = n; next_ = 0; left_ = n; err_ = nullptr; gen_++;
+        }
+        cv_.notify_all();
+        take();
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [this] { return left_ == 0 && busy_ == 0; });
+        fn_ = nullptr;
+        if (err_) { std::exception_ptr e = err_; err_ = nullptr; std::rethrow_exception(e); }
+    }
+private:
+    void take()
+    {
+        for (;;) {
+            int i;
+            const std::function<void(int)> *fn;
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                if (!fn_ || next_ >= n_) return;
+                i = next_++; fn = fn_; busy_++;
+            }
+            std::exception_ptr e;
+            try { (*fn)(i); } catch (...) { e = std::current_exception(); }
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                if (e && !err_) err_ = e;
+                busy_--; left_--;
+                if (left_ == 0 && busy_ == 0) done_.notify_all();
+            }
+        }
+    }
+    void work()
+    {
+        unsigned long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (quit_) return;
+            }
+            take();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int)> *fn_ = nullptr;
+    int n_ = 0, next_ = 0, left_ = 0, busy_ = 0;
+    unsigned long gen_ = 0;
+    bool quit_ = false;
+    std::exception_ptr err_;
+};
+
+EstimatorBatch::EstimatorBatch(HipContext &hip, const Params &p, int n_streams, int host_threads) : hip_(hip), p_(p)
+{
+    if (n_streams < 1) throw std::invalid_argument("EstimatorBatch: n_streams must be >= 1");
+    for (int s = 0; s < n_streams; s++) est_.emplace_back(new Estimator(hip, p));
+    int nt = host_threads;
+    if (nt <= 0) { if (const char *e = std::getenv("LMONO_HOST_THREADS")) nt = std::atoi(e); }
+    if (nt <= 0) nt = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    pool_.reset(new HostPool(std::min(nt, n_streams)));
+}
+EstimatorBatch::~EstimatorBatch()
+{
+    try { marginWait(); } catch (...) {}
+    margin_worker_.reset();
+    if (ba_batch_) lmono_ba_batch_destroy(ba_batch_);
+}
+void EstimatorBatch::marginWait() { if (margin_worker_) margin_worker_->wait(); }
+void EstimatorBatch::setAsyncMargin(bool on)
+{
+    marginWait();
+    if (on && !margin_hip_) { margin_hip_.reset(new HipContext(hip_.device())); margin_hip_->useOwnStream(); }
+    async_margin_ = on;
+}
+
+namespace {
+// exclusive prefix of per-stream sizes
+template <typename F> std::vector<int> offsets(int n, F size_of)
+{
+    std::vector<int> off((size_t)n + 1, 0);
+    for (int s = 0; s < n; s++) off[(size_t)s + 1] = off[(size_t)s] + size_of(s);
+    return off;
+}
+}
+
+// FeatureManager::triangulate of every stream: one lmono_triangulate over N windows
+void EstimatorBatch::triangulate()
+{
+    const int N = size();
+    std::vector<TrackPack> tp((size_t)N);
+    pool_->run(N, [&](int s) { est_[(size_t)s]->packTracks(tp[(size_t)s]); });
+    const std::vector<int> foff = offsets(N, [&](int s) { return (int)tp[(size_t)s].start.size(); });
+    const std::vector<int> ooff = offsets(N, [&](int s) { return (int)tp[(size_t)s].pts.size() / 2; });
+    const int TF = foff[(size_t)N], TO = ooff[(size_t)N];
+    if (TF == 0) return;
+    std::vector<double> R((size_t)N * 99), P((size_t)N * 33), tlc((size_t)N * 16), pts((size_t)TO * 2 + 2), depth((size_t)TF);
+    std::vector<int> start((size_t)TF), off((size_t)TF + 1), flag((size_t)TF, 0);
+    pool_->run(N, [&](int s) {
+        const TrackPack &t = tp[(size_t)s];
+        std::memcpy(&R[(size_t)s * 99], t.R, sizeof(t.R)); std::memcpy(&P[(size_t)s * 33], t.P, sizeof(t.P)); std::memcpy(&tlc[(size_t)s * 16], est_[(size_t)s]->TLC, 128);
+        const int f0 = foff[(size_t)s], o0 = ooff[(size_t)s];
+        for (size_t k = 0; k < t.start.size(); k++) { start[(size_t)f0 + k] = t.start[k]; off[(size_t)f0 + k] = o0 + t.off[k]; depth[(size_t)f0 + k] = t.depth[k]; }
+        if (!t.pts.empty()) std::memcpy(&pts[(size_t)o0 * 2], t.pts.data(), t.pts.size() * sizeof(double));
+    });
+    off[(size_t)TF] = TO;
+    hip_.check(lmono_triangulate(hip_.get(), N, foff.data(), R.data(), P.data(), tlc.data(), start.data(), off.data(), pts.data(), depth.data(), flag.data(),
+                                 p_.TRACK_CNT, WINDOW_SIZE, p_.FACTOR_WEIGHT, 50), "lmono_triangulate");
+    pool_->run(N, [&](int s) {
+        if (foff[(size_t)s + 1] > foff[(size_t)s]) est_[(size_t)s]->feature_manager.triangulateApply(&depth[(size_t)foff[(size_t)s]], &flag[(size_t)foff[(size_t)s]]);
+    });
+}
+
+// Estimator::outliersRejection + removeOutlier of every stream: one lmono_outlier_scores over N windows
+void EstimatorBatch::outliersRejection(double error)
+{
+    const int N = size();
+    std::vector<TrackPack> tp((size_t)N);
+    pool_->run(N, [&](int s) { est_[(size_t)s]->packTracks(tp[(size_t)s]); });
+    const std::vector<int> foff = offsets(N, [&](int s) { return (int)tp[(size_t)s].start.size(); });
+    const std::vector<int> ooff = offsets(N, [&](int s) { return (int)tp[(size_t)s].pts.size() / 2; });
+    const int TF = foff[(size_t)N], TO = ooff[(size_t)N];
+    if (TF == 0) return;
+    std::vector<double> R((size_t)N * 99), P((size_t)N * 33), tlc((size_t)N * 16), pts((size_t)TO * 2 + 2), depth((size_t)TF), score((size_t)TF);
+    std::vector<int> start((size_t)TF), off((size_t)TF + 1);
+    pool_->run(N, [&](int s) {
+        const TrackPack &t = tp[(size_t)s];
+        std::memcpy(&R[(size_t)s * 99], t.R, sizeof(t.R)); std::memcpy(&P[(size_t)s * 33], t.P, sizeof(t.P)); std::memcpy(&tlc[(size_t)s * 16], est_[(size_t)s]->TLC, 128);
+        const int f0 = foff[(size_t)s], o0 = ooff[(size_t)s];
+        for (size_t k = 0; k < t.start.size(); k++) { start[(size_t)f0 + k] = t.start[k]; off[(size_t)f0 + k] = o0 + t.off[k]; depth[(size_t)f0 + k] = t.depth[k]; }
+        if (!t.pts.empty()) std::memcpy(&pts[(size_t)o0 * 2], t.pts.data(), t.pts.size() * sizeof(double));
+    });
+    off[(size_t)TF] = TO;
+    hip_.check(lmono_outlier_scores(hip_.get(), N, foff.data(), R.data(), P.data(), tlc.data(), start.data(), off.data(), pts.data(), depth.data(),
+                                    p_.TRACK_CNT, p_.FACTOR_WEIGHT, score.data()), "lmono_outlier_scores");
+    pool_->run(N, [&](int s) {
+        if (foff[(size_t)s + 1] == foff[(size_t)s]) return;
+        std::set<int> removeIndex;
+        est_[(size_t)s]->applyOutlierScores(&score[(size_t)foff[(size_t)s]], error, removeIndex);
+        est_[(size_t)s]->feature_manager.removeOutlier(removeIndex);
+    });
+}
+
+// Estimator::optimization of every stream: N windows in one lmono_ba_batch_update + lmono_ba_solve + lmono_ba_batch_read, then margin()
+void EstimatorBatch::optimization()
+{
+    const int N = size();
+    std::vector<SolvePack> sp((size_t)N);
+    pool_->run(N, [&](int s) { est_[(size_t)s]->packSolve(sp[(size_t)s]); });
+    const std::vector<int> foff = offsets(N, [&](int s) { return sp[(size_t)s].F; });
+    const std::vector<int> ooff = offsets(N, [&](int s) { return (int)sp[(size_t)s].obs_feat.size(); });
+    const int TF = foff[(size_t)N], TO = ooff[(size_t)N];
+    std::vector<int> flags((size_t)N * 4), obs_feat((size_t)TO + 1), obs_i((size_t)TO + 1), obs_j((size_t)TO + 1);
+    std::vector<double> poses((size_t)N * 77), ex((size_t)N * 7), invd((size_t)TF + 1), obs_pts((size_t)TO * 4 + 4), laser((size_t)N * 240), prior_T((size_t)N * 16);
+    pool_->run(N, [&](int s) {
+        const SolvePack &q = sp[(size_t)s];
+        Estimator &e = *est_[(size_t)s];
+        std::memcpy(&flags[(size_t)s * 4], q.flags, sizeof(q.flags));
+        std::memcpy(&poses[(size_t)s * 77], q.poses, sizeof(q.poses)); std::memcpy(&ex[(size_t)s * 7], e.para_ex[0], 56);
+        std::memcpy(&laser[(size_t)s * 240], q.laser, sizeof(q.laser)); std::memcpy(&prior_T[(size_t)s * 16], e.TLC, 128);
+        if (q.F > 0) std::memcpy(&invd[(size_t)foff[(size_t)s]], e.para_depth_inv.data(), (size_t)q.F * sizeof(double));
+        const size_t o0 = (size_t)ooff[(size_t)s], no = q.obs_feat.size();
+        if (no) {
+            std::memcpy(&obs_feat[o0], q.obs_feat.data(), no * sizeof(int)); std::memcpy(&obs_i[o0], q.obs_i.data(), no * sizeof(int));
+            std::memcpy(&obs_j[o0], q.obs_j.data(), no * sizeof(int)); std::memcpy(&obs_pts[o0 * 4], q.obs_pts.data(), no * 4 * sizeof(double));
+        }
+    });
+    double laser_info[36], mono_info[4], prior_w[2];
+    solve_infos(p_, laser_info, mono_info, prior_w);
+    lmono_ba_desc d{};
+    d.n_windows = N; d.feat_off = foff.data(); d.obs_off = ooff.data(); d.flags = flags.data(); d.poses = poses.data(); d.ex = ex.data();
+    d.inv_depth = invd.data(); d.obs_feat = obs_feat.data(); d.obs_i = obs_i.data(); d.obs_j = obs_j.data(); d.obs_pts = obs_pts.data();
+    d.laser_consts = laser.data(); d.prior_T = prior_T.data(); d.laser_info = laser_info; d.mono_info = mono_info; d.prior_w = prior_w;
+    if (!ba_batch_) {
+        ba_batch_ = lmono_ba_batch_create(hip_.get(), &d);
+        if (!ba_batch_) throw std::runtime_error(std::string("lmono_ba_batch_create: ") + lmono_last_error(hip_.get()));
+    } else
+        hip_.check(lmono_ba_batch_update(hip_.get(), ba_batch_, &d), "lmono_ba_batch_update");
+    hip_.check(lmono_ba_solve(hip_.get(), ba_batch_, p_.NUM_ITERATIONS), "lmono_ba_solve");
+    std::vector<double> summary((size_t)N * 6);
+    hip_.check(lmono_ba_batch_read(hip_.get(), ba_batch_, poses.data(), ex.data(), invd.data(), summary.data()), "lmono_ba_batch_read");
+    pool_->run(N, [&](int s) {
+        est_[(size_t)s]->unpackSolve(sp[(size_t)s], &poses[(size_t)s * 77], &ex[(size_t)s * 7], &invd[(size_t)foff[(size_t)s]], &summary[(size_t)s * 6]);
+    });
+    if (est_[0]->frame_count < WINDOW_SIZE) return;
+    if (p_.ESTIMATE_LASER) margin();
+}
+
+// Estimator::margin of every stream: the MARGIN_OLD streams in one lmono_marginalize, the MARGIN_SECOND_NEW ones in one lmono_marg_second_new
+void EstimatorBatch::margin()
+{
+    marginWait();
+    const int N = size();
+    auto packs = std::make_shared<std::vector<MargPack>>((size_t)N);
+    pool_->run(N, [&](int s) { est_[(size_t)s]->packMargin((*packs)[(size_t)s]); });
+    HipContext *h = async_margin_ ? margin_hip_.get() : &hip_;
+    auto job = [this, h, packs, N]() {
+        std::vector<int> olds, seconds;
+        for (int s = 0; s < N; s++) { const int k = (*packs)[(size_t)s].kind; if (k == 1) olds.push_back(s); else if (k == 2) seconds.push_back(s); }
+        double laser_info[36], mono_info[4], prior_w[2];
+        solve_infos(p_, laser_info, mono_info, prior_w);
+        if (!olds.empty()) {
+            const int W = (int)olds.size();
+            std::vector<int> foff((size_t)W + 1, 0), ooff((size_t)W + 1, 0);
+            for (int w = 0; w < W; w++) { const MargPack &m = (*packs)[(size_t)olds[(size_t)w]]; foff[(size_t)w + 1] = foff[(size_t)w] + m.f0; ooff[(size_t)w + 1] = ooff[(size_t)w] + (int)m.obs_feat.size(); }
+            const int TF = foff[(size_t)W], TO = ooff[(size_t)W];
+            std::vector<double> poses((size_t)W * 77), ex((size_t)W * 7), invd((size_t)TF + 1, 0.0), obs_pts((size_t)TO * 4 + 4, 0.0), laser01((size_t)W * 24);
+            std::vector<int> obs_feat((size_t)TO + 1, 0), obs_j((size_t)TO + 1, 0), status((size_t)W, 0);
+            for (int w = 0; w < W; w++) {
+                const MargPack &m = (*packs)[(size_t)olds[(size_t)w]];
+                std::memcpy(&poses[(size_t)w * 77], m.poses, sizeof(m.poses)); std::memcpy(&ex[(size_t)w * 7], m.ex, sizeof(m.ex)); std::memcpy(&laser01[(size_t)w * 24], m.laser01, sizeof(m.laser01));
+                if (m.f0) std::memcpy(&invd[(size_t)foff[(size_t)w]], m.invd.data(), (size_t)m.f0 * sizeof(double));
+                const size_t no = m.obs_feat.size(), o0 = (size_t)ooff[(size_t)w];
+                if (no) { std::memcpy(&obs_feat[o0], m.obs_feat.data(), no * sizeof(int)); std::memcpy(&obs_j[o0], m.obs_j.data(), no * sizeof(int)); std::memcpy(&obs_pts[o0 * 4], m.obs_pts.data(), no * 4 * sizeof(double)); }
+            }
+            std::vector<double> J((size_t)W * 66 * 66, 0.0), r((size_t)W * 66, 0.0);
+            h->check(lmono_marginalize(h->get(), W, foff.data(), ooff.data(), poses.data(), ex.data(), invd.data(), obs_feat.data(), obs_j.data(), obs_pts.data(),
+                                       laser01.data(), laser_info, mono_info, J.data(), r.data(), status.data()), "lmono_marginalize");
+            for (int w = 0; w < W; w++)
+                est_[(size_t)olds[(size_t)w]]->applyMarginOld((*packs)[(size_t)olds[(size_t)w]], &J[(size_t)w * 66 * 66], &r[(size_t)w * 66], status[(size_t)w]);
+        }
+        if (!seconds.empty()) {
+            // (a prior that still holds para_pose[WINDOW_SIZE - 1]'s block is the one a MARGIN_OLD pass built: 11 blocks, the dropped one last -- the same
+            // shape for every stream; anything else is grouped by shape)
+            std::map<std::pair<int, int>, std::vector<int>> by_shape;
+            for (int s : seconds) by_shape[{ (*packs)[(size_t)s].nb, (*packs)[(size_t)s].drop }].push_back(s);
+            for (auto &grp : by_shape) {
+                const int nb = grp.first.first, drop = grp.first.second, W = (int)grp.second.size();
+                const size_t n0 = 6 * (size_t)nb, n = n0 - 6;
+                std::vector<double> J0((size_t)W * n0 * n0), r0((size_t)W * n0), x0((size_t)W * nb * 7), x((size_t)W * nb * 7), J((size_t)W * n * n), r((size_t)W * n);
+                std::vector<int> status((size_t)W, 0);
+                for (int w = 0; w < W; w++) {
+                    const Estimator::MarginalizationInfo &mi = est_[(size_t)grp.second[(size_t)w]]->last_marginalization_info;
+                    std::memcpy(&J0[(size_t)w * n0 * n0], mi.linearized_jacobians.data(), n0 * n0 * sizeof(double));
+                    std::memcpy(&r0[(size_t)w * n0], mi.linearized_residuals.data(), n0 * sizeof(double));
+                    std::memcpy(&x0[(size_t)w * nb * 7], mi.keep_block_data.data(), (size_t)nb * 7 * sizeof(double));
+                    std::memcpy(&x[(size_t)w * nb * 7], (*packs)[(size_t)grp.second[(size_t)w]].x.data(), (size_t)nb * 7 * sizeof(double));
+                }
+                h->check(lmono_marg_second_new(h->get(), W, nb, drop, J0.data(), r0.data(), x0.data(), x.data(), J.data(), r.data(), status.data()), "lmono_marg_second_new");
+                for (int w = 0; w < W; w++)
+                    est_[(size_t)grp.second[(size_t)w]]->applyMarginSecond((*packs)[(size_t)grp.second[(size_t)w]], &J[(size_t)w * n * n], &r[(size_t)w * n], status[(size_t)w]);
+            }
+        }
+    };
+    if (!async_margin_) { job(); return; }
+    if (!margin_worker_) margin_worker_.reset(new MarginWorker());
+    margin_worker_->submit(std::move(job));
+}
+
+// Estimator::slideWindow of every stream: the depth shifts of the MARGIN_OLD streams in one lmono_shift_depth_batch
+void EstimatorBatch::slideWindow()
+{
+    const int N = size();
+    std::vector<ShiftPack> sp((size_t)N);
+    std::vector<char> due((size_t)N, 0);
+    pool_->run(N, [&](int s) { due[(size_t)s] = est_[(size_t)s]->slideWindowBegin(sp[(size_t)s]) ? 1 : 0; });
+    const std::vector<int> off = offsets(N, [&](int s) { return due[(size_t)s] ? (int)sp[(size_t)s].dep.size() : 0; });
+    const int T = off[(size_t)N];
+    std::vector<double> frames((size_t)N * 40, 0.0), pt((size_t)T * 2 + 2), dep((size_t)T + 1), out((size_t)T + 1);
+    for (int s = 0; s < N; s++) {
+        if (!due[(size_t)s]) continue;
+        std::memcpy(&frames[(size_t)s * 40], sp[(size_t)s].frames, sizeof(sp[(size_t)s].frames));
+        const size_t n = sp[(size_t)s].dep.size();
+        if (n) { std::memcpy(&pt[(size_t)off[(size_t)s] * 2], sp[(size_t)s].pt.data(), n * 2 * sizeof(double)); std::memcpy(&dep[(size_t)off[(size_t)s]], sp[(size_t)s].dep.data(), n * sizeof(double)); }
+    }
+    if (T > 0) hip_.check(lmono_shift_depth_batch(hip_.get(), N, frames.data(), off.data(), pt.data(), dep.data(), out.data()), "lmono_shift_depth_batch");
+    pool_->run(N, [&](int s) { if (due[(size_t)s]) est_[(size_t)s]->slideWindowFinish(&out[(size_t)off[(size_t)s]]); });
+}
+
+// Estimator::processImage (Estimator.cc:367-499) for every stream, the numeric steps batched
+void EstimatorBatch::processImage(const double *headers, const FeatureManager::Image *images, const double (*transform_to_init)[16], bool *keyframe)
+{
+    const int N = size();
+    std::vector<char> kf((size_t)N, 0);
+    pool_->run(N, [&](int s) { bool k = false; est_[(size_t)s]->preFrame(headers[s], images[s], transform_to_init[s], &k); kf[(size_t)s] = k ? 1 : 0; });
+    if (keyframe) for (int s = 0; s < N; s++) keyframe[s] = kf[(size_t)s] != 0;
+    const Estimator &e0 = *est_[0];
+    for (int s = 1; s < N; s++)
+        if (est_[(size_t)s]->stage_flag != e0.stage_flag || est_[(size_t)s]->frame_count != e0.frame_count)
+            throw std::logic_error("EstimatorBatch: the streams are not at the same frame of their sequences");
+    if (e0.stage_flag == Estimator::NOT_INITED) {
+        if (e0.frame_count == WINDOW_SIZE) {
+            if (p_.ESTIMATE_LASER != 2) {
+                // runInitialization :986-1012
+                pool_->run(N, [&](int s) { est_[(size_t)s]->initialPoses(); });
+                triangulate();
+                outliersRejection(100.0);
+                optimization();
+                for (auto &e : est_) e->stage_flag = Estimator::INITED;
+                outliersRejection(3);
+                slideWindow();
+            } else slideWindow();
+        }
+        if (est_[0]->frame_count < WINDOW_SIZE)
+            pool_->run(N, [&](int s) {
+                Estimator &e = *est_[(size_t)s];
+                e.frame_count++;
+                e.Ps[e.frame_count] = e.Ps[e.frame_count - 1]; e.Rs[e.frame_count] = e.Rs[e.frame_count - 1]; e.Header[e.frame_count] = e.Header[e.frame_count - 1];
+            });
+    } else {
+        pool_->run(N, [&](int s) { est_[(size_t)s]->loopCorrection(); });
+        triangulate();
+        optimization();
+        outliersRejection(p_.OUTLIER_T);
+        slideWindow();
+    }
+    if (est_[0]->stage_flag == Estimator::INITED) pool_->run(N, [&](int s) { est_[(size_t)s]->pushOdometryRow(); });
 }
 
 // ---- A-LOAM nodes ---------------------------------------------------------------------------------------------------

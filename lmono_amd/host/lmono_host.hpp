@@ -76,6 +76,12 @@ public:
     void removeOutlier(const std::set<int> &ids);
     void triangulate(int frameCnt, const Mat3 Rs[], const Vec3 Ps[], const double tlc[16]);   // :75-255 -> lmono_triangulate
     void removeBackShiftDepth(const Mat3 &back_R0, const Vec3 &back_P0, const Mat3 &R1, const Vec3 &P1, const double tlc[16]);  // :540-590
+    // the two halves of removeBackShiftDepth around its numeric call (EstimatorBatch makes ONE lmono_shift_depth_batch call for all its streams):
+    // the tracks anchored at the dropped frame that survive it (points, depths); then the list surgery with the shifted depths
+    void shiftDepthPack(std::vector<double> &pt, std::vector<double> &dep) const;
+    void shiftDepthApply(const double *depth_out);
+    // likewise triangulate(): what setDepth-style bookkeeping follows lmono_triangulate
+    void triangulateApply(const double *depth, const int *solve_flag);
     void removeBack();                                       // :497-511
     void removeFront(int frame_count);                       // :513-538
     // one observation of the tracker per feature id: x_n, y_n, u, v (the first four of the reference's 6-vector)
@@ -88,6 +94,30 @@ public:
     // packs tracks with used_num >= TRACK_CNT for the kernels: start, offsets, points (anchor first)
     void pack(std::vector<int> &start, std::vector<int> &off, std::vector<double> &pts, std::vector<double> &depth, bool all_tracks);
 };
+
+// ---- what one Estimator hands to a numeric C-ABI call.  Estimator makes the call for its own pack (n_windows = 1); EstimatorBatch concatenates
+// the packs of N Estimators into one call (n_windows = N) -- the numbers a window gets back are the same bytes either way.
+struct TrackPack {                         // lmono_triangulate / lmono_outlier_scores: every track of the window
+    std::vector<int> start, off; std::vector<double> pts, depth;
+    double R[99], P[33];
+};
+struct SolvePack {                         // lmono_ba_batch_create / _update: the residual blocks of Estimator.cc:1155-1215
+    std::vector<int> obs_feat, obs_i, obs_j; std::vector<double> obs_pts;
+    int F = 0, flags[4] = { 0, 0, 0, 0 };
+    bool use_mono = false;
+    double poses[77], laser[240];
+};
+struct MargPack {                          // lmono_marginalize (kind 1, MARGIN_OLD) / lmono_marg_second_new (kind 2); kind 0: nothing to do this frame
+    int kind = 0;
+    std::vector<int> obs_feat, obs_j; std::vector<double> obs_pts, invd;
+    int f0 = 0;
+    double poses[77], ex[7], laser01[24];
+    int nb = 0, drop = 0; std::vector<double> x;      // kind 2: the prior's blocks at their current values
+};
+struct ShiftPack { std::vector<double> pt, dep; double frames[40]; };     // lmono_shift_depth[_batch]: back_R0, back_P0, R1, P1, TLC
+
+class EstimatorBatch;
+class MarginWorker;
 
 // ---- Estimator ------------------------------------------------------------------------------------------------------
 class Estimator {
@@ -155,6 +185,22 @@ public:
         bool valid = false, present = false;
         int status = 0;
     } last_marginalization_info;
+    // ---- the host halves of the numeric steps (what runs before and behind each C-ABI call); the methods above are made of them, EstimatorBatch
+    //      runs them for N streams around ONE batched call per step
+    bool packTracks(TrackPack &tp);                                       // false: the window holds no track
+    void packSolve(SolvePack &sp);                                        // matrix2Double + the residual blocks
+    void unpackSolve(const SolvePack &sp, const double *poses77, const double *ex7, const double *invd, const double *summary6);   // ... double2Matrix
+    void packMargin(MargPack &mp);                                        // margin() up to its kernel call (both branches)
+    void applyMarginOld(const MargPack &mp, const double *lin_J, const double *lin_r, int status);
+    void applyMarginSecond(MargPack &mp, const double *lin_J, const double *lin_r, int status);
+    void applyOutlierScores(const double *score, double error, std::set<int> &removeIndex);
+    // slideWindow() in two halves: the pose / header shifts and the list surgery that needs no numerics; true = removeBackShiftDepth is due
+    // (sp filled); slideWindowFinish applies its result
+    bool slideWindowBegin(ShiftPack &sp);
+    void slideWindowFinish(const double *depth_out);
+    void preFrame(double header, const FeatureManager::Image &image, const double transform_to_init[16], bool *keyframe);   // processImage up to the stage switch
+    void pushOdometryRow();                                               // new_odometry row, :634-645
+    void initialPoses();                                                  // runInitialization :986-1003 (poses from the LiDAR trajectory, clearDepth)
     int margin_calls[2] = { 0, 0 };        // MARGIN_OLD priors built, MARGIN_SECOND_NEW eliminations done
     // algorithmic flops of the window solves so far, SURVEY.md 8d: iterations x (2000 per projection block + 72^3 / 3) -- bench.py's roofline figure
     double solve_flops = 0.0;
@@ -166,11 +212,46 @@ private:
     std::unique_ptr<HipContext> margin_hip_;   // setAsyncMargin: the context marginalisation runs on
     // the overlapped marginalisation's worker: ONE host thread for the Estimator's lifetime takes the jobs (a thread per frame -- std::async -- cost the
     // frame loop ~70 us per frame); at most one job is pending
-    struct MarginWorker;
     std::unique_ptr<MarginWorker> margin_worker_;
+    friend class EstimatorBatch;
     void marginSubmit(std::function<void()> job);
     bool async_margin_ = false;
     Params p_;
+};
+
+// ---- N independent Estimators stepped in lock-step ("BA ... parallel only across independent sequences / streams") --------
+// One sequence cannot batch (window k starts from window k - 1's result); N sequences can: every numeric step of a frame -- triangulation, the window
+// solve, marginalisation, outlier scores, the depth shift of the slide -- is ONE C-ABI call over the N windows of the N streams (the entry points take
+// n_windows), the host halves around the calls run on a small thread pool.  Every stream's output is the bytes of its own single-stream run: the kernels
+// own one window per workgroup (or one track per thread) and form their sums in an order fixed by the window alone.
+// The streams must be at the same frame of their sequences (same frame_count / stage_flag): they are created together and fed one frame each per call.
+class HostPool;
+class EstimatorBatch {
+public:
+    EstimatorBatch(HipContext &hip, const Params &p, int n_streams, int host_threads = 0);     // host_threads 0: min(hardware threads, 16) (LMONO_HOST_THREADS)
+    ~EstimatorBatch();
+    EstimatorBatch(const EstimatorBatch &) = delete;
+    EstimatorBatch &operator=(const EstimatorBatch &) = delete;
+    int size() const { return (int)est_.size(); }
+    Estimator &stream(int s) { return *est_[(size_t)s]; }
+    // one frame of every stream: headers[n], images[n], transform_to_init[n] (4 x 4 row-major LiDAR poses); keyframe[n] (optional) as processImage returns it
+    void processImage(const double *headers, const FeatureManager::Image *images, const double (*transform_to_init)[16], bool *keyframe = nullptr);
+    void setAsyncMargin(bool on);          // marginalisation of frame k beside frame k + 1 (second context, own stream, one worker thread), as Estimator::setAsyncMargin
+    void marginWait();
+private:
+    void triangulate();
+    void optimization();
+    void margin();
+    void outliersRejection(double error);
+    void slideWindow();
+    HipContext &hip_;
+    Params p_;
+    std::vector<std::unique_ptr<Estimator>> est_;
+    lmono_ba_batch *ba_batch_ = nullptr;
+    std::unique_ptr<HostPool> pool_;
+    std::unique_ptr<HipContext> margin_hip_;
+    std::unique_ptr<MarginWorker> margin_worker_;
+    bool async_margin_ = false;
 };
 
 // ---- A-LOAM nodes ---------------------------------------------------------------------------------------------------

@@ -142,6 +142,15 @@ int lmono_shift_depth(lmono_ctx *, const double *back_R0, const double *back_P0,
     if (n > 0) lo_shift_depth(back_R0, back_P0, R1, P1, tlc, n, pt_i_h, depth_h, depth_out_h);
     return LMONO_OK;
 }
+int lmono_shift_depth_batch(lmono_ctx *, int n_windows, const double *frames_h, const int *track_off_h, const double *pt_i_h, const double *depth_h, double *depth_out_h)
+{
+    for (int w = 0; w < n_windows; w++) {
+        const int f0 = track_off_h[w], n = track_off_h[w + 1] - f0;
+        const double *fr = frames_h + (size_t)w * 40;
+        if (n > 0) lo_shift_depth(fr, fr + 9, fr + 12, fr + 21, fr + 24, n, pt_i_h + (size_t)f0 * 2, depth_h + f0, depth_out_h + f0);
+    }
+    return LMONO_OK;
+}
 int lmono_marginalize(lmono_ctx *, int n_windows, const int *feat_off_h, const int *obs_off_h, const double *poses_h, const double *ex_h,
                       const double *inv_depth_h, const int *obs_feat_h, const int *obs_j_h, const double *obs_pts_h,
                       const double *laser01_h, const double *laser_info_h, const double *mono_info_h,

@@ -88,3 +88,14 @@ def test_gpu_feature_kernels_match_oracle(oracle, gpu_ctx):
     a = gpu_ctx.shift_depth(w["Rs"][0], w["Ps"][0], w["Rs"][1], w["Ps"][1], w["tlc"], pt_i, w["true"][f])
     b = oracle.shift_depth(w["Rs"][0], w["Ps"][0], w["Rs"][1], w["Ps"][1], w["tlc"], pt_i, w["true"][f])
     assert np.abs(a - b).max() < 1e-12 * np.abs(b).max()
+    # the batched entry (EstimatorBatch: one call for N windows) gives every window the single call's bytes, an empty window in the middle included
+    frames, pts, deps, want = [], [], [], []
+    for k, w in enumerate(wins):
+        f = np.nonzero(w["trk_start"] == 0)[0] if k != 1 else np.zeros(0, int)
+        pt_i = np.array([w["trk_pts"][w["trk_off"][j]] for j in f]).reshape(-1, 2)
+        frames.append(np.concatenate([np.ravel(w["Rs"][0]), np.ravel(w["Ps"][0]), np.ravel(w["Rs"][1]), np.ravel(w["Ps"][1]), np.ravel(w["tlc"])]))
+        pts.append(pt_i); deps.append(w["true"][f])
+        want.append(gpu_ctx.shift_depth(w["Rs"][0], w["Ps"][0], w["Rs"][1], w["Ps"][1], w["tlc"], pt_i, w["true"][f]) if len(f) else np.zeros(0))
+    got = gpu_ctx.shift_depth_batch(frames, pts, deps)
+    for g, wv in zip(got, want):
+        assert g.tobytes() == wv.tobytes()

@@ -106,3 +106,62 @@ def test_cxx_mirror_over_the_c_oracle_prints_the_python_replays_trajectory(oracl
     assert len(frm) == len(log)
     for k, (row, r) in enumerate(zip(frm, log)):
         assert (int(row[1]), int(row[2]), int(row[3])) == (r[0], r[1], r[2]) and (int(row[7]), int(row[8])) == (r[6], r[7]), "frame %d" % k
+
+
+def _split_streams(stdout):
+    """estimator_seq streams=N output -> {stream: [its lines]}, {stream: digest}"""
+    cur, by, dig = None, {}, {}
+    for ln in stdout.splitlines():
+        if ln.startswith("STR "):
+            cur = int(ln.split()[1]); by[cur] = []
+        elif ln.startswith("DIG "):
+            dig[int(ln.split()[1])] = ln.split()[2]
+        elif ln.startswith(("TIM", "FLP")):
+            continue
+        elif cur is not None:
+            by[cur].append(ln)
+    return by, dig
+
+
+def test_lockstep_batch_of_estimators_prints_every_streams_own_lines(oracle, tmp_path):
+    """EstimatorBatch: N independent Estimators stepped in lock-step, every numeric step ONE C-ABI call over the N windows, the host
+    halves on a thread pool.  Host logic only here (the C ABI is the CPU shim over the oracle): five streams replaying three different stream files --
+    static stretches, loop events, keyframe / non-keyframe frames that differ between the streams, so the MARGIN_OLD and MARGIN_SECOND_NEW groups of
+    a frame are both non-empty and change from frame to frame -- print, stream by stream, exactly the lines of the single-stream runs of their
+    files, with marginalisation inline and overlapped."""
+    import os
+    import subprocess
+    from workloads import s2
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "estimator_seq_cpu"])
+    exe = os.path.join(root, "oracle", "estimator_seq_cpu")
+    files, single = [], []
+    for k, (seed, stops) in enumerate(((2, (20, 21, 30)), (0, ()), (3, (25,)))):
+        st = s2.make_stream(48, seed=seed, stops=stops)
+        loops = [S.loop_event(st, 30 + 3 * k)] if k != 1 else []
+        for e in loops:                         # (a fixed corrected pose: the event needs no live window here)
+            e["correct_T"] = np.array([0.1 * k, 0.2, 0.3]); e["correct_Q"] = np.array([1.0, 0.0, 0.001, 0.0])
+        fx = tmp_path / ("s%d.bin" % k)
+        S.write_stream(fx, st, loops)
+        files.append(str(fx))
+        out = subprocess.run([exe, str(fx), "-"], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        single.append([ln for ln in out.stdout.splitlines() if not ln.startswith(("TIM", "FLP", "DIG"))])
+        assert [ln for ln in out.stdout.splitlines() if ln.startswith("DIG")]
+    kinds = set()
+    for lines in single:
+        kinds |= {ln.split()[2] for ln in lines if ln.startswith("FRM")}
+    assert kinds == {"0", "1"}                  # keyframes and non-keyframes both occur
+    for mode in ("sync", "async"):
+        out = subprocess.run([exe, files[0], "-", mode, "streams=5", files[1], files[2]], capture_output=True, text=True, timeout=900,
+                             env=dict(os.environ, LMONO_HOST_THREADS="3"))
+        assert out.returncode == 0, out.stderr[-2000:]
+        by, dig = _split_streams(out.stdout)
+        assert sorted(by) == [0, 1, 2, 3, 4] and len(dig) == 5
+        for s in range(5):
+            assert by[s] == single[s % 3], "%s: stream %d differs from the single-stream run of its file" % (mode, s)
+        assert dig[0] == dig[3] and dig[1] == dig[4] and len({dig[0], dig[1], dig[2]}) == 3
+    # digest-only output (what the bench reads for many streams) carries the same digests
+    out = subprocess.run([exe, files[0], "-", "streams=5", "digest", files[1], files[2]], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and not [ln for ln in out.stdout.splitlines() if ln.startswith(("FRM", "ODO"))]
+    assert _split_streams(out.stdout)[1] == dig

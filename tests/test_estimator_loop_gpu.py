@@ -124,3 +124,34 @@ def test_overlapped_marginalisation_is_the_same_bytes(oracle, tmp_path):
     assert abs(float(pri[5]) - sj) <= 1e-6 * sj and abs(float(pri[6]) - sr) <= 1e-6 * max(sr, 1e-12)
     ms = [float([ln for ln in r if ln.startswith("TIM")][0].split()[2]) for r in runs]
     print("200-frame replay: %.2f ms per INITED frame inline, %.2f ms with marginalisation overlapped" % (ms[0], ms[1]))
+
+
+def test_lockstep_batch_of_estimators_is_every_streams_single_run(tmp_path):
+    """EstimatorBatch on the GPU: 6 streams over 3 different stream files (static stretches, loop events, keyframe patterns that differ
+    between streams) stepped in lock-step -- one lmono_triangulate / lmono_ba_batch_update + solve + read / lmono_marginalize + lmono_marg_second_new /
+    lmono_outlier_scores / lmono_shift_depth_batch per frame over all windows -- print, stream by stream, the BYTES of the single-stream runs of their
+    files: a window's numbers depend neither on its neighbours in the batch nor on the cluster size the batch runs with (single stream: 4 workgroups
+    per window, batch of 6: 8)."""
+    from tests.test_estimator_loop_cpu import _split_streams
+    from workloads import s2
+    files, single = [], []
+    for k, (seed, stops) in enumerate(((2, (40, 41, 77)), (0, ()), (3, (25,)))):
+        st = s2.make_stream(100, seed=seed, stops=stops)
+        loops = [S.loop_event(st, 60 + 3 * k)] if k != 1 else []
+        for e in loops:
+            e["correct_T"] = np.array([0.1 * k, 0.2, 0.3]); e["correct_Q"] = np.array([1.0, 0.0, 0.001, 0.0])
+        fx = tmp_path / ("s%d.bin" % k)
+        S.write_stream(fx, st, loops)
+        files.append(str(fx))
+        out = subprocess.run([EXE, str(fx), "-"], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        single.append([ln for ln in out.stdout.splitlines() if not ln.startswith(("TIM", "FLP", "DIG"))])
+    for mode in ("sync", "async"):
+        out = subprocess.run([EXE, files[0], "-", mode, "streams=6", files[1], files[2]], capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        by, dig = _split_streams(out.stdout)
+        assert sorted(by) == list(range(6))
+        for s in range(6):
+            assert by[s] == single[s % 3], "%s: stream %d differs from the single-stream run of its file" % (mode, s)
+        tim = [ln for ln in out.stdout.splitlines() if ln.startswith("TIM")][0].split()
+        print("%s: 6 streams in lock-step, %.2f ms per lock-step frame = %.0f frames/s" % (mode, float(tim[2]), 6e3 / float(tim[2])))
