@@ -73,7 +73,83 @@ def bench_ba(args):
     print(json.dumps(out), flush=True)
 
 
+def _make_seq_stream(job):
+    """(worker of bench_ba_seq_streams' process pool: one S2 frame stream written to a file; no GPU in here)"""
+    from workloads import s2 as K
+    n, seed, path = job
+    st = K.make_stream(n, seed=seed, stops=(400, 401, 1500) if n > 1500 else ())
+    K.write_stream(path, st)
+    return path
+
+
+def bench_ba_seq_streams(args):
+    """N independent sequences through the host mirror's EstimatorBatch (the BA loop is parallel only across independent
+    sequences): N Estimators stepped in lock-step, every numeric step of a frame one batched C-ABI call over the N windows (lmono_triangulate,
+    lmono_ba_batch_update / _solve / _read, lmono_marginalize + lmono_marg_second_new, lmono_outlier_scores, lmono_shift_depth_batch).  Stream s
+    replays file s mod 8 of eight different S2 streams; every stream's output digest must equal the digest of the single-stream run of its file."""
+    import subprocess
+    import tempfile
+    from concurrent.futures import ProcessPoolExecutor
+    n, N = args.frames_seq, args.seq_streams
+    n_files = min(N, 8)
+    d = tempfile.mkdtemp()
+    t0 = time.time()
+    jobs = [(n, 2 + k, os.path.join(d, "stream%d.bin" % k)) for k in range(n_files)]
+    with ProcessPoolExecutor(max_workers=min(n_files, os.cpu_count() or 1)) as ex:
+        files = list(ex.map(_make_seq_stream, jobs))
+    gen_s = time.time() - t0
+    exe = os.path.join(ROOT, "lmono_amd", "host", "estimator_seq")
+    runs = {}
+    for mode in ("sync", "async"):
+        t0 = time.perf_counter()
+        out = subprocess.run([exe, files[0], "-", mode, "streams=%d" % N, "digest"] + files[1:], capture_output=True, text=True)
+        wall = time.perf_counter() - t0
+        if out.returncode != 0:
+            raise RuntimeError("estimator_seq streams=%d failed: %s" % (N, out.stderr[-1000:]))
+        lines = out.stdout.splitlines()
+        tim = [ln for ln in lines if ln.startswith("TIM")][0].split()
+        flp = [ln for ln in lines if ln.startswith("FLP")][0].split()
+        runs[mode] = {"dig": {int(ln.split()[1]): ln.split()[2] for ln in lines if ln.startswith("DIG")}, "n_inited": int(tim[1]), "ms_step": float(tim[2]),
+                      "wall": wall, "flops": float(flp[1]), "obs": int(flp[2])}
+    # every stream against the single-stream run of its file
+    verified, single_ms = 0, []
+    same = runs["sync"]["dig"] == runs["async"]["dig"]
+    for k in range(n_files if not args.no_extras else min(n_files, 1)):
+        out = subprocess.run([exe, files[k], "-", "async"], capture_output=True, text=True)
+        if out.returncode != 0:
+            raise RuntimeError("estimator_seq failed: " + out.stderr[-1000:])
+        dig = [ln for ln in out.stdout.splitlines() if ln.startswith("DIG")][0].split()[2]
+        single_ms.append(float([ln for ln in out.stdout.splitlines() if ln.startswith("TIM")][0].split()[2]))
+        for s in range(k, N, n_files):
+            same = same and runs["async"]["dig"][s] == dig
+        verified += 1
+    r = runs["async"]
+    fps = N * 1e3 / r["ms_step"]
+    tfl = r["flops"] / (r["ms_step"] * 1e-3 * r["n_inited"]) / 1e12
+    res = {"metric": "Estimator frames/sec over N independent sequences in lock-step (sliding-window BA frame loop, S2 synthetic streams)", "value": round(fps, 1),
+           "unit": "frames/s", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": round(r["ms_step"] * r["n_inited"], 1), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "S2 frame streams, KITTI-05 shape (configs[2]): %d streams x %d frames (%d different stream files), <= 150 tracks / frame, "
+                                  "EstimatorBatch: one batched C-ABI call per numeric step" % (N, n, n_files),
+                      "streams": N, "frames": n, "inited_frames_per_stream": r["n_inited"], "ms_per_lockstep_frame": round(r["ms_step"], 3), "wall_s": round(r["wall"], 1),
+                      "gen_s": round(gen_s, 1), "marginalisation": "overlapped with the next frame (second context, own HIP stream, host thread)",
+                      "inline_marginalisation": {"ms_per_lockstep_frame": round(runs["sync"]["ms_step"], 3), "frames_per_s": round(N * 1e3 / runs["sync"]["ms_step"], 1)},
+                      "every_stream_equals_its_single_stream_run": bool(same), "files_verified": verified,
+                      "single_stream_frames_per_s": (round(1e3 / float(np.mean(single_ms)), 1) if single_ms else None)},
+           "roofline": {"bound": "mfma", "kernel": "k_ba_solve (%d windows per launch)" % N, "achieved": round(tfl, 4), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(tfl / FP64_PEAK_TFLOPS, 6), "traffic": None, "algorithmic_flops": r["flops"], "projection_blocks": r["obs"],
+                        "note": "algorithmic flops of all window solves (SURVEY 8d: iterations x (2000 per projection block + 72^3 / 3)) over the WHOLE lock-step frame time "
+                                "(host halves, uploads and read-backs included)"}}
+    print(json.dumps(res), flush=True)
+
+
 def bench_ba_seq(args):
+    if args.seq_streams > 1:
+        return bench_ba_seq_streams(args)
+    return bench_ba_seq_single(args)
+
+
+def bench_ba_seq_single(args):
     """BASELINE configs[2] as a SEQUENCE: KITTI-05-shaped S2 frame stream (2761 frames: LiDAR odometry pose +
     tracker output per frame) through the host mirror's Estimator::processImage loop (lmono_amd/host/estimator_seq: featureCheck ->
     triangulate -> optimization + margin -> outliersRejection -> slideWindow, every numeric step on the GPU through the C ABI), one
@@ -657,6 +733,7 @@ def main():
     ap.add_argument("--lead", type=int, default=6, help="lead-in scans of a chain that does not start at scan 0")
     ap.add_argument("--lead-full", type=int, default=3,
                     help="lead-in scan pairs of a chain (the last ones) that use all feature points; the earlier ones a quarter (-1: all use all)")
+    ap.add_argument("--lead-seed", type=int, default=-1, help="LMONO_OPT_LEAD_SEED (-1: the library's default): 1 = lead-in states re-seeded from the neighbouring chains' first results")
     ap.add_argument("--kitti-dir", default="", help="read the scans of a KITTI-layout sequence directory (velodyne/%%06d.bin + times.txt, e.g. "
                     "dataset/sequences/00: /root/reference/README.md:48-60) instead of generating S1 scans; --scans caps the count")
     ap.add_argument("--seq", type=int, default=0, choices=[0, 1, 2], help="0: the S1 figure-8 sequence (headline); 1: the held-out sequence (other world, clover trajectory); "
@@ -676,6 +753,7 @@ def main():
     ap.add_argument("--windows", type=int, default=1024, help="ba: independent windows per GPU")
     ap.add_argument("--frames-seq", type=int, default=2761, help="ba-seq: frames of the stream (KITTI seq 05 = 2761)")
     ap.add_argument("--streams", type=int, default=64, help="map / colour: independent streams advanced in lock-step")
+    ap.add_argument("--seq-streams", type=int, default=1, help="ba-seq: independent sequences stepped in lock-step by EstimatorBatch (1 = the reference's one sequence)")
     ap.add_argument("--frames", type=int, default=20, help="colour: frames per stream and step")
     ap.add_argument("--keyframes", type=int, default=4541, help="posegraph: keyframes of the graph")
     args = ap.parse_args()
@@ -765,6 +843,8 @@ def main():
     ctx = lmono_amd.Context(local_rank)
     if os.environ.get("LMONO_LEAD_FULL") is None:
         ctx.set_option(ctx.OPT_LEAD_FULL, args.lead_full)
+    if args.lead_seed >= 0:
+        ctx.set_option(ctx.OPT_LEAD_SEED, args.lead_seed)
     xyzi_t = torch.from_numpy(xyzi)
     t0 = time.time()
     xyzi_d = xyzi_t.to(dev)
@@ -931,7 +1011,7 @@ def main():
             "vs_baseline": None, "dtype": "f32 features / f64 solve", "data": "synthetic",
             "config": {"workload": "KITTI-seq-00-shaped synthetic S1 HDL-64, laserOdometry-only (configs[1])",
                        "scans_total": n_total, "scans_per_gpu": n_own, "points_per_scan": round(N), "azimuth_steps": args.az,
-                       "odometry_chains_per_gpu": chains, "chain_lead_in": args.lead, "lead_in_full_pairs": ctx.get_option(ctx.OPT_LEAD_FULL), "odometry_chain_groups": ctx.odom_chain_groups(chains),
+                       "odometry_chains_per_gpu": chains, "chain_lead_in": args.lead, "lead_in_full_pairs": ctx.get_option(ctx.OPT_LEAD_FULL), "lead_in_seed": ctx.get_option(ctx.OPT_LEAD_SEED), "odometry_chain_groups": ctx.odom_chain_groups(chains),
                        "parallelism": ("scan-range shard x%d, one %s all-gather of 7 doubles per rank per exchange" % (world, "gloo (rehearsal)" if rehearse else "RCCL"))
                                       if multi else "no collective (1 rank)",
                        "collective_ranks": world if multi else 0, "collective_backend": (dist.get_backend() if multi else None),

@@ -75,8 +75,11 @@ int         lmono_synchronize(lmono_ctx *);
  * segments); 1, 2, 4, 8 = that many.  Takes effect at the next
  * lmono_ba_batch_create / _update of the context (the scratch is sized then).  (Slot 5 was round 3's LMONO_OPT_ODOM_PERSIST, removed in round 4.)   */
 #define LMONO_OPT_BA_CLUSTER 5
-/* 6: round 3's LMONO_OPT_CORR_SECT (a schedule measured slower and removed); only 0 is accepted */
-#define LMONO_OPT_RESERVED6 6
+/* lead-in seeding of lmono_odom_batch[_d]'s chains (slot 6: round 3's LMONO_OPT_CORR_SECT, removed since): 0 = every lead-in starts from the identity and
+ * keeps its own estimates (the reference's initial para_q / para_t); 1 = after the first step of the pass the state of every chain that is still in its
+ * lead-in becomes the component-wise median of the first results of chains c - 1, c, c + 1 (a constant-velocity prior across 1.8 s that rejects a first
+ * pair gone wrong in clutter).  An accuracy / speed knob like lead: results are validated at the chain boundaries either way; n_chains = 1 is unaffected. */
+#define LMONO_OPT_LEAD_SEED 6
 #define LMONO_OPT_COUNT     7
 int         lmono_set_option(lmono_ctx *, int key, int value);
 int         lmono_get_option(lmono_ctx *, int key, int *value);     /* the configured value (option values may be negative) */

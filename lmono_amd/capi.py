@@ -152,6 +152,7 @@ class Context:
     OPT_LEAD_FULL = 3
     OPT_BOUNDARY_TOL = 4
     OPT_BA_CLUSTER = 5
+    OPT_LEAD_SEED = 6
 
     def set_option(self, key, value):
         self.check(self.L.lmono_set_option(self.h, int(key), int(value)))

@@ -375,7 +375,7 @@ __device__ __noinline__ double ba_small_factors(const BaBatch &B, const BaCtx c,
 #pragma unroll
         for (int k = 0; k < 7; k++) { prm[k] = poses[7 * t + k]; prm[7 + k] = poses[7 * (t + 1) + k]; }
 #pragma unroll
-        for (int k = 0; k < 24; k++) cst[k] = gld(B.laser_consts + ((size_t)blockIdx.x * 10 + t) * 24 + k);
+        for (int k = 0; k < 24; k++) cst[k] = gld(B.laser_consts + ((size_t)c.win * 10 + t) * 24 + k);      // (c.win, not blockIdx.x: with several workgroups per window a block is not a window)
 #pragma unroll
         for (int k = 0; k < 36; k++) inf[k] = gld(laser_info + k);
         ba::laser_factor(prm, cst, inf, r, kJac ? J : nullptr);
@@ -395,7 +395,7 @@ __device__ __noinline__ double ba_small_factors(const BaBatch &B, const BaCtx c,
 #pragma unroll
         for (int k = 0; k < 7; k++) prm[k] = ex[k];
 #pragma unroll
-        for (int k = 0; k < 16; k++) cst[k] = gld(B.prior_T + (size_t)blockIdx.x * 16 + k);
+        for (int k = 0; k < 16; k++) cst[k] = gld(B.prior_T + (size_t)c.win * 16 + k);
         ba::prior_factor(prm, cst, pw, r, kJac ? J : nullptr);
 #pragma unroll
         for (int k = 0; k < 6; k++) cost += 0.5 * r[k] * r[k];

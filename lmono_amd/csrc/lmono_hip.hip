@@ -29,7 +29,7 @@ struct lmono_ctx {
     std::vector<EvSet> sets;   // one event set per scanreg/odometry call since the last lmono_timing_reset
     int n_sets = 0;
     hipEvent_t *ev = nullptr;  // events of the current call
-    int opt[LMONO_OPT_COUNT] = { 3, 0, 4, -1, 1000, 0, 0 };   // LMONO_OPT_CORR_TILE: 3 = flattened sweeps (default, needs no hash grid), 0 = 32-lane groups on the hash grid (diagnostic build)
+    int opt[LMONO_OPT_COUNT] = { 3, 0, 4, -1, 1000, 0, 0 };   // (LMONO_OPT_LEAD_SEED: 0 until measured)   // LMONO_OPT_CORR_TILE: 3 = flattened sweeps (default, needs no hash grid), 0 = 32-lane groups on the hash grid (diagnostic build)
     hipStream_t gstream[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };   // streams of the odometry's chain groups (LMONO_OPT_ODOM_STREAMS > 1)
     hipEvent_t gev[9] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     unsigned long long *stats_d = nullptr;   // [0] feature points deferred by the tile search since the last lmono_timing_reset
@@ -206,7 +206,7 @@ extern "C" int lmono_set_option(lmono_ctx *c, int key, int value)
                   : key == LMONO_OPT_ODOM_STREAMS ? (value >= 1 && value <= 8)
                   : key == LMONO_OPT_BOUNDARY_TOL ? value >= 0
                   : key == LMONO_OPT_BA_CLUSTER ? (value == 0 || value == 1 || value == 2 || value == 4 || value == 8)
-                  : key == LMONO_OPT_RESERVED6 ? value == 0                     // round 3's shelved schedule (removed)
+                  : key == LMONO_OPT_LEAD_SEED ? (value >= 0 && value <= 1)
                   : value >= -1;                                     // LMONO_OPT_LEAD_FULL
     if (!ok) { c->err = "lmono_set_option: value out of range for this option"; return LMONO_EINVAL; }
     c->opt[key] = value;
@@ -795,7 +795,15 @@ static int odom_run(lmono_ctx *c, lmono_scan_batch *b, int n_chains, int lead, i
     if (tile) for (int g = 0; g < G; g++) HIP_TRY(c, hipMemsetAsync(b->wl + g * ((size_t)b->chains_cap * kMaxQueries + 1), 0, sizeof(unsigned int), st));
     EvSet &es = c->sets[c->n_sets - 1];
     int ne = 0;
-    rc = odom_launch_steps(c, b, o, n_chains, 0, max_steps, G, &es, &ne);
+    if (c->opt[LMONO_OPT_LEAD_SEED] > 0 && n_chains > 2 && lead >= 3 && max_steps > 1 && o.ws) {
+        // the first step of every chain, then the lead-in states are re-seeded from the neighbouring chains' first results (k_lead_seed_median)
+        rc = odom_launch_steps(c, b, o, n_chains, 0, 1, G, &es, &ne);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_lead_seed_median, dim3((n_chains + 255) / 256), dim3(256), 0, st, o);
+        hipLaunchKernelGGL(k_lead_seed_apply, dim3((n_chains + 255) / 256), dim3(256), 0, st, o);
+        rc = odom_launch_steps(c, b, o, n_chains, 1, max_steps, G, &es, &ne);
+    } else
+        rc = odom_launch_steps(c, b, o, n_chains, 0, max_steps, G, &es, &ne);
     if (rc) return rc;
     es.n_kev = ne;
     // the chained schedule validates itself: every chain's warm start against its predecessor's last increment, repair where they differ
@@ -1191,6 +1199,7 @@ struct BaPack {
 extern "C" void lmono_ba_batch_destroy(lmono_ba_batch *b)
 {
     if (!b) return;
+    if (b->retries > 0 && getenv("LMONO_BA_REPORT_RETRIES")) fprintf(stderr, "[lmono] lmono_ba_batch: %d cluster solve(s) gave up and were run again with one workgroup per window\n", b->retries);
     if (b->ctx) (void)hipStreamSynchronize(b->ctx->stream);
     if (b->blob) (void)hipFree(b->blob);
     if (b->stage) (void)hipHostFree(b->stage);

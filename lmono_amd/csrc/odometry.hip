@@ -1597,6 +1597,49 @@ __global__ void k_odom_init(OdomView o)
     }
 }
 
+// Lead-in seeding across chains (round 6, LMONO_OPT_LEAD_SEED).  Every chain that does not start at the sequence's first scan begins its
+// lead-in from the identity (A-LOAM's initial para_q / para_t) and needs `lead` pairs to forget it.  After the FIRST step of the main pass every chain
+// holds an estimate of the vehicle's increment at its own start -- 256 samples of a motion that changes slowly along the sequence.  A chain's sample can be
+// an outlier (clutter: a first pair from the identity that settled on wrong correspondences); its neighbours', 1.8 s away, then describe its motion
+// better than it does itself.  k_lead_seed_median replaces the state of every seeded chain by the component-wise median of the samples of chains
+// c - 1, c, c + 1 (quaternion signs aligned to w >= 0, re-normalised): a constant-velocity prior that costs no step.  Only lead-in states are touched
+// (a chain whose first step is an owned pair keeps its state: its increment is a result); the boundary validation stays the arbiter of every result.
+// Two launches: medians into ws (unused until a chain's last lead-in pair), then ws -> state.
+__device__ __forceinline__ double median3(double a, double b, double c) { return fmax(fmin(a, b), fmin(fmax(a, b), c)); }
+__device__ __forceinline__ bool chain_seeded(const OdomView &o, int c)
+{
+    int s, e;
+    chain_bounds(o.first, o.n_scans, o.n_chains, c, s, e);
+    const int begin = max(s - o.lead, 0);
+    return begin + 1 < s - 1;        // its first step is a lead-in pair and not its last one (whose result the boundary check reads from ws)
+}
+__global__ void k_lead_seed_median(OdomView o)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= o.n_chains || !chain_seeded(o, c)) return;
+    const int c0 = min(max(c - 1, 0), max(o.n_chains - 3, 0));
+    double v[3][7];
+    for (int j = 0; j < 3; j++) {
+        const double *st = o.state + (size_t)min(c0 + j, o.n_chains - 1) * 8;
+        const double sg = st[3] < 0.0 ? -1.0 : 1.0;
+        for (int i = 0; i < 4; i++) v[j][i] = sg * st[i];
+        for (int i = 4; i < 7; i++) v[j][i] = st[i];
+    }
+    double m[7], nn = 0.0;
+    for (int i = 0; i < 7; i++) m[i] = median3(v[0][i], v[1][i], v[2][i]);
+    for (int i = 0; i < 4; i++) nn += m[i] * m[i];
+    nn = sqrt(nn);
+    const bool ok = nn > 0.5 && nn == nn;
+    for (int i = 0; i < 4; i++) o.ws[c * 8 + i] = ok ? m[i] / nn : o.state[c * 8 + i];
+    for (int i = 4; i < 7; i++) o.ws[c * 8 + i] = ok && m[i] == m[i] ? m[i] : o.state[c * 8 + i];
+}
+__global__ void k_lead_seed_apply(OdomView o)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= o.n_chains || !chain_seeded(o, c)) return;
+    for (int i = 0; i < 7; i++) o.state[c * 8 + i] = o.ws[c * 8 + i];
+}
+
 // poses[k - first] = incr[first] (+) incr[first+1] (+) ... (+) incr[k]  (t_w += q_w * t ; q_w = q_w * q).
 // incr[0] is the identity, so first = 0 gives poses relative to scan 0; for first > 0 the result is relative to scan
 // first-1 (the previous rank's last scan).  One wave: every lane composes a contiguous segment, an inclusive wave scan

@@ -229,3 +229,25 @@ def test_cluster_that_gives_up_is_solved_again_with_one_workgroup(tmp_path):
         for key in ("p", "e", "d", "sm", "p2", "e2", "d2", "sm2"):
             assert out[name][key].tobytes() == out["k1"][key].tobytes(), "%s: %s differs from the one-workgroup solve" % (name, key)
     assert (out["k1"]["sm"][:, 3] <= 1).all()
+
+
+def test_clusters_beyond_the_first_eight_windows(gpu_ctx):
+    """Round 6 regression: with several workgroups per window, block index != window index.  The LASERFactor chain and the extrinsic prior read their
+    constants by blockIdx.x, which happened to equal the window for the leaders of windows 0..7 -- every cluster test of round 5 used at most seven
+    windows -- and was another window's (or past the array's end) from window 8 on: batches of 9..64 windows (K >= 2) solved a different problem than
+    K = 1.  Found by EstimatorBatch's per-stream byte comparison at 48 and 64 streams.  24 different windows, K = 1 / 2 / 4 and the default (4): same bytes."""
+    base = [K.make_window(70 + s) for s in range(6)]
+    windows = [base[(k * 5 + k // 6) % 6] for k in range(24)]          # neighbours in the batch are different windows
+    got = {}
+    try:
+        for k in (1, 2, 4):
+            gpu_ctx.set_option(gpu_ctx.OPT_BA_CLUSTER, k)
+            _, got[k] = _solve_gpu(gpu_ctx, windows)
+    finally:
+        gpu_ctx.set_option(gpu_ctx.OPT_BA_CLUSTER, 0)
+    _, got[0] = _solve_gpu(gpu_ctx, windows)
+    for k in (2, 4, 0):
+        for a, c in zip(got[1], got[k]):
+            assert a.tobytes() == c.tobytes(), "K = %d differs from K = 1 on a batch of 24 windows" % k
+    # the windows really differ from one another (a block reading its neighbour's constants would show)
+    assert len({got[1][0][k].tobytes() for k in range(24)}) == 6
