@@ -106,6 +106,9 @@ def bench_ba_seq_streams(args):
         wall = time.perf_counter() - t0
         if out.returncode != 0:
             raise RuntimeError("estimator_seq streams=%d failed: %s" % (N, out.stderr[-1000:]))
+        for ln in out.stderr.splitlines():          # LMONO_HOST_TIMING=1: the lock-step frame's phase clocks
+            if ln.startswith("BATCHTIM"):
+                print(mode, ln, file=sys.stderr)
         lines = out.stdout.splitlines()
         tim = [ln for ln in lines if ln.startswith("TIM")][0].split()
         flp = [ln for ln in lines if ln.startswith("FLP")][0].split()

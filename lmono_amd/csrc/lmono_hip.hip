@@ -1246,31 +1246,42 @@ static int ba_fill(lmono_ctx *c, lmono_ba_batch *b, const lmono_ba_desc *d)
     std::vector<int> seg_off((size_t)W + 1, 0), pair_seg, n_multi((size_t)W, 0);
     std::vector<int> slot_obs;                      // the observation (host order) behind every slot: its scratch record is indexed by observation,
                                                     // so a feature's records are contiguous for the per-feature sums of k_ba_solve
+    slot_info.reserve((size_t)TO); slot_obs.reserve((size_t)TO); slot_pts.reserve((size_t)TO * 4); seg_tab.reserve((size_t)TO / 8 + (size_t)W * 16);
+    pair_ij.reserve((size_t)W * 64); pair_slot.reserve((size_t)W * 65); pair_seg.reserve((size_t)W * 65);
     for (int w = 0; w < W; w++) {
         pair_off[w] = (int)pair_ij.size(); pobs_off[w] = (int)slot_info.size(); seg_off[w] = (int)seg_tab.size();
         const int f0 = d->feat_off[w], f1 = d->feat_off[w + 1];
         for (int f = f0; f < f1; f++) if (fo[f + 1] > fo[f]) anchor[f] = d->obs_i[fo[f]];
         if (d->flags[4 * w + 3]) {   // use_mono == 0: the projection factors are not part of the problem
-            std::vector<std::vector<int>> by_pair((size_t)kBaMaxPoses * kBaMaxPoses);
-            for (int o = d->obs_off[w]; o < d->obs_off[w + 1]; o++) by_pair[(size_t)d->obs_i[o] * kBaMaxPoses + d->obs_j[o]].push_back(o);
-            std::vector<int> order;
-            for (int key = 0; key < kBaMaxPoses * kBaMaxPoses; key++) if (!by_pair[(size_t)key].empty()) order.push_back(key);
-            std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return by_pair[(size_t)x].size() > by_pair[(size_t)y].size(); });
-            int local = 0;
-            for (int key : order) {
-                const std::vector<int> &v = by_pair[(size_t)key];
+            // counting sort of the window's observations by frame pair (ascending observation index inside a pair), pairs in descending size (stable: ties
+            // by ascending key) -- no per-window allocations: a lock-step batch of Estimators fills hundreds of windows per frame
+            constexpr int kKeys = kBaMaxPoses * kBaMaxPoses;
+            int cnt[kKeys], base[kKeys], order[kKeys], local_of[kKeys], n_keys = 0;
+            for (int key = 0; key < kKeys; key++) cnt[key] = 0;
+            const int o0w = d->obs_off[w], o1w = d->obs_off[w + 1];
+            for (int o = o0w; o < o1w; o++) cnt[d->obs_i[o] * kBaMaxPoses + d->obs_j[o]]++;
+            for (int key = 0; key < kKeys; key++) if (cnt[key] > 0) order[n_keys++] = key;
+            std::stable_sort(order, order + n_keys, [&](int x, int y) { return cnt[x] > cnt[y]; });
+            const size_t slot0 = slot_info.size();
+            int run = 0;
+            for (int local = 0; local < n_keys; local++) {
+                const int key = order[local];
+                local_of[key] = local; base[key] = run;
                 pair_ij.push_back((key / kBaMaxPoses) | ((key % kBaMaxPoses) << 8));
-                pair_slot.push_back((int)slot_info.size() - pobs_off[w]);
+                pair_slot.push_back(run);
                 pair_seg.push_back((int)seg_tab.size() - seg_off[w]);
-                const int nseg = ((int)v.size() + kBaSeg - 1) / kBaSeg;
+                const int nseg = (cnt[key] + kBaSeg - 1) / kBaSeg;
                 for (int sidx = 0; sidx < nseg; sidx++) seg_tab.push_back((unsigned short)(local | (sidx << 7)));
                 if (nseg > 1) n_multi[w]++;
-                for (int o : v) {
-                    slot_obs.push_back(o);
-                    slot_info.push_back(d->obs_feat[o] | (local << 16));
-                    for (int k = 0; k < 4; k++) slot_pts.push_back(d->obs_pts[(size_t)o * 4 + k]);
-                }
-                local++;
+                run += cnt[key];
+            }
+            slot_obs.resize(slot0 + (size_t)run); slot_info.resize(slot0 + (size_t)run); slot_pts.resize((slot0 + (size_t)run) * 4);
+            for (int o = o0w; o < o1w; o++) {
+                const int key = d->obs_i[o] * kBaMaxPoses + d->obs_j[o];
+                const size_t sl = slot0 + (size_t)base[key]++;
+                slot_obs[sl] = o;
+                slot_info[sl] = d->obs_feat[o] | (local_of[key] << 16);
+                memcpy(&slot_pts[sl * 4], &d->obs_pts[(size_t)o * 4], 4 * sizeof(double));
             }
         }
         pair_slot.push_back((int)slot_info.size() - pobs_off[w]);   // n_pairs + 1 entries per window

@@ -11,6 +11,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <unordered_map>
+#include <iterator>
 
 namespace lmono_host {
 
@@ -178,15 +180,22 @@ bool FeatureManager::featureCheck(int frame_count, const Image &image, double)
     double parallax_sum = 0;
     int parallax_num = 0;
     last_track_num = 0; long_track_num = 0; new_feature_num = 0;
+    // the reference looks every observation up with std::find_if over the list (:330-333: first match in list order); an index of the ids -- first
+    // occurrence wins, entries appended as the tracks are -- finds the same element without the O(tracks) walk per observation
+    std::unordered_map<int, std::list<FeaturePerId>::iterator> index;
+    index.reserve(feature.size() * 2 + image.size());
+    for (auto it = feature.begin(); it != feature.end(); ++it) index.emplace(it->feature_id, it);
     for (const auto &id_pts : image) {
         FeaturePerFrame f_per_fra;
         f_per_fra.pt[0] = id_pts.second[0]; f_per_fra.pt[1] = id_pts.second[1]; f_per_fra.uv[0] = id_pts.second[2]; f_per_fra.uv[1] = id_pts.second[3];
         const int feature_id = id_pts.first;
-        auto it = std::find_if(feature.begin(), feature.end(), [feature_id](const FeaturePerId &f) { return f.feature_id == feature_id; });
+        const auto found = index.find(feature_id);
+        auto it = found == index.end() ? feature.end() : found->second;
         if (it == feature.end()) {
             FeaturePerId f; f.feature_id = feature_id; f.start_frame = frame_count;
             f.feature_per_frame.push_back(f_per_fra);
             feature.push_back(f);
+            index.emplace(feature_id, std::prev(feature.end()));
             new_feature_num++;
         } else {
             it->feature_per_frame.push_back(f_per_fra);
@@ -727,6 +736,40 @@ private:
     std::exception_ptr err_;
 };
 
+// LMONO_HOST_TIMING=1: wall time of the lock-step frame's phases (INITED frames), printed by ~EstimatorBatch
+namespace {
+struct BatchClock {
+    static constexpr int kN = 12;
+    double ms[kN] = { 0 };
+    long frames = 0;
+    const bool on = std::getenv("LMONO_HOST_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t0;
+    void start() { if (on) t0 = std::chrono::steady_clock::now(); }
+    void lap(int k) { if (on) { const auto t1 = std::chrono::steady_clock::now(); ms[k] += std::chrono::duration<double, std::milli>(t1 - t0).count(); t0 = t1; } }
+    void print(int n_streams) const
+    {
+        if (!on || frames == 0) return;
+        static const char *name[kN] = { "pre+pack tracks", "-", "triangulate call", "apply+pack solve", "concat solve", "ba update", "solve+read", "unpack+pack margin/tracks", "margin submit", "outliers call+apply+slide begin", "shift call+finish+rows", "-" };
+        std::fprintf(stderr, "BATCHTIM %d streams, %ld lock-step frames:", n_streams, frames);
+        for (int k = 0; k < kN; k++) std::fprintf(stderr, " %s %.3f", name[k], ms[k] / frames);
+        std::fprintf(stderr, " (ms per lock-step frame)\n");
+    }
+} g_bclock;
+}
+
+// The lock-step frame is a chain of [per-stream host pass on the pool] -> [one batched C-ABI call]; what a call needs is packed by the pass in front of it
+// and what it returns is applied by the pass behind it, so an INITED frame is five passes and four calls (plus the marginalisation, which is handed
+// to its worker).  The packs and the concatenated call arrays live here from frame to frame (their vectors keep their capacity).
+struct EstimatorBatch::Work {
+    std::vector<TrackPack> tp;
+    std::vector<SolvePack> sp;
+    std::vector<ShiftPack> shp;
+    std::vector<char> due;
+    // concatenated arrays of the calls
+    std::vector<int> foff, ooff, start, off, flag, flags, obs_feat, obs_i, obs_j, shoff;
+    std::vector<double> R, P, tlc, pts, depth, score, poses, ex, invd, obs_pts, laser, prior_T, summary, frames, shpt, shdep, shout;
+};
+
 EstimatorBatch::EstimatorBatch(HipContext &hip, const Params &p, int n_streams, int host_threads) : hip_(hip), p_(p)
 {
     if (n_streams < 1) throw std::invalid_argument("EstimatorBatch: n_streams must be >= 1");
@@ -735,12 +778,14 @@ EstimatorBatch::EstimatorBatch(HipContext &hip, const Params &p, int n_streams, 
     if (nt <= 0) { if (const char *e = std::getenv("LMONO_HOST_THREADS")) nt = std::atoi(e); }
     if (nt <= 0) nt = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
     pool_.reset(new HostPool(std::min(nt, n_streams)));
+    work_.reset(new Work());
 }
 EstimatorBatch::~EstimatorBatch()
 {
     try { marginWait(); } catch (...) {}
     margin_worker_.reset();
     if (ba_batch_) lmono_ba_batch_destroy(ba_batch_);
+    g_bclock.print(size());
 }
 void EstimatorBatch::marginWait() { if (margin_worker_) margin_worker_->wait(); }
 void EstimatorBatch::setAsyncMargin(bool on)
@@ -751,124 +796,114 @@ void EstimatorBatch::setAsyncMargin(bool on)
 }
 
 namespace {
-// exclusive prefix of per-stream sizes
-template <typename F> std::vector<int> offsets(int n, F size_of)
-{
-    std::vector<int> off((size_t)n + 1, 0);
-    for (int s = 0; s < n; s++) off[(size_t)s + 1] = off[(size_t)s] + size_of(s);
-    return off;
-}
+template <typename T> void fit(std::vector<T> &v, size_t n) { if (v.size() < n) v.resize(n); }
 }
 
-// FeatureManager::triangulate of every stream: one lmono_triangulate over N windows
-void EstimatorBatch::triangulate()
+// the tracks of every stream (w.tp, packed by the pass before) as one set of windows: w.foff / w.ooff and the concatenated arrays
+void EstimatorBatch::concatTracks()
 {
+    Work &w = *work_;
     const int N = size();
-    std::vector<TrackPack> tp((size_t)N);
-    pool_->run(N, [&](int s) { est_[(size_t)s]->packTracks(tp[(size_t)s]); });
-    const std::vector<int> foff = offsets(N, [&](int s) { return (int)tp[(size_t)s].start.size(); });
-    const std::vector<int> ooff = offsets(N, [&](int s) { return (int)tp[(size_t)s].pts.size() / 2; });
-    const int TF = foff[(size_t)N], TO = ooff[(size_t)N];
-    if (TF == 0) return;
-    std::vector<double> R((size_t)N * 99), P((size_t)N * 33), tlc((size_t)N * 16), pts((size_t)TO * 2 + 2), depth((size_t)TF);
-    std::vector<int> start((size_t)TF), off((size_t)TF + 1), flag((size_t)TF, 0);
+    w.foff.assign((size_t)N + 1, 0); w.ooff.assign((size_t)N + 1, 0);
+    for (int s = 0; s < N; s++) { w.foff[(size_t)s + 1] = w.foff[(size_t)s] + (int)w.tp[(size_t)s].start.size(); w.ooff[(size_t)s + 1] = w.ooff[(size_t)s] + (int)w.tp[(size_t)s].pts.size() / 2; }
+    const int TF = w.foff[(size_t)N], TO = w.ooff[(size_t)N];
+    fit(w.R, (size_t)N * 99); fit(w.P, (size_t)N * 33); fit(w.tlc, (size_t)N * 16); fit(w.pts, (size_t)TO * 2 + 2); fit(w.depth, (size_t)TF + 1);
+    fit(w.start, (size_t)TF + 1); fit(w.off, (size_t)TF + 1); fit(w.flag, (size_t)TF + 1); fit(w.score, (size_t)TF + 1);
     pool_->run(N, [&](int s) {
-        const TrackPack &t = tp[(size_t)s];
-        std::memcpy(&R[(size_t)s * 99], t.R, sizeof(t.R)); std::memcpy(&P[(size_t)s * 33], t.P, sizeof(t.P)); std::memcpy(&tlc[(size_t)s * 16], est_[(size_t)s]->TLC, 128);
-        const int f0 = foff[(size_t)s], o0 = ooff[(size_t)s];
-        for (size_t k = 0; k < t.start.size(); k++) { start[(size_t)f0 + k] = t.start[k]; off[(size_t)f0 + k] = o0 + t.off[k]; depth[(size_t)f0 + k] = t.depth[k]; }
-        if (!t.pts.empty()) std::memcpy(&pts[(size_t)o0 * 2], t.pts.data(), t.pts.size() * sizeof(double));
+        const TrackPack &t = w.tp[(size_t)s];
+        std::memcpy(&w.R[(size_t)s * 99], t.R, sizeof(t.R)); std::memcpy(&w.P[(size_t)s * 33], t.P, sizeof(t.P)); std::memcpy(&w.tlc[(size_t)s * 16], est_[(size_t)s]->TLC, 128);
+        const int f0 = w.foff[(size_t)s], o0 = w.ooff[(size_t)s];
+        for (size_t k = 0; k < t.start.size(); k++) { w.start[(size_t)f0 + k] = t.start[k]; w.off[(size_t)f0 + k] = o0 + t.off[k]; w.depth[(size_t)f0 + k] = t.depth[k]; }
+        if (!t.pts.empty()) std::memcpy(&w.pts[(size_t)o0 * 2], t.pts.data(), t.pts.size() * sizeof(double));
     });
-    off[(size_t)TF] = TO;
-    hip_.check(lmono_triangulate(hip_.get(), N, foff.data(), R.data(), P.data(), tlc.data(), start.data(), off.data(), pts.data(), depth.data(), flag.data(),
+    w.off[(size_t)TF] = TO;
+}
+// FeatureManager::triangulate of every stream: one lmono_triangulate over N windows (results: w.depth, w.flag by w.foff)
+void EstimatorBatch::callTriangulate()
+{
+    Work &w = *work_;
+    concatTracks();
+    const int N = size();
+    if (w.foff[(size_t)N] == 0) return;
+    std::fill(w.flag.begin(), w.flag.begin() + w.foff[(size_t)N], 0);
+    hip_.check(lmono_triangulate(hip_.get(), N, w.foff.data(), w.R.data(), w.P.data(), w.tlc.data(), w.start.data(), w.off.data(), w.pts.data(), w.depth.data(), w.flag.data(),
                                  p_.TRACK_CNT, WINDOW_SIZE, p_.FACTOR_WEIGHT, 50), "lmono_triangulate");
-    pool_->run(N, [&](int s) {
-        if (foff[(size_t)s + 1] > foff[(size_t)s]) est_[(size_t)s]->feature_manager.triangulateApply(&depth[(size_t)foff[(size_t)s]], &flag[(size_t)foff[(size_t)s]]);
-    });
 }
-
-// Estimator::outliersRejection + removeOutlier of every stream: one lmono_outlier_scores over N windows
-void EstimatorBatch::outliersRejection(double error)
+void EstimatorBatch::applyTriangulate(int s)
 {
-    const int N = size();
-    std::vector<TrackPack> tp((size_t)N);
-    pool_->run(N, [&](int s) { est_[(size_t)s]->packTracks(tp[(size_t)s]); });
-    const std::vector<int> foff = offsets(N, [&](int s) { return (int)tp[(size_t)s].start.size(); });
-    const std::vector<int> ooff = offsets(N, [&](int s) { return (int)tp[(size_t)s].pts.size() / 2; });
-    const int TF = foff[(size_t)N], TO = ooff[(size_t)N];
-    if (TF == 0) return;
-    std::vector<double> R((size_t)N * 99), P((size_t)N * 33), tlc((size_t)N * 16), pts((size_t)TO * 2 + 2), depth((size_t)TF), score((size_t)TF);
-    std::vector<int> start((size_t)TF), off((size_t)TF + 1);
-    pool_->run(N, [&](int s) {
-        const TrackPack &t = tp[(size_t)s];
-        std::memcpy(&R[(size_t)s * 99], t.R, sizeof(t.R)); std::memcpy(&P[(size_t)s * 33], t.P, sizeof(t.P)); std::memcpy(&tlc[(size_t)s * 16], est_[(size_t)s]->TLC, 128);
-        const int f0 = foff[(size_t)s], o0 = ooff[(size_t)s];
-        for (size_t k = 0; k < t.start.size(); k++) { start[(size_t)f0 + k] = t.start[k]; off[(size_t)f0 + k] = o0 + t.off[k]; depth[(size_t)f0 + k] = t.depth[k]; }
-        if (!t.pts.empty()) std::memcpy(&pts[(size_t)o0 * 2], t.pts.data(), t.pts.size() * sizeof(double));
-    });
-    off[(size_t)TF] = TO;
-    hip_.check(lmono_outlier_scores(hip_.get(), N, foff.data(), R.data(), P.data(), tlc.data(), start.data(), off.data(), pts.data(), depth.data(),
-                                    p_.TRACK_CNT, p_.FACTOR_WEIGHT, score.data()), "lmono_outlier_scores");
-    pool_->run(N, [&](int s) {
-        if (foff[(size_t)s + 1] == foff[(size_t)s]) return;
-        std::set<int> removeIndex;
-        est_[(size_t)s]->applyOutlierScores(&score[(size_t)foff[(size_t)s]], error, removeIndex);
-        est_[(size_t)s]->feature_manager.removeOutlier(removeIndex);
-    });
+    Work &w = *work_;
+    if (w.foff[(size_t)s + 1] > w.foff[(size_t)s]) est_[(size_t)s]->feature_manager.triangulateApply(&w.depth[(size_t)w.foff[(size_t)s]], &w.flag[(size_t)w.foff[(size_t)s]]);
 }
-
-// Estimator::optimization of every stream: N windows in one lmono_ba_batch_update + lmono_ba_solve + lmono_ba_batch_read, then margin()
-void EstimatorBatch::optimization()
+// Estimator::outliersRejection's statistic for every stream: one lmono_outlier_scores over N windows (results: w.score by w.foff)
+void EstimatorBatch::callOutliers()
 {
+    Work &w = *work_;
+    concatTracks();
     const int N = size();
-    std::vector<SolvePack> sp((size_t)N);
-    pool_->run(N, [&](int s) { est_[(size_t)s]->packSolve(sp[(size_t)s]); });
-    const std::vector<int> foff = offsets(N, [&](int s) { return sp[(size_t)s].F; });
-    const std::vector<int> ooff = offsets(N, [&](int s) { return (int)sp[(size_t)s].obs_feat.size(); });
-    const int TF = foff[(size_t)N], TO = ooff[(size_t)N];
-    std::vector<int> flags((size_t)N * 4), obs_feat((size_t)TO + 1), obs_i((size_t)TO + 1), obs_j((size_t)TO + 1);
-    std::vector<double> poses((size_t)N * 77), ex((size_t)N * 7), invd((size_t)TF + 1), obs_pts((size_t)TO * 4 + 4), laser((size_t)N * 240), prior_T((size_t)N * 16);
+    if (w.foff[(size_t)N] == 0) return;
+    hip_.check(lmono_outlier_scores(hip_.get(), N, w.foff.data(), w.R.data(), w.P.data(), w.tlc.data(), w.start.data(), w.off.data(), w.pts.data(), w.depth.data(),
+                                    p_.TRACK_CNT, p_.FACTOR_WEIGHT, w.score.data()), "lmono_outlier_scores");
+}
+void EstimatorBatch::applyOutliers(int s, double error)
+{
+    Work &w = *work_;
+    if (w.foff[(size_t)s + 1] == w.foff[(size_t)s]) return;
+    std::set<int> removeIndex;
+    est_[(size_t)s]->applyOutlierScores(&w.score[(size_t)w.foff[(size_t)s]], error, removeIndex);
+    est_[(size_t)s]->feature_manager.removeOutlier(removeIndex);
+}
+// Estimator::optimization's solve for every stream (w.sp, packed by the pass before): N windows in one lmono_ba_batch_update + lmono_ba_solve + lmono_ba_batch_read
+void EstimatorBatch::callSolve()
+{
+    Work &w = *work_;
+    const int N = size();
+    w.foff.assign((size_t)N + 1, 0); w.ooff.assign((size_t)N + 1, 0);
+    for (int s = 0; s < N; s++) { w.foff[(size_t)s + 1] = w.foff[(size_t)s] + w.sp[(size_t)s].F; w.ooff[(size_t)s + 1] = w.ooff[(size_t)s] + (int)w.sp[(size_t)s].obs_feat.size(); }
+    const int TF = w.foff[(size_t)N], TO = w.ooff[(size_t)N];
+    fit(w.flags, (size_t)N * 4); fit(w.obs_feat, (size_t)TO + 1); fit(w.obs_i, (size_t)TO + 1); fit(w.obs_j, (size_t)TO + 1);
+    fit(w.poses, (size_t)N * 77); fit(w.ex, (size_t)N * 7); fit(w.invd, (size_t)TF + 1); fit(w.obs_pts, (size_t)TO * 4 + 4); fit(w.laser, (size_t)N * 240); fit(w.prior_T, (size_t)N * 16);
+    fit(w.summary, (size_t)N * 6);
     pool_->run(N, [&](int s) {
-        const SolvePack &q = sp[(size_t)s];
+        const SolvePack &q = w.sp[(size_t)s];
         Estimator &e = *est_[(size_t)s];
-        std::memcpy(&flags[(size_t)s * 4], q.flags, sizeof(q.flags));
-        std::memcpy(&poses[(size_t)s * 77], q.poses, sizeof(q.poses)); std::memcpy(&ex[(size_t)s * 7], e.para_ex[0], 56);
-        std::memcpy(&laser[(size_t)s * 240], q.laser, sizeof(q.laser)); std::memcpy(&prior_T[(size_t)s * 16], e.TLC, 128);
-        if (q.F > 0) std::memcpy(&invd[(size_t)foff[(size_t)s]], e.para_depth_inv.data(), (size_t)q.F * sizeof(double));
-        const size_t o0 = (size_t)ooff[(size_t)s], no = q.obs_feat.size();
+        std::memcpy(&w.flags[(size_t)s * 4], q.flags, sizeof(q.flags));
+        std::memcpy(&w.poses[(size_t)s * 77], q.poses, sizeof(q.poses)); std::memcpy(&w.ex[(size_t)s * 7], e.para_ex[0], 56);
+        std::memcpy(&w.laser[(size_t)s * 240], q.laser, sizeof(q.laser)); std::memcpy(&w.prior_T[(size_t)s * 16], e.TLC, 128);
+        if (q.F > 0) std::memcpy(&w.invd[(size_t)w.foff[(size_t)s]], e.para_depth_inv.data(), (size_t)q.F * sizeof(double));
+        const size_t o0 = (size_t)w.ooff[(size_t)s], no = q.obs_feat.size();
         if (no) {
-            std::memcpy(&obs_feat[o0], q.obs_feat.data(), no * sizeof(int)); std::memcpy(&obs_i[o0], q.obs_i.data(), no * sizeof(int));
-            std::memcpy(&obs_j[o0], q.obs_j.data(), no * sizeof(int)); std::memcpy(&obs_pts[o0 * 4], q.obs_pts.data(), no * 4 * sizeof(double));
+            std::memcpy(&w.obs_feat[o0], q.obs_feat.data(), no * sizeof(int)); std::memcpy(&w.obs_i[o0], q.obs_i.data(), no * sizeof(int));
+            std::memcpy(&w.obs_j[o0], q.obs_j.data(), no * sizeof(int)); std::memcpy(&w.obs_pts[o0 * 4], q.obs_pts.data(), no * 4 * sizeof(double));
         }
     });
+    g_bclock.lap(4);
     double laser_info[36], mono_info[4], prior_w[2];
     solve_infos(p_, laser_info, mono_info, prior_w);
     lmono_ba_desc d{};
-    d.n_windows = N; d.feat_off = foff.data(); d.obs_off = ooff.data(); d.flags = flags.data(); d.poses = poses.data(); d.ex = ex.data();
-    d.inv_depth = invd.data(); d.obs_feat = obs_feat.data(); d.obs_i = obs_i.data(); d.obs_j = obs_j.data(); d.obs_pts = obs_pts.data();
-    d.laser_consts = laser.data(); d.prior_T = prior_T.data(); d.laser_info = laser_info; d.mono_info = mono_info; d.prior_w = prior_w;
+    d.n_windows = N; d.feat_off = w.foff.data(); d.obs_off = w.ooff.data(); d.flags = w.flags.data(); d.poses = w.poses.data(); d.ex = w.ex.data();
+    d.inv_depth = w.invd.data(); d.obs_feat = w.obs_feat.data(); d.obs_i = w.obs_i.data(); d.obs_j = w.obs_j.data(); d.obs_pts = w.obs_pts.data();
+    d.laser_consts = w.laser.data(); d.prior_T = w.prior_T.data(); d.laser_info = laser_info; d.mono_info = mono_info; d.prior_w = prior_w;
     if (!ba_batch_) {
         ba_batch_ = lmono_ba_batch_create(hip_.get(), &d);
         if (!ba_batch_) throw std::runtime_error(std::string("lmono_ba_batch_create: ") + lmono_last_error(hip_.get()));
     } else
         hip_.check(lmono_ba_batch_update(hip_.get(), ba_batch_, &d), "lmono_ba_batch_update");
+    g_bclock.lap(5);
     hip_.check(lmono_ba_solve(hip_.get(), ba_batch_, p_.NUM_ITERATIONS), "lmono_ba_solve");
-    std::vector<double> summary((size_t)N * 6);
-    hip_.check(lmono_ba_batch_read(hip_.get(), ba_batch_, poses.data(), ex.data(), invd.data(), summary.data()), "lmono_ba_batch_read");
-    pool_->run(N, [&](int s) {
-        est_[(size_t)s]->unpackSolve(sp[(size_t)s], &poses[(size_t)s * 77], &ex[(size_t)s * 7], &invd[(size_t)foff[(size_t)s]], &summary[(size_t)s * 6]);
-    });
-    if (est_[0]->frame_count < WINDOW_SIZE) return;
-    if (p_.ESTIMATE_LASER) margin();
+    hip_.check(lmono_ba_batch_read(hip_.get(), ba_batch_, w.poses.data(), w.ex.data(), w.invd.data(), w.summary.data()), "lmono_ba_batch_read");
+    g_bclock.lap(6);
+}
+void EstimatorBatch::applySolve(int s)
+{
+    Work &w = *work_;
+    est_[(size_t)s]->unpackSolve(w.sp[(size_t)s], &w.poses[(size_t)s * 77], &w.ex[(size_t)s * 7], &w.invd[(size_t)w.foff[(size_t)s]], &w.summary[(size_t)s * 6]);
 }
 
-// Estimator::margin of every stream: the MARGIN_OLD streams in one lmono_marginalize, the MARGIN_SECOND_NEW ones in one lmono_marg_second_new
-void EstimatorBatch::margin()
+// Estimator::margin of every stream (packs filled by the pass before): the MARGIN_OLD streams in one lmono_marginalize, the MARGIN_SECOND_NEW ones in one
+// lmono_marg_second_new -- on the marginalisation context and its worker thread when overlapped (the concatenation happens there too)
+void EstimatorBatch::submitMargin(std::shared_ptr<std::vector<MargPack>> packs)
 {
-    marginWait();
     const int N = size();
-    auto packs = std::make_shared<std::vector<MargPack>>((size_t)N);
-    pool_->run(N, [&](int s) { est_[(size_t)s]->packMargin((*packs)[(size_t)s]); });
     HipContext *h = async_margin_ ? margin_hip_.get() : &hip_;
     auto job = [this, h, packs, N]() {
         std::vector<int> olds, seconds;
@@ -923,64 +958,95 @@ void EstimatorBatch::margin()
     margin_worker_->submit(std::move(job));
 }
 
-// Estimator::slideWindow of every stream: the depth shifts of the MARGIN_OLD streams in one lmono_shift_depth_batch
-void EstimatorBatch::slideWindow()
+// the depth shifts of every stream whose slide is removeBackShiftDepth (w.due / w.shp, filled by the pass before): one lmono_shift_depth_batch
+void EstimatorBatch::callShift()
 {
+    Work &w = *work_;
     const int N = size();
-    std::vector<ShiftPack> sp((size_t)N);
-    std::vector<char> due((size_t)N, 0);
-    pool_->run(N, [&](int s) { due[(size_t)s] = est_[(size_t)s]->slideWindowBegin(sp[(size_t)s]) ? 1 : 0; });
-    const std::vector<int> off = offsets(N, [&](int s) { return due[(size_t)s] ? (int)sp[(size_t)s].dep.size() : 0; });
-    const int T = off[(size_t)N];
-    std::vector<double> frames((size_t)N * 40, 0.0), pt((size_t)T * 2 + 2), dep((size_t)T + 1), out((size_t)T + 1);
+    w.shoff.assign((size_t)N + 1, 0);
+    for (int s = 0; s < N; s++) w.shoff[(size_t)s + 1] = w.shoff[(size_t)s] + (w.due[(size_t)s] ? (int)w.shp[(size_t)s].dep.size() : 0);
+    const int T = w.shoff[(size_t)N];
+    fit(w.frames, (size_t)N * 40); fit(w.shpt, (size_t)T * 2 + 2); fit(w.shdep, (size_t)T + 1); fit(w.shout, (size_t)T + 1);
     for (int s = 0; s < N; s++) {
-        if (!due[(size_t)s]) continue;
-        std::memcpy(&frames[(size_t)s * 40], sp[(size_t)s].frames, sizeof(sp[(size_t)s].frames));
-        const size_t n = sp[(size_t)s].dep.size();
-        if (n) { std::memcpy(&pt[(size_t)off[(size_t)s] * 2], sp[(size_t)s].pt.data(), n * 2 * sizeof(double)); std::memcpy(&dep[(size_t)off[(size_t)s]], sp[(size_t)s].dep.data(), n * sizeof(double)); }
+        if (!w.due[(size_t)s]) { std::memset(&w.frames[(size_t)s * 40], 0, 40 * sizeof(double)); continue; }
+        std::memcpy(&w.frames[(size_t)s * 40], w.shp[(size_t)s].frames, sizeof(w.shp[(size_t)s].frames));
+        const size_t n = w.shp[(size_t)s].dep.size();
+        if (n) { std::memcpy(&w.shpt[(size_t)w.shoff[(size_t)s] * 2], w.shp[(size_t)s].pt.data(), n * 2 * sizeof(double)); std::memcpy(&w.shdep[(size_t)w.shoff[(size_t)s]], w.shp[(size_t)s].dep.data(), n * sizeof(double)); }
     }
-    if (T > 0) hip_.check(lmono_shift_depth_batch(hip_.get(), N, frames.data(), off.data(), pt.data(), dep.data(), out.data()), "lmono_shift_depth_batch");
-    pool_->run(N, [&](int s) { if (due[(size_t)s]) est_[(size_t)s]->slideWindowFinish(&out[(size_t)off[(size_t)s]]); });
+    if (T > 0) hip_.check(lmono_shift_depth_batch(hip_.get(), N, w.frames.data(), w.shoff.data(), w.shpt.data(), w.shdep.data(), w.shout.data()), "lmono_shift_depth_batch");
 }
 
 // Estimator::processImage (Estimator.cc:367-499) for every stream, the numeric steps batched
 void EstimatorBatch::processImage(const double *headers, const FeatureManager::Image *images, const double (*transform_to_init)[16], bool *keyframe)
 {
     const int N = size();
+    Work &w = *work_;
+    if ((int)w.tp.size() != N) { w.tp.resize((size_t)N); w.sp.resize((size_t)N); w.shp.resize((size_t)N); w.due.assign((size_t)N, 0); }
     std::vector<char> kf((size_t)N, 0);
-    pool_->run(N, [&](int s) { bool k = false; est_[(size_t)s]->preFrame(headers[s], images[s], transform_to_init[s], &k); kf[(size_t)s] = k ? 1 : 0; });
-    if (keyframe) for (int s = 0; s < N; s++) keyframe[s] = kf[(size_t)s] != 0;
+    g_bclock.start();
     const Estimator &e0 = *est_[0];
     for (int s = 1; s < N; s++)
         if (est_[(size_t)s]->stage_flag != e0.stage_flag || est_[(size_t)s]->frame_count != e0.frame_count)
             throw std::logic_error("EstimatorBatch: the streams are not at the same frame of their sequences");
+    auto pre = [&](int s) { bool k = false; est_[(size_t)s]->preFrame(headers[s], images[s], transform_to_init[s], &k); kf[(size_t)s] = k ? 1 : 0; };
+    auto margin_and_tracks = [&](std::shared_ptr<std::vector<MargPack>> &packs) {
+        // Estimator::optimization behind the solve: double2Matrix, then margin() (frame_count == WINDOW_SIZE here) -- and the tracks for the outlier scores
+        const bool do_margin = p_.ESTIMATE_LASER != 0;
+        if (do_margin) { marginWait(); packs = std::make_shared<std::vector<MargPack>>((size_t)N); }
+        pool_->run(N, [&](int s) {
+            applySolve(s);
+            if (do_margin) est_[(size_t)s]->packMargin((*packs)[(size_t)s]);
+            est_[(size_t)s]->packTracks(w.tp[(size_t)s]);
+        });
+        g_bclock.lap(7);
+        if (do_margin) submitMargin(packs);
+        g_bclock.lap(8);
+    };
+    auto slide_and_rows = [&](double outlier_error) {
+        callOutliers();
+        pool_->run(N, [&](int s) { applyOutliers(s, outlier_error); w.due[(size_t)s] = est_[(size_t)s]->slideWindowBegin(w.shp[(size_t)s]) ? 1 : 0; });
+        g_bclock.lap(9);
+        callShift();
+        pool_->run(N, [&](int s) { if (w.due[(size_t)s]) est_[(size_t)s]->slideWindowFinish(&w.shout[(size_t)w.shoff[(size_t)s]]); est_[(size_t)s]->pushOdometryRow(); });
+        g_bclock.lap(10);
+    };
+    std::shared_ptr<std::vector<MargPack>> packs;
     if (e0.stage_flag == Estimator::NOT_INITED) {
-        if (e0.frame_count == WINDOW_SIZE) {
-            if (p_.ESTIMATE_LASER != 2) {
-                // runInitialization :986-1012
-                pool_->run(N, [&](int s) { est_[(size_t)s]->initialPoses(); });
-                triangulate();
-                outliersRejection(100.0);
-                optimization();
-                for (auto &e : est_) e->stage_flag = Estimator::INITED;
-                outliersRejection(3);
-                slideWindow();
-            } else slideWindow();
-        }
-        if (est_[0]->frame_count < WINDOW_SIZE)
+        if (e0.frame_count == WINDOW_SIZE && p_.ESTIMATE_LASER != 2) {
+            // runInitialization :986-1012, optimization, outliersRejection(3), slideWindow
+            pool_->run(N, [&](int s) { pre(s); est_[(size_t)s]->initialPoses(); est_[(size_t)s]->packTracks(w.tp[(size_t)s]); });
+            callTriangulate();
+            pool_->run(N, [&](int s) { applyTriangulate(s); est_[(size_t)s]->packTracks(w.tp[(size_t)s]); });
+            callOutliers();
+            pool_->run(N, [&](int s) { applyOutliers(s, 100.0); est_[(size_t)s]->packSolve(w.sp[(size_t)s]); });
+            callSolve();
+            margin_and_tracks(packs);
+            for (auto &e : est_) e->stage_flag = Estimator::INITED;
+            slide_and_rows(3.0);
+        } else {
             pool_->run(N, [&](int s) {
+                pre(s);
                 Estimator &e = *est_[(size_t)s];
-                e.frame_count++;
-                e.Ps[e.frame_count] = e.Ps[e.frame_count - 1]; e.Rs[e.frame_count] = e.Rs[e.frame_count - 1]; e.Header[e.frame_count] = e.Header[e.frame_count - 1];
+                if (e.frame_count == WINDOW_SIZE) e.slideWindow();              // (ESTIMATE_LASER == 2: NOT_INITED slides are list surgery only, removeBack)
+                if (e.frame_count < WINDOW_SIZE) {
+                    e.frame_count++;
+                    e.Ps[e.frame_count] = e.Ps[e.frame_count - 1]; e.Rs[e.frame_count] = e.Rs[e.frame_count - 1]; e.Header[e.frame_count] = e.Header[e.frame_count - 1];
+                }
             });
+        }
     } else {
-        pool_->run(N, [&](int s) { est_[(size_t)s]->loopCorrection(); });
-        triangulate();
-        optimization();
-        outliersRejection(p_.OUTLIER_T);
-        slideWindow();
+        pool_->run(N, [&](int s) { pre(s); est_[(size_t)s]->loopCorrection(); est_[(size_t)s]->packTracks(w.tp[(size_t)s]); });
+        g_bclock.lap(0);
+        callTriangulate();
+        g_bclock.lap(2);
+        pool_->run(N, [&](int s) { applyTriangulate(s); est_[(size_t)s]->packSolve(w.sp[(size_t)s]); });
+        g_bclock.lap(3);
+        callSolve();
+        margin_and_tracks(packs);
+        slide_and_rows(p_.OUTLIER_T);
+        g_bclock.frames++;
     }
-    if (est_[0]->stage_flag == Estimator::INITED) pool_->run(N, [&](int s) { est_[(size_t)s]->pushOdometryRow(); });
+    if (keyframe) for (int s = 0; s < N; s++) keyframe[s] = kf[(size_t)s] != 0;
 }
 
 // ---- A-LOAM nodes ---------------------------------------------------------------------------------------------------

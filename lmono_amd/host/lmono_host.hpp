@@ -239,16 +239,22 @@ public:
     void setAsyncMargin(bool on);          // marginalisation of frame k beside frame k + 1 (second context, own stream, one worker thread), as Estimator::setAsyncMargin
     void marginWait();
 private:
-    void triangulate();
-    void optimization();
-    void margin();
-    void outliersRejection(double error);
-    void slideWindow();
+    struct Work;
+    void concatTracks();
+    void callTriangulate();
+    void applyTriangulate(int s);
+    void callOutliers();
+    void applyOutliers(int s, double error);
+    void callSolve();
+    void applySolve(int s);
+    void submitMargin(std::shared_ptr<std::vector<MargPack>> packs);
+    void callShift();
     HipContext &hip_;
     Params p_;
     std::vector<std::unique_ptr<Estimator>> est_;
     lmono_ba_batch *ba_batch_ = nullptr;
     std::unique_ptr<HostPool> pool_;
+    std::unique_ptr<Work> work_;
     std::unique_ptr<HipContext> margin_hip_;
     std::unique_ptr<MarginWorker> margin_worker_;
     bool async_margin_ = false;
