@@ -102,7 +102,7 @@ def bench_ba_seq_streams(args):
     runs = {}
     for mode in ("sync", "async"):
         t0 = time.perf_counter()
-        out = subprocess.run([exe, files[0], "-", mode, "streams=%d" % N, "digest"] + files[1:], capture_output=True, text=True)
+        out = subprocess.run([exe, files[0], "-", mode, "streams=%d" % N, "groups=%d" % args.seq_groups, "digest"] + files[1:], capture_output=True, text=True)
         wall = time.perf_counter() - t0
         if out.returncode != 0:
             raise RuntimeError("estimator_seq streams=%d failed: %s" % (N, out.stderr[-1000:]))
@@ -134,7 +134,7 @@ def bench_ba_seq_streams(args):
            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": "S2 frame streams, KITTI-05 shape (configs[2]): %d streams x %d frames (%d different stream files), <= 150 tracks / frame, "
                                   "EstimatorBatch: one batched C-ABI call per numeric step" % (N, n, n_files),
-                      "streams": N, "frames": n, "inited_frames_per_stream": r["n_inited"], "ms_per_lockstep_frame": round(r["ms_step"], 3), "wall_s": round(r["wall"], 1),
+                      "streams": N, "groups": args.seq_groups, "frames": n, "inited_frames_per_stream": r["n_inited"], "ms_per_lockstep_frame": round(r["ms_step"], 3), "wall_s": round(r["wall"], 1),
                       "gen_s": round(gen_s, 1), "marginalisation": "overlapped with the next frame (second context, own HIP stream, host thread)",
                       "inline_marginalisation": {"ms_per_lockstep_frame": round(runs["sync"]["ms_step"], 3), "frames_per_s": round(N * 1e3 / runs["sync"]["ms_step"], 1)},
                       "every_stream_equals_its_single_stream_run": bool(same), "files_verified": verified,
@@ -756,6 +756,7 @@ def main():
     ap.add_argument("--windows", type=int, default=1024, help="ba: independent windows per GPU")
     ap.add_argument("--frames-seq", type=int, default=2761, help="ba-seq: frames of the stream (KITTI seq 05 = 2761)")
     ap.add_argument("--streams", type=int, default=64, help="map / colour: independent streams advanced in lock-step")
+    ap.add_argument("--seq-groups", type=int, default=1, help="ba-seq: the streams as this many independent lock-step groups (own context, HIP stream and host thread each)")
     ap.add_argument("--seq-streams", type=int, default=1, help="ba-seq: independent sequences stepped in lock-step by EstimatorBatch (1 = the reference's one sequence)")
     ap.add_argument("--frames", type=int, default=20, help="colour: frames per stream and step")
     ap.add_argument("--keyframes", type=int, default=4541, help="posegraph: keyframes of the graph")

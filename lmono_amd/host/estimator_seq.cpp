@@ -4,18 +4,21 @@
 //
 // Stream file (doubles): n_frames, TLC[16], then per frame: header, L0_Pos[16], n_loop (0/1) [loop_time_stamp, old_T[3],
 // old_Q[4] w x y z, correct_T[3], correct_Q[4] w x y z], n_features, n_features x (id, x_n, y_n, u, v).
-// Usage: estimator_seq <stream.bin> [new_odometry.txt | -] [sync | async] [streams=N [digest] [more stream files ...]]
+// Usage: estimator_seq <stream.bin> [new_odometry.txt | -] [sync | async] [streams=N [groups=G] [digest] [more stream files ...]]
 // "async": marginalisation overlapped with the next frame (Estimator::setAsyncMargin); the PRI line (digest of the last prior) and
 // everything else must come out the same bytes as without it.
 // "streams=N": N independent Estimators stepped in lock-step by EstimatorBatch (one batched C-ABI call per numeric step); stream s replays
 // file s mod (number of files given).  Every stream's lines are printed behind a "STR s" line and are, byte for byte, the lines of the
 // single-stream run of its file (and "DIG s <hash>" = FNV-1a of those lines; "digest": print only the DIG lines -- 256 streams x 2761 frames
 // of text is 70 MB).  The single-stream run prints its own "DIG 0 <hash>" over the same lines.
+// "groups=G": the N streams as G EstimatorBatches of N / G streams, each on its own context (own HIP stream) and host thread: the sequences are
+// independent, so the groups need not wait for each other -- one group's host passes run beside another group's kernels.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 #include "lmono_host.hpp"
 
@@ -107,13 +110,14 @@ int main(int argc, char **argv)
 {
     if (argc < 2) return 2;
     try {
-        int n_streams = 0; bool digest_only = false, async = false;
+        int n_streams = 0, n_groups = 1; bool digest_only = false, async = false;
         std::vector<const char *> files{ argv[1] };
         for (int a = 3; a < argc; a++) {
             const std::string s = argv[a];
             if (s == "async") async = true;
             else if (s == "sync") async = false;
             else if (s.rfind("streams=", 0) == 0) n_streams = std::atoi(s.c_str() + 8);
+            else if (s.rfind("groups=", 0) == 0) n_groups = std::max(1, std::atoi(s.c_str() + 7));
             else if (s == "digest") digest_only = true;
             else files.push_back(argv[a]);
         }
@@ -156,39 +160,67 @@ int main(int argc, char **argv)
         for (const char *f : files) src.push_back(parse_stream(f));
         const size_t n_frames = src[0].frames.size();
         for (const Stream &s : src) if (s.frames.size() != n_frames) { std::fprintf(stderr, "estimator_seq: the stream files must hold the same number of frames\n"); return 2; }
-        const int N = n_streams;
-        EstimatorBatch eb(hip, p, N);
-        if (async) eb.setAsyncMargin(true);
+        const int N = n_streams, G = std::min(n_groups, N);
         std::vector<Lines> out((size_t)N);
-        for (int s = 0; s < N; s++) { std::memcpy(eb.stream(s).TLC, src[(size_t)s % src.size()].TLC, 128); out[(size_t)s].keep = !digest_only; }
-        std::vector<double> headers((size_t)N);
-        std::vector<FeatureManager::Image> images((size_t)N);
-        std::vector<std::array<double, 16>> L0((size_t)N);
-        std::unique_ptr<bool[]> kf(new bool[(size_t)N]);
-        double solve_ms = 0; int solves = 0;
-        for (size_t f = 0; f < n_frames; f++) {
-            for (int s = 0; s < N; s++) {
-                const Frame &fr = src[(size_t)s % src.size()].frames[f];
-                headers[(size_t)s] = fr.header; images[(size_t)s] = fr.image; std::memcpy(L0[(size_t)s].data(), fr.L0, 128);
-                if (fr.has_loop) eb.stream(s).setLoopFrame(fr.loop);
-            }
-            const bool was_inited = eb.stream(0).stage_flag == Estimator::INITED;
-            const auto t0 = std::chrono::steady_clock::now();
-            eb.processImage(headers.data(), images.data(), reinterpret_cast<const double (*)[16]>(L0.data()), kf.get());
-            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            if (was_inited) { solve_ms += ms; solves++; }
-            for (int s = 0; s < N; s++) frm_line(out[(size_t)s], (int)f, kf[(size_t)s], eb.stream(s));
+        for (int s = 0; s < N; s++) out[(size_t)s].keep = !digest_only;
+        std::vector<double> g_flops((size_t)G, 0.0); std::vector<long> g_obs((size_t)G, 0);
+        std::vector<std::string> g_err((size_t)G);
+        std::vector<double> g_ms((size_t)G, 0.0); std::vector<int> g_solves((size_t)G, 0);
+        // group g: streams [s0, s1) on its own context / HIP stream / host thread (G = 1: this thread, the context above)
+        auto run_group = [&](int g) {
+            try {
+                const int s0 = (int)((long long)g * N / G), s1 = (int)((long long)(g + 1) * N / G), n = s1 - s0;
+                std::unique_ptr<HipContext> own;
+                if (G > 1) { own.reset(new HipContext(0)); own->useOwnStream(); }
+                HipContext &h = G > 1 ? *own : hip;
+                EstimatorBatch eb(h, p, n, G > 1 ? std::max(1, 16 / G) : 0);
+                if (async) eb.setAsyncMargin(true);
+                for (int s = 0; s < n; s++) std::memcpy(eb.stream(s).TLC, src[(size_t)(s0 + s) % src.size()].TLC, 128);
+                std::vector<double> headers((size_t)n);
+                std::vector<const FeatureManager::Image *> img((size_t)n);
+                std::vector<std::array<double, 16>> L0((size_t)n);
+                std::unique_ptr<bool[]> kf(new bool[(size_t)n]);
+                for (size_t f = 0; f < n_frames; f++) {
+                    for (int s = 0; s < n; s++) {
+                        const Frame &fr = src[(size_t)(s0 + s) % src.size()].frames[f];
+                        headers[(size_t)s] = fr.header; img[(size_t)s] = &fr.image; std::memcpy(L0[(size_t)s].data(), fr.L0, 128);
+                        if (fr.has_loop) eb.stream(s).setLoopFrame(fr.loop);
+                    }
+                    const bool was_inited = eb.stream(0).stage_flag == Estimator::INITED;
+                    const auto t0 = std::chrono::steady_clock::now();
+                    eb.processImage(headers.data(), img.data(), reinterpret_cast<const double (*)[16]>(L0.data()), kf.get());
+                    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                    if (was_inited) { g_ms[(size_t)g] += ms; g_solves[(size_t)g]++; }
+                    for (int s = 0; s < n; s++) frm_line(out[(size_t)(s0 + s)], (int)f, kf[(size_t)s], eb.stream(s));
+                }
+                eb.marginWait();
+                for (int s = 0; s < n; s++) {
+                    tail_lines(out[(size_t)(s0 + s)], eb.stream(s));
+                    g_flops[(size_t)g] += eb.stream(s).solve_flops; g_obs[(size_t)g] += eb.stream(s).solve_obs;
+                }
+            } catch (const std::exception &e) { g_err[(size_t)g] = e.what(); }
+        };
+        const auto wall0 = std::chrono::steady_clock::now();
+        if (G == 1) run_group(0);
+        else {
+            std::vector<std::thread> th;
+            for (int g = 0; g < G; g++) th.emplace_back(run_group, g);
+            for (auto &t : th) t.join();
         }
-        eb.marginWait();
+        const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+        for (const std::string &e : g_err) if (!e.empty()) throw std::runtime_error(e);
         double flops = 0; long obs = 0;
+        for (int g = 0; g < G; g++) { flops += g_flops[(size_t)g]; obs += g_obs[(size_t)g]; }
         for (int s = 0; s < N; s++) {
-            tail_lines(out[(size_t)s], eb.stream(s));
             if (!digest_only) { std::printf("STR %d\n", s); std::fputs(out[(size_t)s].text.c_str(), stdout); }
             std::printf("DIG %d %016llx\n", s, out[(size_t)s].h);
-            flops += eb.stream(s).solve_flops; obs += eb.stream(s).solve_obs;
         }
+        // one group: the INITED lock-step frames' own clock.  Several groups: they overlap, so the figure is the replay's wall time (the few NOT_INITED
+        // frames included) over the INITED frames
+        const int solves = g_solves[0];
+        const double solve_ms = G == 1 ? g_ms[0] : wall_ms;
         // TIM: lock-step frames timed (INITED), milliseconds per lock-step frame (= N stream frames), streams
-        std::printf("TIM %d %.6f %d\n", solves, solves ? solve_ms / solves : 0.0, N);
+        std::printf("TIM %d %.6f %d %d\n", solves, solves ? solve_ms / solves : 0.0, N, G);
         std::printf("FLP %.17g %ld\n", flops, obs);
         return 0;
     } catch (const std::exception &e) {

@@ -979,6 +979,12 @@ void EstimatorBatch::callShift()
 // Estimator::processImage (Estimator.cc:367-499) for every stream, the numeric steps batched
 void EstimatorBatch::processImage(const double *headers, const FeatureManager::Image *images, const double (*transform_to_init)[16], bool *keyframe)
 {
+    std::vector<const FeatureManager::Image *> ptr((size_t)size());
+    for (int s = 0; s < size(); s++) ptr[(size_t)s] = images + s;
+    processImage(headers, ptr.data(), transform_to_init, keyframe);
+}
+void EstimatorBatch::processImage(const double *headers, const FeatureManager::Image *const *images, const double (*transform_to_init)[16], bool *keyframe)
+{
     const int N = size();
     Work &w = *work_;
     if ((int)w.tp.size() != N) { w.tp.resize((size_t)N); w.sp.resize((size_t)N); w.shp.resize((size_t)N); w.due.assign((size_t)N, 0); }
@@ -988,7 +994,7 @@ void EstimatorBatch::processImage(const double *headers, const FeatureManager::I
     for (int s = 1; s < N; s++)
         if (est_[(size_t)s]->stage_flag != e0.stage_flag || est_[(size_t)s]->frame_count != e0.frame_count)
             throw std::logic_error("EstimatorBatch: the streams are not at the same frame of their sequences");
-    auto pre = [&](int s) { bool k = false; est_[(size_t)s]->preFrame(headers[s], images[s], transform_to_init[s], &k); kf[(size_t)s] = k ? 1 : 0; };
+    auto pre = [&](int s) { bool k = false; est_[(size_t)s]->preFrame(headers[s], *images[s], transform_to_init[s], &k); kf[(size_t)s] = k ? 1 : 0; };
     auto margin_and_tracks = [&](std::shared_ptr<std::vector<MargPack>> &packs) {
         // Estimator::optimization behind the solve: double2Matrix, then margin() (frame_count == WINDOW_SIZE here) -- and the tracks for the outlier scores
         const bool do_margin = p_.ESTIMATE_LASER != 0;

@@ -236,6 +236,7 @@ public:
     Estimator &stream(int s) { return *est_[(size_t)s]; }
     // one frame of every stream: headers[n], images[n], transform_to_init[n] (4 x 4 row-major LiDAR poses); keyframe[n] (optional) as processImage returns it
     void processImage(const double *headers, const FeatureManager::Image *images, const double (*transform_to_init)[16], bool *keyframe = nullptr);
+    void processImage(const double *headers, const FeatureManager::Image *const *images, const double (*transform_to_init)[16], bool *keyframe = nullptr);   // images by pointer
     void setAsyncMargin(bool on);          // marginalisation of frame k beside frame k + 1 (second context, own stream, one worker thread), as Estimator::setAsyncMargin
     void marginWait();
 private:

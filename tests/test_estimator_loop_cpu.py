@@ -165,3 +165,7 @@ def test_lockstep_batch_of_estimators_prints_every_streams_own_lines(oracle, tmp
     out = subprocess.run([exe, files[0], "-", "streams=5", "digest", files[1], files[2]], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and not [ln for ln in out.stdout.splitlines() if ln.startswith(("FRM", "ODO"))]
     assert _split_streams(out.stdout)[1] == dig
+    # the same streams as two independent lock-step groups on two host threads (own contexts): same digests
+    out = subprocess.run([exe, files[0], "-", "async", "streams=5", "groups=2", "digest", files[1], files[2]], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert _split_streams(out.stdout)[1] == dig
