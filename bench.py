@@ -691,6 +691,45 @@ def streamed_extra(ctx, off, xyzi_d, args, gold_poses):
     return out
 
 
+def stress_extra(ctx, args, chains, dev):
+    """Untimed extra: the SAME pass over the cluttered stress world (seq 2: 200 small boxes, 20 % stray returns, moving cylinders,
+    dropped ring sectors) -- the headline's world-dependence in the driver line.  Same layout (chains, lead), three passes timed."""
+    import torch
+    import lmono_amd
+    from lmono_amd import trajectory
+    from workloads import s1 as S1
+    n = args.scans
+    w = S1.S1World(seed=4242, n_az=args.az, clutter=True)
+    xyzi, off = w.scans(w.trajectory(n))
+    xd = torch.from_numpy(xyzi).to(dev)
+    del xyzi
+    b = lmono_amd.ScanBatch(ctx, n, int(off[-1]))
+    incr = torch.zeros((n, 7), dtype=torch.float64, device=dev)
+    poses = torch.zeros((n, 7), dtype=torch.float64, device=dev)
+
+    def one():
+        b.scanreg(xd.data_ptr(), off, 64, 5.0, keepalive=xd)
+        b.odometry_d(chains, args.lead, incr.data_ptr(), None)
+        rep = b.boundary_report()
+        ctx.pose_prefix_d(incr.data_ptr(), 0, n, poses.data_ptr())
+        return rep
+    one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = [one() for _ in range(3)]
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / 3
+    rep = reps[-1]
+    out = {"world": "stress sequence (seq 2: cluttered world), %d scans, the headline's layout (%d chains, lead %d)" % (n, chains, args.lead),
+           "scans_per_s": round(n / el, 1), "ms_per_step": round(el * 1e3, 3), "boundaries": rep["n_chains"] - 1, "flagged": rep["flagged"],
+           "pairs_rerun": rep["pairs_rerun"], "rounds": rep["rounds"], "unresolved": rep["unresolved"], "repair_ms": round(float(np.mean([r["repair_ms"] for r in reps])), 3)}
+    if args.az == 2000 and os.path.exists(GOLDEN % 2):
+        gp = np.load(GOLDEN % 2)["poses"]
+        hi = min(n, len(gp))
+        out["ate_vs_cpu_m"] = round(trajectory.ate(poses.cpu().numpy()[:hi], gp[:hi]), 6)
+    return out
+
+
 def latency_extra(ctx, xyzi_d, off, n_steps=64):
     """One scan per call (lmono_odom_step): wall time of a callback for a scan already in HBM -- scanRegistration of ONE scan plus ONE scan
     pair of laserOdometry -- and of the scanRegistration part alone (a 1-scan batch)."""
@@ -793,7 +832,10 @@ def main():
     # LMONO_BENCH_REHEARSE=1: every rank on cuda:0 and the collectives over gloo on CPU copies -- the multi-rank step of this file run end to
     # end on a one-GPU box (tests/test_lidar_gpu.py); never a measurement
     rehearse = world > 1 and os.environ.get("LMONO_BENCH_REHEARSE") == "1"
-    if rehearse:
+    # LMONO_BENCH_SAME_DEVICE=1: every rank on cuda:0 but the collectives through "nccl" (RCCL) itself -- several ranks on the ONE card of a test box
+    # (tests/test_rccl_gpu.py: works only if the library admits two ranks on one device); never a measurement either
+    same_device = world > 1 and os.environ.get("LMONO_BENCH_SAME_DEVICE") == "1"
+    if rehearse or same_device:
         local_rank = 0
     # LMONO_BENCH_FORCE_COLLECTIVES=1: a ONE-rank run takes the multi-rank step -- a world-1 "nccl" (RCCL) group, the all-gathers and
     # all-reduces on device tensors -- so that the collective path runs on the one GPU a test box has (tests/test_rccl_gpu.py)
@@ -981,7 +1023,8 @@ def main():
         # HBM bytes per launch of the dominant kernel from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE and
         # WRITE_SIZE in separate passes, gfx950 correction applied; scripts/profile_round.sh); null if not collected for it
         traffic = None
-        for rnd in ("r5", "r4", "r3", "r2", "r1"):
+        sq = None           # SQ instruction counters of a launch of the dominant kernel (the committed summary's, like traffic)
+        for rnd in ("r6", "r5", "r4", "r3", "r2", "r1"):
             pmc_path = os.path.join(ROOT, "profiles", rnd, "pmc_%s.json" % dom)
             if os.path.exists(pmc_path) and chains == 256:
                 try:
@@ -989,6 +1032,8 @@ def main():
                         pmc = json.load(fh)
                     if dom != "k_correspond" or pmc.get("chain_groups", 1) == chain_groups:     # counters of a launch of this size only
                         traffic = pmc["hbm_bytes_per_launch"]
+                        if "valu_wave_insts_per_launch" in pmc:
+                            sq = (float(pmc["valu_wave_insts_per_launch"]), float(pmc.get("salu_wave_insts_per_launch", 0.0)), "profiles/%s/pmc_%s.json" % (rnd, dom))
                         break
                 except (OSError, ValueError, KeyError, AttributeError):      # an unreadable summary: the line carries null
                     pass
@@ -1001,6 +1046,20 @@ def main():
                     "frontend_fused_frac": round(37 * N * n_local / (groups["frontend_total"] / max(n_reg, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                     "whole_step_frac": round((37 * N + 0.77e6) * n_local / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
                     "group_ms_per_step": {k: round(v / max(args.steps, 1), 3) for k, v in groups.items() if k != "odometry_launch_pairs"}}
+        if sq is not None:
+            # INSTRUCTION roofline (VERDICT r5 #4a): the search is bound by instruction issue, so its distance from THAT peak is the figure that says how
+            # good the kernel is.  A SIMD issues one wave64 VALU instruction per 4 cycles (MI355X_MICROARCH.md: 16 lanes per cycle); 4 SIMDs per CU.
+            # The chain groups' launches share the chip, so the launch's own count is multiplied by the groups that run beside it.
+            simds = 4 * (torch.cuda.get_device_properties(dev).multi_processor_count or 256)
+            clock_hz = 2.4e9
+            issue_peak = simds / 4.0 * clock_hz * (ms_launch * 1e-3)           # wave-level VALU instructions the chip can issue during one launch
+            conc = chain_groups if dom == "k_correspond" else 1
+            roofline["issue_frac"] = round(sq[0] * conc / issue_peak, 4)
+            roofline["issue_frac_valu_plus_salu"] = round((sq[0] + sq[1]) * conc / issue_peak, 4)
+            roofline["issue"] = {"valu_wave_insts_per_launch": sq[0], "salu_wave_insts_per_launch": sq[1], "concurrent_launches": conc, "simds": simds, "clock_GHz": 2.4,
+                                 "peak_wave_insts_per_launch_time": round(issue_peak), "source": sq[2],
+                                 "note": "VALU wave instructions of one launch x the launches that run side by side / (SIMDs / 4 cycles x 2.4 GHz x the launch's duration); "
+                                         "SALU instructions issue on their own port: the second figure is an upper bound on how busy the issue stage is"}
         if dom == "k_correspond":
             # "k_correspond" is the library's timing group of the search; the kernel rocprofv3 lists under it is lmono::k_corr_flat
             roofline["kernel_symbol"] = "lmono::k_corr_flat (+ k_correspond_list for deferred features: 0 here)"
@@ -1075,6 +1134,13 @@ def main():
                 out["secondary"] = {"ba": ba_secondary(ctx)}
             except Exception as e:       # the secondary line must never take the headline down
                 out["secondary"] = {"ba": {"error": repr(e)}}
+            # (5) the same pass over the cluttered world: the chained schedule's price is world-dependent, its result is not
+            if args.seq == 0 and not args.kitti_dir:
+                try:
+                    del seq_incr, seq_poses
+                    out["secondary"]["stress"] = stress_extra(ctx, args, chains, dev)
+                except Exception as e:
+                    out["secondary"]["stress"] = {"error": repr(e)}
         if sample is not None:
             # ---- cpu_baseline leg: the only place the oracle is touched
             from oracle import oracle as O
