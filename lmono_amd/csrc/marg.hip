@@ -49,6 +49,17 @@ struct MargBatch {
 constexpr int kMgAccC = 90, kMgAccJ = 99, kMgAcc = kMgAccC + 10 * kMgAccJ;
 constexpr int kMgAccWaves = (kMargMaxF0 + 63) / 64;
 
+struct MargEigWork {
+    double d[kMargN], e[kMargN], p[kMargN], u[kMargN];
+    double cs[2][2 * kMargN];        // rotation lists of two sweeps in flight: c_i, s_i for i = hi - 1 .. lo
+    double part[(kMgT / 64) * kMargN];   // per-wave partial dot products of the accumulation phase
+    double sc[4];                    // [0] h of the current reflector, [1] K
+    int ctl[2][4];                   // per list: lo, hi (rotations i = hi - 1 .. lo; hi <= lo: none), done
+    int fail;
+#ifdef LMONO_MG_PROF
+    unsigned long long prof[5]; int n_sweeps, n_rot;     // cycles of the three phases, QL sweeps and rotations; [3] wave 0's rotation chains, [4] its barrier waits
+#endif
+};
 struct MargLds {
     double Hrr[kMargN * kMargN];
     union {                             // the eigenvectors are only formed after the last use of W_d
@@ -63,9 +74,7 @@ struct MargLds {
         struct {                        // Schur complement and eigen-decomposition
             double Y[6 * kMargN];
             double SAi[36], u[6];
-            double cs[2 * 33];
-            double red[2 * 16];
-            int pq[2 * 33];
+            MargEigWork eig;
         };
         struct {                        // factor pass
             double acc[kMgAccWaves * kMgAcc];
@@ -127,79 +136,255 @@ __device__ void pinv6(const double *Ain, double *out, double eps, int *degenerat
     }
 }
 
-// Parallel (round-robin) Jacobi eigen-decomposition of the symmetric n x n matrix H (n even, leading dimension n) in LDS, eigenvectors accumulated
-// in V: n - 1 rounds of n / 2 disjoint rotations per sweep, until the off-diagonal mass is below 1e-30 of the diagonal's.  kMgT threads.
-// A round is TWO phases -- the rotation angles, then every 2 x 2 block {p_a, q_a} x {p_b, q_b} of H takes pair b's column rotation and pair a's row
-// rotation in one go (column first, then row), next to the column rotation of V.
-// Round 5: a thread's share of a round is FIXED for the whole call -- pair a = tid / G with G = kMgT / (n / 2) threads per pair, which take the blocks
-// b = g, g + G, .. of the pair's block row of H and the rows g, g + G, .. of its two columns of V -- so the pair's indices and its (c, s) are read
-// once per round and nothing is divided inside the loops (the element loops used to spend ~150 instructions per element on k / n, k % n and the
-// index loads).
-constexpr int kJcB = (kMargN / 2 + kMgT / (kMargN / 2) - 1) / (kMgT / (kMargN / 2));      // blocks of a pair's block row per thread (n <= 66: 3 of 33 at 15 threads per pair)
-constexpr int kJcR = (kMargN + kMgT / (kMargN / 2) - 1) / (kMgT / (kMargN / 2));          // rows of V per thread (5 of 66)
-__device__ __forceinline__ void marg_jacobi(double *H, double *V, int n, double *cs, int *pq, double *red, int tid)
+// Symmetric eigen-decomposition of the n x n matrix H (LDS, leading dimension n, BOTH triangles valid; n <= kMargN) by Householder tridiagonalisation and
+// implicit-shift QL (round 6; EISPACK tred2 / tql2 in the form of Numerical Recipes' tred2 / tqli, laid out for one workgroup of kMgT threads).
+// On return W.d[e] is eigenvalue e (no particular order) and H[e * n + i] component i of its eigenvector -- the eigenvectors are the ROWS of H.
+// Rounds 2-5 ran a round-robin parallel Jacobi here: ~20 sweeps x 65 rounds x (33 rotations applied to H and V through the LDS) = 2.2 M cycles of the
+// kernel's 2.6 M (profiles/r5/marg_phase_cycles.txt), bound by LDS bandwidth.  This form moves ~30 x fewer bytes:
+//   1. tred2: 65 reflectors, each a matrix-vector product and a rank-2 update of the leading block (all threads), three barriers per reflector;
+//   2. the product of the reflectors accumulated in place (two barriers per step), then transposed in place so that an eigenvector is a row;
+//   3. QL: wave 0 runs the scalar recurrence of a sweep (rotations c_i, s_i into a list) while the other waves apply the PREVIOUS sweep's list to the
+//      eigenvector rows -- one thread per component, a rotation touches rows i and i + 1, consecutive threads consecutive addresses; one barrier per sweep.
+// Deterministic (no atomics, fixed association); the eps cut and everything downstream see eigen-pairs accurate to rounding like the Jacobi's.
+__device__ __forceinline__ double mg_readlane_d(double v, int l)
 {
-    const int N1 = n - 1, half = n / 2;
-    const int G = kMgT / half, pa_i = tid / G, g = tid - pa_i * G;          // n <= kMargN: G >= kMgT / 33, so kJcB blocks and kJcR rows per thread cover every n
-    for (int sweep = 0; sweep < 40; sweep++) {
-        double offn = 0, dia = 0;
-        for (int a = tid >> 6; a < n; a += kMgT / 64)             // a wave per row: no division
-            for (int bb = tid & 63; bb < n; bb += 64) { const double v = H[a * n + bb]; if (a == bb) dia += v * v; else if (a < bb) offn += v * v; }
-        offn = wave_sum_d(offn); dia = wave_sum_d(dia);
-        __syncthreads();
-        if ((tid & 63) == 0) { red[tid >> 6] = offn; red[kMgT / 64 + (tid >> 6)] = dia; }
-        __syncthreads();
-        offn = 0.0; dia = 0.0;
-        for (int wv = 0; wv < kMgT / 64; wv++) { offn += red[wv]; dia += red[kMgT / 64 + wv]; }
-        if (offn <= 1e-30 * dia || offn == 0.0) break;
-        for (int rnd = 0; rnd < N1; rnd++) {
-            if (tid < half) {
-                int p0 = rnd + tid, q0 = rnd - tid + N1;
-                if (p0 >= N1) p0 -= N1;
-                if (q0 >= N1) q0 -= N1;
-                if (tid == 0) { p0 = N1; q0 = rnd; }
-                const int p = min(p0, q0), q = max(p0, q0);
-                const double apq = H[p * n + q];
-                const double app = H[p * n + p], aqq = H[q * n + q];
-                double c = 1.0, s = 0.0;
-                if (apq != 0.0) jacobi_cs(app, aqq, apq, c, s);
-                cs[2 * tid] = c; cs[2 * tid + 1] = s;
-                pq[2 * tid] = p; pq[2 * tid + 1] = q;
-            }
-            __syncthreads();
-            if (pa_i < half) {
-                const int pa = pq[2 * pa_i], qa = pq[2 * pa_i + 1];
-                const double ca = cs[2 * pa_i], sa = cs[2 * pa_i + 1];
-                double *Hp = H + pa * n, *Hq = H + qa * n;
-                // every operand of the thread's share is requested before the first result is stored (stores and loads of one array may alias as far as
-                // the compiler knows: element by element the loops were chains of LDS round trips, ~1.7 k cycles per round)
-                int pb[kJcB], qb[kJcB];
-                double cb[kJcB], sb[kJcB], x0[kJcB], y0[kJcB], x1[kJcB], y1[kJcB], va[kJcR], vb[kJcR];
-#pragma unroll
-                for (int u = 0; u < kJcB; u++) { const int b = min(g + u * G, half - 1); pb[u] = pq[2 * b]; qb[u] = pq[2 * b + 1]; cb[u] = cs[2 * b]; sb[u] = cs[2 * b + 1]; }
-#pragma unroll
-                for (int u = 0; u < kJcR; u++) { const int i = min(g + u * G, n - 1); va[u] = V[i * n + pa]; vb[u] = V[i * n + qa]; }
-#pragma unroll
-                for (int u = 0; u < kJcB; u++) { x0[u] = Hp[pb[u]]; y0[u] = Hp[qb[u]]; x1[u] = Hq[pb[u]]; y1[u] = Hq[qb[u]]; }
-                // H <- R^T (H R), block by block
-#pragma unroll
-                for (int u = 0; u < kJcB; u++) {
-                    if (g + u * G < half) {
-                        const double t0 = cb[u] * x0[u] - sb[u] * y0[u], u0 = sb[u] * x0[u] + cb[u] * y0[u], t1 = cb[u] * x1[u] - sb[u] * y1[u], u1 = sb[u] * x1[u] + cb[u] * y1[u];      // columns p_b, q_b
-                        Hp[pb[u]] = ca * t0 - sa * t1; Hq[pb[u]] = sa * t0 + ca * t1;                                                                                               // rows p_a, q_a
-                        Hp[qb[u]] = ca * u0 - sa * u1; Hq[qb[u]] = sa * u0 + ca * u1;
-                    }
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+// the wave's sum in every lane: DPP row steps + one readlane (the ds_bpermute butterfly of wave_sum_d is ~1 k cycles of LDS-crossbar round trips)
+__device__ __forceinline__ double mg_wave_sum(double v) { return mg_readlane_d(wave_sum_d_lane63(v), 63); }
+// sum over the 8 lanes of this lane's group of eight, in every lane of the group: quad_perm [1,0,3,2], [2,3,0,1], then row_half_mirror
+__device__ __forceinline__ double mg_sum8(double v)
+{
+    v += dpp_mov_f64<0xB1, 0xf>(v);
+    v += dpp_mov_f64<0x4E, 0xf>(v);
+    v += dpp_mov_f64<0x141, 0xf>(v);
+    return v;
+}
+// entry i (wave-uniform) of a vector kept one entry per lane in two registers (v0: entries 0..63, v1: 64..127)
+__device__ __forceinline__ double mg_get2(double v0, double v1, int i) { const double a = mg_readlane_d(v0, i & 63), b = mg_readlane_d(v1, i & 63); return i < 64 ? a : b; }     // (both lanes read, a scalar select: no branch)
+__device__ __forceinline__ void mg_set2(double &v0, double &v1, int i, double x, int lane) { if (lane == i) v0 = x; if (64 + lane == i) v1 = x; }
+
+__device__ __noinline__ void marg_eig_ql(double *A, int n, MargEigWork &W, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    constexpr int kWv = kMgT / 64;
+#ifdef LMONO_MG_PROF
+    unsigned long long pt0 = __builtin_readcyclecounter(), p_chain = 0, p_bar = 0;
+    int p_sweeps = 0, p_rot = 0;
+#endif
+    // ---- 1. Householder reduction to tridiagonal form: d, e; reflector i keeps u in row i and u / h in column i
+    for (int i = n - 1; i >= 1; i--) {
+        const int l = i - 1;
+        if (wave == 0) {
+            // (i <= 65 entries of row i: lanes k and 64 + k)
+            const double a0 = lane < i ? A[i * n + lane] : 0.0, a1 = 64 + lane < i ? A[i * n + 64 + lane] : 0.0;
+            double h = 0.0, ei = 0.0;
+            if (l > 0) {
+                const double scale = mg_wave_sum(fabs(a0) + fabs(a1));
+                if (scale == 0.0) ei = mg_get2(a0, a1, l);
+                else {
+                    const double inv = 1.0 / scale;
+                    double u0 = a0 * inv, u1 = a1 * inv;
+                    h = mg_wave_sum(u0 * u0 + u1 * u1);
+                    const double f = mg_get2(u0, u1, l);
+                    const double g = f >= 0.0 ? -sqrt(h) : sqrt(h);
+                    ei = scale * g;
+                    h -= f * g;
+                    mg_set2(u0, u1, l, f - g, lane);
+                    const double ih = 1.0 / h;
+                    if (lane < i) { A[i * n + lane] = u0; A[lane * n + i] = u0 * ih; W.u[lane] = u0; }
+                    if (64 + lane < i) { A[i * n + 64 + lane] = u1; A[(64 + lane) * n + i] = u1 * ih; W.u[64 + lane] = u1; }
                 }
-                // V <- V R
-#pragma unroll
-                for (int u = 0; u < kJcR; u++) {
-                    const int i = g + u * G;
-                    if (i < n) { V[i * n + pa] = ca * va[u] - sa * vb[u]; V[i * n + qa] = sa * va[u] + ca * vb[u]; }
-                }
-            }
-            __syncthreads();
+            } else ei = mg_readlane_d(a0, 0);
+            if (lane == 0) { W.e[i] = ei; W.d[i] = h; W.sc[0] = h; }
         }
+        __syncthreads();
+        const double h = W.sc[0];
+        if (h != 0.0) {                                  // (uniform: every thread reads the same word)
+            // p = A u / h over the leading i x i block: eight threads per row, four products of a thread in flight
+            const double ih = 1.0 / h;
+            for (int j = tid >> 3; j < i; j += kMgT / 8) {
+                double acc = 0.0;
+                for (int k = tid & 7; k < i; k += 32) {
+                    const int k1 = k + 8, k2 = k + 16, k3 = k + 24;
+                    const double x0 = A[j * n + k] * W.u[k], x1 = k1 < i ? A[j * n + k1] * W.u[k1] : 0.0, x2 = k2 < i ? A[j * n + k2] * W.u[k2] : 0.0, x3 = k3 < i ? A[j * n + k3] * W.u[k3] : 0.0;
+                    acc += (x0 + x1) + (x2 + x3);
+                }
+                acc = mg_sum8(acc);
+                if ((tid & 7) == 0) W.p[j] = acc * ih;
+            }
+            __syncthreads();
+            // K = u . p / (2 h) (every wave for itself), A -= u q^T + q u^T with q = p - K u
+            const double pu = (lane < i ? W.p[lane] * W.u[lane] : 0.0) + (64 + lane < i ? W.p[64 + lane] * W.u[64 + lane] : 0.0);
+            const double Kk = mg_wave_sum(pu) / (h + h);
+            const double uk0 = lane < i ? W.u[lane] : 0.0, uk1 = 64 + lane < i ? W.u[64 + lane] : 0.0;
+            const double qk0 = lane < i ? W.p[lane] - Kk * uk0 : 0.0, qk1 = 64 + lane < i ? W.p[64 + lane] - Kk * uk1 : 0.0;
+            for (int j = wave; j < i; j += kWv) {
+                const double uj = W.u[j], qj = W.p[j] - Kk * uj;
+                if (lane < i) A[j * n + lane] -= uj * qk0 + qj * uk0;
+                if (64 + lane < i) A[j * n + 64 + lane] -= uj * qk1 + qj * uk1;
+            }
+        }
+        __syncthreads();
     }
+    if (tid == 0) { W.d[0] = 0.0; W.e[0] = 0.0; }
+    __syncthreads();
+#ifdef LMONO_MG_PROF
+    if (tid == 0) { const unsigned long long t = __builtin_readcyclecounter(); W.prof[0] = t - pt0; pt0 = t; }
+#endif
+    // ---- 2. accumulate the transformation: A becomes Q (columns)
+    for (int i = 0; i < n; i++) {
+        const bool refl = W.d[i] != 0.0;                 // (uniform)
+        if (refl) {
+            // g_j = sum_k A[i][k] A[k][j], eight threads per j (k = part, part + 8, ..); the column i (u / h) is saved: the update below rewrites row and
+            // column i beside it
+            for (int j = tid & 63; j < i; j += 64) {     // lanes: consecutive j (consecutive addresses of a row k); the eight waves: the parts
+                double acc = 0.0;
+                for (int k = wave; k < i; k += 4 * kWv) {
+                    const int k1 = k + kWv, k2 = k + 2 * kWv, k3 = k + 3 * kWv;
+                    const double x0 = A[i * n + k] * A[k * n + j], x1 = k1 < i ? A[i * n + k1] * A[k1 * n + j] : 0.0, x2 = k2 < i ? A[i * n + k2] * A[k2 * n + j] : 0.0,
+                                 x3 = k3 < i ? A[i * n + k3] * A[k3 * n + j] : 0.0;
+                    acc += (x0 + x1) + (x2 + x3);
+                }
+                W.part[wave * kMargN + j] = acc;
+            }
+            if (tid < i) W.u[tid] = A[tid * n + i];
+        }
+        __syncthreads();
+        if (refl && tid < i) {
+            double g = 0.0;
+#pragma unroll
+            for (int wv = 0; wv < kWv; wv++) g += W.part[wv * kMargN + tid];
+            W.p[tid] = g;
+        }
+        __syncthreads();
+        for (int k = wave; k <= i; k += kWv)
+            for (int j = lane; j <= i; j += 64) {
+                if (k == i && j == i) { W.d[i] = A[i * n + i]; A[i * n + i] = 1.0; }
+                else if (k == i || j == i) A[k * n + j] = 0.0;
+                else if (refl) A[k * n + j] -= W.p[j] * W.u[k];
+            }
+        __syncthreads();
+    }
+    // transpose in place: row e becomes eigenvector e's storage
+    for (int k = wave; k < n; k += kWv)
+        for (int j = lane; j < k; j += 64) { const double x = A[k * n + j], y = A[j * n + k]; A[k * n + j] = y; A[j * n + k] = x; }
+    if (tid < n) W.u[tid] = tid + 1 < n ? W.e[tid + 1] : 0.0;       // e shifted down by one
+    if (tid == 0) { W.ctl[0][0] = W.ctl[0][1] = W.ctl[0][2] = 0; W.ctl[1][0] = W.ctl[1][1] = W.ctl[1][2] = 0; W.fail = 0; }
+    __syncthreads();
+    if (tid < n) W.e[tid] = W.u[tid];
+    __syncthreads();
+#ifdef LMONO_MG_PROF
+    if (tid == 0) { const unsigned long long t = __builtin_readcyclecounter(); W.prof[1] = t - pt0; pt0 = t; }
+#endif
+    // ---- 3. QL with implicit shifts.  Wave 0: the scalar recurrences (every lane computes the same values; d, e and the rotation list in LDS: a step's
+    //         operands are requested one step ahead, its results stored by lane 0 and never waited for -- the version with d and e spread over the lanes'
+    //         registers spent 2/3 of a step on v_readlane / v_cndmask: 627 cycles per rotation).  Waves 1..: the eigenvector rows.
+    int l = 0, iter = 0, buf = 0;
+    for (;;) {
+        if (wave == 0) {
+            int lo = 0, hi = 0, done = 0;
+            for (;;) {
+                if (l >= n) { done = 1; break; }
+                // the first negligible sub-diagonal element at or behind l: lanes test m = l + lane, l + 64 + lane
+                int m;
+                {
+                    const int m0 = l + lane, m1 = l + 64 + lane;
+                    bool s0 = m0 >= n - 1, s1 = m1 >= n - 1;
+                    if (!s0) { const double dd = fabs(W.d[m0]) + fabs(W.d[m0 + 1]); s0 = fabs(W.e[m0]) <= 2.220446049250313e-16 * dd; }
+                    if (!s1) { const double dd = fabs(W.d[m1]) + fabs(W.d[m1 + 1]); s1 = fabs(W.e[m1]) <= 2.220446049250313e-16 * dd; }
+                    const unsigned long long b0 = __ballot(s0), b1 = __ballot(s1);
+                    m = b0 ? l + (int)__builtin_ctzll(b0) : l + 64 + (int)__builtin_ctzll(b1 | (1ull << 63));
+                    if (m > n - 1) m = n - 1;
+                    m = __builtin_amdgcn_readfirstlane(m);
+                }
+                // (l, m, i and every branch on them are wave-uniform; readfirstlane says so to the compiler, which otherwise masks lanes around each of them)
+                if (m == l) { l = __builtin_amdgcn_readfirstlane(l + 1); iter = 0; continue; }
+                if (++iter > 60) { if (lane == 0) W.fail = 1; l = __builtin_amdgcn_readfirstlane(l + 1); iter = 0; continue; }      // (never seen; the pair is left as it is)
+#ifdef LMONO_MG_PROF
+                p_sweeps++; p_rot += m - l;
+#endif
+                l = __builtin_amdgcn_readfirstlane(l);
+                const double dl = W.d[l], el = W.e[l];
+                double g = (W.d[l + 1] - dl) / (2.0 * el);
+                double r = sqrt(__builtin_fma(g, g, 1.0));
+                g = W.d[m] - dl + el / (g + (g >= 0.0 ? r : -r));
+                double sn = 1.0, cn = 1.0, pp = 0.0;
+                double *cs = W.cs[buf];
+                int i = __builtin_amdgcn_readfirstlane(m - 1);
+                bool zero_r = false;
+                double e_i = W.e[i], d_i = W.d[i], d_i1 = W.d[i + 1];
+#ifdef LMONO_MG_PROF
+                const unsigned long long pc0 = __builtin_readcyclecounter();
+#endif
+                for (; i >= l; i = __builtin_amdgcn_readfirstlane(i - 1)) {
+                    const int inx = i > l ? i - 1 : l;                                    // the next step's operands (e[i - 1], d[i - 1]: untouched by this sweep so far)
+                    const double e_nx = W.e[inx], d_nx = W.d[inx];
+                    const double f = sn * e_i, bb = cn * e_i;
+                    const double x = __builtin_fma(f, f, g * g);
+                    if (__builtin_amdgcn_readfirstlane((int)(x == 0.0))) {
+                        if (lane == 0) { W.e[i + 1] = 0.0; W.d[i + 1] = d_i1 - pp; W.e[m] = 0.0; }
+                        zero_r = true;
+                        break;
+                    }
+                    const double ir = mg_rsqrt(x);
+                    sn = f * ir; cn = g * ir;
+                    g = d_i1 - pp;
+                    r = __builtin_fma(d_i - g, sn, 2.0 * cn * bb);
+                    pp = sn * r;
+                    if (lane == 0) { W.e[i + 1] = x * ir; W.d[i + 1] = g + pp; cs[2 * (i - l)] = cn; cs[2 * (i - l) + 1] = sn; }
+                    g = __builtin_fma(cn, r, -bb);
+                    d_i1 = d_i; e_i = e_nx; d_i = d_nx;
+                }
+#ifdef LMONO_MG_PROF
+                p_chain += __builtin_readcyclecounter() - pc0;
+#endif
+                if (zero_r) {
+                    // (NR: r == 0 -> recover from underflow; the rotations i = m - 1 .. i + 1 computed so far stand.  Their list positions were written
+                    // relative to l: move them down to start at 0 -- one wave, program order; a lane's read is ahead of every write that could reach it)
+                    lo = i + 1; hi = m;
+                    for (int q = lane; q < 2 * (hi - lo); q += 64) { const double v = cs[2 * (lo - l) + q]; cs[q] = v; }
+                } else {
+                    if (lane == 0) { W.d[l] = dl - pp; W.e[l] = g; W.e[m] = 0.0; }
+                    lo = l; hi = m;
+                }
+                break;
+            }
+            if (lane == 0) { W.ctl[buf][0] = lo; W.ctl[buf][1] = hi; W.ctl[buf][2] = done; }
+        } else {
+            // the previous sweep's rotations on the eigenvector rows: thread per component k
+            const int lo = W.ctl[buf ^ 1][0], hi = W.ctl[buf ^ 1][1];
+            const int k = tid - 64;
+            if (hi > lo && k < n) {
+                const double *cs = W.cs[buf ^ 1];
+                double z1 = A[hi * n + k];
+                double zi = A[(hi - 1) * n + k], cn = cs[2 * (hi - 1 - lo)], sn = cs[2 * (hi - 1 - lo) + 1];
+                for (int i = hi - 1; i >= lo; i--) {
+                    const double z_nx = i > lo ? A[(i - 1) * n + k] : 0.0, c_nx = i > lo ? cs[2 * (i - 1 - lo)] : 0.0, s_nx = i > lo ? cs[2 * (i - 1 - lo) + 1] : 0.0;
+                    A[(i + 1) * n + k] = __builtin_fma(sn, zi, cn * z1);
+                    z1 = __builtin_fma(cn, zi, -sn * z1);
+                    zi = z_nx; cn = c_nx; sn = s_nx;
+                }
+                A[lo * n + k] = z1;
+            }
+        }
+#ifdef LMONO_MG_PROF
+        const unsigned long long pb0 = __builtin_readcyclecounter();
+#endif
+        __syncthreads();
+#ifdef LMONO_MG_PROF
+        p_bar += __builtin_readcyclecounter() - pb0;
+#endif
+        const int done = W.ctl[buf][2];
+        buf ^= 1;
+        if (done) break;
+    }
+    // (the list written in the last productive sweep was applied during the sweep that found nothing left)
+#ifdef LMONO_MG_PROF
+    if (tid == 0) { W.prof[2] = __builtin_readcyclecounter() - pt0; W.n_sweeps = p_sweeps; W.n_rot = p_rot; W.prof[3] = p_chain; W.prof[4] = p_bar; }
+#endif
+    __syncthreads();
 }
 
 __global__ __launch_bounds__(kMgT) void k_marginalize(MargBatch Bt)
@@ -416,29 +601,29 @@ __global__ __launch_bounds__(kMgT) void k_marginalize(MargBatch Bt)
         const int a = k / kMargN, bb = k % kMargN;
         if (a < bb) { const double v = 0.5 * (L.Hrr[k] + L.Hrr[bb * kMargN + a]); L.Hrr[k] = v; L.Hrr[bb * kMargN + a] = v; }
     }
-    for (int k = tid; k < kMargN * kMargN; k += kMgT) L.V[k] = (k / kMargN == k % kMargN) ? 1.0 : 0.0;
     __syncthreads();
-    // ---- parallel Jacobi eigen-decomposition of Hrr (66x66): 65 rounds of 33 disjoint rotations per sweep
+    // ---- eigen-decomposition of H' (66 x 66): Householder + QL; the eigenvectors come back as the rows of Hrr
 #ifdef LMONO_MG_PROF
     const unsigned long long mg_t2 = __builtin_readcyclecounter();
 #endif
-    marg_jacobi(L.Hrr, L.V, kMargN, L.cs, L.pq, L.red, tid);
+    marg_eig_ql(L.Hrr, kMargN, L.eig, tid);
 #ifdef LMONO_MG_PROF
-    if (tid == 0) printf("MGPROF F0 %d obs %d factor %llu schur %llu jacobi %llu\n", F0, Bt.feat_obs_off[f0 + F0] - Bt.feat_obs_off[f0], mg_t1 - mg_t0, mg_t2 - mg_t1, (unsigned long long)__builtin_readcyclecounter() - mg_t2);
+    if (tid == 0) printf("MGPROF F0 %d obs %d factor %llu schur %llu jacobi %llu | tred2 %llu accumulate %llu ql %llu sweeps %d rotations %d chain %llu barrier %llu\n", F0, Bt.feat_obs_off[f0 + F0] - Bt.feat_obs_off[f0], mg_t1 - mg_t0, mg_t2 - mg_t1, (unsigned long long)__builtin_readcyclecounter() - mg_t2,
+                         L.eig.prof[0], L.eig.prof[1], L.eig.prof[2], L.eig.n_sweeps, L.eig.n_rot, L.eig.prof[3], L.eig.prof[4]);
 #endif
     // linearized_jacobians = sqrt(S) V^T, linearized_residuals = sqrt(S^-1) V^T b'
     for (int k = tid; k < kMargN * kMargN; k += kMgT) {
         const int e = k / kMargN, i = k % kMargN;
-        const double wv = L.Hrr[e * kMargN + e];
-        Bt.lin_J[(size_t)w * kMargN * kMargN + k] = (wv > eps ? sqrt(wv) : 0.0) * L.V[i * kMargN + e];
+        const double wv = L.eig.d[e];
+        Bt.lin_J[(size_t)w * kMargN * kMargN + k] = (wv > eps ? sqrt(wv) : 0.0) * L.Hrr[k];
     }
     for (int e = tid; e < kMargN; e += kMgT) {
-        const double wv = L.Hrr[e * kMargN + e];
+        const double wv = L.eig.d[e];
         double vb = 0;
-        for (int i = 0; i < kMargN; i++) vb += L.V[i * kMargN + e] * L.br[i];
+        for (int i = 0; i < kMargN; i++) vb += L.Hrr[e * kMargN + i] * L.br[i];
         Bt.lin_r[(size_t)w * kMargN + e] = (wv > eps ? sqrt(1.0 / wv) : 0.0) * vb;
     }
-    if (tid == 0) Bt.status[w] = L.flag;
+    if (tid == 0) Bt.status[w] = L.flag | (L.eig.fail ? 2 : 0);
 }
 
 // Marginalization::Evaluate: residual = r0 + J dx for the kept blocks x (11 x 7: ex, pose1..pose10); one thread per row
@@ -488,8 +673,8 @@ struct Marg2Lds {
     double T[kMargN * 6];
     double r[kMargN], b[kMargN], dx[kMargN], br[kMargN];
     double Hmm[36], Hinv[36];
-    double cs[2 * 33], red[2 * 16];
-    int perm[kMargN], pq[2 * 33], flag;
+    MargEigWork eig;
+    int perm[kMargN], flag;
 };
 
 __global__ __launch_bounds__(kMgT) void k_marg_second_new(Marg2Batch Bt)
@@ -551,25 +736,23 @@ __global__ __launch_bounds__(kMgT) void k_marg_second_new(Marg2Batch Bt)
     }
     if (tid < n) { double v = 0; for (int q = 0; q < 6; q++) v += L.T[tid * 6 + q] * L.b[q]; L.br[tid] = L.b[6 + tid] - v; }
     __syncthreads();
-    // move H' to H (ld n), V = identity in A
-    for (int k = tid; k < n * n; k += kMgT) L.H[k] = L.A[k];
+    // H' symmetrised into H (ld n): the eigen-solver reads both triangles
+    for (int k = tid; k < n * n; k += kMgT) { const int i = k / n, j = k % n; L.H[k] = 0.5 * (L.A[k] + L.A[j * n + i]); }
     __syncthreads();
-    for (int k = tid; k < n * n; k += kMgT) L.A[k] = (k / n == k % n) ? 1.0 : 0.0;
-    __syncthreads();
-    // parallel Jacobi (round-robin tournament over n = even): n - 1 rounds of n / 2 disjoint rotations per sweep
-    marg_jacobi(L.H, L.A, n, L.cs, L.pq, L.red, tid);
+    // eigen-decomposition (Householder + QL): the eigenvectors come back as the rows of H
+    marg_eig_ql(L.H, n, L.eig, tid);
     for (int k = tid; k < n * n; k += kMgT) {
-        const int e = k / n, i = k % n;
-        const double wv = L.H[e * n + e];
-        Bt.out_J[(size_t)w * n * n + k] = (wv > eps ? sqrt(wv) : 0.0) * L.A[i * n + e];
+        const int e = k / n;
+        const double wv = L.eig.d[e];
+        Bt.out_J[(size_t)w * n * n + k] = (wv > eps ? sqrt(wv) : 0.0) * L.H[k];
     }
     for (int e = tid; e < n; e += kMgT) {
-        const double wv = L.H[e * n + e];
+        const double wv = L.eig.d[e];
         double vb = 0;
-        for (int i = 0; i < n; i++) vb += L.A[i * n + e] * L.br[i];
+        for (int i = 0; i < n; i++) vb += L.H[e * n + i] * L.br[i];
         Bt.out_r[(size_t)w * n + e] = (wv > eps ? sqrt(1.0 / wv) : 0.0) * vb;
     }
-    if (tid == 0) Bt.status[w] = L.flag;
+    if (tid == 0) Bt.status[w] = L.flag | (L.eig.fail ? 2 : 0);
 }
 
 } // namespace lmono

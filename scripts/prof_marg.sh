@@ -17,7 +17,7 @@ LD_LIBRARY_PATH=$PWD/$O/lib:$LD_LIBRARY_PATH lmono_amd/host/estimator_seq $O/str
 rm -rf $O/stream600.bin $O/lib
 python3 - <<PY
 import re
-rows=[[int(x) for x in re.findall(r"\d+", l)][1:] for l in open("$O/marg_phases.txt")]      # ([0] is the 0 of the label "F0")
+rows=[[int(x) for x in re.findall(r"\d+", l.replace("tred2", "tred"))][1:] for l in open("$O/marg_phases.txt")]      # ([0] is the 0 of the label "F0")
 rows.sort(key=lambda r: r[0])
 n=len(rows)
 print("calls", n, "mean cycles: factor %.0f schur %.0f jacobi %.0f, total %.0f, max %d" % (tuple(sum(r[k] for r in rows)/n for k in (2,3,4)) + (sum(r[2]+r[3]+r[4] for r in rows)/n, max(r[2]+r[3]+r[4] for r in rows))))
@@ -25,5 +25,7 @@ for lo,hi in ((0,5),(5,10),(10,20),(20,40),(40,80),(80,161)):
     sel=[r for r in rows if lo<=r[0]<hi]
     if sel:
         m=lambda k: sum(r[k] for r in sel)/len(sel)
-        print("F0 in [%d,%d): %d calls, mean obs %.0f, factor %.0f schur %.0f jacobi %.0f cycles" % (lo,hi,len(sel),m(1),m(2),m(3),m(4)))
+        ext = (" | tred2 %.0f accumulate %.0f ql %.0f sweeps %.0f rotations %.0f" % (m(5),m(6),m(7),m(8),m(9))) if len(sel[0]) >= 10 else ""
+        ext += (" chain %.0f barrier %.0f" % (m(10), m(11))) if len(sel[0]) >= 12 else ""
+        print("F0 in [%d,%d): %d calls, mean obs %.0f, factor %.0f schur %.0f eigen %.0f cycles" % (lo,hi,len(sel),m(1),m(2),m(3),m(4)) + ext)
 PY
