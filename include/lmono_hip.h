@@ -258,6 +258,10 @@ int lmono_ba_batch_reset(lmono_ctx *, lmono_ba_batch *);                 /* rest
 /* poses_h [n][11][7], ex_h [n][7], inv_depth_h [F total], summary_h [n][6] = initial_cost, final_cost, iterations,
  * termination (0 CONVERGENCE, 1 NO_CONVERGENCE, 2 FAILURE), successful steps, unsuccessful steps; any may be NULL */
 int lmono_ba_batch_read(lmono_ctx *, lmono_ba_batch *, double *poses_h, double *ex_h, double *inv_depth_h, double *summary_h);
+/* Diagnostic (no reference counterpart): a -DLMONO_BOUNDS build of the library checks every global access of k_ba_solve against the batch's allocation
+ * and records the first one outside it instead of faulting: out4 = hits, source line of the first, its byte offset, its block.  The product build
+ * answers LMONO_EINVAL.  tests/test_bounds_gpu.py builds the checked library into a scratch directory and runs the BA tests' problems through it.       */
+int lmono_debug_bounds(lmono_ctx *, unsigned long long *out4);
 
 /* ---- per-feature numerics of FeatureManager / Estimator (batched over windows; host arrays) ---------------- *
  * lmono_triangulate: FeatureManager::triangulate (src/image_process/FeatureManager.cc:75-255): linear multi-view

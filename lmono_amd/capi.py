@@ -18,7 +18,7 @@ SYMBOLS = [
     "lmono_map_builder_cloud", "lmono_map_builder_map", "lmono_map_builder_clear",
     "lmono_pose_graph_create", "lmono_pose_graph_destroy", "lmono_pose_graph_reset", "lmono_pose_graph_info", "lmono_pose_graph_reduce_buffer", "lmono_pose_graph_set_reduce_buffer", "lmono_pose_graph_linearise",
     "lmono_pose_graph_step", "lmono_pose_graph_optimize", "lmono_pose_graph_result", "lmono_factor_eval", "lmono_factor_eval_d", "lmono_factor_eval_blocks", "lmono_factor_eval_blocks_d",
-    "lmono_triangulate", "lmono_outlier_scores", "lmono_shift_depth", "lmono_shift_depth_batch", "lmono_marginalize", "lmono_marg_evaluate", "lmono_marg_second_new", "lmono_ba_batch_create", "lmono_ba_batch_update", "lmono_ba_batch_destroy", "lmono_ba_solve", "lmono_ba_batch_reset", "lmono_ba_batch_read",
+    "lmono_triangulate", "lmono_outlier_scores", "lmono_shift_depth", "lmono_shift_depth_batch", "lmono_marginalize", "lmono_marg_evaluate", "lmono_marg_second_new", "lmono_ba_batch_create", "lmono_ba_batch_update", "lmono_ba_batch_destroy", "lmono_ba_solve", "lmono_ba_batch_reset", "lmono_ba_batch_read", "lmono_debug_bounds",
 ]
 
 
@@ -93,6 +93,7 @@ def load_library():
     L.lmono_ba_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.lmono_ba_batch_reset.argtypes = [C.c_void_p, C.c_void_p]
     L.lmono_ba_batch_read.argtypes = [C.c_void_p] * 6
+    L.lmono_debug_bounds.argtypes = [C.c_void_p, C.c_void_p]
     L.lmono_factor_eval.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
     L.lmono_factor_eval_d.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
     L.lmono_factor_eval_blocks.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6
@@ -280,6 +281,12 @@ class Context:
         out = np.zeros(len(d))
         self.check(self.L.lmono_shift_depth_batch(self.h, len(fr), fr.ctypes.data, off.ctypes.data, pt.ctypes.data, d.ctypes.data, out.ctypes.data))
         return [out[off[k]:off[k + 1]] for k in range(len(fr))]
+
+    def debug_bounds(self):
+        """(hits, line of the first, byte offset of the first, block of the first) of a -DLMONO_BOUNDS build; raises LmonoError on the product build."""
+        out = (C.c_ulonglong * 4)()
+        self.check(self.L.lmono_debug_bounds(self.h, out))
+        return tuple(int(v) for v in out)
 
     def marginalize(self, windows):
         """windows: list of dicts(poses [11,7], ex [7], invd [F0], obs_feat, obs_j, pts [O,4], laser01 [24], laser_info, mono_info)."""

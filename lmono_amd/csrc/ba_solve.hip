@@ -102,6 +102,7 @@ struct BaBatch {
     int n_pairs_total;          // stride of the per-rank copies of pairdat
     double *cand;               // scratch [W][kBaMaxFeat]
     double *summary;            // [W][6] initial_cost, final_cost, iterations, termination, successful, unsuccessful
+    const char *blob_lo, *blob_hi;  // the batch's one device allocation (every pointer above points into it): the bounds-checked build's limits
 };
 
 struct BaSchurStage { double et[kBaFT * kBaPS]; double ic[kBaFT]; double gi[kBaFT]; double part[4][kBaPS]; };
@@ -285,9 +286,31 @@ __device__ __forceinline__ double pair_sum(double v)
 typedef __attribute__((address_space(1))) double ba_gd;
 typedef __attribute__((address_space(1))) const double ba_gcd;
 typedef __attribute__((address_space(1))) const int ba_gci;
+#ifdef LMONO_BOUNDS
+// Bounds-checked build (tests/test_bounds_gpu.py): every global access of k_ba_solve is checked against the batch's ONE device allocation
+// (BaBatch::blob_lo / blob_hi: every array of a batch -- inputs, results, scratch -- lives in it).  An access outside it -- what the GPU reports as a
+// "memory access fault" without saying where -- is counted, the first one recorded as (source line, kernel phase tag, byte offset from the blob's start) in
+// g_ba_oob[], and redirected to the blob's first 8 bytes, so the run survives and says which line it was.  LDS accesses need no check: out-of-range LDS
+// reads return zero and writes are dropped (no fault); they show as wrong results, which the parity tests cover.
+__device__ unsigned long long g_ba_oob[4];      // [0] hits, [1] line of the first, [2] its byte offset (two's complement), [3] block index
+__shared__ const char *g_ba_lo_hi[2];
+template <typename T> __device__ __forceinline__ T *ba_chk(T *p, int line)
+{
+    const char *q = (const char *)p;
+    if (q >= g_ba_lo_hi[0] && q + sizeof(T) <= g_ba_lo_hi[1]) return p;
+    if (atomicAdd(&g_ba_oob[0], 1ull) == 0ull) { g_ba_oob[1] = (unsigned long long)line; g_ba_oob[2] = (unsigned long long)(q - g_ba_lo_hi[0]); g_ba_oob[3] = blockIdx.x; }
+    return (T *)g_ba_lo_hi[0];
+}
+#define BA_P(p) ba_chk((p), __LINE__)
+#define gld(p) (*(ba_gcd *)BA_P((const double *)(p)))
+#define gldi(p) (*(ba_gci *)BA_P((const int *)(p)))
+#define gst(p, v) (*(ba_gd *)BA_P((double *)(p)) = (v))
+#else
+#define BA_P(p) (p)
 __device__ __forceinline__ double gld(const double *p) { return *(ba_gcd *)p; }
 __device__ __forceinline__ int gldi(const int *p) { return *(ba_gci *)p; }
 __device__ __forceinline__ void gst(double *p, double v) { *(ba_gd *)p = v; }
+#endif
 
 // this wave among the GW waves that take segments (-1: none).  One workgroup: its eight waves.  Several: the leader's wave 1 evaluates the LASERFactor
 // chain and the prior meanwhile and takes none.
@@ -303,11 +326,13 @@ __device__ __forceinline__ int ba_worker(const BaCtx &c, int wave)
 // CU's L1 and are ordered by the arrival counters; MI355X_MICROARCH.md, hand-off table) when several workgroups share a window, plain ones otherwise
 template <bool kCl> __device__ __forceinline__ double ld_sh(const double *p)
 {
+    p = BA_P(p);
     if (kCl) return __hip_atomic_load((ba_gcd *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return gld(p);
 }
 template <bool kCl> __device__ __forceinline__ void st_sh(double *p, double v)
 {
+    p = BA_P(p);
     if (kCl) __hip_atomic_store((ba_gd *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else gst(p, v);
 }
@@ -330,16 +355,16 @@ template <bool kBig> __device__ __forceinline__ double &ba_vref(double *lds, dou
 // (kBig followers read them straight from the leader's mail box, which the leader rewrites with sc1 stores at every publish inside the same launch: the
 // read must bypass this CU's L1 on ANY placement -- kFol -- or a line cached during the previous linearisation answers with the old state)
 #define BA_VINV(f) (kBig ? ld_sh<kCl || kFol>(G.vinv + (f)) : L.vinv[(f)])
-#define BA_FOBS(f) (kBig ? G.fobs[(f)] - G.o0 : (int)L.fobs[(f)])
-#define BA_FANCHOR(f) (kBig ? G.fanchor[(f)] : (int)L.fanchor[(f)])
-#define BA_SEG(sg) (kBig ? (unsigned int)G.seg[(sg)] : (unsigned int)L.seg[(sg)])
+#define BA_FOBS(f) (kBig ? *BA_P(G.fobs + (f)) - G.o0 : (int)L.fobs[(f)])
+#define BA_FANCHOR(f) (kBig ? *BA_P(G.fanchor + (f)) : (int)L.fanchor[(f)])
+#define BA_SEG(sg) (kBig ? (unsigned int)*BA_P(G.seg + (sg)) : (unsigned int)L.seg[(sg)])
 
 // Hand-offs between the workgroups of a window are FLAG WORDS with one writer each (device-coherent stores, polled with device-coherent loads; no
 // read-modify-write: an agent-scope atomic add is resolved beyond the XCD's L2 and costs a microsecond before anybody can see it): the leader's "go"
 // word holds the number of evaluations it has published, follower r's "done" word the number it has answered.  B.bar: [W][16] words, [0] = go,
 // [r] = done of follower r (rank r >= 1).  Zeroed before every launch.
-__device__ __forceinline__ unsigned int ba_flag_load(const unsigned int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void ba_flag_store(unsigned int *p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned int ba_flag_load(const unsigned int *p) { return __hip_atomic_load(BA_P(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ba_flag_store(unsigned int *p, unsigned int v) { __hip_atomic_store(BA_P(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // the XCD this workgroup runs on (HW_REG_XCC_ID, bits 3:0).  Used for SPEED only: a follower on the leader's XCD shares its L2, so its plain
 // (write-through) stores are where the leader's device-coherent loads look first; a follower elsewhere stores device-coherently (sc1), which is right
 // on any placement and slower to read back
@@ -1382,8 +1407,8 @@ __device__ __noinline__ void ba_setup(const BaBatch &B, const BaCtx c, BaLds &L_
     const int tid = threadIdx.x;
     __syncthreads();
     for (int k = tid; k < kBaMaxPoses * kBaMaxPoses; k += kBaT) L.pair_of[k] = -1;
-    if (!kBig) for (int f = tid; f <= c.F; f += kBaT) L.fobs[f] = (unsigned short)(B.feat_obs_off[c.f0 + f] - c.o0);      // <= 448 x 10 observations per window
-    if (!kBig) for (int f = tid; f < c.F; f += kBaT) L.fanchor[f] = (signed char)B.feat_anchor[c.f0 + f];
+    if (!kBig) for (int f = tid; f <= c.F; f += kBaT) L.fobs[f] = (unsigned short)(*BA_P(B.feat_obs_off + c.f0 + f) - c.o0);      // <= 448 x 10 observations per window
+    if (!kBig) for (int f = tid; f < c.F; f += kBaT) L.fanchor[f] = (signed char)*BA_P(B.feat_anchor + c.f0 + f);
     __syncthreads();
     // (anchor, observer) -> the pair's tile among the window's tiles [segments | pairs]: a pair of several segments has its own (ba_reduce_pairs sums
     // its segments' tiles into it), any other pair's tile is its only segment's
@@ -1413,7 +1438,7 @@ __device__ __noinline__ void ba_setup(const BaBatch &B, const BaCtx c, BaLds &L_
             d1 = (ba_pose_off(c, bm) + om) * kBaP + ba_pose_off(c, bn) + on;
             d2 = (ba_pose_off(c, bn) + on) * kBaP + ba_pose_off(c, bm) + om;
         }
-        gp[a] = o1; gp[kBaGaN + a] = o2; gp[2 * kBaGaN + a] = d1; gp[3 * kBaGaN + a] = d2;
+        *BA_P(gp + a) = o1; *BA_P(gp + kBaGaN + a) = o2; *BA_P(gp + 2 * kBaGaN + a) = d1; *BA_P(gp + 3 * kBaGaN + a) = d2;
     }
     int *gb = gp + 4 * kBaGaN;
     for (int t = tid; t < kBaGbN; t += kBaT) {
@@ -1439,10 +1464,10 @@ __device__ __noinline__ void ba_setup(const BaBatch &B, const BaCtx c, BaLds &L_
         for (int k = 0; k < kBaMaxPoses; k++) {
             const int pa = (on_ && k < np_ && k != f) ? L.pair_of[f * kBaMaxPoses + k] : -1;
             const int pb = (on_ && k < np_ && k != f) ? L.pair_of[k * kBaMaxPoses + f] : -1;
-            gb[k * kBaGbN + t] = pa >= 0 ? pa * kBaPairTile + oi_ : zero;
-            gb[(kBaMaxPoses + k) * kBaGbN + t] = pb >= 0 ? pb * kBaPairTile + oj_ : zero;
+            *BA_P(gb + k * kBaGbN + t) = pa >= 0 ? pa * kBaPairTile + oi_ : zero;
+            *BA_P(gb + (kBaMaxPoses + k) * kBaGbN + t) = pb >= 0 ? pb * kBaPairTile + oj_ : zero;
         }
-        gb[22 * kBaGbN + t] = on_ ? dst : -1; gb[23 * kBaGbN + t] = on_ ? dst2 : -1;
+        *BA_P(gb + 22 * kBaGbN + t) = on_ ? dst : -1; *BA_P(gb + 23 * kBaGbN + t) = on_ ? dst2 : -1;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
@@ -1502,14 +1527,18 @@ __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B, int K, int spread)
     c.GW = c.K == 1 ? kBaW : c.K * kBaW - 1;
     c.win = w;
     if (w >= B.n_windows) return;
-    c.n_poses = B.flags[w * 4 + 0]; c.use_prior = B.flags[w * 4 + 1]; c.ex_constant = B.flags[w * 4 + 2]; c.use_mono = B.flags[w * 4 + 3];
-    c.f0 = B.feat_off[w]; c.o0 = B.obs_off[w];
-    c.F = c.use_mono ? B.feat_off[w + 1] - c.f0 : 0;
+#ifdef LMONO_BOUNDS
+    if (tid == 0) { g_ba_lo_hi[0] = B.blob_lo; g_ba_lo_hi[1] = B.blob_hi; }
+    __syncthreads();
+#endif
+    c.n_poses = *BA_P(B.flags + w * 4 + 0); c.use_prior = *BA_P(B.flags + w * 4 + 1); c.ex_constant = *BA_P(B.flags + w * 4 + 2); c.use_mono = *BA_P(B.flags + w * 4 + 3);
+    c.f0 = *BA_P(B.feat_off + w); c.o0 = *BA_P(B.obs_off + w);
+    c.F = c.use_mono ? *BA_P(B.feat_off + w + 1) - c.f0 : 0;
     c.ex_off = c.ex_constant ? -1 : 0;
     c.P = 6 * c.n_poses + (c.ex_constant ? 0 : 6);
-    c.pp0 = B.pair_off[w]; c.n_pairs = c.use_mono ? B.pair_off[w + 1] - c.pp0 : 0;
-    c.ps0 = B.pobs_off[w]; c.n_slots = c.use_mono ? B.pobs_off[w + 1] - c.ps0 : 0;
-    c.sg0 = B.seg_off[w]; c.n_seg = c.use_mono ? B.seg_off[w + 1] - c.sg0 : 0; c.n_multi = c.use_mono ? B.n_multi[w] : 0;
+    c.pp0 = *BA_P(B.pair_off + w); c.n_pairs = c.use_mono ? *BA_P(B.pair_off + w + 1) - c.pp0 : 0;
+    c.ps0 = *BA_P(B.pobs_off + w); c.n_slots = c.use_mono ? *BA_P(B.pobs_off + w + 1) - c.ps0 : 0;
+    c.sg0 = *BA_P(B.seg_off + w); c.n_seg = c.use_mono ? *BA_P(B.seg_off + w + 1) - c.sg0 : 0; c.n_multi = c.use_mono ? *BA_P(B.n_multi + w) : 0;
     const int P = c.P, F = c.F, N = P + F;
     double *gposes = B.poses + (size_t)w * kBaMaxPoses * 7, *gex = B.ex + (size_t)w * 7, *ginvd = B.inv_depth + c.f0;
     double *hpd = B.hpd + (size_t)w * B.feat_cap * kBaPS;
@@ -1519,17 +1548,17 @@ __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B, int K, int spread)
     {
         double *gv = kBig ? B.bigv + (size_t)w * 8 * kBaMaxFeat : nullptr;
         G.Hdd = gv; G.gdd = gv + kBaMaxFeat; G.scale = gv + 2 * kBaMaxFeat; G.D = gv + 3 * kBaMaxFeat; G.gs = gv + 4 * kBaMaxFeat; G.gn = gv + 5 * kBaMaxFeat;
-        G.va = gv + 6 * kBaMaxFeat; G.vb = gv + 7 * kBaMaxFeat; G.vinv = ginvd; G.fobs = B.feat_obs_off + c.f0; G.fanchor = B.feat_anchor + c.f0; G.seg = B.seg_tab + B.seg_off[w]; G.o0 = c.o0;
+        G.va = gv + 6 * kBaMaxFeat; G.vb = gv + 7 * kBaMaxFeat; G.vinv = ginvd; G.fobs = B.feat_obs_off + c.f0; G.fanchor = B.feat_anchor + c.f0; G.seg = B.seg_tab + c.sg0; G.o0 = c.o0;
     }
     if (tid == 0) { L.eval_no = 0; L.failed = 0; }
 #ifdef LMONO_BA_PROF
     if (tid < 24) L.prof[tid] = 0;
 #endif
-    for (int k = tid; k < c.n_poses * 7; k += kBaT) L.poses[k] = gposes[k];
-    if (tid < 7) L.ex[tid] = gex[tid];
-    for (int k = tid; k < c.n_pairs; k += kBaT) L.pair_ij[k] = B.pair_ij[c.pp0 + k];
-    for (int k = tid; k <= c.n_pairs; k += kBaT) { L.pair_slot[k] = (short)B.pair_slot[c.pp0 + w + k]; L.pair_seg[k] = (short)B.pair_seg[c.pp0 + w + k]; }
-    if (!kBig) for (int k = tid; k < c.n_seg; k += kBaT) L.seg[k] = B.seg_tab[c.sg0 + k];
+    for (int k = tid; k < c.n_poses * 7; k += kBaT) L.poses[k] = *BA_P(gposes + k);
+    if (tid < 7) L.ex[tid] = *BA_P(gex + tid);
+    for (int k = tid; k < c.n_pairs; k += kBaT) L.pair_ij[k] = *BA_P(B.pair_ij + c.pp0 + k);
+    for (int k = tid; k <= c.n_pairs; k += kBaT) { L.pair_slot[k] = (short)*BA_P(B.pair_slot + c.pp0 + w + k); L.pair_seg[k] = (short)*BA_P(B.pair_seg + c.pp0 + w + k); }
+    if (!kBig) for (int k = tid; k < c.n_seg; k += kBaT) L.seg[k] = *BA_P(B.seg_tab + c.sg0 + k);
     __syncthreads();
     ba_setup<kBig>(B, c, L);
     if (kCl && c.rank > 0) { ba_follow<kBig>(B, c, L, G, pairdat); return; }
@@ -1653,7 +1682,7 @@ __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B, int K, int spread)
                 for (int k = 0; k < 7; k++) L.cex[k] = L.ex[k];
             }
         }
-        for (int f = tid; f < F; f += kBaT) cinvd[f] = ginvd[f] + BA_V(va, P + f) * BA_V(scale, P + f);
+        for (int f = tid; f < F; f += kBaT) *BA_P(cinvd + f) = *BA_P(ginvd + f) + BA_V(va, P + f) * BA_V(scale, P + f);
         __syncthreads();
         BA_TOCK(18)
         const double cand_cost = ba_evaluate<false, kCl, kBig>(B, c, L, G, L.cposes, L.cex, cinvd, hpd, pairdat);
@@ -1661,7 +1690,7 @@ __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B, int K, int spread)
         double dq = 0;
         if (c.ex_off >= 0 && tid < 7) dq += (L.ex[tid] - L.cex[tid]) * (L.ex[tid] - L.cex[tid]);
         for (int k = tid; k < 7 * c.n_poses; k += kBaT) dq += (L.poses[k] - L.cposes[k]) * (L.poses[k] - L.cposes[k]);
-        for (int f = tid; f < F; f += kBaT) dq += (ginvd[f] - cinvd[f]) * (ginvd[f] - cinvd[f]);
+        for (int f = tid; f < F; f += kBaT) { const double dv = *BA_P(ginvd + f) - *BA_P(cinvd + f); dq += dv * dv; }
         const double sn = sqrt(block_sum(dq, L.red));
         if (sn <= parameter_tol * (x_norm + parameter_tol)) { termination = 0; break; }
         if (fabs(x_cost - cand_cost) <= function_tol * x_cost) { termination = 0; break; }
@@ -1670,7 +1699,7 @@ __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B, int K, int spread)
             __syncthreads();
             for (int k = tid; k < 7 * c.n_poses; k += kBaT) L.poses[k] = L.cposes[k];
             if (tid < 7) L.ex[tid] = L.cex[tid];
-            for (int f = tid; f < F; f += kBaT) ginvd[f] = cinvd[f];
+            for (int f = tid; f < F; f += kBaT) *BA_P(ginvd + f) = *BA_P(cinvd + f);
             __syncthreads();
             n_succ++;
             records_valid = true;            // the candidate's records are the accepted state's
@@ -1692,10 +1721,10 @@ __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B, int K, int spread)
     __syncthreads();
     if (w == 0 && tid == 0) printf("PROF total %lld | lin: prologue %lld eval %lld mfma %lld | cost %lld | hs %lld | schur: stage+mfma %lld chol %lld subst %lld depth %lld | iters %d | wave-0 turn wait %lld, feature pass + small factors %lld (reduce pairs %lld, wave 0's features %lld) | chol: factor %lld barrier %lld next-panel %lld | glue: norms+D %lld alpha %lld dogleg+candidate %lld decision %lld\n", g_prof[9], g_prof[0], g_prof[1], g_prof[2], g_prof[3], g_prof[4], g_prof[5], g_prof[6], g_prof[7], g_prof[8], iter, g_prof[10] * 0, g_prof[11], g_prof[12], g_prof[13], g_prof[14], g_prof[15], g_prof[10], g_prof[16], g_prof[17], g_prof[18], g_prof[19]);
 #endif
-    for (int k = tid; k < c.n_poses * 7; k += kBaT) gposes[k] = L.poses[k];
-    if (tid < 7) gex[tid] = L.ex[tid];
+    for (int k = tid; k < c.n_poses * 7; k += kBaT) *BA_P(gposes + k) = L.poses[k];
+    if (tid < 7) *BA_P(gex + tid) = L.ex[tid];
     if (tid == 0) {
-        double *sm = B.summary + (size_t)w * 6;
+        double *sm = BA_P(B.summary + (size_t)w * 6 + 5) - 5;
         sm[0] = initial_cost; sm[1] = x_cost; sm[2] = iter; sm[3] = (kCl && L.failed) ? 3 : termination; sm[4] = n_succ; sm[5] = n_unsucc;
     }
 }

@@ -164,6 +164,15 @@ extern "C" lmono_ctx *lmono_create(int device)
 extern "C" void lmono_destroy(lmono_ctx *c)
 {
     if (!c) return;
+#ifdef LMONO_BOUNDS
+    {
+        // the checked build reports when a context goes (a C++ caller -- estimator_seq -- has no other way to ask)
+        unsigned long long o[4] = { 0, 0, 0, 0 };
+        (void)hipDeviceSynchronize();
+        if (hipMemcpyFromSymbol(o, HIP_SYMBOL(g_ba_oob), sizeof(o)) == hipSuccess)
+            fprintf(stderr, "[lmono bounds] k_ba_solve: %llu access(es) outside the batch's allocation (first: ba_solve.hip:%llu, byte offset %lld, block %llu)\n", o[0], o[1], (long long)o[2], o[3]);
+    }
+#endif
     for (auto &s : c->sets) { for (auto &e : s.e) (void)hipEventDestroy(e); for (auto &e : s.kev) (void)hipEventDestroy(e); }
     if (c->stats_d) (void)hipFree(c->stats_d);
     for (auto &s : c->gstream) if (s) (void)hipStreamDestroy(s);
@@ -1357,6 +1366,7 @@ static int ba_fill(lmono_ctx *c, lmono_ba_batch *b, const lmono_ba_desc *d)
     v.laser_consts = laser; v.prior_T = prior; v.info = infod;
     v.feat_obs_off = fobs_d; v.slot_obs = oslot_d;
     v.seg_off = segoff_d; v.seg_tab = segtab_d; v.pair_seg = pseg_d; v.n_multi = nmulti_d;
+    v.blob_lo = b->blob; v.blob_hi = b->blob + pk.up + pk.zero;      // (the arrays of THIS fill: what lies behind them in a larger, re-used allocation is out of bounds too)
     return LMONO_OK;
 }
 
@@ -1412,6 +1422,23 @@ extern "C" int lmono_ba_solve(lmono_ctx *c, lmono_ba_batch *b, int max_iteration
         return check_launch(c, "k_ba_solve");
     }
     return ba_launch_single(c, b);
+}
+
+// Diagnostic: the bounds-checked build's record (-DLMONO_BOUNDS, lmono_amd/csrc/ba_solve.hip ba_chk): out[0] accesses of k_ba_solve outside the batch's
+// allocation since the library was loaded, out[1] source line of the first, out[2] its byte offset from the allocation's start, out[3] its block.
+// The product build has no checks and answers LMONO_EINVAL.
+extern "C" int lmono_debug_bounds(lmono_ctx *c, unsigned long long *out4)
+{
+    if (!c || !out4) return LMONO_EINVAL;
+#ifdef LMONO_BOUNDS
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_ba_oob), 4 * sizeof(unsigned long long)));
+    return LMONO_OK;
+#else
+    c->err = "lmono_debug_bounds: this build carries no bounds checks (build with -DLMONO_BOUNDS)";
+    return LMONO_EINVAL;
+#endif
 }
 
 extern "C" int lmono_ba_batch_reset(lmono_ctx *c, lmono_ba_batch *b)

@@ -1,0 +1,69 @@
+"""VERDICT r5 #6 (Weak #9: a GPU memory fault during round 5's cluster rewrite was never located): the bounds-checked build of the BA solve.
+`hipcc -DLMONO_BOUNDS` turns every global access of k_ba_solve into a checked one (lmono_amd/csrc/ba_solve.hip: ba_chk -- the batch lives in ONE device
+allocation, so "outside the allocation" is exactly what the GPU reports as a memory access fault); an access outside it is counted, its source line recorded, and
+redirected.  The checked library is built into a scratch directory (never over the in-tree one) and a fresh process runs the BA tests' problems through it:
+every cluster size, a window without projection factors, a constant extrinsic, a filling window, a large (kBig) window, 24 windows in clusters, update / reset /
+re-solve, the cluster that gives up, and 80 frames of the Estimator loop (C++ binary, LD_LIBRARY_PATH) -- zero hits."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def test_checked_build_of_the_ba_solve_sees_no_access_outside_the_batch(tmp_path):
+    lib = tmp_path / "liblmono_hip.so"
+    src = os.path.join(ROOT, "lmono_amd", "csrc", "lmono_hip.hip")
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-DLMONO_BOUNDS", "-o", str(lib), src],
+                       capture_output=True, text=True, timeout=900, cwd=os.path.dirname(src))
+    assert r.returncode == 0, r.stderr[-3000:]
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import numpy as np, lmono_amd\n"
+            "from tests import ba_cases as K\n"
+            "ctx = lmono_amd.Context(0)\n"
+            "ws = [K.make_window(s) for s in (30, 31, 32)]\n"
+            "ws[1]['use_mono'] = False; ws[2]['ex_constant'] = True\n"
+            "ws += [K.make_window(33, n_frames=5), K.make_window(34, n_landmarks=2500)]\n"
+            "big = K.make_window(50, n_landmarks=20000, max_tracks=560, min_dist=14)\n"
+            "many = [K.make_window(70 + (k * 5 + k // 6) %% 6) for k in range(24)]\n"
+            "ref = None\n"
+            "for k in (1, 2, 4, 8):\n"
+            "    ctx.set_option(ctx.OPT_BA_CLUSTER, k)\n"
+            "    b = lmono_amd.BaBatch(ctx, ws); b.solve(30); got = b.read()\n"
+            "    ref = ref or got\n"
+            "    assert all(a.tobytes() == c.tobytes() for a, c in zip(ref, got)), k\n"
+            "    b.update([big, ws[0]]); b.solve(30); b.read(); b.reset(); b.solve(5); b.read()\n"
+            "    b.update(many); b.solve(30); b.read()\n"
+            "ctx.set_option(ctx.OPT_BA_CLUSTER, 0)\n"
+            "b = lmono_amd.BaBatch(ctx, [K.make_window(s, n_landmarks=2500) for s in range(8)] * 32); b.solve(30); b.read()\n"
+            "print('BOUNDS', *ctx.debug_bounds())\n") % ROOT
+    env = dict(os.environ, LMONO_HIP_LIB=str(lib))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    hits = [ln for ln in out.stdout.splitlines() if ln.startswith("BOUNDS")][0].split()
+    assert int(hits[1]) == 0, "k_ba_solve touched memory outside its batch: first at ba_solve.hip:%s, offset %s, block %s (%s hits)" % (hits[2], hits[3], hits[4], hits[1])
+    # the cluster that gives up and is solved again (its retry runs the one-workgroup kernel over the same scratch)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(env, LMONO_BA_TEST_FAIL="1"), cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert int([ln for ln in out.stdout.splitlines() if ln.startswith("BOUNDS")][0].split()[1]) == 0
+    # the Estimator loop (C++ host mirror): the checked library is found through LD_LIBRARY_PATH and reports when its contexts go
+    from tests import estimator_stream as S
+    from workloads import s2
+    st = s2.make_stream(80, seed=2, stops=(40, 41))
+    fx = tmp_path / "s.bin"
+    S.write_stream(fx, st, [])
+    exe = os.path.join(ROOT, "lmono_amd", "host", "estimator_seq")
+    for args in ([str(fx), "-", "async"], [str(fx), "-", "async", "streams=12", "digest"]):
+        out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600, env=dict(os.environ, LD_LIBRARY_PATH=str(tmp_path) + ":" + os.environ.get("LD_LIBRARY_PATH", "")))
+        assert out.returncode == 0, out.stderr[-2000:]
+        rep = [ln for ln in out.stderr.splitlines() if ln.startswith("[lmono bounds]")]
+        assert rep, "the checked library was not the one loaded:\n" + out.stderr[-1000:]
+        assert all(" 0 access(es)" in ln for ln in rep), rep
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "bounds_checked_ba_solve.txt"), "w") as fh:
+        fh.write("bounds-checked build (-DLMONO_BOUNDS) of k_ba_solve: K = 1 / 2 / 4 / 8 over 5 mixed windows, an 870-feature window, 24 windows in clusters, 256 windows, update / reset, "
+                 "the give-up retry, 80 frames of the Estimator loop (1 and 12 streams): 0 accesses outside the batch's allocation\n" + "\n".join(rep) + "\n")
