@@ -1052,9 +1052,12 @@ __device__ __noinline__ void ba_hs_mul(const BaCtx c, BaLds &L_arg, const BaBig 
     BA_TICK(4)
     for (int k = tid; k < N; k += kBaT) BA_V(gn, k) = BA_V(scale, k) * BA_V(va, k);
     __syncthreads();
-    // camera rows: wave w sums the features f = w (mod 8); lanes own the parameter columns (coalesced 640-B rows),
-    // eight feature rows in flight
+    // ONE pass over the coupling rows (round 6: the camera rows and the depth rows each read all of them -- 2 x 275 KB per product for a 430-feature
+    // window, a quarter of what the batched solve moves through HBM): wave w takes the features f = w (mod 8), lanes own the parameter columns
+    // (coalesced 640-B rows), eight rows in flight.  A row's share of the camera rows is row x (feature's entry of the vector); its own depth row is the
+    // dot product of the row with the pose part of the vector, summed over the wave (DPP row steps; the eight sums of a round are independent chains).
     {
+        const double gp0 = lane < P ? BA_V(gn, lane) : 0.0, gp1 = 64 + lane < P ? BA_V(gn, 64 + lane) : 0.0;
         double a0 = 0, a1 = 0;
         for (int f = wave; f < F; f += 8 * kBaW) {
             double r0[8], r1[8];
@@ -1062,31 +1065,20 @@ __device__ __noinline__ void ba_hs_mul(const BaCtx c, BaLds &L_arg, const BaBig 
             for (int u = 0; u < 8; u++) {
                 const int fu = f + kBaW * u;
                 const double *row = hpd + (size_t)fu * kBaPS;
-                r0[u] = fu < F ? gld(row + lane) : 0.0;
-                r1[u] = (fu < F && lane < kBaPS - 64) ? gld(row + 64 + lane) : 0.0;
+                r0[u] = (fu < F && lane < P) ? gld(row + lane) : 0.0;
+                r1[u] = (fu < F && 64 + lane < P) ? gld(row + 64 + lane) : 0.0;
             }
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const int fu = f + kBaW * u;
                 const double w = fu < F ? BA_V(gn, P + fu) : 0.0;
                 a0 += r0[u] * w; a1 += r1[u] * w;
+                const double dot = wave_sum_d_lane63(r0[u] * gp0 + r1[u] * gp1);
+                if (lane == 63 && fu < F) BA_V(vb, P + fu) = (dot + BA_F(Hdd, fu) * w) * BA_V(scale, P + fu);
             }
         }
         L.u.hs_part[wave][lane] = a0;
         if (lane < kBaPS - 64) L.u.hs_part[wave][64 + lane] = a1;
-    }
-    // depth rows: four lanes per feature, the 18 entries of a lane requested together
-    for (int f = tid >> 2; f < F; f += kBaT / 4) {
-        const double *row = hpd + (size_t)f * kBaPS;
-        double rv[18];
-#pragma unroll
-        for (int k = 0; k < 18; k++) { const int a = (tid & 3) + 4 * k; rv[k] = a < P ? gld(row + a) : 0.0; }
-        double acc = 0;
-#pragma unroll
-        for (int k = 0; k < 18; k++) { const int a = (tid & 3) + 4 * k; acc += rv[k] * (a < P ? BA_V(gn, a) : 0.0); }
-        acc += __shfl_xor(acc, 1);
-        acc += __shfl_xor(acc, 2);
-        if ((tid & 3) == 0) BA_V(vb, P + f) = (acc + BA_F(Hdd, f) * BA_V(gn, P + f)) * BA_V(scale, P + f);
     }
     __syncthreads();
     if (tid < P) {

@@ -2435,11 +2435,13 @@ static int mapper_process_dev(lmono_ctx *c, lmono_mapper *m, lmono_scan_batch *b
         }
     }
     HIP_TRY(c, hipEventRecord(m->ev_solve, st));
-    // the read-back leaves on the side stream (the main stream goes straight on): [x | stats | bar | n_stack | n_map] of the frame, [bump | err | . | last_sum] of the map
+    // the read-back leaves on the side stream (the main stream goes straight on): [x | stats | bar | n_stack | n_map | snap] of the frame -- snap = the map's
+    // [bump | err | . | last_sum] as k_map_plan_gather copied them at the head of this frame (the live words are rewritten by this frame's own
+    // update on the main stream while the side stream reads; the snapshot is the previous update's, whole, as the header promises for stats[7])
     constexpr size_t kBackA = sizeof(double) * 8 + sizeof(int) * 8 + sizeof(unsigned int) * 16 + sizeof(int) * 4;
+    static_assert(offsetof(MapFrame, snap) == kBackA, "the frame's read-back is one copy: x .. snap");
     HIP_TRY(c, hipStreamWaitEvent(side, m->ev_solve, 0));
-    HIP_TRY(c, hipMemcpyAsync(m->pin_back, blob, kBackA, hipMemcpyDeviceToHost, side));
-    HIP_TRY(c, hipMemcpyAsync(m->pin_back + kBackA, &m->dev->bump[0], sizeof(int) * 6, hipMemcpyDeviceToHost, side));
+    HIP_TRY(c, hipMemcpyAsync(m->pin_back, blob, kBackA + sizeof(int) * 6, hipMemcpyDeviceToHost, side));
     HIP_TRY(c, hipEventRecord(m->ev_pose, side));
     // ---- main stream: the scan joins the map
     {

@@ -548,38 +548,62 @@ __device__ __forceinline__ void map_evaluate(const MapRec *rec, int n_edge, int 
         Rm[3] = 2.0 * (ux * uy + w * uz);       Rm[4] = 1.0 - 2.0 * (ux * ux + uz * uz); Rm[5] = 2.0 * (uy * uz - w * ux);
         Rm[6] = 2.0 * (ux * uz - w * uy);       Rm[7] = 2.0 * (uy * uz + w * ux);       Rm[8] = 1.0 - 2.0 * (ux * ux + uy * uy);
     }
-    // chunks of kMsT consecutive blocks are dealt to the cluster's workgroups in turn
-    for (int q0 = cl.rank * kMsT; q0 < nq; q0 += cl.K * kMsT) {
-        const int qi = q0 + tid;
-        if (qi >= nq) break;
-        if (qi < n_edge) map_eval_block<kJac, true>(rec[qi], Rm, x, acc);
-        else map_eval_block<kJac, false>(rec[qi], Rm, x, acc);
-    }
-    acc.cost = wave_sum_d_lane63(acc.cost);
-    if (kJac) {
-#pragma unroll
-        for (int i = 0; i < 21; i++) acc.H[i] = wave_sum_d_lane63(acc.H[i]);
-#pragma unroll
-        for (int i = 0; i < 6; i++) acc.g[i] = wave_sum_d_lane63(acc.g[i]);
-    }
-    __syncthreads();
-    if (lane == 63) {
-        s_red[wave][27] = acc.cost;
+    // The blocks are dealt in chunks of kMsT to kMsMaxK = 8 VIRTUAL ranks in turn, whatever the cluster size is (round 6): virtual rank v
+    // sums the chunks v, v + 8, .. -- one block per thread and chunk, the thread's blocks in ascending order, the wave by DPP, the waves in wave order --
+    // and the evaluation's sums are the eight virtual ranks' added in rank order.  A workgroup of a K-cluster computes the virtual ranks rank, rank + K, ..
+    // one after the other, so the BYTES of a stream's solve depend on the stream alone -- not on K, i.e. not on how many other streams share the call
+    // (rounds 4-5 split the blocks by the REAL rank: a stream's rounding changed with the batch it travelled in, bounded at 1e-12).  K = 8 (one stream)
+    // does exactly the work it did; K = 1 (64+ streams) pays seven more reductions per evaluation.
+    __shared__ double s_vp[kMsMaxK][28];
+    for (int v = cl.rank; v < kMsMaxK; v += cl.K) {
+        acc.cost = 0.0;
         if (kJac) {
-            for (int i = 0; i < 21; i++) s_red[wave][i] = acc.H[i];
-            for (int i = 0; i < 6; i++) s_red[wave][21 + i] = acc.g[i];
+#pragma unroll
+            for (int i = 0; i < 21; i++) acc.H[i] = 0.0;
+#pragma unroll
+            for (int i = 0; i < 6; i++) acc.g[i] = 0.0;
+        }
+        for (int q0 = v * kMsT; q0 < nq; q0 += kMsMaxK * kMsT) {
+            const int qi = q0 + tid;
+            if (qi >= nq) break;
+            if (qi < n_edge) map_eval_block<kJac, true>(rec[qi], Rm, x, acc);
+            else map_eval_block<kJac, false>(rec[qi], Rm, x, acc);
+        }
+        acc.cost = wave_sum_d_lane63(acc.cost);
+        if (kJac) {
+#pragma unroll
+            for (int i = 0; i < 21; i++) acc.H[i] = wave_sum_d_lane63(acc.H[i]);
+#pragma unroll
+            for (int i = 0; i < 6; i++) acc.g[i] = wave_sum_d_lane63(acc.g[i]);
+        }
+        __syncthreads();
+        if (lane == 63) {
+            s_red[wave][27] = acc.cost;
+            if (kJac) {
+                for (int i = 0; i < 21; i++) s_red[wave][i] = acc.H[i];
+                for (int i = 0; i < 6; i++) s_red[wave][21 + i] = acc.g[i];
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const bool mine = tid < 28 && (kJac || tid == 27);
+            double t = 0.0;
+            if (mine) for (int w = 0; w < kMsT / 64; w++) t += s_red[w][tid];
+            if (mine) { if (cl.K > 1) cl.part[(cl.eval * kMsMaxK + v) * 28 + tid] = t; else s_vp[v][tid] = t; }
         }
     }
-    __syncthreads();
     if (wave == 0) {
         const bool mine = tid < 28 && (kJac || tid == 27);
         double t = 0.0;
-        if (mine) for (int w = 0; w < kMsT / 64; w++) t += s_red[w][tid];
         if (cl.K > 1) {
-            if (mine) cl.part[(cl.eval * cl.K + cl.rank) * 28 + tid] = t;
             ms_cluster_barrier_wave0(cl);
-            t = 0.0;
-            if (mine) for (int w = 0; w < cl.K; w++) t += cl.part[(cl.eval * cl.K + w) * 28 + tid];
+            if (mine) for (int v = 0; v < kMsMaxK; v++) t += cl.part[(cl.eval * kMsMaxK + v) * 28 + tid];
+        } else {
+            // (wave 0 wrote s_vp itself: its LDS operations execute in order)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (mine) for (int v = 0; v < kMsMaxK; v++) t += s_vp[v][tid];
         }
         if (mine) s_sum[tid] = t;
     }
@@ -731,8 +755,8 @@ __global__ __launch_bounds__(kMsT) void k_map_solve(const MapStream *streams, in
 
 // workgroups per stream: K = 8 (measured best for one stream, below), lowered until clusters x K stay within half the chip's 256 CUs -- every workgroup
 // of a cluster must be resident while it spins; the spin is bounded (a cluster that is not resident sets stats[6] and the host returns LMONO_ENODEV).
-// A stream's partial sums are split by K, so its pose depends at rounding level (1e-12, tests/test_mapping_gpu.py::test_solve_cluster_sizes_agree) on
-// how many streams share the call; the budget assumes the card is not shared with another process's resident workgroups.
+// A stream's sums are formed per VIRTUAL rank (always eight, map_evaluate), so its bytes do not depend on K -- on how many streams share the call
+// (tests/test_mapping_gpu.py::test_solve_cluster_sizes_agree: byte equality since round 6); the budget comes from the device's CU count (lmono_ctx::map_budget).
 static inline int map_solve_cluster(int n_streams, int budget)
 {
     static const int forced = [] { const char *e = getenv("LMONO_MAP_SOLVE_K"); return e ? atoi(e) : 0; }();        // measurement switch
@@ -1304,6 +1328,9 @@ struct MapFrame {                            // one per frame, uploaded by the h
     unsigned int bar[16];
     int n_stack[2];                          // the scan filter's counts
     int n_map[2];                            // out: sizes of the neighbourhood clouds
+    int snap[6];                             // out: the map's bump[2] | err | n_gjobs | last_sum[2] as k_map_plan_gather found them -- behind the previous frame's commit,
+                                             // before this frame's update: the read-back of a frame takes THIS copy (x .. snap: one read-back), not the live words the
+                                             // same frame's k_map_plan_update / k_map_commit are about to rewrite
     int cen[3], n_valid;
     int valid[kMdValidMax + 1];
 };
@@ -1370,6 +1397,10 @@ __global__ __launch_bounds__(192) void k_map_plan_gather(MapDevCfg cfg)
     }
     __syncthreads();
     const bool over = s_tot[0][0] > kMdNeighMax || s_tot[1][0] > kMdNeighMax;       // refused: the frame runs on an empty neighbourhood and reports it
+    if (tid >= 128 && tid < 134) {           // (this kernel runs behind the previous commit on the main stream: the words are that update's, whole)
+        const int k = tid - 128;
+        cfg.frame->snap[k] = k < 2 ? dev->bump[k] : k == 2 ? dev->err : k == 3 ? dev->n_gjobs : dev->last_sum[k - 4];
+    }
     if (tid < 2) {
         const int at = over ? 0 : s_tot[tid][0];
         dev->cj[tid].n = at;
