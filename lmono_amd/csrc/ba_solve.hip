@@ -47,6 +47,7 @@ constexpr int kBaSeg = 16;                       // observations of a segment: a
 constexpr int kBaMaxSeg = kBaMaxPairs + kBaLdsFeat * (kBaMaxPoses - 1) / kBaSeg;      // 110 + 280 (segments whose table lives in LDS; kBig reads the table from HBM)
 constexpr int kBaMbox = 96 + kBaMaxFeat;         // leader -> followers: [0] command, [1] re-use the records, [8..84] poses, [88..94] extrinsic, [96..] inverse depths
 constexpr int kBaMaxK = 8;                       // workgroups per window
+constexpr int kBaBar = 32;                       // flag words per window: [0] go, [r] follower r's "segments done", [8] the leader's, [8 + r] follower r's "sums done", [16 + r] its XCD + 1
 // ba_reduce_pairs' gather program (built once per solve: which tile cells an entry of H_pp / g_p is the sum of does not change between iterations):
 // part A = the 36 entries of every lower frame-block pair (two sources, written twice: the tiles are symmetric), part B = per frame the 21 lower
 // entries of its diagonal block, its 36 entries against the extrinsic and its 6 gradient entries (22 sources: the pairs (f, k), then the pairs (k, f))
@@ -55,6 +56,9 @@ constexpr int kBaGbN = 704;                      // part B items (11 frames x 63
 constexpr int kBaGprog = 4 * kBaGaN + 24 * kBaGbN;
 constexpr int kBaObsRec = 24;                    // per-observation record: hdd, gd, hx[6], hi[6], hj[6], oj
 constexpr int kBaT = 512;                        // threads per workgroup (2 waves per SIMD)
+#ifndef LMONO_BA_HS_FUSED
+#define LMONO_BA_HS_FUSED 1                      // the H s product reads the coupling rows once (1) or once for the camera rows and once for the depth rows (0: rounds 1-5)
+#endif
 constexpr int kBaW = kBaT / 64;
 
 typedef double ba_d4 __attribute__((ext_vector_type(4)));
@@ -94,6 +98,8 @@ struct BaBatch {
     // several workgroups per window (k_ba_solve<true>): the leader's mail box [W][kBaMbox] (command, state to evaluate), flag words [W][16]
     // (go, done of every follower; zeroed before every launch), a failure flag; pairdat then holds one copy per workgroup of a window
     int *gprog;                 // scratch [W][kBaGprog]: every window's gather program (see kBaGaN)
+    double *hred;               // scratch [W][kBaHred]: H_pp | g_p of a linearisation whose ordered sums the cluster's workgroups share (ba_reduce_pairs)
+    double *fdg;                // scratch [W][2][feat_cap]: H_ff | g_f likewise (LDS-resident windows; a kBig window's live in bigv anyway)
     int feat_cap;               // stride of the per-window feature arrays hpd / cand / mbox: kBaLdsFeat, or kBaMaxFeat when a window of the batch is larger
     double *bigv;               // scratch [W][8][kBaMaxFeat] (kBig only): H_ff, g_f and the feature part of scale, D, gs, gn, va, vb
     double *mbox;
@@ -142,6 +148,7 @@ struct BaLds {
     signed char fanchor[kBaLdsFeat];             // the frame a feature is anchored in (-1: no observation)
     int ok;
     int eval_no, failed;        // several workgroups per window: evaluations handed out so far; a workgroup did not arrive
+    int coloc;                  // the leader's: -1 unknown, 1 every workgroup of the cluster runs on the leader's XCD (then they share the ordered sums), 0 not
 #ifdef LMONO_BA_PROF
     unsigned long long prof[24];
 #endif
@@ -491,90 +498,75 @@ __device__ __forceinline__ void ba_prior_accumulate_wave(const BaCtx &c, BaLds &
 // by one thread, which adds the tiles that touch it in a fixed order -- a pair's segments in segment order, then the pairs (f, j) by ascending j and
 // the pairs (i, f) by ascending i for an entry of frame f's rows / columns; all segments by index for the extrinsic block -- so the sums are the same
 // bits in every run whatever the waves' timing was and whoever computed a segment.  Entries nothing touches become zero: the pass replaces clearing H_pp.
-template <bool kCl>
-__device__ __forceinline__ void ba_reduce_pairs(const BaBatch &B, const BaCtx c, BaLds &L)
+// Round 6: WHO forms an entry does not change it either, so the entries CAN be dealt to the workgroups of a window's cluster (part of nparts: the gather
+// program's items in turn, the extrinsic block to the last part; VERDICT r5 #2a) instead of the leader forming all of them while the followers wait.
+// Out: where an entry goes -- the leader's LDS when one workgroup forms them all, the window's row of B.hred (72 x 72 + 72 doubles, L2) when the cluster
+// shares them; the leader then loads the row in one sweep.  Built, byte-identical (the K = 1 / 2 / 4 / 8 tests ran on it), and MEASURED SLOWER: single
+// window 3.44 -> 3.51 ms, Estimator loop 393 -> 372 frames/s.  The pass is a chain of three dependent L2 round trips (program words -> tile cells -> the
+// other segments of a pair) whatever the share is, so a smaller share does not end sooner, and sharing adds two flag hand-offs and the leader's read-back
+// of 5.3 k doubles per linearisation.  Kept behind LMONO_BA_SHARE_SUMS=1 (default off: the leader forms every entry).
+struct BaOutLds {
+    BaLds &L;
+    __device__ __forceinline__ void put(int dst, double v) const { if (dst >= kBaP * kBaP) L.gp[dst - kBaP * kBaP] = v; else L.Hpp[dst] = v; }
+};
+template <bool kSc> struct BaOutGlob {
+    double *h;
+    __device__ __forceinline__ void put(int dst, double v) const { st_sh<kSc>(h + dst, v); }
+};
+constexpr int kBaHred = kBaP * kBaP + kBaP;
+template <bool kCl, class Out>
+__device__ __forceinline__ void ba_reduce_pairs(const BaBatch &B, const BaCtx c, BaLds &L, const Out out, int part, int nparts)
 {
-    const int tid = threadIdx.x, np_ = c.n_poses;
-    // the window's tiles: one per segment, then one per pair (used by the pairs of several segments)
+    const int tid = threadIdx.x;
+    // the window's tiles: one per segment
     double *tiles = B.pairH + (size_t)(c.sg0 + c.pp0 + c.win) * kBaPairTile;
-    double *ptile = tiles + (size_t)c.n_seg * kBaPairTile;
-    // (0) pairs of several segments (they come first: the pairs are sorted by size): their tiles summed in segment order into the pair's own tile
-    if (c.n_multi > 0) {
-        constexpr int kE = 4;                                   // entries per thread and turn
-        for (int e0 = tid; e0 < c.n_multi * kBaPairTile; e0 += kE * kBaT) {
-            double acc[kE];
-            int pe[kE], s0[kE], s1[kE], smax = 0;
-#pragma unroll
-            for (int u = 0; u < kE; u++) {
-                const int e = e0 + u * kBaT;
-                const bool in = e < c.n_multi * kBaPairTile;
-                pe[u] = in ? e : -1;
-                const int pq = in ? e / kBaPairTile : 0;
-                s0[u] = L.pair_seg[pq]; s1[u] = in ? (int)L.pair_seg[pq + 1] : s0[u];
-                smax = max(smax, s1[u] - s0[u]);
-                acc[u] = 0.0;
-            }
-            // eight segments of each entry in flight (a pair of up to 128 observations in one trip)
-            for (int b = 0; b < smax; b += 8) {
-                double v[kE][8];
-#pragma unroll
-                for (int u = 0; u < kE; u++)
-#pragma unroll
-                    for (int d = 0; d < 8; d++) {
-                        const int sgm = s0[u] + b + d;
-                        v[u][d] = sgm < s1[u] ? ld_sh<kCl>(tiles + (size_t)sgm * kBaPairTile + (pe[u] % kBaPairTile)) : 0.0;
-                    }
-#pragma unroll
-                for (int u = 0; u < kE; u++)
-#pragma unroll
-                    for (int d = 0; d < 8; d++) acc[u] += v[u][d];
-            }
-#pragma unroll
-            for (int u = 0; u < kE; u++) if (pe[u] >= 0) st_sh<kCl>(ptile + pe[u], acc[u]);
-        }
-        if (kCl) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
     // (A), (B): the entries of H_pp and g_p that are sums over frame pairs, by the window's gather program (ba_setup: the cells an entry is the sum of are
     // the same in every iteration; looking them up anew -- pair tables in LDS, 64-bit address arithmetic, a branch per source -- was 400 instructions
-    // per entry).  An absent source points at the window's tile of zeros.  Part A: the two pairs that can hold a block of two different frames;
-    // part B: the pairs (f, k) by ascending k, then the pairs (k, f), for the entries of ONE frame f.  Sums in the order they always had.
+    // per entry).  A source is a frame PAIR: (position in its first segment's tile) | (segments << 20); the pair's value is the sum of its segments' tiles in
+    // segment order, formed here, inline (round 6: a separate pass used to pre-sum the pairs of several segments into tiles of their own -- one more trip
+    // through the L2 and a workgroup barrier per linearisation; same sums in the same order); an absent source (0 segments) counts as zero.
+    // Part A: the two pairs that can hold a block of two different frames; part B: the pairs (f, k) by ascending k, then the pairs (k, f), for the entries
+    // of ONE frame f.
     const int x0 = c.ex_off;                                   // first extrinsic index (-1: extrinsic constant)
     const int *gp = B.gprog + (size_t)c.win * kBaGprog;
-    {
+    auto pair_value = [&](int src, double first) {             // first = the entry of the pair's first segment (requested with everybody's); the rest in order
+        const int cnt = src >> 20;
+        const double *t0 = tiles + (src & 0xfffff);
+        for (int sgi = 1; sgi < cnt; sgi++) first += ld_sh<kCl>(t0 + (size_t)sgi * kBaPairTile);
+        return first;
+    };
+    for (int a0 = part * kBaT * 4; a0 < kBaGaN; a0 += nparts * kBaT * 4) {
         int o1[4], o2[4], d1[4], d2[4];
         double v1[4], v2[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const int a = tid + u * kBaT;
-            o1[u] = gldi(gp + a); o2[u] = gldi(gp + kBaGaN + a); d1[u] = gldi(gp + 2 * kBaGaN + a); d2[u] = gldi(gp + 3 * kBaGaN + a);
+            const int a = a0 + tid + u * kBaT;
+            const bool in = a < kBaGaN;
+            o1[u] = in ? gldi(gp + a) : 0; o2[u] = in ? gldi(gp + kBaGaN + a) : 0; d1[u] = in ? gldi(gp + 2 * kBaGaN + a) : -1; d2[u] = in ? gldi(gp + 3 * kBaGaN + a) : -1;
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) { v1[u] = ld_sh<kCl>(tiles + o1[u]); v2[u] = ld_sh<kCl>(tiles + o2[u]); }
+        for (int u = 0; u < 4; u++) { v1[u] = (o1[u] >> 20) ? ld_sh<kCl>(tiles + (o1[u] & 0xfffff)) : 0.0; v2[u] = (o2[u] >> 20) ? ld_sh<kCl>(tiles + (o2[u] & 0xfffff)) : 0.0; }
 #pragma unroll
-        for (int u = 0; u < 4; u++) if (d1[u] >= 0) { const double sum = v1[u] + v2[u]; L.Hpp[d1[u]] = sum; L.Hpp[d2[u]] = sum; }
+        for (int u = 0; u < 4; u++) if (d1[u] >= 0) { const double sum = pair_value(o1[u], v1[u]) + pair_value(o2[u], v2[u]); out.put(d1[u], sum); out.put(d2[u], sum); }
     }
     const int *gb = gp + 4 * kBaGaN;
-    for (int t = tid; t < kBaGbN; t += kBaT) {
+    for (int t = part * kBaT + tid; t < kBaGbN; t += nparts * kBaT) {
         int off[22];
         double v[22];
 #pragma unroll
         for (int k = 0; k < 22; k++) off[k] = gldi(gb + k * kBaGbN + t);
         const int dst = gldi(gb + 22 * kBaGbN + t), dst2 = gldi(gb + 23 * kBaGbN + t);
 #pragma unroll
-        for (int k = 0; k < 22; k++) v[k] = ld_sh<kCl>(tiles + off[k]);
+        for (int k = 0; k < 22; k++) v[k] = (off[k] >> 20) ? ld_sh<kCl>(tiles + (off[k] & 0xfffff)) : 0.0;
         double acc = 0.0;
 #pragma unroll
-        for (int k = 0; k < 22; k++) acc += v[k];
-        if (dst >= kBaP * kBaP) L.gp[dst - kBaP * kBaP] = acc;
-        else if (dst >= 0) { L.Hpp[dst] = acc; if (dst2 >= 0) L.Hpp[dst2] = acc; }
+        for (int k = 0; k < 22; k++) acc += pair_value(off[k], v[k]);
+        if (dst >= 0) { out.put(dst, acc); if (dst2 >= 0) out.put(dst2, acc); }
     }
     // (C) the extrinsic block and gradient get a share from EVERY segment: 33 values per segment (rows 12..15 of the tile and of the side tile, and
     //     the five scalar sums of the (4..5, 4..5) corner); 15 threads per value add the segments s = g (mod 15) in ascending order into L.D (dead during
-    //     a linearisation), one thread per value then adds the 15 in order
-    if (x0 >= 0) {
+    //     a linearisation; every workgroup of a cluster has its own), one thread per value then adds the 15 in order.  The last part's.
+    if (x0 >= 0 && part == nparts - 1) {
         constexpr int kG = 15;
         if (tid < 33 * kG) {
             const int e = tid % 33, g = tid / 33;
@@ -597,18 +589,18 @@ __device__ __forceinline__ void ba_reduce_pairs(const BaBatch &B, const BaCtx c,
             double tot = 0.0;
 #pragma unroll
             for (int g = 0; g < kG; g++) tot += L.D[g * 33 + tid];
-            const int e = tid, x4 = x0 + 4, x5 = x0 + 5;
-            if (e < 16) L.Hpp[(x0 + e / 4) * kBaP + x0 + e % 4] = tot;
+            const int e = tid, x4 = x0 + 4, x5 = x0 + 5, G0 = kBaP * kBaP;
+            if (e < 16) out.put((x0 + e / 4) * kBaP + x0 + e % 4, tot);
             else if (e < 28) {
                 const int om = (e - 16) / 3, cc = (e - 16) % 3;
-                if (cc < 2) { L.Hpp[(x0 + om) * kBaP + x4 + cc] = tot; L.Hpp[(x4 + cc) * kBaP + x0 + om] = tot; }
-                else L.gp[x0 + om] = tot;
+                if (cc < 2) { out.put((x0 + om) * kBaP + x4 + cc, tot); out.put((x4 + cc) * kBaP + x0 + om, tot); }
+                else out.put(G0 + x0 + om, tot);
             }
-            else if (e == 28) L.Hpp[x4 * kBaP + x4] = tot;
-            else if (e == 29) { L.Hpp[x4 * kBaP + x5] = tot; L.Hpp[x5 * kBaP + x4] = tot; }
-            else if (e == 30) L.Hpp[x5 * kBaP + x5] = tot;
-            else if (e == 31) L.gp[x4] = tot;
-            else L.gp[x5] = tot;
+            else if (e == 28) out.put(x4 * kBaP + x4, tot);
+            else if (e == 29) { out.put(x4 * kBaP + x5, tot); out.put(x5 * kBaP + x4, tot); }
+            else if (e == 30) out.put(x5 * kBaP + x5, tot);
+            else if (e == 31) out.put(G0 + x4, tot);
+            else out.put(G0 + x5, tot);
         }
     }
     __syncthreads();
@@ -691,11 +683,11 @@ __device__ __forceinline__ void ba_pair_records(const BaCtx &c, BaLds &L, const 
 __device__ __forceinline__ void ba_publish(const BaBatch &B, const BaCtx &c, BaLds &L, int cmd, const double *poses, const double *ex, const double *invd, bool reuse)
 {
     const int tid = threadIdx.x;
-    unsigned int *flags = B.bar + (size_t)c.win * 16;
+    unsigned int *flags = B.bar + (size_t)c.win * kBaBar;
     if (tid < 64 && L.eval_no > 0 && !L.failed) { if (!ba_wait_flags(flags + 1, c.K - 1, (unsigned int)L.eval_no, B.fail) && tid == 0) L.failed = 1; }
     __syncthreads();
     double *mb = B.mbox + (size_t)c.win * kBaMbox;
-    if (tid == 0) { st_sh<true>(mb, (double)cmd); st_sh<true>(mb + 1, reuse ? 1.0 : 0.0); st_sh<true>(mb + 2, (double)ba_xcc_id()); }
+    if (tid == 0) { st_sh<true>(mb, (double)cmd); st_sh<true>(mb + 1, reuse ? 1.0 : 0.0); st_sh<true>(mb + 2, (double)ba_xcc_id()); st_sh<true>(mb + 3, (cmd == 1 && L.coloc == 1) ? 1.0 : 0.0); }
     if (!reuse && cmd != 3) {
         for (int k = tid; k < 7 * c.n_poses; k += kBaT) st_sh<true>(mb + 8 + k, poses[k]);
         if (tid < 7) st_sh<true>(mb + 88 + tid, ex[tid]);
@@ -711,7 +703,7 @@ __device__ __forceinline__ void ba_done(const BaBatch &B, const BaCtx &c, BaLds 
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    unsigned int *flags = B.bar + (size_t)c.win * 16;
+    unsigned int *flags = B.bar + (size_t)c.win * kBaBar;
     if (kLeader) {
         if (threadIdx.x < 64 && !L.failed) { if (!ba_wait_flags(flags + 1, c.K - 1, (unsigned int)(L.eval_no + 1), B.fail) && threadIdx.x == 0) L.failed = 1; }
         __syncthreads();
@@ -912,6 +904,57 @@ __device__ __forceinline__ void ba_segments(const BaBatch &B, const BaCtx &c, Ba
     }
 }
 
+// H_ff, g_f and the coupling rows from the observations' records, the features / observations f = part (mod nparts) of them: 16 lanes per feature, lane k
+// sums entry k of the feature's observation records (contiguous, at most 10: one per other frame of the window) in observation order; the loads are
+// independent and requested together.  kGlob: H_ff / g_f of an LDS-resident window go to the window's row of B.fdg (the cluster shares the pass; the leader
+// loads them), else to the leader's LDS (kBig: the L2 scratch either way).
+template <bool kCl, bool kBig, bool kGlob>
+__device__ __forceinline__ void ba_feature_pass(const BaBatch &B, const BaCtx &c, BaLds &L, const BaBig &G, double *hpd, int part, int nparts)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double *fd = B.fdg + (size_t)c.win * 2 * B.feat_cap;
+    {
+        const int k = lane & 15, t8 = wave * 4 + (lane >> 4);
+        for (int f = part * 4 * kBaW + t8; f < c.F; f += nparts * 4 * kBaW) {
+            const int o0 = c.o0 + BA_FOBS(f), o1 = c.o0 + BA_FOBS(f + 1);
+            double acc = 0.0;
+            for (int ob = o0; ob < o1; ob += 10) {
+                double v[10];
+#pragma unroll
+                for (int u = 0; u < 10; u++) v[u] = ob + u < o1 ? ld_sh<kCl>(B.obsc + (size_t)(ob + u) * kBaObsRec + k) : 0.0;
+#pragma unroll
+                for (int u = 0; u < 10; u++) acc += v[u];
+            }
+            if (k == 0) { if (kGlob && !kBig) st_sh<true>(fd + f, acc); else BA_F(Hdd, f) = acc; }
+            else if (k == 1) { if (kGlob && !kBig) st_sh<true>(fd + B.feat_cap + f, acc); else BA_F(gdd, f) = acc; }
+            else if (k < 14) {
+                double *hrow = hpd + (size_t)f * kBaPS;
+                if (k < 8) { if (c.ex_off >= 0) gst(hrow + c.ex_off + k - 2, acc); }
+                else { const int anchor = BA_FANCHOR(f); if (anchor >= 0) gst(hrow + ba_pose_off(c, anchor) + k - 8, acc); }
+            }
+        }
+        // frame j's share of a coupling row (frame j sees a feature once) moves from the observation's record to its place: 8 lanes per observation, four
+        // observations of a lane in flight
+        const int n_obs = c.use_mono ? BA_FOBS(c.F) : 0;
+        const int kk = tid & 7;
+        for (int ob0 = part * 4 * (kBaT / 8) + (tid >> 3); ob0 < n_obs; ob0 += nparts * 4 * (kBaT / 8)) {
+            double vj[4], vo[4], vf[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int ob = ob0 + u * (kBaT / 8);
+                const double *rc = B.obsc + (size_t)(c.o0 + (ob < n_obs ? ob : ob0)) * kBaObsRec;
+                vj[u] = ld_sh<kCl>(rc + 14 + (kk < 6 ? kk : 0)); vo[u] = ld_sh<kCl>(rc + 20); vf[u] = ld_sh<kCl>(rc + 21);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int ob = ob0 + u * (kBaT / 8);
+                // (an observation outside the problem -- a feature below the track count -- has no record: its cells hold zeros and oj = 0 marks it)
+                if (ob < n_obs && kk < 6 && vo[u] > 0.0) gst(hpd + (size_t)(int)vf[u] * kBaPS + (int)vo[u] - 1 + kk, vj[u]);
+            }
+        }
+    }
+}
+
 // cost (returned to every thread) and, when kJac, the unscaled normal equations: Hpp, gp, Hdd, gdd in LDS, Hpd in HBM -- the LEADER's view of an
 // evaluation (with several workgroups per window the others run ba_follow).
 // records_valid: the pose matrices, the inverse depths in LDS and the pair records in HBM were computed by the previous call for the SAME parameter
@@ -968,58 +1011,59 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
     ba_segments<true, false, kBig>(B, c, L, G, ex, pairdat);          // (the leader's own records: plain stores; it reads them back from the L2 like everybody's)
     BA_TOCK(1)
     BA_TICK(11)
-    if (kCl) ba_done<true>(B, c, L);                             // every workgroup's segment and observation records are written
+    // the cluster shares the ordered sums of this linearisation when all its workgroups sit on the leader's XCD (known from the second linearisation on)
+    const bool shared = kCl && L.coloc == 1;
+    if (kCl) {
+        if (shared) {
+            // the leader's own records are out: its "segments done" word lets the followers start on their shares of the sums
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) ba_flag_store(B.bar + (size_t)c.win * kBaBar + 8, (unsigned int)(L.eval_no + 1));
+        }
+        ba_done<true>(B, c, L);                                  // every workgroup's segment and observation records are written
+        if (L.coloc < 0) {
+            // where the followers run: each left its XCD + 1 in its word before it answered the first linearisation
+            __syncthreads();
+            if (tid == 0) {
+                const unsigned int *fl = B.bar + (size_t)c.win * kBaBar;
+                const unsigned int mine = (unsigned int)ba_xcc_id() + 1u;
+                int same = 1;
+                for (int r = 1; r < c.K; r++) if (ba_flag_load(fl + 16 + r) != mine) same = 0;
+                static_assert(kBaMaxK <= 8, "flag words 16 + r");
+                L.coloc = same;
+            }
+            __syncthreads();
+        }
+    }
     else {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // the segment and observation records are written
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");       // ... and read below by other waves: drop this CU's L1 copies
     }
     BA_TICK(12)
-    ba_reduce_pairs<kCl>(B, c, L);
+    if (shared) ba_reduce_pairs<true>(B, c, L, BaOutGlob<true>{ B.hred + (size_t)c.win * kBaHred }, 0, c.K);
+    else ba_reduce_pairs<kCl>(B, c, L, BaOutLds{ L }, 0, 1);
     BA_TOCK(12)
     BA_TICK(13)
-    {
-        // H_ff, g_f and the extrinsic / anchor parts of the coupling rows: 16 lanes per feature, lane k sums entry k of the feature's observation
-        // records (contiguous, at most 10: one per other frame of the window) in observation order; the loads are independent and requested together
-        const int k = lane & 15, t8 = wave * 4 + (lane >> 4);
-        for (int f = t8; f < c.F; f += 4 * kBaW) {
-            const int o0 = c.o0 + BA_FOBS(f), o1 = c.o0 + BA_FOBS(f + 1);
-            double acc = 0.0;
-            for (int ob = o0; ob < o1; ob += 10) {
-                double v[10];
-#pragma unroll
-                for (int u = 0; u < 10; u++) v[u] = ob + u < o1 ? ld_sh<kCl>(B.obsc + (size_t)(ob + u) * kBaObsRec + k) : 0.0;
-#pragma unroll
-                for (int u = 0; u < 10; u++) acc += v[u];
-            }
-            if (k == 0) BA_F(Hdd, f) = acc;
-            else if (k == 1) BA_F(gdd, f) = acc;
-            else if (k < 14) {
-                double *hrow = hpd + (size_t)f * kBaPS;
-                if (k < 8) { if (c.ex_off >= 0) gst(hrow + c.ex_off + k - 2, acc); }
-                else { const int anchor = BA_FANCHOR(f); if (anchor >= 0) gst(hrow + ba_pose_off(c, anchor) + k - 8, acc); }
-            }
+    if (shared) {
+        ba_feature_pass<true, kBig, true>(B, c, L, G, hpd, 0, c.K);
+        // the other workgroups' shares: wait for their "sums done" words, drop this CU's L1 (their stores went through the shared L2; the coupling rows are
+        // read with plain loads from here on), load H_pp | g_p and H_ff | g_f
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned int *flags = B.bar + (size_t)c.win * kBaBar;
+        if (tid < 64 && !L.failed) { if (!ba_wait_flags(flags + 9, c.K - 1, (unsigned int)(L.eval_no + 1), B.fail) && tid == 0) L.failed = 1; }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const double *hr = B.hred + (size_t)c.win * kBaHred;
+        for (int k = tid; k < kBaHred; k += kBaT) { const double v = ld_sh<true>(hr + k); if (k >= kBaP * kBaP) L.gp[k - kBaP * kBaP] = v; else L.Hpp[k] = v; }
+        if (!kBig) {
+            const double *fd = B.fdg + (size_t)c.win * 2 * B.feat_cap;
+            for (int f = tid; f < c.F; f += kBaT) { L.Hdd[f] = ld_sh<true>(fd + f); L.gdd[f] = ld_sh<true>(fd + B.feat_cap + f); }
         }
-        // frame j's share of a coupling row (frame j sees a feature once) moves from the observation's record to its place: 8 lanes per observation, four
-        // observations of a lane in flight
-        const int n_obs = c.use_mono ? BA_FOBS(c.F) : 0;
-        const int kk = tid & 7;
-        for (int ob0 = tid >> 3; ob0 < n_obs; ob0 += 4 * (kBaT / 8)) {
-            double vj[4], vo[4], vf[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int ob = ob0 + u * (kBaT / 8);
-                const double *rc = B.obsc + (size_t)(c.o0 + (ob < n_obs ? ob : ob0)) * kBaObsRec;
-                vj[u] = ld_sh<kCl>(rc + 14 + (kk < 6 ? kk : 0)); vo[u] = ld_sh<kCl>(rc + 20); vf[u] = ld_sh<kCl>(rc + 21);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int ob = ob0 + u * (kBaT / 8);
-                // (an observation outside the problem -- a feature below the track count -- has no record: its cells hold zeros and oj = 0 marks it)
-                if (ob < n_obs && kk < 6 && vo[u] > 0.0) gst(hpd + (size_t)(int)vf[u] * kBaPS + (int)vo[u] - 1 + kk, vj[u]);
-            }
-        }
-    }
+        __syncthreads();
+    } else
+        ba_feature_pass<kCl, kBig, false>(B, c, L, G, hpd, 0, 1);
     BA_TOCK(13)
     // every segment's block is in H_pp: the LASERFactor chain left in gn | va | vb is added by everybody, the prior by wave 1 -- after the pair
     // blocks in every run
@@ -1052,6 +1096,7 @@ __device__ __noinline__ void ba_hs_mul(const BaCtx c, BaLds &L_arg, const BaBig 
     BA_TICK(4)
     for (int k = tid; k < N; k += kBaT) BA_V(gn, k) = BA_V(scale, k) * BA_V(va, k);
     __syncthreads();
+#if LMONO_BA_HS_FUSED
     // ONE pass over the coupling rows (round 6: the camera rows and the depth rows each read all of them -- 2 x 275 KB per product for a 430-feature
     // window, a quarter of what the batched solve moves through HBM): wave w takes the features f = w (mod 8), lanes own the parameter columns
     // (coalesced 640-B rows), eight rows in flight.  A row's share of the camera rows is row x (feature's entry of the vector); its own depth row is the
@@ -1080,6 +1125,44 @@ __device__ __noinline__ void ba_hs_mul(const BaCtx c, BaLds &L_arg, const BaBig 
         L.u.hs_part[wave][lane] = a0;
         if (lane < kBaPS - 64) L.u.hs_part[wave][64 + lane] = a1;
     }
+#else
+    // camera rows: wave w sums the features f = w (mod 8); lanes own the parameter columns (coalesced 640-B rows),
+    // eight feature rows in flight
+    {
+        double a0 = 0, a1 = 0;
+        for (int f = wave; f < F; f += 8 * kBaW) {
+            double r0[8], r1[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int fu = f + kBaW * u;
+                const double *row = hpd + (size_t)fu * kBaPS;
+                r0[u] = fu < F ? gld(row + lane) : 0.0;
+                r1[u] = (fu < F && lane < kBaPS - 64) ? gld(row + 64 + lane) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int fu = f + kBaW * u;
+                const double w = fu < F ? BA_V(gn, P + fu) : 0.0;
+                a0 += r0[u] * w; a1 += r1[u] * w;
+            }
+        }
+        L.u.hs_part[wave][lane] = a0;
+        if (lane < kBaPS - 64) L.u.hs_part[wave][64 + lane] = a1;
+    }
+    // depth rows: four lanes per feature, the 18 entries of a lane requested together
+    for (int f = tid >> 2; f < F; f += kBaT / 4) {
+        const double *row = hpd + (size_t)f * kBaPS;
+        double rv[18];
+#pragma unroll
+        for (int k = 0; k < 18; k++) { const int a = (tid & 3) + 4 * k; rv[k] = a < P ? gld(row + a) : 0.0; }
+        double acc = 0;
+#pragma unroll
+        for (int k = 0; k < 18; k++) { const int a = (tid & 3) + 4 * k; acc += rv[k] * (a < P ? BA_V(gn, a) : 0.0); }
+        acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 2);
+        if ((tid & 3) == 0) BA_V(vb, P + f) = (acc + BA_F(Hdd, f) * BA_V(gn, P + f)) * BA_V(scale, P + f);
+    }
+#endif
     __syncthreads();
     if (tid < P) {
         double acc = 0;
@@ -1402,18 +1485,20 @@ __device__ __noinline__ void ba_setup(const BaBatch &B, const BaCtx c, BaLds &L_
     if (!kBig) for (int f = tid; f <= c.F; f += kBaT) L.fobs[f] = (unsigned short)(*BA_P(B.feat_obs_off + c.f0 + f) - c.o0);      // <= 448 x 10 observations per window
     if (!kBig) for (int f = tid; f < c.F; f += kBaT) L.fanchor[f] = (signed char)*BA_P(B.feat_anchor + c.f0 + f);
     __syncthreads();
-    // (anchor, observer) -> the pair's tile among the window's tiles [segments | pairs]: a pair of several segments has its own (ba_reduce_pairs sums
-    // its segments' tiles into it), any other pair's tile is its only segment's
+    // (anchor, observer) -> the pair's index in the window's pair list
     for (int p = tid; p < c.n_pairs; p += kBaT) {
         const int ij = L.pair_ij[p];
-        L.pair_of[(ij & 255) * kBaMaxPoses + (ij >> 8)] = (short)(p < c.n_multi ? c.n_seg + p : (int)L.pair_seg[p]);
+        L.pair_of[(ij & 255) * kBaMaxPoses + (ij >> 8)] = (short)p;
     }
     __syncthreads();
     if (c.rank != 0) return;
     // the gather program of ba_reduce_pairs (see kBaGaN); position of (row r, column q) of a tile: rows / columns 0..5 = frame i, 6..11 = frame j,
     // 12..15 = extrinsic 0..3 (the 16 x 16 tile), column 16 / 17 = extrinsic 4 / 5 and column 18 = the residual (the 16 x 4 side tile)
     auto pos = [](int r, int q) { return q < 16 ? (r < 16 ? r * 16 + q : 256 + q * 4 + (r - 16)) : 256 + r * 4 + (q - 16); };
-    const int zero = (c.n_seg + c.n_pairs) * kBaPairTile;          // the window's tile of zeros
+    // a source = a frame pair: (position of the entry in the tile of the pair's FIRST segment) | (its segments << 20); 0 = no such pair
+    auto source = [&](int p, int at) { const int s0 = L.pair_seg[p], cnt = L.pair_seg[p + 1] - s0; return (s0 * kBaPairTile + at) | (cnt << 20); };
+    static_assert((kBaMaxSeg + 64 * kBaMaxPoses) * kBaPairTile < (1 << 20) && kBaMaxFeat / kBaSeg + 1 < (1 << 11), "gather source packing");
+    const int zero = 0;
     int *gp = B.gprog + (size_t)c.win * kBaGprog;
     const int np_ = c.n_poses, x0 = c.ex_off;
     for (int a = tid; a < kBaGaN; a += kBaT) {
@@ -1425,8 +1510,8 @@ __device__ __noinline__ void ba_setup(const BaBatch &B, const BaCtx c, BaLds &L_
         if (bm < np_ && bm < kBaMaxPoses) {
             // frame bn = i is the smaller one: the pair (i, j = bm) holds the block in rows 6.. / columns 0.., the pair (j, i) in rows 0.. / columns 6..
             const int p1 = L.pair_of[bn * kBaMaxPoses + bm], p2 = L.pair_of[bm * kBaMaxPoses + bn];
-            if (p1 >= 0) o1 = p1 * kBaPairTile + pos(6 + om, on);
-            if (p2 >= 0) o2 = p2 * kBaPairTile + pos(om, 6 + on);
+            if (p1 >= 0) o1 = source(p1, pos(6 + om, on));
+            if (p2 >= 0) o2 = source(p2, pos(om, 6 + on));
             d1 = (ba_pose_off(c, bm) + om) * kBaP + ba_pose_off(c, bn) + on;
             d2 = (ba_pose_off(c, bn) + on) * kBaP + ba_pose_off(c, bm) + om;
         }
@@ -1456,8 +1541,8 @@ __device__ __noinline__ void ba_setup(const BaBatch &B, const BaCtx c, BaLds &L_
         for (int k = 0; k < kBaMaxPoses; k++) {
             const int pa = (on_ && k < np_ && k != f) ? L.pair_of[f * kBaMaxPoses + k] : -1;
             const int pb = (on_ && k < np_ && k != f) ? L.pair_of[k * kBaMaxPoses + f] : -1;
-            *BA_P(gb + k * kBaGbN + t) = pa >= 0 ? pa * kBaPairTile + oi_ : zero;
-            *BA_P(gb + (kBaMaxPoses + k) * kBaGbN + t) = pb >= 0 ? pb * kBaPairTile + oj_ : zero;
+            *BA_P(gb + k * kBaGbN + t) = pa >= 0 ? source(pa, oi_) : zero;
+            *BA_P(gb + (kBaMaxPoses + k) * kBaGbN + t) = pb >= 0 ? source(pb, oj_) : zero;
         }
         *BA_P(gb + 22 * kBaGbN + t) = on_ ? dst : -1; *BA_P(gb + 23 * kBaGbN + t) = on_ ? dst2 : -1;
     }
@@ -1474,13 +1559,15 @@ __device__ __noinline__ void ba_follow(const BaBatch &B, const BaCtx c, BaLds &L
     BA_BIND_LDS(L_arg)
     const int tid = threadIdx.x;
     const double *mb = B.mbox + (size_t)c.win * kBaMbox;
-    unsigned int *flags = B.bar + (size_t)c.win * 16;
+    unsigned int *flags = B.bar + (size_t)c.win * kBaBar;
     G.vinv = mb + 96;                                   // (kBig: a follower reads the inverse depths straight from the mail box)
+    if (tid == 0) ba_flag_store(flags + 16 + c.rank, (unsigned int)ba_xcc_id() + 1u);
+    double *hpd = B.hpd + (size_t)c.win * B.feat_cap * kBaPS;
     for (;;) {
         if (tid < 64) { if (!ba_wait_flags(flags, 1, (unsigned int)(L.eval_no + 1), B.fail) && tid == 0) L.failed = 1; }
         __syncthreads();
         if (L.failed) return;
-        const int cmd = (int)ld_sh<true>(mb), reuse = (int)ld_sh<true>(mb + 1);
+        const int cmd = (int)ld_sh<true>(mb), reuse = (int)ld_sh<true>(mb + 1), shared = (int)ld_sh<true>(mb + 3);
         if (cmd == 3) return;
         if (!reuse) {
             for (int k = tid; k < 7 * c.n_poses; k += kBaT) L.cposes[k] = ld_sh<true>(mb + 8 + k);
@@ -1497,6 +1584,22 @@ __device__ __noinline__ void ba_follow(const BaBatch &B, const BaCtx c, BaLds &L
             if ((int)ld_sh<true>(mb + 2) == ba_xcc_id()) ba_segments<true, false, kBig, true>(B, c, L, G, L.cex, pairdat);      // the leader's XCD: plain stores stay in the shared L2
             else ba_segments<true, true, kBig, true>(B, c, L, G, L.cex, pairdat);
             ba_done<false>(B, c, L);
+            if (shared) {
+                // every workgroup's records (the other followers' and the leader's): then this workgroup's share of the ordered sums and of the per-feature
+                // pass -- an entry is formed by one thread from the same records in the same order whoever that thread is
+                if (tid < 64) {
+                    bool ok = ba_wait_flags(flags + 1, c.K - 1, (unsigned int)(L.eval_no + 1), B.fail);
+                    ok = ok && ba_wait_flags(flags + 8, 1, (unsigned int)(L.eval_no + 1), B.fail);
+                    if (!ok && tid == 0) L.failed = 1;
+                }
+                __syncthreads();
+                if (L.failed) return;
+                ba_reduce_pairs<true>(B, c, L, BaOutGlob<true>{ B.hred + (size_t)c.win * kBaHred }, c.rank, c.K);
+                ba_feature_pass<true, kBig, true>(B, c, L, G, hpd, c.rank, c.K);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) ba_flag_store(flags + 8 + c.rank, (unsigned int)(L.eval_no + 1));
+            }
         }
         if (tid == 0) L.eval_no++;
         __syncthreads();
@@ -1515,7 +1618,7 @@ __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B, int K, int spread)
     BaCtx c;
     c.K = kCl ? K : 1;
     c.rank = kCl ? ((int)blockIdx.x / 8) % K : 0;
-    const int w = kCl ? ((int)blockIdx.x / 8 / K) * 8 + (((int)blockIdx.x % 8) + (spread ? 8 - c.rank : 0)) % 8 : (int)blockIdx.x;
+    const int w = kCl ? ((int)blockIdx.x / 8 / K) * 8 + (((int)blockIdx.x % 8) + ((spread & 1) ? 8 - c.rank : 0)) % 8 : (int)blockIdx.x;
     c.GW = c.K == 1 ? kBaW : c.K * kBaW - 1;
     c.win = w;
     if (w >= B.n_windows) return;
@@ -1542,7 +1645,8 @@ __global__ __launch_bounds__(kBaT) void k_ba_solve(BaBatch B, int K, int spread)
         G.Hdd = gv; G.gdd = gv + kBaMaxFeat; G.scale = gv + 2 * kBaMaxFeat; G.D = gv + 3 * kBaMaxFeat; G.gs = gv + 4 * kBaMaxFeat; G.gn = gv + 5 * kBaMaxFeat;
         G.va = gv + 6 * kBaMaxFeat; G.vb = gv + 7 * kBaMaxFeat; G.vinv = ginvd; G.fobs = B.feat_obs_off + c.f0; G.fanchor = B.feat_anchor + c.f0; G.seg = B.seg_tab + c.sg0; G.o0 = c.o0;
     }
-    if (tid == 0) { L.eval_no = 0; L.failed = 0; }
+    // (spread bit 1 = LMONO_BA_SHARE_SUMS: the cluster shares the ordered sums; off by default -- measured slower, see ba_reduce_pairs)
+    if (tid == 0) { L.eval_no = 0; L.failed = 0; L.coloc = (spread & 2) ? -1 : 0; }
 #ifdef LMONO_BA_PROF
     if (tid < 24) L.prof[tid] = 0;
 #endif

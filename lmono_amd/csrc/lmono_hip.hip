@@ -1348,7 +1348,9 @@ static int ba_fill(lmono_ctx *c, lmono_ba_batch *b, const lmono_ba_desc *d)
     }
     pk.add(v.pairdat, (const double *)nullptr, (size_t)b->cluster * pair_ij.size() * kBaPairRec);
     pk.add(v.mbox, (const double *)nullptr, (size_t)W * kBaMbox);
-    pk.add(v.bar, (const unsigned int *)nullptr, (size_t)W * 16);
+    pk.add(v.bar, (const unsigned int *)nullptr, (size_t)W * kBaBar);
+    pk.add(v.hred, (const double *)nullptr, b->cluster > 1 ? (size_t)W * kBaHred : (size_t)1);
+    pk.add(v.fdg, (const double *)nullptr, b->cluster > 1 ? (size_t)W * 2 * v.feat_cap : (size_t)1);
     v.n_pairs_total = (int)pair_ij.size();
     pk.add(v.pairH, (const double *)nullptr, (seg_tab.size() + pair_ij.size() + (size_t)W) * kBaPairTile);
     pk.add(v.gprog, (const int *)nullptr, (size_t)W * kBaGprog);
@@ -1406,7 +1408,7 @@ extern "C" int lmono_ba_solve(lmono_ctx *c, lmono_ba_batch *b, int max_iteration
     if (b->cluster > 1) {
         // the flag words start at zero in every launch (the first solve after a fill finds them zeroed with the rest of the scratch)
         if (!b->flags_clean) {
-            HIP_TRY(c, hipMemsetAsync(b->v.bar, 0, sizeof(unsigned int) * (size_t)b->n_windows * 16, c->stream));
+            HIP_TRY(c, hipMemsetAsync(b->v.bar, 0, sizeof(unsigned int) * (size_t)b->n_windows * kBaBar, c->stream));
             HIP_TRY(c, hipMemsetAsync(b->v.fail, 0, sizeof(int), c->stream));
         }
         b->flags_clean = false;
@@ -1415,7 +1417,9 @@ extern "C" int lmono_ba_solve(lmono_ctx *c, lmono_ba_batch *b, int max_iteration
             HIP_TRY(c, hipMemcpyAsync(b->pre, b->v.poses, (size_t)((const char *)(b->v.inv_depth + b->total_feat) - (const char *)b->v.poses), hipMemcpyDeviceToDevice, c->stream));
         static const int test_fail = [] { const char *e = getenv("LMONO_BA_TEST_FAIL"); return e ? atoi(e) : 0; }();   // test hook: the cluster gives up at its first poll
         if (test_fail) HIP_TRY(c, hipMemsetAsync(b->v.fail, 1, 1, c->stream));
-        static const int spread = [] { const char *e = getenv("LMONO_BA_SPREAD"); return e ? atoi(e) : 0; }();      // test hook: a window's workgroups on different XCDs
+        // bit 0 LMONO_BA_SPREAD (test hook: a window's workgroups on different XCDs), bit 1 LMONO_BA_SHARE_SUMS (measurement switch: the cluster shares the
+        // leader's ordered sums -- byte-identical, measured slower, off)
+        static const int spread = [] { const char *e = getenv("LMONO_BA_SPREAD"); const char *h = getenv("LMONO_BA_SHARE_SUMS"); return ((e && atoi(e)) ? 1 : 0) | ((h && atoi(h)) ? 2 : 0); }();
         const dim3 grid(((b->n_windows + 7) / 8) * 8 * b->cluster);
         if (b->big) hipLaunchKernelGGL((k_ba_solve<true, true>), grid, dim3(kBaT), 0, c->stream, b->v, b->cluster, spread);
         else hipLaunchKernelGGL((k_ba_solve<true, false>), grid, dim3(kBaT), 0, c->stream, b->v, b->cluster, spread);

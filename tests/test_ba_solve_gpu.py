@@ -129,12 +129,16 @@ def test_workgroups_of_a_window_on_different_xcds(tmp_path):
             "np.savez(sys.argv[1], p=p, e=e, d=d, sm=sm)\n") % root
     out = {}
     for name, env in (("k1", {"LMONO_BA_CLUSTER": "1"}), ("k8", {"LMONO_BA_CLUSTER": "8"}), ("k8_spread", {"LMONO_BA_CLUSTER": "8", "LMONO_BA_SPREAD": "1"}),
-                      ("k4_spread", {"LMONO_BA_CLUSTER": "4", "LMONO_BA_SPREAD": "1"})):
+                      ("k4_spread", {"LMONO_BA_CLUSTER": "4", "LMONO_BA_SPREAD": "1"}),
+                      # round 6: the cluster shares the leader's ordered sums (measurement switch, off by default): same bytes; with the workgroups on
+                      # different XCDs the switch must fall back to the leader's own sums
+                      ("k8_shared_sums", {"LMONO_BA_CLUSTER": "8", "LMONO_BA_SHARE_SUMS": "1"}), ("k4_shared_sums", {"LMONO_BA_CLUSTER": "4", "LMONO_BA_SHARE_SUMS": "1"}),
+                      ("k8_shared_spread", {"LMONO_BA_CLUSTER": "8", "LMONO_BA_SHARE_SUMS": "1", "LMONO_BA_SPREAD": "1"})):
         f = str(tmp_path / (name + ".npz"))
         r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300, cwd=root)
         assert r.returncode == 0, r.stderr[-2000:]
         out[name] = np.load(f)
-    for name in ("k8", "k8_spread", "k4_spread"):
+    for name in ("k8", "k8_spread", "k4_spread", "k8_shared_sums", "k4_shared_sums", "k8_shared_spread"):
         for key in ("p", "e", "d", "sm"):
             assert out[name][key].tobytes() == out["k1"][key].tobytes(), "%s: %s differs from the one-workgroup solve" % (name, key)
     assert (out["k1"]["sm"][:, 2] == 30).all()
