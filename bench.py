@@ -251,25 +251,32 @@ def bench_ba_seq_single(args):
 
 
 def _ba_traffic(windows):
-    """HBM bytes of one k_ba_solve launch from the committed counter summary (scripts/profile_round5.sh: 1 and 1024 windows), or None."""
-    path = os.path.join(ROOT, "profiles", "r5", "pmc_k_ba_solve.json")
-    try:
-        with open(path) as fh:
-            return json.load(fh).get("hbm_bytes_per_launch", {}).get(str(windows))
-    except (OSError, ValueError, AttributeError):          # no summary, or an unreadable one: the line carries null
-        return None
+    """HBM bytes of one k_ba_solve launch from the newest committed counter summary (scripts/profile_round6.sh ba: 1 and 1024 windows), or None."""
+    for rnd in ("r6", "r5"):
+        path = os.path.join(ROOT, "profiles", rnd, "pmc_k_ba_solve.json")
+        try:
+            with open(path) as fh:
+                v = json.load(fh).get("hbm_bytes_per_launch", {}).get(str(windows))
+            if v:
+                return v
+        except (OSError, ValueError, AttributeError):          # no summary, or an unreadable one: try the older one, else the line carries null
+            pass
+    return None
 
 
 def _map_traffic(streams):
     """HBM bytes per single-stream laserMapping frame from the committed counter summary (scripts/profile_round5.sh), or None."""
-    path = os.path.join(ROOT, "profiles", "r5", "pmc_map_frame.json")
     if streams != 1 or os.environ.get("LMONO_MAP_HOST_TABLES"):      # (the counters are the device-table frame's)
         return None
-    try:
-        with open(path) as fh:
-            return json.load(fh).get("hbm_bytes_per_frame")
-    except (OSError, ValueError, AttributeError):
-        return None
+    for rnd in ("r6", "r5"):
+        try:
+            with open(os.path.join(ROOT, "profiles", rnd, "pmc_map_frame.json")) as fh:
+                v = json.load(fh).get("hbm_bytes_per_frame")
+            if v:
+                return v
+        except (OSError, ValueError, AttributeError):
+            pass
+    return None
 
 
 def bench_map(args):
