@@ -1071,9 +1071,10 @@ def main():
             # "k_correspond" is the library's timing group of the search; the kernel rocprofv3 lists under it is lmono::k_corr_flat
             roofline["kernel_symbol"] = "lmono::k_corr_flat (+ k_correspond_list for deferred features: 0 here)"
             roofline["note"] = ("exact nearest-neighbour + scan-line walk over a (line, azimuth-bin) index, candidates swept as 64-byte chunks; the kernel is bound by "
-                                "instruction issue and by the dependent rounds of its slowest workgroup, not by HBM or the L1 (46 M VALU + 19 M SALU wave instructions per 256-chain "
-                                "launch, VALU ~80 % busy while the CUs are full, UTCL1 misses 0.04 %; profiles/r4/NOTES.md) -- the HBM fraction is reported because SURVEY 8d prices "
-                                "the path in bytes")
+                                "instruction issue and by the dependent rounds of its slowest workgroup, not by HBM or the L1 (14.4 M VALU + 6.3 M SALU wave instructions per "
+                                "64-chain main-pass launch -- issue_frac; round 4's '46 M + 19 M per 256-chain launch' averaged ALL launches of a validated run at lead 4 / 2 full pairs, "
+                                "thinned lead-in and short repair launches included: the same kernel, another averaging set; VALU ~80 % busy while the CUs are full, UTCL1 misses 0.04 %; "
+                                "profiles/r4/NOTES.md, profiles/r6/NOTES.md) -- the HBM fraction is reported because SURVEY 8d prices the path in bytes")
         out = {
             "metric": "KITTI HDL-64 scans/sec (scanRegistration + laserOdometry)", "value": round(scans_per_s, 1),
             "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
