@@ -605,6 +605,41 @@ def ba_secondary(ctx, windows=1024, steps=3):
             "mean_iterations": iters, "fp64_tflops": round(flops / el / 1e12, 3), "fp64_frac": round(flops / el / 1e12 / FP64_PEAK_TFLOPS, 5)}
 
 
+def ba_streams_secondary(streams=(1, 64, 256), frames=160):
+    """The Estimator frame loop over N independent sequences in lock-step (EstimatorBatch) beside the headline: frames/s at a few stream counts on
+    short S2 streams, and whether every stream's output is the bytes of its single-stream run.  The C++ host mirror runs in a child process (its own GPU context);
+    the full-length figures (2761 frames per stream) are `bench.py --workload ba-seq --seq-streams N` (profiles/r6/ba_seq_*streams.json)."""
+    import subprocess
+    import tempfile
+    d = tempfile.mkdtemp()
+    n_files = 4
+    # (generated in this process, one after the other: a process that holds a GPU context does not fork workers)
+    files = [_make_seq_stream((frames, 2 + k, os.path.join(d, "stream%d.bin" % k))) for k in range(n_files)]
+    exe = os.path.join(ROOT, "lmono_amd", "host", "estimator_seq")
+    single = {}
+    out = {"workload": "S2 frame streams (configs[2] shape), %d frames each, %d different files; EstimatorBatch: one batched C-ABI call per numeric step, marginalisation overlapped" % (frames, n_files),
+           "frames_per_s": {}, "every_stream_equals_its_single_stream_run": True}
+    for N in streams:
+        if N == 1:
+            r = subprocess.run([exe, files[0], "-", "async"], capture_output=True, text=True, timeout=300)
+        else:
+            r = subprocess.run([exe, files[0], "-", "async", "streams=%d" % N, "digest"] + files[1:], capture_output=True, text=True, timeout=600)
+        if r.returncode != 0:
+            raise RuntimeError(r.stderr[-500:])
+        lines = r.stdout.splitlines()
+        tim = [ln for ln in lines if ln.startswith("TIM")][0].split()
+        out["frames_per_s"][str(N)] = round(max(N, 1) * 1e3 / float(tim[2]), 1)
+        dig = {int(ln.split()[1]): ln.split()[2] for ln in lines if ln.startswith("DIG")}
+        if N > 1:
+            for k in range(min(n_files, N)):
+                if k not in single:
+                    q = subprocess.run([exe, files[k], "-", "async"], capture_output=True, text=True, timeout=300)
+                    single[k] = [ln for ln in q.stdout.splitlines() if ln.startswith("DIG")][0].split()[2]
+                for s_ in range(k, N, n_files):
+                    out["every_stream_equals_its_single_stream_run"] = out["every_stream_equals_its_single_stream_run"] and dig[s_] == single[k]
+    return out
+
+
 def streamed_extra(ctx, off, xyzi_d, args, gold_poses):
     """PCIe-inclusive operation (SURVEY 8d "PCIe H2D floor"): the sequence sits in PINNED host memory and streams through
     two device working sets in n_chunks scan ranges -- lmono_batch_stage_h copies range j + 1 on the library's copy stream while range j is
@@ -1142,6 +1177,10 @@ def main():
                 out["secondary"] = {"ba": ba_secondary(ctx)}
             except Exception as e:       # the secondary line must never take the headline down
                 out["secondary"] = {"ba": {"error": repr(e)}}
+            try:
+                out["secondary"]["ba_streams"] = ba_streams_secondary()
+            except Exception as e:
+                out["secondary"]["ba_streams"] = {"error": repr(e)}
             # (5) the same pass over the cluttered world: the chained schedule's price is world-dependent, its result is not
             if args.seq == 0 and not args.kitti_dir:
                 try:
