@@ -108,6 +108,8 @@ struct BaBatch {
     int n_pairs_total;          // stride of the per-rank copies of pairdat
     double *cand;               // scratch [W][kBaMaxFeat]
     double *summary;            // [W][6] initial_cost, final_cost, iterations, termination, successful, unsuccessful
+    int lds_ok;                 // every observation's anchor frame precedes its observer (i < j: what the Estimator produces): the one-workgroup solve may add a
+                                // pair's tiles into H_pp in pair order straight from LDS (ba_linearise_lds); 0: it goes through the scratch like a cluster
     const char *blob_lo, *blob_hi;  // the batch's one device allocation (every pointer above points into it): the bounds-checked build's limits
 };
 
@@ -712,13 +714,17 @@ __device__ __forceinline__ void ba_done(const BaBatch &B, const BaCtx &c, BaLds 
 
 // one workgroup's share of an evaluation: the segments gw, gw + GW, ... of the window (a linearisation takes two per round and wave, a cost evaluation
 // four).  Every result goes to the segment's / the observation's own record.
-template <bool kJac, bool kCl, bool kBig, bool kFol = false>      // kFol: a follower workgroup (its inverse depths are the leader's mail box)
-__device__ __forceinline__ void ba_segments(const BaBatch &B, const BaCtx &c, BaLds &L, const BaBig &G, const double *ex, const double *pairdat)
+// kLds (one workgroup per window, linearisation): ONE round -- the segments 16 round + wave and 16 round + 8 + wave -- and the two tiles stay in the wave's own
+// slice of the LDS stage (ba_linearise_lds adds them into H_pp from there) instead of going to the L2 scratch
+template <bool kJac, bool kCl, bool kBig, bool kFol = false, bool kLds = false>      // kFol: a follower workgroup (its inverse depths are the leader's mail box)
+__device__ __forceinline__ void ba_segments(const BaBatch &B, const BaCtx &c, BaLds &L, const BaBig &G, const double *ex, const double *pairdat, int round = 0,
+                                            const double *minfo = nullptr)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double *Rlc = L.Rp + 9 * c.n_poses;
     const double *mono_info = B.info + 36;
-    const double m00 = gld(mono_info), m01 = gld(mono_info + 1), m10 = gld(mono_info + 2), m11 = gld(mono_info + 3);
+    // (sqrt_info of the projection factor: from the caller's registers when it calls once per round -- four L2 round trips per call otherwise)
+    const double m00 = minfo ? minfo[0] : gld(mono_info), m01 = minfo ? minfo[1] : gld(mono_info + 1), m10 = minfo ? minfo[2] : gld(mono_info + 2), m11 = minfo ? minfo[3] : gld(mono_info + 3);
     const int *sinfo = B.slot_info + c.ps0;
     const double *spts = B.slot_pts + (size_t)c.ps0 * 4;
     const int gw = ba_worker(c, wave), GW = c.GW;        // this wave among the waves that share the window's segments
@@ -765,7 +771,8 @@ __device__ __forceinline__ void ba_segments(const BaBatch &B, const BaCtx &c, Ba
     double *tiles = B.pairH + (size_t)(c.sg0 + c.pp0 + c.win) * kBaPairTile;
     const int q = lane & 1, half = lane >> 5, lo = (lane & 31) >> 1, col = lane & 15, kq = lane >> 4;
     const double *Mx = L.Mq + 18 * c.n_poses, *Mxi = L.Mq + 18 * (kBaMaxPoses + 1);
-    for (int sA = gw; sA < c.n_seg; sA += 2 * GW) {
+    const int s_lo = kLds ? 2 * kBaW * round + gw : gw, s_hi = kLds ? min(c.n_seg, 2 * kBaW * round + kBaW) : c.n_seg;
+    for (int sA = s_lo; sA < s_hi; sA += 2 * GW) {
         const int sB = sA + GW;
         const int sg = half ? sB : sA;                       // this lane's segment
         const bool seg_ok = sg < c.n_seg;
@@ -874,6 +881,7 @@ __device__ __forceinline__ void ba_segments(const BaBatch &B, const BaCtx &c, Ba
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int nA = __builtin_amdgcn_readlane(s_end - s_begin, 0), nB = sB < c.n_seg ? __builtin_amdgcn_readlane(s_end - s_begin, 32) : 0;
+        ba_d4 keep_a[2], keep_b[2];              // kLds: both tiles wait in registers until both products have read the staged rows (the tiles take the rows' place)
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const int n = h ? nB : nA;
@@ -886,6 +894,7 @@ __device__ __forceinline__ void ba_segments(const BaBatch &B, const BaCtx &c, Ba
                     aa = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, aa, 0, 0, 0);
                     ab = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, ab, 0, 0, 0);
                 }
+                if (kLds) { keep_a[h] = aa; keep_b[h] = ab; continue; }
                 // the segment's tile [J_i J_j J_x0..3]^T [J_i J_j J_x0..3 | J_x4 J_x5 r] and its scalar sums go to the segment's own record in the
                 // L2 scratch (plain stores, nobody else touches it); ba_reduce_pairs adds the records in a fixed order afterwards
                 double *tile = tiles + (size_t)(h ? sB : sA) * kBaPairTile;
@@ -897,6 +906,25 @@ __device__ __forceinline__ void ba_segments(const BaBatch &B, const BaCtx &c, Ba
                 if (lane == 32 * h) {
                     st_sh<kCl>(tile + 256 + 3, cst); st_sh<kCl>(tile + 260 + 3, xx44); st_sh<kCl>(tile + 264 + 3, xx45); st_sh<kCl>(tile + 268 + 3, xx55);
                     st_sh<kCl>(tile + 272 + 3, gx4); st_sh<kCl>(tile + 276 + 3, gx5);
+                }
+            }
+        }
+        if (kLds) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();                     // every lane's products have read their rows
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int n = h ? nB : nA;
+                if (n > 0) {
+                    double *tile = wstage + h * kBaPairTile;
+#pragma unroll
+                    for (int v = 0; v < 4; v++) {
+                        tile[(kq + 4 * v) * 16 + col] = keep_a[h][v];
+                        if (col < 3) tile[256 + (kq + 4 * v) * 4 + col] = keep_b[h][v];
+                    }
+                    if (lane == 32 * h) {
+                        tile[256 + 3] = cst; tile[260 + 3] = xx44; tile[264 + 3] = xx45; tile[268 + 3] = xx55; tile[272 + 3] = gx4; tile[276 + 3] = gx5;
+                    }
                 }
             }
         }
@@ -955,6 +983,183 @@ __device__ __forceinline__ void ba_feature_pass(const BaBatch &B, const BaCtx &c
     }
 }
 
+// Linearisation of a window that has ONE workgroup (round 6; VERDICT r5 #1a: the batched solve moved 27 x its algorithmic bytes through HBM, a third of it
+// the segments' tiles -- written to the L2 scratch by ba_segments and gathered back by ba_reduce_pairs).  Alone in its workgroup a window needs neither trip:
+// the eight waves evaluate the segments in ROUNDS of sixteen (wave w: segments 16 r + w and 16 r + 8 + w, as before), leave the sixteen tiles in their slices of
+// the LDS stage, and every entry of H_pp / g_p -- owned by one thread, as in the gather -- adds the round's tiles that touch it, straight from LDS, carrying its
+// running sums in registers.  THE SAME SUMS IN THE SAME ORDER as ba_reduce_pairs forms from the scratch, so the bytes equal the cluster's:
+//   * an entry of frame f adds the window's pairs that touch f in ascending pair order (the gather program's source order: ba_setup), a pair's value being
+//     the sum of its segments in segment order, started from zero -- the pairs are sorted by (observer, anchor), segments follow pairs, so a round delivers
+//     an entry's sources in exactly that order and a cursor over the frame's pair list (flist, built once per solve) replaces the gather program;
+//   * an entry between two frames adds the two pairs that can hold it (either order: a sum of two);
+//   * the extrinsic block's 33 values: 15 partial sums over the segments s = g (mod 15), then the 15 in order;
+//   * the cost: lane t of wave 0 adds the segments s = t (mod 64) in ascending order, then the wave's butterfly.
+// The per-observation records (depth blocks, coupling rows) still go through the scratch: their sums follow the observation order, not the pair order.
+// MEASURED (scripts/r6_ba_ab.sh, one box, A / B): byte-identical to the scratch path (the K = 1 vs K = 2 / 4 / 8 tests ran on it) and SLOWER -- 1024 windows
+// 33.0 k instead of 41.5 k windows/s, one window with one workgroup 5.7 instead of 4.2 ms.  A round ends in a workgroup barrier, so every round pays the
+// full latency of its segments' loads (pair record, slot tables, points, inverse depths: ~3 us) with nothing to overlap it; the scratch path lets each wave
+// run through its segments on its own, eight waves' latencies overlapping, and pays the L2 once in the gather.  The tiles' trip through the scratch is
+// traffic (a third of the solve's), not time.  Default OFF; kept as a compile-time variant (-DLMONO_BA_LDS_TILES=1, tests/test_bounds_gpu.py builds and
+// checks it) because it is the form a solve with a second stage buffer (rounds overlapped two deep) would start from.
+#ifndef LMONO_BA_LDS_TILES
+#define LMONO_BA_LDS_TILES 0
+#endif
+template <bool kBig>
+__device__ __forceinline__ void ba_linearise_lds(const BaBatch &B, const BaCtx &c, BaLds &L, const BaBig &G, const double *ex, const double *pairdat)
+{
+    const int tid = threadIdx.x, np_ = c.n_poses, x0 = c.ex_off;
+    constexpr int kWS = 2 * kBaRound * kBaRow;                   // doubles of a wave's stage slice
+    auto tile_of = [&](int q) { return L.u.stage + (size_t)(q % kBaW) * kWS + (q / kBaW) * kBaPairTile; };      // segment q of the round
+    auto pos = [](int r, int q) { return q < 16 ? (r < 16 ? r * 16 + q : 256 + q * 4 + (r - 16)) : 256 + r * 4 + (q - 16); };
+    // ---- this thread's entries
+    // part A: items a = tid + 512 u of the 55 x 36 frame-block entries (as the gather program numbers them)
+    int a_p1[4], a_p2[4], a_o1[4], a_o2[4], a_d1[4], a_d2[4], a_s1[4][2], a_s2[4][2];      // a_s*: the pair's segments [first, end) (none: an empty range)
+    double a_v1[4], a_v2[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int a = tid + u * kBaT;
+        a_p1[u] = a_p2[u] = -1; a_o1[u] = a_o2[u] = 0; a_d1[u] = a_d2[u] = -1; a_v1[u] = a_v2[u] = 0.0;
+        a_s1[u][0] = a_s1[u][1] = a_s2[u][0] = a_s2[u][1] = 0;
+        if (a < 55 * 36) {
+            const int pb = a / 36, e = a % 36, om = e / 6, on = e % 6;
+            int bm = 1;
+            while (bm * (bm + 1) / 2 <= pb) bm++;
+            const int bn = pb - bm * (bm - 1) / 2;
+            if (bm < np_ && bm < kBaMaxPoses) {
+                a_p1[u] = L.pair_of[bn * kBaMaxPoses + bm]; a_p2[u] = L.pair_of[bm * kBaMaxPoses + bn];
+                a_o1[u] = pos(6 + om, on); a_o2[u] = pos(om, 6 + on);
+                a_d1[u] = (ba_pose_off(c, bm) + om) * kBaP + ba_pose_off(c, bn) + on;
+                a_d2[u] = (ba_pose_off(c, bn) + on) * kBaP + ba_pose_off(c, bm) + om;
+                if (a_p1[u] >= 0) { a_s1[u][0] = L.pair_seg[a_p1[u]]; a_s1[u][1] = L.pair_seg[a_p1[u] + 1]; }
+                if (a_p2[u] >= 0) { a_s2[u][0] = L.pair_seg[a_p2[u]]; a_s2[u][1] = L.pair_seg[a_p2[u] + 1]; }
+            }
+        }
+    }
+    // part B: items t = tid, tid + 512 of the 11 x 63 entries of one frame (diagonal block, frame x extrinsic, gradient)
+    int b_f[2], b_oi[2], b_oj[2], b_dst[2], b_dst2[2], b_cur[2];
+    double b_acc[2], b_pacc[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int t = tid + u * kBaT;
+        b_f[u] = -1; b_oi[u] = b_oj[u] = 0; b_dst[u] = b_dst2[u] = -1; b_cur[u] = 0; b_acc[u] = 0.0; b_pacc[u] = 0.0;
+        if (t < kBaMaxPoses * 63) {
+            const int f = t / 63, r = t % 63;
+            bool on_ = f < np_;
+            int oi_, oj_, dst, dst2 = -1;
+            if (r < 21) {
+                int om = 0;
+                while ((om + 1) * (om + 2) / 2 <= r) om++;
+                const int on = r - om * (om + 1) / 2;
+                oi_ = pos(om, on); oj_ = pos(6 + om, 6 + on);
+                dst = (ba_pose_off(c, f) + om) * kBaP + ba_pose_off(c, f) + on; dst2 = om != on ? (ba_pose_off(c, f) + on) * kBaP + ba_pose_off(c, f) + om : -1;
+            } else if (r < 57) {
+                const int q = r - 21, om = q / 6, ox = q % 6;
+                oi_ = pos(om, 12 + ox); oj_ = pos(6 + om, 12 + ox);
+                dst = (ba_pose_off(c, f) + om) * kBaP + x0 + ox; dst2 = (x0 + ox) * kBaP + ba_pose_off(c, f) + om;
+                if (x0 < 0) on_ = false;
+            } else {
+                const int om = r - 57;
+                oi_ = pos(om, 18); oj_ = pos(6 + om, 18);
+                dst = kBaP * kBaP + ba_pose_off(c, f) + om;
+            }
+            if (on_) { b_f[u] = f; b_oi[u] = oi_; b_oj[u] = oj_; b_dst[u] = dst; b_dst2[u] = dst2; }
+        }
+    }
+    // part C: value e of the extrinsic block, partial sum g
+    constexpr int kG = 15;
+    const int c_e = tid % 33, c_g = tid / 33;
+    int c_off = 0;
+    if (c_e < 16) c_off = (12 + c_e / 4) * 16 + 12 + c_e % 4;
+    else if (c_e < 28) c_off = 256 + (12 + (c_e - 16) / 3) * 4 + (c_e - 16) % 3;
+    else c_off = 256 + (c_e - 27) * 4 + 3;
+    double c_acc = 0.0, cost_acc = 0.0;
+    int c_rb15 = 0;                                              // (first segment of the round) mod 15
+    // ---- every frame's pairs in pair order: flist[f] = pair | (1 << 7 when f is the pair's observer), in L.gs (dead during a linearisation)
+    int *flist = (int *)L.gs;                                    // [kBaMaxPoses][24]: [0] count, [1 ..] entries
+    static_assert(sizeof(double) * kBaN >= sizeof(int) * kBaMaxPoses * 24, "flist fits gs");
+    __syncthreads();
+    if (tid < kBaMaxPoses) {
+        int n = 0;
+        for (int p = 0; p < c.n_pairs; p++) {
+            const int ij = L.pair_ij[p], i = ij & 255, j = ij >> 8;
+            if (i == tid) flist[tid * 24 + 1 + n++] = p;
+            else if (j == tid) flist[tid * 24 + 1 + n++] = p | 128;
+        }
+        flist[tid * 24] = n;
+    }
+    __syncthreads();
+    const int n_rounds = (c.n_seg + 2 * kBaW - 1) / (2 * kBaW);
+    const double minfo[4] = { gld(B.info + 36), gld(B.info + 37), gld(B.info + 38), gld(B.info + 39) };
+    for (int round = 0; round < n_rounds; round++) {
+        ba_segments<true, false, kBig, false, true>(B, c, L, G, ex, pairdat, round, minfo);
+        __syncthreads();
+        const int rb = 2 * kBaW * round, re = min(rb + 2 * kBaW, c.n_seg);      // the round's segments [rb, re)
+        // the value a pair adds to an entry: its segments' cells in order, from zero
+        auto take = [&](int p, int at, double &pacc) -> bool {              // adds the pair's segments of this round; true = the pair is complete
+            const int s0 = L.pair_seg[p], s1 = L.pair_seg[p + 1];
+            for (int sg = max(s0, rb); sg < min(s1, re); sg++) { const double v = tile_of(sg - rb)[at]; pacc = sg == s0 ? v : pacc + v; }
+            return s1 <= re;
+        };
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            for (int sg = max(a_s1[u][0], rb); sg < min(a_s1[u][1], re); sg++) { const double v = tile_of(sg - rb)[a_o1[u]]; a_v1[u] = sg == a_s1[u][0] ? v : a_v1[u] + v; }
+            for (int sg = max(a_s2[u][0], rb); sg < min(a_s2[u][1], re); sg++) { const double v = tile_of(sg - rb)[a_o2[u]]; a_v2[u] = sg == a_s2[u][0] ? v : a_v2[u] + v; }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            if (b_f[u] < 0) continue;
+            const int *fl = flist + b_f[u] * 24;
+            const int n = fl[0];
+            while (b_cur[u] < n) {
+                const int e = fl[1 + b_cur[u]], p = e & 127;
+                if (L.pair_seg[p] >= re) break;                             // the next source comes in a later round
+                if (take(p, (e & 128) ? b_oj[u] : b_oi[u], b_pacc[u])) { b_acc[u] += b_pacc[u]; b_cur[u]++; }
+                else break;                                                 // the pair goes on in the next round
+            }
+        }
+        if (x0 >= 0 && tid < 33 * kG) {
+            // the round's segments s = g (mod 15): at most two of sixteen
+            int sg = rb + (c_g - c_rb15 + kG) % kG;
+            if (sg < re) { c_acc += tile_of(sg - rb)[c_off]; sg += kG; if (sg < re) c_acc += tile_of(sg - rb)[c_off]; }
+        }
+        c_rb15 = (c_rb15 + 2 * kBaW) % kG;
+        if (tid < 64) { const int sg = rb + ((tid - rb) & 63); if (sg < re) cost_acc += tile_of(sg - rb)[256 + 3]; }
+        __syncthreads();                                                    // the stage is rewritten by the next round
+    }
+    // ---- the sums go to their places (entries nothing touches: zero)
+#pragma unroll
+    for (int u = 0; u < 4; u++) if (a_d1[u] >= 0) { const double sum = a_v1[u] + a_v2[u]; L.Hpp[a_d1[u]] = sum; L.Hpp[a_d2[u]] = sum; }
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+        if (b_dst[u] >= 0) {
+            if (b_dst[u] >= kBaP * kBaP) L.gp[b_dst[u] - kBaP * kBaP] = b_acc[u];
+            else { L.Hpp[b_dst[u]] = b_acc[u]; if (b_dst2[u] >= 0) L.Hpp[b_dst2[u]] = b_acc[u]; }
+        }
+    if (x0 >= 0) {
+        if (tid < 33 * kG) L.D[c_g * 33 + c_e] = c_acc;
+        __syncthreads();
+        if (tid < 33) {
+            double tot = 0.0;
+#pragma unroll
+            for (int g = 0; g < kG; g++) tot += L.D[g * 33 + tid];
+            const int e = tid, x4 = x0 + 4, x5 = x0 + 5;
+            if (e < 16) L.Hpp[(x0 + e / 4) * kBaP + x0 + e % 4] = tot;
+            else if (e < 28) {
+                const int om = (e - 16) / 3, cc = (e - 16) % 3;
+                if (cc < 2) { L.Hpp[(x0 + om) * kBaP + x4 + cc] = tot; L.Hpp[(x4 + cc) * kBaP + x0 + om] = tot; }
+                else L.gp[x0 + om] = tot;
+            }
+            else if (e == 28) L.Hpp[x4 * kBaP + x4] = tot;
+            else if (e == 29) { L.Hpp[x4 * kBaP + x5] = tot; L.Hpp[x5 * kBaP + x4] = tot; }
+            else if (e == 30) L.Hpp[x5 * kBaP + x5] = tot;
+            else if (e == 31) L.gp[x4] = tot;
+            else L.gp[x5] = tot;
+        }
+    }
+    if (tid < 64) { cost_acc = wave_sum_d(cost_acc); if (tid == 0) L.red[3 * kBaW - 1] = cost_acc; }
+    __syncthreads();
+}
+
 // cost (returned to every thread) and, when kJac, the unscaled normal equations: Hpp, gp, Hdd, gdd in LDS, Hpd in HBM -- the LEADER's view of an
 // evaluation (with several workgroups per window the others run ba_follow).
 // records_valid: the pose matrices, the inverse depths in LDS and the pair records in HBM were computed by the previous call for the SAME parameter
@@ -1008,7 +1213,10 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
     BA_TOCK(0)
     BA_TICK(1)
     if (kJac && tid >= 64 && tid < 96) small_cost = ba_small_factors<kJac>(B, c, L.gn, poses, ex, tid - 64);
-    ba_segments<true, false, kBig>(B, c, L, G, ex, pairdat);          // (the leader's own records: plain stores; it reads them back from the L2 like everybody's)
+    // one workgroup per window: the tiles never leave the CU (ba_linearise_lds); a cluster's leader: its share of the segments, records in the L2 scratch
+    const bool lds_path = LMONO_BA_LDS_TILES && !kCl && B.lds_ok;
+    if (lds_path) ba_linearise_lds<kBig>(B, c, L, G, ex, pairdat);
+    else ba_segments<true, false, kBig>(B, c, L, G, ex, pairdat);          // (the leader's own records: plain stores; it reads them back from the L2 like everybody's)
     BA_TOCK(1)
     BA_TICK(11)
     // the cluster shares the ordered sums of this linearisation when all its workgroups sit on the leader's XCD (known from the second linearisation on)
@@ -1041,7 +1249,8 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");       // ... and read below by other waves: drop this CU's L1 copies
     }
     BA_TICK(12)
-    if (shared) ba_reduce_pairs<true>(B, c, L, BaOutGlob<true>{ B.hred + (size_t)c.win * kBaHred }, 0, c.K);
+    if (lds_path) { }                                                  // (H_pp, g_p and the segments' cost are in LDS already)
+    else if (shared) ba_reduce_pairs<true>(B, c, L, BaOutGlob<true>{ B.hred + (size_t)c.win * kBaHred }, 0, c.K);
     else ba_reduce_pairs<kCl>(B, c, L, BaOutLds{ L }, 0, 1);
     BA_TOCK(12)
     BA_TICK(13)
@@ -1073,7 +1282,7 @@ __device__ __noinline__ double ba_evaluate(const BaBatch &B, const BaCtx c, BaLd
         small_cost = wave_sum_d(small_cost);
         if (lane == 0) L.red[3 * kBaW - 2] = small_cost;
     }
-    ba_segment_cost<kCl>(c, L, tiles + 256 + 3, kBaPairTile);
+    if (!lds_path) ba_segment_cost<kCl>(c, L, tiles + 256 + 3, kBaPairTile);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     const double cost = L.red[3 * kBaW - 1] + L.red[3 * kBaW - 2];
@@ -1541,8 +1750,10 @@ __device__ __noinline__ void ba_setup(const BaBatch &B, const BaCtx c, BaLds &L_
         for (int k = 0; k < kBaMaxPoses; k++) {
             const int pa = (on_ && k < np_ && k != f) ? L.pair_of[f * kBaMaxPoses + k] : -1;
             const int pb = (on_ && k < np_ && k != f) ? L.pair_of[k * kBaMaxPoses + f] : -1;
-            *BA_P(gb + k * kBaGbN + t) = pa >= 0 ? source(pa, oi_) : zero;
-            *BA_P(gb + (kBaMaxPoses + k) * kBaGbN + t) = pb >= 0 ? source(pb, oj_) : zero;
+            // (sources 0..10: the pairs (k, f) that OBSERVE in f, by ascending k; 11..21: the pairs (f, k) anchored in f, by ascending k -- with the pairs
+            // sorted by (observer, anchor) and anchors preceding their observers that is ascending pair order: the order a one-workgroup solve meets them in)
+            *BA_P(gb + k * kBaGbN + t) = pb >= 0 ? source(pb, oj_) : zero;
+            *BA_P(gb + (kBaMaxPoses + k) * kBaGbN + t) = pa >= 0 ? source(pa, oi_) : zero;
         }
         *BA_P(gb + 22 * kBaGbN + t) = on_ ? dst : -1; *BA_P(gb + 23 * kBaGbN + t) = on_ ? dst2 : -1;
     }

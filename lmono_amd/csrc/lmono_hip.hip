@@ -1262,15 +1262,16 @@ static int ba_fill(lmono_ctx *c, lmono_ba_batch *b, const lmono_ba_desc *d)
         const int f0 = d->feat_off[w], f1 = d->feat_off[w + 1];
         for (int f = f0; f < f1; f++) if (fo[f + 1] > fo[f]) anchor[f] = d->obs_i[fo[f]];
         if (d->flags[4 * w + 3]) {   // use_mono == 0: the projection factors are not part of the problem
-            // counting sort of the window's observations by frame pair (ascending observation index inside a pair), pairs in descending size (stable: ties
-            // by ascending key) -- no per-window allocations: a lock-step batch of Estimators fills hundreds of windows per frame
+            // counting sort of the window's observations by frame pair (ascending observation index inside a pair), pairs by (observer j, anchor i) ascending
+            // (round 6: the order in which a one-workgroup solve can add a pair's tile into H_pp as soon as it is formed -- see ba_linearise_lds; rounds 4-5
+            // sorted by descending size for the waves' work counter, which the 16-slot segments made pointless) -- no per-window allocations: a lock-step
+            // batch of Estimators fills hundreds of windows per frame
             constexpr int kKeys = kBaMaxPoses * kBaMaxPoses;
             int cnt[kKeys], base[kKeys], order[kKeys], local_of[kKeys], n_keys = 0;
             for (int key = 0; key < kKeys; key++) cnt[key] = 0;
             const int o0w = d->obs_off[w], o1w = d->obs_off[w + 1];
             for (int o = o0w; o < o1w; o++) cnt[d->obs_i[o] * kBaMaxPoses + d->obs_j[o]]++;
-            for (int key = 0; key < kKeys; key++) if (cnt[key] > 0) order[n_keys++] = key;
-            std::stable_sort(order, order + n_keys, [&](int x, int y) { return cnt[x] > cnt[y]; });
+            for (int j = 0; j < kBaMaxPoses; j++) for (int i = 0; i < kBaMaxPoses; i++) { const int key = i * kBaMaxPoses + j; if (cnt[key] > 0) order[n_keys++] = key; }
             const size_t slot0 = slot_info.size();
             int run = 0;
             for (int local = 0; local < n_keys; local++) {
@@ -1368,6 +1369,8 @@ static int ba_fill(lmono_ctx *c, lmono_ba_batch *b, const lmono_ba_desc *d)
     v.laser_consts = laser; v.prior_T = prior; v.info = infod;
     v.feat_obs_off = fobs_d; v.slot_obs = oslot_d;
     v.seg_off = segoff_d; v.seg_tab = segtab_d; v.pair_seg = pseg_d; v.n_multi = nmulti_d;
+    v.lds_ok = 1;
+    for (int o = 0; o < TO && v.lds_ok; o++) if (d->obs_i[o] >= d->obs_j[o]) v.lds_ok = 0;
     v.blob_lo = b->blob; v.blob_hi = b->blob + pk.up + pk.zero;      // (the arrays of THIS fill: what lies behind them in a larger, re-used allocation is out of bounds too)
     return LMONO_OK;
 }

@@ -67,3 +67,34 @@ def test_checked_build_of_the_ba_solve_sees_no_access_outside_the_batch(tmp_path
     with open(os.path.join(ROOT, "gpurun_out", "bounds_checked_ba_solve.txt"), "w") as fh:
         fh.write("bounds-checked build (-DLMONO_BOUNDS) of k_ba_solve: K = 1 / 2 / 4 / 8 over 5 mixed windows, an 870-feature window, 24 windows in clusters, 256 windows, update / reset, "
                  "the give-up retry, 80 frames of the Estimator loop (1 and 12 streams): 0 accesses outside the batch's allocation\n" + "\n".join(rep) + "\n")
+
+
+def test_lds_tile_variant_of_the_one_workgroup_solve_is_the_same_bytes(tmp_path):
+    """Round 6 built the one-workgroup linearisation with the segments' tiles kept in LDS (ba_linearise_lds: rounds of sixteen segments, every H_pp entry adds
+    the round's tiles from LDS in the gather's order) -- a third less traffic, measured 20 % slower, so it ships as a compile-time variant
+    (-DLMONO_BA_LDS_TILES=1).  The variant must stay what it claims to be: the same BYTES as the shipped library for K = 1 (and so as every cluster size)."""
+    lib = tmp_path / "liblmono_hip.so"
+    src = os.path.join(ROOT, "lmono_amd", "csrc", "lmono_hip.hip")
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-DLMONO_BA_LDS_TILES=1", "-o", str(lib), src],
+                       capture_output=True, text=True, timeout=900, cwd=os.path.dirname(src))
+    assert r.returncode == 0, r.stderr[-3000:]
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import numpy as np, lmono_amd\n"
+            "from tests import ba_cases as K\n"
+            "ctx = lmono_amd.Context(0)\n"
+            "ws = [K.make_window(s) for s in (30, 31, 32)]\n"
+            "ws[1]['use_mono'] = False; ws[2]['ex_constant'] = True\n"
+            "ws += [K.make_window(33, n_frames=5), K.make_window(34, n_landmarks=2500), K.make_window(50, n_landmarks=20000, max_tracks=560, min_dist=14)]\n"
+            "ctx.set_option(ctx.OPT_BA_CLUSTER, 1)\n"
+            "b = lmono_amd.BaBatch(ctx, ws); b.solve(30); p, e, d, sm = b.read()\n"
+            "np.savez(sys.argv[1], p=p, e=e, d=d, sm=sm)\n") % ROOT
+    import numpy as np
+    out = {}
+    for name, env in (("shipped", {}), ("lds", {"LMONO_HIP_LIB": str(lib)})):
+        f = str(tmp_path / (name + ".npz"))
+        q = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env), cwd=ROOT)
+        assert q.returncode == 0, q.stderr[-2000:]
+        out[name] = np.load(f)
+    for key in ("p", "e", "d", "sm"):
+        assert out["lds"][key].tobytes() == out["shipped"][key].tobytes(), key
