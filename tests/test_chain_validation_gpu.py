@@ -108,6 +108,31 @@ def test_thinner_lead_ins_stay_inside_the_bar(seq):
         ctx.set_option(ctx.OPT_LEAD_FULL, -1)
 
 
+def test_lead_ins_seeded_from_the_neighbouring_chains_stay_inside_the_bar(seq):
+    """LMONO_OPT_LEAD_SEED = 1 (round 6): after the first step of the pass the state of every chain still in its lead-in becomes the
+    component-wise median of the first results of chains c - 1, c, c + 1 (a constant-velocity prior across 1.8 s).  The validation is the arbiter of the
+    result whatever the lead-ins start from: on all three worlds the seeded schedule ends on the sequential oracle's trajectory like the unseeded one.
+    (What it buys is measured in profiles/r6/lead_in_seeding_and_length_three_worlds.txt: nothing -- a first pair from the identity is biased, not an
+    outlier, so its neighbours' first pairs are off the same way; the option ships off.)"""
+    from lmono_amd import trajectory
+    lead, lead_full = _bench_defaults()
+    b = seq["batch"]; ctx = b.ctx
+    ctx.set_option(ctx.OPT_LEAD_FULL, lead_full)
+    try:
+        out = {}
+        for seed in (0, 1):
+            ctx.set_option(ctx.OPT_LEAD_SEED, seed)
+            _, poses = b.odometry(256, lead)
+            rep = b.boundary_report()
+            out[seed] = (trajectory.ate(poses, seq["gold"]["poses"]), rep["flagged"], rep["pairs_rerun"])
+            assert rep["unresolved"] == 0 and out[seed][0] <= 0.002
+        print("seq %d, 256 chains, lead %d: identity lead-ins ATE %.6f m, %d flagged, %d pairs re-run; seeded %.6f m, %d flagged, %d pairs"
+              % ((seq["id"], lead) + out[0] + out[1]))
+    finally:
+        ctx.set_option(ctx.OPT_LEAD_SEED, 0)
+        ctx.set_option(ctx.OPT_LEAD_FULL, -1)
+
+
 def test_validation_off_is_the_round2_schedule_and_on_only_improves(seq):
     """tol 0 = no check (the round-2 behaviour: 224 chains x lead 7 missed the bar on seq 0 by one unlucky boundary)."""
     from lmono_amd import trajectory

@@ -392,9 +392,9 @@ def test_api_errors_and_limits(oracle, gpu_ctx, small_seq):
     incr, poses = one.odometry(1, 0)                                # a single scan: identity
     assert np.array_equal(incr, np.array([[0, 0, 0, 1, 0, 0, 0.0]])) and np.array_equal(poses, incr)
     # options: values are range-checked, a rejected value leaves the option as it was, values may be negative
-    for key, bad in ((gpu_ctx.OPT_CORR_TILE, 4), (gpu_ctx.OPT_CORR_TILE, -1), (gpu_ctx.OPT_CORR_TILE, 1), (gpu_ctx.OPT_BA_CLUSTER, 3), (gpu_ctx.OPT_BA_CLUSTER, 16), (6, 1), (gpu_ctx.OPT_ODOM_STREAMS, 0), (gpu_ctx.OPT_ODOM_STREAMS, 9),
+    for key, bad in ((gpu_ctx.OPT_CORR_TILE, 4), (gpu_ctx.OPT_CORR_TILE, -1), (gpu_ctx.OPT_CORR_TILE, 1), (gpu_ctx.OPT_BA_CLUSTER, 3), (gpu_ctx.OPT_BA_CLUSTER, 16), (gpu_ctx.OPT_LEAD_SEED, 2), (gpu_ctx.OPT_LEAD_SEED, -1), (gpu_ctx.OPT_ODOM_STREAMS, 0), (gpu_ctx.OPT_ODOM_STREAMS, 9),
                      (gpu_ctx.OPT_DEFER_EVERY, -1), (gpu_ctx.OPT_LEAD_FULL, -2), (gpu_ctx.OPT_BOUNDARY_TOL, -1), (17, 0)):
-        before = gpu_ctx.get_option(key) if key < 6 else None
+        before = gpu_ctx.get_option(key) if key < 7 else None
         with pytest.raises(lmono_amd.LmonoError):
             gpu_ctx.set_option(key, bad)
         if before is not None:
