@@ -1007,7 +1007,9 @@ void EstimatorBatch::processImage(const double *headers, const FeatureManager::I
         g_bclock.lap(7);
         // (overlapped marginalisation: the packs are handed to the worker at the END of the frame -- its kernels then run under the next frame's host passes
         // instead of beside this frame's outlier / depth-shift calls, which they delayed by ~0.4 ms at 256 streams; inline: here, the reference's place)
-        static const bool early = std::getenv("LMONO_BATCH_MARGIN_EARLY") != nullptr;      // measurement switch: the round's first placement
+        // (few streams: right away, like the single Estimator -- the job is short and is over before the next frame's first call; LMONO_BATCH_MARGIN_EARLY forces it)
+        static const bool force_early = std::getenv("LMONO_BATCH_MARGIN_EARLY") != nullptr;
+        const bool early = force_early || N < 64;
         if (do_margin && (!async_margin_ || early)) { submitMargin(packs); packs.reset(); }
         g_bclock.lap(8);
     };
