@@ -163,62 +163,68 @@ int main(int argc, char **argv)
         const int N = n_streams, G = std::min(n_groups, N);
         std::vector<Lines> out((size_t)N);
         for (int s = 0; s < N; s++) out[(size_t)s].keep = !digest_only;
-        std::vector<double> g_flops((size_t)G, 0.0); std::vector<long> g_obs((size_t)G, 0);
-        std::vector<std::string> g_err((size_t)G);
-        std::vector<double> g_ms((size_t)G, 0.0); std::vector<int> g_solves((size_t)G, 0);
-        // group g: streams [s0, s1) on its own context / HIP stream / host thread (G = 1: this thread, the context above)
-        auto run_group = [&](int g) {
-            try {
-                const int s0 = (int)((long long)g * N / G), s1 = (int)((long long)(g + 1) * N / G), n = s1 - s0;
-                std::unique_ptr<HipContext> own;
-                if (G > 1) { own.reset(new HipContext(0)); own->useOwnStream(); }
-                HipContext &h = G > 1 ? *own : hip;
-                EstimatorBatch eb(h, p, n, G > 1 ? std::max(1, 16 / G) : 0);
-                if (async) eb.setAsyncMargin(true);
-                for (int s = 0; s < n; s++) std::memcpy(eb.stream(s).TLC, src[(size_t)(s0 + s) % src.size()].TLC, 128);
-                std::vector<double> headers((size_t)n);
-                std::vector<const FeatureManager::Image *> img((size_t)n);
-                std::vector<std::array<double, 16>> L0((size_t)n);
-                std::unique_ptr<bool[]> kf(new bool[(size_t)n]);
-                for (size_t f = 0; f < n_frames; f++) {
-                    for (int s = 0; s < n; s++) {
-                        const Frame &fr = src[(size_t)(s0 + s) % src.size()].frames[f];
-                        headers[(size_t)s] = fr.header; img[(size_t)s] = &fr.image; std::memcpy(L0[(size_t)s].data(), fr.L0, 128);
-                        if (fr.has_loop) eb.stream(s).setLoopFrame(fr.loop);
-                    }
-                    const bool was_inited = eb.stream(0).stage_flag == Estimator::INITED;
-                    const auto t0 = std::chrono::steady_clock::now();
-                    eb.processImage(headers.data(), img.data(), reinterpret_cast<const double (*)[16]>(L0.data()), kf.get());
-                    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-                    if (was_inited) { g_ms[(size_t)g] += ms; g_solves[(size_t)g]++; }
-                    for (int s = 0; s < n; s++) frm_line(out[(size_t)(s0 + s)], (int)f, kf[(size_t)s], eb.stream(s));
-                }
-                eb.marginWait();
-                for (int s = 0; s < n; s++) {
-                    tail_lines(out[(size_t)(s0 + s)], eb.stream(s));
-                    g_flops[(size_t)g] += eb.stream(s).solve_flops; g_obs[(size_t)g] += eb.stream(s).solve_obs;
-                }
-            } catch (const std::exception &e) { g_err[(size_t)g] = e.what(); }
+        // group g: streams [s0, s1) as one EstimatorBatch on its own context / HIP stream (G = 1: the context above).  ONE thread drives all groups, frame by
+        // frame: finish(g, frame f - 1), begin(g, frame f) for g = 0 .. G - 1 -- a group's solve is in flight while the thread runs the other groups' host
+        // passes (threads per group were measured first: the HIP runtime serialises the submitting threads, 9.1 -> 10.4 ms per lock-step frame at G = 2)
+        struct Group {
+            int s0 = 0, n = 0;
+            std::unique_ptr<HipContext> own;
+            std::unique_ptr<EstimatorBatch> eb;
+            std::vector<double> headers;
+            std::vector<const FeatureManager::Image *> img;
+            std::vector<std::array<double, 16>> L0;
+            std::unique_ptr<bool[]> kf;
         };
-        const auto wall0 = std::chrono::steady_clock::now();
-        if (G == 1) run_group(0);
-        else {
-            std::vector<std::thread> th;
-            for (int g = 0; g < G; g++) th.emplace_back(run_group, g);
-            for (auto &t : th) t.join();
+        std::vector<Group> grp((size_t)G);
+        for (int g = 0; g < G; g++) {
+            Group &q = grp[(size_t)g];
+            q.s0 = (int)((long long)g * N / G); q.n = (int)((long long)(g + 1) * N / G) - q.s0;
+            if (G > 1) { q.own.reset(new HipContext(0)); q.own->useOwnStream(); }
+            q.eb.reset(new EstimatorBatch(G > 1 ? *q.own : hip, p, q.n));
+            if (async) q.eb->setAsyncMargin(true);
+            for (int s = 0; s < q.n; s++) std::memcpy(q.eb->stream(s).TLC, src[(size_t)(q.s0 + s) % src.size()].TLC, 128);
+            q.headers.resize((size_t)q.n); q.img.resize((size_t)q.n); q.L0.resize((size_t)q.n); q.kf.reset(new bool[(size_t)q.n]);
         }
-        const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
-        for (const std::string &e : g_err) if (!e.empty()) throw std::runtime_error(e);
+        auto begin = [&](Group &q, size_t f) {
+            for (int s = 0; s < q.n; s++) {
+                const Frame &fr = src[(size_t)(q.s0 + s) % src.size()].frames[f];
+                q.headers[(size_t)s] = fr.header; q.img[(size_t)s] = &fr.image; std::memcpy(q.L0[(size_t)s].data(), fr.L0, 128);
+                if (fr.has_loop) q.eb->stream(s).setLoopFrame(fr.loop);
+            }
+            q.eb->processImageBegin(q.headers.data(), q.img.data(), reinterpret_cast<const double (*)[16]>(q.L0.data()), q.kf.get());
+        };
+        auto finish = [&](Group &q, size_t f) {
+            q.eb->processImageFinish();
+            for (int s = 0; s < q.n; s++) frm_line(out[(size_t)(q.s0 + s)], (int)f, q.kf[(size_t)s], q.eb->stream(s));
+        };
+        double solve_ms = 0; int solves = 0;
+        for (size_t f = 0; f < n_frames; f++) {
+            const bool was_inited = grp[0].eb->stream(0).stage_flag == Estimator::INITED;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int g = 0; g < G; g++) {
+                if (G > 1 && f > 0) finish(grp[(size_t)g], f - 1);
+                begin(grp[(size_t)g], f);
+                if (G == 1) finish(grp[(size_t)g], f);
+            }
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            // (G > 1: an iteration finishes frame f - 1 and begins frame f of every group: one lock-step frame of work, counted when frame f - 1 was an INITED one)
+            if (G == 1 ? was_inited : (f > 0 && was_inited)) { solve_ms += ms; solves++; }
+        }
+        if (G > 1) for (int g = 0; g < G; g++) finish(grp[(size_t)g], n_frames - 1);
         double flops = 0; long obs = 0;
-        for (int g = 0; g < G; g++) { flops += g_flops[(size_t)g]; obs += g_obs[(size_t)g]; }
+        for (int g = 0; g < G; g++) {
+            Group &q = grp[(size_t)g];
+            q.eb->marginWait();
+            for (int s = 0; s < q.n; s++) {
+                tail_lines(out[(size_t)(q.s0 + s)], q.eb->stream(s));
+                flops += q.eb->stream(s).solve_flops; obs += q.eb->stream(s).solve_obs;
+            }
+        }
         for (int s = 0; s < N; s++) {
             if (!digest_only) { std::printf("STR %d\n", s); std::fputs(out[(size_t)s].text.c_str(), stdout); }
             std::printf("DIG %d %016llx\n", s, out[(size_t)s].h);
         }
-        // one group: the INITED lock-step frames' own clock.  Several groups: they overlap, so the figure is the replay's wall time (the few NOT_INITED
-        // frames included) over the INITED frames
-        const int solves = g_solves[0];
-        const double solve_ms = G == 1 ? g_ms[0] : wall_ms;
+        grp.clear();          // (the batches print their phase clocks as they go)
         // TIM: lock-step frames timed (INITED), milliseconds per lock-step frame (= N stream frames), streams
         std::printf("TIM %d %.6f %d %d\n", solves, solves ? solve_ms / solves : 0.0, N, G);
         std::printf("FLP %.17g %ld\n", flops, obs);

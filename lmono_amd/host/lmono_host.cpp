@@ -889,7 +889,11 @@ void EstimatorBatch::callSolve()
     } else
         hip_.check(lmono_ba_batch_update(hip_.get(), ba_batch_, &d), "lmono_ba_batch_update");
     g_bclock.lap(5);
-    hip_.check(lmono_ba_solve(hip_.get(), ba_batch_, p_.NUM_ITERATIONS), "lmono_ba_solve");
+    hip_.check(lmono_ba_solve(hip_.get(), ba_batch_, p_.NUM_ITERATIONS), "lmono_ba_solve");       // asynchronous on the context stream
+}
+void EstimatorBatch::readSolve()
+{
+    Work &w = *work_;
     hip_.check(lmono_ba_batch_read(hip_.get(), ba_batch_, w.poses.data(), w.ex.data(), w.invd.data(), w.summary.data()), "lmono_ba_batch_read");
     g_bclock.lap(6);
 }
@@ -985,6 +989,16 @@ void EstimatorBatch::processImage(const double *headers, const FeatureManager::I
 }
 void EstimatorBatch::processImage(const double *headers, const FeatureManager::Image *const *images, const double (*transform_to_init)[16], bool *keyframe)
 {
+    processImageBegin(headers, images, transform_to_init, keyframe);
+    processImageFinish();
+}
+// The frame in two halves around the window solve, which is the one long GPU step and is launched asynchronously: Begin runs everything up to the launch and
+// returns; Finish waits for the solve and runs the rest.  A caller that drives several EstimatorBatches (each on its own context / stream) from ONE thread
+// interleaves them -- finish(A), begin(A, next frame), finish(B), begin(B, next frame) ... -- so that one batch's host passes run under another's solve
+// (estimator_seq groups=G); processImage = Begin + Finish.
+void EstimatorBatch::processImageBegin(const double *headers, const FeatureManager::Image *const *images, const double (*transform_to_init)[16], bool *keyframe)
+{
+    if (pending_ != 0) throw std::logic_error("EstimatorBatch::processImageBegin: the previous frame was not finished");
     const int N = size();
     Work &w = *work_;
     if ((int)w.tp.size() != N) { w.tp.resize((size_t)N); w.sp.resize((size_t)N); w.shp.resize((size_t)N); w.due.assign((size_t)N, 0); }
@@ -995,46 +1009,16 @@ void EstimatorBatch::processImage(const double *headers, const FeatureManager::I
         if (est_[(size_t)s]->stage_flag != e0.stage_flag || est_[(size_t)s]->frame_count != e0.frame_count)
             throw std::logic_error("EstimatorBatch: the streams are not at the same frame of their sequences");
     auto pre = [&](int s) { bool k = false; est_[(size_t)s]->preFrame(headers[s], *images[s], transform_to_init[s], &k); kf[(size_t)s] = k ? 1 : 0; };
-    auto margin_and_tracks = [&](std::shared_ptr<std::vector<MargPack>> &packs) {
-        // Estimator::optimization behind the solve: double2Matrix, then margin() (frame_count == WINDOW_SIZE here) -- and the tracks for the outlier scores
-        const bool do_margin = p_.ESTIMATE_LASER != 0;
-        if (do_margin) { marginWait(); packs = std::make_shared<std::vector<MargPack>>((size_t)N); }
-        pool_->run(N, [&](int s) {
-            applySolve(s);
-            if (do_margin) est_[(size_t)s]->packMargin((*packs)[(size_t)s]);
-            est_[(size_t)s]->packTracks(w.tp[(size_t)s]);
-        });
-        g_bclock.lap(7);
-        // (overlapped marginalisation: the packs are handed to the worker at the END of the frame -- its kernels then run under the next frame's host passes
-        // instead of beside this frame's outlier / depth-shift calls, which they delayed by ~0.4 ms at 256 streams; inline: here, the reference's place)
-        // (few streams: right away, like the single Estimator -- the job is short and is over before the next frame's first call; LMONO_BATCH_MARGIN_EARLY forces it)
-        static const bool force_early = std::getenv("LMONO_BATCH_MARGIN_EARLY") != nullptr;
-        const bool early = force_early || N < 64;
-        if (do_margin && (!async_margin_ || early)) { submitMargin(packs); packs.reset(); }
-        g_bclock.lap(8);
-    };
-    auto slide_and_rows = [&](double outlier_error) {
-        callOutliers();
-        pool_->run(N, [&](int s) { applyOutliers(s, outlier_error); w.due[(size_t)s] = est_[(size_t)s]->slideWindowBegin(w.shp[(size_t)s]) ? 1 : 0; });
-        g_bclock.lap(9);
-        callShift();
-        pool_->run(N, [&](int s) { if (w.due[(size_t)s]) est_[(size_t)s]->slideWindowFinish(&w.shout[(size_t)w.shoff[(size_t)s]]); est_[(size_t)s]->pushOdometryRow(); });
-        g_bclock.lap(10);
-    };
-    std::shared_ptr<std::vector<MargPack>> packs;
     if (e0.stage_flag == Estimator::NOT_INITED) {
         if (e0.frame_count == WINDOW_SIZE && p_.ESTIMATE_LASER != 2) {
-            // runInitialization :986-1012, optimization, outliersRejection(3), slideWindow
+            // runInitialization :986-1012, then optimization
             pool_->run(N, [&](int s) { pre(s); est_[(size_t)s]->initialPoses(); est_[(size_t)s]->packTracks(w.tp[(size_t)s]); });
             callTriangulate();
             pool_->run(N, [&](int s) { applyTriangulate(s); est_[(size_t)s]->packTracks(w.tp[(size_t)s]); });
             callOutliers();
             pool_->run(N, [&](int s) { applyOutliers(s, 100.0); est_[(size_t)s]->packSolve(w.sp[(size_t)s]); });
             callSolve();
-            margin_and_tracks(packs);
-            for (auto &e : est_) e->stage_flag = Estimator::INITED;
-            slide_and_rows(3.0);
-            if (packs && async_margin_) submitMargin(packs);
+            pending_ = 2;
         } else {
             pool_->run(N, [&](int s) {
                 pre(s);
@@ -1054,12 +1038,46 @@ void EstimatorBatch::processImage(const double *headers, const FeatureManager::I
         pool_->run(N, [&](int s) { applyTriangulate(s); est_[(size_t)s]->packSolve(w.sp[(size_t)s]); });
         g_bclock.lap(3);
         callSolve();
-        margin_and_tracks(packs);
-        slide_and_rows(p_.OUTLIER_T);
-        if (packs && async_margin_) submitMargin(packs);
-        g_bclock.frames++;
+        pending_ = 1;
     }
     if (keyframe) for (int s = 0; s < N; s++) keyframe[s] = kf[(size_t)s] != 0;
+}
+void EstimatorBatch::processImageFinish()
+{
+    if (pending_ == 0) return;
+    const int N = size();
+    Work &w = *work_;
+    const bool init_frame = pending_ == 2;
+    pending_ = 0;
+    g_bclock.start();
+    readSolve();
+    // Estimator::optimization behind the solve: double2Matrix, then margin() (frame_count == WINDOW_SIZE here) -- and the tracks for the outlier scores
+    std::shared_ptr<std::vector<MargPack>> packs;
+    const bool do_margin = p_.ESTIMATE_LASER != 0;
+    if (do_margin) { marginWait(); packs = std::make_shared<std::vector<MargPack>>((size_t)N); }
+    pool_->run(N, [&](int s) {
+        applySolve(s);
+        if (do_margin) est_[(size_t)s]->packMargin((*packs)[(size_t)s]);
+        est_[(size_t)s]->packTracks(w.tp[(size_t)s]);
+    });
+    g_bclock.lap(7);
+    // (overlapped marginalisation: the packs are handed to the worker at the END of the frame -- its kernels then run under the next frame's host passes
+    // instead of beside this frame's outlier / depth-shift calls, which they delayed by ~0.4 ms at 256 streams; inline: here, the reference's place)
+    // (few streams: right away, like the single Estimator -- the job is short and is over before the next frame's first call; LMONO_BATCH_MARGIN_EARLY forces it)
+    static const bool force_early = std::getenv("LMONO_BATCH_MARGIN_EARLY") != nullptr;
+    const bool early = force_early || N < 64;
+    if (do_margin && (!async_margin_ || early)) { submitMargin(packs); packs.reset(); }
+    g_bclock.lap(8);
+    if (init_frame) for (auto &e : est_) e->stage_flag = Estimator::INITED;
+    const double outlier_error = init_frame ? 3.0 : p_.OUTLIER_T;
+    callOutliers();
+    pool_->run(N, [&](int s) { applyOutliers(s, outlier_error); w.due[(size_t)s] = est_[(size_t)s]->slideWindowBegin(w.shp[(size_t)s]) ? 1 : 0; });
+    g_bclock.lap(9);
+    callShift();
+    pool_->run(N, [&](int s) { if (w.due[(size_t)s]) est_[(size_t)s]->slideWindowFinish(&w.shout[(size_t)w.shoff[(size_t)s]]); est_[(size_t)s]->pushOdometryRow(); });
+    g_bclock.lap(10);
+    if (packs && async_margin_) submitMargin(packs);
+    if (!init_frame) g_bclock.frames++;
 }
 
 // ---- A-LOAM nodes ---------------------------------------------------------------------------------------------------

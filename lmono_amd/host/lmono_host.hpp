@@ -237,6 +237,10 @@ public:
     // one frame of every stream: headers[n], images[n], transform_to_init[n] (4 x 4 row-major LiDAR poses); keyframe[n] (optional) as processImage returns it
     void processImage(const double *headers, const FeatureManager::Image *images, const double (*transform_to_init)[16], bool *keyframe = nullptr);
     void processImage(const double *headers, const FeatureManager::Image *const *images, const double (*transform_to_init)[16], bool *keyframe = nullptr);   // images by pointer
+    // the same frame in two halves around the (asynchronous) window solve: Begin returns with the solve in flight, Finish waits for it and runs the rest of the frame.
+    // One thread can interleave several batches (own contexts) that way: a batch's host passes under another batch's solve
+    void processImageBegin(const double *headers, const FeatureManager::Image *const *images, const double (*transform_to_init)[16], bool *keyframe = nullptr);
+    void processImageFinish();
     void setAsyncMargin(bool on);          // marginalisation of frame k beside frame k + 1 (second context, own stream, one worker thread), as Estimator::setAsyncMargin
     void marginWait();
 private:
@@ -247,6 +251,7 @@ private:
     void callOutliers();
     void applyOutliers(int s, double error);
     void callSolve();
+    void readSolve();
     void applySolve(int s);
     void submitMargin(std::shared_ptr<std::vector<MargPack>> packs);
     void callShift();
@@ -259,6 +264,7 @@ private:
     std::unique_ptr<HipContext> margin_hip_;
     std::unique_ptr<MarginWorker> margin_worker_;
     bool async_margin_ = false;
+    int pending_ = 0;                      // a frame between Begin and Finish: 1 = an INITED frame, 2 = the initialisation frame
 };
 
 // ---- A-LOAM nodes ---------------------------------------------------------------------------------------------------
