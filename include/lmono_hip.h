@@ -71,8 +71,9 @@ int         lmono_synchronize(lmono_ctx *);
 #define LMONO_OPT_BOUNDARY_TOL 4
 /* workgroups per window of lmono_ba_solve (the K = 1 / 2 / 4 / 8 workgroups of a window share its linearisations and candidate costs; the sums are formed
  * per 16-observation segment and added in segment order, so the result is the same bit for bit whatever K is): 0 (default) = as many as keep the
- * batch within half the compute units (8 for up to 16 windows, 4 for up to 32, 2 for up to 64, else 1; at most 4 when the windows average fewer than 64
- * segments); 1, 2, 4, 8 = that many.  Takes effect at the next
+ * batch within half the device's compute units (hipDeviceProp_t::multiProcessorCount; on 256 CUs: 8 for up to 16 windows, 4 for up to 32, 2 for up to 64, else 1; at most 4
+ * when the windows average fewer than 64 segments); 1, 2, 4, 8 = that many.  A cluster whose workgroups do not all become resident gives up (bounded polls) and
+ * lmono_ba_batch_read solves the batch again with one workgroup per window: same bytes.  Takes effect at the next
  * lmono_ba_batch_create / _update of the context (the scratch is sized then).  (Slot 5 was round 3's LMONO_OPT_ODOM_PERSIST, removed in round 4.)   */
 #define LMONO_OPT_BA_CLUSTER 5
 /* lead-in seeding of lmono_odom_batch[_d]'s chains (slot 6: round 3's LMONO_OPT_CORR_SECT, removed since): 0 = every lead-in starts from the identity and
@@ -294,7 +295,7 @@ int lmono_shift_depth_batch(lmono_ctx *, int n_windows, const double *frames_h, 
  * tracks anchored at frame 0 (observations grouped by track; obs_j in 1..10; obs_pts = pt_i.xy, pt_j.xy -- the
  * reference passes the never-initialised right_pt here).  Kept blocks, in this order: ex, pose1 .. pose10 (n = 66).
  * lin_J_h [n_windows][66*66] = linearized_jacobians, lin_r_h [n_windows][66] = linearized_residuals (defined up to an
- * orthogonal row transform: compare J^T J and J^T r); status_h bit 0: H_mm needed the eps = 1e-8 cut.
+ * orthogonal row transform: compare J^T J and J^T r); status_h bit 0: H_mm needed the eps = 1e-8 cut; bit 1: the QL iteration of the eigen-decomposition hit its 60-sweep cap on an eigenvalue (never seen).
  * lmono_marg_evaluate: residual = r0 + J dx with x0_h / x_h [n_windows][11][7] (ex, pose1..pose10).               */
 int lmono_marginalize(lmono_ctx *, int n_windows, const int *feat_off_h, const int *obs_off_h, const double *poses_h, const double *ex_h,
                       const double *inv_depth_h, const int *obs_feat_h, const int *obs_j_h, const double *obs_pts_h,

@@ -10,8 +10,8 @@
 // an eps = 1e-8 cut; the structured form applies the same cut to D and to S_A and agrees with it to rounding whenever
 // H_mm has no eigenvalue near eps (every depth observed, pose0 held by the LASERFactor) -- the well-posed case the
 // parity tests cover; a degenerate H_mm is flagged in the status word.  The 66x66 eigen-decomposition of H' that
-// yields linearized_jacobians = sqrt(S) V^T and linearized_residuals = sqrt(S^-1) V^T b' is a parallel (round-robin)
-// Jacobi iteration in LDS.  As in the reference the result is a prior that Estimator::optimization never consumes
+// yields linearized_jacobians = sqrt(S) V^T and linearized_residuals = sqrt(S^-1) V^T b' is a Householder tridiagonalisation +
+// implicit QL in LDS (marg_eig_ql; rounds 2-5: a parallel round-robin Jacobi iteration).  As in the reference the result is a prior that Estimator::optimization never consumes
 // (MarginalizationInfo::valid stays false).
 #include "common.hpp"
 
@@ -655,7 +655,7 @@ __global__ __launch_bounds__(128) void k_marg_evaluate(int n_windows, const doub
 // ---- MARGIN_SECOND_NEW (Estimator.cc:1406-1470): the previous prior, as the only factor (Marginalization::Evaluate at the current
 // parameter values, MarginalizationFactor.cc:309-373), loses the block that aliases para_pose[WINDOW_SIZE - 1].
 // One workgroup per window: dx, r = r0 + J0 dx, H = J0^T J0 and b = J0^T r with the dropped block's six columns first, eigen
-// pseudo-inverse of the 6x6 H_mm (eps cut), Schur complement, parallel Jacobi eigen-decomposition of the (n0 - 6)-square H',
+// pseudo-inverse of the 6x6 H_mm (eps cut), Schur complement, eigen-decomposition (marg_eig_ql) of the (n0 - 6)-square H',
 // linearized_jacobians = sqrt(S) V^T, linearized_residuals = sqrt(S^-1) V^T b'.  Kept blocks stay in their old order.
 struct Marg2Batch {
     int n_windows, nb, drop;     // blocks of the previous prior (<= 11), index of the dropped one

@@ -130,11 +130,13 @@ def test_101_scans_through_both_halves(oracle, gpu_ctx, tmp_path):
     # (twelve draws: the spread is heavy-tailed, and four draws under-estimated it -- a GPU build that only re-ordered its fixed-order sums landed 30 mm away while four draws said 7 mm).  On this stream it moves by 4 ... 27 mm -- the chained, unconverged solves after frame 60 amplify the 12th digit to
     # centimetres -- so no two implementations that differ in rounding can promise north_star's 1 cm here; the bound below is the larger of
     # 1 cm and twice the oracle's own spread over the draws (the spread is heavy-tailed: 4, 12, 20, 27 mm have all been drawn).
-    d_self = 0.0
+    d_draws = []
     for sd in range(12):
         st_p = dict(st); st_p["L0"] = st["L0"].copy(); st_p["L0"][:, :3, 3] += 1e-12 * np.random.default_rng(sd).standard_normal((n, 3))
         est_p, _ = S.replay_oracle(st_p)
-        d_self = max(d_self, np.abs(np.array(est_p.trajectory)[:, 1:4] - np.array(est.trajectory)[:, 1:4]).max())
+        d_draws.append(np.abs(np.array(est_p.trajectory)[:, 1:4] - np.array(est.trajectory)[:, 1:4]).max())
+    d_self = max(d_draws)
+    d_med = float(np.median(d_draws))                # (the bar must not loosen with the number of draws -- a maximum does, a median does not)
     fx = tmp_path / "config0.bin"
     s2.write_stream(fx, st)
     out = subprocess.run([EXE, str(fx), str(tmp_path / "new_odometry.txt")], capture_output=True, text=True, timeout=600)
@@ -169,8 +171,13 @@ def test_101_scans_through_both_halves(oracle, gpu_ctx, tmp_path):
     # fixed-order sums landed 1.7, 3.3, 15.8 and 30 mm from the oracle).  Bars: 1e-6 m over the first 40 windows; overall north_star's 1 cm or the
     # twice the oracle's own spread, whichever is larger; identical keyframe / marginalisation decisions throughout; the same distance from the truth as
     # the CPU path (below).  The implementation-level statement is part (1) above: every window from identical state.
-    assert np.abs(odo_e[:40, 1:4] - ref_e[:40, 1:4]).max() < 1e-6
-    assert d < max(0.01, 2.0 * d_self)                         # north_star's 1 cm, or twice the oracle's own spread where the stream is worse conditioned than that
+    assert np.abs(odo_e[:54, 1:4] - ref_e[:54, 1:4]).max() < 1e-6          # the well-conditioned prefix (frames 10 .. 63: measured 1e-9 .. 5e-8; the stretch behind amplifies 1e-8 to 1e-5 in one frame)
+    # north_star's 1 cm, or -- where the stream is worse conditioned than that -- twice the MEDIAN of the oracle's own spread over the draws (round 6: was the maximum, which
+    # only grows with more draws); the build's distance is recorded so that a drift between builds shows (round 5's builds: 1.7 / 3.3 / 15.8 / 30 mm; round 6: 6.2 mm)
+    if os.path.isdir(dump):
+        with open(os.path.join(dump, "config0_free_run_distance.txt"), "w") as fh:
+            fh.write("GPU free run vs oracle: max |dP| %.3e m; oracle vs itself (12 draws of 1e-12 m): median %.3e, max %.3e m\n" % (d, d_med, d_self))
+    assert d < max(0.01, 2.0 * d_med)
     for k, (row, r) in enumerate(zip(frm, log)):
         assert (int(row[1]), int(row[2]), int(row[3])) == (r[0], r[1], r[2]) and (int(row[7]), int(row[8])) == (r[6], r[7]), "frame %d" % k
     # the fused trajectory (camera-aligned Estimator world) follows the ground truth
