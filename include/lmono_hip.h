@@ -224,13 +224,15 @@ int lmono_factor_eval_blocks_d(lmono_ctx *, int kind, int count, const double *p
  * para_depth_inv[F][1] (Estimator.h:255-257) with PriorFactor / LASERFactor / MonoProjectionFactor+CauchyLoss(1).
  * A window depends on its predecessor, so a batch holds windows of independent sequences.  All arrays are host
  * pointers; lmono_ba_batch_create copies them into HBM once, lmono_ba_solve runs one workgroup per window.
- * Supported maximum: LMONO_BA_MAX_FEATURES = 1024 inverse-depth blocks per window (the reference sizes para_depth_inv[10000],
- * Estimator.h:256; its tracker caps a frame at 150 new tracks, FeatureTracker.cc:21, of which the ones tracked >= TRACK_CNT frames
- * enter a solve -- 100-300 on the S2 streams).  Up to 448 features the per-feature vectors of the dogleg step
+ * Supported maximum: LMONO_BA_MAX_FEATURES = 1664 inverse-depth blocks per window (the reference sizes para_depth_inv[10000],
+ * Estimator.h:256; its tracker caps a frame at MAX_CNT = 150 tracks, FeatureTracker.cc:21, so the 11 frames of a window can hold at
+ * most 1650 tracks, of which the ones tracked >= TRACK_CNT frames enter a solve -- 100-300 on the S2 streams, SURVEY.md section 8:
+ * the bound is above anything the reference's own front end can produce).  Up to 448 features the per-feature vectors of the dogleg step
  * (scale, D, gs, gn, va, vb, H_ff, g_f: 8 doubles per feature) live in LDS beside the 72 x 72 reduced system; a batch with a larger
  * window runs a second instantiation of the kernels that keeps them in an L2 scratch (same arithmetic in the same order, slower per
- * iteration).  A window above 1024 is refused with LMONO_ECAPACITY by lmono_ba_batch_create / _update -- nothing is truncated.       */
-#define LMONO_BA_MAX_FEATURES 1024
+ * iteration).  A window above the bound is refused with LMONO_ECAPACITY by lmono_ba_batch_create / _update (and by the per-track
+ * calls: lmono_triangulate, lmono_depth_refine, lmono_outlier_scores, lmono_shift_depth*) -- nothing is truncated.               */
+#define LMONO_BA_MAX_FEATURES 1664
 typedef struct lmono_ba_batch lmono_ba_batch;
 typedef struct {
     int n_windows;

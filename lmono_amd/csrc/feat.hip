@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void k_depth_refine(FeatBatch B)
     __syncthreads();
     const double *Rlc = sRlc, *Tlc = sTlc;
     // per-thread feature slots: features f0 + tid + 256 m, at most kSlots per thread
-    constexpr int kSlots = 4;   // <= 1024 features per window
+    constexpr int kSlots = (LMONO_BA_MAX_FEATURES + 255) / 256;   // tracks per thread: a window holds at most LMONO_BA_MAX_FEATURES
     double x[kSlots], h[kSlots], g[kSlots], scale[kSlots], diag[kSlots], step[kSlots], cand[kSlots];
     bool act[kSlots];
     for (int m = 0; m < kSlots; m++) {

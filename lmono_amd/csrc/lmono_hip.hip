@@ -1225,7 +1225,7 @@ static int ba_fill(lmono_ctx *c, lmono_ba_batch *b, const lmono_ba_desc *d)
     const int W = d->n_windows;
     const int TF = d->feat_off[W], TO = d->obs_off[W];
     for (int w = 0; w < W; w++) {
-        if (d->feat_off[w + 1] - d->feat_off[w] > kBaMaxFeat) { c->err = "lmono_ba_batch_create: more than LMONO_BA_MAX_FEATURES (1024) features in a window"; return LMONO_ECAPACITY; }
+        if (d->feat_off[w + 1] - d->feat_off[w] > kBaMaxFeat) { c->err = "lmono_ba_batch_create: more than LMONO_BA_MAX_FEATURES (" + std::to_string(kBaMaxFeat) + ") features in a window"; return LMONO_ECAPACITY; }
         if (d->flags[4 * w] < 2 || d->flags[4 * w] > kBaMaxPoses) { c->err = "lmono_ba_batch_create: n_poses must be 2..11"; return LMONO_EINVAL; }
     }
     // first observation of every feature: observations must be grouped by (window, feature) in ascending order
@@ -1616,7 +1616,7 @@ static int feat_setup(lmono_ctx *c, DevBuf &db, FeatBatch &B, int n_windows, con
     if (!c || n_windows <= 0 || !feat_off || !Rs || !Ps || !tlc || !start_frame || !obs_off || !pts || !depth) return LMONO_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
     const int F = feat_off[n_windows];
-    for (int w = 0; w < n_windows; w++) if (feat_off[w + 1] - feat_off[w] > 1024) { c->err = "more than 1024 features in a window"; return LMONO_ECAPACITY; }
+    for (int w = 0; w < n_windows; w++) if (feat_off[w + 1] - feat_off[w] > LMONO_BA_MAX_FEATURES) { c->err = "more than LMONO_BA_MAX_FEATURES (" + std::to_string(LMONO_BA_MAX_FEATURES) + ") tracks in a window"; return LMONO_ECAPACITY; }
     const int TO = F > 0 ? obs_off[F] : 0;
     bool ok = true;
     B.n_windows = n_windows;

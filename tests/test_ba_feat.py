@@ -99,3 +99,26 @@ def test_gpu_feature_kernels_match_oracle(oracle, gpu_ctx):
     got = gpu_ctx.shift_depth_batch(frames, pts, deps)
     for g, wv in zip(got, want):
         assert g.tobytes() == wv.tobytes()
+
+
+@pytest.mark.gpu
+def test_gpu_feature_kernels_at_the_trackers_ceiling(oracle, gpu_ctx):
+    """LMONO_BA_MAX_FEATURES = 1664 tracks per window (11 frames x the tracker's MAX_CNT = 150, FeatureTracker.cc:21): a window of ~1600 tracks goes
+    through the track-per-thread refinement (k_depth_refine: above the 1024 threads of the item kernel) and matches the oracle; a larger one is refused."""
+    import lmono_amd
+    w0 = K.make_window(54, n_landmarks=40000, max_tracks=1000, min_dist=10, pix_sigma=0.5, perturb=False)
+    w = dict(Rs=w0["gt_Rs"], Ps=w0["gt_Ps"], tlc=w0["tlc"], trk_start=w0["trk_start"], trk_off=w0["trk_off"], trk_pts=w0["trk_pts"], true=w0["trk_true_depth"])
+    n = len(w["trk_start"])
+    assert 1024 < n <= 1664
+    d_gpu, flag_gpu = gpu_ctx.triangulate([w], -np.ones(n))
+    d0, d1, flag = oracle.triangulate(w["Rs"], w["Ps"], w["tlc"], w["trk_start"], w["trk_off"], w["trk_pts"], -np.ones(n))
+    assert np.array_equal(flag_gpu, flag)
+    # inverse depths (the optimised quantity), relative: two tracks without a usable linear start run away to 1 / d ~ 6e7 and are flagged 2 on both sides
+    assert (np.abs(1.0 / d_gpu - 1.0 / d1) <= 1e-9 * np.maximum(1.0, np.abs(1.0 / d1))).all()
+    sc = oracle.outlier_scores(w["Rs"], w["Ps"], w["tlc"], w["trk_start"], w["trk_off"], w["trk_pts"], d1)
+    assert np.abs(gpu_ctx.outlier_scores([w], d_gpu) - sc).max() < 1e-6 * (np.abs(sc).max() + 1)
+    w1 = K.make_window(54, n_landmarks=60000, max_tracks=1100, min_dist=9, pix_sigma=0.5, perturb=False)
+    big = dict(Rs=w1["gt_Rs"], Ps=w1["gt_Ps"], tlc=w1["tlc"], trk_start=w1["trk_start"], trk_off=w1["trk_off"], trk_pts=w1["trk_pts"])
+    assert len(big["trk_start"]) > 1664
+    with pytest.raises(lmono_amd.LmonoError):
+        gpu_ctx.triangulate([big], -np.ones(len(big["trk_start"])))
