@@ -259,7 +259,7 @@ private:
     Params p_;
     std::vector<std::unique_ptr<Estimator>> est_;
     lmono_ba_batch *ba_batch_ = nullptr;
-    std::unique_ptr<HostPool> pool_;
+    std::shared_ptr<HostPool> pool_;       // shared by the EstimatorBatches of a process that ask for the same number of threads (groups driven by one thread)
     std::unique_ptr<Work> work_;
     std::unique_ptr<HipContext> margin_hip_;
     std::unique_ptr<MarginWorker> margin_worker_;

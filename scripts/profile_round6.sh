@@ -105,12 +105,14 @@ echo "[ba] done"
 fi
 if [ "$PART" = streams ]; then
 : > $OUT/ba_seq_streams.txt
-for N in 8 64 256; do
-  LMONO_HOST_TIMING=1 timeout -k 10 1000 python3 bench.py --workload ba-seq --seq-streams $N > $OUT/ba_seq_${N}streams.json 2> $OUT/ba_seq_${N}streams.err || { echo "N=$N failed" >> $OUT/ba_seq_streams.txt; continue; }
+# (streams, groups): one lock-step batch per size, then 256 streams as two batches of 128 driven by one thread (one batch's host passes under the other's solve)
+for NG in "8 1" "64 1" "256 1" "256 2"; do
+  set -- $NG; N=$1; G=$2; F=ba_seq_${N}streams; [ "$G" != 1 ] && F=${F}_${G}groups
+  LMONO_HOST_TIMING=1 timeout -k 10 1000 python3 bench.py --workload ba-seq --seq-streams $N --seq-groups $G > $OUT/$F.json 2> $OUT/$F.err || { echo "N=$N G=$G failed" >> $OUT/ba_seq_streams.txt; continue; }
   python3 -c "
-import json; d=json.load(open('$OUT/ba_seq_${N}streams.json')); c=d['config']
-print('streams', c['streams'], '| frames/s', d['value'], '| ms per lock-step frame', c['ms_per_lockstep_frame'], '| inline marginalisation', c['inline_marginalisation']['frames_per_s'], '| every stream = its single-stream run:', c['every_stream_equals_its_single_stream_run'], '(%d files)' % c['files_verified'], '| single stream', c['single_stream_frames_per_s'], 'frames/s')" >> $OUT/ba_seq_streams.txt
-  grep -h BATCHTIM $OUT/ba_seq_${N}streams.err >> $OUT/ba_seq_streams.txt
+import json; d=json.load(open('$OUT/$F.json')); c=d['config']
+print('streams', c['streams'], '| groups', c['groups'], '| frames/s', d['value'], '| ms per lock-step frame', c['ms_per_lockstep_frame'], '| inline marginalisation', c['inline_marginalisation']['frames_per_s'], '| every stream = its single-stream run:', c['every_stream_equals_its_single_stream_run'], '(%d files)' % c['files_verified'], '| single stream', c['single_stream_frames_per_s'], 'frames/s')" >> $OUT/ba_seq_streams.txt
+  grep -h BATCHTIM $OUT/$F.err >> $OUT/ba_seq_streams.txt
 done
 cat $OUT/ba_seq_streams.txt
 echo "[streams] done"
