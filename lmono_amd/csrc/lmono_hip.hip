@@ -11,6 +11,12 @@
 
 #include <string>
 #include <vector>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <atomic>
+#include <functional>
+#include <memory>
 #include <chrono>
 #include <algorithm>
 #include <cstdio>
@@ -21,6 +27,91 @@ constexpr int kListGrid = 256;       // workgroups of k_correspond_list (fixed: 
 using namespace lmono;
 
 struct EvSet { hipEvent_t e[10]; bool reg = false, odom = false; std::vector<hipEvent_t> kev; int n_kev = 0; };  // kev: (begin, mid, end) per odometry launch pair
+
+// Worker threads for the host halves that are per-stream work over many streams (lmono_mapper_process_batch's update plan): fn(item, thread) for
+// item in [0, n).  Every thread owns a contiguous share of the items and takes from the others' when it is done; the caller takes part.
+class HostWorkers {
+public:
+    explicit HostWorkers(int n_threads) : T_(n_threads < 1 ? 1 : n_threads), cur_((size_t)(n_threads < 1 ? 1 : n_threads))
+    {
+        for (int t = 1; t < T_; t++) th_.emplace_back([this, t] { work(t); });
+    }
+    ~HostWorkers()
+    {
+        { std::lock_guard<std::mutex> g(mu_); quit_ = true; gen_.fetch_add(1, std::memory_order_release); }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    int threads() const { return T_; }
+    void run(int n, const std::function<void(int, int)> &fn)
+    {
+        if (n <= 0) return;
+        if (th_.empty() || n == 1) { for (int i = 0; i < n; i++) fn(i, 0); return; }
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            fn_ = &fn; n_ = n;
+            for (int t = 0; t < T_; t++) cur_[(size_t)t].v.store(lo(t, n), std::memory_order_relaxed);
+            left_.store(n, std::memory_order_relaxed);
+            gen_.fetch_add(1, std::memory_order_release);
+        }
+        cv_.notify_all();
+        take(0, &fn, n);
+        while (left_.load(std::memory_order_acquire) != 0) relax();
+        { std::lock_guard<std::mutex> g(mu_); fn_ = nullptr; }                 // nobody joins this pass any more ...
+        while (active_.load(std::memory_order_acquire) != 0) relax();         // ... and those who did have left it
+    }
+private:
+    struct alignas(64) Cursor { std::atomic<int> v{ 0 }; };
+    int lo(int t, int n) const { return (int)((long long)t * n / T_); }
+    static void relax() { __builtin_ia32_pause(); }
+    void take(int me, const std::function<void(int, int)> *fn, int n)
+    {
+        for (int k = 0; k < T_; k++) {
+            const int t = (me + k) % T_, hi = lo(t + 1, n);
+            for (;;) {
+                const int i = cur_[(size_t)t].v.fetch_add(1, std::memory_order_relaxed);
+                if (i >= hi) break;
+                (*fn)(i, me);                       // (the items report errors through their own result slots: nothing throws in here)
+                left_.fetch_sub(1, std::memory_order_acq_rel);
+            }
+        }
+    }
+    void work(int me)
+    {
+        unsigned long seen = 0;
+        for (;;) {
+            bool got = false;
+            for (int spin = 0; spin < 8192; spin++) { if (gen_.load(std::memory_order_acquire) != seen) { got = true; break; } relax(); }
+            const std::function<void(int, int)> *fn; int n;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                if (!got) cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; });
+                seen = gen_.load(std::memory_order_acquire);
+                if (quit_) return;
+                fn = fn_; n = n_;
+                if (fn) active_.fetch_add(1, std::memory_order_acq_rel);
+            }
+            if (fn) { take(me, fn, n); active_.fetch_sub(1, std::memory_order_acq_rel); }
+        }
+    }
+    const int T_;
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    const std::function<void(int, int)> *fn_ = nullptr;
+    int n_ = 0;
+    std::vector<Cursor> cur_;
+    std::atomic<int> left_{ 0 }, active_{ 0 };
+    std::atomic<unsigned long> gen_{ 0 };
+    bool quit_ = false;
+};
+
+// per-thread tables of lmono_mapper_process_batch's update plan (indexed by cube: 21 x 21 x 11)
+struct MapPlanScratch {
+    struct Run { int ind, at, len; };
+    std::vector<char> is_valid; std::vector<int> add, fill, cand; std::vector<int64_t> cat_off; std::vector<Run> runs;
+    MapPlanScratch() : is_valid((size_t)lmono::kMdCubes, 0), add((size_t)lmono::kMdCubes, 0), fill((size_t)lmono::kMdCubes, 0), cat_off((size_t)lmono::kMdCubes, -1) {}
+};
 
 struct lmono_ctx {
     int device = 0;
@@ -47,6 +138,8 @@ struct lmono_ctx {
     char *stage = nullptr;                   // pinned staging of DevBuf's small uploads (stage_all: every buffer ever allocated, freed with the context)
     size_t stage_cap = 0;
     std::vector<void *> stage_all;
+    std::vector<MapPlanScratch> plan_scratch;
+    std::unique_ptr<HostWorkers> workers;    // created by the first batched call that has per-stream host work for them (LMONO_LIB_THREADS, default min(8, cores))
 
     hipEvent_t *next_set()
     {
@@ -2764,16 +2857,33 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
     int *pos_all = (int *)ms[0]->pin_blob;
     sj.resize((size_t)2 * n);
     {
-        std::vector<char> is_valid((size_t)kMapCubes, 0);
-        std::vector<int> add((size_t)kMapCubes, 0), fill((size_t)kMapCubes, 0), cand;
-        std::vector<int64_t> cat_off((size_t)kMapCubes, -1);
-        struct Run { int ind, at, len; };
-        std::vector<Run> runs;
-        for (int s = 0; s < n; s++) {
+        // The streams are independent: every stream's plan is made by one worker thread into the stream's own lists (touched cubes, copy jobs) and its own
+        // range of the placements; the lists are joined in stream order afterwards, so the tables are the ones a single loop over the streams writes.
+        // (64 streams on the caller's thread: 0.75 ms of a 3.5-ms batched frame with the GPU idle.)
+        typedef MapPlanScratch::Run Run;
+        typedef MapPlanScratch PlanScratch;
+        struct PlanOut { std::vector<Touched> touched; std::vector<CopyJob> copy; const char *err = nullptr; };
+        if (!c->workers && n >= 8) {
+            int nt = 0;
+            if (const char *e = getenv("LMONO_LIB_THREADS")) nt = atoi(e);
+            if (nt <= 0) nt = (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency()));        // (4 / 8 / 16 threads: plan 0.36 / 0.26 / 0.25 ms for 64 streams)
+            c->workers.reset(new HostWorkers(nt));
+        }
+        const int T = c->workers && n >= 8 ? c->workers->threads() : 1;
+        if ((int)c->plan_scratch.size() < T) c->plan_scratch.resize((size_t)T);      // (every stream leaves its thread's tables as it found them: they live from call to call)
+        std::vector<PlanScratch> &scratch = c->plan_scratch;
+        std::vector<PlanOut> outs((size_t)n);
+        auto plan_stream = [&](int s, int tid) {
+            PlanScratch &ps = scratch[(size_t)tid];
+            std::vector<char> &is_valid = ps.is_valid;
+            std::vector<int> &add = ps.add, &fill = ps.fill, &cand = ps.cand;
+            std::vector<int64_t> &cat_off = ps.cat_off;
+            std::vector<Run> &runs = ps.runs;
+            PlanOut &out = outs[(size_t)s];
             lmono_mapper *m = ms[s];
             FrameState &f = F[(size_t)s];
             for (int ind : f.valid) is_valid[(size_t)ind] = 1;
-            for (int t = 0; t < 2; t++) {
+            for (int t = 0; t < 2 && !out.err; t++) {
                 // candidates in ascending cube order: the neighbourhood and every other cube a new point falls into
                 // (the stack is in voxel order: neighbours in it mostly share a cube -- the per-point work is done per RUN of equal cube indices)
                 cand.assign(f.valid.begin(), f.valid.end());
@@ -2802,23 +2912,31 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
                     const bool v = is_valid[(size_t)ind] != 0;
                     if (!((v && sg.n + add[(size_t)ind] > 0) || (!v && add[(size_t)ind] > 0))) continue;
                     cat_off[(size_t)ind] = at;
-                    if (sg.n > 0) push_copy(copy, m->arena[t][m->half[t]] + sg.off, m->cat[t] + at, sg.n);
+                    if (sg.n > 0) push_copy(out.copy, m->arena[t][m->half[t]] + sg.off, m->cat[t] + at, sg.n);
                     const int n_in = sg.n + add[(size_t)ind];
-                    if (v && n_in > kVoxCloudMax) { c->err = "lmono_mapper: a cube holds more than 65536 points"; return LMONO_ECAPACITY; }
-                    touched.push_back({ s, t, ind, n_in, at, v });
+                    if (v && n_in > kVoxCloudMax && !out.err) out.err = "lmono_mapper: a cube holds more than 65536 points";
+                    out.touched.push_back({ s, t, ind, n_in, at, v });
                     at += n_in;
                 }
-                if (at > (int64_t)kMapNeighMax + kMapStackMax) { c->err = "lmono_mapper: frame touches more points than the workspace holds"; return LMONO_ECAPACITY; }
-                for (const Run &r : runs) {
-                    const int p0 = (int)(cat_off[(size_t)r.ind] + m->cube[(size_t)t][(size_t)r.ind].n + fill[(size_t)r.ind]);
-                    fill[(size_t)r.ind] += r.len;
-                    for (int k = 0; k < r.len; k++) ph[r.at + k] = p0 + k;
-                }
+                if (at > (int64_t)kMapNeighMax + kMapStackMax && !out.err) out.err = "lmono_mapper: frame touches more points than the workspace holds";
+                if (!out.err)
+                    for (const Run &r : runs) {
+                        const int p0 = (int)(cat_off[(size_t)r.ind] + m->cube[(size_t)t][(size_t)r.ind].n + fill[(size_t)r.ind]);
+                        fill[(size_t)r.ind] += r.len;
+                        for (int k = 0; k < r.len; k++) ph[r.at + k] = p0 + k;
+                    }
                 for (int ind : cand) { add[(size_t)ind] = 0; fill[(size_t)ind] = 0; cat_off[(size_t)ind] = -1; }
                 sj[(size_t)2 * s + t] = { m->newpts[t], nullptr, f.n_stack[t], m->cat[t] };       // .pos: set when the blob is placed
             }
             for (int ind : f.valid) is_valid[(size_t)ind] = 0;
-        }
+        };
+        if (T > 1) c->workers->run(n, plan_stream);
+        else for (int s = 0; s < n; s++) plan_stream(s, 0);
+        for (int s = 0; s < n; s++) if (outs[(size_t)s].err) { c->err = outs[(size_t)s].err; return LMONO_ECAPACITY; }
+        size_t nt_total = 0, nc_total = 0;
+        for (const PlanOut &o : outs) { nt_total += o.touched.size(); nc_total += o.copy.size(); }
+        touched.reserve(nt_total); copy.reserve(nc_total);
+        for (const PlanOut &o : outs) { touched.insert(touched.end(), o.touched.begin(), o.touched.end()); copy.insert(copy.end(), o.copy.begin(), o.copy.end()); }
     }
     if (stats_h) for (const Touched &T : touched) stats_h[(size_t)T.s * 8 + 7] += T.n_in;
     const double tpa = tnow();
