@@ -1994,8 +1994,8 @@ extern "C" int lmono_map_refine(lmono_ctx *c, int n_streams,
     (void)hipEventRecord(ev1, stream);
     for (int outer = 0; outer < 2; outer++) {
         if (max_nq > 0) {
-            hipLaunchKernelGGL(k_map_correspond, dim3((max_nq + 7) / 8, n_streams), dim3(256), 0, stream, (const MapStream *)st_d, outer);
-            hipLaunchKernelGGL(k_map_factor, dim3((max_nq + 63) / 64, n_streams), dim3(64), 0, stream, (const MapStream *)st_d, outer);
+            hipLaunchKernelGGL(k_map_correspond, dim3((max_nq + 7) / 8, n_streams), dim3(256), 0, stream, (const MapStream *)st_d, outer, 0, n_streams);
+            hipLaunchKernelGGL(k_map_factor, dim3((max_nq + 63) / 64, n_streams), dim3(64), 0, stream, (const MapStream *)st_d, outer, 0, n_streams);
         }
         launch_map_solve(stream, (const MapStream *)st_d, n_streams, outer, c->map_budget);
     }
@@ -2528,8 +2528,8 @@ static int mapper_process_dev(lmono_ctx *c, lmono_mapper *m, lmono_scan_batch *b
         const int per_stream = std::max(1, std::max((max_nq + 31) / 32, std::min((max_nq + 7) / 8, 2048)));
         for (int outer = 0; outer < 2; outer++) {
             if (max_nq > 0) {
-                hipLaunchKernelGGL(k_map_correspond, dim3((unsigned)per_stream, 1u), dim3(256), 0, st, S_d, outer);
-                hipLaunchKernelGGL(k_map_factor, dim3((unsigned)std::max(1, (per_stream + 7) / 8), 1u), dim3(64), 0, st, S_d, outer);
+                hipLaunchKernelGGL(k_map_correspond, dim3((unsigned)per_stream, 1u), dim3(256), 0, st, S_d, outer, 0, 1);
+                hipLaunchKernelGGL(k_map_factor, dim3((unsigned)std::max(1, (per_stream + 7) / 8), 1u), dim3(64), 0, st, S_d, outer, 0, 1);
             }
             launch_map_solve(st, S_d, 1, outer, c->map_budget);
         }
@@ -2782,8 +2782,14 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
             const int per_stream = std::max(1, std::max((max_nq + 31) / 32, std::min((max_nq + 7) / 8, (int)(2048 / act.size()))));
             for (int outer = 0; outer < 2; outer++) {
                 if (max_nq > 0) {
-                    hipLaunchKernelGGL(k_map_correspond, dim3((unsigned)per_stream, (unsigned)act.size()), dim3(256), 0, st, S_d, outer);
-                    hipLaunchKernelGGL(k_map_factor, dim3((unsigned)std::max(1, (per_stream + 7) / 8), (unsigned)act.size()), dim3(64), 0, st, S_d, outer);
+                    // (from 8 streams on: every stream's workgroups on one XCD -- map_block_of; LMONO_MAP_XCD=0: the 2-D launch, for measurements)
+                    static const bool xcd_off = [] { const char *e = getenv("LMONO_MAP_XCD"); return e && atoi(e) == 0; }();
+                    int nx_c = 0, nx_f = 0;
+                    const int na = (int)act.size(), per_f = std::max(1, (per_stream + 7) / 8);
+                    const dim3 g_c = xcd_off ? dim3((unsigned)per_stream, (unsigned)na) : map_stream_grid(per_stream, na, nx_c);
+                    const dim3 g_f = xcd_off ? dim3((unsigned)per_f, (unsigned)na) : map_stream_grid(per_f, na, nx_f);
+                    hipLaunchKernelGGL(k_map_correspond, g_c, dim3(256), 0, st, S_d, outer, nx_c, na);
+                    hipLaunchKernelGGL(k_map_factor, g_f, dim3(64), 0, st, S_d, outer, nx_f, na);
                 }
                 launch_map_solve(st, S_d, (int)act.size(), outer, c->map_budget);
             }

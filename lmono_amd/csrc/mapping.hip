@@ -302,15 +302,34 @@ __device__ __forceinline__ void top5_insert(float *td, int *ti, float d, int idx
     }
 }
 
-__global__ __launch_bounds__(256) void k_map_correspond(const MapStream *streams, int outer)
+// Workgroup -> (block bx of nbx, stream) of the per-stream kernels.  nx = 0: a 2-D launch (x = block, y = stream).  nx > 0 (from 8 streams on): a 1-D launch
+// of 8 * nx * ceil(ny / 8) workgroups decoded so that ALL workgroups of a stream run on ONE XCD (workgroup id mod 8), the streams of an XCD one after
+// the other: a stream's map cloud and cell table (4-5 MB) then stay in that XCD's L2 instead of every L2 seeing every stream in flight.
+__device__ __forceinline__ bool map_block_of(int nx, int ny, int &bx, int &nbx, int &stream)
 {
-    const MapStream S = streams[blockIdx.y];
+    if (nx <= 0) { bx = (int)blockIdx.x; nbx = (int)gridDim.x; stream = (int)blockIdx.y; return true; }
+    const int id = (int)blockIdx.x, j = id >> 3;
+    stream = (id & 7) + 8 * (j / nx); bx = j % nx; nbx = nx;
+    return stream < ny;
+}
+static inline dim3 map_stream_grid(int per_stream, int n_streams, int &nx)
+{
+    if (n_streams < 8) { nx = 0; return dim3((unsigned)per_stream, (unsigned)n_streams); }
+    nx = per_stream;
+    return dim3((unsigned)(8 * per_stream * ((n_streams + 7) / 8)));
+}
+
+__global__ __launch_bounds__(256) void k_map_correspond(const MapStream *streams, int outer, int nx, int ny)
+{
+    int bx, nbx, sidx;
+    if (!map_block_of(nx, ny, bx, nbx, sidx)) return;
+    const MapStream S = streams[sidx];
     __shared__ int s_pre[8][kGroup], s_cst[8][kGroup];
     int ns0, ns1;
     map_stack_sizes(S, ns0, ns1);
     const int nq = ns0 + ns1;
     // (grid-stride over the points: the launch may be sized before the voxel filter's counts are known to the host)
-    for (int qi = blockIdx.x * 8 + (threadIdx.x >> 5); qi < nq; qi += gridDim.x * 8) {
+    for (int qi = bx * 8 + (threadIdx.x >> 5); qi < nq; qi += nbx * 8) {
     const int lane = threadIdx.x & 63, gl = threadIdx.x & 31, gbase = lane & ~31;
     const int which = qi < ns0 ? 0 : 1;
     const float4 p = S.stack[which][which ? qi - ns0 : qi];
@@ -398,13 +417,15 @@ __global__ __launch_bounds__(256) void k_map_correspond(const MapStream *streams
 // One thread per down-sampled scan point: the line test (covariance of the five neighbours, eigen-decomposition, largest
 // > 3 x middle -> LidarEdgeFactor against centre +- 0.1 dir) or the plane fit (all five within 0.2 ->
 // LidarPlaneNormFactor), written as an 80-B fp64 record.
-__global__ __launch_bounds__(64) void k_map_factor(const MapStream *streams, int outer)
+__global__ __launch_bounds__(64) void k_map_factor(const MapStream *streams, int outer, int nx, int ny)
 {
-    const MapStream S = streams[blockIdx.y];
+    int bx, nbx, sidx;
+    if (!map_block_of(nx, ny, bx, nbx, sidx)) return;
+    const MapStream S = streams[sidx];
     int ns0, ns1;
     map_stack_sizes(S, ns0, ns1);
     const int nq = ns0 + ns1;
-    for (int qi = blockIdx.x * 64 + threadIdx.x; qi < nq; qi += gridDim.x * 64) {
+    for (int qi = bx * 64 + threadIdx.x; qi < nq; qi += nbx * 64) {
     const int which = qi < ns0 ? 0 : 1;
     const int *nn = S.nn_tmp + (size_t)qi * 5;
     MapRec *rec = S.rec + qi;
