@@ -619,16 +619,17 @@ def ba_streams_secondary(streams=(1, 64, 256), frames=160):
     single = {}
     out = {"workload": "S2 frame streams (configs[2] shape), %d frames each, %d different files; EstimatorBatch: one batched C-ABI call per numeric step, marginalisation overlapped" % (frames, n_files),
            "frames_per_s": {}, "every_stream_equals_its_single_stream_run": True}
-    for N in streams:
+    # (the largest count once more as TWO lock-step batches driven by one thread: a batch's host passes run under the other's solve)
+    for N, G in [(N, 1) for N in streams] + [(max(streams), 2)] * (max(streams) >= 128):
         if N == 1:
             r = subprocess.run([exe, files[0], "-", "async"], capture_output=True, text=True, timeout=300)
         else:
-            r = subprocess.run([exe, files[0], "-", "async", "streams=%d" % N, "digest"] + files[1:], capture_output=True, text=True, timeout=600)
+            r = subprocess.run([exe, files[0], "-", "async", "streams=%d" % N, "groups=%d" % G, "digest"] + files[1:], capture_output=True, text=True, timeout=600)
         if r.returncode != 0:
             raise RuntimeError(r.stderr[-500:])
         lines = r.stdout.splitlines()
         tim = [ln for ln in lines if ln.startswith("TIM")][0].split()
-        out["frames_per_s"][str(N)] = round(max(N, 1) * 1e3 / float(tim[2]), 1)
+        out["frames_per_s"][str(N) if G == 1 else "%d as %d batches" % (N, G)] = round(max(N, 1) * 1e3 / float(tim[2]), 1)
         dig = {int(ln.split()[1]): ln.split()[2] for ln in lines if ln.startswith("DIG")}
         if N > 1:
             for k in range(min(n_files, N)):

@@ -43,13 +43,16 @@ public:
         for (auto &t : th_) t.join();
     }
     int threads() const { return T_; }
-    void run(int n, const std::function<void(int, int)> &fn)
+    bool run(int n, const std::function<void(int, int)> &fn)
     {
-        if (n <= 0) return;
-        if (th_.empty() || n == 1) { for (int i = 0; i < n; i++) fn(i, 0); return; }
+        if (n <= 0) return true;
+        if (th_.empty() || n == 1) {
+            try { for (int i = 0; i < n; i++) fn(i, 0); } catch (...) { return false; }
+            return true;
+        }
         {
             std::lock_guard<std::mutex> g(mu_);
-            fn_ = &fn; n_ = n;
+            fn_ = &fn; n_ = n; failed_.store(false, std::memory_order_relaxed);
             for (int t = 0; t < T_; t++) cur_[(size_t)t].v.store(lo(t, n), std::memory_order_relaxed);
             left_.store(n, std::memory_order_relaxed);
             gen_.fetch_add(1, std::memory_order_release);
@@ -59,6 +62,7 @@ public:
         while (left_.load(std::memory_order_acquire) != 0) relax();
         { std::lock_guard<std::mutex> g(mu_); fn_ = nullptr; }                 // nobody joins this pass any more ...
         while (active_.load(std::memory_order_acquire) != 0) relax();         // ... and those who did have left it
+        return !failed_.load(std::memory_order_relaxed);
     }
 private:
     struct alignas(64) Cursor { std::atomic<int> v{ 0 }; };
@@ -71,7 +75,8 @@ private:
             for (;;) {
                 const int i = cur_[(size_t)t].v.fetch_add(1, std::memory_order_relaxed);
                 if (i >= hi) break;
-                (*fn)(i, me);                       // (the items report errors through their own result slots: nothing throws in here)
+                try { (*fn)(i, me); } catch (...) { failed_.store(true, std::memory_order_relaxed); }      // (an item reports its errors through its own result slot; what is
+                                                                                                      // caught here is an allocation failure: run() returns false)
                 left_.fetch_sub(1, std::memory_order_acq_rel);
             }
         }
@@ -102,6 +107,7 @@ private:
     int n_ = 0;
     std::vector<Cursor> cur_;
     std::atomic<int> left_{ 0 }, active_{ 0 };
+    std::atomic<bool> failed_{ false };
     std::atomic<unsigned long> gen_{ 0 };
     bool quit_ = false;
 };
@@ -2936,8 +2942,10 @@ extern "C" int lmono_mapper_process_batch(lmono_ctx *c, int n, lmono_mapper *con
             }
             for (int ind : f.valid) is_valid[(size_t)ind] = 0;
         };
-        if (T > 1) c->workers->run(n, plan_stream);
-        else for (int s = 0; s < n; s++) plan_stream(s, 0);
+        bool planned = true;
+        if (T > 1) planned = c->workers->run(n, plan_stream);
+        else { try { for (int s = 0; s < n; s++) plan_stream(s, 0); } catch (...) { planned = false; } }
+        if (!planned) { c->plan_scratch.clear(); c->err = "lmono_mapper: out of host memory while planning the map update"; return LMONO_ENOMEM; }      // (the tables may be half-written)
         for (int s = 0; s < n; s++) if (outs[(size_t)s].err) { c->err = outs[(size_t)s].err; return LMONO_ECAPACITY; }
         size_t nt_total = 0, nc_total = 0;
         for (const PlanOut &o : outs) { nt_total += o.touched.size(); nc_total += o.copy.size(); }
