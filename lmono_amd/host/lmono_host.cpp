@@ -1105,11 +1105,12 @@ void EstimatorBatch::processImageFinish()
         est_[(size_t)s]->packTracks(w.tp[(size_t)s]);
     });
     g_bclock.lap(7);
-    // (overlapped marginalisation: the packs are handed to the worker at the END of the frame -- its kernels then run under the next frame's host passes
-    // instead of beside this frame's outlier / depth-shift calls, which they delayed by ~0.4 ms at 256 streams; inline: here, the reference's place)
-    // (few streams: right away, like the single Estimator -- the job is short and is over before the next frame's first call; LMONO_BATCH_MARGIN_EARLY forces it)
-    static const bool force_early = std::getenv("LMONO_BATCH_MARGIN_EARLY") != nullptr;
-    const bool early = force_early || N < 64;
+    // (overlapped marginalisation: the packs go to the worker right here, the reference's place -- its kernels run under this frame's outlier / slide passes
+    // and the next frame's first passes and are done before the next solve wants the CUs.  With the first host pool, whose passes were 2-3x slower, handing
+    // them over at the END of the frame measured better at 256 streams; with per-thread stream ownership it is the other way round (one box, 3 pairs each:
+    // 256 streams 6.60 / 6.79 / 6.82 -> 6.56 / 6.74 / 6.52 ms, 64 streams 5.12 / 5.01 / 4.95 -> 4.91 / 4.43 / 4.87).  LMONO_BATCH_MARGIN_LATE=1: the end of the frame.)
+    static const bool force_late = std::getenv("LMONO_BATCH_MARGIN_LATE") != nullptr;
+    const bool early = !force_late;
     if (do_margin && (!async_margin_ || early)) { submitMargin(packs); packs.reset(); }
     g_bclock.lap(8);
     if (init_frame) for (auto &e : est_) e->stage_flag = Estimator::INITED;
