@@ -1105,12 +1105,12 @@ void EstimatorBatch::processImageFinish()
         est_[(size_t)s]->packTracks(w.tp[(size_t)s]);
     });
     g_bclock.lap(7);
-    // (overlapped marginalisation: the packs go to the worker right here, the reference's place -- its kernels run under this frame's outlier / slide passes
-    // and the next frame's first passes and are done before the next solve wants the CUs.  With the first host pool, whose passes were 2-3x slower, handing
-    // them over at the END of the frame measured better at 256 streams; with per-thread stream ownership it is the other way round (one box, 3 pairs each:
-    // 256 streams 6.60 / 6.79 / 6.82 -> 6.56 / 6.74 / 6.52 ms, 64 streams 5.12 / 5.01 / 4.95 -> 4.91 / 4.43 / 4.87).  LMONO_BATCH_MARGIN_LATE=1: the end of the frame.)
-    static const bool force_late = std::getenv("LMONO_BATCH_MARGIN_LATE") != nullptr;
-    const bool early = !force_late;
+    // (overlapped marginalisation: few streams hand the packs to the worker right here, the reference's place -- the job is short and is over before the next
+    // frame's first call; from 64 streams on they go at the END of the frame.  Both placements were measured again with the owner-share pool, one box, pairs of
+    // runs: 8 streams 3.92 / 3.94 ms here vs 4.08 / 4.06 at the end; 64 streams 4.62 / 4.66 vs 4.64 / 4.63; 256 streams 7.18 / 6.13 vs 6.52 / 6.25 -- and over
+    // 2750 frames 64 streams wait 0.4 ms per frame for a job handed over here.  LMONO_BATCH_MARGIN_EARLY=1 forces this place.)
+    static const bool force_early = std::getenv("LMONO_BATCH_MARGIN_EARLY") != nullptr;
+    const bool early = force_early || N < 64;
     if (do_margin && (!async_margin_ || early)) { submitMargin(packs); packs.reset(); }
     g_bclock.lap(8);
     if (init_frame) for (auto &e : est_) e->stage_flag = Estimator::INITED;
