@@ -2519,11 +2519,17 @@ static int mapper_process_dev(lmono_ctx *c, lmono_mapper *m, lmono_scan_batch *b
         HIP_TRY(c, hipMemcpyAsync(&m->dev->tmp[0][0], &m->dev->tab[0][0], sizeof(int2) * 2 * kMapCubes, hipMemcpyDeviceToDevice, side));
         hipLaunchKernelGGL(k_map_shift, dim3((2 * kMapCubes + 255) / 256), dim3(256), 0, side, m->dev, sh.first, sh.second);
     }
-    hipLaunchKernelGGL(k_map_plan_gather, dim3(1), dim3(192), 0, side, cfg);
-    hipLaunchKernelGGL(k_copy_jobs_n, dim3(128), dim3(256), 0, side, (const CopyJob *)m->dev->gjobs, (const int *)&m->dev->n_gjobs);
+    // the neighbourhood's plan, its copies and the emptied hash tables in one launch (LMONO_MAP_MERGED=0: the three launches of rounds 4-5, for measurements)
+    static const bool merged = [] { const char *e = getenv("LMONO_MAP_MERGED"); return !(e && atoi(e) == 0); }();
+    if (merged)
+        hipLaunchKernelGGL(k_map_gather_copy_clear, dim3(kMgcGrid), dim3(kMgcT), 0, side, cfg);
+    else {
+        hipLaunchKernelGGL(k_map_plan_gather, dim3(1), dim3(192), 0, side, cfg);
+        hipLaunchKernelGGL(k_copy_jobs_n, dim3(128), dim3(256), 0, side, (const CopyJob *)m->dev->gjobs, (const int *)&m->dev->n_gjobs);
+    }
     {
         const int est = std::max(65536, std::max(m->nmap_seen[0], m->nmap_seen[1]) * 5 / 4 + 32768);
-        launch_cloud_grids(side, (const CloudJob *)m->dev->cj, 2, est);
+        launch_cloud_grids(side, (const CloudJob *)m->dev->cj, 2, est, merged);
     }
     HIP_TRY(c, hipEventRecord(m->ev_side, side));
     // ---- main stream: the optimisation
@@ -2554,6 +2560,8 @@ static int mapper_process_dev(lmono_ctx *c, lmono_mapper *m, lmono_scan_batch *b
         const int max_n = std::max(n_last[0], n_last[1]);
         if (max_n > 0) hipLaunchKernelGGL(k_map_assign, dim3((max_n + 255) / 256, 2), dim3(256), 0, st, (const AssignJob *)(blob + o_aj));
         HIP_TRY(c, hipEventRecord(m->ev_assign, st));
+        // (k_map_assign's work inside the plan kernel -- one launch and one gap fewer in front of it -- was built and measured: 2.50-2.61 k frames/s against
+        // 2.76-2.80 k; one compute unit transforming 11 k points costs more than the launch it saves)
         hipLaunchKernelGGL(k_map_plan_update, dim3(1), dim3(kMuT), 0, st, cfg);
         hipLaunchKernelGGL(k_copy_jobs_n, dim3(128), dim3(256), 0, st, (const CopyJob *)m->upd->copy, (const int *)&m->upd->n_copy);
         int cube_passes = 1;

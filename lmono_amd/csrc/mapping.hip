@@ -161,14 +161,14 @@ __global__ __launch_bounds__(kCgT) void k_grid_fill(const CloudJob *jobs)
 }
 
 // the four launches of a table of cloud jobs; max_n = the largest cloud among them
-static inline void launch_cloud_grids(hipStream_t st, const CloudJob *jobs_d, int n_jobs, int max_n)
+static inline void launch_cloud_grids(hipStream_t st, const CloudJob *jobs_d, int n_jobs, int max_n, bool cleared = false)
 {
     if (n_jobs <= 0) return;
     int T = 1024;
     while (T < max_n + 1) T <<= 1;
     const int per = 2048 / (n_jobs < 16 ? 1 : 4);           // elements per workgroup: few jobs -> more workgroups per job
     const unsigned bc = (unsigned)std::min(512, std::max(1, (T + per - 1) / per)), bp = (unsigned)std::min(512, std::max(1, (max_n + per - 1) / per));
-    hipLaunchKernelGGL(k_grid_clear, dim3(bc, (unsigned)n_jobs), dim3(kCgT), 0, st, jobs_d);
+    if (!cleared) hipLaunchKernelGGL(k_grid_clear, dim3(bc, (unsigned)n_jobs), dim3(kCgT), 0, st, jobs_d);      // (cleared: the tables were emptied by the caller's kernel)
     hipLaunchKernelGGL(k_grid_insert, dim3(bp, (unsigned)n_jobs), dim3(kCgT), 0, st, jobs_d);
     hipLaunchKernelGGL(k_grid_starts, dim3((unsigned)std::min(512, std::max(1, T / (8 * kCgT))), (unsigned)n_jobs), dim3(kCgT), 0, st, jobs_d);
     hipLaunchKernelGGL(k_grid_fill, dim3(bp, (unsigned)n_jobs), dim3(kCgT), 0, st, jobs_d);
@@ -1452,6 +1452,76 @@ __global__ __launch_bounds__(256) void k_copy_jobs_n(const CopyJob *jobs, const 
     for (int j = blockIdx.x; j < nj; j += gridDim.x) {
         const CopyJob J = jobs[j];
         for (int i = threadIdx.x; i < J.n; i += 256) J.dst[i] = J.src[i];
+    }
+}
+
+// k_map_plan_gather + k_copy_jobs_n + k_grid_clear in ONE launch (round 6: the single-stream frame is a chain of ~35 dependent launches; these three were
+// ~17 us of kernels and two launch gaps).  EVERY workgroup forms the neighbourhood's plan for itself (150 table rows, two wave scans: a few microseconds,
+// no cross-workgroup dependency); workgroup 0 publishes it (sizes for the grids and the optimisation, the read-back snapshot); then the workgroups stride
+// over the copy chunks (<= 4096 points each, as k_map_plan_gather cut them) and over the cells of the two hash tables, which k_grid_insert expects empty.
+constexpr int kMgcT = 256, kMgcGrid = 256;
+__global__ __launch_bounds__(kMgcT) void k_map_gather_copy_clear(MapDevCfg cfg)
+{
+    __shared__ int2 s_seg[2][kMdValidMax + 1];
+    __shared__ int s_at[2][kMdValidMax + 1], s_job[2][kMdValidMax + 1], s_tot[2][2];
+    MapDev *dev = cfg.dev;
+    const MapFrame *F = cfg.frame;
+    const int tid = threadIdx.x, nv = F->n_valid;
+    if (tid < 2 * kMdValidMax) {
+        const int t = tid / kMdValidMax, v = tid - t * kMdValidMax;
+        s_seg[t][v] = v < nv ? dev->tab[t][F->valid[v]] : make_int2(0, 0);
+    }
+    __syncthreads();
+    if (tid < 128) {         // wave t sums type t: two cubes per lane, one scan for the points and one for the copy chunks
+        const int t = tid >> 6, lane = tid & 63;
+        int n[2], jn[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) { const int v = 2 * lane + u; n[u] = v < nv ? max(s_seg[t][v].y, 0) : 0; jn[u] = (n[u] + 4095) / 4096; }
+        const int in_n = wave_scan_incl(n[0] + n[1]), in_j = wave_scan_incl(jn[0] + jn[1]);
+        int at = in_n - n[0] - n[1], jb = in_j - jn[0] - jn[1];
+#pragma unroll
+        for (int u = 0; u < 2; u++) { const int v = 2 * lane + u; if (v < nv) { s_at[t][v] = at; s_job[t][v] = jb; } at += n[u]; jb += jn[u]; }
+        if (lane == 63) { s_tot[t][0] = in_n; s_tot[t][1] = in_j; }
+    }
+    __syncthreads();
+    const bool over = s_tot[0][0] > kMdNeighMax || s_tot[1][0] > kMdNeighMax;       // refused: the frame runs on an empty neighbourhood and reports it
+    const int n_map[2] = { over ? 0 : s_tot[0][0], over ? 0 : s_tot[1][0] };
+    if (blockIdx.x == 0) {
+        if (tid >= 128 && tid < 134) {       // (behind the previous commit: the words are that update's, whole)
+            const int k = tid - 128;
+            cfg.frame->snap[k] = k < 2 ? dev->bump[k] : k == 2 ? dev->err : k == 3 ? dev->n_gjobs : dev->last_sum[k - 4];
+        }
+        if (tid < 2) { dev->cj[tid].n = n_map[tid]; cfg.S->n_map[tid] = n_map[tid]; cfg.frame->n_map[tid] = n_map[tid]; }
+        if (tid == 0) {
+            dev->n_gjobs = over ? 0 : s_tot[0][1] + s_tot[1][1];
+            if (over) atomicOr(&dev->err, kMdErrNeigh);
+        }
+    }
+    // the hash tables of the two clouds, emptied (k_grid_clear's part; the static fields of the jobs were written by the host when the mapper was made)
+    for (int t = 0; t < 2; t++) {
+        CloudJob J = dev->cj[t];
+        J.n = n_map[t];
+        const int T = cloud_grid_size(J);
+        if (blockIdx.x == 0 && tid == 0) { *J.mask_out = T ? T - 1 : 0; *J.bump = 0; }
+        typedef __attribute__((address_space(1))) GridCell GCell;
+        GridCell *cell = (GridCell *)(GCell *)J.cell;
+        for (int i = blockIdx.x * kMgcT + tid; i < T; i += gridDim.x * kMgcT) { GridCell e; e.key = kEmptyKey; e.start = 0; e.cnt = 0; cell[i] = e; }
+    }
+    if (over) return;
+    // the copy chunks: chunk j of type t = the k-th 4096 points of cube v, found by bisection over the cubes' first chunks
+    const int nj0 = s_tot[0][1], nj = nj0 + s_tot[1][1];
+    for (int j = blockIdx.x; j < nj; j += gridDim.x) {
+        const int t = j >= nj0 ? 1 : 0, jl = j - (t ? nj0 : 0);
+        int lo = 0, hi = nv - 1;                     // last cube whose first chunk is <= jl (cubes without points share theirs with the next)
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_job[t][mid] <= jl) lo = mid; else hi = mid - 1; }
+        // (an empty cube behind the one that holds chunk jl has the same first chunk: step back to the cube that has points)
+        int v = lo;
+        while (v > 0 && (max(s_seg[t][v].y, 0) + 4095) / 4096 <= jl - s_job[t][v]) v--;
+        const int2 sg = s_seg[t][v];
+        const int o = (jl - s_job[t][v]) * 4096, cnt = min(4096, sg.y - o);
+        const float4 *src = cfg.arena[t] + sg.x + o;
+        float4 *dst = cfg.neigh[t] + s_at[t][v] + o;
+        for (int i = tid; i < cnt; i += kMgcT) dst[i] = src[i];
     }
 }
 
