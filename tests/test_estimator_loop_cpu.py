@@ -169,3 +169,36 @@ def test_lockstep_batch_of_estimators_prints_every_streams_own_lines(oracle, tmp
     out = subprocess.run([exe, files[0], "-", "async", "streams=5", "groups=2", "digest", files[1], files[2]], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     assert _split_streams(out.stdout)[1] == dig
+
+
+def test_lockstep_loop_under_thread_sanitizer(oracle, tmp_path):
+    """The lock-step frame loop is host threads around the numeric calls: the pool that walks the streams (every thread owns a share of them and takes
+    from the others' when done), the marginalisation worker beside the next frame, two batches interleaved by one driving thread.  The host mirror over the
+    oracle shim, built with -fsanitize=thread: 24 frames x 8 streams x 2 groups on 4 threads must finish without a report (a report makes the run fail:
+    halt_on_error) and print one digest for the eight streams of one file.  (GPU AddressSanitizer / XNACK are not available: sanitizers run on the CPU build.)"""
+    import os
+    import shutil
+    import subprocess
+    from workloads import s2
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("g++") is None:
+        import pytest
+        pytest.skip("no g++")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "estimator_seq_cpu"])          # (cpu_shim_stubs.o, liblmono_oracle.so)
+    host = os.path.join(root, "lmono_amd", "host")
+    exe = str(tmp_path / "eseq_tsan")
+    cmd = ["g++", "-O1", "-g", "-fsanitize=thread", "-march=x86-64-v3", "-ffp-contract=off", "-std=c++17", "-pthread", "-I" + host,
+           os.path.join(root, "oracle", "cpu_shim.cpp"), os.path.join(host, "lmono_host.cpp"), os.path.join(host, "estimator_seq.cpp"), os.path.join(host, "kitti_io.cpp"),
+           os.path.join(root, "oracle", "cpu_shim_stubs.o"), "-o", exe, "-L" + os.path.join(root, "oracle"), "-llmono_oracle", "-Wl,-rpath," + os.path.join(root, "oracle"), "-lm"]
+    b = subprocess.run(cmd, capture_output=True, text=True)
+    if b.returncode != 0 and ("tsan" in b.stderr or "sanitize" in b.stderr):
+        import pytest
+        pytest.skip("no ThreadSanitizer runtime: " + b.stderr[-200:])
+    assert b.returncode == 0, b.stderr[-2000:]
+    fx = tmp_path / "s.bin"
+    s2.write_stream(str(fx), s2.make_stream(24, seed=2, stops=()))
+    env = dict(os.environ, LMONO_HOST_THREADS="4", TSAN_OPTIONS="halt_on_error=1 exitcode=66")
+    out = subprocess.run([exe, str(fx), "-", "async", "streams=8", "groups=2", "digest"], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0 and "ThreadSanitizer" not in out.stderr, out.stderr[-3000:]
+    digs = {ln.split()[2] for ln in out.stdout.splitlines() if ln.startswith("DIG")}
+    assert len(digs) == 1 and sum(ln.startswith("DIG") for ln in out.stdout.splitlines()) == 8
