@@ -174,6 +174,7 @@ int main(int argc, char **argv)
             std::vector<const FeatureManager::Image *> img;
             std::vector<std::array<double, 16>> L0;
             std::unique_ptr<bool[]> kf;
+            size_t cur_f = 0;           // the frame the batch is working on (begin sets it; the frame hook prints it)
         };
         std::vector<Group> grp((size_t)G);
         for (int g = 0; g < G; g++) {
@@ -184,8 +185,13 @@ int main(int argc, char **argv)
             if (async) q.eb->setAsyncMargin(true);
             for (int s = 0; s < q.n; s++) std::memcpy(q.eb->stream(s).TLC, src[(size_t)(q.s0 + s) % src.size()].TLC, 128);
             q.headers.resize((size_t)q.n); q.img.resize((size_t)q.n); q.L0.resize((size_t)q.n); q.kf.reset(new bool[(size_t)q.n]);
+            // a stream's FRM line is written at the end of its frame by the thread that ran the stream's last pass (EstimatorBatch::setFrameHook): no serial
+            // loop over the streams on the driving thread
+            Group *qp = &q;
+            q.eb->setFrameHook([qp, &out](int s, const Estimator &e) { frm_line(out[(size_t)(qp->s0 + s)], (int)qp->cur_f, qp->kf[(size_t)s], e); });
         }
         auto begin = [&](Group &q, size_t f) {
+            q.cur_f = f;
             for (int s = 0; s < q.n; s++) {
                 const Frame &fr = src[(size_t)(q.s0 + s) % src.size()].frames[f];
                 q.headers[(size_t)s] = fr.header; q.img[(size_t)s] = &fr.image; std::memcpy(q.L0[(size_t)s].data(), fr.L0, 128);
@@ -193,10 +199,7 @@ int main(int argc, char **argv)
             }
             q.eb->processImageBegin(q.headers.data(), q.img.data(), reinterpret_cast<const double (*)[16]>(q.L0.data()), q.kf.get());
         };
-        auto finish = [&](Group &q, size_t f) {
-            q.eb->processImageFinish();
-            for (int s = 0; s < q.n; s++) frm_line(out[(size_t)(q.s0 + s)], (int)f, q.kf[(size_t)s], q.eb->stream(s));
-        };
+        auto finish = [&](Group &q, size_t) { q.eb->processImageFinish(); };
         double solve_ms = 0; int solves = 0;
         for (size_t f = 0; f < n_frames; f++) {
             const bool was_inited = grp[0].eb->stream(0).stage_flag == Estimator::INITED;

@@ -1072,6 +1072,9 @@ void EstimatorBatch::processImageBegin(const double *headers, const FeatureManag
                     e.frame_count++;
                     e.Ps[e.frame_count] = e.Ps[e.frame_count - 1]; e.Rs[e.frame_count] = e.Rs[e.frame_count - 1]; e.Header[e.frame_count] = e.Header[e.frame_count - 1];
                 }
+                // (a frame without a solve ends here: the caller's keyframe flag first, then the hook)
+                if (keyframe) keyframe[s] = kf[(size_t)s] != 0;
+                if (frame_hook_) frame_hook_(s, e);
             });
         }
     } else {
@@ -1119,7 +1122,11 @@ void EstimatorBatch::processImageFinish()
     pool_->run(N, [&](int s) { applyOutliers(s, outlier_error); w.due[(size_t)s] = est_[(size_t)s]->slideWindowBegin(w.shp[(size_t)s]) ? 1 : 0; });
     g_bclock.lap(9);
     callShift();
-    pool_->run(N, [&](int s) { if (w.due[(size_t)s]) est_[(size_t)s]->slideWindowFinish(&w.shout[(size_t)w.shoff[(size_t)s]]); est_[(size_t)s]->pushOdometryRow(); });
+    pool_->run(N, [&](int s) {
+        if (w.due[(size_t)s]) est_[(size_t)s]->slideWindowFinish(&w.shout[(size_t)w.shoff[(size_t)s]]);
+        est_[(size_t)s]->pushOdometryRow();
+        if (frame_hook_) frame_hook_(s, *est_[(size_t)s]);
+    });
     g_bclock.lap(10);
     if (packs && async_margin_) submitMargin(packs);
     if (!init_frame) g_bclock.frames++;

@@ -243,7 +243,11 @@ public:
     void processImageFinish();
     void setAsyncMargin(bool on);          // marginalisation of frame k beside frame k + 1 (second context, own stream, one worker thread), as Estimator::setAsyncMargin
     void marginWait();
+    // called once per stream at the end of every frame, inside the frame's last per-stream pass (on a pool thread: it may touch stream s's own data only) --
+    // what a node does with a stream's result (publishing, logging) without a serial loop over the streams behind the frame
+    void setFrameHook(std::function<void(int stream, const Estimator &)> hook) { frame_hook_ = std::move(hook); }
 private:
+    std::function<void(int, const Estimator &)> frame_hook_;
     struct Work;
     void concatTracks();
     void callTriangulate();

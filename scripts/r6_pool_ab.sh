@@ -1,5 +1,5 @@
 #!/bin/bash
-# EstimatorBatch host pool, A / B of two prebuilt binaries on ONE box.  usage (GPU box): bash scripts/r6_pool_ab.sh binA binB [frames]
+# EstimatorBatch, A / B of two prebuilt binaries on ONE box.  usage (GPU box): bash scripts/r6_pool_ab.sh binA binB [frames] [groups]
 O=gpurun_out/pool_ab; mkdir -p $O
 python3 - <<PY
 import sys
@@ -9,9 +9,9 @@ for k in range(4):
     K.write_stream('$O/s%d.bin' % k, K.make_stream(${3:-300}, seed=2 + k, stops=()))
 PY
 for N in 64 256; do
-  for rep in 1 2; do
+  for rep in 1 2 3; do
     for b in $1 $2; do
-      echo "$b N=$N: $(LMONO_HOST_TIMING=1 $b $O/s0.bin - async streams=$N digest $O/s1.bin $O/s2.bin $O/s3.bin 2>$O/err.txt | grep '^TIM') | $(grep BATCHTIM $O/err.txt | sed 's/.*frames: //; s/ (ms per.*//')"
+      echo "$b N=$N G=${4:-1}: $(LMONO_HOST_TIMING=1 $b $O/s0.bin - async streams=$N groups=${4:-1} digest $O/s1.bin $O/s2.bin $O/s3.bin 2>$O/err.txt | grep '^TIM') | $(grep BATCHTIM $O/err.txt | head -1 | sed 's/.*frames: //; s/ (ms per.*//')"
     done
   done
 done
