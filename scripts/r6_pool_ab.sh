@@ -1,5 +1,5 @@
 #!/bin/bash
-# EstimatorBatch, A / B of two prebuilt binaries on ONE box.  usage (GPU box): bash scripts/r6_pool_ab.sh binA binB [frames] [groups]
+# EstimatorBatch, A / B of two prebuilt binaries on ONE box.  usage (GPU box): bash scripts/r6_pool_ab.sh binA binB [frames] [groups]   (the binaries: builds of two trees into gpurun_bin/, which is git-ignored and travels with gpurun)
 O=gpurun_out/pool_ab; mkdir -p $O
 python3 - <<PY
 import sys
